@@ -1,0 +1,280 @@
+"""ctypes binding of the C-ABI in include/hso_gpu.h (libhso_gpu.so).
+
+This is plumbing for tests and bench.py: the product is the shared library.
+Loading fails loudly when the HIP extension has not been built — there is no
+CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhso_gpu.so")
+
+N_PYR_LEVELS = 5
+N_SOBEL_LEVELS = 3
+CAM_PINHOLE, CAM_FOV, CAM_EQUIDISTANT = 0, 1, 2
+
+
+class Camera(C.Structure):
+    _fields_ = [("model", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("distortion", C.c_int32),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("d", C.c_double * 5)]
+
+
+class SE3(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3)]
+
+    @staticmethod
+    def from_arrays(q, t):
+        s = SE3()
+        s.q[:] = [float(x) for x in q]
+        s.t[:] = [float(x) for x in t]
+        return s
+
+    @staticmethod
+    def identity():
+        return SE3.from_arrays([0, 0, 0, 1], [0, 0, 0])
+
+    def to_arrays(self):
+        return np.array(self.q[:]), np.array(self.t[:])
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("integral_image", C.c_float), ("grad_mean", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class RefFeat(C.Structure):
+    _fields_ = [("px", C.c_double * 2), ("f", C.c_double * 3), ("dist", C.c_double)]
+
+
+REF_FEAT_DTYPE = np.dtype([("px", "<f8", 2), ("f", "<f8", 3), ("dist", "<f8")])
+assert REF_FEAT_DTYPE.itemsize == C.sizeof(RefFeat)
+
+
+class DepthRefIn(C.Structure):
+    _fields_ = [("has_point", C.c_int32), ("host_pose", C.c_int32),
+                ("host_f", C.c_double * 3), ("idist", C.c_double)]
+
+
+DEPTH_REF_IN_DTYPE = np.dtype([("has_point", "<i4"), ("host_pose", "<i4"),
+                               ("host_f", "<f8", 3), ("idist", "<f8")])
+assert DEPTH_REF_IN_DTYPE.itemsize == C.sizeof(DepthRefIn)
+
+
+class TrackParams(C.Structure):
+    _fields_ = [("inverse_composition", C.c_int32), ("max_level", C.c_int32),
+                ("min_level", C.c_int32), ("n_iter", C.c_int32)]
+
+
+class TrackJob(C.Structure):
+    _fields_ = [("ref_frame_id", C.c_int64), ("cur_frame_id", C.c_int64),
+                ("feats", C.c_void_p), ("n_feats", C.c_int32), ("_pad", C.c_int32),
+                ("T_cur_ref", SE3), ("exposure_rat", C.c_float), ("_pad2", C.c_float)]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("T_cur_ref", SE3), ("exposure_rat", C.c_float), ("n_tracked", C.c_int32),
+                ("n_terms_last", C.c_int32), ("n_saturated_last", C.c_int32),
+                ("iters", C.c_int32 * N_PYR_LEVELS), ("n_eval", C.c_int32 * N_PYR_LEVELS),
+                ("accept_mask", C.c_uint64 * N_PYR_LEVELS),
+                ("huber", C.c_float * N_PYR_LEVELS), ("outlier", C.c_float * N_PYR_LEVELS),
+                ("n_select", C.c_int32 * N_PYR_LEVELS), ("energy", C.c_double * N_PYR_LEVELS),
+                ("status", C.c_int32), ("_pad", C.c_int32)]
+
+
+class EvalOut(C.Structure):
+    _fields_ = [("H", C.c_double * 49), ("b", C.c_double * 7), ("energy", C.c_double),
+                ("energy_sum", C.c_double), ("n_terms", C.c_int32), ("n_saturated", C.c_int32),
+                ("n_select", C.c_int32), ("n_visible", C.c_int32),
+                ("huber", C.c_float), ("outlier", C.c_float)]
+
+
+def make_camera(model, width, height, fx, fy, cx, cy, d=(0, 0, 0, 0, 0), distortion=None):
+    cam = Camera()
+    cam.model = model
+    cam.width, cam.height = int(width), int(height)
+    cam.fx, cam.fy, cam.cx, cam.cy = float(fx), float(fy), float(cx), float(cy)
+    dd = list(d) + [0.0] * (5 - len(d))
+    cam.d[:] = [float(x) for x in dd]
+    if distortion is None:
+        distortion = int(model == CAM_PINHOLE and abs(dd[0]) > 1e-7)  # src/camera.cpp:37
+    cam.distortion = int(distortion)
+    return cam
+
+
+class HsoGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libhso_gpu.so.  Raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HsoGpuError(
+            "libhso_gpu.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python -m hso_amd.build`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    P = C.POINTER
+    lib.hso_gpu_create.argtypes = [P(vp), i32, vp]
+    lib.hso_gpu_destroy.argtypes = [vp]
+    lib.hso_gpu_destroy.restype = None
+    lib.hso_gpu_last_error.argtypes = [vp]
+    lib.hso_gpu_last_error.restype = C.c_char_p
+    lib.hso_gpu_abi_version.argtypes = []
+    lib.hso_gpu_synchronize.argtypes = [vp]
+    lib.hso_gpu_frame_upload.argtypes = [vp, i64, vp, i32, i32, i32, P(FrameStats)]
+    lib.hso_gpu_frame_release.argtypes = [vp, i64]
+    lib.hso_gpu_frame_download_level.argtypes = [vp, i64, i32, vp, P(i32), P(i32)]
+    lib.hso_gpu_frame_download_sobel.argtypes = [vp, i64, i32, vp, vp]
+    lib.hso_gpu_make_depth_ref.argtypes = [vp, vp, i32, vp, i32, P(SE3), vp]
+    lib.hso_gpu_coarse_track_batch.argtypes = [vp, P(Camera), P(TrackParams), P(TrackJob), i32, P(TrackResult)]
+    lib.hso_gpu_coarse_track_prepare.argtypes = [vp, P(Camera), P(TrackParams), P(TrackJob), i32]
+    lib.hso_gpu_coarse_track_launch.argtypes = [vp]
+    lib.hso_gpu_coarse_track_collect.argtypes = [vp, P(TrackResult)]
+    lib.hso_gpu_tracker_eval.argtypes = [vp, P(Camera), P(TrackParams), P(TrackJob), i32, P(SE3),
+                                         C.c_float, C.c_float, C.c_float, P(EvalOut), vp, vp, vp]
+    lib.hso_gpu_tracker_pattern.argtypes = [i32, i32, P(i32), P(i32), vp]
+    _lib = lib
+    return lib
+
+
+# Every symbol include/hso_gpu.h declares; tests check the library exports all of them.
+EXPORTED_SYMBOLS = [
+    "hso_gpu_create", "hso_gpu_destroy", "hso_gpu_last_error", "hso_gpu_abi_version",
+    "hso_gpu_synchronize", "hso_gpu_frame_upload", "hso_gpu_frame_release",
+    "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
+    "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
+    "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
+]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """Thin RAII wrapper over hso_gpu_ctx."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.hso_gpu_create(C.byref(self.h), int(device), C.c_void_p(stream or 0))
+        if rc < 0:
+            raise HsoGpuError("hso_gpu_create failed: %d" % rc)
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.hso_gpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            msg = self.lib.hso_gpu_last_error(self.h)
+            raise HsoGpuError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+        return rc
+
+    def synchronize(self):
+        self._check(self.lib.hso_gpu_synchronize(self.h), "synchronize")
+
+    # -- frames
+    def frame_upload(self, frame_id, img, device_ptr=None, width=None, height=None):
+        st = FrameStats()
+        if device_ptr is not None:
+            rc = self.lib.hso_gpu_frame_upload(self.h, frame_id, C.c_void_p(device_ptr), width, height, 1, C.byref(st))
+        else:
+            img = np.ascontiguousarray(img, dtype=np.uint8)
+            h, w = img.shape
+            rc = self.lib.hso_gpu_frame_upload(self.h, frame_id, _ptr(img), w, h, 0, C.byref(st))
+        self._check(rc, "frame_upload")
+        return st
+
+    def frame_release(self, frame_id):
+        self._check(self.lib.hso_gpu_frame_release(self.h, frame_id), "frame_release")
+
+    def frame_level(self, frame_id, level, w0, h0):
+        out = np.empty(((h0 >> level), (w0 >> level)), np.uint8)
+        w, h = C.c_int(), C.c_int()
+        self._check(self.lib.hso_gpu_frame_download_level(self.h, frame_id, level, _ptr(out), C.byref(w), C.byref(h)),
+                    "frame_download_level")
+        assert (h.value, w.value) == out.shape
+        return out
+
+    def frame_sobel(self, frame_id, level, w0, h0):
+        gx = np.empty(((h0 >> level), (w0 >> level)), np.int16)
+        gy = np.empty_like(gx)
+        self._check(self.lib.hso_gpu_frame_download_sobel(self.h, frame_id, level, _ptr(gx), _ptr(gy)),
+                    "frame_download_sobel")
+        return gx, gy
+
+    # -- tracker
+    def make_depth_ref(self, din, poses, T_ref_w):
+        din = np.ascontiguousarray(din, dtype=DEPTH_REF_IN_DTYPE)
+        poses_arr = (SE3 * len(poses))(*poses)
+        out = np.empty(len(din), np.float64)
+        self._check(self.lib.hso_gpu_make_depth_ref(self.h, _ptr(din), len(din), C.cast(poses_arr, C.c_void_p),
+                                                    len(poses), C.byref(T_ref_w), _ptr(out)), "make_depth_ref")
+        return out
+
+    @staticmethod
+    def make_job(ref_id, cur_id, feats, T_cur_ref, exposure_rat):
+        feats = np.ascontiguousarray(feats, dtype=REF_FEAT_DTYPE)
+        job = TrackJob()
+        job.ref_frame_id, job.cur_frame_id = ref_id, cur_id
+        job.feats = feats.ctypes.data
+        job.n_feats = len(feats)
+        job.T_cur_ref = T_cur_ref
+        job.exposure_rat = float(exposure_rat)
+        job._feats_keepalive = feats
+        return job
+
+    def coarse_track_batch(self, cam, params, jobs):
+        arr = (TrackJob * len(jobs))(*jobs)
+        res = (TrackResult * len(jobs))()
+        self._check(self.lib.hso_gpu_coarse_track_batch(self.h, C.byref(cam), C.byref(params), arr, len(jobs), res),
+                    "coarse_track_batch")
+        return list(res)
+
+    def coarse_track_prepare(self, cam, params, jobs):
+        arr = (TrackJob * len(jobs))(*jobs)
+        self._n_prepared = len(jobs)
+        self._check(self.lib.hso_gpu_coarse_track_prepare(self.h, C.byref(cam), C.byref(params), arr, len(jobs)),
+                    "coarse_track_prepare")
+
+    def coarse_track_launch(self):
+        self._check(self.lib.hso_gpu_coarse_track_launch(self.h), "coarse_track_launch")
+
+    def coarse_track_collect(self):
+        res = (TrackResult * self._n_prepared)()
+        self._check(self.lib.hso_gpu_coarse_track_collect(self.h, res), "coarse_track_collect")
+        return list(res)
+
+    def tracker_eval(self, cam, params, job, level, T, exposure_rat, huber=-1.0, outlier=-1.0,
+                     want_cache=False, want_errors=False):
+        out = EvalOut()
+        pa = C.c_int()
+        self.lib.hso_gpu_tracker_pattern(params.max_level, level, C.byref(pa), None, None)
+        n = job.n_feats
+        ref_patch = np.zeros((n, pa.value), np.float32) if want_cache else None
+        visible = np.zeros(n, np.uint8) if want_cache else None
+        errs = np.zeros(n * pa.value, np.float32) if want_errors else None
+        self._check(self.lib.hso_gpu_tracker_eval(self.h, C.byref(cam), C.byref(params), C.byref(job), level,
+                                                  C.byref(T), exposure_rat, huber, outlier, C.byref(out),
+                                                  _ptr(ref_patch), _ptr(visible), _ptr(errs)), "tracker_eval")
+        return out, ref_patch, visible, errs

@@ -1,0 +1,217 @@
+/*
+ * hso_gpu.h — C-ABI of the MI355X-native HSO per-frame numeric hot path.
+ *
+ * Plain C, POD structs, caller-owned buffers, no exceptions, no callbacks.
+ * Every entry point returns an int status: >= 0 ok, < 0 error (HSO_E_*);
+ * hso_gpu_last_error() gives a human-readable reason for the last failure on
+ * the context.  One hso_gpu_ctx per host thread / HIP stream.
+ *
+ * The reference (luodongting/HSO) has no FFI layer: its boundary is the C++
+ * call surface FrameHandlerMono::processFrame() uses.  Each entry point below
+ * names the reference interface (file:line, relative to the reference root)
+ * whose body it replaces; the C++ adapters with the reference's own class and
+ * function names live in hso_amd/host/ and call only this header.
+ *
+ * Conventions
+ *   - poses are Sophus-style SE3: unit quaternion (x,y,z,w) + translation,
+ *     tangent order [upsilon(0:3), omega(3:6)]
+ *     (thirdparty/Sophus/sophus/se3.cpp:170-196);
+ *   - images are 8-bit, row-major, stride == width
+ *     (the reference assumes stride == cols, src/CoarseTracker.cpp:248);
+ *   - feature arrays are in Frame::fts_ list order (include/hso/frame.h:86);
+ *     an index into them is "the feature index" parity tests compare.
+ */
+#ifndef HSO_GPU_H
+#define HSO_GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSO_GPU_ABI_VERSION 1
+#define HSO_N_PYR_LEVELS 5   /* max(n_pyr_levels=3, klt_max_level+1=5), src/frame.cpp:92 */
+#define HSO_N_SOBEL_LEVELS 3 /* Config::nPyrLevels(), src/frame.cpp:214 */
+
+enum {
+  HSO_OK = 0,
+  HSO_E_INVALID = -1,   /* bad argument (null pointer, bad size, bad level) */
+  HSO_E_NOFRAME = -2,   /* frame id not resident in the context */
+  HSO_E_HIP = -3,       /* HIP runtime error, see hso_gpu_last_error */
+  HSO_E_NOMEM = -4,
+  HSO_E_UNSUPPORTED = -5
+};
+
+/* ---- camera: AbstractCamera {Pinhole, FOV, Equidistant}, src/camera.cpp ---- */
+enum { HSO_CAM_PINHOLE = 0, HSO_CAM_FOV = 1, HSO_CAM_EQUIDISTANT = 2 };
+
+typedef struct hso_camera {
+  int32_t model;       /* HSO_CAM_* */
+  int32_t width, height;
+  int32_t distortion;  /* pinhole: |d0| > 1e-7 (camera.cpp:37); FOV: !undistort_ (camera.cpp:208) */
+  double fx, fy, cx, cy;
+  double d[5];         /* pinhole radtan k1,k2,p1,p2,k3 (camera.cpp:105-120); FOV: d[0] = omega */
+} hso_camera;
+
+typedef struct hso_se3 {
+  double q[4]; /* x, y, z, w */
+  double t[3];
+} hso_se3;
+
+/* ---- frames: Frame::initFrame + createImgPyramid + prepareForFeatureDetect,
+ *      src/frame.cpp:82-96,205-246,296-314 ---- */
+typedef struct hso_frame_stats {
+  float integral_image; /* Frame::integralImage_ : mean level-0 intensity, 16 px margin */
+  float grad_mean;      /* Frame::gradMean_ : mean |sobel5| / 30 clamped to [7,20]      */
+  int32_t width, height;
+} hso_frame_stats;
+
+typedef struct hso_gpu_ctx hso_gpu_ctx;
+
+/* stream: a hipStream_t (as void*) the context launches on, or NULL for the
+ * default stream.  device: HIP device ordinal. */
+int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream);
+void hso_gpu_destroy(hso_gpu_ctx* ctx);
+const char* hso_gpu_last_error(const hso_gpu_ctx* ctx);
+int hso_gpu_abi_version(void);
+int hso_gpu_synchronize(hso_gpu_ctx* ctx);
+
+/* Replaces `new Frame(cam, img, ts)` -> Frame::initFrame (src/frame.cpp:82-96):
+ * builds the 5-level u8 pyramid (halfSample, src/vikit/vision.cpp:19-108; the
+ * per-level choice between the SSE2 rounding and the scalar truncation follows
+ * vision.cpp:76), the 5x5 Sobel images of levels 0-2 and the two frame
+ * statistics, all on the device.  `img` is a HOST pointer (img_is_device = 0)
+ * or a DEVICE pointer (img_is_device = 1) to width*height bytes.
+ * Errors: HSO_E_INVALID if the size is not (width % 16 == 0 && height % 16 == 0)
+ * [the cv::resize path of src/frame.cpp:307-312 is not built yet] or the frame
+ * id is already resident. */
+int hso_gpu_frame_upload(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img,
+                         int width, int height, int img_is_device,
+                         hso_frame_stats* stats_out);
+int hso_gpu_frame_release(hso_gpu_ctx* ctx, int64_t frame_id);
+/* parity/debug read-back: level in [0,5); out has (w>>level)*(h>>level) bytes */
+int hso_gpu_frame_download_level(hso_gpu_ctx* ctx, int64_t frame_id, int level,
+                                 uint8_t* out, int* w_out, int* h_out);
+/* level in [0,3); gx/gy each (w>>level)*(h>>level) int16 */
+int hso_gpu_frame_download_sobel(hso_gpu_ctx* ctx, int64_t frame_id, int level,
+                                 int16_t* gx, int16_t* gy);
+
+/* ---- CoarseTracker, src/CoarseTracker.cpp, include/hso/CoarseTracker.h ---- */
+
+/* One reference-frame feature, flattened from Feature{px,f} + the distance
+ * CoarseTracker::makeDepthRef computes (CoarseTracker.cpp:210-240).
+ * dist < 0  <=>  feature has no point or the point is behind the reference
+ * camera; such a slot produces no residual terms but keeps its index. */
+typedef struct hso_ref_feat {
+  double px[2]; /* Feature::px, level-0 pixels (include/hso/feature.h:40) */
+  double f[3];  /* Feature::f, unit bearing (feature.h:41) */
+  double dist;  /* m_pt_ref[i] or -1 */
+} hso_ref_feat;
+
+/* Inputs of makeDepthRef for one feature (CoarseTracker.cpp:214-236). */
+typedef struct hso_depth_ref_in {
+  int32_t has_point;   /* (*it_ft)->point != NULL */
+  int32_t host_pose;   /* index into the pose table: point->hostFeature_->frame->T_f_w_ */
+  double host_f[3];    /* point->hostFeature_->f */
+  double idist;        /* point->idist_ */
+} hso_depth_ref_in;
+
+/* dist_out[i] = | T_ref_w * T_host_w^-1 * (host_f / idist) | or -1. */
+int hso_gpu_make_depth_ref(hso_gpu_ctx* ctx, const hso_depth_ref_in* in, int n,
+                           const hso_se3* poses_f_w, int n_poses,
+                           const hso_se3* T_ref_w, double* dist_out);
+
+typedef struct hso_track_params {
+  int32_t inverse_composition; /* CoarseTracker ctor arg 1 */
+  int32_t max_level;           /* arg 2 (Config::kltMaxLevel() = 4) */
+  int32_t min_level;           /* arg 3 (kltMinLevel()+1 = 1; 0 when relocalising) */
+  int32_t n_iter;              /* arg 4 (50; 15 when relocalising) */
+} hso_track_params;
+
+typedef struct hso_track_job {
+  int64_t ref_frame_id;
+  int64_t cur_frame_id;
+  const hso_ref_feat* feats; /* host pointer, n entries */
+  int32_t n_feats;
+  int32_t _pad;
+  hso_se3 T_cur_ref;         /* cur.T_f_w_ * ref.T_f_w_^-1 (CoarseTracker.cpp:63) */
+  float exposure_rat;        /* cur.integralImage_/ref.integralImage_ (CoarseTracker.cpp:60) */
+  float _pad2;
+} hso_track_job;
+
+#define HSO_TRACK_MAX_ITER 64
+typedef struct hso_track_result {
+  hso_se3 T_cur_ref;      /* m_T_cur_ref after the last level */
+  float exposure_rat;     /* m_exposure_rat */
+  int32_t n_tracked;      /* size_t(float(m_total_terms)/PATCH_AREA) of the last evaluation */
+  int32_t n_terms_last, n_saturated_last;
+  /* per pyramid level (index = level) */
+  int32_t iters[HSO_N_PYR_LEVELS];      /* LM iterations executed */
+  int32_t n_eval[HSO_N_PYR_LEVELS];     /* computeResiduals calls (1 + iters) */
+  uint64_t accept_mask[HSO_N_PYR_LEVELS]; /* bit i = iteration i accepted */
+  float huber[HSO_N_PYR_LEVELS];        /* m_huber_thresh */
+  float outlier[HSO_N_PYR_LEVELS];      /* m_outlier_thresh */
+  int32_t n_select[HSO_N_PYR_LEVELS];   /* errors.size() in selectRobustFunctionLevel */
+  double energy[HSO_N_PYR_LEVELS];      /* final energy_old of the level */
+  int32_t status;                       /* 0 ok */
+  int32_t _pad;
+} hso_track_result;
+
+/* Replaces `CoarseTracker(inverse, max_level, min_level, n_iter, verbose)
+ * .run(ref, cur)` (CoarseTracker.cpp:51-208) for a batch of independent
+ * (ref, cur) pairs: the whole level loop and Levenberg-Marquardt loop run on
+ * the device, one workgroup per pair, no host round trips.  The caller applies
+ * the write-back of CoarseTracker.cpp:198-202 (cur.T_f_w_, m_exposure_time).
+ * Both frames of every job must be resident (hso_gpu_frame_upload). */
+int hso_gpu_coarse_track_batch(hso_gpu_ctx* ctx, const hso_camera* cam,
+                               const hso_track_params* params,
+                               const hso_track_job* jobs, int n_jobs,
+                               hso_track_result* results);
+
+/* Same, split for callers that keep jobs resident and time only the device
+ * work: `prepare` uploads the jobs' feature tables, `launch` enqueues the
+ * kernel on the context stream (asynchronous), `collect` synchronises and
+ * copies the results back. */
+int hso_gpu_coarse_track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam,
+                                 const hso_track_params* params,
+                                 const hso_track_job* jobs, int n_jobs);
+int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx);
+int hso_gpu_coarse_track_collect(hso_gpu_ctx* ctx, hso_track_result* results);
+
+/* One residual + Jacobian + normal-equation evaluation
+ * (precomputeReferencePatches :416-497, optional selectRobustFunctionLevel
+ * :530-644, computeResiduals :242-414, computeGS :499-525) at one level for one
+ * pair — the unit of work of SURVEY.md §8(d) and the per-call parity hook. */
+typedef struct hso_eval_out {
+  double H[49];        /* row-major 7x7, symmetric */
+  double b[7];
+  double energy;       /* E / m_total_terms */
+  double energy_sum;   /* E */
+  int32_t n_terms;     /* m_total_terms */
+  int32_t n_saturated; /* m_saturated_terms */
+  int32_t n_select;    /* errors.size() seen by selectRobustFunctionLevel (0 if not run) */
+  int32_t n_visible;   /* set bits of m_visible_fts */
+  float huber, outlier;/* thresholds used */
+} hso_eval_out;
+
+/* huber_thresh <= 0 => run selectRobustFunctionLevel(T, exposure_rat) first and
+ * use (and report) its thresholds.  ref_patch_out (n*PATCH_AREA floats),
+ * visible_out (n bytes) and abs_err_out (n*PATCH_AREA floats, first n_select
+ * valid, order unspecified) may be NULL. */
+int hso_gpu_tracker_eval(hso_gpu_ctx* ctx, const hso_camera* cam,
+                         const hso_track_params* params, const hso_track_job* job,
+                         int level, const hso_se3* T_cur_ref, float exposure_rat,
+                         float huber_thresh, float outlier_thresh,
+                         hso_eval_out* out, float* ref_patch_out,
+                         uint8_t* visible_out, float* abs_err_out);
+
+/* static tables of include/hso/CoarseTracker.h:58-120 for a level */
+int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
+                            int* half_patch, int8_t* offsets_xy /* 2*40 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSO_GPU_H */

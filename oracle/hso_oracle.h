@@ -1,0 +1,91 @@
+/*
+ * hso_oracle.h — CPU restatement of the reference's per-frame numeric hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product path
+ * (hso_amd/, libhso_gpu.so) never links, imports or calls it.
+ *
+ * PARITY PINNING: the reference (luodongting/HSO) ships no tests, golden
+ * vectors or fixtures for this path and cannot be compiled here (Eigen3, OpenCV,
+ * Boost absent), so the restatement below is *unpinned by the reference* except
+ * for the robust-cost functions (src/vikit/robust_cost.cpp), the one reference
+ * translation unit that builds standalone (oracle/_ref, see Makefile).  Every
+ * function cites the reference file:line it follows so it can be diffed by eye.
+ * Third-party arithmetic that the reference pulls from outside its tree (Eigen
+ * LDLT / Quaternion, OpenCV Sobel) is restated from the published algorithms.
+ *
+ * Floating-point contract: compiled with -ffp-contract=off and no fast-math, so
+ * each C expression is evaluated exactly as written (the reference itself is
+ * built with -O3 -march=native, i.e. defined only up to FMA contraction).
+ */
+#ifndef HSO_ORACLE_H
+#define HSO_ORACLE_H
+
+#include "../include/hso_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Sophus SE3 / SO3 (thirdparty/Sophus/sophus/{se3,so3}.cpp) ---- */
+void hso_or_se3_identity(hso_se3* T);
+void hso_or_se3_mul(const hso_se3* a, const hso_se3* b, hso_se3* out);      /* se3.cpp:59-66 */
+void hso_or_se3_inverse(const hso_se3* a, hso_se3* out);                    /* se3.cpp:76-83 */
+void hso_or_se3_apply(const hso_se3* T, const double p[3], double out[3]);  /* se3.cpp:91-95 */
+void hso_or_se3_exp(const double upsilon_omega[6], hso_se3* out);           /* se3.cpp:170-196 */
+void hso_or_se3_log(const hso_se3* T, double out[6]);                       /* se3.cpp:198-220 */
+void hso_or_so3_matrix(const double q[4], double R[9]);                     /* so3.cpp:98-102 (Eigen toRotationMatrix) */
+
+/* ---- small dense algebra (Eigen, restated) ---- */
+/* Eigen::LDLT<Matrix<double,n,n>>(A).solve(b), pivoted, lower triangle of A read. n <= 8. */
+void hso_or_ldlt_solve(const double* A, const double* b, int n, double* x);
+float hso_or_median_f(float* data, int n);   /* hso::getMedian, include/hso/vikit/math_utils.h:119-126 (upper median; permutes data) */
+double hso_or_median_d(double* data, int n);
+
+/* ---- camera (src/camera.cpp) ---- */
+void hso_or_world2cam(const hso_camera* cam, const double xyz[3], double px[2]); /* camera.cpp:94-125,196-221,295-303 */
+void hso_or_cam2world(const hso_camera* cam, double u, double v, double f[3]);    /* camera.cpp:67-87,171-194,283-286 */
+double hso_or_error_multiplier2(const hso_camera* cam);                          /* fxy_mean_, camera.cpp:59 */
+
+/* ---- frame: pyramid, Sobel, stats (src/frame.cpp, src/vikit/vision.cpp) ---- */
+void hso_or_half_sample(const uint8_t* in, int w, int h, uint8_t* out);       /* vision.cpp:70-108 incl. SSE2 path :19-44 */
+/* levels[] must hold 5 buffers; levels[0] is copied from img */
+int hso_or_create_pyramid(const uint8_t* img, int w, int h, uint8_t* const levels[HSO_N_PYR_LEVELS]); /* frame.cpp:296-314 */
+void hso_or_sobel5(const uint8_t* img, int w, int h, int16_t* gx, int16_t* gy); /* cv::Sobel(CV_16S, k=5, BORDER_REPLICATE), frame.cpp:218-219 */
+void hso_or_frame_stats(const uint8_t* img0, const int16_t* gx0, const int16_t* gy0, int w, int h,
+                        hso_frame_stats* out);                                /* frame.cpp:223-245 */
+
+/* ---- CoarseTracker (src/CoarseTracker.cpp) ---- */
+void hso_or_make_depth_ref(const hso_depth_ref_in* in, int n, const hso_se3* poses_f_w,
+                           const hso_se3* T_ref_w, double* dist_out);         /* :210-240 */
+
+typedef struct hso_or_tracker hso_or_tracker;
+/* ref_pyr/cur_pyr: 5 level pointers of a w x h level-0 frame */
+hso_or_tracker* hso_or_tracker_create(const hso_camera* cam, const hso_track_params* p,
+                                      const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                                      const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS],
+                                      int w, int h, const hso_ref_feat* feats, int n);
+void hso_or_tracker_destroy(hso_or_tracker* t);
+/* set m_level, pattern, run precomputeReferencePatches (:416-497) */
+void hso_or_tracker_set_level(hso_or_tracker* t, int level);
+/* selectRobustFunctionLevel (:530-644); returns errors.size() */
+int hso_or_tracker_select(hso_or_tracker* t, const hso_se3* T, float exposure_rat,
+                          float* huber, float* outlier, float* abs_err_out);
+void hso_or_tracker_set_thresholds(hso_or_tracker* t, float huber, float outlier);
+/* computeResiduals (:242-414) + computeGS (:499-525) */
+void hso_or_tracker_eval(hso_or_tracker* t, const hso_se3* T, float exposure_rat,
+                         hso_eval_out* out);
+/* read-back of m_ref_patch_cache (n*PATCH_AREA) and m_visible_fts */
+void hso_or_tracker_get_cache(const hso_or_tracker* t, float* ref_patch, uint8_t* visible,
+                              int* patch_area);
+/* CoarseTracker::run (:51-208) minus the frame write-back */
+void hso_or_tracker_run(hso_or_tracker* t, const hso_se3* T_init, float exposure_init,
+                        hso_track_result* out);
+/* per-term dump of the last evaluation for debugging: returns number of rows written */
+int hso_or_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch,
+                           int8_t* offsets_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

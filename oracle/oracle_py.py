@@ -1,0 +1,241 @@
+"""ctypes wrapper over oracle/libhso_oracle.so — the CPU restatement.
+
+TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; nothing under hso_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hso_amd.capi import (Camera, SE3, FrameStats, TrackParams, TrackResult, EvalOut,
+                          REF_FEAT_DTYPE, DEPTH_REF_IN_DTYPE, N_PYR_LEVELS)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhso_oracle.so")
+REF_LIB_PATH = os.path.join(_HERE, "_ref", "librobust_cost_ref.so")
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "all"])
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    P = C.POINTER
+    lib.hso_or_se3_mul.argtypes = [P(SE3), P(SE3), P(SE3)]
+    lib.hso_or_se3_inverse.argtypes = [P(SE3), P(SE3)]
+    lib.hso_or_se3_apply.argtypes = [P(SE3), vp, vp]
+    lib.hso_or_se3_exp.argtypes = [vp, P(SE3)]
+    lib.hso_or_se3_log.argtypes = [P(SE3), vp]
+    lib.hso_or_so3_matrix.argtypes = [vp, vp]
+    lib.hso_or_ldlt_solve.argtypes = [vp, vp, i32, vp]
+    lib.hso_or_median_f.argtypes = [vp, i32]
+    lib.hso_or_median_f.restype = C.c_float
+    lib.hso_or_world2cam.argtypes = [P(Camera), vp, vp]
+    lib.hso_or_cam2world.argtypes = [P(Camera), C.c_double, C.c_double, vp]
+    lib.hso_or_error_multiplier2.argtypes = [P(Camera)]
+    lib.hso_or_error_multiplier2.restype = C.c_double
+    lib.hso_or_half_sample.argtypes = [vp, i32, i32, vp]
+    lib.hso_or_create_pyramid.argtypes = [vp, i32, i32, P(vp)]
+    lib.hso_or_sobel5.argtypes = [vp, i32, i32, vp, vp]
+    lib.hso_or_frame_stats.argtypes = [vp, vp, vp, i32, i32, P(FrameStats)]
+    lib.hso_or_make_depth_ref.argtypes = [vp, i32, vp, P(SE3), vp]
+    lib.hso_or_tracker_create.argtypes = [P(Camera), P(TrackParams), P(vp), P(vp), i32, i32, vp, i32]
+    lib.hso_or_tracker_create.restype = vp
+    lib.hso_or_tracker_destroy.argtypes = [vp]
+    lib.hso_or_tracker_destroy.restype = None
+    lib.hso_or_tracker_set_level.argtypes = [vp, i32]
+    lib.hso_or_tracker_set_level.restype = None
+    lib.hso_or_tracker_select.argtypes = [vp, P(SE3), C.c_float, P(C.c_float), P(C.c_float), vp]
+    lib.hso_or_tracker_set_thresholds.argtypes = [vp, C.c_float, C.c_float]
+    lib.hso_or_tracker_set_thresholds.restype = None
+    lib.hso_or_tracker_eval.argtypes = [vp, P(SE3), C.c_float, P(EvalOut)]
+    lib.hso_or_tracker_eval.restype = None
+    lib.hso_or_tracker_get_cache.argtypes = [vp, vp, vp, P(i32)]
+    lib.hso_or_tracker_get_cache.restype = None
+    lib.hso_or_tracker_run.argtypes = [vp, P(SE3), C.c_float, P(TrackResult)]
+    lib.hso_or_tracker_run.restype = None
+    lib.hso_or_tracker_pattern.argtypes = [i32, i32, P(i32), P(i32), vp]
+    _lib = lib
+    return lib
+
+
+def load_ref():
+    """The compiled reference robust_cost.cpp (oracle/_ref), or None if absent."""
+    if not os.path.exists(REF_LIB_PATH):
+        return None
+    lib = C.CDLL(REF_LIB_PATH)
+    for name in ("ref_huber_weight", "ref_tukey_weight", "ref_tdist_weight"):
+        getattr(lib, name).argtypes = [C.c_float, C.c_float]
+        getattr(lib, name).restype = C.c_float
+    lib.ref_mad_scale.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_mad_scale.restype = C.c_float
+    lib.ref_tdist_scale.argtypes = [C.c_float, C.c_void_p, C.c_int]
+    lib.ref_tdist_scale.restype = C.c_float
+    lib.ref_huber_default_k.restype = C.c_float
+    lib.ref_tukey_default_b.restype = C.c_float
+    return lib
+
+
+# ---------------------------------------------------------------- SE3 helpers
+def se3_mul(a, b):
+    o = SE3(); load().hso_or_se3_mul(C.byref(a), C.byref(b), C.byref(o)); return o
+
+
+def se3_inverse(a):
+    o = SE3(); load().hso_or_se3_inverse(C.byref(a), C.byref(o)); return o
+
+
+def se3_exp(v):
+    v = np.ascontiguousarray(v, np.float64)
+    o = SE3(); load().hso_or_se3_exp(_ptr(v), C.byref(o)); return o
+
+
+def se3_log(T):
+    o = np.zeros(6); load().hso_or_se3_log(C.byref(T), _ptr(o)); return o
+
+
+def se3_apply(T, p):
+    p = np.ascontiguousarray(p, np.float64)
+    o = np.zeros(3); load().hso_or_se3_apply(C.byref(T), _ptr(p), _ptr(o)); return o
+
+
+def so3_matrix(q):
+    q = np.ascontiguousarray(q, np.float64)
+    R = np.zeros(9); load().hso_or_so3_matrix(_ptr(q), _ptr(R)); return R.reshape(3, 3)
+
+
+def ldlt_solve(A, b):
+    A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros(len(b)); load().hso_or_ldlt_solve(_ptr(A), _ptr(b), len(b), _ptr(x)); return x
+
+
+def world2cam(cam, xyz):
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    px = np.zeros(2); load().hso_or_world2cam(C.byref(cam), _ptr(xyz), _ptr(px)); return px
+
+
+def cam2world(cam, u, v):
+    f = np.zeros(3); load().hso_or_cam2world(C.byref(cam), float(u), float(v), _ptr(f)); return f
+
+
+# -------------------------------------------------------------------- frames
+def create_pyramid(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    levels = [np.zeros((h >> i, w >> i), np.uint8) for i in range(N_PYR_LEVELS)]
+    ptrs = (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in levels])
+    rc = load().hso_or_create_pyramid(_ptr(img), w, h, ptrs)
+    if rc != 0:
+        raise ValueError("pyramid: size not a multiple of 16")
+    return levels
+
+
+def half_sample(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h // 2, w // 2), np.uint8)
+    load().hso_or_half_sample(_ptr(img), w, h, _ptr(out))
+    return out
+
+
+def sobel5(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    gx = np.zeros((h, w), np.int16); gy = np.zeros((h, w), np.int16)
+    load().hso_or_sobel5(_ptr(img), w, h, _ptr(gx), _ptr(gy))
+    return gx, gy
+
+
+def frame_stats(img0, gx0, gy0):
+    st = FrameStats()
+    h, w = img0.shape
+    load().hso_or_frame_stats(_ptr(np.ascontiguousarray(img0)), _ptr(np.ascontiguousarray(gx0)),
+                              _ptr(np.ascontiguousarray(gy0)), w, h, C.byref(st))
+    return st
+
+
+def make_depth_ref(din, poses, T_ref_w):
+    din = np.ascontiguousarray(din, dtype=DEPTH_REF_IN_DTYPE)
+    arr = (SE3 * len(poses))(*poses)
+    out = np.zeros(len(din))
+    load().hso_or_make_depth_ref(_ptr(din), len(din), C.cast(arr, C.c_void_p), C.byref(T_ref_w), _ptr(out))
+    return out
+
+
+# ------------------------------------------------------------------- tracker
+class Tracker:
+    def __init__(self, cam, params, ref_pyr, cur_pyr, feats):
+        self.lib = load()
+        self.ref_pyr = [np.ascontiguousarray(l) for l in ref_pyr]
+        self.cur_pyr = [np.ascontiguousarray(l) for l in cur_pyr]
+        self.feats = np.ascontiguousarray(feats, dtype=REF_FEAT_DTYPE)
+        self.params = params
+        h, w = self.ref_pyr[0].shape
+        rp = (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in self.ref_pyr])
+        cp = (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in self.cur_pyr])
+        self.h = self.lib.hso_or_tracker_create(C.byref(cam), C.byref(params), rp, cp, w, h,
+                                                _ptr(self.feats), len(self.feats))
+        self.n = len(self.feats)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.hso_or_tracker_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_level(self, level):
+        self.lib.hso_or_tracker_set_level(self.h, level)
+
+    def select(self, T, a, want_errors=False):
+        hu, ou = C.c_float(), C.c_float()
+        errs = np.zeros(self.n * 25, np.float32) if want_errors else None
+        n = self.lib.hso_or_tracker_select(self.h, C.byref(T), a, C.byref(hu), C.byref(ou), _ptr(errs))
+        return n, hu.value, ou.value, (errs[:n] if want_errors else None)
+
+    def set_thresholds(self, huber, outlier):
+        self.lib.hso_or_tracker_set_thresholds(self.h, huber, outlier)
+
+    def eval(self, T, a):
+        out = EvalOut()
+        self.lib.hso_or_tracker_eval(self.h, C.byref(T), a, C.byref(out))
+        return out
+
+    def cache(self):
+        pa = C.c_int()
+        self.lib.hso_or_tracker_get_cache(self.h, None, None, C.byref(pa))
+        rp = np.zeros((self.n, pa.value), np.float32)
+        vis = np.zeros(self.n, np.uint8)
+        self.lib.hso_or_tracker_get_cache(self.h, _ptr(rp), _ptr(vis), C.byref(pa))
+        return rp, vis
+
+    def run(self, T_init, a_init):
+        res = TrackResult()
+        self.lib.hso_or_tracker_run(self.h, C.byref(T_init), a_init, C.byref(res))
+        return res
+
+
+def pattern(max_level, level):
+    pa, hp = C.c_int(), C.c_int()
+    offs = np.zeros((40, 2), np.int8)
+    rc = load().hso_or_tracker_pattern(max_level, level, C.byref(pa), C.byref(hp), _ptr(offs))
+    return rc, pa.value, hp.value, offs[:pa.value].copy()
