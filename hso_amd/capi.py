@@ -133,6 +133,7 @@ def load():
     lib.hso_gpu_abi_version.argtypes = []
     lib.hso_gpu_synchronize.argtypes = [vp]
     lib.hso_gpu_frame_upload.argtypes = [vp, i64, vp, i32, i32, i32, P(FrameStats)]
+    lib.hso_gpu_frame_upload_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.hso_gpu_frame_release.argtypes = [vp, i64]
     lib.hso_gpu_frame_download_level.argtypes = [vp, i64, i32, vp, P(i32), P(i32)]
     lib.hso_gpu_frame_download_sobel.argtypes = [vp, i64, i32, vp, vp]
@@ -151,7 +152,7 @@ def load():
 # Every symbol include/hso_gpu.h declares; tests check the library exports all of them.
 EXPORTED_SYMBOLS = [
     "hso_gpu_create", "hso_gpu_destroy", "hso_gpu_last_error", "hso_gpu_abi_version",
-    "hso_gpu_synchronize", "hso_gpu_frame_upload", "hso_gpu_frame_release",
+    "hso_gpu_synchronize", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release",
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
@@ -204,6 +205,23 @@ class Context:
             rc = self.lib.hso_gpu_frame_upload(self.h, frame_id, _ptr(img), w, h, 0, C.byref(st))
         self._check(rc, "frame_upload")
         return st
+
+    def frame_upload_batch(self, frame_ids, imgs=None, device_ptrs=None, width=None, height=None, want_stats=True):
+        n = len(frame_ids)
+        ids = np.ascontiguousarray(frame_ids, np.int64)
+        if device_ptrs is not None:
+            ptrs = np.ascontiguousarray(device_ptrs, np.uint64)
+            is_dev = 1
+        else:
+            imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in imgs]
+            height, width = imgs[0].shape
+            ptrs = np.array([im.ctypes.data for im in imgs], np.uint64)
+            is_dev = 0
+        stats = (FrameStats * n)() if want_stats else None
+        rc = self.lib.hso_gpu_frame_upload_batch(self.h, _ptr(ids), _ptr(ptrs), n, width, height, is_dev,
+                                                 C.cast(stats, C.c_void_p) if want_stats else None)
+        self._check(rc, "frame_upload_batch")
+        return list(stats) if want_stats else None
 
     def frame_release(self, frame_id):
         self._check(self.lib.hso_gpu_frame_release(self.h, frame_id), "frame_release")

@@ -1,0 +1,66 @@
+// hso_ctx.h — context, resident frames and shared launch helpers behind the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/hso_gpu.h"
+
+// Geometry of one resident frame: 5-level u8 pyramid + Sobel images of levels 0-2.
+// Every level starts 256-byte aligned and is followed by at least one zeroed
+// row + 64 bytes: the reference's dy taps (src/CoarseTracker.cpp:370,491) read
+// row `rows` of a level for features on the bottom border (a heap over-read in
+// the reference, value undefined there); here those bytes are defined as 0.
+struct PyrGeom {
+  int w[HSO_N_PYR_LEVELS], h[HSO_N_PYR_LEVELS];
+  uint32_t off[HSO_N_PYR_LEVELS];     // byte offset of each level in the pyramid block
+  uint32_t pyr_bytes;                 // total bytes of the pyramid block (multiple of 256)
+  uint32_t sob_off[HSO_N_SOBEL_LEVELS][2];  // byte offsets (from the frame base) of gx, gy
+  uint32_t part_off;                  // stats partials (double2 per level-0 Sobel block)
+  uint32_t stats_off;                 // hso_frame_stats
+  uint32_t frame_bytes;
+  int sobel_blocks[HSO_N_SOBEL_LEVELS]; // blocks per level
+  int sobel_bx[HSO_N_SOBEL_LEVELS];     // blocks in x per level
+};
+
+PyrGeom make_geom(int w, int h);
+
+struct FrameRec {
+  int64_t id;
+  PyrGeom g;
+  uint8_t* base;  // device
+};
+
+struct TrackBatchState;  // hso_tracker.hip
+
+struct hso_gpu_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  int n_cu;
+  std::string err;
+  std::unordered_map<int64_t, FrameRec> frames;
+  std::vector<uint8_t*> free_frames;  // recycled allocations (same geometry)
+  uint32_t free_frame_bytes;
+  TrackBatchState* track;
+  // staging for batched frame uploads: [bases | srcs | stats]
+  char* d_batch; size_t batch_cap;
+};
+
+#define HSO_HIP_CHECK(ctx, expr)                                              \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);         \
+      return HSO_E_HIP;                                                       \
+    }                                                                         \
+  } while (0)
+
+int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg);
+
+// frame kernels (hso_frame.hip): build pyramid + Sobel + stats for `n` frames whose
+// level-0 bytes are already in place at base+off[0].
+int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases, const uint8_t* const* d_srcs,
+                    hso_frame_stats* d_stats, int n);
+void hso_track_state_free(hso_gpu_ctx* ctx);

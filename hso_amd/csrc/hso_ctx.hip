@@ -1,0 +1,212 @@
+// hso_ctx.hip — context lifecycle and the frame entry points of include/hso_gpu.h.
+#include "hso_ctx.h"
+#include <string.h>
+#include <vector>
+
+int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg)
+{
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+extern "C" {
+
+int hso_gpu_abi_version(void) { return HSO_GPU_ABI_VERSION; }
+
+int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
+{
+  if (!out) return HSO_E_INVALID;
+  *out = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return HSO_E_HIP;
+  if (device < 0 || device >= n_dev) return HSO_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return HSO_E_HIP;
+  hso_gpu_ctx* ctx = new hso_gpu_ctx();
+  ctx->device = device;
+  ctx->track = nullptr;
+  ctx->free_frame_bytes = 0;
+  ctx->d_batch = nullptr;
+  ctx->batch_cap = 0;
+  if (stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    ctx->own_stream = false;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSO_E_HIP; }
+    ctx->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return HSO_E_HIP; }
+  ctx->n_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return HSO_OK;
+}
+
+void hso_gpu_destroy(hso_gpu_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  hso_track_state_free(ctx);
+  for (auto& kv : ctx->frames) (void)hipFree(kv.second.base);
+  for (auto* p : ctx->free_frames) (void)hipFree(p);
+  if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* hso_gpu_last_error(const hso_gpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int hso_gpu_synchronize(hso_gpu_ctx* ctx)
+{
+  if (!ctx) return HSO_E_INVALID;
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+int hso_gpu_frame_upload(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img, int width, int height,
+                         int img_is_device, hso_frame_stats* stats_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!img || width <= 0 || height <= 0) return hso_fail(ctx, HSO_E_INVALID, "frame_upload: null image or bad size");
+  // src/frame.cpp:302: the halfSample pyramid needs level-0 cols and rows % 16 == 0;
+  // the cv::resize branch (:307-312) is not built.
+  if ((width % 16) != 0 || (height % 16) != 0)
+    return hso_fail(ctx, HSO_E_INVALID, "frame_upload: width and height must be multiples of 16");
+  if (width < 64 || height < 64) return hso_fail(ctx, HSO_E_INVALID, "frame_upload: image smaller than 64x64");
+  if (ctx->frames.count(frame_id)) return hso_fail(ctx, HSO_E_INVALID, "frame_upload: frame id already resident");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  FrameRec rec;
+  rec.id = frame_id;
+  rec.g = make_geom(width, height);
+  rec.base = nullptr;
+  if (!ctx->free_frames.empty() && ctx->free_frame_bytes == rec.g.frame_bytes) {
+    rec.base = ctx->free_frames.back();
+    ctx->free_frames.pop_back();
+  } else {
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&rec.base), rec.g.frame_bytes));
+    // zero once: the inter-level padding rows must read as 0 (see hso_ctx.h)
+    HSO_HIP_CHECK(ctx, hipMemsetAsync(rec.base, 0, rec.g.pyr_bytes, ctx->stream));
+  }
+  hipError_t e = hipMemcpyAsync(rec.base + rec.g.off[0], img, (size_t)width * height,
+                                img_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(rec.base); ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
+  // the kernels take a device array of frame base pointers (batched form); one entry here
+  uint8_t** d_bases = reinterpret_cast<uint8_t**>(rec.base + rec.g.stats_off + 128);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_bases, &rec.base, sizeof(uint8_t*), hipMemcpyHostToDevice, ctx->stream));
+  int rc = hso_frame_build(ctx, rec.g, d_bases, nullptr, nullptr, 1);
+  if (rc < 0) { (void)hipFree(rec.base); return rc; }
+  if (stats_out) {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(stats_out, rec.base + rec.g.stats_off, sizeof(hso_frame_stats),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->frames[frame_id] = rec;
+  return HSO_OK;
+}
+
+int hso_gpu_frame_upload_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, const uint8_t* const* imgs, int n,
+                               int width, int height, int img_is_device, hso_frame_stats* stats_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!frame_ids || !imgs || n <= 0) return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: null argument or n <= 0");
+  if ((width % 16) != 0 || (height % 16) != 0 || width < 64 || height < 64)
+    return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: width and height must be multiples of 16 and >= 64");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const PyrGeom g = make_geom(width, height);
+  std::vector<uint8_t*> bases(n);
+  for (int i = 0; i < n; i++) {
+    if (!imgs[i]) return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: null image");
+    auto it = ctx->frames.find(frame_ids[i]);
+    if (it != ctx->frames.end()) {
+      if (it->second.g.frame_bytes != g.frame_bytes)
+        return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: resident frame has another size");
+      bases[i] = it->second.base;  // refresh in place
+    } else {
+      FrameRec rec;
+      rec.id = frame_ids[i];
+      rec.g = g;
+      if (!ctx->free_frames.empty() && ctx->free_frame_bytes == g.frame_bytes) {
+        rec.base = ctx->free_frames.back();
+        ctx->free_frames.pop_back();
+      } else {
+        HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&rec.base), g.frame_bytes));
+        HSO_HIP_CHECK(ctx, hipMemsetAsync(rec.base, 0, g.pyr_bytes, ctx->stream));
+      }
+      ctx->frames[frame_ids[i]] = rec;
+      bases[i] = rec.base;
+    }
+  }
+  const size_t b_ptr = ((size_t)n * sizeof(void*) + 255) & ~size_t(255);
+  const size_t need = 2 * b_ptr + (size_t)n * sizeof(hso_frame_stats);
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
+  }
+  uint8_t** d_bases = reinterpret_cast<uint8_t**>(ctx->d_batch);
+  const uint8_t** d_srcs = reinterpret_cast<const uint8_t**>(ctx->d_batch + b_ptr);
+  hso_frame_stats* d_stats = reinterpret_cast<hso_frame_stats*>(ctx->d_batch + 2 * b_ptr);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_bases, bases.data(), (size_t)n * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  if (img_is_device) {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_srcs, imgs, (size_t)n * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    for (int i = 0; i < n; i++)
+      HSO_HIP_CHECK(ctx, hipMemcpyAsync(bases[i] + g.off[0], imgs[i], (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int rc = hso_frame_build(ctx, g, d_bases, img_is_device ? d_srcs : nullptr, stats_out ? d_stats : nullptr, n);
+  if (rc < 0) return rc;
+  // the pointer tables above were read from pageable host memory: wait before they go out of scope
+  if (stats_out)
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(stats_out, d_stats, (size_t)n * sizeof(hso_frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+  if (stats_out) HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+int hso_gpu_frame_release(hso_gpu_ctx* ctx, int64_t frame_id)
+{
+  if (!ctx) return HSO_E_INVALID;
+  auto it = ctx->frames.find(frame_id);
+  if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "frame_release: frame not resident");
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if ((ctx->free_frames.empty() || ctx->free_frame_bytes == it->second.g.frame_bytes) && ctx->free_frames.size() < 4096) {
+    ctx->free_frame_bytes = it->second.g.frame_bytes;
+    ctx->free_frames.push_back(it->second.base);
+  } else {
+    (void)hipFree(it->second.base);
+  }
+  ctx->frames.erase(it);
+  return HSO_OK;
+}
+
+int hso_gpu_frame_download_level(hso_gpu_ctx* ctx, int64_t frame_id, int level, uint8_t* out, int* w_out, int* h_out)
+{
+  if (!ctx || !out) return HSO_E_INVALID;
+  if (level < 0 || level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "download_level: bad level");
+  auto it = ctx->frames.find(frame_id);
+  if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "download_level: frame not resident");
+  const PyrGeom& g = it->second.g;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, it->second.base + g.off[level], (size_t)g.w[level] * g.h[level],
+                                    hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (w_out) *w_out = g.w[level];
+  if (h_out) *h_out = g.h[level];
+  return HSO_OK;
+}
+
+int hso_gpu_frame_download_sobel(hso_gpu_ctx* ctx, int64_t frame_id, int level, int16_t* gx, int16_t* gy)
+{
+  if (!ctx || !gx || !gy) return HSO_E_INVALID;
+  if (level < 0 || level >= HSO_N_SOBEL_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "download_sobel: bad level");
+  auto it = ctx->frames.find(frame_id);
+  if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "download_sobel: frame not resident");
+  const PyrGeom& g = it->second.g;
+  const size_t bytes = (size_t)g.w[level] * g.h[level] * 2;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(gx, it->second.base + g.sob_off[level][0], bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(gy, it->second.base + g.sob_off[level][1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1078 @@
+// hso_tracker.hip — CoarseTracker on gfx950: pyramidal direct photometric alignment
+// (7-DoF: exposure ratio + SE(3)) with the whole coarse-to-fine Levenberg-Marquardt
+// loop resident on the device.
+//
+// Replaces CoarseTracker::run and its helpers (reference src/CoarseTracker.cpp):
+//   makeDepthRef :210-240, precomputeReferencePatches :416-497,
+//   selectRobustFunctionLevel :530-644, computeResiduals :242-414,
+//   computeGS :499-525 (+ Accumulator7, include/hso/MatrixAccumulator.h), run :51-208.
+//
+// MI355X design
+//   * one 1024-thread workgroup (16 wave64s, one CU) owns one (ref, cur) pair for
+//     the whole level/LM loop; independent pairs are pulled from a device-side job
+//     counter by a persistent grid (one workgroup per CU), so a batch fills the chip
+//     with no host round trip and no inter-workgroup communication;
+//   * the current level image is staged once per level into LDS (<= 90 KB for
+//     EuRoC level 1); every bilinear / gradient tap is then an LDS read of two
+//     aligned dwords + v_alignbyte_b32 (4 neighbouring pixels per row fetch);
+//   * per-term arithmetic mirrors the reference's float expressions exactly
+//     (compiled with -ffp-contract=off) so residuals, weights, saturation
+//     decisions, term counts and the MAD thresholds are bit-identical to the CPU
+//     restatement; only the sums H, b, E differ (fp64 fixed-tree reductions here,
+//     3-tier fp32 / serial fp32 in the reference);
+//   * J = [-I_ref, dx*A + dy*B] with A = fx_l*J_row0, B = fy_l*J_row1 is never
+//     materialised: per feature nine weighted moments of (I_ref, dx, dy, r) are
+//     accumulated over the pattern and expanded once into the 28+7 normal-equation
+//     entries; wave64 DPP reductions + one LDS stage finish the sum;
+//   * median / MAD are exact order statistics (radix select on float bit patterns),
+//     equal to nth_element at floor(n/2) (include/hso/vikit/math_utils.h:119-126).
+// Nothing here is a dense contraction, so MFMA is not used (BASELINE.json north_star).
+#include "hso_ctx.h"
+#include "hso_dev_math.h"
+#include <string.h>
+#include <algorithm>
+
+using namespace hso_dev;
+
+#define TRK_THREADS 512
+#define TRK_WAVES (TRK_THREADS / 64)
+#define TRK_MAX_PA 25
+#define SEL_BINS 2048
+#define SEL_CAND_CAP 4096
+#define KEY_INVALID 0xFFFFFFFFu
+#define N_RED 38  // 28 H + 7 b + E + n_terms + n_saturated
+
+// include/hso/CoarseTracker.h:58-120 (staticPattern, staticPatternNum, staticPatternPadding)
+__constant__ int8_t c_pattern[8][40][2] = {
+  { {0,0} },
+  { {0,-1}, {-1,0}, {0,0}, {1,0}, {0,1} },
+  { {-1,-1}, {-1,0}, {-1,1}, {-1,0}, {0,0}, {0,1}, {1,-1}, {1,0}, {1,1} },
+  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {0,-1}, {-1,0}, {1,0}, {0,1} },
+  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {-2,-2}, {-2,2}, {2,-2}, {2,2} },
+  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {-2,-2}, {-2,2}, {2,-2}, {2,2},
+    {-3,-1}, {-3,1}, {3,-1}, {3,1}, {1,-3}, {-1,-3}, {1,3}, {-1,3} },
+  { {-2,-2}, {-2,-1}, {-2,0}, {-2,1}, {-2,2}, {-1,-2}, {-1,-1}, {-1,0}, {-1,1}, {-1,2},
+    {0,-2}, {0,-1}, {0,0}, {0,1}, {0,2}, {1,-2}, {1,-1}, {1,0}, {1,1}, {1,2},
+    {2,-2}, {2,-1}, {2,0}, {2,1}, {2,2} },
+  { {-4,-4}, {-4,-2}, {-4,0}, {-4,2}, {-4,4}, {-2,-4}, {-2,-2}, {-2,0}, {-2,2}, {-2,4},
+    {0,-4}, {0,-2}, {0,0}, {0,2}, {0,4}, {2,-4}, {2,-2}, {2,0}, {2,2}, {2,4},
+    {4,-4}, {4,-2}, {4,0}, {4,2}, {4,4} },
+};
+static const int8_t h_pattern[8][40][2] = {
+  { {0,0} },
+  { {0,-1}, {-1,0}, {0,0}, {1,0}, {0,1} },
+  { {-1,-1}, {-1,0}, {-1,1}, {-1,0}, {0,0}, {0,1}, {1,-1}, {1,0}, {1,1} },
+  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {0,-1}, {-1,0}, {1,0}, {0,1} },
+  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {-2,-2}, {-2,2}, {2,-2}, {2,2} },
+  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {-2,-2}, {-2,2}, {2,-2}, {2,2},
+    {-3,-1}, {-3,1}, {3,-1}, {3,1}, {1,-3}, {-1,-3}, {1,3}, {-1,3} },
+  { {-2,-2}, {-2,-1}, {-2,0}, {-2,1}, {-2,2}, {-1,-2}, {-1,-1}, {-1,0}, {-1,1}, {-1,2},
+    {0,-2}, {0,-1}, {0,0}, {0,1}, {0,2}, {1,-2}, {1,-1}, {1,0}, {1,1}, {1,2},
+    {2,-2}, {2,-1}, {2,0}, {2,1}, {2,2} },
+  { {-4,-4}, {-4,-2}, {-4,0}, {-4,2}, {-4,4}, {-2,-4}, {-2,-2}, {-2,0}, {-2,2}, {-2,4},
+    {0,-4}, {0,-2}, {0,0}, {0,2}, {0,4}, {2,-4}, {2,-2}, {2,0}, {2,2}, {2,4},
+    {4,-4}, {4,-2}, {4,0}, {4,2}, {4,4} },
+};
+static const int h_pattern_num[8] = { 1, 5, 9, 13, 13, 21, 25, 25 };
+static const int h_pattern_pad[8] = { 1, 1, 1, 2, 2, 3, 2, 4 };
+#define PATTERN_OFFSET 2  // m_pattern_offset, CoarseTracker.h:122
+
+struct TrackConsts {
+  hso_camera cam;
+  int inverse, max_level, min_level, n_iter;
+  PyrGeom g;
+  int lds_img_cap;    // bytes of LDS available for the staged level image
+  int n_max;          // scratch stride (features)
+  int pat_num[8], pat_pad[8];
+};
+
+struct TrackJobDev {
+  const uint8_t* ref_base;
+  const uint8_t* cur_base;
+  const double* feats;  // SoA [6][n_stride]: px, py, fx, fy, fz, dist
+  int n, n_stride;
+  hso_se3 T;
+  float a;
+  int _pad;
+};
+
+// per-workgroup scratch in global memory (L2 resident): sized for n_max features
+struct Scratch {
+  float* ref_patch;   // [PA][n_max]  reference intensities (m_ref_patch_cache, pixel-major)
+  float* ref_dx;      // [PA][n_max]  inverse-compositional: reference image gradients
+  float* ref_dy;
+  uint32_t* keys;     // [PA*n_max]   |residual| bit patterns for the robust thresholds
+  uint8_t* visible;   // [n_max]      m_visible_fts
+};
+
+HSO_HD size_t scratch_bytes(int n_max)
+{
+  const size_t t = (size_t)TRK_MAX_PA * n_max;
+  return ((t * 4 * 4 + n_max + 255) / 256) * 256;
+}
+HSO_HD Scratch scratch_at(char* base, int n_max)
+{
+  const size_t t = (size_t)TRK_MAX_PA * n_max;
+  Scratch s;
+  s.ref_patch = reinterpret_cast<float*>(base);
+  s.ref_dx = s.ref_patch + t;
+  s.ref_dy = s.ref_dx + t;
+  s.keys = reinterpret_cast<uint32_t*>(s.ref_dy + t);
+  s.visible = reinterpret_cast<uint8_t*>(s.keys + t);
+  return s;
+}
+
+// LDS-resident state of one workgroup
+struct Shared {
+  double red[N_RED];                 // block-reduced sums of the last evaluation
+  double wave_part[TRK_WAVES][N_RED];
+  double H[28], b[7];                // accepted normal equations
+  Se3 T, Tn;                         // m_T_cur_ref, new_T_cur_ref
+  double energy_old;
+  float a, a_new;
+  float huber, outlier, lambda;
+  int level, pat_idx, PA, pad, S;
+  int job, stop, n_select;
+  int use_lds;
+  unsigned hist[SEL_BINS];
+  unsigned cand[SEL_CAND_CAP];
+  unsigned cand_n;
+  int wave_cnt[TRK_WAVES];
+  char2 pat[40];
+};
+
+// the staged level image is addressed either in LDS (explicit address space 3, so the
+// taps compile to ds_read_b32) or in global memory (level too large for LDS)
+typedef const __attribute__((address_space(3))) uint32_t* LdsPtr;
+typedef const uint32_t* GlbPtr;
+
+struct LevelCtx {
+  const TrackConsts* C;
+  const TrackJobDev* job;
+  Scratch sc;
+  GlbPtr cur_glb;          // current level image in global memory (aligned dwords)
+  const uint8_t* ref_img;  // reference level image (global)
+  int cols, rows, level;
+  float scale;
+  double fxl, fyl;
+};
+
+// 4 consecutive bytes starting at byte address `addr` of a dword-aligned buffer
+template <typename Ptr>
+HSO_DEV uint32_t fetch4(Ptr w32, int addr)
+{
+  const int a = addr >> 2;
+  const uint32_t lo = w32[a], hi = w32[a + 1];
+  return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(addr & 3));
+}
+HSO_DEV float b0f(uint32_t v) { return (float)(v & 0xffu); }
+HSO_DEV float b1f(uint32_t v) { return (float)((v >> 8) & 0xffu); }
+HSO_DEV float b2f(uint32_t v) { return (float)((v >> 16) & 0xffu); }
+HSO_DEV float b3f(uint32_t v) { return (float)(v >> 24); }
+
+// projection of one reference feature into the current level
+// (CoarseTracker.cpp:290-323 / :557-583)
+struct Proj {
+  bool ok;
+  int u_i, v_i;
+  float w_tl, w_tr, w_bl, w_br;
+  double x, y, z;
+};
+
+HSO_DEV Proj project_feature(const LevelCtx& L, const Se3& T, int f, int border)
+{
+  Proj p;
+  p.ok = false;
+  const TrackJobDev& J = *L.job;
+  const int ns = J.n_stride;
+  if (!L.sc.visible[f]) return p;
+  const double dist = J.feats[5 * ns + f];
+  if (dist < 0) return p;
+  const double bx = J.feats[2 * ns + f], by = J.feats[3 * ns + f], bz = J.feats[4 * ns + f];
+  se3_apply(T, bx * dist, by * dist, bz * dist, p.x, p.y, p.z);
+  if (p.z < 0) return p;
+  double pu, pv;
+  world2cam(L.C->cam, p.x, p.y, p.z, pu, pv);
+  const float u_cur = (float)pu * L.scale;
+  const float v_cur = (float)pv * L.scale;
+  p.u_i = (int)floorf(u_cur);
+  p.v_i = (int)floorf(v_cur);
+  if (p.u_i - border < 0 || p.v_i - border < 0 || p.u_i + border >= L.cols || p.v_i + border >= L.rows) return p;
+  const float su = u_cur - (float)p.u_i;
+  const float sv = v_cur - (float)p.v_i;
+  p.w_tl = (float)((1.0 - su) * (1.0 - sv));
+  p.w_tr = (float)(su * (1.0 - sv));
+  p.w_bl = (float)((1.0 - su) * sv);
+  p.w_br = su * sv;
+  p.ok = true;
+  return p;
+}
+
+// ------------------------------------------------------- workgroup reductions
+
+struct Acc {
+  float H[28];   // fp32 like the reference's Accumulator7 (MatrixAccumulator.h:33), tree-summed
+  double b[7];   // fp64 like the reference's b (CoarseTracker.cpp:520)
+  double E;
+  int nt, nsat;
+};
+
+HSO_DEV float dpp_sum_f32(float v)
+{
+  v += __int_as_float(dpp_get<0xb1, 0xf>(__float_as_int(v)));
+  v += __int_as_float(dpp_get<0x4e, 0xf>(__float_as_int(v)));
+  v += __int_as_float(dpp_get<0x124, 0xf>(__float_as_int(v)));
+  v += __int_as_float(dpp_get<0x128, 0xf>(__float_as_int(v)));
+  v += __int_as_float(dpp_get<0x142, 0xa>(__float_as_int(v)));
+  v += __int_as_float(dpp_get<0x143, 0xc>(__float_as_int(v)));
+  return v;
+}
+
+HSO_DEV void block_reduce_acc(Shared& s, const Acc& acc)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 28; i++) {
+    const float v = dpp_sum_f32(acc.H[i]);
+    if (lane == 63) s.wave_part[wave][i] = (double)v;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    const double v = wave_sum_to_lane63(acc.b[i]);
+    if (lane == 63) s.wave_part[wave][28 + i] = v;
+  }
+  {
+    const double e = wave_sum_to_lane63(acc.E);
+    const int nt = wave_sum_to_lane63(acc.nt), ns = wave_sum_to_lane63(acc.nsat);
+    if (lane == 63) { s.wave_part[wave][35] = e; s.wave_part[wave][36] = (double)nt; s.wave_part[wave][37] = (double)ns; }
+  }
+  __syncthreads();
+  if (threadIdx.x < N_RED) {
+    double t = 0;
+    for (int w = 0; w < TRK_WAVES; w++) t += s.wave_part[w][threadIdx.x];
+    s.red[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+HSO_DEV int block_sum_int(Shared& s, int v)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = wave_sum_to_lane63(v);
+  __syncthreads();
+  if (lane == 63) s.wave_cnt[wave] = t;
+  __syncthreads();
+  int tot = 0;
+  for (int w = 0; w < TRK_WAVES; w++) tot += s.wave_cnt[w];
+  return tot;
+}
+
+// ------------------------------------------------------------- level set-up
+
+// stage the current level image into LDS (or point at global memory when it does not fit)
+HSO_DEV void stage_level(Shared& s, LevelCtx& L, uint32_t* lds_img)
+{
+  const PyrGeom& g = L.C->g;
+  const int bytes = L.cols * L.rows;
+  const int padded = (bytes + L.cols + 32 + 15) & ~15;  // + the zero row below the image
+  const uint8_t* src = L.job->cur_base + g.off[L.level];
+  if (padded <= L.C->lds_img_cap) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(lds_img);
+    for (int i = threadIdx.x; i < padded / 16; i += TRK_THREADS) d4[i] = s4[i];
+    if (threadIdx.x == 0) s.use_lds = 1;
+  } else {
+    if (threadIdx.x == 0) s.use_lds = 0;
+  }
+  L.cur_glb = reinterpret_cast<const uint32_t*>(src);
+}
+
+// precomputeReferencePatches, CoarseTracker.cpp:416-497.  Thread per (feature, pixel).
+HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L)
+{
+  const TrackJobDev& J = *L.job;
+  const int n = J.n, ns = J.n_stride, nm = L.C->n_max;
+  const int PA = s.PA, border = s.pad + 1;
+  const bool ic = L.C->inverse != 0;
+  const int stride = L.cols;
+  const uint32_t* ref32 = reinterpret_cast<const uint32_t*>(L.ref_img);
+  for (int i = threadIdx.x; i < n * PA; i += TRK_THREADS) {
+    const int f = i % n, pidx = i / n;
+    const float u_ref = (float)(J.feats[0 * ns + f] * (double)L.scale);
+    const float v_ref = (float)(J.feats[1 * ns + f] * (double)L.scale);
+    const int u_i = (int)floorf(u_ref), v_i = (int)floorf(v_ref);
+    const double dist = J.feats[5 * ns + f];
+    const bool vis = dist >= 0 && !(u_i - border < 0 || v_i - border < 0 || u_i + border >= L.cols || v_i + border >= L.rows);
+    if (pidx == 0) L.sc.visible[f] = vis ? 1 : 0;
+    if (!vis) continue;
+    const float su = u_ref - (float)u_i, sv = v_ref - (float)v_i;
+    const float w_tl = (float)((1.0 - su) * (1.0 - sv));
+    const float w_tr = (float)(su * (1.0 - sv));
+    const float w_bl = (float)((1.0 - su) * sv);
+    const float w_br = (float)(1.0 - ((w_tl + w_tr) + w_bl));
+    const int x = u_i + s.pat[pidx].x, y = v_i + s.pat[pidx].y;
+    const int a0 = y * stride + x - 1;
+    const uint32_t r1 = fetch4(ref32, a0), r2 = fetch4(ref32, a0 + stride);
+    L.sc.ref_patch[(size_t)pidx * nm + f] = ((w_tl * b1f(r1) + w_tr * b2f(r1)) + w_bl * b1f(r2)) + w_br * b2f(r2);
+    if (ic) {
+      const uint32_t r0 = fetch4(ref32, a0 - stride), r3 = fetch4(ref32, a0 + 2 * stride);
+      const float dx = 0.5f * ((((w_tl * b2f(r1) + w_tr * b3f(r1)) + w_bl * b2f(r2)) + w_br * b3f(r2))
+                             - (((w_tl * b0f(r1) + w_tr * b1f(r1)) + w_bl * b0f(r2)) + w_br * b1f(r2)));
+      const float dy = 0.5f * ((((w_tl * b1f(r2) + w_tr * b2f(r2)) + w_bl * b1f(r3)) + w_br * b2f(r3))
+                             - (((w_tl * b1f(r0) + w_tr * b2f(r0)) + w_bl * b1f(r1)) + w_br * b2f(r1)));
+      L.sc.ref_dx[(size_t)pidx * nm + f] = dx;
+      L.sc.ref_dy[(size_t)pidx * nm + f] = dy;
+    }
+  }
+}
+
+// ------------------------------------------------------ robust thresholds
+
+// pass 1 of selectRobustFunctionLevel (CoarseTracker.cpp:547-606): |residual| of every
+// in-bounds term, stored as float bit patterns (KEY_INVALID elsewhere).  Returns errors.size().
+template <typename Ptr>
+HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
+{
+  const int n = L.job->n, nm = L.C->n_max;
+  const int PA = s.PA, border = s.pad + 1, S = s.S;
+  const int G = TRK_THREADS / S;
+  const int sub = threadIdx.x % S;
+  const int stride = L.cols;
+  int cnt = 0;
+  for (int base = 0; base < n; base += G) {
+    const int f = base + threadIdx.x / S;
+    if (f >= n) continue;
+    const Proj p = project_feature(L, T, f, border);
+    for (int pidx = sub; pidx < PA; pidx += S) {
+      uint32_t key = KEY_INVALID;
+      if (p.ok) {
+        const int x = p.u_i + s.pat[pidx].x, y = p.v_i + s.pat[pidx].y;
+        const int a0 = y * stride + x;
+        const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
+        const float cur = ((p.w_tl * b0f(r1) + p.w_tr * b1f(r1)) + p.w_bl * b0f(r2)) + p.w_br * b1f(r2);
+        const float res = cur - (a * L.sc.ref_patch[(size_t)pidx * nm + f] + 0.0f);
+        key = __float_as_uint(fabsf(res));
+        cnt++;
+      }
+      L.sc.keys[(size_t)pidx * n + f] = key;
+    }
+  }
+  return block_sum_int(s, cnt);
+}
+
+// Exact k-th smallest (0-based) of the valid keys produced by key_of(i), i in [0, n_slots).
+// Keys are bit patterns of non-negative floats (bit 31 clear), so unsigned order = float
+// order.  MSB-first radix select over digits [30:20], [19:9], [8:0]: a histogram pass per
+// digit narrows the candidates to one bin; as soon as the bin fits in LDS the candidates
+// are gathered and the remaining low bits are fixed one at a time.  The value returned is
+// the element nth_element would leave at position k, whatever the input order.
+// Every wave derives (prefix, rank) from the shared histogram / candidate list on its own,
+// so the running state lives in registers and is identical in all threads by construction.
+template <typename KeyFn>
+HSO_DEV uint32_t radix_select(Shared& s, int n_slots, unsigned k, KeyFn key_of)
+{
+  const int tid = threadIdx.x, lane = threadIdx.x & 63;
+  uint32_t prefix = 0;
+  unsigned rank = k, bin_count = 0;
+  int shift = 31;
+  for (int pass = 0; pass < 3; pass++) {
+    shift = (pass == 0) ? 20 : ((pass == 1) ? 9 : 0);
+    const int width = (pass == 2) ? 9 : 11;
+    const uint32_t hi_mask = ~((1u << (shift + width)) - 1u);  // pass 0: 0x80000000
+    __syncthreads();
+    for (int i = tid; i < SEL_BINS; i += TRK_THREADS) s.hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n_slots; i += TRK_THREADS) {
+      const uint32_t key = key_of(i);
+      if ((key & hi_mask) == prefix) atomicAdd(&s.hist[(key >> shift) & ((1u << width) - 1u)], 1u);
+    }
+    __syncthreads();
+    {
+      // lane l sums bins [32l, 32l+32); inclusive scan over the wave; the owner lane of the
+      // rank walks its 32 bins; the result is broadcast with readlane-style shuffles
+      unsigned local = 0;
+      for (int j = 0; j < 32; j++) local += s.hist[lane * 32 + j];
+      unsigned incl = local;
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+      }
+      const unsigned excl = incl - local;
+      const bool owner = (rank >= excl && rank < incl);
+      unsigned o_bin = 0, o_rank = 0, o_cnt = 0;
+      if (owner) {
+        unsigned run = excl;
+        for (int j = 0; j < 32; j++) {
+          const unsigned c = s.hist[lane * 32 + j];
+          if (rank < run + c) { o_bin = (unsigned)(lane * 32 + j); o_rank = rank - run; o_cnt = c; break; }
+          run += c;
+        }
+      }
+      const unsigned long long m = __ballot(owner);
+      const int src = (m != 0ull) ? (__ffsll((long long)m) - 1) : 0;
+      prefix |= __shfl(o_bin, src) << shift;
+      rank = __shfl(o_rank, src);
+      bin_count = __shfl(o_cnt, src);
+    }
+    if (shift == 0) return prefix;  // all 31 bits fixed
+    if (bin_count <= SEL_CAND_CAP) break;
+  }
+  // gather the candidates (keys that agree with the prefix above bit `shift`) into LDS
+  const uint32_t kmask = ~((1u << shift) - 1u);
+  __syncthreads();
+  if (tid == 0) s.cand_n = 0;
+  __syncthreads();
+  for (int i = tid; i < n_slots; i += TRK_THREADS) {
+    const uint32_t key = key_of(i);
+    if ((key & kmask) == prefix) {
+      const unsigned slot = atomicAdd(&s.cand_n, 1u);
+      if (slot < SEL_CAND_CAP) s.cand[slot] = key;
+    }
+  }
+  __syncthreads();
+  const unsigned nc = min(s.cand_n, (unsigned)SEL_CAND_CAP);
+  uint32_t res = prefix;
+  for (int bit = shift - 1; bit >= 0; bit--) {
+    const uint32_t trial = res | (1u << bit);
+    int c = 0;
+    for (unsigned i = lane; i < nc; i += 64) c += (s.cand[i] < trial) ? 1 : 0;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if ((unsigned)c <= rank) res = trial;  // the rank-th smallest is >= trial
+  }
+  __syncthreads();
+  return res;
+}
+
+// selectRobustFunctionLevel, CoarseTracker.cpp:530-644
+HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
+{
+  const int n_err = s.use_lds ? select_collect<LdsPtr>(s, L, lds_img, T, a)
+                              : select_collect<GlbPtr>(s, L, L.cur_glb, T, a);
+  const int n_slots = L.job->n * s.PA;
+  const uint32_t* keys = L.sc.keys;
+  if (threadIdx.x == 0) s.n_select = n_err;
+  if (n_err < 30) {
+    if (threadIdx.x == 0) { s.huber = 5.2f; s.outlier = 100.f; }
+    __syncthreads();
+    return;
+  }
+  const uint32_t med_bits = radix_select(s, n_slots, (unsigned)(n_err / 2), [&](int i) { return keys[i]; });
+  const float med = __uint_as_float(med_bits);
+  const uint32_t mad_bits = radix_select(s, n_slots, (unsigned)(n_err / 2), [&](int i) {
+    const uint32_t k = keys[i];
+    return (k == KEY_INVALID) ? KEY_INVALID : __float_as_uint(fabsf(__uint_as_float(k) - med));
+  });
+  if (threadIdx.x == 0) {
+    const float standard_deviation = (float)(1.4826 * (double)__uint_as_float(mad_bits));
+    const float huber = med + standard_deviation;
+    float outlier = 3 * huber;
+    if (outlier < 10) outlier = 10;
+    s.huber = huber;
+    s.outlier = outlier;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------ residuals + normal equations
+
+// computeResiduals (CoarseTracker.cpp:242-414) fused with computeGS (:499-525).
+// Leaves the block-reduced sums in s.red: [0..27] H upper triangle (row-major),
+// [28..34] b, [35] E, [36] m_total_terms, [37] m_saturated_terms.
+template <bool IC, typename Ptr>
+HSO_DEV void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
+{
+  const int n = L.job->n, nm = L.C->n_max;
+  const int PA = s.PA, border = s.pad + 1, S = s.S;
+  const int G = TRK_THREADS / S;
+  const int sub = threadIdx.x % S;
+  const int stride = L.cols;
+  const bool top = (L.level == L.C->max_level);
+  const float huber = s.huber;
+  const double cutoff = (double)s.outlier;
+  const float max_energy = (float)((double)(2 * huber) * cutoff - (double)(huber * huber));
+  const int ns = L.job->n_stride;
+
+  Acc acc;
+#pragma unroll
+  for (int i = 0; i < 28; i++) acc.H[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 7; i++) acc.b[i] = 0;
+  acc.E = 0; acc.nt = 0; acc.nsat = 0;
+
+  for (int base = 0; base < n; base += G) {
+    const int f = base + threadIdx.x / S;
+    const bool act = f < n;
+    Proj p; p.ok = false;
+    if (act) p = project_feature(L, T, f, border);
+    // nine weighted moments of (e = -I_ref, dx, dy, r) over this lane's pattern pixels
+    float s_ee = 0, s_ex = 0, s_ey = 0, s_xx = 0, s_xy = 0, s_yy = 0, s_re = 0, s_rx = 0, s_ry = 0;
+    float E = 0;
+    int nt = 0, nsat = 0;
+    if (p.ok) {
+      for (int pidx = sub; pidx < PA; pidx += S) {
+        const int x = p.u_i + s.pat[pidx].x, y = p.v_i + s.pat[pidx].y;
+        const int a0 = y * stride + x - 1;
+        const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
+        const float iref = L.sc.ref_patch[(size_t)pidx * nm + f];
+        const float cur = ((p.w_tl * b1f(r1) + p.w_tr * b2f(r1)) + p.w_bl * b1f(r2)) + p.w_br * b2f(r2);
+        const float res = cur - (a * iref + 0.0f);
+        const float ares = fabsf(res);
+        const float hw = ares < huber ? 1.0f : huber / ares;
+        nt++;
+        if ((double)ares > cutoff && !top) {
+          E += max_energy;
+          nsat++;
+        } else {
+          if (top) E += hw * res * res;
+          else E += hw * res * res * (2 - hw);
+          float dx, dy;
+          if (!IC) {
+            const uint32_t r0 = fetch4(img, a0 - stride), r3 = fetch4(img, a0 + 2 * stride);
+            dx = 0.5f * ((((p.w_tl * b2f(r1) + p.w_tr * b3f(r1)) + p.w_bl * b2f(r2)) + p.w_br * b3f(r2))
+                       - (((p.w_tl * b0f(r1) + p.w_tr * b1f(r1)) + p.w_bl * b0f(r2)) + p.w_br * b1f(r2)));
+            dy = 0.5f * ((((p.w_tl * b1f(r2) + p.w_tr * b2f(r2)) + p.w_bl * b1f(r3)) + p.w_br * b2f(r3))
+                       - (((p.w_tl * b1f(r0) + p.w_tr * b2f(r0)) + p.w_bl * b1f(r1)) + p.w_br * b2f(r1)));
+          } else {
+            dx = L.sc.ref_dx[(size_t)pidx * nm + f];
+            dy = L.sc.ref_dy[(size_t)pidx * nm + f];
+          }
+          const float e = -iref;
+          const float we = hw * e, wx = hw * dx, wy = hw * dy;
+          s_ee = fmaf(we, e, s_ee); s_ex = fmaf(we, dx, s_ex); s_ey = fmaf(we, dy, s_ey);
+          s_xx = fmaf(wx, dx, s_xx); s_xy = fmaf(wx, dy, s_xy); s_yy = fmaf(wy, dy, s_yy);
+          const float wr = hw * res;
+          s_re = fmaf(wr, e, s_re); s_rx = fmaf(wr, dx, s_rx); s_ry = fmaf(wr, dy, s_ry);
+        }
+      }
+    }
+    // combine the S lanes of the feature group (S is a power of two <= 64, groups never straddle waves)
+    for (int m = S >> 1; m > 0; m >>= 1) {
+      s_ee += __shfl_xor(s_ee, m); s_ex += __shfl_xor(s_ex, m); s_ey += __shfl_xor(s_ey, m);
+      s_xx += __shfl_xor(s_xx, m); s_xy += __shfl_xor(s_xy, m); s_yy += __shfl_xor(s_yy, m);
+      s_re += __shfl_xor(s_re, m); s_rx += __shfl_xor(s_rx, m); s_ry += __shfl_xor(s_ry, m);
+      E += __shfl_xor(E, m); nt += __shfl_xor(nt, m); nsat += __shfl_xor(nsat, m);
+    }
+    if (p.ok && sub == 0) {
+      // A = fx_l * J.row(0), B = fy_l * J.row(1) (frame.h:192-212); in inverse-compositional
+      // mode the Jacobian is taken at the reference point and scaled by the exposure ratio
+      // (m_jacobian_cache_true = exposure_rat * m_jacobian_cache_raw, CoarseTracker.cpp:245)
+      double J0[6], J1[6];
+      if (!IC) {
+        jacobian_xyz2uv(p.x, p.y, p.z, J0, J1);
+      } else {
+        const double dist = L.job->feats[5 * ns + f];
+        jacobian_xyz2uv(L.job->feats[2 * ns + f] * dist, L.job->feats[3 * ns + f] * dist,
+                        L.job->feats[4 * ns + f] * dist, J0, J1);
+      }
+      const double sA = IC ? L.fxl * (double)a : L.fxl, sB = IC ? L.fyl * (double)a : L.fyl;
+      double A[6], B[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { A[k] = J0[k] * sA; B[k] = J1[k] * sB; }
+      const double d_ee = s_ee, d_ex = s_ex, d_ey = s_ey, d_xx = s_xx, d_xy = s_xy, d_yy = s_yy;
+      const double d_re = s_re, d_rx = s_rx, d_ry = s_ry;
+      acc.H[0] += (float)d_ee;
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc.H[1 + k] += (float)fma(d_ex, A[k], d_ey * B[k]);
+      int idx = 7;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const double xa = fma(d_xx, A[k], d_xy * B[k]);  // coefficient of A[l]
+        const double xb = fma(d_xy, A[k], d_yy * B[k]);  // coefficient of B[l]
+#pragma unroll
+        for (int l = k; l < 6; l++) { acc.H[idx] += (float)fma(xa, A[l], xb * B[l]); idx++; }
+      }
+      acc.b[0] -= d_re;
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc.b[1 + k] -= fma(d_rx, A[k], d_ry * B[k]);
+      acc.E += (double)E;
+      acc.nt += nt;
+      acc.nsat += nsat;
+    }
+  }
+  block_reduce_acc(s, acc);
+}
+
+template <bool IC>
+HSO_DEV void eval_dispatch(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
+{
+  if (s.use_lds) eval_terms<IC, LdsPtr>(s, L, lds_img, T, a);
+  else eval_terms<IC, GlbPtr>(s, L, L.cur_glb, T, a);
+}
+
+// ----------------------------------------------------------- level + LM loop
+
+HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const TrackJobDev& job,
+                         const Scratch& sc, int level, uint32_t* lds_img)
+{
+  __syncthreads();
+  L.C = &C; L.job = &job; L.sc = sc; L.level = level;
+  L.cols = C.g.w[level]; L.rows = C.g.h[level];
+  L.scale = 1.0f / (float)(1 << level);
+  L.fxl = C.cam.fx * (double)L.scale;
+  L.fyl = C.cam.fy * (double)L.scale;
+  L.ref_img = job.ref_base + C.g.off[level];
+  const int pat_idx = C.max_level - level + PATTERN_OFFSET;  // CoarseTracker.cpp:80
+  if (threadIdx.x == 0) {
+    s.level = level; s.pat_idx = pat_idx; s.PA = C.pat_num[pat_idx]; s.pad = C.pat_pad[pat_idx];
+    int S = 1;
+    while (S < 16 && job.n * S * 2 <= TRK_THREADS) S *= 2;
+    s.S = S;
+  }
+  if (threadIdx.x < 40) s.pat[threadIdx.x] = make_char2(c_pattern[pat_idx][threadIdx.x][0], c_pattern[pat_idx][threadIdx.x][1]);
+  stage_level(s, L, lds_img);
+  __syncthreads();
+  precompute_reference(s, L);
+  __syncthreads();
+}
+
+// thread 0: one Levenberg-Marquardt proposal (CoarseTracker.cpp:112-133)
+HSO_DEV void lm_propose(Shared& s, bool inverse, double step_out[7])
+{
+  double Hl[49], step[7];
+  int idx = 0;
+  for (int r = 0; r < 7; r++)
+    for (int c = r; c < 7; c++) { Hl[r * 7 + c] = Hl[c * 7 + r] = s.H[idx]; idx++; }
+  const float lambda = s.lambda;
+  for (int i = 0; i < 7; i++) Hl[i * 7 + i] *= (double)(1 + lambda);
+  ldlt_solve<7>(Hl, s.b, step);
+  float extrap_fac = 1;
+  if ((double)lambda < 0.001) extrap_fac = (float)sqrt(sqrt(0.001 / (double)lambda));
+  double ssum = 0;
+  for (int i = 0; i < 7; i++) { step[i] *= (double)extrap_fac; ssum += step[i]; }
+  if (!isfinite(ssum) || isnan(step[0])) for (int i = 0; i < 7; i++) step[i] = 0;
+  s.a_new = (float)((double)s.a + step[0]);
+  double neg[6];
+  for (int i = 0; i < 6; i++) neg[i] = -step[1 + i];
+  const Se3 dT = se3_exp(neg);
+  s.Tn = inverse ? se3_mul(s.T, dT) : se3_mul(dT, s.T);
+  for (int i = 0; i < 7; i++) step_out[i] = step[i];
+}
+
+template <bool IC>
+HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, const Scratch& sc,
+                       uint32_t* lds_img, hso_track_result* out)
+{
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    memset(out, 0, sizeof(*out));
+    s.T = se3_from(job.T);
+    s.a = job.a;
+  }
+  __syncthreads();
+  if (job.n == 0) {  // CoarseTracker.cpp:53-54
+    if (tid == 0) { se3_to(s.T, out->T_cur_ref); out->exposure_rat = s.a; }
+    return;
+  }
+  LevelCtx L;
+  for (int level = C.max_level; level >= C.min_level; --level) {
+    begin_level(s, L, C, job, sc, level, lds_img);
+    {
+      const Se3 T0 = s.T; const float a0 = s.a;
+      select_robust(s, L, (LdsPtr)lds_img, T0, a0);
+      eval_dispatch<IC>(s, L, (LdsPtr)lds_img, T0, a0);
+    }
+    if (tid == 0) {
+      for (int i = 0; i < 28; i++) s.H[i] = s.red[i];
+      for (int i = 0; i < 7; i++) s.b[i] = s.red[28 + i];
+      s.energy_old = (double)((float)s.red[35] / (float)(int)s.red[36]);
+      s.lambda = 0.1f;
+      s.stop = 0;
+      out->huber[level] = s.huber; out->outlier[level] = s.outlier;
+      out->n_select[level] = s.n_select;
+      out->n_eval[level] = 1;
+    }
+    __syncthreads();
+    for (int iter = 0; iter < C.n_iter; iter++) {
+      double step[7];
+      if (tid == 0) lm_propose(s, IC, step);
+      __syncthreads();
+      {
+        const Se3 Tn = s.Tn; const float an = s.a_new;
+        eval_dispatch<IC>(s, L, (LdsPtr)lds_img, Tn, an);
+      }
+      if (tid == 0) {
+        const double energy_new = (double)((float)s.red[35] / (float)(int)s.red[36]);
+        out->n_eval[level]++;
+        out->iters[level] = iter + 1;
+        if (energy_new < s.energy_old) {
+          for (int i = 0; i < 28; i++) s.H[i] = s.red[i];
+          for (int i = 0; i < 7; i++) s.b[i] = s.red[28 + i];
+          s.energy_old = energy_new;
+          s.a = s.a_new;
+          s.T = s.Tn;
+          s.lambda = (float)((double)s.lambda * 0.5);
+          if (iter < 64) out->accept_mask[level] |= (1ull << iter);
+        } else {
+          s.lambda = s.lambda * 4;
+          if ((double)s.lambda < 0.001) s.lambda = (float)0.001;
+        }
+        double nrm = 0;
+        for (int i = 0; i < 7; i++) nrm += step[i] * step[i];
+        nrm = sqrt(nrm);
+        if (!(nrm > 1e-4)) s.stop = 1;
+        // the last evaluation defines m_total_terms / m_saturated_terms (CoarseTracker.cpp:207)
+        out->n_terms_last = (int)s.red[36];
+        out->n_saturated_last = (int)s.red[37];
+      }
+      __syncthreads();
+      if (s.stop) break;
+    }
+    if (tid == 0) {
+      out->energy[level] = s.energy_old;
+      if (C.n_iter == 0) { out->n_terms_last = (int)s.red[36]; out->n_saturated_last = (int)s.red[37]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    se3_to(s.T, out->T_cur_ref);
+    out->exposure_rat = s.a;
+    out->n_tracked = (int)((float)out->n_terms_last / (float)s.PA);
+    out->status = 0;
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) char g_smem[];
+
+template <bool IC>
+__global__ __launch_bounds__(TRK_THREADS) void k_track(TrackConsts C, const TrackJobDev* jobs, int n_jobs,
+                                                       int* job_counter, char* scratch, size_t scratch_stride,
+                                                       hso_track_result* results)
+{
+  Shared& s = *reinterpret_cast<Shared*>(g_smem);
+  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
+  const Scratch sc = scratch_at(scratch + (size_t)blockIdx.x * scratch_stride, C.n_max);
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s.job = atomicAdd(job_counter, 1);
+    __syncthreads();
+    const int j = s.job;
+    if (j >= n_jobs) break;
+    track_one<IC>(s, C, jobs[j], sc, lds_img, &results[j]);
+  }
+}
+
+// parity hook: one level, optional threshold selection, one evaluation
+struct EvalArgs {
+  int level;
+  hso_se3 T;
+  float a, huber, outlier;
+};
+
+template <bool IC>
+__global__ __launch_bounds__(TRK_THREADS) void k_eval(TrackConsts C, const TrackJobDev* jobs, EvalArgs ea,
+                                                      char* scratch, hso_eval_out* out)
+{
+  Shared& s = *reinterpret_cast<Shared*>(g_smem);
+  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
+  const Scratch sc = scratch_at(scratch, C.n_max);
+  const TrackJobDev& job = jobs[0];
+  LevelCtx L;
+  if (threadIdx.x == 0) { s.T = se3_from(ea.T); s.a = ea.a; s.n_select = 0; }
+  begin_level(s, L, C, job, sc, ea.level, lds_img);
+  const Se3 T0 = s.T; const float a0 = s.a;
+  if (ea.huber <= 0) {
+    select_robust(s, L, (LdsPtr)lds_img, T0, a0);
+  } else {
+    if (threadIdx.x == 0) { s.huber = ea.huber; s.outlier = ea.outlier; }
+    __syncthreads();
+  }
+  eval_dispatch<IC>(s, L, (LdsPtr)lds_img, T0, a0);
+  int nv = 0;
+  for (int i = threadIdx.x; i < job.n; i += TRK_THREADS) nv += sc.visible[i];
+  nv = block_sum_int(s, nv);
+  if (threadIdx.x == 0) {
+    int idx = 0;
+    for (int r = 0; r < 7; r++)
+      for (int c = r; c < 7; c++) { out->H[r * 7 + c] = out->H[c * 7 + r] = s.red[idx]; idx++; }
+    for (int i = 0; i < 7; i++) out->b[i] = s.red[28 + i];
+    out->energy_sum = s.red[35];
+    out->n_terms = (int)s.red[36];
+    out->n_saturated = (int)s.red[37];
+    out->energy = (double)((float)s.red[35] / (float)out->n_terms);
+    out->n_select = s.n_select;
+    out->n_visible = nv;
+    out->huber = s.huber; out->outlier = s.outlier;
+  }
+}
+
+// makeDepthRef, CoarseTracker.cpp:210-240
+__global__ void k_make_depth_ref(const hso_depth_ref_in* in, int n, const hso_se3* poses, hso_se3 T_ref_w, double* out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double d = -1;
+  if (in[i].has_point) {
+    const double inv = 1.0 / in[i].idist;
+    const Se3 Th = se3_from(poses[in[i].host_pose]);
+    const Se3 T_r_h = se3_mul(se3_from(T_ref_w), se3_inverse(Th));
+    double x, y, z;
+    se3_apply(T_r_h, in[i].host_f[0] * inv, in[i].host_f[1] * inv, in[i].host_f[2] * inv, x, y, z);
+    if (!(z < 0.00001)) d = sqrt(x * x + y * y + z * z);
+  }
+  out[i] = d;
+}
+
+// ------------------------------------------------------------------ host side
+
+struct TrackBatchState {
+  TrackConsts C;
+  int n_jobs = 0, n_max = 0, grid = 0;
+  size_t lds_bytes = 0, scratch_stride = 0;
+  TrackJobDev* d_jobs = nullptr; size_t jobs_cap = 0;
+  double* d_feats = nullptr; size_t feats_cap = 0;
+  char* d_scratch = nullptr; size_t scratch_cap = 0;
+  hso_track_result* d_results = nullptr; size_t results_cap = 0;
+  int* d_counter = nullptr;
+  hso_eval_out* d_eval = nullptr;
+  bool attr_set = false;
+  std::vector<double> h_feats;
+  std::vector<TrackJobDev> h_jobs;
+};
+
+void hso_track_state_free(hso_gpu_ctx* ctx)
+{
+  TrackBatchState* st = ctx->track;
+  if (!st) return;
+  (void)hipFree(st->d_jobs); (void)hipFree(st->d_feats); (void)hipFree(st->d_scratch); (void)hipFree(st->d_results);
+  (void)hipFree(st->d_counter); (void)hipFree(st->d_eval);
+  delete st;
+  ctx->track = nullptr;
+}
+
+template <typename T>
+static int grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need_bytes)
+{
+  if (*cap >= need_bytes && *p) return HSO_OK;
+  if (*p) { HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(*p); *p = nullptr; }
+  const size_t bytes = std::max<size_t>(need_bytes, 256);
+  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
+  *cap = bytes;
+  return HSO_OK;
+}
+
+static const size_t kLdsTotal = 160 * 1024;  // LDS per CU on gfx950
+
+static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* p,
+                         const hso_track_job* jobs, int n_jobs, int max_grid)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!cam || !p || !jobs || n_jobs <= 0) return hso_fail(ctx, HSO_E_INVALID, "coarse_track: null argument or no jobs");
+  if (p->max_level < 0 || p->max_level >= HSO_N_PYR_LEVELS || p->min_level < 0 || p->min_level > p->max_level)
+    return hso_fail(ctx, HSO_E_INVALID, "coarse_track: bad level range");
+  if (p->n_iter < 0) return hso_fail(ctx, HSO_E_INVALID, "coarse_track: n_iter < 0");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->track) ctx->track = new TrackBatchState();
+  TrackBatchState* st = ctx->track;
+
+  // geometry: all frames of a batch share it
+  auto it0 = ctx->frames.find(jobs[0].cur_frame_id);
+  if (it0 == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "coarse_track: current frame not resident");
+  const PyrGeom g = it0->second.g;
+  if (cam->width != g.w[0] || cam->height != g.h[0])
+    return hso_fail(ctx, HSO_E_INVALID, "coarse_track: camera size differs from the frame size");
+
+  int n_max = 1;
+  size_t total_feats = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    if (jobs[j].n_feats < 0 || (jobs[j].n_feats > 0 && !jobs[j].feats))
+      return hso_fail(ctx, HSO_E_INVALID, "coarse_track: bad feature table");
+    n_max = std::max(n_max, jobs[j].n_feats);
+    total_feats += (size_t)((jobs[j].n_feats + 31) & ~31);
+  }
+  st->h_feats.assign(total_feats * 6, 0.0);
+  st->h_jobs.resize(n_jobs);
+  if (int rc = grow(ctx, &st->d_feats, &st->feats_cap, total_feats * 6 * sizeof(double))) return rc;
+  size_t foff = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    auto itr = ctx->frames.find(jobs[j].ref_frame_id);
+    auto itc = ctx->frames.find(jobs[j].cur_frame_id);
+    if (itr == ctx->frames.end() || itc == ctx->frames.end())
+      return hso_fail(ctx, HSO_E_NOFRAME, "coarse_track: frame not resident");
+    if (itr->second.g.w[0] != g.w[0] || itr->second.g.h[0] != g.h[0] || itc->second.g.w[0] != g.w[0] ||
+        itc->second.g.h[0] != g.h[0])
+      return hso_fail(ctx, HSO_E_INVALID, "coarse_track: frames of one batch must share one size");
+    const int n = jobs[j].n_feats, ns = (n + 31) & ~31;
+    double* dst = st->h_feats.data() + foff * 6;
+    for (int i = 0; i < n; i++) {
+      const hso_ref_feat& f = jobs[j].feats[i];
+      dst[0 * ns + i] = f.px[0]; dst[1 * ns + i] = f.px[1];
+      dst[2 * ns + i] = f.f[0]; dst[3 * ns + i] = f.f[1]; dst[4 * ns + i] = f.f[2];
+      dst[5 * ns + i] = f.dist;
+    }
+    TrackJobDev& d = st->h_jobs[j];
+    d.ref_base = itr->second.base;
+    d.cur_base = itc->second.base;
+    d.feats = st->d_feats + foff * 6;
+    d.n = n; d.n_stride = ns;
+    d.T = jobs[j].T_cur_ref;
+    d.a = jobs[j].exposure_rat;
+    d._pad = 0;
+    foff += ns;
+  }
+
+  TrackConsts& C = st->C;
+  C.cam = *cam;
+  C.inverse = p->inverse_composition; C.max_level = p->max_level; C.min_level = p->min_level; C.n_iter = p->n_iter;
+  C.g = g;
+  C.n_max = (n_max + 31) & ~31;
+  for (int i = 0; i < 8; i++) { C.pat_num[i] = h_pattern_num[i]; C.pat_pad[i] = h_pattern_pad[i]; }
+  const size_t fixed = (sizeof(Shared) + 15) & ~size_t(15);
+  C.lds_img_cap = (int)(kLdsTotal - fixed - 256);
+  st->lds_bytes = kLdsTotal - 256;
+  if (fixed + 4096 > kLdsTotal) return hso_fail(ctx, HSO_E_UNSUPPORTED, "coarse_track: LDS layout too large");
+  st->n_jobs = n_jobs;
+  st->n_max = C.n_max;
+  st->grid = std::min(n_jobs, max_grid > 0 ? max_grid : ctx->n_cu);
+  st->scratch_stride = scratch_bytes(C.n_max);
+
+  if (int rc = grow(ctx, &st->d_jobs, &st->jobs_cap, sizeof(TrackJobDev) * n_jobs)) return rc;
+  if (int rc = grow(ctx, &st->d_scratch, &st->scratch_cap, st->scratch_stride * st->grid)) return rc;
+  if (int rc = grow(ctx, &st->d_results, &st->results_cap, sizeof(hso_track_result) * n_jobs)) return rc;
+  if (!st->d_counter) HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&st->d_counter), 256));
+  if (!st->d_eval) HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&st->d_eval), sizeof(hso_eval_out)));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_feats, st->h_feats.data(), total_feats * 6 * sizeof(double),
+                                    hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_jobs, st->h_jobs.data(), sizeof(TrackJobDev) * n_jobs,
+                                    hipMemcpyHostToDevice, ctx->stream));
+  if (!st->attr_set) {
+    HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_track<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes));
+    HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_track<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes));
+    HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes));
+    HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes));
+    st->attr_set = true;
+  }
+  // the staged image may still be read from pageable host vectors until the copies land
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+extern "C" {
+
+int hso_gpu_coarse_track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* params,
+                                 const hso_track_job* jobs, int n_jobs)
+{
+  return track_prepare(ctx, cam, params, jobs, n_jobs, 0);
+}
+
+int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx)
+{
+  if (!ctx || !ctx->track || ctx->track->n_jobs <= 0) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_launch: nothing prepared");
+  TrackBatchState* st = ctx->track;
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(st->d_counter, 0, sizeof(int), ctx->stream));
+  if (st->C.inverse)
+    hipLaunchKernelGGL(k_track<true>, dim3(st->grid), dim3(TRK_THREADS), st->lds_bytes, ctx->stream, st->C, st->d_jobs,
+                       st->n_jobs, st->d_counter, st->d_scratch, st->scratch_stride, st->d_results);
+  else
+    hipLaunchKernelGGL(k_track<false>, dim3(st->grid), dim3(TRK_THREADS), st->lds_bytes, ctx->stream, st->C, st->d_jobs,
+                       st->n_jobs, st->d_counter, st->d_scratch, st->scratch_stride, st->d_results);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
+}
+
+int hso_gpu_coarse_track_collect(hso_gpu_ctx* ctx, hso_track_result* results)
+{
+  if (!ctx || !ctx->track || !results) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_collect: bad argument");
+  TrackBatchState* st = ctx->track;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(results, st->d_results, sizeof(hso_track_result) * st->n_jobs,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+int hso_gpu_coarse_track_batch(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* params,
+                               const hso_track_job* jobs, int n_jobs, hso_track_result* results)
+{
+  if (!results) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_batch: null results");
+  int rc = track_prepare(ctx, cam, params, jobs, n_jobs, 0);
+  if (rc < 0) return rc;
+  rc = hso_gpu_coarse_track_launch(ctx);
+  if (rc < 0) return rc;
+  return hso_gpu_coarse_track_collect(ctx, results);
+}
+
+int hso_gpu_tracker_eval(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* params,
+                         const hso_track_job* job, int level, const hso_se3* T_cur_ref, float exposure_rat,
+                         float huber_thresh, float outlier_thresh, hso_eval_out* out, float* ref_patch_out,
+                         uint8_t* visible_out, float* abs_err_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!job || !T_cur_ref || !out || !params) return hso_fail(ctx, HSO_E_INVALID, "tracker_eval: null argument");
+  if (level < params->min_level || level > params->max_level) return hso_fail(ctx, HSO_E_INVALID, "tracker_eval: level out of range");
+  int rc = track_prepare(ctx, cam, params, job, 1, 1);
+  if (rc < 0) return rc;
+  TrackBatchState* st = ctx->track;
+  EvalArgs ea;
+  ea.level = level; ea.T = *T_cur_ref; ea.a = exposure_rat; ea.huber = huber_thresh; ea.outlier = outlier_thresh;
+  if (st->C.inverse)
+    hipLaunchKernelGGL(k_eval<true>, dim3(1), dim3(TRK_THREADS), st->lds_bytes, ctx->stream, st->C, st->d_jobs, ea,
+                       st->d_scratch, st->d_eval);
+  else
+    hipLaunchKernelGGL(k_eval<false>, dim3(1), dim3(TRK_THREADS), st->lds_bytes, ctx->stream, st->C, st->d_jobs, ea,
+                       st->d_scratch, st->d_eval);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, st->d_eval, sizeof(hso_eval_out), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int pat_idx = params->max_level - level + PATTERN_OFFSET;
+  const int PA = h_pattern_num[pat_idx], n = job->n_feats, nm = st->C.n_max;
+  const Scratch sc = scratch_at(st->d_scratch, nm);
+  if (ref_patch_out && n > 0) {
+    std::vector<float> tmp((size_t)PA * nm);
+    HSO_HIP_CHECK(ctx, hipMemcpy(tmp.data(), sc.ref_patch, tmp.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> vis(nm);
+    HSO_HIP_CHECK(ctx, hipMemcpy(vis.data(), sc.visible, nm, hipMemcpyDeviceToHost));
+    for (int f = 0; f < n; f++)
+      for (int pi = 0; pi < PA; pi++) ref_patch_out[(size_t)f * PA + pi] = vis[f] ? tmp[(size_t)pi * nm + f] : 0.0f;
+  }
+  if (visible_out && n > 0) HSO_HIP_CHECK(ctx, hipMemcpy(visible_out, sc.visible, n, hipMemcpyDeviceToHost));
+  if (abs_err_out && n > 0 && huber_thresh <= 0) {
+    std::vector<uint32_t> keys((size_t)PA * n);
+    HSO_HIP_CHECK(ctx, hipMemcpy(keys.data(), sc.keys, keys.size() * 4, hipMemcpyDeviceToHost));
+    size_t k = 0;
+    for (size_t i = 0; i < keys.size(); i++)
+      if (keys[i] != KEY_INVALID) { float v; memcpy(&v, &keys[i], 4); abs_err_out[k++] = v; }
+  }
+  return HSO_OK;
+}
+
+int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch, int8_t* offsets_xy)
+{
+  const int off = max_level - level + PATTERN_OFFSET;
+  if (off < 0 || off > 7) return HSO_E_INVALID;
+  if (patch_area) *patch_area = h_pattern_num[off];
+  if (half_patch) *half_patch = h_pattern_pad[off];
+  if (offsets_xy) memcpy(offsets_xy, h_pattern[off], 80);
+  return off;
+}
+
+int hso_gpu_make_depth_ref(hso_gpu_ctx* ctx, const hso_depth_ref_in* in, int n, const hso_se3* poses_f_w,
+                           int n_poses, const hso_se3* T_ref_w, double* dist_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n < 0 || (n > 0 && (!in || !dist_out)) || !poses_f_w || !T_ref_w || n_poses <= 0)
+    return hso_fail(ctx, HSO_E_INVALID, "make_depth_ref: bad argument");
+  if (n == 0) return HSO_OK;
+  for (int i = 0; i < n; i++)
+    if (in[i].has_point && (in[i].host_pose < 0 || in[i].host_pose >= n_poses))
+      return hso_fail(ctx, HSO_E_INVALID, "make_depth_ref: host_pose out of range");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  char* d = nullptr;
+  const size_t b_in = sizeof(hso_depth_ref_in) * n, b_p = sizeof(hso_se3) * n_poses, b_o = sizeof(double) * n;
+  const size_t o1 = (b_in + 255) & ~size_t(255), o2 = o1 + ((b_p + 255) & ~size_t(255));
+  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&d), o2 + b_o));
+  (void)hipMemcpyAsync(d, in, b_in, hipMemcpyHostToDevice, ctx->stream);
+  (void)hipMemcpyAsync(d + o1, poses_f_w, b_p, hipMemcpyHostToDevice, ctx->stream);
+  hipLaunchKernelGGL(k_make_depth_ref, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<const hso_depth_ref_in*>(d), n, reinterpret_cast<const hso_se3*>(d + o1),
+                     *T_ref_w, reinterpret_cast<double*>(d + o2));
+  hipError_t e = hipMemcpyAsync(dist_out, d + o2, b_o, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess || e2 != hipSuccess) { ctx->err = "make_depth_ref: HIP failure"; return HSO_E_HIP; }
+  return HSO_OK;
+}
+
+}  // extern "C"

@@ -90,6 +90,16 @@ int hso_gpu_synchronize(hso_gpu_ctx* ctx);
 int hso_gpu_frame_upload(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img,
                          int width, int height, int img_is_device,
                          hso_frame_stats* stats_out);
+/* Batched form: n frames of one size in three launches.  imgs[i] are n HOST
+ * pointers or n DEVICE pointers (img_is_device).  A frame id that is already
+ * resident is refreshed in place (same size required) — the batched analogue of
+ * constructing the next Frame of each of n independent sequences.  With device
+ * images and stats_out == NULL the call is asynchronous on the context stream
+ * (hipMemcpyAsync of the pointer tables from pageable memory returns after the
+ * staging copy, so the host arrays may be reused). */
+int hso_gpu_frame_upload_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids,
+                               const uint8_t* const* imgs, int n, int width, int height,
+                               int img_is_device, hso_frame_stats* stats_out /* n or NULL */);
 int hso_gpu_frame_release(hso_gpu_ctx* ctx, int64_t frame_id);
 /* parity/debug read-back: level in [0,5); out has (w>>level)*(h>>level) bytes */
 int hso_gpu_frame_download_level(hso_gpu_ctx* ctx, int64_t frame_id, int level,

@@ -42,6 +42,13 @@ void hso_or_ldlt_solve(const double* A, const double* b, int n, double* x);
 float hso_or_median_f(float* data, int n);   /* hso::getMedian, include/hso/vikit/math_utils.h:119-126 (upper median; permutes data) */
 double hso_or_median_d(double* data, int n);
 
+/* ---- robust cost (src/vikit/robust_cost.cpp) — pinned against oracle/_ref ---- */
+float hso_or_huber_weight(float k, float t);                    /* robust_cost.cpp:141-148 */
+float hso_or_tukey_weight(float b, float x);                    /* :93-103 */
+float hso_or_tdist_weight(float dof, float x);                  /* :117-121 */
+float hso_or_mad_scale(const float* errors, int n);             /* :67-74 */
+float hso_or_tdist_scale(float dof, const float* errors, int n);/* :38-63 */
+
 /* ---- camera (src/camera.cpp) ---- */
 void hso_or_world2cam(const hso_camera* cam, const double xyz[3], double px[2]); /* camera.cpp:94-125,196-221,295-303 */
 void hso_or_cam2world(const hso_camera* cam, double u, double v, double f[3]);    /* camera.cpp:67-87,171-194,283-286 */

@@ -73,6 +73,13 @@ def load():
     lib.hso_or_tracker_run.argtypes = [vp, P(SE3), C.c_float, P(TrackResult)]
     lib.hso_or_tracker_run.restype = None
     lib.hso_or_tracker_pattern.argtypes = [i32, i32, P(i32), P(i32), vp]
+    for name in ("hso_or_huber_weight", "hso_or_tukey_weight", "hso_or_tdist_weight"):
+        getattr(lib, name).argtypes = [C.c_float, C.c_float]
+        getattr(lib, name).restype = C.c_float
+    lib.hso_or_mad_scale.argtypes = [vp, i32]
+    lib.hso_or_mad_scale.restype = C.c_float
+    lib.hso_or_tdist_scale.argtypes = [C.c_float, vp, i32]
+    lib.hso_or_tdist_scale.restype = C.c_float
     _lib = lib
     return lib
 
@@ -137,10 +144,24 @@ def cam2world(cam, u, v):
 
 
 # -------------------------------------------------------------------- frames
+def _padded_zeros(h, w):
+    """(h, w) view of a buffer with two extra zero rows: the reference's dy taps read
+    row `rows` of a level for features on the bottom border (src/CoarseTracker.cpp:370,491,
+    a heap over-read there); oracle and GPU both define those bytes as 0."""
+    return np.zeros((h + 2, w), np.uint8)[:h]
+
+
+def _padded_copy(a):
+    a = np.asarray(a, np.uint8)
+    out = _padded_zeros(*a.shape)
+    out[:] = a
+    return out
+
+
 def create_pyramid(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
-    levels = [np.zeros((h >> i, w >> i), np.uint8) for i in range(N_PYR_LEVELS)]
+    levels = [_padded_zeros(h >> i, w >> i) for i in range(N_PYR_LEVELS)]
     ptrs = (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in levels])
     rc = load().hso_or_create_pyramid(_ptr(img), w, h, ptrs)
     if rc != 0:
@@ -184,8 +205,8 @@ def make_depth_ref(din, poses, T_ref_w):
 class Tracker:
     def __init__(self, cam, params, ref_pyr, cur_pyr, feats):
         self.lib = load()
-        self.ref_pyr = [np.ascontiguousarray(l) for l in ref_pyr]
-        self.cur_pyr = [np.ascontiguousarray(l) for l in cur_pyr]
+        self.ref_pyr = [_padded_copy(l) for l in ref_pyr]
+        self.cur_pyr = [_padded_copy(l) for l in cur_pyr]
         self.feats = np.ascontiguousarray(feats, dtype=REF_FEAT_DTYPE)
         self.params = params
         h, w = self.ref_pyr[0].shape
