@@ -122,6 +122,13 @@ def load():
         raise HsoGpuError(
             "libhso_gpu.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `python -m hso_amd.build`. There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own libamdhip64; when a process uses both torch and
+    # this library (bench.py, tests), torch's copy must be the one HIP runtime of the
+    # process, so let it load first.  The shared library itself has no torch dependency.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     P = C.POINTER

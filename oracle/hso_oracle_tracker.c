@@ -121,6 +121,7 @@ struct hso_or_tracker {
   int total_terms, saturated_terms;
   float huber, outlier;
   int iter;
+  double E64; /* diagnostics only: the same fp32 terms as E, summed in fp64 */
 };
 
 /* include/hso/frame.h:192-212 */
@@ -331,6 +332,7 @@ static double compute_residuals(hso_or_tracker* t, const hso_se3* T_cur_ref, flo
   t->n_buf = 0;
   t->total_terms = t->saturated_terms = 0;
   float E = 0;
+  double E64 = 0;
 
   for (int fc = 0; fc < t->n; fc++) {
     if (!t->visible[fc]) continue;
@@ -368,12 +370,12 @@ static double compute_residuals(hso_or_tracker* t, const hso_se3* T_cur_ref, flo
       const float hw = fabsf(residual) < setting_huberTH ? 1 : setting_huberTH / fabsf(residual);
 
       if (fabsf(residual) > cutoff_error && t->level < t->p.max_level) {
-        E += max_energy;
+        E += max_energy; E64 += max_energy;
         t->total_terms++;
         t->saturated_terms++;
       } else {
-        if (t->level == t->p.max_level) E += hw * residual * residual;
-        else E += hw * residual * residual * (2 - hw);
+        if (t->level == t->p.max_level) { E += hw * residual * residual; E64 += (float)(hw * residual * residual); }
+        else { E += hw * residual * residual * (2 - hw); E64 += (float)(hw * residual * residual * (2 - hw)); }
         t->total_terms++;
         double* J = t->buf_jac + 7 * (size_t)t->n_buf;
         if (!t->p.inverse_composition) {
@@ -395,6 +397,7 @@ static double compute_residuals(hso_or_tracker* t, const hso_se3* T_cur_ref, flo
     }
   }
   if (E_out) *E_out = E;
+  t->E64 = E64;
   return E / t->total_terms;
 }
 
@@ -429,6 +432,10 @@ void hso_or_tracker_eval(hso_or_tracker* t, const hso_se3* T, float exposure_rat
   for (int i = 0; i < t->n; i++) nv += t->visible[i];
   out->n_visible = nv;
 }
+
+/* diagnostics: fp64 sum of the fp32 energy terms of the last evaluation (the reference's
+ * own E is the serial fp32 sum returned in hso_eval_out.energy_sum) */
+double hso_or_tracker_energy_f64(const hso_or_tracker* t) { return t->E64; }
 
 /* CoarseTracker.cpp:51-208 (without the frame write-back of :198-202) */
 void hso_or_tracker_run(hso_or_tracker* t, const hso_se3* T_init, float exposure_init, hso_track_result* out)

@@ -68,6 +68,8 @@ def load():
     lib.hso_or_tracker_set_thresholds.restype = None
     lib.hso_or_tracker_eval.argtypes = [vp, P(SE3), C.c_float, P(EvalOut)]
     lib.hso_or_tracker_eval.restype = None
+    lib.hso_or_tracker_energy_f64.argtypes = [vp]
+    lib.hso_or_tracker_energy_f64.restype = C.c_double
     lib.hso_or_tracker_get_cache.argtypes = [vp, vp, vp, P(i32)]
     lib.hso_or_tracker_get_cache.restype = None
     lib.hso_or_tracker_run.argtypes = [vp, P(SE3), C.c_float, P(TrackResult)]
@@ -240,6 +242,9 @@ class Tracker:
         out = EvalOut()
         self.lib.hso_or_tracker_eval(self.h, C.byref(T), a, C.byref(out))
         return out
+
+    def energy_f64(self):
+        return self.lib.hso_or_tracker_energy_f64(self.h)
 
     def cache(self):
         pa = C.c_int()
