@@ -29,7 +29,8 @@ def build(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra) + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = list(extra) + os.environ.get("HSO_EXTRA_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

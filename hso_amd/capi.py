@@ -83,6 +83,7 @@ class TrackResult(C.Structure):
                 ("accept_mask", C.c_uint64 * N_PYR_LEVELS),
                 ("huber", C.c_float * N_PYR_LEVELS), ("outlier", C.c_float * N_PYR_LEVELS),
                 ("n_select", C.c_int32 * N_PYR_LEVELS), ("energy", C.c_double * N_PYR_LEVELS),
+                ("phase_cycles", C.c_uint64 * 10),
                 ("status", C.c_int32), ("_pad", C.c_int32)]
 
 

@@ -8,22 +8,25 @@
 //   computeGS :499-525 (+ Accumulator7, include/hso/MatrixAccumulator.h), run :51-208.
 //
 // MI355X design
-//   * one 1024-thread workgroup (16 wave64s, one CU) owns one (ref, cur) pair for
-//     the whole level/LM loop; independent pairs are pulled from a device-side job
+//   * one workgroup of TRK_THREADS threads (wave64s of one CU) owns one (ref, cur) pair
+//     for the whole level/LM loop; independent pairs are pulled from a device-side job
 //     counter by a persistent grid (one workgroup per CU), so a batch fills the chip
 //     with no host round trip and no inter-workgroup communication;
-//   * the current level image is staged once per level into LDS (<= 90 KB for
-//     EuRoC level 1); every bilinear / gradient tap is then an LDS read of two
+//   * per level the reference image, then the current image, is staged once into LDS
+//     (<= 90 KB for EuRoC level 1); every bilinear / gradient tap is an LDS read of two
 //     aligned dwords + v_alignbyte_b32 (4 neighbouring pixels per row fetch);
-//   * per-term arithmetic mirrors the reference's float expressions exactly
-//     (compiled with -ffp-contract=off) so residuals, weights, saturation
-//     decisions, term counts and the MAD thresholds are bit-identical to the CPU
-//     restatement; only the sums H, b, E differ (fp64 fixed-tree reductions here,
-//     3-tier fp32 / serial fp32 in the reference);
+//   * the arithmetic that feeds decisions (projection, bilinear intensity, residual,
+//     Huber weight, saturation test) mirrors the reference's expressions operation by
+//     operation (compiled with -ffp-contract=off), so visibility, term / saturation
+//     counts and the MAD thresholds are bit-identical to the CPU restatement; the image
+//     gradients and the sums H, b, E only feed tolerance-compared quantities and use FMAs
+//     and fixed-tree reductions (fp32 H like the reference's Accumulator7, fp64 b, fp64 E);
 //   * J = [-I_ref, dx*A + dy*B] with A = fx_l*J_row0, B = fy_l*J_row1 is never
 //     materialised: per feature nine weighted moments of (I_ref, dx, dy, r) are
 //     accumulated over the pattern and expanded once into the 28+7 normal-equation
-//     entries; wave64 DPP reductions + one LDS stage finish the sum;
+//     entries; a halving (reduce-scatter) exchange across the wave + one LDS stage
+//     finish the sum;
+//   * the 7x7 pivoted LDL^T solve runs on one wavefront, matrix entries spread over lanes;
 //   * median / MAD are exact order statistics (radix select on float bit patterns),
 //     equal to nth_element at floor(n/2) (include/hso/vikit/math_utils.h:119-126).
 // Nothing here is a dense contraction, so MFMA is not used (BASELINE.json north_star).
@@ -34,7 +37,9 @@
 
 using namespace hso_dev;
 
-#define TRK_THREADS 512
+#ifndef TRK_THREADS
+#define TRK_THREADS 768
+#endif
 #define TRK_WAVES (TRK_THREADS / 64)
 #define TRK_MAX_PA 25
 #define SEL_BINS 2048
@@ -43,21 +48,6 @@ using namespace hso_dev;
 #define N_RED 38  // 28 H + 7 b + E + n_terms + n_saturated
 
 // include/hso/CoarseTracker.h:58-120 (staticPattern, staticPatternNum, staticPatternPadding)
-__constant__ int8_t c_pattern[8][40][2] = {
-  { {0,0} },
-  { {0,-1}, {-1,0}, {0,0}, {1,0}, {0,1} },
-  { {-1,-1}, {-1,0}, {-1,1}, {-1,0}, {0,0}, {0,1}, {1,-1}, {1,0}, {1,1} },
-  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {0,-1}, {-1,0}, {1,0}, {0,1} },
-  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {-2,-2}, {-2,2}, {2,-2}, {2,2} },
-  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {-2,-2}, {-2,2}, {2,-2}, {2,2},
-    {-3,-1}, {-3,1}, {3,-1}, {3,1}, {1,-3}, {-1,-3}, {1,3}, {-1,3} },
-  { {-2,-2}, {-2,-1}, {-2,0}, {-2,1}, {-2,2}, {-1,-2}, {-1,-1}, {-1,0}, {-1,1}, {-1,2},
-    {0,-2}, {0,-1}, {0,0}, {0,1}, {0,2}, {1,-2}, {1,-1}, {1,0}, {1,1}, {1,2},
-    {2,-2}, {2,-1}, {2,0}, {2,1}, {2,2} },
-  { {-4,-4}, {-4,-2}, {-4,0}, {-4,2}, {-4,4}, {-2,-4}, {-2,-2}, {-2,0}, {-2,2}, {-2,4},
-    {0,-4}, {0,-2}, {0,0}, {0,2}, {0,4}, {2,-4}, {2,-2}, {2,0}, {2,2}, {2,4},
-    {4,-4}, {4,-2}, {4,0}, {4,2}, {4,4} },
-};
 static const int8_t h_pattern[8][40][2] = {
   { {0,0} },
   { {0,-1}, {-1,0}, {0,0}, {1,0}, {0,1} },
@@ -83,7 +73,10 @@ struct TrackConsts {
   PyrGeom g;
   int lds_img_cap;    // bytes of LDS available for the staged level image
   int n_max;          // scratch stride (features)
-  int pat_num[8], pat_pad[8];
+  // per pyramid level: PATCH_AREA, HALF_PATCH_SIZE and the byte offset oy*stride+ox of
+  // every pattern pixel in that level's image (CoarseTracker.cpp:80-82,337)
+  int pa[HSO_N_PYR_LEVELS], pad[HSO_N_PYR_LEVELS];
+  int poff[HSO_N_PYR_LEVELS][TRK_MAX_PA];
 };
 
 struct TrackJobDev {
@@ -125,24 +118,28 @@ HSO_HD Scratch scratch_at(char* base, int n_max)
 // LDS-resident state of one workgroup
 struct Shared {
   double red[N_RED];                 // block-reduced sums of the last evaluation
-  double wave_part[TRK_WAVES][N_RED];
+  double wave_part[TRK_WAVES][N_RED + 2];
   double H[28], b[7];                // accepted normal equations
+  double step[8];                    // LM step of the current proposal
   Se3 T, Tn;                         // m_T_cur_ref, new_T_cur_ref
-  double energy_old;
+  double energy_old, step_norm;
   float a, a_new;
   float huber, outlier, lambda;
-  int level, pat_idx, PA, pad, S;
+  int level, PA, pad, S;
   int job, stop, n_select;
   int use_lds;
   unsigned hist[SEL_BINS];
   unsigned cand[SEL_CAND_CAP];
   unsigned cand_n;
   int wave_cnt[TRK_WAVES];
-  char2 pat[40];
+  int poff[32];                      // byte offset oy*stride+ox of every pattern pixel of this level
+#ifdef HSO_PHASE_TIMERS
+  unsigned long long dbg[8];
+#endif
 };
 
 // the staged level image is addressed either in LDS (explicit address space 3, so the
-// taps compile to ds_read_b32) or in global memory (level too large for LDS)
+// taps compile to ds_read2_b32) or in global memory (level too large for LDS)
 typedef const __attribute__((address_space(3))) uint32_t* LdsPtr;
 typedef const uint32_t* GlbPtr;
 
@@ -151,7 +148,7 @@ struct LevelCtx {
   const TrackJobDev* job;
   Scratch sc;
   GlbPtr cur_glb;          // current level image in global memory (aligned dwords)
-  const uint8_t* ref_img;  // reference level image (global)
+  GlbPtr ref_glb;          // reference level image in global memory
   int cols, rows, level;
   float scale;
   double fxl, fyl;
@@ -170,40 +167,100 @@ HSO_DEV float b1f(uint32_t v) { return (float)((v >> 8) & 0xffu); }
 HSO_DEV float b2f(uint32_t v) { return (float)((v >> 16) & 0xffu); }
 HSO_DEV float b3f(uint32_t v) { return (float)(v >> 24); }
 
+HSO_DEV double shfl_d(double v, int src)
+{
+  const int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+HSO_DEV double shfl_xor_d(double v, int m)
+{
+  const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+  return __hiloint2double(hi, lo);
+}
+
+// FOV (atan) camera: rare, transcendental-heavy — kept out of line so that it does not
+// inflate the register budget of the hot loops
+__device__ __noinline__ void world2cam_fov(const hso_camera* cam, double x, double y, double z, double* pu, double* pv)
+{
+  world2cam(*cam, x, y, z, *pu, *pv);
+}
+
 // projection of one reference feature into the current level
 // (CoarseTracker.cpp:290-323 / :557-583)
 struct Proj {
   bool ok;
-  int u_i, v_i;
+  int base;                      // byte address of pixel (u_i - 1, v_i) in the level image
   float w_tl, w_tr, w_bl, w_br;
   double x, y, z;
 };
 
-HSO_DEV Proj project_feature(const LevelCtx& L, const Se3& T, int f, int border)
+// one feature's record as it sits in memory; loaded a round ahead of its use so that the
+// L2 latency of the five loads hides behind the previous feature's pixel loop
+struct FeatRaw {
+  double bx, by, bz, dist;
+  int vis;
+};
+
+HSO_DEV FeatRaw load_feature(const LevelCtx& L, int f)
+{
+  FeatRaw r;
+  r.vis = 0; r.bx = r.by = r.bz = 0; r.dist = -1;
+  if (f < L.job->n) {
+    const TrackJobDev& J = *L.job;
+    const int ns = J.n_stride;
+    r.vis = L.sc.visible[f];
+    r.dist = J.feats[5 * ns + f];
+    r.bx = J.feats[2 * ns + f]; r.by = J.feats[3 * ns + f]; r.bz = J.feats[4 * ns + f];
+  }
+  return r;
+}
+
+HSO_DEV Proj project_feature(const LevelCtx& L, const Se3& T, const FeatRaw& raw, int border)
 {
   Proj p;
   p.ok = false;
-  const TrackJobDev& J = *L.job;
-  const int ns = J.n_stride;
-  if (!L.sc.visible[f]) return p;
-  const double dist = J.feats[5 * ns + f];
+  if (!raw.vis) return p;
+  const double dist = raw.dist;
   if (dist < 0) return p;
-  const double bx = J.feats[2 * ns + f], by = J.feats[3 * ns + f], bz = J.feats[4 * ns + f];
+  const double bx = raw.bx, by = raw.by, bz = raw.bz;
   se3_apply(T, bx * dist, by * dist, bz * dist, p.x, p.y, p.z);
   if (p.z < 0) return p;
   double pu, pv;
-  world2cam(L.C->cam, p.x, p.y, p.z, pu, pv);
+  const hso_camera& cam = L.C->cam;
+  if (cam.model == HSO_CAM_FOV && cam.distortion) {
+    world2cam_fov(&cam, p.x, p.y, p.z, &pu, &pv);
+  } else {
+    // AbstractCamera::world2cam, src/camera.cpp:89-125 (pinhole, optional radtan)
+    const double u = p.x / p.z, v = p.y / p.z;
+    if (cam.model == HSO_CAM_PINHOLE && cam.distortion) {
+      const double r2 = u * u + v * v;
+      const double r4 = r2 * r2;
+      const double r6 = r4 * r2;
+      const double a1 = 2 * u * v;
+      const double a2 = r2 + 2 * u * u;
+      const double a3 = r2 + 2 * v * v;
+      const double cdist = 1 + cam.d[0] * r2 + cam.d[1] * r4 + cam.d[4] * r6;
+      const double xd = u * cdist + cam.d[2] * a1 + cam.d[3] * a2;
+      const double yd = v * cdist + cam.d[2] * a3 + cam.d[3] * a1;
+      pu = xd * cam.fx + cam.cx;
+      pv = yd * cam.fy + cam.cy;
+    } else {
+      pu = cam.fx * u + cam.cx;
+      pv = cam.fy * v + cam.cy;
+    }
+  }
   const float u_cur = (float)pu * L.scale;
   const float v_cur = (float)pv * L.scale;
-  p.u_i = (int)floorf(u_cur);
-  p.v_i = (int)floorf(v_cur);
-  if (p.u_i - border < 0 || p.v_i - border < 0 || p.u_i + border >= L.cols || p.v_i + border >= L.rows) return p;
-  const float su = u_cur - (float)p.u_i;
-  const float sv = v_cur - (float)p.v_i;
+  const int u_i = (int)floorf(u_cur);
+  const int v_i = (int)floorf(v_cur);
+  if (u_i - border < 0 || v_i - border < 0 || u_i + border >= L.cols || v_i + border >= L.rows) return p;
+  const float su = u_cur - (float)u_i;
+  const float sv = v_cur - (float)v_i;
   p.w_tl = (float)((1.0 - su) * (1.0 - sv));
   p.w_tr = (float)(su * (1.0 - sv));
   p.w_bl = (float)((1.0 - su) * sv);
   p.w_br = su * sv;
+  p.base = v_i * L.cols + u_i - 1;
   p.ok = true;
   return p;
 }
@@ -211,56 +268,64 @@ HSO_DEV Proj project_feature(const LevelCtx& L, const Se3& T, int f, int border)
 // ------------------------------------------------------- workgroup reductions
 
 struct Acc {
-  float H[28];   // fp32 like the reference's Accumulator7 (MatrixAccumulator.h:33), tree-summed
-  double b[7];   // fp64 like the reference's b (CoarseTracker.cpp:520)
-  double E;
-  int nt, nsat;
-};
+  float H[32];   // [0..27] used; fp32 like the reference's Accumulator7 (MatrixAccumulator.h:33)
+  double d[16];  // [0..9] used: b[0..6] (fp64 like CoarseTracker.cpp:520), E, n_terms, n_saturated
+};               // sizes padded to powers of two for the halving exchange (the pads stay 0)
 
-HSO_DEV float dpp_sum_f32(float v)
-{
-  v += __int_as_float(dpp_get<0xb1, 0xf>(__float_as_int(v)));
-  v += __int_as_float(dpp_get<0x4e, 0xf>(__float_as_int(v)));
-  v += __int_as_float(dpp_get<0x124, 0xf>(__float_as_int(v)));
-  v += __int_as_float(dpp_get<0x128, 0xf>(__float_as_int(v)));
-  v += __int_as_float(dpp_get<0x142, 0xa>(__float_as_int(v)));
-  v += __int_as_float(dpp_get<0x143, 0xc>(__float_as_int(v)));
-  return v;
-}
-
-HSO_DEV void block_reduce_acc(Shared& s, const Acc& acc)
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < 28; i++) {
-    const float v = dpp_sum_f32(acc.H[i]);
-    if (lane == 63) s.wave_part[wave][i] = (double)v;
-  }
-#pragma unroll
-  for (int i = 0; i < 7; i++) {
-    const double v = wave_sum_to_lane63(acc.b[i]);
-    if (lane == 63) s.wave_part[wave][28 + i] = v;
-  }
+// Sum N (a power of two <= 64) per-lane values over the 64 lanes of a wave by recursive
+// halving: at each step (lane distance 32, 16, ...) a lane hands the half of its values it
+// is not responsible for to its partner and adds the partner's contribution to the half it
+// keeps, so N values cost ~N exchanges instead of 6N.  Afterwards the lane whose `slot` is
+// k (< N) holds the total of value k.  Fixed order => deterministic floating point.
+template <typename T, int N, int M>
+struct Halve {
+  static HSO_DEV void run(T (&v)[N], int lane, int& slot, T& out)
   {
-    const double e = wave_sum_to_lane63(acc.E);
-    const int nt = wave_sum_to_lane63(acc.nt), ns = wave_sum_to_lane63(acc.nsat);
-    if (lane == 63) { s.wave_part[wave][35] = e; s.wave_part[wave][36] = (double)nt; s.wave_part[wave][37] = (double)ns; }
+    static_assert((N & (N - 1)) == 0 && N >= 2, "N must be a power of two");
+    constexpr int HALF = N / 2;
+    const bool up = (lane & M) != 0;
+    T keep[HALF];
+#pragma unroll
+    for (int i = 0; i < HALF; i++) {
+      const T lo = v[i];
+      const T hi = v[HALF + i];
+      const T send = up ? lo : hi;
+      T recv;
+      if constexpr (sizeof(T) == 8) recv = shfl_xor_d(send, M);
+      else recv = __shfl_xor(send, M);
+      keep[i] = (up ? hi : lo) + recv;
+    }
+    if (up) slot += HALF;
+    if constexpr (M == 1) {
+      out = keep[0];  // HALF == 1 here
+    } else {
+      Halve<T, HALF, M / 2>::run(keep, lane, slot, out);
+    }
   }
-  __syncthreads();
-  if (threadIdx.x < N_RED) {
-    double t = 0;
-    for (int w = 0; w < TRK_WAVES; w++) t += s.wave_part[w][threadIdx.x];
-    s.red[threadIdx.x] = t;
+};
+template <typename T, int M>
+struct Halve<T, 1, M> {
+  static HSO_DEV void run(T (&v)[1], int lane, int& slot, T& out)
+  {
+    // a single value left before the lane distance reached 1: finish with plain butterflies
+    T x = v[0];
+#pragma unroll
+    for (int m = M; m >= 1; m >>= 1) {
+      if constexpr (sizeof(T) == 8) x += shfl_xor_d(x, m);
+      else x += __shfl_xor(x, m);
+    }
+    // every lane of the remaining group holds the total; only the group's first lane reports it
+    if ((lane & (2 * M - 1)) != 0) slot = 1 << 20;
+    out = x;
   }
-  __syncthreads();
-}
+};
 
 HSO_DEV int block_sum_int(Shared& s, int v)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t = wave_sum_to_lane63(v);
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   __syncthreads();
-  if (lane == 63) s.wave_cnt[wave] = t;
+  if (lane == 0) s.wave_cnt[wave] = v;
   __syncthreads();
   int tot = 0;
   for (int w = 0; w < TRK_WAVES; w++) tot += s.wave_cnt[w];
@@ -269,33 +334,27 @@ HSO_DEV int block_sum_int(Shared& s, int v)
 
 // ------------------------------------------------------------- level set-up
 
-// stage the current level image into LDS (or point at global memory when it does not fit)
-HSO_DEV void stage_level(Shared& s, LevelCtx& L, uint32_t* lds_img)
+// copy one level image (+ the zero row below it) into LDS; false if it does not fit
+HSO_DEV bool stage_image(const LevelCtx& L, const uint8_t* src, uint32_t* lds_img)
 {
-  const PyrGeom& g = L.C->g;
   const int bytes = L.cols * L.rows;
-  const int padded = (bytes + L.cols + 32 + 15) & ~15;  // + the zero row below the image
-  const uint8_t* src = L.job->cur_base + g.off[L.level];
-  if (padded <= L.C->lds_img_cap) {
-    const uint4* s4 = reinterpret_cast<const uint4*>(src);
-    uint4* d4 = reinterpret_cast<uint4*>(lds_img);
-    for (int i = threadIdx.x; i < padded / 16; i += TRK_THREADS) d4[i] = s4[i];
-    if (threadIdx.x == 0) s.use_lds = 1;
-  } else {
-    if (threadIdx.x == 0) s.use_lds = 0;
-  }
-  L.cur_glb = reinterpret_cast<const uint32_t*>(src);
+  const int padded = (bytes + L.cols + 32 + 15) & ~15;
+  if (padded > L.C->lds_img_cap) return false;
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+  uint4* d4 = reinterpret_cast<uint4*>(lds_img);
+  for (int i = threadIdx.x; i < padded / 16; i += TRK_THREADS) d4[i] = s4[i];
+  return true;
 }
 
 // precomputeReferencePatches, CoarseTracker.cpp:416-497.  Thread per (feature, pixel).
-HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L)
+template <typename Ptr>
+HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
 {
   const TrackJobDev& J = *L.job;
   const int n = J.n, ns = J.n_stride, nm = L.C->n_max;
   const int PA = s.PA, border = s.pad + 1;
   const bool ic = L.C->inverse != 0;
   const int stride = L.cols;
-  const uint32_t* ref32 = reinterpret_cast<const uint32_t*>(L.ref_img);
   for (int i = threadIdx.x; i < n * PA; i += TRK_THREADS) {
     const int f = i % n, pidx = i / n;
     const float u_ref = (float)(J.feats[0 * ns + f] * (double)L.scale);
@@ -310,8 +369,7 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L)
     const float w_tr = (float)(su * (1.0 - sv));
     const float w_bl = (float)((1.0 - su) * sv);
     const float w_br = (float)(1.0 - ((w_tl + w_tr) + w_bl));
-    const int x = u_i + s.pat[pidx].x, y = v_i + s.pat[pidx].y;
-    const int a0 = y * stride + x - 1;
+    const int a0 = v_i * stride + u_i - 1 + s.poff[pidx];
     const uint32_t r1 = fetch4(ref32, a0), r2 = fetch4(ref32, a0 + stride);
     L.sc.ref_patch[(size_t)pidx * nm + f] = ((w_tl * b1f(r1) + w_tr * b2f(r1)) + w_bl * b1f(r2)) + w_br * b2f(r2);
     if (ic) {
@@ -330,27 +388,30 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L)
 
 // pass 1 of selectRobustFunctionLevel (CoarseTracker.cpp:547-606): |residual| of every
 // in-bounds term, stored as float bit patterns (KEY_INVALID elsewhere).  Returns errors.size().
-template <typename Ptr>
+template <bool S1, typename Ptr>
 HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
 {
   const int n = L.job->n, nm = L.C->n_max;
-  const int PA = s.PA, border = s.pad + 1, S = s.S;
+  const int PA = s.PA, border = s.pad + 1, S = S1 ? 1 : s.S;
   const int G = TRK_THREADS / S;
-  const int sub = threadIdx.x % S;
+  const int sub = S1 ? 0 : (int)(threadIdx.x % S);
   const int stride = L.cols;
   int cnt = 0;
+  const int grp = S1 ? (int)threadIdx.x : (int)(threadIdx.x / S);
+  FeatRaw nxt = load_feature(L, grp);
   for (int base = 0; base < n; base += G) {
-    const int f = base + threadIdx.x / S;
+    const int f = base + grp;
+    const FeatRaw raw = nxt;
+    nxt = load_feature(L, f + G);
     if (f >= n) continue;
-    const Proj p = project_feature(L, T, f, border);
+    const Proj p = project_feature(L, T, raw, border);
     for (int pidx = sub; pidx < PA; pidx += S) {
       uint32_t key = KEY_INVALID;
       if (p.ok) {
-        const int x = p.u_i + s.pat[pidx].x, y = p.v_i + s.pat[pidx].y;
-        const int a0 = y * stride + x;
+        const int a0 = p.base + s.poff[pidx];
         const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
-        const float cur = ((p.w_tl * b0f(r1) + p.w_tr * b1f(r1)) + p.w_bl * b0f(r2)) + p.w_br * b1f(r2);
-        const float res = cur - (a * L.sc.ref_patch[(size_t)pidx * nm + f] + 0.0f);
+        const float cur = ((p.w_tl * b1f(r1) + p.w_tr * b2f(r1)) + p.w_bl * b1f(r2)) + p.w_br * b2f(r2);
+        const float res = cur - a * L.sc.ref_patch[(size_t)pidx * nm + f];
         key = __float_as_uint(fabsf(res));
         cnt++;
       }
@@ -388,31 +449,31 @@ HSO_DEV uint32_t radix_select(Shared& s, int n_slots, unsigned k, KeyFn key_of)
     }
     __syncthreads();
     {
-      // lane l sums bins [32l, 32l+32); inclusive scan over the wave; the owner lane of the
-      // rank walks its 32 bins; the result is broadcast with readlane-style shuffles
+      // level 1: lane l sums bins [32l, 32l+32) (rotated start => bank-conflict free),
+      // inclusive scan over the wave, the owner segment is the one containing the rank
       unsigned local = 0;
-      for (int j = 0; j < 32; j++) local += s.hist[lane * 32 + j];
+      for (int j = 0; j < 32; j++) local += s.hist[lane * 32 + ((j + lane) & 31)];
       unsigned incl = local;
       for (int d = 1; d < 64; d <<= 1) {
         const unsigned o = __shfl_up(incl, d);
         if (lane >= d) incl += o;
       }
       const unsigned excl = incl - local;
-      const bool owner = (rank >= excl && rank < incl);
-      unsigned o_bin = 0, o_rank = 0, o_cnt = 0;
-      if (owner) {
-        unsigned run = excl;
-        for (int j = 0; j < 32; j++) {
-          const unsigned c = s.hist[lane * 32 + j];
-          if (rank < run + c) { o_bin = (unsigned)(lane * 32 + j); o_rank = rank - run; o_cnt = c; break; }
-          run += c;
-        }
+      const unsigned long long m = __ballot(rank >= excl && rank < incl);
+      const int seg = (m != 0ull) ? (__ffsll((long long)m) - 1) : 0;
+      const unsigned r2 = rank - __shfl(excl, seg);
+      // level 2: the 32 bins of that segment, one per lane
+      const unsigned c = (lane < 32) ? s.hist[seg * 32 + lane] : 0u;
+      unsigned incl2 = c;
+      for (int d = 1; d < 32; d <<= 1) {
+        const unsigned o = __shfl_up(incl2, d);
+        if (lane >= d) incl2 += o;
       }
-      const unsigned long long m = __ballot(owner);
-      const int src = (m != 0ull) ? (__ffsll((long long)m) - 1) : 0;
-      prefix |= __shfl(o_bin, src) << shift;
-      rank = __shfl(o_rank, src);
-      bin_count = __shfl(o_cnt, src);
+      const unsigned long long m2 = __ballot(lane < 32 && r2 >= incl2 - c && r2 < incl2);
+      const int bl = (m2 != 0ull) ? (__ffsll((long long)m2) - 1) : 0;
+      prefix |= (uint32_t)(seg * 32 + bl) << shift;
+      rank = r2 - __shfl(incl2 - c, bl);
+      bin_count = __shfl(c, bl);
     }
     if (shift == 0) return prefix;  // all 31 bits fixed
     if (bin_count <= SEL_CAND_CAP) break;
@@ -446,8 +507,12 @@ HSO_DEV uint32_t radix_select(Shared& s, int n_slots, unsigned k, KeyFn key_of)
 // selectRobustFunctionLevel, CoarseTracker.cpp:530-644
 HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
 {
-  const int n_err = s.use_lds ? select_collect<LdsPtr>(s, L, lds_img, T, a)
-                              : select_collect<GlbPtr>(s, L, L.cur_glb, T, a);
+  int n_err;
+  if (s.S == 1) {
+    n_err = s.use_lds ? select_collect<true, LdsPtr>(s, L, lds_img, T, a) : select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a);
+  } else {
+    n_err = s.use_lds ? select_collect<false, LdsPtr>(s, L, lds_img, T, a) : select_collect<false, GlbPtr>(s, L, L.cur_glb, T, a);
+  }
   const int n_slots = L.job->n * s.PA;
   const uint32_t* keys = L.sc.keys;
   if (threadIdx.x == 0) s.n_select = n_err;
@@ -475,128 +540,229 @@ HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
 
 // ------------------------------------------ residuals + normal equations
 
+// Weighted moments of one feature's pattern pixels (this lane's share of them).
+struct Moments {
+  float ee, ex, ey, xx, xy, yy, re, rx, ry;  // sum w*{e e, e dx, e dy, dx dx, dx dy, dy dy, r e, r dx, r dy}
+  float E;
+  int nt, nsat;
+};
+
+// One term's raw inputs, fetched ahead of the arithmetic that consumes them.
+struct TermIn {
+  uint32_t r0, r1, r2, r3;  // rows y-1 .. y+2, bytes x-1 .. x+2
+  float iref, dxr, dyr;
+};
+
+template <bool IC, typename Ptr>
+HSO_DEV TermIn load_term(const LevelCtx& L, const Shared& s, Ptr img, const float* rp, int base, int pidx, int nm, int f)
+{
+  TermIn t;
+  const int a0 = base + s.poff[pidx];
+  t.r1 = fetch4(img, a0);
+  t.r2 = fetch4(img, a0 + L.cols);
+  if (!IC) {
+    t.r0 = fetch4(img, a0 - L.cols);
+    t.r3 = fetch4(img, a0 + 2 * L.cols);
+    t.dxr = t.dyr = 0;
+  } else {
+    t.r0 = t.r3 = 0;
+    t.dxr = L.sc.ref_dx[(size_t)pidx * nm + f];
+    t.dyr = L.sc.ref_dy[(size_t)pidx * nm + f];
+  }
+  t.iref = rp[(size_t)pidx * nm];
+  return t;
+}
+
+// The per-term arithmetic of computeResiduals (CoarseTracker.cpp:328-410) for the pattern
+// pixels sub, sub+S, ... of feature f.
+template <bool IC, typename Ptr>
+HSO_DEV Moments feature_terms(const Shared& s, const LevelCtx& L, Ptr img, const Proj& p, int f, float a,
+                              int sub, int S, int PA, bool top, float huber, float outlier, float max_energy)
+{
+  Moments m;
+  m.ee = m.ex = m.ey = m.xx = m.xy = m.yy = m.re = m.rx = m.ry = 0; m.E = 0; m.nt = 0; m.nsat = 0;
+  if (!p.ok) return m;
+  const int nm = L.C->n_max;
+  const float* rp = L.sc.ref_patch + f;
+  int pidx = sub;
+  if (pidx >= PA) return m;
+  TermIn nx = load_term<IC>(L, s, img, rp, p.base, pidx, nm, f);
+  for (; pidx < PA; pidx += S) {
+    const TermIn t = nx;
+    if (pidx + S < PA) nx = load_term<IC>(L, s, img, rp, p.base, pidx + S, nm, f);  // next term in flight
+    const float p11 = b1f(t.r1), p12 = b2f(t.r1), p21 = b1f(t.r2), p22 = b2f(t.r2);
+    // decision arithmetic: exactly the reference's expression order (:339-348)
+    const float cur = ((p.w_tl * p11 + p.w_tr * p12) + p.w_bl * p21) + p.w_br * p22;
+    const float res = cur - a * t.iref;
+    const float ares = fabsf(res);
+    const float hw = ares < huber ? 1.0f : huber / ares;
+    // cutoff_error = m_outlier_thresh is a float value, so the reference's double compare (:350)
+    // equals this float compare
+    const bool sat = (ares > outlier) && !top;
+    const float e_term = top ? (hw * res) * res : ((hw * res) * res) * (2 - hw);
+    m.E += sat ? max_energy : e_term;
+    m.nt++;
+    m.nsat += sat ? 1 : 0;
+    // image gradient; forward mode: twice the central difference (the 1/2 is folded into A, B)
+    float dx, dy;
+    if (!IC) {
+      dx = fmaf(p.w_tl, p12 - b0f(t.r1), fmaf(p.w_tr, b3f(t.r1) - p11, fmaf(p.w_bl, p22 - b0f(t.r2), p.w_br * (b3f(t.r2) - p21))));
+      dy = fmaf(p.w_tl, p21 - b1f(t.r0), fmaf(p.w_tr, p22 - b2f(t.r0), fmaf(p.w_bl, b1f(t.r3) - p11, p.w_br * (b2f(t.r3) - p12))));
+    } else {
+      dx = t.dxr; dy = t.dyr;
+    }
+    // saturated terms contribute no Jacobian row (:350-355): weight 0
+    const float w = sat ? 0.0f : hw;
+    const float e = -t.iref;
+    const float we = w * e, wx = w * dx, wy = w * dy, wr = w * res;
+    m.ee = fmaf(we, e, m.ee); m.ex = fmaf(we, dx, m.ex); m.ey = fmaf(we, dy, m.ey);
+    m.xx = fmaf(wx, dx, m.xx); m.xy = fmaf(wx, dy, m.xy); m.yy = fmaf(wy, dy, m.yy);
+    m.re = fmaf(wr, e, m.re); m.rx = fmaf(wr, dx, m.rx); m.ry = fmaf(wr, dy, m.ry);
+  }
+  return m;
+}
+
+// Expand one feature's moments into the 28 + 7 normal-equation entries (computeGS, :499-525).
+// A = fx_l * J.row(0), B = fy_l * J.row(1) (frame.h:192-212); in inverse-compositional mode the
+// Jacobian is taken at the reference point and scaled by the exposure ratio
+// (m_jacobian_cache_true = exposure_rat * m_jacobian_cache_raw, CoarseTracker.cpp:245).
+template <bool IC>
+HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Moments& m, int f, float a)
+{
+  double J0[6], J1[6];
+  double sA, sB;
+  if (!IC) {
+    jacobian_xyz2uv(p.x, p.y, p.z, J0, J1);
+    sA = 0.5 * L.fxl; sB = 0.5 * L.fyl;  // dx, dy are twice the central differences
+  } else {
+    const int ns = L.job->n_stride;
+    const double dist = L.job->feats[5 * ns + f];
+    jacobian_xyz2uv(L.job->feats[2 * ns + f] * dist, L.job->feats[3 * ns + f] * dist,
+                    L.job->feats[4 * ns + f] * dist, J0, J1);
+    sA = L.fxl * (double)a; sB = L.fyl * (double)a;
+  }
+  double A[6], B[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { A[k] = J0[k] * sA; B[k] = J1[k] * sB; }
+  const double d_ex = m.ex, d_ey = m.ey, d_xx = m.xx, d_xy = m.xy, d_yy = m.yy;
+  const double d_rx = m.rx, d_ry = m.ry;
+  acc.H[0] += m.ee;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc.H[1 + k] += (float)fma(d_ex, A[k], d_ey * B[k]);
+  int idx = 7;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double xa = fma(d_xx, A[k], d_xy * B[k]);  // coefficient of A[l]
+    const double xb = fma(d_xy, A[k], d_yy * B[k]);  // coefficient of B[l]
+#pragma unroll
+    for (int l = k; l < 6; l++) { acc.H[idx] += (float)fma(xa, A[l], xb * B[l]); idx++; }
+  }
+  acc.d[0] -= (double)m.re;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc.d[1 + k] -= fma(d_rx, A[k], d_ry * B[k]);
+  acc.d[7] += (double)m.E;
+  acc.d[8] += (double)m.nt;
+  acc.d[9] += (double)m.nsat;
+}
+
 // computeResiduals (CoarseTracker.cpp:242-414) fused with computeGS (:499-525).
 // Leaves the block-reduced sums in s.red: [0..27] H upper triangle (row-major),
 // [28..34] b, [35] E, [36] m_total_terms, [37] m_saturated_terms.
-template <bool IC, typename Ptr>
-HSO_DEV void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
+//
+// Each thread owns FPT features per round (lane groups of S threads share one feature when
+// the table is small).  The 38 per-feature contributions live in registers only between
+// the expansion and the wave-wide halving exchange that follows it, so the pixel loop —
+// where the time goes — runs without the accumulators' register footprint; what persists
+// across rounds is the single float and the single double each lane is responsible for.
+#ifndef TRK_FPT
+#define TRK_FPT 1
+#endif
+#define HSO_PHASE __device__ __forceinline__
+template <bool IC, bool S1, typename Ptr>
+HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
 {
-  const int n = L.job->n, nm = L.C->n_max;
-  const int PA = s.PA, border = s.pad + 1, S = s.S;
+  const int n = L.job->n;
+  const int PA = s.PA, border = s.pad + 1, S = S1 ? 1 : s.S;
   const int G = TRK_THREADS / S;
-  const int sub = threadIdx.x % S;
-  const int stride = L.cols;
+  const int sub = S1 ? 0 : (int)(threadIdx.x % S);
+  const int grp = S1 ? (int)threadIdx.x : (int)(threadIdx.x / S);
   const bool top = (L.level == L.C->max_level);
   const float huber = s.huber;
-  const double cutoff = (double)s.outlier;
-  const float max_energy = (float)((double)(2 * huber) * cutoff - (double)(huber * huber));
-  const int ns = L.job->n_stride;
+  const float outlier = s.outlier;
+  const float max_energy = (float)((double)(2 * huber) * (double)outlier - (double)(huber * huber));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  Acc acc;
+#ifdef HSO_PHASE_TIMERS
+#define DBG_T(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[k] += n_ - dbg_t; dbg_t = n_; } } while (0)
+  unsigned long long dbg_t = __builtin_readcyclecounter();
+#else
+#define DBG_T(k) do { } while (0)
+#endif
+  float totH = 0;
+  double totD = 0;
+  int slotH = 0, slotD = 0;
+  FeatRaw nxt = load_feature(L, grp);
+  for (int base = 0; base < (n > 0 ? n : 1); base += G * TRK_FPT) {
+    Proj p[TRK_FPT];
+    Moments m[TRK_FPT];
 #pragma unroll
-  for (int i = 0; i < 28; i++) acc.H[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 7; i++) acc.b[i] = 0;
-  acc.E = 0; acc.nt = 0; acc.nsat = 0;
-
-  for (int base = 0; base < n; base += G) {
-    const int f = base + threadIdx.x / S;
-    const bool act = f < n;
-    Proj p; p.ok = false;
-    if (act) p = project_feature(L, T, f, border);
-    // nine weighted moments of (e = -I_ref, dx, dy, r) over this lane's pattern pixels
-    float s_ee = 0, s_ex = 0, s_ey = 0, s_xx = 0, s_xy = 0, s_yy = 0, s_re = 0, s_rx = 0, s_ry = 0;
-    float E = 0;
-    int nt = 0, nsat = 0;
-    if (p.ok) {
-      for (int pidx = sub; pidx < PA; pidx += S) {
-        const int x = p.u_i + s.pat[pidx].x, y = p.v_i + s.pat[pidx].y;
-        const int a0 = y * stride + x - 1;
-        const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
-        const float iref = L.sc.ref_patch[(size_t)pidx * nm + f];
-        const float cur = ((p.w_tl * b1f(r1) + p.w_tr * b2f(r1)) + p.w_bl * b1f(r2)) + p.w_br * b2f(r2);
-        const float res = cur - (a * iref + 0.0f);
-        const float ares = fabsf(res);
-        const float hw = ares < huber ? 1.0f : huber / ares;
-        nt++;
-        if ((double)ares > cutoff && !top) {
-          E += max_energy;
-          nsat++;
-        } else {
-          if (top) E += hw * res * res;
-          else E += hw * res * res * (2 - hw);
-          float dx, dy;
-          if (!IC) {
-            const uint32_t r0 = fetch4(img, a0 - stride), r3 = fetch4(img, a0 + 2 * stride);
-            dx = 0.5f * ((((p.w_tl * b2f(r1) + p.w_tr * b3f(r1)) + p.w_bl * b2f(r2)) + p.w_br * b3f(r2))
-                       - (((p.w_tl * b0f(r1) + p.w_tr * b1f(r1)) + p.w_bl * b0f(r2)) + p.w_br * b1f(r2)));
-            dy = 0.5f * ((((p.w_tl * b1f(r2) + p.w_tr * b2f(r2)) + p.w_bl * b1f(r3)) + p.w_br * b2f(r3))
-                       - (((p.w_tl * b1f(r0) + p.w_tr * b2f(r0)) + p.w_bl * b1f(r1)) + p.w_br * b2f(r1)));
-          } else {
-            dx = L.sc.ref_dx[(size_t)pidx * nm + f];
-            dy = L.sc.ref_dy[(size_t)pidx * nm + f];
-          }
-          const float e = -iref;
-          const float we = hw * e, wx = hw * dx, wy = hw * dy;
-          s_ee = fmaf(we, e, s_ee); s_ex = fmaf(we, dx, s_ex); s_ey = fmaf(we, dy, s_ey);
-          s_xx = fmaf(wx, dx, s_xx); s_xy = fmaf(wx, dy, s_xy); s_yy = fmaf(wy, dy, s_yy);
-          const float wr = hw * res;
-          s_re = fmaf(wr, e, s_re); s_rx = fmaf(wr, dx, s_rx); s_ry = fmaf(wr, dy, s_ry);
+    for (int q = 0; q < TRK_FPT; q++) {
+      const int f = base + q * G + grp;
+      const FeatRaw raw = nxt;
+      nxt = load_feature(L, f + G);  // next feature's record in flight during this pixel loop
+      p[q] = project_feature(L, T, raw, border);
+      DBG_T(0);
+      m[q] = feature_terms<IC>(s, L, img, p[q], f, a, sub, S, PA, top, huber, outlier, max_energy);
+      DBG_T(1);
+      if (!S1) {
+        // combine the S lanes of the feature group (power of two <= 64, never straddles a wave)
+        for (int k = S >> 1; k > 0; k >>= 1) {
+          m[q].ee += __shfl_xor(m[q].ee, k); m[q].ex += __shfl_xor(m[q].ex, k); m[q].ey += __shfl_xor(m[q].ey, k);
+          m[q].xx += __shfl_xor(m[q].xx, k); m[q].xy += __shfl_xor(m[q].xy, k); m[q].yy += __shfl_xor(m[q].yy, k);
+          m[q].re += __shfl_xor(m[q].re, k); m[q].rx += __shfl_xor(m[q].rx, k); m[q].ry += __shfl_xor(m[q].ry, k);
+          m[q].E += __shfl_xor(m[q].E, k); m[q].nt += __shfl_xor(m[q].nt, k); m[q].nsat += __shfl_xor(m[q].nsat, k);
         }
       }
     }
-    // combine the S lanes of the feature group (S is a power of two <= 64, groups never straddle waves)
-    for (int m = S >> 1; m > 0; m >>= 1) {
-      s_ee += __shfl_xor(s_ee, m); s_ex += __shfl_xor(s_ex, m); s_ey += __shfl_xor(s_ey, m);
-      s_xx += __shfl_xor(s_xx, m); s_xy += __shfl_xor(s_xy, m); s_yy += __shfl_xor(s_yy, m);
-      s_re += __shfl_xor(s_re, m); s_rx += __shfl_xor(s_rx, m); s_ry += __shfl_xor(s_ry, m);
-      E += __shfl_xor(E, m); nt += __shfl_xor(nt, m); nsat += __shfl_xor(nsat, m);
-    }
-    if (p.ok && sub == 0) {
-      // A = fx_l * J.row(0), B = fy_l * J.row(1) (frame.h:192-212); in inverse-compositional
-      // mode the Jacobian is taken at the reference point and scaled by the exposure ratio
-      // (m_jacobian_cache_true = exposure_rat * m_jacobian_cache_raw, CoarseTracker.cpp:245)
-      double J0[6], J1[6];
-      if (!IC) {
-        jacobian_xyz2uv(p.x, p.y, p.z, J0, J1);
-      } else {
-        const double dist = L.job->feats[5 * ns + f];
-        jacobian_xyz2uv(L.job->feats[2 * ns + f] * dist, L.job->feats[3 * ns + f] * dist,
-                        L.job->feats[4 * ns + f] * dist, J0, J1);
-      }
-      const double sA = IC ? L.fxl * (double)a : L.fxl, sB = IC ? L.fyl * (double)a : L.fyl;
-      double A[6], B[6];
+    Acc acc;
 #pragma unroll
-      for (int k = 0; k < 6; k++) { A[k] = J0[k] * sA; B[k] = J1[k] * sB; }
-      const double d_ee = s_ee, d_ex = s_ex, d_ey = s_ey, d_xx = s_xx, d_xy = s_xy, d_yy = s_yy;
-      const double d_re = s_re, d_rx = s_rx, d_ry = s_ry;
-      acc.H[0] += (float)d_ee;
+    for (int i = 0; i < 32; i++) acc.H[i] = 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) acc.H[1 + k] += (float)fma(d_ex, A[k], d_ey * B[k]);
-      int idx = 7;
+    for (int i = 0; i < 16; i++) acc.d[i] = 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const double xa = fma(d_xx, A[k], d_xy * B[k]);  // coefficient of A[l]
-        const double xb = fma(d_xy, A[k], d_yy * B[k]);  // coefficient of B[l]
-#pragma unroll
-        for (int l = k; l < 6; l++) { acc.H[idx] += (float)fma(xa, A[l], xb * B[l]); idx++; }
-      }
-      acc.b[0] -= d_re;
-#pragma unroll
-      for (int k = 0; k < 6; k++) acc.b[1 + k] -= fma(d_rx, A[k], d_ry * B[k]);
-      acc.E += (double)E;
-      acc.nt += nt;
-      acc.nsat += nsat;
-    }
+    for (int q = 0; q < TRK_FPT; q++)
+      if (p[q].ok && sub == 0) expand_feature<IC>(acc, L, p[q], m[q], base + q * G + grp, a);
+    DBG_T(2);
+    float th; double td;
+    slotH = 0; slotD = 0;
+    Halve<float, 32, 32>::run(acc.H, lane, slotH, th);
+    Halve<double, 16, 32>::run(acc.d, lane, slotD, td);
+    totH += th;
+    totD += td;
+    DBG_T(3);
   }
-  block_reduce_acc(s, acc);
+  if (slotH < 28) s.wave_part[wave][slotH] = (double)totH;
+  if (slotD < 10) s.wave_part[wave][28 + slotD] = totD;
+  __syncthreads();
+  if (threadIdx.x < N_RED) {
+    double t = 0;
+    for (int w = 0; w < TRK_WAVES; w++) t += s.wave_part[w][threadIdx.x];
+    s.red[threadIdx.x] = t;
+  }
+  __syncthreads();
+  DBG_T(4);
 }
 
 template <bool IC>
 HSO_DEV void eval_dispatch(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
 {
-  if (s.use_lds) eval_terms<IC, LdsPtr>(s, L, lds_img, T, a);
-  else eval_terms<IC, GlbPtr>(s, L, L.cur_glb, T, a);
+  if (s.S == 1) {
+    if (s.use_lds) eval_terms<IC, true, LdsPtr>(s, L, lds_img, T, a);
+    else eval_terms<IC, true, GlbPtr>(s, L, L.cur_glb, T, a);
+  } else {
+    if (s.use_lds) eval_terms<IC, false, LdsPtr>(s, L, lds_img, T, a);
+    else eval_terms<IC, false, GlbPtr>(s, L, L.cur_glb, T, a);
+  }
 }
 
 // ----------------------------------------------------------- level + LM loop
@@ -610,43 +776,152 @@ HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const Tra
   L.scale = 1.0f / (float)(1 << level);
   L.fxl = C.cam.fx * (double)L.scale;
   L.fyl = C.cam.fy * (double)L.scale;
-  L.ref_img = job.ref_base + C.g.off[level];
-  const int pat_idx = C.max_level - level + PATTERN_OFFSET;  // CoarseTracker.cpp:80
+  L.ref_glb = reinterpret_cast<GlbPtr>(job.ref_base + C.g.off[level]);
+  L.cur_glb = reinterpret_cast<GlbPtr>(job.cur_base + C.g.off[level]);
   if (threadIdx.x == 0) {
-    s.level = level; s.pat_idx = pat_idx; s.PA = C.pat_num[pat_idx]; s.pad = C.pat_pad[pat_idx];
+    s.level = level; s.PA = C.pa[level]; s.pad = C.pad[level];
     int S = 1;
     while (S < 16 && job.n * S * 2 <= TRK_THREADS) S *= 2;
     s.S = S;
   }
-  if (threadIdx.x < 40) s.pat[threadIdx.x] = make_char2(c_pattern[pat_idx][threadIdx.x][0], c_pattern[pat_idx][threadIdx.x][1]);
-  stage_level(s, L, lds_img);
+  if (threadIdx.x < TRK_MAX_PA) s.poff[threadIdx.x] = C.poff[level][threadIdx.x];
+  // reference image through LDS for the patch precompute, then the current image stays resident
+  const bool ref_in_lds = stage_image(L, job.ref_base + C.g.off[level], lds_img);
   __syncthreads();
-  precompute_reference(s, L);
+  if (ref_in_lds) precompute_reference<LdsPtr>(s, L, (LdsPtr)lds_img);
+  else precompute_reference<GlbPtr>(s, L, L.ref_glb);
+  __syncthreads();
+  const bool cur_in_lds = stage_image(L, job.cur_base + C.g.off[level], lds_img);
+  if (threadIdx.x == 0) s.use_lds = cur_in_lds ? 1 : 0;
   __syncthreads();
 }
 
-// thread 0: one Levenberg-Marquardt proposal (CoarseTracker.cpp:112-133)
-HSO_DEV void lm_propose(Shared& s, bool inverse, double step_out[7])
+// Hl.ldlt().solve(b) of CoarseTracker.cpp:112-114 on the first eight lanes of one wavefront:
+// lane j holds column j of the 7x7 damped matrix in registers a[0..6] (a[i] = A(i,j)), lane 7
+// holds the right-hand side.  Right-looking LDL^T with diagonal pivoting (largest |diagonal|,
+// first on ties, like Eigen::LDLT): everything a step needs from another lane is a broadcast
+// from a lane known to the whole wave, i.e. v_readlane_b32 — no LDS traffic; the forward
+// substitution rides along in lane 7; then z = D^-1 y (zero where the pivot vanished, Eigen's
+// pseudo-inverse) and the back substitution.  Result: s.step[0..6].
+HSO_DEV double readlane_d(double v, int src_lane)
 {
-  double Hl[49], step[7];
-  int idx = 0;
-  for (int r = 0; r < 7; r++)
-    for (int c = r; c < 7; c++) { Hl[r * 7 + c] = Hl[c * 7 + r] = s.H[idx]; idx++; }
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+HSO_DEV void wave_ldlt7_solve(Shared& s, float lambda)
+{
+  const int lane = threadIdx.x & 63;
+  const int j = lane < 8 ? lane : 7;
+  double a[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    if (j < 7) {
+      const int r = i < j ? i : j, c = i < j ? j : i;
+      double v = s.H[7 * r - (r * (r - 1)) / 2 + (c - r)];
+      if (i == j) v *= (double)(1 + lambda);  // Hl(i,i) *= (1+lambda), CoarseTracker.cpp:113
+      a[i] = v;
+    } else {
+      a[i] = s.b[i];
+    }
+  }
+  int perm[7];  // uniform: original index of the unknown now at position i
+#pragma unroll
+  for (int i = 0; i < 7; i++) perm[i] = i;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    double best = -1;
+    int idx = k;
+#pragma unroll
+    for (int q = k; q < 7; q++) {
+      const double d = fabs(readlane_d(a[q], q));
+      if (d > best) { best = d; idx = q; }
+    }
+#pragma unroll
+    for (int q = k + 1; q < 7; q++) {
+      if (idx == q) {  // wave-uniform: symmetric swap of rows/columns k and q
+        const double t = a[k]; a[k] = a[q]; a[q] = t;                 // rows (incl. the rhs in lane 7)
+        const int tp = perm[k]; perm[k] = perm[q]; perm[q] = tp;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {                                 // columns: lanes k and q trade places
+          const double from_q = readlane_d(a[i], q), from_k = readlane_d(a[i], k);
+          a[i] = (lane == k) ? from_q : ((lane == q) ? from_k : a[i]);
+        }
+      }
+    }
+    const double akk = readlane_d(a[k], k);
+    const bool valid = fabs(akk) > 0;
+#pragma unroll
+    for (int i = k + 1; i < 7; i++) {
+      const double aik = readlane_d(a[i], k);        // A(i,k), column k lives in lane k
+      const double lik = valid ? aik / akk : aik;
+      if (lane > k) a[i] -= lik * a[k];              // columns k+1..6 and the rhs: A(i,j) -= l_ik A(k,j)
+      else if (lane == k) a[i] = lik;                // store L(i,k)
+    }
+  }
+  // lane 7: y (forward-substituted rhs).  z = D^-1 y, then x = L^-T z.
+  const double tolerance = 1.0 / 1.7976931348623157e308;
+  double x[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    const double dii = readlane_d(a[i], i);
+    const double yi = readlane_d(a[i], 7);
+    x[i] = (fabs(dii) > tolerance) ? yi / dii : 0.0;
+  }
+#pragma unroll
+  for (int k = 6; k >= 1; k--) {
+#pragma unroll
+    for (int i = 0; i < k; i++) x[i] -= readlane_d(a[k], i) * x[k];  // L(k,i) sits in lane i, row k
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+#pragma unroll
+      for (int q = 0; q < 7; q++)
+        if (perm[i] == q) s.step[q] = x[i];
+    }
+  }
+}
+
+// lane 0 after wave_ldlt7_solve: extrapolation, NaN guard, exposure and pose proposal
+// (CoarseTracker.cpp:120-133)
+HSO_DEV void lm_finish(Shared& s, bool inverse)
+{
+  double step[7];
   const float lambda = s.lambda;
-  for (int i = 0; i < 7; i++) Hl[i * 7 + i] *= (double)(1 + lambda);
-  ldlt_solve<7>(Hl, s.b, step);
   float extrap_fac = 1;
   if ((double)lambda < 0.001) extrap_fac = (float)sqrt(sqrt(0.001 / (double)lambda));
   double ssum = 0;
-  for (int i = 0; i < 7; i++) { step[i] *= (double)extrap_fac; ssum += step[i]; }
-  if (!isfinite(ssum) || isnan(step[0])) for (int i = 0; i < 7; i++) step[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 7; i++) { step[i] = s.step[i] * (double)extrap_fac; ssum += step[i]; }
+  if (!isfinite(ssum) || isnan(step[0])) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) step[i] = 0;
+  }
   s.a_new = (float)((double)s.a + step[0]);
   double neg[6];
+#pragma unroll
   for (int i = 0; i < 6; i++) neg[i] = -step[1 + i];
   const Se3 dT = se3_exp(neg);
-  s.Tn = inverse ? se3_mul(s.T, dT) : se3_mul(dT, s.T);
-  for (int i = 0; i < 7; i++) step_out[i] = step[i];
+  const Se3 T = s.T;
+  s.Tn = inverse ? se3_mul(T, dT) : se3_mul(dT, T);
+  double nrm = 0;
+#pragma unroll
+  for (int i = 0; i < 7; i++) nrm += step[i] * step[i];
+  s.step_norm = sqrt(nrm);
 }
+
+#ifdef HSO_PHASE_TIMERS
+#define PH_START() unsigned long long ph_t = __builtin_readcyclecounter(); const unsigned long long ph_job = ph_t
+#define PH_ADD(k) do { if (threadIdx.x == 0) { const unsigned long long ph_n = __builtin_readcyclecounter(); \
+                         out->phase_cycles[k] += ph_n - ph_t; ph_t = ph_n; } } while (0)
+#define PH_JOB() do { if (threadIdx.x == 0) { out->phase_cycles[4] = __builtin_readcyclecounter() - ph_job; for (int k_ = 0; k_ < 5; k_++) out->phase_cycles[5 + k_] = s.dbg[k_]; } } while (0)
+#else
+#define PH_START() do { } while (0)
+#define PH_ADD(k) do { } while (0)
+#define PH_JOB() do { } while (0)
+#endif
 
 template <bool IC>
 HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, const Scratch& sc,
@@ -664,12 +939,19 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
     return;
   }
   LevelCtx L;
+#ifdef HSO_PHASE_TIMERS
+  if (tid == 0) for (int k_ = 0; k_ < 8; k_++) s.dbg[k_] = 0;
+#endif
+  PH_START();
   for (int level = C.max_level; level >= C.min_level; --level) {
     begin_level(s, L, C, job, sc, level, lds_img);
+    PH_ADD(0);
     {
       const Se3 T0 = s.T; const float a0 = s.a;
       select_robust(s, L, (LdsPtr)lds_img, T0, a0);
+      PH_ADD(1);
       eval_dispatch<IC>(s, L, (LdsPtr)lds_img, T0, a0);
+      PH_ADD(2);
     }
     if (tid == 0) {
       for (int i = 0; i < 28; i++) s.H[i] = s.red[i];
@@ -683,13 +965,17 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
     }
     __syncthreads();
     for (int iter = 0; iter < C.n_iter; iter++) {
-      double step[7];
-      if (tid == 0) lm_propose(s, IC, step);
+      if (tid < 64) {
+        wave_ldlt7_solve(s, s.lambda);
+        if (tid == 0) lm_finish(s, IC);
+      }
       __syncthreads();
+      PH_ADD(3);
       {
         const Se3 Tn = s.Tn; const float an = s.a_new;
         eval_dispatch<IC>(s, L, (LdsPtr)lds_img, Tn, an);
       }
+      PH_ADD(2);
       if (tid == 0) {
         const double energy_new = (double)((float)s.red[35] / (float)(int)s.red[36]);
         out->n_eval[level]++;
@@ -706,10 +992,7 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
           s.lambda = s.lambda * 4;
           if ((double)s.lambda < 0.001) s.lambda = (float)0.001;
         }
-        double nrm = 0;
-        for (int i = 0; i < 7; i++) nrm += step[i] * step[i];
-        nrm = sqrt(nrm);
-        if (!(nrm > 1e-4)) s.stop = 1;
+        if (!(s.step_norm > 1e-4)) s.stop = 1;
         // the last evaluation defines m_total_terms / m_saturated_terms (CoarseTracker.cpp:207)
         out->n_terms_last = (int)s.red[36];
         out->n_saturated_last = (int)s.red[37];
@@ -729,8 +1012,13 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
     out->n_tracked = (int)((float)out->n_terms_last / (float)s.PA);
     out->status = 0;
   }
+  PH_JOB();
 }
 
+// dynamic LDS: [0, kImgCap) staged level image (address 0 => tap addresses need no base add),
+// then the Shared block
+constexpr int kLdsTotal = 160 * 1024;  // LDS per CU on gfx950
+constexpr int kImgCap = (int)(((kLdsTotal - 256 - sizeof(Shared)) / 256) * 256);
 extern __shared__ __attribute__((aligned(16))) char g_smem[];
 
 template <bool IC>
@@ -738,8 +1026,8 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(TrackConsts C, const Trac
                                                        int* job_counter, char* scratch, size_t scratch_stride,
                                                        hso_track_result* results)
 {
-  Shared& s = *reinterpret_cast<Shared*>(g_smem);
-  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
+  Shared& s = *reinterpret_cast<Shared*>(g_smem + kImgCap);
+  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem);
   const Scratch sc = scratch_at(scratch + (size_t)blockIdx.x * scratch_stride, C.n_max);
   for (;;) {
     __syncthreads();
@@ -762,8 +1050,8 @@ template <bool IC>
 __global__ __launch_bounds__(TRK_THREADS) void k_eval(TrackConsts C, const TrackJobDev* jobs, EvalArgs ea,
                                                       char* scratch, hso_eval_out* out)
 {
-  Shared& s = *reinterpret_cast<Shared*>(g_smem);
-  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
+  Shared& s = *reinterpret_cast<Shared*>(g_smem + kImgCap);
+  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem);
   const Scratch sc = scratch_at(scratch, C.n_max);
   const TrackJobDev& job = jobs[0];
   LevelCtx L;
@@ -850,7 +1138,6 @@ static int grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need_bytes)
   return HSO_OK;
 }
 
-static const size_t kLdsTotal = 160 * 1024;  // LDS per CU on gfx950
 
 static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* p,
                          const hso_track_job* jobs, int n_jobs, int max_grid)
@@ -915,11 +1202,16 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   C.inverse = p->inverse_composition; C.max_level = p->max_level; C.min_level = p->min_level; C.n_iter = p->n_iter;
   C.g = g;
   C.n_max = (n_max + 31) & ~31;
-  for (int i = 0; i < 8; i++) { C.pat_num[i] = h_pattern_num[i]; C.pat_pad[i] = h_pattern_pad[i]; }
-  const size_t fixed = (sizeof(Shared) + 15) & ~size_t(15);
-  C.lds_img_cap = (int)(kLdsTotal - fixed - 256);
-  st->lds_bytes = kLdsTotal - 256;
-  if (fixed + 4096 > kLdsTotal) return hso_fail(ctx, HSO_E_UNSUPPORTED, "coarse_track: LDS layout too large");
+  for (int l = 0; l < HSO_N_PYR_LEVELS; l++) {
+    const int pi = p->max_level - l + PATTERN_OFFSET;  // CoarseTracker.cpp:80
+    C.pa[l] = 0; C.pad[l] = 0;
+    for (int k = 0; k < TRK_MAX_PA; k++) C.poff[l][k] = 0;
+    if (pi < 0 || pi > 7) continue;
+    C.pa[l] = h_pattern_num[pi]; C.pad[l] = h_pattern_pad[pi];
+    for (int k = 0; k < h_pattern_num[pi]; k++) C.poff[l][k] = h_pattern[pi][k][1] * g.w[l] + h_pattern[pi][k][0];
+  }
+  C.lds_img_cap = kImgCap;
+  st->lds_bytes = (size_t)kImgCap + sizeof(Shared);
   st->n_jobs = n_jobs;
   st->n_max = C.n_max;
   st->grid = std::min(n_jobs, max_grid > 0 ? max_grid : ctx->n_cu);

@@ -165,6 +165,12 @@ typedef struct hso_track_result {
   float outlier[HSO_N_PYR_LEVELS];      /* m_outlier_thresh */
   int32_t n_select[HSO_N_PYR_LEVELS];   /* errors.size() in selectRobustFunctionLevel */
   double energy[HSO_N_PYR_LEVELS];      /* final energy_old of the level */
+  /* shader-clock cycles the owning workgroup spent per phase, summed over levels:
+   * [0] stage image to LDS + precompute reference patches, [1] robust thresholds,
+   * [2] residual/Jacobian evaluations incl. reductions, [3] LM solve + SE3 update,
+   * [4] whole job; [5..9] inside the evaluations: projection, pixel loop, expansion,
+   * wave exchange, workgroup combine.  Filled only when built with -DHSO_PHASE_TIMERS. */
+  uint64_t phase_cycles[10];
   int32_t status;                       /* 0 ok */
   int32_t _pad;
 } hso_track_result;
