@@ -72,6 +72,7 @@ def main():
     import torch
     import torch.distributed as dist
     from hso_amd import capi, synth
+    from hso_amd import dist as hdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -126,29 +127,31 @@ def main():
         for k in range(args.steps):
             step(events[k])
         results = ctx.coarse_track_collect()       # synchronises the stream
-        rec = np.zeros((B, 8))
-        for i, r in enumerate(results):
-            rec[i, :4], rec[i, 4:7], rec[i, 7] = r.T_cur_ref.q[:], r.T_cur_ref.t[:], r.exposure_rat
-        if world > 1:
-            # the path's only exchange: gather every rank's per-frame records (RCCL all_gather)
-            mine = torch.from_numpy(rec).cuda()
-            allrec = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-            dist.all_gather_into_tensor(allrec, mine)
+        rec = hdist.pack_records(results)
+        # the path's only exchange: gather every rank's per-frame records (RCCL all_gather)
+        allrec = hdist.gather_records(rec, device=torch.device("cuda", local_rank))
+        assert allrec.shape == (world, B, 8)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    elapsed = hdist.max_over_ranks(t1 - t0, device=torch.device("cuda", local_rank))
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     n_valid = int((pairs[0]["feats"]["dist"] >= 0).sum())
     bytes_launch = algorithmic_bytes(results, n_valid, bool(args.inverse), levels)
     achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
     evals = float(np.mean([sum(r.n_eval[L] for L in levels) for r in results]))
+    # HBM-side bytes of the same kernel from the PMC passes kept under profiles/ (collected by
+    # profiles/collect_r1.sh with rocprofv3 --pmc, separate runs); valid for the profiled shape only
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_track.json")))
+        if pmc["batch"] == B and pmc["feats"] == args.feats and not args.inverse:
+            traffic = (pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        pass
 
     # sanity: every frame converged to its scene's motion (guards against timing a broken run)
     for i in (0, B // 2, B - 1):
@@ -168,7 +171,7 @@ def main():
                    "parallelism": "independent sequences, %d per GPU x %d GPU(s)" % (B, world),
                    "mean_evaluations_per_frame": evals},
         "roofline": {"bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "launch_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch},
     }
 

@@ -21,6 +21,8 @@ def needs_build():
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    host = os.path.join(HERE, "host")
+    deps += [os.path.join(host, f) for f in os.listdir(host) if f.endswith((".cpp", ".h"))]
     deps.append(os.path.join(HERE, "..", "include", "hso_gpu.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -34,7 +36,23 @@ def build(force=False, verbose=False, extra=()):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_host(verbose)
     return OUT
+
+
+def build_host(verbose=False):
+    """The C++ mirror of the reference's call surface (hso_amd/host) + its test driver: plain
+    g++ against the C-ABI only (the library is found at run time through $ORIGIN)."""
+    host = os.path.join(HERE, "host")
+    exe = os.path.join(host, "hso_host_test")
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", os.path.join(host, "hso_host.cpp"),
+           os.path.join(host, "hso_host_test.cpp"), "-L" + CSRC, "-lhso_gpu",
+           "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib"),
+           "-o", exe]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return exe
 
 
 if __name__ == "__main__":

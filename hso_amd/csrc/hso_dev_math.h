@@ -56,10 +56,13 @@ HSO_HD void se3_apply(const Se3& T, double vx, double vy, double vz, double& ox,
   ox = rx + T.tx; oy = ry + T.ty; oz = rz + T.tz;
 }
 
+// Eigen normalize() divides the four coefficients by the norm; one reciprocal and four
+// products differ from that by at most an ulp per coefficient and keep the serial
+// single-lane LM step short
 HSO_HD void quat_normalize(Se3& r)
 {
-  const double n = sqrt(r.qx * r.qx + r.qy * r.qy + r.qz * r.qz + r.qw * r.qw);
-  r.qx /= n; r.qy /= n; r.qz /= n; r.qw /= n;
+  const double inv = 1.0 / sqrt(r.qx * r.qx + r.qy * r.qy + r.qz * r.qz + r.qw * r.qw);
+  r.qx *= inv; r.qy *= inv; r.qz *= inv; r.qw *= inv;
 }
 
 // SE3::operator*(SE3), se3.cpp:59-66 (+ SO3 product normalises, so3.cpp:64-71)
@@ -106,13 +109,17 @@ HSO_HD Se3 se3_exp(const double u[6])
   const double theta = sqrt(o0 * o0 + o1 * o1 + o2 * o2);
   const double half_theta = 0.5 * theta;
   double imag_factor;
-  const double real_factor = cos(half_theta);
+  // one sincos of theta/2 serves both the quaternion and (through the double-angle
+  // identities) the V matrix below, instead of the reference's four separate calls
+  double sh, ch;
+  sincos(half_theta, &sh, &ch);
+  const double real_factor = ch;
   if (theta < SMALL_EPS) {
     const double theta_sq = theta * theta;
     const double theta_po4 = theta_sq * theta_sq;
     imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
   } else {
-    imag_factor = sin(half_theta) / theta;
+    imag_factor = sh / theta;
   }
   Se3 r;
   r.qw = real_factor; r.qx = imag_factor * o0; r.qy = imag_factor * o1; r.qz = imag_factor * o2;
@@ -131,8 +138,8 @@ HSO_HD Se3 se3_exp(const double u[6])
     so3_matrix(r, V);
   } else {
     const double theta_sq = theta * theta;
-    const double c1 = (1 - cos(theta)) / (theta_sq);
-    const double c2 = (theta - sin(theta)) / (theta_sq * theta);
+    const double c1 = (2 * sh * sh) / (theta_sq);                     // 1 - cos(theta)
+    const double c2 = (theta - 2 * sh * ch) / (theta_sq * theta);     // theta - sin(theta)
     for (int i = 0; i < 9; i++) {
       const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
       V[i] = (id + c1 * O[i]) + c2 * O2[i];

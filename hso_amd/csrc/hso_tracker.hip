@@ -133,6 +133,7 @@ struct Shared {
   unsigned cand_n;
   int wave_cnt[TRK_WAVES];
   int poff[32];                      // byte offset oy*stride+ox of every pattern pixel of this level
+  hso_track_result res;              // the job's result record, written to global memory once at the end
 #ifdef HSO_PHASE_TIMERS
   unsigned long long dbg[8];
 #endif
@@ -443,9 +444,14 @@ HSO_DEV uint32_t radix_select(Shared& s, int n_slots, unsigned k, KeyFn key_of)
     __syncthreads();
     for (int i = tid; i < SEL_BINS; i += TRK_THREADS) s.hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n_slots; i += TRK_THREADS) {
-      const uint32_t key = key_of(i);
-      if ((key & hi_mask) == prefix) atomicAdd(&s.hist[(key >> shift) & ((1u << width) - 1u)], 1u);
+    // eight keys per thread in flight: the loads must not queue behind the LDS atomics
+    for (int i0 = tid; i0 < n_slots; i0 += TRK_THREADS * 8) {
+      uint32_t kk[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * TRK_THREADS; kk[u] = (i < n_slots) ? key_of(i) : KEY_INVALID; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if ((kk[u] & hi_mask) == prefix) atomicAdd(&s.hist[(kk[u] >> shift) & ((1u << width) - 1u)], 1u);
     }
     __syncthreads();
     {
@@ -483,11 +489,16 @@ HSO_DEV uint32_t radix_select(Shared& s, int n_slots, unsigned k, KeyFn key_of)
   __syncthreads();
   if (tid == 0) s.cand_n = 0;
   __syncthreads();
-  for (int i = tid; i < n_slots; i += TRK_THREADS) {
-    const uint32_t key = key_of(i);
-    if ((key & kmask) == prefix) {
-      const unsigned slot = atomicAdd(&s.cand_n, 1u);
-      if (slot < SEL_CAND_CAP) s.cand[slot] = key;
+  for (int i0 = tid; i0 < n_slots; i0 += TRK_THREADS * 8) {
+    uint32_t kk[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = i0 + u * TRK_THREADS; kk[u] = (i < n_slots) ? key_of(i) : KEY_INVALID; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if ((kk[u] & kmask) == prefix) {
+        const unsigned slot = atomicAdd(&s.cand_n, 1u);
+        if (slot < SEL_CAND_CAP) s.cand[slot] = kk[u];
+      }
     }
   }
   __syncthreads();
@@ -923,11 +934,20 @@ HSO_DEV void lm_finish(Shared& s, bool inverse)
 #define PH_JOB() do { } while (0)
 #endif
 
+HSO_DEV void publish_result(Shared& s, hso_track_result* gout)
+{
+  __syncthreads();
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&s.res);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(gout);
+  for (int i = threadIdx.x; i < (int)(sizeof(hso_track_result) / 4); i += TRK_THREADS) dst[i] = src[i];
+}
+
 template <bool IC>
 HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, const Scratch& sc,
-                       uint32_t* lds_img, hso_track_result* out)
+                       uint32_t* lds_img, hso_track_result* gout)
 {
   const int tid = threadIdx.x;
+  hso_track_result* const out = &s.res;  // bookkeeping stays in LDS; one coalesced copy at the end
   if (tid == 0) {
     memset(out, 0, sizeof(*out));
     s.T = se3_from(job.T);
@@ -936,6 +956,7 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
   __syncthreads();
   if (job.n == 0) {  // CoarseTracker.cpp:53-54
     if (tid == 0) { se3_to(s.T, out->T_cur_ref); out->exposure_rat = s.a; }
+    publish_result(s, gout);
     return;
   }
   LevelCtx L;
@@ -1013,6 +1034,7 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
     out->status = 0;
   }
   PH_JOB();
+  publish_result(s, gout);
 }
 
 // dynamic LDS: [0, kImgCap) staged level image (address 0 => tap addresses need no base add),

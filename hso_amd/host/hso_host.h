@@ -1,0 +1,106 @@
+// hso_host.h — host-side mirror of the reference's C++ call surface for the hot path.
+//
+// The reference has no FFI: FrameHandlerMono::processFrame() calls C++ classes directly
+// (SURVEY.md §8b).  This header keeps those names, argument meanings and side effects so a
+// maintainer can swap the bodies: `hso::CoarseTracker(inverse, max_level, min_level, n_iter,
+// verbose).run(ref, cur)` is the reference's signature (include/hso/CoarseTracker.h:134,141)
+// and mutates cur->T_f_w_ / cur->m_exposure_time exactly as src/CoarseTracker.cpp:198-202 does;
+// the numeric body is one call into the C-ABI (include/hso_gpu.h).  Plain C++17, no Eigen /
+// OpenCV / Boost (none of them exists on the target image); SE3 is the Sophus convention
+// (unit quaternion + translation, tangent [upsilon, omega]).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <list>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+#include "../../include/hso_gpu.h"
+
+namespace hso {
+
+using Vector2d = std::array<double, 2>;
+using Vector3d = std::array<double, 3>;
+
+// Sophus::SE3 subset (thirdparty/Sophus/sophus/se3.cpp)
+struct SE3 {
+  hso_se3 v{{0, 0, 0, 1}, {0, 0, 0}};
+  SE3 operator*(const SE3& o) const;       // se3.cpp:59-66
+  Vector3d operator*(const Vector3d& p) const;  // se3.cpp:91-95
+  SE3 inverse() const;                     // se3.cpp:76-83
+  Vector3d translation() const { return {v.t[0], v.t[1], v.t[2]}; }
+};
+
+// include/hso/camera.h — only what the hot path calls
+class AbstractCamera {
+public:
+  explicit AbstractCamera(const hso_camera& c) : c_(c) {}
+  int width() const { return c_.width; }
+  int height() const { return c_.height; }
+  Vector2d focal_length() const { return {c_.fx, c_.fy}; }
+  double errorMultiplier2() const;                 // src/camera.cpp:59
+  Vector2d world2cam(const Vector3d& xyz) const;   // src/camera.cpp:89-125,196-221
+  const hso_camera& pod() const { return c_; }
+private:
+  hso_camera c_;
+};
+
+struct Feature;
+class Frame;
+using FramePtr = std::shared_ptr<Frame>;
+
+// include/hso/point.h:53-116 (fields the tracker reads)
+class Point {
+public:
+  double idist_ = 1.0;            // inverse depth in the host frame (point.h:115)
+  Feature* hostFeature_ = nullptr;
+};
+
+// include/hso/feature.h:33-60
+struct Feature {
+  enum FeatureType { CORNER, EDGELET, GRADIENT };
+  FeatureType type = CORNER;
+  Frame* frame = nullptr;
+  Vector2d px{0, 0};
+  Vector3d f{0, 0, 1};
+  int level = 0;
+  Point* point = nullptr;
+  Vector2d grad{1, 0};
+};
+using Features = std::list<Feature*>;
+
+// include/hso/frame.h — a Frame owns a device-resident pyramid in the shared GPU context
+class Frame {
+public:
+  // `new Frame(cam, img, ts)` -> initFrame (src/frame.cpp:82-96): throws std::runtime_error when
+  // the image size differs from the camera's, like the reference
+  Frame(hso_gpu_ctx* ctx, AbstractCamera* cam, const uint8_t* img, int width, int height, double timestamp);
+  ~Frame();
+  Frame(const Frame&) = delete;
+  Frame& operator=(const Frame&) = delete;
+
+  static int frame_counter_;
+  int id_;
+  double timestamp_;
+  AbstractCamera* cam_;
+  SE3 T_f_w_;
+  Features fts_;                 // owned, deleted by ~Frame (src/frame.cpp:54-72)
+  float integralImage_ = 0;      // src/frame.cpp:238
+  float gradMean_ = 0;           // src/frame.cpp:240-245
+  double m_exposure_time = -1;
+  hso_gpu_ctx* ctx_;
+};
+
+// include/hso/CoarseTracker.h:134-141
+class CoarseTracker {
+public:
+  CoarseTracker(bool inverse_composition, int max_level, int min_level, int n_iter, bool verbose);
+  size_t run(FramePtr ref_frame, FramePtr cur_frame);
+  bool m_inverse_composition;
+  int m_max_level, m_min_level, m_n_iter;
+  bool m_verbose;
+  SE3 m_T_cur_ref;
+  hso_track_result m_last{};     // per-level diagnostics of the last run
+};
+
+}  // namespace hso
