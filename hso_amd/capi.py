@@ -94,6 +94,62 @@ class EvalOut(C.Structure):
                 ("huber", C.c_float), ("outlier", C.c_float)]
 
 
+FTR_CORNER, FTR_EDGELET, FTR_GRADIENT = 0, 1, 2
+
+
+class AlignJob(C.Structure):
+    _fields_ = [("ref_frame_id", C.c_int64), ("ref_level", C.c_int32), ("type", C.c_int32),
+                ("px_ref", C.c_double * 2), ("f_ref", C.c_double * 3), ("depth", C.c_double),
+                ("grad", C.c_double * 2), ("T_cur_ref", SE3), ("px_cur", C.c_double * 2),
+                ("exposure_rat", C.c_float), ("kf_gap_lt4", C.c_int32)]
+
+
+class AlignOut(C.Structure):
+    _fields_ = [("success", C.c_int32), ("stage", C.c_int32), ("search_level", C.c_int32), ("iters", C.c_int32),
+                ("px_cur", C.c_double * 2), ("A_cur_ref", C.c_double * 4), ("h_inv", C.c_double),
+                ("ncc", C.c_float), ("chi2", C.c_float)]
+
+
+class PoseFeat(C.Structure):
+    _fields_ = [("has_point", C.c_int32), ("type", C.c_int32), ("level", C.c_int32), ("temporary", C.c_int32),
+                ("host_pose", C.c_int32), ("_pad", C.c_int32), ("f", C.c_double * 3), ("grad", C.c_double * 2),
+                ("host_f", C.c_double * 3), ("idist", C.c_double)]
+
+
+POSE_FEAT_DTYPE = np.dtype([("has_point", "<i4"), ("type", "<i4"), ("level", "<i4"), ("temporary", "<i4"),
+                            ("host_pose", "<i4"), ("_pad", "<i4"), ("f", "<f8", 3), ("grad", "<f8", 2),
+                            ("host_f", "<f8", 3), ("idist", "<f8")])
+assert POSE_FEAT_DTYPE.itemsize == C.sizeof(PoseFeat)
+
+
+class PoseJob(C.Structure):
+    _fields_ = [("feats", C.c_void_p), ("n_feats", C.c_int32), ("n_poses", C.c_int32), ("poses_f_w", C.c_void_p),
+                ("T_f_w", SE3), ("reproj_thresh", C.c_double), ("n_iter", C.c_int32), ("_pad", C.c_int32)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("T_f_w", SE3), ("cov", C.c_double * 36), ("estimated_scale", C.c_double),
+                ("error_init", C.c_double), ("error_final", C.c_double), ("error_in_px", C.c_float),
+                ("num_obs", C.c_int32), ("n_deleted", C.c_int32), ("iters", C.c_int32),
+                ("n_trials_total", C.c_int32), ("status", C.c_int32)]
+
+
+def make_pose_job(feats, poses, T_f_w, reproj_thresh=2.0, n_iter=12):
+    """feats: POSE_FEAT_DTYPE array; poses: list of SE3 (host keyframe T_f_w)."""
+    feats = np.ascontiguousarray(feats, dtype=POSE_FEAT_DTYPE)
+    arr = (SE3 * len(poses))(*poses)
+    j = PoseJob()
+    j.feats = feats.ctypes.data
+    j.n_feats = len(feats)
+    j.n_poses = len(poses)
+    j.poses_f_w = C.cast(arr, C.c_void_p).value
+    j.T_f_w = T_f_w
+    j.reproj_thresh = reproj_thresh
+    j.n_iter = n_iter
+    j._keep = (feats, arr)
+    return j
+
+
 def make_camera(model, width, height, fx, fy, cx, cy, d=(0, 0, 0, 0, 0), distortion=None):
     cam = Camera()
     cam.model = model
@@ -153,6 +209,8 @@ def load():
     lib.hso_gpu_tracker_eval.argtypes = [vp, P(Camera), P(TrackParams), P(TrackJob), i32, P(SE3),
                                          C.c_float, C.c_float, C.c_float, P(EvalOut), vp, vp, vp]
     lib.hso_gpu_tracker_pattern.argtypes = [i32, i32, P(i32), P(i32), vp]
+    lib.hso_gpu_align_batch.argtypes = [vp, P(Camera), i64, P(AlignJob), i32, P(AlignOut)]
+    lib.hso_gpu_pose_optimize_batch.argtypes = [vp, P(Camera), P(PoseJob), i32, P(PoseResult), vp]
     _lib = lib
     return lib
 
@@ -164,6 +222,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
+    "hso_gpu_align_batch", "hso_gpu_pose_optimize_batch",
 ]
 
 
@@ -290,6 +349,22 @@ class Context:
         res = (TrackResult * self._n_prepared)()
         self._check(self.lib.hso_gpu_coarse_track_collect(self.h, res), "coarse_track_collect")
         return list(res)
+
+    # -- reprojection matching
+    def align_batch(self, cam, cur_frame_id, jobs):
+        arr = (AlignJob * len(jobs))(*jobs)
+        out = (AlignOut * len(jobs))()
+        self._check(self.lib.hso_gpu_align_batch(self.h, C.byref(cam), cur_frame_id, arr, len(jobs), out), "align_batch")
+        return list(out)
+
+    # -- pose optimiser
+    def pose_optimize_batch(self, cam, jobs):
+        arr = (PoseJob * len(jobs))(*jobs)
+        res = (PoseResult * len(jobs))()
+        masks = [np.zeros(max(j.n_feats, 1), np.uint8) for j in jobs]
+        mptr = (C.c_void_p * len(jobs))(*[m.ctypes.data for m in masks])
+        self._check(self.lib.hso_gpu_pose_optimize_batch(self.h, C.byref(cam), arr, len(jobs), res, mptr), "pose_optimize_batch")
+        return list(res), [m[:j.n_feats] for m, j in zip(masks, jobs)]
 
     def tracker_eval(self, cam, params, job, level, T, exposure_rat, huber=-1.0, outlier=-1.0,
                      want_cache=False, want_errors=False):

@@ -1,0 +1,526 @@
+// hso_pose.hip — motion-only Levenberg-Marquardt pose refinement on gfx950, batched over
+// independent frames.
+//
+// Replaces pose_optimizer::optimizeLevenbergMarquardt3rd (reference
+// src/pose_optimizer.cpp:399-771): unit-plane reprojection residuals of every feature with a
+// point (2-D for corners, 1-D along the gradient for edgelets, scaled by 1/2^level), MAD scales
+// (src/vikit/robust_cost.cpp:67-74), Huber weights (:141-148, k = 1.345), LM with multiplicative
+// damping A += diag(A)*mu, the mu/nu schedule of :644-674, covariance, outlier culling and the
+// median-based error statistics.
+//
+// MI355X mapping: one 256-thread workgroup per frame, the whole optimisation resident on the
+// device (<= 12 iterations x <= 5 trials, each two passes over <= a few thousand features):
+// this stage is latency-bound by construction, so the design goal is zero host round trips and
+// many frames in flight, not bandwidth.  Per-feature arithmetic follows the reference's fp64
+// expressions; the sums (chi2, A, b) are fixed-tree reductions (reference: serial fp64), the
+// MAD scales and medians are exact order statistics (bitwise search on the IEEE bit patterns).
+#include "hso_ctx.h"
+#include "hso_dev_math.h"
+#include <string.h>
+#include <vector>
+
+using namespace hso_dev;
+
+#define POSE_THREADS 256
+#define POSE_WAVES (POSE_THREADS / 64)
+#define POSE_MAX_FEATS 4096
+#define POSE_MAX_POSES 64
+
+struct PoseJobDev {
+  const hso_pose_feat* feats;
+  const hso_se3* poses;
+  uint8_t* mask;  // may be null
+  int n_feats, n_poses;
+  hso_se3 T;
+  double reproj_thresh;
+  int n_iter, _pad;
+};
+
+struct PoseShared {
+  Se3 T, Tn;
+  Se3 hinv[POSE_MAX_POSES];
+  Se3 Tth[POSE_MAX_POSES];
+  double red[32];
+  double wave_part[POSE_WAVES][32];
+  double A[36], b[6], dT[8];
+  double chi2, new_chi2, mu, nu, rho;
+  float scale_pt, scale_ls;
+  int n_pt, n_ls, n_obs, stop, accept, n_trials, iters, n_trials_total, n_deleted;
+  int cnt[POSE_WAVES];
+  unsigned long long keys64[POSE_MAX_FEATS];
+  unsigned keys32[POSE_MAX_FEATS];
+};
+
+HSO_DEV double p_shfl_xor_d(double v, int m)
+{
+  const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+  return __hiloint2double(hi, lo);
+}
+HSO_DEV double p_readlane_d(double v, int src)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// workgroup sum of K doubles per thread (K <= 32): butterfly within the wave, LDS across waves,
+// fixed order => deterministic.  Result in s.red[0..K).
+template <int K>
+HSO_DEV void pose_block_sum(PoseShared& s, double (&v)[K])
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    double x = v[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += p_shfl_xor_d(x, m);
+    if (lane == 0) s.wave_part[wave][i] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double t = 0;
+    for (int w = 0; w < POSE_WAVES; w++) t += s.wave_part[w][threadIdx.x];
+    s.red[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+HSO_DEV int pose_block_count(PoseShared& s, int v)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  __syncthreads();
+  if (lane == 0) s.cnt[wave] = v;
+  __syncthreads();
+  int t = 0;
+  for (int w = 0; w < POSE_WAVES; w++) t += s.cnt[w];
+  return t;
+}
+
+// k-th smallest (0-based) of n non-negative keys held in LDS, by fixing the bits from the top:
+// exactly the element nth_element would leave at position k (math_utils.h:119-126,
+// robust_cost.cpp:70-71).
+template <typename KeyT, int BITS>
+HSO_DEV KeyT pose_select(PoseShared& s, const KeyT* keys, int n, int k)
+{
+  KeyT res = 0;
+  for (int bit = BITS - 1; bit >= 0; bit--) {
+    const KeyT trial = res | ((KeyT)1 << bit);
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += POSE_THREADS) c += (keys[i] < trial) ? 1 : 0;
+    c = pose_block_count(s, c);
+    if (c <= k) res = trial;
+  }
+  return res;
+}
+
+struct Resid { double e0, e1, px, py, pz; };
+
+HSO_DEV Resid pose_residual(const PoseShared& s, const hso_pose_feat& ft, bool use_new)
+{
+  // pTarget = (T * host^-1) * (host_f / idist); e = project2d(f) - project2d(pTarget), / 2^level (:429-440)
+  Resid r;
+  const double inv = 1.0 / ft.idist;
+  const Se3& Tth = s.Tth[ft.host_pose];
+  (void)use_new;
+  se3_apply(Tth, ft.host_f[0] * inv, ft.host_f[1] * inv, ft.host_f[2] * inv, r.px, r.py, r.pz);
+  const double sc = 1.0 / (double)(1 << ft.level);
+  r.e0 = (ft.f[0] / ft.f[2] - r.px / r.pz) * sc;
+  r.e1 = (ft.f[1] / ft.f[2] - r.py / r.pz) * sc;
+  return r;
+}
+
+// HuberWeightFunction::value(const float&), robust_cost.cpp:141-148, k = 1.345f
+HSO_DEV double huber_w(double t_over_scale)
+{
+  const float t = (float)t_over_scale;
+  const float t_abs = fabsf(t);
+  return (t_abs < 1.345f) ? 1.0 : (double)(1.345f / t_abs);
+}
+
+HSO_DEV void pose_set_Tth(PoseShared& s, const Se3& T, int n_poses)
+{
+  __syncthreads();
+  if ((int)threadIdx.x < n_poses) s.Tth[threadIdx.x] = se3_mul(T, s.hinv[threadIdx.x]);
+  __syncthreads();
+}
+
+// weighted chi2 at the poses currently in s.Tth (:488-526 / :602-641)
+HSO_DEV double pose_chi2(PoseShared& s, const PoseJobDev& J)
+{
+  double v[1] = { 0 };
+  for (int i = threadIdx.x; i < J.n_feats; i += POSE_THREADS) {
+    const hso_pose_feat& ft = J.feats[i];
+    if (!ft.has_point) continue;
+    const Resid r = pose_residual(s, ft, false);
+    if (ft.type == HSO_FTR_EDGELET) {
+      const double error_ls = ft.grad[0] * r.e0 + ft.grad[1] * r.e1;
+      double w = huber_w(fabs(error_ls) / (double)s.scale_ls);
+      if (ft.temporary) w *= 0.5;
+      v[0] += error_ls * error_ls * w;
+    } else {
+      const double error_pt = sqrt(r.e0 * r.e0 + r.e1 * r.e1);
+      double w = huber_w(error_pt / (double)s.scale_pt);
+      if (ft.temporary) w *= 0.5;
+      v[0] += error_pt * error_pt * w;
+    }
+  }
+  pose_block_sum<1>(s, v);
+  return s.red[0];
+}
+
+// A.ldlt().solve(b) for the 6x6 system in s.A/s.b (pivoted LDL^T on eight lanes, broadcasts by
+// v_readlane_b32; same scheme as the tracker's 7x7 solve).  Result in s.dT[0..5].
+HSO_DEV void pose_ldlt6(PoseShared& s)
+{
+  const int lane = threadIdx.x & 63;
+  const int j = lane < 7 ? lane : 6;  // lanes 0..5: columns, lane 6: rhs
+  double a[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) a[i] = (j < 6) ? s.A[i * 6 + j] : s.b[i];
+  int perm[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) perm[i] = i;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double best = -1;
+    int idx = k;
+#pragma unroll
+    for (int q = k; q < 6; q++) {
+      const double d = fabs(p_readlane_d(a[q], q));
+      if (d > best) { best = d; idx = q; }
+    }
+#pragma unroll
+    for (int q = k + 1; q < 6; q++) {
+      if (idx == q) {
+        const double t = a[k]; a[k] = a[q]; a[q] = t;
+        const int tp = perm[k]; perm[k] = perm[q]; perm[q] = tp;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const double from_q = p_readlane_d(a[i], q), from_k = p_readlane_d(a[i], k);
+          a[i] = (lane == k) ? from_q : ((lane == q) ? from_k : a[i]);
+        }
+      }
+    }
+    const double akk = p_readlane_d(a[k], k);
+    const bool valid = fabs(akk) > 0;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double aik = p_readlane_d(a[i], k);
+      const double lik = valid ? aik / akk : aik;
+      if (lane > k) a[i] -= lik * a[k];
+      else if (lane == k) a[i] = lik;
+    }
+  }
+  const double tolerance = 1.0 / 1.7976931348623157e308;
+  double x[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const double dii = p_readlane_d(a[i], i), yi = p_readlane_d(a[i], 6);
+    x[i] = (fabs(dii) > tolerance) ? yi / dii : 0.0;
+  }
+#pragma unroll
+  for (int k = 5; k >= 1; k--) {
+#pragma unroll
+    for (int i = 0; i < k; i++) x[i] -= p_readlane_d(a[k], i) * x[k];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int q = 0; q < 6; q++)
+        if (perm[i] == q) s.dT[q] = x[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const PoseJobDev* jobs, hso_pose_result* results)
+{
+  __shared__ PoseShared s;
+  const PoseJobDev& J = jobs[blockIdx.x];
+  hso_pose_result& out = results[blockIdx.x];
+  const int tid = threadIdx.x, n = J.n_feats;
+  const double em2 = (cam.fx * cam.fy < 0) ? fabs(cam.fx) : fabs((cam.fx + cam.fy) * 0.5);  // camera.cpp:59
+
+  if (tid == 0) {
+    s.T = se3_from(J.T);
+    s.mu = 0.1; s.nu = 2.0; s.rho = 0; s.stop = 0; s.iters = 0; s.n_trials_total = 0; s.n_deleted = 0;
+    for (int q = 0; q < 36; q++) s.A[q] = 0;
+    for (int q = 0; q < 6; q++) s.b[q] = 0;
+  }
+  if (tid < J.n_poses) s.hinv[tid] = se3_inverse(se3_from(J.poses[tid]));
+  __syncthreads();
+  for (int i = tid; i < n; i += POSE_THREADS) if (J.mask) J.mask[i] = 0;
+  pose_set_Tth(s, s.T, J.n_poses);
+
+  // ---- pass 0: initial errors (:426-454).  Slot i keeps the feature order; empty slots hold
+  // all-ones keys (larger than any valid key) so that order statistics ignore them.
+  int c_pt = 0, c_ls = 0;
+  for (int i = tid; i < n; i += POSE_THREADS) {
+    const hso_pose_feat& ft = J.feats[i];
+    unsigned long long k64 = ~0ull;
+    if (ft.has_point) {
+      const Resid r = pose_residual(s, ft, false);
+      if (ft.type == HSO_FTR_EDGELET) {
+        const float error_ls = (float)(ft.grad[0] * r.e0 + ft.grad[1] * r.e1);
+        k64 = (unsigned long long)__double_as_longlong((double)(error_ls * error_ls));
+        c_ls++;
+      } else {
+        const float error_pt = (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
+        k64 = (unsigned long long)__double_as_longlong((double)(error_pt * error_pt));
+        c_pt++;
+      }
+    }
+    s.keys64[i] = k64;
+  }
+  const int n_pt = pose_block_count(s, c_pt), n_ls = pose_block_count(s, c_ls);
+  if (n_pt == 0 && n_ls == 0) {  // :456
+    if (tid == 0) {
+      out.T_f_w = J.T; for (int q = 0; q < 36; q++) out.cov[q] = 0;
+      out.estimated_scale = 0; out.error_init = 0; out.error_final = 0; out.error_in_px = 1.f;
+      out.num_obs = 0; out.n_deleted = 0; out.iters = 0; out.n_trials_total = 0; out.status = 1;
+    }
+    return;
+  }
+  const int n_init = n_pt + n_ls;
+  const double med_init = __longlong_as_double((long long)pose_select<unsigned long long, 63>(s, s.keys64, n, n_init / 2));
+
+  // ---- MAD scales (:459-483): 1.4826f * nth_element(|error|) per residual kind
+  float scale_pt = 0, scale_ls = 0;
+  for (int kind = 0; kind < 2; kind++) {
+    const int cnt = kind == 0 ? n_pt : n_ls;
+    __syncthreads();
+    for (int i = tid; i < n; i += POSE_THREADS) {
+      const hso_pose_feat& ft = J.feats[i];
+      unsigned key = 0xFFFFFFFFu;
+      if (ft.has_point && ((ft.type == HSO_FTR_EDGELET) == (kind == 1))) {
+        const Resid r = pose_residual(s, ft, false);
+        const float e = (kind == 1) ? fabsf((float)(ft.grad[0] * r.e0 + ft.grad[1] * r.e1))
+                                    : (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
+        key = __float_as_uint(e);
+      }
+      s.keys32[i] = key;
+    }
+    __syncthreads();
+    if (cnt > 0) {
+      const float med = __uint_as_float(pose_select<unsigned, 31>(s, s.keys32, n, cnt / 2));
+      if (kind == 0) scale_pt = 1.4826f * med; else scale_ls = 1.4826f * med;
+    }
+  }
+  if (n_pt > 0 && n_ls == 0) scale_ls = (float)(0.5 * (double)scale_pt);
+  if (n_pt == 0 && n_ls > 0) scale_pt = (float)(2 * scale_ls);
+  if (tid == 0) { s.scale_pt = scale_pt; s.scale_ls = scale_ls; }
+  __syncthreads();
+  const double estimated_scale = (double)scale_pt;
+
+  const double chi2_0 = pose_chi2(s, J);
+  if (tid == 0) s.chi2 = chi2_0;
+  __syncthreads();
+
+  // ---- LM (:531-689)
+  for (int iter = 0; iter < J.n_iter; iter++) {
+    if (tid == 0) { s.rho = 0; s.n_trials = 0; s.iters = iter + 1; }
+    __syncthreads();
+    for (;;) {
+      // normal equations at the current pose (:545-592)
+      pose_set_Tth(s, s.T, J.n_poses);
+      double acc[27];
+#pragma unroll
+      for (int q = 0; q < 27; q++) acc[q] = 0;
+      for (int i = tid; i < n; i += POSE_THREADS) {
+        const hso_pose_feat& ft = J.feats[i];
+        if (!ft.has_point) continue;
+        const Resid r = pose_residual(s, ft, false);
+        double J0[6], J1[6];
+        jacobian_xyz2uv(r.px, r.py, r.pz, J0, J1);
+        const double sc = 1.0 / (double)(1 << ft.level);
+#pragma unroll
+        for (int q = 0; q < 6; q++) { J0[q] *= sc; J1[q] *= sc; }
+        if (ft.type == HSO_FTR_EDGELET) {
+          double Je[6];
+#pragma unroll
+          for (int q = 0; q < 6; q++) Je[q] = ft.grad[0] * J0[q] + ft.grad[1] * J1[q];
+          const double e_edge = ft.grad[0] * r.e0 + ft.grad[1] * r.e1;
+          double w = huber_w(fabs(e_edge) / (double)s.scale_ls);
+          if (ft.temporary) w *= 0.5;
+          int idx = 0;
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int c = a; c < 6; c++) { acc[idx] += (Je[a] * Je[c]) * w; idx++; }
+            acc[21 + a] -= (Je[a] * e_edge) * w;
+          }
+        } else {
+          double w = huber_w(sqrt(r.e0 * r.e0 + r.e1 * r.e1) / (double)s.scale_pt);
+          if (ft.temporary) w *= 0.5;
+          int idx = 0;
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int c = a; c < 6; c++) { acc[idx] += (J0[a] * J0[c] + J1[a] * J1[c]) * w; idx++; }
+            acc[21 + a] -= (J0[a] * r.e0 + J1[a] * r.e1) * w;
+          }
+        }
+      }
+      pose_block_sum<27>(s, acc);
+      if (tid == 0) {
+        int idx = 0;
+        for (int a = 0; a < 6; a++)
+          for (int c = a; c < 6; c++) { s.A[a * 6 + c] = s.A[c * 6 + a] = s.red[idx]; idx++; }
+        for (int a = 0; a < 6; a++) s.b[a] = s.red[21 + a];
+        for (int a = 0; a < 6; a++) s.A[a * 6 + a] += s.A[a * 6 + a] * s.mu;  // A += (A.diagonal()*mu).asDiagonal()
+        s.n_trials_total++;
+      }
+      __syncthreads();
+      if (tid < 64) pose_ldlt6(s);
+      __syncthreads();
+      const bool nan_step = isnan(s.dT[0]);
+      double new_chi2 = 0;
+      if (!nan_step) {
+        if (tid == 0) s.Tn = se3_mul(se3_exp(s.dT), s.T);
+        __syncthreads();
+        pose_set_Tth(s, s.Tn, J.n_poses);
+        new_chi2 = pose_chi2(s, J);
+      }
+      if (tid == 0) {
+        s.rho = nan_step ? -1.0 : (s.chi2 - new_chi2);
+        if (s.rho > 0) {
+          s.T = s.Tn;
+          s.chi2 = new_chi2;
+          double nm = -1;
+          for (int q = 0; q < 6; q++) { const double a = fabs(s.dT[q]); if (a > nm) nm = a; }
+          s.stop = nm <= 0.0000000001;  // hso::EPS
+          const double t = 2 * s.rho - 1;
+          s.mu *= fmax(1. / 3., fmin(1. - t * t * t, 2. / 3.));
+          s.nu = 2.;
+        } else {
+          s.mu *= s.nu;
+          s.nu *= 2.;
+          if (s.mu < 0.0001) s.mu = 0.0001;
+          ++s.n_trials;
+          if (s.n_trials >= 5) s.stop = 1;
+        }
+      }
+      __syncthreads();
+      if (s.rho > 0 || s.stop) break;
+    }
+    if (s.stop) break;
+  }
+
+  // ---- covariance, culling, statistics (:691-767)
+  pose_set_Tth(s, s.T, J.n_poses);
+  const float thr_pt = (n < 80) ? (float)(sqrt(5.991) / em2) : (float)(J.reproj_thresh / em2);
+  const float thr_ls = (float)(1.3 / em2);
+  int n_del = 0;
+  for (int i = tid; i < n; i += POSE_THREADS) {
+    const hso_pose_feat& ft = J.feats[i];
+    unsigned long long k64 = ~0ull;
+    if (ft.has_point) {
+      const Resid r = pose_residual(s, ft, false);
+      if (ft.type == HSO_FTR_EDGELET) {
+        const double error_ls = ft.grad[0] * r.e0 + ft.grad[1] * r.e1;
+        if (fabs(error_ls) > (double)thr_ls) { n_del++; if (J.mask) J.mask[i] = 1; }
+        k64 = (unsigned long long)__double_as_longlong(error_ls * error_ls);
+      } else {
+        const float error_pt = (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
+        if (error_pt > thr_pt) { n_del++; if (J.mask) J.mask[i] = 1; }
+        k64 = (unsigned long long)__double_as_longlong((double)(error_pt * error_pt));
+      }
+    }
+    s.keys64[i] = k64;
+  }
+  n_del = pose_block_count(s, n_del);
+  const double med_final = __longlong_as_double((long long)pose_select<unsigned long long, 63>(s, s.keys64, n, n_init / 2));
+  if (tid == 0) {
+    // Cov_ = (A * em2^2)^-1 (:692): Gauss-Jordan with partial pivoting on the last damped A
+    double m[6][12];
+    const double s2 = em2 * em2;
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) { m[i][j] = s.A[i * 6 + j] * s2; m[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; c++) {
+      int piv = c;
+      for (int r = c + 1; r < 6; r++) if (fabs(m[r][c]) > fabs(m[piv][c])) piv = r;
+      if (piv != c) for (int j = 0; j < 12; j++) { const double t = m[c][j]; m[c][j] = m[piv][j]; m[piv][j] = t; }
+      const double d = m[c][c];
+      for (int j = 0; j < 12; j++) m[c][j] /= d;
+      for (int r = 0; r < 6; r++) {
+        if (r == c) continue;
+        const double f = m[r][c];
+        for (int j = 0; j < 12; j++) m[r][j] -= f * m[c][j];
+      }
+    }
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) out.cov[i * 6 + j] = m[i][6 + j];
+    se3_to(s.T, out.T_f_w);
+    out.error_init = sqrt(med_init) * em2;
+    out.error_final = sqrt(med_final) * em2;
+    out.estimated_scale = estimated_scale * em2;
+    out.num_obs = n_init - n_del;
+    out.n_deleted = n_del;
+    out.error_in_px = out.error_final < 1.5 ? 1.0f : (float)(1.5 / out.error_final);
+    out.iters = s.iters;
+    out.n_trials_total = s.n_trials_total;
+    out.status = 0;
+  }
+}
+
+extern "C" int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_pose_job* jobs, int n_jobs,
+                                           hso_pose_result* results, uint8_t* const* outlier_mask)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!cam || n_jobs < 0 || (n_jobs > 0 && (!jobs || !results))) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: bad argument");
+  if (n_jobs == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  size_t tot_feats = 0, tot_poses = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    if (jobs[j].n_feats < 0 || jobs[j].n_feats > POSE_MAX_FEATS) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: n_feats out of range (max 4096)");
+    if (jobs[j].n_poses <= 0 || jobs[j].n_poses > POSE_MAX_POSES || !jobs[j].poses_f_w) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: n_poses out of range (1..64)");
+    if (jobs[j].n_feats > 0 && !jobs[j].feats) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: null feature table");
+    for (int i = 0; i < jobs[j].n_feats; i++) {
+      const hso_pose_feat& f = jobs[j].feats[i];
+      if (f.has_point && (f.host_pose < 0 || f.host_pose >= jobs[j].n_poses || f.level < 0 || f.level > 30))
+        return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: host_pose or level out of range");
+    }
+    tot_feats += jobs[j].n_feats; tot_poses += jobs[j].n_poses;
+  }
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t o_feats = al(sizeof(PoseJobDev) * n_jobs);
+  const size_t o_poses = o_feats + al(sizeof(hso_pose_feat) * tot_feats);
+  const size_t o_mask = o_poses + al(sizeof(hso_se3) * tot_poses);
+  const size_t o_res = o_mask + al(tot_feats);
+  const size_t need = o_res + sizeof(hso_pose_result) * n_jobs;
+  char* d = nullptr;
+  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&d), need));
+  std::vector<char> h(o_res, 0);
+  PoseJobDev* hj = reinterpret_cast<PoseJobDev*>(h.data());
+  size_t fo = 0, po = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    memcpy(h.data() + o_feats + sizeof(hso_pose_feat) * fo, jobs[j].feats, sizeof(hso_pose_feat) * jobs[j].n_feats);
+    memcpy(h.data() + o_poses + sizeof(hso_se3) * po, jobs[j].poses_f_w, sizeof(hso_se3) * jobs[j].n_poses);
+    hj[j].feats = reinterpret_cast<const hso_pose_feat*>(d + o_feats) + fo;
+    hj[j].poses = reinterpret_cast<const hso_se3*>(d + o_poses) + po;
+    hj[j].mask = reinterpret_cast<uint8_t*>(d + o_mask) + fo;
+    hj[j].n_feats = jobs[j].n_feats; hj[j].n_poses = jobs[j].n_poses;
+    hj[j].T = jobs[j].T_f_w; hj[j].reproj_thresh = jobs[j].reproj_thresh; hj[j].n_iter = jobs[j].n_iter; hj[j]._pad = 0;
+    fo += jobs[j].n_feats; po += jobs[j].n_poses;
+  }
+  hipError_t e = hipMemcpyAsync(d, h.data(), o_res, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_pose, dim3(n_jobs), dim3(POSE_THREADS), 0, ctx->stream, *cam, reinterpret_cast<const PoseJobDev*>(d),
+                       reinterpret_cast<hso_pose_result*>(d + o_res));
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(results, d + o_res, sizeof(hso_pose_result) * n_jobs, hipMemcpyDeviceToHost, ctx->stream);
+  std::vector<uint8_t> hm(tot_feats);
+  if (e == hipSuccess && outlier_mask && tot_feats > 0) e = hipMemcpyAsync(hm.data(), d + o_mask, tot_feats, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) { ctx->err = std::string("pose_optimize: ") + hipGetErrorString(e); return HSO_E_HIP; }
+  if (outlier_mask) {
+    fo = 0;
+    for (int j = 0; j < n_jobs; j++) {
+      if (outlier_mask[j] && jobs[j].n_feats > 0) memcpy(outlier_mask[j], hm.data() + fo, jobs[j].n_feats);
+      fo += jobs[j].n_feats;
+    }
+  }
+  return HSO_OK;
+}

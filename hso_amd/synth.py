@@ -139,6 +139,99 @@ class Scene:
         return feats
 
 
+def align_jobs(pair, n, ref_frame_id, seed=7, px_noise=1.5, edgelet_frac=0.3, gx=None, gy=None,
+               pose_noise=0.0, exposure_rat=1.0, kf_gap_lt4=1):
+    """Reprojection candidates for Matcher::findMatchDirect: reference features of `pair`
+    (levels 0-2, corners and edgelets), their depth along the bearing, the pair's true
+    T_cur_ref (optionally perturbed) and a noisy projected start position."""
+    from .capi import AlignJob, SE3, FTR_CORNER, FTR_EDGELET
+    sc = pair["scene"]
+    rng = np.random.default_rng(seed)
+    feats = sc.features(np.array([0, 0, 0, 1.0]), np.zeros(3), n, seed=seed + 1, margin=40)
+    q, t = np.array(pair["q_true"], float), np.array(pair["t_true"], float)
+    if pose_noise > 0:
+        t = t + rng.normal(0, pose_noise, 3)
+    R = quat_to_R(q)
+    jobs = []
+    for i in range(n):
+        j = AlignJob()
+        j.ref_frame_id = ref_frame_id
+        j.ref_level = int(rng.integers(0, 3))
+        px = feats["px"][i]
+        j.px_ref[:] = [float(px[0]), float(px[1])]
+        j.f_ref[:] = [float(v) for v in feats["f"][i]]
+        j.depth = float(feats["dist"][i])
+        is_edge = rng.uniform() < edgelet_frac and gx is not None
+        j.type = FTR_EDGELET if is_edge else FTR_CORNER
+        if is_edge:
+            g = np.array([gx[int(px[1]), int(px[0])], gy[int(px[1]), int(px[0])]], float)
+            g = g / (np.linalg.norm(g) + 1e-9)
+            j.grad[:] = [float(g[0]), float(g[1])]
+        else:
+            j.grad[:] = [1.0, 0.0]
+        j.T_cur_ref = SE3.from_arrays(q, t)
+        X = R @ (feats["f"][i] * feats["dist"][i]) + t
+        u, v = sc.project(X[None, :])
+        j.px_cur[:] = [float(u[0] + rng.normal(0, px_noise)), float(v[0] + rng.normal(0, px_noise))]
+        j.exposure_rat = float(exposure_rat)
+        j.kf_gap_lt4 = int(kf_gap_lt4)
+        jobs.append(j)
+    return jobs
+
+
+def pose_problem(n_feats=200, n_hosts=5, seed=3, px_noise=0.4, outlier_frac=0.05, edgelet_frac=0.3,
+                 temp_frac=0.1, nopoint_frac=0.1, pose_err=(0.02, 0.01), spec=ICL_NUIM):
+    """A frame observing points hosted in `n_hosts` keyframes (inverse-depth parameterisation),
+    as pose_optimizer::optimizeLevenbergMarquardt3rd sees it: returns (feats, host poses,
+    initial T_f_w, true T_f_w)."""
+    from .capi import POSE_FEAT_DTYPE, SE3, FTR_CORNER, FTR_EDGELET
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy, w, h = spec["fx"], spec["fy"], spec["cx"], spec["cy"], spec["width"], spec["height"]
+
+    def rand_pose(sr, st):
+        return rotvec_to_quat(rng.normal(0, sr, 3)), rng.normal(0, st, 3)
+    hosts = [rand_pose(0.05, 0.3) for _ in range(n_hosts)]
+    q_true, t_true = rand_pose(0.05, 0.3)
+    R_true = quat_to_R(q_true)
+    feats = np.zeros(n_feats, POSE_FEAT_DTYPE)
+    for i in range(n_feats):
+        hidx = int(rng.integers(0, n_hosts))
+        qh, th = hosts[hidx]
+        Rh = quat_to_R(qh)
+        # a point in front of both cameras: sample in the host frame, express in world
+        upx = rng.uniform(30, w - 30), rng.uniform(30, h - 30)
+        bear = np.array([(upx[0] - cx) / fx, (upx[1] - cy) / fy, 1.0]); bear /= np.linalg.norm(bear)
+        dist = rng.uniform(2, 8)
+        Xw = Rh.T @ (bear * dist - th)
+        Xc = R_true @ Xw + t_true
+        u = fx * Xc[0] / Xc[2] + cx + rng.normal(0, px_noise)
+        v = fy * Xc[1] / Xc[2] + cy + rng.normal(0, px_noise)
+        if rng.uniform() < outlier_frac:
+            u += rng.normal(0, 25); v += rng.normal(0, 25)
+        fo = np.array([(u - cx) / fx, (v - cy) / fy, 1.0]); fo /= np.linalg.norm(fo)
+        feats["has_point"][i] = 0 if rng.uniform() < nopoint_frac else 1
+        feats["type"][i] = FTR_EDGELET if rng.uniform() < edgelet_frac else FTR_CORNER
+        feats["level"][i] = int(rng.integers(0, 3))
+        feats["temporary"][i] = 1 if rng.uniform() < temp_frac else 0
+        feats["host_pose"][i] = hidx
+        feats["f"][i] = fo
+        g = rng.normal(size=2); feats["grad"][i] = g / np.linalg.norm(g)
+        feats["host_f"][i] = bear
+        feats["idist"][i] = 1.0 / dist
+    q0 = rotvec_to_quat(rng.normal(0, pose_err[1], 3))
+    # initial guess = true pose perturbed on the left
+    R0 = quat_to_R(q0)
+    t0 = R0 @ t_true + rng.normal(0, pose_err[0], 3)
+    # quaternion of R0 * R_true
+    def qmul(a, b):
+        ax, ay, az, aw = a; bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                         aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+    q_init = qmul(q0, q_true)
+    poses = [SE3.from_arrays(q, t) for q, t in hosts]
+    return feats, poses, SE3.from_arrays(q_init, t0), SE3.from_arrays(q_true, t_true)
+
+
 def config2_pair(n_feats=2000, spec=ICL_NUIM, seed=1234, exposure=1.05, noise=1.0,
                  trans_frac=0.02, rot_deg=0.5):
     """reference = frame 0, current = known SE(3) away."""

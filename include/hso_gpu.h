@@ -223,6 +223,97 @@ int hso_gpu_tracker_eval(hso_gpu_ctx* ctx, const hso_camera* cam,
                          hso_eval_out* out, float* ref_patch_out,
                          uint8_t* visible_out, float* abs_err_out);
 
+/* ---- Matcher::findMatchDirect + feature_alignment::align1D/align2D,
+ *      src/matcher.cpp:46-155,226-238,270-440, src/feature_alignment.cpp:164-308,464-605 ---- */
+
+enum { HSO_FTR_CORNER = 0, HSO_FTR_EDGELET = 1, HSO_FTR_GRADIENT = 2 }; /* Feature::FeatureType, feature.h:37 */
+
+/* One reprojection candidate, flattened by the caller from (Point, ref_ftr_ chosen by
+ * Point::getCloseViewObs, src/point.cpp:116-136) exactly as findMatchDirect reads them. */
+typedef struct hso_align_job {
+  int64_t ref_frame_id;   /* ref_ftr_->frame (resident) */
+  int32_t ref_level;      /* ref_ftr_->level */
+  int32_t type;           /* ref_ftr_->type: EDGELET -> align1D + checkNormal, else align2D */
+  double px_ref[2];       /* ref_ftr_->px */
+  double f_ref[3];        /* ref_ftr_->f */
+  double depth;           /* 1/pt.idist_ if the reference is the host frame, else |ref.pos - pt.pos| (matcher.cpp:295-306) */
+  double grad[2];         /* ref_ftr_->grad */
+  hso_se3 T_cur_ref;      /* cur.T_f_w_ * ref.T_f_w_^-1 (matcher.cpp:293) */
+  double px_cur[2];       /* in: projected estimate, level-0 pixels */
+  float exposure_rat;     /* float(cur.m_exposure_time / ref.m_exposure_time) (matcher.cpp:319) */
+  int32_t kf_gap_lt4;     /* cur.keyFrameId_ - ref.keyFrameId_ < 4 (matcher.cpp:317) */
+} hso_align_job;
+
+enum {                    /* hso_align_out.stage: the first check that failed, 0 = success */
+  HSO_ALIGN_OK = 0, HSO_ALIGN_REF_BORDER = 1, HSO_ALIGN_NOT_CONVERGED = 2, HSO_ALIGN_NORMAL = 3,
+  HSO_ALIGN_NCC = 4, HSO_ALIGN_JUMP = 5
+};
+
+typedef struct hso_align_out {
+  int32_t success;        /* findMatchDirect's return value */
+  int32_t stage;
+  int32_t search_level;   /* Matcher::search_level_ */
+  int32_t iters;          /* LK iterations executed */
+  double px_cur[2];       /* refined position, level-0 pixels (px_scaled * 2^search_level) */
+  double A_cur_ref[4];    /* Matcher::A_cur_ref_, row-major (needed to rotate edgelet grads, reprojector.cpp:400-406) */
+  double h_inv;           /* Matcher::h_inv_ (align1D only) */
+  float ncc;              /* the NCC value checkNCC compares with 0.7 */
+  float chi2;             /* chi2 of the last LK iteration */
+} hso_align_out;
+
+/* All candidates of one current frame in one launch, one wavefront per candidate (64 lanes =
+ * the 8x8 patch).  The caller applies Reprojector::reprojectCell's first-success-per-cell
+ * rule (src/reprojector.cpp:352-429) to the result array in its own visiting order. */
+int hso_gpu_align_batch(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id,
+                        const hso_align_job* jobs, int n_jobs, hso_align_out* out);
+
+/* ---- pose_optimizer::optimizeLevenbergMarquardt3rd, src/pose_optimizer.cpp:399-771 ---- */
+
+/* One feature of the frame being optimised, in Frame::fts_ order.  has_point = 0 keeps the
+ * slot (point == NULL features are skipped but still count in fts_.size(), :696). */
+typedef struct hso_pose_feat {
+  int32_t has_point;    /* (*it)->point != NULL */
+  int32_t type;         /* Feature::type (HSO_FTR_*): EDGELET uses the 1-D residual grad^T e */
+  int32_t level;        /* Feature::level: residual scaled by 1/2^level */
+  int32_t temporary;    /* point->type_ == Point::TYPE_TEMPORARY: weight * 0.5 */
+  int32_t host_pose;    /* index into poses_f_w: point->hostFeature_->frame->T_f_w_ */
+  int32_t _pad;
+  double f[3];          /* Feature::f (observation bearing in this frame) */
+  double grad[2];       /* Feature::grad */
+  double host_f[3];     /* point->hostFeature_->f */
+  double idist;         /* point->idist_ */
+} hso_pose_feat;
+
+typedef struct hso_pose_job {
+  const hso_pose_feat* feats;  /* host pointer */
+  int32_t n_feats;             /* frame->fts_.size() */
+  int32_t n_poses;
+  const hso_se3* poses_f_w;    /* host pointer: T_f_w_ of the host keyframes */
+  hso_se3 T_f_w;               /* frame->T_f_w_ (initial) */
+  double reproj_thresh;        /* Config::poseOptimThresh() = 2.0 */
+  int32_t n_iter;              /* 12, frame_handler_mono.cpp:242 */
+  int32_t _pad;
+} hso_pose_job;
+
+typedef struct hso_pose_result {
+  hso_se3 T_f_w;           /* frame->T_f_w_ */
+  double cov[36];          /* frame->Cov_, row-major */
+  double estimated_scale;  /* in pixels (x errorMultiplier2) */
+  double error_init, error_final;
+  float error_in_px;       /* frame->m_error_in_px */
+  int32_t num_obs;         /* after outlier removal */
+  int32_t n_deleted;       /* features whose point was set to NULL */
+  int32_t iters;           /* outer LM iterations entered */
+  int32_t n_trials_total;  /* linear solves performed */
+  int32_t status;          /* 0 ok, 1 = no residuals (early return, :456) */
+} hso_pose_result;
+
+/* Batched over independent frames: one workgroup per job, the whole LM loop on the device.
+ * outlier_mask[j] (n_feats bytes each, may be NULL) = 1 where the reference sets
+ * feature->point = NULL (:722-748). */
+int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_pose_job* jobs,
+                                int n_jobs, hso_pose_result* results, uint8_t* const* outlier_mask);
+
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

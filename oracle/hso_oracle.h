@@ -89,6 +89,25 @@ void hso_or_tracker_get_cache(const hso_or_tracker* t, float* ref_patch, uint8_t
 /* CoarseTracker::run (:51-208) minus the frame write-back */
 void hso_or_tracker_run(hso_or_tracker* t, const hso_se3* T_init, float exposure_init,
                         hso_track_result* out);
+/* ---- Matcher::findMatchDirect and its pieces (src/matcher.cpp, src/feature_alignment.cpp) ---- */
+void hso_or_warp_matrix_affine(const hso_camera* cam_ref, const hso_camera* cam_cur, const double px_ref[2],
+                               const double f_ref[3], double depth_ref, const hso_se3* T_cur_ref, int level_ref,
+                               double A[4]);                                       /* matcher.cpp:46-72 */
+int hso_or_best_search_level(const double A[4], int max_level);                      /* :74-85 */
+int hso_or_warp_affine(const double A_cur_ref[4], const uint8_t* img_ref, int cols, int rows, const double px_ref[2],
+                       int level_ref, int search_level, int halfpatch_size, float* patch); /* :120-155 */
+int hso_or_align2d(const uint8_t* cur_img, int cols, int rows, const float* ref_patch_with_border, const float* ref_patch,
+                   int n_iter, double cur_px_estimate[2], float* cur_patch, int* iters_out, float* chi2_out);
+int hso_or_align1d(const uint8_t* cur_img, int cols, int rows, const float dir[2], const float* ref_patch_with_border,
+                   const float* ref_patch, int n_iter, double cur_px_estimate[2], double* h_inv, float* cur_patch,
+                   int* iters_out, float* chi2_out);                                 /* feature_alignment.cpp */
+double hso_or_ncc(const float* patch1, const float* patch2);                         /* matcher.cpp:379-404 */
+double hso_or_normal_dot(const int16_t* gx, const int16_t* gy, int cols, const double pxLevel[2], const double normal[2]);
+void hso_or_find_match_direct(const hso_camera* cam, const hso_align_job* job, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                              const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
+                              const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_align_out* out);
+/* ---- pose_optimizer::optimizeLevenbergMarquardt3rd (src/pose_optimizer.cpp:399-771) ---- */
+void hso_or_pose_optimize(const hso_camera* cam, const hso_pose_job* job, hso_pose_result* out, uint8_t* outlier_mask);
 /* per-term dump of the last evaluation for debugging: returns number of rows written */
 int hso_or_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch,
                            int8_t* offsets_xy);

@@ -260,6 +260,41 @@ class Tracker:
         return res
 
 
+def find_match_direct(cam, job, ref_pyr, cur_pyr, cur_sobel):
+    """Matcher::findMatchDirect (after the reference observation was chosen) on host arrays.
+    ref_pyr/cur_pyr: 5 level images; cur_sobel: [(gx, gy)] for levels 0..2."""
+    from hso_amd.capi import AlignJob, AlignOut
+    lib = load()
+    lib.hso_or_find_match_direct.argtypes = [C.POINTER(Camera), C.POINTER(AlignJob), C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                             C.c_int, C.c_int, C.POINTER(AlignOut)]
+    lib.hso_or_find_match_direct.restype = None
+    rp = [np.ascontiguousarray(l) for l in ref_pyr]
+    cp = [np.ascontiguousarray(l) for l in cur_pyr]
+    gx = [np.ascontiguousarray(g[0]) for g in cur_sobel]
+    gy = [np.ascontiguousarray(g[1]) for g in cur_sobel]
+    h, w = rp[0].shape
+    out = AlignOut()
+    lib.hso_or_find_match_direct(C.byref(cam), C.byref(job),
+                                 (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in rp]),
+                                 (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in cp]),
+                                 (C.c_void_p * 3)(*[g.ctypes.data for g in gx]),
+                                 (C.c_void_p * 3)(*[g.ctypes.data for g in gy]), w, h, C.byref(out))
+    return out
+
+
+def pose_optimize(cam, job):
+    """optimizeLevenbergMarquardt3rd on a hso_amd.capi.PoseJob; returns (PoseResult, outlier mask)."""
+    from hso_amd.capi import PoseJob, PoseResult
+    lib = load()
+    lib.hso_or_pose_optimize.argtypes = [C.POINTER(Camera), C.POINTER(PoseJob), C.POINTER(PoseResult), C.c_void_p]
+    lib.hso_or_pose_optimize.restype = None
+    res = PoseResult()
+    mask = np.zeros(max(job.n_feats, 1), np.uint8)
+    lib.hso_or_pose_optimize(C.byref(cam), C.byref(job), C.byref(res), _ptr(mask))
+    return res, mask[:job.n_feats]
+
+
 def pattern(max_level, level):
     pa, hp = C.c_int(), C.c_int()
     offs = np.zeros((40, 2), np.int8)
