@@ -150,6 +150,18 @@ def make_pose_job(feats, poses, T_f_w, reproj_thresh=2.0, n_iter=12):
     return j
 
 
+BA_EDGE_DTYPE = np.dtype([("point", "<i4"), ("host", "<i4"), ("target", "<i4"), ("type", "<i4"), ("level", "<i4"),
+                          ("_pad", "<i4"), ("fH", "<f8", 3), ("meas", "<f8", 2), ("normal", "<f8", 2)])
+assert BA_EDGE_DTYPE.itemsize == 80
+
+
+def ba_alloc(n_poses, n_points, n_edges):
+    """Output buffers of hso_gpu_ba_linearize / the oracle's hso_or_ba_linearize."""
+    return dict(Hpp=np.zeros(n_points), bp=np.zeros(n_points), Hpc=np.zeros((n_points, n_poses, 6)),
+                Hcc=np.zeros((n_poses, n_poses, 6, 6)), bc=np.zeros((n_poses, 6)),
+                edge_err=np.zeros((n_edges, 2)), edge_chi2=np.zeros(n_edges), chi2_sum=np.zeros(2))
+
+
 def make_camera(model, width, height, fx, fy, cx, cy, d=(0, 0, 0, 0, 0), distortion=None):
     cam = Camera()
     cam.model = model
@@ -211,6 +223,7 @@ def load():
     lib.hso_gpu_tracker_pattern.argtypes = [i32, i32, P(i32), P(i32), vp]
     lib.hso_gpu_align_batch.argtypes = [vp, P(Camera), i64, P(AlignJob), i32, P(AlignOut)]
     lib.hso_gpu_pose_optimize_batch.argtypes = [vp, P(Camera), P(PoseJob), i32, P(PoseResult), vp]
+    lib.hso_gpu_ba_linearize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double] + [vp] * 8
     _lib = lib
     return lib
 
@@ -222,7 +235,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
-    "hso_gpu_align_batch", "hso_gpu_pose_optimize_batch",
+    "hso_gpu_align_batch", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
 ]
 
 
@@ -365,6 +378,20 @@ class Context:
         mptr = (C.c_void_p * len(jobs))(*[m.ctypes.data for m in masks])
         self._check(self.lib.hso_gpu_pose_optimize_batch(self.h, C.byref(cam), arr, len(jobs), res, mptr), "pose_optimize_batch")
         return list(res), [m[:j.n_feats] for m, j in zip(masks, jobs)]
+
+    # -- bundle adjustment linearisation
+    def ba_linearize(self, poses, fixed, idist, edges, huber_corner, huber_edge):
+        parr = (SE3 * len(poses))(*poses)
+        fixed = np.ascontiguousarray(fixed, np.uint8)
+        idist = np.ascontiguousarray(idist, np.float64)
+        edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+        o = ba_alloc(len(poses), len(idist), len(edges))
+        rc = self.lib.hso_gpu_ba_linearize(self.h, C.cast(parr, C.c_void_p), _ptr(fixed), len(poses), _ptr(idist), len(idist),
+                                           _ptr(edges), len(edges), huber_corner, huber_edge, _ptr(o["Hpp"]), _ptr(o["bp"]),
+                                           _ptr(o["Hpc"]), _ptr(o["Hcc"]), _ptr(o["bc"]), _ptr(o["edge_err"]),
+                                           _ptr(o["edge_chi2"]), _ptr(o["chi2_sum"]))
+        self._check(rc, "ba_linearize")
+        return o
 
     def tracker_eval(self, cam, params, job, level, T, exposure_rat, huber=-1.0, outlier=-1.0,
                      want_cache=False, want_errors=False):

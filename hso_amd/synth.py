@@ -232,6 +232,47 @@ def pose_problem(n_feats=200, n_hosts=5, seed=3, px_noise=0.4, outlier_frac=0.05
     return feats, poses, SE3.from_arrays(q_init, t0), SE3.from_arrays(q_true, t_true)
 
 
+def ba_problem(n_poses=9, n_points=300, obs_per_point=4, seed=9, px_noise=0.5, edgelet_frac=0.3,
+               n_fixed=2, spec=ICL_NUIM):
+    """A local-BA graph as ba::LocalBundleAdjustment builds it: keyframe poses (some fixed),
+    inverse-depth points hosted in one keyframe, one edge per non-host observation."""
+    from .capi import BA_EDGE_DTYPE, SE3, FTR_CORNER, FTR_EDGELET
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy, w, h = spec["fx"], spec["fy"], spec["cx"], spec["cy"], spec["width"], spec["height"]
+    poses = [(rotvec_to_quat(rng.normal(0, 0.04, 3)), rng.normal(0, 0.25, 3)) for _ in range(n_poses)]
+    fixed = np.zeros(n_poses, np.uint8); fixed[:n_fixed] = 1
+    idist = np.zeros(n_points)
+    edges = []
+    for p in range(n_points):
+        host = int(rng.integers(0, n_poses))
+        qh, th = poses[host]; Rh = quat_to_R(qh)
+        upx = rng.uniform(40, w - 40), rng.uniform(40, h - 40)
+        bear = np.array([(upx[0] - cx) / fx, (upx[1] - cy) / fy, 1.0]); bear /= np.linalg.norm(bear)
+        dist = rng.uniform(2, 8)
+        idist[p] = (1.0 / dist) * (1 + rng.normal(0, 0.03))         # perturbed estimate
+        Xw = Rh.T @ (bear * dist - th)
+        others = [k for k in range(n_poses) if k != host]
+        for tgt in rng.choice(others, size=min(obs_per_point, len(others)), replace=False):
+            qt, tt = poses[int(tgt)]
+            Xc = quat_to_R(qt) @ Xw + tt
+            uv = np.array([Xc[0] / Xc[2] + rng.normal(0, px_noise / fx), Xc[1] / Xc[2] + rng.normal(0, px_noise / fy)])
+            e = np.zeros((), BA_EDGE_DTYPE)
+            e["point"], e["host"], e["target"] = p, host, int(tgt)
+            e["level"] = int(rng.integers(0, 3))
+            e["fH"] = bear
+            if rng.uniform() < edgelet_frac:
+                g = rng.normal(size=2); g /= np.linalg.norm(g)
+                e["type"] = FTR_EDGELET
+                e["normal"] = g
+                e["meas"] = [g @ uv, 0.0]
+            else:
+                e["type"] = FTR_CORNER
+                e["normal"] = [1.0, 0.0]
+                e["meas"] = uv
+            edges.append(e)
+    return [SE3.from_arrays(q, t) for q, t in poses], fixed, idist, np.array(edges, BA_EDGE_DTYPE)
+
+
 def config2_pair(n_feats=2000, spec=ICL_NUIM, seed=1234, exposure=1.05, noise=1.0,
                  trans_frac=0.02, rot_deg=0.5):
     """reference = frame 0, current = known SE(3) away."""

@@ -314,6 +314,39 @@ typedef struct hso_pose_result {
 int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_pose_job* jobs,
                                 int n_jobs, hso_pose_result* results, uint8_t* const* outlier_mask);
 
+/* ---- local bundle adjustment: the Jacobian / Hessian build the reference delegates to g2o.
+ *      Edges: EdgeProjectID2UV / EdgeProjectID2UVEdgeLet (include/hso/bundle_adjustment.h:204-404),
+ *      created at src/bundle_adjustment.cpp:690-812; accumulation = g2o BlockSolver::buildSystem
+ *      -> BaseMultiEdge::constructQuadraticForm (thirdparty/g2o/g2o/core/base_multi_edge.hpp:36-48,
+ *      171-222) with RobustKernelHuber (robust_kernel_impl.cpp:78-91) and
+ *      robustInformation = rho'(chi2) * Omega (base_edge.h:96-102). ---- */
+typedef struct hso_ba_edge {
+  int32_t point;      /* vertex 0: inverse-depth point index */
+  int32_t host;       /* vertex 1: host keyframe pose index */
+  int32_t target;     /* vertex 2: observing keyframe pose index */
+  int32_t type;       /* HSO_FTR_EDGELET -> 1-D edge along `normal`, else 2-D edge */
+  int32_t level;      /* information = 1 / 4^level (bundle_adjustment.cpp:758,788) */
+  int32_t _pad;
+  double fH[3];       /* setHostBearing(point->hostFeature_->f) */
+  double meas[2];     /* project2d(obs->f); edgelets: meas[0] = grad^T project2d(obs->f) */
+  double normal[2];   /* setTargetNormal(obs->grad) (edgelets) */
+} hso_ba_edge;
+
+/* Dense outputs, sized by the caller.  Unknown order: points first (1 each), then poses (6 each,
+ * g2o SE3Quat tangent order [omega, upsilon]); entries of fixed poses are left zero.
+ *   Hpp[n_points], bp[n_points]                      point diagonal and gradient
+ *   Hpc[n_points * n_poses * 6]                      point-pose blocks (1x6), row-major
+ *   Hcc[n_poses * n_poses * 36]                      pose-pose blocks (6x6, row-major), block (i,j)
+ *                                                    filled for i <= j (the upper half, like g2o)
+ *   bc[n_poses * 6]
+ *   edge_err[n_edges * 2], edge_chi2[n_edges]        _error and chi2() = e^T Omega e per edge
+ *   chi2_sum[2]                                      sum of chi2, sum of robustified rho(chi2) */
+int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses,
+                         const double* idist, int n_points, const hso_ba_edge* edges, int n_edges,
+                         double huber_corner, double huber_edge,
+                         double* Hpp, double* bp, double* Hpc, double* Hcc, double* bc,
+                         double* edge_err, double* edge_chi2, double* chi2_sum);
+
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

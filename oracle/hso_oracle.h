@@ -108,6 +108,11 @@ void hso_or_find_match_direct(const hso_camera* cam, const hso_align_job* job, c
                               const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_align_out* out);
 /* ---- pose_optimizer::optimizeLevenbergMarquardt3rd (src/pose_optimizer.cpp:399-771) ---- */
 void hso_or_pose_optimize(const hso_camera* cam, const hso_pose_job* job, hso_pose_result* out, uint8_t* outlier_mask);
+/* ---- local BA linearisation (include/hso/bundle_adjustment.h:204-404 + vendored g2o) ---- */
+void hso_or_ba_linearize(const hso_se3* poses, const uint8_t* pose_fixed, int n_poses, const double* idist, int n_points,
+                         const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge,
+                         double* Hpp, double* bp, double* Hpc, double* Hcc, double* bc,
+                         double* edge_err, double* edge_chi2, double* chi2_sum);
 /* per-term dump of the last evaluation for debugging: returns number of rows written */
 int hso_or_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch,
                            int8_t* offsets_xy);

@@ -295,6 +295,24 @@ def pose_optimize(cam, job):
     return res, mask[:job.n_feats]
 
 
+def ba_linearize(poses, fixed, idist, edges, huber_corner, huber_edge):
+    """g2o-style build of the robustified normal equations (see hso_oracle_ba.c)."""
+    from hso_amd.capi import BA_EDGE_DTYPE, ba_alloc
+    lib = load()
+    lib.hso_or_ba_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_double, C.c_double] + [C.c_void_p] * 8
+    lib.hso_or_ba_linearize.restype = None
+    parr = (SE3 * len(poses))(*poses)
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    idist = np.ascontiguousarray(idist, np.float64)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    o = ba_alloc(len(poses), len(idist), len(edges))
+    lib.hso_or_ba_linearize(C.cast(parr, C.c_void_p), _ptr(fixed), len(poses), _ptr(idist), len(idist), _ptr(edges),
+                            len(edges), huber_corner, huber_edge, _ptr(o["Hpp"]), _ptr(o["bp"]), _ptr(o["Hpc"]),
+                            _ptr(o["Hcc"]), _ptr(o["bc"]), _ptr(o["edge_err"]), _ptr(o["edge_chi2"]), _ptr(o["chi2_sum"]))
+    return o
+
+
 def pattern(max_level, level):
     pa, hp = C.c_int(), C.c_int()
     offs = np.zeros((40, 2), np.int8)

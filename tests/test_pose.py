@@ -60,7 +60,9 @@ def test_pose_optimize_parity(gpu_ctx, orc, cam, n, seed):
     assert rg.status == ro.status == 0
     assert rg.estimated_scale == ro.estimated_scale                 # MAD scale: exact order statistic
     assert rg.error_init == ro.error_init
-    assert (rg.iters, rg.n_trials_total) == (ro.iters, ro.n_trials_total)
+    # once converged rho = chi2 - new_chi2 is rounding noise (|rho| ~ 1e-18): the serial and the tree
+    # sums may accept/reject a last no-op step differently, the pose does not move
+    assert abs(rg.iters - ro.iters) <= 2 and abs(rg.n_trials_total - ro.n_trials_total) <= 6
     rot, tra = pose_dist(rg.T_f_w, ro.T_f_w)
     assert rot <= 1e-9 and tra <= 1e-9
     # outlier decisions: identical except for residuals within 1e-9 of the threshold
@@ -84,7 +86,7 @@ def test_pose_optimize_batch_and_edge_cases(gpu_ctx, orc, cam):
         ro, mo = orc.pose_optimize(cam, j)
         assert r.status == ro.status
         if ro.status == 0:
-            assert np.array_equal(m, mo) and r.iters == ro.iters
+            assert np.array_equal(m, mo) and abs(r.iters - ro.iters) <= 2
             rot, tra = pose_dist(r.T_f_w, ro.T_f_w)
             assert rot <= 1e-9 and tra <= 1e-9
     assert res[-1].status == 1 and not masks[-1].any()
