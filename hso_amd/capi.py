@@ -150,13 +150,26 @@ def make_pose_job(feats, poses, T_f_w, reproj_thresh=2.0, n_iter=12):
     return j
 
 
+class Seed(C.Structure):
+    _fields_ = [("ref_frame_id", C.c_int64), ("level", C.c_int32), ("type", C.c_int32), ("px", C.c_double * 2),
+                ("f", C.c_double * 3), ("grad", C.c_double * 2), ("T_ref_w", SE3), ("ref_exposure", C.c_double),
+                ("mu", C.c_float), ("sigma2", C.c_float), ("b", C.c_float), ("_pad", C.c_float)]
+
+
+class SeedOut(C.Structure):
+    _fields_ = [("mu", C.c_float), ("sigma2", C.c_float), ("b", C.c_float), ("result", C.c_int32),
+                ("is_update", C.c_int32), ("is_valid", C.c_int32), ("search_level", C.c_int32),
+                ("epl_start", C.c_int32 * 2), ("epl_end", C.c_int32 * 2), ("n_steps", C.c_int32),
+                ("px_cur", C.c_double * 2), ("z", C.c_double), ("zmncc_best", C.c_float), ("zmncc_second", C.c_float)]
+
+
 BA_EDGE_DTYPE = np.dtype([("point", "<i4"), ("host", "<i4"), ("target", "<i4"), ("type", "<i4"), ("level", "<i4"),
                           ("_pad", "<i4"), ("fH", "<f8", 3), ("meas", "<f8", 2), ("normal", "<f8", 2)])
 assert BA_EDGE_DTYPE.itemsize == 80
 
 
 def ba_alloc(n_poses, n_points, n_edges):
-    """Output buffers of hso_gpu_ba_linearize / the oracle's hso_or_ba_linearize."""
+    """Output buffers of hso_gpu_ba_linearize."""
     return dict(Hpp=np.zeros(n_points), bp=np.zeros(n_points), Hpc=np.zeros((n_points, n_poses, 6)),
                 Hcc=np.zeros((n_poses, n_poses, 6, 6)), bc=np.zeros((n_poses, 6)),
                 edge_err=np.zeros((n_edges, 2)), edge_chi2=np.zeros(n_edges), chi2_sum=np.zeros(2))
@@ -224,6 +237,7 @@ def load():
     lib.hso_gpu_align_batch.argtypes = [vp, P(Camera), i64, P(AlignJob), i32, P(AlignOut)]
     lib.hso_gpu_pose_optimize_batch.argtypes = [vp, P(Camera), P(PoseJob), i32, P(PoseResult), vp]
     lib.hso_gpu_ba_linearize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double] + [vp] * 8
+    lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
     _lib = lib
     return lib
 
@@ -236,6 +250,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
+    "hso_gpu_seed_observe",
 ]
 
 
@@ -392,6 +407,14 @@ class Context:
                                            _ptr(o["edge_chi2"]), _ptr(o["chi2_sum"]))
         self._check(rc, "ba_linearize")
         return o
+
+    # -- depth-filter seed observation
+    def seed_observe(self, cam, cur_frame_id, cur_T_f_w, cur_exposure, px_error_angle, seeds):
+        arr = (Seed * len(seeds))(*seeds)
+        out = (SeedOut * len(seeds))()
+        self._check(self.lib.hso_gpu_seed_observe(self.h, C.byref(cam), cur_frame_id, C.byref(cur_T_f_w), cur_exposure,
+                                                  px_error_angle, arr, len(seeds), out), "seed_observe")
+        return list(out)
 
     def tracker_eval(self, cam, params, job, level, T, exposure_rat, huber=-1.0, outlier=-1.0,
                      want_cache=False, want_errors=False):

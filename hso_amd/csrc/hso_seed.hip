@@ -1,0 +1,476 @@
+// hso_seed.hip — depth-filter seed observation on gfx950: epipolar ZMNCC search, step-limited
+// KLT refinement, triangulation and the Gaussian inverse-depth update, one wavefront per seed.
+//
+// Replaces DepthFilter::observeDepthRow (reference src/depth_filter.cpp:580-675) with
+// updateSeed :527-537 and computeTau :539-555, and Matcher::doLineStereo
+// (src/matcher.cpp:802-1049) with KLTLimited2D :1296-1451, KLTLimited1D :1454-1606,
+// warp::createPatch :159-196, ZMNCC_F (include/hso/vikit/patch_score.h:268-305),
+// checkNormal :406-440, checkNCC :379-404 and depthFromTriangulation :242-255.
+//
+// MI355X mapping: the reference spreads seeds over 4 CPU threads (IndexThreadReduce,
+// MAPPING_THREADS 4); here every seed is a wavefront and lane = pixel of the 8x8 patch, so the
+// 64-tap patch extraction + ZMNCC of one epipolar step is one 4-tap fetch per lane and three
+// xor-butterfly sums.  The march along the epipolar line is inherently sequential per seed
+// (<= ~104 steps); throughput comes from ~900 seeds per keyframe x many sequences in flight.
+// Geometry (fp64) is uniform over the wave and computed redundantly by all lanes.  The fp32
+// sums are butterflies (reference: serial loops) — rounding-level differences only; result
+// codes and the step index of the best score can differ on near-ties (flagged in the tests).
+#include "hso_ctx.h"
+#include "hso_dev_math.h"
+#include <string.h>
+#include <vector>
+
+using namespace hso_dev;
+
+#define SEED_WAVES_PER_BLOCK 4
+
+struct SeedConsts {
+  hso_camera cam;
+  PyrGeom g;
+  const uint8_t* cur_base;
+  hso_se3 cur_T_f_w;
+  double cur_exposure, px_error_angle;
+};
+
+struct SeedDev {
+  const uint8_t* ref_base;
+  hso_seed s;
+};
+
+HSO_DEV float s_wave_sum(float v)
+{
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// AbstractCamera::cam2world, src/camera.cpp:67-87,171-194 (see hso_align.hip for the radtan note)
+HSO_DEV void s_cam2world(const hso_camera& cam, double u, double v, double f[3])
+{
+  double x, y;
+  if (cam.model == HSO_CAM_PINHOLE && cam.distortion) {
+    const double fx = (float)cam.fx, fy = (float)cam.fy, cx = (float)cam.cx, cy = (float)cam.cy;
+    const double k0 = (float)cam.d[0], k1 = (float)cam.d[1], p1 = (float)cam.d[2], p2 = (float)cam.d[3], k2 = (float)cam.d[4];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    x = (float)u; y = (float)v;
+    const double x0 = x = (x - cx) * ifx;
+    const double y0 = y = (y - cy) * ify;
+    for (int it = 0; it < 5; it++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k2 * r2 + k1) * r2 + k0) * r2);
+      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    x = (float)x; y = (float)y;
+  } else if (cam.model == HSO_CAM_FOV && cam.distortion) {
+    const double omega = cam.d[0];
+    const double ud = (u - cam.cx) / cam.fx, vd = (v - cam.cy) / cam.fy;
+    const double dist = sqrt(ud * ud + vd * vd);
+    const double rd = tan(dist * omega) / (2 * dist * tan(omega / 2));
+    x = rd * ud; y = rd * vd;
+  } else {
+    x = (u - cam.cx) / cam.fx; y = (v - cam.cy) / cam.fy;
+  }
+  const double n = sqrt(x * x + y * y + 1.0);
+  f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
+}
+
+HSO_DEV float s_interp_8u(const uint8_t* data, int stride, float u, float v)
+{
+  const int x = (int)floor((double)u), y = (int)floor((double)v);
+  const float sx = u - (float)x, sy = v - (float)y;
+  const float w00 = (1.0f - sx) * (1.0f - sy), w01 = (1.0f - sx) * sy, w10 = sx * (1.0f - sy);
+  const float w11 = ((1.0f - w00) - w01) - w10;
+  const uint8_t* p = data + y * stride + x;
+  return ((w00 * (float)p[0] + w01 * (float)p[stride]) + w10 * (float)p[1]) + w11 * (float)p[stride + 1];
+}
+
+// One lane's sample of warp::createPatch (matcher.cpp:159-196) at patch pixel (px_, py_)
+HSO_DEV float s_patch_sample(const uint8_t* img, int stride, double pxs0, double pxs1, int px_, int py_)
+{
+  const float u = (float)pxs0, v = (float)pxs1;
+  const int ui = (int)floorf(u), vi = (int)floorf(v);
+  const float su = u - (float)ui, sv = v - (float)vi;
+  const float w_tl = (float)((1.0 - su) * (1.0 - sv));
+  const float w_tr = (float)(su * (1.0 - sv));
+  const float w_bl = (float)((1.0 - su) * sv);
+  const float w_br = (float)(((1.0 - w_tl) - w_tr) - w_bl);
+  const uint8_t* c = img + (vi - 4 + py_) * stride + (ui - 4) + px_;
+  return ((w_tl * (float)c[0] + w_tr * (float)c[1]) + w_bl * (float)c[stride]) + w_br * (float)c[stride + 1];
+}
+
+// Matcher::KLTLimited2D / KLTLimited1D (matcher.cpp:1296-1606), one lane per patch pixel.
+// ONE_D: motion restricted to `d0,d1` (double, as passed by the reference).  Returns the bool.
+template <bool ONE_D>
+HSO_DEV bool s_klt_limited(const uint8_t* img, int cols, int rows, float gxr, float gyr, float ref_px, double d0, double d1,
+                           double& pxs0, double& pxs1, float& last_sample, bool& sampled)
+{
+  float Jx, Jy = 0;
+  if (ONE_D) Jx = (float)(0.5 * (d0 * (double)gxr + d1 * (double)gyr));
+  else { Jx = (float)(0.5 * (double)gxr); Jy = (float)(0.5 * (double)gyr); }
+  const float wgt = ONE_D ? sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx))))
+                          : sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx + Jy * Jy))));
+  float Hi[9];
+  {
+    const float h_xx = s_wave_sum((Jx * Jx) * wgt), h_x1 = s_wave_sum((Jx * 1.0f) * wgt), h_11 = s_wave_sum((1.0f * 1.0f) * wgt);
+    if (ONE_D) {
+      const float H00 = (float)((double)h_xx * (1 + 0.001)), H11 = (float)((double)h_11 * (1 + 0.001)), H01 = h_x1;
+      const float det = H00 * H11 - H01 * H01;
+      const float invdet = 1.0f / det;
+      Hi[0] = H11 * invdet; Hi[1] = -H01 * invdet; Hi[3] = -H01 * invdet; Hi[4] = H00 * invdet;
+    } else {
+      const float h_xy = s_wave_sum((Jx * Jy) * wgt), h_yy = s_wave_sum((Jy * Jy) * wgt), h_y1 = s_wave_sum((Jy * 1.0f) * wgt);
+      const float H0 = (float)((double)h_xx * (1 + 0.001)), H4 = (float)((double)h_yy * (1 + 0.001)), H8 = (float)((double)h_11 * (1 + 0.001));
+      const float H1 = h_xy, H2 = h_x1, H5 = h_y1, H3 = H1, H6 = H2, H7 = H5;
+      const float c00 = H4 * H8 - H5 * H7, c01 = H5 * H6 - H3 * H8, c02 = H3 * H7 - H4 * H6;
+      const float det = H0 * c00 + H1 * c01 + H2 * c02;
+      const float invdet = 1.0f / det;
+      Hi[0] = c00 * invdet; Hi[3] = c01 * invdet; Hi[6] = c02 * invdet;
+      Hi[1] = (H2 * H7 - H1 * H8) * invdet; Hi[4] = (H0 * H8 - H2 * H6) * invdet; Hi[7] = (H1 * H6 - H0 * H7) * invdet;
+      Hi[2] = (H1 * H5 - H2 * H4) * invdet; Hi[5] = (H2 * H3 - H0 * H5) * invdet; Hi[8] = (H0 * H4 - H1 * H3) * invdet;
+    }
+  }
+  const int lane = threadIdx.x & 63, px_ = lane & 7, py_ = lane >> 3;
+  float mean_diff = 0;
+  float bestU = (float)pxs0, bestV = (float)pxs1;
+  float bestEnergy = 1e8f;
+  float sb0 = 0, sb1 = 0, sb2 = 0;
+  float uBak = bestU, vBak = bestV, meanBak = mean_diff;
+  for (int iter = 0; iter < 10; ++iter) {
+    const int u_r = (int)floor((double)bestU), v_r = (int)floor((double)bestV);
+    if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;
+    if (isnan(bestU) || isnan(bestV)) return false;
+    const float sx = bestU - (float)u_r, sy = bestV - (float)v_r;
+    const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy), wBR = sx * sy;
+    const uint8_t* it = img + (v_r + py_ - 4) * cols + u_r - 4 + px_;
+    const float sp = ((wTL * (float)it[0] + wTR * (float)it[1]) + wBL * (float)it[cols]) + wBR * (float)it[cols + 1];
+    last_sample = sp; sampled = true;
+    const float res = (sp - ref_px) + mean_diff;
+    const float j0 = -s_wave_sum((res * Jx) * wgt);
+    const float j2 = -s_wave_sum(res * wgt);
+    const float energy = s_wave_sum((res * res) * wgt);
+    float j1 = 0;
+    if (!ONE_D) j1 = -s_wave_sum((res * Jy) * wgt);
+    if (energy > bestEnergy) {
+      sb0 *= 0.5f; sb1 *= 0.5f; sb2 *= 0.5f;
+      if (ONE_D) { bestU = (float)((double)uBak + (double)sb0 * d0); bestV = (float)((double)vBak + (double)sb0 * d1); mean_diff = meanBak + sb1; }
+      else { bestU = uBak + sb0; bestV = vBak + sb1; mean_diff = meanBak + sb2; }
+    } else {
+      float st0, st1, st2 = 0;
+      if (ONE_D) {
+        st0 = Hi[0] * j0 + Hi[1] * j2; st1 = Hi[3] * j0 + Hi[4] * j2;
+        if (st0 < -0.5f) st0 = -0.5f; else if (st0 > 0.5f) st0 = 0.5f;
+        if (!isfinite(st0)) { st0 = 0; st1 = 0; }
+      } else {
+        st0 = (Hi[0] * j0 + Hi[1] * j1) + Hi[2] * j2;
+        st1 = (Hi[3] * j0 + Hi[4] * j1) + Hi[5] * j2;
+        st2 = (Hi[6] * j0 + Hi[7] * j1) + Hi[8] * j2;
+        if (st0 < -0.5f) st0 = -0.5f; else if (st0 > 0.5f) st0 = 0.5f;
+        if (st1 < -0.5f) st1 = -0.5f; else if (st1 > 0.5f) st1 = 0.5f;
+        if (!isfinite(st0)) { st0 = 0; st1 = 0; st2 = 0; }
+      }
+      uBak = bestU; vBak = bestV; meanBak = mean_diff;
+      sb0 = st0; sb1 = st1; sb2 = st2;
+      if (ONE_D) { bestU = (float)((double)bestU + (double)st0 * d0); bestV = (float)((double)bestV + (double)st0 * d1); mean_diff += st1; }
+      else { bestU += st0; bestV += st1; mean_diff += st2; }
+      bestEnergy = energy;
+    }
+    if (ONE_D) { if ((double)fabsf(sb0) < 0.01) break; }
+    else { if ((double)(sb0 * sb1) < 0.01 * 0.01) break; }  // the reference multiplies the two components (:1435)
+  }
+  pxs0 = (double)bestU; pxs1 = (double)bestV;
+  return !(bestEnergy > (float)(650 * 64));
+}
+
+__global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(SeedConsts C, const SeedDev* seeds, int n_seeds,
+                                                                             hso_seed_out* outs)
+{
+  __shared__ float s_pwb[SEED_WAVES_PER_BLOCK][100];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sid = blockIdx.x * SEED_WAVES_PER_BLOCK + wave;
+  if (sid >= n_seeds) return;
+  const SeedDev& SD = seeds[sid];
+  const hso_seed& S = SD.s;
+  const int W = C.g.w[0], H = C.g.h[0];
+  hso_seed_out o;
+  memset(&o, 0, sizeof(o));
+  o.mu = S.mu; o.sigma2 = S.sigma2; o.b = S.b; o.is_valid = 1;
+
+  // ---- visibility in the active frame (depth_filter.cpp:590-606)
+  const Se3 Tcw = se3_from(C.cur_T_f_w), Trw = se3_from(S.T_ref_w);
+  const Se3 T_ref_cur = se3_mul(Trw, se3_inverse(Tcw));
+  {
+    const Se3 Tinv = se3_inverse(T_ref_cur);
+    const double sc = 1.0 / (double)S.mu;
+    double x, y, z;
+    se3_apply(Tinv, sc * S.f[0], sc * S.f[1], sc * S.f[2], x, y, z);
+    bool vis = !(z < 0.0);
+    if (vis) {
+      double cu, cv;
+      world2cam(C.cam, x, y, z, cu, cv);
+      const int ox = (int)cu, oy = (int)cv;
+      vis = (ox >= 0 && ox < W && oy >= 0 && oy < H);
+    }
+    if (!vis) { o.result = 0; o.is_update = 0; if (lane == 0) outs[sid] = o; return; }
+  }
+  o.is_update = 1;
+  const float z_inv_min = S.mu + 2 * sqrtf(S.sigma2);
+  const float z_inv_max = fmaxf(S.mu - 2 * sqrtf(S.sigma2), 0.00000001f);
+  if (isnan(z_inv_min)) o.is_valid = 0;
+  const double min_idepth = 1.0 / (double)z_inv_min, prior_idepth = 1.0 / (double)S.mu, max_idepth = 1.0 / (double)z_inv_max;
+
+  // ---- Matcher::doLineStereo (matcher.cpp:802-1049)
+  const Se3 T = se3_mul(Tcw, se3_inverse(Trw));  // T_cur_ref, :807
+  int res_code = -4;
+  do {
+    double A00, A01, A10, A11;
+    {
+      const int hp = 5;
+      const double xr = S.f[0] * prior_idepth, yr = S.f[1] * prior_idepth, zr = S.f[2] * prior_idepth;
+      const int ratio = 1 << S.level;
+      double du[3], dv[3];
+      s_cam2world(C.cam, S.px[0] + (double)(hp * ratio), S.px[1] + (double)(0 * ratio), du);
+      s_cam2world(C.cam, S.px[0] + (double)(0 * ratio), S.px[1] + (double)(hp * ratio), dv);
+      const double su = zr / du[2], sv = zr / dv[2];
+      for (int i = 0; i < 3; i++) { du[i] *= su; dv[i] *= sv; }
+      double cx, cy, cz, ux, uy, uz, vx, vy, vz, pc0, pc1, pu0, pu1, pv0, pv1;
+      se3_apply(T, xr, yr, zr, cx, cy, cz);
+      se3_apply(T, du[0], du[1], du[2], ux, uy, uz);
+      se3_apply(T, dv[0], dv[1], dv[2], vx, vy, vz);
+      world2cam(C.cam, cx, cy, cz, pc0, pc1);
+      world2cam(C.cam, ux, uy, uz, pu0, pu1);
+      world2cam(C.cam, vx, vy, vz, pv0, pv1);
+      A00 = (pu0 - pc0) / hp; A10 = (pu1 - pc1) / hp; A01 = (pv0 - pc0) / hp; A11 = (pv1 - pc1) / hp;
+    }
+    int sl = 0;
+    { double D = A00 * A11 - A10 * A01; while (D > 3.0 && sl < HSO_N_SOBEL_LEVELS - 1) { sl += 1; D *= 0.25; } }
+    o.search_level = sl;
+    const float exposure_rat = (float)(C.cur_exposure / S.ref_exposure);
+    {
+      const double det = A00 * A11 - A10 * A01;
+      const double invdet = 1.0 / det;
+      const float a00 = (float)(A11 * invdet), a01 = (float)(-A01 * invdet), a10 = (float)(-A10 * invdet), a11 = (float)(A00 * invdet);
+      const bool warp_nan = isnan(a00);
+      const int L = S.level, cols = W >> L, rows = H >> L;
+      const uint8_t* img = SD.ref_base + C.g.off[L];
+      const float rx = (float)(S.px[0] / (double)(1 << L)), ry = (float)(S.px[1] / (double)(1 << L));
+      const float scaleTarget = (float)(1 << sl);
+      const bool scale_exposure = fabsf(exposure_rat * 128 - 128) > 30.0f;  // :818-826 (no keyframe-gap test here)
+      for (int idx = lane; idx < 100; idx += 64) {
+        const int y = idx / 10, x = idx - 10 * y;
+        float p0 = (float)(x - 5), p1 = (float)(y - 5);
+        p0 *= scaleTarget; p1 *= scaleTarget;
+        const float px0 = (a00 * p0 + a01 * p1) + rx, px1 = (a10 * p0 + a11 * p1) + ry;
+        float val = 0;
+        if (!warp_nan && !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1))) val = s_interp_8u(img, cols, px0, px1);
+        if (scale_exposure) val = val * exposure_rat;
+        s_pwb[wave][idx] = val;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int px_ = lane & 7, py_ = lane >> 3;
+    const float* pwb = s_pwb[wave];
+    const int c = (py_ + 1) * 10 + px_ + 1;
+    const float ref_px = pwb[c];
+    const float gxr = pwb[c + 1] - pwb[c - 1], gyr = pwb[c + 10] - pwb[c - 10];
+
+    // close / far points on the unit plane, :834-852
+    double pcx, pcy, pcz, pfx, pfy, pfz;
+    se3_apply(T, S.f[0] * min_idepth, S.f[1] * min_idepth, S.f[2] * min_idepth, pcx, pcy, pcz);
+    pcx /= pcz; pcy /= pcz;
+    se3_apply(T, S.f[0] * max_idepth, S.f[1] * max_idepth, S.f[2] * max_idepth, pfx, pfy, pfz);
+    if (pfz < 0.001 || max_idepth < min_idepth) { res_code = -1; break; }
+    pfx /= pfz; pfy /= pfz;
+    if (isnan((float)(pfx + pcx))) { res_code = -1; break; }
+    double pxc0, pxc1, pxf0, pxf1;
+    world2cam(C.cam, pcx, pcy, 1.0, pxc0, pxc1);
+    o.epl_start[0] = (int)pxc0; o.epl_start[1] = (int)pxc1;
+    pxc0 /= (double)(1 << sl); pxc1 /= (double)(1 << sl);
+    world2cam(C.cam, pfx, pfy, 1.0, pxf0, pxf1);
+    o.epl_end[0] = (int)pxf0; o.epl_end[1] = (int)pxf1;
+    pxf0 /= (double)(1 << sl); pxf1 /= (double)(1 << sl);
+    double incx = pxc0 - pxf0, incy = pxc1 - pxf1;
+    const double eplLength = sqrt(incx * incx + incy * incy);
+    if (((!eplLength) > 0) || isinf(eplLength)) { res_code = -1; break; }  // `!eplLength > 0`, :868
+    if (eplLength > 100.0) { pxc0 = pxf0 + incx * 100.0 / eplLength; pxc1 = pxf1 + incy * 100.0 / eplLength; }
+    incx *= 1.0 / eplLength; incy *= 1.0 / eplLength;
+    pxf0 -= incx; pxf1 -= incy; pxc0 += incx; pxc1 += incy;
+    if (eplLength < 2.0) {
+      const double pad = (2.0 - eplLength) / 2.0;
+      pxf0 -= incx * pad; pxf1 -= incy * pad; pxc0 += incx * pad; pxc1 += incy * pad;
+    }
+    double ed0 = pxc0 - pxf0, ed1 = pxc1 - pxf1;
+    { const double en = sqrt(ed0 * ed0 + ed1 * ed1); ed0 /= en; ed1 /= en; }
+    double dc0 = A00 * S.grad[0] + A01 * S.grad[1], dc1 = A10 * S.grad[0] + A11 * S.grad[1];
+    { const double dn = sqrt(dc0 * dc0 + dc1 * dc1); dc0 /= dn; dc1 /= dn; }
+    if (S.type == HSO_FTR_GRADIENT || S.type == HSO_FTR_EDGELET) {
+      if (fabs(dc0 * ed0 + dc1 * ed1) < 0.4) { res_code = -1; break; }  // epi_search_edgelet_max_angle, matcher.h:130
+    }
+
+    // ---- march along the epipolar line, ZMNCC per step (:906-960)
+    const int cols = W >> sl, rows = H >> sl;
+    const uint8_t* cur = C.cur_base + C.g.off[sl];
+    const float hostMean = s_wave_sum(ref_px) / 64;
+    const float hdev = ref_px - hostMean;
+    const float d1 = s_wave_sum(hdev * hdev);
+    float zmncc_best = 0.1f, zmncc_second = 0.1f;
+    double uvb0 = 0, uvb1 = 0;
+    int loopCounter = 0, loopCBest = -1, loopCSecond = -1;
+    double cpx = pxf0, cpy = pxf1;
+    while ((((incx < 0) == (cpx > pxc0)) && ((incy < 0) == (cpy > pxc1))) || loopCounter == 0) {
+      const int ox = (int)cpx, oy = (int)cpy;
+      if (ox >= 8 && ox < W / (1 << sl) - 8 && oy >= 8 && oy < H / (1 << sl) - 8) {
+        const float sp = s_patch_sample(cur, cols, cpx, cpy, px_, py_);
+        const float tmean = s_wave_sum(sp) / 64;
+        const float t = sp - tmean;
+        const float num = s_wave_sum(hdev * t), d2 = s_wave_sum(t * t);
+        const float zmncc = (float)((double)num / ((double)sqrtf(d1 * d2) + 1e-12));
+        if (zmncc > zmncc_best) {
+          zmncc_second = zmncc_best; uvb0 = cpx; uvb1 = cpy; zmncc_best = zmncc;
+          loopCSecond = loopCBest; loopCBest = loopCounter;
+        } else if (zmncc > zmncc_second) {
+          zmncc_second = zmncc; loopCSecond = loopCounter;
+        }
+      }
+      cpx += incx; cpy += incy; loopCounter++;
+      if (loopCounter > 4096) break;  // defensive bound (NaN increments would never terminate)
+    }
+    o.n_steps = loopCounter; o.zmncc_best = zmncc_best; o.zmncc_second = zmncc_second;
+    const int dl = loopCBest - loopCSecond;
+    if ((float)(dl < 0 ? -dl : dl) > 1.0f && 1.5f * zmncc_second > zmncc_best) { res_code = -4; break; }
+    if (!((double)zmncc_best > 0.8)) { res_code = -4; break; }
+
+    // ---- refinement (:966-1046)
+    double pxcur0 = uvb0 * (double)(1 << sl), pxcur1 = uvb1 * (double)(1 << sl);
+    double ps0 = pxcur0 / (double)(1 << sl), ps1 = pxcur1 / (double)(1 << sl);
+    float samp = 0; bool sampled = false;
+    bool result = s_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, ed0, ed1, ps0, ps1, samp, sampled);
+    if (!result) { ps0 = pxcur0 / (double)(1 << sl); ps1 = pxcur1 / (double)(1 << sl); }
+    samp = 0; sampled = false;  // patch2D: written only by the second KLT (zero where the reference leaves it uninitialised)
+    if (S.type != HSO_FTR_EDGELET) {
+      result = s_klt_limited<false>(cur, cols, rows, gxr, gyr, ref_px, 0, 0, ps0, ps1, samp, sampled);
+    } else {
+      result = s_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, dc0, dc1, ps0, ps1, samp, sampled);
+      if (result) {
+        // Matcher::checkNormal(cur_frame, search_level_, px, dir_cur, 0.7), :406-440
+        const int16_t* gx = reinterpret_cast<const int16_t*>(C.cur_base + C.g.sob_off[sl][0]);
+        const int16_t* gy = reinterpret_cast<const int16_t*>(C.cur_base + C.g.sob_off[sl][1]);
+        const float uf = (float)ps0, vf = (float)ps1;
+        const int ui = (int)floorf((float)ps0), vi = (int)floorf((float)ps1);
+        const float sx = uf - (float)ui, sy = vf - (float)vi;
+        const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy);
+        const float wBR = (float)(((1.0 - wTL) - wTR) - wBL);
+        const int a = vi * cols + ui;
+        double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + cols]) + (double)wBR * (double)gx[a + cols + 1];
+        double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + cols]) + (double)wBR * (double)gy[a + cols + 1];
+        const double nn = sqrt(n0 * n0 + n1 * n1);
+        n0 /= nn; n1 /= nn;
+        result = (dc0 * n0 + dc1 * n1) > (double)(float)0.7;
+      }
+    }
+    if (result) {
+      // Matcher::checkNCC(patch_f_, patch2D, 0.8), :379-404
+      const float mean1 = s_wave_sum(ref_px) / 64, mean2 = s_wave_sum(samp) / 64;
+      const float q1 = ref_px - mean1, q2 = samp - mean2;
+      const float num = s_wave_sum(q1 * q2), den1 = s_wave_sum(q1 * q1), den2 = s_wave_sum(q2 * q2);
+      result = ((double)num / ((double)sqrtf(den1 * den2) + 1e-12)) > (double)(float)0.8;
+    }
+    if (!result) { res_code = -3; break; }
+    pxcur0 = ps0 * (double)(1 << sl); pxcur1 = ps1 * (double)(1 << sl);
+    o.px_cur[0] = pxcur0; o.px_cur[1] = pxcur1;
+    // depthFromTriangulation(T_cur_ref, f_ref, cam2world(px_cur_)), :242-255
+    double fc[3];
+    s_cam2world(C.cam, pxcur0, pxcur1, fc);
+    double R[9];
+    so3_matrix(T, R);
+    double a0[3];
+    for (int i = 0; i < 3; i++) a0[i] = R[i * 3 + 0] * S.f[0] + R[i * 3 + 1] * S.f[1] + R[i * 3 + 2] * S.f[2];
+    const double m00 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2];
+    const double m01 = a0[0] * fc[0] + a0[1] * fc[1] + a0[2] * fc[2];
+    const double m11 = fc[0] * fc[0] + fc[1] * fc[1] + fc[2] * fc[2];
+    const double det = m00 * m11 - m01 * m01;
+    if (det < 0.000001) { res_code = -2; break; }
+    const double invdet = 1.0 / det;
+    const double i00 = m11 * invdet, i01 = -m01 * invdet;
+    const double r0x = (-i00) * a0[0] + (-i01) * fc[0], r0y = (-i00) * a0[1] + (-i01) * fc[1], r0z = (-i00) * a0[2] + (-i01) * fc[2];
+    o.z = fabs(r0x * T.tx + r0y * T.ty + r0z * T.tz);
+    res_code = 1;
+  } while (0);
+
+  o.result = res_code;
+  if (res_code != 1) {
+    o.b = S.b + 1;  // :634
+    o.epl_start[0] = o.epl_start[1] = o.epl_end[0] = o.epl_end[1] = 0;
+  } else {
+    // computeTau (:539-555, with hso::PI = 3.14159265) and updateSeed (:527-537)
+    const double PI_ = 3.14159265;
+    const double z = o.z;
+    const double t0 = T_ref_cur.tx, t1 = T_ref_cur.ty, t2 = T_ref_cur.tz;
+    const double a0 = S.f[0] * z - t0, a1 = S.f[1] * z - t1, a2 = S.f[2] * z - t2;
+    const double t_norm = sqrt(t0 * t0 + t1 * t1 + t2 * t2), a_norm = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+    const double alpha = acos((S.f[0] * t0 + S.f[1] * t1 + S.f[2] * t2) / t_norm);
+    const double beta = acos((a0 * -t0 + a1 * -t1 + a2 * -t2) / (t_norm * a_norm));
+    const double beta_plus = beta + C.px_error_angle;
+    const double gamma_plus = PI_ - alpha - beta_plus;
+    const double z_plus = t_norm * sin(beta_plus) / sin(gamma_plus);
+    const double tau = z_plus - z;
+    const double tau_inverse = 0.5 * (1.0 / fmax(0.0000001, z - tau) - 1.0 / (z + tau));
+    const float x = (float)(1. / z), tau2 = (float)(tau_inverse * tau_inverse);
+    float id_var = S.sigma2 * 1.01f;
+    const float w = tau2 / (tau2 + id_var);
+    const float new_idepth = (1 - w) * x + w * S.mu;
+    // UNZERO (:526): clamp away from zero (comparisons against double constants)
+    const double nd = (double)new_idepth;
+    o.mu = (float)(nd < 0 ? (nd > -1e-10 ? -1e-10 : nd) : (nd < 1e-10 ? 1e-10 : nd));
+    id_var *= w;
+    o.sigma2 = (id_var < S.sigma2) ? id_var : S.sigma2;
+  }
+  if (lane == 0) outs[sid] = o;
+}
+
+extern "C" int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* cur_T_f_w,
+                                    double cur_exposure, double px_error_angle, const hso_seed* seeds, int n_seeds,
+                                    hso_seed_out* out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!cam || !cur_T_f_w || n_seeds < 0 || (n_seeds > 0 && (!seeds || !out))) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: bad argument");
+  if (n_seeds == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto itc = ctx->frames.find(cur_frame_id);
+  if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_observe: active frame not resident");
+  const PyrGeom g = itc->second.g;
+  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: camera size differs from the frame size");
+  std::vector<SeedDev> h(n_seeds);
+  for (int i = 0; i < n_seeds; i++) {
+    auto itr = ctx->frames.find(seeds[i].ref_frame_id);
+    if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_observe: seed host frame not resident");
+    if (itr->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
+    if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: bad level");
+    h[i].ref_base = itr->second.base;
+    h[i].s = seeds[i];
+  }
+  const size_t b_in = ((size_t)n_seeds * sizeof(SeedDev) + 255) & ~size_t(255);
+  const size_t need = b_in + (size_t)n_seeds * sizeof(hso_seed_out);
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
+  }
+  SeedDev* d_in = reinterpret_cast<SeedDev*>(ctx->d_batch);
+  hso_seed_out* d_out = reinterpret_cast<hso_seed_out*>(ctx->d_batch + b_in);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h.data(), (size_t)n_seeds * sizeof(SeedDev), hipMemcpyHostToDevice, ctx->stream));
+  SeedConsts C;
+  C.cam = *cam; C.g = g; C.cur_base = itc->second.base; C.cur_T_f_w = *cur_T_f_w;
+  C.cur_exposure = cur_exposure; C.px_error_angle = px_error_angle;
+  const int blocks = (n_seeds + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(k_seed_observe, dim3(blocks), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, d_in, n_seeds, d_out);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_seeds * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}

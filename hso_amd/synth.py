@@ -273,6 +273,43 @@ def ba_problem(n_poses=9, n_points=300, obs_per_point=4, seed=9, px_noise=0.5, e
     return [SE3.from_arrays(q, t) for q, t in poses], fixed, idist, np.array(edges, BA_EDGE_DTYPE)
 
 
+def seeds_for_pair(pair, n, ref_frame_id, seed=17, depth_noise=0.15, edgelet_frac=0.3, gx=None, gy=None,
+                   depth_mean=4.0, depth_min=2.0):
+    """Depth-filter seeds hosted in the reference frame of `pair` (identity pose), initialised the
+    way Seed::Seed does (mu = 1/depth_mean-ish, z_range = 1/depth_min, sigma2 = z_range^2/36;
+    src/depth_filter.cpp:49-68) with a noisy inverse depth, plus the active frame's pose."""
+    from .capi import Seed, SE3, FTR_CORNER, FTR_EDGELET
+    sc = pair["scene"]
+    rng = np.random.default_rng(seed)
+    feats = sc.features(np.array([0, 0, 0, 1.0]), np.zeros(3), n, seed=seed + 1, margin=40)
+    seeds = []
+    for i in range(n):
+        s = Seed()
+        s.ref_frame_id = ref_frame_id
+        s.level = int(rng.integers(0, 3))
+        px = feats["px"][i]
+        is_edge = rng.uniform() < edgelet_frac and gx is not None
+        s.type = FTR_EDGELET if is_edge else FTR_CORNER
+        s.px[:] = [float(px[0]), float(px[1])]
+        s.f[:] = [float(v) for v in feats["f"][i]]
+        if is_edge:
+            g = np.array([gx[int(px[1]), int(px[0])], gy[int(px[1]), int(px[0])]], float)
+            g = g / (np.linalg.norm(g) + 1e-9)
+            s.grad[:] = [float(g[0]), float(g[1])]
+        else:
+            s.grad[:] = [1.0, 0.0]
+        s.T_ref_w = SE3.identity()
+        s.ref_exposure = 1.0
+        true_idist = 1.0 / feats["dist"][i]
+        s.mu = float(true_idist * (1 + rng.normal(0, depth_noise)))
+        z_range = 1.0 / depth_min
+        s.sigma2 = float(z_range * z_range / 36)
+        s.b = 10.0
+        seeds.append(s)
+    T_cur = SE3.from_arrays(pair["q_true"], pair["t_true"])
+    return seeds, T_cur, feats
+
+
 def config2_pair(n_feats=2000, spec=ICL_NUIM, seed=1234, exposure=1.05, noise=1.0,
                  trans_frac=0.02, rot_deg=0.5):
     """reference = frame 0, current = known SE(3) away."""

@@ -347,6 +347,43 @@ int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8
                          double* Hpp, double* bp, double* Hpc, double* Hcc, double* bc,
                          double* edge_err, double* edge_chi2, double* chi2_sum);
 
+/* ---- DepthFilter seed observation: DepthFilter::observeDepthRow (src/depth_filter.cpp:580-675),
+ *      updateSeed :528-537, computeTau :539-555; Matcher::doLineStereo (src/matcher.cpp:802-1049),
+ *      KLTLimited2D/1D :1296-1606, warp::createPatch :159-196, ZMNCC_F
+ *      (include/hso/vikit/patch_score.h:268-305), depthFromTriangulation :242-255 ---- */
+typedef struct hso_seed {
+  int64_t ref_frame_id;   /* seed.ftr->frame (resident) */
+  int32_t level;          /* seed.ftr->level */
+  int32_t type;           /* seed.ftr->type (HSO_FTR_*) */
+  double px[2];           /* seed.ftr->px */
+  double f[3];            /* seed.ftr->f */
+  double grad[2];         /* seed.ftr->grad */
+  hso_se3 T_ref_w;        /* seed.ftr->frame->T_f_w_ */
+  double ref_exposure;    /* seed.ftr->frame->m_exposure_time */
+  float mu, sigma2;       /* Seed::mu, sigma2 (include/hso/depth_filter.h:54-58) */
+  float b;                /* Seed::b (outlier counter, ++ on a failed match) */
+  float _pad;
+} hso_seed;
+
+typedef struct hso_seed_out {
+  float mu, sigma2, b;    /* updated state */
+  int32_t result;         /* doLineStereo's code 1 / -1..-4; 0 = not visible in the active frame (:593-606) */
+  int32_t is_update;      /* Seed::is_update */
+  int32_t is_valid;       /* 0 if z_inv_min was NaN (:618) */
+  int32_t search_level;   /* Matcher::search_level_ */
+  int32_t epl_start[2], epl_end[2];
+  int32_t n_steps;        /* epipolar samples visited */
+  double px_cur[2];       /* Matcher::px_cur_ (last_matched_px) */
+  double z;               /* triangulated depth (result == 1) */
+  float zmncc_best, zmncc_second;
+} hso_seed_out;
+
+/* One wavefront per seed (lane = patch pixel).  cur_T_f_w / cur_exposure: the active frame's pose
+ * and m_exposure_time; px_error_angle: DepthFilter::px_error_angle_ (:360-366). */
+int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* cur_T_f_w,
+                         double cur_exposure, double px_error_angle, const hso_seed* seeds, int n_seeds,
+                         hso_seed_out* out);
+
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

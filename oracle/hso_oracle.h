@@ -113,6 +113,13 @@ void hso_or_ba_linearize(const hso_se3* poses, const uint8_t* pose_fixed, int n_
                          const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge,
                          double* Hpp, double* bp, double* Hpc, double* Hcc, double* bc,
                          double* edge_err, double* edge_chi2, double* chi2_sum);
+/* ---- depth-filter seed observation (src/depth_filter.cpp:527-675, src/matcher.cpp:802-1049,1296-1606) ---- */
+void hso_or_update_seed(float x, float tau2, float* mu, float* sigma2);
+double hso_or_compute_tau(const hso_se3* T_ref_cur, const double f[3], double z, double px_error_angle);
+void hso_or_seed_observe(const hso_camera* cam, const hso_seed* s, const hso_se3* cur_T_f_w, double cur_exposure,
+                         double px_error_angle, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                         const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
+                         const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_seed_out* o);
 /* per-term dump of the last evaluation for debugging: returns number of rows written */
 int hso_or_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch,
                            int8_t* offsets_xy);

@@ -313,6 +313,28 @@ def ba_linearize(poses, fixed, idist, edges, huber_corner, huber_edge):
     return o
 
 
+def seed_observe(cam, seed, cur_T_f_w, cur_exposure, px_error_angle, ref_pyr, cur_pyr, cur_sobel):
+    """DepthFilter::observeDepthRow for one seed on host arrays."""
+    from hso_amd.capi import Seed, SeedOut
+    lib = load()
+    lib.hso_or_seed_observe.argtypes = [C.POINTER(Camera), C.POINTER(Seed), C.POINTER(SE3), C.c_double, C.c_double,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(SeedOut)]
+    lib.hso_or_seed_observe.restype = None
+    rp = [np.ascontiguousarray(l) for l in ref_pyr]
+    cp = [np.ascontiguousarray(l) for l in cur_pyr]
+    gx = [np.ascontiguousarray(g[0]) for g in cur_sobel]
+    gy = [np.ascontiguousarray(g[1]) for g in cur_sobel]
+    h, w = rp[0].shape
+    out = SeedOut()
+    lib.hso_or_seed_observe(C.byref(cam), C.byref(seed), C.byref(cur_T_f_w), cur_exposure, px_error_angle,
+                            (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in rp]),
+                            (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in cp]),
+                            (C.c_void_p * 3)(*[g.ctypes.data for g in gx]),
+                            (C.c_void_p * 3)(*[g.ctypes.data for g in gy]), w, h, C.byref(out))
+    return out
+
+
 def pattern(max_level, level):
     pa, hp = C.c_int(), C.c_int()
     offs = np.zeros((40, 2), np.int8)
