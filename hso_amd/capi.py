@@ -163,6 +163,19 @@ class SeedOut(C.Structure):
                 ("px_cur", C.c_double * 2), ("z", C.c_double), ("zmncc_best", C.c_float), ("zmncc_second", C.c_float)]
 
 
+ACTIVATE_MAX_TARGETS = 64
+
+
+class ActivateTarget(C.Structure):
+    _fields_ = [("frame_id", C.c_int64), ("T_f_w", SE3), ("exposure", C.c_double)]
+
+
+class ActivateOut(C.Structure):
+    _fields_ = [("activated", C.c_int32), ("is_valid", C.c_int32), ("n_targets", C.c_int32), ("n_matched", C.c_int32),
+                ("dist_mean", C.c_double), ("huber", C.c_double), ("opt_id", C.c_double), ("energy", C.c_double),
+                ("n_iter", C.c_int32), ("_pad", C.c_int32)]
+
+
 BA_EDGE_DTYPE = np.dtype([("point", "<i4"), ("host", "<i4"), ("target", "<i4"), ("type", "<i4"), ("level", "<i4"),
                           ("_pad", "<i4"), ("fH", "<f8", 3), ("meas", "<f8", 2), ("normal", "<f8", 2)])
 assert BA_EDGE_DTYPE.itemsize == 80
@@ -238,6 +251,8 @@ def load():
     lib.hso_gpu_pose_optimize_batch.argtypes = [vp, P(Camera), P(PoseJob), i32, P(PoseResult), vp]
     lib.hso_gpu_ba_linearize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double] + [vp] * 8
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
+    lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
+                                          P(AlignOut)]
     _lib = lib
     return lib
 
@@ -250,7 +265,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
-    "hso_gpu_seed_observe",
+    "hso_gpu_seed_observe", "hso_gpu_seed_activate",
 ]
 
 
@@ -414,6 +429,22 @@ class Context:
         out = (SeedOut * len(seeds))()
         self._check(self.lib.hso_gpu_seed_observe(self.h, C.byref(cam), cur_frame_id, C.byref(cur_T_f_w), cur_exposure,
                                                   px_error_angle, arr, len(seeds), out), "seed_observe")
+        return list(out)
+
+    def seed_activate(self, cam, seeds, targets_per_seed, n_mean_converge_frame=6, want_matches=False):
+        """targets_per_seed: one list of ActivateTarget per seed (optFrames_P + optFrames_A order)."""
+        begin = np.zeros(len(seeds) + 1, np.int32)
+        begin[1:] = np.cumsum([len(t) for t in targets_per_seed])
+        flat = [t for ts in targets_per_seed for t in ts]
+        sarr = (Seed * len(seeds))(*seeds)
+        tarr = (ActivateTarget * max(len(flat), 1))(*flat)
+        out = (ActivateOut * len(seeds))()
+        mo = (AlignOut * max(len(flat), 1))() if want_matches else None
+        self._check(self.lib.hso_gpu_seed_activate(self.h, C.byref(cam), sarr, len(seeds),
+                                                   begin.ctypes.data_as(C.POINTER(C.c_int32)), tarr,
+                                                   n_mean_converge_frame, out, mo), "seed_activate")
+        if want_matches:
+            return list(out), [list(mo[begin[i]:begin[i + 1]]) for i in range(len(seeds))]
         return list(out)
 
     def tracker_eval(self, cam, params, job, level, T, exposure_rat, huber=-1.0, outlier=-1.0,

@@ -1,0 +1,352 @@
+// hso_activate.hip — seed activation on gfx950: re-match every converged seed in the frames that
+// observed it, gate on the mean drift, refine the inverse depth with a 1-D Levenberg-Marquardt.
+//
+// Replaces DepthFilter::activatePoint (reference src/depth_filter.cpp:729-851) and
+// DepthFilter::seedOptimizer (:853-1073) with Matcher::findMatchSeed (src/matcher.cpp:442-518),
+// Point::jacobian_id2uv (include/hso/point.h:174-184) and MADScaleEstimator::compute
+// (src/vikit/robust_cost.cpp:67-74).
+//
+// MI355X mapping: the reference visits a seed's <=30 target frames one after another on the
+// mapping thread.  Here kernel 1 gives every (seed, target) pair its own wavefront (projection,
+// parallax test and the 8x8 Lucas-Kanade of findMatchSeed, lane = patch pixel — the same
+// device body as the reprojection matcher), and kernel 2 gives every seed one thread that
+// applies the gates and runs the scalar LM *serially in fp64 in the reference's order*, so its
+// sums carry the reference's rounding (the only non-IEEE step is pow(x,3) in the damping
+// update).  The optimiser state is a handful of doubles per seed; there is nothing to tile.
+#include "hso_match_dev.h"
+#include <string.h>
+#include <vector>
+
+using namespace hso_dev;
+
+#define ACT_WAVES_PER_BLOCK 4
+
+struct ActSeedDev {
+  const uint8_t* ref_base;
+  hso_seed s;
+  int32_t first, count;  // range in the pair arrays
+};
+
+struct ActPairIn {
+  const uint8_t* cur_base;
+  hso_se3 T_f_w;
+  double exposure;
+  int32_t seed;
+  int32_t _pad;
+};
+
+struct ActPair {          // kernel 1 -> kernel 2
+  int32_t is_target;      // passed the projection test (:741-769)
+  int32_t matched;        // findMatchSeed returned true
+  double px[2];           // projected position before matching
+  hso_se3 Tth;            // target.T_f_w * host.T_f_w^-1
+  double obs[2];          // project2d(cam2world(matched px)), :817-818
+  double normal[2];       // normalised A_cur_ref * grad (edgelets), :803-805
+  hso_align_out mo;
+};
+
+struct ActConsts {
+  hso_camera cam;
+  PyrGeom g;
+};
+
+__global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(ActConsts C, const ActSeedDev* seeds,
+                                                                              const ActPairIn* pin, int n_pairs, ActPair* pout)
+{
+  __shared__ float s_pwb[ACT_WAVES_PER_BLOCK][100];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pid = blockIdx.x * ACT_WAVES_PER_BLOCK + wave;
+  if (pid >= n_pairs) return;
+  const ActPairIn& P = pin[pid];
+  const ActSeedDev& SD = seeds[P.seed];
+  const hso_seed& S = SD.s;
+  const int W = C.g.w[0], H = C.g.h[0];
+  ActPair o;
+  memset(&o, 0, sizeof(o));
+  const Se3 Thost_inv = se3_inverse(se3_from(S.T_ref_w));
+  const Se3 Ttw = se3_from(P.T_f_w);
+  const Se3 Tth = se3_mul(Ttw, Thost_inv);
+  se3_to(Tth, o.Tth);
+  const double sc = 1.0 / (double)S.mu;
+  const double ph0 = S.f[0] * sc, ph1 = S.f[1] * sc, ph2 = S.f[2] * sc;
+  bool go = true;
+  {
+    double x, y, z;
+    se3_apply(Tth, ph0, ph1, ph2, x, y, z);
+    if (z < 0.0001) go = false;
+    if (go) {
+      double pu, pv;
+      world2cam(C.cam, x, y, z, pu, pv);
+      const int ox = (int)pu, oy = (int)pv;
+      if (!(ox >= 8 && ox < W - 8 && oy >= 8 && oy < H - 8)) go = false;  // isInFrame(px.cast<int>(), 8), camera.h:79-83
+      o.px[0] = pu; o.px[1] = pv;
+    }
+  }
+  if (!go) { if (lane == 0) pout[pid] = o; return; }
+  o.is_target = 1;
+  // parallax test of findMatchSeed, matcher.cpp:444-449
+  {
+    double sx, sy, sz;
+    se3_apply(Thost_inv, ph0, ph1, ph2, sx, sy, sz);
+    double r0 = Thost_inv.tx - sx, r1 = Thost_inv.ty - sy, r2 = Thost_inv.tz - sz;
+    const double rn = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    r0 /= rn; r1 /= rn; r2 /= rn;
+    const Se3 Tt_inv = se3_inverse(Ttw);
+    double c0 = Tt_inv.tx - sx, c1 = Tt_inv.ty - sy, c2 = Tt_inv.tz - sz;
+    const double cn = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+    c0 /= cn; c1 /= cn; c2 /= cn;
+    if (r0 * c0 + r1 * c1 + r2 * c2 < 0.5) go = false;
+  }
+  if (!go) { if (lane == 0) pout[pid] = o; return; }
+  hso_align_job J;
+  J.ref_frame_id = S.ref_frame_id; J.ref_level = S.level; J.type = S.type;
+  J.px_ref[0] = S.px[0]; J.px_ref[1] = S.px[1];
+  J.f_ref[0] = S.f[0]; J.f_ref[1] = S.f[1]; J.f_ref[2] = S.f[2];
+  J.depth = 1. / (double)S.mu;
+  J.grad[0] = S.grad[0]; J.grad[1] = S.grad[1];
+  J.T_cur_ref = o.Tth;
+  J.px_cur[0] = o.px[0]; J.px_cur[1] = o.px[1];
+  J.exposure_rat = (float)(P.exposure / S.ref_exposure);
+  J.kf_gap_lt4 = 1;  // findMatchSeed compensates exposure regardless of the keyframe gap (:472-483)
+  o.mo = match_one(C.cam, C.g, P.cur_base, SD.ref_base, J, (double)0.8f, s_pwb[wave]);  // checkNCC(.., 0.8), :509
+  o.matched = o.mo.success;
+  if (o.matched) {
+    double f[3];
+    cam2world_dev(C.cam, o.mo.px_cur[0], o.mo.px_cur[1], f);
+    o.obs[0] = f[0] / f[2]; o.obs[1] = f[1] / f[2];
+    double n0 = o.mo.A_cur_ref[0] * S.grad[0] + o.mo.A_cur_ref[1] * S.grad[1];
+    double n1 = o.mo.A_cur_ref[2] * S.grad[0] + o.mo.A_cur_ref[3] * S.grad[1];
+    const double nn = sqrt(n0 * n0 + n1 * n1);
+    o.normal[0] = n0 / nn; o.normal[1] = n1 / nn;
+  }
+  if (lane == 0) pout[pid] = o;
+}
+
+// residual of one matched target at inverse depth `id`: obs - project2d(Tth * f/id)
+__device__ inline void act_residual(const hso_seed& S, const ActPair& P, double id, double& r0, double& r1, double pT[3])
+{
+  const double sc = 1.0 / id;
+  const Se3 T = se3_from(P.Tth);
+  se3_apply(T, S.f[0] * sc, S.f[1] * sc, S.f[2] * sc, pT[0], pT[1], pT[2]);
+  r0 = P.obs[0] - pT[0] / pT[2]; r1 = P.obs[1] - pT[1] / pT[2];
+}
+
+__device__ inline double act_energy(const hso_seed& S, const ActPair* P, int n, double id, double huberTH)
+{
+  double E = 0;
+  const bool edge = S.type == HSO_FTR_EDGELET;
+  for (int i = 0; i < n; i++) {
+    if (!P[i].matched) continue;
+    double r0, r1, pT[3];
+    act_residual(S, P[i], id, r0, r1, pT);
+    if (edge) {
+      const double re = P[i].normal[0] * r0 + P[i].normal[1] * r1;
+      const double a = (double)fabsf((float)re);
+      const double hw = a < huberTH ? 1 : huberTH / a;
+      E += re * re * hw;
+    } else {
+      const double rd = sqrt(r0 * r0 + r1 * r1);
+      const double hw = rd < huberTH ? 1 : huberTH / rd;
+      E += rd * rd * hw;
+    }
+  }
+  return E;
+}
+
+__global__ __launch_bounds__(64) void k_activate_opt(ActConsts C, const ActSeedDev* seeds, int n_seeds, const ActPair* pairs,
+                                                     int n_mean_converge_frame, hso_activate_out* outs)
+{
+  const int sid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sid >= n_seeds) return;
+  const ActSeedDev& SD = seeds[sid];
+  const hso_seed& S = SD.s;
+  const ActPair* P = pairs + SD.first;
+  const int n = SD.count;
+  hso_activate_out o;
+  memset(&o, 0, sizeof(o));
+  o.is_valid = -1;
+  o.opt_id = (double)S.mu;
+  int n_targets = 0, n_res = 0;
+  for (int i = 0; i < n; i++) { n_targets += P[i].is_target; n_res += P[i].matched; }
+  o.n_targets = n_targets;
+  float n_frame_thresh = (float)((double)n_mean_converge_frame * 0.7);
+  if (n_frame_thresh > 8) n_frame_thresh = 8;
+  if (n_frame_thresh < 3) n_frame_thresh = 3;
+  if ((float)n_targets < n_frame_thresh) { outs[sid] = o; return; }
+  o.n_matched = n_res;
+  const bool edge = S.type == HSO_FTR_EDGELET;
+  double distMean = 0;
+  for (int i = 0; i < n; i++) {
+    if (!P[i].matched) continue;
+    const double d0 = P[i].px[0] - P[i].mo.px_cur[0], d1 = P[i].px[1] - P[i].mo.px_cur[1];
+    double err = edge ? fabs(P[i].normal[0] * d0 + P[i].normal[1] * d1) : sqrt(d0 * d0 + d1 * d1);
+    err /= (double)(1 << P[i].mo.search_level);
+    distMean += err;
+  }
+  if ((float)n_res < n_frame_thresh) { outs[sid] = o; return; }
+  distMean /= (double)n_res;
+  o.dist_mean = distMean;
+  if ((!edge && distMean > 3.2) || (edge && distMean > 2.5)) { o.is_valid = 0; outs[sid] = o; return; }
+  o.is_valid = 1;
+  if ((!edge && distMean > 2.5) || (edge && distMean > 2.0)) { outs[sid] = o; return; }
+
+  // ---- seedOptimizer (:853-1073)
+  double old_id = (double)S.mu;
+  // MAD scale: 1.4826f * the element of rank floor(n/2) of the float |residual|s (robust_cost.cpp:67-74)
+  double huberTH;
+  {
+    const int k = n_res / 2;
+    float errs[HSO_ACTIVATE_MAX_TARGETS];
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+      if (!P[i].matched) continue;
+      double r0, r1, pT[3];
+      act_residual(S, P[i], old_id, r0, r1, pT);
+      errs[m++] = edge ? (float)fabs(P[i].normal[0] * r0 + P[i].normal[1] * r1) : (float)sqrt(r0 * r0 + r1 * r1);
+    }
+    float med = 0;
+    for (int i = 0; i < m; i++) {
+      int lt = 0, le = 0;
+      for (int j = 0; j < m; j++) { lt += errs[j] < errs[i]; le += errs[j] <= errs[i]; }
+      if (lt <= k && k < le) { med = errs[i]; break; }
+    }
+    huberTH = (double)(1.4826f * med);
+  }
+  o.huber = huberTH;
+  double oldEnergy = act_energy(S, P, n, old_id, huberTH);
+  double rho = 0, mu = 0.1, nu = 2.0;
+  bool stop = false;
+  int iter;
+  for (iter = 0; iter < 5; ++iter) {
+    int n_trials = 0;
+    do {
+      double new_id = old_id, newEnergy = 0, Hh = 0, b = 0;
+      for (int i = 0; i < n; i++) {
+        if (!P[i].matched) continue;
+        double r0, r1, pT[3];
+        act_residual(S, P[i], old_id, r0, r1, pT);
+        const double n0 = P[i].normal[0], n1 = P[i].normal[1];
+        // Point::jacobian_id2uv(pTarget, Tth, old_id, f), point.h:174-184
+        const Se3 T = se3_from(P[i].Tth);
+        double R[9];
+        so3_matrix(T, R);
+        const double Rf2 = R[6] * S.f[0] + R[7] * S.f[1] + R[8] * S.f[2];
+        const double J0 = -(T.tx - (pT[0] / pT[2]) * T.tz) / (Rf2 + T.tz * old_id);
+        const double J1 = -(T.ty - (pT[1] / pT[2]) * T.tz) / (Rf2 + T.tz * old_id);
+        if (edge) {
+          const double re = n0 * r0 + n1 * r1;
+          const double a = (double)fabsf((float)re);
+          const double hw = a < huberTH ? 1 : huberTH / a;
+          const double JE = n0 * J0 + n1 * J1;
+          Hh += JE * JE * hw;
+          b -= JE * re * hw;
+        } else {
+          const double rd = sqrt(r0 * r0 + r1 * r1);
+          const double hw = rd < huberTH ? 1 : huberTH / rd;
+          Hh += (J0 * J0 + J1 * J1) * hw;
+          b -= (J0 * r0 + J1 * r1) * hw;
+        }
+      }
+      Hh *= 1.0 + mu;
+      const double step = b / Hh;
+      if (!isnan(step)) {
+        new_id = old_id + step;
+        newEnergy = act_energy(S, P, n, new_id, huberTH);
+        rho = oldEnergy - newEnergy;
+      } else {
+        rho = -1;
+      }
+      if (rho > 0) {
+        oldEnergy = newEnergy;
+        old_id = new_id;
+        o.opt_id = new_id;
+        stop = (double)fabsf((float)step) < 0.00001 * new_id;
+        const double c = 1. - pow(2 * rho - 1, 3);
+        const double m = c < 2. / 3. ? c : 2. / 3.;
+        mu *= (1. / 3. > m ? 1. / 3. : m);
+        nu = 2.;
+      } else {
+        mu *= nu;
+        nu *= 2.;
+        ++n_trials;
+        if (n_trials >= 5) stop = true;
+      }
+    } while (!(rho > 0 || stop));
+    if (stop) break;
+  }
+  o.energy = oldEnergy;
+  o.n_iter = iter < 5 ? iter + 1 : 5;
+  o.activated = 1;
+  outs[sid] = o;
+}
+
+extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
+                                     const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
+                                     hso_activate_out* out, hso_align_out* match_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!cam || n_seeds < 0 || (n_seeds > 0 && (!seeds || !target_begin || !out))) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad argument");
+  if (n_seeds == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int n_pairs = target_begin[n_seeds];
+  if (target_begin[0] != 0 || n_pairs < 0 || (n_pairs > 0 && !targets)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad target ranges");
+  std::vector<ActSeedDev> hs(n_seeds);
+  std::vector<ActPairIn> hp((size_t)n_pairs);
+  PyrGeom g;
+  bool have_g = false;
+  for (int i = 0; i < n_seeds; i++) {
+    const int b = target_begin[i], e = target_begin[i + 1];
+    if (e < b || e - b > HSO_ACTIVATE_MAX_TARGETS) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: a seed has more than HSO_ACTIVATE_MAX_TARGETS targets");
+    auto itr = ctx->frames.find(seeds[i].ref_frame_id);
+    if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: seed host frame not resident");
+    if (!have_g) { g = itr->second.g; have_g = true; }
+    if (itr->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
+    if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad level");
+    hs[i].ref_base = itr->second.base; hs[i].s = seeds[i]; hs[i].first = b; hs[i].count = e - b;
+    for (int k = b; k < e; k++) {
+      auto itt = ctx->frames.find(targets[k].frame_id);
+      if (itt == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: target frame not resident");
+      if (itt->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
+      hp[k].cur_base = itt->second.base; hp[k].T_f_w = targets[k].T_f_w; hp[k].exposure = targets[k].exposure;
+      hp[k].seed = i; hp[k]._pad = 0;
+    }
+  }
+  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: camera size differs from the frame size");
+  auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const size_t o_seeds = 0, o_pin = al(o_seeds + (size_t)n_seeds * sizeof(ActSeedDev));
+  const size_t o_pout = al(o_pin + (size_t)n_pairs * sizeof(ActPairIn));
+  const size_t o_out = al(o_pout + (size_t)n_pairs * sizeof(ActPair));
+  const size_t need = o_out + (size_t)n_seeds * sizeof(hso_activate_out);
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
+  }
+  ActSeedDev* d_seeds = reinterpret_cast<ActSeedDev*>(ctx->d_batch + o_seeds);
+  ActPairIn* d_pin = reinterpret_cast<ActPairIn*>(ctx->d_batch + o_pin);
+  ActPair* d_pout = reinterpret_cast<ActPair*>(ctx->d_batch + o_pout);
+  hso_activate_out* d_out = reinterpret_cast<hso_activate_out*>(ctx->d_batch + o_out);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_seeds, hs.data(), (size_t)n_seeds * sizeof(ActSeedDev), hipMemcpyHostToDevice, ctx->stream));
+  if (n_pairs > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_pin, hp.data(), (size_t)n_pairs * sizeof(ActPairIn), hipMemcpyHostToDevice, ctx->stream));
+  ActConsts C;
+  C.cam = *cam; C.g = g;
+  if (n_pairs > 0) {
+    const int blocks = (n_pairs + ACT_WAVES_PER_BLOCK - 1) / ACT_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(k_activate_match, dim3(blocks), dim3(64 * ACT_WAVES_PER_BLOCK), 0, ctx->stream, C, d_seeds, d_pin, n_pairs, d_pout);
+    HSO_HIP_CHECK(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_activate_opt, dim3((n_seeds + 63) / 64), dim3(64), 0, ctx->stream, C, d_seeds, n_seeds, d_pout,
+                     n_mean_converge_frame, d_out);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_seeds * sizeof(hso_activate_out), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<ActPair> hpo;
+  if (match_out && n_pairs > 0) {
+    hpo.resize((size_t)n_pairs);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(hpo.data(), d_pout, (size_t)n_pairs * sizeof(ActPair), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (match_out) for (int k = 0; k < n_pairs; k++) match_out[k] = hpo[k].mo;
+  return HSO_OK;
+}

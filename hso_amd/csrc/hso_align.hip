@@ -19,8 +19,7 @@
 // tolerance: 1e-3 px on the result).  HBM-bound in principle (100 + <=640
 // taps per candidate); in practice latency-bound per candidate and throughput comes from
 // having thousands of candidates in flight.
-#include "hso_ctx.h"
-#include "hso_dev_math.h"
+#include "hso_match_dev.h"
 #include <vector>
 
 using namespace hso_dev;
@@ -38,61 +37,6 @@ struct AlignJobDev {
   hso_align_job j;
 };
 
-HSO_DEV float wave_sum_all(float v)
-{
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
-}
-
-// AbstractCamera::cam2world, src/camera.cpp:67-87 (pinhole; radtan through the 5-iteration
-// cv::undistortPoints with float K, D and float I/O, :43-45,78-85), :171-194 (FOV)
-HSO_DEV void cam2world_dev(const hso_camera& cam, double u, double v, double f[3])
-{
-  double x, y;
-  if (cam.model == HSO_CAM_PINHOLE && cam.distortion) {
-    const double fx = (float)cam.fx, fy = (float)cam.fy, cx = (float)cam.cx, cy = (float)cam.cy;
-    const double k0 = (float)cam.d[0], k1 = (float)cam.d[1], p1 = (float)cam.d[2], p2 = (float)cam.d[3], k2 = (float)cam.d[4];
-    const double ifx = 1. / fx, ify = 1. / fy;
-    x = (float)u; y = (float)v;
-    const double x0 = x = (x - cx) * ifx;
-    const double y0 = y = (y - cy) * ify;
-    for (int it = 0; it < 5; it++) {
-      const double r2 = x * x + y * y;
-      const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k2 * r2 + k1) * r2 + k0) * r2);
-      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
-      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
-      x = (x0 - deltaX) * icdist;
-      y = (y0 - deltaY) * icdist;
-    }
-    x = (float)x; y = (float)y;
-  } else if (cam.model == HSO_CAM_FOV && cam.distortion) {
-    const double omega = cam.d[0];
-    const double ud = (u - cam.cx) / cam.fx, vd = (v - cam.cy) / cam.fy;
-    const double dist = sqrt(ud * ud + vd * vd);
-    const double rd = tan(dist * omega) / (2 * dist * tan(omega / 2));
-    x = rd * ud; y = rd * vd;
-  } else {
-    x = (u - cam.cx) / cam.fx; y = (v - cam.cy) / cam.fy;
-  }
-  const double n = sqrt(x * x + y * y + 1.0);
-  f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
-}
-
-// hso::interpolateMat_8u, include/hso/vikit/vision.h:49-65
-HSO_DEV float interpolate_8u(const uint8_t* data, int stride, float u, float v)
-{
-  const int x = (int)floor((double)u);
-  const int y = (int)floor((double)v);
-  const float sx = u - (float)x, sy = v - (float)y;
-  const float w00 = (1.0f - sx) * (1.0f - sy);
-  const float w01 = (1.0f - sx) * sy;
-  const float w10 = sx * (1.0f - sy);
-  const float w11 = ((1.0f - w00) - w01) - w10;
-  const uint8_t* p = data + y * stride + x;
-  return ((w00 * (float)p[0] + w01 * (float)p[stride]) + w10 * (float)p[1]) + w11 * (float)p[stride + 1];
-}
-
 __global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align(AlignConsts C, const AlignJobDev* jobs, int n_jobs,
                                                                        hso_align_out* outs)
 {
@@ -101,222 +45,7 @@ __global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align(AlignConst
   const int jid = blockIdx.x * ALIGN_WAVES_PER_BLOCK + wave;
   if (jid >= n_jobs) return;
   const AlignJobDev& JD = jobs[jid];
-  const hso_align_job& J = JD.j;
-  hso_align_out o;
-  o.success = 0; o.stage = HSO_ALIGN_OK; o.search_level = 0; o.iters = 0;
-  o.px_cur[0] = J.px_cur[0]; o.px_cur[1] = J.px_cur[1];
-  o.A_cur_ref[0] = o.A_cur_ref[1] = o.A_cur_ref[2] = o.A_cur_ref[3] = 0; o.h_inv = 0; o.ncc = 0; o.chi2 = 0;
-  const int W = C.g.w[0], H = C.g.h[0];
-  const int halfpatch_size_ = 4;
-
-  // isInFrame((px/(1<<level)).cast<int>(), halfpatch_size_+2, level), matcher.cpp:288, camera.h:85-89
-  {
-    const int L = J.ref_level, b = halfpatch_size_ + 2;
-    const int ox = (int)(J.px_ref[0] / (double)(1 << L)), oy = (int)(J.px_ref[1] / (double)(1 << L));
-    if (!(ox >= b && ox < W / (1 << L) - b && oy >= b && oy < H / (1 << L) - b)) {
-      o.stage = HSO_ALIGN_REF_BORDER;
-      if (lane == 0) outs[jid] = o;
-      return;
-    }
-  }
-
-  // ---- warp::getWarpMatrixAffine, matcher.cpp:46-72 (uniform over the wave)
-  const Se3 T = se3_from(J.T_cur_ref);
-  double A00, A01, A10, A11;
-  {
-    const int hp = 5;
-    const double xr = J.f_ref[0] * J.depth, yr = J.f_ref[1] * J.depth, zr = J.f_ref[2] * J.depth;
-    const int ratio = 1 << J.ref_level;
-    double du[3], dv[3];
-    cam2world_dev(C.cam, J.px_ref[0] + (double)(hp * ratio), J.px_ref[1] + (double)(0 * ratio), du);
-    cam2world_dev(C.cam, J.px_ref[0] + (double)(0 * ratio), J.px_ref[1] + (double)(hp * ratio), dv);
-    const double su = zr / du[2], sv = zr / dv[2];
-    for (int i = 0; i < 3; i++) { du[i] *= su; dv[i] *= sv; }
-    double cx, cy, cz, ux, uy, uz, vx, vy, vz;
-    se3_apply(T, xr, yr, zr, cx, cy, cz);
-    se3_apply(T, du[0], du[1], du[2], ux, uy, uz);
-    se3_apply(T, dv[0], dv[1], dv[2], vx, vy, vz);
-    double pc0, pc1, pu0, pu1, pv0, pv1;
-    world2cam(C.cam, cx, cy, cz, pc0, pc1);
-    world2cam(C.cam, ux, uy, uz, pu0, pu1);
-    world2cam(C.cam, vx, vy, vz, pv0, pv1);
-    A00 = (pu0 - pc0) / hp; A10 = (pu1 - pc1) / hp;
-    A01 = (pv0 - pc0) / hp; A11 = (pv1 - pc1) / hp;
-  }
-  o.A_cur_ref[0] = A00; o.A_cur_ref[1] = A01; o.A_cur_ref[2] = A10; o.A_cur_ref[3] = A11;
-
-  // ---- warp::getBestSearchLevel, :74-85 (max_level = Config::nPyrLevels()-1 = 2)
-  int search_level = 0;
-  {
-    double D = A00 * A11 - A10 * A01;
-    while (D > 3.0 && search_level < HSO_N_SOBEL_LEVELS - 1) { search_level += 1; D *= 0.25; }
-  }
-  o.search_level = search_level;
-
-  // ---- warp::warpAffine (float), :120-155: 10x10 samples of the reference level
-  {
-    const double det = A00 * A11 - A10 * A01;
-    const double invdet = 1.0 / det;
-    const float a00 = (float)(A11 * invdet), a01 = (float)(-A01 * invdet);
-    const float a10 = (float)(-A10 * invdet), a11 = (float)(A00 * invdet);
-    const bool warp_nan = isnan(a00);  // reference: patch left untouched (uninitialised); defined as 0 here
-    const int L = J.ref_level;
-    const int cols = W >> L, rows = H >> L;
-    const uint8_t* img = JD.ref_base + C.g.off[L];
-    const float rx = (float)(J.px_ref[0] / (double)(1 << L)), ry = (float)(J.px_ref[1] / (double)(1 << L));
-    const float scaleTarget = (float)(1 << search_level);
-    const bool scale_exposure = J.kf_gap_lt4 && fabsf(J.exposure_rat * 128 - 128) > 30.0f;  // :317-320, LIGHT_THRESHOLD
-    for (int idx = lane; idx < 100; idx += 64) {
-      const int y = idx / 10, x = idx - 10 * y;
-      float p0 = (float)(x - 5), p1 = (float)(y - 5);
-      p0 *= scaleTarget; p1 *= scaleTarget;
-      const float px0 = (a00 * p0 + a01 * p1) + rx;
-      const float px1 = (a10 * p0 + a11 * p1) + ry;
-      float val = 0;
-      if (!warp_nan && !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1)))
-        val = interpolate_8u(img, cols, px0, px1);
-      if (scale_exposure) val = val * J.exposure_rat;
-      s_pwb[wave][idx] = val;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-  // ---- template gradients, weights, Hessian (align2D :483-512 / align1D :183-207)
-  const int px_ = lane & 7, py_ = lane >> 3;
-  const float* pwb = s_pwb[wave];
-  const int c = (py_ + 1) * 10 + px_ + 1;
-  const float ref_px = pwb[c];
-  const float gxr = pwb[c + 1] - pwb[c - 1], gyr = pwb[c + 10] - pwb[c - 10];
-  const bool edgelet = (J.type == HSO_FTR_EDGELET);
-  double dir0 = 0, dir1 = 0;
-  float dirf0 = 0, dirf1 = 0;
-  float Jx, Jy;  // align2D: (dx, dy); align1D: (dv, unused)
-  if (edgelet) {
-    dir0 = A00 * J.grad[0] + A01 * J.grad[1];
-    dir1 = A10 * J.grad[0] + A11 * J.grad[1];
-    const double dn = sqrt(dir0 * dir0 + dir1 * dir1);
-    dir0 /= dn; dir1 /= dn;
-    dirf0 = (float)dir0; dirf1 = (float)dir1;
-    Jx = (float)(0.5 * (double)(dirf0 * gxr + dirf1 * gyr));
-    Jy = 0;
-  } else {
-    Jx = (float)(0.5 * (double)gxr);
-    Jy = (float)(0.5 * (double)gyr);
-  }
-  const float wgt = edgelet ? sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx))))
-                            : sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx + Jy * Jy))));
-  float Hi[9];  // align2D: 3x3; align1D: [0],[1],[3],[4] used as 2x2 over (dv, 1)
-  float h_xx = wave_sum_all((Jx * Jx) * wgt), h_x1 = wave_sum_all((Jx * 1.0f) * wgt), h_11 = wave_sum_all((1.0f * 1.0f) * wgt);
-  float h_xy = 0, h_yy = 0, h_y1 = 0;
-  if (!edgelet) {
-    h_xy = wave_sum_all((Jx * Jy) * wgt); h_yy = wave_sum_all((Jy * Jy) * wgt); h_y1 = wave_sum_all((Jy * 1.0f) * wgt);
-  }
-  if (edgelet) {
-    float H00 = h_xx, H01 = h_x1, H11 = h_11;
-    H00 = (float)((double)H00 * (1 + 0.001)); H11 = (float)((double)H11 * (1 + 0.001));
-    o.h_inv = 1.0 / (double)H00 * 8 * 8;  // :207
-    const float det = H00 * H11 - H01 * H01;
-    const float invdet = 1.0f / det;
-    Hi[0] = H11 * invdet; Hi[1] = -H01 * invdet; Hi[3] = -H01 * invdet; Hi[4] = H00 * invdet;
-  } else {
-    float H0 = h_xx, H1 = h_xy, H2 = h_x1, H4 = h_yy, H5 = h_y1, H8 = h_11;
-    H0 = (float)((double)H0 * (1 + 0.001)); H4 = (float)((double)H4 * (1 + 0.001)); H8 = (float)((double)H8 * (1 + 0.001));
-    const float H3 = H1, H6 = H2, H7 = H5;
-    const float c00 = H4 * H8 - H5 * H7, c01 = H5 * H6 - H3 * H8, c02 = H3 * H7 - H4 * H6;
-    const float det = H0 * c00 + H1 * c01 + H2 * c02;
-    const float invdet = 1.0f / det;
-    Hi[0] = c00 * invdet; Hi[3] = c01 * invdet; Hi[6] = c02 * invdet;
-    Hi[1] = (H2 * H7 - H1 * H8) * invdet; Hi[4] = (H0 * H8 - H2 * H6) * invdet; Hi[7] = (H1 * H6 - H0 * H7) * invdet;
-    Hi[2] = (H1 * H5 - H2 * H4) * invdet; Hi[5] = (H2 * H3 - H0 * H5) * invdet; Hi[8] = (H0 * H4 - H1 * H3) * invdet;
-  }
-
-  // ---- LK iterations (align2D :526-598 / align1D :214-301)
-  const int cols = W >> search_level, rows = H >> search_level;
-  const uint8_t* cur = C.cur_base + C.g.off[search_level];
-  double pxs0 = J.px_cur[0] / (double)(1 << search_level), pxs1 = J.px_cur[1] / (double)(1 << search_level);
-  const double orig0 = pxs0, orig1 = pxs1;
-  float u = (float)pxs0, v = (float)pxs1;
-  const float min_update_squared = edgelet ? (float)(0.01 * 0.01) : (float)(0.03 * 0.03);
-  float mean_diff = 0, chi2 = 0, search_pixel = 0;
-  bool converged = false, nan_exit = false;
-  int iter = 0;
-  for (iter = 0; iter < 10; ++iter) {  // options_.align_max_iter, matcher.h:124
-    const int u_r = (int)floor((double)u), v_r = (int)floor((double)v);
-    if (u_r < halfpatch_size_ || v_r < halfpatch_size_ || u_r >= cols - halfpatch_size_ || v_r >= rows - halfpatch_size_) break;
-    if (isnan(u) || isnan(v)) { nan_exit = true; break; }
-    const float sx = u - (float)u_r, sy = v - (float)v_r;
-    const float wTL = (float)((1.0 - sx) * (1.0 - sy));
-    const float wTR = (float)(sx * (1.0 - sy));
-    const float wBL = (float)((1.0 - sx) * sy);
-    const float wBR = sx * sy;
-    const uint8_t* it = cur + (v_r + py_ - halfpatch_size_) * cols + u_r - halfpatch_size_ + px_;
-    search_pixel = ((wTL * (float)it[0] + wTR * (float)it[1]) + wBL * (float)it[cols]) + wBR * (float)it[cols + 1];
-    const float res = (search_pixel - ref_px) + mean_diff;
-    const float j0 = wave_sum_all((res * Jx) * wgt);
-    const float j2 = wave_sum_all(res * wgt);
-    chi2 = wave_sum_all((res * res) * wgt);
-    if (edgelet) {
-      const float J0 = -j0, J1 = -j2;
-      const float up0 = Hi[0] * J0 + Hi[1] * J1, up1 = Hi[3] * J0 + Hi[4] * J1;
-      u += up0 * dirf0; v += up0 * dirf1; mean_diff += up1;
-      if (up0 * up0 < min_update_squared) { converged = true; iter++; break; }
-    } else {
-      const float j1 = wave_sum_all((res * Jy) * wgt);
-      const float J0 = -j0, J1 = -j1, J2 = -j2;
-      const float up0 = (Hi[0] * J0 + Hi[1] * J1) + Hi[2] * J2;
-      const float up1 = (Hi[3] * J0 + Hi[4] * J1) + Hi[5] * J2;
-      const float up2 = (Hi[6] * J0 + Hi[7] * J1) + Hi[8] * J2;
-      u += up0; v += up1; mean_diff += up2;
-      if (up0 * up0 + up1 * up1 < min_update_squared) { converged = true; iter++; break; }
-    }
-  }
-  if (chi2 > (float)(1000 * 64)) converged = false;
-  if (!nan_exit) { pxs0 = (double)u; pxs1 = (double)v; }  // `return false` at :230/:537 skips the write-back
-  o.iters = iter; o.chi2 = chi2;
-  bool ok = converged && !nan_exit;
-  if (!ok) o.stage = HSO_ALIGN_NOT_CONVERGED;
-
-  // ---- Matcher::checkNormal, :406-440 (edgelets only)
-  if (ok && edgelet) {
-    const int16_t* gx = reinterpret_cast<const int16_t*>(C.cur_base + C.g.sob_off[search_level][0]);
-    const int16_t* gy = reinterpret_cast<const int16_t*>(C.cur_base + C.g.sob_off[search_level][1]);
-    const float uf = (float)pxs0, vf = (float)pxs1;
-    const int ui = (int)floorf((float)pxs0), vi = (int)floorf((float)pxs1);
-    const float sx = uf - (float)ui, sy = vf - (float)vi;
-    const float wTL = (float)((1.0 - sx) * (1.0 - sy));
-    const float wTR = (float)(sx * (1.0 - sy));
-    const float wBL = (float)((1.0 - sx) * sy);
-    const float wBR = (float)(((1.0 - wTL) - wTR) - wBL);
-    const int a = vi * cols + ui;
-    double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + cols]) + (double)wBR * (double)gx[a + cols + 1];
-    double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + cols]) + (double)wBR * (double)gy[a + cols + 1];
-    const double nn = sqrt(n0 * n0 + n1 * n1);
-    n0 /= nn; n1 /= nn;
-    ok = (dir0 * n0 + dir1 * n1) > (double)(float)0.86;  // Config::edgeLetCosAngle() through a float parameter
-    if (!ok) o.stage = HSO_ALIGN_NORMAL;
-  }
-
-  // ---- Matcher::checkNCC, :379-404 on (ref patch, last iteration's samples)
-  {
-    const float mean1 = wave_sum_all(ref_px) / 64, mean2 = wave_sum_all(search_pixel) / 64;
-    const float d1 = ref_px - mean1, d2 = search_pixel - mean2;
-    const float num = wave_sum_all(d1 * d2), den1 = wave_sum_all(d1 * d1), den2 = wave_sum_all(d2 * d2);
-    const double ncc = (double)num / ((double)sqrtf(den1 * den2) + 1e-12);
-    o.ncc = (float)ncc;
-    if (ok) {
-      ok = ncc > (double)0.7f;
-      if (!ok) o.stage = HSO_ALIGN_NCC;
-    }
-  }
-  if (ok) {
-    const double dx = orig0 - pxs0, dy = orig1 - pxs1;
-    ok = sqrt(dx * dx + dy * dy) < 20;  // :369-370
-    if (!ok) o.stage = HSO_ALIGN_JUMP;
-  }
-  o.px_cur[0] = pxs0 * (double)(1 << search_level);
-  o.px_cur[1] = pxs1 * (double)(1 << search_level);
-  o.success = ok ? 1 : 0;
+  const hso_align_out o = match_one(C.cam, C.g, C.cur_base, JD.ref_base, JD.j, (double)0.7f, s_pwb[wave]);  // checkNCC(…, 0.7), :364
   if (lane == 0) outs[jid] = o;
 }
 

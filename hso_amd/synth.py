@@ -310,6 +310,64 @@ def seeds_for_pair(pair, n, ref_frame_id, seed=17, depth_noise=0.15, edgelet_fra
     return seeds, T_cur, feats
 
 
+def activation_problem(n_seeds=120, n_targets=8, seed=31, spec=ICL_NUIM, depth_noise=0.03, edgelet_frac=0.3,
+                       trans_frac=0.04, rot_deg=0.6, noise=1.0, host_frame_id=9200):
+    """A host frame (identity pose) plus n_targets frames at small random motions, and seeds hosted
+    in the host frame whose inverse depth is close to the truth (converged seeds, the state
+    DepthFilter::activatePoint sees).  Every seed lists all target frames; a few seeds get
+    truncated lists, wrong depths or a far-away target to exercise the gates."""
+    from .capi import Seed, SE3, ActivateTarget, FTR_CORNER, FTR_EDGELET
+    sc = Scene(spec, seed)
+    rng = np.random.default_rng(seed + 1)
+    qi = np.array([0, 0, 0, 1.0]); ti = np.zeros(3)
+    host = sc.render(qi, ti, 1.0, noise, seed + 2)
+    frames, targets = [], []
+    for k in range(n_targets):
+        tdir = rng.normal(size=3); tdir /= np.linalg.norm(tdir)
+        rdir = rng.normal(size=3); rdir /= np.linalg.norm(rdir)
+        t = tdir * trans_frac * 4.0 * rng.uniform(0.4, 1.0)
+        q = rotvec_to_quat(rdir * np.deg2rad(rot_deg) * rng.uniform(0.3, 1.0))
+        expo = float(rng.uniform(0.9, 1.1)) if k != 2 else 1.4     # one frame triggers the exposure compensation
+        frames.append(sc.render(q, t, expo, noise, seed + 10 + k))
+        tg = ActivateTarget()
+        tg.frame_id = host_frame_id + 1 + k
+        tg.T_f_w = SE3.from_arrays(q, t)
+        tg.exposure = expo
+        targets.append(tg)
+    feats = sc.features(qi, ti, n_seeds, seed=seed + 3, margin=48)
+    gy0, gx0 = np.gradient(host.astype(np.float64))
+    seeds, per_seed = [], []
+    for i in range(n_seeds):
+        s = Seed()
+        s.ref_frame_id = host_frame_id
+        s.level = int(rng.integers(0, 3))
+        px = feats["px"][i]
+        is_edge = rng.uniform() < edgelet_frac
+        s.type = FTR_EDGELET if is_edge else FTR_CORNER
+        s.px[:] = [float(px[0]), float(px[1])]
+        s.f[:] = [float(v) for v in feats["f"][i]]
+        g = np.array([gx0[int(px[1]), int(px[0])], gy0[int(px[1]), int(px[0])]])
+        g = g / (np.linalg.norm(g) + 1e-9)
+        s.grad[:] = [float(g[0]), float(g[1])] if is_edge else [1.0, 0.0]
+        s.T_ref_w = SE3.identity()
+        s.ref_exposure = 1.0
+        true_idist = 1.0 / feats["dist"][i]
+        s.mu = float(true_idist * (1 + rng.normal(0, depth_noise)))
+        s.sigma2 = 1e-4
+        s.b = 10.0
+        tl = list(targets)
+        if i % 17 == 3:
+            tl = tl[:2]                      # fewer targets than the frame threshold
+        if i % 19 == 5:
+            s.mu = float(true_idist * 1.6)   # wrong depth: large drift -> isValid = false
+        if i % 23 == 7:
+            tl = []
+        seeds.append(s)
+        per_seed.append(tl)
+    return dict(scene=sc, host=host, frames=frames, targets=targets, seeds=seeds, per_seed=per_seed, feats=feats,
+                host_frame_id=host_frame_id)
+
+
 def config2_pair(n_feats=2000, spec=ICL_NUIM, seed=1234, exposure=1.05, noise=1.0,
                  trans_frac=0.02, rot_deg=0.5):
     """reference = frame 0, current = known SE(3) away."""

@@ -384,6 +384,40 @@ int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_fr
                          double cur_exposure, double px_error_angle, const hso_seed* seeds, int n_seeds,
                          hso_seed_out* out);
 
+/* ---- DepthFilter::activatePoint + seedOptimizer, src/depth_filter.cpp:729-1073 ---- */
+
+#define HSO_ACTIVATE_MAX_TARGETS 64
+
+/* One frame of seed.optFrames_P followed by seed.optFrames_A, in the reference's visiting order. */
+typedef struct hso_activate_target {
+  int64_t frame_id;       /* resident */
+  hso_se3 T_f_w;
+  double exposure;        /* m_exposure_time */
+} hso_activate_target;
+
+typedef struct hso_activate_out {
+  int32_t activated;      /* activatePoint's return value */
+  int32_t is_valid;       /* the isValid out-parameter: 1 / 0, or -1 when the reference leaves it untouched */
+  int32_t n_targets;      /* targets.size() after the projection test (:741-769) */
+  int32_t n_matched;      /* targetResult.size() (:785-822) */
+  double dist_mean;       /* distMean (:827) */
+  double huber;           /* MAD scale used by seedOptimizer (:884) */
+  double opt_id;          /* seed.opt_id */
+  double energy;          /* robust energy at opt_id */
+  int32_t n_iter;         /* outer LM iterations executed */
+  int32_t _pad;
+} hso_activate_out;
+
+/* Seeds [i] use targets[target_begin[i] .. target_begin[i+1]) (<= HSO_ACTIVATE_MAX_TARGETS each).
+ * n_mean_converge_frame: DepthFilter::nMeanConvergeFrame_.  match_out (optional, one per target):
+ * the findMatchSeed result of every visited target (zero where no match was attempted).
+ * Kernel 1: one wavefront per (seed, target) runs the projection test, the parallax test and
+ * findMatchSeed; kernel 2: one thread per seed applies the gates and the 1-D LM serially in
+ * fp64 in the reference's order. */
+int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
+                          const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
+                          hso_activate_out* out, hso_align_out* match_out);
+
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

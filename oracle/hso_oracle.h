@@ -120,6 +120,14 @@ void hso_or_seed_observe(const hso_camera* cam, const hso_seed* s, const hso_se3
                          double px_error_angle, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
                          const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
                          const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_seed_out* o);
+/* ---- seed activation (src/depth_filter.cpp:729-1073, src/matcher.cpp:442-518) ---- */
+void hso_or_find_match_seed(const hso_camera* cam, const hso_align_job* job, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                            const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
+                            const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_align_out* out);
+void hso_or_seed_activate(const hso_camera* cam, const hso_seed* s, const hso_activate_target* tg, int n_tg,
+                          const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS], const uint8_t* const* tg_pyr,
+                          const int16_t* const* tg_gx, const int16_t* const* tg_gy, int w, int h,
+                          int n_mean_converge_frame, hso_activate_out* o, hso_align_out* match_out);
 /* per-term dump of the last evaluation for debugging: returns number of rows written */
 int hso_or_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch,
                            int8_t* offsets_xy);

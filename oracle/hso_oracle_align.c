@@ -291,9 +291,9 @@ double hso_or_normal_dot(const int16_t* gx, const int16_t* gy, int cols, const d
 
 /* Matcher::findMatchDirect after the reference feature has been chosen, src/matcher.cpp:286-375.
  * ref_pyr / cur_pyr: level pointers; cur_gx/cur_gy: Sobel images of the current frame's levels 0-2. */
-void hso_or_find_match_direct(const hso_camera* cam, const hso_align_job* job, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
-                              const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
-                              const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_align_out* out)
+static void find_match(const hso_camera* cam, const hso_align_job* job, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                       const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
+                       const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, double ncc_thresh, hso_align_out* out)
 {
   const int halfpatch_size_ = 4, patch_size_ = 8;
   memset(out, 0, sizeof(*out));
@@ -343,7 +343,7 @@ void hso_or_find_match_direct(const hso_camera* cam, const hso_align_job* job, c
   const double ncc = hso_or_ncc(patch, patchNCC);
   out->ncc = (float)ncc;
   if (ok) {
-    ok = ncc > (double)0.7f;  /* float thresh parameter, matcher.cpp:379 */
+    ok = ncc > ncc_thresh;  /* float thresh parameter, matcher.cpp:379 */
     if (!ok) out->stage = HSO_ALIGN_NCC;
   }
   if (ok) {
@@ -354,4 +354,21 @@ void hso_or_find_match_direct(const hso_camera* cam, const hso_align_job* job, c
   out->px_cur[0] = px_scaled[0] * (1 << search_level);
   out->px_cur[1] = px_scaled[1] * (1 << search_level);
   out->success = ok;
+}
+
+void hso_or_find_match_direct(const hso_camera* cam, const hso_align_job* job, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                              const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
+                              const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_align_out* out)
+{
+  find_match(cam, job, ref_pyr, cur_pyr, cur_gx, cur_gy, w, h, (double)0.7f, out); /* checkNCC(.., 0.7), matcher.cpp:364 */
+}
+
+/* Matcher::findMatchSeed after the parallax test, src/matcher.cpp:451-518: the same body with the
+ * exposure compensation unconditional on the keyframe gap (caller sets kf_gap_lt4 = 1) and
+ * checkNCC(.., 0.8) — the ncc_thresh argument of the reference function is not used. */
+void hso_or_find_match_seed(const hso_camera* cam, const hso_align_job* job, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                            const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
+                            const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_align_out* out)
+{
+  find_match(cam, job, ref_pyr, cur_pyr, cur_gx, cur_gy, w, h, (double)0.8f, out);
 }

@@ -335,6 +335,38 @@ def seed_observe(cam, seed, cur_T_f_w, cur_exposure, px_error_angle, ref_pyr, cu
     return out
 
 
+def seed_activate(cam, seed, targets, ref_pyr, tgt_pyrs, tgt_sobels, n_mean_converge_frame=6):
+    """DepthFilter::activatePoint for one seed.  targets: list of ActivateTarget; tgt_pyrs[i]: the
+    5 levels of target i; tgt_sobels[i]: [(gx, gy)] * 3.  Returns (ActivateOut, [AlignOut])."""
+    from hso_amd.capi import Seed, ActivateTarget, ActivateOut, AlignOut
+    lib = load()
+    vpp = C.POINTER(C.c_void_p)
+    lib.hso_or_seed_activate.argtypes = [C.POINTER(Camera), C.POINTER(Seed), C.POINTER(ActivateTarget), C.c_int, vpp, vpp, vpp,
+                                         vpp, C.c_int, C.c_int, C.c_int, C.POINTER(ActivateOut), C.POINTER(AlignOut)]
+    lib.hso_or_seed_activate.restype = None
+    n = len(targets)
+    rp = [np.ascontiguousarray(l) for l in ref_pyr]
+    h, w = rp[0].shape
+    keep = [rp]
+    pyr_ptrs, gx_ptrs, gy_ptrs = [], [], []
+    for i in range(n):
+        tp = [np.ascontiguousarray(l) for l in tgt_pyrs[i]]
+        gx = [np.ascontiguousarray(g[0]) for g in tgt_sobels[i]]
+        gy = [np.ascontiguousarray(g[1]) for g in tgt_sobels[i]]
+        keep += [tp, gx, gy]
+        pyr_ptrs += [l.ctypes.data for l in tp]
+        gx_ptrs += [g.ctypes.data for g in gx]
+        gy_ptrs += [g.ctypes.data for g in gy]
+    tarr = (ActivateTarget * max(n, 1))(*targets)
+    out = ActivateOut()
+    mo = (AlignOut * max(n, 1))()
+    lib.hso_or_seed_activate(C.byref(cam), C.byref(seed), tarr, n,
+                             (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in rp]),
+                             (C.c_void_p * max(5 * n, 1))(*pyr_ptrs), (C.c_void_p * max(3 * n, 1))(*gx_ptrs),
+                             (C.c_void_p * max(3 * n, 1))(*gy_ptrs), w, h, n_mean_converge_frame, C.byref(out), mo)
+    return out, list(mo[:n])
+
+
 def pattern(max_level, level):
     pa, hp = C.c_int(), C.c_int()
     offs = np.zeros((40, 2), np.int8)
