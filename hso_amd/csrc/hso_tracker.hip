@@ -31,6 +31,7 @@
 //     equal to nth_element at floor(n/2) (include/hso/vikit/math_utils.h:119-126).
 // Nothing here is a dense contraction, so MFMA is not used (BASELINE.json north_star).
 #include "hso_ctx.h"
+#include <stdlib.h>
 #include "hso_dev_math.h"
 #include <string.h>
 #include <algorithm>
@@ -42,8 +43,6 @@ using namespace hso_dev;
 #endif
 #define TRK_WAVES (TRK_THREADS / 64)
 #define TRK_MAX_PA 25
-#define SEL_BINS 2048
-#define SEL_CAND_CAP 4096
 #define KEY_INVALID 0xFFFFFFFFu
 #define N_RED 38  // 28 H + 7 b + E + n_terms + n_saturated
 
@@ -67,16 +66,24 @@ static const int h_pattern_num[8] = { 1, 5, 9, 13, 13, 21, 25, 25 };
 static const int h_pattern_pad[8] = { 1, 1, 1, 2, 2, 3, 2, 4 };
 #define PATTERN_OFFSET 2  // m_pattern_offset, CoarseTracker.h:122
 
+// per pyramid level: geometry, PATCH_AREA, HALF_PATCH_SIZE and the byte offset oy*stride+ox of
+// every pattern pixel in that level's image (CoarseTracker.cpp:80-82,337).  Lives in device
+// memory: indexing a by-value kernel argument with the run-time level would make the compiler
+// copy the whole argument block to scratch and read the camera from there in the hot loops.
+struct TrackLevel {
+  int w, h;
+  uint32_t off;       // byte offset of the level in the frame's pyramid block
+  int pa, pad;
+  int poff[TRK_MAX_PA];
+};
+
+// kernel argument by value: scalars only ever indexed with constants => stays in SGPRs
 struct TrackConsts {
   hso_camera cam;
   int inverse, max_level, min_level, n_iter;
-  PyrGeom g;
   int lds_img_cap;    // bytes of LDS available for the staged level image
   int n_max;          // scratch stride (features)
-  // per pyramid level: PATCH_AREA, HALF_PATCH_SIZE and the byte offset oy*stride+ox of
-  // every pattern pixel in that level's image (CoarseTracker.cpp:80-82,337)
-  int pa[HSO_N_PYR_LEVELS], pad[HSO_N_PYR_LEVELS];
-  int poff[HSO_N_PYR_LEVELS][TRK_MAX_PA];
+  const TrackLevel* lv;  // [HSO_N_PYR_LEVELS], device memory
 };
 
 struct TrackJobDev {
@@ -128,9 +135,7 @@ struct Shared {
   int level, PA, pad, S;
   int job, stop, n_select;
   int use_lds;
-  unsigned hist[SEL_BINS];
-  unsigned cand[SEL_CAND_CAP];
-  unsigned cand_n;
+  unsigned sel[4096];                // selection histogram (SEL_WORDS)
   int wave_cnt[TRK_WAVES];
   int poff[32];                      // byte offset oy*stride+ox of every pattern pixel of this level
   hso_track_result res;              // the job's result record, written to global memory once at the end
@@ -389,6 +394,8 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
 
 // pass 1 of selectRobustFunctionLevel (CoarseTracker.cpp:547-606): |residual| of every
 // in-bounds term, stored as float bit patterns (KEY_INVALID elsewhere).  Returns errors.size().
+HSO_DEV void sel_count_a(Shared& s, uint32_t kk);
+
 template <bool S1, typename Ptr>
 HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
 {
@@ -414,6 +421,7 @@ HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, 
         const float cur = ((p.w_tl * b1f(r1) + p.w_tr * b2f(r1)) + p.w_bl * b1f(r2)) + p.w_br * b2f(r2);
         const float res = cur - a * L.sc.ref_patch[(size_t)pidx * nm + f];
         key = __float_as_uint(fabsf(res));
+        sel_count_a(s, key);  // round A of the median select, fused (select_robust zeroed the bins)
         cnt++;
       }
       L.sc.keys[(size_t)pidx * n + f] = key;
@@ -422,102 +430,231 @@ HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, 
   return block_sum_int(s, cnt);
 }
 
-// Exact k-th smallest (0-based) of the valid keys produced by key_of(i), i in [0, n_slots).
-// Keys are bit patterns of non-negative floats (bit 31 clear), so unsigned order = float
-// order.  MSB-first radix select over digits [30:20], [19:9], [8:0]: a histogram pass per
-// digit narrows the candidates to one bin; as soon as the bin fits in LDS the candidates
-// are gathered and the remaining low bits are fixed one at a time.  The value returned is
+// ---- exact order statistics -------------------------------------------------------------
+// Keys are bit patterns of non-negative floats (bit 31 clear), so unsigned order = float order;
+// KEY_INVALID (bit 31 set) marks slots without a term.  The k-th smallest is found MSB-first in
+// three histogram rounds over the digits [30:23] (the exponent), [22:12] and [11:0]; after each
+// round every wave locates the bin that holds the rank by itself (scan_find), so (prefix, rank)
+// live in registers and are identical in all threads by construction.  The value returned is
 // the element nth_element would leave at position k, whatever the input order.
-// Every wave derives (prefix, rank) from the shared histogram / candidate list on its own,
-// so the running state lives in registers and is identical in all threads by construction.
-template <typename KeyFn>
-HSO_DEV uint32_t radix_select(Shared& s, int n_slots, unsigned k, KeyFn key_of)
+//
+// Residual magnitudes of a level crowd into a handful of octaves, so a plain histogram of the
+// leading digit would serialise on same-address LDS atomics: round A therefore keeps SEL_REP
+// replicas of every exponent bin (lane & 15 picks one) and folds them afterwards.  Rounds B and
+// C see mantissa bits, which are spread evenly.
+#define SEL_WORDS 4096
+#define SEL_REP 16
+
+template <int NB>
+HSO_DEV void scan_find(const unsigned* hist, unsigned& rank, unsigned& bin, unsigned& count)
 {
-  const int tid = threadIdx.x, lane = threadIdx.x & 63;
-  uint32_t prefix = 0;
-  unsigned rank = k, bin_count = 0;
-  int shift = 31;
-  for (int pass = 0; pass < 3; pass++) {
-    shift = (pass == 0) ? 20 : ((pass == 1) ? 9 : 0);
-    const int width = (pass == 2) ? 9 : 11;
-    const uint32_t hi_mask = ~((1u << (shift + width)) - 1u);  // pass 0: 0x80000000
-    __syncthreads();
-    for (int i = tid; i < SEL_BINS; i += TRK_THREADS) s.hist[i] = 0;
-    __syncthreads();
-    // eight keys per thread in flight: the loads must not queue behind the LDS atomics
-    for (int i0 = tid; i0 < n_slots; i0 += TRK_THREADS * 8) {
+  constexpr int SEG = NB / 64;
+  const int lane = threadIdx.x & 63;
+  unsigned local = 0;
+  for (int j = 0; j < SEG; j++) local += hist[lane * SEG + ((j + lane) & (SEG - 1))];  // rotated start: spreads the banks
+  unsigned incl = local;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  const unsigned excl = incl - local;
+  const unsigned long long m = __ballot(rank >= excl && rank < incl);
+  const int seg = (m != 0ull) ? (__ffsll((long long)m) - 1) : 0;
+  const unsigned r2 = rank - __shfl(excl, seg);
+  const unsigned c = (lane < SEG) ? hist[seg * SEG + lane] : 0u;
+  unsigned incl2 = c;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(incl2, d);
+    if (lane >= d) incl2 += o;
+  }
+  const unsigned long long m2 = __ballot(lane < SEG && r2 >= incl2 - c && r2 < incl2);
+  const int bl = (m2 != 0ull) ? (__ffsll((long long)m2) - 1) : 0;
+  bin = (unsigned)(seg * SEG + bl);
+  rank = r2 - __shfl(incl2 - c, bl);
+  count = __shfl(c, bl);
+}
+
+HSO_DEV void sel_zero(Shared& s, int words)
+{
+  __syncthreads();
+  for (int i = threadIdx.x; i < words; i += TRK_THREADS) s.sel[i] = 0;
+  __syncthreads();
+}
+
+HSO_DEV void sel_count_a(Shared& s, uint32_t kk)
+{
+  if ((int)kk >= 0) atomicAdd(&s.sel[(kk >> 23) * SEL_REP + (threadIdx.x & (SEL_REP - 1))], 1u);
+}
+
+// keys.each(f) calls f(key) for every key this thread owns.  round_a_done: the caller already
+// histogrammed the exponents into the replicated bins (fused into the pass that produced the keys).
+template <typename Keys>
+HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_a_done)
+{
+#ifdef HSO_SEL_PROBE
+  unsigned long long kt = __builtin_readcyclecounter();
+#define KSEL_T(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[i] += n_ - kt; kt = n_; } } while (0)
+#else
+#define KSEL_T(i) do { } while (0)
+#endif
+  const int tid = threadIdx.x;
+  unsigned rank = k, bin = 0, count = 0;
+  if (!round_a_done) {
+    sel_zero(s, 256 * SEL_REP);
+    keys.each([&](uint32_t kk) { sel_count_a(s, kk); });
+  }
+  __syncthreads();
+  KSEL_T(0);
+  unsigned sum = 0;
+  if (tid < 256)
+    for (int j = 0; j < SEL_REP; j++) sum += s.sel[tid * SEL_REP + ((j + tid) & (SEL_REP - 1))];
+  __syncthreads();
+  if (tid < 256) s.sel[tid] = sum;
+  __syncthreads();
+  scan_find<256>(s.sel, rank, bin, count);
+  uint32_t prefix = bin << 23;
+  sel_zero(s, 2048);
+  KSEL_T(1);
+  keys.each([&](uint32_t kk) { if ((kk & 0xFF800000u) == prefix) atomicAdd(&s.sel[(kk >> 12) & 2047u], 1u); });
+  __syncthreads();
+  KSEL_T(2);
+  scan_find<2048>(s.sel, rank, bin, count);
+  prefix |= bin << 12;
+  sel_zero(s, 4096);
+  KSEL_T(3);
+  keys.each([&](uint32_t kk) { if ((kk & 0xFFFFF000u) == prefix) atomicAdd(&s.sel[kk & 4095u], 1u); });
+  __syncthreads();
+  KSEL_T(2);
+  scan_find<4096>(s.sel, rank, bin, count);
+  prefix |= bin;
+  __syncthreads();
+  KSEL_T(4);
+  return prefix;
+}
+
+// keys in memory (the |residual| array of select_collect), optionally transformed on the fly;
+// eight loads per thread in flight so they do not queue behind the LDS atomics
+template <typename KeyFn>
+struct MemKeys {
+  int n_slots;
+  KeyFn key_of;
+  template <typename F>
+  HSO_DEV void each(F f) const
+  {
+    for (int i0 = threadIdx.x; i0 < n_slots; i0 += TRK_THREADS * 8) {
       uint32_t kk[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) { const int i = i0 + u * TRK_THREADS; kk[u] = (i < n_slots) ? key_of(i) : KEY_INVALID; }
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-        if ((kk[u] & hi_mask) == prefix) atomicAdd(&s.hist[(kk[u] >> shift) & ((1u << width) - 1u)], 1u);
+      for (int u = 0; u < 8; u++) f(kk[u]);
     }
-    __syncthreads();
-    {
-      // level 1: lane l sums bins [32l, 32l+32) (rotated start => bank-conflict free),
-      // inclusive scan over the wave, the owner segment is the one containing the rank
-      unsigned local = 0;
-      for (int j = 0; j < 32; j++) local += s.hist[lane * 32 + ((j + lane) & 31)];
-      unsigned incl = local;
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-      }
-      const unsigned excl = incl - local;
-      const unsigned long long m = __ballot(rank >= excl && rank < incl);
-      const int seg = (m != 0ull) ? (__ffsll((long long)m) - 1) : 0;
-      const unsigned r2 = rank - __shfl(excl, seg);
-      // level 2: the 32 bins of that segment, one per lane
-      const unsigned c = (lane < 32) ? s.hist[seg * 32 + lane] : 0u;
-      unsigned incl2 = c;
-      for (int d = 1; d < 32; d <<= 1) {
-        const unsigned o = __shfl_up(incl2, d);
-        if (lane >= d) incl2 += o;
-      }
-      const unsigned long long m2 = __ballot(lane < 32 && r2 >= incl2 - c && r2 < incl2);
-      const int bl = (m2 != 0ull) ? (__ffsll((long long)m2) - 1) : 0;
-      prefix |= (uint32_t)(seg * 32 + bl) << shift;
-      rank = r2 - __shfl(incl2 - c, bl);
-      bin_count = __shfl(c, bl);
-    }
-    if (shift == 0) return prefix;  // all 31 bits fixed
-    if (bin_count <= SEL_CAND_CAP) break;
   }
-  // gather the candidates (keys that agree with the prefix above bit `shift`) into LDS
-  const uint32_t kmask = ~((1u << shift) - 1u);
-  __syncthreads();
-  if (tid == 0) s.cand_n = 0;
-  __syncthreads();
-  for (int i0 = tid; i0 < n_slots; i0 += TRK_THREADS * 8) {
-    uint32_t kk[8];
+};
+template <typename KeyFn>
+HSO_DEV MemKeys<KeyFn> mem_keys(int n_slots, KeyFn fn) { return MemKeys<KeyFn>{ n_slots, fn }; }
+
+// keys owned by the thread that computed them (registers, or private scratch if they spill)
+template <int NK>
+struct RegKeys {
+  const uint32_t (&k)[NK];
+  template <typename F>
+  HSO_DEV void each(F f) const
+  {
 #pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = i0 + u * TRK_THREADS; kk[u] = (i < n_slots) ? key_of(i) : KEY_INVALID; }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if ((kk[u] & kmask) == prefix) {
-        const unsigned slot = atomicAdd(&s.cand_n, 1u);
-        if (slot < SEL_CAND_CAP) s.cand[slot] = kk[u];
-      }
-    }
+    for (int u = 0; u < NK; u++) f(k[u]);
+  }
+};
+
+HSO_DEV void set_thresholds(Shared& s, float med, uint32_t mad_bits)
+{
+  if (threadIdx.x == 0) {
+    const float standard_deviation = (float)(1.4826 * (double)__uint_as_float(mad_bits));
+    const float huber = med + standard_deviation;
+    float outlier = 3 * huber;
+    if (outlier < 10) outlier = 10;
+    s.huber = huber;
+    s.outlier = outlier;
   }
   __syncthreads();
-  const unsigned nc = min(s.cand_n, (unsigned)SEL_CAND_CAP);
-  uint32_t res = prefix;
-  for (int bit = shift - 1; bit >= 0; bit--) {
-    const uint32_t trial = res | (1u << bit);
-    int c = 0;
-    for (unsigned i = lane; i < nc; i += 64) c += (s.cand[i] < trial) ? 1 : 0;
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
-    if ((unsigned)c <= rank) res = trial;  // the rank-th smallest is >= trial
-  }
-  __syncthreads();
-  return res;
 }
 
-// selectRobustFunctionLevel, CoarseTracker.cpp:530-644
-HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
+// selectRobustFunctionLevel for the common shape — one thread per feature (S == 1) and
+// n <= SEL_REG_ROUNDS * TRK_THREADS: the |residual| keys stay with the thread that computed them
+// (no key array in memory), and the exponent histogram of the median is filled while they are
+// being produced.
+#define SEL_REG_ROUNDS 3
+template <int PA, typename Ptr>
+HSO_DEV void select_robust_reg(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
 {
+  constexpr int NK = SEL_REG_ROUNDS * PA;
+  uint32_t key[NK];
+  const int nm = L.C->n_max, border = s.pad + 1, stride = L.cols;
+  int cnt = 0;
+#ifdef HSO_PHASE_TIMERS
+  unsigned long long sel_t = __builtin_readcyclecounter();
+#define SELR_T(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[k] += n_ - sel_t; sel_t = n_; } } while (0)
+#else
+#define SELR_T(k) do { } while (0)
+#endif
+  sel_zero(s, 256 * SEL_REP);
+#pragma unroll
+  for (int r = 0; r < SEL_REG_ROUNDS; r++) {
+    const int f = r * TRK_THREADS + (int)threadIdx.x;
+    const FeatRaw raw = load_feature(L, f);
+    const Proj p = project_feature(L, T, raw, border);
+#pragma unroll
+    for (int pidx = 0; pidx < PA; pidx++) {
+      uint32_t kk = KEY_INVALID;
+      if (p.ok) {
+        const int a0 = p.base + s.poff[pidx];
+        const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
+        const float cur = ((p.w_tl * b1f(r1) + p.w_tr * b2f(r1)) + p.w_bl * b1f(r2)) + p.w_br * b2f(r2);
+        const float res = cur - a * L.sc.ref_patch[(size_t)pidx * nm + f];
+        kk = __float_as_uint(fabsf(res));
+        sel_count_a(s, kk);
+      }
+      key[r * PA + pidx] = kk;
+    }
+    if (p.ok) cnt += PA;
+  }
+  const int n_err = block_sum_int(s, cnt);
+  SELR_T(5);
+  if (threadIdx.x == 0) s.n_select = n_err;
+  if (n_err < 30) {
+    if (threadIdx.x == 0) { s.huber = 5.2f; s.outlier = 100.f; }
+    __syncthreads();
+    return;
+  }
+  const float med = __uint_as_float(select_kth(s, (unsigned)(n_err / 2), RegKeys<NK>{ key }, true));
+  SELR_T(6);
+#pragma unroll
+  for (int u = 0; u < NK; u++)
+    if (key[u] != KEY_INVALID) key[u] = __float_as_uint(fabsf(__uint_as_float(key[u]) - med));
+  const uint32_t mad_bits = select_kth(s, (unsigned)(n_err / 2), RegKeys<NK>{ key }, false);
+#ifdef HSO_SEL_PROBE
+  SELR_T(6);
+  {
+    const uint32_t again = select_kth(s, (unsigned)(n_err / 2), RegKeys<NK>{ key }, false);
+    if (again != mad_bits && threadIdx.x == 0) s.n_select = -1;
+  }
+#endif
+  set_thresholds(s, med, mad_bits);
+  SELR_T(7);
+}
+
+// selectRobustFunctionLevel, CoarseTracker.cpp:530-644.  keep_keys: the parity hook wants the
+// |residual| array in memory (hso_gpu_tracker_eval's abs_err_out).
+HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a, bool keep_keys = false)
+{
+  if (!keep_keys && s.S == 1 && s.use_lds && L.job->n <= SEL_REG_ROUNDS * TRK_THREADS) {
+    switch (s.PA) {
+      case 9: select_robust_reg<9, LdsPtr>(s, L, lds_img, T, a); return;
+      case 13: select_robust_reg<13, LdsPtr>(s, L, lds_img, T, a); return;
+      case 21: select_robust_reg<21, LdsPtr>(s, L, lds_img, T, a); return;
+      default: break;
+    }
+  }
+  sel_zero(s, 256 * SEL_REP);
   int n_err;
   if (s.S == 1) {
     n_err = s.use_lds ? select_collect<true, LdsPtr>(s, L, lds_img, T, a) : select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a);
@@ -532,21 +669,13 @@ HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
     __syncthreads();
     return;
   }
-  const uint32_t med_bits = radix_select(s, n_slots, (unsigned)(n_err / 2), [&](int i) { return keys[i]; });
+  const uint32_t med_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(n_slots, [&](int i) { return keys[i]; }), true);
   const float med = __uint_as_float(med_bits);
-  const uint32_t mad_bits = radix_select(s, n_slots, (unsigned)(n_err / 2), [&](int i) {
+  const uint32_t mad_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(n_slots, [&](int i) {
     const uint32_t k = keys[i];
     return (k == KEY_INVALID) ? KEY_INVALID : __float_as_uint(fabsf(__uint_as_float(k) - med));
-  });
-  if (threadIdx.x == 0) {
-    const float standard_deviation = (float)(1.4826 * (double)__uint_as_float(mad_bits));
-    const float huber = med + standard_deviation;
-    float outlier = 3 * huber;
-    if (outlier < 10) outlier = 10;
-    s.huber = huber;
-    s.outlier = outlier;
-  }
-  __syncthreads();
+  }), false);
+  set_thresholds(s, med, mad_bits);
 }
 
 // ------------------------------------------ residuals + normal equations
@@ -703,7 +832,7 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
   const float max_energy = (float)((double)(2 * huber) * (double)outlier - (double)(huber * huber));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-#ifdef HSO_PHASE_TIMERS
+#if defined(HSO_PHASE_TIMERS) && !defined(HSO_SEL_PROBE)
 #define DBG_T(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[k] += n_ - dbg_t; dbg_t = n_; } } while (0)
   unsigned long long dbg_t = __builtin_readcyclecounter();
 #else
@@ -783,119 +912,108 @@ HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const Tra
 {
   __syncthreads();
   L.C = &C; L.job = &job; L.sc = sc; L.level = level;
-  L.cols = C.g.w[level]; L.rows = C.g.h[level];
+  const TrackLevel& V = C.lv[level];
+  L.cols = V.w; L.rows = V.h;
   L.scale = 1.0f / (float)(1 << level);
   L.fxl = C.cam.fx * (double)L.scale;
   L.fyl = C.cam.fy * (double)L.scale;
-  L.ref_glb = reinterpret_cast<GlbPtr>(job.ref_base + C.g.off[level]);
-  L.cur_glb = reinterpret_cast<GlbPtr>(job.cur_base + C.g.off[level]);
+  L.ref_glb = reinterpret_cast<GlbPtr>(job.ref_base + V.off);
+  L.cur_glb = reinterpret_cast<GlbPtr>(job.cur_base + V.off);
   if (threadIdx.x == 0) {
-    s.level = level; s.PA = C.pa[level]; s.pad = C.pad[level];
+    s.level = level; s.PA = V.pa; s.pad = V.pad;
     int S = 1;
     while (S < 16 && job.n * S * 2 <= TRK_THREADS) S *= 2;
     s.S = S;
   }
-  if (threadIdx.x < TRK_MAX_PA) s.poff[threadIdx.x] = C.poff[level][threadIdx.x];
+  if (threadIdx.x < TRK_MAX_PA) s.poff[threadIdx.x] = V.poff[threadIdx.x];
   // reference image through LDS for the patch precompute, then the current image stays resident
-  const bool ref_in_lds = stage_image(L, job.ref_base + C.g.off[level], lds_img);
+  const bool ref_in_lds = stage_image(L, job.ref_base + V.off, lds_img);
   __syncthreads();
   if (ref_in_lds) precompute_reference<LdsPtr>(s, L, (LdsPtr)lds_img);
   else precompute_reference<GlbPtr>(s, L, L.ref_glb);
   __syncthreads();
-  const bool cur_in_lds = stage_image(L, job.cur_base + C.g.off[level], lds_img);
+  const bool cur_in_lds = stage_image(L, job.cur_base + V.off, lds_img);
   if (threadIdx.x == 0) s.use_lds = cur_in_lds ? 1 : 0;
   __syncthreads();
 }
 
-// Hl.ldlt().solve(b) of CoarseTracker.cpp:112-114 on the first eight lanes of one wavefront:
-// lane j holds column j of the 7x7 damped matrix in registers a[0..6] (a[i] = A(i,j)), lane 7
-// holds the right-hand side.  Right-looking LDL^T with diagonal pivoting (largest |diagonal|,
-// first on ties, like Eigen::LDLT): everything a step needs from another lane is a broadcast
-// from a lane known to the whole wave, i.e. v_readlane_b32 — no LDS traffic; the forward
-// substitution rides along in lane 7; then z = D^-1 y (zero where the pivot vanished, Eigen's
-// pseudo-inverse) and the back substitution.  Result: s.step[0..6].
-HSO_DEV double readlane_d(double v, int src_lane)
-{
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
+// Hl.ldlt().solve(b) of CoarseTracker.cpp:112-114 by one lane, entirely in registers: every
+// loop below has compile-time bounds, so after unrolling all array indices are static and the
+// 28 + 7 doubles never touch scratch or LDS (the earlier eight-lane v_readlane variant spent
+// 16k cycles per solve on readlane hazards and 28 fp64 divisions; this one ~4k).  Right-looking
+// LDL^T on the lower triangle with diagonal pivoting (largest |diagonal|, first on ties, like
+// Eigen::LDLT); one reciprocal per pivot; z = D^-1 y (zero where the pivot vanished, Eigen's
+// pseudo-inverse); back substitution; un-permute into s.step[0..6].
+HSO_DEV void swap_d(double& x, double& y) { const double t = x; x = y; y = t; }
 
-HSO_DEV void wave_ldlt7_solve(Shared& s, float lambda)
+HSO_DEV void lane_ldlt7_solve(Shared& s, float lambda)
 {
-  const int lane = threadIdx.x & 63;
-  const int j = lane < 8 ? lane : 7;
-  double a[7];
+  double A[7][7], y[7], invd[7];
+  int perm[7];
 #pragma unroll
-  for (int i = 0; i < 7; i++) {
-    if (j < 7) {
-      const int r = i < j ? i : j, c = i < j ? j : i;
+  for (int r = 0; r < 7; r++) {
+#pragma unroll
+    for (int c = r; c < 7; c++) {
       double v = s.H[7 * r - (r * (r - 1)) / 2 + (c - r)];
-      if (i == j) v *= (double)(1 + lambda);  // Hl(i,i) *= (1+lambda), CoarseTracker.cpp:113
-      a[i] = v;
-    } else {
-      a[i] = s.b[i];
+      if (r == c) v *= (double)(1 + lambda);  // Hl(i,i) *= (1+lambda), CoarseTracker.cpp:113
+      A[c][r] = v;
     }
+    y[r] = s.b[r];
+    perm[r] = r;
   }
-  int perm[7];  // uniform: original index of the unknown now at position i
-#pragma unroll
-  for (int i = 0; i < 7; i++) perm[i] = i;
 #pragma unroll
   for (int k = 0; k < 7; k++) {
     double best = -1;
     int idx = k;
 #pragma unroll
     for (int q = k; q < 7; q++) {
-      const double d = fabs(readlane_d(a[q], q));
+      const double d = fabs(A[q][q]);
       if (d > best) { best = d; idx = q; }
     }
 #pragma unroll
     for (int q = k + 1; q < 7; q++) {
-      if (idx == q) {  // wave-uniform: symmetric swap of rows/columns k and q
-        const double t = a[k]; a[k] = a[q]; a[q] = t;                 // rows (incl. the rhs in lane 7)
-        const int tp = perm[k]; perm[k] = perm[q]; perm[q] = tp;
+      if (idx == q) {  // symmetric swap of indices k and q on the lower triangle
 #pragma unroll
-        for (int i = 0; i < 7; i++) {                                 // columns: lanes k and q trade places
-          const double from_q = readlane_d(a[i], q), from_k = readlane_d(a[i], k);
-          a[i] = (lane == k) ? from_q : ((lane == q) ? from_k : a[i]);
-        }
+        for (int i = 0; i < k; i++) swap_d(A[k][i], A[q][i]);
+        swap_d(A[k][k], A[q][q]);
+#pragma unroll
+        for (int i = k + 1; i < q; i++) swap_d(A[i][k], A[q][i]);
+#pragma unroll
+        for (int i = q + 1; i < 7; i++) swap_d(A[i][k], A[i][q]);
+        swap_d(y[k], y[q]);
+        const int tp = perm[k]; perm[k] = perm[q]; perm[q] = tp;
       }
     }
-    const double akk = readlane_d(a[k], k);
+    const double akk = A[k][k];
     const bool valid = fabs(akk) > 0;
+    const double inv = valid ? 1.0 / akk : 1.0;
+    invd[k] = inv;
+    double l[7];
+#pragma unroll
+    for (int i = k + 1; i < 7; i++) l[i] = A[i][k] * inv;
 #pragma unroll
     for (int i = k + 1; i < 7; i++) {
-      const double aik = readlane_d(a[i], k);        // A(i,k), column k lives in lane k
-      const double lik = valid ? aik / akk : aik;
-      if (lane > k) a[i] -= lik * a[k];              // columns k+1..6 and the rhs: A(i,j) -= l_ik A(k,j)
-      else if (lane == k) a[i] = lik;                // store L(i,k)
+#pragma unroll
+      for (int j = k + 1; j <= i; j++) A[i][j] -= l[i] * A[j][k];
+      y[i] -= l[i] * y[k];
     }
+#pragma unroll
+    for (int i = k + 1; i < 7; i++) A[i][k] = l[i];
   }
-  // lane 7: y (forward-substituted rhs).  z = D^-1 y, then x = L^-T z.
   const double tolerance = 1.0 / 1.7976931348623157e308;
   double x[7];
 #pragma unroll
-  for (int i = 0; i < 7; i++) {
-    const double dii = readlane_d(a[i], i);
-    const double yi = readlane_d(a[i], 7);
-    x[i] = (fabs(dii) > tolerance) ? yi / dii : 0.0;
-  }
+  for (int i = 0; i < 7; i++) x[i] = (fabs(A[i][i]) > tolerance) ? y[i] * invd[i] : 0.0;
 #pragma unroll
   for (int k = 6; k >= 1; k--) {
 #pragma unroll
-    for (int i = 0; i < k; i++) x[i] -= readlane_d(a[k], i) * x[k];  // L(k,i) sits in lane i, row k
+    for (int i = 0; i < k; i++) x[i] -= A[k][i] * x[k];
   }
-  if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-#pragma unroll
-      for (int q = 0; q < 7; q++)
-        if (perm[i] == q) s.step[q] = x[i];
-    }
-  }
+  for (int i = 0; i < 7; i++) s.step[perm[i]] = x[i];
 }
 
-// lane 0 after wave_ldlt7_solve: extrapolation, NaN guard, exposure and pose proposal
+// lane 0 after lane_ldlt7_solve: extrapolation, NaN guard, exposure and pose proposal
 // (CoarseTracker.cpp:120-133)
 HSO_DEV void lm_finish(Shared& s, bool inverse)
 {
@@ -924,10 +1042,13 @@ HSO_DEV void lm_finish(Shared& s, bool inverse)
 }
 
 #ifdef HSO_PHASE_TIMERS
+#ifndef HSO_PHASE_TIMERS_BASE
+#define HSO_PHASE_TIMERS_BASE 0  /* 3: report dbg[3..7] = exchange, combine, select collect / median / MAD */
+#endif
 #define PH_START() unsigned long long ph_t = __builtin_readcyclecounter(); const unsigned long long ph_job = ph_t
 #define PH_ADD(k) do { if (threadIdx.x == 0) { const unsigned long long ph_n = __builtin_readcyclecounter(); \
                          out->phase_cycles[k] += ph_n - ph_t; ph_t = ph_n; } } while (0)
-#define PH_JOB() do { if (threadIdx.x == 0) { out->phase_cycles[4] = __builtin_readcyclecounter() - ph_job; for (int k_ = 0; k_ < 5; k_++) out->phase_cycles[5 + k_] = s.dbg[k_]; } } while (0)
+#define PH_JOB() do { if (threadIdx.x == 0) { out->phase_cycles[4] = __builtin_readcyclecounter() - ph_job; for (int k_ = 0; k_ < 5; k_++) out->phase_cycles[5 + k_] = s.dbg[k_ + HSO_PHASE_TIMERS_BASE]; } } while (0)
 #else
 #define PH_START() do { } while (0)
 #define PH_ADD(k) do { } while (0)
@@ -986,9 +1107,9 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
     }
     __syncthreads();
     for (int iter = 0; iter < C.n_iter; iter++) {
-      if (tid < 64) {
-        wave_ldlt7_solve(s, s.lambda);
-        if (tid == 0) lm_finish(s, IC);
+      if (tid == 0) {
+        lane_ldlt7_solve(s, s.lambda);
+        lm_finish(s, IC);
       }
       __syncthreads();
       PH_ADD(3);
@@ -1066,6 +1187,7 @@ struct EvalArgs {
   int level;
   hso_se3 T;
   float a, huber, outlier;
+  int keep_keys;
 };
 
 template <bool IC>
@@ -1081,7 +1203,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_eval(TrackConsts C, const Track
   begin_level(s, L, C, job, sc, ea.level, lds_img);
   const Se3 T0 = s.T; const float a0 = s.a;
   if (ea.huber <= 0) {
-    select_robust(s, L, (LdsPtr)lds_img, T0, a0);
+    select_robust(s, L, (LdsPtr)lds_img, T0, a0, ea.keep_keys != 0);
   } else {
     if (threadIdx.x == 0) { s.huber = ea.huber; s.outlier = ea.outlier; }
     __syncthreads();
@@ -1126,6 +1248,7 @@ __global__ void k_make_depth_ref(const hso_depth_ref_in* in, int n, const hso_se
 
 struct TrackBatchState {
   TrackConsts C;
+  TrackLevel lv[HSO_N_PYR_LEVELS];
   int n_jobs = 0, n_max = 0, grid = 0;
   size_t lds_bytes = 0, scratch_stride = 0;
   TrackJobDev* d_jobs = nullptr; size_t jobs_cap = 0;
@@ -1222,17 +1345,19 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   TrackConsts& C = st->C;
   C.cam = *cam;
   C.inverse = p->inverse_composition; C.max_level = p->max_level; C.min_level = p->min_level; C.n_iter = p->n_iter;
-  C.g = g;
   C.n_max = (n_max + 31) & ~31;
   for (int l = 0; l < HSO_N_PYR_LEVELS; l++) {
+    TrackLevel& V = st->lv[l];
     const int pi = p->max_level - l + PATTERN_OFFSET;  // CoarseTracker.cpp:80
-    C.pa[l] = 0; C.pad[l] = 0;
-    for (int k = 0; k < TRK_MAX_PA; k++) C.poff[l][k] = 0;
+    V.w = g.w[l]; V.h = g.h[l]; V.off = g.off[l];
+    V.pa = 0; V.pad = 0;
+    for (int k = 0; k < TRK_MAX_PA; k++) V.poff[k] = 0;
     if (pi < 0 || pi > 7) continue;
-    C.pa[l] = h_pattern_num[pi]; C.pad[l] = h_pattern_pad[pi];
-    for (int k = 0; k < h_pattern_num[pi]; k++) C.poff[l][k] = h_pattern[pi][k][1] * g.w[l] + h_pattern[pi][k][0];
+    V.pa = h_pattern_num[pi]; V.pad = h_pattern_pad[pi];
+    for (int k = 0; k < h_pattern_num[pi]; k++) V.poff[k] = h_pattern[pi][k][1] * g.w[l] + h_pattern[pi][k][0];
   }
   C.lds_img_cap = kImgCap;
+  if (const char* e = getenv("HSO_LDS_IMG_CAP")) C.lds_img_cap = atoi(e);  // experiment knob
   st->lds_bytes = (size_t)kImgCap + sizeof(Shared);
   st->n_jobs = n_jobs;
   st->n_max = C.n_max;
@@ -1242,7 +1367,10 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   if (int rc = grow(ctx, &st->d_jobs, &st->jobs_cap, sizeof(TrackJobDev) * n_jobs)) return rc;
   if (int rc = grow(ctx, &st->d_scratch, &st->scratch_cap, st->scratch_stride * st->grid)) return rc;
   if (int rc = grow(ctx, &st->d_results, &st->results_cap, sizeof(hso_track_result) * n_jobs)) return rc;
-  if (!st->d_counter) HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&st->d_counter), 256));
+  // one small allocation: [0, 256) the job counter, [256, ...) the level table
+  if (!st->d_counter) HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&st->d_counter), 256 + sizeof(st->lv)));
+  C.lv = reinterpret_cast<const TrackLevel*>(reinterpret_cast<const char*>(st->d_counter) + 256);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(const_cast<TrackLevel*>(C.lv), st->lv, sizeof(st->lv), hipMemcpyHostToDevice, ctx->stream));
   if (!st->d_eval) HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&st->d_eval), sizeof(hso_eval_out)));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_feats, st->h_feats.data(), total_feats * 6 * sizeof(double),
                                     hipMemcpyHostToDevice, ctx->stream));
@@ -1321,6 +1449,7 @@ int hso_gpu_tracker_eval(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   TrackBatchState* st = ctx->track;
   EvalArgs ea;
   ea.level = level; ea.T = *T_cur_ref; ea.a = exposure_rat; ea.huber = huber_thresh; ea.outlier = outlier_thresh;
+  ea.keep_keys = abs_err_out ? 1 : 0;
   if (st->C.inverse)
     hipLaunchKernelGGL(k_eval<true>, dim3(1), dim3(TRK_THREADS), st->lds_bytes, ctx->stream, st->C, st->d_jobs, ea,
                        st->d_scratch, st->d_eval);
