@@ -449,7 +449,10 @@ template <int NB>
 HSO_DEV void scan_find(const unsigned* hist, unsigned& rank, unsigned& bin, unsigned& count)
 {
   constexpr int SEG = NB / 64;
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
+  // opaque to the optimiser: without this the 8 inlined copies share hoisted LDS addresses, which
+  // then get spilled and are re-read from scratch inside the loops below
+  asm volatile("" : "+v"(lane));
   unsigned local = 0;
   for (int j = 0; j < SEG; j++) local += hist[lane * SEG + ((j + lane) & (SEG - 1))];  // rotated start: spreads the banks
   unsigned incl = local;
@@ -497,7 +500,8 @@ HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_
 #else
 #define KSEL_T(i) do { } while (0)
 #endif
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // see scan_find
   unsigned rank = k, bin = 0, count = 0;
   if (!round_a_done) {
     sel_zero(s, 256 * SEL_REP);
@@ -553,18 +557,6 @@ struct MemKeys {
 template <typename KeyFn>
 HSO_DEV MemKeys<KeyFn> mem_keys(int n_slots, KeyFn fn) { return MemKeys<KeyFn>{ n_slots, fn }; }
 
-// keys owned by the thread that computed them (registers, or private scratch if they spill)
-template <int NK>
-struct RegKeys {
-  const uint32_t (&k)[NK];
-  template <typename F>
-  HSO_DEV void each(F f) const
-  {
-#pragma unroll
-    for (int u = 0; u < NK; u++) f(k[u]);
-  }
-};
-
 HSO_DEV void set_thresholds(Shared& s, float med, uint32_t mad_bits)
 {
   if (threadIdx.x == 0) {
@@ -578,82 +570,15 @@ HSO_DEV void set_thresholds(Shared& s, float med, uint32_t mad_bits)
   __syncthreads();
 }
 
-// selectRobustFunctionLevel for the common shape — one thread per feature (S == 1) and
-// n <= SEL_REG_ROUNDS * TRK_THREADS: the |residual| keys stay with the thread that computed them
-// (no key array in memory), and the exponent histogram of the median is filled while they are
-// being produced.
-#define SEL_REG_ROUNDS 3
-template <int PA, typename Ptr>
-HSO_DEV void select_robust_reg(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
+// selectRobustFunctionLevel, CoarseTracker.cpp:530-644
+HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
 {
-  constexpr int NK = SEL_REG_ROUNDS * PA;
-  uint32_t key[NK];
-  const int nm = L.C->n_max, border = s.pad + 1, stride = L.cols;
-  int cnt = 0;
-#ifdef HSO_PHASE_TIMERS
+#ifdef HSO_SEL_PROBE
   unsigned long long sel_t = __builtin_readcyclecounter();
 #define SELR_T(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[k] += n_ - sel_t; sel_t = n_; } } while (0)
 #else
 #define SELR_T(k) do { } while (0)
 #endif
-  sel_zero(s, 256 * SEL_REP);
-#pragma unroll
-  for (int r = 0; r < SEL_REG_ROUNDS; r++) {
-    const int f = r * TRK_THREADS + (int)threadIdx.x;
-    const FeatRaw raw = load_feature(L, f);
-    const Proj p = project_feature(L, T, raw, border);
-#pragma unroll
-    for (int pidx = 0; pidx < PA; pidx++) {
-      uint32_t kk = KEY_INVALID;
-      if (p.ok) {
-        const int a0 = p.base + s.poff[pidx];
-        const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
-        const float cur = ((p.w_tl * b1f(r1) + p.w_tr * b2f(r1)) + p.w_bl * b1f(r2)) + p.w_br * b2f(r2);
-        const float res = cur - a * L.sc.ref_patch[(size_t)pidx * nm + f];
-        kk = __float_as_uint(fabsf(res));
-        sel_count_a(s, kk);
-      }
-      key[r * PA + pidx] = kk;
-    }
-    if (p.ok) cnt += PA;
-  }
-  const int n_err = block_sum_int(s, cnt);
-  SELR_T(5);
-  if (threadIdx.x == 0) s.n_select = n_err;
-  if (n_err < 30) {
-    if (threadIdx.x == 0) { s.huber = 5.2f; s.outlier = 100.f; }
-    __syncthreads();
-    return;
-  }
-  const float med = __uint_as_float(select_kth(s, (unsigned)(n_err / 2), RegKeys<NK>{ key }, true));
-  SELR_T(6);
-#pragma unroll
-  for (int u = 0; u < NK; u++)
-    if (key[u] != KEY_INVALID) key[u] = __float_as_uint(fabsf(__uint_as_float(key[u]) - med));
-  const uint32_t mad_bits = select_kth(s, (unsigned)(n_err / 2), RegKeys<NK>{ key }, false);
-#ifdef HSO_SEL_PROBE
-  SELR_T(6);
-  {
-    const uint32_t again = select_kth(s, (unsigned)(n_err / 2), RegKeys<NK>{ key }, false);
-    if (again != mad_bits && threadIdx.x == 0) s.n_select = -1;
-  }
-#endif
-  set_thresholds(s, med, mad_bits);
-  SELR_T(7);
-}
-
-// selectRobustFunctionLevel, CoarseTracker.cpp:530-644.  keep_keys: the parity hook wants the
-// |residual| array in memory (hso_gpu_tracker_eval's abs_err_out).
-HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a, bool keep_keys = false)
-{
-  if (!keep_keys && s.S == 1 && s.use_lds && L.job->n <= SEL_REG_ROUNDS * TRK_THREADS) {
-    switch (s.PA) {
-      case 9: select_robust_reg<9, LdsPtr>(s, L, lds_img, T, a); return;
-      case 13: select_robust_reg<13, LdsPtr>(s, L, lds_img, T, a); return;
-      case 21: select_robust_reg<21, LdsPtr>(s, L, lds_img, T, a); return;
-      default: break;
-    }
-  }
   sel_zero(s, 256 * SEL_REP);
   int n_err;
   if (s.S == 1) {
@@ -664,6 +589,7 @@ HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
   const int n_slots = L.job->n * s.PA;
   const uint32_t* keys = L.sc.keys;
   if (threadIdx.x == 0) s.n_select = n_err;
+  SELR_T(5);
   if (n_err < 30) {
     if (threadIdx.x == 0) { s.huber = 5.2f; s.outlier = 100.f; }
     __syncthreads();
@@ -671,11 +597,13 @@ HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
   }
   const uint32_t med_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(n_slots, [&](int i) { return keys[i]; }), true);
   const float med = __uint_as_float(med_bits);
+  SELR_T(6);
   const uint32_t mad_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(n_slots, [&](int i) {
     const uint32_t k = keys[i];
     return (k == KEY_INVALID) ? KEY_INVALID : __float_as_uint(fabsf(__uint_as_float(k) - med));
   }), false);
   set_thresholds(s, med, mad_bits);
+  SELR_T(7);
 }
 
 // ------------------------------------------ residuals + normal equations
@@ -706,10 +634,10 @@ HSO_DEV TermIn load_term(const LevelCtx& L, const Shared& s, Ptr img, const floa
     t.dxr = t.dyr = 0;
   } else {
     t.r0 = t.r3 = 0;
-    t.dxr = L.sc.ref_dx[(size_t)pidx * nm + f];
-    t.dyr = L.sc.ref_dy[(size_t)pidx * nm + f];
+    t.dxr = L.sc.ref_dx[(uint32_t)(pidx * nm + f)];
+    t.dyr = L.sc.ref_dy[(uint32_t)(pidx * nm + f)];
   }
-  t.iref = rp[(size_t)pidx * nm];
+  t.iref = rp[(uint32_t)(pidx * nm + f)];  // 32-bit offset from a uniform base: saddr + voffset addressing
   return t;
 }
 
@@ -723,7 +651,7 @@ HSO_DEV Moments feature_terms(const Shared& s, const LevelCtx& L, Ptr img, const
   m.ee = m.ex = m.ey = m.xx = m.xy = m.yy = m.re = m.rx = m.ry = 0; m.E = 0; m.nt = 0; m.nsat = 0;
   if (!p.ok) return m;
   const int nm = L.C->n_max;
-  const float* rp = L.sc.ref_patch + f;
+  const float* rp = L.sc.ref_patch;  // uniform base
   int pidx = sub;
   if (pidx >= PA) return m;
   TermIn nx = load_term<IC>(L, s, img, rp, p.base, pidx, nm, f);
@@ -735,7 +663,9 @@ HSO_DEV Moments feature_terms(const Shared& s, const LevelCtx& L, Ptr img, const
     const float cur = ((p.w_tl * p11 + p.w_tr * p12) + p.w_bl * p21) + p.w_br * p22;
     const float res = cur - a * t.iref;
     const float ares = fabsf(res);
-    const float hw = ares < huber ? 1.0f : huber / ares;
+    // The Huber weight only enters tolerance-compared sums (E, H, b), never a decision: one
+    // v_rcp_f32 (1 ulp) and a multiply instead of the ten-instruction IEEE division
+    const float hw = ares < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ares);
     // cutoff_error = m_outlier_thresh is a float value, so the reference's double compare (:350)
     // equals this float compare
     const bool sat = (ares > outlier) && !top;
@@ -1187,7 +1117,6 @@ struct EvalArgs {
   int level;
   hso_se3 T;
   float a, huber, outlier;
-  int keep_keys;
 };
 
 template <bool IC>
@@ -1203,7 +1132,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_eval(TrackConsts C, const Track
   begin_level(s, L, C, job, sc, ea.level, lds_img);
   const Se3 T0 = s.T; const float a0 = s.a;
   if (ea.huber <= 0) {
-    select_robust(s, L, (LdsPtr)lds_img, T0, a0, ea.keep_keys != 0);
+    select_robust(s, L, (LdsPtr)lds_img, T0, a0);
   } else {
     if (threadIdx.x == 0) { s.huber = ea.huber; s.outlier = ea.outlier; }
     __syncthreads();
@@ -1449,7 +1378,6 @@ int hso_gpu_tracker_eval(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   TrackBatchState* st = ctx->track;
   EvalArgs ea;
   ea.level = level; ea.T = *T_cur_ref; ea.a = exposure_rat; ea.huber = huber_thresh; ea.outlier = outlier_thresh;
-  ea.keep_keys = abs_err_out ? 1 : 0;
   if (st->C.inverse)
     hipLaunchKernelGGL(k_eval<true>, dim3(1), dim3(TRK_THREADS), st->lds_bytes, ctx->stream, st->C, st->d_jobs, ea,
                        st->d_scratch, st->d_eval);
