@@ -83,6 +83,7 @@ struct TrackConsts {
   int inverse, max_level, min_level, n_iter;
   int lds_img_cap;    // bytes of LDS available for the staged level image
   int n_max;          // scratch stride (features)
+  int keys_in_memory; // parity hook: leave the |residual| keys in the scratch buffer (abs_err_out)
   const TrackLevel* lv;  // [HSO_N_PYR_LEVELS], device memory
 };
 
@@ -135,6 +136,7 @@ struct Shared {
   int level, PA, pad, S;
   int job, stop, n_select;
   int use_lds;
+  int keys_lds_off;                  // byte offset of the level's key array in LDS, 0 = keys in memory
   unsigned sel[4096];                // selection histogram (SEL_WORDS)
   int wave_cnt[TRK_WAVES];
   int poff[32];                      // byte offset oy*stride+ox of every pattern pixel of this level
@@ -396,8 +398,8 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
 // in-bounds term, stored as float bit patterns (KEY_INVALID elsewhere).  Returns errors.size().
 HSO_DEV void sel_count_a(Shared& s, uint32_t kk);
 
-template <bool S1, typename Ptr>
-HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
+template <bool S1, typename Ptr, typename KP>
+HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a, KP kdst)
 {
   const int n = L.job->n, nm = L.C->n_max;
   const int PA = s.PA, border = s.pad + 1, S = S1 ? 1 : s.S;
@@ -424,7 +426,7 @@ HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, 
         sel_count_a(s, key);  // round A of the median select, fused (select_robust zeroed the bins)
         cnt++;
       }
-      L.sc.keys[(size_t)pidx * n + f] = key;
+      kdst[pidx * n + f] = key;
     }
   }
   return block_sum_int(s, cnt);
@@ -536,26 +538,42 @@ HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_
   return prefix;
 }
 
-// keys in memory (the |residual| array of select_collect), optionally transformed on the fly;
-// eight loads per thread in flight so they do not queue behind the LDS atomics
-template <typename KeyFn>
+// keys in memory or LDS (the |residual| array of select_collect), optionally transformed on the
+// fly; read as 16-byte vectors, four per thread in flight, so a pass is a handful of wide loads
+// instead of dozens of dependent dword loads
+typedef __attribute__((address_space(3))) uint32_t* LdsKeys;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename KP> struct Vec4Ptr;
+template <> struct Vec4Ptr<uint32_t*> { typedef const u32x4* type; };
+template <> struct Vec4Ptr<LdsKeys> { typedef const __attribute__((address_space(3))) u32x4* type; };
+
+template <typename KP, typename Xf>
 struct MemKeys {
+  KP keys;
   int n_slots;
-  KeyFn key_of;
+  Xf xf;
   template <typename F>
   HSO_DEV void each(F f) const
   {
-    for (int i0 = threadIdx.x; i0 < n_slots; i0 += TRK_THREADS * 8) {
-      uint32_t kk[8];
+    typedef typename Vec4Ptr<KP>::type V4;
+    const V4 kv = (V4)keys;
+    const int nvec = n_slots >> 2;
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += TRK_THREADS * 4) {
+      u32x4 q[4];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + u * TRK_THREADS; kk[u] = (i < n_slots) ? key_of(i) : KEY_INVALID; }
+      for (int u = 0; u < 4; u++) {
+        const int v = v0 + u * TRK_THREADS;
+        if (v < nvec) q[u] = kv[v];
+        else q[u] = (u32x4)(KEY_INVALID);
+      }
 #pragma unroll
-      for (int u = 0; u < 8; u++) f(kk[u]);
+      for (int u = 0; u < 4; u++) { f(xf(q[u].x)); f(xf(q[u].y)); f(xf(q[u].z)); f(xf(q[u].w)); }
     }
+    if ((int)threadIdx.x < (n_slots & 3)) f(xf(keys[(nvec << 2) + (int)threadIdx.x]));
   }
 };
-template <typename KeyFn>
-HSO_DEV MemKeys<KeyFn> mem_keys(int n_slots, KeyFn fn) { return MemKeys<KeyFn>{ n_slots, fn }; }
+template <typename KP, typename Xf>
+HSO_DEV MemKeys<KP, Xf> mem_keys(KP keys, int n_slots, Xf xf) { return MemKeys<KP, Xf>{ keys, n_slots, xf }; }
 
 HSO_DEV void set_thresholds(Shared& s, float med, uint32_t mad_bits)
 {
@@ -571,7 +589,8 @@ HSO_DEV void set_thresholds(Shared& s, float med, uint32_t mad_bits)
 }
 
 // selectRobustFunctionLevel, CoarseTracker.cpp:530-644
-HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
+template <typename KP>
+HSO_DEV void select_robust_k(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a, KP keys)
 {
 #ifdef HSO_SEL_PROBE
   unsigned long long sel_t = __builtin_readcyclecounter();
@@ -582,12 +601,11 @@ HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
   sel_zero(s, 256 * SEL_REP);
   int n_err;
   if (s.S == 1) {
-    n_err = s.use_lds ? select_collect<true, LdsPtr>(s, L, lds_img, T, a) : select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a);
+    n_err = s.use_lds ? select_collect<true, LdsPtr>(s, L, lds_img, T, a, keys) : select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a, keys);
   } else {
-    n_err = s.use_lds ? select_collect<false, LdsPtr>(s, L, lds_img, T, a) : select_collect<false, GlbPtr>(s, L, L.cur_glb, T, a);
+    n_err = s.use_lds ? select_collect<false, LdsPtr>(s, L, lds_img, T, a, keys) : select_collect<false, GlbPtr>(s, L, L.cur_glb, T, a, keys);
   }
   const int n_slots = L.job->n * s.PA;
-  const uint32_t* keys = L.sc.keys;
   if (threadIdx.x == 0) s.n_select = n_err;
   SELR_T(5);
   if (n_err < 30) {
@@ -595,15 +613,26 @@ HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
     __syncthreads();
     return;
   }
-  const uint32_t med_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(n_slots, [&](int i) { return keys[i]; }), true);
+  const uint32_t med_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(keys, n_slots, [](uint32_t k) { return k; }), true);
   const float med = __uint_as_float(med_bits);
   SELR_T(6);
-  const uint32_t mad_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(n_slots, [&](int i) {
-    const uint32_t k = keys[i];
+  const uint32_t mad_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(keys, n_slots, [med](uint32_t k) {
     return (k == KEY_INVALID) ? KEY_INVALID : __float_as_uint(fabsf(__uint_as_float(k) - med));
   }), false);
   set_thresholds(s, med, mad_bits);
   SELR_T(7);
+}
+
+// The |residual| keys of a level live in LDS above the staged image when they fit (levels 4..2 of
+// a 2000-feature VGA frame: <= 104 KB), else in the workgroup's scratch in memory.
+HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
+{
+  if (s.keys_lds_off > 0) {
+    LdsKeys kl = (LdsKeys)lds_img + (s.keys_lds_off >> 2);
+    select_robust_k<LdsKeys>(s, L, lds_img, T, a, kl);
+  } else {
+    select_robust_k<uint32_t*>(s, L, lds_img, T, a, L.sc.keys);
+  }
 }
 
 // ------------------------------------------ residuals + normal equations
@@ -863,7 +892,12 @@ HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const Tra
   else precompute_reference<GlbPtr>(s, L, L.ref_glb);
   __syncthreads();
   const bool cur_in_lds = stage_image(L, job.cur_base + V.off, lds_img);
-  if (threadIdx.x == 0) s.use_lds = cur_in_lds ? 1 : 0;
+  if (threadIdx.x == 0) {
+    s.use_lds = cur_in_lds ? 1 : 0;
+    const size_t padded = (size_t)((L.cols * L.rows + L.cols + 32 + 15) & ~15);
+    const size_t need = (size_t)job.n * (size_t)V.pa * 4;
+    s.keys_lds_off = (cur_in_lds && !C.keys_in_memory && padded + need <= (size_t)C.lds_img_cap) ? (int)padded : 0;
+  }
   __syncthreads();
 }
 
@@ -1286,6 +1320,7 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
     for (int k = 0; k < h_pattern_num[pi]; k++) V.poff[k] = h_pattern[pi][k][1] * g.w[l] + h_pattern[pi][k][0];
   }
   C.lds_img_cap = kImgCap;
+  C.keys_in_memory = 0;
   if (const char* e = getenv("HSO_LDS_IMG_CAP")) C.lds_img_cap = atoi(e);  // experiment knob
   st->lds_bytes = (size_t)kImgCap + sizeof(Shared);
   st->n_jobs = n_jobs;
@@ -1376,6 +1411,7 @@ int hso_gpu_tracker_eval(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   int rc = track_prepare(ctx, cam, params, job, 1, 1);
   if (rc < 0) return rc;
   TrackBatchState* st = ctx->track;
+  st->C.keys_in_memory = abs_err_out ? 1 : 0;
   EvalArgs ea;
   ea.level = level; ea.T = *T_cur_ref; ea.a = exposure_rat; ea.huber = huber_thresh; ea.outlier = outlier_thresh;
   if (st->C.inverse)
