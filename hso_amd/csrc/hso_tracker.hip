@@ -342,19 +342,26 @@ HSO_DEV int block_sum_int(Shared& s, int v)
 
 // ------------------------------------------------------------- level set-up
 
-// copy one level image (+ the zero row below it) into LDS; false if it does not fit
+// copy one level image (+ the zero row below it) into LDS; false if it does not fit.
+// gfx950 LDS-DMA: each wavefront moves 1 KiB per instruction straight from memory into LDS
+// (global_load_lds_dwordx4: per-lane source address, destination = uniform base + lane * 16),
+// no staging registers and no ds_write pass; the loads of all chunks are in flight together
+// and the barrier that follows drains them.
 HSO_DEV bool stage_image(const LevelCtx& L, const uint8_t* src, uint32_t* lds_img)
 {
   const int bytes = L.cols * L.rows;
   const int padded = (bytes + L.cols + 32 + 15) & ~15;
   if (padded > L.C->lds_img_cap) return false;
-  const uint4* s4 = reinterpret_cast<const uint4*>(src);
-  uint4* d4 = reinterpret_cast<uint4*>(lds_img);
-  for (int i = threadIdx.x; i < padded / 16; i += TRK_THREADS) d4[i] = s4[i];
+  typedef __attribute__((address_space(3))) uint8_t* LdsBytes;
+  typedef const __attribute__((address_space(1))) uint8_t* GlbBytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave * 1024; c < padded; c += TRK_WAVES * 1024) {
+    const int off = c + lane * 16;
+    if (off < padded) __builtin_amdgcn_global_load_lds((GlbBytes)(src + off), (LdsBytes)lds_img + c, 16, 0, 0);
+  }
   return true;
 }
 
-// precomputeReferencePatches, CoarseTracker.cpp:416-497.  Thread per (feature, pixel).
 template <typename Ptr>
 HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
 {
@@ -363,31 +370,38 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
   const int PA = s.PA, border = s.pad + 1;
   const bool ic = L.C->inverse != 0;
   const int stride = L.cols;
-  for (int i = threadIdx.x; i < n * PA; i += TRK_THREADS) {
-    const int f = i % n, pidx = i / n;
+  // one thread per feature (S lanes share a feature when the table is small): position and
+  // bilinear weights once, then the pattern pixels
+  const int S = s.S, G = TRK_THREADS / S;
+  const int sub = (int)threadIdx.x % S, grp = (int)threadIdx.x / S;
+  for (int f = grp; f < n; f += G) {
     const float u_ref = (float)(J.feats[0 * ns + f] * (double)L.scale);
     const float v_ref = (float)(J.feats[1 * ns + f] * (double)L.scale);
     const int u_i = (int)floorf(u_ref), v_i = (int)floorf(v_ref);
     const double dist = J.feats[5 * ns + f];
     const bool vis = dist >= 0 && !(u_i - border < 0 || v_i - border < 0 || u_i + border >= L.cols || v_i + border >= L.rows);
-    if (pidx == 0) L.sc.visible[f] = vis ? 1 : 0;
+    if (sub == 0) L.sc.visible[f] = vis ? 1 : 0;
     if (!vis) continue;
     const float su = u_ref - (float)u_i, sv = v_ref - (float)v_i;
     const float w_tl = (float)((1.0 - su) * (1.0 - sv));
     const float w_tr = (float)(su * (1.0 - sv));
     const float w_bl = (float)((1.0 - su) * sv);
     const float w_br = (float)(1.0 - ((w_tl + w_tr) + w_bl));
-    const int a0 = v_i * stride + u_i - 1 + s.poff[pidx];
-    const uint32_t r1 = fetch4(ref32, a0), r2 = fetch4(ref32, a0 + stride);
-    L.sc.ref_patch[(size_t)pidx * nm + f] = ((w_tl * b1f(r1) + w_tr * b2f(r1)) + w_bl * b1f(r2)) + w_br * b2f(r2);
-    if (ic) {
-      const uint32_t r0 = fetch4(ref32, a0 - stride), r3 = fetch4(ref32, a0 + 2 * stride);
-      const float dx = 0.5f * ((((w_tl * b2f(r1) + w_tr * b3f(r1)) + w_bl * b2f(r2)) + w_br * b3f(r2))
-                             - (((w_tl * b0f(r1) + w_tr * b1f(r1)) + w_bl * b0f(r2)) + w_br * b1f(r2)));
-      const float dy = 0.5f * ((((w_tl * b1f(r2) + w_tr * b2f(r2)) + w_bl * b1f(r3)) + w_br * b2f(r3))
-                             - (((w_tl * b1f(r0) + w_tr * b2f(r0)) + w_bl * b1f(r1)) + w_br * b2f(r1)));
-      L.sc.ref_dx[(size_t)pidx * nm + f] = dx;
-      L.sc.ref_dy[(size_t)pidx * nm + f] = dy;
+    const int base = v_i * stride + u_i - 1;
+    for (int pidx = sub; pidx < PA; pidx += S) {
+      const int a0 = base + s.poff[pidx];
+      const uint32_t o = (uint32_t)(pidx * nm + f);
+      const uint32_t r1 = fetch4(ref32, a0), r2 = fetch4(ref32, a0 + stride);
+      L.sc.ref_patch[o] = ((w_tl * b1f(r1) + w_tr * b2f(r1)) + w_bl * b1f(r2)) + w_br * b2f(r2);
+      if (ic) {
+        const uint32_t r0 = fetch4(ref32, a0 - stride), r3 = fetch4(ref32, a0 + 2 * stride);
+        const float dx = 0.5f * ((((w_tl * b2f(r1) + w_tr * b3f(r1)) + w_bl * b2f(r2)) + w_br * b3f(r2))
+                               - (((w_tl * b0f(r1) + w_tr * b1f(r1)) + w_bl * b0f(r2)) + w_br * b1f(r2)));
+        const float dy = 0.5f * ((((w_tl * b1f(r2) + w_tr * b2f(r2)) + w_bl * b1f(r3)) + w_br * b2f(r3))
+                               - (((w_tl * b1f(r0) + w_tr * b2f(r0)) + w_bl * b1f(r1)) + w_br * b2f(r1)));
+        L.sc.ref_dx[o] = dx;
+        L.sc.ref_dy[o] = dy;
+      }
     }
   }
 }
