@@ -96,69 +96,102 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrGeom g, uint8_t* const* base
 
 // -------------------------------------------------------------------- Sobel
 
-#define SOB_TW 64
-#define SOB_TH 16
+#define SOB_STRIP 15           // rows per lane
+#define SOB_TW 64              // wavefront tile: 16 lanes x 4 pixels wide,
+#define SOB_TH (4 * SOB_STRIP) //                 4 lane groups x SOB_STRIP rows high (60: divides 480, 240, 120)
+#define SOB_WAVES 4            // tiles (wavefronts) per block
 
 // cv::Sobel(CV_16S, ksize 5, BORDER_REPLICATE) for levels 0..2 (src/frame.cpp:216-220):
 // derivative [-1 -2 0 2 1], smoothing [1 4 6 4 1], separable, exact integers.
 // Level-0 blocks also emit one (sum intensity, sum |grad|) partial each over the
 // 16-px-margin interior (src/frame.cpp:223-236).
+//
+// No LDS: a lane owns four adjacent output pixels of a 15-row strip; a wavefront covers a
+// 64 x 60 tile (16 lanes across, 4 strips down), so VGA / EuRoC levels tile without remainder.
+// Per source row a lane reads three dwords (bytes x-4 .. x+7, shared with its neighbours through
+// L1), forms the horizontal derivative / smoothing sums of its four columns, keeps them in a
+// five-row register window and emits one output row per input row: two 8-byte stores per lane =
+// one full 128-byte line per 16 lanes (the previous LDS version stored 2 bytes per lane).  The
+// strip loop is fully unrolled so the window is indexed statically.
 __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
 {
-  __shared__ uint8_t s_src[SOB_TH + 4][SOB_TW + 4];
-  __shared__ short s_hd[SOB_TH + 4][SOB_TW];
-  __shared__ short s_hs[SOB_TH + 4][SOB_TW];
   __shared__ double s_part[4][2];
-
   int b = blockIdx.x, level = 0;
   while (level < HSO_N_SOBEL_LEVELS - 1 && b >= g.sobel_blocks[level]) { b -= g.sobel_blocks[level]; level++; }
   const int W = g.w[level], H = g.h[level];
-  const int bx = b % g.sobel_bx[level], by = b / g.sobel_bx[level];
-  const int x0 = bx * SOB_TW, y0 = by * SOB_TH;
   uint8_t* base = bases[blockIdx.y];
   const uint8_t* img = base + g.off[level];
-  const int t = threadIdx.x;
-
-  for (int i = t; i < (SOB_TH + 4) * (SOB_TW + 4); i += 256) {
-    const int ly = i / (SOB_TW + 4), lx = i % (SOB_TW + 4);
-    int yy = y0 + ly - 2, xx = x0 + lx - 2;
-    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-    xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-    s_src[ly][lx] = img[(size_t)yy * W + xx];
-  }
-  __syncthreads();
-  const int tx = t & 63, tg = t >> 6;
-  for (int r = tg * 5; r < tg * 5 + 5; r++) {
-    const int p0 = s_src[r][tx], p1 = s_src[r][tx + 1], p2 = s_src[r][tx + 2], p3 = s_src[r][tx + 3], p4 = s_src[r][tx + 4];
-    s_hd[r][tx] = (short)(-p0 - 2 * p1 + 2 * p3 + p4);
-    s_hs[r][tx] = (short)(p0 + 4 * p1 + 6 * p2 + 4 * p3 + p4);
-  }
-  __syncthreads();
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int tile = b * SOB_WAVES + wv;  // tiles of a level in row-major order, SOB_WAVES per block
+  const int tiles_x = g.sobel_bx[level];
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int x = tx * SOB_TW + (lane & 15) * 4;
+  const int ys = ty * SOB_TH + (lane >> 4) * SOB_STRIP;
   int16_t* gx = reinterpret_cast<int16_t*>(base + g.sob_off[level][0]);
   int16_t* gy = reinterpret_cast<int16_t*>(base + g.sob_off[level][1]);
   unsigned isum = 0;
   double gsum = 0;
-  const int x = x0 + tx;
+  if (x < W && ys < H) {  // W is a multiple of 4 on levels 0..2: a lane's four pixels are all in or all out
+    const bool fast = (x >= 4) && (x + 8 <= W);
+    int hd[5][4], hs[5][4], cen[5][4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int ry = tg * 4 + k;
-    const int y = y0 + ry;
-    const int sx = s_hd[ry][tx] + 4 * s_hd[ry + 1][tx] + 6 * s_hd[ry + 2][tx] + 4 * s_hd[ry + 3][tx] + s_hd[ry + 4][tx];
-    const int sy = -s_hs[ry][tx] - 2 * s_hs[ry + 1][tx] + 2 * s_hs[ry + 3][tx] + s_hs[ry + 4][tx];
-    if (x < W && y < H) {
-      gx[(size_t)y * W + x] = (int16_t)sx;
-      gy[(size_t)y * W + x] = (int16_t)sy;
-      if (level == 0 && x >= 16 && x < W - 16 && y >= 16 && y < H - 16) {
-        const float fx = (float)sx, fy = (float)sy;
-        gsum += (double)sqrtf(fx * fx + fy * fy);
-        isum += s_src[ry + 2][tx + 2];
+    for (int i = 0; i < SOB_STRIP + 4; i++) {
+      int yy = ys + i - 2;
+      yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+      const uint8_t* row = img + (size_t)yy * W;
+      int p[8];  // columns x-2 .. x+5
+      if (fast) {
+        const uint32_t* r32 = reinterpret_cast<const uint32_t*>(row + x - 4);
+        const uint32_t d0 = r32[0], d1 = r32[1], d2 = r32[2];
+        p[0] = (d0 >> 16) & 255; p[1] = d0 >> 24;
+        p[2] = d1 & 255; p[3] = (d1 >> 8) & 255; p[4] = (d1 >> 16) & 255; p[5] = d1 >> 24;
+        p[6] = d2 & 255; p[7] = (d2 >> 8) & 255;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          int xx = x - 2 + k;
+          xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+          p[k] = row[xx];
+        }
+      }
+      const int sl = i % 5;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        hd[sl][k] = -p[k] - 2 * p[k + 1] + 2 * p[k + 3] + p[k + 4];
+        hs[sl][k] = p[k] + 4 * p[k + 1] + 6 * p[k + 2] + 4 * p[k + 3] + p[k + 4];
+        cen[sl][k] = p[k + 2];
+      }
+      if (i >= 4) {
+        const int y = ys + i - 4;
+        const int ra = (i - 4) % 5, rb = (i - 3) % 5, rc = (i - 2) % 5, rd = (i - 1) % 5, re = i % 5;
+        if (y < H) {
+          int sx[4], sy[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            sx[k] = hd[ra][k] + 4 * hd[rb][k] + 6 * hd[rc][k] + 4 * hd[rd][k] + hd[re][k];
+            sy[k] = -hs[ra][k] - 2 * hs[rb][k] + 2 * hs[rd][k] + hs[re][k];
+          }
+          uint2 vx, vy;
+          vx.x = (uint32_t)(sx[0] & 0xffff) | ((uint32_t)sx[1] << 16); vx.y = (uint32_t)(sx[2] & 0xffff) | ((uint32_t)sx[3] << 16);
+          vy.x = (uint32_t)(sy[0] & 0xffff) | ((uint32_t)sy[1] << 16); vy.y = (uint32_t)(sy[2] & 0xffff) | ((uint32_t)sy[3] << 16);
+          *reinterpret_cast<uint2*>(gx + (size_t)y * W + x) = vx;
+          *reinterpret_cast<uint2*>(gy + (size_t)y * W + x) = vy;
+          if (level == 0 && x >= 16 && x < W - 16 && y >= 16 && y < H - 16) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const float fx = (float)sx[k], fy = (float)sy[k];
+              gsum += (double)sqrtf(fx * fx + fy * fy);
+              isum += (unsigned)cen[rc][k];
+            }
+          }
+        }
       }
     }
   }
   if (level == 0) {
     double is = wave_sum_to_lane63((double)isum);
     double gs = wave_sum_to_lane63(gsum);
-    if (tx == 63) { s_part[tg][0] = is; s_part[tg][1] = gs; }
+    if (lane == 63) { s_part[wv][0] = is; s_part[wv][1] = gs; }
     __syncthreads();
     if (t == 0) {
       double* part = reinterpret_cast<double*>(base + g.part_off);
@@ -218,8 +251,8 @@ PyrGeom make_geom(int w, int h)
   }
   g.pyr_bytes = off;
   for (int l = 0; l < HSO_N_SOBEL_LEVELS; l++) {
-    g.sobel_bx[l] = (g.w[l] + SOB_TW - 1) / SOB_TW;
-    g.sobel_blocks[l] = g.sobel_bx[l] * ((g.h[l] + SOB_TH - 1) / SOB_TH);
+    g.sobel_bx[l] = (g.w[l] + SOB_TW - 1) / SOB_TW;  // tiles per row
+    g.sobel_blocks[l] = (g.sobel_bx[l] * ((g.h[l] + SOB_TH - 1) / SOB_TH) + SOB_WAVES - 1) / SOB_WAVES;
     for (int k = 0; k < 2; k++) {
       g.sob_off[l][k] = off;
       off += ((uint32_t)g.w[l] * g.h[l] * 2u + 255u) & ~255u;
