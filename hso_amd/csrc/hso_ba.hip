@@ -14,8 +14,9 @@
 //                weight; the 29-double linearisation is written once (coalesced SoA).
 //   k_ba_points  thread per point: walks its edges (CSR built on the host, edge order kept) ->
 //                Hpp, bp and the 1x6 point-pose blocks.
-//   k_ba_poses   workgroup per pose pair (i <= j): strided pass over the edges, 36 (+6) partial
-//                sums per thread, fixed-tree reduction -> the 6x6 block (and b_i on the diagonal).
+//   k_ba_poses   workgroup per pose pair (i <= j): strided pass over the pair's own edges (CSR
+//                built on the host), 36 (+6) partial sums per thread, fixed-tree reduction -> the
+//                6x6 block (and b_i on the diagonal).
 // The reference accumulates serially in edge order in fp64; the tree order differs by rounding
 // (parity tolerance 1e-11 relative).  Sizes are small (<= ~15 poses, a few hundred points,
 // 1-3 k edges): latency-bound; throughput comes from issuing many keyframes' problems on one stream.
@@ -190,7 +191,11 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaArgs a, const int* p
   Hpp[p] = hpp; bp[p] = b;
 }
 
-__global__ __launch_bounds__(BA_THREADS) void k_ba_poses(BaArgs a, double* Hcc, double* bc, double* chi2_sum)
+// pr_off / pr_edges: CSR of the edges that touch each block's pose pair (host-built, edge order
+// kept): diagonal block i lists every edge with host == i or target == i, block (i, j) every edge
+// whose two frames are {i, j} — a block reads only its own edges instead of scanning all of them.
+__global__ __launch_bounds__(BA_THREADS) void k_ba_poses(BaArgs a, const int* pr_off, const int* pr_edges, double* Hcc, double* bc,
+                                                         double* chi2_sum)
 {
   __shared__ double s_part[BA_WAVES][44];
   // block -> (i, j), i <= j; one extra block sums the chi2 values
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(BaArgs a, double* Hcc, 
   int b = blockIdx.x, i = 0;
   const int n_pairs = np * (np + 1) / 2;
   const bool chi_block = (b == n_pairs);
+  const int q0 = chi_block ? 0 : pr_off[b], q1 = chi_block ? 0 : pr_off[b + 1];
   int j = 0;
   if (!chi_block) { while (b >= np - i) { b -= np - i; i++; } j = i + b; }
   double acc[44];
@@ -206,7 +212,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(BaArgs a, double* Hcc, 
   if (chi_block) {
     for (int k = threadIdx.x; k < a.n_edges; k += BA_THREADS) { acc[0] += a.edge_chi2[k]; acc[1] += a.edge_rho[k]; }
   } else if (!a.fixed[i] && !a.fixed[j]) {
-    for (int k = threadIdx.x; k < a.n_edges; k += BA_THREADS) {
+    for (int q = q0 + (int)threadIdx.x; q < q1; q += BA_THREADS) {
+      const int k = pr_edges[q];
       const hso_ba_edge& e = a.edges[k];
       const int h = e.host, t = e.target;
       if (i == j) {
@@ -278,6 +285,25 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   for (int p = 0; p < n_points; p++) off[p + 1] += off[p];
   { std::vector<int> cur(off.begin(), off.end() - 1); for (int k = 0; k < n_edges; k++) list[cur[edges[k].point]++] = k; }
 
+  // CSR of edges by pose-pair block (same block numbering as k_ba_poses), edge order kept
+  const int n_pairs = n_poses * (n_poses + 1) / 2;
+  auto pair_id = [n_poses](int i, int j) { return i * n_poses - i * (i - 1) / 2 + (j - i); };  // i <= j
+  std::vector<int> poff(n_pairs + 1, 0), plist((size_t)3 * n_edges);
+  for (int k = 0; k < n_edges; k++) {
+    const int h_ = edges[k].host, t_ = edges[k].target;
+    poff[pair_id(h_, h_) + 1]++; poff[pair_id(t_, t_) + 1]++;
+    poff[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_) + 1]++;
+  }
+  for (int q = 0; q < n_pairs; q++) poff[q + 1] += poff[q];
+  {
+    std::vector<int> cur(poff.begin(), poff.end() - 1);
+    for (int k = 0; k < n_edges; k++) {
+      const int h_ = edges[k].host, t_ = edges[k].target;
+      plist[cur[pair_id(h_, h_)]++] = k; plist[cur[pair_id(t_, t_)]++] = k;
+      plist[cur[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_)]++] = k;
+    }
+  }
+
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   size_t o = 0;
   const size_t o_poses = o; o += al(sizeof(hso_se3) * n_poses);
@@ -286,6 +312,8 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   const size_t o_edges = o; o += al(sizeof(hso_ba_edge) * n_edges);
   const size_t o_off = o; o += al(sizeof(int) * (n_points + 1));
   const size_t o_list = o; o += al(sizeof(int) * n_edges);
+  const size_t o_poff = o; o += al(sizeof(int) * (n_pairs + 1));
+  const size_t o_plist = o; o += al(sizeof(int) * 3 * (size_t)n_edges);
   const size_t in_bytes = o;
   const size_t o_lin = o; o += al(sizeof(double) * BA_LIN * n_edges);
   const size_t o_rho = o; o += al(sizeof(double) * n_edges);
@@ -298,8 +326,14 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   const size_t o_err = o; o += al(sizeof(double) * 2 * n_edges);
   const size_t o_chi = o; o += al(sizeof(double) * n_edges);
   const size_t o_sum = o; o += 256;
-  char* d = nullptr;
-  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&d), o));
+  if (ctx->batch_cap < o) {  // grow-only staging buffer of the context (shared with the other batched entry points)
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), o));
+    ctx->batch_cap = o;
+  }
+  char* d = reinterpret_cast<char*>(ctx->d_batch);
   std::vector<char> h(in_bytes, 0);
   memcpy(h.data() + o_poses, poses_f_w, sizeof(hso_se3) * n_poses);
   memcpy(h.data() + o_fixed, pose_fixed, n_poses);
@@ -307,6 +341,8 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   memcpy(h.data() + o_edges, edges, sizeof(hso_ba_edge) * n_edges);
   memcpy(h.data() + o_off, off.data(), sizeof(int) * (n_points + 1));
   memcpy(h.data() + o_list, list.data(), sizeof(int) * n_edges);
+  memcpy(h.data() + o_poff, poff.data(), sizeof(int) * (n_pairs + 1));
+  memcpy(h.data() + o_plist, plist.data(), sizeof(int) * 3 * (size_t)n_edges);
   hipError_t e = hipMemcpyAsync(d, h.data(), in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(d + o_out, 0, o - o_out, ctx->stream);
   if (e == hipSuccess) {
@@ -321,7 +357,8 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
     hipLaunchKernelGGL(k_ba_points, dim3((n_points + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, a,
                        reinterpret_cast<const int*>(d + o_off), reinterpret_cast<const int*>(d + o_list),
                        reinterpret_cast<double*>(d + o_Hpp), reinterpret_cast<double*>(d + o_bp), reinterpret_cast<double*>(d + o_Hpc));
-    hipLaunchKernelGGL(k_ba_poses, dim3(n_poses * (n_poses + 1) / 2 + 1), dim3(BA_THREADS), 0, ctx->stream, a,
+    hipLaunchKernelGGL(k_ba_poses, dim3(n_pairs + 1), dim3(BA_THREADS), 0, ctx->stream, a,
+                       reinterpret_cast<const int*>(d + o_poff), reinterpret_cast<const int*>(d + o_plist),
                        reinterpret_cast<double*>(d + o_Hcc), reinterpret_cast<double*>(d + o_bc), reinterpret_cast<double*>(d + o_sum));
     e = hipGetLastError();
   }
@@ -335,7 +372,6 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   back(edge_chi2, o_chi, sizeof(double) * n_edges);
   back(chi2_sum, o_sum, sizeof(double) * 2);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d);
   if (e != hipSuccess) { ctx->err = std::string("ba_linearize: ") + hipGetErrorString(e); return HSO_E_HIP; }
   return HSO_OK;
 }

@@ -1,0 +1,88 @@
+"""Timing of the later pipeline stages at keyframe-sized batches:
+reprojection matching, pose optimisation, seed observation, seed activation and BA linearisation.
+
+Prints one JSON object per stage: wall time of the C-ABI call (includes the host<->device copies
+of the job / result records and the stream synchronise the ABI performs) and the work done per
+call.  Run it under `rocprofv3 --kernel-trace --stats` (profiles/collect_r1.sh does) to get the
+kernel-only durations that go with these numbers.  Development / measurement tool: it is not part
+of the product path and uses no CPU reference.
+
+    python -m hso_amd.stage_bench [--reps 20]
+"""
+import argparse
+import json
+import math
+import time
+
+import numpy as np
+
+from hso_amd import capi, synth
+
+
+def timed(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--candidates", type=int, default=2000)
+    ap.add_argument("--seeds", type=int, default=900)
+    ap.add_argument("--pose-frames", type=int, default=256)
+    args = ap.parse_args()
+    ctx = capi.Context(0)
+    cam = synth.camera()
+    out = []
+
+    # a11-a14: one frame's reprojection candidates in one call
+    pair = synth.config2_pair(2000, trans_frac=0.03)
+    ctx.frame_upload(1, pair["ref"]); ctx.frame_upload(2, pair["cur"])
+    gy0, gx0 = np.gradient(pair["ref"].astype(np.float64))
+    jobs = synth.align_jobs(pair, args.candidates, 1, gx=gx0, gy=gy0)
+    dt = timed(lambda: ctx.align_batch(cam, 2, jobs), args.reps)
+    ok = sum(o.success for o in ctx.align_batch(cam, 2, jobs))
+    out.append(dict(stage="align_batch (findMatchDirect)", units="candidates", n=len(jobs), ms_per_call=dt * 1e3,
+                    units_per_s=len(jobs) / dt, matched=ok))
+
+    # a16-a17: one active frame against all seeds
+    seeds, T_cur, feats = synth.seeds_for_pair(pair, args.seeds, 1, gx=gx0, gy=gy0)
+    pea = math.atan(1.0 / (2.0 * 480.6)) * 2.0
+    dt = timed(lambda: ctx.seed_observe(cam, 2, T_cur, 1.05, pea, seeds), args.reps)
+    ok = sum(o.result == 1 for o in ctx.seed_observe(cam, 2, T_cur, 1.05, pea, seeds))
+    out.append(dict(stage="seed_observe (observeDepthRow/doLineStereo)", units="seeds", n=len(seeds), ms_per_call=dt * 1e3,
+                    units_per_s=len(seeds) / dt, matched=ok))
+    ctx.frame_release(1); ctx.frame_release(2)
+
+    # a18: activation of converged seeds against 8 observing frames
+    P = synth.activation_problem(n_seeds=300, n_targets=8)
+    ctx.frame_upload(P["host_frame_id"], P["host"])
+    for t, f in zip(P["targets"], P["frames"]):
+        ctx.frame_upload(t.frame_id, f)
+    dt = timed(lambda: ctx.seed_activate(cam, P["seeds"], P["per_seed"], 6), args.reps)
+    act = sum(o.activated for o in ctx.seed_activate(cam, P["seeds"], P["per_seed"], 6))
+    n_pairs = sum(len(t) for t in P["per_seed"])
+    out.append(dict(stage="seed_activate (activatePoint/seedOptimizer)", units="seed-target pairs", n=n_pairs,
+                    ms_per_call=dt * 1e3, units_per_s=n_pairs / dt, activated=act))
+
+    # a15: a batch of frames, 300 features each
+    feats_p, poses, T0, _ = synth.pose_problem(300, seed=5)
+    pj = [capi.make_pose_job(feats_p, poses, T0) for _ in range(args.pose_frames)]
+    dt = timed(lambda: ctx.pose_optimize_batch(cam, pj), max(args.reps // 4, 2))
+    out.append(dict(stage="pose_optimize_batch (LM3rd)", units="frames", n=len(pj), ms_per_call=dt * 1e3,
+                    units_per_s=len(pj) / dt))
+
+    # a19: one local BA window
+    bposes, fixed, idist, edges = synth.ba_problem(9, 3000, 5, seed=9)
+    dt = timed(lambda: ctx.ba_linearize(bposes, fixed, idist, edges, 1.0, 0.7), args.reps)
+    out.append(dict(stage="ba_linearize", units="edges", n=len(edges), ms_per_call=dt * 1e3, units_per_s=len(edges) / dt))
+
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()
