@@ -181,6 +181,35 @@ def test_tracker_eval_euroc_radtan(gpu_ctx, orc):
     assert rot <= 1e-6 and tra <= 4e-6
 
 
+def test_tracker_large_table_and_fov_camera(gpu_ctx, orc, cam):
+    """3000 features (more rounds per thread than the benchmark shape, keys in memory on every
+    level) and the FOV / ATAN camera model of the TUM-mono configuration (camera.cpp:196-221)."""
+    d = synth.config2_pair(3000, seed=77)
+    upload_pair(gpu_ctx, d, (7, 8))
+    rp, cp = orc.create_pyramid(d["ref"]), orc.create_pyramid(d["cur"])
+    p = capi.TrackParams(0, 4, 1, 50)
+    job = gpu_ctx.make_job(7, 8, d["feats"], capi.SE3.identity(), 1.0)
+    ro = orc.Tracker(cam, p, rp, cp, d["feats"]).run(capi.SE3.identity(), 1.0)
+    rg = gpu_ctx.coarse_track_batch(cam, p, [job])[0]
+    assert list(rg.iters) == list(ro.iters) and list(rg.accept_mask) == list(ro.accept_mask)
+    assert list(rg.n_select) == list(ro.n_select) and rg.huber[4] == ro.huber[4]
+    assert (rg.n_tracked, rg.n_terms_last, rg.n_saturated_last) == (ro.n_tracked, ro.n_terms_last, ro.n_saturated_last)
+    rot, tra = pose_err(rg, ro)
+    assert rot <= 1e-6 and tra <= 4e-6
+    # FOV camera: the bearings come from a pinhole scene, so this is a parity case, not a tracking case
+    camF = capi.make_camera(capi.CAM_FOV, 640, 480, 300.0, 300.0, 319.5, 239.5, d=(0.9, 0, 0, 0, 0), distortion=1)
+    tr = orc.Tracker(camF, p, rp, cp, d["feats"][:1500])
+    jobF = gpu_ctx.make_job(7, 8, d["feats"][:1500], capi.SE3.identity(), 1.0)
+    for level in (3, 1):
+        tr.set_level(level)
+        n, hu, ou, _ = tr.select(capi.SE3.identity(), 1.0)
+        eo = tr.eval(capi.SE3.identity(), 1.0)
+        go, _, _, _ = gpu_ctx.tracker_eval(camF, p, jobF, level, capi.SE3.identity(), 1.0)
+        assert (go.huber, go.outlier, go.n_select) == (hu, ou, n) and n > 1000
+        assert (go.n_terms, go.n_saturated) == (eo.n_terms, eo.n_saturated)
+        assert np.abs(np.array(eo.H[:]) - np.array(go.H[:])).max() <= H_TOL * np.abs(np.array(eo.H[:])).max()
+
+
 # ------------------------------------------------------------------ tracker: full run
 @pytest.mark.parametrize("inv", [0, 1], ids=["forward", "inverse_comp"])
 def test_coarse_track_run_parity(gpu_ctx, orc, cam, pair2000, inv):
