@@ -9,10 +9,10 @@
 // MI355X mapping: the reference visits a seed's <=30 target frames one after another on the
 // mapping thread.  Here kernel 1 gives every (seed, target) pair its own wavefront (projection,
 // parallax test and the 8x8 Lucas-Kanade of findMatchSeed, lane = patch pixel — the same
-// device body as the reprojection matcher), and kernel 2 gives every seed one thread that
-// applies the gates and runs the scalar LM *serially in fp64 in the reference's order*, so its
-// sums carry the reference's rounding (the only non-IEEE step is pow(x,3) in the damping
-// update).  The optimiser state is a handful of doubles per seed; there is nothing to tile.
+// device body as the reprojection matcher), and kernel 2 gives every seed one wavefront with
+// lane = target frame: residuals and Jacobians of all targets are evaluated in parallel, the
+// sums over targets are formed in the reference's order (see k_activate_opt), so they carry the
+// reference's rounding (the only non-IEEE step is pow(x,3) in the damping update).
 #include "hso_match_dev.h"
 #include <string.h>
 #include <vector>
@@ -122,136 +122,165 @@ __global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(Act
   if (lane == 0) pout[pid] = o;
 }
 
-// residual of one matched target at inverse depth `id`: obs - project2d(Tth * f/id)
-__device__ inline void act_residual(const hso_seed& S, const ActPair& P, double id, double& r0, double& r1, double pT[3])
+// ---- kernel 2: gates + DepthFilter::seedOptimizer, one wavefront per seed, lane = target frame.
+// Every lane keeps its target's transform / observation in registers and evaluates its own
+// residual and Jacobian; the sums the reference forms in a serial loop over the targets are formed
+// in the same order by walking the lanes 0..n-1 with a broadcast each (unmatched lanes contribute
+// an exact 0.0), so H, b and the energies carry the reference's rounding.
+HSO_DEV double act_bcast(double v, int src)
+{
+  const int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+HSO_DEV double act_ordered_sum(double x, int n)
+{
+  double s = 0;
+  for (int i = 0; i < n; i++) s += act_bcast(x, i);
+  return s;
+}
+
+struct ActLane {   // one target frame of the seed, in this lane's registers
+  bool matched;
+  Se3 T;
+  double obs0, obs1, n0, n1;
+};
+
+// this lane's residual at inverse depth `id`: obs - project2d(Tth * f/id); pT = the transformed point
+HSO_DEV void act_residual(const hso_seed& S, const ActLane& A, double id, double& r0, double& r1, double pT[3])
 {
   const double sc = 1.0 / id;
-  const Se3 T = se3_from(P.Tth);
-  se3_apply(T, S.f[0] * sc, S.f[1] * sc, S.f[2] * sc, pT[0], pT[1], pT[2]);
-  r0 = P.obs[0] - pT[0] / pT[2]; r1 = P.obs[1] - pT[1] / pT[2];
+  se3_apply(A.T, S.f[0] * sc, S.f[1] * sc, S.f[2] * sc, pT[0], pT[1], pT[2]);
+  r0 = A.obs0 - pT[0] / pT[2]; r1 = A.obs1 - pT[1] / pT[2];
 }
 
-__device__ inline double act_energy(const hso_seed& S, const ActPair* P, int n, double id, double huberTH)
+// this lane's robust energy term (0 for an unmatched lane)
+HSO_DEV double act_energy_term(const hso_seed& S, const ActLane& A, bool edge, double id, double huberTH)
 {
-  double E = 0;
-  const bool edge = S.type == HSO_FTR_EDGELET;
-  for (int i = 0; i < n; i++) {
-    if (!P[i].matched) continue;
-    double r0, r1, pT[3];
-    act_residual(S, P[i], id, r0, r1, pT);
-    if (edge) {
-      const double re = P[i].normal[0] * r0 + P[i].normal[1] * r1;
-      const double a = (double)fabsf((float)re);
-      const double hw = a < huberTH ? 1 : huberTH / a;
-      E += re * re * hw;
-    } else {
-      const double rd = sqrt(r0 * r0 + r1 * r1);
-      const double hw = rd < huberTH ? 1 : huberTH / rd;
-      E += rd * rd * hw;
-    }
+  if (!A.matched) return 0.0;
+  double r0, r1, pT[3];
+  act_residual(S, A, id, r0, r1, pT);
+  if (edge) {
+    const double re = A.n0 * r0 + A.n1 * r1;
+    const double ab = (double)fabsf((float)re);
+    const double hw = ab < huberTH ? 1 : huberTH / ab;
+    return re * re * hw;
   }
-  return E;
+  const double rd = sqrt(r0 * r0 + r1 * r1);
+  const double hw = rd < huberTH ? 1 : huberTH / rd;
+  return rd * rd * hw;
 }
 
-__global__ __launch_bounds__(64) void k_activate_opt(ActConsts C, const ActSeedDev* seeds, int n_seeds, const ActPair* pairs,
-                                                     int n_mean_converge_frame, hso_activate_out* outs)
+#define ACT_OPT_WAVES 4
+__global__ __launch_bounds__(64 * ACT_OPT_WAVES) void k_activate_opt(ActConsts C, const ActSeedDev* seeds, int n_seeds,
+                                                                     const ActPair* pairs, int n_mean_converge_frame,
+                                                                     hso_activate_out* outs)
 {
-  const int sid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int sid = blockIdx.x * ACT_OPT_WAVES + (threadIdx.x >> 6);
   if (sid >= n_seeds) return;
   const ActSeedDev& SD = seeds[sid];
   const hso_seed& S = SD.s;
-  const ActPair* P = pairs + SD.first;
-  const int n = SD.count;
+  const int n = SD.count;  // <= HSO_ACTIVATE_MAX_TARGETS = 64
   hso_activate_out o;
   memset(&o, 0, sizeof(o));
   o.is_valid = -1;
   o.opt_id = (double)S.mu;
-  int n_targets = 0, n_res = 0;
-  for (int i = 0; i < n; i++) { n_targets += P[i].is_target; n_res += P[i].matched; }
+  ActLane A;
+  A.matched = false; A.obs0 = A.obs1 = A.n0 = A.n1 = 0;
+  A.T.qx = A.T.qy = A.T.qz = 0; A.T.qw = 1; A.T.tx = A.T.ty = A.T.tz = 0;
+  bool is_target = false;
+  double err = 0;  // this target's drift (:791-806)
+  const bool edge = S.type == HSO_FTR_EDGELET;
+  if (lane < n) {
+    const ActPair& P = pairs[SD.first + lane];
+    is_target = P.is_target != 0;
+    A.matched = P.matched != 0;
+    if (A.matched) {
+      A.T = se3_from(P.Tth);
+      A.obs0 = P.obs[0]; A.obs1 = P.obs[1]; A.n0 = P.normal[0]; A.n1 = P.normal[1];
+      const double d0 = P.px[0] - P.mo.px_cur[0], d1 = P.px[1] - P.mo.px_cur[1];
+      err = edge ? fabs(A.n0 * d0 + A.n1 * d1) : sqrt(d0 * d0 + d1 * d1);
+      err /= (double)(1 << P.mo.search_level);
+    }
+  }
+  const int n_targets = __popcll(__ballot(is_target)), n_res = __popcll(__ballot(A.matched));
   o.n_targets = n_targets;
   float n_frame_thresh = (float)((double)n_mean_converge_frame * 0.7);
   if (n_frame_thresh > 8) n_frame_thresh = 8;
   if (n_frame_thresh < 3) n_frame_thresh = 3;
-  if ((float)n_targets < n_frame_thresh) { outs[sid] = o; return; }
+  if ((float)n_targets < n_frame_thresh) { if (lane == 0) outs[sid] = o; return; }
   o.n_matched = n_res;
-  const bool edge = S.type == HSO_FTR_EDGELET;
-  double distMean = 0;
-  for (int i = 0; i < n; i++) {
-    if (!P[i].matched) continue;
-    const double d0 = P[i].px[0] - P[i].mo.px_cur[0], d1 = P[i].px[1] - P[i].mo.px_cur[1];
-    double err = edge ? fabs(P[i].normal[0] * d0 + P[i].normal[1] * d1) : sqrt(d0 * d0 + d1 * d1);
-    err /= (double)(1 << P[i].mo.search_level);
-    distMean += err;
-  }
-  if ((float)n_res < n_frame_thresh) { outs[sid] = o; return; }
+  double distMean = act_ordered_sum(err, n);
+  if ((float)n_res < n_frame_thresh) { if (lane == 0) outs[sid] = o; return; }
   distMean /= (double)n_res;
   o.dist_mean = distMean;
-  if ((!edge && distMean > 3.2) || (edge && distMean > 2.5)) { o.is_valid = 0; outs[sid] = o; return; }
+  if ((!edge && distMean > 3.2) || (edge && distMean > 2.5)) { o.is_valid = 0; if (lane == 0) outs[sid] = o; return; }
   o.is_valid = 1;
-  if ((!edge && distMean > 2.5) || (edge && distMean > 2.0)) { outs[sid] = o; return; }
+  if ((!edge && distMean > 2.5) || (edge && distMean > 2.0)) { if (lane == 0) outs[sid] = o; return; }
 
   // ---- seedOptimizer (:853-1073)
   double old_id = (double)S.mu;
-  // MAD scale: 1.4826f * the element of rank floor(n/2) of the float |residual|s (robust_cost.cpp:67-74)
+  // MAD scale: 1.4826f * the element of rank floor(n/2) of the float |residual|s (robust_cost.cpp:67-74),
+  // by rank counting: every lane ranks its own value against the others
   double huberTH;
   {
-    const int k = n_res / 2;
-    float errs[HSO_ACTIVATE_MAX_TARGETS];
-    int m = 0;
-    for (int i = 0; i < n; i++) {
-      if (!P[i].matched) continue;
+    float e = 0;
+    if (A.matched) {
       double r0, r1, pT[3];
-      act_residual(S, P[i], old_id, r0, r1, pT);
-      errs[m++] = edge ? (float)fabs(P[i].normal[0] * r0 + P[i].normal[1] * r1) : (float)sqrt(r0 * r0 + r1 * r1);
+      act_residual(S, A, old_id, r0, r1, pT);
+      e = edge ? (float)fabs(A.n0 * r0 + A.n1 * r1) : (float)sqrt(r0 * r0 + r1 * r1);
     }
-    float med = 0;
-    for (int i = 0; i < m; i++) {
-      int lt = 0, le = 0;
-      for (int j = 0; j < m; j++) { lt += errs[j] < errs[i]; le += errs[j] <= errs[i]; }
-      if (lt <= k && k < le) { med = errs[i]; break; }
+    int lt = 0, le = 0;
+    for (int j = 0; j < n; j++) {
+      const float ej = __shfl(e, j);
+      const int mj = __shfl(A.matched ? 1 : 0, j);
+      lt += (mj && ej < e) ? 1 : 0; le += (mj && ej <= e) ? 1 : 0;
     }
+    const int k = n_res / 2;
+    const unsigned long long hit = __ballot(A.matched && lt <= k && k < le);
+    const float med = hit ? __shfl(e, __ffsll((long long)hit) - 1) : 0.0f;
     huberTH = (double)(1.4826f * med);
   }
   o.huber = huberTH;
-  double oldEnergy = act_energy(S, P, n, old_id, huberTH);
+  double oldEnergy = act_ordered_sum(act_energy_term(S, A, edge, old_id, huberTH), n);
   double rho = 0, mu = 0.1, nu = 2.0;
   bool stop = false;
   int iter;
   for (iter = 0; iter < 5; ++iter) {
     int n_trials = 0;
     do {
-      double new_id = old_id, newEnergy = 0, Hh = 0, b = 0;
-      for (int i = 0; i < n; i++) {
-        if (!P[i].matched) continue;
+      double new_id = old_id, newEnergy = 0;
+      double h_i = 0, b_i = 0;  // this lane's contributions
+      if (A.matched) {
         double r0, r1, pT[3];
-        act_residual(S, P[i], old_id, r0, r1, pT);
-        const double n0 = P[i].normal[0], n1 = P[i].normal[1];
+        act_residual(S, A, old_id, r0, r1, pT);
         // Point::jacobian_id2uv(pTarget, Tth, old_id, f), point.h:174-184
-        const Se3 T = se3_from(P[i].Tth);
         double R[9];
-        so3_matrix(T, R);
+        so3_matrix(A.T, R);
         const double Rf2 = R[6] * S.f[0] + R[7] * S.f[1] + R[8] * S.f[2];
-        const double J0 = -(T.tx - (pT[0] / pT[2]) * T.tz) / (Rf2 + T.tz * old_id);
-        const double J1 = -(T.ty - (pT[1] / pT[2]) * T.tz) / (Rf2 + T.tz * old_id);
+        const double J0 = -(A.T.tx - (pT[0] / pT[2]) * A.T.tz) / (Rf2 + A.T.tz * old_id);
+        const double J1 = -(A.T.ty - (pT[1] / pT[2]) * A.T.tz) / (Rf2 + A.T.tz * old_id);
         if (edge) {
-          const double re = n0 * r0 + n1 * r1;
-          const double a = (double)fabsf((float)re);
-          const double hw = a < huberTH ? 1 : huberTH / a;
-          const double JE = n0 * J0 + n1 * J1;
-          Hh += JE * JE * hw;
-          b -= JE * re * hw;
+          const double re = A.n0 * r0 + A.n1 * r1;
+          const double ab = (double)fabsf((float)re);
+          const double hw = ab < huberTH ? 1 : huberTH / ab;
+          const double JE = A.n0 * J0 + A.n1 * J1;
+          h_i = JE * JE * hw;
+          b_i = JE * re * hw;
         } else {
           const double rd = sqrt(r0 * r0 + r1 * r1);
           const double hw = rd < huberTH ? 1 : huberTH / rd;
-          Hh += (J0 * J0 + J1 * J1) * hw;
-          b -= (J0 * r0 + J1 * r1) * hw;
+          h_i = (J0 * J0 + J1 * J1) * hw;
+          b_i = (J0 * r0 + J1 * r1) * hw;
         }
       }
+      double Hh = 0, b = 0;
+      for (int i = 0; i < n; i++) { Hh += act_bcast(h_i, i); b -= act_bcast(b_i, i); }  // H += ..., b -= ... (:951-967)
       Hh *= 1.0 + mu;
       const double step = b / Hh;
       if (!isnan(step)) {
         new_id = old_id + step;
-        newEnergy = act_energy(S, P, n, new_id, huberTH);
+        newEnergy = act_ordered_sum(act_energy_term(S, A, edge, new_id, huberTH), n);
         rho = oldEnergy - newEnergy;
       } else {
         rho = -1;
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(64) void k_activate_opt(ActConsts C, const ActSeedD
   o.energy = oldEnergy;
   o.n_iter = iter < 5 ? iter + 1 : 5;
   o.activated = 1;
-  outs[sid] = o;
+  if (lane == 0) outs[sid] = o;
 }
 
 extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
@@ -337,7 +366,7 @@ extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, co
     hipLaunchKernelGGL(k_activate_match, dim3(blocks), dim3(64 * ACT_WAVES_PER_BLOCK), 0, ctx->stream, C, d_seeds, d_pin, n_pairs, d_pout);
     HSO_HIP_CHECK(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_activate_opt, dim3((n_seeds + 63) / 64), dim3(64), 0, ctx->stream, C, d_seeds, n_seeds, d_pout,
+  hipLaunchKernelGGL(k_activate_opt, dim3((n_seeds + ACT_OPT_WAVES - 1) / ACT_OPT_WAVES), dim3(64 * ACT_OPT_WAVES), 0, ctx->stream, C, d_seeds, n_seeds, d_pout,
                      n_mean_converge_frame, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_seeds * sizeof(hso_activate_out), hipMemcpyDeviceToHost, ctx->stream));

@@ -412,8 +412,8 @@ typedef struct hso_activate_out {
  * n_mean_converge_frame: DepthFilter::nMeanConvergeFrame_.  match_out (optional, one per target):
  * the findMatchSeed result of every visited target (zero where no match was attempted).
  * Kernel 1: one wavefront per (seed, target) runs the projection test, the parallax test and
- * findMatchSeed; kernel 2: one thread per seed applies the gates and the 1-D LM serially in
- * fp64 in the reference's order. */
+ * findMatchSeed; kernel 2: one wavefront per seed (lane = target) applies the gates and runs the
+ * 1-D LM in fp64, summing over the targets in the reference's order. */
 int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
                           const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
                           hso_activate_out* out, hso_align_out* match_out);
