@@ -142,4 +142,151 @@ size_t CoarseTracker::run(FramePtr ref, FramePtr cur)
   return (size_t)m_last.n_tracked;  // :207
 }
 
+// ---------------------------------------------------------------- Matcher
+static Vector3d sub(const Vector3d& a, const Vector3d& b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+static double norm(const Vector3d& a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
+bool Point::getCloseViewObs(const Vector3d& framepos, Feature*& ftr) const
+{
+  Vector3d obs_dir = sub(framepos, pos_);
+  { const double n = norm(obs_dir); for (double& c : obs_dir) c /= n; }
+  auto min_it = obs_.begin();
+  double min_cos_angle = 0;
+  for (auto it = obs_.begin(), ite = obs_.end(); it != ite; ++it) {
+    Vector3d dir = sub((*it)->frame->pos(), pos_);
+    { const double n = norm(dir); for (double& c : dir) c /= n; }
+    const double cos_angle = obs_dir[0] * dir[0] + obs_dir[1] * dir[1] + obs_dir[2] * dir[2];
+    if (cos_angle > min_cos_angle) { min_cos_angle = cos_angle; min_it = it; }
+  }
+  ftr = *min_it;
+  return !(min_cos_angle < 0.5);
+}
+
+// flatten (Point, chosen reference feature, current frame) the way findMatchDirect reads them
+static hso_align_job make_align_job(const Point& pt, const Feature* ref, const Frame& cur, const Vector2d& px_cur)
+{
+  hso_align_job j{};
+  j.ref_frame_id = ref->frame->id_;
+  j.ref_level = ref->level;
+  j.type = (int)ref->type;
+  j.px_ref[0] = ref->px[0]; j.px_ref[1] = ref->px[1];
+  j.f_ref[0] = ref->f[0]; j.f_ref[1] = ref->f[1]; j.f_ref[2] = ref->f[2];
+  j.grad[0] = ref->grad[0]; j.grad[1] = ref->grad[1];
+  // depth along the reference bearing, src/matcher.cpp:295-306
+  j.depth = (ref->frame->id_ == pt.hostFeature_->frame->id_) ? 1.0 / pt.idist_ : norm(sub(ref->frame->pos(), pt.pos_));
+  j.T_cur_ref = (cur.T_f_w_ * ref->frame->T_f_w_.inverse()).v;
+  j.px_cur[0] = px_cur[0]; j.px_cur[1] = px_cur[1];
+  j.exposure_rat = (float)(cur.m_exposure_time / ref->frame->m_exposure_time);
+  j.kf_gap_lt4 = (cur.keyFrameId_ - ref->frame->keyFrameId_ < 4) ? 1 : 0;
+  return j;
+}
+
+std::vector<hso_align_out> Matcher::findMatchDirectBatch(const std::vector<const Point*>& pts, Frame& cur,
+                                                         const std::vector<Vector2d>& px_cur, std::vector<Feature*>* ref_ftrs)
+{
+  std::vector<hso_align_out> out(pts.size());
+  std::vector<hso_align_job> jobs;
+  std::vector<size_t> slot;
+  if (ref_ftrs) ref_ftrs->assign(pts.size(), nullptr);
+  for (size_t i = 0; i < pts.size(); i++) {
+    out[i] = hso_align_out{};
+    out[i].px_cur[0] = px_cur[i][0]; out[i].px_cur[1] = px_cur[i][1];
+    Feature* ref = nullptr;
+    if (pts[i]->obs_.empty() || !pts[i]->getCloseViewObs(cur.pos(), ref)) continue;  // :276-286
+    if (ref_ftrs) (*ref_ftrs)[i] = ref;
+    jobs.push_back(make_align_job(*pts[i], ref, cur, px_cur[i]));
+    slot.push_back(i);
+  }
+  if (!jobs.empty()) {
+    std::vector<hso_align_out> res(jobs.size());
+    const int rc = hso_gpu_align_batch(cur.ctx_, &cur.cam_->pod(), cur.id_, jobs.data(), (int)jobs.size(), res.data());
+    if (rc < 0) throw std::runtime_error(std::string("Matcher: ") + hso_gpu_last_error(cur.ctx_));
+    for (size_t k = 0; k < jobs.size(); k++) out[slot[k]] = res[k];
+  }
+  return out;
+}
+
+bool Matcher::findMatchDirect(const Point& pt, Frame& cur_frame, Vector2d& px_cur)
+{
+  std::vector<Feature*> refs;
+  const std::vector<hso_align_out> r = findMatchDirectBatch({&pt}, cur_frame, {px_cur}, &refs);
+  last_ = r[0];
+  if (refs[0] == nullptr) return false;
+  ref_ftr_ = refs[0];
+  search_level_ = r[0].search_level;
+  for (int i = 0; i < 4; i++) A_cur_ref_[i] = r[0].A_cur_ref[i];
+  h_inv_ = r[0].h_inv;
+  if (r[0].stage != HSO_ALIGN_REF_BORDER) { px_cur[0] = r[0].px_cur[0]; px_cur[1] = r[0].px_cur[1]; }  // :373
+  return r[0].success != 0;
+}
+
+// ---------------------------------------------------------------- DepthFilter
+Seed::Seed(Feature* ftr_, float depth_mean, float depth_min, float converge_threshold)
+    : ftr(ftr_), mu(1.0f / depth_mean), z_range(1.0f / depth_min), sigma2(z_range * z_range / 36)
+{
+  (void)converge_threshold;
+}
+
+void DepthFilter::updateSeed(float x, float tau2, Seed* seed)
+{
+  float id_var = seed->sigma2 * 1.01f;
+  const float w = tau2 / (tau2 + id_var);
+  const float new_idepth = (1 - w) * x + w * seed->mu;
+  const double nd = new_idepth;
+  seed->mu = (float)(nd < 0 ? (nd > -1e-10 ? -1e-10 : nd) : (nd < 1e-10 ? 1e-10 : nd));
+  id_var *= w;
+  if (id_var < seed->sigma2) seed->sigma2 = id_var;
+}
+
+double DepthFilter::computeTau(const SE3& T_ref_cur, const Vector3d& f, double z, double px_error_angle)
+{
+  const double PI = 3.14159265;  // include/hso/global.h:104
+  const Vector3d t = T_ref_cur.translation();
+  const Vector3d a{f[0] * z - t[0], f[1] * z - t[1], f[2] * z - t[2]};
+  const double t_norm = norm(t), a_norm = norm(a);
+  const double alpha = std::acos((f[0] * t[0] + f[1] * t[1] + f[2] * t[2]) / t_norm);
+  const double beta = std::acos((a[0] * -t[0] + a[1] * -t[1] + a[2] * -t[2]) / (t_norm * a_norm));
+  const double beta_plus = beta + px_error_angle;
+  const double gamma_plus = PI - alpha - beta_plus;
+  const double z_plus = t_norm * std::sin(beta_plus) / std::sin(gamma_plus);
+  return z_plus - z;
+}
+
+size_t DepthFilter::observeDepth(FramePtr frame)
+{
+  std::vector<hso_seed> in;
+  in.reserve(seeds_.size());
+  for (const Seed& s : seeds_) {  // list order = seed index
+    hso_seed h{};
+    h.ref_frame_id = s.ftr->frame->id_;
+    h.level = s.ftr->level; h.type = (int)s.ftr->type;
+    h.px[0] = s.ftr->px[0]; h.px[1] = s.ftr->px[1];
+    h.f[0] = s.ftr->f[0]; h.f[1] = s.ftr->f[1]; h.f[2] = s.ftr->f[2];
+    h.grad[0] = s.ftr->grad[0]; h.grad[1] = s.ftr->grad[1];
+    h.T_ref_w = s.ftr->frame->T_f_w_.v;
+    h.ref_exposure = s.ftr->frame->m_exposure_time;
+    h.mu = s.mu; h.sigma2 = s.sigma2; h.b = s.b;
+    in.push_back(h);
+  }
+  if (in.empty()) return 0;
+  std::vector<hso_seed_out> out(in.size());
+  const int rc = hso_gpu_seed_observe(frame->ctx_, &frame->cam_->pod(), frame->id_, &frame->T_f_w_.v, frame->m_exposure_time,
+                                      px_error_angle_, in.data(), (int)in.size(), out.data());
+  if (rc < 0) throw std::runtime_error(std::string("DepthFilter: ") + hso_gpu_last_error(frame->ctx_));
+  size_t n_ok = 0, k = 0;
+  for (auto it = seeds_.begin(); it != seeds_.end(); ++k) {
+    const hso_seed_out& o = out[k];
+    if (!o.is_valid) { it = seeds_.erase(it); continue; }            // :618-622
+    it->is_update = o.is_update != 0;
+    it->mu = o.mu; it->sigma2 = o.sigma2; it->b = o.b;
+    if (o.result == 1) {                                              // :640-650
+      it->last_matched_px = {o.px_cur[0], o.px_cur[1]};
+      it->last_matched_level = o.search_level;
+      ++n_ok;
+    }
+    ++it;
+  }
+  return n_ok;
+}
+
 }  // namespace hso

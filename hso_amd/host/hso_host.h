@@ -54,6 +54,10 @@ class Point {
 public:
   double idist_ = 1.0;            // inverse depth in the host frame (point.h:115)
   Feature* hostFeature_ = nullptr;
+  Vector3d pos_{0, 0, 0};         // world position (point.h:63)
+  std::list<Feature*> obs_;       // keyframe observations (point.h:66)
+  // src/point.cpp:116-136: the observation whose viewing direction is closest to `framepos`
+  bool getCloseViewObs(const Vector3d& framepos, Feature*& ftr) const;
 };
 
 // include/hso/feature.h:33-60
@@ -84,6 +88,8 @@ public:
   double timestamp_;
   AbstractCamera* cam_;
   SE3 T_f_w_;
+  Vector3d pos() const { return T_f_w_.inverse().translation(); }   // include/hso/frame.h:142
+  int keyFrameId_ = 0;
   Features fts_;                 // owned, deleted by ~Frame (src/frame.cpp:54-72)
   float integralImage_ = 0;      // src/frame.cpp:238
   float gradMean_ = 0;           // src/frame.cpp:240-245
@@ -101,6 +107,47 @@ public:
   bool m_verbose;
   SE3 m_T_cur_ref;
   hso_track_result m_last{};     // per-level diagnostics of the last run
+};
+
+// include/hso/matcher.h:108-215 — reprojection matching of one map point
+class Matcher {
+public:
+  // src/matcher.cpp:270-375.  Chooses the reference observation (getCloseViewObs), then the
+  // warp / Lucas-Kanade / NCC body runs on the device (hso_gpu_align_batch with one job).
+  // px_cur: in = projected position, out = refined position (level-0 pixels).
+  bool findMatchDirect(const Point& pt, Frame& cur_frame, Vector2d& px_cur);
+  // The batched form a Reprojector adapter uses: all candidates of a frame in one launch; the
+  // result array is in candidate order so the caller can apply its first-success-per-cell rule.
+  static std::vector<hso_align_out> findMatchDirectBatch(const std::vector<const Point*>& pts, Frame& cur_frame,
+                                                          const std::vector<Vector2d>& px_cur, std::vector<Feature*>* ref_ftrs);
+  Feature* ref_ftr_ = nullptr;
+  int search_level_ = 0;
+  double A_cur_ref_[4] = {1, 0, 0, 1};
+  double h_inv_ = 0;
+  hso_align_out last_{};
+};
+
+// include/hso/depth_filter.h:45-88
+struct Seed {
+  Feature* ftr = nullptr;        // host feature (frame, px, f, level, type, grad)
+  float a = 10, b = 10;
+  float mu = 0, z_range = 0, sigma2 = 0;
+  bool is_update = false;
+  Vector2d last_matched_px{0, 0};
+  int last_matched_level = 0;
+  Seed(Feature* ftr, float depth_mean, float depth_min, float converge_threshold = 200);  // src/depth_filter.cpp:49-68
+};
+
+class DepthFilter {
+public:
+  explicit DepthFilter(double px_error_angle) : px_error_angle_(px_error_angle) {}
+  // src/depth_filter.cpp:557-675: one observation of every seed in `frame`; seeds whose
+  // z_inv_min turns NaN are erased like :618-622; returns the number of successful matches
+  size_t observeDepth(FramePtr frame);
+  static void updateSeed(float x, float tau2, Seed* seed);                                        // :527-537
+  static double computeTau(const SE3& T_ref_cur, const Vector3d& f, double z, double px_error_angle);  // :539-555
+  std::list<Seed> seeds_;
+  double px_error_angle_;
 };
 
 }  // namespace hso

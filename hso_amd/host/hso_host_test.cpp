@@ -1,7 +1,10 @@
 // hso_host_test.cpp — drives the host mirror the way FrameHandlerMono::processFrame does
 // (src/frame_handler_mono.cpp:173-209): two Frames, features with points hosted in the
-// reference frame, CoarseTracker(...).run(last, new).  Reads a binary case written by
+// reference frame, CoarseTracker(...).run(last, new), then Matcher::findMatchDirect on projected
+// points and one DepthFilter observation of fresh seeds.  Reads a binary case written by
 // tests/test_host_mirror_gpu.py and prints the results as one line of numbers.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -60,6 +63,35 @@ int main(int argc, char** argv)
                 T.q[3], T.t[0], T.t[1], T.t[2], tracker.m_last.exposure_rat, next->m_exposure_time);
     for (int l = 0; l < 5; l++) std::printf(" %d", tracker.m_last.iters[l]);
     std::printf(" %.9g %.9g\n", last->integralImage_, next->integralImage_);
+
+    // ---- reprojection matching the way Reprojector::reprojectCell drives Matcher
+    // (src/reprojector.cpp:352-429): project the point with the tracked pose, refine.
+    const int K = (int)std::min<size_t>(points.size(), 32);
+    std::printf("%d", K);
+    for (int i = 0; i < K; i++) {
+      hso::Point* pt = points[i];
+      const hso::Feature* hf = pt->hostFeature_;
+      const double inv = 1.0 / pt->idist_;
+      pt->pos_ = last->T_f_w_.inverse() * hso::Vector3d{hf->f[0] * inv, hf->f[1] * inv, hf->f[2] * inv};
+      pt->obs_.push_back(pt->hostFeature_);
+      hso::Vector2d px = cam.world2cam(next->T_f_w_ * pt->pos_);
+      hso::Matcher matcher;
+      const bool ok = matcher.findMatchDirect(*pt, *next, px);
+      std::printf(" %d %.12g %.12g %d", ok ? 1 : 0, px[0], px[1], matcher.search_level_);
+    }
+    std::printf("\n");
+
+    // ---- depth filter: seeds on the next 32 features, one observation in the new frame
+    // (src/depth_filter.cpp:557-675); px_error_angle as DepthFilter's constructor derives it (:360-366)
+    hso::DepthFilter df(std::atan(1.0 / (2.0 * cam.errorMultiplier2())) * 2.0);
+    for (int i = K; i < (int)std::min<size_t>(points.size(), 2 * (size_t)K); i++) {
+      hso::Feature* hf = points[i]->hostFeature_;
+      df.seeds_.emplace_back(hf, (float)(1.1 / points[i]->idist_), (float)(0.5 / points[i]->idist_));
+    }
+    const size_t n_seed_ok = df.observeDepth(next);
+    std::printf("%zu %zu", n_seed_ok, df.seeds_.size());
+    for (const hso::Seed& sd : df.seeds_) std::printf(" %.9g %.9g %.9g", sd.mu, sd.sigma2, sd.b);
+    std::printf("\n");
     for (hso::Point* p : points) delete p;
   }
   hso_gpu_destroy(ctx);

@@ -28,7 +28,8 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
         f.write(d["ref"].tobytes()); f.write(d["cur"].tobytes()); f.write(tab.tobytes())
     out = subprocess.run([HOST_EXE, str(case)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    v = out.stdout.split()
+    lines = out.stdout.strip().splitlines()
+    v = lines[0].split()
     threw, n_tracked = int(v[0]), int(v[1])
     q, t = np.array(v[2:6], float), np.array(v[6:9], float)
     a, exposure_time = float(v[9]), float(v[10])
@@ -57,3 +58,55 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
     assert a == pytest.approx(r.exposure_rat, abs=1e-6)
     # write-back rule of CoarseTracker.cpp:200-202 with ref exposure time 1.0
     assert exposure_time == (1.0 if 0.99 < a < 1.01 else pytest.approx(a, rel=1e-6))
+
+    # ---- Matcher::findMatchDirect (line 2) against hso_gpu_align_batch with the same inputs
+    mv = lines[1].split()
+    K = int(mv[0])
+    assert K == 32
+    has_pt = np.nonzero(idist > 0)[0]
+    T_cw = capi.SE3.from_arrays(q, t)
+    R = synth.quat_to_R(q)
+    jobs = []
+    for k in range(K):
+        i = has_pt[k]
+        pos = feats["f"][i] / idist[i]
+        pc = R @ pos + t
+        j = capi.AlignJob()
+        j.ref_frame_id = 41; j.ref_level = 0; j.type = capi.FTR_CORNER
+        j.px_ref[:] = list(feats["px"][i]); j.f_ref[:] = list(feats["f"][i]); j.grad[:] = [1.0, 0.0]
+        j.depth = 1.0 / idist[i]
+        j.T_cur_ref = T_cw
+        j.px_cur[:] = [cam.fx * pc[0] / pc[2] + cam.cx, cam.fy * pc[1] / pc[2] + cam.cy]
+        j.exposure_rat = float(np.float32(exposure_time / 1.0)); j.kf_gap_lt4 = 1
+        jobs.append(j)
+    got = gpu_ctx.align_batch(cam, 42, jobs)
+    n_ok = 0
+    for k, g in enumerate(got):
+        ok, px0, px1, sl = int(mv[1 + 4 * k]), float(mv[2 + 4 * k]), float(mv[3 + 4 * k]), int(mv[4 + 4 * k])
+        assert (ok, sl) == (g.success, g.search_level)
+        assert (px0, px1) == pytest.approx((g.px_cur[0], g.px_cur[1]), abs=1e-6)
+        n_ok += ok
+    assert n_ok >= 24
+
+    # ---- DepthFilter::observeDepth (line 3) against hso_gpu_seed_observe
+    import math
+    sv = lines[2].split()
+    n_seed_ok, n_left = int(sv[0]), int(sv[1])
+    seeds = []
+    for k in range(K, 2 * K):
+        i = has_pt[k]
+        sd = capi.Seed()
+        sd.ref_frame_id = 41; sd.level = 0; sd.type = capi.FTR_CORNER
+        sd.px[:] = list(feats["px"][i]); sd.f[:] = list(feats["f"][i]); sd.grad[:] = [1.0, 0.0]
+        sd.T_ref_w = capi.SE3.identity(); sd.ref_exposure = 1.0
+        depth_mean, depth_min = np.float32(1.1 / idist[i]), np.float32(0.5 / idist[i])
+        z_range = np.float32(1.0) / depth_min
+        sd.mu = float(np.float32(1.0) / depth_mean); sd.sigma2 = float(z_range * z_range / np.float32(36)); sd.b = 10.0
+        seeds.append(sd)
+    pea = math.atan(1.0 / (2.0 * abs((cam.fx + cam.fy) * 0.5))) * 2.0
+    so = gpu_ctx.seed_observe(cam, 42, T_cw, exposure_time, pea, seeds)
+    kept = [o for o in so if o.is_valid]
+    assert n_left == len(kept) and n_seed_ok == sum(o.result == 1 for o in kept) and n_seed_ok >= 16
+    for k, o in enumerate(kept):
+        mu, s2, b = (float(x) for x in sv[2 + 3 * k: 5 + 3 * k])
+        assert (mu, s2, b) == pytest.approx((o.mu, o.sigma2, o.b), rel=1e-6)
