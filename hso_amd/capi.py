@@ -163,6 +163,8 @@ class SeedOut(C.Structure):
                 ("px_cur", C.c_double * 2), ("z", C.c_double), ("zmncc_best", C.c_float), ("zmncc_second", C.c_float)]
 
 
+CORNER_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("score", "<i4"), ("response", "<f4")])   # hso_corner
+assert CORNER_DTYPE.itemsize == 12
 ACTIVATE_MAX_TARGETS = 64
 
 
@@ -253,6 +255,7 @@ def load():
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
                                           P(AlignOut)]
+    lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
     _lib = lib
     return lib
 
@@ -265,7 +268,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
-    "hso_gpu_seed_observe", "hso_gpu_seed_activate",
+    "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect",
 ]
 
 
@@ -430,6 +433,15 @@ class Context:
         self._check(self.lib.hso_gpu_seed_observe(self.h, C.byref(cam), cur_frame_id, C.byref(cur_T_f_w), cur_exposure,
                                                   px_error_angle, arr, len(seeds), out), "seed_observe")
         return list(out)
+
+    # -- FAST-9 corner candidates
+    def fast_detect(self, frame_id, n_levels=3, threshold=20, border=8, cap=20000):
+        """Returns ([structured array per level], [count per level])."""
+        out = np.zeros((n_levels, cap), CORNER_DTYPE)
+        counts = (C.c_int32 * n_levels)()
+        self._check(self.lib.hso_gpu_fast_detect(self.h, frame_id, n_levels, threshold, border, _ptr(out), cap, counts),
+                    "fast_detect")
+        return [out[l, :min(counts[l], cap)].copy() for l in range(n_levels)], list(counts)
 
     def seed_activate(self, cam, seeds, targets_per_seed, n_mean_converge_frame=6, want_matches=False):
         """targets_per_seed: one list of ActivateTarget per seed (optFrames_P + optFrames_A order)."""

@@ -418,6 +418,25 @@ int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_see
                           const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
                           hso_activate_out* out, hso_align_out* match_out);
 
+/* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:547-587 (SURVEY.md section 8f rank 1,
+ *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,
+ *      fast_corner_score_9, fast_nonmax_3x3 (thirdparty/fast/src) — and hso::shiTomasiScore
+ *      (src/vikit/vision.cpp:111-151) of the survivors ---- */
+typedef struct hso_corner {
+  int16_t x, y;      /* level coordinates (fast::fast_xy); KeyPoint position = (x << L, y << L) */
+  int32_t score;     /* fast_corner_score_9 */
+  float response;    /* shiTomasiScore, the KeyPoint response */
+} hso_corner;
+
+/* Level L's non-max-suppressed corners inside the border (x < border || x > W_L - border ||
+ * y < border || y > H_L - border are dropped, :573), in raster order — the order fastDetect pushes
+ * them into featurePerLevel_[L], i.e. the candidate index.  out holds n_levels * cap entries (level
+ * L at out + L * cap); counts[L] = corners found on level L (if > cap only the first cap are
+ * written).  Integer / byte arithmetic throughout: results are bit-identical to the reference
+ * library (tests/golden/fast9.json was produced by it). */
+int hso_gpu_fast_detect(hso_gpu_ctx* ctx, int64_t frame_id, int n_levels, int threshold, int border,
+                        hso_corner* out, int cap, int32_t* counts);
+
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

@@ -8,8 +8,9 @@
  * PARITY PINNING: the reference (luodongting/HSO) ships no tests, golden
  * vectors or fixtures for this path and cannot be compiled here (Eigen3, OpenCV,
  * Boost absent), so the restatement below is *unpinned by the reference* except
- * for the robust-cost functions (src/vikit/robust_cost.cpp), the one reference
- * translation unit that builds standalone (oracle/_ref, see Makefile).  Every
+ * for the two parts whose reference sources build standalone (oracle/_ref, see
+ * Makefile): the robust-cost functions (src/vikit/robust_cost.cpp) and the FAST-9
+ * corner detector (thirdparty/fast, hso_oracle_fast.c).  Every
  * function cites the reference file:line it follows so it can be diffed by eye.
  * Third-party arithmetic that the reference pulls from outside its tree (Eigen
  * LDLT / Quaternion, OpenCV Sobel) is restated from the published algorithms.
@@ -128,6 +129,12 @@ void hso_or_seed_activate(const hso_camera* cam, const hso_seed* s, const hso_ac
                           const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS], const uint8_t* const* tg_pyr,
                           const int16_t* const* tg_gx, const int16_t* const* tg_gy, int w, int h,
                           int n_mean_converge_frame, hso_activate_out* o, hso_align_out* match_out);
+/* ---- FAST-9 corner detection (src/feature_detection.cpp:547-587, thirdparty/fast, vision.cpp:111-151)
+ *      — pinned against oracle/_ref/libfast_ref.so and tests/golden/fast9.json ---- */
+int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y);
+float hso_or_shi_tomasi(const uint8_t* img, int cols, int rows, int u, int v);
+int hso_or_fast9_detect(const uint8_t* img, int w, int h, int threshold, int16_t* xy, int32_t* scores, int cap);
+int hso_or_fast_detect_level(const uint8_t* img, int w, int h, int threshold, int border, hso_corner* out, int cap);
 /* per-term dump of the last evaluation for debugging: returns number of rows written */
 int hso_or_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch,
                            int8_t* offsets_xy);

@@ -367,6 +367,64 @@ def seed_activate(cam, seed, targets, ref_pyr, tgt_pyrs, tgt_sobels, n_mean_conv
     return out, list(mo[:n])
 
 
+CORNER_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("score", "<i4"), ("response", "<f4")])
+REF_FAST_PATH = os.path.join(_HERE, "_ref", "libfast_ref.so")
+
+
+def fast_detect_level(img, threshold, border=8, cap=None):
+    """FeatureExtractor::fastDetect for one level -> structured array of surviving corners."""
+    lib = load()
+    lib.hso_or_fast_detect_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.hso_or_fast_detect_level.restype = C.c_int
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = cap or w * h
+    out = np.zeros(cap, CORNER_DTYPE)
+    n = lib.hso_or_fast_detect_level(img.ctypes.data, w, h, threshold, border, out.ctypes.data, cap)
+    return out[:min(n, cap)].copy(), n
+
+
+def fast9_detect(img, threshold):
+    """All FAST-9 corners (raster order) and their scores, before non-max suppression."""
+    lib = load()
+    lib.hso_or_fast9_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.hso_or_fast9_detect.restype = C.c_int
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    xy = np.zeros((w * h, 2), np.int16); sc = np.zeros(w * h, np.int32)
+    n = lib.hso_or_fast9_detect(img.ctypes.data, w, h, threshold, xy.ctypes.data, sc.ctypes.data, w * h)
+    return xy[:n].copy(), sc[:n].copy()
+
+
+def shi_tomasi(img, u, v):
+    lib = load()
+    lib.hso_or_shi_tomasi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.hso_or_shi_tomasi.restype = C.c_float
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib.hso_or_shi_tomasi(img.ctypes.data, img.shape[1], img.shape[0], int(u), int(v))
+
+
+def ref_fast(img, threshold):
+    """The compiled reference FAST library (oracle/_ref/libfast_ref.so): corners, scores and the
+    indices fast_nonmax_3x3 keeps; None if the library is absent (GPU box)."""
+    if not os.path.exists(REF_FAST_PATH):
+        return None
+    lib = C.CDLL(REF_FAST_PATH)
+    lib.ref_fast9_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.ref_fast9_score.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.ref_fast_nonmax.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    xy = np.zeros((w * h, 2), np.int16)
+    n = lib.ref_fast9_detect(img.ctypes.data, w, h, w, threshold, xy.ctypes.data, w * h)
+    xy = xy[:n].copy()
+    sc = np.zeros(max(n, 1), np.int32)
+    lib.ref_fast9_score(img.ctypes.data, w, xy.ctypes.data, n, threshold, sc.ctypes.data)
+    keep = np.zeros(max(n, 1), np.int32)
+    nk = lib.ref_fast_nonmax(xy.ctypes.data, sc.ctypes.data, n, keep.ctypes.data) if n else 0
+    return xy, sc[:n].copy(), keep[:nk].copy()
+
+
 def pattern(max_level, level):
     pa, hp = C.c_int(), C.c_int()
     offs = np.zeros((40, 2), np.int8)

@@ -1,0 +1,153 @@
+"""FAST-9 corner candidates (FeatureExtractor::fastDetect: fast_corner_detect_9_sse2 +
+fast_corner_score_9 + fast_nonmax_3x3 + shiTomasiScore).
+
+This row is PINNED by the reference's own code: tests/golden/fast9.json was produced by the
+compiled thirdparty/fast library (tests/golden/make_fast_golden.py, oracle/_ref/libfast_ref.so).
+CPU: the C restatement reproduces every golden case bit for bit (and the live library where it is
+present).  GPU: the HIP path equals the restatement bit for bit on the golden images, on full
+pyramids (VGA and EuRoC sizes) and on adversarial images (ties, flat, saturated)."""
+import base64
+import json
+import os
+
+import numpy as np
+import pytest
+
+from hso_amd import capi, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fast9.json")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    g = json.load(open(GOLD))
+    imgs = {k: np.frombuffer(base64.b64decode(v["data"]), np.uint8).reshape(v["h"], v["w"]).copy()
+            for k, v in g["images"].items()}
+    return imgs, g["cases"]
+
+
+def test_oracle_matches_reference_library_golden(orc, gold):
+    imgs, cases = gold
+    n_corners = 0
+    for c in cases:
+        img = imgs[c["image"]]
+        xy, sc = orc.fast9_detect(img, c["threshold"])
+        gxy = np.array(c["xy"], np.int16).reshape(-1, 2)
+        assert xy.shape == gxy.shape and (xy == gxy).all(), (c["image"], c["threshold"])
+        assert (sc == np.array(c["scores"], np.int32)).all()
+        # non-max suppression + border (border 0 keeps everything fast_nonmax_3x3 keeps)
+        out, n = orc.fast_detect_level(img, c["threshold"], border=0)
+        keep = c["nonmax"]
+        assert n == len(keep)
+        assert [(int(o["x"]), int(o["y"]), int(o["score"])) for o in out] == \
+               [(int(gxy[k, 0]), int(gxy[k, 1]), int(c["scores"][k])) for k in keep]
+        n_corners += len(gxy)
+    assert n_corners > 20000 and len(cases) == 21
+
+
+def test_oracle_matches_live_reference_when_present(orc):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (75, 130), dtype=np.uint8)
+    r = orc.ref_fast(img, 15)
+    if r is None:
+        pytest.skip("oracle/_ref/libfast_ref.so absent (reference not on this machine)")
+    rxy, rsc, keep = r
+    xy, sc = orc.fast9_detect(img, 15)
+    assert (xy == rxy).all() and (sc == rsc).all()
+    out, n = orc.fast_detect_level(img, 15, border=0)
+    assert [(o["x"], o["y"]) for o in out] == [(rxy[k, 0], rxy[k, 1]) for k in keep]
+
+
+def test_oracle_shi_tomasi_and_border(orc):
+    img = np.zeros((40, 40), np.uint8)
+    img[:, 20:] = 200                                   # vertical step edge: one zero eigenvalue
+    assert orc.shi_tomasi(img, 20, 20) == 0.0
+    img[20:, :] = np.where(img[20:, :] > 0, 0, 200)     # checkerboard corner: both eigenvalues large
+    assert orc.shi_tomasi(img, 20, 20) > 1000
+    assert orc.shi_tomasi(img, 4, 20) == 0.0            # box touches the image border -> 0 (vision.cpp:126)
+    # corners in the border band are dropped after non-max suppression (feature_detection.cpp:573)
+    rng = np.random.default_rng(8)
+    noise = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    all_, n_all = orc.fast_detect_level(noise, 20, border=0)
+    in_, n_in = orc.fast_detect_level(noise, 20, border=8)
+    sel = [(o["x"], o["y"]) for o in all_ if not (o["x"] < 8 or o["x"] > 56 or o["y"] < 8 or o["y"] > 56)]
+    assert n_in == len(sel) < n_all and [(o["x"], o["y"]) for o in in_] == sel
+
+
+def _check_level(got, want):
+    assert len(got) == len(want)
+    for name in ("x", "y", "score"):
+        assert (got[name] == want[name]).all(), name
+    assert (got["response"].view(np.uint32) == want["response"].view(np.uint32)).all(), "Shi-Tomasi bits"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", [synth.ICL_NUIM, synth.EUROC], ids=["640x480", "752x480"])
+def test_fast_detect_full_pyramid_bit_exact(gpu_ctx, orc, spec):
+    d = synth.config2_pair(10, spec=spec, seed=31)
+    fid = 9300
+    gpu_ctx.frame_upload(fid, d["ref"])
+    try:
+        pyr = orc.create_pyramid(d["ref"])
+        for thr in (10, 20):
+            levels, counts = gpu_ctx.fast_detect(fid, n_levels=3, threshold=thr, border=8, cap=60000)
+            for L in range(3):
+                want, n = orc.fast_detect_level(pyr[L], thr, border=8)
+                assert counts[L] == n and n > 50
+                _check_level(levels[L], want)
+        # cap smaller than the count: the first `cap` corners in raster order, the full count reported
+        levels, counts = gpu_ctx.fast_detect(fid, n_levels=1, threshold=10, border=8, cap=100)
+        want, n = orc.fast_detect_level(pyr[0], 10, border=8)
+        assert counts[0] == n > 100 and len(levels[0]) == 100
+        _check_level(levels[0], want[:100])
+    finally:
+        gpu_ctx.frame_release(fid)
+
+
+@pytest.mark.gpu
+def test_fast_detect_adversarial_images(gpu_ctx, orc):
+    """Ties in the non-max suppression, flat and saturated images, dense noise."""
+    rng = np.random.default_rng(12)
+    w, h = 640, 480
+    imgs = {
+        "four_levels": (rng.integers(0, 4, (h, w)) * 80).astype(np.uint8),
+        "flat": np.full((h, w), 128, np.uint8),
+        "noise": rng.integers(0, 256, (h, w), dtype=np.uint8),
+        "saturated_blocks": (np.kron(rng.integers(0, 2, (h // 4, w // 4)), np.ones((4, 4))) * 255).astype(np.uint8),
+    }
+    fid = 9310
+    for name, img in imgs.items():
+        gpu_ctx.frame_upload(fid, img)
+        try:
+            levels, counts = gpu_ctx.fast_detect(fid, n_levels=1, threshold=20, border=8, cap=200000)
+        finally:
+            gpu_ctx.frame_release(fid)
+        want, n = orc.fast_detect_level(img, 20, border=8)
+        assert counts[0] == n, name
+        _check_level(levels[0], want)
+    assert True
+
+
+@pytest.mark.gpu
+def test_fast_detect_golden_and_errors(gpu_ctx, gold):
+    """Directly against the reference library's outputs (no oracle in between): embed a golden image
+    in a frame-sized canvas whose surroundings cannot create or suppress corners inside it."""
+    imgs, cases = gold
+    img = imgs["scene_crop_160x120"]
+    case = next(c for c in cases if c["image"] == "scene_crop_160x120" and c["threshold"] == 20)
+    canvas = np.zeros((128, 160), np.uint8)            # 160x128: a legal frame size (multiples of 16)
+    canvas[:120, :] = img
+    gxy = np.array(case["xy"], np.int16).reshape(-1, 2)
+    sc = np.array(case["scores"])
+    keep = [k for k in case["nonmax"] if gxy[k, 1] < 120 - 8]   # rows near the pasted edge see the zero padding
+    gpu_ctx.frame_upload(9320, canvas)
+    try:
+        levels, counts = gpu_ctx.fast_detect(9320, n_levels=1, threshold=20, border=0, cap=20000)
+        got = [(int(o["x"]), int(o["y"]), int(o["score"])) for o in levels[0] if o["y"] < 120 - 8]
+        assert got == [(int(gxy[k, 0]), int(gxy[k, 1]), int(sc[k])) for k in keep] and len(got) > 100
+        with pytest.raises(capi.HsoGpuError):
+            gpu_ctx.fast_detect(424242)                                  # frame not resident
+        with pytest.raises(capi.HsoGpuError):
+            gpu_ctx.fast_detect(9320, n_levels=6)
+    finally:
+        gpu_ctx.frame_release(9320)
