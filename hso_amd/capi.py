@@ -256,6 +256,7 @@ def load():
     lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
                                           P(AlignOut)]
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
+    lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
     _lib = lib
     return lib
 
@@ -268,7 +269,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
-    "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect",
+    "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
 ]
 
 
@@ -442,6 +443,16 @@ class Context:
         self._check(self.lib.hso_gpu_fast_detect(self.h, frame_id, n_levels, threshold, border, _ptr(out), cap, counts),
                     "fast_detect")
         return [out[l, :min(counts[l], cap)].copy() for l in range(n_levels)], list(counts)
+
+    def fast_detect_batch(self, frame_ids, n_levels=3, threshold=20, border=8, cap=4096):
+        """Returns (out[n_frames, n_levels, cap] structured array or None when cap == 0, counts[n_frames, n_levels])."""
+        n = len(frame_ids)
+        ids = (C.c_int64 * n)(*frame_ids)
+        out = np.zeros((n, n_levels, cap), CORNER_DTYPE) if cap > 0 else None
+        counts = np.zeros((n, n_levels), np.int32)
+        self._check(self.lib.hso_gpu_fast_detect_batch(self.h, ids, n, n_levels, threshold, border, _ptr(out), cap, _ptr(counts)),
+                    "fast_detect_batch")
+        return out, counts
 
     def seed_activate(self, cam, seeds, targets_per_seed, n_mean_converge_frame=6, want_matches=False):
         """targets_per_seed: one list of ActivateTarget per seed (optFrames_P + optFrames_A order)."""

@@ -34,23 +34,22 @@
 
 __device__ __forceinline__ int fast9_strength(const int d[16])
 {
-  // S = max over starts s of min_{k<9} (+-d[s+k]); sliding minimum by doubling
-  int best = 0;
+  // S = max over starts s of min_{k<9} (+-d[s+k]); sliding minimum by doubling.  Both polarities
+  // ride in the two 16-bit halves of one register (v_pk_min_i16 / v_pk_max_i16): |d| <= 255.
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  s16x2 a[16], m2[16], m4[16], m8[16];
 #pragma unroll
-  for (int pol = 0; pol < 2; pol++) {
-    int a[16], m2[16], m4[16], m8[16];
+  for (int i = 0; i < 16; i++) { a[i].x = (short)d[i]; a[i].y = (short)-d[i]; }
 #pragma unroll
-    for (int i = 0; i < 16; i++) a[i] = pol ? -d[i] : d[i];
+  for (int i = 0; i < 16; i++) m2[i] = __builtin_elementwise_min(a[i], a[(i + 1) & 15]);
 #pragma unroll
-    for (int i = 0; i < 16; i++) m2[i] = min(a[i], a[(i + 1) & 15]);
+  for (int i = 0; i < 16; i++) m4[i] = __builtin_elementwise_min(m2[i], m2[(i + 2) & 15]);
 #pragma unroll
-    for (int i = 0; i < 16; i++) m4[i] = min(m2[i], m2[(i + 2) & 15]);
+  for (int i = 0; i < 16; i++) m8[i] = __builtin_elementwise_min(m4[i], m4[(i + 4) & 15]);
+  s16x2 best = {0, 0};
 #pragma unroll
-    for (int i = 0; i < 16; i++) m8[i] = min(m4[i], m4[(i + 4) & 15]);
-#pragma unroll
-    for (int i = 0; i < 16; i++) best = max(best, min(m8[i], a[(i + 8) & 15]));
-  }
-  return best;
+  for (int i = 0; i < 16; i++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[i], a[(i + 8) & 15]));
+  return max((int)best.x, (int)best.y);
 }
 
 // circle offsets in the library's order (fast_9_score.cpp:4661-4678)
@@ -59,11 +58,26 @@ __device__ __constant__ int8_t c_circle[16][2] = {
   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}
 };
 
-__global__ __launch_bounds__(256) void k_fast_mask(const uint8_t* img, int W, int H, int threshold, int border,
-                                                   unsigned long long* mask, int words_per_row, int* row_count)
+// one level of a batch of frames: blockIdx.z = frame; every frame has its own slice of the work area
+struct FastArgs {
+  const uint8_t* const* bases;  // frame base pointers (device table)
+  uint32_t img_off;             // byte offset of the level inside a frame
+  int W, H, threshold, border, words_per_row, cap;
+  char* work;
+  size_t per_frame, o_cnt, o_mask, o_off, o_out;  // slice size and the level's offsets inside a slice
+  int* totals;                  // [n_frames][n_levels]
+  int n_levels, level;
+};
+
+__global__ __launch_bounds__(256) void k_fast_mask(FastArgs A)
 {
   __shared__ uint8_t s_src[FAST_TH + 8][FAST_TW + 8];
   __shared__ short s_sc[FAST_TH + 2][FAST_TW + 2];
+  const uint8_t* img = A.bases[blockIdx.z] + A.img_off;
+  char* slice = A.work + (size_t)blockIdx.z * A.per_frame;
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(slice + A.o_mask);
+  int* row_count = reinterpret_cast<int*>(slice + A.o_cnt);
+  const int W = A.W, H = A.H, threshold = A.threshold, border = A.border, words_per_row = A.words_per_row;
   const int x0 = blockIdx.x * FAST_TW, y0 = blockIdx.y * FAST_TH;
   const int t = threadIdx.x;
   for (int i = t; i < (FAST_TH + 8) * (FAST_TW + 8); i += 256) {
@@ -110,9 +124,14 @@ __global__ __launch_bounds__(256) void k_fast_mask(const uint8_t* img, int W, in
   }
 }
 
-__global__ __launch_bounds__(256) void k_fast_scan(const int* row_count, int H, int* row_off, int* total_out)
+__global__ __launch_bounds__(256) void k_fast_scan(FastArgs A)
 {
   __shared__ int s_part[256];
+  char* slice = A.work + (size_t)blockIdx.x * A.per_frame;
+  const int* row_count = reinterpret_cast<const int*>(slice + A.o_cnt);
+  int* row_off = reinterpret_cast<int*>(slice + A.o_off);
+  int* total_out = A.totals + (size_t)blockIdx.x * A.n_levels + A.level;
+  const int H = A.H;
   const int t = threadIdx.x;
   const int per = (H + 255) / 256;
   int sum = 0;
@@ -129,9 +148,14 @@ __global__ __launch_bounds__(256) void k_fast_scan(const int* row_count, int H, 
   for (int i = t * per; i < min(H, (t + 1) * per); i++) { row_off[i] = acc; acc += row_count[i]; }
 }
 
-__global__ __launch_bounds__(256) void k_fast_emit(const uint8_t* img, int W, int H, const unsigned long long* mask,
-                                                   int words_per_row, const int* row_off, hso_corner* out, int cap)
+__global__ __launch_bounds__(256) void k_fast_emit(FastArgs A)
 {
+  const uint8_t* img = A.bases[blockIdx.z] + A.img_off;
+  char* slice = A.work + (size_t)blockIdx.z * A.per_frame;
+  const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(slice + A.o_mask);
+  const int* row_off = reinterpret_cast<const int*>(slice + A.o_off);
+  hso_corner* out = reinterpret_cast<hso_corner*>(slice + A.o_out);
+  const int W = A.W, H = A.H, words_per_row = A.words_per_row, cap = A.cap;
   const int lane = threadIdx.x & 63;
   const int widx = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= H * words_per_row) return;
@@ -176,63 +200,82 @@ __global__ __launch_bounds__(256) void k_fast_emit(const uint8_t* img, int W, in
   out[idx] = o;
 }
 
-extern "C" int hso_gpu_fast_detect(hso_gpu_ctx* ctx, int64_t frame_id, int n_levels, int threshold, int border,
-                                   hso_corner* out, int cap, int32_t* counts)
+extern "C" int hso_gpu_fast_detect_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold,
+                                         int border, hso_corner* out, int cap, int32_t* counts)
 {
   if (!ctx) return HSO_E_INVALID;
-  if (n_levels < 1 || n_levels > HSO_N_PYR_LEVELS || threshold < 0 || threshold > 255 || border < 0 || cap < 0 || !counts ||
-      (cap > 0 && !out))
+  if (!frame_ids || n_frames < 0 || n_levels < 1 || n_levels > HSO_N_PYR_LEVELS || threshold < 0 || threshold > 255 || border < 0 ||
+      cap < 0 || !counts || (cap > 0 && !out))
     return hso_fail(ctx, HSO_E_INVALID, "fast_detect: bad argument");
+  if (n_frames == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  auto it = ctx->frames.find(frame_id);
-  if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "fast_detect: frame not resident");
-  const PyrGeom& g = it->second.g;
+  std::vector<const uint8_t*> h_bases(n_frames);
+  PyrGeom g{};
+  for (int i = 0; i < n_frames; i++) {
+    auto it = ctx->frames.find(frame_ids[i]);
+    if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "fast_detect: frame not resident");
+    if (i == 0) g = it->second.g;
+    else if (it->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "fast_detect: frames of one batch must share one size");
+    h_bases[i] = it->second.base;
+  }
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  // per level: mask, row counts, row offsets (+ total), output list
+  // slice of one frame: [row counts of all levels | per level: mask, row offsets, corner list]
   size_t o = 0, o_mask[HSO_N_PYR_LEVELS], o_cnt[HSO_N_PYR_LEVELS], o_off[HSO_N_PYR_LEVELS], o_out[HSO_N_PYR_LEVELS];
   int wpr[HSO_N_PYR_LEVELS];
-  size_t zero_begin = 0, zero_end = 0;
   for (int l = 0; l < n_levels; l++) {
     wpr[l] = (g.w[l] + FAST_TW - 1) / FAST_TW;
     o_cnt[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
   }
-  zero_end = o;
+  const size_t cnt_bytes = o;
   for (int l = 0; l < n_levels; l++) {
     o_mask[l] = o; o += al(sizeof(unsigned long long) * (size_t)g.h[l] * wpr[l]);
-    o_off[l] = o; o += al(sizeof(int) * ((size_t)g.h[l] + 1));
-    o_out[l] = o; o += al(sizeof(hso_corner) * (size_t)(cap > 0 ? cap : 1));
+    o_off[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
+    o_out[l] = o; o += al(sizeof(hso_corner) * (size_t)cap);
   }
-  if (ctx->batch_cap < o) {
+  const size_t per_frame = o;
+  const size_t o_tab = per_frame * (size_t)n_frames;
+  const size_t o_tot = o_tab + al(sizeof(void*) * (size_t)n_frames);
+  const size_t need = o_tot + al(sizeof(int) * (size_t)n_frames * n_levels);
+  if (ctx->batch_cap < need) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), o));
-    ctx->batch_cap = o;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
   }
   char* d = reinterpret_cast<char*>(ctx->d_batch);
-  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + zero_begin, 0, zero_end - zero_begin, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_tab, h_bases.data(), sizeof(void*) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemset2DAsync(d, per_frame, 0, cnt_bytes, (size_t)n_frames, ctx->stream));  // the row counters of every slice
+  FastArgs A;
+  A.bases = reinterpret_cast<const uint8_t* const*>(d + o_tab);
+  A.threshold = threshold; A.border = border; A.cap = cap;
+  A.work = d; A.per_frame = per_frame;
+  A.totals = reinterpret_cast<int*>(d + o_tot);
+  A.n_levels = n_levels;
   for (int l = 0; l < n_levels; l++) {
-    const uint8_t* img = it->second.base + g.off[l];
-    const int W = g.w[l], H = g.h[l];
-    unsigned long long* mask = reinterpret_cast<unsigned long long*>(d + o_mask[l]);
-    int* cnt = reinterpret_cast<int*>(d + o_cnt[l]);
-    int* off = reinterpret_cast<int*>(d + o_off[l]);
-    hso_corner* dout = reinterpret_cast<hso_corner*>(d + o_out[l]);
-    hipLaunchKernelGGL(k_fast_mask, dim3(wpr[l], (H + FAST_TH - 1) / FAST_TH), dim3(256), 0, ctx->stream, img, W, H, threshold,
-                       border, mask, wpr[l], cnt);
-    hipLaunchKernelGGL(k_fast_scan, dim3(1), dim3(256), 0, ctx->stream, cnt, H, off, off + H);
-    hipLaunchKernelGGL(k_fast_emit, dim3((H * wpr[l] + 3) / 4), dim3(256), 0, ctx->stream, img, W, H, mask, wpr[l], off, dout, cap);
+    A.img_off = g.off[l]; A.W = g.w[l]; A.H = g.h[l]; A.words_per_row = wpr[l]; A.level = l;
+    A.o_cnt = o_cnt[l]; A.o_mask = o_mask[l]; A.o_off = o_off[l]; A.o_out = o_out[l];
+    hipLaunchKernelGGL(k_fast_mask, dim3(wpr[l], (A.H + FAST_TH - 1) / FAST_TH, n_frames), dim3(256), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_fast_scan, dim3(n_frames), dim3(256), 0, ctx->stream, A);
+    if (cap > 0) hipLaunchKernelGGL(k_fast_emit, dim3((A.H * wpr[l] + 3) / 4, 1, n_frames), dim3(256), 0, ctx->stream, A);
     HSO_HIP_CHECK(ctx, hipGetLastError());
   }
-  std::vector<int> totals(n_levels, 0);
-  for (int l = 0; l < n_levels; l++)
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(&totals[l], d + o_off[l] + sizeof(int) * (size_t)g.h[l], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(counts, d + o_tot, sizeof(int) * (size_t)n_frames * n_levels, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  for (int l = 0; l < n_levels; l++) {
-    counts[l] = totals[l];
-    const int n = totals[l] < cap ? totals[l] : cap;
-    if (n > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(out + (size_t)l * cap, d + o_out[l], sizeof(hso_corner) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  }
+  for (int i = 0; i < n_frames && cap > 0; i++)
+    for (int l = 0; l < n_levels; l++) {
+      const int c = counts[(size_t)i * n_levels + l];
+      const int n = c < cap ? c : cap;
+      if (n > 0)
+        HSO_HIP_CHECK(ctx, hipMemcpyAsync(out + ((size_t)i * n_levels + l) * cap, d + (size_t)i * per_frame + o_out[l],
+                                          sizeof(hso_corner) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    }
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
+}
+
+extern "C" int hso_gpu_fast_detect(hso_gpu_ctx* ctx, int64_t frame_id, int n_levels, int threshold, int border, hso_corner* out,
+                                   int cap, int32_t* counts)
+{
+  return hso_gpu_fast_detect_batch(ctx, &frame_id, 1, n_levels, threshold, border, out, cap, counts);
 }

@@ -55,6 +55,22 @@ def main():
     ok = sum(o.result == 1 for o in ctx.seed_observe(cam, 2, T_cur, 1.05, pea, seeds))
     out.append(dict(stage="seed_observe (observeDepthRow/doLineStereo)", units="seeds", n=len(seeds), ms_per_call=dt * 1e3,
                     units_per_s=len(seeds) / dt, matched=ok))
+    # section 8f rank 1, first stage: FAST-9 corner candidates of pyramid levels 0..2 of one frame
+    dt = timed(lambda: ctx.fast_detect(1, 3, 20, 8, 20000), args.reps)
+    _, counts = ctx.fast_detect(1, 3, 20, 8, 20000)
+    npx = sum((640 >> l) * (480 >> l) for l in range(3))
+    out.append(dict(stage="fast_detect (FAST-9 + score + nonmax + Shi-Tomasi, levels 0-2)", units="pixels", n=npx,
+                    ms_per_call=dt * 1e3, units_per_s=npx / dt, corners=sum(counts)))
+    # the same for the new keyframes of 256 independent sequences in one call (counts only: no list copy)
+    nb = 256
+    for k in range(nb):
+        ctx.frame_upload(1000 + k, pair["ref"] if k % 2 == 0 else pair["cur"])
+    bid = list(range(1000, 1000 + nb))
+    dt = timed(lambda: ctx.fast_detect_batch(bid, 3, 20, 8, 0), max(args.reps // 2, 2))
+    out.append(dict(stage="fast_detect_batch x256 frames (levels 0-2, counts only)", units="pixels", n=npx * nb,
+                    ms_per_call=dt * 1e3, units_per_s=npx * nb / dt))
+    for k in bid:
+        ctx.frame_release(k)
     ctx.frame_release(1); ctx.frame_release(2)
 
     # a18: activation of converged seeds against 8 observing frames

@@ -436,6 +436,11 @@ typedef struct hso_corner {
  * library (tests/golden/fast9.json was produced by it). */
 int hso_gpu_fast_detect(hso_gpu_ctx* ctx, int64_t frame_id, int n_levels, int threshold, int border,
                         hso_corner* out, int cap, int32_t* counts);
+/* The new keyframes of n independent sequences (one frame size) in three launches per level.
+ * out: n_frames * n_levels * cap entries, frame-major ((i * n_levels + L) * cap); counts likewise
+ * n_frames * n_levels.  cap == 0 (out may be NULL) only counts. */
+int hso_gpu_fast_detect_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold,
+                              int border, hso_corner* out, int cap, int32_t* counts);
 
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,

@@ -105,6 +105,27 @@ def test_fast_detect_full_pyramid_bit_exact(gpu_ctx, orc, spec):
 
 
 @pytest.mark.gpu
+def test_fast_detect_batch_equals_single(gpu_ctx):
+    """Frames of independent sequences in one call: every frame equals its solo result."""
+    frames = [synth.config2_pair(10, seed=40 + k)["ref"] for k in range(3)]
+    ids = [9330, 9331, 9332, 9330]                       # a frame may appear twice
+    for i, f in zip(ids[:3], frames):
+        gpu_ctx.frame_upload(i, f)
+    try:
+        out, counts = gpu_ctx.fast_detect_batch(ids, n_levels=3, threshold=20, border=8, cap=8192)
+        _, counts_only = gpu_ctx.fast_detect_batch(ids, n_levels=3, threshold=20, border=8, cap=0)
+        assert (counts == counts_only).all() and counts.min() > 20
+        for k, i in enumerate(ids):
+            solo, c = gpu_ctx.fast_detect(i, n_levels=3, threshold=20, border=8, cap=8192)
+            assert list(counts[k]) == c
+            for L in range(3):
+                assert out[k, L, :c[L]].tobytes() == solo[L].tobytes()
+    finally:
+        for i in ids[:3]:
+            gpu_ctx.frame_release(i)
+
+
+@pytest.mark.gpu
 def test_fast_detect_adversarial_images(gpu_ctx, orc):
     """Ties in the non-max suppression, flat and saturated images, dense noise."""
     rng = np.random.default_rng(12)
