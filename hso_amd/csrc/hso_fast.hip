@@ -1,7 +1,7 @@
 // hso_fast.hip — FAST-9 corner candidates on gfx950: segment test, corner score, 3x3 non-maximum
 // suppression, border filter and Shi-Tomasi response, emitted in raster order.
 //
-// Replaces the body of FeatureExtractor::fastDetect (reference src/feature_detection.cpp:547-587)
+// Replaces the body of FeatureExtractor::fastDetect (reference src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect))
 // and what it calls: fast::fast_corner_detect_9_sse2 (thirdparty/fast/src/faster_corner_9_sse.cpp,
 // fast_9.cpp), fast::fast_corner_score_9 (fast_9_score.cpp), fast::fast_nonmax_3x3
 // (nonmax_3x3.cpp) and hso::shiTomasiScore (src/vikit/vision.cpp:111-151).

@@ -418,7 +418,7 @@ int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_see
                           const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
                           hso_activate_out* out, hso_align_out* match_out);
 
-/* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:547-587 (SURVEY.md section 8f rank 1,
+/* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
  *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,
  *      fast_corner_score_9, fast_nonmax_3x3 (thirdparty/fast/src) — and hso::shiTomasiScore
  *      (src/vikit/vision.cpp:111-151) of the survivors ---- */

@@ -129,7 +129,7 @@ void hso_or_seed_activate(const hso_camera* cam, const hso_seed* s, const hso_ac
                           const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS], const uint8_t* const* tg_pyr,
                           const int16_t* const* tg_gx, const int16_t* const* tg_gy, int w, int h,
                           int n_mean_converge_frame, hso_activate_out* o, hso_align_out* match_out);
-/* ---- FAST-9 corner detection (src/feature_detection.cpp:547-587, thirdparty/fast, vision.cpp:111-151)
+/* ---- FAST-9 corner detection (src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect), thirdparty/fast, vision.cpp:111-151)
  *      — pinned against oracle/_ref/libfast_ref.so and tests/golden/fast9.json ---- */
 int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y);
 float hso_or_shi_tomasi(const uint8_t* img, int cols, int rows, int u, int v);

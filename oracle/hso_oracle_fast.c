@@ -1,6 +1,6 @@
 /*
  * hso_oracle_fast.c — FAST-9 corners, their scores, 3x3 non-maximum suppression and the
- * Shi-Tomasi response: FeatureExtractor::fastDetect restated (src/feature_detection.cpp:547-587).
+ * Shi-Tomasi response: FeatureExtractor::fastDetect restated (src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect)).
  * TEST INFRASTRUCTURE (see hso_oracle.h).
  *
  * PINNED: unlike the rest of the oracle this part is checked against the reference's own code —

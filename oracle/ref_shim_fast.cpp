@@ -1,6 +1,6 @@
 // ref_shim_fast.cpp — C-linkage entry points over the reference's vendored FAST corner library
 // (thirdparty/fast: fast_corner_detect_9_sse2, fast_corner_score_9, fast_nonmax_3x3), the calls
-// FeatureExtractor::fastDetect makes (src/feature_detection.cpp:547-587).  Built by
+// FeatureExtractor::fastDetect makes (src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect)).  Built by
 // oracle/Makefile into oracle/_ref/libfast_ref.so from the reference sources where they lie;
 // this file contains no reference code, it only calls the library's public interface.
 #include <cstddef>
