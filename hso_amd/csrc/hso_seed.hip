@@ -15,8 +15,7 @@
 // Geometry (fp64) is uniform over the wave and computed redundantly by all lanes.  The fp32
 // sums are butterflies (reference: serial loops) — rounding-level differences only; result
 // codes and the step index of the best score can differ on near-ties (flagged in the tests).
-#include "hso_ctx.h"
-#include "hso_dev_math.h"
+#include "hso_match_dev.h"
 #include <string.h>
 #include <vector>
 
@@ -37,55 +36,7 @@ struct SeedDev {
   hso_seed s;
 };
 
-HSO_DEV float s_wave_sum(float v)
-{
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
-}
-
-// AbstractCamera::cam2world, src/camera.cpp:67-87,171-194 (see hso_align.hip for the radtan note)
-HSO_DEV void s_cam2world(const hso_camera& cam, double u, double v, double f[3])
-{
-  double x, y;
-  if (cam.model == HSO_CAM_PINHOLE && cam.distortion) {
-    const double fx = (float)cam.fx, fy = (float)cam.fy, cx = (float)cam.cx, cy = (float)cam.cy;
-    const double k0 = (float)cam.d[0], k1 = (float)cam.d[1], p1 = (float)cam.d[2], p2 = (float)cam.d[3], k2 = (float)cam.d[4];
-    const double ifx = 1. / fx, ify = 1. / fy;
-    x = (float)u; y = (float)v;
-    const double x0 = x = (x - cx) * ifx;
-    const double y0 = y = (y - cy) * ify;
-    for (int it = 0; it < 5; it++) {
-      const double r2 = x * x + y * y;
-      const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k2 * r2 + k1) * r2 + k0) * r2);
-      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
-      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
-      x = (x0 - deltaX) * icdist;
-      y = (y0 - deltaY) * icdist;
-    }
-    x = (float)x; y = (float)y;
-  } else if (cam.model == HSO_CAM_FOV && cam.distortion) {
-    const double omega = cam.d[0];
-    const double ud = (u - cam.cx) / cam.fx, vd = (v - cam.cy) / cam.fy;
-    const double dist = sqrt(ud * ud + vd * vd);
-    const double rd = tan(dist * omega) / (2 * dist * tan(omega / 2));
-    x = rd * ud; y = rd * vd;
-  } else {
-    x = (u - cam.cx) / cam.fx; y = (v - cam.cy) / cam.fy;
-  }
-  const double n = sqrt(x * x + y * y + 1.0);
-  f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
-}
-
-HSO_DEV float s_interp_8u(const uint8_t* data, int stride, float u, float v)
-{
-  const int x = (int)floor((double)u), y = (int)floor((double)v);
-  const float sx = u - (float)x, sy = v - (float)y;
-  const float w00 = (1.0f - sx) * (1.0f - sy), w01 = (1.0f - sx) * sy, w10 = sx * (1.0f - sy);
-  const float w11 = ((1.0f - w00) - w01) - w10;
-  const uint8_t* p = data + y * stride + x;
-  return ((w00 * (float)p[0] + w01 * (float)p[stride]) + w10 * (float)p[1]) + w11 * (float)p[stride + 1];
-}
+// wave_sum_all, cam2world_dev and interpolate_8u come from hso_match_dev.h (shared with the matcher)
 
 // One lane's sample of warp::createPatch (matcher.cpp:159-196) at patch pixel (px_, py_)
 HSO_DEV float s_patch_sample(const uint8_t* img, int stride, double pxs0, double pxs1, int px_, int py_)
@@ -114,14 +65,14 @@ HSO_DEV bool s_klt_limited(const uint8_t* img, int cols, int rows, float gxr, fl
                           : sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx + Jy * Jy))));
   float Hi[9];
   {
-    const float h_xx = s_wave_sum((Jx * Jx) * wgt), h_x1 = s_wave_sum((Jx * 1.0f) * wgt), h_11 = s_wave_sum((1.0f * 1.0f) * wgt);
+    const float h_xx = wave_sum_all((Jx * Jx) * wgt), h_x1 = wave_sum_all((Jx * 1.0f) * wgt), h_11 = wave_sum_all((1.0f * 1.0f) * wgt);
     if (ONE_D) {
       const float H00 = (float)((double)h_xx * (1 + 0.001)), H11 = (float)((double)h_11 * (1 + 0.001)), H01 = h_x1;
       const float det = H00 * H11 - H01 * H01;
       const float invdet = 1.0f / det;
       Hi[0] = H11 * invdet; Hi[1] = -H01 * invdet; Hi[3] = -H01 * invdet; Hi[4] = H00 * invdet;
     } else {
-      const float h_xy = s_wave_sum((Jx * Jy) * wgt), h_yy = s_wave_sum((Jy * Jy) * wgt), h_y1 = s_wave_sum((Jy * 1.0f) * wgt);
+      const float h_xy = wave_sum_all((Jx * Jy) * wgt), h_yy = wave_sum_all((Jy * Jy) * wgt), h_y1 = wave_sum_all((Jy * 1.0f) * wgt);
       const float H0 = (float)((double)h_xx * (1 + 0.001)), H4 = (float)((double)h_yy * (1 + 0.001)), H8 = (float)((double)h_11 * (1 + 0.001));
       const float H1 = h_xy, H2 = h_x1, H5 = h_y1, H3 = H1, H6 = H2, H7 = H5;
       const float c00 = H4 * H8 - H5 * H7, c01 = H5 * H6 - H3 * H8, c02 = H3 * H7 - H4 * H6;
@@ -148,11 +99,11 @@ HSO_DEV bool s_klt_limited(const uint8_t* img, int cols, int rows, float gxr, fl
     const float sp = ((wTL * (float)it[0] + wTR * (float)it[1]) + wBL * (float)it[cols]) + wBR * (float)it[cols + 1];
     last_sample = sp; sampled = true;
     const float res = (sp - ref_px) + mean_diff;
-    const float j0 = -s_wave_sum((res * Jx) * wgt);
-    const float j2 = -s_wave_sum(res * wgt);
-    const float energy = s_wave_sum((res * res) * wgt);
+    const float j0 = -wave_sum_all((res * Jx) * wgt);
+    const float j2 = -wave_sum_all(res * wgt);
+    const float energy = wave_sum_all((res * res) * wgt);
     float j1 = 0;
-    if (!ONE_D) j1 = -s_wave_sum((res * Jy) * wgt);
+    if (!ONE_D) j1 = -wave_sum_all((res * Jy) * wgt);
     if (energy > bestEnergy) {
       sb0 *= 0.5f; sb1 *= 0.5f; sb2 *= 0.5f;
       if (ONE_D) { bestU = (float)((double)uBak + (double)sb0 * d0); bestV = (float)((double)vBak + (double)sb0 * d1); mean_diff = meanBak + sb1; }
@@ -231,8 +182,8 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
       const double xr = S.f[0] * prior_idepth, yr = S.f[1] * prior_idepth, zr = S.f[2] * prior_idepth;
       const int ratio = 1 << S.level;
       double du[3], dv[3];
-      s_cam2world(C.cam, S.px[0] + (double)(hp * ratio), S.px[1] + (double)(0 * ratio), du);
-      s_cam2world(C.cam, S.px[0] + (double)(0 * ratio), S.px[1] + (double)(hp * ratio), dv);
+      cam2world_dev(C.cam, S.px[0] + (double)(hp * ratio), S.px[1] + (double)(0 * ratio), du);
+      cam2world_dev(C.cam, S.px[0] + (double)(0 * ratio), S.px[1] + (double)(hp * ratio), dv);
       const double su = zr / du[2], sv = zr / dv[2];
       for (int i = 0; i < 3; i++) { du[i] *= su; dv[i] *= sv; }
       double cx, cy, cz, ux, uy, uz, vx, vy, vz, pc0, pc1, pu0, pu1, pv0, pv1;
@@ -264,7 +215,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
         p0 *= scaleTarget; p1 *= scaleTarget;
         const float px0 = (a00 * p0 + a01 * p1) + rx, px1 = (a10 * p0 + a11 * p1) + ry;
         float val = 0;
-        if (!warp_nan && !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1))) val = s_interp_8u(img, cols, px0, px1);
+        if (!warp_nan && !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1))) val = interpolate_8u(img, cols, px0, px1);
         if (scale_exposure) val = val * exposure_rat;
         s_pwb[wave][idx] = val;
       }
@@ -313,9 +264,9 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     // ---- march along the epipolar line, ZMNCC per step (:906-960)
     const int cols = W >> sl, rows = H >> sl;
     const uint8_t* cur = C.cur_base + C.g.off[sl];
-    const float hostMean = s_wave_sum(ref_px) / 64;
+    const float hostMean = wave_sum_all(ref_px) / 64;
     const float hdev = ref_px - hostMean;
-    const float d1 = s_wave_sum(hdev * hdev);
+    const float d1 = wave_sum_all(hdev * hdev);
     float zmncc_best = 0.1f, zmncc_second = 0.1f;
     double uvb0 = 0, uvb1 = 0;
     int loopCounter = 0, loopCBest = -1, loopCSecond = -1;
@@ -324,9 +275,9 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
       const int ox = (int)cpx, oy = (int)cpy;
       if (ox >= 8 && ox < W / (1 << sl) - 8 && oy >= 8 && oy < H / (1 << sl) - 8) {
         const float sp = s_patch_sample(cur, cols, cpx, cpy, px_, py_);
-        const float tmean = s_wave_sum(sp) / 64;
+        const float tmean = wave_sum_all(sp) / 64;
         const float t = sp - tmean;
-        const float num = s_wave_sum(hdev * t), d2 = s_wave_sum(t * t);
+        const float num = wave_sum_all(hdev * t), d2 = wave_sum_all(t * t);
         const float zmncc = (float)((double)num / ((double)sqrtf(d1 * d2) + 1e-12));
         if (zmncc > zmncc_best) {
           zmncc_second = zmncc_best; uvb0 = cpx; uvb1 = cpy; zmncc_best = zmncc;
@@ -373,9 +324,9 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     }
     if (result) {
       // Matcher::checkNCC(patch_f_, patch2D, 0.8), :379-404
-      const float mean1 = s_wave_sum(ref_px) / 64, mean2 = s_wave_sum(samp) / 64;
+      const float mean1 = wave_sum_all(ref_px) / 64, mean2 = wave_sum_all(samp) / 64;
       const float q1 = ref_px - mean1, q2 = samp - mean2;
-      const float num = s_wave_sum(q1 * q2), den1 = s_wave_sum(q1 * q1), den2 = s_wave_sum(q2 * q2);
+      const float num = wave_sum_all(q1 * q2), den1 = wave_sum_all(q1 * q1), den2 = wave_sum_all(q2 * q2);
       result = ((double)num / ((double)sqrtf(den1 * den2) + 1e-12)) > (double)(float)0.8;
     }
     if (!result) { res_code = -3; break; }
@@ -383,7 +334,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     o.px_cur[0] = pxcur0; o.px_cur[1] = pxcur1;
     // depthFromTriangulation(T_cur_ref, f_ref, cam2world(px_cur_)), :242-255
     double fc[3];
-    s_cam2world(C.cam, pxcur0, pxcur1, fc);
+    cam2world_dev(C.cam, pxcur0, pxcur1, fc);
     double R[9];
     so3_matrix(T, R);
     double a0[3];
