@@ -39,7 +39,7 @@
 using namespace hso_dev;
 
 #ifndef TRK_THREADS
-#define TRK_THREADS 768
+#define TRK_THREADS 512  // 8 waves = 2 per SIMD: 256 VGPRs each; measured best with the unrolled pixel loops (768: 168 VGPRs, spills)
 #endif
 #define TRK_WAVES (TRK_THREADS / 64)
 #define TRK_MAX_PA 25
@@ -47,7 +47,7 @@ using namespace hso_dev;
 #define N_RED 38  // 28 H + 7 b + E + n_terms + n_saturated
 
 // include/hso/CoarseTracker.h:58-120 (staticPattern, staticPatternNum, staticPatternPadding)
-static const int8_t h_pattern[8][40][2] = {
+static constexpr int8_t h_pattern[8][40][2] = {
   { {0,0} },
   { {0,-1}, {-1,0}, {0,0}, {1,0}, {0,1} },
   { {-1,-1}, {-1,0}, {-1,1}, {-1,0}, {0,0}, {0,1}, {1,-1}, {1,0}, {1,1} },
@@ -62,8 +62,8 @@ static const int8_t h_pattern[8][40][2] = {
     {0,-4}, {0,-2}, {0,0}, {0,2}, {0,4}, {2,-4}, {2,-2}, {2,0}, {2,2}, {2,4},
     {4,-4}, {4,-2}, {4,0}, {4,2}, {4,4} },
 };
-static const int h_pattern_num[8] = { 1, 5, 9, 13, 13, 21, 25, 25 };
-static const int h_pattern_pad[8] = { 1, 1, 1, 2, 2, 3, 2, 4 };
+static constexpr int h_pattern_num[8] = { 1, 5, 9, 13, 13, 21, 25, 25 };
+static constexpr int h_pattern_pad[8] = { 1, 1, 1, 2, 2, 3, 2, 4 };
 #define PATTERN_OFFSET 2  // m_pattern_offset, CoarseTracker.h:122
 
 // per pyramid level: geometry, PATCH_AREA, HALF_PATCH_SIZE and the byte offset oy*stride+ox of
@@ -74,6 +74,7 @@ struct TrackLevel {
   int w, h;
   uint32_t off;       // byte offset of the level in the frame's pyramid block
   int pa, pad;
+  int pi;             // index into the static pattern tables (max_level - level + 2), -1 = none
   int poff[TRK_MAX_PA];
 };
 
@@ -134,8 +135,10 @@ struct Shared {
   float a, a_new;
   float huber, outlier, lambda;
   int level, PA, pad, S;
+  int pi;                            // pattern index of the level
   int job, stop, n_select;
   int use_lds;
+  hso_camera cam;                    // LDS copy of the camera for the out-of-line projection
   int keys_lds_off;                  // byte offset of the level's key array in LDS, 0 = keys in memory
   unsigned sel[4096];                // selection histogram (SEL_WORDS)
   int wave_cnt[TRK_WAVES];
@@ -160,6 +163,7 @@ struct LevelCtx {
   int cols, rows, level;
   float scale;
   double fxl, fyl;
+  const __attribute__((address_space(3))) hso_camera* cam_lds;  // Shared::cam
 };
 
 // 4 consecutive bytes starting at byte address `addr` of a dword-aligned buffer
@@ -223,54 +227,68 @@ HSO_DEV FeatRaw load_feature(const LevelCtx& L, int f)
   return r;
 }
 
-HSO_DEV Proj project_feature(const LevelCtx& L, const Se3& T, const FeatRaw& raw, int border)
+// Out of line on purpose, with every input passed by value: its fp64 temporaries then never share
+// a register allocation with the pixel loops, and the body fits the call-clobbered registers, so
+// a call saves and restores nothing (the inlined version was the main source of spills in the
+// hot loops).  The camera is read from the workgroup's LDS copy (one address, broadcast reads).
+typedef const __attribute__((address_space(3))) hso_camera* CamPtr;
+__device__ __noinline__ Proj project_feature_nl(CamPtr camp, Se3 T, double bx, double by, double bz, double dist, int vis, int border,
+                                                int cols, int rows, float scale)
 {
   Proj p;
   p.ok = false;
-  if (!raw.vis) return p;
-  const double dist = raw.dist;
+  p.base = 0; p.w_tl = p.w_tr = p.w_bl = p.w_br = 0; p.x = p.y = p.z = 0;
+  if (!vis) return p;
   if (dist < 0) return p;
-  const double bx = raw.bx, by = raw.by, bz = raw.bz;
   se3_apply(T, bx * dist, by * dist, bz * dist, p.x, p.y, p.z);
   if (p.z < 0) return p;
   double pu, pv;
-  const hso_camera& cam = L.C->cam;
-  if (cam.model == HSO_CAM_FOV && cam.distortion) {
+  const int model = camp->model, distortion = camp->distortion;
+  if (model == HSO_CAM_FOV && distortion) {
+    hso_camera cam;
+    cam.model = model; cam.distortion = distortion; cam.width = camp->width; cam.height = camp->height;
+    cam.fx = camp->fx; cam.fy = camp->fy; cam.cx = camp->cx; cam.cy = camp->cy;
+    for (int i = 0; i < 5; i++) cam.d[i] = camp->d[i];
     world2cam_fov(&cam, p.x, p.y, p.z, &pu, &pv);
   } else {
     // AbstractCamera::world2cam, src/camera.cpp:89-125 (pinhole, optional radtan)
     const double u = p.x / p.z, v = p.y / p.z;
-    if (cam.model == HSO_CAM_PINHOLE && cam.distortion) {
+    if (model == HSO_CAM_PINHOLE && distortion) {
       const double r2 = u * u + v * v;
       const double r4 = r2 * r2;
       const double r6 = r4 * r2;
       const double a1 = 2 * u * v;
       const double a2 = r2 + 2 * u * u;
       const double a3 = r2 + 2 * v * v;
-      const double cdist = 1 + cam.d[0] * r2 + cam.d[1] * r4 + cam.d[4] * r6;
-      const double xd = u * cdist + cam.d[2] * a1 + cam.d[3] * a2;
-      const double yd = v * cdist + cam.d[2] * a3 + cam.d[3] * a1;
-      pu = xd * cam.fx + cam.cx;
-      pv = yd * cam.fy + cam.cy;
+      const double cdist = 1 + camp->d[0] * r2 + camp->d[1] * r4 + camp->d[4] * r6;
+      const double xd = u * cdist + camp->d[2] * a1 + camp->d[3] * a2;
+      const double yd = v * cdist + camp->d[2] * a3 + camp->d[3] * a1;
+      pu = xd * camp->fx + camp->cx;
+      pv = yd * camp->fy + camp->cy;
     } else {
-      pu = cam.fx * u + cam.cx;
-      pv = cam.fy * v + cam.cy;
+      pu = camp->fx * u + camp->cx;
+      pv = camp->fy * v + camp->cy;
     }
   }
-  const float u_cur = (float)pu * L.scale;
-  const float v_cur = (float)pv * L.scale;
+  const float u_cur = (float)pu * scale;
+  const float v_cur = (float)pv * scale;
   const int u_i = (int)floorf(u_cur);
   const int v_i = (int)floorf(v_cur);
-  if (u_i - border < 0 || v_i - border < 0 || u_i + border >= L.cols || v_i + border >= L.rows) return p;
+  if (u_i - border < 0 || v_i - border < 0 || u_i + border >= cols || v_i + border >= rows) return p;
   const float su = u_cur - (float)u_i;
   const float sv = v_cur - (float)v_i;
   p.w_tl = (float)((1.0 - su) * (1.0 - sv));
   p.w_tr = (float)(su * (1.0 - sv));
   p.w_bl = (float)((1.0 - su) * sv);
   p.w_br = su * sv;
-  p.base = v_i * L.cols + u_i - 1;
+  p.base = v_i * cols + u_i - 1;
   p.ok = true;
   return p;
+}
+
+HSO_DEV Proj project_feature(const LevelCtx& L, const Se3& T, const FeatRaw& raw, int border)
+{
+  return project_feature_nl(L.cam_lds, T, raw.bx, raw.by, raw.bz, raw.dist, raw.vis, border, L.cols, L.rows, L.scale);
 }
 
 // ------------------------------------------------------- workgroup reductions
@@ -735,6 +753,59 @@ HSO_DEV Moments feature_terms(const Shared& s, const LevelCtx& L, Ptr img, const
   return m;
 }
 
+// The same arithmetic (forward mode, image in LDS) with the pattern known at compile time
+// (PI = index into the static pattern tables), fully unrolled: tap offsets oy*stride+ox and
+// patch-cache offsets k*n_max are scalar expressions, there is no per-term table read and no
+// loop-carried prefetch record — about a quarter fewer instructions per term in a loop that is
+// VALU-issue-bound.  Deliberately NOT inlined: inside the megakernel the unrolled body competes
+// with the state of every other phase for the 168 VGPRs and spills; as a separate function it gets
+// its own register allocation, at the price of one call per feature.
+typedef const __attribute__((address_space(1))) float* GlbF32;
+template <int PI>
+__device__ __forceinline__ Moments feature_terms_static(LdsPtr img, GlbF32 ref_patch, int base, float w_tl, float w_tr, float w_bl,
+                                                      float w_br, uint32_t fb, uint32_t nb, int stride, float a, float huber,
+                                                      float outlier, float max_energy, int top)
+{
+  constexpr int PA = h_pattern_num[PI];
+  Moments m;
+  m.ee = m.ex = m.ey = m.xx = m.xy = m.yy = m.re = m.rx = m.ry = 0; m.E = 0; m.nt = PA; m.nsat = 0;
+  stride = __builtin_amdgcn_readfirstlane(stride);
+  nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+  typedef const __attribute__((address_space(1))) char* GlbBytes;
+  const GlbBytes rpb = (GlbBytes)ref_patch;
+  constexpr int PF = 4;  // reference intensities requested PF terms ahead of their use
+  float ipf[PF];
+#pragma unroll
+  for (int k = 0; k < PF && k < PA; k++) ipf[k] = *(GlbF32)(rpb + (fb + (uint32_t)k * nb));
+#pragma unroll
+  for (int k = 0; k < PA; k++) {
+    const int ox = h_pattern[PI][k][0], oy = h_pattern[PI][k][1];
+    const int a0 = base + (oy * stride + ox);
+    const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
+    const uint32_t r0 = fetch4(img, a0 - stride), r3 = fetch4(img, a0 + 2 * stride);
+    const float iref = ipf[k % PF];
+    if (k + PF < PA) ipf[k % PF] = *(GlbF32)(rpb + (fb + (uint32_t)(k + PF) * nb));
+    const float p11 = b1f(r1), p12 = b2f(r1), p21 = b1f(r2), p22 = b2f(r2);
+    const float cur = ((w_tl * p11 + w_tr * p12) + w_bl * p21) + w_br * p22;
+    const float res = cur - a * iref;
+    const float ares = fabsf(res);
+    const float hw = ares < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ares);
+    const bool sat = (ares > outlier) && !top;
+    const float e_term = top ? (hw * res) * res : ((hw * res) * res) * (2 - hw);
+    m.E += sat ? max_energy : e_term;
+    m.nsat += sat ? 1 : 0;
+    const float dx = fmaf(w_tl, p12 - b0f(r1), fmaf(w_tr, b3f(r1) - p11, fmaf(w_bl, p22 - b0f(r2), w_br * (b3f(r2) - p21))));
+    const float dy = fmaf(w_tl, p21 - b1f(r0), fmaf(w_tr, p22 - b2f(r0), fmaf(w_bl, b1f(r3) - p11, w_br * (b2f(r3) - p12))));
+    const float w = sat ? 0.0f : hw;
+    const float e = -iref;
+    const float we = w * e, wx = w * dx, wy = w * dy, wr = w * res;
+    m.ee = fmaf(we, e, m.ee); m.ex = fmaf(we, dx, m.ex); m.ey = fmaf(we, dy, m.ey);
+    m.xx = fmaf(wx, dx, m.xx); m.xy = fmaf(wx, dy, m.xy); m.yy = fmaf(wy, dy, m.yy);
+    m.re = fmaf(wr, e, m.re); m.rx = fmaf(wr, dx, m.rx); m.ry = fmaf(wr, dy, m.ry);
+  }
+  return m;
+}
+
 // Expand one feature's moments into the 28 + 7 normal-equation entries (computeGS, :499-525).
 // A = fx_l * J.row(0), B = fy_l * J.row(1) (frame.h:192-212); in inverse-compositional mode the
 // Jacobian is taken at the reference point and scaled by the exposure ratio
@@ -791,7 +862,7 @@ HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Mo
 #define TRK_FPT 1
 #endif
 #define HSO_PHASE __device__ __forceinline__
-template <bool IC, bool S1, typename Ptr>
+template <bool IC, bool S1, typename Ptr, int PI = -1>
 HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
 {
   const int n = L.job->n;
@@ -825,7 +896,15 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
       nxt = load_feature(L, f + G);  // next feature's record in flight during this pixel loop
       p[q] = project_feature(L, T, raw, border);
       DBG_T(0);
-      m[q] = feature_terms<IC>(s, L, img, p[q], f, a, sub, S, PA, top, huber, outlier, max_energy);
+      if constexpr (PI >= 0) {
+        if (p[q].ok)
+          m[q] = feature_terms_static<PI>(img, (GlbF32)L.sc.ref_patch, p[q].base, p[q].w_tl, p[q].w_tr, p[q].w_bl, p[q].w_br,
+                                          (uint32_t)f * 4u, (uint32_t)L.C->n_max * 4u, L.cols, a, huber, outlier, max_energy, top ? 1 : 0);
+        else
+          m[q] = Moments{};
+      } else {
+        m[q] = feature_terms<IC>(s, L, img, p[q], f, a, sub, S, PA, top, huber, outlier, max_energy);
+      }
       DBG_T(1);
       if (!S1) {
         // combine the S lanes of the feature group (power of two <= 64, never straddles a wave)
@@ -870,8 +949,20 @@ template <bool IC>
 HSO_DEV void eval_dispatch(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
 {
   if (s.S == 1) {
-    if (s.use_lds) eval_terms<IC, true, LdsPtr>(s, L, lds_img, T, a);
-    else eval_terms<IC, true, GlbPtr>(s, L, L.cur_glb, T, a);
+    if (s.use_lds) {
+      if constexpr (!IC) {
+        switch (s.pi) {  // pattern-specialised pixel loops for the patterns levels 4..1 use
+          case 2: eval_terms<IC, true, LdsPtr, 2>(s, L, lds_img, T, a); return;
+          case 3: eval_terms<IC, true, LdsPtr, 3>(s, L, lds_img, T, a); return;
+          case 4: eval_terms<IC, true, LdsPtr, 4>(s, L, lds_img, T, a); return;
+          case 5: eval_terms<IC, true, LdsPtr, 5>(s, L, lds_img, T, a); return;
+          default: break;
+        }
+      }
+      eval_terms<IC, true, LdsPtr>(s, L, lds_img, T, a);
+    } else {
+      eval_terms<IC, true, GlbPtr>(s, L, L.cur_glb, T, a);
+    }
   } else {
     if (s.use_lds) eval_terms<IC, false, LdsPtr>(s, L, lds_img, T, a);
     else eval_terms<IC, false, GlbPtr>(s, L, L.cur_glb, T, a);
@@ -885,6 +976,8 @@ HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const Tra
 {
   __syncthreads();
   L.C = &C; L.job = &job; L.sc = sc; L.level = level;
+  L.cam_lds = (const __attribute__((address_space(3))) hso_camera*)&s.cam;
+  if (threadIdx.x == 0) s.cam = C.cam;  // visible after the barriers below, before any projection
   const TrackLevel& V = C.lv[level];
   L.cols = V.w; L.rows = V.h;
   L.scale = 1.0f / (float)(1 << level);
@@ -893,7 +986,7 @@ HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const Tra
   L.ref_glb = reinterpret_cast<GlbPtr>(job.ref_base + V.off);
   L.cur_glb = reinterpret_cast<GlbPtr>(job.cur_base + V.off);
   if (threadIdx.x == 0) {
-    s.level = level; s.PA = V.pa; s.pad = V.pad;
+    s.level = level; s.PA = V.pa; s.pad = V.pad; s.pi = V.pi;
     int S = 1;
     while (S < 16 && job.n * S * 2 <= TRK_THREADS) S *= 2;
     s.S = S;
@@ -1327,9 +1420,10 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
     TrackLevel& V = st->lv[l];
     const int pi = p->max_level - l + PATTERN_OFFSET;  // CoarseTracker.cpp:80
     V.w = g.w[l]; V.h = g.h[l]; V.off = g.off[l];
-    V.pa = 0; V.pad = 0;
+    V.pa = 0; V.pad = 0; V.pi = -1;
     for (int k = 0; k < TRK_MAX_PA; k++) V.poff[k] = 0;
     if (pi < 0 || pi > 7) continue;
+    V.pi = pi;
     V.pa = h_pattern_num[pi]; V.pad = h_pattern_pad[pi];
     for (int k = 0; k < h_pattern_num[pi]; k++) V.poff[k] = h_pattern[pi][k][1] * g.w[l] + h_pattern[pi][k][0];
   }
