@@ -859,7 +859,7 @@ HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Mo
 // where the time goes — runs without the accumulators' register footprint; what persists
 // across rounds is the single float and the single double each lane is responsible for.
 #ifndef TRK_FPT
-#define TRK_FPT 1
+#define TRK_FPT 2  // features per thread and round: halves the number of wave exchanges per evaluation
 #endif
 #define HSO_PHASE __device__ __forceinline__
 template <bool IC, bool S1, typename Ptr, int PI = -1>
