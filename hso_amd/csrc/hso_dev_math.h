@@ -112,7 +112,15 @@ HSO_HD Se3 se3_exp(const double u[6])
   // one sincos of theta/2 serves both the quaternion and (through the double-angle
   // identities) the V matrix below, instead of the reference's four separate calls
   double sh, ch;
-  sincos(half_theta, &sh, &ch);
+  if (half_theta < 0.25) {
+    // LM steps are small rotations: Taylor series to x^13 / x^14 (truncation < 1e-21 for x <= 0.25)
+    // instead of the library's range reduction — this runs on one lane while a workgroup waits
+    const double x2 = half_theta * half_theta;
+    sh = half_theta * (1.0 + x2 * (-1.0 / 6 + x2 * (1.0 / 120 + x2 * (-1.0 / 5040 + x2 * (1.0 / 362880 + x2 * (-1.0 / 39916800 + x2 * (1.0 / 6227020800.0)))))));
+    ch = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24 + x2 * (-1.0 / 720 + x2 * (1.0 / 40320 + x2 * (-1.0 / 3628800 + x2 * (1.0 / 479001600.0 + x2 * (-1.0 / 87178291200.0)))))));
+  } else {
+    sincos(half_theta, &sh, &ch);
+  }
   const double real_factor = ch;
   if (theta < SMALL_EPS) {
     const double theta_sq = theta * theta;
