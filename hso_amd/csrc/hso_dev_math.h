@@ -61,7 +61,11 @@ HSO_HD void se3_apply(const Se3& T, double vx, double vy, double vz, double& ox,
 // single-lane LM step short
 HSO_HD void quat_normalize(Se3& r)
 {
+#ifdef __HIP_DEVICE_COMPILE__
+  const double inv = rsqrt(r.qx * r.qx + r.qy * r.qy + r.qz * r.qz + r.qw * r.qw);
+#else
   const double inv = 1.0 / sqrt(r.qx * r.qx + r.qy * r.qy + r.qz * r.qz + r.qw * r.qw);
+#endif
   r.qx *= inv; r.qy *= inv; r.qz *= inv; r.qw *= inv;
 }
 
@@ -122,12 +126,14 @@ HSO_HD Se3 se3_exp(const double u[6])
     sincos(half_theta, &sh, &ch);
   }
   const double real_factor = ch;
+  double inv_theta = 0;
   if (theta < SMALL_EPS) {
     const double theta_sq = theta * theta;
     const double theta_po4 = theta_sq * theta_sq;
     imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
   } else {
-    imag_factor = sh / theta;
+    inv_theta = 1.0 / theta;  // one reciprocal serves imag_factor and the V-matrix coefficients below
+    imag_factor = sh * inv_theta;
   }
   Se3 r;
   r.qw = real_factor; r.qx = imag_factor * o0; r.qy = imag_factor * o1; r.qz = imag_factor * o2;
@@ -145,9 +151,9 @@ HSO_HD Se3 se3_exp(const double u[6])
   if (theta < SMALL_EPS) {
     so3_matrix(r, V);
   } else {
-    const double theta_sq = theta * theta;
-    const double c1 = (2 * sh * sh) / (theta_sq);                     // 1 - cos(theta)
-    const double c2 = (theta - 2 * sh * ch) / (theta_sq * theta);     // theta - sin(theta)
+    const double inv_sq = inv_theta * inv_theta;
+    const double c1 = (2 * sh * sh) * inv_sq;                          // (1 - cos(theta)) / theta^2
+    const double c2 = (theta - 2 * sh * ch) * (inv_sq * inv_theta);    // (theta - sin(theta)) / theta^3
     for (int i = 0; i < 9; i++) {
       const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
       V[i] = (id + c1 * O[i]) + c2 * O2[i];

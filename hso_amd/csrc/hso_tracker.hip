@@ -1109,7 +1109,7 @@ HSO_DEV void lm_finish(Shared& s, bool inverse)
   double nrm = 0;
 #pragma unroll
   for (int i = 0; i < 7; i++) nrm += step[i] * step[i];
-  s.step_norm = sqrt(nrm);
+  s.step_norm = nrm;  // squared; compared with (1e-4)^2 below — no square root on the serial lane
 }
 
 #ifdef HSO_PHASE_TIMERS
@@ -1205,7 +1205,7 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
           s.lambda = s.lambda * 4;
           if ((double)s.lambda < 0.001) s.lambda = (float)0.001;
         }
-        if (!(s.step_norm > 1e-4)) s.stop = 1;
+        if (!(s.step_norm > 1e-8)) s.stop = 1;  // step.norm() > 1e-4 (CoarseTracker.cpp:169), on the squared norm
         // the last evaluation defines m_total_terms / m_saturated_terms (CoarseTracker.cpp:207)
         out->n_terms_last = (int)s.red[36];
         out->n_saturated_last = (int)s.red[37];
