@@ -43,6 +43,9 @@ using namespace hso_dev;
 #endif
 #define TRK_WAVES (TRK_THREADS / 64)
 #define TRK_MAX_PA 25
+#ifndef TRK_OLD_SHARE
+#define TRK_OLD_SHARE 10  // sixteenths of the features given to the older wavefront of each SIMD
+#endif
 #define KEY_INVALID 0xFFFFFFFFu
 #define N_RED 38  // 28 H + 7 b + E + n_terms + n_saturated
 
@@ -885,15 +888,33 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
   float totH = 0;
   double totD = 0;
   int slotH = 0, slotD = 0;
-  FeatRaw nxt = load_feature(L, grp);
-  for (int base = 0; base < (n > 0 ? n : 1); base += G * TRK_FPT) {
+  // Which features this thread owns.  With one thread per feature the split between the two
+  // wavefronts of a SIMD is deliberately uneven: the older wavefront (waves 0..3) wins issue
+  // arbitration and would finish ~25 % early, leaving the younger one to run alone without latency
+  // hiding; giving the older half TRK_OLD_SHARE/16 of the features lets both finish together.
+  // The mapping is static, so results stay bit-reproducible.
+  int gbase = 0, gn = n, gthreads = G, gt = grp;
+  if (S1) {
+    const int n_old = (int)(((long long)n * TRK_OLD_SHARE + 15) / 16);
+    const bool old = threadIdx.x < TRK_THREADS / 2;
+    gthreads = TRK_THREADS / 2;
+    gbase = old ? 0 : n_old;
+    gn = old ? n_old : n - n_old;
+    gt = old ? (int)threadIdx.x : (int)threadIdx.x - TRK_THREADS / 2;
+  }
+  auto fidx = [&](int k) { const int i = gt + k * gthreads; return i < gn ? gbase + i : n; };  // n = "none"
+  const int n_rounds = max(1, (((gn + gthreads - 1) / gthreads) + TRK_FPT - 1) / TRK_FPT);  // >= 1: the exchange assigns the slots
+  FeatRaw nxt = load_feature(L, fidx(0));
+  for (int r = 0; r < n_rounds; r++) {
     Proj p[TRK_FPT];
     Moments m[TRK_FPT];
+    int ff[TRK_FPT];
 #pragma unroll
     for (int q = 0; q < TRK_FPT; q++) {
-      const int f = base + q * G + grp;
+      const int f = fidx(r * TRK_FPT + q);
+      ff[q] = f;
       const FeatRaw raw = nxt;
-      nxt = load_feature(L, f + G);  // next feature's record in flight during this pixel loop
+      nxt = load_feature(L, fidx(r * TRK_FPT + q + 1));  // next feature's record in flight during this pixel loop
       p[q] = project_feature(L, T, raw, border);
       DBG_T(0);
       if constexpr (PI >= 0) {
@@ -923,7 +944,7 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
     for (int i = 0; i < 16; i++) acc.d[i] = 0;
 #pragma unroll
     for (int q = 0; q < TRK_FPT; q++)
-      if (p[q].ok && sub == 0) expand_feature<IC>(acc, L, p[q], m[q], base + q * G + grp, a);
+      if (p[q].ok && sub == 0) expand_feature<IC>(acc, L, p[q], m[q], ff[q], a);
     DBG_T(2);
     float th; double td;
     slotH = 0; slotD = 0;
