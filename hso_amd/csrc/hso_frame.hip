@@ -174,8 +174,9 @@ __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
           uint2 vx, vy;
           vx.x = (uint32_t)(sx[0] & 0xffff) | ((uint32_t)sx[1] << 16); vx.y = (uint32_t)(sx[2] & 0xffff) | ((uint32_t)sx[3] << 16);
           vy.x = (uint32_t)(sy[0] & 0xffff) | ((uint32_t)sy[1] << 16); vy.y = (uint32_t)(sy[2] & 0xffff) | ((uint32_t)sy[3] << 16);
-          *reinterpret_cast<uint2*>(gx + (size_t)y * W + x) = vx;
-          *reinterpret_cast<uint2*>(gy + (size_t)y * W + x) = vy;
+          typedef unsigned long long u64;
+          __builtin_nontemporal_store(((u64)vx.y << 32) | vx.x, reinterpret_cast<u64*>(gx + (size_t)y * W + x));
+          __builtin_nontemporal_store(((u64)vy.y << 32) | vy.x, reinterpret_cast<u64*>(gy + (size_t)y * W + x));
           if (level == 0 && x >= 16 && x < W - 16 && y >= 16 && y < H - 16) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
