@@ -223,9 +223,14 @@ HSO_DEV FeatRaw load_feature(const LevelCtx& L, int f)
   if (f < L.job->n) {
     const TrackJobDev& J = *L.job;
     const int ns = J.n_stride;
-    r.vis = L.sc.visible[f];
-    r.dist = J.feats[5 * ns + f];
-    r.bx = J.feats[2 * ns + f]; r.by = J.feats[3 * ns + f]; r.bz = J.feats[4 * ns + f];
+    // explicit global address space: a generic pointer would make these FLAT loads, which count on
+    // lgkmcnt as well, so every LDS wait of the pixel loop would also wait for this prefetch
+    typedef const __attribute__((address_space(1))) double* GlbF64;
+    typedef const __attribute__((address_space(1))) uint8_t* GlbU8;
+    const GlbF64 ft = (GlbF64)J.feats;
+    r.vis = ((GlbU8)L.sc.visible)[f];
+    r.dist = ft[5 * ns + f];
+    r.bx = ft[2 * ns + f]; r.by = ft[3 * ns + f]; r.bz = ft[4 * ns + f];
   }
   return r;
 }
