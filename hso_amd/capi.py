@@ -250,6 +250,7 @@ def load():
                                          C.c_float, C.c_float, C.c_float, P(EvalOut), vp, vp, vp]
     lib.hso_gpu_tracker_pattern.argtypes = [i32, i32, P(i32), P(i32), vp]
     lib.hso_gpu_align_batch.argtypes = [vp, P(Camera), i64, P(AlignJob), i32, P(AlignOut)]
+    lib.hso_gpu_align_multi.argtypes = [vp, P(Camera), P(i64), P(AlignJob), i32, P(AlignOut)]
     lib.hso_gpu_pose_optimize_batch.argtypes = [vp, P(Camera), P(PoseJob), i32, P(PoseResult), vp]
     lib.hso_gpu_ba_linearize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double] + [vp] * 8
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
@@ -268,7 +269,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
-    "hso_gpu_align_batch", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
+    "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
 ]
 
@@ -403,6 +404,15 @@ class Context:
         out = (AlignOut * len(jobs))()
         self._check(self.lib.hso_gpu_align_batch(self.h, C.byref(cam), cur_frame_id, arr, len(jobs), out), "align_batch")
         return list(out)
+
+    def align_multi(self, cam, cur_frame_ids, jobs, as_list=True):
+        """jobs[i] is searched in frame cur_frame_ids[i]; jobs may be a ready ctypes array."""
+        n = len(jobs)
+        arr = jobs if isinstance(jobs, C.Array) else (AlignJob * n)(*jobs)
+        ids = (C.c_int64 * n)(*cur_frame_ids)
+        out = (AlignOut * n)()
+        self._check(self.lib.hso_gpu_align_multi(self.h, C.byref(cam), ids, arr, n, out), "align_multi")
+        return list(out) if as_list else out
 
     # -- pose optimiser
     def pose_optimize_batch(self, cam, jobs):

@@ -29,11 +29,11 @@ using namespace hso_dev;
 struct AlignConsts {
   hso_camera cam;
   PyrGeom g;
-  const uint8_t* cur_base;
 };
 
 struct AlignJobDev {
   const uint8_t* ref_base;
+  const uint8_t* cur_base;   // the frame this candidate is searched in (jobs of many frames share a launch)
   hso_align_job j;
 };
 
@@ -45,30 +45,40 @@ __global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align(AlignConst
   const int jid = blockIdx.x * ALIGN_WAVES_PER_BLOCK + wave;
   if (jid >= n_jobs) return;
   const AlignJobDev& JD = jobs[jid];
-  const hso_align_out o = match_one(C.cam, C.g, C.cur_base, JD.ref_base, JD.j, (double)0.7f, s_pwb[wave]);  // checkNCC(…, 0.7), :364
+  const hso_align_out o = match_one(C.cam, C.g, JD.cur_base, JD.ref_base, JD.j, (double)0.7f, s_pwb[wave]);  // checkNCC(…, 0.7), :364
   if (lane == 0) outs[jid] = o;
 }
 
-extern "C" int hso_gpu_align_batch(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id,
-                                   const hso_align_job* jobs, int n_jobs, hso_align_out* out)
+// cur_frame_ids: one id per job (stride 1) or one id for all jobs (stride 0)
+static int align_run(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur_frame_ids, int id_stride, const hso_align_job* jobs,
+                     int n_jobs, hso_align_out* out)
 {
   if (!ctx) return HSO_E_INVALID;
-  if (!cam || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out))) return hso_fail(ctx, HSO_E_INVALID, "align_batch: bad argument");
+  if (!cam || !cur_frame_ids || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out))) return hso_fail(ctx, HSO_E_INVALID, "align_batch: bad argument");
   if (n_jobs == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  auto itc = ctx->frames.find(cur_frame_id);
-  if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "align_batch: current frame not resident");
-  const PyrGeom g = itc->second.g;
-  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "align_batch: camera size differs from the frame size");
+  PyrGeom g{};
   std::vector<AlignJobDev> h(n_jobs);
+  int64_t last_id = 0;
+  const uint8_t* last_base = nullptr;
   for (int i = 0; i < n_jobs; i++) {
+    const int64_t cid = cur_frame_ids[(size_t)i * id_stride];
+    if (i == 0 || cid != last_id) {
+      auto itc = ctx->frames.find(cid);
+      if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "align_batch: current frame not resident");
+      if (i == 0) g = itc->second.g;
+      else if (itc->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
+      last_id = cid; last_base = itc->second.base;
+    }
     auto itr = ctx->frames.find(jobs[i].ref_frame_id);
     if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "align_batch: reference frame not resident");
     if (itr->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
     if (jobs[i].ref_level < 0 || jobs[i].ref_level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "align_batch: bad ref_level");
     h[i].ref_base = itr->second.base;
+    h[i].cur_base = last_base;
     h[i].j = jobs[i];
   }
+  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "align_batch: camera size differs from the frame size");
   const size_t b_jobs = ((size_t)n_jobs * sizeof(AlignJobDev) + 255) & ~size_t(255);
   const size_t need = b_jobs + (size_t)n_jobs * sizeof(hso_align_out);
   if (ctx->batch_cap < need) {
@@ -82,11 +92,23 @@ extern "C" int hso_gpu_align_batch(hso_gpu_ctx* ctx, const hso_camera* cam, int6
   hso_align_out* d_out = reinterpret_cast<hso_align_out*>(ctx->d_batch + b_jobs);
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, h.data(), (size_t)n_jobs * sizeof(AlignJobDev), hipMemcpyHostToDevice, ctx->stream));
   AlignConsts C;
-  C.cam = *cam; C.g = g; C.cur_base = itc->second.base;
+  C.cam = *cam; C.g = g;
   const int blocks = (n_jobs + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK;
   hipLaunchKernelGGL(k_align, dim3(blocks), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream, C, d_jobs, n_jobs, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_jobs * sizeof(hso_align_out), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
+}
+
+extern "C" int hso_gpu_align_batch(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_align_job* jobs,
+                                   int n_jobs, hso_align_out* out)
+{
+  return align_run(ctx, cam, &cur_frame_id, 0, jobs, n_jobs, out);
+}
+
+extern "C" int hso_gpu_align_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur_frame_ids, const hso_align_job* jobs,
+                                   int n_jobs, hso_align_out* out)
+{
+  return align_run(ctx, cam, cur_frame_ids, 1, jobs, n_jobs, out);
 }

@@ -66,6 +66,19 @@ def main():
     for k in range(nb):
         ctx.frame_upload(1000 + k, pair["ref"] if k % 2 == 0 else pair["cur"])
     bid = list(range(1000, 1000 + nb))
+    # reprojection candidates of 128 sequences (frame pairs 1000+2k -> 1001+2k) in one launch
+    import ctypes as C
+    nseq = nb // 2
+    big = (capi.AlignJob * (nseq * len(jobs)))()
+    cur_ids = []
+    for q in range(nseq):
+        for i, j in enumerate(jobs):
+            C.memmove(C.byref(big[q * len(jobs) + i]), C.byref(j), C.sizeof(capi.AlignJob))
+            big[q * len(jobs) + i].ref_frame_id = 1000 + 2 * q
+        cur_ids += [1001 + 2 * q] * len(jobs)
+    dt = timed(lambda: ctx.align_multi(cam, cur_ids, big, as_list=False), max(args.reps // 4, 2))
+    out.append(dict(stage="align_multi x128 frames", units="candidates", n=len(cur_ids), ms_per_call=dt * 1e3,
+                    units_per_s=len(cur_ids) / dt))
     dt = timed(lambda: ctx.fast_detect_batch(bid, 3, 20, 8, 0), max(args.reps // 2, 2))
     out.append(dict(stage="fast_detect_batch x256 frames (levels 0-2, counts only)", units="pixels", n=npx * nb,
                     ms_per_call=dt * 1e3, units_per_s=npx * nb / dt))

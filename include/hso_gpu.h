@@ -266,6 +266,10 @@ typedef struct hso_align_out {
  * rule (src/reprojector.cpp:352-429) to the result array in its own visiting order. */
 int hso_gpu_align_batch(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id,
                         const hso_align_job* jobs, int n_jobs, hso_align_out* out);
+/* The candidates of many current frames (independent sequences, one frame size) in one launch:
+ * cur_frame_ids[i] is the frame job i is searched in. */
+int hso_gpu_align_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur_frame_ids,
+                        const hso_align_job* jobs, int n_jobs, hso_align_out* out);
 
 /* ---- pose_optimizer::optimizeLevenbergMarquardt3rd, src/pose_optimizer.cpp:399-771 ---- */
 

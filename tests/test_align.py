@@ -132,3 +132,29 @@ def test_align_batch_errors_and_empty(gpu_ctx, cam, pair2000):
     j = synth.align_jobs(pair2000, 1, 777)[0]
     with pytest.raises(capi.HsoGpuError):
         gpu_ctx.align_batch(cam, 12, [j])          # reference frame 777 not resident (or cur 12 missing)
+
+
+@pytest.mark.gpu
+def test_align_multi_equals_per_frame_calls(gpu_ctx, cam, pair2000, pair200, scene_arrays):
+    """Candidates of several current frames in one launch equal the per-frame calls bit for bit."""
+    rp, cp, sob, gx0, gy0 = scene_arrays
+    ids = (9501, 9502, 9503, 9504)
+    gpu_ctx.frame_upload(9501, pair2000["ref"]); gpu_ctx.frame_upload(9502, pair2000["cur"])
+    gpu_ctx.frame_upload(9503, pair200["ref"]); gpu_ctx.frame_upload(9504, pair200["cur"])
+    try:
+        ja = synth.align_jobs(pair2000, 150, 9501, gx=gx0, gy=gy0, seed=31)
+        jb = synth.align_jobs(pair200, 90, 9503, seed=32)
+        solo = gpu_ctx.align_batch(cam, 9502, ja) + gpu_ctx.align_batch(cam, 9504, jb)
+        # interleave the two frames' candidates
+        jobs, cur, order = [], [], []
+        for k in range(max(len(ja), len(jb))):
+            if k < len(ja): jobs.append(ja[k]); cur.append(9502); order.append(k)
+            if k < len(jb): jobs.append(jb[k]); cur.append(9504); order.append(len(ja) + k)
+        got = gpu_ctx.align_multi(cam, cur, jobs)
+        for g, idx in zip(got, order):
+            assert bytes(g) == bytes(solo[idx])
+        with pytest.raises(capi.HsoGpuError):
+            gpu_ctx.align_multi(cam, [9502, 777777], jobs[:2])          # second current frame not resident
+    finally:
+        for i in ids:
+            gpu_ctx.frame_release(i)
