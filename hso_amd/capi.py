@@ -341,8 +341,18 @@ class Context:
     def frame_release(self, frame_id):
         self._check(self.lib.hso_gpu_frame_release(self.h, frame_id), "frame_release")
 
+    @staticmethod
+    def level_dims(w0, h0, level):
+        """(w, h) of a pyramid level: halfSample sizes for multiples of 16, else the cvRound sizes of
+        the cv::resize branch (src/frame.cpp:302-312)."""
+        if w0 % 16 == 0 and h0 % 16 == 0:
+            return w0 >> level, h0 >> level
+        sc = np.float32(1.0 / (1 << level))
+        return int(np.rint(np.float32(w0) * sc)), int(np.rint(np.float32(h0) * sc))
+
     def frame_level(self, frame_id, level, w0, h0):
-        out = np.empty(((h0 >> level), (w0 >> level)), np.uint8)
+        lw, lh = self.level_dims(w0, h0, level)
+        out = np.empty((lh, lw), np.uint8)
         w, h = C.c_int(), C.c_int()
         self._check(self.lib.hso_gpu_frame_download_level(self.h, frame_id, level, _ptr(out), C.byref(w), C.byref(h)),
                     "frame_download_level")
@@ -350,7 +360,8 @@ class Context:
         return out
 
     def frame_sobel(self, frame_id, level, w0, h0):
-        gx = np.empty(((h0 >> level), (w0 >> level)), np.int16)
+        lw, lh = self.level_dims(w0, h0, level)
+        gx = np.empty((lh, lw), np.int16)
         gy = np.empty_like(gx)
         self._check(self.lib.hso_gpu_frame_download_sobel(self.h, frame_id, level, _ptr(gx), _ptr(gy)),
                     "frame_download_sobel")

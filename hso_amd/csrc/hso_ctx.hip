@@ -68,10 +68,10 @@ int hso_gpu_frame_upload(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img,
 {
   if (!ctx) return HSO_E_INVALID;
   if (!img || width <= 0 || height <= 0) return hso_fail(ctx, HSO_E_INVALID, "frame_upload: null image or bad size");
-  // src/frame.cpp:302: the halfSample pyramid needs level-0 cols and rows % 16 == 0;
-  // the cv::resize branch (:307-312) is not built.
-  if ((width % 16) != 0 || (height % 16) != 0)
-    return hso_fail(ctx, HSO_E_INVALID, "frame_upload: width and height must be multiples of 16");
+  // src/frame.cpp:302-312: halfSample pyramid when cols and rows are multiples of 16, cv::resize
+  // pyramid otherwise; the kernels group four level-0 pixels per lane
+  if ((width % 4) != 0)
+    return hso_fail(ctx, HSO_E_INVALID, "frame_upload: width must be a multiple of 4");
   if (width < 64 || height < 64) return hso_fail(ctx, HSO_E_INVALID, "frame_upload: image smaller than 64x64");
   if (ctx->frames.count(frame_id)) return hso_fail(ctx, HSO_E_INVALID, "frame_upload: frame id already resident");
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -109,8 +109,8 @@ int hso_gpu_frame_upload_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, const
 {
   if (!ctx) return HSO_E_INVALID;
   if (!frame_ids || !imgs || n <= 0) return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: null argument or n <= 0");
-  if ((width % 16) != 0 || (height % 16) != 0 || width < 64 || height < 64)
-    return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: width and height must be multiples of 16 and >= 64");
+  if ((width % 4) != 0 || width < 64 || height < 64)
+    return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: width must be a multiple of 4, width and height >= 64");
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const PyrGeom g = make_geom(width, height);
   std::vector<uint8_t*> bases(n);

@@ -94,6 +94,59 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrGeom g, uint8_t* const* base
   base[g.off[4] + (size_t)cy * g.w[4] + cx] = (uint8_t)r4[0][0];
 }
 
+// ---- cv::resize branch of createImgPyramid (src/frame.cpp:307-312) for level-0 sizes that are
+// not multiples of 16 (e.g. TUM-mono: 1280x1024 is shrunk to 920x736 before it reaches the Frame).
+// OpenCV's INTER_LINEAR for CV_8UC1 restated (imgproc/resize.cpp, C/SIMD path): an exact 2x2
+// decimation takes INTER_AREA's fast path (a + b + c + d + 2) >> 2, anything else the fixed-point
+// bilinear kernel (coefficients rounded to short at 11 bits, horizontal pass in int, vertical pass
+// ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2).  One thread per output pixel;
+// levels are produced one after the other (level l reads level l-1).  Rare path: plain kernel.
+__global__ __launch_bounds__(256) void k_copy_level0(PyrGeom g, uint8_t* const* bases, const uint8_t* const* srcs)
+{
+  const size_t n = (size_t)g.w[0] * g.h[0];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) bases[blockIdx.y][g.off[0] + i] = srcs[blockIdx.y][i];
+}
+
+__global__ __launch_bounds__(256) void k_resize_level(PyrGeom g, uint8_t* const* bases, int l)
+{
+  const int dw = g.w[l], dh = g.h[l], sw = g.w[l - 1], sh = g.h[l - 1];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dw * dh) return;
+  const int dx = i % dw, dy = i / dw;
+  uint8_t* base = bases[blockIdx.y];
+  const uint8_t* src = base + g.off[l - 1];
+  uint8_t* dst = base + g.off[l];
+  const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+  const int iscale_x = __double2int_rn(scale_x), iscale_y = __double2int_rn(scale_y);
+  const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+  if (area_fast && iscale_x == 2 && iscale_y == 2) {
+    const uint8_t* s0 = src + (size_t)(2 * dy) * sw + 2 * dx;
+    dst[(size_t)dy * dw + dx] = (uint8_t)((s0[0] + s0[1] + s0[sw] + s0[sw + 1] + 2) >> 2);
+    return;
+  }
+  float fx = (float)((dx + 0.5) * scale_x - 0.5);
+  int sx = (int)floor((double)fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0; sx = 0; }
+  const bool tail = sx + 1 >= sw;  // dx >= xmax: the horizontal pass copies S[sx] * 2048
+  if (tail && sx >= sw - 1) { fx = 0; sx = sw - 1; }
+  const int a0 = max(-32768, min(32767, __float2int_rn((1.f - fx) * 2048))), a1 = max(-32768, min(32767, __float2int_rn(fx * 2048)));
+  float fy = (float)((dy + 0.5) * scale_y - 0.5);
+  const int sy0 = (int)floor((double)fy);
+  fy -= (float)sy0;
+  const int b0 = max(-32768, min(32767, __float2int_rn((1.f - fy) * 2048))), b1 = max(-32768, min(32767, __float2int_rn(fy * 2048)));
+  int r[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    int sy = sy0 + k;
+    sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;
+    const uint8_t* S = src + (size_t)sy * sw;
+    r[k] = tail ? (int)S[sx] * 2048 : (int)S[sx] * a0 + (int)S[sx + 1] * a1;
+  }
+  dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r[0] >> 4)) >> 16) + ((b1 * (r[1] >> 4)) >> 16) + 2) >> 2);
+}
+
 // -------------------------------------------------------------------- Sobel
 
 #define SOB_STRIP 15           // rows per lane
@@ -131,8 +184,9 @@ __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
   int16_t* gy = reinterpret_cast<int16_t*>(base + g.sob_off[level][1]);
   unsigned isum = 0;
   double gsum = 0;
-  if (x < W && ys < H) {  // W is a multiple of 4 on levels 0..2: a lane's four pixels are all in or all out
-    const bool fast = (x >= 4) && (x + 8 <= W);
+  if (x < W && ys < H) {
+    // three aligned dwords per row when the row start is dword aligned and the lane is interior
+    const bool fast = (x >= 4) && (x + 8 <= W) && ((W & 3) == 0);
     int hd[5][4], hs[5][4], cen[5][4];
 #pragma unroll
     for (int i = 0; i < SOB_STRIP + 4; i++) {
@@ -175,8 +229,14 @@ __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
           vx.x = (uint32_t)(sx[0] & 0xffff) | ((uint32_t)sx[1] << 16); vx.y = (uint32_t)(sx[2] & 0xffff) | ((uint32_t)sx[3] << 16);
           vy.x = (uint32_t)(sy[0] & 0xffff) | ((uint32_t)sy[1] << 16); vy.y = (uint32_t)(sy[2] & 0xffff) | ((uint32_t)sy[3] << 16);
           typedef unsigned long long u64;
-          __builtin_nontemporal_store(((u64)vx.y << 32) | vx.x, reinterpret_cast<u64*>(gx + (size_t)y * W + x));
-          __builtin_nontemporal_store(((u64)vy.y << 32) | vy.x, reinterpret_cast<u64*>(gy + (size_t)y * W + x));
+          if (x + 4 <= W && ((W & 3) == 0)) {
+            __builtin_nontemporal_store(((u64)vx.y << 32) | vx.x, reinterpret_cast<u64*>(gx + (size_t)y * W + x));
+            __builtin_nontemporal_store(((u64)vy.y << 32) | vy.x, reinterpret_cast<u64*>(gy + (size_t)y * W + x));
+          } else {  // widths that are not multiples of 4 (cv::resize pyramids): element-wise, last lane clipped
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (x + k < W) { gx[(size_t)y * W + x + k] = (int16_t)sx[k]; gy[(size_t)y * W + x + k] = (int16_t)sy[k]; }
+          }
           if (level == 0 && x >= 16 && x < W - 16 && y >= 16 && y < H - 16) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -230,9 +290,15 @@ __global__ __launch_bounds__(64) void k_frame_stats(PyrGeom g, uint8_t* const* b
 int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases, const uint8_t* const* d_srcs,
                     hso_frame_stats* d_stats, int n)
 {
-  const int cells = (g.w[0] >> 4) * (g.h[0] >> 4);
-  dim3 gp((cells + 255) / 256, n);
-  hipLaunchKernelGGL(k_pyramid, gp, dim3(256), 0, ctx->stream, g, d_bases, d_srcs);
+  if ((g.w[0] % 16) == 0 && (g.h[0] % 16) == 0) {  // halfSample pyramid, src/frame.cpp:302-305
+    const int cells = (g.w[0] >> 4) * (g.h[0] >> 4);
+    dim3 gp((cells + 255) / 256, n);
+    hipLaunchKernelGGL(k_pyramid, gp, dim3(256), 0, ctx->stream, g, d_bases, d_srcs);
+  } else {                                         // cv::resize pyramid, :307-312
+    if (d_srcs) hipLaunchKernelGGL(k_copy_level0, dim3((g.w[0] * g.h[0] + 255) / 256, n), dim3(256), 0, ctx->stream, g, d_bases, d_srcs);
+    for (int l = 1; l < HSO_N_PYR_LEVELS; l++)
+      hipLaunchKernelGGL(k_resize_level, dim3((g.w[l] * g.h[l] + 255) / 256, n), dim3(256), 0, ctx->stream, g, d_bases, l);
+  }
   const int sob_total = g.sobel_blocks[0] + g.sobel_blocks[1] + g.sobel_blocks[2];
   hipLaunchKernelGGL(k_sobel, dim3(sob_total, n), dim3(256), 0, ctx->stream, g, d_bases);
   hipLaunchKernelGGL(k_frame_stats, dim3(n), dim3(64), 0, ctx->stream, g, d_bases, d_stats);
@@ -245,7 +311,13 @@ PyrGeom make_geom(int w, int h)
   PyrGeom g{};
   uint32_t off = 0;
   for (int l = 0; l < HSO_N_PYR_LEVELS; l++) {
-    g.w[l] = w >> l; g.h[l] = h >> l;
+    if ((w % 16) == 0 && (h % 16) == 0) {
+      g.w[l] = w >> l; g.h[l] = h >> l;
+    } else {  // cv::Size(cvRound((float)cols * scale), cvRound((float)rows * scale)), src/frame.cpp:309-310
+      const float scale = 1.0 / (1 << l);
+      g.w[l] = (int)lrint((double)((float)w * scale));
+      g.h[l] = (int)lrint((double)((float)h * scale));
+    }
     g.off[l] = off;
     const uint32_t bytes = (uint32_t)g.w[l] * g.h[l] + (uint32_t)g.w[l] + 64;  // + one zero row + slack
     off += (bytes + 255u) & ~255u;

@@ -129,7 +129,7 @@ HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const u
     const float a10 = (float)(-A10 * invdet), a11 = (float)(A00 * invdet);
     const bool warp_nan = isnan(a00);  // reference: patch left untouched (uninitialised); defined as 0 here
     const int L = J.ref_level;
-    const int cols = W >> L, rows = H >> L;
+    const int cols = g.w[L], rows = g.h[L];  // img_pyr_[L].cols / rows
     const uint8_t* img = ref_base + g.off[L];
     const float rx = (float)(J.px_ref[0] / (double)(1 << L)), ry = (float)(J.px_ref[1] / (double)(1 << L));
     const float scaleTarget = (float)(1 << search_level);
@@ -200,7 +200,7 @@ HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const u
   }
 
   // ---- LK iterations (align2D :526-598 / align1D :214-301)
-  const int cols = W >> search_level, rows = H >> search_level;
+  const int cols = g.w[search_level], rows = g.h[search_level];
   const uint8_t* cur = cur_base + g.off[search_level];
   double pxs0 = J.px_cur[0] / (double)(1 << search_level), pxs1 = J.px_cur[1] / (double)(1 << search_level);
   const double orig0 = pxs0, orig1 = pxs1;

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
       const double invdet = 1.0 / det;
       const float a00 = (float)(A11 * invdet), a01 = (float)(-A01 * invdet), a10 = (float)(-A10 * invdet), a11 = (float)(A00 * invdet);
       const bool warp_nan = isnan(a00);
-      const int L = S.level, cols = W >> L, rows = H >> L;
+      const int L = S.level, cols = C.g.w[L], rows = C.g.h[L];  // img_pyr_[L].cols / rows
       const uint8_t* img = SD.ref_base + C.g.off[L];
       const float rx = (float)(S.px[0] / (double)(1 << L)), ry = (float)(S.px[1] / (double)(1 << L));
       const float scaleTarget = (float)(1 << sl);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     }
 
     // ---- march along the epipolar line, ZMNCC per step (:906-960)
-    const int cols = W >> sl, rows = H >> sl;
+    const int cols = C.g.w[sl], rows = C.g.h[sl];
     const uint8_t* cur = C.cur_base + C.g.off[sl];
     const float hostMean = wave_sum_all(ref_px) / 64;
     const float hdev = ref_px - hostMean;

@@ -84,9 +84,11 @@ int hso_gpu_synchronize(hso_gpu_ctx* ctx);
  * vision.cpp:76), the 5x5 Sobel images of levels 0-2 and the two frame
  * statistics, all on the device.  `img` is a HOST pointer (img_is_device = 0)
  * or a DEVICE pointer (img_is_device = 1) to width*height bytes.
- * Errors: HSO_E_INVALID if the size is not (width % 16 == 0 && height % 16 == 0)
- * [the cv::resize path of src/frame.cpp:307-312 is not built yet] or the frame
- * id is already resident. */
+ * Sizes that are not multiples of 16 in both dimensions take the cv::resize branch of
+ * createImgPyramid (src/frame.cpp:307-312; e.g. TUM-mono's 920x736): level sizes are
+ * cvRound(size * 2^-L) and the levels come from OpenCV's INTER_LINEAR restated.
+ * Errors: HSO_E_INVALID if width % 4 != 0, the image is smaller than 64x64 or the
+ * frame id is already resident. */
 int hso_gpu_frame_upload(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img,
                          int width, int height, int img_is_device,
                          hso_frame_stats* stats_out);

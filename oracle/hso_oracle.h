@@ -57,7 +57,9 @@ double hso_or_error_multiplier2(const hso_camera* cam);                         
 
 /* ---- frame: pyramid, Sobel, stats (src/frame.cpp, src/vikit/vision.cpp) ---- */
 void hso_or_half_sample(const uint8_t* in, int w, int h, uint8_t* out);       /* vision.cpp:70-108 incl. SSE2 path :19-44 */
-/* levels[] must hold 5 buffers; levels[0] is copied from img */
+void hso_or_pyramid_dims(int w, int h, int level, int* lw, int* lh);           /* frame.cpp:302-312 */
+void hso_or_resize_linear_8u(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh); /* cv::resize INTER_LINEAR, frame.cpp:311 */
+/* levels[] must hold 5 buffers of the sizes hso_or_pyramid_dims reports; levels[0] is copied from img */
 int hso_or_create_pyramid(const uint8_t* img, int w, int h, uint8_t* const levels[HSO_N_PYR_LEVELS]); /* frame.cpp:296-314 */
 void hso_or_sobel5(const uint8_t* img, int w, int h, int16_t* gx, int16_t* gy); /* cv::Sobel(CV_16S, k=5, BORDER_REPLICATE), frame.cpp:218-219 */
 void hso_or_frame_stats(const uint8_t* img0, const int16_t* gx0, const int16_t* gy0, int w, int h,

@@ -308,7 +308,9 @@ static void find_match(const hso_camera* cam, const hso_align_job* job, const ui
   const int search_level = hso_or_best_search_level(out->A_cur_ref, HSO_N_SOBEL_LEVELS - 1);  /* Config::nPyrLevels()-1 */
   out->search_level = search_level;
   float temp[100], pwb[100], patch[64], patchNCC[64];
-  hso_or_warp_affine(out->A_cur_ref, ref_pyr[job->ref_level], w >> job->ref_level, h >> job->ref_level, job->px_ref,
+  int rcols, rrows;  /* img_pyr_[level].cols / rows */
+  hso_or_pyramid_dims(w, h, job->ref_level, &rcols, &rrows);
+  hso_or_warp_affine(out->A_cur_ref, ref_pyr[job->ref_level], rcols, rrows, job->px_ref,
                      job->ref_level, search_level, halfpatch_size_ + 1, temp);
   if (job->kf_gap_lt4 && fabsf(job->exposure_rat * 128 - 128) > 30.0f) {
     for (int i = 0; i < 100; i++) pwb[i] = temp[i] * job->exposure_rat;
@@ -320,7 +322,8 @@ static void find_match(const hso_camera* cam, const hso_align_job* job, const ui
   memset(patchNCC, 0, sizeof(patchNCC));
   double px_scaled[2] = { job->px_cur[0] / (1 << search_level), job->px_cur[1] / (1 << search_level) };
   const double px_scaled_orig[2] = { px_scaled[0], px_scaled[1] };
-  const int cols = w >> search_level, rows = h >> search_level;
+  int cols, rows;
+  hso_or_pyramid_dims(w, h, search_level, &cols, &rows);
   int ok;
   if (job->type == HSO_FTR_EDGELET) {
     double d0 = out->A_cur_ref[0] * job->grad[0] + out->A_cur_ref[1] * job->grad[1];

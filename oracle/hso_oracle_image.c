@@ -54,17 +54,97 @@ void hso_or_half_sample(const uint8_t* in, int w, int h, uint8_t* out)
   }
 }
 
-/* src/frame.cpp:296-314.  Only the halfSample branch (level-0 cols and rows
- * both multiples of 16, :302) is restated; the cv::resize branch (:307-312)
- * returns -1. */
+/* cvRound: lrint under the default rounding mode = round half to even (OpenCV's SSE2 cvRound) */
+static int cv_round(double v) { return (int)lrint(v); }
+static int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+static short sat_short(float v) { int i = cv_round(v); return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i)); }
+
+/* size of pyramid level `level` of a w x h frame, src/frame.cpp:302-312 */
+void hso_or_pyramid_dims(int w, int h, int level, int* lw, int* lh)
+{
+  if ((w % 16) == 0 && (h % 16) == 0) { *lw = w >> level; *lh = h >> level; return; }
+  const float scale = 1.0 / (1 << level);
+  *lw = cv_round((float)w * scale);
+  *lh = cv_round((float)h * scale);
+}
+
+/* cv::resize(src, dst, dsize, 0, 0, cv::INTER_LINEAR) for CV_8UC1 (src/frame.cpp:311), restated from
+ * OpenCV's imgproc/resize.cpp (not vendored; README.md:30 "tested 3.2.0"; the C/SIMD path — an IPP
+ * build of OpenCV rounds differently): an exact 2x2 decimation is redirected to INTER_AREA's fast
+ * path, (a + b + c + d + 2) >> 2; everything else is the fixed-point bilinear kernel with
+ * INTER_RESIZE_COEF_BITS = 11: horizontal pass in int with coefficients rounded to short
+ * (1 - fx, fx) * 2048, vertical pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2,
+ * pixel centres aligned ((d + 0.5) * scale - 0.5), source indices clamped at the borders. */
+void hso_or_resize_linear_8u(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh)
+{
+  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+  const int iscale_x = cv_round(scale_x), iscale_y = cv_round(scale_y);
+  const int is_area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+  if (is_area_fast && iscale_x == 2 && iscale_y == 2) {
+    for (int y = 0; y < dh; y++)
+      for (int x = 0; x < dw; x++) {
+        const uint8_t* s0 = src + (size_t)(2 * y) * sw + 2 * x;
+        dst[(size_t)y * dw + x] = (uint8_t)((s0[0] + s0[1] + s0[sw] + s0[sw + 1] + 2) >> 2);
+      }
+    return;
+  }
+  int* xofs = (int*)malloc(sizeof(int) * (size_t)dw);
+  short* ialpha = (short*)malloc(sizeof(short) * 2 * (size_t)dw);
+  int xmax = dw;
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx + 1 >= sw) { if (dx < xmax) xmax = dx; if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+    xofs[dx] = sx;
+    ialpha[2 * dx] = sat_short((1.f - fx) * 2048);
+    ialpha[2 * dx + 1] = sat_short(fx * 2048);
+  }
+  int* row0 = (int*)malloc(sizeof(int) * (size_t)dw);
+  int* row1 = (int*)malloc(sizeof(int) * (size_t)dw);
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy0 = cv_floor(fy);
+    fy -= sy0;
+    const short b0 = sat_short((1.f - fy) * 2048), b1 = sat_short(fy * 2048);
+    int* rows[2] = { row0, row1 };
+    for (int k = 0; k < 2; k++) {
+      int sy = sy0 + k;
+      sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;
+      const uint8_t* S = src + (size_t)sy * sw;
+      int* D = rows[k];
+      int dx = 0;
+      for (; dx < xmax; dx++) D[dx] = S[xofs[dx]] * ialpha[2 * dx] + S[xofs[dx] + 1] * ialpha[2 * dx + 1];
+      for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * 2048;
+    }
+    for (int x = 0; x < dw; x++)
+      dst[(size_t)dy * dw + x] = (uint8_t)((((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(xofs); free(ialpha); free(row0); free(row1);
+}
+
+/* frame_utils::createImgPyramid, src/frame.cpp:296-314: halfSample when the level-0 size is a
+ * multiple of 16 in both dimensions (:302), cv::resize of the previous level otherwise (:307-312).
+ * levels[i] must hold the size hso_or_pyramid_dims reports. */
 int hso_or_create_pyramid(const uint8_t* img, int w, int h, uint8_t* const levels[HSO_N_PYR_LEVELS])
 {
-  if ((w % 16) != 0 || (h % 16) != 0) return -1;
   memcpy(levels[0], img, (size_t)w * h);
-  int lw = w, lh = h;
+  if ((w % 16) == 0 && (h % 16) == 0) {
+    int lw = w, lh = h;
+    for (int i = 1; i < HSO_N_PYR_LEVELS; i++) {
+      hso_or_half_sample(levels[i - 1], lw, lh, levels[i]);
+      lw /= 2; lh /= 2;
+    }
+    return 0;
+  }
+  int pw = w, ph = h;
   for (int i = 1; i < HSO_N_PYR_LEVELS; i++) {
-    hso_or_half_sample(levels[i - 1], lw, lh, levels[i]);
-    lw /= 2; lh /= 2;
+    int lw, lh;
+    hso_or_pyramid_dims(w, h, i, &lw, &lh);
+    hso_or_resize_linear_8u(levels[i - 1], pw, ph, levels[i], lw, lh);
+    pw = lw; ph = lh;
   }
   return 0;
 }

@@ -270,7 +270,9 @@ static int do_line_stereo(const hso_camera* cam, const hso_seed* s, const hso_se
   const int search_level = hso_or_best_search_level(A, HSO_N_SOBEL_LEVELS - 1);
   o->search_level = search_level;
   float pwb[100], patch[64];
-  hso_or_warp_affine(A, ref_pyr[s->level], w >> s->level, h >> s->level, s->px, s->level, search_level, 5, pwb);
+  int rcols, rrows;  /* img_pyr_[level].cols / rows */
+  hso_or_pyramid_dims(w, h, s->level, &rcols, &rrows);
+  hso_or_warp_affine(A, ref_pyr[s->level], rcols, rrows, s->px, s->level, search_level, 5, pwb);
   if (fabsf(exposure_rat * 128 - 128) > 30.0f)
     for (int i = 0; i < 100; ++i) pwb[i] = pwb[i] * exposure_rat;
   for (int y = 1; y < 9; ++y) for (int x = 0; x < 8; ++x) patch[(y - 1) * 8 + x] = pwb[y * 10 + 1 + x];
@@ -317,7 +319,8 @@ static int do_line_stereo(const hso_camera* cam, const hso_seed* s, const hso_se
   double uv_best[2] = { 0, 0 };
   float patch_f[64];
   int loopCounter = 0, loopCBest = -1, loopCSecond = -1;
-  const int cols = w >> search_level, rows = h >> search_level;
+  int cols, rows;
+  hso_or_pyramid_dims(w, h, search_level, &cols, &rows);
   while ((((incx < 0) == (cpx > px_close[0])) && ((incy < 0) == (cpy > px_close[1]))) || loopCounter == 0) {
     const double px[2] = { cpx, cpy };
     if (!is_in_frame_level(w, h, (int)px[0], (int)px[1], 8, search_level)) { cpx += incx; cpy += incy; loopCounter++; continue; }

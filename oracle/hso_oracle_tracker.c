@@ -168,7 +168,8 @@ static void precompute_reference_patches(hso_or_tracker* t)
 {
   const int border = t->half_patch + 1;
   const uint8_t* ref_img = t->ref_pyr[t->level];
-  const int cols = t->w >> t->level, rows = t->h >> t->level;
+  int cols, rows;  /* img_pyr_[level].cols / rows */
+  hso_or_pyramid_dims(t->w, t->h, t->level, &cols, &rows);
   const int stride = cols;
   const float scale = 1.0f / (1 << t->level);
   const double fxl = t->cam.fx * scale;
@@ -252,7 +253,8 @@ int hso_or_tracker_select(hso_or_tracker* t, const hso_se3* T_cur_ref, float exp
 {
   const float b = 0;
   const uint8_t* cur_img = t->cur_pyr[t->level];
-  const int cols = t->w >> t->level, rows = t->h >> t->level;
+  int cols, rows;  /* img_pyr_[level].cols / rows */
+  hso_or_pyramid_dims(t->w, t->h, t->level, &cols, &rows);
   const int stride = cols;
   const int border = t->half_patch + 1;
   const float scale = 1.0f / (1 << t->level);
@@ -319,7 +321,8 @@ static double compute_residuals(hso_or_tracker* t, const hso_se3* T_cur_ref, flo
     for (size_t i = 0; i < cnt; i++) t->jac_true[i] = (double)exposure_rat * t->jac_raw[i];
   }
   const uint8_t* cur_img = t->cur_pyr[t->level];
-  const int cols = t->w >> t->level, rows = t->h >> t->level;
+  int cols, rows;  /* img_pyr_[level].cols / rows */
+  hso_or_pyramid_dims(t->w, t->h, t->level, &cols, &rows);
   const int stride = cols;
   const int border = t->half_patch + 1;
   const float scale = 1.0f / (1 << t->level);

@@ -163,12 +163,27 @@ def _padded_copy(a):
 def create_pyramid(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
-    levels = [_padded_zeros(h >> i, w >> i) for i in range(N_PYR_LEVELS)]
+    levels = [_padded_zeros(*pyramid_dims(w, h, i)[::-1]) for i in range(N_PYR_LEVELS)]
     ptrs = (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in levels])
     rc = load().hso_or_create_pyramid(_ptr(img), w, h, ptrs)
     if rc != 0:
-        raise ValueError("pyramid: size not a multiple of 16")
+        raise ValueError("pyramid: failed")
     return levels
+
+
+def pyramid_dims(w, h, level):
+    """(width, height) of a pyramid level: w >> l for sizes that are multiples of 16, else the
+    cvRound sizes of the cv::resize branch (frame.cpp:302-312)."""
+    lw, lh = C.c_int(), C.c_int()
+    load().hso_or_pyramid_dims(int(w), int(h), int(level), C.byref(lw), C.byref(lh))
+    return lw.value, lh.value
+
+
+def resize_linear(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros((dh, dw), np.uint8)
+    load().hso_or_resize_linear_8u(_ptr(img), img.shape[1], img.shape[0], _ptr(out), dw, dh)
+    return out
 
 
 def half_sample(img):

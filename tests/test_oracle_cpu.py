@@ -150,8 +150,31 @@ def test_pyramid_euroc_level_paths(orc):
     lv = orc.create_pyramid(img)
     assert [l.shape for l in lv] == [(480, 752), (240, 376), (120, 188), (60, 94), (30, 47)]
     assert np.array_equal(lv[1], orc.half_sample(lv[0])) and np.array_equal(lv[4], orc.half_sample(lv[3]))
-    with pytest.raises(ValueError):
-        orc.create_pyramid(np.zeros((736, 920), np.uint8))  # cv::resize branch not restated
+
+
+def test_pyramid_resize_branch_tum_mono(orc):
+    """Level-0 sizes that are not multiples of 16 take cv::resize (frame.cpp:307-312): TUM-mono's
+    920x736.  Level sizes follow cvRound (58, not 57, at level 4); an exact 2x step is OpenCV's
+    area-fast path (a+b+c+d+2)>>2, the 115->58 step the fixed-point bilinear kernel."""
+    rng = np.random.default_rng(16)
+    img = rng.integers(0, 256, (736, 920), dtype=np.uint8)
+    lv = orc.create_pyramid(img)
+    assert [l.shape for l in lv] == [(736, 920), (368, 460), (184, 230), (92, 115), (46, 58)]
+    for l in (1, 2, 3):
+        a = lv[l - 1].astype(int)
+        assert np.array_equal(lv[l], ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    # 115x92 -> 58x46: within one grey level of real-valued bilinear sampling at aligned pixel centres
+    src = lv[3].astype(float)
+    sx = (np.arange(58) + 0.5) * (115 / 58) - 0.5; sy = (np.arange(46) + 0.5) * (92 / 46) - 0.5
+    x0 = np.clip(np.floor(sx).astype(int), 0, 113); fx = np.clip(sx - x0, 0, 1)
+    y0 = np.clip(np.floor(sy).astype(int), 0, 90); fy = np.clip(sy - y0, 0, 1)
+    top = src[y0][:, x0] * (1 - fx) + src[y0][:, x0 + 1] * fx
+    bot = src[y0 + 1][:, x0] * (1 - fx) + src[y0 + 1][:, x0 + 1] * fx
+    assert np.abs(lv[4].astype(float) - (top * (1 - fy)[:, None] + bot * fy[:, None])).max() <= 1.0
+    # a case small enough to do by hand: [0 100 200] -> 2 pixels, weights (0.75, 0.25) and (0.25, 0.75)
+    tiny = np.array([[0, 100, 200], [0, 100, 200]], np.uint8)
+    assert orc.resize_linear(tiny, 2, 2).tolist() == [[25, 175], [25, 175]]
+    assert orc.pyramid_dims(922, 738, 1) == (461, 369) and orc.pyramid_dims(926, 730, 2) == (232, 182)   # 231.5 -> 232, 182.5 -> 182: half to even
 
 
 def test_sobel5_against_direct_convolution(orc):

@@ -103,7 +103,9 @@ def test_frame_batch_equals_single_and_device_source(gpu_ctx, orc):
 
 def test_frame_errors(gpu_ctx):
     with pytest.raises(capi.HsoGpuError):
-        gpu_ctx.frame_upload(930, np.zeros((736, 920), np.uint8))       # not a multiple of 16 (frame.cpp:302)
+        gpu_ctx.frame_upload(930, np.zeros((736, 922), np.uint8))       # width not a multiple of 4
+    with pytest.raises(capi.HsoGpuError):
+        gpu_ctx.frame_upload(930, np.zeros((48, 64), np.uint8))         # smaller than 64x64
     gpu_ctx.frame_upload(931, np.zeros((64, 64), np.uint8))
     with pytest.raises(capi.HsoGpuError):
         gpu_ctx.frame_upload(931, np.zeros((64, 64), np.uint8))          # already resident
@@ -367,3 +369,60 @@ def test_full_size_properties(gpu_ctx, cam, pair2000):
     rC = gpu_ctx.coarse_track_batch(cam, p, [gpu_ctx.make_job(1, 2, d["feats"], capi.SE3.identity(), 1.08)])[0]
     rot, tra = pose_err(rA, rC)
     assert rot <= 2e-5 and tra <= 2e-4 and abs(rA.exposure_rat - rC.exposure_rat) < 1e-4
+
+
+# ------------------------------------------------------------------ cv::resize pyramid branch (TUM-mono 920x736)
+TUM_MONO = dict(model=capi.CAM_PINHOLE, width=920, height=736, fx=0.349153 * 920 * 1.4, fy=0.436593 * 736 * 1.4, cx=459.5, cy=367.5)
+
+
+def test_resize_branch_frame_and_tracker(gpu_ctx, orc):
+    """A level-0 size that is not a multiple of 16: cv::resize pyramid (level 4 is 58x46, level 2 is
+    230 wide = not a multiple of 4), Sobel, stats, the tracker on all levels and FAST-9."""
+    d = synth.config2_pair(700, spec=TUM_MONO, seed=55)
+    camT = synth.camera(TUM_MONO)
+    w, h = 920, 736
+    for i in (910, 911):
+        try:
+            gpu_ctx.frame_release(i)
+        except capi.HsoGpuError:
+            pass
+    st_r, st_c = gpu_ctx.frame_upload(910, d["ref"]), gpu_ctx.frame_upload(911, d["cur"])
+    try:
+        rp, cp = orc.create_pyramid(d["ref"]), orc.create_pyramid(d["cur"])
+        assert [l.shape for l in cp] == [(736, 920), (368, 460), (184, 230), (92, 115), (46, 58)]
+        for l in range(5):
+            assert np.array_equal(gpu_ctx.frame_level(911, l, w, h), cp[l]), "pyramid level %d" % l
+        for l in range(3):
+            gx, gy = gpu_ctx.frame_sobel(911, l, w, h)
+            ox, oy = orc.sobel5(cp[l])
+            assert np.array_equal(gx, ox) and np.array_equal(gy, oy), "sobel level %d" % l
+        so = orc.frame_stats(cp[0], *orc.sobel5(cp[0]))
+        # the reference sums 6.2e5 pixels serially in fp32 (frame.cpp:223-236): its own rounding
+        # error grows with the pixel count; the device sum is an exact integer
+        assert st_c.integral_image == pytest.approx(so.integral_image, rel=1e-4)
+        assert st_c.integral_image == pytest.approx(float(cp[0][16:-16, 16:-16].astype(np.float64).mean()), rel=1e-6)
+        assert st_c.grad_mean == pytest.approx(so.grad_mean, rel=1e-4)
+        # tracker: per-level evaluation parity and the full run
+        p = capi.TrackParams(0, 4, 1, 50)
+        job = gpu_ctx.make_job(910, 911, d["feats"], capi.SE3.identity(), 1.0)
+        tr = orc.Tracker(camT, p, rp, cp, d["feats"])
+        for level in (4, 2):
+            tr.set_level(level)
+            n, hu, ou, _ = tr.select(capi.SE3.identity(), 1.0)
+            eo = tr.eval(capi.SE3.identity(), 1.0)
+            go, _, _, _ = gpu_ctx.tracker_eval(camT, p, job, level, capi.SE3.identity(), 1.0)
+            assert (go.huber, go.outlier, go.n_select) == (hu, ou, n)
+            assert (go.n_terms, go.n_saturated) == (eo.n_terms, eo.n_saturated)
+        ro = tr.run(capi.SE3.identity(), 1.0)
+        rg = gpu_ctx.coarse_track_batch(camT, p, [job])[0]
+        assert list(rg.iters) == list(ro.iters) and list(rg.accept_mask) == list(ro.accept_mask)
+        rot, tra = pose_err(rg, ro)
+        assert rot <= 1e-6 and tra <= 4e-6
+        # FAST-9 on the odd-sized levels
+        levels, counts = gpu_ctx.fast_detect(911, n_levels=3, threshold=15, border=8, cap=60000)
+        for L in range(3):
+            want, n = orc.fast_detect_level(cp[L], 15, border=8)
+            assert counts[L] == n and n > 20
+            assert levels[L].tobytes() == want.tobytes()
+    finally:
+        gpu_ctx.frame_release(910); gpu_ctx.frame_release(911)
