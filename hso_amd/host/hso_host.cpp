@@ -76,6 +76,36 @@ Vector2d AbstractCamera::world2cam(const Vector3d& xyz) const
   return {c_.fx * u + c_.cx, c_.fy * v + c_.cy};
 }
 
+Vector3d AbstractCamera::cam2world(const Vector2d& px) const
+{
+  double x, y;
+  if (c_.model == HSO_CAM_PINHOLE && c_.distortion) {
+    // cv::undistortPoints with float K, D and float I/O, five fixed-point iterations (src/camera.cpp:43-45,78-85)
+    const double fx = (float)c_.fx, fy = (float)c_.fy, cx = (float)c_.cx, cy = (float)c_.cy;
+    const double k0 = (float)c_.d[0], k1 = (float)c_.d[1], p1 = (float)c_.d[2], p2 = (float)c_.d[3], k2 = (float)c_.d[4];
+    x = (float)px[0]; y = (float)px[1];
+    const double x0 = x = (x - cx) * (1. / fx);
+    const double y0 = y = (y - cy) * (1. / fy);
+    for (int it = 0; it < 5; it++) {
+      const double r2 = x * x + y * y;
+      const double icdist = 1 / (1 + ((k2 * r2 + k1) * r2 + k0) * r2);
+      const double dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+      const double dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      x = (x0 - dX) * icdist; y = (y0 - dY) * icdist;
+    }
+    x = (float)x; y = (float)y;
+  } else if (c_.model == HSO_CAM_FOV && c_.distortion) {
+    const double ud = (px[0] - c_.cx) / c_.fx, vd = (px[1] - c_.cy) / c_.fy;
+    const double dist = std::sqrt(ud * ud + vd * vd);
+    const double rd = std::tan(dist * c_.d[0]) / (2 * dist * std::tan(c_.d[0] / 2));
+    x = rd * ud; y = rd * vd;
+  } else {
+    x = (px[0] - c_.cx) / c_.fx; y = (px[1] - c_.cy) / c_.fy;
+  }
+  const double n = std::sqrt(x * x + y * y + 1.0);
+  return {x / n, y / n, 1.0 / n};
+}
+
 int Frame::frame_counter_ = 0;
 
 Frame::Frame(hso_gpu_ctx* ctx, AbstractCamera* cam, const uint8_t* img, int width, int height, double timestamp)
@@ -218,6 +248,56 @@ bool Matcher::findMatchDirect(const Point& pt, Frame& cur_frame, Vector2d& px_cu
   h_inv_ = r[0].h_inv;
   if (r[0].stage != HSO_ALIGN_REF_BORDER) { px_cur[0] = r[0].px_cur[0]; px_cur[1] = r[0].px_cur[1]; }  // :373
   return r[0].success != 0;
+}
+
+// ---------------------------------------------------------------- pose_optimizer
+void pose_optimizer::optimizeLevenbergMarquardt3rd(const double reproj_thresh, const size_t n_iter, const bool verbose,
+                                                   FramePtr& frame, double& estimated_scale, double& error_init,
+                                                   double& error_final, size_t& num_obs)
+{
+  (void)verbose;
+  // flatten fts_ in list order; host keyframe poses are de-duplicated into a table
+  std::vector<hso_pose_feat> feats;
+  std::vector<hso_se3> poses;
+  std::vector<const Frame*> pose_of;
+  feats.reserve(frame->fts_.size());
+  for (Feature* ft : frame->fts_) {
+    hso_pose_feat pf{};
+    pf.has_point = ft->point != nullptr;
+    pf.type = (int)ft->type;
+    pf.level = ft->level;
+    pf.f[0] = ft->f[0]; pf.f[1] = ft->f[1]; pf.f[2] = ft->f[2];
+    pf.grad[0] = ft->grad[0]; pf.grad[1] = ft->grad[1];
+    if (ft->point) {
+      const Feature* host = ft->point->hostFeature_;
+      pf.temporary = ft->point->type_ == Point::TYPE_TEMPORARY;
+      pf.host_f[0] = host->f[0]; pf.host_f[1] = host->f[1]; pf.host_f[2] = host->f[2];
+      pf.idist = ft->point->idist_;
+      size_t k = 0;
+      while (k < pose_of.size() && pose_of[k] != host->frame) k++;
+      if (k == pose_of.size()) { pose_of.push_back(host->frame); poses.push_back(host->frame->T_f_w_.v); }
+      pf.host_pose = (int)k;
+    }
+    feats.push_back(pf);
+  }
+  hso_pose_job job{};
+  job.feats = feats.data(); job.n_feats = (int)feats.size();
+  job.poses_f_w = poses.data(); job.n_poses = (int)poses.size();
+  job.T_f_w = frame->T_f_w_.v;
+  job.reproj_thresh = reproj_thresh; job.n_iter = (int)n_iter;
+  hso_pose_result res{};
+  std::vector<uint8_t> mask(feats.size() ? feats.size() : 1, 0);
+  uint8_t* mp = mask.data();
+  const int rc = hso_gpu_pose_optimize_batch(frame->ctx_, &frame->cam_->pod(), &job, 1, &res, &mp);
+  if (rc < 0) throw std::runtime_error(std::string("pose_optimizer: ") + hso_gpu_last_error(frame->ctx_));
+  estimated_scale = res.estimated_scale; error_init = res.error_init; error_final = res.error_final;
+  num_obs = (size_t)res.num_obs;
+  if (res.status != 0) return;                      // no residuals: the reference returns early (:456)
+  frame->T_f_w_.v = res.T_f_w;
+  for (int i = 0; i < 36; i++) frame->Cov_[i] = res.cov[i];
+  frame->m_error_in_px = res.error_in_px;
+  size_t i = 0;
+  for (Feature* ft : frame->fts_) { if (mask[i]) ft->point = nullptr; ++i; }   // :722-748
 }
 
 // ---------------------------------------------------------------- DepthFilter

@@ -40,6 +40,7 @@ public:
   Vector2d focal_length() const { return {c_.fx, c_.fy}; }
   double errorMultiplier2() const;                 // src/camera.cpp:59
   Vector2d world2cam(const Vector3d& xyz) const;   // src/camera.cpp:89-125,196-221
+  Vector3d cam2world(const Vector2d& px) const;    // src/camera.cpp:67-87,171-194 (unit bearing)
   const hso_camera& pod() const { return c_; }
 private:
   hso_camera c_;
@@ -52,6 +53,8 @@ using FramePtr = std::shared_ptr<Frame>;
 // include/hso/point.h:53-116 (fields the tracker reads)
 class Point {
 public:
+  enum PointType { TYPE_DELETED, TYPE_TEMPORARY, TYPE_CANDIDATE, TYPE_UNKNOWN, TYPE_GOOD };  // point.h:53
+  PointType type_ = TYPE_UNKNOWN;
   double idist_ = 1.0;            // inverse depth in the host frame (point.h:115)
   Feature* hostFeature_ = nullptr;
   Vector3d pos_{0, 0, 0};         // world position (point.h:63)
@@ -94,6 +97,8 @@ public:
   float integralImage_ = 0;      // src/frame.cpp:238
   float gradMean_ = 0;           // src/frame.cpp:240-245
   double m_exposure_time = -1;
+  double Cov_[36] = {0};         // 6x6 pose covariance, row-major (frame.h:93)
+  float m_error_in_px = 0;
   hso_gpu_ctx* ctx_;
 };
 
@@ -126,6 +131,14 @@ public:
   double h_inv_ = 0;
   hso_align_out last_{};
 };
+
+// include/hso/pose_optimizer.h — motion-only refinement of frame->T_f_w_ over its features' points
+namespace pose_optimizer {
+// src/pose_optimizer.cpp:399-771.  Mutates frame->T_f_w_, frame->Cov_ and frame->m_error_in_px,
+// sets feature->point = NULL for the observations it rejects (:722-748), like the reference.
+void optimizeLevenbergMarquardt3rd(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtr& frame,
+                                   double& estimated_scale, double& error_init, double& error_final, size_t& num_obs);
+}
 
 // include/hso/depth_filter.h:45-88
 struct Seed {

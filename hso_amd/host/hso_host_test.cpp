@@ -66,7 +66,7 @@ int main(int argc, char** argv)
 
     // ---- reprojection matching the way Reprojector::reprojectCell drives Matcher
     // (src/reprojector.cpp:352-429): project the point with the tracked pose, refine.
-    const int K = (int)std::min<size_t>(points.size(), 32);
+    const int K = (int)std::min<size_t>(points.size(), 96);
     std::printf("%d", K);
     for (int i = 0; i < K; i++) {
       hso::Point* pt = points[i];
@@ -78,6 +78,11 @@ int main(int argc, char** argv)
       hso::Matcher matcher;
       const bool ok = matcher.findMatchDirect(*pt, *next, px);
       std::printf(" %d %.12g %.12g %d", ok ? 1 : 0, px[0], px[1], matcher.search_level_);
+      if (ok) {  // the new observation, as Reprojector::reprojectCell creates it (src/reprojector.cpp:385-412)
+        hso::Feature* nf = new hso::Feature();
+        nf->frame = next.get(); nf->px = px; nf->f = cam.cam2world(px); nf->level = matcher.search_level_; nf->point = pt;
+        next->fts_.push_back(nf);
+      }
     }
     std::printf("\n");
 
@@ -92,6 +97,18 @@ int main(int argc, char** argv)
     std::printf("%zu %zu", n_seed_ok, df.seeds_.size());
     for (const hso::Seed& sd : df.seeds_) std::printf(" %.9g %.9g %.9g", sd.mu, sd.sigma2, sd.b);
     std::printf("\n");
+
+    // ---- motion-only pose refinement from a perturbed start (frame_handler_mono.cpp:241-243)
+    const hso::SE3 T_tracked = next->T_f_w_;
+    next->T_f_w_.v.t[0] += 0.004; next->T_f_w_.v.t[1] -= 0.003;
+    double scale = 0, e0 = 0, e1 = 0; size_t nobs = 0;
+    hso::pose_optimizer::optimizeLevenbergMarquardt3rd(2.0, 12, false, next, scale, e0, e1, nobs);
+    size_t culled = 0;
+    for (hso::Feature* ft : next->fts_) culled += ft->point == nullptr;
+    const hso_se3& P = next->T_f_w_.v;
+    std::printf("%zu %zu %zu %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.12g %.12g %.12g %.9g %.17g %.17g\n", next->fts_.size(), nobs,
+                culled, P.q[0], P.q[1], P.q[2], P.q[3], P.t[0], P.t[1], P.t[2], scale, e0, e1, next->m_error_in_px, T_tracked.v.t[0],
+                next->Cov_[0]);
     for (hso::Point* p : points) delete p;
   }
   hso_gpu_destroy(ctx);

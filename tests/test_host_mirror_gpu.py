@@ -62,7 +62,7 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
     # ---- Matcher::findMatchDirect (line 2) against hso_gpu_align_batch with the same inputs
     mv = lines[1].split()
     K = int(mv[0])
-    assert K == 32
+    assert K == 96
     has_pt = np.nonzero(idist > 0)[0]
     T_cw = capi.SE3.from_arrays(q, t)
     R = synth.quat_to_R(q)
@@ -86,14 +86,14 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
         assert (ok, sl) == (g.success, g.search_level)
         assert (px0, px1) == pytest.approx((g.px_cur[0], g.px_cur[1]), abs=1e-6)
         n_ok += ok
-    assert n_ok >= 24
+    assert n_ok >= 70
 
     # ---- DepthFilter::observeDepth (line 3) against hso_gpu_seed_observe
     import math
     sv = lines[2].split()
     n_seed_ok, n_left = int(sv[0]), int(sv[1])
     seeds = []
-    for k in range(K, 2 * K):
+    for k in range(K, min(len(has_pt), 2 * K)):
         i = has_pt[k]
         sd = capi.Seed()
         sd.ref_frame_id = 41; sd.level = 0; sd.type = capi.FTR_CORNER
@@ -110,3 +110,28 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
     for k, o in enumerate(kept):
         mu, s2, b = (float(x) for x in sv[2 + 3 * k: 5 + 3 * k])
         assert (mu, s2, b) == pytest.approx((o.mu, o.sigma2, o.b), rel=1e-6)
+
+    # ---- pose_optimizer::optimizeLevenbergMarquardt3rd (line 4) against hso_gpu_pose_optimize_batch
+    pv = lines[3].split()
+    n_fts, nobs, culled = int(pv[0]), int(pv[1]), int(pv[2])
+    qp, tp = np.array(pv[3:7], float), np.array(pv[7:10], float)
+    scale, e0, e1, err_px = float(pv[10]), float(pv[11]), float(pv[12]), float(pv[13])
+    matched = [k for k, g in enumerate(got) if g.success]
+    assert n_fts == len(matched)
+    pf = np.zeros(len(matched), capi.POSE_FEAT_DTYPE)
+    for r, k in enumerate(matched):
+        i = has_pt[k]
+        g = got[k]
+        x, y = (g.px_cur[0] - cam.cx) / cam.fx, (g.px_cur[1] - cam.cy) / cam.fy
+        nrm = math.sqrt(x * x + y * y + 1.0)
+        pf[r]["has_point"] = 1; pf[r]["type"] = capi.FTR_CORNER; pf[r]["level"] = g.search_level; pf[r]["host_pose"] = 0
+        pf[r]["f"] = [x / nrm, y / nrm, 1.0 / nrm]; pf[r]["grad"] = [1.0, 0.0]
+        pf[r]["host_f"] = feats["f"][i]; pf[r]["idist"] = idist[i]
+    T_start = capi.SE3.from_arrays(q, t + np.array([0.004, -0.003, 0.0]))
+    (rg,), (mg,) = gpu_ctx.pose_optimize_batch(cam, [capi.make_pose_job(pf, [capi.SE3.identity()], T_start)])
+    assert (nobs, culled) == (rg.num_obs, int(mg.sum()))
+    assert np.allclose(qp, rg.T_f_w.q[:], atol=1e-9) and np.allclose(tp, rg.T_f_w.t[:], atol=1e-8)
+    assert (scale, e0, e1) == pytest.approx((rg.estimated_scale, rg.error_init, rg.error_final), rel=1e-6)
+    assert err_px == pytest.approx(rg.error_in_px, rel=1e-5)
+    # the refinement pulls the perturbed start back to the tracked pose
+    assert np.linalg.norm(tp - t) < 1.5e-3 and e1 <= e0
