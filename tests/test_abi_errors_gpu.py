@@ -1,0 +1,66 @@
+"""Error behaviour of the C-ABI: every entry point rejects null / inconsistent arguments with a
+negative status and a readable hso_gpu_last_error(), never crashes, and leaves the context usable
+(the reference throws std::runtime_error at the corresponding places, e.g. src/frame.cpp:85-86)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hso_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+E_INVALID, E_NOFRAME = -1, -2
+
+
+def _err(ctx):
+    return capi.load().hso_gpu_last_error(ctx.h).decode()
+
+
+def test_null_and_inconsistent_arguments(gpu_ctx, cam, pair200):
+    lib = capi.load()
+    h = gpu_ctx.h
+    img = pair200["ref"]
+    # frames
+    assert lib.hso_gpu_frame_upload(h, 9600, None, 640, 480, 0, None) == E_INVALID and "null" in _err(gpu_ctx)
+    assert lib.hso_gpu_frame_upload(h, 9600, img.ctypes.data_as(C.POINTER(C.c_uint8)), 0, 480, 0, None) == E_INVALID
+    assert lib.hso_gpu_frame_release(h, 9600) == E_NOFRAME
+    assert lib.hso_gpu_frame_download_level(h, 9600, 0, None, None, None) < 0
+    gpu_ctx.frame_upload(9600, img)
+    try:
+        out = np.zeros((480, 640), np.uint8)
+        w, hh = C.c_int(), C.c_int()
+        assert lib.hso_gpu_frame_download_level(h, 9600, 7, out.ctypes.data_as(C.c_void_p), C.byref(w), C.byref(hh)) == E_INVALID
+        # tracker: null job table, negative count, null results
+        p = capi.TrackParams(0, 4, 1, 50)
+        assert lib.hso_gpu_coarse_track_batch(h, C.byref(cam), C.byref(p), None, 1, None) == E_INVALID
+        job = gpu_ctx.make_job(9600, 9600, pair200["feats"], capi.SE3.identity(), 1.0)
+        res = capi.TrackResult()
+        assert lib.hso_gpu_coarse_track_batch(h, None, C.byref(p), C.byref(job), 1, C.byref(res)) == E_INVALID
+        bad = capi.TrackParams(0, 1, 4, 50)                      # max_level < min_level
+        assert lib.hso_gpu_coarse_track_batch(h, C.byref(cam), C.byref(bad), C.byref(job), 1, C.byref(res)) == E_INVALID
+        cam2 = synth.camera(synth.EUROC)                         # camera size differs from the frames'
+        assert lib.hso_gpu_coarse_track_batch(h, C.byref(cam2), C.byref(p), C.byref(job), 1, C.byref(res)) == E_INVALID
+        assert lib.hso_gpu_coarse_track_collect(h, None) == E_INVALID
+        # matcher / pose / seeds / BA / FAST: null tables with a positive count
+        assert lib.hso_gpu_align_batch(h, C.byref(cam), 9600, None, 3, None) == E_INVALID
+        assert lib.hso_gpu_align_multi(h, C.byref(cam), None, None, 3, None) == E_INVALID
+        assert lib.hso_gpu_pose_optimize_batch(h, C.byref(cam), None, 2, None, None) == E_INVALID
+        assert lib.hso_gpu_seed_observe(h, C.byref(cam), 9600, None, 1.0, 1e-3, None, 4, None) == E_INVALID
+        assert lib.hso_gpu_seed_activate(h, C.byref(cam), None, 2, None, None, 6, None, None) == E_INVALID
+        assert lib.hso_gpu_ba_linearize(h, None, None, 0, None, 0, None, 0, 1.0, 1.0, *([None] * 8)) == E_INVALID
+        counts = (C.c_int32 * 3)()
+        assert lib.hso_gpu_fast_detect(h, 9600, 9, 20, 8, None, 0, counts) == E_INVALID      # more levels than the pyramid has
+        assert lib.hso_gpu_fast_detect(h, 9600, 3, 300, 8, None, 0, counts) == E_INVALID     # barrier outside 0..255
+        assert lib.hso_gpu_fast_detect(h, 9600, 3, 20, 8, None, 16, counts) == E_INVALID     # cap > 0 without an output buffer
+        # empty batches are fine
+        assert lib.hso_gpu_align_batch(h, C.byref(cam), 9600, None, 0, None) == 0
+        assert lib.hso_gpu_pose_optimize_batch(h, C.byref(cam), None, 0, None, None) == 0
+        # the context still works after all of the above
+        r = gpu_ctx.coarse_track_batch(cam, p, [job])[0]
+        assert r.status == 0 and r.n_tracked > 0
+    finally:
+        gpu_ctx.frame_release(9600)
+    # a null context never dereferences
+    assert lib.hso_gpu_frame_release(None, 1) == E_INVALID
+    assert lib.hso_gpu_synchronize(None) == E_INVALID
