@@ -165,6 +165,8 @@ class SeedOut(C.Structure):
 
 CORNER_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("score", "<i4"), ("response", "<f4")])   # hso_corner
 assert CORNER_DTYPE.itemsize == 12
+EDGELET_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("gx", "<i2"), ("gy", "<i2"), ("grad", "<f4")])   # hso_edgelet
+assert EDGELET_DTYPE.itemsize == 12
 ACTIVATE_MAX_TARGETS = 64
 
 
@@ -258,6 +260,7 @@ def load():
                                           P(AlignOut)]
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
     lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
+    lib.hso_gpu_detect_candidates.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
     _lib = lib
     return lib
 
@@ -271,6 +274,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
+    "hso_gpu_detect_candidates",
 ]
 
 
@@ -474,6 +478,18 @@ class Context:
         self._check(self.lib.hso_gpu_fast_detect_batch(self.h, ids, n, n_levels, threshold, border, _ptr(out), cap, _ptr(counts)),
                     "fast_detect_batch")
         return out, counts
+
+    def detect_candidates(self, frame_ids, n_levels=3, min_thresh=20, corner_cap=8192, edgelet_cap=4800):
+        """fastDetectMT + edgeLetDetectMT of FeatureExtractor::detect for a batch of keyframes.
+        Returns (corners[n, L, cap], corner_counts[n, L], edgelets[n, L, cap], edgelet_counts[n, L])."""
+        n = len(frame_ids)
+        ids = (C.c_int64 * n)(*frame_ids)
+        co = np.zeros((n, n_levels, corner_cap), CORNER_DTYPE) if corner_cap > 0 else None
+        eo = np.zeros((n, n_levels, edgelet_cap), EDGELET_DTYPE) if edgelet_cap > 0 else None
+        cc, ec = np.zeros((n, n_levels), np.int32), np.zeros((n, n_levels), np.int32)
+        self._check(self.lib.hso_gpu_detect_candidates(self.h, ids, n, n_levels, min_thresh, _ptr(co), corner_cap, _ptr(cc),
+                                                       _ptr(eo), edgelet_cap, _ptr(ec)), "detect_candidates")
+        return co, cc, eo, ec
 
     def seed_activate(self, cam, seeds, targets_per_seed, n_mean_converge_frame=6, want_matches=False):
         """targets_per_seed: one list of ActivateTarget per seed (optFrames_P + optFrames_A order)."""

@@ -26,11 +26,8 @@
 //                (exact in fp32: every partial sum is an integer < 2^24).
 // Everything is integer / exactly-representable arithmetic: results are bit-identical to the
 // reference library (tests/golden/fast9.json).
-#include "hso_ctx.h"
+#include "hso_fast_plan.h"
 #include <vector>
-
-#define FAST_TW 64
-#define FAST_TH 16
 
 __device__ __forceinline__ int fast9_strength(const int d[16])
 {
@@ -200,14 +197,10 @@ __global__ __launch_bounds__(256) void k_fast_emit(FastArgs A)
   out[idx] = o;
 }
 
-extern "C" int hso_gpu_fast_detect_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold,
-                                         int border, hso_corner* out, int cap, int32_t* counts)
+int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold, int border, int cap,
+                     size_t extra, FastPlan* plan)
 {
-  if (!ctx) return HSO_E_INVALID;
-  if (!frame_ids || n_frames < 0 || n_levels < 1 || n_levels > HSO_N_PYR_LEVELS || threshold < 0 || threshold > 255 || border < 0 ||
-      cap < 0 || !counts || (cap > 0 && !out))
-    return hso_fail(ctx, HSO_E_INVALID, "fast_detect: bad argument");
-  if (n_frames == 0) return HSO_OK;
+  FastPlan& P = *plan;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   std::vector<const uint8_t*> h_bases(n_frames);
   PyrGeom g{};
@@ -218,24 +211,25 @@ extern "C" int hso_gpu_fast_detect_batch(hso_gpu_ctx* ctx, const int64_t* frame_
     else if (it->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "fast_detect: frames of one batch must share one size");
     h_bases[i] = it->second.base;
   }
+  P.g = g; P.n_frames = n_frames; P.n_levels = n_levels; P.cap = cap;
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   // slice of one frame: [row counts of all levels | per level: mask, row offsets, corner list]
-  size_t o = 0, o_mask[HSO_N_PYR_LEVELS], o_cnt[HSO_N_PYR_LEVELS], o_off[HSO_N_PYR_LEVELS], o_out[HSO_N_PYR_LEVELS];
-  int wpr[HSO_N_PYR_LEVELS];
+  size_t o = 0;
   for (int l = 0; l < n_levels; l++) {
-    wpr[l] = (g.w[l] + FAST_TW - 1) / FAST_TW;
-    o_cnt[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
+    P.wpr[l] = (g.w[l] + FAST_TW - 1) / FAST_TW;
+    P.o_cnt[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
   }
   const size_t cnt_bytes = o;
   for (int l = 0; l < n_levels; l++) {
-    o_mask[l] = o; o += al(sizeof(unsigned long long) * (size_t)g.h[l] * wpr[l]);
-    o_off[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
-    o_out[l] = o; o += al(sizeof(hso_corner) * (size_t)cap);
+    P.o_mask[l] = o; o += al(sizeof(unsigned long long) * (size_t)g.h[l] * P.wpr[l]);
+    P.o_off[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
+    P.o_out[l] = o; o += al(sizeof(hso_corner) * (size_t)cap);
   }
-  const size_t per_frame = o;
-  const size_t o_tab = per_frame * (size_t)n_frames;
-  const size_t o_tot = o_tab + al(sizeof(void*) * (size_t)n_frames);
-  const size_t need = o_tot + al(sizeof(int) * (size_t)n_frames * n_levels);
+  P.per_frame = o;
+  P.o_tab = P.per_frame * (size_t)n_frames;
+  P.o_tot = P.o_tab + al(sizeof(void*) * (size_t)n_frames);
+  P.o_extra = P.o_tot + al(sizeof(int) * (size_t)n_frames * n_levels);
+  const size_t need = P.o_extra + al(extra);
   if (ctx->batch_cap < need) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -244,34 +238,55 @@ extern "C" int hso_gpu_fast_detect_batch(hso_gpu_ctx* ctx, const int64_t* frame_
     ctx->batch_cap = need;
   }
   char* d = reinterpret_cast<char*>(ctx->d_batch);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_tab, h_bases.data(), sizeof(void*) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemset2DAsync(d, per_frame, 0, cnt_bytes, (size_t)n_frames, ctx->stream));  // the row counters of every slice
+  P.d = d;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + P.o_tab, h_bases.data(), sizeof(void*) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemset2DAsync(d, P.per_frame, 0, cnt_bytes, (size_t)n_frames, ctx->stream));  // the row counters of every slice
   FastArgs A;
-  A.bases = reinterpret_cast<const uint8_t* const*>(d + o_tab);
+  A.bases = reinterpret_cast<const uint8_t* const*>(d + P.o_tab);
   A.threshold = threshold; A.border = border; A.cap = cap;
-  A.work = d; A.per_frame = per_frame;
-  A.totals = reinterpret_cast<int*>(d + o_tot);
+  A.work = d; A.per_frame = P.per_frame;
+  A.totals = reinterpret_cast<int*>(d + P.o_tot);
   A.n_levels = n_levels;
   for (int l = 0; l < n_levels; l++) {
-    A.img_off = g.off[l]; A.W = g.w[l]; A.H = g.h[l]; A.words_per_row = wpr[l]; A.level = l;
-    A.o_cnt = o_cnt[l]; A.o_mask = o_mask[l]; A.o_off = o_off[l]; A.o_out = o_out[l];
-    hipLaunchKernelGGL(k_fast_mask, dim3(wpr[l], (A.H + FAST_TH - 1) / FAST_TH, n_frames), dim3(256), 0, ctx->stream, A);
+    A.img_off = g.off[l]; A.W = g.w[l]; A.H = g.h[l]; A.words_per_row = P.wpr[l]; A.level = l;
+    A.o_cnt = P.o_cnt[l]; A.o_mask = P.o_mask[l]; A.o_off = P.o_off[l]; A.o_out = P.o_out[l];
+    hipLaunchKernelGGL(k_fast_mask, dim3(P.wpr[l], (A.H + FAST_TH - 1) / FAST_TH, n_frames), dim3(256), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_fast_scan, dim3(n_frames), dim3(256), 0, ctx->stream, A);
-    if (cap > 0) hipLaunchKernelGGL(k_fast_emit, dim3((A.H * wpr[l] + 3) / 4, 1, n_frames), dim3(256), 0, ctx->stream, A);
+    if (cap > 0) hipLaunchKernelGGL(k_fast_emit, dim3((A.H * P.wpr[l] + 3) / 4, 1, n_frames), dim3(256), 0, ctx->stream, A);
     HSO_HIP_CHECK(ctx, hipGetLastError());
   }
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(counts, d + o_tot, sizeof(int) * (size_t)n_frames * n_levels, hipMemcpyDeviceToHost, ctx->stream));
+  return HSO_OK;
+}
+
+int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& P, hso_corner* out, int32_t* counts)
+{
+  const int n_frames = P.n_frames, n_levels = P.n_levels, cap = P.cap;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(counts, P.d + P.o_tot, sizeof(int) * (size_t)n_frames * n_levels, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < n_frames && cap > 0; i++)
     for (int l = 0; l < n_levels; l++) {
       const int c = counts[(size_t)i * n_levels + l];
       const int n = c < cap ? c : cap;
       if (n > 0)
-        HSO_HIP_CHECK(ctx, hipMemcpyAsync(out + ((size_t)i * n_levels + l) * cap, d + (size_t)i * per_frame + o_out[l],
+        HSO_HIP_CHECK(ctx, hipMemcpyAsync(out + ((size_t)i * n_levels + l) * cap, P.d + (size_t)i * P.per_frame + P.o_out[l],
                                           sizeof(hso_corner) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     }
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
+}
+
+extern "C" int hso_gpu_fast_detect_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold,
+                                         int border, hso_corner* out, int cap, int32_t* counts)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!frame_ids || n_frames < 0 || n_levels < 1 || n_levels > HSO_N_PYR_LEVELS || threshold < 0 || threshold > 255 || border < 0 ||
+      cap < 0 || !counts || (cap > 0 && !out))
+    return hso_fail(ctx, HSO_E_INVALID, "fast_detect: bad argument");
+  if (n_frames == 0) return HSO_OK;
+  FastPlan P;
+  const int rc = hso_fast_enqueue(ctx, frame_ids, n_frames, n_levels, threshold, border, cap, 0, &P);
+  if (rc != HSO_OK) return rc;
+  return hso_fast_collect(ctx, P, out, counts);
 }
 
 extern "C" int hso_gpu_fast_detect(hso_gpu_ctx* ctx, int64_t frame_id, int n_levels, int threshold, int border, hso_corner* out,

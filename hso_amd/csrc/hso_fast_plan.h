@@ -1,0 +1,26 @@
+// hso_fast_plan.h — the device-side layout the FAST stage leaves in ctx->d_batch, shared with the
+// stage chained behind it (hso_edgelet.hip) so the corner masks never leave the GPU.
+#pragma once
+#include "hso_ctx.h"
+
+#define FAST_TW 64
+#define FAST_TH 16
+
+struct FastPlan {
+  PyrGeom g;                 // geometry shared by every frame of the batch
+  int n_frames, n_levels, cap;
+  char* d;                   // ctx->d_batch
+  size_t per_frame;          // one slice per frame: [row counts | per level: mask, row offsets, corners]
+  size_t o_cnt[HSO_N_PYR_LEVELS], o_mask[HSO_N_PYR_LEVELS], o_off[HSO_N_PYR_LEVELS], o_out[HSO_N_PYR_LEVELS];
+  int wpr[HSO_N_PYR_LEVELS]; // 64-bit mask words per image row
+  size_t o_tab;              // frame base pointers (device table, const uint8_t* [n_frames])
+  size_t o_tot;              // corner totals [n_frames][n_levels]
+  size_t o_extra;            // start of the caller's `extra` bytes
+};
+
+// Validates the frames, sizes ctx->d_batch (FAST work area + `extra` bytes for the caller) and
+// enqueues mask / scan / emit for every level on ctx->stream; no synchronisation.
+int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold, int border, int cap,
+                     size_t extra, FastPlan* plan);
+// counts (+ corners when cap > 0) to the host; synchronises the stream.
+int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& plan, hso_corner* out, int32_t* counts);

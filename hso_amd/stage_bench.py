@@ -82,6 +82,14 @@ def main():
     dt = timed(lambda: ctx.fast_detect_batch(bid, 3, 20, 8, 0), max(args.reps // 2, 2))
     out.append(dict(stage="fast_detect_batch x256 frames (levels 0-2, counts only)", units="pixels", n=npx * nb,
                     ms_per_call=dt * 1e3, units_per_s=npx * nb / dt))
+    # section 8f rank 1, second stage: corners + edgelets (FAST, cell occupancy, Canny on the Sobel images, per-cell arg-max)
+    dt = timed(lambda: ctx.detect_candidates([1], 3, 20, 8192, 4800), args.reps)
+    _, cc, _, ec = ctx.detect_candidates([1], 3, 20, 8192, 4800)
+    out.append(dict(stage="detect_candidates (FAST + Canny + edgelets, levels 0-2)", units="pixels", n=npx,
+                    ms_per_call=dt * 1e3, units_per_s=npx / dt, corners=int(cc.sum()), edgelets=int(ec.sum())))
+    dt = timed(lambda: ctx.detect_candidates(bid, 3, 20, 0, 0), max(args.reps // 2, 2))
+    out.append(dict(stage="detect_candidates x256 frames (counts only)", units="pixels", n=npx * nb,
+                    ms_per_call=dt * 1e3, units_per_s=npx * nb / dt))
     for k in bid:
         ctx.frame_release(k)
     ctx.frame_release(1); ctx.frame_release(2)

@@ -448,6 +448,33 @@ int hso_gpu_fast_detect(hso_gpu_ctx* ctx, int64_t frame_id, int n_levels, int th
 int hso_gpu_fast_detect_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold,
                               int border, hso_corner* out, int cap, int32_t* counts);
 
+/* ---- FeatureExtractor::detect, non-init branch up to the oct-tree: fastDetectMT + edgeLetDetectMT
+ *      (src/feature_detection.cpp:408-447, 518-545, 749-830; SURVEY.md section 8f rank 1, second
+ *      stage).  Per level L < n_levels (the reference runs 3, one thread each):
+ *        1. fastDetectST: the corners of hso_gpu_fast_detect with threshold = min_thresh and
+ *           border 8; each one marks haveFeatures_[L][getCellIndex(x, y, L)]
+ *           (include/hso/feature_detection.h:295-299 — x is divided by the number of grid rows,
+ *           as written there);
+ *        2. edgeLetDetectST: cv::Canny(sobelX_[L], sobelY_[L], edges, 31*min_thresh, 70*min_thresh,
+ *           L2gradient = true) on the resident Sobel-5 images, then every grid index without a
+ *           feature keeps the edge pixel with the largest sqrtf(gx^2 + gy^2) of its cell window
+ *           (origin (index % gridCols * g, index / gridRows * g), :769-770, clipped to the 8-pixel
+ *           border; first maximum in raster order wins).
+ *      Levels with Sobel images only (n_levels <= HSO_N_SOBEL_LEVELS). ---- */
+typedef struct hso_edgelet {
+  int16_t x, y;      /* level coordinates; KeyPoint position = (x << L, y << L) */
+  int16_t gx, gy;    /* Sobel-5 gradient at (x, y): KeyPoint::gx, gy -> Feature::grad = normalised */
+  float grad;        /* sqrtf(gx*gx + gy*gy), the KeyPoint response */
+} hso_edgelet;
+
+/* corners / corner_counts as in hso_gpu_fast_detect_batch (frame-major, cap entries per level);
+ * edgelets likewise ((i * n_levels + L) * edgelet_cap), in grid-index order — the order
+ * edgeLetDetectST pushes them into featurePerLevel_[L] after the corners.  Integer arithmetic and
+ * one correctly rounded sqrtf: bit-identical to the oracle. */
+int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int min_thresh,
+                              hso_corner* corners, int corner_cap, int32_t* corner_counts,
+                              hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts);
+
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

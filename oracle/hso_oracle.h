@@ -137,6 +137,12 @@ int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y);
 float hso_or_shi_tomasi(const uint8_t* img, int cols, int rows, int u, int v);
 int hso_or_fast9_detect(const uint8_t* img, int w, int h, int threshold, int16_t* xy, int32_t* scores, int cap);
 int hso_or_fast_detect_level(const uint8_t* img, int w, int h, int threshold, int border, hso_corner* out, int cap);
+/* ---- edgelet candidates (src/feature_detection.cpp:749-830; cv::Canny restated, unpinned) ---- */
+void hso_or_canny_l2(const int16_t* dx, const int16_t* dy, int w, int h, double low_thresh, double high_thresh, uint8_t* edges);
+void hso_or_detect_grid(int width, int height, int level, int* grid, int* gcols, int* grows, int* lw, int* lh);
+int hso_or_detect_cell_index(int x, int y, int grid, int gcols, int grows);
+int hso_or_edgelet_level(const int16_t* gx, const int16_t* gy, int w, int h, int level, int frame_w, int frame_h, int min_thresh,
+                         uint8_t* have, hso_edgelet* out, int cap);
 /* per-term dump of the last evaluation for debugging: returns number of rows written */
 int hso_or_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch,
                            int8_t* offsets_xy);

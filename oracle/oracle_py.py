@@ -440,6 +440,61 @@ def ref_fast(img, threshold):
     return xy, sc[:n].copy(), keep[:nk].copy()
 
 
+EDGELET_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("gx", "<i2"), ("gy", "<i2"), ("grad", "<f4")])
+
+
+def canny_l2(gx, gy, low, high):
+    """cv::Canny(dx, dy, edges, low, high, L2gradient=True) restated -> u8 edge map (0 / 255)."""
+    lib = load()
+    lib.hso_or_canny_l2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    lib.hso_or_canny_l2.restype = None
+    gx, gy = np.ascontiguousarray(gx, np.int16), np.ascontiguousarray(gy, np.int16)
+    h, w = gx.shape
+    out = np.zeros((h, w), np.uint8)
+    lib.hso_or_canny_l2(gx.ctypes.data, gy.ctypes.data, w, h, float(low), float(high), out.ctypes.data)
+    return out
+
+
+def detect_grid(width, height, level):
+    """-> (grid, gcols, grows) of FeatureExtractor's occupancy grid on `level`."""
+    lib = load()
+    v = [C.c_int() for _ in range(5)]
+    lib.hso_or_detect_grid.argtypes = [C.c_int] * 3 + [C.POINTER(C.c_int)] * 5
+    lib.hso_or_detect_grid.restype = None
+    lib.hso_or_detect_grid(width, height, level, *[C.byref(x) for x in v])
+    return v[0].value, v[1].value, v[2].value
+
+
+def cell_index(x, y, grid, gcols, grows):
+    lib = load()
+    lib.hso_or_detect_cell_index.argtypes = [C.c_int] * 5
+    lib.hso_or_detect_cell_index.restype = C.c_int
+    return lib.hso_or_detect_cell_index(int(x), int(y), grid, gcols, grows)
+
+
+def edgelet_level(gx, gy, level, frame_w, frame_h, min_thresh, have):
+    """edgeLetDetectST of one level; `have` (uint8 flags per grid index) is updated in place."""
+    lib = load()
+    lib.hso_or_edgelet_level.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int]
+    lib.hso_or_edgelet_level.restype = C.c_int
+    gx, gy = np.ascontiguousarray(gx, np.int16), np.ascontiguousarray(gy, np.int16)
+    h, w = gx.shape
+    out = np.zeros(len(have), EDGELET_DTYPE)
+    n = lib.hso_or_edgelet_level(gx.ctypes.data, gy.ctypes.data, w, h, level, frame_w, frame_h, int(min_thresh),
+                                 have.ctypes.data, out.ctypes.data, len(out))
+    return out[:n].copy()
+
+
+def detect_candidates_level(img, gx, gy, level, frame_w, frame_h, min_thresh):
+    """fastDetectST + edgeLetDetectST of one level -> (corners, edgelets, have)."""
+    corners, _ = fast_detect_level(img, min_thresh, 8)
+    g, gc, gr = detect_grid(frame_w, frame_h, level)
+    have = np.zeros(gc * gr, np.uint8)
+    for c in corners:
+        have[cell_index(c["x"], c["y"], g, gc, gr)] = 1
+    return corners, edgelet_level(gx, gy, level, frame_w, frame_h, min_thresh, have), have
+
+
 def pattern(max_level, level):
     pa, hp = C.c_int(), C.c_int()
     offs = np.zeros((40, 2), np.int8)

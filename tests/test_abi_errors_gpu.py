@@ -53,6 +53,12 @@ def test_null_and_inconsistent_arguments(gpu_ctx, cam, pair200):
         assert lib.hso_gpu_fast_detect(h, 9600, 9, 20, 8, None, 0, counts) == E_INVALID      # more levels than the pyramid has
         assert lib.hso_gpu_fast_detect(h, 9600, 3, 300, 8, None, 0, counts) == E_INVALID     # barrier outside 0..255
         assert lib.hso_gpu_fast_detect(h, 9600, 3, 20, 8, None, 16, counts) == E_INVALID     # cap > 0 without an output buffer
+        ids1 = (C.c_int64 * 1)(9600)
+        ec = (C.c_int32 * 3)()
+        assert lib.hso_gpu_detect_candidates(h, ids1, 1, 4, 20, None, 0, counts, None, 0, ec) == E_INVALID   # Sobel images exist for 3 levels
+        assert lib.hso_gpu_detect_candidates(h, ids1, 1, 3, 20, None, 0, counts, None, 8, ec) == E_INVALID   # cap > 0 without a buffer
+        assert lib.hso_gpu_detect_candidates(h, ids1, 1, 3, 20, None, 0, None, None, 0, ec) == E_INVALID
+        assert lib.hso_gpu_detect_candidates(h, (C.c_int64 * 1)(123456), 1, 3, 20, None, 0, counts, None, 0, ec) == E_NOFRAME
         # empty batches are fine
         assert lib.hso_gpu_align_batch(h, C.byref(cam), 9600, None, 0, None) == 0
         assert lib.hso_gpu_pose_optimize_batch(h, C.byref(cam), None, 0, None, None) == 0
