@@ -167,6 +167,10 @@ CORNER_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("score", "<i4"), ("respons
 assert CORNER_DTYPE.itemsize == 12
 EDGELET_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("gx", "<i2"), ("gy", "<i2"), ("grad", "<f4")])   # hso_edgelet
 assert EDGELET_DTYPE.itemsize == 12
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("level", "<i4"), ("species", "<i4"),
+                           ("gx", "<i4"), ("gy", "<i4")])   # hso_keypoint
+assert KEYPOINT_DTYPE.itemsize == 28
+KP_CORNER_HIGH, KP_EDGELET, KP_GRAD, KP_OCCUR = 0, 1, 2, 3
 ACTIVATE_MAX_TARGETS = 64
 
 
@@ -261,6 +265,7 @@ def load():
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
     lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
     lib.hso_gpu_detect_candidates.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
+    lib.hso_gpu_select_octree.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
     _lib = lib
     return lib
 
@@ -274,8 +279,19 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
-    "hso_gpu_detect_candidates",
+    "hso_gpu_detect_candidates", "hso_gpu_select_octree",
 ]
+
+
+def select_octree(keys, width, height, n_features):
+    """computeKeyPointsOctTree over (0, width, 0, height): keys = KEYPOINT_DTYPE array in the
+    reference's allFeturesToDistribute_ order -> the selected keys in node-list order."""
+    keys = np.ascontiguousarray(keys, KEYPOINT_DTYPE)
+    out = np.zeros(max(len(keys), 1), KEYPOINT_DTYPE)
+    n = load().hso_gpu_select_octree(_ptr(keys), len(keys), 0, width, 0, height, n_features, _ptr(out), len(out))
+    if n < 0:
+        raise HsoGpuError("select_octree: status %d" % n)
+    return out[:n].copy()
 
 
 def _ptr(a):

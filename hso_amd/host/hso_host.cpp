@@ -332,6 +332,101 @@ double DepthFilter::computeTau(const SE3& T_ref_cur, const Vector3d& f, double z
   return z_plus - z;
 }
 
+FeatureExtractor::FeatureExtractor(int width, int height, int cellSize, int levels, bool isInit, int max_fts)
+    : width_(width), height_(height), cellSize_(cellSize), nLevels_(levels), nFeatures_(isInit ? 2000 : max_fts + 100), isInit_(isInit)
+{
+}
+
+void FeatureExtractor::setExistingFeatures(const Features& fts)
+{
+  for (const Feature* ftr : fts) {
+    hso_keypoint k{};
+    k.x = (float)ftr->px[0]; k.y = (float)ftr->px[1];
+    k.species = HSO_KP_OCCUR;
+    allFeturesToDistribute_.push_back(k);
+  }
+  extFeatures_ += fts.size();
+}
+
+void FeatureExtractor::detect(Frame* frame, float initThresh, float minThresh, Features& fts, Frame* last_frame)
+{
+  (void)initThresh; (void)last_frame;   // initThresh_ is never read; the epipolar-hole filter is commented out in the reference (:798-803)
+  if (isInit_) throw std::logic_error("FeatureExtractor: the initialisation branch (fillingHole) is not built");
+  minThresh_ = (int)minThresh;          // int minThresh_, include/hso/feature_detection.h:339
+  const int64_t id = frame->id_;
+  int corner_cap = 16384;
+  const int edgelet_cap = ((width_ + 7) / 8) * ((height_ + 7) / 8);   // one per grid index; every level has that many
+  std::vector<hso_corner> co;
+  std::vector<hso_edgelet> ed((size_t)nLevels_ * edgelet_cap);
+  std::vector<int32_t> nc(nLevels_), ne(nLevels_);
+  for (;;) {
+    co.resize((size_t)nLevels_ * corner_cap);
+    const int rc = hso_gpu_detect_candidates(frame->ctx_, &id, 1, nLevels_, minThresh_, co.data(), corner_cap, nc.data(), ed.data(),
+                                             edgelet_cap, ne.data());
+    if (rc < 0) throw std::runtime_error(std::string("FeatureExtractor: ") + hso_gpu_last_error(frame->ctx_));
+    int most = 0;
+    for (int c : nc) most = c > most ? c : most;
+    if (most <= corner_cap) break;
+    corner_cap = most;                  // a frame with more corners than the first guess: once more with room for all
+  }
+  // featurePerLevel_[L] = corners then edgelets (:518-545, :749-830), appended level by level (:449-451)
+  for (int L = 0; L < nLevels_; ++L) {
+    for (int i = 0; i < nc[L]; ++i) {
+      const hso_corner& c = co[(size_t)L * corner_cap + i];
+      hso_keypoint k{};
+      k.x = (float)(c.x << L); k.y = (float)(c.y << L); k.response = c.response; k.level = L; k.species = HSO_KP_CORNER_HIGH;
+      allFeturesToDistribute_.push_back(k);
+    }
+    for (int i = 0; i < ne[L]; ++i) {
+      const hso_edgelet& e = ed[(size_t)L * edgelet_cap + i];
+      hso_keypoint k{};
+      k.x = (float)(e.x << L); k.y = (float)(e.y << L); k.response = e.grad; k.level = L; k.species = HSO_KP_EDGELET;
+      k.gx = e.gx; k.gy = e.gy;
+      allFeturesToDistribute_.push_back(k);
+    }
+  }
+  std::vector<hso_keypoint> sel(allFeturesToDistribute_.size() + 1);
+  const int n = hso_gpu_select_octree(allFeturesToDistribute_.data(), (int)allFeturesToDistribute_.size(), 0, width_, 0, height_,
+                                         nFeatures_, sel.data(), (int)sel.size());
+  if (n < 0) throw std::runtime_error("FeatureExtractor: oct-tree selection failed");
+  for (int i = 0; i < n; ++i) {          // :457-484
+    const hso_keypoint& k = sel[i];
+    Feature* f = new Feature();
+    f->frame = frame;
+    f->px = {(double)k.x, (double)k.y};
+    f->f = frame->cam_->cam2world(f->px);
+    f->level = k.level;
+    if (k.species == HSO_KP_CORNER_HIGH) {
+      f->type = Feature::CORNER;
+    } else {
+      f->type = k.species == HSO_KP_GRAD ? Feature::GRADIENT : Feature::EDGELET;
+      const double gx = k.gx, gy = k.gy, nrm = std::sqrt(gx * gx + gy * gy);
+      f->grad = {gx / nrm, gy / nrm};    // Vector2d::normalize()
+    }
+    fts.push_back(f);
+  }
+  allFeturesToDistribute_.clear();       // resetGrid + clear, :486-496
+  extFeatures_ = 0;
+}
+
+void DepthFilter::addKeyframe(FramePtr frame, double depth_mean, double depth_min, float converge_thresh)
+{
+  new_keyframe_min_depth_ = depth_min;
+  new_keyframe_mean_depth_ = depth_mean;
+  convergence_sigma2_thresh_ = converge_thresh;
+  initializeSeeds(frame);
+}
+
+void DepthFilter::initializeSeeds(FramePtr frame)
+{
+  if (!featureExtractor_) throw std::logic_error("DepthFilter: no FeatureExtractor");
+  Features new_features;
+  featureExtractor_->setExistingFeatures(frame->fts_);
+  featureExtractor_->detect(frame.get(), 20, frame->gradMean_, new_features, nullptr);
+  for (Feature* ftr : new_features)
+    seeds_.emplace_back(ftr, (float)new_keyframe_mean_depth_, (float)new_keyframe_min_depth_, convergence_sigma2_thresh_);
+}
+
 size_t DepthFilter::observeDepth(FramePtr frame)
 {
   std::vector<hso_seed> in;

@@ -151,9 +151,34 @@ struct Seed {
   Seed(Feature* ftr, float depth_mean, float depth_min, float converge_threshold = 200);  // src/depth_filter.cpp:49-68
 };
 
+// include/hso/feature_detection.h:283-345 — new candidates of a keyframe
+class FeatureExtractor {
+public:
+  // max_fts stands in for the Config::maxFts() singleton read at construction (:382-385)
+  FeatureExtractor(int width, int height, int cellSize, int levels, bool isInit = false, int max_fts = 200);
+  // src/feature_detection.cpp:408-497: fastDetectMT + edgeLetDetectMT on the device
+  // (hso_gpu_detect_candidates), computeKeyPointsOctTree on the host (hso_gpu_select_octree),
+  // then one new Feature per selected key (caller owns them, like the reference).  The
+  // initialisation branch (fillingHole, FAST-12) is not built: throws std::logic_error.
+  void detect(Frame* frame, float initThresh, float minThresh, Features& fts, Frame* last_frame = nullptr);
+  void setExistingFeatures(const Features& fts);   // :1169-1177
+  int width_, height_, cellSize_, nLevels_, nFeatures_;
+  bool isInit_;
+  int minThresh_ = 0;
+  size_t extFeatures_ = 0;
+  std::vector<hso_keypoint> allFeturesToDistribute_;
+};
+
 class DepthFilter {
 public:
   explicit DepthFilter(double px_error_angle) : px_error_angle_(px_error_angle) {}
+  // src/depth_filter.cpp:146-205 (no thread: addKeyframe -> initializeSeeds): detect new features
+  // away from the frame's existing ones and start one seed per feature
+  void addKeyframe(FramePtr frame, double depth_mean, double depth_min, float converge_thresh = 200);
+  void initializeSeeds(FramePtr frame);
+  FeatureExtractor* featureExtractor_ = nullptr;
+  double new_keyframe_mean_depth_ = 0, new_keyframe_min_depth_ = 0;
+  float convergence_sigma2_thresh_ = 200;
   // src/depth_filter.cpp:557-675: one observation of every seed in `frame`; seeds whose
   // z_inv_min turns NaN are erased like :618-622; returns the number of successful matches
   size_t observeDepth(FramePtr frame);

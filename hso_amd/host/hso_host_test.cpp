@@ -77,7 +77,7 @@ int main(int argc, char** argv)
       hso::Vector2d px = cam.world2cam(next->T_f_w_ * pt->pos_);
       hso::Matcher matcher;
       const bool ok = matcher.findMatchDirect(*pt, *next, px);
-      std::printf(" %d %.12g %.12g %d", ok ? 1 : 0, px[0], px[1], matcher.search_level_);
+      std::printf(" %d %.17g %.17g %d", ok ? 1 : 0, px[0], px[1], matcher.search_level_);
       if (ok) {  // the new observation, as Reprojector::reprojectCell creates it (src/reprojector.cpp:385-412)
         hso::Feature* nf = new hso::Feature();
         nf->frame = next.get(); nf->px = px; nf->f = cam.cam2world(px); nf->level = matcher.search_level_; nf->point = pt;
@@ -109,6 +109,21 @@ int main(int argc, char** argv)
     std::printf("%zu %zu %zu %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.12g %.12g %.12g %.9g %.17g %.17g\n", next->fts_.size(), nobs,
                 culled, P.q[0], P.q[1], P.q[2], P.q[3], P.t[0], P.t[1], P.t[2], scale, e0, e1, next->m_error_in_px, T_tracked.v.t[0],
                 next->Cov_[0]);
+
+    // ---- the frame becomes a keyframe: new features away from the existing ones, one seed each
+    // (DepthFilter::addKeyframe -> initializeSeeds, src/depth_filter.cpp:146-205)
+    hso::FeatureExtractor extractor(w, h, 25, 3, false, 200);
+    hso::DepthFilter kf_filter(df.px_error_angle_);
+    kf_filter.featureExtractor_ = &extractor;
+    kf_filter.addKeyframe(next, 2.0, 0.5);
+    std::printf("%zu %.9g", kf_filter.seeds_.size(), next->gradMean_);
+    for (const hso::Seed& sd : kf_filter.seeds_) {
+      const hso::Feature* ft = sd.ftr;
+      std::printf(" %d %d %.9g %.9g %.17g %.17g %.17g %.17g %.17g %.9g %.9g", (int)ft->type, ft->level, ft->px[0], ft->px[1], ft->grad[0],
+                  ft->grad[1], ft->f[0], ft->f[1], ft->f[2], sd.mu, sd.sigma2);
+    }
+    std::printf("\n");
+    for (const hso::Seed& sd : kf_filter.seeds_) delete sd.ftr;
     for (hso::Point* p : points) delete p;
   }
   hso_gpu_destroy(ctx);

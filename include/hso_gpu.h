@@ -475,6 +475,28 @@ int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_
                               hso_corner* corners, int corner_cap, int32_t* corner_counts,
                               hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts);
 
+/* ---- FeatureExtractor::computeKeyPointsOctTree, src/feature_detection.cpp:833-1122 (ExtractorNode::DivideNode,
+ *      include/hso/feature_detection.h:217-272): the spatial distribution that ends FeatureExtractor::detect
+ *      (:449-455).  Host code (sequential refinement over a few thousand candidates), no context needed. ---- */
+enum { HSO_KP_CORNER_HIGH = 0, HSO_KP_EDGELET = 1, HSO_KP_GRAD = 2, HSO_KP_OCCUR = 3 };  /* FeatureSpecies, feature_detection.h:180-186 */
+typedef struct hso_keypoint {   /* KeyPoint, include/hso/feature_detection.h:188-208 */
+  float x, y;          /* level-0 pixels */
+  float response;
+  int32_t level;
+  int32_t species;     /* HSO_KP_* */
+  int32_t gx, gy;
+} hso_keypoint;
+
+/* keys: allFeturesToDistribute_ in the reference's order — the occupancy keys of the existing
+ * features (setExistingFeatures :1169-1177, species HSO_KP_OCCUR) first, then per level the corners
+ * followed by the edgelets.  The rectangle is (0, width, 0, height) at the call site; n_features =
+ * nFeatures_ (Config::maxFts() + 100, or 2000 while initialising, :382-385).  Returns the number of
+ * selected keys (written to out in the order of the reference's node list, at most cap of them) or
+ * a negative status.  Where the reference orders equal-sized nodes by their heap addresses
+ * (std::sort over (size, pointer) pairs, :974), node creation order is used. */
+int hso_gpu_select_octree(const hso_keypoint* keys, int n, int min_x, int max_x, int min_y, int max_y, int n_features,
+                             hso_keypoint* out, int cap);
+
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

@@ -135,3 +135,46 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
     assert err_px == pytest.approx(rg.error_in_px, rel=1e-5)
     # the refinement pulls the perturbed start back to the tracked pose
     assert np.linalg.norm(tp - t) < 1.5e-3 and e1 <= e0
+
+    # ---- DepthFilter::addKeyframe -> FeatureExtractor::detect -> seeds (line 5) against the C-ABI pieces
+    kv = lines[4].split()
+    n_new, grad_mean = int(kv[0]), float(kv[1])
+    assert grad_mean == pytest.approx(st_c.grad_mean, rel=1e-7)
+    min_thresh = int(grad_mean)
+    co, cc, eo, ec = gpu_ctx.detect_candidates([42], n_levels=3, min_thresh=min_thresh, corner_cap=16384, edgelet_cap=4800)
+    occupied = [(float(mv[2 + 4 * k]), float(mv[3 + 4 * k])) for k in range(K) if int(mv[1 + 4 * k])]
+    keys = np.zeros(len(occupied) + int(cc.sum() + ec.sum()), capi.KEYPOINT_DTYPE)
+    keys["x"][:len(occupied)] = [p[0] for p in occupied]
+    keys["y"][:len(occupied)] = [p[1] for p in occupied]
+    keys["species"][:len(occupied)] = capi.KP_OCCUR
+    at = len(occupied)
+    for L in range(3):
+        c, e = co[0, L, :cc[0, L]], eo[0, L, :ec[0, L]]
+        k = keys[at:at + len(c)]
+        k["x"], k["y"], k["response"], k["level"], k["species"] = c["x"].astype(np.int32) << L, c["y"].astype(np.int32) << L, c["response"], L, capi.KP_CORNER_HIGH
+        at += len(c)
+        k = keys[at:at + len(e)]
+        k["x"], k["y"], k["response"], k["level"], k["species"] = e["x"].astype(np.int32) << L, e["y"].astype(np.int32) << L, e["grad"], L, capi.KP_EDGELET
+        k["gx"], k["gy"] = e["gx"], e["gy"]
+        at += len(e)
+    sel = capi.select_octree(keys, 640, 480, 300)
+    assert n_new == len(sel) and 150 <= n_new <= 303     # ~300 nodes minus those an existing feature occupies
+    rec = np.array(kv[2:], float).reshape(n_new, 11)
+    n_edgelets = 0
+    for r, s in zip(rec, sel):
+        is_corner = s["species"] == capi.KP_CORNER_HIGH
+        assert (int(r[0]), int(r[1])) == (capi.FTR_CORNER if is_corner else capi.FTR_EDGELET, s["level"])
+        assert (r[2], r[3]) == (s["x"], s["y"])
+        if is_corner:
+            assert (r[4], r[5]) == (1.0, 0.0)
+        else:
+            g = np.array([s["gx"], s["gy"]], float)
+            assert np.allclose(r[4:6], g / np.linalg.norm(g), atol=1e-15)
+            n_edgelets += 1
+        f = np.array([(s["x"] - cam.cx) / cam.fx, (s["y"] - cam.cy) / cam.fy, 1.0])
+        assert np.allclose(r[6:9], f / np.linalg.norm(f), atol=1e-12)
+        # Seed(ftr, depth_mean 2.0, depth_min 0.5): mu = 1/2, sigma2 = (1/0.5)^2 / 36
+        assert r[9] == 0.5 and r[10] == pytest.approx(4.0 / 36.0, rel=1e-6)
+    # (on this densely textured frame every node holds a corner, and corners outrank edgelets:
+    # n_edgelets is normally 0 here; tests/test_octree.py covers the edgelet-winning nodes)
+    assert 0 <= n_edgelets <= n_new

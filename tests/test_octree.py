@@ -1,0 +1,181 @@
+"""Spatial distribution of the keyframe candidates (FeatureExtractor::computeKeyPointsOctTree,
+src/feature_detection.cpp:833-1122; ExtractorNode::DivideNode, include/hso/feature_detection.h:217-272).
+
+Host logic behind the C-ABI (hso_gpu_select_octree: index-range nodes over one in-place
+partitioned array).  Checked on the CPU against a restatement written the reference's way — every
+node owns a list of keys, children are pushed to the front of a node list — with the one rule the
+reference leaves to the heap (order of equal-sized nodes in std::sort over (size, pointer)) fixed
+to creation order in both."""
+import math
+
+import numpy as np
+import pytest
+
+from hso_amd import capi
+
+OCCUR = capi.KP_OCCUR
+
+
+class _Node:
+    serial = 0
+
+    def __init__(self, x0, y0, x1, y1):
+        self.x0, self.y0, self.x1, self.y1 = x0, y0, x1, y1
+        self.keys, self.no_more = [], False
+        _Node.serial += 1
+        self.serial = _Node.serial
+
+    def divide(self):
+        half_x = math.ceil(np.float32(self.x1 - self.x0) / 2)
+        half_y = math.ceil(np.float32(self.y1 - self.y0) / 2)
+        mx, my = self.x0 + half_x, self.y0 + half_y
+        n1, n2 = _Node(self.x0, self.y0, mx, my), _Node(mx, self.y0, self.x1, my)
+        n3, n4 = _Node(self.x0, my, mx, self.y1), _Node(mx, my, self.x1, self.y1)
+        for k in self.keys:
+            if k["x"] < mx:
+                (n1 if k["y"] < my else n3).keys.append(k)
+            else:
+                (n2 if k["y"] < my else n4).keys.append(k)
+        for c in (n1, n2, n3, n4):
+            c.no_more = len(c.keys) == 1
+        return n1, n2, n3, n4
+
+
+def _octree_py(keys, width, height, n_features):
+    n_ini = int(round(float(np.float32(width) / np.float32(height))))
+    hx = np.float32(width) / np.float32(n_ini)
+    ini = [_Node(int(hx * np.float32(i)), 0, int(hx * np.float32(i + 1)), height) for i in range(n_ini)]
+    for k in keys:
+        ini[int(np.float32(int(k["x"])) / hx)].keys.append(k)
+    nodes = []
+    for nd in ini:
+        if len(nd.keys) == 1:
+            nd.no_more = True
+        if nd.keys:
+            nodes.append(nd)
+    finish = False
+    while not finish:
+        prev = len(nodes)
+        front, keep, expandable = [], [], []
+        for nd in nodes:                                   # one sweep over the nodes that exist now
+            if nd.no_more:
+                keep.append(nd)
+                continue
+            for c in nd.divide():
+                if c.keys:
+                    front.insert(0, c)                     # push_front
+                    if len(c.keys) > 1:
+                        expandable.append(c)
+        nodes = front + keep
+        if len(nodes) >= n_features or len(nodes) == prev:
+            finish = True
+        elif len(nodes) + 3 * len(expandable) > n_features:
+            while not finish:
+                prev = len(nodes)
+                todo = sorted(expandable, key=lambda c: (len(c.keys), c.serial))
+                expandable = []
+                for nd in reversed(todo):
+                    for c in nd.divide():
+                        if c.keys:
+                            nodes.insert(0, c)
+                            if len(c.keys) > 1:
+                                expandable.append(c)
+                    nodes.remove(nd)
+                    if len(nodes) >= n_features:
+                        break
+                if len(nodes) >= n_features or len(nodes) == prev:
+                    finish = True
+    out = []
+    for nd in nodes:
+        best = nd.keys[0]
+        if best["species"] == OCCUR:
+            continue
+        occur = False
+        for k in nd.keys[1:]:
+            if k["species"] == OCCUR:
+                occur = True
+                break
+            if best["species"] > k["species"] or (best["species"] == k["species"] and k["response"] > best["response"]):
+                best = k
+        if not occur:
+            out.append(best)
+    return out
+
+
+def _random_keys(rng, n, width, height, n_occur=0, clustered=False):
+    keys = np.zeros(n + n_occur, capi.KEYPOINT_DTYPE)
+    if clustered:
+        c = rng.integers(0, 6, n + n_occur)
+        cx = np.array([50, 300, 320, 600, 610, 100])[c] + rng.normal(0, 12, n + n_occur)
+        cy = np.array([40, 200, 240, 440, 100, 400])[c] + rng.normal(0, 9, n + n_occur)
+        keys["x"] = np.clip(cx, 0, width - 1).astype(np.int32)
+        keys["y"] = np.clip(cy, 0, height - 1).astype(np.int32)
+    else:
+        keys["x"] = rng.integers(0, width, n + n_occur)
+        keys["y"] = rng.integers(0, height, n + n_occur)
+    lvl = rng.integers(0, 3, n + n_occur)
+    keys["x"] = (keys["x"].astype(np.int32) >> lvl) << lvl          # level-L candidates sit on a 2^L lattice
+    keys["y"] = (keys["y"].astype(np.int32) >> lvl) << lvl
+    keys["level"] = lvl
+    keys["species"] = rng.integers(0, 2, n + n_occur)
+    keys["response"] = rng.integers(0, 40, n + n_occur) * 12.5        # ties in the response on purpose
+    keys["gx"], keys["gy"] = rng.integers(-900, 900, n + n_occur), rng.integers(-900, 900, n + n_occur)
+    if n_occur:
+        keys["species"][:n_occur] = OCCUR                             # existing features come first
+        keys["x"][:n_occur] = rng.uniform(0, width - 1, n_occur)      # sub-pixel positions
+        keys["y"][:n_occur] = rng.uniform(0, height - 1, n_occur)
+        keys["response"][:n_occur] = 0
+        keys["level"][:n_occur] = 0
+    return keys
+
+
+@pytest.mark.parametrize("width,height", [(640, 480), (752, 480), (920, 736)])
+@pytest.mark.parametrize("n,n_occur,n_features,clustered", [
+    (3000, 0, 300, False), (3000, 120, 300, False), (9000, 60, 2000, False), (800, 0, 2100, False),
+    (2500, 80, 300, True), (40, 5, 300, False), (1, 0, 300, False)])
+def test_octree_matches_list_restatement(width, height, n, n_occur, n_features, clustered):
+    rng = np.random.default_rng(n * 7 + n_occur + width)
+    keys = _random_keys(rng, n, width, height, n_occur, clustered)
+    got = capi.select_octree(keys, width, height, n_features)
+    want = _octree_py(list(keys), width, height, n_features)
+    assert len(got) == len(want)
+    assert got.tobytes() == np.array(want, capi.KEYPOINT_DTYPE).tobytes()
+    # properties: never more than ~n_features nodes' worth, no occupancy key leaves, every output is an input
+    assert (got["species"] != OCCUR).all()
+    assert len(got) <= max(n_features + 3, 4)
+    inp = {k.tobytes() for k in keys}
+    assert all(g.tobytes() in inp for g in got)
+    if n >= 2500 and not clustered and n_occur == 0:
+        assert len(got) >= n_features - 1                  # enough candidates: the budget is met
+        # spread: every 160x160 block of the image keeps at least one feature
+        bx, by = (got["x"] // 160).astype(int), (got["y"] // 160).astype(int)
+        assert len(set(zip(bx, by))) == ((width + 159) // 160) * ((height + 159) // 160)
+
+
+def test_octree_edge_cases():
+    empty = np.zeros(0, capi.KEYPOINT_DTYPE)
+    assert len(capi.select_octree(empty, 640, 480, 300)) == 0
+    # coincident keys can never be separated: the loop ends when a sweep no longer grows the list
+    same = np.zeros(5, capi.KEYPOINT_DTYPE)
+    same["x"], same["y"] = 100, 100
+    same["response"] = [1, 5, 3, 5, 2]
+    got = capi.select_octree(same, 640, 480, 300)
+    assert len(got) == 1 and got[0]["response"] == 5
+    # a corner beats an edgelet with a higher response; an occupancy key anywhere in the node silences it
+    two = np.zeros(2, capi.KEYPOINT_DTYPE)
+    two["x"], two["y"] = [10, 10], [10, 10]
+    two["species"], two["response"] = [capi.KP_EDGELET, capi.KP_CORNER_HIGH], [900, 1]
+    assert capi.select_octree(two, 640, 480, 300)[0]["species"] == capi.KP_CORNER_HIGH
+    occ = np.zeros(3, capi.KEYPOINT_DTYPE)
+    occ["x"], occ["y"] = [10.4, 10, 300], [10.2, 10, 300]
+    occ["species"] = [OCCUR, capi.KP_CORNER_HIGH, capi.KP_CORNER_HIGH]
+    got = capi.select_octree(occ, 640, 480, 300)
+    assert len(got) == 1 and got[0]["x"] == 300
+    # invalid arguments
+    lib = capi.load()
+    assert lib.hso_gpu_select_octree(None, 3, 0, 640, 0, 480, 300, None, 0) == -1
+    assert lib.hso_gpu_select_octree(None, 0, 0, 0, 0, 480, 300, None, 0) == -1
+    bad = np.zeros(1, capi.KEYPOINT_DTYPE)
+    bad["x"] = 700                                           # outside the rectangle: the reference writes out of range
+    out = np.zeros(1, capi.KEYPOINT_DTYPE)
+    assert lib.hso_gpu_select_octree(bad.ctypes.data, 1, 0, 640, 0, 480, 300, out.ctypes.data, 1) == -1
