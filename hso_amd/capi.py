@@ -110,6 +110,17 @@ class AlignOut(C.Structure):
                 ("ncc", C.c_float), ("chi2", C.c_float)]
 
 
+# tables of hso_gpu_reproject_match (hso_kf, hso_obs, hso_map_point, hso_reproj_point)
+KF_DTYPE = np.dtype([("frame_id", "<i8"), ("q", "<f8", 4), ("t", "<f8", 3), ("exposure_time", "<f8"),
+                     ("keyframe_id", "<i4"), ("pad_", "<i4")])
+OBS_DTYPE = np.dtype([("kf", "<i4"), ("level", "<i4"), ("type", "<i4"), ("pad_", "<i4"), ("px", "<f8", 2), ("f", "<f8", 3),
+                      ("grad", "<f8", 2)])
+MAP_POINT_DTYPE = np.dtype([("pos", "<f8", 3), ("idist", "<f8"), ("host_f", "<f8", 3), ("host_kf", "<i4"),
+                            ("obs_begin", "<i4"), ("obs_count", "<i4"), ("pad_", "<i4")])
+REPROJ_POINT_DTYPE = np.dtype([("projected", "<i4"), ("cell", "<i4"), ("px", "<f8", 2), ("ref_obs", "<i4"), ("pad_", "<i4")])
+assert (KF_DTYPE.itemsize, OBS_DTYPE.itemsize, MAP_POINT_DTYPE.itemsize, REPROJ_POINT_DTYPE.itemsize) == (80, 72, 72, 32)
+
+
 class PoseFeat(C.Structure):
     _fields_ = [("has_point", C.c_int32), ("type", C.c_int32), ("level", C.c_int32), ("temporary", C.c_int32),
                 ("host_pose", C.c_int32), ("_pad", C.c_int32), ("f", C.c_double * 3), ("grad", C.c_double * 2),
@@ -266,6 +277,8 @@ def load():
     lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
     lib.hso_gpu_detect_candidates.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
     lib.hso_gpu_select_octree.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
+    lib.hso_gpu_reproject_match.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, i32, vp, i32, vp, i32, vp, i32, i32, i32,
+                                            vp, vp]
     _lib = lib
     return lib
 
@@ -279,7 +292,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
-    "hso_gpu_detect_candidates", "hso_gpu_select_octree",
+    "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match",
 ]
 
 
@@ -435,6 +448,19 @@ class Context:
         out = (AlignOut * len(jobs))()
         self._check(self.lib.hso_gpu_align_batch(self.h, C.byref(cam), cur_frame_id, arr, len(jobs), out), "align_batch")
         return list(out)
+
+    def reproject_match(self, cam, cur_frame_id, T_cur_w, cur_exposure_time, cur_keyframe_id, kfs, points, obs,
+                        cell_size, grid_n_cols):
+        """kfs / points / obs: KF_DTYPE / MAP_POINT_DTYPE / OBS_DTYPE arrays.
+        Returns (REPROJ_POINT_DTYPE array, ctypes AlignOut array), both in point order."""
+        kfs = np.ascontiguousarray(kfs, KF_DTYPE); points = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+        obs = np.ascontiguousarray(obs, OBS_DTYPE)
+        proj = np.zeros(len(points), REPROJ_POINT_DTYPE)
+        match = (AlignOut * max(len(points), 1))()
+        self._check(self.lib.hso_gpu_reproject_match(self.h, C.byref(cam), cur_frame_id, C.byref(T_cur_w), cur_exposure_time,
+                                                     cur_keyframe_id, _ptr(kfs), len(kfs), _ptr(points), len(points), _ptr(obs),
+                                                     len(obs), cell_size, grid_n_cols, _ptr(proj), match), "reproject_match")
+        return proj, match
 
     def align_multi(self, cam, cur_frame_ids, jobs, as_list=True):
         """jobs[i] is searched in frame cur_frame_ids[i]; jobs may be a ready ctypes array."""

@@ -112,3 +112,191 @@ extern "C" int hso_gpu_align_multi(hso_gpu_ctx* ctx, const hso_camera* cam, cons
 {
   return align_run(ctx, cam, cur_frame_ids, 1, jobs, n_jobs, out);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Reprojector candidate generation chained in front of k_align:
+// Reprojector::reprojectPoint (reference src/reprojector.cpp:504-529), Point::getCloseViewObs
+// (src/point.cpp:116-136) and the job findMatchDirect derives from the chosen observation
+// (src/matcher.cpp:288-319).  One lane per map point writes the point's grid record and its
+// AlignJobDev in place; k_align then runs over the same array (ref_base == nullptr = no job), so
+// projection, reference choice and matching need no host round trip.  The per-keyframe products
+// T_cur_w * T_kf_w^-1 and the keyframe positions are formed once on the host (a dozen of them).
+struct ReprojKf {
+  Se3 T_cur_kf;              // cur.T_f_w_ * kf.T_f_w_^-1
+  double pos[3];             // kf.pos()
+  const uint8_t* base;
+  int64_t frame_id;
+  float exposure_rat;        // float(cur.m_exposure_time / kf.m_exposure_time)
+  int32_t kf_gap_lt4;
+};
+
+struct ReprojConsts {
+  hso_camera cam;
+  double cur_pos[3];
+  const uint8_t* cur_base;
+  const ReprojKf* kfs;
+  const hso_map_point* pts;
+  const hso_obs* obs;
+  int n_pts, cell_size, grid_n_cols;
+};
+
+__global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* jobs, hso_reproj_point* proj)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R.n_pts) return;
+  const hso_map_point P = R.pts[i];
+  hso_reproj_point o;
+  o.projected = 0; o.cell = 0; o.px[0] = 0; o.px[1] = 0; o.ref_obs = -1; o.pad_ = 0;
+  AlignJobDev* JD = &jobs[i];
+  JD->ref_base = nullptr; JD->cur_base = R.cur_base;
+  // reprojectPoint, :504-529
+  const ReprojKf& H = R.kfs[P.host_kf];
+  const double s = 1.0 / P.idist;
+  double tx, ty, tz;
+  se3_apply(H.T_cur_kf, P.host_f[0] * s, P.host_f[1] * s, P.host_f[2] * s, tx, ty, tz);
+  if (!(tz < 0.00001)) {
+    double u, v;
+    world2cam(R.cam, tx, ty, tz, u, v);
+    const int ix = (int)u, iy = (int)v;
+    if (ix >= 8 && ix < R.cam.width - 8 && iy >= 8 && iy < R.cam.height - 8) {   // isInFrame(px.cast<int>(), 8)
+      o.projected = 1;
+      o.px[0] = u; o.px[1] = v;
+      o.cell = (int)(v / R.cell_size) * R.grid_n_cols + (int)(u / R.cell_size);
+    }
+  }
+  if (o.projected && P.obs_count > 0) {
+    // getCloseViewObs, src/point.cpp:116-136
+    double ox = R.cur_pos[0] - P.pos[0], oy = R.cur_pos[1] - P.pos[1], oz = R.cur_pos[2] - P.pos[2];
+    { const double n = sqrt(ox * ox + oy * oy + oz * oz); ox /= n; oy /= n; oz /= n; }
+    int best = 0;
+    double min_cos = 0;
+    for (int k = 0; k < P.obs_count; k++) {
+      const ReprojKf& K = R.kfs[R.obs[P.obs_begin + k].kf];
+      double dx = K.pos[0] - P.pos[0], dy = K.pos[1] - P.pos[1], dz = K.pos[2] - P.pos[2];
+      { const double n = sqrt(dx * dx + dy * dy + dz * dz); dx /= n; dy /= n; dz /= n; }
+      const double c = ox * dx + oy * dy + oz * dz;
+      if (c > min_cos) { min_cos = c; best = k; }
+    }
+    if (!(min_cos < 0.5)) {
+      o.ref_obs = P.obs_begin + best;
+      const hso_obs ref = R.obs[o.ref_obs];
+      const ReprojKf& K = R.kfs[ref.kf];
+      hso_align_job j;
+      j.ref_frame_id = K.frame_id;
+      j.ref_level = ref.level; j.type = ref.type;
+      j.px_ref[0] = ref.px[0]; j.px_ref[1] = ref.px[1];
+      j.f_ref[0] = ref.f[0]; j.f_ref[1] = ref.f[1]; j.f_ref[2] = ref.f[2];
+      j.grad[0] = ref.grad[0]; j.grad[1] = ref.grad[1];
+      if (ref.kf == P.host_kf) {
+        j.depth = 1.0 / P.idist;                                    // matcher.cpp:295-299
+      } else {
+        const double dx = K.pos[0] - P.pos[0], dy = K.pos[1] - P.pos[1], dz = K.pos[2] - P.pos[2];
+        j.depth = sqrt(dx * dx + dy * dy + dz * dz);                // :301-305
+      }
+      se3_to(K.T_cur_kf, j.T_cur_ref);
+      j.px_cur[0] = o.px[0]; j.px_cur[1] = o.px[1];
+      j.exposure_rat = K.exposure_rat;
+      j.kf_gap_lt4 = K.kf_gap_lt4;
+      JD->j = j;
+      JD->ref_base = K.base;
+    }
+  }
+  proj[i] = o;
+}
+
+// k_align over device-built jobs: a null reference = "findMatchDirect not reached / returned at once"
+__global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align_sparse(AlignConsts C, const AlignJobDev* jobs, int n_jobs,
+                                                                              hso_align_out* outs)
+{
+  __shared__ float s_pwb[ALIGN_WAVES_PER_BLOCK][100];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int jid = blockIdx.x * ALIGN_WAVES_PER_BLOCK + wave;
+  if (jid >= n_jobs) return;
+  const AlignJobDev& JD = jobs[jid];
+  if (JD.ref_base == nullptr) return;                // outs was zeroed
+  const hso_align_out o = match_one(C.cam, C.g, JD.cur_base, JD.ref_base, JD.j, (double)0.7f, s_pwb[wave]);
+  if (lane == 0) outs[jid] = o;
+}
+
+extern "C" int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* T_cur_w,
+                                       double cur_exposure_time, int cur_keyframe_id, const hso_kf* kfs, int n_kfs,
+                                       const hso_map_point* points, int n_points, const hso_obs* obs, int n_obs, int cell_size,
+                                       int grid_n_cols, hso_reproj_point* proj_out, hso_align_out* match_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!cam || !T_cur_w || n_kfs < 0 || n_points < 0 || n_obs < 0 || cell_size < 1 || grid_n_cols < 1 ||
+      (n_points > 0 && (!points || !proj_out || !match_out || !kfs || n_kfs == 0)) || (n_obs > 0 && !obs))
+    return hso_fail(ctx, HSO_E_INVALID, "reproject_match: bad argument");
+  if (n_points == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto itc = ctx->frames.find(cur_frame_id);
+  if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match: current frame not resident");
+  const PyrGeom g = itc->second.g;
+  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: camera size differs from the frame size");
+  const Se3 Tc = se3_from(*T_cur_w);
+  std::vector<ReprojKf> hk(n_kfs);
+  for (int k = 0; k < n_kfs; k++) {
+    auto it = ctx->frames.find(kfs[k].frame_id);
+    if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match: keyframe not resident");
+    if (it->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frames must share one size");
+    const Se3 inv = se3_inverse(se3_from(kfs[k].T_f_w));
+    hk[k].T_cur_kf = se3_mul(Tc, inv);
+    hk[k].pos[0] = inv.tx; hk[k].pos[1] = inv.ty; hk[k].pos[2] = inv.tz;
+    hk[k].base = it->second.base;
+    hk[k].frame_id = kfs[k].frame_id;
+    hk[k].exposure_rat = (float)(cur_exposure_time / kfs[k].exposure_time);
+    hk[k].kf_gap_lt4 = (cur_keyframe_id - kfs[k].keyframe_id) < 4;
+  }
+  // the index tables are the caller's: check them here, the kernels trust them
+  for (int i = 0; i < n_points; i++) {
+    const hso_map_point& p = points[i];
+    if (p.host_kf < 0 || p.host_kf >= n_kfs || p.obs_count < 0 || p.obs_begin < 0 || (long long)p.obs_begin + p.obs_count > n_obs)
+      return hso_fail(ctx, HSO_E_INVALID, "reproject_match: point table out of range");
+  }
+  for (int i = 0; i < n_obs; i++)
+    if (obs[i].kf < 0 || obs[i].kf >= n_kfs || obs[i].level < 0 || obs[i].level >= HSO_N_PYR_LEVELS)
+      return hso_fail(ctx, HSO_E_INVALID, "reproject_match: observation table out of range");
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t o_jobs = 0, o_out = o_jobs + al(sizeof(AlignJobDev) * (size_t)n_points);
+  const size_t o_proj = o_out + al(sizeof(hso_align_out) * (size_t)n_points);
+  const size_t o_kf = o_proj + al(sizeof(hso_reproj_point) * (size_t)n_points);
+  const size_t o_pts = o_kf + al(sizeof(ReprojKf) * (size_t)n_kfs);
+  const size_t o_obs = o_pts + al(sizeof(hso_map_point) * (size_t)n_points);
+  const size_t need = o_obs + al(sizeof(hso_obs) * (size_t)(n_obs > 0 ? n_obs : 1));
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
+  }
+  char* d = ctx->d_batch;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_kf, hk.data(), sizeof(ReprojKf) * (size_t)n_kfs, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pts, points, sizeof(hso_map_point) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
+  if (n_obs > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_obs, obs, sizeof(hso_obs) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_out, 0, sizeof(hso_align_out) * (size_t)n_points, ctx->stream));
+  ReprojConsts R;
+  R.cam = *cam;
+  {
+    const Se3 ci = se3_inverse(Tc);
+    R.cur_pos[0] = ci.tx; R.cur_pos[1] = ci.ty; R.cur_pos[2] = ci.tz;
+  }
+  R.cur_base = itc->second.base;
+  R.kfs = reinterpret_cast<const ReprojKf*>(d + o_kf);
+  R.pts = reinterpret_cast<const hso_map_point*>(d + o_pts);
+  R.obs = reinterpret_cast<const hso_obs*>(d + o_obs);
+  R.n_pts = n_points; R.cell_size = cell_size; R.grid_n_cols = grid_n_cols;
+  AlignJobDev* d_jobs = reinterpret_cast<AlignJobDev*>(d + o_jobs);
+  hso_align_out* d_out = reinterpret_cast<hso_align_out*>(d + o_out);
+  hso_reproj_point* d_proj = reinterpret_cast<hso_reproj_point*>(d + o_proj);
+  hipLaunchKernelGGL(k_reproject, dim3((n_points + 255) / 256), dim3(256), 0, ctx->stream, R, d_jobs, d_proj);
+  AlignConsts C;
+  C.cam = *cam; C.g = g;
+  hipLaunchKernelGGL(k_align_sparse, dim3((n_points + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0,
+                     ctx->stream, C, d_jobs, n_points, d_out);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(proj_out, d_proj, sizeof(hso_reproj_point) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(match_out, d_out, sizeof(hso_align_out) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}

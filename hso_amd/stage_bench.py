@@ -117,6 +117,19 @@ def main():
     dt = timed(lambda: ctx.ba_linearize(bposes, fixed, idist, edges, 1.0, 0.7), args.reps)
     out.append(dict(stage="ba_linearize", units="edges", n=len(edges), ms_per_call=dt * 1e3, units_per_s=len(edges) / dt))
 
+    # section 8f rank 2: project the map points of 6 keyframes, choose reference observations, match — one call
+    M = synth.map_problem(n_points=3000, first_frame_id=7000)
+    for k, f in zip(M["kfs"], M["frames"]):
+        ctx.frame_upload(int(k["frame_id"]), f)
+    ctx.frame_upload(M["cur_frame_id"], M["cur"])
+    rp_args = (cam, M["cur_frame_id"], M["T_cur_w"], M["cur_exposure"], M["cur_keyframe_id"], M["kfs"], M["points"], M["obs"],
+               M["cell_size"], M["grid_n_cols"])
+    dt = timed(lambda: ctx.reproject_match(*rp_args), args.reps)
+    proj, match = ctx.reproject_match(*rp_args)
+    out.append(dict(stage="reproject_match (reprojectPoint + getCloseViewObs + findMatchDirect)", units="map points", n=len(proj),
+                    ms_per_call=dt * 1e3, units_per_s=len(proj) / dt, projected=int(proj["projected"].sum()),
+                    matched=sum(m.success for m in match)))
+
     for o in out:
         print(json.dumps(o))
 

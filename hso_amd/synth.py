@@ -383,3 +383,95 @@ def config2_pair(n_feats=2000, spec=ICL_NUIM, seed=1234, exposure=1.05, noise=1.
     feats = sc.features(qi, ti, n_feats, seed + 4)
     return dict(scene=sc, ref=ref, cur=cur, feats=feats, q_true=q_true, t_true=t_true,
                 exposure=exposure)
+
+
+def map_problem(n_points=1500, n_kfs=6, seed=71, spec=ICL_NUIM, noise=1.0, trans_frac=0.04, rot_deg=0.8,
+                edgelet_frac=0.3, first_frame_id=9800, max_fts=200):
+    """A small map the way Reprojector::reprojectMap sees it: n_kfs keyframes (kf 0 at the
+    identity) plus one far-away keyframe whose viewing direction is useless (> 60 degrees), map
+    points hosted in different keyframes with 1-4 keyframe observations each, and a current frame.
+    Includes points that project outside the frame, behind the camera, or have no usable
+    observation.  Returns the tables of hso_gpu_reproject_match plus the images."""
+    from .capi import KF_DTYPE, OBS_DTYPE, MAP_POINT_DTYPE, SE3, FTR_CORNER, FTR_EDGELET
+    sc = Scene(spec, seed)
+    rng = np.random.default_rng(seed + 1)
+    poses = [(np.array([0, 0, 0, 1.0]), np.zeros(3))]
+    for k in range(1, n_kfs):
+        tdir = rng.normal(size=3); tdir /= np.linalg.norm(tdir)
+        rdir = rng.normal(size=3); rdir /= np.linalg.norm(rdir)
+        poses.append((rotvec_to_quat(rdir * np.deg2rad(rot_deg) * rng.uniform(0.3, 1.0)), tdir * trans_frac * 4.0 * rng.uniform(0.4, 1.0)))
+    frames = [sc.render(q, t, float(rng.uniform(0.9, 1.1)) if k else 1.0, noise, seed + 10 + k) for k, (q, t) in enumerate(poses)]
+    kfs = np.zeros(n_kfs + 1, KF_DTYPE)
+    for k, (q, t) in enumerate(poses):
+        kfs[k]["frame_id"], kfs[k]["q"], kfs[k]["t"] = first_frame_id + k, q, t
+        kfs[k]["exposure_time"], kfs[k]["keyframe_id"] = 1.0 + 0.02 * k, k
+    # the far keyframe: 30 m away behind the surface, looking back at it (its image is never sampled: no point chooses it)
+    far = n_kfs
+    kfs[far]["frame_id"], kfs[far]["q"], kfs[far]["t"] = first_frame_id + far, [0, 0, 0, 1.0], [0, 0, -30.0]
+    kfs[far]["exposure_time"], kfs[far]["keyframe_id"] = 1.0, far
+    frames.append(frames[0])
+    # current frame
+    tdir = rng.normal(size=3); tdir /= np.linalg.norm(tdir)
+    q_cur, t_cur = rotvec_to_quat(np.array([0.3, -0.8, 0.5]) * np.deg2rad(rot_deg)), tdir * trans_frac * 4.0
+    cur = sc.render(q_cur, t_cur, 1.06, noise, seed + 3)
+    feats = sc.features(poses[0][0], poses[0][1], n_points, seed=seed + 4, margin=12)
+    X0 = feats["f"] * feats["dist"][:, None]                       # world = frame 0
+    grads = [np.gradient(f.astype(np.float64)) for f in frames]
+    points = np.zeros(n_points, MAP_POINT_DTYPE)
+    obs = []
+    w, h = sc.w, sc.h
+
+    def observe(k, X):
+        q, t = poses[k]
+        Xk = quat_to_R(q) @ X + t
+        u, v = sc.project(Xk[None])
+        u, v = float(u[0]), float(v[0])
+        b = sc.unproject(np.array([u]), np.array([v]))[0]
+        return u, v, b / np.linalg.norm(b), Xk
+    for i in range(n_points):
+        X = X0[i].copy()
+        if i % 29 == 4:
+            X[0] += 30.0                                           # far outside the image
+        if i % 31 == 6:
+            X[2] = -1.0                                            # behind every camera
+        host = int(rng.integers(0, n_kfs))
+        u, v, f, Xh = observe(host, X)
+        if not (10 <= u < w - 10 and 10 <= v < h - 10) or Xh[2] <= 0.1:
+            host = 0
+            u, v, f, Xh = observe(0, X0[i]) if i % 29 != 4 and i % 31 != 6 else (feats["px"][i][0], feats["px"][i][1], feats["f"][i], X0[i])
+            if i % 29 == 4 or i % 31 == 6:
+                # keep the bad geometry: the host feature is consistent with the displaced point
+                Xh = X
+                f = X / np.linalg.norm(X) if X[2] > 0 else np.array([0.0, 0.0, 1.0])
+        points[i]["pos"] = X
+        points[i]["idist"] = 1.0 / max(np.linalg.norm(Xh), 1e-3) if i % 31 != 6 else -0.5
+        points[i]["host_f"], points[i]["host_kf"] = f, host
+        ks = [host] + [int(k) for k in rng.permutation(n_kfs)[:int(rng.integers(0, 4))] if k != host]
+        if i % 37 == 9:
+            ks = [far]                                             # only a useless observation
+        if i % 41 == 11:
+            ks = []                                                # no observation at all
+        if i % 13 == 2 and ks and ks != [far]:
+            ks.insert(int(rng.integers(0, len(ks) + 1)), far)
+        points[i]["obs_begin"], points[i]["obs_count"] = len(obs), len(ks)
+        for k in ks:
+            o = np.zeros(1, OBS_DTYPE)[0]
+            kk = k if k != far else 0
+            uu, vv, ff, _ = observe(kk, X0[i])
+            uu, vv = float(np.clip(uu, 0, w - 1)), float(np.clip(vv, 0, h - 1))
+            is_edge = rng.uniform() < edgelet_frac
+            gy, gx = grads[kk]
+            g = np.array([gx[int(vv), int(uu)], gy[int(vv), int(uu)]])
+            g = g / (np.linalg.norm(g) + 1e-9)
+            lvl = int(rng.integers(0, 3))
+            o["kf"], o["level"], o["type"] = k, lvl, FTR_EDGELET if is_edge else FTR_CORNER
+            o["px"] = [np.floor(uu / (1 << lvl)) * (1 << lvl), np.floor(vv / (1 << lvl)) * (1 << lvl)]   # detected on the level's lattice
+            bb = sc.unproject(np.array([o["px"][0]]), np.array([o["px"][1]]))[0]
+            o["f"] = bb / np.linalg.norm(bb)
+            o["grad"] = g if is_edge else [1.0, 0.0]
+            obs.append(o)
+    obs = np.array(obs, OBS_DTYPE) if obs else np.zeros(0, OBS_DTYPE)
+    cell_size = int(np.floor(np.float32(np.sqrt(np.float32(w * h) / max_fts)) * 0.6))    # reprojector.cpp:53-56
+    return dict(scene=sc, frames=frames, cur=cur, kfs=kfs, points=points, obs=obs, T_cur_w=SE3.from_arrays(q_cur, t_cur),
+                cur_exposure=1.06, cur_keyframe_id=n_kfs + 2, cell_size=cell_size, grid_n_cols=int(np.ceil(w / cell_size)),
+                cur_frame_id=first_frame_id + n_kfs + 1)

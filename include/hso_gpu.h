@@ -273,6 +273,56 @@ int hso_gpu_align_batch(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_fra
 int hso_gpu_align_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur_frame_ids,
                         const hso_align_job* jobs, int n_jobs, hso_align_out* out);
 
+/* ---- Reprojector::reprojectPoint + the matching of its candidates, src/reprojector.cpp:504-529 and
+ *      :352-429: project every map point of the overlapping keyframes
+ *      into the current frame, bin it into the reprojection grid, choose its reference observation
+ *      (Point::getCloseViewObs, src/point.cpp:116-136) and run findMatchDirect on it — one call,
+ *      nothing returns to the host between projection and matching.  The caller keeps what walks
+ *      the pointer graph and mutates it: which keyframes overlap (:108-199), the per-cell sort and
+ *      visiting order, the first-success-per-cell / maxFts budget and the n_failed_reproj_
+ *      bookkeeping (:352-429), all of which only read this call's result arrays. ---- */
+typedef struct hso_kf {        /* a keyframe whose points are projected (it must be resident) */
+  int64_t frame_id;
+  hso_se3 T_f_w;
+  double exposure_time;        /* Frame::m_exposure_time */
+  int32_t keyframe_id;         /* Frame::keyFrameId_ */
+  int32_t pad_;
+} hso_kf;
+
+typedef struct hso_obs {       /* one entry of Point::obs_: a keyframe feature observing the point */
+  int32_t kf;                  /* index into the hso_kf table */
+  int32_t level;               /* Feature::level */
+  int32_t type;                /* Feature::type */
+  int32_t pad_;
+  double px[2], f[3], grad[2];
+} hso_obs;
+
+typedef struct hso_map_point {
+  double pos[3];               /* Point::pos_ (world) */
+  double idist;                /* Point::idist_ in the host frame */
+  double host_f[3];            /* hostFeature_->f */
+  int32_t host_kf;             /* index of hostFeature_->frame in the hso_kf table */
+  int32_t obs_begin, obs_count;/* obs_[0..count) = obs[obs_begin ...], in list order */
+  int32_t pad_;
+} hso_map_point;
+
+typedef struct hso_reproj_point {
+  int32_t projected;           /* reprojectPoint's return value (:508, :512) */
+  int32_t cell;                /* grid cell index k (:517-518), valid when projected */
+  double px[2];                /* Candidate::px before refinement */
+  int32_t ref_obs;             /* index into obs of the observation getCloseViewObs chose; -1: none within 60 degrees */
+  int32_t pad_;
+} hso_reproj_point;
+
+/* cell_size, grid_n_cols: Reprojector::initializeGrid (:58-68).  proj_out and match_out hold
+ * n_points entries in point order; match_out[i] is findMatchDirect's result for point i (all zero
+ * when the point is not projected or has no reference observation: the reference never calls the
+ * matcher for the former and returns false at once for the latter, src/matcher.cpp:276-286). */
+int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* T_cur_w,
+                            double cur_exposure_time, int cur_keyframe_id, const hso_kf* kfs, int n_kfs,
+                            const hso_map_point* points, int n_points, const hso_obs* obs, int n_obs,
+                            int cell_size, int grid_n_cols, hso_reproj_point* proj_out, hso_align_out* match_out);
+
 /* ---- pose_optimizer::optimizeLevenbergMarquardt3rd, src/pose_optimizer.cpp:399-771 ---- */
 
 /* One feature of the frame being optimised, in Frame::fts_ order.  has_point = 0 keeps the

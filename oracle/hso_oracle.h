@@ -137,6 +137,12 @@ int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y);
 float hso_or_shi_tomasi(const uint8_t* img, int cols, int rows, int u, int v);
 int hso_or_fast9_detect(const uint8_t* img, int w, int h, int threshold, int16_t* xy, int32_t* scores, int cap);
 int hso_or_fast_detect_level(const uint8_t* img, int w, int h, int threshold, int border, hso_corner* out, int cap);
+/* ---- Reprojector candidate generation (src/reprojector.cpp:504-529, src/point.cpp:116-136, src/matcher.cpp:270-319) ---- */
+int hso_or_reproject_point(const hso_camera* cam, const hso_se3* T_cur_w, const hso_se3* T_host_w, const double host_f[3], double idist,
+                           int cell_size, int grid_n_cols, double px[2], int* cell);
+int hso_or_close_view_obs(const double cur_pos[3], const double pos[3], const hso_kf* kfs, const hso_obs* obs, int n_obs);
+void hso_or_reproject_make_job(const hso_se3* T_cur_w, double cur_exposure_time, int cur_keyframe_id, const hso_kf* kfs,
+                               const hso_map_point* pt, const hso_obs* ref, const double px_cur[2], hso_align_job* j);
 /* ---- edgelet candidates (src/feature_detection.cpp:749-830; cv::Canny restated, unpinned) ---- */
 void hso_or_canny_l2(const int16_t* dx, const int16_t* dy, int w, int h, double low_thresh, double high_thresh, uint8_t* edges);
 void hso_or_detect_grid(int width, int height, int level, int* grid, int* gcols, int* grows, int* lw, int* lh);

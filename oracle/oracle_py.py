@@ -495,6 +495,45 @@ def detect_candidates_level(img, gx, gy, level, frame_w, frame_h, min_thresh):
     return corners, edgelet_level(gx, gy, level, frame_w, frame_h, min_thresh, have), have
 
 
+def reproject_match(cam, T_cur_w, cur_exposure_time, cur_keyframe_id, kfs, points, obs, cell_size, grid_n_cols,
+                    kf_pyrs, cur_pyr, cur_sobel):
+    """Reprojector::reprojectPoint + getCloseViewObs + findMatchDirect per map point.
+    kf_pyrs[k]: pyramid of keyframe k.  Returns (proj array, list of AlignOut or None per point)."""
+    from hso_amd.capi import AlignJob, KF_DTYPE, MAP_POINT_DTYPE, OBS_DTYPE, REPROJ_POINT_DTYPE
+    lib = load()
+    vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+    lib.hso_or_reproject_point.argtypes = [C.POINTER(Camera), C.POINTER(SE3), vp, vp, dbl, i32, i32, vp, C.POINTER(i32)]
+    lib.hso_or_reproject_point.restype = i32
+    lib.hso_or_close_view_obs.argtypes = [vp, vp, vp, vp, i32]
+    lib.hso_or_close_view_obs.restype = i32
+    lib.hso_or_reproject_make_job.argtypes = [C.POINTER(SE3), dbl, i32, vp, vp, vp, vp, C.POINTER(AlignJob)]
+    lib.hso_or_reproject_make_job.restype = None
+    kfs = np.ascontiguousarray(kfs, KF_DTYPE); points = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+    obs = np.ascontiguousarray(obs, OBS_DTYPE)
+    cur_pos = np.array(se3_inverse(T_cur_w).t[:])
+    proj = np.zeros(len(points), REPROJ_POINT_DTYPE)
+    proj["ref_obs"] = -1
+    matches = []
+    for i, p in enumerate(points):
+        px = np.zeros(2); cell = i32(0)
+        T_host = kfs[p["host_kf"]:p["host_kf"] + 1]          # q, t follow frame_id: an hso_se3 in place
+        ok = lib.hso_or_reproject_point(C.byref(cam), C.byref(T_cur_w), T_host.ctypes.data + 8, p["host_f"].ctypes.data,
+                                        float(p["idist"]), cell_size, grid_n_cols, px.ctypes.data, C.byref(cell))
+        m = None
+        if ok:
+            proj[i]["projected"], proj[i]["cell"], proj[i]["px"] = 1, cell.value, px
+            o = obs[p["obs_begin"]:p["obs_begin"] + p["obs_count"]]
+            k = lib.hso_or_close_view_obs(cur_pos.ctypes.data, p["pos"].ctypes.data, kfs.ctypes.data, o.ctypes.data, len(o)) if len(o) else -1
+            if k >= 0:
+                proj[i]["ref_obs"] = p["obs_begin"] + k
+                job = AlignJob()
+                lib.hso_or_reproject_make_job(C.byref(T_cur_w), cur_exposure_time, cur_keyframe_id, kfs.ctypes.data,
+                                              points[i:i + 1].ctypes.data, o[k:k + 1].ctypes.data, px.ctypes.data, C.byref(job))
+                m = find_match_direct(cam, job, kf_pyrs[o[k]["kf"]], cur_pyr, cur_sobel)
+        matches.append(m)
+    return proj, matches
+
+
 def pattern(max_level, level):
     pa, hp = C.c_int(), C.c_int()
     offs = np.zeros((40, 2), np.int8)
