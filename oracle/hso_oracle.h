@@ -8,9 +8,10 @@
  * PARITY PINNING: the reference (luodongting/HSO) ships no tests, golden
  * vectors or fixtures for this path and cannot be compiled here (Eigen3, OpenCV,
  * Boost absent), so the restatement below is *unpinned by the reference* except
- * for the two parts whose reference sources build standalone (oracle/_ref, see
- * Makefile): the robust-cost functions (src/vikit/robust_cost.cpp) and the FAST-9
- * corner detector (thirdparty/fast, hso_oracle_fast.c).  Every
+ * for the three parts whose reference sources build standalone (oracle/_ref, see
+ * Makefile): the robust-cost functions (src/vikit/robust_cost.cpp), the FAST-9
+ * corner detector (thirdparty/fast, hso_oracle_fast.c) and the ZMNCC patch score
+ * (include/hso/vikit/patch_score.h, hso_oracle_seed.c).  Every
  * function cites the reference file:line it follows so it can be diffed by eye.
  * Third-party arithmetic that the reference pulls from outside its tree (Eigen
  * LDLT / Quaternion, OpenCV Sobel) is restated from the published algorithms.
@@ -137,6 +138,7 @@ int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y);
 float hso_or_shi_tomasi(const uint8_t* img, int cols, int rows, int u, int v);
 int hso_or_fast9_detect(const uint8_t* img, int w, int h, int threshold, int16_t* xy, int32_t* scores, int cap);
 int hso_or_fast_detect_level(const uint8_t* img, int w, int h, int threshold, int border, hso_corner* out, int cap);
+float hso_or_zmncc_f8(const float* host, const float* target);   /* ZMNCC_F<4>, include/hso/vikit/patch_score.h:268-305 — pinned (tests/golden/zmncc.json) */
 /* ---- Reprojector candidate generation (src/reprojector.cpp:504-529, src/point.cpp:116-136, src/matcher.cpp:270-319) ---- */
 int hso_or_reproject_point(const hso_camera* cam, const hso_se3* T_cur_w, const hso_se3* T_host_w, const double host_f[3], double idist,
                            int cell_size, int grid_n_cols, double px[2], int* cell);

@@ -83,6 +83,9 @@ static float zmncc_score(const float* host, float hostMean, const float* target)
   return (numerator / (sqrtf(d1 * d2) + 1e-12));
 }
 
+/* exported for the pinning test against the reference's own template (oracle/_ref/libpatch_score_ref.so) */
+float hso_or_zmncc_f8(const float* host, const float* target) { return zmncc_score(host, zmncc_host_mean(host), target); }
+
 /* Matcher::KLTLimited2D, src/matcher.cpp:1296-1451 */
 static int klt_limited_2d(const uint8_t* img, int cols, int rows, const float* pwb, const float* host, int n_iter,
                           double px[2], float* targetPatch)

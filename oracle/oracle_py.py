@@ -20,8 +20,10 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "all"])
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "all"])
+    else:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])      # incremental: a no-op when up to date
     if os.path.isdir("/root/reference"):
         subprocess.check_call(["make", "-C", _HERE, "ref"])
 
@@ -532,6 +534,28 @@ def reproject_match(cam, T_cur_w, cur_exposure_time, cur_keyframe_id, kfs, point
                 m = find_match_direct(cam, job, kf_pyrs[o[k]["kf"]], cur_pyr, cur_sobel)
         matches.append(m)
     return proj, matches
+
+
+REF_PATCH_SCORE_PATH = os.path.join(_HERE, "_ref", "libpatch_score_ref.so")
+
+
+def zmncc_f8(host, target):
+    lib = load()
+    lib.hso_or_zmncc_f8.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hso_or_zmncc_f8.restype = C.c_float
+    host, target = np.ascontiguousarray(host, np.float32), np.ascontiguousarray(target, np.float32)
+    return lib.hso_or_zmncc_f8(host.ctypes.data, target.ctypes.data)
+
+
+def ref_zmncc_f8(host, target):
+    """ZMNCC_F<4> of the compiled reference header (oracle/_ref/libpatch_score_ref.so); None if absent."""
+    if not os.path.exists(REF_PATCH_SCORE_PATH):
+        return None
+    lib = C.CDLL(REF_PATCH_SCORE_PATH)
+    lib.ref_zmncc_f8.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ref_zmncc_f8.restype = C.c_float
+    host, target = np.ascontiguousarray(host, np.float32), np.ascontiguousarray(target, np.float32)
+    return lib.ref_zmncc_f8(host.ctypes.data, target.ctypes.data)
 
 
 def pattern(max_level, level):
