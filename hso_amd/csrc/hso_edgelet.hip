@@ -12,13 +12,15 @@
 // The connectivity closure is the only sequential part (a stack flood fill in OpenCV).  It is a
 // monotone fixed point — labels only move weak -> edge — so any evaluation order ends in the same
 // map; here every 64x32 tile closes itself in LDS and whole-image passes repeat until no tile
-// changed a pixel (a flag per pass lets the remaining queued passes return at once).
+// changed a pixel (a flag per pass lets the remaining queued passes return at once, and a tile
+// reloads its labels only while it still holds weak pixels and a neighbouring tile just grew).
 //
 // MI355X mapping (HBM/L2-bound byte and short work; all levels of all frames in one launch:
 // blockIdx.y = level, blockIdx.z = frame, so a single keyframe still fills ~200 workgroups):
 //   k_cell_mark      FAST mask words -> haveFeatures_ flags (getCellIndex)
-//   k_canny_nms      64x16 tile + 1 ring of packed (gx, gy) in LDS -> label bytes 0 weak / 1 none / 2 edge
-//   k_canny_close    tile closure in LDS; repeated
+//   k_canny_nms      64x32 tile + 2 rings of packed (gx, gy) in LDS -> label bytes 0 weak / 1 none /
+//                    2 edge of the tile + 1 ring, closed inside the tile before they reach HBM
+//   k_canny_close    closure across tile borders; repeated
 //   k_edgelet_cells  one lane per grid index: arg-max of sqrtf(m) over its window
 //   k_edgelet_pack   ordered compaction (grid-index order = the reference's push order)
 #include "hso_fast_plan.h"
@@ -26,14 +28,16 @@
 
 #define EDGE_LEVELS HSO_N_SOBEL_LEVELS
 #define EDGE_MAX_PASSES 64
-#define NMS_TW 64
-#define NMS_TH 16
+#define EDGE_ROUND 4          // closure passes queued per host round trip
 #define CLOSE_TW 64
 #define CLOSE_TH 32
+#define M_STRIDE (CLOSE_TW + 8)   // label tile row: ring column -1 at byte 3, interior at bytes 4..67 (4-byte aligned), ring column 64 at byte 68
+#define MCOL(lx) ((lx) + 3)      // lx = 0..CLOSE_TW+1 in ring coordinates
 
 struct EdgeLevel {
   int W, H;                 // level image
   int grid, gcols, grows;   // occupancy grid of the level (FeatureExtractor ctor :393-400)
+  int tiles_x, tiles_y, tile_base;   // 64x32 tiles; tile_base = first tile of the level in a frame's tile tables
   uint32_t gx_off, gy_off;  // Sobel images inside a frame
   size_t o_map, o_res, o_out, o_have;  // offsets inside a frame's edgelet slice
   size_t o_fmask;           // FAST mask inside a frame's FAST slice
@@ -45,9 +49,11 @@ struct EdgeArgs {
   const uint8_t* const* bases;
   char* fast_work; size_t fast_per_frame;
   char* work; size_t per_frame;      // edgelet slices
+  size_t o_weak, o_chg;              // per frame: weak[tiles], chg[EDGE_ROUND + 1][tiles]
+  int n_tiles;                       // tiles of all levels of one frame
   int* flags;                        // [EDGE_MAX_PASSES + 1]; flags[p + 1] != 0: pass p changed a pixel
   int* totals;                       // [n_frames][n_levels]
-  int n_levels, low, high, cap, pass;
+  int n_levels, low, high, cap, pass, slot;
 };
 
 // static selection of the level record: a dynamic index into the by-value argument would force a
@@ -77,111 +83,244 @@ __device__ __forceinline__ int mag_of(uint32_t g)
   return gx * gx + gy * gy;
 }
 
+// non-maximum suppression of one pixel; (ly, lx) index s_g
+__device__ __forceinline__ uint8_t canny_label(const uint32_t (*s_g)[CLOSE_TW + 4], int ly, int lx, int low, int high)
+{
+  const int TG22 = 13573;                        // (int)(0.41421356... * 2^15 + 0.5)
+  const uint32_t g = s_g[ly][lx];
+  const int m = mag_of(g);
+  if (!(m > low)) return 1;
+  const int xs = (int)(short)(g & 0xffffu), ys = (int)(short)(g >> 16);
+  const int ax = abs(xs), ay = abs(ys) << 15;
+  const int tg22x = ax * TG22;
+  bool keep;
+  if (ay < tg22x) {
+    keep = m > mag_of(s_g[ly][lx - 1]) && m >= mag_of(s_g[ly][lx + 1]);
+  } else {
+    const int tg67x = tg22x + (ax << 16);
+    if (ay > tg67x) {
+      keep = m > mag_of(s_g[ly - 1][lx]) && m >= mag_of(s_g[ly + 1][lx]);
+    } else {
+      const int s = (xs ^ ys) < 0 ? -1 : 1;
+      keep = m > mag_of(s_g[ly - 1][lx - s]) && m > mag_of(s_g[ly + 1][lx + s]);
+    }
+  }
+  if (!keep) return 1;
+  return m > high ? 2 : 0;
+}
+
+// Closure of the tile interior (rows 1..CLOSE_TH, columns 1..CLOSE_TW of s_m) against its ring, as
+// bit-board arithmetic in ONE wavefront: lane = label row, a 64-bit word per lane holds the row's
+// 64 interior columns (edge bits E, weak bits Wk); the ring columns are two constant source bits.
+// One step ORs the rows above and below (two lane shuffles), spreads by one column, and floods every
+// weak run that touches a source along the row with a 6-step Kogge-Stone fill in each direction —
+// so a step costs ~100 scalar-like instructions and no barrier, and the number of steps is the
+// number of ROW changes along the longest weak chain, not its length.  Result in s_E / s_W (final
+// edge / still-weak bits per row); all threads call, wave 0 works.
+__device__ __forceinline__ void close_tile(const uint8_t (*s_m)[M_STRIDE], unsigned long long* s_E, unsigned long long* s_W)
+{
+  if (threadIdx.x < 64) {
+    const int r = threadIdx.x;
+    unsigned long long E = 0, Wk = 0;
+    unsigned hl = 0, hr = 0;
+    if (r < CLOSE_TH + 2) {
+#pragma unroll 8
+      for (int c = 0; c < CLOSE_TW; c++) {
+        const uint8_t v = s_m[r][MCOL(c + 1)];
+        E |= (unsigned long long)(v == 2) << c;
+        Wk |= (unsigned long long)(v == 0) << c;
+      }
+      hl = s_m[r][MCOL(0)] == 2; hr = s_m[r][MCOL(CLOSE_TW + 1)] == 2;
+      if (r == 0 || r == CLOSE_TH + 1) Wk = 0;               // ring rows are sources only
+    }
+    // ring columns seen from row r: rows r-1, r, r+1 (lanes beyond the tile hold zeros)
+    const unsigned hl_up = __shfl_up(hl, 1), hl_dn = __shfl_down(hl, 1), hr_up = __shfl_up(hr, 1), hr_dn = __shfl_down(hr, 1);
+    const unsigned long long ring = ((hl | (r > 0 ? hl_up : 0u) | hl_dn) ? 1ull : 0ull) | ((hr | (r > 0 ? hr_up : 0u) | hr_dn) ? (1ull << 63) : 0ull);
+    for (;;) {
+      unsigned long long up = __shfl_up(E, 1), dn = __shfl_down(E, 1);
+      if (r == 0) up = 0;
+      if (r == 63) dn = 0;
+      const unsigned long long X = E | up | dn;
+      unsigned long long gen = Wk & (X | (X << 1) | (X >> 1) | ring);
+      const int any = __any(gen != 0);
+      if (!any) break;
+      // flood the weak runs that hold a seed: towards higher columns, then lower
+      unsigned long long g = gen, p = Wk;
+      g |= p & (g << 1); p &= p << 1;
+      g |= p & (g << 2); p &= p << 2;
+      g |= p & (g << 4); p &= p << 4;
+      g |= p & (g << 8); p &= p << 8;
+      g |= p & (g << 16); p &= p << 16;
+      g |= p & (g << 32);
+      p = Wk;
+      g |= p & (g >> 1); p &= p >> 1;
+      g |= p & (g >> 2); p &= p >> 2;
+      g |= p & (g >> 4); p &= p >> 4;
+      g |= p & (g >> 8); p &= p >> 8;
+      g |= p & (g >> 16); p &= p >> 16;
+      g |= p & (g >> 32);
+      E |= g; Wk &= ~g;
+    }
+    if (r < CLOSE_TH + 2) { s_E[r] = E; s_W[r] = Wk; }
+  }
+  __syncthreads();
+}
+
+// labels of a 64x32 tile and its ring from the packed gradients of the tile + 2 rings, then the
+// tile's own closure while the labels are still in LDS: the map reaches HBM tile-closed
 __global__ __launch_bounds__(256) void k_canny_nms(EdgeArgs A)
 {
-  __shared__ uint32_t s_g[NMS_TH + 2][NMS_TW + 2];   // packed (gx, gy); zero outside the image = zero magnitude
+  __shared__ uint32_t s_g[CLOSE_TH + 4][CLOSE_TW + 4];   // packed (gx, gy); zero outside the image = zero magnitude
+  __shared__ __attribute__((aligned(8))) uint8_t s_m[CLOSE_TH + 2][M_STRIDE];
+  __shared__ unsigned long long s_E[CLOSE_TH + 2], s_W[CLOSE_TH + 2];
   const EdgeLevel& L = level_of(A, blockIdx.y);
   const int W = L.W, H = L.H;
-  const int tiles_x = (W + NMS_TW - 1) / NMS_TW, tiles_y = (H + NMS_TH - 1) / NMS_TH;
-  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int x0 = tx * NMS_TW, y0 = ty * NMS_TH;
+  if ((int)blockIdx.x >= L.tiles_x * L.tiles_y) return;
+  const int ty = blockIdx.x / L.tiles_x, tx = blockIdx.x - ty * L.tiles_x;
+  const int x0 = tx * CLOSE_TW, y0 = ty * CLOSE_TH;
   const uint8_t* base = A.bases[blockIdx.z];
   const int16_t* gxp = reinterpret_cast<const int16_t*>(base + L.gx_off);
   const int16_t* gyp = reinterpret_cast<const int16_t*>(base + L.gy_off);
   const int t = threadIdx.x;
-  for (int i = t; i < (NMS_TH + 2) * (NMS_TW + 2); i += 256) {
-    const int ly = i / (NMS_TW + 2), lx = i - ly * (NMS_TW + 2);
-    const int y = y0 + ly - 1, x = x0 + lx - 1;
-    uint32_t v = 0;
-    if (x >= 0 && x < W && y >= 0 && y < H) {
-      const size_t o = (size_t)y * W + x;
-      v = (uint32_t)(uint16_t)gxp[o] | ((uint32_t)(uint16_t)gyp[o] << 16);
+  if ((W & 3) == 0) {
+    // interior columns four pixels (8 bytes of gx, 8 of gy) at a time, the 2 + 2 ring columns singly
+    for (int i = t; i < (CLOSE_TH + 4) * (CLOSE_TW / 4); i += 256) {
+      const int ly = i / (CLOSE_TW / 4), q = i - ly * (CLOSE_TW / 4);
+      const int y = y0 + ly - 2, x = x0 + 4 * q;
+      uint2 a = make_uint2(0, 0), b = make_uint2(0, 0);
+      if (y >= 0 && y < H && x < W) {
+        const size_t o = (size_t)y * W + x;
+        a = *reinterpret_cast<const uint2*>(gxp + o);
+        b = *reinterpret_cast<const uint2*>(gyp + o);
+      }
+      uint32_t* d = &s_g[ly][2 + 4 * q];
+      d[0] = (a.x & 0xffffu) | (b.x << 16); d[1] = (a.x >> 16) | (b.x & 0xffff0000u);
+      d[2] = (a.y & 0xffffu) | (b.y << 16); d[3] = (a.y >> 16) | (b.y & 0xffff0000u);
     }
-    s_g[ly][lx] = v;
+    for (int i = t; i < (CLOSE_TH + 4) * 4; i += 256) {
+      const int ly = i >> 2, h = i & 3;
+      const int lx = h < 2 ? h : CLOSE_TW + h;
+      const int y = y0 + ly - 2, x = x0 + lx - 2;
+      uint32_t v = 0;
+      if (x >= 0 && x < W && y >= 0 && y < H) {
+        const size_t o = (size_t)y * W + x;
+        v = (uint32_t)(uint16_t)gxp[o] | ((uint32_t)(uint16_t)gyp[o] << 16);
+      }
+      s_g[ly][lx] = v;
+    }
+  } else {
+    for (int i = t; i < (CLOSE_TH + 4) * (CLOSE_TW + 4); i += 256) {
+      const int ly = i / (CLOSE_TW + 4), lx = i - ly * (CLOSE_TW + 4);
+      const int y = y0 + ly - 2, x = x0 + lx - 2;
+      uint32_t v = 0;
+      if (x >= 0 && x < W && y >= 0 && y < H) {
+        const size_t o = (size_t)y * W + x;
+        v = (uint32_t)(uint16_t)gxp[o] | ((uint32_t)(uint16_t)gyp[o] << 16);
+      }
+      s_g[ly][lx] = v;
+    }
   }
   __syncthreads();
-  const int ly = t >> 4, lx0 = (t & 15) * 4;     // 4 consecutive pixels of one row
-  const int y = y0 + ly;
-  if (y >= H) return;
-  uint8_t* map = reinterpret_cast<uint8_t*>(A.work + (size_t)blockIdx.z * A.per_frame + L.o_map);
   const int low = A.low, high = A.high;
-  const int TG22 = 13573;                        // (int)(0.41421356... * 2^15 + 0.5)
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int lx = lx0 + k, x = x0 + lx;
-    if (x >= W) break;
-    const uint32_t g = s_g[ly + 1][lx + 1];
-    const int m = mag_of(g);
-    uint8_t label = 1;
-    if (m > low) {
-      const int xs = (int)(short)(g & 0xffffu), ys = (int)(short)(g >> 16);
-      const int ax = abs(xs), ay = abs(ys) << 15;
-      const int tg22x = ax * TG22;
-      bool keep;
-      if (ay < tg22x) {
-        keep = m > mag_of(s_g[ly + 1][lx]) && m >= mag_of(s_g[ly + 1][lx + 2]);
-      } else {
-        const int tg67x = tg22x + (ax << 16);
-        if (ay > tg67x) {
-          keep = m > mag_of(s_g[ly][lx + 1]) && m >= mag_of(s_g[ly + 2][lx + 1]);
-        } else {
-          const int s = (xs ^ ys) < 0 ? -1 : 1;
-          keep = m > mag_of(s_g[ly][lx + 1 - s]) && m > mag_of(s_g[ly + 2][lx + 1 + s]);
-        }
-      }
-      if (keep) label = m > high ? 2 : 0;
-    }
-    map[(size_t)y * W + x] = label;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_canny_close(EdgeArgs A)
-{
-  __shared__ uint8_t s_m[CLOSE_TH + 2][CLOSE_TW + 4];
-  if (A.pass > 0 && A.flags[A.pass] == 0) return;      // the previous pass changed nothing: closed
-  const EdgeLevel& L = level_of(A, blockIdx.y);
-  const int W = L.W, H = L.H;
-  const int tiles_x = (W + CLOSE_TW - 1) / CLOSE_TW, tiles_y = (H + CLOSE_TH - 1) / CLOSE_TH;
-  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int x0 = tx * CLOSE_TW, y0 = ty * CLOSE_TH;
-  uint8_t* map = reinterpret_cast<uint8_t*>(A.work + (size_t)blockIdx.z * A.per_frame + L.o_map);
-  const int t = threadIdx.x;
-  int has_weak = 0;
   for (int i = t; i < (CLOSE_TH + 2) * (CLOSE_TW + 2); i += 256) {
     const int ly = i / (CLOSE_TW + 2), lx = i - ly * (CLOSE_TW + 2);
     const int y = y0 + ly - 1, x = x0 + lx - 1;
-    const uint8_t v = (x >= 0 && x < W && y >= 0 && y < H) ? map[(size_t)y * W + x] : (uint8_t)1;
-    s_m[ly][lx] = v;
-    has_weak |= (v == 0);
+    s_m[ly][MCOL(lx)] = (x >= 0 && x < W && y >= 0 && y < H) ? canny_label(s_g, ly + 1, lx + 1, low, high) : (uint8_t)1;
   }
-  if (!__syncthreads_or(has_weak)) return;
-  const int ly = (t >> 3) + 1, lx0 = (t & 7) * 8 + 1;    // 8 consecutive interior pixels of one row
-  unsigned grown = 0;                                    // bit k: pixel k turned into an edge here
-  for (;;) {
-    int changed = 0;
+  __syncthreads();
+  close_tile(s_m, s_E, s_W);
+  const int ly = (t >> 3) + 1, c0 = (t & 7) * 8;           // 8 consecutive interior pixels of one row
+  uint8_t* slice = reinterpret_cast<uint8_t*>(A.work + (size_t)blockIdx.z * A.per_frame);
+  uint8_t* map = slice + L.o_map;
+  const int y = y0 + ly - 1, xb = x0 + c0;
+  const unsigned eb = (unsigned)(s_E[ly] >> c0) & 0xffu, wb = (unsigned)(s_W[ly] >> c0) & 0xffu;
+  int weak = 0;
+  if (y < H) {
+    if ((W & 7) == 0 && xb + 7 < W) {
+      unsigned long long pk = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int lx = lx0 + k;
-      if (s_m[ly][lx] != 0) continue;
-      const bool any = s_m[ly - 1][lx - 1] == 2 || s_m[ly - 1][lx] == 2 || s_m[ly - 1][lx + 1] == 2 || s_m[ly][lx - 1] == 2 ||
-                       s_m[ly][lx + 1] == 2 || s_m[ly + 1][lx - 1] == 2 || s_m[ly + 1][lx] == 2 || s_m[ly + 1][lx + 1] == 2;
-      if (any) { s_m[ly][lx] = 2; grown |= 1u << k; changed = 1; }
-    }
+      for (int k = 0; k < 8; k++) pk |= (unsigned long long)(((eb >> k) & 1u) ? 2u : (((wb >> k) & 1u) ? 0u : 1u)) << (8 * k);
+      *reinterpret_cast<unsigned long long*>(map + (size_t)y * W + xb) = pk;
+    } else {
 #pragma unroll
-    for (int k = 6; k >= 0; k--) {                       // and back, so a run closes in one sweep pair
-      const int lx = lx0 + k;
-      if (s_m[ly][lx] == 0 && s_m[ly][lx + 1] == 2) { s_m[ly][lx] = 2; grown |= 1u << k; changed = 1; }
+      for (int k = 0; k < 8; k++)
+        if (xb + k < W) map[(size_t)y * W + xb + k] = ((eb >> k) & 1u) ? 2 : (((wb >> k) & 1u) ? 0 : 1);
     }
-    if (!__syncthreads_or(changed)) break;
+    weak = wb != 0;
   }
+  weak = __syncthreads_or(weak);
+  if (t == 0) slice[A.o_weak + L.tile_base + blockIdx.x] = (uint8_t)(weak != 0);
+}
+
+// one whole-image pass of the closure across tile borders: a tile runs only while it still holds
+// weak pixels and (after the first pass) one of its 8 neighbours grew an edge in the pass before
+__global__ __launch_bounds__(256) void k_canny_close(EdgeArgs A)
+{
+  __shared__ __attribute__((aligned(8))) uint8_t s_m[CLOSE_TH + 2][M_STRIDE];
+  __shared__ unsigned long long s_E[CLOSE_TH + 2], s_W[CLOSE_TH + 2];
+  if (A.pass > 0 && A.flags[A.pass] == 0) return;      // the previous pass changed nothing: closed
+  const EdgeLevel& L = level_of(A, blockIdx.y);
+  const int W = L.W, H = L.H;
+  if ((int)blockIdx.x >= L.tiles_x * L.tiles_y) return;
+  const int ty = blockIdx.x / L.tiles_x, tx = blockIdx.x - ty * L.tiles_x;
+  uint8_t* slice = reinterpret_cast<uint8_t*>(A.work + (size_t)blockIdx.z * A.per_frame);
+  uint8_t* weak_flag = slice + A.o_weak + L.tile_base + blockIdx.x;
+  if (!*weak_flag) return;
+  if (A.pass > 0) {
+    const uint8_t* chg = slice + A.o_chg + (size_t)A.slot * A.n_tiles + L.tile_base;
+    int any = 0;
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        const int ny = ty + dy, nx = tx + dx;
+        if ((dy | dx) != 0 && ny >= 0 && ny < L.tiles_y && nx >= 0 && nx < L.tiles_x) any |= chg[ny * L.tiles_x + nx];
+      }
+    if (!any) return;
+  }
+  const int x0 = tx * CLOSE_TW, y0 = ty * CLOSE_TH;
+  uint8_t* map = slice + L.o_map;
+  const int t = threadIdx.x;
+  if ((W & 3) == 0) {
+    // interior columns as aligned dwords (x0 and W are multiples of 4), the two ring columns as bytes
+    for (int i = t; i < (CLOSE_TH + 2) * (CLOSE_TW / 4); i += 256) {
+      const int ly = i / (CLOSE_TW / 4), q = i - ly * (CLOSE_TW / 4);
+      const int y = y0 + ly - 1, x = x0 + 4 * q;
+      uint32_t v = 0x01010101u;
+      if (y >= 0 && y < H && x < W) v = *reinterpret_cast<const uint32_t*>(map + (size_t)y * W + x);
+      *reinterpret_cast<uint32_t*>(&s_m[ly][MCOL(1) + 4 * q]) = v;
+    }
+    for (int i = t; i < (CLOSE_TH + 2) * 2; i += 256) {
+      const int ly = i >> 1, lx = (i & 1) ? CLOSE_TW + 1 : 0;
+      const int y = y0 + ly - 1, x = x0 + lx - 1;
+      s_m[ly][MCOL(lx)] = (x >= 0 && x < W && y >= 0 && y < H) ? map[(size_t)y * W + x] : (uint8_t)1;
+    }
+  } else {
+    for (int i = t; i < (CLOSE_TH + 2) * (CLOSE_TW + 2); i += 256) {
+      const int ly = i / (CLOSE_TW + 2), lx = i - ly * (CLOSE_TW + 2);
+      const int y = y0 + ly - 1, x = x0 + lx - 1;
+      s_m[ly][MCOL(lx)] = (x >= 0 && x < W && y >= 0 && y < H) ? map[(size_t)y * W + x] : (uint8_t)1;
+    }
+  }
+  __syncthreads();
+  close_tile(s_m, s_E, s_W);
+  const int ly = (t >> 3) + 1, c0 = (t & 7) * 8;         // 8 consecutive interior pixels of one row
+  const unsigned eb = (unsigned)(s_E[ly] >> c0) & 0xffu;
   const int y = y0 + ly - 1;
-  if (grown) {
+  unsigned grown = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      if ((grown >> k) & 1u) map[(size_t)y * W + (x0 + lx0 - 1 + k)] = 2;   // interior pixels were weak, hence inside the image
-    A.flags[A.pass + 1] = 1;
+  for (int k = 0; k < 8; k++)
+    if (((eb >> k) & 1u) && s_m[ly][MCOL(c0 + 1 + k)] == 0) {   // was weak (hence inside the image), now an edge
+      map[(size_t)y * W + (x0 + c0 + k)] = 2;
+      grown = 1;
+    }
+  int weak = ((unsigned)(s_W[ly] >> c0) & 0xffu) != 0;
+  const int grew = __syncthreads_or(grown != 0);
+  weak = __syncthreads_or(weak);
+  if (t == 0) {
+    *weak_flag = (uint8_t)(weak != 0);
+    if (grew) {
+      slice[A.o_chg + (size_t)(A.slot + 1) * A.n_tiles + L.tile_base + blockIdx.x] = 1;
+      A.flags[A.pass + 1] = 1;
+    }
   }
 }
 
@@ -264,7 +403,7 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
   // extra area: [have flags of every frame | pass flags] (one memset), edgelet totals, then the frame slices
   EdgeArgs A{};
   size_t have_bytes = 0, o = 0;
-  int vw = g.w[0], vh = g.h[0], max_cells = 0, max_nms = 0, max_close = 0, max_words = 0;
+  int vw = g.w[0], vh = g.h[0], max_cells = 0, max_close = 0, max_words = 0, n_tiles = 0;
   for (int l = 0; l < n_levels; l++) {
     EdgeLevel& L = A.lv[l];
     L.W = g.w[l]; L.H = g.h[l];
@@ -282,10 +421,17 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
     L.o_res = o; o += al(sizeof(hso_edgelet) * (size_t)cells);
     L.o_out = o; o += al(sizeof(hso_edgelet) * (size_t)edgelet_cap);
     max_cells = cells > max_cells ? cells : max_cells;
-    const int nms = ((L.W + NMS_TW - 1) / NMS_TW) * ((L.H + NMS_TH - 1) / NMS_TH);
-    const int cl = ((L.W + CLOSE_TW - 1) / CLOSE_TW) * ((L.H + CLOSE_TH - 1) / CLOSE_TH);
-    max_nms = nms > max_nms ? nms : max_nms; max_close = cl > max_close ? cl : max_close;
+    L.tiles_x = (L.W + CLOSE_TW - 1) / CLOSE_TW; L.tiles_y = (L.H + CLOSE_TH - 1) / CLOSE_TH;
+    L.tile_base = n_tiles;
+    const int cl = L.tiles_x * L.tiles_y;
+    n_tiles += cl;
+    max_close = cl > max_close ? cl : max_close;
   }
+  // tile tables behind the maps: weak[n_tiles], chg[EDGE_ROUND + 1][n_tiles]
+  A.n_tiles = n_tiles;
+  A.o_weak = o; o += al((size_t)n_tiles);
+  A.o_chg = o; o += al((size_t)(EDGE_ROUND + 1) * n_tiles);
+  const size_t chg_bytes = (size_t)(EDGE_ROUND + 1) * n_tiles;
   // have flags live per frame in front of the slices: offsets above are relative to a frame's have block
   const size_t have_per_frame = have_bytes;
   const size_t slice = al(o + have_per_frame);
@@ -319,18 +465,25 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
   HSO_HIP_CHECK(ctx, hipMemset2DAsync(A.work + o, slice, 0, have_per_frame, (size_t)n_frames, ctx->stream));
   const dim3 blk(256);
   hipLaunchKernelGGL(k_cell_mark, dim3((max_words + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);
-  hipLaunchKernelGGL(k_canny_nms, dim3(max_nms, n_levels, n_frames), blk, 0, ctx->stream, A);
+  HSO_HIP_CHECK(ctx, hipMemset2DAsync(A.work + A.o_chg, slice, 0, chg_bytes, (size_t)n_frames, ctx->stream));
+  hipLaunchKernelGGL(k_canny_nms, dim3(max_close, n_levels, n_frames), blk, 0, ctx->stream, A);
   int pass = 0, flag = 1;
   int32_t* h_flags = edgelet_counts;   // scratch until the totals arrive (n_frames * n_levels >= 1 ints)
   while (flag) {
-    if (pass + 4 > EDGE_MAX_PASSES) return hso_fail(ctx, HSO_E_INVALID, "detect_candidates: edge closure did not converge");
-    for (int k = 0; k < 4; k++, pass++) {
-      A.pass = pass;
+    if (pass + EDGE_ROUND > EDGE_MAX_PASSES) return hso_fail(ctx, HSO_E_INVALID, "detect_candidates: edge closure did not converge");
+    if (pass > 0) {
+      // next round: the last pass's tile changes become slot 0, the other slots start clear
+      HSO_HIP_CHECK(ctx, hipMemcpy2DAsync(A.work + A.o_chg, slice, A.work + A.o_chg + (size_t)EDGE_ROUND * n_tiles, slice, (size_t)n_tiles,
+                                          (size_t)n_frames, hipMemcpyDeviceToDevice, ctx->stream));
+      HSO_HIP_CHECK(ctx, hipMemset2DAsync(A.work + A.o_chg + n_tiles, slice, 0, (size_t)EDGE_ROUND * n_tiles, (size_t)n_frames, ctx->stream));
+    }
+    for (int k = 0; k < EDGE_ROUND; k++, pass++) {
+      A.pass = pass; A.slot = k;
       hipLaunchKernelGGL(k_canny_close, dim3(max_close, n_levels, n_frames), blk, 0, ctx->stream, A);
     }
     HSO_HIP_CHECK(ctx, hipGetLastError());
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_flags, A.flags + pass, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (pass == 4) {
+    if (pass == EDGE_ROUND) {
       // optimistic: queue the rest behind the flag read; redone below in the rare case the closure needed more passes
       hipLaunchKernelGGL(k_edgelet_cells, dim3((max_cells + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);
       hipLaunchKernelGGL(k_edgelet_pack, dim3(1, n_levels, n_frames), blk, 0, ctx->stream, A);
@@ -338,7 +491,7 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     flag = h_flags[0];
   }
-  if (pass > 4) {
+  if (pass > EDGE_ROUND) {
     hipLaunchKernelGGL(k_edgelet_cells, dim3((max_cells + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);
     hipLaunchKernelGGL(k_edgelet_pack, dim3(1, n_levels, n_frames), blk, 0, ctx->stream, A);
   }
