@@ -21,7 +21,7 @@
 //   k_canny_nms      64x32 tile + 2 rings of packed (gx, gy) in LDS -> label bytes 0 weak / 1 none /
 //                    2 edge of the tile + 1 ring, closed inside the tile before they reach HBM
 //   k_canny_close    closure across tile borders; repeated
-//   k_edgelet_cells  one lane per grid index: arg-max of sqrtf(m) over its window
+//   k_edgelet_cells  eight lanes per grid index (one per window row): arg-max of sqrtf(m) over its window
 //   k_edgelet_pack   ordered compaction (grid-index order = the reference's push order)
 #include "hso_fast_plan.h"
 #include <vector>
@@ -326,41 +326,63 @@ __global__ __launch_bounds__(256) void k_canny_close(EdgeArgs A)
 
 __global__ __launch_bounds__(256) void k_edgelet_cells(EdgeArgs A)
 {
+  // 8 lanes per grid index, one per window row (the windows are at most 8 x 8); the row results
+  // merge by shuffles: larger gradient wins, equal gradients keep the earlier raster position —
+  // the serial scan's strict ">" rule
   const EdgeLevel& L = level_of(A, blockIdx.y);
-  const int index = blockIdx.x * 256 + threadIdx.x;
-  if (index >= L.gcols * L.grows) return;
+  const int index = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+  const bool live = index < L.gcols * L.grows;
   char* slice = A.work + (size_t)blockIdx.z * A.per_frame;
-  hso_edgelet* res = reinterpret_cast<hso_edgelet*>(slice + L.o_res);
-  hso_edgelet r;
-  r.x = -1; r.y = -1; r.gx = 0; r.gy = 0; r.grad = 0.0f;
   const uint8_t* have = reinterpret_cast<const uint8_t*>(slice + L.o_have);
   const int W = L.W, H = L.H, g = L.grid;
   const int border = 8, maxBorderX = W - border, maxBorderY = H - border;
-  int iniX = index % L.gcols * g;
-  int iniY = index / L.grows * g;                        // sic, feature_detection.cpp:770
-  if (!have[index] && !(iniX > maxBorderX || iniY > maxBorderY)) {
-    const int maxX = min(iniX + g, maxBorderX), maxY = min(iniY + g, maxBorderY);
-    iniX = max(iniX, border); iniY = max(iniY, border);
-    const uint8_t* map = reinterpret_cast<const uint8_t*>(slice + L.o_map);
-    const uint8_t* base = A.bases[blockIdx.z];
-    const int16_t* gxp = reinterpret_cast<const int16_t*>(base + L.gx_off);
-    const int16_t* gyp = reinterpret_cast<const int16_t*>(base + L.gy_off);
-    float maxGrad = 0.0f;
-    for (int y = iniY; y < maxY; ++y)
-      for (int x = iniX; x < maxX; ++x) {
-        const size_t o = (size_t)y * W + x;
-        if (map[o] != 2) continue;
-        const int sx = gxp[o], sy = gyp[o];
-        const float grad = sqrtf((float)(sx * sx + sy * sy));
-        if (grad > maxGrad) { r.x = (int16_t)x; r.y = (int16_t)y; r.gx = (int16_t)sx; r.gy = (int16_t)sy; r.grad = grad; maxGrad = grad; }
+  float grad_best = 0.0f;
+  int pos_best = 0x7fffffff, g_best = 0;                 // position y * W + x; packed (gx, gy)
+  if (live) {
+    int iniX = index % L.gcols * g;
+    int iniY = index / L.grows * g;                      // sic, feature_detection.cpp:770
+    if (!have[index] && !(iniX > maxBorderX || iniY > maxBorderY)) {
+      const int maxX = min(iniX + g, maxBorderX), maxY = min(iniY + g, maxBorderY);
+      iniX = max(iniX, border); iniY = max(iniY, border);
+      const int y = iniY + sub;
+      if (y < maxY) {
+        const uint8_t* map = reinterpret_cast<const uint8_t*>(slice + L.o_map);
+        const uint8_t* base = A.bases[blockIdx.z];
+        const int16_t* gxp = reinterpret_cast<const int16_t*>(base + L.gx_off);
+        const int16_t* gyp = reinterpret_cast<const int16_t*>(base + L.gy_off);
+        for (int x = iniX; x < maxX; ++x) {
+          const size_t o = (size_t)y * W + x;
+          if (map[o] != 2) continue;
+          const int sx = gxp[o], sy = gyp[o];
+          const float grad = sqrtf((float)(sx * sx + sy * sy));
+          if (grad > grad_best) { grad_best = grad; pos_best = (int)o; g_best = (sx & 0xffff) | (sy << 16); }
+        }
       }
+    }
   }
-  res[index] = r;
+#pragma unroll
+  for (int d = 1; d < 8; d <<= 1) {
+    const float og = __shfl_xor(grad_best, d);
+    const int op = __shfl_xor(pos_best, d), ogg = __shfl_xor(g_best, d);
+    if (og > grad_best || (og == grad_best && op < pos_best)) { grad_best = og; pos_best = op; g_best = ogg; }
+  }
+  if (live && sub == 0) {
+    hso_edgelet r;
+    r.x = -1; r.y = -1; r.gx = 0; r.gy = 0; r.grad = 0.0f;
+    if (grad_best > 0.0f) {
+      const int y = pos_best / W;
+      r.x = (int16_t)(pos_best - y * W); r.y = (int16_t)y;
+      r.gx = (int16_t)(g_best & 0xffff); r.gy = (int16_t)(g_best >> 16);
+      r.grad = grad_best;
+    }
+    reinterpret_cast<hso_edgelet*>(slice + L.o_res)[index] = r;
+  }
 }
 
-__global__ __launch_bounds__(256) void k_edgelet_pack(EdgeArgs A)
+#define PACK_THREADS 1024
+__global__ __launch_bounds__(PACK_THREADS) void k_edgelet_pack(EdgeArgs A)
 {
-  __shared__ int s_w[4];
+  __shared__ int s_w[PACK_THREADS / 64];
   const EdgeLevel& L = level_of(A, blockIdx.y);
   char* slice = A.work + (size_t)blockIdx.z * A.per_frame;
   const hso_edgelet* res = reinterpret_cast<const hso_edgelet*>(slice + L.o_res);
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(256) void k_edgelet_pack(EdgeArgs A)
   const int cells = L.gcols * L.grows, cap = A.cap;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   int base = 0;
-  for (int c0 = 0; c0 < cells; c0 += 256) {
+  for (int c0 = 0; c0 < cells; c0 += PACK_THREADS) {
     const int i = c0 + t;
     hso_edgelet r;
     r.x = -1;
@@ -377,11 +399,12 @@ __global__ __launch_bounds__(256) void k_edgelet_pack(EdgeArgs A)
     const unsigned long long m = __ballot(set);
     if (lane == 0) s_w[wv] = __popcll(m);
     __syncthreads();
-    int before = base;
-    for (int k = 0; k < wv; k++) before += s_w[k];
+    int before = base, total = 0;
+#pragma unroll
+    for (int k = 0; k < PACK_THREADS / 64; k++) { const int v = s_w[k]; before += k < wv ? v : 0; total += v; }
     const int idx = before + __popcll(m & ((1ull << lane) - 1ull));
     if (set && idx < cap) out[idx] = r;
-    base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    base += total;
     __syncthreads();
   }
   if (t == 0) A.totals[(size_t)blockIdx.z * A.n_levels + blockIdx.y] = base;
@@ -485,15 +508,15 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_flags, A.flags + pass, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if (pass == EDGE_ROUND) {
       // optimistic: queue the rest behind the flag read; redone below in the rare case the closure needed more passes
-      hipLaunchKernelGGL(k_edgelet_cells, dim3((max_cells + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);
-      hipLaunchKernelGGL(k_edgelet_pack, dim3(1, n_levels, n_frames), blk, 0, ctx->stream, A);
+      hipLaunchKernelGGL(k_edgelet_cells, dim3((max_cells * 8 + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);
+      hipLaunchKernelGGL(k_edgelet_pack, dim3(1, n_levels, n_frames), dim3(PACK_THREADS), 0, ctx->stream, A);
     }
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     flag = h_flags[0];
   }
   if (pass > EDGE_ROUND) {
-    hipLaunchKernelGGL(k_edgelet_cells, dim3((max_cells + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);
-    hipLaunchKernelGGL(k_edgelet_pack, dim3(1, n_levels, n_frames), blk, 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_edgelet_cells, dim3((max_cells * 8 + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_edgelet_pack, dim3(1, n_levels, n_frames), dim3(PACK_THREADS), 0, ctx->stream, A);
   }
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(edgelet_counts, A.totals, sizeof(int) * (size_t)n_frames * n_levels, hipMemcpyDeviceToHost, ctx->stream));
