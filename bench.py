@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=4096, help="frame pairs per GPU per step (16 GB of resident frames at 4096)")
     ap.add_argument("--feats", type=int, default=2000)
     ap.add_argument("--pairs", type=int, default=8, help="distinct synthetic pairs rendered per rank")
     ap.add_argument("--inverse", type=int, default=0)

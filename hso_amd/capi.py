@@ -174,6 +174,10 @@ class SeedOut(C.Structure):
                 ("px_cur", C.c_double * 2), ("z", C.c_double), ("zmncc_best", C.c_float), ("zmncc_second", C.c_float)]
 
 
+class SeedFrame(C.Structure):
+    _fields_ = [("frame_id", C.c_int64), ("T_f_w", SE3), ("exposure_time", C.c_double)]
+
+
 CORNER_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("score", "<i4"), ("response", "<f4")])   # hso_corner
 assert CORNER_DTYPE.itemsize == 12
 EDGELET_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("gx", "<i2"), ("gy", "<i2"), ("grad", "<f4")])   # hso_edgelet
@@ -271,6 +275,7 @@ def load():
     lib.hso_gpu_pose_optimize_batch.argtypes = [vp, P(Camera), P(PoseJob), i32, P(PoseResult), vp]
     lib.hso_gpu_ba_linearize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double] + [vp] * 8
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
+    lib.hso_gpu_seed_observe_multi.argtypes = [vp, P(Camera), P(SeedFrame), i32, vp, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
                                           P(AlignOut)]
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
@@ -292,7 +297,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
-    "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match",
+    "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
 ]
 
 
@@ -501,6 +506,19 @@ class Context:
         self._check(self.lib.hso_gpu_seed_observe(self.h, C.byref(cam), cur_frame_id, C.byref(cur_T_f_w), cur_exposure,
                                                   px_error_angle, arr, len(seeds), out), "seed_observe")
         return list(out)
+
+    def seed_observe_multi(self, cam, frames, seed_frame, px_error_angle, seeds, as_list=True):
+        """frames: list of (frame_id, SE3 T_f_w, exposure_time); seed i is observed in frames[seed_frame[i]]."""
+        fr = (SeedFrame * len(frames))()
+        for k, (fid, T, expo) in enumerate(frames):
+            fr[k].frame_id, fr[k].T_f_w, fr[k].exposure_time = fid, T, expo
+        n = len(seeds)
+        arr = seeds if isinstance(seeds, C.Array) else (Seed * n)(*seeds)
+        idx = np.ascontiguousarray(seed_frame, np.int32)
+        out = (SeedOut * max(n, 1))()
+        self._check(self.lib.hso_gpu_seed_observe_multi(self.h, C.byref(cam), fr, len(frames), _ptr(idx), px_error_angle, arr, n, out),
+                    "seed_observe_multi")
+        return list(out)[:n] if as_list else out
 
     # -- FAST-9 corner candidates
     def fast_detect(self, frame_id, n_levels=3, threshold=20, border=8, cap=20000):

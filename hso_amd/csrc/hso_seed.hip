@@ -23,16 +23,24 @@ using namespace hso_dev;
 
 #define SEED_WAVES_PER_BLOCK 4
 
+// the active frame a seed is observed in (seeds of many frames / sequences share a launch)
+struct SeedFrameDev {
+  hso_se3 T_f_w;
+  double exposure;
+};
+
 struct SeedConsts {
   hso_camera cam;
   PyrGeom g;
-  const uint8_t* cur_base;
-  hso_se3 cur_T_f_w;
-  double cur_exposure, px_error_angle;
+  const SeedFrameDev* frames;
+  double px_error_angle;
 };
 
 struct SeedDev {
   const uint8_t* ref_base;
+  const uint8_t* cur_base;
+  int32_t frame;             // index into SeedConsts::frames
+  int32_t pad_;
   hso_seed s;
 };
 
@@ -150,7 +158,9 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
   o.mu = S.mu; o.sigma2 = S.sigma2; o.b = S.b; o.is_valid = 1;
 
   // ---- visibility in the active frame (depth_filter.cpp:590-606)
-  const Se3 Tcw = se3_from(C.cur_T_f_w), Trw = se3_from(S.T_ref_w);
+  const SeedFrameDev& F = C.frames[SD.frame];
+  const uint8_t* const cur_base = SD.cur_base;
+  const Se3 Tcw = se3_from(F.T_f_w), Trw = se3_from(S.T_ref_w);
   const Se3 T_ref_cur = se3_mul(Trw, se3_inverse(Tcw));
   {
     const Se3 Tinv = se3_inverse(T_ref_cur);
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     int sl = 0;
     { double D = A00 * A11 - A10 * A01; while (D > 3.0 && sl < HSO_N_SOBEL_LEVELS - 1) { sl += 1; D *= 0.25; } }
     o.search_level = sl;
-    const float exposure_rat = (float)(C.cur_exposure / S.ref_exposure);
+    const float exposure_rat = (float)(F.exposure / S.ref_exposure);
     {
       const double det = A00 * A11 - A10 * A01;
       const double invdet = 1.0 / det;
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
 
     // ---- march along the epipolar line, ZMNCC per step (:906-960)
     const int cols = C.g.w[sl], rows = C.g.h[sl];
-    const uint8_t* cur = C.cur_base + C.g.off[sl];
+    const uint8_t* cur = cur_base + C.g.off[sl];
     const float hostMean = wave_sum_all(ref_px) / 64;
     const float hdev = ref_px - hostMean;
     const float d1 = wave_sum_all(hdev * hdev);
@@ -307,8 +317,8 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
       result = s_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, dc0, dc1, ps0, ps1, samp, sampled);
       if (result) {
         // Matcher::checkNormal(cur_frame, search_level_, px, dir_cur, 0.7), :406-440
-        const int16_t* gx = reinterpret_cast<const int16_t*>(C.cur_base + C.g.sob_off[sl][0]);
-        const int16_t* gy = reinterpret_cast<const int16_t*>(C.cur_base + C.g.sob_off[sl][1]);
+        const int16_t* gx = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][0]);
+        const int16_t* gy = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][1]);
         const float uf = (float)ps0, vf = (float)ps1;
         const int ui = (int)floorf((float)ps0), vi = (int)floorf((float)ps1);
         const float sx = uf - (float)ui, sy = vf - (float)vi;
@@ -382,29 +392,47 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
   if (lane == 0) outs[sid] = o;
 }
 
-extern "C" int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* cur_T_f_w,
-                                    double cur_exposure, double px_error_angle, const hso_seed* seeds, int n_seeds,
-                                    hso_seed_out* out)
+extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed_frame* frames, int n_frames,
+                                          const int32_t* seed_frame, double px_error_angle, const hso_seed* seeds, int n_seeds,
+                                          hso_seed_out* out)
 {
   if (!ctx) return HSO_E_INVALID;
-  if (!cam || !cur_T_f_w || n_seeds < 0 || (n_seeds > 0 && (!seeds || !out))) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: bad argument");
+  if (!cam || n_frames < 0 || n_seeds < 0 || (n_seeds > 0 && (!seeds || !out || !frames || !seed_frame || n_frames == 0)))
+    return hso_fail(ctx, HSO_E_INVALID, "seed_observe: bad argument");
   if (n_seeds == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  auto itc = ctx->frames.find(cur_frame_id);
-  if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_observe: active frame not resident");
-  const PyrGeom g = itc->second.g;
+  PyrGeom g{};
+  std::vector<const uint8_t*> cur_base(n_frames);
+  std::vector<SeedFrameDev> hf(n_frames);
+  for (int k = 0; k < n_frames; k++) {
+    auto itc = ctx->frames.find(frames[k].frame_id);
+    if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_observe: active frame not resident");
+    if (k == 0) g = itc->second.g;
+    else if (itc->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
+    cur_base[k] = itc->second.base;
+    hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = frames[k].exposure_time;
+  }
   if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: camera size differs from the frame size");
   std::vector<SeedDev> h(n_seeds);
+  int64_t last_id = -1;
+  const uint8_t* last_base = nullptr;
   for (int i = 0; i < n_seeds; i++) {
-    auto itr = ctx->frames.find(seeds[i].ref_frame_id);
-    if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_observe: seed host frame not resident");
-    if (itr->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
+    if (seed_frame[i] < 0 || seed_frame[i] >= n_frames) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: seed_frame out of range");
+    if (i == 0 || seeds[i].ref_frame_id != last_id) {
+      auto itr = ctx->frames.find(seeds[i].ref_frame_id);
+      if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_observe: seed host frame not resident");
+      if (itr->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
+      last_id = seeds[i].ref_frame_id; last_base = itr->second.base;
+    }
     if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: bad level");
-    h[i].ref_base = itr->second.base;
+    h[i].ref_base = last_base;
+    h[i].cur_base = cur_base[seed_frame[i]];
+    h[i].frame = seed_frame[i]; h[i].pad_ = 0;
     h[i].s = seeds[i];
   }
-  const size_t b_in = ((size_t)n_seeds * sizeof(SeedDev) + 255) & ~size_t(255);
-  const size_t need = b_in + (size_t)n_seeds * sizeof(hso_seed_out);
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_in = al((size_t)n_seeds * sizeof(SeedDev)), b_out = al((size_t)n_seeds * sizeof(hso_seed_out));
+  const size_t need = b_in + b_out + al((size_t)n_frames * sizeof(SeedFrameDev));
   if (ctx->batch_cap < need) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -414,14 +442,28 @@ extern "C" int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int
   }
   SeedDev* d_in = reinterpret_cast<SeedDev*>(ctx->d_batch);
   hso_seed_out* d_out = reinterpret_cast<hso_seed_out*>(ctx->d_batch + b_in);
+  SeedFrameDev* d_fr = reinterpret_cast<SeedFrameDev*>(ctx->d_batch + b_in + b_out);
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h.data(), (size_t)n_seeds * sizeof(SeedDev), hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_fr, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
-  C.cam = *cam; C.g = g; C.cur_base = itc->second.base; C.cur_T_f_w = *cur_T_f_w;
-  C.cur_exposure = cur_exposure; C.px_error_angle = px_error_angle;
+  C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle;
   const int blocks = (n_seeds + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK;
   hipLaunchKernelGGL(k_seed_observe, dim3(blocks), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, d_in, n_seeds, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_seeds * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
+}
+
+extern "C" int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* cur_T_f_w,
+                                    double cur_exposure, double px_error_angle, const hso_seed* seeds, int n_seeds,
+                                    hso_seed_out* out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!cam || !cur_T_f_w || n_seeds < 0 || (n_seeds > 0 && (!seeds || !out))) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: bad argument");
+  if (n_seeds == 0) return HSO_OK;
+  hso_seed_frame f;
+  f.frame_id = cur_frame_id; f.T_f_w = *cur_T_f_w; f.exposure_time = cur_exposure;
+  const std::vector<int32_t> zero((size_t)n_seeds, 0);
+  return hso_gpu_seed_observe_multi(ctx, cam, &f, 1, zero.data(), px_error_angle, seeds, n_seeds, out);
 }

@@ -79,6 +79,17 @@ def main():
     dt = timed(lambda: ctx.align_multi(cam, cur_ids, big, as_list=False), max(args.reps // 4, 2))
     out.append(dict(stage="align_multi x128 frames", units="candidates", n=len(cur_ids), ms_per_call=dt * 1e3,
                     units_per_s=len(cur_ids) / dt))
+    # the seeds of 128 sequences observed in their own active frames in one launch
+    big_s = (capi.Seed * (nseq * len(seeds)))()
+    s_frame = np.repeat(np.arange(nseq, dtype=np.int32), len(seeds))
+    for q in range(nseq):
+        for i, sd in enumerate(seeds):
+            C.memmove(C.byref(big_s[q * len(seeds) + i]), C.byref(sd), C.sizeof(capi.Seed))
+            big_s[q * len(seeds) + i].ref_frame_id = 1000 + 2 * q
+    act_frames = [(1001 + 2 * q, T_cur, 1.05) for q in range(nseq)]
+    dt = timed(lambda: ctx.seed_observe_multi(cam, act_frames, s_frame, pea, big_s, as_list=False), max(args.reps // 4, 2))
+    out.append(dict(stage="seed_observe_multi x128 frames", units="seeds", n=len(s_frame), ms_per_call=dt * 1e3,
+                    units_per_s=len(s_frame) / dt))
     dt = timed(lambda: ctx.fast_detect_batch(bid, 3, 20, 8, 0), max(args.reps // 2, 2))
     out.append(dict(stage="fast_detect_batch x256 frames (levels 0-2, counts only)", units="pixels", n=npx * nb,
                     ms_per_call=dt * 1e3, units_per_s=npx * nb / dt))

@@ -440,6 +440,17 @@ int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_fr
                          double cur_exposure, double px_error_angle, const hso_seed* seeds, int n_seeds,
                          hso_seed_out* out);
 
+/* The same for the active frames of many sequences (or the frame queue of one, :208-246) in one
+ * launch: seed i is observed in frames[seed_frame[i]]. */
+typedef struct hso_seed_frame {
+  int64_t frame_id;
+  hso_se3 T_f_w;
+  double exposure_time;
+} hso_seed_frame;
+int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed_frame* frames, int n_frames,
+                               const int32_t* seed_frame, double px_error_angle, const hso_seed* seeds, int n_seeds,
+                               hso_seed_out* out);
+
 /* ---- DepthFilter::activatePoint + seedOptimizer, src/depth_filter.cpp:729-1073 ---- */
 
 #define HSO_ACTIVATE_MAX_TARGETS 64

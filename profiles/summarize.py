@@ -45,7 +45,13 @@ def main():
                 "`python bench.py --steps 3 --warmup 1 --cpu-frames 0` (profiles/collect_r1.sh). Raw counter values: the "
                 "gfx950 x2 read-side correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streams only; this "
                 "kernel's global reads are 4-8 B/lane, so the raw value is a lower bound and 2x the read part an upper bound.")
-        json.dump({"round": 1, "kernel": k, "batch": 512, "feats": 2000,
+        batch = 512
+        try:   # the batch the PMC runs used: the bench line in their log
+            line = [l for l in open(os.path.join(SRC, "bench_fetch.log")) if l.startswith("{")][-1]
+            batch = json.loads(line)["config"]["frames_per_gpu_per_step"]
+        except (OSError, IndexError, KeyError, ValueError):
+            pass
+        json.dump({"round": 1, "kernel": k, "batch": batch, "feats": 2000,
                    "fetch_size_kb": per.get(("FETCH_SIZE", k)), "write_size_kb": per.get(("WRITE_SIZE", k)), "note": note},
                   open(os.path.join(OUT, "pmc_k_track.json"), "w"), indent=1)
     print("wrote summaries from", SRC)

@@ -150,3 +150,34 @@ def test_seed_observe_errors(cam, gpu_ctx, seed_scene):
     with pytest.raises(RuntimeError):
         gpu_ctx.seed_observe(cam, 99999, T_cur, 1.0, PX_ERROR_ANGLE, seeds[:2])   # active frame not resident
     assert gpu_ctx.seed_observe(cam, 99999, T_cur, 1.0, PX_ERROR_ANGLE, []) == []
+
+
+@pytest.mark.gpu
+def test_seed_observe_multi_equals_per_frame_calls(cam, gpu_ctx, seed_scene):
+    """Seeds of several active frames (different poses / exposures) in one launch: every seed gets
+    exactly the result of the single-frame call for its frame."""
+    import ctypes as C
+    d, rp, cp, sob, seeds, T_cur, feats = seed_scene
+    d2 = synth.config2_pair(200, trans_frac=0.05, seed=777)
+    gx2, gy2 = np.gradient(d2["ref"].astype(np.float64))[::-1]
+    seeds2, T_cur2, _ = synth.seeds_for_pair(d2, 150, 9111, seed=5)
+    gpu_ctx.frame_upload(9101, d["ref"]); gpu_ctx.frame_upload(9102, d["cur"])
+    gpu_ctx.frame_upload(9111, d2["ref"]); gpu_ctx.frame_upload(9112, d2["cur"])
+    try:
+        a = gpu_ctx.seed_observe(cam, 9102, T_cur, 1.05, PX_ERROR_ANGLE, seeds)
+        b = gpu_ctx.seed_observe(cam, 9112, T_cur2, 0.93, PX_ERROR_ANGLE, seeds2)
+        # interleave the two frames' seeds
+        order = [(0, i) for i in range(len(seeds))] + [(1, i) for i in range(len(seeds2))]
+        rng = np.random.default_rng(1)
+        order = [order[k] for k in rng.permutation(len(order))]
+        mixed = [(seeds, seeds2)[f][i] for f, i in order]
+        got = gpu_ctx.seed_observe_multi(cam, [(9102, T_cur, 1.05), (9112, T_cur2, 0.93)], [f for f, _ in order], PX_ERROR_ANGLE, mixed)
+        for (f, i), g in zip(order, got):
+            w = (a, b)[f][i]
+            assert bytes(C.string_at(C.addressof(g), C.sizeof(g))) == bytes(C.string_at(C.addressof(w), C.sizeof(w))), (f, i)
+        assert sum(o.result == 1 for o in b) > 60
+        with pytest.raises(RuntimeError, match="out of range"):
+            gpu_ctx.seed_observe_multi(cam, [(9102, T_cur, 1.05)], [0, 1], PX_ERROR_ANGLE, mixed[:2])
+    finally:
+        for i in (9101, 9102, 9111, 9112):
+            gpu_ctx.frame_release(i)
