@@ -281,6 +281,7 @@ def load():
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
     lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
     lib.hso_gpu_detect_candidates.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
+    lib.hso_gpu_detect_candidates_init.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
     lib.hso_gpu_select_octree.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
     lib.hso_gpu_reproject_match.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, i32, vp, i32, vp, i32, vp, i32, i32, i32,
                                             vp, vp]
@@ -298,6 +299,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
+    "hso_gpu_detect_candidates_init",
 ]
 
 
@@ -550,6 +552,18 @@ class Context:
         self._check(self.lib.hso_gpu_detect_candidates(self.h, ids, n, n_levels, min_thresh, _ptr(co), corner_cap, _ptr(cc),
                                                        _ptr(eo), edgelet_cap, _ptr(ec)), "detect_candidates")
         return co, cc, eo, ec
+
+    def detect_candidates_init(self, frame_ids, n_levels=3, min_thresh=20, corner_cap=8192, fill_cap=4800):
+        """fastDetectMT + fillingHole (the initialisation branch of FeatureExtractor::detect).
+        Returns (corners[n, L, cap], corner_counts[n, L], fill[n, cap], fill_counts[n])."""
+        n = len(frame_ids)
+        ids = (C.c_int64 * n)(*frame_ids)
+        co = np.zeros((n, n_levels, corner_cap), CORNER_DTYPE) if corner_cap > 0 else None
+        fo = np.zeros((n, fill_cap), CORNER_DTYPE) if fill_cap > 0 else None
+        cc, fc = np.zeros((n, n_levels), np.int32), np.zeros(n, np.int32)
+        self._check(self.lib.hso_gpu_detect_candidates_init(self.h, ids, n, n_levels, min_thresh, _ptr(co), corner_cap, _ptr(cc),
+                                                            _ptr(fo), fill_cap, _ptr(fc)), "detect_candidates_init")
+        return co, cc, fo, fc
 
     def seed_activate(self, cam, seeds, targets_per_seed, n_mean_converge_frame=6, want_matches=False):
         """targets_per_seed: one list of ActivateTarget per seed (optFrames_P + optFrames_A order)."""

@@ -533,3 +533,149 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The initialisation branch of FeatureExtractor::detect (reference src/feature_detection.cpp:439-442):
+// fastDetectMT as above, then fillingHole on level 0 (:1125-1154) — FAST-12 at barrier
+// max(0.6 * minThresh, 6), non-maximum suppression, border, and a survivor is kept only when its
+// grid index is still free, occupying it (first come in raster order).  On the device: the FAST-12
+// survivors are emitted in raster order, an atomicMin per free grid index finds the first of them,
+// and an ordered compaction keeps exactly those.
+struct FillArgs {
+  const hso_corner* list; size_t list_stride;     // FAST-12 survivors of level 0 per frame (bytes between frames)
+  const int* totals;                              // [n_frames] survivors found
+  int list_cap;
+  char* work; size_t per_frame;                   // edgelet-style slices: have flags, first[], out[]
+  size_t o_have, o_first, o_out;
+  int grid, gcols, grows, cells, cap;
+  int* out_totals;                                // [n_frames]
+};
+
+__global__ __launch_bounds__(256) void k_fill_first(FillArgs A)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = min(A.totals[blockIdx.y], A.list_cap);
+  if (i >= n) return;
+  const hso_corner c = reinterpret_cast<const hso_corner*>(reinterpret_cast<const char*>(A.list) + (size_t)blockIdx.y * A.list_stride)[i];
+  char* slice = A.work + (size_t)blockIdx.y * A.per_frame;
+  const int idx = c.y / A.grid * A.gcols + c.x / A.grows;                       // getCellIndex
+  if (!reinterpret_cast<const uint8_t*>(slice + A.o_have)[idx]) atomicMin(reinterpret_cast<int*>(slice + A.o_first) + idx, i);
+}
+
+__global__ __launch_bounds__(PACK_THREADS) void k_fill_pack(FillArgs A)
+{
+  __shared__ int s_w[PACK_THREADS / 64];
+  const int n = min(A.totals[blockIdx.x], A.list_cap);
+  const hso_corner* list = reinterpret_cast<const hso_corner*>(reinterpret_cast<const char*>(A.list) + (size_t)blockIdx.x * A.list_stride);
+  char* slice = A.work + (size_t)blockIdx.x * A.per_frame;
+  const uint8_t* have = reinterpret_cast<const uint8_t*>(slice + A.o_have);
+  const int* first = reinterpret_cast<const int*>(slice + A.o_first);
+  hso_corner* out = reinterpret_cast<hso_corner*>(slice + A.o_out);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int base = 0;
+  for (int c0 = 0; c0 < n; c0 += PACK_THREADS) {
+    const int i = c0 + t;
+    hso_corner c;
+    bool keep = false;
+    if (i < n) {
+      c = list[i];
+      const int idx = c.y / A.grid * A.gcols + c.x / A.grows;
+      keep = !have[idx] && first[idx] == i;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_w[wv] = __popcll(m);
+    __syncthreads();
+    int before = base, total = 0;
+#pragma unroll
+    for (int k = 0; k < PACK_THREADS / 64; k++) { const int v = s_w[k]; before += k < wv ? v : 0; total += v; }
+    const int idx_out = before + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && idx_out < A.cap) out[idx_out] = c;
+    base += total;
+    __syncthreads();
+  }
+  if (t == 0) A.out_totals[blockIdx.x] = base;
+}
+
+extern "C" int hso_gpu_detect_candidates_init(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int min_thresh,
+                                              hso_corner* corners, int corner_cap, int32_t* corner_counts,
+                                              hso_corner* fill, int fill_cap, int32_t* fill_counts)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!frame_ids || n_frames < 0 || n_levels < 1 || n_levels > EDGE_LEVELS || min_thresh < 0 || min_thresh > 255 || corner_cap < 0 ||
+      fill_cap < 0 || !corner_counts || !fill_counts || (corner_cap > 0 && !corners) || (fill_cap > 0 && !fill))
+    return hso_fail(ctx, HSO_E_INVALID, "detect_candidates_init: bad argument");
+  if (n_frames == 0) return HSO_OK;
+  auto it0 = ctx->frames.find(frame_ids[0]);
+  if (it0 == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "detect_candidates_init: frame not resident");
+  const PyrGeom g = it0->second.g;
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  EdgeArgs A{};
+  size_t o = 0;
+  int vw = g.w[0], vh = g.h[0], max_words = 0;
+  for (int l = 0; l < n_levels; l++) {
+    EdgeLevel& L = A.lv[l];
+    L.W = g.w[l]; L.H = g.h[l];
+    L.grid = 8 / (1 << l);
+    L.gcols = (vw + L.grid - 1) / L.grid; L.grows = (vh + L.grid - 1) / L.grid;
+    vw /= 2; vh /= 2;
+    if ((L.H - 1) / L.grid * L.gcols + (L.W - 1) / L.grows >= L.gcols * L.grows)
+      return hso_fail(ctx, HSO_E_INVALID, "detect_candidates_init: grid index out of range for this image size");
+    L.o_have = o; o += al((size_t)L.gcols * L.grows);
+  }
+  const size_t have_bytes = o;
+  const int cells0 = A.lv[0].gcols * A.lv[0].grows;
+  const size_t o_first = o; o += al(sizeof(int) * (size_t)cells0);
+  const size_t o_fout = o; o += al(sizeof(hso_corner) * (size_t)fill_cap);
+  const size_t slice = o;
+  // FAST-12 survivors of level 0: at most one per 2x2 pixels survives a 3x3 non-maximum suppression
+  const int cap12 = (g.w[0] / 2 + 1) * (g.h[0] / 2 + 1);
+  FastPlan P12;
+  const size_t bytes12 = hso_fast_plan(g, n_frames, 1, cap12, &P12);
+  const size_t o_p12 = 0, o_slices = al(bytes12), o_ftot = o_slices + slice * (size_t)n_frames;
+  const size_t extra = o_ftot + al(sizeof(int) * (size_t)n_frames);
+
+  FastPlan P;
+  const int rc = hso_fast_enqueue(ctx, frame_ids, n_frames, n_levels, min_thresh, 8, corner_cap, extra, &P);
+  if (rc != HSO_OK) return rc;
+  char* x = P.d + P.o_extra;
+  for (int l = 0; l < n_levels; l++) {
+    A.lv[l].o_fmask = P.o_mask[l]; A.lv[l].wpr = P.wpr[l];
+    const int words = A.lv[l].H * P.wpr[l];
+    max_words = words > max_words ? words : max_words;
+  }
+  const uint8_t* const* d_bases = reinterpret_cast<const uint8_t* const*>(P.d + P.o_tab);
+  A.bases = d_bases;
+  A.fast_work = P.d; A.fast_per_frame = P.per_frame;
+  A.work = x + o_slices; A.per_frame = slice;
+  A.n_levels = n_levels;
+  HSO_HIP_CHECK(ctx, hipMemset2DAsync(A.work, slice, 0, have_bytes, (size_t)n_frames, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemset2DAsync(A.work + o_first, slice, 0x7f, sizeof(int) * (size_t)cells0, (size_t)n_frames, ctx->stream));
+  hipLaunchKernelGGL(k_cell_mark, dim3((max_words + 255) / 256, n_levels, n_frames), dim3(256), 0, ctx->stream, A);
+  // const short fastThresh = 0.6*minThresh_ > 6 ? 0.6*minThresh_ : 6, :1129
+  const int thr12 = (int)(short)(0.6 * min_thresh > 6 ? 0.6 * min_thresh : 6);
+  P12.d = x + o_p12;
+  const int rc12 = hso_fast_launch(ctx, P12, d_bases, thr12, 8, 12);
+  if (rc12 != HSO_OK) return rc12;
+  FillArgs F;
+  F.list = reinterpret_cast<const hso_corner*>(P12.d + P12.o_out[0]); F.list_stride = P12.per_frame;
+  F.totals = reinterpret_cast<const int*>(P12.d + P12.o_tot);
+  F.list_cap = cap12;
+  F.work = A.work; F.per_frame = slice;
+  F.o_have = A.lv[0].o_have; F.o_first = o_first; F.o_out = o_fout;
+  F.grid = A.lv[0].grid; F.gcols = A.lv[0].gcols; F.grows = A.lv[0].grows; F.cells = cells0; F.cap = fill_cap;
+  F.out_totals = reinterpret_cast<int*>(x + o_ftot);
+  hipLaunchKernelGGL(k_fill_first, dim3((cap12 + 255) / 256, n_frames), dim3(256), 0, ctx->stream, F);
+  hipLaunchKernelGGL(k_fill_pack, dim3(n_frames), dim3(PACK_THREADS), 0, ctx->stream, F);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(fill_counts, F.out_totals, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  const int rc2 = hso_fast_collect(ctx, P, corners, corner_counts);     // synchronises
+  if (rc2 != HSO_OK) return rc2;
+  for (int i = 0; i < n_frames && fill_cap > 0; i++) {
+    const int n = fill_counts[i] < fill_cap ? fill_counts[i] : fill_cap;
+    if (n > 0)
+      HSO_HIP_CHECK(ctx, hipMemcpyAsync(fill + (size_t)i * fill_cap, A.work + (size_t)i * slice + o_fout, sizeof(hso_corner) * (size_t)n,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}

@@ -29,10 +29,12 @@
 #include "hso_fast_plan.h"
 #include <vector>
 
-__device__ __forceinline__ int fast9_strength(const int d[16])
+template <int ARC>
+__device__ __forceinline__ int fast_strength(const int d[16])
 {
-  // S = max over starts s of min_{k<9} (+-d[s+k]); sliding minimum by doubling.  Both polarities
+  // S = max over starts s of min_{k<ARC} (+-d[s+k]); sliding minimum by doubling.  Both polarities
   // ride in the two 16-bit halves of one register (v_pk_min_i16 / v_pk_max_i16): |d| <= 255.
+  static_assert(ARC == 9 || ARC == 12, "FAST-9 (fastDetect) and FAST-12 (fillingHole)");
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   s16x2 a[16], m2[16], m4[16], m8[16];
 #pragma unroll
@@ -45,7 +47,8 @@ __device__ __forceinline__ int fast9_strength(const int d[16])
   for (int i = 0; i < 16; i++) m8[i] = __builtin_elementwise_min(m4[i], m4[(i + 4) & 15]);
   s16x2 best = {0, 0};
 #pragma unroll
-  for (int i = 0; i < 16; i++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[i], a[(i + 8) & 15]));
+  for (int i = 0; i < 16; i++)
+    best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[i], ARC == 9 ? a[(i + 8) & 15] : m4[(i + 8) & 15]));
   return max((int)best.x, (int)best.y);
 }
 
@@ -66,6 +69,7 @@ struct FastArgs {
   int n_levels, level;
 };
 
+template <int ARC>
 __global__ __launch_bounds__(256) void k_fast_mask(FastArgs A)
 {
   __shared__ uint8_t s_src[FAST_TH + 8][FAST_TW + 8];
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void k_fast_mask(FastArgs A)
       int d[16];
 #pragma unroll
       for (int k = 0; k < 16; k++) d[k] = (int)s_src[cy + c_circle[k][1]][cx + c_circle[k][0]] - p;
-      const int sb = fast9_strength(d) - 1;
+      const int sb = fast_strength<ARC>(d) - 1;
       if (sb >= threshold) sc = (short)sb;
     }
     s_sc[ly][lx] = sc;
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(256) void k_fast_scan(FastArgs A)
   for (int i = t * per; i < min(H, (t + 1) * per); i++) { row_off[i] = acc; acc += row_count[i]; }
 }
 
+template <int ARC>
 __global__ __launch_bounds__(256) void k_fast_emit(FastArgs A)
 {
   const uint8_t* img = A.bases[blockIdx.z] + A.img_off;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void k_fast_emit(FastArgs A)
   for (int k = 0; k < 16; k++) d[k] = (int)c[c_circle[k][1] * W + c_circle[k][0]] - p;
   hso_corner o;
   o.x = (int16_t)x; o.y = (int16_t)y;
-  o.score = fast9_strength(d) - 1;
+  o.score = fast_strength<ARC>(d) - 1;
   // hso::shiTomasiScore, vision.cpp:111-151 (integer-valued float sums: exact)
   float resp = 0.0f;
   {
@@ -197,6 +202,57 @@ __global__ __launch_bounds__(256) void k_fast_emit(FastArgs A)
   out[idx] = o;
 }
 
+size_t hso_fast_plan(const PyrGeom& g, int n_frames, int n_levels, int cap, FastPlan* plan)
+{
+  FastPlan& P = *plan;
+  P.g = g; P.n_frames = n_frames; P.n_levels = n_levels; P.cap = cap;
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  // slice of one frame: [row counts of all levels | per level: mask, row offsets, corner list]
+  size_t o = 0;
+  for (int l = 0; l < n_levels; l++) {
+    P.wpr[l] = (g.w[l] + FAST_TW - 1) / FAST_TW;
+    P.o_cnt[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
+  }
+  P.cnt_bytes = o;
+  for (int l = 0; l < n_levels; l++) {
+    P.o_mask[l] = o; o += al(sizeof(unsigned long long) * (size_t)g.h[l] * P.wpr[l]);
+    P.o_off[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
+    P.o_out[l] = o; o += al(sizeof(hso_corner) * (size_t)cap);
+  }
+  P.per_frame = o;
+  P.o_tab = P.per_frame * (size_t)n_frames;
+  P.o_tot = P.o_tab + al(sizeof(void*) * (size_t)n_frames);
+  P.o_extra = P.o_tot + al(sizeof(int) * (size_t)n_frames * n_levels);
+  return P.o_extra;
+}
+
+int hso_fast_launch(hso_gpu_ctx* ctx, const FastPlan& P, const uint8_t* const* d_bases, int threshold, int border, int arc)
+{
+  const PyrGeom& g = P.g;
+  const int n_frames = P.n_frames, n_levels = P.n_levels, cap = P.cap;
+  HSO_HIP_CHECK(ctx, hipMemset2DAsync(P.d, P.per_frame, 0, P.cnt_bytes, (size_t)n_frames, ctx->stream));  // the row counters of every slice
+  FastArgs A;
+  A.bases = d_bases;
+  A.threshold = threshold; A.border = border; A.cap = cap;
+  A.work = P.d; A.per_frame = P.per_frame;
+  A.totals = reinterpret_cast<int*>(P.d + P.o_tot);
+  A.n_levels = n_levels;
+  for (int l = 0; l < n_levels; l++) {
+    A.img_off = g.off[l]; A.W = g.w[l]; A.H = g.h[l]; A.words_per_row = P.wpr[l]; A.level = l;
+    A.o_cnt = P.o_cnt[l]; A.o_mask = P.o_mask[l]; A.o_off = P.o_off[l]; A.o_out = P.o_out[l];
+    const dim3 gm(P.wpr[l], (A.H + FAST_TH - 1) / FAST_TH, n_frames), ge((A.H * P.wpr[l] + 3) / 4, 1, n_frames);
+    if (arc == 12) hipLaunchKernelGGL(k_fast_mask<12>, gm, dim3(256), 0, ctx->stream, A);
+    else hipLaunchKernelGGL(k_fast_mask<9>, gm, dim3(256), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_fast_scan, dim3(n_frames), dim3(256), 0, ctx->stream, A);
+    if (cap > 0) {
+      if (arc == 12) hipLaunchKernelGGL(k_fast_emit<12>, ge, dim3(256), 0, ctx->stream, A);
+      else hipLaunchKernelGGL(k_fast_emit<9>, ge, dim3(256), 0, ctx->stream, A);
+    }
+    HSO_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return HSO_OK;
+}
+
 int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold, int border, int cap,
                      size_t extra, FastPlan* plan)
 {
@@ -211,25 +267,7 @@ int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, i
     else if (it->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "fast_detect: frames of one batch must share one size");
     h_bases[i] = it->second.base;
   }
-  P.g = g; P.n_frames = n_frames; P.n_levels = n_levels; P.cap = cap;
-  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  // slice of one frame: [row counts of all levels | per level: mask, row offsets, corner list]
-  size_t o = 0;
-  for (int l = 0; l < n_levels; l++) {
-    P.wpr[l] = (g.w[l] + FAST_TW - 1) / FAST_TW;
-    P.o_cnt[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
-  }
-  const size_t cnt_bytes = o;
-  for (int l = 0; l < n_levels; l++) {
-    P.o_mask[l] = o; o += al(sizeof(unsigned long long) * (size_t)g.h[l] * P.wpr[l]);
-    P.o_off[l] = o; o += al(sizeof(int) * (size_t)g.h[l]);
-    P.o_out[l] = o; o += al(sizeof(hso_corner) * (size_t)cap);
-  }
-  P.per_frame = o;
-  P.o_tab = P.per_frame * (size_t)n_frames;
-  P.o_tot = P.o_tab + al(sizeof(void*) * (size_t)n_frames);
-  P.o_extra = P.o_tot + al(sizeof(int) * (size_t)n_frames * n_levels);
-  const size_t need = P.o_extra + al(extra);
+  const size_t need = hso_fast_plan(g, n_frames, n_levels, cap, &P) + ((extra + 255) & ~size_t(255));
   if (ctx->batch_cap < need) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -240,22 +278,7 @@ int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, i
   char* d = reinterpret_cast<char*>(ctx->d_batch);
   P.d = d;
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + P.o_tab, h_bases.data(), sizeof(void*) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemset2DAsync(d, P.per_frame, 0, cnt_bytes, (size_t)n_frames, ctx->stream));  // the row counters of every slice
-  FastArgs A;
-  A.bases = reinterpret_cast<const uint8_t* const*>(d + P.o_tab);
-  A.threshold = threshold; A.border = border; A.cap = cap;
-  A.work = d; A.per_frame = P.per_frame;
-  A.totals = reinterpret_cast<int*>(d + P.o_tot);
-  A.n_levels = n_levels;
-  for (int l = 0; l < n_levels; l++) {
-    A.img_off = g.off[l]; A.W = g.w[l]; A.H = g.h[l]; A.words_per_row = P.wpr[l]; A.level = l;
-    A.o_cnt = P.o_cnt[l]; A.o_mask = P.o_mask[l]; A.o_off = P.o_off[l]; A.o_out = P.o_out[l];
-    hipLaunchKernelGGL(k_fast_mask, dim3(P.wpr[l], (A.H + FAST_TH - 1) / FAST_TH, n_frames), dim3(256), 0, ctx->stream, A);
-    hipLaunchKernelGGL(k_fast_scan, dim3(n_frames), dim3(256), 0, ctx->stream, A);
-    if (cap > 0) hipLaunchKernelGGL(k_fast_emit, dim3((A.H * P.wpr[l] + 3) / 4, 1, n_frames), dim3(256), 0, ctx->stream, A);
-    HSO_HIP_CHECK(ctx, hipGetLastError());
-  }
-  return HSO_OK;
+  return hso_fast_launch(ctx, P, reinterpret_cast<const uint8_t* const*>(d + P.o_tab), threshold, border, 9);
 }
 
 int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& P, hso_corner* out, int32_t* counts)

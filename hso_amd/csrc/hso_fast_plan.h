@@ -10,6 +10,7 @@ struct FastPlan {
   PyrGeom g;                 // geometry shared by every frame of the batch
   int n_frames, n_levels, cap;
   char* d;                   // ctx->d_batch
+  size_t cnt_bytes;          // the row counters at the head of a slice
   size_t per_frame;          // one slice per frame: [row counts | per level: mask, row offsets, corners]
   size_t o_cnt[HSO_N_PYR_LEVELS], o_mask[HSO_N_PYR_LEVELS], o_off[HSO_N_PYR_LEVELS], o_out[HSO_N_PYR_LEVELS];
   int wpr[HSO_N_PYR_LEVELS]; // 64-bit mask words per image row
@@ -22,5 +23,10 @@ struct FastPlan {
 // enqueues mask / scan / emit for every level on ctx->stream; no synchronisation.
 int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold, int border, int cap,
                      size_t extra, FastPlan* plan);
+// The two halves of hso_fast_enqueue for callers that place a second FAST pass (FAST-12 of
+// fillingHole) in their own region: the layout (offsets relative to plan->d; returns the bytes it
+// needs), and the launches for arc = 9 or 12 over a device table of frame base pointers.
+size_t hso_fast_plan(const PyrGeom& g, int n_frames, int n_levels, int cap, FastPlan* plan);
+int hso_fast_launch(hso_gpu_ctx* ctx, const FastPlan& plan, const uint8_t* const* d_bases, int threshold, int border, int arc);
 // counts (+ corners when cap > 0) to the host; synchronises the stream.
 int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& plan, hso_corner* out, int32_t* counts);

@@ -351,18 +351,22 @@ void FeatureExtractor::setExistingFeatures(const Features& fts)
 void FeatureExtractor::detect(Frame* frame, float initThresh, float minThresh, Features& fts, Frame* last_frame)
 {
   (void)initThresh; (void)last_frame;   // initThresh_ is never read; the epipolar-hole filter is commented out in the reference (:798-803)
-  if (isInit_) throw std::logic_error("FeatureExtractor: the initialisation branch (fillingHole) is not built");
   minThresh_ = (int)minThresh;          // int minThresh_, include/hso/feature_detection.h:339
   const int64_t id = frame->id_;
   int corner_cap = 16384;
   const int edgelet_cap = ((width_ + 7) / 8) * ((height_ + 7) / 8);   // one per grid index; every level has that many
-  std::vector<hso_corner> co;
-  std::vector<hso_edgelet> ed((size_t)nLevels_ * edgelet_cap);
-  std::vector<int32_t> nc(nLevels_), ne(nLevels_);
+  std::vector<hso_corner> co, fill;
+  std::vector<hso_edgelet> ed;
+  std::vector<int32_t> nc(nLevels_), ne(nLevels_, 0);
+  int32_t n_fill = 0;
+  if (isInit_) fill.resize(edgelet_cap); else ed.resize((size_t)nLevels_ * edgelet_cap);
   for (;;) {
     co.resize((size_t)nLevels_ * corner_cap);
-    const int rc = hso_gpu_detect_candidates(frame->ctx_, &id, 1, nLevels_, minThresh_, co.data(), corner_cap, nc.data(), ed.data(),
-                                             edgelet_cap, ne.data());
+    // :439-447: fillingHole on level 0 while initialising, the edgelets of every level otherwise
+    const int rc = isInit_ ? hso_gpu_detect_candidates_init(frame->ctx_, &id, 1, nLevels_, minThresh_, co.data(), corner_cap, nc.data(),
+                                                            fill.data(), edgelet_cap, &n_fill)
+                           : hso_gpu_detect_candidates(frame->ctx_, &id, 1, nLevels_, minThresh_, co.data(), corner_cap, nc.data(),
+                                                       ed.data(), edgelet_cap, ne.data());
     if (rc < 0) throw std::runtime_error(std::string("FeatureExtractor: ") + hso_gpu_last_error(frame->ctx_));
     int most = 0;
     for (int c : nc) most = c > most ? c : most;
@@ -375,6 +379,11 @@ void FeatureExtractor::detect(Frame* frame, float initThresh, float minThresh, F
       const hso_corner& c = co[(size_t)L * corner_cap + i];
       hso_keypoint k{};
       k.x = (float)(c.x << L); k.y = (float)(c.y << L); k.response = c.response; k.level = L; k.species = HSO_KP_CORNER_HIGH;
+      allFeturesToDistribute_.push_back(k);
+    }
+    for (int i = 0; L == 0 && i < n_fill; ++i) {   // fillingHole's key points follow the level-0 corners (kGrad, :1150-1151)
+      hso_keypoint k{};
+      k.x = (float)fill[i].x; k.y = (float)fill[i].y; k.response = fill[i].response; k.level = 0; k.species = HSO_KP_GRAD;
       allFeturesToDistribute_.push_back(k);
     }
     for (int i = 0; i < ne[L]; ++i) {
@@ -400,8 +409,10 @@ void FeatureExtractor::detect(Frame* frame, float initThresh, float minThresh, F
       f->type = Feature::CORNER;
     } else {
       f->type = k.species == HSO_KP_GRAD ? Feature::GRADIENT : Feature::EDGELET;
+      // fillingHole never sets KeyPoint::gx / gy (the reference normalises uninitialised ints there,
+      // :466-468); the mirror keeps the default direction for those
       const double gx = k.gx, gy = k.gy, nrm = std::sqrt(gx * gx + gy * gy);
-      f->grad = {gx / nrm, gy / nrm};    // Vector2d::normalize()
+      if (nrm > 0) f->grad = {gx / nrm, gy / nrm};    // Vector2d::normalize()
     }
     fts.push_back(f);
   }

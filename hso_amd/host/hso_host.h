@@ -158,8 +158,8 @@ public:
   FeatureExtractor(int width, int height, int cellSize, int levels, bool isInit = false, int max_fts = 200);
   // src/feature_detection.cpp:408-497: fastDetectMT + edgeLetDetectMT on the device
   // (hso_gpu_detect_candidates), computeKeyPointsOctTree on the host (hso_gpu_select_octree),
-  // then one new Feature per selected key (caller owns them, like the reference).  The
-  // initialisation branch (fillingHole, FAST-12) is not built: throws std::logic_error.
+  // then one new Feature per selected key (caller owns them, like the reference).  isInit:
+  // fastDetectMT + fillingHole (FAST-12 on level 0, hso_gpu_detect_candidates_init), 2000 features.
   void detect(Frame* frame, float initThresh, float minThresh, Features& fts, Frame* last_frame = nullptr);
   void setExistingFeatures(const Features& fts);   // :1169-1177
   int width_, height_, cellSize_, nLevels_, nFeatures_;

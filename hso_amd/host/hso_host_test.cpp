@@ -124,6 +124,16 @@ int main(int argc, char** argv)
     }
     std::printf("\n");
     for (const hso::Seed& sd : kf_filter.seeds_) delete sd.ftr;
+
+    // ---- the initialisation-time extractor on the same frame: fastDetectMT + fillingHole, 2000 features
+    // (FeatureExtractor(..., isInit = true), src/feature_detection.cpp:382-384, 439-442)
+    hso::FeatureExtractor init_extractor(w, h, 25, 3, true, 200);
+    hso::Features init_fts;
+    init_extractor.detect(next.get(), 20, next->gradMean_, init_fts);
+    std::printf("%zu", init_fts.size());
+    for (const hso::Feature* ft : init_fts) std::printf(" %d %d %.9g %.9g", (int)ft->type, ft->level, ft->px[0], ft->px[1]);
+    std::printf("\n");
+    for (hso::Feature* ft : init_fts) delete ft;
     for (hso::Point* p : points) delete p;
   }
   hso_gpu_destroy(ctx);

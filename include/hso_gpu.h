@@ -536,6 +536,17 @@ int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_
                               hso_corner* corners, int corner_cap, int32_t* corner_counts,
                               hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts);
 
+/* The initialisation branch of FeatureExtractor::detect (:439-442): fastDetectMT as above, then
+ * fillingHole on level 0 (src/feature_detection.cpp:1125-1154) — fast_corner_detect_plain_12,
+ * fast_corner_score_12, fast_nonmax_3x3 (thirdparty/fast/src) at barrier max(0.6 * min_thresh, 6),
+ * border 8, and a survivor is kept only if its grid index holds no FAST-9 feature or earlier
+ * survivor (raster order).  fill: n_frames * fill_cap entries (species kGrad, level 0: position,
+ * FAST-12 score, Shi-Tomasi response), fill_counts[n_frames].  Bit-identical to the reference
+ * library (tests/golden/fast12.json was produced by it). */
+int hso_gpu_detect_candidates_init(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int min_thresh,
+                                   hso_corner* corners, int corner_cap, int32_t* corner_counts,
+                                   hso_corner* fill, int fill_cap, int32_t* fill_counts);
+
 /* ---- FeatureExtractor::computeKeyPointsOctTree, src/feature_detection.cpp:833-1122 (ExtractorNode::DivideNode,
  *      include/hso/feature_detection.h:217-272): the spatial distribution that ends FeatureExtractor::detect
  *      (:449-455).  Host code (sequential refinement over a few thousand candidates), no context needed. ---- */

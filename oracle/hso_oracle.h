@@ -135,6 +135,10 @@ void hso_or_seed_activate(const hso_camera* cam, const hso_seed* s, const hso_ac
 /* ---- FAST-9 corner detection (src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect), thirdparty/fast, vision.cpp:111-151)
  *      — pinned against oracle/_ref/libfast_ref.so and tests/golden/fast9.json ---- */
 int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y);
+int hso_or_fast_max_barrier(const uint8_t* img, int stride, int x, int y, int arc);
+int hso_or_fast_detect_arc(const uint8_t* img, int w, int h, int threshold, int arc, int16_t* xy, int32_t* scores, int cap);
+int hso_or_filling_hole_level(const uint8_t* img, int w, int h, int level, int frame_w, int frame_h, int min_thresh, uint8_t* have,
+                              hso_corner* out, int cap);   /* fillingHole, src/feature_detection.cpp:1125-1154 (FAST-12, pinned: tests/golden/fast12.json) */
 float hso_or_shi_tomasi(const uint8_t* img, int cols, int rows, int u, int v);
 int hso_or_fast9_detect(const uint8_t* img, int w, int h, int threshold, int16_t* xy, int32_t* scores, int cap);
 int hso_or_fast_detect_level(const uint8_t* img, int w, int h, int threshold, int border, hso_corner* out, int cap);

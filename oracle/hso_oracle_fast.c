@@ -26,8 +26,9 @@ static const int kCircle[16][2] = {
   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}
 };
 
-/* largest barrier b >= 0 at which (x, y) is still a FAST-9 corner, or -1 if it is not one even at b = 0 */
-int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y)
+/* largest barrier b >= 0 at which (x, y) is still a FAST-`arc` corner (arc contiguous circle pixels
+ * all brighter or all darker), or -1 if it is not one even at b = 0 */
+int hso_or_fast_max_barrier(const uint8_t* img, int stride, int x, int y, int arc)
 {
   const int p = img[y * stride + x];
   int d[16];
@@ -35,7 +36,7 @@ int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y)
   int best = 0;  /* max over arcs of the minimum |difference| along the arc (0: no arc with a common sign) */
   for (int s = 0; s < 16; s++) {
     int mb = 256, md = 256;
-    for (int k = 0; k < 9; k++) {
+    for (int k = 0; k < arc; k++) {
       const int v = d[(s + k) & 15];
       if (v < mb) mb = v;       /* brighter arc: min (I - p) */
       if (-v < md) md = -v;     /* darker arc:   min (p - I) */
@@ -45,6 +46,8 @@ int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y)
   }
   return best - 1;  /* I > p + b for all of the arc  <=>  b <= min(I - p) - 1 */
 }
+
+int hso_or_fast9_max_barrier(const uint8_t* img, int stride, int x, int y) { return hso_or_fast_max_barrier(img, stride, x, y, 9); }
 
 /* hso::shiTomasiScore, src/vikit/vision.cpp:111-151 */
 float hso_or_shi_tomasi(const uint8_t* img, int cols, int rows, int u, int v)
@@ -75,13 +78,13 @@ float hso_or_shi_tomasi(const uint8_t* img, int cols, int rows, int u, int v)
 
 /* fast_corner_detect_9_sse2 + fast_corner_score_9: all corners of one image in raster order.
  * xy / scores hold up to cap entries; returns the number of corners. */
-int hso_or_fast9_detect(const uint8_t* img, int w, int h, int threshold, int16_t* xy, int32_t* scores, int cap)
+int hso_or_fast_detect_arc(const uint8_t* img, int w, int h, int threshold, int arc, int16_t* xy, int32_t* scores, int cap)
 {
   int n = 0;
   if (h < 7 || w < 7) return 0;
   for (int y = 3; y < h - 3; y++)
     for (int x = 3; x < w - 3; x++) {
-      const int mb = hso_or_fast9_max_barrier(img, w, x, y);
+      const int mb = hso_or_fast_max_barrier(img, w, x, y, arc);
       if (mb >= threshold) {
         if (n < cap) { xy[2 * n] = (int16_t)x; xy[2 * n + 1] = (int16_t)y; scores[n] = mb; }
         n++;
@@ -90,18 +93,23 @@ int hso_or_fast9_detect(const uint8_t* img, int w, int h, int threshold, int16_t
   return n;
 }
 
+int hso_or_fast9_detect(const uint8_t* img, int w, int h, int threshold, int16_t* xy, int32_t* scores, int cap)
+{
+  return hso_or_fast_detect_arc(img, w, h, threshold, 9, xy, scores, cap);
+}
+
 /* FeatureExtractor::fastDetect for one level (src/feature_detection.cpp:552-586): detection, score,
  * fast_nonmax_3x3 (thirdparty/fast/src/nonmax_3x3.cpp: a corner survives unless one of its eight
  * neighbours is a corner with score >= its own), border filter, Shi-Tomasi response.
  * Returns the number of surviving corners (only the first cap are written). */
-int hso_or_fast_detect_level(const uint8_t* img, int w, int h, int threshold, int border, hso_corner* out, int cap)
+static int detect_level_arc(const uint8_t* img, int w, int h, int threshold, int border, int arc, hso_corner* out, int cap)
 {
   int16_t* sc = (int16_t*)malloc(sizeof(int16_t) * (size_t)w * h);  /* score per pixel, -1 = not a corner */
   for (int i = 0; i < w * h; i++) sc[i] = -1;
   if (h >= 7 && w >= 7)
     for (int y = 3; y < h - 3; y++)
       for (int x = 3; x < w - 3; x++) {
-        const int mb = hso_or_fast9_max_barrier(img, w, x, y);
+        const int mb = hso_or_fast_max_barrier(img, w, x, y, arc);
         if (mb >= threshold) sc[y * w + x] = (int16_t)mb;
       }
   int n = 0;
@@ -124,5 +132,36 @@ int hso_or_fast_detect_level(const uint8_t* img, int w, int h, int threshold, in
       n++;
     }
   free(sc);
+  return n;
+}
+
+int hso_or_fast_detect_level(const uint8_t* img, int w, int h, int threshold, int border, hso_corner* out, int cap)
+{
+  return detect_level_arc(img, w, h, threshold, border, 9, out, cap);
+}
+
+/* FeatureExtractor::fillingHole, src/feature_detection.cpp:1125-1154 (the initialisation branch of
+ * detect, :439-442, level 0 only): FAST-12 (fast_corner_detect_plain_12 + fast_corner_score_12 +
+ * fast_nonmax_3x3) at barrier max(0.6 * minThresh, 6) truncated to short; a survivor inside the
+ * border is kept only when its grid index (getCellIndex) holds no feature yet, and then occupies it.
+ * have: haveFeatures_[level] as the FAST-9 stage left it (updated).  out: kGrad key points in the
+ * order they are pushed; returns their number. */
+int hso_or_filling_hole_level(const uint8_t* img, int w, int h, int level, int frame_w, int frame_h, int min_thresh, uint8_t* have,
+                              hso_corner* out, int cap)
+{
+  const short fastThresh = 0.6 * min_thresh > 6 ? 0.6 * min_thresh : 6;
+  int grid, gcols, grows, lw, lh;
+  hso_or_detect_grid(frame_w, frame_h, level, &grid, &gcols, &grows, &lw, &lh);
+  hso_corner* all = (hso_corner*)malloc(sizeof(hso_corner) * (size_t)w * h);
+  const int n_all = detect_level_arc(img, w, h, fastThresh, 8, 12, all, w * h);
+  int n = 0;
+  for (int i = 0; i < n_all; i++) {
+    const int index = hso_or_detect_cell_index(all[i].x, all[i].y, grid, gcols, grows);
+    if (have[index]) continue;
+    have[index] = 1;
+    if (n < cap) out[n] = all[i];
+    n++;
+  }
+  free(all);
   return n;
 }

@@ -413,6 +413,53 @@ def fast9_detect(img, threshold):
     return xy[:n].copy(), sc[:n].copy()
 
 
+def fast_detect_arc(img, threshold, arc):
+    """All FAST-`arc` corners and their scores in raster order (arc = 9 or 12)."""
+    lib = load()
+    lib.hso_or_fast_detect_arc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.hso_or_fast_detect_arc.restype = C.c_int
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    xy = np.zeros((w * h, 2), np.int16); sc = np.zeros(w * h, np.int32)
+    n = lib.hso_or_fast_detect_arc(img.ctypes.data, w, h, threshold, arc, xy.ctypes.data, sc.ctypes.data, w * h)
+    return xy[:n].copy(), sc[:n].copy()
+
+
+def filling_hole_level(img, level, frame_w, frame_h, min_thresh, have):
+    """FeatureExtractor::fillingHole of one level; `have` is updated in place."""
+    lib = load()
+    lib.hso_or_filling_hole_level.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int]
+    lib.hso_or_filling_hole_level.restype = C.c_int
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros(len(have), CORNER_DTYPE)
+    n = lib.hso_or_filling_hole_level(img.ctypes.data, w, h, level, frame_w, frame_h, int(min_thresh), have.ctypes.data,
+                                      out.ctypes.data, len(out))
+    return out[:n].copy()
+
+
+def ref_fast12(img, threshold):
+    """FAST-12 of the compiled reference library: corners, scores, fast_nonmax_3x3 survivors; None if absent."""
+    if not os.path.exists(REF_FAST_PATH):
+        return None
+    lib = C.CDLL(REF_FAST_PATH)
+    if not hasattr(lib, "ref_fast12_detect"):
+        return None
+    lib.ref_fast12_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.ref_fast12_score.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.ref_fast_nonmax.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    xy = np.zeros((w * h, 2), np.int16)
+    n = lib.ref_fast12_detect(img.ctypes.data, w, h, w, threshold, xy.ctypes.data, w * h)
+    xy = xy[:n].copy()
+    sc = np.zeros(max(n, 1), np.int32)
+    lib.ref_fast12_score(img.ctypes.data, w, xy.ctypes.data, n, threshold, sc.ctypes.data)
+    keep = np.zeros(max(n, 1), np.int32)
+    nk = lib.ref_fast_nonmax(xy.ctypes.data, sc.ctypes.data, n, keep.ctypes.data) if n else 0
+    return xy, sc[:n].copy(), keep[:nk].copy()
+
+
 def shi_tomasi(img, u, v):
     lib = load()
     lib.hso_or_shi_tomasi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]

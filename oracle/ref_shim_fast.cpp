@@ -40,3 +40,24 @@ int ref_fast_nonmax(const short* xy, const int* scores, int n, int* idx)
   return (int)keep.size();
 }
 }
+
+// FAST-12 (FeatureExtractor::fillingHole, src/feature_detection.cpp:1125-1154)
+extern "C" {
+int ref_fast12_detect(const unsigned char* img, int w, int h, int stride, int barrier, short* xy, int cap)
+{
+  std::vector<fast::fast_xy> c;
+  fast::fast_corner_detect_plain_12(img, w, h, stride, (short)barrier, c);
+  for (int i = 0; i < (int)c.size() && i < cap; i++) { xy[2 * i] = c[i].x; xy[2 * i + 1] = c[i].y; }
+  return (int)c.size();
+}
+
+void ref_fast12_score(const unsigned char* img, int stride, const short* xy, int n, int threshold, int* scores)
+{
+  std::vector<fast::fast_xy> c;
+  c.reserve(n);
+  for (int i = 0; i < n; i++) c.emplace_back(xy[2 * i], xy[2 * i + 1]);
+  std::vector<int> s;
+  fast::fast_corner_score_12(img, stride, c, threshold, s);
+  for (int i = 0; i < n; i++) scores[i] = s[i];
+}
+}

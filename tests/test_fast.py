@@ -172,3 +172,103 @@ def test_fast_detect_golden_and_errors(gpu_ctx, gold):
             gpu_ctx.fast_detect(9320, n_levels=6)
     finally:
         gpu_ctx.frame_release(9320)
+
+
+# ---- FAST-12: FeatureExtractor::fillingHole (src/feature_detection.cpp:1125-1154), the initialisation
+# branch of detect.  PINNED like FAST-9: tests/golden/fast12.json holds the outputs of the compiled
+# reference library (fast_12_detect.cpp, fast_12_score.cpp, nonmax_3x3.cpp; tests/golden/make_fast12_golden.py).
+def test_oracle_fast12_matches_reference_library_golden(orc, gold):
+    imgs, _ = gold
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fast12.json")))["cases"]
+    n_corners = 0
+    for c in cases:
+        img = imgs[c["image"]]
+        xy, sc = orc.fast_detect_arc(img, c["threshold"], 12)
+        gxy = np.array(c["xy"], np.int16).reshape(-1, 2)
+        assert xy.shape == gxy.shape and (xy == gxy).all(), (c["image"], c["threshold"])
+        assert (sc == np.array(c["scores"], np.int32)).all()
+        n_corners += len(gxy)
+    assert n_corners > 10000 and len(cases) == 21
+
+
+def test_oracle_fast12_matches_live_reference_when_present(orc):
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (61, 97), dtype=np.uint8)
+    r = orc.ref_fast12(img, 8)
+    if r is None:
+        pytest.skip("oracle/_ref/libfast_ref.so absent (reference not on this machine)")
+    rxy, rsc, keep = r
+    xy, sc = orc.fast_detect_arc(img, 8, 12)
+    assert (xy == rxy).all() and (sc == rsc).all() and len(keep) > 20
+
+
+def test_oracle_filling_hole_respects_occupancy(orc):
+    rng = np.random.default_rng(10)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    have = np.zeros(4800, np.uint8)
+    free = orc.filling_hole_level(img, 0, 640, 480, 20, have)
+    assert len(free) > 500 and have.sum() == len(free)        # one feature per grid index, each index now occupied
+    idx = [orc.cell_index(c["x"], c["y"], 8, 80, 60) for c in free]
+    assert len(set(idx)) == len(idx)
+    # every index already taken stays silent; the others keep their first survivor
+    have2 = np.zeros(4800, np.uint8)
+    have2[idx[::2]] = 1
+    part = orc.filling_hole_level(img, 0, 640, 480, 20, have2)
+    assert part.tobytes() == free[1::2].tobytes()
+    # barrier: max(0.6 * minThresh, 6) truncated to short -> 6 for minThresh <= 10, 12 for 20
+    a = orc.filling_hole_level(img, 0, 640, 480, 7, np.zeros(4800, np.uint8))
+    b = orc.filling_hole_level(img, 0, 640, 480, 10, np.zeros(4800, np.uint8))
+    assert a.tobytes() == b.tobytes() and len(a) >= len(free)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", [synth.ICL_NUIM, synth.EUROC], ids=["640x480", "752x480"])
+def test_detect_candidates_init_bit_exact(gpu_ctx, orc, spec):
+    base = synth.config2_pair(10, spec=spec, seed=90)["ref"].astype(np.float32)
+    # lower contrast leaves grid indices without a FAST-9 corner for fillingHole's FAST-12 pass to fill
+    frames = [(base * s + 128 * (1 - s)).astype(np.uint8) for s in (1.0, 0.5, 0.35)]
+    rng = np.random.default_rng(3)
+    frames.append((np.kron(rng.integers(0, 2, (spec["height"] // 8, spec["width"] // 8)), np.ones((8, 8))) * 60 + 50).astype(np.uint8))
+    ids = [9350 + k for k in range(len(frames))]
+    for i, f in zip(ids, frames):
+        gpu_ctx.frame_upload(i, f)
+    try:
+        h, w = frames[0].shape
+        for thr in (7, 20):
+            co, cc, fo, fc = gpu_ctx.detect_candidates_init(ids, n_levels=3, min_thresh=thr, corner_cap=30000, fill_cap=6000)
+            for k, img in enumerate(frames):
+                pyr = orc.create_pyramid(img)
+                have0 = None
+                for L in range(3):
+                    want, n = orc.fast_detect_level(np.ascontiguousarray(pyr[L]), thr, border=8)
+                    assert cc[k, L] == n
+                    _check_level(co[k, L, :n], want)
+                    if L == 0:
+                        g, gc, gr = orc.detect_grid(w, h, 0)
+                        have0 = np.zeros(gc * gr, np.uint8)
+                        for c in want:
+                            have0[orc.cell_index(c["x"], c["y"], g, gc, gr)] = 1
+                fill = orc.filling_hole_level(np.ascontiguousarray(pyr[0]), 0, w, h, thr, have0)
+                assert fc[k] == len(fill), (thr, k)
+                _check_level(fo[k, :fc[k]], fill)
+            assert fc.max() > (50 if thr == 20 else 0)
+        # caps smaller than the counts
+        co, cc, fo, fc2 = gpu_ctx.detect_candidates_init(ids[:1], n_levels=1, min_thresh=20, corner_cap=10, fill_cap=10)
+        assert fc2[0] == fc[0] and fo[0, :min(10, fc2[0])].tobytes() == orc.filling_hole_level(
+            np.ascontiguousarray(orc.create_pyramid(frames[0])[0]), 0, w, h, 20,
+            _have_after_fast(orc, frames[0], 20, w, h))[:10].tobytes()
+        co, cc, fo, fc2 = gpu_ctx.detect_candidates_init(ids[1:2], n_levels=1, min_thresh=20, corner_cap=10, fill_cap=10)
+        assert fc2[0] == fc[1] > 10 and fo[0].tobytes() == orc.filling_hole_level(
+            np.ascontiguousarray(orc.create_pyramid(frames[1])[0]), 0, w, h, 20, _have_after_fast(orc, frames[1], 20, w, h))[:10].tobytes()
+    finally:
+        for i in ids:
+            gpu_ctx.frame_release(i)
+
+
+def _have_after_fast(orc, img, thr, w, h):
+    want, _ = orc.fast_detect_level(np.ascontiguousarray(orc.create_pyramid(img)[0]), thr, border=8)
+    g, gc, gr = orc.detect_grid(w, h, 0)
+    have = np.zeros(gc * gr, np.uint8)
+    for c in want:
+        have[orc.cell_index(c["x"], c["y"], g, gc, gr)] = 1
+    return have

@@ -178,3 +178,31 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
     # (on this densely textured frame every node holds a corner, and corners outrank edgelets:
     # n_edgelets is normally 0 here; tests/test_octree.py covers the edgelet-winning nodes)
     assert 0 <= n_edgelets <= n_new
+
+    # ---- FeatureExtractor(isInit=true).detect (line 6): fastDetectMT + fillingHole + oct-tree with 2000 features
+    assert _init_branch_check(gpu_ctx, lines[5], 42, min_thresh) >= 0
+
+
+def _init_branch_check(gpu_ctx, line, frame_id, min_thresh):
+    """Line 6 of the driver: FeatureExtractor(isInit=true).detect against the C-ABI pieces."""
+    v = line.split()
+    n = int(v[0])
+    rec = np.array(v[1:], float).reshape(n, 4)
+    co, cc, fo, fc = gpu_ctx.detect_candidates_init([frame_id], n_levels=3, min_thresh=min_thresh, corner_cap=16384, fill_cap=4800)
+    parts = []
+    for L in range(3):
+        c = co[0, L, :cc[0, L]]
+        k = np.zeros(len(c), capi.KEYPOINT_DTYPE)
+        k["x"], k["y"], k["response"], k["level"], k["species"] = c["x"].astype(np.int32) << L, c["y"].astype(np.int32) << L, c["response"], L, capi.KP_CORNER_HIGH
+        parts.append(k)
+        if L == 0:
+            f = fo[0, :fc[0]]
+            k = np.zeros(len(f), capi.KEYPOINT_DTYPE)
+            k["x"], k["y"], k["response"], k["level"], k["species"] = f["x"], f["y"], f["response"], 0, capi.KP_GRAD
+            parts.append(k)
+    sel = capi.select_octree(np.concatenate(parts), 640, 480, 2000)
+    assert n == len(sel) and n > 1500
+    want_type = np.where(sel["species"] == capi.KP_CORNER_HIGH, 0, 2)       # Feature::CORNER / GRADIENT
+    assert (rec[:, 0] == want_type).all() and (rec[:, 1] == sel["level"]).all()
+    assert (rec[:, 2] == sel["x"]).all() and (rec[:, 3] == sel["y"]).all()
+    return int((want_type == 2).sum())
