@@ -172,78 +172,103 @@ __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
   int b = blockIdx.x, level = 0;
   while (level < HSO_N_SOBEL_LEVELS - 1 && b >= g.sobel_blocks[level]) { b -= g.sobel_blocks[level]; level++; }
   const int W = g.w[level], H = g.h[level];
+  // pointers read from a table are generic; say "global" so the accesses are global_load / global_store
+  // instead of FLAT (which also probes the LDS aperture and ties up both wait counters)
+  typedef const __attribute__((address_space(1))) uint8_t* GlbCU8;
+  typedef const __attribute__((address_space(1))) uint32_t* GlbCU32;
+  typedef __attribute__((address_space(1))) int16_t* GlbI16;
+  typedef __attribute__((address_space(1))) unsigned long long* GlbU64;
   uint8_t* base = bases[blockIdx.y];
-  const uint8_t* img = base + g.off[level];
+  const GlbCU8 img = (GlbCU8)(base + g.off[level]);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int tile = b * SOB_WAVES + wv;  // tiles of a level in row-major order, SOB_WAVES per block
   const int tiles_x = g.sobel_bx[level];
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x = tx * SOB_TW + (lane & 15) * 4;
   const int ys = ty * SOB_TH + (lane >> 4) * SOB_STRIP;
-  int16_t* gx = reinterpret_cast<int16_t*>(base + g.sob_off[level][0]);
-  int16_t* gy = reinterpret_cast<int16_t*>(base + g.sob_off[level][1]);
+  const GlbI16 gx = (GlbI16)(base + g.sob_off[level][0]);
+  const GlbI16 gy = (GlbI16)(base + g.sob_off[level][1]);
   unsigned isum = 0;
   double gsum = 0;
   if (x < W && ys < H) {
-    // three aligned dwords per row when the row start is dword aligned and the lane is interior
-    const bool fast = (x >= 4) && (x + 8 <= W) && ((W & 3) == 0);
-    int hd[5][4], hs[5][4], cen[5][4];
+    // widths that are multiples of 4 (every halfSample pyramid): aligned dwords for every lane; a
+    // lane on the left / right image border replicates its first / last pixel instead of loading
+    const bool fast = (W & 3) == 0;
+    const bool has_left = x >= 4, has_right = x + 8 <= W;
+    // Packed 16-bit arithmetic: every intermediate fits int16 (|hd| <= 6*255, hs <= 16*255,
+    // |gx|, |gy| <= 16*6*255 = 24480), so two pixels ride in one register (v_pk_*_i16) and the
+    // output dwords come out already packed.  P[j] = {p[j], p[j+1]} for the columns x-2+j.
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2 hd[5][2], hs[5][2];
+    uint32_t cdw[5];     // bytes x .. x+3 of the row (the four centre pixels), for the intensity sum
+    const s16x2 k2 = {2, 2}, k4 = {4, 4}, k6 = {6, 6};
 #pragma unroll
     for (int i = 0; i < SOB_STRIP + 4; i++) {
       int yy = ys + i - 2;
       yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-      const uint8_t* row = img + (size_t)yy * W;
-      int p[8];  // columns x-2 .. x+5
+      const GlbCU8 row = img + (size_t)yy * W;
+      uint32_t d0, d1, d2;   // bytes x-4 .. x+7 (only x-2 .. x+5 are used)
       if (fast) {
-        const uint32_t* r32 = reinterpret_cast<const uint32_t*>(row + x - 4);
-        const uint32_t d0 = r32[0], d1 = r32[1], d2 = r32[2];
-        p[0] = (d0 >> 16) & 255; p[1] = d0 >> 24;
-        p[2] = d1 & 255; p[3] = (d1 >> 8) & 255; p[4] = (d1 >> 16) & 255; p[5] = d1 >> 24;
-        p[6] = d2 & 255; p[7] = (d2 >> 8) & 255;
+        const GlbCU32 r32 = (GlbCU32)(row + x);
+        d1 = r32[0];
+        d0 = has_left ? r32[-1] : (d1 & 0xffu) * 0x01010101u;        // BORDER_REPLICATE
+        d2 = has_right ? r32[1] : (d1 >> 24) * 0x01010101u;
       } else {
+        uint32_t p[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
           int xx = x - 2 + k;
           xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
           p[k] = row[xx];
         }
+        d0 = (p[0] << 16) | (p[1] << 24);
+        d1 = p[2] | (p[3] << 8) | (p[4] << 16) | (p[5] << 24);
+        d2 = p[6] | (p[7] << 8);
       }
+      // v_perm_b32: bytes 0-3 of the selector space = second operand, 4-7 = first, 0x0c = zero
+      union { uint32_t u; s16x2 v; } P0, P1, P2, P3, P4, P5, P6;
+      P0.u = __builtin_amdgcn_perm(d0, d0, 0x0c030c02u);
+      P1.u = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u);
+      P2.u = __builtin_amdgcn_perm(d1, d1, 0x0c010c00u);
+      P3.u = __builtin_amdgcn_perm(d1, d1, 0x0c020c01u);
+      P4.u = __builtin_amdgcn_perm(d1, d1, 0x0c030c02u);
+      P5.u = __builtin_amdgcn_perm(d2, d1, 0x0c040c03u);
+      P6.u = __builtin_amdgcn_perm(d2, d2, 0x0c010c00u);
       const int sl = i % 5;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        hd[sl][k] = -p[k] - 2 * p[k + 1] + 2 * p[k + 3] + p[k + 4];
-        hs[sl][k] = p[k] + 4 * p[k + 1] + 6 * p[k + 2] + 4 * p[k + 3] + p[k + 4];
-        cen[sl][k] = p[k + 2];
-      }
+      hd[sl][0] = (P4.v - P0.v) + k2 * (P3.v - P1.v);
+      hd[sl][1] = (P6.v - P2.v) + k2 * (P5.v - P3.v);
+      hs[sl][0] = (P0.v + P4.v) + k4 * (P1.v + P3.v) + k6 * P2.v;
+      hs[sl][1] = (P2.v + P6.v) + k4 * (P3.v + P5.v) + k6 * P4.v;
+      cdw[sl] = d1;
       if (i >= 4) {
         const int y = ys + i - 4;
         const int ra = (i - 4) % 5, rb = (i - 3) % 5, rc = (i - 2) % 5, rd = (i - 1) % 5, re = i % 5;
         if (y < H) {
-          int sx[4], sy[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            sx[k] = hd[ra][k] + 4 * hd[rb][k] + 6 * hd[rc][k] + 4 * hd[rd][k] + hd[re][k];
-            sy[k] = -hs[ra][k] - 2 * hs[rb][k] + 2 * hs[rd][k] + hs[re][k];
-          }
-          uint2 vx, vy;
-          vx.x = (uint32_t)(sx[0] & 0xffff) | ((uint32_t)sx[1] << 16); vx.y = (uint32_t)(sx[2] & 0xffff) | ((uint32_t)sx[3] << 16);
-          vy.x = (uint32_t)(sy[0] & 0xffff) | ((uint32_t)sy[1] << 16); vy.y = (uint32_t)(sy[2] & 0xffff) | ((uint32_t)sy[3] << 16);
+          union { uint32_t u; s16x2 v; } sx0, sx1, sy0, sy1;
+          sx0.v = (hd[ra][0] + hd[re][0]) + k4 * (hd[rb][0] + hd[rd][0]) + k6 * hd[rc][0];
+          sx1.v = (hd[ra][1] + hd[re][1]) + k4 * (hd[rb][1] + hd[rd][1]) + k6 * hd[rc][1];
+          sy0.v = (hs[re][0] - hs[ra][0]) + k2 * (hs[rd][0] - hs[rb][0]);
+          sy1.v = (hs[re][1] - hs[ra][1]) + k2 * (hs[rd][1] - hs[rb][1]);
           typedef unsigned long long u64;
           if (x + 4 <= W && ((W & 3) == 0)) {
-            __builtin_nontemporal_store(((u64)vx.y << 32) | vx.x, reinterpret_cast<u64*>(gx + (size_t)y * W + x));
-            __builtin_nontemporal_store(((u64)vy.y << 32) | vy.x, reinterpret_cast<u64*>(gy + (size_t)y * W + x));
+            __builtin_nontemporal_store(((u64)sx1.u << 32) | sx0.u, (GlbU64)(gx + (size_t)y * W + x));
+            __builtin_nontemporal_store(((u64)sy1.u << 32) | sy0.u, (GlbU64)(gy + (size_t)y * W + x));
           } else {  // widths that are not multiples of 4 (cv::resize pyramids): element-wise, last lane clipped
+            const short sxv[4] = {sx0.v.x, sx0.v.y, sx1.v.x, sx1.v.y}, syv[4] = {sy0.v.x, sy0.v.y, sy1.v.x, sy1.v.y};
 #pragma unroll
             for (int k = 0; k < 4; k++)
-              if (x + k < W) { gx[(size_t)y * W + x + k] = (int16_t)sx[k]; gy[(size_t)y * W + x + k] = (int16_t)sy[k]; }
+              if (x + k < W) { gx[(size_t)y * W + x + k] = sxv[k]; gy[(size_t)y * W + x + k] = syv[k]; }
           }
           if (level == 0 && x >= 16 && x < W - 16 && y >= 16 && y < H - 16) {
+            const short sxv[4] = {sx0.v.x, sx0.v.y, sx1.v.x, sx1.v.y}, syv[4] = {sy0.v.x, sy0.v.y, sy1.v.x, sy1.v.y};
+            float mag[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-              const float fx = (float)sx[k], fy = (float)sy[k];
-              gsum += (double)sqrtf(fx * fx + fy * fy);
-              isum += (unsigned)cen[rc][k];
+              const float fx = (float)sxv[k], fy = (float)syv[k];
+              mag[k] = sqrtf(fx * fx + fy * fy);
             }
+            gsum += (double)((mag[0] + mag[1]) + (mag[2] + mag[3]));   // four values < 3.5e4 each: fp32 pair sums, then fp64
+            isum = __builtin_amdgcn_sad_u8(cdw[rc], 0u, isum);   // + the four centre bytes
           }
         }
       }
