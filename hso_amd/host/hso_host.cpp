@@ -250,6 +250,169 @@ bool Matcher::findMatchDirect(const Point& pt, Frame& cur_frame, Vector2d& px_cu
   return r[0].success != 0;
 }
 
+// ---------------------------------------------------------------- Reprojector
+Reprojector::Reprojector(AbstractCamera* cam, int max_fts) : max_fts_(max_fts)
+{
+  cell_size = (int)floorf(std::sqrt((float)(cam->width() * cam->height()) / max_fts) * 0.6);   // caculateGridSize, :53-56
+  grid_n_cols = (int)std::ceil((double)cam->width() / cell_size);
+  grid_n_rows = (int)std::ceil((double)cam->height() / cell_size);
+  cells_.resize((size_t)grid_n_cols * grid_n_rows);
+  cell_order.resize(cells_.size());
+  for (size_t i = 0; i < cell_order.size(); ++i) cell_order[i] = (int)i;
+}
+
+// what reprojectCell / reprojectCellAll do with one candidate (:366-412): true = matched
+bool Reprojector::applyMatch(const Candidate& c, FramePtr frame)
+{
+  const hso_align_out& m = match_[c.slot];
+  Point* pt = c.pt;
+  if (proj_[c.slot].ref_obs < 0 || !m.success) {
+    pt->n_failed_reproj_++;
+    if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_failed_reproj_ > 15) pt->type_ = Point::TYPE_DELETED;     // map_.safeDeletePoint
+    if (pt->type_ == Point::TYPE_CANDIDATE && pt->n_failed_reproj_ > 30) pt->type_ = Point::TYPE_DELETED;   // deleteCandidatePoint
+    if (pt->type_ == Point::TYPE_TEMPORARY && pt->n_failed_reproj_ > 30) pt->isBad_ = true;
+    return false;
+  }
+  pt->n_succeeded_reproj_++;
+  if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_succeeded_reproj_ > 10) pt->type_ = Point::TYPE_GOOD;
+  Feature* nf = new Feature();
+  nf->frame = frame.get();
+  nf->px = {m.px_cur[0], m.px_cur[1]};
+  nf->f = frame->cam_->cam2world(nf->px);
+  nf->level = m.search_level;
+  nf->point = pt;
+  const Feature* ref = ref_of_slot_[c.slot];
+  if (ref->type == Feature::EDGELET) {
+    nf->type = Feature::EDGELET;
+    const double gx = m.A_cur_ref[0] * ref->grad[0] + m.A_cur_ref[1] * ref->grad[1];
+    const double gy = m.A_cur_ref[2] * ref->grad[0] + m.A_cur_ref[3] * ref->grad[1];
+    const double n = std::sqrt(gx * gx + gy * gy);
+    nf->grad = {gx / n, gy / n};
+  } else {
+    nf->type = ref->type == Feature::GRADIENT ? Feature::GRADIENT : Feature::CORNER;
+  }
+  frame->fts_.push_back(nf);
+  return true;
+}
+
+bool Reprojector::reprojectCell(Cell& cell, FramePtr frame, bool is_2nd, bool is_3rd)
+{
+  if (cell.empty()) return false;
+  if (!is_2nd)
+    cell.sort([](const Candidate& l, const Candidate& r) {          // pointQualityComparator, :333-345
+      if (l.pt->type_ != r.pt->type_) return l.pt->type_ > r.pt->type_;
+      return l.pt->ftr_type_ > r.pt->ftr_type_;
+    });
+  int success = 0;
+  auto it = cell.begin();
+  while (it != cell.end()) {
+    ++n_trials_;
+    if (it->pt->type_ == Point::TYPE_DELETED) { it = cell.erase(it); continue; }
+    const bool ok = applyMatch(*it, frame);
+    it = cell.erase(it);
+    if (!ok) continue;
+    if (!is_3rd) return true;
+    success++;
+    n_matches_++;
+    if (success >= 3 || n_matches_ >= (size_t)max_fts_) return true;
+  }
+  return false;
+}
+
+void Reprojector::reprojectMap(FramePtr frame, const std::vector<FramePtr>& kfs, std::vector<std::pair<FramePtr, size_t>>& overlap_kfs)
+{
+  // resetGrid, :77-84
+  n_matches_ = 0; n_trials_ = 0; nFeatures_ = 0;
+  for (Cell& c : cells_) c.clear();
+  // the points reprojectPoint would see, in the reference's order (:137-152, :176-199)
+  std::vector<Point*> pts;
+  std::vector<size_t> kf_of_pt;
+  for (const FramePtr& kf : kfs) {
+    if (overlap_kfs.size() >= max_n_kfs) break;
+    overlap_kfs.push_back({kf, 0});
+    for (Feature* ft : kf->fts_) {
+      if (ft->point == nullptr) continue;
+      if (ft->point->type_ == Point::TYPE_TEMPORARY) continue;
+      if (ft->point->last_projected_kf_id_ == frame->id_) continue;
+      ft->point->last_projected_kf_id_ = frame->id_;
+      pts.push_back(ft->point);
+      kf_of_pt.push_back(overlap_kfs.size() - 1);
+    }
+  }
+  if (pts.empty()) return;
+  // flatten: keyframe table over every frame a host feature or an observation lives in
+  std::vector<hso_kf> kft;
+  std::vector<const Frame*> kf_frames;
+  auto kf_index = [&](const Frame* f) {
+    for (size_t k = 0; k < kf_frames.size(); ++k) if (kf_frames[k] == f) return (int)k;
+    hso_kf r{};
+    r.frame_id = f->id_; r.T_f_w = f->T_f_w_.v; r.exposure_time = f->m_exposure_time; r.keyframe_id = f->keyFrameId_;
+    kft.push_back(r); kf_frames.push_back(f);
+    return (int)kft.size() - 1;
+  };
+  std::vector<hso_map_point> mp(pts.size());
+  std::vector<hso_obs> obs;
+  std::vector<const Feature*> obs_ftr;
+  for (size_t i = 0; i < pts.size(); ++i) {
+    const Point* p = pts[i];
+    hso_map_point& m = mp[i];
+    m = hso_map_point{};
+    for (int k = 0; k < 3; ++k) { m.pos[k] = p->pos_[k]; m.host_f[k] = p->hostFeature_->f[k]; }
+    m.idist = p->idist_;
+    m.host_kf = kf_index(p->hostFeature_->frame);
+    m.obs_begin = (int)obs.size(); m.obs_count = (int)p->obs_.size();
+    for (const Feature* o : p->obs_) {
+      hso_obs ho{};
+      ho.kf = kf_index(o->frame); ho.level = o->level; ho.type = (int)o->type;
+      ho.px[0] = o->px[0]; ho.px[1] = o->px[1];
+      for (int k = 0; k < 3; ++k) ho.f[k] = o->f[k];
+      ho.grad[0] = o->grad[0]; ho.grad[1] = o->grad[1];
+      obs.push_back(ho); obs_ftr.push_back(o);
+    }
+  }
+  proj_.assign(pts.size(), hso_reproj_point{});
+  match_.assign(pts.size(), hso_align_out{});
+  const int rc = hso_gpu_reproject_match(frame->ctx_, &frame->cam_->pod(), frame->id_, &frame->T_f_w_.v, frame->m_exposure_time,
+                                         frame->keyFrameId_, kft.data(), (int)kft.size(), mp.data(), (int)mp.size(), obs.data(),
+                                         (int)obs.size(), cell_size, grid_n_cols, proj_.data(), match_.data());
+  if (rc < 0) throw std::runtime_error(std::string("Reprojector: ") + hso_gpu_last_error(frame->ctx_));
+  ref_of_slot_.assign(pts.size(), nullptr);
+  std::vector<Candidate> all;                       // allPixelToDistribute, in projection order
+  for (size_t i = 0; i < pts.size(); ++i) {
+    if (!proj_[i].projected) continue;              // reprojectPoint returned false
+    if (proj_[i].ref_obs >= 0) ref_of_slot_[i] = obs_ftr[proj_[i].ref_obs];
+    const Candidate c{pts[i], {proj_[i].px[0], proj_[i].px[1]}, (int)i};
+    cells_.at(proj_[i].cell).push_back(c);
+    all.push_back(c);
+    overlap_kfs[kf_of_pt[i]].second++;
+    nFeatures_++;
+  }
+  if (all.size() < (size_t)max_fts_ + 50) {         // reprojectCellAll, :556-612
+    for (const Candidate& c : all) {
+      ++n_trials_;
+      if (c.pt->type_ == Point::TYPE_DELETED) continue;
+      if (!applyMatch(c, frame)) continue;
+      n_matches_++;
+      if (n_matches_ >= (size_t)max_fts_) return;
+    }
+    return;
+  }
+  for (size_t i = 0; i < cells_.size(); ++i) {      // 1st, :268-278
+    if (reprojectCell(cells_.at(cell_order[i]), frame, false, false)) ++n_matches_;
+    if (n_matches_ >= (size_t)max_fts_) break;
+  }
+  if (n_matches_ < (size_t)max_fts_)                // 2nd, :281-293 (index 0 is never revisited there)
+    for (size_t i = cells_.size() - 1; i > 0; --i) {
+      if (reprojectCell(cells_.at(cell_order[i]), frame, true, false)) ++n_matches_;
+      if (n_matches_ >= (size_t)max_fts_) break;
+    }
+  if (n_matches_ < (size_t)max_fts_)                // 3rd, :296-305
+    for (size_t i = 0; i < cells_.size(); ++i) {
+      reprojectCell(cells_.at(cell_order[i]), frame, true, true);
+      if (n_matches_ >= (size_t)max_fts_) break;
+    }
+}
+
 // ---------------------------------------------------------------- pose_optimizer
 void pose_optimizer::optimizeLevenbergMarquardt3rd(const double reproj_thresh, const size_t n_iter, const bool verbose,
                                                    FramePtr& frame, double& estimated_scale, double& error_init,

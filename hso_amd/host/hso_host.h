@@ -59,6 +59,11 @@ public:
   Feature* hostFeature_ = nullptr;
   Vector3d pos_{0, 0, 0};         // world position (point.h:63)
   std::list<Feature*> obs_;       // keyframe observations (point.h:66)
+  enum FeatureType { FEATURE_GRADIENT, FEATURE_EDGELET, FEATURE_CORNER };                      // point.h:54
+  FeatureType ftr_type_ = FEATURE_CORNER;
+  int last_projected_kf_id_ = -1;                                                              // point.h:73
+  int n_failed_reproj_ = 0, n_succeeded_reproj_ = 0;                                           // point.h:75-76
+  bool isBad_ = false;
   // src/point.cpp:116-136: the observation whose viewing direction is closest to `framepos`
   bool getCloseViewObs(const Vector3d& framepos, Feature*& ftr) const;
 };
@@ -130,6 +135,36 @@ public:
   double A_cur_ref_[4] = {1, 0, 0, 1};
   double h_inv_ = 0;
   hso_align_out last_{};
+};
+
+// include/hso/reprojector.h:55-190 — map points of the overlapping keyframes into the new frame
+class Reprojector {
+public:
+  struct Candidate { Point* pt; Vector2d px; int slot; };   // reprojector.h:95-103 (+ the row of the device call)
+  using Cell = std::list<Candidate>;
+  // initializeGrid, src/reprojector.cpp:53-75; max_fts stands in for Config::maxFts()
+  Reprojector(AbstractCamera* cam, int max_fts);
+  // src/reprojector.cpp:88-331 for the map points of `kfs` — the overlap keyframes in the order
+  // the reference visits them (covisibility first, then by closeness; that walk belongs to the
+  // Map, which the mirror does not have).  One hso_gpu_reproject_match call projects, bins,
+  // chooses reference observations and matches; reprojectCell / reprojectCellAll (:352-429,
+  // :556-612) then read the results in the reference's visiting order: same features added to
+  // frame->fts_, same counters.  Points the reference would hand to Map::safeDeletePoint are
+  // marked TYPE_DELETED.
+  void reprojectMap(FramePtr frame, const std::vector<FramePtr>& kfs, std::vector<std::pair<FramePtr, size_t>>& overlap_kfs);
+  // the visiting order of the cells: the reference reshuffles it with std::random_shuffle on
+  // every call (:72, :82); here it is the caller's (identity by default), so runs are reproducible
+  std::vector<int> cell_order;
+  size_t n_matches_ = 0, n_trials_ = 0, nFeatures_ = 0;
+  int cell_size, grid_n_cols, grid_n_rows, max_fts_;
+  size_t max_n_kfs = 10;           // Options::max_n_kfs, reprojector.h:67
+private:
+  bool reprojectCell(Cell& cell, FramePtr frame, bool is_2nd, bool is_3rd);
+  bool applyMatch(const Candidate& c, FramePtr frame);
+  std::vector<Cell> cells_;
+  std::vector<hso_align_out> match_;
+  std::vector<hso_reproj_point> proj_;
+  std::vector<const Feature*> ref_of_slot_;
 };
 
 // include/hso/pose_optimizer.h — motion-only refinement of frame->T_f_w_ over its features' points

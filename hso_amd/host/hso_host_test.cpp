@@ -134,6 +134,33 @@ int main(int argc, char** argv)
     for (const hso::Feature* ft : init_fts) std::printf(" %d %d %.9g %.9g", (int)ft->type, ft->level, ft->px[0], ft->px[1]);
     std::printf("\n");
     for (hso::Feature* ft : init_fts) delete ft;
+
+    // ---- Reprojector::reprojectMap of the keyframe's points into a fresh copy of the new frame
+    // (src/reprojector.cpp:88-331): once through reprojectCellAll (few candidates), once through
+    // the three cell passes (small feature budget)
+    for (hso::Point* p : points) {
+      const hso::Feature* hf = p->hostFeature_;
+      const double inv = 1.0 / p->idist_;
+      p->pos_ = last->T_f_w_.inverse() * hso::Vector3d{hf->f[0] * inv, hf->f[1] * inv, hf->f[2] * inv};
+      if (p->obs_.empty()) p->obs_.push_back(p->hostFeature_);
+    }
+    for (int budget : {200, 40}) {
+      for (hso::Point* p : points) { p->n_failed_reproj_ = 0; p->n_succeeded_reproj_ = 0; p->type_ = hso::Point::TYPE_UNKNOWN; }
+      hso::FramePtr probe(new hso::Frame(ctx, &cam, cur.data(), w, h, 0.1));
+      probe->T_f_w_ = T_tracked;
+      probe->m_exposure_time = next->m_exposure_time;
+      hso::Reprojector reprojector(&cam, budget);
+      std::vector<std::pair<hso::FramePtr, size_t>> overlap;
+      reprojector.reprojectMap(probe, {last}, overlap);
+      std::printf("%zu %zu %zu %zu %d %d", reprojector.n_matches_, reprojector.n_trials_, reprojector.nFeatures_, overlap[0].second,
+                  reprojector.cell_size, reprojector.grid_n_cols);
+      for (const hso::Feature* ft : probe->fts_) {
+        size_t idx = 0;
+        while (points[idx] != ft->point) idx++;
+        std::printf(" %zu %d %.17g %.17g", idx, ft->level, ft->px[0], ft->px[1]);
+      }
+      std::printf("\n");
+    }
     for (hso::Point* p : points) delete p;
   }
   hso_gpu_destroy(ctx);

@@ -182,6 +182,12 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
     # ---- FeatureExtractor(isInit=true).detect (line 6): fastDetectMT + fillingHole + oct-tree with 2000 features
     assert _init_branch_check(gpu_ctx, lines[5], 42, min_thresh) >= 0
 
+    # ---- Reprojector::reprojectMap (lines 7-8): few candidates -> reprojectCellAll; small budget -> the three cell passes
+    n_sel, n_cand = _reprojector_check(gpu_ctx, cam, lines[6], 200, 41, 42, T_cw, exposure_time, feats, idist, has_pt)
+    assert n_cand > 150 and n_sel > 120
+    n_sel, n_cand = _reprojector_check(gpu_ctx, cam, lines[7], 40, 41, 42, T_cw, exposure_time, feats, idist, has_pt)
+    assert n_sel == 40
+
 
 def _init_branch_check(gpu_ctx, line, frame_id, min_thresh):
     """Line 6 of the driver: FeatureExtractor(isInit=true).detect against the C-ABI pieces."""
@@ -206,3 +212,77 @@ def _init_branch_check(gpu_ctx, line, frame_id, min_thresh):
     assert (rec[:, 0] == want_type).all() and (rec[:, 1] == sel["level"]).all()
     assert (rec[:, 2] == sel["x"]).all() and (rec[:, 3] == sel["y"]).all()
     return int((want_type == 2).sum())
+
+
+def _reprojector_check(gpu_ctx, cam, line, budget, kf_id, cur_id, T_cw, exposure_time, feats, idist, has_pt):
+    """Lines 7-8 of the driver: hso::Reprojector::reprojectMap against hso_gpu_reproject_match + the
+    cell passes of src/reprojector.cpp:261-306 / :352-429 / :556-612 restated here."""
+    v = line.split()
+    n_matches, n_trials, n_feat, n_overlap, cell_size, gcols = (int(x) for x in v[:6])
+    rec = np.array(v[6:], float).reshape(-1, 4)
+    assert cell_size == int(np.floor(np.float32(np.sqrt(np.float32(640 * 480) / budget)) * 0.6))
+    assert gcols == int(np.ceil(640 / cell_size))
+    n_cells = gcols * int(np.ceil(480 / cell_size))
+    kfs = np.zeros(1, capi.KF_DTYPE)
+    kfs[0]["frame_id"], kfs[0]["q"], kfs[0]["exposure_time"], kfs[0]["keyframe_id"] = kf_id, [0, 0, 0, 1], 1.0, 0
+    pts = np.zeros(len(has_pt), capi.MAP_POINT_DTYPE)
+    obs = np.zeros(len(has_pt), capi.OBS_DTYPE)
+    for r, i in enumerate(has_pt):
+        pts[r]["pos"] = feats["f"][i] * (1.0 / idist[i])
+        pts[r]["idist"], pts[r]["host_f"], pts[r]["host_kf"] = idist[i], feats["f"][i], 0
+        pts[r]["obs_begin"], pts[r]["obs_count"] = r, 1
+        obs[r]["kf"], obs[r]["level"], obs[r]["type"] = 0, 0, capi.FTR_CORNER
+        obs[r]["px"], obs[r]["f"], obs[r]["grad"] = feats["px"][i], feats["f"][i], [1.0, 0.0]
+    proj, match = gpu_ctx.reproject_match(cam, cur_id, T_cw, exposure_time, 0, kfs, pts, obs, cell_size, gcols)
+    ok = lambda i: proj["ref_obs"][i] >= 0 and match[i].success == 1
+    cand = [i for i in range(len(pts)) if proj["projected"][i]]
+    assert n_feat == n_overlap == len(cand)
+    sel, trials = [], 0
+    if len(cand) < budget + 50:
+        for i in cand:
+            trials += 1
+            if ok(i):
+                sel.append(i)
+                if len(sel) >= budget:
+                    break
+    else:
+        cells = [[] for _ in range(n_cells)]
+        for i in cand:
+            cells[proj["cell"][i]].append(i)
+        for c in range(n_cells):                                   # 1st pass: one match per cell
+            while cells[c]:
+                trials += 1
+                i = cells[c].pop(0)
+                if ok(i):
+                    sel.append(i)
+                    break
+            if len(sel) >= budget:
+                break
+        if len(sel) < budget:
+            for c in range(n_cells - 1, 0, -1):                    # 2nd pass, backwards, cell 0 skipped
+                while cells[c]:
+                    trials += 1
+                    i = cells[c].pop(0)
+                    if ok(i):
+                        sel.append(i)
+                        break
+                if len(sel) >= budget:
+                    break
+        if len(sel) < budget:
+            for c in range(n_cells):                               # 3rd pass: up to three more per cell
+                got = 0
+                while cells[c]:
+                    trials += 1
+                    i = cells[c].pop(0)
+                    if ok(i):
+                        sel.append(i); got += 1
+                        if got >= 3 or len(sel) >= budget:
+                            break
+                if len(sel) >= budget:
+                    break
+    assert (n_matches, n_trials) == (len(sel), trials), (budget, n_matches, len(sel), n_trials, trials)
+    assert [int(x) for x in rec[:, 0]] == sel
+    for r, i in zip(rec, sel):
+        assert int(r[1]) == match[i].search_level
+        assert (r[2], r[3]) == pytest.approx((match[i].px_cur[0], match[i].px_cur[1]), abs=1e-9)
+    return len(sel), len(cand)
