@@ -1,0 +1,217 @@
+"""The data formats on either side of the hot path, OpenCV-free:
+
+  parse_calibration   the camera files of test/cameras/*.txt as BenchmarkNode::BenchmarkNode reads
+                      them (reference test/test_dataset.cpp:133-248), including the > 848x800
+                      downscale rule with its operator-precedence quirk
+  read_stamps         the four time-stamp line formats of ImageReader (src/ImageReader.cpp:24-66)
+  list_images         ImageReader::getDir (:88-125): *.png / *.jpg of a folder, sorted
+  read_pgm / read_png 8-bit grayscale images without cv::imread (binary PGM; non-interlaced PNG)
+  write_trajectory    BenchmarkNode::saveResult (test/test_dataset.cpp:312-335): one keyframe per
+                      line, "stamp tx ty tz qx qy qz qw" of T_f_w^-1 (the TUM trajectory format)
+  read_trajectory, ate_rmse   the evaluation side: closed-form alignment (Umeyama) + RMSE of positions
+
+Host-side plumbing: nothing here touches the GPU.
+"""
+import os
+import re
+import struct
+import zlib
+
+import numpy as np
+
+from .capi import CAM_PINHOLE, CAM_FOV, make_camera
+
+G_MAX_RESOLUTION = 848 * 800          # test/test_dataset.cpp:55
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def parse_calibration(path_or_text):
+    """-> dict(camera=hso_camera, model, width, height, file_width, file_height, undistort).
+    Line 1: "Pinhole fx fy cx cy d0 d1 d2 d3" | "Equidistant ..." (9 tokens) or
+    "FOV fx fy cx cy omega" (6 tokens); line 2: "width height"; FOV line 3: "true" = undistort the
+    image first.  Values pass through float like the reference's sscanf("%f")."""
+    text = open(path_or_text).read() if os.path.exists(str(path_or_text)) else str(path_or_text)
+    lines = text.splitlines()
+    tok = lines[0].split()
+    kind = tok[0][0].lower()
+    if len(tok) >= 9 and kind in "pe":
+        ic = [_f32(t) for t in tok[1:9]]
+    elif len(tok) >= 6 and kind == "f":
+        ic = [_f32(t) for t in tok[1:6]]
+    else:
+        raise ValueError("Camera file error.")
+    wh = [_f32(t) for t in lines[1].split()[:2]]
+    width_i, height_i = int(wh[0]), int(wh[1])
+    scale_intrinsics = kind != "f" or (ic[2] > 1 and ic[3] > 1)    # normalised FOV intrinsics scale with the ctor instead
+    if float(wh[0] * wh[1]) > G_MAX_RESOLUTION + 0.00000001:
+        resize_rate = np.float64(np.sqrt(wh[0] * wh[1] / _f32(G_MAX_RESOLUTION)))   # float operands, result kept in a double
+        width_i, height_i = int(np.float64(wh[0]) / resize_rate), int(np.float64(wh[1]) / resize_rate)
+        # sic: wh0*wh1/width_i*height_i = ((wh0*wh1)/width_i)*height_i in float (test_dataset.cpp:167)
+        resize_rate = np.float64(np.sqrt(wh[0] * wh[1] / _f32(width_i) * _f32(height_i)))
+        if scale_intrinsics:
+            ic[0:4] = [_f32(np.float64(v) / resize_rate) for v in ic[0:4]]
+    if kind == "e":
+        raise NotImplementedError("EquidistantCamera is outside the hot path's camera models (pinhole / radtan / FOV)")
+    if kind == "p":
+        cam = make_camera(CAM_PINHOLE, width_i, height_i, ic[0], ic[1], ic[2], ic[3], d=[float(v) for v in ic[4:8]] + [0.0])
+        undistort = False
+    else:
+        fx, fy, cx, cy = (float(v) for v in ic[0:4])
+        if cx < 1.0 and cy < 1.0:                                  # FOVCamera ctor, src/camera.cpp:142-148
+            fx, fy, cx, cy = fx * width_i, fy * height_i, cx * width_i, cy * height_i
+        undistort = len(lines) > 2 and lines[2].strip() == "true"
+        cam = make_camera(CAM_FOV, width_i, height_i, fx, fy, cx, cy, d=[float(ic[4])], distortion=0 if undistort else 1)
+    return dict(camera=cam, model={"p": "Pinhole", "f": "FOV"}[kind], width=width_i, height=height_i,
+                file_width=int(wh[0]), file_height=int(wh[1]), undistort=undistort)
+
+
+def read_stamps(path):
+    """ImageReader's stamp file: per line "stamp x y z a b c d" | "id stamp exposure" | "id stamp" |
+    "stamp" (tried in that order, src/ImageReader.cpp:39-62) -> list of stamp strings."""
+    num = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?"
+    out = []
+    for line in open(path).read().splitlines():
+        t = line.split()
+        if not t:
+            continue
+        if len(t) >= 8 and all(re.fullmatch(num, x) for x in t[1:8]):
+            out.append(t[0])
+        elif len(t) >= 2 and re.fullmatch(r"[-+]?\d+", t[0]):
+            out.append(t[1])
+        else:
+            out.append(t[0])
+    return out
+
+
+def list_images(folder):
+    return [os.path.join(folder, n) for n in sorted(os.listdir(folder)) if ".png" in n or ".jpg" in n]
+
+
+def read_pgm(path):
+    data = open(path, "rb").read()
+    m = re.match(rb"P5\s+(?:#[^\n]*\n\s*)*(\d+)\s+(?:#[^\n]*\n\s*)*(\d+)\s+(?:#[^\n]*\n\s*)*(\d+)\s", data)
+    if not m:
+        raise ValueError("not a binary PGM: %s" % path)
+    w, h, maxval = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    if maxval > 255:
+        raise ValueError("16-bit PGM is not an 8-bit grayscale image")
+    return np.frombuffer(data, np.uint8, w * h, m.end()).reshape(h, w).copy()
+
+
+def write_pgm(path, img):
+    img = np.ascontiguousarray(img, np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(img.tobytes())
+
+
+def read_png(path):
+    """8-bit grayscale (colour type 0) or gray+alpha (4, alpha dropped) PNG, non-interlaced."""
+    data = open(path, "rb").read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG: %s" % path)
+    pos, idat, hdr = 8, [], None
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        if kind == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat.append(body)
+        elif kind == b"IEND":
+            break
+        pos += 12 + n
+    w, h, depth, ctype, _, _, interlace = hdr
+    if depth != 8 or ctype not in (0, 4) or interlace:
+        raise ValueError("only non-interlaced 8-bit grayscale PNGs are read without a decoder library")
+    bpp = 1 if ctype == 0 else 2
+    raw = zlib.decompress(b"".join(idat))
+    stride = w * bpp
+    out = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        ft = raw[y * (stride + 1)]
+        line = np.frombuffer(raw, np.uint8, stride, y * (stride + 1) + 1).astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:                       # Sub / Average / Paeth depend on the pixel to the left: sequential
+            cur = np.zeros(stride, np.int32)
+            for x in range(stride):
+                a = cur[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                c = prev[x - bpp] if x >= bpp else 0
+                if ft == 1:
+                    p = a
+                elif ft == 3:
+                    p = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[x] = (line[x] + p) & 255
+        out[y] = cur
+        prev = cur
+    return out[:, ::bpp].copy()
+
+
+def write_png(path, img):
+    """8-bit grayscale PNG (filter 0), for fixtures and round trips."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def _quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def write_trajectory(path, keyframes):
+    """keyframes: iterable of (stamp, q_f_w (x, y, z, w), t_f_w).  Writes T_f_w^-1 per line with
+    operator<< default precision (6 significant digits), like saveResult."""
+    with open(path, "w") as f:
+        for stamp, q, t in keyframes:
+            R = _quat_to_R(q)
+            c = -R.T @ np.asarray(t, float)                # Tinv.translation()
+            qi = (-q[0], -q[1], -q[2], q[3])               # Tinv.unit_quaternion()
+            f.write("%s %s\n" % (stamp if isinstance(stamp, str) else "%g" % stamp, " ".join("%g" % v for v in (*c, *qi))))
+
+
+def read_trajectory(path):
+    """-> (stamps as strings, positions [n, 3], quaternions [n, 4] (x, y, z, w))."""
+    stamps, rows = [], []
+    for line in open(path):
+        t = line.split()
+        if len(t) >= 8 and not t[0].startswith("#"):
+            stamps.append(t[0]); rows.append([float(x) for x in t[1:8]])
+    a = np.array(rows, float).reshape(-1, 7)
+    return stamps, a[:, 0:3], a[:, 3:7]
+
+
+def ate_rmse(gt_xyz, est_xyz, with_scale=True):
+    """Absolute trajectory error after the closed-form similarity (monocular: with_scale) or rigid
+    alignment of est onto gt (Umeyama 1991).  -> (rmse, scale, R, t)."""
+    gt, est = np.asarray(gt_xyz, float), np.asarray(est_xyz, float)
+    mg, me = gt.mean(0), est.mean(0)
+    G, E = gt - mg, est - me
+    U, D, Vt = np.linalg.svd(G.T @ E / len(gt))
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    s = float(np.trace(np.diag(D) @ S) / (E ** 2).sum() * len(gt)) if with_scale else 1.0
+    t = mg - s * R @ me
+    err = gt - (s * (R @ est.T).T + t)
+    return float(np.sqrt((err ** 2).sum(1).mean())), s, R, t

@@ -1,0 +1,121 @@
+"""The data formats either side of the hot path: calibration files
+(test/test_dataset.cpp:133-248; tests/golden/cameras/*.txt are the reference's own test/cameras
+data files), stamp files (src/ImageReader.cpp:24-66), images without OpenCV, the trajectory file
+of BenchmarkNode::saveResult (test/test_dataset.cpp:312-335) and its evaluation."""
+import os
+
+import numpy as np
+import pytest
+
+from hso_amd import capi, formats, synth
+
+CAMS = os.path.join(os.path.dirname(__file__), "golden", "cameras")
+
+
+def test_calibration_files_of_the_reference():
+    e = formats.parse_calibration(os.path.join(CAMS, "euroc.txt"))
+    c = e["camera"]
+    assert (e["model"], c.width, c.height, c.model, c.distortion) == ("Pinhole", 752, 480, capi.CAM_PINHOLE, 1)
+    # values pass through float like sscanf("%f")
+    assert (c.fx, c.fy, c.cx, c.cy) == tuple(float(np.float32(v)) for v in (458.654, 457.296, 367.215, 248.375))
+    assert list(c.d) == [float(np.float32(v)) for v in (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)] + [0.0]
+    ref = synth.camera(synth.EUROC)
+    assert c.fx == pytest.approx(ref.fx, rel=1e-7) and c.d[0] == pytest.approx(ref.d[0], rel=1e-7)
+    i = formats.parse_calibration(os.path.join(CAMS, "icl-nuim.txt"))["camera"]
+    assert (i.width, i.height, i.fx, i.fy, i.cx, i.cy, i.distortion) == (640, 480, float(np.float32(481.2)), 480.0, 319.5, 239.5, 0)
+
+
+def test_calibration_downscale_rule():
+    # TUM mono: 1280 x 1024 > 848 * 800 -> 920 x 736 (the size the cv::resize pyramid branch exists for);
+    # normalised FOV intrinsics are not rescaled by the driver, the camera constructor multiplies them by the new size
+    w = formats.parse_calibration(os.path.join(CAMS, "tum_mono_vo_narrow.txt"))
+    c = w["camera"]
+    assert (w["file_width"], w["file_height"], c.width, c.height) == (1280, 1024, 920, 736)
+    assert c.model == capi.CAM_FOV and c.distortion == 1 and not w["undistort"]
+    assert c.fx == pytest.approx(0.535719308086809 * 920, rel=1e-6) and c.cy == pytest.approx(0.500408664348414 * 736, rel=1e-6)
+    assert c.d[0] == pytest.approx(0.897966326944875, rel=1e-7)
+    n = formats.parse_calibration(os.path.join(CAMS, "tum_mono_vo_wide.txt"))
+    assert n["undistort"] and n["camera"].distortion == 0                  # "true": the image is undistorted first
+    # pixel intrinsics are divided by the second resize rate, sqrt(((w*h)/w_new)*h_new) — sic, :167
+    p = formats.parse_calibration("Pinhole 1000 1000 640 512 0 0 0 0\n1280 1024\nfalse\n")
+    rate = np.sqrt(np.float32(1280 * 1024) / np.float32(920) * np.float32(736))
+    assert p["camera"].width == 920 and p["camera"].fx == pytest.approx(1000 / rate, rel=1e-6)
+    assert rate == pytest.approx(1024.0, rel=1e-3)          # not the ~1.39 the author meant: the quirk is kept
+    # at or under the limit nothing changes
+    q = formats.parse_calibration("Pinhole 500 500 424 400 0 0 0 0\n848 800\nfalse\n")["camera"]
+    assert (q.width, q.height, q.fx) == (848, 800, 500.0)
+    with pytest.raises(ValueError):
+        formats.parse_calibration("Bogus 1 2 3\n640 480\n")
+
+
+def test_stamp_file_formats(tmp_path):
+    f = tmp_path / "times.txt"
+    f.write_text("1403636579.763555527 0.1 0.2 0.3 0 0 0 1\n"      # TUM ground-truth style: stamp + pose
+                 "00017 1403636579.813555456 12.5\n"                # id stamp exposure
+                 "18 1403636579.863555584\n"                         # id stamp
+                 "1403636579.913555456\n\n")                         # stamp
+    assert formats.read_stamps(f) == ["1403636579.763555527", "1403636579.813555456", "1403636579.863555584",
+                                      "1403636579.913555456"]
+
+
+def test_images_without_opencv(tmp_path):
+    img = synth.config2_pair(10)["ref"][100:163, 200:297].copy()          # odd sizes
+    formats.write_pgm(tmp_path / "a.pgm", img)
+    assert (formats.read_pgm(tmp_path / "a.pgm") == img).all()
+    (tmp_path / "c.pgm").write_bytes(b"P5\n# a comment\n4 2\n255\n" + bytes(range(8)))
+    assert formats.read_pgm(tmp_path / "c.pgm").tolist() == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    formats.write_png(tmp_path / "000001.png", img)
+    assert (formats.read_png(tmp_path / "000001.png") == img).all()
+    # every PNG row filter: build the filtered rows by hand and let the reader undo them
+    import struct, zlib
+    rows = img[:5, :16].astype(np.int32)
+    raw = b""
+    for y, ft in enumerate([0, 1, 2, 3, 4]):
+        cur, prev = rows[y], rows[y - 1] if y else np.zeros(16, np.int32)
+        out = []
+        for x in range(16):
+            a = cur[x - 1] if x else 0
+            b = prev[x]
+            c = prev[x - 1] if x else 0
+            pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+            paeth = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            pred = [0, a, b, (a + b) >> 1, paeth][ft]
+            out.append((cur[x] - pred) & 255)
+        raw += bytes([ft]) + bytes(out)
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+    (tmp_path / "f.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 16, 5, 8, 0, 0, 0, 0)) +
+                                     chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    assert (formats.read_png(tmp_path / "f.png") == rows).all()
+    (tmp_path / "000000.jpg").write_bytes(b"x"); (tmp_path / "notes.txt").write_bytes(b"x")
+    assert [os.path.basename(p) for p in formats.list_images(tmp_path)] == ["000000.jpg", "000001.png", "f.png"]
+    with pytest.raises(ValueError):
+        formats.read_png(tmp_path / "a.pgm")
+
+
+def test_trajectory_file_and_ate(tmp_path):
+    rng = np.random.default_rng(4)
+    n = 40
+    kfs, centres = [], []
+    for k in range(n):
+        q = synth.rotvec_to_quat(rng.normal(size=3) * 0.2)
+        c = np.array([np.cos(k / 6.0), np.sin(k / 6.0), 0.05 * k]) * 2.0
+        t = -synth.quat_to_R(q) @ c                          # T_f_w: world -> frame
+        kfs.append(("%.6f" % (1403636579.0 + 0.05 * k), q, t))
+        centres.append(c)
+    centres = np.array(centres)
+    formats.write_trajectory(tmp_path / "traj.txt", kfs)
+    stamps, xyz, quat = formats.read_trajectory(tmp_path / "traj.txt")
+    assert stamps[3] == kfs[3][0] and len(xyz) == n
+    assert np.allclose(xyz, centres, rtol=2e-5, atol=1e-5)     # default stream precision: 6 significant digits
+    assert np.allclose(quat[5], [-kfs[5][1][0], -kfs[5][1][1], -kfs[5][1][2], kfs[5][1][3]], atol=1e-5)
+    # monocular result: unknown scale, arbitrary frame -> the similarity alignment recovers both
+    Rg = synth.quat_to_R(synth.rotvec_to_quat(np.array([0.3, -0.2, 0.9])))
+    est = (centres @ Rg.T) * 0.37 + np.array([4.0, -1.0, 2.5])
+    rmse, s, R, t = formats.ate_rmse(centres, est, with_scale=True)
+    assert rmse < 1e-9 and s == pytest.approx(1 / 0.37, rel=1e-9)
+    noisy = est + rng.normal(0, 0.01, est.shape)
+    rmse, s, _, _ = formats.ate_rmse(centres, noisy)
+    assert 0.02 < rmse < 0.08                                 # 0.01 of noise scaled back by 1 / 0.37, three axes
+    assert formats.ate_rmse(centres, est, with_scale=False)[0] > 0.5
