@@ -258,6 +258,7 @@ def load():
     lib.hso_gpu_abi_version.argtypes = []
     lib.hso_gpu_synchronize.argtypes = [vp]
     lib.hso_gpu_frame_upload.argtypes = [vp, i64, vp, i32, i32, i32, P(FrameStats)]
+    lib.hso_gpu_frame_upload_resized.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, P(FrameStats)]
     lib.hso_gpu_frame_upload_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.hso_gpu_frame_release.argtypes = [vp, i64]
     lib.hso_gpu_frame_download_level.argtypes = [vp, i64, i32, vp, P(i32), P(i32)]
@@ -299,7 +300,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
-    "hso_gpu_detect_candidates_init",
+    "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
 ]
 
 
@@ -359,6 +360,15 @@ class Context:
             h, w = img.shape
             rc = self.lib.hso_gpu_frame_upload(self.h, frame_id, _ptr(img), w, h, 0, C.byref(st))
         self._check(rc, "frame_upload")
+        return st
+
+    def frame_upload_resized(self, frame_id, img, width, height):
+        """Sensor image -> cv::resize to the camera size on the device -> Frame."""
+        st = FrameStats()
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        self._check(self.lib.hso_gpu_frame_upload_resized(self.h, frame_id, _ptr(img), w, h, width, height, 0, C.byref(st)),
+                    "frame_upload_resized")
         return st
 
     def frame_upload_batch(self, frame_ids, imgs=None, device_ptrs=None, width=None, height=None, want_stats=True):

@@ -63,4 +63,6 @@ int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg);
 // level-0 bytes are already in place at base+off[0].
 int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases, const uint8_t* const* d_srcs,
                     hso_frame_stats* d_stats, int n);
+// cv::resize INTER_LINEAR of a device image into a device buffer (hso_frame.hip)
+int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh);
 void hso_track_state_free(hso_gpu_ctx* ctx);

@@ -104,6 +104,54 @@ int hso_gpu_frame_upload(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img,
   return HSO_OK;
 }
 
+int hso_gpu_frame_upload_resized(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img, int src_width, int src_height,
+                                 int width, int height, int img_is_device, hso_frame_stats* stats_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!img || src_width <= 0 || src_height <= 0) return hso_fail(ctx, HSO_E_INVALID, "frame_upload_resized: null image or bad size");
+  if (src_width == width && src_height == height) return hso_gpu_frame_upload(ctx, frame_id, img, width, height, img_is_device, stats_out);
+  if ((width % 4) != 0 || width < 64 || height < 64)
+    return hso_fail(ctx, HSO_E_INVALID, "frame_upload_resized: width must be a multiple of 4, width and height >= 64");
+  if (ctx->frames.count(frame_id)) return hso_fail(ctx, HSO_E_INVALID, "frame_upload_resized: frame id already resident");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const uint8_t* d_src = img;
+  if (!img_is_device) {
+    const size_t need = (size_t)src_width * src_height;
+    if (ctx->batch_cap < need) {
+      HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+      ctx->d_batch = nullptr; ctx->batch_cap = 0;
+      HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+      ctx->batch_cap = need;
+    }
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_batch, img, need, hipMemcpyHostToDevice, ctx->stream));
+    d_src = reinterpret_cast<const uint8_t*>(ctx->d_batch);
+  }
+  FrameRec rec;
+  rec.id = frame_id;
+  rec.g = make_geom(width, height);
+  rec.base = nullptr;
+  if (!ctx->free_frames.empty() && ctx->free_frame_bytes == rec.g.frame_bytes) {
+    rec.base = ctx->free_frames.back();
+    ctx->free_frames.pop_back();
+  } else {
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&rec.base), rec.g.frame_bytes));
+    HSO_HIP_CHECK(ctx, hipMemsetAsync(rec.base, 0, rec.g.pyr_bytes, ctx->stream));
+  }
+  int rc = hso_frame_resize_into(ctx, d_src, src_width, src_height, rec.base + rec.g.off[0], width, height);
+  if (rc < 0) { (void)hipFree(rec.base); return rc; }
+  uint8_t** d_bases = reinterpret_cast<uint8_t**>(rec.base + rec.g.stats_off + 128);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_bases, &rec.base, sizeof(uint8_t*), hipMemcpyHostToDevice, ctx->stream));
+  rc = hso_frame_build(ctx, rec.g, d_bases, nullptr, nullptr, 1);
+  if (rc < 0) { (void)hipFree(rec.base); return rc; }
+  if (stats_out) {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(stats_out, rec.base + rec.g.stats_off, sizeof(hso_frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by later calls
+  ctx->frames[frame_id] = rec;
+  return HSO_OK;
+}
+
 int hso_gpu_frame_upload_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, const uint8_t* const* imgs, int n,
                                int width, int height, int img_is_device, hso_frame_stats* stats_out)
 {

@@ -108,22 +108,15 @@ __global__ __launch_bounds__(256) void k_copy_level0(PyrGeom g, uint8_t* const* 
   if (i < n) bases[blockIdx.y][g.off[0] + i] = srcs[blockIdx.y][i];
 }
 
-__global__ __launch_bounds__(256) void k_resize_level(PyrGeom g, uint8_t* const* bases, int l)
+// one output pixel of cv::resize(src, dst, Size(dw, dh)) with INTER_LINEAR, CV_8UC1
+HSO_DEV uint8_t resize_linear_px(const uint8_t* src, int sw, int sh, int dw, int dh, int dx, int dy)
 {
-  const int dw = g.w[l], dh = g.h[l], sw = g.w[l - 1], sh = g.h[l - 1];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= dw * dh) return;
-  const int dx = i % dw, dy = i / dw;
-  uint8_t* base = bases[blockIdx.y];
-  const uint8_t* src = base + g.off[l - 1];
-  uint8_t* dst = base + g.off[l];
   const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
   const int iscale_x = __double2int_rn(scale_x), iscale_y = __double2int_rn(scale_y);
   const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
   if (area_fast && iscale_x == 2 && iscale_y == 2) {
     const uint8_t* s0 = src + (size_t)(2 * dy) * sw + 2 * dx;
-    dst[(size_t)dy * dw + dx] = (uint8_t)((s0[0] + s0[1] + s0[sw] + s0[sw + 1] + 2) >> 2);
-    return;
+    return (uint8_t)((s0[0] + s0[1] + s0[sw] + s0[sw + 1] + 2) >> 2);
   }
   float fx = (float)((dx + 0.5) * scale_x - 0.5);
   int sx = (int)floor((double)fx);
@@ -144,7 +137,34 @@ __global__ __launch_bounds__(256) void k_resize_level(PyrGeom g, uint8_t* const*
     const uint8_t* S = src + (size_t)sy * sw;
     r[k] = tail ? (int)S[sx] * 2048 : (int)S[sx] * a0 + (int)S[sx + 1] * a1;
   }
-  dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r[0] >> 4)) >> 16) + ((b1 * (r[1] >> 4)) >> 16) + 2) >> 2);
+  return (uint8_t)((((b0 * (r[0] >> 4)) >> 16) + ((b1 * (r[1] >> 4)) >> 16) + 2) >> 2);
+}
+
+__global__ __launch_bounds__(256) void k_resize_level(PyrGeom g, uint8_t* const* bases, int l)
+{
+  const int dw = g.w[l], dh = g.h[l], sw = g.w[l - 1], sh = g.h[l - 1];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dw * dh) return;
+  const int dx = i % dw, dy = i / dw;
+  uint8_t* base = bases[blockIdx.y];
+  base[g.off[l] + (size_t)dy * dw + dx] = resize_linear_px(base + g.off[l - 1], sw, sh, dw, dh, dx, dy);
+}
+
+// ImageReader::readImage's cv::resize(image, image, m_img_new_size) (reference src/ImageReader.cpp:79):
+// the camera file's > 848x800 rule shrinks the sensor image before it becomes a Frame
+__global__ __launch_bounds__(256) void k_resize_image(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dw * dh) return;
+  const int dx = i % dw, dy = i / dw;
+  dst[(size_t)dy * dw + dx] = resize_linear_px(src, sw, sh, dw, dh, dx, dy);
+}
+
+int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh)
+{
+  hipLaunchKernelGGL(k_resize_image, dim3((dw * dh + 255) / 256), dim3(256), 0, ctx->stream, d_src, sw, sh, d_dst, dw, dh);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
 }
 
 // -------------------------------------------------------------------- Sobel

@@ -92,6 +92,13 @@ int hso_gpu_synchronize(hso_gpu_ctx* ctx);
 int hso_gpu_frame_upload(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img,
                          int width, int height, int img_is_device,
                          hso_frame_stats* stats_out);
+/* The same for a sensor image larger than the camera model: ImageReader::readImage's
+ * cv::resize(image, image, Size(cam.width, cam.height)) (src/ImageReader.cpp:79; the calibration
+ * loader shrinks anything above 848x800, test/test_dataset.cpp:162-173, e.g. TUM-mono 1280x1024 ->
+ * 920x736) runs on the device — OpenCV's INTER_LINEAR for CV_8UC1 restated, bit-exact with the
+ * oracle — and the result becomes level 0.  src == dst size: plain hso_gpu_frame_upload. */
+int hso_gpu_frame_upload_resized(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img, int src_width, int src_height,
+                                 int width, int height, int img_is_device, hso_frame_stats* stats_out);
 /* Batched form: n frames of one size in three launches.  imgs[i] are n HOST
  * pointers or n DEVICE pointers (img_is_device).  A frame id that is already
  * resident is refreshed in place (same size required) — the batched analogue of

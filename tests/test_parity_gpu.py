@@ -426,3 +426,35 @@ def test_resize_branch_frame_and_tracker(gpu_ctx, orc):
             assert levels[L].tobytes() == want.tobytes()
     finally:
         gpu_ctx.frame_release(910); gpu_ctx.frame_release(911)
+
+
+@pytest.mark.gpu
+def test_frame_upload_resized_tum_mono(gpu_ctx, orc):
+    """ImageReader::readImage's cv::resize to the downscaled camera size (1280x1024 -> 920x736, the
+    size test/cameras/tum_mono_vo_*.txt yields) on the device, then the cv::resize pyramid."""
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:1024, 0:1280]
+    img = (128 + 60 * np.sin(xx * 0.031) * np.cos(yy * 0.017) + rng.normal(0, 6, (1024, 1280))).clip(0, 255).astype(np.uint8)
+    st = gpu_ctx.frame_upload_resized(9620, img, 920, 736)
+    try:
+        want0 = orc.resize_linear(img, 920, 736)
+        pyr = orc.create_pyramid(want0)
+        for L in range(5):
+            got = gpu_ctx.frame_level(9620, L, 920, 736)
+            assert got.shape == pyr[L].shape and (got == pyr[L]).all(), L
+        gx, gy = orc.sobel5(np.ascontiguousarray(pyr[0]))
+        ggx, ggy = gpu_ctx.frame_sobel(9620, 0, 920, 736)
+        assert (ggx == gx).all() and (ggy == gy).all()
+        assert st.width == 920 and st.height == 736
+        # integer down-scales take the area-fast path; equal sizes are a plain upload
+        half = img[:512, :640]
+        st2 = gpu_ctx.frame_upload_resized(9621, half, 320, 256)
+        assert (gpu_ctx.frame_level(9621, 0, 320, 256) == orc.resize_linear(half, 320, 256)).all()
+        gpu_ctx.frame_release(9621)
+        gpu_ctx.frame_upload_resized(9621, half, 640, 512)
+        assert (gpu_ctx.frame_level(9621, 0, 640, 512) == half).all()
+        gpu_ctx.frame_release(9621)
+        with pytest.raises(capi.HsoGpuError):
+            gpu_ctx.frame_upload_resized(9621, half, 322, 256)          # width % 4
+    finally:
+        gpu_ctx.frame_release(9620)
