@@ -118,6 +118,10 @@ OBS_DTYPE = np.dtype([("kf", "<i4"), ("level", "<i4"), ("type", "<i4"), ("pad_",
 MAP_POINT_DTYPE = np.dtype([("pos", "<f8", 3), ("idist", "<f8"), ("host_f", "<f8", 3), ("host_kf", "<i4"),
                             ("obs_begin", "<i4"), ("obs_count", "<i4"), ("pad_", "<i4")])
 REPROJ_POINT_DTYPE = np.dtype([("projected", "<i4"), ("cell", "<i4"), ("px", "<f8", 2), ("ref_obs", "<i4"), ("pad_", "<i4")])
+REPROJ_FRAME_DTYPE = np.dtype([("cur_frame_id", "<i8"), ("q", "<f8", 4), ("t", "<f8", 3), ("cur_exposure_time", "<f8"),
+                               ("cur_keyframe_id", "<i4"), ("kf_begin", "<i4"), ("kf_count", "<i4"), ("point_begin", "<i4"),
+                               ("point_count", "<i4"), ("pad_", "<i4")])
+assert REPROJ_FRAME_DTYPE.itemsize == 96
 assert (KF_DTYPE.itemsize, OBS_DTYPE.itemsize, MAP_POINT_DTYPE.itemsize, REPROJ_POINT_DTYPE.itemsize) == (80, 72, 72, 32)
 
 
@@ -284,6 +288,7 @@ def load():
     lib.hso_gpu_detect_candidates.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
     lib.hso_gpu_detect_candidates_init.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
     lib.hso_gpu_select_octree.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
+    lib.hso_gpu_reproject_match_multi.argtypes = [vp, P(Camera), vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp]
     lib.hso_gpu_reproject_match.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, i32, vp, i32, vp, i32, vp, i32, i32, i32,
                                             vp, vp]
     _lib = lib
@@ -301,6 +306,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
+    "hso_gpu_reproject_match_multi",
 ]
 
 
@@ -477,6 +483,19 @@ class Context:
         self._check(self.lib.hso_gpu_reproject_match(self.h, C.byref(cam), cur_frame_id, C.byref(T_cur_w), cur_exposure_time,
                                                      cur_keyframe_id, _ptr(kfs), len(kfs), _ptr(points), len(points), _ptr(obs),
                                                      len(obs), cell_size, grid_n_cols, _ptr(proj), match), "reproject_match")
+        return proj, match
+
+    def reproject_match_multi(self, cam, frames, kfs, points, obs, cell_size, grid_n_cols):
+        """frames: REPROJ_FRAME_DTYPE array (one row per current frame); tables as in reproject_match,
+        with host_kf / obs kf relative to the owning frame's kf_begin."""
+        frames = np.ascontiguousarray(frames, REPROJ_FRAME_DTYPE)
+        kfs = np.ascontiguousarray(kfs, KF_DTYPE); points = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+        obs = np.ascontiguousarray(obs, OBS_DTYPE)
+        proj = np.zeros(len(points), REPROJ_POINT_DTYPE)
+        match = (AlignOut * max(len(points), 1))()
+        self._check(self.lib.hso_gpu_reproject_match_multi(self.h, C.byref(cam), _ptr(frames), len(frames), _ptr(kfs), len(kfs),
+                                                           _ptr(points), len(points), _ptr(obs), len(obs), cell_size, grid_n_cols,
+                                                           _ptr(proj), match), "reproject_match_multi")
         return proj, match
 
     def align_multi(self, cam, cur_frame_ids, jobs, as_list=True):

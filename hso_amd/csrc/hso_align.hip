@@ -130,10 +130,18 @@ struct ReprojKf {
   int32_t kf_gap_lt4;
 };
 
-struct ReprojConsts {
-  hso_camera cam;
+// the frame a point is projected into (points of many current frames / sequences share a launch);
+// its keyframes are kfs[kf_begin ...], and the points' keyframe indices are relative to that
+struct ReprojFrameDev {
   double cur_pos[3];
   const uint8_t* cur_base;
+  int kf_begin, pad_;
+};
+
+struct ReprojConsts {
+  hso_camera cam;
+  const ReprojFrameDev* frames;
+  const int* pt_frame;       // frame index of every point
   const ReprojKf* kfs;
   const hso_map_point* pts;
   const hso_obs* obs;
@@ -145,12 +153,14 @@ __global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* 
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R.n_pts) return;
   const hso_map_point P = R.pts[i];
+  const ReprojFrameDev& F = R.frames[R.pt_frame[i]];
+  const ReprojKf* const kfs = R.kfs + F.kf_begin;
   hso_reproj_point o;
   o.projected = 0; o.cell = 0; o.px[0] = 0; o.px[1] = 0; o.ref_obs = -1; o.pad_ = 0;
   AlignJobDev* JD = &jobs[i];
-  JD->ref_base = nullptr; JD->cur_base = R.cur_base;
+  JD->ref_base = nullptr; JD->cur_base = F.cur_base;
   // reprojectPoint, :504-529
-  const ReprojKf& H = R.kfs[P.host_kf];
+  const ReprojKf& H = kfs[P.host_kf];
   const double s = 1.0 / P.idist;
   double tx, ty, tz;
   se3_apply(H.T_cur_kf, P.host_f[0] * s, P.host_f[1] * s, P.host_f[2] * s, tx, ty, tz);
@@ -166,12 +176,12 @@ __global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* 
   }
   if (o.projected && P.obs_count > 0) {
     // getCloseViewObs, src/point.cpp:116-136
-    double ox = R.cur_pos[0] - P.pos[0], oy = R.cur_pos[1] - P.pos[1], oz = R.cur_pos[2] - P.pos[2];
+    double ox = F.cur_pos[0] - P.pos[0], oy = F.cur_pos[1] - P.pos[1], oz = F.cur_pos[2] - P.pos[2];
     { const double n = sqrt(ox * ox + oy * oy + oz * oz); ox /= n; oy /= n; oz /= n; }
     int best = 0;
     double min_cos = 0;
     for (int k = 0; k < P.obs_count; k++) {
-      const ReprojKf& K = R.kfs[R.obs[P.obs_begin + k].kf];
+      const ReprojKf& K = kfs[R.obs[P.obs_begin + k].kf];
       double dx = K.pos[0] - P.pos[0], dy = K.pos[1] - P.pos[1], dz = K.pos[2] - P.pos[2];
       { const double n = sqrt(dx * dx + dy * dy + dz * dz); dx /= n; dy /= n; dz /= n; }
       const double c = ox * dx + oy * dy + oz * dz;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* 
     if (!(min_cos < 0.5)) {
       o.ref_obs = P.obs_begin + best;
       const hso_obs ref = R.obs[o.ref_obs];
-      const ReprojKf& K = R.kfs[ref.kf];
+      const ReprojKf& K = kfs[ref.kf];
       hso_align_job j;
       j.ref_frame_id = K.frame_id;
       j.ref_level = ref.level; j.type = ref.type;
@@ -218,51 +228,70 @@ __global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align_sparse(Ali
   if (lane == 0) outs[jid] = o;
 }
 
-extern "C" int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* T_cur_w,
-                                       double cur_exposure_time, int cur_keyframe_id, const hso_kf* kfs, int n_kfs,
-                                       const hso_map_point* points, int n_points, const hso_obs* obs, int n_obs, int cell_size,
-                                       int grid_n_cols, hso_reproj_point* proj_out, hso_align_out* match_out)
+extern "C" int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_reproj_frame* frames, int n_frames,
+                                             const hso_kf* kfs, int n_kfs, const hso_map_point* points, int n_points,
+                                             const hso_obs* obs, int n_obs, int cell_size, int grid_n_cols,
+                                             hso_reproj_point* proj_out, hso_align_out* match_out)
 {
   if (!ctx) return HSO_E_INVALID;
-  if (!cam || !T_cur_w || n_kfs < 0 || n_points < 0 || n_obs < 0 || cell_size < 1 || grid_n_cols < 1 ||
-      (n_points > 0 && (!points || !proj_out || !match_out || !kfs || n_kfs == 0)) || (n_obs > 0 && !obs))
+  if (!cam || n_frames < 0 || n_kfs < 0 || n_points < 0 || n_obs < 0 || cell_size < 1 || grid_n_cols < 1 ||
+      (n_points > 0 && (!points || !proj_out || !match_out || !kfs || n_kfs == 0 || !frames || n_frames == 0)) || (n_obs > 0 && !obs))
     return hso_fail(ctx, HSO_E_INVALID, "reproject_match: bad argument");
   if (n_points == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  auto itc = ctx->frames.find(cur_frame_id);
-  if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match: current frame not resident");
-  const PyrGeom g = itc->second.g;
-  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: camera size differs from the frame size");
-  const Se3 Tc = se3_from(*T_cur_w);
+  PyrGeom g{};
   std::vector<ReprojKf> hk(n_kfs);
-  for (int k = 0; k < n_kfs; k++) {
-    auto it = ctx->frames.find(kfs[k].frame_id);
-    if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match: keyframe not resident");
-    if (it->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frames must share one size");
-    const Se3 inv = se3_inverse(se3_from(kfs[k].T_f_w));
-    hk[k].T_cur_kf = se3_mul(Tc, inv);
-    hk[k].pos[0] = inv.tx; hk[k].pos[1] = inv.ty; hk[k].pos[2] = inv.tz;
-    hk[k].base = it->second.base;
-    hk[k].frame_id = kfs[k].frame_id;
-    hk[k].exposure_rat = (float)(cur_exposure_time / kfs[k].exposure_time);
-    hk[k].kf_gap_lt4 = (cur_keyframe_id - kfs[k].keyframe_id) < 4;
+  std::vector<ReprojFrameDev> hf(n_frames);
+  std::vector<int> pt_frame(n_points, -1);
+  for (int f = 0; f < n_frames; f++) {
+    const hso_reproj_frame& FR = frames[f];
+    auto itc = ctx->frames.find(FR.cur_frame_id);
+    if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match: current frame not resident");
+    if (f == 0) g = itc->second.g;
+    else if (itc->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frames must share one size");
+    if (FR.kf_begin < 0 || FR.kf_count < 0 || (long long)FR.kf_begin + FR.kf_count > n_kfs || FR.point_begin < 0 || FR.point_count < 0 ||
+        (long long)FR.point_begin + FR.point_count > n_points)
+      return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frame table out of range");
+    const Se3 Tc = se3_from(FR.T_cur_w);
+    const Se3 ci = se3_inverse(Tc);
+    hf[f].cur_pos[0] = ci.tx; hf[f].cur_pos[1] = ci.ty; hf[f].cur_pos[2] = ci.tz;
+    hf[f].cur_base = itc->second.base; hf[f].kf_begin = FR.kf_begin; hf[f].pad_ = 0;
+    for (int k = FR.kf_begin; k < FR.kf_begin + FR.kf_count; k++) {
+      auto it = ctx->frames.find(kfs[k].frame_id);
+      if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match: keyframe not resident");
+      if (it->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frames must share one size");
+      const Se3 inv = se3_inverse(se3_from(kfs[k].T_f_w));
+      hk[k].T_cur_kf = se3_mul(Tc, inv);
+      hk[k].pos[0] = inv.tx; hk[k].pos[1] = inv.ty; hk[k].pos[2] = inv.tz;
+      hk[k].base = it->second.base;
+      hk[k].frame_id = kfs[k].frame_id;
+      hk[k].exposure_rat = (float)(FR.cur_exposure_time / kfs[k].exposure_time);
+      hk[k].kf_gap_lt4 = (FR.cur_keyframe_id - kfs[k].keyframe_id) < 4;
+    }
+    // the index tables are the caller's: check them here, the kernels trust them
+    for (int i = FR.point_begin; i < FR.point_begin + FR.point_count; i++) {
+      const hso_map_point& p = points[i];
+      if (pt_frame[i] != -1) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: point ranges of two frames overlap");
+      pt_frame[i] = f;
+      if (p.host_kf < 0 || p.host_kf >= FR.kf_count || p.obs_count < 0 || p.obs_begin < 0 || (long long)p.obs_begin + p.obs_count > n_obs)
+        return hso_fail(ctx, HSO_E_INVALID, "reproject_match: point table out of range");
+      for (int k = p.obs_begin; k < p.obs_begin + p.obs_count; k++)
+        if (obs[k].kf < 0 || obs[k].kf >= FR.kf_count || obs[k].level < 0 || obs[k].level >= HSO_N_PYR_LEVELS)
+          return hso_fail(ctx, HSO_E_INVALID, "reproject_match: observation table out of range");
+    }
   }
-  // the index tables are the caller's: check them here, the kernels trust them
-  for (int i = 0; i < n_points; i++) {
-    const hso_map_point& p = points[i];
-    if (p.host_kf < 0 || p.host_kf >= n_kfs || p.obs_count < 0 || p.obs_begin < 0 || (long long)p.obs_begin + p.obs_count > n_obs)
-      return hso_fail(ctx, HSO_E_INVALID, "reproject_match: point table out of range");
-  }
-  for (int i = 0; i < n_obs; i++)
-    if (obs[i].kf < 0 || obs[i].kf >= n_kfs || obs[i].level < 0 || obs[i].level >= HSO_N_PYR_LEVELS)
-      return hso_fail(ctx, HSO_E_INVALID, "reproject_match: observation table out of range");
+  for (int i = 0; i < n_points; i++)
+    if (pt_frame[i] < 0) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: a point belongs to no frame");
+  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: camera size differs from the frame size");
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t o_jobs = 0, o_out = o_jobs + al(sizeof(AlignJobDev) * (size_t)n_points);
   const size_t o_proj = o_out + al(sizeof(hso_align_out) * (size_t)n_points);
   const size_t o_kf = o_proj + al(sizeof(hso_reproj_point) * (size_t)n_points);
   const size_t o_pts = o_kf + al(sizeof(ReprojKf) * (size_t)n_kfs);
   const size_t o_obs = o_pts + al(sizeof(hso_map_point) * (size_t)n_points);
-  const size_t need = o_obs + al(sizeof(hso_obs) * (size_t)(n_obs > 0 ? n_obs : 1));
+  const size_t o_fr = o_obs + al(sizeof(hso_obs) * (size_t)(n_obs > 0 ? n_obs : 1));
+  const size_t o_pf = o_fr + al(sizeof(ReprojFrameDev) * (size_t)n_frames);
+  const size_t need = o_pf + al(sizeof(int) * (size_t)n_points);
   if (ctx->batch_cap < need) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -274,14 +303,13 @@ extern "C" int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, 
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_kf, hk.data(), sizeof(ReprojKf) * (size_t)n_kfs, hipMemcpyHostToDevice, ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pts, points, sizeof(hso_map_point) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
   if (n_obs > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_obs, obs, sizeof(hso_obs) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_fr, hf.data(), sizeof(ReprojFrameDev) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pf, pt_frame.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_out, 0, sizeof(hso_align_out) * (size_t)n_points, ctx->stream));
   ReprojConsts R;
   R.cam = *cam;
-  {
-    const Se3 ci = se3_inverse(Tc);
-    R.cur_pos[0] = ci.tx; R.cur_pos[1] = ci.ty; R.cur_pos[2] = ci.tz;
-  }
-  R.cur_base = itc->second.base;
+  R.frames = reinterpret_cast<const ReprojFrameDev*>(d + o_fr);
+  R.pt_frame = reinterpret_cast<const int*>(d + o_pf);
   R.kfs = reinterpret_cast<const ReprojKf*>(d + o_kf);
   R.pts = reinterpret_cast<const hso_map_point*>(d + o_pts);
   R.obs = reinterpret_cast<const hso_obs*>(d + o_obs);
@@ -299,4 +327,17 @@ extern "C" int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, 
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(match_out, d_out, sizeof(hso_align_out) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
+}
+
+extern "C" int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* T_cur_w,
+                                       double cur_exposure_time, int cur_keyframe_id, const hso_kf* kfs, int n_kfs,
+                                       const hso_map_point* points, int n_points, const hso_obs* obs, int n_obs, int cell_size,
+                                       int grid_n_cols, hso_reproj_point* proj_out, hso_align_out* match_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!T_cur_w) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: bad argument");
+  hso_reproj_frame f;
+  f.cur_frame_id = cur_frame_id; f.T_cur_w = *T_cur_w; f.cur_exposure_time = cur_exposure_time; f.cur_keyframe_id = cur_keyframe_id;
+  f.kf_begin = 0; f.kf_count = n_kfs; f.point_begin = 0; f.point_count = n_points; f.pad_ = 0;
+  return hso_gpu_reproject_match_multi(ctx, cam, &f, 1, kfs, n_kfs, points, n_points, obs, n_obs, cell_size, grid_n_cols, proj_out, match_out);
 }

@@ -141,6 +141,24 @@ def main():
                     ms_per_call=dt * 1e3, units_per_s=len(proj) / dt, projected=int(proj["projected"].sum()),
                     matched=sum(m.success for m in match)))
 
+    # the same for 64 sequences in one launch (the tables replicated; the resident frames are shared)
+    nrep = 64
+    q_cur, t_cur = M["T_cur_w"].to_arrays()
+    frames = np.zeros(nrep, capi.REPROJ_FRAME_DTYPE)
+    pts_all, obs_all = [], []
+    for r in range(nrep):
+        frames[r]["cur_frame_id"], frames[r]["q"], frames[r]["t"] = M["cur_frame_id"], q_cur, t_cur
+        frames[r]["cur_exposure_time"], frames[r]["cur_keyframe_id"] = M["cur_exposure"], M["cur_keyframe_id"]
+        frames[r]["kf_begin"], frames[r]["kf_count"] = r * len(M["kfs"]), len(M["kfs"])
+        frames[r]["point_begin"], frames[r]["point_count"] = r * len(M["points"]), len(M["points"])
+        pts = M["points"].copy(); pts["obs_begin"] += r * len(M["obs"])
+        pts_all.append(pts); obs_all.append(M["obs"])
+    kfs_all, pts_all, obs_all = np.concatenate([M["kfs"]] * nrep), np.concatenate(pts_all), np.concatenate(obs_all)
+    dt = timed(lambda: ctx.reproject_match_multi(cam, frames, kfs_all, pts_all, obs_all, M["cell_size"], M["grid_n_cols"]),
+               max(args.reps // 4, 2))
+    out.append(dict(stage="reproject_match_multi x64 frames", units="map points", n=len(pts_all), ms_per_call=dt * 1e3,
+                    units_per_s=len(pts_all) / dt))
+
     for o in out:
         print(json.dumps(o))
 

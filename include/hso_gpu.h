@@ -330,6 +330,24 @@ int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur
                             const hso_map_point* points, int n_points, const hso_obs* obs, int n_obs,
                             int cell_size, int grid_n_cols, hso_reproj_point* proj_out, hso_align_out* match_out);
 
+/* The same for the current frames of many sequences in one launch.  Frame f owns the keyframes
+ * kfs[kf_begin .. kf_begin + kf_count) and the points points[point_begin .. + point_count); inside
+ * those points host_kf and obs[].kf count from the frame's kf_begin (obs_begin stays absolute).
+ * Every point must belong to exactly one frame. */
+typedef struct hso_reproj_frame {
+  int64_t cur_frame_id;
+  hso_se3 T_cur_w;
+  double cur_exposure_time;
+  int32_t cur_keyframe_id;
+  int32_t kf_begin, kf_count;
+  int32_t point_begin, point_count;
+  int32_t pad_;
+} hso_reproj_frame;
+int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_reproj_frame* frames, int n_frames,
+                                  const hso_kf* kfs, int n_kfs, const hso_map_point* points, int n_points,
+                                  const hso_obs* obs, int n_obs, int cell_size, int grid_n_cols,
+                                  hso_reproj_point* proj_out, hso_align_out* match_out);
+
 /* ---- pose_optimizer::optimizeLevenbergMarquardt3rd, src/pose_optimizer.cpp:399-771 ---- */
 
 /* One feature of the frame being optimised, in Frame::fts_ order.  has_point = 0 keeps the

@@ -175,3 +175,55 @@ def test_reproject_match_argument_errors(gpu_ctx):
     finally:
         for i in ids + [P["cur_frame_id"]]:
             gpu_ctx.frame_release(i)
+
+
+@pytest.mark.gpu
+def test_reproject_match_multi_equals_per_frame_calls(gpu_ctx):
+    """Two sequences (their own keyframes, points, current frames) in one launch: every point gets
+    exactly the result of its sequence's single call."""
+    cam = synth.camera()
+    A = synth.map_problem(n_points=400, first_frame_id=9870, seed=71)
+    B = synth.map_problem(n_points=300, first_frame_id=9885, seed=93, n_kfs=4)
+    up = []
+    for P in (A, B):
+        for k, f in zip(P["kfs"], P["frames"]):
+            gpu_ctx.frame_upload(int(k["frame_id"]), f); up.append(int(k["frame_id"]))
+        gpu_ctx.frame_upload(P["cur_frame_id"], P["cur"]); up.append(P["cur_frame_id"])
+    try:
+        solo = [gpu_ctx.reproject_match(cam, P["cur_frame_id"], P["T_cur_w"], P["cur_exposure"], P["cur_keyframe_id"], P["kfs"],
+                                        P["points"], P["obs"], P["cell_size"], P["grid_n_cols"]) for P in (A, B)]
+        frames = np.zeros(2, capi.REPROJ_FRAME_DTYPE)
+        kf_at = pt_at = ob_at = 0
+        pts_all, obs_all = [], []
+        for r, P in enumerate((A, B)):
+            q, t = P["T_cur_w"].to_arrays()
+            frames[r]["cur_frame_id"], frames[r]["q"], frames[r]["t"] = P["cur_frame_id"], q, t
+            frames[r]["cur_exposure_time"], frames[r]["cur_keyframe_id"] = P["cur_exposure"], P["cur_keyframe_id"]
+            frames[r]["kf_begin"], frames[r]["kf_count"] = kf_at, len(P["kfs"])
+            frames[r]["point_begin"], frames[r]["point_count"] = pt_at, len(P["points"])
+            pts = P["points"].copy(); pts["obs_begin"] += ob_at              # obs_begin is absolute, keyframe indices stay relative
+            pts_all.append(pts); obs_all.append(P["obs"])
+            kf_at += len(P["kfs"]); pt_at += len(pts); ob_at += len(P["obs"])
+        proj, match = gpu_ctx.reproject_match_multi(cam, frames, np.concatenate([A["kfs"], B["kfs"]]), np.concatenate(pts_all),
+                                                    np.concatenate(obs_all), A["cell_size"], A["grid_n_cols"])
+        at = ob = 0
+        for (sp, sm), P in zip(solo, (A, B)):
+            n = len(P["points"])
+            want = sp.copy()
+            want["ref_obs"] = np.where(want["ref_obs"] >= 0, want["ref_obs"] + ob, -1)
+            assert proj[at:at + n].tobytes() == want.tobytes()
+            for i in range(n):
+                g, w = match[at + i], sm[i]
+                assert bytes(C.string_at(C.addressof(g), C.sizeof(g))) == bytes(C.string_at(C.addressof(w), C.sizeof(w))), i
+            at += n; ob += len(P["obs"])
+        assert sum(m.success for m in match) > 350
+        # a point outside every frame's range, and overlapping ranges, are refused
+        bad = frames.copy(); bad[1]["point_count"] -= 1
+        with pytest.raises(capi.HsoGpuError, match="no frame"):
+            gpu_ctx.reproject_match_multi(cam, bad, np.concatenate([A["kfs"], B["kfs"]]), np.concatenate(pts_all), np.concatenate(obs_all), 23, 28)
+        bad = frames.copy(); bad[1]["point_begin"] -= 1
+        with pytest.raises(capi.HsoGpuError, match="overlap|no frame"):
+            gpu_ctx.reproject_match_multi(cam, bad, np.concatenate([A["kfs"], B["kfs"]]), np.concatenate(pts_all), np.concatenate(obs_all), 23, 28)
+    finally:
+        for i in up:
+            gpu_ctx.frame_release(i)
