@@ -159,6 +159,48 @@ def main():
     out.append(dict(stage="reproject_match_multi x64 frames", units="map points", n=len(pts_all), ms_per_call=dt * 1e3,
                     units_per_s=len(pts_all) / dt))
 
+    # ---- the per-frame chain for 256 sequences, every stage in its multi-sequence form (inputs are
+    # independent synthetic problems of realistic size sharing resident frames, not one chained
+    # state: a sum of stage times, not an end-to-end VO run)
+    nseq = 256
+    pairs = [synth.config2_pair(2000, seed=1234 + 7 * k) for k in range(4)]
+    ref_ids, cur_ids2 = list(range(20000, 20000 + nseq)), list(range(21000, 21000 + nseq))
+    st_r = ctx.frame_upload_batch(ref_ids, imgs=[pairs[i % 4]["ref"] for i in range(nseq)])
+    st_c = ctx.frame_upload_batch(cur_ids2, imgs=[pairs[i % 4]["cur"] for i in range(nseq)])
+    tjobs = [ctx.make_job(ref_ids[i], cur_ids2[i], pairs[i % 4]["feats"], capi.SE3.identity(),
+                          float(np.float32(st_c[i].integral_image / st_r[i].integral_image))) for i in range(nseq)]
+    ctx.coarse_track_prepare(cam, capi.TrackParams(0, 4, 1, 50), tjobs)
+
+    def track():
+        ctx.frame_upload_batch(cur_ids2, imgs=[pairs[i % 4]["cur"] for i in range(nseq)], want_stats=False)
+        ctx.coarse_track_launch()
+        return ctx.coarse_track_collect()
+    t_track = timed(track, 3)
+    M1 = synth.map_problem(n_points=1000, first_frame_id=7000)      # frames 7000.. are still resident
+    fr = np.zeros(nseq, capi.REPROJ_FRAME_DTYPE)
+    pa, oa = [], []
+    for r in range(nseq):
+        fr[r]["cur_frame_id"], fr[r]["q"], fr[r]["t"] = M1["cur_frame_id"], q_cur, t_cur
+        fr[r]["cur_exposure_time"], fr[r]["cur_keyframe_id"] = M1["cur_exposure"], M1["cur_keyframe_id"]
+        fr[r]["kf_begin"], fr[r]["kf_count"] = r * len(M1["kfs"]), len(M1["kfs"])
+        fr[r]["point_begin"], fr[r]["point_count"] = r * len(M1["points"]), len(M1["points"])
+        pts = M1["points"].copy(); pts["obs_begin"] += r * len(M1["obs"])
+        pa.append(pts); oa.append(M1["obs"])
+    ka, pa, oa = np.concatenate([M1["kfs"]] * nseq), np.concatenate(pa), np.concatenate(oa)
+    t_reproj = timed(lambda: ctx.reproject_match_multi(cam, fr, ka, pa, oa, M1["cell_size"], M1["grid_n_cols"]), 3)
+    t_pose = timed(lambda: ctx.pose_optimize_batch(cam, pj[:nseq]), 3)
+    ctx.frame_upload(1, pair["ref"]); ctx.frame_upload(2, pair["cur"])
+    big2 = (capi.Seed * (nseq * len(seeds)))()
+    for q in range(nseq):
+        for i, sd in enumerate(seeds):
+            C.memmove(C.byref(big2[q * len(seeds) + i]), C.byref(sd), C.sizeof(capi.Seed))
+    sf2 = np.repeat(np.arange(nseq, dtype=np.int32), len(seeds))
+    t_seed = timed(lambda: ctx.seed_observe_multi(cam, [(2, T_cur, 1.05)] * nseq, sf2, pea, big2, as_list=False), 3)
+    total = t_track + t_reproj + t_pose + t_seed
+    out.append(dict(stage="per-frame chain x256 sequences (frame build + track 2000 pts, 1000 map points, pose 300 fts, 900 seeds)",
+                    units="frames", n=nseq, ms_per_call=total * 1e3, units_per_s=nseq / total,
+                    ms_track=t_track * 1e3, ms_reproject=t_reproj * 1e3, ms_pose=t_pose * 1e3, ms_seeds=t_seed * 1e3))
+
     for o in out:
         print(json.dumps(o))
 
