@@ -20,6 +20,7 @@
 // taps per candidate); in practice latency-bound per candidate and throughput comes from
 // having thousands of candidates in flight.
 #include "hso_match_dev.h"
+#include <string.h>
 #include <vector>
 
 using namespace hso_dev;
@@ -58,7 +59,9 @@ static int align_run(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur
   if (n_jobs == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PyrGeom g{};
-  std::vector<AlignJobDev> h(n_jobs);
+  AlignJobDev* h = reinterpret_cast<AlignJobDev*>(hso_pinned(ctx, 0, (size_t)n_jobs * sizeof(AlignJobDev)));
+  hso_align_out* h_out = reinterpret_cast<hso_align_out*>(hso_pinned(ctx, 1, (size_t)n_jobs * sizeof(hso_align_out)));
+  if (!h || !h_out) return HSO_E_NOMEM;
   int64_t last_id = 0;
   const uint8_t* last_base = nullptr;
   for (int i = 0; i < n_jobs; i++) {
@@ -90,14 +93,15 @@ static int align_run(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur
   }
   AlignJobDev* d_jobs = reinterpret_cast<AlignJobDev*>(ctx->d_batch);
   hso_align_out* d_out = reinterpret_cast<hso_align_out*>(ctx->d_batch + b_jobs);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, h.data(), (size_t)n_jobs * sizeof(AlignJobDev), hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, h, (size_t)n_jobs * sizeof(AlignJobDev), hipMemcpyHostToDevice, ctx->stream));
   AlignConsts C;
   C.cam = *cam; C.g = g;
   const int blocks = (n_jobs + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK;
   hipLaunchKernelGGL(k_align, dim3(blocks), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream, C, d_jobs, n_jobs, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_jobs * sizeof(hso_align_out), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n_jobs * sizeof(hso_align_out), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, h_out, (size_t)n_jobs * sizeof(hso_align_out));
   return HSO_OK;
 }
 
@@ -300,11 +304,32 @@ extern "C" int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera*
     ctx->batch_cap = need;
   }
   char* d = ctx->d_batch;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_kf, hk.data(), sizeof(ReprojKf) * (size_t)n_kfs, hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pts, points, sizeof(hso_map_point) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
-  if (n_obs > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_obs, obs, sizeof(hso_obs) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_fr, hf.data(), sizeof(ReprojFrameDev) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pf, pt_frame.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
+  // Small calls (one keyframe-sized sequence) are latency-bound: one pinned staging image of
+  // [kf | points | obs | frames | point->frame] and one DMA each way.  Large multi-sequence tables
+  // go straight from the caller's memory (the runtime pipelines pageable copies in chunks, which
+  // beats an extra host pass over tens of megabytes); only the small derived tables are staged.
+  const size_t in_bytes = need - o_kf;
+  const bool small = in_bytes < ((size_t)1 << 20);
+  char* hin = hso_pinned(ctx, 0, small ? in_bytes : (o_pts - o_kf) + (need - o_fr));
+  char* hout = small ? hso_pinned(ctx, 1, o_kf - o_out) : nullptr;
+  if (!hin || (small && !hout)) return HSO_E_NOMEM;
+  if (small) {
+    memcpy(hin, hk.data(), sizeof(ReprojKf) * (size_t)n_kfs);
+    memcpy(hin + (o_pts - o_kf), points, sizeof(hso_map_point) * (size_t)n_points);
+    if (n_obs > 0) memcpy(hin + (o_obs - o_kf), obs, sizeof(hso_obs) * (size_t)n_obs);
+    memcpy(hin + (o_fr - o_kf), hf.data(), sizeof(ReprojFrameDev) * (size_t)n_frames);
+    memcpy(hin + (o_pf - o_kf), pt_frame.data(), sizeof(int) * (size_t)n_points);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_kf, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    char* hfr = hin + (o_pts - o_kf);
+    memcpy(hin, hk.data(), sizeof(ReprojKf) * (size_t)n_kfs);
+    memcpy(hfr, hf.data(), sizeof(ReprojFrameDev) * (size_t)n_frames);
+    memcpy(hfr + (o_pf - o_fr), pt_frame.data(), sizeof(int) * (size_t)n_points);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_kf, hin, sizeof(ReprojKf) * (size_t)n_kfs, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_fr, hfr, need - o_fr, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pts, points, sizeof(hso_map_point) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
+    if (n_obs > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_obs, obs, sizeof(hso_obs) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+  }
   HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_out, 0, sizeof(hso_align_out) * (size_t)n_points, ctx->stream));
   ReprojConsts R;
   R.cam = *cam;
@@ -323,9 +348,16 @@ extern "C" int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera*
   hipLaunchKernelGGL(k_align_sparse, dim3((n_points + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0,
                      ctx->stream, C, d_jobs, n_points, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(proj_out, d_proj, sizeof(hso_reproj_point) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(match_out, d_out, sizeof(hso_align_out) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (small) {  // [match | proj] are adjacent on the device: one DMA into pinned memory, then to the caller
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(hout, d + o_out, o_kf - o_out, hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(match_out, hout, sizeof(hso_align_out) * (size_t)n_points);
+    memcpy(proj_out, hout + (o_proj - o_out), sizeof(hso_reproj_point) * (size_t)n_points);
+  } else {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(proj_out, d_proj, sizeof(hso_reproj_point) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(match_out, d_out, sizeof(hso_align_out) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return HSO_OK;
 }
 

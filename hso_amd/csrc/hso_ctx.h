@@ -46,6 +46,9 @@ struct hso_gpu_ctx {
   TrackBatchState* track;
   // staging for batched frame uploads: [bases | srcs | stats]
   char* d_batch; size_t batch_cap;
+  // pinned host staging (grow-only): record tables go through it so the DMA runs at PCIe rate
+  // instead of the pageable-memory rate, and the per-call std::vector + page faults disappear
+  char* h_pin[2]; size_t h_pin_cap[2];
 };
 
 #define HSO_HIP_CHECK(ctx, expr)                                              \
@@ -58,6 +61,9 @@ struct hso_gpu_ctx {
   } while (0)
 
 int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg);
+// pinned staging buffer `slot` (0: inputs, 1: results) of at least `bytes`; nullptr if the allocation fails.
+// Contents are only valid until the next call that uses the slot; every entry point synchronises before it returns.
+char* hso_pinned(hso_gpu_ctx* ctx, int slot, size_t bytes);
 
 // frame kernels (hso_frame.hip): build pyramid + Sobel + stats for `n` frames whose
 // level-0 bytes are already in place at base+off[0].

@@ -27,6 +27,8 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   ctx->free_frame_bytes = 0;
   ctx->d_batch = nullptr;
   ctx->batch_cap = 0;
+  ctx->h_pin[0] = ctx->h_pin[1] = nullptr;
+  ctx->h_pin_cap[0] = ctx->h_pin_cap[1] = 0;
   if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     ctx->own_stream = false;
@@ -50,8 +52,20 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   for (auto& kv : ctx->frames) (void)hipFree(kv.second.base);
   for (auto* p : ctx->free_frames) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+  for (int k = 0; k < 2; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+extern "C++" char* hso_pinned(hso_gpu_ctx* ctx, int slot, size_t bytes)
+{
+  if (ctx->h_pin_cap[slot] >= bytes && ctx->h_pin[slot]) return ctx->h_pin[slot];
+  if (ctx->h_pin[slot]) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->h_pin[slot]); ctx->h_pin[slot] = nullptr; ctx->h_pin_cap[slot] = 0; }
+  const size_t cap = bytes + bytes / 2 + 4096;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return nullptr; }
+  ctx->h_pin[slot] = static_cast<char*>(p); ctx->h_pin_cap[slot] = cap;
+  return ctx->h_pin[slot];
 }
 
 const char* hso_gpu_last_error(const hso_gpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

@@ -413,7 +413,9 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
     hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = frames[k].exposure_time;
   }
   if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: camera size differs from the frame size");
-  std::vector<SeedDev> h(n_seeds);
+  SeedDev* h = reinterpret_cast<SeedDev*>(hso_pinned(ctx, 0, (size_t)n_seeds * sizeof(SeedDev)));
+  hso_seed_out* h_out = reinterpret_cast<hso_seed_out*>(hso_pinned(ctx, 1, (size_t)n_seeds * sizeof(hso_seed_out)));
+  if (!h || !h_out) return HSO_E_NOMEM;
   int64_t last_id = -1;
   const uint8_t* last_base = nullptr;
   for (int i = 0; i < n_seeds; i++) {
@@ -443,15 +445,16 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
   SeedDev* d_in = reinterpret_cast<SeedDev*>(ctx->d_batch);
   hso_seed_out* d_out = reinterpret_cast<hso_seed_out*>(ctx->d_batch + b_in);
   SeedFrameDev* d_fr = reinterpret_cast<SeedFrameDev*>(ctx->d_batch + b_in + b_out);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h.data(), (size_t)n_seeds * sizeof(SeedDev), hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h, (size_t)n_seeds * sizeof(SeedDev), hipMemcpyHostToDevice, ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_fr, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
   C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle;
   const int blocks = (n_seeds + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK;
   hipLaunchKernelGGL(k_seed_observe, dim3(blocks), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, d_in, n_seeds, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_seeds * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n_seeds * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, h_out, (size_t)n_seeds * sizeof(hso_seed_out));
   return HSO_OK;
 }
 
