@@ -466,11 +466,12 @@ class Context:
         return list(res)
 
     # -- reprojection matching
-    def align_batch(self, cam, cur_frame_id, jobs):
-        arr = (AlignJob * len(jobs))(*jobs)
+    def align_batch(self, cam, cur_frame_id, jobs, as_list=True):
+        """jobs: list of AlignJob or a ready ctypes array (no per-call marshalling)."""
+        arr = jobs if isinstance(jobs, C.Array) else (AlignJob * len(jobs))(*jobs)
         out = (AlignOut * len(jobs))()
         self._check(self.lib.hso_gpu_align_batch(self.h, C.byref(cam), cur_frame_id, arr, len(jobs), out), "align_batch")
-        return list(out)
+        return list(out) if as_list else out
 
     def reproject_match(self, cam, cur_frame_id, T_cur_w, cur_exposure_time, cur_keyframe_id, kfs, points, obs,
                         cell_size, grid_n_cols):
@@ -531,12 +532,12 @@ class Context:
         return o
 
     # -- depth-filter seed observation
-    def seed_observe(self, cam, cur_frame_id, cur_T_f_w, cur_exposure, px_error_angle, seeds):
-        arr = (Seed * len(seeds))(*seeds)
+    def seed_observe(self, cam, cur_frame_id, cur_T_f_w, cur_exposure, px_error_angle, seeds, as_list=True):
+        arr = seeds if isinstance(seeds, C.Array) else (Seed * len(seeds))(*seeds)
         out = (SeedOut * len(seeds))()
         self._check(self.lib.hso_gpu_seed_observe(self.h, C.byref(cam), cur_frame_id, C.byref(cur_T_f_w), cur_exposure,
                                                   px_error_angle, arr, len(seeds), out), "seed_observe")
-        return list(out)
+        return list(out) if as_list else out
 
     def seed_observe_multi(self, cam, frames, seed_frame, px_error_angle, seeds, as_list=True):
         """frames: list of (frame_id, SE3 T_f_w, exposure_time); seed i is observed in frames[seed_frame[i]]."""

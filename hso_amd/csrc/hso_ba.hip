@@ -334,16 +334,18 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
     ctx->batch_cap = o;
   }
   char* d = reinterpret_cast<char*>(ctx->d_batch);
-  std::vector<char> h(in_bytes, 0);
-  memcpy(h.data() + o_poses, poses_f_w, sizeof(hso_se3) * n_poses);
-  memcpy(h.data() + o_fixed, pose_fixed, n_poses);
-  memcpy(h.data() + o_idist, idist, sizeof(double) * n_points);
-  memcpy(h.data() + o_edges, edges, sizeof(hso_ba_edge) * n_edges);
-  memcpy(h.data() + o_off, off.data(), sizeof(int) * (n_points + 1));
-  memcpy(h.data() + o_list, list.data(), sizeof(int) * n_edges);
-  memcpy(h.data() + o_poff, poff.data(), sizeof(int) * (n_pairs + 1));
-  memcpy(h.data() + o_plist, plist.data(), sizeof(int) * 3 * (size_t)n_edges);
-  hipError_t e = hipMemcpyAsync(d, h.data(), in_bytes, hipMemcpyHostToDevice, ctx->stream);
+  char* h = hso_pinned(ctx, 0, in_bytes);
+  if (!h) return HSO_E_NOMEM;
+  memset(h, 0, in_bytes);
+  memcpy(h + o_poses, poses_f_w, sizeof(hso_se3) * n_poses);
+  memcpy(h + o_fixed, pose_fixed, n_poses);
+  memcpy(h + o_idist, idist, sizeof(double) * n_points);
+  memcpy(h + o_edges, edges, sizeof(hso_ba_edge) * n_edges);
+  memcpy(h + o_off, off.data(), sizeof(int) * (n_points + 1));
+  memcpy(h + o_list, list.data(), sizeof(int) * n_edges);
+  memcpy(h + o_poff, poff.data(), sizeof(int) * (n_pairs + 1));
+  memcpy(h + o_plist, plist.data(), sizeof(int) * 3 * (size_t)n_edges);
+  hipError_t e = hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(d + o_out, 0, o - o_out, ctx->stream);
   if (e == hipSuccess) {
     BaArgs a;

@@ -488,14 +488,24 @@ extern "C" int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* c
   const size_t o_mask = o_poses + al(sizeof(hso_se3) * tot_poses);
   const size_t o_res = o_mask + al(tot_feats);
   const size_t need = o_res + sizeof(hso_pose_result) * n_jobs;
-  char* d = nullptr;
-  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&d), need));
-  std::vector<char> h(o_res, 0);
-  PoseJobDev* hj = reinterpret_cast<PoseJobDev*>(h.data());
+  // device work area and pinned host staging are the context's grow-only buffers: no allocation per call
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
+  }
+  char* d = ctx->d_batch;
+  char* h = hso_pinned(ctx, 0, o_res);
+  char* hm = hso_pinned(ctx, 1, tot_feats + sizeof(hso_pose_result) * n_jobs + 64);
+  if (!h || !hm) return HSO_E_NOMEM;
+  memset(h, 0, o_res);
+  PoseJobDev* hj = reinterpret_cast<PoseJobDev*>(h);
   size_t fo = 0, po = 0;
   for (int j = 0; j < n_jobs; j++) {
-    memcpy(h.data() + o_feats + sizeof(hso_pose_feat) * fo, jobs[j].feats, sizeof(hso_pose_feat) * jobs[j].n_feats);
-    memcpy(h.data() + o_poses + sizeof(hso_se3) * po, jobs[j].poses_f_w, sizeof(hso_se3) * jobs[j].n_poses);
+    memcpy(h + o_feats + sizeof(hso_pose_feat) * fo, jobs[j].feats, sizeof(hso_pose_feat) * jobs[j].n_feats);
+    memcpy(h + o_poses + sizeof(hso_se3) * po, jobs[j].poses_f_w, sizeof(hso_se3) * jobs[j].n_poses);
     hj[j].feats = reinterpret_cast<const hso_pose_feat*>(d + o_feats) + fo;
     hj[j].poses = reinterpret_cast<const hso_se3*>(d + o_poses) + po;
     hj[j].mask = reinterpret_cast<uint8_t*>(d + o_mask) + fo;
@@ -503,22 +513,22 @@ extern "C" int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* c
     hj[j].T = jobs[j].T_f_w; hj[j].reproj_thresh = jobs[j].reproj_thresh; hj[j].n_iter = jobs[j].n_iter; hj[j]._pad = 0;
     fo += jobs[j].n_feats; po += jobs[j].n_poses;
   }
-  hipError_t e = hipMemcpyAsync(d, h.data(), o_res, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemcpyAsync(d, h, o_res, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_pose, dim3(n_jobs), dim3(POSE_THREADS), 0, ctx->stream, *cam, reinterpret_cast<const PoseJobDev*>(d),
                        reinterpret_cast<hso_pose_result*>(d + o_res));
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(results, d + o_res, sizeof(hso_pose_result) * n_jobs, hipMemcpyDeviceToHost, ctx->stream);
-  std::vector<uint8_t> hm(tot_feats);
-  if (e == hipSuccess && outlier_mask && tot_feats > 0) e = hipMemcpyAsync(hm.data(), d + o_mask, tot_feats, hipMemcpyDeviceToHost, ctx->stream);
+  char* hres = hm + ((tot_feats + 63) & ~size_t(63));
+  if (e == hipSuccess) e = hipMemcpyAsync(hres, d + o_res, sizeof(hso_pose_result) * n_jobs, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && outlier_mask && tot_feats > 0) e = hipMemcpyAsync(hm, d + o_mask, tot_feats, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d);
   if (e != hipSuccess) { ctx->err = std::string("pose_optimize: ") + hipGetErrorString(e); return HSO_E_HIP; }
+  memcpy(results, hres, sizeof(hso_pose_result) * n_jobs);
   if (outlier_mask) {
     fo = 0;
     for (int j = 0; j < n_jobs; j++) {
-      if (outlier_mask[j] && jobs[j].n_feats > 0) memcpy(outlier_mask[j], hm.data() + fo, jobs[j].n_feats);
+      if (outlier_mask[j] && jobs[j].n_feats > 0) memcpy(outlier_mask[j], hm + fo, jobs[j].n_feats);
       fo += jobs[j].n_feats;
     }
   }

