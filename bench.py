@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--feats", type=int, default=2000)
     ap.add_argument("--pairs", type=int, default=8, help="distinct synthetic pairs rendered per rank")
     ap.add_argument("--inverse", type=int, default=0)
-    ap.add_argument("--cpu-frames", type=int, default=300, help="frames in the cpu_baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=600, help="frames in the cpu_baseline sample (about 10 s on one host core)")
     ap.add_argument("--shape", choices=["vga", "euroc"], default="vga",
                     help="vga: BASELINE configs[1] (640x480 pinhole, the default and the judged line); "
                          "euroc: the same workload on EuRoC-shaped 752x480 frames with the radtan camera")
