@@ -9,6 +9,7 @@
   write_trajectory    BenchmarkNode::saveResult (test/test_dataset.cpp:312-335): one keyframe per
                       line, "stamp tx ty tz qx qy qz qw" of T_f_w^-1 (the TUM trajectory format)
   read_trajectory, ate_rmse   the evaluation side: closed-form alignment (Umeyama) + RMSE of positions
+  save_snapshot / load_snapshot   the map state in the C-ABI's table layouts, one .npz
 
 Host-side plumbing: nothing here touches the GPU.
 """
@@ -215,3 +216,50 @@ def ate_rmse(gt_xyz, est_xyz, with_scale=True):
     t = mg - s * R @ me
     err = gt - (s * (R @ est.T).T + t)
     return float(np.sqrt((err ** 2).sum(1).mean())), s, R, t
+
+
+# ---- state snapshot: the map state the per-frame entry points consume, in
+# the C-ABI's own table layouts, so a saved state replays through hso_gpu_reproject_match /
+# hso_gpu_seed_observe / hso_gpu_coarse_track_batch without any of the reference's containers.
+SNAPSHOT_VERSION = 1
+
+
+def save_snapshot(path, camera, keyframes, images, points, observations, seeds=None, meta=None):
+    """keyframes: KF_DTYPE array; images: one u8 image per keyframe (level 0; the pyramid is rebuilt
+    on upload); points / observations: MAP_POINT_DTYPE / OBS_DTYPE arrays (obs_begin / kf indices as
+    in include/hso_gpu.h); seeds: optional ctypes array or list of capi.Seed.  One .npz file."""
+    from . import capi
+    import ctypes as C
+    kfs = np.ascontiguousarray(keyframes, capi.KF_DTYPE)
+    if len(images) != len(kfs):
+        raise ValueError("one image per keyframe")
+    cam = np.frombuffer(bytes(camera), np.uint8).copy()
+    arrs = dict(version=np.array([SNAPSHOT_VERSION]), camera=cam, keyframes=kfs,
+                points=np.ascontiguousarray(points, capi.MAP_POINT_DTYPE),
+                observations=np.ascontiguousarray(observations, capi.OBS_DTYPE),
+                meta=np.frombuffer(repr(meta or {}).encode(), np.uint8).copy())
+    for k, img in enumerate(images):
+        arrs["image_%d" % k] = np.ascontiguousarray(img, np.uint8)
+    if seeds is not None:
+        n = len(seeds)
+        sarr = seeds if isinstance(seeds, C.Array) else (capi.Seed * n)(*seeds)
+        arrs["seeds"] = np.frombuffer(bytes(sarr), np.uint8).copy()
+    np.savez_compressed(path, **arrs)
+
+
+def load_snapshot(path):
+    """-> dict(camera, keyframes, images, points, observations, seeds (ctypes array or None), meta)."""
+    from . import capi
+    import ast
+    import ctypes as C
+    z = np.load(path)
+    if int(z["version"][0]) != SNAPSHOT_VERSION:
+        raise ValueError("snapshot version %d" % int(z["version"][0]))
+    cam = capi.Camera.from_buffer_copy(z["camera"].tobytes())
+    kfs = z["keyframes"]
+    seeds = None
+    if "seeds" in z.files:
+        raw = z["seeds"].tobytes()
+        seeds = (capi.Seed * (len(raw) // C.sizeof(capi.Seed))).from_buffer_copy(raw)
+    return dict(camera=cam, keyframes=kfs, images=[z["image_%d" % k] for k in range(len(kfs))], points=z["points"],
+                observations=z["observations"], seeds=seeds, meta=ast.literal_eval(z["meta"].tobytes().decode()))

@@ -119,3 +119,45 @@ def test_trajectory_file_and_ate(tmp_path):
     rmse, s, _, _ = formats.ate_rmse(centres, noisy)
     assert 0.02 < rmse < 0.08                                 # 0.01 of noise scaled back by 1 / 0.37, three axes
     assert formats.ate_rmse(centres, est, with_scale=False)[0] > 0.5
+
+
+def test_snapshot_round_trip(tmp_path):
+    import ctypes as C
+    P = synth.map_problem(n_points=60, n_kfs=3)
+    pair = synth.config2_pair(50)
+    seeds, T_cur, _ = synth.seeds_for_pair(pair, 20, int(P["kfs"][0]["frame_id"]))
+    cam = synth.camera()
+    formats.save_snapshot(tmp_path / "state.npz", cam, P["kfs"], P["frames"], P["points"], P["obs"], seeds=seeds,
+                          meta=dict(cur_frame_id=P["cur_frame_id"], cell_size=P["cell_size"]))
+    S = formats.load_snapshot(tmp_path / "state.npz")
+    assert bytes(S["camera"]) == bytes(cam)
+    assert S["keyframes"].tobytes() == P["kfs"].tobytes() and S["points"].tobytes() == P["points"].tobytes()
+    assert S["observations"].tobytes() == P["obs"].tobytes()
+    assert all((a == b).all() for a, b in zip(S["images"], P["frames"]))
+    assert len(S["seeds"]) == 20 and bytes(S["seeds"]) == bytes((capi.Seed * 20)(*seeds))
+    assert S["meta"] == dict(cur_frame_id=P["cur_frame_id"], cell_size=P["cell_size"])
+    with pytest.raises(ValueError):
+        formats.save_snapshot(tmp_path / "bad.npz", cam, P["kfs"], P["frames"][:1], P["points"], P["obs"])
+
+
+@pytest.mark.gpu
+def test_snapshot_replays_through_the_cabi(gpu_ctx, tmp_path):
+    """A saved state, loaded in a fresh process' terms, gives the same reprojection result."""
+    P = synth.map_problem(n_points=300, first_frame_id=9900)
+    cam = synth.camera()
+    formats.save_snapshot(tmp_path / "s.npz", cam, P["kfs"], P["frames"], P["points"], P["obs"])
+    S = formats.load_snapshot(tmp_path / "s.npz")
+    ids = [int(k["frame_id"]) for k in S["keyframes"]]
+    for i, im in zip(ids, S["images"]):
+        gpu_ctx.frame_upload(i, im)
+    gpu_ctx.frame_upload(P["cur_frame_id"], P["cur"])
+    try:
+        a = gpu_ctx.reproject_match(cam, P["cur_frame_id"], P["T_cur_w"], P["cur_exposure"], P["cur_keyframe_id"], P["kfs"],
+                                    P["points"], P["obs"], P["cell_size"], P["grid_n_cols"])
+        b = gpu_ctx.reproject_match(S["camera"], P["cur_frame_id"], P["T_cur_w"], P["cur_exposure"], P["cur_keyframe_id"],
+                                    S["keyframes"], S["points"], S["observations"], P["cell_size"], P["grid_n_cols"])
+        assert a[0].tobytes() == b[0].tobytes() and bytes(a[1]) == bytes(b[1])
+        assert sum(m.success for m in b[1]) > 150
+    finally:
+        for i in ids + [P["cur_frame_id"]]:
+            gpu_ctx.frame_release(i)
