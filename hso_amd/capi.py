@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhso_gpu.so")
+LIB_PATH = os.environ.get("HSO_GPU_LIB") or os.path.join(_HERE, "csrc", "libhso_gpu.so")   # HSO_GPU_LIB: developer experiments only
 
 N_PYR_LEVELS = 5
 N_SOBEL_LEVELS = 3
@@ -208,6 +208,11 @@ BA_EDGE_DTYPE = np.dtype([("point", "<i4"), ("host", "<i4"), ("target", "<i4"), 
 assert BA_EDGE_DTYPE.itemsize == 80
 
 
+class BaResult(C.Structure):
+    _fields_ = [("init_chi2", C.c_double), ("final_chi2", C.c_double), ("robust_chi2", C.c_double), ("lambda_", C.c_double),
+                ("iterations", C.c_int32), ("n_solves", C.c_int32), ("n_accepted", C.c_int32), ("stop", C.c_int32)]
+
+
 def ba_alloc(n_poses, n_points, n_edges):
     """Output buffers of hso_gpu_ba_linearize."""
     return dict(Hpp=np.zeros(n_points), bp=np.zeros(n_points), Hpc=np.zeros((n_points, n_poses, 6)),
@@ -279,6 +284,8 @@ def load():
     lib.hso_gpu_align_multi.argtypes = [vp, P(Camera), P(i64), P(AlignJob), i32, P(AlignOut)]
     lib.hso_gpu_pose_optimize_batch.argtypes = [vp, P(Camera), P(PoseJob), i32, P(PoseResult), vp]
     lib.hso_gpu_ba_linearize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double] + [vp] * 8
+    lib.hso_gpu_ba_huber_deltas.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, C.c_double, P(C.c_float), P(C.c_float)]
+    lib.hso_gpu_ba_optimize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double, i32, vp, P(BaResult)]
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_observe_multi.argtypes = [vp, P(Camera), P(SeedFrame), i32, vp, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
@@ -306,7 +313,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
-    "hso_gpu_reproject_match_multi",
+    "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize",
 ]
 
 
@@ -530,6 +537,31 @@ class Context:
                                            _ptr(o["edge_chi2"]), _ptr(o["chi2_sum"]))
         self._check(rc, "ba_linearize")
         return o
+
+    def ba_huber_deltas(self, poses, idist, edges, obs_uv, error_multiplier2):
+        """Huber deltas of LocalBundleAdjustment (bundle_adjustment.cpp:618-680) -> (huber_corner, huber_edge) as floats."""
+        parr = (SE3 * len(poses))(*poses)
+        idist = np.ascontiguousarray(idist, np.float64)
+        edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+        obs_uv = np.ascontiguousarray(obs_uv, np.float64)
+        hc, he = C.c_float(), C.c_float()
+        self._check(self.lib.hso_gpu_ba_huber_deltas(self.h, C.cast(parr, C.c_void_p), len(poses), _ptr(idist), len(idist), _ptr(edges),
+                                                     _ptr(obs_uv), len(edges), error_multiplier2, C.byref(hc), C.byref(he)),
+                    "ba_huber_deltas")
+        return hc.value, he.value
+
+    def ba_optimize(self, poses, fixed, idist, edges, huber_corner, huber_edge, n_iter):
+        """The LM optimisation of LocalBundleAdjustment.  Returns (poses, idist, edge_chi2, BaResult)."""
+        parr = (SE3 * len(poses))(*poses)
+        fixed = np.ascontiguousarray(fixed, np.uint8)
+        idist = np.array(idist, np.float64)
+        edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+        chi2 = np.zeros(len(edges))
+        res = BaResult()
+        self._check(self.lib.hso_gpu_ba_optimize(self.h, C.cast(parr, C.c_void_p), _ptr(fixed), len(poses), _ptr(idist), len(idist),
+                                                 _ptr(edges), len(edges), huber_corner, huber_edge, n_iter, _ptr(chi2), C.byref(res)),
+                    "ba_optimize")
+        return list(parr), idist, chi2, res
 
     # -- depth-filter seed observation
     def seed_observe(self, cam, cur_frame_id, cur_T_f_w, cur_exposure, px_error_angle, seeds, as_list=True):

@@ -23,6 +23,8 @@
 #include "hso_ctx.h"
 #include "hso_dev_math.h"
 #include <string.h>
+#include <algorithm>
+#include <cmath>
 #include <vector>
 
 using namespace hso_dev;
@@ -47,6 +49,7 @@ struct BaArgs {
   double* edge_rho;   // [n_edges]
 };
 
+template <bool LIN>   // LIN = false: errors, chi2 and rho only (an LM trial's computeActiveErrors)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_edges(BaArgs a)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,8 +137,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_edges(BaArgs a)
   rec[28] = rho1 * om;   // robustInformation
   rec[29] = om * rho1;   // factor of omega_r = -(om * err) * rho1 (kept separate to mirror the expression order)
   rec[30] = (double)dim;
+  if (LIN) {
 #pragma unroll
-  for (int i = 0; i < BA_LIN; i++) a.lin[(size_t)i * a.n_edges + k] = rec[i];
+    for (int i = 0; i < BA_LIN; i++) a.lin[(size_t)i * a.n_edges + k] = rec[i];
+  }
   a.edge_err[2 * k] = rec[0]; a.edge_err[2 * k + 1] = rec[1];
   a.edge_chi2[k] = chi2;
   a.edge_rho[k] = rho0;
@@ -263,21 +268,79 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(BaArgs a, const int* pr
   }
 }
 
-extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses,
-                                    const double* idist, int n_points, const hso_ba_edge* edges, int n_edges,
-                                    double huber_corner, double huber_edge, double* Hpp, double* bp, double* Hpc,
-                                    double* Hcc, double* bc, double* edge_err, double* edge_chi2, double* chi2_sum)
+
+// sum of chi2 and of the robustified rho(chi2) over all edges (activeChi2 / activeRobustChi2,
+// thirdparty/g2o/g2o/core/sparse_optimizer.cpp:100-113): one workgroup, fixed tree => deterministic
+__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(BaArgs a, double* chi2_sum)
 {
-  if (!ctx) return HSO_E_INVALID;
-  if (!poses_f_w || !pose_fixed || !idist || !edges || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || !Hpp || !bp || !Hpc ||
-      !Hcc || !bc || !edge_err || !edge_chi2 || !chi2_sum)
-    return hso_fail(ctx, HSO_E_INVALID, "ba_linearize: bad argument");
+  __shared__ double s_part[BA_WAVES][2];
+  double c = 0, r = 0;
+  for (int k = threadIdx.x; k < a.n_edges; k += BA_THREADS) { c += a.edge_chi2[k]; r += a.edge_rho[k]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    c += __hiloint2double(__shfl_xor(__double2hiint(c), m), __shfl_xor(__double2loint(c), m));
+    r += __hiloint2double(__shfl_xor(__double2hiint(r), m), __shfl_xor(__double2loint(r), m));
+  }
+  if (lane == 0) { s_part[wave][0] = c; s_part[wave][1] = r; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0;
+    for (int w = 0; w < BA_WAVES; w++) t += s_part[w][threadIdx.x];
+    chi2_sum[threadIdx.x] = t;
+  }
+}
+
+// per-edge error magnitudes for the Huber deltas of LocalBundleAdjustment (src/bundle_adjustment.cpp:618-656):
+// e = (project2d(obs->f) - project2d(Tth * fH / idist)) / 2^level; corners |e|, edgelets |grad^T e| (floats)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_mad_errors(const hso_se3* poses, const double* idist, const hso_ba_edge* edges,
+                                                              const double* obs_uv, int n_edges, float* err_out)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_edges) return;
+  const hso_ba_edge e = edges[k];
+  const Se3 Tth = se3_mul(se3_from(poses[e.target]), se3_inverse(se3_from(poses[e.host])));
+  const double inv = 1.0 / idist[e.point];
+  double x, y, z;
+  se3_apply(Tth, e.fH[0] * inv, e.fH[1] * inv, e.fH[2] * inv, x, y, z);
+  double ex = obs_uv[2 * k] - x / z, ey = obs_uv[2 * k + 1] - y / z;
+  const double sc = 1.0 / (double)(1 << e.level);
+  ex *= sc; ey *= sc;
+  err_out[k] = (e.type == HSO_FTR_EDGELET) ? (float)fabs(e.normal[0] * ex + e.normal[1] * ey) : (float)sqrt(ex * ex + ey * ey);
+}
+
+// ------------------------------------------------------------------ host side
+
+// One BA problem resident in the context's work area: inputs uploaded once, the state (poses, inverse depths)
+// refreshed per evaluation, the blocks read back per linearisation.
+struct BaDev {
+  hso_gpu_ctx* ctx;
+  int n_poses, n_points, n_edges, n_pairs;
+  size_t o_poses, o_fixed, o_idist, o_edges, o_off, o_list, o_poff, o_plist, in_bytes, o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc,
+      o_bc, o_err, o_chi, o_sum, total;
+  char* d;
+  char* h;
+  BaArgs a;
+};
+
+static int ba_check_edges(hso_gpu_ctx* ctx, const hso_ba_edge* edges, int n_edges, int n_points, int n_poses, const char* who)
+{
   for (int k = 0; k < n_edges; k++) {
     const hso_ba_edge& e = edges[k];
     if (e.point < 0 || e.point >= n_points || e.host < 0 || e.host >= n_poses || e.target < 0 || e.target >= n_poses ||
-        e.host == e.target || e.level < 0 || e.level > 14)
-      return hso_fail(ctx, HSO_E_INVALID, "ba_linearize: edge index out of range");
+        e.host == e.target || e.level < 0 || e.level > 14) {
+      ctx->err = std::string(who) + ": edge index out of range";
+      return HSO_E_INVALID;
+    }
   }
+  return HSO_OK;
+}
+
+// lay the problem out in the work area and upload everything that does not change between evaluations
+static int ba_setup(BaDev& B, hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, const double* idist,
+                    int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge)
+{
+  B.ctx = ctx; B.n_poses = n_poses; B.n_points = n_points; B.n_edges = n_edges;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // CSR of edges by point, edge order kept inside a point (g2o visits edges in insertion order)
   std::vector<int> off(n_points + 1, 0), list(n_edges);
@@ -287,6 +350,7 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
 
   // CSR of edges by pose-pair block (same block numbering as k_ba_poses), edge order kept
   const int n_pairs = n_poses * (n_poses + 1) / 2;
+  B.n_pairs = n_pairs;
   auto pair_id = [n_poses](int i, int j) { return i * n_poses - i * (i - 1) / 2 + (j - i); };  // i <= j
   std::vector<int> poff(n_pairs + 1, 0), plist((size_t)3 * n_edges);
   for (int k = 0; k < n_edges; k++) {
@@ -306,27 +370,156 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
 
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   size_t o = 0;
+  B.o_poses = o; o += al(sizeof(hso_se3) * n_poses);
+  B.o_idist = o; o += al(sizeof(double) * n_points);      // poses | idist: the state, contiguous
+  B.o_fixed = o; o += al(n_poses);
+  B.o_edges = o; o += al(sizeof(hso_ba_edge) * n_edges);
+  B.o_off = o; o += al(sizeof(int) * (n_points + 1));
+  B.o_list = o; o += al(sizeof(int) * n_edges);
+  B.o_poff = o; o += al(sizeof(int) * (n_pairs + 1));
+  B.o_plist = o; o += al(sizeof(int) * 3 * (size_t)n_edges);
+  B.in_bytes = o;
+  B.o_lin = o; o += al(sizeof(double) * BA_LIN * n_edges);
+  B.o_rho = o; o += al(sizeof(double) * n_edges);
+  B.o_out = o;
+  B.o_Hpp = o; o += al(sizeof(double) * n_points);
+  B.o_bp = o; o += al(sizeof(double) * n_points);
+  B.o_Hpc = o; o += al(sizeof(double) * (size_t)n_points * n_poses * 6);
+  B.o_Hcc = o; o += al(sizeof(double) * (size_t)n_poses * n_poses * 36);
+  B.o_bc = o; o += al(sizeof(double) * n_poses * 6);
+  B.o_err = o; o += al(sizeof(double) * 2 * n_edges);
+  B.o_chi = o; o += al(sizeof(double) * n_edges);
+  B.o_sum = o; o += 256;
+  B.total = o;
+  if (ctx->batch_cap < o) {  // grow-only work area of the context (shared with the other batched entry points)
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), o));
+    ctx->batch_cap = o;
+  }
+  B.d = reinterpret_cast<char*>(ctx->d_batch);
+  B.h = hso_pinned(ctx, 0, B.in_bytes);
+  if (!B.h) return HSO_E_NOMEM;
+  char* h = B.h;
+  memset(h, 0, B.in_bytes);
+  memcpy(h + B.o_poses, poses_f_w, sizeof(hso_se3) * n_poses);
+  memcpy(h + B.o_fixed, pose_fixed, n_poses);
+  memcpy(h + B.o_idist, idist, sizeof(double) * n_points);
+  memcpy(h + B.o_edges, edges, sizeof(hso_ba_edge) * n_edges);
+  memcpy(h + B.o_off, off.data(), sizeof(int) * (n_points + 1));
+  memcpy(h + B.o_list, list.data(), sizeof(int) * n_edges);
+  memcpy(h + B.o_poff, poff.data(), sizeof(int) * (n_pairs + 1));
+  memcpy(h + B.o_plist, plist.data(), sizeof(int) * 3 * (size_t)n_edges);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d, h, B.in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  char* d = B.d;
+  BaArgs& a = B.a;
+  a.poses = reinterpret_cast<const hso_se3*>(d + B.o_poses); a.fixed = reinterpret_cast<const uint8_t*>(d + B.o_fixed);
+  a.idist = reinterpret_cast<const double*>(d + B.o_idist); a.edges = reinterpret_cast<const hso_ba_edge*>(d + B.o_edges);
+  a.n_poses = n_poses; a.n_points = n_points; a.n_edges = n_edges;
+  a.huber_corner = huber_corner; a.huber_edge = huber_edge;
+  a.lin = reinterpret_cast<double*>(d + B.o_lin); a.edge_err = reinterpret_cast<double*>(d + B.o_err);
+  a.edge_chi2 = reinterpret_cast<double*>(d + B.o_chi); a.edge_rho = reinterpret_cast<double*>(d + B.o_rho);
+  return HSO_OK;
+}
+
+// new state -> device (poses and inverse depths sit next to each other at the start of the work area)
+static int ba_put_state(BaDev& B, const hso_se3* poses, const double* idist)
+{
+  memcpy(B.h + B.o_poses, poses, sizeof(hso_se3) * B.n_poses);
+  memcpy(B.h + B.o_idist, idist, sizeof(double) * B.n_points);
+  HSO_HIP_CHECK(B.ctx, hipMemcpyAsync(B.d, B.h, B.o_fixed, hipMemcpyHostToDevice, B.ctx->stream));
+  return HSO_OK;
+}
+
+// computeActiveErrors + buildSystem at the resident state; the blocks stay on the device
+static int ba_launch_linearize(BaDev& B)
+{
+  hso_gpu_ctx* ctx = B.ctx;
+  char* d = B.d;
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + B.o_out, 0, B.total - B.o_out, ctx->stream));
+  hipLaunchKernelGGL(k_ba_edges<true>, dim3((B.n_edges + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, B.a);
+  hipLaunchKernelGGL(k_ba_points, dim3((B.n_points + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, B.a,
+                     reinterpret_cast<const int*>(d + B.o_off), reinterpret_cast<const int*>(d + B.o_list),
+                     reinterpret_cast<double*>(d + B.o_Hpp), reinterpret_cast<double*>(d + B.o_bp), reinterpret_cast<double*>(d + B.o_Hpc));
+  hipLaunchKernelGGL(k_ba_poses, dim3(B.n_pairs + 1), dim3(BA_THREADS), 0, ctx->stream, B.a,
+                     reinterpret_cast<const int*>(d + B.o_poff), reinterpret_cast<const int*>(d + B.o_plist),
+                     reinterpret_cast<double*>(d + B.o_Hcc), reinterpret_cast<double*>(d + B.o_bc), reinterpret_cast<double*>(d + B.o_sum));
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
+}
+
+// computeActiveErrors only (an LM trial): per-edge error / chi2 / rho and the two sums
+static int ba_launch_errors(BaDev& B)
+{
+  hso_gpu_ctx* ctx = B.ctx;
+  hipLaunchKernelGGL(k_ba_edges<false>, dim3((B.n_edges + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, B.a);
+  hipLaunchKernelGGL(k_ba_chi2, dim3(1), dim3(BA_THREADS), 0, ctx->stream, B.a, reinterpret_cast<double*>(B.d + B.o_sum));
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
+}
+
+static int ba_get(BaDev& B, void* dst, size_t off, size_t bytes)
+{
+  HSO_HIP_CHECK(B.ctx, hipMemcpyAsync(dst, B.d + off, bytes, hipMemcpyDeviceToHost, B.ctx->stream));
+  return HSO_OK;
+}
+
+extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses,
+                                    const double* idist, int n_points, const hso_ba_edge* edges, int n_edges,
+                                    double huber_corner, double huber_edge, double* Hpp, double* bp, double* Hpc,
+                                    double* Hcc, double* bc, double* edge_err, double* edge_chi2, double* chi2_sum)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!poses_f_w || !pose_fixed || !idist || !edges || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || !Hpp || !bp || !Hpc ||
+      !Hcc || !bc || !edge_err || !edge_chi2 || !chi2_sum)
+    return hso_fail(ctx, HSO_E_INVALID, "ba_linearize: bad argument");
+  if (int rc = ba_check_edges(ctx, edges, n_edges, n_points, n_poses, "ba_linearize")) return rc;
+  BaDev B;
+  if (int rc = ba_setup(B, ctx, poses_f_w, pose_fixed, n_poses, idist, n_points, edges, n_edges, huber_corner, huber_edge)) return rc;
+  if (int rc = ba_launch_linearize(B)) return rc;
+  int rc = HSO_OK;
+  if (!rc) rc = ba_get(B, Hpp, B.o_Hpp, sizeof(double) * n_points);
+  if (!rc) rc = ba_get(B, bp, B.o_bp, sizeof(double) * n_points);
+  if (!rc) rc = ba_get(B, Hpc, B.o_Hpc, sizeof(double) * (size_t)n_points * n_poses * 6);
+  if (!rc) rc = ba_get(B, Hcc, B.o_Hcc, sizeof(double) * (size_t)n_poses * n_poses * 36);
+  if (!rc) rc = ba_get(B, bc, B.o_bc, sizeof(double) * n_poses * 6);
+  if (!rc) rc = ba_get(B, edge_err, B.o_err, sizeof(double) * 2 * n_edges);
+  if (!rc) rc = ba_get(B, edge_chi2, B.o_chi, sizeof(double) * n_edges);
+  if (!rc) rc = ba_get(B, chi2_sum, B.o_sum, sizeof(double) * 2);
+  if (rc) return rc;
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+// hso::getMedian (include/hso/vikit/math_utils.h:119-126): nth_element at floor(n/2)
+static float upper_median(std::vector<float>& v)
+{
+  std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+  return v[v.size() / 2];
+}
+
+extern "C" int hso_gpu_ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, int n_poses, const double* idist, int n_points,
+                                       const hso_ba_edge* edges, const double* obs_uv, int n_edges, double error_multiplier2,
+                                       float* huber_corner, float* huber_edge)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!poses_f_w || !idist || !huber_corner || !huber_edge || n_poses <= 0 || n_points <= 0 || n_edges < 0 ||
+      (n_edges > 0 && (!edges || !obs_uv)))
+    return hso_fail(ctx, HSO_E_INVALID, "ba_huber_deltas: bad argument");
+  *huber_corner = 0; *huber_edge = 0;
+  if (n_edges == 0) return HSO_OK;   // both error lists empty: the reference leaves the deltas uninitialised
+  if (int rc = ba_check_edges(ctx, edges, n_edges, n_points, n_poses, "ba_huber_deltas")) return rc;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  size_t o = 0;
   const size_t o_poses = o; o += al(sizeof(hso_se3) * n_poses);
-  const size_t o_fixed = o; o += al(n_poses);
   const size_t o_idist = o; o += al(sizeof(double) * n_points);
   const size_t o_edges = o; o += al(sizeof(hso_ba_edge) * n_edges);
-  const size_t o_off = o; o += al(sizeof(int) * (n_points + 1));
-  const size_t o_list = o; o += al(sizeof(int) * n_edges);
-  const size_t o_poff = o; o += al(sizeof(int) * (n_pairs + 1));
-  const size_t o_plist = o; o += al(sizeof(int) * 3 * (size_t)n_edges);
+  const size_t o_uv = o; o += al(sizeof(double) * 2 * n_edges);
   const size_t in_bytes = o;
-  const size_t o_lin = o; o += al(sizeof(double) * BA_LIN * n_edges);
-  const size_t o_rho = o; o += al(sizeof(double) * n_edges);
-  const size_t o_out = o;
-  const size_t o_Hpp = o; o += al(sizeof(double) * n_points);
-  const size_t o_bp = o; o += al(sizeof(double) * n_points);
-  const size_t o_Hpc = o; o += al(sizeof(double) * (size_t)n_points * n_poses * 6);
-  const size_t o_Hcc = o; o += al(sizeof(double) * (size_t)n_poses * n_poses * 36);
-  const size_t o_bc = o; o += al(sizeof(double) * n_poses * 6);
-  const size_t o_err = o; o += al(sizeof(double) * 2 * n_edges);
-  const size_t o_chi = o; o += al(sizeof(double) * n_edges);
-  const size_t o_sum = o; o += 256;
-  if (ctx->batch_cap < o) {  // grow-only staging buffer of the context (shared with the other batched entry points)
+  const size_t o_err = o; o += al(sizeof(float) * n_edges);
+  if (ctx->batch_cap < o) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
@@ -336,44 +529,317 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   char* d = reinterpret_cast<char*>(ctx->d_batch);
   char* h = hso_pinned(ctx, 0, in_bytes);
   if (!h) return HSO_E_NOMEM;
-  memset(h, 0, in_bytes);
   memcpy(h + o_poses, poses_f_w, sizeof(hso_se3) * n_poses);
-  memcpy(h + o_fixed, pose_fixed, n_poses);
   memcpy(h + o_idist, idist, sizeof(double) * n_points);
   memcpy(h + o_edges, edges, sizeof(hso_ba_edge) * n_edges);
-  memcpy(h + o_off, off.data(), sizeof(int) * (n_points + 1));
-  memcpy(h + o_list, list.data(), sizeof(int) * n_edges);
-  memcpy(h + o_poff, poff.data(), sizeof(int) * (n_pairs + 1));
-  memcpy(h + o_plist, plist.data(), sizeof(int) * 3 * (size_t)n_edges);
-  hipError_t e = hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(d + o_out, 0, o - o_out, ctx->stream);
-  if (e == hipSuccess) {
-    BaArgs a;
-    a.poses = reinterpret_cast<const hso_se3*>(d + o_poses); a.fixed = reinterpret_cast<const uint8_t*>(d + o_fixed);
-    a.idist = reinterpret_cast<const double*>(d + o_idist); a.edges = reinterpret_cast<const hso_ba_edge*>(d + o_edges);
-    a.n_poses = n_poses; a.n_points = n_points; a.n_edges = n_edges;
-    a.huber_corner = huber_corner; a.huber_edge = huber_edge;
-    a.lin = reinterpret_cast<double*>(d + o_lin); a.edge_err = reinterpret_cast<double*>(d + o_err);
-    a.edge_chi2 = reinterpret_cast<double*>(d + o_chi); a.edge_rho = reinterpret_cast<double*>(d + o_rho);
-    hipLaunchKernelGGL(k_ba_edges, dim3((n_edges + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_ba_points, dim3((n_points + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, a,
-                       reinterpret_cast<const int*>(d + o_off), reinterpret_cast<const int*>(d + o_list),
-                       reinterpret_cast<double*>(d + o_Hpp), reinterpret_cast<double*>(d + o_bp), reinterpret_cast<double*>(d + o_Hpc));
-    hipLaunchKernelGGL(k_ba_poses, dim3(n_pairs + 1), dim3(BA_THREADS), 0, ctx->stream, a,
-                       reinterpret_cast<const int*>(d + o_poff), reinterpret_cast<const int*>(d + o_plist),
-                       reinterpret_cast<double*>(d + o_Hcc), reinterpret_cast<double*>(d + o_bc), reinterpret_cast<double*>(d + o_sum));
-    e = hipGetLastError();
+  memcpy(h + o_uv, obs_uv, sizeof(double) * 2 * n_edges);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_ba_mad_errors, dim3((n_edges + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream,
+                     reinterpret_cast<const hso_se3*>(d + o_poses), reinterpret_cast<const double*>(d + o_idist),
+                     reinterpret_cast<const hso_ba_edge*>(d + o_edges), reinterpret_cast<const double*>(d + o_uv), n_edges,
+                     reinterpret_cast<float*>(d + o_err));
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  std::vector<float> err(n_edges);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(err.data(), d + o_err, sizeof(float) * n_edges, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<float> errors_pt, errors_ls;
+  for (int k = 0; k < n_edges; k++) (edges[k].type == HSO_FTR_EDGELET ? errors_ls : errors_pt).push_back(err[k]);
+  // src/bundle_adjustment.cpp:664-680
+  if (!errors_pt.empty() && !errors_ls.empty()) {
+    *huber_corner = (float)(1.4826 * upper_median(errors_pt));
+    *huber_edge = (float)(1.4826 * upper_median(errors_ls));
+  } else if (errors_pt.empty() && !errors_ls.empty()) {
+    *huber_corner = (float)(1.0 / error_multiplier2);
+    *huber_edge = (float)(1.4826 * upper_median(errors_ls));
+  } else if (!errors_pt.empty() && errors_ls.empty()) {
+    *huber_corner = (float)(1.4826 * upper_median(errors_pt));
+    *huber_edge = (float)(0.5 / error_multiplier2);
   }
-  auto back = [&](void* dst, size_t off_, size_t bytes) { if (e == hipSuccess) e = hipMemcpyAsync(dst, d + off_, bytes, hipMemcpyDeviceToHost, ctx->stream); };
-  back(Hpp, o_Hpp, sizeof(double) * n_points);
-  back(bp, o_bp, sizeof(double) * n_points);
-  back(Hpc, o_Hpc, sizeof(double) * (size_t)n_points * n_poses * 6);
-  back(Hcc, o_Hcc, sizeof(double) * (size_t)n_poses * n_poses * 36);
-  back(bc, o_bc, sizeof(double) * n_poses * 6);
-  back(edge_err, o_err, sizeof(double) * 2 * n_edges);
-  back(edge_chi2, o_chi, sizeof(double) * n_edges);
-  back(chi2_sum, o_sum, sizeof(double) * 2);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { ctx->err = std::string("ba_linearize: ") + hipGetErrorString(e); return HSO_E_HIP; }
   return HSO_OK;
+}
+
+// ---- g2o::SE3Quat on the host (thirdparty/g2o/g2o/types/se3quat.h): the pose update of VertexSE3Expmap ----
+namespace {
+
+struct Q4 { double x, y, z, w; };
+
+inline Q4 qmul(const Q4& a, const Q4& b)
+{
+  return { a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+           a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z };
+}
+
+inline void qrot(const Q4& q, const double v[3], double o[3])   // Eigen QuaternionBase::_transformVector
+{
+  double uv[3] = { q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0] };
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  o[0] = (v[0] + q.w * uv[0]) + (q.y * uv[2] - q.z * uv[1]);
+  o[1] = (v[1] + q.w * uv[1]) + (q.z * uv[0] - q.x * uv[2]);
+  o[2] = (v[2] + q.w * uv[2]) + (q.x * uv[1] - q.y * uv[0]);
+}
+
+inline void normalize_rotation(Q4& q)   // se3quat.h:280-285
+{
+  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+
+// SE3Quat::exp(update) * pose, update = [omega, upsilon] (se3quat.h:223-257, :104-110)
+void se3quat_exp_times(const double* upd, hso_se3& pose)
+{
+  const double wx = upd[0], wy = upd[1], wz = upd[2];
+  const double theta = std::sqrt(wx * wx + wy * wy + wz * wz);
+  const double O[9] = { 0, -wz, wy, wz, 0, -wx, -wy, wx, 0 };
+  double O2[9], R[9], V[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) O2[i * 3 + j] = (O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j]) + O[i * 3 + 2] * O[6 + j];
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; i++) { R[i] = ((i % 4 == 0 ? 1.0 : 0.0) + O[i]) + O2[i]; V[i] = R[i]; }
+  } else {
+    const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta), c = (theta - std::sin(theta)) / std::pow(theta, 3);
+    for (int i = 0; i < 9; i++) {
+      const double id = (i % 4 == 0) ? 1.0 : 0.0;
+      R[i] = (id + a * O[i]) + b * O2[i];
+      V[i] = (id + b * O[i]) + c * O2[i];
+    }
+  }
+  // Eigen::Quaterniond(Matrix3d)
+  Q4 q;
+  double t = R[0] + R[4] + R[8];
+  if (t > 0) {
+    t = std::sqrt(t + 1.0);
+    q.w = 0.5 * t; t = 0.5 / t;
+    q.x = (R[7] - R[5]) * t; q.y = (R[2] - R[6]) * t; q.z = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double qv[3];
+    t = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    qv[i] = 0.5 * t; t = 0.5 / t;
+    q.w = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    qv[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    qv[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    q.x = qv[0]; q.y = qv[1]; q.z = qv[2];
+  }
+  normalize_rotation(q);
+  const double tv[3] = { (V[0] * upd[3] + V[1] * upd[4]) + V[2] * upd[5], (V[3] * upd[3] + V[4] * upd[4]) + V[5] * upd[5],
+                         (V[6] * upd[3] + V[7] * upd[4]) + V[8] * upd[5] };
+  // result = exp * pose
+  double rt[3];
+  qrot(q, pose.t, rt);
+  Q4 qp = { pose.q[0], pose.q[1], pose.q[2], pose.q[3] };
+  Q4 qn = qmul(q, qp);
+  normalize_rotation(qn);
+  pose.q[0] = qn.x; pose.q[1] = qn.y; pose.q[2] = qn.z; pose.q[3] = qn.w;
+  pose.t[0] = tv[0] + rt[0]; pose.t[1] = tv[1] + rt[1]; pose.t[2] = tv[2] + rt[2];
+}
+
+// (H + lambda I) x = b through the scalar Schur complement of the inverse-depth unknowns.  Returns false where g2o's
+// factorisation would fail (a vanishing or non-finite pivot).
+struct SchurSolver {
+  int n_points, n_poses, n_free, M;
+  std::vector<int> col;                    // pose -> first row of its block in the reduced system, -1 = fixed
+  std::vector<int> pp_off, pp_pose;        // CSR: free poses connected to each point
+  std::vector<double> S, rhs, xc, w;
+
+  void init(int n_points_, int n_poses_, const uint8_t* fixed, const hso_ba_edge* edges, int n_edges)
+  {
+    n_points = n_points_; n_poses = n_poses_;
+    col.assign(n_poses, -1);
+    n_free = 0;
+    for (int i = 0; i < n_poses; i++) if (!fixed[i]) col[i] = 6 * n_free++;
+    M = 6 * n_free;
+    std::vector<std::vector<int>> con(n_points);
+    for (int k = 0; k < n_edges; k++) {
+      const hso_ba_edge& e = edges[k];
+      for (int v : { e.host, e.target })
+        if (col[v] >= 0 && std::find(con[e.point].begin(), con[e.point].end(), v) == con[e.point].end()) con[e.point].push_back(v);
+    }
+    pp_off.assign(n_points + 1, 0);
+    for (int p = 0; p < n_points; p++) { std::sort(con[p].begin(), con[p].end()); pp_off[p + 1] = pp_off[p] + (int)con[p].size(); }
+    pp_pose.resize(pp_off[n_points]);
+    for (int p = 0; p < n_points; p++) std::copy(con[p].begin(), con[p].end(), pp_pose.begin() + pp_off[p]);
+    S.resize((size_t)M * M); rhs.resize(M); xc.resize(M); w.resize(n_points);
+  }
+
+  // x = [points | poses (n_poses * 6, zeros at fixed ones)]
+  bool solve(const double* Hpp, const double* bp, const double* Hpc, const double* Hcc, const double* bc, double lambda,
+             double* x_points, double* x_poses)
+  {
+    std::fill(S.begin(), S.end(), 0.0);
+    for (int i = 0; i < n_poses; i++) {
+      if (col[i] < 0) continue;
+      for (int q = 0; q < 6; q++) rhs[col[i] + q] = bc[i * 6 + q];
+      for (int j = i; j < n_poses; j++) {
+        if (col[j] < 0) continue;
+        const double* blk = Hcc + ((size_t)i * n_poses + j) * 36;
+        for (int r = 0; r < 6; r++)
+          for (int c = 0; c < 6; c++) {
+            S[(size_t)(col[i] + r) * M + col[j] + c] = blk[r * 6 + c];
+            S[(size_t)(col[j] + c) * M + col[i] + r] = blk[r * 6 + c];
+          }
+      }
+    }
+    for (int k = 0; k < M; k++) S[(size_t)k * M + k] += lambda;
+    bool ok = true;
+    for (int p = 0; p < n_points; p++) {
+      const double dpp = Hpp[p] + lambda;
+      if (!(dpp != 0.0) || !std::isfinite(dpp)) { ok = false; w[p] = 0; continue; }
+      const double inv = 1.0 / dpp;
+      w[p] = inv;
+      const double g = bp[p] * inv;
+      for (int a = pp_off[p]; a < pp_off[p + 1]; a++) {
+        const int ia = pp_pose[a];
+        const double* Wa = Hpc + ((size_t)p * n_poses + ia) * 6;
+        for (int r = 0; r < 6; r++) rhs[col[ia] + r] -= Wa[r] * g;
+        for (int b = a; b < pp_off[p + 1]; b++) {
+          const int ib = pp_pose[b];
+          const double* Wb = Hpc + ((size_t)p * n_poses + ib) * 6;
+          for (int r = 0; r < 6; r++) {
+            const double wr = Wa[r] * inv;
+            for (int c = 0; c < 6; c++) {
+              const double v = wr * Wb[c];
+              S[(size_t)(col[ia] + r) * M + col[ib] + c] -= v;
+              if (ia != ib) S[(size_t)(col[ib] + c) * M + col[ia] + r] -= v;
+            }
+          }
+        }
+      }
+    }
+    // dense LDL^T of the reduced system (lower triangle), no pivoting like the reference's SimplicialLDLT
+    for (int j = 0; j < M && ok; j++) {
+      double dj = S[(size_t)j * M + j];
+      for (int k = 0; k < j; k++) dj -= S[(size_t)j * M + k] * S[(size_t)j * M + k] * S[(size_t)k * M + k];
+      if (!(dj != 0.0) || !std::isfinite(dj)) { ok = false; break; }
+      S[(size_t)j * M + j] = dj;
+      for (int i = j + 1; i < M; i++) {
+        double s = S[(size_t)i * M + j];
+        for (int k = 0; k < j; k++) s -= S[(size_t)i * M + k] * S[(size_t)j * M + k] * S[(size_t)k * M + k];
+        S[(size_t)i * M + j] = s / dj;
+      }
+    }
+    std::fill(x_poses, x_poses + (size_t)n_poses * 6, 0.0);
+    if (!ok) { std::fill(x_points, x_points + n_points, 0.0); return false; }
+    for (int i = 0; i < M; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= S[(size_t)i * M + k] * xc[k]; xc[i] = s; }
+    for (int i = 0; i < M; i++) xc[i] /= S[(size_t)i * M + i];
+    for (int i = M - 1; i >= 0; i--) { double s = xc[i]; for (int k = i + 1; k < M; k++) s -= S[(size_t)k * M + i] * xc[k]; xc[i] = s; }
+    for (int i = 0; i < n_poses; i++)
+      if (col[i] >= 0) for (int q = 0; q < 6; q++) x_poses[i * 6 + q] = xc[col[i] + q];
+    for (int p = 0; p < n_points; p++) {
+      double s = bp[p];
+      for (int a = pp_off[p]; a < pp_off[p + 1]; a++) {
+        const int ia = pp_pose[a];
+        const double* Wa = Hpc + ((size_t)p * n_poses + ia) * 6;
+        for (int r = 0; r < 6; r++) s -= Wa[r] * xc[col[ia] + r];
+      }
+      x_points[p] = s * w[p];
+    }
+    return true;
+  }
+};
+
+}  // namespace
+
+extern "C" int hso_gpu_ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, double* idist,
+                                   int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge,
+                                   int n_iter, double* edge_chi2_out, hso_ba_result* result)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!poses_f_w || !pose_fixed || !idist || !edges || !result || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || n_iter < 0)
+    return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: bad argument");
+  if (int rc = ba_check_edges(ctx, edges, n_edges, n_points, n_poses, "ba_optimize")) return rc;
+  memset(result, 0, sizeof(*result));
+  BaDev B;
+  if (int rc = ba_setup(B, ctx, poses_f_w, pose_fixed, n_poses, idist, n_points, edges, n_edges, huber_corner, huber_edge)) return rc;
+  SchurSolver sol;
+  sol.init(n_points, n_poses, pose_fixed, edges, n_edges);
+  std::vector<double> Hpp(n_points), bp(n_points), Hpc((size_t)n_points * n_poses * 6), Hcc((size_t)n_poses * n_poses * 36),
+      bc((size_t)n_poses * 6), xp(n_points), xc((size_t)n_poses * 6), idist_bak(n_points);
+  std::vector<hso_se3> poses_bak(n_poses);
+  double chi[2] = { 0, 0 };
+  auto sync = [&]() -> int { HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return HSO_OK; };
+
+  // runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()
+  if (int rc = ba_launch_errors(B)) return rc;
+  if (int rc = ba_get(B, chi, B.o_sum, sizeof(chi))) return rc;
+  if (int rc = sync()) return rc;
+  result->init_chi2 = chi[0];
+  result->robust_chi2 = chi[1];
+  double lambda = -1., ni = 2.;
+  int nBad = 0, stop = 0;
+  for (int it = 0; it < n_iter; it++) {
+    // solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem
+    if (int rc = ba_launch_linearize(B)) return rc;
+    int rc = ba_get(B, Hpp.data(), B.o_Hpp, sizeof(double) * n_points);
+    if (!rc) rc = ba_get(B, bp.data(), B.o_bp, sizeof(double) * n_points);
+    if (!rc) rc = ba_get(B, Hpc.data(), B.o_Hpc, sizeof(double) * Hpc.size());
+    if (!rc) rc = ba_get(B, Hcc.data(), B.o_Hcc, sizeof(double) * Hcc.size());
+    if (!rc) rc = ba_get(B, bc.data(), B.o_bc, sizeof(double) * bc.size());
+    if (!rc) rc = ba_get(B, chi, B.o_sum, sizeof(chi));
+    if (!rc) rc = sync();
+    if (rc) return rc;
+    double currentChi = chi[1], tempChi = currentChi;
+    const double iniChi = currentChi;
+    if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices
+      double maxDiagonal = 0.;
+      for (int p = 0; p < n_points; p++) maxDiagonal = std::max(std::fabs(Hpp[p]), maxDiagonal);
+      for (int i = 0; i < n_poses; i++)
+        if (!pose_fixed[i]) for (int q = 0; q < 6; q++) maxDiagonal = std::max(std::fabs(Hcc[((size_t)i * n_poses + i) * 36 + q * 7]), maxDiagonal);
+      lambda = 1e-5 * maxDiagonal;
+      ni = 2; nBad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      std::copy(poses_f_w, poses_f_w + n_poses, poses_bak.begin());   // _optimizer->push()
+      std::copy(idist, idist + n_points, idist_bak.begin());
+      const bool ok2 = sol.solve(Hpp.data(), bp.data(), Hpc.data(), Hcc.data(), bc.data(), lambda, xp.data(), xc.data());
+      result->n_solves++;
+      for (int p = 0; p < n_points; p++) idist[p] += xp[p];                          // VertexSBAPointID::oplusImpl
+      for (int i = 0; i < n_poses; i++) if (!pose_fixed[i]) se3quat_exp_times(&xc[(size_t)i * 6], poses_f_w[i]);  // VertexSE3Expmap::oplusImpl
+      rc = ba_put_state(B, poses_f_w, idist);
+      if (!rc) rc = ba_launch_errors(B);
+      if (!rc) rc = ba_get(B, chi, B.o_sum, sizeof(chi));
+      if (!rc) rc = sync();
+      if (rc) return rc;
+      tempChi = ok2 ? chi[1] : 1.7976931348623157e308;
+      rho = currentChi - tempChi;
+      double scale = 0.;                                               // computeScale
+      for (int p = 0; p < n_points; p++) scale += xp[p] * (lambda * xp[p] + bp[p]);
+      for (int i = 0; i < n_poses; i++)
+        if (!pose_fixed[i]) for (int q = 0; q < 6; q++) scale += xc[i * 6 + q] * (lambda * xc[i * 6 + q] + bc[i * 6 + q]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+        result->n_accepted++;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        std::copy(poses_bak.begin(), poses_bak.end(), poses_f_w);     // _optimizer->pop(): vertices only, edge errors stay
+        std::copy(idist_bak.begin(), idist_bak.end(), idist);
+        if (int rc2 = ba_put_state(B, poses_f_w, idist)) return rc2;
+      }
+      qmax++;
+    } while (rho < 0 && qmax < 5);   // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
+    result->iterations = it + 1;
+    result->robust_chi2 = currentChi;
+    if (qmax == 5 || rho == 0) { stop = 1; break; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
+    if (nBad >= 3) { stop = 2; break; }
+  }
+  result->stop = stop;
+  result->lambda = lambda;
+  result->final_chi2 = chi[0];   // activeChi2() of the last computeActiveErrors
+  if (edge_chi2_out) {
+    if (int rc = ba_get(B, edge_chi2_out, B.o_chi, sizeof(double) * n_edges)) return rc;
+  }
+  return sync();
 }

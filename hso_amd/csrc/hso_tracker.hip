@@ -1257,12 +1257,18 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
 
 // dynamic LDS: [0, kImgCap) staged level image (address 0 => tap addresses need no base add),
 // then the Shared block
-constexpr int kLdsTotal = 160 * 1024;  // LDS per CU on gfx950
+#ifndef TRK_LDS_KB
+#define TRK_LDS_KB 160  // LDS per CU on gfx950; an 80 KB workgroup lets two of them share a CU
+#endif
+#ifndef TRK_WG_PER_CU
+#define TRK_WG_PER_CU 1
+#endif
+constexpr int kLdsTotal = TRK_LDS_KB * 1024;
 constexpr int kImgCap = (int)(((kLdsTotal - 256 - sizeof(Shared)) / 256) * 256);
 extern __shared__ __attribute__((aligned(16))) char g_smem[];
 
 template <bool IC>
-__global__ __launch_bounds__(TRK_THREADS) void k_track(TrackConsts C, const TrackJobDev* jobs, int n_jobs,
+__global__ __launch_bounds__(TRK_THREADS, 2) void k_track(TrackConsts C, const TrackJobDev* jobs, int n_jobs,
                                                        int* job_counter, char* scratch, size_t scratch_stride,
                                                        hso_track_result* results)
 {
@@ -1459,7 +1465,7 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   st->lds_bytes = (size_t)kImgCap + sizeof(Shared);
   st->n_jobs = n_jobs;
   st->n_max = C.n_max;
-  st->grid = std::min(n_jobs, max_grid > 0 ? max_grid : ctx->n_cu);
+  st->grid = std::min(n_jobs, max_grid > 0 ? max_grid : ctx->n_cu * TRK_WG_PER_CU);
   st->scratch_stride = scratch_bytes(C.n_max);
 
   if (int rc = grow(ctx, &st->d_jobs, &st->jobs_cap, sizeof(TrackJobDev) * n_jobs)) return rc;

@@ -428,6 +428,46 @@ int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8
                          double* Hpp, double* bp, double* Hpc, double* Hcc, double* bc,
                          double* edge_err, double* edge_chi2, double* chi2_sum);
 
+/* Huber deltas of ba::LocalBundleAdjustment, src/bundle_adjustment.cpp:618-680: per non-host observation
+ * e = (project2d(obs->f) - project2d(Tth * fH / idist)) / 2^level; corners collect |e| and edgelets
+ * |grad^T e| as floats; delta = 1.4826 * getMedian (upper median, include/hso/vikit/math_utils.h:119-126),
+ * with the fallbacks 1 / errorMultiplier2 (corner) and 0.5 / errorMultiplier2 (edgelet) when one class is
+ * empty (:664-680; both empty: the reference leaves the deltas uninitialised, here they are returned as 0).
+ * obs_uv[2k..2k+1] = project2d(obs->f) of edge k (for a corner edge this equals edges[k].meas; an edgelet's
+ * meas only keeps grad^T of it).  error_multiplier2 = center_kf->cam_->errorMultiplier2(). */
+int hso_gpu_ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, int n_poses, const double* idist, int n_points,
+                            const hso_ba_edge* edges, const double* obs_uv, int n_edges, double error_multiplier2,
+                            float* huber_corner, float* huber_edge);
+
+/* What runSparseBAOptimizer (src/bundle_adjustment.cpp:351-361) leaves behind. */
+typedef struct hso_ba_result {
+  double init_chi2;     /* optimizer.activeChi2() before optimize(): sum of e^T Omega e */
+  double final_chi2;    /* activeChi2() after optimize(): of the LAST evaluation — a rejected trial's errors when the
+                           last LM step was rejected (g2o pops the vertices, not the edge errors) */
+  double robust_chi2;   /* currentChi (activeRobustChi2 of the accepted state) at exit */
+  double lambda;        /* _currentLambda at exit */
+  int32_t iterations;   /* outer iterations executed (SparseOptimizer::optimize's cjIterations) */
+  int32_t n_solves;     /* LM trials = linear solves in total */
+  int32_t n_accepted;   /* trials with rho > 0 */
+  int32_t stop;         /* 0: iteration budget used; 1: Terminate (trials exhausted or rho == 0); 2: nBad >= 3 */
+} hso_ba_result;
+
+/* The numeric core of ba::LocalBundleAdjustment (src/bundle_adjustment.cpp:815-823 -> runSparseBAOptimizer :351-361 ->
+ * SparseOptimizer::optimize, thirdparty/g2o/g2o/core/sparse_optimizer.cpp:354-420): Levenberg-Marquardt exactly as
+ * OptimizationAlgorithmLevenberg::solve drives it (optimization_algorithm_levenberg.cpp:61-164): lambda0 = 1e-5 * max
+ * diagonal entry, per trial (H + lambda I) x = b, SE3Quat::exp(dx) * pose / idist += dx (se3quat.h:223-257,
+ * bundle_adjustment.h:198-200), rho = (chi - chi_new) / (x^T (lambda x + b) + 1e-3), a good step scales lambda by
+ * clamp(1 - (2 rho - 1)^3, 1/3, 2/3), a bad one by ni (ni *= 2), at most 5 trials (setMaxTrialsAfterFailure(5),
+ * bundle_adjustment.cpp:571), ORB-SLAM's stop: three iterations in a row that gain < 0.1 % (:154-161).
+ * Errors, Jacobians and the robustified blocks come from the device kernels of hso_gpu_ba_linearize; the linear
+ * solve eliminates the 1-D inverse-depth unknowns (scalar Schur complement) and factors the remaining
+ * <= 6 * n_free_poses system densely on the host — the same solution as the reference's sparse LDL^T of the full
+ * system up to rounding.  poses_f_w / idist are updated in place (fixed poses unchanged); edge_chi2_out[n_edges]
+ * (may be NULL) = what edge->chi2() returns after optimize(), the input of the culling at :855-892. */
+int hso_gpu_ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, double* idist,
+                        int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge,
+                        int n_iter, double* edge_chi2_out, hso_ba_result* result);
+
 /* ---- DepthFilter seed observation: DepthFilter::observeDepthRow (src/depth_filter.cpp:580-675),
  *      updateSeed :528-537, computeTau :539-555; Matcher::doLineStereo (src/matcher.cpp:802-1049),
  *      KLTLimited2D/1D :1296-1606, warp::createPatch :159-196, ZMNCC_F

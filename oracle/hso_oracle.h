@@ -117,6 +117,16 @@ void hso_or_ba_linearize(const hso_se3* poses, const uint8_t* pose_fixed, int n_
                          const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge,
                          double* Hpp, double* bp, double* Hpc, double* Hcc, double* bc,
                          double* edge_err, double* edge_chi2, double* chi2_sum);
+void hso_or_ba_huber_deltas(const hso_se3* poses, int n_poses, const double* idist, int n_points, const hso_ba_edge* edges,
+                            const double* obs_uv, int n_edges, double error_multiplier2, float* huber_corner, float* huber_edge); /* bundle_adjustment.cpp:618-680 */
+/* ba::LocalBundleAdjustment's optimisation (bundle_adjustment.cpp:815-823) with g2o's LM driver restated
+ * (optimization_algorithm_levenberg.cpp:61-164, sparse_optimizer.cpp:354-420), full dense system */
+void hso_or_ba_optimize(hso_se3* poses, const uint8_t* pose_fixed, int n_poses, double* idist, int n_points,
+                        const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge, int n_iter,
+                        double* edge_chi2_out, hso_ba_result* res);
+/* g2o::SE3Quat (thirdparty/g2o/g2o/types/se3quat.h): exp of [omega, upsilon] (:223-257), product (:104-110) */
+void hso_or_se3quat_exp(const double update[6], hso_se3* out);
+void hso_or_se3quat_mul(const hso_se3* a, const hso_se3* b, hso_se3* out);
 /* ---- depth-filter seed observation (src/depth_filter.cpp:527-675, src/matcher.cpp:802-1049,1296-1606) ---- */
 void hso_or_update_seed(float x, float tau2, float* mu, float* sigma2);
 double hso_or_compute_tau(const hso_se3* T_ref_cur, const double f[3], double z, double px_error_angle);

@@ -172,3 +172,196 @@ void hso_or_ba_linearize(const hso_se3* poses, const uint8_t* pose_fixed, int n_
     }
   }
 }
+
+/* ---- Huber deltas, src/bundle_adjustment.cpp:618-680 ---- */
+void hso_or_ba_huber_deltas(const hso_se3* poses, int n_poses, const double* idist, int n_points, const hso_ba_edge* edges,
+                            const double* obs_uv, int n_edges, double error_multiplier2, float* huber_corner, float* huber_edge)
+{
+  (void)n_poses; (void)n_points;
+  float* errors_pt = (float*)malloc(sizeof(float) * (size_t)(n_edges > 0 ? n_edges : 1));
+  float* errors_ls = (float*)malloc(sizeof(float) * (size_t)(n_edges > 0 ? n_edges : 1));
+  int n_pt = 0, n_ls = 0;
+  for (int k = 0; k < n_edges; k++) {
+    const hso_ba_edge* e = &edges[k];
+    /* SE3 Tth = (*it_ft)->frame->T_f_w_ * host_frame->T_f_w_.inverse(); pTarget = Tth * pHost (:626-634) */
+    hso_se3 Thw_inv, Tth;
+    hso_or_se3_inverse(&poses[e->host], &Thw_inv);
+    hso_or_se3_mul(&poses[e->target], &Thw_inv, &Tth);
+    const double inv = 1.0 / idist[e->point];
+    const double pH[3] = { e->fH[0] * inv, e->fH[1] * inv, e->fH[2] * inv };
+    double pT[3];
+    hso_or_se3_apply(&Tth, pH, pT);
+    double ex = obs_uv[2 * k] - pT[0] / pT[2], ey = obs_uv[2 * k + 1] - pT[1] / pT[2];
+    const double sc = 1.0 / (1 << e->level);
+    ex *= sc; ey *= sc;
+    if (e->type == HSO_FTR_EDGELET) errors_ls[n_ls++] = (float)fabs(e->normal[0] * ex + e->normal[1] * ey);
+    else errors_pt[n_pt++] = (float)sqrt(ex * ex + ey * ey);
+  }
+  float hc = 0, he = 0;
+  if (n_pt > 0 && n_ls > 0) {
+    hc = (float)(1.4826 * hso_or_median_f(errors_pt, n_pt));
+    he = (float)(1.4826 * hso_or_median_f(errors_ls, n_ls));
+  } else if (n_pt == 0 && n_ls > 0) {
+    hc = (float)(1.0 / error_multiplier2);
+    he = (float)(1.4826 * hso_or_median_f(errors_ls, n_ls));
+  } else if (n_pt > 0 && n_ls == 0) {
+    hc = (float)(1.4826 * hso_or_median_f(errors_pt, n_pt));
+    he = (float)(0.5 / error_multiplier2);
+  }  /* else: the reference leaves both uninitialised (:678-680) */
+  *huber_corner = hc; *huber_edge = he;
+  free(errors_pt); free(errors_ls);
+}
+
+/* ---- the g2o Levenberg-Marquardt driver over the blocks above ----
+ * SparseOptimizer::optimize (sparse_optimizer.cpp:354-420) -> OptimizationAlgorithmLevenberg::solve
+ * (optimization_algorithm_levenberg.cpp:61-164).  The reference factors the full sparse system
+ * (BlockSolverX without marginalised vertices + LinearSolverEigen = SimplicialLDLT); this restatement
+ * assembles the same system densely — unknowns: the points (1 each) then the free poses (6 each) —
+ * and factors it with an unpivoted LDL^T, which is what SimplicialLDLT computes up to the fill-reducing
+ * permutation. */
+static int dense_ldlt_solve(double* A, double* b, int n)   /* A destroyed (lower triangle used), b -> x; 0 on failure */
+{
+  for (int j = 0; j < n; j++) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k] * A[(size_t)k * n + k];
+    if (!(d != 0.0) || !isfinite(d)) return 0;
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k] * A[(size_t)k * n + k];
+      A[(size_t)i * n + j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * b[k]; b[i] = s; }
+  for (int i = 0; i < n; i++) b[i] /= A[(size_t)i * n + i];
+  for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * b[k]; b[i] = s; }
+  return 1;
+}
+
+void hso_or_ba_optimize(hso_se3* poses, const uint8_t* pose_fixed, int n_poses, double* idist, int n_points,
+                        const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge, int n_iter,
+                        double* edge_chi2_out, hso_ba_result* res)
+{
+  int* col = (int*)malloc(sizeof(int) * (size_t)n_poses);
+  int n_free = 0;
+  for (int i = 0; i < n_poses; i++) col[i] = pose_fixed[i] ? -1 : n_points + 6 * n_free++;
+  const int N = n_points + 6 * n_free;
+  double* Hpp = (double*)malloc(sizeof(double) * (size_t)n_points);
+  double* bp = (double*)malloc(sizeof(double) * (size_t)n_points);
+  double* Hpc = (double*)malloc(sizeof(double) * (size_t)n_points * n_poses * 6);
+  double* Hcc = (double*)malloc(sizeof(double) * (size_t)n_poses * n_poses * 36);
+  double* bc = (double*)malloc(sizeof(double) * (size_t)n_poses * 6);
+  double* eerr = (double*)malloc(sizeof(double) * 2 * (size_t)n_edges);
+  double* echi = (double*)malloc(sizeof(double) * (size_t)n_edges);
+  double* A = (double*)malloc(sizeof(double) * (size_t)N * N);
+  double* Al = (double*)malloc(sizeof(double) * (size_t)N * N);
+  double* b = (double*)malloc(sizeof(double) * (size_t)N);
+  double* x = (double*)malloc(sizeof(double) * (size_t)N);
+  hso_se3* poses_bak = (hso_se3*)malloc(sizeof(hso_se3) * (size_t)n_poses);
+  double* idist_bak = (double*)malloc(sizeof(double) * (size_t)n_points);
+  double chi[2];
+  memset(res, 0, sizeof(*res));
+
+  /* runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2() */
+  hso_or_ba_linearize(poses, pose_fixed, n_poses, idist, n_points, edges, n_edges, huber_corner, huber_edge,
+                      Hpp, bp, Hpc, Hcc, bc, eerr, echi, chi);
+  res->init_chi2 = chi[0];
+  double lambda = -1., ni = 2.;
+  int nBad = 0;
+  int stop = 0;
+  for (int it = 0; it < n_iter; it++) {
+    /* solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem */
+    hso_or_ba_linearize(poses, pose_fixed, n_poses, idist, n_points, edges, n_edges, huber_corner, huber_edge,
+                        Hpp, bp, Hpc, Hcc, bc, eerr, echi, chi);
+    double currentChi = chi[1], tempChi = currentChi;
+    const double iniChi = currentChi;
+    memset(A, 0, sizeof(double) * (size_t)N * N);
+    for (int p = 0; p < n_points; p++) {
+      A[(size_t)p * N + p] = Hpp[p]; b[p] = bp[p];
+      for (int c = 0; c < n_poses; c++) {
+        if (col[c] < 0) continue;
+        for (int q = 0; q < 6; q++) {
+          const double v = Hpc[((size_t)p * n_poses + c) * 6 + q];
+          A[(size_t)p * N + col[c] + q] = v; A[(size_t)(col[c] + q) * N + p] = v;
+        }
+      }
+    }
+    for (int i = 0; i < n_poses; i++) {
+      if (col[i] < 0) continue;
+      for (int q = 0; q < 6; q++) b[col[i] + q] = bc[i * 6 + q];
+      for (int j = i; j < n_poses; j++) {
+        if (col[j] < 0) continue;
+        for (int r = 0; r < 6; r++)
+          for (int c = 0; c < 6; c++) {
+            const double v = Hcc[((size_t)i * n_poses + j) * 36 + r * 6 + c];
+            A[(size_t)(col[i] + r) * N + col[j] + c] = v;
+            A[(size_t)(col[j] + c) * N + col[i] + r] = v;
+          }
+      }
+    }
+    if (it == 0) {   /* computeLambdaInit: tau * max |diagonal| */
+      double maxDiagonal = 0.;
+      for (int k = 0; k < N; k++) { const double d = fabs(A[(size_t)k * N + k]); if (d > maxDiagonal) maxDiagonal = d; }
+      lambda = 1e-5 * maxDiagonal;
+      ni = 2; nBad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      memcpy(poses_bak, poses, sizeof(hso_se3) * (size_t)n_poses);      /* _optimizer->push() */
+      memcpy(idist_bak, idist, sizeof(double) * (size_t)n_points);
+      memcpy(Al, A, sizeof(double) * (size_t)N * N);
+      for (int k = 0; k < N; k++) Al[(size_t)k * N + k] += lambda;          /* setLambda(_currentLambda, true) */
+      memcpy(x, b, sizeof(double) * (size_t)N);
+      const int ok2 = dense_ldlt_solve(Al, x, N);
+      res->n_solves++;
+      /* _optimizer->update(x): VertexSBAPointID::oplusImpl, VertexSE3Expmap::oplusImpl */
+      for (int p = 0; p < n_points; p++) idist[p] += x[p];
+      for (int i = 0; i < n_poses; i++) {
+        if (col[i] < 0) continue;
+        hso_se3 d, nw;
+        hso_or_se3quat_exp(&x[col[i]], &d);
+        hso_or_se3quat_mul(&d, &poses[i], &nw);
+        poses[i] = nw;
+      }
+      /* computeActiveErrors; tempChi = activeRobustChi2 */
+      hso_or_ba_linearize(poses, pose_fixed, n_poses, idist, n_points, edges, n_edges, huber_corner, huber_edge,
+                          Hpp, bp, Hpc, Hcc, bc, eerr, echi, chi);
+      tempChi = chi[1];
+      if (!ok2) tempChi = 1.7976931348623157e308;
+      rho = (currentChi - tempChi);
+      double scale = 0.;                                                  /* computeScale */
+      for (int j = 0; j < N; j++) scale += x[j] * (lambda * x[j] + b[j]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+        const double scaleFactor = (1. / 3.) > alpha ? (1. / 3.) : alpha;
+        lambda *= scaleFactor;
+        ni = 2;
+        currentChi = tempChi;
+        res->n_accepted++;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        memcpy(poses, poses_bak, sizeof(hso_se3) * (size_t)n_poses);      /* _optimizer->pop() */
+        memcpy(idist, idist_bak, sizeof(double) * (size_t)n_points);
+      }
+      qmax++;
+    } while (rho < 0 && qmax < 5);                                       /* setMaxTrialsAfterFailure(5), bundle_adjustment.cpp:571 */
+    res->iterations = it + 1;
+    res->robust_chi2 = currentChi;
+    if (qmax == 5 || rho == 0) { stop = 1; break; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;     /* "Stop criterium (Raul)" */
+    if (nBad >= 3) { stop = 2; break; }
+  }
+  res->stop = stop;
+  res->lambda = lambda;
+  /* final_error = activeChi2(): the errors of the last computeActiveErrors, wherever that was */
+  res->final_chi2 = chi[0];
+  if (n_iter <= 0) res->robust_chi2 = chi[1];
+  if (edge_chi2_out) memcpy(edge_chi2_out, echi, sizeof(double) * (size_t)n_edges);
+  free(col); free(Hpp); free(bp); free(Hpc); free(Hcc); free(bc); free(eerr); free(echi); free(A); free(Al); free(b); free(x);
+  free(poses_bak); free(idist_bak);
+}

@@ -295,3 +295,88 @@ DEFINE_SELECT(select_d, double)
 
 float hso_or_median_f(float* data, int n) { return select_f(data, n, n / 2); }
 double hso_or_median_d(double* data, int n) { return select_d(data, n, n / 2); }
+
+/* ---- g2o::SE3Quat (thirdparty/g2o/g2o/types/se3quat.h), the pose type of the local BA ---- */
+
+static void g2o_normalize_rotation(double q[4])
+{
+  /* se3quat.h:280-285 */
+  if (q[3] < 0) { q[0] *= -1; q[1] *= -1; q[2] *= -1; q[3] *= -1; }
+  quat_normalize(q);
+}
+
+void hso_or_se3quat_mul(const hso_se3* a, const hso_se3* b, hso_se3* out)
+{
+  /* se3quat.h:104-110: result._t += _r*tr2._t; result._r *= tr2._r; normalizeRotation() */
+  hso_se3 r;
+  double rt[3];
+  quat_rotate(a->q, b->t, rt);
+  r.t[0] = a->t[0] + rt[0]; r.t[1] = a->t[1] + rt[1]; r.t[2] = a->t[2] + rt[2];
+  quat_mul(a->q, b->q, r.q);
+  g2o_normalize_rotation(r.q);
+  *out = r;
+}
+
+static void mat3_to_quat(const double m[9], double q[4])
+{
+  /* Eigen::Quaternion(Matrix3) — quaternionbase_assign_impl<Other,3,3>, "Quaternion Calculus and Fast Animation" */
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
+    q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+    q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+  }
+}
+
+void hso_or_se3quat_exp(const double update[6], hso_se3* out)
+{
+  /* se3quat.h:223-257: update = [omega, upsilon] */
+  const double* omega = update;
+  const double* upsilon = update + 3;
+  const double theta = sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
+  const double O[9] = { 0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0 };
+  double O2[9], R[9], V[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = O[i * 3 + 0] * O[0 * 3 + j];
+      s += O[i * 3 + 1] * O[1 * 3 + j];
+      s += O[i * 3 + 2] * O[2 * 3 + j];
+      O2[i * 3 + j] = s;
+    }
+  if (theta < 0.00001) {
+    /* R = I + Omega + Omega*Omega ("TODO: CHECK WHETHER THIS IS CORRECT" in the reference); V = R */
+    for (int i = 0; i < 9; i++) {
+      const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+      R[i] = (id + O[i]) + O2[i];
+      V[i] = R[i];
+    }
+  } else {
+    const double a = sin(theta) / theta;
+    const double b = (1 - cos(theta)) / (theta * theta);
+    const double c = (theta - sin(theta)) / (pow(theta, 3));
+    for (int i = 0; i < 9; i++) {
+      const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+      R[i] = (id + a * O[i]) + b * O2[i];
+      V[i] = (id + b * O[i]) + c * O2[i];
+    }
+  }
+  hso_se3 r;
+  mat3_to_quat(R, r.q);
+  for (int i = 0; i < 3; i++) r.t[i] = (V[i * 3 + 0] * upsilon[0] + V[i * 3 + 1] * upsilon[1]) + V[i * 3 + 2] * upsilon[2];
+  g2o_normalize_rotation(r.q);   /* SE3Quat(const Quaterniond&, const Vector3d&), se3quat.h:62-64 */
+  *out = r;
+}

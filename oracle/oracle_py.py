@@ -28,6 +28,30 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "ref"])
 
 
+PORTABLE_FLAGS = "gcc -O3 -std=gnu11 -ffp-contract=off -fno-fast-math (portable x86-64, the parity build)"
+
+
+def use_native_build():
+    """bench.py's cpu_baseline leg only: rebuild the restatement for THIS host with the reference's
+    own optimisation level (-O3 -march=native, CMakeLists.txt:24-41; contraction left to the compiler)
+    into oracle/_native/ and make it the library the wrappers below call.  Returns the flags in use
+    (the portable parity build stays in use if the compiler is unavailable)."""
+    global _lib, LIB_PATH
+    import glob
+    out_dir = os.path.join(_HERE, "_native")
+    out = os.path.join(out_dir, "libhso_oracle_native.so")
+    flags = ["-O3", "-march=native", "-std=gnu11", "-fPIC", "-shared"]
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["gcc"] + flags + ["-o", out] + sorted(glob.glob(os.path.join(_HERE, "hso_oracle_*.c"))) + ["-lm"],
+                              stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return PORTABLE_FLAGS
+    LIB_PATH, _lib = out, None
+    load()
+    return "gcc " + " ".join(flags[:3]) + " (rebuilt on the timing host)"
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -610,3 +634,52 @@ def pattern(max_level, level):
     offs = np.zeros((40, 2), np.int8)
     rc = load().hso_or_tracker_pattern(max_level, level, C.byref(pa), C.byref(hp), _ptr(offs))
     return rc, pa.value, hp.value, offs[:pa.value].copy()
+
+
+def ba_huber_deltas(poses, idist, edges, obs_uv, error_multiplier2):
+    from hso_amd.capi import BA_EDGE_DTYPE
+    lib = load()
+    lib.hso_or_ba_huber_deltas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                           C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.hso_or_ba_huber_deltas.restype = None
+    parr = (SE3 * len(poses))(*poses)
+    idist = np.ascontiguousarray(idist, np.float64)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    obs_uv = np.ascontiguousarray(obs_uv, np.float64)
+    hc, he = C.c_float(), C.c_float()
+    lib.hso_or_ba_huber_deltas(C.cast(parr, C.c_void_p), len(poses), _ptr(idist), len(idist), _ptr(edges), _ptr(obs_uv), len(edges),
+                               error_multiplier2, C.byref(hc), C.byref(he))
+    return hc.value, he.value
+
+
+def ba_optimize(poses, fixed, idist, edges, huber_corner, huber_edge, n_iter):
+    """g2o's LM over the local-BA graph (hso_oracle_ba.c) -> (poses, idist, edge_chi2, BaResult)."""
+    from hso_amd.capi import BA_EDGE_DTYPE, BaResult
+    lib = load()
+    lib.hso_or_ba_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double,
+                                       C.c_double, C.c_int, C.c_void_p, C.POINTER(BaResult)]
+    lib.hso_or_ba_optimize.restype = None
+    parr = (SE3 * len(poses))(*poses)
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    idist = np.array(idist, np.float64)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    chi2 = np.zeros(len(edges))
+    res = BaResult()
+    lib.hso_or_ba_optimize(C.cast(parr, C.c_void_p), _ptr(fixed), len(poses), _ptr(idist), len(idist), _ptr(edges), len(edges),
+                           huber_corner, huber_edge, n_iter, _ptr(chi2), C.byref(res))
+    return list(parr), idist, chi2, res
+
+
+def se3quat_exp(update):
+    lib = load()
+    lib.hso_or_se3quat_exp.argtypes = [C.c_void_p, C.POINTER(SE3)]
+    lib.hso_or_se3quat_exp.restype = None
+    u = np.ascontiguousarray(update, np.float64)
+    o = SE3(); lib.hso_or_se3quat_exp(_ptr(u), C.byref(o)); return o
+
+
+def se3quat_mul(a, b):
+    lib = load()
+    lib.hso_or_se3quat_mul.argtypes = [C.POINTER(SE3)] * 3
+    lib.hso_or_se3quat_mul.restype = None
+    o = SE3(); lib.hso_or_se3quat_mul(C.byref(a), C.byref(b), C.byref(o)); return o

@@ -49,6 +49,10 @@ def test_null_and_inconsistent_arguments(gpu_ctx, cam, pair200):
         assert lib.hso_gpu_seed_observe(h, C.byref(cam), 9600, None, 1.0, 1e-3, None, 4, None) == E_INVALID
         assert lib.hso_gpu_seed_activate(h, C.byref(cam), None, 2, None, None, 6, None, None) == E_INVALID
         assert lib.hso_gpu_ba_linearize(h, None, None, 0, None, 0, None, 0, 1.0, 1.0, *([None] * 8)) == E_INVALID
+        br = capi.BaResult()
+        assert lib.hso_gpu_ba_optimize(h, None, None, 0, None, 0, None, 0, 1.0, 1.0, 10, None, C.byref(br)) == E_INVALID
+        hc, he = C.c_float(), C.c_float()
+        assert lib.hso_gpu_ba_huber_deltas(h, None, 0, None, 0, None, None, 0, 480.0, C.byref(hc), C.byref(he)) == E_INVALID
         counts = (C.c_int32 * 3)()
         assert lib.hso_gpu_fast_detect(h, 9600, 9, 20, 8, None, 0, counts) == E_INVALID      # more levels than the pyramid has
         assert lib.hso_gpu_fast_detect(h, 9600, 3, 300, 8, None, 0, counts) == E_INVALID     # barrier outside 0..255

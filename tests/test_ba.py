@@ -123,3 +123,122 @@ def test_ba_linearize_errors(gpu_ctx):
     bad = edges.copy(); bad["point"][0] = 99
     with pytest.raises(capi.HsoGpuError):
         gpu_ctx.ba_linearize(poses, fixed, idist, bad, 1.0, 1.0)
+
+
+def _obs_uv(edges, rng):
+    """project2d(obs->f) per edge: for corners the measurement itself; for edgelets a point whose
+    grad-projection is the stored scalar measurement (plus a tangential offset the edge never sees)."""
+    uv = np.array(edges["meas"], float)
+    ed = edges["type"] == capi.FTR_EDGELET
+    n = edges["normal"][ed]
+    tang = np.stack([-n[:, 1], n[:, 0]], 1)
+    uv[ed] = n * edges["meas"][ed, :1] + tang * rng.normal(0, 1e-3, (ed.sum(), 1))
+    return uv
+
+
+def test_oracle_se3quat_exp_matches_sophus_exp_for_rotations(orc):
+    """g2o's [omega, upsilon] exponential (se3quat.h:223-257) against Sophus' [upsilon, omega] one: same
+    rotation always; same translation for pure rotations / pure translations; and the 2nd-order small-angle
+    branch (theta < 1e-5: R = I + W + W^2, V = R)."""
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        w = rng.normal(0, 0.2, 3)
+        a = orc.se3quat_exp(np.concatenate([w, np.zeros(3)]))
+        b = orc.se3_exp(np.concatenate([np.zeros(3), w]))
+        assert np.allclose(a.q[:], b.q[:], atol=1e-14) and np.allclose(a.t[:], 0)
+        u = rng.normal(0, 0.3, 3)
+        full = orc.se3quat_exp(np.concatenate([w, u])); soph = orc.se3_exp(np.concatenate([u, w]))
+        assert np.allclose(full.q[:], soph.q[:], atol=1e-14) and np.allclose(full.t[:], soph.t[:], atol=1e-13)
+    tiny = orc.se3quat_exp(np.array([3e-6, -2e-6, 1e-6, 0.1, 0.2, 0.3]))
+    W = np.array([[0, -1e-6, -2e-6], [1e-6, 0, -3e-6], [2e-6, 3e-6, 0]])
+    assert np.allclose(tiny.t[:], (np.eye(3) + W + W @ W) @ [0.1, 0.2, 0.3], atol=1e-15)
+    # composition: exp * pose with the rotation kept normalised and w >= 0
+    p = capi.SE3.from_arrays([0.0, 0.0, 1.0, -1e-3] / np.linalg.norm([0.0, 0.0, 1.0, -1e-3]), [1, 2, 3])
+    m = orc.se3quat_mul(orc.se3quat_exp(np.zeros(6)), p)
+    assert m.q[3] >= 0 and np.isclose(np.linalg.norm(m.q[:]), 1.0)
+
+
+def test_oracle_ba_huber_deltas(orc):
+    poses, fixed, idist, edges = synth.ba_problem(6, 80, 3, seed=21)
+    uv = _obs_uv(edges, np.random.default_rng(1))
+    hc, he = orc.ba_huber_deltas(poses, idist, edges, uv, 480.0)
+    # an independent numpy restatement of src/bundle_adjustment.cpp:618-680
+    e_pt, e_ls = [], []
+    for k, e in enumerate(edges):
+        Tth = orc.se3_mul(poses[e["target"]], orc.se3_inverse(poses[e["host"]]))
+        pT = orc.se3_apply(Tth, e["fH"] / idist[e["point"]])
+        d = (uv[k] - pT[:2] / pT[2]) / (1 << e["level"])
+        (e_ls if e["type"] == capi.FTR_EDGELET else e_pt).append(np.float32(abs(e["normal"] @ d)) if e["type"] == capi.FTR_EDGELET
+                                                                 else np.float32(np.linalg.norm(d)))
+    up = lambda v: np.sort(np.array(v, np.float32))[len(v) // 2]
+    assert hc == np.float32(1.4826 * float(up(e_pt))) and he == np.float32(1.4826 * float(up(e_ls)))
+    only_ls = edges[edges["type"] == capi.FTR_EDGELET]
+    hc2, he2 = orc.ba_huber_deltas(poses, idist, only_ls, uv[edges["type"] == capi.FTR_EDGELET], 480.0)
+    assert hc2 == np.float32(1.0 / 480.0) and he2 == he
+    only_pt = edges[edges["type"] != capi.FTR_EDGELET]
+    hc3, he3 = orc.ba_huber_deltas(poses, idist, only_pt, uv[edges["type"] != capi.FTR_EDGELET], 480.0)
+    assert hc3 == hc and he3 == np.float32(0.5 / 480.0)
+
+
+def test_oracle_ba_optimize_converges_and_follows_g2o_rules(orc):
+    """The LM driver on a synthetic graph with perturbed inverse depths and poses: the robust cost falls,
+    fixed poses stay bit-identical, the first lambda is 1e-5 * max diagonal, and the bookkeeping obeys
+    optimization_algorithm_levenberg.cpp:61-164."""
+    poses, fixed, idist, edges = synth.ba_problem(7, 200, 4, seed=33, px_noise=0.3)
+    rng = np.random.default_rng(5)
+    pert = [orc.se3_mul(orc.se3_exp(np.concatenate([rng.normal(0, 4e-3, 3), rng.normal(0, 2e-3, 3)])), p) if not fixed[i] else p
+            for i, p in enumerate(poses)]
+    hc, he = 0.004, 0.002
+    o0 = orc.ba_linearize(pert, fixed, idist, edges, hc, he)
+    po, io, chi2, res = orc.ba_optimize(pert, fixed, idist, edges, hc, he, 10)
+    assert res.init_chi2 == pytest.approx(o0["chi2_sum"][0], rel=1e-14)
+    assert res.robust_chi2 < 0.5 * o0["chi2_sum"][1] and res.n_accepted >= 2
+    assert 1 <= res.iterations <= 10 and res.n_solves >= res.iterations and res.n_solves <= 5 * res.iterations
+    for i in np.where(fixed)[0]:
+        assert po[i].q[:] == pert[i].q[:] and po[i].t[:] == pert[i].t[:]
+    # final_chi2 / edge_chi2 are those of the last evaluation; when the last step was accepted they are the
+    # chi2 of the returned state
+    if res.stop != 1:
+        o1 = orc.ba_linearize(po, fixed, io, edges, hc, he)
+        assert np.allclose(chi2, o1["edge_chi2"], rtol=1e-12) and res.final_chi2 == pytest.approx(o1["chi2_sum"][0], rel=1e-12)
+        assert res.robust_chi2 == pytest.approx(o1["chi2_sum"][1], rel=1e-12)
+    # zero iterations: nothing moves
+    p0, i0, c0, r0 = orc.ba_optimize(pert, fixed, idist, edges, hc, he, 0)
+    assert r0.iterations == 0 and np.array_equal(i0, idist) and r0.init_chi2 == r0.final_chi2
+    # one iteration from lambda0 = 1e-5 * max diag: reproduce the first trial with numpy
+    H, b = dense_system(o0, len(poses), len(idist))
+    free = np.concatenate([np.arange(len(idist))] + [len(idist) + 6 * i + np.arange(6) for i in range(len(poses)) if not fixed[i]])
+    Hf, bf = H[np.ix_(free, free)], b[free]
+    lam0 = 1e-5 * np.abs(np.diag(Hf)).max()
+    x = np.linalg.solve(Hf + lam0 * np.eye(len(free)), bf)
+    p1, i1, c1, r1 = orc.ba_optimize(pert, fixed, idist, edges, hc, he, 1)
+    if r1.n_solves == 1 and r1.n_accepted == 1:
+        assert np.allclose(i1 - idist, x[:len(idist)], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,seed", [((9, 300, 4), 41), ((12, 500, 5), 42), ((3, 25, 2), 43)])
+def test_ba_optimize_parity(gpu_ctx, orc, shape, seed):
+    """hso_gpu_ba_optimize (device linearisation + Schur / dense LDL^T on the host) against the oracle's
+    full-system LM: identical control flow (iterations, trials, accepted steps, stop reason), poses and
+    inverse depths within 1e-9, per-edge chi2 within 1e-8 relative."""
+    poses, fixed, idist, edges = synth.ba_problem(*shape, seed=seed, px_noise=0.3)
+    rng = np.random.default_rng(seed)
+    pert = [orc.se3_mul(orc.se3_exp(np.concatenate([rng.normal(0, 4e-3, 3), rng.normal(0, 2e-3, 3)])), p) if not fixed[i] else p
+            for i, p in enumerate(poses)]
+    uv = _obs_uv(edges, rng)
+    hc_o, he_o = orc.ba_huber_deltas(pert, idist, edges, uv, 480.0)
+    hc_g, he_g = gpu_ctx.ba_huber_deltas(pert, idist, edges, uv, 480.0)
+    assert (hc_g, he_g) == (hc_o, he_o)
+    for n_iter in (10, 3):
+        po, io, co, ro = orc.ba_optimize(pert, fixed, idist, edges, hc_o, he_o, n_iter)
+        pg, ig, cg, rg = gpu_ctx.ba_optimize(pert, fixed, idist, edges, hc_o, he_o, n_iter)
+        assert (rg.iterations, rg.n_solves, rg.n_accepted, rg.stop) == (ro.iterations, ro.n_solves, ro.n_accepted, ro.stop)
+        assert rg.init_chi2 == pytest.approx(ro.init_chi2, rel=1e-10) and rg.final_chi2 == pytest.approx(ro.final_chi2, rel=1e-8)
+        assert rg.robust_chi2 == pytest.approx(ro.robust_chi2, rel=1e-8) and rg.lambda_ == pytest.approx(ro.lambda_, rel=1e-6)
+        assert np.abs(ig - io).max() <= 1e-9
+        for a, b_ in zip(pg, po):
+            assert np.abs(np.array(a.q[:]) - np.array(b_.q[:])).max() <= 1e-9 and np.abs(np.array(a.t[:]) - np.array(b_.t[:])).max() <= 1e-9
+        assert np.allclose(cg, co, rtol=1e-8, atol=1e-16)
+    for i in np.where(fixed)[0]:
+        assert pg[i].q[:] == pert[i].q[:] and pg[i].t[:] == pert[i].t[:]
