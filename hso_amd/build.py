@@ -42,17 +42,20 @@ def build(force=False, verbose=False, extra=()):
 
 
 def build_host(verbose=False):
-    """The C++ mirror of the reference's call surface (hso_amd/host) + its test driver: plain
-    g++ against the C-ABI only (the library is found at run time through $ORIGIN)."""
+    """The host driver in the reference's own C++ class names (hso_amd/host: FrameHandlerMono::addImage and everything
+    below it) as libhso_host.so (C interface: include/hso_vo.h) + the mirror's test driver: plain g++ against the C-ABI
+    only (the device library is found at run time through $ORIGIN)."""
     host = os.path.join(HERE, "host")
+    rpath = ["-L" + CSRC, "-lhso_gpu", "-Wl,-rpath,$ORIGIN/../csrc",
+             "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
+    srcs = [os.path.join(host, "hso_host.cpp"), os.path.join(host, "hso_vo.cpp")]
+    lib = os.path.join(host, "libhso_host.so")
     exe = os.path.join(host, "hso_host_test")
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", os.path.join(host, "hso_host.cpp"),
-           os.path.join(host, "hso_host_test.cpp"), "-L" + CSRC, "-lhso_gpu",
-           "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib"),
-           "-o", exe]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    for cmd in (["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared"] + srcs + rpath + ["-o", lib],
+                ["g++", "-O2", "-std=c++17", "-Wall"] + srcs + [os.path.join(host, "hso_host_test.cpp")] + rpath + ["-o", exe]):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return exe
 
 

@@ -290,6 +290,7 @@ def load():
     lib.hso_gpu_seed_observe_multi.argtypes = [vp, P(Camera), P(SeedFrame), i32, vp, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
                                           P(AlignOut)]
+    lib.hso_gpu_seed_reproject_match.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, vp, i32, i32, i32, vp, vp]
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
     lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
     lib.hso_gpu_detect_candidates.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
@@ -314,6 +315,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize",
+    "hso_gpu_seed_reproject_match",
 ]
 
 

@@ -48,6 +48,7 @@ struct ActPair {          // kernel 1 -> kernel 2
 struct ActConsts {
   hso_camera cam;
   PyrGeom g;
+  double z_min;   // depth below which the projection test fails: 0.0001 in activatePoint (:748), 0.001 in Reprojector::reprojectorSeed
 };
 
 __global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(ActConsts C, const ActSeedDev* seeds,
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(Act
   {
     double x, y, z;
     se3_apply(Tth, ph0, ph1, ph2, x, y, z);
-    if (z < 0.0001) go = false;
+    if (z < C.z_min) go = false;
     if (go) {
       double pu, pv;
       world2cam(C.cam, x, y, z, pu, pv);
@@ -360,7 +361,7 @@ extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, co
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_seeds, hs.data(), (size_t)n_seeds * sizeof(ActSeedDev), hipMemcpyHostToDevice, ctx->stream));
   if (n_pairs > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_pin, hp.data(), (size_t)n_pairs * sizeof(ActPairIn), hipMemcpyHostToDevice, ctx->stream));
   ActConsts C;
-  C.cam = *cam; C.g = g;
+  C.cam = *cam; C.g = g; C.z_min = 0.0001;
   if (n_pairs > 0) {
     const int blocks = (n_pairs + ACT_WAVES_PER_BLOCK - 1) / ACT_WAVES_PER_BLOCK;
     hipLaunchKernelGGL(k_activate_match, dim3(blocks), dim3(64 * ACT_WAVES_PER_BLOCK), 0, ctx->stream, C, d_seeds, d_pin, n_pairs, d_pout);
@@ -377,5 +378,66 @@ extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, co
   }
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (match_out) for (int k = 0; k < n_pairs; k++) match_out[k] = hpo[k].mo;
+  return HSO_OK;
+}
+
+// Reprojector::reprojectorSeed (reference src/reprojector.cpp:504-529 for seeds: :531-554) + Matcher::findMatchSeed
+// (src/matcher.cpp:442-518) of every given seed in one current frame: the seed branch of reprojectMap (:309-329).
+extern "C" int hso_gpu_seed_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* T_cur_w,
+                                            double cur_exposure, const hso_seed* seeds, int n_seeds, int cell_size, int grid_n_cols,
+                                            hso_reproj_point* proj_out, hso_align_out* match_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!cam || !T_cur_w || n_seeds < 0 || cell_size <= 0 || grid_n_cols <= 0 || (n_seeds > 0 && (!seeds || !proj_out || !match_out)))
+    return hso_fail(ctx, HSO_E_INVALID, "seed_reproject_match: bad argument");
+  if (n_seeds == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto itc = ctx->frames.find(cur_frame_id);
+  if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_reproject_match: current frame not resident");
+  const PyrGeom g = itc->second.g;
+  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_reproject_match: camera size differs from the frame size");
+  std::vector<ActSeedDev> hs(n_seeds);
+  std::vector<ActPairIn> hp(n_seeds);
+  for (int i = 0; i < n_seeds; i++) {
+    auto itr = ctx->frames.find(seeds[i].ref_frame_id);
+    if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_reproject_match: seed host frame not resident");
+    if (itr->second.g.w[0] != g.w[0] || itr->second.g.h[0] != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_reproject_match: frames must share one size");
+    if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_reproject_match: bad level");
+    hs[i].ref_base = itr->second.base; hs[i].s = seeds[i]; hs[i].first = i; hs[i].count = 1;
+    hp[i].cur_base = itc->second.base; hp[i].T_f_w = *T_cur_w; hp[i].exposure = cur_exposure; hp[i].seed = i; hp[i]._pad = 0;
+  }
+  auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const size_t o_pin = al((size_t)n_seeds * sizeof(ActSeedDev));
+  const size_t o_pout = al(o_pin + (size_t)n_seeds * sizeof(ActPairIn));
+  const size_t need = o_pout + (size_t)n_seeds * sizeof(ActPair);
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
+  }
+  ActSeedDev* d_seeds = reinterpret_cast<ActSeedDev*>(ctx->d_batch);
+  ActPairIn* d_pin = reinterpret_cast<ActPairIn*>(ctx->d_batch + o_pin);
+  ActPair* d_pout = reinterpret_cast<ActPair*>(ctx->d_batch + o_pout);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_seeds, hs.data(), (size_t)n_seeds * sizeof(ActSeedDev), hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_pin, hp.data(), (size_t)n_seeds * sizeof(ActPairIn), hipMemcpyHostToDevice, ctx->stream));
+  ActConsts C;
+  C.cam = *cam; C.g = g; C.z_min = 0.001;
+  hipLaunchKernelGGL(k_activate_match, dim3((n_seeds + ACT_WAVES_PER_BLOCK - 1) / ACT_WAVES_PER_BLOCK), dim3(64 * ACT_WAVES_PER_BLOCK), 0,
+                     ctx->stream, C, d_seeds, d_pin, n_seeds, d_pout);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  std::vector<ActPair> hpo(n_seeds);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hpo.data(), d_pout, (size_t)n_seeds * sizeof(ActPair), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n_seeds; i++) {
+    hso_reproj_point r{};
+    r.projected = hpo[i].is_target;
+    r.px[0] = hpo[i].px[0]; r.px[1] = hpo[i].px[1];
+    r.cell = r.projected ? (int)(r.px[1] / cell_size) * grid_n_cols + (int)(r.px[0] / cell_size) : 0;
+    r.ref_obs = -1;
+    proj_out[i] = r;
+    match_out[i] = hpo[i].mo;
+  }
   return HSO_OK;
 }

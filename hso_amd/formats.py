@@ -224,6 +224,12 @@ def ate_rmse(gt_xyz, est_xyz, with_scale=True):
 SNAPSHOT_VERSION = 1
 
 
+def _npz_path(path):
+    """np.savez appends '.npz' to a path without it; save and load agree on the final name."""
+    path = os.fspath(path)
+    return path if path.endswith(".npz") else path + ".npz"
+
+
 def save_snapshot(path, camera, keyframes, images, points, observations, seeds=None, meta=None):
     """keyframes: KF_DTYPE array; images: one u8 image per keyframe (level 0; the pyramid is rebuilt
     on upload); points / observations: MAP_POINT_DTYPE / OBS_DTYPE arrays (obs_begin / kf indices as
@@ -244,7 +250,7 @@ def save_snapshot(path, camera, keyframes, images, points, observations, seeds=N
         n = len(seeds)
         sarr = seeds if isinstance(seeds, C.Array) else (capi.Seed * n)(*seeds)
         arrs["seeds"] = np.frombuffer(bytes(sarr), np.uint8).copy()
-    np.savez_compressed(path, **arrs)
+    np.savez_compressed(_npz_path(path), **arrs)
 
 
 def load_snapshot(path):
@@ -252,7 +258,7 @@ def load_snapshot(path):
     from . import capi
     import ast
     import ctypes as C
-    z = np.load(path)
+    z = np.load(_npz_path(path))
     if int(z["version"][0]) != SNAPSHOT_VERSION:
         raise ValueError("snapshot version %d" % int(z["version"][0]))
     cam = capi.Camera.from_buffer_copy(z["camera"].tobytes())

@@ -1,5 +1,6 @@
 // hso_host.cpp — bodies of the host mirror: thin adapters onto the C-ABI.
 #include "hso_host.h"
+#include "hso_api.h"
 #include <cmath>
 #include <string>
 
@@ -107,6 +108,16 @@ Vector3d AbstractCamera::cam2world(const Vector2d& px) const
 }
 
 int Frame::frame_counter_ = 0;
+int Frame::keyFrameCounter_ = 0;
+int Point::point_counter_ = 0;
+int Seed::batch_counter = 0;
+
+bool Point::deleteFrameRef(Frame* frame)
+{
+  for (auto it = obs_.begin(); it != obs_.end(); ++it)
+    if ((*it)->frame == frame) { obs_.erase(it); return true; }
+  return false;
+}
 
 Frame::Frame(hso_gpu_ctx* ctx, AbstractCamera* cam, const uint8_t* img, int width, int height, double timestamp)
     : id_(frame_counter_++), timestamp_(timestamp), cam_(cam), ctx_(ctx)
@@ -115,8 +126,7 @@ Frame::Frame(hso_gpu_ctx* ctx, AbstractCamera* cam, const uint8_t* img, int widt
   if (!img || width != cam->width() || height != cam->height())
     throw std::runtime_error("Frame: provided image has not the same size as the camera model or image is not grayscale");
   hso_frame_stats st{};
-  const int rc = hso_gpu_frame_upload(ctx_, id_, img, width, height, 0, &st);
-  if (rc < 0) throw std::runtime_error(std::string("Frame: ") + hso_gpu_last_error(ctx_));
+  api::frame_upload(ctx_, id_, img, width, height, &st);
   integralImage_ = st.integral_image;
   gradMean_ = st.grad_mean;
 }
@@ -162,8 +172,7 @@ size_t CoarseTracker::run(FramePtr ref, FramePtr cur)
   job.T_cur_ref = (cur->T_f_w_ * ref->T_f_w_.inverse()).v;           // :63
   job.exposure_rat = cur->integralImage_ / ref->integralImage_;       // :60
   hso_track_params p{m_inverse_composition ? 1 : 0, m_max_level, m_min_level, m_n_iter};
-  const int rc = hso_gpu_coarse_track_batch(cur->ctx_, &cur->cam_->pod(), &p, &job, 1, &m_last);
-  if (rc < 0) throw std::runtime_error(std::string("CoarseTracker: ") + hso_gpu_last_error(cur->ctx_));
+  api::coarse_track(cur->ctx_, &cur->cam_->pod(), &p, &job, &m_last);
   m_T_cur_ref.v = m_last.T_cur_ref;
   // write-back, :198-202
   cur->T_f_w_ = m_T_cur_ref * ref->T_f_w_;
@@ -268,8 +277,8 @@ bool Reprojector::applyMatch(const Candidate& c, FramePtr frame)
   Point* pt = c.pt;
   if (proj_[c.slot].ref_obs < 0 || !m.success) {
     pt->n_failed_reproj_++;
-    if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_failed_reproj_ > 15) pt->type_ = Point::TYPE_DELETED;     // map_.safeDeletePoint
-    if (pt->type_ == Point::TYPE_CANDIDATE && pt->n_failed_reproj_ > 30) pt->type_ = Point::TYPE_DELETED;   // deleteCandidatePoint
+    if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_failed_reproj_ > 15) dropUnknownPoint(pt);        // map_.safeDeletePoint
+    if (pt->type_ == Point::TYPE_CANDIDATE && pt->n_failed_reproj_ > 30) dropCandidatePoint(pt);    // deleteCandidatePoint
     if (pt->type_ == Point::TYPE_TEMPORARY && pt->n_failed_reproj_ > 30) pt->isBad_ = true;
     return false;
   }
@@ -340,6 +349,21 @@ void Reprojector::reprojectMap(FramePtr frame, const std::vector<FramePtr>& kfs,
     }
   }
   if (pts.empty()) return;
+  projectAndMatch(frame, pts);
+  std::vector<Candidate> all;                       // allPixelToDistribute, in projection order
+  for (size_t i = 0; i < pts.size(); ++i) {
+    if (!proj_[i].projected) continue;              // reprojectPoint returned false
+    const Candidate c{pts[i], {proj_[i].px[0], proj_[i].px[1]}, (int)i};
+    cells_.at(proj_[i].cell).push_back(c);
+    all.push_back(c);
+    overlap_kfs[kf_of_pt[i]].second++;
+    nFeatures_++;
+  }
+  selectMatches(frame, all);
+}
+
+void Reprojector::projectAndMatch(FramePtr frame, const std::vector<Point*>& pts)
+{
   // flatten: keyframe table over every frame a host feature or an observation lives in
   std::vector<hso_kf> kft;
   std::vector<const Frame*> kf_frames;
@@ -372,21 +396,16 @@ void Reprojector::reprojectMap(FramePtr frame, const std::vector<FramePtr>& kfs,
   }
   proj_.assign(pts.size(), hso_reproj_point{});
   match_.assign(pts.size(), hso_align_out{});
-  const int rc = hso_gpu_reproject_match(frame->ctx_, &frame->cam_->pod(), frame->id_, &frame->T_f_w_.v, frame->m_exposure_time,
-                                         frame->keyFrameId_, kft.data(), (int)kft.size(), mp.data(), (int)mp.size(), obs.data(),
-                                         (int)obs.size(), cell_size, grid_n_cols, proj_.data(), match_.data());
-  if (rc < 0) throw std::runtime_error(std::string("Reprojector: ") + hso_gpu_last_error(frame->ctx_));
+  api::reproject_match(frame->ctx_, &frame->cam_->pod(), frame->id_, &frame->T_f_w_.v, frame->m_exposure_time, frame->keyFrameId_,
+                       kft.data(), (int)kft.size(), mp.data(), (int)mp.size(), obs.data(), (int)obs.size(), cell_size, grid_n_cols,
+                       proj_.data(), match_.data());
   ref_of_slot_.assign(pts.size(), nullptr);
-  std::vector<Candidate> all;                       // allPixelToDistribute, in projection order
-  for (size_t i = 0; i < pts.size(); ++i) {
-    if (!proj_[i].projected) continue;              // reprojectPoint returned false
-    if (proj_[i].ref_obs >= 0) ref_of_slot_[i] = obs_ftr[proj_[i].ref_obs];
-    const Candidate c{pts[i], {proj_[i].px[0], proj_[i].px[1]}, (int)i};
-    cells_.at(proj_[i].cell).push_back(c);
-    all.push_back(c);
-    overlap_kfs[kf_of_pt[i]].second++;
-    nFeatures_++;
-  }
+  for (size_t i = 0; i < pts.size(); ++i)
+    if (proj_[i].projected && proj_[i].ref_obs >= 0) ref_of_slot_[i] = obs_ftr[proj_[i].ref_obs];
+}
+
+void Reprojector::selectMatches(FramePtr frame, const std::vector<Candidate>& all)
+{
   if (all.size() < (size_t)max_fts_ + 50) {         // reprojectCellAll, :556-612
     for (const Candidate& c : all) {
       ++n_trials_;
@@ -450,9 +469,7 @@ void pose_optimizer::optimizeLevenbergMarquardt3rd(const double reproj_thresh, c
   job.reproj_thresh = reproj_thresh; job.n_iter = (int)n_iter;
   hso_pose_result res{};
   std::vector<uint8_t> mask(feats.size() ? feats.size() : 1, 0);
-  uint8_t* mp = mask.data();
-  const int rc = hso_gpu_pose_optimize_batch(frame->ctx_, &frame->cam_->pod(), &job, 1, &res, &mp);
-  if (rc < 0) throw std::runtime_error(std::string("pose_optimizer: ") + hso_gpu_last_error(frame->ctx_));
+  api::pose_optimize(frame->ctx_, &frame->cam_->pod(), &job, &res, mask.data());
   estimated_scale = res.estimated_scale; error_init = res.error_init; error_final = res.error_final;
   num_obs = (size_t)res.num_obs;
   if (res.status != 0) return;                      // no residuals: the reference returns early (:456)
@@ -465,9 +482,10 @@ void pose_optimizer::optimizeLevenbergMarquardt3rd(const double reproj_thresh, c
 
 // ---------------------------------------------------------------- DepthFilter
 Seed::Seed(Feature* ftr_, float depth_mean, float depth_min, float converge_threshold)
-    : ftr(ftr_), mu(1.0f / depth_mean), z_range(1.0f / depth_min), sigma2(z_range * z_range / 36)
+    : ftr(ftr_), mu((float)(1.0 / depth_mean)), z_range((float)(1.0 / depth_min)), sigma2(z_range * z_range / 36)
 {
-  (void)converge_threshold;
+  vec_distance.push_back(depth_mean);    // src/depth_filter.cpp:64
+  converge_thresh = converge_threshold;
 }
 
 void DepthFilter::updateSeed(float x, float tau2, Seed* seed)
@@ -526,16 +544,15 @@ void FeatureExtractor::detect(Frame* frame, float initThresh, float minThresh, F
   for (;;) {
     co.resize((size_t)nLevels_ * corner_cap);
     // :439-447: fillingHole on level 0 while initialising, the edgelets of every level otherwise
-    const int rc = isInit_ ? hso_gpu_detect_candidates_init(frame->ctx_, &id, 1, nLevels_, minThresh_, co.data(), corner_cap, nc.data(),
-                                                            fill.data(), edgelet_cap, &n_fill)
-                           : hso_gpu_detect_candidates(frame->ctx_, &id, 1, nLevels_, minThresh_, co.data(), corner_cap, nc.data(),
-                                                       ed.data(), edgelet_cap, ne.data());
-    if (rc < 0) throw std::runtime_error(std::string("FeatureExtractor: ") + hso_gpu_last_error(frame->ctx_));
+    api::detect_candidates(frame->ctx_, isInit_, id, nLevels_, minThresh_, co.data(), corner_cap, nc.data(), ed.data(), fill.data(),
+                           edgelet_cap, isInit_ ? &n_fill : ne.data());
     int most = 0;
     for (int c : nc) most = c > most ? c : most;
     if (most <= corner_cap) break;
     corner_cap = most;                  // a frame with more corners than the first guess: once more with room for all
   }
+  api::trace_candidates(isInit_, id, nLevels_, minThresh_, co.data(), corner_cap, nc.data(), ed.data(), fill.data(), edgelet_cap,
+                        isInit_ ? &n_fill : ne.data());
   // featurePerLevel_[L] = corners then edgelets (:518-545, :749-830), appended level by level (:449-451)
   for (int L = 0; L < nLevels_; ++L) {
     for (int i = 0; i < nc[L]; ++i) {
@@ -558,9 +575,8 @@ void FeatureExtractor::detect(Frame* frame, float initThresh, float minThresh, F
     }
   }
   std::vector<hso_keypoint> sel(allFeturesToDistribute_.size() + 1);
-  const int n = hso_gpu_select_octree(allFeturesToDistribute_.data(), (int)allFeturesToDistribute_.size(), 0, width_, 0, height_,
-                                         nFeatures_, sel.data(), (int)sel.size());
-  if (n < 0) throw std::runtime_error("FeatureExtractor: oct-tree selection failed");
+  const int n = api::select_octree(allFeturesToDistribute_.data(), (int)allFeturesToDistribute_.size(), width_, height_, nFeatures_,
+                                   sel.data(), (int)sel.size());
   for (int i = 0; i < n; ++i) {          // :457-484
     const hso_keypoint& k = sel[i];
     Feature* f = new Feature();
@@ -619,9 +635,8 @@ size_t DepthFilter::observeDepth(FramePtr frame)
   }
   if (in.empty()) return 0;
   std::vector<hso_seed_out> out(in.size());
-  const int rc = hso_gpu_seed_observe(frame->ctx_, &frame->cam_->pod(), frame->id_, &frame->T_f_w_.v, frame->m_exposure_time,
-                                      px_error_angle_, in.data(), (int)in.size(), out.data());
-  if (rc < 0) throw std::runtime_error(std::string("DepthFilter: ") + hso_gpu_last_error(frame->ctx_));
+  api::seed_observe(frame->ctx_, &frame->cam_->pod(), frame->id_, &frame->T_f_w_.v, frame->m_exposure_time, px_error_angle_, in.data(),
+                    (int)in.size(), out.data());
   size_t n_ok = 0, k = 0;
   for (auto it = seeds_.begin(); it != seeds_.end(); ++k) {
     const hso_seed_out& o = out[k];

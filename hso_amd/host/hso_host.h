@@ -64,6 +64,14 @@ public:
   int last_projected_kf_id_ = -1;                                                              // point.h:73
   int n_failed_reproj_ = 0, n_succeeded_reproj_ = 0;                                           // point.h:75-76
   bool isBad_ = false;
+  static int point_counter_;
+  int id_ = point_counter_++;
+  int seedStates_ = 0;            // temporary points: 0 seed still alive, 1 converged, -1 dropped (point.h)
+  int nBA_ = 0;
+  Point() = default;
+  Point(const Vector3d& pos, Feature* ftr) : pos_(pos) { obs_.push_front(ftr); }                // src/point.cpp:55-73
+  void addFrameRef(Feature* ftr) { obs_.push_front(ftr); }                                     // :78-82
+  bool deleteFrameRef(Frame* frame);                                                           // :92-102
   // src/point.cpp:116-136: the observation whose viewing direction is closest to `framepos`
   bool getCloseViewObs(const Vector3d& framepos, Feature*& ftr) const;
 };
@@ -98,6 +106,20 @@ public:
   SE3 T_f_w_;
   Vector3d pos() const { return T_f_w_.inverse().translation(); }   // include/hso/frame.h:142
   int keyFrameId_ = 0;
+  static int keyFrameCounter_;   // src/frame.cpp:36
+  bool is_keyframe_ = false;
+  bool isKeyframe() const { return is_keyframe_; }
+  void setKeyframe();                          // src/frame.cpp:98-105
+  void setKeyPoints();                         // :121-129
+  void checkKeyPoints(Feature* ftr);           // :131-179
+  void removeKeyPoint(Feature* ftr);           // :181-192
+  bool isVisible(const Vector3d& xyz_w) const; // :194-204
+  void addFeature(Feature* ftr) { fts_.push_back(ftr); }   // :107-111
+  std::array<Feature*, 5> key_pts_{{nullptr, nullptr, nullptr, nullptr, nullptr}};   // frame.h:88
+  std::vector<Frame*> connectedKeyFrames;      // frame.h: covisibility neighbours of this frame (<= 5)
+  std::shared_ptr<Frame> m_last_frame;         // the frame it was tracked against
+  int lastReprojectFrameId_ = -1;
+  size_t m_n_inliers = 0;
   Features fts_;                 // owned, deleted by ~Frame (src/frame.cpp:54-72)
   float integralImage_ = 0;      // src/frame.cpp:238
   float gradMean_ = 0;           // src/frame.cpp:240-245
@@ -158,13 +180,24 @@ public:
   size_t n_matches_ = 0, n_trials_ = 0, nFeatures_ = 0;
   int cell_size, grid_n_cols, grid_n_rows, max_fts_;
   size_t max_n_kfs = 10;           // Options::max_n_kfs, reprojector.h:67
-private:
+  virtual ~Reprojector() {}
+protected:
+  // project every point into `frame`, choose its reference observation and match it: one device call
+  // (hso_gpu_reproject_match); fills proj_ / match_ / ref_of_slot_ in the order of `pts`
+  void projectAndMatch(FramePtr frame, const std::vector<Point*>& pts);
+  // reprojectCellAll or the three reprojectCell passes over the cells (:261-306)
+  void selectMatches(FramePtr frame, const std::vector<Candidate>& all);
   bool reprojectCell(Cell& cell, FramePtr frame, bool is_2nd, bool is_3rd);
   bool applyMatch(const Candidate& c, FramePtr frame);
+  // what the reference hands to Map::safeDeletePoint / MapPointCandidates::deleteCandidatePoint (:377-380);
+  // without a map behind the reprojector the point is only marked
+  virtual void dropUnknownPoint(Point* pt) { pt->type_ = Point::TYPE_DELETED; }
+  virtual void dropCandidatePoint(Point* pt) { pt->type_ = Point::TYPE_DELETED; }
   std::vector<Cell> cells_;
   std::vector<hso_align_out> match_;
   std::vector<hso_reproj_point> proj_;
   std::vector<const Feature*> ref_of_slot_;
+  void* map_ptr_ = nullptr;
 };
 
 // include/hso/pose_optimizer.h — motion-only refinement of frame->T_f_w_ over its features' points
@@ -177,10 +210,17 @@ void optimizeLevenbergMarquardt3rd(const double reproj_thresh, const size_t n_it
 
 // include/hso/depth_filter.h:45-88
 struct Seed {
+  static int batch_counter;      // src/depth_filter.cpp:46
+  int batch_id = batch_counter;  // the keyframe batch the seed was created in
   Feature* ftr = nullptr;        // host feature (frame, px, f, level, type, grad)
   float a = 10, b = 10;
   float mu = 0, z_range = 0, sigma2 = 0;
-  bool is_update = false;
+  bool is_update = false, isValid = true;
+  bool haveReprojected = false;
+  Point* temp = nullptr;         // the temporary point Reprojector::reprojectorSeeds made of it
+  std::vector<float> vec_distance;
+  std::vector<FramePtr> optFrames_P, optFrames_A;
+  float opt_id = 0, converge_thresh = 200;
   Vector2d last_matched_px{0, 0};
   int last_matched_level = 0;
   Seed(Feature* ftr, float depth_mean, float depth_min, float converge_threshold = 200);  // src/depth_filter.cpp:49-68

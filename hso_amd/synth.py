@@ -7,13 +7,24 @@ touches the GPU or the oracle.
 """
 import numpy as np
 
-from .capi import REF_FEAT_DTYPE, CAM_PINHOLE, make_camera
+from .capi import REF_FEAT_DTYPE, CAM_PINHOLE, CAM_FOV, make_camera
 
 # test/cameras/icl-nuim.txt of the reference: pinhole 481.2 480 319.5 239.5, 640x480
 ICL_NUIM = dict(model=CAM_PINHOLE, width=640, height=480, fx=481.2, fy=480.0, cx=319.5, cy=239.5)
 # test/cameras/euroc.txt: pinhole + radtan, 752x480
 EUROC = dict(model=CAM_PINHOLE, width=752, height=480, fx=458.654, fy=457.296, cx=367.215, cy=248.375,
              d=(-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0))
+
+
+# test/cameras/tum_mono_vo_wide.txt at the reference's internal 920x736 (test/test_dataset.cpp:218-224).  Its third line is
+# "true": the image is rectified first (cv::remap, outside the hot path) and the FOV camera then projects without distortion
+# (src/camera.cpp:171-221, undistort_ branch).
+TUM_WIDE = dict(model=CAM_FOV, width=920, height=736, fx=0.349153 * 920, fy=0.436593 * 736, cx=0.49314 * 920, cy=0.499021 * 736,
+                d=(0.933271,), distortion=0)
+# the same sensor geometry with the FOV distortion left in the projection (third line "false").  omega is reduced so that
+# dist * omega < pi / 2 up to the image corners (with the file's 0.933 the model's tan() turns over inside the 920x736 frame,
+# which is why the reference rectifies that camera)
+FOV_920 = dict(TUM_WIDE, d=(0.6,), distortion=1)
 
 
 def camera(spec=ICL_NUIM):
@@ -42,8 +53,9 @@ class Scene:
         self.spec = dict(spec)
         self.w, self.h = spec["width"], spec["height"]
         self.fx, self.fy, self.cx, self.cy = spec["fx"], spec["fy"], spec["cx"], spec["cy"]
-        self.d = np.array(list(spec.get("d", (0, 0, 0, 0, 0))), float)
-        self.distortion = abs(self.d[0]) > 1e-7
+        self.d = np.array(list(spec.get("d", (0, 0, 0, 0, 0))) + [0.0] * 5, float)[:5]
+        self.model = spec.get("model", CAM_PINHOLE)
+        self.distortion = bool(spec.get("distortion", 1)) if self.model == CAM_FOV else abs(self.d[0]) > 1e-7
         rng = np.random.default_rng(seed)
         om = rng.uniform(0.02, 0.6, n_waves)
         ang = rng.uniform(0, 2 * np.pi, n_waves)
@@ -71,6 +83,13 @@ class Scene:
     # camera (src/camera.cpp:94-125 formulas, vectorised for data generation only)
     def project(self, X):
         u, v = X[..., 0] / X[..., 2], X[..., 1] / X[..., 2]
+        if self.model == CAM_FOV:
+            if self.distortion:                      # FOVCamera::world2cam, src/camera.cpp:196-221
+                om = self.d[0]
+                dist = np.sqrt(u * u + v * v)
+                ratio = np.where(dist > 1e-12, np.arctan(2 * dist * np.tan(om / 2)) / (np.maximum(dist, 1e-12) * om), 1.0)
+                u, v = ratio * u, ratio * v
+            return self.fx * u + self.cx, self.fy * v + self.cy
         if self.distortion:
             d = self.d
             r2 = u * u + v * v
@@ -81,6 +100,13 @@ class Scene:
 
     def unproject(self, px, py):
         x, y = (px - self.cx) / self.fx, (py - self.cy) / self.fy
+        if self.model == CAM_FOV:
+            if self.distortion:                      # FOVCamera::cam2world, src/camera.cpp:171-194
+                om = self.d[0]
+                dist = np.sqrt(x * x + y * y)
+                rd = np.where(dist > 1e-12, np.tan(np.maximum(dist, 1e-12) * om) / (2 * np.maximum(dist, 1e-12) * np.tan(om / 2)), 1.0)
+                x, y = rd * x, rd * y
+            return np.stack([x, y, np.ones_like(x)], -1)
         if self.distortion:
             d = self.d
             x0, y0 = x, y
@@ -475,3 +501,34 @@ def map_problem(n_points=1500, n_kfs=6, seed=71, spec=ICL_NUIM, noise=1.0, trans
     return dict(scene=sc, frames=frames, cur=cur, kfs=kfs, points=points, obs=obs, T_cur_w=SE3.from_arrays(q_cur, t_cur),
                 cur_exposure=1.06, cur_keyframe_id=n_kfs + 2, cell_size=cell_size, grid_n_cols=int(np.ceil(w / cell_size)),
                 cur_frame_id=first_frame_id + n_kfs + 1)
+
+
+def _render_frame(args):
+    spec, seed, q, t, expo, noise, k = args
+    return Scene(spec, seed).render(np.asarray(q), np.asarray(t), expo, noise, seed + 100 + k)
+
+
+def sequence(n_frames=60, spec=EUROC, seed=2024, step=(0.016, 0.005, 0.007), rot_deg_per_frame=(0.05, -0.12, 0.03), noise=1.0,
+             exposure_wobble=0.03, workers=None):
+    """A synthetic image sequence over the analytic scene: frame k sees the scene from T_k_0 = (q_k, t_k), a smooth
+    constant-velocity-like path with a slow sinusoidal modulation (so the motion model is good but not exact).
+    Returns dict(images [n], T_f_w [(q, t)], exposure [n], depth0 (optical-axis depth image of frame 0), scene, spec)."""
+    import multiprocessing as mp
+    import os
+    poses, expos = [], []
+    for k in range(n_frames):
+        s = k + 1.5 * np.sin(k / 9.0)                       # modulated arc length
+        rv = np.deg2rad(np.array(rot_deg_per_frame)) * s
+        poses.append((rotvec_to_quat(rv), np.array(step) * s))
+        expos.append(1.0 + exposure_wobble * np.sin(k / 5.0))
+    jobs = [(dict(spec), seed, list(q), list(t), expos[k], noise, k) for k, (q, t) in enumerate(poses)]
+    workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 32))
+    if workers == 1:
+        images = [_render_frame(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            images = pool.map(_render_frame, jobs, chunksize=1)
+    sc = Scene(spec, seed)
+    ys, xs = np.mgrid[0:sc.h, 0:sc.w].astype(np.float64)
+    depth0 = sc.points0(xs, ys)[..., 2].astype(np.float32)
+    return dict(images=images, T_f_w=poses, exposure=expos, depth0=depth0, scene=sc, spec=dict(spec))

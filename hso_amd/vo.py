@@ -1,0 +1,133 @@
+"""ctypes binding of the host driver (include/hso_vo.h, hso_amd/host/libhso_host.so): the reference's
+FrameHandlerMono::addImage pipeline in C++ over the device library, plus a reader for the driver's
+C-ABI call trace (hso_amd/host/hso_trace.h).  Plumbing for the harness and the tests."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "host", "libhso_host.so")
+
+
+class VoStatus(C.Structure):
+    _fields_ = [("T_f_w", capi.SE3), ("timestamp", C.c_double), ("exposure_time", C.c_double),
+                ("frame_id", C.c_int32), ("keyframe_id", C.c_int32), ("is_keyframe", C.c_int32), ("stage", C.c_int32),
+                ("tracking_quality", C.c_int32), ("result", C.c_int32),
+                ("n_features", C.c_int32), ("n_inliers", C.c_int32), ("n_tracked", C.c_int32), ("n_matches", C.c_int32),
+                ("n_trials", C.c_int32), ("n_seed_matches", C.c_int32), ("n_seeds", C.c_int32), ("n_candidates", C.c_int32),
+                ("n_keyframes", C.c_int32), ("used_inverse", C.c_int32), ("ba_removed_1", C.c_int32), ("ba_removed_2", C.c_int32),
+                ("pose_error_init", C.c_double), ("pose_error_final", C.c_double), ("ba_error_init", C.c_double),
+                ("ba_error_final", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    capi.load()                      # the device library (and torch's HIP runtime) first
+    if not os.path.exists(LIB_PATH):
+        raise capi.HsoGpuError("libhso_host.so is not built (%s): run `python -m hso_amd.build`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, P = C.c_void_p, C.c_int, C.POINTER
+    lib.hso_vo_create.argtypes = [P(vp), P(capi.Camera), i32, i32]
+    lib.hso_vo_destroy.argtypes = [vp]
+    lib.hso_vo_destroy.restype = None
+    lib.hso_vo_last_error.argtypes = [vp]
+    lib.hso_vo_last_error.restype = C.c_char_p
+    lib.hso_vo_trace.argtypes = [vp, C.c_char_p]
+    lib.hso_vo_set_first_frame.argtypes = [vp, vp, i32, i32, C.c_double, vp, P(capi.SE3)]
+    lib.hso_vo_add_image.argtypes = [vp, vp, i32, i32, C.c_double]
+    lib.hso_vo_get_status.argtypes = [vp, P(VoStatus)]
+    lib.hso_vo_get_keyframes.argtypes = [vp, vp, vp, vp, i32]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso_vo_trace", "hso_vo_set_first_frame",
+                    "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes"]
+
+
+class VisualOdometry:
+    """FrameHandlerMono behind the C interface."""
+
+    def __init__(self, cam, max_fts=200, device=0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.hso_vo_create(C.byref(self.h), C.byref(cam), int(max_fts), int(device))
+        if rc < 0:
+            raise capi.HsoGpuError("hso_vo_create failed: %d" % rc)
+        self.cam = cam
+
+    def close(self):
+        if self.h:
+            self.lib.hso_vo_trace(self.h, None)
+            self.lib.hso_vo_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise capi.HsoGpuError("%s failed (%d): %s" % (what, rc, (self.lib.hso_vo_last_error(self.h) or b"?").decode()))
+
+    def trace(self, path):
+        self._check(self.lib.hso_vo_trace(self.h, path.encode() if path else None), "trace")
+
+    def set_first_frame(self, img, depth_z, timestamp=0.0, T_f_w=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        depth_z = np.ascontiguousarray(depth_z, np.float32)
+        assert depth_z.shape == img.shape
+        self._check(self.lib.hso_vo_set_first_frame(self.h, capi._ptr(img), img.shape[1], img.shape[0], float(timestamp),
+                                                    capi._ptr(depth_z), C.byref(T_f_w) if T_f_w is not None else None),
+                    "set_first_frame")
+
+    def add_image(self, img, timestamp):
+        img = np.ascontiguousarray(img, np.uint8)
+        self._check(self.lib.hso_vo_add_image(self.h, capi._ptr(img), img.shape[1], img.shape[0], float(timestamp)), "add_image")
+        return self.status()
+
+    def status(self):
+        st = VoStatus()
+        self._check(self.lib.hso_vo_get_status(self.h, C.byref(st)), "get_status")
+        return st
+
+    def keyframes(self):
+        n = self.lib.hso_vo_get_keyframes(self.h, None, None, None, 0)
+        ts = np.zeros(max(n, 1)); T = (capi.SE3 * max(n, 1))(); ids = np.zeros(max(n, 1), np.int32)
+        self.lib.hso_vo_get_keyframes(self.h, capi._ptr(ts), C.cast(T, C.c_void_p), capi._ptr(ids), n)
+        return [(float(ts[i]), T[i], int(ids[i])) for i in range(n)]
+
+
+def read_trace(path):
+    """-> list of (call name, {field: bytes}) in call order; scalars are 8-byte doubles (scalar())."""
+    data = open(path, "rb").read()
+    pos, out = 0, []
+    while pos + 12 <= len(data):
+        magic, nl = struct.unpack_from("<II", data, pos); pos += 8
+        if magic != 0x52545348:
+            raise ValueError("bad trace record at %d" % (pos - 8))
+        name = data[pos:pos + nl].decode(); pos += nl
+        (nf,) = struct.unpack_from("<I", data, pos); pos += 4
+        rec = {}
+        for _ in range(nf):
+            (kl,) = struct.unpack_from("<I", data, pos); pos += 4
+            key = data[pos:pos + kl].decode(); pos += kl
+            (nb,) = struct.unpack_from("<Q", data, pos); pos += 8
+            rec[key] = data[pos:pos + nb]; pos += nb
+        out.append((name, rec))
+    return out
+
+
+def scalar(rec, key):
+    return struct.unpack("<d", rec[key])[0]

@@ -550,6 +550,16 @@ int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_see
                           const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
                           hso_activate_out* out, hso_align_out* match_out);
 
+/* The seed branch of Reprojector::reprojectMap (src/reprojector.cpp:309-329): reprojectorSeed (:531-554) — pTarget =
+ * (T_cur_w * T_ref_w^-1) * (f / mu), rejected when its z < 0.001 or its truncated pixel lies within 8 px of the border —
+ * and Matcher::findMatchSeed (src/matcher.cpp:442-518: parallax test, warp, exposure compensation, align1D / align2D,
+ * NCC 0.8) of every seed in one launch.  proj_out[i].projected / px / cell (ref_obs unused), match_out[i] = the
+ * findMatchSeed result (zero when not projected or the parallax test failed).  The caller keeps which seeds take part
+ * (sigma test, haveReprojected), the per-cell sigma2 order and the first-success-per-cell rule. */
+int hso_gpu_seed_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_frame_id, const hso_se3* T_cur_w,
+                                 double cur_exposure, const hso_seed* seeds, int n_seeds, int cell_size, int grid_n_cols,
+                                 hso_reproj_point* proj_out, hso_align_out* match_out);
+
 /* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
  *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,
  *      fast_corner_score_9, fast_nonmax_3x3 (thirdparty/fast/src) — and hso::shiTomasiScore

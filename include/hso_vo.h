@@ -1,0 +1,54 @@
+/*
+ * hso_vo.h — C interface of the host driver (libhso_host.so): the reference's FrameHandlerMono with its
+ * addImage() entry (include/hso/frame_handler_mono.h:43-50, src/frame_handler_mono.cpp:80-123), as a maintainer's
+ * harness, a language binding or `python -m hso_amd.run_sequence` drives it.  The driver is C++ in the reference's
+ * own class names (hso_amd/host/hso_vo.h); every numeric step inside it is a call into the device library
+ * (include/hso_gpu.h).  What test/test_dataset.cpp does with the class (:264-286, :312-335) maps to:
+ *   new FrameHandlerMono(cam, false)          hso_vo_create
+ *   vo->addImage(img, id, &stamp)             hso_vo_add_image
+ *   vo->lastFrame(), map_.keyframes_          hso_vo_get_status, hso_vo_get_keyframes
+ * The two-view initialisation (src/initialization.cpp: OpenCV KLT + essential-matrix RANSAC) is not part of the
+ * hot path; a sequence starts from hso_vo_set_first_frame — the setFirstFrame hook the reference keeps for
+ * synthetic data (frame_handler_mono.h:49-50, .cpp:419-426) — with a depth image for the first keyframe.
+ */
+#ifndef HSO_VO_H
+#define HSO_VO_H
+#include "hso_gpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hso_vo hso_vo;
+
+/* max_fts = Config::maxFts() (200 by default in the reference; it sizes the reprojection grid and the detector budget) */
+int hso_vo_create(hso_vo** out, const hso_camera* cam, int max_fts, int device);
+void hso_vo_destroy(hso_vo* vo);
+const char* hso_vo_last_error(const hso_vo* vo);
+/* record every device call of the driver (inputs and outputs in the C-ABI's table layouts) to `path`; NULL stops */
+int hso_vo_trace(hso_vo* vo, const char* path);
+/* first keyframe: features are detected the way the initialisation detects them and every feature with
+ * depth_z[y * width + x] > 0 (depth along the optical axis, metres) becomes a map point hosted in this frame */
+int hso_vo_set_first_frame(hso_vo* vo, const uint8_t* img, int width, int height, double timestamp, const float* depth_z,
+                           const hso_se3* T_f_w /* NULL = identity */);
+/* FrameHandlerMono::addImage.  HSO_E_INVALID with hso_vo_last_error() where the reference throws (wrong image size). */
+int hso_vo_add_image(hso_vo* vo, const uint8_t* img, int width, int height, double timestamp);
+
+typedef struct hso_vo_status {
+  hso_se3 T_f_w;              /* lastFrame()->T_f_w_ */
+  double timestamp, exposure_time;
+  int32_t frame_id, keyframe_id, is_keyframe;
+  int32_t stage;              /* FrameHandlerBase::Stage: 0 paused, 1 first, 2 second, 3 default, 4 relocalizing */
+  int32_t tracking_quality;   /* 0 insufficient, 1 bad, 2 good */
+  int32_t result;             /* UpdateResult: 0 no keyframe, 1 keyframe, 2 failure */
+  int32_t n_features, n_inliers, n_tracked, n_matches, n_trials, n_seed_matches, n_seeds, n_candidates, n_keyframes, used_inverse;
+  int32_t ba_removed_1, ba_removed_2;
+  double pose_error_init, pose_error_final, ba_error_init, ba_error_final;
+} hso_vo_status;
+int hso_vo_get_status(hso_vo* vo, hso_vo_status* st);
+/* map_.keyframes_ in list order (what BenchmarkNode::saveResult writes): returns the number of keyframes, fills at most cap */
+int hso_vo_get_keyframes(hso_vo* vo, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -84,3 +84,35 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"hso_or_|oracle_py|from oracle|import oracle|libhso_oracle", txt):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_host_driver_library_exports_its_c_interface(lib):
+    """libhso_host.so (the FrameHandlerMono::addImage pipeline in C++) loads without a GPU, exports every symbol
+    include/hso_vo.h declares, and refuses to create a driver without a device."""
+    from hso_amd import vo
+    src = open(os.path.join(ROOT, "include", "hso_vo.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(hso_vo_\w+)\s*\(", src)))
+    hl = vo.load()
+    for n in names:
+        assert hasattr(hl, n), n
+    assert sorted(vo.EXPORTED_SYMBOLS) == names
+    import torch
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        cam = capi.make_camera(capi.CAM_PINHOLE, 640, 480, 480, 480, 320, 240)
+        assert hl.hso_vo_create(C.byref(h), C.byref(cam), 200, 0) < 0 and not h.value
+        assert hl.hso_vo_last_error(None) == b"null handle"
+
+
+def test_trace_reader_round_trip(tmp_path):
+    """The driver's call trace format (hso_amd/host/hso_trace.h) as vo.read_trace parses it."""
+    import struct
+    from hso_amd import vo
+    p = tmp_path / "t.bin"
+    rec = struct.pack("<II", 0x52545348, 4) + b"call" + struct.pack("<I", 2)
+    rec += struct.pack("<I", 1) + b"x" + struct.pack("<Q", 8) + struct.pack("<d", 2.5)
+    rec += struct.pack("<I", 3) + b"tab" + struct.pack("<Q", 3) + b"abc"
+    p.write_bytes(rec * 2)
+    out = vo.read_trace(str(p))
+    assert [n for n, _ in out] == ["call", "call"] and vo.scalar(out[1][1], "x") == 2.5 and out[0][1]["tab"] == b"abc"
