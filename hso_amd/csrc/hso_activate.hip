@@ -330,13 +330,13 @@ extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, co
     auto itr = ctx->frames.find(seeds[i].ref_frame_id);
     if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: seed host frame not resident");
     if (!have_g) { g = itr->second.g; have_g = true; }
-    if (itr->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
+    if (!same_geom(itr->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
     if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad level");
     hs[i].ref_base = itr->second.base; hs[i].s = seeds[i]; hs[i].first = b; hs[i].count = e - b;
     for (int k = b; k < e; k++) {
       auto itt = ctx->frames.find(targets[k].frame_id);
       if (itt == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: target frame not resident");
-      if (itt->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
+      if (!same_geom(itt->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
       hp[k].cur_base = itt->second.base; hp[k].T_f_w = targets[k].T_f_w; hp[k].exposure = targets[k].exposure;
       hp[k].seed = i; hp[k]._pad = 0;
     }

@@ -70,12 +70,12 @@ static int align_run(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur
       auto itc = ctx->frames.find(cid);
       if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "align_batch: current frame not resident");
       if (i == 0) g = itc->second.g;
-      else if (itc->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
+      else if (!same_geom(itc->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
       last_id = cid; last_base = itc->second.base;
     }
     auto itr = ctx->frames.find(jobs[i].ref_frame_id);
     if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "align_batch: reference frame not resident");
-    if (itr->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
+    if (!same_geom(itr->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
     if (jobs[i].ref_level < 0 || jobs[i].ref_level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "align_batch: bad ref_level");
     h[i].ref_base = itr->second.base;
     h[i].cur_base = last_base;
@@ -252,7 +252,7 @@ extern "C" int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera*
     auto itc = ctx->frames.find(FR.cur_frame_id);
     if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match: current frame not resident");
     if (f == 0) g = itc->second.g;
-    else if (itc->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frames must share one size");
+    else if (!same_geom(itc->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frames must share one size");
     if (FR.kf_begin < 0 || FR.kf_count < 0 || (long long)FR.kf_begin + FR.kf_count > n_kfs || FR.point_begin < 0 || FR.point_count < 0 ||
         (long long)FR.point_begin + FR.point_count > n_points)
       return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frame table out of range");
@@ -263,7 +263,7 @@ extern "C" int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera*
     for (int k = FR.kf_begin; k < FR.kf_begin + FR.kf_count; k++) {
       auto it = ctx->frames.find(kfs[k].frame_id);
       if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match: keyframe not resident");
-      if (it->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frames must share one size");
+      if (!same_geom(it->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "reproject_match: frames must share one size");
       const Se3 inv = se3_inverse(se3_from(kfs[k].T_f_w));
       hk[k].T_cur_kf = se3_mul(Tc, inv);
       hk[k].pos[0] = inv.tx; hk[k].pos[1] = inv.ty; hk[k].pos[2] = inv.tz;

@@ -25,6 +25,9 @@ struct PyrGeom {
 };
 
 PyrGeom make_geom(int w, int h);
+// two frames share kernels' index arithmetic only when their level-0 sizes agree (equal byte totals are not enough:
+// transposed sizes have them too)
+inline bool same_geom(const PyrGeom& a, const PyrGeom& b) { return a.w[0] == b.w[0] && a.h[0] == b.h[0]; }
 
 struct FrameRec {
   int64_t id;
@@ -41,8 +44,8 @@ struct hso_gpu_ctx {
   int n_cu;
   std::string err;
   std::unordered_map<int64_t, FrameRec> frames;
-  std::vector<uint8_t*> free_frames;  // recycled allocations (same geometry)
-  uint32_t free_frame_bytes;
+  std::vector<uint8_t*> free_frames;  // recycled allocations, all of geometry free_w x free_h (their padding rows are still zero)
+  int free_w, free_h;
   TrackBatchState* track;
   // staging for batched frame uploads: [bases | srcs | stats]
   char* d_batch; size_t batch_cap;
@@ -72,3 +75,7 @@ int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases,
 // cv::resize INTER_LINEAR of a device image into a device buffer (hso_frame.hip)
 int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh);
 void hso_track_state_free(hso_gpu_ctx* ctx);
+// a frame allocation of geometry g: recycled when the free list holds that geometry, else fresh with zeroed padding rows.
+// hso_frame_free returns it to the list (or the allocator); neither touches ctx->frames.
+int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base);
+void hso_frame_free(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* base);

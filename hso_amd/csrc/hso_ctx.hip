@@ -9,6 +9,44 @@ int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg)
   return code;
 }
 
+int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base)
+{
+  if (!ctx->free_frames.empty() && ctx->free_w == g.w[0] && ctx->free_h == g.h[0]) {
+    *base = ctx->free_frames.back();
+    ctx->free_frames.pop_back();
+    return HSO_OK;
+  }
+  *base = nullptr;
+  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(base), g.frame_bytes));
+  // zero once: the inter-level padding rows must read as 0 (see hso_ctx.h)
+  hipError_t e = hipMemsetAsync(*base, 0, g.pyr_bytes, ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(*base); *base = nullptr; ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
+  return HSO_OK;
+}
+
+void hso_frame_free(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* base)
+{
+  if (!base) return;
+  if ((ctx->free_frames.empty() || (ctx->free_w == g.w[0] && ctx->free_h == g.h[0])) && ctx->free_frames.size() < 4096) {
+    ctx->free_w = g.w[0]; ctx->free_h = g.h[0];
+    ctx->free_frames.push_back(base);
+  } else {
+    (void)hipFree(base);
+  }
+}
+
+// run `expr`; on failure give the frame allocation back and return the status
+#define HSO_FRAME_TRY(ctx, g, base, expr)                                      \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);         \
+      (void)hipStreamSynchronize((ctx)->stream);                              \
+      hso_frame_free(ctx, g, base);                                           \
+      return HSO_E_HIP;                                                       \
+    }                                                                         \
+  } while (0)
+
 extern "C" {
 
 int hso_gpu_abi_version(void) { return HSO_GPU_ABI_VERSION; }
@@ -24,7 +62,7 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   hso_gpu_ctx* ctx = new hso_gpu_ctx();
   ctx->device = device;
   ctx->track = nullptr;
-  ctx->free_frame_bytes = 0;
+  ctx->free_w = ctx->free_h = 0;
   ctx->d_batch = nullptr;
   ctx->batch_cap = 0;
   ctx->h_pin[0] = ctx->h_pin[1] = nullptr;
@@ -93,26 +131,18 @@ int hso_gpu_frame_upload(hso_gpu_ctx* ctx, int64_t frame_id, const uint8_t* img,
   rec.id = frame_id;
   rec.g = make_geom(width, height);
   rec.base = nullptr;
-  if (!ctx->free_frames.empty() && ctx->free_frame_bytes == rec.g.frame_bytes) {
-    rec.base = ctx->free_frames.back();
-    ctx->free_frames.pop_back();
-  } else {
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&rec.base), rec.g.frame_bytes));
-    // zero once: the inter-level padding rows must read as 0 (see hso_ctx.h)
-    HSO_HIP_CHECK(ctx, hipMemsetAsync(rec.base, 0, rec.g.pyr_bytes, ctx->stream));
-  }
-  hipError_t e = hipMemcpyAsync(rec.base + rec.g.off[0], img, (size_t)width * height,
-                                img_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
-  if (e != hipSuccess) { (void)hipFree(rec.base); ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
+  if (int rc = hso_frame_alloc(ctx, rec.g, &rec.base)) return rc;
+  HSO_FRAME_TRY(ctx, rec.g, rec.base, hipMemcpyAsync(rec.base + rec.g.off[0], img, (size_t)width * height,
+                                                     img_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   // the kernels take a device array of frame base pointers (batched form); one entry here
   uint8_t** d_bases = reinterpret_cast<uint8_t**>(rec.base + rec.g.stats_off + 128);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_bases, &rec.base, sizeof(uint8_t*), hipMemcpyHostToDevice, ctx->stream));
+  HSO_FRAME_TRY(ctx, rec.g, rec.base, hipMemcpyAsync(d_bases, &rec.base, sizeof(uint8_t*), hipMemcpyHostToDevice, ctx->stream));
   int rc = hso_frame_build(ctx, rec.g, d_bases, nullptr, nullptr, 1);
-  if (rc < 0) { (void)hipFree(rec.base); return rc; }
+  if (rc < 0) { (void)hipStreamSynchronize(ctx->stream); hso_frame_free(ctx, rec.g, rec.base); return rc; }
   if (stats_out) {
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(stats_out, rec.base + rec.g.stats_off, sizeof(hso_frame_stats),
-                                      hipMemcpyDeviceToHost, ctx->stream));
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HSO_FRAME_TRY(ctx, rec.g, rec.base, hipMemcpyAsync(stats_out, rec.base + rec.g.stats_off, sizeof(hso_frame_stats),
+                                                       hipMemcpyDeviceToHost, ctx->stream));
+    HSO_FRAME_TRY(ctx, rec.g, rec.base, hipStreamSynchronize(ctx->stream));
   }
   ctx->frames[frame_id] = rec;
   return HSO_OK;
@@ -145,23 +175,16 @@ int hso_gpu_frame_upload_resized(hso_gpu_ctx* ctx, int64_t frame_id, const uint8
   rec.id = frame_id;
   rec.g = make_geom(width, height);
   rec.base = nullptr;
-  if (!ctx->free_frames.empty() && ctx->free_frame_bytes == rec.g.frame_bytes) {
-    rec.base = ctx->free_frames.back();
-    ctx->free_frames.pop_back();
-  } else {
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&rec.base), rec.g.frame_bytes));
-    HSO_HIP_CHECK(ctx, hipMemsetAsync(rec.base, 0, rec.g.pyr_bytes, ctx->stream));
-  }
+  if (int rc = hso_frame_alloc(ctx, rec.g, &rec.base)) return rc;
   int rc = hso_frame_resize_into(ctx, d_src, src_width, src_height, rec.base + rec.g.off[0], width, height);
-  if (rc < 0) { (void)hipFree(rec.base); return rc; }
+  if (rc < 0) { (void)hipStreamSynchronize(ctx->stream); hso_frame_free(ctx, rec.g, rec.base); return rc; }
   uint8_t** d_bases = reinterpret_cast<uint8_t**>(rec.base + rec.g.stats_off + 128);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_bases, &rec.base, sizeof(uint8_t*), hipMemcpyHostToDevice, ctx->stream));
+  HSO_FRAME_TRY(ctx, rec.g, rec.base, hipMemcpyAsync(d_bases, &rec.base, sizeof(uint8_t*), hipMemcpyHostToDevice, ctx->stream));
   rc = hso_frame_build(ctx, rec.g, d_bases, nullptr, nullptr, 1);
-  if (rc < 0) { (void)hipFree(rec.base); return rc; }
-  if (stats_out) {
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(stats_out, rec.base + rec.g.stats_off, sizeof(hso_frame_stats), hipMemcpyDeviceToHost, ctx->stream));
-  }
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by later calls
+  if (rc < 0) { (void)hipStreamSynchronize(ctx->stream); hso_frame_free(ctx, rec.g, rec.base); return rc; }
+  if (stats_out)
+    HSO_FRAME_TRY(ctx, rec.g, rec.base, hipMemcpyAsync(stats_out, rec.base + rec.g.stats_off, sizeof(hso_frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_FRAME_TRY(ctx, rec.g, rec.base, hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by later calls
   ctx->frames[frame_id] = rec;
   return HSO_OK;
 }
@@ -175,54 +198,57 @@ int hso_gpu_frame_upload_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, const
     return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: width must be a multiple of 4, width and height >= 64");
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const PyrGeom g = make_geom(width, height);
+  // validate every entry, then allocate the new ones; ctx->frames is only touched once nothing can fail any more,
+  // so an error in the middle of a batch leaves no half-built frame resident
   std::vector<uint8_t*> bases(n);
+  std::vector<int> fresh;
   for (int i = 0; i < n; i++) {
     if (!imgs[i]) return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: null image");
     auto it = ctx->frames.find(frame_ids[i]);
-    if (it != ctx->frames.end()) {
-      if (it->second.g.frame_bytes != g.frame_bytes)
-        return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: resident frame has another size");
-      bases[i] = it->second.base;  // refresh in place
-    } else {
-      FrameRec rec;
-      rec.id = frame_ids[i];
-      rec.g = g;
-      if (!ctx->free_frames.empty() && ctx->free_frame_bytes == g.frame_bytes) {
-        rec.base = ctx->free_frames.back();
-        ctx->free_frames.pop_back();
-      } else {
-        HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&rec.base), g.frame_bytes));
-        HSO_HIP_CHECK(ctx, hipMemsetAsync(rec.base, 0, g.pyr_bytes, ctx->stream));
-      }
-      ctx->frames[frame_ids[i]] = rec;
-      bases[i] = rec.base;
-    }
+    if (it != ctx->frames.end() && !same_geom(it->second.g, g))
+      return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: resident frame has another size");
+    for (int k = 0; k < i && it == ctx->frames.end(); k++)
+      if (frame_ids[k] == frame_ids[i]) return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: a new frame id appears twice");
   }
+  auto undo = [&]() { (void)hipStreamSynchronize(ctx->stream); for (int i : fresh) hso_frame_free(ctx, g, bases[i]); };
+  for (int i = 0; i < n; i++) {
+    auto it = ctx->frames.find(frame_ids[i]);
+    if (it != ctx->frames.end()) { bases[i] = it->second.base; continue; }   // refresh in place
+    if (int rc = hso_frame_alloc(ctx, g, &bases[i])) { undo(); return rc; }
+    fresh.push_back(i);
+  }
+#define HSO_BATCH_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e); undo(); return HSO_E_HIP; } } while (0)
   const size_t b_ptr = ((size_t)n * sizeof(void*) + 255) & ~size_t(255);
   const size_t need = 2 * b_ptr + (size_t)n * sizeof(hso_frame_stats);
   if (ctx->batch_cap < need) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HSO_BATCH_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    HSO_BATCH_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
     ctx->batch_cap = need;
   }
   uint8_t** d_bases = reinterpret_cast<uint8_t**>(ctx->d_batch);
   const uint8_t** d_srcs = reinterpret_cast<const uint8_t**>(ctx->d_batch + b_ptr);
   hso_frame_stats* d_stats = reinterpret_cast<hso_frame_stats*>(ctx->d_batch + 2 * b_ptr);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_bases, bases.data(), (size_t)n * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  HSO_BATCH_TRY(hipMemcpyAsync(d_bases, bases.data(), (size_t)n * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
   if (img_is_device) {
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_srcs, imgs, (size_t)n * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    HSO_BATCH_TRY(hipMemcpyAsync(d_srcs, imgs, (size_t)n * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
   } else {
     for (int i = 0; i < n; i++)
-      HSO_HIP_CHECK(ctx, hipMemcpyAsync(bases[i] + g.off[0], imgs[i], (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+      HSO_BATCH_TRY(hipMemcpyAsync(bases[i] + g.off[0], imgs[i], (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
   }
   int rc = hso_frame_build(ctx, g, d_bases, img_is_device ? d_srcs : nullptr, stats_out ? d_stats : nullptr, n);
-  if (rc < 0) return rc;
-  // the pointer tables above were read from pageable host memory: wait before they go out of scope
-  if (stats_out)
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(stats_out, d_stats, (size_t)n * sizeof(hso_frame_stats), hipMemcpyDeviceToHost, ctx->stream));
-  if (stats_out) HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (rc < 0) { undo(); return rc; }
+  if (stats_out) {
+    HSO_BATCH_TRY(hipMemcpyAsync(stats_out, d_stats, (size_t)n * sizeof(hso_frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+    HSO_BATCH_TRY(hipStreamSynchronize(ctx->stream));
+  }
+#undef HSO_BATCH_TRY
+  for (int i : fresh) {   // commit
+    FrameRec rec;
+    rec.id = frame_ids[i]; rec.g = g; rec.base = bases[i];
+    ctx->frames[frame_ids[i]] = rec;
+  }
   return HSO_OK;
 }
 
@@ -232,12 +258,7 @@ int hso_gpu_frame_release(hso_gpu_ctx* ctx, int64_t frame_id)
   auto it = ctx->frames.find(frame_id);
   if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "frame_release: frame not resident");
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  if ((ctx->free_frames.empty() || ctx->free_frame_bytes == it->second.g.frame_bytes) && ctx->free_frames.size() < 4096) {
-    ctx->free_frame_bytes = it->second.g.frame_bytes;
-    ctx->free_frames.push_back(it->second.base);
-  } else {
-    (void)hipFree(it->second.base);
-  }
+  hso_frame_free(ctx, it->second.g, it->second.base);
   ctx->frames.erase(it);
   return HSO_OK;
 }

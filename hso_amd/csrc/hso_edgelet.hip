@@ -27,7 +27,10 @@
 #include <vector>
 
 #define EDGE_LEVELS HSO_N_SOBEL_LEVELS
-#define EDGE_MAX_PASSES 64
+// Cross-tile closure passes repeat until one changes nothing.  cv::Canny's flood fill has no iteration limit; here the
+// worst case is bounded by the number of tiles a weak contour can wind through (one tile border per pass), so the loop
+// below stops on its own and only guards against a broken flag with a bound far above any frame's tile count.
+#define EDGE_PASS_GUARD (1 << 20)
 #define EDGE_ROUND 4          // closure passes queued per host round trip
 #define CLOSE_TW 64
 #define CLOSE_TH 32
@@ -51,7 +54,7 @@ struct EdgeArgs {
   char* work; size_t per_frame;      // edgelet slices
   size_t o_weak, o_chg;              // per frame: weak[tiles], chg[EDGE_ROUND + 1][tiles]
   int n_tiles;                       // tiles of all levels of one frame
-  int* flags;                        // [EDGE_MAX_PASSES + 1]; flags[p + 1] != 0: pass p changed a pixel
+  int* flags;                        // [EDGE_ROUND + 1], per round: flags[k + 1] != 0: pass k of the round changed a pixel; flags[0] = the round before
   int* totals;                       // [n_frames][n_levels]
   int n_levels, low, high, cap, pass, slot;
 };
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void k_canny_close(EdgeArgs A)
 {
   __shared__ __attribute__((aligned(8))) uint8_t s_m[CLOSE_TH + 2][M_STRIDE];
   __shared__ unsigned long long s_E[CLOSE_TH + 2], s_W[CLOSE_TH + 2];
-  if (A.pass > 0 && A.flags[A.pass] == 0) return;      // the previous pass changed nothing: closed
+  if (A.pass > 0 && A.flags[A.slot] == 0) return;      // the previous pass changed nothing: closed
   const EdgeLevel& L = level_of(A, blockIdx.y);
   const int W = L.W, H = L.H;
   if ((int)blockIdx.x >= L.tiles_x * L.tiles_y) return;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void k_canny_close(EdgeArgs A)
     *weak_flag = (uint8_t)(weak != 0);
     if (grew) {
       slice[A.o_chg + (size_t)(A.slot + 1) * A.n_tiles + L.tile_base + blockIdx.x] = 1;
-      A.flags[A.pass + 1] = 1;
+      A.flags[A.slot + 1] = 1;
     }
   }
 }
@@ -459,7 +462,7 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
   const size_t have_per_frame = have_bytes;
   const size_t slice = al(o + have_per_frame);
   for (int l = 0; l < n_levels; l++) A.lv[l].o_have += o;    // have block sits at the end of each slice
-  const size_t o_flags = 0, o_totals = al(sizeof(int) * (EDGE_MAX_PASSES + 1));
+  const size_t o_flags = 0, o_totals = al(sizeof(int) * (EDGE_ROUND + 1));
   const size_t o_slices = o_totals + al(sizeof(int) * (size_t)n_frames * n_levels);
   const size_t extra = o_slices + slice * (size_t)n_frames;
 
@@ -484,17 +487,21 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
     lo = lo < 32767.0 ? lo : 32767.0; hi = hi < 32767.0 ? hi : 32767.0;
     A.low = (int)(lo * lo); A.high = (int)(hi * hi);
   }
-  HSO_HIP_CHECK(ctx, hipMemsetAsync(x + o_flags, 0, sizeof(int) * (EDGE_MAX_PASSES + 1), ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(x + o_flags, 0, sizeof(int) * (EDGE_ROUND + 1), ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemset2DAsync(A.work + o, slice, 0, have_per_frame, (size_t)n_frames, ctx->stream));
   const dim3 blk(256);
   hipLaunchKernelGGL(k_cell_mark, dim3((max_words + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);
   HSO_HIP_CHECK(ctx, hipMemset2DAsync(A.work + A.o_chg, slice, 0, chg_bytes, (size_t)n_frames, ctx->stream));
   hipLaunchKernelGGL(k_canny_nms, dim3(max_close, n_levels, n_frames), blk, 0, ctx->stream, A);
   int pass = 0, flag = 1;
-  int32_t* h_flags = edgelet_counts;   // scratch until the totals arrive (n_frames * n_levels >= 1 ints)
+  int32_t* h_flags = reinterpret_cast<int32_t*>(hso_pinned(ctx, 1, 64));   // private flag word (never the caller's output array)
+  if (!h_flags) return HSO_E_NOMEM;
   while (flag) {
-    if (pass + EDGE_ROUND > EDGE_MAX_PASSES) return hso_fail(ctx, HSO_E_INVALID, "detect_candidates: edge closure did not converge");
+    if (pass > EDGE_PASS_GUARD) return hso_fail(ctx, HSO_E_HIP, "detect_candidates: edge closure flag never cleared");
     if (pass > 0) {
+      // next round: the last pass's flag and tile changes become slot 0, the other slots start clear
+      HSO_HIP_CHECK(ctx, hipMemcpyAsync(A.flags, A.flags + EDGE_ROUND, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+      HSO_HIP_CHECK(ctx, hipMemsetAsync(A.flags + 1, 0, sizeof(int) * EDGE_ROUND, ctx->stream));
       // next round: the last pass's tile changes become slot 0, the other slots start clear
       HSO_HIP_CHECK(ctx, hipMemcpy2DAsync(A.work + A.o_chg, slice, A.work + A.o_chg + (size_t)EDGE_ROUND * n_tiles, slice, (size_t)n_tiles,
                                           (size_t)n_frames, hipMemcpyDeviceToDevice, ctx->stream));
@@ -505,7 +512,7 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
       hipLaunchKernelGGL(k_canny_close, dim3(max_close, n_levels, n_frames), blk, 0, ctx->stream, A);
     }
     HSO_HIP_CHECK(ctx, hipGetLastError());
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_flags, A.flags + pass, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_flags, A.flags + EDGE_ROUND, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if (pass == EDGE_ROUND) {
       // optimistic: queue the rest behind the flag read; redone below in the rare case the closure needed more passes
       hipLaunchKernelGGL(k_edgelet_cells, dim3((max_cells * 8 + 255) / 256, n_levels, n_frames), blk, 0, ctx->stream, A);

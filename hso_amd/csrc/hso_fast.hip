@@ -264,7 +264,7 @@ int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, i
     auto it = ctx->frames.find(frame_ids[i]);
     if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "fast_detect: frame not resident");
     if (i == 0) g = it->second.g;
-    else if (it->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "fast_detect: frames of one batch must share one size");
+    else if (!same_geom(it->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "fast_detect: frames of one batch must share one size");
     h_bases[i] = it->second.base;
   }
   const size_t need = hso_fast_plan(g, n_frames, n_levels, cap, &P) + ((extra + 255) & ~size_t(255));

@@ -408,7 +408,7 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
     auto itc = ctx->frames.find(frames[k].frame_id);
     if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_observe: active frame not resident");
     if (k == 0) g = itc->second.g;
-    else if (itc->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
+    else if (!same_geom(itc->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
     cur_base[k] = itc->second.base;
     hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = frames[k].exposure_time;
   }
@@ -423,7 +423,7 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
     if (i == 0 || seeds[i].ref_frame_id != last_id) {
       auto itr = ctx->frames.find(seeds[i].ref_frame_id);
       if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_observe: seed host frame not resident");
-      if (itr->second.g.frame_bytes != g.frame_bytes) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
+      if (!same_geom(itr->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
       last_id = seeds[i].ref_frame_id; last_base = itr->second.base;
     }
     if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: bad level");

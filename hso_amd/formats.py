@@ -70,20 +70,26 @@ def parse_calibration(path_or_text):
 
 
 def read_stamps(path):
-    """ImageReader's stamp file: per line "stamp x y z a b c d" | "id stamp exposure" | "id stamp" |
-    "stamp" (tried in that order, src/ImageReader.cpp:39-62) -> list of stamp strings."""
-    num = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?"
+    """ImageReader's stamp file (src/ImageReader.cpp:24-66): each line goes through the reference's own sscanf
+    cascade — "%s %f %f %f %f %f %f %f" (8 fields), "%d %s %f" (3), "%d %s" (2), "%s" (1), first that converts fully
+    wins — by calling libc's sscanf with those very formats, so every corner of its matching ("123.456" alone is
+    id 123 + stamp ".456"; inf / nan / hex floats in the first form) is the reference's.  -> list of stamp strings."""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
     out = []
-    for line in open(path).read().splitlines():
-        t = line.split()
-        if not t:
-            continue
-        if len(t) >= 8 and all(re.fullmatch(num, x) for x in t[1:8]):
-            out.append(t[0])
-        elif len(t) >= 2 and re.fullmatch(r"[-+]?\d+", t[0]):
-            out.append(t[1])
-        else:
-            out.append(t[0])
+    for line in open(path, "rb").read().split(b"\n"):
+        buf = line[:999]                                   # tr.getline(buf, 1000)
+        stamp = C.create_string_buffer(1024)
+        f = [C.c_float() for _ in range(7)]
+        i = C.c_int()
+        if libc.sscanf(buf, b"%s %f %f %f %f %f %f %f", stamp, *[C.byref(v) for v in f]) == 8:
+            out.append(stamp.value.decode("latin-1"))
+        elif libc.sscanf(buf, b"%d %s %f", C.byref(i), stamp, C.byref(f[0])) == 3:
+            out.append(stamp.value.decode("latin-1"))
+        elif libc.sscanf(buf, b"%d %s", C.byref(i), stamp) == 2:
+            out.append(stamp.value.decode("latin-1"))
+        elif libc.sscanf(buf, b"%s", stamp) == 1:
+            out.append(stamp.value.decode("latin-1"))
     return out
 
 

@@ -29,6 +29,30 @@
 extern "C" {
 #endif
 
+/* ---- decision margins (SURVEY.md App. C "decision robustness") ----
+ * Every comparison that gates control flow in the restatement reports how far its operands were apart; each field
+ * keeps the SMALLEST distance seen since the last reset.  A parity test excuses a differing decision only when the
+ * margin of the comparison that produces it is below 10x the stated tolerance; everything else must match exactly. */
+typedef struct hso_or_margins {
+  double lk_update;    /* LK convergence: min over iterations of | |update|^2 - min_update^2 | / min_update^2 (feature_alignment.cpp:296,593) */
+  double lk_chi2;      /* | chi2 - 1000 * patch_area | / (1000 * patch_area) (:303,:600) */
+  double ncc;          /* | ncc - threshold | of checkNCC (matcher.cpp:379-404) */
+  double normal;       /* | normal . gradient - threshold | of checkNormal (:406-440) */
+  double jump;         /* | |px - px_orig| - 20 | (:369-370) */
+  double zmncc_best;   /* | zmncc_best - 0.8 | (matcher.cpp:1003) */
+  double zmncc_ambig;  /* | 1.5 * zmncc_second - zmncc_best | where the index gap allows the test (:1000) */
+  double zmncc_order;  /* min over epipolar samples of | zmncc - zmncc_best |, | zmncc - zmncc_second | at the comparisons (:985-996) */
+  double klt_energy;   /* | bestEnergy - 650 * 64 | / (650 * 64) (:1449,:1604) */
+  double klt_step;     /* min over KLT iterations of the distance of the step test to its bound (:1435,:1590) */
+  double klt_accept;   /* min over KLT iterations of | newEnergy - bestEnergy | / bestEnergy (step accepted or halved) */
+  double pose_rho;     /* pose LM: min over trials of |rho| / max(chi2, 1e-300) (pose_optimizer.cpp:644-670) */
+} hso_or_margins;
+void hso_or_margins_reset(void);
+void hso_or_margins_get(hso_or_margins* out);
+void hso_or_margin_note(int field, double v);   /* internal: field = index of the double above */
+enum { HSO_M_LK_UPDATE, HSO_M_LK_CHI2, HSO_M_NCC, HSO_M_NORMAL, HSO_M_JUMP, HSO_M_ZMNCC_BEST, HSO_M_ZMNCC_AMBIG, HSO_M_ZMNCC_ORDER,
+       HSO_M_KLT_ENERGY, HSO_M_KLT_STEP, HSO_M_KLT_ACCEPT, HSO_M_POSE_RHO, HSO_M_COUNT };
+
 /* ---- Sophus SE3 / SO3 (thirdparty/Sophus/sophus/{se3,so3}.cpp) ---- */
 void hso_or_se3_identity(hso_se3* T);
 void hso_or_se3_mul(const hso_se3* a, const hso_se3* b, hso_se3* out);      /* se3.cpp:59-66 */

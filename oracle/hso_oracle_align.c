@@ -160,8 +160,10 @@ int hso_or_align2d(const uint8_t* cur_img, int cols, int rows, const float* ref_
     u += update[0];
     v += update[1];
     mean_diff += update[2];
+    hso_or_margin_note(HSO_M_LK_UPDATE, ((double)(update[0] * update[0] + update[1] * update[1]) - min_update_squared) / min_update_squared);
     if (update[0] * update[0] + update[1] * update[1] < min_update_squared) { converged = 1; iter++; break; }
   }
+  hso_or_margin_note(HSO_M_LK_CHI2, ((double)chi2 - 1000 * patch_area_) / (1000 * patch_area_));
   if (chi2 > 1000 * patch_area_) converged = 0;
   cur_px_estimate[0] = u; cur_px_estimate[1] = v;
   if (iters_out) *iters_out = iter;
@@ -239,8 +241,10 @@ int hso_or_align1d(const uint8_t* cur_img, int cols, int rows, const float dir[2
     u += update[0] * dir[0];
     v += update[0] * dir[1];
     mean_diff += update[1];
+    hso_or_margin_note(HSO_M_LK_UPDATE, ((double)(update[0] * update[0]) - min_update_squared) / min_update_squared);
     if (update[0] * update[0] < min_update_squared) { converged = 1; iter++; break; }
   }
+  hso_or_margin_note(HSO_M_LK_CHI2, ((double)chi2 - 1000 * patch_area) / (1000 * patch_area));
   if (chi2 > 1000 * patch_area) converged = 0;
   cur_px_estimate[0] = u; cur_px_estimate[1] = v;
   if (iters_out) *iters_out = iter;
@@ -336,7 +340,9 @@ static void find_match(const hso_camera* cam, const hso_align_job* job, const ui
     if (!ok) out->stage = HSO_ALIGN_NOT_CONVERGED;
     if (ok) {
       const double dir[2] = { d0, d1 };
-      ok = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, px_scaled, dir) > (float)0.86;
+      const double nd_ = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, px_scaled, dir);
+      hso_or_margin_note(HSO_M_NORMAL, nd_ - (float)0.86);
+      ok = nd_ > (float)0.86;
       if (!ok) out->stage = HSO_ALIGN_NORMAL;
     }
   } else {
@@ -346,11 +352,13 @@ static void find_match(const hso_camera* cam, const hso_align_job* job, const ui
   const double ncc = hso_or_ncc(patch, patchNCC);
   out->ncc = (float)ncc;
   if (ok) {
+    hso_or_margin_note(HSO_M_NCC, ncc - ncc_thresh);
     ok = ncc > ncc_thresh;  /* float thresh parameter, matcher.cpp:379 */
     if (!ok) out->stage = HSO_ALIGN_NCC;
   }
   if (ok) {
     const double dx = px_scaled_orig[0] - px_scaled[0], dy = px_scaled_orig[1] - px_scaled[1];
+    hso_or_margin_note(HSO_M_JUMP, sqrt(dx * dx + dy * dy) - 20);
     ok = sqrt(dx * dx + dy * dy) < 20;
     if (!ok) out->stage = HSO_ALIGN_JUMP;
   }

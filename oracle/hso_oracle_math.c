@@ -380,3 +380,9 @@ void hso_or_se3quat_exp(const double update[6], hso_se3* out)
   g2o_normalize_rotation(r.q);   /* SE3Quat(const Quaterniond&, const Vector3d&), se3quat.h:62-64 */
   *out = r;
 }
+
+/* ---- decision margins (see hso_oracle.h) ---- */
+static double g_margins[HSO_M_COUNT];
+void hso_or_margins_reset(void) { for (int i = 0; i < HSO_M_COUNT; i++) g_margins[i] = 1e300; }
+void hso_or_margins_get(hso_or_margins* out) { memcpy(out, g_margins, sizeof(g_margins)); }
+void hso_or_margin_note(int field, double v) { v = fabs(v); if (!(v >= g_margins[field])) g_margins[field] = v; }

@@ -200,6 +200,7 @@ void hso_or_pose_optimize(const hso_camera* cam, const hso_pose_job* job, hso_po
           ++idx_host;
         }
         rho = chi2 - new_chi2;
+        hso_or_margin_note(HSO_M_POSE_RHO, rho / (chi2 > 1e-300 ? chi2 : 1e-300));
       } else
         rho = -1;
       if (rho > 0) {

@@ -140,6 +140,7 @@ static int klt_limited_2d(const uint8_t* img, int cols, int rows, const float* p
         *cp = sp;
       }
     }
+    hso_or_margin_note(HSO_M_KLT_ACCEPT, ((double)energy - bestEnergy) / bestEnergy);
     if (energy > bestEnergy) {
       for (int i = 0; i < 3; i++) stepBack[i] *= 0.5;
       bestU = uBak + stepBack[0]; bestV = vBak + stepBack[1]; mean_diff = meanBak + stepBack[2];
@@ -153,9 +154,11 @@ static int klt_limited_2d(const uint8_t* img, int cols, int rows, const float* p
       bestU += step[0]; bestV += step[1]; mean_diff += step[2];
       bestEnergy = energy;
     }
+    hso_or_margin_note(HSO_M_KLT_STEP, ((double)(stepBack[0] * stepBack[1]) - 0.01 * 0.01) / (0.01 * 0.01));
     if (stepBack[0] * stepBack[1] < 0.01 * 0.01) break;
   }
   px[0] = bestU; px[1] = bestV;
+  hso_or_margin_note(HSO_M_KLT_ENERGY, ((double)bestEnergy - 650 * 64) / (650 * 64));
   if (bestEnergy > 650 * 64) return 0;
   return 1;
 }
@@ -210,6 +213,7 @@ static int klt_limited_1d(const uint8_t* img, int cols, int rows, const float* p
         if (targetPatch != NULL) { *cp = sp; ++cp; }
       }
     }
+    hso_or_margin_note(HSO_M_KLT_ACCEPT, ((double)energy - bestEnergy) / bestEnergy);
     if (energy > bestEnergy) {
       stepBack[0] *= 0.5; stepBack[1] *= 0.5;
       bestU = uBak + stepBack[0] * direct[0];
@@ -227,9 +231,11 @@ static int klt_limited_1d(const uint8_t* img, int cols, int rows, const float* p
       mean_diff += step[1];
       bestEnergy = energy;
     }
+    hso_or_margin_note(HSO_M_KLT_STEP, ((double)fabsf(stepBack[0]) - 0.01) / 0.01);
     if (fabsf(stepBack[0]) < 0.01) break;
   }
   px[0] = bestU; px[1] = bestV;
+  hso_or_margin_note(HSO_M_KLT_ENERGY, ((double)bestEnergy - 650 * 64) / (650 * 64));
   if (bestEnergy > 650 * 64) return 0;
   return 1;
 }
@@ -329,6 +335,8 @@ static int do_line_stereo(const hso_camera* cam, const hso_seed* s, const hso_se
     if (!is_in_frame_level(w, h, (int)px[0], (int)px[1], 8, search_level)) { cpx += incx; cpy += incy; loopCounter++; continue; }
     create_patch(patch_f, px, cur_pyr[search_level], cols);
     const float zmncc = zmncc_score(patch, hostMean, patch_f);
+    hso_or_margin_note(HSO_M_ZMNCC_ORDER, (double)zmncc - zmncc_best);
+    hso_or_margin_note(HSO_M_ZMNCC_ORDER, (double)zmncc - zmncc_second);
     if (zmncc > zmncc_best) {
       zmncc_second = zmncc_best;
       uv_best[0] = px[0]; uv_best[1] = px[1];
@@ -341,7 +349,9 @@ static int do_line_stereo(const hso_camera* cam, const hso_seed* s, const hso_se
   }
   o->n_steps = loopCounter;
   o->zmncc_best = zmncc_best; o->zmncc_second = zmncc_second;
+  if (abs(loopCBest - loopCSecond) > 1.0f) hso_or_margin_note(HSO_M_ZMNCC_AMBIG, 1.5 * (double)zmncc_second - zmncc_best);
   if (abs(loopCBest - loopCSecond) > 1.0f && 1.5f * zmncc_second > zmncc_best) return -4;
+  hso_or_margin_note(HSO_M_ZMNCC_BEST, (double)zmncc_best - 0.8);
   if (zmncc_best > 0.8) {
     double px_cur[2] = { uv_best[0] * (1 << search_level), uv_best[1] * (1 << search_level) };
     double px_scaled[2] = { px_cur[0] / (1 << search_level), px_cur[1] / (1 << search_level) };
@@ -359,10 +369,18 @@ static int do_line_stereo(const hso_camera* cam, const hso_seed* s, const hso_se
       result = klt_limited_2d(cur_pyr[search_level], cols, rows, pwb, patch, 10, pxr, patch2D);
     } else {
       result = klt_limited_1d(cur_pyr[search_level], cols, rows, pwb, patch, 10, pxr, dir_cur, patch2D);
-      if (result) result = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, pxr, dir_cur) > (float)0.7;
+      if (result) {
+        const double nd_ = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, pxr, dir_cur);
+        hso_or_margin_note(HSO_M_NORMAL, nd_ - (float)0.7);
+        result = nd_ > (float)0.7;
+      }
     }
     px_scaled[0] = pxr[0]; px_scaled[1] = pxr[1];
-    if (result) result = hso_or_ncc(patch, patch2D) > (double)(float)0.8;
+    if (result) {
+      const double ncc_ = hso_or_ncc(patch, patch2D);
+      hso_or_margin_note(HSO_M_NCC, ncc_ - (double)(float)0.8);
+      result = ncc_ > (double)(float)0.8;
+    }
     if (result) {
       px_cur[0] = px_scaled[0] * (1 << search_level); px_cur[1] = px_scaled[1] * (1 << search_level);
       o->px_cur[0] = px_cur[0]; o->px_cur[1] = px_cur[1];

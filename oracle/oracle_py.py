@@ -683,3 +683,24 @@ def se3quat_mul(a, b):
     lib.hso_or_se3quat_mul.argtypes = [C.POINTER(SE3)] * 3
     lib.hso_or_se3quat_mul.restype = None
     o = SE3(); lib.hso_or_se3quat_mul(C.byref(a), C.byref(b), C.byref(o)); return o
+
+
+MARGIN_FIELDS = ("lk_update", "lk_chi2", "ncc", "normal", "jump", "zmncc_best", "zmncc_ambig", "zmncc_order", "klt_energy",
+                 "klt_step", "klt_accept", "pose_rho")
+
+
+class Margins(C.Structure):
+    _fields_ = [(n, C.c_double) for n in MARGIN_FIELDS]
+
+
+def margins_reset():
+    load().hso_or_margins_reset()
+
+
+def margins():
+    """The smallest distance of every gating comparison to its threshold since margins_reset() (hso_oracle.h)."""
+    lib = load()
+    lib.hso_or_margins_get.argtypes = [C.POINTER(Margins)]
+    m = Margins()
+    lib.hso_or_margins_get(C.byref(m))
+    return m

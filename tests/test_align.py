@@ -98,19 +98,25 @@ def test_align_batch_parity(gpu_ctx, orc, cam, pair2000, scene_arrays, case):
     n_tie = 0
     n_succ = 0
     for j, g in zip(jobs, got):
+        orc.margins_reset()
         o = orc.find_match_direct(cam, j, rp, cp, sob)
+        m = orc.margins()
         assert g.search_level == o.search_level
         assert np.allclose(g.A_cur_ref[:], o.A_cur_ref[:], rtol=0, atol=1e-12)
         if o.stage == 1:
             assert g.stage == 1 and not g.success
             continue
-        # near-ties: a gate within 10x the tolerance of its threshold, or the LK convergence test close to its bound
-        tie = abs(o.ncc - 0.7) < 2e-3 or g.iters != o.iters
-        if tie:
+        # A differing decision is excused only where the restatement's own comparison was within 10x the tolerance of the
+        # compared quantity: the LK update norm (its squares agree to ~1e-3 relative between the serial and the
+        # butterfly sums), the final chi2 (1e-3 relative), the NCC (1e-4) and the edgelet normal (1e-4); everything else is exact.
+        if g.iters != o.iters:
+            assert m.lk_update < 1e-2, (g.iters, o.iters, m.lk_update)
             n_tie += 1
             continue
-        assert (g.success, g.stage) == (o.success, o.stage), (g.stage, o.stage, g.ncc, o.ncc)
-        assert g.iters == o.iters
+        if (g.success, g.stage) != (o.success, o.stage):
+            assert min(m.ncc / 1e-3, m.normal / 1e-3, m.lk_chi2 / 1e-2, m.lk_update / 1e-2) < 1, (g.stage, o.stage, m.ncc, m.normal, m.lk_chi2)
+            n_tie += 1
+            continue
         # converged LK is a contraction: rounding differences stay at 1e-3 px; a run that used all ten
         # iterations without converging (stage 2, result discarded by the caller) may amplify them
         if o.stage == 2:

@@ -187,3 +187,33 @@ def test_detect_candidates_long_weak_chains_and_batch(gpu_ctx, orc):
     finally:
         for i in ids:
             gpu_ctx.frame_release(i)
+
+
+@pytest.mark.gpu
+def test_detect_candidates_serpentine_chain_needs_many_closure_passes(gpu_ctx, orc):
+    """One weak contour that winds through far more than 64 tile borders (a ribbon of +3 grey levels snaking over the
+    whole frame) with a single strong stretch: cv::Canny's flood fill follows it to the end, so must the tiled closure,
+    however many cross-tile passes that takes (there is no iteration limit)."""
+    h, w = 480, 640
+    img = np.full((h, w), 100.0)
+    runs = list(range(24, h - 40, 36))
+    for k, y0 in enumerate(runs):
+        img[y0:y0 + 12, 24:w - 24] += 3.0                                   # horizontal run of the ribbon
+        if k + 1 < len(runs):                                               # connector on alternating sides
+            x0 = w - 36 if k % 2 == 0 else 24
+            img[y0:runs[k + 1] + 12, x0:x0 + 12] = 103.0
+    img[runs[0]:runs[0] + 12, 24:44] += 2.0                                 # the only strong stretch, at one end of the chain
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    gpu_ctx.frame_upload(9740, img)
+    try:
+        co, cc, eo, ec = gpu_ctx.detect_candidates([9740], n_levels=3, min_thresh=3, corner_cap=40000, edgelet_cap=4800)
+        pyr, sob = _frame_images(orc, img)
+        for L in range(3):
+            corners, edgelets, _ = orc.detect_candidates_level(np.ascontiguousarray(pyr[L]), sob[L][0], sob[L][1], L, w, h, 3)
+            assert (cc[0, L], ec[0, L]) == (len(corners), len(edgelets)), L
+            _check(eo[0, L, :ec[0, L]], edgelets, "edgelets")
+        # the far end of the ribbon (last run) carries edgelets only if the closure walked the whole chain
+        far = eo[0, 0, :ec[0, 0]]
+        assert (far["y"] > runs[-1] - 4).sum() > 10
+    finally:
+        gpu_ctx.frame_release(9740)

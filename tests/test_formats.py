@@ -53,9 +53,13 @@ def test_stamp_file_formats(tmp_path):
     f.write_text("1403636579.763555527 0.1 0.2 0.3 0 0 0 1\n"      # TUM ground-truth style: stamp + pose
                  "00017 1403636579.813555456 12.5\n"                # id stamp exposure
                  "18 1403636579.863555584\n"                         # id stamp
-                 "1403636579.913555456\n\n")                         # stamp
+                 "1403636579913555456\n"                            # stamp (EuRoC: integer nanoseconds)
+                 "frame_0004\n"
+                 "1403636579.963555456\n\n")                         # a bare decimal stamp: "%d %s" takes it apart
+    # the last line shows the reference's cascade as it is (src/ImageReader.cpp:39-62): "%d" consumes "1403636579" and "%s"
+    # the rest, so the stamp becomes ".963555456" — reproduced, not repaired (read_stamps calls libc's sscanf with the same formats)
     assert formats.read_stamps(f) == ["1403636579.763555527", "1403636579.813555456", "1403636579.863555584",
-                                      "1403636579.913555456"]
+                                      "1403636579913555456", "frame_0004", ".963555456"]
 
 
 def test_images_without_opencv(tmp_path):

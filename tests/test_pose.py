@@ -55,14 +55,19 @@ def test_oracle_pose_edge_cases(orc, cam):
 def test_pose_optimize_parity(gpu_ctx, orc, cam, n, seed):
     feats, poses, T0, T_true = synth.pose_problem(n, seed=seed)
     job = capi.make_pose_job(feats, poses, T0)
+    orc.margins_reset()
     ro, mo = orc.pose_optimize(cam, job)
+    margin = orc.margins()
     (rg,), (mg,) = gpu_ctx.pose_optimize_batch(cam, [job])
     assert rg.status == ro.status == 0
     assert rg.estimated_scale == ro.estimated_scale                 # MAD scale: exact order statistic
     assert rg.error_init == ro.error_init
     # once converged rho = chi2 - new_chi2 is rounding noise (|rho| ~ 1e-18): the serial and the tree
     # sums may accept/reject a last no-op step differently, the pose does not move
-    assert abs(rg.iters - ro.iters) <= 2 and abs(rg.n_trials_total - ro.n_trials_total) <= 6
+    # — a differing count is excused only when the restatement itself saw such a step: |rho| / chi2 below 1e-12 (the two
+    # sums agree to ~1e-13 relative), never otherwise
+    if (rg.iters, rg.n_trials_total) != (ro.iters, ro.n_trials_total):
+        assert margin.pose_rho < 1e-12 and abs(rg.iters - ro.iters) <= 2 and abs(rg.n_trials_total - ro.n_trials_total) <= 6, margin.pose_rho
     rot, tra = pose_dist(rg.T_f_w, ro.T_f_w)
     assert rot <= 1e-9 and tra <= 1e-9
     # outlier decisions: identical except for residuals within 1e-9 of the threshold

@@ -113,7 +113,9 @@ def test_seed_observe_matches_oracle(orc, cam, gpu_ctx, seed_scene):
         gpu_ctx.frame_release(9101); gpu_ctx.frame_release(9102)
     n_ok = n_flag = 0
     for s, g in zip(seeds, got):
+        orc.margins_reset()
         o = orc.seed_observe(cam, s, T_cur, 1.05, PX_ERROR_ANGLE, rp, cp, sob)
+        m = orc.margins()
         assert g.is_update == o.is_update and g.is_valid == o.is_valid
         if o.result == 0:
             assert g.result == 0 and g.mu == o.mu and g.sigma2 == o.sigma2 and g.b == o.b
@@ -126,10 +128,16 @@ def test_seed_observe_matches_oracle(orc, cam, gpu_ctx, seed_scene):
         if o.n_steps > 0 and o.zmncc_best > 0.1:
             assert g.zmncc_best == pytest.approx(o.zmncc_best, abs=1e-4)
         if g.result != o.result:
-            # allowed only when a threshold is within rounding of the value compared with it
-            near = (abs(o.zmncc_best - 0.8) < 1e-3 or abs(1.5 * o.zmncc_second - o.zmncc_best) < 1e-3
-                    or {g.result, o.result} == {1, -3} or {g.result, o.result} == {-3, -4})
-            assert near, (g.result, o.result, o.zmncc_best, o.zmncc_second)
+            # excused only when the gate that separates the two codes had its operands within 10x their tolerance in the
+            # restatement: the ZMNCC gates (scores agree to 1e-4), the KLT energy bound / step acceptance (energies to 1e-3
+            # relative), the final NCC and the edgelet normal (1e-4)
+            codes = {g.result, o.result}
+            near = False
+            if codes == {-3, -4} or codes == {1, -4}:
+                near = min(m.zmncc_best, m.zmncc_ambig, m.zmncc_order) < 1e-3
+            if codes == {1, -3}:
+                near = min(m.klt_energy / 1e-2, m.klt_accept / 1e-2, m.klt_step / 1e-1, m.ncc / 1e-3, m.normal / 1e-3) < 1
+            assert near, (g.result, o.result, [getattr(m, f) for f in orc.MARGIN_FIELDS])
             n_flag += 1
             continue
         assert g.b == o.b
