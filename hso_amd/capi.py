@@ -178,6 +178,17 @@ class SeedOut(C.Structure):
                 ("px_cur", C.c_double * 2), ("z", C.c_double), ("zmncc_best", C.c_float), ("zmncc_second", C.c_float)]
 
 
+SEED_BRIEF_DTYPE = np.dtype([("mu", "<f4"), ("sigma2", "<f4"), ("b", "<f4"), ("result", "i1"), ("is_update", "i1"), ("is_valid", "i1"),
+                             ("search_level", "i1")])
+assert SEED_BRIEF_DTYPE.itemsize == 16
+MAP_CALL_DTYPE = np.dtype([("map", "<i4"), ("cur_keyframe_id", "<i4"), ("cur_frame_id", "<i8"), ("q", "<f8", 4), ("t", "<f8", 3),
+                           ("cur_exposure_time", "<f8")])
+assert MAP_CALL_DTYPE.itemsize == 80
+MATCH_BRIEF_DTYPE = np.dtype([("px", "<f8", 2), ("px_cur", "<f8", 2), ("grad", "<f4", 2), ("cell", "<i4"), ("ref_obs", "<i4"),
+                              ("success", "i1"), ("stage", "i1"), ("search_level", "i1"), ("ref_type", "i1"), ("pad_", "<i4")])
+assert MATCH_BRIEF_DTYPE.itemsize == 56
+
+
 class SeedFrame(C.Structure):
     _fields_ = [("frame_id", C.c_int64), ("T_f_w", SE3), ("exposure_time", C.c_double)]
 
@@ -290,6 +301,16 @@ def load():
     lib.hso_gpu_seed_observe_multi.argtypes = [vp, P(Camera), P(SeedFrame), i32, vp, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
                                           P(AlignOut)]
+    lib.hso_gpu_seed_table_create.argtypes = [vp, P(i32)]
+    lib.hso_gpu_seed_table_destroy.argtypes = [vp, i32]
+    lib.hso_gpu_seed_table_append.argtypes = [vp, i32, vp, vp, i32, P(C.c_int32)]
+    lib.hso_gpu_seed_table_erase.argtypes = [vp, i32, vp, i32]
+    lib.hso_gpu_seed_table_size.argtypes = [vp, i32, P(i32), P(i32)]
+    lib.hso_gpu_seed_table_observe.argtypes = [vp, P(Camera), i32, P(SeedFrame), i32, C.c_double, vp, vp]
+    lib.hso_gpu_seed_table_read.argtypes = [vp, i32, i32, i32, vp]
+    lib.hso_gpu_map_reserve.argtypes = [vp, i32, i32, i32, i32]
+    lib.hso_gpu_map_store.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32]
+    lib.hso_gpu_reproject_match_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32]
     lib.hso_gpu_seed_reproject_match.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, vp, i32, i32, i32, vp, vp]
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
     lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
@@ -316,6 +337,9 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize",
     "hso_gpu_seed_reproject_match",
+    "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
+    "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
+    "hso_gpu_map_reserve", "hso_gpu_map_store", "hso_gpu_reproject_match_maps",
 ]
 
 
@@ -585,6 +609,66 @@ class Context:
         self._check(self.lib.hso_gpu_seed_observe_multi(self.h, C.byref(cam), fr, len(frames), _ptr(idx), px_error_angle, arr, n, out),
                     "seed_observe_multi")
         return list(out)[:n] if as_list else out
+
+    # -- resident seed tables
+    def seed_table_create(self):
+        t = C.c_int()
+        self._check(self.lib.hso_gpu_seed_table_create(self.h, C.byref(t)), "seed_table_create")
+        return t.value
+
+    def seed_table_destroy(self, table):
+        self._check(self.lib.hso_gpu_seed_table_destroy(self.h, table), "seed_table_destroy")
+
+    def seed_table_append(self, table, seeds, group=None):
+        n = len(seeds)
+        arr = seeds if isinstance(seeds, C.Array) else (Seed * max(n, 1))(*seeds)
+        grp = np.ascontiguousarray(group, np.int32) if group is not None else None
+        first = C.c_int32()
+        self._check(self.lib.hso_gpu_seed_table_append(self.h, table, C.cast(arr, C.c_void_p), _ptr(grp), n, C.byref(first)), "seed_table_append")
+        return first.value
+
+    def seed_table_erase(self, table, slots):
+        sl = np.ascontiguousarray(slots, np.int32)
+        self._check(self.lib.hso_gpu_seed_table_erase(self.h, table, _ptr(sl), len(sl)), "seed_table_erase")
+
+    def seed_table_size(self, table):
+        a, b = C.c_int(), C.c_int()
+        self._check(self.lib.hso_gpu_seed_table_size(self.h, table, C.byref(a), C.byref(b)), "seed_table_size")
+        return a.value, b.value
+
+    def seed_table_observe(self, cam, table, frames, px_error_angle, want_brief=True, want_full=False):
+        """frames: list of (frame_id, SE3 T_f_w, exposure_time), one per group.  -> (brief array or None, full ctypes array or None)"""
+        fr = (SeedFrame * len(frames))()
+        for k, (fid, T, expo) in enumerate(frames):
+            fr[k].frame_id, fr[k].T_f_w, fr[k].exposure_time = fid, T, expo
+        n, _ = self.seed_table_size(table)
+        brief = np.zeros(n, SEED_BRIEF_DTYPE) if want_brief else None
+        full = (SeedOut * max(n, 1))() if want_full else None
+        self._check(self.lib.hso_gpu_seed_table_observe(self.h, C.byref(cam), table, fr, len(frames), px_error_angle, _ptr(brief),
+                                                        C.cast(full, C.c_void_p) if want_full else None), "seed_table_observe")
+        return brief, full
+
+    def seed_table_read(self, table, first, n):
+        out = (Seed * max(n, 1))()
+        self._check(self.lib.hso_gpu_seed_table_read(self.h, table, first, n, C.cast(out, C.c_void_p)), "seed_table_read")
+        return out
+
+    # -- resident maps
+    def map_reserve(self, n_maps, max_kfs, max_points, max_obs):
+        self._check(self.lib.hso_gpu_map_reserve(self.h, n_maps, max_kfs, max_points, max_obs), "map_reserve")
+
+    def map_store(self, index, kfs, points, obs):
+        kfs = np.ascontiguousarray(kfs, KF_DTYPE); points = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+        obs = np.ascontiguousarray(obs, OBS_DTYPE)
+        self._check(self.lib.hso_gpu_map_store(self.h, index, _ptr(kfs), len(kfs), _ptr(points), len(points), _ptr(obs), len(obs)), "map_store")
+
+    def reproject_match_maps(self, cam, calls, cell_size, grid_n_cols, capacity):
+        """calls: MAP_CALL_DTYPE array.  -> MATCH_BRIEF_DTYPE array (the calls' points back to back)."""
+        calls = np.ascontiguousarray(calls, MAP_CALL_DTYPE)
+        out = np.zeros(capacity, MATCH_BRIEF_DTYPE)
+        n = self._check(self.lib.hso_gpu_reproject_match_maps(self.h, C.byref(cam), _ptr(calls), len(calls), cell_size, grid_n_cols, _ptr(out),
+                                                              capacity), "reproject_match_maps")
+        return out[:n]
 
     # -- FAST-9 corner candidates
     def fast_detect(self, frame_id, n_levels=3, threshold=20, border=8, cap=20000):

@@ -152,16 +152,12 @@ struct ReprojConsts {
   int n_pts, cell_size, grid_n_cols;
 };
 
-__global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* jobs, hso_reproj_point* proj)
+// one map point: reprojectPoint + getCloseViewObs + the findMatchDirect job (shared by the value-passing and the resident form)
+HSO_DEV hso_reproj_point reproject_one(const hso_camera& cam, const hso_map_point& P, const ReprojFrameDev& F, const ReprojKf* kfs,
+                                       const hso_obs* obs, int cell_size, int grid_n_cols, AlignJobDev* JD)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= R.n_pts) return;
-  const hso_map_point P = R.pts[i];
-  const ReprojFrameDev& F = R.frames[R.pt_frame[i]];
-  const ReprojKf* const kfs = R.kfs + F.kf_begin;
   hso_reproj_point o;
   o.projected = 0; o.cell = 0; o.px[0] = 0; o.px[1] = 0; o.ref_obs = -1; o.pad_ = 0;
-  AlignJobDev* JD = &jobs[i];
   JD->ref_base = nullptr; JD->cur_base = F.cur_base;
   // reprojectPoint, :504-529
   const ReprojKf& H = kfs[P.host_kf];
@@ -170,12 +166,12 @@ __global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* 
   se3_apply(H.T_cur_kf, P.host_f[0] * s, P.host_f[1] * s, P.host_f[2] * s, tx, ty, tz);
   if (!(tz < 0.00001)) {
     double u, v;
-    world2cam(R.cam, tx, ty, tz, u, v);
+    world2cam(cam, tx, ty, tz, u, v);
     const int ix = (int)u, iy = (int)v;
-    if (ix >= 8 && ix < R.cam.width - 8 && iy >= 8 && iy < R.cam.height - 8) {   // isInFrame(px.cast<int>(), 8)
+    if (ix >= 8 && ix < cam.width - 8 && iy >= 8 && iy < cam.height - 8) {   // isInFrame(px.cast<int>(), 8)
       o.projected = 1;
       o.px[0] = u; o.px[1] = v;
-      o.cell = (int)(v / R.cell_size) * R.grid_n_cols + (int)(u / R.cell_size);
+      o.cell = (int)(v / cell_size) * grid_n_cols + (int)(u / cell_size);
     }
   }
   if (o.projected && P.obs_count > 0) {
@@ -185,7 +181,7 @@ __global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* 
     int best = 0;
     double min_cos = 0;
     for (int k = 0; k < P.obs_count; k++) {
-      const ReprojKf& K = kfs[R.obs[P.obs_begin + k].kf];
+      const ReprojKf& K = kfs[obs[P.obs_begin + k].kf];
       double dx = K.pos[0] - P.pos[0], dy = K.pos[1] - P.pos[1], dz = K.pos[2] - P.pos[2];
       { const double n = sqrt(dx * dx + dy * dy + dz * dz); dx /= n; dy /= n; dz /= n; }
       const double c = ox * dx + oy * dy + oz * dz;
@@ -193,7 +189,7 @@ __global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* 
     }
     if (!(min_cos < 0.5)) {
       o.ref_obs = P.obs_begin + best;
-      const hso_obs ref = R.obs[o.ref_obs];
+      const hso_obs ref = obs[o.ref_obs];
       const ReprojKf& K = kfs[ref.kf];
       hso_align_job j;
       j.ref_frame_id = K.frame_id;
@@ -215,7 +211,68 @@ __global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* 
       JD->ref_base = K.base;
     }
   }
-  proj[i] = o;
+  return o;
+}
+
+__global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* jobs, hso_reproj_point* proj)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R.n_pts) return;
+  const ReprojFrameDev& F = R.frames[R.pt_frame[i]];
+  proj[i] = reproject_one(R.cam, R.pts[i], F, R.kfs + F.kf_begin, R.obs, R.cell_size, R.grid_n_cols, &jobs[i]);
+}
+
+// ---- resident maps: the tables of many sequences' local maps stay in HBM (one equal-sized region each); a call names its map
+struct MapCallDev {
+  ReprojFrameDev F;          // kf_begin = first row of the call's ReprojKf block
+  int map, point_begin, point_count, pad_;
+};
+struct MapConsts {
+  hso_camera cam;
+  const MapCallDev* calls;
+  int n_calls, n_total;
+  const ReprojKf* kfs;       // per call: max_kfs rows
+  const hso_map_point* pts;  // arena: [n_maps][max_points]
+  const hso_obs* obs;        // arena: [n_maps][max_obs]
+  int max_points, max_obs, cell_size, grid_n_cols;
+};
+
+__global__ __launch_bounds__(256) void k_reproject_maps(MapConsts M, AlignJobDev* jobs, hso_reproj_point* proj)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= M.n_total) return;
+  int lo = 0, hi = M.n_calls - 1;          // the call whose point range holds g
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (M.calls[mid].point_begin <= g) lo = mid; else hi = mid - 1; }
+  const MapCallDev& C = M.calls[lo];
+  const int i = g - C.point_begin;
+  proj[g] = reproject_one(M.cam, M.pts[(size_t)C.map * M.max_points + i], C.F, M.kfs + C.F.kf_begin, M.obs + (size_t)C.map * M.max_obs,
+                          M.cell_size, M.grid_n_cols, &jobs[g]);
+}
+
+// projection + match of one point -> the compact record the host's grid selection consumes
+__global__ __launch_bounds__(256) void k_match_brief(int n, const hso_reproj_point* proj, const hso_align_out* match, const AlignJobDev* jobs,
+                                                     hso_match_brief* out)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= n) return;
+  const hso_reproj_point p = proj[g];
+  const hso_align_out m = match[g];
+  hso_match_brief b;
+  memset(&b, 0, sizeof(b));
+  b.cell = p.projected ? p.cell : -1;
+  b.ref_obs = p.ref_obs;
+  b.px[0] = p.px[0]; b.px[1] = p.px[1];
+  b.px_cur[0] = m.px_cur[0]; b.px_cur[1] = m.px_cur[1];
+  b.success = (int8_t)m.success; b.stage = (int8_t)m.stage; b.search_level = (int8_t)m.search_level;
+  if (p.ref_obs >= 0) {
+    const hso_align_job& j = jobs[g].j;
+    b.ref_type = (int8_t)j.type;
+    // the new feature's gradient direction (reprojector.cpp:400-406): normalised A_cur_ref * ref grad
+    const double gx = m.A_cur_ref[0] * j.grad[0] + m.A_cur_ref[1] * j.grad[1], gy = m.A_cur_ref[2] * j.grad[0] + m.A_cur_ref[3] * j.grad[1];
+    const double nn = sqrt(gx * gx + gy * gy);
+    b.grad[0] = nn > 0 ? (float)(gx / nn) : 0.f; b.grad[1] = nn > 0 ? (float)(gy / nn) : 0.f;
+  }
+  out[g] = b;
 }
 
 // k_align over device-built jobs: a null reference = "findMatchDirect not reached / returned at once"
@@ -372,4 +429,167 @@ extern "C" int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, 
   f.cur_frame_id = cur_frame_id; f.T_cur_w = *T_cur_w; f.cur_exposure_time = cur_exposure_time; f.cur_keyframe_id = cur_keyframe_id;
   f.kf_begin = 0; f.kf_count = n_kfs; f.point_begin = 0; f.point_count = n_points; f.pad_ = 0;
   return hso_gpu_reproject_match_multi(ctx, cam, &f, 1, kfs, n_kfs, points, n_points, obs, n_obs, cell_size, grid_n_cols, proj_out, match_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident maps: a sequence's local map — keyframe poses, map points, observations,
+// the tables of hso_gpu_reproject_match — changes at keyframe rate only, so it is stored once per keyframe
+// (hso_gpu_map_store) and every frame in between passes its pose alone; the results come back as 56-byte records.
+struct MapArena {
+  int n_maps = 0, max_kfs = 0, max_points = 0, max_obs = 0;
+  hso_map_point* d_pts = nullptr;
+  hso_obs* d_obs = nullptr;
+  std::vector<std::vector<hso_kf>> kfs;     // per map (host: the per-call products are formed from them)
+  std::vector<int> n_points, n_obs;
+  PyrGeom g{}; bool have_g = false;
+};
+
+void hso_map_arena_free(hso_gpu_ctx* ctx)
+{
+  if (!ctx->maps) return;
+  (void)hipFree(ctx->maps->d_pts); (void)hipFree(ctx->maps->d_obs);
+  delete ctx->maps;
+  ctx->maps = nullptr;
+}
+
+extern "C" int hso_gpu_map_reserve(hso_gpu_ctx* ctx, int n_maps, int max_kfs, int max_points, int max_obs)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_maps <= 0 || max_kfs <= 0 || max_points <= 0 || max_obs <= 0) return hso_fail(ctx, HSO_E_INVALID, "map_reserve: bad argument");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  hso_map_arena_free(ctx);
+  MapArena* A = new MapArena();
+  A->n_maps = n_maps; A->max_kfs = max_kfs; A->max_points = max_points; A->max_obs = max_obs;
+  A->kfs.resize(n_maps); A->n_points.assign(n_maps, 0); A->n_obs.assign(n_maps, 0);
+  if (hipMalloc(reinterpret_cast<void**>(&A->d_pts), sizeof(hso_map_point) * (size_t)n_maps * max_points) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&A->d_obs), sizeof(hso_obs) * (size_t)n_maps * max_obs) != hipSuccess) {
+    (void)hipFree(A->d_pts); (void)hipFree(A->d_obs); delete A;
+    return hso_fail(ctx, HSO_E_NOMEM, "map_reserve: out of device memory");
+  }
+  ctx->maps = A;
+  return HSO_OK;
+}
+
+extern "C" int hso_gpu_map_store(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, int n_kfs, const hso_map_point* points, int n_points,
+                                 const hso_obs* obs, int n_obs)
+{
+  if (!ctx) return HSO_E_INVALID;
+  MapArena* A = ctx->maps;
+  if (!A || map < 0 || map >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "map_store: no such map (hso_gpu_map_reserve first)");
+  if (n_kfs < 0 || n_points < 0 || n_obs < 0 || n_kfs > A->max_kfs || n_points > A->max_points || n_obs > A->max_obs ||
+      (n_kfs > 0 && !kfs) || (n_points > 0 && !points) || (n_obs > 0 && !obs))
+    return hso_fail(ctx, HSO_E_INVALID, "map_store: table larger than the reserved region, or null");
+  for (int k = 0; k < n_kfs; k++) {
+    auto it = ctx->frames.find(kfs[k].frame_id);
+    if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "map_store: keyframe not resident");
+    if (!A->have_g) { A->g = it->second.g; A->have_g = true; }
+    if (!same_geom(it->second.g, A->g)) return hso_fail(ctx, HSO_E_INVALID, "map_store: frames must share one size");
+  }
+  for (int i = 0; i < n_points; i++) {
+    const hso_map_point& p = points[i];
+    if (p.host_kf < 0 || p.host_kf >= n_kfs || p.obs_count < 0 || p.obs_begin < 0 || (long long)p.obs_begin + p.obs_count > n_obs)
+      return hso_fail(ctx, HSO_E_INVALID, "map_store: point table out of range");
+  }
+  for (int k = 0; k < n_obs; k++)
+    if (obs[k].kf < 0 || obs[k].kf >= n_kfs || obs[k].level < 0 || obs[k].level >= HSO_N_PYR_LEVELS)
+      return hso_fail(ctx, HSO_E_INVALID, "map_store: observation table out of range");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t bp = sizeof(hso_map_point) * (size_t)n_points, bo = sizeof(hso_obs) * (size_t)n_obs;
+  char* h = hso_pinned(ctx, 0, bp + bo + 64);
+  if (!h) return HSO_E_NOMEM;
+  if (bp) memcpy(h, points, bp);
+  if (bo) memcpy(h + bp, obs, bo);
+  if (bp) HSO_HIP_CHECK(ctx, hipMemcpyAsync(A->d_pts + (size_t)map * A->max_points, h, bp, hipMemcpyHostToDevice, ctx->stream));
+  if (bo) HSO_HIP_CHECK(ctx, hipMemcpyAsync(A->d_obs + (size_t)map * A->max_obs, h + bp, bo, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  A->kfs[map].assign(kfs, kfs + n_kfs);
+  A->n_points[map] = n_points; A->n_obs[map] = n_obs;
+  return HSO_OK;
+}
+
+extern "C" int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                                            int grid_n_cols, hso_match_brief* out, int out_capacity)
+{
+  if (!ctx) return HSO_E_INVALID;
+  MapArena* A = ctx->maps;
+  if (!A || !cam || n_calls < 0 || (n_calls > 0 && !calls) || cell_size < 1 || grid_n_cols < 1)
+    return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: bad argument");
+  if (n_calls == 0) return 0;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  size_t total = 0;
+  for (int c = 0; c < n_calls; c++) {
+    if (calls[c].map < 0 || calls[c].map >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: no such map");
+    total += (size_t)A->n_points[calls[c].map];
+  }
+  if (total == 0) return 0;
+  if (!out || (size_t)out_capacity < total) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: output smaller than the calls' points");
+  if (cam->width != A->g.w[0] || cam->height != A->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: camera size differs from the frame size");
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_calls = al(sizeof(MapCallDev) * (size_t)n_calls), b_kfs = al(sizeof(ReprojKf) * (size_t)n_calls * A->max_kfs);
+  char* hin = hso_pinned(ctx, 0, b_calls + b_kfs);
+  if (!hin) return HSO_E_NOMEM;
+  MapCallDev* hc = reinterpret_cast<MapCallDev*>(hin);
+  ReprojKf* hk = reinterpret_cast<ReprojKf*>(hin + b_calls);
+  int begin = 0;
+  for (int c = 0; c < n_calls; c++) {
+    const hso_map_call& K = calls[c];
+    auto itc = ctx->frames.find(K.cur_frame_id);
+    if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match_maps: current frame not resident");
+    if (!same_geom(itc->second.g, A->g)) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: frames must share one size");
+    const Se3 Tc = se3_from(K.T_cur_w);
+    const Se3 ci = se3_inverse(Tc);
+    MapCallDev& D = hc[c];
+    D.F.cur_pos[0] = ci.tx; D.F.cur_pos[1] = ci.ty; D.F.cur_pos[2] = ci.tz;
+    D.F.cur_base = itc->second.base; D.F.kf_begin = c * A->max_kfs; D.F.pad_ = 0;
+    D.map = K.map; D.point_begin = begin; D.point_count = A->n_points[K.map]; D.pad_ = 0;
+    begin += D.point_count;
+    const std::vector<hso_kf>& kfs = A->kfs[K.map];
+    for (size_t k = 0; k < kfs.size(); k++) {
+      auto it = ctx->frames.find(kfs[k].frame_id);
+      if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match_maps: a stored keyframe is no longer resident");
+      ReprojKf& R = hk[(size_t)c * A->max_kfs + k];
+      const Se3 inv = se3_inverse(se3_from(kfs[k].T_f_w));
+      R.T_cur_kf = se3_mul(Tc, inv);
+      R.pos[0] = inv.tx; R.pos[1] = inv.ty; R.pos[2] = inv.tz;
+      R.base = it->second.base; R.frame_id = kfs[k].frame_id;
+      R.exposure_rat = (float)(K.cur_exposure_time / kfs[k].exposure_time);
+      R.kf_gap_lt4 = (K.cur_keyframe_id - kfs[k].keyframe_id) < 4;
+    }
+  }
+  const size_t o_jobs = 0, o_match = o_jobs + al(sizeof(AlignJobDev) * total), o_proj = o_match + al(sizeof(hso_align_out) * total);
+  const size_t o_brief = o_proj + al(sizeof(hso_reproj_point) * total), o_in = o_brief + al(sizeof(hso_match_brief) * total);
+  const size_t need = o_in + b_calls + b_kfs;
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
+  }
+  char* d = ctx->d_batch;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_in, hin, b_calls + b_kfs, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_match, 0, sizeof(hso_align_out) * total, ctx->stream));
+  MapConsts M;
+  M.cam = *cam; M.calls = reinterpret_cast<const MapCallDev*>(d + o_in); M.n_calls = n_calls; M.n_total = (int)total;
+  M.kfs = reinterpret_cast<const ReprojKf*>(d + o_in + b_calls); M.pts = A->d_pts; M.obs = A->d_obs;
+  M.max_points = A->max_points; M.max_obs = A->max_obs; M.cell_size = cell_size; M.grid_n_cols = grid_n_cols;
+  AlignJobDev* d_jobs = reinterpret_cast<AlignJobDev*>(d + o_jobs);
+  hso_align_out* d_match = reinterpret_cast<hso_align_out*>(d + o_match);
+  hso_reproj_point* d_proj = reinterpret_cast<hso_reproj_point*>(d + o_proj);
+  hso_match_brief* d_brief = reinterpret_cast<hso_match_brief*>(d + o_brief);
+  const int n = (int)total;
+  hipLaunchKernelGGL(k_reproject_maps, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, M, d_jobs, d_proj);
+  AlignConsts C;
+  C.cam = *cam; C.g = A->g;
+  hipLaunchKernelGGL(k_align_sparse, dim3((n + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream,
+                     C, d_jobs, n, d_match);
+  hipLaunchKernelGGL(k_match_brief, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_proj, d_match, d_jobs, d_brief);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  hso_match_brief* hb = reinterpret_cast<hso_match_brief*>(hso_pinned(ctx, 1, sizeof(hso_match_brief) * total));
+  if (!hb) return HSO_E_NOMEM;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hb, d_brief, sizeof(hso_match_brief) * total, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, hb, sizeof(hso_match_brief) * total);
+  return (int)total;
 }

@@ -36,6 +36,8 @@ struct FrameRec {
 };
 
 struct TrackBatchState;  // hso_tracker.hip
+struct SeedTables;       // hso_seed.hip: resident seed tables
+struct MapArena;         // hso_align.hip: resident map tables
 
 struct hso_gpu_ctx {
   int device;
@@ -47,6 +49,8 @@ struct hso_gpu_ctx {
   std::vector<uint8_t*> free_frames;  // recycled allocations, all of geometry free_w x free_h (their padding rows are still zero)
   int free_w, free_h;
   TrackBatchState* track;
+  SeedTables* seed_tables;
+  MapArena* maps;
   // staging for batched frame uploads: [bases | srcs | stats]
   char* d_batch; size_t batch_cap;
   // pinned host staging (grow-only): record tables go through it so the DMA runs at PCIe rate
@@ -75,6 +79,8 @@ int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases,
 // cv::resize INTER_LINEAR of a device image into a device buffer (hso_frame.hip)
 int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh);
 void hso_track_state_free(hso_gpu_ctx* ctx);
+void hso_seed_tables_free(hso_gpu_ctx* ctx);
+void hso_map_arena_free(hso_gpu_ctx* ctx);
 // a frame allocation of geometry g: recycled when the free list holds that geometry, else fresh with zeroed padding rows.
 // hso_frame_free returns it to the list (or the allocator); neither touches ctx->frames.
 int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base);

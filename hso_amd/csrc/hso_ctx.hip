@@ -62,6 +62,8 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   hso_gpu_ctx* ctx = new hso_gpu_ctx();
   ctx->device = device;
   ctx->track = nullptr;
+  ctx->seed_tables = nullptr;
+  ctx->maps = nullptr;
   ctx->free_w = ctx->free_h = 0;
   ctx->d_batch = nullptr;
   ctx->batch_cap = 0;
@@ -87,6 +89,8 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   hso_track_state_free(ctx);
+  hso_seed_tables_free(ctx);
+  hso_map_arena_free(ctx);
   for (auto& kv : ctx->frames) (void)hipFree(kv.second.base);
   for (auto* p : ctx->free_frames) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);

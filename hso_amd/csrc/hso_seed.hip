@@ -17,6 +17,7 @@
 // codes and the step index of the best score can differ on near-ties (flagged in the tests).
 #include "hso_match_dev.h"
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 using namespace hso_dev;
@@ -27,6 +28,7 @@ using namespace hso_dev;
 struct SeedFrameDev {
   hso_se3 T_f_w;
   double exposure;
+  const uint8_t* cur_base;   // resident tables: the seed's own cur_base is null and the frame's is used
 };
 
 struct SeedConsts {
@@ -34,6 +36,8 @@ struct SeedConsts {
   PyrGeom g;
   const SeedFrameDev* frames;
   double px_error_angle;
+  int update_in_place;       // resident tables: write mu / sigma2 / b back into the seed record
+  hso_seed_brief* brief;     // resident tables: compact per-slot result (may be null)
 };
 
 struct SeedDev {
@@ -143,7 +147,21 @@ HSO_DEV bool s_klt_limited(const uint8_t* img, int cols, int rows, float gxr, fl
   return !(bestEnergy > (float)(650 * 64));
 }
 
-__global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(SeedConsts C, const SeedDev* seeds, int n_seeds,
+// the common exit: full record, and for resident tables the state update + the compact record
+HSO_DEV void seed_finish(const SeedConsts& C, SeedDev* seeds, int sid, hso_seed_out* outs, const hso_seed_out& o, int lane)
+{
+  if (lane != 0) return;
+  if (outs) outs[sid] = o;
+  if (C.update_in_place) { seeds[sid].s.mu = o.mu; seeds[sid].s.sigma2 = o.sigma2; seeds[sid].s.b = o.b; }
+  if (C.brief) {
+    hso_seed_brief br;
+    br.mu = o.mu; br.sigma2 = o.sigma2; br.b = o.b;
+    br.result = (int8_t)o.result; br.is_update = (int8_t)o.is_update; br.is_valid = (int8_t)o.is_valid; br.search_level = (int8_t)o.search_level;
+    C.brief[sid] = br;
+  }
+}
+
+__global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(SeedConsts C, SeedDev* seeds, int n_seeds,
                                                                              hso_seed_out* outs)
 {
   __shared__ float s_pwb[SEED_WAVES_PER_BLOCK][100];
@@ -151,6 +169,10 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
   const int sid = blockIdx.x * SEED_WAVES_PER_BLOCK + wave;
   if (sid >= n_seeds) return;
   const SeedDev& SD = seeds[sid];
+  if (SD.ref_base == nullptr) {   // an erased slot of a resident table
+    if (lane == 0 && C.brief) { hso_seed_brief br; memset(&br, 0, sizeof(br)); C.brief[sid] = br; }
+    return;
+  }
   const hso_seed& S = SD.s;
   const int W = C.g.w[0], H = C.g.h[0];
   hso_seed_out o;
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
 
   // ---- visibility in the active frame (depth_filter.cpp:590-606)
   const SeedFrameDev& F = C.frames[SD.frame];
-  const uint8_t* const cur_base = SD.cur_base;
+  const uint8_t* const cur_base = SD.cur_base ? SD.cur_base : F.cur_base;
   const Se3 Tcw = se3_from(F.T_f_w), Trw = se3_from(S.T_ref_w);
   const Se3 T_ref_cur = se3_mul(Trw, se3_inverse(Tcw));
   {
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
       const int ox = (int)cu, oy = (int)cv;
       vis = (ox >= 0 && ox < W && oy >= 0 && oy < H);
     }
-    if (!vis) { o.result = 0; o.is_update = 0; if (lane == 0) outs[sid] = o; return; }
+    if (!vis) { o.result = 0; o.is_update = 0; seed_finish(C, seeds, sid, outs, o, lane); return; }
   }
   o.is_update = 1;
   const float z_inv_min = S.mu + 2 * sqrtf(S.sigma2);
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     id_var *= w;
     o.sigma2 = (id_var < S.sigma2) ? id_var : S.sigma2;
   }
-  if (lane == 0) outs[sid] = o;
+  seed_finish(C, seeds, sid, outs, o, lane);
 }
 
 extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed_frame* frames, int n_frames,
@@ -410,7 +432,7 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
     if (k == 0) g = itc->second.g;
     else if (!same_geom(itc->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: frames must share one size");
     cur_base[k] = itc->second.base;
-    hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = frames[k].exposure_time;
+    hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = frames[k].exposure_time; hf[k].cur_base = itc->second.base;
   }
   if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_observe: camera size differs from the frame size");
   SeedDev* h = reinterpret_cast<SeedDev*>(hso_pinned(ctx, 0, (size_t)n_seeds * sizeof(SeedDev)));
@@ -448,7 +470,7 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h, (size_t)n_seeds * sizeof(SeedDev), hipMemcpyHostToDevice, ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_fr, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
-  C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle;
+  C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle; C.update_in_place = 0; C.brief = nullptr;
   const int blocks = (n_seeds + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK;
   hipLaunchKernelGGL(k_seed_observe, dim3(blocks), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, d_in, n_seeds, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
@@ -470,3 +492,198 @@ extern "C" int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int
   const std::vector<int32_t> zero((size_t)n_seeds, 0);
   return hso_gpu_seed_observe_multi(ctx, cam, &f, 1, zero.data(), px_error_angle, seeds, n_seeds, out);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Resident seed tables: the seeds of a DepthFilter (of one sequence, or of many — a seed names its group) live in HBM
+// between calls.  DepthFilter::initializeSeeds appends (src/depth_filter.cpp:164-205), updateSeeds' erase sites erase
+// (:368-401, :423-497), and one observation of every live seed (observeDepth, :557-675) runs over the table in place: what
+// crosses PCIe per frame is one hso_seed_frame per group in and one 16-byte hso_seed_brief per slot out, instead of the
+// 216-byte seed record in and the 88-byte result out of the value-passing call.
+struct SeedTable {
+  SeedDev* d = nullptr;
+  size_t cap = 0, n = 0;              // slots allocated / used (erased slots keep their index)
+  std::vector<uint8_t> alive;
+  hso_seed_brief* d_brief = nullptr; size_t brief_cap = 0;
+  hso_seed_out* d_full = nullptr; size_t full_cap = 0;
+  SeedFrameDev* d_frames = nullptr; size_t frames_cap = 0;
+  PyrGeom g{}; bool have_g = false;
+  int max_group = -1;
+};
+struct SeedTables { std::vector<SeedTable*> t; };
+
+void hso_seed_tables_free(hso_gpu_ctx* ctx)
+{
+  if (!ctx->seed_tables) return;
+  for (SeedTable* t : ctx->seed_tables->t)
+    if (t) { (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); delete t; }
+  delete ctx->seed_tables;
+  ctx->seed_tables = nullptr;
+}
+
+static SeedTable* seed_table_of(hso_gpu_ctx* ctx, int table)
+{
+  if (!ctx->seed_tables || table < 0 || table >= (int)ctx->seed_tables->t.size()) return nullptr;
+  return ctx->seed_tables->t[table];
+}
+
+template <typename T> static int grow_dev(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need, size_t keep)
+{
+  if (*cap >= need) return HSO_OK;
+  const size_t ncap = std::max(need, *cap * 2 + 1024);
+  T* q = nullptr;
+  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&q), ncap * sizeof(T)));
+  if (*p && keep) {
+    hipError_t e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(q); ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
+  } else if (*p) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (*p) (void)hipFree(*p);
+  *p = q; *cap = ncap;
+  return HSO_OK;
+}
+
+extern "C" {
+
+int hso_gpu_seed_table_create(hso_gpu_ctx* ctx, int* table_out)
+{
+  if (!ctx || !table_out) return HSO_E_INVALID;
+  if (!ctx->seed_tables) ctx->seed_tables = new SeedTables();
+  ctx->seed_tables->t.push_back(new SeedTable());
+  *table_out = (int)ctx->seed_tables->t.size() - 1;
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_destroy(hso_gpu_ctx* ctx, int table)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t) return hso_fail(ctx, HSO_E_INVALID, "seed_table: no such table");
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames);
+  delete t;
+  ctx->seed_tables->t[table] = nullptr;
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_append(hso_gpu_ctx* ctx, int table, const hso_seed* seeds, const int32_t* group, int n, int32_t* first_slot)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || n < 0 || (n > 0 && !seeds)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_append: bad argument");
+  if (first_slot) *first_slot = (int32_t)t->n;
+  if (n == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  SeedDev* h = reinterpret_cast<SeedDev*>(hso_pinned(ctx, 0, (size_t)n * sizeof(SeedDev)));
+  if (!h) return HSO_E_NOMEM;
+  int64_t last_id = -1;
+  const uint8_t* last_base = nullptr;
+  for (int i = 0; i < n; i++) {
+    if (i == 0 || seeds[i].ref_frame_id != last_id) {
+      auto itr = ctx->frames.find(seeds[i].ref_frame_id);
+      if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_table_append: seed host frame not resident");
+      if (!t->have_g) { t->g = itr->second.g; t->have_g = true; }
+      if (!same_geom(itr->second.g, t->g)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_append: frames must share one size");
+      last_id = seeds[i].ref_frame_id; last_base = itr->second.base;
+    }
+    if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_table_append: bad level");
+    const int gi = group ? group[i] : 0;
+    if (gi < 0) return hso_fail(ctx, HSO_E_INVALID, "seed_table_append: negative group");
+    h[i].ref_base = last_base; h[i].cur_base = nullptr; h[i].frame = gi; h[i].pad_ = 0; h[i].s = seeds[i];
+    t->max_group = std::max(t->max_group, gi);
+  }
+  if (int rc = grow_dev(ctx, &t->d, &t->cap, t->n + (size_t)n, t->n)) return rc;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d + t->n, h, (size_t)n * sizeof(SeedDev), hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer is reused by the next call
+  t->n += (size_t)n;
+  t->alive.resize(t->n, 1);
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, int n)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || n < 0 || (n > 0 && !slots)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_erase: bad argument");
+  for (int i = 0; i < n; i++)
+    if (slots[i] < 0 || (size_t)slots[i] >= t->n) return hso_fail(ctx, HSO_E_INVALID, "seed_table_erase: slot out of range");
+  const uint8_t* null_base = nullptr;
+  for (int i = 0; i < n; i++) {
+    if (!t->alive[slots[i]]) continue;
+    t->alive[slots[i]] = 0;
+    // ref_base is the first member of SeedDev: a null there marks the slot dead for the kernel
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(reinterpret_cast<char*>(t->d + slots[i]), &null_base, sizeof(null_base), hipMemcpyHostToDevice, ctx->stream));
+  }
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_size(hso_gpu_ctx* ctx, int table, int* n_slots, int* n_live)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t) return hso_fail(ctx, HSO_E_INVALID, "seed_table: no such table");
+  if (n_slots) *n_slots = (int)t->n;
+  if (n_live) { int c = 0; for (uint8_t a : t->alive) c += a; *n_live = c; }
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
+                               double px_error_angle, hso_seed_brief* brief_out, hso_seed_out* full_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || !cam || !frames || n_frames <= 0) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe: bad argument");
+  if (t->n == 0) return HSO_OK;
+  if (t->max_group >= n_frames) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe: a seed's group has no frame");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<SeedFrameDev> hf(n_frames);
+  for (int k = 0; k < n_frames; k++) {
+    auto itc = ctx->frames.find(frames[k].frame_id);
+    if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_table_observe: active frame not resident");
+    if (!same_geom(itc->second.g, t->g)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe: frames must share one size");
+    hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = frames[k].exposure_time; hf[k].cur_base = itc->second.base;
+  }
+  if (cam->width != t->g.w[0] || cam->height != t->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe: camera size differs from the frame size");
+  if (int rc = grow_dev(ctx, &t->d_frames, &t->frames_cap, (size_t)n_frames, 0)) return rc;
+  if (int rc = grow_dev(ctx, &t->d_brief, &t->brief_cap, t->n, 0)) return rc;
+  if (full_out) if (int rc = grow_dev(ctx, &t->d_full, &t->full_cap, t->n, 0)) return rc;
+  SeedFrameDev* hfp = reinterpret_cast<SeedFrameDev*>(hso_pinned(ctx, 0, (size_t)n_frames * sizeof(SeedFrameDev)));
+  if (!hfp) return HSO_E_NOMEM;
+  memcpy(hfp, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, hfp, (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
+  SeedConsts C;
+  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief;
+  const int n = (int)t->n;
+  hipLaunchKernelGGL(k_seed_observe, dim3((n + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C,
+                     t->d, n, full_out ? t->d_full : nullptr);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  if (brief_out) {
+    hso_seed_brief* hb = reinterpret_cast<hso_seed_brief*>(hso_pinned(ctx, 1, t->n * sizeof(hso_seed_brief)));
+    if (!hb) return HSO_E_NOMEM;
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(hb, t->d_brief, t->n * sizeof(hso_seed_brief), hipMemcpyDeviceToHost, ctx->stream));
+    if (full_out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(full_out, t->d_full, t->n * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(brief_out, hb, t->n * sizeof(hso_seed_brief));
+  } else {
+    if (full_out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(full_out, t->d_full, t->n * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_read(hso_gpu_ctx* ctx, int table, int first, int n, hso_seed* seeds_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || first < 0 || n < 0 || (size_t)first + (size_t)n > t->n || (n > 0 && !seeds_out)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_read: bad argument");
+  if (n == 0) return HSO_OK;
+  std::vector<SeedDev> h((size_t)n);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), t->d + first, (size_t)n * sizeof(SeedDev), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n; i++) seeds_out[i] = h[i].s;
+  return HSO_OK;
+}
+
+}  // extern "C"

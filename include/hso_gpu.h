@@ -348,6 +348,37 @@ int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const
                                   const hso_obs* obs, int n_obs, int cell_size, int grid_n_cols,
                                   hso_reproj_point* proj_out, hso_align_out* match_out);
 
+/* ---- resident maps: the tables of hso_gpu_reproject_match kept in HBM.  A sequence's local map (keyframe poses, points,
+ *      observations) changes at keyframe rate (a new keyframe, local BA), so it is stored once then (hso_gpu_map_store) and the
+ *      frames in between pass their pose alone; results come back as 56-byte records instead of 128 bytes per point.
+ *      hso_gpu_map_reserve sizes n_maps equal regions (one per sequence served by this context). ---- */
+typedef struct hso_map_call {
+  int32_t map;                 /* which stored map */
+  int32_t cur_keyframe_id;     /* Frame::keyFrameId_ of the current frame */
+  int64_t cur_frame_id;        /* resident current frame */
+  hso_se3 T_cur_w;
+  double cur_exposure_time;
+} hso_map_call;
+
+typedef struct hso_match_brief {
+  double px[2];                /* Candidate::px, the projected position */
+  double px_cur[2];            /* the refined position (valid when success) */
+  float grad[2];               /* the new feature's gradient direction: normalised A_cur_ref * ref grad (reprojector.cpp:400-406) */
+  int32_t cell;                /* grid cell, -1: reprojectPoint returned false */
+  int32_t ref_obs;             /* chosen observation, index into the map's obs table; -1: none within 60 degrees */
+  int8_t success, stage, search_level, ref_type;   /* findMatchDirect's result, HSO_ALIGN_* stage, Matcher::search_level_, ref_ftr_->type */
+  int32_t pad_;
+} hso_match_brief;
+
+int hso_gpu_map_reserve(hso_gpu_ctx* ctx, int n_maps, int max_kfs, int max_points, int max_obs);
+/* replace map `map` (index kept; points' host_kf / obs kf index the map's own kfs, obs_begin its own obs table) */
+int hso_gpu_map_store(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, int n_kfs, const hso_map_point* points, int n_points,
+                      const hso_obs* obs, int n_obs);
+/* project + choose the reference observation + findMatchDirect for every point of every call's map, one launch chain.
+ * out: the calls' points back to back in call order (out_capacity entries available); returns their number or a status < 0 */
+int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                                 int grid_n_cols, hso_match_brief* out, int out_capacity);
+
 /* ---- pose_optimizer::optimizeLevenbergMarquardt3rd, src/pose_optimizer.cpp:399-771 ---- */
 
 /* One feature of the frame being optimised, in Frame::fts_ order.  has_point = 0 keeps the
@@ -515,6 +546,31 @@ typedef struct hso_seed_frame {
 int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed_frame* frames, int n_frames,
                                const int32_t* seed_frame, double px_error_angle, const hso_seed* seeds, int n_seeds,
                                hso_seed_out* out);
+
+/* ---- resident seed tables: the std::list<Seed> of a DepthFilter (include/hso/depth_filter.h:211) kept in HBM between calls.
+ *      initializeSeeds (src/depth_filter.cpp:164-205) appends, the erase sites of updateSeeds (:368-401, :423-497) erase, and one
+ *      observation of every live seed (observeDepth, :557-675) updates mu / sigma2 / b in place.  Per frame only one hso_seed_frame
+ *      per group goes in and one 16-byte hso_seed_brief per slot comes out (the value-passing hso_gpu_seed_observe moves a 216-byte
+ *      record in and an 88-byte one out per seed).  A seed's `group` names which entry of the observe call's frames[] it is
+ *      observed in: 0 for the table of one sequence; the sequence index when one table serves many.  Slot indices are stable:
+ *      an erased slot is skipped, never reused.  Host frames of the seeds must stay resident while their seeds are alive. ---- */
+typedef struct hso_seed_brief {
+  float mu, sigma2, b;       /* the state after the observation (what the table now holds) */
+  int8_t result;             /* doLineStereo's code 1 / -1..-4; 0 = not visible in the active frame, or an erased slot */
+  int8_t is_update, is_valid, search_level;
+} hso_seed_brief;
+int hso_gpu_seed_table_create(hso_gpu_ctx* ctx, int* table_out);
+int hso_gpu_seed_table_destroy(hso_gpu_ctx* ctx, int table);
+int hso_gpu_seed_table_append(hso_gpu_ctx* ctx, int table, const hso_seed* seeds, const int32_t* group /* n or NULL = all 0 */, int n,
+                              int32_t* first_slot);
+int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, int n);
+int hso_gpu_seed_table_size(hso_gpu_ctx* ctx, int table, int* n_slots, int* n_live);
+/* brief_out: n_slots entries or NULL; full_out: n_slots hso_seed_out records or NULL (epipolar end points, px_cur, z: what a
+ * keyframe observation needs for FeatureExtractor::setGridOccpuancy, :669-673) */
+int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
+                               double px_error_angle, hso_seed_brief* brief_out, hso_seed_out* full_out);
+/* the records of slots [first, first + n) as the table holds them now (convergence / activation read them at keyframe rate) */
+int hso_gpu_seed_table_read(hso_gpu_ctx* ctx, int table, int first, int n, hso_seed* seeds_out);
 
 /* ---- DepthFilter::activatePoint + seedOptimizer, src/depth_filter.cpp:729-1073 ---- */
 
