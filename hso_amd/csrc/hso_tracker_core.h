@@ -1,0 +1,1244 @@
+// hso_tracker_core.h — the device code of the tracker, parametrised by the workgroup shape.  Included (twice) by
+// hso_tracker.hip inside a namespace, with
+//   TRK_THREADS    threads per workgroup (a multiple of 64),
+//   TRK_LDS_KB     LDS the workgroup may use (image + state),
+//   TRK_OLD_SHARE  sixteenths of the features given to the first half of the waves (8 = even split)
+// defined by the includer.  No include guard on purpose.
+#define TRK_WAVES (TRK_THREADS / 64)
+// LDS-resident state of one workgroup
+struct Shared {
+  double red[N_RED];                 // block-reduced sums of the last evaluation
+  double wave_part[TRK_WAVES][N_RED + 2];
+  double H[28], b[7];                // accepted normal equations
+  double step[8];                    // LM step of the current proposal
+  Se3 T, Tn;                         // m_T_cur_ref, new_T_cur_ref
+  double energy_old, step_norm;
+  float a, a_new;
+  float huber, outlier, lambda;
+  int level, PA, pad, S;
+  int pi;                            // pattern index of the level
+  int job, stop, n_select;
+  int use_lds;
+  hso_camera cam;                    // LDS copy of the camera for the out-of-line projection
+  int keys_lds_off;                  // byte offset of the level's key array in LDS, 0 = keys in memory
+  unsigned sel[4096];                // selection histogram (SEL_WORDS)
+  int wave_cnt[TRK_WAVES];
+  int poff[32];                      // byte offset oy*stride+ox of every pattern pixel of this level
+  hso_track_result res;              // the job's result record, written to global memory once at the end
+#ifdef HSO_PHASE_TIMERS
+  unsigned long long dbg[8];
+#endif
+};
+
+// the staged level image is addressed either in LDS (explicit address space 3, so the
+// taps compile to ds_read2_b32) or in global memory (level too large for LDS)
+typedef const __attribute__((address_space(3))) uint32_t* LdsPtr;
+typedef const uint32_t* GlbPtr;
+
+struct LevelCtx {
+  const TrackConsts* C;
+  const TrackJobDev* job;
+  Scratch sc;
+  GlbPtr cur_glb;          // current level image in global memory (aligned dwords)
+  GlbPtr ref_glb;          // reference level image in global memory
+  int cols, rows, level;
+  float scale;
+  double fxl, fyl;
+  const __attribute__((address_space(3))) hso_camera* cam_lds;  // Shared::cam
+};
+
+// 4 consecutive bytes starting at byte address `addr` of a dword-aligned buffer
+template <typename Ptr>
+HSO_DEV uint32_t fetch4(Ptr w32, int addr)
+{
+  const int a = addr >> 2;
+  const uint32_t lo = w32[a], hi = w32[a + 1];
+  return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(addr & 3));
+}
+HSO_DEV float b0f(uint32_t v) { return (float)(v & 0xffu); }
+HSO_DEV float b1f(uint32_t v) { return (float)((v >> 8) & 0xffu); }
+HSO_DEV float b2f(uint32_t v) { return (float)((v >> 16) & 0xffu); }
+HSO_DEV float b3f(uint32_t v) { return (float)(v >> 24); }
+
+HSO_DEV double shfl_d(double v, int src)
+{
+  const int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+HSO_DEV double shfl_xor_d(double v, int m)
+{
+  const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+  return __hiloint2double(hi, lo);
+}
+
+// FOV (atan) camera: rare, transcendental-heavy — kept out of line so that it does not
+// inflate the register budget of the hot loops
+__device__ __noinline__ void world2cam_fov(const hso_camera* cam, double x, double y, double z, double* pu, double* pv)
+{
+  world2cam(*cam, x, y, z, *pu, *pv);
+}
+
+// projection of one reference feature into the current level
+// (CoarseTracker.cpp:290-323 / :557-583)
+struct Proj {
+  bool ok;
+  int base;                      // byte address of pixel (u_i - 1, v_i) in the level image
+  float w_tl, w_tr, w_bl, w_br;
+  double x, y, z;
+};
+
+// one feature's record as it sits in memory; loaded a round ahead of its use so that the
+// L2 latency of the five loads hides behind the previous feature's pixel loop
+struct FeatRaw {
+  double bx, by, bz, dist;
+  int vis;
+};
+
+HSO_DEV FeatRaw load_feature(const LevelCtx& L, int f)
+{
+  FeatRaw r;
+  r.vis = 0; r.bx = r.by = r.bz = 0; r.dist = -1;
+  if (f < L.job->n) {
+    const TrackJobDev& J = *L.job;
+    const int ns = J.n_stride;
+    // explicit global address space: a generic pointer would make these FLAT loads, which count on
+    // lgkmcnt as well, so every LDS wait of the pixel loop would also wait for this prefetch
+    typedef const __attribute__((address_space(1))) double* GlbF64;
+    typedef const __attribute__((address_space(1))) uint8_t* GlbU8;
+    const GlbF64 ft = (GlbF64)J.feats;
+    r.vis = ((GlbU8)L.sc.visible)[f];
+    r.dist = ft[5 * ns + f];
+    r.bx = ft[2 * ns + f]; r.by = ft[3 * ns + f]; r.bz = ft[4 * ns + f];
+  }
+  return r;
+}
+
+// Out of line on purpose, with every input passed by value: its fp64 temporaries then never share
+// a register allocation with the pixel loops, and the body fits the call-clobbered registers, so
+// a call saves and restores nothing (the inlined version was the main source of spills in the
+// hot loops).  The camera is read from the workgroup's LDS copy (one address, broadcast reads).
+typedef const __attribute__((address_space(3))) hso_camera* CamPtr;
+__device__ __noinline__ Proj project_feature_nl(CamPtr camp, Se3 T, double bx, double by, double bz, double dist, int vis, int border,
+                                                int cols, int rows, float scale)
+{
+  Proj p;
+  p.ok = false;
+  p.base = 0; p.w_tl = p.w_tr = p.w_bl = p.w_br = 0; p.x = p.y = p.z = 0;
+  if (!vis) return p;
+  if (dist < 0) return p;
+  se3_apply(T, bx * dist, by * dist, bz * dist, p.x, p.y, p.z);
+  if (p.z < 0) return p;
+  double pu, pv;
+  const int model = camp->model, distortion = camp->distortion;
+  if (model == HSO_CAM_FOV && distortion) {
+    hso_camera cam;
+    cam.model = model; cam.distortion = distortion; cam.width = camp->width; cam.height = camp->height;
+    cam.fx = camp->fx; cam.fy = camp->fy; cam.cx = camp->cx; cam.cy = camp->cy;
+    for (int i = 0; i < 5; i++) cam.d[i] = camp->d[i];
+    world2cam_fov(&cam, p.x, p.y, p.z, &pu, &pv);
+  } else {
+    // AbstractCamera::world2cam, src/camera.cpp:89-125 (pinhole, optional radtan)
+    const double u = p.x / p.z, v = p.y / p.z;
+    if (model == HSO_CAM_PINHOLE && distortion) {
+      const double r2 = u * u + v * v;
+      const double r4 = r2 * r2;
+      const double r6 = r4 * r2;
+      const double a1 = 2 * u * v;
+      const double a2 = r2 + 2 * u * u;
+      const double a3 = r2 + 2 * v * v;
+      const double cdist = 1 + camp->d[0] * r2 + camp->d[1] * r4 + camp->d[4] * r6;
+      const double xd = u * cdist + camp->d[2] * a1 + camp->d[3] * a2;
+      const double yd = v * cdist + camp->d[2] * a3 + camp->d[3] * a1;
+      pu = xd * camp->fx + camp->cx;
+      pv = yd * camp->fy + camp->cy;
+    } else {
+      pu = camp->fx * u + camp->cx;
+      pv = camp->fy * v + camp->cy;
+    }
+  }
+  const float u_cur = (float)pu * scale;
+  const float v_cur = (float)pv * scale;
+  const int u_i = (int)floorf(u_cur);
+  const int v_i = (int)floorf(v_cur);
+  if (u_i - border < 0 || v_i - border < 0 || u_i + border >= cols || v_i + border >= rows) return p;
+  const float su = u_cur - (float)u_i;
+  const float sv = v_cur - (float)v_i;
+  p.w_tl = (float)((1.0 - su) * (1.0 - sv));
+  p.w_tr = (float)(su * (1.0 - sv));
+  p.w_bl = (float)((1.0 - su) * sv);
+  p.w_br = su * sv;
+  p.base = v_i * cols + u_i - 1;
+  p.ok = true;
+  return p;
+}
+
+HSO_DEV Proj project_feature(const LevelCtx& L, const Se3& T, const FeatRaw& raw, int border)
+{
+  return project_feature_nl(L.cam_lds, T, raw.bx, raw.by, raw.bz, raw.dist, raw.vis, border, L.cols, L.rows, L.scale);
+}
+
+// ------------------------------------------------------- workgroup reductions
+
+struct Acc {
+  float H[32];   // [0..27] used; fp32 like the reference's Accumulator7 (MatrixAccumulator.h:33)
+  double d[16];  // [0..9] used: b[0..6] (fp64 like CoarseTracker.cpp:520), E, n_terms, n_saturated
+};               // sizes padded to powers of two for the halving exchange (the pads stay 0)
+
+// Sum N (a power of two <= 64) per-lane values over the 64 lanes of a wave by recursive
+// halving: at each step (lane distance 32, 16, ...) a lane hands the half of its values it
+// is not responsible for to its partner and adds the partner's contribution to the half it
+// keeps, so N values cost ~N exchanges instead of 6N.  Afterwards the lane whose `slot` is
+// k (< N) holds the total of value k.  Fixed order => deterministic floating point.
+template <typename T, int N, int M>
+struct Halve {
+  static HSO_DEV void run(T (&v)[N], int lane, int& slot, T& out)
+  {
+    static_assert((N & (N - 1)) == 0 && N >= 2, "N must be a power of two");
+    constexpr int HALF = N / 2;
+    const bool up = (lane & M) != 0;
+    T keep[HALF];
+#pragma unroll
+    for (int i = 0; i < HALF; i++) {
+      const T lo = v[i];
+      const T hi = v[HALF + i];
+      const T send = up ? lo : hi;
+      T recv;
+      if constexpr (sizeof(T) == 8) recv = shfl_xor_d(send, M);
+      else recv = __shfl_xor(send, M);
+      keep[i] = (up ? hi : lo) + recv;
+    }
+    if (up) slot += HALF;
+    if constexpr (M == 1) {
+      out = keep[0];  // HALF == 1 here
+    } else {
+      Halve<T, HALF, M / 2>::run(keep, lane, slot, out);
+    }
+  }
+};
+template <typename T, int M>
+struct Halve<T, 1, M> {
+  static HSO_DEV void run(T (&v)[1], int lane, int& slot, T& out)
+  {
+    // a single value left before the lane distance reached 1: finish with plain butterflies
+    T x = v[0];
+#pragma unroll
+    for (int m = M; m >= 1; m >>= 1) {
+      if constexpr (sizeof(T) == 8) x += shfl_xor_d(x, m);
+      else x += __shfl_xor(x, m);
+    }
+    // every lane of the remaining group holds the total; only the group's first lane reports it
+    if ((lane & (2 * M - 1)) != 0) slot = 1 << 20;
+    out = x;
+  }
+};
+
+HSO_DEV int block_sum_int(Shared& s, int v)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  __syncthreads();
+  if (lane == 0) s.wave_cnt[wave] = v;
+  __syncthreads();
+  int tot = 0;
+  for (int w = 0; w < TRK_WAVES; w++) tot += s.wave_cnt[w];
+  return tot;
+}
+
+// ------------------------------------------------------------- level set-up
+
+// copy one level image (+ the zero row below it) into LDS; false if it does not fit.
+// gfx950 LDS-DMA: each wavefront moves 1 KiB per instruction straight from memory into LDS
+// (global_load_lds_dwordx4: per-lane source address, destination = uniform base + lane * 16),
+// no staging registers and no ds_write pass; the loads of all chunks are in flight together
+// and the barrier that follows drains them.
+HSO_DEV bool stage_image(const LevelCtx& L, const uint8_t* src, uint32_t* lds_img)
+{
+  const int bytes = L.cols * L.rows;
+  const int padded = (bytes + L.cols + 32 + 15) & ~15;
+  if (padded > L.C->lds_img_cap) return false;
+  typedef __attribute__((address_space(3))) uint8_t* LdsBytes;
+  typedef const __attribute__((address_space(1))) uint8_t* GlbBytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave * 1024; c < padded; c += TRK_WAVES * 1024) {
+    const int off = c + lane * 16;
+    if (off < padded) __builtin_amdgcn_global_load_lds((GlbBytes)(src + off), (LdsBytes)lds_img + c, 16, 0, 0);
+  }
+  return true;
+}
+
+template <typename Ptr>
+HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
+{
+  const TrackJobDev& J = *L.job;
+  const int n = J.n, ns = J.n_stride, nm = L.C->n_max;
+  const int PA = s.PA, border = s.pad + 1;
+  const bool ic = L.C->inverse != 0;
+  const int stride = L.cols;
+  // one thread per feature (S lanes share a feature when the table is small): position and
+  // bilinear weights once, then the pattern pixels
+  const int S = s.S, G = TRK_THREADS / S;
+  const int sub = (int)threadIdx.x % S, grp = (int)threadIdx.x / S;
+  for (int f = grp; f < n; f += G) {
+    const float u_ref = (float)(J.feats[0 * ns + f] * (double)L.scale);
+    const float v_ref = (float)(J.feats[1 * ns + f] * (double)L.scale);
+    const int u_i = (int)floorf(u_ref), v_i = (int)floorf(v_ref);
+    const double dist = J.feats[5 * ns + f];
+    const bool vis = dist >= 0 && !(u_i - border < 0 || v_i - border < 0 || u_i + border >= L.cols || v_i + border >= L.rows);
+    if (sub == 0) L.sc.visible[f] = vis ? 1 : 0;
+    if (!vis) continue;
+    const float su = u_ref - (float)u_i, sv = v_ref - (float)v_i;
+    const float w_tl = (float)((1.0 - su) * (1.0 - sv));
+    const float w_tr = (float)(su * (1.0 - sv));
+    const float w_bl = (float)((1.0 - su) * sv);
+    const float w_br = (float)(1.0 - ((w_tl + w_tr) + w_bl));
+    const int base = v_i * stride + u_i - 1;
+    for (int pidx = sub; pidx < PA; pidx += S) {
+      const int a0 = base + s.poff[pidx];
+      const uint32_t o = (uint32_t)(pidx * nm + f);
+      const uint32_t r1 = fetch4(ref32, a0), r2 = fetch4(ref32, a0 + stride);
+      L.sc.ref_patch[o] = ((w_tl * b1f(r1) + w_tr * b2f(r1)) + w_bl * b1f(r2)) + w_br * b2f(r2);
+      if (ic) {
+        const uint32_t r0 = fetch4(ref32, a0 - stride), r3 = fetch4(ref32, a0 + 2 * stride);
+        const float dx = 0.5f * ((((w_tl * b2f(r1) + w_tr * b3f(r1)) + w_bl * b2f(r2)) + w_br * b3f(r2))
+                               - (((w_tl * b0f(r1) + w_tr * b1f(r1)) + w_bl * b0f(r2)) + w_br * b1f(r2)));
+        const float dy = 0.5f * ((((w_tl * b1f(r2) + w_tr * b2f(r2)) + w_bl * b1f(r3)) + w_br * b2f(r3))
+                               - (((w_tl * b1f(r0) + w_tr * b2f(r0)) + w_bl * b1f(r1)) + w_br * b2f(r1)));
+        L.sc.ref_dx[o] = dx;
+        L.sc.ref_dy[o] = dy;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------ robust thresholds
+
+// pass 1 of selectRobustFunctionLevel (CoarseTracker.cpp:547-606): |residual| of every
+// in-bounds term, stored as float bit patterns (KEY_INVALID elsewhere).  Returns errors.size().
+HSO_DEV void sel_count_a(Shared& s, uint32_t kk);
+
+template <bool S1, typename Ptr, typename KP>
+HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a, KP kdst)
+{
+  const int n = L.job->n, nm = L.C->n_max;
+  const int PA = s.PA, border = s.pad + 1, S = S1 ? 1 : s.S;
+  const int G = TRK_THREADS / S;
+  const int sub = S1 ? 0 : (int)(threadIdx.x % S);
+  const int stride = L.cols;
+  int cnt = 0;
+  const int grp = S1 ? (int)threadIdx.x : (int)(threadIdx.x / S);
+  FeatRaw nxt = load_feature(L, grp);
+  for (int base = 0; base < n; base += G) {
+    const int f = base + grp;
+    const FeatRaw raw = nxt;
+    nxt = load_feature(L, f + G);
+    if (f >= n) continue;
+    const Proj p = project_feature(L, T, raw, border);
+    for (int pidx = sub; pidx < PA; pidx += S) {
+      uint32_t key = KEY_INVALID;
+      if (p.ok) {
+        const int a0 = p.base + s.poff[pidx];
+        const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
+        const float cur = ((p.w_tl * b1f(r1) + p.w_tr * b2f(r1)) + p.w_bl * b1f(r2)) + p.w_br * b2f(r2);
+        const float res = cur - a * L.sc.ref_patch[(size_t)pidx * nm + f];
+        key = __float_as_uint(fabsf(res));
+        sel_count_a(s, key);  // round A of the median select, fused (select_robust zeroed the bins)
+        cnt++;
+      }
+      kdst[pidx * n + f] = key;
+    }
+  }
+  return block_sum_int(s, cnt);
+}
+
+// ---- exact order statistics -------------------------------------------------------------
+// Keys are bit patterns of non-negative floats (bit 31 clear), so unsigned order = float order;
+// KEY_INVALID (bit 31 set) marks slots without a term.  The k-th smallest is found MSB-first in
+// three histogram rounds over the digits [30:23] (the exponent), [22:12] and [11:0]; after each
+// round every wave locates the bin that holds the rank by itself (scan_find), so (prefix, rank)
+// live in registers and are identical in all threads by construction.  The value returned is
+// the element nth_element would leave at position k, whatever the input order.
+//
+// Residual magnitudes of a level crowd into a handful of octaves, so a plain histogram of the
+// leading digit would serialise on same-address LDS atomics: round A therefore keeps SEL_REP
+// replicas of every exponent bin (lane & 15 picks one) and folds them afterwards.  Rounds B and
+// C see mantissa bits, which are spread evenly.
+#define SEL_WORDS 4096
+#define SEL_REP 16
+
+template <int NB>
+HSO_DEV void scan_find(const unsigned* hist, unsigned& rank, unsigned& bin, unsigned& count)
+{
+  constexpr int SEG = NB / 64;
+  int lane = threadIdx.x & 63;
+  // opaque to the optimiser: without this the 8 inlined copies share hoisted LDS addresses, which
+  // then get spilled and are re-read from scratch inside the loops below
+  asm volatile("" : "+v"(lane));
+  unsigned local = 0;
+  for (int j = 0; j < SEG; j++) local += hist[lane * SEG + ((j + lane) & (SEG - 1))];  // rotated start: spreads the banks
+  unsigned incl = local;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  const unsigned excl = incl - local;
+  const unsigned long long m = __ballot(rank >= excl && rank < incl);
+  const int seg = (m != 0ull) ? (__ffsll((long long)m) - 1) : 0;
+  const unsigned r2 = rank - __shfl(excl, seg);
+  const unsigned c = (lane < SEG) ? hist[seg * SEG + lane] : 0u;
+  unsigned incl2 = c;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(incl2, d);
+    if (lane >= d) incl2 += o;
+  }
+  const unsigned long long m2 = __ballot(lane < SEG && r2 >= incl2 - c && r2 < incl2);
+  const int bl = (m2 != 0ull) ? (__ffsll((long long)m2) - 1) : 0;
+  bin = (unsigned)(seg * SEG + bl);
+  rank = r2 - __shfl(incl2 - c, bl);
+  count = __shfl(c, bl);
+}
+
+HSO_DEV void sel_zero(Shared& s, int words)
+{
+  __syncthreads();
+  for (int i = threadIdx.x; i < words; i += TRK_THREADS) s.sel[i] = 0;
+  __syncthreads();
+}
+
+HSO_DEV void sel_count_a(Shared& s, uint32_t kk)
+{
+  if ((int)kk >= 0) atomicAdd(&s.sel[(kk >> 23) * SEL_REP + (threadIdx.x & (SEL_REP - 1))], 1u);
+}
+
+// keys.each(f) calls f(key) for every key this thread owns.  round_a_done: the caller already
+// histogrammed the exponents into the replicated bins (fused into the pass that produced the keys).
+template <typename Keys>
+HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_a_done)
+{
+#ifdef HSO_SEL_PROBE
+  unsigned long long kt = __builtin_readcyclecounter();
+#define KSEL_T(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[i] += n_ - kt; kt = n_; } } while (0)
+#else
+#define KSEL_T(i) do { } while (0)
+#endif
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // see scan_find
+  unsigned rank = k, bin = 0, count = 0;
+  if (!round_a_done) {
+    sel_zero(s, 256 * SEL_REP);
+    keys.each([&](uint32_t kk) { sel_count_a(s, kk); });
+  }
+  __syncthreads();
+  KSEL_T(0);
+  unsigned sum = 0;
+  if (tid < 256)
+    for (int j = 0; j < SEL_REP; j++) sum += s.sel[tid * SEL_REP + ((j + tid) & (SEL_REP - 1))];
+  __syncthreads();
+  if (tid < 256) s.sel[tid] = sum;
+  __syncthreads();
+  scan_find<256>(s.sel, rank, bin, count);
+  uint32_t prefix = bin << 23;
+  sel_zero(s, 2048);
+  KSEL_T(1);
+  keys.each([&](uint32_t kk) { if ((kk & 0xFF800000u) == prefix) atomicAdd(&s.sel[(kk >> 12) & 2047u], 1u); });
+  __syncthreads();
+  KSEL_T(2);
+  scan_find<2048>(s.sel, rank, bin, count);
+  prefix |= bin << 12;
+  sel_zero(s, 4096);
+  KSEL_T(3);
+  keys.each([&](uint32_t kk) { if ((kk & 0xFFFFF000u) == prefix) atomicAdd(&s.sel[kk & 4095u], 1u); });
+  __syncthreads();
+  KSEL_T(2);
+  scan_find<4096>(s.sel, rank, bin, count);
+  prefix |= bin;
+  __syncthreads();
+  KSEL_T(4);
+  return prefix;
+}
+
+// keys in memory or LDS (the |residual| array of select_collect), optionally transformed on the
+// fly; read as 16-byte vectors, four per thread in flight, so a pass is a handful of wide loads
+// instead of dozens of dependent dword loads
+typedef __attribute__((address_space(3))) uint32_t* LdsKeys;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename KP> struct Vec4Ptr;
+template <> struct Vec4Ptr<uint32_t*> { typedef const u32x4* type; };
+template <> struct Vec4Ptr<LdsKeys> { typedef const __attribute__((address_space(3))) u32x4* type; };
+
+template <typename KP, typename Xf>
+struct MemKeys {
+  KP keys;
+  int n_slots;
+  Xf xf;
+  template <typename F>
+  HSO_DEV void each(F f) const
+  {
+    typedef typename Vec4Ptr<KP>::type V4;
+    const V4 kv = (V4)keys;
+    const int nvec = n_slots >> 2;
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += TRK_THREADS * 4) {
+      u32x4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int v = v0 + u * TRK_THREADS;
+        if (v < nvec) q[u] = kv[v];
+        else q[u] = (u32x4)(KEY_INVALID);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { f(xf(q[u].x)); f(xf(q[u].y)); f(xf(q[u].z)); f(xf(q[u].w)); }
+    }
+    if ((int)threadIdx.x < (n_slots & 3)) f(xf(keys[(nvec << 2) + (int)threadIdx.x]));
+  }
+};
+template <typename KP, typename Xf>
+HSO_DEV MemKeys<KP, Xf> mem_keys(KP keys, int n_slots, Xf xf) { return MemKeys<KP, Xf>{ keys, n_slots, xf }; }
+
+HSO_DEV void set_thresholds(Shared& s, float med, uint32_t mad_bits)
+{
+  if (threadIdx.x == 0) {
+    const float standard_deviation = (float)(1.4826 * (double)__uint_as_float(mad_bits));
+    const float huber = med + standard_deviation;
+    float outlier = 3 * huber;
+    if (outlier < 10) outlier = 10;
+    s.huber = huber;
+    s.outlier = outlier;
+  }
+  __syncthreads();
+}
+
+// selectRobustFunctionLevel, CoarseTracker.cpp:530-644
+template <typename KP>
+HSO_DEV void select_robust_k(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a, KP keys)
+{
+#ifdef HSO_SEL_PROBE
+  unsigned long long sel_t = __builtin_readcyclecounter();
+#define SELR_T(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[k] += n_ - sel_t; sel_t = n_; } } while (0)
+#else
+#define SELR_T(k) do { } while (0)
+#endif
+  sel_zero(s, 256 * SEL_REP);
+  int n_err;
+  if (s.S == 1) {
+    n_err = s.use_lds ? select_collect<true, LdsPtr>(s, L, lds_img, T, a, keys) : select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a, keys);
+  } else {
+    n_err = s.use_lds ? select_collect<false, LdsPtr>(s, L, lds_img, T, a, keys) : select_collect<false, GlbPtr>(s, L, L.cur_glb, T, a, keys);
+  }
+  const int n_slots = L.job->n * s.PA;
+  if (threadIdx.x == 0) s.n_select = n_err;
+  SELR_T(5);
+  if (n_err < 30) {
+    if (threadIdx.x == 0) { s.huber = 5.2f; s.outlier = 100.f; }
+    __syncthreads();
+    return;
+  }
+  const uint32_t med_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(keys, n_slots, [](uint32_t k) { return k; }), true);
+  const float med = __uint_as_float(med_bits);
+  SELR_T(6);
+  const uint32_t mad_bits = select_kth(s, (unsigned)(n_err / 2), mem_keys(keys, n_slots, [med](uint32_t k) {
+    return (k == KEY_INVALID) ? KEY_INVALID : __float_as_uint(fabsf(__uint_as_float(k) - med));
+  }), false);
+  set_thresholds(s, med, mad_bits);
+  SELR_T(7);
+}
+
+// The |residual| keys of a level live in LDS above the staged image when they fit (levels 4..2 of
+// a 2000-feature VGA frame: <= 104 KB), else in the workgroup's scratch in memory.
+HSO_DEV void select_robust(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
+{
+  if (s.keys_lds_off > 0) {
+    LdsKeys kl = (LdsKeys)lds_img + (s.keys_lds_off >> 2);
+    select_robust_k<LdsKeys>(s, L, lds_img, T, a, kl);
+  } else {
+    select_robust_k<uint32_t*>(s, L, lds_img, T, a, L.sc.keys);
+  }
+}
+
+// ------------------------------------------ residuals + normal equations
+
+// Weighted moments of one feature's pattern pixels (this lane's share of them).
+struct Moments {
+  float ee, ex, ey, xx, xy, yy, re, rx, ry;  // sum w*{e e, e dx, e dy, dx dx, dx dy, dy dy, r e, r dx, r dy}
+  float E;
+  int nt, nsat;
+};
+
+// One term's raw inputs, fetched ahead of the arithmetic that consumes them.
+struct TermIn {
+  uint32_t r0, r1, r2, r3;  // rows y-1 .. y+2, bytes x-1 .. x+2
+  float iref, dxr, dyr;
+};
+
+template <bool IC, typename Ptr>
+HSO_DEV TermIn load_term(const LevelCtx& L, const Shared& s, Ptr img, const float* rp, int base, int pidx, int nm, int f)
+{
+  TermIn t;
+  const int a0 = base + s.poff[pidx];
+  t.r1 = fetch4(img, a0);
+  t.r2 = fetch4(img, a0 + L.cols);
+  if (!IC) {
+    t.r0 = fetch4(img, a0 - L.cols);
+    t.r3 = fetch4(img, a0 + 2 * L.cols);
+    t.dxr = t.dyr = 0;
+  } else {
+    t.r0 = t.r3 = 0;
+    t.dxr = L.sc.ref_dx[(uint32_t)(pidx * nm + f)];
+    t.dyr = L.sc.ref_dy[(uint32_t)(pidx * nm + f)];
+  }
+  t.iref = rp[(uint32_t)(pidx * nm + f)];  // 32-bit offset from a uniform base: saddr + voffset addressing
+  return t;
+}
+
+// The per-term arithmetic of computeResiduals (CoarseTracker.cpp:328-410) for the pattern
+// pixels sub, sub+S, ... of feature f.
+template <bool IC, typename Ptr>
+HSO_DEV Moments feature_terms(const Shared& s, const LevelCtx& L, Ptr img, const Proj& p, int f, float a,
+                              int sub, int S, int PA, bool top, float huber, float outlier, float max_energy)
+{
+  Moments m;
+  m.ee = m.ex = m.ey = m.xx = m.xy = m.yy = m.re = m.rx = m.ry = 0; m.E = 0; m.nt = 0; m.nsat = 0;
+  if (!p.ok) return m;
+  const int nm = L.C->n_max;
+  const float* rp = L.sc.ref_patch;  // uniform base
+  int pidx = sub;
+  if (pidx >= PA) return m;
+  TermIn nx = load_term<IC>(L, s, img, rp, p.base, pidx, nm, f);
+  for (; pidx < PA; pidx += S) {
+    const TermIn t = nx;
+    if (pidx + S < PA) nx = load_term<IC>(L, s, img, rp, p.base, pidx + S, nm, f);  // next term in flight
+    const float p11 = b1f(t.r1), p12 = b2f(t.r1), p21 = b1f(t.r2), p22 = b2f(t.r2);
+    // decision arithmetic: exactly the reference's expression order (:339-348)
+    const float cur = ((p.w_tl * p11 + p.w_tr * p12) + p.w_bl * p21) + p.w_br * p22;
+    const float res = cur - a * t.iref;
+    const float ares = fabsf(res);
+    // The Huber weight only enters tolerance-compared sums (E, H, b), never a decision: one
+    // v_rcp_f32 (1 ulp) and a multiply instead of the ten-instruction IEEE division
+    const float hw = ares < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ares);
+    // cutoff_error = m_outlier_thresh is a float value, so the reference's double compare (:350)
+    // equals this float compare
+    const bool sat = (ares > outlier) && !top;
+    const float e_term = top ? (hw * res) * res : ((hw * res) * res) * (2 - hw);
+    m.E += sat ? max_energy : e_term;
+    m.nt++;
+    m.nsat += sat ? 1 : 0;
+    // image gradient; forward mode: twice the central difference (the 1/2 is folded into A, B)
+    float dx, dy;
+    if (!IC) {
+      dx = fmaf(p.w_tl, p12 - b0f(t.r1), fmaf(p.w_tr, b3f(t.r1) - p11, fmaf(p.w_bl, p22 - b0f(t.r2), p.w_br * (b3f(t.r2) - p21))));
+      dy = fmaf(p.w_tl, p21 - b1f(t.r0), fmaf(p.w_tr, p22 - b2f(t.r0), fmaf(p.w_bl, b1f(t.r3) - p11, p.w_br * (b2f(t.r3) - p12))));
+    } else {
+      dx = t.dxr; dy = t.dyr;
+    }
+    // saturated terms contribute no Jacobian row (:350-355): weight 0
+    const float w = sat ? 0.0f : hw;
+    const float e = -t.iref;
+    const float we = w * e, wx = w * dx, wy = w * dy, wr = w * res;
+    m.ee = fmaf(we, e, m.ee); m.ex = fmaf(we, dx, m.ex); m.ey = fmaf(we, dy, m.ey);
+    m.xx = fmaf(wx, dx, m.xx); m.xy = fmaf(wx, dy, m.xy); m.yy = fmaf(wy, dy, m.yy);
+    m.re = fmaf(wr, e, m.re); m.rx = fmaf(wr, dx, m.rx); m.ry = fmaf(wr, dy, m.ry);
+  }
+  return m;
+}
+
+// The same arithmetic (forward mode, image in LDS) with the pattern known at compile time
+// (PI = index into the static pattern tables), fully unrolled: tap offsets oy*stride+ox and
+// patch-cache offsets k*n_max are scalar expressions, there is no per-term table read and no
+// loop-carried prefetch record — about a quarter fewer instructions per term in a loop that is
+// VALU-issue-bound.  Deliberately NOT inlined: inside the megakernel the unrolled body competes
+// with the state of every other phase for the 168 VGPRs and spills; as a separate function it gets
+// its own register allocation, at the price of one call per feature.
+typedef const __attribute__((address_space(1))) float* GlbF32;
+template <int PI>
+__device__ __forceinline__ Moments feature_terms_static(LdsPtr img, GlbF32 ref_patch, int base, float w_tl, float w_tr, float w_bl,
+                                                      float w_br, uint32_t fb, uint32_t nb, int stride, float a, float huber,
+                                                      float outlier, float max_energy, int top)
+{
+  constexpr int PA = h_pattern_num[PI];
+  Moments m;
+  m.ee = m.ex = m.ey = m.xx = m.xy = m.yy = m.re = m.rx = m.ry = 0; m.E = 0; m.nt = PA; m.nsat = 0;
+  stride = __builtin_amdgcn_readfirstlane(stride);
+  nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+  typedef const __attribute__((address_space(1))) char* GlbBytes;
+  const GlbBytes rpb = (GlbBytes)ref_patch;
+  constexpr int PF = 4;  // reference intensities requested PF terms ahead of their use
+  float ipf[PF];
+#pragma unroll
+  for (int k = 0; k < PF && k < PA; k++) ipf[k] = *(GlbF32)(rpb + (fb + (uint32_t)k * nb));
+#pragma unroll
+  for (int k = 0; k < PA; k++) {
+    const int ox = h_pattern[PI][k][0], oy = h_pattern[PI][k][1];
+    const int a0 = base + (oy * stride + ox);
+    const uint32_t r1 = fetch4(img, a0), r2 = fetch4(img, a0 + stride);
+    const uint32_t r0 = fetch4(img, a0 - stride), r3 = fetch4(img, a0 + 2 * stride);
+    const float iref = ipf[k % PF];
+    if (k + PF < PA) ipf[k % PF] = *(GlbF32)(rpb + (fb + (uint32_t)(k + PF) * nb));
+    const float p11 = b1f(r1), p12 = b2f(r1), p21 = b1f(r2), p22 = b2f(r2);
+    const float cur = ((w_tl * p11 + w_tr * p12) + w_bl * p21) + w_br * p22;
+    const float res = cur - a * iref;
+    const float ares = fabsf(res);
+    const float hw = ares < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ares);
+    const bool sat = (ares > outlier) && !top;
+    const float e_term = top ? (hw * res) * res : ((hw * res) * res) * (2 - hw);
+    m.E += sat ? max_energy : e_term;
+    m.nsat += sat ? 1 : 0;
+    const float dx = fmaf(w_tl, p12 - b0f(r1), fmaf(w_tr, b3f(r1) - p11, fmaf(w_bl, p22 - b0f(r2), w_br * (b3f(r2) - p21))));
+    const float dy = fmaf(w_tl, p21 - b1f(r0), fmaf(w_tr, p22 - b2f(r0), fmaf(w_bl, b1f(r3) - p11, w_br * (b2f(r3) - p12))));
+    const float w = sat ? 0.0f : hw;
+    const float e = -iref;
+    const float we = w * e, wx = w * dx, wy = w * dy, wr = w * res;
+    m.ee = fmaf(we, e, m.ee); m.ex = fmaf(we, dx, m.ex); m.ey = fmaf(we, dy, m.ey);
+    m.xx = fmaf(wx, dx, m.xx); m.xy = fmaf(wx, dy, m.xy); m.yy = fmaf(wy, dy, m.yy);
+    m.re = fmaf(wr, e, m.re); m.rx = fmaf(wr, dx, m.rx); m.ry = fmaf(wr, dy, m.ry);
+  }
+  return m;
+}
+
+// Expand one feature's moments into the 28 + 7 normal-equation entries (computeGS, :499-525).
+// A = fx_l * J.row(0), B = fy_l * J.row(1) (frame.h:192-212); in inverse-compositional mode the
+// Jacobian is taken at the reference point and scaled by the exposure ratio
+// (m_jacobian_cache_true = exposure_rat * m_jacobian_cache_raw, CoarseTracker.cpp:245).
+template <bool IC>
+HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Moments& m, int f, float a)
+{
+  double J0[6], J1[6];
+  double sA, sB;
+  if (!IC) {
+    jacobian_xyz2uv(p.x, p.y, p.z, J0, J1);
+    sA = 0.5 * L.fxl; sB = 0.5 * L.fyl;  // dx, dy are twice the central differences
+  } else {
+    const int ns = L.job->n_stride;
+    const double dist = L.job->feats[5 * ns + f];
+    jacobian_xyz2uv(L.job->feats[2 * ns + f] * dist, L.job->feats[3 * ns + f] * dist,
+                    L.job->feats[4 * ns + f] * dist, J0, J1);
+    sA = L.fxl * (double)a; sB = L.fyl * (double)a;
+  }
+  double A[6], B[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { A[k] = J0[k] * sA; B[k] = J1[k] * sB; }
+  const double d_ex = m.ex, d_ey = m.ey, d_xx = m.xx, d_xy = m.xy, d_yy = m.yy;
+  const double d_rx = m.rx, d_ry = m.ry;
+  acc.H[0] += m.ee;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc.H[1 + k] += (float)fma(d_ex, A[k], d_ey * B[k]);
+  int idx = 7;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double xa = fma(d_xx, A[k], d_xy * B[k]);  // coefficient of A[l]
+    const double xb = fma(d_xy, A[k], d_yy * B[k]);  // coefficient of B[l]
+#pragma unroll
+    for (int l = k; l < 6; l++) { acc.H[idx] += (float)fma(xa, A[l], xb * B[l]); idx++; }
+  }
+  acc.d[0] -= (double)m.re;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc.d[1 + k] -= fma(d_rx, A[k], d_ry * B[k]);
+  acc.d[7] += (double)m.E;
+  acc.d[8] += (double)m.nt;
+  acc.d[9] += (double)m.nsat;
+}
+
+// computeResiduals (CoarseTracker.cpp:242-414) fused with computeGS (:499-525).
+// Leaves the block-reduced sums in s.red: [0..27] H upper triangle (row-major),
+// [28..34] b, [35] E, [36] m_total_terms, [37] m_saturated_terms.
+//
+// Each thread owns FPT features per round (lane groups of S threads share one feature when
+// the table is small).  The 38 per-feature contributions live in registers only between
+// the expansion and the wave-wide halving exchange that follows it, so the pixel loop —
+// where the time goes — runs without the accumulators' register footprint; what persists
+// across rounds is the single float and the single double each lane is responsible for.
+#ifndef TRK_FPT
+#define TRK_FPT 2  // features per thread and round: halves the number of wave exchanges per evaluation
+#endif
+#define HSO_PHASE __device__ __forceinline__
+template <bool IC, bool S1, typename Ptr, int PI = -1>
+HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
+{
+  const int n = L.job->n;
+  const int PA = s.PA, border = s.pad + 1, S = S1 ? 1 : s.S;
+  const int G = TRK_THREADS / S;
+  const int sub = S1 ? 0 : (int)(threadIdx.x % S);
+  const int grp = S1 ? (int)threadIdx.x : (int)(threadIdx.x / S);
+  const bool top = (L.level == L.C->max_level);
+  const float huber = s.huber;
+  const float outlier = s.outlier;
+  const float max_energy = (float)((double)(2 * huber) * (double)outlier - (double)(huber * huber));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+#if defined(HSO_PHASE_TIMERS) && !defined(HSO_SEL_PROBE)
+#define DBG_T(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[k] += n_ - dbg_t; dbg_t = n_; } } while (0)
+  unsigned long long dbg_t = __builtin_readcyclecounter();
+#else
+#define DBG_T(k) do { } while (0)
+#endif
+  float totH = 0;
+  double totD = 0;
+  int slotH = 0, slotD = 0;
+  // Which features this thread owns.  With one thread per feature the split between the two
+  // wavefronts of a SIMD is deliberately uneven: the older wavefront (waves 0..3) wins issue
+  // arbitration and would finish ~25 % early, leaving the younger one to run alone without latency
+  // hiding; giving the older half TRK_OLD_SHARE/16 of the features lets both finish together.
+  // The mapping is static, so results stay bit-reproducible.
+  int gbase = 0, gn = n, gthreads = G, gt = grp;
+  if (S1) {
+    const int n_old = (int)(((long long)n * TRK_OLD_SHARE + 15) / 16);
+    const bool old = threadIdx.x < TRK_THREADS / 2;
+    gthreads = TRK_THREADS / 2;
+    gbase = old ? 0 : n_old;
+    gn = old ? n_old : n - n_old;
+    gt = old ? (int)threadIdx.x : (int)threadIdx.x - TRK_THREADS / 2;
+  }
+  auto fidx = [&](int k) { const int i = gt + k * gthreads; return i < gn ? gbase + i : n; };  // n = "none"
+  const int n_rounds = max(1, (((gn + gthreads - 1) / gthreads) + TRK_FPT - 1) / TRK_FPT);  // >= 1: the exchange assigns the slots
+  FeatRaw nxt = load_feature(L, fidx(0));
+  for (int r = 0; r < n_rounds; r++) {
+    Proj p[TRK_FPT];
+    Moments m[TRK_FPT];
+    int ff[TRK_FPT];
+#pragma unroll
+    for (int q = 0; q < TRK_FPT; q++) {
+      const int f = fidx(r * TRK_FPT + q);
+      ff[q] = f;
+      const FeatRaw raw = nxt;
+      nxt = load_feature(L, fidx(r * TRK_FPT + q + 1));  // next feature's record in flight during this pixel loop
+      p[q] = project_feature(L, T, raw, border);
+      DBG_T(0);
+      if constexpr (PI >= 0) {
+        if (p[q].ok)
+          m[q] = feature_terms_static<PI>(img, (GlbF32)L.sc.ref_patch, p[q].base, p[q].w_tl, p[q].w_tr, p[q].w_bl, p[q].w_br,
+                                          (uint32_t)f * 4u, (uint32_t)L.C->n_max * 4u, L.cols, a, huber, outlier, max_energy, top ? 1 : 0);
+        else
+          m[q] = Moments{};
+      } else {
+        m[q] = feature_terms<IC>(s, L, img, p[q], f, a, sub, S, PA, top, huber, outlier, max_energy);
+      }
+      DBG_T(1);
+      if (!S1) {
+        // combine the S lanes of the feature group (power of two <= 64, never straddles a wave)
+        for (int k = S >> 1; k > 0; k >>= 1) {
+          m[q].ee += __shfl_xor(m[q].ee, k); m[q].ex += __shfl_xor(m[q].ex, k); m[q].ey += __shfl_xor(m[q].ey, k);
+          m[q].xx += __shfl_xor(m[q].xx, k); m[q].xy += __shfl_xor(m[q].xy, k); m[q].yy += __shfl_xor(m[q].yy, k);
+          m[q].re += __shfl_xor(m[q].re, k); m[q].rx += __shfl_xor(m[q].rx, k); m[q].ry += __shfl_xor(m[q].ry, k);
+          m[q].E += __shfl_xor(m[q].E, k); m[q].nt += __shfl_xor(m[q].nt, k); m[q].nsat += __shfl_xor(m[q].nsat, k);
+        }
+      }
+    }
+    Acc acc;
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc.H[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc.d[i] = 0;
+#pragma unroll
+    for (int q = 0; q < TRK_FPT; q++)
+      if (p[q].ok && sub == 0) expand_feature<IC>(acc, L, p[q], m[q], ff[q], a);
+    DBG_T(2);
+    float th; double td;
+    slotH = 0; slotD = 0;
+    Halve<float, 32, 32>::run(acc.H, lane, slotH, th);
+    Halve<double, 16, 32>::run(acc.d, lane, slotD, td);
+    totH += th;
+    totD += td;
+    DBG_T(3);
+  }
+  if (slotH < 28) s.wave_part[wave][slotH] = (double)totH;
+  if (slotD < 10) s.wave_part[wave][28 + slotD] = totD;
+  __syncthreads();
+  if (threadIdx.x < N_RED) {
+    double t = 0;
+    for (int w = 0; w < TRK_WAVES; w++) t += s.wave_part[w][threadIdx.x];
+    s.red[threadIdx.x] = t;
+  }
+  __syncthreads();
+  DBG_T(4);
+}
+
+template <bool IC>
+HSO_DEV void eval_dispatch(Shared& s, const LevelCtx& L, LdsPtr lds_img, const Se3& T, float a)
+{
+  if (s.S == 1) {
+    if (s.use_lds) {
+      if constexpr (!IC) {
+        switch (s.pi) {  // pattern-specialised pixel loops for the patterns levels 4..1 use
+          case 2: eval_terms<IC, true, LdsPtr, 2>(s, L, lds_img, T, a); return;
+          case 3: eval_terms<IC, true, LdsPtr, 3>(s, L, lds_img, T, a); return;
+          case 4: eval_terms<IC, true, LdsPtr, 4>(s, L, lds_img, T, a); return;
+          case 5: eval_terms<IC, true, LdsPtr, 5>(s, L, lds_img, T, a); return;
+          default: break;
+        }
+      }
+      eval_terms<IC, true, LdsPtr>(s, L, lds_img, T, a);
+    } else {
+      eval_terms<IC, true, GlbPtr>(s, L, L.cur_glb, T, a);
+    }
+  } else {
+    if (s.use_lds) eval_terms<IC, false, LdsPtr>(s, L, lds_img, T, a);
+    else eval_terms<IC, false, GlbPtr>(s, L, L.cur_glb, T, a);
+  }
+}
+
+// ----------------------------------------------------------- level + LM loop
+
+HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const TrackJobDev& job,
+                         const Scratch& sc, int level, uint32_t* lds_img)
+{
+  __syncthreads();
+  L.C = &C; L.job = &job; L.sc = sc; L.level = level;
+  L.cam_lds = (const __attribute__((address_space(3))) hso_camera*)&s.cam;
+  if (threadIdx.x == 0) s.cam = C.cam;  // visible after the barriers below, before any projection
+  const TrackLevel& V = C.lv[level];
+  L.cols = V.w; L.rows = V.h;
+  L.scale = 1.0f / (float)(1 << level);
+  L.fxl = C.cam.fx * (double)L.scale;
+  L.fyl = C.cam.fy * (double)L.scale;
+  L.ref_glb = reinterpret_cast<GlbPtr>(job.ref_base + V.off);
+  L.cur_glb = reinterpret_cast<GlbPtr>(job.cur_base + V.off);
+  if (threadIdx.x == 0) {
+    s.level = level; s.PA = V.pa; s.pad = V.pad; s.pi = V.pi;
+    int S = 1;
+    while (S < 16 && job.n * S * 2 <= TRK_THREADS) S *= 2;
+    s.S = S;
+  }
+  if (threadIdx.x < TRK_MAX_PA) s.poff[threadIdx.x] = V.poff[threadIdx.x];
+  // reference image through LDS for the patch precompute, then the current image stays resident
+  const bool ref_in_lds = stage_image(L, job.ref_base + V.off, lds_img);
+  __syncthreads();
+  if (ref_in_lds) precompute_reference<LdsPtr>(s, L, (LdsPtr)lds_img);
+  else precompute_reference<GlbPtr>(s, L, L.ref_glb);
+  __syncthreads();
+  const bool cur_in_lds = stage_image(L, job.cur_base + V.off, lds_img);
+  if (threadIdx.x == 0) {
+    s.use_lds = cur_in_lds ? 1 : 0;
+    const size_t padded = (size_t)((L.cols * L.rows + L.cols + 32 + 15) & ~15);
+    const size_t need = (size_t)job.n * (size_t)V.pa * 4;
+    s.keys_lds_off = (cur_in_lds && !C.keys_in_memory && padded + need <= (size_t)C.lds_img_cap) ? (int)padded : 0;
+  }
+  __syncthreads();
+}
+
+// Hl.ldlt().solve(b) of CoarseTracker.cpp:112-114 by one lane, entirely in registers: every
+// loop below has compile-time bounds, so after unrolling all array indices are static and the
+// 28 + 7 doubles never touch scratch or LDS (the earlier eight-lane v_readlane variant spent
+// 16k cycles per solve on readlane hazards and 28 fp64 divisions; this one ~4k).  Right-looking
+// LDL^T on the lower triangle with diagonal pivoting (largest |diagonal|, first on ties, like
+// Eigen::LDLT); one reciprocal per pivot; z = D^-1 y (zero where the pivot vanished, Eigen's
+// pseudo-inverse); back substitution; un-permute into s.step[0..6].
+HSO_DEV void swap_d(double& x, double& y) { const double t = x; x = y; y = t; }
+
+HSO_DEV void lane_ldlt7_solve(Shared& s, float lambda)
+{
+  double A[7][7], y[7], invd[7];
+  int perm[7];
+#pragma unroll
+  for (int r = 0; r < 7; r++) {
+#pragma unroll
+    for (int c = r; c < 7; c++) {
+      double v = s.H[7 * r - (r * (r - 1)) / 2 + (c - r)];
+      if (r == c) v *= (double)(1 + lambda);  // Hl(i,i) *= (1+lambda), CoarseTracker.cpp:113
+      A[c][r] = v;
+    }
+    y[r] = s.b[r];
+    perm[r] = r;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    double best = -1;
+    int idx = k;
+#pragma unroll
+    for (int q = k; q < 7; q++) {
+      const double d = fabs(A[q][q]);
+      if (d > best) { best = d; idx = q; }
+    }
+#pragma unroll
+    for (int q = k + 1; q < 7; q++) {
+      if (idx == q) {  // symmetric swap of indices k and q on the lower triangle
+#pragma unroll
+        for (int i = 0; i < k; i++) swap_d(A[k][i], A[q][i]);
+        swap_d(A[k][k], A[q][q]);
+#pragma unroll
+        for (int i = k + 1; i < q; i++) swap_d(A[i][k], A[q][i]);
+#pragma unroll
+        for (int i = q + 1; i < 7; i++) swap_d(A[i][k], A[i][q]);
+        swap_d(y[k], y[q]);
+        const int tp = perm[k]; perm[k] = perm[q]; perm[q] = tp;
+      }
+    }
+    const double akk = A[k][k];
+    const bool valid = fabs(akk) > 0;
+    const double inv = valid ? 1.0 / akk : 1.0;
+    invd[k] = inv;
+    double l[7];
+#pragma unroll
+    for (int i = k + 1; i < 7; i++) l[i] = A[i][k] * inv;
+#pragma unroll
+    for (int i = k + 1; i < 7; i++) {
+#pragma unroll
+      for (int j = k + 1; j <= i; j++) A[i][j] -= l[i] * A[j][k];
+      y[i] -= l[i] * y[k];
+    }
+#pragma unroll
+    for (int i = k + 1; i < 7; i++) A[i][k] = l[i];
+  }
+  const double tolerance = 1.0 / 1.7976931348623157e308;
+  double x[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) x[i] = (fabs(A[i][i]) > tolerance) ? y[i] * invd[i] : 0.0;
+#pragma unroll
+  for (int k = 6; k >= 1; k--) {
+#pragma unroll
+    for (int i = 0; i < k; i++) x[i] -= A[k][i] * x[k];
+  }
+#pragma unroll
+  for (int i = 0; i < 7; i++) s.step[perm[i]] = x[i];
+}
+
+// lane 0 after lane_ldlt7_solve: extrapolation, NaN guard, exposure and pose proposal
+// (CoarseTracker.cpp:120-133)
+HSO_DEV void lm_finish(Shared& s, bool inverse)
+{
+  double step[7];
+  const float lambda = s.lambda;
+  float extrap_fac = 1;
+  if ((double)lambda < 0.001) extrap_fac = (float)sqrt(sqrt(0.001 / (double)lambda));
+  double ssum = 0;
+#pragma unroll
+  for (int i = 0; i < 7; i++) { step[i] = s.step[i] * (double)extrap_fac; ssum += step[i]; }
+  if (!isfinite(ssum) || isnan(step[0])) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) step[i] = 0;
+  }
+  s.a_new = (float)((double)s.a + step[0]);
+  double neg[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) neg[i] = -step[1 + i];
+  const Se3 dT = se3_exp(neg);
+  const Se3 T = s.T;
+  s.Tn = inverse ? se3_mul(T, dT) : se3_mul(dT, T);
+  double nrm = 0;
+#pragma unroll
+  for (int i = 0; i < 7; i++) nrm += step[i] * step[i];
+  s.step_norm = nrm;  // squared; compared with (1e-4)^2 below — no square root on the serial lane
+}
+
+#ifdef HSO_PHASE_TIMERS
+#ifndef HSO_PHASE_TIMERS_BASE
+#define HSO_PHASE_TIMERS_BASE 0  /* 3: report dbg[3..7] = exchange, combine, select collect / median / MAD */
+#endif
+#define PH_START() unsigned long long ph_t = __builtin_readcyclecounter(); const unsigned long long ph_job = ph_t
+#define PH_ADD(k) do { if (threadIdx.x == 0) { const unsigned long long ph_n = __builtin_readcyclecounter(); \
+                         out->phase_cycles[k] += ph_n - ph_t; ph_t = ph_n; } } while (0)
+#define PH_JOB() do { if (threadIdx.x == 0) { out->phase_cycles[4] = __builtin_readcyclecounter() - ph_job; for (int k_ = 0; k_ < 5; k_++) out->phase_cycles[5 + k_] = s.dbg[k_ + HSO_PHASE_TIMERS_BASE]; } } while (0)
+#else
+#define PH_START() do { } while (0)
+#define PH_ADD(k) do { } while (0)
+#define PH_JOB() do { } while (0)
+#endif
+
+HSO_DEV void publish_result(Shared& s, hso_track_result* gout)
+{
+  __syncthreads();
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&s.res);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(gout);
+  for (int i = threadIdx.x; i < (int)(sizeof(hso_track_result) / 4); i += TRK_THREADS) dst[i] = src[i];
+}
+
+template <bool IC>
+HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, const Scratch& sc,
+                       uint32_t* lds_img, hso_track_result* gout)
+{
+  const int tid = threadIdx.x;
+  hso_track_result* const out = &s.res;  // bookkeeping stays in LDS; one coalesced copy at the end
+  if (C.resume) {
+    // an earlier launch worked through the levels above: its record (pose, exposure, per-level bookkeeping) is the start
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(gout);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out);
+    for (int i = tid; i < (int)(sizeof(hso_track_result) / 4); i += TRK_THREADS) dst[i] = src[i];
+    __syncthreads();
+    if (tid == 0) { s.T = se3_from(out->T_cur_ref); s.a = out->exposure_rat; }
+  } else if (tid == 0) {
+    memset(out, 0, sizeof(*out));
+    s.T = se3_from(job.T);
+    s.a = job.a;
+  }
+  __syncthreads();
+  if (job.n == 0) {  // CoarseTracker.cpp:53-54
+    if (tid == 0) { se3_to(s.T, out->T_cur_ref); out->exposure_rat = s.a; }
+    publish_result(s, gout);
+    return;
+  }
+  LevelCtx L;
+#ifdef HSO_PHASE_TIMERS
+  if (tid == 0) for (int k_ = 0; k_ < 8; k_++) s.dbg[k_] = 0;
+#endif
+  PH_START();
+  for (int level = C.level_first; level >= C.level_last; --level) {
+    begin_level(s, L, C, job, sc, level, lds_img);
+    PH_ADD(0);
+    {
+      const Se3 T0 = s.T; const float a0 = s.a;
+      select_robust(s, L, (LdsPtr)lds_img, T0, a0);
+      PH_ADD(1);
+      eval_dispatch<IC>(s, L, (LdsPtr)lds_img, T0, a0);
+      PH_ADD(2);
+    }
+    if (tid == 0) {
+      for (int i = 0; i < 28; i++) s.H[i] = s.red[i];
+      for (int i = 0; i < 7; i++) s.b[i] = s.red[28 + i];
+      s.energy_old = (double)((float)s.red[35] / (float)(int)s.red[36]);
+      s.lambda = 0.1f;
+      s.stop = 0;
+      out->huber[level] = s.huber; out->outlier[level] = s.outlier;
+      out->n_select[level] = s.n_select;
+      out->n_eval[level] = 1;
+    }
+    __syncthreads();
+    for (int iter = 0; iter < C.n_iter; iter++) {
+      if (tid == 0) {
+        lane_ldlt7_solve(s, s.lambda);
+        lm_finish(s, IC);
+      }
+      __syncthreads();
+      PH_ADD(3);
+      {
+        const Se3 Tn = s.Tn; const float an = s.a_new;
+        eval_dispatch<IC>(s, L, (LdsPtr)lds_img, Tn, an);
+      }
+      PH_ADD(2);
+      if (tid == 0) {
+        const double energy_new = (double)((float)s.red[35] / (float)(int)s.red[36]);
+        out->n_eval[level]++;
+        out->iters[level] = iter + 1;
+        if (energy_new < s.energy_old) {
+          for (int i = 0; i < 28; i++) s.H[i] = s.red[i];
+          for (int i = 0; i < 7; i++) s.b[i] = s.red[28 + i];
+          s.energy_old = energy_new;
+          s.a = s.a_new;
+          s.T = s.Tn;
+          s.lambda = (float)((double)s.lambda * 0.5);
+          if (iter < 64) out->accept_mask[level] |= (1ull << iter);
+        } else {
+          s.lambda = s.lambda * 4;
+          if ((double)s.lambda < 0.001) s.lambda = (float)0.001;
+        }
+        if (!(s.step_norm > 1e-8)) s.stop = 1;  // step.norm() > 1e-4 (CoarseTracker.cpp:169), on the squared norm
+        // the last evaluation defines m_total_terms / m_saturated_terms (CoarseTracker.cpp:207)
+        out->n_terms_last = (int)s.red[36];
+        out->n_saturated_last = (int)s.red[37];
+      }
+      __syncthreads();
+      if (s.stop) break;
+    }
+    if (tid == 0) {
+      out->energy[level] = s.energy_old;
+      if (C.n_iter == 0) { out->n_terms_last = (int)s.red[36]; out->n_saturated_last = (int)s.red[37]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    se3_to(s.T, out->T_cur_ref);
+    out->exposure_rat = s.a;
+    out->n_tracked = (int)((float)out->n_terms_last / (float)s.PA);
+    out->status = 0;
+  }
+  PH_JOB();
+  publish_result(s, gout);
+}
+
+// dynamic LDS: [0, kImgCap) staged level image (address 0 => tap addresses need no base add),
+// then the Shared block
+constexpr int kLdsTotal = TRK_LDS_KB * 1024;
+constexpr int kImgCap = (int)(((kLdsTotal - 256 - sizeof(Shared)) / 256) * 256);
+extern __shared__ __attribute__((aligned(16))) char g_smem[];
+
+template <bool IC>
+__global__ __launch_bounds__(TRK_THREADS, 2) void k_track(TrackConsts C, const TrackJobDev* jobs, int n_jobs,
+                                                       int* job_counter, char* scratch, size_t scratch_stride,
+                                                       hso_track_result* results)
+{
+  Shared& s = *reinterpret_cast<Shared*>(g_smem + kImgCap);
+  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem);
+  const Scratch sc = scratch_at(scratch + (size_t)blockIdx.x * scratch_stride, C.n_max);
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s.job = atomicAdd(job_counter, 1);
+    __syncthreads();
+    const int j = s.job;
+    if (j >= n_jobs) break;
+    track_one<IC>(s, C, jobs[j], sc, lds_img, &results[j]);
+  }
+}
+
+// parity hook: one level, optional threshold selection, one evaluation
+struct EvalArgs {
+  int level;
+  hso_se3 T;
+  float a, huber, outlier;
+};
+
+template <bool IC>
+__global__ __launch_bounds__(TRK_THREADS) void k_eval(TrackConsts C, const TrackJobDev* jobs, EvalArgs ea,
+                                                      char* scratch, hso_eval_out* out)
+{
+  Shared& s = *reinterpret_cast<Shared*>(g_smem + kImgCap);
+  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem);
+  const Scratch sc = scratch_at(scratch, C.n_max);
+  const TrackJobDev& job = jobs[0];
+  LevelCtx L;
+  if (threadIdx.x == 0) { s.T = se3_from(ea.T); s.a = ea.a; s.n_select = 0; }
+  begin_level(s, L, C, job, sc, ea.level, lds_img);
+  const Se3 T0 = s.T; const float a0 = s.a;
+  if (ea.huber <= 0) {
+    select_robust(s, L, (LdsPtr)lds_img, T0, a0);
+  } else {
+    if (threadIdx.x == 0) { s.huber = ea.huber; s.outlier = ea.outlier; }
+    __syncthreads();
+  }
+  eval_dispatch<IC>(s, L, (LdsPtr)lds_img, T0, a0);
+  int nv = 0;
+  for (int i = threadIdx.x; i < job.n; i += TRK_THREADS) nv += sc.visible[i];
+  nv = block_sum_int(s, nv);
+  if (threadIdx.x == 0) {
+    int idx = 0;
+    for (int r = 0; r < 7; r++)
+      for (int c = r; c < 7; c++) { out->H[r * 7 + c] = out->H[c * 7 + r] = s.red[idx]; idx++; }
+    for (int i = 0; i < 7; i++) out->b[i] = s.red[28 + i];
+    out->energy_sum = s.red[35];
+    out->n_terms = (int)s.red[36];
+    out->n_saturated = (int)s.red[37];
+    out->energy = (double)((float)s.red[35] / (float)out->n_terms);
+    out->n_select = s.n_select;
+    out->n_visible = nv;
+    out->huber = s.huber; out->outlier = s.outlier;
+  }
+}
+
+#undef TRK_WAVES
+#ifdef SEL_WORDS
+#undef SEL_WORDS
+#endif
+#ifdef SEL_REP
+#undef SEL_REP
+#endif
+#ifdef KSEL_T
+#undef KSEL_T
+#endif
+#ifdef SELR_T
+#undef SELR_T
+#endif
+#ifdef DBG_T
+#undef DBG_T
+#endif
+#ifdef HSO_PHASE
+#undef HSO_PHASE
+#endif
+#ifdef PH_START
+#undef PH_START
+#endif
+#ifdef PH_ADD
+#undef PH_ADD
+#endif
+#ifdef PH_JOB
+#undef PH_JOB
+#endif
+#ifdef HSO_PHASE_TIMERS_BASE
+#undef HSO_PHASE_TIMERS_BASE
+#endif
+#ifdef TRK_FPT
+#undef TRK_FPT
+#endif

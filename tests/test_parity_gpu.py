@@ -261,6 +261,36 @@ def test_coarse_track_batch_is_deterministic_and_order_free(gpu_ctx, orc, cam, p
     assert rot <= 1e-6 and tra <= 4e-6
 
 
+@pytest.mark.parametrize("inv", [0, 1], ids=["forward", "inverse_comp"])
+def test_coarse_track_large_batch_takes_the_two_launch_path(gpu_ctx, orc, cam, pair2000, pair200, inv):
+    """A batch that fills the chip at least twice runs levels 4..2 on two 256-thread workgroups per CU and level 1 on one
+    512-thread workgroup (hso_tracker.hip: track_launch): a different split of the same sums, so every job must still equal
+    the CPU restatement's decisions and pose, equal its twins bit for bit, and agree with the one-launch path to rounding."""
+    import torch
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    upload_pair(gpu_ctx, pair2000, (1, 2)); upload_pair(gpu_ctx, pair200, (5, 6))
+    p = capi.TrackParams(inv, 4, 1, 50)
+    T0 = capi.SE3.from_arrays(synth.rotvec_to_quat(0.6 * np.deg2rad(0.5) * np.array([0.2, -0.7, 0.4])), 0.7 * np.array(pair2000["t_true"]))
+    jobs = [gpu_ctx.make_job(1, 2, pair2000["feats"], T0, 1.04), gpu_ctx.make_job(5, 6, pair200["feats"], capi.SE3.identity(), 1.0),
+            gpu_ctx.make_job(1, 2, pair2000["feats"][:900], capi.SE3.identity(), 1.0)]
+    n = 2 * n_cu + 7
+    batch = gpu_ctx.coarse_track_batch(cam, p, [jobs[i % 3] for i in range(n)])
+    solo = [gpu_ctx.coarse_track_batch(cam, p, [j])[0] for j in jobs]             # one launch, 512 threads
+    rp, cp = orc.create_pyramid(pair2000["ref"]), orc.create_pyramid(pair2000["cur"])
+    ro = orc.Tracker(cam, p, rp, cp, pair2000["feats"]).run(T0, 1.04)
+    for i, r in enumerate(batch):
+        assert bytes(r) == bytes(batch[i % 3]), "job %d differs from its twin" % i
+        assert r.status == 0 and list(r.iters) == list(solo[i % 3].iters) and list(r.accept_mask) == list(solo[i % 3].accept_mask)
+        rot, tra = pose_err(r, solo[i % 3])
+        assert rot <= 1e-6 and tra <= 4e-6
+        assert list(r.huber) == pytest.approx(list(solo[i % 3].huber), rel=1e-5) and r.huber[4] == solo[i % 3].huber[4]
+    r = batch[0]
+    assert list(r.iters) == list(ro.iters) and list(r.accept_mask) == list(ro.accept_mask) and list(r.n_eval) == list(ro.n_eval)
+    assert (r.n_tracked, r.n_terms_last, r.n_saturated_last) == (ro.n_tracked, ro.n_terms_last, ro.n_saturated_last)
+    rot, tra = pose_err(r, ro)
+    assert rot <= 1e-6 and tra <= 4e-6
+
+
 def test_coarse_track_edge_cases(gpu_ctx, orc, cam, pair200):
     d = pair200
     upload_pair(gpu_ctx, d, (5, 6))
