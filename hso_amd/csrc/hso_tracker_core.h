@@ -692,6 +692,118 @@ __device__ __forceinline__ Moments feature_terms_static(LdsPtr img, GlbF32 ref_p
   return m;
 }
 
+// The same per-term arithmetic with the image taps organised by ROW instead of by term.  A feature's pattern touches the
+// rows min_oy-1 .. max_oy+2 and, in each, the bytes u_i-1+min_ox .. u_i+2+max_ox (<= 10 for the 21-pixel pattern): one
+// row = two ds_read2_b32 + three v_alignbyte that bring those bytes to FIXED positions of three registers, whatever the
+// lane's alignment.  Every tap of every term is then a byte select at a compile-time position (v_cvt_f32_ubyteN, SDWA
+// operands) — no per-tap address arithmetic, no per-tap LDS read: 20 LDS reads per feature instead of 74 at level 1.
+// Terms are visited row by row (ascending oy), so four rows of windows are live at a time.  The order of the moment sums
+// changes with it (they are tolerance-compared); the per-term decision arithmetic is untouched.
+#ifndef TRK_ROW_WINDOWS
+#define TRK_ROW_WINDOWS 1
+#endif
+template <int PI>
+struct PatRows {
+  static constexpr int N = h_pattern_num[PI];
+  struct T { int idx[TRK_MAX_PA]; int min_ox, max_ox, min_oy, max_oy; };
+  static constexpr T make()
+  {
+    T t{};
+    t.min_ox = t.min_oy = 127; t.max_ox = t.max_oy = -127;
+    for (int k = 0; k < N; k++) {
+      t.idx[k] = k;
+      const int ox = h_pattern[PI][k][0], oy = h_pattern[PI][k][1];
+      if (ox < t.min_ox) t.min_ox = ox;
+      if (ox > t.max_ox) t.max_ox = ox;
+      if (oy < t.min_oy) t.min_oy = oy;
+      if (oy > t.max_oy) t.max_oy = oy;
+    }
+    for (int i = 1; i < N; i++) {                      // stable insertion sort by oy
+      const int v = t.idx[i];
+      int j = i - 1;
+      while (j >= 0 && h_pattern[PI][t.idx[j]][1] > h_pattern[PI][v][1]) { t.idx[j + 1] = t.idx[j]; j--; }
+      t.idx[j + 1] = v;
+    }
+    return t;
+  }
+  static constexpr T v = make();
+};
+
+HSO_DEV float win_byte(const uint32_t (&w)[3], int j) { return (float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu); }
+
+template <int PI>
+__device__ __forceinline__ Moments feature_terms_rows(LdsPtr img, GlbF32 ref_patch, int base, float w_tl, float w_tr, float w_bl,
+                                                    float w_br, uint32_t fb, uint32_t nb, int stride, float a, float huber,
+                                                    float outlier, float max_energy, int top)
+{
+  constexpr auto P = PatRows<PI>::v;
+  constexpr int PA = h_pattern_num[PI];
+  constexpr int NB = P.max_ox - P.min_ox + 4;          // bytes of a row the pattern touches
+  constexpr int NW = (NB + 3) / 4;                     // registers per row window (2 or 3)
+  constexpr int R0 = P.min_oy - 1, R1 = P.max_oy + 2;  // first / last row
+  Moments m;
+  m.ee = m.ex = m.ey = m.xx = m.xy = m.yy = m.re = m.rx = m.ry = 0; m.E = 0; m.nt = PA; m.nsat = 0;
+  stride = __builtin_amdgcn_readfirstlane(stride);
+  nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+  typedef const __attribute__((address_space(1))) char* GlbBytes;
+  const GlbBytes rpb = (GlbBytes)ref_patch;
+  constexpr int PF = 4;  // reference intensities requested PF terms ahead of their use
+  float ipf[PF];
+#pragma unroll
+  for (int t = 0; t < PF && t < PA; t++) ipf[t] = *(GlbF32)(rpb + (fb + (uint32_t)P.idx[t] * nb));
+  uint32_t win[4][3];
+  const int c0 = base + P.min_ox;                      // byte address of the window's first byte in row 0 (v_i)
+  int t = 0;                                           // next term (in row order)
+#pragma unroll
+  for (int R = R0; R <= R1; R++) {
+    {
+      const int addr = c0 + R * stride;
+      const int A = addr >> 2;
+      const uint32_t sh = (uint32_t)(addr & 3);
+      uint32_t (&w)[3] = win[(R - R0) & 3];
+      const uint32_t d0 = img[A], d1 = img[A + 1], d2 = img[A + 2];
+      w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      if (NW == 3) { const uint32_t d3 = img[A + 3]; w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); } else w[2] = 0;
+    }
+    const int oy = R - 2;                              // the terms whose four rows are now complete
+#pragma unroll
+    for (int q = 0; q < PA; q++) {
+      if (h_pattern[PI][P.idx[q]][1] != oy) continue;
+      const int kk = P.idx[q];
+      const int j = h_pattern[PI][kk][0] - P.min_ox;   // window byte of pixel (u_i - 1 + ox)
+      const uint32_t (&w0)[3] = win[(oy - 1 - R0) & 3];
+      const uint32_t (&w1)[3] = win[(oy - R0) & 3];
+      const uint32_t (&w2)[3] = win[(oy + 1 - R0) & 3];
+      const uint32_t (&w3)[3] = win[(oy + 2 - R0) & 3];
+      const float iref = ipf[t % PF];
+      if (t + PF < PA) ipf[t % PF] = *(GlbF32)(rpb + (fb + (uint32_t)P.idx[(t + PF) < PA ? (t + PF) : 0] * nb));
+      t++;
+      const float p10 = win_byte(w1, j), p11 = win_byte(w1, j + 1), p12 = win_byte(w1, j + 2), p13 = win_byte(w1, j + 3);
+      const float p20 = win_byte(w2, j), p21 = win_byte(w2, j + 1), p22 = win_byte(w2, j + 2), p23 = win_byte(w2, j + 3);
+      const float p01 = win_byte(w0, j + 1), p02 = win_byte(w0, j + 2), p31 = win_byte(w3, j + 1), p32 = win_byte(w3, j + 2);
+      // decision arithmetic: exactly the reference's expression order (:339-348)
+      const float cur = ((w_tl * p11 + w_tr * p12) + w_bl * p21) + w_br * p22;
+      const float res = cur - a * iref;
+      const float ares = fabsf(res);
+      const float hw = ares < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ares);
+      const bool sat = (ares > outlier) && !top;
+      const float e_term = top ? (hw * res) * res : ((hw * res) * res) * (2 - hw);
+      m.E += sat ? max_energy : e_term;
+      m.nsat += sat ? 1 : 0;
+      const float dx = fmaf(w_tl, p12 - p10, fmaf(w_tr, p13 - p11, fmaf(w_bl, p22 - p20, w_br * (p23 - p21))));
+      const float dy = fmaf(w_tl, p21 - p01, fmaf(w_tr, p22 - p02, fmaf(w_bl, p31 - p11, w_br * (p32 - p12))));
+      const float wgt = sat ? 0.0f : hw;
+      const float e = -iref;
+      const float we = wgt * e, wx = wgt * dx, wy = wgt * dy, wr = wgt * res;
+      m.ee = fmaf(we, e, m.ee); m.ex = fmaf(we, dx, m.ex); m.ey = fmaf(we, dy, m.ey);
+      m.xx = fmaf(wx, dx, m.xx); m.xy = fmaf(wx, dy, m.xy); m.yy = fmaf(wy, dy, m.yy);
+      m.re = fmaf(wr, e, m.re); m.rx = fmaf(wr, dx, m.rx); m.ry = fmaf(wr, dy, m.ry);
+    }
+  }
+  return m;
+}
+
 // Expand one feature's moments into the 28 + 7 normal-equation entries (computeGS, :499-525).
 // A = fx_l * J.row(0), B = fy_l * J.row(1) (frame.h:192-212); in inverse-compositional mode the
 // Jacobian is taken at the reference point and scaled by the exposure ratio
@@ -802,8 +914,13 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
       DBG_T(0);
       if constexpr (PI >= 0) {
         if (p[q].ok)
+#if TRK_ROW_WINDOWS
+          m[q] = feature_terms_rows<PI>(img, (GlbF32)L.sc.ref_patch, p[q].base, p[q].w_tl, p[q].w_tr, p[q].w_bl, p[q].w_br,
+                                        (uint32_t)f * 4u, (uint32_t)L.C->n_max * 4u, L.cols, a, huber, outlier, max_energy, top ? 1 : 0);
+#else
           m[q] = feature_terms_static<PI>(img, (GlbF32)L.sc.ref_patch, p[q].base, p[q].w_tl, p[q].w_tr, p[q].w_bl, p[q].w_br,
                                           (uint32_t)f * 4u, (uint32_t)L.C->n_max * 4u, L.cols, a, huber, outlier, max_energy, top ? 1 : 0);
+#endif
         else
           m[q] = Moments{};
       } else {
