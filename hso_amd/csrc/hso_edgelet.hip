@@ -42,6 +42,7 @@ struct EdgeLevel {
   int grid, gcols, grows;   // occupancy grid of the level (FeatureExtractor ctor :393-400)
   int tiles_x, tiles_y, tile_base;   // 64x32 tiles; tile_base = first tile of the level in a frame's tile tables
   uint32_t gx_off, gy_off;  // Sobel images inside a frame
+  int gs;                   // their row stride in pixels (PyrGeom::sob_stride)
   size_t o_map, o_res, o_out, o_have;  // offsets inside a frame's edgelet slice
   size_t o_fmask;           // FAST mask inside a frame's FAST slice
   int wpr;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_canny_nms(EdgeArgs A)
       const int y = y0 + ly - 2, x = x0 + 4 * q;
       uint2 a = make_uint2(0, 0), b = make_uint2(0, 0);
       if (y >= 0 && y < H && x < W) {
-        const size_t o = (size_t)y * W + x;
+        const size_t o = (size_t)y * L.gs + x;
         a = *reinterpret_cast<const uint2*>(gxp + o);
         b = *reinterpret_cast<const uint2*>(gyp + o);
       }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void k_canny_nms(EdgeArgs A)
       const int y = y0 + ly - 2, x = x0 + lx - 2;
       uint32_t v = 0;
       if (x >= 0 && x < W && y >= 0 && y < H) {
-        const size_t o = (size_t)y * W + x;
+        const size_t o = (size_t)y * L.gs + x;
         v = (uint32_t)(uint16_t)gxp[o] | ((uint32_t)(uint16_t)gyp[o] << 16);
       }
       s_g[ly][lx] = v;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void k_canny_nms(EdgeArgs A)
       const int y = y0 + ly - 2, x = x0 + lx - 2;
       uint32_t v = 0;
       if (x >= 0 && x < W && y >= 0 && y < H) {
-        const size_t o = (size_t)y * W + x;
+        const size_t o = (size_t)y * L.gs + x;
         v = (uint32_t)(uint16_t)gxp[o] | ((uint32_t)(uint16_t)gyp[o] << 16);
       }
       s_g[ly][lx] = v;
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(256) void k_edgelet_cells(EdgeArgs A)
         for (int x = iniX; x < maxX; ++x) {
           const size_t o = (size_t)y * W + x;
           if (map[o] != 2) continue;
-          const int sx = gxp[o], sy = gyp[o];
+          const size_t og = (size_t)y * L.gs + x;
+          const int sx = gxp[og], sy = gyp[og];
           const float grad = sqrtf((float)(sx * sx + sy * sy));
           if (grad > grad_best) { grad_best = grad; pos_best = (int)o; g_best = (sx & 0xffff) | (sy << 16); }
         }
@@ -436,7 +438,7 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
     L.grid = 8 / (1 << l);                                   // gridSize_ = 8, :395
     L.gcols = (vw + L.grid - 1) / L.grid; L.grows = (vh + L.grid - 1) / L.grid;   // vecWidth_[l] = vecWidth_[l-1] / 2, :362-366
     vw /= 2; vh /= 2;
-    L.gx_off = g.sob_off[l][0]; L.gy_off = g.sob_off[l][1];
+    L.gx_off = g.sob_off[l][0]; L.gy_off = g.sob_off[l][1]; L.gs = g.sob_stride[l];
     const int cells = L.gcols * L.grows;
     // the windows and getCellIndex stay inside the level image / the flag array for the sizes the
     // frame store accepts; .at() would throw in the reference otherwise

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
   __shared__ double s_part[4][2];
   int b = blockIdx.x, level = 0;
   while (level < HSO_N_SOBEL_LEVELS - 1 && b >= g.sobel_blocks[level]) { b -= g.sobel_blocks[level]; level++; }
-  const int W = g.w[level], H = g.h[level];
+  const int W = g.w[level], H = g.h[level], GS = g.sob_stride[level];
   // pointers read from a table are generic; say "global" so the accesses are global_load / global_store
   // instead of FLAT (which also probes the LDS aperture and ties up both wait counters)
   typedef const __attribute__((address_space(1))) uint8_t* GlbCU8;
@@ -271,13 +271,13 @@ __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
           sy1.v = (hs[re][1] - hs[ra][1]) + k2 * (hs[rd][1] - hs[rb][1]);
           typedef unsigned long long u64;
           if (x + 4 <= W && ((W & 3) == 0)) {
-            __builtin_nontemporal_store(((u64)sx1.u << 32) | sx0.u, (GlbU64)(gx + (size_t)y * W + x));
-            __builtin_nontemporal_store(((u64)sy1.u << 32) | sy0.u, (GlbU64)(gy + (size_t)y * W + x));
+            __builtin_nontemporal_store(((u64)sx1.u << 32) | sx0.u, (GlbU64)(gx + (size_t)y * GS + x));
+            __builtin_nontemporal_store(((u64)sy1.u << 32) | sy0.u, (GlbU64)(gy + (size_t)y * GS + x));
           } else {  // widths that are not multiples of 4 (cv::resize pyramids): element-wise, last lane clipped
             const short sxv[4] = {sx0.v.x, sx0.v.y, sx1.v.x, sx1.v.y}, syv[4] = {sy0.v.x, sy0.v.y, sy1.v.x, sy1.v.y};
 #pragma unroll
             for (int k = 0; k < 4; k++)
-              if (x + k < W) { gx[(size_t)y * W + x + k] = sxv[k]; gy[(size_t)y * W + x + k] = syv[k]; }
+              if (x + k < W) { gx[(size_t)y * GS + x + k] = sxv[k]; gy[(size_t)y * GS + x + k] = syv[k]; }
           }
           if (level == 0 && x >= 16 && x < W - 16 && y >= 16 && y < H - 16) {
             const short sxv[4] = {sx0.v.x, sx0.v.y, sx1.v.x, sx1.v.y}, syv[4] = {sy0.v.x, sy0.v.y, sy1.v.x, sy1.v.y};
@@ -371,9 +371,10 @@ PyrGeom make_geom(int w, int h)
   for (int l = 0; l < HSO_N_SOBEL_LEVELS; l++) {
     g.sobel_bx[l] = (g.w[l] + SOB_TW - 1) / SOB_TW;  // tiles per row
     g.sobel_blocks[l] = (g.sobel_bx[l] * ((g.h[l] + SOB_TH - 1) / SOB_TH) + SOB_WAVES - 1) / SOB_WAVES;
+    g.sob_stride[l] = (g.w[l] + 63) & ~63;
     for (int k = 0; k < 2; k++) {
       g.sob_off[l][k] = off;
-      off += ((uint32_t)g.w[l] * g.h[l] * 2u + 255u) & ~255u;
+      off += ((uint32_t)g.sob_stride[l] * g.h[l] * 2u + 255u) & ~255u;
     }
   }
   g.part_off = off;

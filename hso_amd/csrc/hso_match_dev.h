@@ -256,9 +256,10 @@ HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const u
     const float wTR = (float)(sx * (1.0 - sy));
     const float wBL = (float)((1.0 - sx) * sy);
     const float wBR = (float)(((1.0 - wTL) - wTR) - wBL);
-    const int a = vi * cols + ui;
-    double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + cols]) + (double)wBR * (double)gx[a + cols + 1];
-    double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + cols]) + (double)wBR * (double)gy[a + cols + 1];
+    const int gs = g.sob_stride[search_level];   // gradient rows are padded (hso_ctx.h)
+    const int a = vi * gs + ui;
+    double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + gs]) + (double)wBR * (double)gx[a + gs + 1];
+    double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + gs]) + (double)wBR * (double)gy[a + gs + 1];
     const double nn = sqrt(n0 * n0 + n1 * n1);
     n0 /= nn; n1 /= nn;
     ok = (dir0 * n0 + dir1 * n1) > (double)(float)0.86;  // Config::edgeLetCosAngle() through a float parameter

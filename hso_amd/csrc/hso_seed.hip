@@ -346,9 +346,10 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
         const float sx = uf - (float)ui, sy = vf - (float)vi;
         const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy);
         const float wBR = (float)(((1.0 - wTL) - wTR) - wBL);
-        const int a = vi * cols + ui;
-        double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + cols]) + (double)wBR * (double)gx[a + cols + 1];
-        double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + cols]) + (double)wBR * (double)gy[a + cols + 1];
+        const int gs = C.g.sob_stride[sl];
+        const int a = vi * gs + ui;
+        double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + gs]) + (double)wBR * (double)gx[a + gs + 1];
+        double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + gs]) + (double)wBR * (double)gy[a + gs + 1];
         const double nn = sqrt(n0 * n0 + n1 * n1);
         n0 /= nn; n1 /= nn;
         result = (dc0 * n0 + dc1 * n1) > (double)(float)0.7;
