@@ -130,7 +130,10 @@ HSO_HD Scratch scratch_at(char* base, int n_max)
 // A batch that fills the chip twice over runs the coarse levels on trk2 and the last level(s) on trk1 (track_launch below).
 #define TRK_THREADS 512
 #define TRK_LDS_KB 160
-#define TRK_OLD_SHARE 10  // the older wavefront of a SIMD wins issue arbitration: it gets 10/16 of the features
+#ifndef TRK1_OLD_SHARE
+#define TRK1_OLD_SHARE 10
+#endif
+#define TRK_OLD_SHARE TRK1_OLD_SHARE  // the older wavefront of a SIMD wins issue arbitration: it gets 10/16 of the features
 namespace trk1 {
 #include "hso_tracker_core.h"
 }

@@ -113,12 +113,11 @@ HSO_DEV FeatRaw load_feature(const LevelCtx& L, int f)
   return r;
 }
 
-// Out of line on purpose, with every input passed by value: its fp64 temporaries then never share
-// a register allocation with the pixel loops, and the body fits the call-clobbered registers, so
-// a call saves and restores nothing (the inlined version was the main source of spills in the
-// hot loops).  The camera is read from the workgroup's LDS copy (one address, broadcast reads).
 typedef const __attribute__((address_space(3))) hso_camera* CamPtr;
-__device__ __noinline__ Proj project_feature_nl(CamPtr camp, Se3 T, double bx, double by, double bz, double dist, int vis, int border,
+// Inlined: as a call (the choice while the kernel had 168 registers) the result record came back through scratch memory
+// plus 74 register moves per feature; the 256-register budget of two waves per SIMD has room for the fp64 temporaries
+// (k_track 19.1 -> 18.0 ms on 4096 EuRoC pairs).  The camera is read from the workgroup's LDS copy (broadcast reads).
+__device__ __forceinline__ Proj project_feature_nl(CamPtr camp, Se3 T, double bx, double by, double bz, double dist, int vis, int border,
                                                 int cols, int rows, float scale)
 {
   Proj p;
@@ -859,10 +858,14 @@ HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Mo
 #ifndef TRK_FPT
 #define TRK_FPT 2  // features per thread and round: halves the number of wave exchanges per evaluation
 #endif
+#ifndef TRK_FPT_P21
+#define TRK_FPT_P21 1  // the 21-pixel pattern (finest level): two features in flight spill 68 registers per feature in the pixel loop, one spills 31
+#endif
 #define HSO_PHASE __device__ __forceinline__
 template <bool IC, bool S1, typename Ptr, int PI = -1>
 HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a)
 {
+  constexpr int FPT = (PI == 5) ? TRK_FPT_P21 : TRK_FPT;   // features per thread and round
   const int n = L.job->n;
   const int PA = s.PA, border = s.pad + 1, S = S1 ? 1 : s.S;
   const int G = TRK_THREADS / S;
@@ -898,18 +901,18 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
     gt = old ? (int)threadIdx.x : (int)threadIdx.x - TRK_THREADS / 2;
   }
   auto fidx = [&](int k) { const int i = gt + k * gthreads; return i < gn ? gbase + i : n; };  // n = "none"
-  const int n_rounds = max(1, (((gn + gthreads - 1) / gthreads) + TRK_FPT - 1) / TRK_FPT);  // >= 1: the exchange assigns the slots
+  const int n_rounds = max(1, (((gn + gthreads - 1) / gthreads) + FPT - 1) / FPT);  // >= 1: the exchange assigns the slots
   FeatRaw nxt = load_feature(L, fidx(0));
   for (int r = 0; r < n_rounds; r++) {
-    Proj p[TRK_FPT];
-    Moments m[TRK_FPT];
-    int ff[TRK_FPT];
+    Proj p[FPT];
+    Moments m[FPT];
+    int ff[FPT];
 #pragma unroll
-    for (int q = 0; q < TRK_FPT; q++) {
-      const int f = fidx(r * TRK_FPT + q);
+    for (int q = 0; q < FPT; q++) {
+      const int f = fidx(r * FPT + q);
       ff[q] = f;
       const FeatRaw raw = nxt;
-      nxt = load_feature(L, fidx(r * TRK_FPT + q + 1));  // next feature's record in flight during this pixel loop
+      nxt = load_feature(L, fidx(r * FPT + q + 1));  // next feature's record in flight during this pixel loop
       p[q] = project_feature(L, T, raw, border);
       DBG_T(0);
       if constexpr (PI >= 0) {
@@ -943,7 +946,7 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
 #pragma unroll
     for (int i = 0; i < 16; i++) acc.d[i] = 0;
 #pragma unroll
-    for (int q = 0; q < TRK_FPT; q++)
+    for (int q = 0; q < FPT; q++)
       if (p[q].ok && sub == 0) expand_feature<IC>(acc, L, p[q], m[q], ff[q], a);
     DBG_T(2);
     float th; double td;
@@ -1358,4 +1361,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_eval(TrackConsts C, const Track
 #endif
 #ifdef TRK_FPT
 #undef TRK_FPT
+#endif
+#ifdef TRK_FPT_P21
+#undef TRK_FPT_P21
 #endif
