@@ -37,6 +37,7 @@ The JSON line also carries
                  half of BASELINE.json's metric.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -191,7 +192,7 @@ def main():
             ctx.coarse_track_launch()
             if ev is not None:
                 ev[1].record(stream)
-            return ctx.coarse_track_collect()          # synchronises the stream, D2H of the result records
+            return ctx.coarse_track_collect(as_list=False)   # synchronises the stream, D2H of the result records
 
         for k in range(args.warmup):
             step(k)
@@ -202,6 +203,10 @@ def main():
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(args.steps)]
         res_set = [None, None]
+        # the interpreter's cyclic collector would otherwise walk the rendered scenes (millions of objects) somewhere inside
+        # the timed loop: a 40 ms stall that has nothing to do with the path being measured
+        gc.collect()
+        gc.freeze()
         t0 = time.perf_counter()
         for k in range(args.steps):
             res_set[k & 1] = step(k, events[k])

@@ -493,10 +493,12 @@ class Context:
     def coarse_track_launch(self):
         self._check(self.lib.hso_gpu_coarse_track_launch(self.h), "coarse_track_launch")
 
-    def coarse_track_collect(self):
+    def coarse_track_collect(self, as_list=True):
+        """as_list=False returns the ctypes array itself (records are wrapped on access): a list of 4096 wrappers per
+        call is ~1 ms of interpreter time and feeds the garbage collector."""
         res = (TrackResult * self._n_prepared)()
         self._check(self.lib.hso_gpu_coarse_track_collect(self.h, res), "coarse_track_collect")
-        return list(res)
+        return list(res) if as_list else res
 
     # -- reprojection matching
     def align_batch(self, cam, cur_frame_id, jobs, as_list=True):

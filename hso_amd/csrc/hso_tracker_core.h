@@ -18,6 +18,7 @@ struct Shared {
   int level, PA, pad, S;
   int pi;                            // pattern index of the level
   int job, stop, n_select;
+  int n_cand;                        // select_kth: keys appended to the candidate list
   int use_lds;
   hso_camera cam;                    // LDS copy of the camera for the out-of-line projection
   int keys_lds_off;                  // byte offset of the level's key array in LDS, 0 = keys in memory
@@ -311,11 +312,96 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
 
 // ------------------------------------------------------ robust thresholds
 
+#ifndef TRK_ROW_WINDOWS
+#define TRK_ROW_WINDOWS 1
+#endif
+template <int PI>
+struct PatRows {
+  static constexpr int N = h_pattern_num[PI];
+  struct T { int idx[TRK_MAX_PA]; int min_ox, max_ox, min_oy, max_oy; };
+  static constexpr T make()
+  {
+    T t{};
+    t.min_ox = t.min_oy = 127; t.max_ox = t.max_oy = -127;
+    for (int k = 0; k < N; k++) {
+      t.idx[k] = k;
+      const int ox = h_pattern[PI][k][0], oy = h_pattern[PI][k][1];
+      if (ox < t.min_ox) t.min_ox = ox;
+      if (ox > t.max_ox) t.max_ox = ox;
+      if (oy < t.min_oy) t.min_oy = oy;
+      if (oy > t.max_oy) t.max_oy = oy;
+    }
+    for (int i = 1; i < N; i++) {                      // stable insertion sort by oy
+      const int v = t.idx[i];
+      int j = i - 1;
+      while (j >= 0 && h_pattern[PI][t.idx[j]][1] > h_pattern[PI][v][1]) { t.idx[j + 1] = t.idx[j]; j--; }
+      t.idx[j + 1] = v;
+    }
+    return t;
+  }
+  static constexpr T v = make();
+};
+
+HSO_DEV float win_byte(const uint32_t (&w)[3], int j) { return (float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu); }
+
+typedef const __attribute__((address_space(1))) float* GlbF32;
+
 // pass 1 of selectRobustFunctionLevel (CoarseTracker.cpp:547-606): |residual| of every
 // in-bounds term, stored as float bit patterns (KEY_INVALID elsewhere).  Returns errors.size().
 HSO_DEV void sel_count_a(Shared& s, uint32_t kk);
 
-template <bool S1, typename Ptr, typename KP>
+// The keys of one feature with the pattern known at compile time: the taps of the bilinear intensity come from per-row
+// windows (see feature_terms_rows below: two rows live here, no gradient), the reference intensities are requested up front.
+template <int PI, typename KP>
+__device__ __forceinline__ void collect_terms_rows(Shared& s, LdsPtr img, GlbF32 ref_patch, KP kdst, int n, int f, int base,
+                                                   float w_tl, float w_tr, float w_bl, float w_br, uint32_t fb, uint32_t nb,
+                                                   int stride, float a)
+{
+  constexpr auto P = PatRows<PI>::v;
+  constexpr int PA = h_pattern_num[PI];
+  constexpr int NB = P.max_ox - P.min_ox + 4;
+  constexpr int NW = (NB + 3) / 4;
+  constexpr int R0 = P.min_oy, R1 = P.max_oy + 1;
+  stride = __builtin_amdgcn_readfirstlane(stride);
+  nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+  typedef const __attribute__((address_space(1))) char* GlbBytes;
+  const GlbBytes rpb = (GlbBytes)ref_patch;
+  float iref[PA];
+#pragma unroll
+  for (int k = 0; k < PA; k++) iref[k] = *(GlbF32)(rpb + (fb + (uint32_t)k * nb));
+  uint32_t win[2][3];
+  const int c0 = base + P.min_ox;
+#pragma unroll
+  for (int R = R0; R <= R1; R++) {
+    {
+      const int addr = c0 + R * stride;
+      const int A = addr >> 2;
+      const uint32_t sh = (uint32_t)(addr & 3);
+      uint32_t (&w)[3] = win[(R - R0) & 1];
+      const uint32_t d0 = img[A], d1 = img[A + 1], d2 = img[A + 2];
+      w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      if (NW == 3) { const uint32_t d3 = img[A + 3]; w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); } else w[2] = 0;
+    }
+    const int oy = R - 1;                              // the terms whose two rows are now complete
+#pragma unroll
+    for (int q = 0; q < PA; q++) {
+      if (h_pattern[PI][P.idx[q]][1] != oy) continue;
+      const int kk = P.idx[q];
+      const int j = h_pattern[PI][kk][0] - P.min_ox;
+      const uint32_t (&w1)[3] = win[(oy - R0) & 1];
+      const uint32_t (&w2)[3] = win[(oy + 1 - R0) & 1];
+      const float p11 = win_byte(w1, j + 1), p12 = win_byte(w1, j + 2), p21 = win_byte(w2, j + 1), p22 = win_byte(w2, j + 2);
+      const float cur = ((w_tl * p11 + w_tr * p12) + w_bl * p21) + w_br * p22;   // CoarseTracker.cpp:339-348 order
+      const float res = cur - a * iref[kk];
+      const uint32_t key = __float_as_uint(fabsf(res));
+      sel_count_a(s, key);
+      kdst[kk * n + f] = key;
+    }
+  }
+}
+
+template <bool S1, typename Ptr, typename KP, int PI = -1>
 HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, float a, KP kdst)
 {
   const int n = L.job->n, nm = L.C->n_max;
@@ -332,6 +418,16 @@ HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, 
     nxt = load_feature(L, f + G);
     if (f >= n) continue;
     const Proj p = project_feature(L, T, raw, border);
+    if constexpr (PI >= 0) {
+      if (p.ok) {
+        collect_terms_rows<PI>(s, img, (GlbF32)L.sc.ref_patch, kdst, n, f, p.base, p.w_tl, p.w_tr, p.w_bl, p.w_br, (uint32_t)f * 4u,
+                               (uint32_t)nm * 4u, stride, a);
+        cnt += PA;
+      } else {
+        for (int pidx = 0; pidx < PA; pidx++) kdst[pidx * n + f] = KEY_INVALID;
+      }
+      continue;
+    }
     for (int pidx = sub; pidx < PA; pidx += S) {
       uint32_t key = KEY_INVALID;
       if (p.ok) {
@@ -351,18 +447,21 @@ HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, 
 
 // ---- exact order statistics -------------------------------------------------------------
 // Keys are bit patterns of non-negative floats (bit 31 clear), so unsigned order = float order;
-// KEY_INVALID (bit 31 set) marks slots without a term.  The k-th smallest is found MSB-first in
-// three histogram rounds over the digits [30:23] (the exponent), [22:12] and [11:0]; after each
-// round every wave locates the bin that holds the rank by itself (scan_find), so (prefix, rank)
-// live in registers and are identical in all threads by construction.  The value returned is
-// the element nth_element would leave at position k, whatever the input order.
-//
-// Residual magnitudes of a level crowd into a handful of octaves, so a plain histogram of the
-// leading digit would serialise on same-address LDS atomics: round A therefore keeps SEL_REP
-// replicas of every exponent bin (lane & 15 picks one) and folds them afterwards.  Rounds B and
-// C see mantissa bits, which are spread evenly.
+// KEY_INVALID (bit 31 set) marks slots without a term.  The k-th smallest is found MSB-first:
+//   round A  histogram of the digits [30:19] (exponent + 4 mantissa bits, 4096 bins) over all keys — for the median it is
+//            fused into the pass that produces the keys.  Residual magnitudes crowd into a handful of octaves; the four
+//            mantissa bits spread them over ~80 bins, so the LDS atomics rarely collide (a histogram of the exponent alone
+//            needed 16 replicas per bin) and the bin that holds the rank is left with a few percent of the keys;
+//   compact  one more pass over all keys copies the keys of that bin into LDS (wave-aggregated append);
+//   rounds B, C  digits [18:8] and [7:0] over the compacted keys only.
+// So the median costs one pass over the keys beyond the one that wrote them, the MAD two — instead of two and three passes
+// with three full-size scans each.  If the bin holds more keys than the LDS list (SEL_CAND_CAP; degenerate inputs such as
+// constant residuals), rounds B and C run over all keys instead.  After each round every wave locates the bin that holds the
+// rank by itself (scan_find), so (prefix, rank) live in registers and are identical in all threads by construction.  The
+// value returned is the element nth_element would leave at position k, whatever the input order.
 #define SEL_WORDS 4096
-#define SEL_REP 16
+#define SEL_A_SHIFT 19
+#define SEL_CAND_CAP 2048   // candidates live in sel[0, 2048), the round B / C histograms in sel[2048, 4096)
 
 template <int NB>
 HSO_DEV void scan_find(const unsigned* hist, unsigned& rank, unsigned& bin, unsigned& count)
@@ -405,11 +504,11 @@ HSO_DEV void sel_zero(Shared& s, int words)
 
 HSO_DEV void sel_count_a(Shared& s, uint32_t kk)
 {
-  if ((int)kk >= 0) atomicAdd(&s.sel[(kk >> 23) * SEL_REP + (threadIdx.x & (SEL_REP - 1))], 1u);
+  if ((int)kk >= 0) atomicAdd(&s.sel[kk >> SEL_A_SHIFT], 1u);
 }
 
 // keys.each(f) calls f(key) for every key this thread owns.  round_a_done: the caller already
-// histogrammed the exponents into the replicated bins (fused into the pass that produced the keys).
+// histogrammed the leading digit (fused into the pass that produced the keys).
 template <typename Keys>
 HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_a_done)
 {
@@ -423,32 +522,52 @@ HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_
   asm volatile("" : "+v"(tid));  // see scan_find
   unsigned rank = k, bin = 0, count = 0;
   if (!round_a_done) {
-    sel_zero(s, 256 * SEL_REP);
+    sel_zero(s, SEL_WORDS);
     keys.each([&](uint32_t kk) { sel_count_a(s, kk); });
   }
   __syncthreads();
   KSEL_T(0);
-  unsigned sum = 0;
-  if (tid < 256)
-    for (int j = 0; j < SEL_REP; j++) sum += s.sel[tid * SEL_REP + ((j + tid) & (SEL_REP - 1))];
+  scan_find<4096>(s.sel, rank, bin, count);
+  uint32_t prefix = bin << SEL_A_SHIFT;
+  __syncthreads();   // every wave has read the histogram: its words are free
+  KSEL_T(1);
+  if (count <= SEL_CAND_CAP) {
+    unsigned* const cand = s.sel;
+    unsigned* const hist = s.sel + SEL_CAND_CAP;
+    if (tid == 0) s.n_cand = 0;
+    for (int i = tid; i < 2048; i += TRK_THREADS) hist[i] = 0;
+    __syncthreads();
+    keys.compact(bin, cand, &s.n_cand);
+    __syncthreads();
+    KSEL_T(2);
+    const int nc = (int)count;
+    for (int i = tid; i < nc; i += TRK_THREADS) atomicAdd(&hist[(cand[i] >> 8) & 2047u], 1u);
+    __syncthreads();
+    unsigned bin_b = 0, cnt_b = 0;
+    scan_find<2048>(hist, rank, bin_b, cnt_b);
+    prefix |= bin_b << 8;
+    __syncthreads();
+    for (int i = tid; i < 256; i += TRK_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nc; i += TRK_THREADS) { const uint32_t kk = cand[i]; if ((kk & 0xFFFFFF00u) == prefix) atomicAdd(&hist[kk & 255u], 1u); }
+    __syncthreads();
+    unsigned bin_c = 0, cnt_c = 0;
+    scan_find<256>(hist, rank, bin_c, cnt_c);
+    prefix |= bin_c;
+    __syncthreads();
+    KSEL_T(3);
+    return prefix;
+  }
+  // the bin is too full for the LDS list: digits [18:8] and [7:0] over all keys
+  sel_zero(s, 2048);
+  keys.each([&](uint32_t kk) { if ((kk >> SEL_A_SHIFT) == bin) atomicAdd(&s.sel[(kk >> 8) & 2047u], 1u); });
   __syncthreads();
-  if (tid < 256) s.sel[tid] = sum;
+  scan_find<2048>(s.sel, rank, bin, count);
+  prefix |= bin << 8;
+  sel_zero(s, 256);
+  keys.each([&](uint32_t kk) { if ((kk & 0xFFFFFF00u) == prefix) atomicAdd(&s.sel[kk & 255u], 1u); });
   __syncthreads();
   scan_find<256>(s.sel, rank, bin, count);
-  uint32_t prefix = bin << 23;
-  sel_zero(s, 2048);
-  KSEL_T(1);
-  keys.each([&](uint32_t kk) { if ((kk & 0xFF800000u) == prefix) atomicAdd(&s.sel[(kk >> 12) & 2047u], 1u); });
-  __syncthreads();
-  KSEL_T(2);
-  scan_find<2048>(s.sel, rank, bin, count);
-  prefix |= bin << 12;
-  sel_zero(s, 4096);
-  KSEL_T(3);
-  keys.each([&](uint32_t kk) { if ((kk & 0xFFFFF000u) == prefix) atomicAdd(&s.sel[kk & 4095u], 1u); });
-  __syncthreads();
-  KSEL_T(2);
-  scan_find<4096>(s.sel, rank, bin, count);
   prefix |= bin;
   __syncthreads();
   KSEL_T(4);
@@ -464,6 +583,7 @@ template <typename KP> struct Vec4Ptr;
 template <> struct Vec4Ptr<uint32_t*> { typedef const u32x4* type; };
 template <> struct Vec4Ptr<LdsKeys> { typedef const __attribute__((address_space(3))) u32x4* type; };
 
+#define SEL_VPT 4   // 16-byte key vectors a thread has in flight per step (8 costs more in spills around the passes than it hides in load latency)
 template <typename KP, typename Xf>
 struct MemKeys {
   KP keys;
@@ -475,18 +595,60 @@ struct MemKeys {
     typedef typename Vec4Ptr<KP>::type V4;
     const V4 kv = (V4)keys;
     const int nvec = n_slots >> 2;
-    for (int v0 = threadIdx.x; v0 < nvec; v0 += TRK_THREADS * 4) {
-      u32x4 q[4];
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += TRK_THREADS * SEL_VPT) {
+      u32x4 q[SEL_VPT];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < SEL_VPT; u++) {
         const int v = v0 + u * TRK_THREADS;
         if (v < nvec) q[u] = kv[v];
         else q[u] = (u32x4)(KEY_INVALID);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) { f(xf(q[u].x)); f(xf(q[u].y)); f(xf(q[u].z)); f(xf(q[u].w)); }
+      for (int u = 0; u < SEL_VPT; u++) { f(xf(q[u].x)); f(xf(q[u].y)); f(xf(q[u].z)); f(xf(q[u].w)); }
     }
     if ((int)threadIdx.x < (n_slots & 3)) f(xf(keys[(nvec << 2) + (int)threadIdx.x]));
+  }
+  // Append every key whose leading digit is `bin` to cand[] (order irrelevant).  4 * SEL_VPT (+1) keys per thread and step:
+  // a thread counts its matches, one wave-wide prefix sum and ONE LDS atomic per wave and step reserve the slots (a ballot +
+  // atomic per key made this pass twice as slow as the histogram pass it replaces).
+  HSO_DEV void compact(unsigned bin, unsigned* cand, int* n_cand) const
+  {
+    typedef typename Vec4Ptr<KP>::type V4;
+    const V4 kv = (V4)keys;
+    const int nvec = n_slots >> 2;
+    const int lane = threadIdx.x & 63;
+    const int tail = n_slots & 3;
+    constexpr int NK = 4 * SEL_VPT + 1;
+    const int n_steps = max(1, (nvec + TRK_THREADS * SEL_VPT - 1) / (TRK_THREADS * SEL_VPT));
+    for (int step = 0; step < n_steps; step++) {   // the same trip count in every lane: the prefix sum needs the whole wave
+      const int v0 = (int)threadIdx.x + step * TRK_THREADS * SEL_VPT;
+      uint32_t k[NK];
+#pragma unroll
+      for (int u = 0; u < SEL_VPT; u++) {
+        const int v = v0 + u * TRK_THREADS;
+        u32x4 q;
+        if (v < nvec) q = kv[v];
+        else q = (u32x4)(KEY_INVALID);
+        k[4 * u + 0] = xf(q.x); k[4 * u + 1] = xf(q.y); k[4 * u + 2] = xf(q.z); k[4 * u + 3] = xf(q.w);
+      }
+      // the (< 4) keys behind the last full vector: one each for the first threads, in the first step
+      k[NK - 1] = (step == 0 && (int)threadIdx.x < tail) ? xf(keys[(nvec << 2) + (int)threadIdx.x]) : KEY_INVALID;
+      unsigned long long mbits = 0;
+#pragma unroll
+      for (int i = 0; i < NK; i++) mbits |= (unsigned long long)((k[i] >> SEL_A_SHIFT) == bin ? 1u : 0u) << i;
+      const int c = (int)__popcll(mbits);
+      int incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      const int total = __shfl(incl, 63);
+      if (total == 0) continue;
+      int base = 0;
+      if (lane == 63) base = atomicAdd(n_cand, total);
+      base = __shfl(base, 63) + incl - c;
+#pragma unroll
+      for (int i = 0; i < NK; i++)
+        if ((mbits >> i) & 1ull) cand[base + (int)__popcll(mbits & ((1ull << i) - 1ull))] = k[i];
+    }
   }
 };
 template <typename KP, typename Xf>
@@ -515,10 +677,20 @@ HSO_DEV void select_robust_k(Shared& s, const LevelCtx& L, LdsPtr lds_img, const
 #else
 #define SELR_T(k) do { } while (0)
 #endif
-  sel_zero(s, 256 * SEL_REP);
+  sel_zero(s, SEL_WORDS);
   int n_err;
   if (s.S == 1) {
-    n_err = s.use_lds ? select_collect<true, LdsPtr>(s, L, lds_img, T, a, keys) : select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a, keys);
+    if (s.use_lds) {
+      switch (s.pi) {  // pattern-specialised taps for the patterns levels 4..1 use
+        case 2: n_err = select_collect<true, LdsPtr, KP, 2>(s, L, lds_img, T, a, keys); break;
+        case 3: n_err = select_collect<true, LdsPtr, KP, 3>(s, L, lds_img, T, a, keys); break;
+        case 4: n_err = select_collect<true, LdsPtr, KP, 4>(s, L, lds_img, T, a, keys); break;
+        case 5: n_err = select_collect<true, LdsPtr, KP, 5>(s, L, lds_img, T, a, keys); break;
+        default: n_err = select_collect<true, LdsPtr>(s, L, lds_img, T, a, keys); break;
+      }
+    } else {
+      n_err = select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a, keys);
+    }
   } else {
     n_err = s.use_lds ? select_collect<false, LdsPtr>(s, L, lds_img, T, a, keys) : select_collect<false, GlbPtr>(s, L, L.cur_glb, T, a, keys);
   }
@@ -645,7 +817,6 @@ HSO_DEV Moments feature_terms(const Shared& s, const LevelCtx& L, Ptr img, const
 // VALU-issue-bound.  Deliberately NOT inlined: inside the megakernel the unrolled body competes
 // with the state of every other phase for the 168 VGPRs and spills; as a separate function it gets
 // its own register allocation, at the price of one call per feature.
-typedef const __attribute__((address_space(1))) float* GlbF32;
 template <int PI>
 __device__ __forceinline__ Moments feature_terms_static(LdsPtr img, GlbF32 ref_patch, int base, float w_tl, float w_tr, float w_bl,
                                                       float w_br, uint32_t fb, uint32_t nb, int stride, float a, float huber,
@@ -698,38 +869,6 @@ __device__ __forceinline__ Moments feature_terms_static(LdsPtr img, GlbF32 ref_p
 // operands) — no per-tap address arithmetic, no per-tap LDS read: 20 LDS reads per feature instead of 74 at level 1.
 // Terms are visited row by row (ascending oy), so four rows of windows are live at a time.  The order of the moment sums
 // changes with it (they are tolerance-compared); the per-term decision arithmetic is untouched.
-#ifndef TRK_ROW_WINDOWS
-#define TRK_ROW_WINDOWS 1
-#endif
-template <int PI>
-struct PatRows {
-  static constexpr int N = h_pattern_num[PI];
-  struct T { int idx[TRK_MAX_PA]; int min_ox, max_ox, min_oy, max_oy; };
-  static constexpr T make()
-  {
-    T t{};
-    t.min_ox = t.min_oy = 127; t.max_ox = t.max_oy = -127;
-    for (int k = 0; k < N; k++) {
-      t.idx[k] = k;
-      const int ox = h_pattern[PI][k][0], oy = h_pattern[PI][k][1];
-      if (ox < t.min_ox) t.min_ox = ox;
-      if (ox > t.max_ox) t.max_ox = ox;
-      if (oy < t.min_oy) t.min_oy = oy;
-      if (oy > t.max_oy) t.max_oy = oy;
-    }
-    for (int i = 1; i < N; i++) {                      // stable insertion sort by oy
-      const int v = t.idx[i];
-      int j = i - 1;
-      while (j >= 0 && h_pattern[PI][t.idx[j]][1] > h_pattern[PI][v][1]) { t.idx[j + 1] = t.idx[j]; j--; }
-      t.idx[j + 1] = v;
-    }
-    return t;
-  }
-  static constexpr T v = make();
-};
-
-HSO_DEV float win_byte(const uint32_t (&w)[3], int j) { return (float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu); }
-
 template <int PI>
 __device__ __forceinline__ Moments feature_terms_rows(LdsPtr img, GlbF32 ref_patch, int base, float w_tl, float w_tr, float w_bl,
                                                     float w_br, uint32_t fb, uint32_t nb, int stride, float a, float huber,
@@ -1332,8 +1471,14 @@ __global__ __launch_bounds__(TRK_THREADS) void k_eval(TrackConsts C, const Track
 #ifdef SEL_WORDS
 #undef SEL_WORDS
 #endif
-#ifdef SEL_REP
-#undef SEL_REP
+#ifdef SEL_A_SHIFT
+#undef SEL_A_SHIFT
+#endif
+#ifdef SEL_VPT
+#undef SEL_VPT
+#endif
+#ifdef SEL_CAND_CAP
+#undef SEL_CAND_CAP
 #endif
 #ifdef KSEL_T
 #undef KSEL_T
