@@ -189,6 +189,52 @@ struct Acc {
 // is not responsible for to its partner and adds the partner's contribution to the half it
 // keeps, so N values cost ~N exchanges instead of 6N.  Afterwards the lane whose `slot` is
 // k (< N) holds the total of value k.  Fixed order => deterministic floating point.
+// Lane exchanges of the halving sum, cheapest form per distance (gfx950):
+//   32, 16  v_permlane32_swap / v_permlane16_swap: the instruction swaps the upper half (odd rows) of one register with the
+//           lower half (even rows) of another — exactly "hand over the half you do not keep": afterwards both registers
+//           hold, in every lane, the two values that lane has to add.  No select, no LDS crossbar trip;
+//   8, 2, 1 DPP (row_ror:8, quad_perm) on the value handed over;
+//   4       ds_bpermute (no DPP pattern for it).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int M> HSO_DEV unsigned xor_lane_u32(unsigned v)
+{
+  if constexpr (M == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);       // row_ror:8
+  else if constexpr (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
+  else if constexpr (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+  else return (unsigned)__shfl_xor((int)v, M);
+}
+template <int M> HSO_DEV float xor_lane(float v) { return __uint_as_float(xor_lane_u32<M>(__float_as_uint(v))); }
+template <int M> HSO_DEV double xor_lane(double v)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = xor_lane_u32<M>((unsigned)b), hi = xor_lane_u32<M>((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// lanes with (lane & M) == 0 get lo + lo', the others hi + hi' (primes: the partner lane's values)
+template <int M> HSO_DEV float swap_sum(float lo, float hi)
+{
+  static_assert(M == 32 || M == 16, "swap distances");
+  u32x2 r;
+  if constexpr (M == 32) r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+  else r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int M> HSO_DEV double swap_sum(double lo, double hi)
+{
+  const unsigned long long bl = (unsigned long long)__double_as_longlong(lo), bh = (unsigned long long)__double_as_longlong(hi);
+  u32x2 r0, r1;
+  if constexpr (M == 32) {
+    r0 = __builtin_amdgcn_permlane32_swap((unsigned)bl, (unsigned)bh, false, false);
+    r1 = __builtin_amdgcn_permlane32_swap((unsigned)(bl >> 32), (unsigned)(bh >> 32), false, false);
+  } else {
+    r0 = __builtin_amdgcn_permlane16_swap((unsigned)bl, (unsigned)bh, false, false);
+    r1 = __builtin_amdgcn_permlane16_swap((unsigned)(bl >> 32), (unsigned)(bh >> 32), false, false);
+  }
+  const double a = __longlong_as_double((long long)(((unsigned long long)r1[0] << 32) | r0[0]));
+  const double b = __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r0[1]));
+  return a + b;
+}
+
 template <typename T, int N, int M>
 struct Halve {
   static HSO_DEV void run(T (&v)[N], int lane, int& slot, T& out)
@@ -201,11 +247,12 @@ struct Halve {
     for (int i = 0; i < HALF; i++) {
       const T lo = v[i];
       const T hi = v[HALF + i];
-      const T send = up ? lo : hi;
-      T recv;
-      if constexpr (sizeof(T) == 8) recv = shfl_xor_d(send, M);
-      else recv = __shfl_xor(send, M);
-      keep[i] = (up ? hi : lo) + recv;
+      if constexpr (M == 32 || M == 16) {
+        keep[i] = swap_sum<M>(lo, hi);
+      } else {
+        const T send = up ? lo : hi;
+        keep[i] = (up ? hi : lo) + xor_lane<M>(send);
+      }
     }
     if (up) slot += HALF;
     if constexpr (M == 1) {
@@ -215,17 +262,19 @@ struct Halve {
     }
   }
 };
+template <typename T, int M> HSO_DEV void butterfly_from(T& x)
+{
+  if constexpr (M == 32 || M == 16) x = swap_sum<M>(x, x);
+  else x += xor_lane<M>(x);
+  if constexpr (M > 1) butterfly_from<T, M / 2>(x);
+}
 template <typename T, int M>
 struct Halve<T, 1, M> {
   static HSO_DEV void run(T (&v)[1], int lane, int& slot, T& out)
   {
     // a single value left before the lane distance reached 1: finish with plain butterflies
     T x = v[0];
-#pragma unroll
-    for (int m = M; m >= 1; m >>= 1) {
-      if constexpr (sizeof(T) == 8) x += shfl_xor_d(x, m);
-      else x += __shfl_xor(x, m);
-    }
+    butterfly_from<T, M>(x);
     // every lane of the remaining group holds the total; only the group's first lane reports it
     if ((lane & (2 * M - 1)) != 0) slot = 1 << 20;
     out = x;
@@ -342,7 +391,29 @@ struct PatRows {
   static constexpr T v = make();
 };
 
-HSO_DEV float win_byte(const uint32_t (&w)[3], int j) { return (float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu); }
+// Byte j of a row window as a float.  Written as the conversion instruction itself: from `(float)byte_a - (float)byte_b` the
+// optimiser makes an integer subtract + int-to-float convert per DIFFERENCE (two instructions each, nothing shared), whereas
+// a pixel converted once is shared by every term and every difference that touches it (~50 conversions per 13-pixel feature
+// instead of ~210 subtract/convert pairs).  Not volatile: identical conversions are merged.
+#ifndef TRK_CVT_ASM
+#define TRK_CVT_ASM 1
+#endif
+HSO_DEV float win_byte(const uint32_t (&w)[3], int j)
+{
+#if TRK_CVT_ASM
+  float f;
+  const uint32_t v = w[j >> 2];
+  switch (j & 3) {
+    case 0: asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(v)); break;
+    case 1: asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(v)); break;
+    case 2: asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(v)); break;
+    default: asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(v)); break;
+  }
+  return f;
+#else
+  return (float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+#endif
+}
 
 typedef const __attribute__((address_space(1))) float* GlbF32;
 
@@ -998,7 +1069,7 @@ HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Mo
 #define TRK_FPT 2  // features per thread and round: halves the number of wave exchanges per evaluation
 #endif
 #ifndef TRK_FPT_P21
-#define TRK_FPT_P21 1  // the 21-pixel pattern (finest level): two features in flight spill 68 registers per feature in the pixel loop, one spills 31
+#define TRK_FPT_P21 TRK_FPT  // the 21-pixel pattern (finest level) can be set apart: with the old pixel loop it spilled at 2
 #endif
 #define HSO_PHASE __device__ __forceinline__
 template <bool IC, bool S1, typename Ptr, int PI = -1>
