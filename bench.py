@@ -244,7 +244,8 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_k_track.json")))
         for e in pmc["records"]:
-            if (e["shape"], e["batch"], e["feats"], e["inverse"], e["scenes"]) == (args.shape, B, args.feats, args.inverse, n_sc):
+            if (e["shape"], e["batch"], e["feats"], e["inverse"], e["scenes"], e.get("min_level", 1)) == \
+                    (args.shape, B, args.feats, args.inverse, n_sc, args.min_level):
                 traffic, traffic_src = e["hbm_bytes_per_launch"], "profiles/r2_pmc_k_track.json (rocprofv3 --pmc, separate passes)"
     except (OSError, KeyError, ValueError):
         pass
@@ -266,7 +267,7 @@ def main():
         "data": "synthetic (%d distinct scenes per rank, motion-model initial poses, replicated to %d resident pairs; "
                 "two alternating current-image sets)" % (n_sc, B),
         "config": {"workload": shape_txt + ", %d points, frame build (pyramid/Sobel/stats) + CoarseTracker levels 4..1 + result read-back" % args.feats,
-                   "shape": args.shape, "frames_per_gpu_per_step": B, "mode": "inverse_compositional" if args.inverse else "forward",
+                   "shape": args.shape, "min_level": args.min_level, "frames_per_gpu_per_step": B, "mode": "inverse_compositional" if args.inverse else "forward",
                    "parallelism": "independent sequences, %d per GPU x %d GPU(s)" % (B, world),
                    "mean_evaluations_per_frame": evals, "distinct_scenes_per_rank": n_sc},
         "per_gpu_frames_per_s": per_gpu, "gather_ms": 1e3 * t_gather, "setup_render_s": t_render,

@@ -51,37 +51,60 @@ def main():
         for cname, kname, n, mean in sorted(rows):
             fh.write("%s,%s,%d,%.1f\n" % (cname, kname, n, mean))
 
-    kt = sorted({k for (c, k) in per if k.startswith("k_track")})
+    # the tracker is two kernels per batch since the two-launch split (trk2:: coarse levels, trk1:: the finest level)
+    kt = sorted({k for (c, k) in per if "k_track" in k})
     # SQ counters of the tracker with the derived fractions (MI355X_MICROARCH.md "rocprofv3 PMC slots":
     # WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES; SQ_* cycle counters tick once per 4 clocks;
     # SQ_BUSY_CYCLES sums the 32 shader engines)
     if kt and ("SQ_WAVE_CYCLES", kt[0]) in per:
-        k = kt[0]
-        g = lambda c: per.get((c, k), float("nan"))
         with open(os.path.join(OUT, TAG + "_sq_counters.csv"), "w") as fh:
-            fh.write("# rocprofv3 --pmc SQ passes of `python bench.py --cpu-frames 0 --steps 2 --warmup 1` (profiles/collect_%s.sh); mean per k_track dispatch\n" % RND)
-            fh.write("counter,value\n")
-            for (c, kk), v in sorted(per.items()):
-                if kk == k and c.startswith("SQ_"):
-                    fh.write("%s,%.0f\n" % (c, v))
-            wc = g("SQ_WAVE_CYCLES")
-            fh.write("valu_busy_frac,%.3f\n" % (4 * g("SQ_ACTIVE_INST_VALU") / (1024 * g("SQ_BUSY_CYCLES") / 32)))
-            fh.write("wave_parked_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES),%.3f\n" % (g("SQ_WAIT_ANY") / wc))
-            fh.write("issue_stall_frac (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES),%.3f\n" % (g("SQ_WAIT_INST_ANY") / wc))
-            fh.write("lds_issue_stall_frac (SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES),%.3f\n" % (g("SQ_WAIT_INST_LDS") / wc))
-            fh.write("active_frac (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES),%.3f\n" % (g("SQ_ACTIVE_INST_ANY") / wc))
-            if ("SQ_INSTS_LDS", k) in per:
-                fh.write("lds_bank_conflict_cycles_per_lds_inst,%.3f\n" % (g("SQ_LDS_BANK_CONFLICT") / g("SQ_INSTS_LDS")))
+            fh.write("# rocprofv3 --pmc SQ passes of `python bench.py --cpu-frames 0 --steps 2 --warmup 1` (profiles/collect_%s.sh); mean per dispatch, per tracker kernel\n" % RND)
+            fh.write("kernel,counter,value\n")
+            for k in kt:
+                g = lambda c: per.get((c, k), float("nan"))
+                for (c, kk), v in sorted(per.items()):
+                    if kk == k and c.startswith("SQ_"):
+                        fh.write("%s,%s,%.0f\n" % (k, c, v))
+                wc = g("SQ_WAVE_CYCLES")
+                fh.write("%s,valu_busy_frac,%.3f\n" % (k, 4 * g("SQ_ACTIVE_INST_VALU") / (1024 * g("SQ_BUSY_CYCLES") / 32)))
+                fh.write("%s,wave_parked_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES),%.3f\n" % (k, g("SQ_WAIT_ANY") / wc))
+                fh.write("%s,issue_stall_frac (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES),%.3f\n" % (k, g("SQ_WAIT_INST_ANY") / wc))
+                fh.write("%s,lds_issue_stall_frac (SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES),%.3f\n" % (k, g("SQ_WAIT_INST_LDS") / wc))
+                fh.write("%s,active_frac (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES),%.3f\n" % (k, g("SQ_ACTIVE_INST_ANY") / wc))
+                if ("SQ_INSTS_LDS", k) in per:
+                    fh.write("%s,lds_bank_conflict_cycles_per_lds_inst,%.3f\n" % (k, g("SQ_LDS_BANK_CONFLICT") / g("SQ_INSTS_LDS")))
+
+    # the bench line's roofline fraction, reproduced from the kernel-stats pass: algorithmic bytes per batch (the line's own
+    # figure) / summed average duration of the tracker kernels of one batch / 8 TB/s
+    line = bench_line("bench_trace.log")
+    stats = glob.glob(os.path.join(SRC, "*_kernel_stats.csv"))
+    if line and stats:
+        dur = {}
+        with open(stats[0]) as fh:
+            for r in csv.DictReader(fh):
+                if "k_track" in r["Name"]:
+                    dur[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
+        tot_ms = sum(v[1] for v in dur.values()) * 1e-6
+        rf = line["roofline"]
+        with open(os.path.join(OUT, TAG + "_roofline_check.txt"), "w") as fh:
+            fh.write("bench line under rocprofv3 --kernel-trace --stats (bench_trace.log): launch_ms %.3f, frac %.4f, algorithmic bytes / batch %.0f\n"
+                     % (rf["launch_ms"], rf["frac"], rf["algorithmic_bytes_per_launch"]))
+            for k, (calls, avg) in sorted(dur.items()):
+                fh.write("kernel stats: %s  calls %d  average %.3f ms\n" % (k, calls, avg * 1e-6))
+            fh.write("sum of the tracker kernels of one batch: %.3f ms -> %.1f GB/s -> frac %.4f of 8000 GB/s\n"
+                     % (tot_ms, rf["algorithmic_bytes_per_launch"] / (tot_ms * 1e-3) / 1e9, rf["algorithmic_bytes_per_launch"] / (tot_ms * 1e-3) / 8e12))
 
     if kt and ("FETCH_SIZE", kt[0]) in per and ("WRITE_SIZE", kt[0]) in per:
-        k = kt[0]
+        k = " + ".join(kt)
         line = bench_line("bench_fetch.log")
         cfg = line["config"] if line else {}
-        fetch_kb, write_kb = per[("FETCH_SIZE", k)], per[("WRITE_SIZE", k)]
+        # one batch = one dispatch of every tracker kernel: the per-dispatch means add up
+        fetch_kb = sum(per[("FETCH_SIZE", x)] for x in kt)
+        write_kb = sum(per[("WRITE_SIZE", x)] for x in kt)
         rec = {"round": RND, "tag": TAG, "kernel": k,
                "shape": cfg.get("shape"), "batch": cfg.get("frames_per_gpu_per_step"), "feats": 2000,
                "inverse": 1 if cfg.get("mode") == "inverse_compositional" else 0,
-               "scenes": cfg.get("distinct_scenes_per_rank"),
+               "scenes": cfg.get("distinct_scenes_per_rank"), "min_level": cfg.get("min_level", 1),
                "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
                # the guide's gfx950 correction: FETCH_SIZE counts 128-B read requests at 64 B -> x2 on the read
                # side; WRITE_SIZE is taken as reported
@@ -95,8 +118,8 @@ def main():
             doc = json.load(open(path))
         except (OSError, ValueError):
             doc = {"records": []}
-        doc["records"] = [e for e in doc["records"] if (e["shape"], e["batch"], e["inverse"], e["scenes"]) !=
-                          (rec["shape"], rec["batch"], rec["inverse"], rec["scenes"])] + [rec]
+        doc["records"] = [e for e in doc["records"] if (e["shape"], e["batch"], e["inverse"], e["scenes"], e.get("min_level", 1)) !=
+                          (rec["shape"], rec["batch"], rec["inverse"], rec["scenes"], rec["min_level"])] + [rec]
         json.dump(doc, open(path, "w"), indent=1)
     print("wrote summaries from", SRC)
 
