@@ -15,6 +15,80 @@
 
 namespace hso_dev {
 
+// ---- lane exchanges at a fixed xor distance, cheapest gfx950 form per distance (no LDS crossbar trip except none at all):
+//   32, 16  v_permlane32_swap / v_permlane16_swap (swap the upper half / odd rows of one register with the lower half /
+//           even rows of another: called with the same value twice, the second result is the partner's value in the
+//           lower lanes and the first result is it in the upper lanes);
+//   8       DPP row_ror:8;   2, 1  DPP quad_perm;   4  two DPP moves (quad_perm [3,2,1,0] then row_half_mirror: 3 ^ 7 = 4).
+// The value every lane receives is exactly what __shfl_xor(v, M) returns, so butterfly sums keep their bits.
+typedef unsigned lane_u32x2 __attribute__((ext_vector_type(2)));
+template <int M> HSO_DEV unsigned lane_xor_u32(unsigned v)
+{
+  if constexpr (M == 32 || M == 16) {
+    lane_u32x2 r;
+    if constexpr (M == 32) r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    else r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    const bool up = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & M) != 0;
+    return up ? r[0] : r[1];
+  } else if constexpr (M == 8) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);       // row_ror:8
+  } else if constexpr (M == 4) {
+    const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x1b, 0xf, 0xf, false);           // quad_perm:[3,2,1,0]  (lane ^ 3)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, t, 0x141, 0xf, 0xf, false);            // row_half_mirror      (lane ^ 7)
+  } else if constexpr (M == 2) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);        // quad_perm:[2,3,0,1]
+  } else {
+    static_assert(M == 1, "xor distance");
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);        // quad_perm:[1,0,3,2]
+  }
+}
+template <int M> HSO_DEV float lane_xor(float v) { return __uint_as_float(lane_xor_u32<M>(__float_as_uint(v))); }
+template <int M> HSO_DEV int lane_xor(int v) { return (int)lane_xor_u32<M>((unsigned)v); }
+template <int M> HSO_DEV double lane_xor(double v)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = lane_xor_u32<M>((unsigned)b), hi = lane_xor_u32<M>((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// v + partner at distance 32 or 16 straight from the swap: its two results are, in every lane, the lane's own value and
+// its partner's (in one order or the other; the sum does not care), so no select is needed
+template <int M> HSO_DEV float lane_swap_sum(float v)
+{
+  lane_u32x2 r;
+  if constexpr (M == 32) r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  else r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int M> HSO_DEV int lane_swap_sum(int v)
+{
+  lane_u32x2 r;
+  if constexpr (M == 32) r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  else r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)(r[0] + r[1]);
+}
+template <int M> HSO_DEV double lane_swap_sum(double v)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  lane_u32x2 r0, r1;
+  if constexpr (M == 32) {
+    r0 = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    r1 = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  } else {
+    r0 = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    r1 = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  }
+  return __longlong_as_double((long long)(((unsigned long long)r1[0] << 32) | r0[0])) +
+         __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r0[1]));
+}
+// v + partner at distances 32, 16, 8, 4, 2, 1: every lane ends with the wave total, summed in the order of the
+// __shfl_xor butterfly it replaces
+template <typename T> HSO_DEV T wave_butterfly_sum(T v)
+{
+  v = lane_swap_sum<32>(v); v = lane_swap_sum<16>(v); v += lane_xor<8>(v);
+  v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);
+  return v;
+}
+
 struct Se3 {
   double qx, qy, qz, qw;
   double tx, ty, tz;

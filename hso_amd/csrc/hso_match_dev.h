@@ -9,12 +9,7 @@
 namespace hso_dev {
 
 
-HSO_DEV float wave_sum_all(float v)
-{
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
-}
+HSO_DEV float wave_sum_all(float v) { return wave_butterfly_sum(v); }
 
 // AbstractCamera::cam2world, src/camera.cpp:67-87 (pinhole; radtan through the 5-iteration
 // cv::undistortPoints with float K, D and float I/O, :43-45,78-85), :171-194 (FOV)

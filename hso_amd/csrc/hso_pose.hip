@@ -70,9 +70,7 @@ HSO_DEV void pose_block_sum(PoseShared& s, double (&v)[K])
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < K; i++) {
-    double x = v[i];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += p_shfl_xor_d(x, m);
+    const double x = wave_butterfly_sum(v[i]);
     if (lane == 0) s.wave_part[wave][i] = x;
   }
   __syncthreads();
@@ -87,7 +85,7 @@ HSO_DEV void pose_block_sum(PoseShared& s, double (&v)[K])
 HSO_DEV int pose_block_count(PoseShared& s, int v)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  v = wave_butterfly_sum(v);
   __syncthreads();
   if (lane == 0) s.cnt[wave] = v;
   __syncthreads();

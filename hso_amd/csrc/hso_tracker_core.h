@@ -194,14 +194,14 @@ struct Acc {
 //           lower half (even rows) of another — exactly "hand over the half you do not keep": afterwards both registers
 //           hold, in every lane, the two values that lane has to add.  No select, no LDS crossbar trip;
 //   8, 2, 1 DPP (row_ror:8, quad_perm) on the value handed over;
-//   4       ds_bpermute (no DPP pattern for it).
+//   4       two DPP moves (quad_perm [3,2,1,0], then row_half_mirror).
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int M> HSO_DEV unsigned xor_lane_u32(unsigned v)
 {
   if constexpr (M == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);       // row_ror:8
   else if constexpr (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
   else if constexpr (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
-  else return (unsigned)__shfl_xor((int)v, M);
+  else return lane_xor_u32<M>(v);   // 4: two DPP moves (hso_dev_math.h)
 }
 template <int M> HSO_DEV float xor_lane(float v) { return __uint_as_float(xor_lane_u32<M>(__float_as_uint(v))); }
 template <int M> HSO_DEV double xor_lane(double v)
