@@ -45,6 +45,12 @@ HSO_DEV void cam2world_dev(const hso_camera& cam, double u, double v, double f[3
   f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
 }
 
+// two horizontally adjacent pixels by ONE unaligned 16-bit load (low byte = p[0]): half the memory instructions of the
+// bilinear taps in the latency-bound per-candidate loops
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+// (the images live in device memory: say so, or the access is a FLAT load that has to resolve the aperture first)
+HSO_DEV unsigned load_px_pair(const uint8_t* p) { return *(const __attribute__((address_space(1))) u16_unaligned*)p; }
+
 // hso::interpolateMat_8u, include/hso/vikit/vision.h:49-65
 HSO_DEV float interpolate_8u(const uint8_t* data, int stride, float u, float v)
 {
@@ -56,7 +62,8 @@ HSO_DEV float interpolate_8u(const uint8_t* data, int stride, float u, float v)
   const float w10 = sx * (1.0f - sy);
   const float w11 = ((1.0f - w00) - w01) - w10;
   const uint8_t* p = data + y * stride + x;
-  return ((w00 * (float)p[0] + w01 * (float)p[stride]) + w10 * (float)p[1]) + w11 * (float)p[stride + 1];
+  const unsigned r0 = load_px_pair(p), r1 = load_px_pair(p + stride);
+  return ((w00 * (float)(r0 & 0xffu) + w01 * (float)(r1 & 0xffu)) + w10 * (float)(r0 >> 8)) + w11 * (float)(r1 >> 8);
 }
 
 // Matcher::findMatchDirect after the reference feature has been chosen (src/matcher.cpp:286-375);
@@ -214,7 +221,8 @@ HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const u
     const float wBL = (float)((1.0 - sx) * sy);
     const float wBR = sx * sy;
     const uint8_t* it = cur + (v_r + py_ - halfpatch_size_) * cols + u_r - halfpatch_size_ + px_;
-    search_pixel = ((wTL * (float)it[0] + wTR * (float)it[1]) + wBL * (float)it[cols]) + wBR * (float)it[cols + 1];
+    const unsigned it0 = load_px_pair(it), it1 = load_px_pair(it + cols);
+    search_pixel = ((wTL * (float)(it0 & 0xffu) + wTR * (float)(it0 >> 8)) + wBL * (float)(it1 & 0xffu)) + wBR * (float)(it1 >> 8);
     const float res = (search_pixel - ref_px) + mean_diff;
     const float j0 = wave_sum_all((res * Jx) * wgt);
     const float j2 = wave_sum_all(res * wgt);

@@ -50,8 +50,21 @@ struct SeedDev {
 
 // wave_sum_all, cam2world_dev and interpolate_8u come from hso_match_dev.h (shared with the matcher)
 
-// One lane's sample of warp::createPatch (matcher.cpp:159-196) at patch pixel (px_, py_)
-HSO_DEV float s_patch_sample(const uint8_t* img, int stride, double pxs0, double pxs1, int px_, int py_)
+// One lane's sample of warp::createPatch (matcher.cpp:159-196) at patch pixel (px_, py_), in two halves so that the march
+// can request the bytes of the NEXT step before it does the arithmetic of this one: the fetch is two unaligned 16-bit loads
+// (the two horizontally adjacent pixels of each row) instead of four byte loads.
+struct PatchTaps { unsigned r0, r1; };
+HSO_DEV PatchTaps s_patch_fetch(const uint8_t* img, int stride, double pxs0, double pxs1, int px_, int py_)
+{
+  const float u = (float)pxs0, v = (float)pxs1;
+  const int ui = (int)floorf(u), vi = (int)floorf(v);
+  const uint8_t* c = img + (vi - 4 + py_) * stride + (ui - 4) + px_;
+  PatchTaps t;
+  t.r0 = load_px_pair(c);
+  t.r1 = load_px_pair(c + stride);
+  return t;
+}
+HSO_DEV float s_patch_value(const PatchTaps& t, double pxs0, double pxs1)
 {
   const float u = (float)pxs0, v = (float)pxs1;
   const int ui = (int)floorf(u), vi = (int)floorf(v);
@@ -60,8 +73,11 @@ HSO_DEV float s_patch_sample(const uint8_t* img, int stride, double pxs0, double
   const float w_tr = (float)(su * (1.0 - sv));
   const float w_bl = (float)((1.0 - su) * sv);
   const float w_br = (float)(((1.0 - w_tl) - w_tr) - w_bl);
-  const uint8_t* c = img + (vi - 4 + py_) * stride + (ui - 4) + px_;
-  return ((w_tl * (float)c[0] + w_tr * (float)c[1]) + w_bl * (float)c[stride]) + w_br * (float)c[stride + 1];
+  return ((w_tl * (float)(t.r0 & 0xffu) + w_tr * (float)(t.r0 >> 8)) + w_bl * (float)(t.r1 & 0xffu)) + w_br * (float)(t.r1 >> 8);
+}
+HSO_DEV float s_patch_sample(const uint8_t* img, int stride, double pxs0, double pxs1, int px_, int py_)
+{
+  return s_patch_value(s_patch_fetch(img, stride, pxs0, pxs1, px_, py_), pxs0, pxs1);
 }
 
 // Matcher::KLTLimited2D / KLTLimited1D (matcher.cpp:1296-1606), one lane per patch pixel.
@@ -108,7 +124,8 @@ HSO_DEV bool s_klt_limited(const uint8_t* img, int cols, int rows, float gxr, fl
     const float sx = bestU - (float)u_r, sy = bestV - (float)v_r;
     const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy), wBR = sx * sy;
     const uint8_t* it = img + (v_r + py_ - 4) * cols + u_r - 4 + px_;
-    const float sp = ((wTL * (float)it[0] + wTR * (float)it[1]) + wBL * (float)it[cols]) + wBR * (float)it[cols + 1];
+    const unsigned it0 = load_px_pair(it), it1 = load_px_pair(it + cols);
+    const float sp = ((wTL * (float)(it0 & 0xffu) + wTR * (float)(it0 >> 8)) + wBL * (float)(it1 & 0xffu)) + wBR * (float)(it1 >> 8);
     last_sample = sp; sampled = true;
     const float res = (sp - ref_px) + mean_diff;
     const float j0 = -wave_sum_all((res * Jx) * wgt);
@@ -303,10 +320,20 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     double uvb0 = 0, uvb1 = 0;
     int loopCounter = 0, loopCBest = -1, loopCSecond = -1;
     double cpx = pxf0, cpy = pxf1;
+    // the steps are independent and their positions known in advance: the bytes of step k+1 are requested before the three
+    // dependent wave sums of step k, so the march pays one memory latency per step less (positions are wave-uniform)
+    const int lim_x = W / (1 << sl) - 8, lim_y = H / (1 << sl) - 8;
+    auto in_image = [&](double x, double y) { const int ox = (int)x, oy = (int)y; return ox >= 8 && ox < lim_x && oy >= 8 && oy < lim_y; };
+    bool have = in_image(cpx, cpy);
+    PatchTaps taps = { 0, 0 };
+    if (have) taps = s_patch_fetch(cur, cols, cpx, cpy, px_, py_);
     while ((((incx < 0) == (cpx > pxc0)) && ((incy < 0) == (cpy > pxc1))) || loopCounter == 0) {
-      const int ox = (int)cpx, oy = (int)cpy;
-      if (ox >= 8 && ox < W / (1 << sl) - 8 && oy >= 8 && oy < H / (1 << sl) - 8) {
-        const float sp = s_patch_sample(cur, cols, cpx, cpy, px_, py_);
+      const double nx = cpx + incx, ny = cpy + incy;
+      const bool have_next = in_image(nx, ny);
+      PatchTaps taps_next = { 0, 0 };
+      if (have_next) taps_next = s_patch_fetch(cur, cols, nx, ny, px_, py_);
+      if (have) {
+        const float sp = s_patch_value(taps, cpx, cpy);
         const float tmean = wave_sum_all(sp) / 64;
         const float t = sp - tmean;
         const float num = wave_sum_all(hdev * t), d2 = wave_sum_all(t * t);
@@ -318,7 +345,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
           zmncc_second = zmncc; loopCSecond = loopCounter;
         }
       }
-      cpx += incx; cpy += incy; loopCounter++;
+      cpx = nx; cpy = ny; have = have_next; taps = taps_next; loopCounter++;
       if (loopCounter > 4096) break;  // defensive bound (NaN increments would never terminate)
     }
     o.n_steps = loopCounter; o.zmncc_best = zmncc_best; o.zmncc_second = zmncc_second;
