@@ -224,6 +224,13 @@ class BaResult(C.Structure):
                 ("iterations", C.c_int32), ("n_solves", C.c_int32), ("n_accepted", C.c_int32), ("stop", C.c_int32)]
 
 
+class BaProblem(C.Structure):
+    _fields_ = [("poses_f_w", C.c_void_p), ("pose_fixed", C.c_void_p), ("idist", C.c_void_p), ("edges", C.c_void_p),
+                ("edge_chi2_out", C.c_void_p), ("result", C.c_void_p),
+                ("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32), ("n_iter", C.c_int32),
+                ("huber_corner", C.c_double), ("huber_edge", C.c_double)]
+
+
 def ba_alloc(n_poses, n_points, n_edges):
     """Output buffers of hso_gpu_ba_linearize."""
     return dict(Hpp=np.zeros(n_points), bp=np.zeros(n_points), Hpc=np.zeros((n_points, n_poses, 6)),
@@ -297,6 +304,9 @@ def load():
     lib.hso_gpu_ba_linearize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double] + [vp] * 8
     lib.hso_gpu_ba_huber_deltas.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, C.c_double, P(C.c_float), P(C.c_float)]
     lib.hso_gpu_ba_optimize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double, i32, vp, P(BaResult)]
+    lib.hso_gpu_ba_optimize_multi.argtypes = [vp, P(BaProblem), i32]
+    lib.hso_gpu_seed_activate_multi.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), P(i32), P(ActivateOut),
+                                                P(AlignOut)]
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_observe_multi.argtypes = [vp, P(Camera), P(SeedFrame), i32, vp, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
@@ -335,7 +345,8 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
-    "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize",
+    "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize", "hso_gpu_ba_optimize_multi",
+    "hso_gpu_seed_activate_multi",
     "hso_gpu_seed_reproject_match",
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
@@ -591,6 +602,26 @@ class Context:
                     "ba_optimize")
         return list(parr), idist, chi2, res
 
+    def ba_optimize_multi(self, problems):
+        """problems: list of (poses, fixed, idist, edges, huber_corner, huber_edge, n_iter); one call, the windows advance in
+        lockstep.  Returns a list of (poses, idist, edge_chi2, BaResult)."""
+        keep, arr = [], (BaProblem * len(problems))()
+        for q, (poses, fixed, idist, edges, hc, he, n_iter) in enumerate(problems):
+            parr = (SE3 * len(poses))(*poses)
+            fixed = np.ascontiguousarray(fixed, np.uint8)
+            idist = np.array(idist, np.float64)
+            edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+            chi2 = np.zeros(len(edges))
+            res = BaResult()
+            keep.append((parr, fixed, idist, edges, chi2, res))
+            P_ = arr[q]
+            P_.poses_f_w = C.cast(parr, C.c_void_p).value; P_.pose_fixed = fixed.ctypes.data; P_.idist = idist.ctypes.data
+            P_.edges = edges.ctypes.data; P_.edge_chi2_out = chi2.ctypes.data; P_.result = C.addressof(res)
+            P_.n_poses, P_.n_points, P_.n_edges, P_.n_iter = len(poses), len(idist), len(edges), n_iter
+            P_.huber_corner, P_.huber_edge = hc, he
+        self._check(self.lib.hso_gpu_ba_optimize_multi(self.h, arr, len(problems)), "ba_optimize_multi")
+        return [(list(k[0]), k[2], k[4], k[5]) for k in keep]
+
     # -- depth-filter seed observation
     def seed_observe(self, cam, cur_frame_id, cur_T_f_w, cur_exposure, px_error_angle, seeds, as_list=True):
         arr = seeds if isinstance(seeds, C.Array) else (Seed * len(seeds))(*seeds)
@@ -729,6 +760,21 @@ class Context:
                                                    n_mean_converge_frame, out, mo), "seed_activate")
         if want_matches:
             return list(out), [list(mo[begin[i]:begin[i + 1]]) for i in range(len(seeds))]
+        return list(out)
+
+    def seed_activate_multi(self, cam, seeds, targets_per_seed, n_mean_converge_frame):
+        """The converged seeds of many sequences in one call; n_mean_converge_frame: one value per seed."""
+        begin = np.zeros(len(seeds) + 1, np.int32)
+        begin[1:] = np.cumsum([len(t) for t in targets_per_seed])
+        flat = [t for ts in targets_per_seed for t in ts]
+        sarr = (Seed * len(seeds))(*seeds)
+        tarr = (ActivateTarget * max(len(flat), 1))(*flat)
+        nm = np.ascontiguousarray(n_mean_converge_frame, np.int32)
+        assert len(nm) == len(seeds)
+        out = (ActivateOut * len(seeds))()
+        self._check(self.lib.hso_gpu_seed_activate_multi(self.h, C.byref(cam), sarr, len(seeds),
+                                                         begin.ctypes.data_as(C.POINTER(C.c_int32)), tarr,
+                                                         nm.ctypes.data_as(C.POINTER(C.c_int32)), out, None), "seed_activate_multi")
         return list(out)
 
     def tracker_eval(self, cam, params, job, level, T, exposure_rat, huber=-1.0, outlier=-1.0,

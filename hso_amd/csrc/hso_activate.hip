@@ -25,6 +25,7 @@ struct ActSeedDev {
   const uint8_t* ref_base;
   hso_seed s;
   int32_t first, count;  // range in the pair arrays
+  int32_t n_mean_converge_frame, _pad;   // DepthFilter::nMeanConvergeFrame_ of the sequence the seed belongs to
 };
 
 struct ActPairIn {
@@ -173,8 +174,7 @@ HSO_DEV double act_energy_term(const hso_seed& S, const ActLane& A, bool edge, d
 
 #define ACT_OPT_WAVES 4
 __global__ __launch_bounds__(64 * ACT_OPT_WAVES) void k_activate_opt(ActConsts C, const ActSeedDev* seeds, int n_seeds,
-                                                                     const ActPair* pairs, int n_mean_converge_frame,
-                                                                     hso_activate_out* outs)
+                                                                     const ActPair* pairs, hso_activate_out* outs)
 {
   const int lane = threadIdx.x & 63;
   const int sid = blockIdx.x * ACT_OPT_WAVES + (threadIdx.x >> 6);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * ACT_OPT_WAVES) void k_activate_opt(ActConsts C
   }
   const int n_targets = __popcll(__ballot(is_target)), n_res = __popcll(__ballot(A.matched));
   o.n_targets = n_targets;
-  float n_frame_thresh = (float)((double)n_mean_converge_frame * 0.7);
+  float n_frame_thresh = (float)((double)seeds[sid].n_mean_converge_frame * 0.7);
   if (n_frame_thresh > 8) n_frame_thresh = 8;
   if (n_frame_thresh < 3) n_frame_thresh = 3;
   if ((float)n_targets < n_frame_thresh) { if (lane == 0) outs[sid] = o; return; }
@@ -310,9 +310,10 @@ __global__ __launch_bounds__(64 * ACT_OPT_WAVES) void k_activate_opt(ActConsts C
   if (lane == 0) outs[sid] = o;
 }
 
-extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
-                                     const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
-                                     hso_activate_out* out, hso_align_out* match_out)
+// n_mean_per_seed == nullptr: every seed uses n_mean_all
+static int seed_activate_impl(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
+                              const int32_t* target_begin, const hso_activate_target* targets, const int32_t* n_mean_per_seed,
+                              int n_mean_all, hso_activate_out* out, hso_align_out* match_out)
 {
   if (!ctx) return HSO_E_INVALID;
   if (!cam || n_seeds < 0 || (n_seeds > 0 && (!seeds || !target_begin || !out))) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad argument");
@@ -333,6 +334,7 @@ extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, co
     if (!same_geom(itr->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
     if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad level");
     hs[i].ref_base = itr->second.base; hs[i].s = seeds[i]; hs[i].first = b; hs[i].count = e - b;
+    hs[i].n_mean_converge_frame = n_mean_per_seed ? n_mean_per_seed[i] : n_mean_all; hs[i]._pad = 0;
     for (int k = b; k < e; k++) {
       auto itt = ctx->frames.find(targets[k].frame_id);
       if (itt == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: target frame not resident");
@@ -367,8 +369,7 @@ extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, co
     hipLaunchKernelGGL(k_activate_match, dim3(blocks), dim3(64 * ACT_WAVES_PER_BLOCK), 0, ctx->stream, C, d_seeds, d_pin, n_pairs, d_pout);
     HSO_HIP_CHECK(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_activate_opt, dim3((n_seeds + ACT_OPT_WAVES - 1) / ACT_OPT_WAVES), dim3(64 * ACT_OPT_WAVES), 0, ctx->stream, C, d_seeds, n_seeds, d_pout,
-                     n_mean_converge_frame, d_out);
+  hipLaunchKernelGGL(k_activate_opt, dim3((n_seeds + ACT_OPT_WAVES - 1) / ACT_OPT_WAVES), dim3(64 * ACT_OPT_WAVES), 0, ctx->stream, C, d_seeds, n_seeds, d_pout, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_seeds * sizeof(hso_activate_out), hipMemcpyDeviceToHost, ctx->stream));
   std::vector<ActPair> hpo;
@@ -379,6 +380,21 @@ extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, co
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (match_out) for (int k = 0; k < n_pairs; k++) match_out[k] = hpo[k].mo;
   return HSO_OK;
+}
+
+extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
+                                     const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
+                                     hso_activate_out* out, hso_align_out* match_out)
+{
+  return seed_activate_impl(ctx, cam, seeds, n_seeds, target_begin, targets, nullptr, n_mean_converge_frame, out, match_out);
+}
+
+extern "C" int hso_gpu_seed_activate_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
+                                           const int32_t* target_begin, const hso_activate_target* targets,
+                                           const int32_t* n_mean_converge_frame, hso_activate_out* out, hso_align_out* match_out)
+{
+  if (ctx && n_seeds > 0 && !n_mean_converge_frame) return hso_fail(ctx, HSO_E_INVALID, "seed_activate_multi: null n_mean_converge_frame");
+  return seed_activate_impl(ctx, cam, seeds, n_seeds, target_begin, targets, n_mean_converge_frame, 0, out, match_out);
 }
 
 // Reprojector::reprojectorSeed (reference src/reprojector.cpp:504-529 for seeds: :531-554) + Matcher::findMatchSeed

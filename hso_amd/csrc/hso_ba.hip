@@ -321,6 +321,8 @@ struct BaDev {
   char* d;
   char* h;
   BaArgs a;
+  std::vector<int> off, list, poff, plist;   // CSR of edges by point / by pose-pair block (host copies, uploaded by ba_place)
+  double huber_corner, huber_edge;
 };
 
 static int ba_check_edges(hso_gpu_ctx* ctx, const hso_ba_edge* edges, int n_edges, int n_points, int n_poses, const char* who)
@@ -336,14 +338,15 @@ static int ba_check_edges(hso_gpu_ctx* ctx, const hso_ba_edge* edges, int n_edge
   return HSO_OK;
 }
 
-// lay the problem out in the work area and upload everything that does not change between evaluations
-static int ba_setup(BaDev& B, hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, const double* idist,
-                    int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge)
+// sizes, offsets and the two CSR tables of one problem (no device work)
+static void ba_layout(BaDev& B, hso_gpu_ctx* ctx, int n_poses, int n_points, const hso_ba_edge* edges, int n_edges,
+                      double huber_corner, double huber_edge)
 {
   B.ctx = ctx; B.n_poses = n_poses; B.n_points = n_points; B.n_edges = n_edges;
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  B.huber_corner = huber_corner; B.huber_edge = huber_edge;
   // CSR of edges by point, edge order kept inside a point (g2o visits edges in insertion order)
-  std::vector<int> off(n_points + 1, 0), list(n_edges);
+  std::vector<int>& off = B.off; std::vector<int>& list = B.list;
+  off.assign(n_points + 1, 0); list.assign(n_edges, 0);
   for (int k = 0; k < n_edges; k++) off[edges[k].point + 1]++;
   for (int p = 0; p < n_points; p++) off[p + 1] += off[p];
   { std::vector<int> cur(off.begin(), off.end() - 1); for (int k = 0; k < n_edges; k++) list[cur[edges[k].point]++] = k; }
@@ -352,7 +355,8 @@ static int ba_setup(BaDev& B, hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const 
   const int n_pairs = n_poses * (n_poses + 1) / 2;
   B.n_pairs = n_pairs;
   auto pair_id = [n_poses](int i, int j) { return i * n_poses - i * (i - 1) / 2 + (j - i); };  // i <= j
-  std::vector<int> poff(n_pairs + 1, 0), plist((size_t)3 * n_edges);
+  std::vector<int>& poff = B.poff; std::vector<int>& plist = B.plist;
+  poff.assign(n_pairs + 1, 0); plist.assign((size_t)3 * n_edges, 0);
   for (int k = 0; k < n_edges; k++) {
     const int h_ = edges[k].host, t_ = edges[k].target;
     poff[pair_id(h_, h_) + 1]++; poff[pair_id(t_, t_) + 1]++;
@@ -391,36 +395,59 @@ static int ba_setup(BaDev& B, hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const 
   B.o_chi = o; o += al(sizeof(double) * n_edges);
   B.o_sum = o; o += 256;
   B.total = o;
-  if (ctx->batch_cap < o) {  // grow-only work area of the context (shared with the other batched entry points)
+}
+
+// one grow-only device work area + pinned staging for a set of problems laid out one after the other
+static int ba_reserve(hso_gpu_ctx* ctx, size_t dev_bytes, size_t pinned_bytes, char** d, char** h)
+{
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (ctx->batch_cap < dev_bytes) {  // grow-only work area of the context (shared with the other batched entry points)
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), o));
-    ctx->batch_cap = o;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), dev_bytes));
+    ctx->batch_cap = dev_bytes;
   }
-  B.d = reinterpret_cast<char*>(ctx->d_batch);
-  B.h = hso_pinned(ctx, 0, B.in_bytes);
-  if (!B.h) return HSO_E_NOMEM;
-  char* h = B.h;
+  *d = reinterpret_cast<char*>(ctx->d_batch);
+  *h = hso_pinned(ctx, 0, pinned_bytes);
+  return *h ? HSO_OK : HSO_E_NOMEM;
+}
+
+// put a laid-out problem at d / h and upload everything that does not change between evaluations
+static int ba_place(BaDev& B, char* d, char* h, const hso_se3* poses_f_w, const uint8_t* pose_fixed, const double* idist,
+                    const hso_ba_edge* edges)
+{
+  hso_gpu_ctx* ctx = B.ctx;
+  const int n_poses = B.n_poses, n_points = B.n_points, n_edges = B.n_edges;
+  B.d = d; B.h = h;
   memset(h, 0, B.in_bytes);
   memcpy(h + B.o_poses, poses_f_w, sizeof(hso_se3) * n_poses);
   memcpy(h + B.o_fixed, pose_fixed, n_poses);
   memcpy(h + B.o_idist, idist, sizeof(double) * n_points);
   memcpy(h + B.o_edges, edges, sizeof(hso_ba_edge) * n_edges);
-  memcpy(h + B.o_off, off.data(), sizeof(int) * (n_points + 1));
-  memcpy(h + B.o_list, list.data(), sizeof(int) * n_edges);
-  memcpy(h + B.o_poff, poff.data(), sizeof(int) * (n_pairs + 1));
-  memcpy(h + B.o_plist, plist.data(), sizeof(int) * 3 * (size_t)n_edges);
+  memcpy(h + B.o_off, B.off.data(), sizeof(int) * (n_points + 1));
+  memcpy(h + B.o_list, B.list.data(), sizeof(int) * n_edges);
+  memcpy(h + B.o_poff, B.poff.data(), sizeof(int) * (B.n_pairs + 1));
+  memcpy(h + B.o_plist, B.plist.data(), sizeof(int) * 3 * (size_t)n_edges);
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d, h, B.in_bytes, hipMemcpyHostToDevice, ctx->stream));
-  char* d = B.d;
   BaArgs& a = B.a;
   a.poses = reinterpret_cast<const hso_se3*>(d + B.o_poses); a.fixed = reinterpret_cast<const uint8_t*>(d + B.o_fixed);
   a.idist = reinterpret_cast<const double*>(d + B.o_idist); a.edges = reinterpret_cast<const hso_ba_edge*>(d + B.o_edges);
   a.n_poses = n_poses; a.n_points = n_points; a.n_edges = n_edges;
-  a.huber_corner = huber_corner; a.huber_edge = huber_edge;
+  a.huber_corner = B.huber_corner; a.huber_edge = B.huber_edge;
   a.lin = reinterpret_cast<double*>(d + B.o_lin); a.edge_err = reinterpret_cast<double*>(d + B.o_err);
   a.edge_chi2 = reinterpret_cast<double*>(d + B.o_chi); a.edge_rho = reinterpret_cast<double*>(d + B.o_rho);
   return HSO_OK;
+}
+
+// single problem: layout + reserve + place
+static int ba_setup(BaDev& B, hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, const double* idist,
+                    int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge)
+{
+  ba_layout(B, ctx, n_poses, n_points, edges, n_edges, huber_corner, huber_edge);
+  char *d, *h;
+  if (int rc = ba_reserve(ctx, B.total, B.in_bytes, &d, &h)) return rc;
+  return ba_place(B, d, h, poses_f_w, pose_fixed, idist, edges);
 }
 
 // new state -> device (poses and inverse depths sit next to each other at the start of the work area)
@@ -743,103 +770,198 @@ struct SchurSolver {
 
 }  // namespace
 
+// One local-BA problem being optimised: the Levenberg loop of OptimizationAlgorithmLevenberg::solve written as a state
+// machine, so that many problems advance in lockstep — advance() does host work until the next device result is needed,
+// queues the device work on the context's stream and returns; the caller synchronises ONCE for all problems and calls
+// advance() again.  The arithmetic per problem is the same statement sequence whether it runs alone or among others.
+struct BaLm {
+  enum State { INIT_WAIT, ITER_BEGIN, LIN_WAIT, TRIAL_BEGIN, TRIAL_WAIT, FINISH, CHI_WAIT, DONE };
+  hso_gpu_ctx* ctx;
+  BaDev B;
+  SchurSolver sol;
+  hso_se3* poses_f_w; const uint8_t* pose_fixed; double* idist;
+  int n_poses, n_points, n_edges, n_iter;
+  double* edge_chi2_out; hso_ba_result* result;
+  std::vector<double> Hpp, bp, Hpc, Hcc, bc, xp, xc, idist_bak;
+  std::vector<hso_se3> poses_bak;
+  double chi[2];
+  double lambda, ni, currentChi, tempChi, iniChi, rho;
+  int nBad, stop, it, qmax;
+  bool ok2;
+  State st;
+
+  int begin()   // runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()
+  {
+    memset(result, 0, sizeof(*result));
+    Hpp.resize(n_points); bp.resize(n_points); Hpc.resize((size_t)n_points * n_poses * 6); Hcc.resize((size_t)n_poses * n_poses * 36);
+    bc.resize((size_t)n_poses * 6); xp.resize(n_points); xc.resize((size_t)n_poses * 6); idist_bak.resize(n_points);
+    poses_bak.resize(n_poses);
+    chi[0] = chi[1] = 0;
+    lambda = -1.; ni = 2.; nBad = 0; stop = 0; it = 0; qmax = 0; rho = 0; currentChi = tempChi = iniChi = 0; ok2 = true;
+    if (int rc = ba_launch_errors(B)) return rc;
+    if (int rc = ba_get(B, chi, B.o_sum, sizeof(chi))) return rc;
+    st = INIT_WAIT;
+    return HSO_OK;
+  }
+
+  // returns < 0 on error; afterwards st == DONE or device work is queued and a synchronise is due
+  int advance()
+  {
+    for (;;) {
+      switch (st) {
+        case INIT_WAIT:
+          result->init_chi2 = chi[0];
+          result->robust_chi2 = chi[1];
+          st = ITER_BEGIN;
+          break;
+        case ITER_BEGIN: {
+          if (it >= n_iter) { st = FINISH; break; }
+          // solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem
+          if (int rc = ba_launch_linearize(B)) return rc;
+          int rc = ba_get(B, Hpp.data(), B.o_Hpp, sizeof(double) * n_points);
+          if (!rc) rc = ba_get(B, bp.data(), B.o_bp, sizeof(double) * n_points);
+          if (!rc) rc = ba_get(B, Hpc.data(), B.o_Hpc, sizeof(double) * Hpc.size());
+          if (!rc) rc = ba_get(B, Hcc.data(), B.o_Hcc, sizeof(double) * Hcc.size());
+          if (!rc) rc = ba_get(B, bc.data(), B.o_bc, sizeof(double) * bc.size());
+          if (!rc) rc = ba_get(B, chi, B.o_sum, sizeof(chi));
+          if (rc) return rc;
+          st = LIN_WAIT;
+          return HSO_OK;
+        }
+        case LIN_WAIT:
+          currentChi = chi[1]; tempChi = currentChi;
+          iniChi = currentChi;
+          if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices
+            double maxDiagonal = 0.;
+            for (int p = 0; p < n_points; p++) maxDiagonal = std::max(std::fabs(Hpp[p]), maxDiagonal);
+            for (int i = 0; i < n_poses; i++)
+              if (!pose_fixed[i]) for (int q = 0; q < 6; q++) maxDiagonal = std::max(std::fabs(Hcc[((size_t)i * n_poses + i) * 36 + q * 7]), maxDiagonal);
+            lambda = 1e-5 * maxDiagonal;
+            ni = 2; nBad = 0;
+          }
+          rho = 0; qmax = 0;
+          st = TRIAL_BEGIN;
+          break;
+        case TRIAL_BEGIN: {
+          std::copy(poses_f_w, poses_f_w + n_poses, poses_bak.begin());   // _optimizer->push()
+          std::copy(idist, idist + n_points, idist_bak.begin());
+          ok2 = sol.solve(Hpp.data(), bp.data(), Hpc.data(), Hcc.data(), bc.data(), lambda, xp.data(), xc.data());
+          result->n_solves++;
+          for (int p = 0; p < n_points; p++) idist[p] += xp[p];                          // VertexSBAPointID::oplusImpl
+          for (int i = 0; i < n_poses; i++) if (!pose_fixed[i]) se3quat_exp_times(&xc[(size_t)i * 6], poses_f_w[i]);  // VertexSE3Expmap::oplusImpl
+          int rc = ba_put_state(B, poses_f_w, idist);
+          if (!rc) rc = ba_launch_errors(B);
+          if (!rc) rc = ba_get(B, chi, B.o_sum, sizeof(chi));
+          if (rc) return rc;
+          st = TRIAL_WAIT;
+          return HSO_OK;
+        }
+        case TRIAL_WAIT: {
+          tempChi = ok2 ? chi[1] : 1.7976931348623157e308;
+          rho = currentChi - tempChi;
+          double scale = 0.;                                               // computeScale
+          for (int p = 0; p < n_points; p++) scale += xp[p] * (lambda * xp[p] + bp[p]);
+          for (int i = 0; i < n_poses; i++)
+            if (!pose_fixed[i]) for (int q = 0; q < 6; q++) scale += xc[i * 6 + q] * (lambda * xc[i * 6 + q] + bc[i * 6 + q]);
+          scale += 1e-3;
+          rho /= scale;
+          if (rho > 0 && std::isfinite(tempChi)) {
+            double alpha = 1. - std::pow((2 * rho - 1), 3);
+            alpha = std::min(alpha, 2. / 3.);
+            lambda *= std::max(1. / 3., alpha);
+            ni = 2;
+            currentChi = tempChi;
+            result->n_accepted++;
+          } else {
+            lambda *= ni;
+            ni *= 2;
+            std::copy(poses_bak.begin(), poses_bak.end(), poses_f_w);     // _optimizer->pop(): vertices only, edge errors stay
+            std::copy(idist_bak.begin(), idist_bak.end(), idist);
+            if (int rc2 = ba_put_state(B, poses_f_w, idist)) return rc2;
+          }
+          qmax++;
+          if (rho < 0 && qmax < 5) { st = TRIAL_BEGIN; break; }   // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
+          result->iterations = it + 1;
+          result->robust_chi2 = currentChi;
+          if (qmax == 5 || rho == 0) { stop = 1; st = FINISH; break; }
+          if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
+          if (nBad >= 3) { stop = 2; st = FINISH; break; }
+          it++;
+          st = ITER_BEGIN;
+          break;
+        }
+        case FINISH:
+          result->stop = stop;
+          result->lambda = lambda;
+          result->final_chi2 = chi[0];   // activeChi2() of the last computeActiveErrors
+          if (edge_chi2_out) {
+            if (int rc = ba_get(B, edge_chi2_out, B.o_chi, sizeof(double) * n_edges)) return rc;
+            st = CHI_WAIT;
+            return HSO_OK;
+          }
+          st = DONE;
+          return HSO_OK;
+        case CHI_WAIT:
+          st = DONE;
+          return HSO_OK;
+        case DONE:
+          return HSO_OK;
+      }
+    }
+  }
+};
+
+// pinned staging is used by ba_put_state of every problem between two synchronises: each problem keeps its own slice
+extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_problems < 0 || (n_problems > 0 && !problems)) return hso_fail(ctx, HSO_E_INVALID, "ba_optimize_multi: bad argument");
+  if (n_problems == 0) return HSO_OK;
+  std::vector<BaLm> lm(n_problems);
+  size_t dev = 0, pin = 0;
+  std::vector<size_t> d_off(n_problems), h_off(n_problems);
+  for (int q = 0; q < n_problems; q++) {
+    const hso_ba_problem& P = problems[q];
+    if (!P.poses_f_w || !P.pose_fixed || !P.idist || !P.edges || !P.result || P.n_poses <= 0 || P.n_points <= 0 || P.n_edges <= 0 || P.n_iter < 0)
+      return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: bad argument");
+    if (int rc = ba_check_edges(ctx, P.edges, P.n_edges, P.n_points, P.n_poses, "ba_optimize")) return rc;
+    BaLm& L = lm[q];
+    L.ctx = ctx; L.poses_f_w = P.poses_f_w; L.pose_fixed = P.pose_fixed; L.idist = P.idist;
+    L.n_poses = P.n_poses; L.n_points = P.n_points; L.n_edges = P.n_edges; L.n_iter = P.n_iter;
+    L.edge_chi2_out = P.edge_chi2_out; L.result = P.result;
+    ba_layout(L.B, ctx, P.n_poses, P.n_points, P.edges, P.n_edges, P.huber_corner, P.huber_edge);
+    d_off[q] = dev; dev += L.B.total;
+    h_off[q] = pin; pin += L.B.in_bytes;
+  }
+  char *d, *h;
+  if (int rc = ba_reserve(ctx, dev, pin, &d, &h)) return rc;
+  for (int q = 0; q < n_problems; q++) {
+    const hso_ba_problem& P = problems[q];
+    if (int rc = ba_place(lm[q].B, d + d_off[q], h + h_off[q], P.poses_f_w, P.pose_fixed, P.idist, P.edges)) return rc;
+    lm[q].sol.init(P.n_points, P.n_poses, P.pose_fixed, P.edges, P.n_edges);
+    if (int rc = lm[q].begin()) return rc;
+  }
+  for (;;) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    bool pending = false;
+    for (int q = 0; q < n_problems; q++) {
+      if (lm[q].st == BaLm::DONE) continue;
+      if (int rc = lm[q].advance()) return rc;
+      if (lm[q].st != BaLm::DONE) pending = true;
+    }
+    if (!pending) break;
+  }
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
 extern "C" int hso_gpu_ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, double* idist,
                                    int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge,
                                    int n_iter, double* edge_chi2_out, hso_ba_result* result)
 {
-  if (!ctx) return HSO_E_INVALID;
-  if (!poses_f_w || !pose_fixed || !idist || !edges || !result || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || n_iter < 0)
-    return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: bad argument");
-  if (int rc = ba_check_edges(ctx, edges, n_edges, n_points, n_poses, "ba_optimize")) return rc;
-  memset(result, 0, sizeof(*result));
-  BaDev B;
-  if (int rc = ba_setup(B, ctx, poses_f_w, pose_fixed, n_poses, idist, n_points, edges, n_edges, huber_corner, huber_edge)) return rc;
-  SchurSolver sol;
-  sol.init(n_points, n_poses, pose_fixed, edges, n_edges);
-  std::vector<double> Hpp(n_points), bp(n_points), Hpc((size_t)n_points * n_poses * 6), Hcc((size_t)n_poses * n_poses * 36),
-      bc((size_t)n_poses * 6), xp(n_points), xc((size_t)n_poses * 6), idist_bak(n_points);
-  std::vector<hso_se3> poses_bak(n_poses);
-  double chi[2] = { 0, 0 };
-  auto sync = [&]() -> int { HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return HSO_OK; };
-
-  // runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()
-  if (int rc = ba_launch_errors(B)) return rc;
-  if (int rc = ba_get(B, chi, B.o_sum, sizeof(chi))) return rc;
-  if (int rc = sync()) return rc;
-  result->init_chi2 = chi[0];
-  result->robust_chi2 = chi[1];
-  double lambda = -1., ni = 2.;
-  int nBad = 0, stop = 0;
-  for (int it = 0; it < n_iter; it++) {
-    // solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem
-    if (int rc = ba_launch_linearize(B)) return rc;
-    int rc = ba_get(B, Hpp.data(), B.o_Hpp, sizeof(double) * n_points);
-    if (!rc) rc = ba_get(B, bp.data(), B.o_bp, sizeof(double) * n_points);
-    if (!rc) rc = ba_get(B, Hpc.data(), B.o_Hpc, sizeof(double) * Hpc.size());
-    if (!rc) rc = ba_get(B, Hcc.data(), B.o_Hcc, sizeof(double) * Hcc.size());
-    if (!rc) rc = ba_get(B, bc.data(), B.o_bc, sizeof(double) * bc.size());
-    if (!rc) rc = ba_get(B, chi, B.o_sum, sizeof(chi));
-    if (!rc) rc = sync();
-    if (rc) return rc;
-    double currentChi = chi[1], tempChi = currentChi;
-    const double iniChi = currentChi;
-    if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices
-      double maxDiagonal = 0.;
-      for (int p = 0; p < n_points; p++) maxDiagonal = std::max(std::fabs(Hpp[p]), maxDiagonal);
-      for (int i = 0; i < n_poses; i++)
-        if (!pose_fixed[i]) for (int q = 0; q < 6; q++) maxDiagonal = std::max(std::fabs(Hcc[((size_t)i * n_poses + i) * 36 + q * 7]), maxDiagonal);
-      lambda = 1e-5 * maxDiagonal;
-      ni = 2; nBad = 0;
-    }
-    double rho = 0;
-    int qmax = 0;
-    do {
-      std::copy(poses_f_w, poses_f_w + n_poses, poses_bak.begin());   // _optimizer->push()
-      std::copy(idist, idist + n_points, idist_bak.begin());
-      const bool ok2 = sol.solve(Hpp.data(), bp.data(), Hpc.data(), Hcc.data(), bc.data(), lambda, xp.data(), xc.data());
-      result->n_solves++;
-      for (int p = 0; p < n_points; p++) idist[p] += xp[p];                          // VertexSBAPointID::oplusImpl
-      for (int i = 0; i < n_poses; i++) if (!pose_fixed[i]) se3quat_exp_times(&xc[(size_t)i * 6], poses_f_w[i]);  // VertexSE3Expmap::oplusImpl
-      rc = ba_put_state(B, poses_f_w, idist);
-      if (!rc) rc = ba_launch_errors(B);
-      if (!rc) rc = ba_get(B, chi, B.o_sum, sizeof(chi));
-      if (!rc) rc = sync();
-      if (rc) return rc;
-      tempChi = ok2 ? chi[1] : 1.7976931348623157e308;
-      rho = currentChi - tempChi;
-      double scale = 0.;                                               // computeScale
-      for (int p = 0; p < n_points; p++) scale += xp[p] * (lambda * xp[p] + bp[p]);
-      for (int i = 0; i < n_poses; i++)
-        if (!pose_fixed[i]) for (int q = 0; q < 6; q++) scale += xc[i * 6 + q] * (lambda * xc[i * 6 + q] + bc[i * 6 + q]);
-      scale += 1e-3;
-      rho /= scale;
-      if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
-        alpha = std::min(alpha, 2. / 3.);
-        lambda *= std::max(1. / 3., alpha);
-        ni = 2;
-        currentChi = tempChi;
-        result->n_accepted++;
-      } else {
-        lambda *= ni;
-        ni *= 2;
-        std::copy(poses_bak.begin(), poses_bak.end(), poses_f_w);     // _optimizer->pop(): vertices only, edge errors stay
-        std::copy(idist_bak.begin(), idist_bak.end(), idist);
-        if (int rc2 = ba_put_state(B, poses_f_w, idist)) return rc2;
-      }
-      qmax++;
-    } while (rho < 0 && qmax < 5);   // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
-    result->iterations = it + 1;
-    result->robust_chi2 = currentChi;
-    if (qmax == 5 || rho == 0) { stop = 1; break; }
-    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
-    if (nBad >= 3) { stop = 2; break; }
-  }
-  result->stop = stop;
-  result->lambda = lambda;
-  result->final_chi2 = chi[0];   // activeChi2() of the last computeActiveErrors
-  if (edge_chi2_out) {
-    if (int rc = ba_get(B, edge_chi2_out, B.o_chi, sizeof(double) * n_edges)) return rc;
-  }
-  return sync();
+  hso_ba_problem P;
+  P.poses_f_w = poses_f_w; P.pose_fixed = pose_fixed; P.n_poses = n_poses; P.idist = idist; P.n_points = n_points;
+  P.edges = edges; P.n_edges = n_edges; P.huber_corner = huber_corner; P.huber_edge = huber_edge; P.n_iter = n_iter;
+  P.edge_chi2_out = edge_chi2_out; P.result = result;
+  return hso_gpu_ba_optimize_multi(ctx, &P, 1);
 }

@@ -130,6 +130,17 @@ def main():
     dt = timed(lambda: ctx.ba_linearize(bposes, fixed, idist, edges, 1.0, 0.7), args.reps)
     out.append(dict(stage="ba_linearize", units="edges", n=len(edges), ms_per_call=dt * 1e3, units_per_s=len(edges) / dt))
 
+    # a19 complete: the Levenberg optimisation of one window, and of the windows of 32 sequences in one lockstep call
+    prob = (bposes, fixed, idist, edges, 1.0, 0.7, 10)
+    dt1 = timed(lambda: ctx.ba_optimize(*prob), max(args.reps // 4, 2))
+    r1 = ctx.ba_optimize(*prob)[3]
+    out.append(dict(stage="ba_optimize (LM: device linearisation + host Schur solve), one window", units="edges", n=len(edges),
+                    ms_per_call=dt1 * 1e3, units_per_s=len(edges) / dt1, iterations=r1.iterations, solves=r1.n_solves))
+    probs = [prob] * 32
+    dtm = timed(lambda: ctx.ba_optimize_multi(probs), 2)
+    out.append(dict(stage="ba_optimize_multi x32 windows (lockstep)", units="edges", n=32 * len(edges), ms_per_call=dtm * 1e3,
+                    units_per_s=32 * len(edges) / dtm, ms_per_window=dtm * 1e3 / 32))
+
     # section 8f rank 2: project the map points of 6 keyframes, choose reference observations, match — one call
     M = synth.map_problem(n_points=3000, first_frame_id=7000)
     for k, f in zip(M["kfs"], M["frames"]):

@@ -499,6 +499,22 @@ int hso_gpu_ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses_f_w, const uint8_t* pos
                         int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge,
                         int n_iter, double* edge_chi2_out, hso_ba_result* result);
 
+/* The local-BA windows of many sequences (one per keyframe event) in one call: the problems advance through the
+ * Levenberg loop in lockstep — per round every unfinished problem queues its next device work, ONE synchronise serves them
+ * all — so a multi-sequence driver pays one round trip per LM step instead of one per problem and step, and the small
+ * kernels of different windows run back to back.  Each problem's arithmetic is exactly that of hso_gpu_ba_optimize. */
+typedef struct hso_ba_problem {
+  hso_se3* poses_f_w;          /* in / out */
+  const uint8_t* pose_fixed;
+  double* idist;               /* in / out */
+  const hso_ba_edge* edges;
+  double* edge_chi2_out;       /* [n_edges] or NULL */
+  hso_ba_result* result;
+  int32_t n_poses, n_points, n_edges, n_iter;
+  double huber_corner, huber_edge;
+} hso_ba_problem;
+int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems);
+
 /* ---- DepthFilter seed observation: DepthFilter::observeDepthRow (src/depth_filter.cpp:580-675),
  *      updateSeed :528-537, computeTau :539-555; Matcher::doLineStereo (src/matcher.cpp:802-1049),
  *      KLTLimited2D/1D :1296-1606, warp::createPatch :159-196, ZMNCC_F
@@ -605,6 +621,11 @@ typedef struct hso_activate_out {
 int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
                           const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
                           hso_activate_out* out, hso_align_out* match_out);
+/* The same for the converged seeds of many sequences in one call (seeds and targets name their frames by id, so the tables
+ * simply concatenate): n_mean_converge_frame[i] = nMeanConvergeFrame_ of the DepthFilter seed i belongs to. */
+int hso_gpu_seed_activate_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
+                                const int32_t* target_begin, const hso_activate_target* targets,
+                                const int32_t* n_mean_converge_frame, hso_activate_out* out, hso_align_out* match_out);
 
 /* The seed branch of Reprojector::reprojectMap (src/reprojector.cpp:309-329): reprojectorSeed (:531-554) — pTarget =
  * (T_cur_w * T_ref_w^-1) * (f / mu), rejected when its z < 0.001 or its truncated pixel lies within 8 px of the border —

@@ -119,3 +119,26 @@ def test_seed_activate_errors(cam, gpu_ctx, act_problem):
         assert out[0].activated == 0 and out[0].n_targets == 0 and out[0].opt_id == s.mu
     finally:
         gpu_ctx.frame_release(P["host_frame_id"])
+
+
+@pytest.mark.gpu
+def test_seed_activate_multi_equals_per_sequence_calls(cam, gpu_ctx, act_problem):
+    """hso_gpu_seed_activate_multi: the seeds of two "sequences" with different nMeanConvergeFrame_ (6 -> threshold 4.2,
+    20 -> threshold 8) in one call return exactly the bytes of the two single calls."""
+    P = act_problem[0]
+    ids = [P["host_frame_id"]] + [t.frame_id for t in P["targets"]]
+    gpu_ctx.frame_upload(ids[0], P["host"])
+    for t, f in zip(P["targets"], P["frames"]):
+        gpu_ctx.frame_upload(t.frame_id, f)
+    try:
+        a = gpu_ctx.seed_activate(cam, P["seeds"], P["per_seed"], 6)
+        b = gpu_ctx.seed_activate(cam, P["seeds"], P["per_seed"], 20)
+        n = len(P["seeds"])
+        both = gpu_ctx.seed_activate_multi(cam, list(P["seeds"]) + list(P["seeds"]), list(P["per_seed"]) + list(P["per_seed"]),
+                                           [6] * n + [20] * n)
+    finally:
+        for i in ids:
+            gpu_ctx.frame_release(i)
+    assert [bytes(x) for x in both[:n]] == [bytes(x) for x in a]
+    assert [bytes(x) for x in both[n:]] == [bytes(x) for x in b]
+    assert any(x.activated != y.activated for x, y in zip(a, b)), "the two thresholds must differ somewhere for the test to mean anything"

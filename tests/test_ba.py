@@ -242,3 +242,22 @@ def test_ba_optimize_parity(gpu_ctx, orc, shape, seed):
         assert np.allclose(cg, co, rtol=1e-8, atol=1e-16)
     for i in np.where(fixed)[0]:
         assert pg[i].q[:] == pert[i].q[:] and pg[i].t[:] == pert[i].t[:]
+
+
+@pytest.mark.gpu
+def test_ba_optimize_multi_equals_single_calls(gpu_ctx):
+    """hso_gpu_ba_optimize_multi: three windows of different size, Huber deltas and iteration budgets advance through the
+    Levenberg loop in lockstep and return exactly what three single calls return (poses, inverse depths, per-edge chi2,
+    result records bit for bit)."""
+    problems = []
+    for shape, seed, n_iter in (((9, 300, 4), 51, 10), ((4, 60, 3), 52, 3), ((12, 500, 5), 53, 6)):
+        poses, fixed, idist, edges = synth.ba_problem(*shape, seed=seed, px_noise=0.3)
+        problems.append((poses, fixed, idist, edges, 1.0 + 0.1 * seed % 3, 0.6, n_iter))
+    singles = [gpu_ctx.ba_optimize(*p) for p in problems]
+    multi = gpu_ctx.ba_optimize_multi(problems)
+    for (ps, is_, cs, rs), (pm, im, cm, rm) in zip(singles, multi):
+        assert bytes(rs) == bytes(rm)
+        assert np.array_equal(is_, im) and np.array_equal(cs, cm)
+        for a, b_ in zip(ps, pm):
+            assert a.q[:] == b_.q[:] and a.t[:] == b_.t[:]
+    assert len({r[3].iterations for r in multi}) > 1, "the windows should not all stop together"
