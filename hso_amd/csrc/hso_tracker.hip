@@ -292,9 +292,10 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   // the smaller LDS share; a single sequence (latency, not throughput) keeps all eight wavefronts of a CU on its one job.
   st->split_level = -1;
   if (max_grid <= 0 && n_jobs >= 2 * ctx->n_cu && C.max_level >= 2 && C.min_level <= 1 && !getenv("HSO_TRACK_NO_SPLIT")) {
-    const int lvl = 2;   // levels max_level .. 2 on trk2, 1 .. min_level on trk1
+    int lvl = 2;   // levels max_level .. 2 on trk2, 1 .. min_level on trk1
+    if (getenv("HSO_TRACK_ALL_TRK2")) lvl = C.min_level;   // experiment: every level on trk2 (the finest image read from memory)
     const size_t need = (size_t)g.w[lvl] * g.h[lvl] + g.w[lvl] + 64;
-    if (need <= (size_t)trk2::kImgCap) st->split_level = lvl;
+    if (need <= (size_t)trk2::kImgCap || getenv("HSO_TRACK_ALL_TRK2")) st->split_level = lvl;
   }
   st->grid2 = std::min(n_jobs, 2 * ctx->n_cu);
   st->scratch_stride = scratch_bytes(C.n_max);
@@ -354,6 +355,7 @@ int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx)
     else
       hipLaunchKernelGGL(trk2::k_track<false>, dim3(st->grid2), dim3(256), st->lds_bytes2, ctx->stream, C, st->d_jobs, st->n_jobs, st->d_counter,
                          st->d_scratch, st->scratch_stride, st->d_results);
+    if (st->split_level <= C.min_level) { HSO_HIP_CHECK(ctx, hipGetLastError()); return HSO_OK; }   // every level ran above
     // the remaining level(s): one 512-thread workgroup per CU with the whole LDS, continuing from the records above
     C.level_first = st->split_level - 1; C.level_last = C.min_level; C.resume = 1;
   }

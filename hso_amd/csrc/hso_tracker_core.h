@@ -364,6 +364,9 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
 #ifndef TRK_ROW_WINDOWS
 #define TRK_ROW_WINDOWS 1
 #endif
+#ifndef TRK_GLOBAL_ROWS
+#define TRK_GLOBAL_ROWS 1   // pattern-specialised loops also for images left in device memory (level 0 when relocalising)
+#endif
 template <int PI>
 struct PatRows {
   static constexpr int N = h_pattern_num[PI];
@@ -423,8 +426,9 @@ HSO_DEV void sel_count_a(Shared& s, uint32_t kk);
 
 // The keys of one feature with the pattern known at compile time: the taps of the bilinear intensity come from per-row
 // windows (see feature_terms_rows below: two rows live here, no gradient), the reference intensities are requested up front.
-template <int PI, typename KP>
-__device__ __forceinline__ void collect_terms_rows(Shared& s, LdsPtr img, GlbF32 ref_patch, KP kdst, int n, int f, int base,
+typedef const __attribute__((address_space(1))) uint32_t* GlbW32;   // a level image in device memory, dword view
+template <int PI, typename KP, typename IP>
+__device__ __forceinline__ void collect_terms_rows(Shared& s, IP img, GlbF32 ref_patch, KP kdst, int n, int f, int base,
                                                    float w_tl, float w_tr, float w_bl, float w_br, uint32_t fb, uint32_t nb,
                                                    int stride, float a)
 {
@@ -491,7 +495,7 @@ HSO_DEV int select_collect(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, 
     const Proj p = project_feature(L, T, raw, border);
     if constexpr (PI >= 0) {
       if (p.ok) {
-        collect_terms_rows<PI>(s, img, (GlbF32)L.sc.ref_patch, kdst, n, f, p.base, p.w_tl, p.w_tr, p.w_bl, p.w_br, (uint32_t)f * 4u,
+        collect_terms_rows<PI, KP>(s, img, (GlbF32)L.sc.ref_patch, kdst, n, f, p.base, p.w_tl, p.w_tr, p.w_bl, p.w_br, (uint32_t)f * 4u,
                                (uint32_t)nm * 4u, stride, a);
         cnt += PA;
       } else {
@@ -757,10 +761,22 @@ HSO_DEV void select_robust_k(Shared& s, const LevelCtx& L, LdsPtr lds_img, const
         case 3: n_err = select_collect<true, LdsPtr, KP, 3>(s, L, lds_img, T, a, keys); break;
         case 4: n_err = select_collect<true, LdsPtr, KP, 4>(s, L, lds_img, T, a, keys); break;
         case 5: n_err = select_collect<true, LdsPtr, KP, 5>(s, L, lds_img, T, a, keys); break;
+        case 6: n_err = select_collect<true, LdsPtr, KP, 6>(s, L, lds_img, T, a, keys); break;
         default: n_err = select_collect<true, LdsPtr>(s, L, lds_img, T, a, keys); break;
       }
     } else {
+#if TRK_GLOBAL_ROWS
+      switch (s.pi) {
+        case 2: n_err = select_collect<true, GlbW32, KP, 2>(s, L, (GlbW32)L.cur_glb, T, a, keys); break;
+        case 3: n_err = select_collect<true, GlbW32, KP, 3>(s, L, (GlbW32)L.cur_glb, T, a, keys); break;
+        case 4: n_err = select_collect<true, GlbW32, KP, 4>(s, L, (GlbW32)L.cur_glb, T, a, keys); break;
+        case 5: n_err = select_collect<true, GlbW32, KP, 5>(s, L, (GlbW32)L.cur_glb, T, a, keys); break;
+        case 6: n_err = select_collect<true, GlbW32, KP, 6>(s, L, (GlbW32)L.cur_glb, T, a, keys); break;
+        default: n_err = select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a, keys); break;
+      }
+#else
       n_err = select_collect<true, GlbPtr>(s, L, L.cur_glb, T, a, keys);
+#endif
     }
   } else {
     n_err = s.use_lds ? select_collect<false, LdsPtr>(s, L, lds_img, T, a, keys) : select_collect<false, GlbPtr>(s, L, L.cur_glb, T, a, keys);
@@ -940,8 +956,8 @@ __device__ __forceinline__ Moments feature_terms_static(LdsPtr img, GlbF32 ref_p
 // operands) — no per-tap address arithmetic, no per-tap LDS read: 20 LDS reads per feature instead of 74 at level 1.
 // Terms are visited row by row (ascending oy), so four rows of windows are live at a time.  The order of the moment sums
 // changes with it (they are tolerance-compared); the per-term decision arithmetic is untouched.
-template <int PI>
-__device__ __forceinline__ Moments feature_terms_rows(LdsPtr img, GlbF32 ref_patch, int base, float w_tl, float w_tr, float w_bl,
+template <int PI, typename IP>
+__device__ __forceinline__ Moments feature_terms_rows(IP img, GlbF32 ref_patch, int base, float w_tl, float w_tr, float w_bl,
                                                     float w_br, uint32_t fb, uint32_t nb, int stride, float a, float huber,
                                                     float outlier, float max_energy, int top)
 {
@@ -1190,11 +1206,24 @@ HSO_DEV void eval_dispatch(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
           case 3: eval_terms<IC, true, LdsPtr, 3>(s, L, lds_img, T, a); return;
           case 4: eval_terms<IC, true, LdsPtr, 4>(s, L, lds_img, T, a); return;
           case 5: eval_terms<IC, true, LdsPtr, 5>(s, L, lds_img, T, a); return;
+          case 6: eval_terms<IC, true, LdsPtr, 6>(s, L, lds_img, T, a); return;   // level 0 (relocalisation) of a small image
           default: break;
         }
       }
       eval_terms<IC, true, LdsPtr>(s, L, lds_img, T, a);
     } else {
+#if TRK_GLOBAL_ROWS
+      if constexpr (!IC) {
+        switch (s.pi) {  // the same row-window loops on the image in device memory (a level that does not fit this shape's LDS)
+          case 2: eval_terms<IC, true, GlbW32, 2>(s, L, (GlbW32)L.cur_glb, T, a); return;
+          case 3: eval_terms<IC, true, GlbW32, 3>(s, L, (GlbW32)L.cur_glb, T, a); return;
+          case 4: eval_terms<IC, true, GlbW32, 4>(s, L, (GlbW32)L.cur_glb, T, a); return;
+          case 5: eval_terms<IC, true, GlbW32, 5>(s, L, (GlbW32)L.cur_glb, T, a); return;
+          case 6: eval_terms<IC, true, GlbW32, 6>(s, L, (GlbW32)L.cur_glb, T, a); return;
+          default: break;
+        }
+      }
+#endif
       eval_terms<IC, true, GlbPtr>(s, L, L.cur_glb, T, a);
     }
   } else {
