@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libhso_gpu.so")
 SOURCES = ["hso_ctx.hip", "hso_frame.hip", "hso_tracker.hip", "hso_align.hip", "hso_pose.hip", "hso_ba.hip",
-           "hso_seed.hip", "hso_activate.hip", "hso_fast.hip", "hso_edgelet.hip", "hso_octree.cpp"]
+           "hso_seed.hip", "hso_activate.hip", "hso_fast.hip", "hso_edgelet.hip", "hso_select.hip", "hso_octree.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

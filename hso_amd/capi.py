@@ -305,6 +305,7 @@ def load():
     lib.hso_gpu_ba_huber_deltas.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, C.c_double, P(C.c_float), P(C.c_float)]
     lib.hso_gpu_ba_optimize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double, i32, vp, P(BaResult)]
     lib.hso_gpu_ba_optimize_multi.argtypes = [vp, P(BaProblem), i32]
+    lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.hso_gpu_seed_activate_multi.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), P(i32), P(ActivateOut),
                                                 P(AlignOut)]
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
@@ -346,7 +347,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize", "hso_gpu_ba_optimize_multi",
-    "hso_gpu_seed_activate_multi",
+    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select",
     "hso_gpu_seed_reproject_match",
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
@@ -601,6 +602,23 @@ class Context:
                                                  _ptr(edges), len(edges), huber_corner, huber_edge, n_iter, _ptr(chi2), C.byref(res)),
                     "ba_optimize")
         return list(parr), idist, chi2, res
+
+    def reproject_select(self, frame_begin, cell, quality, flags, cell_order, max_fts):
+        """The cell passes of Reprojector::reprojectMap for any number of frames.  Returns (per-frame list of
+        (index, taken) in examination order, counts[n_frames, 4])."""
+        fb = np.ascontiguousarray(frame_begin, np.int32)
+        cell = np.ascontiguousarray(cell, np.int32); quality = np.ascontiguousarray(quality, np.uint8)
+        flags = np.ascontiguousarray(flags, np.uint8); order = np.ascontiguousarray(cell_order, np.int32)
+        nf = len(fb) - 1
+        out = np.zeros(max(len(cell), 1), np.int32)
+        counts = np.zeros((nf, 4), np.int32)
+        self._check(self.lib.hso_gpu_reproject_select(self.h, _ptr(fb), nf, _ptr(cell), _ptr(quality), _ptr(flags), _ptr(order),
+                                                      len(order), max_fts, _ptr(out), _ptr(counts)), "reproject_select")
+        res = []
+        for f in range(nf):
+            ex = out[fb[f]:fb[f] + counts[f, 0]].astype(np.int64)
+            res.append([(int(v & 0x7fffffff), bool(v & 0x80000000)) for v in ex])
+        return res, counts
 
     def ba_optimize_multi(self, problems):
         """problems: list of (poses, fixed, idist, edges, huber_corner, huber_edge, n_iter); one call, the windows advance in

@@ -1,0 +1,322 @@
+// hso_select.hip — the grid selection of Reprojector::reprojectMap on the device (remainder):
+// which of a frame's projected candidates are examined, in which order, and which of them become features.
+//
+// Reference: src/reprojector.cpp — reprojectMap :253-306 (reprojectCellAll when fewer than max_fts + 50 candidates were
+// projected, else three passes over the cells in `cell_order`), reprojectCell :352-429 (first visit sorts the cell with
+// pointQualityComparator :333-345 — point type, then feature type, both descending, stable; every examined candidate is
+// erased; a deleted point costs a trial and nothing else; pass 1 and 2 stop at the cell's first success, pass 3 takes up to
+// three), reprojectCellAll :556-612.  The matching itself has already happened for every candidate (hso_gpu_reproject_match
+// matches all projected points in one launch), so the policy is a pure function of (cell, quality, deleted, matched) per
+// candidate, the cell order and the budget — it only decides which results the caller applies, and in which order
+// (n_failed_reproj_ / n_succeeded_reproj_ bookkeeping and the order of frame->fts_ follow from it).
+//
+// One 256-thread workgroup per frame.  Per-cell work (sorting the few candidates of a cell, locating its successes) is one
+// thread per cell; the budget — "stop after the cell in which n_matches reaches max_fts" — is a prefix sum over the cells in
+// visiting order with a search for the cut, done per pass by the whole workgroup.  No atomics decide anything: the result is
+// deterministic, and equal to the sequential walk.
+#include "hso_ctx.h"
+#include "hso_dev_math.h"
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+using namespace hso_dev;
+
+#define SEL_THREADS 256
+#define SEL_WAVES (SEL_THREADS / 64)
+
+struct SelFrame {
+  int first, n;           // candidate range (projection order)
+  int* cnt;               // [n_cells + 1] cell start offsets into list
+  int* fill;              // [n_cells]
+  int* list;              // [n] candidates by cell, each cell ordered by (quality desc, projection order)
+  int* e1; int* e2;       // [n_cells] candidates examined in pass 1 / 2 when the cell is visited
+  int* p3;                // [3 * n_cells] pass 3: examined count when stopping at the 1st / 2nd / 3rd remaining success
+  int* a3;                // [n_cells] pass 3: successes among the remaining candidates
+  int* scan;              // [n_cells] work array of the budget scans
+  int* out;               // [n] examined candidates in order: index | taken << 31
+  int* counts;            // [4] n_examined (= n_trials), n_matches, passes run, branch (0 = all, 1 = cells)
+};
+
+struct SelArgs {
+  const int32_t* cell; const uint8_t* quality; const uint8_t* flags;   // per candidate; flags bit 0 matched, bit 1 deleted
+  const int32_t* cell_order;
+  int n_cells, max_fts;
+};
+
+// inclusive scan of v over the workgroup (SEL_THREADS values); *total = sum
+__device__ int sel_block_scan(int v, int* s_wave, int& total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  __syncthreads();
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0; total = 0;
+  for (int w = 0; w < SEL_WAVES; w++) { if (w < wave) base += s_wave[w]; total += s_wave[w]; }
+  return incl + base;
+}
+
+// For the visiting sequence k = 0 .. m-1 (cell = visit(k)) with per-cell gains gain(cell): the first k at which the running
+// sum reaches `budget` (m if never), the total gained (capped at budget) and, in `scan`, the EXCLUSIVE prefix per k.
+template <typename Visit, typename Gain>
+__device__ void sel_budget_scan(int m, int budget, Visit visit, Gain gain, int* scan, int* s_wave, int* s_cut, int& cut, int& gained)
+{
+  if (threadIdx.x == 0) *s_cut = m;
+  __syncthreads();
+  int carry = 0;
+  for (int k0 = 0; k0 < m; k0 += SEL_THREADS) {
+    const int k = k0 + (int)threadIdx.x;
+    const int g = k < m ? gain(visit(k)) : 0;
+    int tot;
+    const int incl = sel_block_scan(g, s_wave, tot) + carry;
+    if (k < m) {
+      scan[k] = incl - g;
+      if (g > 0 && incl >= budget && incl - g < budget) atomicMin(s_cut, k);
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  __syncthreads();
+  cut = *s_cut;
+  gained = carry < budget ? carry : budget;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_select(SelArgs A, const SelFrame* frames)
+{
+  __shared__ int s_wave[SEL_WAVES];
+  __shared__ int s_cut, s_n;
+  const SelFrame F = frames[blockIdx.x];
+  const int tid = threadIdx.x, n = F.n, nc = A.n_cells, budget = A.max_fts;
+  const int32_t* cell = A.cell + F.first; const uint8_t* qual = A.quality + F.first; const uint8_t* flg = A.flags + F.first;
+  auto matched = [&](int i) { return (flg[i] & 3) == 1; };   // matched and not deleted
+  auto deleted = [&](int i) { return (flg[i] & 2) != 0; };
+  if (n == 0 || budget <= 0) { if (tid == 0) { F.counts[0] = F.counts[1] = F.counts[2] = 0; F.counts[3] = 0; } return; }
+
+  if (n < budget + 50) {
+    // reprojectCellAll: projection order; every candidate costs a trial; stop when the budget is met
+    int cut, gained;
+    sel_budget_scan(n, budget, [](int k) { return k; }, [&](int i) { return matched(i) ? 1 : 0; }, F.scan /* >= n_cells? see host */, s_wave, &s_cut, cut, gained);
+    const int n_ex = cut < n ? cut + 1 : n;
+    for (int i = tid; i < n_ex; i += SEL_THREADS) F.out[i] = i | (matched(i) ? (int)0x80000000 : 0);
+    if (tid == 0) { F.counts[0] = n_ex; F.counts[1] = gained; F.counts[2] = 0; F.counts[3] = 0; }
+    return;
+  }
+
+  // ---- candidates by cell
+  for (int c = tid; c <= nc; c += SEL_THREADS) F.cnt[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += SEL_THREADS) atomicAdd(&F.cnt[cell[i] + 1], 1);   // integer counts: order-free
+  __syncthreads();
+  {
+    int carry = 0;
+    for (int c0 = 0; c0 <= nc; c0 += SEL_THREADS) {
+      const int c = c0 + tid;
+      const int v = c <= nc ? F.cnt[c] : 0;
+      int tot;
+      const int incl = sel_block_scan(v, s_wave, tot) + carry;
+      if (c <= nc) F.cnt[c] = incl;     // cnt[c] = start of cell c (cnt[0] = 0 since the count of "cell -1" is 0)
+      carry += tot;
+      __syncthreads();
+    }
+  }
+  for (int c = tid; c < nc; c += SEL_THREADS) F.fill[c] = F.cnt[c];
+  __syncthreads();
+  for (int i = tid; i < n; i += SEL_THREADS) F.list[atomicAdd(&F.fill[cell[i]], 1)] = i;   // any order: sorted next
+  __syncthreads();
+  // ---- per cell: order by (quality desc, projection order) = the stable sort of reprojectCell; locate the successes
+  for (int c = tid; c < nc; c += SEL_THREADS) {
+    const int b = F.cnt[c], e = F.cnt[c + 1];
+    for (int x = b + 1; x < e; x++) {                 // insertion sort, cells hold a handful of candidates
+      const int v = F.list[x];
+      int y = x - 1;
+      while (y >= b) {
+        const int w = F.list[y];
+        if (qual[w] > qual[v] || (qual[w] == qual[v] && w < v)) break;
+        F.list[y + 1] = w; y--;
+      }
+      F.list[y + 1] = v;
+    }
+    // pass 1: up to and including the first success (or everything)
+    int x = b, e1 = 0, e2 = 0, h1 = 0, h2 = 0;
+    for (; x < e; x++) { e1++; if (matched(F.list[x])) { h1 = 1; x++; break; } }
+    for (; x < e; x++) { e2++; if (matched(F.list[x])) { h2 = 1; x++; break; } }
+    // pass 3 starts behind what passes 1 and 2 erased; whether pass 2 ran for this cell is decided later: keep both variants
+    F.e1[c] = e1 | (h1 << 30);
+    F.e2[c] = e2 | (h2 << 30);
+  }
+  __syncthreads();
+
+  int n_out = 0, n_match = 0, passes = 1;
+  // ---- pass 1 (:268-278): cells in order, one match each, stop when the budget is met
+  int cut1, g1;
+  sel_budget_scan(nc, budget, [&](int k) { return A.cell_order[k]; }, [&](int c) { return (F.e1[c] >> 30) & 1; }, F.scan, s_wave, &s_cut, cut1, g1);
+  const int m1 = cut1 < nc ? cut1 + 1 : nc;       // cells visited
+  {
+    // emit: exclusive prefix of the examined counts over the visited cells
+    int carry = 0;
+    for (int k0 = 0; k0 < m1; k0 += SEL_THREADS) {
+      const int k = k0 + tid;
+      const int c = k < m1 ? A.cell_order[k] : 0;
+      const int ex = k < m1 ? (F.e1[c] & 0x3fffffff) : 0;
+      int tot;
+      const int off = sel_block_scan(ex, s_wave, tot) + carry - ex;
+      if (k < m1) {
+        const int b = F.cnt[c];
+        for (int x = 0; x < ex; x++) { const int i = F.list[b + x]; F.out[off + x] = i | ((x == ex - 1 && ((F.e1[c] >> 30) & 1)) ? (int)0x80000000 : 0); }
+      }
+      carry += tot;
+      __syncthreads();
+    }
+    n_out = carry; n_match = g1;
+  }
+  // ---- pass 2 (:281-293): cells in reverse order without index 0, the next match of each
+  if (n_match < budget) {
+    passes = 2;
+    const int m = nc - 1;   // k = nc-1 .. 1
+    auto visit2 = [&](int j) { return A.cell_order[nc - 1 - j]; };
+    int cut2, g2;
+    sel_budget_scan(m, budget - n_match, visit2, [&](int c) { return (F.e2[c] >> 30) & 1; }, F.scan, s_wave, &s_cut, cut2, g2);
+    const int m2 = cut2 < m ? cut2 + 1 : m;
+    int carry = 0;
+    for (int k0 = 0; k0 < m2; k0 += SEL_THREADS) {
+      const int k = k0 + tid;
+      const int c = k < m2 ? visit2(k) : 0;
+      const int ex = k < m2 ? (F.e2[c] & 0x3fffffff) : 0;
+      int tot;
+      const int off = sel_block_scan(ex, s_wave, tot) + carry - ex;
+      if (k < m2) {
+        const int b = F.cnt[c] + (F.e1[c] & 0x3fffffff);
+        for (int x = 0; x < ex; x++) { const int i = F.list[b + x]; F.out[n_out + off + x] = i | ((x == ex - 1 && ((F.e2[c] >> 30) & 1)) ? (int)0x80000000 : 0); }
+        F.e2[c] |= 1 << 29;   // visited in pass 2: its candidates are erased
+      }
+      carry += tot;
+      __syncthreads();
+    }
+    n_out += carry; n_match += g2;
+    // ---- pass 3 (:296-305): cells in order, up to three more matches each, stop when the budget is met
+    if (n_match < budget) {
+      passes = 3;
+      __syncthreads();
+      for (int c = tid; c < nc; c += SEL_THREADS) {
+        const int b = F.cnt[c] + (F.e1[c] & 0x3fffffff) + (((F.e2[c] >> 29) & 1) ? (F.e2[c] & 0x1fffffff) : 0), e = F.cnt[c + 1];
+        int a = 0, p[3] = { 0, 0, 0 };
+        for (int x = b; x < e; x++) if (matched(F.list[x])) { if (a < 3) p[a] = x - b + 1; a++; }
+        F.a3[c] = a | ((e - b) << 8);          // successes (at most 255 matter) and the remaining length
+        F.p3[3 * c] = p[0]; F.p3[3 * c + 1] = p[1]; F.p3[3 * c + 2] = p[2];
+      }
+      __syncthreads();
+      const int R = budget - n_match;
+      int cut3, g3;
+      sel_budget_scan(nc, R, [&](int k) { return A.cell_order[k]; }, [&](int c) { const int a = F.a3[c] & 0xff; return a < 3 ? a : 3; }, F.scan, s_wave, &s_cut, cut3, g3);
+      const int m3 = cut3 < nc ? cut3 + 1 : nc;
+      int carry3 = 0;
+      for (int k0 = 0; k0 < m3; k0 += SEL_THREADS) {
+        const int k = k0 + tid;
+        int ex = 0, take = 0, c = 0;
+        if (k < m3) {
+          c = A.cell_order[k];
+          const int a = F.a3[c] & 0xff, len = F.a3[c] >> 8;
+          take = a < 3 ? a : 3;
+          if (k == cut3) take = R - F.scan[k];                 // the budget runs out inside this cell
+          ex = (take == 3 || k == cut3) ? F.p3[3 * c + take - 1] : len;   // stopped at a success, or walked to the end
+        }
+        int tot;
+        const int off = sel_block_scan(ex, s_wave, tot) + carry3 - ex;
+        if (k < m3) {
+          const int b = F.cnt[c] + (F.e1[c] & 0x3fffffff) + (((F.e2[c] >> 29) & 1) ? (F.e2[c] & 0x1fffffff) : 0);
+          for (int x = 0; x < ex; x++) { const int i = F.list[b + x]; F.out[n_out + off + x] = i | (matched(i) ? (int)0x80000000 : 0); }
+        }
+        carry3 += tot;
+        __syncthreads();
+      }
+      n_out += carry3; n_match += g3;
+    }
+  }
+  if (tid == 0) { F.counts[0] = n_out; F.counts[1] = n_match; F.counts[2] = passes; F.counts[3] = 1; }
+  (void)s_n; (void)deleted;
+}
+
+extern "C" int hso_gpu_reproject_select(hso_gpu_ctx* ctx, const int32_t* frame_begin, int n_frames, const int32_t* cell,
+                                        const uint8_t* quality, const uint8_t* flags, const int32_t* cell_order, int n_cells,
+                                        int max_fts, int32_t* examined_out, int32_t* counts_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_frames < 0 || (n_frames > 0 && (!frame_begin || !counts_out)) || n_cells <= 0 || !cell_order || max_fts < 0)
+    return hso_fail(ctx, HSO_E_INVALID, "reproject_select: bad argument");
+  if (n_frames == 0) return HSO_OK;
+  const int n_total = frame_begin[n_frames];
+  if (frame_begin[0] != 0 || n_total < 0 || (n_total > 0 && (!cell || !quality || !flags || !examined_out)))
+    return hso_fail(ctx, HSO_E_INVALID, "reproject_select: bad candidate tables");
+  for (int f = 0; f < n_frames; f++)
+    if (frame_begin[f + 1] < frame_begin[f]) return hso_fail(ctx, HSO_E_INVALID, "reproject_select: frame ranges must ascend");
+  for (int i = 0; i < n_total; i++)
+    if (cell[i] < 0 || cell[i] >= n_cells) return hso_fail(ctx, HSO_E_INVALID, "reproject_select: cell out of range");
+  {
+    std::vector<uint8_t> seen(n_cells, 0);
+    for (int k = 0; k < n_cells; k++) {
+      if (cell_order[k] < 0 || cell_order[k] >= n_cells || seen[cell_order[k]]) return hso_fail(ctx, HSO_E_INVALID, "reproject_select: cell_order is not a permutation");
+      seen[cell_order[k]] = 1;
+    }
+  }
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  // inputs | frame records | per-frame scratch | outputs
+  size_t o = 0;
+  const size_t o_cell = o; o += al(sizeof(int32_t) * (size_t)n_total);
+  const size_t o_q = o; o += al((size_t)n_total);
+  const size_t o_f = o; o += al((size_t)n_total);
+  const size_t o_ord = o; o += al(sizeof(int32_t) * (size_t)n_cells);
+  const size_t o_fr = o; o += al(sizeof(SelFrame) * (size_t)n_frames);
+  const size_t in_bytes = o;
+  const size_t o_out = o; o += al(sizeof(int32_t) * (size_t)std::max(n_total, 1));
+  const size_t o_cnt = o; o += al(sizeof(int32_t) * 4 * (size_t)n_frames);
+  const size_t o_list = o; o += al(sizeof(int32_t) * (size_t)std::max(n_total, 1));
+  const size_t per_frame = al(sizeof(int32_t) * (size_t)(n_cells + 1)) + 4 * al(sizeof(int32_t) * (size_t)n_cells) + al(sizeof(int32_t) * 3 * (size_t)n_cells);
+  // the scan array also serves reprojectCellAll (indexed by candidate): n < max_fts + 50 entries
+  const size_t scan_bytes = al(sizeof(int32_t) * (size_t)std::max(n_cells, max_fts + 50));
+  const size_t o_scr = o; o += (per_frame + scan_bytes) * (size_t)n_frames;
+  if (ctx->batch_cap < o) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), o));
+    ctx->batch_cap = o;
+  }
+  char* d = ctx->d_batch;
+  char* h = hso_pinned(ctx, 0, in_bytes);
+  if (!h) return HSO_E_NOMEM;
+  memcpy(h + o_cell, cell, sizeof(int32_t) * (size_t)n_total);
+  memcpy(h + o_q, quality, (size_t)n_total);
+  memcpy(h + o_f, flags, (size_t)n_total);
+  memcpy(h + o_ord, cell_order, sizeof(int32_t) * (size_t)n_cells);
+  SelFrame* hf = reinterpret_cast<SelFrame*>(h + o_fr);
+  for (int f = 0; f < n_frames; f++) {
+    char* s = d + o_scr + (per_frame + scan_bytes) * (size_t)f;
+    SelFrame& F = hf[f];
+    F.first = frame_begin[f]; F.n = frame_begin[f + 1] - frame_begin[f];
+    F.cnt = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * (size_t)(n_cells + 1));
+    F.fill = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * (size_t)n_cells);
+    F.e1 = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * (size_t)n_cells);
+    F.e2 = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * (size_t)n_cells);
+    F.a3 = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * (size_t)n_cells);
+    F.p3 = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * 3 * (size_t)n_cells);
+    F.scan = reinterpret_cast<int*>(s);
+    F.list = reinterpret_cast<int*>(d + o_list) + F.first;
+    F.out = reinterpret_cast<int*>(d + o_out) + F.first;
+    F.counts = reinterpret_cast<int*>(d + o_cnt) + 4 * f;
+  }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SelArgs A;
+  A.cell = reinterpret_cast<const int32_t*>(d + o_cell); A.quality = reinterpret_cast<const uint8_t*>(d + o_q);
+  A.flags = reinterpret_cast<const uint8_t*>(d + o_f); A.cell_order = reinterpret_cast<const int32_t*>(d + o_ord);
+  A.n_cells = n_cells; A.max_fts = max_fts;
+  hipLaunchKernelGGL(k_select, dim3(n_frames), dim3(SEL_THREADS), 0, ctx->stream, A, reinterpret_cast<const SelFrame*>(d + o_fr));
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  if (n_total > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(examined_out, d + o_out, sizeof(int32_t) * (size_t)n_total, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, d + o_cnt, sizeof(int32_t) * 4 * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}

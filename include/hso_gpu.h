@@ -637,6 +637,25 @@ int hso_gpu_seed_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_
                                  double cur_exposure, const hso_seed* seeds, int n_seeds, int cell_size, int grid_n_cols,
                                  hso_reproj_point* proj_out, hso_align_out* match_out);
 
+/* ---- the grid selection of Reprojector::reprojectMap (remainder), src/reprojector.cpp:253-306
+ *      (branch on the number of projected candidates, three passes over the cells in cell_order), reprojectCell :352-429
+ *      (pointQualityComparator :333-345 on first visit, every examined candidate erased, first success per cell in passes 1
+ *      and 2, up to three in pass 3), reprojectCellAll :556-612.  With every projected candidate already matched
+ *      (hso_gpu_reproject_match), the policy is a pure function of the per-candidate (cell, quality, flags), the cell order
+ *      and max_fts; this call evaluates it on the device for any number of frames (one workgroup each).
+ *   frame_begin[n_frames + 1]  candidate ranges, candidates of a frame in projection order (the order reprojectPoint saw them)
+ *   cell[i]                    grid cell (hso_reproj_point.cell)
+ *   quality[i]                 (Point::type_ << 4) | Point::ftr_type_ — the comparator's key; higher sorts first, ties keep order
+ *   flags[i]                   bit 0: findMatchDirect succeeded; bit 1: the point is TYPE_DELETED (costs a trial, nothing else)
+ *   cell_order[n_cells]        the permutation Reprojector::initializeGrid shuffles once (:70-76)
+ *   examined_out               per frame, at frame_begin[f]: the candidates examined, in examination order, as
+ *                              (index within the frame) | (became a feature ? 0x80000000 : 0) — the caller walks the list and
+ *                              applies the reference's bookkeeping (n_failed_reproj_ / n_succeeded_reproj_, new Feature)
+ *   counts_out[4 * n_frames]   n_examined (= n_trials_), n_matches_, cell passes run (0 for reprojectCellAll), branch ---- */
+int hso_gpu_reproject_select(hso_gpu_ctx* ctx, const int32_t* frame_begin, int n_frames, const int32_t* cell,
+                             const uint8_t* quality, const uint8_t* flags, const int32_t* cell_order, int n_cells, int max_fts,
+                             int32_t* examined_out, int32_t* counts_out);
+
 /* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
  *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,
  *      fast_corner_score_9, fast_nonmax_3x3 (thirdparty/fast/src) — and hso::shiTomasiScore

@@ -282,6 +282,12 @@ def _reprojector_check(gpu_ctx, cam, line, budget, kf_id, cur_id, T_cw, exposure
                     break
     assert (n_matches, n_trials) == (len(sel), trials), (budget, n_matches, len(sel), n_trials, trials)
     assert [int(x) for x in rec[:, 0]] == sel
+    # the same policy evaluated on the device (hso_gpu_reproject_select): the mirror visits the cells in index order here
+    flags = np.array([1 if ok(i) else 0 for i in cand], np.uint8)
+    ex, counts = gpu_ctx.reproject_select([0, len(cand)], proj["cell"][cand], np.full(len(cand), (3 << 4) | 0, np.uint8), flags,
+                                          np.arange(n_cells, dtype=np.int32), budget)
+    assert (int(counts[0, 1]), int(counts[0, 0])) == (n_matches, n_trials)
+    assert [cand[j] for j, taken in ex[0] if taken] == sel
     for r, i in zip(rec, sel):
         assert int(r[1]) == match[i].search_level
         assert (r[2], r[3]) == pytest.approx((match[i].px_cur[0], match[i].px_cur[1]), abs=1e-9)
