@@ -180,8 +180,10 @@ HSO_DEV Proj project_feature(const LevelCtx& L, const Se3& T, const FeatRaw& raw
 // ------------------------------------------------------- workgroup reductions
 
 struct Acc {
-  float H[32];   // [0..27] used; fp32 like the reference's Accumulator7 (MatrixAccumulator.h:33)
-  double d[16];  // [0..9] used: b[0..6] (fp64 like CoarseTracker.cpp:520), E, n_terms, n_saturated
+  float H[32];   // [0..27] H, fp32 like the reference's Accumulator7 (MatrixAccumulator.h:33); [28] n_terms, [29] n_saturated
+                 // (integers far below 2^24: exact in fp32); [30..31] pad
+  double d[8];   // b[0..6] (fp64 like CoarseTracker.cpp:520), E — eight values: the halving exchange needs no pad
+                 // (with the two counts as doubles it carried 6 zero values = 12 of its 32 dword exchanges)
 };               // sizes padded to powers of two for the halving exchange (the pads stay 0)
 
 // Sum N (a power of two <= 64) per-lane values over the 64 lanes of a wave by recursive
@@ -1068,8 +1070,8 @@ HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Mo
 #pragma unroll
   for (int k = 0; k < 6; k++) acc.d[1 + k] -= fma(d_rx, A[k], d_ry * B[k]);
   acc.d[7] += (double)m.E;
-  acc.d[8] += (double)m.nt;
-  acc.d[9] += (double)m.nsat;
+  acc.H[28] += (float)m.nt;
+  acc.H[29] += (float)m.nsat;
 }
 
 // computeResiduals (CoarseTracker.cpp:242-414) fused with computeGS (:499-525).
@@ -1170,7 +1172,7 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
 #pragma unroll
     for (int i = 0; i < 32; i++) acc.H[i] = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc.d[i] = 0;
+    for (int i = 0; i < 8; i++) acc.d[i] = 0;
 #pragma unroll
     for (int q = 0; q < FPT; q++)
       if (p[q].ok && sub == 0) expand_feature<IC>(acc, L, p[q], m[q], ff[q], a);
@@ -1178,13 +1180,14 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
     float th; double td;
     slotH = 0; slotD = 0;
     Halve<float, 32, 32>::run(acc.H, lane, slotH, th);
-    Halve<double, 16, 32>::run(acc.d, lane, slotD, td);
+    Halve<double, 8, 32>::run(acc.d, lane, slotD, td);
     totH += th;
     totD += td;
     DBG_T(3);
   }
   if (slotH < 28) s.wave_part[wave][slotH] = (double)totH;
-  if (slotD < 10) s.wave_part[wave][28 + slotD] = totD;
+  else if (slotH < 30) s.wave_part[wave][8 + slotH] = (double)totH;   // n_terms, n_saturated -> [36], [37]
+  if (slotD < 8) s.wave_part[wave][28 + slotD] = totD;
   __syncthreads();
   if (threadIdx.x < N_RED) {
     double t = 0;
