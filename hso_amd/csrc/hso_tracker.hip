@@ -7,27 +7,27 @@
 //   selectRobustFunctionLevel :530-644, computeResiduals :242-414,
 //   computeGS :499-525 (+ Accumulator7, include/hso/MatrixAccumulator.h), run :51-208.
 //
-// MI355X design
-//   * one workgroup of TRK_THREADS threads (wave64s of one CU) owns one (ref, cur) pair
-//     for the whole level/LM loop; independent pairs are pulled from a device-side job
-//     counter by a persistent grid (one workgroup per CU), so a batch fills the chip
-//     with no host round trip and no inter-workgroup communication;
-//   * per level the reference image, then the current image, is staged once into LDS
-//     (<= 90 KB for EuRoC level 1); every bilinear / gradient tap is an LDS read of two
-//     aligned dwords + v_alignbyte_b32 (4 neighbouring pixels per row fetch);
-//   * the arithmetic that feeds decisions (projection, bilinear intensity, residual,
-//     Huber weight, saturation test) mirrors the reference's expressions operation by
-//     operation (compiled with -ffp-contract=off), so visibility, term / saturation
-//     counts and the MAD thresholds are bit-identical to the CPU restatement; the image
-//     gradients and the sums H, b, E only feed tolerance-compared quantities and use FMAs
-//     and fixed-tree reductions (fp32 H like the reference's Accumulator7, fp64 b, fp64 E);
-//   * J = [-I_ref, dx*A + dy*B] with A = fx_l*J_row0, B = fy_l*J_row1 is never
-//     materialised: per feature nine weighted moments of (I_ref, dx, dy, r) are
-//     accumulated over the pattern and expanded once into the 28+7 normal-equation
-//     entries; a halving (reduce-scatter) exchange across the wave + one LDS stage
-//     finish the sum;
-//   * the 7x7 pivoted LDL^T solve runs on one wavefront, matrix entries spread over lanes;
-//   * median / MAD are exact order statistics (radix select on float bit patterns),
+// MI355X design (details and measurements: DESIGN.md section 3.2)
+//   * one workgroup owns one (ref, cur) pair for the whole level/LM loop; independent pairs are pulled from a
+//     device-side job counter by a persistent grid, so a batch fills the chip with no host round trip and no
+//     inter-workgroup communication.  The device code (hso_tracker_core.h) is compiled in two shapes — 512 threads
+//     with the whole LDS, 256 threads with half of it — and a large batch runs the coarse levels two-per-CU and the
+//     finest level one-per-CU (see below);
+//   * per level the reference image, then the current image, is staged once into LDS (LDS-DMA; <= 90 KB for EuRoC
+//     level 1); the taps of a feature's pattern are read as per-row windows (two aligned ds_read2_b32 +
+//     v_alignbyte_b32 per row) and every pixel is converted to float once;
+//   * the arithmetic that feeds decisions (projection, bilinear intensity, residual, Huber weight, saturation test)
+//     mirrors the reference's expressions operation by operation (compiled with -ffp-contract=off), so visibility,
+//     term / saturation counts and the MAD thresholds are bit-identical to the CPU restatement; the image gradients
+//     and the sums H, b, E only feed tolerance-compared quantities and use FMAs and fixed-tree reductions (fp32 H
+//     like the reference's Accumulator7, fp64 b, fp64 E);
+//   * J = [-I_ref, dx*A + dy*B] with A = fx_l*J_row0, B = fy_l*J_row1 is never materialised: per feature nine
+//     weighted moments of (I_ref, dx, dy, r) are accumulated over the pattern and expanded once into the 28+7
+//     normal-equation entries; a halving (reduce-scatter) exchange across the wave (v_permlane32/16_swap + DPP) and
+//     one LDS stage finish the sum;
+//   * the 7x7 pivoted LDL^T solve and the SE(3) update run on one lane, fully unrolled in registers;
+//   * median / MAD are exact order statistics (radix select on float bit patterns: 12-bit leading digit histogrammed
+//     while the keys are produced, the winning bin compacted into LDS, the remaining digits over the candidates),
 //     equal to nth_element at floor(n/2) (include/hso/vikit/math_utils.h:119-126).
 // Nothing here is a dense contraction, so MFMA is not used (BASELINE.json north_star).
 #include "hso_ctx.h"
