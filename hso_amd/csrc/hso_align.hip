@@ -38,16 +38,51 @@ struct AlignJobDev {
   hso_align_job j;
 };
 
-__global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align(AlignConsts C, const AlignJobDev* jobs, int n_jobs,
-                                                                       hso_align_out* outs)
+// One wavefront matches `cpw` consecutive candidates (a power of two <= 64, chosen by the launch: 1 when the batch is small
+// enough to spread one candidate per wave over the chip, up to 64 for multi-sequence batches).  Phase 1: one LANE per candidate
+// computes the candidate's geometry (match_geometry: the wave-uniform fp64 half of findMatchDirect) into LDS — 64 candidates
+// for the instruction issue of one; phase 2: the whole wave walks the candidates (lane = patch pixel).
+// SPARSE: candidates with a null reference are skipped (the output array was zeroed): the chained projection + matching calls.
+template <bool SPARSE>
+__global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align_t(AlignConsts C, const AlignJobDev* jobs, int n_jobs,
+                                                                         hso_align_out* outs, int cpw)
 {
   __shared__ float s_pwb[ALIGN_WAVES_PER_BLOCK][100];
+  __shared__ MatchGeom s_geom[ALIGN_WAVES_PER_BLOCK][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int jid = blockIdx.x * ALIGN_WAVES_PER_BLOCK + wave;
-  if (jid >= n_jobs) return;
-  const AlignJobDev& JD = jobs[jid];
-  const hso_align_out o = match_one(C.cam, C.g, JD.cur_base, JD.ref_base, JD.j, (double)0.7f, s_pwb[wave]);  // checkNCC(…, 0.7), :364
-  if (lane == 0) outs[jid] = o;
+  const int first = (blockIdx.x * ALIGN_WAVES_PER_BLOCK + wave) * cpw;
+  if (first >= n_jobs) return;
+  if (lane < cpw && first + lane < n_jobs) {
+    const AlignJobDev& JD = jobs[first + lane];
+    if (!SPARSE || JD.ref_base != nullptr) s_geom[wave][lane] = match_geometry(C.cam, C.g, JD.j);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int q = 0; q < cpw; q++) {
+    const int jid = first + q;
+    if (jid >= n_jobs) break;
+    const AlignJobDev& JD = jobs[jid];
+    if (SPARSE && JD.ref_base == nullptr) continue;    // outs was zeroed
+    const hso_align_out o = match_patch(C.g, JD.cur_base, JD.ref_base, JD.j, s_geom[wave][q], (double)0.7f, s_pwb[wave]);  // checkNCC(…, 0.7), :364
+    if (lane == 0) outs[jid] = o;
+    __builtin_amdgcn_wave_barrier();                   // the next candidate overwrites this wave's patch
+  }
+}
+
+// candidates per wave for a batch of n: one per wave until the chip holds ~8 waves per SIMD of them, then doubling
+static int align_cpw(const hso_gpu_ctx* ctx, int n)
+{
+  const long long spread = (long long)ctx->n_cu * 4 * 8;
+  int cpw = 1;
+  while (cpw < 64 && (long long)n > spread * cpw) cpw *= 2;
+  return cpw;
+}
+static void launch_align(hso_gpu_ctx* ctx, bool sparse, const AlignConsts& C, const AlignJobDev* d_jobs, int n, hso_align_out* d_out)
+{
+  const int cpw = align_cpw(ctx, n);
+  const int waves = (n + cpw - 1) / cpw, blocks = (waves + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK;
+  if (sparse) hipLaunchKernelGGL(k_align_t<true>, dim3(blocks), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream, C, d_jobs, n, d_out, cpw);
+  else hipLaunchKernelGGL(k_align_t<false>, dim3(blocks), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream, C, d_jobs, n, d_out, cpw);
 }
 
 // cur_frame_ids: one id per job (stride 1) or one id for all jobs (stride 0)
@@ -96,8 +131,7 @@ static int align_run(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, h, (size_t)n_jobs * sizeof(AlignJobDev), hipMemcpyHostToDevice, ctx->stream));
   AlignConsts C;
   C.cam = *cam; C.g = g;
-  const int blocks = (n_jobs + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK;
-  hipLaunchKernelGGL(k_align, dim3(blocks), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream, C, d_jobs, n_jobs, d_out);
+  launch_align(ctx, false, C, d_jobs, n_jobs, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n_jobs * sizeof(hso_align_out), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -276,18 +310,6 @@ __global__ __launch_bounds__(256) void k_match_brief(int n, const hso_reproj_poi
 }
 
 // k_align over device-built jobs: a null reference = "findMatchDirect not reached / returned at once"
-__global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align_sparse(AlignConsts C, const AlignJobDev* jobs, int n_jobs,
-                                                                              hso_align_out* outs)
-{
-  __shared__ float s_pwb[ALIGN_WAVES_PER_BLOCK][100];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int jid = blockIdx.x * ALIGN_WAVES_PER_BLOCK + wave;
-  if (jid >= n_jobs) return;
-  const AlignJobDev& JD = jobs[jid];
-  if (JD.ref_base == nullptr) return;                // outs was zeroed
-  const hso_align_out o = match_one(C.cam, C.g, JD.cur_base, JD.ref_base, JD.j, (double)0.7f, s_pwb[wave]);
-  if (lane == 0) outs[jid] = o;
-}
 
 extern "C" int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_reproj_frame* frames, int n_frames,
                                              const hso_kf* kfs, int n_kfs, const hso_map_point* points, int n_points,
@@ -402,8 +424,7 @@ extern "C" int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera*
   hipLaunchKernelGGL(k_reproject, dim3((n_points + 255) / 256), dim3(256), 0, ctx->stream, R, d_jobs, d_proj);
   AlignConsts C;
   C.cam = *cam; C.g = g;
-  hipLaunchKernelGGL(k_align_sparse, dim3((n_points + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0,
-                     ctx->stream, C, d_jobs, n_points, d_out);
+  launch_align(ctx, true, C, d_jobs, n_points, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   if (small) {  // [match | proj] are adjacent on the device: one DMA into pinned memory, then to the caller
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(hout, d + o_out, o_kf - o_out, hipMemcpyDeviceToHost, ctx->stream));
@@ -582,8 +603,7 @@ extern "C" int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* 
   hipLaunchKernelGGL(k_reproject_maps, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, M, d_jobs, d_proj);
   AlignConsts C;
   C.cam = *cam; C.g = A->g;
-  hipLaunchKernelGGL(k_align_sparse, dim3((n + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream,
-                     C, d_jobs, n, d_match);
+  launch_align(ctx, true, C, d_jobs, n, d_match);
   hipLaunchKernelGGL(k_match_brief, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_proj, d_match, d_jobs, d_brief);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   hso_match_brief* hb = reinterpret_cast<hso_match_brief*>(hso_pinned(ctx, 1, sizeof(hso_match_brief) * total));

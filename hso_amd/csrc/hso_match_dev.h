@@ -66,31 +66,30 @@ HSO_DEV float interpolate_8u(const uint8_t* data, int stride, float u, float v)
   return ((w00 * (float)(r0 & 0xffu) + w01 * (float)(r1 & 0xffu)) + w10 * (float)(r0 >> 8)) + w11 * (float)(r1 >> 8);
 }
 
-// Matcher::findMatchDirect after the reference feature has been chosen (src/matcher.cpp:286-375);
-// findMatchSeed (:442-518) is the same body with ncc_thresh = 0.8 and J.kf_gap_lt4 = 1.
-// pwb_lds: 100 floats of LDS private to this wavefront.
-HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const uint8_t* cur_base, const uint8_t* ref_base,
-                                const hso_align_job& J, double ncc_thresh, float* pwb_lds)
+// The part of findMatchDirect that is the same in all 64 lanes of the wavefront that matches a candidate — the border test of
+// the reference position, warp::getWarpMatrixAffine (two cam2world, three rigid transforms, three projections: ~700 fp64
+// instructions, nearly half of a candidate's instruction count) and warp::getBestSearchLevel.  Callable by ONE lane per
+// candidate: the batched kernels compute it for 64 candidates at a time, one per lane, before they walk the candidates with
+// the whole wave (hso_align.hip).
+struct MatchGeom {
+  double A00, A01, A10, A11;     // A_cur_ref
+  int32_t search_level;
+  int32_t ref_border;            // != 0: the reference position fails isInFrame (HSO_ALIGN_REF_BORDER)
+};
+
+HSO_DEV MatchGeom match_geometry(const hso_camera& cam, const PyrGeom& g, const hso_align_job& J)
 {
-  const int lane = threadIdx.x & 63;
-  hso_align_out o;
-  o.success = 0; o.stage = HSO_ALIGN_OK; o.search_level = 0; o.iters = 0;
-  o.px_cur[0] = J.px_cur[0]; o.px_cur[1] = J.px_cur[1];
-  o.A_cur_ref[0] = o.A_cur_ref[1] = o.A_cur_ref[2] = o.A_cur_ref[3] = 0; o.h_inv = 0; o.ncc = 0; o.chi2 = 0;
+  MatchGeom G;
+  G.A00 = G.A01 = G.A10 = G.A11 = 0; G.search_level = 0; G.ref_border = 0;
   const int W = g.w[0], H = g.h[0];
   const int halfpatch_size_ = 4;
-
   // isInFrame((px/(1<<level)).cast<int>(), halfpatch_size_+2, level), matcher.cpp:288, camera.h:85-89
   {
     const int L = J.ref_level, b = halfpatch_size_ + 2;
     const int ox = (int)(J.px_ref[0] / (double)(1 << L)), oy = (int)(J.px_ref[1] / (double)(1 << L));
-    if (!(ox >= b && ox < W / (1 << L) - b && oy >= b && oy < H / (1 << L) - b)) {
-      o.stage = HSO_ALIGN_REF_BORDER;
-      return o;
-    }
+    if (!(ox >= b && ox < W / (1 << L) - b && oy >= b && oy < H / (1 << L) - b)) { G.ref_border = 1; return G; }
   }
-
-  // ---- warp::getWarpMatrixAffine, matcher.cpp:46-72 (uniform over the wave)
+  // ---- warp::getWarpMatrixAffine, matcher.cpp:46-72
   const Se3 T = se3_from(J.T_cur_ref);
   double A00, A01, A10, A11;
   {
@@ -113,14 +112,33 @@ HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const u
     A00 = (pu0 - pc0) / hp; A10 = (pu1 - pc1) / hp;
     A01 = (pv0 - pc0) / hp; A11 = (pv1 - pc1) / hp;
   }
-  o.A_cur_ref[0] = A00; o.A_cur_ref[1] = A01; o.A_cur_ref[2] = A10; o.A_cur_ref[3] = A11;
-
+  G.A00 = A00; G.A01 = A01; G.A10 = A10; G.A11 = A11;
   // ---- warp::getBestSearchLevel, :74-85 (max_level = Config::nPyrLevels()-1 = 2)
   int search_level = 0;
   {
     double D = A00 * A11 - A10 * A01;
     while (D > 3.0 && search_level < HSO_N_SOBEL_LEVELS - 1) { search_level += 1; D *= 0.25; }
   }
+  G.search_level = search_level;
+  return G;
+}
+
+// Matcher::findMatchDirect after the reference feature has been chosen (src/matcher.cpp:286-375), given the candidate's
+// geometry; findMatchSeed (:442-518) is the same body with ncc_thresh = 0.8 and J.kf_gap_lt4 = 1.
+// One wavefront, lane = pixel of the 8x8 patch.  pwb_lds: 100 floats of LDS private to this wavefront.
+HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, const uint8_t* ref_base,
+                                  const hso_align_job& J, const MatchGeom& G, double ncc_thresh, float* pwb_lds)
+{
+  const int lane = threadIdx.x & 63;
+  hso_align_out o;
+  o.success = 0; o.stage = HSO_ALIGN_OK; o.search_level = 0; o.iters = 0;
+  o.px_cur[0] = J.px_cur[0]; o.px_cur[1] = J.px_cur[1];
+  o.A_cur_ref[0] = o.A_cur_ref[1] = o.A_cur_ref[2] = o.A_cur_ref[3] = 0; o.h_inv = 0; o.ncc = 0; o.chi2 = 0;
+  const int halfpatch_size_ = 4;
+  if (G.ref_border) { o.stage = HSO_ALIGN_REF_BORDER; return o; }
+  const double A00 = G.A00, A01 = G.A01, A10 = G.A10, A11 = G.A11;
+  o.A_cur_ref[0] = A00; o.A_cur_ref[1] = A01; o.A_cur_ref[2] = A10; o.A_cur_ref[3] = A11;
+  const int search_level = G.search_level;
   o.search_level = search_level;
 
   // ---- warp::warpAffine (float), :120-155: 10x10 samples of the reference level
@@ -290,6 +308,14 @@ HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const u
   o.px_cur[1] = pxs1 * (double)(1 << search_level);
   o.success = ok ? 1 : 0;
   return o;
+}
+
+// geometry by every lane + patch: for the kernels that handle one candidate per wave (seed activation, seed reprojection)
+HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const uint8_t* cur_base, const uint8_t* ref_base,
+                                const hso_align_job& J, double ncc_thresh, float* pwb_lds)
+{
+  const MatchGeom G = match_geometry(cam, g, J);
+  return match_patch(g, cur_base, ref_base, J, G, ncc_thresh, pwb_lds);
 }
 
 }  // namespace hso_dev
