@@ -178,27 +178,37 @@ HSO_DEV void seed_finish(const SeedConsts& C, SeedDev* seeds, int sid, hso_seed_
   }
 }
 
-__global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(SeedConsts C, SeedDev* seeds, int n_seeds,
-                                                                             hso_seed_out* outs)
+// observeDepthRow in three phases, so that what is identical in all 64 lanes of the wave that observes a seed is computed by
+// ONE lane per seed for a group of seeds at a time (SEED_CPW per wave) instead of by every lane of every wave — about half of
+// the kernel's instructions (two se3 products, the visibility projection, the affine warp matrix with its two radtan
+// cam2world, the epipolar end points; afterwards cam2world of the match, the triangulation, computeTau's acos / sin and
+// the update):
+//   pre   lane = seed   everything up to the first image access                      -> SeedPre  (LDS)
+//   wave  lane = pixel  createPatch, the epipolar march, the two KLT refinements, checkNormal / checkNCC -> SeedMid (LDS)
+//   post  lane = seed   depthFromTriangulation, computeTau, updateSeed, the output records
+// Each phase runs the statements of the one-phase kernel it replaces in their order; only the lane that executes them changed.
+struct SeedPre {
+  double pxc0, pxc1, pxf0, pxf1, incx, incy, ed0, ed1, dc0, dc1;
+  float a00, a01, a10, a11, exposure_rat;
+  int32_t sl, epl_start[2], epl_end[2];
+  int8_t state;      // 0: run the wave phase; 1: not visible in the active frame; 2: doLineStereo returns -1 before any image access
+  int8_t is_valid, warp_nan, scale_exposure;
+};
+struct SeedMid {
+  double px0, px1;                 // px_cur (level 0) when res_code == 1
+  float zmncc_best, zmncc_second;
+  int32_t n_steps, res_code;       // 1: matched (triangulate next), -4 / -3: rejected by the march / the refinement
+};
+#define SEED_CPW_MAX 16
+
+HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrameDev& F)
 {
-  __shared__ float s_pwb[SEED_WAVES_PER_BLOCK][100];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sid = blockIdx.x * SEED_WAVES_PER_BLOCK + wave;
-  if (sid >= n_seeds) return;
-  const SeedDev& SD = seeds[sid];
-  if (SD.ref_base == nullptr) {   // an erased slot of a resident table
-    if (lane == 0 && C.brief) { hso_seed_brief br; memset(&br, 0, sizeof(br)); C.brief[sid] = br; }
-    return;
-  }
   const hso_seed& S = SD.s;
   const int W = C.g.w[0], H = C.g.h[0];
-  hso_seed_out o;
-  memset(&o, 0, sizeof(o));
-  o.mu = S.mu; o.sigma2 = S.sigma2; o.b = S.b; o.is_valid = 1;
-
+  SeedPre P;
+  memset(&P, 0, sizeof(P));
+  P.is_valid = 1;
   // ---- visibility in the active frame (depth_filter.cpp:590-606)
-  const SeedFrameDev& F = C.frames[SD.frame];
-  const uint8_t* const cur_base = SD.cur_base ? SD.cur_base : F.cur_base;
   const Se3 Tcw = se3_from(F.T_f_w), Trw = se3_from(S.T_ref_w);
   const Se3 T_ref_cur = se3_mul(Trw, se3_inverse(Tcw));
   {
@@ -213,51 +223,107 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
       const int ox = (int)cu, oy = (int)cv;
       vis = (ox >= 0 && ox < W && oy >= 0 && oy < H);
     }
-    if (!vis) { o.result = 0; o.is_update = 0; seed_finish(C, seeds, sid, outs, o, lane); return; }
+    if (!vis) { P.state = 1; return P; }
   }
-  o.is_update = 1;
   const float z_inv_min = S.mu + 2 * sqrtf(S.sigma2);
   const float z_inv_max = fmaxf(S.mu - 2 * sqrtf(S.sigma2), 0.00000001f);
-  if (isnan(z_inv_min)) o.is_valid = 0;
+  if (isnan(z_inv_min)) P.is_valid = 0;
   const double min_idepth = 1.0 / (double)z_inv_min, prior_idepth = 1.0 / (double)S.mu, max_idepth = 1.0 / (double)z_inv_max;
 
-  // ---- Matcher::doLineStereo (matcher.cpp:802-1049)
+  // ---- Matcher::doLineStereo (matcher.cpp:802-1049), the part before the first image access
   const Se3 T = se3_mul(Tcw, se3_inverse(Trw));  // T_cur_ref, :807
+  P.state = 2;
+  double A00, A01, A10, A11;
+  {
+    const int hp = 5;
+    const double xr = S.f[0] * prior_idepth, yr = S.f[1] * prior_idepth, zr = S.f[2] * prior_idepth;
+    const int ratio = 1 << S.level;
+    double du[3], dv[3];
+    cam2world_dev(C.cam, S.px[0] + (double)(hp * ratio), S.px[1] + (double)(0 * ratio), du);
+    cam2world_dev(C.cam, S.px[0] + (double)(0 * ratio), S.px[1] + (double)(hp * ratio), dv);
+    const double su = zr / du[2], sv = zr / dv[2];
+    for (int i = 0; i < 3; i++) { du[i] *= su; dv[i] *= sv; }
+    double cx, cy, cz, ux, uy, uz, vx, vy, vz, pc0, pc1, pu0, pu1, pv0, pv1;
+    se3_apply(T, xr, yr, zr, cx, cy, cz);
+    se3_apply(T, du[0], du[1], du[2], ux, uy, uz);
+    se3_apply(T, dv[0], dv[1], dv[2], vx, vy, vz);
+    world2cam(C.cam, cx, cy, cz, pc0, pc1);
+    world2cam(C.cam, ux, uy, uz, pu0, pu1);
+    world2cam(C.cam, vx, vy, vz, pv0, pv1);
+    A00 = (pu0 - pc0) / hp; A10 = (pu1 - pc1) / hp; A01 = (pv0 - pc0) / hp; A11 = (pv1 - pc1) / hp;
+  }
+  int sl = 0;
+  { double D = A00 * A11 - A10 * A01; while (D > 3.0 && sl < HSO_N_SOBEL_LEVELS - 1) { sl += 1; D *= 0.25; } }
+  P.sl = sl;
+  P.exposure_rat = (float)(F.exposure / S.ref_exposure);
+  {
+    const double det = A00 * A11 - A10 * A01;
+    const double invdet = 1.0 / det;
+    P.a00 = (float)(A11 * invdet); P.a01 = (float)(-A01 * invdet); P.a10 = (float)(-A10 * invdet); P.a11 = (float)(A00 * invdet);
+    P.warp_nan = isnan(P.a00) ? 1 : 0;
+    P.scale_exposure = fabsf(P.exposure_rat * 128 - 128) > 30.0f ? 1 : 0;  // :818-826 (no keyframe-gap test here)
+  }
+  // close / far points on the unit plane, :834-852
+  double pcx, pcy, pcz, pfx, pfy, pfz;
+  se3_apply(T, S.f[0] * min_idepth, S.f[1] * min_idepth, S.f[2] * min_idepth, pcx, pcy, pcz);
+  pcx /= pcz; pcy /= pcz;
+  se3_apply(T, S.f[0] * max_idepth, S.f[1] * max_idepth, S.f[2] * max_idepth, pfx, pfy, pfz);
+  if (pfz < 0.001 || max_idepth < min_idepth) return P;
+  pfx /= pfz; pfy /= pfz;
+  if (isnan((float)(pfx + pcx))) return P;
+  double pxc0, pxc1, pxf0, pxf1;
+  world2cam(C.cam, pcx, pcy, 1.0, pxc0, pxc1);
+  P.epl_start[0] = (int)pxc0; P.epl_start[1] = (int)pxc1;
+  pxc0 /= (double)(1 << sl); pxc1 /= (double)(1 << sl);
+  world2cam(C.cam, pfx, pfy, 1.0, pxf0, pxf1);
+  P.epl_end[0] = (int)pxf0; P.epl_end[1] = (int)pxf1;
+  pxf0 /= (double)(1 << sl); pxf1 /= (double)(1 << sl);
+  double incx = pxc0 - pxf0, incy = pxc1 - pxf1;
+  const double eplLength = sqrt(incx * incx + incy * incy);
+  if (((!eplLength) > 0) || isinf(eplLength)) return P;  // `!eplLength > 0`, :868
+  if (eplLength > 100.0) { pxc0 = pxf0 + incx * 100.0 / eplLength; pxc1 = pxf1 + incy * 100.0 / eplLength; }
+  incx *= 1.0 / eplLength; incy *= 1.0 / eplLength;
+  pxf0 -= incx; pxf1 -= incy; pxc0 += incx; pxc1 += incy;
+  if (eplLength < 2.0) {
+    const double pad = (2.0 - eplLength) / 2.0;
+    pxf0 -= incx * pad; pxf1 -= incy * pad; pxc0 += incx * pad; pxc1 += incy * pad;
+  }
+  double ed0 = pxc0 - pxf0, ed1 = pxc1 - pxf1;
+  { const double en = sqrt(ed0 * ed0 + ed1 * ed1); ed0 /= en; ed1 /= en; }
+  double dc0 = A00 * S.grad[0] + A01 * S.grad[1], dc1 = A10 * S.grad[0] + A11 * S.grad[1];
+  { const double dn = sqrt(dc0 * dc0 + dc1 * dc1); dc0 /= dn; dc1 /= dn; }
+  if (S.type == HSO_FTR_GRADIENT || S.type == HSO_FTR_EDGELET) {
+    if (fabs(dc0 * ed0 + dc1 * ed1) < 0.4) return P;  // epi_search_edgelet_max_angle, matcher.h:130
+  }
+  P.pxc0 = pxc0; P.pxc1 = pxc1; P.pxf0 = pxf0; P.pxf1 = pxf1; P.incx = incx; P.incy = incy;
+  P.ed0 = ed0; P.ed1 = ed1; P.dc0 = dc0; P.dc1 = dc1;
+  P.state = 0;
+  return P;
+}
+
+HSO_DEV SeedMid seed_wave(const SeedConsts& C, const SeedDev& SD, const uint8_t* cur_base, const SeedPre& P, float* pwb_lds)
+{
+  const hso_seed& S = SD.s;
+  const int lane = threadIdx.x & 63;
+  const int W = C.g.w[0], H = C.g.h[0];
+  SeedMid M;
+  M.px0 = M.px1 = 0; M.zmncc_best = M.zmncc_second = 0; M.n_steps = 0; M.res_code = -4;
+  const int sl = P.sl;
+  const double pxc0 = P.pxc0, pxc1 = P.pxc1, pxf0 = P.pxf0, pxf1 = P.pxf1, incx = P.incx, incy = P.incy;
+  const double ed0 = P.ed0, ed1 = P.ed1, dc0 = P.dc0, dc1 = P.dc1;
+  hso_seed_out o;   // the march bookkeeping below writes o.n_steps / o.zmncc_*: collected into M afterwards
+  o.n_steps = 0; o.zmncc_best = 0; o.zmncc_second = 0;
   int res_code = -4;
+  double match_px0 = 0, match_px1 = 0;
   do {
-    double A00, A01, A10, A11;
     {
-      const int hp = 5;
-      const double xr = S.f[0] * prior_idepth, yr = S.f[1] * prior_idepth, zr = S.f[2] * prior_idepth;
-      const int ratio = 1 << S.level;
-      double du[3], dv[3];
-      cam2world_dev(C.cam, S.px[0] + (double)(hp * ratio), S.px[1] + (double)(0 * ratio), du);
-      cam2world_dev(C.cam, S.px[0] + (double)(0 * ratio), S.px[1] + (double)(hp * ratio), dv);
-      const double su = zr / du[2], sv = zr / dv[2];
-      for (int i = 0; i < 3; i++) { du[i] *= su; dv[i] *= sv; }
-      double cx, cy, cz, ux, uy, uz, vx, vy, vz, pc0, pc1, pu0, pu1, pv0, pv1;
-      se3_apply(T, xr, yr, zr, cx, cy, cz);
-      se3_apply(T, du[0], du[1], du[2], ux, uy, uz);
-      se3_apply(T, dv[0], dv[1], dv[2], vx, vy, vz);
-      world2cam(C.cam, cx, cy, cz, pc0, pc1);
-      world2cam(C.cam, ux, uy, uz, pu0, pu1);
-      world2cam(C.cam, vx, vy, vz, pv0, pv1);
-      A00 = (pu0 - pc0) / hp; A10 = (pu1 - pc1) / hp; A01 = (pv0 - pc0) / hp; A11 = (pv1 - pc1) / hp;
-    }
-    int sl = 0;
-    { double D = A00 * A11 - A10 * A01; while (D > 3.0 && sl < HSO_N_SOBEL_LEVELS - 1) { sl += 1; D *= 0.25; } }
-    o.search_level = sl;
-    const float exposure_rat = (float)(F.exposure / S.ref_exposure);
-    {
-      const double det = A00 * A11 - A10 * A01;
-      const double invdet = 1.0 / det;
-      const float a00 = (float)(A11 * invdet), a01 = (float)(-A01 * invdet), a10 = (float)(-A10 * invdet), a11 = (float)(A00 * invdet);
-      const bool warp_nan = isnan(a00);
+      // warp::createPatch (matcher.cpp:159-196): 10x10 samples of the reference level
+      const float a00 = P.a00, a01 = P.a01, a10 = P.a10, a11 = P.a11, exposure_rat = P.exposure_rat;
+      const bool warp_nan = P.warp_nan != 0, scale_exposure = P.scale_exposure != 0;
       const int L = S.level, cols = C.g.w[L], rows = C.g.h[L];  // img_pyr_[L].cols / rows
       const uint8_t* img = SD.ref_base + C.g.off[L];
       const float rx = (float)(S.px[0] / (double)(1 << L)), ry = (float)(S.px[1] / (double)(1 << L));
       const float scaleTarget = (float)(1 << sl);
-      const bool scale_exposure = fabsf(exposure_rat * 128 - 128) > 30.0f;  // :818-826 (no keyframe-gap test here)
       for (int idx = lane; idx < 100; idx += 64) {
         const int y = idx / 10, x = idx - 10 * y;
         float p0 = (float)(x - 5), p1 = (float)(y - 5);
@@ -266,49 +332,16 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
         float val = 0;
         if (!warp_nan && !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1))) val = interpolate_8u(img, cols, px0, px1);
         if (scale_exposure) val = val * exposure_rat;
-        s_pwb[wave][idx] = val;
+        pwb_lds[idx] = val;
       }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int px_ = lane & 7, py_ = lane >> 3;
-    const float* pwb = s_pwb[wave];
+    const float* pwb = pwb_lds;
     const int c = (py_ + 1) * 10 + px_ + 1;
     const float ref_px = pwb[c];
     const float gxr = pwb[c + 1] - pwb[c - 1], gyr = pwb[c + 10] - pwb[c - 10];
-
-    // close / far points on the unit plane, :834-852
-    double pcx, pcy, pcz, pfx, pfy, pfz;
-    se3_apply(T, S.f[0] * min_idepth, S.f[1] * min_idepth, S.f[2] * min_idepth, pcx, pcy, pcz);
-    pcx /= pcz; pcy /= pcz;
-    se3_apply(T, S.f[0] * max_idepth, S.f[1] * max_idepth, S.f[2] * max_idepth, pfx, pfy, pfz);
-    if (pfz < 0.001 || max_idepth < min_idepth) { res_code = -1; break; }
-    pfx /= pfz; pfy /= pfz;
-    if (isnan((float)(pfx + pcx))) { res_code = -1; break; }
-    double pxc0, pxc1, pxf0, pxf1;
-    world2cam(C.cam, pcx, pcy, 1.0, pxc0, pxc1);
-    o.epl_start[0] = (int)pxc0; o.epl_start[1] = (int)pxc1;
-    pxc0 /= (double)(1 << sl); pxc1 /= (double)(1 << sl);
-    world2cam(C.cam, pfx, pfy, 1.0, pxf0, pxf1);
-    o.epl_end[0] = (int)pxf0; o.epl_end[1] = (int)pxf1;
-    pxf0 /= (double)(1 << sl); pxf1 /= (double)(1 << sl);
-    double incx = pxc0 - pxf0, incy = pxc1 - pxf1;
-    const double eplLength = sqrt(incx * incx + incy * incy);
-    if (((!eplLength) > 0) || isinf(eplLength)) { res_code = -1; break; }  // `!eplLength > 0`, :868
-    if (eplLength > 100.0) { pxc0 = pxf0 + incx * 100.0 / eplLength; pxc1 = pxf1 + incy * 100.0 / eplLength; }
-    incx *= 1.0 / eplLength; incy *= 1.0 / eplLength;
-    pxf0 -= incx; pxf1 -= incy; pxc0 += incx; pxc1 += incy;
-    if (eplLength < 2.0) {
-      const double pad = (2.0 - eplLength) / 2.0;
-      pxf0 -= incx * pad; pxf1 -= incy * pad; pxc0 += incx * pad; pxc1 += incy * pad;
-    }
-    double ed0 = pxc0 - pxf0, ed1 = pxc1 - pxf1;
-    { const double en = sqrt(ed0 * ed0 + ed1 * ed1); ed0 /= en; ed1 /= en; }
-    double dc0 = A00 * S.grad[0] + A01 * S.grad[1], dc1 = A10 * S.grad[0] + A11 * S.grad[1];
-    { const double dn = sqrt(dc0 * dc0 + dc1 * dc1); dc0 /= dn; dc1 /= dn; }
-    if (S.type == HSO_FTR_GRADIENT || S.type == HSO_FTR_EDGELET) {
-      if (fabs(dc0 * ed0 + dc1 * ed1) < 0.4) { res_code = -1; break; }  // epi_search_edgelet_max_angle, matcher.h:130
-    }
 
     // ---- march along the epipolar line, ZMNCC per step (:906-960)
     const int cols = C.g.w[sl], rows = C.g.h[sl];
@@ -390,27 +423,53 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
       result = ((double)num / ((double)sqrtf(den1 * den2) + 1e-12)) > (double)(float)0.8;
     }
     if (!result) { res_code = -3; break; }
-    pxcur0 = ps0 * (double)(1 << sl); pxcur1 = ps1 * (double)(1 << sl);
-    o.px_cur[0] = pxcur0; o.px_cur[1] = pxcur1;
-    // depthFromTriangulation(T_cur_ref, f_ref, cam2world(px_cur_)), :242-255
-    double fc[3];
-    cam2world_dev(C.cam, pxcur0, pxcur1, fc);
-    double R[9];
-    so3_matrix(T, R);
-    double a0[3];
-    for (int i = 0; i < 3; i++) a0[i] = R[i * 3 + 0] * S.f[0] + R[i * 3 + 1] * S.f[1] + R[i * 3 + 2] * S.f[2];
-    const double m00 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2];
-    const double m01 = a0[0] * fc[0] + a0[1] * fc[1] + a0[2] * fc[2];
-    const double m11 = fc[0] * fc[0] + fc[1] * fc[1] + fc[2] * fc[2];
-    const double det = m00 * m11 - m01 * m01;
-    if (det < 0.000001) { res_code = -2; break; }
-    const double invdet = 1.0 / det;
-    const double i00 = m11 * invdet, i01 = -m01 * invdet;
-    const double r0x = (-i00) * a0[0] + (-i01) * fc[0], r0y = (-i00) * a0[1] + (-i01) * fc[1], r0z = (-i00) * a0[2] + (-i01) * fc[2];
-    o.z = fabs(r0x * T.tx + r0y * T.ty + r0z * T.tz);
+    match_px0 = ps0 * (double)(1 << sl); match_px1 = ps1 * (double)(1 << sl);
     res_code = 1;
   } while (0);
+  M.res_code = res_code; M.px0 = match_px0; M.px1 = match_px1;
+  M.n_steps = o.n_steps; M.zmncc_best = o.zmncc_best; M.zmncc_second = o.zmncc_second;
+  return M;
+}
 
+HSO_DEV hso_seed_out seed_post(const SeedConsts& C, const SeedDev& SD, const SeedFrameDev& F, const SeedPre& P, const SeedMid& M)
+{
+  const hso_seed& S = SD.s;
+  hso_seed_out o;
+  memset(&o, 0, sizeof(o));
+  o.mu = S.mu; o.sigma2 = S.sigma2; o.b = S.b; o.is_valid = 1;
+  if (P.state == 1) { o.result = 0; o.is_update = 0; return o; }   // not visible: nothing else is touched
+  o.is_update = 1;
+  o.is_valid = P.is_valid;
+  o.search_level = P.sl;
+  const Se3 Tcw = se3_from(F.T_f_w), Trw = se3_from(S.T_ref_w);
+  const Se3 T_ref_cur = se3_mul(Trw, se3_inverse(Tcw));
+  const Se3 T = se3_mul(Tcw, se3_inverse(Trw));  // T_cur_ref, :807
+  int res_code = -1;
+  if (P.state == 0) {
+    o.epl_start[0] = P.epl_start[0]; o.epl_start[1] = P.epl_start[1]; o.epl_end[0] = P.epl_end[0]; o.epl_end[1] = P.epl_end[1];
+    o.n_steps = M.n_steps; o.zmncc_best = M.zmncc_best; o.zmncc_second = M.zmncc_second;
+    res_code = M.res_code;
+    if (res_code == 1) do {
+      const double pxcur0 = M.px0, pxcur1 = M.px1;
+      o.px_cur[0] = pxcur0; o.px_cur[1] = pxcur1;
+      // depthFromTriangulation(T_cur_ref, f_ref, cam2world(px_cur_)), :242-255
+      double fc[3];
+      cam2world_dev(C.cam, pxcur0, pxcur1, fc);
+      double R[9];
+      so3_matrix(T, R);
+      double a0[3];
+      for (int i = 0; i < 3; i++) a0[i] = R[i * 3 + 0] * S.f[0] + R[i * 3 + 1] * S.f[1] + R[i * 3 + 2] * S.f[2];
+      const double m00 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2];
+      const double m01 = a0[0] * fc[0] + a0[1] * fc[1] + a0[2] * fc[2];
+      const double m11 = fc[0] * fc[0] + fc[1] * fc[1] + fc[2] * fc[2];
+      const double det = m00 * m11 - m01 * m01;
+      if (det < 0.000001) { res_code = -2; break; }
+      const double invdet = 1.0 / det;
+      const double i00 = m11 * invdet, i01 = -m01 * invdet;
+      const double r0x = (-i00) * a0[0] + (-i01) * fc[0], r0y = (-i00) * a0[1] + (-i01) * fc[1], r0z = (-i00) * a0[2] + (-i01) * fc[2];
+      o.z = fabs(r0x * T.tx + r0y * T.ty + r0z * T.tz);
+    } while (0);
+  }
   o.result = res_code;
   if (res_code != 1) {
     o.b = S.b + 1;  // :634
@@ -439,7 +498,53 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     id_var *= w;
     o.sigma2 = (id_var < S.sigma2) ? id_var : S.sigma2;
   }
-  seed_finish(C, seeds, sid, outs, o, lane);
+  return o;
+}
+
+__global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(SeedConsts C, SeedDev* seeds, int n_seeds,
+                                                                             hso_seed_out* outs, int cpw)
+{
+  __shared__ float s_pwb[SEED_WAVES_PER_BLOCK][100];
+  __shared__ SeedPre s_pre[SEED_WAVES_PER_BLOCK][SEED_CPW_MAX];
+  __shared__ SeedMid s_mid[SEED_WAVES_PER_BLOCK][SEED_CPW_MAX];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int first = (blockIdx.x * SEED_WAVES_PER_BLOCK + wave) * cpw;
+  if (first >= n_seeds) return;
+  const int mine = first + lane;
+  const bool own = lane < cpw && mine < n_seeds;
+  const bool live = own && seeds[mine].ref_base != nullptr;     // a null reference: an erased slot of a resident table
+  if (live) s_pre[wave][lane] = seed_pre(C, seeds[mine], C.frames[seeds[mine].frame]);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int q = 0; q < cpw; q++) {
+    const int sid = first + q;
+    if (sid >= n_seeds) break;
+    const SeedDev& SD = seeds[sid];
+    if (SD.ref_base == nullptr || s_pre[wave][q].state != 0) continue;
+    const uint8_t* const cur_base = SD.cur_base ? SD.cur_base : C.frames[SD.frame].cur_base;
+    const SeedMid M = seed_wave(C, SD, cur_base, s_pre[wave][q], s_pwb[wave]);
+    if (lane == 0) s_mid[wave][q] = M;
+    __builtin_amdgcn_wave_barrier();                          // the next seed overwrites this wave's patch
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (own) {
+    if (!live) {
+      if (C.brief) { hso_seed_brief br; memset(&br, 0, sizeof(br)); C.brief[mine] = br; }
+    } else {
+      const hso_seed_out o = seed_post(C, seeds[mine], C.frames[seeds[mine].frame], s_pre[wave][lane], s_mid[wave][lane]);
+      seed_finish(C, seeds, mine, outs, o, 0);
+    }
+  }
+}
+
+// seeds per wave for a batch of n: one per wave until the chip holds ~8 waves per SIMD of them, then doubling (see align_cpw)
+static int seed_cpw(const hso_gpu_ctx* ctx, int n)
+{
+  const long long spread = (long long)ctx->n_cu * 4 * 8;
+  int cpw = 1;
+  while (cpw < SEED_CPW_MAX && (long long)n > spread * cpw) cpw *= 2;
+  return cpw;
 }
 
 extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed_frame* frames, int n_frames,
@@ -499,8 +604,9 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_fr, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
   C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle; C.update_in_place = 0; C.brief = nullptr;
-  const int blocks = (n_seeds + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK;
-  hipLaunchKernelGGL(k_seed_observe, dim3(blocks), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, d_in, n_seeds, d_out);
+  const int cpw = seed_cpw(ctx, n_seeds);
+  const int blocks = ((n_seeds + cpw - 1) / cpw + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(k_seed_observe, dim3(blocks), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, d_in, n_seeds, d_out, cpw);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n_seeds * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -684,8 +790,9 @@ int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int tabl
   SeedConsts C;
   C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief;
   const int n = (int)t->n;
-  hipLaunchKernelGGL(k_seed_observe, dim3((n + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C,
-                     t->d, n, full_out ? t->d_full : nullptr);
+  const int cpw = seed_cpw(ctx, n);
+  hipLaunchKernelGGL(k_seed_observe, dim3(((n + cpw - 1) / cpw + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK), dim3(64 * SEED_WAVES_PER_BLOCK), 0,
+                     ctx->stream, C, t->d, n, full_out ? t->d_full : nullptr, cpw);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   if (brief_out) {
     hso_seed_brief* hb = reinterpret_cast<hso_seed_brief*>(hso_pinned(ctx, 1, t->n * sizeof(hso_seed_brief)));
