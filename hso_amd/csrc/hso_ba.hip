@@ -49,9 +49,27 @@ struct BaArgs {
   double* edge_rho;   // [n_edges]
 };
 
+// One local-BA window on the device.  Every kernel below takes the table of windows and a list of the windows it works on
+// (blockIdx.y indexes the list): the windows of many sequences share every launch.
+struct BaProb {
+  BaArgs a;
+  const int* off; const int* list;      // CSR of edges by point (edge order kept)
+  const int* poff; const int* plist;    // CSR of edges by pose-pair block
+  double* Hpp; double* bp; double* Hpc; double* Hcc; double* bc;
+  double* sum;                          // [0] chi2, [1] robust chi2, [2] sum over points of xp (lambda xp + bp)
+  const int* col;                       // [n_poses] first row of the pose in the reduced system, -1 = fixed
+  double* S; double* rhs;               // reduced (Schur) system [M * M], [M]; S[M * M] doubles as the "solvable" flag slot
+  const double* trial;                  // [0] lambda, [1 ...] pose steps xc [6 * n_poses], then != 0: the solve failed, no step
+  double* xp;                           // [n_points] point steps of the last back-substitution
+  double* idist_rw;                     // a.idist, writable
+  double* idist_bak;                    // the state before the last step (g2o's push())
+  int M, n_pairs;
+};
+
 template <bool LIN>   // LIN = false: errors, chi2 and rho only (an LM trial's computeActiveErrors)
-__global__ __launch_bounds__(BA_THREADS) void k_ba_edges(BaArgs a)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_edges(const BaProb* probs, const int* active)
 {
+  const BaArgs a = probs[active[blockIdx.y]].a;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.n_edges) return;
   const hso_ba_edge e = a.edges[k];
@@ -174,9 +192,12 @@ HSO_DEV double ba_omega_r(const BaArgs& a, int k, const EdgeLin& L, int d)
   return -(om * L.err[d]) * rho1;
 }
 
-__global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaArgs a, const int* pt_off, const int* pt_edges,
-                                                          double* Hpp, double* bp, double* Hpc)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_points(const BaProb* probs, const int* active)
 {
+  const BaProb& P = probs[active[blockIdx.y]];
+  const BaArgs a = P.a;
+  const int* pt_off = P.off; const int* pt_edges = P.list;
+  double* Hpp = P.Hpp; double* bp = P.bp; double* Hpc = P.Hpc;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.n_points) return;
   double hpp = 0, b = 0;
@@ -199,14 +220,18 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaArgs a, const int* p
 // pr_off / pr_edges: CSR of the edges that touch each block's pose pair (host-built, edge order
 // kept): diagonal block i lists every edge with host == i or target == i, block (i, j) every edge
 // whose two frames are {i, j} — a block reads only its own edges instead of scanning all of them.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_poses(BaArgs a, const int* pr_off, const int* pr_edges, double* Hcc, double* bc,
-                                                         double* chi2_sum)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, const int* active)
 {
   __shared__ double s_part[BA_WAVES][44];
+  const BaProb& P = probs[active[blockIdx.y]];
+  const BaArgs a = P.a;
+  const int* pr_off = P.poff; const int* pr_edges = P.plist;
+  double* Hcc = P.Hcc; double* bc = P.bc; double* chi2_sum = P.sum;
   // block -> (i, j), i <= j; one extra block sums the chi2 values
   const int np = a.n_poses;
   int b = blockIdx.x, i = 0;
   const int n_pairs = np * (np + 1) / 2;
+  if (b > n_pairs) return;   // the grid is sized for the largest window of the launch
   const bool chi_block = (b == n_pairs);
   const int q0 = chi_block ? 0 : pr_off[b], q1 = chi_block ? 0 : pr_off[b + 1];
   int j = 0;
@@ -271,9 +296,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(BaArgs a, const int* pr
 
 // sum of chi2 and of the robustified rho(chi2) over all edges (activeChi2 / activeRobustChi2,
 // thirdparty/g2o/g2o/core/sparse_optimizer.cpp:100-113): one workgroup, fixed tree => deterministic
-__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(BaArgs a, double* chi2_sum)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, const int* active)
 {
   __shared__ double s_part[BA_WAVES][2];
+  const BaProb& P = probs[active[blockIdx.y]];
+  const BaArgs a = P.a;
+  double* chi2_sum = P.sum;
   double c = 0, r = 0;
   for (int k = threadIdx.x; k < a.n_edges; k += BA_THREADS) { c += a.edge_chi2[k]; r += a.edge_rho[k]; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -289,6 +317,119 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(BaArgs a, double* chi2_s
     for (int w = 0; w < BA_WAVES; w++) t += s_part[w][threadIdx.x];
     chi2_sum[threadIdx.x] = t;
   }
+}
+
+// The reduced system of one LM trial on the device: S = Hcc_free + lambda I - sum_p Hpc_p^T (Hpp_p + lambda)^-1 Hpc_p and
+// rhs = bc - sum_p Hpc_p^T bp_p / (Hpp_p + lambda) (the points are 1-D, so the Schur complement is scalar).  One block per
+// pose-pair block (i <= j) of the window: threads stride over the points (rows of Hpc of unconnected poses are zero), then
+// the fixed tree of k_ba_poses; the block writes its 6x6 piece to both triangles of S.  Only M * M + M doubles go back to the
+// host for the dense factorisation — not the n_points x n_poses x 6 block table.
+__global__ __launch_bounds__(BA_THREADS) void k_ba_schur(const BaProb* probs, const int* active)
+{
+  __shared__ double s_part[BA_WAVES][44];
+  const BaProb& P = probs[active[blockIdx.y]];
+  const int np = P.a.n_poses, n_pairs = np * (np + 1) / 2, M = P.M;
+  int b = blockIdx.x, i = 0;
+  if (b > n_pairs) return;
+  const double lambda = P.trial[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (b == n_pairs) {   // the extra block: is every point diagonal invertible?  (the host solver's `ok`)
+    int bad = 0;
+    for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) { const double dpp = P.Hpp[p] + lambda; if (!(dpp != 0.0) || !isfinite(dpp)) bad = 1; }
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) P.S[(size_t)M * M] = bad ? 0.0 : 1.0;
+    return;
+  }
+  while (b >= np - i) { b -= np - i; i++; }
+  const int j = i + b;
+  const int ci = P.col[i], cj = P.col[j];
+  if (ci < 0 || cj < 0) return;
+  double acc[44];
+#pragma unroll
+  for (int q = 0; q < 44; q++) acc[q] = 0;
+  for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) {
+    const double dpp = P.Hpp[p] + lambda;
+    if (!(dpp != 0.0) || !isfinite(dpp)) continue;
+    const double inv = 1.0 / dpp;
+    const double* Wi = P.Hpc + ((size_t)p * np + i) * 6;
+    const double* Wj = P.Hpc + ((size_t)p * np + j) * 6;
+    double wi[6], wj[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) { wi[r] = Wi[r]; wj[r] = Wj[r]; }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double wr = wi[r] * inv;
+#pragma unroll
+      for (int c = 0; c < 6; c++) acc[r * 6 + c] += wr * wj[c];
+    }
+    if (i == j) {
+      const double g = P.bp[p] * inv;
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[36 + r] += wi[r] * g;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 44; q++) {
+    const double x = wave_butterfly_sum(acc[q]);
+    if (lane == 0) s_part[wave][q] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 42) {
+    double t = 0;
+    for (int w = 0; w < BA_WAVES; w++) t += s_part[w][threadIdx.x];
+    if (threadIdx.x < 36) {
+      const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+      double v = P.Hcc[((size_t)i * np + j) * 36 + threadIdx.x];
+      if (i == j && r == c) v += lambda;
+      v -= t;
+      P.S[(size_t)(ci + r) * M + cj + c] = v;
+      if (i != j) P.S[(size_t)(cj + c) * M + ci + r] = v;
+    } else if (i == j) {
+      P.rhs[ci + threadIdx.x - 36] = P.bc[i * 6 + threadIdx.x - 36] - t;
+    }
+  }
+}
+
+// Back-substitution of the points, their update and the point part of computeScale: x_p = (bp_p - Hpc_p . xc) / (Hpp_p +
+// lambda) with the poses in index order (products with the zero rows of unconnected poses change nothing, so the value
+// equals the sparse loop's); idist_bak keeps the state before the step (g2o's push()).  One block per window.
+__global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, const int* active)
+{
+  __shared__ double s_part[BA_WAVES];
+  const BaProb& P = probs[active[blockIdx.y]];
+  const int np = P.a.n_poses;
+  const double lambda = P.trial[0];
+  const double* xc = P.trial + 1;
+  const bool no_step = P.trial[1 + 6 * np] != 0.0;   // the reduced system could not be solved: x = 0 (the trial is rejected)
+  double sc = 0;
+  for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) {
+    const double dpp = P.Hpp[p] + lambda;
+    const double inv = 1.0 / dpp;
+    double s = P.bp[p];
+    for (int i = 0; i < np; i++) {
+      if (P.col[i] < 0) continue;
+      const double* W = P.Hpc + ((size_t)p * np + i) * 6;
+#pragma unroll
+      for (int r = 0; r < 6; r++) s -= W[r] * xc[i * 6 + r];
+    }
+    const double x = no_step ? 0.0 : s * inv;
+    P.xp[p] = x;
+    const double id = P.idist_rw[p];
+    P.idist_bak[p] = id;
+    P.idist_rw[p] = id + x;                          // VertexSBAPointID::oplusImpl
+    sc += x * (lambda * x + P.bp[p]);
+  }
+  sc = wave_butterfly_sum(sc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < BA_WAVES; w++) t += s_part[w]; P.sum[2] = t; }
+}
+
+// g2o's pop() for the points: the state before the rejected step
+__global__ __launch_bounds__(BA_THREADS) void k_ba_restore(const BaProb* probs, const int* active)
+{
+  const BaProb& P = probs[active[blockIdx.y]];
+  for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) P.idist_rw[p] = P.idist_bak[p];
 }
 
 // per-edge error magnitudes for the Huber deltas of LocalBundleAdjustment (src/bundle_adjustment.cpp:618-656):
@@ -313,17 +454,32 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_mad_errors(const hso_se3* pos
 
 // One BA problem resident in the context's work area: inputs uploaded once, the state (poses, inverse depths)
 // refreshed per evaluation, the blocks read back per linearisation.
-struct BaDev {
-  hso_gpu_ctx* ctx;
-  int n_poses, n_points, n_edges, n_pairs;
-  size_t o_poses, o_fixed, o_idist, o_edges, o_off, o_list, o_poff, o_plist, in_bytes, o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc,
-      o_bc, o_err, o_chi, o_sum, total;
-  char* d;
-  char* h;
-  BaArgs a;
-  std::vector<int> off, list, poff, plist;   // CSR of edges by point / by pose-pair block (host copies, uploaded by ba_place)
+// ---------------------------------------------------------------------------------------------------------------- host side
+// A set of windows laid out one after the other in the context's work area, with one table of BaProb records and the lists
+// of windows each launch works on.  Pinned staging mirrors the small per-trial blocks (in) and the small results (out).
+struct BaWin {
+  int n_poses, n_points, n_edges, n_pairs, M;
   double huber_corner, huber_edge;
+  std::vector<int> off, list, poff, plist, col;
+  // byte offsets inside the window's device slice
+  size_t o_trial, o_poses, o_idist, o_fixed, o_edges, o_off, o_list, o_poff, o_plist, o_col, in_bytes;
+  size_t o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc, o_bc, o_err, o_chi, o_sum, o_S, o_rhs, o_xp, o_bak, total;
+  size_t trial_bytes;   // [lambda | xc | pad | poses]: what an LM trial uploads
+  char* d;              // device slice
+  char* h_in;           // pinned: the window's upload image (first in_bytes of the slice)
+  char* h_out;          // pinned: [sum (256 B) | S | flag | rhs]
+  size_t out_bytes;
 };
+
+struct BaBatch {
+  hso_gpu_ctx* ctx;
+  std::vector<BaWin> win;
+  BaProb* d_probs = nullptr;
+  int* d_active = nullptr;       // BA_N_LISTS lists of n windows each
+  int* h_active = nullptr;       // pinned
+  int n = 0;
+};
+#define BA_N_LISTS 6
 
 static int ba_check_edges(hso_gpu_ctx* ctx, const hso_ba_edge* edges, int n_edges, int n_points, int n_poses, const char* who)
 {
@@ -338,50 +494,56 @@ static int ba_check_edges(hso_gpu_ctx* ctx, const hso_ba_edge* edges, int n_edge
   return HSO_OK;
 }
 
-// sizes, offsets and the two CSR tables of one problem (no device work)
-static void ba_layout(BaDev& B, hso_gpu_ctx* ctx, int n_poses, int n_points, const hso_ba_edge* edges, int n_edges,
+// sizes, offsets and the CSR tables of one window (no device work)
+static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_fixed, const hso_ba_edge* edges, int n_edges,
                       double huber_corner, double huber_edge)
 {
-  B.ctx = ctx; B.n_poses = n_poses; B.n_points = n_points; B.n_edges = n_edges;
+  B.n_poses = n_poses; B.n_points = n_points; B.n_edges = n_edges;
   B.huber_corner = huber_corner; B.huber_edge = huber_edge;
   // CSR of edges by point, edge order kept inside a point (g2o visits edges in insertion order)
-  std::vector<int>& off = B.off; std::vector<int>& list = B.list;
-  off.assign(n_points + 1, 0); list.assign(n_edges, 0);
-  for (int k = 0; k < n_edges; k++) off[edges[k].point + 1]++;
-  for (int p = 0; p < n_points; p++) off[p + 1] += off[p];
-  { std::vector<int> cur(off.begin(), off.end() - 1); for (int k = 0; k < n_edges; k++) list[cur[edges[k].point]++] = k; }
-
+  B.off.assign(n_points + 1, 0); B.list.assign(n_edges, 0);
+  for (int k = 0; k < n_edges; k++) B.off[edges[k].point + 1]++;
+  for (int p = 0; p < n_points; p++) B.off[p + 1] += B.off[p];
+  { std::vector<int> cur(B.off.begin(), B.off.end() - 1); for (int k = 0; k < n_edges; k++) B.list[cur[edges[k].point]++] = k; }
   // CSR of edges by pose-pair block (same block numbering as k_ba_poses), edge order kept
   const int n_pairs = n_poses * (n_poses + 1) / 2;
   B.n_pairs = n_pairs;
   auto pair_id = [n_poses](int i, int j) { return i * n_poses - i * (i - 1) / 2 + (j - i); };  // i <= j
-  std::vector<int>& poff = B.poff; std::vector<int>& plist = B.plist;
-  poff.assign(n_pairs + 1, 0); plist.assign((size_t)3 * n_edges, 0);
+  B.poff.assign(n_pairs + 1, 0); B.plist.assign((size_t)3 * n_edges, 0);
   for (int k = 0; k < n_edges; k++) {
     const int h_ = edges[k].host, t_ = edges[k].target;
-    poff[pair_id(h_, h_) + 1]++; poff[pair_id(t_, t_) + 1]++;
-    poff[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_) + 1]++;
+    B.poff[pair_id(h_, h_) + 1]++; B.poff[pair_id(t_, t_) + 1]++;
+    B.poff[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_) + 1]++;
   }
-  for (int q = 0; q < n_pairs; q++) poff[q + 1] += poff[q];
+  for (int q = 0; q < n_pairs; q++) B.poff[q + 1] += B.poff[q];
   {
-    std::vector<int> cur(poff.begin(), poff.end() - 1);
+    std::vector<int> cur(B.poff.begin(), B.poff.end() - 1);
     for (int k = 0; k < n_edges; k++) {
       const int h_ = edges[k].host, t_ = edges[k].target;
-      plist[cur[pair_id(h_, h_)]++] = k; plist[cur[pair_id(t_, t_)]++] = k;
-      plist[cur[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_)]++] = k;
+      B.plist[cur[pair_id(h_, h_)]++] = k; B.plist[cur[pair_id(t_, t_)]++] = k;
+      B.plist[cur[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_)]++] = k;
     }
   }
+  // the reduced system: free poses in index order
+  B.col.assign(n_poses, -1);
+  int n_free = 0;
+  for (int i = 0; i < n_poses; i++) if (!pose_fixed[i]) B.col[i] = 6 * n_free++;
+  B.M = 6 * n_free;
 
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   size_t o = 0;
+  // [lambda | xc | pad | poses | idist]: the trial block first, the state right behind it
+  B.o_trial = o; o += al(sizeof(double) * (2 + 6 * (size_t)n_poses));   // lambda, xc, "no step" flag
   B.o_poses = o; o += al(sizeof(hso_se3) * n_poses);
-  B.o_idist = o; o += al(sizeof(double) * n_points);      // poses | idist: the state, contiguous
+  B.trial_bytes = o;
+  B.o_idist = o; o += al(sizeof(double) * n_points);
   B.o_fixed = o; o += al(n_poses);
   B.o_edges = o; o += al(sizeof(hso_ba_edge) * n_edges);
   B.o_off = o; o += al(sizeof(int) * (n_points + 1));
   B.o_list = o; o += al(sizeof(int) * n_edges);
   B.o_poff = o; o += al(sizeof(int) * (n_pairs + 1));
   B.o_plist = o; o += al(sizeof(int) * 3 * (size_t)n_edges);
+  B.o_col = o; o += al(sizeof(int) * n_poses);
   B.in_bytes = o;
   B.o_lin = o; o += al(sizeof(double) * BA_LIN * n_edges);
   B.o_rho = o; o += al(sizeof(double) * n_edges);
@@ -393,102 +555,131 @@ static void ba_layout(BaDev& B, hso_gpu_ctx* ctx, int n_poses, int n_points, con
   B.o_bc = o; o += al(sizeof(double) * n_poses * 6);
   B.o_err = o; o += al(sizeof(double) * 2 * n_edges);
   B.o_chi = o; o += al(sizeof(double) * n_edges);
+  // [sum | S | flag | rhs] contiguous: one copy brings a trial's results to the host
   B.o_sum = o; o += 256;
+  B.o_S = o; o += sizeof(double) * ((size_t)B.M * B.M + 1);
+  B.o_rhs = o; o += sizeof(double) * (size_t)B.M;
+  o = al(o);
+  B.out_bytes = o - B.o_sum;
+  B.o_xp = o; o += al(sizeof(double) * n_points);
+  B.o_bak = o; o += al(sizeof(double) * n_points);
   B.total = o;
 }
 
-// one grow-only device work area + pinned staging for a set of problems laid out one after the other
-static int ba_reserve(hso_gpu_ctx* ctx, size_t dev_bytes, size_t pinned_bytes, char** d, char** h)
+// reserve the work area and staging for all windows, upload everything that does not change between evaluations
+static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n)
 {
+  Q.ctx = ctx; Q.n = n;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (ctx->batch_cap < dev_bytes) {  // grow-only work area of the context (shared with the other batched entry points)
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  size_t dev = al(sizeof(BaProb) * (size_t)n) + al(sizeof(int) * (size_t)n * BA_N_LISTS), pin_in = dev, pin_out = 0;
+  const size_t hdr = dev;
+  for (int q = 0; q < n; q++) { dev += Q.win[q].total; pin_in += Q.win[q].in_bytes; pin_out += Q.win[q].out_bytes; }
+  if (ctx->batch_cap < dev) {  // grow-only work area of the context (shared with the other batched entry points)
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), dev_bytes));
-    ctx->batch_cap = dev_bytes;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), dev));
+    ctx->batch_cap = dev;
   }
-  *d = reinterpret_cast<char*>(ctx->d_batch);
-  *h = hso_pinned(ctx, 0, pinned_bytes);
-  return *h ? HSO_OK : HSO_E_NOMEM;
-}
-
-// put a laid-out problem at d / h and upload everything that does not change between evaluations
-static int ba_place(BaDev& B, char* d, char* h, const hso_se3* poses_f_w, const uint8_t* pose_fixed, const double* idist,
-                    const hso_ba_edge* edges)
-{
-  hso_gpu_ctx* ctx = B.ctx;
-  const int n_poses = B.n_poses, n_points = B.n_points, n_edges = B.n_edges;
-  B.d = d; B.h = h;
-  memset(h, 0, B.in_bytes);
-  memcpy(h + B.o_poses, poses_f_w, sizeof(hso_se3) * n_poses);
-  memcpy(h + B.o_fixed, pose_fixed, n_poses);
-  memcpy(h + B.o_idist, idist, sizeof(double) * n_points);
-  memcpy(h + B.o_edges, edges, sizeof(hso_ba_edge) * n_edges);
-  memcpy(h + B.o_off, B.off.data(), sizeof(int) * (n_points + 1));
-  memcpy(h + B.o_list, B.list.data(), sizeof(int) * n_edges);
-  memcpy(h + B.o_poff, B.poff.data(), sizeof(int) * (B.n_pairs + 1));
-  memcpy(h + B.o_plist, B.plist.data(), sizeof(int) * 3 * (size_t)n_edges);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d, h, B.in_bytes, hipMemcpyHostToDevice, ctx->stream));
-  BaArgs& a = B.a;
-  a.poses = reinterpret_cast<const hso_se3*>(d + B.o_poses); a.fixed = reinterpret_cast<const uint8_t*>(d + B.o_fixed);
-  a.idist = reinterpret_cast<const double*>(d + B.o_idist); a.edges = reinterpret_cast<const hso_ba_edge*>(d + B.o_edges);
-  a.n_poses = n_poses; a.n_points = n_points; a.n_edges = n_edges;
-  a.huber_corner = B.huber_corner; a.huber_edge = B.huber_edge;
-  a.lin = reinterpret_cast<double*>(d + B.o_lin); a.edge_err = reinterpret_cast<double*>(d + B.o_err);
-  a.edge_chi2 = reinterpret_cast<double*>(d + B.o_chi); a.edge_rho = reinterpret_cast<double*>(d + B.o_rho);
+  char* d = reinterpret_cast<char*>(ctx->d_batch);
+  char* h = hso_pinned(ctx, 0, pin_in);
+  char* ho = hso_pinned(ctx, 1, std::max<size_t>(pin_out, 256));
+  if (!h || !ho) return HSO_E_NOMEM;
+  Q.d_probs = reinterpret_cast<BaProb*>(d);
+  Q.d_active = reinterpret_cast<int*>(d + al(sizeof(BaProb) * (size_t)n));
+  BaProb* hp = reinterpret_cast<BaProb*>(h);
+  Q.h_active = reinterpret_cast<int*>(h + al(sizeof(BaProb) * (size_t)n));
+  size_t od = hdr, oh = hdr, oo = 0;
+  for (int q = 0; q < n; q++) {
+    BaWin& B = Q.win[q];
+    const hso_ba_problem& P = problems[q];
+    B.d = d + od; B.h_in = h + oh; B.h_out = ho + oo;
+    od += B.total; oh += B.in_bytes; oo += B.out_bytes;
+    char* w = B.h_in;
+    memset(w, 0, B.in_bytes);
+    memcpy(w + B.o_poses, P.poses_f_w, sizeof(hso_se3) * B.n_poses);
+    memcpy(w + B.o_idist, P.idist, sizeof(double) * B.n_points);
+    memcpy(w + B.o_fixed, P.pose_fixed, B.n_poses);
+    memcpy(w + B.o_edges, P.edges, sizeof(hso_ba_edge) * B.n_edges);
+    memcpy(w + B.o_off, B.off.data(), sizeof(int) * (B.n_points + 1));
+    memcpy(w + B.o_list, B.list.data(), sizeof(int) * B.n_edges);
+    memcpy(w + B.o_poff, B.poff.data(), sizeof(int) * (B.n_pairs + 1));
+    memcpy(w + B.o_plist, B.plist.data(), sizeof(int) * 3 * (size_t)B.n_edges);
+    memcpy(w + B.o_col, B.col.data(), sizeof(int) * B.n_poses);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d, w, B.in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    BaProb& R = hp[q];
+    char* dd = B.d;
+    R.a.poses = reinterpret_cast<const hso_se3*>(dd + B.o_poses); R.a.fixed = reinterpret_cast<const uint8_t*>(dd + B.o_fixed);
+    R.a.idist = reinterpret_cast<const double*>(dd + B.o_idist); R.a.edges = reinterpret_cast<const hso_ba_edge*>(dd + B.o_edges);
+    R.a.n_poses = B.n_poses; R.a.n_points = B.n_points; R.a.n_edges = B.n_edges;
+    R.a.huber_corner = B.huber_corner; R.a.huber_edge = B.huber_edge;
+    R.a.lin = reinterpret_cast<double*>(dd + B.o_lin); R.a.edge_err = reinterpret_cast<double*>(dd + B.o_err);
+    R.a.edge_chi2 = reinterpret_cast<double*>(dd + B.o_chi); R.a.edge_rho = reinterpret_cast<double*>(dd + B.o_rho);
+    R.off = reinterpret_cast<const int*>(dd + B.o_off); R.list = reinterpret_cast<const int*>(dd + B.o_list);
+    R.poff = reinterpret_cast<const int*>(dd + B.o_poff); R.plist = reinterpret_cast<const int*>(dd + B.o_plist);
+    R.Hpp = reinterpret_cast<double*>(dd + B.o_Hpp); R.bp = reinterpret_cast<double*>(dd + B.o_bp);
+    R.Hpc = reinterpret_cast<double*>(dd + B.o_Hpc); R.Hcc = reinterpret_cast<double*>(dd + B.o_Hcc);
+    R.bc = reinterpret_cast<double*>(dd + B.o_bc); R.sum = reinterpret_cast<double*>(dd + B.o_sum);
+    R.col = reinterpret_cast<const int*>(dd + B.o_col);
+    R.S = reinterpret_cast<double*>(dd + B.o_S); R.rhs = reinterpret_cast<double*>(dd + B.o_rhs);
+    R.trial = reinterpret_cast<const double*>(dd + B.o_trial);
+    R.xp = reinterpret_cast<double*>(dd + B.o_xp);
+    R.idist_rw = reinterpret_cast<double*>(dd + B.o_idist); R.idist_bak = reinterpret_cast<double*>(dd + B.o_bak);
+    R.M = B.M; R.n_pairs = B.n_pairs;
+  }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_probs, hp, sizeof(BaProb) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   return HSO_OK;
 }
 
-// single problem: layout + reserve + place
-static int ba_setup(BaDev& B, hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, const double* idist,
-                    int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge)
+// Launch helpers: `which` = the windows (indices) this launch works on, written to list slot `slot` (a slot may be reused
+// only after a synchronise, which every round of the driver ends with).
+static int ba_list(BaBatch& Q, int slot, const std::vector<int>& which, const int** d_list)
 {
-  ba_layout(B, ctx, n_poses, n_points, edges, n_edges, huber_corner, huber_edge);
-  char *d, *h;
-  if (int rc = ba_reserve(ctx, B.total, B.in_bytes, &d, &h)) return rc;
-  return ba_place(B, d, h, poses_f_w, pose_fixed, idist, edges);
-}
-
-// new state -> device (poses and inverse depths sit next to each other at the start of the work area)
-static int ba_put_state(BaDev& B, const hso_se3* poses, const double* idist)
-{
-  memcpy(B.h + B.o_poses, poses, sizeof(hso_se3) * B.n_poses);
-  memcpy(B.h + B.o_idist, idist, sizeof(double) * B.n_points);
-  HSO_HIP_CHECK(B.ctx, hipMemcpyAsync(B.d, B.h, B.o_fixed, hipMemcpyHostToDevice, B.ctx->stream));
+  int* hl = Q.h_active + (size_t)slot * Q.n;
+  for (size_t k = 0; k < which.size(); k++) hl[k] = which[k];
+  int* dl = Q.d_active + (size_t)slot * Q.n;
+  HSO_HIP_CHECK(Q.ctx, hipMemcpyAsync(dl, hl, sizeof(int) * which.size(), hipMemcpyHostToDevice, Q.ctx->stream));
+  *d_list = dl;
   return HSO_OK;
 }
-
+static int ba_max(const BaBatch& Q, const std::vector<int>& which, int BaWin::*field)
+{
+  int m = 0;
+  for (int q : which) m = std::max(m, Q.win[q].*field);
+  return m;
+}
 // computeActiveErrors + buildSystem at the resident state; the blocks stay on the device
-static int ba_launch_linearize(BaDev& B)
+static int ba_launch_linearize(BaBatch& Q, int slot, const std::vector<int>& which)
 {
-  hso_gpu_ctx* ctx = B.ctx;
-  char* d = B.d;
-  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + B.o_out, 0, B.total - B.o_out, ctx->stream));
-  hipLaunchKernelGGL(k_ba_edges<true>, dim3((B.n_edges + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, B.a);
-  hipLaunchKernelGGL(k_ba_points, dim3((B.n_points + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, B.a,
-                     reinterpret_cast<const int*>(d + B.o_off), reinterpret_cast<const int*>(d + B.o_list),
-                     reinterpret_cast<double*>(d + B.o_Hpp), reinterpret_cast<double*>(d + B.o_bp), reinterpret_cast<double*>(d + B.o_Hpc));
-  hipLaunchKernelGGL(k_ba_poses, dim3(B.n_pairs + 1), dim3(BA_THREADS), 0, ctx->stream, B.a,
-                     reinterpret_cast<const int*>(d + B.o_poff), reinterpret_cast<const int*>(d + B.o_plist),
-                     reinterpret_cast<double*>(d + B.o_Hcc), reinterpret_cast<double*>(d + B.o_bc), reinterpret_cast<double*>(d + B.o_sum));
+  hso_gpu_ctx* ctx = Q.ctx;
+  if (which.empty()) return HSO_OK;
+  const int* dl;
+  if (int rc = ba_list(Q, slot, which, &dl)) return rc;
+  for (int q : which) { const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemsetAsync(B.d + B.o_out, 0, B.o_sum + 256 - B.o_out, ctx->stream)); }
+  const int ny = (int)which.size();
+  hipLaunchKernelGGL(k_ba_edges<true>, dim3((ba_max(Q, which, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+  hipLaunchKernelGGL(k_ba_points, dim3((ba_max(Q, which, &BaWin::n_points) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+  hipLaunchKernelGGL(k_ba_poses, dim3(ba_max(Q, which, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
 }
-
 // computeActiveErrors only (an LM trial): per-edge error / chi2 / rho and the two sums
-static int ba_launch_errors(BaDev& B)
+static int ba_launch_errors(BaBatch& Q, int slot, const std::vector<int>& which)
 {
-  hso_gpu_ctx* ctx = B.ctx;
-  hipLaunchKernelGGL(k_ba_edges<false>, dim3((B.n_edges + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream, B.a);
-  hipLaunchKernelGGL(k_ba_chi2, dim3(1), dim3(BA_THREADS), 0, ctx->stream, B.a, reinterpret_cast<double*>(B.d + B.o_sum));
+  hso_gpu_ctx* ctx = Q.ctx;
+  if (which.empty()) return HSO_OK;
+  const int* dl;
+  if (int rc = ba_list(Q, slot, which, &dl)) return rc;
+  const int ny = (int)which.size();
+  hipLaunchKernelGGL(k_ba_edges<false>, dim3((ba_max(Q, which, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+  hipLaunchKernelGGL(k_ba_chi2, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
 }
-
-static int ba_get(BaDev& B, void* dst, size_t off, size_t bytes)
+static int ba_get(BaBatch& Q, int q, void* dst, size_t off, size_t bytes)
 {
-  HSO_HIP_CHECK(B.ctx, hipMemcpyAsync(dst, B.d + off, bytes, hipMemcpyDeviceToHost, B.ctx->stream));
+  HSO_HIP_CHECK(Q.ctx, hipMemcpyAsync(dst, Q.win[q].d + off, bytes, hipMemcpyDeviceToHost, Q.ctx->stream));
   return HSO_OK;
 }
 
@@ -502,18 +693,25 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
       !Hcc || !bc || !edge_err || !edge_chi2 || !chi2_sum)
     return hso_fail(ctx, HSO_E_INVALID, "ba_linearize: bad argument");
   if (int rc = ba_check_edges(ctx, edges, n_edges, n_points, n_poses, "ba_linearize")) return rc;
-  BaDev B;
-  if (int rc = ba_setup(B, ctx, poses_f_w, pose_fixed, n_poses, idist, n_points, edges, n_edges, huber_corner, huber_edge)) return rc;
-  if (int rc = ba_launch_linearize(B)) return rc;
+  BaBatch Q;
+  Q.win.resize(1);
+  ba_layout(Q.win[0], n_poses, n_points, pose_fixed, edges, n_edges, huber_corner, huber_edge);
+  hso_ba_problem P;
+  memset(&P, 0, sizeof(P));
+  P.poses_f_w = const_cast<hso_se3*>(poses_f_w); P.pose_fixed = pose_fixed; P.idist = const_cast<double*>(idist); P.edges = edges;
+  if (int rc = ba_batch_begin(Q, ctx, &P, 1)) return rc;
+  const std::vector<int> all(1, 0);
+  if (int rc = ba_launch_linearize(Q, 0, all)) return rc;
+  const BaWin& B = Q.win[0];
   int rc = HSO_OK;
-  if (!rc) rc = ba_get(B, Hpp, B.o_Hpp, sizeof(double) * n_points);
-  if (!rc) rc = ba_get(B, bp, B.o_bp, sizeof(double) * n_points);
-  if (!rc) rc = ba_get(B, Hpc, B.o_Hpc, sizeof(double) * (size_t)n_points * n_poses * 6);
-  if (!rc) rc = ba_get(B, Hcc, B.o_Hcc, sizeof(double) * (size_t)n_poses * n_poses * 36);
-  if (!rc) rc = ba_get(B, bc, B.o_bc, sizeof(double) * n_poses * 6);
-  if (!rc) rc = ba_get(B, edge_err, B.o_err, sizeof(double) * 2 * n_edges);
-  if (!rc) rc = ba_get(B, edge_chi2, B.o_chi, sizeof(double) * n_edges);
-  if (!rc) rc = ba_get(B, chi2_sum, B.o_sum, sizeof(double) * 2);
+  if (!rc) rc = ba_get(Q, 0, Hpp, B.o_Hpp, sizeof(double) * n_points);
+  if (!rc) rc = ba_get(Q, 0, bp, B.o_bp, sizeof(double) * n_points);
+  if (!rc) rc = ba_get(Q, 0, Hpc, B.o_Hpc, sizeof(double) * (size_t)n_points * n_poses * 6);
+  if (!rc) rc = ba_get(Q, 0, Hcc, B.o_Hcc, sizeof(double) * (size_t)n_poses * n_poses * 36);
+  if (!rc) rc = ba_get(Q, 0, bc, B.o_bc, sizeof(double) * n_poses * 6);
+  if (!rc) rc = ba_get(Q, 0, edge_err, B.o_err, sizeof(double) * 2 * n_edges);
+  if (!rc) rc = ba_get(Q, 0, edge_chi2, B.o_chi, sizeof(double) * n_edges);
+  if (!rc) rc = ba_get(Q, 0, chi2_sum, B.o_sum, sizeof(double) * 2);
   if (rc) return rc;
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
@@ -666,292 +864,247 @@ void se3quat_exp_times(const double* upd, hso_se3& pose)
 
 // (H + lambda I) x = b through the scalar Schur complement of the inverse-depth unknowns.  Returns false where g2o's
 // factorisation would fail (a vanishing or non-finite pivot).
-struct SchurSolver {
-  int n_points, n_poses, n_free, M;
-  std::vector<int> col;                    // pose -> first row of its block in the reduced system, -1 = fixed
-  std::vector<int> pp_off, pp_pose;        // CSR: free poses connected to each point
-  std::vector<double> S, rhs, xc, w;
-
-  void init(int n_points_, int n_poses_, const uint8_t* fixed, const hso_ba_edge* edges, int n_edges)
-  {
-    n_points = n_points_; n_poses = n_poses_;
-    col.assign(n_poses, -1);
-    n_free = 0;
-    for (int i = 0; i < n_poses; i++) if (!fixed[i]) col[i] = 6 * n_free++;
-    M = 6 * n_free;
-    std::vector<std::vector<int>> con(n_points);
-    for (int k = 0; k < n_edges; k++) {
-      const hso_ba_edge& e = edges[k];
-      for (int v : { e.host, e.target })
-        if (col[v] >= 0 && std::find(con[e.point].begin(), con[e.point].end(), v) == con[e.point].end()) con[e.point].push_back(v);
+// Dense LDL^T of the reduced system (lower triangle), no pivoting like the reference's SimplicialLDLT; S is overwritten.
+// false: a zero or non-finite pivot (g2o: the solver reports failure, the trial is rejected).
+static bool dense_ldlt_solve(double* S, const double* rhs, int M, double* xc)
+{
+  for (int j = 0; j < M; j++) {
+    double dj = S[(size_t)j * M + j];
+    for (int k = 0; k < j; k++) dj -= S[(size_t)j * M + k] * S[(size_t)j * M + k] * S[(size_t)k * M + k];
+    if (!(dj != 0.0) || !std::isfinite(dj)) return false;
+    S[(size_t)j * M + j] = dj;
+    for (int i = j + 1; i < M; i++) {
+      double t = S[(size_t)i * M + j];
+      for (int k = 0; k < j; k++) t -= S[(size_t)i * M + k] * S[(size_t)j * M + k] * S[(size_t)k * M + k];
+      S[(size_t)i * M + j] = t / dj;
     }
-    pp_off.assign(n_points + 1, 0);
-    for (int p = 0; p < n_points; p++) { std::sort(con[p].begin(), con[p].end()); pp_off[p + 1] = pp_off[p] + (int)con[p].size(); }
-    pp_pose.resize(pp_off[n_points]);
-    for (int p = 0; p < n_points; p++) std::copy(con[p].begin(), con[p].end(), pp_pose.begin() + pp_off[p]);
-    S.resize((size_t)M * M); rhs.resize(M); xc.resize(M); w.resize(n_points);
   }
-
-  // x = [points | poses (n_poses * 6, zeros at fixed ones)]
-  bool solve(const double* Hpp, const double* bp, const double* Hpc, const double* Hcc, const double* bc, double lambda,
-             double* x_points, double* x_poses)
-  {
-    std::fill(S.begin(), S.end(), 0.0);
-    for (int i = 0; i < n_poses; i++) {
-      if (col[i] < 0) continue;
-      for (int q = 0; q < 6; q++) rhs[col[i] + q] = bc[i * 6 + q];
-      for (int j = i; j < n_poses; j++) {
-        if (col[j] < 0) continue;
-        const double* blk = Hcc + ((size_t)i * n_poses + j) * 36;
-        for (int r = 0; r < 6; r++)
-          for (int c = 0; c < 6; c++) {
-            S[(size_t)(col[i] + r) * M + col[j] + c] = blk[r * 6 + c];
-            S[(size_t)(col[j] + c) * M + col[i] + r] = blk[r * 6 + c];
-          }
-      }
-    }
-    for (int k = 0; k < M; k++) S[(size_t)k * M + k] += lambda;
-    bool ok = true;
-    for (int p = 0; p < n_points; p++) {
-      const double dpp = Hpp[p] + lambda;
-      if (!(dpp != 0.0) || !std::isfinite(dpp)) { ok = false; w[p] = 0; continue; }
-      const double inv = 1.0 / dpp;
-      w[p] = inv;
-      const double g = bp[p] * inv;
-      for (int a = pp_off[p]; a < pp_off[p + 1]; a++) {
-        const int ia = pp_pose[a];
-        const double* Wa = Hpc + ((size_t)p * n_poses + ia) * 6;
-        for (int r = 0; r < 6; r++) rhs[col[ia] + r] -= Wa[r] * g;
-        for (int b = a; b < pp_off[p + 1]; b++) {
-          const int ib = pp_pose[b];
-          const double* Wb = Hpc + ((size_t)p * n_poses + ib) * 6;
-          for (int r = 0; r < 6; r++) {
-            const double wr = Wa[r] * inv;
-            for (int c = 0; c < 6; c++) {
-              const double v = wr * Wb[c];
-              S[(size_t)(col[ia] + r) * M + col[ib] + c] -= v;
-              if (ia != ib) S[(size_t)(col[ib] + c) * M + col[ia] + r] -= v;
-            }
-          }
-        }
-      }
-    }
-    // dense LDL^T of the reduced system (lower triangle), no pivoting like the reference's SimplicialLDLT
-    for (int j = 0; j < M && ok; j++) {
-      double dj = S[(size_t)j * M + j];
-      for (int k = 0; k < j; k++) dj -= S[(size_t)j * M + k] * S[(size_t)j * M + k] * S[(size_t)k * M + k];
-      if (!(dj != 0.0) || !std::isfinite(dj)) { ok = false; break; }
-      S[(size_t)j * M + j] = dj;
-      for (int i = j + 1; i < M; i++) {
-        double s = S[(size_t)i * M + j];
-        for (int k = 0; k < j; k++) s -= S[(size_t)i * M + k] * S[(size_t)j * M + k] * S[(size_t)k * M + k];
-        S[(size_t)i * M + j] = s / dj;
-      }
-    }
-    std::fill(x_poses, x_poses + (size_t)n_poses * 6, 0.0);
-    if (!ok) { std::fill(x_points, x_points + n_points, 0.0); return false; }
-    for (int i = 0; i < M; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= S[(size_t)i * M + k] * xc[k]; xc[i] = s; }
-    for (int i = 0; i < M; i++) xc[i] /= S[(size_t)i * M + i];
-    for (int i = M - 1; i >= 0; i--) { double s = xc[i]; for (int k = i + 1; k < M; k++) s -= S[(size_t)k * M + i] * xc[k]; xc[i] = s; }
-    for (int i = 0; i < n_poses; i++)
-      if (col[i] >= 0) for (int q = 0; q < 6; q++) x_poses[i * 6 + q] = xc[col[i] + q];
-    for (int p = 0; p < n_points; p++) {
-      double s = bp[p];
-      for (int a = pp_off[p]; a < pp_off[p + 1]; a++) {
-        const int ia = pp_pose[a];
-        const double* Wa = Hpc + ((size_t)p * n_poses + ia) * 6;
-        for (int r = 0; r < 6; r++) s -= Wa[r] * xc[col[ia] + r];
-      }
-      x_points[p] = s * w[p];
-    }
-    return true;
-  }
-};
+  for (int i = 0; i < M; i++) { double t = rhs[i]; for (int k = 0; k < i; k++) t -= S[(size_t)i * M + k] * xc[k]; xc[i] = t; }
+  for (int i = 0; i < M; i++) xc[i] /= S[(size_t)i * M + i];
+  for (int i = M - 1; i >= 0; i--) { double t = xc[i]; for (int k = i + 1; k < M; k++) t -= S[(size_t)k * M + i] * xc[k]; xc[i] = t; }
+  return true;
+}
 
 }  // namespace
 
-// One local-BA problem being optimised: the Levenberg loop of OptimizationAlgorithmLevenberg::solve written as a state
-// machine, so that many problems advance in lockstep — advance() does host work until the next device result is needed,
-// queues the device work on the context's stream and returns; the caller synchronises ONCE for all problems and calls
-// advance() again.  The arithmetic per problem is the same statement sequence whether it runs alone or among others.
+// One local-BA window being optimised: the Levenberg loop of OptimizationAlgorithmLevenberg::solve written as a state
+// machine, so that many windows advance in lockstep.  A round of the driver asks every unfinished window what it needs
+// next (want), launches each kind of device work ONCE for all windows that want it (blockIdx.y = window), synchronises once,
+// and lets every window consume its results (advance).  Per LM trial a window needs two device steps: the reduced system
+// (k_ba_schur -> S, rhs to the host, dense LDL^T there), then back-substitution + point update + error evaluation
+// (k_ba_backsub, k_ba_edges<false>, k_ba_chi2 -> three sums to the host).  The block table Hpc never leaves the device.
 struct BaLm {
-  enum State { INIT_WAIT, ITER_BEGIN, LIN_WAIT, TRIAL_BEGIN, TRIAL_WAIT, FINISH, CHI_WAIT, DONE };
-  hso_gpu_ctx* ctx;
-  BaDev B;
-  SchurSolver sol;
+  enum Want { W_ERRORS, W_LINEARIZE, W_SCHUR, W_STEP, W_RESTORE_THEN_SCHUR, W_FINAL, W_NONE };
+  enum State { INIT_WAIT, LIN_WAIT, SCHUR_WAIT, STEP_WAIT, FINAL_WAIT, DONE };
+  BaWin* B;
   hso_se3* poses_f_w; const uint8_t* pose_fixed; double* idist;
   int n_poses, n_points, n_edges, n_iter;
   double* edge_chi2_out; hso_ba_result* result;
-  std::vector<double> Hpp, bp, Hpc, Hcc, bc, xp, xc, idist_bak;
+  std::vector<double> bc, xc, Hpp_h, Hcc_h;
   std::vector<hso_se3> poses_bak;
-  double chi[2];
   double lambda, ni, currentChi, tempChi, iniChi, rho;
   int nBad, stop, it, qmax;
-  bool ok2;
-  State st;
+  bool ok2, need_restore;
+  State st; Want want;
 
-  int begin()   // runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()
+  double* out_sum() const { return reinterpret_cast<double*>(B->h_out); }
+  double* out_S() const { return reinterpret_cast<double*>(B->h_out + (B->o_S - B->o_sum)); }
+  double* out_rhs() const { return reinterpret_cast<double*>(B->h_out + (B->o_rhs - B->o_sum)); }
+  double* trial() const { return reinterpret_cast<double*>(B->h_in + B->o_trial); }
+  hso_se3* poses_stage() const { return reinterpret_cast<hso_se3*>(B->h_in + B->o_poses); }
+
+  void begin()   // runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()
   {
     memset(result, 0, sizeof(*result));
-    Hpp.resize(n_points); bp.resize(n_points); Hpc.resize((size_t)n_points * n_poses * 6); Hcc.resize((size_t)n_poses * n_poses * 36);
-    bc.resize((size_t)n_poses * 6); xp.resize(n_points); xc.resize((size_t)n_poses * 6); idist_bak.resize(n_points);
+    bc.assign((size_t)n_poses * 6, 0.0); xc.assign((size_t)n_poses * 6, 0.0);
+    Hpp_h.assign(n_points, 0.0); Hcc_h.assign((size_t)n_poses * n_poses * 36, 0.0);
     poses_bak.resize(n_poses);
-    chi[0] = chi[1] = 0;
-    lambda = -1.; ni = 2.; nBad = 0; stop = 0; it = 0; qmax = 0; rho = 0; currentChi = tempChi = iniChi = 0; ok2 = true;
-    if (int rc = ba_launch_errors(B)) return rc;
-    if (int rc = ba_get(B, chi, B.o_sum, sizeof(chi))) return rc;
-    st = INIT_WAIT;
-    return HSO_OK;
+    lambda = -1.; ni = 2.; nBad = 0; stop = 0; it = 0; qmax = 0; rho = 0; currentChi = tempChi = iniChi = 0; ok2 = true; need_restore = false;
+    st = INIT_WAIT; want = W_ERRORS;
   }
+  void finish() { result->stop = stop; result->lambda = lambda; st = FINAL_WAIT; want = W_FINAL; }
 
-  // returns < 0 on error; afterwards st == DONE or device work is queued and a synchronise is due
-  int advance()
+  // consume the results of the device work asked for by `want`; decide what is needed next
+  void advance()
   {
-    for (;;) {
-      switch (st) {
-        case INIT_WAIT:
-          result->init_chi2 = chi[0];
-          result->robust_chi2 = chi[1];
-          st = ITER_BEGIN;
-          break;
-        case ITER_BEGIN: {
-          if (it >= n_iter) { st = FINISH; break; }
-          // solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem
-          if (int rc = ba_launch_linearize(B)) return rc;
-          int rc = ba_get(B, Hpp.data(), B.o_Hpp, sizeof(double) * n_points);
-          if (!rc) rc = ba_get(B, bp.data(), B.o_bp, sizeof(double) * n_points);
-          if (!rc) rc = ba_get(B, Hpc.data(), B.o_Hpc, sizeof(double) * Hpc.size());
-          if (!rc) rc = ba_get(B, Hcc.data(), B.o_Hcc, sizeof(double) * Hcc.size());
-          if (!rc) rc = ba_get(B, bc.data(), B.o_bc, sizeof(double) * bc.size());
-          if (!rc) rc = ba_get(B, chi, B.o_sum, sizeof(chi));
-          if (rc) return rc;
-          st = LIN_WAIT;
-          return HSO_OK;
-        }
-        case LIN_WAIT:
-          currentChi = chi[1]; tempChi = currentChi;
-          iniChi = currentChi;
-          if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices
-            double maxDiagonal = 0.;
-            for (int p = 0; p < n_points; p++) maxDiagonal = std::max(std::fabs(Hpp[p]), maxDiagonal);
-            for (int i = 0; i < n_poses; i++)
-              if (!pose_fixed[i]) for (int q = 0; q < 6; q++) maxDiagonal = std::max(std::fabs(Hcc[((size_t)i * n_poses + i) * 36 + q * 7]), maxDiagonal);
-            lambda = 1e-5 * maxDiagonal;
-            ni = 2; nBad = 0;
-          }
-          rho = 0; qmax = 0;
-          st = TRIAL_BEGIN;
-          break;
-        case TRIAL_BEGIN: {
-          std::copy(poses_f_w, poses_f_w + n_poses, poses_bak.begin());   // _optimizer->push()
-          std::copy(idist, idist + n_points, idist_bak.begin());
-          ok2 = sol.solve(Hpp.data(), bp.data(), Hpc.data(), Hcc.data(), bc.data(), lambda, xp.data(), xc.data());
-          result->n_solves++;
-          for (int p = 0; p < n_points; p++) idist[p] += xp[p];                          // VertexSBAPointID::oplusImpl
-          for (int i = 0; i < n_poses; i++) if (!pose_fixed[i]) se3quat_exp_times(&xc[(size_t)i * 6], poses_f_w[i]);  // VertexSE3Expmap::oplusImpl
-          int rc = ba_put_state(B, poses_f_w, idist);
-          if (!rc) rc = ba_launch_errors(B);
-          if (!rc) rc = ba_get(B, chi, B.o_sum, sizeof(chi));
-          if (rc) return rc;
-          st = TRIAL_WAIT;
-          return HSO_OK;
-        }
-        case TRIAL_WAIT: {
-          tempChi = ok2 ? chi[1] : 1.7976931348623157e308;
-          rho = currentChi - tempChi;
-          double scale = 0.;                                               // computeScale
-          for (int p = 0; p < n_points; p++) scale += xp[p] * (lambda * xp[p] + bp[p]);
+    switch (st) {
+      case INIT_WAIT:
+        result->init_chi2 = out_sum()[0];
+        result->robust_chi2 = out_sum()[1];
+        result->final_chi2 = out_sum()[0];
+        if (it >= n_iter) { finish(); return; }
+        st = LIN_WAIT; want = W_LINEARIZE;
+        return;
+      case LIN_WAIT:
+        // solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem
+        result->final_chi2 = out_sum()[0];
+        currentChi = out_sum()[1]; tempChi = currentChi;
+        iniChi = currentChi;
+        if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices
+          double maxDiagonal = 0.;
+          for (int p = 0; p < n_points; p++) maxDiagonal = std::max(std::fabs(Hpp_h[p]), maxDiagonal);
           for (int i = 0; i < n_poses; i++)
-            if (!pose_fixed[i]) for (int q = 0; q < 6; q++) scale += xc[i * 6 + q] * (lambda * xc[i * 6 + q] + bc[i * 6 + q]);
-          scale += 1e-3;
-          rho /= scale;
-          if (rho > 0 && std::isfinite(tempChi)) {
-            double alpha = 1. - std::pow((2 * rho - 1), 3);
-            alpha = std::min(alpha, 2. / 3.);
-            lambda *= std::max(1. / 3., alpha);
-            ni = 2;
-            currentChi = tempChi;
-            result->n_accepted++;
-          } else {
-            lambda *= ni;
-            ni *= 2;
-            std::copy(poses_bak.begin(), poses_bak.end(), poses_f_w);     // _optimizer->pop(): vertices only, edge errors stay
-            std::copy(idist_bak.begin(), idist_bak.end(), idist);
-            if (int rc2 = ba_put_state(B, poses_f_w, idist)) return rc2;
-          }
-          qmax++;
-          if (rho < 0 && qmax < 5) { st = TRIAL_BEGIN; break; }   // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
-          result->iterations = it + 1;
-          result->robust_chi2 = currentChi;
-          if (qmax == 5 || rho == 0) { stop = 1; st = FINISH; break; }
-          if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
-          if (nBad >= 3) { stop = 2; st = FINISH; break; }
-          it++;
-          st = ITER_BEGIN;
-          break;
+            if (!pose_fixed[i]) for (int q = 0; q < 6; q++) maxDiagonal = std::max(std::fabs(Hcc_h[((size_t)i * n_poses + i) * 36 + q * 7]), maxDiagonal);
+          lambda = 1e-5 * maxDiagonal;
+          ni = 2; nBad = 0;
         }
-        case FINISH:
-          result->stop = stop;
-          result->lambda = lambda;
-          result->final_chi2 = chi[0];   // activeChi2() of the last computeActiveErrors
-          if (edge_chi2_out) {
-            if (int rc = ba_get(B, edge_chi2_out, B.o_chi, sizeof(double) * n_edges)) return rc;
-            st = CHI_WAIT;
-            return HSO_OK;
-          }
-          st = DONE;
-          return HSO_OK;
-        case CHI_WAIT:
-          st = DONE;
-          return HSO_OK;
-        case DONE:
-          return HSO_OK;
+        rho = 0; qmax = 0;
+        trial()[0] = lambda;
+        st = SCHUR_WAIT; want = W_SCHUR;
+        return;
+      case SCHUR_WAIT: {
+        // the trial's linear solve: dense LDL^T of the reduced system on the host, then the step goes back to the device
+        const int M = B->M;
+        std::copy(poses_f_w, poses_f_w + n_poses, poses_bak.begin());   // _optimizer->push()
+        ok2 = out_S()[(size_t)M * M] != 0.0;
+        std::vector<double> x(M > 0 ? M : 1, 0.0);
+        if (ok2) ok2 = dense_ldlt_solve(out_S(), out_rhs(), M, x.data());
+        result->n_solves++;
+        std::fill(xc.begin(), xc.end(), 0.0);
+        if (ok2) for (int i = 0; i < n_poses; i++) if (B->col[i] >= 0) for (int q = 0; q < 6; q++) xc[(size_t)i * 6 + q] = x[B->col[i] + q];
+        for (int i = 0; i < n_poses; i++) if (!pose_fixed[i]) se3quat_exp_times(&xc[(size_t)i * 6], poses_f_w[i]);  // VertexSE3Expmap::oplusImpl
+        std::copy(xc.begin(), xc.end(), trial() + 1);
+        trial()[1 + 6 * (size_t)n_poses] = ok2 ? 0.0 : 1.0;
+        std::copy(poses_f_w, poses_f_w + n_poses, poses_stage());
+        st = STEP_WAIT; want = W_STEP;
+        return;
       }
+      case STEP_WAIT: {
+        result->final_chi2 = out_sum()[0];   // activeChi2() of the last computeActiveErrors
+        tempChi = ok2 ? out_sum()[1] : 1.7976931348623157e308;
+        rho = currentChi - tempChi;
+        double scale = ok2 ? out_sum()[2] : 0.;                          // computeScale: the points' part from the device
+        for (int i = 0; i < n_poses; i++)
+          if (!pose_fixed[i]) for (int q = 0; q < 6; q++) scale += xc[i * 6 + q] * (lambda * xc[i * 6 + q] + bc[i * 6 + q]);
+        scale += 1e-3;
+        rho /= scale;
+        bool restore = false;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+          result->n_accepted++;
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          std::copy(poses_bak.begin(), poses_bak.end(), poses_f_w);     // _optimizer->pop(): vertices only, edge errors stay
+          std::copy(poses_f_w, poses_f_w + n_poses, poses_stage());
+          restore = true;
+        }
+        qmax++;
+        if (rho < 0 && qmax < 5) {   // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
+          trial()[0] = lambda;
+          st = SCHUR_WAIT; want = restore ? W_RESTORE_THEN_SCHUR : W_SCHUR;
+          return;
+        }
+        need_restore = restore;
+        result->iterations = it + 1;
+        result->robust_chi2 = currentChi;
+        if (qmax == 5 || rho == 0) { stop = 1; finish(); return; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
+        if (nBad >= 3) { stop = 2; finish(); return; }
+        it++;
+        if (it >= n_iter) { finish(); return; }
+        st = LIN_WAIT; want = W_LINEARIZE;   // (need_restore: only after a step with a NaN gain ratio; the driver restores first)
+        return;
+      }
+      case FINAL_WAIT:
+        st = DONE; want = W_NONE;
+        return;
+      case DONE:
+        return;
     }
   }
 };
 
-// pinned staging is used by ba_put_state of every problem between two synchronises: each problem keeps its own slice
 extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems)
 {
   if (!ctx) return HSO_E_INVALID;
   if (n_problems < 0 || (n_problems > 0 && !problems)) return hso_fail(ctx, HSO_E_INVALID, "ba_optimize_multi: bad argument");
   if (n_problems == 0) return HSO_OK;
+  BaBatch Q;
+  Q.win.resize(n_problems);
   std::vector<BaLm> lm(n_problems);
-  size_t dev = 0, pin = 0;
-  std::vector<size_t> d_off(n_problems), h_off(n_problems);
   for (int q = 0; q < n_problems; q++) {
     const hso_ba_problem& P = problems[q];
     if (!P.poses_f_w || !P.pose_fixed || !P.idist || !P.edges || !P.result || P.n_poses <= 0 || P.n_points <= 0 || P.n_edges <= 0 || P.n_iter < 0)
       return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: bad argument");
     if (int rc = ba_check_edges(ctx, P.edges, P.n_edges, P.n_points, P.n_poses, "ba_optimize")) return rc;
-    BaLm& L = lm[q];
-    L.ctx = ctx; L.poses_f_w = P.poses_f_w; L.pose_fixed = P.pose_fixed; L.idist = P.idist;
-    L.n_poses = P.n_poses; L.n_points = P.n_points; L.n_edges = P.n_edges; L.n_iter = P.n_iter;
-    L.edge_chi2_out = P.edge_chi2_out; L.result = P.result;
-    ba_layout(L.B, ctx, P.n_poses, P.n_points, P.edges, P.n_edges, P.huber_corner, P.huber_edge);
-    d_off[q] = dev; dev += L.B.total;
-    h_off[q] = pin; pin += L.B.in_bytes;
+    ba_layout(Q.win[q], P.n_poses, P.n_points, P.pose_fixed, P.edges, P.n_edges, P.huber_corner, P.huber_edge);
   }
-  char *d, *h;
-  if (int rc = ba_reserve(ctx, dev, pin, &d, &h)) return rc;
+  if (int rc = ba_batch_begin(Q, ctx, problems, n_problems)) return rc;
   for (int q = 0; q < n_problems; q++) {
     const hso_ba_problem& P = problems[q];
-    if (int rc = ba_place(lm[q].B, d + d_off[q], h + h_off[q], P.poses_f_w, P.pose_fixed, P.idist, P.edges)) return rc;
-    lm[q].sol.init(P.n_points, P.n_poses, P.pose_fixed, P.edges, P.n_edges);
-    if (int rc = lm[q].begin()) return rc;
+    BaLm& L = lm[q];
+    L.B = &Q.win[q]; L.poses_f_w = P.poses_f_w; L.pose_fixed = P.pose_fixed; L.idist = P.idist;
+    L.n_poses = P.n_poses; L.n_points = P.n_points; L.n_edges = P.n_edges; L.n_iter = P.n_iter;
+    L.edge_chi2_out = P.edge_chi2_out; L.result = P.result;
+    L.begin();
   }
+  std::vector<int> w_err, w_lin, w_schur, w_step, w_restore, w_final;
   for (;;) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    bool pending = false;
-    for (int q = 0; q < n_problems; q++) {
-      if (lm[q].st == BaLm::DONE) continue;
-      if (int rc = lm[q].advance()) return rc;
-      if (lm[q].st != BaLm::DONE) pending = true;
+    w_err.clear(); w_lin.clear(); w_schur.clear(); w_step.clear(); w_restore.clear(); w_final.clear();
+    for (int q = 0; q < n_problems; q++)
+      switch (lm[q].want) {
+        case BaLm::W_ERRORS: w_err.push_back(q); break;
+        case BaLm::W_LINEARIZE: w_lin.push_back(q); break;
+        case BaLm::W_RESTORE_THEN_SCHUR: w_restore.push_back(q); w_schur.push_back(q); break;
+        case BaLm::W_SCHUR: w_schur.push_back(q); break;
+        case BaLm::W_STEP: w_step.push_back(q); break;
+        case BaLm::W_FINAL: w_final.push_back(q); break;
+        case BaLm::W_NONE: break;
+      }
+    if (w_err.empty() && w_lin.empty() && w_schur.empty() && w_step.empty() && w_final.empty()) break;
+    // --- the trial blocks (lambda, pose steps, poses) of every window that uses them this round
+    for (int q : w_schur) { const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d + B.o_trial, B.h_in + B.o_trial, B.trial_bytes, hipMemcpyHostToDevice, ctx->stream)); }
+    for (int q : w_step) { const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d + B.o_trial, B.h_in + B.o_trial, B.trial_bytes, hipMemcpyHostToDevice, ctx->stream)); }
+    // windows that finish after a rejected step put the popped poses and points back (what the caller reads out)
+    for (int q : w_final) if (lm[q].need_restore) { w_restore.push_back(q); const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d + B.o_trial, B.h_in + B.o_trial, B.trial_bytes, hipMemcpyHostToDevice, ctx->stream)); }
+    // a window that linearises after an accepted step has its state in place; after a step with a NaN gain ratio (rejected,
+    // yet the trial loop ends) the popped state goes back first
+    for (int q : w_lin) if (lm[q].need_restore) { w_restore.push_back(q); lm[q].need_restore = false; const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d + B.o_trial, B.h_in + B.o_trial, B.trial_bytes, hipMemcpyHostToDevice, ctx->stream)); }
+    if (int rc = ba_launch_errors(Q, 0, w_err)) return rc;
+    if (!w_restore.empty()) {
+      const int* dl;
+      if (int rc = ba_list(Q, 1, w_restore, &dl)) return rc;
+      hipLaunchKernelGGL(k_ba_restore, dim3(1, (int)w_restore.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
     }
-    if (!pending) break;
+    if (int rc = ba_launch_linearize(Q, 2, w_lin)) return rc;
+    if (!w_schur.empty()) {
+      const int* dl;
+      if (int rc = ba_list(Q, 3, w_schur, &dl)) return rc;
+      hipLaunchKernelGGL(k_ba_schur, dim3(ba_max(Q, w_schur, &BaWin::n_pairs) + 1, (int)w_schur.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+    }
+    if (!w_step.empty()) {
+      const int* dl;
+      if (int rc = ba_list(Q, 4, w_step, &dl)) return rc;
+      hipLaunchKernelGGL(k_ba_backsub, dim3(1, (int)w_step.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+      if (int rc = ba_launch_errors(Q, 5, w_step)) return rc;
+    }
+    HSO_HIP_CHECK(ctx, hipGetLastError());
+    // --- results
+    for (int q : w_err) if (int rc = ba_get(Q, q, Q.win[q].h_out, Q.win[q].o_sum, 256)) return rc;
+    for (int q : w_lin) {
+      const BaWin& B = Q.win[q];
+      int rc = ba_get(Q, q, B.h_out, B.o_sum, 256);
+      if (!rc) rc = ba_get(Q, q, lm[q].bc.data(), B.o_bc, sizeof(double) * lm[q].bc.size());
+      if (!rc && lm[q].it == 0) rc = ba_get(Q, q, lm[q].Hpp_h.data(), B.o_Hpp, sizeof(double) * B.n_points);
+      if (!rc && lm[q].it == 0) rc = ba_get(Q, q, lm[q].Hcc_h.data(), B.o_Hcc, sizeof(double) * lm[q].Hcc_h.size());
+      if (rc) return rc;
+    }
+    for (int q : w_schur) if (int rc = ba_get(Q, q, Q.win[q].h_out, Q.win[q].o_sum, Q.win[q].out_bytes)) return rc;
+    for (int q : w_step) if (int rc = ba_get(Q, q, Q.win[q].h_out, Q.win[q].o_sum, 256)) return rc;
+    for (int q : w_final) {
+      const BaWin& B = Q.win[q];
+      int rc = ba_get(Q, q, lm[q].idist, B.o_idist, sizeof(double) * B.n_points);
+      if (!rc && lm[q].edge_chi2_out) rc = ba_get(Q, q, lm[q].edge_chi2_out, B.o_chi, sizeof(double) * B.n_edges);
+      if (rc) return rc;
+    }
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < n_problems; q++) if (lm[q].want != BaLm::W_NONE) lm[q].advance();
   }
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }
 
