@@ -63,8 +63,90 @@ struct BaProb {
   double* xp;                           // [n_points] point steps of the last back-substitution
   double* idist_rw;                     // a.idist, writable
   double* idist_bak;                    // the state before the last step (g2o's push())
+  double* trial_rw;                     // = trial, writable: the solve kernel leaves the pose steps and the "no step" flag there
+  const double* lam;                    // this window's damping of the current trial (one contiguous array for all windows)
+  hso_se3* poses_rw;                    // = a.poses, writable
+  hso_se3* poses_bak;
   int M, n_pairs;
 };
+
+// ---- g2o's SE3Quat update (host and device: the optimiser applies it on the device, the tests' helpers on the host)
+struct Q4 { double x, y, z, w; };
+
+HSO_HD Q4 qmul(const Q4& a, const Q4& b)
+{
+  return { a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+           a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z };
+}
+
+HSO_HD void qrot(const Q4& q, const double v[3], double o[3])   // Eigen QuaternionBase::_transformVector
+{
+  double uv[3] = { q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0] };
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  o[0] = (v[0] + q.w * uv[0]) + (q.y * uv[2] - q.z * uv[1]);
+  o[1] = (v[1] + q.w * uv[1]) + (q.z * uv[0] - q.x * uv[2]);
+  o[2] = (v[2] + q.w * uv[2]) + (q.x * uv[1] - q.y * uv[0]);
+}
+
+HSO_HD void normalize_rotation(Q4& q)   // se3quat.h:280-285
+{
+  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+
+// SE3Quat::exp(update) * pose, update = [omega, upsilon] (se3quat.h:223-257, :104-110)
+HSO_HD void se3quat_exp_times(const double* upd, hso_se3& pose)
+{
+  const double wx = upd[0], wy = upd[1], wz = upd[2];
+  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  const double O[9] = { 0, -wz, wy, wz, 0, -wx, -wy, wx, 0 };
+  double O2[9], R[9], V[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) O2[i * 3 + j] = (O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j]) + O[i * 3 + 2] * O[6 + j];
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; i++) { R[i] = ((i % 4 == 0 ? 1.0 : 0.0) + O[i]) + O2[i]; V[i] = R[i]; }
+  } else {
+    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3.0);
+    for (int i = 0; i < 9; i++) {
+      const double id = (i % 4 == 0) ? 1.0 : 0.0;
+      R[i] = (id + a * O[i]) + b * O2[i];
+      V[i] = (id + b * O[i]) + c * O2[i];
+    }
+  }
+  // Eigen::Quaterniond(Matrix3d)
+  Q4 q;
+  double t = R[0] + R[4] + R[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q.w = 0.5 * t; t = 0.5 / t;
+    q.x = (R[7] - R[5]) * t; q.y = (R[2] - R[6]) * t; q.z = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double qv[3];
+    t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    qv[i] = 0.5 * t; t = 0.5 / t;
+    q.w = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    qv[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    qv[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    q.x = qv[0]; q.y = qv[1]; q.z = qv[2];
+  }
+  normalize_rotation(q);
+  const double tv[3] = { (V[0] * upd[3] + V[1] * upd[4]) + V[2] * upd[5], (V[3] * upd[3] + V[4] * upd[4]) + V[5] * upd[5],
+                         (V[6] * upd[3] + V[7] * upd[4]) + V[8] * upd[5] };
+  // result = exp * pose
+  double rt[3];
+  qrot(q, pose.t, rt);
+  Q4 qp = { pose.q[0], pose.q[1], pose.q[2], pose.q[3] };
+  Q4 qn = qmul(q, qp);
+  normalize_rotation(qn);
+  pose.q[0] = qn.x; pose.q[1] = qn.y; pose.q[2] = qn.z; pose.q[3] = qn.w;
+  pose.t[0] = tv[0] + rt[0]; pose.t[1] = tv[1] + rt[1]; pose.t[2] = tv[2] + rt[2];
+}
+
 
 template <bool LIN>   // LIN = false: errors, chi2 and rho only (an LM trial's computeActiveErrors)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_edges(const BaProb* probs, const int* active)
@@ -331,7 +413,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_schur(const BaProb* probs, co
   const int np = P.a.n_poses, n_pairs = np * (np + 1) / 2, M = P.M;
   int b = blockIdx.x, i = 0;
   if (b > n_pairs) return;
-  const double lambda = P.trial[0];
+  const double lambda = P.lam[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (b == n_pairs) {   // the extra block: is every point diagonal invertible?  (the host solver's `ok`)
     int bad = 0;
@@ -390,6 +472,87 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_schur(const BaProb* probs, co
   }
 }
 
+// The dense LDL^T of the reduced system (no pivoting, like the reference's SimplicialLDLT), the triangular solves, the pose
+// part of computeScale and the pose update SE3Quat::exp(dx) * pose — one workgroup per window, the matrix in LDS.
+// Right-looking factorisation: column j is scaled by 1 / d_j, then every entry (i, m) of the trailing lower triangle loses
+// (L_ij L_mj) d_j — per entry the same subtractions in the same order (j ascending) as a sequential left-looking loop, spread
+// over the threads; the substitutions are column sweeps (x_k final, then x_i -= L_ik x_k for all i at once).  A vanishing or
+// non-finite pivot, or a point diagonal that cannot be inverted (flag from k_ba_schur), means "no step": g2o's solver reports
+// failure and the trial is rejected.
+__global__ __launch_bounds__(BA_THREADS) void k_ba_solve(const BaProb* probs, const int* active)
+{
+  extern __shared__ double s_S[];
+  __shared__ double s_x[96], s_col[96], s_sc[64];
+  __shared__ int s_ok;
+  const BaProb& P = probs[active[blockIdx.y]];
+  const int M = P.M, np = P.a.n_poses, tid = threadIdx.x;
+  const double lambda = P.lam[0];
+  for (int q = tid; q < M * M; q += BA_THREADS) s_S[q] = P.S[q];
+  if (tid == 0) s_ok = (P.S[(size_t)M * M] != 0.0) ? 1 : 0;
+  __syncthreads();
+  for (int j = 0; j < M; j++) {
+    if (!s_ok) break;                       // uniform: read after a barrier
+    const double dj = s_S[j * M + j];
+    if (!(dj != 0.0) || !isfinite(dj)) { __syncthreads(); if (tid == 0) s_ok = 0; __syncthreads(); break; }
+    for (int i = j + 1 + tid; i < M; i += BA_THREADS) { const double l = s_S[i * M + j] / dj; s_col[i] = l; }
+    __syncthreads();
+    // trailing lower triangle (i >= m > j), one entry per thread and step
+    const int n = M - j - 1;
+    for (int e = tid; e < n * n; e += BA_THREADS) {
+      const int ii = e / n, mm = e - ii * n;
+      if (mm > ii) continue;
+      const int i = j + 1 + ii, m = j + 1 + mm;
+      s_S[i * M + m] -= (s_col[i] * s_col[m]) * dj;
+    }
+    for (int i = j + 1 + tid; i < M; i += BA_THREADS) s_S[i * M + j] = s_col[i];
+    __syncthreads();
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  if (ok) {
+    for (int i = tid; i < M; i += BA_THREADS) s_x[i] = P.rhs[i];
+    __syncthreads();
+    for (int k = 0; k < M; k++) {           // L y = rhs
+      const double xk = s_x[k];
+      __syncthreads();
+      for (int i = k + 1 + tid; i < M; i += BA_THREADS) s_x[i] -= s_S[i * M + k] * xk;
+      __syncthreads();
+    }
+    for (int i = tid; i < M; i += BA_THREADS) s_x[i] /= s_S[i * M + i];
+    __syncthreads();
+    for (int k = M - 1; k >= 0; k--) {      // L^T x = y
+      const double xk = s_x[k];
+      __syncthreads();
+      for (int i = tid; i < k; i += BA_THREADS) s_x[i] -= s_S[k * M + i] * xk;
+      __syncthreads();
+    }
+  }
+  // pose steps, push(), SE3Quat::exp(dx) * pose, the pose part of computeScale: one pose per thread
+  double* xc = P.trial_rw + 1;
+  if (tid < np) {
+    const int i = tid, c = P.col[i];
+    double x6[6];
+    for (int q = 0; q < 6; q++) { x6[q] = (ok && c >= 0) ? s_x[c + q] : 0.0; xc[i * 6 + q] = x6[q]; }
+    P.poses_bak[i] = P.poses_rw[i];                                                    // _optimizer->push()
+    double sc = 0;
+    if (c >= 0) {
+      hso_se3 pose = P.poses_rw[i];
+      se3quat_exp_times(x6, pose);                                                     // VertexSE3Expmap::oplusImpl
+      P.poses_rw[i] = pose;
+      for (int q = 0; q < 6; q++) sc += x6[q] * (lambda * x6[q] + P.bc[i * 6 + q]);     // computeScale, pose part
+    }
+    s_sc[i] = sc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double sc = 0;
+    for (int i = 0; i < np; i++) sc += s_sc[i];
+    P.trial_rw[1 + 6 * np] = ok ? 0.0 : 1.0;
+    P.sum[3] = sc;
+    P.sum[4] = ok ? 1.0 : 0.0;
+  }
+}
+
 // Back-substitution of the points, their update and the point part of computeScale: x_p = (bp_p - Hpc_p . xc) / (Hpp_p +
 // lambda) with the poses in index order (products with the zero rows of unconnected poses change nothing, so the value
 // equals the sparse loop's); idist_bak keeps the state before the step (g2o's push()).  One block per window.
@@ -398,7 +561,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, 
   __shared__ double s_part[BA_WAVES];
   const BaProb& P = probs[active[blockIdx.y]];
   const int np = P.a.n_poses;
-  const double lambda = P.trial[0];
+  const double lambda = P.lam[0];
   const double* xc = P.trial + 1;
   const bool no_step = P.trial[1 + 6 * np] != 0.0;   // the reduced system could not be solved: x = 0 (the trial is rejected)
   double sc = 0;
@@ -430,6 +593,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_restore(const BaProb* probs, 
 {
   const BaProb& P = probs[active[blockIdx.y]];
   for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) P.idist_rw[p] = P.idist_bak[p];
+  for (int i = threadIdx.x; i < P.a.n_poses; i += BA_THREADS) P.poses_rw[i] = P.poses_bak[i];
 }
 
 // per-edge error magnitudes for the Huber deltas of LocalBundleAdjustment (src/bundle_adjustment.cpp:618-656):
@@ -463,7 +627,7 @@ struct BaWin {
   std::vector<int> off, list, poff, plist, col;
   // byte offsets inside the window's device slice
   size_t o_trial, o_poses, o_idist, o_fixed, o_edges, o_off, o_list, o_poff, o_plist, o_col, in_bytes;
-  size_t o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc, o_bc, o_err, o_chi, o_sum, o_S, o_rhs, o_xp, o_bak, total;
+  size_t o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc, o_bc, o_err, o_chi, o_sum, o_S, o_rhs, o_xp, o_bak, o_pbak, total;
   size_t trial_bytes;   // [lambda | xc | pad | poses]: what an LM trial uploads
   char* d;              // device slice
   char* h_in;           // pinned: the window's upload image (first in_bytes of the slice)
@@ -477,6 +641,10 @@ struct BaBatch {
   BaProb* d_probs = nullptr;
   int* d_active = nullptr;       // BA_N_LISTS lists of n windows each
   int* h_active = nullptr;       // pinned
+  double* d_lambda = nullptr;    // [n] the damping of each window's current trial
+  double* h_lambda = nullptr;    // pinned
+  double* d_sums = nullptr;      // [n][8] chi2, robust chi2, scale (points), scale (poses), solvable
+  double* h_sums = nullptr;      // pinned (results staging)
   int n = 0;
 };
 #define BA_N_LISTS 6
@@ -563,6 +731,7 @@ static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_f
   B.out_bytes = o - B.o_sum;
   B.o_xp = o; o += al(sizeof(double) * n_points);
   B.o_bak = o; o += al(sizeof(double) * n_points);
+  B.o_pbak = o; o += al(sizeof(hso_se3) * n_poses);
   B.total = o;
 }
 
@@ -572,7 +741,9 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   Q.ctx = ctx; Q.n = n;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  size_t dev = al(sizeof(BaProb) * (size_t)n) + al(sizeof(int) * (size_t)n * BA_N_LISTS), pin_in = dev, pin_out = 0;
+  const size_t o_act = al(sizeof(BaProb) * (size_t)n), o_lam = o_act + al(sizeof(int) * (size_t)n * BA_N_LISTS);
+  const size_t o_sums = o_lam + al(sizeof(double) * (size_t)n);
+  size_t dev = o_sums + al(sizeof(double) * 8 * (size_t)n), pin_in = dev, pin_out = al(sizeof(double) * 8 * (size_t)n);
   const size_t hdr = dev;
   for (int q = 0; q < n; q++) { dev += Q.win[q].total; pin_in += Q.win[q].in_bytes; pin_out += Q.win[q].out_bytes; }
   if (ctx->batch_cap < dev) {  // grow-only work area of the context (shared with the other batched entry points)
@@ -587,10 +758,14 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   char* ho = hso_pinned(ctx, 1, std::max<size_t>(pin_out, 256));
   if (!h || !ho) return HSO_E_NOMEM;
   Q.d_probs = reinterpret_cast<BaProb*>(d);
-  Q.d_active = reinterpret_cast<int*>(d + al(sizeof(BaProb) * (size_t)n));
+  Q.d_active = reinterpret_cast<int*>(d + o_act);
+  Q.d_lambda = reinterpret_cast<double*>(d + o_lam);
+  Q.d_sums = reinterpret_cast<double*>(d + o_sums);
   BaProb* hp = reinterpret_cast<BaProb*>(h);
-  Q.h_active = reinterpret_cast<int*>(h + al(sizeof(BaProb) * (size_t)n));
-  size_t od = hdr, oh = hdr, oo = 0;
+  Q.h_active = reinterpret_cast<int*>(h + o_act);
+  Q.h_lambda = reinterpret_cast<double*>(h + o_lam);
+  Q.h_sums = reinterpret_cast<double*>(ho);
+  size_t od = hdr, oh = hdr, oo = al(sizeof(double) * 8 * (size_t)n);
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
     const hso_ba_problem& P = problems[q];
@@ -620,12 +795,14 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
     R.poff = reinterpret_cast<const int*>(dd + B.o_poff); R.plist = reinterpret_cast<const int*>(dd + B.o_plist);
     R.Hpp = reinterpret_cast<double*>(dd + B.o_Hpp); R.bp = reinterpret_cast<double*>(dd + B.o_bp);
     R.Hpc = reinterpret_cast<double*>(dd + B.o_Hpc); R.Hcc = reinterpret_cast<double*>(dd + B.o_Hcc);
-    R.bc = reinterpret_cast<double*>(dd + B.o_bc); R.sum = reinterpret_cast<double*>(dd + B.o_sum);
+    R.bc = reinterpret_cast<double*>(dd + B.o_bc); R.sum = Q.d_sums + 8 * (size_t)q; R.lam = Q.d_lambda + q;
     R.col = reinterpret_cast<const int*>(dd + B.o_col);
     R.S = reinterpret_cast<double*>(dd + B.o_S); R.rhs = reinterpret_cast<double*>(dd + B.o_rhs);
     R.trial = reinterpret_cast<const double*>(dd + B.o_trial);
     R.xp = reinterpret_cast<double*>(dd + B.o_xp);
     R.idist_rw = reinterpret_cast<double*>(dd + B.o_idist); R.idist_bak = reinterpret_cast<double*>(dd + B.o_bak);
+    R.trial_rw = reinterpret_cast<double*>(dd + B.o_trial);
+    R.poses_rw = reinterpret_cast<hso_se3*>(dd + B.o_poses); R.poses_bak = reinterpret_cast<hso_se3*>(dd + B.o_pbak);
     R.M = B.M; R.n_pairs = B.n_pairs;
   }
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_probs, hp, sizeof(BaProb) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -711,7 +888,7 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   if (!rc) rc = ba_get(Q, 0, bc, B.o_bc, sizeof(double) * n_poses * 6);
   if (!rc) rc = ba_get(Q, 0, edge_err, B.o_err, sizeof(double) * 2 * n_edges);
   if (!rc) rc = ba_get(Q, 0, edge_chi2, B.o_chi, sizeof(double) * n_edges);
-  if (!rc) rc = ba_get(Q, 0, chi2_sum, B.o_sum, sizeof(double) * 2);
+  if (!rc) { HSO_HIP_CHECK(ctx, hipMemcpyAsync(chi2_sum, Q.d_sums, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream)); }
   if (rc) return rc;
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
@@ -786,140 +963,36 @@ extern "C" int hso_gpu_ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses_f_
 // ---- g2o::SE3Quat on the host (thirdparty/g2o/g2o/types/se3quat.h): the pose update of VertexSE3Expmap ----
 namespace {
 
-struct Q4 { double x, y, z, w; };
-
-inline Q4 qmul(const Q4& a, const Q4& b)
-{
-  return { a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
-           a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z };
-}
-
-inline void qrot(const Q4& q, const double v[3], double o[3])   // Eigen QuaternionBase::_transformVector
-{
-  double uv[3] = { q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0] };
-  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
-  o[0] = (v[0] + q.w * uv[0]) + (q.y * uv[2] - q.z * uv[1]);
-  o[1] = (v[1] + q.w * uv[1]) + (q.z * uv[0] - q.x * uv[2]);
-  o[2] = (v[2] + q.w * uv[2]) + (q.x * uv[1] - q.y * uv[0]);
-}
-
-inline void normalize_rotation(Q4& q)   // se3quat.h:280-285
-{
-  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
-  const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
-}
-
-// SE3Quat::exp(update) * pose, update = [omega, upsilon] (se3quat.h:223-257, :104-110)
-void se3quat_exp_times(const double* upd, hso_se3& pose)
-{
-  const double wx = upd[0], wy = upd[1], wz = upd[2];
-  const double theta = std::sqrt(wx * wx + wy * wy + wz * wz);
-  const double O[9] = { 0, -wz, wy, wz, 0, -wx, -wy, wx, 0 };
-  double O2[9], R[9], V[9];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) O2[i * 3 + j] = (O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j]) + O[i * 3 + 2] * O[6 + j];
-  if (theta < 0.00001) {
-    for (int i = 0; i < 9; i++) { R[i] = ((i % 4 == 0 ? 1.0 : 0.0) + O[i]) + O2[i]; V[i] = R[i]; }
-  } else {
-    const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta), c = (theta - std::sin(theta)) / std::pow(theta, 3);
-    for (int i = 0; i < 9; i++) {
-      const double id = (i % 4 == 0) ? 1.0 : 0.0;
-      R[i] = (id + a * O[i]) + b * O2[i];
-      V[i] = (id + b * O[i]) + c * O2[i];
-    }
-  }
-  // Eigen::Quaterniond(Matrix3d)
-  Q4 q;
-  double t = R[0] + R[4] + R[8];
-  if (t > 0) {
-    t = std::sqrt(t + 1.0);
-    q.w = 0.5 * t; t = 0.5 / t;
-    q.x = (R[7] - R[5]) * t; q.y = (R[2] - R[6]) * t; q.z = (R[3] - R[1]) * t;
-  } else {
-    int i = 0;
-    if (R[4] > R[0]) i = 1;
-    if (R[8] > R[i * 4]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double qv[3];
-    t = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
-    qv[i] = 0.5 * t; t = 0.5 / t;
-    q.w = (R[k * 3 + j] - R[j * 3 + k]) * t;
-    qv[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-    qv[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-    q.x = qv[0]; q.y = qv[1]; q.z = qv[2];
-  }
-  normalize_rotation(q);
-  const double tv[3] = { (V[0] * upd[3] + V[1] * upd[4]) + V[2] * upd[5], (V[3] * upd[3] + V[4] * upd[4]) + V[5] * upd[5],
-                         (V[6] * upd[3] + V[7] * upd[4]) + V[8] * upd[5] };
-  // result = exp * pose
-  double rt[3];
-  qrot(q, pose.t, rt);
-  Q4 qp = { pose.q[0], pose.q[1], pose.q[2], pose.q[3] };
-  Q4 qn = qmul(q, qp);
-  normalize_rotation(qn);
-  pose.q[0] = qn.x; pose.q[1] = qn.y; pose.q[2] = qn.z; pose.q[3] = qn.w;
-  pose.t[0] = tv[0] + rt[0]; pose.t[1] = tv[1] + rt[1]; pose.t[2] = tv[2] + rt[2];
-}
-
-// (H + lambda I) x = b through the scalar Schur complement of the inverse-depth unknowns.  Returns false where g2o's
-// factorisation would fail (a vanishing or non-finite pivot).
-// Dense LDL^T of the reduced system (lower triangle), no pivoting like the reference's SimplicialLDLT; S is overwritten.
-// false: a zero or non-finite pivot (g2o: the solver reports failure, the trial is rejected).
-static bool dense_ldlt_solve(double* S, const double* rhs, int M, double* xc)
-{
-  for (int j = 0; j < M; j++) {
-    double dj = S[(size_t)j * M + j];
-    for (int k = 0; k < j; k++) dj -= S[(size_t)j * M + k] * S[(size_t)j * M + k] * S[(size_t)k * M + k];
-    if (!(dj != 0.0) || !std::isfinite(dj)) return false;
-    S[(size_t)j * M + j] = dj;
-    for (int i = j + 1; i < M; i++) {
-      double t = S[(size_t)i * M + j];
-      for (int k = 0; k < j; k++) t -= S[(size_t)i * M + k] * S[(size_t)j * M + k] * S[(size_t)k * M + k];
-      S[(size_t)i * M + j] = t / dj;
-    }
-  }
-  for (int i = 0; i < M; i++) { double t = rhs[i]; for (int k = 0; k < i; k++) t -= S[(size_t)i * M + k] * xc[k]; xc[i] = t; }
-  for (int i = 0; i < M; i++) xc[i] /= S[(size_t)i * M + i];
-  for (int i = M - 1; i >= 0; i--) { double t = xc[i]; for (int k = i + 1; k < M; k++) t -= S[(size_t)k * M + i] * xc[k]; xc[i] = t; }
-  return true;
-}
-
 }  // namespace
 
 // One local-BA window being optimised: the Levenberg loop of OptimizationAlgorithmLevenberg::solve written as a state
 // machine, so that many windows advance in lockstep.  A round of the driver asks every unfinished window what it needs
 // next (want), launches each kind of device work ONCE for all windows that want it (blockIdx.y = window), synchronises once,
-// and lets every window consume its results (advance).  Per LM trial a window needs two device steps: the reduced system
-// (k_ba_schur -> S, rhs to the host, dense LDL^T there), then back-substitution + point update + error evaluation
-// (k_ba_backsub, k_ba_edges<false>, k_ba_chi2 -> three sums to the host).  The block table Hpc never leaves the device.
+// and lets every window consume its results (advance).  An LM trial is ONE device sequence — reduced system (k_ba_schur),
+// dense LDL^T + pose update (k_ba_solve), back-substitution + point update (k_ba_backsub), error evaluation
+// (k_ba_edges<false>, k_ba_chi2) — and five doubles come back; the host only takes the accept / reject decision.
 struct BaLm {
-  enum Want { W_ERRORS, W_LINEARIZE, W_SCHUR, W_STEP, W_RESTORE_THEN_SCHUR, W_FINAL, W_NONE };
-  enum State { INIT_WAIT, LIN_WAIT, SCHUR_WAIT, STEP_WAIT, FINAL_WAIT, DONE };
+  enum Want { W_ERRORS, W_LINEARIZE, W_TRIAL, W_RESTORE_THEN_TRIAL, W_FINAL, W_NONE };
+  enum State { INIT_WAIT, LIN_WAIT, STEP_WAIT, FINAL_WAIT, DONE };
   BaWin* B;
   hso_se3* poses_f_w; const uint8_t* pose_fixed; double* idist;
   int n_poses, n_points, n_edges, n_iter;
   double* edge_chi2_out; hso_ba_result* result;
-  std::vector<double> bc, xc, Hpp_h, Hcc_h;
-  std::vector<hso_se3> poses_bak;
+  std::vector<double> Hpp_h, Hcc_h;
   double lambda, ni, currentChi, tempChi, iniChi, rho;
   int nBad, stop, it, qmax;
-  bool ok2, need_restore;
+  bool need_restore;
   State st; Want want;
 
-  double* out_sum() const { return reinterpret_cast<double*>(B->h_out); }
-  double* out_S() const { return reinterpret_cast<double*>(B->h_out + (B->o_S - B->o_sum)); }
-  double* out_rhs() const { return reinterpret_cast<double*>(B->h_out + (B->o_rhs - B->o_sum)); }
-  double* trial() const { return reinterpret_cast<double*>(B->h_in + B->o_trial); }
-  hso_se3* poses_stage() const { return reinterpret_cast<hso_se3*>(B->h_in + B->o_poses); }
+  double* sums;       // pinned: chi2, robust chi2, scale (points), scale (poses), solvable — of the last device step
+  double* lam_stage;  // pinned: the damping the next trial uses
+  double* out_sum() const { return sums; }
 
   void begin()   // runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()
   {
     memset(result, 0, sizeof(*result));
-    bc.assign((size_t)n_poses * 6, 0.0); xc.assign((size_t)n_poses * 6, 0.0);
     Hpp_h.assign(n_points, 0.0); Hcc_h.assign((size_t)n_poses * n_poses * 36, 0.0);
-    poses_bak.resize(n_poses);
-    lambda = -1.; ni = 2.; nBad = 0; stop = 0; it = 0; qmax = 0; rho = 0; currentChi = tempChi = iniChi = 0; ok2 = true; need_restore = false;
+    lambda = -1.; ni = 2.; nBad = 0; stop = 0; it = 0; qmax = 0; rho = 0; currentChi = tempChi = iniChi = 0; need_restore = false;
     st = INIT_WAIT; want = W_ERRORS;
   }
   void finish() { result->stop = stop; result->lambda = lambda; st = FINAL_WAIT; want = W_FINAL; }
@@ -949,33 +1022,16 @@ struct BaLm {
           ni = 2; nBad = 0;
         }
         rho = 0; qmax = 0;
-        trial()[0] = lambda;
-        st = SCHUR_WAIT; want = W_SCHUR;
+        *lam_stage = lambda;
+        st = STEP_WAIT; want = W_TRIAL;
         return;
-      case SCHUR_WAIT: {
-        // the trial's linear solve: dense LDL^T of the reduced system on the host, then the step goes back to the device
-        const int M = B->M;
-        std::copy(poses_f_w, poses_f_w + n_poses, poses_bak.begin());   // _optimizer->push()
-        ok2 = out_S()[(size_t)M * M] != 0.0;
-        std::vector<double> x(M > 0 ? M : 1, 0.0);
-        if (ok2) ok2 = dense_ldlt_solve(out_S(), out_rhs(), M, x.data());
-        result->n_solves++;
-        std::fill(xc.begin(), xc.end(), 0.0);
-        if (ok2) for (int i = 0; i < n_poses; i++) if (B->col[i] >= 0) for (int q = 0; q < 6; q++) xc[(size_t)i * 6 + q] = x[B->col[i] + q];
-        for (int i = 0; i < n_poses; i++) if (!pose_fixed[i]) se3quat_exp_times(&xc[(size_t)i * 6], poses_f_w[i]);  // VertexSE3Expmap::oplusImpl
-        std::copy(xc.begin(), xc.end(), trial() + 1);
-        trial()[1 + 6 * (size_t)n_poses] = ok2 ? 0.0 : 1.0;
-        std::copy(poses_f_w, poses_f_w + n_poses, poses_stage());
-        st = STEP_WAIT; want = W_STEP;
-        return;
-      }
       case STEP_WAIT: {
+        const bool ok2 = out_sum()[4] != 0.0;
+        result->n_solves++;
         result->final_chi2 = out_sum()[0];   // activeChi2() of the last computeActiveErrors
         tempChi = ok2 ? out_sum()[1] : 1.7976931348623157e308;
         rho = currentChi - tempChi;
-        double scale = ok2 ? out_sum()[2] : 0.;                          // computeScale: the points' part from the device
-        for (int i = 0; i < n_poses; i++)
-          if (!pose_fixed[i]) for (int q = 0; q < 6; q++) scale += xc[i * 6 + q] * (lambda * xc[i * 6 + q] + bc[i * 6 + q]);
+        double scale = out_sum()[2] + out_sum()[3];                      // computeScale (zero when the solve failed: no step)
         scale += 1e-3;
         rho /= scale;
         bool restore = false;
@@ -989,14 +1045,12 @@ struct BaLm {
         } else {
           lambda *= ni;
           ni *= 2;
-          std::copy(poses_bak.begin(), poses_bak.end(), poses_f_w);     // _optimizer->pop(): vertices only, edge errors stay
-          std::copy(poses_f_w, poses_f_w + n_poses, poses_stage());
-          restore = true;
+          restore = true;                                                // _optimizer->pop(): vertices only, edge errors stay
         }
         qmax++;
         if (rho < 0 && qmax < 5) {   // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
-          trial()[0] = lambda;
-          st = SCHUR_WAIT; want = restore ? W_RESTORE_THEN_SCHUR : W_SCHUR;
+          *lam_stage = lambda;
+          st = STEP_WAIT; want = restore ? W_RESTORE_THEN_TRIAL : W_TRIAL;
           return;
         }
         need_restore = restore;
@@ -1033,6 +1087,7 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
       return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: bad argument");
     if (int rc = ba_check_edges(ctx, P.edges, P.n_edges, P.n_points, P.n_poses, "ba_optimize")) return rc;
     ba_layout(Q.win[q], P.n_poses, P.n_points, P.pose_fixed, P.edges, P.n_edges, P.huber_corner, P.huber_edge);
+    if (Q.win[q].M > 96 || P.n_poses > 64) return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: more than 16 free (64 in all) poses in one window");
   }
   if (int rc = ba_batch_begin(Q, ctx, problems, n_problems)) return rc;
   for (int q = 0; q < n_problems; q++) {
@@ -1041,64 +1096,55 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
     L.B = &Q.win[q]; L.poses_f_w = P.poses_f_w; L.pose_fixed = P.pose_fixed; L.idist = P.idist;
     L.n_poses = P.n_poses; L.n_points = P.n_points; L.n_edges = P.n_edges; L.n_iter = P.n_iter;
     L.edge_chi2_out = P.edge_chi2_out; L.result = P.result;
+    L.sums = Q.h_sums + 8 * (size_t)q; L.lam_stage = Q.h_lambda + q;
     L.begin();
   }
-  std::vector<int> w_err, w_lin, w_schur, w_step, w_restore, w_final;
+  std::vector<int> w_err, w_lin, w_trial, w_restore, w_final;
   for (;;) {
-    w_err.clear(); w_lin.clear(); w_schur.clear(); w_step.clear(); w_restore.clear(); w_final.clear();
+    w_err.clear(); w_lin.clear(); w_trial.clear(); w_restore.clear(); w_final.clear();
     for (int q = 0; q < n_problems; q++)
       switch (lm[q].want) {
         case BaLm::W_ERRORS: w_err.push_back(q); break;
-        case BaLm::W_LINEARIZE: w_lin.push_back(q); break;
-        case BaLm::W_RESTORE_THEN_SCHUR: w_restore.push_back(q); w_schur.push_back(q); break;
-        case BaLm::W_SCHUR: w_schur.push_back(q); break;
-        case BaLm::W_STEP: w_step.push_back(q); break;
-        case BaLm::W_FINAL: w_final.push_back(q); break;
+        case BaLm::W_LINEARIZE: w_lin.push_back(q); if (lm[q].need_restore) { w_restore.push_back(q); lm[q].need_restore = false; } break;
+        case BaLm::W_RESTORE_THEN_TRIAL: w_restore.push_back(q); w_trial.push_back(q); break;
+        case BaLm::W_TRIAL: w_trial.push_back(q); break;
+        case BaLm::W_FINAL: w_final.push_back(q); if (lm[q].need_restore) w_restore.push_back(q); break;
         case BaLm::W_NONE: break;
       }
-    if (w_err.empty() && w_lin.empty() && w_schur.empty() && w_step.empty() && w_final.empty()) break;
-    // --- the trial blocks (lambda, pose steps, poses) of every window that uses them this round
-    for (int q : w_schur) { const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d + B.o_trial, B.h_in + B.o_trial, B.trial_bytes, hipMemcpyHostToDevice, ctx->stream)); }
-    for (int q : w_step) { const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d + B.o_trial, B.h_in + B.o_trial, B.trial_bytes, hipMemcpyHostToDevice, ctx->stream)); }
-    // windows that finish after a rejected step put the popped poses and points back (what the caller reads out)
-    for (int q : w_final) if (lm[q].need_restore) { w_restore.push_back(q); const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d + B.o_trial, B.h_in + B.o_trial, B.trial_bytes, hipMemcpyHostToDevice, ctx->stream)); }
-    // a window that linearises after an accepted step has its state in place; after a step with a NaN gain ratio (rejected,
-    // yet the trial loop ends) the popped state goes back first
-    for (int q : w_lin) if (lm[q].need_restore) { w_restore.push_back(q); lm[q].need_restore = false; const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d + B.o_trial, B.h_in + B.o_trial, B.trial_bytes, hipMemcpyHostToDevice, ctx->stream)); }
+    if (w_err.empty() && w_lin.empty() && w_trial.empty() && w_final.empty()) break;
+    // the damping of this round's trials: one copy for all windows (poses and points are owned by the device during the optimisation)
+    if (!w_trial.empty()) HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_lambda, Q.h_lambda, sizeof(double) * (size_t)n_problems, hipMemcpyHostToDevice, ctx->stream));
     if (int rc = ba_launch_errors(Q, 0, w_err)) return rc;
-    if (!w_restore.empty()) {
+    if (!w_restore.empty()) {   // g2o's pop() after a rejected step, before anything reads the state again
       const int* dl;
       if (int rc = ba_list(Q, 1, w_restore, &dl)) return rc;
       hipLaunchKernelGGL(k_ba_restore, dim3(1, (int)w_restore.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
     }
     if (int rc = ba_launch_linearize(Q, 2, w_lin)) return rc;
-    if (!w_schur.empty()) {
+    if (!w_trial.empty()) {
       const int* dl;
-      if (int rc = ba_list(Q, 3, w_schur, &dl)) return rc;
-      hipLaunchKernelGGL(k_ba_schur, dim3(ba_max(Q, w_schur, &BaWin::n_pairs) + 1, (int)w_schur.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-    }
-    if (!w_step.empty()) {
-      const int* dl;
-      if (int rc = ba_list(Q, 4, w_step, &dl)) return rc;
-      hipLaunchKernelGGL(k_ba_backsub, dim3(1, (int)w_step.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-      if (int rc = ba_launch_errors(Q, 5, w_step)) return rc;
+      if (int rc = ba_list(Q, 3, w_trial, &dl)) return rc;
+      const int ny = (int)w_trial.size(), max_m = ba_max(Q, w_trial, &BaWin::M);
+      hipLaunchKernelGGL(k_ba_schur, dim3(ba_max(Q, w_trial, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+      hipLaunchKernelGGL(k_ba_solve, dim3(1, ny), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, dl);
+      hipLaunchKernelGGL(k_ba_backsub, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+      if (int rc = ba_launch_errors(Q, 4, w_trial)) return rc;
     }
     HSO_HIP_CHECK(ctx, hipGetLastError());
     // --- results
-    for (int q : w_err) if (int rc = ba_get(Q, q, Q.win[q].h_out, Q.win[q].o_sum, 256)) return rc;
+    // the sums of every window in one copy (windows that did nothing this round keep their old values, nobody reads them)
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_sums, Q.d_sums, sizeof(double) * 8 * (size_t)n_problems, hipMemcpyDeviceToHost, ctx->stream));
     for (int q : w_lin) {
       const BaWin& B = Q.win[q];
-      int rc = ba_get(Q, q, B.h_out, B.o_sum, 256);
-      if (!rc) rc = ba_get(Q, q, lm[q].bc.data(), B.o_bc, sizeof(double) * lm[q].bc.size());
+      int rc = HSO_OK;
       if (!rc && lm[q].it == 0) rc = ba_get(Q, q, lm[q].Hpp_h.data(), B.o_Hpp, sizeof(double) * B.n_points);
       if (!rc && lm[q].it == 0) rc = ba_get(Q, q, lm[q].Hcc_h.data(), B.o_Hcc, sizeof(double) * lm[q].Hcc_h.size());
       if (rc) return rc;
     }
-    for (int q : w_schur) if (int rc = ba_get(Q, q, Q.win[q].h_out, Q.win[q].o_sum, Q.win[q].out_bytes)) return rc;
-    for (int q : w_step) if (int rc = ba_get(Q, q, Q.win[q].h_out, Q.win[q].o_sum, 256)) return rc;
     for (int q : w_final) {
       const BaWin& B = Q.win[q];
       int rc = ba_get(Q, q, lm[q].idist, B.o_idist, sizeof(double) * B.n_points);
+      if (!rc) rc = ba_get(Q, q, lm[q].poses_f_w, B.o_poses, sizeof(hso_se3) * B.n_poses);
       if (!rc && lm[q].edge_chi2_out) rc = ba_get(Q, q, lm[q].edge_chi2_out, B.o_chi, sizeof(double) * B.n_edges);
       if (rc) return rc;
     }

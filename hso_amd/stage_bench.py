@@ -134,7 +134,7 @@ def main():
     prob = (bposes, fixed, idist, edges, 1.0, 0.7, 10)
     dt1 = timed(lambda: ctx.ba_optimize(*prob), max(args.reps // 4, 2))
     r1 = ctx.ba_optimize(*prob)[3]
-    out.append(dict(stage="ba_optimize (LM: device linearisation, Schur complement and back-substitution; 54x54 LDL^T on the host), one window", units="edges", n=len(edges),
+    out.append(dict(stage="ba_optimize (LM; linearisation, Schur complement, dense LDL^T, updates and errors on the device), one window", units="edges", n=len(edges),
                     ms_per_call=dt1 * 1e3, units_per_s=len(edges) / dt1, iterations=r1.iterations, solves=r1.n_solves))
     probs = [prob] * 32
     dtm = timed(lambda: ctx.ba_optimize_multi(probs), 2)

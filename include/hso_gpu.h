@@ -492,8 +492,8 @@ typedef struct hso_ba_result {
  * bundle_adjustment.cpp:571), ORB-SLAM's stop: three iterations in a row that gain < 0.1 % (:154-161).
  * Errors, Jacobians and the robustified blocks come from the device kernels of hso_gpu_ba_linearize; the linear
  * solve eliminates the 1-D inverse-depth unknowns on the device (scalar Schur complement, then back-substitution of the
- * points) and factors the remaining <= 6 * n_free_poses system densely on the host — the same solution as the reference's
- * sparse LDL^T of the full system up to rounding.  poses_f_w / idist are updated in place (fixed poses unchanged); edge_chi2_out[n_edges]
+ * points) and factors the remaining <= 6 * n_free_poses (<= 96) system densely, also on the device — the same solution as
+ * the reference's sparse LDL^T of the full system up to rounding.  poses_f_w / idist are updated in place (fixed poses unchanged); edge_chi2_out[n_edges]
  * (may be NULL) = what edge->chi2() returns after optimize(), the input of the culling at :855-892. */
 int hso_gpu_ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, double* idist,
                         int n_points, const hso_ba_edge* edges, int n_edges, double huber_corner, double huber_edge,
