@@ -306,6 +306,7 @@ def load():
     lib.hso_gpu_ba_optimize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double, i32, vp, P(BaResult)]
     lib.hso_gpu_ba_optimize_multi.argtypes = [vp, P(BaProblem), i32]
     lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.hso_gpu_reproject_select_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.hso_gpu_seed_activate_multi.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), P(i32), P(ActivateOut),
                                                 P(AlignOut)]
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
@@ -347,7 +348,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize", "hso_gpu_ba_optimize_multi",
-    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select",
+    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select", "hso_gpu_reproject_select_maps",
     "hso_gpu_seed_reproject_match",
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
@@ -720,6 +721,19 @@ class Context:
         n = self._check(self.lib.hso_gpu_reproject_match_maps(self.h, C.byref(cam), _ptr(calls), len(calls), cell_size, grid_n_cols, _ptr(out),
                                                               capacity), "reproject_match_maps")
         return out[:n]
+
+    def reproject_select_maps(self, cam, calls, cell_size, grid_n_cols, cell_order, max_fts, capacity):
+        """reproject_match_maps + the grid selection on the device.  -> (MATCH_BRIEF_DTYPE array of the examined candidates of
+        all calls back to back, begin[n_calls + 1], counts[n_calls, 4])."""
+        calls = np.ascontiguousarray(calls, MAP_CALL_DTYPE)
+        order = np.ascontiguousarray(cell_order, np.int32)
+        out = np.zeros(capacity, MATCH_BRIEF_DTYPE)
+        begin = np.zeros(len(calls) + 1, np.int32)
+        counts = np.zeros((len(calls), 4), np.int32)
+        n = self._check(self.lib.hso_gpu_reproject_select_maps(self.h, C.byref(cam), _ptr(calls), len(calls), cell_size, grid_n_cols,
+                                                               _ptr(order), len(order), max_fts, _ptr(out), capacity, _ptr(begin),
+                                                               _ptr(counts)), "reproject_select_maps")
+        return out[:n], begin, counts
 
     # -- FAST-9 corner candidates
     def fast_detect(self, frame_id, n_levels=3, threshold=20, border=8, cap=20000):

@@ -279,8 +279,10 @@ __global__ __launch_bounds__(256) void k_reproject_maps(MapConsts M, AlignJobDev
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (M.calls[mid].point_begin <= g) lo = mid; else hi = mid - 1; }
   const MapCallDev& C = M.calls[lo];
   const int i = g - C.point_begin;
-  proj[g] = reproject_one(M.cam, M.pts[(size_t)C.map * M.max_points + i], C.F, M.kfs + C.F.kf_begin, M.obs + (size_t)C.map * M.max_obs,
-                          M.cell_size, M.grid_n_cols, &jobs[g]);
+  const hso_map_point& pt = M.pts[(size_t)C.map * M.max_points + i];
+  hso_reproj_point r = reproject_one(M.cam, pt, C.F, M.kfs + C.F.kf_begin, M.obs + (size_t)C.map * M.max_obs, M.cell_size, M.grid_n_cols, &jobs[g]);
+  r.pad_ = pt.pad_;   // the point's quality key rides along for the on-device grid selection (hso_gpu_reproject_select_maps)
+  proj[g] = r;
 }
 
 // projection + match of one point -> the compact record the host's grid selection consumes
@@ -529,22 +531,36 @@ extern "C" int hso_gpu_map_store(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, i
   return HSO_OK;
 }
 
-extern "C" int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
-                                            int grid_n_cols, hso_match_brief* out, int out_capacity)
+int hso_map_call_sizes(hso_gpu_ctx* ctx, const hso_map_call* calls, int n_calls, MapArenaSizes* Z)
 {
-  if (!ctx) return HSO_E_INVALID;
+  MapArena* A = ctx->maps;
+  Z->total = 0;
+  if (!A || n_calls < 0 || (n_calls > 0 && !calls)) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: bad argument");
+  for (int c = 0; c < n_calls; c++) {
+    if (calls[c].map < 0 || calls[c].map >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: no such map");
+    Z->total += A->n_points[calls[c].map];
+  }
+  return HSO_OK;
+}
+
+// The launch chain of hso_gpu_reproject_match_maps without the read-back: the records stay on the device (R), with
+// `extra_bytes` of the work area reserved behind them for a caller that goes on working there (the grid selection).
+int hso_reproject_maps_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                           int grid_n_cols, size_t extra_bytes, HsoMapsRun* R)
+{
   MapArena* A = ctx->maps;
   if (!A || !cam || n_calls < 0 || (n_calls > 0 && !calls) || cell_size < 1 || grid_n_cols < 1)
     return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: bad argument");
+  R->n = 0; R->begin.assign(n_calls + 1, 0);
   if (n_calls == 0) return 0;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   size_t total = 0;
   for (int c = 0; c < n_calls; c++) {
     if (calls[c].map < 0 || calls[c].map >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: no such map");
     total += (size_t)A->n_points[calls[c].map];
+    R->begin[c + 1] = (int)total;
   }
   if (total == 0) return 0;
-  if (!out || (size_t)out_capacity < total) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: output smaller than the calls' points");
   if (cam->width != A->g.w[0] || cam->height != A->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: camera size differs from the frame size");
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t b_calls = al(sizeof(MapCallDev) * (size_t)n_calls), b_kfs = al(sizeof(ReprojKf) * (size_t)n_calls * A->max_kfs);
@@ -580,7 +596,8 @@ extern "C" int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* 
   }
   const size_t o_jobs = 0, o_match = o_jobs + al(sizeof(AlignJobDev) * total), o_proj = o_match + al(sizeof(hso_align_out) * total);
   const size_t o_brief = o_proj + al(sizeof(hso_reproj_point) * total), o_in = o_brief + al(sizeof(hso_match_brief) * total);
-  const size_t need = o_in + b_calls + b_kfs;
+  const size_t o_extra = o_in + al(b_calls + b_kfs);
+  const size_t need = o_extra + extra_bytes;
   if (ctx->batch_cap < need) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -606,10 +623,22 @@ extern "C" int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* 
   launch_align(ctx, true, C, d_jobs, n, d_match);
   hipLaunchKernelGGL(k_match_brief, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_proj, d_match, d_jobs, d_brief);
   HSO_HIP_CHECK(ctx, hipGetLastError());
-  hso_match_brief* hb = reinterpret_cast<hso_match_brief*>(hso_pinned(ctx, 1, sizeof(hso_match_brief) * total));
+  R->n = n; R->d_proj = d_proj; R->d_brief = d_brief; R->d_extra = d + o_extra;
+  return n;
+}
+
+extern "C" int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                                            int grid_n_cols, hso_match_brief* out, int out_capacity)
+{
+  if (!ctx) return HSO_E_INVALID;
+  HsoMapsRun R;
+  const int total = hso_reproject_maps_run(ctx, cam, calls, n_calls, cell_size, grid_n_cols, 0, &R);
+  if (total <= 0) return total;
+  if (!out || out_capacity < total) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: output smaller than the calls' points");
+  hso_match_brief* hb = reinterpret_cast<hso_match_brief*>(hso_pinned(ctx, 1, sizeof(hso_match_brief) * (size_t)total));
   if (!hb) return HSO_E_NOMEM;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hb, d_brief, sizeof(hso_match_brief) * total, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hb, R.d_brief, sizeof(hso_match_brief) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(out, hb, sizeof(hso_match_brief) * total);
-  return (int)total;
+  memcpy(out, hb, sizeof(hso_match_brief) * (size_t)total);
+  return total;
 }

@@ -85,5 +85,19 @@ void hso_seed_tables_free(hso_gpu_ctx* ctx);
 void hso_map_arena_free(hso_gpu_ctx* ctx);
 // a frame allocation of geometry g: recycled when the free list holds that geometry, else fresh with zeroed padding rows.
 // hso_frame_free returns it to the list (or the allocator); neither touches ctx->frames.
+// hso_align.hip: project + reference choice + findMatchDirect for every point of every call's stored map, results left on the
+// device (begin[c] = first record of call c); extra_bytes of the work area are reserved behind them (hso_select.hip chains the
+// grid selection there).  Returns the number of records or a status < 0.
+struct HsoMapsRun {
+  int n;
+  std::vector<int> begin;
+  const hso_reproj_point* d_proj;
+  const hso_match_brief* d_brief;
+  char* d_extra;
+};
+struct MapArenaSizes { long long total; };   // points of a set of calls
+int hso_map_call_sizes(hso_gpu_ctx* ctx, const hso_map_call* calls, int n_calls, MapArenaSizes* Z);
+int hso_reproject_maps_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                           int grid_n_cols, size_t extra_bytes, HsoMapsRun* R);
 int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base);
 void hso_frame_free(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* base);

@@ -27,6 +27,7 @@ using namespace hso_dev;
 
 struct SelFrame {
   int first, n;           // candidate range (projection order)
+  const int* n_dev;       // when set: the candidate count is only known on the device (the chained call)
   int* cnt;               // [n_cells + 1] cell start offsets into list
   int* fill;              // [n_cells]
   int* list;              // [n] candidates by cell, each cell ordered by (quality desc, projection order)
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(SelArgs A, const SelFram
   __shared__ int s_wave[SEL_WAVES];
   __shared__ int s_cut, s_n;
   const SelFrame F = frames[blockIdx.x];
-  const int tid = threadIdx.x, n = F.n, nc = A.n_cells, budget = A.max_fts;
+  const int tid = threadIdx.x, n = F.n_dev ? *F.n_dev : F.n, nc = A.n_cells, budget = A.max_fts;
   const int32_t* cell = A.cell + F.first; const uint8_t* qual = A.quality + F.first; const uint8_t* flg = A.flags + F.first;
   auto matched = [&](int i) { return (flg[i] & 3) == 1; };   // matched and not deleted
   auto deleted = [&](int i) { return (flg[i] & 2) != 0; };
@@ -296,7 +297,7 @@ extern "C" int hso_gpu_reproject_select(hso_gpu_ctx* ctx, const int32_t* frame_b
   for (int f = 0; f < n_frames; f++) {
     char* s = d + o_scr + (per_frame + scan_bytes) * (size_t)f;
     SelFrame& F = hf[f];
-    F.first = frame_begin[f]; F.n = frame_begin[f + 1] - frame_begin[f];
+    F.first = frame_begin[f]; F.n = frame_begin[f + 1] - frame_begin[f]; F.n_dev = nullptr;
     F.cnt = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * (size_t)(n_cells + 1));
     F.fill = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * (size_t)n_cells);
     F.e1 = reinterpret_cast<int*>(s); s += al(sizeof(int32_t) * (size_t)n_cells);
@@ -319,4 +320,150 @@ extern "C" int hso_gpu_reproject_select(hso_gpu_ctx* ctx, const int32_t* frame_b
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, d + o_cnt, sizeof(int32_t) * 4 * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ chained behind the stored maps
+
+// the projected points of one call, in point order, as the candidate tables of k_select; cand_pt = candidate -> record
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_gather(const hso_reproj_point* proj, const hso_match_brief* brief, const int* begin,
+                                                           int32_t* cell, uint8_t* quality, uint8_t* flags, int32_t* cand_pt, int* n_cand)
+{
+  __shared__ int s_wave[SEL_WAVES];
+  const int c = blockIdx.x, b = begin[c], e = begin[c + 1];
+  int carry = 0;
+  for (int i0 = b; i0 < e; i0 += SEL_THREADS) {
+    const int i = i0 + (int)threadIdx.x;
+    const int is = (i < e && proj[i].projected) ? 1 : 0;
+    int tot;
+    const int pos = sel_block_scan(is, s_wave, tot) + carry - is;
+    if (is) {
+      const int q = proj[i].pad_ & 0xff;
+      cell[b + pos] = proj[i].cell;
+      quality[b + pos] = (uint8_t)q;
+      flags[b + pos] = (uint8_t)(((proj[i].ref_obs >= 0 && brief[i].success) ? 1 : 0) | (((q >> 4) == 0) ? 2 : 0));
+      cand_pt[b + pos] = i;
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_cand[c] = carry;
+}
+
+// where each call's examined records start in the packed output, and their total
+__global__ void k_sel_offsets(int n_calls, const int* counts, int* offs)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int t = 0;
+  for (int c = 0; c < n_calls; c++) { offs[c] = t; t += counts[4 * c]; }
+  offs[n_calls] = t;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_emit(const hso_match_brief* brief, const int* begin, const int32_t* examined,
+                                                         const int32_t* cand_pt, const int* counts, const int* offs, hso_match_brief* out)
+{
+  const int c = blockIdx.x, b = begin[c], n_ex = counts[4 * c], o = offs[c];
+  for (int k = threadIdx.x; k < n_ex; k += SEL_THREADS) {
+    const int v = examined[b + k];
+    const int g = cand_pt[b + (v & 0x7fffffff)];
+    hso_match_brief r = brief[g];
+    r.success = (v < 0) ? 1 : 0;          // became a feature (a matched candidate the budget never reached stays 0)
+    r.pad_ = g - b;                       // the point's index in its map
+    out[o + k] = r;
+  }
+}
+
+extern "C" int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                                             int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
+                                             int out_capacity, int32_t* begin_out, int32_t* counts_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_calls < 0 || n_cells <= 0 || !cell_order || max_fts < 0 || (n_calls > 0 && (!begin_out || !counts_out)))
+    return hso_fail(ctx, HSO_E_INVALID, "reproject_select_maps: bad argument");
+  {
+    std::vector<uint8_t> seen(n_cells, 0);
+    for (int k = 0; k < n_cells; k++) {
+      if (cell_order[k] < 0 || cell_order[k] >= n_cells || seen[cell_order[k]]) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_maps: cell_order is not a permutation");
+      seen[cell_order[k]] = 1;
+    }
+  }
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  // the points of all calls are known on the host (stored maps): size the selection scratch before the launch chain
+  MapArenaSizes Z;
+  if (int rc = hso_map_call_sizes(ctx, calls, n_calls, &Z)) return rc;
+  const size_t n_total = (size_t)Z.total;
+  if (n_total == 0) { for (int c = 0; c <= n_calls; c++) if (begin_out) begin_out[c] = 0; for (int c = 0; c < 4 * n_calls; c++) counts_out[c] = 0; return 0; }
+  const size_t per_frame = al(sizeof(int32_t) * (size_t)(n_cells + 1)) + 4 * al(sizeof(int32_t) * (size_t)n_cells) + al(sizeof(int32_t) * 3 * (size_t)n_cells) +
+                           al(sizeof(int32_t) * (size_t)std::max(n_cells, max_fts + 50));
+  size_t o = 0;
+  const size_t o_begin = o; o += al(sizeof(int) * (size_t)(n_calls + 1));
+  const size_t o_order = o; o += al(sizeof(int32_t) * (size_t)n_cells);
+  const size_t o_frames = o; o += al(sizeof(SelFrame) * (size_t)n_calls);
+  const size_t in_bytes = o;
+  const size_t o_cell = o; o += al(sizeof(int32_t) * n_total);
+  const size_t o_q = o; o += al(n_total);
+  const size_t o_f = o; o += al(n_total);
+  const size_t o_pt = o; o += al(sizeof(int32_t) * n_total);
+  const size_t o_ncand = o; o += al(sizeof(int) * (size_t)n_calls);
+  const size_t o_list = o; o += al(sizeof(int32_t) * n_total);
+  const size_t o_exam = o; o += al(sizeof(int32_t) * n_total);
+  const size_t o_counts = o; o += al(sizeof(int32_t) * 4 * (size_t)n_calls);
+  const size_t o_offs = o; o += al(sizeof(int) * (size_t)(n_calls + 1));
+  const size_t o_out = o; o += al(sizeof(hso_match_brief) * n_total);
+  const size_t o_scr = o; o += per_frame * (size_t)n_calls;
+  HsoMapsRun R;
+  const int total = hso_reproject_maps_run(ctx, cam, calls, n_calls, cell_size, grid_n_cols, o, &R);
+  if (total < 0) return total;
+  char* d = R.d_extra;
+  // staging: hso_reproject_maps_run used pinned slot 0 for its own tables and its copy may still be in flight: use slot 1
+  char* h = hso_pinned(ctx, 1, std::max(in_bytes, sizeof(int32_t) * (5 * (size_t)n_calls + 2)));
+  if (!h) return HSO_E_NOMEM;
+  int* hb = reinterpret_cast<int*>(h + o_begin);
+  for (int c = 0; c <= n_calls; c++) hb[c] = R.begin[c];
+  memcpy(h + o_order, cell_order, sizeof(int32_t) * (size_t)n_cells);
+  SelFrame* hf = reinterpret_cast<SelFrame*>(h + o_frames);
+  for (int c = 0; c < n_calls; c++) {
+    char* sc = d + o_scr + per_frame * (size_t)c;
+    SelFrame& F = hf[c];
+    F.first = R.begin[c]; F.n = 0; F.n_dev = reinterpret_cast<const int*>(d + o_ncand) + c;
+    F.cnt = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)(n_cells + 1));
+    F.fill = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)n_cells);
+    F.e1 = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)n_cells);
+    F.e2 = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)n_cells);
+    F.a3 = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)n_cells);
+    F.p3 = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * 3 * (size_t)n_cells);
+    F.scan = reinterpret_cast<int*>(sc);
+    F.list = reinterpret_cast<int*>(d + o_list) + F.first;
+    F.out = reinterpret_cast<int*>(d + o_exam) + F.first;
+    F.counts = reinterpret_cast<int*>(d + o_counts) + 4 * c;
+  }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int* d_begin = reinterpret_cast<const int*>(d + o_begin);
+  hipLaunchKernelGGL(k_sel_gather, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_proj, R.d_brief, d_begin,
+                     reinterpret_cast<int32_t*>(d + o_cell), reinterpret_cast<uint8_t*>(d + o_q), reinterpret_cast<uint8_t*>(d + o_f),
+                     reinterpret_cast<int32_t*>(d + o_pt), reinterpret_cast<int*>(d + o_ncand));
+  SelArgs A;
+  A.cell = reinterpret_cast<const int32_t*>(d + o_cell); A.quality = reinterpret_cast<const uint8_t*>(d + o_q);
+  A.flags = reinterpret_cast<const uint8_t*>(d + o_f); A.cell_order = reinterpret_cast<const int32_t*>(d + o_order);
+  A.n_cells = n_cells; A.max_fts = max_fts;
+  hipLaunchKernelGGL(k_select, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, A, reinterpret_cast<const SelFrame*>(d + o_frames));
+  hipLaunchKernelGGL(k_sel_offsets, dim3(1), dim3(64), 0, ctx->stream, n_calls, reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<int*>(d + o_offs));
+  hipLaunchKernelGGL(k_sel_emit, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_brief, d_begin, reinterpret_cast<const int32_t*>(d + o_exam),
+                     reinterpret_cast<const int32_t*>(d + o_pt), reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<const int*>(d + o_offs),
+                     reinterpret_cast<hso_match_brief*>(d + o_out));
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  // counts and offsets first (small), then exactly the examined records
+  int32_t* hs = reinterpret_cast<int32_t*>(h);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hs, d + o_counts, sizeof(int32_t) * 4 * (size_t)n_calls, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hs + 4 * n_calls, d + o_offs, sizeof(int) * (size_t)(n_calls + 1), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(counts_out, hs, sizeof(int32_t) * 4 * (size_t)n_calls);
+  memcpy(begin_out, hs + 4 * n_calls, sizeof(int32_t) * (size_t)(n_calls + 1));
+  const int n_out = begin_out[n_calls];
+  if (n_out > 0) {
+    if (!out || out_capacity < n_out) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_maps: output smaller than the examined candidates");
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d + o_out, sizeof(hso_match_brief) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return n_out;
 }

@@ -231,6 +231,7 @@ def main():
         return ctx.coarse_track_collect()
     t_track_r = timed(track_res, 5)
     ctx.map_reserve(nseq, 16, len(M1["points"]), len(M1["obs"]))
+    M1["points"]["pad_"] = (4 << 4) | 0        # quality keys of the on-device selection: every point TYPE_GOOD, corner
     for r in range(nseq):
         ctx.map_store(r, M1["kfs"], M1["points"], M1["obs"])
     calls = np.zeros(nseq, capi.MAP_CALL_DTYPE)
@@ -238,6 +239,11 @@ def main():
     calls["q"], calls["t"], calls["cur_exposure_time"] = q_cur, t_cur, M1["cur_exposure"]
     cap = nseq * len(M1["points"])
     t_reproj_r = timed(lambda: ctx.reproject_match_maps(cam, calls, M1["cell_size"], M1["grid_n_cols"], cap), 5)
+    # ... and with the grid selection chained on the device: only the examined candidates come back (max_fts = 200)
+    n_cells_sel = M1["grid_n_cols"] * int(math.ceil(480 / M1["cell_size"]))
+    order_sel = np.random.default_rng(3).permutation(n_cells_sel).astype(np.int32)
+    t_reproj_sel = timed(lambda: ctx.reproject_select_maps(cam, calls, M1["cell_size"], M1["grid_n_cols"], order_sel, 200, cap), 5)
+    sel_out, _, sel_counts = ctx.reproject_select_maps(cam, calls, M1["cell_size"], M1["grid_n_cols"], order_sel, 200, cap)
     tab = ctx.seed_table_create()
     ctx.seed_table_append(tab, big2, group=sf2)
     frs = [(2, T_cur, 1.05)] * nseq
@@ -245,7 +251,9 @@ def main():
     total_r = t_track_r + t_reproj_r + t_pose + t_seed_r
     out.append(dict(stage="per-frame chain x256 sequences, resident tables (images, maps and seeds in HBM; poses in, compact records out)",
                     units="frames", n=nseq, ms_per_call=total_r * 1e3, units_per_s=nseq / total_r,
-                    ms_track=t_track_r * 1e3, ms_reproject=t_reproj_r * 1e3, ms_pose=t_pose * 1e3, ms_seeds=t_seed_r * 1e3))
+                    ms_track=t_track_r * 1e3, ms_reproject=t_reproj_r * 1e3, ms_pose=t_pose * 1e3, ms_seeds=t_seed_r * 1e3,
+                    ms_reproject_with_device_selection=t_reproj_sel * 1e3, examined_per_frame=float(sel_counts[:, 0].mean()),
+                    matches_per_frame=float(sel_counts[:, 1].mean())))
 
     for o in out:
         print(json.dumps(o))

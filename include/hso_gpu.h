@@ -310,7 +310,8 @@ typedef struct hso_map_point {
   double host_f[3];            /* hostFeature_->f */
   int32_t host_kf;             /* index of hostFeature_->frame in the hso_kf table */
   int32_t obs_begin, obs_count;/* obs_[0..count) = obs[obs_begin ...], in list order */
-  int32_t pad_;
+  int32_t pad_;                /* stored maps: the point's quality key (Point::type_ << 4) | Point::ftr_type_ for the on-device grid
+                                  selection (hso_gpu_reproject_select_maps); 0 = TYPE_DELETED; unused elsewhere */
 } hso_map_point;
 
 typedef struct hso_reproj_point {
@@ -367,7 +368,7 @@ typedef struct hso_match_brief {
   int32_t cell;                /* grid cell, -1: reprojectPoint returned false */
   int32_t ref_obs;             /* chosen observation, index into the map's obs table; -1: none within 60 degrees */
   int8_t success, stage, search_level, ref_type;   /* findMatchDirect's result, HSO_ALIGN_* stage, Matcher::search_level_, ref_ftr_->type */
-  int32_t pad_;
+  int32_t pad_;                /* hso_gpu_reproject_select_maps: the point's index in its map */
 } hso_match_brief;
 
 int hso_gpu_map_reserve(hso_gpu_ctx* ctx, int n_maps, int max_kfs, int max_points, int max_obs);
@@ -655,6 +656,15 @@ int hso_gpu_seed_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_
 int hso_gpu_reproject_select(hso_gpu_ctx* ctx, const int32_t* frame_begin, int n_frames, const int32_t* cell,
                              const uint8_t* quality, const uint8_t* flags, const int32_t* cell_order, int n_cells, int max_fts,
                              int32_t* examined_out, int32_t* counts_out);
+
+/* hso_gpu_reproject_match_maps followed by the grid selection, nothing returned in between: per call (sequence) only the
+ * candidates the reference would have EXAMINED come back, in examination order — out[begin_out[c] .. begin_out[c + 1]) with
+ * success = the candidate became a feature, pad_ = the point's index in its map — plus counts_out[4 * c ..] as in
+ * hso_gpu_reproject_select.  The points' quality keys are their hso_map_point.pad_.  Returns the total number of records
+ * (<= the calls' points; out_capacity must cover it, HSO_E_INVALID otherwise) or a status < 0. */
+int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                                  int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
+                                  int out_capacity, int32_t* begin_out, int32_t* counts_out);
 
 /* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
  *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,
