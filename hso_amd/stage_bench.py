@@ -255,6 +255,10 @@ def main():
                     ms_reproject_with_device_selection=t_reproj_sel * 1e3, examined_per_frame=float(sel_counts[:, 0].mean()),
                     matches_per_frame=float(sel_counts[:, 1].mean())))
 
+    total_s = t_track_r + t_reproj_sel + t_pose + t_seed_r
+    out.append(dict(stage="per-frame chain x256 sequences, resident tables + the grid selection on the device (only examined candidates return)",
+                    units="frames", n=nseq, ms_per_call=total_s * 1e3, units_per_s=nseq / total_s,
+                    ms_track=t_track_r * 1e3, ms_reproject_select=t_reproj_sel * 1e3, ms_pose=t_pose * 1e3, ms_seeds=t_seed_r * 1e3))
     for o in out:
         print(json.dumps(o))
 
