@@ -142,7 +142,10 @@ namespace trk1 {
 #undef TRK_OLD_SHARE
 #define TRK_THREADS 256
 #define TRK_LDS_KB 80
-#define TRK_OLD_SHARE 8   // one wavefront per SIMD and workgroup: even split
+#ifndef TRK2_OLD_SHARE
+#define TRK2_OLD_SHARE 8
+#endif
+#define TRK_OLD_SHARE TRK2_OLD_SHARE   // one wavefront per SIMD and workgroup: even split
 namespace trk2 {
 #include "hso_tracker_core.h"
 }
