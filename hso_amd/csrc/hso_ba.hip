@@ -628,11 +628,8 @@ struct BaWin {
   // byte offsets inside the window's device slice
   size_t o_trial, o_poses, o_idist, o_fixed, o_edges, o_off, o_list, o_poff, o_plist, o_col, in_bytes;
   size_t o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc, o_bc, o_err, o_chi, o_sum, o_S, o_rhs, o_xp, o_bak, o_pbak, total;
-  size_t trial_bytes;   // [lambda | xc | pad | poses]: what an LM trial uploads
   char* d;              // device slice
   char* h_in;           // pinned: the window's upload image (first in_bytes of the slice)
-  char* h_out;          // pinned: [sum (256 B) | S | flag | rhs]
-  size_t out_bytes;
 };
 
 struct BaBatch {
@@ -703,7 +700,6 @@ static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_f
   // [lambda | xc | pad | poses | idist]: the trial block first, the state right behind it
   B.o_trial = o; o += al(sizeof(double) * (2 + 6 * (size_t)n_poses));   // lambda, xc, "no step" flag
   B.o_poses = o; o += al(sizeof(hso_se3) * n_poses);
-  B.trial_bytes = o;
   B.o_idist = o; o += al(sizeof(double) * n_points);
   B.o_fixed = o; o += al(n_poses);
   B.o_edges = o; o += al(sizeof(hso_ba_edge) * n_edges);
@@ -723,12 +719,11 @@ static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_f
   B.o_bc = o; o += al(sizeof(double) * n_poses * 6);
   B.o_err = o; o += al(sizeof(double) * 2 * n_edges);
   B.o_chi = o; o += al(sizeof(double) * n_edges);
-  // [sum | S | flag | rhs] contiguous: one copy brings a trial's results to the host
+  // the reduced system of a trial: S, the "solvable" flag behind it, rhs (they stay on the device)
   B.o_sum = o; o += 256;
   B.o_S = o; o += sizeof(double) * ((size_t)B.M * B.M + 1);
   B.o_rhs = o; o += sizeof(double) * (size_t)B.M;
   o = al(o);
-  B.out_bytes = o - B.o_sum;
   B.o_xp = o; o += al(sizeof(double) * n_points);
   B.o_bak = o; o += al(sizeof(double) * n_points);
   B.o_pbak = o; o += al(sizeof(hso_se3) * n_poses);
@@ -745,7 +740,7 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   const size_t o_sums = o_lam + al(sizeof(double) * (size_t)n);
   size_t dev = o_sums + al(sizeof(double) * 8 * (size_t)n), pin_in = dev, pin_out = al(sizeof(double) * 8 * (size_t)n);
   const size_t hdr = dev;
-  for (int q = 0; q < n; q++) { dev += Q.win[q].total; pin_in += Q.win[q].in_bytes; pin_out += Q.win[q].out_bytes; }
+  for (int q = 0; q < n; q++) { dev += Q.win[q].total; pin_in += Q.win[q].in_bytes; }
   if (ctx->batch_cap < dev) {  // grow-only work area of the context (shared with the other batched entry points)
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -765,12 +760,12 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   Q.h_active = reinterpret_cast<int*>(h + o_act);
   Q.h_lambda = reinterpret_cast<double*>(h + o_lam);
   Q.h_sums = reinterpret_cast<double*>(ho);
-  size_t od = hdr, oh = hdr, oo = al(sizeof(double) * 8 * (size_t)n);
+  size_t od = hdr, oh = hdr;
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
     const hso_ba_problem& P = problems[q];
-    B.d = d + od; B.h_in = h + oh; B.h_out = ho + oo;
-    od += B.total; oh += B.in_bytes; oo += B.out_bytes;
+    B.d = d + od; B.h_in = h + oh;
+    od += B.total; oh += B.in_bytes;
     char* w = B.h_in;
     memset(w, 0, B.in_bytes);
     memcpy(w + B.o_poses, P.poses_f_w, sizeof(hso_se3) * B.n_poses);
