@@ -261,3 +261,19 @@ def test_ba_optimize_multi_equals_single_calls(gpu_ctx):
         for a, b_ in zip(ps, pm):
             assert a.q[:] == b_.q[:] and a.t[:] == b_.t[:]
     assert len({r[3].iterations for r in multi}) > 1, "the windows should not all stop together"
+
+
+@pytest.mark.gpu
+def test_ba_optimize_points_only_window(gpu_ctx, orc):
+    """Every pose fixed: the reduced system is empty (M = 0), the optimisation moves the inverse depths only — the device solve
+    has nothing to factor and must still follow the oracle's Levenberg loop."""
+    poses, fixed, idist, edges = synth.ba_problem(5, 120, 3, seed=61, px_noise=0.3)
+    fixed = np.ones(len(poses), np.uint8)
+    idist = idist * (1 + 0.02 * np.random.default_rng(61).normal(size=len(idist)))
+    po, io, co, ro = orc.ba_optimize(poses, fixed, idist, edges, 1.0, 0.7, 6)
+    pg, ig, cg, rg = gpu_ctx.ba_optimize(poses, fixed, idist, edges, 1.0, 0.7, 6)
+    assert (rg.iterations, rg.n_solves, rg.n_accepted, rg.stop) == (ro.iterations, ro.n_solves, ro.n_accepted, ro.stop)
+    assert np.abs(ig - io).max() <= 1e-9 and np.allclose(cg, co, rtol=1e-8, atol=1e-16)
+    for a, b_ in zip(pg, poses):
+        assert a.q[:] == b_.q[:] and a.t[:] == b_.t[:]
+    assert rg.n_accepted >= 1 and np.abs(ig - idist).max() > 0
