@@ -97,8 +97,9 @@ static int align_run(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur
   AlignJobDev* h = reinterpret_cast<AlignJobDev*>(hso_pinned(ctx, 0, (size_t)n_jobs * sizeof(AlignJobDev)));
   hso_align_out* h_out = reinterpret_cast<hso_align_out*>(hso_pinned(ctx, 1, (size_t)n_jobs * sizeof(hso_align_out)));
   if (!h || !h_out) return HSO_E_NOMEM;
-  int64_t last_id = 0;
+  int64_t last_id = 0, last_ref_id = 0;
   const uint8_t* last_base = nullptr;
+  const uint8_t* last_ref_base = nullptr;
   for (int i = 0; i < n_jobs; i++) {
     const int64_t cid = cur_frame_ids[(size_t)i * id_stride];
     if (i == 0 || cid != last_id) {
@@ -108,11 +109,14 @@ static int align_run(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur
       else if (!same_geom(itc->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
       last_id = cid; last_base = itc->second.base;
     }
-    auto itr = ctx->frames.find(jobs[i].ref_frame_id);
-    if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "align_batch: reference frame not resident");
-    if (!same_geom(itr->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
+    if (i == 0 || jobs[i].ref_frame_id != last_ref_id) {   // candidates come grouped by reference keyframe: one lookup per group
+      auto itr = ctx->frames.find(jobs[i].ref_frame_id);
+      if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "align_batch: reference frame not resident");
+      if (!same_geom(itr->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "align_batch: frames must share one size");
+      last_ref_id = jobs[i].ref_frame_id; last_ref_base = itr->second.base;
+    }
     if (jobs[i].ref_level < 0 || jobs[i].ref_level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "align_batch: bad ref_level");
-    h[i].ref_base = itr->second.base;
+    h[i].ref_base = last_ref_base;
     h[i].cur_base = last_base;
     h[i].j = jobs[i];
   }
