@@ -366,6 +366,9 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
 #ifndef TRK_ROW_WINDOWS
 #define TRK_ROW_WINDOWS 1
 #endif
+#ifndef TRK_PRECOMPUTE_ROWS
+#define TRK_PRECOMPUTE_ROWS 1   // pattern-specialised reference patch precompute (forward mode, reference level in LDS)
+#endif
 #ifndef TRK_GLOBAL_ROWS
 #define TRK_GLOBAL_ROWS 1   // pattern-specialised loops also for images left in device memory (level 0 when relocalising)
 #endif
@@ -421,6 +424,75 @@ HSO_DEV float win_byte(const uint32_t (&w)[3], int j)
 }
 
 typedef const __attribute__((address_space(1))) float* GlbF32;
+
+// precompute_reference for the forward mode with the pattern known at compile time and the reference level in LDS: the
+// taps come from per-row windows (two rows live, as in collect_terms_rows below), tap and cache offsets are compile-time
+// expressions, and the next feature's record is in flight while this one's patch is interpolated (the generic loop above
+// waited for three dependent fp64 loads per feature).  Same expression order, so the cache is bit-identical.
+template <int PI>
+HSO_DEV void precompute_reference_rows(const LevelCtx& L, LdsPtr img, int border)
+{
+  constexpr auto P = PatRows<PI>::v;
+  constexpr int PA = h_pattern_num[PI];
+  constexpr int NB = P.max_ox - P.min_ox + 4;
+  constexpr int NW = (NB + 3) / 4;
+  constexpr int R0 = P.min_oy, R1 = P.max_oy + 1;
+  typedef const __attribute__((address_space(1))) double* GlbF64;
+  typedef __attribute__((address_space(1))) float* GlbF32W;
+  typedef __attribute__((address_space(1))) uint8_t* GlbU8W;
+  const int n = L.job->n, ns = L.job->n_stride;
+  const uint32_t nm = (uint32_t)L.C->n_max;
+  const GlbF64 ft = (GlbF64)L.job->feats;
+  const GlbF32W rp = (GlbF32W)L.sc.ref_patch;
+  const GlbU8W visible = (GlbU8W)L.sc.visible;
+  const int stride = L.cols, cols = L.cols, rows = L.rows;
+  const double scale = (double)L.scale;
+  int f = (int)threadIdx.x;
+  double nu = 0, nv = 0, nd = -1;
+  if (f < n) { nu = ft[f]; nv = ft[ns + f]; nd = ft[5 * ns + f]; }
+  for (; f < n; f += TRK_THREADS) {
+    const double fu = nu, fv = nv, dist = nd;
+    const int fn = f + TRK_THREADS;
+    if (fn < n) { nu = ft[fn]; nv = ft[ns + fn]; nd = ft[5 * ns + fn]; }
+    const float u_ref = (float)(fu * scale);
+    const float v_ref = (float)(fv * scale);
+    const int u_i = (int)floorf(u_ref), v_i = (int)floorf(v_ref);
+    const bool vis = dist >= 0 && !(u_i - border < 0 || v_i - border < 0 || u_i + border >= cols || v_i + border >= rows);
+    visible[f] = vis ? 1 : 0;
+    if (!vis) continue;
+    const float su = u_ref - (float)u_i, sv = v_ref - (float)v_i;
+    const float w_tl = (float)((1.0 - su) * (1.0 - sv));
+    const float w_tr = (float)(su * (1.0 - sv));
+    const float w_bl = (float)((1.0 - su) * sv);
+    const float w_br = (float)(1.0 - ((w_tl + w_tr) + w_bl));
+    const int c0 = v_i * stride + u_i - 1 + P.min_ox;
+    uint32_t win[2][3];
+#pragma unroll
+    for (int R = R0; R <= R1; R++) {
+      {
+        const int addr = c0 + R * stride;
+        const int A = addr >> 2;
+        const uint32_t sh = (uint32_t)(addr & 3);
+        uint32_t (&w)[3] = win[(R - R0) & 1];
+        const uint32_t d0 = img[A], d1 = img[A + 1], d2 = img[A + 2];
+        w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        if (NW == 3) { const uint32_t d3 = img[A + 3]; w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); } else w[2] = 0;
+      }
+      const int oy = R - 1;
+#pragma unroll
+      for (int q = 0; q < PA; q++) {
+        if (h_pattern[PI][P.idx[q]][1] != oy) continue;
+        const int kk = P.idx[q];
+        const int j = h_pattern[PI][kk][0] - P.min_ox;
+        const uint32_t (&w1)[3] = win[(oy - R0) & 1];
+        const uint32_t (&w2)[3] = win[(oy + 1 - R0) & 1];
+        const float p11 = win_byte(w1, j + 1), p12 = win_byte(w1, j + 2), p21 = win_byte(w2, j + 1), p22 = win_byte(w2, j + 2);
+        rp[(uint32_t)kk * nm + (uint32_t)f] = ((w_tl * p11 + w_tr * p12) + w_bl * p21) + w_br * p22;
+      }
+    }
+  }
+}
 
 // pass 1 of selectRobustFunctionLevel (CoarseTracker.cpp:547-606): |residual| of every
 // in-bounds term, stored as float bit patterns (KEY_INVALID elsewhere).  Returns errors.size().
@@ -1261,11 +1333,34 @@ HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const Tra
   }
   if (threadIdx.x < TRK_MAX_PA) s.poff[threadIdx.x] = V.poff[threadIdx.x];
   // reference image through LDS for the patch precompute, then the current image stays resident
+#ifdef HSO_STAGE_PROBE
+  unsigned long long sp_t = __builtin_readcyclecounter();
+#define SP_T(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[k] += n_ - sp_t; sp_t = n_; } } while (0)
+#else
+#define SP_T(k) do { } while (0)
+#endif
   const bool ref_in_lds = stage_image(L, job.ref_base + V.off, lds_img);
   __syncthreads();
-  if (ref_in_lds) precompute_reference<LdsPtr>(s, L, (LdsPtr)lds_img);
+  SP_T(5);
+  bool pre_done = false;
+#if TRK_PRECOMPUTE_ROWS
+  if (ref_in_lds && !C.inverse) {
+    pre_done = true;
+    switch (V.pi) {
+      case 2: precompute_reference_rows<2>(L, (LdsPtr)lds_img, V.pad + 1); break;
+      case 3: precompute_reference_rows<3>(L, (LdsPtr)lds_img, V.pad + 1); break;
+      case 4: precompute_reference_rows<4>(L, (LdsPtr)lds_img, V.pad + 1); break;
+      case 5: precompute_reference_rows<5>(L, (LdsPtr)lds_img, V.pad + 1); break;
+      case 6: precompute_reference_rows<6>(L, (LdsPtr)lds_img, V.pad + 1); break;
+      default: pre_done = false; break;
+    }
+  }
+#endif
+  if (pre_done) { }
+  else if (ref_in_lds) precompute_reference<LdsPtr>(s, L, (LdsPtr)lds_img);
   else precompute_reference<GlbPtr>(s, L, L.ref_glb);
   __syncthreads();
+  SP_T(6);
   const bool cur_in_lds = stage_image(L, job.cur_base + V.off, lds_img);
   if (threadIdx.x == 0) {
     s.use_lds = cur_in_lds ? 1 : 0;
@@ -1274,6 +1369,7 @@ HSO_DEV void begin_level(Shared& s, LevelCtx& L, const TrackConsts& C, const Tra
     s.keys_lds_off = (cur_in_lds && !C.keys_in_memory && padded + need <= (size_t)C.lds_img_cap) ? (int)padded : 0;
   }
   __syncthreads();
+  SP_T(7);
 }
 
 // Hl.ldlt().solve(b) of CoarseTracker.cpp:112-114 by one lane, entirely in registers: every
