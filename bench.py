@@ -34,7 +34,9 @@ The JSON line also carries
                  -O3 -march=native for the timing) on the same frames, bounded sample;
   se3_vs_cpu   — per-frame SE(3) deviation GPU vs the strict CPU restatement on the distinct
                  scenes (rotation angle, translation, iteration-count agreement) — the second
-                 half of BASELINE.json's metric.
+                 half of BASELINE.json's metric; `vs_f64_energy_sum` repeats it against the restatement
+                 deciding on the fp64 sum of the same fp32 energy terms (a diagnostic form, not the
+                 reference's: it shows which differences come from the reference's serial fp32 sum).
 """
 import argparse
 import gc
@@ -284,6 +286,7 @@ def main():
         orc.load()
         res_a = res_set[0] if res_set[0] is not None else results
         rot, tr, it_eq, acc_eq = [], [], 0, 0
+        rot64, tr64, acc_eq64, self_eq64 = [], [], 0, 0
         pyr = {}
         n_cmp = min(n_sc, B)
         for i in range(n_cmp):
@@ -294,9 +297,21 @@ def main():
             rot.append(rot_angle(qg, qo)); tr.append(float(np.linalg.norm(tg - to)))
             it_eq += int(list(res_a[i].iters) == list(ro.iters))
             acc_eq += int(list(res_a[i].accept_mask) == list(ro.accept_mask))
+            # diagnostics: the same restatement deciding on the fp64 sum of the same fp32 energy terms (not the reference's
+            # behaviour): separates "the device decides differently" from "the reference's serial fp32 sum decided by its rounding"
+            t64 = orc.Tracker(cam, params, pyr[i][0], pyr[i][1], d["feats"]); t64.decide_on_f64_sum(True)
+            r64 = t64.run(capi.SE3.from_arrays(d["q_init"], d["t_init"]), a0s[i])
+            q6, t6 = r64.T_cur_ref.to_arrays()
+            rot64.append(rot_angle(qg, q6)); tr64.append(float(np.linalg.norm(tg - t6)))
+            acc_eq64 += int(list(res_a[i].accept_mask) == list(r64.accept_mask) and list(res_a[i].iters) == list(r64.iters))
+            self_eq64 += int(list(ro.accept_mask) == list(r64.accept_mask) and list(ro.iters) == list(r64.iters))
         out["se3_vs_cpu"] = {"frames": n_cmp, "rot_rad_max": max(rot), "trans_max": max(tr),
                              "rot_rad_mean": float(np.mean(rot)), "trans_mean": float(np.mean(tr)),
                              "iters_equal_frac": it_eq / n_cmp, "accept_sequence_equal_frac": acc_eq / n_cmp,
+                             "vs_f64_energy_sum": {"accept_sequence_equal_frac": acc_eq64 / n_cmp, "rot_rad_max": max(rot64),
+                                                   "trans_max": max(tr64), "cpu_serial_vs_f64_equal_frac": self_eq64 / n_cmp,
+                                                   "note": "diagnostics: CPU restatement deciding on the fp64 sum of the same fp32 "
+                                                           "energy terms instead of the reference's serial fp32 sum"},
                              "cpu": "oracle/ strict build (-O3 -ffp-contract=off), scene depth 2..6 m",
                              "trans_err_vs_truth_max": max(terr)}
         # (2) timing: the same restatement rebuilt for this host (-O3 -march=native, contraction on)

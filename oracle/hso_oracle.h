@@ -111,6 +111,7 @@ void hso_or_tracker_set_thresholds(hso_or_tracker* t, float huber, float outlier
 void hso_or_tracker_eval(hso_or_tracker* t, const hso_se3* T, float exposure_rat,
                          hso_eval_out* out);
 double hso_or_tracker_energy_f64(const hso_or_tracker* t); /* diagnostics, see .c */
+void hso_or_tracker_decide_on_f64_sum(hso_or_tracker* t, int on); /* diagnostics, see .c */
 /* read-back of m_ref_patch_cache (n*PATCH_AREA) and m_visible_fts */
 void hso_or_tracker_get_cache(const hso_or_tracker* t, float* ref_patch, uint8_t* visible,
                               int* patch_area);

@@ -122,6 +122,7 @@ struct hso_or_tracker {
   float huber, outlier;
   int iter;
   double E64; /* diagnostics only: the same fp32 terms as E, summed in fp64 */
+  int decide_on_e64; /* diagnostics only, default 0: see hso_or_tracker_decide_on_f64_sum */
 };
 
 /* include/hso/frame.h:192-212 */
@@ -401,6 +402,7 @@ static double compute_residuals(hso_or_tracker* t, const hso_se3* T_cur_ref, flo
   }
   if (E_out) *E_out = E;
   t->E64 = E64;
+  if (t->decide_on_e64) return (float)E64 / t->total_terms;  /* diagnostics: the same terms, summed without the serial fp32 rounding */
   return E / t->total_terms;
 }
 
@@ -439,6 +441,12 @@ void hso_or_tracker_eval(hso_or_tracker* t, const hso_se3* T, float exposure_rat
 /* diagnostics: fp64 sum of the fp32 energy terms of the last evaluation (the reference's
  * own E is the serial fp32 sum returned in hso_eval_out.energy_sum) */
 double hso_or_tracker_energy_f64(const hso_or_tracker* t) { return t->E64; }
+
+/* diagnostics: on != 0 makes run() compare energies formed from the fp64 sum of the same fp32 terms instead of the
+ * reference's serial fp32 sum (CoarseTracker.cpp:272,352-361,413).  NOT the reference's behaviour: it exists to measure how
+ * many of the reference's accept decisions (:143) are decided by the rounding of that serial sum (~26 000 terms, relative
+ * noise ~1e-5) rather than by the energies; bench.py reports it as se3_vs_cpu.accept_sequence_equal_frac_f64_sum. */
+void hso_or_tracker_decide_on_f64_sum(hso_or_tracker* t, int on) { t->decide_on_e64 = on; }
 
 /* CoarseTracker.cpp:51-208 (without the frame write-back of :198-202) */
 void hso_or_tracker_run(hso_or_tracker* t, const hso_se3* T_init, float exposure_init, hso_track_result* out)

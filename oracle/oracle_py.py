@@ -96,6 +96,8 @@ def load():
     lib.hso_or_tracker_eval.restype = None
     lib.hso_or_tracker_energy_f64.argtypes = [vp]
     lib.hso_or_tracker_energy_f64.restype = C.c_double
+    lib.hso_or_tracker_decide_on_f64_sum.argtypes = [vp, C.c_int]
+    lib.hso_or_tracker_decide_on_f64_sum.restype = None
     lib.hso_or_tracker_get_cache.argtypes = [vp, vp, vp, P(i32)]
     lib.hso_or_tracker_get_cache.restype = None
     lib.hso_or_tracker_run.argtypes = [vp, P(SE3), C.c_float, P(TrackResult)]
@@ -286,6 +288,10 @@ class Tracker:
 
     def energy_f64(self):
         return self.lib.hso_or_tracker_energy_f64(self.h)
+
+    def decide_on_f64_sum(self, on=True):
+        """Diagnostics (not the reference's behaviour): accept decisions on the fp64 sum of the same fp32 energy terms."""
+        self.lib.hso_or_tracker_decide_on_f64_sum(self.h, 1 if on else 0)
 
     def cache(self):
         pa = C.c_int()
