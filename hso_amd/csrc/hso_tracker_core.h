@@ -1107,6 +1107,9 @@ __device__ __forceinline__ Moments feature_terms_rows(IP img, GlbF32 ref_patch, 
 // A = fx_l * J.row(0), B = fy_l * J.row(1) (frame.h:192-212); in inverse-compositional mode the
 // Jacobian is taken at the reference point and scaled by the exposure ratio
 // (m_jacobian_cache_true = exposure_rat * m_jacobian_cache_raw, CoarseTracker.cpp:245).
+#ifndef TRK_EXPAND_F32
+#define TRK_EXPAND_F32 1
+#endif
 template <bool IC>
 HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Moments& m, int f, float a)
 {
@@ -1125,9 +1128,26 @@ HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Mo
   double A[6], B[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) { A[k] = J0[k] * sA; B[k] = J1[k] * sB; }
-  const double d_ex = m.ex, d_ey = m.ey, d_xx = m.xx, d_xy = m.xy, d_yy = m.yy;
   const double d_rx = m.rx, d_ry = m.ry;
   acc.H[0] += m.ee;
+#if TRK_EXPAND_F32
+  // H is an fp32 quantity in the reference (Accumulator7, MatrixAccumulator.h:33: products and sums in float): expanding the
+  // 27 entries in fp32 as well drops 34 fp64 -> fp32 conversions (quarter rate) and the fp64 products per feature
+  float Af[6], Bf[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { Af[k] = (float)A[k]; Bf[k] = (float)B[k]; }
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc.H[1 + k] += fmaf(m.ex, Af[k], m.ey * Bf[k]);
+  int idx = 7;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float xa = fmaf(m.xx, Af[k], m.xy * Bf[k]);  // coefficient of A[l]
+    const float xb = fmaf(m.xy, Af[k], m.yy * Bf[k]);  // coefficient of B[l]
+#pragma unroll
+    for (int l = k; l < 6; l++) { acc.H[idx] += fmaf(xa, Af[l], xb * Bf[l]); idx++; }
+  }
+#else
+  const double d_ex = m.ex, d_ey = m.ey, d_xx = m.xx, d_xy = m.xy, d_yy = m.yy;
 #pragma unroll
   for (int k = 0; k < 6; k++) acc.H[1 + k] += (float)fma(d_ex, A[k], d_ey * B[k]);
   int idx = 7;
@@ -1138,6 +1158,7 @@ HSO_DEV void expand_feature(Acc& acc, const LevelCtx& L, const Proj& p, const Mo
 #pragma unroll
     for (int l = k; l < 6; l++) { acc.H[idx] += (float)fma(xa, A[l], xb * B[l]); idx++; }
   }
+#endif
   acc.d[0] -= (double)m.re;
 #pragma unroll
   for (int k = 0; k < 6; k++) acc.d[1 + k] -= fma(d_rx, A[k], d_ry * B[k]);
