@@ -128,8 +128,12 @@ HSO_HD Scratch scratch_at(char* base, int n_max)
 //   trk2: 256 threads, 80 KB — two workgroups share a CU, so one job's serial phases (robust thresholds, the 7x7 solve)
 //         overlap the other's evaluations; fits level images up to ~60 KB (levels 4..2).
 // A batch that fills the chip twice over runs the coarse levels on trk2 and the last level(s) on trk1 (track_launch below).
-#define TRK_THREADS 512
+#ifndef TRK1_THREADS
+#define TRK1_THREADS 512
+#endif
+#define TRK_THREADS TRK1_THREADS
 #define TRK_LDS_KB 160
+#define TRK_WAVES_PER_EU (TRK1_THREADS / 256)
 #ifndef TRK1_OLD_SHARE
 #define TRK1_OLD_SHARE 10
 #endif
@@ -140,8 +144,13 @@ namespace trk1 {
 #undef TRK_THREADS
 #undef TRK_LDS_KB
 #undef TRK_OLD_SHARE
+#undef TRK_WAVES_PER_EU
+#ifndef TRK2_PER_CU
+#define TRK2_PER_CU 2     // workgroups of the small shape per CU (3: 168 registers, 52 KB — measured slower)
+#endif
 #define TRK_THREADS 256
-#define TRK_LDS_KB 80
+#define TRK_LDS_KB (TRK2_PER_CU == 2 ? 80 : 52)
+#define TRK_WAVES_PER_EU TRK2_PER_CU
 #ifndef TRK2_OLD_SHARE
 #define TRK2_OLD_SHARE 8
 #endif
@@ -152,6 +161,7 @@ namespace trk2 {
 #undef TRK_THREADS
 #undef TRK_LDS_KB
 #undef TRK_OLD_SHARE
+#undef TRK_WAVES_PER_EU
 
 // makeDepthRef, CoarseTracker.cpp:210-240
 __global__ void k_make_depth_ref(const hso_depth_ref_in* in, int n, const hso_se3* poses, hso_se3 T_ref_w, double* out)
@@ -300,7 +310,7 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
     const size_t need = (size_t)g.w[lvl] * g.h[lvl] + g.w[lvl] + 64;
     if (need <= (size_t)trk2::kImgCap || getenv("HSO_TRACK_ALL_TRK2")) st->split_level = lvl;
   }
-  st->grid2 = std::min(n_jobs, 2 * ctx->n_cu);
+  st->grid2 = std::min(n_jobs, TRK2_PER_CU * ctx->n_cu);
   st->scratch_stride = scratch_bytes(C.n_max);
 
   if (int rc = grow(ctx, &st->d_jobs, &st->jobs_cap, sizeof(TrackJobDev) * n_jobs)) return rc;
@@ -366,10 +376,10 @@ int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx)
   if (const char* e = getenv("HSO_LDS_IMG_CAP")) C.lds_img_cap = atoi(e);  // experiment knob
   HSO_HIP_CHECK(ctx, hipMemsetAsync(st->d_counter, 0, sizeof(int), ctx->stream));
   if (C.inverse)
-    hipLaunchKernelGGL(trk1::k_track<true>, dim3(st->grid), dim3(512), st->lds_bytes, ctx->stream, C, st->d_jobs,
+    hipLaunchKernelGGL(trk1::k_track<true>, dim3(st->grid), dim3(TRK1_THREADS), st->lds_bytes, ctx->stream, C, st->d_jobs,
                        st->n_jobs, st->d_counter, st->d_scratch, st->scratch_stride, st->d_results);
   else
-    hipLaunchKernelGGL(trk1::k_track<false>, dim3(st->grid), dim3(512), st->lds_bytes, ctx->stream, C, st->d_jobs,
+    hipLaunchKernelGGL(trk1::k_track<false>, dim3(st->grid), dim3(TRK1_THREADS), st->lds_bytes, ctx->stream, C, st->d_jobs,
                        st->n_jobs, st->d_counter, st->d_scratch, st->scratch_stride, st->d_results);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
@@ -411,10 +421,10 @@ int hso_gpu_tracker_eval(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   trk1::EvalArgs ea;
   ea.level = level; ea.T = *T_cur_ref; ea.a = exposure_rat; ea.huber = huber_thresh; ea.outlier = outlier_thresh;
   if (st->C.inverse)
-    hipLaunchKernelGGL(trk1::k_eval<true>, dim3(1), dim3(512), st->lds_bytes, ctx->stream, st->C, st->d_jobs, ea,
+    hipLaunchKernelGGL(trk1::k_eval<true>, dim3(1), dim3(TRK1_THREADS), st->lds_bytes, ctx->stream, st->C, st->d_jobs, ea,
                        st->d_scratch, st->d_eval);
   else
-    hipLaunchKernelGGL(trk1::k_eval<false>, dim3(1), dim3(512), st->lds_bytes, ctx->stream, st->C, st->d_jobs, ea,
+    hipLaunchKernelGGL(trk1::k_eval<false>, dim3(1), dim3(TRK1_THREADS), st->lds_bytes, ctx->stream, st->C, st->d_jobs, ea,
                        st->d_scratch, st->d_eval);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, st->d_eval, sizeof(hso_eval_out), hipMemcpyDeviceToHost, ctx->stream));

@@ -1628,7 +1628,7 @@ constexpr int kImgCap = (int)(((kLdsTotal - 256 - sizeof(Shared)) / 256) * 256);
 extern __shared__ __attribute__((aligned(16))) char g_smem[];
 
 template <bool IC>
-__global__ __launch_bounds__(TRK_THREADS, 2) void k_track(TrackConsts C, const TrackJobDev* jobs, int n_jobs,
+__global__ __launch_bounds__(TRK_THREADS, TRK_WAVES_PER_EU) void k_track(TrackConsts C, const TrackJobDev* jobs, int n_jobs,
                                                        int* job_counter, char* scratch, size_t scratch_stride,
                                                        hso_track_result* results)
 {
