@@ -32,6 +32,17 @@ The JSON line also carries
                  shape/batch if a matching record exists under profiles/, else null;
   cpu_baseline — the CPU restatement (oracle/, single thread, rebuilt on this host with
                  -O3 -march=native for the timing) on the same frames, bounded sample;
+  roofline_valu — the same kernel priced against what actually limits it, VALU issue: wave-level VALU instructions per launch
+                 (SQ_INSTS_VALU of a PMC pass on exactly this workload, profiles/) / the live launch duration, against
+                 1024 SIMDs x clock / 4 (one wave64 VALU instruction per four clocks and SIMD), plus the PMC pass's own
+                 VALU-busy fraction;
+  chain        — the WHOLE per-frame chain (frame build + tracker -> reprojection / matching / grid selection -> pose
+                 optimisation -> seed updates) for 256 independent sequences at the same shape through the resident-table
+                 entry points: frames/s, per-stage ms and algorithmic-byte fractions (hso_amd/chain_bench.py), with the CPU
+                 restatement of the same stages timed beside it (1 thread; seed updates also on the reference's 4 threads);
+  single_sequence — BASELINE configs[2]/[3] are ONE sequence: latency of one tracker call (1 job: the cooperative shape splits
+                 it across the CUs of an XCD) and ms per frame of one sequence through the C++ driver libhso_host.so
+                 (FrameHandlerMono::addImage), at 200 and 2000 features (hso_amd/latency_bench.py);
   se3_vs_cpu   — per-frame SE(3) deviation GPU vs the strict CPU restatement on the distinct
                  scenes (rotation angle, translation, iteration-count agreement) — the second
                  half of BASELINE.json's metric; `vs_f64_energy_sum` repeats it against the restatement
@@ -55,6 +66,7 @@ if ROOT not in sys.path:
 PA = {4: 9, 3: 13, 2: 13, 1: 21, 0: 25}      # include/hso/CoarseTracker.h:100-109 via :80
 PAD = {4: 1, 3: 2, 2: 2, 1: 3, 0: 2}         # CoarseTracker.h:111-120
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_CLOCK_GHZ = 2.4                         # MI355X_MICROARCH.md: max clock
 
 
 def algorithmic_bytes(results, n_valid, inverse, levels):
@@ -94,15 +106,25 @@ def _render_scene(job):
                 q_init=synth.rotvec_to_quat(rv0), t_init=t0)
 
 
-def render_scenes(shape, feats, seeds):
-    """Scenes render in worker processes (forked before any GPU runtime exists in this process)."""
+def _render_any(job):
+    if job[0] == "chain":
+        from hso_amd import chain_bench
+        return chain_bench.build_scene(job[1])
+    return _render_scene(job[1])
+
+
+def render_scenes(shape, feats, seeds, chain_jobs=()):
+    """Scenes render in worker processes (forked before any GPU runtime exists in this process).  The chain's little worlds
+    (seven rendered frames each) go first: they take longest."""
     import multiprocessing as mp
-    jobs = [(shape, feats, int(s)) for s in seeds]
+    jobs = [("chain", j) for j in chain_jobs] + [("pair", (shape, feats, int(s))) for s in seeds]
     nproc = max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 32))
     if nproc == 1:
-        return [_render_scene(j) for j in jobs]
-    with mp.get_context("fork").Pool(nproc) as pool:
-        return pool.map(_render_scene, jobs, chunksize=1)
+        out = [_render_any(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(nproc) as pool:
+            out = pool.map(_render_any, jobs, chunksize=1)
+    return out[len(chain_jobs):], out[:len(chain_jobs)]
 
 
 def self_launch(args):
@@ -122,7 +144,102 @@ def rot_angle(qa, qb):
     return 2 * np.arccos(min(1.0, d))
 
 
+def extra_measurements(out, args, ctx, stream, spec, chain_scenes, seq_S, cam, orc):
+    """rank 0, N = 1, after the timed region: the whole per-frame chain for many sequences, the single-sequence latency, and
+    the CPU restatement of the chain's stages (the tracker's is out["cpu_baseline"])."""
+    import torch
+    from hso_amd import capi, chain_bench, latency_bench
+    if chain_scenes:
+        with torch.cuda.stream(stream):
+            chain, ch = chain_bench.measure(ctx, stream, spec, chain_scenes, args.chain_seqs, args.feats, algorithmic_bytes=algorithmic_bytes)
+        out["chain"] = chain
+        if orc is not None and args.cpu_frames > 0:
+            out["chain"]["cpu_baseline"] = chain_cpu_baseline(orc, cam, chain_scenes[0], ch, out.get("cpu_baseline"))
+        del ch
+    single = {"shape": "%dx%d" % (spec["width"], spec["height"]), "track": [], "sequence": []}
+    for n in (200, args.feats):
+        single["track"].append(latency_bench.track_latency(ctx, stream, cam, spec, n, 20))
+    if seq_S is not None:
+        for n in (200, args.feats):
+            single["sequence"].append(latency_bench.sequence_latency(cam, seq_S, n))
+    single["what"] = ("track: ONE job per call (hso_gpu_coarse_track_batch wall time incl. table upload, launch, read-back; launch_ms "
+                      "between HIP events); sequence: ms per addImage of one synthetic %d-frame sequence through libhso_host.so" % args.seq_frames)
+    out["single_sequence"] = single
+
+
+def chain_cpu_baseline(orc, cam, S, ch, track_cpu):
+    """The CPU restatement (oracle/, -O3 -march=native build already selected by the tracker's baseline) on the stages of the
+    chain, one distinct scene, batch entry points (no per-item interpreter time): findMatchDirect over the projected map
+    points, optimizeLevenbergMarquardt3rd, observeDepthRow over the seeds — 1 thread, and the seeds also on 4 threads like the
+    reference's depth filter (include/hso/IndexThreadReduce.h:27)."""
+    import ctypes as C
+    from hso_amd import capi
+    M = S["M"]
+    lib = orc.load()
+    T = capi.SE3.from_arrays(*M["T_cur_w"])
+    kf_pyrs = [orc.create_pyramid(f) for f in M["frames"]]
+    cur_pyr = orc.create_pyramid(M["cur"])
+    cur_sob = [orc.sobel5(np.ascontiguousarray(cur_pyr[L])) for L in range(3)]
+    # candidate list (untimed set-up through the per-point wrappers: projection + reference choice)
+    lib.hso_or_reproject_point.argtypes = [C.POINTER(capi.Camera), C.POINTER(capi.SE3), C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
+                                           C.c_void_p, C.POINTER(C.c_int)]
+    lib.hso_or_reproject_point.restype = C.c_int
+    lib.hso_or_close_view_obs.argtypes = [C.c_void_p] * 4 + [C.c_int]
+    lib.hso_or_close_view_obs.restype = C.c_int
+    lib.hso_or_reproject_make_job.argtypes = [C.POINTER(capi.SE3), C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.POINTER(capi.AlignJob)]
+    lib.hso_or_reproject_make_job.restype = None
+    kfs, pts, obs = M["kfs"], M["points"], M["obs"]
+    cur_pos = np.array(orc.se3_inverse(T).t[:])
+    jobs, job_kf = [], []
+    for i, p in enumerate(pts):
+        px = np.zeros(2); cell = C.c_int(0)
+        Th = kfs[p["host_kf"]:p["host_kf"] + 1]
+        if not lib.hso_or_reproject_point(C.byref(cam), C.byref(T), Th.ctypes.data + 8, p["host_f"].ctypes.data, float(p["idist"]),
+                                          M["cell_size"], M["grid_n_cols"], px.ctypes.data, C.byref(cell)):
+            continue
+        o = obs[p["obs_begin"]:p["obs_begin"] + p["obs_count"]]
+        k = lib.hso_or_close_view_obs(cur_pos.ctypes.data, p["pos"].ctypes.data, kfs.ctypes.data, o.ctypes.data, len(o)) if len(o) else -1
+        if k < 0:
+            continue
+        j = capi.AlignJob()
+        lib.hso_or_reproject_make_job(C.byref(T), M["cur_exposure"], M["cur_keyframe_id"], kfs.ctypes.data, pts[i:i + 1].ctypes.data,
+                                      o[k:k + 1].ctypes.data, px.ctypes.data, C.byref(j))
+        jobs.append(j); job_kf.append(int(o[k]["kf"]))
+    ja = (capi.AlignJob * len(jobs))(*jobs)
+    t0 = time.perf_counter(); reps = 0
+    while time.perf_counter() - t0 < 3.0:
+        mo = orc.find_match_direct_batch(cam, ja, job_kf, kf_pyrs, cur_pyr, cur_sob); reps += 1
+    t_match = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter(); reps = 0
+    while time.perf_counter() - t0 < 2.0:
+        orc.pose_optimize(cam, ch._pj[0]); reps += 1
+    t_pose = (time.perf_counter() - t0) / reps
+    seeds = (capi.Seed * S["n_seeds"]).from_buffer_copy(S["seeds_bytes"])
+    pea = ch.pea
+    t_seed = {}
+    for nt in (1, 4):
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < 3.0:
+            so = orc.seed_observe_batch(cam, seeds, T, M["cur_exposure"], pea, kf_pyrs[0], cur_pyr, cur_sob, nt); reps += 1
+        t_seed[nt] = (time.perf_counter() - t0) / reps
+    t_track = 1.0 / track_cpu["value"] if track_cpu else None
+    tot1 = (t_track or 0) + t_match + t_pose + t_seed[1]
+    tot4 = (t_track or 0) + t_match + t_pose + t_seed[4]
+    return {"value": 1.0 / tot1, "unit": "frames/s", "cores": 1, "kind": "port",
+            "value_seed_updates_on_4_threads": 1.0 / tot4, "cores_seed_updates": 4,
+            "ms_per_frame": {"track": 1e3 * t_track if t_track else None, "match": 1e3 * t_match, "pose": 1e3 * t_pose,
+                             "seeds_1_thread": 1e3 * t_seed[1], "seeds_4_threads": 1e3 * t_seed[4]},
+            "sample": "one frame of one distinct scene per stage, repeated for 2-3 s each: findMatchDirect over %d projected map points "
+                      "(projection and reference choice not timed), optimizeLevenbergMarquardt3rd on %d features, observeDepthRow over %d "
+                      "seeds; oracle/ C restatement through its batch entry points; track = the tracker baseline above"
+                      % (len(jobs), len(ch.pose_feats), S["n_seeds"]),
+            "matched": int(sum(m.success for m in mo)), "seeds_updated": int(sum(o.result == 1 for o in so))}
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -133,6 +250,8 @@ def main():
     ap.add_argument("--inverse", type=int, default=0)
     ap.add_argument("--min-level", type=int, default=1, help="developer knob: stop the tracker above level 1 (the judged line uses 1)")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames in the cpu_baseline sample (about 10 s on one host core)")
+    ap.add_argument("--chain-seqs", type=int, default=256, help="sequences of the whole-chain measurement (0 = skip; N = 1 only)")
+    ap.add_argument("--seq-frames", type=int, default=24, help="frames of the single-sequence run through libhso_host.so (0 = skip; N = 1 only)")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
                          "BASELINE.json's metric is quoted on; vga: BASELINE configs[1], 640x480 pinhole")
@@ -149,7 +268,15 @@ def main():
     n_sc = max(1, min(args.scenes, args.batch))
     seq_ids = hdist.shard_sequences(world * n_sc, rank, world)      # distinct sequences per rank
     t_r0 = time.perf_counter()
-    scenes = render_scenes(args.shape, args.feats, [1234 + 7 * s for s in seq_ids])
+    from hso_amd import synth as _synth
+    spec0 = _synth.EUROC if args.shape == "euroc" else _synth.ICL_NUIM
+    extras = rank == 0 and world == 1
+    chain_jobs = []
+    if extras and args.chain_seqs > 0:
+        from hso_amd import chain_bench
+        chain_jobs = chain_bench.scene_jobs(spec0, args.feats, 2 * args.feats, 3 * args.feats, 4)
+    scenes, chain_scenes = render_scenes(args.shape, args.feats, [1234 + 7 * s for s in seq_ids], chain_jobs)
+    seq_S = _synth.sequence(args.seq_frames, spec=spec0) if extras and args.seq_frames > 1 else None   # forks its own renderers
     t_render = time.perf_counter() - t_r0
 
     import torch
@@ -242,15 +369,19 @@ def main():
     evals = float(np.mean([sum(r.n_eval[L] for L in levels) for r in results]))
 
     # HBM-side bytes of the same kernel: only a PMC record collected for exactly this workload counts
-    traffic, traffic_src = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_k_track.json")))
-        for e in pmc["records"]:
-            if (e["shape"], e["batch"], e["feats"], e["inverse"], e["scenes"], e.get("min_level", 1)) == \
-                    (args.shape, B, args.feats, args.inverse, n_sc, args.min_level):
-                traffic, traffic_src = e["hbm_bytes_per_launch"], "profiles/r2_pmc_k_track.json (rocprofv3 --pmc, separate passes)"
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_src, valu = None, None, None
+    for fn in ("r3_pmc_k_track.json", "r2_pmc_k_track.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            for e in pmc["records"]:
+                if (e["shape"], e["batch"], e["feats"], e["inverse"], e["scenes"], e.get("min_level", 1)) == \
+                        (args.shape, B, args.feats, args.inverse, n_sc, args.min_level):
+                    if traffic is None and e.get("hbm_bytes_per_launch"):
+                        traffic, traffic_src = e["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, separate passes)" % fn
+                    if valu is None and e.get("valu_insts_per_launch"):
+                        valu = dict(e, source="profiles/%s" % fn)
+        except (OSError, KeyError, ValueError):
+            pass
 
     # sanity: every frame converged to its scene's motion (guards against timing a broken run)
     terr = [float(np.linalg.norm(rec[i, 4:7] - scenes[i % n_sc]["t_true"])) for i in range(min(B, n_sc))]
@@ -279,6 +410,17 @@ def main():
                                 "the algorithmic bytes (DESIGN.md section 3.2)",
                      "launch_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch},
     }
+    # the limiter itself: VALU issue.  Instructions from a PMC pass on exactly this workload (SQ_INSTS_VALU counts wave-level
+    # instructions, summed over the tracker's launches of one batch); time = the live launch duration above.
+    if valu is not None:
+        peak_ginst = 1024 * VALU_CLOCK_GHZ / 4.0          # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 clocks each
+        ach = valu["valu_insts_per_launch"] / (kern_ms * 1e-3) / 1e9
+        out["roofline_valu"] = {"bound": "valu_issue", "kernel": "k_track", "achieved": ach, "peak": peak_ginst, "unit": "G wave-instructions/s",
+                                "frac": ach / peak_ginst, "valu_insts_per_launch": valu["valu_insts_per_launch"],
+                                "valu_busy_frac_pmc": valu.get("valu_busy_frac"), "clock_ghz": VALU_CLOCK_GHZ, "source": valu["source"],
+                                "note": "peak = 1024 SIMDs x 2.4 GHz / 4 clocks per wave64 instruction (MI355X_MICROARCH.md max clock; the "
+                                        "sustained clock under this kernel is lower, so frac is a lower bound); valu_busy_frac_pmc = "
+                                        "4 x SQ_ACTIVE_INST_VALU / (SIMDs x busy cycles) of the PMC pass, time-weighted over the two launches"}
 
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import oracle_py as orc   # checker / baseline only, never the product path
@@ -334,6 +476,8 @@ def main():
                                "sample": "%d frames of the same workload (pyramid + Sobel + stats + CoarseTracker from the same "
                                          "initial poses), oracle/ C restatement, 1 thread, %.1f s" % (n_cpu, tc1 - tc0),
                                "build": flags, "host_cpus": os.cpu_count()}
+    if extras and (args.chain_seqs > 0 or seq_S is not None):
+        extra_measurements(out, args, ctx, stream, spec, chain_scenes, seq_S, cam, locals().get("orc"))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

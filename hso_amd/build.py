@@ -11,14 +11,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libhso_gpu.so")
-SOURCES = ["hso_ctx.hip", "hso_frame.hip", "hso_tracker.hip", "hso_align.hip", "hso_pose.hip", "hso_ba.hip",
+SOURCES = ["hso_ctx.hip", "hso_frame.hip", "hso_tracker.hip", "hso_tracker_coop.hip", "hso_align.hip", "hso_pose.hip", "hso_ba.hip",
            "hso_seed.hip", "hso_activate.hip", "hso_fast.hip", "hso_edgelet.hip", "hso_select.hip", "hso_octree.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # Per-file additions.  The tracker megakernel is compiled without LLVM's SLP vectoriser: the packed fp32 / packed 16-bit
 # operations it forms there need register pairs, and forming them cost 55-61 spilled VGPRs at the kernel's 256-register
 # budget (3-7 without; k_track 13.9 -> 13.3 ms on 4096 EuRoC pairs).
-PER_FILE = {"hso_tracker.hip": ["-fno-slp-vectorize"],
+PER_FILE = {"hso_tracker.hip": ["-fno-slp-vectorize"], "hso_tracker_coop.hip": ["-fno-slp-vectorize"],
             # no spills either way, but the scalar forms are faster here too: k_align_t 596 -> 559 us, k_seed_observe 931 -> 852 us
             # (128 sequences, profiles/collect_stages.sh); k_pose, k_sobel unchanged, the remaining files not measured
             "hso_align.hip": ["-fno-slp-vectorize"], "hso_seed.hip": ["-fno-slp-vectorize"]}

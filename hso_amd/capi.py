@@ -84,7 +84,7 @@ class TrackResult(C.Structure):
                 ("huber", C.c_float * N_PYR_LEVELS), ("outlier", C.c_float * N_PYR_LEVELS),
                 ("n_select", C.c_int32 * N_PYR_LEVELS), ("energy", C.c_double * N_PYR_LEVELS),
                 ("phase_cycles", C.c_uint64 * 10),
-                ("status", C.c_int32), ("_pad", C.c_int32)]
+                ("status", C.c_int32), ("coop_workgroups", C.c_int16), ("coop_same_xcd", C.c_int16)]
 
 
 class EvalOut(C.Structure):

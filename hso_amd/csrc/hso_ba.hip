@@ -482,7 +482,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_schur(const BaProb* probs, co
 __global__ __launch_bounds__(BA_THREADS) void k_ba_solve(const BaProb* probs, const int* active)
 {
   extern __shared__ double s_S[];
-  __shared__ double s_x[96], s_col[96], s_sc[64];
+  __shared__ double s_x[96], s_col[96], s_sc[16];   // s_sc: one entry per FREE pose (M <= 96 unknowns = 16 poses)
   __shared__ int s_ok;
   const BaProb& P = probs[active[blockIdx.y]];
   const int M = P.M, np = P.a.n_poses, tid = threadIdx.x;
@@ -529,24 +529,24 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_solve(const BaProb* probs, co
   }
   // pose steps, push(), SE3Quat::exp(dx) * pose, the pose part of computeScale: one pose per thread
   double* xc = P.trial_rw + 1;
-  if (tid < np) {
-    const int i = tid, c = P.col[i];
+  for (int i = tid; i < np; i += BA_THREADS) {   // any number of poses in the window: the fixed ones (host / neighbour keyframes) only get a zero step
+    const int c = P.col[i];
     double x6[6];
     for (int q = 0; q < 6; q++) { x6[q] = (ok && c >= 0) ? s_x[c + q] : 0.0; xc[i * 6 + q] = x6[q]; }
     P.poses_bak[i] = P.poses_rw[i];                                                    // _optimizer->push()
-    double sc = 0;
     if (c >= 0) {
+      double sc = 0;
       hso_se3 pose = P.poses_rw[i];
       se3quat_exp_times(x6, pose);                                                     // VertexSE3Expmap::oplusImpl
       P.poses_rw[i] = pose;
       for (int q = 0; q < 6; q++) sc += x6[q] * (lambda * x6[q] + P.bc[i * 6 + q]);     // computeScale, pose part
+      s_sc[c / 6] = sc;                                                                // columns are handed out in pose order
     }
-    s_sc[i] = sc;
   }
   __syncthreads();
   if (tid == 0) {
     double sc = 0;
-    for (int i = 0; i < np; i++) sc += s_sc[i];
+    for (int f = 0; f < M / 6; f++) sc += s_sc[f];                                     // pose order, as the serial loop adds them
     P.trial_rw[1 + 6 * np] = ok ? 0.0 : 1.0;
     P.sum[3] = sc;
     P.sum[4] = ok ? 1.0 : 0.0;
@@ -1082,7 +1082,7 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
       return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: bad argument");
     if (int rc = ba_check_edges(ctx, P.edges, P.n_edges, P.n_points, P.n_poses, "ba_optimize")) return rc;
     ba_layout(Q.win[q], P.n_poses, P.n_points, P.pose_fixed, P.edges, P.n_edges, P.huber_corner, P.huber_edge);
-    if (Q.win[q].M > 96 || P.n_poses > 64) return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: more than 16 free (64 in all) poses in one window");
+    if (Q.win[q].M > 96) return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: more than 16 free poses in one window (the reference's core is 7 keyframes)");
   }
   if (int rc = ba_batch_begin(Q, ctx, problems, n_problems)) return rc;
   for (int q = 0; q < n_problems; q++) {
@@ -1121,6 +1121,11 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
       if (int rc = ba_list(Q, 3, w_trial, &dl)) return rc;
       const int ny = (int)w_trial.size(), max_m = ba_max(Q, w_trial, &BaWin::M);
       hipLaunchKernelGGL(k_ba_schur, dim3(ba_max(Q, w_trial, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+      static bool solve_attr = false;   // 96 x 96 doubles = 72 KiB of dynamic LDS: above the 64 KiB a launch gets without asking
+      if (!solve_attr) {
+        HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * (int)sizeof(double)));
+        solve_attr = true;
+      }
       hipLaunchKernelGGL(k_ba_solve, dim3(1, ny), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, dl);
       hipLaunchKernelGGL(k_ba_backsub, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
       if (int rc = ba_launch_errors(Q, 4, w_trial)) return rc;

@@ -271,7 +271,9 @@ HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, con
     const int16_t* gx = reinterpret_cast<const int16_t*>(cur_base + g.sob_off[search_level][0]);
     const int16_t* gy = reinterpret_cast<const int16_t*>(cur_base + g.sob_off[search_level][1]);
     const float uf = (float)pxs0, vf = (float)pxs1;
-    const int ui = (int)floorf((float)pxs0), vi = (int)floorf((float)pxs1);
+    // (an LK result is inside the level with a 4-pixel margin by its own loop test, :234; the guard only keeps the read defined)
+    const bool inside = uf >= 0 && vf >= 0 && uf < (float)(cols - 1) && vf < (float)(rows - 1);
+    const int ui = inside ? (int)floorf((float)pxs0) : 0, vi = inside ? (int)floorf((float)pxs1) : 0;
     const float sx = uf - (float)ui, sy = vf - (float)vi;
     const float wTL = (float)((1.0 - sx) * (1.0 - sy));
     const float wTR = (float)(sx * (1.0 - sy));
@@ -283,7 +285,7 @@ HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, con
     double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + gs]) + (double)wBR * (double)gy[a + gs + 1];
     const double nn = sqrt(n0 * n0 + n1 * n1);
     n0 /= nn; n1 /= nn;
-    ok = (dir0 * n0 + dir1 * n1) > (double)(float)0.86;  // Config::edgeLetCosAngle() through a float parameter
+    ok = inside && (dir0 * n0 + dir1 * n1) > (double)(float)0.86;  // Config::edgeLetCosAngle() through a float parameter
     if (!ok) o.stage = HSO_ALIGN_NORMAL;
   }
 

@@ -402,17 +402,24 @@ HSO_DEV SeedMid seed_wave(const SeedConsts& C, const SeedDev& SD, const uint8_t*
         const int16_t* gx = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][0]);
         const int16_t* gy = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][1]);
         const float uf = (float)ps0, vf = (float)ps1;
-        const int ui = (int)floorf((float)ps0), vi = (int)floorf((float)ps1);
-        const float sx = uf - (float)ui, sy = vf - (float)vi;
-        const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy);
-        const float wBR = (float)(((1.0 - wTL) - wTR) - wBL);
-        const int gs = C.g.sob_stride[sl];
-        const int a = vi * gs + ui;
-        double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + gs]) + (double)wBR * (double)gx[a + gs + 1];
-        double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + gs]) + (double)wBR * (double)gy[a + gs + 1];
-        const double nn = sqrt(n0 * n0 + n1 * n1);
-        n0 /= nn; n1 /= nn;
-        result = (dc0 * n0 + dc1 * n1) > (double)(float)0.7;
+        // The reference reads the four taps unchecked (:421-428): a NaN position (an edgelet direction of norm 0 lets
+        // KLTLimited1D "succeed" with a NaN pixel) or one outside the image is an out-of-bounds read there.  Defined here and in
+        // the CPU restatement alike: such a position fails the check.
+        if (!(uf >= 0 && vf >= 0 && uf < (float)(cols - 1) && vf < (float)(rows - 1))) {
+          result = false;
+        } else {
+          const int ui = (int)floorf((float)ps0), vi = (int)floorf((float)ps1);
+          const float sx = uf - (float)ui, sy = vf - (float)vi;
+          const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy);
+          const float wBR = (float)(((1.0 - wTL) - wTR) - wBL);
+          const int gs = C.g.sob_stride[sl];
+          const int a = vi * gs + ui;
+          double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + gs]) + (double)wBR * (double)gx[a + gs + 1];
+          double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + gs]) + (double)wBR * (double)gy[a + gs + 1];
+          const double nn = sqrt(n0 * n0 + n1 * n1);
+          n0 /= nn; n1 /= nn;
+          result = (dc0 * n0 + dc1 * n1) > (double)(float)0.7;
+        }
       }
     }
     if (result) {

@@ -38,89 +38,7 @@
 
 using namespace hso_dev;
 
-#define TRK_MAX_PA 25
-#define KEY_INVALID 0xFFFFFFFFu
-#define N_RED 38  // 28 H + 7 b + E + n_terms + n_saturated
-
-// include/hso/CoarseTracker.h:58-120 (staticPattern, staticPatternNum, staticPatternPadding)
-static constexpr int8_t h_pattern[8][40][2] = {
-  { {0,0} },
-  { {0,-1}, {-1,0}, {0,0}, {1,0}, {0,1} },
-  { {-1,-1}, {-1,0}, {-1,1}, {-1,0}, {0,0}, {0,1}, {1,-1}, {1,0}, {1,1} },
-  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {0,-1}, {-1,0}, {1,0}, {0,1} },
-  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {-2,-2}, {-2,2}, {2,-2}, {2,2} },
-  { {0,-2}, {-1,-1}, {1,-1}, {-2,0}, {0,0}, {2,0}, {-1,1}, {1,1}, {0,2}, {-2,-2}, {-2,2}, {2,-2}, {2,2},
-    {-3,-1}, {-3,1}, {3,-1}, {3,1}, {1,-3}, {-1,-3}, {1,3}, {-1,3} },
-  { {-2,-2}, {-2,-1}, {-2,0}, {-2,1}, {-2,2}, {-1,-2}, {-1,-1}, {-1,0}, {-1,1}, {-1,2},
-    {0,-2}, {0,-1}, {0,0}, {0,1}, {0,2}, {1,-2}, {1,-1}, {1,0}, {1,1}, {1,2},
-    {2,-2}, {2,-1}, {2,0}, {2,1}, {2,2} },
-  { {-4,-4}, {-4,-2}, {-4,0}, {-4,2}, {-4,4}, {-2,-4}, {-2,-2}, {-2,0}, {-2,2}, {-2,4},
-    {0,-4}, {0,-2}, {0,0}, {0,2}, {0,4}, {2,-4}, {2,-2}, {2,0}, {2,2}, {2,4},
-    {4,-4}, {4,-2}, {4,0}, {4,2}, {4,4} },
-};
-static constexpr int h_pattern_num[8] = { 1, 5, 9, 13, 13, 21, 25, 25 };
-static constexpr int h_pattern_pad[8] = { 1, 1, 1, 2, 2, 3, 2, 4 };
-#define PATTERN_OFFSET 2  // m_pattern_offset, CoarseTracker.h:122
-
-// per pyramid level: geometry, PATCH_AREA, HALF_PATCH_SIZE and the byte offset oy*stride+ox of
-// every pattern pixel in that level's image (CoarseTracker.cpp:80-82,337).  Lives in device
-// memory: indexing a by-value kernel argument with the run-time level would make the compiler
-// copy the whole argument block to scratch and read the camera from there in the hot loops.
-struct TrackLevel {
-  int w, h;
-  uint32_t off;       // byte offset of the level in the frame's pyramid block
-  int pa, pad;
-  int pi;             // index into the static pattern tables (max_level - level + 2), -1 = none
-  int poff[TRK_MAX_PA];
-};
-
-// kernel argument by value: scalars only ever indexed with constants => stays in SGPRs
-struct TrackConsts {
-  hso_camera cam;
-  int inverse, max_level, min_level, n_iter;
-  int level_first, level_last;  // the levels this launch works through (max_level .. min_level, or a part of it: see track_launch)
-  int resume;         // != 0: start from the pose / exposure / bookkeeping an earlier launch left in the result record
-  int lds_img_cap;    // bytes of LDS available for the staged level image
-  int n_max;          // scratch stride (features)
-  int keys_in_memory; // parity hook: leave the |residual| keys in the scratch buffer (abs_err_out)
-  const TrackLevel* lv;  // [HSO_N_PYR_LEVELS], device memory
-};
-
-struct TrackJobDev {
-  const uint8_t* ref_base;
-  const uint8_t* cur_base;
-  const double* feats;  // SoA [6][n_stride]: px, py, fx, fy, fz, dist
-  int n, n_stride;
-  hso_se3 T;
-  float a;
-  int _pad;
-};
-
-// per-workgroup scratch in global memory (L2 resident): sized for n_max features
-struct Scratch {
-  float* ref_patch;   // [PA][n_max]  reference intensities (m_ref_patch_cache, pixel-major)
-  float* ref_dx;      // [PA][n_max]  inverse-compositional: reference image gradients
-  float* ref_dy;
-  uint32_t* keys;     // [PA*n_max]   |residual| bit patterns for the robust thresholds
-  uint8_t* visible;   // [n_max]      m_visible_fts
-};
-
-HSO_HD size_t scratch_bytes(int n_max)
-{
-  const size_t t = (size_t)TRK_MAX_PA * n_max;
-  return ((t * 4 * 4 + n_max + 255) / 256) * 256;
-}
-HSO_HD Scratch scratch_at(char* base, int n_max)
-{
-  const size_t t = (size_t)TRK_MAX_PA * n_max;
-  Scratch s;
-  s.ref_patch = reinterpret_cast<float*>(base);
-  s.ref_dx = s.ref_patch + t;
-  s.ref_dy = s.ref_dx + t;
-  s.keys = reinterpret_cast<uint32_t*>(s.ref_dy + t);
-  s.visible = reinterpret_cast<uint8_t*>(s.keys + t);
-  return s;
-}
+#include "hso_tracker_defs.h"
 
 
 // Two shapes of the same device code (hso_tracker_core.h):
@@ -128,6 +46,8 @@ HSO_HD Scratch scratch_at(char* base, int n_max)
 //   trk2: 256 threads, 80 KB — two workgroups share a CU, so one job's serial phases (robust thresholds, the 7x7 solve)
 //         overlap the other's evaluations; fits level images up to ~60 KB (levels 4..2).
 // A batch that fills the chip twice over runs the coarse levels on trk2 and the last level(s) on trk1 (track_launch below).
+// (a third shape, several workgroups per job for small batches, lives in hso_tracker_coop.hip)
+#define TRK_COOP 0
 #ifndef TRK1_THREADS
 #define TRK1_THREADS 512
 #endif
@@ -196,6 +116,12 @@ struct TrackBatchState {
   bool attr_set = false;
   std::vector<double> h_feats;
   std::vector<TrackJobDev> h_jobs;
+  // cooperative shape (small batches): coop_K >= 2 workgroups per job
+  int coop_K = 0, coop_scatter = 0;
+  bool coop_broken = false;       // a cooperative launch timed out once: this context stays on the one-workgroup shapes
+  TrackJobDev* d_subjobs = nullptr; size_t subjobs_cap = 0;
+  CoopJobState* d_coop = nullptr; size_t coop_cap = 0;
+  std::vector<TrackJobDev> h_subjobs;
 };
 
 void hso_track_state_free(hso_gpu_ctx* ctx)
@@ -203,7 +129,7 @@ void hso_track_state_free(hso_gpu_ctx* ctx)
   TrackBatchState* st = ctx->track;
   if (!st) return;
   (void)hipFree(st->d_jobs); (void)hipFree(st->d_feats); (void)hipFree(st->d_scratch); (void)hipFree(st->d_results);
-  (void)hipFree(st->d_counter); (void)hipFree(st->d_eval);
+  (void)hipFree(st->d_counter); (void)hipFree(st->d_eval); (void)hipFree(st->d_subjobs); (void)hipFree(st->d_coop);
   delete st;
   ctx->track = nullptr;
 }
@@ -274,7 +200,8 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
     d.n = n; d.n_stride = ns;
     d.T = jobs[j].T_cur_ref;
     d.a = jobs[j].exposure_rat;
-    d._pad = 0;
+    d.n_total = n;
+    d.coop_K = 1; d.coop_pad_ = 0;
     foff += ns;
   }
 
@@ -312,9 +239,51 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   }
   st->grid2 = std::min(n_jobs, TRK2_PER_CU * ctx->n_cu);
   st->scratch_stride = scratch_bytes(C.n_max);
+  // Small batches (a single sequence: BASELINE configs[2] / [3]; up to one job per XCD): K_j workgroups share job j
+  // (hso_tracker_coop.hip).  K_j follows the job's own feature count — about COOP_FEATS_PER_WG per workgroup — so a job's
+  // result does not depend on what else is in the batch; all workgroups of the launch are resident at once (K_j <= CUs per XCD).
+  st->coop_K = 0;
+  st->coop_scatter = getenv("HSO_TRACK_COOP_SCATTER") ? 1 : 0;
+  if (max_grid <= 0 && n_jobs <= COOP_MAX_JOBS && !st->coop_broken && !getenv("HSO_TRACK_NO_COOP")) {
+    const int per_xcd = std::min(COOP_KMAX, std::max(1, ctx->n_cu / 8));
+    int fpw = COOP_FEATS_PER_WG;
+    if (const char* e = getenv("HSO_TRACK_COOP_FPW")) fpw = std::max(1, atoi(e));
+    int kmax = 0;
+    for (int j = 0; j < n_jobs; j++) {
+      int K = std::max(1, (st->h_jobs[j].n + fpw - 1) / fpw);
+      if (const char* e = getenv("HSO_TRACK_COOP_K")) K = std::max(1, atoi(e));
+      K = std::min(K, per_xcd);
+      st->h_jobs[j].coop_K = K;
+      kmax = std::max(kmax, K);
+    }
+    // the stride of the slice table.  Every job of a small batch takes the cooperative kernel, also the ones that stay on one
+    // workgroup (K_j = 1: no exchange happens) — a job's result must not depend on which kernel its neighbours need
+    st->coop_K = kmax;
+  }
+  if (st->coop_K) st->split_level = -1;
 
   if (int rc = grow(ctx, &st->d_jobs, &st->jobs_cap, sizeof(TrackJobDev) * n_jobs)) return rc;
-  if (int rc = grow(ctx, &st->d_scratch, &st->scratch_cap, st->scratch_stride * std::max(st->grid, st->split_level >= 0 ? st->grid2 : 0))) return rc;
+  if (int rc = grow(ctx, &st->d_scratch, &st->scratch_cap, st->scratch_stride * std::max(std::max(st->grid, st->split_level >= 0 ? st->grid2 : 0), n_jobs * st->coop_K))) return rc;
+  if (st->coop_K) {
+    const int KS = st->coop_K;
+    st->h_subjobs.assign((size_t)n_jobs * KS, TrackJobDev{});
+    for (int j = 0; j < n_jobs; j++) {
+      const TrackJobDev& d = st->h_jobs[j];
+      const int K = d.coop_K;
+      const int chunk = (d.n + K - 1) / K;
+      for (int r = 0; r < K; r++) {
+        TrackJobDev& q = st->h_subjobs[(size_t)j * KS + r];
+        q = d;
+        const int f0 = std::min(d.n, r * chunk), f1 = std::min(d.n, f0 + chunk);
+        q.feats = d.feats + f0;      // SoA [6][n_stride]: a slice is the same table advanced by f0 columns
+        q.n = f1 - f0;
+        q.n_total = d.n;
+      }
+    }
+    if (int rc = grow(ctx, &st->d_subjobs, &st->subjobs_cap, sizeof(TrackJobDev) * n_jobs * KS)) return rc;
+    if (int rc = grow(ctx, &st->d_coop, &st->coop_cap, sizeof(CoopJobState) * n_jobs)) return rc;
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_subjobs, st->h_subjobs.data(), sizeof(TrackJobDev) * n_jobs * KS, hipMemcpyHostToDevice, ctx->stream));
+  }
   if (int rc = grow(ctx, &st->d_results, &st->results_cap, sizeof(hso_track_result) * n_jobs)) return rc;
   // one small allocation: [0, 256) the job counter, [256, ...) the level table
   if (!st->d_counter) HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&st->d_counter), 256 + sizeof(st->lv)));
@@ -358,6 +327,14 @@ int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx)
   if (!ctx || !ctx->track || ctx->track->n_jobs <= 0) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_launch: nothing prepared");
   TrackBatchState* st = ctx->track;
   TrackConsts C = st->C;
+  if (st->coop_K) {
+    C.lds_img_cap = hso_track_coop_img_cap();
+    HSO_HIP_CHECK(ctx, hipMemsetAsync(st->d_counter, 0, 2 * sizeof(int), ctx->stream));   // [1] = the fail flag
+    HSO_HIP_CHECK(ctx, hipMemsetAsync(st->d_coop, 0, sizeof(CoopJobState) * st->n_jobs, ctx->stream));
+    HSO_HIP_CHECK(ctx, hso_track_coop_launch(ctx->stream, C, st->d_subjobs, st->n_jobs, st->coop_K, st->coop_scatter, st->d_coop,
+                                             reinterpret_cast<unsigned*>(st->d_counter) + 1, st->d_scratch, st->scratch_stride, st->d_results));
+    return HSO_OK;
+  }
   if (st->split_level >= 0) {
     // coarse levels: two 256-thread workgroups per CU (one job's thresholds / LM solve overlap the other's evaluations)
     C.level_first = C.max_level; C.level_last = st->split_level; C.resume = 0; C.lds_img_cap = trk2::kImgCap;
@@ -392,6 +369,19 @@ int hso_gpu_coarse_track_collect(hso_gpu_ctx* ctx, hso_track_result* results)
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(results, st->d_results, sizeof(hso_track_result) * st->n_jobs,
                                     hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (st->coop_K) {
+    bool failed = false;
+    for (int j = 0; j < st->n_jobs; j++) failed = failed || results[j].status != 0;
+    if (failed) {
+      // A workgroup of the cooperative launch never became resident within the spin bound (other work held its CU for
+      // seconds).  Not a result: rerun the batch on the one-workgroup shapes — same arithmetic per feature, no co-residency
+      // requirement — and keep this context on them from now on.
+      st->coop_K = 0;
+      st->coop_broken = true;
+      if (int rc = hso_gpu_coarse_track_launch(ctx)) return rc;
+      return hso_gpu_coarse_track_collect(ctx, results);
+    }
+  }
   return HSO_OK;
 }
 

@@ -26,6 +26,17 @@ struct Shared {
   int wave_cnt[TRK_WAVES];
   int poff[32];                      // byte offset oy*stride+ox of every pattern pixel of this level
   hso_track_result res;              // the job's result record, written to global memory once at the end
+#if TRK_COOP
+  // cooperative shape: this workgroup is one of coop_K that share ONE job (a slice of its features each)
+  alignas(8) unsigned coop_in[COOP_KMAX][COOP_NG + 2];  // the peers' partial sums of the running exchange, as granule values
+  int coop_fast;                     // all workgroups of the job sit on one XCD: exchange through its L2
+  CoopJobState* coop_state;          // the job's exchange area in device memory
+  int coop_K, coop_rank;
+  unsigned coop_epoch;               // exchanges done (granule tag of the next one = coop_epoch + 1)
+  int coop_region;                   // next unused histogram / list region
+  unsigned coop_base;
+  int coop_fail;                     // a peer did not answer within the spin bound (not resident): results are invalid
+#endif
 #ifdef HSO_PHASE_TIMERS
   unsigned long long dbg[8];
 #endif
@@ -294,6 +305,203 @@ HSO_DEV int block_sum_int(Shared& s, int v)
   for (int w = 0; w < TRK_WAVES; w++) tot += s.wave_cnt[w];
   return tot;
 }
+
+
+#if TRK_COOP
+// ------------------------------------------------- exchange between the workgroups of one job (cooperative shape)
+// K workgroups own feature slices of ONE (ref, cur) pair.  Everything that depends on all features is exchanged through the
+// job's CoopJobState in device memory, and every workgroup then computes the same continuation from the same numbers in the
+// same order (the LM step, the accept decision, the thresholds) — no broadcast, no leader, one exchange per evaluation.
+// Visibility follows cdna_hip_programming.md section 6, Guideline 16: every shared word is an agent-scope access in the
+// global address space; no result depends on workgroup placement or timing.
+//   sums        8-byte {tag, value} granules, one sc1 store each; a reader re-reads a granule until its tag is the exchange
+//               number (form R2: the data is the flag).  Two granule sets alternate, so a fast workgroup's next exchange
+//               cannot overwrite what a slow one still reads.
+//   histograms  device-scope atomic adds into a region that no exchange has touched before (zeroed by the launch's memset),
+//               drained (vmcnt), then one arrival counter; read back with agent-scope loads.
+typedef __attribute__((address_space(1))) unsigned long long* CoopG64;
+typedef __attribute__((address_space(1))) unsigned* CoopG32;
+#define COOP_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// Transport primitives.  `fast` (workgroup-uniform): every workgroup of the job runs on the same XCD (verified at run time by
+// coop_hello), so that XCD's L2 is their common point of coherence: a plain store lands there (the vector L1 is write-through)
+// and an L2-scope atomic executes there; the agent-scope forms (sc1: write through to memory, line dropped from the L2) are
+// what any other placement needs.  Loads are agent-scope relaxed in both cases (they bypass the CU's L1 and are L2-served).
+HSO_DEV void coop_store64(CoopG64 p, unsigned long long v, bool fast)
+{
+  if (fast) asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+  else __hip_atomic_store(p, v, COOP_RLX);
+}
+HSO_DEV void coop_store32(CoopG32 p, unsigned v, bool fast)
+{
+  if (fast) asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+  else __hip_atomic_store(p, v, COOP_RLX);
+}
+HSO_DEV void coop_add32(CoopG32 p, unsigned v, bool fast)
+{
+  if (fast) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_add(p, v, COOP_RLX);
+}
+HSO_DEV unsigned coop_fetch_add32(CoopG32 p, unsigned v, bool fast)
+{
+  if (fast) return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __hip_atomic_fetch_add(p, v, COOP_RLX);
+}
+HSO_DEV unsigned long long coop_poll64(Shared& s, CoopG64 src, unsigned tag)
+{
+  unsigned long long x;
+  for (unsigned spins = 0;;) {
+    x = __hip_atomic_load(src, COOP_RLX);
+    if ((unsigned)(x >> 32) == tag) break;
+    if (++spins > COOP_SPIN_LIMIT) { s.coop_fail = 1; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return x;
+}
+
+// Placement census through the safe transport: every workgroup publishes the id of the XCD it runs on
+// (s_getreg_b32 HW_REG_XCC_ID); the fast transport is chosen only when all K agree.
+HSO_DEV void coop_hello(Shared& s)
+{
+  const int tid = threadIdx.x, K = s.coop_K;
+  if (K == 1) return;   // a job on one workgroup: nothing to exchange (coop_fast stays 0)
+  CoopJobState* const st = s.coop_state;
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
+  if (tid == 0) {
+    s.coop_fast = 1;
+    __hip_atomic_store((CoopG64)&st->hello[s.coop_rank], (1ull << 32) | xcc, COOP_RLX);
+  }
+  __syncthreads();
+  if (tid < K) {
+    const unsigned long long x = coop_poll64(s, (CoopG64)&st->hello[tid], 1u);
+    if ((unsigned)x != xcc) s.coop_fast = 0;
+  }
+  __syncthreads();
+#ifdef HSO_COOP_FORCE_SAFE
+  if (tid == 0) s.coop_fast = 0;
+  __syncthreads();
+#endif
+}
+
+HSO_DEV void coop_allreduce(Shared& s)
+{
+#ifdef HSO_PHASE_TIMERS
+  unsigned long long ct = __builtin_readcyclecounter();
+#define COOP_T(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.dbg[k] += n_ - ct; ct = n_; } } while (0)
+#else
+#define COOP_T(k) do { } while (0)
+#endif
+  if (s.coop_K == 1) return;   // the sums are already the job's
+  __syncthreads();   // s.red is complete; nobody reads coop_in of the previous exchange any more
+  const int tid = threadIdx.x, K = s.coop_K;
+  const unsigned e = s.coop_epoch + 1;
+  const bool fast = s.coop_fast != 0;
+  CoopJobState* const st = s.coop_state;
+  if (tid < COOP_NG)
+    coop_store64((CoopG64)&st->gran[e & 1][s.coop_rank][tid],
+                 ((unsigned long long)e << 32) | (unsigned long long)reinterpret_cast<const unsigned*>(s.red)[tid], fast);
+  COOP_T(5);
+  // every thread polls its (<= NPT) granules together: all loads of a pass are in flight at once, so a pass costs one memory
+  // round trip whatever K is
+  constexpr int NPT = (COOP_KMAX * COOP_NG + TRK_THREADS - 1) / TRK_THREADS;
+  const int total = K * COOP_NG;
+  unsigned done = 0;
+#pragma unroll
+  for (int q = 0; q < NPT; q++) if (tid + q * TRK_THREADS >= total) done |= 1u << q;
+  for (unsigned spins = 0; done != (1u << NPT) - 1u;) {
+    unsigned long long x[NPT];
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+      const int g = tid + q * TRK_THREADS;
+      x[q] = 0;
+      if (!((done >> q) & 1u)) { const int r = g / COOP_NG, i = g - r * COOP_NG; x[q] = __hip_atomic_load((CoopG64)&st->gran[e & 1][r][i], COOP_RLX); }
+    }
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+      if (!((done >> q) & 1u) && (unsigned)(x[q] >> 32) == e) {
+        const int g = tid + q * TRK_THREADS;
+        const int r = g / COOP_NG, i = g - r * COOP_NG;
+        s.coop_in[r][i] = (unsigned)x[q];
+        done |= 1u << q;
+      }
+    }
+    if (done != (1u << NPT) - 1u) {
+      if (++spins > COOP_SPIN_LIMIT) { s.coop_fail = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  COOP_T(6);
+  if (tid < N_RED) {   // rank order, the same in every workgroup => identical bits everywhere
+    double t = 0;
+    for (int r = 0; r < K; r++) t += reinterpret_cast<const double*>(s.coop_in[r])[tid];
+    s.red[tid] = t;
+  }
+  if (tid == 0) s.coop_epoch = e;
+  __syncthreads();
+  COOP_T(7);
+}
+
+// all K workgroups have passed this point of region R (their drained stores / atomics to R included)
+HSO_DEV void coop_arrive_wait(Shared& s, CoopRegion* R, bool fast)
+{
+  if (threadIdx.x == 0) {
+    const CoopG32 a = (CoopG32)&R->arrive;
+    coop_add32(a, 1u, fast);
+    for (unsigned spins = 0; __hip_atomic_load(a, COOP_RLX) < (unsigned)s.coop_K;) {
+      if (++spins > COOP_SPIN_LIMIT) { s.coop_fail = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+// s.sel[0, words) := sum over the workgroups of the job; *extra (a workgroup-uniform count) likewise
+HSO_DEV void coop_merge(Shared& s, int words, int* extra)
+{
+  if (s.coop_K == 1) return;
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const bool fast = s.coop_fast != 0;
+  CoopRegion* const R = &s.coop_state->region[s.coop_region];
+  const CoopG32 w = (CoopG32)R->w;
+  for (int i = tid; i < words; i += TRK_THREADS) {
+    const unsigned c = s.sel[i];
+    if (c) coop_add32(w + i, c, fast);
+  }
+  if (extra && tid == 0 && *extra) coop_add32((CoopG32)&R->extra, (unsigned)*extra, fast);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  coop_arrive_wait(s, R, fast);
+  for (int i = tid; i < words; i += TRK_THREADS) s.sel[i] = __hip_atomic_load(w + i, COOP_RLX);
+  if (extra) *extra = (int)__hip_atomic_load((CoopG32)&R->extra, COOP_RLX);
+  if (tid == 0) s.coop_region++;
+  __syncthreads();
+}
+
+// cand[0, s.n_cand) holds this workgroup's keys of the winning bin; afterwards cand[0, count) holds the job's (any order)
+HSO_DEV void coop_gather(Shared& s, unsigned* cand, int count)
+{
+  if (s.coop_K == 1) return;
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const bool fast = s.coop_fast != 0;
+  CoopRegion* const R = &s.coop_state->region[s.coop_region];
+  const CoopG32 w = (CoopG32)R->w;
+  const int n_local = s.n_cand;
+  if (tid == 0) s.coop_base = coop_fetch_add32((CoopG32)&R->count, (unsigned)n_local, fast);
+  __syncthreads();
+  const unsigned base = s.coop_base;
+  for (int i = tid; i < n_local; i += TRK_THREADS)
+    if (base + (unsigned)i < COOP_REGION_WORDS) coop_store32(w + base + i, cand[i], fast);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  coop_arrive_wait(s, R, fast);
+  for (int i = tid; i < count; i += TRK_THREADS) cand[i] = __hip_atomic_load(w + i, COOP_RLX);
+  if (tid == 0) s.coop_region++;
+  __syncthreads();
+}
+#endif  // TRK_COOP
 
 // ------------------------------------------------------------- level set-up
 
@@ -673,6 +881,9 @@ HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_
   if (!round_a_done) {
     sel_zero(s, SEL_WORDS);
     keys.each([&](uint32_t kk) { sel_count_a(s, kk); });
+#if TRK_COOP
+    coop_merge(s, SEL_WORDS, nullptr);
+#endif
   }
   __syncthreads();
   KSEL_T(0);
@@ -688,6 +899,9 @@ HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_
     __syncthreads();
     keys.compact(bin, cand, &s.n_cand);
     __syncthreads();
+#if TRK_COOP
+    coop_gather(s, cand, (int)count);
+#endif
     KSEL_T(2);
     const int nc = (int)count;
     for (int i = tid; i < nc; i += TRK_THREADS) atomicAdd(&hist[(cand[i] >> 8) & 2047u], 1u);
@@ -710,11 +924,17 @@ HSO_DEV uint32_t select_kth(Shared& s, unsigned k, const Keys& keys, bool round_
   // the bin is too full for the LDS list: digits [18:8] and [7:0] over all keys
   sel_zero(s, 2048);
   keys.each([&](uint32_t kk) { if ((kk >> SEL_A_SHIFT) == bin) atomicAdd(&s.sel[(kk >> 8) & 2047u], 1u); });
+#if TRK_COOP
+  coop_merge(s, 2048, nullptr);
+#endif
   __syncthreads();
   scan_find<2048>(s.sel, rank, bin, count);
   prefix |= bin << 8;
   sel_zero(s, 256);
   keys.each([&](uint32_t kk) { if ((kk & 0xFFFFFF00u) == prefix) atomicAdd(&s.sel[kk & 255u], 1u); });
+#if TRK_COOP
+  coop_merge(s, 256, nullptr);
+#endif
   __syncthreads();
   scan_find<256>(s.sel, rank, bin, count);
   prefix |= bin;
@@ -855,6 +1075,9 @@ HSO_DEV void select_robust_k(Shared& s, const LevelCtx& L, LdsPtr lds_img, const
   } else {
     n_err = s.use_lds ? select_collect<false, LdsPtr>(s, L, lds_img, T, a, keys) : select_collect<false, GlbPtr>(s, L, L.cur_glb, T, a, keys);
   }
+#if TRK_COOP
+  coop_merge(s, SEL_WORDS, &n_err);   // the job's leading-digit histogram and errors.size()
+#endif
   const int n_slots = L.job->n * s.PA;
   if (threadIdx.x == 0) s.n_select = n_err;
   SELR_T(5);
@@ -1288,6 +1511,9 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
     s.red[threadIdx.x] = t;
   }
   __syncthreads();
+#if TRK_COOP
+  coop_allreduce(s);
+#endif
   DBG_T(4);
 }
 
@@ -1514,6 +1740,9 @@ HSO_DEV void lm_finish(Shared& s, bool inverse)
 HSO_DEV void publish_result(Shared& s, hso_track_result* gout)
 {
   __syncthreads();
+#if TRK_COOP
+  if (s.coop_rank != 0) return;   // every workgroup of the job holds the same record; the first one writes it
+#endif
   const uint32_t* src = reinterpret_cast<const uint32_t*>(&s.res);
   uint32_t* dst = reinterpret_cast<uint32_t*>(gout);
   for (int i = threadIdx.x; i < (int)(sizeof(hso_track_result) / 4); i += TRK_THREADS) dst[i] = src[i];
@@ -1538,7 +1767,11 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
     s.a = job.a;
   }
   __syncthreads();
+#if TRK_COOP
+  if (job.n_total == 0) {  // CoarseTracker.cpp:53-54 (the whole job's table, not this workgroup's slice)
+#else
   if (job.n == 0) {  // CoarseTracker.cpp:53-54
+#endif
     if (tid == 0) { se3_to(s.T, out->T_cur_ref); out->exposure_rat = s.a; }
     publish_result(s, gout);
     return;
@@ -1558,9 +1791,8 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
       eval_dispatch<IC>(s, L, (LdsPtr)lds_img, T0, a0);
       PH_ADD(2);
     }
+    if (tid < 35) { if (tid < 28) s.H[tid] = s.red[tid]; else s.b[tid - 28] = s.red[tid]; }
     if (tid == 0) {
-      for (int i = 0; i < 28; i++) s.H[i] = s.red[i];
-      for (int i = 0; i < 7; i++) s.b[i] = s.red[28 + i];
       s.energy_old = (double)((float)s.red[35] / (float)(int)s.red[36]);
       s.lambda = 0.1f;
       s.stop = 0;
@@ -1581,26 +1813,30 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
         eval_dispatch<IC>(s, L, (LdsPtr)lds_img, Tn, an);
       }
       PH_ADD(2);
-      if (tid == 0) {
+      if (tid < 64) {
+        // the first wavefront: every lane forms the same decision from the same LDS words; the accepted normal equations are
+        // copied by 35 lanes instead of one (one lane: ~2 k cycles per iteration of a job that has nothing else to run)
         const double energy_new = (double)((float)s.red[35] / (float)(int)s.red[36]);
-        out->n_eval[level]++;
-        out->iters[level] = iter + 1;
-        if (energy_new < s.energy_old) {
-          for (int i = 0; i < 28; i++) s.H[i] = s.red[i];
-          for (int i = 0; i < 7; i++) s.b[i] = s.red[28 + i];
-          s.energy_old = energy_new;
-          s.a = s.a_new;
-          s.T = s.Tn;
-          s.lambda = (float)((double)s.lambda * 0.5);
-          if (iter < 64) out->accept_mask[level] |= (1ull << iter);
-        } else {
-          s.lambda = s.lambda * 4;
-          if ((double)s.lambda < 0.001) s.lambda = (float)0.001;
+        const bool accept = energy_new < s.energy_old;
+        if (accept && tid < 35) { if (tid < 28) s.H[tid] = s.red[tid]; else s.b[tid - 28] = s.red[tid]; }
+        if (tid == 0) {
+          out->n_eval[level]++;
+          out->iters[level] = iter + 1;
+          if (accept) {
+            s.energy_old = energy_new;
+            s.a = s.a_new;
+            s.T = s.Tn;
+            s.lambda = (float)((double)s.lambda * 0.5);
+            if (iter < 64) out->accept_mask[level] |= (1ull << iter);
+          } else {
+            s.lambda = s.lambda * 4;
+            if ((double)s.lambda < 0.001) s.lambda = (float)0.001;
+          }
+          if (!(s.step_norm > 1e-8)) s.stop = 1;  // step.norm() > 1e-4 (CoarseTracker.cpp:169), on the squared norm
+          // the last evaluation defines m_total_terms / m_saturated_terms (CoarseTracker.cpp:207)
+          out->n_terms_last = (int)s.red[36];
+          out->n_saturated_last = (int)s.red[37];
         }
-        if (!(s.step_norm > 1e-8)) s.stop = 1;  // step.norm() > 1e-4 (CoarseTracker.cpp:169), on the squared norm
-        // the last evaluation defines m_total_terms / m_saturated_terms (CoarseTracker.cpp:207)
-        out->n_terms_last = (int)s.red[36];
-        out->n_saturated_last = (int)s.red[37];
       }
       __syncthreads();
       if (s.stop) break;
@@ -1616,6 +1852,10 @@ HSO_DEV void track_one(Shared& s, const TrackConsts& C, const TrackJobDev& job, 
     out->exposure_rat = s.a;
     out->n_tracked = (int)((float)out->n_terms_last / (float)s.PA);
     out->status = 0;
+#if TRK_COOP
+    if (s.coop_fail) out->status = HSO_E_HIP;   // a peer workgroup never answered: the sums above are not the job's
+    out->coop_workgroups = (int16_t)s.coop_K; out->coop_same_xcd = (int16_t)s.coop_fast;
+#endif
   }
   PH_JOB();
   publish_result(s, gout);
@@ -1644,6 +1884,35 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES_PER_EU) void k_track(TrackCo
     track_one<IC>(s, C, jobs[j], sc, lds_img, &results[j]);
   }
 }
+
+#if TRK_COOP
+// Cooperative shape: coop_K workgroups per job, each with its own slice of the job's feature table (a TrackJobDev of its own:
+// the same frames, `feats` advanced to the slice, `n` its length, `n_total` the job's).  Block b runs on XCD b % 8 (observed,
+// relied on for speed only), so the workgroups of job j are the blocks b = (j % 8) + 8 * i: they share one L2.
+template <bool IC>
+__global__ __launch_bounds__(TRK_THREADS, TRK_WAVES_PER_EU) void k_track_coop(TrackConsts C, const TrackJobDev* subjobs, int n_jobs, int k_stride,
+                                                                                int scatter, CoopJobState* state, unsigned* fail_flag,
+                                                                                char* scratch, size_t scratch_stride, hso_track_result* results)
+{
+  const int b = blockIdx.x;
+  const int j = scatter ? b / k_stride : (b & 7), rank = scatter ? b % k_stride : (b >> 3);
+  if (j >= n_jobs) return;
+  const int w = j * k_stride + rank;
+  const int K = subjobs[j * k_stride].coop_K;
+  if (rank >= K) return;
+  Shared& s = *reinterpret_cast<Shared*>(g_smem + kImgCap);
+  uint32_t* lds_img = reinterpret_cast<uint32_t*>(g_smem);
+  if (threadIdx.x == 0) {
+    s.coop_state = state + j; s.coop_K = K; s.coop_rank = rank;
+    s.coop_epoch = 0; s.coop_region = 0; s.coop_base = 0; s.coop_fail = 0; s.coop_fast = 0;
+  }
+  __syncthreads();
+  coop_hello(s);
+  const Scratch sc = scratch_at(scratch + (size_t)w * scratch_stride, C.n_max);
+  track_one<IC>(s, C, subjobs[w], sc, lds_img, &results[j]);
+  if (threadIdx.x == 0 && s.coop_fail) atomicOr(fail_flag, 1u);
+}
+#endif
 
 // parity hook: one level, optional threshold selection, one evaluation
 struct EvalArgs {

@@ -43,9 +43,14 @@ struct Trace {
 
 Trace& trace();   // one per process (hso_vo.cpp)
 
+// A failed device call in the middle of processFrame: unlike the reference's own exceptions (wrong image size, thrown before
+// anything is touched) it can leave the pointer graph half updated (a keyframe already registered, features already
+// referenced by points), so the driver treats it as fatal for the handle (hso_vo.cpp: vo_guard).
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+
 inline void check(hso_gpu_ctx* ctx, int rc, const char* what)
 {
-  if (rc < 0) throw std::runtime_error(std::string(what) + ": " + hso_gpu_last_error(ctx));
+  if (rc < 0) throw DeviceError(std::string(what) + ": " + hso_gpu_last_error(ctx));
 }
 
 }  // namespace api

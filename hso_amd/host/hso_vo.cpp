@@ -923,13 +923,19 @@ struct hso_vo {
   hso::AbstractCamera* cam = nullptr;
   hso::FrameHandlerMono* vo = nullptr;
   std::string err;
+  bool poisoned = false;   // a device call failed inside processFrame: the map may be half updated, the handle refuses further frames
 };
 static int g_vo_alive = 0;
 
 template <typename F> static int vo_guard(hso_vo* v, F f)
 {
   if (!v) return HSO_E_INVALID;
+  if (v->poisoned) {
+    if (v->err.find("handle unusable") == std::string::npos) v->err = "handle unusable after a device error (" + v->err + "): destroy it and create a new one";
+    return HSO_E_HIP;
+  }
   try { f(); return HSO_OK; }
+  catch (const hso::api::DeviceError& e) { v->err = e.what(); v->poisoned = true; return HSO_E_HIP; }
   catch (const std::exception& e) { v->err = e.what(); return HSO_E_INVALID; }
 }
 

@@ -22,9 +22,13 @@ def main(n_feats=2000, batch=1, inverse=0):
     names = ["stage+precompute", "thresholds", "evaluations", "lm_solve", "job total"]
     for k in range(5):
         print("%-18s %10.0f cycles  %5.1f%%" % (names[k], ph[k], 100 * ph[k] / max(ph[4], 1)))
-    for k, nm in enumerate(["  project", "  pixel loop", "  expansion", "  wave exchange", "  wg combine"]):
+    import os
+    labels = ["  project", "  pixel loop", "  expansion", "  wave exchange", "  wg combine"]
+    if os.environ.get("HSO_PROBE_BASE3"):   # library built with -DHSO_PHASE_TIMERS_BASE=3
+        labels = ["  wave exchange", "  wg combine (all)", "   coop: sync+store", "   coop: poll", "   coop: sum"]
+    for k, nm in enumerate(labels):
         print("%-18s %10.0f cycles  %5.1f%%" % (nm, ph[5 + k], 100 * ph[5 + k] / max(ph[4], 1)))
-    print("evals", n_eval, "cycles/eval", ph[2] / max(n_eval, 1), "iters", list(r.iters))
+    print("evals", n_eval, "cycles/eval", ph[2] / max(n_eval, 1), "iters", list(r.iters), "coop K", r.coop_workgroups, "same xcd", r.coop_same_xcd)
 
 
 if __name__ == "__main__":

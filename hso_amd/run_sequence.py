@@ -7,12 +7,12 @@ FrameHandlerMono::addImage in order, write the keyframe trajectory in the refere
 
 Options (the reference's `key=value` style, test_dataset.cpp:66-114):
   start=<i> end=<i>        frame range (test/euroc_batch.sh:9 uses start=50 for MH_01)
-  depth0=<file.npy|.f32>   optical-axis depth image of the first frame: the initial map (the driver has no two-view
-                           initialisation; see include/hso_vo.h).  Required.
+  depth0=<file.npy|.f32>   optical-axis depth image of the first frame: the initial map.  Required while the driver has no
+                           two-view initialisation (HAS_TWO_VIEW_INIT below; see include/hso_vo.h).
   max_fts=<n>              Config::maxFts() (200)
   result=<path>            trajectory file (default ./result/KeyFrameTrajectory.txt)
   gt=<trajectory file>     ground truth in the same format: prints the ATE (RMSE after similarity alignment)
-  trace=<path>             record every device call of the run
+  trace=<path>             record every device call of the run (trace_frames=<n>: only of the first n frames)
   times=1                  print per-frame wall time
 
 Layout of a sequence folder = the reference's: <folder>/*.png (or .pgm), one stamp per line in the stamp file."""
@@ -22,13 +22,15 @@ import time
 
 import numpy as np
 
+HAS_TWO_VIEW_INIT = False      # the driver starts from hso_vo_set_first_frame + a depth image (SURVEY section 8(f) rank 4 not built)
+
 
 def load_image(path):
     from . import formats
     return formats.read_pgm(path) if path.lower().endswith(".pgm") else formats.read_png(path)
 
 
-def main(argv):
+def main(argv, return_line=False):
     if len(argv) < 3:
         print(__doc__)
         return 2
@@ -41,7 +43,7 @@ def main(argv):
     files = formats.list_images(folder) or sorted(os.path.join(folder, n) for n in os.listdir(folder) if n.lower().endswith(".pgm"))
     stamps = formats.read_stamps(stamp_file) if stamp_file not in ("None", "none", "") else None
     start, end = int(opt.get("start", 0)), min(int(opt.get("end", len(files))), len(files))
-    if "depth0" not in opt:
+    if "depth0" not in opt and not HAS_TWO_VIEW_INIT:
         print("depth0=<file> is required: the driver starts from a first keyframe with known depths (no two-view initialisation)")
         return 2
     d0 = np.load(opt["depth0"]) if opt["depth0"].endswith(".npy") else np.fromfile(opt["depth0"], np.float32).reshape(H, W)
@@ -62,27 +64,33 @@ def main(argv):
         resize_ctx.frame_release(1)
         return out
 
-    rows, t_frames = [], []
+    rows, t_frames, n_fail = [], [], 0
+    trace_frames = int(opt.get("trace_frames", 0))
     for k, i in enumerate(range(start, end)):
         img = prepare(load_image(files[i]))
+        if trace_frames and k == trace_frames:
+            odo.trace(None)
         t0 = time.perf_counter()
         if k == 0:
             odo.set_first_frame(img, d0, float(i))
             st = odo.status()
         else:
             st = odo.add_image(img, float(i))          # vo_->addImage(image, img_id, &time_stamp)
+            n_fail += int(st.result == 2 or st.stage != 3)     # RESULT_FAILURE / not STAGE_DEFAULT_FRAME
         t_frames.append(time.perf_counter() - t0)
         if opt.get("times"):
             print("frame %d  %.2f ms  kf=%d stage=%d obs=%d matches=%d seeds=%d" % (i, 1e3 * t_frames[-1], st.is_keyframe, st.stage,
                                                                                    st.n_inliers, st.n_matches, st.n_seeds))
     for ts, T, fid in odo.keyframes():
-        name = stamps[int(ts)] if stamps is not None and int(ts) < len(stamps) else str(fid)
+        # the reference names a pose by the frame's line of the stamp file; EuRoC images are named by their stamp, so without a
+        # stamp file the image's base name serves
+        name = stamps[int(ts)] if stamps is not None and int(ts) < len(stamps) else os.path.splitext(os.path.basename(files[int(ts)]))[0]
         rows.append((name, tuple(T.q[:]), tuple(T.t[:])))
     result = opt.get("result", os.path.join("result", "KeyFrameTrajectory.txt"))
     os.makedirs(os.path.dirname(os.path.abspath(result)), exist_ok=True)
     formats.write_trajectory(result, rows)
     line = {"frames": end - start, "keyframes": len(rows), "frames_per_s": (len(t_frames) - 1) / max(sum(t_frames[1:]), 1e-9),
-            "result": result}
+            "tracking_failures": n_fail, "result": result}
     if "gt" in opt:
         (es, exyz, _), (gs, gxyz, _) = formats.read_trajectory(result), formats.read_trajectory(opt["gt"])
         common = [s_ for s_ in es if s_ in set(gs)]
@@ -91,7 +99,7 @@ def main(argv):
             line["ate_rmse"], line["ate_scale"], line["ate_keyframes"] = rmse, scale, len(common)
     print(line)
     odo.close()
-    return 0
+    return line if return_line else 0
 
 
 if __name__ == "__main__":

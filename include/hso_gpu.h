@@ -181,7 +181,8 @@ typedef struct hso_track_result {
    * wave exchange, workgroup combine.  Filled only when built with -DHSO_PHASE_TIMERS. */
   uint64_t phase_cycles[10];
   int32_t status;                       /* 0 ok */
-  int32_t _pad;
+  int16_t coop_workgroups;              /* workgroups that shared this job (0: the one-workgroup batch shapes) */
+  int16_t coop_same_xcd;                /* 1: they all ran on one XCD and exchanged through its L2 (diagnostic; results do not depend on it) */
 } hso_track_result;
 
 /* Replaces `CoarseTracker(inverse, max_level, min_level, n_iter, verbose)

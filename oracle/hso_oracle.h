@@ -46,12 +46,17 @@ typedef struct hso_or_margins {
   double klt_step;     /* min over KLT iterations of the distance of the step test to its bound (:1435,:1590) */
   double klt_accept;   /* min over KLT iterations of | newEnergy - bestEnergy | / bestEnergy (step accepted or halved) */
   double pose_rho;     /* pose LM: min over trials of |rho| / max(chi2, 1e-300) (pose_optimizer.cpp:644-670) */
+  double march_end;    /* epipolar march: min over steps of the distance of the position to px_close along an axis the loop
+                          condition tests (matcher.cpp:893-900): ~0 = the last step lands ON the end point and the step count is
+                          decided by rounding (segments padded to exactly 4 units, :880-886) */
+  double track_accept; /* CoarseTracker::run: min over LM iterations of | energy_new - energy_old | / energy_old at the accept test
+                          (CoarseTracker.cpp:143); the energies are float quotients, so a gap near 1e-7 is decided by rounding */
 } hso_or_margins;
 void hso_or_margins_reset(void);
 void hso_or_margins_get(hso_or_margins* out);
 void hso_or_margin_note(int field, double v);   /* internal: field = index of the double above */
 enum { HSO_M_LK_UPDATE, HSO_M_LK_CHI2, HSO_M_NCC, HSO_M_NORMAL, HSO_M_JUMP, HSO_M_ZMNCC_BEST, HSO_M_ZMNCC_AMBIG, HSO_M_ZMNCC_ORDER,
-       HSO_M_KLT_ENERGY, HSO_M_KLT_STEP, HSO_M_KLT_ACCEPT, HSO_M_POSE_RHO, HSO_M_COUNT };
+       HSO_M_KLT_ENERGY, HSO_M_KLT_STEP, HSO_M_KLT_ACCEPT, HSO_M_POSE_RHO, HSO_M_MARCH_END, HSO_M_TRACK_ACCEPT, HSO_M_COUNT };
 
 /* ---- Sophus SE3 / SO3 (thirdparty/Sophus/sophus/{se3,so3}.cpp) ---- */
 void hso_or_se3_identity(hso_se3* T);
@@ -131,7 +136,11 @@ int hso_or_align1d(const uint8_t* cur_img, int cols, int rows, const float dir[2
                    const float* ref_patch, int n_iter, double cur_px_estimate[2], double* h_inv, float* cur_patch,
                    int* iters_out, float* chi2_out);                                 /* feature_alignment.cpp */
 double hso_or_ncc(const float* patch1, const float* patch2);                         /* matcher.cpp:379-404 */
-double hso_or_normal_dot(const int16_t* gx, const int16_t* gy, int cols, const double pxLevel[2], const double normal[2]);
+/* Matcher::checkNormal's dot product.  The reference reads the four gradient taps unchecked (matcher.cpp:421-428): a position
+ * that is NaN (an edgelet direction of norm 0 makes KLTLimited1D return a NaN pixel with "success") or outside the image is an
+ * out-of-bounds heap read there — undefined.  Defined here, and identically on the device: such a position fails the check
+ * (-2 is returned, below every threshold). */
+double hso_or_normal_dot(const int16_t* gx, const int16_t* gy, int cols, int rows, const double pxLevel[2], const double normal[2]);
 void hso_or_find_match_direct(const hso_camera* cam, const hso_align_job* job, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
                               const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
                               const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_align_out* out);

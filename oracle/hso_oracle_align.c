@@ -272,10 +272,12 @@ double hso_or_ncc(const float* patch1, const float* patch2)
 }
 
 /* Matcher::checkNormal, src/matcher.cpp:406-440; returns normal.dot(n) */
-double hso_or_normal_dot(const int16_t* gx, const int16_t* gy, int cols, const double pxLevel[2], const double normal[2])
+double hso_or_normal_dot(const int16_t* gx, const int16_t* gy, int cols, int rows, const double pxLevel[2], const double normal[2])
 {
   const float uf = pxLevel[0];
   const float vf = pxLevel[1];
+  /* defined behaviour where the reference's is not (see hso_oracle.h): the 2x2 taps must lie inside the gradient image */
+  if (!(uf >= 0 && vf >= 0 && uf < (float)(cols - 1) && vf < (float)(rows - 1))) return -2.0;
   const int ui = floorf(pxLevel[0]);
   const int vi = floorf(pxLevel[1]);
   const float subpix_x = uf - ui;
@@ -340,7 +342,7 @@ static void find_match(const hso_camera* cam, const hso_align_job* job, const ui
     if (!ok) out->stage = HSO_ALIGN_NOT_CONVERGED;
     if (ok) {
       const double dir[2] = { d0, d1 };
-      const double nd_ = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, px_scaled, dir);
+      const double nd_ = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, rows, px_scaled, dir);
       hso_or_margin_note(HSO_M_NORMAL, nd_ - (float)0.86);
       ok = nd_ > (float)0.86;
       if (!ok) out->stage = HSO_ALIGN_NORMAL;

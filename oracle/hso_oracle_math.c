@@ -382,7 +382,7 @@ void hso_or_se3quat_exp(const double update[6], hso_se3* out)
 }
 
 /* ---- decision margins (see hso_oracle.h) ---- */
-static double g_margins[HSO_M_COUNT];
+static __thread double g_margins[HSO_M_COUNT];   /* per thread: the batch forms (hso_oracle_batch.c) run seeds on worker threads */
 void hso_or_margins_reset(void) { for (int i = 0; i < HSO_M_COUNT; i++) g_margins[i] = 1e300; }
 void hso_or_margins_get(hso_or_margins* out) { memcpy(out, g_margins, sizeof(g_margins)); }
 void hso_or_margin_note(int field, double v) { v = fabs(v); if (!(v >= g_margins[field])) g_margins[field] = v; }

@@ -332,6 +332,8 @@ static int do_line_stereo(const hso_camera* cam, const hso_seed* s, const hso_se
   hso_or_pyramid_dims(w, h, search_level, &cols, &rows);
   while ((((incx < 0) == (cpx > px_close[0])) && ((incy < 0) == (cpy > px_close[1]))) || loopCounter == 0) {
     const double px[2] = { cpx, cpy };
+    if (incx != 0) hso_or_margin_note(HSO_M_MARCH_END, cpx + incx - px_close[0]);   /* what the next test of the loop condition compares */
+    if (incy != 0) hso_or_margin_note(HSO_M_MARCH_END, cpy + incy - px_close[1]);
     if (!is_in_frame_level(w, h, (int)px[0], (int)px[1], 8, search_level)) { cpx += incx; cpy += incy; loopCounter++; continue; }
     create_patch(patch_f, px, cur_pyr[search_level], cols);
     const float zmncc = zmncc_score(patch, hostMean, patch_f);
@@ -370,7 +372,7 @@ static int do_line_stereo(const hso_camera* cam, const hso_seed* s, const hso_se
     } else {
       result = klt_limited_1d(cur_pyr[search_level], cols, rows, pwb, patch, 10, pxr, dir_cur, patch2D);
       if (result) {
-        const double nd_ = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, pxr, dir_cur);
+        const double nd_ = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, rows, pxr, dir_cur);
         hso_or_margin_note(HSO_M_NORMAL, nd_ - (float)0.7);
         result = nd_ > (float)0.7;
       }

@@ -489,6 +489,7 @@ void hso_or_tracker_run(hso_or_tracker* t, const hso_se3* T_init, float exposure
       const double energy_new = compute_residuals(t, &new_T, new_exposure_rat, cutoff_error, NULL);
       out->n_eval[level]++;
       out->iters[level] = t->iter + 1;
+      hso_or_margin_note(HSO_M_TRACK_ACCEPT, (energy_new - energy_old) / energy_old);
       if (energy_new < energy_old) {
         compute_gs(t, H, b);
         energy_old = energy_new;

@@ -43,7 +43,7 @@ def use_native_build():
     flags = ["-O3", "-march=native", "-std=gnu11", "-fPIC", "-shared"]
     try:
         os.makedirs(out_dir, exist_ok=True)
-        subprocess.check_call(["gcc"] + flags + ["-o", out] + sorted(glob.glob(os.path.join(_HERE, "hso_oracle_*.c"))) + ["-lm"],
+        subprocess.check_call(["gcc"] + flags + ["-o", out] + sorted(glob.glob(os.path.join(_HERE, "hso_oracle_*.c"))) + ["-lm", "-lpthread"],
                               stderr=subprocess.DEVNULL)
     except (OSError, subprocess.CalledProcessError):
         return PORTABLE_FLAGS
@@ -330,6 +330,57 @@ def find_match_direct(cam, job, ref_pyr, cur_pyr, cur_sobel):
     return out
 
 
+def _pyr_ptrs(pyr, n):
+    arrs = [np.ascontiguousarray(l) for l in pyr]
+    return arrs, (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+
+
+def find_match_direct_batch(cam, jobs, job_kf, kf_pyrs, cur_pyr, cur_sobel):
+    """bench.py's cpu_baseline leg: hso_or_find_match_direct over a ctypes array of AlignJob (job i against keyframe
+    job_kf[i]'s pyramid) in one call (no per-item interpreter time).  Returns the AlignOut array."""
+    from hso_amd.capi import AlignJob, AlignOut
+    lib = load()
+    vp = C.c_void_p
+    lib.hso_or_find_match_direct_batch.argtypes = [C.POINTER(Camera), vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.hso_or_find_match_direct_batch.restype = None
+    keep, flat = [], []
+    for p in kf_pyrs:
+        a, _ = _pyr_ptrs(p, N_PYR_LEVELS)
+        keep.append(a); flat += [x.ctypes.data for x in a]
+    kfp = (C.c_void_p * len(flat))(*flat)
+    ca, cp = _pyr_ptrs(cur_pyr, N_PYR_LEVELS)
+    gxa, gx = _pyr_ptrs([g[0] for g in cur_sobel], 3)
+    gya, gy = _pyr_ptrs([g[1] for g in cur_sobel], 3)
+    n = len(jobs)
+    h, w = ca[0].shape
+    idx = np.ascontiguousarray(job_kf, np.int32)
+    out = (AlignOut * max(n, 1))()
+    lib.hso_or_find_match_direct_batch(C.byref(cam), C.cast(jobs, vp), _ptr(idx), n, C.cast(kfp, vp), C.cast(cp, vp), C.cast(gx, vp),
+                                       C.cast(gy, vp), w, h, C.cast(out, vp))
+    return out
+
+
+def seed_observe_batch(cam, seeds, cur_T_f_w, cur_exposure, px_error_angle, ref_pyr, cur_pyr, cur_sobel, n_threads=1):
+    """bench.py's cpu_baseline leg: hso_or_seed_observe over a ctypes array of Seed hosted in ONE frame, in one call, on
+    n_threads threads (4 = the reference's depth-filter workers, include/hso/IndexThreadReduce.h:27)."""
+    from hso_amd.capi import SeedOut
+    lib = load()
+    vp = C.c_void_p
+    lib.hso_or_seed_observe_batch.argtypes = [C.POINTER(Camera), vp, C.c_int, C.POINTER(SE3), C.c_double, C.c_double, vp, vp, vp, vp,
+                                              C.c_int, C.c_int, vp, C.c_int]
+    lib.hso_or_seed_observe_batch.restype = None
+    ra, rp = _pyr_ptrs(ref_pyr, N_PYR_LEVELS)
+    ca, cp = _pyr_ptrs(cur_pyr, N_PYR_LEVELS)
+    gxa, gx = _pyr_ptrs([g[0] for g in cur_sobel], 3)
+    gya, gy = _pyr_ptrs([g[1] for g in cur_sobel], 3)
+    n = len(seeds)
+    h, w = ca[0].shape
+    out = (SeedOut * max(n, 1))()
+    lib.hso_or_seed_observe_batch(C.byref(cam), C.cast(seeds, vp), n, C.byref(cur_T_f_w), cur_exposure, px_error_angle, C.cast(rp, vp),
+                                  C.cast(cp, vp), C.cast(gx, vp), C.cast(gy, vp), w, h, C.cast(out, vp), n_threads)
+    return out
+
+
 def pose_optimize(cam, job):
     """optimizeLevenbergMarquardt3rd on a hso_amd.capi.PoseJob; returns (PoseResult, outlier mask)."""
     from hso_amd.capi import PoseJob, PoseResult
@@ -575,9 +626,10 @@ def detect_candidates_level(img, gx, gy, level, frame_w, frame_h, min_thresh):
 
 
 def reproject_match(cam, T_cur_w, cur_exposure_time, cur_keyframe_id, kfs, points, obs, cell_size, grid_n_cols,
-                    kf_pyrs, cur_pyr, cur_sobel):
+                    kf_pyrs, cur_pyr, cur_sobel, margins_out=None):
     """Reprojector::reprojectPoint + getCloseViewObs + findMatchDirect per map point.
-    kf_pyrs[k]: pyramid of keyframe k.  Returns (proj array, list of AlignOut or None per point)."""
+    kf_pyrs[k]: pyramid of keyframe k.  Returns (proj array, list of AlignOut or None per point); margins_out (a list)
+    receives the decision margins of every point's findMatchDirect (None where none ran)."""
     from hso_amd.capi import AlignJob, KF_DTYPE, MAP_POINT_DTYPE, OBS_DTYPE, REPROJ_POINT_DTYPE
     lib = load()
     vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
@@ -598,7 +650,7 @@ def reproject_match(cam, T_cur_w, cur_exposure_time, cur_keyframe_id, kfs, point
         T_host = kfs[p["host_kf"]:p["host_kf"] + 1]          # q, t follow frame_id: an hso_se3 in place
         ok = lib.hso_or_reproject_point(C.byref(cam), C.byref(T_cur_w), T_host.ctypes.data + 8, p["host_f"].ctypes.data,
                                         float(p["idist"]), cell_size, grid_n_cols, px.ctypes.data, C.byref(cell))
-        m = None
+        m = mg = None
         if ok:
             proj[i]["projected"], proj[i]["cell"], proj[i]["px"] = 1, cell.value, px
             o = obs[p["obs_begin"]:p["obs_begin"] + p["obs_count"]]
@@ -608,8 +660,12 @@ def reproject_match(cam, T_cur_w, cur_exposure_time, cur_keyframe_id, kfs, point
                 job = AlignJob()
                 lib.hso_or_reproject_make_job(C.byref(T_cur_w), cur_exposure_time, cur_keyframe_id, kfs.ctypes.data,
                                               points[i:i + 1].ctypes.data, o[k:k + 1].ctypes.data, px.ctypes.data, C.byref(job))
+                margins_reset()
                 m = find_match_direct(cam, job, kf_pyrs[o[k]["kf"]], cur_pyr, cur_sobel)
+                mg = margins()
         matches.append(m)
+        if margins_out is not None:
+            margins_out.append(mg if m is not None else None)
     return proj, matches
 
 
@@ -692,7 +748,7 @@ def se3quat_mul(a, b):
 
 
 MARGIN_FIELDS = ("lk_update", "lk_chi2", "ncc", "normal", "jump", "zmncc_best", "zmncc_ambig", "zmncc_order", "klt_energy",
-                 "klt_step", "klt_accept", "pose_rho")
+                 "klt_step", "klt_accept", "pose_rho", "march_end", "track_accept")
 
 
 class Margins(C.Structure):

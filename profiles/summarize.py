@@ -3,8 +3,8 @@ tracked summaries under profiles/:
   <tag>_kernel_stats.csv      (copied from the --kernel-trace --stats pass)
   <tag>_pmc_summary.csv       (mean counter value per kernel and dispatch, every PMC pass)
   <tag>_sq_counters.csv       (SQ passes of k_track with the derived busy / wait fractions)
-  r2_pmc_k_track.json         (HBM-side bytes per k_track launch, keyed by the workload it was
-                               measured on — what bench.py reports as roofline.traffic)
+  <round>_pmc_k_track.json    (HBM-side bytes and VALU instructions per k_track launch, keyed by the workload they
+                               were measured on — what bench.py reports as roofline.traffic / roofline_valu)
 usage: python profiles/summarize.py [round-prefix=r2] [tag=<round-prefix>]"""
 import csv
 import glob
@@ -113,7 +113,12 @@ def main():
                        "`python bench.py --cpu-frames 0 --steps 3 --warmup 1`; hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE "
                        "(MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE reports half the bytes of wide reads; this kernel's "
                        "global reads are partly 4-8 B/lane, for which the x2 is an upper bound)."}
-        path = os.path.join(OUT, "r2_pmc_k_track.json")
+        if all(("SQ_INSTS_VALU", x) in per and ("SQ_ACTIVE_INST_VALU", x) in per and ("SQ_BUSY_CYCLES", x) in per for x in kt):
+            # what bench.py's roofline_valu needs: wave-level VALU instructions of one batch (both launches) and the VALU-busy
+            # fraction over the two launches together (busy cycles add up: the launches run one after the other)
+            rec["valu_insts_per_launch"] = sum(per[("SQ_INSTS_VALU", x)] for x in kt)
+            rec["valu_busy_frac"] = 4 * sum(per[("SQ_ACTIVE_INST_VALU", x)] for x in kt) / (1024 * sum(per[("SQ_BUSY_CYCLES", x)] for x in kt) / 32)
+        path = os.path.join(OUT, RND + "_pmc_k_track.json")
         try:
             doc = json.load(open(path))
         except (OSError, ValueError):

@@ -75,13 +75,19 @@ def test_seed_activate_matches_oracle(orc, cam, gpu_ctx, act_problem):
     assert [bytes(a) for a in got] == [bytes(a) for a in got2]
     n_cmp = n_flag = 0
     for i, (s, g) in enumerate(zip(P["seeds"], got)):
+        orc.margins_reset()
         o, mo = _oracle(orc, cam, act_problem, i)
+        mg = orc.margins()          # smallest margins over this seed's findMatchSeed calls
         assert g.n_targets == o.n_targets
         if o.n_targets < 4.2:
             assert g.activated == 0 and g.is_valid == -1 and g.opt_id == o.opt_id
             continue
         same = all(a.success == b.success for a, b in zip(gmo[i], mo))
         if not same:
+            # a differing match decision only where a gate of the matcher was within 10x its tolerance in the restatement
+            # (the rule of tests/test_align.py)
+            assert min(mg.ncc / 1e-3, mg.normal / 1e-3, mg.lk_chi2 / 1e-2, mg.lk_update / 1e-2, mg.jump / 1e-2) < 1, \
+                (i, [getattr(mg, f) for f in orc.MARGIN_FIELDS])
             n_flag += 1
             continue
         for a, b in zip(gmo[i], mo):
@@ -101,7 +107,7 @@ def test_seed_activate_matches_oracle(orc, cam, gpu_ctx, act_problem):
             assert g.huber == pytest.approx(o.huber, rel=0.05, abs=1e-6)
             assert g.opt_id == pytest.approx(o.opt_id, rel=1e-3)
             n_cmp += 1
-    assert n_cmp > 60 and n_flag <= 0.05 * len(got), (n_cmp, n_flag)
+    assert n_cmp > 60, (n_cmp, n_flag)     # coverage; ties were excused by margin (matcher gates) or by the 10x drift-gate band
 
 
 @pytest.mark.gpu

@@ -76,16 +76,38 @@ class Replayer:
         ref, cur = self.frame(vo.scalar(r, "ref_frame_id")), self.frame(vo.scalar(r, "cur_frame_id"))
         g = capi.TrackResult.from_buffer_copy(r["result"])
         T0 = capi.SE3.from_buffer_copy(r["T_cur_ref"])
-        o = self.orc.Tracker(cam, p, ref["pyr"], cur["pyr"], feats).run(T0, float(np.float32(vo.scalar(r, "exposure_rat"))))
+        a0 = float(np.float32(vo.scalar(r, "exposure_rat")))
+        o = self.orc.Tracker(cam, p, ref["pyr"], cur["pyr"], feats).run(T0, a0)
         qg, tg = g.T_cur_ref.to_arrays(); qo, to = o.T_cur_ref.to_arrays()
         self.bump("track", "n")
-        same = list(g.iters) == list(o.iters) and list(g.accept_mask) == list(o.accept_mask)
-        if not same:
-            self.bump("track", "iter_mismatch")
-        # per-frame SE(3): the bar of the round (<= 1e-4) with a wide margin; equal decisions give ~1e-8
-        assert _rot_err(qg, qo) <= (2e-6 if same else 1e-4) and np.linalg.norm(tg - to) <= (8e-6 if same else 1e-4)
-        assert g.n_tracked == pytest.approx(o.n_tracked, abs=2 if same else 20)
-        self.track_dev = max(getattr(self, "track_dev", 0.0), _rot_err(qg, qo), float(np.linalg.norm(tg - to)))
+        seq = lambda x: (list(x.iters), list(x.accept_mask))
+        if seq(g) == seq(o):
+            assert _rot_err(qg, qo) <= 2e-6 and np.linalg.norm(tg - to) <= 8e-6
+            assert g.n_tracked == pytest.approx(o.n_tracked, abs=2)
+            self.track_dev = max(getattr(self, "track_dev", 0.0), _rot_err(qg, qo), float(np.linalg.norm(tg - to)))
+            return
+        # A different LM accept sequence is excused by margin, not by count (tests/test_parity_gpu.py::
+        # test_accept_decisions_over_many_scenes): the device sums the bit-identical fp32 energy terms in a tree, the reference
+        # serially in fp32, so only an accept decision inside the serial sum's own rounding noise may differ.  Evidence required
+        # per call: the device equals the restatement that decides on the fp64 sum of the same terms (sequence and pose), and the
+        # serial-sum restatement itself differs from that form.
+        self.bump("track", "iter_mismatch")
+        t64 = self.orc.Tracker(cam, p, ref["pyr"], cur["pyr"], feats); t64.decide_on_f64_sum(True)
+        self.orc.margins_reset()
+        r64 = t64.run(T0, a0)
+        m64 = self.orc.margins()
+        q6, t6 = r64.T_cur_ref.to_arrays()
+        if seq(g) == seq(r64):
+            assert seq(o) != seq(r64), (seq(g), seq(o), seq(r64))
+            assert _rot_err(qg, q6) <= 2e-7 and np.linalg.norm(tg - t6) <= 8e-7
+            assert g.n_tracked == pytest.approx(r64.n_tracked, abs=2)
+        else:
+            # differs from the exact-sum form as well: only where that form itself met an accept test (energy_new < energy_old on
+            # float quotients, CoarseTracker.cpp:143) whose two energies agree to within 10x the rounding of the device's fp32 per-feature
+            # partial sums (3e-7): a decision no arithmetic pins
+            self.bump("track", "accept_tie")
+            assert m64.track_accept < 3e-6, (seq(g), seq(o), seq(r64), m64.track_accept)
+        assert _rot_err(qg, qo) <= 1e-4 and np.linalg.norm(tg - to) <= 1e-4   # both converge to the same minimum
 
     def reproject_match(self, r):
         cam = capi.Camera.from_buffer_copy(r["cam"])
@@ -95,9 +117,15 @@ class Replayer:
         cur = self.frame(vo.scalar(r, "cur_frame_id"))
         T = capi.SE3.from_buffer_copy(r["T_cur_w"])
         kf_pyrs = [self.frame(k["frame_id"])["pyr"] for k in kfs]
+        margins = []
         wproj, wmatch = self.orc.reproject_match(cam, T, vo.scalar(r, "cur_exposure"), int(vo.scalar(r, "cur_keyframe_id")), kfs, pts, obs,
-                                                 int(vo.scalar(r, "cell_size")), int(vo.scalar(r, "grid_n_cols")), kf_pyrs, cur["pyr"], cur["sobel"])
+                                                 int(vo.scalar(r, "cell_size")), int(vo.scalar(r, "grid_n_cols")), kf_pyrs, cur["pyr"], cur["sobel"],
+                                                 margins_out=margins)
         radtan = cam.model == capi.CAM_PINHOLE and cam.distortion
+        # radtan: cam2world runs OpenCV's five fp32 undistortion iterations (src/camera.cpp:171-194); host and device round them
+        # differently at the 1e-7 level of the bearing, so A_cur_ref — and with it the warped patch — carries a 2e-5 tolerance
+        # instead of 1e-8; the decision margins scale with it
+        k = 5.0 if radtan else 1.0
         for i in range(len(pts)):
             g, w = proj[i], wproj[i]
             self.bump("reproject", "points")
@@ -111,14 +139,26 @@ class Replayer:
             assert np.allclose(g["px"], w["px"], atol=1e-8, rtol=0) and g["ref_obs"] == w["ref_obs"]
             if g["ref_obs"] < 0:
                 continue
-            m, o = match[i], wmatch[i]
+            m, o, mg = match[i], wmatch[i], margins[i]
             self.bump("reproject", "matched_calls")
-            if (m.success, m.stage, m.search_level, m.iters) != (o.success, o.stage, o.search_level, o.iters):
+            assert m.search_level == o.search_level
+            assert np.allclose(m.A_cur_ref[:], o.A_cur_ref[:], atol=2e-5 if radtan else 1e-8)
+            if o.stage == 1:
+                assert m.stage == 1 and not m.success
+                continue
+            # the margin rule of tests/test_align.py: a differing decision only where the restatement's own comparison was within
+            # 10x the tolerance of the compared quantity
+            if m.iters != o.iters:
+                assert mg.lk_update < 1e-2 * k, (i, m.iters, o.iters, mg.lk_update)
                 self.bump("reproject", "tie")
                 continue
-            assert np.allclose(m.A_cur_ref[:], o.A_cur_ref[:], atol=2e-5 if radtan else 1e-8)
+            if (m.success, m.stage) != (o.success, o.stage):
+                assert min(mg.ncc / 1e-3, mg.normal / 1e-3, mg.lk_chi2 / 1e-2, mg.lk_update / 1e-2, mg.jump / 1e-2) < k, \
+                    (i, m.stage, o.stage, [getattr(mg, f) for f in self.orc.MARGIN_FIELDS])
+                self.bump("reproject", "tie")
+                continue
             if o.success:
-                assert np.allclose(m.px_cur[:], o.px_cur[:], atol=2e-3)
+                assert np.allclose(m.px_cur[:], o.px_cur[:], atol=2e-3 * (1 << m.search_level))
                 self.bump("reproject", "success")
 
     def pose_optimize(self, r):
@@ -127,16 +167,20 @@ class Replayer:
         poses, n = _arr(capi.SE3, r["poses"])
         job = capi.make_pose_job(feats, list(poses[:n]), capi.SE3.from_buffer_copy(r["T_f_w"]), vo.scalar(r, "reproj_thresh"), int(vo.scalar(r, "n_iter")))
         g = capi.PoseResult.from_buffer_copy(r["result"]); gmask = np.frombuffer(r["mask"], np.uint8)
+        self.orc.margins_reset()
         o, omask = self.orc.pose_optimize(cam, job)
+        mg = self.orc.margins()
         qg, tg = g.T_f_w.to_arrays(); qo, to = o.T_f_w.to_arrays()
         self.bump("pose", "n")
         same = (g.iters, g.n_trials_total) == (o.iters, o.n_trials_total)
         if not same:
+            # tests/test_pose.py: once converged rho = chi2 - new_chi2 is rounding noise; only then may the serial and the tree sums
+            # accept / reject a last no-op step differently — the restatement itself must have seen |rho| / chi2 < 1e-12
+            assert mg.pose_rho < 1e-12 and abs(g.iters - o.iters) <= 2 and abs(g.n_trials_total - o.n_trials_total) <= 6, mg.pose_rho
             self.bump("pose", "iter_mismatch")
-        assert _rot_err(qg, qo) <= (1e-7 if same else 1e-5) and np.linalg.norm(tg - to) <= (1e-7 if same else 1e-5)
-        assert g.status == o.status and abs(g.num_obs - o.num_obs) <= (0 if same else 2)
-        if same:
-            assert np.array_equal(gmask, omask) and g.estimated_scale == pytest.approx(o.estimated_scale, rel=1e-6)
+        assert _rot_err(qg, qo) <= 1e-7 and np.linalg.norm(tg - to) <= 1e-7
+        assert g.status == o.status and g.num_obs == o.num_obs
+        assert np.array_equal(gmask, omask) and g.estimated_scale == pytest.approx(o.estimated_scale, rel=1e-6)
 
     def seed_observe(self, r):
         cam = capi.Camera.from_buffer_copy(r["cam"])
@@ -145,23 +189,42 @@ class Replayer:
         # radtan: cam2world of the matched pixel runs OpenCV's five fp32 undistortion iterations (src/camera.cpp:78-85); host and
         # device round them differently at the 1e-7 level of the bearing, which the triangulation amplifies by depth / baseline
         kz = 30.0 if (cam.model == capi.CAM_PINHOLE and cam.distortion) else 1.0
+        kz_dec = 5.0 if kz > 1 else 1.0
         for i in range(n):
             s, g = seeds[i], got[i]
+            self.orc.margins_reset()
             o = self.orc.seed_observe(cam, s, T, vo.scalar(r, "exposure"), vo.scalar(r, "px_error_angle"), self.frame(s.ref_frame_id)["pyr"],
                                       cur["pyr"], cur["sobel"])
+            mg = self.orc.margins()
             self.bump("seed", "n")
             assert g.is_update == o.is_update and g.is_valid == o.is_valid
             if o.result == 0:
                 assert g.result == 0 and g.mu == o.mu and g.sigma2 == o.sigma2
                 continue
-            if (g.result, g.search_level) == (o.result, o.search_level) and abs(g.n_steps - o.n_steps) == 1 and \
-                    g.zmncc_best == pytest.approx(o.zmncc_best, abs=1e-4):
+            assert g.search_level == o.search_level
+            if o.result == -1 or g.result == -1:
+                assert g.result == o.result
+                continue
+            if g.n_steps != o.n_steps:
                 # the epipolar march (src/matcher.cpp:893-1000) walks unit steps from px_far - inc to px_close + inc and stops when the
                 # position passes px_close; a segment shorter than 2 px is padded to exactly 4 units, so in exact arithmetic the last step
-                # lands ON the end point and the reference's own `>` there is decided by rounding: one sample more or less at the far end,
-                # same best score, same match.  Counted, and everything else is still compared.
+                # lands ON the end point and the reference's own `>` there is decided by rounding.  Excused only when the restatement
+                # saw that: a tested position within 1e-9 px of the end point; then one sample more or less, same best score.
+                assert abs(g.n_steps - o.n_steps) == 1 and mg.march_end < 1e-9, (g.n_steps, o.n_steps, mg.march_end)
                 self.bump("seed", "march_end_tie")
-            elif (g.result, g.search_level, g.n_steps) != (o.result, o.search_level, o.n_steps):
+                if g.zmncc_best != pytest.approx(o.zmncc_best, abs=1e-4):
+                    continue      # the sample only one side visited was the best one: everything downstream follows from that tie
+            elif o.n_steps > 0 and o.zmncc_best > 0.1:
+                assert g.zmncc_best == pytest.approx(o.zmncc_best, abs=1e-4)
+            if g.result != o.result:
+                # tests/test_seed.py's rule: the gate that separates the two codes had its operands within 10x their tolerance
+                codes = {g.result, o.result}
+                near = False
+                if codes == {-3, -4} or codes == {1, -4}:
+                    near = min(mg.zmncc_best, mg.zmncc_ambig, mg.zmncc_order) < 1e-3
+                if codes == {1, -3}:
+                    near = min(mg.klt_energy / 1e-2, mg.klt_accept / 1e-2, mg.klt_step / 1e-1, mg.ncc / 1e-3, mg.normal / 1e-3) < kz_dec
+                assert near, (i, g.result, o.result, [getattr(mg, f) for f in self.orc.MARGIN_FIELDS])
                 self.bump("seed", "tie")
                 continue
             if o.result == 1:
@@ -197,15 +260,27 @@ class Replayer:
         seeds, n = _arr(capi.Seed, r["seeds"]); got, _ = _arr(capi.ActivateOut, r["out"])
         begin = np.frombuffer(r["target_begin"], np.int32); tg, _ = _arr(capi.ActivateTarget, r["targets"])
         n_mean = int(vo.scalar(r, "n_mean_converge_frame"))
+        kd = 5.0 if (cam.model == capi.CAM_PINHOLE and cam.distortion) else 1.0
         for i in range(n):
             tl = [tg[k] for k in range(begin[i], begin[i + 1])]
             fr = [self.frame(t.frame_id) for t in tl]
+            self.orc.margins_reset()
             o, _ = self.orc.seed_activate(cam, seeds[i], tl, self.frame(seeds[i].ref_frame_id)["pyr"], [f["pyr"] for f in fr],
                                           [f["sobel"] for f in fr], n_mean)
+            mg = self.orc.margins()
             g = got[i]
             self.bump("activate", "n")
             assert g.n_targets == o.n_targets
-            if g.n_matched != o.n_matched or min(abs(o.dist_mean - t) for t in (2.0, 2.5, 3.2)) < 1e-2:
+            if g.n_matched != o.n_matched:
+                # one of the seed's findMatchSeed calls decided differently: only with a gate of that matcher inside its tolerance
+                # (the margins of the restatement's run over all targets of this seed)
+                assert min(mg.ncc / 1e-3, mg.normal / 1e-3, mg.lk_chi2 / 1e-2, mg.lk_update / 1e-2, mg.jump / 1e-2) < kd, \
+                    (i, g.n_matched, o.n_matched, [getattr(mg, f) for f in self.orc.MARGIN_FIELDS])
+                self.bump("activate", "tie")
+                continue
+            if o.n_matched >= 1:
+                assert g.dist_mean == pytest.approx(o.dist_mean, abs=2e-3 * kd)
+            if min(abs(o.dist_mean - t) for t in (2.0, 2.5, 3.2)) < 1e-2 * kd:     # the drift gates (depth_filter.cpp:846-870), 10x the tolerance above
                 self.bump("activate", "tie")
                 continue
             assert g.is_valid == o.is_valid and g.activated == o.activated
@@ -220,14 +295,20 @@ class Replayer:
         cur = self.frame(vo.scalar(r, "cur_frame_id"))
         t = capi.ActivateTarget()
         t.frame_id, t.T_f_w, t.exposure = int(vo.scalar(r, "cur_frame_id")), capi.SE3.from_buffer_copy(r["T_f_w"]), vo.scalar(r, "exposure")
+        kd = 5.0 if (cam.model == capi.CAM_PINHOLE and cam.distortion) else 1.0
         for i in range(n):
             # findMatchSeed of one (seed, frame) pair = the oracle's activation matcher with a single target
+            self.orc.margins_reset()
             o, mo = self.orc.seed_activate(cam, seeds[i], [t], self.frame(seeds[i].ref_frame_id)["pyr"], [cur["pyr"]], [cur["sobel"]], 6)
+            mg = self.orc.margins()
             self.bump("seed_reproject", "n")
             assert int(proj[i]["projected"]) == o.n_targets
             if not o.n_targets:
                 continue
-            if (match[i].success, match[i].search_level) != (mo[0].success, mo[0].search_level):
+            assert match[i].search_level == mo[0].search_level
+            if match[i].success != mo[0].success:
+                assert min(mg.ncc / 1e-3, mg.normal / 1e-3, mg.lk_chi2 / 1e-2, mg.lk_update / 1e-2, mg.jump / 1e-2) < kd, \
+                    (i, [getattr(mg, f) for f in self.orc.MARGIN_FIELDS])
                 self.bump("seed_reproject", "tie")
                 continue
             if mo[0].success:
@@ -268,7 +349,13 @@ class Replayer:
             self.bump("detect", "corners", len(gc)); self.bump("detect", "edgelets", len(ge))
 
     def select_octree(self, r):
-        self.bump("detect", "octree")
+        # FeatureExtractor::computeKeyPointsOctTree: the product's index-range implementation against the list-of-lists
+        # restatement (oracle/octree_py.py) on the keys the driver passed — bit for bit, order included
+        from oracle.octree_py import octree_py
+        keys = np.frombuffer(r["keys"], capi.KEYPOINT_DTYPE)
+        want = octree_py(list(keys), int(vo.scalar(r, "width")), int(vo.scalar(r, "height")), int(vo.scalar(r, "n_features")))
+        assert r["out"] == np.array(want, capi.KEYPOINT_DTYPE).tobytes()
+        self.bump("detect", "octree"); self.bump("detect", "octree_selected", len(want))
 
 
 CASES = [("euroc", synth.EUROC, 60, 200), ("tum_wide", synth.TUM_WIDE, 50, 200), ("fov_920", synth.FOV_920, 90, 200),
@@ -308,10 +395,11 @@ def test_chain_stage_by_stage(orc, tmp_path, name, spec, n_frames, max_fts):
     s = rp.stat
     print(name, "ATE %.2e m over %d frames, %d keyframes;" % (rmse, n_frames, n_kf), "max tracker deviation vs CPU %.2e;" % rp.track_dev, s)
     assert s["track"]["n"] == n_frames - 1 and s["pose"]["n"] == n_frames - 1 and s["ba"]["n"] == n_kf - 1
-    assert s["track"].get("iter_mismatch", 0) <= 0.1 * s["track"]["n"] and s["pose"].get("iter_mismatch", 0) <= 0.1 * s["pose"]["n"]
-    assert s["reproject"].get("tie", 0) <= 0.03 * s["reproject"]["points"] and s["reproject"]["success"] >= 0.8 * s["reproject"]["matched_calls"]
-    assert s["seed"].get("tie", 0) <= 0.03 * s["seed"]["n"] and s["seed"]["updated"] > 0.3 * s["seed"]["n"]
-    assert s["activate"]["n"] > 20 and s["activate"].get("tie", 0) <= 0.1 * s["activate"]["n"]
+    # every differing decision above was excused by the margin of the comparison that produced it (or failed the test); what is
+    # left here are sanity bounds on the replay itself — that it compared enough — not tie allowances
+    assert s["reproject"]["success"] >= 0.8 * s["reproject"]["matched_calls"]
+    assert s["seed"]["updated"] > 0.3 * s["seed"]["n"]
+    assert s["activate"]["n"] > 20 and s["detect"]["octree"] >= n_kf - 1 and s["detect"]["octree_selected"] > 50
 
 
 def test_run_sequence_harness(tmp_path):

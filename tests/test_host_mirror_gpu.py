@@ -12,137 +12,179 @@ pytestmark = pytest.mark.gpu
 HOST_EXE = os.path.join(os.path.dirname(capi.__file__), "host", "hso_host_test")
 
 
-@pytest.mark.parametrize("inverse", [0, 1])
-def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, inverse):
-    d = pair200
-    n = len(d["feats"])
-    feats = d["feats"].copy()
-    idist = 1.0 / feats["dist"]
-    idist[::17] = -1.0                      # features without a point keep their slot
-    tab = np.zeros((n, 6))
-    tab[:, 0:2], tab[:, 2:5], tab[:, 5] = feats["px"], feats["f"], idist
-    case = tmp_path / "case.bin"
-    with open(case, "wb") as f:
-        f.write(np.array([640, 480, n, inverse], np.int32).tobytes())
-        f.write(np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float64).tobytes())
-        f.write(d["ref"].tobytes()); f.write(d["cur"].tobytes()); f.write(tab.tobytes())
-    out = subprocess.run([HOST_EXE, str(case)], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    lines = out.stdout.strip().splitlines()
-    v = lines[0].split()
-    threw, n_tracked = int(v[0]), int(v[1])
-    q, t = np.array(v[2:6], float), np.array(v[6:9], float)
-    a, exposure_time = float(v[9]), float(v[10])
-    iters = [int(x) for x in v[11:16]]
-    ii_ref, ii_cur = float(v[16]), float(v[17])
-    assert threw == 1                       # wrong image size -> std::runtime_error (frame.cpp:85-86)
+class MirrorRun:
+    """One run of the C++ mirror's test driver (hso_amd/host/hso_host_test) on a synthetic pair, plus the direct C-ABI calls
+    on the same inputs that several of the per-adapter tests below share (each computed once, on first use)."""
 
-    # the same job through the C-ABI directly; dist = |f / idist| as makeDepthRef computes it
-    # for a point hosted in the reference frame itself (CoarseTracker.cpp:219-235)
-    for i in (41, 42):
-        try:
-            gpu_ctx.frame_release(i)
-        except capi.HsoGpuError:
-            pass
-    st_r, st_c = gpu_ctx.frame_upload(41, d["ref"]), gpu_ctx.frame_upload(42, d["cur"])
-    assert (st_r.integral_image, st_c.integral_image) == pytest.approx((ii_ref, ii_cur), rel=1e-7)
-    f2 = feats.copy()
-    p = feats["f"] * (1.0 / np.where(idist > 0, idist, 1.0))[:, None]
-    f2["dist"] = np.where(idist > 0, np.linalg.norm(p, axis=1), -1.0)
-    a0 = float(np.float32(st_c.integral_image) / np.float32(st_r.integral_image))
-    r = gpu_ctx.coarse_track_batch(cam, capi.TrackParams(inverse, 4, 1, 50),
-                                   [gpu_ctx.make_job(41, 42, f2, capi.SE3.identity(), a0)])[0]
-    assert iters == list(r.iters) and n_tracked == r.n_tracked
+    def __init__(self, gpu_ctx, tmp_path, d, cam, inverse):
+        self.ctx, self.cam, self.d, self.inverse = gpu_ctx, cam, d, inverse
+        n = len(d["feats"])
+        self.feats = d["feats"].copy()
+        self.idist = 1.0 / self.feats["dist"]
+        self.idist[::17] = -1.0                      # features without a point keep their slot
+        tab = np.zeros((n, 6))
+        tab[:, 0:2], tab[:, 2:5], tab[:, 5] = self.feats["px"], self.feats["f"], self.idist
+        case = tmp_path / "case.bin"
+        with open(case, "wb") as f:
+            f.write(np.array([640, 480, n, inverse], np.int32).tobytes())
+            f.write(np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float64).tobytes())
+            f.write(d["ref"].tobytes()); f.write(d["cur"].tobytes()); f.write(tab.tobytes())
+        out = subprocess.run([HOST_EXE, str(case)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        self.lines = out.stdout.strip().splitlines()
+        v = self.lines[0].split()
+        self.threw, self.n_tracked = int(v[0]), int(v[1])
+        self.q, self.t = np.array(v[2:6], float), np.array(v[6:9], float)
+        self.a, self.exposure_time = float(v[9]), float(v[10])
+        self.iters = [int(x) for x in v[11:16]]
+        self.ii_ref, self.ii_cur = float(v[16]), float(v[17])
+        self.has_pt = np.nonzero(self.idist > 0)[0]
+        self.T_cw = capi.SE3.from_arrays(self.q, self.t)
+        for i in (41, 42):
+            try:
+                gpu_ctx.frame_release(i)
+            except capi.HsoGpuError:
+                pass
+        self.st_r, self.st_c = gpu_ctx.frame_upload(41, d["ref"]), gpu_ctx.frame_upload(42, d["cur"])
+        self.K = int(self.lines[1].split()[0])
+        self._got = None
+
+    def matches(self):
+        """hso_gpu_align_batch on the jobs the mirror's Matcher::findMatchDirect calls amount to (driver line 2)."""
+        if self._got is None:
+            cam, feats, idist = self.cam, self.feats, self.idist
+            R = synth.quat_to_R(self.q)
+            jobs = []
+            for k in range(self.K):
+                i = self.has_pt[k]
+                pos = feats["f"][i] / idist[i]
+                pc = R @ pos + self.t
+                j = capi.AlignJob()
+                j.ref_frame_id = 41; j.ref_level = 0; j.type = capi.FTR_CORNER
+                j.px_ref[:] = list(feats["px"][i]); j.f_ref[:] = list(feats["f"][i]); j.grad[:] = [1.0, 0.0]
+                j.depth = 1.0 / idist[i]
+                j.T_cur_ref = self.T_cw
+                j.px_cur[:] = [cam.fx * pc[0] / pc[2] + cam.cx, cam.fy * pc[1] / pc[2] + cam.cy]
+                j.exposure_rat = float(np.float32(self.exposure_time / 1.0)); j.kf_gap_lt4 = 1
+                jobs.append(j)
+            self._got = self.ctx.align_batch(cam, 42, jobs)
+        return self._got
+
+
+@pytest.fixture(scope="module", params=[0, 1], ids=["forward", "inverse_comp"])
+def mirror(request, gpu_ctx, tmp_path_factory, pair200, cam):
+    return MirrorRun(gpu_ctx, tmp_path_factory.mktemp("mirror"), pair200, cam, request.param)
+
+
+def test_frame_adapter_rejects_a_wrong_image_size(mirror):
+    assert mirror.threw == 1                       # wrong image size -> std::runtime_error (frame.cpp:85-86)
+    assert (mirror.st_r.integral_image, mirror.st_c.integral_image) == pytest.approx((mirror.ii_ref, mirror.ii_cur), rel=1e-7)
+
+
+def test_coarse_tracker_adapter_matches_cabi(mirror):
+    """CoarseTracker(...).run(ref, cur) of the mirror == hso_gpu_coarse_track_batch on the same job; dist = |f / idist| as
+    makeDepthRef computes it for a point hosted in the reference frame itself (CoarseTracker.cpp:219-235)."""
+    m = mirror
+    f2 = m.feats.copy()
+    p = m.feats["f"] * (1.0 / np.where(m.idist > 0, m.idist, 1.0))[:, None]
+    f2["dist"] = np.where(m.idist > 0, np.linalg.norm(p, axis=1), -1.0)
+    a0 = float(np.float32(m.st_c.integral_image) / np.float32(m.st_r.integral_image))
+    r = m.ctx.coarse_track_batch(m.cam, capi.TrackParams(m.inverse, 4, 1, 50), [m.ctx.make_job(41, 42, f2, capi.SE3.identity(), a0)])[0]
+    assert m.iters == list(r.iters) and m.n_tracked == r.n_tracked
     # identity ref pose: cur.T_f_w_ = T_cur_ref * I; dist differs from the adapter's by fp64 rounding only
-    assert np.allclose(q, r.T_cur_ref.q[:], atol=1e-9) and np.allclose(t, r.T_cur_ref.t[:], atol=1e-8)
-    assert a == pytest.approx(r.exposure_rat, abs=1e-6)
+    assert np.allclose(m.q, r.T_cur_ref.q[:], atol=1e-9) and np.allclose(m.t, r.T_cur_ref.t[:], atol=1e-8)
+    assert m.a == pytest.approx(r.exposure_rat, abs=1e-6)
     # write-back rule of CoarseTracker.cpp:200-202 with ref exposure time 1.0
-    assert exposure_time == (1.0 if 0.99 < a < 1.01 else pytest.approx(a, rel=1e-6))
+    assert m.exposure_time == (1.0 if 0.99 < m.a < 1.01 else pytest.approx(m.a, rel=1e-6))
 
-    # ---- Matcher::findMatchDirect (line 2) against hso_gpu_align_batch with the same inputs
-    mv = lines[1].split()
-    K = int(mv[0])
-    assert K == 96
-    has_pt = np.nonzero(idist > 0)[0]
-    T_cw = capi.SE3.from_arrays(q, t)
-    R = synth.quat_to_R(q)
-    jobs = []
-    for k in range(K):
-        i = has_pt[k]
-        pos = feats["f"][i] / idist[i]
-        pc = R @ pos + t
-        j = capi.AlignJob()
-        j.ref_frame_id = 41; j.ref_level = 0; j.type = capi.FTR_CORNER
-        j.px_ref[:] = list(feats["px"][i]); j.f_ref[:] = list(feats["f"][i]); j.grad[:] = [1.0, 0.0]
-        j.depth = 1.0 / idist[i]
-        j.T_cur_ref = T_cw
-        j.px_cur[:] = [cam.fx * pc[0] / pc[2] + cam.cx, cam.fy * pc[1] / pc[2] + cam.cy]
-        j.exposure_rat = float(np.float32(exposure_time / 1.0)); j.kf_gap_lt4 = 1
-        jobs.append(j)
-    got = gpu_ctx.align_batch(cam, 42, jobs)
+
+def test_matcher_adapter_matches_cabi(mirror):
+    """Matcher::findMatchDirect (driver line 2) against hso_gpu_align_batch with the same inputs."""
+    mv = mirror.lines[1].split()
+    assert mirror.K == 96
     n_ok = 0
-    for k, g in enumerate(got):
+    for k, g in enumerate(mirror.matches()):
         ok, px0, px1, sl = int(mv[1 + 4 * k]), float(mv[2 + 4 * k]), float(mv[3 + 4 * k]), int(mv[4 + 4 * k])
         assert (ok, sl) == (g.success, g.search_level)
         assert (px0, px1) == pytest.approx((g.px_cur[0], g.px_cur[1]), abs=1e-6)
         n_ok += ok
     assert n_ok >= 70
 
-    # ---- DepthFilter::observeDepth (line 3) against hso_gpu_seed_observe
+
+def test_depth_filter_adapter_matches_cabi(mirror):
+    """DepthFilter::observeDepth (driver line 3) against hso_gpu_seed_observe."""
     import math
-    sv = lines[2].split()
+    m = mirror
+    sv = m.lines[2].split()
     n_seed_ok, n_left = int(sv[0]), int(sv[1])
     seeds = []
-    for k in range(K, min(len(has_pt), 2 * K)):
-        i = has_pt[k]
+    for k in range(m.K, min(len(m.has_pt), 2 * m.K)):
+        i = m.has_pt[k]
         sd = capi.Seed()
         sd.ref_frame_id = 41; sd.level = 0; sd.type = capi.FTR_CORNER
-        sd.px[:] = list(feats["px"][i]); sd.f[:] = list(feats["f"][i]); sd.grad[:] = [1.0, 0.0]
+        sd.px[:] = list(m.feats["px"][i]); sd.f[:] = list(m.feats["f"][i]); sd.grad[:] = [1.0, 0.0]
         sd.T_ref_w = capi.SE3.identity(); sd.ref_exposure = 1.0
-        depth_mean, depth_min = np.float32(1.1 / idist[i]), np.float32(0.5 / idist[i])
+        depth_mean, depth_min = np.float32(1.1 / m.idist[i]), np.float32(0.5 / m.idist[i])
         z_range = np.float32(1.0) / depth_min
         sd.mu = float(np.float32(1.0) / depth_mean); sd.sigma2 = float(z_range * z_range / np.float32(36)); sd.b = 10.0
         seeds.append(sd)
-    pea = math.atan(1.0 / (2.0 * abs((cam.fx + cam.fy) * 0.5))) * 2.0
-    so = gpu_ctx.seed_observe(cam, 42, T_cw, exposure_time, pea, seeds)
+    pea = math.atan(1.0 / (2.0 * abs((m.cam.fx + m.cam.fy) * 0.5))) * 2.0
+    so = m.ctx.seed_observe(m.cam, 42, m.T_cw, m.exposure_time, pea, seeds)
     kept = [o for o in so if o.is_valid]
     assert n_left == len(kept) and n_seed_ok == sum(o.result == 1 for o in kept) and n_seed_ok >= 16
     for k, o in enumerate(kept):
         mu, s2, b = (float(x) for x in sv[2 + 3 * k: 5 + 3 * k])
         assert (mu, s2, b) == pytest.approx((o.mu, o.sigma2, o.b), rel=1e-6)
 
-    # ---- pose_optimizer::optimizeLevenbergMarquardt3rd (line 4) against hso_gpu_pose_optimize_batch
-    pv = lines[3].split()
+
+def test_pose_optimizer_adapter_matches_cabi(mirror):
+    """pose_optimizer::optimizeLevenbergMarquardt3rd (driver line 4) against hso_gpu_pose_optimize_batch."""
+    import math
+    m = mirror
+    cam = m.cam
+    pv = m.lines[3].split()
     n_fts, nobs, culled = int(pv[0]), int(pv[1]), int(pv[2])
     qp, tp = np.array(pv[3:7], float), np.array(pv[7:10], float)
     scale, e0, e1, err_px = float(pv[10]), float(pv[11]), float(pv[12]), float(pv[13])
+    got = m.matches()
     matched = [k for k, g in enumerate(got) if g.success]
     assert n_fts == len(matched)
     pf = np.zeros(len(matched), capi.POSE_FEAT_DTYPE)
     for r, k in enumerate(matched):
-        i = has_pt[k]
+        i = m.has_pt[k]
         g = got[k]
         x, y = (g.px_cur[0] - cam.cx) / cam.fx, (g.px_cur[1] - cam.cy) / cam.fy
         nrm = math.sqrt(x * x + y * y + 1.0)
         pf[r]["has_point"] = 1; pf[r]["type"] = capi.FTR_CORNER; pf[r]["level"] = g.search_level; pf[r]["host_pose"] = 0
         pf[r]["f"] = [x / nrm, y / nrm, 1.0 / nrm]; pf[r]["grad"] = [1.0, 0.0]
-        pf[r]["host_f"] = feats["f"][i]; pf[r]["idist"] = idist[i]
-    T_start = capi.SE3.from_arrays(q, t + np.array([0.004, -0.003, 0.0]))
-    (rg,), (mg,) = gpu_ctx.pose_optimize_batch(cam, [capi.make_pose_job(pf, [capi.SE3.identity()], T_start)])
+        pf[r]["host_f"] = m.feats["f"][i]; pf[r]["idist"] = m.idist[i]
+    T_start = capi.SE3.from_arrays(m.q, m.t + np.array([0.004, -0.003, 0.0]))
+    (rg,), (mg,) = m.ctx.pose_optimize_batch(cam, [capi.make_pose_job(pf, [capi.SE3.identity()], T_start)])
     assert (nobs, culled) == (rg.num_obs, int(mg.sum()))
     assert np.allclose(qp, rg.T_f_w.q[:], atol=1e-9) and np.allclose(tp, rg.T_f_w.t[:], atol=1e-8)
     assert (scale, e0, e1) == pytest.approx((rg.estimated_scale, rg.error_init, rg.error_final), rel=1e-6)
     assert err_px == pytest.approx(rg.error_in_px, rel=1e-5)
     # the refinement pulls the perturbed start back to the tracked pose
-    assert np.linalg.norm(tp - t) < 1.5e-3 and e1 <= e0
+    assert np.linalg.norm(tp - m.t) < 1.5e-3 and e1 <= e0
 
-    # ---- DepthFilter::addKeyframe -> FeatureExtractor::detect -> seeds (line 5) against the C-ABI pieces
-    kv = lines[4].split()
-    n_new, grad_mean = int(kv[0]), float(kv[1])
-    assert grad_mean == pytest.approx(st_c.grad_mean, rel=1e-7)
-    min_thresh = int(grad_mean)
-    co, cc, eo, ec = gpu_ctx.detect_candidates([42], n_levels=3, min_thresh=min_thresh, corner_cap=16384, edgelet_cap=4800)
-    occupied = [(float(mv[2 + 4 * k]), float(mv[3 + 4 * k])) for k in range(K) if int(mv[1 + 4 * k])]
+
+def _min_thresh(m):
+    kv = m.lines[4].split()
+    grad_mean = float(kv[1])
+    assert grad_mean == pytest.approx(m.st_c.grad_mean, rel=1e-7)
+    return int(grad_mean)
+
+
+def test_add_keyframe_adapter_matches_cabi(mirror):
+    """DepthFilter::addKeyframe -> FeatureExtractor::detect -> seeds (driver line 5) against the C-ABI pieces."""
+    m = mirror
+    cam = m.cam
+    mv = m.lines[1].split()
+    kv = m.lines[4].split()
+    n_new = int(kv[0])
+    min_thresh = _min_thresh(m)
+    co, cc, eo, ec = m.ctx.detect_candidates([42], n_levels=3, min_thresh=min_thresh, corner_cap=16384, edgelet_cap=4800)
+    occupied = [(float(mv[2 + 4 * k]), float(mv[3 + 4 * k])) for k in range(m.K) if int(mv[1 + 4 * k])]
     keys = np.zeros(len(occupied) + int(cc.sum() + ec.sum()), capi.KEYPOINT_DTYPE)
     keys["x"][:len(occupied)] = [p[0] for p in occupied]
     keys["y"][:len(occupied)] = [p[1] for p in occupied]
@@ -179,14 +221,21 @@ def test_coarse_tracker_adapter_matches_cabi(gpu_ctx, tmp_path, pair200, cam, in
     # n_edgelets is normally 0 here; tests/test_octree.py covers the edgelet-winning nodes)
     assert 0 <= n_edgelets <= n_new
 
-    # ---- FeatureExtractor(isInit=true).detect (line 6): fastDetectMT + fillingHole + oct-tree with 2000 features
-    assert _init_branch_check(gpu_ctx, lines[5], 42, min_thresh) >= 0
 
-    # ---- Reprojector::reprojectMap (lines 7-8): few candidates -> reprojectCellAll; small budget -> the three cell passes
-    n_sel, n_cand = _reprojector_check(gpu_ctx, cam, lines[6], 200, 41, 42, T_cw, exposure_time, feats, idist, has_pt)
-    assert n_cand > 150 and n_sel > 120
-    n_sel, n_cand = _reprojector_check(gpu_ctx, cam, lines[7], 40, 41, 42, T_cw, exposure_time, feats, idist, has_pt)
-    assert n_sel == 40
+def test_init_detect_adapter_matches_cabi(mirror):
+    """FeatureExtractor(isInit=true).detect (driver line 6): fastDetectMT + fillingHole + oct-tree with 2000 features."""
+    assert _init_branch_check(mirror.ctx, mirror.lines[5], 42, _min_thresh(mirror)) >= 0
+
+
+@pytest.mark.parametrize("line,budget", [(6, 200), (7, 40)], ids=["reprojectCellAll", "three_cell_passes"])
+def test_reprojector_adapter_matches_cabi(mirror, line, budget):
+    """Reprojector::reprojectMap (driver lines 7-8): few candidates -> reprojectCellAll; small budget -> the three cell passes."""
+    m = mirror
+    n_sel, n_cand = _reprojector_check(m.ctx, m.cam, m.lines[line], budget, 41, 42, m.T_cw, m.exposure_time, m.feats, m.idist, m.has_pt)
+    if budget == 200:
+        assert n_cand > 150 and n_sel > 120
+    else:
+        assert n_sel == 40
 
 
 def _init_branch_check(gpu_ctx, line, frame_id, min_thresh):

@@ -282,8 +282,11 @@ def test_coarse_track_batch_is_deterministic_and_order_free(gpu_ctx, orc, cam, p
     jA = gpu_ctx.make_job(1, 2, pair2000["feats"], capi.SE3.identity(), 1.0)
     jB = gpu_ctx.make_job(5, 6, pair200["feats"], capi.SE3.identity(), 1.0)
     jC = gpu_ctx.make_job(1, 2, pair2000["feats"][:700], capi.SE3.identity(), 1.04)
-    solo = [gpu_ctx.coarse_track_batch(cam, p, [j])[0] for j in (jA, jB, jC)]
-    batch = gpu_ctx.coarse_track_batch(cam, p, [jA, jB, jC] * 40)
+    # the one-workgroup-per-job shapes (a solo call would otherwise take the cooperative shape: tests/test_track_coop_gpu.py)
+    from conftest import track_env
+    with track_env("one_wg"):
+        solo = [gpu_ctx.coarse_track_batch(cam, p, [j])[0] for j in (jA, jB, jC)]
+        batch = gpu_ctx.coarse_track_batch(cam, p, [jA, jB, jC] * 40)
     for i, r in enumerate(batch):
         s = solo[i % 3]
         assert bytes(r) == bytes(s), "job %d differs from its solo run" % i
@@ -309,7 +312,9 @@ def test_coarse_track_large_batch_takes_the_two_launch_path(gpu_ctx, orc, cam, p
             gpu_ctx.make_job(1, 2, pair2000["feats"][:900], capi.SE3.identity(), 1.0)]
     n = 2 * n_cu + 7
     batch = gpu_ctx.coarse_track_batch(cam, p, [jobs[i % 3] for i in range(n)])
-    solo = [gpu_ctx.coarse_track_batch(cam, p, [j])[0] for j in jobs]             # one launch, 512 threads
+    from conftest import track_env
+    with track_env("one_wg"):
+        solo = [gpu_ctx.coarse_track_batch(cam, p, [j])[0] for j in jobs]         # one launch, 512 threads
     rp, cp = orc.create_pyramid(pair2000["ref"]), orc.create_pyramid(pair2000["cur"])
     ro = orc.Tracker(cam, p, rp, cp, pair2000["feats"]).run(T0, 1.04)
     for i, r in enumerate(batch):

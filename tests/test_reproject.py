@@ -87,8 +87,10 @@ def test_reproject_match_equals_oracle(gpu_ctx, orc, spec):
         kf_pyrs = [orc.create_pyramid(f) for f in P["frames"]]
         cur_pyr = orc.create_pyramid(P["cur"])
         cur_sobel = [orc.sobel5(np.ascontiguousarray(cur_pyr[L])) for L in range(3)]
+        margins = []
         wproj, wmatch = orc.reproject_match(cam, P["T_cur_w"], P["cur_exposure"], P["cur_keyframe_id"], P["kfs"], P["points"],
-                                            P["obs"], P["cell_size"], P["grid_n_cols"], kf_pyrs, cur_pyr, cur_sobel)
+                                            P["obs"], P["cell_size"], P["grid_n_cols"], kf_pyrs, cur_pyr, cur_sobel, margins_out=margins)
+        kd = 1.0 if spec is synth.ICL_NUIM else 5.0   # radtan: A_cur_ref carries 2e-5 instead of 1e-9 (see below)
         n_proj = n_ref = n_ok = n_tie = 0
         for i in range(len(proj)):
             g, w = proj[i], wproj[i]
@@ -110,8 +112,15 @@ def test_reproject_match_equals_oracle(gpu_ctx, orc, spec):
                 continue
             n_ref += 1
             o = wmatch[i]
-            if (m.success, m.stage, m.search_level) != (o.success, o.stage, o.search_level) or m.iters != o.iters:
-                # near-tie of a convergence / NCC threshold (as in tests/test_align.py)
+            assert m.search_level == o.search_level
+            mg = margins[i]
+            if m.iters != o.iters:
+                assert mg.lk_update < 1e-2 * kd, (i, m.iters, o.iters, mg.lk_update)     # the margin rule of tests/test_align.py
+                n_tie += 1
+                continue
+            if (m.success, m.stage) != (o.success, o.stage):
+                assert min(mg.ncc / 1e-3, mg.normal / 1e-3, mg.lk_chi2 / 1e-2, mg.lk_update / 1e-2, mg.jump / 1e-2) < kd, \
+                    (i, m.stage, o.stage, [getattr(mg, f) for f in orc.MARGIN_FIELDS])
                 n_tie += 1
                 continue
             # radtan: cam2world runs OpenCV's five fp32 undistortion iterations (src/camera.cpp:171-194),
@@ -120,7 +129,7 @@ def test_reproject_match_equals_oracle(gpu_ctx, orc, spec):
             if o.success:
                 n_ok += 1
                 assert np.allclose(m.px_cur[:], o.px_cur[:], atol=2e-3)
-        assert n_proj > 600 and n_ref > 500 and n_ok > 350 and n_tie <= 6, (n_proj, n_ref, n_ok, n_tie)
+        assert n_proj > 600 and n_ref > 500 and n_ok > 350, (n_proj, n_ref, n_ok, n_tie)   # coverage; ties excused by margin only
         # the cases the generator plants: outside / behind -> not projected; useless or no observation -> no reference
         idx = np.arange(len(proj))
         assert not proj["projected"][(idx % 29 == 4) | (idx % 31 == 6)].any()
