@@ -149,6 +149,11 @@ class PoseResult(C.Structure):
                 ("n_trials_total", C.c_int32), ("status", C.c_int32)]
 
 
+class PoseChain(C.Structure):
+    _fields_ = [("reproj_thresh", C.c_double), ("n_iter", C.c_int32), ("pad_", C.c_int32), ("results", C.c_void_p),
+                ("n_feats", C.c_void_p), ("outlier_mask", C.c_void_p)]
+
+
 def make_pose_job(feats, poses, T_f_w, reproj_thresh=2.0, n_iter=12):
     """feats: POSE_FEAT_DTYPE array; poses: list of SE3 (host keyframe T_f_w)."""
     feats = np.ascontiguousarray(feats, dtype=POSE_FEAT_DTYPE)
@@ -307,6 +312,7 @@ def load():
     lib.hso_gpu_ba_optimize_multi.argtypes = [vp, P(BaProblem), i32]
     lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.hso_gpu_reproject_select_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
+    lib.hso_gpu_reproject_select_pose_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp, P(PoseChain)]
     lib.hso_gpu_seed_activate_multi.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), P(i32), P(ActivateOut),
                                                 P(AlignOut)]
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
@@ -348,7 +354,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize", "hso_gpu_ba_optimize_multi",
-    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select", "hso_gpu_reproject_select_maps",
+    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select", "hso_gpu_reproject_select_maps", "hso_gpu_reproject_select_pose_maps",
     "hso_gpu_seed_reproject_match",
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
@@ -734,6 +740,24 @@ class Context:
                                                                _ptr(order), len(order), max_fts, _ptr(out), capacity, _ptr(begin),
                                                                _ptr(counts)), "reproject_select_maps")
         return out[:n], begin, counts
+
+    def reproject_select_pose_maps(self, cam, calls, cell_size, grid_n_cols, cell_order, max_fts, capacity, reproj_thresh=2.0, n_iter=12,
+                                   want_mask=True):
+        """reproject_select_maps + the pose optimisation chained on the device.
+        -> (briefs, begin, counts, PoseResult array, n_feats[n_calls], mask[n_calls, max(max_fts, 1)] or None)"""
+        calls = np.ascontiguousarray(calls, MAP_CALL_DTYPE)
+        order = np.ascontiguousarray(cell_order, np.int32)
+        out = np.zeros(capacity, MATCH_BRIEF_DTYPE)
+        begin = np.zeros(len(calls) + 1, np.int32)
+        counts = np.zeros((len(calls), 4), np.int32)
+        res = (PoseResult * max(len(calls), 1))()
+        nf = np.zeros(max(len(calls), 1), np.int32)
+        mask = np.zeros((max(len(calls), 1), max(max_fts, 1)), np.uint8) if want_mask else None
+        pc = PoseChain(reproj_thresh, n_iter, 0, C.cast(res, C.c_void_p), nf.ctypes.data, mask.ctypes.data if want_mask else None)
+        n = self._check(self.lib.hso_gpu_reproject_select_pose_maps(self.h, C.byref(cam), _ptr(calls), len(calls), cell_size, grid_n_cols,
+                                                                    _ptr(order), len(order), max_fts, _ptr(out), capacity, _ptr(begin),
+                                                                    _ptr(counts), C.byref(pc)), "reproject_select_pose_maps")
+        return out[:n], begin, counts, res, nf[:len(calls)], mask
 
     # -- FAST-9 corner candidates
     def fast_detect(self, frame_id, n_levels=3, threshold=20, border=8, cap=20000):

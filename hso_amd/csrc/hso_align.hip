@@ -479,6 +479,17 @@ void hso_map_arena_free(hso_gpu_ctx* ctx)
   ctx->maps = nullptr;
 }
 
+// what the chained pose optimisation (hso_select.hip) needs of the stored maps
+const hso_map_point* hso_map_points_dev(hso_gpu_ctx* ctx) { return ctx->maps ? ctx->maps->d_pts : nullptr; }
+int hso_map_max_points(hso_gpu_ctx* ctx) { return ctx->maps ? ctx->maps->max_points : 0; }
+int hso_map_max_kfs(hso_gpu_ctx* ctx) { return ctx->maps ? ctx->maps->max_kfs : 0; }
+int hso_map_kf_poses(hso_gpu_ctx* ctx, int map, hso_se3* out)
+{
+  const std::vector<hso_kf>& kfs = ctx->maps->kfs[map];
+  for (size_t k = 0; k < kfs.size(); k++) out[k] = kfs[k].T_f_w;
+  return (int)kfs.size();
+}
+
 extern "C" int hso_gpu_map_reserve(hso_gpu_ctx* ctx, int n_maps, int max_kfs, int max_points, int max_obs)
 {
   if (!ctx) return HSO_E_INVALID;

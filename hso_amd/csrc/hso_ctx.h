@@ -99,5 +99,9 @@ struct MapArenaSizes { long long total; };   // points of a set of calls
 int hso_map_call_sizes(hso_gpu_ctx* ctx, const hso_map_call* calls, int n_calls, MapArenaSizes* Z);
 int hso_reproject_maps_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
                            int grid_n_cols, size_t extra_bytes, HsoMapsRun* R);
+const hso_map_point* hso_map_points_dev(hso_gpu_ctx* ctx);
+int hso_map_max_points(hso_gpu_ctx* ctx);
+int hso_map_max_kfs(hso_gpu_ctx* ctx);
+int hso_map_kf_poses(hso_gpu_ctx* ctx, int map, hso_se3* out);   // T_f_w of map `map`'s keyframes in table order; returns their number
 int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base);
 void hso_frame_free(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* base);

@@ -14,27 +14,19 @@
 // many frames in flight, not bandwidth.  Per-feature arithmetic follows the reference's fp64
 // expressions; the sums (chi2, A, b) are fixed-tree reductions (reference: serial fp64), the
 // MAD scales and medians are exact order statistics (bitwise search on the IEEE bit patterns).
-#include "hso_ctx.h"
+#include "hso_pose_dev.h"
 #include "hso_dev_math.h"
+#include "hso_wave_reduce.h"
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 using namespace hso_dev;
 
-#define POSE_THREADS 256
+#define POSE_THREADS 512
 #define POSE_WAVES (POSE_THREADS / 64)
-#define POSE_MAX_FEATS 4096
-#define POSE_MAX_POSES 64
-
-struct PoseJobDev {
-  const hso_pose_feat* feats;
-  const hso_se3* poses;
-  uint8_t* mask;  // may be null
-  int n_feats, n_poses;
-  hso_se3 T;
-  double reproj_thresh;
-  int n_iter, _pad;
-};
+#define POSE_MAX_FEATS HSO_POSE_MAX_FEATS
+#define POSE_MAX_POSES HSO_POSE_MAX_POSES
 
 struct PoseShared {
   Se3 T, Tn;
@@ -47,39 +39,44 @@ struct PoseShared {
   float scale_pt, scale_ls;
   int n_pt, n_ls, n_obs, stop, accept, n_trials, iters, n_trials_total, n_deleted;
   int cnt[POSE_WAVES];
-  unsigned long long keys64[POSE_MAX_FEATS];
-  unsigned keys32[POSE_MAX_FEATS];
+  unsigned hist[256];                       // radix select: digit histogram
+  unsigned sel_bin, sel_rank;
+  unsigned long long keys64[POSE_MAX_FEATS];   // also the 32-bit keys of the MAD scales (never live together)
 };
 
-HSO_DEV double p_shfl_xor_d(double v, int m)
-{
-  const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
-  return __hiloint2double(hi, lo);
-}
 HSO_DEV double p_readlane_d(double v, int src)
 {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
 
-// workgroup sum of K doubles per thread (K <= 32): butterfly within the wave, LDS across waves,
-// fixed order => deterministic.  Result in s.red[0..K).
-template <int K>
-HSO_DEV void pose_block_sum(PoseShared& s, double (&v)[K])
+// workgroup sum of 27 doubles per thread: one halving exchange per wave (32 slots, 5 of them zero pads: ~40 lane exchanges
+// instead of 27 butterflies = 162), LDS across the waves in wave order => deterministic.  Result in s.red[0..27).
+HSO_DEV void pose_block_sum27(PoseShared& s, double (&v)[32])
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < K; i++) {
-    const double x = wave_butterfly_sum(v[i]);
-    if (lane == 0) s.wave_part[wave][i] = x;
-  }
+  int slot;
+  const double x = wave_reduce_scatter32(v, lane, slot);
+  if ((lane & 1) == 0) s.wave_part[wave][slot] = x;     // two adjacent lanes hold each slot's total
   __syncthreads();
-  if (threadIdx.x < K) {
+  if (threadIdx.x < 27) {
     double t = 0;
     for (int w = 0; w < POSE_WAVES; w++) t += s.wave_part[w][threadIdx.x];
     s.red[threadIdx.x] = t;
   }
   __syncthreads();
+}
+
+HSO_DEV double pose_block_sum1(PoseShared& s, double v)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double x = wave_butterfly_sum(v);
+  __syncthreads();
+  if (lane == 0) s.wave_part[wave][0] = x;
+  __syncthreads();
+  double t = 0;
+  for (int w = 0; w < POSE_WAVES; w++) t += s.wave_part[w][0];
+  return t;
 }
 
 HSO_DEV int pose_block_count(PoseShared& s, int v)
@@ -94,36 +91,84 @@ HSO_DEV int pose_block_count(PoseShared& s, int v)
   return t;
 }
 
-// k-th smallest (0-based) of n non-negative keys held in LDS, by fixing the bits from the top:
-// exactly the element nth_element would leave at position k (math_utils.h:119-126,
-// robust_cost.cpp:70-71).
+// k-th smallest (0-based) of n keys held in LDS — exactly the element nth_element would leave at position k
+// (math_utils.h:119-126, robust_cost.cpp:70-71) — by an MSB-first radix select, 8 bits per pass: histogram of the digit over
+// the keys that match the prefix found so far (LDS atomics), the bin that holds the rank located by the first 256 threads.
+// Empty slots hold all-ones keys (larger than any valid key; k is always below the number of valid keys).
 template <typename KeyT, int BITS>
 HSO_DEV KeyT pose_select(PoseShared& s, const KeyT* keys, int n, int k)
 {
-  KeyT res = 0;
-  for (int bit = BITS - 1; bit >= 0; bit--) {
-    const KeyT trial = res | ((KeyT)1 << bit);
-    int c = 0;
-    for (int i = threadIdx.x; i < n; i += POSE_THREADS) c += (keys[i] < trial) ? 1 : 0;
-    c = pose_block_count(s, c);
-    if (c <= k) res = trial;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  KeyT prefix = 0;
+  unsigned rank = (unsigned)k;
+  for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+    __syncthreads();
+    if (tid < 256) s.hist[tid] = 0;
+    __syncthreads();
+    const KeyT hi_mask = (shift + 8 >= BITS) ? (KeyT)0 : (KeyT)(~(KeyT)0 << (shift + 8));
+    for (int i = tid; i < n; i += POSE_THREADS) {
+      const KeyT key = keys[i];
+      if ((key & hi_mask) == prefix) atomicAdd(&s.hist[(unsigned)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // inclusive scan of the 256 bins: within each of the first four wavefronts, then across them
+    unsigned c = 0, incl = 0;
+    if (tid < 256) {
+      c = s.hist[tid];
+      incl = c;
+      for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      if (lane == 63) s.cnt[wave] = (int)incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      for (int w = 0; w < wave; w++) incl += (unsigned)s.cnt[w];
+      if (rank >= incl - c && rank < incl) { s.sel_bin = (unsigned)tid; s.sel_rank = rank - (incl - c); }
+    }
+    __syncthreads();
+    prefix |= (KeyT)s.sel_bin << shift;
+    rank = s.sel_rank;
   }
-  return res;
+  return prefix;
 }
 
 struct Resid { double e0, e1, px, py, pz; };
 
-HSO_DEV Resid pose_residual(const PoseShared& s, const hso_pose_feat& ft, bool use_new)
+// What a thread keeps of one of its features for the whole optimisation (registers): the point in its host frame, the
+// observation on the unit plane, the level scale, the edgelet direction.  The reference recomputes host_f / idist and
+// f.x / f.z, f.y / f.z in every pass (:429-440); the values are the same bits each time, so they are formed once.
+struct PoseFeatReg {
+  double X0, X1, X2;     // host_f * (1 / idist)
+  double u, v;           // f[0] / f[2], f[1] / f[2]
+  double sc;             // 1 / 2^level
+  double g0, g1;         // grad
+  int host_pose;
+  int kind;              // 0 no point, 1 corner (2-D residual), 2 edgelet (1-D residual); bit 2: temporary point (weight x 0.5)
+};
+
+HSO_DEV PoseFeatReg pose_load_feat(const hso_pose_feat& ft)
+{
+  PoseFeatReg r;
+  r.kind = 0; r.host_pose = 0;
+  r.X0 = r.X1 = r.X2 = 0; r.u = r.v = 0; r.sc = 1; r.g0 = r.g1 = 0;
+  if (ft.has_point) {
+    const double inv = 1.0 / ft.idist;
+    r.X0 = ft.host_f[0] * inv; r.X1 = ft.host_f[1] * inv; r.X2 = ft.host_f[2] * inv;
+    r.u = ft.f[0] / ft.f[2]; r.v = ft.f[1] / ft.f[2];
+    r.sc = 1.0 / (double)(1 << ft.level);
+    r.g0 = ft.grad[0]; r.g1 = ft.grad[1];
+    r.host_pose = ft.host_pose;
+    r.kind = (ft.type == HSO_FTR_EDGELET ? 2 : 1) | (ft.temporary ? 4 : 0);
+  }
+  return r;
+}
+
+HSO_DEV Resid pose_residual(const PoseShared& s, const PoseFeatReg& f)
 {
   // pTarget = (T * host^-1) * (host_f / idist); e = project2d(f) - project2d(pTarget), / 2^level (:429-440)
   Resid r;
-  const double inv = 1.0 / ft.idist;
-  const Se3& Tth = s.Tth[ft.host_pose];
-  (void)use_new;
-  se3_apply(Tth, ft.host_f[0] * inv, ft.host_f[1] * inv, ft.host_f[2] * inv, r.px, r.py, r.pz);
-  const double sc = 1.0 / (double)(1 << ft.level);
-  r.e0 = (ft.f[0] / ft.f[2] - r.px / r.pz) * sc;
-  r.e1 = (ft.f[1] / ft.f[2] - r.py / r.pz) * sc;
+  se3_apply(s.Tth[f.host_pose], f.X0, f.X1, f.X2, r.px, r.py, r.pz);
+  r.e0 = (f.u - r.px / r.pz) * f.sc;
+  r.e1 = (f.v - r.py / r.pz) * f.sc;
   return r;
 }
 
@@ -143,27 +188,28 @@ HSO_DEV void pose_set_Tth(PoseShared& s, const Se3& T, int n_poses)
 }
 
 // weighted chi2 at the poses currently in s.Tth (:488-526 / :602-641)
-HSO_DEV double pose_chi2(PoseShared& s, const PoseJobDev& J)
+template <int FPT>
+HSO_DEV double pose_chi2(PoseShared& s, const PoseFeatReg (&pf)[FPT])
 {
-  double v[1] = { 0 };
-  for (int i = threadIdx.x; i < J.n_feats; i += POSE_THREADS) {
-    const hso_pose_feat& ft = J.feats[i];
-    if (!ft.has_point) continue;
-    const Resid r = pose_residual(s, ft, false);
-    if (ft.type == HSO_FTR_EDGELET) {
-      const double error_ls = ft.grad[0] * r.e0 + ft.grad[1] * r.e1;
+  double v = 0;
+#pragma unroll
+  for (int q = 0; q < FPT; q++) {
+    const PoseFeatReg& f = pf[q];
+    if (!(f.kind & 3)) continue;
+    const Resid r = pose_residual(s, f);
+    if ((f.kind & 3) == 2) {
+      const double error_ls = f.g0 * r.e0 + f.g1 * r.e1;
       double w = huber_w(fabs(error_ls) / (double)s.scale_ls);
-      if (ft.temporary) w *= 0.5;
-      v[0] += error_ls * error_ls * w;
+      if (f.kind & 4) w *= 0.5;
+      v += error_ls * error_ls * w;
     } else {
       const double error_pt = sqrt(r.e0 * r.e0 + r.e1 * r.e1);
       double w = huber_w(error_pt / (double)s.scale_pt);
-      if (ft.temporary) w *= 0.5;
-      v[0] += error_pt * error_pt * w;
+      if (f.kind & 4) w *= 0.5;
+      v += error_pt * error_pt * w;
     }
   }
-  pose_block_sum<1>(s, v);
-  return s.red[0];
+  return pose_block_sum1(s, v);
 }
 
 // A.ldlt().solve(b) for the 6x6 system in s.A/s.b (pivoted LDL^T on eight lanes, broadcasts by
@@ -231,13 +277,19 @@ HSO_DEV void pose_ldlt6(PoseShared& s)
   }
 }
 
-__global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const PoseJobDev* jobs, hso_pose_result* results)
+// One 512-thread workgroup per frame (two wavefronts per SIMD); a thread owns up to FPT features (slot i = tid + q * 512 keeps
+// the feature order) and holds what it needs of them in registers for the whole optimisation, so a pass touches no global
+// memory: the previous form re-read the 96-byte feature records from L2 in every one of the ~60 passes, one dependent load
+// chain per feature with a single wavefront per SIMD to hide it (2000 features: 5.0 ms per 256 frames, profiles/r3_*).
+template <int FPT>
+__global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const PoseJobDev* jobs, hso_pose_result* results)
 {
   __shared__ PoseShared s;
   const PoseJobDev& J = jobs[blockIdx.x];
   hso_pose_result& out = results[blockIdx.x];
   const int tid = threadIdx.x, n = J.n_feats;
   const double em2 = (cam.fx * cam.fy < 0) ? fabs(cam.fx) : fabs((cam.fx + cam.fy) * 0.5);  // camera.cpp:59
+  unsigned* const keys32 = reinterpret_cast<unsigned*>(s.keys64);
 
   if (tid == 0) {
     s.T = se3_from(J.T);
@@ -246,20 +298,28 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
     for (int q = 0; q < 6; q++) s.b[q] = 0;
   }
   if (tid < J.n_poses) s.hinv[tid] = se3_inverse(se3_from(J.poses[tid]));
+  PoseFeatReg pf[FPT];
+#pragma unroll
+  for (int q = 0; q < FPT; q++) {
+    const int i = tid + q * POSE_THREADS;
+    if (i < n) { pf[q] = pose_load_feat(J.feats[i]); if (J.mask) J.mask[i] = 0; }
+    else { pf[q].kind = 0; pf[q].host_pose = 0; pf[q].X0 = pf[q].X1 = pf[q].X2 = pf[q].u = pf[q].v = pf[q].g0 = pf[q].g1 = 0; pf[q].sc = 1; }
+  }
   __syncthreads();
-  for (int i = tid; i < n; i += POSE_THREADS) if (J.mask) J.mask[i] = 0;
   pose_set_Tth(s, s.T, J.n_poses);
 
   // ---- pass 0: initial errors (:426-454).  Slot i keeps the feature order; empty slots hold
   // all-ones keys (larger than any valid key) so that order statistics ignore them.
   int c_pt = 0, c_ls = 0;
-  for (int i = tid; i < n; i += POSE_THREADS) {
-    const hso_pose_feat& ft = J.feats[i];
+#pragma unroll
+  for (int q = 0; q < FPT; q++) {
+    const int i = tid + q * POSE_THREADS;
+    if (i >= n) continue;
     unsigned long long k64 = ~0ull;
-    if (ft.has_point) {
-      const Resid r = pose_residual(s, ft, false);
-      if (ft.type == HSO_FTR_EDGELET) {
-        const float error_ls = (float)(ft.grad[0] * r.e0 + ft.grad[1] * r.e1);
+    if (pf[q].kind & 3) {
+      const Resid r = pose_residual(s, pf[q]);
+      if ((pf[q].kind & 3) == 2) {
+        const float error_ls = (float)(pf[q].g0 * r.e0 + pf[q].g1 * r.e1);
         k64 = (unsigned long long)__double_as_longlong((double)(error_ls * error_ls));
         c_ls++;
       } else {
@@ -280,37 +340,39 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
     return;
   }
   const int n_init = n_pt + n_ls;
-  const double med_init = __longlong_as_double((long long)pose_select<unsigned long long, 63>(s, s.keys64, n, n_init / 2));
+  const double med_init = __longlong_as_double((long long)pose_select<unsigned long long, 64>(s, s.keys64, n, n_init / 2));
 
   // ---- MAD scales (:459-483): 1.4826f * nth_element(|error|) per residual kind
   float scale_pt = 0, scale_ls = 0;
   for (int kind = 0; kind < 2; kind++) {
     const int cnt = kind == 0 ? n_pt : n_ls;
     __syncthreads();
-    for (int i = tid; i < n; i += POSE_THREADS) {
-      const hso_pose_feat& ft = J.feats[i];
+#pragma unroll
+    for (int q = 0; q < FPT; q++) {
+      const int i = tid + q * POSE_THREADS;
+      if (i >= n) continue;
       unsigned key = 0xFFFFFFFFu;
-      if (ft.has_point && ((ft.type == HSO_FTR_EDGELET) == (kind == 1))) {
-        const Resid r = pose_residual(s, ft, false);
-        const float e = (kind == 1) ? fabsf((float)(ft.grad[0] * r.e0 + ft.grad[1] * r.e1))
-                                    : (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
+      if ((pf[q].kind & 3) == (kind == 1 ? 2 : 1)) {
+        const Resid r = pose_residual(s, pf[q]);
+        const float e = (kind == 1) ? fabsf((float)(pf[q].g0 * r.e0 + pf[q].g1 * r.e1)) : (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
         key = __float_as_uint(e);
       }
-      s.keys32[i] = key;
+      keys32[i] = key;
     }
     __syncthreads();
     if (cnt > 0) {
-      const float med = __uint_as_float(pose_select<unsigned, 31>(s, s.keys32, n, cnt / 2));
+      const float med = __uint_as_float(pose_select<unsigned, 32>(s, keys32, n, cnt / 2));
       if (kind == 0) scale_pt = 1.4826f * med; else scale_ls = 1.4826f * med;
     }
   }
   if (n_pt > 0 && n_ls == 0) scale_ls = (float)(0.5 * (double)scale_pt);
   if (n_pt == 0 && n_ls > 0) scale_pt = (float)(2 * scale_ls);
+  __syncthreads();
   if (tid == 0) { s.scale_pt = scale_pt; s.scale_ls = scale_ls; }
   __syncthreads();
   const double estimated_scale = (double)scale_pt;
 
-  const double chi2_0 = pose_chi2(s, J);
+  const double chi2_0 = pose_chi2<FPT>(s, pf);
   if (tid == 0) s.chi2 = chi2_0;
   __syncthreads();
 
@@ -321,25 +383,25 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
     for (;;) {
       // normal equations at the current pose (:545-592)
       pose_set_Tth(s, s.T, J.n_poses);
-      double acc[27];
+      double acc[32];
 #pragma unroll
-      for (int q = 0; q < 27; q++) acc[q] = 0;
-      for (int i = tid; i < n; i += POSE_THREADS) {
-        const hso_pose_feat& ft = J.feats[i];
-        if (!ft.has_point) continue;
-        const Resid r = pose_residual(s, ft, false);
+      for (int q = 0; q < 32; q++) acc[q] = 0;
+#pragma unroll
+      for (int q = 0; q < FPT; q++) {
+        const PoseFeatReg& f = pf[q];
+        if (!(f.kind & 3)) continue;
+        const Resid r = pose_residual(s, f);
         double J0[6], J1[6];
         jacobian_xyz2uv(r.px, r.py, r.pz, J0, J1);
-        const double sc = 1.0 / (double)(1 << ft.level);
 #pragma unroll
-        for (int q = 0; q < 6; q++) { J0[q] *= sc; J1[q] *= sc; }
-        if (ft.type == HSO_FTR_EDGELET) {
+        for (int k = 0; k < 6; k++) { J0[k] *= f.sc; J1[k] *= f.sc; }
+        if ((f.kind & 3) == 2) {
           double Je[6];
 #pragma unroll
-          for (int q = 0; q < 6; q++) Je[q] = ft.grad[0] * J0[q] + ft.grad[1] * J1[q];
-          const double e_edge = ft.grad[0] * r.e0 + ft.grad[1] * r.e1;
+          for (int k = 0; k < 6; k++) Je[k] = f.g0 * J0[k] + f.g1 * J1[k];
+          const double e_edge = f.g0 * r.e0 + f.g1 * r.e1;
           double w = huber_w(fabs(e_edge) / (double)s.scale_ls);
-          if (ft.temporary) w *= 0.5;
+          if (f.kind & 4) w *= 0.5;
           int idx = 0;
 #pragma unroll
           for (int a = 0; a < 6; a++) {
@@ -349,7 +411,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
           }
         } else {
           double w = huber_w(sqrt(r.e0 * r.e0 + r.e1 * r.e1) / (double)s.scale_pt);
-          if (ft.temporary) w *= 0.5;
+          if (f.kind & 4) w *= 0.5;
           int idx = 0;
 #pragma unroll
           for (int a = 0; a < 6; a++) {
@@ -359,7 +421,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
           }
         }
       }
-      pose_block_sum<27>(s, acc);
+      pose_block_sum27(s, acc);
       if (tid == 0) {
         int idx = 0;
         for (int a = 0; a < 6; a++)
@@ -377,7 +439,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
         if (tid == 0) s.Tn = se3_mul(se3_exp(s.dT), s.T);
         __syncthreads();
         pose_set_Tth(s, s.Tn, J.n_poses);
-        new_chi2 = pose_chi2(s, J);
+        new_chi2 = pose_chi2<FPT>(s, pf);
       }
       if (tid == 0) {
         s.rho = nan_step ? -1.0 : (s.chi2 - new_chi2);
@@ -409,13 +471,15 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
   const float thr_pt = (n < 80) ? (float)(sqrt(5.991) / em2) : (float)(J.reproj_thresh / em2);
   const float thr_ls = (float)(1.3 / em2);
   int n_del = 0;
-  for (int i = tid; i < n; i += POSE_THREADS) {
-    const hso_pose_feat& ft = J.feats[i];
+#pragma unroll
+  for (int q = 0; q < FPT; q++) {
+    const int i = tid + q * POSE_THREADS;
+    if (i >= n) continue;
     unsigned long long k64 = ~0ull;
-    if (ft.has_point) {
-      const Resid r = pose_residual(s, ft, false);
-      if (ft.type == HSO_FTR_EDGELET) {
-        const double error_ls = ft.grad[0] * r.e0 + ft.grad[1] * r.e1;
+    if (pf[q].kind & 3) {
+      const Resid r = pose_residual(s, pf[q]);
+      if ((pf[q].kind & 3) == 2) {
+        const double error_ls = pf[q].g0 * r.e0 + pf[q].g1 * r.e1;
         if (fabs(error_ls) > (double)thr_ls) { n_del++; if (J.mask) J.mask[i] = 1; }
         k64 = (unsigned long long)__double_as_longlong(error_ls * error_ls);
       } else {
@@ -427,27 +491,47 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
     s.keys64[i] = k64;
   }
   n_del = pose_block_count(s, n_del);
-  const double med_final = __longlong_as_double((long long)pose_select<unsigned long long, 63>(s, s.keys64, n, n_init / 2));
-  if (tid == 0) {
-    // Cov_ = (A * em2^2)^-1 (:692): Gauss-Jordan with partial pivoting on the last damped A
-    double m[6][12];
+  const double med_final = __longlong_as_double((long long)pose_select<unsigned long long, 64>(s, s.keys64, n, n_init / 2));
+  if (tid < 64) {
+    // Cov_ = (A * em2^2)^-1 (:692): Gauss-Jordan with partial pivoting on the last damped A — lane r holds row r of
+    // [A | I] in registers (12 doubles, static indices: the one-lane form indexed a 6 x 12 array dynamically and lived in
+    // scratch memory), rows travel by v_readlane
+    const int lane = tid;
+    const int r = lane < 6 ? lane : 5;
+    double m[12];
     const double s2 = em2 * em2;
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 6; j++) { m[i][j] = s.A[i * 6 + j] * s2; m[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int j = 0; j < 6; j++) { m[j] = s.A[r * 6 + j] * s2; m[6 + j] = (r == j) ? 1.0 : 0.0; }
+#pragma unroll
     for (int c = 0; c < 6; c++) {
       int piv = c;
-      for (int r = c + 1; r < 6; r++) if (fabs(m[r][c]) > fabs(m[piv][c])) piv = r;
-      if (piv != c) for (int j = 0; j < 12; j++) { const double t = m[c][j]; m[c][j] = m[piv][j]; m[piv][j] = t; }
-      const double d = m[c][c];
-      for (int j = 0; j < 12; j++) m[c][j] /= d;
-      for (int r = 0; r < 6; r++) {
-        if (r == c) continue;
-        const double f = m[r][c];
-        for (int j = 0; j < 12; j++) m[r][j] -= f * m[c][j];
+      double best = fabs(p_readlane_d(m[c], c));
+#pragma unroll
+      for (int q = c + 1; q < 6; q++) { const double v = fabs(p_readlane_d(m[c], q)); if (v > best) { best = v; piv = q; } }
+#pragma unroll
+      for (int q = c + 1; q < 6; q++) {
+        if (piv == q) {   // swap rows c and q
+#pragma unroll
+          for (int j = 0; j < 12; j++) {
+            const double from_q = p_readlane_d(m[j], q), from_c = p_readlane_d(m[j], c);
+            m[j] = (lane == c) ? from_q : ((lane == q) ? from_c : m[j]);
+          }
+        }
       }
+      const double d = p_readlane_d(m[c], c);
+      double rowc[12];
+#pragma unroll
+      for (int j = 0; j < 12; j++) rowc[j] = p_readlane_d(m[j], c) / d;
+      const double f = m[c];
+#pragma unroll
+      for (int j = 0; j < 12; j++) m[j] = (lane == c) ? rowc[j] : m[j] - f * rowc[j];
     }
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 6; j++) out.cov[i * 6 + j] = m[i][6 + j];
+    if (lane < 6) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) out.cov[lane * 6 + j] = m[6 + j];
+    }
+  }
+  if (tid == 0) {
     se3_to(s.T, out.T_f_w);
     out.error_init = sqrt(med_init) * em2;
     out.error_final = sqrt(med_final) * em2;
@@ -459,6 +543,25 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(hso_camera cam, const Pos
     out.n_trials_total = s.n_trials_total;
     out.status = 0;
   }
+}
+
+static void pose_launch(hipStream_t stream, const hso_camera* cam, const PoseJobDev* dj, int n_jobs, int n_max, hso_pose_result* dr)
+{
+  // features per thread: the smallest power of two that covers the largest table of the batch
+  if (n_max <= POSE_THREADS) hipLaunchKernelGGL(k_pose<1>, dim3(n_jobs), dim3(POSE_THREADS), 0, stream, *cam, dj, dr);
+  else if (n_max <= 2 * POSE_THREADS) hipLaunchKernelGGL(k_pose<2>, dim3(n_jobs), dim3(POSE_THREADS), 0, stream, *cam, dj, dr);
+  else if (n_max <= 4 * POSE_THREADS) hipLaunchKernelGGL(k_pose<4>, dim3(n_jobs), dim3(POSE_THREADS), 0, stream, *cam, dj, dr);
+  else hipLaunchKernelGGL(k_pose<8>, dim3(n_jobs), dim3(POSE_THREADS), 0, stream, *cam, dj, dr);
+}
+
+int hso_pose_launch_device(hso_gpu_ctx* ctx, const hso_camera* cam, const PoseJobDev* d_jobs, int n_jobs, int n_max_feats,
+                           hso_pose_result* d_results)
+{
+  if (n_jobs <= 0) return HSO_OK;
+  if (n_max_feats > POSE_MAX_FEATS) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: n_feats out of range (max 4096)");
+  pose_launch(ctx->stream, cam, d_jobs, n_jobs, n_max_feats, d_results);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
 }
 
 extern "C" int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_pose_job* jobs, int n_jobs,
@@ -513,8 +616,9 @@ extern "C" int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* c
   }
   hipError_t e = hipMemcpyAsync(d, h, o_res, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_pose, dim3(n_jobs), dim3(POSE_THREADS), 0, ctx->stream, *cam, reinterpret_cast<const PoseJobDev*>(d),
-                       reinterpret_cast<hso_pose_result*>(d + o_res));
+    int n_max = 0;
+    for (int j = 0; j < n_jobs; j++) n_max = std::max(n_max, (int)jobs[j].n_feats);
+    pose_launch(ctx->stream, cam, reinterpret_cast<const PoseJobDev*>(d), n_jobs, n_max, reinterpret_cast<hso_pose_result*>(d + o_res));
     e = hipGetLastError();
   }
   char* hres = hm + ((tot_feats + 63) & ~size_t(63));

@@ -15,7 +15,8 @@
 // visiting order with a search for the cut, done per pass by the whole workgroup.  No atomics decide anything: the result is
 // deterministic, and equal to the sequential walk.
 #include "hso_ctx.h"
-#include "hso_dev_math.h"
+#include "hso_pose_dev.h"
+#include "hso_match_dev.h"
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -373,13 +374,53 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_emit(const hso_match_brief*
   }
 }
 
-extern "C" int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+
+// The frame's features as pose_optimizer sees them, built where the selection left its result: every examined candidate that
+// became a feature (success), in examination order = the order Reprojector::reprojectCell pushes `new Feature` into fts_
+// (src/reprojector.cpp:395-425): f = cam->cam2world(px_cur), level = the matcher's search level, type = the reference
+// feature's, grad = the rotated reference gradient, the point's host bearing / inverse depth / host keyframe from the stored
+// map, temporary = Point::TYPE_TEMPORARY (quality key >> 4 == 1).  One workgroup per call; ranks by a block scan.
+__global__ __launch_bounds__(SEL_THREADS) void k_pose_feats_from_sel(hso_camera cam, const hso_match_brief* out, const int* offs, const int* maps,
+                                                                    const hso_map_point* pts, int max_points, int feat_cap,
+                                                                    hso_pose_feat* feats, PoseJobDev* jobs, uint8_t* masks, int* n_feats)
+{
+  __shared__ int s_wave[SEL_WAVES];
+  const int c = blockIdx.x, b = offs[c], e = offs[c + 1];
+  const hso_map_point* P = pts + (size_t)maps[c] * max_points;
+  hso_pose_feat* F = feats + (size_t)c * feat_cap;
+  int carry = 0;
+  for (int i0 = b; i0 < e; i0 += SEL_THREADS) {
+    const int i = i0 + (int)threadIdx.x;
+    const int is = (i < e && out[i].success) ? 1 : 0;
+    int tot;
+    const int pos = sel_block_scan(is, s_wave, tot) + carry - is;
+    if (is && pos < feat_cap) {
+      const hso_match_brief& r = out[i];
+      const hso_map_point& p = P[r.pad_];
+      hso_pose_feat f;
+      f.has_point = 1; f.type = r.ref_type; f.level = r.search_level; f.temporary = ((p.pad_ >> 4) == 1) ? 1 : 0;
+      f.host_pose = p.host_kf; f._pad = 0;
+      hso_dev::cam2world_dev(cam, r.px_cur[0], r.px_cur[1], f.f);
+      f.grad[0] = (double)r.grad[0]; f.grad[1] = (double)r.grad[1];
+      f.host_f[0] = p.host_f[0]; f.host_f[1] = p.host_f[1]; f.host_f[2] = p.host_f[2];
+      f.idist = p.idist;
+      F[pos] = f;
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { const int n = carry < feat_cap ? carry : feat_cap; jobs[c].n_feats = n; n_feats[c] = n; }
+}
+
+static int reproject_select_maps_impl(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
                                              int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
-                                             int out_capacity, int32_t* begin_out, int32_t* counts_out)
+                                             int out_capacity, int32_t* begin_out, int32_t* counts_out, const hso_pose_chain* pose)
 {
   if (!ctx) return HSO_E_INVALID;
   if (n_calls < 0 || n_cells <= 0 || !cell_order || max_fts < 0 || (n_calls > 0 && (!begin_out || !counts_out)))
     return hso_fail(ctx, HSO_E_INVALID, "reproject_select_maps: bad argument");
+  if (pose && (n_calls > 0 && (!pose->results || pose->n_iter < 0))) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_maps: bad pose argument");
+  if (pose && max_fts > HSO_POSE_MAX_FEATS) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_maps: max_fts above the pose optimiser's table size (4096)");
   {
     std::vector<uint8_t> seen(n_cells, 0);
     for (int k = 0; k < n_cells; k++) {
@@ -411,6 +452,18 @@ extern "C" int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera*
   const size_t o_offs = o; o += al(sizeof(int) * (size_t)(n_calls + 1));
   const size_t o_out = o; o += al(sizeof(hso_match_brief) * n_total);
   const size_t o_scr = o; o += per_frame * (size_t)n_calls;
+  // the chained pose optimisation: feature tables, job records, keyframe poses, results, cull masks
+  const int feat_cap = std::max(max_fts, 1);
+  MapArena* const A_ = ctx->maps;
+  const int max_kfs = pose ? hso_map_max_kfs(ctx) : 0;
+  const size_t o_pf = o; if (pose) o += al(sizeof(hso_pose_feat) * (size_t)n_calls * feat_cap);
+  const size_t o_pj = o; if (pose) o += al(sizeof(PoseJobDev) * (size_t)n_calls);
+  const size_t o_pp = o; if (pose) o += al(sizeof(hso_se3) * (size_t)n_calls * max_kfs);
+  const size_t o_pm = o; if (pose) o += al(sizeof(int) * (size_t)n_calls);
+  const size_t o_pr = o; if (pose) o += al(sizeof(hso_pose_result) * (size_t)n_calls);
+  const size_t o_pk = o; if (pose) o += al((size_t)n_calls * feat_cap);
+  const size_t o_pn = o; if (pose) o += al(sizeof(int) * (size_t)n_calls);
+  (void)A_;
   HsoMapsRun R;
   const int total = hso_reproject_maps_run(ctx, cam, calls, n_calls, cell_size, grid_n_cols, o, &R);
   if (total < 0) return total;
@@ -452,6 +505,47 @@ extern "C" int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera*
                      reinterpret_cast<const int32_t*>(d + o_pt), reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<const int*>(d + o_offs),
                      reinterpret_cast<hso_match_brief*>(d + o_out));
   HSO_HIP_CHECK(ctx, hipGetLastError());
+  if (pose) {
+    // job records (poses = the stored maps' keyframe poses, start = the call's pose) and the map index per call: one small
+    // upload; the feature tables are built on the device from the records k_sel_emit just wrote
+    const size_t b_pj = al(sizeof(PoseJobDev) * (size_t)n_calls), b_pp = al(sizeof(hso_se3) * (size_t)n_calls * max_kfs), b_pm = al(sizeof(int) * (size_t)n_calls);
+    char* hp = hso_pinned(ctx, 0, b_pj + b_pp + b_pm);      // slot 0: hso_reproject_maps_run's upload has been enqueued before its kernels above
+    if (!hp) return HSO_E_NOMEM;
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // ... and must have left the staging buffer before it is rewritten
+    PoseJobDev* pj = reinterpret_cast<PoseJobDev*>(hp);
+    hso_se3* pp = reinterpret_cast<hso_se3*>(hp + b_pj);
+    int* pm = reinterpret_cast<int*>(hp + b_pj + b_pp);
+    for (int c = 0; c < n_calls; c++) {
+      const int nk = hso_map_kf_poses(ctx, calls[c].map, pp + (size_t)c * max_kfs);
+      pj[c].feats = reinterpret_cast<const hso_pose_feat*>(d + o_pf) + (size_t)c * feat_cap;
+      pj[c].poses = reinterpret_cast<const hso_se3*>(d + o_pp) + (size_t)c * max_kfs;
+      pj[c].mask = reinterpret_cast<uint8_t*>(d + o_pk) + (size_t)c * feat_cap;
+      pj[c].n_feats = 0; pj[c].n_poses = nk; pj[c].T = calls[c].T_cur_w; pj[c].reproj_thresh = pose->reproj_thresh;
+      pj[c].n_iter = pose->n_iter; pj[c]._pad = 0;
+      pm[c] = calls[c].map;
+    }
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pj, hp, b_pj, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pp, hp + b_pj, b_pp, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pm, hp + b_pj + b_pp, b_pm, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_pose_feats_from_sel, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, *cam, reinterpret_cast<const hso_match_brief*>(d + o_out),
+                       reinterpret_cast<const int*>(d + o_offs), reinterpret_cast<const int*>(d + o_pm), hso_map_points_dev(ctx), hso_map_max_points(ctx),
+                       feat_cap, reinterpret_cast<hso_pose_feat*>(d + o_pf), reinterpret_cast<PoseJobDev*>(d + o_pj),
+                       reinterpret_cast<uint8_t*>(d + o_pk), reinterpret_cast<int*>(d + o_pn));
+    if (int rc = hso_pose_launch_device(ctx, cam, reinterpret_cast<const PoseJobDev*>(d + o_pj), n_calls, feat_cap,
+                                        reinterpret_cast<hso_pose_result*>(d + o_pr))) return rc;
+    char* hr = hso_pinned(ctx, 0, al(sizeof(hso_pose_result) * (size_t)n_calls) + al(sizeof(int) * (size_t)n_calls) + (size_t)n_calls * feat_cap);
+    if (!hr) return HSO_E_NOMEM;
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above have left slot 0
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(hr, d + o_pr, sizeof(hso_pose_result) * (size_t)n_calls, hipMemcpyDeviceToHost, ctx->stream));
+    char* hn = hr + al(sizeof(hso_pose_result) * (size_t)n_calls);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(hn, d + o_pn, sizeof(int) * (size_t)n_calls, hipMemcpyDeviceToHost, ctx->stream));
+    char* hk = hn + al(sizeof(int) * (size_t)n_calls);
+    if (pose->outlier_mask) HSO_HIP_CHECK(ctx, hipMemcpyAsync(hk, d + o_pk, (size_t)n_calls * feat_cap, hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(pose->results, hr, sizeof(hso_pose_result) * (size_t)n_calls);
+    if (pose->n_feats) memcpy(pose->n_feats, hn, sizeof(int) * (size_t)n_calls);
+    if (pose->outlier_mask) memcpy(pose->outlier_mask, hk, (size_t)n_calls * feat_cap);
+  }
   // counts and offsets first (small), then exactly the examined records
   int32_t* hs = reinterpret_cast<int32_t*>(h);
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(hs, d + o_counts, sizeof(int32_t) * 4 * (size_t)n_calls, hipMemcpyDeviceToHost, ctx->stream));
@@ -466,4 +560,21 @@ extern "C" int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera*
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return n_out;
+}
+
+extern "C" int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                                             int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
+                                             int out_capacity, int32_t* begin_out, int32_t* counts_out)
+{
+  return reproject_select_maps_impl(ctx, cam, calls, n_calls, cell_size, grid_n_cols, cell_order, n_cells, max_fts, out, out_capacity, begin_out,
+                                    counts_out, nullptr);
+}
+
+extern "C" int hso_gpu_reproject_select_pose_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                                                  int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
+                                                  int out_capacity, int32_t* begin_out, int32_t* counts_out, const hso_pose_chain* pose)
+{
+  if (!pose) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_maps: null pose argument");
+  return reproject_select_maps_impl(ctx, cam, calls, n_calls, cell_size, grid_n_cols, cell_order, n_cells, max_fts, out, out_capacity, begin_out,
+                                    counts_out, pose);
 }

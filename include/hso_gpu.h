@@ -667,6 +667,25 @@ int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const
                                   int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
                                   int out_capacity, int32_t* begin_out, int32_t* counts_out);
 
+/* The same with pose_optimizer::optimizeLevenbergMarquardt3rd (src/pose_optimizer.cpp:399-771; frame_handler_mono.cpp:241-243)
+ * chained behind the selection on the device: the frame's feature table is built there from the candidates that became
+ * features, in examination order — f = cam2world(px_cur), level = search level, type = ref_type, grad = the record's grad,
+ * host bearing / inverse depth / host keyframe from the stored map, temporary = Point::TYPE_TEMPORARY (quality key >> 4 == 1);
+ * the host keyframes' poses are the stored maps', the start pose the call's T_cur_w — so the 96-byte feature records never
+ * cross PCIe (value-passing form: hso_gpu_pose_optimize_batch).  results[c] and n_feats[c] per call; outlier_mask (may be
+ * NULL): n_calls rows of max(max_fts, 1) bytes, row c holds n_feats[c] flags in feature order. */
+typedef struct hso_pose_chain {
+  double reproj_thresh;        /* Config::poseOptimThresh() = 2.0 */
+  int32_t n_iter;              /* 12 */
+  int32_t pad_;
+  hso_pose_result* results;    /* [n_calls] */
+  int32_t* n_feats;            /* [n_calls], may be NULL */
+  uint8_t* outlier_mask;       /* may be NULL */
+} hso_pose_chain;
+int hso_gpu_reproject_select_pose_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
+                                       int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
+                                       int out_capacity, int32_t* begin_out, int32_t* counts_out, const hso_pose_chain* pose);
+
 /* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
  *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,
  *      fast_corner_score_9, fast_nonmax_3x3 (thirdparty/fast/src) — and hso::shiTomasiScore
