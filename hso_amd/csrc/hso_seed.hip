@@ -7,14 +7,14 @@
 // warp::createPatch :159-196, ZMNCC_F (include/hso/vikit/patch_score.h:268-305),
 // checkNormal :406-440, checkNCC :379-404 and depthFromTriangulation :242-255.
 //
-// MI355X mapping: the reference spreads seeds over 4 CPU threads (IndexThreadReduce,
-// MAPPING_THREADS 4); here every seed is a wavefront and lane = pixel of the 8x8 patch, so the
-// 64-tap patch extraction + ZMNCC of one epipolar step is one 4-tap fetch per lane and three
-// xor-butterfly sums.  The march along the epipolar line is inherently sequential per seed
-// (<= ~104 steps); throughput comes from ~900 seeds per keyframe x many sequences in flight.
-// Geometry (fp64) is uniform over the wave and computed redundantly by all lanes.  The fp32
-// sums are butterflies (reference: serial loops) — rounding-level differences only; result
-// codes and the step index of the best score can differ on near-ties (flagged in the tests).
+// MI355X mapping: the reference spreads seeds over 4 CPU threads (IndexThreadReduce, MAPPING_THREADS 4).  Here the image
+// work of a seed (the 8x8 patch: createPatch, the epipolar ZMNCC march, the two KLT refinements, the checks) runs on a DPP
+// row of 16 lanes, four seeds per wavefront, four patch pixels per lane: a patch sum is three adds and four DPP steps inside
+// the row, the wave-uniform arithmetic of a step serves four seeds, and rows diverge freely (the march is inherently
+// sequential per seed, <= ~104 steps); the fp64 geometry before and after the image work runs one LANE per seed (pre / post
+// phases below).  Throughput comes from thousands of seeds per keyframe x many sequences in flight.  The fp32 sums are tree
+// sums (reference: serial loops) — rounding-level differences only; result codes and the step index of the best score can
+// differ on near-ties (excused by margin in the tests).
 #include "hso_match_dev.h"
 #include <string.h>
 #include <algorithm>
@@ -50,21 +50,42 @@ struct SeedDev {
 
 // wave_sum_all, cam2world_dev and interpolate_8u come from hso_match_dev.h (shared with the matcher)
 
-// One lane's sample of warp::createPatch (matcher.cpp:159-196) at patch pixel (px_, py_), in two halves so that the march
-// can request the bytes of the NEXT step before it does the arithmetic of this one: the fetch is two unaligned 16-bit loads
-// (the two horizontally adjacent pixels of each row) instead of four byte loads.
-struct PatchTaps { unsigned r0, r1; };
-HSO_DEV PatchTaps s_patch_fetch(const uint8_t* img, int stride, double pxs0, double pxs1, int px_, int py_)
+// ---- sixteen lanes per seed ---------------------------------------------------------------------------------------------------
+// The image phase of a seed is 64 patch pixels wide; a wavefront used to spend its 64 lanes on ONE seed, so every wave-uniform
+// instruction of the march (the ZMNCC quotient, the loop tests, the KLT weights and updates: well over half of the ~3700
+// wave-instructions per seed that the SQ counters show, profiles/r3_stage_sq_seed.csv: VALU 100 % busy) served one seed.  Now a
+// DPP row of 16 lanes owns a seed — four seeds per wavefront — and a lane owns four horizontally adjacent pixels of the 8x8
+// patch: the uniform instructions serve four seeds, a patch sum is three adds + four DPP steps inside the row (no cross-row
+// traffic at all), and the rows diverge freely (a row that has finished its march simply drops out of the exec mask).
+// Pixel (px0 + j, py), j = 0..3, of lane l16 = lane & 15: py = l16 >> 1, px0 = (l16 & 1) * 4.
+HSO_DEV float row_sum_all(float v)
+{
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4e, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xb1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
+  return v;   // every lane of the row holds the same bits (each step adds the same two partial sums in both partners)
+}
+HSO_DEV float row_sum4(const float (&v)[4]) { return row_sum_all((v[0] + v[1]) + (v[2] + v[3])); }
+
+// the 5 + 5 bytes a lane's four bilinear samples need: two unaligned 8-byte loads (the rows are followed by at least one
+// padded row + 64 bytes, so the three bytes read beyond the fifth stay inside the frame allocation)
+typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
+HSO_DEV unsigned long long load_px8(const uint8_t* p) { return *(const __attribute__((address_space(1))) u64_unaligned*)p; }
+struct PatchTaps4 { unsigned long long r0, r1; };
+HSO_DEV PatchTaps4 q_patch_fetch(const uint8_t* img, int stride, double pxs0, double pxs1, int px0, int py_)
 {
   const float u = (float)pxs0, v = (float)pxs1;
   const int ui = (int)floorf(u), vi = (int)floorf(v);
-  const uint8_t* c = img + (vi - 4 + py_) * stride + (ui - 4) + px_;
-  PatchTaps t;
-  t.r0 = load_px_pair(c);
-  t.r1 = load_px_pair(c + stride);
+  const uint8_t* c = img + (vi - 4 + py_) * stride + (ui - 4) + px0;
+  PatchTaps4 t;
+  t.r0 = load_px8(c);
+  t.r1 = load_px8(c + stride);
   return t;
 }
-HSO_DEV float s_patch_value(const PatchTaps& t, double pxs0, double pxs1)
+HSO_DEV float byte_f(unsigned long long w, int j) { return (float)(unsigned)((w >> (8 * j)) & 0xffull); }
+// warp::createPatch's bilinear sample (matcher.cpp:159-196) for the lane's four pixels, the reference's expression order
+HSO_DEV void q_patch_values(const PatchTaps4& t, double pxs0, double pxs1, float (&out)[4])
 {
   const float u = (float)pxs0, v = (float)pxs1;
   const int ui = (int)floorf(u), vi = (int)floorf(v);
@@ -73,34 +94,40 @@ HSO_DEV float s_patch_value(const PatchTaps& t, double pxs0, double pxs1)
   const float w_tr = (float)(su * (1.0 - sv));
   const float w_bl = (float)((1.0 - su) * sv);
   const float w_br = (float)(((1.0 - w_tl) - w_tr) - w_bl);
-  return ((w_tl * (float)(t.r0 & 0xffu) + w_tr * (float)(t.r0 >> 8)) + w_bl * (float)(t.r1 & 0xffu)) + w_br * (float)(t.r1 >> 8);
-}
-HSO_DEV float s_patch_sample(const uint8_t* img, int stride, double pxs0, double pxs1, int px_, int py_)
-{
-  return s_patch_value(s_patch_fetch(img, stride, pxs0, pxs1, px_, py_), pxs0, pxs1);
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    out[j] = ((w_tl * byte_f(t.r0, j) + w_tr * byte_f(t.r0, j + 1)) + w_bl * byte_f(t.r1, j)) + w_br * byte_f(t.r1, j + 1);
 }
 
-// Matcher::KLTLimited2D / KLTLimited1D (matcher.cpp:1296-1606), one lane per patch pixel.
+// Matcher::KLTLimited2D / KLTLimited1D (matcher.cpp:1296-1606), a row of 16 lanes per seed, four patch pixels per lane.
 // ONE_D: motion restricted to `d0,d1` (double, as passed by the reference).  Returns the bool.
 template <bool ONE_D>
-HSO_DEV bool s_klt_limited(const uint8_t* img, int cols, int rows, float gxr, float gyr, float ref_px, double d0, double d1,
-                           double& pxs0, double& pxs1, float& last_sample, bool& sampled)
+HSO_DEV bool q_klt_limited(const uint8_t* img, int cols, int rows, const float (&gxr)[4], const float (&gyr)[4], const float (&ref_px)[4],
+                           double d0, double d1, double& pxs0, double& pxs1, float (&last_sample)[4], int px0, int py_)
 {
-  float Jx, Jy = 0;
-  if (ONE_D) Jx = (float)(0.5 * (d0 * (double)gxr + d1 * (double)gyr));
-  else { Jx = (float)(0.5 * (double)gxr); Jy = (float)(0.5 * (double)gyr); }
-  const float wgt = ONE_D ? sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx))))
-                          : sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx + Jy * Jy))));
+  float Jx[4], Jy[4], wgt[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (ONE_D) { Jx[j] = (float)(0.5 * (d0 * (double)gxr[j] + d1 * (double)gyr[j])); Jy[j] = 0; }
+    else { Jx[j] = (float)(0.5 * (double)gxr[j]); Jy[j] = (float)(0.5 * (double)gyr[j]); }
+    wgt[j] = ONE_D ? sqrtf((float)(250.0 / (250.0 + (double)(Jx[j] * Jx[j]))))
+                   : sqrtf((float)(250.0 / (250.0 + (double)(Jx[j] * Jx[j] + Jy[j] * Jy[j]))));
+  }
   float Hi[9];
   {
-    const float h_xx = wave_sum_all((Jx * Jx) * wgt), h_x1 = wave_sum_all((Jx * 1.0f) * wgt), h_11 = wave_sum_all((1.0f * 1.0f) * wgt);
+    float t0[4], t1[4], t2[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { t0[j] = (Jx[j] * Jx[j]) * wgt[j]; t1[j] = (Jx[j] * 1.0f) * wgt[j]; t2[j] = (1.0f * 1.0f) * wgt[j]; }
+    const float h_xx = row_sum4(t0), h_x1 = row_sum4(t1), h_11 = row_sum4(t2);
     if (ONE_D) {
       const float H00 = (float)((double)h_xx * (1 + 0.001)), H11 = (float)((double)h_11 * (1 + 0.001)), H01 = h_x1;
       const float det = H00 * H11 - H01 * H01;
       const float invdet = 1.0f / det;
       Hi[0] = H11 * invdet; Hi[1] = -H01 * invdet; Hi[3] = -H01 * invdet; Hi[4] = H00 * invdet;
     } else {
-      const float h_xy = wave_sum_all((Jx * Jy) * wgt), h_yy = wave_sum_all((Jy * Jy) * wgt), h_y1 = wave_sum_all((Jy * 1.0f) * wgt);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { t0[j] = (Jx[j] * Jy[j]) * wgt[j]; t1[j] = (Jy[j] * Jy[j]) * wgt[j]; t2[j] = (Jy[j] * 1.0f) * wgt[j]; }
+      const float h_xy = row_sum4(t0), h_yy = row_sum4(t1), h_y1 = row_sum4(t2);
       const float H0 = (float)((double)h_xx * (1 + 0.001)), H4 = (float)((double)h_yy * (1 + 0.001)), H8 = (float)((double)h_11 * (1 + 0.001));
       const float H1 = h_xy, H2 = h_x1, H5 = h_y1, H3 = H1, H6 = H2, H7 = H5;
       const float c00 = H4 * H8 - H5 * H7, c01 = H5 * H6 - H3 * H8, c02 = H3 * H7 - H4 * H6;
@@ -111,7 +138,6 @@ HSO_DEV bool s_klt_limited(const uint8_t* img, int cols, int rows, float gxr, fl
       Hi[2] = (H1 * H5 - H2 * H4) * invdet; Hi[5] = (H2 * H3 - H0 * H5) * invdet; Hi[8] = (H0 * H4 - H1 * H3) * invdet;
     }
   }
-  const int lane = threadIdx.x & 63, px_ = lane & 7, py_ = lane >> 3;
   float mean_diff = 0;
   float bestU = (float)pxs0, bestV = (float)pxs1;
   float bestEnergy = 1e8f;
@@ -123,16 +149,21 @@ HSO_DEV bool s_klt_limited(const uint8_t* img, int cols, int rows, float gxr, fl
     if (isnan(bestU) || isnan(bestV)) return false;
     const float sx = bestU - (float)u_r, sy = bestV - (float)v_r;
     const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy), wBR = sx * sy;
-    const uint8_t* it = img + (v_r + py_ - 4) * cols + u_r - 4 + px_;
-    const unsigned it0 = load_px_pair(it), it1 = load_px_pair(it + cols);
-    const float sp = ((wTL * (float)(it0 & 0xffu) + wTR * (float)(it0 >> 8)) + wBL * (float)(it1 & 0xffu)) + wBR * (float)(it1 >> 8);
-    last_sample = sp; sampled = true;
-    const float res = (sp - ref_px) + mean_diff;
-    const float j0 = -wave_sum_all((res * Jx) * wgt);
-    const float j2 = -wave_sum_all(res * wgt);
-    const float energy = wave_sum_all((res * res) * wgt);
+    const uint8_t* it = img + (v_r + py_ - 4) * cols + u_r - 4 + px0;
+    const unsigned long long it0 = load_px8(it), it1 = load_px8(it + cols);
+    float a0[4], a1[4], a2[4], a3[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float sp = ((wTL * byte_f(it0, j) + wTR * byte_f(it0, j + 1)) + wBL * byte_f(it1, j)) + wBR * byte_f(it1, j + 1);
+      last_sample[j] = sp;
+      const float res = (sp - ref_px[j]) + mean_diff;
+      a0[j] = (res * Jx[j]) * wgt[j]; a1[j] = res * wgt[j]; a2[j] = (res * res) * wgt[j]; a3[j] = (res * Jy[j]) * wgt[j];
+    }
+    const float j0 = -row_sum4(a0);
+    const float j2 = -row_sum4(a1);
+    const float energy = row_sum4(a2);
     float j1 = 0;
-    if (!ONE_D) j1 = -wave_sum_all((res * Jy) * wgt);
+    if (!ONE_D) j1 = -row_sum4(a3);
     if (energy > bestEnergy) {
       sb0 *= 0.5f; sb1 *= 0.5f; sb2 *= 0.5f;
       if (ONE_D) { bestU = (float)((double)uBak + (double)sb0 * d0); bestV = (float)((double)vBak + (double)sb0 * d1); mean_diff = meanBak + sb1; }
@@ -301,10 +332,11 @@ HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrame
   return P;
 }
 
+// the image phase of ONE seed on ONE DPP row of 16 lanes (see "sixteen lanes per seed" above); pwb_lds: 100 floats private to the row
 HSO_DEV SeedMid seed_wave(const SeedConsts& C, const SeedDev& SD, const uint8_t* cur_base, const SeedPre& P, float* pwb_lds)
 {
   const hso_seed& S = SD.s;
-  const int lane = threadIdx.x & 63;
+  const int l16 = threadIdx.x & 15;
   const int W = C.g.w[0], H = C.g.h[0];
   SeedMid M;
   M.px0 = M.px1 = 0; M.zmncc_best = M.zmncc_second = 0; M.n_steps = 0; M.res_code = -4;
@@ -324,7 +356,7 @@ HSO_DEV SeedMid seed_wave(const SeedConsts& C, const SeedDev& SD, const uint8_t*
       const uint8_t* img = SD.ref_base + C.g.off[L];
       const float rx = (float)(S.px[0] / (double)(1 << L)), ry = (float)(S.px[1] / (double)(1 << L));
       const float scaleTarget = (float)(1 << sl);
-      for (int idx = lane; idx < 100; idx += 64) {
+      for (int idx = l16; idx < 100; idx += 16) {
         const int y = idx / 10, x = idx - 10 * y;
         float p0 = (float)(x - 5), p1 = (float)(y - 5);
         p0 *= scaleTarget; p1 *= scaleTarget;
@@ -335,41 +367,48 @@ HSO_DEV SeedMid seed_wave(const SeedConsts& C, const SeedDev& SD, const uint8_t*
         pwb_lds[idx] = val;
       }
     }
-    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int px_ = lane & 7, py_ = lane >> 3;
+    const int px0 = (l16 & 1) * 4, py_ = l16 >> 1;
     const float* pwb = pwb_lds;
-    const int c = (py_ + 1) * 10 + px_ + 1;
-    const float ref_px = pwb[c];
-    const float gxr = pwb[c + 1] - pwb[c - 1], gyr = pwb[c + 10] - pwb[c - 10];
+    float ref_px[4], gxr[4], gyr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = (py_ + 1) * 10 + px0 + j + 1;
+      ref_px[j] = pwb[c];
+      gxr[j] = pwb[c + 1] - pwb[c - 1]; gyr[j] = pwb[c + 10] - pwb[c - 10];
+    }
 
     // ---- march along the epipolar line, ZMNCC per step (:906-960)
     const int cols = C.g.w[sl], rows = C.g.h[sl];
     const uint8_t* cur = cur_base + C.g.off[sl];
-    const float hostMean = wave_sum_all(ref_px) / 64;
-    const float hdev = ref_px - hostMean;
-    const float d1 = wave_sum_all(hdev * hdev);
+    const float hostMean = row_sum4(ref_px) / 64;
+    float hdev[4], hh[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { hdev[j] = ref_px[j] - hostMean; hh[j] = hdev[j] * hdev[j]; }
+    const float d1 = row_sum4(hh);
     float zmncc_best = 0.1f, zmncc_second = 0.1f;
     double uvb0 = 0, uvb1 = 0;
     int loopCounter = 0, loopCBest = -1, loopCSecond = -1;
     double cpx = pxf0, cpy = pxf1;
     // the steps are independent and their positions known in advance: the bytes of step k+1 are requested before the three
-    // dependent wave sums of step k, so the march pays one memory latency per step less (positions are wave-uniform)
+    // dependent row sums of step k, so the march pays one memory latency per step less (positions are uniform over the row)
     const int lim_x = W / (1 << sl) - 8, lim_y = H / (1 << sl) - 8;
     auto in_image = [&](double x, double y) { const int ox = (int)x, oy = (int)y; return ox >= 8 && ox < lim_x && oy >= 8 && oy < lim_y; };
     bool have = in_image(cpx, cpy);
-    PatchTaps taps = { 0, 0 };
-    if (have) taps = s_patch_fetch(cur, cols, cpx, cpy, px_, py_);
+    PatchTaps4 taps = { 0, 0 };
+    if (have) taps = q_patch_fetch(cur, cols, cpx, cpy, px0, py_);
     while ((((incx < 0) == (cpx > pxc0)) && ((incy < 0) == (cpy > pxc1))) || loopCounter == 0) {
       const double nx = cpx + incx, ny = cpy + incy;
       const bool have_next = in_image(nx, ny);
-      PatchTaps taps_next = { 0, 0 };
-      if (have_next) taps_next = s_patch_fetch(cur, cols, nx, ny, px_, py_);
+      PatchTaps4 taps_next = { 0, 0 };
+      if (have_next) taps_next = q_patch_fetch(cur, cols, nx, ny, px0, py_);
       if (have) {
-        const float sp = s_patch_value(taps, cpx, cpy);
-        const float tmean = wave_sum_all(sp) / 64;
-        const float t = sp - tmean;
-        const float num = wave_sum_all(hdev * t), d2 = wave_sum_all(t * t);
+        float sp[4], t[4], ht[4], tt[4];
+        q_patch_values(taps, cpx, cpy, sp);
+        const float tmean = row_sum4(sp) / 64;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { t[j] = sp[j] - tmean; ht[j] = hdev[j] * t[j]; tt[j] = t[j] * t[j]; }
+        const float num = row_sum4(ht), d2 = row_sum4(tt);
         const float zmncc = (float)((double)num / ((double)sqrtf(d1 * d2) + 1e-12));
         if (zmncc > zmncc_best) {
           zmncc_second = zmncc_best; uvb0 = cpx; uvb1 = cpy; zmncc_best = zmncc;
@@ -389,14 +428,14 @@ HSO_DEV SeedMid seed_wave(const SeedConsts& C, const SeedDev& SD, const uint8_t*
     // ---- refinement (:966-1046)
     double pxcur0 = uvb0 * (double)(1 << sl), pxcur1 = uvb1 * (double)(1 << sl);
     double ps0 = pxcur0 / (double)(1 << sl), ps1 = pxcur1 / (double)(1 << sl);
-    float samp = 0; bool sampled = false;
-    bool result = s_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, ed0, ed1, ps0, ps1, samp, sampled);
+    float samp[4] = { 0, 0, 0, 0 };
+    bool result = q_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, ed0, ed1, ps0, ps1, samp, px0, py_);
     if (!result) { ps0 = pxcur0 / (double)(1 << sl); ps1 = pxcur1 / (double)(1 << sl); }
-    samp = 0; sampled = false;  // patch2D: written only by the second KLT (zero where the reference leaves it uninitialised)
+    samp[0] = samp[1] = samp[2] = samp[3] = 0;  // patch2D: written only by the second KLT (zero where the reference leaves it uninitialised)
     if (S.type != HSO_FTR_EDGELET) {
-      result = s_klt_limited<false>(cur, cols, rows, gxr, gyr, ref_px, 0, 0, ps0, ps1, samp, sampled);
+      result = q_klt_limited<false>(cur, cols, rows, gxr, gyr, ref_px, 0, 0, ps0, ps1, samp, px0, py_);
     } else {
-      result = s_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, dc0, dc1, ps0, ps1, samp, sampled);
+      result = q_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, dc0, dc1, ps0, ps1, samp, px0, py_);
       if (result) {
         // Matcher::checkNormal(cur_frame, search_level_, px, dir_cur, 0.7), :406-440
         const int16_t* gx = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][0]);
@@ -424,9 +463,11 @@ HSO_DEV SeedMid seed_wave(const SeedConsts& C, const SeedDev& SD, const uint8_t*
     }
     if (result) {
       // Matcher::checkNCC(patch_f_, patch2D, 0.8), :379-404
-      const float mean1 = wave_sum_all(ref_px) / 64, mean2 = wave_sum_all(samp) / 64;
-      const float q1 = ref_px - mean1, q2 = samp - mean2;
-      const float num = wave_sum_all(q1 * q2), den1 = wave_sum_all(q1 * q1), den2 = wave_sum_all(q2 * q2);
+      const float mean1 = row_sum4(ref_px) / 64, mean2 = row_sum4(samp) / 64;
+      float qq[4], q11[4], q22[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const float q1 = ref_px[j] - mean1, q2 = samp[j] - mean2; qq[j] = q1 * q2; q11[j] = q1 * q1; q22[j] = q2 * q2; }
+      const float num = row_sum4(qq), den1 = row_sum4(q11), den2 = row_sum4(q22);
       result = ((double)num / ((double)sqrtf(den1 * den2) + 1e-12)) > (double)(float)0.8;
     }
     if (!result) { res_code = -3; break; }
@@ -511,7 +552,7 @@ HSO_DEV hso_seed_out seed_post(const SeedConsts& C, const SeedDev& SD, const See
 __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(SeedConsts C, SeedDev* seeds, int n_seeds,
                                                                              hso_seed_out* outs, int cpw)
 {
-  __shared__ float s_pwb[SEED_WAVES_PER_BLOCK][100];
+  __shared__ float s_pwb[SEED_WAVES_PER_BLOCK][4][100];
   __shared__ SeedPre s_pre[SEED_WAVES_PER_BLOCK][SEED_CPW_MAX];
   __shared__ SeedMid s_mid[SEED_WAVES_PER_BLOCK][SEED_CPW_MAX];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -523,15 +564,17 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
   if (live) s_pre[wave][lane] = seed_pre(C, seeds[mine], C.frames[seeds[mine].frame]);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (int q = 0; q < cpw; q++) {
+  // image phase: row r of the wavefront (16 lanes) walks seeds r, r + 4, r + 8, ... of the wave's group on its own
+  const int row = lane >> 4;
+  for (int q = row; q < cpw; q += 4) {
     const int sid = first + q;
     if (sid >= n_seeds) break;
     const SeedDev& SD = seeds[sid];
     if (SD.ref_base == nullptr || s_pre[wave][q].state != 0) continue;
     const uint8_t* const cur_base = SD.cur_base ? SD.cur_base : C.frames[SD.frame].cur_base;
-    const SeedMid M = seed_wave(C, SD, cur_base, s_pre[wave][q], s_pwb[wave]);
-    if (lane == 0) s_mid[wave][q] = M;
-    __builtin_amdgcn_wave_barrier();                          // the next seed overwrites this wave's patch
+    const SeedMid M = seed_wave(C, SD, cur_base, s_pre[wave][q], s_pwb[wave][row]);
+    if ((lane & 15) == 0) s_mid[wave][q] = M;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the row's next seed overwrites its patch
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -545,11 +588,11 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
   }
 }
 
-// seeds per wave for a batch of n: one per wave until the chip holds ~8 waves per SIMD of them, then doubling (see align_cpw)
+// seeds per wave for a batch of n: four (one per 16-lane row) until the chip holds ~8 waves per SIMD of them, then doubling
 static int seed_cpw(const hso_gpu_ctx* ctx, int n)
 {
   const long long spread = (long long)ctx->n_cu * 4 * 8;
-  int cpw = 1;
+  int cpw = 4;
   while (cpw < SEED_CPW_MAX && (long long)n > spread * cpw) cpw *= 2;
   return cpw;
 }

@@ -163,16 +163,20 @@ def test_pose_chained_behind_the_selection_equals_the_value_passing_optimiser(gp
                 (rv,), (mv,) = gpu_ctx.pose_optimize_batch(cam, [job])
                 g = res[c]
                 assert (g.status, g.iters, g.n_trials_total, g.num_obs, g.n_deleted) == (rv.status, rv.iters, rv.n_trials_total, rv.num_obs, rv.n_deleted)
-                assert np.allclose(g.T_f_w.q[:], rv.T_f_w.q[:], atol=1e-9, rtol=0) and np.allclose(g.T_f_w.t[:], rv.T_f_w.t[:], atol=1e-9, rtol=0)
-                assert np.array_equal(mask[c, :nf[c]], mv) and g.estimated_scale == pytest.approx(rv.estimated_scale, rel=1e-9)
+                # radtan: cam2world runs OpenCV's five fp32 undistortion iterations (src/camera.cpp:78-85), which host and device round
+                # differently at the 1e-7 level of the bearing (tests/test_reproject.py): the host-built table differs from the
+                # device-built one by that much, and the poses by 1e-8
+                tol = 1e-9 if spec is synth.ICL_NUIM else 5e-8
+                assert np.allclose(g.T_f_w.q[:], rv.T_f_w.q[:], atol=tol, rtol=0) and np.allclose(g.T_f_w.t[:], rv.T_f_w.t[:], atol=tol, rtol=0)
+                assert np.array_equal(mask[c, :nf[c]], mv) and g.estimated_scale == pytest.approx(rv.estimated_scale, rel=100 * tol)
                 # the restatement on the same table
                 orc.margins_reset()
                 ro, mo = orc.pose_optimize(cam, job)
                 mg = orc.margins()
-                if (g.iters, g.n_trials_total) != (ro.iters, ro.n_trials_total):
+                if (rv.iters, rv.n_trials_total) != (ro.iters, ro.n_trials_total):
                     assert mg.pose_rho < 1e-12
-                assert np.allclose(g.T_f_w.q[:], ro.T_f_w.q[:], atol=1e-9, rtol=0) and np.allclose(g.T_f_w.t[:], ro.T_f_w.t[:], atol=1e-9, rtol=0)
-                assert np.array_equal(mask[c, :nf[c]], mo)
+                assert np.allclose(rv.T_f_w.q[:], ro.T_f_w.q[:], atol=1e-9, rtol=0) and np.allclose(rv.T_f_w.t[:], ro.T_f_w.t[:], atol=1e-9, rtol=0)
+                assert np.array_equal(mv, mo)
             assert int((P["points"]["pad_"][out[out["success"] == 1]["pad_"]] >> 4 == 1).sum()) > 5      # temporary points took part
         finally:
             for i in ids + [P["cur_frame_id"]]:
