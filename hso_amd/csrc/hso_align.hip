@@ -9,16 +9,13 @@
 // align1D(float) :164-308, Matcher::checkNCC :379-404, checkNormal :406-440,
 // hso::interpolateMat_8u include/hso/vikit/vision.h:49-65.
 //
-// MI355X mapping: one wavefront per candidate, lane = pixel of the 8x8 patch (64 lanes = 64
-// pixels, the reason this path is a natural fit for wave64).  The per-candidate geometry
-// (fp64 warp matrix, search level) is computed redundantly by all lanes — it is uniform, so
-// there is no divergence and no broadcast; the 10x10 warped patch lives in LDS; every LK
-// iteration is one 4-tap bilinear fetch per lane + xor-butterfly sums (all lanes end with
-// identical bits, so the iteration state stays uniform).  The reference accumulates the same
-// sums serially in fp32; the butterfly order differs from it by rounding only (stated
-// tolerance: 1e-3 px on the result).  HBM-bound in principle (100 + <=640
-// taps per candidate); in practice latency-bound per candidate and throughput comes from
-// having thousands of candidates in flight.
+// MI355X mapping: a DPP row of 16 lanes per candidate, four candidates per wavefront, four pixels of the 8x8 patch per lane
+// (hso_match_dev.h).  The per-candidate geometry (fp64 warp matrix, search level) is computed one LANE per candidate for the
+// wave's whole group first; the 10x10 warped patch lives in LDS; every LK iteration is two 8-byte loads per lane + row sums
+// (three adds + four DPP steps; all lanes of a row end with identical bits, so the iteration state stays uniform per row and
+// rows diverge freely).  The reference accumulates the same sums serially in fp32; the tree order differs from it by rounding
+// only (stated tolerance: 1e-3 px on the result).  Instruction-issue-bound (profiles/r3_stage_sq_align.csv:
+// VALU 100 % busy with one candidate per wave), hence the packing.
 #include "hso_match_dev.h"
 #include <string.h>
 #include <vector>
@@ -47,7 +44,7 @@ template <bool SPARSE>
 __global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align_t(AlignConsts C, const AlignJobDev* jobs, int n_jobs,
                                                                          hso_align_out* outs, int cpw)
 {
-  __shared__ float s_pwb[ALIGN_WAVES_PER_BLOCK][100];
+  __shared__ float s_pwb[ALIGN_WAVES_PER_BLOCK][4][100];
   __shared__ MatchGeom s_geom[ALIGN_WAVES_PER_BLOCK][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int first = (blockIdx.x * ALIGN_WAVES_PER_BLOCK + wave) * cpw;
@@ -58,22 +55,24 @@ __global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align_t(AlignCon
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (int q = 0; q < cpw; q++) {
+  // phase 2: row r of the wavefront (16 lanes) walks candidates r, r + 4, r + 8, ... of the wave's group on its own
+  const int row = lane >> 4;
+  for (int q = row; q < cpw; q += 4) {
     const int jid = first + q;
     if (jid >= n_jobs) break;
     const AlignJobDev& JD = jobs[jid];
     if (SPARSE && JD.ref_base == nullptr) continue;    // outs was zeroed
-    const hso_align_out o = match_patch(C.g, JD.cur_base, JD.ref_base, JD.j, s_geom[wave][q], (double)0.7f, s_pwb[wave]);  // checkNCC(…, 0.7), :364
-    if (lane == 0) outs[jid] = o;
-    __builtin_amdgcn_wave_barrier();                   // the next candidate overwrites this wave's patch
+    const hso_align_out o = match_patch(C.g, JD.cur_base, JD.ref_base, JD.j, s_geom[wave][q], (double)0.7f, s_pwb[wave][row]);  // checkNCC(…, 0.7), :364
+    if ((lane & 15) == 0) outs[jid] = o;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the row's next candidate overwrites its patch
   }
 }
 
-// candidates per wave for a batch of n: one per wave until the chip holds ~8 waves per SIMD of them, then doubling
+// candidates per wave for a batch of n: four (one per 16-lane row) until the chip holds ~8 waves per SIMD of them, then doubling
 static int align_cpw(const hso_gpu_ctx* ctx, int n)
 {
   const long long spread = (long long)ctx->n_cu * 4 * 8;
-  int cpw = 1;
+  int cpw = 4;
   while (cpw < 64 && (long long)n > spread * cpw) cpw *= 2;
   return cpw;
 }

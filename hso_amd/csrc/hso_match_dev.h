@@ -1,7 +1,8 @@
 // hso_match_dev.h — device-side Matcher::findMatchDirect / findMatchSeed body shared by the
 // reprojection-matching kernel (hso_align.hip) and the seed-activation kernels (hso_activate.hip).
-// One wavefront executes match_one(); lane = pixel of the 8x8 patch.  See hso_align.hip for the
-// reference citations of each step.
+// A DPP row of 16 lanes executes match_patch() for one candidate (four pixels of the 8x8 patch per lane), so a wavefront
+// matches four candidates at once; match_one() is the one-candidate-per-wave form (its four rows do the same candidate).
+// See hso_align.hip for the reference citations of each step.
 #pragma once
 #include "hso_ctx.h"
 #include "hso_dev_math.h"
@@ -50,6 +51,24 @@ HSO_DEV void cam2world_dev(const hso_camera& cam, double u, double v, double f[3
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 // (the images live in device memory: say so, or the access is a FLAT load that has to resolve the aperture first)
 HSO_DEV unsigned load_px_pair(const uint8_t* p) { return *(const __attribute__((address_space(1))) u16_unaligned*)p; }
+
+// ---- sixteen lanes per patch: a DPP row owns an 8x8 patch, a lane four horizontally adjacent pixels of it (pixel (px0 + j, py),
+// j = 0..3, of lane l16 = lane & 15: py = l16 >> 1, px0 = (l16 & 1) * 4).  Four patches per wavefront, sums inside the row.
+HSO_DEV float row_sum_all(float v)
+{
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4e, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xb1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
+  return v;   // every lane of the row holds the same bits (each step adds the same two partial sums in both partners)
+}
+HSO_DEV float row_sum4(const float (&v)[4]) { return row_sum_all((v[0] + v[1]) + (v[2] + v[3])); }
+
+// the 5 + 5 bytes a lane's four bilinear samples need: two unaligned 8-byte loads (the rows are followed by at least one
+// padded row + 64 bytes, so the three bytes read beyond the fifth stay inside the frame allocation)
+typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
+HSO_DEV unsigned long long load_px8(const uint8_t* p) { return *(const __attribute__((address_space(1))) u64_unaligned*)p; }
+HSO_DEV float byte_f(unsigned long long w, int j) { return (float)(unsigned)((w >> (8 * j)) & 0xffull); }
 
 // hso::interpolateMat_8u, include/hso/vikit/vision.h:49-65
 HSO_DEV float interpolate_8u(const uint8_t* data, int stride, float u, float v)
@@ -125,11 +144,14 @@ HSO_DEV MatchGeom match_geometry(const hso_camera& cam, const PyrGeom& g, const 
 
 // Matcher::findMatchDirect after the reference feature has been chosen (src/matcher.cpp:286-375), given the candidate's
 // geometry; findMatchSeed (:442-518) is the same body with ncc_thresh = 0.8 and J.kf_gap_lt4 = 1.
-// One wavefront, lane = pixel of the 8x8 patch.  pwb_lds: 100 floats of LDS private to this wavefront.
+// One DPP row of 16 lanes, four pixels of the 8x8 patch per lane.  pwb_lds: 100 floats of LDS private to this row.
+// The wave-uniform arithmetic of the LK loop (weights, the 3x3 update, the convergence test) used to serve one candidate per
+// wave-instruction — k_align_t ran at 100 % VALU busy with ~1100 wave-instructions per candidate, most of them uniform
+// (profiles/r3_stage_sq_align.csv); now it serves four, and a patch sum is three adds + four DPP steps.
 HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, const uint8_t* ref_base,
                                   const hso_align_job& J, const MatchGeom& G, double ncc_thresh, float* pwb_lds)
 {
-  const int lane = threadIdx.x & 63;
+  const int l16 = threadIdx.x & 15;
   hso_align_out o;
   o.success = 0; o.stage = HSO_ALIGN_OK; o.search_level = 0; o.iters = 0;
   o.px_cur[0] = J.px_cur[0]; o.px_cur[1] = J.px_cur[1];
@@ -154,7 +176,7 @@ HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, con
     const float rx = (float)(J.px_ref[0] / (double)(1 << L)), ry = (float)(J.px_ref[1] / (double)(1 << L));
     const float scaleTarget = (float)(1 << search_level);
     const bool scale_exposure = J.kf_gap_lt4 && fabsf(J.exposure_rat * 128 - 128) > 30.0f;  // :317-320, LIGHT_THRESHOLD
-    for (int idx = lane; idx < 100; idx += 64) {
+    for (int idx = l16; idx < 100; idx += 16) {
       const int y = idx / 10, x = idx - 10 * y;
       float p0 = (float)(x - 5), p1 = (float)(y - 5);
       p0 *= scaleTarget; p1 *= scaleTarget;
@@ -167,38 +189,46 @@ HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, con
       pwb_lds[idx] = val;
     }
   }
-  __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
   // ---- template gradients, weights, Hessian (align2D :483-512 / align1D :183-207)
-  const int px_ = lane & 7, py_ = lane >> 3;
+  const int px0_ = (l16 & 1) * 4, py_ = l16 >> 1;
   const float* pwb = pwb_lds;
-  const int c = (py_ + 1) * 10 + px_ + 1;
-  const float ref_px = pwb[c];
-  const float gxr = pwb[c + 1] - pwb[c - 1], gyr = pwb[c + 10] - pwb[c - 10];
+  float ref_px[4], gxr[4], gyr[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = (py_ + 1) * 10 + px0_ + j + 1;
+    ref_px[j] = pwb[c];
+    gxr[j] = pwb[c + 1] - pwb[c - 1]; gyr[j] = pwb[c + 10] - pwb[c - 10];
+  }
   const bool edgelet = (J.type == HSO_FTR_EDGELET);
   double dir0 = 0, dir1 = 0;
   float dirf0 = 0, dirf1 = 0;
-  float Jx, Jy;  // align2D: (dx, dy); align1D: (dv, unused)
   if (edgelet) {
     dir0 = A00 * J.grad[0] + A01 * J.grad[1];
     dir1 = A10 * J.grad[0] + A11 * J.grad[1];
     const double dn = sqrt(dir0 * dir0 + dir1 * dir1);
     dir0 /= dn; dir1 /= dn;
     dirf0 = (float)dir0; dirf1 = (float)dir1;
-    Jx = (float)(0.5 * (double)(dirf0 * gxr + dirf1 * gyr));
-    Jy = 0;
-  } else {
-    Jx = (float)(0.5 * (double)gxr);
-    Jy = (float)(0.5 * (double)gyr);
   }
-  const float wgt = edgelet ? sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx))))
-                            : sqrtf((float)(250.0 / (250.0 + (double)(Jx * Jx + Jy * Jy))));
+  float Jx[4], Jy[4], wgt[4];  // align2D: (dx, dy); align1D: (dv, unused)
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (edgelet) { Jx[j] = (float)(0.5 * (double)(dirf0 * gxr[j] + dirf1 * gyr[j])); Jy[j] = 0; }
+    else { Jx[j] = (float)(0.5 * (double)gxr[j]); Jy[j] = (float)(0.5 * (double)gyr[j]); }
+    wgt[j] = edgelet ? sqrtf((float)(250.0 / (250.0 + (double)(Jx[j] * Jx[j]))))
+                     : sqrtf((float)(250.0 / (250.0 + (double)(Jx[j] * Jx[j] + Jy[j] * Jy[j]))));
+  }
   float Hi[9];  // align2D: 3x3; align1D: [0],[1],[3],[4] used as 2x2 over (dv, 1)
-  float h_xx = wave_sum_all((Jx * Jx) * wgt), h_x1 = wave_sum_all((Jx * 1.0f) * wgt), h_11 = wave_sum_all((1.0f * 1.0f) * wgt);
+  float t0[4], t1[4], t2[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { t0[j] = (Jx[j] * Jx[j]) * wgt[j]; t1[j] = (Jx[j] * 1.0f) * wgt[j]; t2[j] = (1.0f * 1.0f) * wgt[j]; }
+  float h_xx = row_sum4(t0), h_x1 = row_sum4(t1), h_11 = row_sum4(t2);
   float h_xy = 0, h_yy = 0, h_y1 = 0;
   if (!edgelet) {
-    h_xy = wave_sum_all((Jx * Jy) * wgt); h_yy = wave_sum_all((Jy * Jy) * wgt); h_y1 = wave_sum_all((Jy * 1.0f) * wgt);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { t0[j] = (Jx[j] * Jy[j]) * wgt[j]; t1[j] = (Jy[j] * Jy[j]) * wgt[j]; t2[j] = (Jy[j] * 1.0f) * wgt[j]; }
+    h_xy = row_sum4(t0); h_yy = row_sum4(t1); h_y1 = row_sum4(t2);
   }
   if (edgelet) {
     float H00 = h_xx, H01 = h_x1, H11 = h_11;
@@ -226,7 +256,8 @@ HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, con
   const double orig0 = pxs0, orig1 = pxs1;
   float u = (float)pxs0, v = (float)pxs1;
   const float min_update_squared = edgelet ? (float)(0.01 * 0.01) : (float)(0.03 * 0.03);
-  float mean_diff = 0, chi2 = 0, search_pixel = 0;
+  float mean_diff = 0, chi2 = 0;
+  float search_pixel[4] = { 0, 0, 0, 0 };
   bool converged = false, nan_exit = false;
   int iter = 0;
   for (iter = 0; iter < 10; ++iter) {  // options_.align_max_iter, matcher.h:124
@@ -238,20 +269,25 @@ HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, con
     const float wTR = (float)(sx * (1.0 - sy));
     const float wBL = (float)((1.0 - sx) * sy);
     const float wBR = sx * sy;
-    const uint8_t* it = cur + (v_r + py_ - halfpatch_size_) * cols + u_r - halfpatch_size_ + px_;
-    const unsigned it0 = load_px_pair(it), it1 = load_px_pair(it + cols);
-    search_pixel = ((wTL * (float)(it0 & 0xffu) + wTR * (float)(it0 >> 8)) + wBL * (float)(it1 & 0xffu)) + wBR * (float)(it1 >> 8);
-    const float res = (search_pixel - ref_px) + mean_diff;
-    const float j0 = wave_sum_all((res * Jx) * wgt);
-    const float j2 = wave_sum_all(res * wgt);
-    chi2 = wave_sum_all((res * res) * wgt);
+    const uint8_t* it = cur + (v_r + py_ - halfpatch_size_) * cols + u_r - halfpatch_size_ + px0_;
+    const unsigned long long it0 = load_px8(it), it1 = load_px8(it + cols);
+    float a0[4], a1[4], a2[4], a3[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      search_pixel[j] = ((wTL * byte_f(it0, j) + wTR * byte_f(it0, j + 1)) + wBL * byte_f(it1, j)) + wBR * byte_f(it1, j + 1);
+      const float res = (search_pixel[j] - ref_px[j]) + mean_diff;
+      a0[j] = (res * Jx[j]) * wgt[j]; a1[j] = res * wgt[j]; a2[j] = (res * res) * wgt[j]; a3[j] = (res * Jy[j]) * wgt[j];
+    }
+    const float j0 = row_sum4(a0);
+    const float j2 = row_sum4(a1);
+    chi2 = row_sum4(a2);
     if (edgelet) {
       const float J0 = -j0, J1 = -j2;
       const float up0 = Hi[0] * J0 + Hi[1] * J1, up1 = Hi[3] * J0 + Hi[4] * J1;
       u += up0 * dirf0; v += up0 * dirf1; mean_diff += up1;
       if (up0 * up0 < min_update_squared) { converged = true; iter++; break; }
     } else {
-      const float j1 = wave_sum_all((res * Jy) * wgt);
+      const float j1 = row_sum4(a3);
       const float J0 = -j0, J1 = -j1, J2 = -j2;
       const float up0 = (Hi[0] * J0 + Hi[1] * J1) + Hi[2] * J2;
       const float up1 = (Hi[3] * J0 + Hi[4] * J1) + Hi[5] * J2;
@@ -291,9 +327,11 @@ HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, con
 
   // ---- Matcher::checkNCC, :379-404 on (ref patch, last iteration's samples)
   {
-    const float mean1 = wave_sum_all(ref_px) / 64, mean2 = wave_sum_all(search_pixel) / 64;
-    const float d1 = ref_px - mean1, d2 = search_pixel - mean2;
-    const float num = wave_sum_all(d1 * d2), den1 = wave_sum_all(d1 * d1), den2 = wave_sum_all(d2 * d2);
+    const float mean1 = row_sum4(ref_px) / 64, mean2 = row_sum4(search_pixel) / 64;
+    float qq[4], q11[4], q22[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const float d1 = ref_px[j] - mean1, d2 = search_pixel[j] - mean2; qq[j] = d1 * d2; q11[j] = d1 * d1; q22[j] = d2 * d2; }
+    const float num = row_sum4(qq), den1 = row_sum4(q11), den2 = row_sum4(q22);
     const double ncc = (double)num / ((double)sqrtf(den1 * den2) + 1e-12);
     o.ncc = (float)ncc;
     if (ok) {
@@ -312,7 +350,8 @@ HSO_DEV hso_align_out match_patch(const PyrGeom& g, const uint8_t* cur_base, con
   return o;
 }
 
-// geometry by every lane + patch: for the kernels that handle one candidate per wave (seed activation, seed reprojection)
+// geometry by every lane + patch: for the kernels that handle one candidate per wave (seed activation, seed reprojection); the
+// four rows of the wave match the same candidate (identical results; their patch writes coincide)
 HSO_DEV hso_align_out match_one(const hso_camera& cam, const PyrGeom& g, const uint8_t* cur_base, const uint8_t* ref_base,
                                 const hso_align_job& J, double ncc_thresh, float* pwb_lds)
 {

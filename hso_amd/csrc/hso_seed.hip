@@ -48,7 +48,7 @@ struct SeedDev {
   hso_seed s;
 };
 
-// wave_sum_all, cam2world_dev and interpolate_8u come from hso_match_dev.h (shared with the matcher)
+// row_sum_all / row_sum4, load_px8 / byte_f, cam2world_dev and interpolate_8u come from hso_match_dev.h (shared with the matcher)
 
 // ---- sixteen lanes per seed ---------------------------------------------------------------------------------------------------
 // The image phase of a seed is 64 patch pixels wide; a wavefront used to spend its 64 lanes on ONE seed, so every wave-uniform
@@ -58,20 +58,6 @@ struct SeedDev {
 // patch: the uniform instructions serve four seeds, a patch sum is three adds + four DPP steps inside the row (no cross-row
 // traffic at all), and the rows diverge freely (a row that has finished its march simply drops out of the exec mask).
 // Pixel (px0 + j, py), j = 0..3, of lane l16 = lane & 15: py = l16 >> 1, px0 = (l16 & 1) * 4.
-HSO_DEV float row_sum_all(float v)
-{
-  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));   // row_ror:8
-  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));   // row_ror:4
-  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4e, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
-  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xb1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
-  return v;   // every lane of the row holds the same bits (each step adds the same two partial sums in both partners)
-}
-HSO_DEV float row_sum4(const float (&v)[4]) { return row_sum_all((v[0] + v[1]) + (v[2] + v[3])); }
-
-// the 5 + 5 bytes a lane's four bilinear samples need: two unaligned 8-byte loads (the rows are followed by at least one
-// padded row + 64 bytes, so the three bytes read beyond the fifth stay inside the frame allocation)
-typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
-HSO_DEV unsigned long long load_px8(const uint8_t* p) { return *(const __attribute__((address_space(1))) u64_unaligned*)p; }
 struct PatchTaps4 { unsigned long long r0, r1; };
 HSO_DEV PatchTaps4 q_patch_fetch(const uint8_t* img, int stride, double pxs0, double pxs1, int px0, int py_)
 {
@@ -83,7 +69,6 @@ HSO_DEV PatchTaps4 q_patch_fetch(const uint8_t* img, int stride, double pxs0, do
   t.r1 = load_px8(c + stride);
   return t;
 }
-HSO_DEV float byte_f(unsigned long long w, int j) { return (float)(unsigned)((w >> (8 * j)) & 0xffull); }
 // warp::createPatch's bilinear sample (matcher.cpp:159-196) for the lane's four pixels, the reference's expression order
 HSO_DEV void q_patch_values(const PatchTaps4& t, double pxs0, double pxs1, float (&out)[4])
 {

@@ -165,8 +165,8 @@ def test_pose_chained_behind_the_selection_equals_the_value_passing_optimiser(gp
                 assert (g.status, g.iters, g.n_trials_total, g.num_obs, g.n_deleted) == (rv.status, rv.iters, rv.n_trials_total, rv.num_obs, rv.n_deleted)
                 # radtan: cam2world runs OpenCV's five fp32 undistortion iterations (src/camera.cpp:78-85), which host and device round
                 # differently at the 1e-7 level of the bearing (tests/test_reproject.py): the host-built table differs from the
-                # device-built one by that much, and the poses by 1e-8
-                tol = 1e-9 if spec is synth.ICL_NUIM else 5e-8
+                # device-built one by that much, and the poses by ~1e-7 (rotation) / (translation, scene depth 2..6 m)
+                tol = 1e-9 if spec is synth.ICL_NUIM else 5e-7
                 assert np.allclose(g.T_f_w.q[:], rv.T_f_w.q[:], atol=tol, rtol=0) and np.allclose(g.T_f_w.t[:], rv.T_f_w.t[:], atol=tol, rtol=0)
                 assert np.array_equal(mask[c, :nf[c]], mv) and g.estimated_scale == pytest.approx(rv.estimated_scale, rel=100 * tol)
                 # the restatement on the same table
