@@ -71,11 +71,11 @@ def build_host(verbose=False):
     host = os.path.join(HERE, "host")
     rpath = ["-L" + CSRC, "-lhso_gpu", "-Wl,-rpath,$ORIGIN/../csrc",
              "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
-    srcs = [os.path.join(host, "hso_host.cpp"), os.path.join(host, "hso_vo.cpp")]
+    srcs = [os.path.join(host, "hso_host.cpp"), os.path.join(host, "hso_vo.cpp"), os.path.join(host, "hso_multi.cpp")]
     lib = os.path.join(host, "libhso_host.so")
     exe = os.path.join(host, "hso_host_test")
-    for cmd in (["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared"] + srcs + rpath + ["-o", lib],
-                ["g++", "-O2", "-std=c++17", "-Wall"] + srcs + [os.path.join(host, "hso_host_test.cpp")] + rpath + ["-o", exe]):
+    for cmd in (["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", "-pthread"] + srcs + rpath + ["-o", lib],
+                ["g++", "-O2", "-std=c++17", "-Wall", "-pthread"] + srcs + [os.path.join(host, "hso_host_test.cpp")] + rpath + ["-o", exe]):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

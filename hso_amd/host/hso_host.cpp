@@ -107,10 +107,13 @@ Vector3d AbstractCamera::cam2world(const Vector2d& px) const
   return {x / n, y / n, 1.0 / n};
 }
 
-int Frame::frame_counter_ = 0;
-int Frame::keyFrameCounter_ = 0;
-int Point::point_counter_ = 0;
-int Seed::batch_counter = 0;
+// per driver thread: a sequence lives on one thread (the single-sequence driver on its caller's, the multi-sequence driver on one
+// worker each), so every sequence counts its own frames, keyframes, points and seed batches like a process of the reference does
+thread_local int Frame::frame_counter_ = 0;
+thread_local int Frame::id_base_ = 0;
+thread_local int Frame::keyFrameCounter_ = 0;
+thread_local int Point::point_counter_ = 0;
+thread_local int Seed::batch_counter = 0;
 
 bool Point::deleteFrameRef(Frame* frame)
 {
@@ -134,7 +137,7 @@ Frame::Frame(hso_gpu_ctx* ctx, AbstractCamera* cam, const uint8_t* img, int widt
 Frame::~Frame()
 {
   for (Feature* f : fts_) delete f;
-  hso_gpu_frame_release(ctx_, id_);
+  if (api::router()) api::router()->frame_release(id_); else hso_gpu_frame_release(ctx_, id_);
 }
 
 CoarseTracker::CoarseTracker(bool inverse_composition, int max_level, int min_level, int n_iter, bool verbose)
@@ -238,8 +241,9 @@ std::vector<hso_align_out> Matcher::findMatchDirectBatch(const std::vector<const
   }
   if (!jobs.empty()) {
     std::vector<hso_align_out> res(jobs.size());
-    const int rc = hso_gpu_align_batch(cur.ctx_, &cur.cam_->pod(), cur.id_, jobs.data(), (int)jobs.size(), res.data());
-    if (rc < 0) throw std::runtime_error(std::string("Matcher: ") + hso_gpu_last_error(cur.ctx_));
+    const int rc = api::router() ? api::router()->align_batch(&cur.cam_->pod(), cur.id_, jobs.data(), (int)jobs.size(), res.data())
+                                 : hso_gpu_align_batch(cur.ctx_, &cur.cam_->pod(), cur.id_, jobs.data(), (int)jobs.size(), res.data());
+    api::check(cur.ctx_, rc, "Matcher");
     for (size_t k = 0; k < jobs.size(); k++) out[slot[k]] = res[k];
   }
   return out;

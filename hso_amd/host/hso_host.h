@@ -64,7 +64,7 @@ public:
   int last_projected_kf_id_ = -1;                                                              // point.h:73
   int n_failed_reproj_ = 0, n_succeeded_reproj_ = 0;                                           // point.h:75-76
   bool isBad_ = false;
-  static int point_counter_;
+  static thread_local int point_counter_;
   int id_ = point_counter_++;
   int seedStates_ = 0;            // temporary points: 0 seed still alive, 1 converged, -1 dropped (point.h)
   int nBA_ = 0;
@@ -99,14 +99,15 @@ public:
   Frame(const Frame&) = delete;
   Frame& operator=(const Frame&) = delete;
 
-  static int frame_counter_;
+  static thread_local int frame_counter_;
+  static thread_local int id_base_;   // the id the sequence's first frame gets (0; k << 24 for sequence k of the multi-sequence driver: one context holds all frames)
   int id_;
   double timestamp_;
   AbstractCamera* cam_;
   SE3 T_f_w_;
   Vector3d pos() const { return T_f_w_.inverse().translation(); }   // include/hso/frame.h:142
   int keyFrameId_ = 0;
-  static int keyFrameCounter_;   // src/frame.cpp:36
+  static thread_local int keyFrameCounter_;   // src/frame.cpp:36
   bool is_keyframe_ = false;
   bool isKeyframe() const { return is_keyframe_; }
   void setKeyframe();                          // src/frame.cpp:98-105
@@ -210,7 +211,7 @@ void optimizeLevenbergMarquardt3rd(const double reproj_thresh, const size_t n_it
 
 // include/hso/depth_filter.h:45-88
 struct Seed {
-  static int batch_counter;      // src/depth_filter.cpp:46
+  static thread_local int batch_counter;      // src/depth_filter.cpp:46
   int batch_id = batch_counter;  // the keyframe batch the seed was created in
   Feature* ftr = nullptr;        // host feature (frame, px, f, level, type, grad)
   float a = 10, b = 10;

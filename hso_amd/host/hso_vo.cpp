@@ -10,7 +10,8 @@
 
 namespace hso {
 
-api::Trace& api::trace() { static Trace t; return t; }
+api::Trace& api::trace() { static thread_local Trace t; return t; }
+api::Router*& api::router() { static thread_local Router* r = nullptr; return r; }
 
 static Vector3d vsub(const Vector3d& a, const Vector3d& b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
 static double vnorm(const Vector3d& a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
@@ -580,7 +581,7 @@ void ba::LocalBundleAdjustment(Frame* center_kf, std::set<Frame*>* core_kfs, Map
   for (Frame* kf : core) {
     vidx[kf] = (int)vframes.size();
     vframes.push_back(kf);
-    fixed.push_back((kf->id_ == 0 || kf->keyFrameId_ + 20 < center_kf->keyFrameId_) ? 1 : 0);
+    fixed.push_back((kf->id_ == Frame::id_base_ || kf->keyFrameId_ + 20 < center_kf->keyFrameId_) ? 1 : 0);   // id 0 = the sequence's first frame
     for (Feature* ft : kf->fts_)
       if (ft->point != nullptr) mps.push_back(ft->point);
   }
@@ -924,6 +925,8 @@ struct hso_vo {
   hso::FrameHandlerMono* vo = nullptr;
   std::string err;
   bool poisoned = false;   // a device call failed inside processFrame: the map may be half updated, the handle refuses further frames
+  bool owns_ctx = true;    // false: one of the sequences of a multi-sequence driver (hso_multi.cpp), the context is shared
+  int id_base = 0;         // Frame::id_base_ of the sequence's thread: reported frame ids are relative to it
 };
 static int g_vo_alive = 0;
 
@@ -970,6 +973,29 @@ void hso_vo_destroy(hso_vo* v)
   delete v;
   --g_vo_alive;
 }
+
+}  // extern "C"
+
+// One sequence of the multi-sequence driver (hso_multi.cpp): called on the sequence's own worker thread, whose thread-local
+// counters and router are already set; the context is shared and Config::maxFts() was set by the caller before the threads started.
+hso_vo* hso_vo_create_shared(hso_gpu_ctx* ctx, const hso_camera* cam, int max_fts)
+{
+  (void)max_fts;
+  hso_vo* v = new hso_vo();
+  v->ctx = ctx; v->owns_ctx = false; v->id_base = hso::Frame::id_base_;
+  v->cam = new hso::AbstractCamera(*cam);
+  v->vo = new hso::FrameHandlerMono(ctx, v->cam, false);
+  return v;
+}
+void hso_vo_destroy_shared(hso_vo* v)
+{
+  if (!v) return;
+  delete v->vo;      // releases the sequence's resident frames through the router
+  delete v->cam;
+  delete v;
+}
+
+extern "C" {
 
 const char* hso_vo_last_error(const hso_vo* v) { return v ? v->err.c_str() : "null handle"; }
 
@@ -1033,7 +1059,7 @@ int hso_vo_get_status(hso_vo* v, hso_vo_status* st)
     st->T_f_w = f->T_f_w_.v;
     st->timestamp = f->timestamp_;
     st->exposure_time = f->m_exposure_time;
-    st->frame_id = f->id_; st->keyframe_id = f->keyFrameId_;
+    st->frame_id = f->id_ - v->id_base; st->keyframe_id = f->keyFrameId_;
     st->is_keyframe = f->isKeyframe() ? 1 : 0;
     st->stage = (int)v->vo->stage(); st->tracking_quality = (int)v->vo->trackingQuality(); st->result = (int)v->vo->lastResult();
     st->n_features = (int)f->fts_.size(); st->n_inliers = (int)f->m_n_inliers;
@@ -1054,7 +1080,7 @@ int hso_vo_get_keyframes(hso_vo* v, double* timestamps, hso_se3* T_f_w, int32_t*
     if (n < cap) {
       if (timestamps) timestamps[n] = kf->timestamp_;
       if (T_f_w) T_f_w[n] = kf->T_f_w_.v;
-      if (frame_ids) frame_ids[n] = kf->id_;
+      if (frame_ids) frame_ids[n] = kf->id_ - v->id_base;
     }
     ++n;
   }

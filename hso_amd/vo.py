@@ -46,12 +46,89 @@ def load():
     lib.hso_vo_add_image.argtypes = [vp, vp, i32, i32, C.c_double]
     lib.hso_vo_get_status.argtypes = [vp, P(VoStatus)]
     lib.hso_vo_get_keyframes.argtypes = [vp, vp, vp, vp, i32]
+    lib.hso_vo_multi_create.argtypes = [P(vp), P(capi.Camera), i32, i32, i32]
+    lib.hso_vo_multi_destroy.argtypes = [vp]
+    lib.hso_vo_multi_destroy.restype = None
+    lib.hso_vo_multi_last_error.argtypes = [vp]
+    lib.hso_vo_multi_last_error.restype = C.c_char_p
+    lib.hso_vo_multi_size.argtypes = [vp]
+    lib.hso_vo_multi_set_first_frames.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.hso_vo_multi_add_images.argtypes = [vp, vp, i32, i32, vp]
+    lib.hso_vo_multi_get_status.argtypes = [vp, i32, P(VoStatus)]
+    lib.hso_vo_multi_get_keyframes.argtypes = [vp, i32, vp, vp, vp, i32]
+    lib.hso_vo_multi_call_counts.argtypes = [vp, vp, vp, i32]
     _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso_vo_trace", "hso_vo_set_first_frame",
-                    "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes"]
+                    "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes",
+                    "hso_vo_multi_create", "hso_vo_multi_destroy", "hso_vo_multi_last_error", "hso_vo_multi_size",
+                    "hso_vo_multi_set_first_frames", "hso_vo_multi_add_images", "hso_vo_multi_get_status", "hso_vo_multi_get_keyframes",
+                    "hso_vo_multi_call_counts"]
+
+CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_match", "align", "pose", "seed_observe", "seed_activate", "ba", "solo"]
+
+
+class MultiVisualOdometry:
+    """N FrameHandlerMono over one device context, advancing in lockstep (include/hso_vo.h: hso_vo_multi_*)."""
+
+    def __init__(self, cam, n_sequences, max_fts=200, device=0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.hso_vo_multi_create(C.byref(self.h), C.byref(cam), int(max_fts), int(n_sequences), int(device))
+        if rc < 0:
+            raise capi.HsoGpuError("hso_vo_multi_create failed: %d" % rc)
+        self.n = n_sequences
+
+    def close(self):
+        if self.h:
+            self.lib.hso_vo_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise capi.HsoGpuError("%s failed (%d): %s" % (what, rc, (self.lib.hso_vo_multi_last_error(self.h) or b"?").decode()))
+
+    @staticmethod
+    def _ptrs(arrs):
+        return (C.c_void_p * len(arrs))(*[a.ctypes.data if a is not None else None for a in arrs])
+
+    def set_first_frames(self, imgs, depths, timestamps=None):
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        depths = [np.ascontiguousarray(d, np.float32) for d in depths]
+        ts = np.ascontiguousarray(timestamps if timestamps is not None else np.zeros(self.n), np.float64)
+        h, w = imgs[0].shape
+        self._check(self.lib.hso_vo_multi_set_first_frames(self.h, self._ptrs(imgs), w, h, ts.ctypes.data, self._ptrs(depths), None), "set_first_frames")
+
+    def add_images(self, imgs, timestamps):
+        """imgs: one image per sequence, None = the sequence sits this step out."""
+        imgs = [np.ascontiguousarray(i, np.uint8) if i is not None else None for i in imgs]
+        ts = np.ascontiguousarray(timestamps, np.float64)
+        shape = next(i.shape for i in imgs if i is not None)
+        self._check(self.lib.hso_vo_multi_add_images(self.h, self._ptrs(imgs), shape[1], shape[0], ts.ctypes.data), "add_images")
+
+    def status(self, k):
+        st = VoStatus()
+        self._check(self.lib.hso_vo_multi_get_status(self.h, k, C.byref(st)), "get_status")
+        return st
+
+    def keyframes(self, k):
+        n = self.lib.hso_vo_multi_get_keyframes(self.h, k, None, None, None, 0)
+        ts = np.zeros(max(n, 1)); T = (capi.SE3 * max(n, 1))(); ids = np.zeros(max(n, 1), np.int32)
+        self.lib.hso_vo_multi_get_keyframes(self.h, k, capi._ptr(ts), C.cast(T, C.c_void_p), capi._ptr(ids), n)
+        return [(float(ts[i]), T[i], int(ids[i])) for i in range(n)]
+
+    def call_counts(self):
+        calls = np.zeros(16, np.int64); items = np.zeros(16, np.int64)
+        n = self.lib.hso_vo_multi_call_counts(self.h, calls.ctypes.data, items.ctypes.data, 16)
+        return {CALL_KINDS[k]: (int(calls[k]), int(items[k])) for k in range(n)}
 
 
 class VisualOdometry:

@@ -48,6 +48,28 @@ int hso_vo_get_status(hso_vo* vo, hso_vo_status* st);
 /* map_.keyframes_ in list order (what BenchmarkNode::saveResult writes): returns the number of keyframes, fills at most cap */
 int hso_vo_get_keyframes(hso_vo* vo, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
 
+/* ---- N independent sequences over one device context, in lockstep (hso_amd/host/hso_multi.cpp): BASELINE north_star
+ * "independent sequences ... batched"; configs[4] = what test/euroc_batch.sh:9-18 runs one after the other.  Every sequence is
+ * a FrameHandlerMono of its own; per step the device calls of all sequences leave as one batched C-ABI call per kind
+ * (hso_gpu_coarse_track_batch with N jobs, hso_gpu_reproject_match_multi, hso_gpu_pose_optimize_batch,
+ * hso_gpu_seed_observe_multi, hso_gpu_seed_activate_multi, hso_gpu_ba_optimize_multi, hso_gpu_frame_upload_batch).  A sequence
+ * run here equals the same sequence run alone through hso_vo_* bit for bit.  Up to 127 sequences. */
+typedef struct hso_vo_multi hso_vo_multi;
+int hso_vo_multi_create(hso_vo_multi** out, const hso_camera* cam, int max_fts, int n_sequences, int device);
+void hso_vo_multi_destroy(hso_vo_multi* m);
+const char* hso_vo_multi_last_error(const hso_vo_multi* m);
+int hso_vo_multi_size(const hso_vo_multi* m);
+/* arrays of n_sequences entries; a NULL image = the sequence sits this step out (sequences need not have equal lengths) */
+int hso_vo_multi_set_first_frames(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps,
+                                  const float* const* depth_z, const hso_se3* T_f_w /* n_sequences or NULL */);
+int hso_vo_multi_add_images(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps);
+int hso_vo_multi_get_status(hso_vo_multi* m, int sequence, hso_vo_status* st);
+int hso_vo_multi_get_keyframes(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
+/* batched C-ABI calls issued so far and the per-sequence requests they carried, per kind: [0] frame upload, [1] frame release,
+ * [2] tracker, [3] reprojection + matching, [4] matching alone, [5] pose, [6] seed observation, [7] seed activation, [8] local BA,
+ * [9] calls without a multi-sequence form.  Returns the number of kinds. */
+int hso_vo_multi_call_counts(hso_vo_multi* m, int64_t* calls, int64_t* items, int cap);
+
 #ifdef __cplusplus
 }
 #endif

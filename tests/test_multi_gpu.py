@@ -1,0 +1,65 @@
+"""hso_vo_multi_* (hso_amd/host/hso_multi.cpp): N FrameHandlerMono over one device context in lockstep, the device calls of all
+sequences leaving as one batched C-ABI call per kind.  The claim to check: a sequence run inside the multi-sequence driver equals
+the same sequence run alone through hso_vo_* bit for bit — every per-frame status record (pose, exposure, match / seed / keyframe
+counters, pose-optimisation and BA errors) and the keyframe trajectory — although its tracker jobs, reprojections, pose
+optimisations, seed updates, activations and BA windows travelled in batches with the other sequences' (BASELINE configs[4]:
+8 sequences, here 4 with different scenes, lengths and keyframe timing)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hso_amd import synth, vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _status_bytes(st):
+    return bytes(st)
+
+
+def test_four_sequences_in_lockstep_equal_four_single_runs():
+    spec = synth.EUROC
+    cam = synth.camera(spec)
+    lengths = [34, 40, 28, 40]
+    seqs = [synth.sequence(n, spec=spec, seed=3100 + 17 * k, step=(0.016 + 0.002 * k, 0.005, 0.007 - 0.001 * k)) for k, n in enumerate(lengths)]
+    # ---- reference: each sequence alone
+    solo_status, solo_kfs = [], []
+    for S in seqs:
+        odo = vo.VisualOdometry(cam, 200)
+        odo.set_first_frame(S["images"][0], S["depth0"], 0.0)
+        sts = [_status_bytes(odo.status())]
+        for k in range(1, len(S["images"])):
+            sts.append(_status_bytes(odo.add_image(S["images"][k], float(k))))
+        solo_status.append(sts)
+        solo_kfs.append([(ts, bytes(T), fid) for ts, T, fid in odo.keyframes()])
+        odo.close()
+    # ---- the four in lockstep over one context
+    multi = vo.MultiVisualOdometry(cam, len(seqs), 200)
+    multi.set_first_frames([S["images"][0] for S in seqs], [S["depth0"] for S in seqs])
+    got = [[_status_bytes(multi.status(q))] for q in range(len(seqs))]
+    for k in range(1, max(lengths)):
+        imgs = [S["images"][k] if k < len(S["images"]) else None for S in seqs]       # shorter sequences sit the later steps out
+        multi.add_images(imgs, [float(k)] * len(seqs))
+        for q, im in enumerate(imgs):
+            if im is not None:
+                got[q].append(_status_bytes(multi.status(q)))
+    counts = multi.call_counts()
+    kfs = [[(ts, bytes(T), fid) for ts, T, fid in multi.keyframes(q)] for q in range(len(seqs))]
+    multi.close()
+    n_kf = 0
+    for q in range(len(seqs)):
+        assert len(got[q]) == len(solo_status[q]) == lengths[q]
+        for k, (a, b) in enumerate(zip(got[q], solo_status[q])):
+            assert a == b, "sequence %d frame %d differs from its solo run" % (q, k)
+        assert kfs[q] == solo_kfs[q] and len(kfs[q]) >= 2
+        n_kf += len(kfs[q])
+    # the calls really travelled together: far fewer tracker / pose / seed launches than frames, several requests per launch
+    n_frames = sum(lengths) - len(seqs)
+    for kind in ("track", "pose", "frame_upload"):
+        calls, items = counts[kind]
+        assert items >= n_frames and calls <= max(lengths) + 8 and items / calls > 2.5, (kind, counts)
+    calls, items = counts["seed_observe"]          # only frames that have seeds to update (not the keyframes themselves)
+    assert items > n_frames // 2 and items / calls > 2.0, counts
+    assert counts["ba"][1] >= n_kf - len(seqs) - 4 and counts["seed_activate"][1] > 0 and counts["solo"][0] > 0
+    print("multi-sequence driver: batched calls / requests per kind", counts)
