@@ -251,7 +251,8 @@ def main():
     ap.add_argument("--min-level", type=int, default=1, help="developer knob: stop the tracker above level 1 (the judged line uses 1)")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames in the cpu_baseline sample (about 10 s on one host core)")
     ap.add_argument("--chain-seqs", type=int, default=256, help="sequences of the whole-chain measurement (0 = skip; N = 1 only)")
-    ap.add_argument("--seq-frames", type=int, default=24, help="frames of the single-sequence run through libhso_host.so (0 = skip; N = 1 only)")
+    ap.add_argument("--seq-frames", type=int, default=24, help="frames per sequence of the end-to-end runs through libhso_host.so (0 = skip)")
+    ap.add_argument("--sequences", type=int, default=8, help="sequences per rank of the lockstep multi-sequence run (hso_vo_multi_*; 0 = skip)")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
                          "BASELINE.json's metric is quoted on; vga: BASELINE configs[1], 640x480 pinhole")
@@ -276,7 +277,10 @@ def main():
         from hso_amd import chain_bench
         chain_jobs = chain_bench.scene_jobs(spec0, args.feats, 2 * args.feats, 3 * args.feats, 4)
     scenes, chain_scenes = render_scenes(args.shape, args.feats, [1234 + 7 * s for s in seq_ids], chain_jobs)
-    seq_S = _synth.sequence(args.seq_frames, spec=spec0) if extras and args.seq_frames > 1 else None   # forks its own renderers
+    # sequences for the end-to-end driver: `--sequences` per rank through hso_vo_multi_* at every N (their trajectories are what the
+    # ranks gather); the first one also serves the single-sequence latency at N = 1.  Rendered by their own pool, before the GPU runtime.
+    seq_list = _synth.sequences(args.sequences, args.seq_frames, spec=spec0, seed0=2024 + 1000 * rank) if args.seq_frames > 1 and args.sequences > 0 else []
+    seq_S = seq_list[0] if extras and seq_list else None
     t_render = time.perf_counter() - t_r0
 
     import torch
@@ -476,6 +480,30 @@ def main():
                                "sample": "%d frames of the same workload (pyramid + Sobel + stats + CoarseTracker from the same "
                                          "initial poses), oracle/ C restatement, 1 thread, %.1f s" % (n_cpu, tc1 - tc0),
                                "build": flags, "host_cpus": os.cpu_count()}
+    # ---- the end-to-end driver at every N: `--sequences` sequences per rank in lockstep through hso_vo_multi_* (one context per GPU,
+    # the device calls of all sequences batched per kind); the ranks' per-frame trajectories are gathered over RCCL — the path's
+    # only exchange (BASELINE north_star / configs[4])
+    if seq_list:
+        from hso_amd import latency_bench
+        if world > 1:
+            dist.barrier()
+        tq0 = time.perf_counter()
+        mres, traj = latency_bench.multi_sequence_run(cam, seq_list, 200, local_rank)
+        t_multi = time.perf_counter() - tq0
+        tr_rec = hdist.pack_trajectories(traj, args.seq_frames)
+        all_tr = hdist.gather_records(tr_rec, device=dev)
+        assert all_tr.shape == (world, len(seq_list), args.seq_frames, 8) and (world == 1 or dist.get_world_size() == world)
+        t_multi_max = hdist.max_over_ranks(t_multi, device=dev)
+        fps_all = hdist.max_over_ranks(0.0, device=dev)  # (keeps the collective count equal on every rank)
+        del fps_all
+        tl = torch.tensor([mres["frames_per_s"]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tl)
+        out["sequences"] = dict(mres, ranks=world, sequences_total=world * len(seq_list), frames_per_s_all_ranks=float(tl.item()),
+                                gathered_trajectory_shape=list(all_tr.shape), wall_s_incl_setup=t_multi_max,
+                                what="end-to-end FrameHandlerMono::addImage for %d sequences per GPU in lockstep (hso_vo_multi_*: one batched C-ABI "
+                                     "call per kind and step), 200 features; trajectories of all ranks gathered (torch.distributed %s, world %d)"
+                                     % (len(seq_list), "nccl = RCCL" if world > 1 else "not initialised", world))
     if extras and (args.chain_seqs > 0 or seq_S is not None):
         extra_measurements(out, args, ctx, stream, spec, chain_scenes, seq_S, cam, locals().get("orc"))
     if rank == 0:

@@ -21,6 +21,16 @@ def pack_records(results):
     return rec
 
 
+def pack_trajectories(trajs, n_frames):
+    """[S, n_frames, 8] float64 for S sequences: per frame quaternion (x,y,z,w), translation, time stamp; NaN rows where a
+    sequence is shorter.  trajs[s] = list of (timestamp, (q, t))."""
+    out = np.full((len(trajs), n_frames, 8), np.nan)
+    for s, tr in enumerate(trajs):
+        for k, (ts, (q, t)) in enumerate(tr[:n_frames]):
+            out[s, k, :4], out[s, k, 4:7], out[s, k, 7] = q, t, ts
+    return out
+
+
 def gather_records(rec, device=None):
     """all_gather of equally-shaped per-rank record blocks -> [world, n, 8] on every rank."""
     import torch

@@ -70,6 +70,32 @@ def sequence_latency(cam, S, max_fts):
                 n_matches_last=int(st.n_matches), trans_err_last=err)
 
 
+def multi_sequence_run(cam, seqs, max_fts, device=0):
+    """S sequences in lockstep through hso_vo_multi_* (one context; the device calls of all sequences batched per kind).
+    -> (dict for the bench line, per-sequence trajectories [(timestamp, (q, t))])."""
+    from hso_amd import vo
+    S = len(seqs)
+    n_frames = min(len(q["images"]) for q in seqs)
+    m = vo.MultiVisualOdometry(cam, S, max_fts, device)
+    m.set_first_frames([q["images"][0] for q in seqs], [q["depth0"] for q in seqs])
+    traj = [[(0.0, m.status(q).T_f_w.to_arrays())] for q in range(S)]
+    t_steps = []
+    for k in range(1, n_frames):
+        t0 = time.perf_counter()
+        m.add_images([q["images"][k] for q in seqs], [float(k)] * S)
+        t_steps.append(time.perf_counter() - t0)
+        for q in range(S):
+            traj[q].append((float(k), m.status(q).T_f_w.to_arrays()))
+    err = [float(np.linalg.norm(traj[q][-1][1][1] - seqs[q]["T_f_w"][n_frames - 1][1])) for q in range(S)]
+    n_kf = [len(m.keyframes(q)) for q in range(S)]
+    counts = m.call_counts()
+    m.close()
+    total = sum(t_steps)
+    return dict(sequences=S, frames_per_sequence=n_frames - 1, max_fts=max_fts, frames_per_s=S * (n_frames - 1) / total,
+                ms_per_step=1e3 * total / (n_frames - 1), keyframes=n_kf, trans_err_last_max=max(err),
+                batched_calls={k: v[0] for k, v in counts.items()}, requests={k: v[1] for k, v in counts.items()}), traj
+
+
 def measure(reps=30, frames=24, feats=(200, 2000), spec=None, device=0):
     import torch
     spec = spec or synth.EUROC

@@ -532,3 +532,36 @@ def sequence(n_frames=60, spec=EUROC, seed=2024, step=(0.016, 0.005, 0.007), rot
     ys, xs = np.mgrid[0:sc.h, 0:sc.w].astype(np.float64)
     depth0 = sc.points0(xs, ys)[..., 2].astype(np.float32)
     return dict(images=images, T_f_w=poses, exposure=expos, depth0=depth0, scene=sc, spec=dict(spec))
+
+
+def sequences(n_seq, n_frames, spec=EUROC, seed0=2024, workers=None):
+    """n_seq synthetic sequences (different scenes and motions) rendered through ONE worker pool: what the multi-sequence
+    driver / bench feed to hso_vo_multi_*.  Returns a list of dicts like sequence()."""
+    import multiprocessing as mp
+    import os
+    metas, jobs = [], []
+    for q in range(n_seq):
+        seed = seed0 + 17 * q
+        step = (0.016 + 0.002 * (q % 4), 0.005, 0.007 - 0.001 * (q % 3))
+        rot = (0.05, -0.12 + 0.01 * (q % 5), 0.03)
+        poses, expos = [], []
+        for k in range(n_frames):
+            s_ = k + 1.5 * np.sin(k / 9.0)
+            rv = np.deg2rad(np.array(rot)) * s_
+            poses.append((rotvec_to_quat(rv), np.array(step) * s_))
+            expos.append(1.0 + 0.03 * np.sin(k / 5.0))
+        metas.append((seed, poses, expos))
+        jobs += [(dict(spec), seed, list(q_), list(t_), expos[k], 1.0, k) for k, (q_, t_) in enumerate(poses)]
+    workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 32))
+    if workers == 1:
+        images = [_render_frame(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            images = pool.map(_render_frame, jobs, chunksize=1)
+    out = []
+    for q, (seed, poses, expos) in enumerate(metas):
+        sc = Scene(spec, seed)
+        ys, xs = np.mgrid[0:sc.h, 0:sc.w].astype(np.float64)
+        depth0 = sc.points0(xs, ys)[..., 2].astype(np.float32)
+        out.append(dict(images=images[q * n_frames:(q + 1) * n_frames], T_f_w=poses, exposure=expos, depth0=depth0, scene=sc, spec=dict(spec)))
+    return out

@@ -13,7 +13,7 @@ rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$ROOT
-B="python $ROOT/bench.py --cpu-frames 0 --chain-seqs 0 --seq-frames 0"
+B="python $ROOT/bench.py --cpu-frames 0 --chain-seqs 0 --seq-frames 0 --sequences 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG} -- $B --steps 10 --warmup 2 > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o ${TAG}_fetch -- $B --steps 3 --warmup 1 > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o ${TAG}_write -- $B --steps 3 --warmup 1 > $OUT/bench_write.log 2>&1

@@ -30,8 +30,11 @@ def _worker(rank, world, port, q):
     rec = hdist.pack_records(res)
     allrec = hdist.gather_records(rec)
     tmax = hdist.max_over_ranks(0.5 + rank)
+    # the chain's records: per-frame trajectories of this rank's sequences (bench.py "sequences": hso_vo_multi_* per GPU), NaN-padded
+    trajs = [[(float(k), ([0, 0, 0, 1], [rank, s, k])) for k in range(3 + s)] for s in range(2)]
+    alltr = hdist.gather_records(hdist.pack_trajectories(trajs, 5))
     dist.barrier()
-    q.put((rank, seqs, allrec, tmax))
+    q.put((rank, seqs, allrec, tmax, alltr))
     dist.destroy_process_group()
 
 
@@ -47,7 +50,10 @@ def test_two_rank_gather_and_timing():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, s0, a0, t0), (r1, s1, a1, t1) = out
+    (r0, s0, a0, t0, tr0), (r1, s1, a1, t1, tr1) = out
+    # trajectories: [world, sequences, frames, 8], every rank holds all; short sequences padded with NaN
+    assert tr0.shape == (2, 2, 5, 8) and np.array_equal(tr0, tr1, equal_nan=True)
+    assert np.allclose(tr0[1, 1, 3, 4:8], [1, 1, 3, 3]) and np.isnan(tr0[0, 0, 3:, :]).all() and not np.isnan(tr0[0, 1, :4, :]).any()
     assert s0 == [0, 1, 2, 3] and s1 == [4, 5, 6]          # 7 sequences over 2 ranks
     assert a0.shape == (2, 4, 8) and np.array_equal(a0, a1)  # every rank holds every record
     assert np.allclose(a0[1, 2, 4:7], [1, 2, 3]) and np.isclose(a0[1, 0, 7], 1.01, atol=1e-6)
