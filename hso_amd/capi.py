@@ -312,6 +312,7 @@ def load():
     lib.hso_gpu_ba_optimize_multi.argtypes = [vp, P(BaProblem), i32]
     lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.hso_gpu_reproject_select_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
+    lib.hso_gpu_map_update_quality.argtypes = [vp, vp, i32, vp]
     lib.hso_gpu_reproject_select_pose_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp, P(PoseChain)]
     lib.hso_gpu_seed_activate_multi.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), P(i32), P(ActivateOut),
                                                 P(AlignOut)]
@@ -354,7 +355,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize", "hso_gpu_ba_optimize_multi",
-    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select", "hso_gpu_reproject_select_maps", "hso_gpu_reproject_select_pose_maps",
+    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select", "hso_gpu_reproject_select_maps", "hso_gpu_reproject_select_pose_maps", "hso_gpu_map_update_quality",
     "hso_gpu_seed_reproject_match",
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
@@ -719,6 +720,12 @@ class Context:
         kfs = np.ascontiguousarray(kfs, KF_DTYPE); points = np.ascontiguousarray(points, MAP_POINT_DTYPE)
         obs = np.ascontiguousarray(obs, OBS_DTYPE)
         self._check(self.lib.hso_gpu_map_store(self.h, index, _ptr(kfs), len(kfs), _ptr(points), len(points), _ptr(obs), len(obs)), "map_store")
+
+    def map_update_quality(self, maps, quality):
+        """maps: map indices; quality: their points' keys back to back (uint8)."""
+        m = np.ascontiguousarray(np.atleast_1d(maps), np.int32)
+        q = np.ascontiguousarray(quality, np.uint8)
+        self._check(self.lib.hso_gpu_map_update_quality(self.h, _ptr(m), len(m), _ptr(q)), "map_update_quality")
 
     def reproject_match_maps(self, cam, calls, cell_size, grid_n_cols, capacity):
         """calls: MAP_CALL_DTYPE array.  -> MATCH_BRIEF_DTYPE array (the calls' points back to back)."""

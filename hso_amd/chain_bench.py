@@ -100,6 +100,8 @@ class Chain:
             calls[q]["q"], calls[q]["t"] = scenes[q % nd]["M"]["T_cur_w"]
         calls["cur_exposure_time"] = M0["cur_exposure"]
         self.calls = calls
+        self.map_ids = np.arange(nseq, dtype=np.int32)
+        self.quality = np.full(nseq * len(M0["points"]), (4 << 4) | 0, np.uint8)
         self.cell_size, self.grid_n_cols = M0["cell_size"], M0["grid_n_cols"]
         n_cells = self.grid_n_cols * int(math.ceil(self.H / self.cell_size))
         self.cell_order = np.random.default_rng(3).permutation(n_cells).astype(np.int32)
@@ -136,7 +138,10 @@ class Chain:
         return self.ctx.reproject_select_maps(self.cam, self.calls, self.cell_size, self.grid_n_cols, self.cell_order, self.feats, self.sel_cap)
 
     def reproject_pose(self):
-        """reprojectMap + optimizeLevenbergMarquardt3rd chained on the device (the selected matches ARE the frame's features)"""
+        """reprojectMap + optimizeLevenbergMarquardt3rd chained on the device (the selected matches ARE the frame's features).
+        The maps' per-frame part goes in first: the quality keys of every point (Point::type_ promotions and deletions happen
+        between keyframes, src/reprojector.cpp:376-423) — one byte per stored point and frame."""
+        self.ctx.map_update_quality(self.map_ids, self.quality)
         return self.ctx.reproject_select_pose_maps(self.cam, self.calls, self.cell_size, self.grid_n_cols, self.cell_order, self.feats, self.sel_cap,
                                                    want_mask=True)
 

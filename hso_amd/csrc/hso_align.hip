@@ -17,6 +17,8 @@
 // only (stated tolerance: 1e-3 px on the result).  Instruction-issue-bound (profiles/r3_stage_sq_align.csv:
 // VALU 100 % busy with one candidate per wave), hence the packing.
 #include "hso_match_dev.h"
+#include <stddef.h>
+#include <algorithm>
 #include <string.h>
 #include <vector>
 
@@ -542,6 +544,63 @@ extern "C" int hso_gpu_map_store(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, i
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   A->kfs[map].assign(kfs, kfs + n_kfs);
   A->n_points[map] = n_points; A->n_obs[map] = n_obs;
+  return HSO_OK;
+}
+
+// The per-frame part of a stored map.  Between two hso_gpu_map_store calls the reference changes, every frame, what the grid
+// selection orders and skips by: n_succeeded_reproj_ > 10 turns TYPE_UNKNOWN into TYPE_GOOD (the comparator's key), n_failed_reproj_
+// > 15 / 30 deletes points (src/reprojector.cpp:376-392, 412-423).  Those live in hso_map_point.pad_ — the quality key
+// (Point::type_ << 4) | ftr_type_, 0 = deleted — and this call refreshes the keys of one stored map from a byte per point
+// for any number of stored maps in one call (the bytes cross PCIe, not the tables; one small kernel scatters them onto the pad_
+// column).  Structural changes — new points (candidates
+// promoted on non-keyframes, temporary points), new observations, another keyframe set — still need hso_gpu_map_store.
+__global__ void k_map_quality(hso_map_point* pts, int max_points, const int* maps, const int* begin, int n_maps, const uint8_t* quality)
+{
+  const int m = blockIdx.y;
+  if (m >= n_maps) return;
+  const int n = begin[m + 1] - begin[m];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    pts[(size_t)maps[m] * max_points + i].pad_ = quality[begin[m] + i];
+}
+
+extern "C" int hso_gpu_map_update_quality(hso_gpu_ctx* ctx, const int32_t* maps, int n_maps, const uint8_t* quality)
+{
+  if (!ctx) return HSO_E_INVALID;
+  MapArena* A = ctx->maps;
+  if (!A || n_maps < 0 || (n_maps > 0 && (!maps || !quality))) return hso_fail(ctx, HSO_E_INVALID, "map_update_quality: bad argument");
+  if (n_maps == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  size_t total = 0;
+  for (int m = 0; m < n_maps; m++) {
+    if (maps[m] < 0 || maps[m] >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "map_update_quality: no such map");
+    total += (size_t)A->n_points[maps[m]];
+  }
+  if (total == 0) return HSO_OK;
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_maps = al(sizeof(int) * (size_t)n_maps), b_begin = al(sizeof(int) * (size_t)(n_maps + 1)), need = b_maps + b_begin + al(total);
+  char* h = hso_pinned(ctx, 0, need);
+  if (!h) return HSO_E_NOMEM;
+  int* hm = reinterpret_cast<int*>(h);
+  int* hb = reinterpret_cast<int*>(h + b_maps);
+  int t = 0;
+  for (int m = 0; m < n_maps; m++) { hm[m] = maps[m]; hb[m] = t; t += A->n_points[maps[m]]; }
+  hb[n_maps] = t;
+  memcpy(h + b_maps + b_begin, quality, total);
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
+    ctx->batch_cap = need;
+  }
+  char* d = ctx->d_batch;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, ctx->stream));
+  int max_n = 0;
+  for (int m = 0; m < n_maps; m++) max_n = std::max(max_n, A->n_points[maps[m]]);
+  hipLaunchKernelGGL(k_map_quality, dim3((max_n + 255) / 256, n_maps), dim3(256), 0, ctx->stream, A->d_pts, A->max_points,
+                     reinterpret_cast<const int*>(d), reinterpret_cast<const int*>(d + b_maps), n_maps, reinterpret_cast<const uint8_t*>(d + b_maps + b_begin));
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }
 

@@ -82,6 +82,7 @@ int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases,
 int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh);
 void hso_track_state_free(hso_gpu_ctx* ctx);
 void hso_seed_tables_free(hso_gpu_ctx* ctx);
+bool hso_seed_tables_pin(hso_gpu_ctx* ctx, int64_t frame_id);   // a resident seed table hosts live seeds in this frame
 void hso_map_arena_free(hso_gpu_ctx* ctx);
 // a frame allocation of geometry g: recycled when the free list holds that geometry, else fresh with zeroed padding rows.
 // hso_frame_free returns it to the list (or the allocator); neither touches ctx->frames.

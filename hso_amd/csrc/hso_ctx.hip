@@ -261,6 +261,8 @@ int hso_gpu_frame_release(hso_gpu_ctx* ctx, int64_t frame_id)
   if (!ctx) return HSO_E_INVALID;
   auto it = ctx->frames.find(frame_id);
   if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "frame_release: frame not resident");
+  if (hso_seed_tables_pin(ctx, frame_id))
+    return hso_fail(ctx, HSO_E_INVALID, "frame_release: live seeds of a resident seed table are hosted in this frame (erase them or destroy the table first)");
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   hso_frame_free(ctx, it->second.g, it->second.base);
   ctx->frames.erase(it);

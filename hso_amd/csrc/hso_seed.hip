@@ -18,6 +18,7 @@
 #include "hso_match_dev.h"
 #include <string.h>
 #include <algorithm>
+#include <unordered_map>
 #include <vector>
 
 using namespace hso_dev;
@@ -672,6 +673,8 @@ struct SeedTable {
   SeedDev* d = nullptr;
   size_t cap = 0, n = 0;              // slots allocated / used (erased slots keep their index)
   std::vector<uint8_t> alive;
+  std::vector<int64_t> host_frame;    // per slot: the frame the seed is hosted in (the device record caches that frame's base pointer)
+  std::unordered_map<int64_t, int> pins;   // host frame id -> live seeds hosted there: such a frame must stay resident
   hso_seed_brief* d_brief = nullptr; size_t brief_cap = 0;
   hso_seed_out* d_full = nullptr; size_t full_cap = 0;
   SeedFrameDev* d_frames = nullptr; size_t frames_cap = 0;
@@ -687,6 +690,16 @@ void hso_seed_tables_free(hso_gpu_ctx* ctx)
     if (t) { (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); delete t; }
   delete ctx->seed_tables;
   ctx->seed_tables = nullptr;
+}
+
+// hso_gpu_frame_release asks: a resident table caches the base pointer of every live seed's host frame, so releasing such a frame
+// (its buffer goes back to the free list and to another frame id) would make the table read another frame's pyramid
+bool hso_seed_tables_pin(hso_gpu_ctx* ctx, int64_t frame_id)
+{
+  if (!ctx->seed_tables) return false;
+  for (SeedTable* t : ctx->seed_tables->t)
+    if (t && t->pins.count(frame_id)) return true;
+  return false;
 }
 
 static SeedTable* seed_table_of(hso_gpu_ctx* ctx, int table)
@@ -767,6 +780,7 @@ int hso_gpu_seed_table_append(hso_gpu_ctx* ctx, int table, const hso_seed* seeds
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer is reused by the next call
   t->n += (size_t)n;
   t->alive.resize(t->n, 1);
+  for (int i = 0; i < n; i++) { t->host_frame.push_back(seeds[i].ref_frame_id); t->pins[seeds[i].ref_frame_id]++; }
   return HSO_OK;
 }
 
@@ -781,6 +795,7 @@ int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, 
   for (int i = 0; i < n; i++) {
     if (!t->alive[slots[i]]) continue;
     t->alive[slots[i]] = 0;
+    if (--t->pins[t->host_frame[slots[i]]] <= 0) t->pins.erase(t->host_frame[slots[i]]);
     // ref_base is the first member of SeedDev: a null there marks the slot dead for the kernel
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(reinterpret_cast<char*>(t->d + slots[i]), &null_base, sizeof(null_base), hipMemcpyHostToDevice, ctx->stream));
   }

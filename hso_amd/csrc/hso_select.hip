@@ -206,7 +206,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(SelArgs A, const SelFram
         const int b = F.cnt[c] + (F.e1[c] & 0x3fffffff) + (((F.e2[c] >> 29) & 1) ? (F.e2[c] & 0x1fffffff) : 0), e = F.cnt[c + 1];
         int a = 0, p[3] = { 0, 0, 0 };
         for (int x = b; x < e; x++) if (matched(F.list[x])) { if (a < 3) p[a] = x - b + 1; a++; }
-        F.a3[c] = a | ((e - b) << 8);          // successes (at most 255 matter) and the remaining length
+        F.a3[c] = (a < 255 ? a : 255) | ((e - b) << 8);   // successes (at most 3 matter: clamped to the byte) and the remaining length
         F.p3[3 * c] = p[0]; F.p3[3 * c + 1] = p[1]; F.p3[3 * c + 2] = p[2];
       }
       __syncthreads();

@@ -376,6 +376,12 @@ int hso_gpu_map_reserve(hso_gpu_ctx* ctx, int n_maps, int max_kfs, int max_point
 /* replace map `map` (index kept; points' host_kf / obs kf index the map's own kfs, obs_begin its own obs table) */
 int hso_gpu_map_store(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, int n_kfs, const hso_map_point* points, int n_points,
                       const hso_obs* obs, int n_obs);
+/* The per-frame part of a stored map: refresh the points' quality keys ((Point::type_ << 4) | ftr_type_, 0 = TYPE_DELETED; what
+ * hso_map_point.pad_ holds) of any number of stored maps from one byte per point, without re-sending the tables.  The reference changes these every frame
+ * (n_succeeded_reproj_ > 10: UNKNOWN -> GOOD; n_failed_reproj_ > 15 / 30: deleted, src/reprojector.cpp:376-392, 412-423), and the
+ * device selection orders and skips by them.  New points / observations / keyframes need hso_gpu_map_store. */
+int hso_gpu_map_update_quality(hso_gpu_ctx* ctx, const int32_t* maps, int n_maps, const uint8_t* quality /* the maps' keys back to back,
+                               one byte per stored point */);
 /* project + choose the reference observation + findMatchDirect for every point of every call's map, one launch chain.
  * out: the calls' points back to back in call order (out_capacity entries available); returns their number or a status < 0 */
 int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,

@@ -39,6 +39,9 @@ def test_seed_table_matches_value_passing_calls(gpu_ctx, cam, pair2000):
                 gone = np.arange(0, 700, 7)
                 gpu_ctx.seed_table_erase(t, gone); alive[gone] = False
                 assert gpu_ctx.seed_table_size(t) == (700, 600)
+        # the table caches the host frame's base pointer per live seed: that frame cannot be released under it
+        with pytest.raises(capi.HsoGpuError, match="live seeds"):
+            gpu_ctx.frame_release(9301)
         back = gpu_ctx.seed_table_read(t, 0, 700)
         for i in np.where(alive)[0][:50]:
             assert (back[i].mu, back[i].sigma2, back[i].b) == (host[i].mu, host[i].sigma2, host[i].b)

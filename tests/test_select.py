@@ -183,6 +183,21 @@ def test_reproject_select_maps_equals_match_then_select(gpu_ctx):
                     assert (r["cell"], r["ref_obs"], r["search_level"], r["stage"]) == (src["cell"], src["ref_obs"], src["search_level"], src["stage"])
                     assert r["px"].tobytes() == src["px"].tobytes() and r["px_cur"].tobytes() == src["px_cur"].tobytes()   # (NaN where nothing matched)
         assert len(passes_seen) >= 2
+        # ---- the per-frame part of a stored map: the reference promotes (UNKNOWN -> GOOD) and deletes points between keyframes;
+        # hso_gpu_map_update_quality refreshes the keys alone, and the selection must follow them exactly like a re-stored map
+        q2 = P["points"]["pad_"].astype(np.uint8).copy()
+        flip = rng.random(len(q2)) < 0.3
+        q2[flip] = ((rng.integers(0, 5, size=int(flip.sum())) << 4) | (q2[flip] & 15)).astype(np.uint8)     # incl. new deletions (type 0)
+        base = gpu_ctx.reproject_select_maps(cam, calls, P["cell_size"], P["grid_n_cols"], order, 250, 2000)
+        gpu_ctx.map_update_quality([0], q2)
+        got_u, begin_u, counts_u = gpu_ctx.reproject_select_maps(cam, calls, P["cell_size"], P["grid_n_cols"], order, 250, 2000)
+        P2 = P["points"].copy(); P2["pad_"] = q2
+        gpu_ctx.map_store(0, P["kfs"], P2, P["obs"])
+        got_s, begin_s, counts_s = gpu_ctx.reproject_select_maps(cam, calls, P["cell_size"], P["grid_n_cols"], order, 250, 2000)
+        assert got_u.tobytes() == got_s.tobytes() and np.array_equal(begin_u, begin_s) and np.array_equal(counts_u, counts_s)
+        assert got_u.tobytes() != base[0].tobytes()                 # and it changed something
+        with pytest.raises(RuntimeError):
+            gpu_ctx.map_update_quality([9], q2)                     # no such map
     finally:
         for i in ids + [P["cur_frame_id"]]:
             gpu_ctx.frame_release(i)
