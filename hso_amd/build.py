@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libhso_gpu.so")
 SOURCES = ["hso_ctx.hip", "hso_frame.hip", "hso_tracker.hip", "hso_tracker_coop.hip", "hso_align.hip", "hso_pose.hip", "hso_ba.hip",
-           "hso_seed.hip", "hso_activate.hip", "hso_fast.hip", "hso_edgelet.hip", "hso_select.hip", "hso_octree.cpp"]
+           "hso_seed.hip", "hso_activate.hip", "hso_fast.hip", "hso_edgelet.hip", "hso_select.hip", "hso_klt.hip", "hso_octree.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # Per-file additions.  The tracker megakernel is compiled without LLVM's SLP vectoriser: the packed fp32 / packed 16-bit
@@ -71,7 +71,7 @@ def build_host(verbose=False):
     host = os.path.join(HERE, "host")
     rpath = ["-L" + CSRC, "-lhso_gpu", "-Wl,-rpath,$ORIGIN/../csrc",
              "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
-    srcs = [os.path.join(host, "hso_host.cpp"), os.path.join(host, "hso_vo.cpp"), os.path.join(host, "hso_multi.cpp")]
+    srcs = [os.path.join(host, "hso_host.cpp"), os.path.join(host, "hso_vo.cpp"), os.path.join(host, "hso_multi.cpp"), os.path.join(host, "hso_init.cpp")]
     lib = os.path.join(host, "libhso_host.so")
     exe = os.path.join(host, "hso_host_test")
     for cmd in (["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", "-pthread"] + srcs + rpath + ["-o", lib],

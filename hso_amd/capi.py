@@ -42,6 +42,19 @@ class SE3(C.Structure):
         return np.array(self.q[:]), np.array(self.t[:])
 
 
+class KltParams(C.Structure):
+    # hso_klt_params: the constants of initialization::trackKlt (src/initialization.cpp:236-245)
+    _fields_ = [("win_size", C.c_int32), ("max_level", C.c_int32), ("max_iter", C.c_int32), ("use_initial_flow", C.c_int32),
+                ("epsilon", C.c_double)]
+
+    def __init__(self, win_size=30, max_level=4, max_iter=30, use_initial_flow=1, epsilon=1e-4):
+        super().__init__(win_size, max_level, max_iter, use_initial_flow, epsilon)
+
+
+KLT_RESULT_DTYPE = np.dtype([("px", np.float32, 2), ("ncc", np.float32), ("status", np.int32)])
+KLT_TRACKED, KLT_PATCH_OK = 1, 2
+
+
 class FrameStats(C.Structure):
     _fields_ = [("integral_image", C.c_float), ("grad_mean", C.c_float),
                 ("width", C.c_int32), ("height", C.c_int32)]
@@ -313,6 +326,9 @@ def load():
     lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.hso_gpu_reproject_select_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.hso_gpu_map_update_quality.argtypes = [vp, vp, i32, vp]
+    lib.hso_gpu_klt_track.argtypes = [vp, i64, i64, vp, vp, i32, P(KltParams), vp]
+    lib.hso_gpu_klt_levels.argtypes = [i32, i32, i32, i32]
+    lib.hso_gpu_klt_debug_level.argtypes = [vp, i64, i32, vp, vp]
     lib.hso_gpu_reproject_select_pose_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp, P(PoseChain)]
     lib.hso_gpu_seed_activate_multi.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), P(i32), P(ActivateOut),
                                                 P(AlignOut)]
@@ -360,6 +376,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
     "hso_gpu_map_reserve", "hso_gpu_map_store", "hso_gpu_reproject_match_maps",
+    "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level",
 ]
 
 
@@ -726,6 +743,26 @@ class Context:
         m = np.ascontiguousarray(np.atleast_1d(maps), np.int32)
         q = np.ascontiguousarray(quality, np.uint8)
         self._check(self.lib.hso_gpu_map_update_quality(self.h, _ptr(m), len(m), _ptr(q)), "map_update_quality")
+
+    def klt_track(self, frame_prev, frame_cur, px_prev, px_init, params=None):
+        """initialization::trackKlt's device part between two resident frames -> KLT_RESULT_DTYPE array."""
+        a = np.ascontiguousarray(px_prev, np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(px_init, np.float32).reshape(-1, 2)
+        if len(a) != len(b):
+            raise ValueError("klt_track: px_prev and px_init differ in length")
+        out = np.zeros(len(a), KLT_RESULT_DTYPE)
+        params = params or KltParams()
+        self._check(self.lib.hso_gpu_klt_track(self.h, frame_prev, frame_cur, _ptr(a), _ptr(b), len(a), C.byref(params), _ptr(out)), "klt_track")
+        return out
+
+    def klt_debug_level(self, frame, level, width, height):
+        """Gaussian pyramid level + Scharr image the KLT tracker uses (test hook) -> (img uint8 [h, w], deriv int16 [h, w, 2])."""
+        w, h = width, height
+        for _ in range(level):
+            w, h = (w + 1) // 2, (h + 1) // 2
+        img = np.zeros((h, w), np.uint8); der = np.zeros((h, w, 2), np.int16)
+        self._check(self.lib.hso_gpu_klt_debug_level(self.h, frame, level, _ptr(img), _ptr(der)), "klt_debug_level")
+        return img, der
 
     def reproject_match_maps(self, cam, calls, cell_size, grid_n_cols, capacity):
         """calls: MAP_CALL_DTYPE array.  -> MATCH_BRIEF_DTYPE array (the calls' points back to back)."""

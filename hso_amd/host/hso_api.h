@@ -65,6 +65,19 @@ inline void pose_optimize(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_pos
   }
 }
 
+inline void klt_track(hso_gpu_ctx* ctx, int64_t prev_id, int64_t cur_id, const float* px_prev, const float* px_init, int n,
+                      const hso_klt_params* params, hso_klt_result* out)
+{
+  check(ctx, routed([&]() { return hso_gpu_klt_track(ctx, prev_id, cur_id, px_prev, px_init, n, params, out); }), "trackKlt");
+  Trace& t = trace();
+  if (t.on()) {
+    t.begin("klt_track", 6);
+    t.scalar("prev_frame_id", (double)prev_id); t.scalar("cur_frame_id", (double)cur_id);
+    t.field("px_prev", px_prev, sizeof(float) * 2 * (size_t)n); t.field("px_init", px_init, sizeof(float) * 2 * (size_t)n);
+    t.field("params", params, sizeof(*params)); t.field("result", out, sizeof(hso_klt_result) * (size_t)n);
+  }
+}
+
 inline void detect_candidates(hso_gpu_ctx* ctx, bool init, int64_t id, int n_levels, int min_thresh, hso_corner* co, int corner_cap,
                               int32_t* nc, hso_edgelet* ed, hso_corner* fill, int second_cap, int32_t* n_second)
 {

@@ -444,6 +444,15 @@ int hso_vo_multi_set_first_frames(hso_vo_multi* M, const uint8_t* const* imgs, i
   return step(M, tasks);
 }
 
+int hso_vo_multi_start(hso_vo_multi* M, const uint8_t* which)
+{
+  if (!M) return HSO_E_INVALID;
+  std::vector<std::function<int()>> tasks(M->seq.size());
+  for (size_t k = 0; k < M->seq.size(); k++)
+    if (!which || which[k]) tasks[k] = [=]() { return hso_vo_start(M->seq[k]->vo); };
+  return step(M, tasks);
+}
+
 int hso_vo_multi_add_images(hso_vo_multi* M, const uint8_t* const* imgs, int width, int height, const double* timestamps)
 {
   if (!M || !imgs) return HSO_E_INVALID;

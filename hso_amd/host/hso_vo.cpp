@@ -709,8 +709,10 @@ void FrameHandlerMono::resetAll()
   set_reset_ = false; set_start_ = false;
   tracking_quality_ = TRACKING_INSUFFICIENT;
   num_obs_last_ = 0;
-  last_frame_.reset(); new_frame_.reset();
+  last_frame_.reset(); new_frame_.reset(); firstFrame_.reset();
   core_kfs_.clear(); overlap_kfs_.clear();
+  klt_homography_init_.reset();
+  afterInit_ = false;
   depth_filter_->reset();
 }
 
@@ -740,13 +742,39 @@ void FrameHandlerMono::addImage(const uint8_t* img, int width, int height, doubl
   new_frame_->keyFrameId_ = map_.size() == 0 ? 0 : map_.lastKeyframe()->keyFrameId_;
   UpdateResult res = RESULT_FAILURE;
   if (stage_ == STAGE_DEFAULT_FRAME) res = processFrame();
+  else if (stage_ == STAGE_SECOND_FRAME) res = processSecondFrame();
+  else if (stage_ == STAGE_FIRST_FRAME) res = processFirstFrame();
   else if (stage_ == STAGE_RELOCALIZING) res = relocalizeFrame(SE3(), map_.getClosestKeyframe(last_frame_));
-  else throw std::logic_error("FrameHandlerMono: two-view initialisation is not part of this driver; call setFirstFrame()");
   if (last_frame_ && last_frame_ != new_frame_) last_frame_->m_last_frame.reset();   // do not chain every frame ever seen
   last_frame_ = new_frame_;
   new_frame_.reset();
   last_result_ = res;
   finishFrameProcessingCommon((size_t)last_frame_->id_, res, last_frame_->m_n_inliers);
+}
+
+FrameHandlerMono::UpdateResult FrameHandlerMono::processFirstFrame()      // src/frame_handler_mono.cpp:125-151
+{
+  new_frame_->T_f_w_ = SE3();
+  klt_homography_init_.poseoptim_thresh = Config::get().poseoptim_thresh;
+  if (klt_homography_init_.addFirstFrame(new_frame_) == initialization::FAILURE) return RESULT_NO_KEYFRAME;
+  new_frame_->setKeyframe();
+  map_.addKeyframe(new_frame_);
+  stage_ = STAGE_SECOND_FRAME;
+  firstFrame_ = new_frame_;
+  firstFrame_->m_exposure_time = 1.0;
+  return RESULT_IS_KEYFRAME;
+}
+
+FrameHandlerMono::UpdateResult FrameHandlerMono::processSecondFrame()     // :154-172
+{
+  const initialization::InitResult res = klt_homography_init_.addSecondFrame(new_frame_);
+  if (res == initialization::FAILURE) return RESULT_FAILURE;
+  if (res == initialization::NO_KEYFRAME) return RESULT_NO_KEYFRAME;
+  stage_ = STAGE_DEFAULT_FRAME;
+  klt_homography_init_.reset();
+  afterInit_ = true;
+  firstFrame_->setKeyPoints();
+  return RESULT_IS_KEYFRAME;
 }
 
 FrameHandlerMono::UpdateResult FrameHandlerMono::processFrame()
@@ -1040,6 +1068,31 @@ int hso_vo_set_first_frame(hso_vo* v, const uint8_t* img, int width, int height,
     frame_utils::getSceneDistance(*frame, distance_mean);
     v->vo->depth_filter_->addKeyframe(frame, distance_mean, 0.5 * depth_min, 200);
   });
+}
+
+int hso_vo_init_compute_matrix(const double* f_ref, const double* f_cur, int n, double focal_length, double reproj_thresh, hso_se3* T_cur_from_ref,
+                            int32_t* inliers, int cap, double* xyz_in_cur, int32_t* used_homography)
+{
+  if (!f_ref || !f_cur || n < 0 || !T_cur_from_ref) return HSO_E_INVALID;
+  try {
+    std::vector<hso::Vector3d> a(n), b(n), xyz;
+    for (int i = 0; i < n; i++) { a[i] = {f_ref[3 * i], f_ref[3 * i + 1], f_ref[3 * i + 2]}; b[i] = {f_cur[3 * i], f_cur[3 * i + 1], f_cur[3 * i + 2]}; }
+    std::vector<int> in;
+    hso::SE3 T;
+    int used = 0;
+    hso::initialization::computeInitializeMatrix(a, b, focal_length, reproj_thresh, in, xyz, T, &used);
+    *T_cur_from_ref = T.v;
+    if (used_homography) *used_homography = used;
+    for (size_t i = 0; i < in.size() && (int)i < cap && inliers; i++) inliers[i] = in[i];
+    for (size_t i = 0; i < xyz.size() && xyz_in_cur; i++) { xyz_in_cur[3 * i] = xyz[i][0]; xyz_in_cur[3 * i + 1] = xyz[i][1]; xyz_in_cur[3 * i + 2] = xyz[i][2]; }
+    return (int)in.size();
+  } catch (const std::exception&) { return HSO_E_INVALID; }
+}
+
+int hso_vo_start(hso_vo* v)
+{
+  if (!v) return HSO_E_INVALID;
+  return vo_guard(v, [&]() { v->vo->start(); });
 }
 
 int hso_vo_add_image(hso_vo* v, const uint8_t* img, int width, int height, double timestamp)

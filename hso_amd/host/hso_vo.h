@@ -23,6 +23,7 @@
 #include <string>
 #include <utility>
 #include "hso_host.h"
+#include "hso_init.h"
 
 namespace hso {
 
@@ -138,6 +139,10 @@ public:
   void addImage(const uint8_t* img, int width, int height, double timestamp);
   // :419-426 — the first keyframe comes from the caller (features with points), no two-view initialisation
   void setFirstFrame(const FramePtr& first_frame);
+  // FrameHandlerBase::start() (include/hso/frame_handler_base.h:75): the next addImage is the first frame of the two-view
+  // initialisation (processFirstFrame / processSecondFrame, src/frame_handler_mono.cpp:125-172)
+  void start() { set_start_ = true; }
+  initialization::KltHomographyInit klt_homography_init_;
   FramePtr lastFrame() { return last_frame_; }
   Stage stage() const { return stage_; }
   TrackingQuality trackingQuality() const { return tracking_quality_; }
@@ -155,6 +160,8 @@ public:
   std::set<Frame*> LocalMap_;
 
 protected:
+  UpdateResult processFirstFrame();
+  UpdateResult processSecondFrame();
   UpdateResult processFrame();
   UpdateResult relocalizeFrame(const SE3& T_cur_ref, FramePtr ref_keyframe);
   bool needNewKf(const double& scene_depth_mean, const size_t& num_observations);

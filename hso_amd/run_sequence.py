@@ -7,8 +7,8 @@ FrameHandlerMono::addImage in order, write the keyframe trajectory in the refere
 
 Options (the reference's `key=value` style, test_dataset.cpp:66-114):
   start=<i> end=<i>        frame range (test/euroc_batch.sh:9 uses start=50 for MH_01)
-  depth0=<file.npy|.f32>   optical-axis depth image of the first frame: the initial map.  Required while the driver has no
-                           two-view initialisation (HAS_TWO_VIEW_INIT below; see include/hso_vo.h).
+  depth0=<file.npy|.f32>   optical-axis depth image of the first frame: the initial map comes from it (hso_vo_set_first_frame)
+                           instead of the two-view initialisation (hso_vo_start, the reference's own start)
   max_fts=<n>              Config::maxFts() (200)
   result=<path>            trajectory file (default ./result/KeyFrameTrajectory.txt)
   gt=<trajectory file>     ground truth in the same format: prints the ATE (RMSE after similarity alignment)
@@ -22,7 +22,7 @@ import time
 
 import numpy as np
 
-HAS_TWO_VIEW_INIT = False      # the driver starts from hso_vo_set_first_frame + a depth image (SURVEY section 8(f) rank 4 not built)
+HAS_TWO_VIEW_INIT = True       # hso_vo_start: KLT + essential matrix / homography (hso_amd/host/hso_init.h)
 
 
 def load_image(path):
@@ -43,10 +43,9 @@ def main(argv, return_line=False):
     files = formats.list_images(folder) or sorted(os.path.join(folder, n) for n in os.listdir(folder) if n.lower().endswith(".pgm"))
     stamps = formats.read_stamps(stamp_file) if stamp_file not in ("None", "none", "") else None
     start, end = int(opt.get("start", 0)), min(int(opt.get("end", len(files))), len(files))
-    if "depth0" not in opt and not HAS_TWO_VIEW_INIT:
-        print("depth0=<file> is required: the driver starts from a first keyframe with known depths (no two-view initialisation)")
-        return 2
-    d0 = np.load(opt["depth0"]) if opt["depth0"].endswith(".npy") else np.fromfile(opt["depth0"], np.float32).reshape(H, W)
+    d0 = None
+    if "depth0" in opt:
+        d0 = np.load(opt["depth0"]) if opt["depth0"].endswith(".npy") else np.fromfile(opt["depth0"], np.float32).reshape(H, W)
     odo = vo.VisualOdometry(cam, int(opt.get("max_fts", 200)))
     if "trace" in opt:
         odo.trace(opt["trace"])
@@ -64,19 +63,25 @@ def main(argv, return_line=False):
         resize_ctx.frame_release(1)
         return out
 
-    rows, t_frames, n_fail = [], [], 0
+    rows, t_frames, n_fail, n_init = [], [], 0, 0
+    if d0 is None:
+        odo.start()                                     # vo_->start(), test/test_dataset.cpp:276
     trace_frames = int(opt.get("trace_frames", 0))
     for k, i in enumerate(range(start, end)):
         img = prepare(load_image(files[i]))
         if trace_frames and k == trace_frames:
             odo.trace(None)
         t0 = time.perf_counter()
-        if k == 0:
+        if k == 0 and d0 is not None:
             odo.set_first_frame(img, d0, float(i))
             st = odo.status()
         else:
             st = odo.add_image(img, float(i))          # vo_->addImage(image, img_id, &time_stamp)
-            n_fail += int(st.result == 2 or st.stage != 3)     # RESULT_FAILURE / not STAGE_DEFAULT_FRAME
+            if st.stage == 0 and d0 is None:            # the initialisation failed and paused the handler: start over, like a user of the reference would
+                odo.start()
+            initialising = st.stage in (0, 1, 2) and d0 is None and n_init == k
+            n_init += int(initialising)
+            n_fail += int(not initialising and (st.result == 2 or st.stage != 3))     # RESULT_FAILURE / not STAGE_DEFAULT_FRAME
         t_frames.append(time.perf_counter() - t0)
         if opt.get("times"):
             print("frame %d  %.2f ms  kf=%d stage=%d obs=%d matches=%d seeds=%d" % (i, 1e3 * t_frames[-1], st.is_keyframe, st.stage,
@@ -90,7 +95,7 @@ def main(argv, return_line=False):
     os.makedirs(os.path.dirname(os.path.abspath(result)), exist_ok=True)
     formats.write_trajectory(result, rows)
     line = {"frames": end - start, "keyframes": len(rows), "frames_per_s": (len(t_frames) - 1) / max(sum(t_frames[1:]), 1e-9),
-            "tracking_failures": n_fail, "result": result}
+            "tracking_failures": n_fail, "init_frames": n_init, "result": result}
     if "gt" in opt:
         (es, exyz, _), (gs, gxyz, _) = formats.read_trajectory(result), formats.read_trajectory(opt["gt"])
         common = [s_ for s_ in es if s_ in set(gs)]

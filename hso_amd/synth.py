@@ -28,7 +28,7 @@ FOV_920 = dict(TUM_WIDE, d=(0.6,), distortion=1)
 
 
 def camera(spec=ICL_NUIM):
-    return make_camera(**spec)
+    return make_camera(**{k: v for k, v in spec.items() if k != "texture_om"})    # texture_om describes the scene, not the camera
 
 
 def quat_to_R(q):
@@ -58,6 +58,12 @@ class Scene:
         self.distortion = bool(spec.get("distortion", 1)) if self.model == CAM_FOV else abs(self.d[0]) > 1e-7
         rng = np.random.default_rng(seed)
         om = rng.uniform(0.02, 0.6, n_waves)
+        if "texture_om" in spec:
+            # optional bands of spatial frequency (rad / px), the waves split evenly among them: a scene with the low-frequency
+            # content natural images have (the default band has none below a 314 px wavelength; a large misprediction of the
+            # tracker's start, as after the two-view initialisation, then has no coarse level to recover on)
+            bands = list(spec["texture_om"])
+            om = np.concatenate([rng.uniform(lo, hi, len(part)) for (lo, hi), part in zip(bands, np.array_split(np.arange(n_waves), len(bands)))])
         ang = rng.uniform(0, 2 * np.pi, n_waves)
         self.wx, self.wy = om * np.cos(ang), om * np.sin(ang)
         self.ph = rng.uniform(0, 2 * np.pi, n_waves)

@@ -44,6 +44,8 @@ def load():
     lib.hso_vo_trace.argtypes = [vp, C.c_char_p]
     lib.hso_vo_set_first_frame.argtypes = [vp, vp, i32, i32, C.c_double, vp, P(capi.SE3)]
     lib.hso_vo_add_image.argtypes = [vp, vp, i32, i32, C.c_double]
+    lib.hso_vo_start.argtypes = [vp]
+    lib.hso_vo_init_compute_matrix.argtypes = [vp, vp, i32, C.c_double, C.c_double, P(capi.SE3), vp, i32, vp, vp]
     lib.hso_vo_get_status.argtypes = [vp, P(VoStatus)]
     lib.hso_vo_get_keyframes.argtypes = [vp, vp, vp, vp, i32]
     lib.hso_vo_multi_create.argtypes = [P(vp), P(capi.Camera), i32, i32, i32]
@@ -54,6 +56,7 @@ def load():
     lib.hso_vo_multi_size.argtypes = [vp]
     lib.hso_vo_multi_set_first_frames.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.hso_vo_multi_add_images.argtypes = [vp, vp, i32, i32, vp]
+    lib.hso_vo_multi_start.argtypes = [vp, vp]
     lib.hso_vo_multi_get_status.argtypes = [vp, i32, P(VoStatus)]
     lib.hso_vo_multi_get_keyframes.argtypes = [vp, i32, vp, vp, vp, i32]
     lib.hso_vo_multi_call_counts.argtypes = [vp, vp, vp, i32]
@@ -62,10 +65,10 @@ def load():
 
 
 EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso_vo_trace", "hso_vo_set_first_frame",
-                    "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes",
+                    "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes", "hso_vo_start", "hso_vo_init_compute_matrix",
                     "hso_vo_multi_create", "hso_vo_multi_destroy", "hso_vo_multi_last_error", "hso_vo_multi_size",
                     "hso_vo_multi_set_first_frames", "hso_vo_multi_add_images", "hso_vo_multi_get_status", "hso_vo_multi_get_keyframes",
-                    "hso_vo_multi_call_counts"]
+                    "hso_vo_multi_call_counts", "hso_vo_multi_start"]
 
 CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_match", "align", "pose", "seed_observe", "seed_activate", "ba", "solo"]
 
@@ -106,6 +109,10 @@ class MultiVisualOdometry:
         ts = np.ascontiguousarray(timestamps if timestamps is not None else np.zeros(self.n), np.float64)
         h, w = imgs[0].shape
         self._check(self.lib.hso_vo_multi_set_first_frames(self.h, self._ptrs(imgs), w, h, ts.ctypes.data, self._ptrs(depths), None), "set_first_frames")
+
+    def start(self, which=None):
+        w = np.ascontiguousarray(which, np.uint8) if which is not None else None
+        self._check(self.lib.hso_vo_multi_start(self.h, w.ctypes.data if w is not None else None), "start")
 
     def add_images(self, imgs, timestamps):
         """imgs: one image per sequence, None = the sequence sits this step out."""
@@ -169,6 +176,10 @@ class VisualOdometry:
                                                     capi._ptr(depth_z), C.byref(T_f_w) if T_f_w is not None else None),
                     "set_first_frame")
 
+    def start(self):
+        """FrameHandlerBase::start(): the next images run the two-view initialisation."""
+        self._check(self.lib.hso_vo_start(self.h), "start")
+
     def add_image(self, img, timestamp):
         img = np.ascontiguousarray(img, np.uint8)
         self._check(self.lib.hso_vo_add_image(self.h, capi._ptr(img), img.shape[1], img.shape[0], float(timestamp)), "add_image")
@@ -184,6 +195,20 @@ class VisualOdometry:
         ts = np.zeros(max(n, 1)); T = (capi.SE3 * max(n, 1))(); ids = np.zeros(max(n, 1), np.int32)
         self.lib.hso_vo_get_keyframes(self.h, capi._ptr(ts), C.cast(T, C.c_void_p), capi._ptr(ids), n)
         return [(float(ts[i]), T[i], int(ids[i])) for i in range(n)]
+
+
+def init_compute_matrix(f_ref, f_cur, focal_length, reproj_thresh=2.0):
+    """initialization::computeInitializeMatrix on unit bearings (n, 3) -> (T_cur_from_ref SE3, inlier indices, xyz_in_cur (n, 3),
+    used_homography).  Host code only."""
+    lib = load()
+    a = np.ascontiguousarray(f_ref, np.float64); b = np.ascontiguousarray(f_cur, np.float64)
+    n = len(a)
+    T = capi.SE3(); inl = np.zeros(max(n, 1), np.int32); xyz = np.zeros((max(n, 1), 3)); used = np.zeros(1, np.int32)
+    k = lib.hso_vo_init_compute_matrix(capi._ptr(a), capi._ptr(b), n, float(focal_length), float(reproj_thresh), C.byref(T), capi._ptr(inl), n,
+                                    capi._ptr(xyz), capi._ptr(used))
+    if k < 0:
+        raise capi.HsoGpuError("hso_vo_init_compute_matrix failed: %d" % k)
+    return T, inl[:k].copy(), xyz[:n], int(used[0])
 
 
 def read_trace(path):

@@ -776,6 +776,32 @@ typedef struct hso_keypoint {   /* KeyPoint, include/hso/feature_detection.h:188
 int hso_gpu_select_octree(const hso_keypoint* keys, int n, int min_x, int max_x, int min_y, int max_y, int n_features,
                              hso_keypoint* out, int cap);
 
+/* ---- two-view initialisation, image side: initialization::trackKlt (src/initialization.cpp:225-300) =
+ *      cv::calcOpticalFlowPyrLK(img_prev, img_cur, px_prev, px_cur, status, error, Size(30, 30), 4,
+ *      TermCriteria(COUNT + EPS, 30, 0.0001), OPTFLOW_USE_INITIAL_FLOW) and patchCheck (:476-563) per point.  The geometry that
+ *      follows (computeInitializeMatrix, :300-385) is host code (hso_amd/host/hso_init.cpp). ---- */
+typedef struct hso_klt_params {
+  int32_t win_size;          /* 30 (klt_win_size); 3..32 */
+  int32_t max_level;         /* 4: the pyramid stops earlier when the next level would not exceed the window (752x480: levels 0..3) */
+  int32_t max_iter;          /* 30 (klt_max_iter) */
+  int32_t use_initial_flow;  /* 1: px_init is the start (OPTFLOW_USE_INITIAL_FLOW); 0: px_prev is */
+  double epsilon;            /* 0.0001 (klt_eps): the stop test is |delta|^2 <= epsilon^2 */
+} hso_klt_params;
+enum { HSO_KLT_TRACKED = 1,  /* calcOpticalFlowPyrLK's status byte */
+       HSO_KLT_PATCH_OK = 2  /* patchCheck: both 8x8 patches inside their images and zero-mean NCC > 0.8 */ };
+typedef struct hso_klt_result {
+  float px[2];               /* px_cur */
+  float ncc;                 /* patchCheck's correlation; -2 when a patch leaves its image */
+  int32_t status;            /* HSO_KLT_* bits; trackKlt keeps a point iff both are set */
+} hso_klt_result;
+/* Both frames resident (same size).  px_prev / px_init: n x 2 floats (host); out: n results (host). */
+int hso_gpu_klt_track(hso_gpu_ctx* ctx, int64_t frame_prev, int64_t frame_cur, const float* px_prev, const float* px_init, int n,
+                      const hso_klt_params* params, hso_klt_result* out);
+int hso_gpu_klt_levels(int width, int height, int win, int max_level);   /* index of the coarsest level the call above uses */
+/* test hook: Gaussian pyramid level `level` of a resident frame (cv::pyrDown chain) and its Scharr derivative image
+ * (interleaved Ix, Iy); either output may be NULL */
+int hso_gpu_klt_debug_level(hso_gpu_ctx* ctx, int64_t frame, int level, uint8_t* img_out, int16_t* deriv_out);
+
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

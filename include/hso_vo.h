@@ -7,9 +7,12 @@
  *   new FrameHandlerMono(cam, false)          hso_vo_create
  *   vo->addImage(img, id, &stamp)             hso_vo_add_image
  *   vo->lastFrame(), map_.keyframes_          hso_vo_get_status, hso_vo_get_keyframes
- * The two-view initialisation (src/initialization.cpp: OpenCV KLT + essential-matrix RANSAC) is not part of the
- * hot path; a sequence starts from hso_vo_set_first_frame — the setFirstFrame hook the reference keeps for
- * synthetic data (frame_handler_mono.h:49-50, .cpp:419-426) — with a depth image for the first keyframe.
+ *   vo->start()                               hso_vo_start
+ * A sequence starts either like the reference's harness — hso_vo_start, then images: the two-view initialisation
+ * (src/initialization.cpp; pyramidal KLT on the device, essential matrix / homography on the host, see
+ * hso_amd/host/hso_init.h for what replaces its OpenCV calls) builds the first map once the median disparity reaches
+ * Config::initMinDisparity — or from hso_vo_set_first_frame, the setFirstFrame hook the reference keeps for synthetic data
+ * (frame_handler_mono.h:49-50, .cpp:419-426), with a depth image for the first keyframe.
  */
 #ifndef HSO_VO_H
 #define HSO_VO_H
@@ -30,6 +33,10 @@ int hso_vo_trace(hso_vo* vo, const char* path);
  * depth_z[y * width + x] > 0 (depth along the optical axis, metres) becomes a map point hosted in this frame */
 int hso_vo_set_first_frame(hso_vo* vo, const uint8_t* img, int width, int height, double timestamp, const float* depth_z,
                            const hso_se3* T_f_w /* NULL = identity */);
+/* FrameHandlerBase::start(): the next image is the first frame of the two-view initialisation (stage 1, then 2 until the
+ * disparity suffices, then 3).  hso_vo_status.result is 1 for the frames that became keyframes, 0 while the disparity is short,
+ * 2 when it failed (too few tracked points / inliers: the handle is paused again, call hso_vo_start to retry). */
+int hso_vo_start(hso_vo* vo);
 /* FrameHandlerMono::addImage.  HSO_E_INVALID with hso_vo_last_error() where the reference throws (wrong image size). */
 int hso_vo_add_image(hso_vo* vo, const uint8_t* img, int width, int height, double timestamp);
 
@@ -62,6 +69,9 @@ int hso_vo_multi_size(const hso_vo_multi* m);
 /* arrays of n_sequences entries; a NULL image = the sequence sits this step out (sequences need not have equal lengths) */
 int hso_vo_multi_set_first_frames(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps,
                                   const float* const* depth_z, const hso_se3* T_f_w /* n_sequences or NULL */);
+/* hso_vo_start for every sequence (which = NULL) or for the sequences with which[k] != 0: their next images run the two-view
+ * initialisation; its KLT call has no multi-sequence form and is serialised with the other sequences' device calls */
+int hso_vo_multi_start(hso_vo_multi* m, const uint8_t* which);
 int hso_vo_multi_add_images(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps);
 int hso_vo_multi_get_status(hso_vo_multi* m, int sequence, hso_vo_status* st);
 int hso_vo_multi_get_keyframes(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
@@ -69,6 +79,12 @@ int hso_vo_multi_get_keyframes(hso_vo_multi* m, int sequence, double* timestamps
  * [2] tracker, [3] reprojection + matching, [4] matching alone, [5] pose, [6] seed observation, [7] seed activation, [8] local BA,
  * [9] calls without a multi-sequence form.  Returns the number of kinds. */
 int hso_vo_multi_call_counts(hso_vo_multi* m, int64_t* calls, int64_t* items, int cap);
+
+/* initialization::computeInitializeMatrix (src/initialization.cpp:300-385) alone, for tests and tools: n unit bearings per frame
+ * (3 doubles each) -> T_cur_from_ref, the inlier indices (at most cap; returns their number), the triangulated points in the
+ * current frame (n x 3, unscaled: |t| = 1) and which model won (0 essential, 1 homography).  Pure host code: no device call. */
+int hso_vo_init_compute_matrix(const double* f_ref, const double* f_cur, int n, double focal_length, double reproj_thresh, hso_se3* T_cur_from_ref,
+                            int32_t* inliers, int cap, double* xyz_in_cur, int32_t* used_homography);
 
 #ifdef __cplusplus
 }

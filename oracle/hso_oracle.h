@@ -199,6 +199,14 @@ void hso_or_detect_grid(int width, int height, int level, int* grid, int* gcols,
 int hso_or_detect_cell_index(int x, int y, int grid, int gcols, int grows);
 int hso_or_edgelet_level(const int16_t* gx, const int16_t* gy, int w, int h, int level, int frame_w, int frame_h, int min_thresh,
                          uint8_t* have, hso_edgelet* out, int cap);
+/* ---- two-view initialisation, image side (src/initialization.cpp:225-300, :476-563; cv::calcOpticalFlowPyrLK restated, unpinned:
+ *      hso_oracle_klt.c) ---- */
+void hso_or_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst);
+void hso_or_scharr_deriv(const uint8_t* src, int w, int h, int16_t* d);
+int hso_or_klt_levels(int w, int h, int win, int max_level);
+void hso_or_klt_track(const uint8_t* prev, const uint8_t* cur, int w, int h, const float* pts_prev, float* pts_cur, uint8_t* status, int n,
+                      int win, int max_level, int max_count, double epsilon, int use_initial_flow, float* margin);
+int hso_or_patch_check(const uint8_t* img_pre, const uint8_t* img_cur, int w, int h, const float px_pre[2], const float px_cur[2], float* ncc_out);
 /* per-term dump of the last evaluation for debugging: returns number of rows written */
 int hso_or_tracker_pattern(int max_level, int level, int* patch_area, int* half_patch,
                            int8_t* offsets_xy);

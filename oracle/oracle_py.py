@@ -766,3 +766,61 @@ def margins():
     m = Margins()
     lib.hso_or_margins_get(C.byref(m))
     return m
+
+
+# ---- two-view initialisation, image side (hso_oracle_klt.c) ----
+def pyr_down(img):
+    """cv::pyrDown (8-bit, BORDER_REFLECT_101)."""
+    lib = load()
+    lib.hso_or_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib.hso_or_pyr_down(img.ctypes.data, w, h, out.ctypes.data)
+    return out
+
+
+def scharr_deriv(img):
+    """calcSharrDeriv -> (h, w, 2) int16 (Ix, Iy)."""
+    lib = load()
+    lib.hso_or_scharr_deriv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w, 2), np.int16)
+    lib.hso_or_scharr_deriv(img.ctypes.data, w, h, out.ctypes.data)
+    return out
+
+
+def klt_levels(w, h, win=30, max_level=4):
+    lib = load()
+    lib.hso_or_klt_levels.restype = C.c_int
+    return lib.hso_or_klt_levels(C.c_int(w), C.c_int(h), C.c_int(win), C.c_int(max_level))
+
+
+def klt_track(prev, cur, px_prev, px_init, win=30, max_level=4, max_count=30, epsilon=1e-4, use_initial_flow=True):
+    """initialization::trackKlt's cv::calcOpticalFlowPyrLK call -> (px_cur (n, 2) float32, status (n,) uint8, margin (n,) float32)."""
+    lib = load()
+    lib.hso_or_klt_track.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_double, C.c_int, C.c_void_p]
+    prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+    h, w = prev.shape
+    a = np.ascontiguousarray(px_prev, np.float32).reshape(-1, 2)
+    b = np.array(px_init, np.float32).reshape(-1, 2).copy()
+    n = len(a)
+    st = np.zeros(n, np.uint8); mg = np.zeros(n, np.float32)
+    lib.hso_or_klt_track(prev.ctypes.data, cur.ctypes.data, w, h, a.ctypes.data, b.ctypes.data, st.ctypes.data, n, win, max_level, max_count,
+                         epsilon, 1 if use_initial_flow else 0, mg.ctypes.data)
+    return b, st, mg
+
+
+def patch_check(img_pre, img_cur, px_pre, px_cur):
+    """initialization::patchCheck -> (ok, ncc); ncc = -2 when a patch leaves the image."""
+    lib = load()
+    lib.hso_or_patch_check.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hso_or_patch_check.restype = C.c_int
+    img_pre = np.ascontiguousarray(img_pre, np.uint8); img_cur = np.ascontiguousarray(img_cur, np.uint8)
+    h, w = img_pre.shape
+    a = np.ascontiguousarray(px_pre, np.float32); b = np.ascontiguousarray(px_cur, np.float32)
+    ncc = C.c_float(0)
+    ok = lib.hso_or_patch_check(img_pre.ctypes.data, img_cur.ctypes.data, w, h, a.ctypes.data, b.ctypes.data, C.byref(ncc))
+    return bool(ok), ncc.value
