@@ -70,6 +70,25 @@ class Replayer:
         assert st.integral_image == pytest.approx(so.integral_image, rel=2e-4) and st.grad_mean == pytest.approx(so.grad_mean, rel=2e-4)
         self.bump("frame", "n")
 
+    def klt_track(self, r):
+        """initialization::trackKlt's device call (tests/test_klt.py states the bar: status equal, position within 2e-3 px unless the
+        restatement's own decision margin was below 1e-3; the patch check restated on the device's position)."""
+        kp = capi.KltParams.from_buffer_copy(r["params"])
+        prev, cur = self.frames[int(vo.scalar(r, "prev_frame_id"))]["img"], self.frames[int(vo.scalar(r, "cur_frame_id"))]["img"]
+        a = np.frombuffer(r["px_prev"], np.float32).reshape(-1, 2); b = np.frombuffer(r["px_init"], np.float32).reshape(-1, 2)
+        g = np.frombuffer(r["result"], capi.KLT_RESULT_DTYPE)
+        o_px, o_st, o_mg = self.orc.klt_track(prev, cur, a, b, kp.win_size, kp.max_level, kp.max_iter, kp.epsilon, bool(kp.use_initial_flow))
+        excused = o_mg < 1e-3
+        tracked = (g["status"] & capi.KLT_TRACKED) != 0
+        assert not ((tracked != (o_st > 0)) & ~excused).any()
+        both = tracked & (o_st > 0)
+        assert not (both & ~excused & (np.abs(g["px"] - o_px).max(axis=1) > 2e-3)).any()
+        for i in np.flatnonzero(both):
+            ok, ncc = self.orc.patch_check(prev, cur, a[i], g["px"][i])
+            assert abs(ncc - g["ncc"][i]) <= 1e-5
+            assert ok == bool(g["status"][i] & capi.KLT_PATCH_OK) or abs(ncc - 0.8) < 1e-4
+        self.bump("klt", "n"); self.bump("klt", "points", len(a)); self.bump("klt", "excused", int(excused.sum()))
+
     def coarse_track(self, r):
         cam = capi.Camera.from_buffer_copy(r["cam"]); p = capi.TrackParams.from_buffer_copy(r["params"])
         feats = np.frombuffer(r["feats"], capi.REF_FEAT_DTYPE)
@@ -400,6 +419,28 @@ def test_chain_stage_by_stage(orc, tmp_path, name, spec, n_frames, max_fts):
     assert s["reproject"]["success"] >= 0.8 * s["reproject"]["matched_calls"]
     assert s["seed"]["updated"] > 0.3 * s["seed"]["n"]
     assert s["activate"]["n"] > 20 and s["detect"]["octree"] >= n_kf - 1 and s["detect"]["octree_selected"] > 50
+
+
+def test_chain_from_two_view_start(orc, tmp_path):
+    """The reference's own start (hso_vo_start, no depth image): every device call of the initialisation (the 2000-feature
+    detection of the first frame, one KLT call per following frame) and of the frames after it replayed against the restatement."""
+    spec = dict(synth.EUROC, texture_om=((0.004, 0.05), (0.05, 0.6)))            # see tests/test_init.py: init_seq
+    S = synth.sequence(24, spec=spec, step=(0.05, 0.015, 0.01), rot_deg_per_frame=(0.05, -0.1, 0.03))
+    odo = vo.VisualOdometry(synth.camera(spec), 200)
+    trace = str(tmp_path / "trace.bin")
+    odo.trace(trace)
+    odo.start()
+    stages = [odo.add_image(im, float(k)).stage for k, im in enumerate(S["images"])]
+    odo.close()
+    k_init = stages.index(3)
+    assert stages[:k_init] == [2] * k_init and stages[k_init:] == [3] * (len(stages) - k_init) and 5 <= k_init <= 16, stages
+    rp = Replayer(orc)
+    for call, r in vo.read_trace(trace):
+        getattr(rp, call)(r)
+    s = rp.stat
+    print("two-view start replay:", s)
+    assert s["klt"]["n"] == k_init and s["klt"]["points"] > 500 * k_init and s["klt"]["excused"] < 0.05 * s["klt"]["points"]
+    assert s["track"]["n"] == len(stages) - 1 - k_init and s["pose"]["n"] == s["track"]["n"]
 
 
 def test_run_sequence_harness(tmp_path):

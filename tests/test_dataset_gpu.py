@@ -12,7 +12,7 @@ then replay the recorded device calls of the first frames against the CPU restat
 same margin rules) and report the ATE against the data set's ground truth when `$HSO_EUROC_MH01_GT` / `$HSO_TUM_SEQ01_GT` name a
 trajectory file in the harness's own format (stamp tx ty tz qx qy qz qw).
 
-The first keyframe's depths come from the two-view initialisation (hso_vo's KLT + essential-matrix start) or, when
+The first keyframe's depths come from the two-view initialisation (hso_vo_start: KLT on the device, essential matrix / homography on the host) or, when
 `$HSO_EUROC_MH01_DEPTH0` / `$HSO_TUM_SEQ01_DEPTH0` name an optical-axis depth image (.npy, camera size) for the first frame used,
 from that image."""
 import os

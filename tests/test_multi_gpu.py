@@ -63,3 +63,32 @@ def test_four_sequences_in_lockstep_equal_four_single_runs():
     assert items > n_frames // 2 and items / calls > 2.0, counts
     assert counts["ba"][1] >= n_kf - len(seqs) - 4 and counts["seed_activate"][1] > 0 and counts["solo"][0] > 0
     print("multi-sequence driver: batched calls / requests per kind", counts)
+
+
+def test_two_sequences_started_from_images_equal_their_single_runs():
+    """hso_vo_multi_start: both sequences run the two-view initialisation (at different frames: different speeds) inside the
+    lockstep driver — its KLT calls serialised through the router — and every status record equals the solo run's."""
+    spec = dict(synth.EUROC, texture_om=((0.004, 0.05), (0.05, 0.6)))            # see tests/test_init.py: init_seq
+    cam = synth.camera(spec)
+    steps = [(0.05, 0.015, 0.01), (0.07, 0.01, 0.015)]
+    seqs = [synth.sequence(22, spec=spec, seed=4100 + 13 * k, step=steps[k], rot_deg_per_frame=(0.05, -0.1, 0.03)) for k in range(2)]
+    solo = []
+    for S in seqs:
+        odo = vo.VisualOdometry(cam, 200)
+        odo.start()
+        solo.append([_status_bytes(odo.add_image(im, float(k))) for k, im in enumerate(S["images"])])
+        odo.close()
+    multi = vo.MultiVisualOdometry(cam, 2, 200)
+    multi.start()
+    got = [[], []]
+    for k in range(22):
+        multi.add_images([S["images"][k] for S in seqs], [float(k)] * 2)
+        for q in range(2):
+            got[q].append(_status_bytes(multi.status(q)))
+    stages = [[multi.status(q).stage for q in range(2)]]
+    multi.close()
+    for q in range(2):
+        for k, (a, b) in enumerate(zip(got[q], solo[q])):
+            assert a == b, "sequence %d frame %d differs from its solo run" % (q, k)
+    init_at = [next(k for k, b in enumerate(got[q]) if vo.VoStatus.from_buffer_copy(b).stage == 3) for q in range(2)]
+    assert init_at[0] != init_at[1] and stages[0] == [3, 3], (init_at, stages)
