@@ -326,6 +326,8 @@ def load():
     lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.hso_gpu_reproject_select_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.hso_gpu_map_update_quality.argtypes = [vp, vp, i32, vp]
+    lib.hso_gpu_host_alloc.argtypes = [vp, C.c_size_t, P(vp)]
+    lib.hso_gpu_host_free.argtypes = [vp, vp]
     lib.hso_gpu_klt_track.argtypes = [vp, i64, i64, vp, vp, i32, P(KltParams), vp]
     lib.hso_gpu_klt_levels.argtypes = [i32, i32, i32, i32]
     lib.hso_gpu_klt_debug_level.argtypes = [vp, i64, i32, vp, vp]
@@ -376,7 +378,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
     "hso_gpu_map_reserve", "hso_gpu_map_store", "hso_gpu_reproject_match_maps",
-    "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level",
+    "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level", "hso_gpu_host_alloc", "hso_gpu_host_free",
 ]
 
 
@@ -425,6 +427,18 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.hso_gpu_synchronize(self.h), "synchronize")
+
+    def host_array(self, shape, dtype):
+        """A numpy array over page-locked memory of hso_gpu_host_alloc (zeroed): pass it as an `out=` / input table and the DMA goes
+        straight to it.  Lives as long as the context."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+        p = C.c_void_p()
+        self._check(self.lib.hso_gpu_host_alloc(self.h, max(n * dt.itemsize, 1), C.byref(p)), "host_alloc")
+        buf = (C.c_char * max(n * dt.itemsize, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+        a[...] = np.zeros((), dt)
+        return a
 
     # -- frames
     def frame_upload(self, frame_id, img, device_ptr=None, width=None, height=None):
@@ -712,13 +726,18 @@ class Context:
         self._check(self.lib.hso_gpu_seed_table_size(self.h, table, C.byref(a), C.byref(b)), "seed_table_size")
         return a.value, b.value
 
-    def seed_table_observe(self, cam, table, frames, px_error_angle, want_brief=True, want_full=False):
-        """frames: list of (frame_id, SE3 T_f_w, exposure_time), one per group.  -> (brief array or None, full ctypes array or None)"""
+    def seed_table_observe(self, cam, table, frames, px_error_angle, want_brief=True, want_full=False, brief_out=None):
+        """frames: list of (frame_id, SE3 T_f_w, exposure_time), one per group.  -> (brief array or None, full ctypes array or None)
+        brief_out: a SEED_BRIEF_DTYPE array of >= the table's size to receive the briefs (host_array(): no staging copy)."""
         fr = (SeedFrame * len(frames))()
         for k, (fid, T, expo) in enumerate(frames):
             fr[k].frame_id, fr[k].T_f_w, fr[k].exposure_time = fid, T, expo
         n, _ = self.seed_table_size(table)
-        brief = np.zeros(n, SEED_BRIEF_DTYPE) if want_brief else None
+        if brief_out is not None:
+            assert brief_out.dtype == SEED_BRIEF_DTYPE and len(brief_out) >= n and brief_out.flags.c_contiguous
+            brief = brief_out[:n]
+        else:
+            brief = np.zeros(n, SEED_BRIEF_DTYPE) if want_brief else None
         full = (SeedOut * max(n, 1))() if want_full else None
         self._check(self.lib.hso_gpu_seed_table_observe(self.h, C.byref(cam), table, fr, len(frames), px_error_angle, _ptr(brief),
                                                         C.cast(full, C.c_void_p) if want_full else None), "seed_table_observe")
@@ -786,12 +805,15 @@ class Context:
         return out[:n], begin, counts
 
     def reproject_select_pose_maps(self, cam, calls, cell_size, grid_n_cols, cell_order, max_fts, capacity, reproj_thresh=2.0, n_iter=12,
-                                   want_mask=True):
+                                   want_mask=True, out=None):
         """reproject_select_maps + the pose optimisation chained on the device.
-        -> (briefs, begin, counts, PoseResult array, n_feats[n_calls], mask[n_calls, max(max_fts, 1)] or None)"""
+        -> (briefs, begin, counts, PoseResult array, n_feats[n_calls], mask[n_calls, max(max_fts, 1)] or None).
+        out: a MATCH_BRIEF_DTYPE array of >= capacity records to receive the briefs (host_array(): no staging copy)."""
         calls = np.ascontiguousarray(calls, MAP_CALL_DTYPE)
         order = np.ascontiguousarray(cell_order, np.int32)
-        out = np.zeros(capacity, MATCH_BRIEF_DTYPE)
+        if out is None:
+            out = np.zeros(capacity, MATCH_BRIEF_DTYPE)
+        assert out.dtype == MATCH_BRIEF_DTYPE and len(out) >= capacity and out.flags.c_contiguous
         begin = np.zeros(len(calls) + 1, np.int32)
         counts = np.zeros((len(calls), 4), np.int32)
         res = (PoseResult * max(len(calls), 1))()

@@ -127,6 +127,10 @@ class Chain:
         self.seed_frames = [(self.cur_ids[q], capi.SE3.from_arrays(*scenes[q % nd]["M"]["T_cur_w"]), M0["cur_exposure"]) for q in range(nseq)]
         self.pea = math.atan(1.0 / (2.0 * spec["fx"])) * 2.0
         self.n_seeds, self.n_points = n_seeds, len(M0["points"])
+        # result tables in page-locked memory (hso_gpu_host_alloc), allocated once like a caller's per-sequence buffers would be:
+        # the match / seed records of a step (tens of MB at 256 sequences) are then DMA'd straight into them
+        self.sel_out = ctx.host_array(self.sel_cap, capi.MATCH_BRIEF_DTYPE)
+        self.seed_out = ctx.host_array(nseq * n_seeds, capi.SEED_BRIEF_DTYPE)
 
     # ---- the four stages
     def track(self):
@@ -143,14 +147,14 @@ class Chain:
         between keyframes, src/reprojector.cpp:376-423) — one byte per stored point and frame."""
         self.ctx.map_update_quality(self.map_ids, self.quality)
         return self.ctx.reproject_select_pose_maps(self.cam, self.calls, self.cell_size, self.grid_n_cols, self.cell_order, self.feats, self.sel_cap,
-                                                   want_mask=True)
+                                                   want_mask=True, out=self.sel_out)
 
     def pose(self):
         self.ctx._check(self.ctx.lib.hso_gpu_pose_optimize_batch(self.ctx.h, C.byref(self.cam), self.pj_arr, self.nseq, self.pj_res, self.pj_mptr), "pose")
         return self.pj_res
 
     def seeds(self):
-        return self.ctx.seed_table_observe(self.cam, self.tab, self.seed_frames, self.pea)
+        return self.ctx.seed_table_observe(self.cam, self.tab, self.seed_frames, self.pea, brief_out=self.seed_out)
 
     # ---- work counts for the algorithmic bytes (one value-passing call per distinct scene)
     def work_counts(self):

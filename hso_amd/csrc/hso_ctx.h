@@ -58,6 +58,7 @@ struct hso_gpu_ctx {
   // pinned host staging (grow-only): record tables go through it so the DMA runs at PCIe rate
   // instead of the pageable-memory rate, and the per-call std::vector + page faults disappear
   char* h_pin[2]; size_t h_pin_cap[2];
+  std::vector<void*> host_allocs;   // hso_gpu_host_alloc
 };
 
 #define HSO_HIP_CHECK(ctx, expr)                                              \

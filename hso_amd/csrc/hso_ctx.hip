@@ -95,6 +95,7 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   for (auto* p : ctx->free_frames) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
   for (int k = 0; k < 2; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
+  for (void* p : ctx->host_allocs) (void)hipHostFree(p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -111,6 +112,30 @@ extern "C++" char* hso_pinned(hso_gpu_ctx* ctx, int slot, size_t bytes)
 }
 
 const char* hso_gpu_last_error(const hso_gpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int hso_gpu_host_alloc(hso_gpu_ctx* ctx, size_t bytes, void** out)
+{
+  if (!ctx || !out) return HSO_E_INVALID;
+  *out = nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return hso_fail(ctx, HSO_E_NOMEM, "host_alloc: hipHostMalloc failed");
+  ctx->host_allocs.push_back(p);
+  *out = p;
+  return HSO_OK;
+}
+
+int hso_gpu_host_free(hso_gpu_ctx* ctx, void* p)
+{
+  if (!ctx) return HSO_E_INVALID;
+  for (size_t i = 0; i < ctx->host_allocs.size(); i++)
+    if (ctx->host_allocs[i] == p) {
+      HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipHostFree(p);
+      ctx->host_allocs.erase(ctx->host_allocs.begin() + (long)i);
+      return HSO_OK;
+    }
+  return hso_fail(ctx, HSO_E_INVALID, "host_free: not an allocation of hso_gpu_host_alloc");
+}
 
 int hso_gpu_synchronize(hso_gpu_ctx* ctx)
 {

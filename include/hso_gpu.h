@@ -77,6 +77,13 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx);
 const char* hso_gpu_last_error(const hso_gpu_ctx* ctx);
 int hso_gpu_abi_version(void);
 int hso_gpu_synchronize(hso_gpu_ctx* ctx);
+/* Page-locked host memory for the tables a caller hands to / receives from the entry points.  Every entry point accepts any host
+ * pointer; result and input tables that live in memory from this allocator are DMA targets / sources as they are (tens of GB/s),
+ * pageable memory goes through the runtime's staging copies (and its first-touch page faults) at a fraction of that — with tens
+ * of megabytes of match / seed records per multi-sequence step, the difference is several milliseconds.
+ * Freed by hso_gpu_host_free or with the context. */
+int hso_gpu_host_alloc(hso_gpu_ctx* ctx, size_t bytes, void** out);
+int hso_gpu_host_free(hso_gpu_ctx* ctx, void* p);
 
 /* Replaces `new Frame(cam, img, ts)` -> Frame::initFrame (src/frame.cpp:82-96):
  * builds the 5-level u8 pyramid (halfSample, src/vikit/vision.cpp:19-108; the
