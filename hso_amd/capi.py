@@ -343,6 +343,7 @@ def load():
     lib.hso_gpu_seed_table_append.argtypes = [vp, i32, vp, vp, i32, P(C.c_int32)]
     lib.hso_gpu_seed_table_erase.argtypes = [vp, i32, vp, i32]
     lib.hso_gpu_seed_table_size.argtypes = [vp, i32, P(i32), P(i32)]
+    lib.hso_gpu_seed_table_compact.argtypes = [vp, i32, vp]
     lib.hso_gpu_seed_table_observe.argtypes = [vp, P(Camera), i32, P(SeedFrame), i32, C.c_double, vp, vp]
     lib.hso_gpu_seed_table_read.argtypes = [vp, i32, i32, i32, vp]
     lib.hso_gpu_map_reserve.argtypes = [vp, i32, i32, i32, i32]
@@ -378,7 +379,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
     "hso_gpu_map_reserve", "hso_gpu_map_store", "hso_gpu_reproject_match_maps",
-    "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level", "hso_gpu_host_alloc", "hso_gpu_host_free",
+    "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level", "hso_gpu_host_alloc", "hso_gpu_host_free", "hso_gpu_seed_table_compact",
 ]
 
 
@@ -742,6 +743,13 @@ class Context:
         self._check(self.lib.hso_gpu_seed_table_observe(self.h, C.byref(cam), table, fr, len(frames), px_error_angle, _ptr(brief),
                                                         C.cast(full, C.c_void_p) if want_full else None), "seed_table_observe")
         return brief, full
+
+    def seed_table_compact(self, table):
+        """-> (new number of slots, remap[old slot] = new slot or -1)"""
+        n, _ = self.seed_table_size(table)
+        remap = np.full(max(n, 1), -1, np.int32)
+        k = self._check(self.lib.hso_gpu_seed_table_compact(self.h, table, _ptr(remap)), "seed_table_compact")
+        return k, remap[:n]
 
     def seed_table_read(self, table, first, n):
         out = (Seed * max(n, 1))()

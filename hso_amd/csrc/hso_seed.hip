@@ -803,6 +803,63 @@ int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, 
   return HSO_OK;
 }
 
+}  // extern "C"
+
+// dst[i] = src[idx[i]]: 16 bytes per thread, a record = sizeof(SeedDev) / 16 threads
+static __global__ void k_seed_gather(const uint4* __restrict__ src, const int* __restrict__ idx, uint4* __restrict__ dst, int n_live)
+{
+  constexpr int Q = sizeof(SeedDev) / 16;
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n_live * Q) return;
+  const size_t i = g / Q, q = g - i * Q;
+  dst[i * Q + q] = src[(size_t)idx[i] * Q + q];
+}
+static_assert(sizeof(SeedDev) % 16 == 0, "k_seed_gather copies a slot in 16-byte pieces");
+
+extern "C" {
+
+int hso_gpu_seed_table_compact(hso_gpu_ctx* ctx, int table, int32_t* remap)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t) return hso_fail(ctx, HSO_E_INVALID, "seed_table_compact: no such table");
+  std::vector<int> idx;
+  idx.reserve(t->n);
+  for (size_t i = 0; i < t->n; i++) {
+    if (remap) remap[i] = t->alive[i] ? (int32_t)idx.size() : -1;
+    if (t->alive[i]) idx.push_back((int)i);
+  }
+  if (idx.size() == t->n) return (int)t->n;                      // nothing erased
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t n_live = idx.size();
+  if (n_live) {
+    SeedDev* q = nullptr;
+    int* d_idx = nullptr;
+    const size_t ncap = n_live + 1024;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&q), ncap * sizeof(SeedDev)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_idx), n_live * sizeof(int)) != hipSuccess) { (void)hipFree(q); return hso_fail(ctx, HSO_E_NOMEM, "seed_table_compact"); }
+    hipError_t e = hipMemcpyAsync(d_idx, idx.data(), n_live * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      const size_t threads = n_live * (sizeof(SeedDev) / 16);
+      k_seed_gather<<<(unsigned)((threads + 255) / 256), 256, 0, ctx->stream>>>(reinterpret_cast<const uint4*>(t->d), d_idx, reinterpret_cast<uint4*>(q), (int)n_live);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_idx);
+    if (e != hipSuccess) { (void)hipFree(q); ctx->err = std::string("seed_table_compact: ") + hipGetErrorString(e); return HSO_E_HIP; }
+    (void)hipFree(t->d);
+    t->d = q; t->cap = ncap;
+  } else {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<int64_t> hf(n_live);
+  for (size_t k = 0; k < n_live; k++) hf[k] = t->host_frame[idx[k]];
+  t->host_frame.swap(hf);
+  t->alive.assign(n_live, 1);
+  t->n = n_live;
+  return (int)n_live;
+}
+
 int hso_gpu_seed_table_size(hso_gpu_ctx* ctx, int table, int* n_slots, int* n_live)
 {
   if (!ctx) return HSO_E_INVALID;

@@ -120,6 +120,11 @@ void Map::reset()
   keyframes_.clear();
   point_candidates_.reset();
   emptyTrash();
+  // nothing dereferences a trashed point after a reset (the handler drops its frames and seeds with it): free the storage
+  for (Point* p : graveyard_) if (!point_candidates_.graveyard_.count(p)) delete p;
+  graveyard_.clear();
+  for (Point* p : point_candidates_.graveyard_) delete p;
+  point_candidates_.graveyard_.clear();
 }
 
 void Map::removePtFrameRef(Frame* frame, Feature* ftr)
@@ -206,7 +211,8 @@ bool Map::getKeyframeById(int id, FramePtr& frame) const
 void Map::emptyTrash()
 {
   // the reference deletes the points here; observations that the pose optimiser detached (feature->point = NULL
-  // without touching obs_) can still name a trashed point there, so the mirror keeps the storage until reset
+  // without touching obs_) can still name a trashed point there, so the mirror keeps the storage until reset()
+  graveyard_.insert(trash_points_.begin(), trash_points_.end());
   trash_points_.clear();
   point_candidates_.emptyTrash();
 }
@@ -272,7 +278,7 @@ void MapPointCandidates::deleteCandidate(PointCandidate& c)
   trash_points_.push_back(c.first);
 }
 
-void MapPointCandidates::emptyTrash() { trash_points_.clear(); }
+void MapPointCandidates::emptyTrash() { graveyard_.insert(trash_points_.begin(), trash_points_.end()); trash_points_.clear(); }
 
 // ------------------------------------------------------------------------------------------------ seeds
 static hso_seed flatten_seed(const Seed& s)

@@ -43,6 +43,7 @@ public:
   PointCandidateList candidates_;
   std::list<std::pair<Point*, Feature*>> temporaryPoints_;
   std::list<Point*> trash_points_;
+  std::set<Point*> graveyard_;   // trashed points: storage kept until reset() (see Map::emptyTrash), freed there
   ~MapPointCandidates() { reset(); }
   void newCandidatePoint(Point* point, double depth_sigma2);     // src/map.cpp:300-306
   void addPauseSeedPoint(Point* point);                         // :308-316
@@ -60,6 +61,7 @@ class Map {
 public:
   std::list<FramePtr> keyframes_;
   std::list<Point*> trash_points_;
+  std::set<Point*> graveyard_;   // see emptyTrash
   MapPointCandidates point_candidates_;
   ~Map() { reset(); }
   void reset();                                                 // src/map.cpp:42-47

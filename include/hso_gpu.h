@@ -596,6 +596,11 @@ int hso_gpu_seed_table_append(hso_gpu_ctx* ctx, int table, const hso_seed* seeds
                               int32_t* first_slot);
 int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, int n);
 int hso_gpu_seed_table_size(hso_gpu_ctx* ctx, int table, int* n_slots, int* n_live);
+/* Erased slots keep their index (and their place in the launch grid and in brief_out) until the table is compacted: the live
+ * records move to slots 0 .. n_live - 1 in their order; remap (n_slots entries of before the call, or NULL) receives each old
+ * slot's new index, -1 for an erased one.  Returns the new number of slots.  A long sequence erases as many seeds as it starts
+ * (convergence, divergence, host keyframe dropped): compact at keyframe rate to keep the table at the live size. */
+int hso_gpu_seed_table_compact(hso_gpu_ctx* ctx, int table, int32_t* remap);
 /* brief_out: n_slots entries or NULL; full_out: n_slots hso_seed_out records or NULL (epipolar end points, px_cur, z: what a
  * keyframe observation needs for FeatureExtractor::setGridOccpuancy, :669-673) */
 int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,

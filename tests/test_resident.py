@@ -45,6 +45,20 @@ def test_seed_table_matches_value_passing_calls(gpu_ctx, cam, pair2000):
         back = gpu_ctx.seed_table_read(t, 0, 700)
         for i in np.where(alive)[0][:50]:
             assert (back[i].mu, back[i].sigma2, back[i].b) == (host[i].mu, host[i].sigma2, host[i].b)
+        # compaction: the 600 live records move to slots 0..599 in order, the table shrinks, and the next observation equals the
+        # value-passing call over the live seeds alone
+        n_new, remap = gpu_ctx.seed_table_compact(t)
+        live = np.where(alive)[0]
+        assert n_new == 600 and gpu_ctx.seed_table_size(t) == (600, 600)
+        assert np.array_equal(remap[live], np.arange(600)) and (remap[~alive] == -1).all()
+        moved = gpu_ctx.seed_table_read(t, 0, 600)
+        assert all(bytes(moved[k]) == bytes(back[i]) for k, i in enumerate(live))
+        brief, _ = gpu_ctx.seed_table_observe(cam, t, [(9303, T2, 1.02)], PX_ERROR_ANGLE)
+        ref = gpu_ctx.seed_observe(cam, 9303, T2, 1.02, PX_ERROR_ANGLE, [host[i] for i in live])
+        assert len(brief) == 600
+        assert all((b["mu"], b["sigma2"], b["b"], b["result"]) == (o.mu, o.sigma2, o.b, o.result) for b, o in zip(brief, ref))
+        assert gpu_ctx.seed_table_compact(t)[0] == 600                         # nothing erased: a no-op
+        assert gpu_ctx.seed_table_append(t, seeds[:5]) == 600                  # appends continue behind the compacted records
         gpu_ctx.seed_table_destroy(t)
         with pytest.raises(capi.HsoGpuError):
             gpu_ctx.seed_table_size(t)
