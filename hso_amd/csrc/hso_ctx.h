@@ -61,6 +61,32 @@ struct hso_gpu_ctx {
   std::vector<void*> host_allocs;   // hso_gpu_host_alloc
 };
 
+// ---- host memory and the runtime's copy calls -----------------------------------------------------------------------------
+// The entry points accept any host pointer.  Handing PAGEABLE caller memory to hipMemcpyAsync is not harmless on this stack: the
+// runtime registers such ranges with the kernel driver to DMA from / to them, and when the caller later frees the memory (a large
+// std::vector or numpy array is an mmap'd region; free() = munmap()) the driver's MMU notifier EVICTS the process's GPU queues and
+// restores them >= 10 ms later — the next launch, of whatever kernel, starts 10-35 ms late.  Measured in the multi-sequence driver
+// at 32 sequences (tables of a few MB built and freed every step): 20-30 ms per step instead of 4.5 (hip trace + kernel trace:
+// the launch returns in microseconds, the GPU idles, the kernel starts tens of milliseconds later; gone with
+// MALLOC_MMAP_THRESHOLD_ raised so that free() never unmaps).  So every copy between host and device in this library goes through
+// the wrappers below: page-locked host memory (hso_pinned, hso_gpu_host_alloc, anything hipHostMalloc'ed / registered) is passed
+// through as it is; pageable memory is staged through page-locked chunks owned by the stream (host-to-device: copied into the
+// chunk now, DMA from there; device-to-host: DMA into the chunk, copied out by the stream synchronisation that every entry point
+// performs before it returns).  The runtime never sees a pageable pointer of the caller.
+hipError_t hso_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream);
+hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind,
+                            hipStream_t stream);
+hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t hso_stream_sync(hipStream_t stream);
+void hso_stream_forget(hipStream_t stream);   // context teardown: free the stream's staging chunks
+#ifndef HSO_RAW_HIP_COPIES
+#define hipMemcpyAsync(dst, src, bytes, kind, stream) hso_copy_async((dst), (src), (bytes), (kind), (stream))
+#define hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream) \
+  hso_copy2d_async((dst), (dpitch), (src), (spitch), (width), (height), (kind), (stream))
+#define hipMemcpy(dst, src, bytes, kind) hso_copy_sync((dst), (src), (bytes), (kind))
+#define hipStreamSynchronize(stream) hso_stream_sync(stream)
+#endif
+
 #define HSO_HIP_CHECK(ctx, expr)                                              \
   do {                                                                        \
     hipError_t _e = (expr);                                                   \
@@ -74,6 +100,7 @@ int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg);
 // pinned staging buffer `slot` (0: inputs, 1: results) of at least `bytes`; nullptr if the allocation fails.
 // Contents are only valid until the next call that uses the slot; every entry point synchronises before it returns.
 char* hso_pinned(hso_gpu_ctx* ctx, int slot, size_t bytes);
+
 
 // frame kernels (hso_frame.hip): build pyramid + Sobel + stats for `n` frames whose
 // level-0 bytes are already in place at base+off[0].

@@ -1,7 +1,123 @@
 // hso_ctx.hip — context lifecycle and the frame entry points of include/hso_gpu.h.
+#include <algorithm>
+#define HSO_RAW_HIP_COPIES          // this file implements the copy wrappers: it alone calls the runtime's copy functions
 #include "hso_ctx.h"
 #include <string.h>
+#include <mutex>
 #include <vector>
+
+// ---- staging of pageable host memory (see hso_ctx.h) ----
+namespace {
+struct StageChunk { char* p; size_t cap, used; };
+struct StageFix { void* dst; const char* src; size_t bytes, dpitch, width, height; };   // height 0: a flat copy of `bytes`
+struct Stager {
+  std::vector<StageChunk> chunks;
+  std::vector<StageFix> fixes;      // device-to-host copies to finish after the next synchronisation
+};
+std::mutex g_stage_mutex;
+std::unordered_map<hipStream_t, Stager> g_stagers;
+
+bool host_is_page_locked(const void* p)
+{
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime: ordinary memory
+  return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeArray;
+}
+
+char* stage_alloc(Stager& S, size_t bytes)
+{
+  const size_t need = (bytes + 255) & ~size_t(255);
+  for (StageChunk& c : S.chunks)
+    if (c.cap - c.used >= need) { char* r = c.p + c.used; c.used += need; return r; }
+  StageChunk c{nullptr, std::max(need, size_t(8) << 20), 0};
+  if (hipHostMalloc(reinterpret_cast<void**>(&c.p), c.cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+  c.used = need;
+  S.chunks.push_back(c);
+  return c.p;
+}
+}  // namespace
+
+hipError_t hso_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream)
+{
+  if (bytes == 0) return hipSuccess;
+  if (kind == hipMemcpyHostToDevice && !host_is_page_locked(src)) {
+    std::lock_guard<std::mutex> lk(g_stage_mutex);
+    char* p = stage_alloc(g_stagers[stream], bytes);
+    if (!p) return hipErrorOutOfMemory;
+    memcpy(p, src, bytes);
+    return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, stream);
+  }
+  if (kind == hipMemcpyDeviceToHost && !host_is_page_locked(dst)) {
+    std::lock_guard<std::mutex> lk(g_stage_mutex);
+    Stager& S = g_stagers[stream];
+    char* p = stage_alloc(S, bytes);
+    if (!p) return hipErrorOutOfMemory;
+    S.fixes.push_back({dst, p, bytes, 0, 0, 0});
+    return hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, stream);
+  }
+  return hipMemcpyAsync(dst, src, bytes, kind, stream);
+}
+
+hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind,
+                            hipStream_t stream)
+{
+  if (width == 0 || height == 0) return hipSuccess;
+  if (kind == hipMemcpyDeviceToHost && !host_is_page_locked(dst)) {   // rows packed in the chunk, spread out after the synchronisation
+    std::lock_guard<std::mutex> lk(g_stage_mutex);
+    Stager& S = g_stagers[stream];
+    char* p = stage_alloc(S, width * height);
+    if (!p) return hipErrorOutOfMemory;
+    S.fixes.push_back({dst, p, width * height, dpitch, width, height});
+    return hipMemcpy2DAsync(p, width, src, spitch, width, height, hipMemcpyDeviceToHost, stream);
+  }
+  if (kind == hipMemcpyHostToDevice && !host_is_page_locked(src)) {
+    std::lock_guard<std::mutex> lk(g_stage_mutex);
+    char* p = stage_alloc(g_stagers[stream], width * height);
+    if (!p) return hipErrorOutOfMemory;
+    for (size_t r = 0; r < height; r++) memcpy(p + r * width, static_cast<const char*>(src) + r * spitch, width);
+    return hipMemcpy2DAsync(dst, dpitch, p, width, width, height, hipMemcpyHostToDevice, stream);
+  }
+  return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream);
+}
+
+hipError_t hso_stream_sync(hipStream_t stream)
+{
+  const hipError_t e = hipStreamSynchronize(stream);
+  std::lock_guard<std::mutex> lk(g_stage_mutex);
+  auto it = g_stagers.find(stream);
+  if (it == g_stagers.end()) return e;
+  Stager& S = it->second;
+  if (e == hipSuccess)
+    for (const StageFix& f : S.fixes) {
+      if (f.height == 0) memcpy(f.dst, f.src, f.bytes);
+      else for (size_t r = 0; r < f.height; r++) memcpy(static_cast<char*>(f.dst) + r * f.dpitch, f.src + r * f.width, f.width);
+    }
+  S.fixes.clear();
+  for (StageChunk& c : S.chunks) c.used = 0;
+  return e;
+}
+
+// the blocking copy on the null stream (debug / test read-backs): through a chunk of the null stream's stager
+hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+  const hipError_t e = hso_copy_async(dst, src, bytes, kind, nullptr);
+  if (e != hipSuccess) return e;
+  return hso_stream_sync(nullptr);
+}
+
+void hso_stream_forget(hipStream_t stream)
+{
+  std::lock_guard<std::mutex> lk(g_stage_mutex);
+  auto it = g_stagers.find(stream);
+  if (it == g_stagers.end()) return;
+  for (StageChunk& c : it->second.chunks) (void)hipHostFree(c.p);
+  g_stagers.erase(it);
+}
+
+#define hipMemcpyAsync(dst, src, bytes, kind, stream) hso_copy_async((dst), (src), (bytes), (kind), (stream))
+#define hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream) \
+  hso_copy2d_async((dst), (dpitch), (src), (spitch), (width), (height), (kind), (stream))
+#define hipStreamSynchronize(stream) hso_stream_sync(stream)
 
 int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg)
 {
@@ -96,6 +212,7 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
   for (int k = 0; k < 2; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
   for (void* p : ctx->host_allocs) (void)hipHostFree(p);
+  hso_stream_forget(ctx->stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -19,6 +19,7 @@
 // bytes of the per-item call (tests/test_align.py, test_seed.py, test_activate.py, test_ba.py, test_pose.py, test_track_coop_gpu.py),
 // so a sequence run here equals the same sequence run alone through hso_vo_* bit for bit (tests/test_multi_gpu.py).
 // No control-plane logic lives here: which calls happen, in which order and on which data is FrameHandlerMono's business.
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -62,20 +63,45 @@ struct Batcher {
   int active = 0;                      // sequences currently inside a frame (or inside set_first_frame)
   long long n_calls[K_COUNT] = {0};    // batched C-ABI calls issued, per kind
   long long n_items[K_COUNT] = {0};    // requests they carried
+  std::chrono::steady_clock::time_point t_last_flush = std::chrono::steady_clock::now();
 
+  // Every batched C-ABI call is issued by ONE thread: the API caller's own (the thread inside hso_vo_multi_add_images etc. serves
+  // the rendezvous while the sequences run, serve() below) — the thread that created the context and its stream.
+  std::condition_variable cv_dev;
+  bool flush_wanted = false;
+  int tasks_left = 0;                  // sequence tasks of the current step that have not finished yet
+  std::vector<hso_reproj_frame> m_fr; std::vector<hso_kf> m_kfs; std::vector<hso_map_point> m_pts; std::vector<hso_obs> m_obs;   // run_reproject
+  std::vector<hso_reproj_point> m_proj; std::vector<hso_align_out> m_match;
+  std::vector<int64_t> release_queue;  // frames whose owners have gone (SeqRouter::frame_release)
+  void drain_releases()                // lock held
+  {
+    for (int64_t id : release_queue) { (void)hso_gpu_frame_release(ctx, id); n_calls[K_RELEASE]++; n_items[K_RELEASE]++; }
+    release_queue.clear();
+  }
+  void serve()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_dev.wait(lk, [&] { return flush_wanted || tasks_left == 0; });
+      if (flush_wanted) { flush_wanted = false; if (!pending.empty()) flush(); continue; }   // with the lock held: arrivals wait until served
+      break;
+    }
+    drain_releases();
+  }
   void enter() { std::lock_guard<std::mutex> lk(m); ++active; }
   void leave()
   {
     std::unique_lock<std::mutex> lk(m);
-    --active;
-    if (!pending.empty() && (int)pending.size() >= active) flush();
+    --active; --tasks_left;
+    if (!pending.empty() && (int)pending.size() >= active) flush_wanted = true;
+    if (flush_wanted || tasks_left == 0) cv_dev.notify_one();
   }
   int submit(Req& r)
   {
     std::unique_lock<std::mutex> lk(m);
     pending.push_back(&r);
-    if ((int)pending.size() >= active) flush();      // the last one in does the work for everybody
-    else cv.wait(lk, [&] { return r.done; });
+    if ((int)pending.size() >= active) { flush_wanted = true; cv_dev.notify_one(); }   // the last one in completes the rendezvous
+    cv.wait(lk, [&] { return r.done; });
     return r.rc;
   }
   void fail(std::vector<Req*>& v, int rc) { for (Req* r : v) { r->rc = rc; if (rc < 0 && r->err) *r->err = hso_gpu_last_error(ctx); } }
@@ -86,16 +112,29 @@ struct Batcher {
     std::vector<Req*> by[K_COUNT];
     for (Req* r : pending) by[r->kind].push_back(r);
     for (int k = 0; k < K_COUNT; k++) if (!by[k].empty()) { n_items[k] += (long long)by[k].size(); }
-    run_upload(by[K_UPLOAD]);
+    static const bool timing = getenv("HSO_MULTI_TIMING") != nullptr;      // developer probe: wall time of every batched call
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what, size_t n) {
+      if (!timing || n == 0) return;
+      const auto t = std::chrono::steady_clock::now();
+      fprintf(stderr, "[hso_multi] %-10s %3zu requests %8.3f ms (gap since previous flush %.3f ms)\n", what, n,
+              std::chrono::duration<double, std::milli>(t - t_prev).count(), std::chrono::duration<double, std::milli>(t_prev - t_last_flush).count());
+      t_prev = t;
+    };
+    drain_releases();
+    run_upload(by[K_UPLOAD]); lap("upload", by[K_UPLOAD].size());
     for (Req* r : by[K_RELEASE]) { r->rc = hso_gpu_frame_release(ctx, r->id); n_calls[K_RELEASE]++; }
-    run_track(by[K_TRACK]);
-    run_reproject(by[K_REPROJECT]);
-    run_align(by[K_ALIGN]);
-    run_pose(by[K_POSE]);
-    run_seed(by[K_SEED]);
-    run_activate(by[K_ACTIVATE]);
-    run_ba(by[K_BA]);
+    lap("release", by[K_RELEASE].size());
+    run_track(by[K_TRACK]); lap("track", by[K_TRACK].size());
+    run_reproject(by[K_REPROJECT]); lap("reproject", by[K_REPROJECT].size());
+    run_align(by[K_ALIGN]); lap("align", by[K_ALIGN].size());
+    run_pose(by[K_POSE]); lap("pose", by[K_POSE].size());
+    run_seed(by[K_SEED]); lap("seed", by[K_SEED].size());
+    run_activate(by[K_ACTIVATE]); lap("activate", by[K_ACTIVATE].size());
+    run_ba(by[K_BA]); lap("ba", by[K_BA].size());
     for (Req* r : by[K_SOLO]) { r->rc = r->fn(r->arg); if (r->rc < 0 && r->err) *r->err = hso_gpu_last_error(ctx); n_calls[K_SOLO]++; }
+    lap("solo", by[K_SOLO].size());
+    t_last_flush = std::chrono::steady_clock::now();
     for (Req* r : pending) r->done = true;
     pending.clear();
     cv.notify_all();
@@ -149,8 +188,11 @@ struct Batcher {
       }
       return;
     }
-    std::vector<hso_reproj_frame> fr(v.size());
-    std::vector<hso_kf> kfs; std::vector<hso_map_point> pts; std::vector<hso_obs> obs;
+    // the merged tables keep their storage between steps (members): a fresh multi-megabyte vector per step costs its page faults
+    // on the way in and an munmap on the way out
+    std::vector<hso_reproj_frame>& fr = m_fr; std::vector<hso_kf>& kfs = m_kfs; std::vector<hso_map_point>& pts = m_pts; std::vector<hso_obs>& obs = m_obs;
+    std::vector<hso_reproj_point>& proj = m_proj; std::vector<hso_align_out>& match = m_match;
+    fr.assign(v.size(), hso_reproj_frame{}); kfs.clear(); pts.clear(); obs.clear();
     for (size_t i = 0; i < v.size(); i++) {
       Req* r = v[i];
       hso_reproj_frame& f = fr[i];
@@ -161,7 +203,7 @@ struct Batcher {
       for (int k = 0; k < r->n_pts; k++) { hso_map_point p = r->pts[k]; p.obs_begin += ob; pts.push_back(p); }
       if (r->n_obs > 0) obs.insert(obs.end(), r->obs, r->obs + r->n_obs);
     }
-    std::vector<hso_reproj_point> proj(pts.size() ? pts.size() : 1); std::vector<hso_align_out> match(pts.size() ? pts.size() : 1);
+    proj.resize(pts.size() ? pts.size() : 1); match.resize(pts.size() ? pts.size() : 1);
     const int rc = hso_gpu_reproject_match_multi(ctx, v[0]->cam, fr.data(), (int)fr.size(), kfs.data(), (int)kfs.size(), pts.data(), (int)pts.size(),
                                                  obs.data(), (int)obs.size(), v[0]->cell_size, v[0]->grid_n_cols, proj.data(), match.data());
     n_calls[K_REPROJECT]++;
@@ -270,9 +312,11 @@ struct SeqRouter : hso::api::Router {
   { Req r = make(K_UPLOAD); r.id = id; r.img = img; r.w = w; r.h = h; r.st = st; return B->submit(r); }
   int frame_release(int64_t id) override
   {
-    // frames are released from destructors, possibly outside a frame step (no rendezvous partner is waiting then)
+    // frames are released from destructors on the sequence threads; the device call itself is left to the serving thread (every
+    // HIP call of the driver comes from one thread), which drains the list with its next batch or when the step ends
     std::lock_guard<std::mutex> lk(B->m);
-    return hso_gpu_frame_release(B->ctx, id);
+    B->release_queue.push_back(id);
+    return HSO_OK;
   }
   int coarse_track(const hso_camera* cam, const hso_track_params* p, const hso_track_job* job, hso_track_result* res) override
   { Req r = make(K_TRACK); r.cam = cam; r.tp = p; r.tj = job; r.tr = res; return B->submit(r); }
@@ -362,13 +406,14 @@ int step(hso_vo_multi* M, const std::vector<std::function<int()>>& tasks)
 {
   int n_run = 0;
   for (auto& t : tasks) if (t) ++n_run;
-  { std::lock_guard<std::mutex> lk(M->B.m); M->B.active = n_run; }
+  { std::lock_guard<std::mutex> lk(M->B.m); M->B.active = n_run; M->B.tasks_left = n_run; }
   for (size_t k = 0; k < tasks.size(); k++) {
     if (!tasks[k]) continue;
     Seq* S = M->seq[k];
     { std::lock_guard<std::mutex> lk(S->m); S->task = tasks[k]; S->has_task = true; S->task_done = false; }
     S->cv.notify_all();
   }
+  M->B.serve();                         // this thread issues the batched device calls until every sequence has finished its task
   int rc = HSO_OK;
   for (size_t k = 0; k < tasks.size(); k++) {
     if (!tasks[k]) continue;
