@@ -3,6 +3,7 @@
 #include "hso_vo.h"
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <numeric>
@@ -739,12 +740,31 @@ void FrameHandlerMono::setFirstFrame(const FramePtr& first_frame)
   stage_ = STAGE_DEFAULT_FRAME;
 }
 
+namespace {
+// developer probe (HSO_VO_TIMING=1): wall time per stage of processFrame, printed when the handler goes away
+struct StageClock {
+  bool on = getenv("HSO_VO_TIMING") != nullptr;
+  double acc[6] = {0, 0, 0, 0, 0, 0}; long n = 0;
+  std::chrono::steady_clock::time_point t;
+  void start() { if (on) t = std::chrono::steady_clock::now(); }
+  void lap(int k) { if (!on) return; const auto u = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::milli>(u - t).count(); t = u; }
+  ~StageClock()
+  {
+    if (on && n) fprintf(stderr, "[hso_vo] %ld frames: frame build %.3f, track %.3f, reproject %.3f, pose %.3f, seeds (non-keyframes) %.3f, keyframe work %.3f ms per frame\n",
+                         n, acc[5] / n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n);
+  }
+};
+thread_local StageClock g_clock;
+}  // namespace
+
 void FrameHandlerMono::addImage(const uint8_t* img, int width, int height, double timestamp)
 {
   if (!startFrameProcessingCommon(timestamp)) return;
   core_kfs_.clear();
   overlap_kfs_.clear();
+  g_clock.start();
   new_frame_.reset(new Frame(ctx_, cam_, img, width, height, timestamp));
+  g_clock.lap(5);
   new_frame_->keyFrameId_ = map_.size() == 0 ? 0 : map_.lastKeyframe()->keyFrameId_;
   UpdateResult res = RESULT_FAILURE;
   if (stage_ == STAGE_DEFAULT_FRAME) res = processFrame();
@@ -787,6 +807,7 @@ FrameHandlerMono::UpdateResult FrameHandlerMono::processFrame()
 {
   const Config& cfg = Config::get();
   log_ = FrameLog();
+  g_clock.n++; g_clock.start();
   new_frame_->T_f_w_ = motionModel_ * last_frame_->T_f_w_;      // :176
   if (afterInit_) last_frame_ = firstFrame_;
   new_frame_->m_last_frame = last_frame_;
@@ -796,7 +817,9 @@ FrameHandlerMono::UpdateResult FrameHandlerMono::processFrame()
     log_.img_align_n_tracked = Tracker.run(last_frame_, new_frame_);
     log_.used_inverse = inverse ? 1 : 0;
   }
+  g_clock.lap(0);
   reprojector_.reprojectMap(new_frame_, overlap_kfs_);          // :217
+  g_clock.lap(1);
   const size_t repr_n_new_references = reprojector_.n_matches_;
   log_.repr_n_matches = repr_n_new_references; log_.repr_n_mps = reprojector_.n_trials_; log_.repr_n_seeds = reprojector_.n_seeds_;
   if (repr_n_new_references < (size_t)cfg.quality_min_fts) {
@@ -808,6 +831,7 @@ FrameHandlerMono::UpdateResult FrameHandlerMono::processFrame()
   double sfba_thresh = 0, sfba_error_init = 0, sfba_error_final = 0;
   pose_optimizer::optimizeLevenbergMarquardt3rd(cfg.poseoptim_thresh, 12, false, new_frame_, sfba_thresh, sfba_error_init,
                                                 sfba_error_final, sfba_n_edges_final);
+  g_clock.lap(2);
   new_frame_->m_n_inliers = sfba_n_edges_final;
   log_.sfba_n_edges_final = sfba_n_edges_final; log_.sfba_thresh = sfba_thresh; log_.sfba_error_init = sfba_error_init;
   log_.sfba_error_final = sfba_error_final;
@@ -826,6 +850,7 @@ FrameHandlerMono::UpdateResult FrameHandlerMono::processFrame()
   if (!needNewKf(distance_mean, sfba_n_edges_final) && !afterInit_) {   // :274-291
     createCovisibilityGraph(new_frame_, cfg.core_n_kfs, false);
     depth_filter_->addFrame(new_frame_);
+    g_clock.lap(3);
     regular_counter_++;
     motionModel_ = new_frame_->T_f_w_ * last_frame_->T_f_w_.inverse();
     log_.n_seeds = depth_filter_->seeds_.size(); log_.n_candidates = map_.point_candidates_.candidates_.size();
@@ -845,6 +870,7 @@ FrameHandlerMono::UpdateResult FrameHandlerMono::processFrame()
   if (sfba_n_edges_final <= 70) depth_filter_->addKeyframe(new_frame_, distance_mean, 0.5 * depth_min, 100);   // :335-338
   else depth_filter_->addKeyframe(new_frame_, distance_mean, 0.5 * depth_min, 200);
   map_.addKeyframe(new_frame_);
+  g_clock.lap(4);
   motionModel_ = new_frame_->T_f_w_ * last_frame_->T_f_w_.inverse();
   log_.n_seeds = depth_filter_->seeds_.size(); log_.n_candidates = map_.point_candidates_.candidates_.size();
   return RESULT_IS_KEYFRAME;
