@@ -63,8 +63,8 @@ struct hso_gpu_ctx {
 
 // ---- host memory and the runtime's copy calls -----------------------------------------------------------------------------
 // The entry points accept any host pointer.  Handing PAGEABLE caller memory to hipMemcpyAsync is not harmless on this stack: the
-// runtime registers such ranges with the kernel driver to DMA from / to them, and when the caller later frees the memory (a large
-// std::vector or numpy array is an mmap'd region; free() = munmap()) the driver's MMU notifier EVICTS the process's GPU queues and
+// runtime registers such ranges with the kernel driver to DMA from / to them, and when the caller later returns the memory to the
+// kernel (a large std::vector or numpy array is an mmap'd region; malloc arenas of threads are trimmed) the driver's MMU notifier EVICTS the process's GPU queues and
 // restores them >= 10 ms later — the next launch, of whatever kernel, starts 10-35 ms late.  Measured in the multi-sequence driver
 // at 32 sequences (tables of a few MB built and freed every step): 20-30 ms per step instead of 4.5 (hip trace + kernel trace:
 // the launch returns in microseconds, the GPU idles, the kernel starts tens of milliseconds later; gone with
