@@ -439,7 +439,6 @@ int hso_vo_multi_create(hso_vo_multi** out, const hso_camera* cam, int max_fts, 
   hso_gpu_ctx* ctx = nullptr;
   const int rc = hso_gpu_create(&ctx, device, nullptr);
   if (rc < 0) return rc;
-  hso::Config::get().max_fts = max_fts;   // read when the reprojectors and extractors are built; before any thread starts
   hso_vo_multi* M = new hso_vo_multi();
   M->ctx = ctx; M->B.ctx = ctx;
   M->seq.resize(n_sequences);

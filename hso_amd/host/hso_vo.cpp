@@ -11,6 +11,7 @@
 
 namespace hso {
 
+thread_local Config* Config::current_ = nullptr;
 api::Trace& api::trace() { static thread_local Trace t; return t; }
 api::Router*& api::router() { static thread_local Router* r = nullptr; return r; }
 
@@ -987,8 +988,34 @@ struct hso_vo {
   bool poisoned = false;   // a device call failed inside processFrame: the map may be half updated, the handle refuses further frames
   bool owns_ctx = true;    // false: one of the sequences of a multi-sequence driver (hso_multi.cpp), the context is shared
   int id_base = 0;         // Frame::id_base_ of the sequence's thread: reported frame ids are relative to it
+  hso::Config cfg;         // this handle's configuration (Config::get() inside its calls)
+  // this handle's values of the reference's static counters (Frame::frame_counter_, keyFrameCounter_, Point::point_counter_,
+  // Seed::batch_counter): keyframe-id gaps gate decisions (reprojector.cpp: cur - kf < 4), so they must not advance with another
+  // handle's keyframes
+  int c_frame = 0, c_kf = 0, c_point = 0, c_batch = 0;
 };
-static int g_vo_alive = 0;
+namespace {
+struct ConfigScope {       // the handle's configuration and counters are the thread's current ones while one of its calls runs
+  hso_vo* v;
+  hso::Config* prev;
+  int t_frame, t_kf, t_point, t_batch, t_base;
+  explicit ConfigScope(hso_vo* v_) : v(v_), prev(hso::Config::current_)
+  {
+    hso::Config::current_ = &v->cfg;
+    t_frame = hso::Frame::frame_counter_; t_kf = hso::Frame::keyFrameCounter_; t_point = hso::Point::point_counter_; t_batch = hso::Seed::batch_counter;
+    t_base = hso::Frame::id_base_;
+    hso::Frame::frame_counter_ = v->c_frame; hso::Frame::keyFrameCounter_ = v->c_kf; hso::Point::point_counter_ = v->c_point;
+    hso::Seed::batch_counter = v->c_batch; hso::Frame::id_base_ = v->id_base;
+  }
+  ~ConfigScope()
+  {
+    v->c_frame = hso::Frame::frame_counter_; v->c_kf = hso::Frame::keyFrameCounter_; v->c_point = hso::Point::point_counter_; v->c_batch = hso::Seed::batch_counter;
+    hso::Frame::frame_counter_ = t_frame; hso::Frame::keyFrameCounter_ = t_kf; hso::Point::point_counter_ = t_point; hso::Seed::batch_counter = t_batch;
+    hso::Frame::id_base_ = t_base;
+    hso::Config::current_ = prev;
+  }
+};
+}  // namespace
 
 template <typename F> static int vo_guard(hso_vo* v, F f)
 {
@@ -997,6 +1024,7 @@ template <typename F> static int vo_guard(hso_vo* v, F f)
     if (v->err.find("handle unusable") == std::string::npos) v->err = "handle unusable after a device error (" + v->err + "): destroy it and create a new one";
     return HSO_E_HIP;
   }
+  ConfigScope scope(v);
   try { f(); return HSO_OK; }
   catch (const hso::api::DeviceError& e) { v->err = e.what(); v->poisoned = true; return HSO_E_HIP; }
   catch (const std::exception& e) { v->err = e.what(); return HSO_E_INVALID; }
@@ -1011,15 +1039,12 @@ int hso_vo_create(hso_vo** out, const hso_camera* cam, int max_fts, int device)
   hso_gpu_ctx* ctx = nullptr;
   const int rc = hso_gpu_create(&ctx, device, nullptr);
   if (rc < 0) return rc;
-  if (g_vo_alive == 0) {   // the reference's static counters (Frame::frame_counter_, keyFrameCounter_, Point::point_counter_, Seed::batch_counter)
-    hso::Frame::frame_counter_ = 0; hso::Frame::keyFrameCounter_ = 0; hso::Point::point_counter_ = 0; hso::Seed::batch_counter = 0;
-  }
-  hso::Config::get().max_fts = max_fts;   // Config::maxFts() is read when the reprojector and the extractor are built
-  hso_vo* v = new hso_vo();
+  hso_vo* v = new hso_vo();               // its counters start at 0 like the reference's statics in a fresh process
+  v->cfg.max_fts = max_fts;               // Config::maxFts() is read when the reprojector and the extractor are built
+  ConfigScope scope(v);
   v->ctx = ctx;
   v->cam = new hso::AbstractCamera(*cam);
   v->vo = new hso::FrameHandlerMono(ctx, v->cam, false);
-  ++g_vo_alive;
   *out = v;
   return HSO_OK;
 }
@@ -1027,11 +1052,10 @@ int hso_vo_create(hso_vo** out, const hso_camera* cam, int max_fts, int device)
 void hso_vo_destroy(hso_vo* v)
 {
   if (!v) return;
-  delete v->vo;
+  { ConfigScope scope(v); delete v->vo; v->vo = nullptr; }
   delete v->cam;
   hso_gpu_destroy(v->ctx);
   delete v;
-  --g_vo_alive;
 }
 
 }  // extern "C"
@@ -1040,9 +1064,12 @@ void hso_vo_destroy(hso_vo* v)
 // counters and router are already set; the context is shared and Config::maxFts() was set by the caller before the threads started.
 hso_vo* hso_vo_create_shared(hso_gpu_ctx* ctx, const hso_camera* cam, int max_fts)
 {
-  (void)max_fts;
   hso_vo* v = new hso_vo();
-  v->ctx = ctx; v->owns_ctx = false; v->id_base = hso::Frame::id_base_;
+  v->cfg.max_fts = max_fts;
+  v->id_base = hso::Frame::id_base_; v->c_frame = hso::Frame::frame_counter_; v->c_kf = hso::Frame::keyFrameCounter_;
+  v->c_point = hso::Point::point_counter_; v->c_batch = hso::Seed::batch_counter;       // the worker thread set them for this sequence
+  ConfigScope scope(v);
+  v->ctx = ctx; v->owns_ctx = false;
   v->cam = new hso::AbstractCamera(*cam);
   v->vo = new hso::FrameHandlerMono(ctx, v->cam, false);
   return v;
@@ -1050,7 +1077,7 @@ hso_vo* hso_vo_create_shared(hso_gpu_ctx* ctx, const hso_camera* cam, int max_ft
 void hso_vo_destroy_shared(hso_vo* v)
 {
   if (!v) return;
-  delete v->vo;      // releases the sequence's resident frames through the router
+  { ConfigScope scope(v); delete v->vo; v->vo = nullptr; }      // releases the sequence's resident frames through the router
   delete v->cam;
   delete v;
 }

@@ -28,8 +28,12 @@
 namespace hso {
 
 // src/config.cpp:28-64 — the values the hot path reads
+// The reference's Config is a process-wide singleton (include/hso/config.h).  Here every handle owns one (hso_vo::cfg) and the C
+// interface makes it the calling thread's current configuration for the duration of each call (vo_guard, hso_vo.cpp), so two
+// handles with different max_fts do not change each other's behaviour; code outside a handle sees the defaults.
 struct Config {
-  static Config& get() { static Config c; return c; }
+  static thread_local Config* current_;
+  static Config& get() { static Config defaults; return current_ ? *current_ : defaults; }
   int n_pyr_levels = 3, core_n_kfs = 7, grid_size = 36, klt_max_level = 4, klt_min_level = 0;
   double poseoptim_thresh = 2.0;
   int loba_num_iter = 10, max_fts = 200, quality_min_fts = 5, quality_max_drop_fts = 40;

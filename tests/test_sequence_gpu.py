@@ -59,3 +59,36 @@ def test_sequence_tracking_matches_oracle_and_ground_truth(gpu_ctx, orc, cam):
     # trajectory against ground truth: ATE (RMSE of positions) well below a millimetre-scale bound
     ate = float(np.sqrt(np.mean(np.square(pos_err))))
     assert ate < 2e-3, pos_err
+
+
+@pytest.mark.gpu
+def test_two_handles_with_different_max_fts_do_not_interfere():
+    """Config is per handle (the reference's is a process singleton): a 2000-feature handle created next to a 200-feature one
+    leaves the first one's results exactly as they are alone."""
+    from hso_amd import vo
+    spec = synth.EUROC
+    cam = synth.camera(spec)
+    S = synth.sequence(14, spec=spec)
+
+    def run(odo):
+        odo.set_first_frame(S["images"][0], S["depth0"], 0.0)
+        return [bytes(odo.add_image(S["images"][k], float(k))) for k in range(1, 14)]
+    a = vo.VisualOdometry(cam, 200)
+    alone = run(a)
+    a.close()
+    a = vo.VisualOdometry(cam, 200)
+    b = vo.VisualOdometry(cam, 2000)                     # created after a: with a process-wide Config this changed a's max_fts
+    a.set_first_frame(S["images"][0], S["depth0"], 0.0)
+    b.set_first_frame(S["images"][0], S["depth0"], 0.0)
+    mixed, nb = [], []
+    for k in range(1, 14):                                # interleaved calls
+        mixed.append(bytes(a.add_image(S["images"][k], float(k))))
+        nb.append(b.add_image(S["images"][k], float(k)).n_matches)
+    a.close(); b.close()
+    # frame / keyframe / point counters are per THREAD (the reference's are process globals): ids differ, everything else must not
+    def strip(rec):
+        st = vo.VoStatus.from_buffer_copy(rec)
+        return (bytes(st.T_f_w), st.stage, st.result, st.n_features, st.n_inliers, st.n_tracked, st.n_matches, st.n_trials, st.n_seeds,
+                st.n_candidates, st.is_keyframe, st.pose_error_final)
+    assert [strip(r) for r in mixed] == [strip(r) for r in alone]
+    assert max(nb) > 1000                                 # b really ran with its own budget
