@@ -353,8 +353,8 @@ static int seed_activate_impl(hso_gpu_ctx* ctx, const hso_camera* cam, const hso
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-    ctx->batch_cap = need;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
   }
   ActSeedDev* d_seeds = reinterpret_cast<ActSeedDev*>(ctx->d_batch + o_seeds);
   ActPairIn* d_pin = reinterpret_cast<ActPairIn*>(ctx->d_batch + o_pin);
@@ -430,8 +430,8 @@ extern "C" int hso_gpu_seed_reproject_match(hso_gpu_ctx* ctx, const hso_camera* 
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-    ctx->batch_cap = need;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
   }
   ActSeedDev* d_seeds = reinterpret_cast<ActSeedDev*>(ctx->d_batch);
   ActPairIn* d_pin = reinterpret_cast<ActPairIn*>(ctx->d_batch + o_pin);

@@ -128,8 +128,8 @@ static int align_run(hso_gpu_ctx* ctx, const hso_camera* cam, const int64_t* cur
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-    ctx->batch_cap = need;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
   }
   AlignJobDev* d_jobs = reinterpret_cast<AlignJobDev*>(ctx->d_batch);
   hso_align_out* d_out = reinterpret_cast<hso_align_out*>(ctx->d_batch + b_jobs);
@@ -386,8 +386,8 @@ extern "C" int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera*
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-    ctx->batch_cap = need;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
   }
   char* d = ctx->d_batch;
   // Small calls (one keyframe-sized sequence) are latency-bound: one pinned staging image of
@@ -590,8 +590,8 @@ extern "C" int hso_gpu_map_update_quality(hso_gpu_ctx* ctx, const int32_t* maps,
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-    ctx->batch_cap = need;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
   }
   char* d = ctx->d_batch;
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, ctx->stream));
@@ -675,8 +675,8 @@ int hso_reproject_maps_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_ma
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-    ctx->batch_cap = need;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
   }
   char* d = ctx->d_batch;
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_in, hin, b_calls + b_kfs, hipMemcpyHostToDevice, ctx->stream));

@@ -745,8 +745,8 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), dev));
-    ctx->batch_cap = dev;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(dev)));
+    ctx->batch_cap = hso_grown(dev);
   }
   char* d = reinterpret_cast<char*>(ctx->d_batch);
   char* h = hso_pinned(ctx, 0, pin_in);
@@ -920,8 +920,8 @@ extern "C" int hso_gpu_ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses_f_
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), o));
-    ctx->batch_cap = o;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(o)));
+    ctx->batch_cap = hso_grown(o);
   }
   char* d = reinterpret_cast<char*>(ctx->d_batch);
   char* h = hso_pinned(ctx, 0, in_bytes);

@@ -97,6 +97,9 @@ void hso_stream_forget(hipStream_t stream);   // context teardown: free the stre
   } while (0)
 
 int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg);
+// size of a grow-only buffer that must hold `need` bytes now: half again as much + 1 MB, so that tables that grow a little with
+// every keyframe do not re-allocate (hipFree synchronises the device: 0.2-0.4 ms each, 18 per step at 32 sequences before this)
+inline size_t hso_grown(size_t need) { return need + need / 2 + (size_t(1) << 20); }
 // pinned staging buffer `slot` (0: inputs, 1: results) of at least `bytes`; nullptr if the allocation fails.
 // Contents are only valid until the next call that uses the slot; every entry point synchronises before it returns.
 char* hso_pinned(hso_gpu_ctx* ctx, int slot, size_t bytes);

@@ -19,7 +19,7 @@ std::unordered_map<hipStream_t, Stager> g_stagers;
 
 bool host_is_page_locked(const void* p)
 {
-  // measurement knob: hand pageable memory to the runtime like rounds 1-2 did (tests/test_host_memory_gpu.py reproduces the stall with it)
+  // measurement knob: hand pageable memory to the runtime like rounds 1-2 did (profiles/r3_host_memory_eviction.txt)
   static const bool passthrough = getenv("HSO_COPY_PASSTHROUGH") != nullptr;
   if (passthrough) return true;
   hipPointerAttribute_t at{};
@@ -314,8 +314,8 @@ int hso_gpu_frame_upload_resized(hso_gpu_ctx* ctx, int64_t frame_id, const uint8
       HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_batch) (void)hipFree(ctx->d_batch);
       ctx->d_batch = nullptr; ctx->batch_cap = 0;
-      HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-      ctx->batch_cap = need;
+      HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+      ctx->batch_cap = hso_grown(need);
     }
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_batch, img, need, hipMemcpyHostToDevice, ctx->stream));
     d_src = reinterpret_cast<const uint8_t*>(ctx->d_batch);
@@ -373,8 +373,8 @@ int hso_gpu_frame_upload_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, const
     HSO_BATCH_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_BATCH_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-    ctx->batch_cap = need;
+    HSO_BATCH_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
   }
   uint8_t** d_bases = reinterpret_cast<uint8_t**>(ctx->d_batch);
   const uint8_t** d_srcs = reinterpret_cast<const uint8_t**>(ctx->d_batch + b_ptr);

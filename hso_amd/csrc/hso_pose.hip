@@ -594,8 +594,8 @@ extern "C" int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* c
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), need));
-    ctx->batch_cap = need;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
   }
   char* d = ctx->d_batch;
   char* h = hso_pinned(ctx, 0, o_res);

@@ -284,8 +284,8 @@ extern "C" int hso_gpu_reproject_select(hso_gpu_ctx* ctx, const int32_t* frame_b
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), o));
-    ctx->batch_cap = o;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(o)));
+    ctx->batch_cap = hso_grown(o);
   }
   char* d = ctx->d_batch;
   char* h = hso_pinned(ctx, 0, in_bytes);

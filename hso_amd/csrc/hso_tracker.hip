@@ -139,7 +139,7 @@ static int grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need_bytes)
 {
   if (*cap >= need_bytes && *p) return HSO_OK;
   if (*p) { HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(*p); *p = nullptr; }
-  const size_t bytes = std::max<size_t>(need_bytes, 256);
+  const size_t bytes = std::max<size_t>(need_bytes + need_bytes / 4, 256);   // headroom: feature tables vary a little from call to call
   HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
   *cap = bytes;
   return HSO_OK;
