@@ -261,8 +261,15 @@ extern "C" int hso_gpu_klt_track(hso_gpu_ctx* ctx, int64_t frame_prev, int64_t f
   for (int f = 0; f < 2; f++) for (int l = 1; l <= L.last; l++) img_off[f][l] = take((size_t)L.w[l] * L.h[l]);
   for (int l = 0; l <= L.last; l++) der_off[l] = take(sizeof(short2) * (size_t)L.w[l] * L.h[l]);
   const size_t o_prev = take(sizeof(float2) * (size_t)n), o_init = take(sizeof(float2) * (size_t)n), o_out = take(sizeof(hso_klt_result) * (size_t)n);
-  char* d = nullptr;
-  if (hipMalloc(&d, off) != hipSuccess) return hso_fail(ctx, HSO_E_NOMEM, "klt_track: work area");
+  // the context's grow-only work area (no allocation per call: hipFree synchronises the device)
+  if (ctx->batch_cap < off) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(off)));
+    ctx->batch_cap = hso_grown(off);
+  }
+  char* d = ctx->d_batch;
   int rc = HSO_OK;
   auto body = [&]() -> int {
     L.prev[0] = ip->second.base + g.off[0]; L.cur[0] = ic->second.base + g.off[0];
@@ -295,7 +302,6 @@ extern "C" int hso_gpu_klt_track(hso_gpu_ctx* ctx, int64_t frame_prev, int64_t f
   };
   rc = body();
   if (rc != HSO_OK) (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d);
   return rc;
 }
 
