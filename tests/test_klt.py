@@ -163,3 +163,28 @@ def test_klt_track_argument_errors(gpu_ctx, klt_seq):
         assert np.abs(res["px"] - px).max() < 1e-3 and (res["status"] == 3).all() and (res["ncc"] > 0.999).all()
     finally:
         gpu_ctx.frame_release(88010)
+
+
+@pytest.mark.gpu
+def test_klt_parity_on_a_size_with_odd_pyramid_levels(orc, gpu_ctx):
+    """920x736 (the TUM-mono camera after its downscale rule): Gaussian levels 460x368, 230x184, 115x92, 58x46 — an odd width on the
+    way down ((115 + 1) / 2 = 58: the reflected column takes part) and five levels instead of four."""
+    S = synth.sequence(n_frames=3, spec=synth.TUM_WIDE, step=(0.05, 0.015, 0.01), workers=3)
+    im = S["images"]
+    h, w = im[0].shape
+    assert (w, h) == (920, 736) and orc.klt_levels(w, h) == 4
+    gpu_ctx.frame_upload(88020, im[0])
+    try:
+        lvl = im[0]
+        for level in range(5):
+            if level:
+                lvl = orc.pyr_down(lvl)
+            g_img, g_der = gpu_ctx.klt_debug_level(88020, level, w, h)
+            assert g_img.shape == lvl.shape and np.array_equal(g_img, lvl), level
+            assert np.array_equal(g_der, orc.scharr_deriv(lvl)), level
+    finally:
+        gpu_ctx.frame_release(88020)
+    px = _points(im[0].shape, 800, 21, border=6)
+    s = _compare(orc, gpu_ctx, im[0], im[2], px, px, "tum 920x736")
+    assert s["tracked"] > 0.9 * s["n"] and s["excused"] < 0.15 * s["n"], s      # two frames apart: more points end a level at the iteration cap
+    print("klt parity 920x736:", s)
