@@ -79,6 +79,11 @@ def test_two_view_geometry_is_reproducible_and_rejects_garbage():
     assert len(i0) == 0
 
 
+def _init_sequence(base_spec, n_frames=26):
+    spec = dict(base_spec, texture_om=((0.004, 0.05), (0.05, 0.6)))
+    return synth.sequence(n_frames=n_frames, spec=spec, step=(0.05, 0.015, 0.01), rot_deg_per_frame=(0.05, -0.1, 0.03), workers=8)
+
+
 @pytest.fixture(scope="module")
 def init_seq():
     # The frame after the initialisation starts from motionModel_ = T_new * T_first^-1 (src/frame_handler_mono.cpp:352 with
@@ -87,6 +92,34 @@ def init_seq():
     # images do; the default synthetic texture (wavelengths 10..314 px) does not, hence the low band.
     spec = dict(synth.EUROC, texture_om=((0.004, 0.05), (0.05, 0.6)))
     return synth.sequence(n_frames=26, spec=spec, step=(0.05, 0.015, 0.01), rot_deg_per_frame=(0.05, -0.1, 0.03), workers=8)
+
+
+@pytest.mark.gpu
+def test_sequence_starts_from_two_images_wide_camera():
+    """The same start on the 920x736 TUM-mono camera (FOV model file, rectified: pinhole projection; the cv::resize pyramid branch,
+    five KLT levels): stage sequence and trajectory."""
+    from hso_amd import formats
+    S = _init_sequence(synth.TUM_WIDE, n_frames=34)
+    odo = vo.VisualOdometry(synth.camera(S["spec"]), 200)
+    try:
+        odo.start()
+        stages, results, est = [], [], []
+        for k, img in enumerate(S["images"]):
+            st = odo.add_image(img, float(k))
+            stages.append(st.stage); results.append(st.result)
+            est.append((np.array(st.T_f_w.q), np.array(st.T_f_w.t)))
+        k_init = stages.index(3)
+        assert 6 <= k_init <= 24 and all(s == 2 for s in stages[:k_init]) and all(s == 3 for s in stages[k_init:]), stages
+        assert all(r != 2 for r in results[k_init:]), results
+        gt = np.array([-(synth.quat_to_R(q).T @ t) for q, t in S["T_f_w"]])
+        ex = np.array([-(synth.quat_to_R(q).T @ t) for q, t in est])
+        idx = np.arange(k_init, len(est))
+        rmse, scale, _, _ = formats.ate_rmse(gt[idx], ex[idx])
+        path = np.linalg.norm(gt[idx[-1]] - gt[idx[0]])
+        print("two-view start 920x736: init at frame %d, ATE rmse %.4f m over %.2f m (scale %.3f)" % (k_init, rmse, path, scale))
+        assert rmse < 0.03 * path, (rmse, path)
+    finally:
+        odo.close()
 
 
 @pytest.mark.gpu
