@@ -79,6 +79,8 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
 hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t hso_stream_sync(hipStream_t stream);
 void hso_stream_forget(hipStream_t stream);   // context teardown: free the stream's staging chunks
+void hso_stream_abandon(hipStream_t stream);  // error path: wait for the stream, then DROP the pending copies into caller memory
+                                              // (the entry point returns an error; the caller may free its buffers at once)
 #ifndef HSO_RAW_HIP_COPIES
 #define hipMemcpyAsync(dst, src, bytes, kind, stream) hso_copy_async((dst), (src), (bytes), (kind), (stream))
 #define hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream) \
@@ -92,6 +94,7 @@ void hso_stream_forget(hipStream_t stream);   // context teardown: free the stre
     hipError_t _e = (expr);                                                   \
     if (_e != hipSuccess) {                                                   \
       (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);         \
+      hso_stream_abandon((ctx)->stream);                                      \
       return HSO_E_HIP;                                                       \
     }                                                                         \
   } while (0)

@@ -108,6 +108,17 @@ hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind
   return hso_stream_sync(nullptr);
 }
 
+void hso_stream_abandon(hipStream_t stream)
+{
+  (void)hipStreamSynchronize(stream);                      // the raw call: nothing is copied out
+  (void)hipGetLastError();
+  std::lock_guard<std::mutex> lk(g_stage_mutex);
+  auto it = g_stagers.find(stream);
+  if (it == g_stagers.end()) return;
+  it->second.fixes.clear();
+  for (StageChunk& c : it->second.chunks) c.used = 0;
+}
+
 void hso_stream_forget(hipStream_t stream)
 {
   std::lock_guard<std::mutex> lk(g_stage_mutex);
