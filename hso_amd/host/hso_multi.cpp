@@ -22,6 +22,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <new>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -55,6 +56,33 @@ struct Req {
   int (*fn)(void*) = nullptr; void* arg = nullptr;
 };
 
+// A grow-only array in page-locked memory of the context (hso_gpu_host_alloc): the merged tables of a batched call are DMA sources
+// / targets as they are (the library stages pageable memory through a copy of its own).
+template <typename T> struct PinnedVec {
+  hso_gpu_ctx** ctx; T* p = nullptr; size_t n = 0, cap = 0;
+  explicit PinnedVec(hso_gpu_ctx** c) : ctx(c) {}
+  PinnedVec(const PinnedVec&) = delete;
+  PinnedVec& operator=(const PinnedVec&) = delete;
+  ~PinnedVec() { }                         // freed with the context (hso_gpu_destroy releases every host allocation)
+  void reserve(size_t want)
+  {
+    if (want <= cap) return;
+    const size_t ncap = want + want / 2 + 1024;
+    void* q = nullptr;
+    if (hso_gpu_host_alloc(*ctx, ncap * sizeof(T), &q) < 0) throw std::bad_alloc();
+    if (n) memcpy(q, p, n * sizeof(T));
+    if (p) hso_gpu_host_free(*ctx, p);
+    p = static_cast<T*>(q); cap = ncap;
+  }
+  void clear() { n = 0; }
+  size_t size() const { return n; }
+  T* data() { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  void push_back(const T& v) { if (n == cap) reserve(n + 1); p[n++] = v; }
+  void append(const T* src, size_t k) { reserve(n + k); if (k) memcpy(p + n, src, k * sizeof(T)); n += k; }
+  void resize(size_t k) { reserve(k); n = k; }
+};
+
 struct Batcher {
   hso_gpu_ctx* ctx = nullptr;
   std::mutex m;
@@ -70,8 +98,9 @@ struct Batcher {
   std::condition_variable cv_dev;
   bool flush_wanted = false;
   int tasks_left = 0;                  // sequence tasks of the current step that have not finished yet
-  std::vector<hso_reproj_frame> m_fr; std::vector<hso_kf> m_kfs; std::vector<hso_map_point> m_pts; std::vector<hso_obs> m_obs;   // run_reproject
-  std::vector<hso_reproj_point> m_proj; std::vector<hso_align_out> m_match;
+  std::vector<hso_reproj_frame> m_fr;                                                  // run_reproject: the merged tables
+  PinnedVec<hso_kf> m_kfs{&ctx}; PinnedVec<hso_map_point> m_pts{&ctx}; PinnedVec<hso_obs> m_obs{&ctx};
+  PinnedVec<hso_reproj_point> m_proj{&ctx}; PinnedVec<hso_align_out> m_match{&ctx};
   std::vector<int64_t> release_queue;  // frames whose owners have gone (SeqRouter::frame_release)
   void drain_releases()                // lock held
   {
@@ -188,22 +217,25 @@ struct Batcher {
       }
       return;
     }
-    // the merged tables keep their storage between steps (members): a fresh multi-megabyte vector per step costs its page faults
-    // on the way in and an munmap on the way out
-    std::vector<hso_reproj_frame>& fr = m_fr; std::vector<hso_kf>& kfs = m_kfs; std::vector<hso_map_point>& pts = m_pts; std::vector<hso_obs>& obs = m_obs;
-    std::vector<hso_reproj_point>& proj = m_proj; std::vector<hso_align_out>& match = m_match;
+    // the merged tables keep their storage between steps (members, page-locked): a fresh multi-megabyte vector per step costs its
+    // page faults on the way in and an munmap on the way out
+    std::vector<hso_reproj_frame>& fr = m_fr; PinnedVec<hso_kf>& kfs = m_kfs; PinnedVec<hso_map_point>& pts = m_pts; PinnedVec<hso_obs>& obs = m_obs;
+    PinnedVec<hso_reproj_point>& proj = m_proj; PinnedVec<hso_align_out>& match = m_match;
     fr.assign(v.size(), hso_reproj_frame{}); kfs.clear(); pts.clear(); obs.clear();
+    try {
     for (size_t i = 0; i < v.size(); i++) {
       Req* r = v[i];
       hso_reproj_frame& f = fr[i];
       f.cur_frame_id = r->id; f.T_cur_w = *r->T; f.cur_exposure_time = r->exposure; f.cur_keyframe_id = r->cur_kf_id;
       f.kf_begin = (int)kfs.size(); f.kf_count = r->n_kfs; f.point_begin = (int)pts.size(); f.point_count = r->n_pts; f.pad_ = 0;
       const int ob = (int)obs.size();
-      kfs.insert(kfs.end(), r->kfs, r->kfs + r->n_kfs);
+      kfs.append(r->kfs, (size_t)r->n_kfs);
+      pts.reserve(pts.size() + (size_t)r->n_pts);
       for (int k = 0; k < r->n_pts; k++) { hso_map_point p = r->pts[k]; p.obs_begin += ob; pts.push_back(p); }
-      if (r->n_obs > 0) obs.insert(obs.end(), r->obs, r->obs + r->n_obs);
+      if (r->n_obs > 0) obs.append(r->obs, (size_t)r->n_obs);
     }
     proj.resize(pts.size() ? pts.size() : 1); match.resize(pts.size() ? pts.size() : 1);
+    } catch (const std::bad_alloc&) { fail(v, HSO_E_NOMEM); return; }
     const int rc = hso_gpu_reproject_match_multi(ctx, v[0]->cam, fr.data(), (int)fr.size(), kfs.data(), (int)kfs.size(), pts.data(), (int)pts.size(),
                                                  obs.data(), (int)obs.size(), v[0]->cell_size, v[0]->grid_n_cols, proj.data(), match.data());
     n_calls[K_REPROJECT]++;
