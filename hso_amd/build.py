@@ -25,15 +25,24 @@ PER_FILE = {"hso_tracker.hip": ["-fno-slp-vectorize"], "hso_tracker_coop.hip": [
 OBJ = os.path.join(HERE, "..", "build", "obj")
 
 
+def _headers():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(HERE, "..", "include", "hso_gpu.h"))
+    return deps
+
+
+def _host_sources():
+    host = os.path.join(HERE, "host")
+    return [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith((".cpp", ".h"))] + [os.path.join(HERE, "..", "include", "hso_vo.h")]
+
+
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(os.path.join(HERE, "host", "libhso_host.so")):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp"))]
-    host = os.path.join(HERE, "host")
-    deps += [os.path.join(host, f) for f in os.listdir(host) if f.endswith((".cpp", ".h"))]
-    deps.append(os.path.join(HERE, "..", "include", "hso_gpu.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    deps = [os.path.join(CSRC, f) for f in SOURCES] + _headers()
+    th = os.path.getmtime(os.path.join(HERE, "host", "libhso_host.so"))
+    return any(os.path.getmtime(d) > t for d in deps) or any(os.path.getmtime(d) > th for d in _host_sources() + _headers())
 
 
 def build(force=False, verbose=False, extra=()):
@@ -42,11 +51,16 @@ def build(force=False, verbose=False, extra=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = list(extra) + os.environ.get("HSO_EXTRA_FLAGS", "").split()
     os.makedirs(OBJ, exist_ok=True)
+    newest_header = max(os.path.getmtime(d) for d in _headers())
     objs, cmds = [], []
     for src in SOURCES:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        cmds.append([hipcc] + FLAGS + PER_FILE.get(src, []) + extra + ["-c", "-o", obj, os.path.join(CSRC, src)])
+        path = os.path.join(CSRC, src)
+        # a translation unit is recompiled when it or any header is newer than its object (or flags were added for this run)
+        if not force and not extra and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            continue
+        cmds.append([hipcc] + FLAGS + PER_FILE.get(src, []) + extra + ["-c", "-o", obj, path])
     # one compiler process per translation unit, all at once (the tracker alone takes about as long as the rest together)
     procs = []
     for cmd in cmds:
@@ -56,22 +70,25 @@ def build(force=False, verbose=False, extra=()):
     failed = [cmd for cmd, pr in zip(cmds, procs) if pr.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
-    if verbose:
-        print(" ".join(link))
-    subprocess.check_call(link)
+    if cmds or not os.path.exists(OUT):
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(link))
+        subprocess.check_call(link)
     build_host(verbose)
     return OUT
 
 
 def build_host(verbose=False):
-    """The host driver in the reference's own C++ class names (hso_amd/host: FrameHandlerMono::addImage and everything
-    below it) as libhso_host.so (C interface: include/hso_vo.h) + the mirror's test driver: plain g++ against the C-ABI
-    only (the device library is found at run time through $ORIGIN)."""
+    """libhso_host.so: the sequence engine (hso_engine*.cpp; C interface include/hso_vo.h) and the per-call mirror of the
+    reference's class surface (hso_host.cpp) + the mirror's test driver: plain g++ against the C-ABI only (the device library is
+    found at run time through $ORIGIN)."""
     host = os.path.join(HERE, "host")
     rpath = ["-L" + CSRC, "-lhso_gpu", "-Wl,-rpath,$ORIGIN/../csrc",
              "-Wl,-rpath," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
-    srcs = [os.path.join(host, "hso_host.cpp"), os.path.join(host, "hso_vo.cpp"), os.path.join(host, "hso_multi.cpp"), os.path.join(host, "hso_init.cpp")]
+    engine = [os.path.join(host, f) for f in ("hso_math.cpp", "hso_init.cpp", "hso_engine.cpp", "hso_engine_step.cpp", "hso_engine_kf.cpp",
+                                              "hso_engine_init.cpp", "hso_engine_c.cpp")]
+    srcs = engine + [os.path.join(host, "hso_host.cpp")]
     lib = os.path.join(host, "libhso_host.so")
     exe = os.path.join(host, "hso_host_test")
     for cmd in (["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", "-pthread"] + srcs + rpath + ["-o", lib],

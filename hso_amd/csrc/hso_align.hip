@@ -192,6 +192,9 @@ struct ReprojConsts {
 };
 
 // one map point: reprojectPoint + getCloseViewObs + the findMatchDirect job (shared by the value-passing and the resident form)
+// LINKED: the point's observations are a list threaded through the observation rows (obs_begin = first row, hso_obs.pad_ = next
+// row: the sequence maps); otherwise the rows obs_begin .. obs_begin + obs_count (the value-passing and the stored-map forms)
+template <bool LINKED = false>
 HSO_DEV hso_reproj_point reproject_one(const hso_camera& cam, const hso_map_point& P, const ReprojFrameDev& F, const ReprojKf* kfs,
                                        const hso_obs* obs, int cell_size, int grid_n_cols, AlignJobDev* JD)
 {
@@ -217,17 +220,18 @@ HSO_DEV hso_reproj_point reproject_one(const hso_camera& cam, const hso_map_poin
     // getCloseViewObs, src/point.cpp:116-136
     double ox = F.cur_pos[0] - P.pos[0], oy = F.cur_pos[1] - P.pos[1], oz = F.cur_pos[2] - P.pos[2];
     { const double n = sqrt(ox * ox + oy * oy + oz * oz); ox /= n; oy /= n; oz /= n; }
-    int best = 0;
+    int best = P.obs_begin;
     double min_cos = 0;
-    for (int k = 0; k < P.obs_count; k++) {
-      const ReprojKf& K = kfs[obs[P.obs_begin + k].kf];
+    for (int k = 0, row = P.obs_begin; k < P.obs_count; k++) {
+      const ReprojKf& K = kfs[obs[row].kf];
       double dx = K.pos[0] - P.pos[0], dy = K.pos[1] - P.pos[1], dz = K.pos[2] - P.pos[2];
       { const double n = sqrt(dx * dx + dy * dy + dz * dz); dx /= n; dy /= n; dz /= n; }
       const double c = ox * dx + oy * dy + oz * dz;
-      if (c > min_cos) { min_cos = c; best = k; }
+      if (c > min_cos) { min_cos = c; best = row; }
+      row = LINKED ? obs[row].pad_ : row + 1;
     }
     if (!(min_cos < 0.5)) {
-      o.ref_obs = P.obs_begin + best;
+      o.ref_obs = best;
       const hso_obs ref = obs[o.ref_obs];
       const ReprojKf& K = kfs[ref.kf];
       hso_align_job j;
@@ -714,4 +718,383 @@ extern "C" int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* 
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(out, hb, sizeof(hso_match_brief) * (size_t)total);
   return total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sequence maps (include/hso_gpu.h: hso_gpu_seqmap_*): the point and observation tables of a whole sequence, indexed by the
+// caller's own point / feature ids and patched row by row; a frame names the points it projects as an id list.
+struct SeqMap {
+  hso_map_point* d_pts = nullptr; size_t pts_cap = 0, n_pts = 0;
+  hso_obs* d_obs = nullptr; size_t obs_cap = 0, n_obs = 0;
+  std::vector<hso_kf> kfs;
+};
+struct SeqMaps {
+  std::vector<SeqMap*> m;
+  PyrGeom g{}; bool have_g = false;
+  // where the last hso_gpu_reproject_select_pose_frames call left its tables (hso_gpu_debug_fetch)
+  const void* dbg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t dbg_bytes[5] = {0, 0, 0, 0, 0};
+};
+
+void hso_seqmaps_free(hso_gpu_ctx* ctx)
+{
+  if (!ctx->seqmaps) return;
+  for (SeqMap* m : ctx->seqmaps->m)
+    if (m) { (void)hipFree(m->d_pts); (void)hipFree(m->d_obs); delete m; }
+  delete ctx->seqmaps;
+  ctx->seqmaps = nullptr;
+}
+
+static SeqMap* seqmap_of(hso_gpu_ctx* ctx, int map)
+{
+  if (!ctx->seqmaps || map < 0 || map >= (int)ctx->seqmaps->m.size()) return nullptr;
+  return ctx->seqmaps->m[map];
+}
+
+// rows of 8-byte granules: dst[ids[i]] = src[i]
+static __global__ void k_scatter_rows(unsigned long long* __restrict__ dst, const int* __restrict__ ids, const unsigned long long* __restrict__ src, int n,
+                                      int granules)
+{
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * granules) return;
+  const size_t i = g / granules, q = g - i * granules;
+  dst[(size_t)ids[i] * granules + q] = src[g];
+}
+static __global__ void k_gather_rows(const unsigned long long* __restrict__ src, const int* __restrict__ ids, unsigned long long* __restrict__ dst, int n,
+                                     int granules)
+{
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * granules) return;
+  const size_t i = g / granules, q = g - i * granules;
+  dst[g] = src[(size_t)ids[i] * granules + q];
+}
+static_assert(sizeof(hso_map_point) % 8 == 0 && sizeof(hso_obs) % 8 == 0, "rows move in 8-byte granules");
+
+template <typename T> static int seqmap_grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need, size_t keep)
+{
+  if (*cap >= need) return HSO_OK;
+  const size_t ncap = std::max(need + need / 2, (size_t)4096);
+  T* q = nullptr;
+  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&q), ncap * sizeof(T)));
+  hipError_t e = hipMemsetAsync(q, 0, ncap * sizeof(T), ctx->stream);
+  if (e == hipSuccess && *p && keep) e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(q); ctx->err = std::string("seqmap: ") + hipGetErrorString(e); return HSO_E_HIP; }
+  if (*p) (void)hipFree(*p);
+  *p = q; *cap = ncap;
+  return HSO_OK;
+}
+
+extern "C" {
+
+int hso_gpu_seqmap_create(hso_gpu_ctx* ctx, int* map_out)
+{
+  if (!ctx || !map_out) return HSO_E_INVALID;
+  if (!ctx->seqmaps) ctx->seqmaps = new SeqMaps();
+  ctx->seqmaps->m.push_back(new SeqMap());
+  *map_out = (int)ctx->seqmaps->m.size() - 1;
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_destroy(hso_gpu_ctx* ctx, int map)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m) return hso_fail(ctx, HSO_E_INVALID, "seqmap: no such map");
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(m->d_pts); (void)hipFree(m->d_obs);
+  delete m;
+  ctx->seqmaps->m[map] = nullptr;
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_set_keyframes(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, int n_kfs)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || n_kfs < 0 || (n_kfs > 0 && !kfs)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_set_keyframes: bad argument");
+  SeqMaps* S = ctx->seqmaps;
+  for (int k = 0; k < n_kfs; k++) {
+    auto it = ctx->frames.find(kfs[k].frame_id);
+    if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seqmap_set_keyframes: keyframe not resident");
+    if (!S->have_g) { S->g = it->second.g; S->have_g = true; }
+    if (!same_geom(it->second.g, S->g)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_set_keyframes: frames must share one size");
+  }
+  m->kfs.assign(kfs, kfs + n_kfs);
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_patch(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, const hso_map_point* points, int n_points,
+                         const int32_t* obs_ids, const hso_obs* obs, int n_obs)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || n_points < 0 || n_obs < 0 || (n_points > 0 && (!point_ids || !points)) || (n_obs > 0 && (!obs_ids || !obs)))
+    return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: bad argument");
+  if (n_points == 0 && n_obs == 0) return HSO_OK;
+  // the kernels trust the tables: check every index a row carries before it reaches the device
+  const int nk = (int)m->kfs.size();
+  size_t need_pts = m->n_pts, need_obs = m->n_obs;
+  for (int i = 0; i < n_obs; i++) {
+    if (obs_ids[i] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: negative observation id");
+    need_obs = std::max(need_obs, (size_t)obs_ids[i] + 1);
+  }
+  for (int i = 0; i < n_obs; i++) {
+    const hso_obs& o = obs[i];
+    if (o.kf < 0 || o.kf >= nk || o.level < 0 || o.level >= HSO_N_PYR_LEVELS || o.pad_ < -1 || (o.pad_ >= 0 && (size_t)o.pad_ >= need_obs))
+      return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: observation row out of range (keyframe table set first?)");
+  }
+  for (int i = 0; i < n_points; i++) {
+    const hso_map_point& p = points[i];
+    if (point_ids[i] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: negative point id");
+    need_pts = std::max(need_pts, (size_t)point_ids[i] + 1);
+    if (p.host_kf < 0 || p.host_kf >= nk || p.obs_count < 0 || (p.obs_count > 0 && (p.obs_begin < 0 || (size_t)p.obs_begin >= need_obs)))
+      return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: point row out of range");
+  }
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rc = seqmap_grow(ctx, &m->d_pts, &m->pts_cap, need_pts, m->n_pts)) return rc;
+  if (int rc = seqmap_grow(ctx, &m->d_obs, &m->obs_cap, need_obs, m->n_obs)) return rc;
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_pid = al(sizeof(int) * (size_t)n_points), b_pts = al(sizeof(hso_map_point) * (size_t)n_points);
+  const size_t b_oid = al(sizeof(int) * (size_t)n_obs), b_obs = al(sizeof(hso_obs) * (size_t)n_obs);
+  const size_t need = b_pid + b_pts + b_oid + b_obs;
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
+  }
+  char* d = ctx->d_batch;
+  if (n_points) {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, point_ids, sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + b_pid, points, sizeof(hso_map_point) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
+    const int G = sizeof(hso_map_point) / 8;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)(((size_t)n_points * G + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<unsigned long long*>(m->d_pts), reinterpret_cast<const int*>(d), reinterpret_cast<const unsigned long long*>(d + b_pid), n_points, G);
+  }
+  if (n_obs) {
+    char* e = d + b_pid + b_pts;
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(e, obs_ids, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(e + b_oid, obs, sizeof(hso_obs) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+    const int G = sizeof(hso_obs) / 8;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)(((size_t)n_obs * G + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<unsigned long long*>(m->d_obs), reinterpret_cast<const int*>(e), reinterpret_cast<const unsigned long long*>(e + b_oid), n_obs, G);
+  }
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  // No synchronisation: the rows were copied out of the caller's memory when the copies were enqueued (pinned staging chunks of
+  // the stream, hso_ctx.h), and whatever uses the work area or the tables next is ordered behind the scatter on the same stream.
+  // A map patched for many sequences per step thus costs enqueues only; the step's next synchronising call releases the chunks.
+  m->n_pts = need_pts; m->n_obs = need_obs;
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_size(hso_gpu_ctx* ctx, int map, int* n_kfs, int* n_points, int* n_obs)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m) return hso_fail(ctx, HSO_E_INVALID, "seqmap: no such map");
+  if (n_kfs) *n_kfs = (int)m->kfs.size();
+  if (n_points) *n_points = (int)m->n_pts;
+  if (n_obs) *n_obs = (int)m->n_obs;
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_read(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, int n_points, hso_map_point* points_out,
+                        const int32_t* obs_ids, int n_obs, hso_obs* obs_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || n_points < 0 || n_obs < 0 || (n_points > 0 && (!point_ids || !points_out)) || (n_obs > 0 && (!obs_ids || !obs_out)))
+    return hso_fail(ctx, HSO_E_INVALID, "seqmap_read: bad argument");
+  for (int i = 0; i < n_points; i++) if (point_ids[i] < 0 || (size_t)point_ids[i] >= m->n_pts) return hso_fail(ctx, HSO_E_INVALID, "seqmap_read: point id out of range");
+  for (int i = 0; i < n_obs; i++) if (obs_ids[i] < 0 || (size_t)obs_ids[i] >= m->n_obs) return hso_fail(ctx, HSO_E_INVALID, "seqmap_read: observation id out of range");
+  if (n_points == 0 && n_obs == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_pid = al(sizeof(int) * (size_t)n_points), b_pts = al(sizeof(hso_map_point) * (size_t)n_points);
+  const size_t b_oid = al(sizeof(int) * (size_t)n_obs), b_obs = al(sizeof(hso_obs) * (size_t)n_obs);
+  const size_t need = b_pid + b_pts + b_oid + b_obs;
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
+  }
+  char* d = ctx->d_batch;
+  if (n_points) {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, point_ids, sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
+    const int G = sizeof(hso_map_point) / 8;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)(((size_t)n_points * G + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const unsigned long long*>(m->d_pts), reinterpret_cast<const int*>(d), reinterpret_cast<unsigned long long*>(d + b_pid), n_points, G);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(points_out, d + b_pid, sizeof(hso_map_point) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (n_obs) {
+    char* e = d + b_pid + b_pts;
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(e, obs_ids, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+    const int G = sizeof(hso_obs) / 8;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)(((size_t)n_obs * G + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const unsigned long long*>(m->d_obs), reinterpret_cast<const int*>(e), reinterpret_cast<unsigned long long*>(e + b_oid), n_obs, G);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(obs_out, e + b_oid, sizeof(hso_obs) * (size_t)n_obs, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+int hso_gpu_debug_fetch(hso_gpu_ctx* ctx, int what, void* out, size_t bytes)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMaps* S = ctx->seqmaps;
+  if (!S || what < 0 || what > 4 || !out || !S->dbg[what] || S->dbg_bytes[what] != bytes) return hso_fail(ctx, HSO_E_INVALID, "debug_fetch: no such table, or a size mismatch");
+  if (bytes == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, S->dbg[what], bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+}  // extern "C"
+
+void hso_seqmaps_debug_set(hso_gpu_ctx* ctx, int what, const void* d, size_t bytes)
+{
+  if (!ctx->seqmaps) return;
+  ctx->seqmaps->dbg[what] = d; ctx->seqmaps->dbg_bytes[what] = bytes;
+}
+
+// one frame of a sequence map: the listed points
+struct ListCallDev {
+  ReprojFrameDev F;                // kf_begin = first row of the call's ReprojKf block
+  const hso_map_point* pts; const hso_obs* obs;
+  int n_pts_table, n_kfs;
+  int list_begin, list_count;      // the call's slice of the id / quality arrays
+};
+struct ListConsts {
+  hso_camera cam;
+  const ListCallDev* calls;
+  int n_calls, n_total;
+  const ReprojKf* kfs;
+  const int32_t* ids; const uint8_t* quality;
+  int cell_size, grid_n_cols;
+};
+
+__global__ __launch_bounds__(256) void k_reproject_list(ListConsts M, AlignJobDev* jobs, hso_reproj_point* proj)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= M.n_total) return;
+  int lo = 0, hi = M.n_calls - 1;          // the call whose slice holds g
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (M.calls[mid].list_begin <= g) lo = mid; else hi = mid - 1; }
+  const ListCallDev& C = M.calls[lo];
+  const int pid = M.ids[g];
+  hso_reproj_point r;
+  if (pid < 0 || pid >= C.n_pts_table) {   // an id the table does not hold: not projected (the host checked the tables, not the list)
+    r.projected = 0; r.cell = 0; r.px[0] = 0; r.px[1] = 0; r.ref_obs = -1;
+    jobs[g].ref_base = nullptr; jobs[g].cur_base = C.F.cur_base;
+  } else {
+    r = reproject_one<true>(M.cam, C.pts[pid], C.F, M.kfs + C.F.kf_begin, C.obs, M.cell_size, M.grid_n_cols, &jobs[g]);
+  }
+  r.pad_ = M.quality[g];
+  proj[g] = r;
+}
+
+// The launch chain of hso_gpu_reproject_select_pose_frames up to the per-point records (cf. hso_reproject_maps_run)
+int hso_reproject_frames_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_frame* frames, int n_frames, int cell_size,
+                             int grid_n_cols, size_t extra_bytes, HsoMapsRun* R, HsoFramesAux* X)
+{
+  SeqMaps* S = ctx->seqmaps;
+  if (!S || !cam || n_frames < 0 || (n_frames > 0 && !frames) || cell_size < 1 || grid_n_cols < 1)
+    return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: bad argument");
+  R->n = 0; R->begin.assign(n_frames + 1, 0);
+  if (n_frames == 0) return 0;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  size_t total = 0, total_kfs = 0;
+  X->kf_begin.assign(n_frames + 1, 0);
+  for (int c = 0; c < n_frames; c++) {
+    const SeqMap* m = seqmap_of(ctx, frames[c].map);
+    if (!m) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: no such map");
+    if (frames[c].n_points < 0 || (frames[c].n_points > 0 && (!frames[c].point_ids || !frames[c].quality)))
+      return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: null point list");
+    total += (size_t)frames[c].n_points; total_kfs += m->kfs.size();
+    R->begin[c + 1] = (int)total; X->kf_begin[c + 1] = (int)total_kfs;
+  }
+  if (total == 0) return 0;
+  if (!S->have_g || cam->width != S->g.w[0] || cam->height != S->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: camera size differs from the frame size");
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_calls = al(sizeof(ListCallDev) * (size_t)n_frames), b_kfs = al(sizeof(ReprojKf) * std::max(total_kfs, (size_t)1));
+  const size_t b_ids = al(sizeof(int32_t) * total), b_q = al(total);
+  char* hin = hso_pinned(ctx, 0, b_calls + b_kfs + b_ids + b_q);
+  if (!hin) return HSO_E_NOMEM;
+  ListCallDev* hc = reinterpret_cast<ListCallDev*>(hin);
+  ReprojKf* hk = reinterpret_cast<ReprojKf*>(hin + b_calls);
+  int32_t* hid = reinterpret_cast<int32_t*>(hin + b_calls + b_kfs);
+  uint8_t* hq = reinterpret_cast<uint8_t*>(hin + b_calls + b_kfs + b_ids);
+  for (int c = 0; c < n_frames; c++) {
+    const hso_map_frame& K = frames[c];
+    const SeqMap* m = seqmap_of(ctx, K.map);
+    auto itc = ctx->frames.find(K.cur_frame_id);
+    if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_select_pose_frames: current frame not resident");
+    if (!same_geom(itc->second.g, S->g)) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: frames must share one size");
+    const Se3 Tc = se3_from(K.T_cur_w);
+    const Se3 ci = se3_inverse(Tc);
+    ListCallDev& D = hc[c];
+    D.F.cur_pos[0] = ci.tx; D.F.cur_pos[1] = ci.ty; D.F.cur_pos[2] = ci.tz;
+    D.F.cur_base = itc->second.base; D.F.kf_begin = X->kf_begin[c]; D.F.pad_ = 0;
+    D.pts = m->d_pts; D.obs = m->d_obs; D.n_pts_table = (int)m->n_pts; D.n_kfs = (int)m->kfs.size();
+    D.list_begin = R->begin[c]; D.list_count = K.n_points;
+    for (size_t k = 0; k < m->kfs.size(); k++) {
+      auto it = ctx->frames.find(m->kfs[k].frame_id);
+      if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_select_pose_frames: a keyframe of the map is no longer resident");
+      ReprojKf& Q = hk[(size_t)X->kf_begin[c] + k];
+      const Se3 inv = se3_inverse(se3_from(m->kfs[k].T_f_w));
+      Q.T_cur_kf = se3_mul(Tc, inv);
+      Q.pos[0] = inv.tx; Q.pos[1] = inv.ty; Q.pos[2] = inv.tz;
+      Q.base = it->second.base; Q.frame_id = m->kfs[k].frame_id;
+      Q.exposure_rat = (float)(K.cur_exposure_time / m->kfs[k].exposure_time);
+      Q.kf_gap_lt4 = (K.cur_keyframe_id - m->kfs[k].keyframe_id) < 4;
+    }
+    if (K.n_points) {
+      memcpy(hid + R->begin[c], K.point_ids, sizeof(int32_t) * (size_t)K.n_points);
+      memcpy(hq + R->begin[c], K.quality, (size_t)K.n_points);
+    }
+  }
+  const size_t o_jobs = 0, o_match = o_jobs + al(sizeof(AlignJobDev) * total), o_proj = o_match + al(sizeof(hso_align_out) * total);
+  const size_t o_brief = o_proj + al(sizeof(hso_reproj_point) * total), o_in = o_brief + al(sizeof(hso_match_brief) * total);
+  const size_t b_in = b_calls + b_kfs + b_ids + b_q;
+  const size_t o_extra = o_in + al(b_in);
+  const size_t need = o_extra + extra_bytes;
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
+  }
+  char* d = ctx->d_batch;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_in, hin, b_in, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_match, 0, sizeof(hso_align_out) * total, ctx->stream));
+  ListConsts M;
+  M.cam = *cam; M.calls = reinterpret_cast<const ListCallDev*>(d + o_in); M.n_calls = n_frames; M.n_total = (int)total;
+  M.kfs = reinterpret_cast<const ReprojKf*>(d + o_in + b_calls);
+  M.ids = reinterpret_cast<const int32_t*>(d + o_in + b_calls + b_kfs); M.quality = reinterpret_cast<const uint8_t*>(d + o_in + b_calls + b_kfs + b_ids);
+  M.cell_size = cell_size; M.grid_n_cols = grid_n_cols;
+  AlignJobDev* d_jobs = reinterpret_cast<AlignJobDev*>(d + o_jobs);
+  hso_align_out* d_match = reinterpret_cast<hso_align_out*>(d + o_match);
+  hso_reproj_point* d_proj = reinterpret_cast<hso_reproj_point*>(d + o_proj);
+  hso_match_brief* d_brief = reinterpret_cast<hso_match_brief*>(d + o_brief);
+  const int n = (int)total;
+  hipLaunchKernelGGL(k_reproject_list, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, M, d_jobs, d_proj);
+  AlignConsts C;
+  C.cam = *cam; C.g = S->g;
+  launch_align(ctx, true, C, d_jobs, n, d_match);
+  hipLaunchKernelGGL(k_match_brief, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_proj, d_match, d_jobs, d_brief);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  R->n = n; R->d_proj = d_proj; R->d_brief = d_brief; R->d_extra = d + o_extra;
+  X->d_ids = M.ids; X->d_quality = M.quality; X->d_match = d_match;
+  X->pts.resize(n_frames); X->kf_poses.clear();
+  for (int c = 0; c < n_frames; c++) {
+    const SeqMap* m = seqmap_of(ctx, frames[c].map);
+    X->pts[c] = m->d_pts;
+    for (const hso_kf& k : m->kfs) X->kf_poses.push_back(k.T_f_w);
+  }
+  return n;
 }

@@ -40,6 +40,7 @@ struct FrameRec {
 struct TrackBatchState;  // hso_tracker.hip
 struct SeedTables;       // hso_seed.hip: resident seed tables
 struct MapArena;         // hso_align.hip: resident map tables
+struct SeqMaps;          // hso_align.hip: sequence maps (tables mirrored row for row, patched in place)
 
 struct hso_gpu_ctx {
   int device;
@@ -53,6 +54,7 @@ struct hso_gpu_ctx {
   TrackBatchState* track;
   SeedTables* seed_tables;
   MapArena* maps;
+  SeqMaps* seqmaps;
   // staging for batched frame uploads: [bases | srcs | stats]
   char* d_batch; size_t batch_cap;
   // pinned host staging (grow-only): record tables go through it so the DMA runs at PCIe rate
@@ -118,6 +120,7 @@ void hso_track_state_free(hso_gpu_ctx* ctx);
 void hso_seed_tables_free(hso_gpu_ctx* ctx);
 bool hso_seed_tables_pin(hso_gpu_ctx* ctx, int64_t frame_id);   // a resident seed table hosts live seeds in this frame
 void hso_map_arena_free(hso_gpu_ctx* ctx);
+void hso_seqmaps_free(hso_gpu_ctx* ctx);
 // a frame allocation of geometry g: recycled when the free list holds that geometry, else fresh with zeroed padding rows.
 // hso_frame_free returns it to the list (or the allocator); neither touches ctx->frames.
 // hso_align.hip: project + reference choice + findMatchDirect for every point of every call's stored map, results left on the
@@ -134,6 +137,18 @@ struct MapArenaSizes { long long total; };   // points of a set of calls
 int hso_map_call_sizes(hso_gpu_ctx* ctx, const hso_map_call* calls, int n_calls, MapArenaSizes* Z);
 int hso_reproject_maps_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
                            int grid_n_cols, size_t extra_bytes, HsoMapsRun* R);
+// the sequence-map form (hso_gpu_reproject_select_pose_frames): the same records for the points each frame LISTS; what the
+// chained pose optimisation needs beside them comes back in X
+struct HsoFramesAux {
+  std::vector<int> kf_begin;                   // per frame: first row of its keyframes in kf_poses (n_frames + 1)
+  std::vector<hso_se3> kf_poses;               // T_f_w of every frame's map keyframes, frames back to back
+  std::vector<const hso_map_point*> pts;       // per frame: its map's point table (device)
+  const int32_t* d_ids; const uint8_t* d_quality;   // the listed ids / quality keys, frames back to back (device)
+  const hso_align_out* d_match;
+};
+int hso_reproject_frames_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_frame* frames, int n_frames, int cell_size,
+                             int grid_n_cols, size_t extra_bytes, HsoMapsRun* R, HsoFramesAux* X);
+void hso_seqmaps_debug_set(hso_gpu_ctx* ctx, int what, const void* d, size_t bytes);
 const hso_map_point* hso_map_points_dev(hso_gpu_ctx* ctx);
 int hso_map_max_points(hso_gpu_ctx* ctx);
 int hso_map_max_kfs(hso_gpu_ctx* ctx);

@@ -194,6 +194,7 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   ctx->track = nullptr;
   ctx->seed_tables = nullptr;
   ctx->maps = nullptr;
+  ctx->seqmaps = nullptr;
   ctx->free_w = ctx->free_h = 0;
   ctx->d_batch = nullptr;
   ctx->batch_cap = 0;
@@ -221,6 +222,7 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   hso_track_state_free(ctx);
   hso_seed_tables_free(ctx);
   hso_map_arena_free(ctx);
+  hso_seqmaps_free(ctx);
   for (auto& kv : ctx->frames) (void)hipFree(kv.second.base);
   for (auto* p : ctx->free_frames) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);

@@ -574,7 +574,7 @@ extern "C" int hso_gpu_pose_optimize_batch(hso_gpu_ctx* ctx, const hso_camera* c
   size_t tot_feats = 0, tot_poses = 0;
   for (int j = 0; j < n_jobs; j++) {
     if (jobs[j].n_feats < 0 || jobs[j].n_feats > POSE_MAX_FEATS) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: n_feats out of range (max 4096)");
-    if (jobs[j].n_poses <= 0 || jobs[j].n_poses > POSE_MAX_POSES || !jobs[j].poses_f_w) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: n_poses out of range (1..64)");
+    if (jobs[j].n_poses <= 0 || jobs[j].n_poses > POSE_MAX_POSES || !jobs[j].poses_f_w) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: n_poses out of range (1..128)");
     if (jobs[j].n_feats > 0 && !jobs[j].feats) return hso_fail(ctx, HSO_E_INVALID, "pose_optimize: null feature table");
     for (int i = 0; i < jobs[j].n_feats; i++) {
       const hso_pose_feat& f = jobs[j].feats[i];

@@ -15,7 +15,7 @@ struct PoseJobDev {
 };
 
 #define HSO_POSE_MAX_FEATS 4096
-#define HSO_POSE_MAX_POSES 64
+#define HSO_POSE_MAX_POSES 128
 // one workgroup per job; n_max_feats = an upper bound of the jobs' n_feats (selects the features-per-thread instantiation)
 int hso_pose_launch_device(hso_gpu_ctx* ctx, const hso_camera* cam, const PoseJobDev* d_jobs, int n_jobs, int n_max_feats,
                            hso_pose_result* d_results);

@@ -39,6 +39,7 @@ struct SeedConsts {
   double px_error_angle;
   int update_in_place;       // resident tables: write mu / sigma2 / b back into the seed record
   hso_seed_brief* brief;     // resident tables: compact per-slot result (may be null)
+  float* px;                 // resident tables: Matcher::px_cur_ of the matched seeds, two floats per slot (may be null)
 };
 
 struct SeedDev {
@@ -193,6 +194,7 @@ HSO_DEV void seed_finish(const SeedConsts& C, SeedDev* seeds, int sid, hso_seed_
     br.result = (int8_t)o.result; br.is_update = (int8_t)o.is_update; br.is_valid = (int8_t)o.is_valid; br.search_level = (int8_t)o.search_level;
     C.brief[sid] = br;
   }
+  if (C.px) { C.px[2 * sid] = (float)o.px_cur[0]; C.px[2 * sid + 1] = (float)o.px_cur[1]; }
 }
 
 // observeDepthRow in three phases, so that what is identical in all 64 lanes of the wave that observes a seed is computed by
@@ -546,7 +548,8 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
   if (first >= n_seeds) return;
   const int mine = first + lane;
   const bool own = lane < cpw && mine < n_seeds;
-  const bool live = own && seeds[mine].ref_base != nullptr;     // a null reference: an erased slot of a resident table
+  // a null reference: an erased slot of a resident table; a null active frame: the seed's group sits this call out
+  const bool live = own && seeds[mine].ref_base != nullptr && (seeds[mine].cur_base != nullptr || C.frames[seeds[mine].frame].cur_base != nullptr);
   if (live) s_pre[wave][lane] = seed_pre(C, seeds[mine], C.frames[seeds[mine].frame]);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -556,8 +559,8 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
     const int sid = first + q;
     if (sid >= n_seeds) break;
     const SeedDev& SD = seeds[sid];
-    if (SD.ref_base == nullptr || s_pre[wave][q].state != 0) continue;
     const uint8_t* const cur_base = SD.cur_base ? SD.cur_base : C.frames[SD.frame].cur_base;
+    if (SD.ref_base == nullptr || cur_base == nullptr || s_pre[wave][q].state != 0) continue;
     const SeedMid M = seed_wave(C, SD, cur_base, s_pre[wave][q], s_pwb[wave][row]);
     if ((lane & 15) == 0) s_mid[wave][q] = M;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the row's next seed overwrites its patch
@@ -567,6 +570,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(Seed
   if (own) {
     if (!live) {
       if (C.brief) { hso_seed_brief br; memset(&br, 0, sizeof(br)); C.brief[mine] = br; }
+      if (C.px) { C.px[2 * mine] = 0.f; C.px[2 * mine + 1] = 0.f; }
     } else {
       const hso_seed_out o = seed_post(C, seeds[mine], C.frames[seeds[mine].frame], s_pre[wave][lane], s_mid[wave][lane]);
       seed_finish(C, seeds, mine, outs, o, 0);
@@ -639,7 +643,7 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h, (size_t)n_seeds * sizeof(SeedDev), hipMemcpyHostToDevice, ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_fr, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
-  C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle; C.update_in_place = 0; C.brief = nullptr;
+  C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle; C.update_in_place = 0; C.brief = nullptr; C.px = nullptr;
   const int cpw = seed_cpw(ctx, n_seeds);
   const int blocks = ((n_seeds + cpw - 1) / cpw + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK;
   hipLaunchKernelGGL(k_seed_observe, dim3(blocks), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, d_in, n_seeds, d_out, cpw);
@@ -677,6 +681,7 @@ struct SeedTable {
   std::unordered_map<int64_t, int> pins;   // host frame id -> live seeds hosted there: such a frame must stay resident
   hso_seed_brief* d_brief = nullptr; size_t brief_cap = 0;
   hso_seed_out* d_full = nullptr; size_t full_cap = 0;
+  float* d_px = nullptr; size_t px_cap = 0;
   SeedFrameDev* d_frames = nullptr; size_t frames_cap = 0;
   PyrGeom g{}; bool have_g = false;
   int max_group = -1;
@@ -687,7 +692,7 @@ void hso_seed_tables_free(hso_gpu_ctx* ctx)
 {
   if (!ctx->seed_tables) return;
   for (SeedTable* t : ctx->seed_tables->t)
-    if (t) { (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); delete t; }
+    if (t) { (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); (void)hipFree(t->d_px); delete t; }
   delete ctx->seed_tables;
   ctx->seed_tables = nullptr;
 }
@@ -743,7 +748,7 @@ int hso_gpu_seed_table_destroy(hso_gpu_ctx* ctx, int table)
   SeedTable* t = seed_table_of(ctx, table);
   if (!t) return hso_fail(ctx, HSO_E_INVALID, "seed_table: no such table");
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames);
+  (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); (void)hipFree(t->d_px);
   delete t;
   ctx->seed_tables->t[table] = nullptr;
   return HSO_OK;
@@ -804,6 +809,16 @@ int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, 
 }
 
 }  // extern "C"
+
+// local BA moved a keyframe: the live seeds hosted there take its new pose
+static __global__ void k_seed_set_host_pose(SeedDev* seeds, int n_slots, const int64_t* ids, const hso_se3* poses, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots || seeds[i].ref_base == nullptr) return;
+  const int64_t id = seeds[i].s.ref_frame_id;
+  for (int k = 0; k < n; k++)
+    if (ids[k] == id) { seeds[i].s.T_ref_w = poses[k]; return; }
+}
 
 // dst[i] = src[idx[i]]: 16 bytes per thread, a record = sizeof(SeedDev) / 16 threads
 static __global__ void k_seed_gather(const uint4* __restrict__ src, const int* __restrict__ idx, uint4* __restrict__ dst, int n_live)
@@ -870,8 +885,8 @@ int hso_gpu_seed_table_size(hso_gpu_ctx* ctx, int table, int* n_slots, int* n_li
   return HSO_OK;
 }
 
-int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
-                               double px_error_angle, hso_seed_brief* brief_out, hso_seed_out* full_out)
+static int seed_table_observe_impl(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
+                                   double px_error_angle, hso_seed_brief* brief_out, float* px_out, hso_seed_out* full_out, bool allow_skip)
 {
   if (!ctx) return HSO_E_INVALID;
   SeedTable* t = seed_table_of(ctx, table);
@@ -881,6 +896,7 @@ int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int tabl
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   std::vector<SeedFrameDev> hf(n_frames);
   for (int k = 0; k < n_frames; k++) {
+    if (allow_skip && frames[k].frame_id < 0) { hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = 1.0; hf[k].cur_base = nullptr; continue; }
     auto itc = ctx->frames.find(frames[k].frame_id);
     if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_table_observe: active frame not resident");
     if (!same_geom(itc->second.g, t->g)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe: frames must share one size");
@@ -890,17 +906,19 @@ int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int tabl
   if (int rc = grow_dev(ctx, &t->d_frames, &t->frames_cap, (size_t)n_frames, 0)) return rc;
   if (int rc = grow_dev(ctx, &t->d_brief, &t->brief_cap, t->n, 0)) return rc;
   if (full_out) if (int rc = grow_dev(ctx, &t->d_full, &t->full_cap, t->n, 0)) return rc;
+  if (px_out) if (int rc = grow_dev(ctx, &t->d_px, &t->px_cap, 2 * t->n, 0)) return rc;
   SeedFrameDev* hfp = reinterpret_cast<SeedFrameDev*>(hso_pinned(ctx, 0, (size_t)n_frames * sizeof(SeedFrameDev)));
   if (!hfp) return HSO_E_NOMEM;
   memcpy(hfp, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, hfp, (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
-  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief;
+  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = px_out ? t->d_px : nullptr;
   const int n = (int)t->n;
   const int cpw = seed_cpw(ctx, n);
   hipLaunchKernelGGL(k_seed_observe, dim3(((n + cpw - 1) / cpw + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK), dim3(64 * SEED_WAVES_PER_BLOCK), 0,
                      ctx->stream, C, t->d, n, full_out ? t->d_full : nullptr, cpw);
   HSO_HIP_CHECK(ctx, hipGetLastError());
+  if (px_out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(px_out, t->d_px, 2 * t->n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (brief_out) {
     hso_seed_brief* hb = reinterpret_cast<hso_seed_brief*>(hso_pinned(ctx, 1, t->n * sizeof(hso_seed_brief)));
     if (!hb) return HSO_E_NOMEM;
@@ -912,6 +930,43 @@ int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int tabl
     if (full_out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(full_out, t->d_full, t->n * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
+                               double px_error_angle, hso_seed_brief* brief_out, hso_seed_out* full_out)
+{
+  return seed_table_observe_impl(ctx, cam, table, frames, n_frames, px_error_angle, brief_out, nullptr, full_out, false);
+}
+
+int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
+                                      double px_error_angle, hso_seed_brief* brief_out, float* px_out, hso_seed_out* full_out)
+{
+  return seed_table_observe_impl(ctx, cam, table, frames, n_frames, px_error_angle, brief_out, px_out, full_out, true);
+}
+
+int hso_gpu_seed_table_set_host_pose(hso_gpu_ctx* ctx, int table, const int64_t* frame_ids, const hso_se3* T_f_w, int n)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || n < 0 || (n > 0 && (!frame_ids || !T_f_w))) return hso_fail(ctx, HSO_E_INVALID, "seed_table_set_host_pose: bad argument");
+  if (n == 0 || t->n == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_id = al(sizeof(int64_t) * (size_t)n), need = b_id + al(sizeof(hso_se3) * (size_t)n);
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
+  }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_batch, frame_ids, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_batch + b_id, T_f_w, sizeof(hso_se3) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_seed_set_host_pose, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream, t->d, (int)t->n,
+                     reinterpret_cast<const int64_t*>(ctx->d_batch), reinterpret_cast<const hso_se3*>(ctx->d_batch + b_id), n);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }
 

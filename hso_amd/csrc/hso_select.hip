@@ -578,3 +578,248 @@ extern "C" int hso_gpu_reproject_select_pose_maps(hso_gpu_ctx* ctx, const hso_ca
   return reproject_select_maps_impl(ctx, cam, calls, n_calls, cell_size, grid_n_cols, cell_order, n_cells, max_fts, out, out_capacity, begin_out,
                                     counts_out, pose);
 }
+
+
+// ------------------------------------------------------------------------------------------------ chained behind the sequence maps
+// hso_gpu_reproject_select_pose_frames: the same chain over the points each frame LISTS (hso_align.hip: hso_reproject_frames_run).
+// What differs behind the selection: the feature table takes the point row through the frame's id list, the quality key from
+// the list's key array, and the pose job's keyframe table is compacted here to the keyframes that host a selected feature (a
+// sequence map holds every keyframe of its sequence; k_pose keeps HSO_POSE_MAX_POSES transforms in LDS).
+struct PoseSrcDev {
+  const hso_map_point* pts;     // the frame's map
+  const hso_se3* kf_poses;      // its keyframe poses (map order)
+  int list_begin, n_kfs;
+};
+
+#define SEL_KF_WORDS 64         // 4096 keyframes per sequence map take part in the compaction bitmask
+
+__global__ __launch_bounds__(SEL_THREADS) void k_pose_feats_from_list(hso_camera cam, const hso_match_brief* out, const int* offs, const PoseSrcDev* src,
+                                                                     const int32_t* ids, const uint8_t* quality, int feat_cap, hso_pose_feat* feats,
+                                                                     PoseJobDev* jobs, hso_se3* poses_out, int* n_poses_out, double* feat_f, int* n_feats)
+{
+  __shared__ int s_wave[SEL_WAVES];
+  __shared__ unsigned long long s_used[SEL_KF_WORDS];
+  __shared__ int s_base[SEL_KF_WORDS];
+  const int c = blockIdx.x, b = offs[c], e = offs[c + 1];
+  const PoseSrcDev S = src[c];
+  hso_pose_feat* F = feats + (size_t)c * feat_cap;
+  double* FF = feat_f ? feat_f + (size_t)c * feat_cap * 3 : nullptr;
+  for (int w = threadIdx.x; w < SEL_KF_WORDS; w += SEL_THREADS) s_used[w] = 0;
+  __syncthreads();
+  int carry = 0;
+  for (int i0 = b; i0 < e; i0 += SEL_THREADS) {
+    const int i = i0 + (int)threadIdx.x;
+    const int is = (i < e && out[i].success) ? 1 : 0;
+    int tot;
+    const int pos = sel_block_scan(is, s_wave, tot) + carry - is;
+    if (is && pos < feat_cap) {
+      const hso_match_brief& r = out[i];
+      const int at = S.list_begin + r.pad_;
+      const hso_map_point& p = S.pts[ids[at]];
+      hso_pose_feat f;
+      f.has_point = 1; f.type = r.ref_type; f.level = r.search_level; f.temporary = ((quality[at] >> 4) == 1) ? 1 : 0;
+      f.host_pose = p.host_kf; f._pad = 0;
+      hso_dev::cam2world_dev(cam, r.px_cur[0], r.px_cur[1], f.f);
+      f.grad[0] = (double)r.grad[0]; f.grad[1] = (double)r.grad[1];
+      f.host_f[0] = p.host_f[0]; f.host_f[1] = p.host_f[1]; f.host_f[2] = p.host_f[2];
+      f.idist = p.idist;
+      F[pos] = f;
+      if (FF) { FF[3 * pos] = f.f[0]; FF[3 * pos + 1] = f.f[1]; FF[3 * pos + 2] = f.f[2]; }
+      if (p.host_kf < SEL_KF_WORDS * 64) atomicOr(&s_used[p.host_kf >> 6], 1ull << (p.host_kf & 63));
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  const int n = carry < feat_cap ? carry : feat_cap;
+  // compact keyframe index = rank of the keyframe among the used ones, in map order
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < SEL_KF_WORDS; w++) { s_base[w] = t; t += __popcll(s_used[w]); }
+    n_poses_out[c] = t;
+    jobs[c].n_feats = n; jobs[c].n_poses = t < HSO_POSE_MAX_POSES ? t : HSO_POSE_MAX_POSES; n_feats[c] = n;
+  }
+  __syncthreads();
+  hso_se3* PO = poses_out + (size_t)c * HSO_POSE_MAX_POSES;
+  for (int k = threadIdx.x; k < S.n_kfs && k < SEL_KF_WORDS * 64; k += SEL_THREADS) {
+    const unsigned long long word = s_used[k >> 6], bit = 1ull << (k & 63);
+    if (!(word & bit)) continue;
+    const int idx = s_base[k >> 6] + __popcll(word & (bit - 1));
+    if (idx < HSO_POSE_MAX_POSES) PO[idx] = S.kf_poses[k];
+  }
+  for (int i = threadIdx.x; i < n; i += SEL_THREADS) {
+    const int k = F[i].host_pose;
+    int idx = HSO_POSE_MAX_POSES;
+    if (k < SEL_KF_WORDS * 64) { const unsigned long long word = s_used[k >> 6], bit = 1ull << (k & 63); idx = s_base[k >> 6] + __popcll(word & (bit - 1)); }
+    if (idx < HSO_POSE_MAX_POSES) F[i].host_pose = idx;
+    else { F[i].has_point = 0; F[i].host_pose = 0; }     // more host keyframes than the optimiser's table holds: the feature sits out
+  }
+}
+
+__global__ void k_projected_flags(const hso_reproj_point* proj, int n, uint8_t* out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = proj[i].projected ? 1 : 0;
+}
+
+extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_frame* frames, int n_calls, int cell_size,
+                                                    int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
+                                                    int out_capacity, int32_t* begin_out, int32_t* counts_out, uint8_t* projected_out,
+                                                    const hso_pose_chain* pose)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_calls < 0 || n_cells <= 0 || !cell_order || max_fts < 0 || (n_calls > 0 && (!frames || !begin_out || !counts_out)) || !pose)
+    return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: bad argument");
+  if (n_calls > 0 && (!pose->results || pose->n_iter < 0)) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: bad pose argument");
+  if (max_fts > HSO_POSE_MAX_FEATS) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: max_fts above the pose optimiser's table size (4096)");
+  {
+    std::vector<uint8_t> seen(n_cells, 0);
+    for (int k = 0; k < n_cells; k++) {
+      if (cell_order[k] < 0 || cell_order[k] >= n_cells || seen[cell_order[k]]) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: cell_order is not a permutation");
+      seen[cell_order[k]] = 1;
+    }
+  }
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  size_t n_total = 0;
+  for (int c = 0; c < n_calls; c++) { if (frames[c].n_points < 0) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: negative list length"); n_total += (size_t)frames[c].n_points; }
+  for (int c = 0; c <= n_calls; c++) begin_out[c] = 0;
+  for (int c = 0; c < 4 * n_calls; c++) counts_out[c] = 0;
+  for (int c = 0; c < n_calls; c++) {
+    memset(&pose->results[c], 0, sizeof(hso_pose_result));
+    pose->results[c].status = 1; pose->results[c].T_f_w = frames[c].T_cur_w;
+    if (pose->n_feats) pose->n_feats[c] = 0;
+  }
+  if (n_total == 0) return 0;
+  const int feat_cap = std::max(max_fts, 1);
+  const size_t per_frame = al(sizeof(int32_t) * (size_t)(n_cells + 1)) + 4 * al(sizeof(int32_t) * (size_t)n_cells) + al(sizeof(int32_t) * 3 * (size_t)n_cells) +
+                           al(sizeof(int32_t) * (size_t)std::max(n_cells, max_fts + 50));
+  size_t o = 0;
+  const size_t o_begin = o; o += al(sizeof(int) * (size_t)(n_calls + 1));
+  const size_t o_order = o; o += al(sizeof(int32_t) * (size_t)n_cells);
+  const size_t o_frames = o; o += al(sizeof(SelFrame) * (size_t)n_calls);
+  const size_t in_bytes = o;
+  const size_t o_cell = o; o += al(sizeof(int32_t) * n_total);
+  const size_t o_q = o; o += al(n_total);
+  const size_t o_f = o; o += al(n_total);
+  const size_t o_pt = o; o += al(sizeof(int32_t) * n_total);
+  const size_t o_ncand = o; o += al(sizeof(int) * (size_t)n_calls);
+  const size_t o_list = o; o += al(sizeof(int32_t) * n_total);
+  const size_t o_exam = o; o += al(sizeof(int32_t) * n_total);
+  const size_t o_counts = o; o += al(sizeof(int32_t) * 4 * (size_t)n_calls);
+  const size_t o_offs = o; o += al(sizeof(int) * (size_t)(n_calls + 1));
+  const size_t o_out = o; o += al(sizeof(hso_match_brief) * n_total);
+  const size_t o_flag = o; o += al(n_total);
+  const size_t o_scr = o; o += per_frame * (size_t)n_calls;
+  const size_t o_pf = o; o += al(sizeof(hso_pose_feat) * (size_t)n_calls * feat_cap);
+  const size_t o_pj = o; o += al(sizeof(PoseJobDev) * (size_t)n_calls);
+  const size_t o_ps = o; o += al(sizeof(PoseSrcDev) * (size_t)n_calls);
+  const size_t o_pp = o; o += al(sizeof(hso_se3) * (size_t)n_calls * HSO_POSE_MAX_POSES);
+  const size_t o_pnp = o; o += al(sizeof(int) * (size_t)n_calls);
+  const size_t o_pr = o; o += al(sizeof(hso_pose_result) * (size_t)n_calls);
+  const size_t o_pk = o; o += al((size_t)n_calls * feat_cap);
+  const size_t o_pn = o; o += al(sizeof(int) * (size_t)n_calls);
+  const size_t o_ff = o; o += al(sizeof(double) * 3 * (size_t)n_calls * feat_cap);
+  const size_t o_kp_fixed = o;   // every frame's keyframe poses follow; their number is known after the run below
+  HsoMapsRun R; HsoFramesAux X;
+  // the keyframe pose tables: sized by the maps' keyframe counts (a few dozen rows per frame); reserve generously, checked below
+  size_t kf_rows = 0;
+  {
+    int nk = 0, np = 0, no = 0;
+    for (int c = 0; c < n_calls; c++) { if (hso_gpu_seqmap_size(ctx, frames[c].map, &nk, &np, &no) < 0) return HSO_E_INVALID; kf_rows += (size_t)nk; }
+  }
+  o += al(sizeof(hso_se3) * std::max(kf_rows, (size_t)1));
+  const int total = hso_reproject_frames_run(ctx, cam, frames, n_calls, cell_size, grid_n_cols, o, &R, &X);
+  if (total < 0) return total;
+  char* d = R.d_extra;
+  char* h = hso_pinned(ctx, 1, std::max(in_bytes, sizeof(int32_t) * (5 * (size_t)n_calls + 2)));   // slot 0 holds hso_reproject_frames_run's upload
+  if (!h) return HSO_E_NOMEM;
+  int* hb = reinterpret_cast<int*>(h + o_begin);
+  for (int c = 0; c <= n_calls; c++) hb[c] = R.begin[c];
+  memcpy(h + o_order, cell_order, sizeof(int32_t) * (size_t)n_cells);
+  SelFrame* hf = reinterpret_cast<SelFrame*>(h + o_frames);
+  for (int c = 0; c < n_calls; c++) {
+    char* sc = d + o_scr + per_frame * (size_t)c;
+    SelFrame& F = hf[c];
+    F.first = R.begin[c]; F.n = 0; F.n_dev = reinterpret_cast<const int*>(d + o_ncand) + c;
+    F.cnt = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)(n_cells + 1));
+    F.fill = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)n_cells);
+    F.e1 = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)n_cells);
+    F.e2 = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)n_cells);
+    F.a3 = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * (size_t)n_cells);
+    F.p3 = reinterpret_cast<int*>(sc); sc += al(sizeof(int32_t) * 3 * (size_t)n_cells);
+    F.scan = reinterpret_cast<int*>(sc);
+    F.list = reinterpret_cast<int*>(d + o_list) + F.first;
+    F.out = reinterpret_cast<int*>(d + o_exam) + F.first;
+    F.counts = reinterpret_cast<int*>(d + o_counts) + 4 * c;
+  }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int* d_begin = reinterpret_cast<const int*>(d + o_begin);
+  hipLaunchKernelGGL(k_sel_gather, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_proj, R.d_brief, d_begin,
+                     reinterpret_cast<int32_t*>(d + o_cell), reinterpret_cast<uint8_t*>(d + o_q), reinterpret_cast<uint8_t*>(d + o_f),
+                     reinterpret_cast<int32_t*>(d + o_pt), reinterpret_cast<int*>(d + o_ncand));
+  SelArgs A;
+  A.cell = reinterpret_cast<const int32_t*>(d + o_cell); A.quality = reinterpret_cast<const uint8_t*>(d + o_q);
+  A.flags = reinterpret_cast<const uint8_t*>(d + o_f); A.cell_order = reinterpret_cast<const int32_t*>(d + o_order);
+  A.n_cells = n_cells; A.max_fts = max_fts;
+  hipLaunchKernelGGL(k_select, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, A, reinterpret_cast<const SelFrame*>(d + o_frames));
+  hipLaunchKernelGGL(k_sel_offsets, dim3(1), dim3(64), 0, ctx->stream, n_calls, reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<int*>(d + o_offs));
+  hipLaunchKernelGGL(k_sel_emit, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_brief, d_begin, reinterpret_cast<const int32_t*>(d + o_exam),
+                     reinterpret_cast<const int32_t*>(d + o_pt), reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<const int*>(d + o_offs),
+                     reinterpret_cast<hso_match_brief*>(d + o_out));
+  if (projected_out) hipLaunchKernelGGL(k_projected_flags, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, R.d_proj, total, reinterpret_cast<uint8_t*>(d + o_flag));
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  {
+    // job records + per-frame sources + the frames' keyframe poses: one staging image (slot 0 is free again once the run's upload has
+    // left it: synchronise first)
+    const size_t b_pj = al(sizeof(PoseJobDev) * (size_t)n_calls), b_ps = al(sizeof(PoseSrcDev) * (size_t)n_calls);
+    const size_t b_kp = al(sizeof(hso_se3) * std::max(X.kf_poses.size(), (size_t)1));
+    if (X.kf_poses.size() > kf_rows) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: keyframe tables changed during the call");
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    char* hp = hso_pinned(ctx, 0, b_pj + b_ps + b_kp);
+    if (!hp) return HSO_E_NOMEM;
+    PoseJobDev* pj = reinterpret_cast<PoseJobDev*>(hp);
+    PoseSrcDev* ps = reinterpret_cast<PoseSrcDev*>(hp + b_pj);
+    if (!X.kf_poses.empty()) memcpy(hp + b_pj + b_ps, X.kf_poses.data(), sizeof(hso_se3) * X.kf_poses.size());
+    const hso_se3* d_kp = reinterpret_cast<const hso_se3*>(d + o_kp_fixed);
+    for (int c = 0; c < n_calls; c++) {
+      pj[c].feats = reinterpret_cast<const hso_pose_feat*>(d + o_pf) + (size_t)c * feat_cap;
+      pj[c].poses = reinterpret_cast<const hso_se3*>(d + o_pp) + (size_t)c * HSO_POSE_MAX_POSES;
+      pj[c].mask = reinterpret_cast<uint8_t*>(d + o_pk) + (size_t)c * feat_cap;
+      pj[c].n_feats = 0; pj[c].n_poses = 0; pj[c].T = frames[c].T_cur_w; pj[c].reproj_thresh = pose->reproj_thresh;
+      pj[c].n_iter = pose->n_iter; pj[c]._pad = 0;
+      ps[c].pts = X.pts[c]; ps[c].kf_poses = d_kp + X.kf_begin[c]; ps[c].list_begin = R.begin[c]; ps[c].n_kfs = X.kf_begin[c + 1] - X.kf_begin[c];
+    }
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pj, hp, b_pj, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_ps, hp + b_pj, b_ps, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_kp_fixed, hp + b_pj + b_ps, b_kp, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_pk, 0, (size_t)n_calls * feat_cap, ctx->stream));
+    hipLaunchKernelGGL(k_pose_feats_from_list, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, *cam, reinterpret_cast<const hso_match_brief*>(d + o_out),
+                       reinterpret_cast<const int*>(d + o_offs), reinterpret_cast<const PoseSrcDev*>(d + o_ps), X.d_ids, X.d_quality, feat_cap,
+                       reinterpret_cast<hso_pose_feat*>(d + o_pf), reinterpret_cast<PoseJobDev*>(d + o_pj), reinterpret_cast<hso_se3*>(d + o_pp),
+                       reinterpret_cast<int*>(d + o_pnp), pose->feat_f ? reinterpret_cast<double*>(d + o_ff) : nullptr, reinterpret_cast<int*>(d + o_pn));
+    if (int rc = hso_pose_launch_device(ctx, cam, reinterpret_cast<const PoseJobDev*>(d + o_pj), n_calls, feat_cap,
+                                        reinterpret_cast<hso_pose_result*>(d + o_pr))) return rc;
+  }
+  // read-back: counts + offsets + pose results + feature counts first; then exactly the examined records and the used rows
+  hso_pose_result* const h_res = pose->results;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, d + o_counts, sizeof(int32_t) * 4 * (size_t)n_calls, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(begin_out, d + o_offs, sizeof(int) * (size_t)(n_calls + 1), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_res, d + o_pr, sizeof(hso_pose_result) * (size_t)n_calls, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int> nf((size_t)n_calls, 0);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(pose->n_feats ? pose->n_feats : nf.data(), d + o_pn, sizeof(int) * (size_t)n_calls, hipMemcpyDeviceToHost, ctx->stream));
+  if (pose->outlier_mask) HSO_HIP_CHECK(ctx, hipMemcpyAsync(pose->outlier_mask, d + o_pk, (size_t)n_calls * feat_cap, hipMemcpyDeviceToHost, ctx->stream));
+  if (pose->feat_f) HSO_HIP_CHECK(ctx, hipMemcpyAsync(pose->feat_f, d + o_ff, sizeof(double) * 3 * (size_t)n_calls * feat_cap, hipMemcpyDeviceToHost, ctx->stream));
+  if (projected_out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(projected_out, d + o_flag, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int n_out = begin_out[n_calls];
+  if (n_out > 0) {
+    if (!out || out_capacity < n_out) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: output smaller than the examined candidates");
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d + o_out, sizeof(hso_match_brief) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  hso_seqmaps_debug_set(ctx, HSO_DBG_PROJ, R.d_proj, sizeof(hso_reproj_point) * (size_t)total);
+  hso_seqmaps_debug_set(ctx, HSO_DBG_MATCH, X.d_match, sizeof(hso_align_out) * (size_t)total);
+  hso_seqmaps_debug_set(ctx, HSO_DBG_POSE_FEATS, d + o_pf, sizeof(hso_pose_feat) * (size_t)n_calls * feat_cap);
+  hso_seqmaps_debug_set(ctx, HSO_DBG_POSE_POSES, d + o_pp, sizeof(hso_se3) * (size_t)n_calls * HSO_POSE_MAX_POSES);
+  hso_seqmaps_debug_set(ctx, HSO_DBG_POSE_NPOSES, d + o_pnp, sizeof(int) * (size_t)n_calls);
+  return n_out;
+}

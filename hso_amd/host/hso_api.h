@@ -9,7 +9,7 @@ namespace api {
 
 inline void frame_upload(hso_gpu_ctx* ctx, int64_t id, const uint8_t* img, int w, int h, hso_frame_stats* st)
 {
-  check(ctx, router() ? router()->frame_upload(id, img, w, h, st) : hso_gpu_frame_upload(ctx, id, img, w, h, 0, st), "Frame");
+  check(ctx, hso_gpu_frame_upload(ctx, id, img, w, h, 0, st), "Frame");
   Trace& t = trace();
   if (t.on()) {
     t.begin("frame_upload", 5);
@@ -20,7 +20,7 @@ inline void frame_upload(hso_gpu_ctx* ctx, int64_t id, const uint8_t* img, int w
 
 inline void coarse_track(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* p, const hso_track_job* job, hso_track_result* res)
 {
-  check(ctx, router() ? router()->coarse_track(cam, p, job, res) : hso_gpu_coarse_track_batch(ctx, cam, p, job, 1, res), "CoarseTracker");
+  check(ctx, hso_gpu_coarse_track_batch(ctx, cam, p, job, 1, res), "CoarseTracker");
   Trace& t = trace();
   if (t.on()) {
     t.begin("coarse_track", 8);
@@ -36,9 +36,7 @@ inline void reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur
                             int cur_kf_id, const hso_kf* kfs, int n_kfs, const hso_map_point* pts, int n_pts, const hso_obs* obs,
                             int n_obs, int cell_size, int grid_n_cols, hso_reproj_point* proj, hso_align_out* match)
 {
-  check(ctx, router() ? router()->reproject_match(cam, cur_id, T_cur_w, cur_exposure, cur_kf_id, kfs, n_kfs, pts, n_pts, obs, n_obs, cell_size, grid_n_cols,
-                                                  proj, match)
-                      : hso_gpu_reproject_match(ctx, cam, cur_id, T_cur_w, cur_exposure, cur_kf_id, kfs, n_kfs, pts, n_pts, obs, n_obs, cell_size,
+  check(ctx, hso_gpu_reproject_match(ctx, cam, cur_id, T_cur_w, cur_exposure, cur_kf_id, kfs, n_kfs, pts, n_pts, obs, n_obs, cell_size,
                                                 grid_n_cols, proj, match), "Reprojector");
   Trace& t = trace();
   if (t.on()) {
@@ -54,7 +52,7 @@ inline void reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur
 inline void pose_optimize(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_pose_job* job, hso_pose_result* res, uint8_t* mask)
 {
   uint8_t* mp = mask;
-  check(ctx, router() ? router()->pose_optimize(cam, job, res, mask) : hso_gpu_pose_optimize_batch(ctx, cam, job, 1, res, &mp), "pose_optimizer");
+  check(ctx, hso_gpu_pose_optimize_batch(ctx, cam, job, 1, res, &mp), "pose_optimizer");
   Trace& t = trace();
   if (t.on()) {
     t.begin("pose_optimize", 8);
@@ -68,7 +66,7 @@ inline void pose_optimize(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_pos
 inline void klt_track(hso_gpu_ctx* ctx, int64_t prev_id, int64_t cur_id, const float* px_prev, const float* px_init, int n,
                       const hso_klt_params* params, hso_klt_result* out)
 {
-  check(ctx, routed([&]() { return hso_gpu_klt_track(ctx, prev_id, cur_id, px_prev, px_init, n, params, out); }), "trackKlt");
+  check(ctx, hso_gpu_klt_track(ctx, prev_id, cur_id, px_prev, px_init, n, params, out), "trackKlt");
   Trace& t = trace();
   if (t.on()) {
     t.begin("klt_track", 6);
@@ -81,9 +79,8 @@ inline void klt_track(hso_gpu_ctx* ctx, int64_t prev_id, int64_t cur_id, const f
 inline void detect_candidates(hso_gpu_ctx* ctx, bool init, int64_t id, int n_levels, int min_thresh, hso_corner* co, int corner_cap,
                               int32_t* nc, hso_edgelet* ed, hso_corner* fill, int second_cap, int32_t* n_second)
 {
-  const int rc = routed([&]() {
-    return init ? hso_gpu_detect_candidates_init(ctx, &id, 1, n_levels, min_thresh, co, corner_cap, nc, fill, second_cap, n_second)
-                : hso_gpu_detect_candidates(ctx, &id, 1, n_levels, min_thresh, co, corner_cap, nc, ed, second_cap, n_second); });
+  const int rc = init ? hso_gpu_detect_candidates_init(ctx, &id, 1, n_levels, min_thresh, co, corner_cap, nc, fill, second_cap, n_second)
+                      : hso_gpu_detect_candidates(ctx, &id, 1, n_levels, min_thresh, co, corner_cap, nc, ed, second_cap, n_second);
   check(ctx, rc, "FeatureExtractor");
 }
 
@@ -129,8 +126,7 @@ inline int select_octree(const hso_keypoint* keys, int n, int w, int h, int n_fe
 inline void seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_id, const hso_se3* T, double exposure, double px_error_angle,
                          const hso_seed* seeds, int n, hso_seed_out* out)
 {
-  check(ctx, router() ? router()->seed_observe(cam, cur_id, T, exposure, px_error_angle, seeds, n, out)
-                      : hso_gpu_seed_observe(ctx, cam, cur_id, T, exposure, px_error_angle, seeds, n, out), "DepthFilter");
+  check(ctx, hso_gpu_seed_observe(ctx, cam, cur_id, T, exposure, px_error_angle, seeds, n, out), "DepthFilter");
   Trace& t = trace();
   if (t.on()) {
     t.begin("seed_observe", 7);
@@ -143,8 +139,7 @@ inline void seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_id
 inline void seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n, const int32_t* begin,
                           const hso_activate_target* targets, int n_mean, hso_activate_out* out)
 {
-  check(ctx, router() ? router()->seed_activate(cam, seeds, n, begin, targets, n_mean, out)
-                      : hso_gpu_seed_activate(ctx, cam, seeds, n, begin, targets, n_mean, out, nullptr), "DepthFilter::activatePoint");
+  check(ctx, hso_gpu_seed_activate(ctx, cam, seeds, n, begin, targets, n_mean, out, nullptr), "DepthFilter::activatePoint");
   Trace& t = trace();
   if (t.on()) {
     t.begin("seed_activate", 6);
@@ -158,7 +153,7 @@ inline void seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_see
 inline void seed_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_t cur_id, const hso_se3* T, double exposure,
                                  const hso_seed* seeds, int n, int cell_size, int grid_n_cols, hso_reproj_point* proj, hso_align_out* match)
 {
-  check(ctx, routed([&]() { return hso_gpu_seed_reproject_match(ctx, cam, cur_id, T, exposure, seeds, n, cell_size, grid_n_cols, proj, match); }),
+  check(ctx, hso_gpu_seed_reproject_match(ctx, cam, cur_id, T, exposure, seeds, n, cell_size, grid_n_cols, proj, match),
         "Reprojector (seeds)");
   Trace& t = trace();
   if (t.on()) {
@@ -173,7 +168,7 @@ inline void seed_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, int64_
 inline void ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses, int n_poses, const double* idist, int n_points, const hso_ba_edge* edges,
                             const double* obs_uv, int n_edges, double err_mult2, float* hc, float* he)
 {
-  check(ctx, routed([&]() { return hso_gpu_ba_huber_deltas(ctx, poses, n_poses, idist, n_points, edges, obs_uv, n_edges, err_mult2, hc, he); }),
+  check(ctx, hso_gpu_ba_huber_deltas(ctx, poses, n_poses, idist, n_points, edges, obs_uv, n_edges, err_mult2, hc, he),
         "LocalBundleAdjustment");
   Trace& t = trace();
   if (t.on()) {
@@ -190,8 +185,7 @@ inline void ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses, const uint8_t* fixed, 
   Trace& t = trace();
   std::vector<hso_se3> p0; std::vector<double> i0;
   if (t.on()) { p0.assign(poses, poses + n_poses); i0.assign(idist, idist + n_points); }
-  check(ctx, router() ? router()->ba_optimize(poses, fixed, n_poses, idist, n_points, edges, n_edges, hc, he, n_iter, chi2, res)
-                      : hso_gpu_ba_optimize(ctx, poses, fixed, n_poses, idist, n_points, edges, n_edges, hc, he, n_iter, chi2, res), "LocalBundleAdjustment");
+  check(ctx, hso_gpu_ba_optimize(ctx, poses, fixed, n_poses, idist, n_points, edges, n_edges, hc, he, n_iter, chi2, res), "LocalBundleAdjustment");
   if (t.on()) {
     t.begin("ba_optimize", 11);
     t.field("poses_in", p0.data(), sizeof(hso_se3) * (size_t)n_poses); t.field("fixed", fixed, (size_t)n_poses);

@@ -1,0 +1,122 @@
+// hso_engine.cpp — the sequence engine (see hso_engine.h): per-sequence tables, the phases of a step, the keyframe work.
+#include "hso_engine_impl.h"
+
+namespace hso {
+namespace engine {
+
+// ------------------------------------------------------------------------------------------------ trace
+bool Trace::open(const char* path) { close(); f = std::fopen(path, "wb"); return f != nullptr; }
+void Trace::close() { if (f) std::fclose(f); f = nullptr; }
+void Trace::begin(const char* name, uint32_t nf)
+{
+  const uint32_t magic = 0x52545348u, nl = (uint32_t)std::strlen(name);
+  std::fwrite(&magic, 4, 1, f); std::fwrite(&nl, 4, 1, f); std::fwrite(name, 1, nl, f); std::fwrite(&nf, 4, 1, f);
+}
+void Trace::field(const char* key, const void* data, size_t bytes)
+{
+  const uint32_t kl = (uint32_t)std::strlen(key); const uint64_t nb = bytes;
+  std::fwrite(&kl, 4, 1, f); std::fwrite(key, 1, kl, f); std::fwrite(&nb, 8, 1, f);
+  if (bytes) std::fwrite(data, 1, bytes, f);
+}
+
+// ------------------------------------------------------------------------------------------------ bank
+Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Settings& cfg, int n_sequences)
+    : ctx_(ctx), owns_ctx_(owns_ctx), cam_(cam), cfg_(cfg)
+{
+  // Reprojector::initializeGrid (src/reprojector.cpp:53-75); the cell order the reference shuffles is the identity here
+  cell_size_ = (int)floorf(std::sqrt((float)(cam.width * cam.height) / cfg.max_fts) * 0.6);
+  grid_cols_ = (int)std::ceil((double)cam.width / cell_size_);
+  grid_rows_ = (int)std::ceil((double)cam.height / cell_size_);
+  cell_order_.resize((size_t)grid_cols_ * grid_rows_);
+  std::iota(cell_order_.begin(), cell_order_.end(), 0);
+  for (int k = 0; k < n_sequences; k++) {
+    Seq* s = new Seq();
+    s->index = k; s->cam = &cam_; s->cfg = &cfg_;
+    seq_.push_back(s);
+    step_.push_back(new StepData());
+    check(hso_gpu_seqmap_create(ctx_, &s->map), "seqmap_create");
+  }
+  check(hso_gpu_seed_table_create(ctx_, &seed_table_), "seed_table_create");
+  int n_threads = 0;
+  if (n_sequences > 1) {
+    const unsigned hc = std::thread::hardware_concurrency();
+    n_threads = (int)std::min<unsigned>(hc > 2 ? hc - 2 : 0, std::min(n_sequences - 1, 31));
+    if (const char* e = getenv("HSO_ENGINE_THREADS")) n_threads = std::max(0, atoi(e));
+  }
+  pool_ = new Pool(n_threads);
+}
+
+Bank::~Bank()
+{
+  delete pool_;
+  for (Seq* s : seq_) {
+    for (Frame& F : s->frames) if (F.in_use && F.dev_id >= 0) (void)hso_gpu_frame_release(ctx_, F.dev_id);
+    delete s;
+  }
+  for (StepData* d : step_) delete d;
+  if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);
+  for (size_t k = 0; k < seq_.size(); k++) (void)k;
+  if (owns_ctx_) hso_gpu_destroy(ctx_);
+}
+
+void Bank::check(int rc, const char* what)
+{
+  if (rc < 0) throw DeviceFault(std::string(what) + ": " + hso_gpu_last_error(ctx_));
+}
+
+void Bank::par(const std::vector<int>& who, const std::function<void(int)>& fn)
+{
+  pool_->run((int)who.size(), [&](int i) { fn(who[i]); });
+}
+
+bool Bank::trace(int k, const char* path)
+{
+  if (k < 0 || k >= size()) return false;
+  if (!path) { seq_[k]->trace.close(); return true; }
+  return seq_[k]->trace.open(path);
+}
+
+void Bank::call_counts(int64_t* calls, int64_t* items, int cap) const
+{
+  for (int i = 0; i < cap && i < 10; i++) { if (calls) calls[i] = n_calls_[i]; if (items) items[i] = n_items_[i]; }
+}
+
+void Bank::status(int k, hso_vo_status* st) const
+{
+  const Seq& s = *seq_[k];
+  *st = s.log;
+  st->stage = s.stage; st->tracking_quality = s.quality; st->result = s.outcome;
+  st->n_keyframes = (int)s.kfs.size();
+  if (s.last != kNone) {
+    const Frame& F = s.frames[s.last];
+    st->T_f_w = F.T.v; st->timestamp = F.stamp; st->exposure_time = F.exposure;
+    st->frame_id = F.serial; st->keyframe_id = F.kf_id; st->is_keyframe = F.kf_row >= 0 ? 1 : 0;
+    st->n_features = (int)s.n_feats(F); st->n_inliers = F.n_inliers;
+  }
+}
+
+int Bank::keyframes(int k, double* stamps, hso_se3* T_f_w, int32_t* frame_ids, int cap) const
+{
+  const Seq& s = *seq_[k];
+  int n = 0;
+  for (Id kf : s.kfs) {
+    if (n < cap) {
+      const Frame& F = s.frames[kf];
+      if (stamps) stamps[n] = F.stamp;
+      if (T_f_w) T_f_w[n] = F.T.v;
+      if (frame_ids) frame_ids[n] = F.serial;
+    }
+    ++n;
+  }
+  return n;
+}
+
+void Bank::release_frame(Seq& s, Id fr)
+{
+  if (fr == kNone) return;
+  const int64_t dev = s.frames[fr].dev_id;
+  if (s.drop(fr)) to_release_.push_back(dev);
+}
+
+}  // namespace engine
+}  // namespace hso

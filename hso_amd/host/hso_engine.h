@@ -1,0 +1,203 @@
+// hso_engine.h — the sequence engine of libhso_host.so: N independent visual-odometry sequences over one device context.
+//
+// State is tables with integer links (frames, keyframe features = observation rows, points, seeds), the shapes the device
+// library keeps resident (include/hso_gpu.h: hso_gpu_seqmap_*, hso_gpu_seed_table_*).  A step of the engine takes one image per
+// sequence and runs every numeric stage ONCE for all sequences:
+//
+//     frame upload (batch)  ->  CoarseTracker (batch)  ->  reprojection + matching + grid selection + pose optimisation
+//     (hso_gpu_reproject_select_pose_frames)  ->  [sequences that take a keyframe: local BA (multi)]  ->  seed observation in the
+//     resident table  ->  seed activation (multi)  ->  [keyframes: detection (batch), oct-tree, new seeds]
+//
+// Between the device calls the sequences' bookkeeping runs in parallel on a small thread pool (it touches nothing but the
+// sequence's own tables), and only the main thread talks to the device.  What the bookkeeping decides — which keyframes a frame
+// projects and in which order, the quality keys, when a keyframe is taken, which keyframes form the local BA window, what
+// happens to seeds, candidates and temporary points — reproduces the reference's decisions (its call order
+// and argument values are the drop-in contract): FrameHandlerMono::processFrame (src/frame_handler_mono.cpp:173-355), needNewKf
+// (:428-507), createCovisibilityGraph (:559-647), Reprojector::reprojectMap (src/reprojector.cpp:88-331), DepthFilter::updateSeeds
+// (src/depth_filter.cpp:330-509), ba::LocalBundleAdjustment (src/bundle_adjustment.cpp:556-897), Map / MapPointCandidates
+// (src/map.cpp).  The schedule of the reference's depth-filter thread is the synchronous one (its thread keeping up): a frame's
+// seed update runs before the next frame is tracked.
+#pragma once
+#include <array>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/hso_vo.h"
+#include "hso_math.h"
+
+namespace hso {
+namespace engine {
+
+using Id = int32_t;
+constexpr Id kNone = -1;
+
+// Point::PointType / Point::FeatureType (include/hso/point.h:53-54): the numeric values order the grid selection
+enum : int8_t { kPtDeleted = 0, kPtTemporary = 1, kPtCandidate = 2, kPtUnknown = 3, kPtGood = 4 };
+enum : int8_t { kOnGradient = 0, kOnEdgelet = 1, kOnCorner = 2 };
+
+struct Settings {                 // src/config.cpp:28-64 and the Options structs the path reads
+  int max_fts = 200;
+  int n_pyr_levels = 3, core_n_kfs = 7, grid_size = 36, klt_max_level = 4, klt_min_level = 0;
+  double poseoptim_thresh = 2.0;
+  int loba_num_iter = 10, quality_min_fts = 5, quality_max_drop_fts = 40;
+  int reproject_max_kfs = 10;     // Reprojector::Options::max_n_kfs
+  float reproject_seed_thresh = 86;
+  int seed_max_kfs = 3;           // DepthFilter::Options::max_n_kfs
+  double map_scale = 1.0, init_min_disparity = 40.0;
+  int init_min_tracked = 50, init_min_inliers = 40;
+};
+
+struct Feat {                     // a feature; rows of Seq::feats are also the device's observation rows
+  double px[2] = {0, 0}, f[3] = {0, 0, 1}, grad[2] = {1, 0};
+  Id frame = kNone, point = kNone;
+  Id next = kNone;                // the next (older) observation of `point` while `linked`
+  int8_t level = 0, type = 0;     // HSO_FTR_*
+  bool linked = false;
+};
+
+struct Point {
+  double pos[3] = {0, 0, 0}, idist = 1;
+  Id host = kNone;                // host feature (row of Seq::feats)
+  Id head = kNone;                // newest observation
+  int32_t n_obs = 0;
+  int8_t kind = kPtUnknown, on = kOnCorner;
+  int32_t n_fail = 0, n_ok = 0, stamp = -1, n_ba = 0;
+  int8_t seed_state = 0;          // temporary points: 0 the seed lives, 1 it converged, -1 it was dropped
+  bool bad = false;
+};
+
+struct Frame {
+  int64_t dev_id = -1;            // id of the resident frame
+  int32_t serial = -1;            // Frame::id_ within the sequence
+  int32_t kf_id = 0;              // Frame::keyFrameId_
+  int32_t kf_row = -1;            // row in the keyframe table once a keyframe
+  double stamp = 0;
+  SE3 T;                          // T_f_w_
+  float integral = 0, grad_mean = 0;
+  double exposure = -1;
+  double cov[36] = {0};
+  float err_px = 0;
+  int32_t n_inliers = 0;
+  int32_t refs = 0;               // holders: the handler's last / current frame, the map, seeds' frame lists
+  bool in_use = false;
+  std::vector<Feat> loose;        // a frame that is not a keyframe owns its features
+  std::vector<Id> fts;            // a keyframe lists rows of Seq::feats (Frame::fts_ order)
+  std::array<Id, 5> key{{kNone, kNone, kNone, kNone, kNone}};   // Frame::key_pts_
+  std::vector<Id> covis;          // connectedKeyFrames (frame slots)
+  int32_t visited = -1;           // lastReprojectFrameId_
+};
+
+struct Seed {
+  Id feat = kNone;                // host feature
+  int32_t batch = 0, slot = -1;   // Seed::batch_id; slot in the resident table
+  float a = 10, b = 10, mu = 0, z_range = 0, sigma2 = 0, converge = 200;
+  bool alive = true, valid = true, updated = false, reprojected = false;
+  Id temp = kNone;                // the temporary point made of it
+  int32_t n_dist = 1;             // vec_distance.size()
+  std::vector<Id> seen;           // optFrames_A: frames it was visible in (<= 15)
+  std::vector<Id> before;         // pre_frames: the frames before its keyframe, newest first
+  std::vector<Id> seen_before;    // optFrames_P
+};
+
+class Pool;                       // the bookkeeping threads
+
+struct Trace {                    // device-call recorder (hso_trace.h format), one per sequence
+  FILE* f = nullptr;
+  ~Trace() { close(); }
+  bool open(const char* path);
+  void close();
+  bool on() const { return f != nullptr; }
+  void begin(const char* name, uint32_t n_fields);
+  void field(const char* key, const void* data, size_t bytes);
+  void scalar(const char* key, double v) { field(key, &v, 8); }
+};
+
+struct Seq;                       // one sequence's tables (hso_engine.cpp)
+struct StepData;                  // one sequence's scratch for the running step
+
+class Bank {
+public:
+  Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Settings& cfg, int n_sequences);
+  ~Bank();
+  Bank(const Bank&) = delete;
+  Bank& operator=(const Bank&) = delete;
+
+  int size() const { return (int)seq_.size(); }
+  // imgs[k] == nullptr: sequence k sits the step out
+  void set_first_frames(const uint8_t* const* imgs, int w, int h, const double* stamps, const float* const* depth_z, const hso_se3* T_f_w);
+  void start(const uint8_t* which);
+  void add_images(const uint8_t* const* imgs, int w, int h, const double* stamps);
+  void status(int k, hso_vo_status* st) const;
+  int keyframes(int k, double* stamps, hso_se3* T_f_w, int32_t* frame_ids, int cap) const;
+  bool trace(int k, const char* path);
+  void call_counts(int64_t* calls, int64_t* items, int cap) const;
+  std::string err;
+  bool poisoned = false;
+
+private:
+  friend struct Seq;
+  void step(const uint8_t* const* imgs, int w, int h, const double* stamps);
+  // phases of a step (device calls on the caller's thread; per-sequence work through par() / the pool)
+  void upload(const std::vector<int>& who, const uint8_t* const* imgs, int w, int h, const double* stamps);
+  void initialise(const std::vector<int>& who);
+  void track(const std::vector<int>& who);
+  void track_group(const std::vector<int>& who, const std::vector<Id>& ref, const std::vector<Id>& cur, const hso_track_params& p);
+  void reproject(const std::vector<int>& who);
+  void list_points(int k);
+  void apply_selection(int k, const hso_match_brief* rec, int n_rec, const uint8_t* projected, const double* feat_f);
+  void trace_reproject(const std::vector<int>& who, const std::vector<hso_map_frame>& calls, const std::vector<size_t>& list_at,
+                       const std::vector<int32_t>& begin, const std::vector<int32_t>& counts, const std::vector<hso_pose_result>& pose,
+                       const std::vector<int32_t>& n_feats);
+  void seed_branch(const std::vector<int>& who);
+  void decide(int k);
+  bool wants_keyframe(int k);
+  void link_covisible(int k, bool is_keyframe);
+  void promote(int k);
+  void make_keyframe(Seq& s, Id fr);
+  void assemble_window(int k);
+  void keyframe_ba(const std::vector<int>& who);
+  void apply_window(int k);
+  void observe_seeds(const std::vector<int>& who);
+  void activate_seeds(const std::vector<int>& who);
+  void start_seeds(const std::vector<int>& who);
+  void kill_seed(Seq& s, StepData& d, int i, bool keep_feature);
+  void erase_slots(const std::vector<int>& who);
+  void drop_sequence_seeds(int k);
+  void flush_maps(const std::vector<int>& who);
+  void finish(const std::vector<int>& who);
+  void par(const std::vector<int>& who, const std::function<void(int)>& fn);
+  void check(int rc, const char* what);
+  void release_frame(Seq& s, Id fr);
+  void release_frame_deferred(Seq& s, StepData& d, Id fr);
+  void detect(const std::vector<int>& who, const std::vector<Id>& frame, const std::vector<int>& thresh, bool init, int n_levels, int n_features,
+              std::vector<std::vector<hso_keypoint>>& keys, std::vector<std::vector<hso_keypoint>>& sel);
+  Feat feature_from_key(const hso_keypoint& kp, Id fr) const;
+
+  hso_gpu_ctx* ctx_;
+  bool owns_ctx_;
+  AbstractCamera cam_;
+  Settings cfg_;
+  std::vector<Seq*> seq_;
+  std::vector<StepData*> step_;
+  Pool* pool_ = nullptr;
+  int seed_table_ = -1;
+  int cell_size_ = 0, grid_cols_ = 0, grid_rows_ = 0;
+  std::vector<int32_t> cell_order_;
+  double px_error_angle_ = -1;
+  int64_t n_calls_[10] = {0}, n_items_[10] = {0};
+  std::vector<int64_t> to_release_;
+  // result tables of the batched calls (kept between steps: no allocation per step)
+  std::vector<hso_match_brief> briefs_;
+  std::vector<uint8_t> projected_, mask_;
+  std::vector<double> feat_f_;
+  std::vector<hso_seed_brief> seed_brief_;
+  std::vector<float> seed_px_;
+};
+
+}  // namespace engine
+}  // namespace hso

@@ -1,0 +1,379 @@
+// hso_engine_impl.h — what the engine's translation units share: the per-sequence tables with their list / map operations,
+// the scratch a sequence carries through a step, the worker pool.
+#pragma once
+#include "hso_engine.h"
+#include <algorithm>
+#include <atomic>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+
+namespace hso {
+namespace engine {
+
+// ------------------------------------------------------------------------------------------------ small helpers
+
+struct DeviceFault : std::runtime_error { using std::runtime_error::runtime_error; };
+
+inline double len3(const double* a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+inline Vector3d along(const double* f, double s) { return {f[0] * s, f[1] * s, f[2] * s}; }
+
+// the element std::nth_element leaves at floor(n / 2) (vikit getMedian: the upper median); v is permuted
+template <typename T> inline T upper_median(std::vector<T>& v)
+{
+  auto mid = v.begin() + (std::ptrdiff_t)(v.size() / 2);
+  std::nth_element(v.begin(), mid, v.end());
+  return *mid;
+}
+
+inline uint8_t quality_key(const Point& p) { return (uint8_t)((p.kind << 4) | p.on); }
+inline int8_t point_face(int8_t feature_type) { return feature_type == HSO_FTR_EDGELET ? kOnEdgelet : feature_type == HSO_FTR_CORNER ? kOnCorner : kOnGradient; }
+
+
+// ------------------------------------------------------------------------------------------------ worker pool
+// parallel-for over the sequences of a phase; the caller takes part, so a pool of zero threads is the serial engine
+class Pool {
+public:
+  explicit Pool(int n_threads)
+  {
+    for (int i = 0; i < n_threads; i++) th_.emplace_back([this] { loop(); });
+  }
+  ~Pool()
+  {
+    { std::lock_guard<std::mutex> lk(m_); quit_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void run(int n, const std::function<void(int)>& fn)
+  {
+    if (n <= 0) return;
+    if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; n_ = n; next_ = 0; left_ = n; err_ = nullptr; ++gen_;
+    }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return left_ == 0; });
+    fn_ = nullptr;
+    if (err_) std::rethrow_exception(err_);
+  }
+private:
+  void drain()
+  {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_) return;
+      try { (*fn_)(i); }
+      catch (...) { std::lock_guard<std::mutex> lk(m_); if (!err_) err_ = std::current_exception(); }
+      std::lock_guard<std::mutex> lk(m_);
+      if (--left_ == 0) done_.notify_all();
+    }
+  }
+  void loop()
+  {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (quit_) return;
+      }
+      drain();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, left_ = 0;
+  uint64_t gen_ = 0;
+  bool quit_ = false;
+  std::exception_ptr err_;
+};
+
+// ------------------------------------------------------------------------------------------------ one sequence
+enum Stage { kPaused = 0, kFirst = 1, kSecond = 2, kRunning = 3, kRelocalising = 4 };
+enum Outcome { kNoKeyframe = 0, kKeyframe = 1, kFailure = 2 };
+enum Quality { kInsufficient = 0, kBad = 1, kGood = 2 };
+
+struct TwoView {                  // KltHomographyInit's state (src/initialization.cpp:39-223) as parallel arrays
+  Id ref = kNone, prev = kNone;   // frame slots: the first frame; the frame KLT continues from
+  std::vector<Vector2d> px_ref, px_cur;
+  std::vector<Vector3d> f_ref, f_cur;
+  std::vector<std::array<double, 3>> kind;   // gradient direction + feature type of the reference detection
+  void clear() { ref = prev = kNone; px_ref.clear(); px_cur.clear(); f_ref.clear(); f_cur.clear(); kind.clear(); }
+};
+
+struct Seq {
+  int index = 0, map = -1;
+  const AbstractCamera* cam = nullptr;
+  const Settings* cfg = nullptr;
+  std::vector<Frame> frames;
+  std::vector<Id> free_slots;
+  std::vector<Feat> feats;
+  std::vector<Point> points;
+  std::vector<Seed> seeds;
+  int n_dead_seeds = 0;
+  std::vector<Id> kfs;            // Map::keyframes_
+  std::vector<Id> dev_kfs;        // rows of the device keyframe table (promotion order)
+  std::vector<Id> candidates, temps;
+  std::vector<Id> dirty_pts, dirty_obs;
+  std::vector<uint8_t> pt_flag, obs_flag;
+  bool kfs_dirty = false;
+  // handler
+  int stage = kPaused, quality = kInsufficient, outcome = kNoKeyframe;
+  bool want_start = false, after_init = false;
+  Id last = kNone, cur = kNone, first = kNone;
+  SE3 motion;
+  int regular = 0, n_obs_last = 0;
+  int32_t n_frames = 0, n_kfs_made = 0, batch = 0;
+  std::vector<Id> local_map;
+  std::vector<int> converge_hist;
+  size_t n_mean_converge = 6;
+  std::vector<std::pair<int, std::vector<Id>>> prior;   // frame_prior_: (batch, frames newest first), the last few batches
+  float converge_thresh = 200;
+  double kf_depth_mean = 0, kf_depth_min = 0;
+  TwoView init;
+  std::vector<int> votes;         // scratch of the covisibility count
+  hso_vo_status log{};
+  Trace trace;
+
+  // ---- frames
+  Id new_frame()
+  {
+    Id fr;
+    if (!free_slots.empty()) { fr = free_slots.back(); free_slots.pop_back(); }
+    else { fr = (Id)frames.size(); frames.emplace_back(); }
+    Frame& F = frames[fr];
+    F = Frame();
+    F.in_use = true;
+    F.serial = n_frames++;
+    F.dev_id = ((int64_t)index << 32) | (int64_t)(uint32_t)F.serial;
+    return fr;
+  }
+  void hold(Id fr) { if (fr != kNone) frames[fr].refs++; }
+  // returns true when the frame may leave the device (the caller queues the release)
+  bool drop(Id fr)
+  {
+    if (fr == kNone) return false;
+    Frame& F = frames[fr];
+    if (--F.refs > 0 || F.kf_row >= 0) return false;
+    F.in_use = false;
+    F.loose.clear(); F.loose.shrink_to_fit();
+    F.fts.clear(); F.covis.clear();
+    free_slots.push_back(fr);
+    return true;
+  }
+  size_t n_feats(const Frame& F) const { return F.kf_row >= 0 ? F.fts.size() : F.loose.size(); }
+  Feat& feat_of(Frame& F, size_t i) { return F.kf_row >= 0 ? feats[F.fts[i]] : F.loose[i]; }
+  const Feat& feat_of(const Frame& F, size_t i) const { return F.kf_row >= 0 ? feats[F.fts[i]] : F.loose[i]; }
+  Vector3d centre(const Frame& F) const { return F.T.inverse().translation(); }
+
+  // ---- device mirror
+  void touch_point(Id p) { if ((size_t)p >= pt_flag.size()) pt_flag.resize(points.size() + 64, 0); if (!pt_flag[p]) { pt_flag[p] = 1; dirty_pts.push_back(p); } }
+  void touch_obs(Id f) { if ((size_t)f >= obs_flag.size()) obs_flag.resize(feats.size() + 64, 0); if (!obs_flag[f]) { obs_flag[f] = 1; dirty_obs.push_back(f); } }
+
+  // ---- observation lists (Point::obs_: push_front, erase)
+  void observe(Id p, Id f)        // Point::addFrameRef
+  {
+    Feat& o = feats[f];
+    Point& P = points[p];
+    o.next = P.head; o.linked = true;
+    P.head = f; P.n_obs++;
+    touch_obs(f); touch_point(p);
+  }
+  bool unobserve(Id p, Id frame)  // Point::deleteFrameRef: the first observation made in `frame`
+  {
+    Point& P = points[p];
+    Id prev = kNone;
+    for (Id o = P.head; o != kNone; prev = o, o = feats[o].next) {
+      if (feats[o].frame != frame) continue;
+      if (prev == kNone) P.head = feats[o].next; else { feats[prev].next = feats[o].next; touch_obs(prev); }
+      feats[o].next = kNone; feats[o].linked = false;
+      P.n_obs--;
+      touch_point(p);
+      return true;
+    }
+    return false;
+  }
+
+  // ---- Frame::key_pts_ (src/frame.cpp:121-192): the feature nearest the image centre and, per quadrant, the one farthest
+  // out (largest |dx * dy|); an occupied place changes hands only for a strictly better feature
+  void offer_key(Frame& F, Id f)
+  {
+    const int cu = cam->width() / 2, cv = cam->height() / 2;
+    const Feat& n = feats[f];
+    const double dx = n.px[0] - cu, dy = n.px[1] - cv;
+    auto cheb = [&](Id g) { return std::max(std::fabs(feats[g].px[0] - cu), std::fabs(feats[g].px[1] - cv)); };
+    if (F.key[0] == kNone || std::max(std::fabs(dx), std::fabs(dy)) < cheb(F.key[0])) F.key[0] = f;
+    const int quadrant = n.px[0] >= cu ? (n.px[1] >= cv ? 1 : 2) : (n.px[1] >= cv ? 3 : 4);
+    const double sx = (quadrant == 1 || quadrant == 2) ? 1.0 : -1.0, sy = (quadrant == 1 || quadrant == 3) ? 1.0 : -1.0;
+    Id& place = F.key[quadrant];
+    if (place == kNone) place = f;
+    else {
+      const Feat& h = feats[place];
+      if ((sx * dx) * (sy * dy) > (sx * (h.px[0] - cu)) * (sy * (h.px[1] - cv))) place = f;
+    }
+  }
+  void refresh_keys(Frame& F)     // Frame::setKeyPoints
+  {
+    for (Id& k : F.key) if (k != kNone && feats[k].point == kNone) k = kNone;
+    for (Id f : F.fts) if (feats[f].point != kNone) offer_key(F, f);
+  }
+  void lose_key(Id f)             // Frame::removeKeyPoint
+  {
+    Frame& F = frames[feats[f].frame];
+    bool was = false;
+    for (Id& k : F.key) if (k == f) { k = kNone; was = true; }
+    if (was) refresh_keys(F);
+  }
+  bool sees(const Frame& F, const double* xyz_w) const   // Frame::isVisible
+  {
+    const Vector3d p = F.T * Vector3d{xyz_w[0], xyz_w[1], xyz_w[2]};
+    if (p[2] < 0.0) return false;
+    const Vector2d px = cam->world2cam(p);
+    return px[0] >= 0.0 && px[1] >= 0.0 && px[0] < cam->width() && px[1] < cam->height();
+  }
+
+  // ---- Map (src/map.cpp:102-188)
+  void erase_point(Id p)          // Map::safeDeletePoint
+  {
+    Point& P = points[p];
+    for (Id o = P.head; o != kNone;) {
+      const Id nx = feats[o].next;
+      feats[o].point = kNone; feats[o].next = kNone; feats[o].linked = false;
+      lose_key(o);
+      o = nx;
+    }
+    P.head = kNone; P.n_obs = 0;
+    P.kind = kPtDeleted;
+  }
+  void detach(Id frame, Id f)     // Map::removePtFrameRef
+  {
+    const Id p = feats[f].point;
+    if (p == kNone) return;
+    feats[f].point = kNone;
+    if (points[p].n_obs <= 2) { erase_point(p); return; }
+    unobserve(p, frame);
+    lose_key(f);
+  }
+  void place_in_host(Id p)        // pos_ = T_host^-1 * (f / idist)
+  {
+    Point& P = points[p];
+    const Feat& h = feats[P.host];
+    const Vector3d w = frames[h.frame].T.inverse() * along(h.f, 1.0 / P.idist);
+    P.pos[0] = w[0]; P.pos[1] = w[1]; P.pos[2] = w[2];
+    touch_point(p);
+  }
+  bool erase_candidate(Id p)      // MapPointCandidates::deleteCandidatePoint: the host feature lives in no frame's list yet
+  {
+    auto it = std::find(candidates.begin(), candidates.end(), p);
+    if (it == candidates.end()) return false;
+    candidates.erase(it);
+    Point& P = points[p];
+    if (P.host != kNone) { feats[P.host].point = kNone; feats[P.host].linked = false; feats[P.host].next = kNone; }
+    P.head = kNone; P.n_obs = 0;
+    P.kind = kPtDeleted;
+    return true;
+  }
+  // Map::safeDeleteTempPoint: what becomes of a temporary point once its seed has finished
+  void retire_temp(Id p)
+  {
+    Point& P = points[p];
+    if (P.seed_state == -1) {                   // the seed was dropped
+      if (P.bad) { erase_point(p); return; }
+      place_in_host(p);
+      P.n_fail = 0; P.n_ok = 0;
+      if (P.n_obs == 1) { P.kind = kPtCandidate; candidates.push_back(p); }
+      else { P.kind = kPtUnknown; frames[feats[P.host].frame].fts.push_back(P.host); }
+      return;
+    }
+    // the seed converged into a point of its own, which took over the host feature; every other observation of the temporary
+    // point is released
+    const Id heir = feats[P.host].point;
+    for (Id o = P.head; o != kNone;) {
+      const Id nx = feats[o].next;
+      if (feats[o].point != heir) { feats[o].point = kNone; feats[o].next = kNone; feats[o].linked = false; lose_key(o); }
+      else if (o != P.host) { feats[o].next = kNone; feats[o].linked = false; }
+      o = nx;
+    }
+    P.head = kNone; P.n_obs = 0;
+    P.kind = kPtDeleted;
+  }
+  void closest_keyframes(const Frame& F, std::vector<std::pair<double, Id>>& out) const   // Map::getCloseKeyframes
+  {
+    for (Id k : kfs) {
+      const Frame& K = frames[k];
+      for (Id key : K.key) {
+        if (key == kNone || feats[key].point == kNone) continue;
+        if (!sees(F, points[feats[key].point].pos)) continue;
+        const double d[3] = {F.T.v.t[0] - K.T.v.t[0], F.T.v.t[1] - K.T.v.t[1], F.T.v.t[2] - K.T.v.t[2]};
+        out.emplace_back(len3(d), k);
+        break;
+      }
+    }
+  }
+  Id new_point(const Vector3d& pos, Id host_feat, double idist, int8_t kind)
+  {
+    points.emplace_back();
+    const Id p = (Id)points.size() - 1;
+    Point& P = points[p];
+    P.pos[0] = pos[0]; P.pos[1] = pos[1]; P.pos[2] = pos[2];
+    P.idist = idist; P.host = host_feat; P.kind = kind;
+    P.on = point_face(feats[host_feat].type);
+    return p;
+  }
+  void reset_tables()
+  {
+    frames.clear(); free_slots.clear(); feats.clear(); points.clear(); seeds.clear(); n_dead_seeds = 0;
+    kfs.clear(); dev_kfs.clear(); candidates.clear(); temps.clear(); dirty_pts.clear(); dirty_obs.clear(); pt_flag.clear(); obs_flag.clear();
+    kfs_dirty = true; local_map.clear(); converge_hist.clear(); prior.clear(); init.clear();
+    last = cur = first = kNone;
+  }
+};
+
+// what a sequence carries through one step
+struct StepData {
+  bool active = false, tracked = false, ok = false, make_kf = false, seed_path = false, relocalised = false;
+  int stage0 = 0;                              // the sequence's stage when the step began
+  SE3 reloc_pose;
+  hso_pose_result pose{};
+  std::vector<uint8_t> pose_mask;
+  int n_core = 0;
+  std::vector<int64_t> released;               // device frames to release (collected on pool threads)
+  Id ref = kNone;                              // the frame the tracker aligns against
+  int inverse = 1;
+  std::vector<hso_ref_feat> ref_feats;
+  hso_track_job job{};
+  hso_track_result track{};
+  std::vector<Id> visit;                       // overlap keyframes in visiting order
+  std::vector<int32_t> list; std::vector<uint8_t> list_q;
+  int n_kf_points = 0, n_cand_listed = 0;      // list layout: keyframe points | candidates | temporary points
+  hso_map_frame call{};
+  size_t n_inliers = 0;
+  double depth_mean = 0, depth_min = 0, dist_mean = 0;
+  // keyframe: the local BA window
+  std::vector<Id> ba_frames; std::vector<uint8_t> ba_fixed; std::vector<hso_se3> ba_poses;
+  std::vector<Id> ba_points; std::vector<double> ba_idist;
+  std::vector<hso_ba_edge> ba_edges; std::vector<Id> ba_edge_feat; std::vector<double> ba_uv, ba_chi2;
+  hso_ba_result ba_res{};
+  float huber_corner = 0, huber_edge = 0;
+  int ba_iters = 0;
+  std::vector<Id> moved_kfs;                   // keyframes whose pose local BA changed
+  // seeds
+  std::vector<int> conv;                       // indices of converged seeds
+  std::vector<hso_seed> act_seeds; std::vector<int32_t> act_begin; std::vector<hso_activate_target> act_targets; std::vector<hso_activate_out> act_out;
+  std::vector<hso_keypoint> occupied;          // FeatureExtractor::setGridOccpuancy keys of this keyframe's observation
+  std::vector<int32_t> erase_slots;
+  std::vector<hso_seed> new_seeds;
+};
+
+}  // namespace engine
+}  // namespace hso

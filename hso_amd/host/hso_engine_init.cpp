@@ -1,0 +1,304 @@
+// hso_engine_init.cpp — how a sequence starts: from a first keyframe with known depths (the setFirstFrame hook the reference
+// keeps for synthetic data, src/frame_handler_mono.cpp:419-426) or from images alone (processFirstFrame / processSecondFrame,
+// :125-172, with initialization::KltHomographyInit, src/initialization.cpp:39-223, on the engine's tables); and the trace records
+// of the chained reprojection call.
+#include "hso_engine_impl.h"
+#include "hso_init.h"
+
+namespace hso {
+namespace engine {
+
+// ------------------------------------------------------------------------------------------------ first keyframe with depths
+void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const double* stamps, const float* const* depth_z, const hso_se3* T_f_w)
+{
+  if (w != cam_.width() || h != cam_.height())
+    throw std::invalid_argument("Frame: provided image has not the same size as the camera model or image is not grayscale");
+  std::vector<int> who;
+  for (int k = 0; k < size(); k++) {
+    *step_[k] = StepData();
+    if (!imgs[k]) continue;
+    if (!depth_z || !depth_z[k]) throw std::invalid_argument("set_first_frame: no depth image");
+    Seq& s = *seq_[k];
+    for (Frame& F : s.frames) if (F.in_use && F.dev_id >= 0) to_release_.push_back(F.dev_id);
+    drop_sequence_seeds(k);
+    s.reset_tables();                                             // resetAll
+    s.motion = SE3(); s.after_init = false; s.regular = 0; s.n_obs_last = 0; s.quality = kInsufficient; s.want_start = false;
+    who.push_back(k);
+  }
+  for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
+  to_release_.clear();
+  if (who.empty()) return;
+  upload(who, imgs, w, h, stamps);
+  // the detector of the initialisation (2000 features, FAST-12 hole filling), then one point per feature whose depth is known —
+  // what the two-view initialisation leaves behind for its inliers
+  std::vector<std::vector<hso_keypoint>> keys(who.size()), sel;
+  std::vector<Id> frame(who.size()); std::vector<int> thresh(who.size());
+  for (size_t i = 0; i < who.size(); i++) {
+    Seq& s = *seq_[who[i]];
+    Frame& C = s.frames[s.cur];
+    if (T_f_w) C.T.v = T_f_w[who[i]];
+    C.exposure = 1.0;                                             // processFirstFrame, :138
+    frame[i] = s.cur; thresh[i] = (int)C.grad_mean;
+  }
+  detect(who, frame, thresh, true, cfg_.n_pyr_levels, 2000, keys, sel);
+  for (size_t i = 0; i < who.size(); i++) {
+    const int k = who[i];
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    Frame& C = s.frames[s.cur];
+    const float* depth = depth_z[k];
+    std::vector<double> dist_of;
+    for (const hso_keypoint& kp : sel[i]) {
+      Feat ft = feature_from_key(kp, s.cur);
+      const int x = (int)ft.px[0], y = (int)ft.px[1];
+      const float z = (x >= 0 && y >= 0 && x < w && y < h) ? depth[(size_t)y * w + x] : 0.f;
+      if (!(z > 0)) continue;
+      C.loose.push_back(ft);
+      dist_of.push_back((double)z / ft.f[2]);                     // the point on the bearing whose depth along the optical axis is z
+    }
+    if (C.loose.size() < 10) throw std::runtime_error("set_first_frame: fewer than 10 features with a depth");
+    make_keyframe(s, s.cur);
+    const SE3 T_w_f = C.T.inverse();
+    for (size_t j = 0; j < C.fts.size(); j++) {
+      const Id f = C.fts[j];
+      const Vector3d X = T_w_f * along(s.feats[f].f, dist_of[j]);
+      const Id p = s.new_point(X, f, 1.0 / dist_of[j], kPtUnknown);
+      s.feats[f].point = p;
+      s.observe(p, f);
+    }
+    s.refresh_keys(C);
+    s.kfs.push_back(s.cur);
+    s.stage = kRunning;
+    // the first keyframe's seeds: DepthFilter::addKeyframe with the scene's depth statistics
+    std::vector<double> z, r;
+    d.depth_min = std::numeric_limits<double>::max();
+    for (Id f : C.fts) {
+      const double* wpos = s.points[s.feats[f].point].pos;
+      const Vector3d c = C.T * Vector3d{wpos[0], wpos[1], wpos[2]};
+      z.push_back(c[2]); r.push_back(std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]));
+      d.depth_min = std::fmin(c[2], d.depth_min);
+    }
+    d.depth_mean = upper_median(z); d.dist_mean = upper_median(r);
+    d.n_inliers = 1000;                                           // convergence threshold 200
+    d.ok = true; d.make_kf = true; d.active = true;
+    s.outcome = kKeyframe;
+    s.log = hso_vo_status{};
+  }
+  observe_seeds(who);                                             // no seeds yet: only the frame lists
+  start_seeds(who);
+  flush_maps(who);
+  for (int k : who) {
+    Seq& s = *seq_[k];
+    const Id old = s.last;
+    s.last = s.cur; s.cur = kNone;
+    if (old != kNone) release_frame(s, old);
+    s.n_obs_last = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ two-view start
+namespace {
+bool inside(const AbstractCamera& cam, int x, int y, int margin) { return x >= margin && x < cam.width() - margin && y >= margin && y < cam.height() - margin; }
+}
+
+void Bank::initialise(const std::vector<int>& who)
+{
+  std::vector<int> first, second;
+  for (int k : who) (seq_[k]->stage == kFirst ? first : second).push_back(k);
+  if (!first.empty()) {
+    // processFirstFrame + KltHomographyInit::addFirstFrame: the initialisation's detector on one level, 2000 features
+    std::vector<std::vector<hso_keypoint>> keys(first.size()), sel;
+    std::vector<Id> frame(first.size()); std::vector<int> thresh(first.size());
+    for (size_t i = 0; i < first.size(); i++) {
+      Seq& s = *seq_[first[i]];
+      Frame& C = s.frames[s.cur];
+      C.T = SE3();
+      frame[i] = s.cur; thresh[i] = (int)(C.grad_mean + 0.5f);
+    }
+    detect(first, frame, thresh, true, 1, 2000, keys, sel);
+    for (size_t i = 0; i < first.size(); i++) {
+      Seq& s = *seq_[first[i]];
+      Frame& C = s.frames[s.cur];
+      s.log = hso_vo_status{};
+      s.init.clear();
+      if (sel[i].size() < 200) { s.outcome = kNoKeyframe; continue; }          // too few corners: wait for a better image (:45-49)
+      for (const hso_keypoint& kp : sel[i]) {
+        const Feat ft = feature_from_key(kp, s.cur);
+        s.init.px_ref.push_back({(double)(float)ft.px[0], (double)(float)ft.px[1]});
+        s.init.f_ref.push_back({ft.f[0], ft.f[1], ft.f[2]});
+        s.init.kind.push_back({ft.grad[0], ft.grad[1], ft.type == HSO_FTR_EDGELET ? 1.0 : ft.type == HSO_FTR_CORNER ? 0.0 : 2.0});
+      }
+      s.init.px_cur = s.init.px_ref;
+      s.init.ref = s.init.prev = s.cur;
+      s.hold(s.cur); s.hold(s.cur);                               // frame_ref_, frame_prev_
+      make_keyframe(s, s.cur);                                    // setKeyframe + Map::addKeyframe
+      s.kfs.push_back(s.cur);
+      s.first = s.cur; s.hold(s.cur);
+      C.exposure = 1.0;
+      s.stage = kSecond;
+      s.outcome = kKeyframe;
+    }
+  }
+  for (int k : second) {
+    // KltHomographyInit::addSecondFrame: KLT from the previous frame (one device call per sequence: a handful per run)
+    Seq& s = *seq_[k];
+    TwoView& I = s.init;
+    Frame& C = s.frames[s.cur];
+    s.log = hso_vo_status{};
+    const size_t n = I.px_cur.size();
+    std::vector<float> a(2 * n), b(2 * n);
+    // px_prev_ = the positions in the previous frame; while only the reference has been seen both are the reference's
+    for (size_t i = 0; i < n; i++) { a[2 * i] = (float)I.px_cur[i][0]; a[2 * i + 1] = (float)I.px_cur[i][1]; b[2 * i] = a[2 * i]; b[2 * i + 1] = a[2 * i + 1]; }
+    std::vector<hso_klt_result> res(n);
+    hso_klt_params kp{};
+    kp.win_size = 30; kp.max_level = 4; kp.max_iter = 30; kp.use_initial_flow = 1; kp.epsilon = 0.0001;
+    check(hso_gpu_klt_track(ctx_, s.frames[I.prev].dev_id, C.dev_id, a.data(), b.data(), (int)n, &kp, res.data()), "trackKlt");
+    n_calls_[9]++; n_items_[9]++;
+    if (s.trace.on()) {
+      Trace& t = s.trace;
+      t.begin("klt_track", 6);
+      t.scalar("prev_frame_id", (double)s.frames[I.prev].dev_id); t.scalar("cur_frame_id", (double)C.dev_id);
+      t.field("px_prev", a.data(), sizeof(float) * a.size()); t.field("px_init", b.data(), sizeof(float) * b.size());
+      t.field("params", &kp, sizeof(kp)); t.field("result", res.data(), sizeof(hso_klt_result) * n);
+    }
+    std::vector<double> disparity;
+    {
+      TwoView K;
+      for (size_t i = 0; i < n; i++) {
+        if ((res[i].status & (HSO_KLT_TRACKED | HSO_KLT_PATCH_OK)) != (HSO_KLT_TRACKED | HSO_KLT_PATCH_OK)) continue;
+        const Vector2d pc = {(double)res[i].px[0], (double)res[i].px[1]};
+        K.px_ref.push_back(I.px_ref[i]); K.px_cur.push_back(pc); K.f_ref.push_back(I.f_ref[i]); K.kind.push_back(I.kind[i]);
+        K.f_cur.push_back(cam_.cam2world(pc));
+        disparity.push_back(std::hypot(I.px_ref[i][0] - pc[0], I.px_ref[i][1] - pc[1]));
+      }
+      I.px_ref.swap(K.px_ref); I.px_cur.swap(K.px_cur); I.f_ref.swap(K.f_ref); I.f_cur.swap(K.f_cur); I.kind.swap(K.kind);
+    }
+    { const Id old = I.prev; I.prev = s.cur; s.hold(s.cur); release_frame(s, old); }
+    if ((int)disparity.size() < cfg_.init_min_tracked) { s.outcome = kFailure; continue; }
+    { std::vector<double> dd = disparity; if (upper_median(dd) < cfg_.init_min_disparity) { s.outcome = kNoKeyframe; continue; } }
+    std::vector<int> inliers; std::vector<Vector3d> xyz; SE3 T_cur_ref; int used_h = 0;
+    initialization::computeInitializeMatrix(I.f_ref, I.f_cur, cam_.errorMultiplier2(), cfg_.poseoptim_thresh, inliers, xyz, T_cur_ref, &used_h);
+    if ((int)inliers.size() < cfg_.init_min_inliers) { s.outcome = kFailure; continue; }
+    // the map is rescaled so that the median depth of the triangulated points equals map_scale (:97-104)
+    std::vector<double> depths;
+    for (const Vector3d& p : xyz) depths.push_back(p[2]);
+    const double scale = cfg_.map_scale / upper_median(depths);
+    Frame& R = s.frames[I.ref];
+    C.T = T_cur_ref * R.T;
+    {
+      const Vector3d pr = s.centre(R), pc = s.centre(C);
+      const Vector3d moved = {pr[0] + (pc[0] - pr[0]) * scale, pr[1] + (pc[1] - pr[1]) * scale, pr[2] + (pc[2] - pr[2]) * scale};
+      SE3 rot = C.T; rot.v.t[0] = rot.v.t[1] = rot.v.t[2] = 0;
+      const Vector3d t = rot * moved;
+      C.T.v.t[0] = -t[0]; C.T.v.t[1] = -t[1]; C.T.v.t[2] = -t[2];
+    }
+    const SE3 T_w_cur = C.T.inverse();
+    C.loose.clear();
+    for (int id : inliers) {                                      // one point per inlier, observed in both frames (:110-170)
+      const Vector2d pc = I.px_cur[id], pr = I.px_ref[id];
+      if (!(inside(cam_, (int)pc[0], (int)pc[1], 10) && inside(cam_, (int)pr[0], (int)pr[1], 10) && xyz[id][2] > 0)) continue;
+      const Vector3d pos = T_w_cur * Vector3d{xyz[id][0] * scale, xyz[id][1] * scale, xyz[id][2] * scale};
+      const std::array<double, 3>& kind = I.kind[id];
+      Feat in_ref, in_cur;
+      in_ref.frame = I.ref; in_cur.frame = s.cur;
+      in_ref.px[0] = pr[0]; in_ref.px[1] = pr[1]; in_cur.px[0] = pc[0]; in_cur.px[1] = pc[1];
+      in_ref.type = in_cur.type = kind[2] == 0 ? HSO_FTR_CORNER : kind[2] == 1 ? HSO_FTR_EDGELET : HSO_FTR_GRADIENT;
+      Vector3d fr = I.f_ref[id], fc = I.f_cur[id];
+      if (in_ref.type == HSO_FTR_GRADIENT) { fr = cam_.cam2world(pr); fc = cam_.cam2world(pc); }
+      if (in_ref.type == HSO_FTR_EDGELET) { in_ref.grad[0] = in_cur.grad[0] = kind[0]; in_ref.grad[1] = in_cur.grad[1] = kind[1]; }
+      for (int c = 0; c < 3; c++) { in_ref.f[c] = fr[c]; in_cur.f[c] = fc[c]; }
+      s.feats.push_back(in_ref);
+      const Id f = (Id)s.feats.size() - 1;
+      R.fts.push_back(f);
+      const double pn[3] = {pos[0], pos[1], pos[2]};
+      const Id p = s.new_point(pos, f, 1.0 / len3(pn), kPtUnknown);   // as written (:124): the reference frame sits at the origin
+      s.feats[f].point = p;
+      s.observe(p, f);
+      in_cur.point = p;
+      C.loose.push_back(in_cur);
+    }
+    release_frame(s, I.ref); release_frame(s, I.prev);
+    I.clear();
+    s.stage = kRunning;
+    s.after_init = true;
+    s.refresh_keys(R);                                            // firstFrame_->setKeyPoints()
+    s.outcome = kKeyframe;
+    s.log.n_matches = (int)C.loose.size();
+    C.n_inliers = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ trace of the chained call
+// One hso_gpu_reproject_select_pose_frames call = three records per traced sequence, with the tables AS THE DEVICE HOLDS THEM
+// (read back through hso_gpu_seqmap_read / hso_gpu_debug_fetch — the host mirror is not trusted here): "reproject_match" in the
+// value-passing call's layout (the observation lists flattened), "reproject_select" (the examined candidates) and "pose_optimize"
+// (the feature table the device built from them).
+void Bank::trace_reproject(const std::vector<int>& who, const std::vector<hso_map_frame>& calls, const std::vector<size_t>& list_at,
+                           const std::vector<int32_t>& begin, const std::vector<int32_t>& counts, const std::vector<hso_pose_result>& pose,
+                           const std::vector<int32_t>& n_feats)
+{
+  const int n = (int)who.size(), cap = std::max(cfg_.max_fts, 1);
+  size_t total = 0;
+  for (const hso_map_frame& c : calls) total += (size_t)c.n_points;
+  std::vector<hso_reproj_point> proj(total); std::vector<hso_align_out> match(total);
+  std::vector<hso_pose_feat> pf((size_t)n * cap); std::vector<hso_se3> pp((size_t)n * 128); std::vector<int32_t> np((size_t)n);
+  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_PROJ, proj.data(), sizeof(hso_reproj_point) * total), "trace");
+  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_MATCH, match.data(), sizeof(hso_align_out) * total), "trace");
+  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_POSE_FEATS, pf.data(), sizeof(hso_pose_feat) * pf.size()), "trace");
+  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_POSE_POSES, pp.data(), sizeof(hso_se3) * pp.size()), "trace");
+  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_POSE_NPOSES, np.data(), sizeof(int32_t) * np.size()), "trace");
+  for (int i = 0; i < n; i++) {
+    Seq& s = *seq_[who[i]];
+    if (!s.trace.on()) continue;
+    const StepData& d = *step_[who[i]];
+    const hso_map_frame& c = calls[i];
+    int nk = 0, n_pts = 0, n_obs = 0;
+    check(hso_gpu_seqmap_size(ctx_, s.map, &nk, &n_pts, &n_obs), "trace");
+    std::vector<hso_map_point> rows((size_t)c.n_points);
+    std::vector<int32_t> all_obs((size_t)n_obs);
+    std::iota(all_obs.begin(), all_obs.end(), 0);
+    std::vector<hso_obs> obs_rows((size_t)n_obs);
+    check(hso_gpu_seqmap_read(ctx_, s.map, c.point_ids, c.n_points, rows.data(), all_obs.data(), n_obs, obs_rows.data()), "trace");
+    std::vector<hso_kf> kfs;
+    for (Id fr : s.dev_kfs) { const Frame& F = s.frames[fr]; hso_kf r{}; r.frame_id = F.dev_id; r.T_f_w = F.T.v; r.exposure_time = F.exposure; r.keyframe_id = F.kf_id; kfs.push_back(r); }
+    std::vector<hso_obs> flat;
+    std::vector<hso_reproj_point> pr(proj.begin() + (std::ptrdiff_t)list_at[i], proj.begin() + (std::ptrdiff_t)(list_at[i] + (size_t)c.n_points));
+    for (int j = 0; j < c.n_points; j++) {
+      hso_map_point& r = rows[(size_t)j];
+      const int first = (int)flat.size();
+      int at = -1;
+      for (int q = 0, row = r.obs_begin; q < r.obs_count; q++) {
+        hso_obs o = obs_rows[(size_t)row];
+        if (pr[(size_t)j].ref_obs == row) at = first + q;
+        row = o.pad_; o.pad_ = 0;
+        flat.push_back(o);
+      }
+      r.obs_begin = first;
+      r.pad_ = c.quality[j];
+      if (pr[(size_t)j].ref_obs >= 0) pr[(size_t)j].ref_obs = at;
+      pr[(size_t)j].pad_ = 0;
+    }
+    Trace& t = s.trace;
+    const Frame& C = s.frames[s.cur];
+    hso_obs none_obs{};
+    t.begin("reproject_match", 12);
+    t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.scalar("cur_frame_id", (double)c.cur_frame_id); t.field("T_cur_w", &c.T_cur_w, sizeof(hso_se3));
+    t.scalar("cur_exposure", c.cur_exposure_time); t.scalar("cur_keyframe_id", c.cur_keyframe_id);
+    t.field("kfs", kfs.data(), sizeof(hso_kf) * kfs.size()); t.field("points", rows.data(), sizeof(hso_map_point) * rows.size());
+    t.field("obs", flat.empty() ? &none_obs : flat.data(), sizeof(hso_obs) * flat.size()); t.scalar("cell_size", cell_size_); t.scalar("grid_n_cols", grid_cols_);
+    t.field("proj", pr.data(), sizeof(hso_reproj_point) * pr.size()); t.field("match", match.data() + list_at[i], sizeof(hso_align_out) * (size_t)c.n_points);
+    t.begin("reproject_select", 6);
+    t.field("quality", c.quality, (size_t)c.n_points); t.field("cell_order", cell_order_.data(), sizeof(int32_t) * cell_order_.size());
+    t.scalar("max_fts", cfg_.max_fts); t.field("examined", briefs_.data() + begin[i], sizeof(hso_match_brief) * (size_t)(begin[i + 1] - begin[i]));
+    t.field("counts", &counts[4 * (size_t)i], sizeof(int32_t) * 4); t.field("projected", projected_.data() + list_at[i], (size_t)c.n_points);
+    t.begin("pose_optimize", 8);
+    t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("feats", pf.data() + (size_t)i * cap, sizeof(hso_pose_feat) * (size_t)n_feats[i]);
+    t.field("poses", pp.data() + (size_t)i * 128, sizeof(hso_se3) * (size_t)std::min(np[(size_t)i], 128)); t.field("T_f_w", &c.T_cur_w, sizeof(hso_se3));
+    t.scalar("reproj_thresh", cfg_.poseoptim_thresh); t.scalar("n_iter", 12);
+    t.field("result", &pose[(size_t)i], sizeof(hso_pose_result)); t.field("mask", mask_.data() + (size_t)i * cap, (size_t)n_feats[i]);
+    (void)d; (void)C;
+  }
+}
+
+}  // namespace engine
+}  // namespace hso

@@ -1,0 +1,792 @@
+// hso_engine_kf.cpp — the keyframe-rate half of a step: the local BA window, the depth filter's seed bookkeeping around the
+// resident seed table, new seeds, the mirror of the sequence tables on the device, the end of a frame.
+#include "hso_engine_impl.h"
+
+namespace hso {
+namespace engine {
+
+// ------------------------------------------------------------------------------------------------ local BA
+// ba::LocalBundleAdjustment's graph (src/bundle_adjustment.cpp:592-812) as flat tables: the window's keyframes first (the
+// reference walks std::set<Frame*> / std::set<Point*> in address order; frame serials and point ids give a run-independent one),
+// then every keyframe that hosts or observes one of their points, fixed.
+void Bank::assemble_window(int k)
+{
+  Seq& s = *seq_[k];
+  StepData& d = *step_[k];
+  const Frame& C = s.frames[s.cur];
+  std::vector<Id> core = s.local_map;
+  std::sort(core.begin(), core.end(), [&](Id a, Id b) { return s.frames[a].serial < s.frames[b].serial; });
+  std::vector<int> vertex(s.frames.size(), -1);
+  d.ba_frames.clear(); d.ba_fixed.clear(); d.ba_points.clear(); d.ba_edges.clear(); d.ba_edge_feat.clear(); d.ba_uv.clear();
+  for (Id kf : core) {
+    const Frame& K = s.frames[kf];
+    vertex[kf] = (int)d.ba_frames.size();
+    d.ba_frames.push_back(kf);
+    d.ba_fixed.push_back((K.serial == 0 || K.kf_id + 20 < C.kf_id) ? 1 : 0);   // :595
+    for (Id f : K.fts) if (s.feats[f].point != kNone) d.ba_points.push_back(s.feats[f].point);
+  }
+  std::sort(d.ba_points.begin(), d.ba_points.end());
+  d.ba_points.erase(std::unique(d.ba_points.begin(), d.ba_points.end()), d.ba_points.end());
+  auto vertex_of = [&](Id fr) {
+    if (vertex[fr] < 0) { vertex[fr] = (int)d.ba_frames.size(); d.ba_frames.push_back(fr); d.ba_fixed.push_back(1); }   // :700-737
+    return vertex[fr];
+  };
+  d.ba_idist.resize(d.ba_points.size());
+  for (size_t i = 0; i < d.ba_points.size(); i++) {
+    Point& P = s.points[d.ba_points[i]];
+    d.ba_idist[i] = P.idist;
+    P.n_ba++;
+    const Feat& host = s.feats[P.host];
+    const int vh = vertex_of(host.frame);
+    for (Id o = P.head; o != kNone; o = s.feats[o].next) {
+      const Feat& ob = s.feats[o];
+      if (ob.frame == host.frame) continue;
+      hso_ba_edge e{};
+      e.point = (int)i; e.host = vh; e.target = vertex_of(ob.frame);
+      e.type = ob.type == HSO_FTR_EDGELET ? HSO_FTR_EDGELET : HSO_FTR_CORNER;
+      e.level = ob.level;
+      e.fH[0] = host.f[0]; e.fH[1] = host.f[1]; e.fH[2] = host.f[2];
+      const double u = ob.f[0] / ob.f[2], v = ob.f[1] / ob.f[2];
+      if (e.type == HSO_FTR_EDGELET) { e.normal[0] = ob.grad[0]; e.normal[1] = ob.grad[1]; e.meas[0] = ob.grad[0] * u + ob.grad[1] * v; }
+      else { e.normal[0] = 1; e.normal[1] = 0; e.meas[0] = u; e.meas[1] = v; }
+      d.ba_edges.push_back(e); d.ba_edge_feat.push_back(o);
+      d.ba_uv.push_back(u); d.ba_uv.push_back(v);
+    }
+  }
+  d.ba_poses.resize(d.ba_frames.size());
+  for (size_t i = 0; i < d.ba_frames.size(); i++) d.ba_poses[i] = s.frames[d.ba_frames[i]].T.v;
+  d.ba_chi2.assign(d.ba_edges.size(), 0.0);
+  d.ba_iters = 100;                                               // :815-823
+  if (s.kfs.size() > 5) d.ba_iters = C.fts.size() < 100 ? cfg_.loba_num_iter + 10 : cfg_.loba_num_iter;
+  d.n_core = (int)core.size();
+}
+
+void Bank::keyframe_ba(const std::vector<int>& who)
+{
+  std::vector<int> with;
+  for (int k : who) if (!step_[k]->ba_edges.empty() && !step_[k]->ba_points.empty()) with.push_back(k);
+  const double fmean = cam_.errorMultiplier2();
+  std::vector<std::vector<hso_se3>> poses_in(with.size());
+  std::vector<std::vector<double>> idist_in(with.size());
+  for (size_t i = 0; i < with.size(); i++) {
+    Seq& s = *seq_[with[i]];
+    StepData& d = *step_[with[i]];
+    check(hso_gpu_ba_huber_deltas(ctx_, d.ba_poses.data(), (int)d.ba_poses.size(), d.ba_idist.data(), (int)d.ba_idist.size(), d.ba_edges.data(),
+                                  d.ba_uv.data(), (int)d.ba_edges.size(), fmean, &d.huber_corner, &d.huber_edge), "LocalBundleAdjustment");
+    if (s.trace.on()) {
+      Trace& t = s.trace;
+      t.begin("ba_huber_deltas", 7);
+      t.field("poses", d.ba_poses.data(), sizeof(hso_se3) * d.ba_poses.size()); t.field("idist", d.ba_idist.data(), sizeof(double) * d.ba_idist.size());
+      t.field("edges", d.ba_edges.data(), sizeof(hso_ba_edge) * d.ba_edges.size()); t.field("obs_uv", d.ba_uv.data(), sizeof(double) * d.ba_uv.size());
+      t.scalar("error_multiplier2", fmean); t.scalar("huber_corner", d.huber_corner); t.scalar("huber_edge", d.huber_edge);
+      poses_in[i] = d.ba_poses; idist_in[i] = d.ba_idist;
+    }
+  }
+  if (!with.empty()) {
+    std::vector<hso_ba_problem> pr(with.size());
+    for (size_t i = 0; i < with.size(); i++) {
+      StepData& d = *step_[with[i]];
+      hso_ba_problem& p = pr[i];
+      p.poses_f_w = d.ba_poses.data(); p.pose_fixed = d.ba_fixed.data(); p.idist = d.ba_idist.data(); p.edges = d.ba_edges.data();
+      p.edge_chi2_out = d.ba_chi2.data(); p.result = &d.ba_res;
+      p.n_poses = (int)d.ba_poses.size(); p.n_points = (int)d.ba_idist.size(); p.n_edges = (int)d.ba_edges.size(); p.n_iter = d.ba_iters;
+      p.huber_corner = d.huber_corner; p.huber_edge = d.huber_edge;
+    }
+    check(hso_gpu_ba_optimize_multi(ctx_, pr.data(), (int)pr.size()), "LocalBundleAdjustment");
+    n_calls_[8]++; n_items_[8] += (int64_t)pr.size();
+    for (size_t i = 0; i < with.size(); i++) {
+      Seq& s = *seq_[with[i]];
+      StepData& d = *step_[with[i]];
+      if (!s.trace.on()) continue;
+      Trace& t = s.trace;
+      t.begin("ba_optimize", 11);
+      t.field("poses_in", poses_in[i].data(), sizeof(hso_se3) * poses_in[i].size()); t.field("fixed", d.ba_fixed.data(), d.ba_fixed.size());
+      t.field("idist_in", idist_in[i].data(), sizeof(double) * idist_in[i].size()); t.field("edges", d.ba_edges.data(), sizeof(hso_ba_edge) * d.ba_edges.size());
+      t.scalar("huber_corner", d.huber_corner); t.scalar("huber_edge", d.huber_edge); t.scalar("n_iter", d.ba_iters);
+      t.field("poses_out", d.ba_poses.data(), sizeof(hso_se3) * d.ba_poses.size()); t.field("idist_out", d.ba_idist.data(), sizeof(double) * d.ba_idist.size());
+      t.field("edge_chi2", d.ba_chi2.data(), sizeof(double) * d.ba_chi2.size()); t.field("result", &d.ba_res, sizeof(d.ba_res));
+    }
+  }
+  par(with, [&](int k) { apply_window(k); });
+  // setKeyPoints of the overlap keyframes (src/frame_handler_mono.cpp:331)
+  par(who, [&](int k) { Seq& s = *seq_[k]; for (Id kf : step_[k]->visit) s.refresh_keys(s.frames[kf]); });
+  // the resident seeds of the moved keyframes follow them
+  std::vector<int64_t> ids; std::vector<hso_se3> poses;
+  for (int k : with) for (Id kf : step_[k]->moved_kfs) { ids.push_back(seq_[k]->frames[kf].dev_id); poses.push_back(seq_[k]->frames[kf].T.v); }
+  if (!ids.empty()) check(hso_gpu_seed_table_set_host_pose(ctx_, seed_table_, ids.data(), poses.data(), (int)ids.size()), "DepthFilter");
+}
+
+// what LocalBundleAdjustment does with the optimiser's result (:826-892)
+void Bank::apply_window(int k)
+{
+  Seq& s = *seq_[k];
+  StepData& d = *step_[k];
+  const double fmean = cam_.errorMultiplier2();
+  d.moved_kfs.clear();
+  for (int i = 0; i < d.n_core; i++) {
+    const Id kf = d.ba_frames[i];
+    Frame& K = s.frames[kf];
+    K.T.v = d.ba_poses[i];
+    if (!d.ba_fixed[i]) d.moved_kfs.push_back(kf);
+    for (Id c : s.candidates)                                     // MapPointCandidates::changeCandidatePosition
+      if (s.feats[s.points[c].host].frame == kf) s.place_in_host(c);
+  }
+  s.kfs_dirty = true;
+  for (size_t i = 0; i < d.ba_points.size(); i++) {
+    s.points[d.ba_points[i]].idist = d.ba_idist[i];
+    s.place_in_host(d.ba_points[i]);
+  }
+  const double tight = 1.2 / fmean, loose = 2.0 / fmean;
+  int dropped[2] = {0, 0};
+  for (int pass = 0; pass < 2; pass++)                            // corner edges first, then edgelet edges
+    for (size_t e = 0; e < d.ba_edges.size(); e++) {
+      const bool edgelet = d.ba_edges[e].type == HSO_FTR_EDGELET;
+      if (edgelet != (pass == 1)) continue;
+      const Id f = d.ba_edge_feat[e];
+      const Id p = s.feats[f].point;
+      if (p == kNone) continue;
+      if (!(d.ba_chi2[e] > (edgelet ? tight * tight : loose * loose))) continue;
+      if (s.points[p].kind == kPtTemporary) { s.points[p].bad = true; continue; }
+      s.detach(s.feats[f].frame, f);
+      dropped[pass]++;
+    }
+  s.log.ba_removed_1 = dropped[0]; s.log.ba_removed_2 = dropped[1];
+  s.log.ba_error_init = std::sqrt(d.ba_res.init_chi2) * fmean;
+  s.log.ba_error_final = std::sqrt(d.ba_res.final_chi2) * fmean;
+}
+
+// ------------------------------------------------------------------------------------------------ depth filter
+namespace {
+
+hso_seed seed_record(const Seq& s, const Seed& sd)
+{
+  const Feat& ft = s.feats[sd.feat];
+  const Frame& H = s.frames[ft.frame];
+  hso_seed h{};
+  h.ref_frame_id = H.dev_id;
+  h.level = ft.level; h.type = ft.type;
+  h.px[0] = ft.px[0]; h.px[1] = ft.px[1];
+  h.f[0] = ft.f[0]; h.f[1] = ft.f[1]; h.f[2] = ft.f[2];
+  h.grad[0] = ft.grad[0]; h.grad[1] = ft.grad[1];
+  h.T_ref_w = H.T.v; h.ref_exposure = H.exposure;
+  h.mu = sd.mu; h.sigma2 = sd.sigma2; h.b = sd.b;
+  return h;
+}
+
+}  // namespace
+
+void Bank::kill_seed(Seq& s, StepData& d, int i, bool keep_feature)
+{
+  Seed& sd = s.seeds[i];
+  if (!sd.alive) return;
+  sd.alive = false; s.n_dead_seeds++;
+  if (sd.slot >= 0) d.erase_slots.push_back(sd.slot);
+  for (Id fr : sd.seen) release_frame_deferred(s, d, fr);
+  for (Id fr : sd.before) release_frame_deferred(s, d, fr);
+  for (Id fr : sd.seen_before) release_frame_deferred(s, d, fr);
+  sd.seen.clear(); sd.before.clear(); sd.seen_before.clear();
+  (void)keep_feature;
+}
+
+void Bank::release_frame_deferred(Seq& s, StepData& d, Id fr)
+{
+  if (fr == kNone) return;
+  const int64_t dev = s.frames[fr].dev_id;
+  if (s.drop(fr)) d.released.push_back(dev);
+}
+
+void Bank::drop_sequence_seeds(int k)
+{
+  Seq& s = *seq_[k];
+  std::vector<int32_t> slots;
+  for (Seed& sd : s.seeds) if (sd.alive && sd.slot >= 0) slots.push_back(sd.slot);
+  if (!slots.empty()) check(hso_gpu_seed_table_erase(ctx_, seed_table_, slots.data(), (int)slots.size()), "DepthFilter");
+  s.seeds.clear(); s.n_dead_seeds = 0;
+}
+
+// DepthFilter::updateSeeds (src/depth_filter.cpp:330-509) for the frames of all sequences: the bookkeeping before the
+// observation, ONE observation of every live seed in its sequence's frame, the bookkeeping after it
+void Bank::observe_seeds(const std::vector<int>& who)
+{
+  par(who, [&](int k) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    // frame_prior_ (:332-350): the frames between keyframes, newest first; a keyframe opens the next batch's list
+    const int slot = d.make_kf ? s.batch + 1 : s.batch;
+    auto it = std::find_if(s.prior.begin(), s.prior.end(), [&](const std::pair<int, std::vector<Id>>& p) { return p.first == slot; });
+    if (it == s.prior.end()) { s.prior.emplace_back(slot, std::vector<Id>()); it = s.prior.end() - 1; }
+    it->second.insert(it->second.begin(), s.cur);
+    s.hold(s.cur);
+    for (size_t i = 0; i < s.prior.size();) {
+      if (s.prior[i].first + 5 > s.batch || !d.make_kf) { ++i; continue; }
+      for (Id fr : s.prior[i].second) release_frame_deferred(s, d, fr);
+      s.prior.erase(s.prior.begin() + (std::ptrdiff_t)i);
+    }
+    // seeds older than max_n_kfs keyframes (:368-401)
+    for (size_t i = 0; i < s.seeds.size(); i++) {
+      Seed& sd = s.seeds[i];
+      if (!sd.alive || s.batch - sd.batch <= cfg_.seed_max_kfs) continue;
+      if (sd.temp != kNone && sd.reprojected) s.points[sd.temp].seed_state = -1;
+      kill_seed(s, d, (int)i, sd.temp != kNone && sd.reprojected);
+    }
+  });
+  erase_slots(who);
+  int n_slots = 0, n_live = 0;
+  check(hso_gpu_seed_table_size(ctx_, seed_table_, &n_slots, &n_live), "DepthFilter");
+  if (n_slots == 0 || n_live == 0) return;
+  std::vector<hso_seed_frame> frames(seq_.size());
+  for (hso_seed_frame& f : frames) { f = hso_seed_frame{}; f.frame_id = -1; f.T_f_w = hso_se3{{0, 0, 0, 1}, {0, 0, 0}}; f.exposure_time = 1; }
+  bool want_px = false, tracing = false;
+  for (int k : who) {
+    const Seq& s = *seq_[k];
+    const Frame& C = s.frames[s.cur];
+    frames[k].frame_id = C.dev_id; frames[k].T_f_w = C.T.v; frames[k].exposure_time = C.exposure;
+    want_px |= step_[k]->make_kf;
+    tracing |= s.trace.on();
+  }
+  seed_brief_.resize((size_t)n_slots);
+  if (want_px) seed_px_.resize(2 * (size_t)n_slots);
+  std::vector<hso_seed> before; std::vector<hso_seed_out> full;
+  if (tracing) {
+    before.resize((size_t)n_slots); full.resize((size_t)n_slots);
+    check(hso_gpu_seed_table_read(ctx_, seed_table_, 0, n_slots, before.data()), "DepthFilter");
+  }
+  check(hso_gpu_seed_table_observe_groups(ctx_, &cam_.pod(), seed_table_, frames.data(), (int)frames.size(), px_error_angle_, seed_brief_.data(),
+                                          want_px ? seed_px_.data() : nullptr, tracing ? full.data() : nullptr), "DepthFilter");
+  n_calls_[6]++; n_items_[6] += (int64_t)who.size();
+  par(who, [&](int k) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    const Frame& C = s.frames[s.cur];
+    if (s.trace.on()) {
+      std::vector<hso_seed> in; std::vector<hso_seed_out> out;
+      for (const Seed& sd : s.seeds) if (sd.alive && sd.slot >= 0 && sd.slot < n_slots) { in.push_back(before[sd.slot]); out.push_back(full[sd.slot]); }
+      Trace& t = s.trace;
+      t.begin("seed_observe", 7);
+      t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.scalar("cur_frame_id", (double)C.dev_id); t.field("T_f_w", &C.T.v, sizeof(hso_se3));
+      t.scalar("exposure", C.exposure); t.scalar("px_error_angle", px_error_angle_);
+      t.field("seeds", in.data(), sizeof(hso_seed) * in.size()); t.field("out", out.data(), sizeof(hso_seed_out) * out.size());
+    }
+    // DepthFilter::observeDepthRow's effects on the seed (:593-673)
+    d.occupied.clear();
+    for (Seed& sd : s.seeds) {
+      if (!sd.alive || sd.slot < 0 || sd.slot >= n_slots) continue;
+      const hso_seed_brief& o = seed_brief_[sd.slot];
+      sd.updated = o.is_update != 0;
+      if (!sd.updated) continue;
+      if (sd.seen.size() < 15) { sd.seen.push_back(s.cur); s.hold(s.cur); }
+      if (!o.is_valid) sd.valid = false;
+      sd.mu = o.mu; sd.sigma2 = o.sigma2; sd.b = o.b;
+      if (o.result != 1) continue;
+      sd.n_dist++;
+      if (d.make_kf) {                                            // FeatureExtractor::setGridOccpuancy
+        hso_keypoint kp{};
+        kp.x = seed_px_[2 * (size_t)sd.slot]; kp.y = seed_px_[2 * (size_t)sd.slot + 1]; kp.species = HSO_KP_OCCUR;
+        d.occupied.push_back(kp);
+      }
+    }
+  });
+}
+
+void Bank::erase_slots(const std::vector<int>& who)
+{
+  std::vector<int32_t> slots;
+  for (int k : who) {
+    StepData& d = *step_[k];
+    slots.insert(slots.end(), d.erase_slots.begin(), d.erase_slots.end());
+    d.erase_slots.clear();
+    to_release_.insert(to_release_.end(), d.released.begin(), d.released.end());
+    d.released.clear();
+  }
+  if (!slots.empty()) check(hso_gpu_seed_table_erase(ctx_, seed_table_, slots.data(), (int)slots.size()), "DepthFilter");
+}
+
+// the convergence loop of updateSeeds (:405-497): activatePoint (+ seedOptimizer) for every converged seed of every sequence in
+// one device call, then the new candidate points
+void Bank::activate_seeds(const std::vector<int>& who)
+{
+  par(who, [&](int k) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    d.conv.clear(); d.act_seeds.clear(); d.act_targets.clear(); d.act_begin.assign(1, 0);
+    for (size_t i = 0; i < s.seeds.size(); i++) {
+      Seed& sd = s.seeds[i];
+      if (!sd.alive) continue;
+      if (std::sqrt(sd.sigma2) < sd.z_range / sd.converge) d.conv.push_back((int)i);
+      else if (!sd.valid) kill_seed(s, d, (int)i, false);         // "z_min is NaN" (:494-498)
+    }
+    for (int i : d.conv) {
+      const Seed& sd = s.seeds[i];
+      d.act_seeds.push_back(seed_record(s, sd));
+      for (const std::vector<Id>* lst : {&sd.seen_before, &sd.seen})
+        for (Id fr : *lst) {
+          hso_activate_target a{};
+          a.frame_id = s.frames[fr].dev_id; a.T_f_w = s.frames[fr].T.v; a.exposure = s.frames[fr].exposure;
+          d.act_targets.push_back(a);
+        }
+      d.act_begin.push_back((int32_t)d.act_targets.size());
+    }
+    d.act_out.assign(d.conv.size(), hso_activate_out{});
+  });
+  std::vector<hso_seed> seeds; std::vector<int32_t> begin(1, 0), n_mean; std::vector<hso_activate_target> targets;
+  std::vector<size_t> at;
+  for (int k : who) {
+    const StepData& d = *step_[k];
+    at.push_back(seeds.size());
+    for (size_t i = 0; i < d.conv.size(); i++) {
+      seeds.push_back(d.act_seeds[i]);
+      targets.insert(targets.end(), d.act_targets.begin() + d.act_begin[i], d.act_targets.begin() + d.act_begin[i + 1]);
+      begin.push_back((int32_t)targets.size());
+      n_mean.push_back((int32_t)seq_[k]->n_mean_converge);
+    }
+  }
+  std::vector<hso_activate_out> out(seeds.size());
+  if (!seeds.empty()) {
+    hso_activate_target none{};
+    check(hso_gpu_seed_activate_multi(ctx_, &cam_.pod(), seeds.data(), (int)seeds.size(), begin.data(), targets.empty() ? &none : targets.data(),
+                                      n_mean.data(), out.data(), nullptr), "DepthFilter::activatePoint");
+    n_calls_[7]++; n_items_[7] += (int64_t)who.size();
+  }
+  for (size_t w = 0; w < who.size(); w++) {
+    StepData& d = *step_[who[w]];
+    for (size_t i = 0; i < d.conv.size(); i++) d.act_out[i] = out[at[w] + i];
+  }
+  par(who, [&](int k) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    if (s.trace.on() && !d.conv.empty()) {
+      Trace& t = s.trace;
+      hso_activate_target none{};
+      t.begin("seed_activate", 6);
+      t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("seeds", d.act_seeds.data(), sizeof(hso_seed) * d.act_seeds.size());
+      t.field("target_begin", d.act_begin.data(), sizeof(int32_t) * d.act_begin.size());
+      t.field("targets", d.act_targets.empty() ? &none : d.act_targets.data(), sizeof(hso_activate_target) * d.act_targets.size());
+      t.scalar("n_mean_converge_frame", (double)s.n_mean_converge); t.field("out", d.act_out.data(), sizeof(hso_activate_out) * d.act_out.size());
+    }
+    for (size_t c = 0; c < d.conv.size(); c++) {
+      const int i = d.conv[c];
+      Seed& sd = s.seeds[i];
+      const hso_activate_out& o = d.act_out[c];
+      bool valid = o.is_valid != 0;                               // -1: activatePoint left the flag alone
+      if (o.activated) sd.mu = (float)o.opt_id;                   // :418-419
+      const Feat& ft = s.feats[sd.feat];
+      const Vector3d in_host = along(ft.f, 1.0 / sd.mu);
+      if (sd.mu < 1e-10 || in_host[2] < 1e-10) valid = false;     // :423-424
+      if (!valid) {
+        if (sd.temp != kNone && sd.reprojected) s.points[sd.temp].seed_state = -1;
+        kill_seed(s, d, i, false);
+        continue;
+      }
+      if (s.converge_hist.size() > (size_t)cfg_.max_fts) s.converge_hist.erase(s.converge_hist.begin());
+      s.converge_hist.push_back(sd.n_dist);
+      // the seed becomes a candidate point hosted by its feature (:447-463, MapPointCandidates::newCandidatePoint)
+      const Vector3d world = s.frames[ft.frame].T.inverse() * in_host;
+      const Id p = s.new_point(world, sd.feat, sd.mu, kPtCandidate);
+      Feat& host = s.feats[sd.feat];
+      host.point = p;
+      if (!host.linked) { host.linked = true; host.next = kNone; }   // else: still the oldest observation of the seed's temporary point
+      s.points[p].head = sd.feat; s.points[p].n_obs = 1;
+      s.touch_point(p); s.touch_obs(sd.feat);
+      if (sd.temp != kNone && sd.reprojected) s.points[sd.temp].seed_state = 1;
+      s.candidates.push_back(p);
+      kill_seed(s, d, i, true);
+    }
+    // nMeanConvergeFrame_ (:503-507)
+    if (s.converge_hist.size() > size_t(0.5 * cfg_.max_fts))
+      s.n_mean_converge = (size_t)(std::accumulate(s.converge_hist.begin(), s.converge_hist.end(), 0) / (int)s.converge_hist.size());
+    else s.n_mean_converge = 6;
+  });
+  erase_slots(who);
+}
+
+// FeatureExtractor::detect (src/feature_detection.cpp:408-497) for one new keyframe per sequence: candidates on the device (batched
+// per detection threshold), the oct-tree distribution on the host; sel[i] receives the selected keys of who[i]
+void Bank::detect(const std::vector<int>& who, const std::vector<Id>& frame, const std::vector<int>& thresh, bool init, int n_levels, int n_features,
+                  std::vector<std::vector<hso_keypoint>>& keys, std::vector<std::vector<hso_keypoint>>& sel)
+{
+  const int W = cam_.width(), H = cam_.height();
+  const int second_cap = ((W + 7) / 8) * ((H + 7) / 8);
+  sel.assign(who.size(), {});
+  std::vector<int> todo(who.size());
+  std::iota(todo.begin(), todo.end(), 0);
+  while (!todo.empty()) {
+    const int th = thresh[todo[0]];
+    std::vector<int> grp, rest;
+    for (int i : todo) (thresh[i] == th ? grp : rest).push_back(i);
+    todo.swap(rest);
+    std::vector<int64_t> ids;
+    for (int i : grp) ids.push_back(seq_[who[i]]->frames[frame[i]].dev_id);
+    const int n = (int)grp.size();
+    int corner_cap = 16384;
+    std::vector<hso_corner> co, fill; std::vector<hso_edgelet> ed;
+    std::vector<int32_t> nc((size_t)n * n_levels), ns((size_t)n * (init ? 1 : n_levels));
+    if (init) fill.resize((size_t)n * second_cap); else ed.resize((size_t)n * n_levels * second_cap);
+    for (;;) {
+      co.resize((size_t)n * n_levels * corner_cap);
+      const int rc = init ? hso_gpu_detect_candidates_init(ctx_, ids.data(), n, n_levels, th, co.data(), corner_cap, nc.data(), fill.data(), second_cap, ns.data())
+                          : hso_gpu_detect_candidates(ctx_, ids.data(), n, n_levels, th, co.data(), corner_cap, nc.data(), ed.data(), second_cap, ns.data());
+      check(rc, "FeatureExtractor");
+      n_calls_[9]++; n_items_[9] += n;
+      const int most = *std::max_element(nc.begin(), nc.end());
+      if (most <= corner_cap) break;
+      corner_cap = most;                                          // more corners than the first guess: once more with room for all
+    }
+    pool_->run(n, [&](int g) {
+      const int i = grp[g];
+      Seq& s = *seq_[who[i]];
+      const hso_corner* cg = co.data() + (size_t)g * n_levels * corner_cap;
+      const int32_t* ncg = nc.data() + (size_t)g * n_levels;
+      if (s.trace.on()) {
+        Trace& t = s.trace;
+        t.begin("detect_candidates", 5 + 2 * (uint32_t)n_levels + 1);
+        t.scalar("init", init ? 1 : 0); t.scalar("frame_id", (double)ids[g]); t.scalar("n_levels", n_levels); t.scalar("min_thresh", th);
+        t.field("corner_counts", ncg, sizeof(int32_t) * (size_t)n_levels);
+        for (int L = 0; L < n_levels; L++) t.field(("corners" + std::to_string(L)).c_str(), cg + (size_t)L * corner_cap, sizeof(hso_corner) * (size_t)ncg[L]);
+        if (init) {
+          t.field("fill", fill.data() + (size_t)g * second_cap, sizeof(hso_corner) * (size_t)ns[g]);
+          for (int L = 1; L < n_levels; L++) t.field("unused", nullptr, 0);
+          t.field("second_counts", &ns[g], sizeof(int32_t));
+        } else {
+          for (int L = 0; L < n_levels; L++)
+            t.field(("edgelets" + std::to_string(L)).c_str(), ed.data() + ((size_t)g * n_levels + L) * second_cap, sizeof(hso_edgelet) * (size_t)ns[(size_t)g * n_levels + L]);
+          t.field("second_counts", &ns[(size_t)g * n_levels], sizeof(int32_t) * (size_t)n_levels);
+        }
+      }
+      // allFeturesToDistribute_: the keys already there (occupancy), then per level the corners followed by the second kind
+      std::vector<hso_keypoint>& all = keys[i];
+      for (int L = 0; L < n_levels; L++) {
+        for (int j = 0; j < ncg[L]; j++) {
+          const hso_corner& c = cg[(size_t)L * corner_cap + j];
+          hso_keypoint kp{};
+          kp.x = (float)(c.x << L); kp.y = (float)(c.y << L); kp.response = c.response; kp.level = L; kp.species = HSO_KP_CORNER_HIGH;
+          all.push_back(kp);
+        }
+        if (init) {
+          for (int j = 0; L == 0 && j < ns[g]; j++) {
+            const hso_corner& c = fill[(size_t)g * second_cap + j];
+            hso_keypoint kp{};
+            kp.x = (float)c.x; kp.y = (float)c.y; kp.response = c.response; kp.level = 0; kp.species = HSO_KP_GRAD;
+            all.push_back(kp);
+          }
+        } else {
+          for (int j = 0; j < ns[(size_t)g * n_levels + L]; j++) {
+            const hso_edgelet& e = ed[((size_t)g * n_levels + L) * second_cap + j];
+            hso_keypoint kp{};
+            kp.x = (float)(e.x << L); kp.y = (float)(e.y << L); kp.response = e.grad; kp.level = L; kp.species = HSO_KP_EDGELET; kp.gx = e.gx; kp.gy = e.gy;
+            all.push_back(kp);
+          }
+        }
+      }
+      std::vector<hso_keypoint>& out = sel[i];
+      out.resize(all.size() + 1);
+      const int m = hso_gpu_select_octree(all.data(), (int)all.size(), 0, W, 0, H, n_features, out.data(), (int)out.size());
+      if (m < 0) throw std::runtime_error("FeatureExtractor: oct-tree selection failed");
+      out.resize((size_t)m);
+      if (s.trace.on()) {
+        Trace& t = s.trace;
+        t.begin("select_octree", 5);
+        t.field("keys", all.data(), sizeof(hso_keypoint) * all.size()); t.scalar("width", W); t.scalar("height", H); t.scalar("n_features", n_features);
+        t.field("out", out.data(), sizeof(hso_keypoint) * out.size());
+      }
+    });
+  }
+}
+
+// a selected key as a feature of `fr` (src/feature_detection.cpp:457-484)
+Feat Bank::feature_from_key(const hso_keypoint& kp, Id fr) const
+{
+  Feat ft;
+  ft.frame = fr;
+  ft.px[0] = kp.x; ft.px[1] = kp.y;
+  const Vector3d b = cam_.cam2world({ft.px[0], ft.px[1]});
+  ft.f[0] = b[0]; ft.f[1] = b[1]; ft.f[2] = b[2];
+  ft.level = (int8_t)kp.level;
+  if (kp.species == HSO_KP_CORNER_HIGH) ft.type = HSO_FTR_CORNER;
+  else {
+    ft.type = kp.species == HSO_KP_GRAD ? HSO_FTR_GRADIENT : HSO_FTR_EDGELET;
+    const double gx = kp.gx, gy = kp.gy, nrm = std::sqrt(gx * gx + gy * gy);   // fillingHole never sets gx / gy: the default direction stays
+    if (nrm > 0) { ft.grad[0] = gx / nrm; ft.grad[1] = gy / nrm; }
+  }
+  return ft;
+}
+
+// DepthFilter::addKeyframe -> initializeSeeds (src/depth_filter.cpp:146-205): new features away from the keyframe's own and from
+// the seeds just matched in it, one seed each
+void Bank::start_seeds(const std::vector<int>& who)
+{
+  std::vector<std::vector<hso_keypoint>> keys(who.size()), sel;
+  std::vector<Id> frame(who.size()); std::vector<int> thresh(who.size());
+  for (size_t i = 0; i < who.size(); i++) {
+    Seq& s = *seq_[who[i]];
+    StepData& d = *step_[who[i]];
+    const Frame& C = s.frames[s.cur];
+    s.kf_depth_mean = d.dist_mean; s.kf_depth_min = 0.5 * d.depth_min;        // src/frame_handler_mono.cpp:335-338
+    s.converge_thresh = d.n_inliers <= 70 ? 100.f : 200.f;
+    keys[i] = d.occupied;
+    for (Id f : C.fts) {                                          // FeatureExtractor::setExistingFeatures
+      hso_keypoint kp{};
+      kp.x = (float)s.feats[f].px[0]; kp.y = (float)s.feats[f].px[1]; kp.species = HSO_KP_OCCUR;
+      keys[i].push_back(kp);
+    }
+    frame[i] = s.cur; thresh[i] = (int)C.grad_mean;
+  }
+  detect(who, frame, thresh, false, cfg_.n_pyr_levels, cfg_.max_fts + 100, keys, sel);
+  pool_->run((int)who.size(), [&](int i) {
+    Seq& s = *seq_[who[i]];
+    StepData& d = *step_[who[i]];
+    ++s.batch;
+    const std::vector<Id>* before = nullptr;
+    for (const auto& p : s.prior) if (p.first == s.batch - 1) before = &p.second;
+    d.new_seeds.clear();
+    for (const hso_keypoint& kp : sel[i]) {
+      s.feats.push_back(feature_from_key(kp, s.cur));
+      Seed sd;
+      sd.feat = (Id)s.feats.size() - 1;
+      sd.batch = s.batch;
+      sd.mu = (float)(1.0 / (float)s.kf_depth_mean); sd.z_range = (float)(1.0 / (float)s.kf_depth_min);   // Seed::Seed, :49-68
+      sd.sigma2 = sd.z_range * sd.z_range / 36;
+      sd.converge = s.converge_thresh;
+      if (before) { sd.before = *before; for (Id fr : sd.before) s.hold(fr); }
+      s.seeds.push_back(sd);
+      d.new_seeds.push_back(seed_record(s, s.seeds.back()));
+    }
+  });
+  std::vector<hso_seed> rows; std::vector<int32_t> group;
+  for (int k : who) { const StepData& d = *step_[k]; rows.insert(rows.end(), d.new_seeds.begin(), d.new_seeds.end()); group.insert(group.end(), d.new_seeds.size(), k); }
+  if (rows.empty()) return;
+  int32_t first = 0;
+  check(hso_gpu_seed_table_append(ctx_, seed_table_, rows.data(), group.data(), (int)rows.size(), &first), "DepthFilter");
+  for (int k : who) {
+    Seq& s = *seq_[k];
+    const size_t n_new = step_[k]->new_seeds.size();
+    for (size_t j = 0; j < n_new; j++) s.seeds[s.seeds.size() - n_new + j].slot = first++;
+  }
+}
+
+// The seed branch of Reprojector::reprojectMap (src/reprojector.cpp:309-329, reprojectorSeeds :431-502): with fewer than 100
+// matches the nearly converged seeds are matched as well, per cell the one with the smallest variance that matches becomes a
+// temporary point observed in this frame.  The frame's feature list changes, so its pose is optimised again, value-passing.
+void Bank::seed_branch(const std::vector<int>& who)
+{
+  std::vector<int> again;
+  for (int k : who) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    Frame& C = s.frames[s.cur];
+    std::vector<int> pick; std::vector<hso_seed> in;
+    for (size_t i = 0; i < s.seeds.size(); i++) {
+      const Seed& sd = s.seeds[i];
+      if (!sd.alive || sd.reprojected || !(std::sqrt(sd.sigma2) < sd.z_range / cfg_.reproject_seed_thresh)) continue;
+      pick.push_back((int)i); in.push_back(seed_record(s, sd));
+    }
+    if (pick.empty()) continue;
+    std::vector<hso_reproj_point> proj(pick.size()); std::vector<hso_align_out> match(pick.size());
+    check(hso_gpu_seed_reproject_match(ctx_, &cam_.pod(), C.dev_id, &C.T.v, C.exposure, in.data(), (int)in.size(), cell_size_, grid_cols_, proj.data(),
+                                       match.data()), "Reprojector (seeds)");
+    if (s.trace.on()) {
+      Trace& t = s.trace;
+      t.begin("seed_reproject_match", 9);
+      t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.scalar("cur_frame_id", (double)C.dev_id); t.field("T_f_w", &C.T.v, sizeof(hso_se3));
+      t.scalar("exposure", C.exposure); t.field("seeds", in.data(), sizeof(hso_seed) * in.size());
+      t.scalar("cell_size", cell_size_); t.scalar("grid_n_cols", grid_cols_);
+      t.field("proj", proj.data(), sizeof(hso_reproj_point) * proj.size()); t.field("match", match.data(), sizeof(hso_align_out) * match.size());
+    }
+    std::vector<std::vector<int>> cell(cell_order_.size());
+    for (size_t j = 0; j < pick.size(); j++) if (proj[j].projected) cell[(size_t)proj[j].cell].push_back((int)j);
+    int n_matches = s.log.n_matches;
+    bool added = false;
+    for (size_t ci = 0; ci < cell.size(); ci++) {
+      std::vector<int>& in_cell = cell[(size_t)cell_order_[ci]];
+      std::stable_sort(in_cell.begin(), in_cell.end(), [&](int a, int b) { return s.seeds[pick[a]].sigma2 < s.seeds[pick[b]].sigma2; });
+      bool got = false;
+      for (int j : in_cell) {
+        if (!match[j].success) continue;
+        Seed& sd = s.seeds[pick[j]];
+        const Feat host = s.feats[sd.feat];
+        const Vector3d world = s.frames[host.frame].T.inverse() * along(host.f, 1.0 / sd.mu);
+        const Id p = s.new_point(world, sd.feat, sd.mu, kPtTemporary);
+        s.observe(p, sd.feat);                                    // Point(pos, ftr): the host feature is its first observation
+        Feat nf;
+        nf.frame = s.cur; nf.point = p;
+        nf.px[0] = match[j].px_cur[0]; nf.px[1] = match[j].px_cur[1];
+        const Vector3d b = cam_.cam2world({nf.px[0], nf.px[1]});
+        nf.f[0] = b[0]; nf.f[1] = b[1]; nf.f[2] = b[2];
+        nf.level = (int8_t)match[j].search_level;
+        if (host.type == HSO_FTR_EDGELET) {
+          nf.type = HSO_FTR_EDGELET;
+          const double gx = match[j].A_cur_ref[0] * host.grad[0] + match[j].A_cur_ref[1] * host.grad[1];
+          const double gy = match[j].A_cur_ref[2] * host.grad[0] + match[j].A_cur_ref[3] * host.grad[1];
+          const double nn = std::sqrt(gx * gx + gy * gy);
+          nf.grad[0] = gx / nn; nf.grad[1] = gy / nn;
+        } else nf.type = host.type == HSO_FTR_GRADIENT ? HSO_FTR_GRADIENT : HSO_FTR_CORNER;
+        C.loose.push_back(nf);
+        sd.reprojected = true; sd.temp = p;
+        s.points[p].seed_state = 0;
+        s.temps.push_back(p);                                     // MapPointCandidates::addPauseSeedPoint
+        s.log.n_seed_matches++;
+        got = added = true;
+        break;
+      }
+      if (got) ++n_matches;
+      if (n_matches >= cfg_.max_fts) break;
+    }
+    s.log.n_matches = n_matches;
+    if (added) again.push_back(k);
+    (void)d;
+  }
+  if (again.empty()) return;
+  // pose_optimizer::optimizeLevenbergMarquardt3rd over the complete feature lists
+  std::vector<std::vector<hso_pose_feat>> feats(again.size());
+  std::vector<std::vector<hso_se3>> poses(again.size());
+  std::vector<hso_pose_job> jobs(again.size());
+  std::vector<hso_pose_result> res(again.size());
+  std::vector<std::vector<uint8_t>> mask(again.size());
+  std::vector<uint8_t*> mask_ptr(again.size());
+  for (size_t i = 0; i < again.size(); i++) {
+    Seq& s = *seq_[again[i]];
+    const Frame& C = s.frames[s.cur];
+    std::vector<Id> host_frames;
+    for (const Feat& ft : C.loose) {
+      hso_pose_feat pf{};
+      pf.has_point = ft.point != kNone; pf.type = ft.type; pf.level = ft.level;
+      pf.f[0] = ft.f[0]; pf.f[1] = ft.f[1]; pf.f[2] = ft.f[2]; pf.grad[0] = ft.grad[0]; pf.grad[1] = ft.grad[1];
+      if (ft.point != kNone) {
+        const Point& P = s.points[ft.point];
+        const Feat& host = s.feats[P.host];
+        pf.temporary = P.kind == kPtTemporary;
+        pf.host_f[0] = host.f[0]; pf.host_f[1] = host.f[1]; pf.host_f[2] = host.f[2];
+        pf.idist = P.idist;
+        size_t h = 0;
+        while (h < host_frames.size() && host_frames[h] != host.frame) h++;
+        if (h == host_frames.size()) { host_frames.push_back(host.frame); poses[i].push_back(s.frames[host.frame].T.v); }
+        pf.host_pose = (int)h;
+      }
+      feats[i].push_back(pf);
+    }
+    hso_pose_job& j = jobs[i];
+    j = hso_pose_job{};
+    j.feats = feats[i].data(); j.n_feats = (int)feats[i].size(); j.poses_f_w = poses[i].data(); j.n_poses = (int)poses[i].size();
+    j.T_f_w = C.T.v; j.reproj_thresh = cfg_.poseoptim_thresh; j.n_iter = 12;
+    mask[i].assign(std::max(feats[i].size(), (size_t)1), 0);
+    mask_ptr[i] = mask[i].data();
+  }
+  check(hso_gpu_pose_optimize_batch(ctx_, &cam_.pod(), jobs.data(), (int)jobs.size(), res.data(), mask_ptr.data()), "pose_optimizer");
+  n_calls_[5]++; n_items_[5] += (int64_t)jobs.size();
+  for (size_t i = 0; i < again.size(); i++) {
+    Seq& s = *seq_[again[i]];
+    StepData& d = *step_[again[i]];
+    d.pose = res[i]; d.pose_mask = mask[i];
+    if (s.trace.on()) {
+      Trace& t = s.trace;
+      t.begin("pose_optimize", 8);
+      t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("feats", feats[i].data(), sizeof(hso_pose_feat) * feats[i].size());
+      t.field("poses", poses[i].data(), sizeof(hso_se3) * poses[i].size()); t.field("T_f_w", &jobs[i].T_f_w, sizeof(hso_se3));
+      t.scalar("reproj_thresh", jobs[i].reproj_thresh); t.scalar("n_iter", jobs[i].n_iter);
+      t.field("result", &res[i], sizeof(res[i])); t.field("mask", mask[i].data(), feats[i].size());
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ device mirror
+// the rows of the sequence tables that changed since the last flush, as the device's record types
+void Bank::flush_maps(const std::vector<int>& who)
+{
+  struct Patch { std::vector<hso_kf> kfs; std::vector<int32_t> pid, oid; std::vector<hso_map_point> pts; std::vector<hso_obs> obs; bool kf = false; };
+  std::vector<Patch> patch(who.size());
+  pool_->run((int)who.size(), [&](int i) {
+    Seq& s = *seq_[who[i]];
+    Patch& P = patch[i];
+    if (s.kfs_dirty) {
+      P.kf = true;
+      for (Id fr : s.dev_kfs) {
+        const Frame& F = s.frames[fr];
+        hso_kf r{};
+        r.frame_id = F.dev_id; r.T_f_w = F.T.v; r.exposure_time = F.exposure; r.keyframe_id = F.kf_id;
+        P.kfs.push_back(r);
+      }
+    }
+    for (Id p : s.dirty_pts) {
+      const Point& pt = s.points[p];
+      s.pt_flag[p] = 0;
+      if (pt.host == kNone) continue;
+      const Feat& host = s.feats[pt.host];
+      hso_map_point r{};
+      r.pos[0] = pt.pos[0]; r.pos[1] = pt.pos[1]; r.pos[2] = pt.pos[2];
+      r.idist = pt.idist;
+      r.host_f[0] = host.f[0]; r.host_f[1] = host.f[1]; r.host_f[2] = host.f[2];
+      r.host_kf = s.frames[host.frame].kf_row;
+      r.obs_begin = pt.head; r.obs_count = pt.n_obs;
+      if (r.host_kf < 0) continue;                                // hosted in a frame that never became a keyframe: not projectable
+      P.pid.push_back(p); P.pts.push_back(r);
+    }
+    s.dirty_pts.clear();
+    for (Id f : s.dirty_obs) {
+      const Feat& ft = s.feats[f];
+      s.obs_flag[f] = 0;
+      hso_obs r{};
+      r.kf = s.frames[ft.frame].kf_row; r.level = ft.level; r.type = ft.type; r.pad_ = ft.linked ? ft.next : -1;
+      r.px[0] = ft.px[0]; r.px[1] = ft.px[1]; r.f[0] = ft.f[0]; r.f[1] = ft.f[1]; r.f[2] = ft.f[2]; r.grad[0] = ft.grad[0]; r.grad[1] = ft.grad[1];
+      if (r.kf < 0) continue;
+      P.oid.push_back(f); P.obs.push_back(r);
+    }
+    s.dirty_obs.clear();
+  });
+  for (size_t i = 0; i < who.size(); i++) {
+    Seq& s = *seq_[who[i]];
+    Patch& P = patch[i];
+    if (P.kf) { check(hso_gpu_seqmap_set_keyframes(ctx_, s.map, P.kfs.data(), (int)P.kfs.size()), "Map"); s.kfs_dirty = false; }
+    if (!P.pid.empty() || !P.oid.empty())
+      check(hso_gpu_seqmap_patch(ctx_, s.map, P.pid.data(), P.pts.data(), (int)P.pid.size(), P.oid.data(), P.obs.data(), (int)P.oid.size()), "Map");
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ end of the frame
+// FrameHandlerMono::addImage's tail (:113-122) and FrameHandlerBase::finishFrameProcessingCommon (src/frame_handler_base.cpp:116-152)
+void Bank::finish(const std::vector<int>& who)
+{
+  for (int k : who) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    if (d.stage0 == kRunning || d.stage0 == kRelocalising) {
+      Frame& C = s.frames[s.cur];
+      if (!d.tracked) s.outcome = kFailure;                       // relocalisation found no keyframe / too few tracked features
+      if (d.ok) {
+        const Frame& L = s.frames[d.ref];
+        if (d.make_kf) { s.kfs.push_back(s.cur); s.kfs_dirty = true; }   // Map::addKeyframe
+        else s.regular++;
+        s.motion = C.T * L.T.inverse();                           // :287, :352
+        if (d.relocalised) s.stage = kRunning;
+      } else if (d.relocalised) C.T = d.reloc_pose;               // "reset to last well localized pose"
+      s.log.n_seeds = (int)s.seeds.size() - s.n_dead_seeds; s.log.n_candidates = (int)s.candidates.size();
+      if (s.outcome == kFailure) { s.stage = kRelocalising; s.quality = kInsufficient; }
+    } else if (s.outcome == kFailure) {
+      // a failed start: everything is dropped and the handler pauses (resetAll)
+      for (Frame& F : s.frames) if (F.in_use && F.dev_id >= 0) to_release_.push_back(F.dev_id);
+      drop_sequence_seeds(k);
+      s.reset_tables();
+      s.stage = kPaused; s.quality = kInsufficient; s.n_obs_last = 0;
+      continue;
+    }
+    // the new frame becomes the last one
+    const Id old = s.last;
+    s.last = s.cur; s.cur = kNone;
+    if (old != kNone && old != s.last) release_frame(s, old);
+    s.n_obs_last = s.frames[s.last].n_inliers;
+    // dead seeds leave the list once they are the majority (list order of the live ones is kept)
+    if (s.n_dead_seeds > 256 && s.n_dead_seeds * 2 > (int)s.seeds.size()) {
+      size_t keep = 0;
+      for (size_t i = 0; i < s.seeds.size(); i++) if (s.seeds[i].alive) { if (keep != i) s.seeds[keep] = std::move(s.seeds[i]); keep++; }
+      s.seeds.resize(keep); s.n_dead_seeds = 0;
+    }
+  }
+  // the resident table drops its erased slots once they are the majority
+  int n_slots = 0, n_live = 0;
+  if (hso_gpu_seed_table_size(ctx_, seed_table_, &n_slots, &n_live) == HSO_OK && n_slots > 4096 && n_live * 2 < n_slots) {
+    std::vector<int32_t> remap((size_t)n_slots);
+    check(hso_gpu_seed_table_compact(ctx_, seed_table_, remap.data()), "DepthFilter");
+    for (Seq* s : seq_) for (Seed& sd : s->seeds) if (sd.alive && sd.slot >= 0) sd.slot = remap[(size_t)sd.slot];
+  }
+}
+
+}  // namespace engine
+}  // namespace hso

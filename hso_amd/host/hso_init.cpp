@@ -566,138 +566,5 @@ void computeInitializeMatrix(const std::vector<Vector3d>& f_ref, const std::vect
   }
 }
 
-// ---------------------------------------------------------------------------------------------- KltHomographyInit
-namespace {
-// detectFeatures, src/initialization.cpp:183-223
-void detectFeatures(FramePtr frame, std::vector<Vector2d>& px_vec, std::vector<Vector3d>& f_vec, std::vector<Vector3d>& ftr_type)
-{
-  Features new_features;
-  FeatureExtractor featureExt(frame->cam_->width(), frame->cam_->height(), 20, 1, true);
-  featureExt.detect(frame.get(), 20, frame->gradMean_ + 0.5f, new_features);
-  px_vec.clear(); px_vec.reserve(new_features.size());
-  f_vec.clear(); f_vec.reserve(new_features.size());
-  for (Feature* ftr : new_features) {
-    ftr_type.push_back({ftr->grad[0], ftr->grad[1], ftr->type == Feature::EDGELET ? 1.0 : ftr->type == Feature::CORNER ? 0.0 : 2.0});
-    px_vec.push_back({(double)(float)ftr->px[0], (double)(float)ftr->px[1]});
-    f_vec.push_back(ftr->f);
-    delete ftr;
-  }
-}
-
-bool isInFrame(const AbstractCamera* cam, int x, int y, int boundary)     // include/hso/camera.h: isInFrame(Vector2i, boundary)
-{
-  return x >= boundary && x < cam->width() - boundary && y >= boundary && y < cam->height() - boundary;
-}
-}  // namespace
-
-InitResult KltHomographyInit::addFirstFrame(FramePtr frame_ref)
-{
-  reset();
-  ftr_type_.clear();
-  detectFeatures(frame_ref, px_ref_, f_ref_, ftr_type_);
-  if (px_ref_.size() < 200) return FAILURE;                     // :45-49
-  frame_ref_ = frame_ref;
-  px_cur_.insert(px_cur_.begin(), px_ref_.begin(), px_ref_.end());
-  frame_prev_ = frame_ref_;
-  px_prev_ = px_ref_;
-  return SUCCESS;
-}
-
-InitResult KltHomographyInit::addSecondFrame(FramePtr frame_cur)
-{
-  // trackKlt, :225-298: the device call returns the LK result and the patch check per point
-  const size_t n = px_prev_.size();
-  std::vector<float> a(2 * n), b(2 * n);
-  for (size_t i = 0; i < n; i++) { a[2 * i] = (float)px_prev_[i][0]; a[2 * i + 1] = (float)px_prev_[i][1]; b[2 * i] = (float)px_cur_[i][0]; b[2 * i + 1] = (float)px_cur_[i][1]; }
-  std::vector<hso_klt_result> res(n);
-  hso_klt_params kp{};
-  kp.win_size = 30; kp.max_level = 4; kp.max_iter = 30; kp.use_initial_flow = 1; kp.epsilon = 0.0001;
-  api::klt_track(frame_cur->ctx_, frame_prev_->id_, frame_cur->id_, a.data(), b.data(), (int)n, &kp, res.data());
-  {
-    std::vector<Vector2d> px_ref, px_cur;
-    std::vector<Vector3d> f_ref, ftr_type;
-    f_cur_.clear(); disparities_.clear();
-    for (size_t i = 0; i < n; i++) {
-      if ((res[i].status & (HSO_KLT_TRACKED | HSO_KLT_PATCH_OK)) != (HSO_KLT_TRACKED | HSO_KLT_PATCH_OK)) continue;
-      const Vector2d pc = {(double)res[i].px[0], (double)res[i].px[1]};
-      px_ref.push_back(px_ref_[i]); px_cur.push_back(pc); f_ref.push_back(f_ref_[i]); ftr_type.push_back(ftr_type_[i]);
-      f_cur_.push_back(frame_cur->cam_->cam2world(pc));
-      disparities_.push_back(std::hypot(px_ref_[i][0] - pc[0], px_ref_[i][1] - pc[1]));
-    }
-    px_ref_.swap(px_ref); px_cur_.swap(px_cur); f_ref_.swap(f_ref); ftr_type_.swap(ftr_type);
-    frame_prev_ = frame_cur;
-    px_prev_ = px_cur_;
-  }
-  n_tracked_ = disparities_.size();
-  if (disparities_.size() < init_min_tracked) return FAILURE;
-  {
-    std::vector<double> d = disparities_;
-    disparity_ = getMedian(d);
-  }
-  if (disparity_ < init_min_disparity) return NO_KEYFRAME;
-
-  computeInitializeMatrix(f_ref_, f_cur_, frame_ref_->cam_->errorMultiplier2(), poseoptim_thresh, inliers_, xyz_in_cur_, T_cur_from_ref_,
-                          &used_homography_);
-  if (inliers_.size() < init_min_inliers) return FAILURE;
-
-  // rescale the map so that the median scene depth equals mapScale (:97-104)
-  std::vector<double> depth_vec;
-  for (const Vector3d& p : xyz_in_cur_) depth_vec.push_back(p[2]);
-  const double scene_depth_median = getMedian(depth_vec);
-  const double sc = map_scale / scene_depth_median;
-  frame_cur->T_f_w_ = T_cur_from_ref_ * frame_ref_->T_f_w_;
-  {
-    const Matrix3d Rcw = rotation_matrix(frame_cur->T_f_w_);
-    const Vector3d pr = frame_ref_->pos(), pc = frame_cur->pos();
-    const Vector3d tn = scale(mat_vec(Rcw, add(pr, scale(sub(pc, pr), sc))), -1.0);
-    frame_cur->T_f_w_.v.t[0] = tn[0]; frame_cur->T_f_w_.v.t[1] = tn[1]; frame_cur->T_f_w_.v.t[2] = tn[2];
-  }
-  const SE3 T_world_cur = frame_cur->T_f_w_.inverse();
-  for (int id : inliers_) {                                     // :110-170
-    const Vector2d px_cur = px_cur_[id], px_ref = px_ref_[id];
-    const Vector3d& ft = ftr_type_[id];
-    if (!(isInFrame(frame_ref_->cam_, (int)px_cur[0], (int)px_cur[1], 10) && isInFrame(frame_ref_->cam_, (int)px_ref[0], (int)px_ref[1], 10) &&
-          xyz_in_cur_[id][2] > 0))
-      continue;
-    const Vector3d pos = T_world_cur * scale(xyz_in_cur_[id], sc);
-    Point* new_point = new Point();
-    new_point->pos_ = pos;
-    new_point->idist_ = 1.0 / norm(pos);                        // as written (:124): the reference frame sits at the origin when it is the first
-    Feature* ftr_cur = new Feature();
-    Feature* ftr_ref = new Feature();
-    ftr_cur->frame = frame_cur.get(); ftr_ref->frame = frame_ref_.get();
-    ftr_cur->point = new_point; ftr_ref->point = new_point;
-    ftr_cur->px = px_cur; ftr_ref->px = px_ref;
-    ftr_cur->level = 0; ftr_ref->level = 0;
-    if (ft[2] == 0) {
-      new_point->ftr_type_ = Point::FEATURE_CORNER;
-      ftr_cur->type = ftr_ref->type = Feature::CORNER;
-      ftr_cur->f = f_cur_[id]; ftr_ref->f = f_ref_[id];
-    } else if (ft[2] == 1) {
-      new_point->ftr_type_ = Point::FEATURE_EDGELET;
-      ftr_cur->type = ftr_ref->type = Feature::EDGELET;
-      ftr_cur->f = f_cur_[id]; ftr_ref->f = f_ref_[id];
-      ftr_cur->grad = ftr_ref->grad = {ft[0], ft[1]};
-    } else {
-      new_point->ftr_type_ = Point::FEATURE_GRADIENT;
-      ftr_cur->type = ftr_ref->type = Feature::GRADIENT;
-      ftr_cur->f = frame_cur->cam_->cam2world(px_cur);          // Feature(frame, point, px, level, GRADIENT): f from the camera model
-      ftr_ref->f = frame_ref_->cam_->cam2world(px_ref);
-    }
-    frame_cur->addFeature(ftr_cur);
-    frame_ref_->addFeature(ftr_ref);
-    new_point->addFrameRef(ftr_ref);
-    new_point->hostFeature_ = ftr_ref;
-  }
-  return SUCCESS;
-}
-
-void KltHomographyInit::reset()
-{
-  px_cur_.clear();
-  frame_ref_.reset();
-  frame_prev_.reset();
-}
-
 }  // namespace initialization
 }  // namespace hso

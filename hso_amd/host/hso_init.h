@@ -1,6 +1,6 @@
-// hso_init.h — the two-view start of a sequence: initialization::KltHomographyInit (reference include/hso/initialization.h,
-// src/initialization.cpp:39-223).  The image side (trackKlt: pyramidal LK + patchCheck) is one device call
-// (hso_gpu_klt_track); the geometry (computeInitializeMatrix :300-385, computeP3D :387-424, distancePointOnce :428-474,
+// hso_init.h — the geometry of the two-view start of a sequence (reference src/initialization.cpp:300-474; the frame handling
+// around it — KltHomographyInit::addFirstFrame / addSecondFrame, :39-223 — lives in the engine, hso_engine_init.cpp).  The image
+// side (trackKlt: pyramidal LK + patchCheck) is one device call (hso_gpu_klt_track); the geometry (computeInitializeMatrix :300-385, computeP3D :387-424, distancePointOnce :428-474,
 // vikit's Homography decomposition) is host code in plain C++17 like the rest of the mirror.
 //
 // What differs from the reference, and why: it estimates the essential matrix and the homography with OpenCV
@@ -14,7 +14,7 @@
 // not bit-level: the selected inliers and the pose agree with ground truth in the synthetic tests.
 #pragma once
 #include <vector>
-#include "hso_host.h"
+#include "hso_math.h"
 
 namespace hso {
 namespace initialization {
@@ -36,29 +36,6 @@ bool estimateEssential(const std::vector<Vector2d>& x1, const std::vector<Vector
 bool estimateHomography(const std::vector<Vector2d>& x1, const std::vector<Vector2d>& x2, double thresh, Matrix3d& H);
 bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& fts_c1, const std::vector<Vector2d>& fts_c2, double error_multiplier2,
                          double thresh, SE3& T_c2_from_c1);
-
-class KltHomographyInit {
-public:
-  FramePtr frame_ref_;
-  InitResult addFirstFrame(FramePtr frame_ref);     // :39-61
-  InitResult addSecondFrame(FramePtr frame_cur);    // :63-175
-  void reset();                                     // :177-181
-  // the constants Config holds in the reference (src/config.cpp:35-39)
-  double map_scale = 1.0, init_min_disparity = 40.0, poseoptim_thresh = 2.0;
-  size_t init_min_tracked = 50, init_min_inliers = 40;
-  // diagnostics of the last addSecondFrame
-  size_t n_tracked_ = 0;
-  double disparity_ = 0;
-  int used_homography_ = 0;
-  std::vector<int> inliers_;
-protected:
-  std::vector<Vector2d> px_ref_, px_cur_, px_prev_;         // cv::Point2f in the reference: values are kept in float precision
-  std::vector<Vector3d> f_ref_, f_cur_, ftr_type_;
-  std::vector<double> disparities_;
-  std::vector<Vector3d> xyz_in_cur_;
-  SE3 T_cur_from_ref_;
-  FramePtr frame_prev_;                                     // img_prev_ of the reference: the frame whose resident image KLT starts from
-};
 
 }  // namespace initialization
 }  // namespace hso

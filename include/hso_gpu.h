@@ -605,6 +605,14 @@ int hso_gpu_seed_table_compact(hso_gpu_ctx* ctx, int table, int32_t* remap);
  * keyframe observation needs for FeatureExtractor::setGridOccpuancy, :669-673) */
 int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
                                double px_error_angle, hso_seed_brief* brief_out, hso_seed_out* full_out);
+/* The same with (a) groups that sit a step out: frames[g].frame_id < 0 skips every seed of group g (state untouched, brief all
+ * zero); (b) px_out (n_slots x 2 floats, may be NULL): Matcher::px_cur_ of the seeds whose result is 1 — what a keyframe
+ * observation feeds to FeatureExtractor::setGridOccpuancy (src/depth_filter.cpp:669-673). */
+int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
+                                      double px_error_angle, hso_seed_brief* brief_out, float* px_out, hso_seed_out* full_out);
+/* Local BA moved keyframes (src/bundle_adjustment.cpp:826-834): refresh T_ref_w of every live seed hosted in one of these frames
+ * (the reference reads seed.ftr->frame->T_f_w_ at every observation, src/depth_filter.cpp:588) */
+int hso_gpu_seed_table_set_host_pose(hso_gpu_ctx* ctx, int table, const int64_t* frame_ids, const hso_se3* T_f_w, int n);
 /* the records of slots [first, first + n) as the table holds them now (convergence / activation read them at keyframe rate) */
 int hso_gpu_seed_table_read(hso_gpu_ctx* ctx, int table, int first, int n, hso_seed* seeds_out);
 
@@ -699,10 +707,66 @@ typedef struct hso_pose_chain {
   hso_pose_result* results;    /* [n_calls] */
   int32_t* n_feats;            /* [n_calls], may be NULL */
   uint8_t* outlier_mask;       /* may be NULL */
+  double* feat_f;              /* may be NULL: n_calls rows of max(max_fts, 1) * 3 doubles, row c holds the unit bearings the device
+                                  formed for the n_feats[c] features (cam2world of the refined pixel) — what Feature::f of the new
+                                  features must hold so that host and device agree bit for bit */
 } hso_pose_chain;
 int hso_gpu_reproject_select_pose_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
                                        int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
                                        int out_capacity, int32_t* begin_out, int32_t* counts_out, const hso_pose_chain* pose);
+
+/* ---- sequence maps: the whole map of a sequence resident in HBM, mirrored row for row from the caller's tables and patched in
+ *      place.  hso_gpu_map_store keeps a frozen projection list; the reference, however, decides per frame which keyframes'
+ *      points it projects and in which order (src/reprojector.cpp:124-202: the covisible keyframes of the last frame, then the
+ *      closest ones until ten), appends points between keyframes (converged seeds become candidates, :207-226) and threads every
+ *      new keyframe's features into its points' observation lists (Point::addFrameRef, src/point.cpp:78-82: push_front).  Here
+ *        - the point table is indexed by the caller's point id, the observation table by its feature id (a keyframe feature IS
+ *          the observation row); a point's observations form a linked list through the observation rows
+ *          (hso_map_point.obs_begin = first row, obs_count = length, hso_obs.pad_ = next row), so push_front / erase of one
+ *          observation patches one or two rows;
+ *        - hso_gpu_seqmap_patch scatters changed rows (asynchronous on the context stream; rows past the end grow the tables);
+ *        - per frame the caller names the points to project, in the reference's visiting order, as a list of point ids with
+ *          their quality keys (hso_map_frame) — 5 bytes per point in, the examined candidates out. ---- */
+typedef struct hso_map_frame {
+  int32_t map;                 /* which sequence map */
+  int32_t cur_keyframe_id;     /* Frame::keyFrameId_ of the current frame */
+  int64_t cur_frame_id;        /* resident current frame */
+  hso_se3 T_cur_w;
+  double cur_exposure_time;
+  const int32_t* point_ids;    /* host: rows of the point table in reprojectMap's visiting order */
+  const uint8_t* quality;      /* host: their keys (Point::type_ << 4) | Point::ftr_type_ (what the stored maps keep in pad_) */
+  int32_t n_points;
+  int32_t pad_;
+} hso_map_frame;
+int hso_gpu_seqmap_create(hso_gpu_ctx* ctx, int* map_out);
+int hso_gpu_seqmap_destroy(hso_gpu_ctx* ctx, int map);
+/* the keyframe table (whole table every time: a few dozen rows kept on the host side of the library; poses change with every
+ * local BA).  points' host_kf and observations' kf index it; every keyframe must be resident. */
+int hso_gpu_seqmap_set_keyframes(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, int n_kfs);
+/* row point_ids[i] of the point table = points[i]; row obs_ids[i] of the observation table = obs[i].  Either part may be empty.
+ * Asynchronous on the context stream: the rows are copied out of the caller's arrays before the call returns. */
+int hso_gpu_seqmap_patch(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, const hso_map_point* points, int n_points,
+                         const int32_t* obs_ids, const hso_obs* obs, int n_obs);
+int hso_gpu_seqmap_size(hso_gpu_ctx* ctx, int map, int* n_kfs, int* n_points, int* n_obs);
+/* parity / trace read-back of rows as the device holds them now */
+int hso_gpu_seqmap_read(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, int n_points, hso_map_point* points_out,
+                        const int32_t* obs_ids, int n_obs, hso_obs* obs_out);
+/* hso_gpu_reproject_select_pose_maps over sequence maps: per frame the listed points are projected, matched against their
+ * closest observation, put through the grid selection and the pose optimisation, nothing returning to the host in between.
+ * out / begin_out / counts_out / pose as there, with hso_match_brief.pad_ = the candidate's POSITION in its frame's list;
+ * projected_out (may be NULL): one byte per listed point, frames back to back: reprojectPoint's return value
+ * (src/reprojector.cpp:504-529), which the caller needs for the candidates' and temporary points' n_failed_reproj_ (:214-251).
+ * The pose job's keyframe table is compacted on the device to the host keyframes of the selected features (<= 128; the features of any further keyframe take no part in the optimisation). */
+int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_frame* frames, int n_frames, int cell_size,
+                                         int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
+                                         int out_capacity, int32_t* begin_out, int32_t* counts_out, uint8_t* projected_out,
+                                         const hso_pose_chain* pose);
+/* trace / parity hook: tables the last hso_gpu_reproject_select_pose_frames call left in the work area (valid until the next
+ * entry point that uses it): HSO_DBG_PROJ = hso_reproj_point per listed point, HSO_DBG_MATCH = hso_align_out per listed point,
+ * HSO_DBG_POSE_FEATS = n_frames rows of max(max_fts, 1) hso_pose_feat (host_pose = index into HSO_DBG_POSE_POSES' row),
+ * HSO_DBG_POSE_POSES = n_frames rows of 128 hso_se3, HSO_DBG_POSE_NPOSES = n_frames int32.  bytes must equal the table's size. */
+enum { HSO_DBG_PROJ = 0, HSO_DBG_MATCH = 1, HSO_DBG_POSE_FEATS = 2, HSO_DBG_POSE_POSES = 3, HSO_DBG_POSE_NPOSES = 4 };
+int hso_gpu_debug_fetch(hso_gpu_ctx* ctx, int what, void* out, size_t bytes);
 
 /* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
  *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,

@@ -73,6 +73,8 @@ int hso_vo_multi_set_first_frames(hso_vo_multi* m, const uint8_t* const* imgs, i
  * initialisation; its KLT call has no multi-sequence form and is serialised with the other sequences' device calls */
 int hso_vo_multi_start(hso_vo_multi* m, const uint8_t* which);
 int hso_vo_multi_add_images(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps);
+/* hso_vo_trace for one sequence of the bank */
+int hso_vo_multi_trace(hso_vo_multi* m, int sequence, const char* path);
 int hso_vo_multi_get_status(hso_vo_multi* m, int sequence, hso_vo_status* st);
 int hso_vo_multi_get_keyframes(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
 /* batched C-ABI calls issued so far and the per-sequence requests they carried, per kind: [0] frame upload, [1] frame release,
