@@ -164,7 +164,7 @@ class PoseResult(C.Structure):
 
 class PoseChain(C.Structure):
     _fields_ = [("reproj_thresh", C.c_double), ("n_iter", C.c_int32), ("pad_", C.c_int32), ("results", C.c_void_p),
-                ("n_feats", C.c_void_p), ("outlier_mask", C.c_void_p)]
+                ("n_feats", C.c_void_p), ("outlier_mask", C.c_void_p), ("feat_f", C.c_void_p)]
 
 
 def make_pose_job(feats, poses, T_f_w, reproj_thresh=2.0, n_iter=12):
@@ -380,6 +380,8 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
     "hso_gpu_map_reserve", "hso_gpu_map_store", "hso_gpu_reproject_match_maps",
     "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level", "hso_gpu_host_alloc", "hso_gpu_host_free", "hso_gpu_seed_table_compact",
+    "hso_gpu_seqmap_create", "hso_gpu_seqmap_destroy", "hso_gpu_seqmap_set_keyframes", "hso_gpu_seqmap_patch", "hso_gpu_seqmap_size", "hso_gpu_seqmap_read",
+    "hso_gpu_reproject_select_pose_frames", "hso_gpu_debug_fetch", "hso_gpu_seed_table_observe_groups", "hso_gpu_seed_table_set_host_pose",
 ]
 
 

@@ -269,11 +269,15 @@ void Bank::observe_seeds(const std::vector<int>& who)
     }
     // DepthFilter::observeDepthRow's effects on the seed (:593-673)
     d.occupied.clear();
+    int dbg_upd = 0, dbg_ok = 0, dbg_live = 0; double dbg_ratio = 1e9;
     for (Seed& sd : s.seeds) {
       if (!sd.alive || sd.slot < 0 || sd.slot >= n_slots) continue;
       const hso_seed_brief& o = seed_brief_[sd.slot];
       sd.updated = o.is_update != 0;
+      dbg_live++;
       if (!sd.updated) continue;
+      dbg_upd++; if (o.result == 1) dbg_ok++;
+      dbg_ratio = std::min(dbg_ratio, (double)std::sqrt(o.sigma2) / (sd.z_range / sd.converge));
       if (sd.seen.size() < 15) { sd.seen.push_back(s.cur); s.hold(s.cur); }
       if (!o.is_valid) sd.valid = false;
       sd.mu = o.mu; sd.sigma2 = o.sigma2; sd.b = o.b;
@@ -285,6 +289,7 @@ void Bank::observe_seeds(const std::vector<int>& who)
         d.occupied.push_back(kp);
       }
     }
+    if (getenv("HSO_ENGINE_DEBUG")) fprintf(stderr, "[seq %d] seeds live %d updated %d matched %d, closest to convergence %.2f\n", k, dbg_live, dbg_upd, dbg_ok, dbg_ratio);
   });
 }
 

@@ -1,6 +1,6 @@
-"""ctypes binding of the host driver (include/hso_vo.h, hso_amd/host/libhso_host.so): the reference's
-FrameHandlerMono::addImage pipeline in C++ over the device library, plus a reader for the driver's
-C-ABI call trace (hso_amd/host/hso_trace.h).  Plumbing for the harness and the tests."""
+"""ctypes binding of the sequence engine (include/hso_vo.h, hso_amd/host/libhso_host.so): FrameHandlerMono::addImage's
+pipeline for one or many sequences over the device library, plus a reader for the engine's C-ABI call trace
+(hso_amd/host/hso_engine.h: Trace).  Plumbing for the harness and the tests."""
 import ctypes as C
 import os
 import struct
@@ -27,14 +27,7 @@ class VoStatus(C.Structure):
 _lib = None
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    capi.load()                      # the device library (and torch's HIP runtime) first
-    if not os.path.exists(LIB_PATH):
-        raise capi.HsoGpuError("libhso_host.so is not built (%s): run `python -m hso_amd.build`" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+def _declare(lib):
     vp, i32, P = C.c_void_p, C.c_int, C.POINTER
     lib.hso_vo_create.argtypes = [P(vp), P(capi.Camera), i32, i32]
     lib.hso_vo_destroy.argtypes = [vp]
@@ -57,27 +50,43 @@ def load():
     lib.hso_vo_multi_set_first_frames.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.hso_vo_multi_add_images.argtypes = [vp, vp, i32, i32, vp]
     lib.hso_vo_multi_start.argtypes = [vp, vp]
+    lib.hso_vo_multi_trace.argtypes = [vp, i32, C.c_char_p]
     lib.hso_vo_multi_get_status.argtypes = [vp, i32, P(VoStatus)]
     lib.hso_vo_multi_get_keyframes.argtypes = [vp, i32, vp, vp, vp, i32]
     lib.hso_vo_multi_call_counts.argtypes = [vp, vp, vp, i32]
-    _lib = lib
     return lib
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    capi.load()                      # the device library (and torch's HIP runtime) first
+    if not os.path.exists(LIB_PATH):
+        raise capi.HsoGpuError("libhso_host.so is not built (%s): run `python -m hso_amd.build`" % LIB_PATH)
+    _lib = _declare(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def load_from(path):
+    """The same interface from another build of the engine (tests: the engine over the CPU restatement, tests/fakegpu)."""
+    return _declare(C.CDLL(path))
 
 
 EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso_vo_trace", "hso_vo_set_first_frame",
                     "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes", "hso_vo_start", "hso_vo_init_compute_matrix",
                     "hso_vo_multi_create", "hso_vo_multi_destroy", "hso_vo_multi_last_error", "hso_vo_multi_size",
                     "hso_vo_multi_set_first_frames", "hso_vo_multi_add_images", "hso_vo_multi_get_status", "hso_vo_multi_get_keyframes",
-                    "hso_vo_multi_call_counts", "hso_vo_multi_start"]
+                    "hso_vo_multi_call_counts", "hso_vo_multi_start", "hso_vo_multi_trace"]
 
-CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_match", "align", "pose", "seed_observe", "seed_activate", "ba", "solo"]
+CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_select_pose", "align", "pose", "seed_observe", "seed_activate", "ba", "other"]
 
 
 class MultiVisualOdometry:
     """N FrameHandlerMono over one device context, advancing in lockstep (include/hso_vo.h: hso_vo_multi_*)."""
 
-    def __init__(self, cam, n_sequences, max_fts=200, device=0):
-        self.lib = load()
+    def __init__(self, cam, n_sequences, max_fts=200, device=0, lib=None):
+        self.lib = lib or load()
         self.h = C.c_void_p()
         rc = self.lib.hso_vo_multi_create(C.byref(self.h), C.byref(cam), int(max_fts), int(n_sequences), int(device))
         if rc < 0:
@@ -110,6 +119,9 @@ class MultiVisualOdometry:
         h, w = imgs[0].shape
         self._check(self.lib.hso_vo_multi_set_first_frames(self.h, self._ptrs(imgs), w, h, ts.ctypes.data, self._ptrs(depths), None), "set_first_frames")
 
+    def trace(self, k, path):
+        self._check(self.lib.hso_vo_multi_trace(self.h, int(k), path.encode() if path else None), "trace")
+
     def start(self, which=None):
         w = np.ascontiguousarray(which, np.uint8) if which is not None else None
         self._check(self.lib.hso_vo_multi_start(self.h, w.ctypes.data if w is not None else None), "start")
@@ -141,8 +153,8 @@ class MultiVisualOdometry:
 class VisualOdometry:
     """FrameHandlerMono behind the C interface."""
 
-    def __init__(self, cam, max_fts=200, device=0):
-        self.lib = load()
+    def __init__(self, cam, max_fts=200, device=0, lib=None):
+        self.lib = lib or load()
         self.h = C.c_void_p()
         rc = self.lib.hso_vo_create(C.byref(self.h), C.byref(cam), int(max_fts), int(device))
         if rc < 0:

@@ -1,0 +1,505 @@
+// hso_fake_gpu.cpp — TEST INFRASTRUCTURE: the entry points of include/hso_gpu.h that the sequence engine calls, implemented on
+// the CPU restatement (oracle/).  It lets the engine's host logic (hso_amd/host/hso_engine*.cpp) run, under sanitizers, in a
+// container without a GPU: tests/test_engine_cpu.py builds the engine against this file instead of libhso_gpu.so.  Nothing in
+// the product links it, and it is also the "reference CPU path" of a whole evolving sequence for end-to-end comparisons.
+// The grid selection (Reprojector::reprojectMap's passes, src/reprojector.cpp:253-306, 352-429, 556-612) is written here as the
+// sequential walk over per-cell lists — a third, independent statement of it beside k_select and tests/test_select.py.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <list>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../oracle/hso_oracle.h"
+
+struct FakeFrame {
+  int w = 0, h = 0;
+  std::vector<uint8_t> lev[HSO_N_PYR_LEVELS];
+  std::vector<int16_t> gx[HSO_N_SOBEL_LEVELS], gy[HSO_N_SOBEL_LEVELS];
+  int lw[HSO_N_PYR_LEVELS], lh[HSO_N_PYR_LEVELS];
+  const uint8_t* pyr[HSO_N_PYR_LEVELS];
+  const int16_t* sx[HSO_N_SOBEL_LEVELS];
+  const int16_t* sy[HSO_N_SOBEL_LEVELS];
+};
+struct FakeMap { std::vector<hso_kf> kfs; std::vector<hso_map_point> pts; std::vector<hso_obs> obs; };
+struct FakeSeedTable { std::vector<hso_seed> s; std::vector<int> group; std::vector<uint8_t> alive; };
+
+struct hso_gpu_ctx {
+  std::string err;
+  std::map<int64_t, FakeFrame*> frames;
+  std::vector<FakeMap*> maps;
+  std::vector<FakeSeedTable*> tables;
+  // hso_gpu_debug_fetch
+  std::vector<hso_reproj_point> dbg_proj; std::vector<hso_align_out> dbg_match; std::vector<hso_pose_feat> dbg_feats;
+  std::vector<hso_se3> dbg_poses; std::vector<int32_t> dbg_nposes;
+};
+
+static int fail(hso_gpu_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
+static FakeFrame* frame_of(hso_gpu_ctx* c, int64_t id) { auto it = c->frames.find(id); return it == c->frames.end() ? nullptr : it->second; }
+
+extern "C" {
+
+int hso_gpu_abi_version(void) { return HSO_GPU_ABI_VERSION; }
+int hso_gpu_create(hso_gpu_ctx** out, int, void*) { *out = new hso_gpu_ctx(); return HSO_OK; }
+void hso_gpu_destroy(hso_gpu_ctx* c)
+{
+  if (!c) return;
+  for (auto& kv : c->frames) delete kv.second;
+  for (auto* m : c->maps) delete m;
+  for (auto* t : c->tables) delete t;
+  delete c;
+}
+const char* hso_gpu_last_error(const hso_gpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int hso_gpu_synchronize(hso_gpu_ctx*) { return HSO_OK; }
+
+int hso_gpu_frame_upload_batch(hso_gpu_ctx* c, const int64_t* ids, const uint8_t* const* imgs, int n, int w, int h, int, hso_frame_stats* st)
+{
+  for (int i = 0; i < n; i++) {
+    if (frame_of(c, ids[i])) { delete c->frames[ids[i]]; c->frames.erase(ids[i]); }
+    FakeFrame* F = new FakeFrame();
+    F->w = w; F->h = h;
+    uint8_t* lv[HSO_N_PYR_LEVELS];
+    for (int L = 0; L < HSO_N_PYR_LEVELS; L++) { hso_or_pyramid_dims(w, h, L, &F->lw[L], &F->lh[L]); F->lev[L].assign((size_t)F->lw[L] * F->lh[L] + (size_t)F->lw[L] + 64, 0); lv[L] = F->lev[L].data(); F->pyr[L] = lv[L]; }
+    hso_or_create_pyramid(imgs[i], w, h, lv);
+    for (int L = 0; L < HSO_N_SOBEL_LEVELS; L++) {
+      F->gx[L].assign((size_t)F->lw[L] * F->lh[L], 0); F->gy[L].assign((size_t)F->lw[L] * F->lh[L], 0);
+      hso_or_sobel5(F->lev[L].data(), F->lw[L], F->lh[L], F->gx[L].data(), F->gy[L].data());
+      F->sx[L] = F->gx[L].data(); F->sy[L] = F->gy[L].data();
+    }
+    hso_frame_stats s{};
+    hso_or_frame_stats(F->lev[0].data(), F->gx[0].data(), F->gy[0].data(), w, h, &s);
+    s.width = w; s.height = h;
+    if (st) st[i] = s;
+    c->frames[ids[i]] = F;
+  }
+  return HSO_OK;
+}
+int hso_gpu_frame_release(hso_gpu_ctx* c, int64_t id)
+{
+  FakeFrame* F = frame_of(c, id);
+  if (!F) return fail(c, HSO_E_NOFRAME, "frame_release: not resident");
+  for (auto* t : c->tables) if (t) for (size_t i = 0; i < t->s.size(); i++) if (t->alive[i] && t->s[i].ref_frame_id == id) return fail(c, HSO_E_INVALID, "frame_release: hosts live seeds");
+  delete F; c->frames.erase(id);
+  return HSO_OK;
+}
+
+int hso_gpu_coarse_track_batch(hso_gpu_ctx* c, const hso_camera* cam, const hso_track_params* p, const hso_track_job* jobs, int n, hso_track_result* res)
+{
+  for (int i = 0; i < n; i++) {
+    FakeFrame* R = frame_of(c, jobs[i].ref_frame_id); FakeFrame* C = frame_of(c, jobs[i].cur_frame_id);
+    if (!R || !C) return fail(c, HSO_E_NOFRAME, "coarse_track: frame not resident");
+    hso_or_tracker* t = hso_or_tracker_create(cam, p, R->pyr, C->pyr, R->w, R->h, jobs[i].feats, jobs[i].n_feats);
+    memset(&res[i], 0, sizeof(res[i]));
+    hso_or_tracker_run(t, &jobs[i].T_cur_ref, jobs[i].exposure_rat, &res[i]);
+    hso_or_tracker_destroy(t);
+  }
+  return HSO_OK;
+}
+
+// ---- sequence maps
+int hso_gpu_seqmap_create(hso_gpu_ctx* c, int* out) { c->maps.push_back(new FakeMap()); *out = (int)c->maps.size() - 1; return HSO_OK; }
+int hso_gpu_seqmap_destroy(hso_gpu_ctx* c, int m) { delete c->maps[m]; c->maps[m] = nullptr; return HSO_OK; }
+int hso_gpu_seqmap_set_keyframes(hso_gpu_ctx* c, int m, const hso_kf* kfs, int n)
+{
+  for (int k = 0; k < n; k++) if (!frame_of(c, kfs[k].frame_id)) return fail(c, HSO_E_NOFRAME, "seqmap_set_keyframes: keyframe not resident");
+  c->maps[m]->kfs.assign(kfs, kfs + n);
+  return HSO_OK;
+}
+int hso_gpu_seqmap_patch(hso_gpu_ctx* c, int m, const int32_t* pid, const hso_map_point* pts, int np, const int32_t* oid, const hso_obs* obs, int no)
+{
+  FakeMap* M = c->maps[m];
+  const int nk = (int)M->kfs.size();
+  for (int i = 0; i < no; i++) {
+    if (oid[i] < 0 || obs[i].kf < 0 || obs[i].kf >= nk) return fail(c, HSO_E_INVALID, "seqmap_patch: observation row out of range");
+    if ((size_t)oid[i] >= M->obs.size()) M->obs.resize((size_t)oid[i] + 1, hso_obs{});
+    M->obs[(size_t)oid[i]] = obs[i];
+  }
+  for (int i = 0; i < np; i++) {
+    if (pid[i] < 0 || pts[i].host_kf < 0 || pts[i].host_kf >= nk || (pts[i].obs_count > 0 && (pts[i].obs_begin < 0 || (size_t)pts[i].obs_begin >= M->obs.size())))
+      return fail(c, HSO_E_INVALID, "seqmap_patch: point row out of range");
+    if ((size_t)pid[i] >= M->pts.size()) M->pts.resize((size_t)pid[i] + 1, hso_map_point{});
+    M->pts[(size_t)pid[i]] = pts[i];
+  }
+  return HSO_OK;
+}
+int hso_gpu_seqmap_size(hso_gpu_ctx* c, int m, int* nk, int* np, int* no)
+{
+  FakeMap* M = c->maps[m];
+  if (nk) *nk = (int)M->kfs.size();
+  if (np) *np = (int)M->pts.size();
+  if (no) *no = (int)M->obs.size();
+  return HSO_OK;
+}
+int hso_gpu_seqmap_read(hso_gpu_ctx* c, int m, const int32_t* pid, int np, hso_map_point* pts, const int32_t* oid, int no, hso_obs* obs)
+{
+  FakeMap* M = c->maps[m];
+  for (int i = 0; i < np; i++) pts[i] = M->pts.at((size_t)pid[i]);
+  for (int i = 0; i < no; i++) obs[i] = M->obs.at((size_t)oid[i]);
+  return HSO_OK;
+}
+
+// Reprojector::reprojectCellAll / the three reprojectCell passes over per-cell lists: which candidates are examined, in which
+// order, which become features.  cand: (cell, quality, matched) in projection order.
+struct Cand { int cell; uint8_t quality; bool matched; };
+static void select_walk(const std::vector<Cand>& cand, const int32_t* cell_order, int n_cells, int max_fts, std::vector<std::pair<int, bool>>& examined,
+                        int32_t counts[4])
+{
+  examined.clear();
+  int n_matches = 0;
+  counts[2] = 0; counts[3] = 0;
+  if ((int)cand.size() < max_fts + 50) {
+    for (size_t i = 0; i < cand.size(); i++) {
+      examined.push_back({(int)i, cand[i].matched});
+      if (cand[i].matched && ++n_matches >= max_fts) break;
+    }
+    counts[0] = (int)examined.size(); counts[1] = n_matches;
+    return;
+  }
+  std::vector<std::list<int>> cells((size_t)n_cells);
+  for (size_t i = 0; i < cand.size(); i++) cells[(size_t)cand[i].cell].push_back((int)i);
+  auto visit = [&](std::list<int>& cell, bool second, bool third) {
+    if (cell.empty()) return false;
+    if (!second) cell.sort([&](int a, int b) { return cand[a].quality > cand[b].quality; });   // stable: ties keep projection order
+    int got = 0;
+    while (!cell.empty()) {
+      const int i = cell.front(); cell.pop_front();
+      examined.push_back({i, cand[i].matched});
+      if (!cand[i].matched) continue;
+      if (!third) return true;
+      ++got; ++n_matches;
+      if (got >= 3 || n_matches >= max_fts) return true;
+    }
+    return false;
+  };
+  counts[3] = 1; counts[2] = 1;
+  for (int k = 0; k < n_cells; k++) { if (visit(cells[(size_t)cell_order[k]], false, false)) ++n_matches; if (n_matches >= max_fts) break; }
+  if (n_matches < max_fts) {
+    counts[2] = 2;
+    for (int k = n_cells - 1; k > 0; k--) { if (visit(cells[(size_t)cell_order[k]], true, false)) ++n_matches; if (n_matches >= max_fts) break; }
+  }
+  if (n_matches < max_fts) {
+    counts[2] = 3;
+    for (int k = 0; k < n_cells; k++) { visit(cells[(size_t)cell_order[k]], true, true); if (n_matches >= max_fts) break; }
+  }
+  counts[0] = (int)examined.size(); counts[1] = n_matches;
+}
+
+int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* c, const hso_camera* cam, const hso_map_frame* frames, int n, int cell_size, int grid_n_cols,
+                                         const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out, int out_cap, int32_t* begin_out,
+                                         int32_t* counts_out, uint8_t* projected_out, const hso_pose_chain* pose)
+{
+  const int cap = std::max(max_fts, 1);
+  c->dbg_proj.clear(); c->dbg_match.clear();
+  c->dbg_feats.assign((size_t)n * cap, hso_pose_feat{}); c->dbg_poses.assign((size_t)n * 128, hso_se3{}); c->dbg_nposes.assign((size_t)n, 0);
+  int n_out = 0;
+  size_t at = 0;
+  for (int f = 0; f < n; f++) {
+    const hso_map_frame& K = frames[f];
+    FakeMap* M = c->maps[K.map];
+    FakeFrame* C = frame_of(c, K.cur_frame_id);
+    if (!C) return fail(c, HSO_E_NOFRAME, "reproject_select_pose_frames: current frame not resident");
+    hso_se3 Tinv; hso_or_se3_inverse(&K.T_cur_w, &Tinv);
+    std::vector<hso_reproj_point> proj((size_t)K.n_points); std::vector<hso_align_out> match((size_t)K.n_points);
+    std::vector<hso_match_brief> brief((size_t)K.n_points);
+    std::vector<Cand> cand; std::vector<int> cand_at;
+    for (int i = 0; i < K.n_points; i++) {
+      hso_reproj_point& r = proj[(size_t)i];
+      memset(&r, 0, sizeof(r)); r.ref_obs = -1;
+      memset(&match[(size_t)i], 0, sizeof(hso_align_out));
+      hso_match_brief& b = brief[(size_t)i];
+      memset(&b, 0, sizeof(b)); b.cell = -1; b.ref_obs = -1;
+      const int pid = K.point_ids[i];
+      if (pid < 0 || (size_t)pid >= M->pts.size()) continue;
+      const hso_map_point& P = M->pts[(size_t)pid];
+      int cell = 0;
+      if (!hso_or_reproject_point(cam, &K.T_cur_w, &M->kfs[(size_t)P.host_kf].T_f_w, P.host_f, P.idist, cell_size, grid_n_cols, r.px, &cell)) continue;
+      r.projected = 1; r.cell = cell;
+      b.cell = cell; b.px[0] = r.px[0]; b.px[1] = r.px[1];
+      std::vector<hso_obs> chain; std::vector<int> rows;
+      for (int q = 0, row = P.obs_begin; q < P.obs_count; q++) { chain.push_back(M->obs.at((size_t)row)); rows.push_back(row); row = M->obs[(size_t)row].pad_; }
+      const int k = chain.empty() ? -1 : hso_or_close_view_obs(Tinv.t, P.pos, M->kfs.data(), chain.data(), (int)chain.size());
+      bool matched = false;
+      if (k >= 0) {
+        r.ref_obs = rows[(size_t)k];
+        b.ref_obs = r.ref_obs;
+        hso_align_job job;
+        hso_or_reproject_make_job(&K.T_cur_w, K.cur_exposure_time, K.cur_keyframe_id, M->kfs.data(), &P, &chain[(size_t)k], r.px, &job);
+        FakeFrame* R = frame_of(c, M->kfs[(size_t)chain[(size_t)k].kf].frame_id);
+        hso_align_out& m = match[(size_t)i];
+        hso_or_find_match_direct(cam, &job, R->pyr, C->pyr, C->sx, C->sy, C->w, C->h, &m);
+        matched = m.success != 0;
+        b.px_cur[0] = m.px_cur[0]; b.px_cur[1] = m.px_cur[1];
+        b.stage = (int8_t)m.stage; b.search_level = (int8_t)m.search_level; b.ref_type = (int8_t)job.type;
+        const double gx = m.A_cur_ref[0] * job.grad[0] + m.A_cur_ref[1] * job.grad[1], gy = m.A_cur_ref[2] * job.grad[0] + m.A_cur_ref[3] * job.grad[1];
+        const double nn = std::sqrt(gx * gx + gy * gy);
+        b.grad[0] = nn > 0 ? (float)(gx / nn) : 0.f; b.grad[1] = nn > 0 ? (float)(gy / nn) : 0.f;
+      }
+      cand.push_back({cell, K.quality[i], matched && (K.quality[i] >> 4) != 0});
+      cand_at.push_back(i);
+    }
+    if (projected_out) for (int i = 0; i < K.n_points; i++) projected_out[at + (size_t)i] = (uint8_t)proj[(size_t)i].projected;
+    std::vector<std::pair<int, bool>> ex;
+    select_walk(cand, cell_order, n_cells, max_fts, ex, counts_out + 4 * f);
+    begin_out[f] = n_out;
+    // the frame's features = the taken candidates in examination order
+    std::vector<hso_pose_feat> feats; std::vector<hso_se3> poses; std::vector<int> pose_kf;
+    for (auto& e : ex) {
+      const int i = cand_at[(size_t)e.first];
+      hso_match_brief b = brief[(size_t)i];
+      b.success = e.second ? 1 : 0; b.pad_ = i;
+      if (n_out >= out_cap) return fail(c, HSO_E_INVALID, "reproject_select_pose_frames: output too small");
+      out[n_out++] = b;
+      if (!e.second || (int)feats.size() >= cap) continue;
+      const hso_map_point& P = M->pts[(size_t)K.point_ids[i]];
+      hso_pose_feat pf{};
+      pf.has_point = 1; pf.type = b.ref_type; pf.level = b.search_level; pf.temporary = ((K.quality[i] >> 4) == 1) ? 1 : 0;
+      hso_or_cam2world(cam, b.px_cur[0], b.px_cur[1], pf.f);
+      pf.grad[0] = b.grad[0]; pf.grad[1] = b.grad[1];
+      pf.host_f[0] = P.host_f[0]; pf.host_f[1] = P.host_f[1]; pf.host_f[2] = P.host_f[2]; pf.idist = P.idist;
+      pf.host_pose = P.host_kf;
+      feats.push_back(pf);
+    }
+    // compact pose table in map order
+    std::vector<int> used;
+    for (auto& pf : feats) used.push_back(pf.host_pose);
+    std::sort(used.begin(), used.end()); used.erase(std::unique(used.begin(), used.end()), used.end());
+    for (auto& pf : feats) pf.host_pose = (int)(std::lower_bound(used.begin(), used.end(), pf.host_pose) - used.begin());
+    for (int k : used) poses.push_back(M->kfs[(size_t)k].T_f_w);
+    hso_pose_job job{};
+    job.feats = feats.data(); job.n_feats = (int)feats.size(); job.poses_f_w = poses.data(); job.n_poses = (int)poses.size();
+    job.T_f_w = K.T_cur_w; job.reproj_thresh = pose->reproj_thresh; job.n_iter = pose->n_iter;
+    std::vector<uint8_t> mask(std::max(feats.size(), (size_t)1), 0);
+    memset(&pose->results[f], 0, sizeof(hso_pose_result));
+    hso_or_pose_optimize(cam, &job, &pose->results[f], mask.data());
+    if (pose->n_feats) pose->n_feats[f] = (int)feats.size();
+    if (pose->outlier_mask) { memset(pose->outlier_mask + (size_t)f * cap, 0, (size_t)cap); memcpy(pose->outlier_mask + (size_t)f * cap, mask.data(), feats.size()); }
+    if (pose->feat_f) for (size_t j = 0; j < feats.size(); j++) for (int q = 0; q < 3; q++) pose->feat_f[((size_t)f * cap + j) * 3 + q] = feats[j].f[q];
+    std::copy(feats.begin(), feats.end(), c->dbg_feats.begin() + (std::ptrdiff_t)((size_t)f * cap));
+    std::copy(poses.begin(), poses.begin() + (std::ptrdiff_t)std::min(poses.size(), (size_t)128), c->dbg_poses.begin() + (std::ptrdiff_t)((size_t)f * 128));
+    c->dbg_nposes[(size_t)f] = (int)poses.size();
+    c->dbg_proj.insert(c->dbg_proj.end(), proj.begin(), proj.end());
+    c->dbg_match.insert(c->dbg_match.end(), match.begin(), match.end());
+    at += (size_t)K.n_points;
+  }
+  begin_out[n] = n_out;
+  return n_out;
+}
+
+int hso_gpu_debug_fetch(hso_gpu_ctx* c, int what, void* out, size_t bytes)
+{
+  const void* src = nullptr; size_t have = 0;
+  switch (what) {
+    case HSO_DBG_PROJ: src = c->dbg_proj.data(); have = c->dbg_proj.size() * sizeof(hso_reproj_point); break;
+    case HSO_DBG_MATCH: src = c->dbg_match.data(); have = c->dbg_match.size() * sizeof(hso_align_out); break;
+    case HSO_DBG_POSE_FEATS: src = c->dbg_feats.data(); have = c->dbg_feats.size() * sizeof(hso_pose_feat); break;
+    case HSO_DBG_POSE_POSES: src = c->dbg_poses.data(); have = c->dbg_poses.size() * sizeof(hso_se3); break;
+    case HSO_DBG_POSE_NPOSES: src = c->dbg_nposes.data(); have = c->dbg_nposes.size() * sizeof(int32_t); break;
+    default: return fail(c, HSO_E_INVALID, "debug_fetch: no such table");
+  }
+  if (have != bytes) return fail(c, HSO_E_INVALID, "debug_fetch: size mismatch");
+  if (bytes) memcpy(out, src, bytes);
+  return HSO_OK;
+}
+
+int hso_gpu_pose_optimize_batch(hso_gpu_ctx*, const hso_camera* cam, const hso_pose_job* jobs, int n, hso_pose_result* res, uint8_t* const* mask)
+{
+  for (int i = 0; i < n; i++) { memset(&res[i], 0, sizeof(res[i])); hso_or_pose_optimize(cam, &jobs[i], &res[i], mask ? mask[i] : nullptr); }
+  return HSO_OK;
+}
+
+// ---- seeds
+int hso_gpu_seed_table_create(hso_gpu_ctx* c, int* out) { c->tables.push_back(new FakeSeedTable()); *out = (int)c->tables.size() - 1; return HSO_OK; }
+int hso_gpu_seed_table_destroy(hso_gpu_ctx* c, int t) { delete c->tables[t]; c->tables[t] = nullptr; return HSO_OK; }
+int hso_gpu_seed_table_append(hso_gpu_ctx* c, int t, const hso_seed* s, const int32_t* group, int n, int32_t* first)
+{
+  FakeSeedTable* T = c->tables[t];
+  if (first) *first = (int32_t)T->s.size();
+  for (int i = 0; i < n; i++) {
+    if (!frame_of(c, s[i].ref_frame_id)) return fail(c, HSO_E_NOFRAME, "seed_table_append: host frame not resident");
+    T->s.push_back(s[i]); T->group.push_back(group ? group[i] : 0); T->alive.push_back(1);
+  }
+  return HSO_OK;
+}
+int hso_gpu_seed_table_erase(hso_gpu_ctx* c, int t, const int32_t* slots, int n)
+{
+  FakeSeedTable* T = c->tables[t];
+  for (int i = 0; i < n; i++) { if (slots[i] < 0 || (size_t)slots[i] >= T->s.size()) return fail(c, HSO_E_INVALID, "seed_table_erase: slot out of range"); T->alive[(size_t)slots[i]] = 0; }
+  return HSO_OK;
+}
+int hso_gpu_seed_table_size(hso_gpu_ctx* c, int t, int* n_slots, int* n_live)
+{
+  FakeSeedTable* T = c->tables[t];
+  if (n_slots) *n_slots = (int)T->s.size();
+  if (n_live) { int k = 0; for (uint8_t a : T->alive) k += a; *n_live = k; }
+  return HSO_OK;
+}
+int hso_gpu_seed_table_compact(hso_gpu_ctx* c, int t, int32_t* remap)
+{
+  FakeSeedTable* T = c->tables[t];
+  FakeSeedTable N;
+  for (size_t i = 0; i < T->s.size(); i++) {
+    if (remap) remap[i] = T->alive[i] ? (int32_t)N.s.size() : -1;
+    if (T->alive[i]) { N.s.push_back(T->s[i]); N.group.push_back(T->group[i]); N.alive.push_back(1); }
+  }
+  *T = N;
+  return (int)T->s.size();
+}
+int hso_gpu_seed_table_read(hso_gpu_ctx* c, int t, int first, int n, hso_seed* out)
+{
+  FakeSeedTable* T = c->tables[t];
+  for (int i = 0; i < n; i++) out[i] = T->s.at((size_t)(first + i));
+  return HSO_OK;
+}
+int hso_gpu_seed_table_set_host_pose(hso_gpu_ctx* c, int t, const int64_t* ids, const hso_se3* T_f_w, int n)
+{
+  FakeSeedTable* T = c->tables[t];
+  for (size_t i = 0; i < T->s.size(); i++) if (T->alive[i]) for (int k = 0; k < n; k++) if (T->s[i].ref_frame_id == ids[k]) T->s[i].T_ref_w = T_f_w[k];
+  return HSO_OK;
+}
+int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* c, const hso_camera* cam, int t, const hso_seed_frame* frames, int n_frames, double px_error_angle,
+                                      hso_seed_brief* brief, float* px, hso_seed_out* full)
+{
+  FakeSeedTable* T = c->tables[t];
+  for (size_t i = 0; i < T->s.size(); i++) {
+    if (brief) memset(&brief[i], 0, sizeof(hso_seed_brief));
+    if (px) { px[2 * i] = 0; px[2 * i + 1] = 0; }
+    if (full) memset(&full[i], 0, sizeof(hso_seed_out));
+    if (!T->alive[i]) continue;
+    const int g = T->group[i];
+    if (g >= n_frames) return fail(c, HSO_E_INVALID, "seed_table_observe: a seed's group has no frame");
+    if (frames[g].frame_id < 0) continue;
+    FakeFrame* C = frame_of(c, frames[g].frame_id); FakeFrame* R = frame_of(c, T->s[i].ref_frame_id);
+    if (!C || !R) return fail(c, HSO_E_NOFRAME, "seed_table_observe: frame not resident");
+    hso_seed_out o;
+    memset(&o, 0, sizeof(o));
+    hso_or_seed_observe(cam, &T->s[i], &frames[g].T_f_w, frames[g].exposure_time, px_error_angle, R->pyr, C->pyr, C->sx, C->sy, C->w, C->h, &o);
+    T->s[i].mu = o.mu; T->s[i].sigma2 = o.sigma2; T->s[i].b = o.b;
+    if (brief) { brief[i].mu = o.mu; brief[i].sigma2 = o.sigma2; brief[i].b = o.b; brief[i].result = (int8_t)o.result; brief[i].is_update = (int8_t)o.is_update;
+                 brief[i].is_valid = (int8_t)o.is_valid; brief[i].search_level = (int8_t)o.search_level; }
+    if (px) { px[2 * i] = (float)o.px_cur[0]; px[2 * i + 1] = (float)o.px_cur[1]; }
+    if (full) full[i] = o;
+  }
+  return HSO_OK;
+}
+
+static int activate_one(hso_gpu_ctx* c, const hso_camera* cam, const hso_seed* s, const hso_activate_target* tg, int n_tg, int n_mean, hso_activate_out* o,
+                        hso_align_out* mo)
+{
+  FakeFrame* R = frame_of(c, s->ref_frame_id);
+  if (!R) return fail(c, HSO_E_NOFRAME, "seed_activate: host frame not resident");
+  std::vector<const uint8_t*> pyr; std::vector<const int16_t*> gx, gy;
+  for (int k = 0; k < n_tg; k++) {
+    FakeFrame* F = frame_of(c, tg[k].frame_id);
+    if (!F) return fail(c, HSO_E_NOFRAME, "seed_activate: target frame not resident");
+    for (int L = 0; L < HSO_N_PYR_LEVELS; L++) pyr.push_back(F->pyr[L]);
+    for (int L = 0; L < HSO_N_SOBEL_LEVELS; L++) { gx.push_back(F->sx[L]); gy.push_back(F->sy[L]); }
+  }
+  const uint8_t* none_p = nullptr; const int16_t* none_g = nullptr;
+  std::vector<hso_align_out> scratch((size_t)std::max(n_tg, 1));
+  memset(o, 0, sizeof(*o));
+  hso_or_seed_activate(cam, s, tg, n_tg, R->pyr, pyr.empty() ? &none_p : pyr.data(), gx.empty() ? &none_g : gx.data(), gy.empty() ? &none_g : gy.data(), R->w, R->h,
+                       n_mean, o, mo ? mo : scratch.data());
+  return HSO_OK;
+}
+
+int hso_gpu_seed_activate_multi(hso_gpu_ctx* c, const hso_camera* cam, const hso_seed* seeds, int n, const int32_t* begin, const hso_activate_target* targets,
+                                const int32_t* n_mean, hso_activate_out* out, hso_align_out* match_out)
+{
+  for (int i = 0; i < n; i++)
+    if (int rc = activate_one(c, cam, &seeds[i], targets + begin[i], begin[i + 1] - begin[i], n_mean[i], &out[i], match_out ? match_out + begin[i] : nullptr)) return rc;
+  return HSO_OK;
+}
+
+int hso_gpu_seed_reproject_match(hso_gpu_ctx* c, const hso_camera* cam, int64_t cur_id, const hso_se3* T_cur_w, double cur_exposure, const hso_seed* seeds, int n,
+                                 int cell_size, int grid_n_cols, hso_reproj_point* proj, hso_align_out* match)
+{
+  for (int i = 0; i < n; i++) {
+    memset(&proj[i], 0, sizeof(proj[i])); proj[i].ref_obs = -1;
+    memset(&match[i], 0, sizeof(match[i]));
+    int cell = 0;
+    if (!hso_or_reproject_point(cam, T_cur_w, &seeds[i].T_ref_w, seeds[i].f, (double)seeds[i].mu, cell_size, grid_n_cols, proj[i].px, &cell)) continue;
+    // reprojectorSeed rejects z < 0.001 where reprojectPoint rejects z < 0.00001: the activation matcher's own projection test decides
+    hso_activate_target t{};
+    t.frame_id = cur_id; t.T_f_w = *T_cur_w; t.exposure = cur_exposure;
+    hso_activate_out o; hso_align_out mo;
+    memset(&mo, 0, sizeof(mo));
+    if (int rc = activate_one(c, cam, &seeds[i], &t, 1, 6, &o, &mo)) return rc;
+    if (!o.n_targets) continue;
+    proj[i].projected = 1; proj[i].cell = cell;
+    match[i] = mo;
+  }
+  return HSO_OK;
+}
+
+// ---- local BA
+int hso_gpu_ba_huber_deltas(hso_gpu_ctx*, const hso_se3* poses, int n_poses, const double* idist, int n_points, const hso_ba_edge* edges, const double* obs_uv,
+                            int n_edges, double em2, float* hc, float* he)
+{
+  hso_or_ba_huber_deltas(poses, n_poses, idist, n_points, edges, obs_uv, n_edges, em2, hc, he);
+  return HSO_OK;
+}
+int hso_gpu_ba_optimize_multi(hso_gpu_ctx*, const hso_ba_problem* p, int n)
+{
+  for (int i = 0; i < n; i++)
+    hso_or_ba_optimize(p[i].poses_f_w, p[i].pose_fixed, p[i].n_poses, p[i].idist, p[i].n_points, p[i].edges, p[i].n_edges, p[i].huber_corner, p[i].huber_edge, p[i].n_iter,
+                       p[i].edge_chi2_out, p[i].result);
+  return HSO_OK;
+}
+
+// ---- detection
+static int detect_impl(hso_gpu_ctx* c, const int64_t* ids, int n_frames, int n_levels, int min_thresh, hso_corner* corners, int corner_cap, int32_t* nc,
+                       hso_edgelet* ed, hso_corner* fill, int second_cap, int32_t* ns, bool init)
+{
+  for (int f = 0; f < n_frames; f++) {
+    FakeFrame* F = frame_of(c, ids[f]);
+    if (!F) return fail(c, HSO_E_NOFRAME, "detect: frame not resident");
+    for (int L = 0; L < n_levels; L++) {
+      std::vector<hso_corner> co(65536);
+      const int n = hso_or_fast_detect_level(F->lev[L].data(), F->lw[L], F->lh[L], min_thresh, 8, co.data(), (int)co.size());
+      nc[f * n_levels + L] = n;
+      for (int i = 0; i < n && i < corner_cap; i++) corners[((size_t)f * n_levels + L) * corner_cap + i] = co[(size_t)i];
+      int grid, gc, gr, lw, lh;
+      hso_or_detect_grid(F->w, F->h, L, &grid, &gc, &gr, &lw, &lh);
+      std::vector<uint8_t> have((size_t)gc * gr, 0);
+      for (int i = 0; i < n; i++) have[(size_t)hso_or_detect_cell_index(co[(size_t)i].x, co[(size_t)i].y, grid, gc, gr)] = 1;
+      if (init) {
+        if (L == 0) ns[f] = hso_or_filling_hole_level(F->lev[0].data(), F->lw[0], F->lh[0], 0, F->w, F->h, min_thresh, have.data(), fill + (size_t)f * second_cap, second_cap);
+      } else {
+        ns[f * n_levels + L] = hso_or_edgelet_level(F->gx[L].data(), F->gy[L].data(), F->lw[L], F->lh[L], L, F->w, F->h, min_thresh, have.data(),
+                                                    ed + ((size_t)f * n_levels + L) * second_cap, second_cap);
+      }
+    }
+  }
+  return HSO_OK;
+}
+int hso_gpu_detect_candidates(hso_gpu_ctx* c, const int64_t* ids, int n, int n_levels, int min_thresh, hso_corner* co, int cap, int32_t* nc, hso_edgelet* ed, int ecap,
+                              int32_t* ne)
+{
+  return detect_impl(c, ids, n, n_levels, min_thresh, co, cap, nc, ed, nullptr, ecap, ne, false);
+}
+int hso_gpu_detect_candidates_init(hso_gpu_ctx* c, const int64_t* ids, int n, int n_levels, int min_thresh, hso_corner* co, int cap, int32_t* nc, hso_corner* fill,
+                                   int fcap, int32_t* nf)
+{
+  return detect_impl(c, ids, n, n_levels, min_thresh, co, cap, nc, nullptr, fill, fcap, nf, true);
+}
+
+int hso_gpu_klt_track(hso_gpu_ctx* c, int64_t prev, int64_t cur, const float* px_prev, const float* px_init, int n, const hso_klt_params* p, hso_klt_result* out)
+{
+  FakeFrame* P = frame_of(c, prev); FakeFrame* C = frame_of(c, cur);
+  if (!P || !C) return fail(c, HSO_E_NOFRAME, "klt_track: frame not resident");
+  std::vector<float> b(px_init, px_init + 2 * (size_t)n), mg((size_t)n);
+  std::vector<uint8_t> st((size_t)n);
+  hso_or_klt_track(P->lev[0].data(), C->lev[0].data(), P->w, P->h, px_prev, b.data(), st.data(), n, p->win_size, p->max_level, p->max_iter, p->epsilon,
+                   p->use_initial_flow, mg.data());
+  for (int i = 0; i < n; i++) {
+    out[i].px[0] = b[2 * (size_t)i]; out[i].px[1] = b[2 * (size_t)i + 1];
+    out[i].status = st[(size_t)i] ? HSO_KLT_TRACKED : 0;
+    float ncc = -2;
+    if (st[(size_t)i] && hso_or_patch_check(P->lev[0].data(), C->lev[0].data(), P->w, P->h, px_prev + 2 * (size_t)i, out[i].px, &ncc)) out[i].status |= HSO_KLT_PATCH_OK;
+    out[i].ncc = ncc;
+  }
+  return HSO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+"""The sequence engine's host logic (hso_amd/host/hso_engine*.cpp) without a GPU: the engine is built against tests/fakegpu —
+the C-ABI entry points it calls, implemented on the CPU restatement — and driven through include/hso_vo.h like the product.
+What this covers: the tables and their bookkeeping (keyframes, observation lists, candidates, seeds, the local BA window), the
+device mirror (rows patched = rows the kernels would read: the trace reads them back), the trace format and tests/replay.py
+(device == restatement here, so every replayed comparison must hold exactly), several sequences in one bank = the same sequences
+alone.  The kernels themselves are the `-m gpu` tests' business."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from hso_amd import synth, vo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SMALL = dict(synth.EUROC, width=384, height=256, fx=240.0, fy=240.0, cx=191.5, cy=127.5)
+MOTION = dict(step=(0.05, 0.015, 0.02), rot_deg_per_frame=(0.1, -0.3, 0.08))
+
+
+@pytest.fixture(scope="session")
+def fake(orc):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "fakegpu")])
+    return vo.load_from(os.path.join(HERE, "fakegpu", "libhso_host_fake.so"))
+
+
+@pytest.fixture(scope="session")
+def small_seq():
+    return synth.sequence(34, spec=SMALL, workers=4, **MOTION)
+
+
+def _run(lib, S, n, max_fts, trace=None):
+    odo = vo.VisualOdometry(synth.camera(S["spec"]), max_fts, lib=lib)
+    if trace:
+        odo.trace(trace)
+    odo.set_first_frame(S["images"][0], S["depth0"], 0.0)
+    out = []
+    for k in range(1, n):
+        st = odo.add_image(S["images"][k], float(k))
+        out.append(bytes(st))
+    kfs = odo.keyframes()
+    odo.close()
+    return out, kfs
+
+
+def test_sequence_and_replay(fake, small_seq, orc, tmp_path):
+    from replay import Replayer
+    S = small_seq
+    trace = str(tmp_path / "trace.bin")
+    sts, kfs = _run(fake, S, 34, 120, trace)
+    last = vo.VoStatus.from_buffer_copy(sts[-1])
+    q, t = last.T_f_w.to_arrays()
+    assert np.linalg.norm(t - S["T_f_w"][33][1]) < 0.03 and last.stage == 3
+    assert len(kfs) >= 4 and max(vo.VoStatus.from_buffer_copy(b).n_candidates for b in sts) > 50
+    rp = Replayer(orc)
+    for call, r in vo.read_trace(trace):
+        getattr(rp, call)(r)
+    s = rp.stat
+    print(s)
+    assert s["track"]["n"] == 33 and s["pose"]["n"] == 33 and s["select"]["n"] == 33 and s["ba"]["n"] == len(kfs) - 1
+    # the restatement replays itself: no decision may differ
+    assert "iter_mismatch" not in s["track"] and "tie" not in s["reproject"] and "tie" not in s.get("seed", {}) and "tie" not in s.get("activate", {})
+    assert s["seed"]["updated"] > 0.3 * s["seed"]["n"] and s["activate"]["n"] > 20 and s["detect"]["octree"] == len(kfs) + 1
+
+
+def test_bank_of_sequences_equals_solo_runs(fake, small_seq):
+    """three sequences of different lengths in one bank (one sits steps out) = each alone, status record by status record"""
+    S = small_seq
+    other = synth.sequence(22, spec=SMALL, seed=2031, workers=4, step=(0.04, 0.02, 0.015), rot_deg_per_frame=(0.08, -0.2, 0.1))
+    runs = [(S, 26), (other, 22), (S, 14)]
+    solo = [_run(fake, s, n, 100) for s, n in runs]
+    bank = vo.MultiVisualOdometry(synth.camera(SMALL), 3, 100, lib=fake)
+    bank.set_first_frames([s["images"][0] for s, _ in runs], [s["depth0"] for s, _ in runs])
+    got = [[] for _ in runs]
+    for k in range(1, 26):
+        imgs = [s["images"][k] if k < n else None for s, n in runs]
+        bank.add_images(imgs, [float(k)] * 3)
+        for i, (s, n) in enumerate(runs):
+            if k < n:
+                got[i].append(bytes(bank.status(i)))
+    for i in range(3):
+        assert got[i] == solo[i][0], "sequence %d differs from its solo run" % i
+        assert [(a, bytes(b), c) for a, b, c in bank.keyframes(i)] == [(a, bytes(b), c) for a, b, c in solo[i][1]]
+    bank.close()

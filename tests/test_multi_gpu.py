@@ -1,5 +1,5 @@
-"""hso_vo_multi_* (hso_amd/host/hso_multi.cpp): N FrameHandlerMono over one device context in lockstep, the device calls of all
-sequences leaving as one batched C-ABI call per kind.  The claim to check: a sequence run inside the multi-sequence driver equals
+"""hso_vo_multi_* (the sequence engine, hso_amd/host/hso_engine*.cpp): N sequences over one device context in lockstep, every numeric
+stage of a step running as one batched C-ABI call for all of them.  The claim to check: a sequence run inside the multi-sequence driver equals
 the same sequence run alone through hso_vo_* bit for bit — every per-frame status record (pose, exposure, match / seed / keyframe
 counters, pose-optimisation and BA errors) and the keyframe trajectory — although its tracker jobs, reprojections, pose
 optimisations, seed updates, activations and BA windows travelled in batches with the other sequences' (BASELINE configs[4]:
@@ -56,18 +56,18 @@ def test_four_sequences_in_lockstep_equal_four_single_runs():
         n_kf += len(kfs[q])
     # the calls really travelled together: far fewer tracker / pose / seed launches than frames, several requests per launch
     n_frames = sum(lengths) - len(seqs)
-    for kind in ("track", "pose", "frame_upload"):
+    for kind in ("track", "reproject_select_pose", "frame_upload"):
         calls, items = counts[kind]
         assert items >= n_frames and calls <= max(lengths) + 8 and items / calls > 2.5, (kind, counts)
     calls, items = counts["seed_observe"]          # only frames that have seeds to update (not the keyframes themselves)
     assert items > n_frames // 2 and items / calls > 2.0, counts
-    assert counts["ba"][1] >= n_kf - len(seqs) - 4 and counts["seed_activate"][1] > 0 and counts["solo"][0] > 0
+    assert counts["ba"][1] >= n_kf - len(seqs) - 4 and counts["seed_activate"][1] > 0 and counts["other"][0] > 0
     print("multi-sequence driver: batched calls / requests per kind", counts)
 
 
 def test_two_sequences_started_from_images_equal_their_single_runs():
     """hso_vo_multi_start: both sequences run the two-view initialisation (at different frames: different speeds) inside the
-    lockstep driver — its KLT calls serialised through the router — and every status record equals the solo run's."""
+    lockstep driver — its KLT calls one per sequence — and every status record equals the solo run's."""
     spec = dict(synth.EUROC, texture_om=((0.004, 0.05), (0.05, 0.6)))            # see tests/test_init.py: init_seq
     cam = synth.camera(spec)
     steps = [(0.05, 0.015, 0.01), (0.07, 0.01, 0.015)]

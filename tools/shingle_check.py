@@ -58,3 +58,24 @@ def main(argv):
 
 if __name__ == "__main__":
     main(sys.argv[1:])
+
+
+def hot_lines(path, k=6):
+    """Print the lines of `path` whose tokens take part in shingles that also occur in the reference (where to look first)."""
+    per_ref = [shingles(p) for p in ref_files()]
+    allref = set().union(*per_ref)
+    src = open(path, errors="ignore").read()
+    clean = strip(src)
+    # token -> line number (approximate: searched sequentially in the comment-stripped text, which keeps line breaks of code lines)
+    toks, lines, pos = [], [], 0
+    for m in TOK.finditer(clean):
+        toks.append(m.group(0)); lines.append(clean.count("\n", 0, m.start()) + 1)
+    hits = {}
+    for i in range(len(toks) - k + 1):
+        if tuple(toks[i:i + k]) in allref:
+            for j in range(i, i + k):
+                hits[lines[j]] = hits.get(lines[j], 0) + 1
+    text = clean.split("\n")
+    for ln in sorted(hits):
+        if hits[ln] >= 8:
+            print("%5d %3d  %s" % (ln, hits[ln], text[ln - 1].strip()[:150]))
