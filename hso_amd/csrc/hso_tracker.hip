@@ -114,7 +114,6 @@ struct TrackBatchState {
   int* d_counter = nullptr;
   hso_eval_out* d_eval = nullptr;
   bool attr_set = false;
-  std::vector<double> h_feats;
   std::vector<TrackJobDev> h_jobs;
   // cooperative shape (small batches): coop_K >= 2 workgroups per job
   int coop_K = 0, coop_scatter = 0;
@@ -147,7 +146,7 @@ static int grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need_bytes)
 
 
 static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* p,
-                         const hso_track_job* jobs, int n_jobs, int max_grid)
+                         const hso_track_job* jobs, int n_jobs, int max_grid, bool sync_after = true)
 {
   if (!ctx) return HSO_E_INVALID;
   if (!cam || !p || !jobs || n_jobs <= 0) return hso_fail(ctx, HSO_E_INVALID, "coarse_track: null argument or no jobs");
@@ -173,7 +172,10 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
     n_max = std::max(n_max, jobs[j].n_feats);
     total_feats += (size_t)((jobs[j].n_feats + 31) & ~31);
   }
-  st->h_feats.assign(total_feats * 6, 0.0);
+  // the SoA feature tables are formed directly in the context's page-locked staging buffer (one pass; a std::vector staged by the
+  // copy wrapper meant a zero fill, the transpose and a staging copy: three passes over 6 MB for 64 jobs of 2000 features)
+  double* const h_feats = reinterpret_cast<double*>(hso_pinned(ctx, 0, total_feats * 6 * sizeof(double) + 64));
+  if (!h_feats) return HSO_E_NOMEM;
   st->h_jobs.resize(n_jobs);
   if (int rc = grow(ctx, &st->d_feats, &st->feats_cap, total_feats * 6 * sizeof(double))) return rc;
   size_t foff = 0;
@@ -186,13 +188,14 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
         itc->second.g.h[0] != g.h[0])
       return hso_fail(ctx, HSO_E_INVALID, "coarse_track: frames of one batch must share one size");
     const int n = jobs[j].n_feats, ns = (n + 31) & ~31;
-    double* dst = st->h_feats.data() + foff * 6;
+    double* dst = h_feats + foff * 6;
     for (int i = 0; i < n; i++) {
       const hso_ref_feat& f = jobs[j].feats[i];
       dst[0 * ns + i] = f.px[0]; dst[1 * ns + i] = f.px[1];
       dst[2 * ns + i] = f.f[0]; dst[3 * ns + i] = f.f[1]; dst[4 * ns + i] = f.f[2];
       dst[5 * ns + i] = f.dist;
     }
+    for (int i = n; i < ns; i++) for (int c = 0; c < 6; c++) dst[c * ns + i] = 0.0;   // the pad columns
     TrackJobDev& d = st->h_jobs[j];
     d.ref_base = itr->second.base;
     d.cur_base = itc->second.base;
@@ -290,7 +293,7 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   C.lv = reinterpret_cast<const TrackLevel*>(reinterpret_cast<const char*>(st->d_counter) + 256);
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(const_cast<TrackLevel*>(C.lv), st->lv, sizeof(st->lv), hipMemcpyHostToDevice, ctx->stream));
   if (!st->d_eval) HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&st->d_eval), sizeof(hso_eval_out)));
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_feats, st->h_feats.data(), total_feats * 6 * sizeof(double),
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_feats, h_feats, total_feats * 6 * sizeof(double),
                                     hipMemcpyHostToDevice, ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_jobs, st->h_jobs.data(), sizeof(TrackJobDev) * n_jobs,
                                     hipMemcpyHostToDevice, ctx->stream));
@@ -309,8 +312,9 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes2));
     st->attr_set = true;
   }
-  // the staged image may still be read from pageable host vectors until the copies land
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // the feature tables leave the staging buffer asynchronously: a caller of the split interface may use other entry points (which
+  // reuse that buffer) before it launches, so it waits here; hso_gpu_coarse_track_batch goes straight on to launch + collect
+  if (sync_after) HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }
 
@@ -389,7 +393,7 @@ int hso_gpu_coarse_track_batch(hso_gpu_ctx* ctx, const hso_camera* cam, const hs
                                const hso_track_job* jobs, int n_jobs, hso_track_result* results)
 {
   if (!results) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_batch: null results");
-  int rc = track_prepare(ctx, cam, params, jobs, n_jobs, 0);
+  int rc = track_prepare(ctx, cam, params, jobs, n_jobs, 0, false);
   if (rc < 0) return rc;
   rc = hso_gpu_coarse_track_launch(ctx);
   if (rc < 0) return rc;

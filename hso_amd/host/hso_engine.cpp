@@ -49,6 +49,11 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
 
 Bank::~Bank()
 {
+  if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0)
+    fprintf(stderr, "[hso engine] %lld steps of %d sequences, %lld keyframes; ms per step: upload %.3f, track %.3f, reproject+select+pose %.3f, decide %.3f, "
+            "local BA %.3f, seed observe %.3f, seed activate %.3f, new seeds %.3f, flush+finish %.3f\n", (long long)n_steps_, size(), (long long)n_kf_events_,
+            phase_ms_[0] / n_steps_, phase_ms_[1] / n_steps_, phase_ms_[2] / n_steps_, phase_ms_[3] / n_steps_, phase_ms_[4] / n_steps_, phase_ms_[5] / n_steps_,
+            phase_ms_[6] / n_steps_, phase_ms_[7] / n_steps_, phase_ms_[8] / n_steps_);
   delete pool_;
   for (Seq* s : seq_) {
     for (Frame& F : s->frames) if (F.in_use && F.dev_id >= 0) (void)hso_gpu_frame_release(ctx_, F.dev_id);
@@ -57,6 +62,7 @@ Bank::~Bank()
   for (StepData* d : step_) delete d;
   if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);
   for (size_t k = 0; k < seq_.size(); k++) (void)k;
+  briefs_.release(); projected_.release(); mask_.release(); feat_f_.release(); seed_brief_.release(); seed_px_.release();   // before the context goes
   if (owns_ctx_) hso_gpu_destroy(ctx_);
 }
 

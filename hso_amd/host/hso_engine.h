@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <functional>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -106,6 +107,26 @@ struct Seed {
 
 class Pool;                       // the bookkeeping threads
 
+// a grow-only array in page-locked host memory (hso_gpu_host_alloc): the result tables of the batched calls are DMA targets as they
+// are — no staging copy on the way back
+template <typename T> struct Pinned {
+  hso_gpu_ctx* ctx = nullptr; T* p = nullptr; size_t cap = 0;
+  ~Pinned() { release(); }
+  void release() { if (p) (void)hso_gpu_host_free(ctx, p); p = nullptr; cap = 0; }
+  T* need(hso_gpu_ctx* c, size_t n)
+  {
+    if (n <= cap && p) return p;
+    if (p) (void)hso_gpu_host_free(ctx, p);
+    ctx = c; p = nullptr; cap = 0;
+    void* q = nullptr;
+    const size_t want = n + n / 2 + 1024;
+    if (hso_gpu_host_alloc(c, want * sizeof(T), &q) < 0) throw std::bad_alloc();
+    p = static_cast<T*>(q); cap = want;
+    return p;
+  }
+  T* data() { return p; }
+};
+
 struct Trace {                    // device-call recorder (hso_trace.h format), one per sequence
   FILE* f = nullptr;
   ~Trace() { close(); }
@@ -131,7 +152,8 @@ public:
   // imgs[k] == nullptr: sequence k sits the step out
   void set_first_frames(const uint8_t* const* imgs, int w, int h, const double* stamps, const float* const* depth_z, const hso_se3* T_f_w);
   void start(const uint8_t* which);
-  void add_images(const uint8_t* const* imgs, int w, int h, const double* stamps);
+  // on_device: imgs are device pointers (the images are already in HBM: no PCIe copy in the step)
+  void add_images(const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device = false);
   void status(int k, hso_vo_status* st) const;
   int keyframes(int k, double* stamps, hso_se3* T_f_w, int32_t* frame_ids, int cap) const;
   bool trace(int k, const char* path);
@@ -141,9 +163,9 @@ public:
 
 private:
   friend struct Seq;
-  void step(const uint8_t* const* imgs, int w, int h, const double* stamps);
+  void step(const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device);
   // phases of a step (device calls on the caller's thread; per-sequence work through par() / the pool)
-  void upload(const std::vector<int>& who, const uint8_t* const* imgs, int w, int h, const double* stamps);
+  void upload(const std::vector<int>& who, const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device = false);
   void initialise(const std::vector<int>& who);
   void track(const std::vector<int>& who);
   void track_group(const std::vector<int>& who, const std::vector<Id>& ref, const std::vector<Id>& cur, const hso_track_params& p);
@@ -191,12 +213,14 @@ private:
   double px_error_angle_ = -1;
   int64_t n_calls_[10] = {0}, n_items_[10] = {0};
   std::vector<int64_t> to_release_;
+  double phase_ms_[9] = {0};
+  int64_t n_steps_ = 0, n_kf_events_ = 0;
   // result tables of the batched calls (kept between steps: no allocation per step)
-  std::vector<hso_match_brief> briefs_;
-  std::vector<uint8_t> projected_, mask_;
-  std::vector<double> feat_f_;
-  std::vector<hso_seed_brief> seed_brief_;
-  std::vector<float> seed_px_;
+  Pinned<hso_match_brief> briefs_;
+  Pinned<uint8_t> projected_, mask_;
+  Pinned<double> feat_f_;
+  Pinned<hso_seed_brief> seed_brief_;
+  Pinned<float> seed_px_;
 };
 
 }  // namespace engine

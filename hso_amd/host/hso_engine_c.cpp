@@ -101,6 +101,11 @@ int hso_vo_multi_add_images(hso_vo_multi* m, const uint8_t* const* imgs, int wid
   if (!m || !imgs) return HSO_E_INVALID;
   return guarded(m->bank, [&]() { m->bank->add_images(imgs, width, height, timestamps); });
 }
+int hso_vo_multi_add_images_device(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps)
+{
+  if (!m || !imgs) return HSO_E_INVALID;
+  return guarded(m->bank, [&]() { m->bank->add_images(imgs, width, height, timestamps, true); });
+}
 int hso_vo_multi_get_status(hso_vo_multi* m, int sequence, hso_vo_status* st)
 {
   if (!m || !st || sequence < 0 || sequence >= m->bank->size()) return HSO_E_INVALID;

@@ -244,8 +244,8 @@ void Bank::observe_seeds(const std::vector<int>& who)
     want_px |= step_[k]->make_kf;
     tracing |= s.trace.on();
   }
-  seed_brief_.resize((size_t)n_slots);
-  if (want_px) seed_px_.resize(2 * (size_t)n_slots);
+  seed_brief_.need(ctx_, (size_t)n_slots);
+  if (want_px) seed_px_.need(ctx_, 2 * (size_t)n_slots);
   std::vector<hso_seed> before; std::vector<hso_seed_out> full;
   if (tracing) {
     before.resize((size_t)n_slots); full.resize((size_t)n_slots);
@@ -272,7 +272,7 @@ void Bank::observe_seeds(const std::vector<int>& who)
     int dbg_upd = 0, dbg_ok = 0, dbg_live = 0; double dbg_ratio = 1e9;
     for (Seed& sd : s.seeds) {
       if (!sd.alive || sd.slot < 0 || sd.slot >= n_slots) continue;
-      const hso_seed_brief& o = seed_brief_[sd.slot];
+      const hso_seed_brief& o = seed_brief_.data()[sd.slot];
       sd.updated = o.is_update != 0;
       dbg_live++;
       if (!sd.updated) continue;
@@ -285,7 +285,7 @@ void Bank::observe_seeds(const std::vector<int>& who)
       sd.n_dist++;
       if (d.make_kf) {                                            // FeatureExtractor::setGridOccpuancy
         hso_keypoint kp{};
-        kp.x = seed_px_[2 * (size_t)sd.slot]; kp.y = seed_px_[2 * (size_t)sd.slot + 1]; kp.species = HSO_KP_OCCUR;
+        kp.x = seed_px_.data()[2 * (size_t)sd.slot]; kp.y = seed_px_.data()[2 * (size_t)sd.slot + 1]; kp.species = HSO_KP_OCCUR;
         d.occupied.push_back(kp);
       }
     }

@@ -1,16 +1,27 @@
 // hso_engine_step.cpp — the per-frame phases of a step: frame construction, CoarseTracker, reprojection + selection + pose
 // optimisation, and what FrameHandlerMono::processFrame decides from their results.
 #include "hso_engine_impl.h"
+#include <chrono>
 
 namespace hso {
 namespace engine {
 
+namespace {
+// developer probe (HSO_ENGINE_TIMING=1): wall time per phase of a step, printed when the bank goes away
+struct Clock {
+  double* acc; bool on;
+  std::chrono::steady_clock::time_point t;
+  Clock(double* a, bool o) : acc(a), on(o) { if (on) t = std::chrono::steady_clock::now(); }
+  void lap(int k) { if (!on) return; const auto u = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::milli>(u - t).count(); t = u; }
+};
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------ entry points
-void Bank::add_images(const uint8_t* const* imgs, int w, int h, const double* stamps)
+void Bank::add_images(const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device)
 {
   if (w != cam_.width() || h != cam_.height())      // src/frame.cpp:85-86: thrown before anything is touched
     throw std::invalid_argument("Frame: provided image has not the same size as the camera model or image is not grayscale");
-  step(imgs, w, h, stamps);
+  step(imgs, w, h, stamps, on_device);
 }
 
 void Bank::start(const uint8_t* which)
@@ -20,7 +31,7 @@ void Bank::start(const uint8_t* which)
 
 // One step.  Every phase takes the list of sequences it applies to; a phase = per-sequence preparation (pool) -> one batched
 // device call -> per-sequence consumption (pool).
-void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps)
+void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device)
 {
   std::vector<int> who;
   for (int k = 0; k < size(); k++) {
@@ -43,38 +54,50 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps)
   for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
   to_release_.clear();
 
-  upload(who, imgs, w, h, stamps);
+  Clock ck(phase_ms_, getenv("HSO_ENGINE_TIMING") != nullptr);
+  upload(who, imgs, w, h, stamps, on_device);
+  ck.lap(0);
   std::vector<int> starting, running;
   for (int k : who) (seq_[k]->stage == kFirst || seq_[k]->stage == kSecond ? starting : running).push_back(k);
   if (!starting.empty()) initialise(starting);
   if (!running.empty()) {
     track(running);
+    ck.lap(1);
     std::vector<int> tracked;
     for (int k : running) if (step_[k]->tracked) tracked.push_back(k);
     if (!tracked.empty()) {
       reproject(tracked);
+      ck.lap(2);
       std::vector<int> thin, ok, kf;
       for (int k : tracked) if (step_[k]->seed_path) thin.push_back(k);
       if (!thin.empty()) seed_branch(thin);
       par(tracked, [&](int k) { decide(k); });
+      ck.lap(3);
       for (int k : tracked) if (step_[k]->ok) { ok.push_back(k); if (step_[k]->make_kf) kf.push_back(k); }
       if (!kf.empty()) keyframe_ba(kf);
+      ck.lap(4);
       if (!ok.empty()) {
         observe_seeds(ok);
+        ck.lap(5);
         activate_seeds(ok);
+        ck.lap(6);
       }
       if (!kf.empty()) start_seeds(kf);
+      ck.lap(7);
+      n_kf_events_ += (int64_t)kf.size();
     }
   }
   flush_maps(who);
   finish(who);
   for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
   to_release_.clear();
+  ck.lap(8);
+  n_steps_++;
 }
 
 // ------------------------------------------------------------------------------------------------ frame construction
 // `new Frame(cam, img, ts)` of every sequence in one batched call (src/frame_handler_mono.cpp:91-97)
-void Bank::upload(const std::vector<int>& who, const uint8_t* const* imgs, int w, int h, const double* stamps)
+void Bank::upload(const std::vector<int>& who, const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device)
 {
   std::vector<int64_t> ids; std::vector<const uint8_t*> ptr;
   for (int k : who) {
@@ -88,13 +111,14 @@ void Bank::upload(const std::vector<int>& who, const uint8_t* const* imgs, int w
     ids.push_back(F.dev_id); ptr.push_back(imgs[k]);
   }
   std::vector<hso_frame_stats> st(who.size());
-  check(hso_gpu_frame_upload_batch(ctx_, ids.data(), ptr.data(), (int)who.size(), w, h, 0, st.data()), "Frame");
+  check(hso_gpu_frame_upload_batch(ctx_, ids.data(), ptr.data(), (int)who.size(), w, h, on_device ? 1 : 0, st.data()), "Frame");
   n_calls_[0]++; n_items_[0] += (int64_t)who.size();
   for (size_t i = 0; i < who.size(); i++) {
     Seq& s = *seq_[who[i]];
     Frame& F = s.frames[s.cur];
     F.integral = st[i].integral_image; F.grad_mean = st[i].grad_mean;
     if (s.trace.on()) {
+      if (on_device) throw std::invalid_argument("trace: images must be host images");
       s.trace.begin("frame_upload", 5);
       s.trace.scalar("frame_id", (double)F.dev_id); s.trace.scalar("width", w); s.trace.scalar("height", h);
       s.trace.field("img", imgs[who[i]], (size_t)w * h); s.trace.field("stats", &st[i], sizeof(st[i]));
@@ -342,17 +366,17 @@ void Bank::reproject(const std::vector<int>& who)
   size_t total = 0;
   std::vector<size_t> list_at(n);
   for (int i = 0; i < n; i++) { calls[i] = step_[who[i]]->call; list_at[i] = total; total += (size_t)calls[i].n_points; }
-  briefs_.resize(std::max(total, (size_t)1));
-  projected_.assign(std::max(total, (size_t)1), 0);
+  briefs_.need(ctx_, std::max(total, (size_t)1));
+  projected_.need(ctx_, std::max(total, (size_t)1));
   std::vector<int32_t> begin(n + 1, 0), counts(4 * (size_t)n, 0), n_feats(n, 0);
   std::vector<hso_pose_result> pose(n);
-  mask_.assign((size_t)n * cap, 0);
-  feat_f_.resize((size_t)n * cap * 3);
+  mask_.need(ctx_, (size_t)n * cap);
+  feat_f_.need(ctx_, (size_t)n * cap * 3);
   hso_pose_chain chain{};
   chain.reproj_thresh = cfg_.poseoptim_thresh; chain.n_iter = 12;
   chain.results = pose.data(); chain.n_feats = n_feats.data(); chain.outlier_mask = mask_.data(); chain.feat_f = feat_f_.data();
   const int rc = hso_gpu_reproject_select_pose_frames(ctx_, &cam_.pod(), calls.data(), n, cell_size_, grid_cols_, cell_order_.data(), (int)cell_order_.size(),
-                                                      cfg_.max_fts, briefs_.data(), (int)briefs_.size(), begin.data(), counts.data(), projected_.data(), &chain);
+                                                      cfg_.max_fts, briefs_.data(), (int)std::max(total, (size_t)1), begin.data(), counts.data(), projected_.data(), &chain);
   check(rc, "Reprojector");
   n_calls_[3]++; n_items_[3] += n;
   bool any_trace = false;
@@ -366,7 +390,7 @@ void Bank::reproject(const std::vector<int>& who)
     apply_selection(k, briefs_.data() + begin[i], begin[i + 1] - begin[i], projected_.data() + list_at[i], feat_f_.data() + (size_t)i * cap * 3);
     s.log.n_trials = counts[4 * i]; s.log.n_matches = counts[4 * i + 1]; s.log.n_seed_matches = 0;
     d.pose = pose[i];
-    d.pose_mask.assign(mask_.begin() + (size_t)i * cap, mask_.begin() + (size_t)i * cap + C.loose.size());
+    d.pose_mask.assign(mask_.data() + (size_t)i * cap, mask_.data() + (size_t)i * cap + C.loose.size());
     // too few matches: the nearly converged seeds are tried as well (:309-329) — the frame's features change, so the pose
     // optimisation that ran behind the selection does not count for it
     d.seed_path = s.log.n_matches < 100 && !s.seeds.empty() && (int)s.seeds.size() > s.n_dead_seeds;

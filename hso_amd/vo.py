@@ -50,6 +50,8 @@ def _declare(lib):
     lib.hso_vo_multi_set_first_frames.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.hso_vo_multi_add_images.argtypes = [vp, vp, i32, i32, vp]
     lib.hso_vo_multi_start.argtypes = [vp, vp]
+    if hasattr(lib, "hso_vo_multi_add_images_device"):
+        lib.hso_vo_multi_add_images_device.argtypes = [vp, vp, i32, i32, vp]
     lib.hso_vo_multi_trace.argtypes = [vp, i32, C.c_char_p]
     lib.hso_vo_multi_get_status.argtypes = [vp, i32, P(VoStatus)]
     lib.hso_vo_multi_get_keyframes.argtypes = [vp, i32, vp, vp, vp, i32]
@@ -77,7 +79,7 @@ EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso
                     "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes", "hso_vo_start", "hso_vo_init_compute_matrix",
                     "hso_vo_multi_create", "hso_vo_multi_destroy", "hso_vo_multi_last_error", "hso_vo_multi_size",
                     "hso_vo_multi_set_first_frames", "hso_vo_multi_add_images", "hso_vo_multi_get_status", "hso_vo_multi_get_keyframes",
-                    "hso_vo_multi_call_counts", "hso_vo_multi_start", "hso_vo_multi_trace"]
+                    "hso_vo_multi_call_counts", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device"]
 
 CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_select_pose", "align", "pose", "seed_observe", "seed_activate", "ba", "other"]
 
@@ -132,6 +134,12 @@ class MultiVisualOdometry:
         ts = np.ascontiguousarray(timestamps, np.float64)
         shape = next(i.shape for i in imgs if i is not None)
         self._check(self.lib.hso_vo_multi_add_images(self.h, self._ptrs(imgs), shape[1], shape[0], ts.ctypes.data), "add_images")
+
+    def add_images_device(self, ptrs, width, height, timestamps):
+        """ptrs: one device pointer (int) per sequence, 0 / None = the sequence sits this step out."""
+        arr = (C.c_void_p * len(ptrs))(*[p if p else None for p in ptrs])
+        ts = np.ascontiguousarray(timestamps, np.float64)
+        self._check(self.lib.hso_vo_multi_add_images_device(self.h, arr, width, height, ts.ctypes.data), "add_images_device")
 
     def status(self, k):
         st = VoStatus()

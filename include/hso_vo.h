@@ -73,6 +73,9 @@ int hso_vo_multi_set_first_frames(hso_vo_multi* m, const uint8_t* const* imgs, i
  * initialisation; its KLT call has no multi-sequence form and is serialised with the other sequences' device calls */
 int hso_vo_multi_start(hso_vo_multi* m, const uint8_t* which);
 int hso_vo_multi_add_images(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps);
+/* the same with images that already live in device memory (imgs[k] = device pointer to width * height bytes): a capture or
+ * decode pipeline that ends on the GPU, and the form throughput is measured with (inputs resident in HBM) */
+int hso_vo_multi_add_images_device(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps);
 /* hso_vo_trace for one sequence of the bank */
 int hso_vo_multi_trace(hso_vo_multi* m, int sequence, const char* path);
 int hso_vo_multi_get_status(hso_vo_multi* m, int sequence, hso_vo_status* st);

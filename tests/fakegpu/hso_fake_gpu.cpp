@@ -6,6 +6,7 @@
 // sequential walk over per-cell lists — a third, independent statement of it beside k_select and tests/test_select.py.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -52,6 +53,8 @@ void hso_gpu_destroy(hso_gpu_ctx* c)
 }
 const char* hso_gpu_last_error(const hso_gpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int hso_gpu_synchronize(hso_gpu_ctx*) { return HSO_OK; }
+int hso_gpu_host_alloc(hso_gpu_ctx*, size_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? HSO_OK : HSO_E_NOMEM; }
+int hso_gpu_host_free(hso_gpu_ctx*, void* p) { free(p); return HSO_OK; }
 
 int hso_gpu_frame_upload_batch(hso_gpu_ctx* c, const int64_t* ids, const uint8_t* const* imgs, int n, int w, int h, int, hso_frame_stats* st)
 {
