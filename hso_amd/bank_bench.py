@@ -9,7 +9,9 @@ import time
 import numpy as np
 
 
-def run(n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None):
+def run(n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, on_device=True):
+    """on_device: the images are copied to HBM once, before the timed steps, and handed over as device pointers (throughput with
+    inputs resident in HBM, as bench.py's headline); False: host images, 361 KB of PCIe per frame inside every step."""
     from hso_amd import synth, vo
     spec = spec or synth.EUROC
     cam = synth.camera(spec)
@@ -19,10 +21,21 @@ def run(n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None):
     m = vo.MultiVisualOdometry(cam, n_seq, max_fts, device=device)
     m.set_first_frames([q["images"][0] for q in pick], [q["depth0"] for q in pick])
     step_ms, fails = [], 0
+    dev = None
+    if on_device:
+        import torch
+        dev = [[torch.from_numpy(np.ascontiguousarray(im)).cuda(device) for im in q["images"]] for q in seqs]
+        torch.cuda.synchronize(device)
+    h, w = pick[0]["images"][0].shape
     for k in range(1, frames):
-        imgs = [q["images"][k] for q in pick]
-        t0 = time.perf_counter()
-        m.add_images(imgs, [float(k)] * n_seq)
+        if on_device:
+            ptrs = [dev[q % len(seqs)][k].data_ptr() for q in range(n_seq)]
+            t0 = time.perf_counter()
+            m.add_images_device(ptrs, w, h, [float(k)] * n_seq)
+        else:
+            imgs = [q["images"][k] for q in pick]
+            t0 = time.perf_counter()
+            m.add_images(imgs, [float(k)] * n_seq)
         step_ms.append(1e3 * (time.perf_counter() - t0))
     kfs = [len(m.keyframes(q)) for q in range(n_seq)]
     sts = [m.status(q) for q in range(n_seq)]
@@ -31,13 +44,66 @@ def run(n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None):
     counts = m.call_counts()
     m.close()
     warm = step_ms[2:] if len(step_ms) > 4 else step_ms
-    return dict(sequences=n_seq, distinct=len(seqs), frames=frames - 1, max_fts=max_fts, frames_per_s=1e3 * n_seq / float(np.mean(warm)),
+    return dict(sequences=n_seq, distinct=len(seqs), frames=frames - 1, max_fts=max_fts, images="device" if on_device else "host", frames_per_s=1e3 * n_seq / float(np.mean(warm)),
                 ms_per_step_mean=float(np.mean(warm)), ms_per_step_median=float(np.median(warm)), ms_per_step_max=float(np.max(warm)),
                 ms_first_steps=[round(x, 2) for x in step_ms[:3]], keyframes_per_sequence=float(np.mean(kfs)) - 1, failures=fails,
                 trans_err_max=max(err), n_matches_last=int(np.mean([st.n_matches for st in sts])), n_seeds_last=int(np.mean([st.n_seeds for st in sts])),
                 calls=counts)
 
 
+def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None):
+    """n_banks engines of n_seq sequences each, every one on its own host thread with its own device context / stream: the
+    device work of one bank overlaps the bookkeeping and the PCIe traffic of the others (independent sequences shard freely, also
+    within one GPU).  Whole-run throughput: all frames / wall time from the first step to the last bank's last step."""
+    import threading
+    from hso_amd import synth
+    spec = spec or synth.EUROC
+    if seqs is None:
+        seqs = synth.sequences(min(distinct, n_seq), frames, spec=spec, seed0=777)
+    res = [None] * n_banks
+    gate = threading.Barrier(n_banks + 1)
+    t_end = [0.0] * n_banks
+
+    def work(b):
+        from hso_amd import vo
+        import torch
+        cam = synth.camera(spec)
+        pick = [seqs[q % len(seqs)] for q in range(n_seq)]
+        m = vo.MultiVisualOdometry(cam, n_seq, max_fts, device=device)
+        m.set_first_frames([q["images"][0] for q in pick], [q["depth0"] for q in pick])
+        dev = [[torch.from_numpy(np.ascontiguousarray(im)).cuda(device) for im in q["images"]] for q in seqs]
+        torch.cuda.synchronize(device)
+        h, w = pick[0]["images"][0].shape
+        gate.wait()
+        ms = []
+        for k in range(1, frames):
+            ptrs = [dev[q % len(seqs)][k].data_ptr() for q in range(n_seq)]
+            t0 = time.perf_counter()
+            m.add_images_device(ptrs, w, h, [float(k)] * n_seq)
+            ms.append(1e3 * (time.perf_counter() - t0))
+        t_end[b] = time.perf_counter()
+        sts = [m.status(q) for q in range(n_seq)]
+        res[b] = dict(ms_per_step_mean=float(np.mean(ms[2:])), failures=sum(int(st.stage != 3 or st.result == 2) for st in sts),
+                      trans_err_max=max(float(np.linalg.norm(np.array(sts[q].T_f_w.t[:]) - pick[q]["T_f_w"][frames - 1][1])) for q in range(n_seq)))
+        m.close()
+
+    th = [threading.Thread(target=work, args=(b,)) for b in range(n_banks)]
+    for t in th:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    wall = max(t_end) - t0
+    return dict(banks=n_banks, sequences_per_bank=n_seq, sequences=n_banks * n_seq, frames=frames - 1, max_fts=max_fts, images="device",
+                frames_per_s=n_banks * n_seq * (frames - 1) / wall, wall_s=wall, ms_per_step_mean_per_bank=[r["ms_per_step_mean"] for r in res],
+                failures=sum(r["failures"] for r in res), trans_err_max=max(r["trans_err_max"] for r in res))
+
+
 if __name__ == "__main__":
-    a = [int(x) for x in sys.argv[1:]]
-    print(json.dumps(run(a[0], a[1], a[2], a[3] if len(a) > 3 else 8)))
+    if sys.argv[1] == "banks":
+        a = [int(x) for x in sys.argv[2:]]
+        print(json.dumps(run_banks(a[0], a[1], a[2], a[3], a[4] if len(a) > 4 else 8)))
+    else:
+        a = [int(x) for x in sys.argv[1:]]
+        print(json.dumps(run(a[0], a[1], a[2], a[3] if len(a) > 3 else 8, on_device=(a[4] != 0 if len(a) > 4 else True))))

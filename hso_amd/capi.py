@@ -85,7 +85,7 @@ class TrackParams(C.Structure):
 
 class TrackJob(C.Structure):
     _fields_ = [("ref_frame_id", C.c_int64), ("cur_frame_id", C.c_int64),
-                ("feats", C.c_void_p), ("n_feats", C.c_int32), ("_pad", C.c_int32),
+                ("feats", C.c_void_p), ("n_feats", C.c_int32), ("feats_soa", C.c_int32),
                 ("T_cur_ref", SE3), ("exposure_rat", C.c_float), ("_pad2", C.c_float)]
 
 
@@ -380,7 +380,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
     "hso_gpu_map_reserve", "hso_gpu_map_store", "hso_gpu_reproject_match_maps",
     "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level", "hso_gpu_host_alloc", "hso_gpu_host_free", "hso_gpu_seed_table_compact",
-    "hso_gpu_seqmap_create", "hso_gpu_seqmap_destroy", "hso_gpu_seqmap_set_keyframes", "hso_gpu_seqmap_patch", "hso_gpu_seqmap_size", "hso_gpu_seqmap_read",
+    "hso_gpu_seqmap_create", "hso_gpu_seqmap_destroy", "hso_gpu_seqmap_set_keyframes", "hso_gpu_seqmap_patch", "hso_gpu_seqmap_patch_multi", "hso_gpu_seqmap_size", "hso_gpu_seqmap_read",
     "hso_gpu_reproject_select_pose_frames", "hso_gpu_debug_fetch", "hso_gpu_seed_table_observe_groups", "hso_gpu_seed_table_set_host_pose",
 ]
 

@@ -767,6 +767,14 @@ static __global__ void k_gather_rows(const unsigned long long* __restrict__ src,
   const size_t i = g / granules, q = g - i * granules;
   dst[g] = src[(size_t)ids[i] * granules + q];
 }
+// rows to arbitrary destinations (the patches of many maps in one launch): row i goes to dst[i]
+static __global__ void k_scatter_rows_to(unsigned long long* const* __restrict__ dst, const unsigned long long* __restrict__ src, int n, int granules)
+{
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * granules) return;
+  const size_t i = g / granules, q = g - i * granules;
+  dst[i][q] = src[g];
+}
 static_assert(sizeof(hso_map_point) % 8 == 0 && sizeof(hso_obs) % 8 == 0, "rows move in 8-byte granules");
 
 template <typename T> static int seqmap_grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need, size_t keep)
@@ -885,6 +893,83 @@ int hso_gpu_seqmap_patch(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, co
   // the stream, hso_ctx.h), and whatever uses the work area or the tables next is ordered behind the scatter on the same stream.
   // A map patched for many sequences per step thus costs enqueues only; the step's next synchronising call releases the chunks.
   m->n_pts = need_pts; m->n_obs = need_obs;
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches, int n_patches)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_patches < 0 || (n_patches > 0 && !patches)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: bad argument");
+  size_t tp = 0, to = 0;
+  for (int i = 0; i < n_patches; i++) {
+    const hso_seqmap_rows& P = patches[i];
+    SeqMap* m = seqmap_of(ctx, P.map);
+    if (!m || P.n_points < 0 || P.n_obs < 0 || (P.n_points > 0 && (!P.point_ids || !P.points)) || (P.n_obs > 0 && (!P.obs_ids || !P.obs)))
+      return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: bad patch");
+    const int nk = (int)m->kfs.size();
+    size_t need_pts = m->n_pts, need_obs = m->n_obs;
+    for (int k = 0; k < P.n_obs; k++) { if (P.obs_ids[k] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: negative observation id"); need_obs = std::max(need_obs, (size_t)P.obs_ids[k] + 1); }
+    for (int k = 0; k < P.n_obs; k++) {
+      const hso_obs& o = P.obs[k];
+      if (o.kf < 0 || o.kf >= nk || o.level < 0 || o.level >= HSO_N_PYR_LEVELS || o.pad_ < -1 || (o.pad_ >= 0 && (size_t)o.pad_ >= need_obs))
+        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: observation row out of range (keyframe table set first?)");
+    }
+    for (int k = 0; k < P.n_points; k++) {
+      const hso_map_point& p = P.points[k];
+      if (P.point_ids[k] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: negative point id");
+      need_pts = std::max(need_pts, (size_t)P.point_ids[k] + 1);
+      if (p.host_kf < 0 || p.host_kf >= nk || p.obs_count < 0 || (p.obs_count > 0 && (p.obs_begin < 0 || (size_t)p.obs_begin >= need_obs)))
+        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: point row out of range");
+    }
+    if (need_pts > m->pts_cap || need_obs > m->obs_cap) {
+      HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+      if (int rc = seqmap_grow(ctx, &m->d_pts, &m->pts_cap, need_pts, m->n_pts)) return rc;
+      if (int rc = seqmap_grow(ctx, &m->d_obs, &m->obs_cap, need_obs, m->n_obs)) return rc;
+    }
+    m->n_pts = need_pts; m->n_obs = need_obs;
+    tp += (size_t)P.n_points; to += (size_t)P.n_obs;
+  }
+  if (tp + to == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  // [destination row pointers of the points | of the observations | point rows | observation rows]
+  const size_t b_dp = al(sizeof(void*) * tp), b_do = al(sizeof(void*) * to), b_p = al(sizeof(hso_map_point) * tp), b_o = al(sizeof(hso_obs) * to);
+  const size_t need = b_dp + b_do + b_p + b_o;
+  char* h = hso_pinned(ctx, 0, need);
+  if (!h) return HSO_E_NOMEM;
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
+  }
+  hso_map_point** dp = reinterpret_cast<hso_map_point**>(h);
+  hso_obs** dob = reinterpret_cast<hso_obs**>(h + b_dp);
+  hso_map_point* rp = reinterpret_cast<hso_map_point*>(h + b_dp + b_do);
+  hso_obs* ro = reinterpret_cast<hso_obs*>(h + b_dp + b_do + b_p);
+  size_t ip = 0, io = 0;
+  for (int i = 0; i < n_patches; i++) {
+    const hso_seqmap_rows& P = patches[i];
+    SeqMap* m = seqmap_of(ctx, P.map);
+    for (int k = 0; k < P.n_points; k++) { dp[ip] = m->d_pts + P.point_ids[k]; rp[ip] = P.points[k]; ip++; }
+    for (int k = 0; k < P.n_obs; k++) { dob[io] = m->d_obs + P.obs_ids[k]; ro[io] = P.obs[k]; io++; }
+  }
+  char* d = ctx->d_batch;
+  // the staging buffer is rewritten by the next entry point: this one waits for its copy (a step patches once or twice)
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, ctx->stream));
+  if (tp) {
+    const int G = sizeof(hso_map_point) / 8;
+    hipLaunchKernelGGL(k_scatter_rows_to, dim3((unsigned)((tp * G + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<unsigned long long* const*>(d), reinterpret_cast<const unsigned long long*>(d + b_dp + b_do), (int)tp, G);
+  }
+  if (to) {
+    const int G = sizeof(hso_obs) / 8;
+    hipLaunchKernelGGL(k_scatter_rows_to, dim3((unsigned)((to * G + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<unsigned long long* const*>(d + b_dp), reinterpret_cast<const unsigned long long*>(d + b_dp + b_do + b_p), (int)to, G);
+  }
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }
 

@@ -139,6 +139,11 @@ int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg)
   return code;
 }
 
+// Frame storage comes in slabs: the device allocator takes 0.1-0.2 ms per call on this stack, and a bank of 64 sequences
+// constructs 64 frames per step (10 ms of a step went into 64 hipMalloc calls until the first frames were released).  A slab
+// holds HSO_FRAMES_PER_SLAB frames of one geometry; pieces are handed out and returned through the free list of that geometry and
+// the slabs are freed with the context.
+#define HSO_FRAMES_PER_SLAB 32
 int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base)
 {
   if (!ctx->free_frames.empty() && ctx->free_w == g.w[0] && ctx->free_h == g.h[0]) {
@@ -147,22 +152,32 @@ int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base)
     return HSO_OK;
   }
   *base = nullptr;
-  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(base), g.frame_bytes));
+  if (!ctx->free_frames.empty()) {
+    // another geometry than the pool's (a context normally sees one camera): a plain allocation, freed with the context
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(base), g.frame_bytes));
+    ctx->frame_slabs.push_back(*base);
+    hipError_t e = hipMemsetAsync(*base, 0, g.pyr_bytes, ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
+    return HSO_OK;
+  }
+  const size_t stride = ((size_t)g.frame_bytes + 255) & ~size_t(255);
+  uint8_t* slab = nullptr;
+  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&slab), stride * HSO_FRAMES_PER_SLAB));
+  ctx->frame_slabs.push_back(slab);
   // zero once: the inter-level padding rows must read as 0 (see hso_ctx.h)
-  hipError_t e = hipMemsetAsync(*base, 0, g.pyr_bytes, ctx->stream);
-  if (e != hipSuccess) { (void)hipFree(*base); *base = nullptr; ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
+  hipError_t e = hipMemsetAsync(slab, 0, stride * HSO_FRAMES_PER_SLAB, ctx->stream);
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
+  ctx->free_w = g.w[0]; ctx->free_h = g.h[0];
+  for (int i = HSO_FRAMES_PER_SLAB - 1; i >= 1; i--) ctx->free_frames.push_back(slab + stride * (size_t)i);
+  *base = slab;
   return HSO_OK;
 }
 
 void hso_frame_free(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* base)
 {
   if (!base) return;
-  if ((ctx->free_frames.empty() || (ctx->free_w == g.w[0] && ctx->free_h == g.h[0])) && ctx->free_frames.size() < 4096) {
-    ctx->free_w = g.w[0]; ctx->free_h = g.h[0];
-    ctx->free_frames.push_back(base);
-  } else {
-    (void)hipFree(base);
-  }
+  // pieces of the pool's geometry go back to its free list; anything else stays allocated until the context goes
+  if (ctx->free_w == g.w[0] && ctx->free_h == g.h[0]) ctx->free_frames.push_back(base);
 }
 
 // run `expr`; on failure give the frame allocation back and return the status
@@ -223,8 +238,7 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   hso_seed_tables_free(ctx);
   hso_map_arena_free(ctx);
   hso_seqmaps_free(ctx);
-  for (auto& kv : ctx->frames) (void)hipFree(kv.second.base);
-  for (auto* p : ctx->free_frames) (void)hipFree(p);
+  for (auto* p : ctx->frame_slabs) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
   for (int k = 0; k < 2; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
   for (void* p : ctx->host_allocs) (void)hipHostFree(p);

@@ -673,6 +673,12 @@ extern "C" int hso_gpu_seed_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int
 // (:368-401, :423-497), and one observation of every live seed (observeDepth, :557-675) runs over the table in place: what
 // crosses PCIe per frame is one hso_seed_frame per group in and one 16-byte hso_seed_brief per slot out, instead of the
 // 216-byte seed record in and the 88-byte result out of the value-passing call.
+static __global__ void k_seed_mark_dead(SeedDev* seeds, const int32_t* slots, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) seeds[slots[i]].ref_base = nullptr;
+}
+
 struct SeedTable {
   SeedDev* d = nullptr;
   size_t cap = 0, n = 0;              // slots allocated / used (erased slots keep their index)
@@ -796,14 +802,29 @@ int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, 
   if (!t || n < 0 || (n > 0 && !slots)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_erase: bad argument");
   for (int i = 0; i < n; i++)
     if (slots[i] < 0 || (size_t)slots[i] >= t->n) return hso_fail(ctx, HSO_E_INVALID, "seed_table_erase: slot out of range");
-  const uint8_t* null_base = nullptr;
+  std::vector<int32_t> dead;
   for (int i = 0; i < n; i++) {
     if (!t->alive[slots[i]]) continue;
     t->alive[slots[i]] = 0;
     if (--t->pins[t->host_frame[slots[i]]] <= 0) t->pins.erase(t->host_frame[slots[i]]);
-    // ref_base is the first member of SeedDev: a null there marks the slot dead for the kernel
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(reinterpret_cast<char*>(t->d + slots[i]), &null_base, sizeof(null_base), hipMemcpyHostToDevice, ctx->stream));
+    dead.push_back(slots[i]);
   }
+  if (dead.empty()) return HSO_OK;
+  // a null ref_base marks a slot dead for the kernels: ONE slot list + one small kernel (a copy per slot was ~900 eight-byte
+  // copies per step of 64 sequences: 3 ms of copy kernels and as much enqueue time)
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t need = sizeof(int32_t) * dead.size();
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
+  }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_batch, dead.data(), need, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_seed_mark_dead, dim3((unsigned)((dead.size() + 255) / 256)), dim3(256), 0, ctx->stream, t->d, reinterpret_cast<const int32_t*>(ctx->d_batch),
+                     (int)dead.size());
+  HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }

@@ -730,7 +730,13 @@ extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_
   const int total = hso_reproject_frames_run(ctx, cam, frames, n_calls, cell_size, grid_n_cols, o, &R, &X);
   if (total < 0) return total;
   char* d = R.d_extra;
-  char* h = hso_pinned(ctx, 1, std::max(in_bytes, sizeof(int32_t) * (5 * (size_t)n_calls + 2)));   // slot 0 holds hso_reproject_frames_run's upload
+  // ONE staging image (slot 1: slot 0 holds hso_reproject_frames_run's upload, still in flight) for everything the chain behind the
+  // projection needs — selection tables, pose job records, per-frame sources, keyframe poses — uploaded before the first kernel, so
+  // the kernels of the chain run back to back with no synchronisation in between
+  const size_t b_pj = al(sizeof(PoseJobDev) * (size_t)n_calls), b_ps = al(sizeof(PoseSrcDev) * (size_t)n_calls);
+  const size_t b_kp = al(sizeof(hso_se3) * std::max(X.kf_poses.size(), (size_t)1));
+  if (X.kf_poses.size() > kf_rows) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: keyframe tables changed during the call");
+  char* h = hso_pinned(ctx, 1, in_bytes + b_pj + b_ps + b_kp);
   if (!h) return HSO_E_NOMEM;
   int* hb = reinterpret_cast<int*>(h + o_begin);
   for (int c = 0; c <= n_calls; c++) hb[c] = R.begin[c];
@@ -751,6 +757,24 @@ extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_
     F.out = reinterpret_cast<int*>(d + o_exam) + F.first;
     F.counts = reinterpret_cast<int*>(d + o_counts) + 4 * c;
   }
+  {
+    char* hp = h + in_bytes;
+    PoseJobDev* pj = reinterpret_cast<PoseJobDev*>(hp);
+    PoseSrcDev* ps = reinterpret_cast<PoseSrcDev*>(hp + b_pj);
+    if (!X.kf_poses.empty()) memcpy(hp + b_pj + b_ps, X.kf_poses.data(), sizeof(hso_se3) * X.kf_poses.size());
+    const hso_se3* d_kp = reinterpret_cast<const hso_se3*>(d + o_kp_fixed);
+    for (int c = 0; c < n_calls; c++) {
+      pj[c].feats = reinterpret_cast<const hso_pose_feat*>(d + o_pf) + (size_t)c * feat_cap;
+      pj[c].poses = reinterpret_cast<const hso_se3*>(d + o_pp) + (size_t)c * HSO_POSE_MAX_POSES;
+      pj[c].mask = reinterpret_cast<uint8_t*>(d + o_pk) + (size_t)c * feat_cap;
+      pj[c].n_feats = 0; pj[c].n_poses = 0; pj[c].T = frames[c].T_cur_w; pj[c].reproj_thresh = pose->reproj_thresh;
+      pj[c].n_iter = pose->n_iter; pj[c]._pad = 0;
+      ps[c].pts = X.pts[c]; ps[c].kf_poses = d_kp + X.kf_begin[c]; ps[c].list_begin = R.begin[c]; ps[c].n_kfs = X.kf_begin[c + 1] - X.kf_begin[c];
+    }
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pj, hp, b_pj, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_ps, hp + b_pj, b_ps, hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_kp_fixed, hp + b_pj + b_ps, b_kp, hipMemcpyHostToDevice, ctx->stream));
+  }
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   const int* d_begin = reinterpret_cast<const int*>(d + o_begin);
   hipLaunchKernelGGL(k_sel_gather, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_proj, R.d_brief, d_begin,
@@ -768,29 +792,6 @@ extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_
   if (projected_out) hipLaunchKernelGGL(k_projected_flags, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, R.d_proj, total, reinterpret_cast<uint8_t*>(d + o_flag));
   HSO_HIP_CHECK(ctx, hipGetLastError());
   {
-    // job records + per-frame sources + the frames' keyframe poses: one staging image (slot 0 is free again once the run's upload has
-    // left it: synchronise first)
-    const size_t b_pj = al(sizeof(PoseJobDev) * (size_t)n_calls), b_ps = al(sizeof(PoseSrcDev) * (size_t)n_calls);
-    const size_t b_kp = al(sizeof(hso_se3) * std::max(X.kf_poses.size(), (size_t)1));
-    if (X.kf_poses.size() > kf_rows) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: keyframe tables changed during the call");
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    char* hp = hso_pinned(ctx, 0, b_pj + b_ps + b_kp);
-    if (!hp) return HSO_E_NOMEM;
-    PoseJobDev* pj = reinterpret_cast<PoseJobDev*>(hp);
-    PoseSrcDev* ps = reinterpret_cast<PoseSrcDev*>(hp + b_pj);
-    if (!X.kf_poses.empty()) memcpy(hp + b_pj + b_ps, X.kf_poses.data(), sizeof(hso_se3) * X.kf_poses.size());
-    const hso_se3* d_kp = reinterpret_cast<const hso_se3*>(d + o_kp_fixed);
-    for (int c = 0; c < n_calls; c++) {
-      pj[c].feats = reinterpret_cast<const hso_pose_feat*>(d + o_pf) + (size_t)c * feat_cap;
-      pj[c].poses = reinterpret_cast<const hso_se3*>(d + o_pp) + (size_t)c * HSO_POSE_MAX_POSES;
-      pj[c].mask = reinterpret_cast<uint8_t*>(d + o_pk) + (size_t)c * feat_cap;
-      pj[c].n_feats = 0; pj[c].n_poses = 0; pj[c].T = frames[c].T_cur_w; pj[c].reproj_thresh = pose->reproj_thresh;
-      pj[c].n_iter = pose->n_iter; pj[c]._pad = 0;
-      ps[c].pts = X.pts[c]; ps[c].kf_poses = d_kp + X.kf_begin[c]; ps[c].list_begin = R.begin[c]; ps[c].n_kfs = X.kf_begin[c + 1] - X.kf_begin[c];
-    }
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_pj, hp, b_pj, hipMemcpyHostToDevice, ctx->stream));
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_ps, hp + b_pj, b_ps, hipMemcpyHostToDevice, ctx->stream));
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_kp_fixed, hp + b_pj + b_ps, b_kp, hipMemcpyHostToDevice, ctx->stream));
     HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_pk, 0, (size_t)n_calls * feat_cap, ctx->stream));
     hipLaunchKernelGGL(k_pose_feats_from_list, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, *cam, reinterpret_cast<const hso_match_brief*>(d + o_out),
                        reinterpret_cast<const int*>(d + o_offs), reinterpret_cast<const PoseSrcDev*>(d + o_ps), X.d_ids, X.d_quality, feat_cap,

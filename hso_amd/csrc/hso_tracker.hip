@@ -172,9 +172,21 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
     n_max = std::max(n_max, jobs[j].n_feats);
     total_feats += (size_t)((jobs[j].n_feats + 31) & ~31);
   }
-  // the SoA feature tables are formed directly in the context's page-locked staging buffer (one pass; a std::vector staged by the
-  // copy wrapper meant a zero fill, the transpose and a staging copy: three passes over 6 MB for 64 jobs of 2000 features)
-  double* const h_feats = reinterpret_cast<double*>(hso_pinned(ctx, 0, total_feats * 6 * sizeof(double) + 64));
+  // Callers that hand over the kernel's layout (feats_soa) in one contiguous block skip the host pass altogether.
+  bool direct = true;
+  for (int j = 0; j < n_jobs && direct; j++) {
+    direct = jobs[j].feats_soa == 1;
+    if (direct && j > 0 && jobs[j].n_feats > 0) {
+      const double* want = reinterpret_cast<const double*>(jobs[0].feats);
+      size_t off = 0;
+      for (int q = 0; q < j; q++) off += (size_t)((jobs[q].n_feats + 31) & ~31) * 6;
+      direct = reinterpret_cast<const double*>(jobs[j].feats) == want + off;
+    }
+  }
+  // Otherwise the SoA feature tables are formed in the context's page-locked staging buffer (one pass; a std::vector staged by
+  // the copy wrapper meant a zero fill, the transpose and a staging copy: three passes over 6 MB for 64 jobs of 2000 features)
+  double* const h_feats = direct ? const_cast<double*>(reinterpret_cast<const double*>(jobs[0].feats))
+                                 : reinterpret_cast<double*>(hso_pinned(ctx, 0, total_feats * 6 * sizeof(double) + 64));
   if (!h_feats) return HSO_E_NOMEM;
   st->h_jobs.resize(n_jobs);
   if (int rc = grow(ctx, &st->d_feats, &st->feats_cap, total_feats * 6 * sizeof(double))) return rc;
@@ -189,13 +201,19 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
       return hso_fail(ctx, HSO_E_INVALID, "coarse_track: frames of one batch must share one size");
     const int n = jobs[j].n_feats, ns = (n + 31) & ~31;
     double* dst = h_feats + foff * 6;
-    for (int i = 0; i < n; i++) {
-      const hso_ref_feat& f = jobs[j].feats[i];
-      dst[0 * ns + i] = f.px[0]; dst[1 * ns + i] = f.px[1];
-      dst[2 * ns + i] = f.f[0]; dst[3 * ns + i] = f.f[1]; dst[4 * ns + i] = f.f[2];
-      dst[5 * ns + i] = f.dist;
+    if (direct) {
+      // nothing to do: the caller's block is the upload image
+    } else if (jobs[j].feats_soa == 1) {
+      memcpy(dst, jobs[j].feats, sizeof(double) * 6 * (size_t)ns);
+    } else {
+      for (int i = 0; i < n; i++) {
+        const hso_ref_feat& f = jobs[j].feats[i];
+        dst[0 * ns + i] = f.px[0]; dst[1 * ns + i] = f.px[1];
+        dst[2 * ns + i] = f.f[0]; dst[3 * ns + i] = f.f[1]; dst[4 * ns + i] = f.f[2];
+        dst[5 * ns + i] = f.dist;
+      }
+      for (int i = n; i < ns; i++) for (int c = 0; c < 6; c++) dst[c * ns + i] = 0.0;   // the pad columns
     }
-    for (int i = n; i < ns; i++) for (int c = 0; c < 6; c++) dst[c * ns + i] = 0.0;   // the pad columns
     TrackJobDev& d = st->h_jobs[j];
     d.ref_base = itr->second.base;
     d.cur_base = itc->second.base;
@@ -247,8 +265,14 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   // result does not depend on what else is in the batch; all workgroups of the launch are resident at once (K_j <= CUs per XCD).
   st->coop_K = 0;
   st->coop_scatter = getenv("HSO_TRACK_COOP_SCATTER") ? 1 : 0;
-  if (max_grid <= 0 && n_jobs <= COOP_MAX_JOBS && !st->coop_broken && !getenv("HSO_TRACK_NO_COOP")) {
-    const int per_xcd = std::min(COOP_KMAX, std::max(1, ctx->n_cu / 8));
+  // Medium batches (more jobs than XCDs, fewer than CUs: a bank of 16..128 sequences): the chip would run one workgroup per job
+  // and leave the other CUs idle for the ~1.3 ms a 2000-feature job takes; instead every job is split over floor(CUs / jobs)
+  // workgroups, spread over the XCDs (the placement-independent transport).  Here K does depend on the batch size — results of a
+  // job agree with its solo run within the tracker's tolerance, not bit for bit (HSO_TRACK_NO_COOP=1 pins the one-workgroup shape).
+  const int share = n_jobs > COOP_MAX_JOBS ? ctx->n_cu / n_jobs : COOP_KMAX;
+  if (n_jobs > COOP_MAX_JOBS && share >= 2) st->coop_scatter = 1;
+  if (max_grid <= 0 && (n_jobs <= COOP_MAX_JOBS || share >= 2) && !st->coop_broken && !getenv("HSO_TRACK_NO_COOP")) {
+    const int per_xcd = std::min(std::min(COOP_KMAX, std::max(1, ctx->n_cu / 8)), share);
     int fpw = COOP_FEATS_PER_WG;
     if (const char* e = getenv("HSO_TRACK_COOP_FPW")) fpw = std::max(1, atoi(e));
     int kmax = 0;

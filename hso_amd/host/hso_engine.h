@@ -218,7 +218,7 @@ private:
   // result tables of the batched calls (kept between steps: no allocation per step)
   Pinned<hso_match_brief> briefs_;
   Pinned<uint8_t> projected_, mask_;
-  Pinned<double> feat_f_;
+  Pinned<double> feat_f_, track_tables_;
   Pinned<hso_seed_brief> seed_brief_;
   Pinned<float> seed_px_;
 };

@@ -736,13 +736,18 @@ void Bank::flush_maps(const std::vector<int>& who)
     }
     s.dirty_obs.clear();
   });
+  std::vector<hso_seqmap_rows> rows;
   for (size_t i = 0; i < who.size(); i++) {
     Seq& s = *seq_[who[i]];
     Patch& P = patch[i];
     if (P.kf) { check(hso_gpu_seqmap_set_keyframes(ctx_, s.map, P.kfs.data(), (int)P.kfs.size()), "Map"); s.kfs_dirty = false; }
-    if (!P.pid.empty() || !P.oid.empty())
-      check(hso_gpu_seqmap_patch(ctx_, s.map, P.pid.data(), P.pts.data(), (int)P.pid.size(), P.oid.data(), P.obs.data(), (int)P.oid.size()), "Map");
+    if (P.pid.empty() && P.oid.empty()) continue;
+    hso_seqmap_rows r{};
+    r.map = s.map; r.n_points = (int)P.pid.size(); r.n_obs = (int)P.oid.size();
+    r.point_ids = P.pid.data(); r.points = P.pts.data(); r.obs_ids = P.oid.data(); r.obs = P.obs.data();
+    rows.push_back(r);
   }
+  if (!rows.empty()) check(hso_gpu_seqmap_patch_multi(ctx_, rows.data(), (int)rows.size()), "Map");
 }
 
 // ------------------------------------------------------------------------------------------------ end of the frame

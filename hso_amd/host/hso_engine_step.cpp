@@ -131,23 +131,27 @@ namespace {
 
 // the reference frame's features as CoarseTracker::makeDepthRef sees them (src/CoarseTracker.cpp:210-240): the distance of the
 // point along the bearing, from its host-frame inverse depth; -1 keeps the slot of a feature without a usable point
-void reference_features(const Seq& s, const Frame& R, std::vector<hso_ref_feat>& out)
+// Written straight into the tracker kernel's layout: six arrays px[0] | px[1] | f[0] | f[1] | f[2] | dist of `stride` doubles.
+void reference_features(const Seq& s, const Frame& R, double* out, size_t stride)
 {
   const size_t n = s.n_feats(R);
-  out.resize(n);
+  double* px0 = out; double* px1 = out + stride; double* f0 = out + 2 * stride; double* f1 = out + 3 * stride; double* f2 = out + 4 * stride;
+  double* dist = out + 5 * stride;
+  Id cached = kNone;
+  SE3 T_ref_host;
   for (size_t i = 0; i < n; i++) {
     const Feat& ft = s.feat_of(R, i);
-    hso_ref_feat& r = out[i];
-    r.px[0] = ft.px[0]; r.px[1] = ft.px[1];
-    r.f[0] = ft.f[0]; r.f[1] = ft.f[1]; r.f[2] = ft.f[2];
-    r.dist = -1;
+    px0[i] = ft.px[0]; px1[i] = ft.px[1];
+    f0[i] = ft.f[0]; f1[i] = ft.f[1]; f2[i] = ft.f[2];
+    dist[i] = -1;
     if (ft.point == kNone) continue;
     const Point& P = s.points[ft.point];
     const Feat& host = s.feats[P.host];
-    const SE3 T_ref_host = R.T * s.frames[host.frame].T.inverse();
+    if (host.frame != cached) { T_ref_host = R.T * s.frames[host.frame].T.inverse(); cached = host.frame; }   // runs of points share a host keyframe
     const Vector3d p = T_ref_host * along(host.f, 1.0 / P.idist);
-    if (!(p[2] < 0.00001)) r.dist = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    if (!(p[2] < 0.00001)) dist[i] = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
   }
+  for (size_t i = n; i < stride; i++) px0[i] = px1[i] = f0[i] = f1[i] = f2[i] = dist[i] = 0.0;
 }
 
 void trace_track(Trace& t, const hso_camera& cam, const hso_track_params& p, const hso_track_job& job, const hso_track_result& res)
@@ -155,7 +159,14 @@ void trace_track(Trace& t, const hso_camera& cam, const hso_track_params& p, con
   t.begin("coarse_track", 8);
   t.field("cam", &cam, sizeof(cam)); t.field("params", &p, sizeof(p));
   t.scalar("ref_frame_id", (double)job.ref_frame_id); t.scalar("cur_frame_id", (double)job.cur_frame_id);
-  t.field("feats", job.feats, sizeof(hso_ref_feat) * (size_t)job.n_feats);
+  {
+    // the trace keeps the record form of the table (what the value-passing call takes and the replay reads)
+    const size_t n = (size_t)job.n_feats, st = (n + 31) & ~size_t(31);
+    const double* a = reinterpret_cast<const double*>(job.feats);
+    std::vector<hso_ref_feat> rec(n);
+    for (size_t i = 0; i < n; i++) { rec[i].px[0] = a[i]; rec[i].px[1] = a[st + i]; rec[i].f[0] = a[2 * st + i]; rec[i].f[1] = a[3 * st + i]; rec[i].f[2] = a[4 * st + i]; rec[i].dist = a[5 * st + i]; }
+    t.field("feats", rec.data(), sizeof(hso_ref_feat) * n);
+  }
   t.field("T_cur_ref", &job.T_cur_ref, sizeof(hso_se3)); t.scalar("exposure_rat", job.exposure_rat);
   t.field("result", &res, sizeof(res));
 }
@@ -168,16 +179,20 @@ void Bank::track_group(const std::vector<int>& who, const std::vector<Id>& ref, 
   if (who.empty()) return;
   std::vector<hso_track_job> jobs(who.size());
   std::vector<hso_track_result> res(who.size());
+  // all jobs' feature tables in one page-locked block, back to back in the kernel's layout: the sequences fill their parts in
+  // parallel and the block leaves in one DMA
+  std::vector<size_t> at(who.size() + 1, 0);
+  for (size_t i = 0; i < who.size(); i++) at[i + 1] = at[i] + 6 * ((seq_[who[i]]->n_feats(seq_[who[i]]->frames[ref[i]]) + 31) & ~size_t(31));
+  double* const block = track_tables_.need(ctx_, at.back() + 64);
   pool_->run((int)who.size(), [&](int i) {
     Seq& s = *seq_[who[i]];
-    StepData& d = *step_[who[i]];
     const Frame& R = s.frames[ref[i]];
     const Frame& C = s.frames[cur[i]];
-    reference_features(s, R, d.ref_feats);
+    reference_features(s, R, block + at[i], (at[i + 1] - at[i]) / 6);
     hso_track_job& j = jobs[i];
     j = hso_track_job{};
     j.ref_frame_id = R.dev_id; j.cur_frame_id = C.dev_id;
-    j.feats = d.ref_feats.data(); j.n_feats = (int)d.ref_feats.size();
+    j.feats = reinterpret_cast<const hso_ref_feat*>(block + at[i]); j.n_feats = (int)s.n_feats(R); j.feats_soa = 1;
     j.T_cur_ref = (C.T * R.T.inverse()).v;                        // src/CoarseTracker.cpp:63
     j.exposure_rat = C.integral / R.integral;                     // :60
   });

@@ -161,7 +161,10 @@ typedef struct hso_track_job {
   int64_t cur_frame_id;
   const hso_ref_feat* feats; /* host pointer, n entries */
   int32_t n_feats;
-  int32_t _pad;
+  int32_t feats_soa;         /* 0: `feats` are n_feats hso_ref_feat records.  1: `feats` points to the kernel's own layout — six
+                                arrays px[0] | px[1] | f[0] | f[1] | f[2] | dist of ((n_feats + 31) & ~31) doubles each (pad entries 0)
+                                — which a caller that builds tables for many sequences in parallel writes directly; page-locked
+                                tables of consecutive jobs laid out back to back leave in one DMA */
   hso_se3 T_cur_ref;         /* cur.T_f_w_ * ref.T_f_w_^-1 (CoarseTracker.cpp:63) */
   float exposure_rat;        /* cur.integralImage_/ref.integralImage_ (CoarseTracker.cpp:60) */
   float _pad2;
@@ -747,6 +750,13 @@ int hso_gpu_seqmap_set_keyframes(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, i
  * Asynchronous on the context stream: the rows are copied out of the caller's arrays before the call returns. */
 int hso_gpu_seqmap_patch(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, const hso_map_point* points, int n_points,
                          const int32_t* obs_ids, const hso_obs* obs, int n_obs);
+/* the patches of many maps (one step of many sequences) in one call: one staging image, one scatter per row kind */
+typedef struct hso_seqmap_rows {
+  int32_t map, n_points, n_obs, pad_;
+  const int32_t* point_ids; const hso_map_point* points;
+  const int32_t* obs_ids; const hso_obs* obs;
+} hso_seqmap_rows;
+int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches, int n_patches);
 int hso_gpu_seqmap_size(hso_gpu_ctx* ctx, int map, int* n_kfs, int* n_points, int* n_obs);
 /* parity / trace read-back of rows as the device holds them now */
 int hso_gpu_seqmap_read(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, int n_points, hso_map_point* points_out,

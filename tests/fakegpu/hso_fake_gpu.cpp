@@ -92,7 +92,16 @@ int hso_gpu_coarse_track_batch(hso_gpu_ctx* c, const hso_camera* cam, const hso_
   for (int i = 0; i < n; i++) {
     FakeFrame* R = frame_of(c, jobs[i].ref_frame_id); FakeFrame* C = frame_of(c, jobs[i].cur_frame_id);
     if (!R || !C) return fail(c, HSO_E_NOFRAME, "coarse_track: frame not resident");
-    hso_or_tracker* t = hso_or_tracker_create(cam, p, R->pyr, C->pyr, R->w, R->h, jobs[i].feats, jobs[i].n_feats);
+    std::vector<hso_ref_feat> rec;
+    const hso_ref_feat* feats = jobs[i].feats;
+    if (jobs[i].feats_soa) {
+      const size_t n = (size_t)jobs[i].n_feats, st = (n + 31) & ~size_t(31);
+      const double* a = reinterpret_cast<const double*>(jobs[i].feats);
+      rec.resize(n);
+      for (size_t q = 0; q < n; q++) { rec[q].px[0] = a[q]; rec[q].px[1] = a[st + q]; rec[q].f[0] = a[2 * st + q]; rec[q].f[1] = a[3 * st + q]; rec[q].f[2] = a[4 * st + q]; rec[q].dist = a[5 * st + q]; }
+      feats = rec.data();
+    }
+    hso_or_tracker* t = hso_or_tracker_create(cam, p, R->pyr, C->pyr, R->w, R->h, feats, jobs[i].n_feats);
     memset(&res[i], 0, sizeof(res[i]));
     hso_or_tracker_run(t, &jobs[i].T_cur_ref, jobs[i].exposure_rat, &res[i]);
     hso_or_tracker_destroy(t);
@@ -124,6 +133,12 @@ int hso_gpu_seqmap_patch(hso_gpu_ctx* c, int m, const int32_t* pid, const hso_ma
     if ((size_t)pid[i] >= M->pts.size()) M->pts.resize((size_t)pid[i] + 1, hso_map_point{});
     M->pts[(size_t)pid[i]] = pts[i];
   }
+  return HSO_OK;
+}
+int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* c, const hso_seqmap_rows* p, int n)
+{
+  for (int i = 0; i < n; i++)
+    if (int rc = hso_gpu_seqmap_patch(c, p[i].map, p[i].point_ids, p[i].points, p[i].n_points, p[i].obs_ids, p[i].obs, p[i].n_obs)) return rc;
   return HSO_OK;
 }
 int hso_gpu_seqmap_size(hso_gpu_ctx* c, int m, int* nk, int* np, int* no)
