@@ -36,13 +36,15 @@ The JSON line also carries
                  (SQ_INSTS_VALU of a PMC pass on exactly this workload, profiles/) / the live launch duration, against
                  1024 SIMDs x clock / 4 (one wave64 VALU instruction per four clocks and SIMD), plus the PMC pass's own
                  VALU-busy fraction;
-  chain        — the WHOLE per-frame chain (frame build + tracker -> reprojection / matching / grid selection -> pose
-                 optimisation -> seed updates) for 256 independent sequences at the same shape through the resident-table
-                 entry points: frames/s, per-stage ms and algorithmic-byte fractions (hso_amd/chain_bench.py), with the CPU
-                 restatement of the same stages timed beside it (1 thread; seed updates also on the reference's 4 threads);
-  single_sequence — BASELINE configs[2]/[3] are ONE sequence: latency of one tracker call (1 job: the cooperative shape splits
-                 it across the CUs of an XCD) and ms per frame of one sequence through the C++ driver libhso_host.so
-                 (FrameHandlerMono::addImage), at 200 and 2000 features (hso_amd/latency_bench.py);
+  sequences_frames_per_s — the WHOLE per-frame chain end to end on evolving state (FrameHandlerMono::addImage: frame build, tracker,
+                 reprojection + matching + grid selection + pose optimisation, local BA, depth filter) through the sequence
+                 engine (libhso_host.so, hso_vo_multi_*): `--banks` engines x `--sequences` sequences of `--seq-feats` features
+                 per GPU, images resident in HBM; sequences_cpu_frames_per_s = the same engine over the CPU restatement
+                 (one sequence, one thread; tests/fakegpu);
+  single_sequence_ms_200 / _2000 — BASELINE configs[2]/[3] are ONE sequence: ms per addImage of one sequence through the engine;
+                 single_track_call_ms_2000: one tracker call (the cooperative shape splits a job across the CUs of an XCD);
+  (everything else — per-bank step times, call counts, the single-sequence tables, the gathered trajectory shape — goes to
+   bench_detail.json beside this file: the printed line stays small)
   se3_vs_cpu   — per-frame SE(3) deviation GPU vs the strict CPU restatement on the distinct
                  scenes (rotation angle, translation, iteration-count agreement) — the second
                  half of BASELINE.json's metric; `vs_f64_energy_sum` repeats it against the restatement
@@ -106,25 +108,39 @@ def _render_scene(job):
                 q_init=synth.rotvec_to_quat(rv0), t_init=t0)
 
 
-def _render_any(job):
-    if job[0] == "chain":
-        from hso_amd import chain_bench
-        return chain_bench.build_scene(job[1])
-    return _render_scene(job[1])
-
-
-def render_scenes(shape, feats, seeds, chain_jobs=()):
-    """Scenes render in worker processes (forked before any GPU runtime exists in this process).  The chain's little worlds
-    (seven rendered frames each) go first: they take longest."""
+def render_scenes(shape, feats, seeds):
+    """Distinct scenes render in worker processes (forked before any GPU runtime exists in this process) and are cached under the
+    temporary directory, keyed by their parameters: the 1 / 2 / 4 / 8-GPU runs of one node, and repeated runs on one box, render once."""
     import multiprocessing as mp
-    jobs = [("chain", j) for j in chain_jobs] + [("pair", (shape, feats, int(s))) for s in seeds]
-    nproc = max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 32))
-    if nproc == 1:
-        out = [_render_any(j) for j in jobs]
-    else:
-        with mp.get_context("fork").Pool(nproc) as pool:
-            out = pool.map(_render_any, jobs, chunksize=1)
-    return out[len(chain_jobs):], out[:len(chain_jobs)]
+    import pickle
+    import tempfile
+    cache = os.path.join(tempfile.gettempdir(), "hso_bench_scenes_v4")
+    os.makedirs(cache, exist_ok=True)
+    out, todo = {}, []
+    for s in seeds:
+        fn = os.path.join(cache, "%s_%d_%d.pkl" % (shape, feats, int(s)))
+        try:
+            with open(fn, "rb") as f:
+                out[int(s)] = pickle.load(f)
+        except (OSError, EOFError, pickle.UnpicklingError):
+            todo.append((shape, feats, int(s)))
+    if todo:
+        nproc = max(1, min(len(todo), (os.cpu_count() or 2) - 1, 64))
+        if nproc == 1:
+            res = [_render_scene(j) for j in todo]
+        else:
+            with mp.get_context("fork").Pool(nproc) as pool:
+                res = pool.map(_render_scene, todo, chunksize=1)
+        for j, r in zip(todo, res):
+            out[j[2]] = r
+            try:
+                tmp = os.path.join(cache, "%s_%d_%d.pkl.%d" % (j[0], j[1], j[2], os.getpid()))
+                with open(tmp, "wb") as f:
+                    pickle.dump(r, f, protocol=4)
+                os.replace(tmp, tmp[:tmp.rindex(".")])
+            except OSError:
+                pass
+    return [out[int(s)] for s in seeds]
 
 
 def self_launch(args):
@@ -138,24 +154,30 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def start_pose(sc, variant):
+    """The motion-model prediction a job starts from.  Variant 0 is the scene's own; 1..3 are other plausible predictions of the
+    same motion (scaled / perturbed deterministically), so that replicas of a scene walk different Levenberg-Marquardt paths: the
+    per-frame SE(3) comparison with the CPU restatement then covers 4 x scenes distinct (scene, start) frames."""
+    if variant == 0:
+        return sc["q_init"], sc["t_init"]
+    rng = np.random.default_rng(9000 + 31 * variant + int(1e6 * abs(float(sc["t_true"][0]))) % 100000)
+    from hso_amd import synth
+    q = np.asarray(sc["q_true"], float)
+    rv = 2 * np.arctan2(np.linalg.norm(q[:3]), q[3]) * q[:3] / max(np.linalg.norm(q[:3]), 1e-12)
+    rv0 = rv * rng.uniform(0.5, 1.2) + rng.normal(0, np.deg2rad(0.05), 3)
+    t0 = np.asarray(sc["t_true"]) * rng.uniform(0.5, 1.2) + rng.normal(0, 0.12 * np.linalg.norm(sc["t_true"]), 3)
+    return synth.rotvec_to_quat(rv0), t0
+
+
 def rot_angle(qa, qb):
     """Angle of qa * qb^-1 for unit quaternions (x, y, z, w)."""
     d = abs(float(np.dot(qa, qb)))
     return 2 * np.arccos(min(1.0, d))
 
 
-def extra_measurements(out, args, ctx, stream, spec, chain_scenes, seq_S, cam, orc):
-    """rank 0, N = 1, after the timed region: the whole per-frame chain for many sequences, the single-sequence latency, and
-    the CPU restatement of the chain's stages (the tracker's is out["cpu_baseline"])."""
-    import torch
-    from hso_amd import capi, chain_bench, latency_bench
-    if chain_scenes:
-        with torch.cuda.stream(stream):
-            chain, ch = chain_bench.measure(ctx, stream, spec, chain_scenes, args.chain_seqs, args.feats, algorithmic_bytes=algorithmic_bytes)
-        out["chain"] = chain
-        if orc is not None and args.cpu_frames > 0:
-            out["chain"]["cpu_baseline"] = chain_cpu_baseline(orc, cam, chain_scenes[0], ch, out.get("cpu_baseline"))
-        del ch
+def single_sequence(args, ctx, stream, spec, seq_S, cam):
+    """BASELINE configs[2]/[3] are ONE sequence: latency of one tracker call and ms per addImage of one sequence through the engine."""
+    from hso_amd import latency_bench
     single = {"shape": "%dx%d" % (spec["width"], spec["height"]), "track": [], "sequence": []}
     for n in (200, args.feats):
         single["track"].append(latency_bench.track_latency(ctx, stream, cam, spec, n, 20))
@@ -164,77 +186,32 @@ def extra_measurements(out, args, ctx, stream, spec, chain_scenes, seq_S, cam, o
             single["sequence"].append(latency_bench.sequence_latency(cam, seq_S, n))
     single["what"] = ("track: ONE job per call (hso_gpu_coarse_track_batch wall time incl. table upload, launch, read-back; launch_ms "
                       "between HIP events); sequence: ms per addImage of one synthetic %d-frame sequence through libhso_host.so" % args.seq_frames)
-    out["single_sequence"] = single
+    return single
 
 
-def chain_cpu_baseline(orc, cam, S, ch, track_cpu):
-    """The CPU restatement (oracle/, -O3 -march=native build already selected by the tracker's baseline) on the stages of the
-    chain, one distinct scene, batch entry points (no per-item interpreter time): findMatchDirect over the projected map
-    points, optimizeLevenbergMarquardt3rd, observeDepthRow over the seeds — 1 thread, and the seeds also on 4 threads like the
-    reference's depth filter (include/hso/IndexThreadReduce.h:27)."""
-    import ctypes as C
-    from hso_amd import capi
-    M = S["M"]
-    lib = orc.load()
-    T = capi.SE3.from_arrays(*M["T_cur_w"])
-    kf_pyrs = [orc.create_pyramid(f) for f in M["frames"]]
-    cur_pyr = orc.create_pyramid(M["cur"])
-    cur_sob = [orc.sobel5(np.ascontiguousarray(cur_pyr[L])) for L in range(3)]
-    # candidate list (untimed set-up through the per-point wrappers: projection + reference choice)
-    lib.hso_or_reproject_point.argtypes = [C.POINTER(capi.Camera), C.POINTER(capi.SE3), C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
-                                           C.c_void_p, C.POINTER(C.c_int)]
-    lib.hso_or_reproject_point.restype = C.c_int
-    lib.hso_or_close_view_obs.argtypes = [C.c_void_p] * 4 + [C.c_int]
-    lib.hso_or_close_view_obs.restype = C.c_int
-    lib.hso_or_reproject_make_job.argtypes = [C.POINTER(capi.SE3), C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                              C.POINTER(capi.AlignJob)]
-    lib.hso_or_reproject_make_job.restype = None
-    kfs, pts, obs = M["kfs"], M["points"], M["obs"]
-    cur_pos = np.array(orc.se3_inverse(T).t[:])
-    jobs, job_kf = [], []
-    for i, p in enumerate(pts):
-        px = np.zeros(2); cell = C.c_int(0)
-        Th = kfs[p["host_kf"]:p["host_kf"] + 1]
-        if not lib.hso_or_reproject_point(C.byref(cam), C.byref(T), Th.ctypes.data + 8, p["host_f"].ctypes.data, float(p["idist"]),
-                                          M["cell_size"], M["grid_n_cols"], px.ctypes.data, C.byref(cell)):
-            continue
-        o = obs[p["obs_begin"]:p["obs_begin"] + p["obs_count"]]
-        k = lib.hso_or_close_view_obs(cur_pos.ctypes.data, p["pos"].ctypes.data, kfs.ctypes.data, o.ctypes.data, len(o)) if len(o) else -1
-        if k < 0:
-            continue
-        j = capi.AlignJob()
-        lib.hso_or_reproject_make_job(C.byref(T), M["cur_exposure"], M["cur_keyframe_id"], kfs.ctypes.data, pts[i:i + 1].ctypes.data,
-                                      o[k:k + 1].ctypes.data, px.ctypes.data, C.byref(j))
-        jobs.append(j); job_kf.append(int(o[k]["kf"]))
-    ja = (capi.AlignJob * len(jobs))(*jobs)
-    t0 = time.perf_counter(); reps = 0
-    while time.perf_counter() - t0 < 3.0:
-        mo = orc.find_match_direct_batch(cam, ja, job_kf, kf_pyrs, cur_pyr, cur_sob); reps += 1
-    t_match = (time.perf_counter() - t0) / reps
-    t0 = time.perf_counter(); reps = 0
-    while time.perf_counter() - t0 < 2.0:
-        orc.pose_optimize(cam, ch._pj[0]); reps += 1
-    t_pose = (time.perf_counter() - t0) / reps
-    seeds = (capi.Seed * S["n_seeds"]).from_buffer_copy(S["seeds_bytes"])
-    pea = ch.pea
-    t_seed = {}
-    for nt in (1, 4):
-        t0 = time.perf_counter(); reps = 0
-        while time.perf_counter() - t0 < 3.0:
-            so = orc.seed_observe_batch(cam, seeds, T, M["cur_exposure"], pea, kf_pyrs[0], cur_pyr, cur_sob, nt); reps += 1
-        t_seed[nt] = (time.perf_counter() - t0) / reps
-    t_track = 1.0 / track_cpu["value"] if track_cpu else None
-    tot1 = (t_track or 0) + t_match + t_pose + t_seed[1]
-    tot4 = (t_track or 0) + t_match + t_pose + t_seed[4]
-    return {"value": 1.0 / tot1, "unit": "frames/s", "cores": 1, "kind": "port",
-            "value_seed_updates_on_4_threads": 1.0 / tot4, "cores_seed_updates": 4,
-            "ms_per_frame": {"track": 1e3 * t_track if t_track else None, "match": 1e3 * t_match, "pose": 1e3 * t_pose,
-                             "seeds_1_thread": 1e3 * t_seed[1], "seeds_4_threads": 1e3 * t_seed[4]},
-            "sample": "one frame of one distinct scene per stage, repeated for 2-3 s each: findMatchDirect over %d projected map points "
-                      "(projection and reference choice not timed), optimizeLevenbergMarquardt3rd on %d features, observeDepthRow over %d "
-                      "seeds; oracle/ C restatement through its batch entry points; track = the tracker baseline above"
-                      % (len(jobs), len(ch.pose_feats), S["n_seeds"]),
-            "matched": int(sum(m.success for m in mo)), "seeds_updated": int(sum(o.result == 1 for o in so))}
+def cpu_sequence_baseline(cam, seq_S, max_fts, n_frames):
+    """The CPU path of a WHOLE evolving sequence, timed beside the GPU's: the same engine (hso_amd/host/hso_engine*.cpp) linked
+    against the CPU restatement instead of libhso_gpu.so (tests/fakegpu: every numeric stage = the oracle's function, one thread) —
+    frame construction, tracker, reprojection + matching + selection, pose optimisation, local BA, depth filter."""
+    from hso_amd import vo
+    path = os.path.join(ROOT, "tests", "fakegpu", "libhso_host_fake.so")
+    if not os.path.exists(path):
+        return None
+    lib = vo.load_from(path)
+    odo = vo.VisualOdometry(cam, max_fts, lib=lib)
+    odo.set_first_frame(seq_S["images"][0], seq_S["depth0"], 0.0)
+    t0 = time.perf_counter()
+    n_kf = 0
+    for k in range(1, n_frames):
+        st = odo.add_image(seq_S["images"][k], float(k))
+        n_kf += st.is_keyframe
+    dt = time.perf_counter() - t0
+    q, t = odo.status().T_f_w.to_arrays()
+    err = float(np.linalg.norm(t - seq_S["T_f_w"][n_frames - 1][1]))
+    odo.close()
+    return {"value": (n_frames - 1) / dt, "unit": "frames/s", "cores": 1, "kind": "port", "ms_per_frame": 1e3 * dt / (n_frames - 1),
+            "sample": "%d frames (%d keyframes) of one %d-feature sequence through the engine over oracle/ (strict build), %.1f s"
+                      % (n_frames - 1, n_kf, max_fts, dt), "trans_err_last": err}
 
 
 def main():
@@ -249,10 +226,13 @@ def main():
     ap.add_argument("--scenes", type=int, default=64, help="distinct synthetic scenes rendered per rank")
     ap.add_argument("--inverse", type=int, default=0)
     ap.add_argument("--min-level", type=int, default=1, help="developer knob: stop the tracker above level 1 (the judged line uses 1)")
-    ap.add_argument("--cpu-frames", type=int, default=600, help="frames in the cpu_baseline sample (about 10 s on one host core)")
-    ap.add_argument("--chain-seqs", type=int, default=256, help="sequences of the whole-chain measurement (0 = skip; N = 1 only)")
+    ap.add_argument("--cpu-frames", type=int, default=400, help="frames in the cpu_baseline sample (about 7 s on one host core)")
     ap.add_argument("--seq-frames", type=int, default=24, help="frames per sequence of the end-to-end runs through libhso_host.so (0 = skip)")
-    ap.add_argument("--sequences", type=int, default=8, help="sequences per rank of the lockstep multi-sequence run (hso_vo_multi_*; 0 = skip)")
+    ap.add_argument("--sequences", type=int, default=128, help="sequences per engine (bank) of the end-to-end run (hso_vo_multi_*; 0 = skip)")
+    ap.add_argument("--banks", type=int, default=2, help="engines per GPU, each on its own host thread and stream")
+    ap.add_argument("--seq-feats", type=int, default=2000, help="Config::maxFts() of the end-to-end run")
+    ap.add_argument("--seq-distinct", type=int, default=8, help="distinct rendered sequences per rank (replicated to --sequences x --banks)")
+    ap.add_argument("--se3-frames", type=int, default=256, help="frames of the per-frame SE(3) comparison with the CPU restatement")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
                          "BASELINE.json's metric is quoted on; vga: BASELINE configs[1], 640x480 pinhole")
@@ -272,14 +252,11 @@ def main():
     from hso_amd import synth as _synth
     spec0 = _synth.EUROC if args.shape == "euroc" else _synth.ICL_NUIM
     extras = rank == 0 and world == 1
-    chain_jobs = []
-    if extras and args.chain_seqs > 0:
-        from hso_amd import chain_bench
-        chain_jobs = chain_bench.scene_jobs(spec0, args.feats, 2 * args.feats, 3 * args.feats, 4)
-    scenes, chain_scenes = render_scenes(args.shape, args.feats, [1234 + 7 * s for s in seq_ids], chain_jobs)
-    # sequences for the end-to-end driver: `--sequences` per rank through hso_vo_multi_* at every N (their trajectories are what the
-    # ranks gather); the first one also serves the single-sequence latency at N = 1.  Rendered by their own pool, before the GPU runtime.
-    seq_list = _synth.sequences(args.sequences, args.seq_frames, spec=spec0, seed0=2024 + 1000 * rank) if args.seq_frames > 1 and args.sequences > 0 else []
+    scenes = render_scenes(args.shape, args.feats, [1234 + 7 * s for s in seq_ids])
+    # sequences for the end-to-end engine: `--seq-distinct` rendered per rank (replicated to banks x sequences) at every N — their
+    # trajectories are what the ranks gather; the first one also serves the single-sequence latency and the CPU sequence baseline
+    seq_list = (_synth.sequences(max(1, min(args.seq_distinct, args.sequences)), args.seq_frames, spec=spec0, seed0=2024 + 1000 * rank)
+                if args.seq_frames > 1 and args.sequences > 0 else [])
     seq_S = seq_list[0] if extras and seq_list else None
     t_render = time.perf_counter() - t_r0
 
@@ -310,12 +287,13 @@ def main():
         cur_dev = [[torch.from_numpy(scenes[i % n_sc][k]).cuda() for i in range(B)] for k in ("cur", "cur_b")]
         cur_ptrs = [np.array([t.data_ptr() for t in cd], np.uint64) for cd in cur_dev]
         st_cur = ctx.frame_upload_batch(cur_ids, device_ptrs=cur_ptrs[0], width=W, height=H)
-        jobs, a0s = [], []
+        jobs, a0s, starts = [], [], []
         for i in range(B):
             sc = scenes[i % n_sc]
             a0 = float(np.float32(st_cur[i].integral_image / st_ref[i].integral_image))  # CoarseTracker.cpp:60
             a0s.append(a0)
-            jobs.append(ctx.make_job(ref_ids[i], cur_ids[i], sc["feats"], capi.SE3.from_arrays(sc["q_init"], sc["t_init"]), a0))
+            starts.append(start_pose(sc, (i // n_sc) % 4))
+            jobs.append(ctx.make_job(ref_ids[i], cur_ids[i], sc["feats"], capi.SE3.from_arrays(*starts[i]), a0))
         ctx.coarse_track_prepare(cam, params, jobs)
 
         def step(k, ev=None):
@@ -388,7 +366,7 @@ def main():
             pass
 
     # sanity: every frame converged to its scene's motion (guards against timing a broken run)
-    terr = [float(np.linalg.norm(rec[i, 4:7] - scenes[i % n_sc]["t_true"])) for i in range(min(B, n_sc))]
+    terr = [float(np.linalg.norm(rec[i, 4:7] - scenes[i % n_sc]["t_true"])) for i in range(min(B, 4 * n_sc))]
     assert max(terr) < 1e-2, "tracking diverged in the benchmark (%.3g)" % max(terr)
 
     shape_txt = ("EuRoC-shaped synthetic 752x480 (radtan camera, test/cameras/euroc.txt) 5-level pyramid" if args.shape == "euroc"
@@ -434,19 +412,22 @@ def main():
         rot, tr, it_eq, acc_eq = [], [], 0, 0
         rot64, tr64, acc_eq64, self_eq64 = [], [], 0, 0
         pyr = {}
-        n_cmp = min(n_sc, B)
+        n_cmp = min(4 * n_sc, B, max(1, args.se3_frames))
         for i in range(n_cmp):
-            d = scenes[i]
-            pyr[i] = (orc.create_pyramid(d["ref"]), orc.create_pyramid(d["cur"]))
-            ro = orc.Tracker(cam, params, pyr[i][0], pyr[i][1], d["feats"]).run(capi.SE3.from_arrays(d["q_init"], d["t_init"]), a0s[i])
+            d = scenes[i % n_sc]
+            if i % n_sc not in pyr:
+                pyr[i % n_sc] = (orc.create_pyramid(d["ref"]), orc.create_pyramid(d["cur"]))
+            P = pyr[i % n_sc]
+            T0 = capi.SE3.from_arrays(*starts[i])
+            ro = orc.Tracker(cam, params, P[0], P[1], d["feats"]).run(T0, a0s[i])
             qg, tg = res_a[i].T_cur_ref.to_arrays(); qo, to = ro.T_cur_ref.to_arrays()
             rot.append(rot_angle(qg, qo)); tr.append(float(np.linalg.norm(tg - to)))
             it_eq += int(list(res_a[i].iters) == list(ro.iters))
             acc_eq += int(list(res_a[i].accept_mask) == list(ro.accept_mask))
             # diagnostics: the same restatement deciding on the fp64 sum of the same fp32 energy terms (not the reference's
             # behaviour): separates "the device decides differently" from "the reference's serial fp32 sum decided by its rounding"
-            t64 = orc.Tracker(cam, params, pyr[i][0], pyr[i][1], d["feats"]); t64.decide_on_f64_sum(True)
-            r64 = t64.run(capi.SE3.from_arrays(d["q_init"], d["t_init"]), a0s[i])
+            t64 = orc.Tracker(cam, params, P[0], P[1], d["feats"]); t64.decide_on_f64_sum(True)
+            r64 = t64.run(T0, a0s[i])
             q6, t6 = r64.T_cur_ref.to_arrays()
             rot64.append(rot_angle(qg, q6)); tr64.append(float(np.linalg.norm(tg - t6)))
             acc_eq64 += int(list(res_a[i].accept_mask) == list(r64.accept_mask) and list(res_a[i].iters) == list(r64.iters))
@@ -465,7 +446,7 @@ def main():
         n_cpu = args.cpu_frames
         tc0 = time.perf_counter()
         for i in range(n_cpu):
-            k = i % n_cmp
+            k = i % min(n_cmp, n_sc)
             d = scenes[k]
             cp = orc.create_pyramid(d["cur"])
             for l in range(3):
@@ -480,33 +461,63 @@ def main():
                                "sample": "%d frames of the same workload (pyramid + Sobel + stats + CoarseTracker from the same "
                                          "initial poses), oracle/ C restatement, 1 thread, %.1f s" % (n_cpu, tc1 - tc0),
                                "build": flags, "host_cpus": os.cpu_count()}
-    # ---- the end-to-end driver at every N: `--sequences` sequences per rank in lockstep through hso_vo_multi_* (one context per GPU,
-    # the device calls of all sequences batched per kind); the ranks' per-frame trajectories are gathered over RCCL — the path's
-    # only exchange (BASELINE north_star / configs[4])
+    # ---- the end-to-end engine at every N: `--banks` engines x `--sequences` sequences per rank (hso_vo_multi_*: every numeric stage
+    # of a step one batched C-ABI call for a bank's sequences; the banks on their own threads and streams), images resident in
+    # HBM; the ranks' per-frame trajectories are gathered over RCCL — the path's only exchange (BASELINE north_star / configs[4])
+    detail_extra = {}
     if seq_list:
-        from hso_amd import latency_bench
+        from hso_amd import bank_bench
+        ctx.close()                                  # the headline's 4096 resident pairs leave HBM before the engines start
+        del cur_dev
+        torch.cuda.empty_cache()
         if world > 1:
             dist.barrier()
-        tq0 = time.perf_counter()
-        mres, traj = latency_bench.multi_sequence_run(cam, seq_list, 200, local_rank)
-        t_multi = time.perf_counter() - tq0
-        tr_rec = hdist.pack_trajectories(traj, args.seq_frames)
-        all_tr = hdist.gather_records(tr_rec, device=dev)
-        assert all_tr.shape == (world, len(seq_list), args.seq_frames, 8) and (world == 1 or dist.get_world_size() == world)
-        t_multi_max = hdist.max_over_ranks(t_multi, device=dev)
-        fps_all = hdist.max_over_ranks(0.0, device=dev)  # (keeps the collective count equal on every rank)
-        del fps_all
+        mres, traj = bank_bench.run_banks(args.banks, args.sequences, args.seq_frames, args.seq_feats, spec=spec, device=local_rank, seqs=seq_list,
+                                          want_traj=True)
+        n_seq_rank = args.banks * args.sequences
+        tr_rec = np.zeros((n_seq_rank, args.seq_frames, 8))
+        for q, T in enumerate(traj):
+            tr_rec[q, :len(T), :7] = T[:args.seq_frames]
+            tr_rec[q, :len(T), 7] = 1.0
+        all_tr = hdist.gather_records(tr_rec.reshape(n_seq_rank * args.seq_frames, 8), device=dev)
+        assert all_tr.shape[0] == world and (world == 1 or dist.get_world_size() == world)
         tl = torch.tensor([mres["frames_per_s"]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tl)
-        out["sequences"] = dict(mres, ranks=world, sequences_total=world * len(seq_list), frames_per_s_all_ranks=float(tl.item()),
-                                gathered_trajectory_shape=list(all_tr.shape), wall_s_incl_setup=t_multi_max,
-                                what="end-to-end FrameHandlerMono::addImage for %d sequences per GPU in lockstep (hso_vo_multi_*: one batched C-ABI "
-                                     "call per kind and step), 200 features; trajectories of all ranks gathered (torch.distributed %s, world %d)"
-                                     % (len(seq_list), "nccl = RCCL" if world > 1 else "not initialised", world))
-    if extras and (args.chain_seqs > 0 or seq_S is not None):
-        extra_measurements(out, args, ctx, stream, spec, chain_scenes, seq_S, cam, locals().get("orc"))
+        detail_extra["sequences"] = dict(mres, ranks=world, sequences_total=world * n_seq_rank, frames_per_s_all_ranks=float(tl.item()),
+                                   gathered_trajectory_shape=list(all_tr.shape),
+                                   what="end-to-end FrameHandlerMono::addImage on evolving state: frame build, tracker, reprojection + matching + grid "
+                                        "selection + pose optimisation, local BA, depth filter (seed observation, activation, new seeds); %d engines x %d "
+                                        "sequences per GPU, %d features, %d distinct rendered sequences replicated; images resident in HBM; "
+                                        "trajectories of all ranks gathered (torch.distributed %s, world %d)"
+                                        % (args.banks, args.sequences, args.seq_feats, len(seq_list), "nccl = RCCL" if world > 1 else "not initialised", world))
+        out["sequences_frames_per_s"] = float(tl.item())
+        out["sequences_config"] = "%d engines x %d sequences x %d features per GPU, %d frames, end to end on evolving state" % (
+            args.banks, args.sequences, args.seq_feats, args.seq_frames - 1)
+        out["sequences_failures"] = mres["failures"]
+    if extras and seq_S is not None:
+        ctx2 = capi.Context(local_rank, stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            single = single_sequence(args, ctx2, stream, spec, seq_S, cam)
+        ctx2.close()
+        detail_extra["single_sequence"] = single
+        out["single_sequence_ms_200"] = single["sequence"][0]["ms_per_frame"]
+        out["single_sequence_ms_2000"] = single["sequence"][1]["ms_per_frame"]
+        out["single_track_call_ms_2000"] = single["track"][1]["call_ms"]
+        if args.cpu_frames > 0:
+            cb = cpu_sequence_baseline(cam, seq_S, args.seq_feats, args.seq_frames)
+            if cb:
+                detail_extra["sequences_cpu_baseline"] = cb
+                out["sequences_cpu_frames_per_s"] = cb["value"]
     if rank == 0:
+        # the judged line stays small (the driver keeps what fits its parser); everything else goes to a side file
+        try:
+            detail = dict(out)
+            detail.update(detail_extra)
+            with open(os.path.join(ROOT, "bench_detail.json"), "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError:
+            pass
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -51,7 +51,7 @@ def run(n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, on_d
                 calls=counts)
 
 
-def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None):
+def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False):
     """n_banks engines of n_seq sequences each, every one on its own host thread with its own device context / stream: the
     device work of one bank overlaps the bookkeeping and the PCIe traffic of the others (independent sequences shard freely, also
     within one GPU).  Whole-run throughput: all frames / wall time from the first step to the last bank's last step."""
@@ -61,6 +61,7 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
     if seqs is None:
         seqs = synth.sequences(min(distinct, n_seq), frames, spec=spec, seed0=777)
     res = [None] * n_banks
+    traj = [None] * n_banks
     gate = threading.Barrier(n_banks + 1)
     t_end = [0.0] * n_banks
 
@@ -83,7 +84,10 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
             ms.append(1e3 * (time.perf_counter() - t0))
         t_end[b] = time.perf_counter()
         sts = [m.status(q) for q in range(n_seq)]
-        res[b] = dict(ms_per_step_mean=float(np.mean(ms[2:])), failures=sum(int(st.stage != 3 or st.result == 2) for st in sts),
+        if want_traj:
+            traj[b] = [m.trajectory(q)[1] for q in range(n_seq)]
+        kfs = [len(m.keyframes(q)) - 1 for q in range(n_seq)]
+        res[b] = dict(ms_per_step_mean=float(np.mean(ms[2:])), ms_per_step_median=float(np.median(ms[2:])), keyframes=float(np.mean(kfs)), failures=sum(int(st.stage != 3 or st.result == 2) for st in sts),
                       trans_err_max=max(float(np.linalg.norm(np.array(sts[q].T_f_w.t[:]) - pick[q]["T_f_w"][frames - 1][1])) for q in range(n_seq)))
         m.close()
 
@@ -95,9 +99,14 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
     for t in th:
         t.join()
     wall = max(t_end) - t0
-    return dict(banks=n_banks, sequences_per_bank=n_seq, sequences=n_banks * n_seq, frames=frames - 1, max_fts=max_fts, images="device",
-                frames_per_s=n_banks * n_seq * (frames - 1) / wall, wall_s=wall, ms_per_step_mean_per_bank=[r["ms_per_step_mean"] for r in res],
-                failures=sum(r["failures"] for r in res), trans_err_max=max(r["trans_err_max"] for r in res))
+    out = dict(banks=n_banks, sequences_per_bank=n_seq, sequences=n_banks * n_seq, frames=frames - 1, max_fts=max_fts, images="device",
+               distinct=len(seqs), frames_per_s=n_banks * n_seq * (frames - 1) / wall, wall_s=wall,
+               ms_per_step_mean_per_bank=[r["ms_per_step_mean"] for r in res], ms_per_step_median_per_bank=[r["ms_per_step_median"] for r in res],
+               keyframes_per_sequence=float(np.mean([r["keyframes"] for r in res])),
+               failures=sum(r["failures"] for r in res), trans_err_max=max(r["trans_err_max"] for r in res))
+    if want_traj:
+        return out, [t for b in traj for t in b]
+    return out
 
 
 if __name__ == "__main__":

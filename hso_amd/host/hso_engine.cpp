@@ -118,6 +118,14 @@ int Bank::keyframes(int k, double* stamps, hso_se3* T_f_w, int32_t* frame_ids, i
   return n;
 }
 
+int Bank::trajectory(int k, double* stamps, hso_se3* T_f_w, int cap) const
+{
+  const Seq& s = *seq_[k];
+  const int n = (int)s.hist_pose.size();
+  for (int i = 0; i < n && i < cap; i++) { if (stamps) stamps[i] = s.hist_stamp[i]; if (T_f_w) T_f_w[i] = s.hist_pose[i]; }
+  return n;
+}
+
 void Bank::release_frame(Seq& s, Id fr)
 {
   if (fr == kNone) return;

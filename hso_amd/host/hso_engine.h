@@ -156,6 +156,8 @@ public:
   void add_images(const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device = false);
   void status(int k, hso_vo_status* st) const;
   int keyframes(int k, double* stamps, hso_se3* T_f_w, int32_t* frame_ids, int cap) const;
+  // every frame the sequence has processed since its start: (timestamp, T_f_w as it stood when the frame was finished)
+  int trajectory(int k, double* stamps, hso_se3* T_f_w, int cap) const;
   bool trace(int k, const char* path);
   void call_counts(int64_t* calls, int64_t* items, int cap) const;
   std::string err;

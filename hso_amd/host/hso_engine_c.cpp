@@ -116,6 +116,12 @@ int hso_vo_multi_get_keyframes(hso_vo_multi* m, int sequence, double* timestamps
   if (!m || sequence < 0 || sequence >= m->bank->size()) return HSO_E_INVALID;
   return m->bank->keyframes(sequence, timestamps, T_f_w, frame_ids, cap);
 }
+int hso_vo_multi_get_trajectory(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int cap)
+{
+  if (!m || sequence < 0 || sequence >= m->bank->size()) return HSO_E_INVALID;
+  return m->bank->trajectory(sequence, timestamps, T_f_w, cap);
+}
+int hso_vo_get_trajectory(hso_vo* v, double* timestamps, hso_se3* T_f_w, int cap) { return v ? v->bank->trajectory(0, timestamps, T_f_w, cap) : HSO_E_INVALID; }
 int hso_vo_multi_call_counts(hso_vo_multi* m, int64_t* calls, int64_t* items, int cap)
 {
   if (!m) return HSO_E_INVALID;

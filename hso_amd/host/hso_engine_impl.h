@@ -142,6 +142,7 @@ struct Seq {
   double kf_depth_mean = 0, kf_depth_min = 0;
   TwoView init;
   std::vector<int> votes;         // scratch of the covisibility count
+  std::vector<double> hist_stamp; std::vector<hso_se3> hist_pose;   // every processed frame's final pose (what a harness writes as the trajectory)
   hso_vo_status log{};
   Trace trace;
 
@@ -334,7 +335,7 @@ struct Seq {
   {
     frames.clear(); free_slots.clear(); feats.clear(); points.clear(); seeds.clear(); n_dead_seeds = 0;
     kfs.clear(); dev_kfs.clear(); candidates.clear(); temps.clear(); dirty_pts.clear(); dirty_obs.clear(); pt_flag.clear(); obs_flag.clear();
-    kfs_dirty = true; local_map.clear(); converge_hist.clear(); prior.clear(); init.clear();
+    kfs_dirty = true; local_map.clear(); converge_hist.clear(); prior.clear(); init.clear(); hist_stamp.clear(); hist_pose.clear();
     last = cur = first = kNone;
   }
 };

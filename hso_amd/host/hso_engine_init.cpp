@@ -93,6 +93,7 @@ void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const doub
     s.last = s.cur; s.cur = kNone;
     if (old != kNone) release_frame(s, old);
     s.n_obs_last = 0;
+    s.hist_stamp.push_back(s.frames[s.last].stamp); s.hist_pose.push_back(s.frames[s.last].T.v);
   }
 }
 

@@ -782,6 +782,7 @@ void Bank::finish(const std::vector<int>& who)
     s.last = s.cur; s.cur = kNone;
     if (old != kNone && old != s.last) release_frame(s, old);
     s.n_obs_last = s.frames[s.last].n_inliers;
+    s.hist_stamp.push_back(s.frames[s.last].stamp); s.hist_pose.push_back(s.frames[s.last].T.v);
     // dead seeds leave the list once they are the majority (list order of the live ones is kept)
     if (s.n_dead_seeds > 256 && s.n_dead_seeds * 2 > (int)s.seeds.size()) {
       size_t keep = 0;

@@ -56,6 +56,8 @@ def _declare(lib):
     lib.hso_vo_multi_get_status.argtypes = [vp, i32, P(VoStatus)]
     lib.hso_vo_multi_get_keyframes.argtypes = [vp, i32, vp, vp, vp, i32]
     lib.hso_vo_multi_call_counts.argtypes = [vp, vp, vp, i32]
+    lib.hso_vo_multi_get_trajectory.argtypes = [vp, i32, vp, vp, i32]
+    lib.hso_vo_get_trajectory.argtypes = [vp, vp, vp, i32]
     return lib
 
 
@@ -79,7 +81,7 @@ EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso
                     "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes", "hso_vo_start", "hso_vo_init_compute_matrix",
                     "hso_vo_multi_create", "hso_vo_multi_destroy", "hso_vo_multi_last_error", "hso_vo_multi_size",
                     "hso_vo_multi_set_first_frames", "hso_vo_multi_add_images", "hso_vo_multi_get_status", "hso_vo_multi_get_keyframes",
-                    "hso_vo_multi_call_counts", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device"]
+                    "hso_vo_multi_call_counts", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device", "hso_vo_multi_get_trajectory", "hso_vo_get_trajectory"]
 
 CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_select_pose", "align", "pose", "seed_observe", "seed_activate", "ba", "other"]
 
@@ -151,6 +153,13 @@ class MultiVisualOdometry:
         ts = np.zeros(max(n, 1)); T = (capi.SE3 * max(n, 1))(); ids = np.zeros(max(n, 1), np.int32)
         self.lib.hso_vo_multi_get_keyframes(self.h, k, capi._ptr(ts), C.cast(T, C.c_void_p), capi._ptr(ids), n)
         return [(float(ts[i]), T[i], int(ids[i])) for i in range(n)]
+
+    def trajectory(self, k):
+        """-> (timestamps [n], poses [n, 7] as qx qy qz qw tx ty tz) of every frame sequence k has processed"""
+        n = self.lib.hso_vo_multi_get_trajectory(self.h, k, None, None, 0)
+        ts = np.zeros(max(n, 1)); T = np.zeros((max(n, 1), 7))
+        self.lib.hso_vo_multi_get_trajectory(self.h, k, ts.ctypes.data, T.ctypes.data, n)
+        return ts[:n], T[:n]
 
     def call_counts(self):
         calls = np.zeros(16, np.int64); items = np.zeros(16, np.int64)

@@ -55,6 +55,10 @@ int hso_vo_get_status(hso_vo* vo, hso_vo_status* st);
 /* map_.keyframes_ in list order (what BenchmarkNode::saveResult writes): returns the number of keyframes, fills at most cap */
 int hso_vo_get_keyframes(hso_vo* vo, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
 
+/* every frame processed since the sequence started: (timestamp, T_f_w when the frame was finished) — the per-frame trajectory a
+ * harness gathers (BASELINE configs[4]); returns the number of frames, fills at most cap */
+int hso_vo_get_trajectory(hso_vo* vo, double* timestamps, hso_se3* T_f_w, int cap);
+
 /* ---- N independent sequences over one device context, in lockstep (hso_amd/host/hso_multi.cpp): BASELINE north_star
  * "independent sequences ... batched"; configs[4] = what test/euroc_batch.sh:9-18 runs one after the other.  Every sequence is
  * a FrameHandlerMono of its own; per step the device calls of all sequences leave as one batched C-ABI call per kind
@@ -80,6 +84,7 @@ int hso_vo_multi_add_images_device(hso_vo_multi* m, const uint8_t* const* imgs, 
 int hso_vo_multi_trace(hso_vo_multi* m, int sequence, const char* path);
 int hso_vo_multi_get_status(hso_vo_multi* m, int sequence, hso_vo_status* st);
 int hso_vo_multi_get_keyframes(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
+int hso_vo_multi_get_trajectory(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int cap);
 /* batched C-ABI calls issued so far and the per-sequence requests they carried, per kind: [0] frame upload, [1] frame release,
  * [2] tracker, [3] reprojection + matching, [4] matching alone, [5] pose, [6] seed observation, [7] seed activation, [8] local BA,
  * [9] calls without a multi-sequence form.  Returns the number of kinds. */

@@ -183,38 +183,53 @@ def test_tracker_eval_euroc_radtan(gpu_ctx, orc):
     assert rot <= 1e-6 and tra <= 4e-6
 
 
-def test_accept_decisions_over_many_scenes(gpu_ctx, orc):
-    """Many distinct EuRoC-shaped scenes with motion-model starts.  The device sums the (bit-identical) fp32 energy terms in a
-    fixed tree, the reference serially in fp32 (CoarseTracker.cpp:272,413), so an accept decision (:143) whose two energies
-    lie within that serial sum's rounding noise can differ.  Margin rule instead of a count: the device must reproduce the
-    restatement that decides on the fp64 sum of the same terms in EVERY scene (iterations, accept sequence, pose to 1e-7), and
-    wherever it differs from the serial-sum restatement, that restatement must differ from its own exact-sum form too."""
-    camE = synth.camera(synth.EUROC)
+ACCEPT_TOL_ROT, ACCEPT_TOL_TRANS = 5e-5, 2e-4    # BASELINE.md "stated tolerance": frames whose accept sequence differs from the serial-sum restatement's
+
+
+@pytest.mark.parametrize("shape,n_scenes", [("euroc", 64), ("vga", 16)])
+def test_accept_decisions_over_many_scenes(gpu_ctx, orc, shape, n_scenes):
+    """Many distinct scenes x 4 motion-model starts each (256 frames at the metric's shape, 64 at BASELINE configs[1]'s).  The
+    device sums the (bit-identical) fp32 energy terms in a fixed tree, the reference serially in fp32 (CoarseTracker.cpp:272,413),
+    so an accept decision (:143) whose two energies lie within that serial sum's rounding noise can differ.  Asserted per frame:
+      * the device reproduces the restatement that decides on the fp64 sum of the same terms (iterations, accept sequence, pose to
+        1e-7) — always;
+      * where its accept sequence equals the serial-sum restatement's (the reference's arithmetic), the pose agrees to 1e-6 rad /
+        4e-6 m; where it differs, that restatement differs from its own exact-sum form too, and the pose still agrees within
+        5e-5 rad / 2e-4 m (both runs reach the same minimum along different iteration sequences; SURVEY App. C's end-to-end
+        bound is 1e-4);
+      * such frames are at most 15 % (measured: 8-12 %)."""
+    spec = synth.EUROC if shape == "euroc" else synth.ICL_NUIM
+    camS = synth.camera(spec)
     p = capi.TrackParams(0, 4, 1, 50)
     rng = np.random.default_rng(5)
-    n_scenes, n_diff = 20, 0
+    n_frames, n_diff, worst = 0, 0, [0.0, 0.0]
     for k in range(n_scenes):
-        d = synth.config2_pair(600, spec=synth.EUROC, seed=4000 + 13 * k, exposure=float(rng.uniform(0.92, 1.08)),
+        d = synth.config2_pair(600, spec=spec, seed=4000 + 13 * k, exposure=float(rng.uniform(0.92, 1.08)),
                                trans_frac=float(rng.uniform(0.012, 0.028)), rot_deg=float(rng.uniform(0.3, 0.7)))
-        T0 = capi.SE3.from_arrays(synth.rotvec_to_quat(rng.normal(0, np.deg2rad(0.05), 3)), rng.uniform(0.6, 1.1) * np.array(d["t_true"]))
-        a0 = float(np.float32(rng.uniform(0.95, 1.05)))
         upload_pair(gpu_ctx, d, (3, 4))
-        rg = gpu_ctx.coarse_track_batch(camE, p, [gpu_ctx.make_job(3, 4, d["feats"], T0, a0)])[0]
         rp, cp = orc.create_pyramid(d["ref"]), orc.create_pyramid(d["cur"])
-        ro = orc.Tracker(camE, p, rp, cp, d["feats"]).run(T0, a0)
-        t64 = orc.Tracker(camE, p, rp, cp, d["feats"]); t64.decide_on_f64_sum(True)
-        r64 = t64.run(T0, a0)
-        assert list(rg.iters) == list(r64.iters) and list(rg.accept_mask) == list(r64.accept_mask), "scene %d" % k
-        rot, tra = pose_err(rg, r64)
-        assert rot <= 1e-7 and tra <= 4e-7, "scene %d" % k
-        same = list(rg.iters) == list(ro.iters) and list(rg.accept_mask) == list(ro.accept_mask)
-        if same:
+        starts = [(capi.SE3.from_arrays(synth.rotvec_to_quat(rng.normal(0, np.deg2rad(0.05), 3)), rng.uniform(0.5, 1.2) * np.array(d["t_true"])),
+                   float(np.float32(rng.uniform(0.95, 1.05)))) for _ in range(4)]
+        got = gpu_ctx.coarse_track_batch(camS, p, [gpu_ctx.make_job(3, 4, d["feats"], T0, a0) for T0, a0 in starts])
+        for (T0, a0), rg in zip(starts, got):
+            ro = orc.Tracker(camS, p, rp, cp, d["feats"]).run(T0, a0)
+            t64 = orc.Tracker(camS, p, rp, cp, d["feats"]); t64.decide_on_f64_sum(True)
+            r64 = t64.run(T0, a0)
+            n_frames += 1
+            assert list(rg.iters) == list(r64.iters) and list(rg.accept_mask) == list(r64.accept_mask), "scene %d" % k
+            rot, tra = pose_err(rg, r64)
+            assert rot <= 1e-7 and tra <= 4e-7, "scene %d" % k
             rot, tra = pose_err(rg, ro)
-            assert rot <= 1e-6 and tra <= 4e-6, "scene %d" % k
-        else:
-            n_diff += 1
-            assert not (list(ro.iters) == list(r64.iters) and list(ro.accept_mask) == list(r64.accept_mask)), "scene %d" % k
-    assert n_diff <= n_scenes // 4
+            if list(rg.iters) == list(ro.iters) and list(rg.accept_mask) == list(ro.accept_mask):
+                assert rot <= 1e-6 and tra <= 4e-6, "scene %d" % k
+            else:
+                n_diff += 1
+                assert not (list(ro.iters) == list(r64.iters) and list(ro.accept_mask) == list(r64.accept_mask)), "scene %d" % k
+                assert rot <= ACCEPT_TOL_ROT and tra <= ACCEPT_TOL_TRANS, ("scene %d" % k, rot, tra)
+                worst = [max(worst[0], rot), max(worst[1], tra)]
+    print("%s: %d frames, %d with a different accept sequence (%.1f %%), worst pose gap among them %.2e rad / %.2e m" % (
+        shape, n_frames, n_diff, 100.0 * n_diff / n_frames, worst[0], worst[1]))
+    assert n_diff <= 0.15 * n_frames
 
 
 def test_tracker_large_table_and_fov_camera(gpu_ctx, orc, cam):
