@@ -154,6 +154,56 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+class GpuSide:
+    """Everything bench.py needs of the device side in one place: HIP stream / events through torch, the C-ABI context, device
+    copies of images, the collective backend.  tests/test_bench_cpu.py swaps it (HSO_BENCH_SIDE="module:Class") for a stand-in over
+    the CPU restatement and gloo, so that the multi-rank control flow of this file — self-launch, sharding, both gathers, the JSON
+    line — runs without a GPU."""
+    backend = "nccl"
+    engine_lib = None            # None = hso_amd/host/libhso_host.so
+
+    def __init__(self, local_rank):
+        import torch
+        self.torch, self.rank = torch, local_rank
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+
+    def init_group(self, rank, world):
+        import torch.distributed as dist
+        dist.init_process_group(self.backend, rank=rank, world_size=world, device_id=self.dev)
+
+    def new_stream(self):
+        return self.torch.cuda.Stream()
+
+    def on(self, stream):
+        return self.torch.cuda.stream(stream)
+
+    def context(self, stream):
+        from hso_amd import capi
+        return capi.Context(self.rank, stream.cuda_stream)
+
+    def to_device(self, img):
+        return self.torch.from_numpy(img).cuda()
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def release_cached(self):
+        self.torch.cuda.empty_cache()
+
+
+def make_side(local_rank):
+    spec = os.environ.get("HSO_BENCH_SIDE")
+    if not spec:
+        return GpuSide(local_rank)
+    import importlib
+    mod, cls = spec.split(":")
+    return getattr(importlib.import_module(mod), cls)(local_rank)
+
+
 def start_pose(sc, variant):
     """The motion-model prediction a job starts from.  Variant 0 is the scene's own; 1..3 are other plausible predictions of the
     same motion (scaled / perturbed deterministically), so that replicas of a scene walk different Levenberg-Marquardt paths: the
@@ -232,6 +282,7 @@ def main():
     ap.add_argument("--banks", type=int, default=2, help="engines per GPU, each on its own host thread and stream")
     ap.add_argument("--seq-feats", type=int, default=2000, help="Config::maxFts() of the end-to-end run")
     ap.add_argument("--seq-distinct", type=int, default=8, help="distinct rendered sequences per rank (replicated to --sequences x --banks)")
+    ap.add_argument("--single", type=int, default=1, help="0: skip the single-sequence latency section (N = 1 only)")
     ap.add_argument("--se3-frames", type=int, default=256, help="frames of the per-frame SE(3) comparison with the CPU restatement")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
@@ -264,27 +315,26 @@ def main():
     import torch.distributed as dist
     from hso_amd import capi, synth
 
-    torch.cuda.set_device(local_rank)
+    side = make_side(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        side.init_group(rank, world)
+    dev = side.dev
 
-    stream = torch.cuda.Stream()
+    stream = side.new_stream()
     spec = synth.EUROC if args.shape == "euroc" else synth.ICL_NUIM
     B, W, H = args.batch, spec["width"], spec["height"]
     cam = synth.camera(spec)
     params = capi.TrackParams(args.inverse, 4, args.min_level, 50)   # frame_handler_mono.cpp:190,203
     levels = tuple(range(4, args.min_level - 1, -1))
 
-    with torch.cuda.stream(stream):
-        ctx = capi.Context(local_rank, stream.cuda_stream)
+    with side.on(stream):
+        ctx = side.context(stream)
         ref_ids = list(range(0, B))
         cur_ids = list(range(B, 2 * B))
         st_ref = ctx.frame_upload_batch(ref_ids, imgs=[scenes[i % n_sc]["ref"] for i in range(B)])
         # raw level-0 images of the two alternating current-frame sets, resident in HBM
-        cur_dev = [[torch.from_numpy(scenes[i % n_sc][k]).cuda() for i in range(B)] for k in ("cur", "cur_b")]
+        cur_dev = [[side.to_device(scenes[i % n_sc][k]) for i in range(B)] for k in ("cur", "cur_b")]
         cur_ptrs = [np.array([t.data_ptr() for t in cd], np.uint64) for cd in cur_dev]
         st_cur = ctx.frame_upload_batch(cur_ids, device_ptrs=cur_ptrs[0], width=W, height=H)
         jobs, a0s, starts = [], [], []
@@ -310,8 +360,8 @@ def main():
         stream.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        side.synchronize()
+        events = [(side.event(), side.event())
                   for _ in range(args.steps)]
         res_set = [None, None]
         # the interpreter's cyclic collector would otherwise walk the rendered scenes (millions of objects) somewhere inside
@@ -327,7 +377,7 @@ def main():
         tg0 = time.perf_counter()
         allrec = hdist.gather_records(rec, device=dev)
         assert allrec.shape == (world, B, 8)
-        torch.cuda.synchronize()
+        side.synchronize()
         t_gather = time.perf_counter() - tg0
         if world > 1:
             dist.barrier()
@@ -469,11 +519,11 @@ def main():
         from hso_amd import bank_bench
         ctx.close()                                  # the headline's 4096 resident pairs leave HBM before the engines start
         del cur_dev
-        torch.cuda.empty_cache()
+        side.release_cached()
         if world > 1:
             dist.barrier()
         mres, traj = bank_bench.run_banks(args.banks, args.sequences, args.seq_frames, args.seq_feats, spec=spec, device=local_rank, seqs=seq_list,
-                                          want_traj=True)
+                                          want_traj=True, lib_path=side.engine_lib, to_device=side.to_device)
         n_seq_rank = args.banks * args.sequences
         tr_rec = np.zeros((n_seq_rank, args.seq_frames, 8))
         for q, T in enumerate(traj):
@@ -495,9 +545,9 @@ def main():
         out["sequences_config"] = "%d engines x %d sequences x %d features per GPU, %d frames, end to end on evolving state" % (
             args.banks, args.sequences, args.seq_feats, args.seq_frames - 1)
         out["sequences_failures"] = mres["failures"]
-    if extras and seq_S is not None:
-        ctx2 = capi.Context(local_rank, stream.cuda_stream)
-        with torch.cuda.stream(stream):
+    if extras and seq_S is not None and args.single:
+        ctx2 = side.context(stream)
+        with side.on(stream):
             single = single_sequence(args, ctx2, stream, spec, seq_S, cam)
         ctx2.close()
         detail_extra["single_sequence"] = single

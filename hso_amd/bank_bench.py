@@ -51,7 +51,7 @@ def run(n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, on_d
                 calls=counts)
 
 
-def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False):
+def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False, lib_path=None, to_device=None):
     """n_banks engines of n_seq sequences each, every one on its own host thread with its own device context / stream: the
     device work of one bank overlaps the bookkeeping and the PCIe traffic of the others (independent sequences shard freely, also
     within one GPU).  Whole-run throughput: all frames / wall time from the first step to the last bank's last step."""
@@ -67,13 +67,16 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
 
     def work(b):
         from hso_amd import vo
-        import torch
         cam = synth.camera(spec)
         pick = [seqs[q % len(seqs)] for q in range(n_seq)]
-        m = vo.MultiVisualOdometry(cam, n_seq, max_fts, device=device)
+        m = vo.MultiVisualOdometry(cam, n_seq, max_fts, device=device, lib=vo.load_from(lib_path) if lib_path else None)
         m.set_first_frames([q["images"][0] for q in pick], [q["depth0"] for q in pick])
-        dev = [[torch.from_numpy(np.ascontiguousarray(im)).cuda(device) for im in q["images"]] for q in seqs]
-        torch.cuda.synchronize(device)
+        if to_device is None:
+            import torch
+            dev = [[torch.from_numpy(np.ascontiguousarray(im)).cuda(device) for im in q["images"]] for q in seqs]
+            torch.cuda.synchronize(device)
+        else:
+            dev = [[to_device(np.ascontiguousarray(im)) for im in q["images"]] for q in seqs]
         h, w = pick[0]["images"][0].shape
         gate.wait()
         ms = []
@@ -87,7 +90,7 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
         if want_traj:
             traj[b] = [m.trajectory(q)[1] for q in range(n_seq)]
         kfs = [len(m.keyframes(q)) - 1 for q in range(n_seq)]
-        res[b] = dict(ms_per_step_mean=float(np.mean(ms[2:])), ms_per_step_median=float(np.median(ms[2:])), keyframes=float(np.mean(kfs)), failures=sum(int(st.stage != 3 or st.result == 2) for st in sts),
+        res[b] = dict(ms_per_step_mean=float(np.mean(ms[2:] or ms)), ms_per_step_median=float(np.median(ms[2:] or ms)), keyframes=float(np.mean(kfs)), failures=sum(int(st.stage != 3 or st.result == 2) for st in sts),
                       trans_err_max=max(float(np.linalg.norm(np.array(sts[q].T_f_w.t[:]) - pick[q]["T_f_w"][frames - 1][1])) for q in range(n_seq)))
         m.close()
 
