@@ -6,6 +6,7 @@ CPU fallback anywhere in this package.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -410,11 +411,23 @@ class Context:
         if rc < 0:
             raise HsoGpuError("hso_gpu_create failed: %d" % rc)
         self._keep = []
+        self._n_host_live, self._close_pending = 0, False
 
     def close(self):
+        """Destroys the context — once no array of host_array() is alive any more: those arrays are views of memory the context
+        owns, so closing earlier would leave them dangling; the destruction then happens when the last of them goes."""
+        if self._n_host_live > 0:
+            self._close_pending = True
+            return
         if self.h:
             self.lib.hso_gpu_destroy(self.h)
             self.h = C.c_void_p()
+
+    def _host_array_gone(self):
+        self._n_host_live -= 1
+        if self._close_pending and self._n_host_live == 0:
+            self._close_pending = False
+            self.close()
 
     def __del__(self):
         try:
@@ -439,9 +452,22 @@ class Context:
         p = C.c_void_p()
         self._check(self.lib.hso_gpu_host_alloc(self.h, max(n * dt.itemsize, 1), C.byref(p)), "host_alloc")
         buf = (C.c_char * max(n * dt.itemsize, 1)).from_address(p.value)
+        # the memory belongs to the context: the buffer object keeps the Context alive (an array that outlives its creator's
+        # last reference keeps the context, and with it the allocation, open), and close() refuses while such arrays exist
+        buf._hso_owner = self
+        self._n_host_live += 1
+        weakref.finalize(buf, self._host_array_gone)
         a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
         a[...] = np.zeros((), dt)
         return a
+
+    def host_free(self, a):
+        """Give a host_array's memory back now (the array must not be used afterwards)."""
+        base = a
+        while getattr(base, "base", None) is not None:
+            base = base.base
+        addr = C.addressof(base.obj) if isinstance(base, memoryview) else C.addressof(base)
+        self._check(self.lib.hso_gpu_host_free(self.h, C.c_void_p(addr)), "host_free")
 
     # -- frames
     def frame_upload(self, frame_id, img, device_ptr=None, width=None, height=None):

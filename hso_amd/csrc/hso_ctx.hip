@@ -4,6 +4,7 @@
 #include "hso_ctx.h"
 #include <string.h>
 #include <mutex>
+#include <unordered_set>
 #include <vector>
 
 // ---- staging of pageable host memory (see hso_ctx.h) ----
@@ -16,6 +17,7 @@ struct Stager {
 };
 std::mutex g_stage_mutex;
 std::unordered_map<hipStream_t, Stager> g_stagers;
+std::unordered_set<hipStream_t> g_streams_in_use;   // caller-provided streams that a live context launches on
 
 bool host_is_page_locked(const void* p)
 {
@@ -133,9 +135,20 @@ void hso_stream_forget(hipStream_t stream)
   hso_copy2d_async((dst), (dpitch), (src), (spitch), (width), (height), (kind), (stream))
 #define hipStreamSynchronize(stream) hso_stream_sync(stream)
 
+// Every failing exit of an entry point ends here or in HSO_HIP_CHECK: device-to-host copies already enqueued into the CALLER's
+// memory (finished by the next synchronisation, hso_stream_sync) must not outlive the failed call — the caller may free its
+// buffers the moment it sees the error.  The common case (argument checks before anything was enqueued) costs a map lookup.
 int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg)
 {
-  if (ctx) ctx->err = msg;
+  if (!ctx) return code;
+  ctx->err = msg;
+  bool pending = false;
+  {
+    std::lock_guard<std::mutex> lk(g_stage_mutex);
+    auto it = g_stagers.find(ctx->stream);
+    pending = it != g_stagers.end() && !it->second.fixes.empty();
+  }
+  if (pending) hso_stream_abandon(ctx->stream);
   return code;
 }
 
@@ -216,6 +229,12 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   ctx->h_pin[0] = ctx->h_pin[1] = nullptr;
   ctx->h_pin_cap[0] = ctx->h_pin_cap[1] = 0;
   if (stream) {
+    // "one context per stream" is enforced: the page-locked staging of a stream (chunks, copies waiting for its next
+    // synchronisation) belongs to the one context that launches on it; two contexts on one stream, on different threads, would
+    // finish and recycle each other's copies
+    std::lock_guard<std::mutex> lk(g_stage_mutex);
+    if (g_streams_in_use.count(reinterpret_cast<hipStream_t>(stream))) { delete ctx; return HSO_E_INVALID; }
+    g_streams_in_use.insert(reinterpret_cast<hipStream_t>(stream));
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     ctx->own_stream = false;
   } else {
@@ -244,6 +263,7 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   for (void* p : ctx->host_allocs) (void)hipHostFree(p);
   hso_stream_forget(ctx->stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  else { std::lock_guard<std::mutex> lk(g_stage_mutex); g_streams_in_use.erase(ctx->stream); }
   delete ctx;
 }
 
@@ -386,7 +406,7 @@ int hso_gpu_frame_upload_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, const
     for (int k = 0; k < i && it == ctx->frames.end(); k++)
       if (frame_ids[k] == frame_ids[i]) return hso_fail(ctx, HSO_E_INVALID, "frame_upload_batch: a new frame id appears twice");
   }
-  auto undo = [&]() { (void)hipStreamSynchronize(ctx->stream); for (int i : fresh) hso_frame_free(ctx, g, bases[i]); };
+  auto undo = [&]() { hso_stream_abandon(ctx->stream); for (int i : fresh) hso_frame_free(ctx, g, bases[i]); };
   for (int i = 0; i < n; i++) {
     auto it = ctx->frames.find(frame_ids[i]);
     if (it != ctx->frames.end()) { bases[i] = it->second.base; continue; }   // refresh in place

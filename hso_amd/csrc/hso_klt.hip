@@ -332,6 +332,6 @@ extern "C" int hso_gpu_klt_debug_level(hso_gpu_ctx* ctx, int64_t frame, int leve
   if (e == hipSuccess && deriv_out) e = hipMemcpyAsync(deriv_out, dd, sizeof(short2) * (size_t)w[level] * h[level], hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d);
-  if (e != hipSuccess) { ctx->err = std::string("klt_debug_level: ") + hipGetErrorString(e); return HSO_E_HIP; }
+  if (e != hipSuccess) { ctx->err = std::string("klt_debug_level: ") + hipGetErrorString(e); hso_stream_abandon(ctx->stream); return HSO_E_HIP; }
   return HSO_OK;
 }

@@ -452,16 +452,16 @@ int hso_gpu_tracker_eval(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   const Scratch sc = scratch_at(st->d_scratch, nm);
   if (ref_patch_out && n > 0) {
     std::vector<float> tmp((size_t)PA * nm);
-    HSO_HIP_CHECK(ctx, hipMemcpy(tmp.data(), sc.ref_patch, tmp.size() * 4, hipMemcpyDeviceToHost));
+    { HSO_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), sc.ref_patch, tmp.size() * 4, hipMemcpyDeviceToHost, ctx->stream)); HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); }
     std::vector<uint8_t> vis(nm);
-    HSO_HIP_CHECK(ctx, hipMemcpy(vis.data(), sc.visible, nm, hipMemcpyDeviceToHost));
+    { HSO_HIP_CHECK(ctx, hipMemcpyAsync(vis.data(), sc.visible, nm, hipMemcpyDeviceToHost, ctx->stream)); HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); }
     for (int f = 0; f < n; f++)
       for (int pi = 0; pi < PA; pi++) ref_patch_out[(size_t)f * PA + pi] = vis[f] ? tmp[(size_t)pi * nm + f] : 0.0f;
   }
-  if (visible_out && n > 0) HSO_HIP_CHECK(ctx, hipMemcpy(visible_out, sc.visible, n, hipMemcpyDeviceToHost));
+  if (visible_out && n > 0) { HSO_HIP_CHECK(ctx, hipMemcpyAsync(visible_out, sc.visible, n, hipMemcpyDeviceToHost, ctx->stream)); HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); }
   if (abs_err_out && n > 0 && huber_thresh <= 0) {
     std::vector<uint32_t> keys((size_t)PA * n);
-    HSO_HIP_CHECK(ctx, hipMemcpy(keys.data(), sc.keys, keys.size() * 4, hipMemcpyDeviceToHost));
+    { HSO_HIP_CHECK(ctx, hipMemcpyAsync(keys.data(), sc.keys, keys.size() * 4, hipMemcpyDeviceToHost, ctx->stream)); HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); }
     size_t k = 0;
     for (size_t i = 0; i < keys.size(); i++)
       if (keys[i] != KEY_INVALID) { float v; memcpy(&v, &keys[i], 4); abs_err_out[k++] = v; }
