@@ -58,6 +58,8 @@ struct hso_gpu_ctx {
   SeqMaps* seqmaps;
   // staging for batched frame uploads: [bases | srcs | stats]
   char* d_batch; size_t batch_cap;
+  // between the three kernels of a seed observation (hso_seed.hip): [SeedPre | SeedMid] per seed, grow-only
+  char* d_seed_scratch; size_t seed_scratch_cap;
   // pinned host staging (grow-only): record tables go through it so the DMA runs at PCIe rate
   // instead of the pageable-memory rate, and the per-call std::vector + page faults disappear
   char* h_pin[2]; size_t h_pin_cap[2];

@@ -225,6 +225,7 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   ctx->seqmaps = nullptr;
   ctx->free_w = ctx->free_h = 0;
   ctx->d_batch = nullptr;
+  ctx->d_seed_scratch = nullptr; ctx->seed_scratch_cap = 0;
   ctx->batch_cap = 0;
   ctx->h_pin[0] = ctx->h_pin[1] = nullptr;
   ctx->h_pin_cap[0] = ctx->h_pin_cap[1] = 0;
@@ -259,6 +260,7 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   hso_seqmaps_free(ctx);
   for (auto* p : ctx->frame_slabs) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+  if (ctx->d_seed_scratch) (void)hipFree(ctx->d_seed_scratch);
   for (int k = 0; k < 2; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
   for (void* p : ctx->host_allocs) (void)hipHostFree(p);
   hso_stream_forget(ctx->stream);

@@ -52,60 +52,127 @@ struct SeedDev {
 
 // row_sum_all / row_sum4, load_px8 / byte_f, cam2world_dev and interpolate_8u come from hso_match_dev.h (shared with the matcher)
 
-// ---- sixteen lanes per seed ---------------------------------------------------------------------------------------------------
-// The image phase of a seed is 64 patch pixels wide; a wavefront used to spend its 64 lanes on ONE seed, so every wave-uniform
-// instruction of the march (the ZMNCC quotient, the loop tests, the KLT weights and updates: well over half of the ~3700
-// wave-instructions per seed that the SQ counters show, profiles/r3_stage_sq_seed.csv: VALU 100 % busy) served one seed.  Now a
-// DPP row of 16 lanes owns a seed — four seeds per wavefront — and a lane owns four horizontally adjacent pixels of the 8x8
-// patch: the uniform instructions serve four seeds, a patch sum is three adds + four DPP steps inside the row (no cross-row
-// traffic at all), and the rows diverge freely (a row that has finished its march simply drops out of the exec mask).
-// Pixel (px0 + j, py), j = 0..3, of lane l16 = lane & 15: py = l16 >> 1, px0 = (l16 & 1) * 4.
-struct PatchTaps4 { unsigned long long r0, r1; };
-HSO_DEV PatchTaps4 q_patch_fetch(const uint8_t* img, int stride, double pxs0, double pxs1, int px0, int py_)
+// ---- eight lanes per seed ------------------------------------------------------------------------------------------------------
+// The image phase of a seed works on an 8x8 patch.  Round 3 gave a DPP row of 16 lanes to a seed (four pixels per lane); the SQ
+// counters (profiles/r3_stage_sq_seed.csv: VALU saturated, 1 870 wave-instructions per seed) and the ISA showed where those
+// went: of the march's 218 instructions per step ~110 are the same in all 16 lanes (position, bounds, bilinear weights, the
+// fp64 ZMNCC quotient, the best / second bookkeeping) and 21 are DPP row sums, so a step cost 54 instructions per seed of which
+// 12 touch pixels.  Now a group of EIGHT lanes owns a seed (eight seeds per wavefront, lane l8 = lane & 7 owns row l8 of the
+// patch), and the two loops are laid out for what they are:
+//   * the epipolar march has independent steps, so a LANE evaluates a whole step — all 64 bilinear samples and the three ZMNCC
+//     sums, serially, in the reference's own summation order (patch_score.h:268-305; the score is now bit-identical to the
+//     serial CPU arithmetic, no tree sums) — eight steps of a seed at a time; nothing in a step is redundant any more
+//     (~17 wave-instructions per seed and step);
+//   * the KLT iterations depend on one another, so there the eight lanes share an iteration (eight pixels each, a patch sum is
+//     seven adds and three DPP steps inside the group) and the uniform arithmetic of an iteration serves eight seeds.
+HSO_DEV float grp_sum_all(float v)
 {
-  const float u = (float)pxs0, v = (float)pxs1;
-  const int ui = (int)floorf(u), vi = (int)floorf(v);
-  const uint8_t* c = img + (vi - 4 + py_) * stride + (ui - 4) + px0;
-  PatchTaps4 t;
-  t.r0 = load_px8(c);
-  t.r1 = load_px8(c + stride);
-  return t;
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xf, 0xf, false));   // row_half_mirror: l8 <-> 7 - l8
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xb1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4e, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
+  return v;   // the same bits in all eight lanes: every step adds the same two partial sums in both partners
 }
-// warp::createPatch's bilinear sample (matcher.cpp:159-196) for the lane's four pixels, the reference's expression order
-HSO_DEV void q_patch_values(const PatchTaps4& t, double pxs0, double pxs1, float (&out)[4])
+HSO_DEV float grp_sum8(const float (&v)[8]) { return grp_sum_all(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))); }
+// the value lane `j` of the caller's group of eight holds
+HSO_DEV float grp_get(float v, int j) { return __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & 63) & ~7) | j) << 2), (int)__float_as_uint(v))); }
+HSO_DEV int grp_get(int v, int j) { return __builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & 63) & ~7) | j) << 2), v); }
+HSO_DEV double grp_get(double v, int j)
 {
-  const float u = (float)pxs0, v = (float)pxs1;
-  const int ui = (int)floorf(u), vi = (int)floorf(v);
-  const float su = u - (float)ui, sv = v - (float)vi;
-  const float w_tl = (float)((1.0 - su) * (1.0 - sv));
-  const float w_tr = (float)(su * (1.0 - sv));
-  const float w_bl = (float)((1.0 - su) * sv);
-  const float w_br = (float)(((1.0 - w_tl) - w_tr) - w_bl);
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-    out[j] = ((w_tl * byte_f(t.r0, j) + w_tr * byte_f(t.r0, j + 1)) + w_bl * byte_f(t.r1, j)) + w_br * byte_f(t.r1, j + 1);
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)grp_get((int)(unsigned)b, j), hi = (unsigned)grp_get((int)(unsigned)(b >> 32), j);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// Matcher::KLTLimited2D / KLTLimited1D (matcher.cpp:1296-1606), a row of 16 lanes per seed, four patch pixels per lane.
+// twelve bytes from an unaligned address in ONE load (the three beyond the ninth stay inside the frame allocation, like load_px8's)
+struct Px12 { unsigned long long lo; unsigned hi; };
+typedef unsigned __attribute__((ext_vector_type(3), aligned(1))) u32x3_unaligned;
+HSO_DEV Px12 load_px12(const uint8_t* p)
+{
+  const u32x3_unaligned v = *(const __attribute__((address_space(1))) u32x3_unaligned*)p;
+  Px12 t;
+  t.lo = ((unsigned long long)v.y << 32) | v.x; t.hi = v.z;
+  return t;
+}
+// nine bytes of an image row as floats: what eight horizontally adjacent bilinear samples read from it
+HSO_DEV void row9(const uint8_t* p, float (&f)[9])
+{
+  const Px12 t = load_px12(p);
+#pragma unroll
+  for (int j = 0; j < 8; j++) f[j] = byte_f(t.lo, j);
+  f[8] = (float)(t.hi & 0xffu);
+}
+// warp::createPatch's weights (matcher.cpp:159-196).  The reference forms the three products in double from float operands
+// and rounds to float; for a position >= 1 px the factors 1 - su, 1 - sv are exact in float (su is a multiple of ulp(u) >=
+// 2^-23 below 1) and the double product of two floats is exact, so the float product rounds the same real number: bit-equal.
+struct Bilin { float tl, tr, bl, br; };
+HSO_DEV Bilin bilin_weights(float su, float sv)
+{
+  Bilin w;
+  const float cu = 1.0f - su, cv = 1.0f - sv;
+  w.tl = cu * cv; w.tr = su * cv; w.bl = cu * sv;
+  w.br = (float)(((1.0 - (double)w.tl) - (double)w.tr) - (double)w.bl);
+  return w;
+}
+
+// One step of the epipolar march on ONE lane: createPatch at (u, v) = (float)px of the search level and ZMNCC_F::computeScore against the
+// host patch (`hd`: host[i] - hostMean in LDS, `d1` their squared sum), every sum in the reference's order.
+HSO_DEV float lane_zmncc(const uint8_t* img, int stride, float u, float v, const float* hd, float d1)
+{
+  const int ui = (int)floorf(u), vi = (int)floorf(v);
+  const Bilin w = bilin_weights(u - (float)ui, v - (float)vi);
+  const uint8_t* c = img + (vi - 4) * stride + (ui - 4);
+  unsigned long long rw[9];
+  unsigned rb[9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) { const Px12 t = load_px12(c + r * stride); rw[r] = t.lo; rb[r] = t.hi & 0xffu; }
+  float sp[64];
+  float top[9], bot[9];
+#pragma unroll
+  for (int j = 0; j < 8; j++) top[j] = byte_f(rw[0], j);
+  top[8] = (float)rb[0];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) bot[j] = byte_f(rw[r + 1], j);
+    bot[8] = (float)rb[r + 1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) sp[r * 8 + j] = ((w.tl * top[j] + w.tr * top[j + 1]) + w.bl * bot[j]) + w.br * bot[j + 1];
+#pragma unroll
+    for (int j = 0; j < 9; j++) top[j] = bot[j];
+  }
+  float tmean = 0;
+#pragma unroll
+  for (int i = 0; i < 64; i++) tmean += sp[i];
+  tmean /= 64;
+  float num = 0, d2 = 0;
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    const float t = sp[i] - tmean;
+    num += hd[i] * t; d2 += t * t;
+  }
+  return (float)((double)num / ((double)sqrtf(d1 * d2) + 1e-12));
+}
+
+// Matcher::KLTLimited2D / KLTLimited1D (matcher.cpp:1296-1606), eight lanes per seed, a patch row (eight pixels) per lane.
 // ONE_D: motion restricted to `d0,d1` (double, as passed by the reference).  Returns the bool.
 template <bool ONE_D>
-HSO_DEV bool q_klt_limited(const uint8_t* img, int cols, int rows, const float (&gxr)[4], const float (&gyr)[4], const float (&ref_px)[4],
-                           double d0, double d1, double& pxs0, double& pxs1, float (&last_sample)[4], int px0, int py_)
+HSO_DEV bool g_klt_limited(const uint8_t* img, int cols, int rows, const float (&gxr)[8], const float (&gyr)[8], const float (&ref_px)[8],
+                           double d0, double d1, double& pxs0, double& pxs1, float (&last_sample)[8], int l8)
 {
-  float Jx[4], Jy[4], wgt[4];
+  float Jx[8], Jy[8], wgt[8];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < 8; j++) {
     if (ONE_D) { Jx[j] = (float)(0.5 * (d0 * (double)gxr[j] + d1 * (double)gyr[j])); Jy[j] = 0; }
-    else { Jx[j] = (float)(0.5 * (double)gxr[j]); Jy[j] = (float)(0.5 * (double)gyr[j]); }
+    else { Jx[j] = 0.5f * gxr[j]; Jy[j] = 0.5f * gyr[j]; }   // (float)(0.5 * (double)g): halving is exact
     wgt[j] = ONE_D ? sqrtf((float)(250.0 / (250.0 + (double)(Jx[j] * Jx[j]))))
                    : sqrtf((float)(250.0 / (250.0 + (double)(Jx[j] * Jx[j] + Jy[j] * Jy[j]))));
   }
   float Hi[9];
   {
-    float t0[4], t1[4], t2[4];
+    float t0[8], t1[8], t2[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { t0[j] = (Jx[j] * Jx[j]) * wgt[j]; t1[j] = (Jx[j] * 1.0f) * wgt[j]; t2[j] = (1.0f * 1.0f) * wgt[j]; }
-    const float h_xx = row_sum4(t0), h_x1 = row_sum4(t1), h_11 = row_sum4(t2);
+    for (int j = 0; j < 8; j++) { t0[j] = (Jx[j] * Jx[j]) * wgt[j]; t1[j] = (Jx[j] * 1.0f) * wgt[j]; t2[j] = (1.0f * 1.0f) * wgt[j]; }
+    const float h_xx = grp_sum8(t0), h_x1 = grp_sum8(t1), h_11 = grp_sum8(t2);
     if (ONE_D) {
       const float H00 = (float)((double)h_xx * (1 + 0.001)), H11 = (float)((double)h_11 * (1 + 0.001)), H01 = h_x1;
       const float det = H00 * H11 - H01 * H01;
@@ -113,8 +180,8 @@ HSO_DEV bool q_klt_limited(const uint8_t* img, int cols, int rows, const float (
       Hi[0] = H11 * invdet; Hi[1] = -H01 * invdet; Hi[3] = -H01 * invdet; Hi[4] = H00 * invdet;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; j++) { t0[j] = (Jx[j] * Jy[j]) * wgt[j]; t1[j] = (Jy[j] * Jy[j]) * wgt[j]; t2[j] = (Jy[j] * 1.0f) * wgt[j]; }
-      const float h_xy = row_sum4(t0), h_yy = row_sum4(t1), h_y1 = row_sum4(t2);
+      for (int j = 0; j < 8; j++) { t0[j] = (Jx[j] * Jy[j]) * wgt[j]; t1[j] = (Jy[j] * Jy[j]) * wgt[j]; t2[j] = (Jy[j] * 1.0f) * wgt[j]; }
+      const float h_xy = grp_sum8(t0), h_yy = grp_sum8(t1), h_y1 = grp_sum8(t2);
       const float H0 = (float)((double)h_xx * (1 + 0.001)), H4 = (float)((double)h_yy * (1 + 0.001)), H8 = (float)((double)h_11 * (1 + 0.001));
       const float H1 = h_xy, H2 = h_x1, H5 = h_y1, H3 = H1, H6 = H2, H7 = H5;
       const float c00 = H4 * H8 - H5 * H7, c01 = H5 * H6 - H3 * H8, c02 = H3 * H7 - H4 * H6;
@@ -131,26 +198,29 @@ HSO_DEV bool q_klt_limited(const uint8_t* img, int cols, int rows, const float (
   float sb0 = 0, sb1 = 0, sb2 = 0;
   float uBak = bestU, vBak = bestV, meanBak = mean_diff;
   for (int iter = 0; iter < 10; ++iter) {
-    const int u_r = (int)floor((double)bestU), v_r = (int)floor((double)bestV);
+    const int u_r = (int)floorf(bestU), v_r = (int)floorf(bestV);   // (int)floor((double)bestU): the same integer
     if (u_r < 4 || v_r < 4 || u_r >= cols - 4 || v_r >= rows - 4) break;
     if (isnan(bestU) || isnan(bestV)) return false;
     const float sx = bestU - (float)u_r, sy = bestV - (float)v_r;
-    const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy), wBR = sx * sy;
-    const uint8_t* it = img + (v_r + py_ - 4) * cols + u_r - 4 + px0;
-    const unsigned long long it0 = load_px8(it), it1 = load_px8(it + cols);
-    float a0[4], a1[4], a2[4], a3[4];
+    // (float)((1.0 - sx) * (1.0 - sy)) etc.: exact factors, see bilin_weights; wBR is the reference's plain float product here
+    const float cx = 1.0f - sx, cy = 1.0f - sy;
+    const float wTL = cx * cy, wTR = sx * cy, wBL = cx * sy, wBR = sx * sy;
+    const uint8_t* it = img + (v_r + l8 - 4) * cols + u_r - 4;
+    float top[9], bot[9];
+    row9(it, top); row9(it + cols, bot);
+    float a0[8], a1[8], a2[8], a3[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float sp = ((wTL * byte_f(it0, j) + wTR * byte_f(it0, j + 1)) + wBL * byte_f(it1, j)) + wBR * byte_f(it1, j + 1);
+    for (int j = 0; j < 8; j++) {
+      const float sp = ((wTL * top[j] + wTR * top[j + 1]) + wBL * bot[j]) + wBR * bot[j + 1];
       last_sample[j] = sp;
       const float res = (sp - ref_px[j]) + mean_diff;
       a0[j] = (res * Jx[j]) * wgt[j]; a1[j] = res * wgt[j]; a2[j] = (res * res) * wgt[j]; a3[j] = (res * Jy[j]) * wgt[j];
     }
-    const float j0 = -row_sum4(a0);
-    const float j2 = -row_sum4(a1);
-    const float energy = row_sum4(a2);
+    const float j0 = -grp_sum8(a0);
+    const float j2 = -grp_sum8(a1);
+    const float energy = grp_sum8(a2);
     float j1 = 0;
-    if (!ONE_D) j1 = -row_sum4(a3);
+    if (!ONE_D) j1 = -grp_sum8(a3);
     if (energy > bestEnergy) {
       sb0 *= 0.5f; sb1 *= 0.5f; sb2 *= 0.5f;
       if (ONE_D) { bestU = (float)((double)uBak + (double)sb0 * d0); bestV = (float)((double)vBak + (double)sb0 * d1); mean_diff = meanBak + sb1; }
@@ -202,15 +272,16 @@ HSO_DEV void seed_finish(const SeedConsts& C, SeedDev* seeds, int sid, hso_seed_
 // the kernel's instructions (two se3 products, the visibility projection, the affine warp matrix with its two radtan
 // cam2world, the epipolar end points; afterwards cam2world of the match, the triangulation, computeTau's acos / sin and
 // the update):
-//   pre   lane = seed   everything up to the first image access                      -> SeedPre  (LDS)
-//   wave  lane = pixel  createPatch, the epipolar march, the two KLT refinements, checkNormal / checkNCC -> SeedMid (LDS)
-//   post  lane = seed   depthFromTriangulation, computeTau, updateSeed, the output records
+//   pre   thread = seed     everything up to the first image access                      -> SeedPre
+//   image 8 lanes = seed    createPatch, the epipolar march, the two KLT refinements, checkNormal / checkNCC -> SeedMid
+//   post  thread = seed     depthFromTriangulation, computeTau, updateSeed, the output records
 // Each phase runs the statements of the one-phase kernel it replaces in their order; only the lane that executes them changed.
 struct SeedPre {
   double pxc0, pxc1, pxf0, pxf1, incx, incy, ed0, ed1, dc0, dc1;
   float a00, a01, a10, a11, exposure_rat;
   int32_t sl, epl_start[2], epl_end[2];
-  int8_t state;      // 0: run the wave phase; 1: not visible in the active frame; 2: doLineStereo returns -1 before any image access
+  int8_t state;      // 0: run the image phase; 1: not visible in the active frame; 2: doLineStereo returns -1 before any image
+                     // access; 3: nothing to observe (erased slot, or the seed's group sits this call out)
   int8_t is_valid, warp_nan, scale_exposure;
 };
 struct SeedMid {
@@ -218,7 +289,6 @@ struct SeedMid {
   float zmncc_best, zmncc_second;
   int32_t n_steps, res_code;       // 1: matched (triangulate next), -4 / -3: rejected by the march / the refinement
 };
-#define SEED_CPW_MAX 16
 
 HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrameDev& F)
 {
@@ -320,151 +390,160 @@ HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrame
   return P;
 }
 
-// the image phase of ONE seed on ONE DPP row of 16 lanes (see "sixteen lanes per seed" above); pwb_lds: 100 floats private to the row
-HSO_DEV SeedMid seed_wave(const SeedConsts& C, const SeedDev& SD, const uint8_t* cur_base, const SeedPre& P, float* pwb_lds)
+// Matcher::doLineStereo's refinement of a march result (matcher.cpp:966-1046; the same statements close
+// findEpipolarMatchPrevious, :1102-1150 / :1236-1290): KLTLimited1D along the epipolar direction, then KLTLimited2D (or, for an
+// edgelet, KLTLimited1D along the warped gradient + checkNormal), then checkNCC.  `ps0, ps1`: the start position on the search
+// level, replaced by the refined one.  Eight lanes per seed; `pwb`: the seed's 10x10 patch in LDS.
+HSO_DEV bool g_refine(const SeedConsts& C, const uint8_t* cur_base, int sl, int type, const float* pwb, double ed0, double ed1,
+                      double dc0, double dc1, double& ps0, double& ps1, int l8)
+{
+  const int cols = C.g.w[sl], rows = C.g.h[sl];
+  const uint8_t* cur = cur_base + C.g.off[sl];
+  float ref_px[8], gxr[8], gyr[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int c = (l8 + 1) * 10 + j + 1;
+    ref_px[j] = pwb[c];
+    gxr[j] = pwb[c + 1] - pwb[c - 1]; gyr[j] = pwb[c + 10] - pwb[c - 10];
+  }
+  const double start0 = ps0, start1 = ps1;
+  float samp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  bool result = g_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, ed0, ed1, ps0, ps1, samp, l8);
+  if (!result) { ps0 = start0; ps1 = start1; }
+#pragma unroll
+  for (int j = 0; j < 8; j++) samp[j] = 0;  // patch2D: written only by the second KLT (zero where the reference leaves it uninitialised)
+  if (type != HSO_FTR_EDGELET) {
+    result = g_klt_limited<false>(cur, cols, rows, gxr, gyr, ref_px, 0, 0, ps0, ps1, samp, l8);
+  } else {
+    result = g_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, dc0, dc1, ps0, ps1, samp, l8);
+    if (result) {
+      // Matcher::checkNormal(cur_frame, search_level_, px, dir_cur, 0.7), :406-440
+      const int16_t* gx = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][0]);
+      const int16_t* gy = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][1]);
+      const float uf = (float)ps0, vf = (float)ps1;
+      // The reference reads the four taps unchecked (:421-428): a NaN position (an edgelet direction of norm 0 lets
+      // KLTLimited1D "succeed" with a NaN pixel) or one outside the image is an out-of-bounds read there.  Defined here and in
+      // the CPU restatement alike: such a position fails the check.
+      if (!(uf >= 0 && vf >= 0 && uf < (float)(cols - 1) && vf < (float)(rows - 1))) {
+        result = false;
+      } else {
+        const int ui = (int)floorf((float)ps0), vi = (int)floorf((float)ps1);
+        const float sx = uf - (float)ui, sy = vf - (float)vi;
+        const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy);
+        const float wBR = (float)(((1.0 - wTL) - wTR) - wBL);
+        const int gs = C.g.sob_stride[sl];
+        const int a = vi * gs + ui;
+        double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + gs]) + (double)wBR * (double)gx[a + gs + 1];
+        double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + gs]) + (double)wBR * (double)gy[a + gs + 1];
+        const double nn = sqrt(n0 * n0 + n1 * n1);
+        n0 /= nn; n1 /= nn;
+        result = (dc0 * n0 + dc1 * n1) > (double)(float)0.7;
+      }
+    }
+  }
+  if (result) {
+    // Matcher::checkNCC(patch_f_, patch2D, 0.8), :379-404
+    const float mean1 = grp_sum8(ref_px) / 64, mean2 = grp_sum8(samp) / 64;
+    float qq[8], q11[8], q22[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const float q1 = ref_px[j] - mean1, q2 = samp[j] - mean2; qq[j] = q1 * q2; q11[j] = q1 * q1; q22[j] = q2 * q2; }
+    const float num = grp_sum8(qq), den1 = grp_sum8(q11), den2 = grp_sum8(q22);
+    result = ((double)num / ((double)sqrtf(den1 * den2) + 1e-12)) > (double)(float)0.8;
+  }
+  return result;
+}
+
+// ZMNCC_F's constructor part (patch_score.h:268-285) for the patch in `pwb`: host[i] - hostMean into `hd` (LDS, 64 floats),
+// returns d1 = sum of their squares.  Serial sums in the reference's order, every lane of the group computes the same bits.
+HSO_DEV float g_host_terms(const float* pwb, float* hd, int l8)
+{
+  float m = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) m += pwb[(r + 1) * 10 + j + 1];
+  m /= 64;
+#pragma unroll
+  for (int j = 0; j < 8; j++) hd[l8 * 8 + j] = pwb[(l8 + 1) * 10 + j + 1] - m;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  float d1 = 0;
+#pragma unroll
+  for (int i = 0; i < 64; i++) d1 += hd[i] * hd[i];
+  return d1;
+}
+
+// the best / second-best bookkeeping of a march (matcher.cpp:940-957), for the scores of up to eight steps held one per lane
+// (`z`: -inf where the lane has no step or the step is outside the image; `k`: the step's index), applied in step order
+struct MarchBest { float best, second; int i_best, i_second; };
+HSO_DEV void g_march_fold(MarchBest& B, float z, int k)
+{
+  // a score can only matter if it beats the second best the group held before these eight steps
+  const unsigned long long hot = __ballot(z > B.second);
+  const unsigned mine = (unsigned)(hot >> ((threadIdx.x & 63) & ~7)) & 0xffu;
+  for (unsigned m = mine; m; m &= m - 1) {
+    const int j = __builtin_ctz(m);
+    const float zj = grp_get(z, j);
+    const int kj = grp_get(k, j);
+    if (zj > B.best) { B.second = B.best; B.i_second = B.i_best; B.best = zj; B.i_best = kj; }
+    else if (zj > B.second) { B.second = zj; B.i_second = kj; }
+  }
+}
+
+// warp::createPatch (matcher.cpp:159-196) for the host patch of a seed: 10x10 samples of the reference level into `pwb_lds`
+HSO_DEV void g_host_patch(const SeedConsts& C, const SeedDev& SD, const SeedPre& P, float* pwb_lds, int l8)
 {
   const hso_seed& S = SD.s;
-  const int l16 = threadIdx.x & 15;
-  const int W = C.g.w[0], H = C.g.h[0];
-  SeedMid M;
-  M.px0 = M.px1 = 0; M.zmncc_best = M.zmncc_second = 0; M.n_steps = 0; M.res_code = -4;
-  const int sl = P.sl;
-  const double pxc0 = P.pxc0, pxc1 = P.pxc1, pxf0 = P.pxf0, pxf1 = P.pxf1, incx = P.incx, incy = P.incy;
-  const double ed0 = P.ed0, ed1 = P.ed1, dc0 = P.dc0, dc1 = P.dc1;
-  hso_seed_out o;   // the march bookkeeping below writes o.n_steps / o.zmncc_*: collected into M afterwards
-  o.n_steps = 0; o.zmncc_best = 0; o.zmncc_second = 0;
-  int res_code = -4;
-  double match_px0 = 0, match_px1 = 0;
-  do {
-    {
-      // warp::createPatch (matcher.cpp:159-196): 10x10 samples of the reference level
-      const float a00 = P.a00, a01 = P.a01, a10 = P.a10, a11 = P.a11, exposure_rat = P.exposure_rat;
-      const bool warp_nan = P.warp_nan != 0, scale_exposure = P.scale_exposure != 0;
-      const int L = S.level, cols = C.g.w[L], rows = C.g.h[L];  // img_pyr_[L].cols / rows
-      const uint8_t* img = SD.ref_base + C.g.off[L];
-      const float rx = (float)(S.px[0] / (double)(1 << L)), ry = (float)(S.px[1] / (double)(1 << L));
-      const float scaleTarget = (float)(1 << sl);
-      for (int idx = l16; idx < 100; idx += 16) {
-        const int y = idx / 10, x = idx - 10 * y;
-        float p0 = (float)(x - 5), p1 = (float)(y - 5);
-        p0 *= scaleTarget; p1 *= scaleTarget;
-        const float px0 = (a00 * p0 + a01 * p1) + rx, px1 = (a10 * p0 + a11 * p1) + ry;
-        float val = 0;
-        if (!warp_nan && !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1))) val = interpolate_8u(img, cols, px0, px1);
-        if (scale_exposure) val = val * exposure_rat;
-        pwb_lds[idx] = val;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int px0 = (l16 & 1) * 4, py_ = l16 >> 1;
-    const float* pwb = pwb_lds;
-    float ref_px[4], gxr[4], gyr[4];
+  const float a00 = P.a00, a01 = P.a01, a10 = P.a10, a11 = P.a11, exposure_rat = P.exposure_rat;
+  const bool warp_nan = P.warp_nan != 0, scale_exposure = P.scale_exposure != 0;
+  const int L = S.level, cols = C.g.w[L], rows = C.g.h[L];  // img_pyr_[L].cols / rows
+  const uint8_t* img = SD.ref_base + C.g.off[L];
+  const float rx = (float)(S.px[0] / (double)(1 << L)), ry = (float)(S.px[1] / (double)(1 << L));
+  const float scaleTarget = (float)(1 << P.sl);
+  // thirteen samples per lane, unrolled and without a branch around the loads, so that all 26 of them are in flight at once
+  // (the loop form paid thirteen memory latencies one after the other: the longest wait of the kernel)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int c = (py_ + 1) * 10 + px0 + j + 1;
-      ref_px[j] = pwb[c];
-      gxr[j] = pwb[c + 1] - pwb[c - 1]; gyr[j] = pwb[c + 10] - pwb[c - 10];
-    }
+  for (int it = 0; it < 13; it++) {
+    const int idx = l8 + 8 * it;
+    const int y = idx / 10, x = idx - 10 * y;
+    float p0 = (float)(x - 5), p1 = (float)(y - 5);
+    p0 *= scaleTarget; p1 *= scaleTarget;
+    const float px0 = (a00 * p0 + a01 * p1) + rx, px1 = (a10 * p0 + a11 * p1) + ry;
+    const bool inside = !warp_nan && !(px0 < 0 || px1 < 0 || px0 >= (float)(cols - 1) || px1 >= (float)(rows - 1));
+    float val = interpolate_8u(img, cols, inside ? px0 : 0.f, inside ? px1 : 0.f);
+    if (!inside) val = 0;
+    if (scale_exposure) val = val * exposure_rat;
+    if (idx < 100) pwb_lds[idx] = val;
+  }
+}
 
-    // ---- march along the epipolar line, ZMNCC per step (:906-960)
-    const int cols = C.g.w[sl], rows = C.g.h[sl];
-    const uint8_t* cur = cur_base + C.g.off[sl];
-    const float hostMean = row_sum4(ref_px) / 64;
-    float hdev[4], hh[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { hdev[j] = ref_px[j] - hostMean; hh[j] = hdev[j] * hdev[j]; }
-    const float d1 = row_sum4(hh);
-    float zmncc_best = 0.1f, zmncc_second = 0.1f;
-    double uvb0 = 0, uvb1 = 0;
-    int loopCounter = 0, loopCBest = -1, loopCSecond = -1;
-    double cpx = pxf0, cpy = pxf1;
-    // the steps are independent and their positions known in advance: the bytes of step k+1 are requested before the three
-    // dependent row sums of step k, so the march pays one memory latency per step less (positions are uniform over the row)
-    const int lim_x = W / (1 << sl) - 8, lim_y = H / (1 << sl) - 8;
-    auto in_image = [&](double x, double y) { const int ox = (int)x, oy = (int)y; return ox >= 8 && ox < lim_x && oy >= 8 && oy < lim_y; };
-    bool have = in_image(cpx, cpy);
-    PatchTaps4 taps = { 0, 0 };
-    if (have) taps = q_patch_fetch(cur, cols, cpx, cpy, px0, py_);
-    while ((((incx < 0) == (cpx > pxc0)) && ((incy < 0) == (cpy > pxc1))) || loopCounter == 0) {
-      const double nx = cpx + incx, ny = cpy + incy;
-      const bool have_next = in_image(nx, ny);
-      PatchTaps4 taps_next = { 0, 0 };
-      if (have_next) taps_next = q_patch_fetch(cur, cols, nx, ny, px0, py_);
-      if (have) {
-        float sp[4], t[4], ht[4], tt[4];
-        q_patch_values(taps, cpx, cpy, sp);
-        const float tmean = row_sum4(sp) / 64;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { t[j] = sp[j] - tmean; ht[j] = hdev[j] * t[j]; tt[j] = t[j] * t[j]; }
-        const float num = row_sum4(ht), d2 = row_sum4(tt);
-        const float zmncc = (float)((double)num / ((double)sqrtf(d1 * d2) + 1e-12));
-        if (zmncc > zmncc_best) {
-          zmncc_second = zmncc_best; uvb0 = cpx; uvb1 = cpy; zmncc_best = zmncc;
-          loopCSecond = loopCBest; loopCBest = loopCounter;
-        } else if (zmncc > zmncc_second) {
-          zmncc_second = zmncc; loopCSecond = loopCounter;
-        }
-      }
-      cpx = nx; cpy = ny; have = have_next; taps = taps_next; loopCounter++;
-      if (loopCounter > 4096) break;  // defensive bound (NaN increments would never terminate)
-    }
-    o.n_steps = loopCounter; o.zmncc_best = zmncc_best; o.zmncc_second = zmncc_second;
-    const int dl = loopCBest - loopCSecond;
-    if ((float)(dl < 0 ? -dl : dl) > 1.0f && 1.5f * zmncc_second > zmncc_best) { res_code = -4; break; }
-    if (!((double)zmncc_best > 0.8)) { res_code = -4; break; }
+// The march of a seed (matcher.cpp:906-960) in three steps, so that the 64 lanes of the wave share the steps of its eight seeds
+// evenly however unequal the eight epipolar segments are (7 .. 27 steps in profiles' seed stage: a group that evaluated only
+// its own steps, eight at a time, kept the wave for max over groups of ceil(steps / 8) rounds = 3.2 on average, the shared
+// list needs ceil(sum / 64) = 2.1):
+//   1. every group walks its segment and lists the steps that lie inside the image: float position + step index (LDS);
+//   2. the wave evaluates the listed steps of all eight seeds, one step per lane and round (lane_zmncc);
+//   3. every group folds its scores in step order into best / second.
+// A list holds SEED_MARCH_CAP steps per seed (a segment is at most ~104 steps long); longer marches (the defensive 4096 bound:
+// NaN increments) take further passes of the three steps.
+#define SEED_MARCH_CAP 112
+struct MarchSlot { float a, b; };   // step 1: u, v of the step (u NaN: outside the image, no score); after step 2: a = its score
+struct MarchWalk { double x, y; int count; bool more; };
 
-    // ---- refinement (:966-1046)
-    double pxcur0 = uvb0 * (double)(1 << sl), pxcur1 = uvb1 * (double)(1 << sl);
-    double ps0 = pxcur0 / (double)(1 << sl), ps1 = pxcur1 / (double)(1 << sl);
-    float samp[4] = { 0, 0, 0, 0 };
-    bool result = q_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, ed0, ed1, ps0, ps1, samp, px0, py_);
-    if (!result) { ps0 = pxcur0 / (double)(1 << sl); ps1 = pxcur1 / (double)(1 << sl); }
-    samp[0] = samp[1] = samp[2] = samp[3] = 0;  // patch2D: written only by the second KLT (zero where the reference leaves it uninitialised)
-    if (S.type != HSO_FTR_EDGELET) {
-      result = q_klt_limited<false>(cur, cols, rows, gxr, gyr, ref_px, 0, 0, ps0, ps1, samp, px0, py_);
-    } else {
-      result = q_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, dc0, dc1, ps0, ps1, samp, px0, py_);
-      if (result) {
-        // Matcher::checkNormal(cur_frame, search_level_, px, dir_cur, 0.7), :406-440
-        const int16_t* gx = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][0]);
-        const int16_t* gy = reinterpret_cast<const int16_t*>(cur_base + C.g.sob_off[sl][1]);
-        const float uf = (float)ps0, vf = (float)ps1;
-        // The reference reads the four taps unchecked (:421-428): a NaN position (an edgelet direction of norm 0 lets
-        // KLTLimited1D "succeed" with a NaN pixel) or one outside the image is an out-of-bounds read there.  Defined here and in
-        // the CPU restatement alike: such a position fails the check.
-        if (!(uf >= 0 && vf >= 0 && uf < (float)(cols - 1) && vf < (float)(rows - 1))) {
-          result = false;
-        } else {
-          const int ui = (int)floorf((float)ps0), vi = (int)floorf((float)ps1);
-          const float sx = uf - (float)ui, sy = vf - (float)vi;
-          const float wTL = (float)((1.0 - sx) * (1.0 - sy)), wTR = (float)(sx * (1.0 - sy)), wBL = (float)((1.0 - sx) * sy);
-          const float wBR = (float)(((1.0 - wTL) - wTR) - wBL);
-          const int gs = C.g.sob_stride[sl];
-          const int a = vi * gs + ui;
-          double n0 = (((double)wTL * (double)gx[a] + (double)wTR * (double)gx[a + 1]) + (double)wBL * (double)gx[a + gs]) + (double)wBR * (double)gx[a + gs + 1];
-          double n1 = (((double)wTL * (double)gy[a] + (double)wTR * (double)gy[a + 1]) + (double)wBL * (double)gy[a + gs]) + (double)wBR * (double)gy[a + gs + 1];
-          const double nn = sqrt(n0 * n0 + n1 * n1);
-          n0 /= nn; n1 /= nn;
-          result = (dc0 * n0 + dc1 * n1) > (double)(float)0.7;
-        }
-      }
-    }
-    if (result) {
-      // Matcher::checkNCC(patch_f_, patch2D, 0.8), :379-404
-      const float mean1 = row_sum4(ref_px) / 64, mean2 = row_sum4(samp) / 64;
-      float qq[4], q11[4], q22[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) { const float q1 = ref_px[j] - mean1, q2 = samp[j] - mean2; qq[j] = q1 * q2; q11[j] = q1 * q1; q22[j] = q2 * q2; }
-      const float num = row_sum4(qq), den1 = row_sum4(q11), den2 = row_sum4(q22);
-      result = ((double)num / ((double)sqrtf(den1 * den2) + 1e-12)) > (double)(float)0.8;
-    }
-    if (!result) { res_code = -3; break; }
-    match_px0 = ps0 * (double)(1 << sl); match_px1 = ps1 * (double)(1 << sl);
-    res_code = 1;
-  } while (0);
-  M.res_code = res_code; M.px0 = match_px0; M.px1 = match_px1;
-  M.n_steps = o.n_steps; M.zmncc_best = o.zmncc_best; M.zmncc_second = o.zmncc_second;
-  return M;
+// step 1; returns the number of steps listed (step `first + j` in slot j, `first` = Wk.count on entry)
+HSO_DEV int g_march_list(const SeedPre& P, MarchWalk& Wk, int lim_x, int lim_y, MarchSlot* slots, int l8)
+{
+  const double pxc0 = P.pxc0, pxc1 = P.pxc1, incx = P.incx, incy = P.incy;
+  int m = 0;
+#pragma unroll 1
+  for (; m < SEED_MARCH_CAP; m++) {
+    if (!((((incx < 0) == (Wk.x > pxc0)) && ((incy < 0) == (Wk.y > pxc1))) || Wk.count == 0)) { Wk.more = false; break; }
+    const int ox = (int)Wk.x, oy = (int)Wk.y;
+    const bool inside = ox >= 8 && ox < lim_x && oy >= 8 && oy < lim_y;
+    if (l8 == 0) { slots[m].a = inside ? (float)Wk.x : __builtin_nanf(""); slots[m].b = (float)Wk.y; }
+    Wk.x += incx; Wk.y += incy; Wk.count++;
+    if (Wk.count > 4096) { Wk.more = false; m++; break; }  // defensive bound (NaN increments would never terminate)
+  }
+  return m;
 }
 
 HSO_DEV hso_seed_out seed_post(const SeedConsts& C, const SeedDev& SD, const SeedFrameDev& F, const SeedPre& P, const SeedMid& M)
@@ -537,54 +616,154 @@ HSO_DEV hso_seed_out seed_post(const SeedConsts& C, const SeedDev& SD, const See
   return o;
 }
 
-__global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) void k_seed_observe(SeedConsts C, SeedDev* seeds, int n_seeds,
-                                                                             hso_seed_out* outs, int cpw)
+// ---- the three kernels of an observation ---------------------------------------------------------------------------------
+// pre and post run one THREAD per seed (all 64 lanes of a wave busy with fp64 geometry; in round 3 they ran inside the image
+// kernel on the 4-16 lanes of a wave that owned a seed: ~440 wave-instructions per seed at 16 seeds per wave, ~110 now), the
+// image kernel eight lanes per seed, eight seeds per wave and exactly one seed per group, so a batch of n seeds is n / 8 waves
+// whatever its size.  SeedPre / SeedMid travel through HBM (160 B per seed written once and read once or twice: < 0.1 ms per
+// million seeds at HBM rate).
+static __global__ __launch_bounds__(256) void k_seed_pre(SeedConsts C, const SeedDev* __restrict__ seeds, int n_seeds, SeedPre* __restrict__ pre)
 {
-  __shared__ float s_pwb[SEED_WAVES_PER_BLOCK][4][100];
-  __shared__ SeedPre s_pre[SEED_WAVES_PER_BLOCK][SEED_CPW_MAX];
-  __shared__ SeedMid s_mid[SEED_WAVES_PER_BLOCK][SEED_CPW_MAX];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int first = (blockIdx.x * SEED_WAVES_PER_BLOCK + wave) * cpw;
-  if (first >= n_seeds) return;
-  const int mine = first + lane;
-  const bool own = lane < cpw && mine < n_seeds;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_seeds) return;
+  const SeedDev& SD = seeds[i];
   // a null reference: an erased slot of a resident table; a null active frame: the seed's group sits this call out
-  const bool live = own && seeds[mine].ref_base != nullptr && (seeds[mine].cur_base != nullptr || C.frames[seeds[mine].frame].cur_base != nullptr);
-  if (live) s_pre[wave][lane] = seed_pre(C, seeds[mine], C.frames[seeds[mine].frame]);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // image phase: row r of the wavefront (16 lanes) walks seeds r, r + 4, r + 8, ... of the wave's group on its own
-  const int row = lane >> 4;
-  for (int q = row; q < cpw; q += 4) {
-    const int sid = first + q;
-    if (sid >= n_seeds) break;
-    const SeedDev& SD = seeds[sid];
-    const uint8_t* const cur_base = SD.cur_base ? SD.cur_base : C.frames[SD.frame].cur_base;
-    if (SD.ref_base == nullptr || cur_base == nullptr || s_pre[wave][q].state != 0) continue;
-    const SeedMid M = seed_wave(C, SD, cur_base, s_pre[wave][q], s_pwb[wave][row]);
-    if ((lane & 15) == 0) s_mid[wave][q] = M;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the row's next seed overwrites its patch
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (own) {
-    if (!live) {
-      if (C.brief) { hso_seed_brief br; memset(&br, 0, sizeof(br)); C.brief[mine] = br; }
-      if (C.px) { C.px[2 * mine] = 0.f; C.px[2 * mine + 1] = 0.f; }
-    } else {
-      const hso_seed_out o = seed_post(C, seeds[mine], C.frames[seeds[mine].frame], s_pre[wave][lane], s_mid[wave][lane]);
-      seed_finish(C, seeds, mine, outs, o, 0);
-    }
-  }
+  const bool live = SD.ref_base != nullptr && (SD.cur_base != nullptr || C.frames[SD.frame].cur_base != nullptr);
+  if (!live) { pre[i].state = 3; return; }
+  pre[i] = seed_pre(C, SD, C.frames[SD.frame]);
 }
 
-// seeds per wave for a batch of n: four (one per 16-lane row) until the chip holds ~8 waves per SIMD of them, then doubling
-static int seed_cpw(const hso_gpu_ctx* ctx, int n)
+// three waves per SIMD: the lane-serial march step holds its 64 samples in registers (168 VGPRs); LDS 12.4 KB per wave
+static __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_seed_image(SeedConsts C, const SeedDev* __restrict__ seeds, int n_seeds, const SeedPre* __restrict__ pre, SeedMid* __restrict__ mid)
 {
-  const long long spread = (long long)ctx->n_cu * 4 * 8;
-  int cpw = 4;
-  while (cpw < SEED_CPW_MAX && (long long)n > spread * cpw) cpw *= 2;
-  return cpw;
+  __shared__ float s_pwb[SEED_WAVES_PER_BLOCK][8][100];
+  __shared__ __attribute__((aligned(16))) float s_hd[SEED_WAVES_PER_BLOCK][8][64];
+  __shared__ MarchSlot s_slot[SEED_WAVES_PER_BLOCK][8][SEED_MARCH_CAP];
+  struct GroupImg { const uint8_t* cur; int cols; float d1; int count; int pad_; };
+  __shared__ GroupImg s_grp[SEED_WAVES_PER_BLOCK][8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 3, l8 = lane & 7;
+  const int first = (blockIdx.x * SEED_WAVES_PER_BLOCK + wave) * 8;
+  if (first >= n_seeds) return;
+  const int sid = min(first + grp, n_seeds - 1);
+  const SeedPre& P = pre[sid];
+  const SeedDev& SD = seeds[sid];
+  // a group without a seed to observe stays: its lanes evaluate march steps of the other groups
+  const bool active = first + grp < n_seeds && P.state == 0;
+  const uint8_t* const cur_base = SD.cur_base ? SD.cur_base : C.frames[SD.frame].cur_base;
+  float* const pwb = s_pwb[wave][grp];
+  float* const hd = s_hd[wave][grp];
+  const int sl = active ? P.sl : 0;
+  if (active) {
+    g_host_patch(C, SD, P, pwb, l8);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float d1 = g_host_terms(pwb, hd, l8);
+    if (l8 == 0) { s_grp[wave][grp].cur = cur_base + C.g.off[sl]; s_grp[wave][grp].cols = C.g.w[sl]; s_grp[wave][grp].d1 = d1; }
+  }
+
+  // ---- march along the epipolar line, ZMNCC per step (:906-960)
+  MarchBest B;
+  B.best = 0.1f; B.second = 0.1f; B.i_best = -1; B.i_second = -1;
+  MarchWalk Wk;
+  Wk.x = active ? P.pxf0 : 0.0; Wk.y = active ? P.pxf1 : 0.0; Wk.count = 0; Wk.more = active;
+  const int lim_x = C.g.w[0] / (1 << sl) - 8, lim_y = C.g.h[0] / (1 << sl) - 8;
+  do {
+    int m = 0;
+    const int k_first = Wk.count;
+    if (Wk.more) m = g_march_list(P, Wk, lim_x, lim_y, s_slot[wave][grp], l8);
+    if (l8 == 0) s_grp[wave][grp].count = m;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int end[8];
+    {
+      int acc = 0;
+#pragma unroll
+      for (int g = 0; g < 8; g++) { acc += s_grp[wave][g].count; end[g] = acc; }
+    }
+    for (int item = lane; item < end[7]; item += 64) {
+      int g = 0, base = 0;
+#pragma unroll
+      for (int h = 0; h < 7; h++) if (item >= end[h]) { g = h + 1; base = end[h]; }
+      MarchSlot& slot = s_slot[wave][g][item - base];
+      const GroupImg& G = s_grp[wave][g];
+      const float u = slot.a;
+      slot.a = isnan(u) ? -__builtin_inff() : lane_zmncc(G.cur, G.cols, u, slot.b, s_hd[wave][g], G.d1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j0 = 0; j0 < m; j0 += 8) {
+      const int j = j0 + l8;
+      const float z = j < m ? s_slot[wave][grp][j].a : -__builtin_inff();
+      const int k = j < m ? k_first + j : -2;
+      g_march_fold(B, z, k);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } while (__ballot(Wk.more) != 0ull);
+  if (!active) return;
+
+  SeedMid M;
+  M.px0 = M.px1 = 0; M.res_code = -4;
+  M.n_steps = Wk.count; M.zmncc_best = B.best; M.zmncc_second = B.second;
+  do {
+    const int dl = B.i_best - B.i_second;
+    if ((float)(dl < 0 ? -dl : dl) > 1.0f && 1.5f * B.second > B.best) break;
+    if (!((double)B.best > 0.8)) break;
+    // ---- refinement (:966-1046).  uv_best: the position of step i_best, by the additions that led there (zmncc_best > 0.8 >
+    // 0.1: a step was recorded)
+    double uvb0 = P.pxf0, uvb1 = P.pxf1;
+    {
+      const double incx = P.incx, incy = P.incy;
+#pragma unroll 1
+      for (int k = 0; k < B.i_best; k++) { uvb0 += incx; uvb1 += incy; }
+    }
+    const double pxcur0 = uvb0 * (double)(1 << sl), pxcur1 = uvb1 * (double)(1 << sl);
+    double ps0 = pxcur0 / (double)(1 << sl), ps1 = pxcur1 / (double)(1 << sl);
+    if (!g_refine(C, cur_base, sl, SD.s.type, pwb, P.ed0, P.ed1, P.dc0, P.dc1, ps0, ps1, l8)) { M.res_code = -3; break; }
+    M.px0 = ps0 * (double)(1 << sl); M.px1 = ps1 * (double)(1 << sl);
+    M.res_code = 1;
+  } while (0);
+  if (l8 == 0) mid[sid] = M;
+}
+
+static __global__ __launch_bounds__(256) void k_seed_post(SeedConsts C, SeedDev* __restrict__ seeds, int n_seeds, const SeedPre* __restrict__ pre,
+                                                           const SeedMid* __restrict__ mid, hso_seed_out* __restrict__ outs)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_seeds) return;
+  const SeedPre P = pre[i];
+  if (P.state == 3) {
+    if (C.brief) { hso_seed_brief br; memset(&br, 0, sizeof(br)); C.brief[i] = br; }
+    if (C.px) { C.px[2 * i] = 0.f; C.px[2 * i + 1] = 0.f; }
+    return;
+  }
+  SeedMid M;
+  memset(&M, 0, sizeof(M));
+  if (P.state == 0) M = mid[i];
+  const hso_seed_out o = seed_post(C, seeds[i], C.frames[seeds[i].frame], P, M);
+  seed_finish(C, seeds, i, outs, o, 0);
+}
+
+// one observation of `n` seed records on the context's stream
+static int seed_observe_launch(hso_gpu_ctx* ctx, const SeedConsts& C, SeedDev* seeds, int n, hso_seed_out* outs)
+{
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t need = al((size_t)n * sizeof(SeedPre)) + al((size_t)n * sizeof(SeedMid));
+  if (ctx->seed_scratch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_seed_scratch) (void)hipFree(ctx->d_seed_scratch);
+    ctx->d_seed_scratch = nullptr; ctx->seed_scratch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_seed_scratch), hso_grown(need)));
+    ctx->seed_scratch_cap = hso_grown(need);
+  }
+  SeedPre* pre = reinterpret_cast<SeedPre*>(ctx->d_seed_scratch);
+  SeedMid* mid = reinterpret_cast<SeedMid*>(ctx->d_seed_scratch + al((size_t)n * sizeof(SeedPre)));
+  const int per_block = 8 * SEED_WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(k_seed_pre, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, C, seeds, n, pre);
+  hipLaunchKernelGGL(k_seed_image, dim3((n + per_block - 1) / per_block), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, seeds, n, pre, mid);
+  hipLaunchKernelGGL(k_seed_post, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, C, seeds, n, pre, mid, outs);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
 }
 
 extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed_frame* frames, int n_frames,
@@ -644,10 +823,7 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_fr, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
   C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle; C.update_in_place = 0; C.brief = nullptr; C.px = nullptr;
-  const int cpw = seed_cpw(ctx, n_seeds);
-  const int blocks = ((n_seeds + cpw - 1) / cpw + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK;
-  hipLaunchKernelGGL(k_seed_observe, dim3(blocks), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, d_in, n_seeds, d_out, cpw);
-  HSO_HIP_CHECK(ctx, hipGetLastError());
+  if (int rc = seed_observe_launch(ctx, C, d_in, n_seeds, d_out)) return rc;
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n_seeds * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(out, h_out, (size_t)n_seeds * sizeof(hso_seed_out));
@@ -935,10 +1111,7 @@ static int seed_table_observe_impl(hso_gpu_ctx* ctx, const hso_camera* cam, int 
   SeedConsts C;
   C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = px_out ? t->d_px : nullptr;
   const int n = (int)t->n;
-  const int cpw = seed_cpw(ctx, n);
-  hipLaunchKernelGGL(k_seed_observe, dim3(((n + cpw - 1) / cpw + SEED_WAVES_PER_BLOCK - 1) / SEED_WAVES_PER_BLOCK), dim3(64 * SEED_WAVES_PER_BLOCK), 0,
-                     ctx->stream, C, t->d, n, full_out ? t->d_full : nullptr, cpw);
-  HSO_HIP_CHECK(ctx, hipGetLastError());
+  if (int rc = seed_observe_launch(ctx, C, t->d, n, full_out ? t->d_full : nullptr)) return rc;
   if (px_out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(px_out, t->d_px, 2 * t->n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (brief_out) {
     hso_seed_brief* hb = reinterpret_cast<hso_seed_brief*>(hso_pinned(ctx, 1, t->n * sizeof(hso_seed_brief)));

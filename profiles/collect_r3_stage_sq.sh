@@ -12,7 +12,7 @@ rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$ROOT
-for S in align seed pose; do
+for S in ${STAGES:-align seed pose}; do
   rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS \
     --output-format csv -d $OUT -o ${S}_sq1 -- python -m hso_amd.stage_roofline --stage $S --reps 2 > $OUT/${S}_sq1.log 2>&1 || echo "$S sq1 failed" >> $OUT/errors.txt
   rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_FLAT \

@@ -12,11 +12,11 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r3"
 SRC = os.path.join(ROOT, "gpurun_out", "stage_sq_" + TAG)
-KERNELS = {"align": "k_align_t", "seed": "k_seed_observe", "pose": "k_pose"}
+KERNELS = {"align": ["k_align_t"], "seed": ["k_seed_observe", "k_seed_pre", "k_seed_image", "k_seed_post"], "pose": ["k_pose"]}
 
 
 def main():
-    for stage, kern in KERNELS.items():
+    for stage, kern in [(st, k) for st, ks in KERNELS.items() for k in ks]:
         per = defaultdict(list)
         geom = {}
         for path in sorted(glob.glob(os.path.join(SRC, stage + "_sq*_counter_collection.csv"))):
@@ -31,7 +31,7 @@ def main():
         m = {k: sum(v) / len(v) for k, v in per.items()}
         g = lambda c: m.get(c, float("nan"))
         wc = g("SQ_WAVE_CYCLES")
-        out = os.path.join(ROOT, "profiles", "%s_stage_sq_%s.csv" % (TAG, stage))
+        out = os.path.join(ROOT, "profiles", "%s_stage_sq_%s%s.csv" % (TAG, stage, "" if len(KERNELS[stage]) == 1 or kern == "k_seed_observe" else "_" + kern))
         with open(out, "w") as fh:
             fh.write("# rocprofv3 --pmc SQ passes of `python -m hso_amd.stage_roofline --stage %s --reps 2` (profiles/collect_r3_stage_sq.sh); mean per dispatch of %s\n" % (stage, kern))
             fh.write("# launch: grid %(grid)s threads, workgroup %(wg)s, LDS %(lds)s B, VGPRs %(vgpr)s, SGPRs %(sgpr)s, scratch %(scratch)s B\n" % geom)
