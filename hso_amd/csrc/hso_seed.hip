@@ -1,5 +1,5 @@
 // hso_seed.hip — depth-filter seed observation on gfx950: epipolar ZMNCC search, step-limited
-// KLT refinement, triangulation and the Gaussian inverse-depth update, one wavefront per seed.
+// KLT refinement, triangulation and the Gaussian inverse-depth update.
 //
 // Replaces DepthFilter::observeDepthRow (reference src/depth_filter.cpp:580-675) with
 // updateSeed :527-537 and computeTau :539-555, and Matcher::doLineStereo
@@ -7,14 +7,16 @@
 // warp::createPatch :159-196, ZMNCC_F (include/hso/vikit/patch_score.h:268-305),
 // checkNormal :406-440, checkNCC :379-404 and depthFromTriangulation :242-255.
 //
-// MI355X mapping: the reference spreads seeds over 4 CPU threads (IndexThreadReduce, MAPPING_THREADS 4).  Here the image
-// work of a seed (the 8x8 patch: createPatch, the epipolar ZMNCC march, the two KLT refinements, the checks) runs on a DPP
-// row of 16 lanes, four seeds per wavefront, four patch pixels per lane: a patch sum is three adds and four DPP steps inside
-// the row, the wave-uniform arithmetic of a step serves four seeds, and rows diverge freely (the march is inherently
-// sequential per seed, <= ~104 steps); the fp64 geometry before and after the image work runs one LANE per seed (pre / post
-// phases below).  Throughput comes from thousands of seeds per keyframe x many sequences in flight.  The fp32 sums are tree
-// sums (reference: serial loops) — rounding-level differences only; result codes and the step index of the best score can
-// differ on near-ties (excused by margin in the tests).
+// MI355X mapping: the reference spreads seeds over 4 CPU threads (IndexThreadReduce, MAPPING_THREADS 4).  Here an observation
+// is three kernels (k_seed_pre / k_seed_image / k_seed_post below): the fp64 geometry before and after the image work runs one
+// THREAD per seed; the image work of a seed (the 8x8 patch: createPatch, the epipolar ZMNCC march, the two KLT refinements, the
+// checks) runs on eight lanes, eight seeds per wavefront.  The march's steps are independent, so a lane evaluates a whole step
+// serially — in the reference's summation order, the scores are bit-identical to the CPU arithmetic — and the 64 lanes of the
+// wave share the steps of its eight seeds; the KLT iterations are sequential, so there the eight lanes share an iteration
+// (packed fp32 for the per-pixel arithmetic, a patch sum = a fixed in-lane tree + three DPP steps; rounding-level differences
+// from the reference's serial sums, excused by margin in the tests).  Throughput comes from thousands of seeds per keyframe x
+// many sequences in flight.  Round-4 counters: profiles/r4_stage_sq_seed_k_seed_image.csv (1 866 -> 1 006 VALU instructions
+// per seed against profiles/r3_stage_sq_seed.csv).
 #include "hso_match_dev.h"
 #include <string.h>
 #include <algorithm>
@@ -23,7 +25,7 @@
 
 using namespace hso_dev;
 
-#define SEED_WAVES_PER_BLOCK 4
+#define SEED_WAVES_PER_BLOCK 2
 
 // the active frame a seed is observed in (seeds of many frames / sequences share a launch)
 struct SeedFrameDev {
@@ -93,13 +95,29 @@ HSO_DEV Px12 load_px12(const uint8_t* p)
   t.lo = ((unsigned long long)v.y << 32) | v.x; t.hi = v.z;
   return t;
 }
-// nine bytes of an image row as floats: what eight horizontally adjacent bilinear samples read from it
-HSO_DEV void row9(const uint8_t* p, float (&f)[9])
+// Packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 operations per lane and instruction, the rate the MI355X's vector
+// fp32 peak is quoted at).  The per-pixel arithmetic of the march and of the KLT iterations is elementwise, so two horizontally
+// adjacent pixels share an instruction; each element is rounded exactly as the scalar operation would round it.
+typedef float f2 __attribute__((ext_vector_type(2)));
+HSO_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+// nine bytes of an image row as floats, in the two register layouts the eight bilinear samples of a patch row read them in:
+// A[k] = (b[2k], b[2k+1]) under the left taps of pixels 2k, 2k+1, S[k] = (b[2k+1], b[2k+2]) under their right taps
+struct Row9 { f2 A[4], S[4]; };
+HSO_DEV Row9 row9_of(const Px12& t)
 {
-  const Px12 t = load_px12(p);
+  Row9 r;
 #pragma unroll
-  for (int j = 0; j < 8; j++) f[j] = byte_f(t.lo, j);
-  f[8] = (float)(t.hi & 0xffu);
+  for (int k = 0; k < 4; k++) r.A[k] = mk2(byte_f(t.lo, 2 * k), byte_f(t.lo, 2 * k + 1));
+#pragma unroll
+  for (int k = 0; k < 3; k++) r.S[k] = mk2(byte_f(t.lo, 2 * k + 1), byte_f(t.lo, 2 * k + 2));
+  r.S[3] = mk2(byte_f(t.lo, 7), (float)(t.hi & 0xffu));
+  return r;
+}
+// the eight samples of a patch row: ((w_tl * tl + w_tr * tr) + w_bl * bl) + w_br * br, the reference's expression order
+HSO_DEV void bilin_row(float wtl, float wtr, float wbl, float wbr, const Row9& top, const Row9& bot, f2 (&out)[4])
+{
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[k] = ((wtl * top.A[k] + wtr * top.S[k]) + wbl * bot.A[k]) + wbr * bot.S[k];
 }
 // warp::createPatch's weights (matcher.cpp:159-196).  The reference forms the three products in double from float operands
 // and rounds to float; for a position >= 1 px the factors 1 - su, 1 - sv are exact in float (su is a multiple of ulp(u) >=
@@ -121,57 +139,62 @@ HSO_DEV float lane_zmncc(const uint8_t* img, int stride, float u, float v, const
   const int ui = (int)floorf(u), vi = (int)floorf(v);
   const Bilin w = bilin_weights(u - (float)ui, v - (float)vi);
   const uint8_t* c = img + (vi - 4) * stride + (ui - 4);
-  unsigned long long rw[9];
-  unsigned rb[9];
+  Px12 raw[9];
 #pragma unroll
-  for (int r = 0; r < 9; r++) { const Px12 t = load_px12(c + r * stride); rw[r] = t.lo; rb[r] = t.hi & 0xffu; }
-  float sp[64];
-  float top[9], bot[9];
-#pragma unroll
-  for (int j = 0; j < 8; j++) top[j] = byte_f(rw[0], j);
-  top[8] = (float)rb[0];
+  for (int r = 0; r < 9; r++) raw[r] = load_px12(c + r * stride);
+  f2 sp[32];
+  float tmean = 0;
+  Row9 top = row9_of(raw[0]);
 #pragma unroll
   for (int r = 0; r < 8; r++) {
+    const Row9 bot = row9_of(raw[r + 1]);
+    f2 row[4];
+    bilin_row(w.tl, w.tr, w.bl, w.br, top, bot, row);
 #pragma unroll
-    for (int j = 0; j < 8; j++) bot[j] = byte_f(rw[r + 1], j);
-    bot[8] = (float)rb[r + 1];
-#pragma unroll
-    for (int j = 0; j < 8; j++) sp[r * 8 + j] = ((w.tl * top[j] + w.tr * top[j + 1]) + w.bl * bot[j]) + w.br * bot[j + 1];
-#pragma unroll
-    for (int j = 0; j < 9; j++) top[j] = bot[j];
+    for (int k = 0; k < 4; k++) { sp[r * 4 + k] = row[k]; tmean += row[k].x; tmean += row[k].y; }
+    top = bot;
   }
-  float tmean = 0;
-#pragma unroll
-  for (int i = 0; i < 64; i++) tmean += sp[i];
   tmean /= 64;
   float num = 0, d2 = 0;
+  const f2* hd2 = reinterpret_cast<const f2*>(hd);
 #pragma unroll
-  for (int i = 0; i < 64; i++) {
-    const float t = sp[i] - tmean;
-    num += hd[i] * t; d2 += t * t;
+  for (int i = 0; i < 32; i++) {
+    const f2 t = sp[i] - tmean;
+    const f2 ht = hd2[i] * t, tt = t * t;
+    num += ht.x; num += ht.y;
+    d2 += tt.x; d2 += tt.y;
   }
   return (float)((double)num / ((double)sqrtf(d1 * d2) + 1e-12));
 }
 
 // Matcher::KLTLimited2D / KLTLimited1D (matcher.cpp:1296-1606), eight lanes per seed, a patch row (eight pixels) per lane.
 // ONE_D: motion restricted to `d0,d1` (double, as passed by the reference).  Returns the bool.
-template <bool ONE_D>
-HSO_DEV bool g_klt_limited(const uint8_t* img, int cols, int rows, const float (&gxr)[8], const float (&gyr)[8], const float (&ref_px)[8],
-                           double d0, double d1, double& pxs0, double& pxs1, float (&last_sample)[8], int l8)
+// a sum over the 64 pixels of the patch, eight per lane as four pairs: a fixed tree (the reference sums serially)
+HSO_DEV float grp_sum8(const f2 (&v)[4])
 {
-  float Jx[8], Jy[8], wgt[8];
+  const f2 s = (v[0] + v[1]) + (v[2] + v[3]);
+  return grp_sum_all(s.x + s.y);
+}
+
+template <bool ONE_D>
+HSO_DEV bool g_klt_limited(const uint8_t* img, int cols, int rows, const f2 (&gxr)[4], const f2 (&gyr)[4], const f2 (&ref_px)[4],
+                           double d0, double d1, double& pxs0, double& pxs1, f2 (&last_sample)[4], int l8)
+{
+  f2 Jx[4], Jy[4], wgt[4];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    if (ONE_D) { Jx[j] = (float)(0.5 * (d0 * (double)gxr[j] + d1 * (double)gyr[j])); Jy[j] = 0; }
-    else { Jx[j] = 0.5f * gxr[j]; Jy[j] = 0.5f * gyr[j]; }   // (float)(0.5 * (double)g): halving is exact
-    wgt[j] = ONE_D ? sqrtf((float)(250.0 / (250.0 + (double)(Jx[j] * Jx[j]))))
-                   : sqrtf((float)(250.0 / (250.0 + (double)(Jx[j] * Jx[j] + Jy[j] * Jy[j]))));
+  for (int k = 0; k < 4; k++) {
+    if (ONE_D) {
+      Jx[k] = mk2((float)(0.5 * (d0 * (double)gxr[k].x + d1 * (double)gyr[k].x)), (float)(0.5 * (d0 * (double)gxr[k].y + d1 * (double)gyr[k].y)));
+      Jy[k] = mk2(0.f, 0.f);
+    } else { Jx[k] = 0.5f * gxr[k]; Jy[k] = 0.5f * gyr[k]; }   // (float)(0.5 * (double)g): halving is exact
+    const f2 jj = ONE_D ? Jx[k] * Jx[k] : Jx[k] * Jx[k] + Jy[k] * Jy[k];
+    wgt[k] = mk2(sqrtf((float)(250.0 / (250.0 + (double)jj.x))), sqrtf((float)(250.0 / (250.0 + (double)jj.y))));
   }
   float Hi[9];
   {
-    float t0[8], t1[8], t2[8];
+    f2 t0[4], t1[4], t2[4];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { t0[j] = (Jx[j] * Jx[j]) * wgt[j]; t1[j] = (Jx[j] * 1.0f) * wgt[j]; t2[j] = (1.0f * 1.0f) * wgt[j]; }
+    for (int k = 0; k < 4; k++) { t0[k] = (Jx[k] * Jx[k]) * wgt[k]; t1[k] = (Jx[k] * 1.0f) * wgt[k]; t2[k] = wgt[k]; }
     const float h_xx = grp_sum8(t0), h_x1 = grp_sum8(t1), h_11 = grp_sum8(t2);
     if (ONE_D) {
       const float H00 = (float)((double)h_xx * (1 + 0.001)), H11 = (float)((double)h_11 * (1 + 0.001)), H01 = h_x1;
@@ -180,7 +203,7 @@ HSO_DEV bool g_klt_limited(const uint8_t* img, int cols, int rows, const float (
       Hi[0] = H11 * invdet; Hi[1] = -H01 * invdet; Hi[3] = -H01 * invdet; Hi[4] = H00 * invdet;
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; j++) { t0[j] = (Jx[j] * Jy[j]) * wgt[j]; t1[j] = (Jy[j] * Jy[j]) * wgt[j]; t2[j] = (Jy[j] * 1.0f) * wgt[j]; }
+      for (int k = 0; k < 4; k++) { t0[k] = (Jx[k] * Jy[k]) * wgt[k]; t1[k] = (Jy[k] * Jy[k]) * wgt[k]; t2[k] = (Jy[k] * 1.0f) * wgt[k]; }
       const float h_xy = grp_sum8(t0), h_yy = grp_sum8(t1), h_y1 = grp_sum8(t2);
       const float H0 = (float)((double)h_xx * (1 + 0.001)), H4 = (float)((double)h_yy * (1 + 0.001)), H8 = (float)((double)h_11 * (1 + 0.001));
       const float H1 = h_xy, H2 = h_x1, H5 = h_y1, H3 = H1, H6 = H2, H7 = H5;
@@ -206,15 +229,14 @@ HSO_DEV bool g_klt_limited(const uint8_t* img, int cols, int rows, const float (
     const float cx = 1.0f - sx, cy = 1.0f - sy;
     const float wTL = cx * cy, wTR = sx * cy, wBL = cx * sy, wBR = sx * sy;
     const uint8_t* it = img + (v_r + l8 - 4) * cols + u_r - 4;
-    float top[9], bot[9];
-    row9(it, top); row9(it + cols, bot);
-    float a0[8], a1[8], a2[8], a3[8];
+    const Row9 top = row9_of(load_px12(it)), bot = row9_of(load_px12(it + cols));
+    bilin_row(wTL, wTR, wBL, wBR, top, bot, last_sample);
+    f2 a0[4], a1[4], a2[4], a3[4];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const float sp = ((wTL * top[j] + wTR * top[j + 1]) + wBL * bot[j]) + wBR * bot[j + 1];
-      last_sample[j] = sp;
-      const float res = (sp - ref_px[j]) + mean_diff;
-      a0[j] = (res * Jx[j]) * wgt[j]; a1[j] = res * wgt[j]; a2[j] = (res * res) * wgt[j]; a3[j] = (res * Jy[j]) * wgt[j];
+    for (int k = 0; k < 4; k++) {
+      const f2 res = (last_sample[k] - ref_px[k]) + mean_diff;
+      a0[k] = (res * Jx[k]) * wgt[k]; a1[k] = res * wgt[k]; a2[k] = (res * res) * wgt[k];
+      if (!ONE_D) a3[k] = (res * Jy[k]) * wgt[k];
     }
     const float j0 = -grp_sum8(a0);
     const float j2 = -grp_sum8(a1);
@@ -399,19 +421,22 @@ HSO_DEV bool g_refine(const SeedConsts& C, const uint8_t* cur_base, int sl, int 
 {
   const int cols = C.g.w[sl], rows = C.g.h[sl];
   const uint8_t* cur = cur_base + C.g.off[sl];
-  float ref_px[8], gxr[8], gyr[8];
+  f2 ref_px[4], gxr[4], gyr[4];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int c = (l8 + 1) * 10 + j + 1;
-    ref_px[j] = pwb[c];
-    gxr[j] = pwb[c + 1] - pwb[c - 1]; gyr[j] = pwb[c + 10] - pwb[c - 10];
+  for (int k = 0; k < 4; k++) {
+    const int c = (l8 + 1) * 10 + 2 * k + 1;
+    ref_px[k] = mk2(pwb[c], pwb[c + 1]);
+    gxr[k] = mk2(pwb[c + 1] - pwb[c - 1], pwb[c + 2] - pwb[c]);
+    gyr[k] = mk2(pwb[c + 10] - pwb[c - 10], pwb[c + 11] - pwb[c - 9]);
   }
   const double start0 = ps0, start1 = ps1;
-  float samp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  f2 samp[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) samp[k] = mk2(0.f, 0.f);
   bool result = g_klt_limited<true>(cur, cols, rows, gxr, gyr, ref_px, ed0, ed1, ps0, ps1, samp, l8);
   if (!result) { ps0 = start0; ps1 = start1; }
 #pragma unroll
-  for (int j = 0; j < 8; j++) samp[j] = 0;  // patch2D: written only by the second KLT (zero where the reference leaves it uninitialised)
+  for (int k = 0; k < 4; k++) samp[k] = mk2(0.f, 0.f);  // patch2D: written only by the second KLT (zero where the reference leaves it uninitialised)
   if (type != HSO_FTR_EDGELET) {
     result = g_klt_limited<false>(cur, cols, rows, gxr, gyr, ref_px, 0, 0, ps0, ps1, samp, l8);
   } else {
@@ -444,9 +469,9 @@ HSO_DEV bool g_refine(const SeedConsts& C, const uint8_t* cur_base, int sl, int 
   if (result) {
     // Matcher::checkNCC(patch_f_, patch2D, 0.8), :379-404
     const float mean1 = grp_sum8(ref_px) / 64, mean2 = grp_sum8(samp) / 64;
-    float qq[8], q11[8], q22[8];
+    f2 qq[4], q11[4], q22[4];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { const float q1 = ref_px[j] - mean1, q2 = samp[j] - mean2; qq[j] = q1 * q2; q11[j] = q1 * q1; q22[j] = q2 * q2; }
+    for (int k = 0; k < 4; k++) { const f2 q1 = ref_px[k] - mean1, q2 = samp[k] - mean2; qq[k] = q1 * q2; q11[k] = q1 * q1; q22[k] = q2 * q2; }
     const float num = grp_sum8(qq), den1 = grp_sum8(q11), den2 = grp_sum8(q22);
     result = ((double)num / ((double)sqrtf(den1 * den2) + 1e-12)) > (double)(float)0.8;
   }
