@@ -168,6 +168,10 @@ void hso_or_seed_observe(const hso_camera* cam, const hso_seed* s, const hso_se3
                          double px_error_angle, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
                          const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],
                          const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_seed_out* o);
+void hso_or_seed_observe_previous(const hso_camera* cam, const hso_seed* s, const hso_se3* pre_T_f_w, double pre_exposure,
+                                  double px_error_angle, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                                  const uint8_t* const pre_pyr[HSO_N_PYR_LEVELS], const int16_t* const pre_gx[HSO_N_SOBEL_LEVELS],
+                                  const int16_t* const pre_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_seed_out* o);
 /* ---- seed activation (src/depth_filter.cpp:729-1073, src/matcher.cpp:442-518) ---- */
 void hso_or_find_match_seed(const hso_camera* cam, const hso_align_job* job, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
                             const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS], const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS],

@@ -440,3 +440,159 @@ void hso_or_seed_observe(const hso_camera* cam, const hso_seed* s, const hso_se3
   const double tau_inverse = 0.5 * (1.0 / fmax(0.0000001, z - tau) - 1.0 / (z + tau));
   hso_or_update_seed(1. / z, tau_inverse * tau_inverse, &o->mu, &o->sigma2);
 }
+
+/* Matcher::findEpipolarMatchPrevious, src/matcher.cpp:1051-1293 (cur_frame = the earlier frame).  Returns 1 and the depth, or
+ * the reason for `false`: -1 the edgelet / epipolar angle filter (:1078-1084) or too many steps (:1161), -4 the march (ambiguous
+ * or best score <= 0.8), -3 the refinement, -2 the triangulation. */
+static int find_epipolar_match_previous(const hso_camera* cam, const hso_seed* s, const hso_se3* T_cur_ref, float exposure_rat,
+                                        const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS], const uint8_t* const cur_pyr[HSO_N_PYR_LEVELS],
+                                        const int16_t* const cur_gx[HSO_N_SOBEL_LEVELS], const int16_t* const cur_gy[HSO_N_SOBEL_LEVELS],
+                                        int w, int h, double d_estimate, double d_min, double d_max, hso_seed_out* o)
+{
+  double A2[2], B2[2];
+  { const double v[3] = { s->f[0] * d_min, s->f[1] * d_min, s->f[2] * d_min }; double q[3]; hso_or_se3_apply(T_cur_ref, v, q); A2[0] = q[0] / q[2]; A2[1] = q[1] / q[2]; }
+  { const double v[3] = { s->f[0] * d_max, s->f[1] * d_max, s->f[2] * d_max }; double q[3]; hso_or_se3_apply(T_cur_ref, v, q); B2[0] = q[0] / q[2]; B2[1] = q[1] / q[2]; }
+  const double epi_dir[2] = { A2[0] - B2[0], A2[1] - B2[1] };
+  double A[4];
+  hso_or_warp_matrix_affine(cam, cam, s->px, s->f, d_estimate, T_cur_ref, s->level, A);
+  const int search_level = hso_or_best_search_level(A, HSO_N_SOBEL_LEVELS - 1);
+  o->search_level = search_level;
+  double px_A[2], px_B[2];
+  { const double v[3] = { A2[0], A2[1], 1.0 }; hso_or_world2cam(cam, v, px_A); }
+  { const double v[3] = { B2[0], B2[1], 1.0 }; hso_or_world2cam(cam, v, px_B); }
+  const double dAB[2] = { px_A[0] - px_B[0], px_A[1] - px_B[1] };
+  const double epi_length = sqrt(dAB[0] * dAB[0] + dAB[1] * dAB[1]) / (1 << search_level);
+  float pwb[100], patch[64];
+  int rcols, rrows;
+  hso_or_pyramid_dims(w, h, s->level, &rcols, &rrows);
+  hso_or_warp_affine(A, ref_pyr[s->level], rcols, rrows, s->px, s->level, search_level, 5, pwb);
+  if (s->type == HSO_FTR_GRADIENT || s->type == HSO_FTR_EDGELET) {
+    double g0 = A[0] * s->grad[0] + A[1] * s->grad[1], g1 = A[2] * s->grad[0] + A[3] * s->grad[1];
+    const double gn = sqrt(g0 * g0 + g1 * g1); g0 /= gn; g1 /= gn;
+    const double en = sqrt(epi_dir[0] * epi_dir[0] + epi_dir[1] * epi_dir[1]);
+    const double cosangle = fabs(g0 * (epi_dir[0] / en) + g1 * (epi_dir[1] / en));
+    if (cosangle < 0.4) return -1;
+  }
+  if (fabsf(exposure_rat * 128 - 128) > 30.0f)
+    for (int i = 0; i < 100; ++i) pwb[i] = pwb[i] * exposure_rat;
+  for (int y = 1; y < 9; ++y) for (int x = 0; x < 8; ++x) patch[(y - 1) * 8 + x] = pwb[y * 10 + 1 + x];
+  int cols, rows;
+  hso_or_pyramid_dims(w, h, search_level, &cols, &rows);
+  double px_cur[2];
+  if (!(epi_length < 2.0)) {
+    size_t n_steps = epi_length / 0.7;
+    const double step[2] = { epi_dir[0] / n_steps, epi_dir[1] / n_steps };
+    if (n_steps > 100) return -1;   /* options_.max_epi_search_steps, matcher.h:126 */
+    const float hostMean = zmncc_host_mean(patch);
+    float zmncc_best = 0.1f, zmncc_second = zmncc_best;
+    size_t bestCounter = 0, secondCounter = 0;
+    double uv_best[2] = { 0, 0 };
+    double uv[2] = { B2[0] - step[0], B2[1] - step[1] };
+    ++n_steps;
+    float patch_f[64];
+    for (size_t i = 0; i < n_steps; ++i, uv[0] += step[0], uv[1] += step[1]) {
+      double px[2];
+      { const double v[3] = { uv[0], uv[1], 1.0 }; hso_or_world2cam(cam, v, px); }
+      const double px_scaled[2] = { px[0] / (1 << search_level), px[1] / (1 << search_level) };
+      if (!is_in_frame_level(w, h, (int)px_scaled[0], (int)px_scaled[1], 8, search_level)) continue;
+      create_patch(patch_f, px_scaled, cur_pyr[search_level], cols);
+      const float zmncc = zmncc_score(patch, hostMean, patch_f);
+      hso_or_margin_note(HSO_M_ZMNCC_ORDER, (double)zmncc - zmncc_best);
+      hso_or_margin_note(HSO_M_ZMNCC_ORDER, (double)zmncc - zmncc_second);
+      if (zmncc > zmncc_best) {
+        zmncc_second = zmncc_best; secondCounter = bestCounter;
+        zmncc_best = zmncc; bestCounter = i;
+        uv_best[0] = uv[0]; uv_best[1] = uv[1];
+      } else if (zmncc > zmncc_second) {
+        zmncc_second = zmncc; secondCounter = i;
+      }
+    }
+    o->n_steps = (int)n_steps; o->zmncc_best = zmncc_best; o->zmncc_second = zmncc_second;
+    /* fabs(bestCounter - secondCounter) on size_t: the difference wraps, so only "second == best" and "second == best - 1"
+     * count as adjacent (:1219) */
+    const int apart = fabs((double)(size_t)(bestCounter - secondCounter)) > 1.0f;
+    if (apart) hso_or_margin_note(HSO_M_ZMNCC_AMBIG, 1.5 * (double)zmncc_second - zmncc_best);
+    if (apart && 1.5f * zmncc_second > zmncc_best) return -4;
+    hso_or_margin_note(HSO_M_ZMNCC_BEST, (double)zmncc_best - 0.8);
+    if (!(zmncc_best > 0.8)) return -4;
+    { const double v[3] = { uv_best[0], uv_best[1], 1.0 }; hso_or_world2cam(cam, v, px_cur); }
+  } else {
+    px_cur[0] = (px_A[0] + px_B[0]) / 2.0; px_cur[1] = (px_A[1] + px_B[1]) / 2.0;
+  }
+  /* the refinement both branches share (:1102-1150, :1236-1290) */
+  double px_scaled[2] = { px_cur[0] / (1 << search_level), px_cur[1] / (1 << search_level) };
+  double ed[2] = { dAB[0], dAB[1] };
+  { const double en = sqrt(ed[0] * ed[0] + ed[1] * ed[1]); ed[0] /= en; ed[1] /= en; }
+  int result = klt_limited_1d(cur_pyr[search_level], cols, rows, pwb, patch, 10, px_scaled, ed, NULL);
+  float patch2D[64];
+  memset(patch2D, 0, sizeof(patch2D));
+  double dir_cur[2] = { A[0] * s->grad[0] + A[1] * s->grad[1], A[2] * s->grad[0] + A[3] * s->grad[1] };
+  { const double dn = sqrt(dir_cur[0] * dir_cur[0] + dir_cur[1] * dir_cur[1]); dir_cur[0] /= dn; dir_cur[1] /= dn; }
+  double* pxr = px_scaled;
+  double px_2d[2] = { px_cur[0] / (1 << search_level), px_cur[1] / (1 << search_level) };
+  if (!result) pxr = px_2d;
+  if (s->type != HSO_FTR_EDGELET) {
+    result = klt_limited_2d(cur_pyr[search_level], cols, rows, pwb, patch, 10, pxr, patch2D);
+  } else {
+    result = klt_limited_1d(cur_pyr[search_level], cols, rows, pwb, patch, 10, pxr, dir_cur, patch2D);
+    if (result) {
+      const double nd_ = hso_or_normal_dot(cur_gx[search_level], cur_gy[search_level], cols, rows, pxr, dir_cur);
+      hso_or_margin_note(HSO_M_NORMAL, nd_ - (float)0.7);
+      result = nd_ > (float)0.7;
+    }
+  }
+  px_scaled[0] = pxr[0]; px_scaled[1] = pxr[1];
+  if (result) {
+    const double ncc_ = hso_or_ncc(patch, patch2D);
+    hso_or_margin_note(HSO_M_NCC, ncc_ - (double)(float)0.8);
+    result = ncc_ > (double)(float)0.8;
+  }
+  if (!result) return -3;
+  px_cur[0] = px_scaled[0] * (1 << search_level); px_cur[1] = px_scaled[1] * (1 << search_level);
+  o->px_cur[0] = px_cur[0]; o->px_cur[1] = px_cur[1];
+  double fc[3];
+  hso_or_cam2world(cam, px_cur[0], px_cur[1], fc);
+  if (depth_from_triangulation(T_cur_ref, s->f, fc, &o->z)) return 1;
+  return -2;
+}
+
+/* DepthFilter::observeDepthWithPreviousFrameOnce for one seed and the first of its pre_frames, src/depth_filter.cpp:677-726.
+ * o->is_update = 1: the earlier frame saw the seed's point (it joins optFrames_P, :702-703); o->result = 1: matched, mu / sigma2
+ * updated (:718-722).  The seed's b is never touched here. */
+void hso_or_seed_observe_previous(const hso_camera* cam, const hso_seed* s, const hso_se3* pre_T_f_w, double pre_exposure,
+                                  double px_error_angle, const uint8_t* const ref_pyr[HSO_N_PYR_LEVELS],
+                                  const uint8_t* const pre_pyr[HSO_N_PYR_LEVELS], const int16_t* const pre_gx[HSO_N_SOBEL_LEVELS],
+                                  const int16_t* const pre_gy[HSO_N_SOBEL_LEVELS], int w, int h, hso_seed_out* o)
+{
+  memset(o, 0, sizeof(*o));
+  o->mu = s->mu; o->sigma2 = s->sigma2; o->b = s->b; o->is_valid = 1;
+  hso_se3 pre_inv, T_ref_cur, T_cur_ref;
+  hso_or_se3_inverse(pre_T_f_w, &pre_inv);
+  hso_or_se3_mul(&s->T_ref_w, &pre_inv, &T_ref_cur);
+  hso_or_se3_inverse(&T_ref_cur, &T_cur_ref);
+  const double sc = 1.0 / s->mu;
+  const double pr[3] = { sc * s->f[0], sc * s->f[1], sc * s->f[2] };
+  double xyz_f[3];
+  hso_or_se3_apply(&T_cur_ref, pr, xyz_f);
+  if (xyz_f[2] < 0.0) return;
+  double c[2];
+  hso_or_world2cam(cam, xyz_f, c);
+  { const int ox = (int)c[0], oy = (int)c[1];
+    if (!(ox >= 0 && ox < w && oy >= 0 && oy < h)) return; }
+  o->is_update = 1;
+  const float z_inv_min = s->mu + 2 * sqrtf(s->sigma2);
+  const float z_inv_max = fmaxf(s->mu - 2 * sqrtf(s->sigma2), 0.00000001f);
+  /* findEpipolarMatchPrevious recomputes T_cur_ref = cur.T_f_w_ * ref.T_f_w_.inverse() (matcher.cpp:1055) */
+  hso_se3 ref_inv, T_cr;
+  hso_or_se3_inverse(&s->T_ref_w, &ref_inv);
+  hso_or_se3_mul(pre_T_f_w, &ref_inv, &T_cr);
+  const float exposure_rat = pre_exposure / s->ref_exposure;
+  const int res = find_epipolar_match_previous(cam, s, &T_cr, exposure_rat, ref_pyr, pre_pyr, pre_gx, pre_gy, w, h,
+                                               1.0 / s->mu, 1.0 / z_inv_min, 1.0 / z_inv_max, o);
+  o->result = res;
+  if (res != 1) return;
+  const double z = o->z;
+  const double tau = hso_or_compute_tau(&T_ref_cur, s->f, z, px_error_angle);
+  const double tau_inverse = 0.5 * (1.0 / fmax(0.0000001, z - tau) - 1.0 / (z + tau));
+  hso_or_update_seed(1. / z, tau_inverse * tau_inverse, &o->mu, &o->sigma2);
+}
