@@ -42,6 +42,10 @@ struct SeedConsts {
   int update_in_place;       // resident tables: write mu / sigma2 / b back into the seed record
   hso_seed_brief* brief;     // resident tables: compact per-slot result (may be null)
   float* px;                 // resident tables: Matcher::px_cur_ of the matched seeds, two floats per slot (may be null)
+  // previous-frame pass (observeDepthWithPreviousFrameOnce): frames[k] is the earlier frame the seeds hosted in keyframe
+  // frame_keys[k] (ascending) observe; seeds of other keyframes sit the call out.  Null: the ordinary pass (frames by group).
+  const int64_t* frame_keys;
+  int n_frame_keys;
 };
 
 struct SeedDev {
@@ -302,8 +306,11 @@ struct SeedPre {
   double pxc0, pxc1, pxf0, pxf1, incx, incy, ed0, ed1, dc0, dc1;
   float a00, a01, a10, a11, exposure_rat;
   int32_t sl, epl_start[2], epl_end[2];
+  int32_t frame;     // index into SeedConsts::frames of the frame observed
+  int32_t n_march;   // previous-frame pass: the number of steps of the march (after "expand one step", matcher.cpp:1177)
   int8_t state;      // 0: run the image phase; 1: not visible in the active frame; 2: doLineStereo returns -1 before any image
-                     // access; 3: nothing to observe (erased slot, or the seed's group sits this call out)
+                     // access; 3: nothing to observe (erased slot, or the seed's group sits this call out); 4 (previous-frame pass):
+                     // the epipolar segment is shorter than two pixels, no march, the refinement starts at (pxc0, pxc1) (:1102)
   int8_t is_valid, warp_nan, scale_exposure;
 };
 struct SeedMid {
@@ -312,14 +319,16 @@ struct SeedMid {
   int32_t n_steps, res_code;       // 1: matched (triangulate next), -4 / -3: rejected by the march / the refinement
 };
 
-HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrameDev& F)
+// What the ordinary pass and the previous-frame pass share before the epipolar geometry: the visibility test (depth_filter.cpp:
+// 590-606 / :688-699), the inverse-depth interval, T_cur_ref, the affine warp (warp::getWarpMatrixAffine, matcher.cpp:46-72), the
+// search level, the inverse warp matrix and the exposure ratio.  Returns false when the point is not visible (P.state = 1).
+struct SeedGeom { Se3 T; double A00, A01, A10, A11, min_idepth, prior_idepth, max_idepth; };
+HSO_DEV bool seed_pre_common(const SeedConsts& C, const SeedDev& SD, const SeedFrameDev& F, SeedPre& P, SeedGeom& G)
 {
   const hso_seed& S = SD.s;
   const int W = C.g.w[0], H = C.g.h[0];
-  SeedPre P;
   memset(&P, 0, sizeof(P));
   P.is_valid = 1;
-  // ---- visibility in the active frame (depth_filter.cpp:590-606)
   const Se3 Tcw = se3_from(F.T_f_w), Trw = se3_from(S.T_ref_w);
   const Se3 T_ref_cur = se3_mul(Trw, se3_inverse(Tcw));
   {
@@ -334,20 +343,18 @@ HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrame
       const int ox = (int)cu, oy = (int)cv;
       vis = (ox >= 0 && ox < W && oy >= 0 && oy < H);
     }
-    if (!vis) { P.state = 1; return P; }
+    if (!vis) { P.state = 1; return false; }
   }
   const float z_inv_min = S.mu + 2 * sqrtf(S.sigma2);
   const float z_inv_max = fmaxf(S.mu - 2 * sqrtf(S.sigma2), 0.00000001f);
   if (isnan(z_inv_min)) P.is_valid = 0;
-  const double min_idepth = 1.0 / (double)z_inv_min, prior_idepth = 1.0 / (double)S.mu, max_idepth = 1.0 / (double)z_inv_max;
-
-  // ---- Matcher::doLineStereo (matcher.cpp:802-1049), the part before the first image access
-  const Se3 T = se3_mul(Tcw, se3_inverse(Trw));  // T_cur_ref, :807
+  G.min_idepth = 1.0 / (double)z_inv_min; G.prior_idepth = 1.0 / (double)S.mu; G.max_idepth = 1.0 / (double)z_inv_max;
+  G.T = se3_mul(Tcw, se3_inverse(Trw));  // T_cur_ref, matcher.cpp:807 / :1055
+  const Se3& T = G.T;
   P.state = 2;
-  double A00, A01, A10, A11;
   {
     const int hp = 5;
-    const double xr = S.f[0] * prior_idepth, yr = S.f[1] * prior_idepth, zr = S.f[2] * prior_idepth;
+    const double xr = S.f[0] * G.prior_idepth, yr = S.f[1] * G.prior_idepth, zr = S.f[2] * G.prior_idepth;
     const int ratio = 1 << S.level;
     double du[3], dv[3];
     cam2world_dev(C.cam, S.px[0] + (double)(hp * ratio), S.px[1] + (double)(0 * ratio), du);
@@ -361,19 +368,33 @@ HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrame
     world2cam(C.cam, cx, cy, cz, pc0, pc1);
     world2cam(C.cam, ux, uy, uz, pu0, pu1);
     world2cam(C.cam, vx, vy, vz, pv0, pv1);
-    A00 = (pu0 - pc0) / hp; A10 = (pu1 - pc1) / hp; A01 = (pv0 - pc0) / hp; A11 = (pv1 - pc1) / hp;
+    G.A00 = (pu0 - pc0) / hp; G.A10 = (pu1 - pc1) / hp; G.A01 = (pv0 - pc0) / hp; G.A11 = (pv1 - pc1) / hp;
   }
   int sl = 0;
-  { double D = A00 * A11 - A10 * A01; while (D > 3.0 && sl < HSO_N_SOBEL_LEVELS - 1) { sl += 1; D *= 0.25; } }
+  { double D = G.A00 * G.A11 - G.A10 * G.A01; while (D > 3.0 && sl < HSO_N_SOBEL_LEVELS - 1) { sl += 1; D *= 0.25; } }
   P.sl = sl;
   P.exposure_rat = (float)(F.exposure / S.ref_exposure);
   {
-    const double det = A00 * A11 - A10 * A01;
+    const double det = G.A00 * G.A11 - G.A10 * G.A01;
     const double invdet = 1.0 / det;
-    P.a00 = (float)(A11 * invdet); P.a01 = (float)(-A01 * invdet); P.a10 = (float)(-A10 * invdet); P.a11 = (float)(A00 * invdet);
+    P.a00 = (float)(G.A11 * invdet); P.a01 = (float)(-G.A01 * invdet); P.a10 = (float)(-G.A10 * invdet); P.a11 = (float)(G.A00 * invdet);
     P.warp_nan = isnan(P.a00) ? 1 : 0;
     P.scale_exposure = fabsf(P.exposure_rat * 128 - 128) > 30.0f ? 1 : 0;  // :818-826 (no keyframe-gap test here)
   }
+  return true;
+}
+
+HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrameDev& F)
+{
+  const hso_seed& S = SD.s;
+  SeedPre P;
+  SeedGeom G;
+  if (!seed_pre_common(C, SD, F, P, G)) return P;
+  // ---- Matcher::doLineStereo (matcher.cpp:802-1049), the part before the first image access
+  const Se3& T = G.T;
+  const double A00 = G.A00, A01 = G.A01, A10 = G.A10, A11 = G.A11;
+  const double min_idepth = G.min_idepth, max_idepth = G.max_idepth;
+  const int sl = P.sl;
   // close / far points on the unit plane, :834-852
   double pcx, pcy, pcz, pfx, pfy, pfz;
   se3_apply(T, S.f[0] * min_idepth, S.f[1] * min_idepth, S.f[2] * min_idepth, pcx, pcy, pcz);
@@ -408,6 +429,52 @@ HSO_DEV SeedPre seed_pre(const SeedConsts& C, const SeedDev& SD, const SeedFrame
   }
   P.pxc0 = pxc0; P.pxc1 = pxc1; P.pxf0 = pxf0; P.pxf1 = pxf1; P.incx = incx; P.incy = incy;
   P.ed0 = ed0; P.ed1 = ed1; P.dc0 = dc0; P.dc1 = dc1;
+  P.state = 0;
+  return P;
+}
+
+// Matcher::findEpipolarMatchPrevious (matcher.cpp:1051-1293), the part before the first image access.  The march of this
+// matcher walks the unit plane in equal steps from B - step towards A and projects every step (:1174-1186): P.pxf = the first
+// point, P.inc = the step, P.n_march = the number of steps; P.ed = (px_A - px_B).normalized(), P.dc = the warped gradient.
+HSO_DEV SeedPre seed_pre_prev(const SeedConsts& C, const SeedDev& SD, const SeedFrameDev& F)
+{
+  const hso_seed& S = SD.s;
+  SeedPre P;
+  SeedGeom G;
+  if (!seed_pre_common(C, SD, F, P, G)) return P;
+  const Se3& T = G.T;
+  double ax, ay, az, bx, by, bz;
+  se3_apply(T, S.f[0] * G.min_idepth, S.f[1] * G.min_idepth, S.f[2] * G.min_idepth, ax, ay, az);
+  ax /= az; ay /= az;
+  se3_apply(T, S.f[0] * G.max_idepth, S.f[1] * G.max_idepth, S.f[2] * G.max_idepth, bx, by, bz);
+  bx /= bz; by /= bz;
+  const double epi0 = ax - bx, epi1 = ay - by;
+  double pxa0, pxa1, pxb0, pxb1;
+  world2cam(C.cam, ax, ay, 1.0, pxa0, pxa1);
+  world2cam(C.cam, bx, by, 1.0, pxb0, pxb1);
+  const double dab0 = pxa0 - pxb0, dab1 = pxa1 - pxb1;
+  const double dabn = sqrt(dab0 * dab0 + dab1 * dab1);
+  const double epi_length = dabn / (double)(1 << P.sl);
+  double dc0 = G.A00 * S.grad[0] + G.A01 * S.grad[1], dc1 = G.A10 * S.grad[0] + G.A11 * S.grad[1];
+  { const double dn = sqrt(dc0 * dc0 + dc1 * dc1); dc0 /= dn; dc1 /= dn; }
+  if (S.type == HSO_FTR_GRADIENT || S.type == HSO_FTR_EDGELET) {
+    const double en = sqrt(epi0 * epi0 + epi1 * epi1);
+    if (fabs(dc0 * (epi0 / en) + dc1 * (epi1 / en)) < 0.4) return P;   // :1078-1084 (state 2: "false" before any image access)
+  }
+  P.ed0 = dab0 / dabn; P.ed1 = dab1 / dabn; P.dc0 = dc0; P.dc1 = dc1;
+  if (epi_length < 2.0) {
+    P.pxc0 = (pxa0 + pxb0) / 2.0; P.pxc1 = (pxa1 + pxb1) / 2.0;   // px_cur_, level 0 (:1100)
+    P.state = 4;
+    return P;
+  }
+  // size_t n_steps = epi_length_ / 0.7; ... if(n_steps > max_epi_search_steps) return false (:1158-1162).  A NaN length converts to
+  // 2^63 on the reference's x86 build (cvttsd2si) and is rejected there too; said explicitly here and in the CPU restatement
+  const double q_steps = epi_length / 0.7;
+  if (!(q_steps < 101.0)) return P;
+  const unsigned long long n_steps = (unsigned long long)q_steps;
+  const double st0 = epi0 / (double)n_steps, st1 = epi1 / (double)n_steps;
+  P.pxf0 = bx - st0; P.pxf1 = by - st1; P.incx = st0; P.incy = st1;
+  P.n_march = (int)n_steps + 1;
   P.state = 0;
   return P;
 }
@@ -584,8 +651,9 @@ HSO_DEV hso_seed_out seed_post(const SeedConsts& C, const SeedDev& SD, const See
   const Se3 Tcw = se3_from(F.T_f_w), Trw = se3_from(S.T_ref_w);
   const Se3 T_ref_cur = se3_mul(Trw, se3_inverse(Tcw));
   const Se3 T = se3_mul(Tcw, se3_inverse(Trw));  // T_cur_ref, :807
+  const bool prev = C.frame_keys != nullptr;   // observeDepthWithPreviousFrameOnce: a failed match leaves b alone (:710-714)
   int res_code = -1;
-  if (P.state == 0) {
+  if (P.state == 0 || P.state == 4) {
     o.epl_start[0] = P.epl_start[0]; o.epl_start[1] = P.epl_start[1]; o.epl_end[0] = P.epl_end[0]; o.epl_end[1] = P.epl_end[1];
     o.n_steps = M.n_steps; o.zmncc_best = M.zmncc_best; o.zmncc_second = M.zmncc_second;
     res_code = M.res_code;
@@ -612,7 +680,7 @@ HSO_DEV hso_seed_out seed_post(const SeedConsts& C, const SeedDev& SD, const See
   }
   o.result = res_code;
   if (res_code != 1) {
-    o.b = S.b + 1;  // :634
+    if (!prev) o.b = S.b + 1;  // :634
     o.epl_start[0] = o.epl_start[1] = o.epl_end[0] = o.epl_end[1] = 0;
   } else {
     // computeTau (:539-555, with hso::PI = 3.14159265) and updateSeed (:527-537)
@@ -641,6 +709,35 @@ HSO_DEV hso_seed_out seed_post(const SeedConsts& C, const SeedDev& SD, const See
   return o;
 }
 
+// step 1 of the march for the previous-frame matcher (matcher.cpp:1174-1186): the steps are equal steps on the unit plane,
+// every one projected by world2cam; lane l8 projects steps l8, l8 + 8, ... of the group's seed
+HSO_DEV int g_march_list_prev(const SeedConsts& C, const SeedPre& P, MarchWalk& Wk, int sl, int lim_x, int lim_y, MarchSlot* slots, int l8)
+{
+  const double incx = P.incx, incy = P.incy;
+  const int n_march = P.n_march;
+  int m = 0;
+  while (m < SEED_MARCH_CAP - 7 && Wk.count < n_march) {
+    double ux = 0, uy = 0;
+    int taken = 0;
+#pragma unroll 1
+    for (int j = 0; j < 8 && Wk.count < n_march; j++) {
+      if (j == l8) { ux = Wk.x; uy = Wk.y; }
+      Wk.x += incx; Wk.y += incy; Wk.count++; taken++;
+    }
+    if (l8 < taken) {
+      double px, py;
+      world2cam(C.cam, ux, uy, 1.0, px, py);
+      px /= (double)(1 << sl); py /= (double)(1 << sl);
+      const int ox = (int)px, oy = (int)py;
+      const bool inside = ox >= 8 && ox < lim_x && oy >= 8 && oy < lim_y;
+      slots[m + l8].a = inside ? (float)px : __builtin_nanf(""); slots[m + l8].b = (float)py;
+    }
+    m += taken;
+  }
+  Wk.more = Wk.count < n_march;
+  return m;
+}
+
 // ---- the three kernels of an observation ---------------------------------------------------------------------------------
 // pre and post run one THREAD per seed (all 64 lanes of a wave busy with fp64 geometry; in round 3 they ran inside the image
 // kernel on the 4-16 lanes of a wave that owned a seed: ~440 wave-instructions per seed at 16 seeds per wave, ~110 now), the
@@ -652,13 +749,27 @@ static __global__ __launch_bounds__(256) void k_seed_pre(SeedConsts C, const See
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_seeds) return;
   const SeedDev& SD = seeds[i];
-  // a null reference: an erased slot of a resident table; a null active frame: the seed's group sits this call out
-  const bool live = SD.ref_base != nullptr && (SD.cur_base != nullptr || C.frames[SD.frame].cur_base != nullptr);
-  if (!live) { pre[i].state = 3; return; }
-  pre[i] = seed_pre(C, SD, C.frames[SD.frame]);
+  if (SD.ref_base == nullptr) { pre[i].state = 3; return; }   // an erased slot of a resident table
+  if (C.frame_keys) {
+    // previous-frame pass: the frame this seed's keyframe observes, if it is in the call (keys ascending)
+    const int64_t key = SD.s.ref_frame_id;
+    int lo = 0, hi = C.n_frame_keys;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (C.frame_keys[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo >= C.n_frame_keys || C.frame_keys[lo] != key || C.frames[lo].cur_base == nullptr) { pre[i].state = 3; return; }
+    SeedPre P = seed_pre_prev(C, SD, C.frames[lo]);
+    P.frame = lo;
+    pre[i] = P;
+    return;
+  }
+  // a null active frame: the seed's group sits this call out
+  if (SD.cur_base == nullptr && C.frames[SD.frame].cur_base == nullptr) { pre[i].state = 3; return; }
+  SeedPre P = seed_pre(C, SD, C.frames[SD.frame]);
+  P.frame = SD.frame;
+  pre[i] = P;
 }
 
 // three waves per SIMD: the lane-serial march step holds its 64 samples in registers (168 VGPRs); LDS 12.4 KB per wave
+template <bool PREV>
 static __global__ __launch_bounds__(64 * SEED_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_seed_image(SeedConsts C, const SeedDev* __restrict__ seeds, int n_seeds, const SeedPre* __restrict__ pre, SeedMid* __restrict__ mid)
 {
@@ -674,8 +785,8 @@ void k_seed_image(SeedConsts C, const SeedDev* __restrict__ seeds, int n_seeds, 
   const SeedPre& P = pre[sid];
   const SeedDev& SD = seeds[sid];
   // a group without a seed to observe stays: its lanes evaluate march steps of the other groups
-  const bool active = first + grp < n_seeds && P.state == 0;
-  const uint8_t* const cur_base = SD.cur_base ? SD.cur_base : C.frames[SD.frame].cur_base;
+  const bool active = first + grp < n_seeds && (P.state == 0 || (PREV && P.state == 4));
+  const uint8_t* const cur_base = (!PREV && SD.cur_base) ? SD.cur_base : C.frames[active ? P.frame : 0].cur_base;
   float* const pwb = s_pwb[wave][grp];
   float* const hd = s_hd[wave][grp];
   const int sl = active ? P.sl : 0;
@@ -688,14 +799,14 @@ void k_seed_image(SeedConsts C, const SeedDev* __restrict__ seeds, int n_seeds, 
 
   // ---- march along the epipolar line, ZMNCC per step (:906-960)
   MarchBest B;
-  B.best = 0.1f; B.second = 0.1f; B.i_best = -1; B.i_second = -1;
+  B.best = 0.1f; B.second = 0.1f; B.i_best = PREV ? 0 : -1; B.i_second = PREV ? 0 : -1;   // bestCounter / secondCounter start at 0 (:1168)
   MarchWalk Wk;
-  Wk.x = active ? P.pxf0 : 0.0; Wk.y = active ? P.pxf1 : 0.0; Wk.count = 0; Wk.more = active;
+  Wk.x = active ? P.pxf0 : 0.0; Wk.y = active ? P.pxf1 : 0.0; Wk.count = 0; Wk.more = active && P.state == 0;
   const int lim_x = C.g.w[0] / (1 << sl) - 8, lim_y = C.g.h[0] / (1 << sl) - 8;
   do {
     int m = 0;
     const int k_first = Wk.count;
-    if (Wk.more) m = g_march_list(P, Wk, lim_x, lim_y, s_slot[wave][grp], l8);
+    if (Wk.more) m = PREV ? g_march_list_prev(C, P, Wk, sl, lim_x, lim_y, s_slot[wave][grp], l8) : g_march_list(P, Wk, lim_x, lim_y, s_slot[wave][grp], l8);
     if (l8 == 0) s_grp[wave][grp].count = m;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -731,19 +842,34 @@ void k_seed_image(SeedConsts C, const SeedDev* __restrict__ seeds, int n_seeds, 
   M.px0 = M.px1 = 0; M.res_code = -4;
   M.n_steps = Wk.count; M.zmncc_best = B.best; M.zmncc_second = B.second;
   do {
-    const int dl = B.i_best - B.i_second;
-    if ((float)(dl < 0 ? -dl : dl) > 1.0f && 1.5f * B.second > B.best) break;
-    if (!((double)B.best > 0.8)) break;
-    // ---- refinement (:966-1046).  uv_best: the position of step i_best, by the additions that led there (zmncc_best > 0.8 >
-    // 0.1: a step was recorded)
-    double uvb0 = P.pxf0, uvb1 = P.pxf1;
-    {
-      const double incx = P.incx, incy = P.incy;
+    double ps0, ps1;
+    if (PREV && P.state == 4) {
+      M.zmncc_best = M.zmncc_second = 0;   // no march
+      ps0 = P.pxc0 / (double)(1 << sl); ps1 = P.pxc1 / (double)(1 << sl);
+    } else {
+      const int dl = B.i_best - B.i_second;
+      // doLineStereo: abs(loopCBest - loopCSecond) > 1 (:962).  findEpipolarMatchPrevious: fabs() of a size_t difference
+      // (:1219), which wraps: only "second == best" and "second == best - 1" count as adjacent
+      const bool apart = PREV ? !(dl == 0 || dl == 1) : (float)(dl < 0 ? -dl : dl) > 1.0f;
+      if (apart && 1.5f * B.second > B.best) break;
+      if (!((double)B.best > 0.8)) break;
+      // uv_best: the position of step i_best, by the additions that led there (zmncc_best > 0.8 > 0.1: a step was recorded)
+      double uvb0 = P.pxf0, uvb1 = P.pxf1;
+      {
+        const double incx = P.incx, incy = P.incy;
 #pragma unroll 1
-      for (int k = 0; k < B.i_best; k++) { uvb0 += incx; uvb1 += incy; }
+        for (int k = 0; k < B.i_best; k++) { uvb0 += incx; uvb1 += incy; }
+      }
+      if (PREV) {
+        double px, py;
+        world2cam(C.cam, uvb0, uvb1, 1.0, px, py);   // px_cur_ = world2cam(uv_best), :1226
+        ps0 = px / (double)(1 << sl); ps1 = py / (double)(1 << sl);
+      } else {
+        const double pxcur0 = uvb0 * (double)(1 << sl), pxcur1 = uvb1 * (double)(1 << sl);
+        ps0 = pxcur0 / (double)(1 << sl); ps1 = pxcur1 / (double)(1 << sl);
+      }
     }
-    const double pxcur0 = uvb0 * (double)(1 << sl), pxcur1 = uvb1 * (double)(1 << sl);
-    double ps0 = pxcur0 / (double)(1 << sl), ps1 = pxcur1 / (double)(1 << sl);
+    // ---- refinement (:966-1046 / :1102-1150, :1236-1290)
     if (!g_refine(C, cur_base, sl, SD.s.type, pwb, P.ed0, P.ed1, P.dc0, P.dc1, ps0, ps1, l8)) { M.res_code = -3; break; }
     M.px0 = ps0 * (double)(1 << sl); M.px1 = ps1 * (double)(1 << sl);
     M.res_code = 1;
@@ -764,8 +890,8 @@ static __global__ __launch_bounds__(256) void k_seed_post(SeedConsts C, SeedDev*
   }
   SeedMid M;
   memset(&M, 0, sizeof(M));
-  if (P.state == 0) M = mid[i];
-  const hso_seed_out o = seed_post(C, seeds[i], C.frames[seeds[i].frame], P, M);
+  if (P.state == 0 || P.state == 4) M = mid[i];
+  const hso_seed_out o = seed_post(C, seeds[i], C.frames[P.frame], P, M);
   seed_finish(C, seeds, i, outs, o, 0);
 }
 
@@ -785,7 +911,8 @@ static int seed_observe_launch(hso_gpu_ctx* ctx, const SeedConsts& C, SeedDev* s
   SeedMid* mid = reinterpret_cast<SeedMid*>(ctx->d_seed_scratch + al((size_t)n * sizeof(SeedPre)));
   const int per_block = 8 * SEED_WAVES_PER_BLOCK;
   hipLaunchKernelGGL(k_seed_pre, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, C, seeds, n, pre);
-  hipLaunchKernelGGL(k_seed_image, dim3((n + per_block - 1) / per_block), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, seeds, n, pre, mid);
+  if (C.frame_keys) hipLaunchKernelGGL(k_seed_image<true>, dim3((n + per_block - 1) / per_block), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, seeds, n, pre, mid);
+  else hipLaunchKernelGGL(k_seed_image<false>, dim3((n + per_block - 1) / per_block), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, seeds, n, pre, mid);
   hipLaunchKernelGGL(k_seed_post, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, C, seeds, n, pre, mid, outs);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
@@ -847,7 +974,7 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h, (size_t)n_seeds * sizeof(SeedDev), hipMemcpyHostToDevice, ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_fr, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
-  C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle; C.update_in_place = 0; C.brief = nullptr; C.px = nullptr;
+  C.cam = *cam; C.g = g; C.frames = d_fr; C.px_error_angle = px_error_angle; C.update_in_place = 0; C.brief = nullptr; C.px = nullptr; C.frame_keys = nullptr; C.n_frame_keys = 0;
   if (int rc = seed_observe_launch(ctx, C, d_in, n_seeds, d_out)) return rc;
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n_seeds * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -890,6 +1017,7 @@ struct SeedTable {
   hso_seed_out* d_full = nullptr; size_t full_cap = 0;
   float* d_px = nullptr; size_t px_cap = 0;
   SeedFrameDev* d_frames = nullptr; size_t frames_cap = 0;
+  int64_t* d_keys = nullptr; size_t keys_cap = 0;   // previous-frame pass: host keyframe ids, ascending
   PyrGeom g{}; bool have_g = false;
   int max_group = -1;
 };
@@ -899,7 +1027,7 @@ void hso_seed_tables_free(hso_gpu_ctx* ctx)
 {
   if (!ctx->seed_tables) return;
   for (SeedTable* t : ctx->seed_tables->t)
-    if (t) { (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); (void)hipFree(t->d_px); delete t; }
+    if (t) { (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); (void)hipFree(t->d_px); (void)hipFree(t->d_keys); delete t; }
   delete ctx->seed_tables;
   ctx->seed_tables = nullptr;
 }
@@ -1134,7 +1262,7 @@ static int seed_table_observe_impl(hso_gpu_ctx* ctx, const hso_camera* cam, int 
   memcpy(hfp, hf.data(), (size_t)n_frames * sizeof(SeedFrameDev));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, hfp, (size_t)n_frames * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
   SeedConsts C;
-  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = px_out ? t->d_px : nullptr;
+  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = px_out ? t->d_px : nullptr; C.frame_keys = nullptr; C.n_frame_keys = 0;
   const int n = (int)t->n;
   if (int rc = seed_observe_launch(ctx, C, t->d, n, full_out ? t->d_full : nullptr)) return rc;
   if (px_out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(px_out, t->d_px, 2 * t->n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1162,6 +1290,58 @@ int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* ctx, const hso_camera* cam, i
                                       double px_error_angle, hso_seed_brief* brief_out, float* px_out, hso_seed_out* full_out)
 {
   return seed_table_observe_impl(ctx, cam, table, frames, n_frames, px_error_angle, brief_out, px_out, full_out, true);
+}
+
+int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int64_t* host_frame_ids,
+                                        const hso_seed_frame* pre_frames, int n, double px_error_angle, hso_seed_brief* brief_out,
+                                        hso_seed_out* full_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || !cam || n < 0 || (n > 0 && (!host_frame_ids || !pre_frames))) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous: bad argument");
+  if (t->n == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (cam->width != t->g.w[0] || cam->height != t->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous: camera size differs from the frame size");
+  // the (keyframe, earlier frame) pairs sorted by keyframe id: the pre kernel finds a seed's entry by bisection
+  std::vector<int> order(n);
+  for (int k = 0; k < n; k++) order[k] = k;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return host_frame_ids[a] < host_frame_ids[b]; });
+  const size_t b_fr = ((size_t)std::max(n, 1) * sizeof(SeedFrameDev) + 255) & ~size_t(255);
+  char* stage = reinterpret_cast<char*>(hso_pinned(ctx, 0, b_fr + (size_t)std::max(n, 1) * sizeof(int64_t)));
+  if (!stage) return HSO_E_NOMEM;
+  SeedFrameDev* hf = reinterpret_cast<SeedFrameDev*>(stage);
+  int64_t* hk = reinterpret_cast<int64_t*>(stage + b_fr);
+  for (int k = 0; k < n; k++) {
+    const int src = order[k];
+    if (k > 0 && host_frame_ids[src] == hk[k - 1]) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous: a keyframe is listed twice");
+    auto itc = ctx->frames.find(pre_frames[src].frame_id);
+    if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_table_observe_previous: earlier frame not resident");
+    if (!same_geom(itc->second.g, t->g)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous: frames must share one size");
+    hk[k] = host_frame_ids[src];
+    hf[k].T_f_w = pre_frames[src].T_f_w; hf[k].exposure = pre_frames[src].exposure_time; hf[k].cur_base = itc->second.base;
+  }
+  if (int rc = grow_dev(ctx, &t->d_frames, &t->frames_cap, (size_t)std::max(n, 1), 0)) return rc;
+  if (int rc = grow_dev(ctx, &t->d_keys, &t->keys_cap, (size_t)std::max(n, 1), 0)) return rc;
+  if (int rc = grow_dev(ctx, &t->d_brief, &t->brief_cap, t->n, 0)) return rc;
+  if (full_out) if (int rc = grow_dev(ctx, &t->d_full, &t->full_cap, t->n, 0)) return rc;
+  if (n > 0) {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, hf, (size_t)n * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_keys, hk, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  SeedConsts C;
+  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = nullptr;
+  C.frame_keys = t->d_keys; C.n_frame_keys = n;
+  if (int rc = seed_observe_launch(ctx, C, t->d, (int)t->n, full_out ? t->d_full : nullptr)) return rc;
+  hso_seed_brief* hb = nullptr;
+  if (brief_out) {
+    hb = reinterpret_cast<hso_seed_brief*>(hso_pinned(ctx, 1, t->n * sizeof(hso_seed_brief)));
+    if (!hb) return HSO_E_NOMEM;
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(hb, t->d_brief, t->n * sizeof(hso_seed_brief), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (full_out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(full_out, t->d_full, t->n * sizeof(hso_seed_out), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (brief_out) memcpy(brief_out, hb, t->n * sizeof(hso_seed_brief));
+  return HSO_OK;
 }
 
 int hso_gpu_seed_table_set_host_pose(hso_gpu_ctx* ctx, int table, const int64_t* frame_ids, const hso_se3* T_f_w, int n)

@@ -613,6 +613,17 @@ int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int tabl
  * observation feeds to FeatureExtractor::setGridOccpuancy (src/depth_filter.cpp:669-673). */
 int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
                                       double px_error_angle, hso_seed_brief* brief_out, float* px_out, hso_seed_out* full_out);
+/* DepthFilter::observeDepthWithPreviousFrameOnce (reference src/depth_filter.cpp:677-726, called from the depth thread's idle loop,
+ * :254-263) with Matcher::findEpipolarMatchPrevious (src/matcher.cpp:1051-1293) over a resident table: every live seed hosted in
+ * keyframe host_frame_ids[k] observes the EARLIER frame pre_frames[k] (the first of Seed::pre_frames; the caller owns those lists,
+ * one per keyframe, and drops the entry afterwards whatever the outcome, :693-724); seeds of keyframes not named sit the call
+ * out.  mu / sigma2 are updated in place where the match succeeds; b is never touched.  Per slot (brief_out / full_out sized to
+ * the table, may be null): is_update = 1 when the earlier frame saw the point (it then joins Seed::optFrames_P, :702-703), result =
+ * 1 matched and updated, -1 epipolar-angle filter or > 100 steps, -4 march rejected, -3 refinement rejected, -2 triangulation; a
+ * slot not addressed reports zeros.  The frames must be resident. */
+int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int64_t* host_frame_ids,
+                                        const hso_seed_frame* pre_frames, int n, double px_error_angle, hso_seed_brief* brief_out,
+                                        hso_seed_out* full_out);
 /* Local BA moved keyframes (src/bundle_adjustment.cpp:826-834): refresh T_ref_w of every live seed hosted in one of these frames
  * (the reference reads seed.ftr->frame->T_f_w_ at every observation, src/depth_filter.cpp:588) */
 int hso_gpu_seed_table_set_host_pose(hso_gpu_ctx* ctx, int table, const int64_t* frame_ids, const hso_se3* T_f_w, int n);

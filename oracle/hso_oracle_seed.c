@@ -480,9 +480,11 @@ static int find_epipolar_match_previous(const hso_camera* cam, const hso_seed* s
   hso_or_pyramid_dims(w, h, search_level, &cols, &rows);
   double px_cur[2];
   if (!(epi_length < 2.0)) {
+    /* size_t n_steps = epi_length_ / 0.7; if (n_steps > options_.max_epi_search_steps (100, matcher.h:126)) return false.  A NaN
+     * length is undefined in that conversion; the reference's x86 build yields 2^63 (cvttsd2si) and rejects: said explicitly */
+    if (!(epi_length / 0.7 < 101.0)) return -1;
     size_t n_steps = epi_length / 0.7;
     const double step[2] = { epi_dir[0] / n_steps, epi_dir[1] / n_steps };
-    if (n_steps > 100) return -1;   /* options_.max_epi_search_steps, matcher.h:126 */
     const float hostMean = zmncc_host_mean(patch);
     float zmncc_best = 0.1f, zmncc_second = zmncc_best;
     size_t bestCounter = 0, secondCounter = 0;

@@ -433,6 +433,28 @@ def seed_observe(cam, seed, cur_T_f_w, cur_exposure, px_error_angle, ref_pyr, cu
     return out
 
 
+def seed_observe_previous(cam, seed, pre_T_f_w, pre_exposure, px_error_angle, ref_pyr, pre_pyr, pre_sobel):
+    """DepthFilter::observeDepthWithPreviousFrameOnce for one seed and one earlier frame, on host arrays."""
+    from hso_amd.capi import Seed, SeedOut
+    lib = load()
+    lib.hso_or_seed_observe_previous.argtypes = [C.POINTER(Camera), C.POINTER(Seed), C.POINTER(SE3), C.c_double, C.c_double,
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(SeedOut)]
+    lib.hso_or_seed_observe_previous.restype = None
+    rp = [np.ascontiguousarray(l) for l in ref_pyr]
+    cp = [np.ascontiguousarray(l) for l in pre_pyr]
+    gx = [np.ascontiguousarray(g[0]) for g in pre_sobel]
+    gy = [np.ascontiguousarray(g[1]) for g in pre_sobel]
+    h, w = rp[0].shape
+    out = SeedOut()
+    lib.hso_or_seed_observe_previous(C.byref(cam), C.byref(seed), C.byref(pre_T_f_w), pre_exposure, px_error_angle,
+                                     (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in rp]),
+                                     (C.c_void_p * N_PYR_LEVELS)(*[l.ctypes.data for l in cp]),
+                                     (C.c_void_p * 3)(*[g.ctypes.data for g in gx]),
+                                     (C.c_void_p * 3)(*[g.ctypes.data for g in gy]), w, h, C.byref(out))
+    return out
+
+
 def seed_activate(cam, seed, targets, ref_pyr, tgt_pyrs, tgt_sobels, n_mean_converge_frame=6):
     """DepthFilter::activatePoint for one seed.  targets: list of ActivateTarget; tgt_pyrs[i]: the
     5 levels of target i; tgt_sobels[i]: [(gx, gy)] * 3.  Returns (ActivateOut, [AlignOut])."""
