@@ -49,6 +49,7 @@ struct Settings {                 // src/config.cpp:28-64 and the Options struct
   int reproject_max_kfs = 10;     // Reprojector::Options::max_n_kfs
   float reproject_seed_thresh = 86;
   int seed_max_kfs = 3;           // DepthFilter::Options::max_n_kfs
+  bool previous_frame_pass = true;   // the depth thread's idle-time pass (src/depth_filter.cpp:254-263): one sweep per frame
   double map_scale = 1.0, init_min_disparity = 40.0;
   int init_min_tracked = 50, init_min_inliers = 40;
 };
@@ -101,7 +102,6 @@ struct Seed {
   Id temp = kNone;                // the temporary point made of it
   int32_t n_dist = 1;             // vec_distance.size()
   std::vector<Id> seen;           // optFrames_A: frames it was visible in (<= 15)
-  std::vector<Id> before;         // pre_frames: the frames before its keyframe, newest first
   std::vector<Id> seen_before;    // optFrames_P
 };
 
@@ -188,6 +188,7 @@ private:
   void apply_window(int k);
   void observe_seeds(const std::vector<int>& who);
   void activate_seeds(const std::vector<int>& who);
+  void observe_previous(const std::vector<int>& who);
   void start_seeds(const std::vector<int>& who);
   void kill_seed(Seq& s, StepData& d, int i, bool keep_feature);
   void erase_slots(const std::vector<int>& who);

@@ -138,6 +138,10 @@ struct Seq {
   std::vector<int> converge_hist;
   size_t n_mean_converge = 6;
   std::vector<std::pair<int, std::vector<Id>>> prior;   // frame_prior_: (batch, frames newest first), the last few batches
+  // Seed::pre_frames: every seed of a keyframe starts with the same list (src/depth_filter.cpp:186-192) and every sweep of the
+  // idle-time pass takes the first entry from all of them, so the list is kept once per keyframe (batch): frames newest first
+  struct PreList { Id host; int32_t batch; std::vector<Id> frames; };
+  std::vector<PreList> pre_lists;
   float converge_thresh = 200;
   double kf_depth_mean = 0, kf_depth_min = 0;
   TwoView init;
@@ -335,7 +339,7 @@ struct Seq {
   {
     frames.clear(); free_slots.clear(); feats.clear(); points.clear(); seeds.clear(); n_dead_seeds = 0;
     kfs.clear(); dev_kfs.clear(); candidates.clear(); temps.clear(); dirty_pts.clear(); dirty_obs.clear(); pt_flag.clear(); obs_flag.clear();
-    kfs_dirty = true; local_map.clear(); converge_hist.clear(); prior.clear(); init.clear(); hist_stamp.clear(); hist_pose.clear();
+    kfs_dirty = true; local_map.clear(); converge_hist.clear(); prior.clear(); pre_lists.clear(); init.clear(); hist_stamp.clear(); hist_pose.clear();
     last = cur = first = kNone;
   }
 };

@@ -182,9 +182,8 @@ void Bank::kill_seed(Seq& s, StepData& d, int i, bool keep_feature)
   sd.alive = false; s.n_dead_seeds++;
   if (sd.slot >= 0) d.erase_slots.push_back(sd.slot);
   for (Id fr : sd.seen) release_frame_deferred(s, d, fr);
-  for (Id fr : sd.before) release_frame_deferred(s, d, fr);
   for (Id fr : sd.seen_before) release_frame_deferred(s, d, fr);
-  sd.seen.clear(); sd.before.clear(); sd.seen_before.clear();
+  sd.seen.clear(); sd.seen_before.clear();
   (void)keep_feature;
 }
 
@@ -404,6 +403,85 @@ void Bank::activate_seeds(const std::vector<int>& who)
   erase_slots(who);
 }
 
+// The idle-time pass of the depth thread (src/depth_filter.cpp:254-263): while no frame is queued, every seed observes the first of
+// the frames that preceded its keyframe (observeDepthWithPreviousFrameOnce, :677-726).  The reference runs as much of a sweep as
+// fits before the next frame arrives; the device is always idle between frames, so here it is exactly ONE sweep per frame, over
+// all sequences in one call: per keyframe with a list left, its seeds observe the list's first frame, which is then dropped.
+void Bank::observe_previous(const std::vector<int>& who)
+{
+  if (!cfg_.previous_frame_pass) return;
+  std::vector<int64_t> hosts; std::vector<hso_seed_frame> pre;
+  bool tracing = false;
+  par(who, [&](int k) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    // a list whose keyframe has no live seed left goes with them
+    for (size_t i = 0; i < s.pre_lists.size();) {
+      Seq::PreList& L = s.pre_lists[i];
+      bool any = false;
+      for (const Seed& sd : s.seeds) if (sd.alive && sd.batch == L.batch) { any = true; break; }
+      if (any && !L.frames.empty()) { ++i; continue; }
+      for (Id fr : L.frames) release_frame_deferred(s, d, fr);
+      s.pre_lists.erase(s.pre_lists.begin() + (std::ptrdiff_t)i);
+    }
+  });
+  for (int k : who) {
+    const Seq& s = *seq_[k];
+    for (const Seq::PreList& L : s.pre_lists) {
+      const Frame& F = s.frames[L.frames.front()];
+      hso_seed_frame f{};
+      f.frame_id = F.dev_id; f.T_f_w = F.T.v; f.exposure_time = F.exposure;
+      hosts.push_back(s.frames[L.host].dev_id); pre.push_back(f);
+    }
+    tracing |= s.trace.on();
+  }
+  if (!hosts.empty()) {
+    int n_slots = 0, n_live = 0;
+    check(hso_gpu_seed_table_size(ctx_, seed_table_, &n_slots, &n_live), "DepthFilter");
+    seed_brief_.need(ctx_, (size_t)std::max(n_slots, 1));
+    std::vector<hso_seed> before; std::vector<hso_seed_out> full;
+    if (tracing) {
+      before.resize((size_t)n_slots); full.resize((size_t)n_slots);
+      check(hso_gpu_seed_table_read(ctx_, seed_table_, 0, n_slots, before.data()), "DepthFilter");
+    }
+    check(hso_gpu_seed_table_observe_previous(ctx_, &cam_.pod(), seed_table_, hosts.data(), pre.data(), (int)hosts.size(), px_error_angle_,
+                                              seed_brief_.data(), tracing ? full.data() : nullptr), "DepthFilter::observeDepthWithPreviousFrameOnce");
+    n_calls_[9]++; n_items_[9] += (int64_t)who.size();
+    par(who, [&](int k) {
+      Seq& s = *seq_[k];
+      for (const Seq::PreList& L : s.pre_lists) {
+        const Id fr = L.frames.front();
+        if (s.trace.on()) {
+          const Frame& F = s.frames[fr];
+          std::vector<hso_seed> in; std::vector<hso_seed_out> out;
+          for (const Seed& sd : s.seeds) if (sd.alive && sd.batch == L.batch && sd.slot >= 0 && sd.slot < n_slots) { in.push_back(before[sd.slot]); out.push_back(full[sd.slot]); }
+          Trace& t = s.trace;
+          t.begin("seed_observe_previous", 7);
+          t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.scalar("pre_frame_id", (double)F.dev_id); t.field("T_f_w", &F.T.v, sizeof(hso_se3));
+          t.scalar("exposure", F.exposure); t.scalar("px_error_angle", px_error_angle_);
+          t.field("seeds", in.data(), sizeof(hso_seed) * in.size()); t.field("out", out.data(), sizeof(hso_seed_out) * out.size());
+        }
+        for (Seed& sd : s.seeds) {
+          if (!sd.alive || sd.batch != L.batch || sd.slot < 0 || sd.slot >= n_slots) continue;
+          const hso_seed_brief& o = seed_brief_.data()[sd.slot];
+          if (!o.is_update) continue;
+          if (sd.seen_before.size() < 15) { sd.seen_before.push_back(fr); s.hold(fr); }   // optFrames_P (:702-703)
+          if (o.result == 1) { sd.mu = o.mu; sd.sigma2 = o.sigma2; }                      // updateSeed (:721)
+        }
+      }
+    });
+  }
+  par(who, [&](int k) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    for (Seq::PreList& L : s.pre_lists) {                          // pre_frames.erase(begin()) on every path (:693-724)
+      release_frame_deferred(s, d, L.frames.front());
+      L.frames.erase(L.frames.begin());
+    }
+  });
+  erase_slots(who);
+}
+
 // FeatureExtractor::detect (src/feature_detection.cpp:408-497) for one new keyframe per sequence: candidates on the device (batched
 // per detection threshold), the oct-tree distribution on the host; sel[i] receives the selected keys of who[i]
 void Bank::detect(const std::vector<int>& who, const std::vector<Id>& frame, const std::vector<int>& thresh, bool init, int n_levels, int n_features,
@@ -551,9 +629,12 @@ void Bank::start_seeds(const std::vector<int>& who)
       sd.mu = (float)(1.0 / (float)s.kf_depth_mean); sd.z_range = (float)(1.0 / (float)s.kf_depth_min);   // Seed::Seed, :49-68
       sd.sigma2 = sd.z_range * sd.z_range / 36;
       sd.converge = s.converge_thresh;
-      if (before) { sd.before = *before; for (Id fr : sd.before) s.hold(fr); }
       s.seeds.push_back(sd);
       d.new_seeds.push_back(seed_record(s, s.seeds.back()));
+    }
+    if (before && !before->empty() && !sel[i].empty() && cfg_.previous_frame_pass) {   // Seed::pre_frames (:186-192)
+      s.pre_lists.push_back(Seq::PreList{s.cur, s.batch, *before});
+      for (Id fr : *before) s.hold(fr);
     }
   });
   std::vector<hso_seed> rows; std::vector<int32_t> group;

@@ -83,6 +83,7 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
         ck.lap(6);
       }
       if (!kf.empty()) start_seeds(kf);
+      if (!ok.empty()) observe_previous(ok);
       ck.lap(7);
       n_kf_events_ += (int64_t)kf.size();
     }

@@ -401,6 +401,30 @@ int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* c, const hso_camera* cam, int
   return HSO_OK;
 }
 
+int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* c, const hso_camera* cam, int t, const int64_t* host_ids, const hso_seed_frame* pre, int n,
+                                        double px_error_angle, hso_seed_brief* brief, hso_seed_out* full)
+{
+  FakeSeedTable* T = c->tables[t];
+  for (size_t i = 0; i < T->s.size(); i++) {
+    if (brief) memset(&brief[i], 0, sizeof(hso_seed_brief));
+    if (full) memset(&full[i], 0, sizeof(hso_seed_out));
+    if (!T->alive[i]) continue;
+    int k = 0;
+    while (k < n && host_ids[k] != T->s[i].ref_frame_id) k++;
+    if (k == n) continue;
+    FakeFrame* C = frame_of(c, pre[k].frame_id); FakeFrame* R = frame_of(c, T->s[i].ref_frame_id);
+    if (!C || !R) return fail(c, HSO_E_NOFRAME, "seed_table_observe_previous: frame not resident");
+    hso_seed_out o;
+    memset(&o, 0, sizeof(o));
+    hso_or_seed_observe_previous(cam, &T->s[i], &pre[k].T_f_w, pre[k].exposure_time, px_error_angle, R->pyr, C->pyr, C->sx, C->sy, C->w, C->h, &o);
+    T->s[i].mu = o.mu; T->s[i].sigma2 = o.sigma2;
+    if (brief) { brief[i].mu = o.mu; brief[i].sigma2 = o.sigma2; brief[i].b = o.b; brief[i].result = (int8_t)o.result; brief[i].is_update = (int8_t)o.is_update;
+                 brief[i].is_valid = (int8_t)o.is_valid; brief[i].search_level = (int8_t)o.search_level; }
+    if (full) full[i] = o;
+  }
+  return HSO_OK;
+}
+
 static int activate_one(hso_gpu_ctx* c, const hso_camera* cam, const hso_seed* s, const hso_activate_target* tg, int n_tg, int n_mean, hso_activate_out* o,
                         hso_align_out* mo)
 {

@@ -286,6 +286,55 @@ class Replayer:
             else:
                 assert g.mu == o.mu and g.sigma2 == o.sigma2 and g.b == o.b
 
+    def seed_observe_previous(self, r):
+        """observeDepthWithPreviousFrameOnce: the seeds of one keyframe against the earlier frame they observed (tests/test_seed.py's rules:
+        the march is bit-equal, codes differ only at the refinement's gates, excused by margin; b is never touched)"""
+        cam = capi.Camera.from_buffer_copy(r["cam"])
+        seeds, n = _arr(capi.Seed, r["seeds"]); got, _ = _arr(capi.SeedOut, r["out"])
+        pre = self.frame(vo.scalar(r, "pre_frame_id")); T = capi.SE3.from_buffer_copy(r["T_f_w"])
+        kz = 30.0 if (cam.model == capi.CAM_PINHOLE and cam.distortion) else 1.0
+        kz_dec = 5.0 if kz > 1 else 1.0
+        for i in range(n):
+            s, g = seeds[i], got[i]
+            self.orc.margins_reset()
+            o = self.orc.seed_observe_previous(cam, s, T, vo.scalar(r, "exposure"), vo.scalar(r, "px_error_angle"), self.frame(s.ref_frame_id)["pyr"],
+                                               pre["pyr"], pre["sobel"])
+            mg = self.orc.margins()
+            self.bump("seed_previous", "n")
+            assert g.is_update == o.is_update and g.b == s.b
+            if o.is_update == 0:
+                assert g.result == 0 and g.mu == s.mu and g.sigma2 == s.sigma2
+                continue
+            assert g.search_level == o.search_level and g.n_steps == o.n_steps
+            if o.result == -1 or g.result == -1:
+                assert g.result == o.result
+                continue
+            assert g.zmncc_best == o.zmncc_best and g.zmncc_second == o.zmncc_second
+            if g.result != o.result:
+                assert {g.result, o.result} == {1, -3}, (i, g.result, o.result)
+                assert min(mg.klt_energy / 1e-2, mg.klt_accept / 1e-2, mg.klt_step / 1e-1, mg.ncc / 1e-3, mg.normal / 1e-3) < kz_dec
+                self.bump("seed_previous", "tie")
+                continue
+            if o.result == 1:
+                assert np.allclose(list(g.px_cur), list(o.px_cur), atol=2e-3 * (1 << g.search_level), rtol=0)
+                T_cur_ref = self.orc.se3_mul(T, self.orc.se3_inverse(s.T_ref_w))
+                fc = self.orc.cam2world(cam, g.px_cur[0], g.px_cur[1])
+                a0 = self.orc.so3_matrix(np.array(T_cur_ref.q[:])) @ np.array(s.f[:]); a1 = fc
+                m00, m01, m11 = a0 @ a0, a0 @ a1, a1 @ a1
+                inv = 1.0 / (m00 * m11 - m01 * m01)
+                z_at_g = abs(((-m11 * inv) * a0 + (m01 * inv) * a1) @ np.array(T_cur_ref.t[:]))
+                assert g.z == pytest.approx(z_at_g, rel=1e-5 * kz)
+                T_ref_cur = self.orc.se3_mul(s.T_ref_w, self.orc.se3_inverse(T))
+                f3 = np.array(s.f[:], float)
+                tau = self.tau(C.byref(T_ref_cur), f3.ctypes.data, g.z, vo.scalar(r, "px_error_angle"))
+                tau_inverse = 0.5 * (1.0 / max(0.0000001, g.z - tau) - 1.0 / (g.z + tau))
+                mu, sigma2 = C.c_float(s.mu), C.c_float(s.sigma2)
+                self.upd(1. / g.z, tau_inverse * tau_inverse, C.byref(mu), C.byref(sigma2))
+                assert g.mu == pytest.approx(mu.value, rel=1e-5) and g.sigma2 == pytest.approx(sigma2.value, rel=1e-4)
+                self.bump("seed_previous", "updated")
+            else:
+                assert g.mu == s.mu and g.sigma2 == s.sigma2
+
     def seed_activate(self, r):
         cam = capi.Camera.from_buffer_copy(r["cam"])
         seeds, n = _arr(capi.Seed, r["seeds"]); got, _ = _arr(capi.ActivateOut, r["out"])

@@ -66,6 +66,7 @@ def test_chain_stage_by_stage(orc, tmp_path, name, spec, n_frames, max_fts):
     # left here are sanity bounds on the replay itself — that it compared enough — not tie allowances
     assert s["reproject"]["success"] >= 0.8 * s["reproject"]["matched_calls"]
     assert s["seed"]["updated"] > 0.3 * s["seed"]["n"]
+    assert s["seed_previous"]["n"] > 0.2 * s["seed"]["n"] and s["seed_previous"]["updated"] > 0.2 * s["seed_previous"]["n"]   # the idle-time pass
     assert s["activate"]["n"] > 20 and s["detect"]["octree"] >= n_kf - 1 and s["detect"]["octree_selected"] > 50
 
 

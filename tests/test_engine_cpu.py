@@ -60,18 +60,20 @@ def test_sequence_and_replay(fake, small_seq, orc, tmp_path):
     # the restatement replays itself: no decision may differ
     assert "iter_mismatch" not in s["track"] and "tie" not in s["reproject"] and "tie" not in s.get("seed", {}) and "tie" not in s.get("activate", {})
     assert s["seed"]["updated"] > 0.3 * s["seed"]["n"] and s["activate"]["n"] > 20 and s["detect"]["octree"] == len(kfs) + 1
+    # the idle-time pass (observeDepthWithPreviousFrameOnce) ran: one sweep per frame while a keyframe's list of earlier frames lasts
+    assert s["seed_previous"]["n"] > 500 and s["seed_previous"]["updated"] > 0.3 * s["seed_previous"]["n"] and "tie" not in s["seed_previous"]
 
 
 def test_bank_of_sequences_equals_solo_runs(fake, small_seq):
     """three sequences of different lengths in one bank (one sits steps out) = each alone, status record by status record"""
     S = small_seq
     other = synth.sequence(22, spec=SMALL, seed=2031, workers=4, step=(0.04, 0.02, 0.015), rot_deg_per_frame=(0.08, -0.2, 0.1))
-    runs = [(S, 26), (other, 22), (S, 14)]
-    solo = [_run(fake, s, n, 100) for s, n in runs]
-    bank = vo.MultiVisualOdometry(synth.camera(SMALL), 3, 100, lib=fake)
+    runs = [(S, 15), (other, 13), (S, 8)]
+    solo = [_run(fake, s, n, 80) for s, n in runs]
+    bank = vo.MultiVisualOdometry(synth.camera(SMALL), 3, 80, lib=fake)
     bank.set_first_frames([s["images"][0] for s, _ in runs], [s["depth0"] for s, _ in runs])
     got = [[] for _ in runs]
-    for k in range(1, 26):
+    for k in range(1, 15):
         imgs = [s["images"][k] if k < n else None for s, n in runs]
         bank.add_images(imgs, [float(k)] * 3)
         for i, (s, n) in enumerate(runs):
