@@ -278,8 +278,8 @@ def main():
     ap.add_argument("--min-level", type=int, default=1, help="developer knob: stop the tracker above level 1 (the judged line uses 1)")
     ap.add_argument("--cpu-frames", type=int, default=400, help="frames in the cpu_baseline sample (about 7 s on one host core)")
     ap.add_argument("--seq-frames", type=int, default=24, help="frames per sequence of the end-to-end runs through libhso_host.so (0 = skip)")
-    ap.add_argument("--sequences", type=int, default=128, help="sequences per engine (bank) of the end-to-end run (hso_vo_multi_*; 0 = skip)")
-    ap.add_argument("--banks", type=int, default=2, help="engines per GPU, each on its own host thread and stream")
+    ap.add_argument("--sequences", type=int, default=96, help="sequences per engine (bank) of the end-to-end run (hso_vo_multi_*; 0 = skip)")
+    ap.add_argument("--banks", type=int, default=3, help="engines per GPU, each on its own host thread and stream")
     ap.add_argument("--seq-feats", type=int, default=2000, help="Config::maxFts() of the end-to-end run")
     ap.add_argument("--seq-distinct", type=int, default=8, help="distinct rendered sequences per rank (replicated to --sequences x --banks)")
     ap.add_argument("--single", type=int, default=1, help="0: skip the single-sequence latency section (N = 1 only)")

@@ -348,6 +348,8 @@ def load():
     lib.hso_gpu_seed_table_observe.argtypes = [vp, P(Camera), i32, P(SeedFrame), i32, C.c_double, vp, vp]
     lib.hso_gpu_seed_table_read.argtypes = [vp, i32, i32, i32, vp]
     lib.hso_gpu_seed_table_observe_previous.argtypes = [vp, P(Camera), i32, vp, P(SeedFrame), i32, C.c_double, vp, vp]
+    lib.hso_gpu_seed_table_observe_previous_begin.argtypes = [vp, P(Camera), i32, vp, P(SeedFrame), i32, C.c_double]
+    lib.hso_gpu_seed_table_observe_previous_end.argtypes = [vp, i32, vp, i32]
     lib.hso_gpu_map_reserve.argtypes = [vp, i32, i32, i32, i32]
     lib.hso_gpu_map_store.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32]
     lib.hso_gpu_reproject_match_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32]
@@ -384,7 +386,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level", "hso_gpu_host_alloc", "hso_gpu_host_free", "hso_gpu_seed_table_compact",
     "hso_gpu_seqmap_create", "hso_gpu_seqmap_destroy", "hso_gpu_seqmap_set_keyframes", "hso_gpu_seqmap_patch", "hso_gpu_seqmap_patch_multi", "hso_gpu_seqmap_size", "hso_gpu_seqmap_read",
     "hso_gpu_reproject_select_pose_frames", "hso_gpu_debug_fetch", "hso_gpu_seed_table_observe_groups", "hso_gpu_seed_table_set_host_pose",
-    "hso_gpu_seed_table_observe_previous",
+    "hso_gpu_seed_table_observe_previous", "hso_gpu_seed_table_observe_previous_begin", "hso_gpu_seed_table_observe_previous_end",
 ]
 
 
@@ -787,6 +789,20 @@ class Context:
         self._check(self.lib.hso_gpu_seed_table_observe_previous(self.h, C.byref(cam), table, _ptr(ids), fr, n, px_error_angle, _ptr(brief),
                                                                  C.cast(full, C.c_void_p) if want_full else None), "seed_table_observe_previous")
         return brief, full
+
+    def seed_table_observe_previous_begin(self, cam, table, pairs, px_error_angle):
+        """the same pass queued on the depth filter's stream; collect with seed_table_observe_previous_end"""
+        n = len(pairs)
+        ids = np.ascontiguousarray([p[0] for p in pairs], np.int64)
+        fr = (SeedFrame * max(n, 1))()
+        for k, (_, (fid, T, expo)) in enumerate(pairs):
+            fr[k].frame_id, fr[k].T_f_w, fr[k].exposure_time = fid, T, expo
+        self._check(self.lib.hso_gpu_seed_table_observe_previous_begin(self.h, C.byref(cam), table, _ptr(ids), fr, n, px_error_angle), "seed_table_observe_previous_begin")
+
+    def seed_table_observe_previous_end(self, table, n_slots):
+        brief = np.zeros(max(n_slots, 1), SEED_BRIEF_DTYPE)
+        self._check(self.lib.hso_gpu_seed_table_observe_previous_end(self.h, table, _ptr(brief), len(brief)), "seed_table_observe_previous_end")
+        return brief[:n_slots]
 
     def seed_table_compact(self, table):
         """-> (new number of slots, remap[old slot] = new slot or -1)"""

@@ -60,6 +60,14 @@ struct hso_gpu_ctx {
   char* d_batch; size_t batch_cap;
   // between the three kernels of a seed observation (hso_seed.hip): [SeedPre | SeedMid] per seed, grow-only
   char* d_seed_scratch; size_t seed_scratch_cap;
+  // The depth filter's own stream (the reference runs it on its own thread, src/depth_filter.cpp:130-162): the previous-frame pass
+  // of a seed table can be started on it and collected later (hso_gpu_seed_table_observe_previous_begin / _end), overlapping the
+  // tracker's work on `stream`.  While a pass is in flight, every entry point that touches seed tables or releases a frame waits
+  // for it first (hso_seed_async_quiesce).
+  hipStream_t seed_stream; hipEvent_t seed_go, seed_done;
+  bool seed_inflight; int seed_inflight_table; size_t seed_inflight_n;
+  char* d_seed_scratch_async; size_t seed_scratch_async_cap;
+  char* h_seed_pin; size_t h_seed_pin_cap, h_seed_brief_off;
   // pinned host staging (grow-only): record tables go through it so the DMA runs at PCIe rate
   // instead of the pageable-memory rate, and the per-call std::vector + page faults disappear
   char* h_pin[2]; size_t h_pin_cap[2];
@@ -121,6 +129,7 @@ int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases,
 int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh);
 void hso_track_state_free(hso_gpu_ctx* ctx);
 void hso_seed_tables_free(hso_gpu_ctx* ctx);
+int hso_seed_async_quiesce(hso_gpu_ctx* ctx);   // wait for a previous-frame pass in flight (its results stay collectable)
 bool hso_seed_tables_pin(hso_gpu_ctx* ctx, int64_t frame_id);   // a resident seed table hosts live seeds in this frame
 void hso_map_arena_free(hso_gpu_ctx* ctx);
 void hso_seqmaps_free(hso_gpu_ctx* ctx);

@@ -226,6 +226,10 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   ctx->free_w = ctx->free_h = 0;
   ctx->d_batch = nullptr;
   ctx->d_seed_scratch = nullptr; ctx->seed_scratch_cap = 0;
+  ctx->seed_stream = nullptr; ctx->seed_go = nullptr; ctx->seed_done = nullptr;
+  ctx->seed_inflight = false; ctx->seed_inflight_table = -1; ctx->seed_inflight_n = 0;
+  ctx->d_seed_scratch_async = nullptr; ctx->seed_scratch_async_cap = 0;
+  ctx->h_seed_pin = nullptr; ctx->h_seed_pin_cap = 0; ctx->h_seed_brief_off = 0;
   ctx->batch_cap = 0;
   ctx->h_pin[0] = ctx->h_pin[1] = nullptr;
   ctx->h_pin_cap[0] = ctx->h_pin_cap[1] = 0;
@@ -261,6 +265,11 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   for (auto* p : ctx->frame_slabs) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
   if (ctx->d_seed_scratch) (void)hipFree(ctx->d_seed_scratch);
+  if (ctx->seed_stream) { (void)hipStreamSynchronize(ctx->seed_stream); (void)hipStreamDestroy(ctx->seed_stream); }
+  if (ctx->seed_go) (void)hipEventDestroy(ctx->seed_go);
+  if (ctx->seed_done) (void)hipEventDestroy(ctx->seed_done);
+  if (ctx->d_seed_scratch_async) (void)hipFree(ctx->d_seed_scratch_async);
+  if (ctx->h_seed_pin) (void)hipHostFree(ctx->h_seed_pin);
   for (int k = 0; k < 2; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
   for (void* p : ctx->host_allocs) (void)hipHostFree(p);
   hso_stream_forget(ctx->stream);
@@ -309,6 +318,7 @@ int hso_gpu_host_free(hso_gpu_ctx* ctx, void* p)
 int hso_gpu_synchronize(hso_gpu_ctx* ctx)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return HSO_OK;
 }
@@ -457,6 +467,7 @@ int hso_gpu_frame_release(hso_gpu_ctx* ctx, int64_t frame_id)
   if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "frame_release: frame not resident");
   if (hso_seed_tables_pin(ctx, frame_id))
     return hso_fail(ctx, HSO_E_INVALID, "frame_release: live seeds of a resident seed table are hosted in this frame (erase them or destroy the table first)");
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;   // a pass in flight may be reading this frame
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   hso_frame_free(ctx, it->second.g, it->second.base);
   ctx->frames.erase(it);

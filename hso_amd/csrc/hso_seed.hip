@@ -895,26 +895,40 @@ static __global__ __launch_bounds__(256) void k_seed_post(SeedConsts C, SeedDev*
   seed_finish(C, seeds, i, outs, o, 0);
 }
 
-// one observation of `n` seed records on the context's stream
-static int seed_observe_launch(hso_gpu_ctx* ctx, const SeedConsts& C, SeedDev* seeds, int n, hso_seed_out* outs)
+// one observation of `n` seed records on `stream` (the context's, or the depth filter's own), through the scratch buffer given
+static int seed_observe_launch_on(hso_gpu_ctx* ctx, hipStream_t stream, char** scratch, size_t* scratch_cap, const SeedConsts& C, SeedDev* seeds, int n,
+                                  hso_seed_out* outs)
 {
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t need = al((size_t)n * sizeof(SeedPre)) + al((size_t)n * sizeof(SeedMid));
-  if (ctx->seed_scratch_cap < need) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_seed_scratch) (void)hipFree(ctx->d_seed_scratch);
-    ctx->d_seed_scratch = nullptr; ctx->seed_scratch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_seed_scratch), hso_grown(need)));
-    ctx->seed_scratch_cap = hso_grown(need);
+  if (*scratch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(stream));
+    if (*scratch) (void)hipFree(*scratch);
+    *scratch = nullptr; *scratch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(scratch), hso_grown(need)));
+    *scratch_cap = hso_grown(need);
   }
-  SeedPre* pre = reinterpret_cast<SeedPre*>(ctx->d_seed_scratch);
-  SeedMid* mid = reinterpret_cast<SeedMid*>(ctx->d_seed_scratch + al((size_t)n * sizeof(SeedPre)));
+  SeedPre* pre = reinterpret_cast<SeedPre*>(*scratch);
+  SeedMid* mid = reinterpret_cast<SeedMid*>(*scratch + al((size_t)n * sizeof(SeedPre)));
   const int per_block = 8 * SEED_WAVES_PER_BLOCK;
-  hipLaunchKernelGGL(k_seed_pre, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, C, seeds, n, pre);
-  if (C.frame_keys) hipLaunchKernelGGL(k_seed_image<true>, dim3((n + per_block - 1) / per_block), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, seeds, n, pre, mid);
-  else hipLaunchKernelGGL(k_seed_image<false>, dim3((n + per_block - 1) / per_block), dim3(64 * SEED_WAVES_PER_BLOCK), 0, ctx->stream, C, seeds, n, pre, mid);
-  hipLaunchKernelGGL(k_seed_post, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, C, seeds, n, pre, mid, outs);
+  hipLaunchKernelGGL(k_seed_pre, dim3((n + 255) / 256), dim3(256), 0, stream, C, seeds, n, pre);
+  if (C.frame_keys) hipLaunchKernelGGL(k_seed_image<true>, dim3((n + per_block - 1) / per_block), dim3(64 * SEED_WAVES_PER_BLOCK), 0, stream, C, seeds, n, pre, mid);
+  else hipLaunchKernelGGL(k_seed_image<false>, dim3((n + per_block - 1) / per_block), dim3(64 * SEED_WAVES_PER_BLOCK), 0, stream, C, seeds, n, pre, mid);
+  hipLaunchKernelGGL(k_seed_post, dim3((n + 255) / 256), dim3(256), 0, stream, C, seeds, n, pre, mid, outs);
   HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
+}
+static int seed_observe_launch(hso_gpu_ctx* ctx, const SeedConsts& C, SeedDev* seeds, int n, hso_seed_out* outs)
+{
+  return seed_observe_launch_on(ctx, ctx->stream, &ctx->d_seed_scratch, &ctx->seed_scratch_cap, C, seeds, n, outs);
+}
+
+// A previous-frame pass in flight on the depth filter's stream: wait for it (its briefs stay in page-locked memory until
+// hso_gpu_seed_table_observe_previous_end collects them).  Called by everything that touches seed tables or releases frames.
+int hso_seed_async_quiesce(hso_gpu_ctx* ctx)
+{
+  if (!ctx->seed_inflight || !ctx->seed_stream) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->seed_stream));
   return HSO_OK;
 }
 
@@ -923,6 +937,7 @@ extern "C" int hso_gpu_seed_observe_multi(hso_gpu_ctx* ctx, const hso_camera* ca
                                           hso_seed_out* out)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   if (!cam || n_frames < 0 || n_seeds < 0 || (n_seeds > 0 && (!seeds || !out || !frames || !seed_frame || n_frames == 0)))
     return hso_fail(ctx, HSO_E_INVALID, "seed_observe: bad argument");
   if (n_seeds == 0) return HSO_OK;
@@ -1080,6 +1095,7 @@ int hso_gpu_seed_table_create(hso_gpu_ctx* ctx, int* table_out)
 int hso_gpu_seed_table_destroy(hso_gpu_ctx* ctx, int table)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   SeedTable* t = seed_table_of(ctx, table);
   if (!t) return hso_fail(ctx, HSO_E_INVALID, "seed_table: no such table");
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1092,6 +1108,7 @@ int hso_gpu_seed_table_destroy(hso_gpu_ctx* ctx, int table)
 int hso_gpu_seed_table_append(hso_gpu_ctx* ctx, int table, const hso_seed* seeds, const int32_t* group, int n, int32_t* first_slot)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   SeedTable* t = seed_table_of(ctx, table);
   if (!t || n < 0 || (n > 0 && !seeds)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_append: bad argument");
   if (first_slot) *first_slot = (int32_t)t->n;
@@ -1127,6 +1144,7 @@ int hso_gpu_seed_table_append(hso_gpu_ctx* ctx, int table, const hso_seed* seeds
 int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, int n)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   SeedTable* t = seed_table_of(ctx, table);
   if (!t || n < 0 || (n > 0 && !slots)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_erase: bad argument");
   for (int i = 0; i < n; i++)
@@ -1186,6 +1204,7 @@ extern "C" {
 int hso_gpu_seed_table_compact(hso_gpu_ctx* ctx, int table, int32_t* remap)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   SeedTable* t = seed_table_of(ctx, table);
   if (!t) return hso_fail(ctx, HSO_E_INVALID, "seed_table_compact: no such table");
   std::vector<int> idx;
@@ -1239,6 +1258,7 @@ static int seed_table_observe_impl(hso_gpu_ctx* ctx, const hso_camera* cam, int 
                                    double px_error_angle, hso_seed_brief* brief_out, float* px_out, hso_seed_out* full_out, bool allow_skip)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   SeedTable* t = seed_table_of(ctx, table);
   if (!t || !cam || !frames || n_frames <= 0) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe: bad argument");
   if (t->n == 0) return HSO_OK;
@@ -1292,23 +1312,15 @@ int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* ctx, const hso_camera* cam, i
   return seed_table_observe_impl(ctx, cam, table, frames, n_frames, px_error_angle, brief_out, px_out, full_out, true);
 }
 
-int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int64_t* host_frame_ids,
-                                        const hso_seed_frame* pre_frames, int n, double px_error_angle, hso_seed_brief* brief_out,
-                                        hso_seed_out* full_out)
+// the arguments of a previous-frame pass checked and staged: (keyframe, earlier frame) pairs sorted by keyframe id — the pre kernel
+// finds a seed's entry by bisection — into `stage` (page-locked): [SeedFrameDev x n | int64 x n]
+static int seed_previous_stage(hso_gpu_ctx* ctx, SeedTable* t, const hso_camera* cam, const int64_t* host_frame_ids, const hso_seed_frame* pre_frames, int n,
+                               char* stage, size_t b_fr)
 {
-  if (!ctx) return HSO_E_INVALID;
-  SeedTable* t = seed_table_of(ctx, table);
-  if (!t || !cam || n < 0 || (n > 0 && (!host_frame_ids || !pre_frames))) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous: bad argument");
-  if (t->n == 0) return HSO_OK;
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (cam->width != t->g.w[0] || cam->height != t->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous: camera size differs from the frame size");
-  // the (keyframe, earlier frame) pairs sorted by keyframe id: the pre kernel finds a seed's entry by bisection
   std::vector<int> order(n);
   for (int k = 0; k < n; k++) order[k] = k;
   std::sort(order.begin(), order.end(), [&](int a, int b) { return host_frame_ids[a] < host_frame_ids[b]; });
-  const size_t b_fr = ((size_t)std::max(n, 1) * sizeof(SeedFrameDev) + 255) & ~size_t(255);
-  char* stage = reinterpret_cast<char*>(hso_pinned(ctx, 0, b_fr + (size_t)std::max(n, 1) * sizeof(int64_t)));
-  if (!stage) return HSO_E_NOMEM;
   SeedFrameDev* hf = reinterpret_cast<SeedFrameDev*>(stage);
   int64_t* hk = reinterpret_cast<int64_t*>(stage + b_fr);
   for (int k = 0; k < n; k++) {
@@ -1320,13 +1332,31 @@ int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* ctx, const hso_camera* cam,
     hk[k] = host_frame_ids[src];
     hf[k].T_f_w = pre_frames[src].T_f_w; hf[k].exposure = pre_frames[src].exposure_time; hf[k].cur_base = itc->second.base;
   }
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int64_t* host_frame_ids,
+                                        const hso_seed_frame* pre_frames, int n, double px_error_angle, hso_seed_brief* brief_out,
+                                        hso_seed_out* full_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
+  if (ctx->seed_inflight) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous: a pass started with _begin has not been collected");
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || !cam || n < 0 || (n > 0 && (!host_frame_ids || !pre_frames))) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous: bad argument");
+  if (t->n == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t b_fr = ((size_t)std::max(n, 1) * sizeof(SeedFrameDev) + 255) & ~size_t(255);
+  char* stage = reinterpret_cast<char*>(hso_pinned(ctx, 0, b_fr + (size_t)std::max(n, 1) * sizeof(int64_t)));
+  if (!stage) return HSO_E_NOMEM;
+  if (int rc = seed_previous_stage(ctx, t, cam, host_frame_ids, pre_frames, n, stage, b_fr)) return rc;
   if (int rc = grow_dev(ctx, &t->d_frames, &t->frames_cap, (size_t)std::max(n, 1), 0)) return rc;
   if (int rc = grow_dev(ctx, &t->d_keys, &t->keys_cap, (size_t)std::max(n, 1), 0)) return rc;
   if (int rc = grow_dev(ctx, &t->d_brief, &t->brief_cap, t->n, 0)) return rc;
   if (full_out) if (int rc = grow_dev(ctx, &t->d_full, &t->full_cap, t->n, 0)) return rc;
   if (n > 0) {
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, hf, (size_t)n * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_keys, hk, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, stage, (size_t)n * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_keys, stage + b_fr, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
   }
   SeedConsts C;
   C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = nullptr;
@@ -1344,9 +1374,80 @@ int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* ctx, const hso_camera* cam,
   return HSO_OK;
 }
 
+int hso_gpu_seed_table_observe_previous_begin(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int64_t* host_frame_ids,
+                                              const hso_seed_frame* pre_frames, int n, double px_error_angle)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (ctx->seed_inflight) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous_begin: the previous pass has not been collected");
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || !cam || n < 0 || (n > 0 && (!host_frame_ids || !pre_frames))) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous_begin: bad argument");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->seed_stream) {
+    HSO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->seed_stream, hipStreamNonBlocking));
+    HSO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->seed_go, hipEventDisableTiming));
+    HSO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->seed_done, hipEventDisableTiming));
+  }
+  ctx->seed_inflight_table = table; ctx->seed_inflight_n = t->n;
+  if (t->n == 0) { ctx->seed_inflight = true; return HSO_OK; }   // nothing to launch; _end reports nothing
+  // page-locked staging of its own (the context's slots are reused by the calls that overlap this pass): [frames | keys | briefs]
+  const size_t b_fr = ((size_t)std::max(n, 1) * sizeof(SeedFrameDev) + 255) & ~size_t(255);
+  const size_t b_key = ((size_t)std::max(n, 1) * sizeof(int64_t) + 255) & ~size_t(255);
+  const size_t need = b_fr + b_key + t->n * sizeof(hso_seed_brief);
+  if (ctx->h_seed_pin_cap < need) {
+    if (ctx->h_seed_pin) (void)hipHostFree(ctx->h_seed_pin);
+    ctx->h_seed_pin = nullptr; ctx->h_seed_pin_cap = 0;
+    HSO_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_seed_pin), hso_grown(need), hipHostMallocDefault));
+    ctx->h_seed_pin_cap = hso_grown(need);
+  }
+  if (int rc = seed_previous_stage(ctx, t, cam, host_frame_ids, pre_frames, n, ctx->h_seed_pin, b_fr)) return rc;
+  if (int rc = grow_dev(ctx, &t->d_frames, &t->frames_cap, (size_t)std::max(n, 1), 0)) return rc;
+  if (int rc = grow_dev(ctx, &t->d_keys, &t->keys_cap, (size_t)std::max(n, 1), 0)) return rc;
+  if (int rc = grow_dev(ctx, &t->d_brief, &t->brief_cap, t->n, 0)) return rc;
+  // everything queued on the context's stream so far (appends, erases, pose updates of this table, uploads of the frames) first
+  HSO_HIP_CHECK(ctx, hipEventRecord(ctx->seed_go, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->seed_stream, ctx->seed_go, 0));
+  if (n > 0) {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, ctx->h_seed_pin, (size_t)n * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->seed_stream));
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_keys, ctx->h_seed_pin + b_fr, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->seed_stream));
+  }
+  SeedConsts C;
+  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = nullptr;
+  C.frame_keys = t->d_keys; C.n_frame_keys = n;
+  if (int rc = seed_observe_launch_on(ctx, ctx->seed_stream, &ctx->d_seed_scratch_async, &ctx->seed_scratch_async_cap, C, t->d, (int)t->n, nullptr)) return rc;
+  ctx->h_seed_brief_off = b_fr + b_key;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_seed_pin + b_fr + b_key, t->d_brief, t->n * sizeof(hso_seed_brief), hipMemcpyDeviceToHost, ctx->seed_stream));
+  HSO_HIP_CHECK(ctx, hipEventRecord(ctx->seed_done, ctx->seed_stream));
+  ctx->seed_inflight = true;
+  return HSO_OK;
+}
+
+int hso_gpu_seed_table_observe_previous_end(hso_gpu_ctx* ctx, int table, hso_seed_brief* brief_out, int n_brief)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!ctx->seed_inflight) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous_end: no pass in flight");
+  if (table != ctx->seed_inflight_table) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous_end: the pass in flight is another table's");
+  if (brief_out && (size_t)n_brief < ctx->seed_inflight_n) return hso_fail(ctx, HSO_E_INVALID, "seed_table_observe_previous_end: brief_out is smaller than the table was at _begin");
+  const size_t n = ctx->seed_inflight_n;
+  if (n > 0) {
+    HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HSO_HIP_CHECK(ctx, hipEventSynchronize(ctx->seed_done));
+    // the context's stream continues behind the pass (the table's records changed)
+    HSO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->seed_done, 0));
+    if (brief_out) {
+      // the briefs sit behind the staged frames and keys: their offsets are those _begin used for this pass
+      SeedTable* t = seed_table_of(ctx, table);
+      (void)t;
+      memcpy(brief_out, ctx->h_seed_pin + ctx->h_seed_brief_off, n * sizeof(hso_seed_brief));
+    }
+  }
+  ctx->seed_inflight = false;
+  return HSO_OK;
+}
+
 int hso_gpu_seed_table_set_host_pose(hso_gpu_ctx* ctx, int table, const int64_t* frame_ids, const hso_se3* T_f_w, int n)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   SeedTable* t = seed_table_of(ctx, table);
   if (!t || n < 0 || (n > 0 && (!frame_ids || !T_f_w))) return hso_fail(ctx, HSO_E_INVALID, "seed_table_set_host_pose: bad argument");
   if (n == 0 || t->n == 0) return HSO_OK;
@@ -1372,6 +1473,7 @@ int hso_gpu_seed_table_set_host_pose(hso_gpu_ctx* ctx, int table, const int64_t*
 int hso_gpu_seed_table_read(hso_gpu_ctx* ctx, int table, int first, int n, hso_seed* seeds_out)
 {
   if (!ctx) return HSO_E_INVALID;
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
   SeedTable* t = seed_table_of(ctx, table);
   if (!t || first < 0 || n < 0 || (size_t)first + (size_t)n > t->n || (n > 0 && !seeds_out)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_read: bad argument");
   if (n == 0) return HSO_OK;

@@ -29,6 +29,8 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
   grid_rows_ = (int)std::ceil((double)cam.height / cell_size_);
   cell_order_.resize((size_t)grid_cols_ * grid_rows_);
   std::iota(cell_order_.begin(), cell_order_.end(), 0);
+  sync_previous_ = getenv("HSO_ENGINE_SYNC_PREVIOUS") != nullptr;
+  if (getenv("HSO_ENGINE_NO_PREVIOUS")) cfg_.previous_frame_pass = false;   // measurement aid: the step without the idle-time pass
   px_error_angle_ = std::atan(1.0 / (2.0 * cam_.errorMultiplier2())) * 2.0;   // one pixel of noise (src/depth_filter.cpp:360-366)
   for (int k = 0; k < n_sequences; k++) {
     Seq* s = new Seq();

@@ -188,7 +188,8 @@ private:
   void apply_window(int k);
   void observe_seeds(const std::vector<int>& who);
   void activate_seeds(const std::vector<int>& who);
-  void observe_previous(const std::vector<int>& who);
+  void previous_begin(const std::vector<int>& who);
+  void previous_collect();
   void start_seeds(const std::vector<int>& who);
   void kill_seed(Seq& s, StepData& d, int i, bool keep_feature);
   void erase_slots(const std::vector<int>& who);
@@ -215,6 +216,10 @@ private:
   std::vector<int32_t> cell_order_;
   double px_error_angle_ = -1;
   int64_t n_calls_[10] = {0}, n_items_[10] = {0};
+  // the previous-frame pass between previous_begin and previous_collect
+  struct PendingPrev { bool on = false, async = false; std::vector<int> who; std::vector<size_t> n_lists; int n_slots = 0;
+                       std::vector<hso_seed> before; std::vector<hso_seed_out> full; } pending_prev_;
+  bool sync_previous_ = false;     // HSO_ENGINE_SYNC_PREVIOUS=1: the pass runs inside the step (tests compare both modes)
   std::vector<int64_t> to_release_;
   double phase_ms_[9] = {0};
   int64_t n_steps_ = 0, n_kf_events_ = 0;

@@ -11,6 +11,7 @@ namespace engine {
 // ------------------------------------------------------------------------------------------------ first keyframe with depths
 void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const double* stamps, const float* const* depth_z, const hso_se3* T_f_w)
 {
+  previous_collect();
   if (w != cam_.width() || h != cam_.height())
     throw std::invalid_argument("Frame: provided image has not the same size as the camera model or image is not grayscale");
   std::vector<int> who;
@@ -104,6 +105,7 @@ bool inside(const AbstractCamera& cam, int x, int y, int margin) { return x >= m
 
 void Bank::initialise(const std::vector<int>& who)
 {
+  previous_collect();
   std::vector<int> first, second;
   for (int k : who) (seq_[k]->stage == kFirst ? first : second).push_back(k);
   if (!first.empty()) {

@@ -63,6 +63,7 @@ void Bank::assemble_window(int k)
 
 void Bank::keyframe_ba(const std::vector<int>& who)
 {
+  previous_collect();                                              // the keyframes' new poses go to the seed table below
   std::vector<int> with;
   for (int k : who) if (!step_[k]->ba_edges.empty() && !step_[k]->ba_points.empty()) with.push_back(k);
   const double fmean = cam_.errorMultiplier2();
@@ -196,6 +197,7 @@ void Bank::release_frame_deferred(Seq& s, StepData& d, Id fr)
 
 void Bank::drop_sequence_seeds(int k)
 {
+  previous_collect();
   Seq& s = *seq_[k];
   std::vector<int32_t> slots;
   for (Seed& sd : s.seeds) if (sd.alive && sd.slot >= 0) slots.push_back(sd.slot);
@@ -207,6 +209,7 @@ void Bank::drop_sequence_seeds(int k)
 // observation, ONE observation of every live seed in its sequence's frame, the bookkeeping after it
 void Bank::observe_seeds(const std::vector<int>& who)
 {
+  previous_collect();
   par(who, [&](int k) {
     Seq& s = *seq_[k];
     StepData& d = *step_[k];
@@ -407,9 +410,12 @@ void Bank::activate_seeds(const std::vector<int>& who)
 // the frames that preceded its keyframe (observeDepthWithPreviousFrameOnce, :677-726).  The reference runs as much of a sweep as
 // fits before the next frame arrives; the device is always idle between frames, so here it is exactly ONE sweep per frame, over
 // all sequences in one call: per keyframe with a list left, its seeds observe the list's first frame, which is then dropped.
-void Bank::observe_previous(const std::vector<int>& who)
+// Like the reference's depth thread the sweep runs BESIDE the tracker: previous_begin queues it on the depth filter's stream at the
+// end of a step, the next step's upload / tracking / reprojection / pose overlap it, and previous_collect — called before the first
+// thing that reads or changes seeds — applies its results.  The results do not depend on when they are collected.
+void Bank::previous_begin(const std::vector<int>& who)
 {
-  if (!cfg_.previous_frame_pass) return;
+  if (!cfg_.previous_frame_pass || pending_prev_.on) return;
   std::vector<int64_t> hosts; std::vector<hso_seed_frame> pre;
   bool tracing = false;
   par(who, [&](int k) {
@@ -425,57 +431,82 @@ void Bank::observe_previous(const std::vector<int>& who)
       s.pre_lists.erase(s.pre_lists.begin() + (std::ptrdiff_t)i);
     }
   });
+  erase_slots(who);                                                // moves the frames dropped above to the release list
+  pending_prev_.who.clear(); pending_prev_.n_lists.clear();
   for (int k : who) {
     const Seq& s = *seq_[k];
+    if (s.pre_lists.empty()) continue;
     for (const Seq::PreList& L : s.pre_lists) {
       const Frame& F = s.frames[L.frames.front()];
       hso_seed_frame f{};
       f.frame_id = F.dev_id; f.T_f_w = F.T.v; f.exposure_time = F.exposure;
       hosts.push_back(s.frames[L.host].dev_id); pre.push_back(f);
     }
+    pending_prev_.who.push_back(k); pending_prev_.n_lists.push_back(s.pre_lists.size());
     tracing |= s.trace.on();
   }
-  if (!hosts.empty()) {
-    int n_slots = 0, n_live = 0;
-    check(hso_gpu_seed_table_size(ctx_, seed_table_, &n_slots, &n_live), "DepthFilter");
+  if (hosts.empty()) return;
+  int n_slots = 0, n_live = 0;
+  check(hso_gpu_seed_table_size(ctx_, seed_table_, &n_slots, &n_live), "DepthFilter");
+  pending_prev_.n_slots = n_slots;
+  pending_prev_.before.clear(); pending_prev_.full.clear();
+  if (tracing || sync_previous_) {
+    // recorded runs (and HSO_ENGINE_SYNC_PREVIOUS=1) take the synchronous call: the trace wants the records before and the full results
     seed_brief_.need(ctx_, (size_t)std::max(n_slots, 1));
-    std::vector<hso_seed> before; std::vector<hso_seed_out> full;
     if (tracing) {
-      before.resize((size_t)n_slots); full.resize((size_t)n_slots);
-      check(hso_gpu_seed_table_read(ctx_, seed_table_, 0, n_slots, before.data()), "DepthFilter");
+      pending_prev_.before.resize((size_t)n_slots); pending_prev_.full.resize((size_t)n_slots);
+      check(hso_gpu_seed_table_read(ctx_, seed_table_, 0, n_slots, pending_prev_.before.data()), "DepthFilter");
     }
     check(hso_gpu_seed_table_observe_previous(ctx_, &cam_.pod(), seed_table_, hosts.data(), pre.data(), (int)hosts.size(), px_error_angle_,
-                                              seed_brief_.data(), tracing ? full.data() : nullptr), "DepthFilter::observeDepthWithPreviousFrameOnce");
-    n_calls_[9]++; n_items_[9] += (int64_t)who.size();
-    par(who, [&](int k) {
-      Seq& s = *seq_[k];
-      for (const Seq::PreList& L : s.pre_lists) {
-        const Id fr = L.frames.front();
-        if (s.trace.on()) {
-          const Frame& F = s.frames[fr];
-          std::vector<hso_seed> in; std::vector<hso_seed_out> out;
-          for (const Seed& sd : s.seeds) if (sd.alive && sd.batch == L.batch && sd.slot >= 0 && sd.slot < n_slots) { in.push_back(before[sd.slot]); out.push_back(full[sd.slot]); }
-          Trace& t = s.trace;
-          t.begin("seed_observe_previous", 7);
-          t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.scalar("pre_frame_id", (double)F.dev_id); t.field("T_f_w", &F.T.v, sizeof(hso_se3));
-          t.scalar("exposure", F.exposure); t.scalar("px_error_angle", px_error_angle_);
-          t.field("seeds", in.data(), sizeof(hso_seed) * in.size()); t.field("out", out.data(), sizeof(hso_seed_out) * out.size());
-        }
-        for (Seed& sd : s.seeds) {
-          if (!sd.alive || sd.batch != L.batch || sd.slot < 0 || sd.slot >= n_slots) continue;
-          const hso_seed_brief& o = seed_brief_.data()[sd.slot];
-          if (!o.is_update) continue;
-          if (sd.seen_before.size() < 15) { sd.seen_before.push_back(fr); s.hold(fr); }   // optFrames_P (:702-703)
-          if (o.result == 1) { sd.mu = o.mu; sd.sigma2 = o.sigma2; }                      // updateSeed (:721)
-        }
-      }
-    });
+                                              seed_brief_.data(), tracing ? pending_prev_.full.data() : nullptr), "DepthFilter::observeDepthWithPreviousFrameOnce");
+    pending_prev_.async = false;
+  } else {
+    check(hso_gpu_seed_table_observe_previous_begin(ctx_, &cam_.pod(), seed_table_, hosts.data(), pre.data(), (int)hosts.size(), px_error_angle_),
+          "DepthFilter::observeDepthWithPreviousFrameOnce");
+    pending_prev_.async = true;
   }
-  par(who, [&](int k) {
+  n_calls_[9]++; n_items_[9] += (int64_t)pending_prev_.who.size();
+  pending_prev_.on = true;
+  if (!pending_prev_.async) previous_collect();                    // nothing to overlap: apply at once
+}
+
+void Bank::previous_collect()
+{
+  if (!pending_prev_.on) return;
+  pending_prev_.on = false;
+  const int n_slots = pending_prev_.n_slots;
+  if (pending_prev_.async) {
+    seed_brief_.need(ctx_, (size_t)std::max(n_slots, 1));
+    check(hso_gpu_seed_table_observe_previous_end(ctx_, seed_table_, seed_brief_.data(), std::max(n_slots, 1)), "DepthFilter::observeDepthWithPreviousFrameOnce");
+  }
+  const std::vector<int>& who = pending_prev_.who;
+  pool_->run((int)who.size(), [&](int w) {
+    const int k = who[(size_t)w];
     Seq& s = *seq_[k];
     StepData& d = *step_[k];
-    for (Seq::PreList& L : s.pre_lists) {                          // pre_frames.erase(begin()) on every path (:693-724)
-      release_frame_deferred(s, d, L.frames.front());
+    const size_t n_lists = std::min(pending_prev_.n_lists[(size_t)w], s.pre_lists.size());
+    for (size_t li = 0; li < n_lists; li++) {
+      Seq::PreList& L = s.pre_lists[li];
+      const Id fr = L.frames.front();
+      if (s.trace.on() && !pending_prev_.full.empty()) {
+        const Frame& F = s.frames[fr];
+        std::vector<hso_seed> in; std::vector<hso_seed_out> out;
+        for (const Seed& sd : s.seeds)
+          if (sd.alive && sd.batch == L.batch && sd.slot >= 0 && sd.slot < n_slots) { in.push_back(pending_prev_.before[sd.slot]); out.push_back(pending_prev_.full[sd.slot]); }
+        Trace& t = s.trace;
+        t.begin("seed_observe_previous", 7);
+        t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.scalar("pre_frame_id", (double)F.dev_id); t.field("T_f_w", &F.T.v, sizeof(hso_se3));
+        t.scalar("exposure", F.exposure); t.scalar("px_error_angle", px_error_angle_);
+        t.field("seeds", in.data(), sizeof(hso_seed) * in.size()); t.field("out", out.data(), sizeof(hso_seed_out) * out.size());
+      }
+      for (Seed& sd : s.seeds) {
+        if (!sd.alive || sd.batch != L.batch || sd.slot < 0 || sd.slot >= n_slots) continue;
+        const hso_seed_brief& o = seed_brief_.data()[sd.slot];
+        if (!o.is_update) continue;
+        if (sd.seen_before.size() < 15) { sd.seen_before.push_back(fr); s.hold(fr); }   // optFrames_P (:702-703)
+        if (o.result == 1) { sd.mu = o.mu; sd.sigma2 = o.sigma2; }                      // updateSeed (:721)
+      }
+      release_frame_deferred(s, d, fr);                              // pre_frames.erase(begin()) on every path (:693-724)
       L.frames.erase(L.frames.begin());
     }
   });
@@ -654,6 +685,7 @@ void Bank::start_seeds(const std::vector<int>& who)
 // temporary point observed in this frame.  The frame's feature list changes, so its pose is optimised again, value-passing.
 void Bank::seed_branch(const std::vector<int>& who)
 {
+  previous_collect();
   std::vector<int> again;
   for (int k : who) {
     Seq& s = *seq_[k];

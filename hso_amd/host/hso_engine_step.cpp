@@ -83,7 +83,6 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
         ck.lap(6);
       }
       if (!kf.empty()) start_seeds(kf);
-      if (!ok.empty()) observe_previous(ok);
       ck.lap(7);
       n_kf_events_ += (int64_t)kf.size();
     }
@@ -92,6 +91,12 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
   finish(who);
   for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
   to_release_.clear();
+  // the depth filter's idle-time sweep over the sequences that stepped, beside the next step's tracking
+  {
+    std::vector<int> swept;
+    for (int k : who) if (seq_[k]->stage == kRunning && step_[k]->ok) swept.push_back(k);
+    if (!swept.empty()) previous_begin(swept);
+  }
   ck.lap(8);
   n_steps_++;
 }

@@ -624,6 +624,15 @@ int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* ctx, const hso_camera* cam, i
 int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int64_t* host_frame_ids,
                                         const hso_seed_frame* pre_frames, int n, double px_error_angle, hso_seed_brief* brief_out,
                                         hso_seed_out* full_out);
+/* The same pass on the depth filter's own stream, overlapped with whatever the caller issues next on the context's stream (the
+ * reference runs the depth filter on its own thread beside the tracker, src/depth_filter.cpp:130-162): _begin queues the pass behind
+ * everything already issued and returns at once; _end waits for it and delivers the briefs (brief_out: n_brief >= the table's size at
+ * _begin, or NULL).  One pass in flight per context.  Until _end the caller must not rely on the table's contents; the library itself
+ * waits for the pass before any other seed-table entry point, hso_gpu_frame_release and hso_gpu_synchronize proceed, so nothing it
+ * reads can be changed or freed under it.  Results are those of hso_gpu_seed_table_observe_previous. */
+int hso_gpu_seed_table_observe_previous_begin(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int64_t* host_frame_ids,
+                                              const hso_seed_frame* pre_frames, int n, double px_error_angle);
+int hso_gpu_seed_table_observe_previous_end(hso_gpu_ctx* ctx, int table, hso_seed_brief* brief_out, int n_brief);
 /* Local BA moved keyframes (src/bundle_adjustment.cpp:826-834): refresh T_ref_w of every live seed hosted in one of these frames
  * (the reference reads seed.ftr->frame->T_f_w_ at every observation, src/depth_filter.cpp:588) */
 int hso_gpu_seed_table_set_host_pose(hso_gpu_ctx* ctx, int table, const int64_t* frame_ids, const hso_se3* T_f_w, int n);

@@ -34,6 +34,7 @@ struct hso_gpu_ctx {
   // hso_gpu_debug_fetch
   std::vector<hso_reproj_point> dbg_proj; std::vector<hso_align_out> dbg_match; std::vector<hso_pose_feat> dbg_feats;
   std::vector<hso_se3> dbg_poses; std::vector<int32_t> dbg_nposes;
+  std::vector<hso_seed_brief> prev_briefs; int prev_table = -1;   // hso_gpu_seed_table_observe_previous_begin / _end
 };
 
 static int fail(hso_gpu_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
@@ -422,6 +423,24 @@ int hso_gpu_seed_table_observe_previous(hso_gpu_ctx* c, const hso_camera* cam, i
                  brief[i].is_valid = (int8_t)o.is_valid; brief[i].search_level = (int8_t)o.search_level; }
     if (full) full[i] = o;
   }
+  return HSO_OK;
+}
+
+// the overlapped form: the fake has nothing to overlap, _begin runs the pass and keeps the briefs for _end
+int hso_gpu_seed_table_observe_previous_begin(hso_gpu_ctx* c, const hso_camera* cam, int t, const int64_t* host_ids, const hso_seed_frame* pre, int n,
+                                              double px_error_angle)
+{
+  FakeSeedTable* T = c->tables[t];
+  c->prev_briefs.assign(T->s.size() + 1, hso_seed_brief{});
+  c->prev_table = t;
+  return hso_gpu_seed_table_observe_previous(c, cam, t, host_ids, pre, n, px_error_angle, c->prev_briefs.data(), nullptr);
+}
+int hso_gpu_seed_table_observe_previous_end(hso_gpu_ctx* c, int t, hso_seed_brief* brief, int n_brief)
+{
+  if (c->prev_table != t) return fail(c, HSO_E_INVALID, "seed_table_observe_previous_end: no pass in flight for this table");
+  const size_t n = c->prev_briefs.size() - 1;
+  if (brief) { if ((size_t)n_brief < n) return fail(c, HSO_E_INVALID, "seed_table_observe_previous_end: brief_out too small"); memcpy(brief, c->prev_briefs.data(), n * sizeof(hso_seed_brief)); }
+  c->prev_table = -1;
   return HSO_OK;
 }
 

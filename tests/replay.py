@@ -309,10 +309,20 @@ class Replayer:
             if o.result == -1 or g.result == -1:
                 assert g.result == o.result
                 continue
-            assert g.zmncc_best == o.zmncc_best and g.zmncc_second == o.zmncc_second
+            if kz == 1.0:
+                assert g.zmncc_best == o.zmncc_best and g.zmncc_second == o.zmncc_second     # the same host patch: bit-equal march
+            elif o.n_steps > 0 and o.zmncc_best > 0.1:
+                # radtan: the warp matrix goes through cam2world's fp32 undistortion iterations, which host and device round differently
+                # (see seed_observe above): the host patch differs at the 1e-6 level and the scores with it
+                assert g.zmncc_best == pytest.approx(o.zmncc_best, abs=1e-4)
             if g.result != o.result:
-                assert {g.result, o.result} == {1, -3}, (i, g.result, o.result)
-                assert min(mg.klt_energy / 1e-2, mg.klt_accept / 1e-2, mg.klt_step / 1e-1, mg.ncc / 1e-3, mg.normal / 1e-3) < kz_dec
+                codes = {g.result, o.result}
+                near = False
+                if kz > 1.0 and (codes == {-3, -4} or codes == {1, -4}):
+                    near = min(mg.zmncc_best, mg.zmncc_ambig, mg.zmncc_order) < 1e-3
+                if codes == {1, -3}:
+                    near = min(mg.klt_energy / 1e-2, mg.klt_accept / 1e-2, mg.klt_step / 1e-1, mg.ncc / 1e-3, mg.normal / 1e-3) < kz_dec
+                assert near, (i, g.result, o.result, [getattr(mg, f) for f in self.orc.MARGIN_FIELDS])
                 self.bump("seed_previous", "tie")
                 continue
             if o.result == 1:

@@ -92,3 +92,30 @@ def test_two_sequences_started_from_images_equal_their_single_runs():
             assert a == b, "sequence %d frame %d differs from its solo run" % (q, k)
     init_at = [next(k for k, b in enumerate(got[q]) if vo.VoStatus.from_buffer_copy(b).stage == 3) for q in range(2)]
     assert init_at[0] != init_at[1] and stages[0] == [3, 3], (init_at, stages)
+
+
+def test_depth_filter_stream_gives_the_results_of_the_synchronous_pass(monkeypatch):
+    """The idle-time pass of the depth filter (observeDepthWithPreviousFrameOnce) runs on its own stream beside the next frame's
+    tracking and is collected before the first thing that reads seeds: every status record and keyframe equals the run in which
+    the pass executes inside the step (HSO_ENGINE_SYNC_PREVIOUS=1), bit for bit."""
+    spec = synth.EUROC
+    cam = synth.camera(spec)
+    seqs = [synth.sequence(30, spec=spec, seed=3300 + 11 * k, step=(0.018 + 0.002 * k, 0.005, 0.006)) for k in range(3)]
+
+    def run():
+        multi = vo.MultiVisualOdometry(cam, len(seqs), 300)
+        multi.set_first_frames([S["images"][0] for S in seqs], [S["depth0"] for S in seqs])
+        got = []
+        for k in range(1, 30):
+            multi.add_images([S["images"][k] for S in seqs], [float(k)] * len(seqs))
+            got.append([_status_bytes(multi.status(q)) for q in range(len(seqs))])
+        kfs = [[(ts, bytes(T), fid) for ts, T, fid in multi.keyframes(q)] for q in range(len(seqs))]
+        counts = multi.call_counts()
+        multi.close()
+        return got, kfs, counts
+
+    overlapped, kfs_o, counts = run()
+    monkeypatch.setenv("HSO_ENGINE_SYNC_PREVIOUS", "1")
+    inside, kfs_i, _ = run()
+    assert overlapped == inside and kfs_o == kfs_i
+    assert all(len(k) >= 2 for k in kfs_o) and counts["other"][0] > 10        # the pass ran (it is counted with the other calls)

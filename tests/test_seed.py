@@ -276,3 +276,30 @@ def test_seed_table_observe_previous_matches_oracle(orc, cam, gpu_ctx, seed_scen
         else:
             assert g.mu == s.mu and g.sigma2 == s.sigma2 and after[k].mu == s.mu
     assert n_ok > 80 and n_short >= 5, (n_ok, n_flag, n_short)
+
+
+@pytest.mark.gpu
+def test_previous_pass_on_the_depth_filter_stream_equals_the_synchronous_call(cam, gpu_ctx, seed_scene):
+    """_begin / _end: the briefs and the table afterwards equal the synchronous call's; table calls and frame releases issued while
+    the pass is in flight wait for it (nothing it reads is changed under it); a second _begin before _end is refused."""
+    d, rp, cp, sob, seeds, T_cur, feats = seed_scene
+    for s in seeds:
+        s.ref_frame_id = 9101
+    gpu_ctx.frame_upload(9101, d["ref"]); gpu_ctx.frame_upload(9102, d["cur"]); gpu_ctx.frame_upload(9103, d["cur"])
+    ta, tb = gpu_ctx.seed_table_create(), gpu_ctx.seed_table_create()
+    try:
+        gpu_ctx.seed_table_append(ta, seeds); gpu_ctx.seed_table_append(tb, seeds)
+        pairs = [(9101, (9102, T_cur, 1.05))]
+        want, _ = gpu_ctx.seed_table_observe_previous(cam, ta, pairs, PX_ERROR_ANGLE)
+        gpu_ctx.seed_table_observe_previous_begin(cam, tb, pairs, PX_ERROR_ANGLE)
+        with pytest.raises(capi.HsoGpuError):
+            gpu_ctx.seed_table_observe_previous_begin(cam, tb, pairs, PX_ERROR_ANGLE)
+        gpu_ctx.frame_release(9103)                      # waits for the pass, then frees
+        mid = gpu_ctx.seed_table_read(tb, 0, len(seeds))  # waits too: sees the finished pass
+        got = gpu_ctx.seed_table_observe_previous_end(tb, len(seeds))
+        a, b = gpu_ctx.seed_table_read(ta, 0, len(seeds)), gpu_ctx.seed_table_read(tb, 0, len(seeds))
+    finally:
+        gpu_ctx.seed_table_destroy(ta); gpu_ctx.seed_table_destroy(tb)
+        gpu_ctx.frame_release(9101); gpu_ctx.frame_release(9102)
+    assert got.tobytes() == want.tobytes() and (want["result"] == 1).sum() > 50
+    assert bytes(a) == bytes(b) == bytes(mid)
