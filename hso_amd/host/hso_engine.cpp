@@ -56,6 +56,9 @@ Bank::~Bank()
             "local BA %.3f, seed observe %.3f, seed activate %.3f, new seeds %.3f, flush+finish %.3f\n", (long long)n_steps_, size(), (long long)n_kf_events_,
             phase_ms_[0] / n_steps_, phase_ms_[1] / n_steps_, phase_ms_[2] / n_steps_, phase_ms_[3] / n_steps_, phase_ms_[4] / n_steps_, phase_ms_[5] / n_steps_,
             phase_ms_[6] / n_steps_, phase_ms_[7] / n_steps_, phase_ms_[8] / n_steps_);
+  if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0)
+    fprintf(stderr, "[hso engine] reproject+select+pose = list points + patch maps %.3f, device call %.3f, apply %.3f\n", sub_ms_[0] / n_steps_, sub_ms_[1] / n_steps_,
+            sub_ms_[2] / n_steps_);
   delete pool_;
   for (Seq* s : seq_) {
     for (Frame& F : s->frames) if (F.in_use && F.dev_id >= 0) (void)hso_gpu_frame_release(ctx_, F.dev_id);

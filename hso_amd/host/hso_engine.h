@@ -216,6 +216,7 @@ private:
   std::vector<int32_t> cell_order_;
   double px_error_angle_ = -1;
   int64_t n_calls_[10] = {0}, n_items_[10] = {0};
+  double sub_ms_[4] = {0};         // HSO_ENGINE_TIMING: reproject() split into listing / device call / applying
   // the previous-frame pass between previous_begin and previous_collect
   struct PendingPrev { bool on = false, async = false; std::vector<int> who; std::vector<size_t> n_lists; int n_slots = 0;
                        std::vector<hso_seed> before; std::vector<hso_seed_out> full; } pending_prev_;

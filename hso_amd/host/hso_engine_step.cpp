@@ -380,8 +380,12 @@ void Bank::apply_selection(int k, const hso_match_brief* rec, int n_rec, const u
 
 void Bank::reproject(const std::vector<int>& who)
 {
+  const bool timing = getenv("HSO_ENGINE_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t0 = now();
   par(who, [&](int k) { list_points(k); });
   flush_maps(who);                                                // rows the listing touched (temporary points' positions) and earlier changes
+  if (timing) { sub_ms_[0] += std::chrono::duration<double, std::milli>(now() - t0).count(); t0 = now(); }
   const int n = (int)who.size(), cap = std::max(cfg_.max_fts, 1);
   std::vector<hso_map_frame> calls(n);
   size_t total = 0;
@@ -399,6 +403,7 @@ void Bank::reproject(const std::vector<int>& who)
   const int rc = hso_gpu_reproject_select_pose_frames(ctx_, &cam_.pod(), calls.data(), n, cell_size_, grid_cols_, cell_order_.data(), (int)cell_order_.size(),
                                                       cfg_.max_fts, briefs_.data(), (int)std::max(total, (size_t)1), begin.data(), counts.data(), projected_.data(), &chain);
   check(rc, "Reprojector");
+  if (timing) { sub_ms_[1] += std::chrono::duration<double, std::milli>(now() - t0).count(); t0 = now(); }
   n_calls_[3]++; n_items_[3] += n;
   bool any_trace = false;
   for (int k : who) any_trace |= seq_[k]->trace.on();
@@ -416,6 +421,7 @@ void Bank::reproject(const std::vector<int>& who)
     // optimisation that ran behind the selection does not count for it
     d.seed_path = s.log.n_matches < 100 && !s.seeds.empty() && (int)s.seeds.size() > s.n_dead_seeds;
   });
+  if (timing) sub_ms_[2] += std::chrono::duration<double, std::milli>(now() - t0).count();
 }
 
 // the frame's pose result (pose_optimizer::optimizeLevenbergMarquardt3rd's effects, src/pose_optimizer.cpp:692-767) and the

@@ -1,6 +1,7 @@
 // hso_host.cpp — bodies of the host mirror: thin adapters onto the C-ABI.
 #include "hso_host.h"
 #include "hso_api.h"
+#include <algorithm>
 #include <cmath>
 #include <string>
 
@@ -18,9 +19,10 @@ thread_local int Seed::batch_counter = 0;
 
 bool Point::deleteFrameRef(Frame* frame)
 {
-  for (auto it = obs_.begin(); it != obs_.end(); ++it)
-    if ((*it)->frame == frame) { obs_.erase(it); return true; }
-  return false;
+  const auto hit = std::find_if(obs_.begin(), obs_.end(), [frame](const Feature* o) { return o->frame == frame; });
+  if (hit == obs_.end()) return false;
+  obs_.erase(hit);
+  return true;
 }
 
 Frame::Frame(hso_gpu_ctx* ctx, AbstractCamera* cam, const uint8_t* img, int width, int height, double timestamp)
@@ -93,16 +95,18 @@ bool Point::getCloseViewObs(const Vector3d& framepos, Feature*& ftr) const
 {
   Vector3d obs_dir = sub(framepos, pos_);
   { const double n = norm(obs_dir); for (double& c : obs_dir) c /= n; }
-  auto min_it = obs_.begin();
-  double min_cos_angle = 0;
-  for (auto it = obs_.begin(), ite = obs_.end(); it != ite; ++it) {
-    Vector3d dir = sub((*it)->frame->pos(), pos_);
-    { const double n = norm(dir); for (double& c : dir) c /= n; }
-    const double cos_angle = obs_dir[0] * dir[0] + obs_dir[1] * dir[1] + obs_dir[2] * dir[2];
-    if (cos_angle > min_cos_angle) { min_cos_angle = cos_angle; min_it = it; }
+  // the observation whose viewing ray is closest to the new one; the first observation when none has a positive cosine
+  Feature* chosen = obs_.front();
+  double best = 0;
+  for (Feature* o : obs_) {
+    Vector3d ray = sub(o->frame->pos(), pos_);
+    const double len = norm(ray);
+    for (double& x : ray) x /= len;                                 // Eigen's normalize(): component by component
+    const double c = obs_dir[0] * ray[0] + obs_dir[1] * ray[1] + obs_dir[2] * ray[2];
+    if (c > best) { best = c; chosen = o; }
   }
-  ftr = *min_it;
-  return !(min_cos_angle < 0.5);
+  ftr = chosen;
+  return !(best < 0.5);
 }
 
 // flatten (Point, chosen reference feature, current frame) the way findMatchDirect reads them
@@ -169,8 +173,7 @@ Reprojector::Reprojector(AbstractCamera* cam, int max_fts) : max_fts_(max_fts)
   cell_size = (int)floorf(std::sqrt((float)(cam->width() * cam->height()) / max_fts) * 0.6);   // caculateGridSize, :53-56
   grid_n_cols = (int)std::ceil((double)cam->width() / cell_size);
   grid_n_rows = (int)std::ceil((double)cam->height() / cell_size);
-  cells_.resize((size_t)grid_n_cols * grid_n_rows);
-  cell_order.resize(cells_.size());
+  cell_order.resize((size_t)grid_n_cols * grid_n_rows);
   for (size_t i = 0; i < cell_order.size(); ++i) cell_order[i] = (int)i;
 }
 
@@ -180,14 +183,16 @@ bool Reprojector::applyMatch(const Candidate& c, FramePtr frame)
   const hso_align_out& m = match_[c.slot];
   Point* pt = c.pt;
   if (proj_[c.slot].ref_obs < 0 || !m.success) {
-    pt->n_failed_reproj_++;
-    if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_failed_reproj_ > 15) dropUnknownPoint(pt);        // map_.safeDeletePoint
-    if (pt->type_ == Point::TYPE_CANDIDATE && pt->n_failed_reproj_ > 30) dropCandidatePoint(pt);    // deleteCandidatePoint
-    if (pt->type_ == Point::TYPE_TEMPORARY && pt->n_failed_reproj_ > 30) pt->isBad_ = true;
+    const int fails = ++pt->n_failed_reproj_;
+    switch (pt->type_) {                                            // :376-392
+      case Point::TYPE_UNKNOWN: if (fails > 15) dropUnknownPoint(pt); break;        // map_.safeDeletePoint
+      case Point::TYPE_CANDIDATE: if (fails > 30) dropCandidatePoint(pt); break;    // deleteCandidatePoint
+      case Point::TYPE_TEMPORARY: if (fails > 30) pt->isBad_ = true; break;
+      default: break;
+    }
     return false;
   }
-  pt->n_succeeded_reproj_++;
-  if (pt->type_ == Point::TYPE_UNKNOWN && pt->n_succeeded_reproj_ > 10) pt->type_ = Point::TYPE_GOOD;
+  if (++pt->n_succeeded_reproj_ > 10 && pt->type_ == Point::TYPE_UNKNOWN) pt->type_ = Point::TYPE_GOOD;   // :412-423
   Feature* nf = new Feature();
   nf->frame = frame.get();
   nf->px = {m.px_cur[0], m.px_cur[1]};
@@ -208,48 +213,22 @@ bool Reprojector::applyMatch(const Candidate& c, FramePtr frame)
   return true;
 }
 
-bool Reprojector::reprojectCell(Cell& cell, FramePtr frame, bool is_2nd, bool is_3rd)
-{
-  if (cell.empty()) return false;
-  if (!is_2nd)
-    cell.sort([](const Candidate& l, const Candidate& r) {          // pointQualityComparator, :333-345
-      if (l.pt->type_ != r.pt->type_) return l.pt->type_ > r.pt->type_;
-      return l.pt->ftr_type_ > r.pt->ftr_type_;
-    });
-  int success = 0;
-  auto it = cell.begin();
-  while (it != cell.end()) {
-    ++n_trials_;
-    if (it->pt->type_ == Point::TYPE_DELETED) { it = cell.erase(it); continue; }
-    const bool ok = applyMatch(*it, frame);
-    it = cell.erase(it);
-    if (!ok) continue;
-    if (!is_3rd) return true;
-    success++;
-    n_matches_++;
-    if (success >= 3 || n_matches_ >= (size_t)max_fts_) return true;
-  }
-  return false;
-}
-
 void Reprojector::reprojectMap(FramePtr frame, const std::vector<FramePtr>& kfs, std::vector<std::pair<FramePtr, size_t>>& overlap_kfs)
 {
   // resetGrid, :77-84
   n_matches_ = 0; n_trials_ = 0; nFeatures_ = 0;
-  for (Cell& c : cells_) c.clear();
   // the points reprojectPoint would see, in the reference's order (:137-152, :176-199)
   std::vector<Point*> pts;
   std::vector<size_t> kf_of_pt;
   for (const FramePtr& kf : kfs) {
     if (overlap_kfs.size() >= max_n_kfs) break;
     overlap_kfs.push_back({kf, 0});
+    const size_t row = overlap_kfs.size() - 1;
     for (Feature* ft : kf->fts_) {
-      if (ft->point == nullptr) continue;
-      if (ft->point->type_ == Point::TYPE_TEMPORARY) continue;
-      if (ft->point->last_projected_kf_id_ == frame->id_) continue;
-      ft->point->last_projected_kf_id_ = frame->id_;
-      pts.push_back(ft->point);
-      kf_of_pt.push_back(overlap_kfs.size() - 1);
+      Point* p = ft->point;
+      if (!p || p->type_ == Point::TYPE_TEMPORARY || p->last_projected_kf_id_ == frame->id_) continue;   // seen from an earlier keyframe
+      p->last_projected_kf_id_ = frame->id_;
+      pts.push_back(p); kf_of_pt.push_back(row);
     }
   }
   if (pts.empty()) return;
@@ -257,9 +236,7 @@ void Reprojector::reprojectMap(FramePtr frame, const std::vector<FramePtr>& kfs,
   std::vector<Candidate> all;                       // allPixelToDistribute, in projection order
   for (size_t i = 0; i < pts.size(); ++i) {
     if (!proj_[i].projected) continue;              // reprojectPoint returned false
-    const Candidate c{pts[i], {proj_[i].px[0], proj_[i].px[1]}, (int)i};
-    cells_.at(proj_[i].cell).push_back(c);
-    all.push_back(c);
+    all.push_back(Candidate{pts[i], {proj_[i].px[0], proj_[i].px[1]}, (int)i});
     overlap_kfs[kf_of_pt[i]].second++;
     nFeatures_++;
   }
@@ -308,32 +285,32 @@ void Reprojector::projectAndMatch(FramePtr frame, const std::vector<Point*>& pts
     if (proj_[i].projected && proj_[i].ref_obs >= 0) ref_of_slot_[i] = obs_ftr[proj_[i].ref_obs];
 }
 
+// Which candidates get examined, in which order, and which of them become features (:261-306, :352-429, :556-612) is a function of
+// the candidates' cells, quality keys and match results, the cell order and max_fts: hso_gpu_reproject_select evaluates it (the
+// engine runs the same policy fused behind the matcher); here the list it returns is walked and the bookkeeping applied.
 void Reprojector::selectMatches(FramePtr frame, const std::vector<Candidate>& all)
 {
-  if (all.size() < (size_t)max_fts_ + 50) {         // reprojectCellAll, :556-612
-    for (const Candidate& c : all) {
-      ++n_trials_;
-      if (c.pt->type_ == Point::TYPE_DELETED) continue;
-      if (!applyMatch(c, frame)) continue;
-      n_matches_++;
-      if (n_matches_ >= (size_t)max_fts_) return;
-    }
-    return;
+  const int n = (int)all.size();
+  if (n == 0) return;
+  std::vector<int32_t> cell((size_t)n), examined((size_t)n), begin{0, n};
+  std::vector<uint8_t> quality((size_t)n), flags((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const Candidate& c = all[(size_t)i];
+    cell[(size_t)i] = proj_[c.slot].cell;
+    const bool gone = c.pt->type_ == Point::TYPE_DELETED;
+    quality[(size_t)i] = gone ? 0 : (uint8_t)(((int)c.pt->type_ << 4) | (int)c.pt->ftr_type_);
+    flags[(size_t)i] = (uint8_t)((proj_[c.slot].ref_obs >= 0 && match_[c.slot].success ? 1 : 0) | (gone ? 2 : 0));
   }
-  for (size_t i = 0; i < cells_.size(); ++i) {      // 1st, :268-278
-    if (reprojectCell(cells_.at(cell_order[i]), frame, false, false)) ++n_matches_;
-    if (n_matches_ >= (size_t)max_fts_) break;
+  int32_t counts[4] = {0, 0, 0, 0};
+  api::check(frame->ctx_, hso_gpu_reproject_select(frame->ctx_, begin.data(), 1, cell.data(), quality.data(), flags.data(), cell_order.data(),
+                                                   (int)cell_order.size(), max_fts_, examined.data(), counts), "Reprojector");
+  for (int k = 0; k < counts[0]; ++k) {
+    const Candidate& c = all[(size_t)(examined[(size_t)k] & 0x7fffffff)];
+    if (c.pt->type_ == Point::TYPE_DELETED) continue;
+    const bool made = applyMatch(c, frame);
+    (void)made;   // == (examined[k] < 0): the policy saw the same success flag
   }
-  if (n_matches_ < (size_t)max_fts_)                // 2nd, :281-293 (index 0 is never revisited there)
-    for (size_t i = cells_.size() - 1; i > 0; --i) {
-      if (reprojectCell(cells_.at(cell_order[i]), frame, true, false)) ++n_matches_;
-      if (n_matches_ >= (size_t)max_fts_) break;
-    }
-  if (n_matches_ < (size_t)max_fts_)                // 3rd, :296-305
-    for (size_t i = 0; i < cells_.size(); ++i) {
-      reprojectCell(cells_.at(cell_order[i]), frame, true, true);
-      if (n_matches_ >= (size_t)max_fts_) break;
-    }
+  n_trials_ = (size_t)counts[0]; n_matches_ = (size_t)counts[1];
 }
 
 // ---------------------------------------------------------------- pose_optimizer
@@ -390,31 +367,6 @@ Seed::Seed(Feature* ftr_, float depth_mean, float depth_min, float converge_thre
 {
   vec_distance.push_back(depth_mean);    // src/depth_filter.cpp:64
   converge_thresh = converge_threshold;
-}
-
-void DepthFilter::updateSeed(float x, float tau2, Seed* seed)
-{
-  float id_var = seed->sigma2 * 1.01f;
-  const float w = tau2 / (tau2 + id_var);
-  const float new_idepth = (1 - w) * x + w * seed->mu;
-  const double nd = new_idepth;
-  seed->mu = (float)(nd < 0 ? (nd > -1e-10 ? -1e-10 : nd) : (nd < 1e-10 ? 1e-10 : nd));
-  id_var *= w;
-  if (id_var < seed->sigma2) seed->sigma2 = id_var;
-}
-
-double DepthFilter::computeTau(const SE3& T_ref_cur, const Vector3d& f, double z, double px_error_angle)
-{
-  const double PI = 3.14159265;  // include/hso/global.h:104
-  const Vector3d t = T_ref_cur.translation();
-  const Vector3d a{f[0] * z - t[0], f[1] * z - t[1], f[2] * z - t[2]};
-  const double t_norm = norm(t), a_norm = norm(a);
-  const double alpha = std::acos((f[0] * t[0] + f[1] * t[1] + f[2] * t[2]) / t_norm);
-  const double beta = std::acos((a[0] * -t[0] + a[1] * -t[1] + a[2] * -t[2]) / (t_norm * a_norm));
-  const double beta_plus = beta + px_error_angle;
-  const double gamma_plus = PI - alpha - beta_plus;
-  const double z_plus = t_norm * std::sin(beta_plus) / std::sin(gamma_plus);
-  return z_plus - z;
 }
 
 FeatureExtractor::FeatureExtractor(int width, int height, int cellSize, int levels, bool isInit, int max_fts)

@@ -138,7 +138,6 @@ public:
 class Reprojector {
 public:
   struct Candidate { Point* pt; Vector2d px; int slot; };   // reprojector.h:95-103 (+ the row of the device call)
-  using Cell = std::list<Candidate>;
   // initializeGrid, src/reprojector.cpp:53-75; max_fts stands in for Config::maxFts()
   Reprojector(AbstractCamera* cam, int max_fts);
   // src/reprojector.cpp:88-331 for the map points of `kfs` — the overlap keyframes in the order
@@ -160,15 +159,14 @@ protected:
   // project every point into `frame`, choose its reference observation and match it: one device call
   // (hso_gpu_reproject_match); fills proj_ / match_ / ref_of_slot_ in the order of `pts`
   void projectAndMatch(FramePtr frame, const std::vector<Point*>& pts);
-  // reprojectCellAll or the three reprojectCell passes over the cells (:261-306)
+  // reprojectCellAll or the three reprojectCell passes over the cells (:261-306): the policy runs on the device
+  // (hso_gpu_reproject_select), its list of examined candidates is applied here
   void selectMatches(FramePtr frame, const std::vector<Candidate>& all);
-  bool reprojectCell(Cell& cell, FramePtr frame, bool is_2nd, bool is_3rd);
   bool applyMatch(const Candidate& c, FramePtr frame);
   // what the reference hands to Map::safeDeletePoint / MapPointCandidates::deleteCandidatePoint (:377-380);
   // without a map behind the reprojector the point is only marked
   virtual void dropUnknownPoint(Point* pt) { pt->type_ = Point::TYPE_DELETED; }
   virtual void dropCandidatePoint(Point* pt) { pt->type_ = Point::TYPE_DELETED; }
-  std::vector<Cell> cells_;
   std::vector<hso_align_out> match_;
   std::vector<hso_reproj_point> proj_;
   std::vector<const Feature*> ref_of_slot_;
@@ -232,8 +230,6 @@ public:
   // src/depth_filter.cpp:557-675: one observation of every seed in `frame`; seeds whose
   // z_inv_min turns NaN are erased like :618-622; returns the number of successful matches
   size_t observeDepth(FramePtr frame);
-  static void updateSeed(float x, float tau2, Seed* seed);                                        // :527-537
-  static double computeTau(const SE3& T_ref_cur, const Vector3d& f, double z, double px_error_angle);  // :539-555
   std::list<Seed> seeds_;
   double px_error_angle_;
 };

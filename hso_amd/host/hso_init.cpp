@@ -232,38 +232,32 @@ double reprojError(const Vector3d& f1, const Vector3d& f2, double error_multipli
 // include/hso/point.h:174-184
 void jacobian_id2uv(const Vector3d& p_in_f, const Matrix3d& R_th, const Vector3d& t_th, double idH, const Vector3d& fH, double jac[2])
 {
-  const Vector2d proj = project2d(p_in_f);
-  const Vector3d Rf = mat_vec(R_th, fH);
-  jac[0] = -(t_th[0] - proj[0] * t_th[2]) / (Rf[2] + t_th[2] * idH);
-  jac[1] = -(t_th[1] - proj[1] * t_th[2]) / (Rf[2] + t_th[2] * idH);
+  // d(projection) / d(inverse distance along the host bearing): the common denominator once
+  const Vector2d uv = project2d(p_in_f);
+  const double den = mat_vec(R_th, fH)[2] + t_th[2] * idH;
+  for (int r = 0; r < 2; r++) jac[r] = -(t_th[r] - uv[r] * t_th[2]) / den;
 }
 
-// src/initialization.cpp:428-474: three Gauss-Newton steps on the inverse distance along the reference bearing
+// src/initialization.cpp:428-474: at most three Gauss-Newton steps on the inverse distance along the reference bearing; a step
+// that raises the energy (or is NaN) is taken back
 Vector3d distancePointOnce(const Vector3d& pointW, const Vector3d& bearingRef, const Vector3d& bearingCur, const Matrix3d& R_c_r, const Vector3d& t_c_r)
 {
-  double idist_old = 1. / norm(pointW);
-  double idist_new = idist_old;
-  Vector3d pHost = scale(bearingRef, 1.0 / idist_old);
-  double oldEnergy = 0;
+  const Vector2d seen = project2d(bearingCur);
+  double id_prev = 1. / norm(pointW), id = id_prev, energy_prev = 0;
   for (int iter = 0; iter < 3; ++iter) {
-    double newEnergy = 0, H = 0, b = 0;
-    const Vector3d pTarget = add(mat_vec(R_c_r, pHost), t_c_r);
-    const Vector2d pc = project2d(bearingCur), pt = project2d(pTarget);
-    const double e[2] = {pc[0] - pt[0], pc[1] - pt[1]};
-    newEnergy += e[0] * e[0] + e[1] * e[1];
+    const Vector3d in_cur = add(mat_vec(R_c_r, scale(bearingRef, 1.0 / id)), t_c_r);
+    const Vector2d predicted = project2d(in_cur);
+    const double e[2] = {seen[0] - predicted[0], seen[1] - predicted[1]};
+    const double energy = e[0] * e[0] + e[1] * e[1];
     double J[2];
-    jacobian_id2uv(pTarget, R_c_r, t_c_r, idist_new, bearingRef, J);
-    H += J[0] * J[0] + J[1] * J[1];
-    b -= J[0] * e[0] + J[1] * e[1];
-    const double step = (1.0 / H) * b;
-    if ((iter > 0 && newEnergy > oldEnergy) || std::isnan(step)) { idist_new = idist_old; break; }
-    idist_old = idist_new;
-    idist_new += step;
-    oldEnergy = newEnergy;
-    pHost = scale(bearingRef, 1.0 / idist_new);
-    if (step <= 0.000001 * idist_new) break;
+    jacobian_id2uv(in_cur, R_c_r, t_c_r, id, bearingRef, J);
+    const double step = (1.0 / (J[0] * J[0] + J[1] * J[1])) * (-(J[0] * e[0] + J[1] * e[1]));
+    if ((iter > 0 && energy > energy_prev) || std::isnan(step)) { id = id_prev; break; }
+    id_prev = id; energy_prev = energy;
+    id += step;
+    if (step <= 0.000001 * id) break;
   }
-  return scale(bearingRef, 1.0 / idist_new);
+  return scale(bearingRef, 1.0 / id);
 }
 
 template <typename T> T getMedian(std::vector<T>& v)   // vikit/math_utils.h:119-126 (permutes v)
@@ -418,31 +412,29 @@ bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& fts_c1,
   svd3(H, U, sv, V);
   const double d1 = std::fabs(sv[0]), d2 = std::fabs(sv[1]), d3 = std::fabs(sv[2]);
   const double s = mat_det(U) * mat_det(V);
-  const double dPrime_PM = d2;
   if (!(d1 != d2 && d2 != d3)) return false;                    // nCase != 1: "not implemented or degenerate" (:111-115)
-  const double x1_PM = std::sqrt((d1 * d1 - d2 * d2) / (d1 * d1 - d3 * d3));
-  const double x2 = 0;
-  const double x3_PM = std::sqrt((d2 * d2 - d3 * d3) / (d1 * d1 - d3 * d3));
-  const double e1[4] = {1.0, -1.0, 1.0, -1.0}, e3[4] = {1.0, 1.0, -1.0, -1.0};
-  for (int pass = 0; pass < 2; pass++) {
-    Decomp dc{};
-    dc.d = pass == 0 ? s * dPrime_PM : s * -dPrime_PM;
+  // Faugeras & Lustman, case of three distinct singular values: the plane normal is (+-a, 0, +-c) in V's frame with
+  //   a = sqrt((d1^2 - d2^2) / (d1^2 - d3^2)),  c = sqrt((d2^2 - d3^2) / (d1^2 - d3^2));
+  // for d' = +d2 the rotation is about the middle axis by theta (Eq. 13, 14), for d' = -d2 a reflection by phi (Eq. 15, 16)
+  const double span = d1 * d1 - d3 * d3;
+  const double a = std::sqrt((d1 * d1 - d2 * d2) / span), c = std::sqrt((d2 * d2 - d3 * d3) / span);
+  for (int positive = 1; positive >= 0; positive--) {
     for (int k = 0; k < 4; k++) {
-      if (pass == 0) {                                          // case 1, d' > 0 (Eq. 13, 14)
-        dc.R = mat_identity();
-        const double dSinTheta = (d1 - d3) * x1_PM * x3_PM * e1[k] * e3[k] / d2;
-        const double dCosTheta = (d1 * x3_PM * x3_PM + d3 * x1_PM * x1_PM) / d2;
-        dc.R.m[0][0] = dCosTheta; dc.R.m[0][2] = -dSinTheta; dc.R.m[2][0] = dSinTheta; dc.R.m[2][2] = dCosTheta;
-        dc.t = {(d1 - d3) * x1_PM * e1[k], 0.0, (d1 - d3) * -x3_PM * e3[k]};
-      } else {                                                  // case 1, d' < 0 (Eq. 15, 16)
-        dc.R = mat_identity();
-        for (int i = 0; i < 3; i++) dc.R.m[i][i] = -1;
-        const double dSinPhi = (d1 + d3) * x1_PM * x3_PM * e1[k] * e3[k] / d2;
-        const double dCosPhi = (d3 * x1_PM * x1_PM - d1 * x3_PM * x3_PM) / d2;
-        dc.R.m[0][0] = dCosPhi; dc.R.m[0][2] = dSinPhi; dc.R.m[2][0] = dSinPhi; dc.R.m[2][2] = -dCosPhi;
-        dc.t = {(d1 + d3) * x1_PM * e1[k], 0.0, (d1 + d3) * x3_PM * e3[k]};
+      const double sa = (k & 1) ? -1.0 : 1.0, sc = (k & 2) ? -1.0 : 1.0;   // signs of the normal's first and third component
+      Decomp dc{};
+      dc.d = positive ? s * d2 : s * -d2;
+      dc.R = mat_identity();
+      if (positive) {
+        const double sin_t = (d1 - d3) * a * c * sa * sc / d2, cos_t = (d1 * c * c + d3 * a * a) / d2;
+        dc.R.m[0][0] = cos_t; dc.R.m[0][2] = -sin_t; dc.R.m[2][0] = sin_t; dc.R.m[2][2] = cos_t;
+        dc.t = {(d1 - d3) * a * sa, 0.0, (d1 - d3) * -c * sc};
+      } else {
+        const double sin_p = (d1 + d3) * a * c * sa * sc / d2, cos_p = (d3 * a * a - d1 * c * c) / d2;
+        dc.R.m[1][1] = -1;
+        dc.R.m[0][0] = cos_p; dc.R.m[0][2] = sin_p; dc.R.m[2][0] = sin_p; dc.R.m[2][2] = -cos_p;
+        dc.t = {(d1 + d3) * a * sa, 0.0, (d1 + d3) * c * sc};
       }
-      dc.n = mat_vec(V, {x1_PM * e1[k], x2, x3_PM * e3[k]});
+      dc.n = mat_vec(V, {a * sa, 0.0, c * sc});
       decompositions.push_back(dc);
     }
   }
