@@ -165,7 +165,7 @@ class PoseResult(C.Structure):
 
 class PoseChain(C.Structure):
     _fields_ = [("reproj_thresh", C.c_double), ("n_iter", C.c_int32), ("pad_", C.c_int32), ("results", C.c_void_p),
-                ("n_feats", C.c_void_p), ("outlier_mask", C.c_void_p), ("feat_f", C.c_void_p)]
+                ("n_feats", C.c_void_p), ("outlier_mask", C.c_void_p), ("feat_f", C.c_void_p), ("records", C.c_void_p)]
 
 
 def make_pose_job(feats, poses, T_f_w, reproj_thresh=2.0, n_iter=12):

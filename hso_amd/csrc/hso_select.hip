@@ -361,7 +361,8 @@ __global__ void k_sel_offsets(int n_calls, const int* counts, int* offs)
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void k_sel_emit(const hso_match_brief* brief, const int* begin, const int32_t* examined,
-                                                         const int32_t* cand_pt, const int* counts, const int* offs, hso_match_brief* out)
+                                                         const int32_t* cand_pt, const int* counts, const int* offs, hso_match_brief* out,
+                                                         hso_frame_match* records = nullptr)
 {
   const int c = blockIdx.x, b = begin[c], n_ex = counts[4 * c], o = offs[c];
   for (int k = threadIdx.x; k < n_ex; k += SEL_THREADS) {
@@ -371,6 +372,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_emit(const hso_match_brief*
     r.success = (v < 0) ? 1 : 0;          // became a feature (a matched candidate the budget never reached stays 0)
     r.pad_ = g - b;                       // the point's index in its map
     out[o + k] = r;
+    if (records) {
+      hso_frame_match m;
+      m.px_cur[0] = r.px_cur[0]; m.px_cur[1] = r.px_cur[1]; m.grad[0] = r.grad[0]; m.grad[1] = r.grad[1];
+      m.point = r.pad_; m.success = r.success; m.search_level = r.search_level; m.ref_type = r.ref_type; m.pad_ = 0;
+      records[o + k] = m;
+    }
   }
 }
 
@@ -708,6 +715,7 @@ extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_
   const size_t o_offs = o; o += al(sizeof(int) * (size_t)(n_calls + 1));
   const size_t o_out = o; o += al(sizeof(hso_match_brief) * n_total);
   const size_t o_flag = o; o += al(n_total);
+  const size_t o_rec = o; o += al(sizeof(hso_frame_match) * n_total);
   const size_t o_scr = o; o += per_frame * (size_t)n_calls;
   const size_t o_pf = o; o += al(sizeof(hso_pose_feat) * (size_t)n_calls * feat_cap);
   const size_t o_pj = o; o += al(sizeof(PoseJobDev) * (size_t)n_calls);
@@ -788,7 +796,7 @@ extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_
   hipLaunchKernelGGL(k_sel_offsets, dim3(1), dim3(64), 0, ctx->stream, n_calls, reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<int*>(d + o_offs));
   hipLaunchKernelGGL(k_sel_emit, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_brief, d_begin, reinterpret_cast<const int32_t*>(d + o_exam),
                      reinterpret_cast<const int32_t*>(d + o_pt), reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<const int*>(d + o_offs),
-                     reinterpret_cast<hso_match_brief*>(d + o_out));
+                     reinterpret_cast<hso_match_brief*>(d + o_out), pose->records ? reinterpret_cast<hso_frame_match*>(d + o_rec) : nullptr);
   if (projected_out) hipLaunchKernelGGL(k_projected_flags, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, R.d_proj, total, reinterpret_cast<uint8_t*>(d + o_flag));
   HSO_HIP_CHECK(ctx, hipGetLastError());
   {
@@ -813,8 +821,9 @@ extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const int n_out = begin_out[n_calls];
   if (n_out > 0) {
-    if (!out || out_capacity < n_out) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: output smaller than the examined candidates");
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d + o_out, sizeof(hso_match_brief) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream));
+    if ((!out && !pose->records) || out_capacity < n_out) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: output smaller than the examined candidates");
+    if (out) HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d + o_out, sizeof(hso_match_brief) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream));
+    if (pose->records) HSO_HIP_CHECK(ctx, hipMemcpyAsync(pose->records, d + o_rec, sizeof(hso_frame_match) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream));
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   hso_seqmaps_debug_set(ctx, HSO_DBG_PROJ, R.d_proj, sizeof(hso_reproj_point) * (size_t)total);

@@ -67,7 +67,7 @@ Bank::~Bank()
   for (StepData* d : step_) delete d;
   if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);
   for (size_t k = 0; k < seq_.size(); k++) (void)k;
-  briefs_.release(); projected_.release(); mask_.release(); feat_f_.release(); track_tables_.release(); seed_brief_.release(); seed_px_.release();   // before the context goes
+  briefs_.release(); records_.release(); projected_.release(); mask_.release(); feat_f_.release(); track_tables_.release(); seed_brief_.release(); seed_px_.release();   // before the context goes
   if (owns_ctx_) hso_gpu_destroy(ctx_);
 }
 

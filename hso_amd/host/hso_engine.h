@@ -173,7 +173,7 @@ private:
   void track_group(const std::vector<int>& who, const std::vector<Id>& ref, const std::vector<Id>& cur, const hso_track_params& p);
   void reproject(const std::vector<int>& who);
   void list_points(int k);
-  void apply_selection(int k, const hso_match_brief* rec, int n_rec, const uint8_t* projected, const double* feat_f);
+  void apply_selection(int k, const hso_frame_match* rec, int n_rec, const uint8_t* projected, const double* feat_f);
   void trace_reproject(const std::vector<int>& who, const std::vector<hso_map_frame>& calls, const std::vector<size_t>& list_at,
                        const std::vector<int32_t>& begin, const std::vector<int32_t>& counts, const std::vector<hso_pose_result>& pose,
                        const std::vector<int32_t>& n_feats);
@@ -225,7 +225,8 @@ private:
   double phase_ms_[9] = {0};
   int64_t n_steps_ = 0, n_kf_events_ = 0;
   // result tables of the batched calls (kept between steps: no allocation per step)
-  Pinned<hso_match_brief> briefs_;
+  Pinned<hso_match_brief> briefs_;   // recorded runs only: the full records of the examined candidates
+  Pinned<hso_frame_match> records_;
   Pinned<uint8_t> projected_, mask_;
   Pinned<double> feat_f_, track_tables_;
   Pinned<hso_seed_brief> seed_brief_;

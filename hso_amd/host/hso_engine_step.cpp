@@ -337,7 +337,7 @@ void Bank::list_points(int k)
 
 // what Reprojector::reprojectCell / reprojectCellAll do with the candidates they examine (:352-429, :556-612), applied to the
 // examined records the device returned, in examination order; a record that became a feature adds it to the frame
-void Bank::apply_selection(int k, const hso_match_brief* rec, int n_rec, const uint8_t* projected, const double* feat_f)
+void Bank::apply_selection(int k, const hso_frame_match* rec, int n_rec, const uint8_t* projected, const double* feat_f)
 {
   Seq& s = *seq_[k];
   StepData& d = *step_[k];
@@ -353,8 +353,8 @@ void Bank::apply_selection(int k, const hso_match_brief* rec, int n_rec, const u
   C.loose.clear();
   int taken = 0;
   for (int i = 0; i < n_rec; i++) {
-    const hso_match_brief& r = rec[i];
-    const Id p = d.list[r.pad_];
+    const hso_frame_match& r = rec[i];
+    const Id p = d.list[r.point];
     Point& P = s.points[p];
     if (P.kind == kPtDeleted) continue;
     if (!r.success) {
@@ -391,7 +391,10 @@ void Bank::reproject(const std::vector<int>& who)
   size_t total = 0;
   std::vector<size_t> list_at(n);
   for (int i = 0; i < n; i++) { calls[i] = step_[who[i]]->call; list_at[i] = total; total += (size_t)calls[i].n_points; }
-  briefs_.need(ctx_, std::max(total, (size_t)1));
+  bool any_trace = false;
+  for (int k : who) any_trace |= seq_[k]->trace.on();
+  records_.need(ctx_, std::max(total, (size_t)1));
+  if (any_trace) briefs_.need(ctx_, std::max(total, (size_t)1));   // the full 56-byte records only for the trace
   projected_.need(ctx_, std::max(total, (size_t)1));
   std::vector<int32_t> begin(n + 1, 0), counts(4 * (size_t)n, 0), n_feats(n, 0);
   std::vector<hso_pose_result> pose(n);
@@ -400,20 +403,19 @@ void Bank::reproject(const std::vector<int>& who)
   hso_pose_chain chain{};
   chain.reproj_thresh = cfg_.poseoptim_thresh; chain.n_iter = 12;
   chain.results = pose.data(); chain.n_feats = n_feats.data(); chain.outlier_mask = mask_.data(); chain.feat_f = feat_f_.data();
+  chain.records = records_.data();
   const int rc = hso_gpu_reproject_select_pose_frames(ctx_, &cam_.pod(), calls.data(), n, cell_size_, grid_cols_, cell_order_.data(), (int)cell_order_.size(),
-                                                      cfg_.max_fts, briefs_.data(), (int)std::max(total, (size_t)1), begin.data(), counts.data(), projected_.data(), &chain);
+                                                      cfg_.max_fts, any_trace ? briefs_.data() : nullptr, (int)std::max(total, (size_t)1), begin.data(), counts.data(), projected_.data(), &chain);
   check(rc, "Reprojector");
   if (timing) { sub_ms_[1] += std::chrono::duration<double, std::milli>(now() - t0).count(); t0 = now(); }
   n_calls_[3]++; n_items_[3] += n;
-  bool any_trace = false;
-  for (int k : who) any_trace |= seq_[k]->trace.on();
   if (any_trace) trace_reproject(who, calls, list_at, begin, counts, pose, n_feats);
   pool_->run(n, [&](int i) {
     const int k = who[i];
     Seq& s = *seq_[k];
     StepData& d = *step_[k];
     Frame& C = s.frames[s.cur];
-    apply_selection(k, briefs_.data() + begin[i], begin[i + 1] - begin[i], projected_.data() + list_at[i], feat_f_.data() + (size_t)i * cap * 3);
+    apply_selection(k, records_.data() + begin[i], begin[i + 1] - begin[i], projected_.data() + list_at[i], feat_f_.data() + (size_t)i * cap * 3);
     s.log.n_trials = counts[4 * i]; s.log.n_matches = counts[4 * i + 1]; s.log.n_seed_matches = 0;
     d.pose = pose[i];
     d.pose_mask.assign(mask_.data() + (size_t)i * cap, mask_.data() + (size_t)i * cap + C.loose.size());

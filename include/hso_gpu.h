@@ -723,6 +723,15 @@ int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const
  * the host keyframes' poses are the stored maps', the start pose the call's T_cur_w — so the 96-byte feature records never
  * cross PCIe (value-passing form: hso_gpu_pose_optimize_batch).  results[c] and n_feats[c] per call; outlier_mask (may be
  * NULL): n_calls rows of max(max_fts, 1) bytes, row c holds n_feats[c] flags in feature order. */
+/* An examined candidate of hso_gpu_reproject_select_pose_frames in the form a driver applies it (src/reprojector.cpp:366-425): the
+ * point (index in the frame's list), whether it became a feature, and the new feature's pixel, level, type and gradient. */
+typedef struct hso_frame_match {
+  double px_cur[2];
+  float grad[2];
+  int32_t point;               /* index in the frame's point list (hso_match_brief.pad_) */
+  int8_t success, search_level, ref_type, pad_;
+} hso_frame_match;
+
 typedef struct hso_pose_chain {
   double reproj_thresh;        /* Config::poseOptimThresh() = 2.0 */
   int32_t n_iter;              /* 12 */
@@ -733,6 +742,9 @@ typedef struct hso_pose_chain {
   double* feat_f;              /* may be NULL: n_calls rows of max(max_fts, 1) * 3 doubles, row c holds the unit bearings the device
                                   formed for the n_feats[c] features (cam2world of the refined pixel) — what Feature::f of the new
                                   features must hold so that host and device agree bit for bit */
+  struct hso_frame_match* records;  /* hso_gpu_reproject_select_pose_frames only, may be NULL: the examined candidates as 32-byte records
+                                  (what a driver's bookkeeping reads of a hso_match_brief), laid out like `out` (same begin_out);
+                                  with it `out` may be NULL — 43 % less to read back per frame */
 } hso_pose_chain;
 int hso_gpu_reproject_select_pose_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
                                        int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,

@@ -268,7 +268,14 @@ int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* c, const hso_camera* cam, 
       hso_match_brief b = brief[(size_t)i];
       b.success = e.second ? 1 : 0; b.pad_ = i;
       if (n_out >= out_cap) return fail(c, HSO_E_INVALID, "reproject_select_pose_frames: output too small");
-      out[n_out++] = b;
+      if (pose->records) {
+        hso_frame_match m{};
+        m.px_cur[0] = b.px_cur[0]; m.px_cur[1] = b.px_cur[1]; m.grad[0] = b.grad[0]; m.grad[1] = b.grad[1];
+        m.point = b.pad_; m.success = b.success; m.search_level = b.search_level; m.ref_type = b.ref_type;
+        pose->records[n_out] = m;
+      }
+      if (out) out[n_out] = b;
+      n_out++;
       if (!e.second || (int)feats.size() >= cap) continue;
       const hso_map_point& P = M->pts[(size_t)K.point_ids[i]];
       hso_pose_feat pf{};
