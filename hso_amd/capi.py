@@ -368,6 +368,7 @@ def load():
 
 # Every symbol include/hso_gpu.h declares; tests check the library exports all of them.
 EXPORTED_SYMBOLS = [
+    "hso_gpu_debug_census", "hso_gpu_ba_huber_deltas_multi",
     "hso_gpu_create", "hso_gpu_destroy", "hso_gpu_last_error", "hso_gpu_abi_version",
     "hso_gpu_synchronize", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release",
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",

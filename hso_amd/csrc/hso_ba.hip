@@ -68,6 +68,7 @@ struct BaProb {
   hso_se3* poses_rw;                    // = a.poses, writable
   hso_se3* poses_bak;
   int M, n_pairs;
+  char* zero_begin; size_t zero_bytes;  // [Hpp ... chi2 sums]: what a linearisation accumulates into (16-byte units)
 };
 
 // ---- g2o's SE3Quat update (host and device: the optimiser applies it on the device, the tests' helpers on the host)
@@ -318,12 +319,15 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, co
   const int q0 = chi_block ? 0 : pr_off[b], q1 = chi_block ? 0 : pr_off[b + 1];
   int j = 0;
   if (!chi_block) { while (b >= np - i) { b -= np - i; i++; } j = i + b; }
+  // a block with a fixed pose stays zero (the linearisation zeroes Hcc / bc first): most blocks of a local-BA window, whose
+  // observing keyframes outside the core are all fixed — they leave before the 44-value reduction
+  if (!chi_block && (a.fixed[i] || a.fixed[j])) return;
   double acc[44];
 #pragma unroll
   for (int q = 0; q < 44; q++) acc[q] = 0;
   if (chi_block) {
     for (int k = threadIdx.x; k < a.n_edges; k += BA_THREADS) { acc[0] += a.edge_chi2[k]; acc[1] += a.edge_rho[k]; }
-  } else if (!a.fixed[i] && !a.fixed[j]) {
+  } else {
     for (int q = q0 + (int)threadIdx.x; q < q1; q += BA_THREADS) {
       const int k = pr_edges[q];
       const hso_ba_edge& e = a.edges[k];
@@ -375,6 +379,36 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, co
   }
 }
 
+
+// the blocks a linearisation accumulates into, zeroed for every window of the launch at once (was: one memset per window)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_zero(const BaProb* probs, const int* active)
+{
+  const BaProb& P = probs[active[blockIdx.y]];
+  uint4* z = reinterpret_cast<uint4*>(P.zero_begin);
+  const size_t n = P.zero_bytes / 16;
+  for (size_t i = (size_t)blockIdx.x * BA_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * BA_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+}
+
+// computeLambdaInit (thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:191-201): the largest |diagonal entry| of the
+// Hessian blocks of every free vertex — points: Hpp, free poses: the diagonal of their Hcc block — into sum[5].  A maximum does
+// not depend on the order it is taken in; the host used to read Hpp and the whole Hcc table of every window for this one number.
+__global__ __launch_bounds__(BA_THREADS) void k_ba_maxdiag(const BaProb* probs, const int* active)
+{
+  __shared__ double s_part[BA_WAVES];
+  const BaProb& P = probs[active[blockIdx.y]];
+  const int np = P.a.n_poses;
+  double m = 0;
+  for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) m = fmax(m, fabs(P.Hpp[p]));
+  for (int k = threadIdx.x; k < np * 6; k += BA_THREADS) {
+    const int i = k / 6, q = k - 6 * i;
+    if (!P.a.fixed[i]) m = fmax(m, fabs(P.Hcc[((size_t)i * np + i) * 36 + q * 7]));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __hiloint2double(__shfl_xor(__double2hiint(m), d), __shfl_xor(__double2loint(m), d)));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < BA_WAVES; w++) t = fmax(t, s_part[w]); P.sum[5] = t; }
+}
 
 // sum of chi2 and of the robustified rho(chi2) over all edges (activeChi2 / activeRobustChi2,
 // thirdparty/g2o/g2o/core/sparse_optimizer.cpp:100-113): one workgroup, fixed tree => deterministic
@@ -596,24 +630,6 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_restore(const BaProb* probs, 
   for (int i = threadIdx.x; i < P.a.n_poses; i += BA_THREADS) P.poses_rw[i] = P.poses_bak[i];
 }
 
-// per-edge error magnitudes for the Huber deltas of LocalBundleAdjustment (src/bundle_adjustment.cpp:618-656):
-// e = (project2d(obs->f) - project2d(Tth * fH / idist)) / 2^level; corners |e|, edgelets |grad^T e| (floats)
-__global__ __launch_bounds__(BA_THREADS) void k_ba_mad_errors(const hso_se3* poses, const double* idist, const hso_ba_edge* edges,
-                                                              const double* obs_uv, int n_edges, float* err_out)
-{
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_edges) return;
-  const hso_ba_edge e = edges[k];
-  const Se3 Tth = se3_mul(se3_from(poses[e.target]), se3_inverse(se3_from(poses[e.host])));
-  const double inv = 1.0 / idist[e.point];
-  double x, y, z;
-  se3_apply(Tth, e.fH[0] * inv, e.fH[1] * inv, e.fH[2] * inv, x, y, z);
-  double ex = obs_uv[2 * k] - x / z, ey = obs_uv[2 * k + 1] - y / z;
-  const double sc = 1.0 / (double)(1 << e.level);
-  ex *= sc; ey *= sc;
-  err_out[k] = (e.type == HSO_FTR_EDGELET) ? (float)fabs(e.normal[0] * ex + e.normal[1] * ey) : (float)sqrt(ex * ex + ey * ey);
-}
-
 // ------------------------------------------------------------------ host side
 
 // One BA problem resident in the context's work area: inputs uploaded once, the state (poses, inverse depths)
@@ -799,6 +815,7 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
     R.trial_rw = reinterpret_cast<double*>(dd + B.o_trial);
     R.poses_rw = reinterpret_cast<hso_se3*>(dd + B.o_poses); R.poses_bak = reinterpret_cast<hso_se3*>(dd + B.o_pbak);
     R.M = B.M; R.n_pairs = B.n_pairs;
+    R.zero_begin = dd + B.o_out; R.zero_bytes = B.o_sum + 256 - B.o_out;
   }
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_probs, hp, sizeof(BaProb) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   return HSO_OK;
@@ -828,11 +845,12 @@ static int ba_launch_linearize(BaBatch& Q, int slot, const std::vector<int>& whi
   if (which.empty()) return HSO_OK;
   const int* dl;
   if (int rc = ba_list(Q, slot, which, &dl)) return rc;
-  for (int q : which) { const BaWin& B = Q.win[q]; HSO_HIP_CHECK(ctx, hipMemsetAsync(B.d + B.o_out, 0, B.o_sum + 256 - B.o_out, ctx->stream)); }
   const int ny = (int)which.size();
+  hipLaunchKernelGGL(k_ba_zero, dim3(64, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
   hipLaunchKernelGGL(k_ba_edges<true>, dim3((ba_max(Q, which, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
   hipLaunchKernelGGL(k_ba_points, dim3((ba_max(Q, which, &BaWin::n_points) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
   hipLaunchKernelGGL(k_ba_poses, dim3(ba_max(Q, which, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+  hipLaunchKernelGGL(k_ba_maxdiag, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
 }
@@ -896,26 +914,58 @@ static float upper_median(std::vector<float>& v)
   return v[v.size() / 2];
 }
 
-extern "C" int hso_gpu_ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, int n_poses, const double* idist, int n_points,
-                                       const hso_ba_edge* edges, const double* obs_uv, int n_edges, double error_multiplier2,
-                                       float* huber_corner, float* huber_edge)
+// per-edge error magnitudes for the Huber deltas of LocalBundleAdjustment (src/bundle_adjustment.cpp:618-656):
+// e = (project2d(obs->f) - project2d(Tth * fH / idist)) / 2^level; corners |e|, edgelets |grad^T e| (floats).
+// One table of (tables, edge count) per window, blockIdx.y = window.
+struct MadWin { const hso_se3* poses; const double* idist; const hso_ba_edge* edges; const double* uv; float* err; int n_edges, pad_; };
+
+__global__ __launch_bounds__(BA_THREADS) void k_ba_mad_errors(const MadWin* wins)
+{
+  const MadWin W = wins[blockIdx.y];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < W.n_edges; k += gridDim.x * blockDim.x) {
+    const hso_ba_edge e = W.edges[k];
+    const Se3 Tth = se3_mul(se3_from(W.poses[e.target]), se3_inverse(se3_from(W.poses[e.host])));
+    const double inv = 1.0 / W.idist[e.point];
+    double x, y, z;
+    se3_apply(Tth, e.fH[0] * inv, e.fH[1] * inv, e.fH[2] * inv, x, y, z);
+    double ex = W.uv[2 * k] - x / z, ey = W.uv[2 * k + 1] - y / z;
+    const double sc = 1.0 / (double)(1 << e.level);
+    ex *= sc; ey *= sc;
+    W.err[k] = (e.type == HSO_FTR_EDGELET) ? (float)fabs(e.normal[0] * ex + e.normal[1] * ey) : (float)sqrt(ex * ex + ey * ey);
+  }
+}
+
+// All windows of a step in one upload, one launch, one read-back and one synchronisation (a keyframe step of a bank of sequences
+// asks for two dozen windows' deltas; one call each was two dozen host round trips).
+extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job* jobs, int n_jobs, double error_multiplier2)
 {
   if (!ctx) return HSO_E_INVALID;
-  if (!poses_f_w || !idist || !huber_corner || !huber_edge || n_poses <= 0 || n_points <= 0 || n_edges < 0 ||
-      (n_edges > 0 && (!edges || !obs_uv)))
-    return hso_fail(ctx, HSO_E_INVALID, "ba_huber_deltas: bad argument");
-  *huber_corner = 0; *huber_edge = 0;
-  if (n_edges == 0) return HSO_OK;   // both error lists empty: the reference leaves the deltas uninitialised
-  if (int rc = ba_check_edges(ctx, edges, n_edges, n_points, n_poses, "ba_huber_deltas")) return rc;
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return hso_fail(ctx, HSO_E_INVALID, "ba_huber_deltas: bad argument");
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  size_t o = 0;
-  const size_t o_poses = o; o += al(sizeof(hso_se3) * n_poses);
-  const size_t o_idist = o; o += al(sizeof(double) * n_points);
-  const size_t o_edges = o; o += al(sizeof(hso_ba_edge) * n_edges);
-  const size_t o_uv = o; o += al(sizeof(double) * 2 * n_edges);
+  struct Lay { size_t o_poses, o_idist, o_edges, o_uv, o_err; };
+  std::vector<Lay> lay((size_t)n_jobs);
+  std::vector<int> live;
+  size_t o = al(sizeof(MadWin) * (size_t)std::max(n_jobs, 1));
+  int max_edges = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    hso_ba_deltas_job& J = jobs[j];
+    if (!J.poses_f_w || !J.idist || J.n_poses <= 0 || J.n_points <= 0 || J.n_edges < 0 || (J.n_edges > 0 && (!J.edges || !J.obs_uv)))
+      return hso_fail(ctx, HSO_E_INVALID, "ba_huber_deltas: bad argument");
+    J.huber_corner = 0; J.huber_edge = 0;
+    if (J.n_edges == 0) continue;   // both error lists empty: the reference leaves the deltas uninitialised
+    if (int rc = ba_check_edges(ctx, J.edges, J.n_edges, J.n_points, J.n_poses, "ba_huber_deltas")) return rc;
+    Lay& L = lay[(size_t)j];
+    L.o_poses = o; o += al(sizeof(hso_se3) * (size_t)J.n_poses);
+    L.o_idist = o; o += al(sizeof(double) * (size_t)J.n_points);
+    L.o_edges = o; o += al(sizeof(hso_ba_edge) * (size_t)J.n_edges);
+    L.o_uv = o; o += al(sizeof(double) * 2 * (size_t)J.n_edges);
+    live.push_back(j); max_edges = std::max(max_edges, (int)J.n_edges);
+  }
+  if (live.empty()) return HSO_OK;
   const size_t in_bytes = o;
-  const size_t o_err = o; o += al(sizeof(float) * n_edges);
+  for (int j : live) { lay[(size_t)j].o_err = o; o += al(sizeof(float) * (size_t)jobs[j].n_edges); }
+  const size_t err_bytes = o - in_bytes;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (ctx->batch_cap < o) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -925,34 +975,60 @@ extern "C" int hso_gpu_ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses_f_
   }
   char* d = reinterpret_cast<char*>(ctx->d_batch);
   char* h = hso_pinned(ctx, 0, in_bytes);
-  if (!h) return HSO_E_NOMEM;
-  memcpy(h + o_poses, poses_f_w, sizeof(hso_se3) * n_poses);
-  memcpy(h + o_idist, idist, sizeof(double) * n_points);
-  memcpy(h + o_edges, edges, sizeof(hso_ba_edge) * n_edges);
-  memcpy(h + o_uv, obs_uv, sizeof(double) * 2 * n_edges);
+  char* he = hso_pinned(ctx, 1, err_bytes);
+  if (!h || !he) return HSO_E_NOMEM;
+  MadWin* hw = reinterpret_cast<MadWin*>(h);
+  for (size_t w = 0; w < live.size(); w++) {
+    const hso_ba_deltas_job& J = jobs[live[w]];
+    const Lay& L = lay[(size_t)live[w]];
+    memcpy(h + L.o_poses, J.poses_f_w, sizeof(hso_se3) * (size_t)J.n_poses);
+    memcpy(h + L.o_idist, J.idist, sizeof(double) * (size_t)J.n_points);
+    memcpy(h + L.o_edges, J.edges, sizeof(hso_ba_edge) * (size_t)J.n_edges);
+    memcpy(h + L.o_uv, J.obs_uv, sizeof(double) * 2 * (size_t)J.n_edges);
+    hw[w].poses = reinterpret_cast<const hso_se3*>(d + L.o_poses); hw[w].idist = reinterpret_cast<const double*>(d + L.o_idist);
+    hw[w].edges = reinterpret_cast<const hso_ba_edge*>(d + L.o_edges); hw[w].uv = reinterpret_cast<const double*>(d + L.o_uv);
+    hw[w].err = reinterpret_cast<float*>(d + L.o_err); hw[w].n_edges = J.n_edges; hw[w].pad_ = 0;
+  }
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_ba_mad_errors, dim3((n_edges + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, ctx->stream,
-                     reinterpret_cast<const hso_se3*>(d + o_poses), reinterpret_cast<const double*>(d + o_idist),
-                     reinterpret_cast<const hso_ba_edge*>(d + o_edges), reinterpret_cast<const double*>(d + o_uv), n_edges,
-                     reinterpret_cast<float*>(d + o_err));
+  hipLaunchKernelGGL(k_ba_mad_errors, dim3((max_edges + BA_THREADS - 1) / BA_THREADS, (unsigned)live.size()), dim3(BA_THREADS), 0, ctx->stream,
+                     reinterpret_cast<const MadWin*>(d));
   HSO_HIP_CHECK(ctx, hipGetLastError());
-  std::vector<float> err(n_edges);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(err.data(), d + o_err, sizeof(float) * n_edges, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(he, d + in_bytes, err_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<float> errors_pt, errors_ls;
-  for (int k = 0; k < n_edges; k++) (edges[k].type == HSO_FTR_EDGELET ? errors_ls : errors_pt).push_back(err[k]);
-  // src/bundle_adjustment.cpp:664-680
-  if (!errors_pt.empty() && !errors_ls.empty()) {
-    *huber_corner = (float)(1.4826 * upper_median(errors_pt));
-    *huber_edge = (float)(1.4826 * upper_median(errors_ls));
-  } else if (errors_pt.empty() && !errors_ls.empty()) {
-    *huber_corner = (float)(1.0 / error_multiplier2);
-    *huber_edge = (float)(1.4826 * upper_median(errors_ls));
-  } else if (!errors_pt.empty() && errors_ls.empty()) {
-    *huber_corner = (float)(1.4826 * upper_median(errors_pt));
-    *huber_edge = (float)(0.5 / error_multiplier2);
+  for (int j : live) {
+    hso_ba_deltas_job& J = jobs[j];
+    const float* err = reinterpret_cast<const float*>(he + (lay[(size_t)j].o_err - in_bytes));
+    errors_pt.clear(); errors_ls.clear();
+    for (int k = 0; k < J.n_edges; k++) (J.edges[k].type == HSO_FTR_EDGELET ? errors_ls : errors_pt).push_back(err[k]);
+    // src/bundle_adjustment.cpp:664-680
+    if (!errors_pt.empty() && !errors_ls.empty()) {
+      J.huber_corner = (float)(1.4826 * upper_median(errors_pt));
+      J.huber_edge = (float)(1.4826 * upper_median(errors_ls));
+    } else if (errors_pt.empty() && !errors_ls.empty()) {
+      J.huber_corner = (float)(1.0 / error_multiplier2);
+      J.huber_edge = (float)(1.4826 * upper_median(errors_ls));
+    } else if (!errors_pt.empty() && errors_ls.empty()) {
+      J.huber_corner = (float)(1.4826 * upper_median(errors_pt));
+      J.huber_edge = (float)(0.5 / error_multiplier2);
+    }
   }
   return HSO_OK;
+}
+
+extern "C" int hso_gpu_ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, int n_poses, const double* idist, int n_points,
+                                       const hso_ba_edge* edges, const double* obs_uv, int n_edges, double error_multiplier2,
+                                       float* huber_corner, float* huber_edge)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!huber_corner || !huber_edge) return hso_fail(ctx, HSO_E_INVALID, "ba_huber_deltas: bad argument");
+  hso_ba_deltas_job J;
+  J.poses_f_w = poses_f_w; J.n_poses = n_poses; J.idist = idist; J.n_points = n_points; J.edges = edges; J.obs_uv = obs_uv; J.n_edges = n_edges;
+  J.huber_corner = 0; J.huber_edge = 0;
+  *huber_corner = 0; *huber_edge = 0;
+  const int rc = hso_gpu_ba_huber_deltas_multi(ctx, &J, 1, error_multiplier2);
+  if (rc == HSO_OK) { *huber_corner = J.huber_corner; *huber_edge = J.huber_edge; }
+  return rc;
 }
 
 // ---- g2o::SE3Quat on the host (thirdparty/g2o/g2o/types/se3quat.h): the pose update of VertexSE3Expmap ----
@@ -973,7 +1049,6 @@ struct BaLm {
   hso_se3* poses_f_w; const uint8_t* pose_fixed; double* idist;
   int n_poses, n_points, n_edges, n_iter;
   double* edge_chi2_out; hso_ba_result* result;
-  std::vector<double> Hpp_h, Hcc_h;
   double lambda, ni, currentChi, tempChi, iniChi, rho;
   int nBad, stop, it, qmax;
   bool need_restore;
@@ -986,7 +1061,6 @@ struct BaLm {
   void begin()   // runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()
   {
     memset(result, 0, sizeof(*result));
-    Hpp_h.assign(n_points, 0.0); Hcc_h.assign((size_t)n_poses * n_poses * 36, 0.0);
     lambda = -1.; ni = 2.; nBad = 0; stop = 0; it = 0; qmax = 0; rho = 0; currentChi = tempChi = iniChi = 0; need_restore = false;
     st = INIT_WAIT; want = W_ERRORS;
   }
@@ -1008,12 +1082,8 @@ struct BaLm {
         result->final_chi2 = out_sum()[0];
         currentChi = out_sum()[1]; tempChi = currentChi;
         iniChi = currentChi;
-        if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices
-          double maxDiagonal = 0.;
-          for (int p = 0; p < n_points; p++) maxDiagonal = std::max(std::fabs(Hpp_h[p]), maxDiagonal);
-          for (int i = 0; i < n_poses; i++)
-            if (!pose_fixed[i]) for (int q = 0; q < 6; q++) maxDiagonal = std::max(std::fabs(Hcc_h[((size_t)i * n_poses + i) * 36 + q * 7]), maxDiagonal);
-          lambda = 1e-5 * maxDiagonal;
+        if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices (k_ba_maxdiag)
+          lambda = 1e-5 * out_sum()[5];
           ni = 2; nBad = 0;
         }
         rho = 0; qmax = 0;
@@ -1134,21 +1204,15 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
     // --- results
     // the sums of every window in one copy (windows that did nothing this round keep their old values, nobody reads them)
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_sums, Q.d_sums, sizeof(double) * 8 * (size_t)n_problems, hipMemcpyDeviceToHost, ctx->stream));
-    for (int q : w_lin) {
-      const BaWin& B = Q.win[q];
-      int rc = HSO_OK;
-      if (!rc && lm[q].it == 0) rc = ba_get(Q, q, lm[q].Hpp_h.data(), B.o_Hpp, sizeof(double) * B.n_points);
-      if (!rc && lm[q].it == 0) rc = ba_get(Q, q, lm[q].Hcc_h.data(), B.o_Hcc, sizeof(double) * lm[q].Hcc_h.size());
-      if (rc) return rc;
-    }
+    // the windows that finished this round hand back their state: every table of every such window in one DMA
+    std::vector<HsoListCopy> back;
     for (int q : w_final) {
       const BaWin& B = Q.win[q];
-      int rc = ba_get(Q, q, lm[q].idist, B.o_idist, sizeof(double) * B.n_points);
-      if (!rc) rc = ba_get(Q, q, lm[q].poses_f_w, B.o_poses, sizeof(hso_se3) * B.n_poses);
-      if (!rc && lm[q].edge_chi2_out) rc = ba_get(Q, q, lm[q].edge_chi2_out, B.o_chi, sizeof(double) * B.n_edges);
-      if (rc) return rc;
+      back.push_back({lm[q].idist, B.d + B.o_idist, sizeof(double) * (size_t)B.n_points});
+      back.push_back({lm[q].poses_f_w, B.d + B.o_poses, sizeof(hso_se3) * (size_t)B.n_poses});
+      if (lm[q].edge_chi2_out) back.push_back({lm[q].edge_chi2_out, B.d + B.o_chi, sizeof(double) * (size_t)B.n_edges});
     }
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = hso_lists_to_host(ctx, back)) return rc;   // synchronises (also when there is nothing to read back)
     for (int q = 0; q < n_problems; q++) if (lm[q].want != BaLm::W_NONE) lm[q].advance();
   }
   return HSO_OK;

@@ -72,7 +72,16 @@ struct hso_gpu_ctx {
   // instead of the pageable-memory rate, and the per-call std::vector + page faults disappear
   char* h_pin[2]; size_t h_pin_cap[2];
   std::vector<void*> host_allocs;   // hso_gpu_host_alloc
+  // hso_lists_to_host: the packed image of many short device lists (device side, page-locked host side), grow-only
+  char* d_pack; size_t d_pack_cap;
+  char* h_pack; size_t h_pack_cap;
 };
+
+// Many short device lists (per frame and level: corners, edgelets ...) to caller memory in ONE DMA: a gather kernel packs them back
+// to back, one copy brings the image to page-locked memory, the pieces are copied out from there.  One copy per list costs ~10 us
+// of launch + DMA set-up each; a keyframe step of 24 sequences reads 240 lists.  Synchronises the context's stream.
+struct HsoListCopy { void* dst; const void* src; size_t bytes; };   // bytes: a multiple of 4, src 4-byte aligned
+int hso_lists_to_host(hso_gpu_ctx* ctx, const std::vector<HsoListCopy>& lists);
 
 // ---- host memory and the runtime's copy calls -----------------------------------------------------------------------------
 // The entry points accept any host pointer.  Handing PAGEABLE caller memory to hipMemcpyAsync is not harmless on this stack: the
@@ -90,6 +99,7 @@ hipError_t hso_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKin
 hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind,
                             hipStream_t stream);
 hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t hso_memset_async(void* dst, int value, size_t bytes, hipStream_t stream);   // counted (hso_gpu_debug_census)
 hipError_t hso_stream_sync(hipStream_t stream);
 void hso_stream_forget(hipStream_t stream);   // context teardown: free the stream's staging chunks
 void hso_stream_abandon(hipStream_t stream);  // error path: wait for the stream, then DROP the pending copies into caller memory
@@ -100,6 +110,7 @@ void hso_stream_abandon(hipStream_t stream);  // error path: wait for the stream
   hso_copy2d_async((dst), (dpitch), (src), (spitch), (width), (height), (kind), (stream))
 #define hipMemcpy(dst, src, bytes, kind) hso_copy_sync((dst), (src), (bytes), (kind))
 #define hipStreamSynchronize(stream) hso_stream_sync(stream)
+#define hipMemsetAsync(dst, value, bytes, stream) hso_memset_async((dst), (value), (bytes), (stream))
 #endif
 
 #define HSO_HIP_CHECK(ctx, expr)                                              \

@@ -3,6 +3,8 @@
 #define HSO_RAW_HIP_COPIES          // this file implements the copy wrappers: it alone calls the runtime's copy functions
 #include "hso_ctx.h"
 #include <string.h>
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <unordered_set>
 #include <vector>
@@ -42,10 +44,22 @@ char* stage_alloc(Stager& S, size_t bytes)
 }
 }  // namespace
 
+// developer census (hso_gpu_debug_census): what the library asked of the runtime since the process started
+static std::atomic<int64_t> g_census[HSO_CENSUS_N];
+static inline void census(int what, int64_t by = 1) { g_census[what].fetch_add(by, std::memory_order_relaxed); }
+
+hipError_t hso_memset_async(void* dst, int value, size_t bytes, hipStream_t stream)
+{
+  census(HSO_CENSUS_MEMSETS);
+  return hipMemsetAsync(dst, value, bytes, stream);
+}
+
 hipError_t hso_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream)
 {
   if (bytes == 0) return hipSuccess;
+  census(HSO_CENSUS_COPIES); census(HSO_CENSUS_COPY_BYTES, (int64_t)bytes);
   if (kind == hipMemcpyHostToDevice && !host_is_page_locked(src)) {
+    census(HSO_CENSUS_STAGED);
     std::lock_guard<std::mutex> lk(g_stage_mutex);
     char* p = stage_alloc(g_stagers[stream], bytes);
     if (!p) return hipErrorOutOfMemory;
@@ -53,6 +67,7 @@ hipError_t hso_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKin
     return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, stream);
   }
   if (kind == hipMemcpyDeviceToHost && !host_is_page_locked(dst)) {
+    census(HSO_CENSUS_STAGED);
     std::lock_guard<std::mutex> lk(g_stage_mutex);
     Stager& S = g_stagers[stream];
     char* p = stage_alloc(S, bytes);
@@ -67,6 +82,7 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
                             hipStream_t stream)
 {
   if (width == 0 || height == 0) return hipSuccess;
+  census(HSO_CENSUS_COPIES); census(HSO_CENSUS_COPY_BYTES, (int64_t)(width * height));
   if (kind == hipMemcpyDeviceToHost && !host_is_page_locked(dst)) {   // rows packed in the chunk, spread out after the synchronisation
     std::lock_guard<std::mutex> lk(g_stage_mutex);
     Stager& S = g_stagers[stream];
@@ -87,7 +103,10 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
 
 hipError_t hso_stream_sync(hipStream_t stream)
 {
+  const auto t0 = std::chrono::steady_clock::now();
   const hipError_t e = hipStreamSynchronize(stream);
+  census(HSO_CENSUS_SYNCS);
+  census(HSO_CENSUS_SYNC_NS, std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
   std::lock_guard<std::mutex> lk(g_stage_mutex);
   auto it = g_stagers.find(stream);
   if (it == g_stagers.end()) return e;
@@ -134,6 +153,7 @@ void hso_stream_forget(hipStream_t stream)
 #define hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream) \
   hso_copy2d_async((dst), (dpitch), (src), (spitch), (width), (height), (kind), (stream))
 #define hipStreamSynchronize(stream) hso_stream_sync(stream)
+#define hipMemsetAsync(dst, value, bytes, stream) hso_memset_async((dst), (value), (bytes), (stream))
 
 // Every failing exit of an entry point ends here or in HSO_HIP_CHECK: device-to-host copies already enqueued into the CALLER's
 // memory (finished by the next synchronisation, hso_stream_sync) must not outlive the failed call — the caller may free its
@@ -233,6 +253,7 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   ctx->batch_cap = 0;
   ctx->h_pin[0] = ctx->h_pin[1] = nullptr;
   ctx->h_pin_cap[0] = ctx->h_pin_cap[1] = 0;
+  ctx->d_pack = nullptr; ctx->d_pack_cap = 0; ctx->h_pack = nullptr; ctx->h_pack_cap = 0;
   if (stream) {
     // "one context per stream" is enforced: the page-locked staging of a stream (chunks, copies waiting for its next
     // synchronisation) belongs to the one context that launches on it; two contexts on one stream, on different threads, would
@@ -271,6 +292,8 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   if (ctx->d_seed_scratch_async) (void)hipFree(ctx->d_seed_scratch_async);
   if (ctx->h_seed_pin) (void)hipHostFree(ctx->h_seed_pin);
   for (int k = 0; k < 2; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
+  if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+  if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   for (void* p : ctx->host_allocs) (void)hipHostFree(p);
   hso_stream_forget(ctx->stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -288,6 +311,60 @@ extern "C++" char* hso_pinned(hso_gpu_ctx* ctx, int slot, size_t bytes)
   ctx->h_pin[slot] = static_cast<char*>(p); ctx->h_pin_cap[slot] = cap;
   return ctx->h_pin[slot];
 }
+
+}  // extern "C"
+
+// ---- hso_lists_to_host ----
+struct ListRec { const uint32_t* src; uint64_t dst_word, n_words; };
+
+__global__ __launch_bounds__(256) void k_gather_lists(const ListRec* recs, uint32_t* out)
+{
+  const ListRec r = recs[blockIdx.y];
+  uint32_t* o = out + r.dst_word;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.n_words; i += (uint64_t)gridDim.x * blockDim.x) o[i] = r.src[i];
+}
+
+int hso_lists_to_host(hso_gpu_ctx* ctx, const std::vector<HsoListCopy>& lists)
+{
+  std::vector<const HsoListCopy*> live;
+  for (const HsoListCopy& c : lists) if (c.bytes > 0) live.push_back(&c);
+  if (live.empty()) { HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return HSO_OK; }
+  const size_t n = live.size();
+  const size_t tab = (sizeof(ListRec) * n + 255) & ~size_t(255);
+  size_t words = 0, longest = 0;
+  for (const HsoListCopy* c : live) {
+    if ((c->bytes & 3) || (reinterpret_cast<uintptr_t>(c->src) & 3)) return hso_fail(ctx, HSO_E_INVALID, "lists_to_host: list not in 4-byte units");
+    words += c->bytes / 4; longest = std::max(longest, c->bytes / 4);
+  }
+  const size_t need = tab + words * 4;
+  if (ctx->d_pack_cap < need || ctx->h_pack_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+    if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+    ctx->d_pack = nullptr; ctx->h_pack = nullptr; ctx->d_pack_cap = ctx->h_pack_cap = 0;
+    const size_t cap = hso_grown(need);
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_pack), cap));
+    ctx->d_pack_cap = cap;
+    HSO_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pack), cap, hipHostMallocDefault));
+    ctx->h_pack_cap = cap;
+  }
+  ListRec* hr = reinterpret_cast<ListRec*>(ctx->h_pack);
+  size_t at = 0;
+  for (size_t i = 0; i < n; i++) { hr[i].src = static_cast<const uint32_t*>(live[i]->src); hr[i].dst_word = at; hr[i].n_words = live[i]->bytes / 4; at += live[i]->bytes / 4; }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_pack, ctx->h_pack, sizeof(ListRec) * n, hipMemcpyHostToDevice, ctx->stream));
+  const unsigned gx = (unsigned)std::min<size_t>(16, (longest + 1023) / 1024);
+  for (size_t y0 = 0; y0 < n; y0 += 32768)     // blockIdx.y is a 16-bit quantity
+    hipLaunchKernelGGL(k_gather_lists, dim3(gx ? gx : 1, (unsigned)std::min<size_t>(32768, n - y0)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const ListRec*>(ctx->d_pack) + y0, reinterpret_cast<uint32_t*>(ctx->d_pack + tab));
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_pack + tab, ctx->d_pack + tab, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  at = 0;
+  for (size_t i = 0; i < n; i++) { memcpy(live[i]->dst, ctx->h_pack + tab + at, live[i]->bytes); at += live[i]->bytes; }
+  return HSO_OK;
+}
+
+extern "C" {
 
 const char* hso_gpu_last_error(const hso_gpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -313,6 +390,11 @@ int hso_gpu_host_free(hso_gpu_ctx* ctx, void* p)
       return HSO_OK;
     }
   return hso_fail(ctx, HSO_E_INVALID, "host_free: not an allocation of hso_gpu_host_alloc");
+}
+
+void hso_gpu_debug_census(int64_t* out, int n)
+{
+  for (int i = 0; i < n; i++) out[i] = i < HSO_CENSUS_N ? g_census[i].load(std::memory_order_relaxed) : 0;
 }
 
 int hso_gpu_synchronize(hso_gpu_ctx* ctx)

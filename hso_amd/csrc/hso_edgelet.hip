@@ -529,18 +529,16 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
   }
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(edgelet_counts, A.totals, sizeof(int) * (size_t)n_frames * n_levels, hipMemcpyDeviceToHost, ctx->stream));
-  const int rc2 = hso_fast_collect(ctx, P, corners, corner_counts);     // synchronises
+  std::vector<HsoListCopy> lists;
+  const int rc2 = hso_fast_collect(ctx, P, corners, corner_counts, &lists);     // synchronises: both count tables are on the host
   if (rc2 != HSO_OK) return rc2;
   for (int i = 0; i < n_frames && edgelet_cap > 0; i++)
     for (int l = 0; l < n_levels; l++) {
       const int c = edgelet_counts[(size_t)i * n_levels + l];
       const int n = c < edgelet_cap ? c : edgelet_cap;
-      if (n > 0)
-        HSO_HIP_CHECK(ctx, hipMemcpyAsync(edgelets + ((size_t)i * n_levels + l) * edgelet_cap, A.work + (size_t)i * slice + A.lv[l].o_out,
-                                          sizeof(hso_edgelet) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+      if (n > 0) lists.push_back({edgelets + ((size_t)i * n_levels + l) * edgelet_cap, A.work + (size_t)i * slice + A.lv[l].o_out, sizeof(hso_edgelet) * (size_t)n});
     }
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return HSO_OK;
+  return hso_lists_to_host(ctx, lists);     // corners and edgelets of every frame and level: one DMA
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -677,14 +675,12 @@ extern "C" int hso_gpu_detect_candidates_init(hso_gpu_ctx* ctx, const int64_t* f
   hipLaunchKernelGGL(k_fill_pack, dim3(n_frames), dim3(PACK_THREADS), 0, ctx->stream, F);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(fill_counts, F.out_totals, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
-  const int rc2 = hso_fast_collect(ctx, P, corners, corner_counts);     // synchronises
+  std::vector<HsoListCopy> lists;
+  const int rc2 = hso_fast_collect(ctx, P, corners, corner_counts, &lists);     // synchronises: both count tables are on the host
   if (rc2 != HSO_OK) return rc2;
   for (int i = 0; i < n_frames && fill_cap > 0; i++) {
     const int n = fill_counts[i] < fill_cap ? fill_counts[i] : fill_cap;
-    if (n > 0)
-      HSO_HIP_CHECK(ctx, hipMemcpyAsync(fill + (size_t)i * fill_cap, A.work + (size_t)i * slice + o_fout, sizeof(hso_corner) * (size_t)n,
-                                        hipMemcpyDeviceToHost, ctx->stream));
+    if (n > 0) lists.push_back({fill + (size_t)i * fill_cap, A.work + (size_t)i * slice + o_fout, sizeof(hso_corner) * (size_t)n});
   }
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return HSO_OK;
+  return hso_lists_to_host(ctx, lists);
 }

@@ -281,21 +281,22 @@ int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, i
   return hso_fast_launch(ctx, P, reinterpret_cast<const uint8_t* const*>(d + P.o_tab), threshold, border, 9);
 }
 
-int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& P, hso_corner* out, int32_t* counts)
+int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& P, hso_corner* out, int32_t* counts, std::vector<HsoListCopy>* more)
 {
   const int n_frames = P.n_frames, n_levels = P.n_levels, cap = P.cap;
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(counts, P.d + P.o_tot, sizeof(int) * (size_t)n_frames * n_levels, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // the corner lists of every frame and level (and whatever lists the caller reads back with them) in one DMA
+  std::vector<HsoListCopy> own;
+  std::vector<HsoListCopy>& L = more ? *more : own;
   for (int i = 0; i < n_frames && cap > 0; i++)
     for (int l = 0; l < n_levels; l++) {
       const int c = counts[(size_t)i * n_levels + l];
       const int n = c < cap ? c : cap;
-      if (n > 0)
-        HSO_HIP_CHECK(ctx, hipMemcpyAsync(out + ((size_t)i * n_levels + l) * cap, P.d + (size_t)i * P.per_frame + P.o_out[l],
-                                          sizeof(hso_corner) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+      if (n > 0) L.push_back({out + ((size_t)i * n_levels + l) * cap, P.d + (size_t)i * P.per_frame + P.o_out[l], sizeof(hso_corner) * (size_t)n});
     }
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return HSO_OK;
+  if (more) return HSO_OK;   // the caller adds its lists and runs hso_lists_to_host
+  return hso_lists_to_host(ctx, L);
 }
 
 extern "C" int hso_gpu_fast_detect_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold,

@@ -1,6 +1,7 @@
 // hso_fast_plan.h — the device-side layout the FAST stage leaves in ctx->d_batch, shared with the
 // stage chained behind it (hso_edgelet.hip) so the corner masks never leave the GPU.
 #pragma once
+#include <vector>
 #include "hso_ctx.h"
 
 #define FAST_TW 64
@@ -29,4 +30,6 @@ int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, i
 size_t hso_fast_plan(const PyrGeom& g, int n_frames, int n_levels, int cap, FastPlan* plan);
 int hso_fast_launch(hso_gpu_ctx* ctx, const FastPlan& plan, const uint8_t* const* d_bases, int threshold, int border, int arc);
 // counts (+ corners when cap > 0) to the host; synchronises the stream.
-int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& plan, hso_corner* out, int32_t* counts);
+// more != nullptr: the corner lists are appended to *more instead of being read back; the caller adds its own lists and runs
+// hso_lists_to_host once (one DMA for everything the call returns)
+int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& plan, hso_corner* out, int32_t* counts, std::vector<HsoListCopy>* more = nullptr);

@@ -56,6 +56,13 @@ Bank::~Bank()
             "local BA %.3f, seed observe %.3f, seed activate %.3f, new seeds %.3f, flush+finish %.3f\n", (long long)n_steps_, size(), (long long)n_kf_events_,
             phase_ms_[0] / n_steps_, phase_ms_[1] / n_steps_, phase_ms_[2] / n_steps_, phase_ms_[3] / n_steps_, phase_ms_[4] / n_steps_, phase_ms_[5] / n_steps_,
             phase_ms_[6] / n_steps_, phase_ms_[7] / n_steps_, phase_ms_[8] / n_steps_);
+  if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0) {
+    static const char* const names[9] = {"upload", "track", "reproject+select+pose", "decide", "local BA", "seed observe", "seed activate", "new seeds", "flush+finish"};
+    for (int k = 0; k < 9; k++)
+      fprintf(stderr, "[hso engine]   %-22s per step: %6.1f copies (%5.1f staged, %8.1f KB), %5.1f syncs (%.3f ms blocked), %5.1f memsets\n", names[k],
+              (double)phase_census_[k][0] / n_steps_, (double)phase_census_[k][2] / n_steps_, (double)phase_census_[k][1] / n_steps_ / 1024.0,
+              (double)phase_census_[k][3] / n_steps_, (double)phase_census_[k][4] / n_steps_ * 1e-6, (double)phase_census_[k][5] / n_steps_);
+  }
   if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0)
     fprintf(stderr, "[hso engine] reproject+select+pose = list points + patch maps %.3f, device call %.3f, apply %.3f\n", sub_ms_[0] / n_steps_, sub_ms_[1] / n_steps_,
             sub_ms_[2] / n_steps_);
@@ -67,7 +74,7 @@ Bank::~Bank()
   for (StepData* d : step_) delete d;
   if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);
   for (size_t k = 0; k < seq_.size(); k++) (void)k;
-  briefs_.release(); records_.release(); projected_.release(); mask_.release(); feat_f_.release(); track_tables_.release(); seed_brief_.release(); seed_px_.release();   // before the context goes
+  briefs_.release(); records_.release(); projected_.release(); mask_.release(); feat_f_.release(); track_tables_.release(); seed_brief_.release(); seed_px_.release(); det_corners_.release(); det_fill_.release(); det_edgelets_.release();   // before the context goes
   if (owns_ctx_) hso_gpu_destroy(ctx_);
 }
 

@@ -223,6 +223,7 @@ private:
   bool sync_previous_ = false;     // HSO_ENGINE_SYNC_PREVIOUS=1: the pass runs inside the step (tests compare both modes)
   std::vector<int64_t> to_release_;
   double phase_ms_[9] = {0};
+  int64_t phase_census_[9][6] = {{0}};   // per phase: copies, bytes, staged copies, synchronisations, ns blocked in them, memsets
   int64_t n_steps_ = 0, n_kf_events_ = 0;
   // result tables of the batched calls (kept between steps: no allocation per step)
   Pinned<hso_match_brief> briefs_;   // recorded runs only: the full records of the examined candidates
@@ -231,6 +232,9 @@ private:
   Pinned<double> feat_f_, track_tables_;
   Pinned<hso_seed_brief> seed_brief_;
   Pinned<float> seed_px_;
+  Pinned<hso_corner> det_corners_, det_fill_;   // detect(): the candidate lists of a step's new keyframes
+  Pinned<hso_edgelet> det_edgelets_;
+  int det_corner_cap_ = 8192;                   // corners per (frame, level) the lists hold; grows when a frame has more
 };
 
 }  // namespace engine

@@ -69,11 +69,22 @@ void Bank::keyframe_ba(const std::vector<int>& who)
   const double fmean = cam_.errorMultiplier2();
   std::vector<std::vector<hso_se3>> poses_in(with.size());
   std::vector<std::vector<double>> idist_in(with.size());
+  {
+    // the Huber deltas of every window of the step in one device call
+    std::vector<hso_ba_deltas_job> dj(with.size());
+    for (size_t i = 0; i < with.size(); i++) {
+      StepData& d = *step_[with[i]];
+      hso_ba_deltas_job& j = dj[i];
+      j = hso_ba_deltas_job{};
+      j.poses_f_w = d.ba_poses.data(); j.n_poses = (int)d.ba_poses.size(); j.idist = d.ba_idist.data(); j.n_points = (int)d.ba_idist.size();
+      j.edges = d.ba_edges.data(); j.obs_uv = d.ba_uv.data(); j.n_edges = (int)d.ba_edges.size();
+    }
+    if (!with.empty()) check(hso_gpu_ba_huber_deltas_multi(ctx_, dj.data(), (int)dj.size(), fmean), "LocalBundleAdjustment");
+    for (size_t i = 0; i < with.size(); i++) { step_[with[i]]->huber_corner = dj[i].huber_corner; step_[with[i]]->huber_edge = dj[i].huber_edge; }
+  }
   for (size_t i = 0; i < with.size(); i++) {
     Seq& s = *seq_[with[i]];
     StepData& d = *step_[with[i]];
-    check(hso_gpu_ba_huber_deltas(ctx_, d.ba_poses.data(), (int)d.ba_poses.size(), d.ba_idist.data(), (int)d.ba_idist.size(), d.ba_edges.data(),
-                                  d.ba_uv.data(), (int)d.ba_edges.size(), fmean, &d.huber_corner, &d.huber_edge), "LocalBundleAdjustment");
     if (s.trace.on()) {
       Trace& t = s.trace;
       t.begin("ba_huber_deltas", 7);
@@ -531,24 +542,27 @@ void Bank::detect(const std::vector<int>& who, const std::vector<Id>& frame, con
     std::vector<int64_t> ids;
     for (int i : grp) ids.push_back(seq_[who[i]]->frames[frame[i]].dev_id);
     const int n = (int)grp.size();
-    int corner_cap = 16384;
-    std::vector<hso_corner> co, fill; std::vector<hso_edgelet> ed;
+    // the result tables are the bank's own page-locked arrays, kept between keyframes (fresh pageable vectors of this size cost
+    // more in first-touch page faults and staging copies than the detection itself)
+    int corner_cap = det_corner_cap_;
     std::vector<int32_t> nc((size_t)n * n_levels), ns((size_t)n * (init ? 1 : n_levels));
-    if (init) fill.resize((size_t)n * second_cap); else ed.resize((size_t)n * n_levels * second_cap);
+    hso_corner* fill = init ? det_fill_.need(ctx_, (size_t)n * second_cap) : nullptr;
+    hso_edgelet* ed = init ? nullptr : det_edgelets_.need(ctx_, (size_t)n * n_levels * second_cap);
+    hso_corner* co = nullptr;
     for (;;) {
-      co.resize((size_t)n * n_levels * corner_cap);
-      const int rc = init ? hso_gpu_detect_candidates_init(ctx_, ids.data(), n, n_levels, th, co.data(), corner_cap, nc.data(), fill.data(), second_cap, ns.data())
-                          : hso_gpu_detect_candidates(ctx_, ids.data(), n, n_levels, th, co.data(), corner_cap, nc.data(), ed.data(), second_cap, ns.data());
+      co = det_corners_.need(ctx_, (size_t)n * n_levels * corner_cap);
+      const int rc = init ? hso_gpu_detect_candidates_init(ctx_, ids.data(), n, n_levels, th, co, corner_cap, nc.data(), fill, second_cap, ns.data())
+                          : hso_gpu_detect_candidates(ctx_, ids.data(), n, n_levels, th, co, corner_cap, nc.data(), ed, second_cap, ns.data());
       check(rc, "FeatureExtractor");
       n_calls_[9]++; n_items_[9] += n;
       const int most = *std::max_element(nc.begin(), nc.end());
       if (most <= corner_cap) break;
-      corner_cap = most;                                          // more corners than the first guess: once more with room for all
+      corner_cap = det_corner_cap_ = most + most / 4;             // more corners than the lists hold: once more with room for all
     }
     pool_->run(n, [&](int g) {
       const int i = grp[g];
       Seq& s = *seq_[who[i]];
-      const hso_corner* cg = co.data() + (size_t)g * n_levels * corner_cap;
+      const hso_corner* cg = co + (size_t)g * n_levels * corner_cap;
       const int32_t* ncg = nc.data() + (size_t)g * n_levels;
       if (s.trace.on()) {
         Trace& t = s.trace;
@@ -557,12 +571,12 @@ void Bank::detect(const std::vector<int>& who, const std::vector<Id>& frame, con
         t.field("corner_counts", ncg, sizeof(int32_t) * (size_t)n_levels);
         for (int L = 0; L < n_levels; L++) t.field(("corners" + std::to_string(L)).c_str(), cg + (size_t)L * corner_cap, sizeof(hso_corner) * (size_t)ncg[L]);
         if (init) {
-          t.field("fill", fill.data() + (size_t)g * second_cap, sizeof(hso_corner) * (size_t)ns[g]);
+          t.field("fill", fill + (size_t)g * second_cap, sizeof(hso_corner) * (size_t)ns[g]);
           for (int L = 1; L < n_levels; L++) t.field("unused", nullptr, 0);
           t.field("second_counts", &ns[g], sizeof(int32_t));
         } else {
           for (int L = 0; L < n_levels; L++)
-            t.field(("edgelets" + std::to_string(L)).c_str(), ed.data() + ((size_t)g * n_levels + L) * second_cap, sizeof(hso_edgelet) * (size_t)ns[(size_t)g * n_levels + L]);
+            t.field(("edgelets" + std::to_string(L)).c_str(), ed + ((size_t)g * n_levels + L) * second_cap, sizeof(hso_edgelet) * (size_t)ns[(size_t)g * n_levels + L]);
           t.field("second_counts", &ns[(size_t)g * n_levels], sizeof(int32_t) * (size_t)n_levels);
         }
       }

@@ -8,11 +8,22 @@ namespace engine {
 
 namespace {
 // developer probe (HSO_ENGINE_TIMING=1): wall time per phase of a step, printed when the bank goes away
+// and what the device library asked of the runtime meanwhile (hso_gpu_debug_census; process-wide, so meaningful for one bank)
 struct Clock {
-  double* acc; bool on;
+  double* acc; int64_t (*cen)[6]; bool on;
   std::chrono::steady_clock::time_point t;
-  Clock(double* a, bool o) : acc(a), on(o) { if (on) t = std::chrono::steady_clock::now(); }
-  void lap(int k) { if (!on) return; const auto u = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::milli>(u - t).count(); t = u; }
+  int64_t c0[6];
+  Clock(double* a, int64_t (*c)[6], bool o) : acc(a), cen(c), on(o) { if (on) { t = std::chrono::steady_clock::now(); hso_gpu_debug_census(c0, 6); } }
+  void lap(int k)
+  {
+    if (!on) return;
+    const auto u = std::chrono::steady_clock::now();
+    acc[k] += std::chrono::duration<double, std::milli>(u - t).count();
+    int64_t c1[6];
+    hso_gpu_debug_census(c1, 6);
+    for (int i = 0; i < 6; i++) { cen[k][i] += c1[i] - c0[i]; c0[i] = c1[i]; }
+    t = std::chrono::steady_clock::now();
+  }
 };
 }  // namespace
 
@@ -54,7 +65,7 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
   for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
   to_release_.clear();
 
-  Clock ck(phase_ms_, getenv("HSO_ENGINE_TIMING") != nullptr);
+  Clock ck(phase_ms_, phase_census_, getenv("HSO_ENGINE_TIMING") != nullptr);
   upload(who, imgs, w, h, stamps, on_device);
   ck.lap(0);
   std::vector<int> starting, running;

@@ -487,6 +487,14 @@ int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, const uint8
 int hso_gpu_ba_huber_deltas(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, int n_poses, const double* idist, int n_points,
                             const hso_ba_edge* edges, const double* obs_uv, int n_edges, double error_multiplier2,
                             float* huber_corner, float* huber_edge);
+/* The same for the windows of many sequences in one call (one upload, one launch, one read-back): huber_corner / huber_edge of
+ * every job are written; a job with n_edges == 0 gets 0 / 0. */
+typedef struct hso_ba_deltas_job {
+  const hso_se3* poses_f_w; const double* idist; const hso_ba_edge* edges; const double* obs_uv;
+  int32_t n_poses, n_points, n_edges;
+  float huber_corner, huber_edge;   /* out */
+} hso_ba_deltas_job;
+int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job* jobs, int n_jobs, double error_multiplier2);
 
 /* What runSparseBAOptimizer (src/bundle_adjustment.cpp:351-361) leaves behind. */
 typedef struct hso_ba_result {
@@ -809,6 +817,12 @@ int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_camera* cam
  * HSO_DBG_POSE_POSES = n_frames rows of 128 hso_se3, HSO_DBG_POSE_NPOSES = n_frames int32.  bytes must equal the table's size. */
 enum { HSO_DBG_PROJ = 0, HSO_DBG_MATCH = 1, HSO_DBG_POSE_FEATS = 2, HSO_DBG_POSE_POSES = 3, HSO_DBG_POSE_NPOSES = 4 };
 int hso_gpu_debug_fetch(hso_gpu_ctx* ctx, int what, void* out, size_t bytes);
+/* developer census: what the library has asked of the HIP runtime since the process started (all contexts): copies enqueued, their
+ * bytes, copies that went through page-locked staging because the caller's memory was pageable, stream synchronisations, nanoseconds
+ * the calling threads spent blocked in them, memsets.  out[i] for i < n; entries beyond HSO_CENSUS_N read 0.  A driver that
+ * differences it around its phases sees where the host round trips of a step are (hso_amd/host: HSO_ENGINE_TIMING=1). */
+enum { HSO_CENSUS_COPIES = 0, HSO_CENSUS_COPY_BYTES = 1, HSO_CENSUS_STAGED = 2, HSO_CENSUS_SYNCS = 3, HSO_CENSUS_SYNC_NS = 4, HSO_CENSUS_MEMSETS = 5, HSO_CENSUS_N = 6 };
+void hso_gpu_debug_census(int64_t* out, int n);
 
 /* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
  *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,

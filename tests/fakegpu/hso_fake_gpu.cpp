@@ -312,6 +312,8 @@ int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* c, const hso_camera* cam, 
   return n_out;
 }
 
+void hso_gpu_debug_census(int64_t* out, int n) { for (int i = 0; i < n; i++) out[i] = 0; }   // no runtime underneath
+
 int hso_gpu_debug_fetch(hso_gpu_ctx* c, int what, void* out, size_t bytes)
 {
   const void* src = nullptr; size_t have = 0;
@@ -505,6 +507,14 @@ int hso_gpu_ba_huber_deltas(hso_gpu_ctx*, const hso_se3* poses, int n_poses, con
                             int n_edges, double em2, float* hc, float* he)
 {
   hso_or_ba_huber_deltas(poses, n_poses, idist, n_points, edges, obs_uv, n_edges, em2, hc, he);
+  return HSO_OK;
+}
+int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx*, hso_ba_deltas_job* j, int n, double em2)
+{
+  for (int i = 0; i < n; i++) {
+    j[i].huber_corner = 0; j[i].huber_edge = 0;
+    if (j[i].n_edges > 0) hso_or_ba_huber_deltas(j[i].poses_f_w, j[i].n_poses, j[i].idist, j[i].n_points, j[i].edges, j[i].obs_uv, j[i].n_edges, em2, &j[i].huber_corner, &j[i].huber_edge);
+  }
   return HSO_OK;
 }
 int hso_gpu_ba_optimize_multi(hso_gpu_ctx*, const hso_ba_problem* p, int n)
