@@ -328,7 +328,8 @@ extern "C" int hso_gpu_reproject_select(hso_gpu_ctx* ctx, const int32_t* frame_b
 
 // the projected points of one call, in point order, as the candidate tables of k_select; cand_pt = candidate -> record
 __global__ __launch_bounds__(SEL_THREADS) void k_sel_gather(const hso_reproj_point* proj, const hso_match_brief* brief, const int* begin,
-                                                           int32_t* cell, uint8_t* quality, uint8_t* flags, int32_t* cand_pt, int* n_cand)
+                                                           int32_t* cell, uint8_t* quality, uint8_t* flags, int32_t* cand_pt, int* n_cand,
+                                                           uint8_t* projected_out)
 {
   __shared__ int s_wave[SEL_WAVES];
   const int c = blockIdx.x, b = begin[c], e = begin[c + 1];
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_gather(const hso_reproj_poi
   for (int i0 = b; i0 < e; i0 += SEL_THREADS) {
     const int i = i0 + (int)threadIdx.x;
     const int is = (i < e && proj[i].projected) ? 1 : 0;
+    if (projected_out && i < e) projected_out[i] = (uint8_t)is;   // reprojectPoint's return value per listed point, for the caller
     int tot;
     const int pos = sel_block_scan(is, s_wave, tot) + carry - is;
     if (is) {
@@ -501,7 +503,7 @@ static int reproject_select_maps_impl(hso_gpu_ctx* ctx, const hso_camera* cam, c
   const int* d_begin = reinterpret_cast<const int*>(d + o_begin);
   hipLaunchKernelGGL(k_sel_gather, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_proj, R.d_brief, d_begin,
                      reinterpret_cast<int32_t*>(d + o_cell), reinterpret_cast<uint8_t*>(d + o_q), reinterpret_cast<uint8_t*>(d + o_f),
-                     reinterpret_cast<int32_t*>(d + o_pt), reinterpret_cast<int*>(d + o_ncand));
+                     reinterpret_cast<int32_t*>(d + o_pt), reinterpret_cast<int*>(d + o_ncand), static_cast<uint8_t*>(nullptr));
   SelArgs A;
   A.cell = reinterpret_cast<const int32_t*>(d + o_cell); A.quality = reinterpret_cast<const uint8_t*>(d + o_q);
   A.flags = reinterpret_cast<const uint8_t*>(d + o_f); A.cell_order = reinterpret_cast<const int32_t*>(d + o_order);
@@ -600,14 +602,50 @@ struct PoseSrcDev {
 
 #define SEL_KF_WORDS 64         // 4096 keyframes per sequence map take part in the compaction bitmask
 
-__global__ __launch_bounds__(SEL_THREADS) void k_pose_feats_from_list(hso_camera cam, const hso_match_brief* out, const int* offs, const PoseSrcDev* src,
-                                                                     const int32_t* ids, const uint8_t* quality, int feat_cap, hso_pose_feat* feats,
-                                                                     PoseJobDev* jobs, hso_se3* poses_out, int* n_poses_out, double* feat_f, int* n_feats)
+// One workgroup per frame finishes what the selection left: (1) where the frame's examined records start in the packed output —
+// the sum of the earlier frames' counts, a few hundred integers at most, so every workgroup forms its own instead of waiting for a
+// one-thread prefix kernel; (2) the examined candidates' records, packed (k_sel_emit's work); (3) the frame's pose-optimisation
+// feature table from the records it has just written.  Three launches (offsets, emit, features) were ~50 us of a 1.5 ms call.
+struct EmitArgs {
+  const hso_match_brief* brief; const int* begin; const int32_t* examined; const int32_t* cand_pt; const int* counts;
+  int* offs; hso_match_brief* out; hso_frame_match* records; int n_calls;
+};
+
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_emit_feats(EmitArgs E, hso_camera cam, const PoseSrcDev* src,
+                                                               const int32_t* ids, const uint8_t* quality, int feat_cap, hso_pose_feat* feats,
+                                                               PoseJobDev* jobs, hso_se3* poses_out, int* n_poses_out, double* feat_f, int* n_feats)
 {
   __shared__ int s_wave[SEL_WAVES];
   __shared__ unsigned long long s_used[SEL_KF_WORDS];
   __shared__ int s_base[SEL_KF_WORDS];
-  const int c = blockIdx.x, b = offs[c], e = offs[c + 1];
+  const int c = blockIdx.x;
+  int b, e;
+  {
+    int part = 0;
+    for (int q = threadIdx.x; q < c; q += SEL_THREADS) part += E.counts[4 * q];
+    int before;
+    (void)sel_block_scan(part, s_wave, before);
+    const int n_ex = E.counts[4 * c], lb = E.begin[c];
+    b = before; e = before + n_ex;
+    if (threadIdx.x == 0) { E.offs[c] = b; if (c == E.n_calls - 1) E.offs[E.n_calls] = e; }
+    for (int k = threadIdx.x; k < n_ex; k += SEL_THREADS) {
+      const int v = E.examined[lb + k];
+      const int g = E.cand_pt[lb + (v & 0x7fffffff)];
+      hso_match_brief r = E.brief[g];
+      r.success = (v < 0) ? 1 : 0;          // became a feature (a matched candidate the budget never reached stays 0)
+      r.pad_ = g - lb;                      // the point's index in its frame's list
+      E.out[b + k] = r;
+      if (E.records) {
+        hso_frame_match m;
+        m.px_cur[0] = r.px_cur[0]; m.px_cur[1] = r.px_cur[1]; m.grad[0] = r.grad[0]; m.grad[1] = r.grad[1];
+        m.point = r.pad_; m.success = r.success; m.search_level = r.search_level; m.ref_type = r.ref_type; m.pad_ = 0;
+        E.records[b + k] = m;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();                        // the records this workgroup wrote are what it reads below
+  }
+  const hso_match_brief* out = E.out;
   const PoseSrcDev S = src[c];
   hso_pose_feat* F = feats + (size_t)c * feat_cap;
   double* FF = feat_f ? feat_f + (size_t)c * feat_cap * 3 : nullptr;
@@ -660,12 +698,6 @@ __global__ __launch_bounds__(SEL_THREADS) void k_pose_feats_from_list(hso_camera
     if (idx < HSO_POSE_MAX_POSES) F[i].host_pose = idx;
     else { F[i].has_point = 0; F[i].host_pose = 0; }     // more host keyframes than the optimiser's table holds: the feature sits out
   }
-}
-
-__global__ void k_projected_flags(const hso_reproj_point* proj, int n, uint8_t* out)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = proj[i].projected ? 1 : 0;
 }
 
 extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_frame* frames, int n_calls, int cell_size,
@@ -787,24 +819,22 @@ extern "C" int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_
   const int* d_begin = reinterpret_cast<const int*>(d + o_begin);
   hipLaunchKernelGGL(k_sel_gather, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_proj, R.d_brief, d_begin,
                      reinterpret_cast<int32_t*>(d + o_cell), reinterpret_cast<uint8_t*>(d + o_q), reinterpret_cast<uint8_t*>(d + o_f),
-                     reinterpret_cast<int32_t*>(d + o_pt), reinterpret_cast<int*>(d + o_ncand));
+                     reinterpret_cast<int32_t*>(d + o_pt), reinterpret_cast<int*>(d + o_ncand), projected_out ? reinterpret_cast<uint8_t*>(d + o_flag) : nullptr);
   SelArgs A;
   A.cell = reinterpret_cast<const int32_t*>(d + o_cell); A.quality = reinterpret_cast<const uint8_t*>(d + o_q);
   A.flags = reinterpret_cast<const uint8_t*>(d + o_f); A.cell_order = reinterpret_cast<const int32_t*>(d + o_order);
   A.n_cells = n_cells; A.max_fts = max_fts;
   hipLaunchKernelGGL(k_select, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, A, reinterpret_cast<const SelFrame*>(d + o_frames));
-  hipLaunchKernelGGL(k_sel_offsets, dim3(1), dim3(64), 0, ctx->stream, n_calls, reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<int*>(d + o_offs));
-  hipLaunchKernelGGL(k_sel_emit, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, R.d_brief, d_begin, reinterpret_cast<const int32_t*>(d + o_exam),
-                     reinterpret_cast<const int32_t*>(d + o_pt), reinterpret_cast<const int*>(d + o_counts), reinterpret_cast<const int*>(d + o_offs),
-                     reinterpret_cast<hso_match_brief*>(d + o_out), pose->records ? reinterpret_cast<hso_frame_match*>(d + o_rec) : nullptr);
-  if (projected_out) hipLaunchKernelGGL(k_projected_flags, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, R.d_proj, total, reinterpret_cast<uint8_t*>(d + o_flag));
-  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_pk, 0, (size_t)n_calls * feat_cap, ctx->stream));
   {
-    HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_pk, 0, (size_t)n_calls * feat_cap, ctx->stream));
-    hipLaunchKernelGGL(k_pose_feats_from_list, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, *cam, reinterpret_cast<const hso_match_brief*>(d + o_out),
-                       reinterpret_cast<const int*>(d + o_offs), reinterpret_cast<const PoseSrcDev*>(d + o_ps), X.d_ids, X.d_quality, feat_cap,
-                       reinterpret_cast<hso_pose_feat*>(d + o_pf), reinterpret_cast<PoseJobDev*>(d + o_pj), reinterpret_cast<hso_se3*>(d + o_pp),
+    EmitArgs E;
+    E.brief = R.d_brief; E.begin = d_begin; E.examined = reinterpret_cast<const int32_t*>(d + o_exam); E.cand_pt = reinterpret_cast<const int32_t*>(d + o_pt);
+    E.counts = reinterpret_cast<const int*>(d + o_counts); E.offs = reinterpret_cast<int*>(d + o_offs); E.out = reinterpret_cast<hso_match_brief*>(d + o_out);
+    E.records = pose->records ? reinterpret_cast<hso_frame_match*>(d + o_rec) : nullptr; E.n_calls = n_calls;
+    hipLaunchKernelGGL(k_sel_emit_feats, dim3(n_calls), dim3(SEL_THREADS), 0, ctx->stream, E, *cam, reinterpret_cast<const PoseSrcDev*>(d + o_ps), X.d_ids, X.d_quality,
+                       feat_cap, reinterpret_cast<hso_pose_feat*>(d + o_pf), reinterpret_cast<PoseJobDev*>(d + o_pj), reinterpret_cast<hso_se3*>(d + o_pp),
                        reinterpret_cast<int*>(d + o_pnp), pose->feat_f ? reinterpret_cast<double*>(d + o_ff) : nullptr, reinterpret_cast<int*>(d + o_pn));
+    HSO_HIP_CHECK(ctx, hipGetLastError());
     if (int rc = hso_pose_launch_device(ctx, cam, reinterpret_cast<const PoseJobDev*>(d + o_pj), n_calls, feat_cap,
                                         reinterpret_cast<hso_pose_result*>(d + o_pr))) return rc;
   }

@@ -35,6 +35,8 @@
 #include "hso_dev_math.h"
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 
 using namespace hso_dev;
 
@@ -118,15 +120,42 @@ struct TrackBatchState {
   // cooperative shape (small batches): coop_K >= 2 workgroups per job
   int coop_K = 0, coop_scatter = 0;
   bool coop_broken = false;       // a cooperative launch timed out once: this context stays on the one-workgroup shapes
+  bool coop_turn = false;         // this context holds its device's cooperative-launch turn (launch .. collect)
   TrackJobDev* d_subjobs = nullptr; size_t subjobs_cap = 0;
   CoopJobState* d_coop = nullptr; size_t coop_cap = 0;
   std::vector<TrackJobDev> h_subjobs;
 };
 
+// One cooperative launch per device at a time.  Its workgroups wait for each other, so all of them must become resident; two such
+// launches from two contexts (two banks of sequences on their own streams) can each take part of the CUs and then wait for the
+// rest forever — until the spin bound fails both and both contexts fall back to the one-workgroup shape for good.  A launch of this
+// shape fills the chip anyway, so contexts take turns: the turn is held from the launch to the collect that follows it.
+namespace {
+struct CoopTurn { std::mutex m; std::condition_variable cv; bool busy = false; };
+CoopTurn g_coop_turn[16];
+void coop_turn_take(hso_gpu_ctx* ctx, TrackBatchState* st)
+{
+  if (st->coop_turn) return;
+  CoopTurn& T = g_coop_turn[ctx->device & 15];
+  std::unique_lock<std::mutex> lk(T.m);
+  T.cv.wait(lk, [&] { return !T.busy; });
+  T.busy = true; st->coop_turn = true;
+}
+void coop_turn_give(hso_gpu_ctx* ctx, TrackBatchState* st)
+{
+  if (!st->coop_turn) return;
+  CoopTurn& T = g_coop_turn[ctx->device & 15];
+  { std::lock_guard<std::mutex> lk(T.m); T.busy = false; }
+  st->coop_turn = false;
+  T.cv.notify_one();
+}
+}  // namespace
+
 void hso_track_state_free(hso_gpu_ctx* ctx)
 {
   TrackBatchState* st = ctx->track;
   if (!st) return;
+  coop_turn_give(ctx, st);
   (void)hipFree(st->d_jobs); (void)hipFree(st->d_feats); (void)hipFree(st->d_scratch); (void)hipFree(st->d_results);
   (void)hipFree(st->d_counter); (void)hipFree(st->d_eval); (void)hipFree(st->d_subjobs); (void)hipFree(st->d_coop);
   delete st;
@@ -357,10 +386,13 @@ int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx)
   TrackConsts C = st->C;
   if (st->coop_K) {
     C.lds_img_cap = hso_track_coop_img_cap();
-    HSO_HIP_CHECK(ctx, hipMemsetAsync(st->d_counter, 0, 2 * sizeof(int), ctx->stream));   // [1] = the fail flag
-    HSO_HIP_CHECK(ctx, hipMemsetAsync(st->d_coop, 0, sizeof(CoopJobState) * st->n_jobs, ctx->stream));
-    HSO_HIP_CHECK(ctx, hso_track_coop_launch(ctx->stream, C, st->d_subjobs, st->n_jobs, st->coop_K, st->coop_scatter, st->d_coop,
-                                             reinterpret_cast<unsigned*>(st->d_counter) + 1, st->d_scratch, st->scratch_stride, st->d_results));
+    if (!getenv("HSO_TRACK_COOP_NO_TURNS")) coop_turn_take(ctx, st);   // given back by the collect (measurement knob: no turns)
+    hipError_t e = hipMemsetAsync(st->d_counter, 0, 2 * sizeof(int), ctx->stream);   // [1] = the fail flag
+    if (e == hipSuccess) e = hipMemsetAsync(st->d_coop, 0, sizeof(CoopJobState) * st->n_jobs, ctx->stream);
+    if (e == hipSuccess) e = hso_track_coop_launch(ctx->stream, C, st->d_subjobs, st->n_jobs, st->coop_K, st->coop_scatter, st->d_coop,
+                                                   reinterpret_cast<unsigned*>(st->d_counter) + 1, st->d_scratch, st->scratch_stride, st->d_results);
+    if (e != hipSuccess) coop_turn_give(ctx, st);
+    HSO_HIP_CHECK(ctx, e);
     return HSO_OK;
   }
   if (st->split_level >= 0) {
@@ -394,9 +426,12 @@ int hso_gpu_coarse_track_collect(hso_gpu_ctx* ctx, hso_track_result* results)
 {
   if (!ctx || !ctx->track || !results) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_collect: bad argument");
   TrackBatchState* st = ctx->track;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(results, st->d_results, sizeof(hso_track_result) * st->n_jobs,
-                                    hipMemcpyDeviceToHost, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    hipError_t e = hipMemcpyAsync(results, st->d_results, sizeof(hso_track_result) * st->n_jobs, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    coop_turn_give(ctx, st);       // the cooperative kernel has left the device (or the stream failed)
+    HSO_HIP_CHECK(ctx, e);
+  }
   if (st->coop_K) {
     bool failed = false;
     for (int j = 0; j < st->n_jobs; j++) failed = failed || results[j].status != 0;
@@ -406,6 +441,7 @@ int hso_gpu_coarse_track_collect(hso_gpu_ctx* ctx, hso_track_result* results)
       // requirement — and keep this context on them from now on.
       st->coop_K = 0;
       st->coop_broken = true;
+      if (getenv("HSO_TRACK_DEBUG")) fprintf(stderr, "[hso tracker] cooperative launch of %d jobs timed out: this context stays on the one-workgroup shape\n", st->n_jobs);
       if (int rc = hso_gpu_coarse_track_launch(ctx)) return rc;
       return hso_gpu_coarse_track_collect(ctx, results);
     }

@@ -20,6 +20,27 @@ void Trace::field(const char* key, const void* data, size_t bytes)
 }
 
 // ------------------------------------------------------------------------------------------------ bank
+// How many CPUs the process may keep busy: the hardware threads, or less when a cgroup caps its CPU time (cpu.max: "quota period" in
+// microseconds).  The GPU boxes this was measured on show 256 hardware threads under a quota of 16 CPUs: 31 bookkeeping threads per
+// bank, three banks, ran into the throttle (whole steps stalled for a scheduler period); about one worker per CPU of the quota and
+// bank is where the throughput peaks (tools/bank_threads.sh: 3 banks x 96 sequences 17.2 k frames/s with 31 workers each, 19.6 k with 12).
+static unsigned cpu_budget()
+{
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  double quota = -1, period = -1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {               // cgroup v2
+    char q[64] = {0};
+    if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+    fclose(f);
+  } else {
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lf", &quota) != 1) quota = -1; fclose(g); }   // v1
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lf", &period) != 1) period = -1; fclose(g); }
+  }
+  if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1.0, std::floor(quota / period + 0.5)));
+  return n;
+}
+
 Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Settings& cfg, int n_sequences)
     : ctx_(ctx), owns_ctx_(owns_ctx), cam_(cam), cfg_(cfg)
 {
@@ -42,8 +63,8 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
   check(hso_gpu_seed_table_create(ctx_, &seed_table_), "seed_table_create");
   int n_threads = 0;
   if (n_sequences > 1) {
-    const unsigned hc = std::thread::hardware_concurrency();
-    n_threads = (int)std::min<unsigned>(hc > 2 ? hc - 2 : 0, std::min(n_sequences - 1, 31));
+    const unsigned hc = cpu_budget();
+    n_threads = (int)std::min<unsigned>(hc > 2 ? hc - 1 : 0, std::min(n_sequences - 1, 31));
     if (const char* e = getenv("HSO_ENGINE_THREADS")) n_threads = std::max(0, atoi(e));
   }
   pool_ = new Pool(n_threads);

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -34,16 +35,24 @@ inline int8_t point_face(int8_t feature_type) { return feature_type == HSO_FTR_E
 
 
 // ------------------------------------------------------------------------------------------------ worker pool
-// parallel-for over the sequences of a phase; the caller takes part, so a pool of zero threads is the serial engine
+// parallel-for over the sequences of a phase; the caller takes part, so a pool of zero threads is the serial engine.
+// A step is a chain of ~20 short parallel phases (0.1-1 ms of work each) separated by device calls, so what a wake-up costs
+// decides how well the phases scale.  A worker that finds no work can keep polling the generation counter for HSO_ENGINE_SPIN_US
+// microseconds before it blocks on the condition variable — off by default: on a host whose CPU time is capped (the GPU boxes of
+// this project run under a 16-CPU cgroup quota) polling workers burn the quota the bookkeeping itself needs, and whole steps then
+// stall for a scheduler period (measured: 10 k -> 6 k frames/s for one bank of 128, 17 k -> 5 k for three banks).  The caller
+// polls for the last stragglers of a phase (microseconds).  Work is handed out through one 64-bit ticket (generation << 32 |
+// next index), so a worker that is late leaving one phase can never take an index of the next.
 class Pool {
 public:
   explicit Pool(int n_threads)
   {
+    if (const char* e = getenv("HSO_ENGINE_SPIN_US")) spin_us_ = std::max(0, atoi(e));
     for (int i = 0; i < n_threads; i++) th_.emplace_back([this] { loop(); });
   }
   ~Pool()
   {
-    { std::lock_guard<std::mutex> lk(m_); quit_ = true; ++gen_; }
+    { std::lock_guard<std::mutex> lk(m_); quit_.store(true); gen_.fetch_add(1); }
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
@@ -51,50 +60,64 @@ public:
   {
     if (n <= 0) return;
     if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; n_ = n; next_ = 0; left_ = n; err_ = nullptr; ++gen_;
-    }
-    cv_.notify_all();
-    drain();
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return left_ == 0; });
+    // no ticket is valid while the phase's fields change: a worker still looking at the finished phase's ticket (index == its n)
+    // must not see the new, larger n and take that index
+    ticket_.store(~uint64_t(0));
+    fn_ = &fn; n_ = n; err_ = nullptr;
+    left_.store(n);
+    const uint64_t g = gen_.load() + 1;
+    ticket_.store(g << 32);
+    gen_.store(g);                                   // sequentially consistent against the workers' sleepers_ / gen_ pair below
+    if (sleepers_.load() > 0) { std::lock_guard<std::mutex> lk(m_); cv_.notify_all(); }
+    drain(g);
+    for (int spins = 0; left_.load(std::memory_order_acquire) != 0; spins++) { if (spins < 4096) relax(); else std::this_thread::yield(); }
     fn_ = nullptr;
     if (err_) std::rethrow_exception(err_);
   }
 private:
-  void drain()
+  static void relax() { __builtin_ia32_pause(); }
+  void drain(uint64_t g)
   {
     for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= n_) return;
-      try { (*fn_)(i); }
+      uint64_t t = ticket_.load(std::memory_order_acquire);
+      if ((t >> 32) != g || (int)(uint32_t)t >= n_) return;
+      if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+      try { (*fn_)((int)(uint32_t)t); }
       catch (...) { std::lock_guard<std::mutex> lk(m_); if (!err_) err_ = std::current_exception(); }
-      std::lock_guard<std::mutex> lk(m_);
-      if (--left_ == 0) done_.notify_all();
+      left_.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
   void loop()
   {
     uint64_t seen = 0;
     for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
-        if (quit_) return;
+      const auto t0 = std::chrono::steady_clock::now();
+      bool got = false;
+      for (int k = 0;; k++) {
+        if (gen_.load(std::memory_order_acquire) != seen) { got = true; break; }
+        relax();
+        if ((k & 255) == 255 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us_) break;
       }
-      drain();
+      if (!got) {
+        std::unique_lock<std::mutex> lk(m_);
+        sleepers_.fetch_add(1);
+        cv_.wait(lk, [&] { return gen_.load() != seen; });
+        sleepers_.fetch_sub(1);
+      }
+      if (quit_.load()) return;
+      seen = gen_.load(std::memory_order_acquire);
+      drain(seen);
     }
   }
   std::vector<std::thread> th_;
   std::mutex m_;
-  std::condition_variable cv_, done_;
+  std::condition_variable cv_;
   const std::function<void(int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, left_ = 0;
-  uint64_t gen_ = 0;
-  bool quit_ = false;
+  std::atomic<uint64_t> ticket_{0}, gen_{0};
+  std::atomic<int> left_{0}, sleepers_{0};
+  std::atomic<bool> quit_{false};
+  int n_ = 0;
+  long spin_us_ = 0;
   std::exception_ptr err_;
 };
 

@@ -110,6 +110,12 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
   }
   ck.lap(8);
   n_steps_++;
+  if (const char* e = getenv("HSO_ENGINE_TIMING")) if (atoi(e) >= 2) {   // one line per step: the phases' wall time since the last step's line
+    static thread_local double last[9] = {0};
+    fprintf(stderr, "[hso engine step %lld] kf %lld |", (long long)n_steps_, (long long)n_kf_events_);
+    for (int k = 0; k < 9; k++) { fprintf(stderr, " %.2f", phase_ms_[k] - last[k]); last[k] = phase_ms_[k]; }
+    fprintf(stderr, "\n");
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ frame construction

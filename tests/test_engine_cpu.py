@@ -83,3 +83,14 @@ def test_bank_of_sequences_equals_solo_runs(fake, small_seq):
         assert got[i] == solo[i][0], "sequence %d differs from its solo run" % i
         assert [(a, bytes(b), c) for a, b, c in bank.keyframes(i)] == [(a, bytes(b), c) for a, b, c in solo[i][1]]
     bank.close()
+
+
+def test_worker_pool_hands_out_every_item_once(tmp_path):
+    """The engine's parallel-for under stress (tests/pool_stress.cpp): two pools, 60 000 phases each of 2..121 near-empty items,
+    with and without more workers than cores; every item exactly once, no hang (the timeout is the hang check)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "pool_stress")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(here, "pool_stress.cpp"), "-o", exe])
+    for threads in (3, 12):
+        out = subprocess.run([exe, str(threads), "60000"], capture_output=True, text=True, timeout=240)
+        assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-400:]
