@@ -1,9 +1,11 @@
 /*
  * hso_vo.h — C interface of the host driver (libhso_host.so): the reference's FrameHandlerMono with its
  * addImage() entry (include/hso/frame_handler_mono.h:43-50, src/frame_handler_mono.cpp:80-123), as a maintainer's
- * harness, a language binding or `python -m hso_amd.run_sequence` drives it.  The driver is C++ in the reference's
- * own class names (hso_amd/host/hso_vo.h); every numeric step inside it is a call into the device library
- * (include/hso_gpu.h).  What test/test_dataset.cpp does with the class (:264-286, :312-335) maps to:
+ * harness, a language binding or `python -m hso_amd.run_sequence` drives it.  Behind it sits the sequence engine
+ * (hso_amd/host/hso_engine.h): per-sequence state as index-linked tables mirrored on the device, every numeric step a
+ * batched call into the device library (include/hso_gpu.h), the reference's decisions (keyframe choice, covisibility,
+ * reprojection order, seed / candidate life cycle) reproduced from its call order and argument values.  A single handle is
+ * an engine of one sequence.  What test/test_dataset.cpp does with the class (:264-286, :312-335) maps to:
  *   new FrameHandlerMono(cam, false)          hso_vo_create
  *   vo->addImage(img, id, &stamp)             hso_vo_add_image
  *   vo->lastFrame(), map_.keyframes_          hso_vo_get_status, hso_vo_get_keyframes
@@ -59,12 +61,17 @@ int hso_vo_get_keyframes(hso_vo* vo, double* timestamps, hso_se3* T_f_w, int32_t
  * harness gathers (BASELINE configs[4]); returns the number of frames, fills at most cap */
 int hso_vo_get_trajectory(hso_vo* vo, double* timestamps, hso_se3* T_f_w, int cap);
 
-/* ---- N independent sequences over one device context, in lockstep (hso_amd/host/hso_multi.cpp): BASELINE north_star
- * "independent sequences ... batched"; configs[4] = what test/euroc_batch.sh:9-18 runs one after the other.  Every sequence is
- * a FrameHandlerMono of its own; per step the device calls of all sequences leave as one batched C-ABI call per kind
- * (hso_gpu_coarse_track_batch with N jobs, hso_gpu_reproject_match_multi, hso_gpu_pose_optimize_batch,
- * hso_gpu_seed_observe_multi, hso_gpu_seed_activate_multi, hso_gpu_ba_optimize_multi, hso_gpu_frame_upload_batch).  A sequence
- * run here equals the same sequence run alone through hso_vo_* bit for bit.  Up to 127 sequences. */
+/* ---- N independent sequences over one device context, in lockstep (hso_amd/host/hso_engine*.cpp): BASELINE north_star
+ * "independent sequences ... batched"; configs[4] = what test/euroc_batch.sh:9-18 runs one after the other.  One step takes one
+ * image per sequence and runs every stage ONCE for all of them: hso_gpu_frame_upload_batch, hso_gpu_coarse_track_batch (N jobs),
+ * hso_gpu_reproject_select_pose_frames (projection + matching + grid selection + pose optimisation on the sequences' resident
+ * maps), hso_gpu_ba_huber_deltas_multi / hso_gpu_ba_optimize_multi for the sequences that take a keyframe,
+ * hso_gpu_seed_table_observe_groups, hso_gpu_seed_activate_multi, hso_gpu_detect_candidates; the depth filter's idle-time pass
+ * (hso_gpu_seed_table_observe_previous_begin / _end) runs on its own stream beside the next step's tracking.  A sequence run
+ * among up to 8 equals the same sequence run alone through hso_vo_* bit for bit (tests/test_multi_gpu.py); in larger banks the
+ * tracker splits a job over a number of workgroups that depends on the batch size, and the results agree within the tracker's
+ * stated tolerance instead.  Several engines ("banks") may run in one process on their own threads and contexts;
+ * that is how one GPU is kept busy (bench.py: sequences). */
 typedef struct hso_vo_multi hso_vo_multi;
 int hso_vo_multi_create(hso_vo_multi** out, const hso_camera* cam, int max_fts, int n_sequences, int device);
 void hso_vo_multi_destroy(hso_vo_multi* m);
