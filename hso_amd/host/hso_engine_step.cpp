@@ -368,6 +368,7 @@ void Bank::apply_selection(int k, const hso_frame_match* rec, int n_rec, const u
     if (i < d.n_kf_points + d.n_cand_listed) s.erase_candidate(d.list[i]); else P.bad = true;
   }
   C.loose.clear();
+  C.loose.reserve((size_t)std::min(n_rec, cfg_.max_fts + 8));
   int taken = 0;
   for (int i = 0; i < n_rec; i++) {
     const hso_frame_match& r = rec[i];
@@ -473,9 +474,19 @@ void Bank::decide(int k)
   if ((int)d.n_inliers < cfg_.quality_min_fts) s.quality = kInsufficient;
   if (std::min(s.n_obs_last, cfg_.max_fts) - (int)d.n_inliers > cfg_.quality_max_drop_fts) s.quality = kBad;
   if (s.quality == kInsufficient) { C.T = L.T; return; }
-  // frame_utils::getSceneDepth / getSceneDistance (src/frame.cpp:323-366)
+  d.ok = true;
+  d.make_kf = s.after_init || wants_keyframe(k);
+  if (!d.make_kf) {
+    link_covisible(k, false);
+    s.outcome = kNoKeyframe;
+    return;
+  }
+  // frame_utils::getSceneDepth / getSceneDistance (src/frame.cpp:323-366).  The reference computes them for every frame
+  // (src/frame_handler_mono.cpp:268-271) but only a keyframe uses them (depth_filter_->addKeyframe, :335-338; needNewKf ignores its
+  // depth argument): two medians over the frame's 2000 points were the largest single item of a regular frame's bookkeeping.
   {
     std::vector<double> z, r;
+    z.reserve(C.loose.size()); r.reserve(C.loose.size());
     d.depth_min = std::numeric_limits<double>::max();
     for (const Feat& ft : C.loose) {
       if (ft.point == kNone) continue;
@@ -485,13 +496,6 @@ void Bank::decide(int k)
       d.depth_min = std::fmin(c[2], d.depth_min);
     }
     if (!z.empty()) { d.depth_mean = upper_median(z); d.dist_mean = upper_median(r); }
-  }
-  d.ok = true;
-  d.make_kf = s.after_init || wants_keyframe(k);
-  if (!d.make_kf) {
-    link_covisible(k, false);
-    s.outcome = kNoKeyframe;
-    return;
   }
   s.outcome = kKeyframe;
   promote(k);
