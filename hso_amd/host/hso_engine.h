@@ -65,6 +65,8 @@ struct Feat {                     // a feature; rows of Seq::feats are also the 
 struct Point {
   double pos[3] = {0, 0, 0}, idist = 1;
   Id host = kNone;                // host feature (row of Seq::feats)
+  Id host_frame = kNone;          // ... its frame and bearing, copied when the point is made (a point never changes its host): the
+  double host_f[3] = {0, 0, 1};   // per-frame loops over a frame's points then touch the point row only
   Id head = kNone;                // newest observation
   int32_t n_obs = 0;
   int8_t kind = kPtUnknown, on = kOnCorner;

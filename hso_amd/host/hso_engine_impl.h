@@ -295,8 +295,7 @@ struct Seq {
   void place_in_host(Id p)        // pos_ = T_host^-1 * (f / idist)
   {
     Point& P = points[p];
-    const Feat& h = feats[P.host];
-    const Vector3d w = frames[h.frame].T.inverse() * along(h.f, 1.0 / P.idist);
+    const Vector3d w = frames[P.host_frame].T.inverse() * along(P.host_f, 1.0 / P.idist);
     P.pos[0] = w[0]; P.pos[1] = w[1]; P.pos[2] = w[2];
     touch_point(p);
   }
@@ -355,6 +354,8 @@ struct Seq {
     Point& P = points[p];
     P.pos[0] = pos[0]; P.pos[1] = pos[1]; P.pos[2] = pos[2];
     P.idist = idist; P.host = host_feat; P.kind = kind;
+    P.host_frame = feats[host_feat].frame;
+    P.host_f[0] = feats[host_feat].f[0]; P.host_f[1] = feats[host_feat].f[1]; P.host_f[2] = feats[host_feat].f[2];
     P.on = point_face(feats[host_feat].type);
     return p;
   }

@@ -169,9 +169,8 @@ void reference_features(const Seq& s, const Frame& R, double* out, size_t stride
     dist[i] = -1;
     if (ft.point == kNone) continue;
     const Point& P = s.points[ft.point];
-    const Feat& host = s.feats[P.host];
-    if (host.frame != cached) { T_ref_host = R.T * s.frames[host.frame].T.inverse(); cached = host.frame; }   // runs of points share a host keyframe
-    const Vector3d p = T_ref_host * along(host.f, 1.0 / P.idist);
+    if (P.host_frame != cached) { T_ref_host = R.T * s.frames[P.host_frame].T.inverse(); cached = P.host_frame; }   // runs of points share a host keyframe
+    const Vector3d p = T_ref_host * along(P.host_f, 1.0 / P.idist);
     if (!(p[2] < 0.00001)) dist[i] = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
   }
   for (size_t i = n; i < stride; i++) px0[i] = px1[i] = f0[i] = f1[i] = f2[i] = dist[i] = 0.0;
