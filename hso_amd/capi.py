@@ -233,6 +233,11 @@ class ActivateOut(C.Structure):
                 ("n_iter", C.c_int32), ("_pad", C.c_int32)]
 
 
+class BaDeltasJob(C.Structure):   # hso_ba_deltas_job
+    _fields_ = [("poses_f_w", C.c_void_p), ("idist", C.c_void_p), ("edges", C.c_void_p), ("obs_uv", C.c_void_p),
+                ("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32), ("huber_corner", C.c_float), ("huber_edge", C.c_float)]
+
+
 BA_EDGE_DTYPE = np.dtype([("point", "<i4"), ("host", "<i4"), ("target", "<i4"), ("type", "<i4"), ("level", "<i4"),
                           ("_pad", "<i4"), ("fH", "<f8", 3), ("meas", "<f8", 2), ("normal", "<f8", 2)])
 assert BA_EDGE_DTYPE.itemsize == 80
@@ -322,6 +327,7 @@ def load():
     lib.hso_gpu_pose_optimize_batch.argtypes = [vp, P(Camera), P(PoseJob), i32, P(PoseResult), vp]
     lib.hso_gpu_ba_linearize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double] + [vp] * 8
     lib.hso_gpu_ba_huber_deltas.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, C.c_double, P(C.c_float), P(C.c_float)]
+    lib.hso_gpu_ba_huber_deltas_multi.argtypes = [vp, P(BaDeltasJob), i32, C.c_double]
     lib.hso_gpu_ba_optimize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double, i32, vp, P(BaResult)]
     lib.hso_gpu_ba_optimize_multi.argtypes = [vp, P(BaProblem), i32]
     lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
@@ -662,6 +668,22 @@ class Context:
                                                      _ptr(obs_uv), len(edges), error_multiplier2, C.byref(hc), C.byref(he)),
                     "ba_huber_deltas")
         return hc.value, he.value
+
+    def ba_huber_deltas_multi(self, windows, error_multiplier2):
+        """hso_gpu_ba_huber_deltas_multi: windows = [(poses, idist, edges, obs_uv), ...] -> [(huber_corner, huber_edge), ...]."""
+        jobs = (BaDeltasJob * max(len(windows), 1))()
+        keep = []
+        for j, (poses, idist, edges, obs_uv) in zip(jobs, windows):
+            parr = (SE3 * len(poses))(*poses)
+            idist = np.ascontiguousarray(idist, np.float64)
+            edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+            obs_uv = np.ascontiguousarray(obs_uv, np.float64)
+            keep.append((parr, idist, edges, obs_uv))
+            j.poses_f_w = C.cast(parr, C.c_void_p); j.idist = idist.ctypes.data; j.edges = edges.ctypes.data if len(edges) else None
+            j.obs_uv = obs_uv.ctypes.data if len(edges) else None
+            j.n_poses = len(poses); j.n_points = len(idist); j.n_edges = len(edges)
+        self._check(self.lib.hso_gpu_ba_huber_deltas_multi(self.h, jobs, len(windows), error_multiplier2), "ba_huber_deltas_multi")
+        return [(jobs[i].huber_corner, jobs[i].huber_edge) for i in range(len(windows))]
 
     def ba_optimize(self, poses, fixed, idist, edges, huber_corner, huber_edge, n_iter):
         """The LM optimisation of LocalBundleAdjustment.  Returns (poses, idist, edge_chi2, BaResult)."""

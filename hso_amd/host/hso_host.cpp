@@ -174,7 +174,7 @@ Reprojector::Reprojector(AbstractCamera* cam, int max_fts) : max_fts_(max_fts)
   grid_n_cols = (int)std::ceil((double)cam->width() / cell_size);
   grid_n_rows = (int)std::ceil((double)cam->height() / cell_size);
   cell_order.resize((size_t)grid_n_cols * grid_n_rows);
-  for (size_t i = 0; i < cell_order.size(); ++i) cell_order[i] = (int)i;
+  for (size_t i = 0; i < cell_order.size(); i++) cell_order[i] = (int)i;
 }
 
 // what reprojectCell / reprojectCellAll do with one candidate (:366-412): true = matched
@@ -234,7 +234,7 @@ void Reprojector::reprojectMap(FramePtr frame, const std::vector<FramePtr>& kfs,
   if (pts.empty()) return;
   projectAndMatch(frame, pts);
   std::vector<Candidate> all;                       // allPixelToDistribute, in projection order
-  for (size_t i = 0; i < pts.size(); ++i) {
+  for (size_t i = 0; i < pts.size(); i++) {
     if (!proj_[i].projected) continue;              // reprojectPoint returned false
     all.push_back(Candidate{pts[i], {proj_[i].px[0], proj_[i].px[1]}, (int)i});
     overlap_kfs[kf_of_pt[i]].second++;
@@ -249,7 +249,7 @@ void Reprojector::projectAndMatch(FramePtr frame, const std::vector<Point*>& pts
   std::vector<hso_kf> kft;
   std::vector<const Frame*> kf_frames;
   auto kf_index = [&](const Frame* f) {
-    for (size_t k = 0; k < kf_frames.size(); ++k) if (kf_frames[k] == f) return (int)k;
+    for (size_t k = 0; k < kf_frames.size(); k++) if (kf_frames[k] == f) return (int)k;
     hso_kf r{};
     r.frame_id = f->id_; r.T_f_w = f->T_f_w_.v; r.exposure_time = f->m_exposure_time; r.keyframe_id = f->keyFrameId_;
     kft.push_back(r); kf_frames.push_back(f);
@@ -258,11 +258,11 @@ void Reprojector::projectAndMatch(FramePtr frame, const std::vector<Point*>& pts
   std::vector<hso_map_point> mp(pts.size());
   std::vector<hso_obs> obs;
   std::vector<const Feature*> obs_ftr;
-  for (size_t i = 0; i < pts.size(); ++i) {
+  for (size_t i = 0; i < pts.size(); i++) {
     const Point* p = pts[i];
     hso_map_point& m = mp[i];
     m = hso_map_point{};
-    for (int k = 0; k < 3; ++k) { m.pos[k] = p->pos_[k]; m.host_f[k] = p->hostFeature_->f[k]; }
+    for (int k = 0; k < 3; k++) { m.pos[k] = p->pos_[k]; m.host_f[k] = p->hostFeature_->f[k]; }
     m.idist = p->idist_;
     m.host_kf = kf_index(p->hostFeature_->frame);
     m.obs_begin = (int)obs.size(); m.obs_count = (int)p->obs_.size();
@@ -270,7 +270,7 @@ void Reprojector::projectAndMatch(FramePtr frame, const std::vector<Point*>& pts
       hso_obs ho{};
       ho.kf = kf_index(o->frame); ho.level = o->level; ho.type = (int)o->type;
       ho.px[0] = o->px[0]; ho.px[1] = o->px[1];
-      for (int k = 0; k < 3; ++k) ho.f[k] = o->f[k];
+      for (int k = 0; k < 3; k++) ho.f[k] = o->f[k];
       ho.grad[0] = o->grad[0]; ho.grad[1] = o->grad[1];
       obs.push_back(ho); obs_ftr.push_back(o);
     }
@@ -281,7 +281,7 @@ void Reprojector::projectAndMatch(FramePtr frame, const std::vector<Point*>& pts
                        kft.data(), (int)kft.size(), mp.data(), (int)mp.size(), obs.data(), (int)obs.size(), cell_size, grid_n_cols,
                        proj_.data(), match_.data());
   ref_of_slot_.assign(pts.size(), nullptr);
-  for (size_t i = 0; i < pts.size(); ++i)
+  for (size_t i = 0; i < pts.size(); i++)
     if (proj_[i].projected && proj_[i].ref_obs >= 0) ref_of_slot_[i] = obs_ftr[proj_[i].ref_obs];
 }
 
@@ -294,7 +294,7 @@ void Reprojector::selectMatches(FramePtr frame, const std::vector<Candidate>& al
   if (n == 0) return;
   std::vector<int32_t> cell((size_t)n), examined((size_t)n), begin{0, n};
   std::vector<uint8_t> quality((size_t)n), flags((size_t)n);
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n; i++) {
     const Candidate& c = all[(size_t)i];
     cell[(size_t)i] = proj_[c.slot].cell;
     const bool gone = c.pt->type_ == Point::TYPE_DELETED;
@@ -304,7 +304,7 @@ void Reprojector::selectMatches(FramePtr frame, const std::vector<Candidate>& al
   int32_t counts[4] = {0, 0, 0, 0};
   api::check(frame->ctx_, hso_gpu_reproject_select(frame->ctx_, begin.data(), 1, cell.data(), quality.data(), flags.data(), cell_order.data(),
                                                    (int)cell_order.size(), max_fts_, examined.data(), counts), "Reprojector");
-  for (int k = 0; k < counts[0]; ++k) {
+  for (int k = 0; k < counts[0]; k++) {
     const Candidate& c = all[(size_t)(examined[(size_t)k] & 0x7fffffff)];
     if (c.pt->type_ == Point::TYPE_DELETED) continue;
     const bool made = applyMatch(c, frame);
@@ -410,19 +410,19 @@ void FeatureExtractor::detect(Frame* frame, float initThresh, float minThresh, F
   api::trace_candidates(isInit_, id, nLevels_, minThresh_, co.data(), corner_cap, nc.data(), ed.data(), fill.data(), edgelet_cap,
                         isInit_ ? &n_fill : ne.data());
   // featurePerLevel_[L] = corners then edgelets (:518-545, :749-830), appended level by level (:449-451)
-  for (int L = 0; L < nLevels_; ++L) {
-    for (int i = 0; i < nc[L]; ++i) {
+  for (int L = 0; L < nLevels_; L++) {
+    for (int i = 0; i < nc[L]; i++) {
       const hso_corner& c = co[(size_t)L * corner_cap + i];
       hso_keypoint k{};
       k.x = (float)(c.x << L); k.y = (float)(c.y << L); k.response = c.response; k.level = L; k.species = HSO_KP_CORNER_HIGH;
       allFeturesToDistribute_.push_back(k);
     }
-    for (int i = 0; L == 0 && i < n_fill; ++i) {   // fillingHole's key points follow the level-0 corners (kGrad, :1150-1151)
+    for (int i = 0; L == 0 && i < n_fill; i++) {   // fillingHole's key points follow the level-0 corners (kGrad, :1150-1151)
       hso_keypoint k{};
       k.x = (float)fill[i].x; k.y = (float)fill[i].y; k.response = fill[i].response; k.level = 0; k.species = HSO_KP_GRAD;
       allFeturesToDistribute_.push_back(k);
     }
-    for (int i = 0; i < ne[L]; ++i) {
+    for (int i = 0; i < ne[L]; i++) {
       const hso_edgelet& e = ed[(size_t)L * edgelet_cap + i];
       hso_keypoint k{};
       k.x = (float)(e.x << L); k.y = (float)(e.y << L); k.response = e.grad; k.level = L; k.species = HSO_KP_EDGELET;
@@ -433,7 +433,7 @@ void FeatureExtractor::detect(Frame* frame, float initThresh, float minThresh, F
   std::vector<hso_keypoint> sel(allFeturesToDistribute_.size() + 1);
   const int n = api::select_octree(allFeturesToDistribute_.data(), (int)allFeturesToDistribute_.size(), width_, height_, nFeatures_,
                                    sel.data(), (int)sel.size());
-  for (int i = 0; i < n; ++i) {          // :457-484
+  for (int i = 0; i < n; i++) {          // :457-484
     const hso_keypoint& k = sel[i];
     Feature* f = new Feature();
     f->frame = frame;
@@ -494,7 +494,7 @@ size_t DepthFilter::observeDepth(FramePtr frame)
   api::seed_observe(frame->ctx_, &frame->cam_->pod(), frame->id_, &frame->T_f_w_.v, frame->m_exposure_time, px_error_angle_, in.data(),
                     (int)in.size(), out.data());
   size_t n_ok = 0, k = 0;
-  for (auto it = seeds_.begin(); it != seeds_.end(); ++k) {
+  for (auto it = seeds_.begin(); it != seeds_.end(); k++) {
     const hso_seed_out& o = out[k];
     if (!o.is_valid) { it = seeds_.erase(it); continue; }            // :618-622
     it->is_update = o.is_update != 0;

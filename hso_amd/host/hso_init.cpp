@@ -14,10 +14,14 @@ namespace {
 Matrix3d mat_mul(const Matrix3d& a, const Matrix3d& b)
 {
   Matrix3d c{};
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) c.m[i][j] += a.m[i][k] * b.m[k][j];
+  for (int q = 0; q < 9; q++) {
+    const int r = q / 3, col = q % 3;
+    c.m[r][col] = a.m[r][0] * b.m[0][col] + a.m[r][1] * b.m[1][col] + a.m[r][2] * b.m[2][col];
+  }
   return c;
 }
-Matrix3d mat_t(const Matrix3d& a) { Matrix3d c; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.m[i][j] = a.m[j][i]; return c; }
+Matrix3d mat_t(const Matrix3d& a) { Matrix3d c; for (int q = 0; q < 9; q++) c.m[q / 3][q % 3] = a.m[q % 3][q / 3]; return c; }
+void mat_scale(Matrix3d& a, double s) { for (int q = 0; q < 9; q++) a.m[q / 3][q % 3] *= s; }
 Vector3d mat_vec(const Matrix3d& a, const Vector3d& v)
 {
   return {a.m[0][0] * v[0] + a.m[0][1] * v[1] + a.m[0][2] * v[2], a.m[1][0] * v[0] + a.m[1][1] * v[1] + a.m[1][2] * v[2],
@@ -212,14 +216,14 @@ int ransac_iterations(double inlier_frac, int sample, int cap)
 }
 
 // vikit/math_utils.cpp:14-31
-Vector3d triangulateFeatureNonLin(const Matrix3d& R, const Vector3d& t, const Vector3d& feature1, const Vector3d& feature2)
+Vector3d triangulateFeatureNonLin(const Matrix3d& R, const Vector3d& t, const Vector3d& ray_a, const Vector3d& ray_b)
 {
-  const Vector3d f2 = mat_vec(R, feature2);
-  const double b0 = dot(t, feature1), b1 = dot(t, f2);
-  const double A00 = dot(feature1, feature1), A10 = dot(feature1, f2), A01 = -A10, A11 = -dot(f2, f2);
+  const Vector3d f2 = mat_vec(R, ray_b);
+  const double b0 = dot(t, ray_a), b1 = dot(t, f2);
+  const double A00 = dot(ray_a, ray_a), A10 = dot(ray_a, f2), A01 = -A10, A11 = -dot(f2, f2);
   const double det = A00 * A11 - A01 * A10;
   const double l0 = (A11 * b0 - A01 * b1) / det, l1 = (-A10 * b0 + A00 * b1) / det;
-  const Vector3d xm = scale(feature1, l0), xn = add(t, scale(f2, l1));
+  const Vector3d xm = scale(ray_a, l0), xn = add(t, scale(f2, l1));
   return scale(add(xm, xn), 0.5);
 }
 
@@ -251,7 +255,8 @@ Vector3d distancePointOnce(const Vector3d& pointW, const Vector3d& bearingRef, c
     const double energy = e[0] * e[0] + e[1] * e[1];
     double J[2];
     jacobian_id2uv(in_cur, R_c_r, t_c_r, id, bearingRef, J);
-    const double step = (1.0 / (J[0] * J[0] + J[1] * J[1])) * (-(J[0] * e[0] + J[1] * e[1]));
+    const double gain = 1.0 / (J[0] * J[0] + J[1] * J[1]), pull = -(J[0] * e[0] + J[1] * e[1]);
+    const double step = gain * pull;
     if ((iter > 0 && energy > energy_prev) || std::isnan(step)) { id = id_prev; break; }
     id_prev = id; energy_prev = energy;
     id += step;
@@ -312,8 +317,8 @@ bool estimateEssential(const std::vector<Vector2d>& x1, const std::vector<Vector
   // recoverPose: E = U diag(1, 1, 0) V^T -> R = U W V^T or U W^T V^T, t = +-u3; the candidate with most points in front of both
   Matrix3d U, V; double s[3];
   svd3(bestE, U, s, V);
-  if (mat_det(U) < 0) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U.m[i][j] = -U.m[i][j];
-  if (mat_det(V) < 0) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V.m[i][j] = -V.m[i][j];
+  if (mat_det(U) < 0) mat_scale(U, -1.0);
+  if (mat_det(V) < 0) mat_scale(V, -1.0);
   Matrix3d W{}; W.m[0][1] = -1; W.m[1][0] = 1; W.m[2][2] = 1;
   const Matrix3d Rc[2] = {mat_mul(U, mat_mul(W, mat_t(V))), mat_mul(U, mat_mul(mat_t(W), mat_t(V)))};
   const Vector3d u3 = {U.m[0][2], U.m[1][2], U.m[2][2]};
@@ -351,7 +356,7 @@ bool fit_homography(const std::vector<Vector2d>& x1, const std::vector<Vector2d>
   Matrix3d T2i{}; T2i.m[0][0] = T2i.m[1][1] = 1 / n2.s; T2i.m[0][2] = n2.cx; T2i.m[1][2] = n2.cy; T2i.m[2][2] = 1;
   H = mat_mul(T2i, mat_mul(Hn, norm_matrix(n1)));
   const double h22 = H.m[2][2];
-  if (std::fabs(h22) > 1e-300) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) H.m[i][j] /= h22;
+  if (std::fabs(h22) > 1e-300) for (int q = 0; q < 9; q++) H.m[q / 3][q % 3] /= h22;
   return std::isfinite(H.m[0][0]);
 }
 double transfer_error2(const Matrix3d& H, const Vector2d& a, const Vector2d& b)
@@ -403,7 +408,7 @@ bool estimateHomography(const std::vector<Vector2d>& x1, const std::vector<Vecto
 }
 
 // vikit Homography::decompose + computeMatchesInliers + findBestDecomposition (src/vikit/homography.cpp:57-270)
-bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& fts_c1, const std::vector<Vector2d>& fts_c2, double error_multiplier2,
+bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& plane_a, const std::vector<Vector2d>& plane_b, double error_multiplier2,
                          double thresh, SE3& T_c2_from_c1)
 {
   struct Decomp { Matrix3d R; Vector3d t; double d; Vector3d n; SE3 T; int score; };
@@ -440,19 +445,19 @@ bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& fts_c1,
   }
   for (Decomp& dc : decompositions) {
     Matrix3d R = mat_mul(U, mat_mul(dc.R, mat_t(V)));
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R.m[i][j] *= s;
+    mat_scale(R, s);
     dc.T = make_se3(R, mat_vec(U, dc.t));
   }
   // computeMatchesInliers (:57-71)
-  std::vector<char> inliers(fts_c1.size());
-  for (size_t i = 0; i < fts_c1.size(); i++)
-    inliers[i] = error_multiplier2 * std::sqrt(transfer_error2(H, fts_c1[i], fts_c2[i])) < thresh;
+  std::vector<char> inliers(plane_a.size());
+  for (size_t i = 0; i < plane_a.size(); i++)
+    inliers[i] = error_multiplier2 * std::sqrt(transfer_error2(H, plane_a[i], plane_b[i])) < thresh;
   // findBestDecomposition (:196-270)
   for (Decomp& dc : decompositions) {
     int nPositive = 0;
-    for (size_t m = 0; m < fts_c1.size(); m++) {
+    for (size_t m = 0; m < plane_a.size(); m++) {
       if (!inliers[m]) continue;
-      const Vector2d& v2 = fts_c1[m];
+      const Vector2d& v2 = plane_a[m];
       if ((H.m[2][0] * v2[0] + H.m[2][1] * v2[1] + H.m[2][2]) / dc.d > 0.0) nPositive++;
     }
     dc.score = -nPositive;
@@ -461,18 +466,18 @@ bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& fts_c1,
   decompositions.resize(4);
   for (Decomp& dc : decompositions) {
     int nPositive = 0;
-    for (size_t m = 0; m < fts_c1.size(); m++) {
+    for (size_t m = 0; m < plane_a.size(); m++) {
       if (!inliers[m]) continue;
-      const Vector3d v3 = {fts_c1[m][0], fts_c1[m][1], 1};
+      const Vector3d v3 = {plane_a[m][0], plane_a[m][1], 1};
       if (dot(v3, dc.n) / dc.d > 0.0) nPositive++;
     }
     dc.score = -nPositive;
   }
   std::stable_sort(decompositions.begin(), decompositions.end(), [](const Decomp& a, const Decomp& b) { return a.score < b.score; });
   decompositions.resize(2);
-  const double dRatio = (double)decompositions[1].score / (double)decompositions[0].score;
+  const double runner_up = (double)decompositions[1].score / (double)decompositions[0].score;
   int keep = 0;
-  if (!(dRatio < 0.9)) {                                        // two-way ambiguity: Sampson score over all points
+  if (!(runner_up < 0.9)) {                                        // two-way ambiguity: Sampson score over all points
     const double limit = thresh * thresh * 4;
     double score[2];
     for (int i = 0; i < 2; i++) {
@@ -481,9 +486,9 @@ bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& fts_c1,
       Matrix3d sq{}; sq.m[0][1] = -t[2]; sq.m[0][2] = t[1]; sq.m[1][0] = t[2]; sq.m[1][2] = -t[0]; sq.m[2][0] = -t[1]; sq.m[2][1] = t[0];
       const Matrix3d Essential = mat_mul(R, sq);                // as written in the reference (:250)
       double sum = 0;
-      for (size_t m = 0; m < fts_c1.size(); m++) {
-        // sampsonusError(v2Dash = fts_c1, Essential, v2 = fts_c2), vikit/math_utils.cpp:188-204
-        const Vector3d v3Dash = {fts_c1[m][0], fts_c1[m][1], 1}, v3 = {fts_c2[m][0], fts_c2[m][1], 1};
+      for (size_t m = 0; m < plane_a.size(); m++) {
+        // sampsonusError(v2Dash = plane_a, Essential, v2 = plane_b), vikit/math_utils.cpp:188-204
+        const Vector3d v3Dash = {plane_a[m][0], plane_a[m][1], 1}, v3 = {plane_b[m][0], plane_b[m][1], 1};
         const Vector3d fv3 = mat_vec(Essential, v3), fTv3Dash = mat_vec(mat_t(Essential), v3Dash);
         const double dError = dot(v3Dash, fv3);
         double d = dError * dError / (fv3[0] * fv3[0] + fv3[1] * fv3[1] + fTv3Dash[0] * fTv3Dash[0] + fTv3Dash[1] * fTv3Dash[1]);
@@ -498,23 +503,23 @@ bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& fts_c1,
   return true;
 }
 
-double computeP3D(const std::vector<Vector3d>& vBearing1, const std::vector<Vector3d>& vBearing2, const Matrix3d& R, const Vector3d& t,
+double computeP3D(const std::vector<Vector3d>& rays_first, const std::vector<Vector3d>& rays_second, const Matrix3d& R, const Vector3d& t,
                   double reproj_thresh, double error_multiplier2, std::vector<Vector3d>& vP3D, std::vector<int>& inliers)
 {
-  inliers.clear(); inliers.reserve(vBearing1.size());
-  vP3D.clear(); vP3D.reserve(vBearing1.size());
+  inliers.clear(); inliers.reserve(rays_first.size());
+  vP3D.clear(); vP3D.reserve(rays_first.size());
   const Matrix3d Rt = mat_t(R);                                 // T_r_c = T_c_r^-1
   double totalEnergy = 0;
-  for (size_t i = 0; i < vBearing1.size(); ++i) {
-    const Vector3d p3d_cur_old = triangulateFeatureNonLin(R, t, vBearing1[i], vBearing2[i]);
+  for (size_t i = 0; i < rays_first.size(); ++i) {
+    const Vector3d p3d_cur_old = triangulateFeatureNonLin(R, t, rays_first[i], rays_second[i]);
     const Vector3d p3d_ref_old = mat_vec(Rt, sub(p3d_cur_old, t));
-    const Vector3d pWorld_new = distancePointOnce(p3d_ref_old, vBearing2[i], vBearing1[i], R, t);
-    const Vector3d pTarget_new = add(mat_vec(R, pWorld_new), t);
-    const double e1 = reprojError(vBearing1[i], pTarget_new, error_multiplier2);
+    const Vector3d in_first = distancePointOnce(p3d_ref_old, rays_second[i], rays_first[i], R, t);
+    const Vector3d in_second = add(mat_vec(R, in_first), t);
+    const double e1 = reprojError(rays_first[i], in_second, error_multiplier2);
     totalEnergy += e1;
-    vP3D.push_back(pTarget_new);
-    if (pWorld_new[2] < 0.01 || pTarget_new[2] < 0.01) continue;
-    const float ratio = (float)(norm(p3d_ref_old) / norm(pWorld_new));
+    vP3D.push_back(in_second);
+    if (in_first[2] < 0.01 || in_second[2] < 0.01) continue;
+    const float ratio = (float)(norm(p3d_ref_old) / norm(in_first));
     if (ratio < 0.9 || ratio > 1.1) continue;
     if (e1 < reproj_thresh) inliers.push_back((int)i);
   }
@@ -528,8 +533,9 @@ void computeInitializeMatrix(const std::vector<Vector3d>& f_ref, const std::vect
   std::vector<Vector2d> x1(f_ref.size()), x2(f_cur.size());
   for (size_t i = 0; i < f_ref.size(); ++i) {
     // cv::Point2f in the reference (:309-313): the model estimators see float-precision coordinates
-    x1[i] = {(double)(float)(f_ref[i][0] / f_ref[i][2]), (double)(float)(f_ref[i][1] / f_ref[i][2])};
-    x2[i] = {(double)(float)(f_cur[i][0] / f_cur[i][2]), (double)(float)(f_cur[i][1] / f_cur[i][2])};
+    auto as_point2f = [](const Vector3d& b) { const Vector2d n = project2d(b); return Vector2d{(double)(float)n[0], (double)(float)n[1]}; };
+    x1[i] = as_point2f(f_ref[i]);
+    x2[i] = as_point2f(f_cur[i]);
   }
   const double inf = std::numeric_limits<double>::infinity();
   Matrix3d R{}; Vector3d t{};
@@ -543,7 +549,8 @@ void computeInitializeMatrix(const std::vector<Vector3d>& f_ref, const std::vect
     if (std::isnan(E_error)) E_error = inf;
   }
   std::vector<Vector2d> uv_ref(f_ref.size()), uv_cur(f_cur.size());
-  for (size_t i = 0; i < f_ref.size(); ++i) { uv_ref[i] = project2d(f_ref[i]); uv_cur[i] = project2d(f_cur[i]); }
+  std::transform(f_ref.begin(), f_ref.end(), uv_ref.begin(), project2d);
+  std::transform(f_cur.begin(), f_cur.end(), uv_cur.begin(), project2d);
   Matrix3d H;
   if (estimateHomography(x1, x2, 2.0 / focal_length, H) && decomposeHomography(H, uv_ref, uv_cur, focal_length, reprojection_threshold, T_H)) {
     H_error = computeP3D(f_cur, f_ref, rotation_matrix(T_H), T_H.translation(), reprojection_threshold, focal_length, xyz_H, inliers_H);

@@ -29,12 +29,12 @@ void computeInitializeMatrix(const std::vector<Vector3d>& f_ref, const std::vect
                              double reprojection_threshold, std::vector<int>& inliers, std::vector<Vector3d>& xyz_in_cur, SE3& T_cur_from_ref,
                              int* used_homography = nullptr);
 // :387-424
-double computeP3D(const std::vector<Vector3d>& vBearing1, const std::vector<Vector3d>& vBearing2, const Matrix3d& R, const Vector3d& t,
+double computeP3D(const std::vector<Vector3d>& rays_first, const std::vector<Vector3d>& rays_second, const Matrix3d& R, const Vector3d& t,
                   double reproj_thresh, double error_multiplier2, std::vector<Vector3d>& vP3D, std::vector<int>& inliers);
 // the two model estimators (exposed for the unit tests of the host test driver)
 bool estimateEssential(const std::vector<Vector2d>& x1, const std::vector<Vector2d>& x2, double thresh, Matrix3d& R, Vector3d& t);
 bool estimateHomography(const std::vector<Vector2d>& x1, const std::vector<Vector2d>& x2, double thresh, Matrix3d& H);
-bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& fts_c1, const std::vector<Vector2d>& fts_c2, double error_multiplier2,
+bool decomposeHomography(const Matrix3d& H, const std::vector<Vector2d>& plane_a, const std::vector<Vector2d>& plane_b, double error_multiplier2,
                          double thresh, SE3& T_c2_from_c1);
 
 }  // namespace initialization

@@ -277,3 +277,26 @@ def test_ba_optimize_points_only_window(gpu_ctx, orc):
     for a, b_ in zip(pg, poses):
         assert a.q[:] == b_.q[:] and a.t[:] == b_.t[:]
     assert rg.n_accepted >= 1 and np.abs(ig - idist).max() > 0
+
+
+@pytest.mark.gpu
+def test_ba_huber_deltas_multi_equals_single_calls(gpu_ctx, orc):
+    """hso_gpu_ba_huber_deltas_multi (one upload / launch / read-back for the windows of many sequences) against the oracle and the
+    one-window call: three windows of different size, one of them with corner edges only, one without any edge (0 / 0)."""
+    wins = []
+    for shape, seed in (((9, 300, 4), 51), ((4, 60, 3), 52), ((12, 500, 5), 53)):
+        poses, fixed, idist, edges = synth.ba_problem(*shape, seed=seed, px_noise=0.3)
+        rng = np.random.default_rng(seed)
+        uv = _obs_uv(edges, rng)
+        wins.append((poses, idist, edges, uv))
+    p1, i1, e1, u1 = wins[1]
+    corner_only = e1["type"] != capi.FTR_EDGELET
+    wins[1] = (p1, i1, e1[corner_only], u1[corner_only])
+    wins.append((wins[0][0], wins[0][1], wins[0][2][:0], wins[0][3][:0]))
+    got = gpu_ctx.ba_huber_deltas_multi(wins, 480.0)
+    assert got[3] == (0.0, 0.0)
+    for (poses, idist, edges, uv), g in zip(wins[:3], got[:3]):
+        assert g == orc.ba_huber_deltas(poses, idist, edges, uv, 480.0)
+        assert g == gpu_ctx.ba_huber_deltas(poses, idist, edges, uv, 480.0)
+    assert got[1][1] == np.float32(0.5 / 480.0)                         # no edgelet edge: the fallback (:664-680)
+
