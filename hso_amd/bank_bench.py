@@ -51,6 +51,15 @@ def run(n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, on_d
                 calls=counts)
 
 
+def _cgroup_cpu():
+    """(usage_usec, nr_throttled, nr_periods) of the process's cgroup (v2), or None"""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d["usage_usec"]), int(d.get("nr_throttled", 0)), int(d.get("nr_periods", 0))
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False, lib_path=None, to_device=None):
     """n_banks engines of n_seq sequences each, every one on its own host thread with its own device context / stream: the
     device work of one bank overlaps the bookkeeping and the PCIe traffic of the others (independent sequences shard freely, also
@@ -98,15 +107,20 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
     for t in th:
         t.start()
     gate.wait()
+    c0 = _cgroup_cpu()
     t0 = time.perf_counter()
     for t in th:
         t.join()
     wall = max(t_end) - t0
+    c1 = _cgroup_cpu()
     out = dict(banks=n_banks, sequences_per_bank=n_seq, sequences=n_banks * n_seq, frames=frames - 1, max_fts=max_fts, images="device",
                distinct=len(seqs), frames_per_s=n_banks * n_seq * (frames - 1) / wall, wall_s=wall,
                ms_per_step_mean_per_bank=[r["ms_per_step_mean"] for r in res], ms_per_step_median_per_bank=[r["ms_per_step_median"] for r in res],
                keyframes_per_sequence=float(np.mean([r["keyframes"] for r in res])),
                failures=sum(r["failures"] for r in res), trans_err_max=max(r["trans_err_max"] for r in res))
+    if c0 and c1:   # host CPUs the process kept busy over the timed steps (incl. the banks' teardown) and CFS periods it was throttled in
+        out["host_cpus_used"] = (c1[0] - c0[0]) / 1e6 / max(time.perf_counter() - t0, 1e-9)
+        out["host_throttled_periods"] = [c1[1] - c0[1], c1[2] - c0[2]]
     if want_traj:
         return out, [t for b in traj for t in b]
     return out

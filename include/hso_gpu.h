@@ -209,7 +209,11 @@ int hso_gpu_coarse_track_batch(hso_gpu_ctx* ctx, const hso_camera* cam,
 /* Same, split for callers that keep jobs resident and time only the device
  * work: `prepare` uploads the jobs' feature tables, `launch` enqueues the
  * kernel on the context stream (asynchronous), `collect` synchronises and
- * copies the results back. */
+ * copies the results back.  Every successful `launch` must be followed by its
+ * `collect` (or the context's destruction): a launch of the cooperative shape
+ * (a batch smaller than the chip, split over workgroups that wait for each other)
+ * holds its device's cooperative-launch turn until then, and another context's
+ * such launch on the same device waits for the turn. */
 int hso_gpu_coarse_track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam,
                                  const hso_track_params* params,
                                  const hso_track_job* jobs, int n_jobs);
