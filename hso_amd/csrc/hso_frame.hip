@@ -174,6 +174,111 @@ int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh
 #define SOB_TH (4 * SOB_STRIP) //                 4 lane groups x SOB_STRIP rows high (60: divides 480, 240, 120)
 #define SOB_WAVES 4            // tiles (wavefronts) per block
 
+typedef const __attribute__((address_space(1))) uint8_t* SobGlbCU8;
+typedef const __attribute__((address_space(1))) uint32_t* SobGlbCU32;
+typedef __attribute__((address_space(1))) int16_t* SobGlbI16;
+typedef __attribute__((address_space(1))) unsigned long long* SobGlbU64;
+
+// One lane's strip on a level whose width is a multiple of 4 (every halfSample pyramid): four adjacent output pixels of
+// SOB_STRIP rows from aligned dwords, no branch between a row's loads and the arithmetic of the rows before it, and the
+// loads of row i + PF issued before row i is worked on.  Same arithmetic as the general strip inside k_sobel<false>.
+// Measured on 4096 EuRoC frames (rocprofv3, profiles/r4_sobel_variants.md): PF 0 / 1 / 2 / 3 / 4 = 2.41 / 2.30 / 2.31 /
+// 2.39 / 2.40 ms at 54 / 61 / 65 / 69 / 72 VGPRs; all 57 loads at the top (82 VGPRs) 2.79 ms; the general kernel 2.50 ms.
+template <int PF>
+HSO_DEV void sobel_strip(const SobGlbCU8 img, const SobGlbI16 gx, const SobGlbI16 gy, const int W, const int H, const int GS,
+                         const int level, const int x, const int ys, unsigned& isum, double& gsum)
+{
+  typedef SobGlbCU8 GlbCU8;
+  typedef SobGlbCU32 GlbCU32;
+  typedef SobGlbU64 GlbU64;
+  const bool has_left = x >= 4, has_right = x + 8 <= W;
+  int o_left = has_left ? -1 : 0, o_right = has_right ? 1 : 0;
+  // keep the compiler from turning the two neighbour loads back into loads under has_left / has_right (it does, and the
+  // branches put every row's loads behind the previous row's arithmetic)
+  asm volatile("" : "+v"(o_left), "+v"(o_right));
+  // Packed 16-bit arithmetic: every intermediate fits int16 (|hd| <= 6*255, hs <= 16*255,
+  // |gx|, |gy| <= 16*6*255 = 24480), so two pixels ride in one register (v_pk_*_i16) and the
+  // output dwords come out already packed.  P[j] = {p[j], p[j+1]} for the columns x-2+j.
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  s16x2 hd[5][2], hs[5][2];
+  uint32_t cdw[5];     // bytes x .. x+3 of the row (the four centre pixels), for the intensity sum
+  const s16x2 k2 = {2, 2}, k4 = {4, 4}, k6 = {6, 6};
+  constexpr int NR = SOB_STRIP + 4;
+  uint32_t ld[NR][3];   // statically indexed (the strip loop is fully unrolled): registers, live from issue to use
+  auto issue = [&](const int i) {
+    int yy = ys + i - 2;
+    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+    const GlbCU8 row = img + (size_t)yy * W;
+    // three unconditional loads (a lane on the image border re-reads its own dword and replicates its edge pixel
+    // below, BORDER_REPLICATE)
+    const GlbCU32 r32 = (GlbCU32)(row + x);
+    ld[i][1] = r32[0];
+    ld[i][0] = r32[o_left];
+    ld[i][2] = r32[o_right];
+  };
+#pragma unroll
+  for (int i = 0; i < PF; i++) issue(i);
+#pragma unroll
+  for (int i = 0; i < NR; i++) {
+    // the loads of row i + PF go out before row i's arithmetic; the scheduling barriers keep the compiler from
+    // moving them (it would otherwise issue all 57 at the top: 82 VGPRs, 2.79 ms against 2.49 ms)
+    if (i + PF < NR) issue(i + PF);
+    if (PF > 0) __builtin_amdgcn_sched_barrier(0);
+    uint32_t d0 = ld[i][0], d1 = ld[i][1], d2 = ld[i][2];   // bytes x-4 .. x+7 (only x-2 .. x+5 are used)
+    d0 = has_left ? d0 : (d1 & 0xffu) * 0x01010101u;
+    d2 = has_right ? d2 : (d1 >> 24) * 0x01010101u;
+    // v_perm_b32: bytes 0-3 of the selector space = second operand, 4-7 = first, 0x0c = zero
+    union { uint32_t u; s16x2 v; } P0, P1, P2, P3, P4, P5, P6;
+    P0.u = __builtin_amdgcn_perm(d0, d0, 0x0c030c02u);
+    P1.u = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u);
+    P2.u = __builtin_amdgcn_perm(d1, d1, 0x0c010c00u);
+    P3.u = __builtin_amdgcn_perm(d1, d1, 0x0c020c01u);
+    P4.u = __builtin_amdgcn_perm(d1, d1, 0x0c030c02u);
+    P5.u = __builtin_amdgcn_perm(d2, d1, 0x0c040c03u);
+    P6.u = __builtin_amdgcn_perm(d2, d2, 0x0c010c00u);
+    const int sl = i % 5;
+    hd[sl][0] = (P4.v - P0.v) + k2 * (P3.v - P1.v);
+    hd[sl][1] = (P6.v - P2.v) + k2 * (P5.v - P3.v);
+    hs[sl][0] = (P0.v + P4.v) + k4 * (P1.v + P3.v) + k6 * P2.v;
+    hs[sl][1] = (P2.v + P6.v) + k4 * (P3.v + P5.v) + k6 * P4.v;
+    cdw[sl] = d1;
+    if (i >= 4) {
+      const int y = ys + i - 4;
+      const int ra = (i - 4) % 5, rb = (i - 3) % 5, rc = (i - 2) % 5, rd = (i - 1) % 5, re = i % 5;
+      if (y < H) {
+        union { uint32_t u; s16x2 v; } sx0, sx1, sy0, sy1;
+        sx0.v = (hd[ra][0] + hd[re][0]) + k4 * (hd[rb][0] + hd[rd][0]) + k6 * hd[rc][0];
+        sx1.v = (hd[ra][1] + hd[re][1]) + k4 * (hd[rb][1] + hd[rd][1]) + k6 * hd[rc][1];
+        sy0.v = (hs[re][0] - hs[ra][0]) + k2 * (hs[rd][0] - hs[rb][0]);
+        sy1.v = (hs[re][1] - hs[ra][1]) + k2 * (hs[rd][1] - hs[rb][1]);
+        typedef unsigned long long u64;
+        __builtin_nontemporal_store(((u64)sx1.u << 32) | sx0.u, (GlbU64)(gx + (size_t)y * GS + x));
+        __builtin_nontemporal_store(((u64)sy1.u << 32) | sy0.u, (GlbU64)(gy + (size_t)y * GS + x));
+        if (level == 0 && x >= 16 && x < W - 16 && y >= 16 && y < H - 16) {
+          // |grad| of the four pixels.  gx^2 + gy^2 <= 2 * 24480^2 < 2^31 is formed exactly by one
+          // v_dot2_i32_i16 per pixel on the {gx, gy} pair (v_perm_b32 pairs them up), converted once
+          // and rooted by the hardware v_sqrt_f32 (1 ulp).  The reference (src/frame.cpp:231) rounds
+          // both squares and their sum to fp32 and adds 3e5 roots into ONE fp32 accumulator; the
+          // difference of this form to a correctly rounded root is < 1e-7 of a term, four orders
+          // below what the reference's own running fp32 sum loses (tests: means to 2e-5).
+          union { uint32_t u; s16x2 v; } q0, q1, q2, q3;
+          q0.u = __builtin_amdgcn_perm(sy0.u, sx0.u, 0x05040100u);
+          q1.u = __builtin_amdgcn_perm(sy0.u, sx0.u, 0x07060302u);
+          q2.u = __builtin_amdgcn_perm(sy1.u, sx1.u, 0x05040100u);
+          q3.u = __builtin_amdgcn_perm(sy1.u, sx1.u, 0x07060302u);
+          float mag[4];
+          mag[0] = __builtin_amdgcn_sqrtf((float)__builtin_amdgcn_sdot2(q0.v, q0.v, 0, false));
+          mag[1] = __builtin_amdgcn_sqrtf((float)__builtin_amdgcn_sdot2(q1.v, q1.v, 0, false));
+          mag[2] = __builtin_amdgcn_sqrtf((float)__builtin_amdgcn_sdot2(q2.v, q2.v, 0, false));
+          mag[3] = __builtin_amdgcn_sqrtf((float)__builtin_amdgcn_sdot2(q3.v, q3.v, 0, false));
+          gsum += (double)((mag[0] + mag[1]) + (mag[2] + mag[3]));   // four values < 3.5e4 each: fp32 pair sums, then fp64
+          isum = __builtin_amdgcn_sad_u8(cdw[rc], 0u, isum);   // + the four centre bytes
+        }
+      }
+    }
+  }
+}
+
 // cv::Sobel(CV_16S, ksize 5, BORDER_REPLICATE) for levels 0..2 (src/frame.cpp:216-220):
 // derivative [-1 -2 0 2 1], smoothing [1 4 6 4 1], separable, exact integers.
 // Level-0 blocks also emit one (sum intensity, sum |grad|) partial each over the
@@ -186,6 +291,8 @@ int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh
 // five-row register window and emits one output row per input row: two 8-byte stores per lane =
 // one full 128-byte line per 16 lanes (the previous LDS version stored 2 bytes per lane).  The
 // strip loop is fully unrolled so the window is indexed statically.
+// ALLFAST: every Sobel level's width is a multiple of 4 (chosen on the host): the pipelined strip above, 61 VGPRs.
+template <bool ALLFAST>
 __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
 {
   __shared__ double s_part[4][2];
@@ -210,6 +317,9 @@ __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
   const GlbI16 gy = (GlbI16)(base + g.sob_off[level][1]);
   unsigned isum = 0;
   double gsum = 0;
+  if (ALLFAST) {
+    if (x < W && ys < H) sobel_strip<1>((SobGlbCU8)img, (SobGlbI16)gx, (SobGlbI16)gy, W, H, GS, level, x, ys, isum, gsum);
+  } else
   if (x < W && ys < H) {
     // widths that are multiples of 4 (every halfSample pyramid): aligned dwords for every lane; a
     // lane on the left / right image border replicates its first / last pixel instead of loading
@@ -280,13 +390,22 @@ __global__ __launch_bounds__(256) void k_sobel(PyrGeom g, uint8_t* const* bases)
               if (x + k < W) { gx[(size_t)y * GS + x + k] = sxv[k]; gy[(size_t)y * GS + x + k] = syv[k]; }
           }
           if (level == 0 && x >= 16 && x < W - 16 && y >= 16 && y < H - 16) {
-            const short sxv[4] = {sx0.v.x, sx0.v.y, sx1.v.x, sx1.v.y}, syv[4] = {sy0.v.x, sy0.v.y, sy1.v.x, sy1.v.y};
+            // |grad| of the four pixels.  gx^2 + gy^2 <= 2 * 24480^2 < 2^31 is formed exactly by one
+            // v_dot2_i32_i16 per pixel on the {gx, gy} pair (v_perm_b32 pairs them up), converted once
+            // and rooted by the hardware v_sqrt_f32 (1 ulp).  The reference (src/frame.cpp:231) rounds
+            // both squares and their sum to fp32 and adds 3e5 roots into ONE fp32 accumulator; the
+            // difference of this form to a correctly rounded root is < 1e-7 of a term, four orders
+            // below what the reference's own running fp32 sum loses (tests: means to 2e-5).
+            union { uint32_t u; s16x2 v; } q0, q1, q2, q3;
+            q0.u = __builtin_amdgcn_perm(sy0.u, sx0.u, 0x05040100u);
+            q1.u = __builtin_amdgcn_perm(sy0.u, sx0.u, 0x07060302u);
+            q2.u = __builtin_amdgcn_perm(sy1.u, sx1.u, 0x05040100u);
+            q3.u = __builtin_amdgcn_perm(sy1.u, sx1.u, 0x07060302u);
             float mag[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const float fx = (float)sxv[k], fy = (float)syv[k];
-              mag[k] = sqrtf(fx * fx + fy * fy);
-            }
+            mag[0] = __builtin_amdgcn_sqrtf((float)__builtin_amdgcn_sdot2(q0.v, q0.v, 0, false));
+            mag[1] = __builtin_amdgcn_sqrtf((float)__builtin_amdgcn_sdot2(q1.v, q1.v, 0, false));
+            mag[2] = __builtin_amdgcn_sqrtf((float)__builtin_amdgcn_sdot2(q2.v, q2.v, 0, false));
+            mag[3] = __builtin_amdgcn_sqrtf((float)__builtin_amdgcn_sdot2(q3.v, q3.v, 0, false));
             gsum += (double)((mag[0] + mag[1]) + (mag[2] + mag[3]));   // four values < 3.5e4 each: fp32 pair sums, then fp64
             isum = __builtin_amdgcn_sad_u8(cdw[rc], 0u, isum);   // + the four centre bytes
           }
@@ -345,7 +464,10 @@ int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases,
       hipLaunchKernelGGL(k_resize_level, dim3((g.w[l] * g.h[l] + 255) / 256, n), dim3(256), 0, ctx->stream, g, d_bases, l);
   }
   const int sob_total = g.sobel_blocks[0] + g.sobel_blocks[1] + g.sobel_blocks[2];
-  hipLaunchKernelGGL(k_sobel, dim3(sob_total, n), dim3(256), 0, ctx->stream, g, d_bases);
+  bool all_fast = true;
+  for (int l = 0; l < HSO_N_SOBEL_LEVELS; l++) all_fast = all_fast && (g.w[l] & 3) == 0;
+  if (all_fast) hipLaunchKernelGGL(k_sobel<true>, dim3(sob_total, n), dim3(256), 0, ctx->stream, g, d_bases);
+  else hipLaunchKernelGGL(k_sobel<false>, dim3(sob_total, n), dim3(256), 0, ctx->stream, g, d_bases);
   hipLaunchKernelGGL(k_frame_stats, dim3(n), dim3(64), 0, ctx->stream, g, d_bases, d_stats);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;

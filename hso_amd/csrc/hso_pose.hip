@@ -32,7 +32,8 @@ struct PoseShared {
   Se3 T, Tn;
   Se3 hinv[POSE_MAX_POSES];
   Se3 Tth[POSE_MAX_POSES];
-  double red[32];
+  double red[32];      // the 27 sums of the normal equations at s.T (undamped), valid from the first evaluation on
+  double red_n[32];    // the same at the trial pose s.Tn; [27] = the trial's chi2
   double wave_part[POSE_WAVES][32];
   double A[36], b[6], dT[8];
   double chi2, new_chi2, mu, nu, rho;
@@ -63,6 +64,25 @@ HSO_DEV void pose_block_sum27(PoseShared& s, double (&v)[32])
     double t = 0;
     for (int w = 0; w < POSE_WAVES; w++) t += s.wave_part[w][threadIdx.x];
     s.red[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// pose_block_sum27 into dst[0..27) plus the workgroup sum of one more double into dst[27], the latter by the butterfly /
+// wave-order sum of pose_block_sum1 (the chi2 of a trial keeps the bits it had as a pass of its own).
+HSO_DEV void pose_block_sum27_1(PoseShared& s, double (&v)[32], double c, double* dst)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int slot;
+  const double x = wave_reduce_scatter32(v, lane, slot);
+  const double cw = wave_butterfly_sum(c);
+  if ((lane & 1) == 0 && slot < 27) s.wave_part[wave][slot] = x;
+  if (lane == 0) s.wave_part[wave][27] = cw;
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    double t = 0;
+    for (int w = 0; w < POSE_WAVES; w++) t += s.wave_part[w][threadIdx.x];
+    dst[threadIdx.x] = t;
   }
   __syncthreads();
 }
@@ -277,6 +297,57 @@ HSO_DEV void pose_ldlt6(PoseShared& s)
   }
 }
 
+// One pass over the thread's features at the poses in s.Tth: the 27 sums of the normal equations (:545-592) into acc and,
+// with CHI2, the weighted chi2 (:602-641) of the same residuals.  A trial evaluates both at its pose in one pass: if it is
+// accepted (the common case) the sums ARE the next iteration's normal equations, if it is rejected the sums at the
+// unchanged pose are still in s.red, so after the first evaluation a trial costs one pass instead of two and one pose
+// table instead of two.  Term by term the operations are those of the two separate passes: results are bit-identical.
+template <int FPT, bool CHI2>
+HSO_DEV void pose_normal_pass(const PoseShared& s, const PoseFeatReg (&pf)[FPT], double (&acc)[32], double& chi2)
+{
+#pragma unroll
+  for (int q = 0; q < 32; q++) acc[q] = 0;
+  chi2 = 0;
+#pragma unroll
+  for (int q = 0; q < FPT; q++) {
+    const PoseFeatReg& f = pf[q];
+    if (!(f.kind & 3)) continue;
+    const Resid r = pose_residual(s, f);
+    double J0[6], J1[6];
+    jacobian_xyz2uv(r.px, r.py, r.pz, J0, J1);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { J0[k] *= f.sc; J1[k] *= f.sc; }
+    if ((f.kind & 3) == 2) {
+      double Je[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) Je[k] = f.g0 * J0[k] + f.g1 * J1[k];
+      const double e_edge = f.g0 * r.e0 + f.g1 * r.e1;
+      double w = huber_w(fabs(e_edge) / (double)s.scale_ls);
+      if (f.kind & 4) w *= 0.5;
+      if (CHI2) chi2 += e_edge * e_edge * w;   // pose_chi2's term, same operations
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int c = a; c < 6; c++) { acc[idx] += (Je[a] * Je[c]) * w; idx++; }
+        acc[21 + a] -= (Je[a] * e_edge) * w;
+      }
+    } else {
+      const double error_pt = sqrt(r.e0 * r.e0 + r.e1 * r.e1);
+      double w = huber_w(error_pt / (double)s.scale_pt);
+      if (f.kind & 4) w *= 0.5;
+      if (CHI2) chi2 += error_pt * error_pt * w;
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int c = a; c < 6; c++) { acc[idx] += (J0[a] * J0[c] + J1[a] * J1[c]) * w; idx++; }
+        acc[21 + a] -= (J0[a] * r.e0 + J1[a] * r.e1) * w;
+      }
+    }
+  }
+}
+
 // One 512-thread workgroup per frame (two wavefronts per SIMD); a thread owns up to FPT features (slot i = tid + q * 512 keeps
 // the feature order) and holds what it needs of them in registers for the whole optimisation, so a pass touches no global
 // memory: the previous form re-read the 96-byte feature records from L2 in every one of the ~60 passes, one dependent load
@@ -377,51 +448,15 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
   __syncthreads();
 
   // ---- LM (:531-689)
+  {  // normal equations at the initial pose; every later set comes out of a trial's own pass
+    double acc[32], unused;
+    pose_normal_pass<FPT, false>(s, pf, acc, unused);
+    pose_block_sum27(s, acc);
+  }
   for (int iter = 0; iter < J.n_iter; iter++) {
     if (tid == 0) { s.rho = 0; s.n_trials = 0; s.iters = iter + 1; }
     __syncthreads();
     for (;;) {
-      // normal equations at the current pose (:545-592)
-      pose_set_Tth(s, s.T, J.n_poses);
-      double acc[32];
-#pragma unroll
-      for (int q = 0; q < 32; q++) acc[q] = 0;
-#pragma unroll
-      for (int q = 0; q < FPT; q++) {
-        const PoseFeatReg& f = pf[q];
-        if (!(f.kind & 3)) continue;
-        const Resid r = pose_residual(s, f);
-        double J0[6], J1[6];
-        jacobian_xyz2uv(r.px, r.py, r.pz, J0, J1);
-#pragma unroll
-        for (int k = 0; k < 6; k++) { J0[k] *= f.sc; J1[k] *= f.sc; }
-        if ((f.kind & 3) == 2) {
-          double Je[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) Je[k] = f.g0 * J0[k] + f.g1 * J1[k];
-          const double e_edge = f.g0 * r.e0 + f.g1 * r.e1;
-          double w = huber_w(fabs(e_edge) / (double)s.scale_ls);
-          if (f.kind & 4) w *= 0.5;
-          int idx = 0;
-#pragma unroll
-          for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int c = a; c < 6; c++) { acc[idx] += (Je[a] * Je[c]) * w; idx++; }
-            acc[21 + a] -= (Je[a] * e_edge) * w;
-          }
-        } else {
-          double w = huber_w(sqrt(r.e0 * r.e0 + r.e1 * r.e1) / (double)s.scale_pt);
-          if (f.kind & 4) w *= 0.5;
-          int idx = 0;
-#pragma unroll
-          for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int c = a; c < 6; c++) { acc[idx] += (J0[a] * J0[c] + J1[a] * J1[c]) * w; idx++; }
-            acc[21 + a] -= (J0[a] * r.e0 + J1[a] * r.e1) * w;
-          }
-        }
-      }
-      pose_block_sum27(s, acc);
       if (tid == 0) {
         int idx = 0;
         for (int a = 0; a < 6; a++)
@@ -434,18 +469,21 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
       if (tid < 64) pose_ldlt6(s);
       __syncthreads();
       const bool nan_step = isnan(s.dT[0]);
-      double new_chi2 = 0;
       if (!nan_step) {
         if (tid == 0) s.Tn = se3_mul(se3_exp(s.dT), s.T);
         __syncthreads();
         pose_set_Tth(s, s.Tn, J.n_poses);
-        new_chi2 = pose_chi2<FPT>(s, pf);
+        double acc[32], c;
+        pose_normal_pass<FPT, true>(s, pf, acc, c);
+        pose_block_sum27_1(s, acc, c, s.red_n);
       }
       if (tid == 0) {
+        const double new_chi2 = nan_step ? 0.0 : s.red_n[27];
         s.rho = nan_step ? -1.0 : (s.chi2 - new_chi2);
         if (s.rho > 0) {
           s.T = s.Tn;
           s.chi2 = new_chi2;
+          for (int q = 0; q < 27; q++) s.red[q] = s.red_n[q];
           double nm = -1;
           for (int q = 0; q < 6; q++) { const double a = fabs(s.dT[q]); if (a > nm) nm = a; }
           s.stop = nm <= 0.0000000001;  // hso::EPS

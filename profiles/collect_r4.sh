@@ -14,12 +14,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$ROOT
 B="python $ROOT/bench.py --cpu-frames 0 --seq-frames 0 --sequences 0 --single 0 --se3-frames 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG} -- $B --steps 10 --warmup 2 > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o ${TAG}_fetch -- $B --steps 3 --warmup 1 > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o ${TAG}_write -- $B --steps 3 --warmup 1 > $OUT/bench_write.log 2>&1
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS \
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG} -- $B --steps 10 --warmup 2 > $OUT/bench_trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o ${TAG}_fetch -- $B --steps 3 --warmup 1 > $OUT/bench_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o ${TAG}_write -- $B --steps 3 --warmup 1 > $OUT/bench_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS \
   --output-format csv -d $OUT -o ${TAG}_sq1 -- $B --steps 2 --warmup 1 > $OUT/bench_sq1.log 2>&1 || echo "sq1 pass failed" >> $OUT/errors.txt
-rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_FLAT \
+timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_FLAT \
   --output-format csv -d $OUT -o ${TAG}_sq2 -- $B --steps 2 --warmup 1 > $OUT/bench_sq2.log 2>&1 || echo "sq2 pass failed" >> $OUT/errors.txt
 rm -f $OUT/*kernel_trace.csv   # per-dispatch traces are large; the stats files carry what is summarised
 ls -la $OUT
