@@ -284,6 +284,9 @@ def main():
     ap.add_argument("--seq-distinct", type=int, default=8, help="distinct rendered sequences per rank (replicated to --sequences x --banks)")
     ap.add_argument("--single", type=int, default=1, help="0: skip the single-sequence latency section (N = 1 only)")
     ap.add_argument("--se3-frames", type=int, default=256, help="frames of the per-frame SE(3) comparison with the CPU restatement")
+    ap.add_argument("--native-gather", type=int, default=0,
+                    help="1: repeat the trajectory gather through libhso_gather.so (ncclAllGather from C, include/hso_vo.h) and "
+                         "require it to equal the torch.distributed one; reported in bench_detail.json")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
                          "BASELINE.json's metric is quoted on; vga: BASELINE configs[1], 640x480 pinhole")
@@ -531,11 +534,23 @@ def main():
             tr_rec[q, :len(T), 7] = 1.0
         all_tr = hdist.gather_records(tr_rec.reshape(n_seq_rank * args.seq_frames, 8), device=dev)
         assert all_tr.shape[0] == world and (world == 1 or dist.get_world_size() == world)
+        native = None
+        if args.native_gather and torch.cuda.is_available():
+            # the same exchange through the C interface (hso_gather_*): rank 0's communicator id travels by a broadcast
+            uid = [hdist.NativeGather.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            ng = hdist.NativeGather(uid[0], rank, world, local_rank)
+            t0 = time.perf_counter()
+            nat = ng.gather(tr_rec.reshape(n_seq_rank * args.seq_frames, 8))
+            native = {"ms": 1e3 * (time.perf_counter() - t0), "equal_to_torch_gather": bool(np.array_equal(nat, all_tr)), "shape": list(nat.shape)}
+            ng.close()
+            assert native["equal_to_torch_gather"]
         tl = torch.tensor([mres["frames_per_s"]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tl)
         detail_extra["sequences"] = dict(mres, ranks=world, sequences_total=world * n_seq_rank, frames_per_s_all_ranks=float(tl.item()),
-                                   gathered_trajectory_shape=list(all_tr.shape),
+                                   gathered_trajectory_shape=list(all_tr.shape), native_gather=native,
                                    what="end-to-end FrameHandlerMono::addImage on evolving state: frame build, tracker, reprojection + matching + grid "
                                         "selection + pose optimisation, local BA, depth filter (seed observation, activation, new seeds); %d engines x %d "
                                         "sequences per GPU, %d features, %d distinct rendered sequences replicated; images resident in HBM; "

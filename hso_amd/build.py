@@ -37,7 +37,8 @@ def _host_sources():
 
 
 def needs_build():
-    if not os.path.exists(OUT) or not os.path.exists(os.path.join(HERE, "host", "libhso_host.so")):
+    if not os.path.exists(OUT) or not os.path.exists(os.path.join(HERE, "host", "libhso_host.so")) \
+            or not os.path.exists(os.path.join(HERE, "host", "libhso_gather.so")):
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in SOURCES] + _headers()
@@ -96,6 +97,14 @@ def build_host(verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # libhso_gather.so: the native result gather (ncclAllGather), on its own so that the engine library has no RCCL dependency
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared",
+           os.path.join(host, "hso_gather.cpp"), "-L" + os.path.join(rocm, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(rocm, "lib"),
+           "-o", os.path.join(host, "libhso_gather.so")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
     return exe
 
 

@@ -54,3 +54,83 @@ def max_over_ranks(value, device=None):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- the native gather (include/hso_vo.h: hso_gather_*, hso_amd/host/libhso_gather.so): ncclAllGather straight from C,
+# for harnesses without torch; bench.py keeps torch.distributed for its gathers and can cross-check them with this one
+# (`--native-gather 1`).
+GATHER_SYMBOLS = ["hso_gather_unique_id", "hso_gather_create", "hso_gather_destroy", "hso_gather_size", "hso_gather_rank",
+                  "hso_gather_records", "hso_gather_last_error"]
+GATHER_ID_BYTES = 128
+_gather_lib = None
+
+
+def load_gather():
+    """dlopen libhso_gather.so (RCCL is resolved through its rpath).  Raises if the library was not built."""
+    global _gather_lib
+    if _gather_lib is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "libhso_gather.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libhso_gather.so is missing: run python -m hso_amd.build")
+        lib = C.CDLL(path)
+        lib.hso_gather_last_error.restype = C.c_char_p
+        lib.hso_gather_unique_id.argtypes = [C.c_void_p]
+        lib.hso_gather_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.hso_gather_destroy.argtypes = [C.c_void_p]
+        lib.hso_gather_size.argtypes = [C.c_void_p]
+        lib.hso_gather_rank.argtypes = [C.c_void_p]
+        lib.hso_gather_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _gather_lib = lib
+    return _gather_lib
+
+
+class NativeGather:
+    """One rank's handle on the RCCL communicator.  `uid` = the 128 bytes of rank 0's NativeGather.unique_id(), carried to the
+    other ranks by the caller (bench.py: a torch.distributed broadcast; a C++ harness: whatever launched it)."""
+
+    def __init__(self, uid, rank, world, device=0):
+        import ctypes as C
+        self.lib = load_gather()
+        if len(uid) != GATHER_ID_BYTES:
+            raise ValueError("communicator id must be %d bytes" % GATHER_ID_BYTES)
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * GATHER_ID_BYTES).from_buffer_copy(bytes(uid))
+        rc = self.lib.hso_gather_create(C.byref(self.h), buf, rank, world, device)
+        if rc != 0:
+            raise RuntimeError("hso_gather_create: %d %s" % (rc, self.lib.hso_gather_last_error().decode()))
+        self.world, self.rank = world, rank
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        lib = load_gather()
+        buf = (C.c_uint8 * GATHER_ID_BYTES)()
+        rc = lib.hso_gather_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("hso_gather_unique_id: %d %s" % (rc, lib.hso_gather_last_error().decode()))
+        return bytes(buf)
+
+    def gather(self, rec):
+        """rec [..., 8] float64 (same shape on every rank) -> [world, ...same..., 8]."""
+        rec = np.ascontiguousarray(rec, dtype=np.float64)
+        if rec.shape[-1] != 8:
+            raise ValueError("records are rows of 8 doubles")
+        n_rows = rec.size // 8
+        out = np.empty((self.world,) + rec.shape)
+        rc = self.lib.hso_gather_records(self.h, rec.ctypes.data, n_rows, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("hso_gather_records: %d %s" % (rc, self.lib.hso_gather_last_error().decode()))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.hso_gather_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -103,6 +103,26 @@ int hso_vo_multi_call_counts(hso_vo_multi* m, int64_t* calls, int64_t* items, in
 int hso_vo_init_compute_matrix(const double* f_ref, const double* f_cur, int n, double focal_length, double reproj_thresh, hso_se3* T_cur_from_ref,
                             int32_t* inliers, int cap, double* xyz_in_cur, int32_t* used_homography);
 
+/* ---- The path's only exchange, native (hso_amd/host/hso_gather.cpp, libhso_gather.so): one ncclAllGather (RCCL over xGMI)
+ * of the per-frame records of all ranks — BASELINE.json north_star "RCCL over xGMI used only to gather results", configs[4]:
+ * what a C++ harness calls after hso_vo_multi_get_trajectory where bench.py uses torch.distributed.  One process per GPU.
+ * Rank 0 makes the communicator id and the launcher's own channel (environment, file, MPI, a socket) carries its 128 bytes to
+ * the other ranks; every rank then creates its handle (collective: returns when all `world` ranks have called).
+ * hso_gather_records: every rank passes n_rows records of HSO_GATHER_RECORD doubles (quaternion x y z w, translation, time
+ * stamp or exposure ratio: the row hso_amd/dist.py packs; same n_rows on every rank, short sequences padded with NaN rows);
+ * `all` receives [world][n_rows][HSO_GATHER_RECORD] in rank order on every rank.  Host pointers; the staging through HBM is
+ * the library's.  Errors: HSO_E_INVALID (arguments), HSO_E_HIP (HIP or RCCL failure, text in hso_gather_last_error). */
+#define HSO_GATHER_ID_BYTES 128
+#define HSO_GATHER_RECORD 8
+typedef struct hso_gather hso_gather;
+int hso_gather_unique_id(uint8_t id[HSO_GATHER_ID_BYTES]);
+int hso_gather_create(hso_gather** out, const uint8_t id[HSO_GATHER_ID_BYTES], int rank, int world, int device);
+void hso_gather_destroy(hso_gather* g);
+int hso_gather_size(const hso_gather* g);
+int hso_gather_rank(const hso_gather* g);
+int hso_gather_records(hso_gather* g, const double* mine, int n_rows, double* all);
+const char* hso_gather_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif
