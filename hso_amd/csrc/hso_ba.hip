@@ -288,14 +288,33 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(const BaProb* probs, c
     const int k = pt_edges[q];
     const EdgeLin L = ba_load(a, k);
     const hso_ba_edge& e = a.edges[k];
+    // static indices (the residual's second row behind `two`): the edge record stays in registers (it lived in scratch memory
+    // with run-time loop bounds); operations and their order are unchanged
+    const bool two = L.dim > 1;
     double s = 0, g = 0;
-    double AtO[2];
-    for (int d = 0; d < L.dim; d++) { AtO[d] = L.Jp[d] * L.omega; s += AtO[d] * L.Jp[d]; g += L.Jp[d] * ba_omega_r(a, k, L, d); }
+    const double AtO0 = L.Jp[0] * L.omega;
+    s += AtO0 * L.Jp[0]; g += L.Jp[0] * ba_omega_r(a, k, L, 0);
+    double AtO1 = 0;
+    if (two) { AtO1 = L.Jp[1] * L.omega; s += AtO1 * L.Jp[1]; g += L.Jp[1] * ba_omega_r(a, k, L, 1); }
     hpp += s; b += g;
-    if (!a.fixed[e.host])
-      for (int c = 0; c < 6; c++) { double v = 0; for (int d = 0; d < L.dim; d++) v += AtO[d] * L.Jh[d * 6 + c]; Hpc[((size_t)p * a.n_poses + e.host) * 6 + c] += v; }
-    if (!a.fixed[e.target])
-      for (int c = 0; c < 6; c++) { double v = 0; for (int d = 0; d < L.dim; d++) v += AtO[d] * L.Jt[d * 6 + c]; Hpc[((size_t)p * a.n_poses + e.target) * 6 + c] += v; }
+    if (!a.fixed[e.host]) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double v = 0;
+        v += AtO0 * L.Jh[c];
+        if (two) v += AtO1 * L.Jh[6 + c];
+        Hpc[((size_t)p * a.n_poses + e.host) * 6 + c] += v;
+      }
+    }
+    if (!a.fixed[e.target]) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double v = 0;
+        v += AtO0 * L.Jt[c];
+        if (two) v += AtO1 * L.Jt[6 + c];
+        Hpc[((size_t)p * a.n_poses + e.target) * 6 + c] += v;
+      }
+    }
   }
   Hpp[p] = hpp; bp[p] = b;
 }
@@ -332,15 +351,27 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, co
       const int k = pr_edges[q];
       const hso_ba_edge& e = a.edges[k];
       const int h = e.host, t = e.target;
+      // Everything below is indexed statically (r, c unrolled, the residual's second row behind `two`): the edge's linearisation
+      // and the 44 sums stay in registers.  With run-time loop bounds and a run-time choice between L.Jh and L.Jt the
+      // record and the sums lived in scratch memory (264 B per lane) and a diagonal block of the newest keyframe — 2-3 k
+      // edges, ten per thread — took 150 us.  Operations and their order per sum are unchanged.
       if (i == j) {
         if (h != i && t != i) continue;
         const EdgeLin L = ba_load(a, k);
-        const double* Jx = (h == i) ? L.Jh : L.Jt;
+        const bool two = L.dim > 1, hs = (h == i);
+        double Jx[12];
+#pragma unroll
+        for (int m = 0; m < 12; m++) Jx[m] = hs ? L.Jh[m] : L.Jt[m];
+        const double w0 = ba_omega_r(a, k, L, 0), w1 = two ? ba_omega_r(a, k, L, 1) : 0.0;
+#pragma unroll
         for (int r = 0; r < 6; r++) {
-          for (int d = 0; d < L.dim; d++) acc[36 + r] += Jx[d * 6 + r] * ba_omega_r(a, k, L, d);
+          acc[36 + r] += Jx[r] * w0;
+          if (two) acc[36 + r] += Jx[6 + r] * w1;
+#pragma unroll
           for (int c = 0; c < 6; c++) {
             double v = 0;
-            for (int d = 0; d < L.dim; d++) v += (Jx[d * 6 + r] * L.omega) * Jx[d * 6 + c];
+            v += (Jx[r] * L.omega) * Jx[c];
+            if (two) v += (Jx[6 + r] * L.omega) * Jx[6 + c];
             acc[r * 6 + c] += v;
           }
         }
@@ -348,13 +379,22 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, co
         const bool fwd = (h == i && t == j), rev = (h == j && t == i);
         if (!fwd && !rev) continue;
         const EdgeLin L = ba_load(a, k);
+        const bool two = L.dim > 1;
         // block (host, target) = Jh^T Omega Jt; stored at (i,j) directly or transposed
+        double v[36];
+#pragma unroll
         for (int r = 0; r < 6; r++)
+#pragma unroll
           for (int c = 0; c < 6; c++) {
-            double v = 0;
-            for (int d = 0; d < L.dim; d++) v += (L.Jh[d * 6 + r] * L.omega) * L.Jt[d * 6 + c];
-            if (fwd) acc[r * 6 + c] += v; else acc[c * 6 + r] += v;
+            double x = 0;
+            x += (L.Jh[r] * L.omega) * L.Jt[c];
+            if (two) x += (L.Jh[6 + r] * L.omega) * L.Jt[6 + c];
+            v[r * 6 + c] = x;
           }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) acc[r * 6 + c] += fwd ? v[r * 6 + c] : v[c * 6 + r];
       }
     }
   }
