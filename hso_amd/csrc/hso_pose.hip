@@ -69,7 +69,7 @@ HSO_DEV void pose_block_sum27(PoseShared& s, double (&v)[32])
 }
 
 // pose_block_sum27 into dst[0..27) plus the workgroup sum of one more double into dst[27], the latter by the butterfly /
-// wave-order sum of pose_block_sum1 (the chi2 of a trial keeps the bits it had as a pass of its own).
+// sum of the waves' totals in wave order (the chi2 keeps the bits it had when it was a pass of its own).
 HSO_DEV void pose_block_sum27_1(PoseShared& s, double (&v)[32], double c, double* dst)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -85,18 +85,6 @@ HSO_DEV void pose_block_sum27_1(PoseShared& s, double (&v)[32], double c, double
     dst[threadIdx.x] = t;
   }
   __syncthreads();
-}
-
-HSO_DEV double pose_block_sum1(PoseShared& s, double v)
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double x = wave_butterfly_sum(v);
-  __syncthreads();
-  if (lane == 0) s.wave_part[wave][0] = x;
-  __syncthreads();
-  double t = 0;
-  for (int w = 0; w < POSE_WAVES; w++) t += s.wave_part[w][0];
-  return t;
 }
 
 HSO_DEV int pose_block_count(PoseShared& s, int v)
@@ -207,31 +195,6 @@ HSO_DEV void pose_set_Tth(PoseShared& s, const Se3& T, int n_poses)
   __syncthreads();
 }
 
-// weighted chi2 at the poses currently in s.Tth (:488-526 / :602-641)
-template <int FPT>
-HSO_DEV double pose_chi2(PoseShared& s, const PoseFeatReg (&pf)[FPT])
-{
-  double v = 0;
-#pragma unroll
-  for (int q = 0; q < FPT; q++) {
-    const PoseFeatReg& f = pf[q];
-    if (!(f.kind & 3)) continue;
-    const Resid r = pose_residual(s, f);
-    if ((f.kind & 3) == 2) {
-      const double error_ls = f.g0 * r.e0 + f.g1 * r.e1;
-      double w = huber_w(fabs(error_ls) / (double)s.scale_ls);
-      if (f.kind & 4) w *= 0.5;
-      v += error_ls * error_ls * w;
-    } else {
-      const double error_pt = sqrt(r.e0 * r.e0 + r.e1 * r.e1);
-      double w = huber_w(error_pt / (double)s.scale_pt);
-      if (f.kind & 4) w *= 0.5;
-      v += error_pt * error_pt * w;
-    }
-  }
-  return pose_block_sum1(s, v);
-}
-
 // A.ldlt().solve(b) for the 6x6 system in s.A/s.b (pivoted LDL^T on eight lanes, broadcasts by
 // v_readlane_b32; same scheme as the tracker's 7x7 solve).  Result in s.dT[0..5].
 HSO_DEV void pose_ldlt6(PoseShared& s)
@@ -324,7 +287,7 @@ HSO_DEV void pose_normal_pass(const PoseShared& s, const PoseFeatReg (&pf)[FPT],
       const double e_edge = f.g0 * r.e0 + f.g1 * r.e1;
       double w = huber_w(fabs(e_edge) / (double)s.scale_ls);
       if (f.kind & 4) w *= 0.5;
-      if (CHI2) chi2 += e_edge * e_edge * w;   // pose_chi2's term, same operations
+      if (CHI2) chi2 += e_edge * e_edge * w;   // the chi2 term (:488-526 / :602-641)
       int idx = 0;
 #pragma unroll
       for (int a = 0; a < 6; a++) {
@@ -380,26 +343,28 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
   pose_set_Tth(s, s.T, J.n_poses);
 
   // ---- pass 0: initial errors (:426-454).  Slot i keeps the feature order; empty slots hold
-  // all-ones keys (larger than any valid key) so that order statistics ignore them.
+  // all-ones keys (larger than any valid key) so that order statistics ignore them.  The squared errors are products of
+  // floats (`float error_pt` / `float error_ls`, :441-450, pushed into a vector<double>): non-negative fp32 bit patterns order
+  // like the doubles they convert to, so the median is a 32-bit select (4 radix passes instead of 8) and converts exactly.
   int c_pt = 0, c_ls = 0;
 #pragma unroll
   for (int q = 0; q < FPT; q++) {
     const int i = tid + q * POSE_THREADS;
     if (i >= n) continue;
-    unsigned long long k64 = ~0ull;
+    unsigned k32 = 0xFFFFFFFFu;
     if (pf[q].kind & 3) {
       const Resid r = pose_residual(s, pf[q]);
       if ((pf[q].kind & 3) == 2) {
         const float error_ls = (float)(pf[q].g0 * r.e0 + pf[q].g1 * r.e1);
-        k64 = (unsigned long long)__double_as_longlong((double)(error_ls * error_ls));
+        k32 = __float_as_uint(error_ls * error_ls);
         c_ls++;
       } else {
         const float error_pt = (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
-        k64 = (unsigned long long)__double_as_longlong((double)(error_pt * error_pt));
+        k32 = __float_as_uint(error_pt * error_pt);
         c_pt++;
       }
     }
-    s.keys64[i] = k64;
+    keys32[i] = k32;
   }
   const int n_pt = pose_block_count(s, c_pt), n_ls = pose_block_count(s, c_ls);
   if (n_pt == 0 && n_ls == 0) {  // :456
@@ -411,7 +376,7 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
     return;
   }
   const int n_init = n_pt + n_ls;
-  const double med_init = __longlong_as_double((long long)pose_select<unsigned long long, 64>(s, s.keys64, n, n_init / 2));
+  const double med_init = (double)__uint_as_float(pose_select<unsigned, 32>(s, keys32, n, n_init / 2));
 
   // ---- MAD scales (:459-483): 1.4826f * nth_element(|error|) per residual kind
   float scale_pt = 0, scale_ls = 0;
@@ -443,15 +408,13 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
   __syncthreads();
   const double estimated_scale = (double)scale_pt;
 
-  const double chi2_0 = pose_chi2<FPT>(s, pf);
-  if (tid == 0) s.chi2 = chi2_0;
-  __syncthreads();
-
   // ---- LM (:531-689)
-  {  // normal equations at the initial pose; every later set comes out of a trial's own pass
-    double acc[32], unused;
-    pose_normal_pass<FPT, false>(s, pf, acc, unused);
-    pose_block_sum27(s, acc);
+  {  // chi2 (:488-526) and normal equations at the initial pose in one pass; every later set comes out of a trial's own pass
+    double acc[32], c;
+    pose_normal_pass<FPT, true>(s, pf, acc, c);
+    pose_block_sum27_1(s, acc, c, s.red);
+    if (tid == 0) s.chi2 = s.red[27];
+    __syncthreads();
   }
   for (int iter = 0; iter < J.n_iter; iter++) {
     if (tid == 0) { s.rho = 0; s.n_trials = 0; s.iters = iter + 1; }
