@@ -44,7 +44,7 @@ The JSON line also carries
   single_sequence_ms_200 / _2000 — BASELINE configs[2]/[3] are ONE sequence: ms per addImage of one sequence through the engine;
                  single_track_call_ms_2000: one tracker call (the cooperative shape splits a job across the CUs of an XCD);
   (everything else — per-bank step times, call counts, the single-sequence tables, the gathered trajectory shape — goes to
-   bench_detail.json beside this file: the printed line stays small)
+   bench_detail.json beside this file, or the path in HSO_BENCH_DETAIL: the printed line stays small)
   se3_vs_cpu   — per-frame SE(3) deviation GPU vs the strict CPU restatement on the distinct
                  scenes (rotation angle, translation, iteration-count agreement) — the second
                  half of BASELINE.json's metric; `vs_f64_energy_sum` repeats it against the restatement
@@ -579,7 +579,7 @@ def main():
         try:
             detail = dict(out)
             detail.update(detail_extra)
-            with open(os.path.join(ROOT, "bench_detail.json"), "w") as f:
+            with open(os.environ.get("HSO_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")), "w") as f:
                 json.dump(detail, f, indent=1)
         except OSError:
             pass

@@ -14,10 +14,10 @@ ROOT = os.path.dirname(HERE)
 
 
 @pytest.mark.parametrize("gpus", [1, 2])
-def test_bench_self_launch_and_gathers(gpus, orc):
+def test_bench_self_launch_and_gathers(gpus, orc, tmp_path):
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "fakegpu")])
     env = dict(os.environ, HSO_BENCH_SIDE="bench_cpu_side:CpuSide", PYTHONPATH=HERE + os.pathsep + ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
-               MASTER_ADDR="127.0.0.1", HSO_ENGINE_THREADS="1")
+               MASTER_ADDR="127.0.0.1", HSO_ENGINE_THREADS="1", HSO_BENCH_DETAIL=str(tmp_path / "bench_detail.json"))   # not the tracked file
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--batch", "4", "--scenes", "2",
            "--feats", "150", "--shape", "vga", "--cpu-frames", "0", "--sequences", "2", "--banks", "2", "--seq-feats", "60", "--seq-frames", "4", "--seq-distinct", "2", "--single", "0"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -29,6 +29,6 @@ def test_bench_self_launch_and_gathers(gpus, orc):
     assert len(out["per_gpu_frames_per_s"]) == gpus and out["value"] > 0 and out["unit"] == "frames/s"
     assert out["config"]["frames_per_gpu_per_step"] == 4 and out["roofline"]["frac"] > 0
     assert out["sequences_frames_per_s"] > 0 and out["sequences_failures"] == 0
-    detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
+    detail = json.load(open(tmp_path / "bench_detail.json"))
     # both gathers: [world, records per rank, 8]
     assert detail["sequences"]["gathered_trajectory_shape"] == [gpus, 2 * 2 * 4, 8] and detail["sequences"]["sequences_total"] == gpus * 4
