@@ -37,6 +37,7 @@ def test_gather_library_exports_its_c_interface():
 @pytest.mark.gpu
 def test_one_rank_gather_returns_the_records():
     from hso_amd import dist
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")   # one rank, one node: the bootstrap needs no other interface
     rng = np.random.default_rng(5)
     g = dist.NativeGather(dist.NativeGather.unique_id(), 0, 1, 0)
     try:
