@@ -52,24 +52,9 @@ HSO_DEV double p_readlane_d(double v, int src)
 }
 
 // workgroup sum of 27 doubles per thread: one halving exchange per wave (32 slots, 5 of them zero pads: ~40 lane exchanges
-// instead of 27 butterflies = 162), LDS across the waves in wave order => deterministic.  Result in s.red[0..27).
-HSO_DEV void pose_block_sum27(PoseShared& s, double (&v)[32])
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int slot;
-  const double x = wave_reduce_scatter32(v, lane, slot);
-  if ((lane & 1) == 0) s.wave_part[wave][slot] = x;     // two adjacent lanes hold each slot's total
-  __syncthreads();
-  if (threadIdx.x < 27) {
-    double t = 0;
-    for (int w = 0; w < POSE_WAVES; w++) t += s.wave_part[w][threadIdx.x];
-    s.red[threadIdx.x] = t;
-  }
-  __syncthreads();
-}
-
-// pose_block_sum27 into dst[0..27) plus the workgroup sum of one more double into dst[27], the latter by the butterfly /
-// sum of the waves' totals in wave order (the chi2 keeps the bits it had when it was a pass of its own).
+// instead of 27 butterflies = 162), LDS across the waves in wave order => deterministic.  Result in dst[0..27);
+// plus the workgroup sum of one more double into dst[27], by the butterfly + the sum of the waves' totals in wave order (the
+// chi2 keeps the bits it had when it was a pass of its own).
 HSO_DEV void pose_block_sum27_1(PoseShared& s, double (&v)[32], double c, double* dst)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
