@@ -229,7 +229,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_edges(const BaProb* probs, co
   const float inv_sigma2 = (float)(1.0 / (double)((1 << e.level) * (1 << e.level)));
   const double om = (double)inv_sigma2;
   double chi2 = 0;
-  for (int d = 0; d < dim; d++) chi2 += rec[d] * om * rec[d];
+  chi2 += rec[0] * om * rec[0];                 // static indices: a loop to the run-time `dim` put the whole record in scratch memory
+  if (dim > 1) chi2 += rec[1] * om * rec[1];
   const double delta = (e.type == HSO_FTR_EDGELET) ? a.huber_edge : a.huber_corner;
   const double dsqr = delta * delta;
   double rho0, rho1;
