@@ -49,8 +49,8 @@ struct hso_gpu_ctx {
   int n_cu;
   std::string err;
   std::unordered_map<int64_t, FrameRec> frames;
-  std::vector<uint8_t*> free_frames;  // recycled allocations, all of geometry free_w x free_h (their padding rows are still zero)
-  int free_w, free_h;
+  // recycled frame allocations, one free list per geometry (key = width << 32 | height; their padding rows are still zero)
+  std::unordered_map<uint64_t, std::vector<uint8_t*>> free_frames;
   std::vector<uint8_t*> frame_slabs;  // what hipMalloc returned: slabs of frames (hso_ctx.hip: hso_frame_alloc), freed with the context
   TrackBatchState* track;
   SeedTables* seed_tables;

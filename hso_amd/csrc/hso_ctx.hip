@@ -177,22 +177,16 @@ int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg)
 // holds HSO_FRAMES_PER_SLAB frames of one geometry; pieces are handed out and returned through the free list of that geometry and
 // the slabs are freed with the context.
 #define HSO_FRAMES_PER_SLAB 32
+static inline uint64_t geom_key(const PyrGeom& g) { return ((uint64_t)(uint32_t)g.w[0] << 32) | (uint32_t)g.h[0]; }
 int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base)
 {
-  if (!ctx->free_frames.empty() && ctx->free_w == g.w[0] && ctx->free_h == g.h[0]) {
-    *base = ctx->free_frames.back();
-    ctx->free_frames.pop_back();
+  std::vector<uint8_t*>& fl = ctx->free_frames[geom_key(g)];
+  if (!fl.empty()) {
+    *base = fl.back();
+    fl.pop_back();
     return HSO_OK;
   }
   *base = nullptr;
-  if (!ctx->free_frames.empty()) {
-    // another geometry than the pool's (a context normally sees one camera): a plain allocation, freed with the context
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(base), g.frame_bytes));
-    ctx->frame_slabs.push_back(*base);
-    hipError_t e = hipMemsetAsync(*base, 0, g.pyr_bytes, ctx->stream);
-    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
-    return HSO_OK;
-  }
   const size_t stride = ((size_t)g.frame_bytes + 255) & ~size_t(255);
   uint8_t* slab = nullptr;
   HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&slab), stride * HSO_FRAMES_PER_SLAB));
@@ -200,8 +194,7 @@ int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base)
   // zero once: the inter-level padding rows must read as 0 (see hso_ctx.h)
   hipError_t e = hipMemsetAsync(slab, 0, stride * HSO_FRAMES_PER_SLAB, ctx->stream);
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return HSO_E_HIP; }
-  ctx->free_w = g.w[0]; ctx->free_h = g.h[0];
-  for (int i = HSO_FRAMES_PER_SLAB - 1; i >= 1; i--) ctx->free_frames.push_back(slab + stride * (size_t)i);
+  for (int i = HSO_FRAMES_PER_SLAB - 1; i >= 1; i--) fl.push_back(slab + stride * (size_t)i);
   *base = slab;
   return HSO_OK;
 }
@@ -209,8 +202,7 @@ int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base)
 void hso_frame_free(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* base)
 {
   if (!base) return;
-  // pieces of the pool's geometry go back to its free list; anything else stays allocated until the context goes
-  if (ctx->free_w == g.w[0] && ctx->free_h == g.h[0]) ctx->free_frames.push_back(base);
+  ctx->free_frames[geom_key(g)].push_back(base);   // every piece goes back to the free list of its own geometry
 }
 
 // run `expr`; on failure give the frame allocation back and return the status
@@ -243,7 +235,6 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   ctx->seed_tables = nullptr;
   ctx->maps = nullptr;
   ctx->seqmaps = nullptr;
-  ctx->free_w = ctx->free_h = 0;
   ctx->d_batch = nullptr;
   ctx->d_seed_scratch = nullptr; ctx->seed_scratch_cap = 0;
   ctx->seed_stream = nullptr; ctx->seed_go = nullptr; ctx->seed_done = nullptr;
@@ -268,7 +259,12 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
     ctx->own_stream = true;
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return HSO_E_HIP; }
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    else { std::lock_guard<std::mutex> lk(g_stage_mutex); g_streams_in_use.erase(ctx->stream); }
+    delete ctx;
+    return HSO_E_HIP;
+  }
   ctx->n_cu = prop.multiProcessorCount;
   *out = ctx;
   return HSO_OK;
@@ -553,6 +549,28 @@ int hso_gpu_frame_release(hso_gpu_ctx* ctx, int64_t frame_id)
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   hso_frame_free(ctx, it->second.g, it->second.base);
   ctx->frames.erase(it);
+  return HSO_OK;
+}
+
+int hso_gpu_frame_release_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n < 0 || (n > 0 && !frame_ids)) return hso_fail(ctx, HSO_E_INVALID, "frame_release_batch: bad argument");
+  if (n == 0) return HSO_OK;
+  // nothing is released unless everything can be
+  for (int i = 0; i < n; i++) {
+    if (ctx->frames.find(frame_ids[i]) == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "frame_release_batch: frame not resident");
+    if (hso_seed_tables_pin(ctx, frame_ids[i]))
+      return hso_fail(ctx, HSO_E_INVALID, "frame_release_batch: live seeds of a resident seed table are hosted in one of the frames");
+  }
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;   // a pass in flight may be reading these frames
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // ONE wait for all of them (a bank of 128 sequences releases ~50 frames per step)
+  for (int i = 0; i < n; i++) {
+    auto it = ctx->frames.find(frame_ids[i]);
+    if (it == ctx->frames.end()) continue;                 // an id named twice
+    hso_frame_free(ctx, it->second.g, it->second.base);
+    ctx->frames.erase(it);
+  }
   return HSO_OK;
 }
 

@@ -1099,7 +1099,7 @@ int hso_gpu_seed_table_destroy(hso_gpu_ctx* ctx, int table)
   SeedTable* t = seed_table_of(ctx, table);
   if (!t) return hso_fail(ctx, HSO_E_INVALID, "seed_table: no such table");
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); (void)hipFree(t->d_px);
+  (void)hipFree(t->d); (void)hipFree(t->d_brief); (void)hipFree(t->d_full); (void)hipFree(t->d_frames); (void)hipFree(t->d_px); (void)hipFree(t->d_keys);
   delete t;
   ctx->seed_tables->t[table] = nullptr;
   return HSO_OK;
@@ -1403,20 +1403,26 @@ int hso_gpu_seed_table_observe_previous_begin(hso_gpu_ctx* ctx, const hso_camera
   if (int rc = grow_dev(ctx, &t->d_frames, &t->frames_cap, (size_t)std::max(n, 1), 0)) return rc;
   if (int rc = grow_dev(ctx, &t->d_keys, &t->keys_cap, (size_t)std::max(n, 1), 0)) return rc;
   if (int rc = grow_dev(ctx, &t->d_brief, &t->brief_cap, t->n, 0)) return rc;
-  // everything queued on the context's stream so far (appends, erases, pose updates of this table, uploads of the frames) first
-  HSO_HIP_CHECK(ctx, hipEventRecord(ctx->seed_go, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->seed_stream, ctx->seed_go, 0));
-  if (n > 0) {
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, ctx->h_seed_pin, (size_t)n * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->seed_stream));
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_keys, ctx->h_seed_pin + b_fr, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->seed_stream));
-  }
-  SeedConsts C;
-  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = nullptr;
-  C.frame_keys = t->d_keys; C.n_frame_keys = n;
-  if (int rc = seed_observe_launch_on(ctx, ctx->seed_stream, &ctx->d_seed_scratch_async, &ctx->seed_scratch_async_cap, C, t->d, (int)t->n, nullptr)) return rc;
-  ctx->h_seed_brief_off = b_fr + b_key;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_seed_pin + b_fr + b_key, t->d_brief, t->n * sizeof(hso_seed_brief), hipMemcpyDeviceToHost, ctx->seed_stream));
-  HSO_HIP_CHECK(ctx, hipEventRecord(ctx->seed_done, ctx->seed_stream));
+  // everything queued on the context's stream so far (appends, erases, pose updates of this table, uploads of the frames) first.
+  // From here on work may be queued on the depth filter's stream: a failing exit waits for it before it returns, so no later entry
+  // point (which would skip hso_seed_async_quiesce: seed_inflight stays false) can meet an in-place update still running.
+  const int rc = [&]() -> int {
+    HSO_HIP_CHECK(ctx, hipEventRecord(ctx->seed_go, ctx->stream));
+    HSO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->seed_stream, ctx->seed_go, 0));
+    if (n > 0) {
+      HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_frames, ctx->h_seed_pin, (size_t)n * sizeof(SeedFrameDev), hipMemcpyHostToDevice, ctx->seed_stream));
+      HSO_HIP_CHECK(ctx, hipMemcpyAsync(t->d_keys, ctx->h_seed_pin + b_fr, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->seed_stream));
+    }
+    SeedConsts C;
+    C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = nullptr;
+    C.frame_keys = t->d_keys; C.n_frame_keys = n;
+    if (int rc = seed_observe_launch_on(ctx, ctx->seed_stream, &ctx->d_seed_scratch_async, &ctx->seed_scratch_async_cap, C, t->d, (int)t->n, nullptr)) return rc;
+    ctx->h_seed_brief_off = b_fr + b_key;
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_seed_pin + b_fr + b_key, t->d_brief, t->n * sizeof(hso_seed_brief), hipMemcpyDeviceToHost, ctx->seed_stream));
+    HSO_HIP_CHECK(ctx, hipEventRecord(ctx->seed_done, ctx->seed_stream));
+    return HSO_OK;
+  }();
+  if (rc != HSO_OK) { (void)hso_stream_sync(ctx->seed_stream); return rc; }
   ctx->seed_inflight = true;
   return HSO_OK;
 }

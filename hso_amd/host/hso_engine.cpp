@@ -44,30 +44,44 @@ static unsigned cpu_budget()
 Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Settings& cfg, int n_sequences)
     : ctx_(ctx), owns_ctx_(owns_ctx), cam_(cam), cfg_(cfg)
 {
-  // Reprojector::initializeGrid (src/reprojector.cpp:53-75); the cell order the reference shuffles is the identity here
-  cell_size_ = (int)floorf(std::sqrt((float)(cam.width * cam.height) / cfg.max_fts) * 0.6);
-  grid_cols_ = (int)std::ceil((double)cam.width / cell_size_);
-  grid_rows_ = (int)std::ceil((double)cam.height / cell_size_);
-  cell_order_.resize((size_t)grid_cols_ * grid_rows_);
-  std::iota(cell_order_.begin(), cell_order_.end(), 0);
-  sync_previous_ = getenv("HSO_ENGINE_SYNC_PREVIOUS") != nullptr;
-  if (getenv("HSO_ENGINE_NO_PREVIOUS")) cfg_.previous_frame_pass = false;   // measurement aid: the step without the idle-time pass
-  px_error_angle_ = std::atan(1.0 / (2.0 * cam_.errorMultiplier2())) * 2.0;   // one pixel of noise (src/depth_filter.cpp:360-366)
-  for (int k = 0; k < n_sequences; k++) {
-    Seq* s = new Seq();
-    s->index = k; s->cam = &cam_; s->cfg = &cfg_;
-    seq_.push_back(s);
-    step_.push_back(new StepData());
-    check(hso_gpu_seqmap_create(ctx_, &s->map), "seqmap_create");
-  }
-  check(hso_gpu_seed_table_create(ctx_, &seed_table_), "seed_table_create");
-  int n_threads = 0;
-  if (n_sequences > 1) {
-    const unsigned hc = cpu_budget();
-    n_threads = (int)std::min<unsigned>(hc > 2 ? hc - 1 : 0, std::min(n_sequences - 1, 31));
-    if (const char* e = getenv("HSO_ENGINE_THREADS")) n_threads = std::max(0, atoi(e));
-  }
-  pool_ = new Pool(n_threads);
+  // a constructor that throws runs no destructor: everything made so far is taken down here (and the context, when it is the bank's)
+  auto undo = [&]() {
+    delete pool_; pool_ = nullptr;
+    for (Seq* s : seq_) { if (s->map >= 0) (void)hso_gpu_seqmap_destroy(ctx_, s->map); delete s; }
+    for (StepData* d : step_) delete d;
+    seq_.clear(); step_.clear();
+    if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);
+    seed_table_ = -1;
+    if (owns_ctx_) hso_gpu_destroy(ctx_);
+  };
+  try {
+    // Reprojector::initializeGrid (src/reprojector.cpp:53-75); the cell order the reference shuffles is the identity here
+    if (cam.width <= 0 || cam.height <= 0 || cfg.max_fts <= 0) throw Refused("camera size and max_fts must be positive");
+    cell_size_ = (int)floorf(std::sqrt((float)(cam.width * cam.height) / cfg.max_fts) * 0.6);
+    if (cell_size_ < 1) throw Refused("max_fts is too large for the image: the reprojection grid's cell size would be zero");
+    grid_cols_ = (int)std::ceil((double)cam.width / cell_size_);
+    grid_rows_ = (int)std::ceil((double)cam.height / cell_size_);
+    cell_order_.resize((size_t)grid_cols_ * grid_rows_);
+    std::iota(cell_order_.begin(), cell_order_.end(), 0);
+    sync_previous_ = getenv("HSO_ENGINE_SYNC_PREVIOUS") != nullptr;
+    if (getenv("HSO_ENGINE_NO_PREVIOUS")) cfg_.previous_frame_pass = false;   // measurement aid: the step without the idle-time pass
+    px_error_angle_ = std::atan(1.0 / (2.0 * cam_.errorMultiplier2())) * 2.0;   // one pixel of noise (src/depth_filter.cpp:360-366)
+    for (int k = 0; k < n_sequences; k++) {
+      Seq* s = new Seq();
+      s->index = k; s->cam = &cam_; s->cfg = &cfg_;
+      seq_.push_back(s);
+      step_.push_back(new StepData());
+      check(hso_gpu_seqmap_create(ctx_, &s->map), "seqmap_create");
+    }
+    check(hso_gpu_seed_table_create(ctx_, &seed_table_), "seed_table_create");
+    int n_threads = 0;
+    if (n_sequences > 1) {
+      const unsigned hc = cpu_budget();
+      n_threads = (int)std::min<unsigned>(hc > 2 ? hc - 1 : 0, std::min(n_sequences - 1, 31));
+      if (const char* e = getenv("HSO_ENGINE_THREADS")) n_threads = std::max(0, atoi(e));
+    }
+    pool_ = new Pool(n_threads);
+  } catch (...) { undo(); throw; }
 }
 
 Bank::~Bank()
@@ -88,14 +102,16 @@ Bank::~Bank()
     fprintf(stderr, "[hso engine] reproject+select+pose = list points + patch maps %.3f, device call %.3f, apply %.3f\n", sub_ms_[0] / n_steps_, sub_ms_[1] / n_steps_,
             sub_ms_[2] / n_steps_);
   delete pool_;
+  if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);   // before the frames its seeds are hosted in (waits for a pass in flight)
+  for (int64_t id : after_prev_release_) (void)hso_gpu_frame_release(ctx_, id);
+  for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
   for (Seq* s : seq_) {
+    if (s->map >= 0) (void)hso_gpu_seqmap_destroy(ctx_, s->map);
     for (Frame& F : s->frames) if (F.in_use && F.dev_id >= 0) (void)hso_gpu_frame_release(ctx_, F.dev_id);
     delete s;
   }
   for (StepData* d : step_) delete d;
-  if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);
-  for (size_t k = 0; k < seq_.size(); k++) (void)k;
-  briefs_.release(); records_.release(); projected_.release(); mask_.release(); feat_f_.release(); track_tables_.release(); seed_brief_.release(); seed_px_.release(); det_corners_.release(); det_fill_.release(); det_edgelets_.release();   // before the context goes
+  briefs_.release(); records_.release(); projected_.release(); mask_.release(); feat_f_.release(); track_tables_.release(); act_seeds_.release(); act_targets_.release(); act_ints_.release(); act_out_.release(); seed_brief_.release(); seed_px_.release(); det_corners_.release(); det_fill_.release(); det_edgelets_.release();   // before the context goes
   if (owns_ctx_) hso_gpu_destroy(ctx_);
 }
 
@@ -157,6 +173,17 @@ int Bank::trajectory(int k, double* stamps, hso_se3* T_f_w, int cap) const
   const int n = (int)s.hist_pose.size();
   for (int i = 0; i < n && i < cap; i++) { if (stamps) stamps[i] = s.hist_stamp[i]; if (T_f_w) T_f_w[i] = s.hist_pose[i]; }
   return n;
+}
+
+// the frames the sequences dropped since the last call leave the device: one call, one wait
+void Bank::release_queued()
+{
+  if (to_release_.empty()) return;
+  std::sort(to_release_.begin(), to_release_.end());
+  to_release_.erase(std::unique(to_release_.begin(), to_release_.end()), to_release_.end());
+  if (hso_gpu_frame_release_batch(ctx_, to_release_.data(), (int)to_release_.size()) < 0)
+    for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);   // one of them cannot go (yet): the others still do
+  to_release_.clear();
 }
 
 void Bank::release_frame(Seq& s, Id fr)

@@ -201,6 +201,7 @@ private:
   void par(const std::vector<int>& who, const std::function<void(int)>& fn);
   void check(int rc, const char* what);
   void release_frame(Seq& s, Id fr);
+  void release_queued();
   void release_frame_deferred(Seq& s, StepData& d, Id fr);
   void detect(const std::vector<int>& who, const std::vector<Id>& frame, const std::vector<int>& thresh, bool init, int n_levels, int n_features,
               std::vector<std::vector<hso_keypoint>>& keys, std::vector<std::vector<hso_keypoint>>& sel);
@@ -224,6 +225,7 @@ private:
                        std::vector<hso_seed> before; std::vector<hso_seed_out> full; } pending_prev_;
   bool sync_previous_ = false;     // HSO_ENGINE_SYNC_PREVIOUS=1: the pass runs inside the step (tests compare both modes)
   std::vector<int64_t> to_release_;
+  std::vector<int64_t> after_prev_release_;   // frames the previous-frame pass dropped from its lists: released once the pass is collected
   double phase_ms_[9] = {0};
   int64_t phase_census_[9][6] = {{0}};   // per phase: copies, bytes, staged copies, synchronisations, ns blocked in them, memsets
   int64_t n_steps_ = 0, n_kf_events_ = 0;
@@ -232,6 +234,7 @@ private:
   Pinned<hso_frame_match> records_;
   Pinned<uint8_t> projected_, mask_;
   Pinned<double> feat_f_, track_tables_;
+  Pinned<hso_seed> act_seeds_; Pinned<hso_activate_target> act_targets_; Pinned<int32_t> act_ints_; Pinned<hso_activate_out> act_out_;   // activate_seeds()
   Pinned<hso_seed_brief> seed_brief_;
   Pinned<float> seed_px_;
   Pinned<hso_corner> det_corners_, det_fill_;   // detect(): the candidate lists of a step's new keyframes

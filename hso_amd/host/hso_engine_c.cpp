@@ -1,7 +1,7 @@
 // hso_engine_c.cpp — the C interface of libhso_host.so (include/hso_vo.h) over the sequence engine: a single sequence is a bank
 // of one.  Errors: where the reference throws before touching anything (wrong image size) the call returns HSO_E_INVALID and the
-// handle stays usable; a failed device call in the middle of a step can leave the tables half updated, so the handle is poisoned
-// and every later call reports the first error.
+// handle stays usable (engine::Refused); a failed device call — or any other exception — in the middle of a step can leave the
+// tables half updated, so the handle is poisoned and every later call reports the first error.
 #include "hso_engine_impl.h"
 #include "hso_init.h"
 
@@ -20,8 +20,10 @@ Bank* make_bank(const hso_camera* cam, int max_fts, int n, int device, int* rc)
   if (*rc < 0) return nullptr;
   Settings cfg;
   cfg.max_fts = max_fts;
+  // the bank owns the context from here: its constructor cleans up after itself when it throws (and destroys the context)
   try { return new Bank(ctx, true, *cam, cfg, n); }
-  catch (const std::exception&) { hso_gpu_destroy(ctx); *rc = HSO_E_HIP; return nullptr; }
+  catch (const hso::engine::Refused&) { *rc = HSO_E_INVALID; return nullptr; }
+  catch (const std::exception&) { *rc = HSO_E_HIP; return nullptr; }
 }
 
 template <typename F> int guarded(Bank* b, F f)
@@ -32,8 +34,11 @@ template <typename F> int guarded(Bank* b, F f)
     return HSO_E_HIP;
   }
   try { f(); return HSO_OK; }
+  catch (const hso::engine::Refused& e) { b->err = e.what(); return HSO_E_INVALID; }             // nothing was touched (or everything put back)
   catch (const hso::engine::DeviceFault& e) { b->err = e.what(); b->poisoned = true; return HSO_E_HIP; }
-  catch (const std::exception& e) { b->err = e.what(); return HSO_E_INVALID; }
+  catch (const std::bad_alloc&) { b->err = "out of (page-locked) host memory in the middle of a step"; b->poisoned = true; return HSO_E_NOMEM; }
+  // anything else was thrown after a step had begun to change the tables: they may be half updated
+  catch (const std::exception& e) { b->err = e.what(); b->poisoned = true; return HSO_E_INVALID; }
 }
 
 }  // namespace
@@ -42,7 +47,7 @@ extern "C" {
 
 int hso_vo_create(hso_vo** out, const hso_camera* cam, int max_fts, int device)
 {
-  if (!out || !cam || max_fts <= 0) return HSO_E_INVALID;
+  if (!out || !cam || max_fts <= 0 || cam->width <= 0 || cam->height <= 0) return HSO_E_INVALID;
   *out = nullptr;
   int rc = HSO_OK;
   Bank* b = make_bank(cam, max_fts, 1, device, &rc);
@@ -77,7 +82,7 @@ int hso_vo_get_keyframes(hso_vo* v, double* timestamps, hso_se3* T_f_w, int32_t*
 
 int hso_vo_multi_create(hso_vo_multi** out, const hso_camera* cam, int max_fts, int n_sequences, int device)
 {
-  if (!out || !cam || max_fts <= 0 || n_sequences < 1 || n_sequences > 4096) return HSO_E_INVALID;
+  if (!out || !cam || max_fts <= 0 || cam->width <= 0 || cam->height <= 0 || n_sequences < 1 || n_sequences > 4096) return HSO_E_INVALID;
   *out = nullptr;
   int rc = HSO_OK;
   Bank* b = make_bank(cam, max_fts, n_sequences, device, &rc);

@@ -18,6 +18,10 @@ namespace engine {
 // ------------------------------------------------------------------------------------------------ small helpers
 
 struct DeviceFault : std::runtime_error { using std::runtime_error::runtime_error; };
+// thrown by an entry point BEFORE it has touched any table (wrong image size, missing argument), or after it has put every table
+// back in order (a sequence that could not start was reset and paused): the handle stays usable.  Any other exception that leaves
+// a mutating entry point means half-updated tables, and the C interface poisons the handle (hso_engine_c.cpp: guarded).
+struct Refused : std::invalid_argument { using std::invalid_argument::invalid_argument; };
 
 inline double len3(const double* a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
 inline Vector3d along(const double* f, double s) { return {f[0] * s, f[1] * s, f[2] * s}; }

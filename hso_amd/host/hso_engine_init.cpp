@@ -13,12 +13,12 @@ void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const doub
 {
   previous_collect();
   if (w != cam_.width() || h != cam_.height())
-    throw std::invalid_argument("Frame: provided image has not the same size as the camera model or image is not grayscale");
+    throw Refused("Frame: provided image has not the same size as the camera model or image is not grayscale");
+  for (int k = 0; k < size(); k++) if (imgs[k] && (!depth_z || !depth_z[k])) throw Refused("set_first_frame: no depth image");   // before anything is touched
   std::vector<int> who;
   for (int k = 0; k < size(); k++) {
     *step_[k] = StepData();
     if (!imgs[k]) continue;
-    if (!depth_z || !depth_z[k]) throw std::invalid_argument("set_first_frame: no depth image");
     Seq& s = *seq_[k];
     for (Frame& F : s.frames) if (F.in_use && F.dev_id >= 0) to_release_.push_back(F.dev_id);
     drop_sequence_seeds(k);
@@ -26,8 +26,7 @@ void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const doub
     s.motion = SE3(); s.after_init = false; s.regular = 0; s.n_obs_last = 0; s.quality = kInsufficient; s.want_start = false;
     who.push_back(k);
   }
-  for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
-  to_release_.clear();
+  release_queued();
   if (who.empty()) return;
   upload(who, imgs, w, h, stamps);
   // the detector of the initialisation (2000 features, FAST-12 hole filling), then one point per feature whose depth is known —
@@ -42,6 +41,7 @@ void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const doub
     frame[i] = s.cur; thresh[i] = (int)C.grad_mean;
   }
   detect(who, frame, thresh, true, cfg_.n_pyr_levels, 2000, keys, sel);
+  std::vector<int> started, refused;
   for (size_t i = 0; i < who.size(); i++) {
     const int k = who[i];
     Seq& s = *seq_[k];
@@ -57,7 +57,16 @@ void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const doub
       C.loose.push_back(ft);
       dist_of.push_back((double)z / ft.f[2]);                     // the point on the bearing whose depth along the optical axis is z
     }
-    if (C.loose.size() < 10) throw std::runtime_error("set_first_frame: fewer than 10 features with a depth");
+    if (C.loose.size() < 10) {
+      // this sequence cannot start: it goes back to the paused state with empty tables (like a failed two-view start, finish());
+      // the others start, and the call reports the refusal once every table is in order
+      to_release_.push_back(C.dev_id);
+      s.reset_tables();
+      s.stage = kPaused; s.quality = kInsufficient; s.outcome = kFailure;
+      refused.push_back(k);
+      continue;
+    }
+    started.push_back(k);
     make_keyframe(s, s.cur);
     const SE3 T_w_f = C.T.inverse();
     for (size_t j = 0; j < C.fts.size(); j++) {
@@ -85,9 +94,12 @@ void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const doub
     s.outcome = kKeyframe;
     s.log = hso_vo_status{};
   }
-  observe_seeds(who);                                             // no seeds yet: only the frame lists
-  start_seeds(who);
-  flush_maps(who);
+  who.swap(started);
+  if (!who.empty()) {
+    observe_seeds(who);                                           // no seeds yet: only the frame lists
+    start_seeds(who);
+    flush_maps(who);
+  }
   for (int k : who) {
     Seq& s = *seq_[k];
     const Id old = s.last;
@@ -95,6 +107,12 @@ void Bank::set_first_frames(const uint8_t* const* imgs, int w, int h, const doub
     if (old != kNone) release_frame(s, old);
     s.n_obs_last = 0;
     s.hist_stamp.push_back(s.frames[s.last].stamp); s.hist_pose.push_back(s.frames[s.last].T.v);
+  }
+  release_queued();
+  if (!refused.empty()) {
+    std::string msg = "set_first_frame: fewer than 10 features with a depth in sequence";
+    for (int k : refused) msg += " " + std::to_string(k);
+    throw Refused(msg + " (left paused; the other sequences started)");
   }
 }
 

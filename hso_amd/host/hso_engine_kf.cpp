@@ -323,68 +323,73 @@ void Bank::erase_slots(const std::vector<int>& who)
 // one device call, then the new candidate points
 void Bank::activate_seeds(const std::vector<int>& who)
 {
-  par(who, [&](int k) {
-    Seq& s = *seq_[k];
-    StepData& d = *step_[k];
-    d.conv.clear(); d.act_seeds.clear(); d.act_targets.clear(); d.act_begin.assign(1, 0);
+  // pass 1 (pool): which seeds converged, and how many target frames they bring
+  std::vector<size_t> n_tg(who.size(), 0);
+  pool_->run((int)who.size(), [&](int w) {
+    Seq& s = *seq_[who[w]];
+    StepData& d = *step_[who[w]];
+    d.conv.clear();
     for (size_t i = 0; i < s.seeds.size(); i++) {
       Seed& sd = s.seeds[i];
       if (!sd.alive) continue;
-      if (std::sqrt(sd.sigma2) < sd.z_range / sd.converge) d.conv.push_back((int)i);
+      if (std::sqrt(sd.sigma2) < sd.z_range / sd.converge) { d.conv.push_back((int)i); n_tg[w] += sd.seen_before.size() + sd.seen.size(); }
       else if (!sd.valid) kill_seed(s, d, (int)i, false);         // "z_min is NaN" (:494-498)
     }
-    for (int i : d.conv) {
-      const Seed& sd = s.seeds[i];
-      d.act_seeds.push_back(seed_record(s, sd));
+  });
+  // where each sequence's records go in the call's tables (page-locked, kept between steps: the sequences write their parts in
+  // parallel and the tables leave as they are — the merged std::vectors of the first version were 10 MB of serial copying and a
+  // staged copy per step of 128 sequences)
+  std::vector<size_t> at(who.size() + 1, 0), tg_at(who.size() + 1, 0);
+  for (size_t w = 0; w < who.size(); w++) { at[w + 1] = at[w] + step_[who[w]]->conv.size(); tg_at[w + 1] = tg_at[w] + n_tg[w]; }
+  const size_t n_seeds = at.back(), n_targets = tg_at.back();
+  hso_seed* const seeds = act_seeds_.need(ctx_, std::max(n_seeds, (size_t)1));
+  hso_activate_target* const targets = act_targets_.need(ctx_, std::max(n_targets, (size_t)1));
+  int32_t* const ints = act_ints_.need(ctx_, 2 * n_seeds + 2);     // [target_begin (n + 1) | n_mean (n)]
+  hso_activate_out* const out = act_out_.need(ctx_, std::max(n_seeds, (size_t)1));
+  int32_t* const begin = ints; int32_t* const n_mean = ints + n_seeds + 1;
+  begin[0] = 0;
+  pool_->run((int)who.size(), [&](int w) {
+    Seq& s = *seq_[who[w]];
+    StepData& d = *step_[who[w]];
+    size_t t = tg_at[w];
+    for (size_t c = 0; c < d.conv.size(); c++) {
+      const Seed& sd = s.seeds[d.conv[c]];
+      seeds[at[w] + c] = seed_record(s, sd);
       for (const std::vector<Id>* lst : {&sd.seen_before, &sd.seen})
         for (Id fr : *lst) {
-          hso_activate_target a{};
+          hso_activate_target& a = targets[t++];
+          a = hso_activate_target{};
           a.frame_id = s.frames[fr].dev_id; a.T_f_w = s.frames[fr].T.v; a.exposure = s.frames[fr].exposure;
-          d.act_targets.push_back(a);
         }
-      d.act_begin.push_back((int32_t)d.act_targets.size());
+      begin[at[w] + c + 1] = (int32_t)t;
+      n_mean[at[w] + c] = (int32_t)s.n_mean_converge;
     }
-    d.act_out.assign(d.conv.size(), hso_activate_out{});
   });
-  std::vector<hso_seed> seeds; std::vector<int32_t> begin(1, 0), n_mean; std::vector<hso_activate_target> targets;
-  std::vector<size_t> at;
-  for (int k : who) {
-    const StepData& d = *step_[k];
-    at.push_back(seeds.size());
-    for (size_t i = 0; i < d.conv.size(); i++) {
-      seeds.push_back(d.act_seeds[i]);
-      targets.insert(targets.end(), d.act_targets.begin() + d.act_begin[i], d.act_targets.begin() + d.act_begin[i + 1]);
-      begin.push_back((int32_t)targets.size());
-      n_mean.push_back((int32_t)seq_[k]->n_mean_converge);
-    }
-  }
-  std::vector<hso_activate_out> out(seeds.size());
-  if (!seeds.empty()) {
-    hso_activate_target none{};
-    check(hso_gpu_seed_activate_multi(ctx_, &cam_.pod(), seeds.data(), (int)seeds.size(), begin.data(), targets.empty() ? &none : targets.data(),
-                                      n_mean.data(), out.data(), nullptr), "DepthFilter::activatePoint");
+  if (n_seeds > 0) {
+    if (n_targets == 0) targets[0] = hso_activate_target{};
+    check(hso_gpu_seed_activate_multi(ctx_, &cam_.pod(), seeds, (int)n_seeds, begin, targets, n_mean, out, nullptr), "DepthFilter::activatePoint");
     n_calls_[7]++; n_items_[7] += (int64_t)who.size();
   }
-  for (size_t w = 0; w < who.size(); w++) {
-    StepData& d = *step_[who[w]];
-    for (size_t i = 0; i < d.conv.size(); i++) d.act_out[i] = out[at[w] + i];
-  }
-  par(who, [&](int k) {
+  pool_->run((int)who.size(), [&](int w) {
+    const int k = who[w];
     Seq& s = *seq_[k];
     StepData& d = *step_[k];
+    const hso_activate_out* const act_out = out + at[w];
     if (s.trace.on() && !d.conv.empty()) {
       Trace& t = s.trace;
       hso_activate_target none{};
+      std::vector<int32_t> rel(d.conv.size() + 1);
+      for (size_t c = 0; c <= d.conv.size(); c++) rel[c] = begin[at[w] + c] - begin[at[w]];
       t.begin("seed_activate", 6);
-      t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("seeds", d.act_seeds.data(), sizeof(hso_seed) * d.act_seeds.size());
-      t.field("target_begin", d.act_begin.data(), sizeof(int32_t) * d.act_begin.size());
-      t.field("targets", d.act_targets.empty() ? &none : d.act_targets.data(), sizeof(hso_activate_target) * d.act_targets.size());
-      t.scalar("n_mean_converge_frame", (double)s.n_mean_converge); t.field("out", d.act_out.data(), sizeof(hso_activate_out) * d.act_out.size());
+      t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("seeds", seeds + at[w], sizeof(hso_seed) * d.conv.size());
+      t.field("target_begin", rel.data(), sizeof(int32_t) * rel.size());
+      t.field("targets", n_tg[w] == 0 ? &none : targets + tg_at[w], sizeof(hso_activate_target) * n_tg[w]);
+      t.scalar("n_mean_converge_frame", (double)s.n_mean_converge); t.field("out", act_out, sizeof(hso_activate_out) * d.conv.size());
     }
     for (size_t c = 0; c < d.conv.size(); c++) {
       const int i = d.conv[c];
       Seed& sd = s.seeds[i];
-      const hso_activate_out& o = d.act_out[c];
+      const hso_activate_out& o = act_out[c];
       bool valid = o.is_valid != 0;                               // -1: activatePoint left the flag alone
       if (o.activated) sd.mu = (float)o.opt_id;                   // :418-419
       const Feat& ft = s.feats[sd.feat];
@@ -443,6 +448,10 @@ void Bank::previous_begin(const std::vector<int>& who)
     }
   });
   erase_slots(who);                                                // moves the frames dropped above to the release list
+  // ... which waits until the pass has been collected: hso_gpu_frame_release waits for a pass in flight, and releasing these frames
+  // at the start of the next step would end the overlap the second stream exists for
+  after_prev_release_.insert(after_prev_release_.end(), to_release_.begin(), to_release_.end());
+  to_release_.clear();
   pending_prev_.who.clear(); pending_prev_.n_lists.clear();
   for (int k : who) {
     const Seq& s = *seq_[k];
@@ -456,7 +465,7 @@ void Bank::previous_begin(const std::vector<int>& who)
     pending_prev_.who.push_back(k); pending_prev_.n_lists.push_back(s.pre_lists.size());
     tracing |= s.trace.on();
   }
-  if (hosts.empty()) return;
+  if (hosts.empty()) { to_release_.insert(to_release_.end(), after_prev_release_.begin(), after_prev_release_.end()); after_prev_release_.clear(); return; }
   int n_slots = 0, n_live = 0;
   check(hso_gpu_seed_table_size(ctx_, seed_table_, &n_slots, &n_live), "DepthFilter");
   pending_prev_.n_slots = n_slots;
@@ -485,6 +494,8 @@ void Bank::previous_collect()
 {
   if (!pending_prev_.on) return;
   pending_prev_.on = false;
+  to_release_.insert(to_release_.end(), after_prev_release_.begin(), after_prev_release_.end());
+  after_prev_release_.clear();
   const int n_slots = pending_prev_.n_slots;
   if (pending_prev_.async) {
     seed_brief_.need(ctx_, (size_t)std::max(n_slots, 1));

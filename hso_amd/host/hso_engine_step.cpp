@@ -31,7 +31,8 @@ struct Clock {
 void Bank::add_images(const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device)
 {
   if (w != cam_.width() || h != cam_.height())      // src/frame.cpp:85-86: thrown before anything is touched
-    throw std::invalid_argument("Frame: provided image has not the same size as the camera model or image is not grayscale");
+    throw Refused("Frame: provided image has not the same size as the camera model or image is not grayscale");
+  if (on_device) for (int k = 0; k < size(); k++) if (imgs[k] && seq_[k]->trace.on()) throw Refused("trace: images must be host images");
   step(imgs, w, h, stamps, on_device);
 }
 
@@ -62,8 +63,7 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
     who.push_back(k);
   }
   if (who.empty()) return;
-  for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
-  to_release_.clear();
+  release_queued();
 
   Clock ck(phase_ms_, phase_census_, getenv("HSO_ENGINE_TIMING") != nullptr);
   upload(who, imgs, w, h, stamps, on_device);
@@ -100,8 +100,7 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
   }
   flush_maps(who);
   finish(who);
-  for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);
-  to_release_.clear();
+  release_queued();
   // the depth filter's idle-time sweep over the sequences that stepped, beside the next step's tracking
   {
     std::vector<int> swept;
@@ -141,7 +140,6 @@ void Bank::upload(const std::vector<int>& who, const uint8_t* const* imgs, int w
     Frame& F = s.frames[s.cur];
     F.integral = st[i].integral_image; F.grad_mean = st[i].grad_mean;
     if (s.trace.on()) {
-      if (on_device) throw std::invalid_argument("trace: images must be host images");
       s.trace.begin("frame_upload", 5);
       s.trace.scalar("frame_id", (double)F.dev_id); s.trace.scalar("width", w); s.trace.scalar("height", h);
       s.trace.field("img", imgs[who[i]], (size_t)w * h); s.trace.field("stats", &st[i], sizeof(st[i]));

@@ -117,6 +117,9 @@ int hso_gpu_frame_upload_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids,
                                const uint8_t* const* imgs, int n, int width, int height,
                                int img_is_device, hso_frame_stats* stats_out /* n or NULL */);
 int hso_gpu_frame_release(hso_gpu_ctx* ctx, int64_t frame_id);
+/* n frames with one wait for the stream (~Frame of the frames n sequences dropped in a step); all or nothing: HSO_E_NOFRAME /
+ * HSO_E_INVALID (a frame hosts live seeds of a resident table) leave every frame resident. */
+int hso_gpu_frame_release_batch(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n);
 /* parity/debug read-back: level in [0,5); out has (w>>level)*(h>>level) bytes */
 int hso_gpu_frame_download_level(hso_gpu_ctx* ctx, int64_t frame_id, int level,
                                  uint8_t* out, int* w_out, int* h_out);
@@ -815,6 +818,136 @@ int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_camera* cam
                                          int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
                                          int out_capacity, int32_t* begin_out, int32_t* counts_out, uint8_t* projected_out,
                                          const hso_pose_chain* pose);
+/* ---- the resident per-frame chain ("removes the last per-frame host loop over the
+ *      pointer graph and the D2H / H2D of candidates between tracker and alignment").  FrameHandlerMono::processFrame from the motion
+ *      prior to the inputs of its keyframe decision (src/frame_handler_mono.cpp:173-291) for the current frames of n sequences, every
+ *      table it reads or writes resident in the sequence maps:
+ *        1. CoarseTracker::makeDepthRef (src/CoarseTracker.cpp:210-240): the reference frame's feature table (px, f, distance of the
+ *           point along the bearing) is built on the device from the features the previous call left for that frame — or, when the
+ *           reference is a keyframe, from the keyframe's feature list — and the point rows; CoarseTracker::run; the write-back of
+ *           :198-202 (cur.T_f_w_, m_exposure_time);
+ *        2. Reprojector::reprojectMap's walk (src/reprojector.cpp:98-254): the covisible keyframes the job names, then the keyframes
+ *           that see the frame (Map::getCloseKeyframes, src/map.cpp:193-213: a key point of the keyframe projects into the frame),
+ *           nearest first, up to max_kfs; the points of their features once each (Point::last_projected_kf_id_), TYPE_TEMPORARY
+ *           skipped; then the candidates; then the temporary points the job lists;
+ *        3. projection, reference choice, findMatchDirect, the grid selection, the frame's features, optimizeLevenbergMarquardt3rd
+ *           (what hso_gpu_reproject_select_pose_frames chained, now over the device's own list);
+ *        4. the bookkeeping of reprojectCell / reprojectCellAll on the examined candidates (:366-425, :214-222, :247-251):
+ *           n_failed_reproj_ / n_succeeded_reproj_, UNKNOWN -> GOOD above 10 successes, deletion above 15 / 30 failures — applied to
+ *           the point rows' state words, the changes of kind reported as events; the outlier mask of the pose optimiser applied to the
+ *           frame's feature table (feature->point = NULL, src/pose_optimizer.cpp:722-748);
+ *        5. the inputs of the decisions that follow: needNewKf's two optical-flow sums over the last keyframe's features
+ *           (src/frame_handler_mono.cpp:428-507), createCovisibilityGraph's votes and ranking (:559-647), getSceneDepth /
+ *           getSceneDistance (src/frame.cpp:323-366: upper medians and the minimum depth).
+ *      Per sequence one hso_seq_job goes in and one hso_seq_result comes back; the caller keeps the keyframe-rate bookkeeping
+ *      (promotion, local BA, seeds) and mirrors the events. ---- */
+
+/* hso_map_point.pad_ of a sequence map = the point's state word */
+#define HSO_PT_KEY(w)     ((uint32_t)(w) & 0xffu)            /* (Point::type_ << 4) | Point::ftr_type_; type 0 = TYPE_DELETED */
+#define HSO_PT_NFAIL(w)   (((uint32_t)(w) >> 8) & 0x3ffu)    /* n_failed_reproj_, saturating at 1023 */
+#define HSO_PT_BAD        (1u << 18)                         /* a temporary point given up (isBad_) */
+#define HSO_PT_KEEP       (1u << 19)                         /* in a PATCHED row only: keep the device's counters and bad flag, take key */
+#define HSO_PT_NOK(w)     (((uint32_t)(w) >> 20) & 0x7ffu)   /* n_succeeded_reproj_, saturating at 2047 */
+#define HSO_PT_WORD(key, n_fail, bad, n_ok) ((int32_t)(((uint32_t)(key) & 0xffu) | (((uint32_t)(n_fail) & 0x3ffu) << 8) | ((bad) ? HSO_PT_BAD : 0u) | (((uint32_t)(n_ok) & 0x7ffu) << 20)))
+
+enum { HSO_LIST_CANDIDATES = -1 };   /* hso_seqmap_list_patch.list: MapPointCandidates::candidates_ in list order; >= 0: Frame::fts_ of that keyframe row */
+typedef struct hso_seqmap_list_patch {
+  int32_t map, list;
+  int32_t first, n;            /* entries [first, first + n) are written; the list's length becomes first + n */
+  const int32_t* ids;          /* feature (= observation) rows of a keyframe's list; point rows of the candidate list */
+} hso_seqmap_list_patch;
+/* fts_cap: capacity of a keyframe's feature list (its own features + the features of its seeds that became points:
+ * max(2000, max_fts) + max_fts + 100 in the reference's configuration).  Once per map, before the first list patch. */
+int hso_gpu_seqmap_configure(hso_gpu_ctx* ctx, int map, int fts_cap);
+int hso_gpu_seqmap_patch_lists(hso_gpu_ctx* ctx, const hso_seqmap_list_patch* patches, int n_patches);
+/* Feature::point of observation rows (the row of the point a keyframe feature observes, -1: none) and Frame::key_pts_ of the
+ * keyframes as point rows (5 per keyframe row, -1: none), the two links the chain follows that the tables above do not carry */
+int hso_gpu_seqmap_patch_links(hso_gpu_ctx* ctx, int map, const int32_t* obs_ids, const int32_t* obs_point, int n_obs);
+int hso_gpu_seqmap_set_key_points(hso_gpu_ctx* ctx, int map, const int32_t* key_points /* 5 * n_kfs */, int n_kfs);
+
+#define HSO_SEQ_MAX_VISIT 24
+#define HSO_SEQ_MAX_COVIS 8
+#define HSO_SEQ_EVENTS 40
+enum { HSO_EV_ERASE_POINT = 1,       /* Map::safeDeletePoint (a TYPE_UNKNOWN point failed more than 15 times, reprojector.cpp:376-381) */
+       HSO_EV_ERASE_CANDIDATE = 2,   /* MapPointCandidates::deleteCandidatePoint (more than 30 failures, :382-386, :214-222) */
+       HSO_EV_TEMP_BAD = 3,          /* a temporary point's isBad_ (:387-390, :247-251) */
+       HSO_EV_GOOD = 4 };            /* TYPE_UNKNOWN -> TYPE_GOOD (:412-416) */
+enum { HSO_SEQ_NO_TRACK = 1 };       /* hso_seq_job.flags: the reference frame has no features: CoarseTracker::run returns 0 at once (CoarseTracker.cpp:53-54) */
+
+typedef struct hso_seq_job {
+  int32_t map;                 /* the sequence map */
+  int32_t flags;               /* HSO_SEQ_* */
+  int64_t ref_frame_id;        /* the frame the tracker aligns against; resident */
+  int64_t cur_frame_id;        /* the new frame; resident */
+  hso_se3 T_ref_w;             /* ref.T_f_w_ */
+  hso_se3 T_cur_w;             /* cur.T_f_w_ as processFrame sets it before tracking: motion model * last pose (:176) */
+  double ref_exposure;         /* ref.m_exposure_time */
+  int32_t ref_kf_row;          /* >= 0: the reference frame is this keyframe of the map (its fts list is the feature table);
+                                  -1: it is the frame whose features the previous chain call (or hso_gpu_seq_set_frame_features) left */
+  int32_t n_ref_feats;         /* ref.fts_.size() (the caller knows it: the previous result's n_feats, or the keyframe list's length) */
+  int32_t cur_keyframe_id;     /* cur.keyFrameId_ */
+  int32_t last_kf_row;         /* Map::lastKeyframe() (needNewKf's keyframe), -1: skip the flow sums */
+  int32_t covis[5];            /* ref.connectedKeyFrames as keyframe rows in list order, -1 padded (reprojector.cpp:124-170) */
+  int32_t temps_begin, n_temps;/* this job's slice of the call's `temps` array: the temporary points to list (not bad, positions already placed) */
+  int32_t pad_;
+} hso_seq_job;
+
+typedef struct hso_seq_chain_cfg {
+  hso_track_params track;      /* CoarseTracker's constructor arguments; every job of a call runs the same mode */
+  int32_t cell_size, grid_n_cols, n_cells, max_fts;   /* Reprojector::initializeGrid; Config::maxFts() */
+  const int32_t* cell_order;   /* host, n_cells entries */
+  int32_t max_kfs;             /* Reprojector::Options::max_n_kfs (10) */
+  int32_t pose_n_iter;         /* 12 */
+  double pose_reproj_thresh;   /* Config::poseOptimThresh() */
+  int32_t want_debug;          /* 1: keep the intermediate tables for hso_gpu_debug_fetch (recorded runs) */
+  int32_t pad_;
+} hso_seq_chain_cfg;
+
+typedef struct hso_seq_result {
+  hso_track_result track;
+  hso_pose_result pose;
+  hso_se3 T_tracked;           /* cur.T_f_w_ after CoarseTracker::run (the pose the reprojection used) */
+  double exposure;             /* cur.m_exposure_time */
+  int32_t counts[4];           /* n_trials_, n_matches_, cell passes, branch (hso_gpu_reproject_select) */
+  int32_t n_feats;             /* features of the frame = candidates that became features, in fts_ order */
+  int32_t n_listed, n_kf_points, n_candidates;   /* the list: keyframe points | candidates | temporary points */
+  int32_t n_visit, visit[HSO_SEQ_MAX_VISIT];     /* keyframe rows whose points were listed, in visiting order */
+  float flow_full, flow_shift; /* needNewKf: the two float sums over the last keyframe's features with a point (serial, in list order) */
+  int32_t flow_count;
+  int32_t n_with_point;        /* features of the frame that still have a point after the pose optimiser's culling */
+  int32_t n_covis;             /* keyframes observing at least one of the frame's points */
+  int32_t covis[HSO_SEQ_MAX_COVIS], covis_votes[HSO_SEQ_MAX_COVIS];   /* the ranking of createCovisibilityGraph: keyframe rows, best first */
+  int32_t covis_best;          /* the keyframe row with the most votes (the fallback when none reaches the bar) */
+  double depth_median, dist_median, depth_min;   /* getSceneDepth / getSceneDistance over the frame's points; depth_min = DBL_MAX when none */
+  int32_t n_events;            /* kind changes of points, in the order the reference makes them; > HSO_SEQ_EVENTS: fetch them all with hso_gpu_seq_events */
+  int32_t events[HSO_SEQ_EVENTS];   /* (HSO_EV_* << 28) | point row */
+} hso_seq_result;
+
+/* temps: the jobs' temporary-point lists back to back (host; may be NULL when n_temps_total == 0) */
+int hso_gpu_seq_chain(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seq_chain_cfg* cfg, const hso_seq_job* jobs, int n_jobs,
+                      const int32_t* temps, int n_temps_total, hso_seq_result* results);
+/* every event of job `job` of the last chain call (n_events of them) */
+int hso_gpu_seq_events(hso_gpu_ctx* ctx, int job, int32_t* events_out, int cap);
+
+/* A frame's features as the chain keeps them for the sequence's newest frame (Frame::fts_ of a frame that is not a keyframe) */
+typedef struct hso_seq_feature {
+  double px[2];                /* Feature::px */
+  double f[3];                 /* Feature::f */
+  float grad[2];               /* Feature::grad (edgelets) */
+  int32_t point;               /* Feature::point as a point row, -1: NULL */
+  int8_t level, type;          /* Feature::level, Feature::type */
+  int16_t pad_;
+} hso_seq_feature;
+/* read the feature tables the last chain call left for the frames of `maps` (a keyframe promotion needs them on the host):
+ * out holds n_maps rows of cap features; n_out[i] = the table's length.  The frame ids must match what the maps hold. */
+int hso_gpu_seq_frame_features(hso_gpu_ctx* ctx, const int32_t* maps, const int64_t* frame_ids, int n_maps, hso_seq_feature* out, int cap, int32_t* n_out);
+/* replace the table a map holds (the caller changed the frame's features: the seed branch of reprojectMap, a two-view start) */
+int hso_gpu_seq_set_frame_features(hso_gpu_ctx* ctx, int map, int64_t frame_id, const hso_seq_feature* feats, int n);
+/* recorded runs / parity: the list of job `job` of the last chain call (point rows and quality keys, n_listed of them), and its
+ * reference feature table in hso_ref_feat records */
+int hso_gpu_seq_debug_list(hso_gpu_ctx* ctx, int job, int32_t* ids_out, uint8_t* quality_out, int cap);
+int hso_gpu_seq_debug_ref_table(hso_gpu_ctx* ctx, int job, hso_ref_feat* out, int cap);
+
 /* trace / parity hook: tables the last hso_gpu_reproject_select_pose_frames call left in the work area (valid until the next
  * entry point that uses it): HSO_DBG_PROJ = hso_reproj_point per listed point, HSO_DBG_MATCH = hso_align_out per listed point,
  * HSO_DBG_POSE_FEATS = n_frames rows of max(max_fts, 1) hso_pose_feat (host_pose = index into HSO_DBG_POSE_POSES' row),

@@ -88,6 +88,16 @@ int hso_gpu_frame_release(hso_gpu_ctx* c, int64_t id)
   return HSO_OK;
 }
 
+int hso_gpu_frame_release_batch(hso_gpu_ctx* c, const int64_t* ids, int n)
+{
+  for (int i = 0; i < n; i++) {
+    if (!frame_of(c, ids[i])) return fail(c, HSO_E_NOFRAME, "frame_release_batch: not resident");
+    for (auto* t : c->tables) if (t) for (size_t k = 0; k < t->s.size(); k++) if (t->alive[k] && t->s[k].ref_frame_id == ids[i]) return fail(c, HSO_E_INVALID, "frame_release_batch: hosts live seeds");
+  }
+  for (int i = 0; i < n; i++) if (FakeFrame* F = frame_of(c, ids[i])) { delete F; c->frames.erase(ids[i]); }
+  return HSO_OK;
+}
+
 int hso_gpu_coarse_track_batch(hso_gpu_ctx* c, const hso_camera* cam, const hso_track_params* p, const hso_track_job* jobs, int n, hso_track_result* res)
 {
   for (int i = 0; i < n; i++) {
