@@ -163,11 +163,6 @@ class PoseResult(C.Structure):
                 ("n_trials_total", C.c_int32), ("status", C.c_int32)]
 
 
-class PoseChain(C.Structure):
-    _fields_ = [("reproj_thresh", C.c_double), ("n_iter", C.c_int32), ("pad_", C.c_int32), ("results", C.c_void_p),
-                ("n_feats", C.c_void_p), ("outlier_mask", C.c_void_p), ("feat_f", C.c_void_p), ("records", C.c_void_p)]
-
-
 def make_pose_job(feats, poses, T_f_w, reproj_thresh=2.0, n_iter=12):
     """feats: POSE_FEAT_DTYPE array; poses: list of SE3 (host keyframe T_f_w)."""
     feats = np.ascontiguousarray(feats, dtype=POSE_FEAT_DTYPE)
@@ -200,9 +195,6 @@ class SeedOut(C.Structure):
 SEED_BRIEF_DTYPE = np.dtype([("mu", "<f4"), ("sigma2", "<f4"), ("b", "<f4"), ("result", "i1"), ("is_update", "i1"), ("is_valid", "i1"),
                              ("search_level", "i1")])
 assert SEED_BRIEF_DTYPE.itemsize == 16
-MAP_CALL_DTYPE = np.dtype([("map", "<i4"), ("cur_keyframe_id", "<i4"), ("cur_frame_id", "<i8"), ("q", "<f8", 4), ("t", "<f8", 3),
-                           ("cur_exposure_time", "<f8")])
-assert MAP_CALL_DTYPE.itemsize == 80
 MATCH_BRIEF_DTYPE = np.dtype([("px", "<f8", 2), ("px_cur", "<f8", 2), ("grad", "<f4", 2), ("cell", "<i4"), ("ref_obs", "<i4"),
                               ("success", "i1"), ("stage", "i1"), ("search_level", "i1"), ("ref_type", "i1"), ("pad_", "<i4")])
 assert MATCH_BRIEF_DTYPE.itemsize == 56
@@ -332,14 +324,11 @@ def load():
     lib.hso_gpu_ba_optimize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double, i32, vp, P(BaResult)]
     lib.hso_gpu_ba_optimize_multi.argtypes = [vp, P(BaProblem), i32]
     lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
-    lib.hso_gpu_reproject_select_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
-    lib.hso_gpu_map_update_quality.argtypes = [vp, vp, i32, vp]
     lib.hso_gpu_host_alloc.argtypes = [vp, C.c_size_t, P(vp)]
     lib.hso_gpu_host_free.argtypes = [vp, vp]
     lib.hso_gpu_klt_track.argtypes = [vp, i64, i64, vp, vp, i32, P(KltParams), vp]
     lib.hso_gpu_klt_levels.argtypes = [i32, i32, i32, i32]
     lib.hso_gpu_klt_debug_level.argtypes = [vp, i64, i32, vp, vp]
-    lib.hso_gpu_reproject_select_pose_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp, P(PoseChain)]
     lib.hso_gpu_seed_activate_multi.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), P(i32), P(ActivateOut),
                                                 P(AlignOut)]
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
@@ -357,9 +346,6 @@ def load():
     lib.hso_gpu_seed_table_observe_previous.argtypes = [vp, P(Camera), i32, vp, P(SeedFrame), i32, C.c_double, vp, vp]
     lib.hso_gpu_seed_table_observe_previous_begin.argtypes = [vp, P(Camera), i32, vp, P(SeedFrame), i32, C.c_double]
     lib.hso_gpu_seed_table_observe_previous_end.argtypes = [vp, i32, vp, i32]
-    lib.hso_gpu_map_reserve.argtypes = [vp, i32, i32, i32, i32]
-    lib.hso_gpu_map_store.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32]
-    lib.hso_gpu_reproject_match_maps.argtypes = [vp, P(Camera), vp, i32, i32, i32, vp, i32]
     lib.hso_gpu_seed_reproject_match.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, vp, i32, i32, i32, vp, vp]
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
     lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
@@ -386,14 +372,15 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize", "hso_gpu_ba_optimize_multi",
-    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select", "hso_gpu_reproject_select_maps", "hso_gpu_reproject_select_pose_maps", "hso_gpu_map_update_quality",
+    "hso_gpu_seed_activate_multi", "hso_gpu_reproject_select",
     "hso_gpu_seed_reproject_match",
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
-    "hso_gpu_map_reserve", "hso_gpu_map_store", "hso_gpu_reproject_match_maps",
     "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level", "hso_gpu_host_alloc", "hso_gpu_host_free", "hso_gpu_seed_table_compact",
     "hso_gpu_seqmap_create", "hso_gpu_seqmap_destroy", "hso_gpu_seqmap_set_keyframes", "hso_gpu_seqmap_patch", "hso_gpu_seqmap_patch_multi", "hso_gpu_seqmap_size", "hso_gpu_seqmap_read",
-    "hso_gpu_reproject_select_pose_frames", "hso_gpu_debug_fetch", "hso_gpu_seed_table_observe_groups", "hso_gpu_seed_table_set_host_pose",
+    "hso_gpu_seqmap_configure", "hso_gpu_seqmap_patch_lists", "hso_gpu_seqmap_patch_links", "hso_gpu_seqmap_set_key_points",
+    "hso_gpu_seq_chain", "hso_gpu_seq_events", "hso_gpu_seq_frame_features", "hso_gpu_seq_set_frame_features", "hso_gpu_seq_debug_list", "hso_gpu_seq_debug_ref_table",
+    "hso_gpu_debug_fetch", "hso_gpu_seed_table_observe_groups", "hso_gpu_seed_table_set_host_pose",
     "hso_gpu_seed_table_observe_previous", "hso_gpu_seed_table_observe_previous_begin", "hso_gpu_seed_table_observe_previous_end",
 ]
 
@@ -840,21 +827,6 @@ class Context:
         self._check(self.lib.hso_gpu_seed_table_read(self.h, table, first, n, C.cast(out, C.c_void_p)), "seed_table_read")
         return out
 
-    # -- resident maps
-    def map_reserve(self, n_maps, max_kfs, max_points, max_obs):
-        self._check(self.lib.hso_gpu_map_reserve(self.h, n_maps, max_kfs, max_points, max_obs), "map_reserve")
-
-    def map_store(self, index, kfs, points, obs):
-        kfs = np.ascontiguousarray(kfs, KF_DTYPE); points = np.ascontiguousarray(points, MAP_POINT_DTYPE)
-        obs = np.ascontiguousarray(obs, OBS_DTYPE)
-        self._check(self.lib.hso_gpu_map_store(self.h, index, _ptr(kfs), len(kfs), _ptr(points), len(points), _ptr(obs), len(obs)), "map_store")
-
-    def map_update_quality(self, maps, quality):
-        """maps: map indices; quality: their points' keys back to back (uint8)."""
-        m = np.ascontiguousarray(np.atleast_1d(maps), np.int32)
-        q = np.ascontiguousarray(quality, np.uint8)
-        self._check(self.lib.hso_gpu_map_update_quality(self.h, _ptr(m), len(m), _ptr(q)), "map_update_quality")
-
     def klt_track(self, frame_prev, frame_cur, px_prev, px_init, params=None):
         """initialization::trackKlt's device part between two resident frames -> KLT_RESULT_DTYPE array."""
         a = np.ascontiguousarray(px_prev, np.float32).reshape(-1, 2)
@@ -874,48 +846,6 @@ class Context:
         img = np.zeros((h, w), np.uint8); der = np.zeros((h, w, 2), np.int16)
         self._check(self.lib.hso_gpu_klt_debug_level(self.h, frame, level, _ptr(img), _ptr(der)), "klt_debug_level")
         return img, der
-
-    def reproject_match_maps(self, cam, calls, cell_size, grid_n_cols, capacity):
-        """calls: MAP_CALL_DTYPE array.  -> MATCH_BRIEF_DTYPE array (the calls' points back to back)."""
-        calls = np.ascontiguousarray(calls, MAP_CALL_DTYPE)
-        out = np.zeros(capacity, MATCH_BRIEF_DTYPE)
-        n = self._check(self.lib.hso_gpu_reproject_match_maps(self.h, C.byref(cam), _ptr(calls), len(calls), cell_size, grid_n_cols, _ptr(out),
-                                                              capacity), "reproject_match_maps")
-        return out[:n]
-
-    def reproject_select_maps(self, cam, calls, cell_size, grid_n_cols, cell_order, max_fts, capacity):
-        """reproject_match_maps + the grid selection on the device.  -> (MATCH_BRIEF_DTYPE array of the examined candidates of
-        all calls back to back, begin[n_calls + 1], counts[n_calls, 4])."""
-        calls = np.ascontiguousarray(calls, MAP_CALL_DTYPE)
-        order = np.ascontiguousarray(cell_order, np.int32)
-        out = np.zeros(capacity, MATCH_BRIEF_DTYPE)
-        begin = np.zeros(len(calls) + 1, np.int32)
-        counts = np.zeros((len(calls), 4), np.int32)
-        n = self._check(self.lib.hso_gpu_reproject_select_maps(self.h, C.byref(cam), _ptr(calls), len(calls), cell_size, grid_n_cols,
-                                                               _ptr(order), len(order), max_fts, _ptr(out), capacity, _ptr(begin),
-                                                               _ptr(counts)), "reproject_select_maps")
-        return out[:n], begin, counts
-
-    def reproject_select_pose_maps(self, cam, calls, cell_size, grid_n_cols, cell_order, max_fts, capacity, reproj_thresh=2.0, n_iter=12,
-                                   want_mask=True, out=None):
-        """reproject_select_maps + the pose optimisation chained on the device.
-        -> (briefs, begin, counts, PoseResult array, n_feats[n_calls], mask[n_calls, max(max_fts, 1)] or None).
-        out: a MATCH_BRIEF_DTYPE array of >= capacity records to receive the briefs (host_array(): no staging copy)."""
-        calls = np.ascontiguousarray(calls, MAP_CALL_DTYPE)
-        order = np.ascontiguousarray(cell_order, np.int32)
-        if out is None:
-            out = np.zeros(capacity, MATCH_BRIEF_DTYPE)
-        assert out.dtype == MATCH_BRIEF_DTYPE and len(out) >= capacity and out.flags.c_contiguous
-        begin = np.zeros(len(calls) + 1, np.int32)
-        counts = np.zeros((len(calls), 4), np.int32)
-        res = (PoseResult * max(len(calls), 1))()
-        nf = np.zeros(max(len(calls), 1), np.int32)
-        mask = np.zeros((max(len(calls), 1), max(max_fts, 1)), np.uint8) if want_mask else None
-        pc = PoseChain(reproj_thresh, n_iter, 0, C.cast(res, C.c_void_p), nf.ctypes.data, mask.ctypes.data if want_mask else None)
-        n = self._check(self.lib.hso_gpu_reproject_select_pose_maps(self.h, C.byref(cam), _ptr(calls), len(calls), cell_size, grid_n_cols,
-                                                                    _ptr(order), len(order), max_fts, _ptr(out), capacity, _ptr(begin),
-                                                                    _ptr(counts), C.byref(pc)), "reproject_select_pose_maps")
-        return out[:n], begin, counts, res, nf[:len(calls)], mask
 
     # -- FAST-9 corner candidates
     def fast_detect(self, frame_id, n_levels=3, threshold=20, border=8, cap=20000):

@@ -17,6 +17,7 @@
 // only (stated tolerance: 1e-3 px on the result).  Instruction-issue-bound (profiles/r3_stage_sq_align.csv:
 // VALU 100 % busy with one candidate per wave), hence the packing.
 #include "hso_match_dev.h"
+#include "hso_pose_dev.h"
 #include <stddef.h>
 #include <algorithm>
 #include <string.h>
@@ -265,35 +266,6 @@ __global__ __launch_bounds__(256) void k_reproject(ReprojConsts R, AlignJobDev* 
   proj[i] = reproject_one(R.cam, R.pts[i], F, R.kfs + F.kf_begin, R.obs, R.cell_size, R.grid_n_cols, &jobs[i]);
 }
 
-// ---- resident maps: the tables of many sequences' local maps stay in HBM (one equal-sized region each); a call names its map
-struct MapCallDev {
-  ReprojFrameDev F;          // kf_begin = first row of the call's ReprojKf block
-  int map, point_begin, point_count, pad_;
-};
-struct MapConsts {
-  hso_camera cam;
-  const MapCallDev* calls;
-  int n_calls, n_total;
-  const ReprojKf* kfs;       // per call: max_kfs rows
-  const hso_map_point* pts;  // arena: [n_maps][max_points]
-  const hso_obs* obs;        // arena: [n_maps][max_obs]
-  int max_points, max_obs, cell_size, grid_n_cols;
-};
-
-__global__ __launch_bounds__(256) void k_reproject_maps(MapConsts M, AlignJobDev* jobs, hso_reproj_point* proj)
-{
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= M.n_total) return;
-  int lo = 0, hi = M.n_calls - 1;          // the call whose point range holds g
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (M.calls[mid].point_begin <= g) lo = mid; else hi = mid - 1; }
-  const MapCallDev& C = M.calls[lo];
-  const int i = g - C.point_begin;
-  const hso_map_point& pt = M.pts[(size_t)C.map * M.max_points + i];
-  hso_reproj_point r = reproject_one(M.cam, pt, C.F, M.kfs + C.F.kf_begin, M.obs + (size_t)C.map * M.max_obs, M.cell_size, M.grid_n_cols, &jobs[g]);
-  r.pad_ = pt.pad_;   // the point's quality key rides along for the on-device grid selection (hso_gpu_reproject_select_maps)
-  proj[g] = r;
-}
-
 // projection + match of one point -> the compact record the host's grid selection consumes
 __global__ __launch_bounds__(256) void k_match_brief(int n, const hso_reproj_point* proj, const hso_align_out* match, const AlignJobDev* jobs,
                                                      hso_match_brief* out)
@@ -464,284 +436,52 @@ extern "C" int hso_gpu_reproject_match(hso_gpu_ctx* ctx, const hso_camera* cam, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Resident maps: a sequence's local map — keyframe poses, map points, observations,
-// the tables of hso_gpu_reproject_match — changes at keyframe rate only, so it is stored once per keyframe
-// (hso_gpu_map_store) and every frame in between passes its pose alone; the results come back as 56-byte records.
-struct MapArena {
-  int n_maps = 0, max_kfs = 0, max_points = 0, max_obs = 0;
-  hso_map_point* d_pts = nullptr;
-  hso_obs* d_obs = nullptr;
-  std::vector<std::vector<hso_kf>> kfs;     // per map (host: the per-call products are formed from them)
-  std::vector<int> n_points, n_obs;
-  PyrGeom g{}; bool have_g = false;
-};
-
-void hso_map_arena_free(hso_gpu_ctx* ctx)
-{
-  if (!ctx->maps) return;
-  (void)hipFree(ctx->maps->d_pts); (void)hipFree(ctx->maps->d_obs);
-  delete ctx->maps;
-  ctx->maps = nullptr;
-}
-
-// what the chained pose optimisation (hso_select.hip) needs of the stored maps
-const hso_map_point* hso_map_points_dev(hso_gpu_ctx* ctx) { return ctx->maps ? ctx->maps->d_pts : nullptr; }
-int hso_map_max_points(hso_gpu_ctx* ctx) { return ctx->maps ? ctx->maps->max_points : 0; }
-int hso_map_max_kfs(hso_gpu_ctx* ctx) { return ctx->maps ? ctx->maps->max_kfs : 0; }
-int hso_map_kf_poses(hso_gpu_ctx* ctx, int map, hso_se3* out)
-{
-  const std::vector<hso_kf>& kfs = ctx->maps->kfs[map];
-  for (size_t k = 0; k < kfs.size(); k++) out[k] = kfs[k].T_f_w;
-  return (int)kfs.size();
-}
-
-extern "C" int hso_gpu_map_reserve(hso_gpu_ctx* ctx, int n_maps, int max_kfs, int max_points, int max_obs)
-{
-  if (!ctx) return HSO_E_INVALID;
-  if (n_maps <= 0 || max_kfs <= 0 || max_points <= 0 || max_obs <= 0) return hso_fail(ctx, HSO_E_INVALID, "map_reserve: bad argument");
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  hso_map_arena_free(ctx);
-  MapArena* A = new MapArena();
-  A->n_maps = n_maps; A->max_kfs = max_kfs; A->max_points = max_points; A->max_obs = max_obs;
-  A->kfs.resize(n_maps); A->n_points.assign(n_maps, 0); A->n_obs.assign(n_maps, 0);
-  if (hipMalloc(reinterpret_cast<void**>(&A->d_pts), sizeof(hso_map_point) * (size_t)n_maps * max_points) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&A->d_obs), sizeof(hso_obs) * (size_t)n_maps * max_obs) != hipSuccess) {
-    (void)hipFree(A->d_pts); (void)hipFree(A->d_obs); delete A;
-    return hso_fail(ctx, HSO_E_NOMEM, "map_reserve: out of device memory");
-  }
-  ctx->maps = A;
-  return HSO_OK;
-}
-
-extern "C" int hso_gpu_map_store(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, int n_kfs, const hso_map_point* points, int n_points,
-                                 const hso_obs* obs, int n_obs)
-{
-  if (!ctx) return HSO_E_INVALID;
-  MapArena* A = ctx->maps;
-  if (!A || map < 0 || map >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "map_store: no such map (hso_gpu_map_reserve first)");
-  if (n_kfs < 0 || n_points < 0 || n_obs < 0 || n_kfs > A->max_kfs || n_points > A->max_points || n_obs > A->max_obs ||
-      (n_kfs > 0 && !kfs) || (n_points > 0 && !points) || (n_obs > 0 && !obs))
-    return hso_fail(ctx, HSO_E_INVALID, "map_store: table larger than the reserved region, or null");
-  for (int k = 0; k < n_kfs; k++) {
-    auto it = ctx->frames.find(kfs[k].frame_id);
-    if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "map_store: keyframe not resident");
-    if (!A->have_g) { A->g = it->second.g; A->have_g = true; }
-    if (!same_geom(it->second.g, A->g)) return hso_fail(ctx, HSO_E_INVALID, "map_store: frames must share one size");
-  }
-  for (int i = 0; i < n_points; i++) {
-    const hso_map_point& p = points[i];
-    if (p.host_kf < 0 || p.host_kf >= n_kfs || p.obs_count < 0 || p.obs_begin < 0 || (long long)p.obs_begin + p.obs_count > n_obs)
-      return hso_fail(ctx, HSO_E_INVALID, "map_store: point table out of range");
-  }
-  for (int k = 0; k < n_obs; k++)
-    if (obs[k].kf < 0 || obs[k].kf >= n_kfs || obs[k].level < 0 || obs[k].level >= HSO_N_PYR_LEVELS)
-      return hso_fail(ctx, HSO_E_INVALID, "map_store: observation table out of range");
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  const size_t bp = sizeof(hso_map_point) * (size_t)n_points, bo = sizeof(hso_obs) * (size_t)n_obs;
-  char* h = hso_pinned(ctx, 0, bp + bo + 64);
-  if (!h) return HSO_E_NOMEM;
-  if (bp) memcpy(h, points, bp);
-  if (bo) memcpy(h + bp, obs, bo);
-  if (bp) HSO_HIP_CHECK(ctx, hipMemcpyAsync(A->d_pts + (size_t)map * A->max_points, h, bp, hipMemcpyHostToDevice, ctx->stream));
-  if (bo) HSO_HIP_CHECK(ctx, hipMemcpyAsync(A->d_obs + (size_t)map * A->max_obs, h + bp, bo, hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  A->kfs[map].assign(kfs, kfs + n_kfs);
-  A->n_points[map] = n_points; A->n_obs[map] = n_obs;
-  return HSO_OK;
-}
-
-// The per-frame part of a stored map.  Between two hso_gpu_map_store calls the reference changes, every frame, what the grid
-// selection orders and skips by: n_succeeded_reproj_ > 10 turns TYPE_UNKNOWN into TYPE_GOOD (the comparator's key), n_failed_reproj_
-// > 15 / 30 deletes points (src/reprojector.cpp:376-392, 412-423).  Those live in hso_map_point.pad_ — the quality key
-// (Point::type_ << 4) | ftr_type_, 0 = deleted — and this call refreshes the keys of one stored map from a byte per point
-// for any number of stored maps in one call (the bytes cross PCIe, not the tables; one small kernel scatters them onto the pad_
-// column).  Structural changes — new points (candidates
-// promoted on non-keyframes, temporary points), new observations, another keyframe set — still need hso_gpu_map_store.
-__global__ void k_map_quality(hso_map_point* pts, int max_points, const int* maps, const int* begin, int n_maps, const uint8_t* quality)
-{
-  const int m = blockIdx.y;
-  if (m >= n_maps) return;
-  const int n = begin[m + 1] - begin[m];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    pts[(size_t)maps[m] * max_points + i].pad_ = quality[begin[m] + i];
-}
-
-extern "C" int hso_gpu_map_update_quality(hso_gpu_ctx* ctx, const int32_t* maps, int n_maps, const uint8_t* quality)
-{
-  if (!ctx) return HSO_E_INVALID;
-  MapArena* A = ctx->maps;
-  if (!A || n_maps < 0 || (n_maps > 0 && (!maps || !quality))) return hso_fail(ctx, HSO_E_INVALID, "map_update_quality: bad argument");
-  if (n_maps == 0) return HSO_OK;
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  size_t total = 0;
-  for (int m = 0; m < n_maps; m++) {
-    if (maps[m] < 0 || maps[m] >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "map_update_quality: no such map");
-    total += (size_t)A->n_points[maps[m]];
-  }
-  if (total == 0) return HSO_OK;
-  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  const size_t b_maps = al(sizeof(int) * (size_t)n_maps), b_begin = al(sizeof(int) * (size_t)(n_maps + 1)), need = b_maps + b_begin + al(total);
-  char* h = hso_pinned(ctx, 0, need);
-  if (!h) return HSO_E_NOMEM;
-  int* hm = reinterpret_cast<int*>(h);
-  int* hb = reinterpret_cast<int*>(h + b_maps);
-  int t = 0;
-  for (int m = 0; m < n_maps; m++) { hm[m] = maps[m]; hb[m] = t; t += A->n_points[maps[m]]; }
-  hb[n_maps] = t;
-  memcpy(h + b_maps + b_begin, quality, total);
-  if (ctx->batch_cap < need) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
-    ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
-    ctx->batch_cap = hso_grown(need);
-  }
-  char* d = ctx->d_batch;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, ctx->stream));
-  int max_n = 0;
-  for (int m = 0; m < n_maps; m++) max_n = std::max(max_n, A->n_points[maps[m]]);
-  hipLaunchKernelGGL(k_map_quality, dim3((max_n + 255) / 256, n_maps), dim3(256), 0, ctx->stream, A->d_pts, A->max_points,
-                     reinterpret_cast<const int*>(d), reinterpret_cast<const int*>(d + b_maps), n_maps, reinterpret_cast<const uint8_t*>(d + b_maps + b_begin));
-  HSO_HIP_CHECK(ctx, hipGetLastError());
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return HSO_OK;
-}
-
-int hso_map_call_sizes(hso_gpu_ctx* ctx, const hso_map_call* calls, int n_calls, MapArenaSizes* Z)
-{
-  MapArena* A = ctx->maps;
-  Z->total = 0;
-  if (!A || n_calls < 0 || (n_calls > 0 && !calls)) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: bad argument");
-  for (int c = 0; c < n_calls; c++) {
-    if (calls[c].map < 0 || calls[c].map >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: no such map");
-    Z->total += A->n_points[calls[c].map];
-  }
-  return HSO_OK;
-}
-
-// The launch chain of hso_gpu_reproject_match_maps without the read-back: the records stay on the device (R), with
-// `extra_bytes` of the work area reserved behind them for a caller that goes on working there (the grid selection).
-int hso_reproject_maps_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
-                           int grid_n_cols, size_t extra_bytes, HsoMapsRun* R)
-{
-  MapArena* A = ctx->maps;
-  if (!A || !cam || n_calls < 0 || (n_calls > 0 && !calls) || cell_size < 1 || grid_n_cols < 1)
-    return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: bad argument");
-  R->n = 0; R->begin.assign(n_calls + 1, 0);
-  if (n_calls == 0) return 0;
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  size_t total = 0;
-  for (int c = 0; c < n_calls; c++) {
-    if (calls[c].map < 0 || calls[c].map >= A->n_maps) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: no such map");
-    total += (size_t)A->n_points[calls[c].map];
-    R->begin[c + 1] = (int)total;
-  }
-  if (total == 0) return 0;
-  if (cam->width != A->g.w[0] || cam->height != A->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: camera size differs from the frame size");
-  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  const size_t b_calls = al(sizeof(MapCallDev) * (size_t)n_calls), b_kfs = al(sizeof(ReprojKf) * (size_t)n_calls * A->max_kfs);
-  char* hin = hso_pinned(ctx, 0, b_calls + b_kfs);
-  if (!hin) return HSO_E_NOMEM;
-  MapCallDev* hc = reinterpret_cast<MapCallDev*>(hin);
-  ReprojKf* hk = reinterpret_cast<ReprojKf*>(hin + b_calls);
-  int begin = 0;
-  for (int c = 0; c < n_calls; c++) {
-    const hso_map_call& K = calls[c];
-    auto itc = ctx->frames.find(K.cur_frame_id);
-    if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match_maps: current frame not resident");
-    if (!same_geom(itc->second.g, A->g)) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: frames must share one size");
-    const Se3 Tc = se3_from(K.T_cur_w);
-    const Se3 ci = se3_inverse(Tc);
-    MapCallDev& D = hc[c];
-    D.F.cur_pos[0] = ci.tx; D.F.cur_pos[1] = ci.ty; D.F.cur_pos[2] = ci.tz;
-    D.F.cur_base = itc->second.base; D.F.kf_begin = c * A->max_kfs; D.F.pad_ = 0;
-    D.map = K.map; D.point_begin = begin; D.point_count = A->n_points[K.map]; D.pad_ = 0;
-    begin += D.point_count;
-    const std::vector<hso_kf>& kfs = A->kfs[K.map];
-    for (size_t k = 0; k < kfs.size(); k++) {
-      auto it = ctx->frames.find(kfs[k].frame_id);
-      if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_match_maps: a stored keyframe is no longer resident");
-      ReprojKf& R = hk[(size_t)c * A->max_kfs + k];
-      const Se3 inv = se3_inverse(se3_from(kfs[k].T_f_w));
-      R.T_cur_kf = se3_mul(Tc, inv);
-      R.pos[0] = inv.tx; R.pos[1] = inv.ty; R.pos[2] = inv.tz;
-      R.base = it->second.base; R.frame_id = kfs[k].frame_id;
-      R.exposure_rat = (float)(K.cur_exposure_time / kfs[k].exposure_time);
-      R.kf_gap_lt4 = (K.cur_keyframe_id - kfs[k].keyframe_id) < 4;
-    }
-  }
-  const size_t o_jobs = 0, o_match = o_jobs + al(sizeof(AlignJobDev) * total), o_proj = o_match + al(sizeof(hso_align_out) * total);
-  const size_t o_brief = o_proj + al(sizeof(hso_reproj_point) * total), o_in = o_brief + al(sizeof(hso_match_brief) * total);
-  const size_t o_extra = o_in + al(b_calls + b_kfs);
-  const size_t need = o_extra + extra_bytes;
-  if (ctx->batch_cap < need) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
-    ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
-    ctx->batch_cap = hso_grown(need);
-  }
-  char* d = ctx->d_batch;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_in, hin, b_calls + b_kfs, hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_match, 0, sizeof(hso_align_out) * total, ctx->stream));
-  MapConsts M;
-  M.cam = *cam; M.calls = reinterpret_cast<const MapCallDev*>(d + o_in); M.n_calls = n_calls; M.n_total = (int)total;
-  M.kfs = reinterpret_cast<const ReprojKf*>(d + o_in + b_calls); M.pts = A->d_pts; M.obs = A->d_obs;
-  M.max_points = A->max_points; M.max_obs = A->max_obs; M.cell_size = cell_size; M.grid_n_cols = grid_n_cols;
-  AlignJobDev* d_jobs = reinterpret_cast<AlignJobDev*>(d + o_jobs);
-  hso_align_out* d_match = reinterpret_cast<hso_align_out*>(d + o_match);
-  hso_reproj_point* d_proj = reinterpret_cast<hso_reproj_point*>(d + o_proj);
-  hso_match_brief* d_brief = reinterpret_cast<hso_match_brief*>(d + o_brief);
-  const int n = (int)total;
-  hipLaunchKernelGGL(k_reproject_maps, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, M, d_jobs, d_proj);
-  AlignConsts C;
-  C.cam = *cam; C.g = A->g;
-  launch_align(ctx, true, C, d_jobs, n, d_match);
-  hipLaunchKernelGGL(k_match_brief, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_proj, d_match, d_jobs, d_brief);
-  HSO_HIP_CHECK(ctx, hipGetLastError());
-  R->n = n; R->d_proj = d_proj; R->d_brief = d_brief; R->d_extra = d + o_extra;
-  return n;
-}
-
-extern "C" int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
-                                            int grid_n_cols, hso_match_brief* out, int out_capacity)
-{
-  if (!ctx) return HSO_E_INVALID;
-  HsoMapsRun R;
-  const int total = hso_reproject_maps_run(ctx, cam, calls, n_calls, cell_size, grid_n_cols, 0, &R);
-  if (total <= 0) return total;
-  if (!out || out_capacity < total) return hso_fail(ctx, HSO_E_INVALID, "reproject_match_maps: output smaller than the calls' points");
-  hso_match_brief* hb = reinterpret_cast<hso_match_brief*>(hso_pinned(ctx, 1, sizeof(hso_match_brief) * (size_t)total));
-  if (!hb) return HSO_E_NOMEM;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hb, R.d_brief, sizeof(hso_match_brief) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(out, hb, sizeof(hso_match_brief) * (size_t)total);
-  return total;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Sequence maps (include/hso_gpu.h: hso_gpu_seqmap_*): the point and observation tables of a whole sequence, indexed by the
-// caller's own point / feature ids and patched row by row; a frame names the points it projects as an id list.
+// Sequence maps (include/hso_gpu.h: hso_gpu_seqmap_*): the tables of a whole sequence, indexed by the caller's own point / feature
+// ids and patched row by row — points (with their state words), observations (= keyframe features) with their Feature::point
+// links, the keyframe table with Frame::key_pts_, the keyframes' feature lists (Frame::fts_), the candidate list, and the feature
+// table of the sequence's newest frame.  The resident per-frame chain (hso_gpu_seq_chain, hso_select.hip) walks them on the device.
+#define SEQ_FIRST_UNSET 0x7f7f7f7f
 struct SeqMap {
   hso_map_point* d_pts = nullptr; size_t pts_cap = 0, n_pts = 0;
+  int32_t* d_first = nullptr; size_t first_cap = 0;          // per point row: the listing's stamp scratch (SEQ_FIRST_UNSET between calls)
   hso_obs* d_obs = nullptr; size_t obs_cap = 0, n_obs = 0;
+  int32_t* d_obs_pt = nullptr; size_t obs_pt_cap = 0;        // Feature::point per observation row, -1 none
   std::vector<hso_kf> kfs;
+  std::vector<int32_t> key_points;                            // 5 per keyframe row
+  SeqKfDev* d_kfs = nullptr; size_t kfs_cap = 0;
+  int fts_cap = 0;
+  int32_t* d_kf_fts = nullptr; size_t kf_rows_cap = 0;       // [rows][fts_cap]
+  std::vector<int32_t> kf_nfts;                               // length of every keyframe's list
+  int32_t* d_cands = nullptr; size_t cands_cap = 0; int n_cands = 0;
+  hso_seq_feature* d_ff[2] = {nullptr, nullptr}; int ff_cap = 0;
+  int64_t ff_frame[2] = {-1, -1}; int ff_n[2] = {0, 0}; int ff_newest = 0;
 };
 struct SeqMaps {
   std::vector<SeqMap*> m;
   PyrGeom g{}; bool have_g = false;
-  // where the last hso_gpu_reproject_select_pose_frames call left its tables (hso_gpu_debug_fetch)
-  const void* dbg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t dbg_bytes[5] = {0, 0, 0, 0, 0};
+  // where the last hso_gpu_seq_chain call left its tables (hso_gpu_debug_fetch)
+  const void* dbg[HSO_DBG_N] = {nullptr}; size_t dbg_bytes[HSO_DBG_N] = {0};
 };
+
+static void seqmap_release(SeqMap* m)
+{
+  (void)hipFree(m->d_pts); (void)hipFree(m->d_first); (void)hipFree(m->d_obs); (void)hipFree(m->d_obs_pt); (void)hipFree(m->d_kfs);
+  (void)hipFree(m->d_kf_fts); (void)hipFree(m->d_cands); (void)hipFree(m->d_ff[0]); (void)hipFree(m->d_ff[1]);
+  delete m;
+}
 
 void hso_seqmaps_free(hso_gpu_ctx* ctx)
 {
   if (!ctx->seqmaps) return;
-  for (SeqMap* m : ctx->seqmaps->m)
-    if (m) { (void)hipFree(m->d_pts); (void)hipFree(m->d_obs); delete m; }
+  for (SeqMap* m : ctx->seqmaps->m) if (m) seqmap_release(m);
   delete ctx->seqmaps;
   ctx->seqmaps = nullptr;
+}
+
+PyrGeom hso_seqmaps_geom(hso_gpu_ctx* ctx, bool* have)
+{
+  *have = ctx->seqmaps && ctx->seqmaps->have_g;
+  return *have ? ctx->seqmaps->g : PyrGeom{};
 }
 
 static SeqMap* seqmap_of(hso_gpu_ctx* ctx, int map)
@@ -775,20 +515,111 @@ static __global__ void k_scatter_rows_to(unsigned long long* const* __restrict__
   const size_t i = g / granules, q = g - i * granules;
   dst[i][q] = src[g];
 }
+// point rows: the quality key and the bad flag of a patched row are the caller's (it mirrors the kinds from the chain's events); a
+// counter is the caller's too unless the word says to keep the device's (HSO_PT_KEEP_NFAIL / HSO_PT_KEEP_NOK): the device counts the
+// reprojection failures / successes, the caller resets them (a new point, a promotion, a retired temporary point)
+HSO_DEV void point_row_store(hso_map_point* dst, const hso_map_point& src)
+{
+  uint32_t w = (uint32_t)src.pad_;
+  const uint32_t old = (uint32_t)dst->pad_;
+  if (w & HSO_PT_KEEP_NFAIL) w = (w & ~(0x3ffu << 8)) | (old & (0x3ffu << 8));
+  if (w & HSO_PT_KEEP_NOK) w = (w & ~(0x7ffu << 20)) | (old & (0x7ffu << 20));
+  w &= ~(HSO_PT_KEEP_NFAIL | HSO_PT_KEEP_NOK);
+  hso_map_point r = src;
+  r.pad_ = (int32_t)w;
+  *dst = r;
+}
+static __global__ void k_scatter_points(hso_map_point* __restrict__ dst, const int* __restrict__ ids, const hso_map_point* __restrict__ src, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) point_row_store(dst + ids[i], src[i]);
+}
+static __global__ void k_scatter_points_to(hso_map_point* const* __restrict__ dst, const hso_map_point* __restrict__ src, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) point_row_store(dst[i], src[i]);
+}
+static __global__ void k_scatter_ints_to(int32_t* const* __restrict__ dst, const int32_t* __restrict__ src, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) *dst[i] = src[i];
+}
+static __global__ void k_scatter_links(int32_t* __restrict__ dst, const int32_t* __restrict__ ids, const int32_t* __restrict__ src, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[ids[i]] = src[i];
+}
+// inclusive scan of v over a 256-thread workgroup; *total = the sum (all threads must call)
+__device__ int sel_scan256(int v, int* s_wave, int& total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  __syncthreads();
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0; total = 0;
+  for (int w = 0; w < 4; w++) { if (w < wave) base += s_wave[w]; total += s_wave[w]; }
+  return incl + base;
+}
 static_assert(sizeof(hso_map_point) % 8 == 0 && sizeof(hso_obs) % 8 == 0, "rows move in 8-byte granules");
 
-template <typename T> static int seqmap_grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need, size_t keep)
+// grow-only device array: new memory is filled with `fill` bytes, the first `keep` elements are carried over
+template <typename T> static int seqmap_grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need, size_t keep, int fill = 0)
 {
   if (*cap >= need) return HSO_OK;
   const size_t ncap = std::max(need + need / 2, (size_t)4096);
   T* q = nullptr;
   HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&q), ncap * sizeof(T)));
-  hipError_t e = hipMemsetAsync(q, 0, ncap * sizeof(T), ctx->stream);
+  hipError_t e = hipMemsetAsync(q, fill, ncap * sizeof(T), ctx->stream);
   if (e == hipSuccess && *p && keep) e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { (void)hipFree(q); ctx->err = std::string("seqmap: ") + hipGetErrorString(e); return HSO_E_HIP; }
   if (*p) (void)hipFree(*p);
   *p = q; *cap = ncap;
+  return HSO_OK;
+}
+
+// the tables that grow in step with the point / observation tables
+static int seqmap_grow_tables(hso_gpu_ctx* ctx, SeqMap* m, size_t need_pts, size_t need_obs)
+{
+  if (need_pts > m->pts_cap || need_obs > m->obs_cap || need_pts > m->first_cap || need_obs > m->obs_pt_cap) HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rc = seqmap_grow(ctx, &m->d_pts, &m->pts_cap, need_pts, m->n_pts)) return rc;
+  if (int rc = seqmap_grow(ctx, &m->d_first, &m->first_cap, m->pts_cap, 0, 0x7f)) return rc;          // never holds state between calls
+  if (int rc = seqmap_grow(ctx, &m->d_obs, &m->obs_cap, need_obs, m->n_obs)) return rc;
+  if (int rc = seqmap_grow(ctx, &m->d_obs_pt, &m->obs_pt_cap, m->obs_cap, m->n_obs, 0xff)) return rc;  // -1: no point
+  return HSO_OK;
+}
+
+static int seqmap_work_area(hso_gpu_ctx* ctx, size_t need)
+{
+  if (ctx->batch_cap >= need) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+  ctx->d_batch = nullptr; ctx->batch_cap = 0;
+  HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+  ctx->batch_cap = hso_grown(need);
+  return HSO_OK;
+}
+
+// the device copy of the keyframe table (+ base pointers, key points): rebuilt whenever either half changes (keyframe rate)
+static int seqmap_upload_kfs(hso_gpu_ctx* ctx, SeqMap* m)
+{
+  const size_t n = m->kfs.size();
+  if (n == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rc = seqmap_grow(ctx, &m->d_kfs, &m->kfs_cap, n, 0)) return rc;
+  std::vector<SeqKfDev> rows(n);
+  for (size_t k = 0; k < n; k++) {
+    auto it = ctx->frames.find(m->kfs[k].frame_id);
+    if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seqmap: keyframe not resident");
+    SeqKfDev& r = rows[k];
+    r.T_f_w = m->kfs[k].T_f_w; r.exposure_time = m->kfs[k].exposure_time; r.base = it->second.base; r.frame_id = m->kfs[k].frame_id;
+    r.keyframe_id = m->kfs[k].keyframe_id;
+    for (int q = 0; q < 5; q++) r.key_point[q] = 5 * k + q < m->key_points.size() ? m->key_points[5 * k + q] : -1;
+  }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(m->d_kfs, rows.data(), sizeof(SeqKfDev) * n, hipMemcpyHostToDevice, ctx->stream));   // staged: `rows` may go
   return HSO_OK;
 }
 
@@ -809,9 +640,18 @@ int hso_gpu_seqmap_destroy(hso_gpu_ctx* ctx, int map)
   SeqMap* m = seqmap_of(ctx, map);
   if (!m) return hso_fail(ctx, HSO_E_INVALID, "seqmap: no such map");
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(m->d_pts); (void)hipFree(m->d_obs);
-  delete m;
+  seqmap_release(m);
   ctx->seqmaps->m[map] = nullptr;
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_configure(hso_gpu_ctx* ctx, int map, int fts_cap)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || fts_cap < 1) return hso_fail(ctx, HSO_E_INVALID, "seqmap_configure: bad argument");
+  if (m->d_kf_fts && fts_cap != m->fts_cap) return hso_fail(ctx, HSO_E_INVALID, "seqmap_configure: the keyframe lists are already in use");
+  m->fts_cap = fts_cap;
   return HSO_OK;
 }
 
@@ -828,72 +668,27 @@ int hso_gpu_seqmap_set_keyframes(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, i
     if (!same_geom(it->second.g, S->g)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_set_keyframes: frames must share one size");
   }
   m->kfs.assign(kfs, kfs + n_kfs);
-  return HSO_OK;
+  m->key_points.resize(5 * (size_t)n_kfs, -1);
+  m->kf_nfts.resize((size_t)n_kfs, 0);
+  return seqmap_upload_kfs(ctx, m);
+}
+
+int hso_gpu_seqmap_set_key_points(hso_gpu_ctx* ctx, int map, const int32_t* key_points, int n_kfs)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || n_kfs < 0 || (size_t)n_kfs != m->kfs.size() || (n_kfs > 0 && !key_points)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_set_key_points: one row of five per keyframe of the table");
+  for (int i = 0; i < 5 * n_kfs; i++) if (key_points[i] < -1 || (key_points[i] >= 0 && (size_t)key_points[i] >= m->n_pts)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_set_key_points: point row out of range");
+  m->key_points.assign(key_points, key_points + 5 * (size_t)n_kfs);
+  return seqmap_upload_kfs(ctx, m);
 }
 
 int hso_gpu_seqmap_patch(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, const hso_map_point* points, int n_points,
                          const int32_t* obs_ids, const hso_obs* obs, int n_obs)
 {
-  if (!ctx) return HSO_E_INVALID;
-  SeqMap* m = seqmap_of(ctx, map);
-  if (!m || n_points < 0 || n_obs < 0 || (n_points > 0 && (!point_ids || !points)) || (n_obs > 0 && (!obs_ids || !obs)))
-    return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: bad argument");
-  if (n_points == 0 && n_obs == 0) return HSO_OK;
-  // the kernels trust the tables: check every index a row carries before it reaches the device
-  const int nk = (int)m->kfs.size();
-  size_t need_pts = m->n_pts, need_obs = m->n_obs;
-  for (int i = 0; i < n_obs; i++) {
-    if (obs_ids[i] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: negative observation id");
-    need_obs = std::max(need_obs, (size_t)obs_ids[i] + 1);
-  }
-  for (int i = 0; i < n_obs; i++) {
-    const hso_obs& o = obs[i];
-    if (o.kf < 0 || o.kf >= nk || o.level < 0 || o.level >= HSO_N_PYR_LEVELS || o.pad_ < -1 || (o.pad_ >= 0 && (size_t)o.pad_ >= need_obs))
-      return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: observation row out of range (keyframe table set first?)");
-  }
-  for (int i = 0; i < n_points; i++) {
-    const hso_map_point& p = points[i];
-    if (point_ids[i] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: negative point id");
-    need_pts = std::max(need_pts, (size_t)point_ids[i] + 1);
-    if (p.host_kf < 0 || p.host_kf >= nk || p.obs_count < 0 || (p.obs_count > 0 && (p.obs_begin < 0 || (size_t)p.obs_begin >= need_obs)))
-      return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: point row out of range");
-  }
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (int rc = seqmap_grow(ctx, &m->d_pts, &m->pts_cap, need_pts, m->n_pts)) return rc;
-  if (int rc = seqmap_grow(ctx, &m->d_obs, &m->obs_cap, need_obs, m->n_obs)) return rc;
-  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  const size_t b_pid = al(sizeof(int) * (size_t)n_points), b_pts = al(sizeof(hso_map_point) * (size_t)n_points);
-  const size_t b_oid = al(sizeof(int) * (size_t)n_obs), b_obs = al(sizeof(hso_obs) * (size_t)n_obs);
-  const size_t need = b_pid + b_pts + b_oid + b_obs;
-  if (ctx->batch_cap < need) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
-    ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
-    ctx->batch_cap = hso_grown(need);
-  }
-  char* d = ctx->d_batch;
-  if (n_points) {
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, point_ids, sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + b_pid, points, sizeof(hso_map_point) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
-    const int G = sizeof(hso_map_point) / 8;
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)(((size_t)n_points * G + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<unsigned long long*>(m->d_pts), reinterpret_cast<const int*>(d), reinterpret_cast<const unsigned long long*>(d + b_pid), n_points, G);
-  }
-  if (n_obs) {
-    char* e = d + b_pid + b_pts;
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(e, obs_ids, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(e + b_oid, obs, sizeof(hso_obs) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
-    const int G = sizeof(hso_obs) / 8;
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)(((size_t)n_obs * G + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<unsigned long long*>(m->d_obs), reinterpret_cast<const int*>(e), reinterpret_cast<const unsigned long long*>(e + b_oid), n_obs, G);
-  }
-  HSO_HIP_CHECK(ctx, hipGetLastError());
-  // No synchronisation: the rows were copied out of the caller's memory when the copies were enqueued (pinned staging chunks of
-  // the stream, hso_ctx.h), and whatever uses the work area or the tables next is ordered behind the scatter on the same stream.
-  // A map patched for many sequences per step thus costs enqueues only; the step's next synchronising call releases the chunks.
-  m->n_pts = need_pts; m->n_obs = need_obs;
-  return HSO_OK;
+  hso_seqmap_rows r{};
+  r.map = map; r.n_points = n_points; r.n_obs = n_obs; r.point_ids = point_ids; r.points = points; r.obs_ids = obs_ids; r.obs = obs;
+  return hso_gpu_seqmap_patch_multi(ctx, &r, 1);
 }
 
 int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches, int n_patches)
@@ -905,71 +700,148 @@ int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches,
     const hso_seqmap_rows& P = patches[i];
     SeqMap* m = seqmap_of(ctx, P.map);
     if (!m || P.n_points < 0 || P.n_obs < 0 || (P.n_points > 0 && (!P.point_ids || !P.points)) || (P.n_obs > 0 && (!P.obs_ids || !P.obs)))
-      return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: bad patch");
+      return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: bad patch");
+    // the kernels trust the tables: check every index a row carries before it reaches the device
     const int nk = (int)m->kfs.size();
     size_t need_pts = m->n_pts, need_obs = m->n_obs;
-    for (int k = 0; k < P.n_obs; k++) { if (P.obs_ids[k] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: negative observation id"); need_obs = std::max(need_obs, (size_t)P.obs_ids[k] + 1); }
+    for (int k = 0; k < P.n_obs; k++) { if (P.obs_ids[k] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: negative observation id"); need_obs = std::max(need_obs, (size_t)P.obs_ids[k] + 1); }
+    for (int k = 0; k < P.n_points; k++) { if (P.point_ids[k] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: negative point id"); need_pts = std::max(need_pts, (size_t)P.point_ids[k] + 1); }
     for (int k = 0; k < P.n_obs; k++) {
       const hso_obs& o = P.obs[k];
       if (o.kf < 0 || o.kf >= nk || o.level < 0 || o.level >= HSO_N_PYR_LEVELS || o.pad_ < -1 || (o.pad_ >= 0 && (size_t)o.pad_ >= need_obs))
-        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: observation row out of range (keyframe table set first?)");
+        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: observation row out of range (keyframe table set first?)");
+      if (P.obs_point && (P.obs_point[k] < -1 || (P.obs_point[k] >= 0 && (size_t)P.obs_point[k] >= need_pts)))
+        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: Feature::point link out of range");
     }
     for (int k = 0; k < P.n_points; k++) {
       const hso_map_point& p = P.points[k];
-      if (P.point_ids[k] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: negative point id");
-      need_pts = std::max(need_pts, (size_t)P.point_ids[k] + 1);
       if (p.host_kf < 0 || p.host_kf >= nk || p.obs_count < 0 || (p.obs_count > 0 && (p.obs_begin < 0 || (size_t)p.obs_begin >= need_obs)))
-        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: point row out of range");
+        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: point row out of range");
     }
-    if (need_pts > m->pts_cap || need_obs > m->obs_cap) {
-      HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-      if (int rc = seqmap_grow(ctx, &m->d_pts, &m->pts_cap, need_pts, m->n_pts)) return rc;
-      if (int rc = seqmap_grow(ctx, &m->d_obs, &m->obs_cap, need_obs, m->n_obs)) return rc;
-    }
+    if (int rc = seqmap_grow_tables(ctx, m, need_pts, need_obs)) return rc;
     m->n_pts = need_pts; m->n_obs = need_obs;
     tp += (size_t)P.n_points; to += (size_t)P.n_obs;
   }
   if (tp + to == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  // [destination row pointers of the points | of the observations | point rows | observation rows]
-  const size_t b_dp = al(sizeof(void*) * tp), b_do = al(sizeof(void*) * to), b_p = al(sizeof(hso_map_point) * tp), b_o = al(sizeof(hso_obs) * to);
-  const size_t need = b_dp + b_do + b_p + b_o;
-  char* h = hso_pinned(ctx, 0, need);
-  if (!h) return HSO_E_NOMEM;
-  if (ctx->batch_cap < need) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
-    ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
-    ctx->batch_cap = hso_grown(need);
-  }
+  // [destination row pointers of the points | of the observations | of the links | point rows | observation rows | links]
+  size_t tl = 0;
+  for (int i = 0; i < n_patches; i++) if (patches[i].obs_point) tl += (size_t)patches[i].n_obs;
+  const size_t b_dp = al(sizeof(void*) * tp), b_do = al(sizeof(void*) * to), b_dl = al(sizeof(void*) * tl);
+  const size_t b_p = al(sizeof(hso_map_point) * tp), b_o = al(sizeof(hso_obs) * to), b_l = al(sizeof(int32_t) * tl);
+  const size_t need = b_dp + b_do + b_dl + b_p + b_o + b_l;
+  // the image is assembled in ordinary memory and leaves through the stream's page-locked staging chunks (hso_copy_async): no wait
+  // for the copy here — a step patches before its chain call, whose own synchronisation releases the chunks
+  std::vector<char> img(need);
+  char* h = img.data();
+  if (int rc = seqmap_work_area(ctx, need)) return rc;
   hso_map_point** dp = reinterpret_cast<hso_map_point**>(h);
   hso_obs** dob = reinterpret_cast<hso_obs**>(h + b_dp);
-  hso_map_point* rp = reinterpret_cast<hso_map_point*>(h + b_dp + b_do);
-  hso_obs* ro = reinterpret_cast<hso_obs*>(h + b_dp + b_do + b_p);
-  size_t ip = 0, io = 0;
+  int32_t** dl = reinterpret_cast<int32_t**>(h + b_dp + b_do);
+  hso_map_point* rp = reinterpret_cast<hso_map_point*>(h + b_dp + b_do + b_dl);
+  hso_obs* ro = reinterpret_cast<hso_obs*>(h + b_dp + b_do + b_dl + b_p);
+  int32_t* rl = reinterpret_cast<int32_t*>(h + b_dp + b_do + b_dl + b_p + b_o);
+  size_t ip = 0, io = 0, il = 0;
   for (int i = 0; i < n_patches; i++) {
     const hso_seqmap_rows& P = patches[i];
     SeqMap* m = seqmap_of(ctx, P.map);
     for (int k = 0; k < P.n_points; k++) { dp[ip] = m->d_pts + P.point_ids[k]; rp[ip] = P.points[k]; ip++; }
-    for (int k = 0; k < P.n_obs; k++) { dob[io] = m->d_obs + P.obs_ids[k]; ro[io] = P.obs[k]; io++; }
+    for (int k = 0; k < P.n_obs; k++) {
+      dob[io] = m->d_obs + P.obs_ids[k]; ro[io] = P.obs[k]; io++;
+      if (P.obs_point) { dl[il] = m->d_obs_pt + P.obs_ids[k]; rl[il] = P.obs_point[k]; il++; }
+    }
   }
   char* d = ctx->d_batch;
-  // the staging buffer is rewritten by the next entry point: this one waits for its copy (a step patches once or twice)
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, ctx->stream));
-  if (tp) {
-    const int G = sizeof(hso_map_point) / 8;
-    hipLaunchKernelGGL(k_scatter_rows_to, dim3((unsigned)((tp * G + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<unsigned long long* const*>(d), reinterpret_cast<const unsigned long long*>(d + b_dp + b_do), (int)tp, G);
-  }
+  if (tp) hipLaunchKernelGGL(k_scatter_points_to, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, ctx->stream,
+                             reinterpret_cast<hso_map_point* const*>(d), reinterpret_cast<const hso_map_point*>(d + b_dp + b_do + b_dl), (int)tp);
   if (to) {
     const int G = sizeof(hso_obs) / 8;
     hipLaunchKernelGGL(k_scatter_rows_to, dim3((unsigned)((to * G + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<unsigned long long* const*>(d + b_dp), reinterpret_cast<const unsigned long long*>(d + b_dp + b_do + b_p), (int)to, G);
+                       reinterpret_cast<unsigned long long* const*>(d + b_dp), reinterpret_cast<const unsigned long long*>(d + b_dp + b_do + b_dl + b_p), (int)to, G);
   }
+  if (tl) hipLaunchKernelGGL(k_scatter_ints_to, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, ctx->stream,
+                             reinterpret_cast<int32_t* const*>(d + b_dp + b_do), reinterpret_cast<const int32_t*>(d + b_dp + b_do + b_dl + b_p + b_o), (int)tl);
   HSO_HIP_CHECK(ctx, hipGetLastError());
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_patch_links(hso_gpu_ctx* ctx, int map, const int32_t* obs_ids, const int32_t* obs_point, int n_obs)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || n_obs < 0 || (n_obs > 0 && (!obs_ids || !obs_point))) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_links: bad argument");
+  if (n_obs == 0) return HSO_OK;
+  for (int i = 0; i < n_obs; i++)
+    if (obs_ids[i] < 0 || (size_t)obs_ids[i] >= m->n_obs || obs_point[i] < -1 || (obs_point[i] >= 0 && (size_t)obs_point[i] >= m->n_pts))
+      return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_links: row out of range");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t b_id = ((size_t)n_obs * sizeof(int32_t) + 255) & ~size_t(255);
+  if (int rc = seqmap_work_area(ctx, 2 * b_id)) return rc;
+  char* d = ctx->d_batch;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, obs_ids, sizeof(int32_t) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + b_id, obs_point, sizeof(int32_t) * (size_t)n_obs, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_scatter_links, dim3((unsigned)((n_obs + 255) / 256)), dim3(256), 0, ctx->stream, m->d_obs_pt, reinterpret_cast<const int32_t*>(d),
+                     reinterpret_cast<const int32_t*>(d + b_id), n_obs);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
+}
+
+int hso_gpu_seqmap_patch_lists(hso_gpu_ctx* ctx, const hso_seqmap_list_patch* patches, int n_patches)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_patches < 0 || (n_patches > 0 && !patches)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: bad argument");
+  size_t total = 0;
+  for (int i = 0; i < n_patches; i++) {
+    const hso_seqmap_list_patch& P = patches[i];
+    SeqMap* m = seqmap_of(ctx, P.map);
+    if (!m || P.first < 0 || P.n < 0 || (P.n > 0 && !P.ids)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: bad patch");
+    if (P.list == HSO_LIST_CANDIDATES) {
+      if (P.first > m->n_cands) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: a patch of the candidate list must start inside it or at its end");
+      for (int k = 0; k < P.n; k++) if (P.ids[k] < 0 || (size_t)P.ids[k] >= m->n_pts) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: candidate point row out of range");
+      HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+      if (int rc = seqmap_grow(ctx, &m->d_cands, &m->cands_cap, (size_t)P.first + (size_t)P.n, (size_t)m->n_cands)) return rc;
+    } else {
+      if (P.list < 0 || (size_t)P.list >= m->kfs.size()) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: no such keyframe row");
+      if (m->fts_cap < 1) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: hso_gpu_seqmap_configure first");
+      if (P.first > m->kf_nfts[(size_t)P.list] || P.first + P.n > m->fts_cap) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: a keyframe's feature list outgrows fts_cap, or the patch leaves a gap");
+      for (int k = 0; k < P.n; k++) if (P.ids[k] < 0 || (size_t)P.ids[k] >= m->n_obs) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: feature row out of range");
+      if (m->kf_rows_cap < m->kfs.size()) {
+        HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        size_t cap_el = m->kf_rows_cap * (size_t)m->fts_cap;
+        const size_t rows = m->kfs.size() + m->kfs.size() / 2 + 8;
+        if (int rc = seqmap_grow(ctx, &m->d_kf_fts, &cap_el, rows * (size_t)m->fts_cap, cap_el)) return rc;
+        m->kf_rows_cap = cap_el / (size_t)m->fts_cap;
+      }
+    }
+    total += (size_t)P.n;
+  }
+  if (total > 0) {
+    HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t b_d = al(sizeof(void*) * total), need = b_d + al(sizeof(int32_t) * total);
+    std::vector<char> img(need);
+    int32_t** dst = reinterpret_cast<int32_t**>(img.data());
+    int32_t* val = reinterpret_cast<int32_t*>(img.data() + b_d);
+    size_t at = 0;
+    for (int i = 0; i < n_patches; i++) {
+      const hso_seqmap_list_patch& P = patches[i];
+      SeqMap* m = seqmap_of(ctx, P.map);
+      int32_t* base = P.list == HSO_LIST_CANDIDATES ? m->d_cands : m->d_kf_fts + (size_t)P.list * (size_t)m->fts_cap;
+      for (int k = 0; k < P.n; k++) { dst[at] = base + P.first + k; val[at] = P.ids[k]; at++; }
+    }
+    if (int rc = seqmap_work_area(ctx, need)) return rc;
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_batch, img.data(), need, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_scatter_ints_to, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<int32_t* const*>(ctx->d_batch), reinterpret_cast<const int32_t*>(ctx->d_batch + b_d), (int)total);
+    HSO_HIP_CHECK(ctx, hipGetLastError());
+  }
+  for (int i = 0; i < n_patches; i++) {   // the lengths (host side: the chain call sends them along)
+    const hso_seqmap_list_patch& P = patches[i];
+    SeqMap* m = seqmap_of(ctx, P.map);
+    if (P.list == HSO_LIST_CANDIDATES) m->n_cands = P.first + P.n; else m->kf_nfts[(size_t)P.list] = P.first + P.n;
+  }
   return HSO_OK;
 }
 
@@ -998,14 +870,7 @@ int hso_gpu_seqmap_read(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, int
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t b_pid = al(sizeof(int) * (size_t)n_points), b_pts = al(sizeof(hso_map_point) * (size_t)n_points);
   const size_t b_oid = al(sizeof(int) * (size_t)n_obs), b_obs = al(sizeof(hso_obs) * (size_t)n_obs);
-  const size_t need = b_pid + b_pts + b_oid + b_obs;
-  if (ctx->batch_cap < need) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
-    ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
-    ctx->batch_cap = hso_grown(need);
-  }
+  if (int rc = seqmap_work_area(ctx, b_pid + b_pts + b_oid + b_obs)) return rc;
   char* d = ctx->d_batch;
   if (n_points) {
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, point_ids, sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
@@ -1027,11 +892,57 @@ int hso_gpu_seqmap_read(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, int
   return HSO_OK;
 }
 
+int hso_gpu_seq_frame_features(hso_gpu_ctx* ctx, const int32_t* maps, const int64_t* frame_ids, int n_maps, hso_seq_feature* out, int cap, int32_t* n_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_maps < 0 || cap < 0 || (n_maps > 0 && (!maps || !frame_ids || !out || !n_out))) return hso_fail(ctx, HSO_E_INVALID, "seq_frame_features: bad argument");
+  if (n_maps == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < n_maps; i++) {
+    SeqMap* m = seqmap_of(ctx, maps[i]);
+    if (!m) return hso_fail(ctx, HSO_E_INVALID, "seq_frame_features: no such map");
+    const int b = m->ff_frame[0] == frame_ids[i] && m->d_ff[0] ? 0 : (m->ff_frame[1] == frame_ids[i] && m->d_ff[1] ? 1 : -1);
+    if (b < 0) return hso_fail(ctx, HSO_E_NOFRAME, "seq_frame_features: the map holds no feature table of that frame");
+    if (m->ff_n[b] > cap) return hso_fail(ctx, HSO_E_INVALID, "seq_frame_features: cap is smaller than the table");
+    n_out[i] = m->ff_n[b];
+    if (m->ff_n[b] > 0)
+      HSO_HIP_CHECK(ctx, hipMemcpyAsync(out + (size_t)i * cap, m->d_ff[b], sizeof(hso_seq_feature) * (size_t)m->ff_n[b], hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
+int hso_gpu_seq_set_frame_features(hso_gpu_ctx* ctx, int map, int64_t frame_id, const hso_seq_feature* feats, int n)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || n < 0 || (n > 0 && !feats)) return hso_fail(ctx, HSO_E_INVALID, "seq_set_frame_features: bad argument");
+  for (int i = 0; i < n; i++) if (feats[i].point < -1 || (feats[i].point >= 0 && (size_t)feats[i].point >= m->n_pts)) return hso_fail(ctx, HSO_E_INVALID, "seq_set_frame_features: point row out of range");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (n > m->ff_cap) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const int ncap = n + n / 2 + 64;
+    for (int b = 0; b < 2; b++) {
+      hso_seq_feature* q = nullptr;
+      HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&q), sizeof(hso_seq_feature) * (size_t)ncap));
+      if (m->d_ff[b] && m->ff_n[b] > 0) HSO_HIP_CHECK(ctx, hipMemcpy(q, m->d_ff[b], sizeof(hso_seq_feature) * (size_t)m->ff_n[b], hipMemcpyDeviceToDevice));
+      (void)hipFree(m->d_ff[b]);
+      m->d_ff[b] = q;
+    }
+    m->ff_cap = ncap;
+  }
+  // the table of that frame if the map holds one, else the older of the two
+  int b = m->ff_frame[0] == frame_id ? 0 : (m->ff_frame[1] == frame_id ? 1 : 1 - m->ff_newest);
+  if (n > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(m->d_ff[b], feats, sizeof(hso_seq_feature) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  m->ff_frame[b] = frame_id; m->ff_n[b] = n; m->ff_newest = b;
+  return HSO_OK;
+}
+
 int hso_gpu_debug_fetch(hso_gpu_ctx* ctx, int what, void* out, size_t bytes)
 {
   if (!ctx) return HSO_E_INVALID;
   SeqMaps* S = ctx->seqmaps;
-  if (!S || what < 0 || what > 4 || !out || !S->dbg[what] || S->dbg_bytes[what] != bytes) return hso_fail(ctx, HSO_E_INVALID, "debug_fetch: no such table, or a size mismatch");
+  if (!S || what < 0 || what >= HSO_DBG_N || !out || !S->dbg[what] || S->dbg_bytes[what] != bytes) return hso_fail(ctx, HSO_E_INVALID, "debug_fetch: no such table, or a size mismatch");
   if (bytes == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, S->dbg[what], bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1047,139 +958,322 @@ void hso_seqmaps_debug_set(hso_gpu_ctx* ctx, int what, const void* d, size_t byt
   ctx->seqmaps->dbg[what] = d; ctx->seqmaps->dbg_bytes[what] = bytes;
 }
 
-// one frame of a sequence map: the listed points
-struct ListCallDev {
-  ReprojFrameDev F;                // kf_begin = first row of the call's ReprojKf block
-  const hso_map_point* pts; const hso_obs* obs;
-  int n_pts_table, n_kfs;
-  int list_begin, list_count;      // the call's slice of the id / quality arrays
-};
-struct ListConsts {
-  hso_camera cam;
-  const ListCallDev* calls;
-  int n_calls, n_total;
-  const ReprojKf* kfs;
-  const int32_t* ids; const uint8_t* quality;
-  int cell_size, grid_n_cols;
+// ---------------------------------------------------------------------------------------------
+// The front half of the resident chain (include/hso_gpu.h: hso_gpu_seq_chain; orchestrated in hso_select.hip).
+size_t hso_chain_sizeof_reproj_kf() { return sizeof(ReprojKf); }
+size_t hso_chain_sizeof_align_job() { return sizeof(AlignJobDev); }
+
+// a map's device view for one job.  The reference frame's features: the keyframe's list, or the table the map holds for that frame;
+// the new frame's table goes into the other of the map's two buffers.
+int hso_seqmap_chain_view(hso_gpu_ctx* ctx, const hso_seq_job& job, SeqMapDev* out, int* n_kfs, const int32_t** kf_nfts_host)
+{
+  SeqMap* m = seqmap_of(ctx, job.map);
+  if (!m) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: no such map");
+  if (m->kfs.empty() || !m->d_kfs) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: the map has no keyframes");
+  const int nk = (int)m->kfs.size();
+  if (m->fts_cap < 1 || m->kf_rows_cap < (size_t)nk) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: the keyframes' feature lists were never sent (hso_gpu_seqmap_patch_lists)");
+  if (job.last_kf_row < -1 || job.last_kf_row >= nk || job.ref_kf_row < -1 || job.ref_kf_row >= nk) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: keyframe row out of range");
+  for (int q = 0; q < 5; q++) if (job.covis[q] < -1 || job.covis[q] >= nk) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: covisible keyframe row out of range");
+  int ref = -1;
+  if (job.n_ref_feats < 0) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: negative feature count");
+  if (job.ref_kf_row >= 0) {
+    if (job.n_ref_feats != m->kf_nfts[(size_t)job.ref_kf_row]) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: n_ref_feats differs from the keyframe's list");
+  } else if (!(job.flags & HSO_SEQ_NO_TRACK)) {
+    ref = m->ff_frame[0] == job.ref_frame_id && m->d_ff[0] ? 0 : (m->ff_frame[1] == job.ref_frame_id && m->d_ff[1] ? 1 : -1);
+    if (ref < 0) return hso_fail(ctx, HSO_E_NOFRAME, "seq_chain: the map holds no feature table of the reference frame");
+    if (job.n_ref_feats != m->ff_n[ref]) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: n_ref_feats differs from the reference frame's table");
+  }
+  const int cur = ref >= 0 ? 1 - ref : 1 - m->ff_newest;
+  out->pts = m->d_pts; out->obs = m->d_obs; out->obs_pt = m->d_obs_pt; out->kfs = m->d_kfs; out->kf_fts = m->d_kf_fts; out->cands = m->d_cands;
+  out->first = m->d_first; out->ff_ref = ref >= 0 ? m->d_ff[ref] : nullptr; out->ff_cur = m->d_ff[cur];
+  out->n_pts = (int)m->n_pts; out->n_obs = (int)m->n_obs; out->n_kfs = nk; out->fts_cap = m->fts_cap; out->n_cands = m->n_cands; out->ff_cap = m->ff_cap;
+  *n_kfs = nk; *kf_nfts_host = m->kf_nfts.data();
+  return HSO_OK;
+}
+
+// the new frame's table needs room for max_fts rows in both buffers (before any view is taken)
+int hso_seqmap_chain_reserve(hso_gpu_ctx* ctx, int map, int rows)
+{
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: no such map");
+  if (rows <= m->ff_cap) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int ncap = rows + 64;
+  for (int b = 0; b < 2; b++) {
+    hso_seq_feature* q = nullptr;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&q), sizeof(hso_seq_feature) * (size_t)ncap));
+    if (m->d_ff[b] && m->ff_n[b] > 0) HSO_HIP_CHECK(ctx, hipMemcpy(q, m->d_ff[b], sizeof(hso_seq_feature) * (size_t)m->ff_n[b], hipMemcpyDeviceToDevice));
+    (void)hipFree(m->d_ff[b]);
+    m->d_ff[b] = q;
+  }
+  m->ff_cap = ncap;
+  return HSO_OK;
+}
+
+void hso_seqmap_chain_commit(hso_gpu_ctx* ctx, const hso_seq_job& job, int n_feats)
+{
+  SeqMap* m = seqmap_of(ctx, job.map);
+  if (!m) return;
+  const int ref = job.ref_kf_row >= 0 ? -1 : (m->ff_frame[0] == job.ref_frame_id && m->d_ff[0] ? 0 : (m->ff_frame[1] == job.ref_frame_id && m->d_ff[1] ? 1 : -1));
+  const int cur = ref >= 0 ? 1 - ref : 1 - m->ff_newest;
+  m->ff_frame[cur] = job.cur_frame_id; m->ff_n[cur] = n_feats; m->ff_newest = cur;
+}
+
+// ---- CoarseTracker::makeDepthRef (src/CoarseTracker.cpp:210-240) into the tracker's own table layout: per reference feature
+// (px, f, distance of its point along the bearing in the reference frame, -1 without a usable point); pad columns zero
+__global__ __launch_bounds__(256) void k_chain_table(const ChainJobDev* jobs)
+{
+  const ChainJobDev& J = jobs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= J.n_ref_stride) return;
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  if (i < J.n_ref) {
+    int p;
+    if (J.ref_kf_row >= 0) {
+      const int f = J.M.kf_fts[(size_t)J.ref_kf_row * J.M.fts_cap + i];
+      const hso_obs& o = J.M.obs[f];
+      v[0] = o.px[0]; v[1] = o.px[1]; v[2] = o.f[0]; v[3] = o.f[1]; v[4] = o.f[2];
+      p = J.M.obs_pt[f];
+    } else {
+      const hso_seq_feature& r = J.M.ff_ref[i];
+      v[0] = r.px[0]; v[1] = r.px[1]; v[2] = r.f[0]; v[3] = r.f[1]; v[4] = r.f[2];
+      p = r.point;
+    }
+    v[5] = -1;
+    if (p >= 0 && p < J.M.n_pts) {
+      const hso_map_point& P = J.M.pts[p];
+      if (P.idist != 0.0) {      // a row the caller never sent (a point hosted in no keyframe) has no usable depth
+        const Se3 T_ref_host = se3_mul(se3_from(J.T_ref_w), se3_inverse(se3_from(J.M.kfs[P.host_kf].T_f_w)));
+        const double s = 1.0 / P.idist;
+        double x, y, z;
+        se3_apply(T_ref_host, P.host_f[0] * s, P.host_f[1] * s, P.host_f[2] * s, x, y, z);
+        if (!(z < 0.00001)) v[5] = sqrt(x * x + y * y + z * z);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; c++) J.table[(size_t)c * J.n_ref_stride + i] = v[c];
+}
+
+int hso_chain_table_launch(hso_gpu_ctx* ctx, const ChainJobDev* d_jobs, int n_jobs, int n_max_stride)
+{
+  if (n_jobs <= 0 || n_max_stride <= 0) return HSO_OK;
+  hipLaunchKernelGGL(k_chain_table, dim3((unsigned)((n_max_stride + 255) / 256), (unsigned)n_jobs), dim3(256), 0, ctx->stream, d_jobs);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
+}
+
+// ---- after the tracker: the write-back of CoarseTracker::run (:198-202), the per-keyframe products of the reprojection, and which
+// keyframes the frame visits (Reprojector::reprojectMap, src/reprojector.cpp:108-199: the reference frame's connected keyframes,
+// then Map::getCloseKeyframes (src/map.cpp:193-213) sorted by distance, until max_kfs).  One workgroup per job.
+#define CHAIN_MAX_KFS 2048
+struct ChainFrontDev {
+  const ChainJobDev* jobs; ChainCur* cur; const hso_track_result* track; const int32_t* kf_nfts; const int32_t* temps;
+  ReprojKf* kfs; int32_t* ids; uint8_t* quality; PoseJobDev* pose_jobs;
+  int n_jobs, n_total, max_kfs, cell_size, grid_n_cols;
 };
 
-__global__ __launch_bounds__(256) void k_reproject_list(ListConsts M, AlignJobDev* jobs, hso_reproj_point* proj)
+__global__ __launch_bounds__(256) void k_chain_visit(ChainFrontDev F, hso_camera cam)
+{
+  __shared__ double s_dist[CHAIN_MAX_KFS];
+  __shared__ Se3 s_Tc;
+  __shared__ double s_expo;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const ChainJobDev& J = F.jobs[b];
+  ChainCur& C = F.cur[b];
+  if (tid == 0) {
+    Se3 Tc = se3_from(J.T_cur_w0);
+    double expo = -1.0;                                            // Frame::m_exposure_time as constructed
+    if (!(J.flags & HSO_SEQ_NO_TRACK)) {
+      const hso_track_result& R = F.track[b];
+      Tc = se3_mul(se3_from(R.T_cur_ref), se3_from(J.T_ref_w));  // cur.T_f_w_ = m_T_cur_ref * ref.T_f_w_
+      expo = (double)R.exposure_rat * J.ref_exposure;
+      if (R.exposure_rat > 0.99f && R.exposure_rat < 1.01f) expo = J.ref_exposure;
+    }
+    s_Tc = Tc; s_expo = expo;
+    se3_to(Tc, C.T_cur_w); C.exposure = expo;
+    const Se3 inv = se3_inverse(Tc);
+    C.cur_pos[0] = inv.tx; C.cur_pos[1] = inv.ty; C.cur_pos[2] = inv.tz;
+    se3_to(Tc, F.pose_jobs[b].T);                                  // the pose optimiser starts from the tracked pose
+  }
+  __syncthreads();
+  const Se3 Tc = s_Tc;
+  const int nk = J.M.n_kfs < CHAIN_MAX_KFS ? J.M.n_kfs : CHAIN_MAX_KFS;
+  for (int k = tid; k < J.M.n_kfs; k += 256) {
+    const SeqKfDev& K = J.M.kfs[k];
+    const Se3 Tk = se3_from(K.T_f_w);
+    const Se3 inv = se3_inverse(Tk);
+    ReprojKf& Q = F.kfs[J.kf_begin + k];
+    Q.T_cur_kf = se3_mul(Tc, inv);
+    Q.pos[0] = inv.tx; Q.pos[1] = inv.ty; Q.pos[2] = inv.tz;
+    Q.base = K.base; Q.frame_id = K.frame_id;
+    Q.exposure_rat = (float)(s_expo / K.exposure_time);
+    Q.kf_gap_lt4 = (J.cur_keyframe_id - K.keyframe_id) < 4;
+    if (k >= CHAIN_MAX_KFS) continue;
+    // getCloseKeyframes: the first key point of the keyframe that the frame sees (Frame::isVisible) makes it a neighbour, at the
+    // distance of the two T_f_w translations (as written there)
+    double dist = -1.0;
+    for (int q = 0; q < 5; q++) {
+      const int p = K.key_point[q];
+      if (p < 0 || p >= J.M.n_pts) continue;
+      const hso_map_point& P = J.M.pts[p];
+      double x, y, z;
+      se3_apply(Tc, P.pos[0], P.pos[1], P.pos[2], x, y, z);
+      if (z < 0.0) continue;
+      double u, v;
+      world2cam(cam, x, y, z, u, v);
+      if (!(u >= 0.0 && v >= 0.0 && u < cam.width && v < cam.height)) continue;
+      const double dx = Tc.tx - Tk.tx, dy = Tc.ty - Tk.ty, dz = Tc.tz - Tk.tz;
+      dist = sqrt(dx * dx + dy * dy + dz * dz);
+      break;
+    }
+    s_dist[k] = dist;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int q = 0; q < 5; q++) {
+      const int r = J.covis[q];
+      if (r < 0 || r >= J.M.n_kfs) continue;
+      bool dup = false;
+      for (int e = 0; e < n; e++) dup |= C.visit[e] == r;
+      if (!dup && n < HSO_SEQ_MAX_VISIT) C.visit[n++] = r;
+    }
+    // the neighbours in ascending distance (stable: equal distances keep table order), skipping the ones already visited
+    int count = n;
+    double last_d = -1.0; int last_k = -1;
+    while (count < F.max_kfs && n < HSO_SEQ_MAX_VISIT) {
+      int best = -1; double bd = 0;
+      for (int k = 0; k < nk; k++) {
+        const double d = s_dist[k];
+        if (d < 0.0) continue;
+        if (d < last_d || (d == last_d && k <= last_k)) continue;   // already considered
+        if (best < 0 || d < bd) { best = k; bd = d; }
+      }
+      if (best < 0) break;
+      last_d = bd; last_k = best;
+      bool dup = false;
+      for (int e = 0; e < n; e++) dup |= C.visit[e] == best;
+      if (dup) continue;
+      C.visit[n++] = best; ++count;
+    }
+    C.n_visit = n;
+  }
+}
+
+// ---- the list of points the frame projects, in the reference's order: per visited keyframe the points of its features (once each
+// per frame: the first feature that names a point lists it; deleted and temporary points are skipped), then the candidates, then the
+// temporary points.  One workgroup per job; "first feature that names it" = atomicMin over the flat feature positions, kept
+// entries compacted in order by block scans: the result is the sequential walk's.
+__global__ __launch_bounds__(256) void k_chain_list(ChainFrontDev F)
+{
+  __shared__ int s_wave[4];
+  __shared__ int s_off[HSO_SEQ_MAX_VISIT + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const ChainJobDev& J = F.jobs[b];
+  ChainCur& C = F.cur[b];
+  const int nv = C.n_visit;
+  if (tid == 0) {
+    int t = 0;
+    for (int v = 0; v < nv; v++) { s_off[v] = t; t += F.kf_nfts[J.kf_begin + C.visit[v]]; }
+    s_off[nv] = t;
+  }
+  __syncthreads();
+  const int total = s_off[nv];
+  int32_t* ids = F.ids + J.slice_begin; uint8_t* qual = F.quality + J.slice_begin;
+  auto point_at = [&](int g, int& key) -> int {
+    int v = 0;
+    while (v + 1 < nv && s_off[v + 1] <= g) v++;
+    const int f = J.M.kf_fts[(size_t)C.visit[v] * J.M.fts_cap + (g - s_off[v])];
+    const int p = J.M.obs_pt[f];
+    if (p < 0 || p >= J.M.n_pts) return -1;
+    key = (int)((uint32_t)J.M.pts[p].pad_ & 0xffu);
+    const int kind = key >> 4;
+    if (kind == 0 || kind == 1) return -1;                         // TYPE_DELETED (its features' links are NULL in the reference), TYPE_TEMPORARY
+    return p;
+  };
+  for (int g = tid; g < total; g += 256) { int key; const int p = point_at(g, key); if (p >= 0) atomicMin(&J.M.first[p], g); }
+  __threadfence_block();
+  __syncthreads();
+  int n = 0;
+  for (int g0 = 0; g0 < total; g0 += 256) {
+    const int g = g0 + tid;
+    int key = 0, p = -1;
+    if (g < total) { p = point_at(g, key); if (p >= 0 && J.M.first[p] != g) p = -1; }
+    int tot;
+    const int pos = sel_scan256(p >= 0 ? 1 : 0, s_wave, tot) + n - (p >= 0 ? 1 : 0);
+    if (p >= 0 && pos < J.slice_cap) { ids[pos] = p; qual[pos] = (uint8_t)key; }
+    n += tot;
+    __syncthreads();
+  }
+  for (int g = tid; g < total; g += 256) { int key; const int p = point_at(g, key); if (p >= 0) J.M.first[p] = SEQ_FIRST_UNSET; }
+  const int n_kf_points = n < J.slice_cap ? n : J.slice_cap;
+  n = n_kf_points;
+  // MapPointCandidates::candidates_ in list order (an entry the device deleted since the caller last sent the list is skipped)
+  int n_c = 0;
+  for (int i0 = 0; i0 < J.M.n_cands; i0 += 256) {
+    const int i = i0 + tid;
+    int key = 0, p = -1;
+    if (i < J.M.n_cands) { p = J.M.cands[i]; key = (int)((uint32_t)J.M.pts[p].pad_ & 0xffu); if ((key >> 4) != 2) p = -1; }
+    int tot;
+    const int pos = sel_scan256(p >= 0 ? 1 : 0, s_wave, tot) + n - (p >= 0 ? 1 : 0);
+    if (p >= 0 && pos < J.slice_cap) { ids[pos] = p; qual[pos] = (uint8_t)key; }
+    n += tot; n_c += tot;
+    __syncthreads();
+  }
+  if (n > J.slice_cap) { n_c -= n - J.slice_cap; n = J.slice_cap; }
+  const int n_before_temps = n;
+  for (int i = tid; i < J.n_temps; i += 256) {
+    const int p = F.temps[J.temps_begin + i];
+    if (n_before_temps + i < J.slice_cap) { ids[n_before_temps + i] = p; qual[n_before_temps + i] = (uint8_t)((uint32_t)J.M.pts[p].pad_ & 0xffu); }
+  }
+  n = n_before_temps + J.n_temps < J.slice_cap ? n_before_temps + J.n_temps : J.slice_cap;
+  if (tid == 0) { C.n_listed = n; C.n_kf_points = n_kf_points; C.n_cands_listed = n_c; }
+}
+
+// one listed point: reprojectPoint + getCloseViewObs + the findMatchDirect job (slice entries past the list's end: null jobs)
+__global__ __launch_bounds__(256) void k_chain_reproject(ChainFrontDev F, hso_camera cam, AlignJobDev* jobs, hso_reproj_point* proj)
 {
   const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= M.n_total) return;
-  int lo = 0, hi = M.n_calls - 1;          // the call whose slice holds g
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (M.calls[mid].list_begin <= g) lo = mid; else hi = mid - 1; }
-  const ListCallDev& C = M.calls[lo];
-  const int pid = M.ids[g];
+  if (g >= F.n_total) return;
+  int lo = 0, hi = F.n_jobs - 1;          // the job whose slice holds g
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (F.jobs[mid].slice_begin <= g) lo = mid; else hi = mid - 1; }
+  const ChainJobDev& J = F.jobs[lo];
+  const ChainCur& C = F.cur[lo];
+  const int i = g - J.slice_begin;
   hso_reproj_point r;
-  if (pid < 0 || pid >= C.n_pts_table) {   // an id the table does not hold: not projected (the host checked the tables, not the list)
-    r.projected = 0; r.cell = 0; r.px[0] = 0; r.px[1] = 0; r.ref_obs = -1;
-    jobs[g].ref_base = nullptr; jobs[g].cur_base = C.F.cur_base;
-  } else {
-    r = reproject_one<true>(M.cam, C.pts[pid], C.F, M.kfs + C.F.kf_begin, C.obs, M.cell_size, M.grid_n_cols, &jobs[g]);
+  r.projected = 0; r.cell = 0; r.px[0] = 0; r.px[1] = 0; r.ref_obs = -1; r.pad_ = 0;
+  jobs[g].ref_base = nullptr; jobs[g].cur_base = J.cur_base;
+  if (i < C.n_listed) {
+    const int pid = F.ids[g];
+    if (pid >= 0 && pid < J.M.n_pts) {
+      ReprojFrameDev Fr;
+      Fr.cur_pos[0] = C.cur_pos[0]; Fr.cur_pos[1] = C.cur_pos[1]; Fr.cur_pos[2] = C.cur_pos[2];
+      Fr.cur_base = J.cur_base; Fr.kf_begin = J.kf_begin; Fr.pad_ = 0;
+      r = reproject_one<true>(cam, J.M.pts[pid], Fr, F.kfs + J.kf_begin, J.M.obs, F.cell_size, F.grid_n_cols, &jobs[g]);
+    }
+    r.pad_ = F.quality[g];
   }
-  r.pad_ = M.quality[g];
   proj[g] = r;
 }
 
-// The launch chain of hso_gpu_reproject_select_pose_frames up to the per-point records (cf. hso_reproject_maps_run)
-int hso_reproject_frames_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_frame* frames, int n_frames, int cell_size,
-                             int grid_n_cols, size_t extra_bytes, HsoMapsRun* R, HsoFramesAux* X)
+int hso_chain_front_launch(hso_gpu_ctx* ctx, const hso_camera* cam, const ChainFront& A)
 {
   SeqMaps* S = ctx->seqmaps;
-  if (!S || !cam || n_frames < 0 || (n_frames > 0 && !frames) || cell_size < 1 || grid_n_cols < 1)
-    return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: bad argument");
-  R->n = 0; R->begin.assign(n_frames + 1, 0);
-  if (n_frames == 0) return 0;
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  size_t total = 0, total_kfs = 0;
-  X->kf_begin.assign(n_frames + 1, 0);
-  for (int c = 0; c < n_frames; c++) {
-    const SeqMap* m = seqmap_of(ctx, frames[c].map);
-    if (!m) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: no such map");
-    if (frames[c].n_points < 0 || (frames[c].n_points > 0 && (!frames[c].point_ids || !frames[c].quality)))
-      return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: null point list");
-    total += (size_t)frames[c].n_points; total_kfs += m->kfs.size();
-    R->begin[c + 1] = (int)total; X->kf_begin[c + 1] = (int)total_kfs;
+  if (!S || !S->have_g || cam->width != S->g.w[0] || cam->height != S->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: camera size differs from the frame size");
+  ChainFrontDev F;
+  F.jobs = A.d_jobs; F.cur = A.d_cur; F.track = A.d_track; F.kf_nfts = A.d_kf_nfts; F.temps = A.d_temps; F.kfs = A.d_kfs; F.ids = A.d_ids; F.quality = A.d_quality;
+  F.pose_jobs = A.d_pose_jobs; F.n_jobs = A.n_jobs; F.n_total = A.n_total; F.max_kfs = A.max_kfs; F.cell_size = A.cell_size; F.grid_n_cols = A.grid_n_cols;
+  hipLaunchKernelGGL(k_chain_visit, dim3(A.n_jobs), dim3(256), 0, ctx->stream, F, *cam);
+  hipLaunchKernelGGL(k_chain_list, dim3(A.n_jobs), dim3(256), 0, ctx->stream, F);
+  if (A.n_total > 0) {
+    HSO_HIP_CHECK(ctx, hipMemsetAsync(A.d_match, 0, sizeof(hso_align_out) * (size_t)A.n_total, ctx->stream));
+    hipLaunchKernelGGL(k_chain_reproject, dim3((A.n_total + 255) / 256), dim3(256), 0, ctx->stream, F, *cam, A.d_align, A.d_proj);
+    AlignConsts C;
+    C.cam = *cam; C.g = S->g;
+    launch_align(ctx, true, C, A.d_align, A.n_total, A.d_match);
+    hipLaunchKernelGGL(k_match_brief, dim3((A.n_total + 255) / 256), dim3(256), 0, ctx->stream, A.n_total, A.d_proj, A.d_match, A.d_align, A.d_brief);
   }
-  if (total == 0) return 0;
-  if (!S->have_g || cam->width != S->g.w[0] || cam->height != S->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: camera size differs from the frame size");
-  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  const size_t b_calls = al(sizeof(ListCallDev) * (size_t)n_frames), b_kfs = al(sizeof(ReprojKf) * std::max(total_kfs, (size_t)1));
-  const size_t b_ids = al(sizeof(int32_t) * total), b_q = al(total);
-  char* hin = hso_pinned(ctx, 0, b_calls + b_kfs + b_ids + b_q);
-  if (!hin) return HSO_E_NOMEM;
-  ListCallDev* hc = reinterpret_cast<ListCallDev*>(hin);
-  ReprojKf* hk = reinterpret_cast<ReprojKf*>(hin + b_calls);
-  int32_t* hid = reinterpret_cast<int32_t*>(hin + b_calls + b_kfs);
-  uint8_t* hq = reinterpret_cast<uint8_t*>(hin + b_calls + b_kfs + b_ids);
-  for (int c = 0; c < n_frames; c++) {
-    const hso_map_frame& K = frames[c];
-    const SeqMap* m = seqmap_of(ctx, K.map);
-    auto itc = ctx->frames.find(K.cur_frame_id);
-    if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_select_pose_frames: current frame not resident");
-    if (!same_geom(itc->second.g, S->g)) return hso_fail(ctx, HSO_E_INVALID, "reproject_select_pose_frames: frames must share one size");
-    const Se3 Tc = se3_from(K.T_cur_w);
-    const Se3 ci = se3_inverse(Tc);
-    ListCallDev& D = hc[c];
-    D.F.cur_pos[0] = ci.tx; D.F.cur_pos[1] = ci.ty; D.F.cur_pos[2] = ci.tz;
-    D.F.cur_base = itc->second.base; D.F.kf_begin = X->kf_begin[c]; D.F.pad_ = 0;
-    D.pts = m->d_pts; D.obs = m->d_obs; D.n_pts_table = (int)m->n_pts; D.n_kfs = (int)m->kfs.size();
-    D.list_begin = R->begin[c]; D.list_count = K.n_points;
-    for (size_t k = 0; k < m->kfs.size(); k++) {
-      auto it = ctx->frames.find(m->kfs[k].frame_id);
-      if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "reproject_select_pose_frames: a keyframe of the map is no longer resident");
-      ReprojKf& Q = hk[(size_t)X->kf_begin[c] + k];
-      const Se3 inv = se3_inverse(se3_from(m->kfs[k].T_f_w));
-      Q.T_cur_kf = se3_mul(Tc, inv);
-      Q.pos[0] = inv.tx; Q.pos[1] = inv.ty; Q.pos[2] = inv.tz;
-      Q.base = it->second.base; Q.frame_id = m->kfs[k].frame_id;
-      Q.exposure_rat = (float)(K.cur_exposure_time / m->kfs[k].exposure_time);
-      Q.kf_gap_lt4 = (K.cur_keyframe_id - m->kfs[k].keyframe_id) < 4;
-    }
-    if (K.n_points) {
-      memcpy(hid + R->begin[c], K.point_ids, sizeof(int32_t) * (size_t)K.n_points);
-      memcpy(hq + R->begin[c], K.quality, (size_t)K.n_points);
-    }
-  }
-  const size_t o_jobs = 0, o_match = o_jobs + al(sizeof(AlignJobDev) * total), o_proj = o_match + al(sizeof(hso_align_out) * total);
-  const size_t o_brief = o_proj + al(sizeof(hso_reproj_point) * total), o_in = o_brief + al(sizeof(hso_match_brief) * total);
-  const size_t b_in = b_calls + b_kfs + b_ids + b_q;
-  const size_t o_extra = o_in + al(b_in);
-  const size_t need = o_extra + extra_bytes;
-  if (ctx->batch_cap < need) {
-    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
-    ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
-    ctx->batch_cap = hso_grown(need);
-  }
-  char* d = ctx->d_batch;
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + o_in, hin, b_in, hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemsetAsync(d + o_match, 0, sizeof(hso_align_out) * total, ctx->stream));
-  ListConsts M;
-  M.cam = *cam; M.calls = reinterpret_cast<const ListCallDev*>(d + o_in); M.n_calls = n_frames; M.n_total = (int)total;
-  M.kfs = reinterpret_cast<const ReprojKf*>(d + o_in + b_calls);
-  M.ids = reinterpret_cast<const int32_t*>(d + o_in + b_calls + b_kfs); M.quality = reinterpret_cast<const uint8_t*>(d + o_in + b_calls + b_kfs + b_ids);
-  M.cell_size = cell_size; M.grid_n_cols = grid_n_cols;
-  AlignJobDev* d_jobs = reinterpret_cast<AlignJobDev*>(d + o_jobs);
-  hso_align_out* d_match = reinterpret_cast<hso_align_out*>(d + o_match);
-  hso_reproj_point* d_proj = reinterpret_cast<hso_reproj_point*>(d + o_proj);
-  hso_match_brief* d_brief = reinterpret_cast<hso_match_brief*>(d + o_brief);
-  const int n = (int)total;
-  hipLaunchKernelGGL(k_reproject_list, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, M, d_jobs, d_proj);
-  AlignConsts C;
-  C.cam = *cam; C.g = S->g;
-  launch_align(ctx, true, C, d_jobs, n, d_match);
-  hipLaunchKernelGGL(k_match_brief, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_proj, d_match, d_jobs, d_brief);
   HSO_HIP_CHECK(ctx, hipGetLastError());
-  R->n = n; R->d_proj = d_proj; R->d_brief = d_brief; R->d_extra = d + o_extra;
-  X->d_ids = M.ids; X->d_quality = M.quality; X->d_match = d_match;
-  X->pts.resize(n_frames); X->kf_poses.clear();
-  for (int c = 0; c < n_frames; c++) {
-    const SeqMap* m = seqmap_of(ctx, frames[c].map);
-    X->pts[c] = m->d_pts;
-    for (const hso_kf& k : m->kfs) X->kf_poses.push_back(k.T_f_w);
-  }
-  return n;
+  return HSO_OK;
 }

@@ -39,7 +39,6 @@ struct FrameRec {
 
 struct TrackBatchState;  // hso_tracker.hip
 struct SeedTables;       // hso_seed.hip: resident seed tables
-struct MapArena;         // hso_align.hip: resident map tables
 struct SeqMaps;          // hso_align.hip: sequence maps (tables mirrored row for row, patched in place)
 
 struct hso_gpu_ctx {
@@ -54,7 +53,6 @@ struct hso_gpu_ctx {
   std::vector<uint8_t*> frame_slabs;  // what hipMalloc returned: slabs of frames (hso_ctx.hip: hso_frame_alloc), freed with the context
   TrackBatchState* track;
   SeedTables* seed_tables;
-  MapArena* maps;
   SeqMaps* seqmaps;
   // staging for batched frame uploads: [bases | srcs | stats]
   char* d_batch; size_t batch_cap;
@@ -142,39 +140,72 @@ void hso_track_state_free(hso_gpu_ctx* ctx);
 void hso_seed_tables_free(hso_gpu_ctx* ctx);
 int hso_seed_async_quiesce(hso_gpu_ctx* ctx);   // wait for a previous-frame pass in flight (its results stay collectable)
 bool hso_seed_tables_pin(hso_gpu_ctx* ctx, int64_t frame_id);   // a resident seed table hosts live seeds in this frame
-void hso_map_arena_free(hso_gpu_ctx* ctx);
 void hso_seqmaps_free(hso_gpu_ctx* ctx);
 // a frame allocation of geometry g: recycled when the free list holds that geometry, else fresh with zeroed padding rows.
 // hso_frame_free returns it to the list (or the allocator); neither touches ctx->frames.
-// hso_align.hip: project + reference choice + findMatchDirect for every point of every call's stored map, results left on the
-// device (begin[c] = first record of call c); extra_bytes of the work area are reserved behind them (hso_select.hip chains the
-// grid selection there).  Returns the number of records or a status < 0.
-struct HsoMapsRun {
-  int n;
-  std::vector<int> begin;
-  const hso_reproj_point* d_proj;
-  const hso_match_brief* d_brief;
-  char* d_extra;
+// ---- the resident per-frame chain (hso_gpu_seq_chain: orchestrated in hso_select.hip; the sequence maps' storage and the kernels
+// that walk it live in hso_align.hip, the tracker in hso_tracker.hip) ----
+struct SeqKfDev {              // a keyframe row of a sequence map on the device
+  hso_se3 T_f_w;
+  double exposure_time;
+  const uint8_t* base;         // the resident frame
+  int64_t frame_id;
+  int32_t keyframe_id;
+  int32_t key_point[5];        // Frame::key_pts_ as point rows, -1: none
 };
-struct MapArenaSizes { long long total; };   // points of a set of calls
-int hso_map_call_sizes(hso_gpu_ctx* ctx, const hso_map_call* calls, int n_calls, MapArenaSizes* Z);
-int hso_reproject_maps_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
-                           int grid_n_cols, size_t extra_bytes, HsoMapsRun* R);
-// the sequence-map form (hso_gpu_reproject_select_pose_frames): the same records for the points each frame LISTS; what the
-// chained pose optimisation needs beside them comes back in X
-struct HsoFramesAux {
-  std::vector<int> kf_begin;                   // per frame: first row of its keyframes in kf_poses (n_frames + 1)
-  std::vector<hso_se3> kf_poses;               // T_f_w of every frame's map keyframes, frames back to back
-  std::vector<const hso_map_point*> pts;       // per frame: its map's point table (device)
-  const int32_t* d_ids; const uint8_t* d_quality;   // the listed ids / quality keys, frames back to back (device)
-  const hso_align_out* d_match;
+struct SeqMapDev {             // one sequence map as the chain's kernels see it
+  hso_map_point* pts; const hso_obs* obs; const int32_t* obs_pt; const SeqKfDev* kfs;
+  const int32_t* kf_fts;       // list of keyframe row r: kf_fts + r * fts_cap
+  const int32_t* cands;
+  int32_t* first;              // n_pts scratch integers, all 0x7fffffff between calls (the listing's "seen in this frame" stamps)
+  const hso_seq_feature* ff_ref; hso_seq_feature* ff_cur;   // the reference frame's feature table (null: it is a keyframe) / the new frame's
+  int n_pts, n_obs, n_kfs, fts_cap, n_cands, ff_cap;
 };
-int hso_reproject_frames_run(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_frame* frames, int n_frames, int cell_size,
-                             int grid_n_cols, size_t extra_bytes, HsoMapsRun* R, HsoFramesAux* X);
+struct ChainJobDev {
+  SeqMapDev M;
+  const uint8_t* cur_base;
+  double* table;               // the tracker's SoA feature table of this job: [6][n_ref_stride]
+  hso_se3 T_ref_w, T_cur_w0;
+  double ref_exposure;
+  int ref_kf_row, n_ref, n_ref_stride, flags;
+  int cur_keyframe_id, last_kf_row;
+  int covis[5];
+  int slice_begin, slice_cap;  // the job's slice of the per-listed-point arrays
+  int temps_begin, n_temps;
+  int kf_begin;                // first row of the job's blocks in the per-keyframe arrays (ReprojKf rows, list lengths)
+  int pad_;
+};
+struct ChainCur {              // what the chain's kernels hand on about a job's new frame
+  hso_se3 T_cur_w;             // after CoarseTracker::run
+  double exposure;
+  double cur_pos[3];           // the new frame's position in the world (Frame::pos())
+  int n_listed, n_kf_points, n_cands_listed, n_visit;
+  int visit[HSO_SEQ_MAX_VISIT];
+};
+struct ReprojKf;               // hso_align.hip
+struct AlignJobDev;
+// a map's device view for one chain job; flips the map's frame-feature tables (the previous new frame becomes the reference)
+int hso_seqmap_chain_view(hso_gpu_ctx* ctx, const hso_seq_job& job, SeqMapDev* out, int* n_kfs, const int32_t** kf_nfts_host);
+int hso_seqmap_chain_reserve(hso_gpu_ctx* ctx, int map, int rows);        // room for `rows` features in the map's two frame tables (before any view)
+void hso_seqmap_chain_commit(hso_gpu_ctx* ctx, const hso_seq_job& job, int n_feats);   // after a successful call: the new frame's table is the map's newest
+// stage launchers (asynchronous on the context's stream); d_* are device pointers into the work area
+struct ChainFront {
+  const ChainJobDev* d_jobs; ChainCur* d_cur; const hso_track_result* d_track; const int32_t* d_kf_nfts; const int32_t* d_temps;
+  ReprojKf* d_kfs; int32_t* d_ids; uint8_t* d_quality; AlignJobDev* d_align; hso_align_out* d_match; hso_reproj_point* d_proj;
+  hso_match_brief* d_brief; struct PoseJobDev* d_pose_jobs;
+  int n_jobs, n_total, max_kfs, cell_size, grid_n_cols;
+};
+int hso_chain_table_launch(hso_gpu_ctx* ctx, const ChainJobDev* d_jobs, int n_jobs, int n_max_stride);
+int hso_chain_front_launch(hso_gpu_ctx* ctx, const hso_camera* cam, const ChainFront& F);
+size_t hso_chain_sizeof_reproj_kf();
+size_t hso_chain_sizeof_align_job();
+PyrGeom hso_seqmaps_geom(hso_gpu_ctx* ctx, bool* have);
+void hso_chain_forget(hso_gpu_ctx* ctx);   // hso_select.hip: drop what the last chain call of a context left (context teardown)
+// hso_tracker.hip: the tracker over device-built feature tables (hso_track_job.feats_soa == 2: `feats` is a DEVICE pointer to the
+// kernel's layout); the result records stay on the device (*d_results).  Asynchronous for the batch shapes; a cooperative launch
+// (a batch smaller than the chip) is waited for, because its time-out fallback has to be known before the chain goes on.
+int hso_track_chain_launch(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* p, const hso_track_job* jobs, int n_jobs,
+                           const hso_track_result** d_results, bool* cooperative);
 void hso_seqmaps_debug_set(hso_gpu_ctx* ctx, int what, const void* d, size_t bytes);
-const hso_map_point* hso_map_points_dev(hso_gpu_ctx* ctx);
-int hso_map_max_points(hso_gpu_ctx* ctx);
-int hso_map_max_kfs(hso_gpu_ctx* ctx);
-int hso_map_kf_poses(hso_gpu_ctx* ctx, int map, hso_se3* out);   // T_f_w of map `map`'s keyframes in table order; returns their number
 int hso_frame_alloc(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t** base);
 void hso_frame_free(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* base);

@@ -233,7 +233,6 @@ int hso_gpu_create(hso_gpu_ctx** out, int device, void* stream)
   ctx->device = device;
   ctx->track = nullptr;
   ctx->seed_tables = nullptr;
-  ctx->maps = nullptr;
   ctx->seqmaps = nullptr;
   ctx->d_batch = nullptr;
   ctx->d_seed_scratch = nullptr; ctx->seed_scratch_cap = 0;
@@ -277,8 +276,8 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   hso_track_state_free(ctx);
   hso_seed_tables_free(ctx);
-  hso_map_arena_free(ctx);
   hso_seqmaps_free(ctx);
+  hso_chain_forget(ctx);
   for (auto* p : ctx->frame_slabs) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
   if (ctx->d_seed_scratch) (void)hipFree(ctx->d_seed_scratch);

@@ -201,8 +201,11 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
     n_max = std::max(n_max, jobs[j].n_feats);
     total_feats += (size_t)((jobs[j].n_feats + 31) & ~31);
   }
+  // feats_soa == 2: the tables are already on the device in the kernel's layout (the resident chain builds them there)
+  bool resident = n_jobs > 0 && jobs[0].feats_soa == 2;
+  for (int j = 0; j < n_jobs; j++) if ((jobs[j].feats_soa == 2) != resident) return hso_fail(ctx, HSO_E_INVALID, "coarse_track: device-resident and host feature tables cannot share a batch");
   // Callers that hand over the kernel's layout (feats_soa) in one contiguous block skip the host pass altogether.
-  bool direct = true;
+  bool direct = !resident;
   for (int j = 0; j < n_jobs && direct; j++) {
     direct = jobs[j].feats_soa == 1;
     if (direct && j > 0 && jobs[j].n_feats > 0) {
@@ -214,11 +217,11 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   }
   // Otherwise the SoA feature tables are formed in the context's page-locked staging buffer (one pass; a std::vector staged by
   // the copy wrapper meant a zero fill, the transpose and a staging copy: three passes over 6 MB for 64 jobs of 2000 features)
-  double* const h_feats = direct ? const_cast<double*>(reinterpret_cast<const double*>(jobs[0].feats))
+  double* const h_feats = resident ? nullptr : direct ? const_cast<double*>(reinterpret_cast<const double*>(jobs[0].feats))
                                  : reinterpret_cast<double*>(hso_pinned(ctx, 0, total_feats * 6 * sizeof(double) + 64));
-  if (!h_feats) return HSO_E_NOMEM;
+  if (!h_feats && !resident) return HSO_E_NOMEM;
   st->h_jobs.resize(n_jobs);
-  if (int rc = grow(ctx, &st->d_feats, &st->feats_cap, total_feats * 6 * sizeof(double))) return rc;
+  if (!resident) if (int rc = grow(ctx, &st->d_feats, &st->feats_cap, total_feats * 6 * sizeof(double))) return rc;
   size_t foff = 0;
   for (int j = 0; j < n_jobs; j++) {
     auto itr = ctx->frames.find(jobs[j].ref_frame_id);
@@ -229,9 +232,9 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
         itc->second.g.h[0] != g.h[0])
       return hso_fail(ctx, HSO_E_INVALID, "coarse_track: frames of one batch must share one size");
     const int n = jobs[j].n_feats, ns = (n + 31) & ~31;
-    double* dst = h_feats + foff * 6;
-    if (direct) {
-      // nothing to do: the caller's block is the upload image
+    double* dst = resident ? nullptr : h_feats + foff * 6;
+    if (direct || resident) {
+      // nothing to do: the caller's block is the upload image / the table is on the device
     } else if (jobs[j].feats_soa == 1) {
       memcpy(dst, jobs[j].feats, sizeof(double) * 6 * (size_t)ns);
     } else {
@@ -246,7 +249,7 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
     TrackJobDev& d = st->h_jobs[j];
     d.ref_base = itr->second.base;
     d.cur_base = itc->second.base;
-    d.feats = st->d_feats + foff * 6;
+    d.feats = resident ? const_cast<double*>(reinterpret_cast<const double*>(jobs[j].feats)) : st->d_feats + foff * 6;
     d.n = n; d.n_stride = ns;
     d.T = jobs[j].T_cur_ref;
     d.a = jobs[j].exposure_rat;
@@ -346,8 +349,8 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   C.lv = reinterpret_cast<const TrackLevel*>(reinterpret_cast<const char*>(st->d_counter) + 256);
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(const_cast<TrackLevel*>(C.lv), st->lv, sizeof(st->lv), hipMemcpyHostToDevice, ctx->stream));
   if (!st->d_eval) HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&st->d_eval), sizeof(hso_eval_out)));
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_feats, h_feats, total_feats * 6 * sizeof(double),
-                                    hipMemcpyHostToDevice, ctx->stream));
+  if (!resident) HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_feats, h_feats, total_feats * 6 * sizeof(double),
+                                                   hipMemcpyHostToDevice, ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(st->d_jobs, st->h_jobs.data(), sizeof(TrackJobDev) * n_jobs,
                                     hipMemcpyHostToDevice, ctx->stream));
   if (!st->attr_set) {
@@ -448,6 +451,31 @@ int hso_gpu_coarse_track_collect(hso_gpu_ctx* ctx, hso_track_result* results)
   }
   return HSO_OK;
 }
+
+}  // extern "C"
+
+// The tracker inside the resident chain (hso_gpu_seq_chain): prepare + launch over device-built tables; the result records stay on
+// the device, where the chain's next kernel reads them.  A cooperative launch (a batch smaller than the chip) is collected here —
+// its time-out fallback must be known before the chain goes on changing the sequence tables — so *d_results is valid either way.
+int hso_track_chain_launch(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* p, const hso_track_job* jobs, int n_jobs,
+                           const hso_track_result** d_results, bool* cooperative)
+{
+  int rc = track_prepare(ctx, cam, p, jobs, n_jobs, 0, false);
+  if (rc < 0) return rc;
+  TrackBatchState* st = ctx->track;
+  rc = hso_gpu_coarse_track_launch(ctx);
+  if (rc < 0) return rc;
+  *cooperative = st->coop_K != 0;
+  if (st->coop_K) {
+    std::vector<hso_track_result> tmp((size_t)n_jobs);
+    rc = hso_gpu_coarse_track_collect(ctx, tmp.data());   // waits; reruns on the one-workgroup shape after a time-out
+    if (rc < 0) return rc;
+  }
+  *d_results = st->d_results;
+  return HSO_OK;
+}
+
+extern "C" {
 
 int hso_gpu_coarse_track_batch(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_track_params* params,
                                const hso_track_job* jobs, int n_jobs, hso_track_result* results)

@@ -72,6 +72,9 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
       seq_.push_back(s);
       step_.push_back(new StepData());
       check(hso_gpu_seqmap_create(ctx_, &s->map), "seqmap_create");
+      // a keyframe's feature list: its own features (the first keyframe: up to the initialisation's 2000) + the features of its
+      // seeds that became points (at most max_fts + 100 seeds per keyframe)
+      check(hso_gpu_seqmap_configure(ctx_, s->map, std::max(2000, cfg_.max_fts) + cfg_.max_fts + 128), "seqmap_configure");
     }
     check(hso_gpu_seed_table_create(ctx_, &seed_table_), "seed_table_create");
     int n_threads = 0;
@@ -111,7 +114,7 @@ Bank::~Bank()
     delete s;
   }
   for (StepData* d : step_) delete d;
-  briefs_.release(); records_.release(); projected_.release(); mask_.release(); feat_f_.release(); track_tables_.release(); act_seeds_.release(); act_targets_.release(); act_ints_.release(); act_out_.release(); seed_brief_.release(); seed_px_.release(); det_corners_.release(); det_fill_.release(); det_edgelets_.release();   // before the context goes
+  chain_res_.release(); feat_rows_.release(); track_tables_.release(); act_seeds_.release(); act_targets_.release(); act_ints_.release(); act_out_.release(); seed_brief_.release(); seed_px_.release(); det_corners_.release(); det_fill_.release(); det_edgelets_.release();   // before the context goes
   if (owns_ctx_) hso_gpu_destroy(ctx_);
 }
 

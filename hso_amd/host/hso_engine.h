@@ -70,9 +70,12 @@ struct Point {
   Id head = kNone;                // newest observation
   int32_t n_obs = 0;
   int8_t kind = kPtUnknown, on = kOnCorner;
-  int32_t n_fail = 0, n_ok = 0, stamp = -1, n_ba = 0;
+  int32_t n_ba = 0;
   int8_t seed_state = 0;          // temporary points: 0 the seed lives, 1 it converged, -1 it was dropped
   bool bad = false;
+  // n_failed_reproj_ / n_succeeded_reproj_ live in the device's point row (include/hso_gpu.h: HSO_PT_*): the chain counts them and
+  // reports the kind changes they cause; the next patch of the row resets the counters named here (bit 0 failures, bit 1 successes)
+  uint8_t dev_reset = 3;
 };
 
 struct Frame {
@@ -89,8 +92,11 @@ struct Frame {
   int32_t n_inliers = 0;
   int32_t refs = 0;               // holders: the handler's last / current frame, the map, seeds' frame lists
   bool in_use = false;
-  std::vector<Feat> loose;        // a frame that is not a keyframe owns its features
+  std::vector<Feat> loose;        // a frame that is not a keyframe owns its features — on the device (the sequence map's frame table);
+                                  // here only while the host needs them (promotion to a keyframe, the seed branch, a two-view start)
+  int32_t n_fts = 0;              // their number
   std::vector<Id> fts;            // a keyframe lists rows of Seq::feats (Frame::fts_ order)
+  int32_t fts_sent = 0;           // ... of which the device's copy of the list holds this many
   std::array<Id, 5> key{{kNone, kNone, kNone, kNone, kNone}};   // Frame::key_pts_
   std::vector<Id> covis;          // connectedKeyFrames (frame slots)
   int32_t visited = -1;           // lastReprojectFrameId_
@@ -171,16 +177,16 @@ private:
   // phases of a step (device calls on the caller's thread; per-sequence work through par() / the pool)
   void upload(const std::vector<int>& who, const uint8_t* const* imgs, int w, int h, const double* stamps, bool on_device = false);
   void initialise(const std::vector<int>& who);
-  void track(const std::vector<int>& who);
+  void chain(const std::vector<int>& who);
   void track_group(const std::vector<int>& who, const std::vector<Id>& ref, const std::vector<Id>& cur, const hso_track_params& p);
-  void reproject(const std::vector<int>& who);
-  void list_points(int k);
-  void apply_selection(int k, const hso_frame_match* rec, int n_rec, const uint8_t* projected, const double* feat_f);
-  void trace_reproject(const std::vector<int>& who, const std::vector<hso_map_frame>& calls, const std::vector<size_t>& list_at,
-                       const std::vector<int32_t>& begin, const std::vector<int32_t>& counts, const std::vector<hso_pose_result>& pose,
-                       const std::vector<int32_t>& n_feats);
+  void prepare_job(int k, hso_seq_job& job, std::vector<int32_t>& temps);
+  void consume_result(int k, const hso_seq_result& r, const std::vector<int32_t>& more_events);
+  void trace_chain(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const hso_seq_result* res);
+  void fetch_features(const std::vector<int>& who);
+  void send_features(const std::vector<int>& who);
   void seed_branch(const std::vector<int>& who);
   void decide(int k);
+  void decide_keyframe(int k);
   bool wants_keyframe(int k);
   void link_covisible(int k, bool is_keyframe);
   void promote(int k);
@@ -230,10 +236,9 @@ private:
   int64_t phase_census_[9][6] = {{0}};   // per phase: copies, bytes, staged copies, synchronisations, ns blocked in them, memsets
   int64_t n_steps_ = 0, n_kf_events_ = 0;
   // result tables of the batched calls (kept between steps: no allocation per step)
-  Pinned<hso_match_brief> briefs_;   // recorded runs only: the full records of the examined candidates
-  Pinned<hso_frame_match> records_;
-  Pinned<uint8_t> projected_, mask_;
-  Pinned<double> feat_f_, track_tables_;
+  Pinned<hso_seq_result> chain_res_;   // the chain's result records
+  Pinned<hso_seq_feature> feat_rows_;  // frame feature tables on their way to / from the device
+  Pinned<double> track_tables_;
   Pinned<hso_seed> act_seeds_; Pinned<hso_activate_target> act_targets_; Pinned<int32_t> act_ints_; Pinned<hso_activate_out> act_out_;   // activate_seeds()
   Pinned<hso_seed_brief> seed_brief_;
   Pinned<float> seed_px_;

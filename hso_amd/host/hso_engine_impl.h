@@ -154,6 +154,9 @@ struct Seq {
   std::vector<Id> dirty_pts, dirty_obs;
   std::vector<uint8_t> pt_flag, obs_flag;
   bool kfs_dirty = false;
+  bool keys_dirty = false;        // a keyframe's key points changed
+  std::vector<Id> dirty_lists;    // keyframes whose feature list grew since the last flush
+  std::vector<Id> dev_cands;      // the candidate list as the device holds it (entries the device deleted itself stay until the next full send)
   // handler
   int stage = kPaused, quality = kInsufficient, outcome = kNoKeyframe;
   bool want_start = false, after_init = false;
@@ -203,7 +206,8 @@ struct Seq {
     free_slots.push_back(fr);
     return true;
   }
-  size_t n_feats(const Frame& F) const { return F.kf_row >= 0 ? F.fts.size() : F.loose.size(); }
+  size_t n_feats(const Frame& F) const { return F.kf_row >= 0 ? F.fts.size() : (size_t)F.n_fts; }
+  void list_grew(Id fr) { if (std::find(dirty_lists.begin(), dirty_lists.end(), fr) == dirty_lists.end()) dirty_lists.push_back(fr); }
   Feat& feat_of(Frame& F, size_t i) { return F.kf_row >= 0 ? feats[F.fts[i]] : F.loose[i]; }
   const Feat& feat_of(const Frame& F, size_t i) const { return F.kf_row >= 0 ? feats[F.fts[i]] : F.loose[i]; }
   Vector3d centre(const Frame& F) const { return F.T.inverse().translation(); }
@@ -244,6 +248,7 @@ struct Seq {
     const Feat& n = feats[f];
     const double dx = n.px[0] - cu, dy = n.px[1] - cv;
     auto cheb = [&](Id g) { return std::max(std::fabs(feats[g].px[0] - cu), std::fabs(feats[g].px[1] - cv)); };
+    keys_dirty = true;
     if (F.key[0] == kNone || std::max(std::fabs(dx), std::fabs(dy)) < cheb(F.key[0])) F.key[0] = f;
     const int quadrant = n.px[0] >= cu ? (n.px[1] >= cv ? 1 : 2) : (n.px[1] >= cv ? 3 : 4);
     const double sx = (quadrant == 1 || quadrant == 2) ? 1.0 : -1.0, sy = (quadrant == 1 || quadrant == 3) ? 1.0 : -1.0;
@@ -256,6 +261,7 @@ struct Seq {
   }
   void refresh_keys(Frame& F)     // Frame::setKeyPoints
   {
+    keys_dirty = true;
     for (Id& k : F.key) if (k != kNone && feats[k].point == kNone) k = kNone;
     for (Id f : F.fts) if (feats[f].point != kNone) offer_key(F, f);
   }
@@ -281,17 +287,20 @@ struct Seq {
     for (Id o = P.head; o != kNone;) {
       const Id nx = feats[o].next;
       feats[o].point = kNone; feats[o].next = kNone; feats[o].linked = false;
+      touch_obs(o);
       lose_key(o);
       o = nx;
     }
     P.head = kNone; P.n_obs = 0;
     P.kind = kPtDeleted;
+    touch_point(p);
   }
   void detach(Id frame, Id f)     // Map::removePtFrameRef
   {
     const Id p = feats[f].point;
     if (p == kNone) return;
     feats[f].point = kNone;
+    touch_obs(f);
     if (points[p].n_obs <= 2) { erase_point(p); return; }
     unobserve(p, frame);
     lose_key(f);
@@ -309,9 +318,10 @@ struct Seq {
     if (it == candidates.end()) return false;
     candidates.erase(it);
     Point& P = points[p];
-    if (P.host != kNone) { feats[P.host].point = kNone; feats[P.host].linked = false; feats[P.host].next = kNone; }
+    if (P.host != kNone) { feats[P.host].point = kNone; feats[P.host].linked = false; feats[P.host].next = kNone; touch_obs(P.host); }
     P.head = kNone; P.n_obs = 0;
     P.kind = kPtDeleted;
+    touch_point(p);
     return true;
   }
   // Map::safeDeleteTempPoint: what becomes of a temporary point once its seed has finished
@@ -321,9 +331,9 @@ struct Seq {
     if (P.seed_state == -1) {                   // the seed was dropped
       if (P.bad) { erase_point(p); return; }
       place_in_host(p);
-      P.n_fail = 0; P.n_ok = 0;
+      P.dev_reset = 3;                               // n_failed_reproj_ = n_succeeded_reproj_ = 0
       if (P.n_obs == 1) { P.kind = kPtCandidate; candidates.push_back(p); }
-      else { P.kind = kPtUnknown; frames[feats[P.host].frame].fts.push_back(P.host); }
+      else { P.kind = kPtUnknown; frames[feats[P.host].frame].fts.push_back(P.host); list_grew(feats[P.host].frame); }
       return;
     }
     // the seed converged into a point of its own, which took over the host feature; every other observation of the temporary
@@ -333,10 +343,12 @@ struct Seq {
       const Id nx = feats[o].next;
       if (feats[o].point != heir) { feats[o].point = kNone; feats[o].next = kNone; feats[o].linked = false; lose_key(o); }
       else if (o != P.host) { feats[o].next = kNone; feats[o].linked = false; }
+      touch_obs(o);
       o = nx;
     }
     P.head = kNone; P.n_obs = 0;
     P.kind = kPtDeleted;
+    touch_point(p);
   }
   void closest_keyframes(const Frame& F, std::vector<std::pair<double, Id>>& out) const   // Map::getCloseKeyframes
   {
@@ -367,6 +379,7 @@ struct Seq {
   {
     frames.clear(); free_slots.clear(); feats.clear(); points.clear(); seeds.clear(); n_dead_seeds = 0;
     kfs.clear(); dev_kfs.clear(); candidates.clear(); temps.clear(); dirty_pts.clear(); dirty_obs.clear(); pt_flag.clear(); obs_flag.clear();
+    dirty_lists.clear(); dev_cands.clear(); keys_dirty = true;
     kfs_dirty = true; local_map.clear(); converge_hist.clear(); prior.clear(); pre_lists.clear(); init.clear(); hist_stamp.clear(); hist_pose.clear();
     last = cur = first = kNone;
   }
@@ -383,13 +396,11 @@ struct StepData {
   std::vector<int64_t> released;               // device frames to release (collected on pool threads)
   Id ref = kNone;                              // the frame the tracker aligns against
   int inverse = 1;
-  std::vector<hso_ref_feat> ref_feats;
-  hso_track_job job{};
   hso_track_result track{};
   std::vector<Id> visit;                       // overlap keyframes in visiting order
-  std::vector<int32_t> list; std::vector<uint8_t> list_q;
-  int n_kf_points = 0, n_cand_listed = 0;      // list layout: keyframe points | candidates | temporary points
-  hso_map_frame call{};
+  std::vector<Id> temps_listed;                // the temporary points the frame lists
+  hso_seq_result res{};                        // the chain's result record
+  bool host_pose = false;                      // the pose was optimised again over host tables (the seed branch)
   size_t n_inliers = 0;
   double depth_mean = 0, depth_min = 0, dist_mean = 0;
   // keyframe: the local BA window

@@ -231,6 +231,7 @@ void Bank::initialise(const std::vector<int>& who)
       s.feats.push_back(in_ref);
       const Id f = (Id)s.feats.size() - 1;
       R.fts.push_back(f);
+      s.list_grew(I.ref);
       const double pn[3] = {pos[0], pos[1], pos[2]};
       const Id p = s.new_point(pos, f, 1.0 / len3(pn), kPtUnknown);   // as written (:124): the reference frame sits at the origin
       s.feats[f].point = p;
@@ -245,79 +246,104 @@ void Bank::initialise(const std::vector<int>& who)
     s.refresh_keys(R);                                            // firstFrame_->setKeyPoints()
     s.outcome = kKeyframe;
     s.log.n_matches = (int)C.loose.size();
+    C.n_fts = (int32_t)C.loose.size();
     C.n_inliers = 0;
   }
 }
 
-// ------------------------------------------------------------------------------------------------ trace of the chained call
-// One hso_gpu_reproject_select_pose_frames call = three records per traced sequence, with the tables AS THE DEVICE HOLDS THEM
-// (read back through hso_gpu_seqmap_read / hso_gpu_debug_fetch — the host mirror is not trusted here): "reproject_match" in the
-// value-passing call's layout (the observation lists flattened), "reproject_select" (the examined candidates) and "pose_optimize"
-// (the feature table the device built from them).
-void Bank::trace_reproject(const std::vector<int>& who, const std::vector<hso_map_frame>& calls, const std::vector<size_t>& list_at,
-                           const std::vector<int32_t>& begin, const std::vector<int32_t>& counts, const std::vector<hso_pose_result>& pose,
-                           const std::vector<int32_t>& n_feats)
+// ------------------------------------------------------------------------------------------------ trace of the chain call
+// One hso_gpu_seq_chain call = four records per traced sequence, with the tables AS THE DEVICE HOLDS THEM (read back through
+// hso_gpu_seq_debug_* / hso_gpu_seqmap_read / hso_gpu_debug_fetch — the host mirror is not trusted here): "coarse_track" with the
+// feature table the device built, "reproject_match" in the value-passing call's layout (the device's own point list, the
+// observation lists flattened), "reproject_select" (the examined candidates) and "pose_optimize" (the feature table the device
+// built from them).
+void Bank::trace_chain(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const hso_seq_result* res)
 {
   const int n = (int)who.size(), cap = std::max(cfg_.max_fts, 1);
-  size_t total = 0;
-  for (const hso_map_frame& c : calls) total += (size_t)c.n_points;
-  std::vector<hso_reproj_point> proj(total); std::vector<hso_align_out> match(total);
-  std::vector<hso_pose_feat> pf((size_t)n * cap); std::vector<hso_se3> pp((size_t)n * 128); std::vector<int32_t> np((size_t)n);
-  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_PROJ, proj.data(), sizeof(hso_reproj_point) * total), "trace");
-  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_MATCH, match.data(), sizeof(hso_align_out) * total), "trace");
+  std::vector<int32_t> slices((size_t)n + 1), ex_begin((size_t)n + 1);
+  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_SLICES, slices.data(), sizeof(int32_t) * slices.size()), "trace");
+  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_EXAMINED_BEGIN, ex_begin.data(), sizeof(int32_t) * ex_begin.size()), "trace");
+  const size_t total = (size_t)slices[(size_t)n], n_exam = (size_t)ex_begin[(size_t)n];
+  std::vector<hso_reproj_point> proj(total); std::vector<hso_align_out> match(total); std::vector<uint8_t> projected(total);
+  std::vector<hso_match_brief> briefs(std::max(n_exam, (size_t)1));
+  std::vector<hso_pose_feat> pf((size_t)n * cap); std::vector<hso_se3> pp((size_t)n * 128); std::vector<int32_t> np((size_t)n); std::vector<uint8_t> pmask((size_t)n * cap);
+  if (total) {
+    check(hso_gpu_debug_fetch(ctx_, HSO_DBG_PROJ, proj.data(), sizeof(hso_reproj_point) * total), "trace");
+    check(hso_gpu_debug_fetch(ctx_, HSO_DBG_MATCH, match.data(), sizeof(hso_align_out) * total), "trace");
+    check(hso_gpu_debug_fetch(ctx_, HSO_DBG_PROJECTED, projected.data(), total), "trace");
+  }
+  if (n_exam) check(hso_gpu_debug_fetch(ctx_, HSO_DBG_BRIEF, briefs.data(), sizeof(hso_match_brief) * n_exam), "trace");
   check(hso_gpu_debug_fetch(ctx_, HSO_DBG_POSE_FEATS, pf.data(), sizeof(hso_pose_feat) * pf.size()), "trace");
   check(hso_gpu_debug_fetch(ctx_, HSO_DBG_POSE_POSES, pp.data(), sizeof(hso_se3) * pp.size()), "trace");
   check(hso_gpu_debug_fetch(ctx_, HSO_DBG_POSE_NPOSES, np.data(), sizeof(int32_t) * np.size()), "trace");
+  check(hso_gpu_debug_fetch(ctx_, HSO_DBG_POSE_MASK, pmask.data(), pmask.size()), "trace");
   for (int i = 0; i < n; i++) {
-    Seq& s = *seq_[who[i]];
+    Seq& s = *seq_[who[(size_t)i]];
     if (!s.trace.on()) continue;
-    const StepData& d = *step_[who[i]];
-    const hso_map_frame& c = calls[i];
+    const hso_seq_job& jb = jobs[(size_t)i];
+    const hso_seq_result& r = res[i];
+    Trace& t = s.trace;
+    // ---- CoarseTracker::run over the table the device built
+    if (!(jb.flags & HSO_SEQ_NO_TRACK)) {
+      std::vector<hso_ref_feat> rec((size_t)std::max(jb.n_ref_feats, 1));
+      const int got = hso_gpu_seq_debug_ref_table(ctx_, i, rec.data(), (int)rec.size());
+      check(got, "trace");
+      const SE3 Tc{jb.T_cur_w}, Tr{jb.T_ref_w};
+      const hso_se3 T_cur_ref = (Tc * Tr.inverse()).v;
+      t.begin("coarse_track", 8);
+      t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("params", &cfg.track, sizeof(cfg.track));
+      t.scalar("ref_frame_id", (double)jb.ref_frame_id); t.scalar("cur_frame_id", (double)jb.cur_frame_id);
+      t.field("feats", rec.data(), sizeof(hso_ref_feat) * (size_t)got);
+      t.field("T_cur_ref", &T_cur_ref, sizeof(hso_se3)); t.scalar("exposure_rat", jb.exposure_rat);
+      t.field("result", &r.track, sizeof(r.track));
+    }
+    // ---- the list the device walked, and what became of its points
+    const int nl = r.n_listed;
+    std::vector<int32_t> ids((size_t)std::max(nl, 1)); std::vector<uint8_t> quality((size_t)std::max(nl, 1));
+    check(hso_gpu_seq_debug_list(ctx_, i, ids.data(), quality.data(), (int)ids.size()), "trace");
     int nk = 0, n_pts = 0, n_obs = 0;
     check(hso_gpu_seqmap_size(ctx_, s.map, &nk, &n_pts, &n_obs), "trace");
-    std::vector<hso_map_point> rows((size_t)c.n_points);
+    std::vector<hso_map_point> rows((size_t)nl);
     std::vector<int32_t> all_obs((size_t)n_obs);
     std::iota(all_obs.begin(), all_obs.end(), 0);
     std::vector<hso_obs> obs_rows((size_t)n_obs);
-    check(hso_gpu_seqmap_read(ctx_, s.map, c.point_ids, c.n_points, rows.data(), all_obs.data(), n_obs, obs_rows.data()), "trace");
+    check(hso_gpu_seqmap_read(ctx_, s.map, ids.data(), nl, rows.data(), all_obs.data(), n_obs, obs_rows.data()), "trace");
     std::vector<hso_kf> kfs;
-    for (Id fr : s.dev_kfs) { const Frame& F = s.frames[fr]; hso_kf r{}; r.frame_id = F.dev_id; r.T_f_w = F.T.v; r.exposure_time = F.exposure; r.keyframe_id = F.kf_id; kfs.push_back(r); }
+    for (Id fr : s.dev_kfs) { const Frame& F = s.frames[fr]; hso_kf k{}; k.frame_id = F.dev_id; k.T_f_w = F.T.v; k.exposure_time = F.exposure; k.keyframe_id = F.kf_id; kfs.push_back(k); }
     std::vector<hso_obs> flat;
-    std::vector<hso_reproj_point> pr(proj.begin() + (std::ptrdiff_t)list_at[i], proj.begin() + (std::ptrdiff_t)(list_at[i] + (size_t)c.n_points));
-    for (int j = 0; j < c.n_points; j++) {
-      hso_map_point& r = rows[(size_t)j];
+    const size_t at0 = (size_t)slices[(size_t)i];
+    std::vector<hso_reproj_point> pr(proj.begin() + (std::ptrdiff_t)at0, proj.begin() + (std::ptrdiff_t)(at0 + (size_t)nl));
+    for (int j = 0; j < nl; j++) {
+      hso_map_point& row = rows[(size_t)j];
       const int first = (int)flat.size();
       int at = -1;
-      for (int q = 0, row = r.obs_begin; q < r.obs_count; q++) {
-        hso_obs o = obs_rows[(size_t)row];
-        if (pr[(size_t)j].ref_obs == row) at = first + q;
-        row = o.pad_; o.pad_ = 0;
+      for (int q = 0, orow = row.obs_begin; q < row.obs_count; q++) {
+        hso_obs o = obs_rows[(size_t)orow];
+        if (pr[(size_t)j].ref_obs == orow) at = first + q;
+        orow = o.pad_; o.pad_ = 0;
         flat.push_back(o);
       }
-      r.obs_begin = first;
-      r.pad_ = c.quality[j];
+      row.obs_begin = first;
+      row.pad_ = quality[(size_t)j];
       if (pr[(size_t)j].ref_obs >= 0) pr[(size_t)j].ref_obs = at;
       pr[(size_t)j].pad_ = 0;
     }
-    Trace& t = s.trace;
-    const Frame& C = s.frames[s.cur];
     hso_obs none_obs{};
     t.begin("reproject_match", 12);
-    t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.scalar("cur_frame_id", (double)c.cur_frame_id); t.field("T_cur_w", &c.T_cur_w, sizeof(hso_se3));
-    t.scalar("cur_exposure", c.cur_exposure_time); t.scalar("cur_keyframe_id", c.cur_keyframe_id);
+    t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.scalar("cur_frame_id", (double)jb.cur_frame_id); t.field("T_cur_w", &r.T_tracked, sizeof(hso_se3));
+    t.scalar("cur_exposure", r.exposure); t.scalar("cur_keyframe_id", jb.cur_keyframe_id);
     t.field("kfs", kfs.data(), sizeof(hso_kf) * kfs.size()); t.field("points", rows.data(), sizeof(hso_map_point) * rows.size());
     t.field("obs", flat.empty() ? &none_obs : flat.data(), sizeof(hso_obs) * flat.size()); t.scalar("cell_size", cell_size_); t.scalar("grid_n_cols", grid_cols_);
-    t.field("proj", pr.data(), sizeof(hso_reproj_point) * pr.size()); t.field("match", match.data() + list_at[i], sizeof(hso_align_out) * (size_t)c.n_points);
+    t.field("proj", pr.data(), sizeof(hso_reproj_point) * pr.size()); t.field("match", match.data() + at0, sizeof(hso_align_out) * (size_t)nl);
     t.begin("reproject_select", 6);
-    t.field("quality", c.quality, (size_t)c.n_points); t.field("cell_order", cell_order_.data(), sizeof(int32_t) * cell_order_.size());
-    t.scalar("max_fts", cfg_.max_fts); t.field("examined", briefs_.data() + begin[i], sizeof(hso_match_brief) * (size_t)(begin[i + 1] - begin[i]));
-    t.field("counts", &counts[4 * (size_t)i], sizeof(int32_t) * 4); t.field("projected", projected_.data() + list_at[i], (size_t)c.n_points);
+    t.field("quality", quality.data(), (size_t)nl); t.field("cell_order", cell_order_.data(), sizeof(int32_t) * cell_order_.size());
+    t.scalar("max_fts", cfg_.max_fts); t.field("examined", briefs.data() + ex_begin[(size_t)i], sizeof(hso_match_brief) * (size_t)(ex_begin[(size_t)i + 1] - ex_begin[(size_t)i]));
+    t.field("counts", r.counts, sizeof(int32_t) * 4); t.field("projected", projected.data() + at0, (size_t)nl);
     t.begin("pose_optimize", 8);
-    t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("feats", pf.data() + (size_t)i * cap, sizeof(hso_pose_feat) * (size_t)n_feats[i]);
-    t.field("poses", pp.data() + (size_t)i * 128, sizeof(hso_se3) * (size_t)std::min(np[(size_t)i], 128)); t.field("T_f_w", &c.T_cur_w, sizeof(hso_se3));
+    t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("feats", pf.data() + (size_t)i * cap, sizeof(hso_pose_feat) * (size_t)r.n_feats);
+    t.field("poses", pp.data() + (size_t)i * 128, sizeof(hso_se3) * (size_t)std::min(np[(size_t)i], 128)); t.field("T_f_w", &r.T_tracked, sizeof(hso_se3));
     t.scalar("reproj_thresh", cfg_.poseoptim_thresh); t.scalar("n_iter", 12);
-    t.field("result", &pose[(size_t)i], sizeof(hso_pose_result)); t.field("mask", mask_.data() + (size_t)i * cap, (size_t)n_feats[i]);
-    (void)d; (void)C;
+    t.field("result", &r.pose, sizeof(hso_pose_result)); t.field("mask", pmask.data() + (size_t)i * cap, (size_t)r.n_feats);
   }
 }
 

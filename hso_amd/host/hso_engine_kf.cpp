@@ -723,6 +723,7 @@ void Bank::seed_branch(const std::vector<int>& who)
       pick.push_back((int)i); in.push_back(seed_record(s, sd));
     }
     if (pick.empty()) continue;
+    C.n_fts = (int32_t)C.loose.size();
     std::vector<hso_reproj_point> proj(pick.size()); std::vector<hso_align_out> match(pick.size());
     check(hso_gpu_seed_reproject_match(ctx_, &cam_.pod(), C.dev_id, &C.T.v, C.exposure, in.data(), (int)in.size(), cell_size_, grid_cols_, proj.data(),
                                        match.data()), "Reprojector (seeds)");
@@ -774,9 +775,11 @@ void Bank::seed_branch(const std::vector<int>& who)
       if (n_matches >= cfg_.max_fts) break;
     }
     s.log.n_matches = n_matches;
-    if (added) again.push_back(k);
-    (void)d;
+    (void)added; (void)d;
   }
+  // every sequence of the branch gets its pose optimised here, over the complete feature list as the host holds it (the chain left
+  // the optimiser's culling unapplied for them)
+  for (int k : who) again.push_back(k);
   if (again.empty()) return;
   // pose_optimizer::optimizeLevenbergMarquardt3rd over the complete feature lists
   std::vector<std::vector<hso_pose_feat>> feats(again.size());
@@ -818,7 +821,8 @@ void Bank::seed_branch(const std::vector<int>& who)
   for (size_t i = 0; i < again.size(); i++) {
     Seq& s = *seq_[again[i]];
     StepData& d = *step_[again[i]];
-    d.pose = res[i]; d.pose_mask = mask[i];
+    d.pose = res[i]; d.pose_mask = mask[i]; d.host_pose = true;
+    s.frames[s.cur].n_fts = (int32_t)s.frames[s.cur].loose.size();
     if (s.trace.on()) {
       Trace& t = s.trace;
       t.begin("pose_optimize", 8);
@@ -831,10 +835,15 @@ void Bank::seed_branch(const std::vector<int>& who)
 }
 
 // ------------------------------------------------------------------------------------------------ device mirror
-// the rows of the sequence tables that changed since the last flush, as the device's record types
+// what changed in the sequence tables since the last flush, as the device's record types: keyframe table and key points, point and
+// observation rows (with the Feature::point links), the keyframes' feature lists, the candidate list
 void Bank::flush_maps(const std::vector<int>& who)
 {
-  struct Patch { std::vector<hso_kf> kfs; std::vector<int32_t> pid, oid; std::vector<hso_map_point> pts; std::vector<hso_obs> obs; bool kf = false; };
+  struct Patch {
+    std::vector<hso_kf> kfs; std::vector<int32_t> keys; std::vector<int32_t> pid, oid, olink; std::vector<hso_map_point> pts; std::vector<hso_obs> obs;
+    std::vector<std::pair<int32_t, std::pair<int32_t, std::vector<int32_t>>>> lists;   // (list, (first, ids))
+    bool kf = false, key = false;
+  };
   std::vector<Patch> patch(who.size());
   pool_->run((int)who.size(), [&](int i) {
     Seq& s = *seq_[who[i]];
@@ -848,8 +857,14 @@ void Bank::flush_maps(const std::vector<int>& who)
         P.kfs.push_back(r);
       }
     }
+    if ((s.kfs_dirty || s.keys_dirty) && !s.dev_kfs.empty()) {
+      // Frame::key_pts_ as point rows (what Map::getCloseKeyframes looks at)
+      P.key = true;
+      for (Id fr : s.dev_kfs) for (Id kf_feat : s.frames[fr].key) P.keys.push_back(kf_feat == kNone ? -1 : s.feats[kf_feat].point);
+      s.keys_dirty = false;
+    }
     for (Id p : s.dirty_pts) {
-      const Point& pt = s.points[p];
+      Point& pt = s.points[p];
       s.pt_flag[p] = 0;
       if (pt.host == kNone) continue;
       const Feat& host = s.feats[pt.host];
@@ -860,6 +875,10 @@ void Bank::flush_maps(const std::vector<int>& who)
       r.host_kf = s.frames[host.frame].kf_row;
       r.obs_begin = pt.head; r.obs_count = pt.n_obs;
       if (r.host_kf < 0) continue;                                // hosted in a frame that never became a keyframe: not projectable
+      // the state word: kind and face (the selection's quality key) and the bad flag are the host's; the device keeps counting the
+      // failures / successes unless this patch resets them
+      r.pad_ = (int32_t)((uint32_t)HSO_PT_WORD(quality_key(pt), 0, pt.bad, 0) | ((pt.dev_reset & 1) ? 0u : HSO_PT_KEEP_NFAIL) | ((pt.dev_reset & 2) ? 0u : HSO_PT_KEEP_NOK));
+      pt.dev_reset = 0;
       P.pid.push_back(p); P.pts.push_back(r);
     }
     s.dirty_pts.clear();
@@ -870,22 +889,61 @@ void Bank::flush_maps(const std::vector<int>& who)
       r.kf = s.frames[ft.frame].kf_row; r.level = ft.level; r.type = ft.type; r.pad_ = ft.linked ? ft.next : -1;
       r.px[0] = ft.px[0]; r.px[1] = ft.px[1]; r.f[0] = ft.f[0]; r.f[1] = ft.f[1]; r.f[2] = ft.f[2]; r.grad[0] = ft.grad[0]; r.grad[1] = ft.grad[1];
       if (r.kf < 0) continue;
-      P.oid.push_back(f); P.obs.push_back(r);
+      P.oid.push_back(f); P.obs.push_back(r); P.olink.push_back(ft.point);
     }
     s.dirty_obs.clear();
+    // Frame::fts_ of the keyframes whose list grew (lists only grow: a new keyframe's own features, later the features of its
+    // seeds whose points were promoted)
+    for (Id fr : s.dirty_lists) {
+      Frame& F = s.frames[fr];
+      if (!F.in_use || F.kf_row < 0 || (size_t)F.fts_sent >= F.fts.size()) continue;
+      P.lists.emplace_back(F.kf_row, std::make_pair(F.fts_sent, std::vector<int32_t>(F.fts.begin() + F.fts_sent, F.fts.end())));
+      F.fts_sent = (int32_t)F.fts.size();
+    }
+    s.dirty_lists.clear();
+    // MapPointCandidates::candidates_: the device's copy is the host's list plus the entries the device deleted itself (it skips
+    // those).  While the host's list is the live part of the device's plus a tail, the tail is all that goes; otherwise (a
+    // promotion took candidates out) the whole list
+    {
+      size_t at = 0; bool prefix = true;
+      for (Id p : s.dev_cands) {
+        if (s.points[p].kind != kPtCandidate) continue;           // deleted on the device (event) — or taken out by the host: then no prefix
+        if (at < s.candidates.size() && s.candidates[at] == p) at++; else { prefix = false; break; }
+      }
+      if (prefix) for (Id p : s.dev_cands) if (s.points[p].kind != kPtCandidate && s.points[p].kind != kPtDeleted) { prefix = false; break; }
+      if (prefix && s.dev_cands.size() < 4 * s.candidates.size() + 64) {
+        if (at < s.candidates.size()) {
+          P.lists.emplace_back((int32_t)HSO_LIST_CANDIDATES, std::make_pair((int32_t)s.dev_cands.size(), std::vector<int32_t>(s.candidates.begin() + (std::ptrdiff_t)at, s.candidates.end())));
+          s.dev_cands.insert(s.dev_cands.end(), s.candidates.begin() + (std::ptrdiff_t)at, s.candidates.end());
+        }
+      } else {
+        P.lists.emplace_back((int32_t)HSO_LIST_CANDIDATES, std::make_pair(0, std::vector<int32_t>(s.candidates.begin(), s.candidates.end())));
+        s.dev_cands = s.candidates;
+      }
+    }
   });
   std::vector<hso_seqmap_rows> rows;
+  std::vector<hso_seqmap_list_patch> lists;
   for (size_t i = 0; i < who.size(); i++) {
     Seq& s = *seq_[who[i]];
     Patch& P = patch[i];
     if (P.kf) { check(hso_gpu_seqmap_set_keyframes(ctx_, s.map, P.kfs.data(), (int)P.kfs.size()), "Map"); s.kfs_dirty = false; }
-    if (P.pid.empty() && P.oid.empty()) continue;
-    hso_seqmap_rows r{};
-    r.map = s.map; r.n_points = (int)P.pid.size(); r.n_obs = (int)P.oid.size();
-    r.point_ids = P.pid.data(); r.points = P.pts.data(); r.obs_ids = P.oid.data(); r.obs = P.obs.data();
-    rows.push_back(r);
+    if (!P.pid.empty() || !P.oid.empty()) {
+      hso_seqmap_rows r{};
+      r.map = s.map; r.n_points = (int)P.pid.size(); r.n_obs = (int)P.oid.size();
+      r.point_ids = P.pid.data(); r.points = P.pts.data(); r.obs_ids = P.oid.data(); r.obs = P.obs.data(); r.obs_point = P.olink.data();
+      rows.push_back(r);
+    }
+    for (auto& L : P.lists) {
+      hso_seqmap_list_patch lp{};
+      lp.map = s.map; lp.list = L.first; lp.first = L.second.first; lp.n = (int32_t)L.second.second.size(); lp.ids = L.second.second.data();
+      lists.push_back(lp);
+    }
   }
   if (!rows.empty()) check(hso_gpu_seqmap_patch_multi(ctx_, rows.data(), (int)rows.size()), "Map");
+  if (!lists.empty()) check(hso_gpu_seqmap_patch_lists(ctx_, lists.data(), (int)lists.size()), "Map");
+  for (size_t i = 0; i < who.size(); i++)                          // after the point rows they name exist
+    if (patch[i].key) check(hso_gpu_seqmap_set_key_points(ctx_, seq_[who[i]]->map, patch[i].keys.data(), (int)(patch[i].keys.size() / 5)), "Map");
 }
 
 // ------------------------------------------------------------------------------------------------ end of the frame

@@ -72,19 +72,26 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
   for (int k : who) (seq_[k]->stage == kFirst || seq_[k]->stage == kSecond ? starting : running).push_back(k);
   if (!starting.empty()) initialise(starting);
   if (!running.empty()) {
-    track(running);
+    chain(running);
     ck.lap(1);
     std::vector<int> tracked;
     for (int k : running) if (step_[k]->tracked) tracked.push_back(k);
     if (!tracked.empty()) {
-      reproject(tracked);
-      ck.lap(2);
       std::vector<int> thin, ok, kf;
       for (int k : tracked) if (step_[k]->seed_path) thin.push_back(k);
-      if (!thin.empty()) seed_branch(thin);
+      if (!thin.empty()) { fetch_features(thin); seed_branch(thin); }
       par(tracked, [&](int k) { decide(k); });
-      ck.lap(3);
+      if (!thin.empty()) send_features(thin);                      // the seed branch changed these frames' features
+      ck.lap(2);
       for (int k : tracked) if (step_[k]->ok) { ok.push_back(k); if (step_[k]->make_kf) kf.push_back(k); }
+      if (!kf.empty()) {
+        // a keyframe's features move into the sequence's tables: the host needs them now
+        std::vector<int> need;
+        for (int k : kf) if (!step_[k]->seed_path) need.push_back(k);
+        fetch_features(need);
+        par(kf, [&](int k) { decide_keyframe(k); });
+      }
+      ck.lap(3);
       if (!kf.empty()) keyframe_ba(kf);
       ck.lap(4);
       if (!ok.empty()) {
@@ -147,21 +154,23 @@ void Bank::upload(const std::vector<int>& who, const uint8_t* const* imgs, int w
   }
 }
 
-// ------------------------------------------------------------------------------------------------ CoarseTracker
+// ------------------------------------------------------------------------------------------------ CoarseTracker (value-passing)
 namespace {
 
 // the reference frame's features as CoarseTracker::makeDepthRef sees them (src/CoarseTracker.cpp:210-240): the distance of the
 // point along the bearing, from its host-frame inverse depth; -1 keeps the slot of a feature without a usable point
 // Written straight into the tracker kernel's layout: six arrays px[0] | px[1] | f[0] | f[1] | f[2] | dist of `stride` doubles.
+// (The per-frame chain builds this table on the device; the host form serves relocalizeFrame's first alignment, whose reference
+// is a keyframe the sequence may not have looked at for a long time.)
 void reference_features(const Seq& s, const Frame& R, double* out, size_t stride)
 {
-  const size_t n = s.n_feats(R);
+  const size_t n = R.fts.size();
   double* px0 = out; double* px1 = out + stride; double* f0 = out + 2 * stride; double* f1 = out + 3 * stride; double* f2 = out + 4 * stride;
   double* dist = out + 5 * stride;
   Id cached = kNone;
   SE3 T_ref_host;
   for (size_t i = 0; i < n; i++) {
-    const Feat& ft = s.feat_of(R, i);
+    const Feat& ft = s.feats[R.fts[i]];
     px0[i] = ft.px[0]; px1[i] = ft.px[1];
     f0[i] = ft.f[0]; f1[i] = ft.f[1]; f2[i] = ft.f[2];
     dist[i] = -1;
@@ -174,35 +183,28 @@ void reference_features(const Seq& s, const Frame& R, double* out, size_t stride
   for (size_t i = n; i < stride; i++) px0[i] = px1[i] = f0[i] = f1[i] = f2[i] = dist[i] = 0.0;
 }
 
-void trace_track(Trace& t, const hso_camera& cam, const hso_track_params& p, const hso_track_job& job, const hso_track_result& res)
+void trace_track(Trace& t, const hso_camera& cam, const hso_track_params& p, int64_t ref_id, int64_t cur_id, const hso_ref_feat* rec, size_t n, const hso_se3& T_cur_ref,
+                 float exposure_rat, const hso_track_result& res)
 {
   t.begin("coarse_track", 8);
   t.field("cam", &cam, sizeof(cam)); t.field("params", &p, sizeof(p));
-  t.scalar("ref_frame_id", (double)job.ref_frame_id); t.scalar("cur_frame_id", (double)job.cur_frame_id);
-  {
-    // the trace keeps the record form of the table (what the value-passing call takes and the replay reads)
-    const size_t n = (size_t)job.n_feats, st = (n + 31) & ~size_t(31);
-    const double* a = reinterpret_cast<const double*>(job.feats);
-    std::vector<hso_ref_feat> rec(n);
-    for (size_t i = 0; i < n; i++) { rec[i].px[0] = a[i]; rec[i].px[1] = a[st + i]; rec[i].f[0] = a[2 * st + i]; rec[i].f[1] = a[3 * st + i]; rec[i].f[2] = a[4 * st + i]; rec[i].dist = a[5 * st + i]; }
-    t.field("feats", rec.data(), sizeof(hso_ref_feat) * n);
-  }
-  t.field("T_cur_ref", &job.T_cur_ref, sizeof(hso_se3)); t.scalar("exposure_rat", job.exposure_rat);
+  t.scalar("ref_frame_id", (double)ref_id); t.scalar("cur_frame_id", (double)cur_id);
+  t.field("feats", rec, sizeof(hso_ref_feat) * n);
+  t.field("T_cur_ref", &T_cur_ref, sizeof(hso_se3)); t.scalar("exposure_rat", exposure_rat);
   t.field("result", &res, sizeof(res));
 }
 
 }  // namespace
 
-// run one tracker configuration over (reference, current) pairs of several sequences; results in StepData::track
+// run one tracker configuration over (reference KEYFRAME, current) pairs of several sequences with host-built tables; results in
+// StepData::track
 void Bank::track_group(const std::vector<int>& who, const std::vector<Id>& ref, const std::vector<Id>& cur, const hso_track_params& p)
 {
   if (who.empty()) return;
   std::vector<hso_track_job> jobs(who.size());
   std::vector<hso_track_result> res(who.size());
-  // all jobs' feature tables in one page-locked block, back to back in the kernel's layout: the sequences fill their parts in
-  // parallel and the block leaves in one DMA
   std::vector<size_t> at(who.size() + 1, 0);
-  for (size_t i = 0; i < who.size(); i++) at[i + 1] = at[i] + 6 * ((seq_[who[i]]->n_feats(seq_[who[i]]->frames[ref[i]]) + 31) & ~size_t(31));
+  for (size_t i = 0; i < who.size(); i++) at[i + 1] = at[i] + 6 * ((seq_[who[i]]->frames[ref[i]].fts.size() + 31) & ~size_t(31));
   double* const block = track_tables_.need(ctx_, at.back() + 64);
   pool_->run((int)who.size(), [&](int i) {
     Seq& s = *seq_[who[i]];
@@ -212,7 +214,7 @@ void Bank::track_group(const std::vector<int>& who, const std::vector<Id>& ref, 
     hso_track_job& j = jobs[i];
     j = hso_track_job{};
     j.ref_frame_id = R.dev_id; j.cur_frame_id = C.dev_id;
-    j.feats = reinterpret_cast<const hso_ref_feat*>(block + at[i]); j.n_feats = (int)s.n_feats(R); j.feats_soa = 1;
+    j.feats = reinterpret_cast<const hso_ref_feat*>(block + at[i]); j.n_feats = (int)R.fts.size(); j.feats_soa = 1;
     j.T_cur_ref = (C.T * R.T.inverse()).v;                        // src/CoarseTracker.cpp:63
     j.exposure_rat = C.integral / R.integral;                     // :60
   });
@@ -222,7 +224,6 @@ void Bank::track_group(const std::vector<int>& who, const std::vector<Id>& ref, 
     Seq& s = *seq_[who[i]];
     StepData& d = *step_[who[i]];
     d.track = res[i];
-    d.job = jobs[i];
     // the write-back of CoarseTracker::run (:198-202)
     Frame& C = s.frames[cur[i]];
     const Frame& R = s.frames[ref[i]];
@@ -230,11 +231,115 @@ void Bank::track_group(const std::vector<int>& who, const std::vector<Id>& ref, 
     C.T = T_cur_ref * R.T;
     C.exposure = (double)res[i].exposure_rat * R.exposure;
     if (res[i].exposure_rat > 0.99 && res[i].exposure_rat < 1.01) C.exposure = R.exposure;
-    if (s.trace.on()) trace_track(s.trace, cam_.pod(), p, jobs[i], res[i]);
+    if (s.trace.on()) {
+      const size_t n = (size_t)jobs[i].n_feats, st = (n + 31) & ~size_t(31);
+      const double* a = block + at[i];
+      std::vector<hso_ref_feat> rec(n);
+      for (size_t q = 0; q < n; q++) { rec[q].px[0] = a[q]; rec[q].px[1] = a[st + q]; rec[q].f[0] = a[2 * st + q]; rec[q].f[1] = a[3 * st + q]; rec[q].f[2] = a[4 * st + q]; rec[q].dist = a[5 * st + q]; }
+      trace_track(s.trace, cam_.pod(), p, jobs[i].ref_frame_id, jobs[i].cur_frame_id, rec.data(), n, jobs[i].T_cur_ref, jobs[i].exposure_rat, res[i]);
+    }
   }
 }
 
-void Bank::track(const std::vector<int>& who)
+// ------------------------------------------------------------------------------------------------ the per-frame chain
+// FrameHandlerMono::processFrame from the motion prior to the inputs of its decisions (src/frame_handler_mono.cpp:173-291), on the
+// device for all sequences (hso_gpu_seq_chain): CoarseTracker::run against the last frame's features, Reprojector::reprojectMap's
+// walk over the overlap keyframes, matching, grid selection, the frame's features, the pose optimiser, the candidates' failure /
+// success counters, needNewKf's flow sums, the covisibility votes, the scene depth.  What the host contributes per sequence is one
+// job record — the motion prior, which keyframes the last frame was connected to, the temporary points — and what it reads is one
+// result record; its own tables follow the device's through the events (kind changes of points).
+void Bank::prepare_job(int k, hso_seq_job& job, std::vector<int32_t>& temps)
+{
+  Seq& s = *seq_[k];
+  StepData& d = *step_[k];
+  Frame& C = s.frames[s.cur];
+  Id last = d.relocalised ? d.ref : s.last;
+  C.T = s.motion * s.frames[last].T;                              // processFrame, :176
+  if (s.after_init) last = s.first;                               // :180
+  d.ref = last;
+  d.tracked = true;
+  s.log = hso_vo_status{};
+  Frame& L = s.frames[last];
+  d.inverse = !(C.grad_mean > L.grad_mean + 0.5f) ? 1 : 0;        // :184
+  // the temporary points whose seed has finished are retired before the map is projected (src/reprojector.cpp:98-106)
+  {
+    size_t keep = 0;
+    for (size_t i = 0; i < s.temps.size(); i++) {
+      const Id p = s.temps[i];
+      if (s.points[p].seed_state == 0) { s.temps[keep++] = p; continue; }
+      s.retire_temp(p);
+    }
+    s.temps.resize(keep);
+  }
+  job = hso_seq_job{};
+  job.map = s.map;
+  job.ref_frame_id = L.dev_id; job.cur_frame_id = C.dev_id;
+  job.T_ref_w = L.T.v; job.T_cur_w = C.T.v; job.ref_exposure = L.exposure;
+  job.ref_kf_row = L.kf_row;
+  job.n_ref_feats = (int32_t)s.n_feats(L);
+  if (job.n_ref_feats == 0) job.flags |= HSO_SEQ_NO_TRACK;        // CoarseTracker::run returns 0 at once (src/CoarseTracker.cpp:53-54)
+  if (!s.seeds.empty() && (int)s.seeds.size() > s.n_dead_seeds) job.flags |= HSO_SEQ_SEED_BRANCH;   // see consume_result: seed_path
+  job.cur_keyframe_id = C.kf_id;
+  job.exposure_rat = C.integral / L.integral;                     // src/CoarseTracker.cpp:60
+  // needNewKf looks at the flow only once three regular frames have passed (:430-437)
+  job.last_kf_row = (s.regular >= 3 && s.regular >= std::min(3, int(s.n_mean_converge * 0.8)) && !s.after_init && !s.kfs.empty()) ? s.frames[s.kfs.back()].kf_row : -1;
+  // the reference frame's connected keyframes that are still keyframes of the map (src/reprojector.cpp:124-170)
+  int nc = 0;
+  for (int q = 0; q < 5; q++) job.covis[q] = -1;
+  for (Id kf : L.covis) {
+    const Frame& K = s.frames[kf];
+    if (!K.in_use || K.kf_row < 0 || nc >= 5) continue;
+    if (std::find(s.kfs.begin(), s.kfs.end(), kf) == s.kfs.end()) continue;   // Map::getKeyframeById
+    job.covis[nc++] = K.kf_row;
+  }
+  L.covis.clear();
+  // the temporary points the frame lists (:228-251): not given up, at the position their seed's current depth puts them
+  d.temps_listed.clear();
+  job.temps_begin = (int32_t)temps.size();
+  for (Id p : s.temps) {
+    Point& P = s.points[p];
+    if (P.bad) continue;
+    s.place_in_host(p);
+    d.temps_listed.push_back(p);
+    temps.push_back(p);
+  }
+  job.n_temps = (int32_t)d.temps_listed.size();
+}
+
+// what the chain reports about a frame, applied to the sequence's own tables
+void Bank::consume_result(int k, const hso_seq_result& r, const std::vector<int32_t>& more_events)
+{
+  Seq& s = *seq_[k];
+  StepData& d = *step_[k];
+  Frame& C = s.frames[s.cur];
+  d.res = r;
+  d.track = r.track;
+  C.T.v = r.T_tracked;                                            // the write-back of CoarseTracker::run (:198-202)
+  C.exposure = r.exposure;
+  s.log.n_tracked = d.track.n_tracked; s.log.used_inverse = d.inverse;
+  // the kind changes reprojectCell / reprojectCellAll made (src/reprojector.cpp:366-425, 214-222, 247-251), in their order
+  const int n_ev = r.n_events;
+  for (int i = 0; i < n_ev; i++) {
+    const int32_t e = i < HSO_SEQ_EVENTS && more_events.empty() ? r.events[i] : more_events[(size_t)i];
+    const int code = (int)((uint32_t)e >> 28);
+    const Id p = (Id)(e & 0x0fffffff);
+    if (code == HSO_EV_ERASE_POINT) s.erase_point(p);
+    else if (code == HSO_EV_ERASE_CANDIDATE) s.erase_candidate(p);
+    else if (code == HSO_EV_TEMP_BAD) s.points[p].bad = true;
+    else if (code == HSO_EV_GOOD) { s.points[p].kind = kPtGood; s.touch_point(p); }
+  }
+  C.loose.clear();
+  C.n_fts = r.n_feats;
+  s.log.n_trials = r.counts[0]; s.log.n_matches = r.counts[1]; s.log.n_seed_matches = 0;
+  d.pose = r.pose;
+  d.visit.clear();
+  for (int q = 0; q < r.n_visit && q < HSO_SEQ_MAX_VISIT; q++) d.visit.push_back(s.dev_kfs[(size_t)r.visit[q]]);
+  // too few matches: the nearly converged seeds are tried as well (:309-329) — the frame's features change, so the pose
+  // optimisation that ran behind the selection does not count for it
+  d.seed_path = s.log.n_matches < 100 && !s.seeds.empty() && (int)s.seeds.size() > s.n_dead_seeds;
+}
+
+void Bank::chain(const std::vector<int>& who)
 {
   // a sequence that lost track first aligns its LAST frame against the closest keyframe (relocalizeFrame,
   // src/frame_handler_mono.cpp:357-386: inverse compositional, levels 4..0, 15 iterations); more than 30 tracked features
@@ -260,185 +365,92 @@ void Bank::track(const std::vector<int>& who)
       if (d.track.n_tracked > 30) { d.relocalised = true; d.ref = ref[i]; d.reloc_pose = s.frames[s.last].T; }
     }
   }
-  std::vector<int> group[2]; std::vector<Id> ref[2], cur[2];
+  std::vector<int> in;
+  for (int k : who) if (!(seq_[k]->stage == kRelocalising && !step_[k]->relocalised)) in.push_back(k);
+  if (in.empty()) return;
+  // the job records: serial (they append to one list of temporary points; a few dozen assignments per sequence)
+  std::vector<hso_seq_job> all(in.size());
+  std::vector<int32_t> temps;
+  for (size_t i = 0; i < in.size(); i++) prepare_job(in[i], all[i], temps);
+  flush_maps(in);                                                 // the rows, lists and links that changed since the last frame
+  hso_seq_chain_cfg cfg{};
+  cfg.cell_size = cell_size_; cfg.grid_n_cols = grid_cols_; cfg.n_cells = (int)cell_order_.size(); cfg.max_fts = cfg_.max_fts;
+  cfg.cell_order = cell_order_.data(); cfg.max_kfs = cfg_.reproject_max_kfs; cfg.pose_n_iter = 12; cfg.pose_reproj_thresh = cfg_.poseoptim_thresh;
+  cfg.quality_min_fts = cfg_.quality_min_fts;
+  bool any_trace = false;
+  for (int k : in) any_trace |= seq_[k]->trace.on();
+  cfg.want_debug = any_trace ? 1 : 0;
+  for (int mode = 0; mode < 2; mode++) {
+    // one call per tracker mode (almost always one: the mode follows the gradient statistics of consecutive frames); inside a
+    // call the sequences whose reference frame has no features come last (the tracker skips them)
+    std::vector<int> grp; std::vector<hso_seq_job> jobs;
+    for (int pass = 0; pass < 2; pass++)
+      for (size_t i = 0; i < in.size(); i++)
+        if (step_[in[i]]->inverse == mode && ((all[i].flags & HSO_SEQ_NO_TRACK) != 0) == (pass == 1)) { grp.push_back(in[i]); jobs.push_back(all[i]); }
+    if (grp.empty()) continue;
+    cfg.track = hso_track_params{mode, cfg_.klt_max_level, cfg_.klt_min_level + 1, 50};
+    hso_seq_result* res = chain_res_.need(ctx_, grp.size());
+    check(hso_gpu_seq_chain(ctx_, &cam_.pod(), &cfg, jobs.data(), (int)jobs.size(), temps.empty() ? nullptr : temps.data(), (int)temps.size(), res), "processFrame");
+    n_calls_[2]++; n_items_[2] += (int64_t)grp.size();
+    n_calls_[3]++; n_items_[3] += (int64_t)grp.size();
+    std::vector<std::vector<int32_t>> more(grp.size());
+    for (size_t i = 0; i < grp.size(); i++)
+      if (res[i].n_events > HSO_SEQ_EVENTS) {                      // more kind changes than the record holds: fetch them all
+        more[i].resize((size_t)res[i].n_events);
+        check(hso_gpu_seq_events(ctx_, (int)i, more[i].data(), (int)more[i].size()), "processFrame");
+      }
+    if (any_trace) trace_chain(grp, jobs, cfg, res);
+    pool_->run((int)grp.size(), [&](int i) { consume_result(grp[(size_t)i], res[i], more[(size_t)i]); });
+  }
+}
+
+// the features of these sequences' new frames, from the device's tables into Frame::loose
+void Bank::fetch_features(const std::vector<int>& who)
+{
+  if (who.empty()) return;
+  const int cap = std::max(cfg_.max_fts, 1);
+  std::vector<int32_t> maps, n_out(who.size(), 0); std::vector<int64_t> ids;
+  for (int k : who) { maps.push_back(seq_[k]->map); ids.push_back(seq_[k]->frames[seq_[k]->cur].dev_id); }
+  hso_seq_feature* rows = feat_rows_.need(ctx_, who.size() * (size_t)cap);
+  check(hso_gpu_seq_frame_features(ctx_, maps.data(), ids.data(), (int)who.size(), rows, cap, n_out.data()), "Frame::fts_");
+  pool_->run((int)who.size(), [&](int i) {
+    Seq& s = *seq_[who[(size_t)i]];
+    Frame& C = s.frames[s.cur];
+    C.loose.clear();
+    C.loose.reserve((size_t)n_out[(size_t)i] + 8);
+    for (int q = 0; q < n_out[(size_t)i]; q++) {
+      const hso_seq_feature& r = rows[(size_t)i * cap + q];
+      Feat nf;
+      nf.frame = s.cur; nf.point = r.point;
+      nf.px[0] = r.px[0]; nf.px[1] = r.px[1];
+      nf.f[0] = r.f[0]; nf.f[1] = r.f[1]; nf.f[2] = r.f[2];
+      nf.level = r.level;
+      if (r.type == HSO_FTR_EDGELET) { nf.type = HSO_FTR_EDGELET; nf.grad[0] = r.grad[0]; nf.grad[1] = r.grad[1]; }
+      else nf.type = r.type == HSO_FTR_GRADIENT ? HSO_FTR_GRADIENT : HSO_FTR_CORNER;
+      C.loose.push_back(nf);
+    }
+    C.n_fts = (int32_t)C.loose.size();
+  });
+}
+
+// ... and back, after the host changed them (the seed branch added features; the pose optimiser ran over host tables)
+void Bank::send_features(const std::vector<int>& who)
+{
   for (int k : who) {
     Seq& s = *seq_[k];
-    StepData& d = *step_[k];
-    if (s.stage == kRelocalising && !d.relocalised) continue;
-    Id last = d.relocalised ? d.ref : s.last;
     Frame& C = s.frames[s.cur];
-    C.T = s.motion * s.frames[last].T;                            // processFrame, :176
-    if (s.after_init) last = s.first;                             // :180
-    d.ref = last;
-    d.tracked = true;
-    s.log = hso_vo_status{};
-    if (s.n_feats(s.frames[last]) == 0) { d.track = hso_track_result{}; continue; }   // CoarseTracker::run returns 0 at once (:53-54)
-    d.inverse = !(C.grad_mean > s.frames[last].grad_mean + 0.5f) ? 1 : 0;             // :184
-    group[d.inverse].push_back(k); ref[d.inverse].push_back(last); cur[d.inverse].push_back(s.cur);
-  }
-  for (int mode = 0; mode < 2; mode++) {
-    const hso_track_params p{mode, cfg_.klt_max_level, cfg_.klt_min_level + 1, 50};
-    track_group(group[mode], ref[mode], cur[mode], p);
-  }
-  for (int k : who) if (step_[k]->tracked) { seq_[k]->log.n_tracked = step_[k]->track.n_tracked; seq_[k]->log.used_inverse = step_[k]->inverse; }
-}
-
-// ------------------------------------------------------------------------------------------------ Reprojector::reprojectMap
-// Which points the frame projects, in the reference's visiting order (src/reprojector.cpp:98-254): the temporary points whose seed
-// has finished are retired first; then the covisible keyframes of the last frame, then the keyframes that see the frame, nearest
-// first, up to the keyframe budget — each contributing the points of its features once; then the candidates; then the temporary
-// points.
-void Bank::list_points(int k)
-{
-  Seq& s = *seq_[k];
-  StepData& d = *step_[k];
-  Frame& C = s.frames[s.cur];
-  {
-    size_t keep = 0;
-    for (size_t i = 0; i < s.temps.size(); i++) {
-      const Id p = s.temps[i];
-      if (s.points[p].seed_state == 0) { s.temps[keep++] = p; continue; }
-      s.retire_temp(p);
+    if (C.kf_row >= 0) continue;
+    std::vector<hso_seq_feature> rows(C.loose.size());
+    for (size_t i = 0; i < C.loose.size(); i++) {
+      const Feat& ft = C.loose[i];
+      hso_seq_feature& r = rows[i];
+      r = hso_seq_feature{};
+      r.px[0] = ft.px[0]; r.px[1] = ft.px[1]; r.f[0] = ft.f[0]; r.f[1] = ft.f[1]; r.f[2] = ft.f[2];
+      r.grad[0] = (float)ft.grad[0]; r.grad[1] = (float)ft.grad[1]; r.point = ft.point; r.level = ft.level; r.type = ft.type;
     }
-    s.temps.resize(keep);
+    check(hso_gpu_seq_set_frame_features(ctx_, s.map, C.dev_id, rows.data(), (int)rows.size()), "Frame::fts_");
+    C.n_fts = (int32_t)rows.size();
   }
-  d.visit.clear(); d.list.clear(); d.list_q.clear();
-  auto take = [&](Id kf) {
-    Frame& K = s.frames[kf];
-    K.visited = C.serial;
-    d.visit.push_back(kf);
-    for (Id f : K.fts) {
-      const Id p = s.feats[f].point;
-      if (p == kNone) continue;
-      Point& P = s.points[p];
-      if (P.kind == kPtTemporary || P.stamp == C.serial) continue;
-      P.stamp = C.serial;
-      d.list.push_back(p); d.list_q.push_back(quality_key(P));
-    }
-  };
-  Frame& L = s.frames[d.ref];                                     // new_frame_->m_last_frame
-  for (Id kf : L.covis) {
-    const Frame& K = s.frames[kf];
-    if (!K.in_use || K.kf_row < 0 || K.visited == C.serial) continue;
-    if (std::find(s.kfs.begin(), s.kfs.end(), kf) == s.kfs.end()) continue;   // Map::getKeyframeById
-    take(kf);
-  }
-  L.covis.clear();
-  std::vector<std::pair<double, Id>> near;
-  s.closest_keyframes(C, near);
-  std::stable_sort(near.begin(), near.end(), [](const std::pair<double, Id>& a, const std::pair<double, Id>& b) { return a.first < b.first; });
-  size_t n = d.visit.size();
-  for (size_t i = 0; i < near.size() && n < (size_t)cfg_.reproject_max_kfs; i++) {
-    if (s.frames[near[i].second].visited == C.serial) continue;
-    take(near[i].second);
-    ++n;
-  }
-  d.n_kf_points = (int)d.list.size();
-  for (Id p : s.candidates) { d.list.push_back(p); d.list_q.push_back(quality_key(s.points[p])); }
-  d.n_cand_listed = (int)s.candidates.size();
-  for (Id p : s.temps) {
-    Point& P = s.points[p];
-    if (P.bad) continue;
-    P.stamp = C.serial;
-    s.place_in_host(p);
-    d.list.push_back(p); d.list_q.push_back(quality_key(P));
-  }
-  hso_map_frame& c = d.call;
-  c = hso_map_frame{};
-  c.map = s.map; c.cur_keyframe_id = C.kf_id; c.cur_frame_id = C.dev_id; c.T_cur_w = C.T.v; c.cur_exposure_time = C.exposure;
-  c.point_ids = d.list.data(); c.quality = d.list_q.data(); c.n_points = (int)d.list.size();
-}
-
-// what Reprojector::reprojectCell / reprojectCellAll do with the candidates they examine (:352-429, :556-612), applied to the
-// examined records the device returned, in examination order; a record that became a feature adds it to the frame
-void Bank::apply_selection(int k, const hso_frame_match* rec, int n_rec, const uint8_t* projected, const double* feat_f)
-{
-  Seq& s = *seq_[k];
-  StepData& d = *step_[k];
-  Frame& C = s.frames[s.cur];
-  // points the projection rejected: candidates and temporary points pay for it (:214-222, :247-251)
-  for (int i = d.n_kf_points; i < (int)d.list.size(); i++) {
-    if (projected[i]) continue;
-    Point& P = s.points[d.list[i]];
-    P.n_fail += 3;
-    if (P.n_fail <= 30) continue;
-    if (i < d.n_kf_points + d.n_cand_listed) s.erase_candidate(d.list[i]); else P.bad = true;
-  }
-  C.loose.clear();
-  C.loose.reserve((size_t)std::min(n_rec, cfg_.max_fts + 8));
-  int taken = 0;
-  for (int i = 0; i < n_rec; i++) {
-    const hso_frame_match& r = rec[i];
-    const Id p = d.list[r.point];
-    Point& P = s.points[p];
-    if (P.kind == kPtDeleted) continue;
-    if (!r.success) {
-      P.n_fail++;
-      if (P.kind == kPtUnknown && P.n_fail > 15) s.erase_point(p);
-      else if (P.kind == kPtCandidate && P.n_fail > 30) s.erase_candidate(p);
-      else if (P.kind == kPtTemporary && P.n_fail > 30) P.bad = true;
-      continue;
-    }
-    P.n_ok++;
-    if (P.kind == kPtUnknown && P.n_ok > 10) P.kind = kPtGood;
-    Feat nf;
-    nf.frame = s.cur; nf.point = p;
-    nf.px[0] = r.px_cur[0]; nf.px[1] = r.px_cur[1];
-    nf.f[0] = feat_f[3 * taken]; nf.f[1] = feat_f[3 * taken + 1]; nf.f[2] = feat_f[3 * taken + 2];
-    nf.level = r.search_level;
-    if (r.ref_type == HSO_FTR_EDGELET) { nf.type = HSO_FTR_EDGELET; nf.grad[0] = r.grad[0]; nf.grad[1] = r.grad[1]; }
-    else nf.type = r.ref_type == HSO_FTR_GRADIENT ? HSO_FTR_GRADIENT : HSO_FTR_CORNER;
-    C.loose.push_back(nf);
-    ++taken;
-  }
-}
-
-void Bank::reproject(const std::vector<int>& who)
-{
-  const bool timing = getenv("HSO_ENGINE_TIMING") != nullptr;
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto t0 = now();
-  par(who, [&](int k) { list_points(k); });
-  flush_maps(who);                                                // rows the listing touched (temporary points' positions) and earlier changes
-  if (timing) { sub_ms_[0] += std::chrono::duration<double, std::milli>(now() - t0).count(); t0 = now(); }
-  const int n = (int)who.size(), cap = std::max(cfg_.max_fts, 1);
-  std::vector<hso_map_frame> calls(n);
-  size_t total = 0;
-  std::vector<size_t> list_at(n);
-  for (int i = 0; i < n; i++) { calls[i] = step_[who[i]]->call; list_at[i] = total; total += (size_t)calls[i].n_points; }
-  bool any_trace = false;
-  for (int k : who) any_trace |= seq_[k]->trace.on();
-  records_.need(ctx_, std::max(total, (size_t)1));
-  if (any_trace) briefs_.need(ctx_, std::max(total, (size_t)1));   // the full 56-byte records only for the trace
-  projected_.need(ctx_, std::max(total, (size_t)1));
-  std::vector<int32_t> begin(n + 1, 0), counts(4 * (size_t)n, 0), n_feats(n, 0);
-  std::vector<hso_pose_result> pose(n);
-  mask_.need(ctx_, (size_t)n * cap);
-  feat_f_.need(ctx_, (size_t)n * cap * 3);
-  hso_pose_chain chain{};
-  chain.reproj_thresh = cfg_.poseoptim_thresh; chain.n_iter = 12;
-  chain.results = pose.data(); chain.n_feats = n_feats.data(); chain.outlier_mask = mask_.data(); chain.feat_f = feat_f_.data();
-  chain.records = records_.data();
-  const int rc = hso_gpu_reproject_select_pose_frames(ctx_, &cam_.pod(), calls.data(), n, cell_size_, grid_cols_, cell_order_.data(), (int)cell_order_.size(),
-                                                      cfg_.max_fts, any_trace ? briefs_.data() : nullptr, (int)std::max(total, (size_t)1), begin.data(), counts.data(), projected_.data(), &chain);
-  check(rc, "Reprojector");
-  if (timing) { sub_ms_[1] += std::chrono::duration<double, std::milli>(now() - t0).count(); t0 = now(); }
-  n_calls_[3]++; n_items_[3] += n;
-  if (any_trace) trace_reproject(who, calls, list_at, begin, counts, pose, n_feats);
-  pool_->run(n, [&](int i) {
-    const int k = who[i];
-    Seq& s = *seq_[k];
-    StepData& d = *step_[k];
-    Frame& C = s.frames[s.cur];
-    apply_selection(k, records_.data() + begin[i], begin[i + 1] - begin[i], projected_.data() + list_at[i], feat_f_.data() + (size_t)i * cap * 3);
-    s.log.n_trials = counts[4 * i]; s.log.n_matches = counts[4 * i + 1]; s.log.n_seed_matches = 0;
-    d.pose = pose[i];
-    d.pose_mask.assign(mask_.data() + (size_t)i * cap, mask_.data() + (size_t)i * cap + C.loose.size());
-    // too few matches: the nearly converged seeds are tried as well (:309-329) — the frame's features change, so the pose
-    // optimisation that ran behind the selection does not count for it
-    d.seed_path = s.log.n_matches < 100 && !s.seeds.empty() && (int)s.seeds.size() > s.n_dead_seeds;
-  });
-  if (timing) sub_ms_[2] += std::chrono::duration<double, std::milli>(now() - t0).count();
 }
 
 // the frame's pose result (pose_optimizer::optimizeLevenbergMarquardt3rd's effects, src/pose_optimizer.cpp:692-767) and the
@@ -460,7 +472,8 @@ void Bank::decide(int k)
     C.T.v = d.pose.T_f_w;
     std::memcpy(C.cov, d.pose.cov, sizeof(C.cov));
     C.err_px = d.pose.error_in_px;
-    for (size_t i = 0; i < C.loose.size() && i < d.pose_mask.size(); i++) if (d.pose_mask[i]) C.loose[i].point = kNone;
+    // the culled features (feature->point = NULL): on the device's table already, unless the pose ran over host tables
+    if (d.host_pose) for (size_t i = 0; i < C.loose.size() && i < d.pose_mask.size(); i++) if (d.pose_mask[i]) C.loose[i].point = kNone;
   }
   d.n_inliers = (size_t)d.pose.num_obs;
   C.n_inliers = d.pose.num_obs;
@@ -474,16 +487,26 @@ void Bank::decide(int k)
   d.ok = true;
   d.make_kf = s.after_init || wants_keyframe(k);
   if (!d.make_kf) {
-    link_covisible(k, false);
+    // createCovisibilityGraph of a regular frame (:559-647): the ranking came with the result
+    if (!d.host_pose) {
+      for (int q = 0; q < HSO_SEQ_MAX_COVIS && q < 5; q++) if (d.res.covis[q] >= 0) C.covis.push_back(s.dev_kfs[(size_t)d.res.covis[q]]);
+    } else link_covisible(k, false);
     s.outcome = kNoKeyframe;
-    return;
   }
+}
+
+// the frame becomes a keyframe: its features are on the host now
+void Bank::decide_keyframe(int k)
+{
+  Seq& s = *seq_[k];
+  StepData& d = *step_[k];
+  Frame& C = s.frames[s.cur];
   // frame_utils::getSceneDepth / getSceneDistance (src/frame.cpp:323-366).  The reference computes them for every frame
   // (src/frame_handler_mono.cpp:268-271) but only a keyframe uses them (depth_filter_->addKeyframe, :335-338; needNewKf ignores its
-  // depth argument): two medians over the frame's 2000 points were the largest single item of a regular frame's bookkeeping.
-  {
+  // depth argument)
+  if (!d.host_pose) { d.depth_mean = d.res.depth_median; d.dist_mean = d.res.dist_median; d.depth_min = d.res.depth_min; }
+  else {
     std::vector<double> z, r;
-    z.reserve(C.loose.size()); r.reserve(C.loose.size());
     d.depth_min = std::numeric_limits<double>::max();
     for (const Feat& ft : C.loose) {
       if (ft.point == kNone) continue;
@@ -499,29 +522,35 @@ void Bank::decide(int k)
 }
 
 // FrameHandlerMono::needNewKf (:428-507): the mean optical flow the motion since the last keyframe induces on that keyframe's
-// features — once with the full motion, once with its translation alone — weighted the way DSO weights them
+// features — once with the full motion, once with its translation alone — weighted the way DSO weights them.  The two sums over
+// the keyframe's features came with the chain's result.
 bool Bank::wants_keyframe(int k)
 {
   Seq& s = *seq_[k];
+  StepData& d = *step_[k];
   if (s.regular < 3) return false;
   if (s.regular < std::min(3, int(s.n_mean_converge * 0.8))) return false;
-  const Frame& C = s.frames[s.cur];
-  const Frame& K = s.frames[s.kfs.back()];
-  const SE3 T_cur_kf = C.T * K.T.inverse();
-  const Vector3d kf_centre = s.centre(K);
-  float flow_full = 0, flow_shift = 0;
-  size_t count = 0;
-  for (Id f : K.fts) {
-    const Feat& ft = s.feats[f];
-    if (ft.point == kNone) continue;
-    const double* w = s.points[ft.point].pos;
-    const double off[3] = {w[0] - kf_centre[0], w[1] - kf_centre[1], w[2] - kf_centre[2]};
-    const Vector3d in_kf = along(ft.f, len3(off));
-    const Vector2d a = cam_.world2cam(T_cur_kf * in_kf);
-    const Vector2d b = cam_.world2cam(Vector3d{in_kf[0] + T_cur_kf.v.t[0], in_kf[1] + T_cur_kf.v.t[1], in_kf[2] + T_cur_kf.v.t[2]});
-    flow_full += (a[0] - ft.px[0]) * (a[0] - ft.px[0]) + (a[1] - ft.px[1]) * (a[1] - ft.px[1]);
-    flow_shift += (b[0] - ft.px[0]) * (b[0] - ft.px[0]) + (b[1] - ft.px[1]) * (b[1] - ft.px[1]);
-    ++count;
+  float flow_full = d.res.flow_full, flow_shift = d.res.flow_shift;
+  size_t count = (size_t)d.res.flow_count;
+  if (d.host_pose) {
+    // the pose changed after the chain (the seed branch): the sums are formed here
+    const Frame& C = s.frames[s.cur];
+    const Frame& K = s.frames[s.kfs.back()];
+    const SE3 T_cur_kf = C.T * K.T.inverse();
+    const Vector3d kf_centre = s.centre(K);
+    flow_full = 0; flow_shift = 0; count = 0;
+    for (Id f : K.fts) {
+      const Feat& ft = s.feats[f];
+      if (ft.point == kNone) continue;
+      const double* w = s.points[ft.point].pos;
+      const double off[3] = {w[0] - kf_centre[0], w[1] - kf_centre[1], w[2] - kf_centre[2]};
+      const Vector3d in_kf = along(ft.f, len3(off));
+      const Vector2d a = cam_.world2cam(T_cur_kf * in_kf);
+      const Vector2d b = cam_.world2cam(Vector3d{in_kf[0] + T_cur_kf.v.t[0], in_kf[1] + T_cur_kf.v.t[1], in_kf[2] + T_cur_kf.v.t[2]});
+      flow_full += (a[0] - ft.px[0]) * (a[0] - ft.px[0]) + (a[1] - ft.px[1]) * (a[1] - ft.px[1]);
+      flow_shift += (b[0] - ft.px[0]) * (b[0] - ft.px[0]) + (b[1] - ft.px[1]) * (b[1] - ft.px[1]);
+      ++count;
+    }
   }
   flow_full /= count;
   if (flow_full < 133) return false;
@@ -534,7 +563,8 @@ bool Bank::wants_keyframe(int k)
   return score > 1;
 }
 
-// createCovisibilityGraph (:559-647): keyframes ranked by how many of the frame's points they observe
+// createCovisibilityGraph (:559-647) on the host's tables: keyframes ranked by how many of the frame's points they observe (a new
+// keyframe, whose features have just joined their points' observation lists; a frame whose features the host changed)
 void Bank::link_covisible(int k, bool is_keyframe)
 {
   Seq& s = *seq_[k];
@@ -543,7 +573,7 @@ void Bank::link_covisible(int k, bool is_keyframe)
   votes.assign(s.frames.size(), 0);
   std::vector<Id> seen;
   int with_point = 0;
-  const size_t n = s.n_feats(C);
+  const size_t n = C.kf_row >= 0 ? C.fts.size() : C.loose.size();
   for (size_t i = 0; i < n; i++) {
     const Id p = s.feat_of(C, i).point;
     if (p == kNone) continue;
@@ -592,8 +622,10 @@ void Bank::promote(int k)
       const Id p = s.candidates[i];
       Point& P = s.points[p];
       if (P.head == kNone || s.feats[P.head].frame != s.cur) { s.candidates[keep++] = p; continue; }
-      P.kind = kPtUnknown; P.n_fail = 0;
+      P.kind = kPtUnknown; P.dev_reset |= 1;                     // n_failed_reproj_ = 0
+      s.touch_point(p);
       s.frames[s.feats[P.host].frame].fts.push_back(P.host);
+      s.list_grew(s.feats[P.host].frame);
     }
     s.candidates.resize(keep);
   }
@@ -617,6 +649,8 @@ void Bank::make_keyframe(Seq& s, Id fr)
     F.fts.push_back(f);
     s.touch_obs(f);
   }
+  F.fts_sent = 0;
+  s.list_grew(fr);
   F.loose.clear(); F.loose.shrink_to_fit();
   s.refresh_keys(F);
   F.kf_id = ++s.n_kfs_made;

@@ -328,8 +328,8 @@ typedef struct hso_map_point {
   double host_f[3];            /* hostFeature_->f */
   int32_t host_kf;             /* index of hostFeature_->frame in the hso_kf table */
   int32_t obs_begin, obs_count;/* obs_[0..count) = obs[obs_begin ...], in list order */
-  int32_t pad_;                /* stored maps: the point's quality key (Point::type_ << 4) | Point::ftr_type_ for the on-device grid
-                                  selection (hso_gpu_reproject_select_maps); 0 = TYPE_DELETED; unused elsewhere */
+  int32_t pad_;                /* sequence maps: the point's state word (HSO_PT_*: quality key (Point::type_ << 4) | Point::ftr_type_,
+                                  n_failed_reproj_, n_succeeded_reproj_, isBad_); unused by the value-passing calls */
 } hso_map_point;
 
 typedef struct hso_reproj_point {
@@ -367,18 +367,7 @@ int hso_gpu_reproject_match_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const
                                   const hso_obs* obs, int n_obs, int cell_size, int grid_n_cols,
                                   hso_reproj_point* proj_out, hso_align_out* match_out);
 
-/* ---- resident maps: the tables of hso_gpu_reproject_match kept in HBM.  A sequence's local map (keyframe poses, points,
- *      observations) changes at keyframe rate (a new keyframe, local BA), so it is stored once then (hso_gpu_map_store) and the
- *      frames in between pass their pose alone; results come back as 56-byte records instead of 128 bytes per point.
- *      hso_gpu_map_reserve sizes n_maps equal regions (one per sequence served by this context). ---- */
-typedef struct hso_map_call {
-  int32_t map;                 /* which stored map */
-  int32_t cur_keyframe_id;     /* Frame::keyFrameId_ of the current frame */
-  int64_t cur_frame_id;        /* resident current frame */
-  hso_se3 T_cur_w;
-  double cur_exposure_time;
-} hso_map_call;
-
+/* one listed point after projection and matching (the record the grid selection reads; recorded runs fetch the examined ones) */
 typedef struct hso_match_brief {
   double px[2];                /* Candidate::px, the projected position */
   double px_cur[2];            /* the refined position (valid when success) */
@@ -388,21 +377,6 @@ typedef struct hso_match_brief {
   int8_t success, stage, search_level, ref_type;   /* findMatchDirect's result, HSO_ALIGN_* stage, Matcher::search_level_, ref_ftr_->type */
   int32_t pad_;                /* hso_gpu_reproject_select_maps: the point's index in its map */
 } hso_match_brief;
-
-int hso_gpu_map_reserve(hso_gpu_ctx* ctx, int n_maps, int max_kfs, int max_points, int max_obs);
-/* replace map `map` (index kept; points' host_kf / obs kf index the map's own kfs, obs_begin its own obs table) */
-int hso_gpu_map_store(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, int n_kfs, const hso_map_point* points, int n_points,
-                      const hso_obs* obs, int n_obs);
-/* The per-frame part of a stored map: refresh the points' quality keys ((Point::type_ << 4) | ftr_type_, 0 = TYPE_DELETED; what
- * hso_map_point.pad_ holds) of any number of stored maps from one byte per point, without re-sending the tables.  The reference changes these every frame
- * (n_succeeded_reproj_ > 10: UNKNOWN -> GOOD; n_failed_reproj_ > 15 / 30: deleted, src/reprojector.cpp:376-392, 412-423), and the
- * device selection orders and skips by them.  New points / observations / keyframes need hso_gpu_map_store. */
-int hso_gpu_map_update_quality(hso_gpu_ctx* ctx, const int32_t* maps, int n_maps, const uint8_t* quality /* the maps' keys back to back,
-                               one byte per stored point */);
-/* project + choose the reference observation + findMatchDirect for every point of every call's map, one launch chain.
- * out: the calls' points back to back in call order (out_capacity entries available); returns their number or a status < 0 */
-int hso_gpu_reproject_match_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
-                                 int grid_n_cols, hso_match_brief* out, int out_capacity);
 
 /* ---- pose_optimizer::optimizeLevenbergMarquardt3rd, src/pose_optimizer.cpp:399-771 ---- */
 
@@ -722,23 +696,7 @@ int hso_gpu_reproject_select(hso_gpu_ctx* ctx, const int32_t* frame_begin, int n
                              const uint8_t* quality, const uint8_t* flags, const int32_t* cell_order, int n_cells, int max_fts,
                              int32_t* examined_out, int32_t* counts_out);
 
-/* hso_gpu_reproject_match_maps followed by the grid selection, nothing returned in between: per call (sequence) only the
- * candidates the reference would have EXAMINED come back, in examination order — out[begin_out[c] .. begin_out[c + 1]) with
- * success = the candidate became a feature, pad_ = the point's index in its map — plus counts_out[4 * c ..] as in
- * hso_gpu_reproject_select.  The points' quality keys are their hso_map_point.pad_.  Returns the total number of records
- * (<= the calls' points; out_capacity must cover it, HSO_E_INVALID otherwise) or a status < 0. */
-int hso_gpu_reproject_select_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
-                                  int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
-                                  int out_capacity, int32_t* begin_out, int32_t* counts_out);
-
-/* The same with pose_optimizer::optimizeLevenbergMarquardt3rd (src/pose_optimizer.cpp:399-771; frame_handler_mono.cpp:241-243)
- * chained behind the selection on the device: the frame's feature table is built there from the candidates that became
- * features, in examination order — f = cam2world(px_cur), level = search level, type = ref_type, grad = the record's grad,
- * host bearing / inverse depth / host keyframe from the stored map, temporary = Point::TYPE_TEMPORARY (quality key >> 4 == 1);
- * the host keyframes' poses are the stored maps', the start pose the call's T_cur_w — so the 96-byte feature records never
- * cross PCIe (value-passing form: hso_gpu_pose_optimize_batch).  results[c] and n_feats[c] per call; outlier_mask (may be
- * NULL): n_calls rows of max(max_fts, 1) bytes, row c holds n_feats[c] flags in feature order. */
-/* An examined candidate of hso_gpu_reproject_select_pose_frames in the form a driver applies it (src/reprojector.cpp:366-425): the
+/* An examined candidate of the chain in the form a driver applies it (src/reprojector.cpp:366-425): the
  * point (index in the frame's list), whether it became a feature, and the new feature's pixel, level, type and gradient. */
 typedef struct hso_frame_match {
   double px_cur[2];
@@ -747,26 +705,8 @@ typedef struct hso_frame_match {
   int8_t success, search_level, ref_type, pad_;
 } hso_frame_match;
 
-typedef struct hso_pose_chain {
-  double reproj_thresh;        /* Config::poseOptimThresh() = 2.0 */
-  int32_t n_iter;              /* 12 */
-  int32_t pad_;
-  hso_pose_result* results;    /* [n_calls] */
-  int32_t* n_feats;            /* [n_calls], may be NULL */
-  uint8_t* outlier_mask;       /* may be NULL */
-  double* feat_f;              /* may be NULL: n_calls rows of max(max_fts, 1) * 3 doubles, row c holds the unit bearings the device
-                                  formed for the n_feats[c] features (cam2world of the refined pixel) — what Feature::f of the new
-                                  features must hold so that host and device agree bit for bit */
-  struct hso_frame_match* records;  /* hso_gpu_reproject_select_pose_frames only, may be NULL: the examined candidates as 32-byte records
-                                  (what a driver's bookkeeping reads of a hso_match_brief), laid out like `out` (same begin_out);
-                                  with it `out` may be NULL — 43 % less to read back per frame */
-} hso_pose_chain;
-int hso_gpu_reproject_select_pose_maps(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_call* calls, int n_calls, int cell_size,
-                                       int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
-                                       int out_capacity, int32_t* begin_out, int32_t* counts_out, const hso_pose_chain* pose);
-
 /* ---- sequence maps: the whole map of a sequence resident in HBM, mirrored row for row from the caller's tables and patched in
- *      place.  hso_gpu_map_store keeps a frozen projection list; the reference, however, decides per frame which keyframes'
+ *      place.  The reference decides per frame which keyframes'
  *      points it projects and in which order (src/reprojector.cpp:124-202: the covisible keyframes of the last frame, then the
  *      closest ones until ten), appends points between keyframes (converged seeds become candidates, :207-226) and threads every
  *      new keyframe's features into its points' observation lists (Point::addFrameRef, src/point.cpp:78-82: push_front).  Here
@@ -775,19 +715,9 @@ int hso_gpu_reproject_select_pose_maps(hso_gpu_ctx* ctx, const hso_camera* cam, 
  *          (hso_map_point.obs_begin = first row, obs_count = length, hso_obs.pad_ = next row), so push_front / erase of one
  *          observation patches one or two rows;
  *        - hso_gpu_seqmap_patch scatters changed rows (asynchronous on the context stream; rows past the end grow the tables);
- *        - per frame the caller names the points to project, in the reference's visiting order, as a list of point ids with
- *          their quality keys (hso_map_frame) — 5 bytes per point in, the examined candidates out. ---- */
-typedef struct hso_map_frame {
-  int32_t map;                 /* which sequence map */
-  int32_t cur_keyframe_id;     /* Frame::keyFrameId_ of the current frame */
-  int64_t cur_frame_id;        /* resident current frame */
-  hso_se3 T_cur_w;
-  double cur_exposure_time;
-  const int32_t* point_ids;    /* host: rows of the point table in reprojectMap's visiting order */
-  const uint8_t* quality;      /* host: their keys (Point::type_ << 4) | Point::ftr_type_ (what the stored maps keep in pad_) */
-  int32_t n_points;
-  int32_t pad_;
-} hso_map_frame;
+ *        - the keyframes' feature lists (Frame::fts_), the candidate list and the Feature::point / Frame::key_pts_ links are
+ *          mirrored too (hso_gpu_seqmap_patch_lists / _patch_links / _set_key_points), so that the per-frame walk of
+ *          Reprojector::reprojectMap runs on the device (hso_gpu_seq_chain below). ---- */
 int hso_gpu_seqmap_create(hso_gpu_ctx* ctx, int* map_out);
 int hso_gpu_seqmap_destroy(hso_gpu_ctx* ctx, int map);
 /* the keyframe table (whole table every time: a few dozen rows kept on the host side of the library; poses change with every
@@ -802,22 +732,13 @@ typedef struct hso_seqmap_rows {
   int32_t map, n_points, n_obs, pad_;
   const int32_t* point_ids; const hso_map_point* points;
   const int32_t* obs_ids; const hso_obs* obs;
+  const int32_t* obs_point;    /* may be NULL: Feature::point of the patched observation rows (point row, -1: NULL) */
 } hso_seqmap_rows;
 int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches, int n_patches);
 int hso_gpu_seqmap_size(hso_gpu_ctx* ctx, int map, int* n_kfs, int* n_points, int* n_obs);
 /* parity / trace read-back of rows as the device holds them now */
 int hso_gpu_seqmap_read(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, int n_points, hso_map_point* points_out,
                         const int32_t* obs_ids, int n_obs, hso_obs* obs_out);
-/* hso_gpu_reproject_select_pose_maps over sequence maps: per frame the listed points are projected, matched against their
- * closest observation, put through the grid selection and the pose optimisation, nothing returning to the host in between.
- * out / begin_out / counts_out / pose as there, with hso_match_brief.pad_ = the candidate's POSITION in its frame's list;
- * projected_out (may be NULL): one byte per listed point, frames back to back: reprojectPoint's return value
- * (src/reprojector.cpp:504-529), which the caller needs for the candidates' and temporary points' n_failed_reproj_ (:214-251).
- * The pose job's keyframe table is compacted on the device to the host keyframes of the selected features (<= 128; the features of any further keyframe take no part in the optimisation). */
-int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_map_frame* frames, int n_frames, int cell_size,
-                                         int grid_n_cols, const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out,
-                                         int out_capacity, int32_t* begin_out, int32_t* counts_out, uint8_t* projected_out,
-                                         const hso_pose_chain* pose);
 /* ---- the resident per-frame chain ("removes the last per-frame host loop over the
  *      pointer graph and the D2H / H2D of candidates between tracker and alignment").  FrameHandlerMono::processFrame from the motion
  *      prior to the inputs of its keyframe decision (src/frame_handler_mono.cpp:173-291) for the current frames of n sequences, every
@@ -846,8 +767,10 @@ int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* ctx, const hso_camera* cam
 #define HSO_PT_KEY(w)     ((uint32_t)(w) & 0xffu)            /* (Point::type_ << 4) | Point::ftr_type_; type 0 = TYPE_DELETED */
 #define HSO_PT_NFAIL(w)   (((uint32_t)(w) >> 8) & 0x3ffu)    /* n_failed_reproj_, saturating at 1023 */
 #define HSO_PT_BAD        (1u << 18)                         /* a temporary point given up (isBad_) */
-#define HSO_PT_KEEP       (1u << 19)                         /* in a PATCHED row only: keep the device's counters and bad flag, take key */
+#define HSO_PT_KEEP_NFAIL (1u << 19)                         /* in a PATCHED row only: keep the device's n_failed_reproj_ ... */
 #define HSO_PT_NOK(w)     (((uint32_t)(w) >> 20) & 0x7ffu)   /* n_succeeded_reproj_, saturating at 2047 */
+#define HSO_PT_KEEP_NOK   (1u << 31)                         /* ... / n_succeeded_reproj_ (the device counts them; the caller owns key and bad flag,
+                                                                which it mirrors from the chain's events, and resets a counter by sending it) */
 #define HSO_PT_WORD(key, n_fail, bad, n_ok) ((int32_t)(((uint32_t)(key) & 0xffu) | (((uint32_t)(n_fail) & 0x3ffu) << 8) | ((bad) ? HSO_PT_BAD : 0u) | (((uint32_t)(n_ok) & 0x7ffu) << 20)))
 
 enum { HSO_LIST_CANDIDATES = -1 };   /* hso_seqmap_list_patch.list: MapPointCandidates::candidates_ in list order; >= 0: Frame::fts_ of that keyframe row */
@@ -872,7 +795,10 @@ enum { HSO_EV_ERASE_POINT = 1,       /* Map::safeDeletePoint (a TYPE_UNKNOWN poi
        HSO_EV_ERASE_CANDIDATE = 2,   /* MapPointCandidates::deleteCandidatePoint (more than 30 failures, :382-386, :214-222) */
        HSO_EV_TEMP_BAD = 3,          /* a temporary point's isBad_ (:387-390, :247-251) */
        HSO_EV_GOOD = 4 };            /* TYPE_UNKNOWN -> TYPE_GOOD (:412-416) */
-enum { HSO_SEQ_NO_TRACK = 1 };       /* hso_seq_job.flags: the reference frame has no features: CoarseTracker::run returns 0 at once (CoarseTracker.cpp:53-54) */
+enum { HSO_SEQ_NO_TRACK = 1,         /* hso_seq_job.flags: the reference frame has no features: CoarseTracker::run returns 0 at once (CoarseTracker.cpp:53-54) */
+       HSO_SEQ_SEED_BRANCH = 2 };    /* the sequence has seeds: with fewer than 100 matches reprojectMap goes on to match them (src/reprojector.cpp:309-329),
+                                        the frame's features change and the pose is optimised after that — by the caller: the chain's pose
+                                        result is then informative only and its culling is NOT applied to the frame's feature table */
 
 typedef struct hso_seq_job {
   int32_t map;                 /* the sequence map */
@@ -889,7 +815,7 @@ typedef struct hso_seq_job {
   int32_t last_kf_row;         /* Map::lastKeyframe() (needNewKf's keyframe), -1: skip the flow sums */
   int32_t covis[5];            /* ref.connectedKeyFrames as keyframe rows in list order, -1 padded (reprojector.cpp:124-170) */
   int32_t temps_begin, n_temps;/* this job's slice of the call's `temps` array: the temporary points to list (not bad, positions already placed) */
-  int32_t pad_;
+  float exposure_rat;          /* cur.integralImage_ / ref.integralImage_: the tracker's initial exposure ratio (src/CoarseTracker.cpp:60) */
 } hso_seq_job;
 
 typedef struct hso_seq_chain_cfg {
@@ -899,8 +825,9 @@ typedef struct hso_seq_chain_cfg {
   int32_t max_kfs;             /* Reprojector::Options::max_n_kfs (10) */
   int32_t pose_n_iter;         /* 12 */
   double pose_reproj_thresh;   /* Config::poseOptimThresh() */
+  int32_t quality_min_fts;     /* Config::qualityMinFts(): with fewer matches processFrame gives the frame up before the pose
+                                  optimiser's result is used (frame_handler_mono.cpp:224-230) — its culling is then not applied */
   int32_t want_debug;          /* 1: keep the intermediate tables for hso_gpu_debug_fetch (recorded runs) */
-  int32_t pad_;
 } hso_seq_chain_cfg;
 
 typedef struct hso_seq_result {
@@ -948,11 +875,16 @@ int hso_gpu_seq_set_frame_features(hso_gpu_ctx* ctx, int map, int64_t frame_id, 
 int hso_gpu_seq_debug_list(hso_gpu_ctx* ctx, int job, int32_t* ids_out, uint8_t* quality_out, int cap);
 int hso_gpu_seq_debug_ref_table(hso_gpu_ctx* ctx, int job, hso_ref_feat* out, int cap);
 
-/* trace / parity hook: tables the last hso_gpu_reproject_select_pose_frames call left in the work area (valid until the next
- * entry point that uses it): HSO_DBG_PROJ = hso_reproj_point per listed point, HSO_DBG_MATCH = hso_align_out per listed point,
- * HSO_DBG_POSE_FEATS = n_frames rows of max(max_fts, 1) hso_pose_feat (host_pose = index into HSO_DBG_POSE_POSES' row),
- * HSO_DBG_POSE_POSES = n_frames rows of 128 hso_se3, HSO_DBG_POSE_NPOSES = n_frames int32.  bytes must equal the table's size. */
-enum { HSO_DBG_PROJ = 0, HSO_DBG_MATCH = 1, HSO_DBG_POSE_FEATS = 2, HSO_DBG_POSE_POSES = 3, HSO_DBG_POSE_NPOSES = 4 };
+/* trace / parity hook: tables the last hso_gpu_seq_chain call (cfg.want_debug = 1) left in the work area (valid until the next
+ * entry point that uses it).  The listed points of the jobs lie in slices of the call: job j's at HSO_DBG_SLICES[j] (n_jobs + 1
+ * int32; a slice is as long as the job's list can get, its first n_listed entries are used).  HSO_DBG_PROJ = hso_reproj_point per
+ * slice entry, HSO_DBG_MATCH = hso_align_out per slice entry, HSO_DBG_BRIEF = hso_match_brief per EXAMINED candidate (job j's at
+ * HSO_DBG_EXAMINED_BEGIN[j], n_jobs + 1 int32; pad_ = the candidate's position in its list), HSO_DBG_PROJECTED = one byte per slice
+ * entry (reprojectPoint's return value), HSO_DBG_POSE_FEATS = n_jobs rows of max(max_fts, 1) hso_pose_feat (host_pose = index into
+ * HSO_DBG_POSE_POSES' row), HSO_DBG_POSE_POSES = n_jobs rows of 128 hso_se3, HSO_DBG_POSE_NPOSES = n_jobs int32, HSO_DBG_POSE_MASK =
+ * n_jobs rows of max(max_fts, 1) bytes.  bytes must equal the table's size. */
+enum { HSO_DBG_PROJ = 0, HSO_DBG_MATCH = 1, HSO_DBG_POSE_FEATS = 2, HSO_DBG_POSE_POSES = 3, HSO_DBG_POSE_NPOSES = 4, HSO_DBG_SLICES = 5,
+       HSO_DBG_BRIEF = 6, HSO_DBG_EXAMINED_BEGIN = 7, HSO_DBG_PROJECTED = 8, HSO_DBG_POSE_MASK = 9, HSO_DBG_N = 10 };
 int hso_gpu_debug_fetch(hso_gpu_ctx* ctx, int what, void* out, size_t bytes);
 /* developer census: what the library has asked of the HIP runtime since the process started (all contexts): copies enqueued, their
  * bytes, copies that went through page-locked staging because the caller's memory was pageable, stream synchronisations, nanoseconds

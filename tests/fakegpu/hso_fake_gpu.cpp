@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <list>
 #include <map>
 #include <string>
@@ -23,7 +24,15 @@ struct FakeFrame {
   const int16_t* sx[HSO_N_SOBEL_LEVELS];
   const int16_t* sy[HSO_N_SOBEL_LEVELS];
 };
-struct FakeMap { std::vector<hso_kf> kfs; std::vector<hso_map_point> pts; std::vector<hso_obs> obs; };
+struct FakeMap {
+  std::vector<hso_kf> kfs; std::vector<hso_map_point> pts; std::vector<hso_obs> obs;
+  std::vector<int32_t> obs_pt;                       // Feature::point per observation row
+  std::vector<int32_t> keys;                         // Frame::key_pts_ as point rows, 5 per keyframe
+  std::vector<std::vector<int32_t>> kf_fts;          // Frame::fts_ per keyframe row
+  std::vector<int32_t> cands;                        // MapPointCandidates::candidates_
+  int fts_cap = 0;
+  std::vector<hso_seq_feature> ff[2]; int64_t ff_frame[2] = {-1, -1}; int ff_newest = 0;
+};
 struct FakeSeedTable { std::vector<hso_seed> s; std::vector<int> group; std::vector<uint8_t> alive; };
 
 struct hso_gpu_ctx {
@@ -31,9 +40,11 @@ struct hso_gpu_ctx {
   std::map<int64_t, FakeFrame*> frames;
   std::vector<FakeMap*> maps;
   std::vector<FakeSeedTable*> tables;
-  // hso_gpu_debug_fetch
+  // hso_gpu_debug_fetch / hso_gpu_seq_debug_* / hso_gpu_seq_events: what the last chain call left
   std::vector<hso_reproj_point> dbg_proj; std::vector<hso_align_out> dbg_match; std::vector<hso_pose_feat> dbg_feats;
-  std::vector<hso_se3> dbg_poses; std::vector<int32_t> dbg_nposes;
+  std::vector<hso_se3> dbg_poses; std::vector<int32_t> dbg_nposes, dbg_slices, dbg_exbegin; std::vector<hso_match_brief> dbg_brief;
+  std::vector<uint8_t> dbg_projected, dbg_mask;
+  std::vector<std::vector<int32_t>> last_ids, last_events; std::vector<std::vector<uint8_t>> last_quality; std::vector<std::vector<hso_ref_feat>> last_table;
   std::vector<hso_seed_brief> prev_briefs; int prev_table = -1;   // hso_gpu_seed_table_observe_previous_begin / _end
 };
 
@@ -123,33 +134,84 @@ int hso_gpu_coarse_track_batch(hso_gpu_ctx* c, const hso_camera* cam, const hso_
 // ---- sequence maps
 int hso_gpu_seqmap_create(hso_gpu_ctx* c, int* out) { c->maps.push_back(new FakeMap()); *out = (int)c->maps.size() - 1; return HSO_OK; }
 int hso_gpu_seqmap_destroy(hso_gpu_ctx* c, int m) { delete c->maps[m]; c->maps[m] = nullptr; return HSO_OK; }
+int hso_gpu_seqmap_configure(hso_gpu_ctx* c, int m, int fts_cap) { if (fts_cap < 1) return fail(c, HSO_E_INVALID, "seqmap_configure"); c->maps[m]->fts_cap = fts_cap; return HSO_OK; }
 int hso_gpu_seqmap_set_keyframes(hso_gpu_ctx* c, int m, const hso_kf* kfs, int n)
 {
   for (int k = 0; k < n; k++) if (!frame_of(c, kfs[k].frame_id)) return fail(c, HSO_E_NOFRAME, "seqmap_set_keyframes: keyframe not resident");
-  c->maps[m]->kfs.assign(kfs, kfs + n);
+  FakeMap* M = c->maps[m];
+  M->kfs.assign(kfs, kfs + n);
+  M->keys.resize(5 * (size_t)n, -1);
+  M->kf_fts.resize((size_t)n);
   return HSO_OK;
 }
-int hso_gpu_seqmap_patch(hso_gpu_ctx* c, int m, const int32_t* pid, const hso_map_point* pts, int np, const int32_t* oid, const hso_obs* obs, int no)
+int hso_gpu_seqmap_set_key_points(hso_gpu_ctx* c, int m, const int32_t* keys, int n)
+{
+  FakeMap* M = c->maps[m];
+  if ((size_t)n != M->kfs.size()) return fail(c, HSO_E_INVALID, "seqmap_set_key_points: one row per keyframe");
+  for (int i = 0; i < 5 * n; i++) if (keys[i] < -1 || (keys[i] >= 0 && (size_t)keys[i] >= M->pts.size())) return fail(c, HSO_E_INVALID, "seqmap_set_key_points: point row out of range");
+  M->keys.assign(keys, keys + 5 * (size_t)n);
+  return HSO_OK;
+}
+// a patched point row: key and bad flag are the caller's, a counter too unless its KEEP bit says the device's stays
+static void store_point(hso_map_point& dst, const hso_map_point& src)
+{
+  uint32_t w = (uint32_t)src.pad_;
+  const uint32_t old = (uint32_t)dst.pad_;
+  if (w & HSO_PT_KEEP_NFAIL) w = (w & ~(0x3ffu << 8)) | (old & (0x3ffu << 8));
+  if (w & HSO_PT_KEEP_NOK) w = (w & ~(0x7ffu << 20)) | (old & (0x7ffu << 20));
+  w &= ~(HSO_PT_KEEP_NFAIL | HSO_PT_KEEP_NOK);
+  dst = src;
+  dst.pad_ = (int32_t)w;
+}
+static int patch_rows(hso_gpu_ctx* c, int m, const int32_t* pid, const hso_map_point* pts, int np, const int32_t* oid, const hso_obs* obs, int no, const int32_t* olink)
 {
   FakeMap* M = c->maps[m];
   const int nk = (int)M->kfs.size();
   for (int i = 0; i < no; i++) {
     if (oid[i] < 0 || obs[i].kf < 0 || obs[i].kf >= nk) return fail(c, HSO_E_INVALID, "seqmap_patch: observation row out of range");
-    if ((size_t)oid[i] >= M->obs.size()) M->obs.resize((size_t)oid[i] + 1, hso_obs{});
+    if ((size_t)oid[i] >= M->obs.size()) { M->obs.resize((size_t)oid[i] + 1, hso_obs{}); M->obs_pt.resize((size_t)oid[i] + 1, -1); }
     M->obs[(size_t)oid[i]] = obs[i];
+    if (olink) M->obs_pt[(size_t)oid[i]] = olink[i];
   }
   for (int i = 0; i < np; i++) {
     if (pid[i] < 0 || pts[i].host_kf < 0 || pts[i].host_kf >= nk || (pts[i].obs_count > 0 && (pts[i].obs_begin < 0 || (size_t)pts[i].obs_begin >= M->obs.size())))
       return fail(c, HSO_E_INVALID, "seqmap_patch: point row out of range");
     if ((size_t)pid[i] >= M->pts.size()) M->pts.resize((size_t)pid[i] + 1, hso_map_point{});
-    M->pts[(size_t)pid[i]] = pts[i];
+    store_point(M->pts[(size_t)pid[i]], pts[i]);
   }
   return HSO_OK;
+}
+int hso_gpu_seqmap_patch(hso_gpu_ctx* c, int m, const int32_t* pid, const hso_map_point* pts, int np, const int32_t* oid, const hso_obs* obs, int no)
+{
+  return patch_rows(c, m, pid, pts, np, oid, obs, no, nullptr);
 }
 int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* c, const hso_seqmap_rows* p, int n)
 {
   for (int i = 0; i < n; i++)
-    if (int rc = hso_gpu_seqmap_patch(c, p[i].map, p[i].point_ids, p[i].points, p[i].n_points, p[i].obs_ids, p[i].obs, p[i].n_obs)) return rc;
+    if (int rc = patch_rows(c, p[i].map, p[i].point_ids, p[i].points, p[i].n_points, p[i].obs_ids, p[i].obs, p[i].n_obs, p[i].obs_point)) return rc;
+  return HSO_OK;
+}
+int hso_gpu_seqmap_patch_links(hso_gpu_ctx* c, int m, const int32_t* oid, const int32_t* link, int n)
+{
+  FakeMap* M = c->maps[m];
+  for (int i = 0; i < n; i++) { if (oid[i] < 0 || (size_t)oid[i] >= M->obs.size()) return fail(c, HSO_E_INVALID, "seqmap_patch_links: row out of range"); M->obs_pt[(size_t)oid[i]] = link[i]; }
+  return HSO_OK;
+}
+int hso_gpu_seqmap_patch_lists(hso_gpu_ctx* c, const hso_seqmap_list_patch* p, int n)
+{
+  for (int i = 0; i < n; i++) {
+    FakeMap* M = c->maps[p[i].map];
+    std::vector<int32_t>* L = nullptr;
+    if (p[i].list == HSO_LIST_CANDIDATES) L = &M->cands;
+    else {
+      if (p[i].list < 0 || (size_t)p[i].list >= M->kf_fts.size()) return fail(c, HSO_E_INVALID, "seqmap_patch_lists: no such keyframe row");
+      if (p[i].first + p[i].n > M->fts_cap) return fail(c, HSO_E_INVALID, "seqmap_patch_lists: a keyframe's feature list outgrows fts_cap");
+      L = &M->kf_fts[(size_t)p[i].list];
+    }
+    if (p[i].first < 0 || (size_t)p[i].first > L->size()) return fail(c, HSO_E_INVALID, "seqmap_patch_lists: the patch leaves a gap");
+    L->resize((size_t)p[i].first);
+    L->insert(L->end(), p[i].ids, p[i].ids + p[i].n);
+  }
   return HSO_OK;
 }
 int hso_gpu_seqmap_size(hso_gpu_ctx* c, int m, int* nk, int* np, int* no)
@@ -165,6 +227,25 @@ int hso_gpu_seqmap_read(hso_gpu_ctx* c, int m, const int32_t* pid, int np, hso_m
   FakeMap* M = c->maps[m];
   for (int i = 0; i < np; i++) pts[i] = M->pts.at((size_t)pid[i]);
   for (int i = 0; i < no; i++) obs[i] = M->obs.at((size_t)oid[i]);
+  return HSO_OK;
+}
+int hso_gpu_seq_frame_features(hso_gpu_ctx* c, const int32_t* maps, const int64_t* ids, int n, hso_seq_feature* out, int cap, int32_t* n_out)
+{
+  for (int i = 0; i < n; i++) {
+    FakeMap* M = c->maps[maps[i]];
+    const int b = M->ff_frame[0] == ids[i] ? 0 : (M->ff_frame[1] == ids[i] ? 1 : -1);
+    if (b < 0) return fail(c, HSO_E_NOFRAME, "seq_frame_features: the map holds no feature table of that frame");
+    if ((int)M->ff[b].size() > cap) return fail(c, HSO_E_INVALID, "seq_frame_features: cap is smaller than the table");
+    n_out[i] = (int)M->ff[b].size();
+    std::copy(M->ff[b].begin(), M->ff[b].end(), out + (size_t)i * cap);
+  }
+  return HSO_OK;
+}
+int hso_gpu_seq_set_frame_features(hso_gpu_ctx* c, int m, int64_t id, const hso_seq_feature* f, int n)
+{
+  FakeMap* M = c->maps[m];
+  const int b = M->ff_frame[0] == id ? 0 : (M->ff_frame[1] == id ? 1 : 1 - M->ff_newest);
+  M->ff[b].assign(f, f + n); M->ff_frame[b] = id; M->ff_newest = b;
   return HSO_OK;
 }
 
@@ -214,35 +295,129 @@ static void select_walk(const std::vector<Cand>& cand, const int32_t* cell_order
   counts[0] = (int)examined.size(); counts[1] = n_matches;
 }
 
-int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* c, const hso_camera* cam, const hso_map_frame* frames, int n, int cell_size, int grid_n_cols,
-                                         const int32_t* cell_order, int n_cells, int max_fts, hso_match_brief* out, int out_cap, int32_t* begin_out,
-                                         int32_t* counts_out, uint8_t* projected_out, const hso_pose_chain* pose)
+// hso_gpu_seq_chain on the restatement: FrameHandlerMono::processFrame from the motion prior to the inputs of its decisions
+// (src/frame_handler_mono.cpp:173-291), one sequence after the other, every step the sequential way the reference does it.
+int hso_gpu_seq_chain(hso_gpu_ctx* c, const hso_camera* cam, const hso_seq_chain_cfg* cfg, const hso_seq_job* jobs, int n, const int32_t* temps, int,
+                      hso_seq_result* results)
 {
-  const int cap = std::max(max_fts, 1);
-  c->dbg_proj.clear(); c->dbg_match.clear();
+  const int cap = std::max(cfg->max_fts, 1), n_cells = cfg->n_cells;
+  c->dbg_proj.clear(); c->dbg_match.clear(); c->dbg_brief.clear(); c->dbg_projected.clear();
   c->dbg_feats.assign((size_t)n * cap, hso_pose_feat{}); c->dbg_poses.assign((size_t)n * 128, hso_se3{}); c->dbg_nposes.assign((size_t)n, 0);
-  int n_out = 0;
-  size_t at = 0;
-  for (int f = 0; f < n; f++) {
-    const hso_map_frame& K = frames[f];
-    FakeMap* M = c->maps[K.map];
-    FakeFrame* C = frame_of(c, K.cur_frame_id);
-    if (!C) return fail(c, HSO_E_NOFRAME, "reproject_select_pose_frames: current frame not resident");
-    hso_se3 Tinv; hso_or_se3_inverse(&K.T_cur_w, &Tinv);
-    std::vector<hso_reproj_point> proj((size_t)K.n_points); std::vector<hso_align_out> match((size_t)K.n_points);
-    std::vector<hso_match_brief> brief((size_t)K.n_points);
+  c->dbg_mask.assign((size_t)n * cap, 0); c->dbg_slices.assign((size_t)n + 1, 0); c->dbg_exbegin.assign((size_t)n + 1, 0);
+  c->last_ids.assign((size_t)n, {}); c->last_events.assign((size_t)n, {}); c->last_quality.assign((size_t)n, {}); c->last_table.assign((size_t)n, {});
+  for (int j = 0; j < n; j++) {
+    const hso_seq_job& J = jobs[j];
+    hso_seq_result& R = results[j];
+    memset(&R, 0, sizeof(R));
+    FakeMap* M = c->maps[J.map];
+    FakeFrame* C = frame_of(c, J.cur_frame_id); FakeFrame* Rf = frame_of(c, J.ref_frame_id);
+    if (!C || !Rf) return fail(c, HSO_E_NOFRAME, "seq_chain: frame not resident");
+    const int nk = (int)M->kfs.size();
+    // ---- CoarseTracker::makeDepthRef (src/CoarseTracker.cpp:210-240) + run (:51-208) + the write-back (:198-202)
+    const bool no_track = (J.flags & HSO_SEQ_NO_TRACK) != 0 || J.n_ref_feats == 0;
+    int ref_buf = -1;
+    std::vector<hso_ref_feat>& table = c->last_table[(size_t)j];
+    if (!no_track) {
+      std::vector<int32_t> pt;
+      if (J.ref_kf_row >= 0) {
+        const std::vector<int32_t>& L = M->kf_fts.at((size_t)J.ref_kf_row);
+        if ((int)L.size() != J.n_ref_feats) return fail(c, HSO_E_INVALID, "seq_chain: n_ref_feats differs from the keyframe's list");
+        for (int32_t f : L) { const hso_obs& o = M->obs.at((size_t)f); hso_ref_feat r{}; r.px[0] = o.px[0]; r.px[1] = o.px[1]; r.f[0] = o.f[0]; r.f[1] = o.f[1]; r.f[2] = o.f[2]; table.push_back(r); pt.push_back(M->obs_pt.at((size_t)f)); }
+      } else {
+        ref_buf = M->ff_frame[0] == J.ref_frame_id ? 0 : (M->ff_frame[1] == J.ref_frame_id ? 1 : -1);
+        if (ref_buf < 0) return fail(c, HSO_E_NOFRAME, "seq_chain: the map holds no feature table of the reference frame");
+        if ((int)M->ff[ref_buf].size() != J.n_ref_feats) return fail(c, HSO_E_INVALID, "seq_chain: n_ref_feats differs from the reference frame's table");
+        for (const hso_seq_feature& q : M->ff[ref_buf]) { hso_ref_feat r{}; r.px[0] = q.px[0]; r.px[1] = q.px[1]; r.f[0] = q.f[0]; r.f[1] = q.f[1]; r.f[2] = q.f[2]; table.push_back(r); pt.push_back(q.point); }
+      }
+      for (size_t i = 0; i < table.size(); i++) {
+        table[i].dist = -1;
+        if (pt[i] < 0 || (size_t)pt[i] >= M->pts.size()) continue;
+        const hso_map_point& P = M->pts[(size_t)pt[i]];
+        if (P.idist == 0.0) continue;
+        hso_se3 inv, T_ref_host;
+        hso_or_se3_inverse(&M->kfs[(size_t)P.host_kf].T_f_w, &inv);
+        hso_or_se3_mul(&J.T_ref_w, &inv, &T_ref_host);
+        const double s = 1.0 / P.idist, in_host[3] = {P.host_f[0] * s, P.host_f[1] * s, P.host_f[2] * s};
+        double q[3];
+        hso_or_se3_apply(&T_ref_host, in_host, q);
+        if (!(q[2] < 0.00001)) table[i].dist = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+      }
+    }
+    hso_se3 T_cur = J.T_cur_w;
+    double exposure = -1.0;
+    if (!no_track) {
+      hso_se3 inv, T_cur_ref;
+      hso_or_se3_inverse(&J.T_ref_w, &inv);
+      hso_or_se3_mul(&J.T_cur_w, &inv, &T_cur_ref);
+      hso_or_tracker* t = hso_or_tracker_create(cam, &cfg->track, Rf->pyr, C->pyr, Rf->w, Rf->h, table.data(), (int)table.size());
+      hso_or_tracker_run(t, &T_cur_ref, J.exposure_rat, &R.track);
+      hso_or_tracker_destroy(t);
+      hso_or_se3_mul(&R.track.T_cur_ref, &J.T_ref_w, &T_cur);
+      exposure = (double)R.track.exposure_rat * J.ref_exposure;
+      if (R.track.exposure_rat > 0.99f && R.track.exposure_rat < 1.01f) exposure = J.ref_exposure;
+    }
+    R.T_tracked = T_cur; R.exposure = exposure;
+    hso_se3 Tinv; hso_or_se3_inverse(&T_cur, &Tinv);
+    // ---- which keyframes the frame visits (src/reprojector.cpp:108-199; Map::getCloseKeyframes, src/map.cpp:193-213)
+    std::vector<int> visit;
+    for (int q = 0; q < 5; q++) { const int r = J.covis[q]; if (r >= 0 && r < nk && std::find(visit.begin(), visit.end(), r) == visit.end()) visit.push_back(r); }
+    {
+      std::vector<std::pair<double, int>> near;
+      for (int k = 0; k < nk; k++)
+        for (int q = 0; q < 5; q++) {
+          const int p = M->keys[5 * (size_t)k + q];
+          if (p < 0 || (size_t)p >= M->pts.size()) continue;
+          double xc[3], px[2];
+          hso_or_se3_apply(&T_cur, M->pts[(size_t)p].pos, xc);
+          if (xc[2] < 0.0) continue;
+          hso_or_world2cam(cam, xc, px);
+          if (!(px[0] >= 0.0 && px[1] >= 0.0 && px[0] < cam->width && px[1] < cam->height)) continue;
+          const double* a = T_cur.t; const double* b = M->kfs[(size_t)k].T_f_w.t;
+          near.push_back({std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2])), k});
+          break;
+        }
+      std::stable_sort(near.begin(), near.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+      size_t cnt = visit.size();
+      for (size_t i = 0; i < near.size() && (int)cnt < cfg->max_kfs && visit.size() < HSO_SEQ_MAX_VISIT; i++) {
+        if (std::find(visit.begin(), visit.end(), near[i].second) != visit.end()) continue;
+        visit.push_back(near[i].second); ++cnt;
+      }
+    }
+    R.n_visit = (int)visit.size();
+    for (int q = 0; q < HSO_SEQ_MAX_VISIT; q++) R.visit[q] = q < (int)visit.size() ? visit[(size_t)q] : -1;
+    // ---- the list: per visited keyframe the points of its features once each, then candidates, then temporary points
+    std::vector<int32_t>& ids = c->last_ids[(size_t)j]; std::vector<uint8_t>& quality = c->last_quality[(size_t)j];
+    {
+      std::vector<uint8_t> stamped(M->pts.size(), 0);
+      for (int r : visit)
+        for (int32_t f : M->kf_fts.at((size_t)r)) {
+          const int p = M->obs_pt.at((size_t)f);
+          if (p < 0 || (size_t)p >= M->pts.size()) continue;
+          const int key = (int)HSO_PT_KEY(M->pts[(size_t)p].pad_), kind = key >> 4;
+          if (kind == 0 || kind == 1 || stamped[(size_t)p]) continue;
+          stamped[(size_t)p] = 1;
+          ids.push_back(p); quality.push_back((uint8_t)key);
+        }
+    }
+    R.n_kf_points = (int)ids.size();
+    for (int32_t p : M->cands) { const int key = (int)HSO_PT_KEY(M->pts.at((size_t)p).pad_); if ((key >> 4) != 2) continue; ids.push_back(p); quality.push_back((uint8_t)key); }
+    R.n_candidates = (int)ids.size() - R.n_kf_points;
+    for (int q = 0; q < J.n_temps; q++) { const int32_t p = temps[J.temps_begin + q]; ids.push_back(p); quality.push_back((uint8_t)HSO_PT_KEY(M->pts.at((size_t)p).pad_)); }
+    const int n_listed = (int)ids.size();
+    R.n_listed = n_listed;
+    // ---- projection, reference choice, findMatchDirect
+    std::vector<hso_reproj_point> proj((size_t)n_listed); std::vector<hso_align_out> match((size_t)n_listed);
+    std::vector<hso_match_brief> brief((size_t)n_listed);
     std::vector<Cand> cand; std::vector<int> cand_at;
-    for (int i = 0; i < K.n_points; i++) {
+    for (int i = 0; i < n_listed; i++) {
       hso_reproj_point& r = proj[(size_t)i];
       memset(&r, 0, sizeof(r)); r.ref_obs = -1;
       memset(&match[(size_t)i], 0, sizeof(hso_align_out));
       hso_match_brief& b = brief[(size_t)i];
       memset(&b, 0, sizeof(b)); b.cell = -1; b.ref_obs = -1;
-      const int pid = K.point_ids[i];
-      if (pid < 0 || (size_t)pid >= M->pts.size()) continue;
-      const hso_map_point& P = M->pts[(size_t)pid];
+      const hso_map_point& P = M->pts[(size_t)ids[(size_t)i]];
       int cell = 0;
-      if (!hso_or_reproject_point(cam, &K.T_cur_w, &M->kfs[(size_t)P.host_kf].T_f_w, P.host_f, P.idist, cell_size, grid_n_cols, r.px, &cell)) continue;
+      if (!hso_or_reproject_point(cam, &T_cur, &M->kfs[(size_t)P.host_kf].T_f_w, P.host_f, P.idist, cfg->cell_size, cfg->grid_n_cols, r.px, &cell)) continue;
       r.projected = 1; r.cell = cell;
       b.cell = cell; b.px[0] = r.px[0]; b.px[1] = r.px[1];
       std::vector<hso_obs> chain; std::vector<int> rows;
@@ -253,10 +428,10 @@ int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* c, const hso_camera* cam, 
         r.ref_obs = rows[(size_t)k];
         b.ref_obs = r.ref_obs;
         hso_align_job job;
-        hso_or_reproject_make_job(&K.T_cur_w, K.cur_exposure_time, K.cur_keyframe_id, M->kfs.data(), &P, &chain[(size_t)k], r.px, &job);
-        FakeFrame* R = frame_of(c, M->kfs[(size_t)chain[(size_t)k].kf].frame_id);
+        hso_or_reproject_make_job(&T_cur, exposure, J.cur_keyframe_id, M->kfs.data(), &P, &chain[(size_t)k], r.px, &job);
+        FakeFrame* Rk = frame_of(c, M->kfs[(size_t)chain[(size_t)k].kf].frame_id);
         hso_align_out& m = match[(size_t)i];
-        hso_or_find_match_direct(cam, &job, R->pyr, C->pyr, C->sx, C->sy, C->w, C->h, &m);
+        hso_or_find_match_direct(cam, &job, Rk->pyr, C->pyr, C->sx, C->sy, C->w, C->h, &m);
         matched = m.success != 0;
         b.px_cur[0] = m.px_cur[0]; b.px_cur[1] = m.px_cur[1];
         b.stage = (int8_t)m.stage; b.search_level = (int8_t)m.search_level; b.ref_type = (int8_t)job.type;
@@ -264,62 +439,184 @@ int hso_gpu_reproject_select_pose_frames(hso_gpu_ctx* c, const hso_camera* cam, 
         const double nn = std::sqrt(gx * gx + gy * gy);
         b.grad[0] = nn > 0 ? (float)(gx / nn) : 0.f; b.grad[1] = nn > 0 ? (float)(gy / nn) : 0.f;
       }
-      cand.push_back({cell, K.quality[i], matched && (K.quality[i] >> 4) != 0});
+      cand.push_back({cell, quality[(size_t)i], matched && (quality[(size_t)i] >> 4) != 0});
       cand_at.push_back(i);
     }
-    if (projected_out) for (int i = 0; i < K.n_points; i++) projected_out[at + (size_t)i] = (uint8_t)proj[(size_t)i].projected;
+    // ---- the grid selection, the frame's features, the pose optimiser
     std::vector<std::pair<int, bool>> ex;
-    select_walk(cand, cell_order, n_cells, max_fts, ex, counts_out + 4 * f);
-    begin_out[f] = n_out;
-    // the frame's features = the taken candidates in examination order
-    std::vector<hso_pose_feat> feats; std::vector<hso_se3> poses; std::vector<int> pose_kf;
+    select_walk(cand, cfg->cell_order, n_cells, cfg->max_fts, ex, R.counts);
+    c->dbg_exbegin[(size_t)j] = (int32_t)c->dbg_brief.size();
+    std::vector<hso_pose_feat> feats; std::vector<hso_se3> poses;
+    std::vector<hso_seq_feature> ff;
+    std::vector<hso_frame_match> records;
     for (auto& e : ex) {
       const int i = cand_at[(size_t)e.first];
       hso_match_brief b = brief[(size_t)i];
       b.success = e.second ? 1 : 0; b.pad_ = i;
-      if (n_out >= out_cap) return fail(c, HSO_E_INVALID, "reproject_select_pose_frames: output too small");
-      if (pose->records) {
-        hso_frame_match m{};
-        m.px_cur[0] = b.px_cur[0]; m.px_cur[1] = b.px_cur[1]; m.grad[0] = b.grad[0]; m.grad[1] = b.grad[1];
-        m.point = b.pad_; m.success = b.success; m.search_level = b.search_level; m.ref_type = b.ref_type;
-        pose->records[n_out] = m;
-      }
-      if (out) out[n_out] = b;
-      n_out++;
+      c->dbg_brief.push_back(b);
+      hso_frame_match m{};
+      m.px_cur[0] = b.px_cur[0]; m.px_cur[1] = b.px_cur[1]; m.grad[0] = b.grad[0]; m.grad[1] = b.grad[1];
+      m.point = i; m.success = b.success; m.search_level = b.search_level; m.ref_type = b.ref_type;
+      records.push_back(m);
       if (!e.second || (int)feats.size() >= cap) continue;
-      const hso_map_point& P = M->pts[(size_t)K.point_ids[i]];
+      const hso_map_point& P = M->pts[(size_t)ids[(size_t)i]];
       hso_pose_feat pf{};
-      pf.has_point = 1; pf.type = b.ref_type; pf.level = b.search_level; pf.temporary = ((K.quality[i] >> 4) == 1) ? 1 : 0;
+      pf.has_point = 1; pf.type = b.ref_type; pf.level = b.search_level; pf.temporary = ((quality[(size_t)i] >> 4) == 1) ? 1 : 0;
       hso_or_cam2world(cam, b.px_cur[0], b.px_cur[1], pf.f);
       pf.grad[0] = b.grad[0]; pf.grad[1] = b.grad[1];
       pf.host_f[0] = P.host_f[0]; pf.host_f[1] = P.host_f[1]; pf.host_f[2] = P.host_f[2]; pf.idist = P.idist;
       pf.host_pose = P.host_kf;
       feats.push_back(pf);
+      hso_seq_feature q{};
+      q.px[0] = b.px_cur[0]; q.px[1] = b.px_cur[1]; q.f[0] = pf.f[0]; q.f[1] = pf.f[1]; q.f[2] = pf.f[2]; q.grad[0] = b.grad[0]; q.grad[1] = b.grad[1];
+      q.point = ids[(size_t)i]; q.level = b.search_level; q.type = b.ref_type;
+      ff.push_back(q);
     }
-    // compact pose table in map order
     std::vector<int> used;
     for (auto& pf : feats) used.push_back(pf.host_pose);
     std::sort(used.begin(), used.end()); used.erase(std::unique(used.begin(), used.end()), used.end());
     for (auto& pf : feats) pf.host_pose = (int)(std::lower_bound(used.begin(), used.end(), pf.host_pose) - used.begin());
     for (int k : used) poses.push_back(M->kfs[(size_t)k].T_f_w);
-    hso_pose_job job{};
-    job.feats = feats.data(); job.n_feats = (int)feats.size(); job.poses_f_w = poses.data(); job.n_poses = (int)poses.size();
-    job.T_f_w = K.T_cur_w; job.reproj_thresh = pose->reproj_thresh; job.n_iter = pose->n_iter;
+    hso_pose_job pjob{};
+    pjob.feats = feats.data(); pjob.n_feats = (int)feats.size(); pjob.poses_f_w = poses.data(); pjob.n_poses = (int)poses.size();
+    pjob.T_f_w = T_cur; pjob.reproj_thresh = cfg->pose_reproj_thresh; pjob.n_iter = cfg->pose_n_iter;
     std::vector<uint8_t> mask(std::max(feats.size(), (size_t)1), 0);
-    memset(&pose->results[f], 0, sizeof(hso_pose_result));
-    hso_or_pose_optimize(cam, &job, &pose->results[f], mask.data());
-    if (pose->n_feats) pose->n_feats[f] = (int)feats.size();
-    if (pose->outlier_mask) { memset(pose->outlier_mask + (size_t)f * cap, 0, (size_t)cap); memcpy(pose->outlier_mask + (size_t)f * cap, mask.data(), feats.size()); }
-    if (pose->feat_f) for (size_t j = 0; j < feats.size(); j++) for (int q = 0; q < 3; q++) pose->feat_f[((size_t)f * cap + j) * 3 + q] = feats[j].f[q];
-    std::copy(feats.begin(), feats.end(), c->dbg_feats.begin() + (std::ptrdiff_t)((size_t)f * cap));
-    std::copy(poses.begin(), poses.begin() + (std::ptrdiff_t)std::min(poses.size(), (size_t)128), c->dbg_poses.begin() + (std::ptrdiff_t)((size_t)f * 128));
-    c->dbg_nposes[(size_t)f] = (int)poses.size();
+    R.pose.status = 1; R.pose.T_f_w = T_cur;
+    if (!feats.empty()) { memset(&R.pose, 0, sizeof(R.pose)); hso_or_pose_optimize(cam, &pjob, &R.pose, mask.data()); }
+    R.n_feats = (int)feats.size();
+    std::copy(feats.begin(), feats.end(), c->dbg_feats.begin() + (std::ptrdiff_t)((size_t)j * cap));
+    std::copy(poses.begin(), poses.begin() + (std::ptrdiff_t)std::min(poses.size(), (size_t)128), c->dbg_poses.begin() + (std::ptrdiff_t)((size_t)j * 128));
+    std::copy(mask.begin(), mask.begin() + (std::ptrdiff_t)feats.size(), c->dbg_mask.begin() + (std::ptrdiff_t)((size_t)j * cap));
+    c->dbg_nposes[(size_t)j] = (int)poses.size();
+    c->dbg_slices[(size_t)j] = (int32_t)c->dbg_proj.size();
     c->dbg_proj.insert(c->dbg_proj.end(), proj.begin(), proj.end());
     c->dbg_match.insert(c->dbg_match.end(), match.begin(), match.end());
-    at += (size_t)K.n_points;
+    for (int i = 0; i < n_listed; i++) c->dbg_projected.push_back((uint8_t)proj[(size_t)i].projected);
+    // ---- what reprojectCell / reprojectCellAll do with the candidates they examine (src/reprojector.cpp:366-425, 214-222, 247-251)
+    std::vector<int32_t>& ev = c->last_events[(size_t)j];
+    auto word = [&](int p) -> uint32_t& { return reinterpret_cast<uint32_t&>(M->pts[(size_t)p].pad_); };
+    auto add_fail = [&](uint32_t& w, uint32_t k) { uint32_t nf = HSO_PT_NFAIL(w) + k; if (nf > 1023) nf = 1023; w = (w & ~(0x3ffu << 8)) | (nf << 8); return nf; };
+    for (int i = R.n_kf_points; i < n_listed; i++) {
+      if (proj[(size_t)i].projected) continue;
+      const int p = ids[(size_t)i];
+      uint32_t& w = word(p);
+      if (add_fail(w, 3) <= 30) continue;
+      if (i < R.n_kf_points + R.n_candidates) { w &= ~0xf0u; ev.push_back((HSO_EV_ERASE_CANDIDATE << 28) | p); }
+      else { w |= HSO_PT_BAD; ev.push_back((HSO_EV_TEMP_BAD << 28) | p); }
+    }
+    for (const hso_frame_match& r : records) {
+      const int p = ids[(size_t)r.point];
+      uint32_t& w = word(p);
+      const uint32_t kind = (w & 0xffu) >> 4;
+      if (kind == 0) continue;
+      if (!r.success) {
+        const uint32_t nf = add_fail(w, 1);
+        if (kind == 3 && nf > 15) { w &= ~0xf0u; ev.push_back((HSO_EV_ERASE_POINT << 28) | p); }
+        else if (kind == 2 && nf > 30) { w &= ~0xf0u; ev.push_back((HSO_EV_ERASE_CANDIDATE << 28) | p); }
+        else if (kind == 1 && nf > 30) { w |= HSO_PT_BAD; ev.push_back((HSO_EV_TEMP_BAD << 28) | p); }
+        continue;
+      }
+      uint32_t nk2 = HSO_PT_NOK(w) + 1; if (nk2 > 2047) nk2 = 2047;
+      w = (w & ~(0x7ffu << 20)) | (nk2 << 20);
+      if (kind == 3 && nk2 > 10) { w = (w & ~0xf0u) | (4u << 4); ev.push_back((HSO_EV_GOOD << 28) | p); }
+    }
+    R.n_events = (int)ev.size();
+    for (int q = 0; q < HSO_SEQ_EVENTS; q++) R.events[q] = q < (int)ev.size() ? ev[(size_t)q] : 0;
+    // ---- the pose optimiser's culling, when processFrame gets that far (:224-243)
+    const bool used_pose = R.counts[1] >= cfg->quality_min_fts && R.pose.status == 0 && !((J.flags & HSO_SEQ_SEED_BRANCH) && R.counts[1] < 100);
+    if (used_pose) for (size_t i = 0; i < ff.size(); i++) if (mask[i]) ff[i].point = -1;
+    const hso_se3 T_fin = used_pose ? R.pose.T_f_w : T_cur;
+    // ---- getSceneDepth / getSceneDistance (src/frame.cpp:323-366)
+    {
+      std::vector<double> z, r;
+      R.depth_min = std::numeric_limits<double>::max();
+      for (const hso_seq_feature& q : ff) {
+        if (q.point < 0) continue;
+        double xc[3];
+        hso_or_se3_apply(&T_fin, M->pts[(size_t)q.point].pos, xc);
+        z.push_back(xc[2]); r.push_back(std::sqrt(xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2]));
+        R.depth_min = std::fmin(xc[2], R.depth_min);
+      }
+      R.n_with_point = (int)z.size();
+      if (!z.empty()) {
+        std::nth_element(z.begin(), z.begin() + (std::ptrdiff_t)(z.size() / 2), z.end()); R.depth_median = z[z.size() / 2];
+        std::nth_element(r.begin(), r.begin() + (std::ptrdiff_t)(r.size() / 2), r.end()); R.dist_median = r[r.size() / 2];
+      }
+    }
+    // ---- createCovisibilityGraph (src/frame_handler_mono.cpp:559-647)
+    {
+      std::vector<int> votes((size_t)nk, 0);
+      for (const hso_seq_feature& q : ff) {
+        if (q.point < 0) continue;
+        const hso_map_point& P = M->pts[(size_t)q.point];
+        for (int t = 0, o = P.obs_begin; t < P.obs_count && o >= 0; t++) { votes[(size_t)M->obs[(size_t)o].kf]++; o = M->obs[(size_t)o].pad_; }
+      }
+      const int need = R.n_with_point > 30 ? 5 : 3;
+      std::vector<int> ranked; int best = -1, seen = 0;
+      for (int k = 0; k < nk; k++) {
+        if (votes[(size_t)k] == 0) continue;
+        ++seen;
+        if (best < 0 || votes[(size_t)k] > votes[(size_t)best]) best = k;
+        if (votes[(size_t)k] >= need) ranked.push_back(k);
+      }
+      if (ranked.empty() && best >= 0) ranked.push_back(best);
+      std::stable_sort(ranked.begin(), ranked.end(), [&](int a, int b) { return votes[(size_t)a] > votes[(size_t)b]; });
+      for (int q = 0; q < HSO_SEQ_MAX_COVIS; q++) { R.covis[q] = q < (int)ranked.size() ? ranked[(size_t)q] : -1; R.covis_votes[q] = q < (int)ranked.size() ? votes[(size_t)ranked[(size_t)q]] : 0; }
+      R.n_covis = seen; R.covis_best = best;
+    }
+    // ---- needNewKf's two sums (:428-507)
+    if (J.last_kf_row >= 0) {
+      const hso_kf& K = M->kfs[(size_t)J.last_kf_row];
+      hso_se3 Kinv, T_cur_kf;
+      hso_or_se3_inverse(&K.T_f_w, &Kinv);
+      hso_or_se3_mul(&T_fin, &Kinv, &T_cur_kf);
+      float full = 0, shift = 0; int count = 0;
+      for (int32_t f : M->kf_fts.at((size_t)J.last_kf_row)) {
+        const int p = M->obs_pt.at((size_t)f);
+        if (p < 0 || (HSO_PT_KEY(M->pts[(size_t)p].pad_) >> 4) == 0) continue;
+        const hso_obs& o = M->obs[(size_t)f];
+        const double* w = M->pts[(size_t)p].pos;
+        const double off[3] = {w[0] - Kinv.t[0], w[1] - Kinv.t[1], w[2] - Kinv.t[2]};
+        const double len = std::sqrt(off[0] * off[0] + off[1] * off[1] + off[2] * off[2]);
+        const double in_kf[3] = {o.f[0] * len, o.f[1] * len, o.f[2] * len};
+        double xc[3], a[2], b[2];
+        hso_or_se3_apply(&T_cur_kf, in_kf, xc);
+        hso_or_world2cam(cam, xc, a);
+        const double moved[3] = {in_kf[0] + T_cur_kf.t[0], in_kf[1] + T_cur_kf.t[1], in_kf[2] + T_cur_kf.t[2]};
+        hso_or_world2cam(cam, moved, b);
+        full += (a[0] - o.px[0]) * (a[0] - o.px[0]) + (a[1] - o.px[1]) * (a[1] - o.px[1]);
+        shift += (b[0] - o.px[0]) * (b[0] - o.px[0]) + (b[1] - o.px[1]) * (b[1] - o.px[1]);
+        ++count;
+      }
+      R.flow_full = full; R.flow_shift = shift; R.flow_count = count;
+    }
+    // ---- the new frame's table becomes the map's newest
+    const int cur_buf = ref_buf >= 0 ? 1 - ref_buf : 1 - M->ff_newest;
+    M->ff[cur_buf] = ff; M->ff_frame[cur_buf] = J.cur_frame_id; M->ff_newest = cur_buf;
   }
-  begin_out[n] = n_out;
-  return n_out;
+  c->dbg_slices[(size_t)n] = (int32_t)c->dbg_proj.size();
+  c->dbg_exbegin[(size_t)n] = (int32_t)c->dbg_brief.size();
+  return HSO_OK;
+}
+
+int hso_gpu_seq_events(hso_gpu_ctx* c, int job, int32_t* out, int cap)
+{
+  if (job < 0 || (size_t)job >= c->last_events.size() || (int)c->last_events[(size_t)job].size() > cap) return fail(c, HSO_E_INVALID, "seq_events: bad argument");
+  std::copy(c->last_events[(size_t)job].begin(), c->last_events[(size_t)job].end(), out);
+  return (int)c->last_events[(size_t)job].size();
+}
+int hso_gpu_seq_debug_list(hso_gpu_ctx* c, int job, int32_t* ids, uint8_t* q, int cap)
+{
+  if (job < 0 || (size_t)job >= c->last_ids.size() || (int)c->last_ids[(size_t)job].size() > cap) return fail(c, HSO_E_INVALID, "seq_debug_list: bad argument");
+  std::copy(c->last_ids[(size_t)job].begin(), c->last_ids[(size_t)job].end(), ids);
+  std::copy(c->last_quality[(size_t)job].begin(), c->last_quality[(size_t)job].end(), q);
+  return (int)c->last_ids[(size_t)job].size();
+}
+int hso_gpu_seq_debug_ref_table(hso_gpu_ctx* c, int job, hso_ref_feat* out, int cap)
+{
+  if (job < 0 || (size_t)job >= c->last_table.size() || (int)c->last_table[(size_t)job].size() > cap) return fail(c, HSO_E_INVALID, "seq_debug_ref_table: bad argument");
+  std::copy(c->last_table[(size_t)job].begin(), c->last_table[(size_t)job].end(), out);
+  return (int)c->last_table[(size_t)job].size();
 }
 
 void hso_gpu_debug_census(int64_t* out, int n) { for (int i = 0; i < n; i++) out[i] = 0; }   // no runtime underneath
@@ -333,6 +630,11 @@ int hso_gpu_debug_fetch(hso_gpu_ctx* c, int what, void* out, size_t bytes)
     case HSO_DBG_POSE_FEATS: src = c->dbg_feats.data(); have = c->dbg_feats.size() * sizeof(hso_pose_feat); break;
     case HSO_DBG_POSE_POSES: src = c->dbg_poses.data(); have = c->dbg_poses.size() * sizeof(hso_se3); break;
     case HSO_DBG_POSE_NPOSES: src = c->dbg_nposes.data(); have = c->dbg_nposes.size() * sizeof(int32_t); break;
+    case HSO_DBG_SLICES: src = c->dbg_slices.data(); have = c->dbg_slices.size() * sizeof(int32_t); break;
+    case HSO_DBG_EXAMINED_BEGIN: src = c->dbg_exbegin.data(); have = c->dbg_exbegin.size() * sizeof(int32_t); break;
+    case HSO_DBG_BRIEF: src = c->dbg_brief.data(); have = c->dbg_brief.size() * sizeof(hso_match_brief); break;
+    case HSO_DBG_PROJECTED: src = c->dbg_projected.data(); have = c->dbg_projected.size(); break;
+    case HSO_DBG_POSE_MASK: src = c->dbg_mask.data(); have = c->dbg_mask.size(); break;
     default: return fail(c, HSO_E_INVALID, "debug_fetch: no such table");
   }
   if (have != bytes) return fail(c, HSO_E_INVALID, "debug_fetch: size mismatch");

@@ -128,76 +128,3 @@ def test_reproject_select_rejects_bad_tables(gpu_ctx):
         gpu_ctx.reproject_select([0, 2], [0, 7], [16, 16], [1, 1], [0, 1, 2], 10)          # cell out of range
     with pytest.raises(RuntimeError):
         gpu_ctx.reproject_select([0, 2], [0, 1], [16, 16], [1, 1], [0, 1, 1], 10)          # cell_order not a permutation
-
-
-@pytest.mark.gpu
-def test_reproject_select_maps_equals_match_then_select(gpu_ctx):
-    """hso_gpu_reproject_select_maps (projection + matching + selection, nothing returned in between) against
-    hso_gpu_reproject_match_maps followed by the sequential walk on the host: the same examined candidates in the same order,
-    the same features, the same records — for three sequences in one call, budgets that end in different passes."""
-    from hso_amd import capi, synth
-    spec = synth.ICL_NUIM
-    cam = synth.camera(spec)
-    P = synth.map_problem(n_points=700, spec=spec, first_frame_id=9500)
-    Q = synth.map_problem(n_points=500, spec=spec, first_frame_id=9500, seed=72)
-    rng = np.random.default_rng(11)
-    for M in (P, Q):                                    # quality keys: type 1..4 (0 = deleted for a few), feature type 0..2
-        t = rng.integers(1, 5, size=len(M["points"])); t[rng.random(len(t)) < 0.03] = 0
-        M["points"]["pad_"] = (t << 4) | rng.integers(0, 3, size=len(t))
-    ids = [int(k["frame_id"]) for k in P["kfs"]]
-    for i, f in zip(ids, P["frames"]):
-        gpu_ctx.frame_upload(i, f)
-    gpu_ctx.frame_upload(P["cur_frame_id"], P["cur"])
-    try:
-        gpu_ctx.map_reserve(3, 16, 800, 4000)
-        gpu_ctx.map_store(0, P["kfs"], P["points"], P["obs"])
-        gpu_ctx.map_store(2, Q["kfs"], Q["points"], Q["obs"])
-        calls = np.zeros(3, capi.MAP_CALL_DTYPE)
-        q, t = P["T_cur_w"].to_arrays()
-        for c, m in enumerate((0, 2, 0)):
-            calls[c]["map"], calls[c]["cur_keyframe_id"], calls[c]["cur_frame_id"] = m, P["cur_keyframe_id"], P["cur_frame_id"]
-            calls[c]["q"], calls[c]["t"], calls[c]["cur_exposure_time"] = q, t, P["cur_exposure"]
-        calls[2]["t"] = t * 1.2
-        n_cells = P["grid_n_cols"] * int(np.ceil(spec["height"] / P["cell_size"]))
-        order = np.random.default_rng(3).permutation(n_cells).astype(np.int32)
-        full = gpu_ctx.reproject_match_maps(cam, calls, P["cell_size"], P["grid_n_cols"], 2000)
-        lo = [0, 700, 1200, 1900]
-        quality = [P["points"]["pad_"], Q["points"]["pad_"], P["points"]["pad_"]]
-        passes_seen = set()
-        for budget in (60, 250, 520):
-            got, begin, counts = gpu_ctx.reproject_select_maps(cam, calls, P["cell_size"], P["grid_n_cols"], order, budget, 2000)
-            assert begin[0] == 0 and begin[3] == len(got)
-            for c in range(3):
-                rec = full[lo[c]:lo[c + 1]]
-                cand = np.where(rec["cell"] >= 0)[0]
-                qk = quality[c][cand].astype(np.uint8)
-                flags = ((rec["success"][cand] == 1) & (rec["ref_obs"][cand] >= 0)).astype(np.uint8) | (((qk >> 4) == 0).astype(np.uint8) << 1)
-                ref, m, passes = select_reference(rec["cell"][cand], qk, flags, order, n_cells, budget)
-                passes_seen.add(passes)
-                mine = got[begin[c]:begin[c + 1]]
-                assert (counts[c, 0], counts[c, 1], counts[c, 2]) == (len(ref), m, passes), (budget, c)
-                assert [int(cand[j]) for j, _ in ref] == list(mine["pad_"])
-                assert [bool(tk) for _, tk in ref] == [bool(x) for x in mine["success"]]
-                for (j, _), r in zip(ref, mine):
-                    src = rec[cand[j]]
-                    assert (r["cell"], r["ref_obs"], r["search_level"], r["stage"]) == (src["cell"], src["ref_obs"], src["search_level"], src["stage"])
-                    assert r["px"].tobytes() == src["px"].tobytes() and r["px_cur"].tobytes() == src["px_cur"].tobytes()   # (NaN where nothing matched)
-        assert len(passes_seen) >= 2
-        # ---- the per-frame part of a stored map: the reference promotes (UNKNOWN -> GOOD) and deletes points between keyframes;
-        # hso_gpu_map_update_quality refreshes the keys alone, and the selection must follow them exactly like a re-stored map
-        q2 = P["points"]["pad_"].astype(np.uint8).copy()
-        flip = rng.random(len(q2)) < 0.3
-        q2[flip] = ((rng.integers(0, 5, size=int(flip.sum())) << 4) | (q2[flip] & 15)).astype(np.uint8)     # incl. new deletions (type 0)
-        base = gpu_ctx.reproject_select_maps(cam, calls, P["cell_size"], P["grid_n_cols"], order, 250, 2000)
-        gpu_ctx.map_update_quality([0], q2)
-        got_u, begin_u, counts_u = gpu_ctx.reproject_select_maps(cam, calls, P["cell_size"], P["grid_n_cols"], order, 250, 2000)
-        P2 = P["points"].copy(); P2["pad_"] = q2
-        gpu_ctx.map_store(0, P["kfs"], P2, P["obs"])
-        got_s, begin_s, counts_s = gpu_ctx.reproject_select_maps(cam, calls, P["cell_size"], P["grid_n_cols"], order, 250, 2000)
-        assert got_u.tobytes() == got_s.tobytes() and np.array_equal(begin_u, begin_s) and np.array_equal(counts_u, counts_s)
-        assert got_u.tobytes() != base[0].tobytes()                 # and it changed something
-        with pytest.raises(RuntimeError):
-            gpu_ctx.map_update_quality([9], q2)                     # no such map
-    finally:
-        for i in ids + [P["cur_frame_id"]]:
-            gpu_ctx.frame_release(i)
