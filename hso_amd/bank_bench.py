@@ -71,7 +71,13 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
         seqs = synth.sequences(min(distinct, n_seq), frames, spec=spec, seed0=777)
     res = [None] * n_banks
     traj = [None] * n_banks
+    threads_per_bank = [0] * n_banks
     gate = threading.Barrier(n_banks + 1)
+    # every bank sizes its worker pool to its share of the host's CPU budget (include/hso_vo.h: hso_vo_host_share)
+    from hso_amd import vo as _vo
+    _lib = _vo.load_from(lib_path) if lib_path else _vo.load()
+    _lib.hso_vo_host_share(n_banks)
+    host_quota = int(_lib.hso_vo_host_cpu_quota())
     t_end = [0.0] * n_banks
 
     def work(b):
@@ -80,6 +86,7 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
         pick = [seqs[q % len(seqs)] for q in range(n_seq)]
         m = vo.MultiVisualOdometry(cam, n_seq, max_fts, device=device, lib=vo.load_from(lib_path) if lib_path else None)
         m.set_first_frames([q["images"][0] for q in pick], [q["depth0"] for q in pick])
+        threads_per_bank[b] = int(m.lib.hso_vo_multi_threads(m.h))
         if to_device is None:
             import torch
             dev = [[torch.from_numpy(np.ascontiguousarray(im)).cuda(device) for im in q["images"]] for q in seqs]
@@ -118,6 +125,8 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
                ms_per_step_mean_per_bank=[r["ms_per_step_mean"] for r in res], ms_per_step_median_per_bank=[r["ms_per_step_median"] for r in res],
                keyframes_per_sequence=float(np.mean([r["keyframes"] for r in res])),
                failures=sum(r["failures"] for r in res), trans_err_max=max(r["trans_err_max"] for r in res))
+    out["host_cpu_quota"] = host_quota
+    out["threads_per_bank"] = threads_per_bank[0]
     if c0 and c1:   # host CPUs the process kept busy over the timed steps (incl. the banks' teardown) and CFS periods it was throttled in
         out["host_cpus_used"] = (c1[0] - c0[0]) / 1e6 / max(time.perf_counter() - t0, 1e-9)
         out["host_throttled_periods"] = [c1[1] - c0[1], c1[2] - c0[2]]

@@ -300,6 +300,7 @@ def load():
     lib.hso_gpu_last_error.restype = C.c_char_p
     lib.hso_gpu_abi_version.argtypes = []
     lib.hso_gpu_synchronize.argtypes = [vp]
+    lib.hso_gpu_set_shared_device.argtypes = [vp, i32]
     lib.hso_gpu_frame_upload.argtypes = [vp, i64, vp, i32, i32, i32, P(FrameStats)]
     lib.hso_gpu_frame_upload_resized.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, P(FrameStats)]
     lib.hso_gpu_frame_upload_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
@@ -363,7 +364,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "hso_gpu_debug_census", "hso_gpu_ba_huber_deltas_multi",
     "hso_gpu_create", "hso_gpu_destroy", "hso_gpu_last_error", "hso_gpu_abi_version",
-    "hso_gpu_synchronize", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
+    "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",

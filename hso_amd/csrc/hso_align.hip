@@ -566,10 +566,13 @@ __device__ int sel_scan256(int v, int* s_wave, int& total)
 static_assert(sizeof(hso_map_point) % 8 == 0 && sizeof(hso_obs) % 8 == 0, "rows move in 8-byte granules");
 
 // grow-only device array: new memory is filled with `fill` bytes, the first `keep` elements are carried over
-template <typename T> static int seqmap_grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need, size_t keep, int fill = 0)
+template <typename T> static int seqmap_grow(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need, size_t keep, int fill = 0, size_t min_cap = 65536)
 {
   if (*cap >= need) return HSO_OK;
-  const size_t ncap = std::max(need + need / 2, (size_t)4096);
+  // a growth = allocation + fill + copy + a wait for the stream: with one map per sequence and hundreds of sequences growing in step
+  // with their keyframes, small increments meant ten growths per step of 128 sequences.  So: room for a dozen keyframes' rows at
+  // once (a few MB per map of 288 GB), doubling after that.
+  const size_t ncap = std::max(need * 2, min_cap);
   T* q = nullptr;
   HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&q), ncap * sizeof(T)));
   hipError_t e = hipMemsetAsync(q, fill, ncap * sizeof(T), ctx->stream);
@@ -609,7 +612,7 @@ static int seqmap_upload_kfs(hso_gpu_ctx* ctx, SeqMap* m)
   const size_t n = m->kfs.size();
   if (n == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (int rc = seqmap_grow(ctx, &m->d_kfs, &m->kfs_cap, n, 0)) return rc;
+  if (int rc = seqmap_grow(ctx, &m->d_kfs, &m->kfs_cap, n, 0, 0, 256)) return rc;
   std::vector<SeqKfDev> rows(n);
   for (size_t k = 0; k < n; k++) {
     auto it = ctx->frames.find(m->kfs[k].frame_id);
@@ -801,7 +804,7 @@ int hso_gpu_seqmap_patch_lists(hso_gpu_ctx* ctx, const hso_seqmap_list_patch* pa
       if (P.first > m->n_cands) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: a patch of the candidate list must start inside it or at its end");
       for (int k = 0; k < P.n; k++) if (P.ids[k] < 0 || (size_t)P.ids[k] >= m->n_pts) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: candidate point row out of range");
       HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-      if (int rc = seqmap_grow(ctx, &m->d_cands, &m->cands_cap, (size_t)P.first + (size_t)P.n, (size_t)m->n_cands)) return rc;
+      if (int rc = seqmap_grow(ctx, &m->d_cands, &m->cands_cap, (size_t)P.first + (size_t)P.n, (size_t)m->n_cands, 0, 16384)) return rc;
     } else {
       if (P.list < 0 || (size_t)P.list >= m->kfs.size()) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: no such keyframe row");
       if (m->fts_cap < 1) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_lists: hso_gpu_seqmap_configure first");
@@ -810,7 +813,7 @@ int hso_gpu_seqmap_patch_lists(hso_gpu_ctx* ctx, const hso_seqmap_list_patch* pa
       if (m->kf_rows_cap < m->kfs.size()) {
         HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         size_t cap_el = m->kf_rows_cap * (size_t)m->fts_cap;
-        const size_t rows = m->kfs.size() + m->kfs.size() / 2 + 8;
+        const size_t rows = 2 * m->kfs.size() + 16;
         if (int rc = seqmap_grow(ctx, &m->d_kf_fts, &cap_el, rows * (size_t)m->fts_cap, cap_el)) return rc;
         m->kf_rows_cap = cap_el / (size_t)m->fts_cap;
       }

@@ -46,6 +46,7 @@ struct hso_gpu_ctx {
   hipStream_t stream;
   bool own_stream;
   int n_cu;
+  bool shared_device = false;   // hso_gpu_set_shared_device: other contexts keep the device busy beside this one
   std::string err;
   std::unordered_map<int64_t, FrameRec> frames;
   // recycled frame allocations, one free list per geometry (key = width << 32 | height; their padding rows are still zero)

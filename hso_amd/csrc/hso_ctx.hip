@@ -392,6 +392,13 @@ void hso_gpu_debug_census(int64_t* out, int n)
   for (int i = 0; i < n; i++) out[i] = i < HSO_CENSUS_N ? g_census[i].load(std::memory_order_relaxed) : 0;
 }
 
+int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared)
+{
+  if (!ctx) return HSO_E_INVALID;
+  ctx->shared_device = shared != 0;
+  return HSO_OK;
+}
+
 int hso_gpu_synchronize(hso_gpu_ctx* ctx)
 {
   if (!ctx) return HSO_E_INVALID;

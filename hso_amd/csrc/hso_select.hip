@@ -498,6 +498,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_finish(FinishArgs A, hso_
   __shared__ int s_votes[2048];
   __shared__ int s_wave[SEL_WAVES];
   __shared__ double s_min[SEL_WAVES];
+  __shared__ float s_flow_full, s_flow_shift;
+  __shared__ int s_flow_count;
   const int c = blockIdx.x, tid = threadIdx.x;
   const ChainJobDev& J = A.jobs[c];
   const ChainCur& C = A.cur[c];
@@ -567,40 +569,13 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_finish(FinishArgs A, hso_
   __threadfence_block();
   __syncthreads();
   const Se3 Tc = used_pose ? se3_from(PR.T_f_w) : se3_from(C.T_cur_w);
-  // (4a) getSceneDepth / getSceneDistance (src/frame.cpp:323-366): upper medians of depth and distance over the frame's points
+  // (4a) the number of the frame's features that kept their point, and (below, once the flow sums say the frame may become a
+  // keyframe) getSceneDepth / getSceneDistance (src/frame.cpp:323-366): upper medians of depth and distance over those points
   int n_pt = 0;
-  double zmin = 1.7976931348623157e308;
-  for (int pass = 0; pass < 2; pass++) {
-    for (int i = tid; i < FIN_SORT_N; i += SEL_THREADS) {
-      double key = 1.0 / 0.0;
-      if (i < nf && ff[i].point >= 0) {
-        const hso_map_point& P = pts[ff[i].point];
-        double x, y, z;
-        se3_apply(Tc, P.pos[0], P.pos[1], P.pos[2], x, y, z);
-        key = pass == 0 ? z : sqrt(x * x + y * y + z * z);
-        if (pass == 0) { zmin = fmin(z, zmin); }
-      }
-      s_buf[i] = key;
-    }
-    __syncthreads();
-    if (pass == 0) {
-      int mine = 0;
-      for (int i = tid; i < nf && i < FIN_SORT_N; i += SEL_THREADS) mine += ff[i].point >= 0 ? 1 : 0;
-      int tot;
-      (void)sel_block_scan(mine, s_wave, tot);
-      n_pt = tot;
-      // the minimum over the workgroup
-      double m = zmin;
-      for (int d = 32; d > 0; d >>= 1) m = fmin(m, __shfl_xor(m, d));
-      if ((tid & 63) == 0) s_min[tid >> 6] = m;
-      __syncthreads();
-      zmin = fmin(fmin(s_min[0], s_min[1]), fmin(s_min[2], s_min[3]));
-    }
-    fin_sort(s_buf);
-    if (tid == 0) {
-      const double med = n_pt > 0 ? s_buf[n_pt / 2] : 0.0;
-      if (pass == 0) { R.depth_median = med; R.depth_min = zmin; } else R.dist_median = med;
-    }
+  {
+    int mine = 0;
+    for (int i = tid; i < nf && i < FIN_SORT_N; i += SEL_THREADS) mine += ff[i].point >= 0 ? 1 : 0;
+    (void)sel_block_scan(mine, s_wave, n_pt);
     __syncthreads();
   }
   // (4b) createCovisibilityGraph (src/frame_handler_mono.cpp:559-647): a vote per observation of each of the frame's points
@@ -671,8 +646,58 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_finish(FinishArgs A, hso_
       if (tid == 64) { for (int i = 0; i < m; i++) if (t_full[i] >= 0.0) flow_shift = (float)((double)flow_shift + t_shift[i]); }
       __syncthreads();
     }
-    if (tid == 64) R.flow_shift = flow_shift;
-  } else if (tid == 64) R.flow_shift = 0.f;
+    if (tid == 64) { R.flow_shift = flow_shift; s_flow_shift = flow_shift; }
+    if (tid == 0) { s_flow_full = flow_full; s_flow_count = flow_count; }
+  } else { if (tid == 64) { R.flow_shift = 0.f; s_flow_shift = 0.f; } if (tid == 0) { s_flow_full = 0.f; s_flow_count = 0; } }
+  __syncthreads();
+  flow_full = s_flow_full; flow_count = s_flow_count;
+  // (4d) getSceneDepth / getSceneDistance — only a keyframe's are ever read (depth_filter_->addKeyframe, src/frame_handler_mono.cpp:
+  // 335-338; needNewKf ignores its depth argument): formed when the job says the frame is one for sure (the frame after the
+  // initialisation) or the flow criterion says it will be; two 4096-key sorts otherwise saved
+  bool want_depth = (J.flags & HSO_SEQ_DEPTH_STATS) != 0;
+  if (!want_depth && J.last_kf_row >= 0 && flow_count > 0) {
+    // needNewKf's test, as the caller evaluates it (:486-506)
+    float ff_full = flow_full / (float)flow_count;
+    if (!(ff_full < 133.f)) {
+      ff_full = sqrtf(ff_full);
+      const float ff_shift = sqrtf(s_flow_shift / (float)flow_count);
+      const int nominal = 752 + 480;
+      const float w_shift = 0.04 * nominal, w_full = 0.02 * nominal, w_global = 0.75;
+      const int extent = cam.width + cam.height;
+      const float score = w_global * w_shift * ff_shift / extent + w_global * w_full * ff_full / extent;
+      want_depth = score > 0.9f;                                   // a margin below the threshold of 1: the caller decides
+    }
+  }
+  if (want_depth) {
+    double zmin = 1.7976931348623157e308;
+    for (int pass = 0; pass < 2; pass++) {
+      for (int i = tid; i < FIN_SORT_N; i += SEL_THREADS) {
+        double key = 1.0 / 0.0;
+        if (i < nf && ff[i].point >= 0) {
+          const hso_map_point& P = pts[ff[i].point];
+          double x, y, z;
+          se3_apply(Tc, P.pos[0], P.pos[1], P.pos[2], x, y, z);
+          key = pass == 0 ? z : sqrt(x * x + y * y + z * z);
+          if (pass == 0) zmin = fmin(z, zmin);
+        }
+        s_buf[i] = key;
+      }
+      __syncthreads();
+      if (pass == 0) {
+        double m = zmin;
+        for (int d = 32; d > 0; d >>= 1) m = fmin(m, __shfl_xor(m, d));
+        if ((tid & 63) == 0) s_min[tid >> 6] = m;
+        __syncthreads();
+        zmin = fmin(fmin(s_min[0], s_min[1]), fmin(s_min[2], s_min[3]));
+      }
+      fin_sort(s_buf);
+      if (tid == 0) {
+        const double med = n_pt > 0 ? s_buf[n_pt / 2] : 0.0;
+        if (pass == 0) { R.depth_median = med; R.depth_min = zmin; } else R.dist_median = med;
+      }
+      __syncthreads();
+    }
+  } else if (tid == 0) { R.depth_median = 0.0; R.dist_median = 0.0; R.depth_min = -1.0; }   // depth_min < 0: not computed
   // (5) the result record
   if (tid == 0) {
     if (J.flags & HSO_SEQ_NO_TRACK) memset(&R.track, 0, sizeof(R.track)); else R.track = A.track[c];

@@ -41,6 +41,24 @@ static unsigned cpu_budget()
   return n;
 }
 
+// How many engines share this process's CPU budget (hso_vo_host_share) and how many processes share the host (LOCAL_WORLD_SIZE of a
+// torchrun launch, one rank per GPU): a bank sizes its pool to its share.  Round 4 sized every pool to the whole quota: 8 ranks x 3
+// banks x 15 workers on a 16-CPU quota would have spent the run in the CFS throttle.
+static std::atomic<int> g_host_share{1};
+void set_host_share(int banks_in_process) { g_host_share.store(std::max(1, banks_in_process)); }
+int host_cpu_budget() { return (int)cpu_budget(); }
+int pool_threads_for(int n_sequences)
+{
+  if (n_sequences <= 1) return 0;
+  if (const char* e = getenv("HSO_ENGINE_THREADS")) return std::max(0, atoi(e));
+  int ranks = 1;
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+  const int budget = (int)cpu_budget();
+  const int share = std::max(1, budget / (ranks * g_host_share.load()));
+  // the bank's own thread takes part in every phase: share - 1 workers, but at least one so that a step's phases overlap at all
+  return std::max(1, std::min(std::min(share - 1, n_sequences - 1), 31));
+}
+
 Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Settings& cfg, int n_sequences)
     : ctx_(ctx), owns_ctx_(owns_ctx), cam_(cam), cfg_(cfg)
 {
@@ -77,13 +95,9 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
       check(hso_gpu_seqmap_configure(ctx_, s->map, std::max(2000, cfg_.max_fts) + cfg_.max_fts + 128), "seqmap_configure");
     }
     check(hso_gpu_seed_table_create(ctx_, &seed_table_), "seed_table_create");
-    int n_threads = 0;
-    if (n_sequences > 1) {
-      const unsigned hc = cpu_budget();
-      n_threads = (int)std::min<unsigned>(hc > 2 ? hc - 1 : 0, std::min(n_sequences - 1, 31));
-      if (const char* e = getenv("HSO_ENGINE_THREADS")) n_threads = std::max(0, atoi(e));
-    }
-    pool_ = new Pool(n_threads);
+    if (g_host_share.load() > 1) check(hso_gpu_set_shared_device(ctx_, 1), "set_shared_device");   // throughput shapes: the other banks fill the device
+    n_threads_ = pool_threads_for(n_sequences);
+    pool_ = new Pool(n_threads_);
   } catch (...) { undo(); throw; }
 }
 

@@ -114,6 +114,9 @@ struct Seed {
 };
 
 class Pool;                       // the bookkeeping threads
+void set_host_share(int banks_in_process);   // how many banks this process runs side by side (each sizes its pool to its share)
+int pool_threads_for(int n_sequences);        // worker threads a bank of n sequences would get now
+int host_cpu_budget();                        // CPUs the process may keep busy (hardware threads, or the cgroup quota)
 
 // a grow-only array in page-locked host memory (hso_gpu_host_alloc): the result tables of the batched calls are DMA targets as they
 // are — no staging copy on the way back
@@ -157,6 +160,7 @@ public:
   Bank& operator=(const Bank&) = delete;
 
   int size() const { return (int)seq_.size(); }
+  int threads() const { return n_threads_; }
   // imgs[k] == nullptr: sequence k sits the step out
   void set_first_frames(const uint8_t* const* imgs, int w, int h, const double* stamps, const float* const* depth_z, const hso_se3* T_f_w);
   void start(const uint8_t* which);
@@ -220,6 +224,7 @@ private:
   std::vector<Seq*> seq_;
   std::vector<StepData*> step_;
   Pool* pool_ = nullptr;
+  int n_threads_ = 0;
   int seed_table_ = -1;
   int cell_size_ = 0, grid_cols_ = 0, grid_rows_ = 0;
   std::vector<int32_t> cell_order_;

@@ -279,6 +279,7 @@ void Bank::prepare_job(int k, hso_seq_job& job, std::vector<int32_t>& temps)
   job.n_ref_feats = (int32_t)s.n_feats(L);
   if (job.n_ref_feats == 0) job.flags |= HSO_SEQ_NO_TRACK;        // CoarseTracker::run returns 0 at once (src/CoarseTracker.cpp:53-54)
   if (!s.seeds.empty() && (int)s.seeds.size() > s.n_dead_seeds) job.flags |= HSO_SEQ_SEED_BRANCH;   // see consume_result: seed_path
+  if (s.after_init) job.flags |= HSO_SEQ_DEPTH_STATS;             // a keyframe for sure (:279): its scene depth is wanted
   job.cur_keyframe_id = C.kf_id;
   job.exposure_rat = C.integral / L.integral;                     // src/CoarseTracker.cpp:60
   // needNewKf looks at the flow only once three regular frames have passed (:430-437)
@@ -504,7 +505,7 @@ void Bank::decide_keyframe(int k)
   // frame_utils::getSceneDepth / getSceneDistance (src/frame.cpp:323-366).  The reference computes them for every frame
   // (src/frame_handler_mono.cpp:268-271) but only a keyframe uses them (depth_filter_->addKeyframe, :335-338; needNewKf ignores its
   // depth argument)
-  if (!d.host_pose) { d.depth_mean = d.res.depth_median; d.dist_mean = d.res.dist_median; d.depth_min = d.res.depth_min; }
+  if (!d.host_pose && d.res.depth_min >= 0.0) { d.depth_mean = d.res.depth_median; d.dist_mean = d.res.dist_median; d.depth_min = d.res.depth_min; }
   else {
     std::vector<double> z, r;
     d.depth_min = std::numeric_limits<double>::max();

@@ -77,6 +77,11 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx);
 const char* hso_gpu_last_error(const hso_gpu_ctx* ctx);
 int hso_gpu_abi_version(void);
 int hso_gpu_synchronize(hso_gpu_ctx* ctx);
+/* shared != 0: other contexts of the process keep the device busy beside this one (several banks of sequences per GPU, each on its
+ * own stream).  Batches smaller than the chip then stay on the one-workgroup-per-job kernel shapes instead of being split over the
+ * idle CUs — the other contexts' work fills those — which is what gives the best THROUGHPUT; the default (0) gives a lone batch
+ * the best LATENCY.  Results agree within the tracker's stated tolerance either way. */
+int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared);
 /* Page-locked host memory for the tables a caller hands to / receives from the entry points.  Every entry point accepts any host
  * pointer; result and input tables that live in memory from this allocator are DMA targets / sources as they are (tens of GB/s),
  * pageable memory goes through the runtime's staging copies (and its first-touch page faults) at a fraction of that — with tens
@@ -790,12 +795,14 @@ int hso_gpu_seqmap_set_key_points(hso_gpu_ctx* ctx, int map, const int32_t* key_
 
 #define HSO_SEQ_MAX_VISIT 24
 #define HSO_SEQ_MAX_COVIS 8
-#define HSO_SEQ_EVENTS 40
+#define HSO_SEQ_EVENTS 120
 enum { HSO_EV_ERASE_POINT = 1,       /* Map::safeDeletePoint (a TYPE_UNKNOWN point failed more than 15 times, reprojector.cpp:376-381) */
        HSO_EV_ERASE_CANDIDATE = 2,   /* MapPointCandidates::deleteCandidatePoint (more than 30 failures, :382-386, :214-222) */
        HSO_EV_TEMP_BAD = 3,          /* a temporary point's isBad_ (:387-390, :247-251) */
        HSO_EV_GOOD = 4 };            /* TYPE_UNKNOWN -> TYPE_GOOD (:412-416) */
-enum { HSO_SEQ_NO_TRACK = 1,         /* hso_seq_job.flags: the reference frame has no features: CoarseTracker::run returns 0 at once (CoarseTracker.cpp:53-54) */
+enum { HSO_SEQ_DEPTH_STATS = 4,      /* the frame will be a keyframe whatever the flow says (the frame after the initialisation): form depth_median / dist_median / depth_min.
+                                        Without the flag they are formed when needNewKf's flow score comes within 10 % of its threshold, else depth_min = -1 */
+       HSO_SEQ_NO_TRACK = 1,         /* hso_seq_job.flags: the reference frame has no features: CoarseTracker::run returns 0 at once (CoarseTracker.cpp:53-54) */
        HSO_SEQ_SEED_BRANCH = 2 };    /* the sequence has seeds: with fewer than 100 matches reprojectMap goes on to match them (src/reprojector.cpp:309-329),
                                         the frame's features change and the pose is optimised after that — by the caller: the chain's pose
                                         result is then informative only and its culling is NOT applied to the frame's feature table */

@@ -96,6 +96,14 @@ int hso_vo_multi_get_trajectory(hso_vo_multi* m, int sequence, double* timestamp
  * [2] tracker, [3] reprojection + matching, [4] matching alone, [5] pose, [6] seed observation, [7] seed activation, [8] local BA,
  * [9] calls without a multi-sequence form.  Returns the number of kinds. */
 int hso_vo_multi_call_counts(hso_vo_multi* m, int64_t* calls, int64_t* items, int cap);
+/* The host side of a bank is a small thread pool (per-sequence bookkeeping between the device calls).  A process that runs several
+ * banks side by side (one thread each, independent sequences shard freely within a GPU too) says so BEFORE it creates them: every
+ * bank then sizes its pool to max(1, cpu quota / (LOCAL_WORLD_SIZE * banks_in_process) - 1) workers — the CPUs the process may keep
+ * busy (hardware threads, or its cgroup's cpu.max) shared among the ranks of a node (LOCAL_WORLD_SIZE of the launcher) and its own
+ * banks.  HSO_ENGINE_THREADS overrides.  hso_vo_multi_threads: the workers a bank got; hso_vo_host_cpu_quota: the quota. */
+int hso_vo_host_share(int banks_in_process);
+int hso_vo_multi_threads(const hso_vo_multi* m);
+int hso_vo_host_cpu_quota(void);
 
 /* initialization::computeInitializeMatrix (src/initialization.cpp:300-385) alone, for tests and tools: n unit bearings per frame
  * (3 doubles each) -> T_cur_from_ref, the inlier indices (at most cap; returns their number), the triangulated points in the

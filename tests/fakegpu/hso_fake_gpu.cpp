@@ -65,6 +65,7 @@ void hso_gpu_destroy(hso_gpu_ctx* c)
 }
 const char* hso_gpu_last_error(const hso_gpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int hso_gpu_synchronize(hso_gpu_ctx*) { return HSO_OK; }
+int hso_gpu_set_shared_device(hso_gpu_ctx*, int) { return HSO_OK; }
 int hso_gpu_host_alloc(hso_gpu_ctx*, size_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? HSO_OK : HSO_E_NOMEM; }
 int hso_gpu_host_free(hso_gpu_ctx*, void* p) { free(p); return HSO_OK; }
 
