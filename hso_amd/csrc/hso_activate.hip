@@ -14,7 +14,9 @@
 // sums over targets are formed in the reference's order (see k_activate_opt), so they carry the
 // reference's rounding (the only non-IEEE step is pow(x,3) in the damping update).
 #include "hso_match_dev.h"
+#include "hso_align_dev.h"
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 using namespace hso_dev;
@@ -28,13 +30,8 @@ struct ActSeedDev {
   int32_t n_mean_converge_frame, _pad;   // DepthFilter::nMeanConvergeFrame_ of the sequence the seed belongs to
 };
 
-struct ActPairIn {
-  const uint8_t* cur_base;
-  hso_se3 T_f_w;
-  double exposure;
-  int32_t seed;
-  int32_t _pad;
-};
+struct ActPairIn { int32_t seed, frame; };   // (seed, index into the call's table of target frames)
+struct ActFrameDev { const uint8_t* base; hso_se3 T_f_w; double exposure; };
 
 struct ActPair {          // kernel 1 -> kernel 2
   int32_t is_target;      // passed the projection test (:741-769)
@@ -52,21 +49,26 @@ struct ActConsts {
   double z_min;   // depth below which the projection test fails: 0.0001 in activatePoint (:748), 0.001 in Reprojector::reprojectorSeed
 };
 
-__global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(ActConsts C, const ActSeedDev* seeds,
-                                                                              const ActPairIn* pin, int n_pairs, ActPair* pout)
+// ---- kernel 1a: one THREAD per (seed, target) pair — the projection test of activatePoint (:741-769), the parallax test of
+// findMatchSeed (src/matcher.cpp:444-449) and the matcher's job record; a pair that fails a test gets a null job.  The matching
+// itself (kernel 1b) is the reprojection matcher's kernel over these jobs (hso_align.hip: k_align_t<true>, four pairs per
+// wavefront, NCC threshold 0.8 — checkNCC(.., 0.8), :509): the first version gave every pair a wavefront of its own, whose 64 lanes
+// all repeated the fp64 geometry and whose four 16-lane rows all matched the same pair (0.74 ms per step of 128 sequences).
+__global__ __launch_bounds__(256) void k_activate_prep(ActConsts C, const ActSeedDev* seeds, const ActPairIn* pin, const ActFrameDev* frames, int n_pairs,
+                                                      ActPair* pout, AlignJobDev* jobs)
 {
-  __shared__ float s_pwb[ACT_WAVES_PER_BLOCK][100];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int pid = blockIdx.x * ACT_WAVES_PER_BLOCK + wave;
+  const int pid = blockIdx.x * 256 + threadIdx.x;
   if (pid >= n_pairs) return;
   const ActPairIn& P = pin[pid];
+  const ActFrameDev& Fr = frames[P.frame];
   const ActSeedDev& SD = seeds[P.seed];
   const hso_seed& S = SD.s;
   const int W = C.g.w[0], H = C.g.h[0];
   ActPair o;
   memset(&o, 0, sizeof(o));
+  jobs[pid].ref_base = nullptr; jobs[pid].cur_base = Fr.base;
   const Se3 Thost_inv = se3_inverse(se3_from(S.T_ref_w));
-  const Se3 Ttw = se3_from(P.T_f_w);
+  const Se3 Ttw = se3_from(Fr.T_f_w);
   const Se3 Tth = se3_mul(Ttw, Thost_inv);
   se3_to(Tth, o.Tth);
   const double sc = 1.0 / (double)S.mu;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(Act
       o.px[0] = pu; o.px[1] = pv;
     }
   }
-  if (!go) { if (lane == 0) pout[pid] = o; return; }
+  if (!go) { pout[pid] = o; return; }
   o.is_target = 1;
   // parallax test of findMatchSeed, matcher.cpp:444-449
   {
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(Act
     c0 /= cn; c1 /= cn; c2 /= cn;
     if (r0 * c0 + r1 * c1 + r2 * c2 < 0.5) go = false;
   }
-  if (!go) { if (lane == 0) pout[pid] = o; return; }
+  pout[pid] = o;
+  if (!go) return;
   hso_align_job J;
   J.ref_frame_id = S.ref_frame_id; J.ref_level = S.level; J.type = S.type;
   J.px_ref[0] = S.px[0]; J.px_ref[1] = S.px[1];
@@ -108,9 +111,20 @@ __global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(Act
   J.grad[0] = S.grad[0]; J.grad[1] = S.grad[1];
   J.T_cur_ref = o.Tth;
   J.px_cur[0] = o.px[0]; J.px_cur[1] = o.px[1];
-  J.exposure_rat = (float)(P.exposure / S.ref_exposure);
+  J.exposure_rat = (float)(Fr.exposure / S.ref_exposure);
   J.kf_gap_lt4 = 1;  // findMatchSeed compensates exposure regardless of the keyframe gap (:472-483)
-  o.mo = match_one(C.cam, C.g, P.cur_base, SD.ref_base, J, (double)0.8f, s_pwb[wave]);  // checkNCC(.., 0.8), :509
+  jobs[pid].j = J;
+  jobs[pid].ref_base = SD.ref_base;
+}
+
+// ---- kernel 1c: the pair's record for kernel 2 from the matcher's result
+__global__ __launch_bounds__(256) void k_activate_finish(ActConsts C, const ActSeedDev* seeds, const ActPairIn* pin, int n_pairs, const hso_align_out* match, ActPair* pout)
+{
+  const int pid = blockIdx.x * 256 + threadIdx.x;
+  if (pid >= n_pairs) return;
+  const hso_seed& S = seeds[pin[pid].seed].s;
+  ActPair o = pout[pid];
+  o.mo = match[pid];
   o.matched = o.mo.success;
   if (o.matched) {
     double f[3];
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(64 * ACT_WAVES_PER_BLOCK) void k_activate_match(Act
     const double nn = sqrt(n0 * n0 + n1 * n1);
     o.normal[0] = n0 / nn; o.normal[1] = n1 / nn;
   }
-  if (lane == 0) pout[pid] = o;
+  pout[pid] = o;
 }
 
 // ---- kernel 2: gates + DepthFilter::seedOptimizer, one wavefront per seed, lane = target frame.
@@ -310,65 +324,106 @@ __global__ __launch_bounds__(64 * ACT_OPT_WAVES) void k_activate_opt(ActConsts C
   if (lane == 0) outs[sid] = o;
 }
 
-// n_mean_per_seed == nullptr: every seed uses n_mean_all
+// the (seed, target frame) pairs on the device: prep -> the shared matcher -> finish; d_pout receives the pairs' records.
+// The work area `d` must hold [seeds | pairs in | frames | pairs out | jobs | match] as laid out by act_layout.
+struct ActLayout { size_t o_seeds, o_pin, o_frames, o_pout, o_jobs, o_match, o_out, need; };
+static ActLayout act_layout(int n_seeds, int n_pairs, int n_frames)
+{
+  auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+  ActLayout L;
+  L.o_seeds = 0;
+  L.o_pin = al((size_t)n_seeds * sizeof(ActSeedDev));
+  L.o_frames = L.o_pin + al((size_t)std::max(n_pairs, 1) * sizeof(ActPairIn));
+  L.o_pout = L.o_frames + al((size_t)std::max(n_frames, 1) * sizeof(ActFrameDev));
+  L.o_jobs = L.o_pout + al((size_t)std::max(n_pairs, 1) * sizeof(ActPair));
+  L.o_match = L.o_jobs + al((size_t)std::max(n_pairs, 1) * sizeof(AlignJobDev));
+  L.o_out = L.o_match + al((size_t)std::max(n_pairs, 1) * sizeof(hso_align_out));
+  L.need = L.o_out + al((size_t)n_seeds * sizeof(hso_activate_out));
+  return L;
+}
+static int act_match_pairs(hso_gpu_ctx* ctx, const hso_camera* cam, const PyrGeom& g, double z_min, char* d, const ActLayout& L, int n_pairs)
+{
+  if (n_pairs <= 0) return HSO_OK;
+  ActConsts C;
+  C.cam = *cam; C.g = g; C.z_min = z_min;
+  const ActSeedDev* d_seeds = reinterpret_cast<const ActSeedDev*>(d + L.o_seeds);
+  const ActPairIn* d_pin = reinterpret_cast<const ActPairIn*>(d + L.o_pin);
+  ActPair* d_pout = reinterpret_cast<ActPair*>(d + L.o_pout);
+  AlignJobDev* d_jobs = reinterpret_cast<AlignJobDev*>(d + L.o_jobs);
+  hso_align_out* d_match = reinterpret_cast<hso_align_out*>(d + L.o_match);
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(d_match, 0, (size_t)n_pairs * sizeof(hso_align_out), ctx->stream));
+  hipLaunchKernelGGL(k_activate_prep, dim3((n_pairs + 255) / 256), dim3(256), 0, ctx->stream, C, d_seeds, d_pin, reinterpret_cast<const ActFrameDev*>(d + L.o_frames), n_pairs,
+                     d_pout, d_jobs);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  if (int rc = hso_align_launch_sparse(ctx, cam, g, 0.8f, d_jobs, n_pairs, d_match)) return rc;
+  hipLaunchKernelGGL(k_activate_finish, dim3((n_pairs + 255) / 256), dim3(256), 0, ctx->stream, C, d_seeds, d_pin, n_pairs, d_match, d_pout);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
+}
+
+// target_frame: per pair the index into `frames` (the unique target frames of the call); n_mean_per_seed == nullptr: every seed
+// uses n_mean_all
 static int seed_activate_impl(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
-                              const int32_t* target_begin, const hso_activate_target* targets, const int32_t* n_mean_per_seed,
-                              int n_mean_all, hso_activate_out* out, hso_align_out* match_out)
+                              const int32_t* target_begin, const int32_t* target_frame, const hso_activate_target* frames, int n_frames,
+                              const int32_t* n_mean_per_seed, int n_mean_all, hso_activate_out* out, hso_align_out* match_out)
 {
   if (!ctx) return HSO_E_INVALID;
-  if (!cam || n_seeds < 0 || (n_seeds > 0 && (!seeds || !target_begin || !out))) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad argument");
+  if (!cam || n_seeds < 0 || n_frames < 0 || (n_seeds > 0 && (!seeds || !target_begin || !out))) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad argument");
   if (n_seeds == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int n_pairs = target_begin[n_seeds];
-  if (target_begin[0] != 0 || n_pairs < 0 || (n_pairs > 0 && !targets)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad target ranges");
-  std::vector<ActSeedDev> hs(n_seeds);
-  std::vector<ActPairIn> hp((size_t)n_pairs);
+  if (target_begin[0] != 0 || n_pairs < 0 || (n_pairs > 0 && (!frames || !target_frame))) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad target ranges");
+  const ActLayout L = act_layout(n_seeds, n_pairs, n_frames);
+  // the call's tables are assembled in page-locked staging (one DMA): [seeds | pairs | frames]
+  char* h = hso_pinned(ctx, 0, L.o_pout);
+  if (!h) return HSO_E_NOMEM;
+  ActSeedDev* hs = reinterpret_cast<ActSeedDev*>(h + L.o_seeds);
+  ActPairIn* hp = reinterpret_cast<ActPairIn*>(h + L.o_pin);
+  ActFrameDev* hf = reinterpret_cast<ActFrameDev*>(h + L.o_frames);
   PyrGeom g;
   bool have_g = false;
+  for (int k = 0; k < n_frames; k++) {
+    auto itt = ctx->frames.find(frames[k].frame_id);
+    if (itt == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: target frame not resident");
+    if (!have_g) { g = itt->second.g; have_g = true; }
+    if (!same_geom(itt->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
+    hf[k].base = itt->second.base; hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = frames[k].exposure;
+  }
+  int64_t last_id = -1; const uint8_t* last_base = nullptr;
   for (int i = 0; i < n_seeds; i++) {
     const int b = target_begin[i], e = target_begin[i + 1];
     if (e < b || e - b > HSO_ACTIVATE_MAX_TARGETS) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: a seed has more than HSO_ACTIVATE_MAX_TARGETS targets");
-    auto itr = ctx->frames.find(seeds[i].ref_frame_id);
-    if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: seed host frame not resident");
-    if (!have_g) { g = itr->second.g; have_g = true; }
-    if (!same_geom(itr->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
+    if (seeds[i].ref_frame_id != last_id || !last_base) {         // runs of seeds share a host keyframe
+      auto itr = ctx->frames.find(seeds[i].ref_frame_id);
+      if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: seed host frame not resident");
+      if (!have_g) { g = itr->second.g; have_g = true; }
+      if (!same_geom(itr->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
+      last_id = seeds[i].ref_frame_id; last_base = itr->second.base;
+    }
     if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad level");
-    hs[i].ref_base = itr->second.base; hs[i].s = seeds[i]; hs[i].first = b; hs[i].count = e - b;
+    hs[i].ref_base = last_base; hs[i].s = seeds[i]; hs[i].first = b; hs[i].count = e - b;
     hs[i].n_mean_converge_frame = n_mean_per_seed ? n_mean_per_seed[i] : n_mean_all; hs[i]._pad = 0;
     for (int k = b; k < e; k++) {
-      auto itt = ctx->frames.find(targets[k].frame_id);
-      if (itt == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_activate: target frame not resident");
-      if (!same_geom(itt->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: frames must share one size");
-      hp[k].cur_base = itt->second.base; hp[k].T_f_w = targets[k].T_f_w; hp[k].exposure = targets[k].exposure;
-      hp[k].seed = i; hp[k]._pad = 0;
+      if (target_frame[k] < 0 || target_frame[k] >= n_frames) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: target frame index out of range");
+      hp[k].seed = i; hp[k].frame = target_frame[k];
     }
   }
   if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: camera size differs from the frame size");
-  auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-  const size_t o_seeds = 0, o_pin = al(o_seeds + (size_t)n_seeds * sizeof(ActSeedDev));
-  const size_t o_pout = al(o_pin + (size_t)n_pairs * sizeof(ActPairIn));
-  const size_t o_out = al(o_pout + (size_t)n_pairs * sizeof(ActPair));
-  const size_t need = o_out + (size_t)n_seeds * sizeof(hso_activate_out);
-  if (ctx->batch_cap < need) {
+  if (ctx->batch_cap < L.need) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
-    ctx->batch_cap = hso_grown(need);
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(L.need)));
+    ctx->batch_cap = hso_grown(L.need);
   }
-  ActSeedDev* d_seeds = reinterpret_cast<ActSeedDev*>(ctx->d_batch + o_seeds);
-  ActPairIn* d_pin = reinterpret_cast<ActPairIn*>(ctx->d_batch + o_pin);
-  ActPair* d_pout = reinterpret_cast<ActPair*>(ctx->d_batch + o_pout);
-  hso_activate_out* d_out = reinterpret_cast<hso_activate_out*>(ctx->d_batch + o_out);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_seeds, hs.data(), (size_t)n_seeds * sizeof(ActSeedDev), hipMemcpyHostToDevice, ctx->stream));
-  if (n_pairs > 0) HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_pin, hp.data(), (size_t)n_pairs * sizeof(ActPairIn), hipMemcpyHostToDevice, ctx->stream));
+  char* d = ctx->d_batch;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, L.o_pout, hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = act_match_pairs(ctx, cam, g, 0.0001, d, L, n_pairs)) return rc;
   ActConsts C;
   C.cam = *cam; C.g = g; C.z_min = 0.0001;
-  if (n_pairs > 0) {
-    const int blocks = (n_pairs + ACT_WAVES_PER_BLOCK - 1) / ACT_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(k_activate_match, dim3(blocks), dim3(64 * ACT_WAVES_PER_BLOCK), 0, ctx->stream, C, d_seeds, d_pin, n_pairs, d_pout);
-    HSO_HIP_CHECK(ctx, hipGetLastError());
-  }
+  const ActSeedDev* d_seeds = reinterpret_cast<const ActSeedDev*>(d + L.o_seeds);
+  ActPair* d_pout = reinterpret_cast<ActPair*>(d + L.o_pout);
+  hso_activate_out* d_out = reinterpret_cast<hso_activate_out*>(d + L.o_out);
   hipLaunchKernelGGL(k_activate_opt, dim3((n_seeds + ACT_OPT_WAVES - 1) / ACT_OPT_WAVES), dim3(64 * ACT_OPT_WAVES), 0, ctx->stream, C, d_seeds, n_seeds, d_pout, d_out);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_seeds * sizeof(hso_activate_out), hipMemcpyDeviceToHost, ctx->stream));
@@ -382,11 +437,24 @@ static int seed_activate_impl(hso_gpu_ctx* ctx, const hso_camera* cam, const hso
   return HSO_OK;
 }
 
+// the per-pair form of the targets: every pair names its own frame record (table = the pairs' records, index = identity)
+static int seed_activate_pairs(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds, const int32_t* target_begin,
+                               const hso_activate_target* targets, const int32_t* n_mean_per_seed, int n_mean_all, hso_activate_out* out, hso_align_out* match_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_seeds < 0 || (n_seeds > 0 && !target_begin)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad argument");
+  const int n_pairs = n_seeds > 0 ? target_begin[n_seeds] : 0;
+  if (n_pairs < 0 || (n_pairs > 0 && !targets)) return hso_fail(ctx, HSO_E_INVALID, "seed_activate: bad target ranges");
+  std::vector<int32_t> ix((size_t)std::max(n_pairs, 0));
+  for (int k = 0; k < n_pairs; k++) ix[(size_t)k] = k;
+  return seed_activate_impl(ctx, cam, seeds, n_seeds, target_begin, ix.data(), targets, n_pairs, n_mean_per_seed, n_mean_all, out, match_out);
+}
+
 extern "C" int hso_gpu_seed_activate(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
                                      const int32_t* target_begin, const hso_activate_target* targets, int n_mean_converge_frame,
                                      hso_activate_out* out, hso_align_out* match_out)
 {
-  return seed_activate_impl(ctx, cam, seeds, n_seeds, target_begin, targets, nullptr, n_mean_converge_frame, out, match_out);
+  return seed_activate_pairs(ctx, cam, seeds, n_seeds, target_begin, targets, nullptr, n_mean_converge_frame, out, match_out);
 }
 
 extern "C" int hso_gpu_seed_activate_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds,
@@ -394,7 +462,15 @@ extern "C" int hso_gpu_seed_activate_multi(hso_gpu_ctx* ctx, const hso_camera* c
                                            const int32_t* n_mean_converge_frame, hso_activate_out* out, hso_align_out* match_out)
 {
   if (ctx && n_seeds > 0 && !n_mean_converge_frame) return hso_fail(ctx, HSO_E_INVALID, "seed_activate_multi: null n_mean_converge_frame");
-  return seed_activate_impl(ctx, cam, seeds, n_seeds, target_begin, targets, n_mean_converge_frame, 0, out, match_out);
+  return seed_activate_pairs(ctx, cam, seeds, n_seeds, target_begin, targets, n_mean_converge_frame, 0, out, match_out);
+}
+
+extern "C" int hso_gpu_seed_activate_frames(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds, const int32_t* target_begin,
+                                            const int32_t* target_frame, const hso_activate_target* frames, int n_frames,
+                                            const int32_t* n_mean_converge_frame, hso_activate_out* out)
+{
+  if (ctx && n_seeds > 0 && !n_mean_converge_frame) return hso_fail(ctx, HSO_E_INVALID, "seed_activate_frames: null n_mean_converge_frame");
+  return seed_activate_impl(ctx, cam, seeds, n_seeds, target_begin, target_frame, frames, n_frames, n_mean_converge_frame, 0, out, nullptr);
 }
 
 // Reprojector::reprojectorSeed (reference src/reprojector.cpp:504-529 for seeds: :531-554) + Matcher::findMatchSeed
@@ -412,39 +488,33 @@ extern "C" int hso_gpu_seed_reproject_match(hso_gpu_ctx* ctx, const hso_camera* 
   if (itc == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_reproject_match: current frame not resident");
   const PyrGeom g = itc->second.g;
   if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_reproject_match: camera size differs from the frame size");
-  std::vector<ActSeedDev> hs(n_seeds);
-  std::vector<ActPairIn> hp(n_seeds);
+  const ActLayout L = act_layout(n_seeds, n_seeds, 1);
+  char* h = hso_pinned(ctx, 0, L.o_pout);
+  if (!h) return HSO_E_NOMEM;
+  ActSeedDev* hs = reinterpret_cast<ActSeedDev*>(h + L.o_seeds);
+  ActPairIn* hp = reinterpret_cast<ActPairIn*>(h + L.o_pin);
+  ActFrameDev* hf = reinterpret_cast<ActFrameDev*>(h + L.o_frames);
+  hf[0].base = itc->second.base; hf[0].T_f_w = *T_cur_w; hf[0].exposure = cur_exposure;
   for (int i = 0; i < n_seeds; i++) {
     auto itr = ctx->frames.find(seeds[i].ref_frame_id);
     if (itr == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_reproject_match: seed host frame not resident");
     if (itr->second.g.w[0] != g.w[0] || itr->second.g.h[0] != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_reproject_match: frames must share one size");
     if (seeds[i].level < 0 || seeds[i].level >= HSO_N_PYR_LEVELS) return hso_fail(ctx, HSO_E_INVALID, "seed_reproject_match: bad level");
-    hs[i].ref_base = itr->second.base; hs[i].s = seeds[i]; hs[i].first = i; hs[i].count = 1;
-    hp[i].cur_base = itc->second.base; hp[i].T_f_w = *T_cur_w; hp[i].exposure = cur_exposure; hp[i].seed = i; hp[i]._pad = 0;
+    hs[i].ref_base = itr->second.base; hs[i].s = seeds[i]; hs[i].first = i; hs[i].count = 1; hs[i].n_mean_converge_frame = 0; hs[i]._pad = 0;
+    hp[i].seed = i; hp[i].frame = 0;
   }
-  auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-  const size_t o_pin = al((size_t)n_seeds * sizeof(ActSeedDev));
-  const size_t o_pout = al(o_pin + (size_t)n_seeds * sizeof(ActPairIn));
-  const size_t need = o_pout + (size_t)n_seeds * sizeof(ActPair);
-  if (ctx->batch_cap < need) {
+  if (ctx->batch_cap < L.need) {
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     ctx->d_batch = nullptr; ctx->batch_cap = 0;
-    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
-    ctx->batch_cap = hso_grown(need);
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(L.need)));
+    ctx->batch_cap = hso_grown(L.need);
   }
-  ActSeedDev* d_seeds = reinterpret_cast<ActSeedDev*>(ctx->d_batch);
-  ActPairIn* d_pin = reinterpret_cast<ActPairIn*>(ctx->d_batch + o_pin);
-  ActPair* d_pout = reinterpret_cast<ActPair*>(ctx->d_batch + o_pout);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_seeds, hs.data(), (size_t)n_seeds * sizeof(ActSeedDev), hipMemcpyHostToDevice, ctx->stream));
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_pin, hp.data(), (size_t)n_seeds * sizeof(ActPairIn), hipMemcpyHostToDevice, ctx->stream));
-  ActConsts C;
-  C.cam = *cam; C.g = g; C.z_min = 0.001;
-  hipLaunchKernelGGL(k_activate_match, dim3((n_seeds + ACT_WAVES_PER_BLOCK - 1) / ACT_WAVES_PER_BLOCK), dim3(64 * ACT_WAVES_PER_BLOCK), 0,
-                     ctx->stream, C, d_seeds, d_pin, n_seeds, d_pout);
-  HSO_HIP_CHECK(ctx, hipGetLastError());
+  char* d = ctx->d_batch;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, L.o_pout, hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = act_match_pairs(ctx, cam, g, 0.001, d, L, n_seeds)) return rc;
   std::vector<ActPair> hpo(n_seeds);
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hpo.data(), d_pout, (size_t)n_seeds * sizeof(ActPair), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hpo.data(), d + L.o_pout, (size_t)n_seeds * sizeof(ActPair), hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < n_seeds; i++) {
     hso_reproj_point r{};

@@ -17,6 +17,7 @@
 // only (stated tolerance: 1e-3 px on the result).  Instruction-issue-bound (profiles/r3_stage_sq_align.csv:
 // VALU 100 % busy with one candidate per wave), hence the packing.
 #include "hso_match_dev.h"
+#include "hso_align_dev.h"
 #include "hso_pose_dev.h"
 #include <stddef.h>
 #include <algorithm>
@@ -27,16 +28,6 @@ using namespace hso_dev;
 
 #define ALIGN_WAVES_PER_BLOCK 4
 
-struct AlignConsts {
-  hso_camera cam;
-  PyrGeom g;
-};
-
-struct AlignJobDev {
-  const uint8_t* ref_base;
-  const uint8_t* cur_base;   // the frame this candidate is searched in (jobs of many frames share a launch)
-  hso_align_job j;
-};
 
 // One wavefront matches `cpw` consecutive candidates (a power of two <= 64, chosen by the launch: 1 when the batch is small
 // enough to spread one candidate per wave over the chip, up to 64 for multi-sequence batches).  Phase 1: one LANE per candidate
@@ -65,7 +56,7 @@ __global__ __launch_bounds__(64 * ALIGN_WAVES_PER_BLOCK) void k_align_t(AlignCon
     if (jid >= n_jobs) break;
     const AlignJobDev& JD = jobs[jid];
     if (SPARSE && JD.ref_base == nullptr) continue;    // outs was zeroed
-    const hso_align_out o = match_patch(C.g, JD.cur_base, JD.ref_base, JD.j, s_geom[wave][q], (double)0.7f, s_pwb[wave][row]);  // checkNCC(…, 0.7), :364
+    const hso_align_out o = match_patch(C.g, JD.cur_base, JD.ref_base, JD.j, s_geom[wave][q], (double)C.ncc_thresh, s_pwb[wave][row]);  // checkNCC(…, 0.7), :364 (0.8 for seeds, :509)
     if ((lane & 15) == 0) outs[jid] = o;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the row's next candidate overwrites its patch
   }
@@ -85,6 +76,16 @@ static void launch_align(hso_gpu_ctx* ctx, bool sparse, const AlignConsts& C, co
   const int waves = (n + cpw - 1) / cpw, blocks = (waves + ALIGN_WAVES_PER_BLOCK - 1) / ALIGN_WAVES_PER_BLOCK;
   if (sparse) hipLaunchKernelGGL(k_align_t<true>, dim3(blocks), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream, C, d_jobs, n, d_out, cpw);
   else hipLaunchKernelGGL(k_align_t<false>, dim3(blocks), dim3(64 * ALIGN_WAVES_PER_BLOCK), 0, ctx->stream, C, d_jobs, n, d_out, cpw);
+}
+
+int hso_align_launch_sparse(hso_gpu_ctx* ctx, const hso_camera* cam, const PyrGeom& g, float ncc_thresh, const AlignJobDev* d_jobs, int n, hso_align_out* d_out)
+{
+  if (n <= 0) return HSO_OK;
+  AlignConsts C;
+  C.cam = *cam; C.g = g; C.ncc_thresh = ncc_thresh;
+  launch_align(ctx, true, C, d_jobs, n, d_out);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  return HSO_OK;
 }
 
 // cur_frame_ids: one id per job (stride 1) or one id for all jobs (stride 0)

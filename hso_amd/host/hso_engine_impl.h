@@ -413,7 +413,7 @@ struct StepData {
   std::vector<Id> moved_kfs;                   // keyframes whose pose local BA changed
   // seeds
   std::vector<int> conv;                       // indices of converged seeds
-  std::vector<hso_seed> act_seeds; std::vector<int32_t> act_begin; std::vector<hso_activate_target> act_targets; std::vector<hso_activate_out> act_out;
+  std::vector<Id> act_frames; std::vector<int32_t> act_pair_frame;   // the converged seeds' target frames, named once; per (seed, target) pair its index there
   std::vector<hso_keypoint> occupied;          // FeatureExtractor::setGridOccpuancy keys of this keyframe's observation
   std::vector<int32_t> erase_slots;
   std::vector<hso_seed> new_seeds;

@@ -323,51 +323,65 @@ void Bank::erase_slots(const std::vector<int>& who)
 // one device call, then the new candidate points
 void Bank::activate_seeds(const std::vector<int>& who)
 {
-  // pass 1 (pool): which seeds converged, and how many target frames they bring
+  // pass 1 (pool): which seeds converged, which frames they were seen in (each named once per sequence), how many pairs that makes
   std::vector<size_t> n_tg(who.size(), 0);
   pool_->run((int)who.size(), [&](int w) {
     Seq& s = *seq_[who[w]];
     StepData& d = *step_[who[w]];
-    d.conv.clear();
+    d.conv.clear(); d.act_frames.clear(); d.act_pair_frame.clear();
+    std::vector<int>& ix = s.votes;                                // scratch: frame slot -> index in this sequence's frame table
+    ix.assign(s.frames.size(), -1);
     for (size_t i = 0; i < s.seeds.size(); i++) {
       Seed& sd = s.seeds[i];
       if (!sd.alive) continue;
-      if (std::sqrt(sd.sigma2) < sd.z_range / sd.converge) { d.conv.push_back((int)i); n_tg[w] += sd.seen_before.size() + sd.seen.size(); }
+      if (std::sqrt(sd.sigma2) < sd.z_range / sd.converge) {
+        d.conv.push_back((int)i);
+        for (const std::vector<Id>* lst : {&sd.seen_before, &sd.seen})
+          for (Id fr : *lst) {
+            if (ix[(size_t)fr] < 0) { ix[(size_t)fr] = (int)d.act_frames.size(); d.act_frames.push_back(fr); }
+            d.act_pair_frame.push_back(ix[(size_t)fr]);
+          }
+      }
       else if (!sd.valid) kill_seed(s, d, (int)i, false);         // "z_min is NaN" (:494-498)
     }
+    n_tg[w] = d.act_pair_frame.size();
   });
   // where each sequence's records go in the call's tables (page-locked, kept between steps: the sequences write their parts in
-  // parallel and the tables leave as they are — the merged std::vectors of the first version were 10 MB of serial copying and a
-  // staged copy per step of 128 sequences)
-  std::vector<size_t> at(who.size() + 1, 0), tg_at(who.size() + 1, 0);
-  for (size_t w = 0; w < who.size(); w++) { at[w + 1] = at[w] + step_[who[w]]->conv.size(); tg_at[w + 1] = tg_at[w] + n_tg[w]; }
-  const size_t n_seeds = at.back(), n_targets = tg_at.back();
+  // parallel and the tables leave as they are)
+  std::vector<size_t> at(who.size() + 1, 0), tg_at(who.size() + 1, 0), fr_at(who.size() + 1, 0);
+  for (size_t w = 0; w < who.size(); w++) {
+    const StepData& d = *step_[who[w]];
+    at[w + 1] = at[w] + d.conv.size(); tg_at[w + 1] = tg_at[w] + n_tg[w]; fr_at[w + 1] = fr_at[w] + d.act_frames.size();
+  }
+  const size_t n_seeds = at.back(), n_pairs = tg_at.back(), n_frames = fr_at.back();
   hso_seed* const seeds = act_seeds_.need(ctx_, std::max(n_seeds, (size_t)1));
-  hso_activate_target* const targets = act_targets_.need(ctx_, std::max(n_targets, (size_t)1));
-  int32_t* const ints = act_ints_.need(ctx_, 2 * n_seeds + 2);     // [target_begin (n + 1) | n_mean (n)]
+  hso_activate_target* const targets = act_targets_.need(ctx_, std::max(n_frames, (size_t)1));
+  int32_t* const ints = act_ints_.need(ctx_, 2 * n_seeds + 2 + n_pairs);     // [target_begin (n + 1) | n_mean (n) | frame index per pair]
   hso_activate_out* const out = act_out_.need(ctx_, std::max(n_seeds, (size_t)1));
-  int32_t* const begin = ints; int32_t* const n_mean = ints + n_seeds + 1;
+  int32_t* const begin = ints; int32_t* const n_mean = ints + n_seeds + 1; int32_t* const pair_frame = ints + 2 * n_seeds + 1;
   begin[0] = 0;
   pool_->run((int)who.size(), [&](int w) {
     Seq& s = *seq_[who[w]];
     StepData& d = *step_[who[w]];
-    size_t t = tg_at[w];
+    for (size_t q = 0; q < d.act_frames.size(); q++) {
+      const Frame& F = s.frames[d.act_frames[q]];
+      hso_activate_target& a = targets[fr_at[w] + q];
+      a = hso_activate_target{};
+      a.frame_id = F.dev_id; a.T_f_w = F.T.v; a.exposure = F.exposure;
+    }
+    size_t t = tg_at[w], local = 0;
     for (size_t c = 0; c < d.conv.size(); c++) {
       const Seed& sd = s.seeds[d.conv[c]];
       seeds[at[w] + c] = seed_record(s, sd);
-      for (const std::vector<Id>* lst : {&sd.seen_before, &sd.seen})
-        for (Id fr : *lst) {
-          hso_activate_target& a = targets[t++];
-          a = hso_activate_target{};
-          a.frame_id = s.frames[fr].dev_id; a.T_f_w = s.frames[fr].T.v; a.exposure = s.frames[fr].exposure;
-        }
+      const size_t np = sd.seen_before.size() + sd.seen.size();
+      for (size_t q = 0; q < np; q++) pair_frame[t++] = (int32_t)fr_at[w] + d.act_pair_frame[local++];
       begin[at[w] + c + 1] = (int32_t)t;
       n_mean[at[w] + c] = (int32_t)s.n_mean_converge;
     }
   });
   if (n_seeds > 0) {
-    if (n_targets == 0) targets[0] = hso_activate_target{};
-    check(hso_gpu_seed_activate_multi(ctx_, &cam_.pod(), seeds, (int)n_seeds, begin, targets, n_mean, out, nullptr), "DepthFilter::activatePoint");
+    if (n_frames == 0) targets[0] = hso_activate_target{};
+    check(hso_gpu_seed_activate_frames(ctx_, &cam_.pod(), seeds, (int)n_seeds, begin, pair_frame, targets, (int)n_frames, n_mean, out), "DepthFilter::activatePoint");
     n_calls_[7]++; n_items_[7] += (int64_t)who.size();
   }
   pool_->run((int)who.size(), [&](int w) {
@@ -383,7 +397,9 @@ void Bank::activate_seeds(const std::vector<int>& who)
       t.begin("seed_activate", 6);
       t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("seeds", seeds + at[w], sizeof(hso_seed) * d.conv.size());
       t.field("target_begin", rel.data(), sizeof(int32_t) * rel.size());
-      t.field("targets", n_tg[w] == 0 ? &none : targets + tg_at[w], sizeof(hso_activate_target) * n_tg[w]);
+      std::vector<hso_activate_target> per_pair(n_tg[w]);           // the trace keeps the per-pair form (what the replay feeds the restatement)
+      for (size_t q = 0; q < n_tg[w]; q++) per_pair[q] = targets[pair_frame[tg_at[w] + q]];
+      t.field("targets", n_tg[w] == 0 ? &none : per_pair.data(), sizeof(hso_activate_target) * n_tg[w]);
       t.scalar("n_mean_converge_frame", (double)s.n_mean_converge); t.field("out", act_out, sizeof(hso_activate_out) * d.conv.size());
     }
     for (size_t c = 0; c < d.conv.size(); c++) {

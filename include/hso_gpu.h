@@ -672,6 +672,14 @@ int hso_gpu_seed_activate_multi(hso_gpu_ctx* ctx, const hso_camera* cam, const h
                                 const int32_t* target_begin, const hso_activate_target* targets,
                                 const int32_t* n_mean_converge_frame, hso_activate_out* out, hso_align_out* match_out);
 
+/* The same with the target frames named once: the seeds of a sequence share their few dozen target frames (Seed::optFrames_P / _A
+ * hold the frames since their keyframes), so the call takes the UNIQUE frames (`frames`, n_frames of them) and, per (seed, target)
+ * pair, an index into that table (target_frame[target_begin[i] .. target_begin[i+1])) — 4 bytes per pair instead of a 72-byte
+ * record, one frame lookup per frame instead of one per pair (77 000 pairs per step of 128 sequences). */
+int hso_gpu_seed_activate_frames(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds, const int32_t* target_begin,
+                                 const int32_t* target_frame, const hso_activate_target* frames, int n_frames,
+                                 const int32_t* n_mean_converge_frame, hso_activate_out* out);
+
 /* The seed branch of Reprojector::reprojectMap (src/reprojector.cpp:309-329): reprojectorSeed (:531-554) — pTarget =
  * (T_cur_w * T_ref_w^-1) * (f / mu), rejected when its z < 0.001 or its truncated pixel lies within 8 px of the border —
  * and Matcher::findMatchSeed (src/matcher.cpp:442-518: parallax test, warp, exposure compensation, align1D / align2D,

@@ -794,6 +794,19 @@ int hso_gpu_seed_activate_multi(hso_gpu_ctx* c, const hso_camera* cam, const hso
   return HSO_OK;
 }
 
+int hso_gpu_seed_activate_frames(hso_gpu_ctx* c, const hso_camera* cam, const hso_seed* seeds, int n, const int32_t* begin, const int32_t* target_frame,
+                                 const hso_activate_target* frames, int n_frames, const int32_t* n_mean, hso_activate_out* out)
+{
+  std::vector<hso_activate_target> t;
+  for (int i = 0; i < n; i++) {
+    t.clear();
+    for (int k = begin[i]; k < begin[i + 1]; k++) { if (target_frame[k] < 0 || target_frame[k] >= n_frames) return fail(c, HSO_E_INVALID, "seed_activate_frames: index out of range"); t.push_back(frames[target_frame[k]]); }
+    hso_activate_target none{};
+    if (int rc = activate_one(c, cam, &seeds[i], t.empty() ? &none : t.data(), (int)t.size(), n_mean[i], &out[i], nullptr)) return rc;
+  }
+  return HSO_OK;
+}
+
 int hso_gpu_seed_reproject_match(hso_gpu_ctx* c, const hso_camera* cam, int64_t cur_id, const hso_se3* T_cur_w, double cur_exposure, const hso_seed* seeds, int n,
                                  int cell_size, int grid_n_cols, hso_reproj_point* proj, hso_align_out* match)
 {

@@ -87,6 +87,8 @@ class Replayer:
         o = self.orc.Tracker(cam, p, ref["pyr"], cur["pyr"], feats).run(T0, a0)
         qg, tg = g.T_cur_ref.to_arrays(); qo, to = o.T_cur_ref.to_arrays()
         self.bump("track", "n")
+        if p.min_level == 0 and p.n_iter == 15:
+            self.bump("track", "reloc")     # relocalizeFrame's tracker (src/frame_handler_mono.cpp:366: levels 4..0, 15 iterations)
         seq = lambda x: (list(x.iters), list(x.accept_mask))
         if seq(g) == seq(o):
             assert _rot_err(qg, qo) <= 2e-6 and np.linalg.norm(tg - to) <= 8e-6

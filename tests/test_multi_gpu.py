@@ -119,3 +119,83 @@ def test_depth_filter_stream_gives_the_results_of_the_synchronous_pass(monkeypat
     inside, kfs_i, _ = run()
     assert overlapped == inside and kfs_o == kfs_i
     assert all(len(k) >= 2 for k in kfs_o) and counts["other"][0] > 10        # the pass ran (it is counted with the other calls)
+
+
+def test_bank_of_96_at_2000_features_equals_solo_runs(monkeypatch):
+    """The end-to-end figure's shape — a bank of 96 sequences at 2000 features — against the same sequences alone, status record by
+    status record.  Both runs keep the tracker on its one-workgroup-per-job shape (what a bank that shares the device runs,
+    hso_gpu_set_shared_device; a lone sequence would otherwise split its job over workgroups, whose partial sums add in another
+    order: equal within the tracker's tolerance only)."""
+    monkeypatch.setenv("HSO_TRACK_NO_COOP", "1")
+    spec = synth.EUROC
+    cam = synth.camera(spec)
+    n_frames = 18
+    seqs = [synth.sequence(n_frames, spec=spec, seed=5200 + 19 * k, step=(0.016 + 0.003 * k, 0.005, 0.007)) for k in range(4)]
+    solo = []
+    for S in seqs:
+        odo = vo.VisualOdometry(cam, 2000)
+        odo.set_first_frame(S["images"][0], S["depth0"], 0.0)
+        solo.append([_status_bytes(odo.add_image(S["images"][k], float(k))) for k in range(1, n_frames)])
+        odo.close()
+    bank = vo.MultiVisualOdometry(cam, 96, 2000)
+    pick = [seqs[q % 4] for q in range(96)]
+    bank.set_first_frames([S["images"][0] for S in pick], [S["depth0"] for S in pick])
+    for k in range(1, n_frames):
+        bank.add_images([S["images"][k] for S in pick], [float(k)] * 96)
+        for q in (0, 1, 2, 3, 49, 94, 95):
+            assert _status_bytes(bank.status(q)) == solo[q % 4][k - 1], "sequence %d (scene %d) frame %d differs from its solo run" % (q, q % 4, k)
+    assert all(bank.status(q).n_matches >= 1500 for q in range(96))
+    bank.close()
+
+
+def test_traced_sequence_inside_three_concurrent_banks_replays(orc, tmp_path):
+    """What `sequences_frames_per_s` times: three engines of 96 sequences at 2000 features side by side on one device, each on its own
+    thread / context / stream.  One sequence of the middle bank records its device calls; the trace replays through the restatement
+    under the margin rules of tests/replay.py — the concurrent banks' kernels and copies interleave with it on the device."""
+    import threading
+    from replay import Replayer
+    spec = synth.EUROC
+    cam = synth.camera(spec)
+    n_frames, n_seq = 14, 96
+    seqs = [synth.sequence(n_frames, spec=spec, seed=5300 + 23 * k, step=(0.017 + 0.002 * k, 0.005, 0.007)) for k in range(4)]
+    lib = vo.load()
+    lib.hso_vo_host_share(3)
+    trace = str(tmp_path / "trace.bin")
+    errors, last = [], [None] * 3
+    gate = threading.Barrier(3)
+
+    def work(b):
+        try:
+            m = vo.MultiVisualOdometry(cam, n_seq, 2000)
+            pick = [seqs[(q + b) % 4] for q in range(n_seq)]
+            if b == 1:
+                m.trace(37, trace)
+            m.set_first_frames([S["images"][0] for S in pick], [S["depth0"] for S in pick])
+            gate.wait()
+            for k in range(1, n_frames):
+                m.add_images([S["images"][k] for S in pick], [float(k)] * n_seq)
+            last[b] = [m.status(q) for q in range(n_seq)]
+            m.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append((b, repr(e)))
+            try:
+                gate.abort()
+            except Exception:   # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=work, args=(b,)) for b in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    lib.hso_vo_host_share(1)
+    assert not errors, errors
+    for b in range(3):
+        assert all(st.stage == 3 and st.result != 2 and st.n_matches >= 1500 for st in last[b])
+    rp = Replayer(orc)
+    for call, r in vo.read_trace(trace):
+        getattr(rp, call)(r)
+    s = rp.stat
+    print("traced sequence inside 3 x 96 x 2000:", s)
+    assert s["track"]["n"] == n_frames - 1 and s["pose"]["n"] == n_frames - 1 and s["select"]["n"] == n_frames - 1
+    assert s["reproject"]["success"] >= 0.8 * s["reproject"]["matched_calls"]
