@@ -795,7 +795,19 @@ void Bank::seed_branch(const std::vector<int>& who)
   }
   // every sequence of the branch gets its pose optimised here, over the complete feature list as the host holds it (the chain left
   // the optimiser's culling unapplied for them)
-  for (int k : who) again.push_back(k);
+  for (int k : who) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    const Frame& C = s.frames[s.cur];
+    bool any = false;
+    for (const Feat& ft : C.loose) any |= ft.point != kNone;
+    if (any) { again.push_back(k); continue; }
+    // nothing to optimise over (no feature with a point: a textureless frame): the optimiser's early return (src/pose_optimizer.cpp:456)
+    d.pose = hso_pose_result{};
+    d.pose.status = 1; d.pose.T_f_w = C.T.v;
+    d.pose_mask.assign(std::max(C.loose.size(), (size_t)1), 0);
+    d.host_pose = true;
+  }
   if (again.empty()) return;
   // pose_optimizer::optimizeLevenbergMarquardt3rd over the complete feature lists
   std::vector<std::vector<hso_pose_feat>> feats(again.size());

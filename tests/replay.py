@@ -54,8 +54,10 @@ class Replayer:
         f = self.frame(vo.scalar(r, "frame_id"))
         so = self.orc.frame_stats(f["pyr"][0], *f["sobel"][0])
         # the reference sums ~3.4e5 pixels serially in fp32 (src/frame.cpp:223-238): its own rounding walk is ~3e-5 relative;
-        # the device sums exactly
-        assert st.integral_image == pytest.approx(so.integral_image, rel=2e-4) and st.grad_mean == pytest.approx(so.grad_mean, rel=2e-4)
+        # the device sums exactly.  On a textureless image (tests/test_relocalise.py) the serial sum's rounding is systematic instead
+        # of a random walk — above 2^24 every addend of 117 rounds the same way — and the reference's own mean is off by up to 1 %
+        rel = 2e-4 if float(img.std()) > 1.0 else 1e-2
+        assert st.integral_image == pytest.approx(so.integral_image, rel=rel) and st.grad_mean == pytest.approx(so.grad_mean, rel=rel)
         self.bump("frame", "n")
 
     def klt_track(self, r):
@@ -116,7 +118,10 @@ class Replayer:
             # partial sums (3e-7): a decision no arithmetic pins
             self.bump("track", "accept_tie")
             assert m64.track_accept < 3e-6, (seq(g), seq(o), seq(r64), m64.track_accept)
-        assert _rot_err(qg, qo) <= 1e-4 and np.linalg.norm(tg - to) <= 1e-4   # both converge to the same minimum
+        # both converge to the same minimum — where there is one: against a textureless image (tests/test_relocalise.py: the frames
+        # that make the handler lose track) the photometric energy is flat and two runs that part at a tie go where rounding takes them
+        if float(cur["img"].std()) > 1.0 and float(ref["img"].std()) > 1.0:
+            assert _rot_err(qg, qo) <= 1e-4 and np.linalg.norm(tg - to) <= 1e-4
 
     def reproject_match(self, r):
         cam = capi.Camera.from_buffer_copy(r["cam"])
@@ -396,6 +401,11 @@ class Replayer:
             self.bump("seed_reproject", "n")
             assert int(proj[i]["projected"]) == o.n_targets
             if not o.n_targets:
+                continue
+            if float(cur["img"].std()) <= 1.0:
+                # a textureless current frame (tests/test_relocalise.py): its pose is wherever the tracker drifted on a flat
+                # energy, the warp of a seed seen from there is degenerate (NaN / huge determinants), and nothing can match
+                assert not match[i].success
                 continue
             assert match[i].search_level == mo[0].search_level
             if match[i].success != mo[0].success:
