@@ -60,7 +60,23 @@ def _cgroup_cpu():
         return None
 
 
-def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False, lib_path=None, to_device=None):
+def _gpu_busy_reader(device):
+    """-> a callable returning the device's busy percentage now (amdgpu sysfs), or None where the file is not there"""
+    import glob
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))
+    if not cards:
+        return None
+    path = cards[min(device, len(cards) - 1)]
+
+    def read():
+        try:
+            return float(open(path).read().strip())
+        except (OSError, ValueError):
+            return None
+    return read if read() is not None else None
+
+
+def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False, lib_path=None, to_device=None, steady_from=None):
     """n_banks engines of n_seq sequences each, every one on its own host thread with its own device context / stream: the
     device work of one bank overlaps the bookkeeping and the PCIe traffic of the others (independent sequences shard freely, also
     within one GPU).  Whole-run throughput: all frames / wall time from the first step to the last bank's last step."""
@@ -79,6 +95,12 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
     _lib.hso_vo_host_share(n_banks)
     host_quota = int(_lib.hso_vo_host_cpu_quota())
     t_end = [0.0] * n_banks
+    step_end = [None] * n_banks          # per bank: perf_counter at the end of every step
+    alg = [None] * n_banks
+    # steady state: from the step at which every sequence carries a full local-BA window and three live seed batches
+    # (Config::coreNKfs() = 7 keyframes, src/config.cpp:34; DepthFilter::Options::max_n_kfs = 3): by default the second half of the run
+    if steady_from is None:
+        steady_from = (frames - 1) // 2
 
     def work(b):
         from hso_amd import vo
@@ -95,13 +117,17 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
             dev = [[to_device(np.ascontiguousarray(im)) for im in q["images"]] for q in seqs]
         h, w = pick[0]["images"][0].shape
         gate.wait()
-        ms = []
+        ms, ends = [], []
         for k in range(1, frames):
             ptrs = [dev[q % len(seqs)][k].data_ptr() for q in range(n_seq)]
             t0 = time.perf_counter()
             m.add_images_device(ptrs, w, h, [float(k)] * n_seq)
-            ms.append(1e3 * (time.perf_counter() - t0))
+            t1 = time.perf_counter()
+            ms.append(1e3 * (t1 - t0))
+            ends.append(t1)
         t_end[b] = time.perf_counter()
+        step_end[b] = ends
+        alg[b] = m.alg_bytes()
         sts = [m.status(q) for q in range(n_seq)]
         if want_traj:
             traj[b] = [m.trajectory(q)[1] for q in range(n_seq)]
@@ -116,8 +142,22 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
     gate.wait()
     c0 = _cgroup_cpu()
     t0 = time.perf_counter()
+    busy_read = _gpu_busy_reader(device)
+    busy = []
+    if busy_read:
+        stop = threading.Event()
+
+        def sample():
+            while not stop.wait(0.02):
+                v = busy_read()
+                if v is not None:
+                    busy.append((time.perf_counter(), v))
+        sampler = threading.Thread(target=sample)
+        sampler.start()
     for t in th:
         t.join()
+    if busy_read:
+        stop.set(); sampler.join()
     wall = max(t_end) - t0
     c1 = _cgroup_cpu()
     out = dict(banks=n_banks, sequences_per_bank=n_seq, sequences=n_banks * n_seq, frames=frames - 1, max_fts=max_fts, images="device",
@@ -127,6 +167,22 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
                failures=sum(r["failures"] for r in res), trans_err_max=max(r["trans_err_max"] for r in res))
     out["host_cpu_quota"] = host_quota
     out["threads_per_bank"] = threads_per_bank[0]
+    # steady state: the window in which every bank is past step `steady_from` and none has finished
+    if all(e is not None and len(e) > steady_from + 1 for e in step_end):
+        wa, wb = max(e[steady_from] for e in step_end), min(e[-1] for e in step_end)
+        if wb > wa:
+            steps_in = sum(sum(1 for t in e if wa < t <= wb) for e in step_end)
+            out["steady_from_step"] = steady_from
+            out["steady_window_s"] = wb - wa
+            out["steady_frames_per_s"] = steps_in * n_seq / (wb - wa)
+            out["warmup_frames_per_s"] = n_banks * n_seq * steady_from / (max(e[steady_from - 1] for e in step_end) - t0) if steady_from > 0 else None
+            in_win = [v for t, v in busy if wa <= t <= wb]
+            out["steady_gpu_busy_frac"] = float(np.mean(in_win)) / 100.0 if in_win else None
+            # the algorithmic bytes of the chain's kernels over the whole run / its wall time / the HBM peak
+            tot = {k: sum(a[k] for a in alg) for k in alg[0]}
+            out["alg_bytes_per_frame"] = {k: v / (n_banks * n_seq * (frames - 1)) for k, v in tot.items()}
+            out["roofline_frac_hbm"] = sum(tot.values()) / wall / 8.0e12
+    out["gpu_busy_frac"] = float(np.mean([v for _, v in busy])) / 100.0 if busy else None
     if c0 and c1:   # host CPUs the process kept busy over the timed steps (incl. the banks' teardown) and CFS periods it was throttled in
         out["host_cpus_used"] = (c1[0] - c0[0]) / 1e6 / max(time.perf_counter() - t0, 1e-9)
         out["host_throttled_periods"] = [c1[1] - c0[1], c1[2] - c0[2]]

@@ -172,6 +172,8 @@ public:
   int trajectory(int k, double* stamps, hso_se3* T_f_w, int cap) const;
   bool trace(int k, const char* path);
   void call_counts(int64_t* calls, int64_t* items, int cap) const;
+  // algorithmic bytes (SURVEY.md section 8(d) units) of the steps so far: [frame build, tracker, matcher, pose optimiser, seeds]
+  void alg_bytes(double* out, int cap) const { for (int i = 0; i < cap && i < 5; i++) out[i] = alg_bytes_[i]; }
   std::string err;
   bool poisoned = false;
 
@@ -230,6 +232,7 @@ private:
   std::vector<int32_t> cell_order_;
   double px_error_angle_ = -1;
   int64_t n_calls_[10] = {0}, n_items_[10] = {0};
+  double alg_bytes_[5] = {0, 0, 0, 0, 0};
   double sub_ms_[4] = {0};         // HSO_ENGINE_TIMING: reproject() split into listing / device call / applying
   // the previous-frame pass between previous_begin and previous_collect
   struct PendingPrev { bool on = false, async = false; std::vector<int> who; std::vector<size_t> n_lists; int n_slots = 0;

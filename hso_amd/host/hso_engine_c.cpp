@@ -134,6 +134,7 @@ int hso_vo_multi_call_counts(hso_vo_multi* m, int64_t* calls, int64_t* items, in
   return 10;
 }
 
+int hso_vo_multi_alg_bytes(const hso_vo_multi* m, double* out, int cap) { if (!m || !out) return HSO_E_INVALID; m->bank->alg_bytes(out, cap); return 5; }
 int hso_vo_host_share(int banks_in_process) { if (banks_in_process < 1) return HSO_E_INVALID; hso::engine::set_host_share(banks_in_process); return HSO_OK; }
 int hso_vo_multi_threads(const hso_vo_multi* m) { return m ? m->bank->threads() : HSO_E_INVALID; }
 int hso_vo_host_cpu_quota(void) { return hso::engine::host_cpu_budget(); }

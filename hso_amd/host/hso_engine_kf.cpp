@@ -267,6 +267,7 @@ void Bank::observe_seeds(const std::vector<int>& who)
   check(hso_gpu_seed_table_observe_groups(ctx_, &cam_.pod(), seed_table_, frames.data(), (int)frames.size(), px_error_angle_, seed_brief_.data(),
                                           want_px ? seed_px_.data() : nullptr, tracing ? full.data() : nullptr), "DepthFilter");
   n_calls_[6]++; n_items_[6] += (int64_t)who.size();
+  alg_bytes_[4] += (double)n_live * 13.3 * 64 * 4;                 // per seed: 13.3 epipolar steps of 64 samples (the measured mean)
   par(who, [&](int k) {
     Seq& s = *seq_[k];
     StepData& d = *step_[k];

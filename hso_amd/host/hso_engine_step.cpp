@@ -402,6 +402,25 @@ void Bank::chain(const std::vector<int>& who)
       }
     if (any_trace) trace_chain(grp, jobs, cfg, res);
     pool_->run((int)grp.size(), [&](int i) { consume_result(grp[(size_t)i], res[i], more[(size_t)i]); });
+    // the algorithmic bytes of this call's work (a measurement aid: hso_vo_multi_alg_bytes)
+    {
+      static const int PA[5] = {25, 21, 13, 13, 9}, PAD[5] = {2, 3, 2, 2, 1};
+      const double wh = (double)cam_.width() * cam_.height();
+      for (size_t i = 0; i < grp.size(); i++) {
+        const hso_seq_result& r = res[i];
+        const double n = (double)jobs[i].n_ref_feats;
+        alg_bytes_[0] += (1.33 + 0.33 + 1.31 + 5.25) * wh;                      // pyramid read + written, Sobel read + written
+        for (int L = cfg.track.min_level; L <= cfg.track.max_level; L++) {
+          const double pa = PA[L], u_fwd = (2.0 * PAD[L] + 4) * (2.0 * PAD[L] + 4), u_ic = (2.0 * PAD[L] + 2) * (2.0 * PAD[L] + 2);
+          const double b_alg = mode ? n * (32 + 28 * pa + u_ic) : n * (32 + 4 * pa + u_fwd);
+          const double b_pre = mode ? n * (16 + u_fwd + 4 * pa + 24 * pa) : n * (16 + u_ic + 4 * pa);
+          const double b_sel = n * (32 + 4 * pa + u_ic);
+          if (!(jobs[i].flags & HSO_SEQ_NO_TRACK)) alg_bytes_[1] += r.track.n_eval[L] * b_alg + b_pre + b_sel;
+        }
+        alg_bytes_[2] += (double)r.n_listed * (100 * 4 + 4.2 * 64 * 4);         // per listed point: the warped patch + 4.2 LK iterations (the measured mean)
+        alg_bytes_[3] += (double)(r.pose.n_trials_total + 1) * r.n_feats * sizeof(hso_pose_feat);
+      }
+    }
   }
 }
 

@@ -57,6 +57,7 @@ def _declare(lib):
     lib.hso_vo_multi_get_keyframes.argtypes = [vp, i32, vp, vp, vp, i32]
     lib.hso_vo_multi_call_counts.argtypes = [vp, vp, vp, i32]
     lib.hso_vo_host_share.argtypes = [i32]
+    lib.hso_vo_multi_alg_bytes.argtypes = [vp, vp, i32]
     lib.hso_vo_multi_threads.argtypes = [vp]
     lib.hso_vo_host_cpu_quota.argtypes = []
     lib.hso_vo_multi_get_trajectory.argtypes = [vp, i32, vp, vp, i32]
@@ -84,7 +85,7 @@ EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso
                     "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes", "hso_vo_start", "hso_vo_init_compute_matrix",
                     "hso_vo_multi_create", "hso_vo_multi_destroy", "hso_vo_multi_last_error", "hso_vo_multi_size",
                     "hso_vo_multi_set_first_frames", "hso_vo_multi_add_images", "hso_vo_multi_get_status", "hso_vo_multi_get_keyframes",
-                    "hso_vo_multi_call_counts", "hso_vo_host_share", "hso_vo_multi_threads", "hso_vo_host_cpu_quota", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device", "hso_vo_multi_get_trajectory", "hso_vo_get_trajectory"]
+                    "hso_vo_multi_call_counts", "hso_vo_host_share", "hso_vo_multi_alg_bytes", "hso_vo_multi_threads", "hso_vo_host_cpu_quota", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device", "hso_vo_multi_get_trajectory", "hso_vo_get_trajectory"]
 
 CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_select_pose", "align", "pose", "seed_observe", "seed_activate", "ba", "other"]
 
@@ -163,6 +164,11 @@ class MultiVisualOdometry:
         ts = np.zeros(max(n, 1)); T = np.zeros((max(n, 1), 7))
         self.lib.hso_vo_multi_get_trajectory(self.h, k, ts.ctypes.data, T.ctypes.data, n)
         return ts[:n], T[:n]
+
+    def alg_bytes(self):
+        out = np.zeros(5)
+        self.lib.hso_vo_multi_alg_bytes(self.h, out.ctypes.data, 5)
+        return dict(zip(("frame", "track", "match", "pose", "seed"), [float(x) for x in out]))
 
     def call_counts(self):
         calls = np.zeros(16, np.int64); items = np.zeros(16, np.int64)

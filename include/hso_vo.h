@@ -102,6 +102,10 @@ int hso_vo_multi_call_counts(hso_vo_multi* m, int64_t* calls, int64_t* items, in
  * busy (hardware threads, or its cgroup's cpu.max) shared among the ranks of a node (LOCAL_WORLD_SIZE of the launcher) and its own
  * banks.  HSO_ENGINE_THREADS overrides.  hso_vo_multi_threads: the workers a bank got; hso_vo_host_cpu_quota: the quota. */
 int hso_vo_host_share(int banks_in_process);
+/* measurement aid: the algorithmic bytes (SURVEY.md section 8(d) units) of the steps so far, by stage: out[0] frame construction,
+ * [1] CoarseTracker (n_eval x B_alg + B_pre + B_sel per level, from the evaluation counts the kernel reports), [2] the matcher
+ * (per listed point), [3] the pose optimiser, [4] seed observation.  Returns 5. */
+int hso_vo_multi_alg_bytes(const hso_vo_multi* m, double* out, int cap);
 int hso_vo_multi_threads(const hso_vo_multi* m);
 int hso_vo_host_cpu_quota(void);
 

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 def test_bench_self_launch_and_gathers(gpus, orc, tmp_path):
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "fakegpu")])
     env = dict(os.environ, HSO_BENCH_SIDE="bench_cpu_side:CpuSide", PYTHONPATH=HERE + os.pathsep + ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
-               MASTER_ADDR="127.0.0.1", HSO_ENGINE_THREADS="1", HSO_BENCH_DETAIL=str(tmp_path / "bench_detail.json"))   # not the tracked file
+               MASTER_ADDR="127.0.0.1", HSO_BENCH_DETAIL=str(tmp_path / "bench_detail.json"))   # not the tracked file
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--batch", "4", "--scenes", "2",
            "--feats", "150", "--shape", "vga", "--cpu-frames", "0", "--sequences", "2", "--banks", "2", "--seq-feats", "60", "--seq-frames", "4", "--seq-distinct", "2", "--single", "0"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -29,6 +29,8 @@ def test_bench_self_launch_and_gathers(gpus, orc, tmp_path):
     assert len(out["per_gpu_frames_per_s"]) == gpus and out["value"] > 0 and out["unit"] == "frames/s"
     assert out["config"]["frames_per_gpu_per_step"] == 4 and out["roofline"]["frac"] > 0
     assert out["sequences_frames_per_s"] > 0 and out["sequences_failures"] == 0
+    # the host budget: every bank's pool is its share of the CPU quota (ranks of the node x banks of the process), never the whole
+    assert out["host_cpu_quota"] >= 1 and 1 <= out["threads_per_bank"] <= max(1, (5 * out["host_cpu_quota"]) // (2 * gpus * 2))
     detail = json.load(open(tmp_path / "bench_detail.json"))
     # both gathers: [world, records per rank, 8]
     assert detail["sequences"]["gathered_trajectory_shape"] == [gpus, 2 * 2 * 4, 8] and detail["sequences"]["sequences_total"] == gpus * 4
