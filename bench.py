@@ -326,6 +326,7 @@ def main():
     ap.add_argument("--native-gather", type=int, default=-1,
                     help="1: repeat the trajectory gather through libhso_gather.so (ncclAllGather from C, include/hso_vo.h) and "
                          "require it to equal the torch.distributed one; reported in bench_detail.json.  -1 (default): on when N > 1")
+    ap.add_argument("--overlap-readback", type=int, default=1, help="1: step k's result read-back is waited for after step k + 1 is enqueued (collect_begin / _end); 0: the synchronous collect")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
                          "BASELINE.json's metric is quoted on; vga: BASELINE configs[1], 640x480 pinhole")
@@ -388,13 +389,18 @@ def main():
             jobs.append(ctx.make_job(ref_ids[i], cur_ids[i], sc["feats"], capi.SE3.from_arrays(*starts[i]), a0))
         ctx.coarse_track_prepare(cam, params, jobs)
 
-        def step(k, ev=None):
+        overlap = bool(args.overlap_readback) and hasattr(ctx, "coarse_track_collect_begin")
+
+        def enqueue(k, ev=None):
             ctx.frame_upload_batch(cur_ids, device_ptrs=cur_ptrs[k & 1], width=W, height=H, want_stats=False)
             if ev is not None:
                 ev[0].record(stream)
             ctx.coarse_track_launch()
             if ev is not None:
                 ev[1].record(stream)
+
+        def step(k, ev=None):
+            enqueue(k, ev)
             return ctx.coarse_track_collect(as_list=False)   # synchronises the stream, D2H of the result records
 
         for k in range(args.warmup):
@@ -411,8 +417,19 @@ def main():
         gc.collect()
         gc.freeze()
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            res_set[k & 1] = step(k, events[k])
+        if overlap:
+            # the read-back of step k is waited for after step k + 1 has been enqueued (hso_gpu_coarse_track_collect_begin / _end): the
+            # stream never runs dry between steps; every step's records still reach the host inside the timed region
+            for k in range(args.steps):
+                enqueue(k, events[k])
+                ctx.coarse_track_collect_begin()
+                if k > 0:
+                    res_set[(k - 1) & 1] = ctx.coarse_track_collect_end(as_list=False)
+            res_set[(args.steps - 1) & 1] = ctx.coarse_track_collect_end(as_list=False)
+            stream.synchronize()
+        else:
+            for k in range(args.steps):
+                res_set[k & 1] = step(k, events[k])
         results = res_set[(args.steps - 1) & 1]
         rec = hdist.pack_records(results)
         # the path's only exchange: gather every rank's per-frame records (RCCL all_gather)

@@ -313,6 +313,8 @@ def load():
     lib.hso_gpu_coarse_track_prepare.argtypes = [vp, P(Camera), P(TrackParams), P(TrackJob), i32]
     lib.hso_gpu_coarse_track_launch.argtypes = [vp]
     lib.hso_gpu_coarse_track_collect.argtypes = [vp, P(TrackResult)]
+    lib.hso_gpu_coarse_track_collect_begin.argtypes = [vp]
+    lib.hso_gpu_coarse_track_collect_end.argtypes = [vp, P(TrackResult)]
     lib.hso_gpu_tracker_eval.argtypes = [vp, P(Camera), P(TrackParams), P(TrackJob), i32, P(SE3),
                                          C.c_float, C.c_float, C.c_float, P(EvalOut), vp, vp, vp]
     lib.hso_gpu_tracker_pattern.argtypes = [i32, i32, P(i32), P(i32), vp]
@@ -367,7 +369,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
-    "hso_gpu_coarse_track_collect", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
+    "hso_gpu_coarse_track_collect", "hso_gpu_coarse_track_collect_begin", "hso_gpu_coarse_track_collect_end", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
     "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
@@ -578,6 +580,14 @@ class Context:
         call is ~1 ms of interpreter time and feeds the garbage collector."""
         res = (TrackResult * self._n_prepared)()
         self._check(self.lib.hso_gpu_coarse_track_collect(self.h, res), "coarse_track_collect")
+        return list(res) if as_list else res
+
+    def coarse_track_collect_begin(self):
+        self._check(self.lib.hso_gpu_coarse_track_collect_begin(self.h), "coarse_track_collect_begin")
+
+    def coarse_track_collect_end(self, as_list=True):
+        res = (TrackResult * self._n_prepared)()
+        self._check(self.lib.hso_gpu_coarse_track_collect_end(self.h, res), "coarse_track_collect_end")
         return list(res) if as_list else res
 
     # -- reprojection matching

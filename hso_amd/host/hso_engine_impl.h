@@ -67,7 +67,7 @@ public:
     // no ticket is valid while the phase's fields change: a worker still looking at the finished phase's ticket (index == its n)
     // must not see the new, larger n and take that index
     ticket_.store(~uint64_t(0));
-    fn_ = &fn; n_ = n; err_ = nullptr;
+    fn_.store(&fn, std::memory_order_relaxed); n_.store(n, std::memory_order_relaxed); err_ = nullptr;
     left_.store(n);
     const uint64_t g = gen_.load() + 1;
     ticket_.store(g << 32);
@@ -75,7 +75,7 @@ public:
     if (sleepers_.load() > 0) { std::lock_guard<std::mutex> lk(m_); cv_.notify_all(); }
     drain(g);
     for (int spins = 0; left_.load(std::memory_order_acquire) != 0; spins++) { if (spins < 4096) relax(); else std::this_thread::yield(); }
-    fn_ = nullptr;
+    fn_.store(nullptr, std::memory_order_relaxed);
     if (err_) std::rethrow_exception(err_);
   }
 private:
@@ -84,9 +84,13 @@ private:
   {
     for (;;) {
       uint64_t t = ticket_.load(std::memory_order_acquire);
-      if ((t >> 32) != g || (int)(uint32_t)t >= n_) return;
+      // n_ / fn_ are read by a worker that may be late leaving the finished phase while the caller writes the next phase's values:
+      // atomics (ThreadSanitizer, profiles/r5_sanitizers.md); a stale read is harmless — the ticket's compare-exchange below only
+      // succeeds on a ticket of the worker's own generation, published after the fields
+      if ((t >> 32) != g || (int)(uint32_t)t >= n_.load(std::memory_order_relaxed)) return;
       if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
-      try { (*fn_)((int)(uint32_t)t); }
+      const std::function<void(int)>* fn = fn_.load(std::memory_order_relaxed);
+      try { (*fn)((int)(uint32_t)t); }
       catch (...) { std::lock_guard<std::mutex> lk(m_); if (!err_) err_ = std::current_exception(); }
       left_.fetch_sub(1, std::memory_order_acq_rel);
     }
@@ -116,11 +120,10 @@ private:
   std::vector<std::thread> th_;
   std::mutex m_;
   std::condition_variable cv_;
-  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<const std::function<void(int)>*> fn_{nullptr};
   std::atomic<uint64_t> ticket_{0}, gen_{0};
-  std::atomic<int> left_{0}, sleepers_{0};
+  std::atomic<int> left_{0}, sleepers_{0}, n_{0};
   std::atomic<bool> quit_{false};
-  int n_ = 0;
   long spin_us_ = 0;
   std::exception_ptr err_;
 };

@@ -17,16 +17,16 @@ void Bank::assemble_window(int k)
   std::vector<Id> core = s.local_map;
   std::sort(core.begin(), core.end(), [&](Id a, Id b) { return s.frames[a].serial < s.frames[b].serial; });
   std::vector<int> vertex(s.frames.size(), -1);
+  std::vector<uint8_t> in_window(s.points.size(), 0);
   d.ba_frames.clear(); d.ba_fixed.clear(); d.ba_points.clear(); d.ba_edges.clear(); d.ba_edge_feat.clear(); d.ba_uv.clear();
   for (Id kf : core) {
     const Frame& K = s.frames[kf];
     vertex[kf] = (int)d.ba_frames.size();
     d.ba_frames.push_back(kf);
     d.ba_fixed.push_back((K.serial == 0 || K.kf_id + 20 < C.kf_id) ? 1 : 0);   // :595
-    for (Id f : K.fts) if (s.feats[f].point != kNone) d.ba_points.push_back(s.feats[f].point);
+    for (Id f : K.fts) if (s.feats[f].point != kNone) in_window[(size_t)s.feats[f].point] = 1;
   }
-  std::sort(d.ba_points.begin(), d.ba_points.end());
-  d.ba_points.erase(std::unique(d.ba_points.begin(), d.ba_points.end()), d.ba_points.end());
+  for (size_t p = 0; p < in_window.size(); p++) if (in_window[p]) d.ba_points.push_back((Id)p);   // ascending point ids, each once
   auto vertex_of = [&](Id fr) {
     if (vertex[fr] < 0) { vertex[fr] = (int)d.ba_frames.size(); d.ba_frames.push_back(fr); d.ba_fixed.push_back(1); }   // :700-737
     return vertex[fr];
@@ -140,13 +140,29 @@ void Bank::apply_window(int k)
     Frame& K = s.frames[kf];
     K.T.v = d.ba_poses[i];
     if (!d.ba_fixed[i]) d.moved_kfs.push_back(kf);
-    for (Id c : s.candidates)                                     // MapPointCandidates::changeCandidatePosition
-      if (s.feats[s.points[c].host].frame == kf) s.place_in_host(c);
   }
   s.kfs_dirty = true;
+  // pos_ = T_host^-1 * (f / idist) of every point of the window and of the candidates hosted in its keyframes
+  // (MapPointCandidates::changeCandidatePosition): the inverse pose once per host keyframe, not once per point (16 000 points per
+  // window at 2000 features: the per-point inverse was the largest single item of a keyframe's bookkeeping)
+  std::vector<int8_t> have(s.frames.size(), 0);
+  std::vector<SE3> inv(s.frames.size());
+  auto place = [&](Id p) {
+    Point& P = s.points[p];
+    const Id h = P.host_frame;
+    if (!have[(size_t)h]) { inv[(size_t)h] = s.frames[h].T.inverse(); have[(size_t)h] = 1; }
+    const Vector3d w = inv[(size_t)h] * along(P.host_f, 1.0 / P.idist);
+    P.pos[0] = w[0]; P.pos[1] = w[1]; P.pos[2] = w[2];
+    s.touch_point(p);
+  };
+  {
+    std::vector<int8_t> core(s.frames.size(), 0);
+    for (int i = 0; i < d.n_core; i++) core[(size_t)d.ba_frames[i]] = 1;
+    for (Id c : s.candidates) if (core[(size_t)s.feats[s.points[c].host].frame]) place(c);
+  }
   for (size_t i = 0; i < d.ba_points.size(); i++) {
     s.points[d.ba_points[i]].idist = d.ba_idist[i];
-    s.place_in_host(d.ba_points[i]);
+    place(d.ba_points[i]);
   }
   const double tight = 1.2 / fmean, loose = 2.0 / fmean;
   int dropped[2] = {0, 0};

@@ -227,6 +227,12 @@ int hso_gpu_coarse_track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam,
                                  const hso_track_job* jobs, int n_jobs);
 int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx);
 int hso_gpu_coarse_track_collect(hso_gpu_ctx* ctx, hso_track_result* results);
+/* The read-back in two halves for a caller that steps a resident batch repeatedly: _begin queues the copy of the launch's result
+ * records behind it and returns at once, _end waits for the OLDEST read-back in flight (at most two) and delivers its records — the
+ * caller enqueues the next step (frame construction, launch, _begin) before it calls _end for this one, so the stream never runs
+ * dry between steps.  Batch shapes only (HSO_E_UNSUPPORTED for a cooperative launch: use hso_gpu_coarse_track_collect). */
+int hso_gpu_coarse_track_collect_begin(hso_gpu_ctx* ctx);
+int hso_gpu_coarse_track_collect_end(hso_gpu_ctx* ctx, hso_track_result* results);
 
 /* One residual + Jacobian + normal-equation evaluation
  * (precomputeReferencePatches :416-497, optional selectRobustFunctionLevel
