@@ -174,7 +174,7 @@ struct ChainJobDev {
   int slice_begin, slice_cap;  // the job's slice of the per-listed-point arrays
   int temps_begin, n_temps;
   int kf_begin;                // first row of the job's blocks in the per-keyframe arrays (ReprojKf rows, list lengths)
-  int pad_;
+  int seed_group;              // the job's group in the call's seed table, -1 none
 };
 struct ChainCur {              // what the chain's kernels hand on about a job's new frame
   hso_se3 T_cur_w;             // after CoarseTracker::run
@@ -202,6 +202,18 @@ size_t hso_chain_sizeof_reproj_kf();
 size_t hso_chain_sizeof_align_job();
 PyrGeom hso_seqmaps_geom(hso_gpu_ctx* ctx, bool* have);
 void hso_chain_forget(hso_gpu_ctx* ctx);   // hso_select.hip: drop what the last chain call of a context left (context teardown)
+// hso_seed.hip: the frame a group of a resident seed table is observed in (cur_base == null: the group sits the observation out)
+struct SeedFrameDev {
+  hso_se3 T_f_w;
+  double exposure;
+  const uint8_t* cur_base;   // resident tables: the seed's own cur_base is null and the frame's is used
+};
+// The chain's tail observes the seeds of the sequences whose frame turned out a regular one (no keyframe, enough inliers):
+// _frames gives the table's per-group frame records on the device, all set to "sits out" (asynchronous memset), for the chain's last
+// kernel to fill in; _launch then queues one observation of every live seed (hso_gpu_seed_table_observe_groups' kernels) and
+// returns where the briefs will be (device) and how many slots the table has.  Nothing here waits for the device.
+int hso_seed_table_chain_frames(hso_gpu_ctx* ctx, int table, int n_groups, SeedFrameDev** d_frames);
+int hso_seed_table_chain_launch(hso_gpu_ctx* ctx, const hso_camera* cam, int table, int n_groups, double px_error_angle, const hso_seed_brief** d_brief, int* n_slots);
 // hso_tracker.hip: the tracker over device-built feature tables (hso_track_job.feats_soa == 2: `feats` is a DEVICE pointer to the
 // kernel's layout); the result records stay on the device (*d_results).  Asynchronous for the batch shapes; a cooperative launch
 // (a batch smaller than the chip) is waited for, because its time-out fallback has to be known before the chain goes on.

@@ -28,12 +28,6 @@ using namespace hso_dev;
 #define SEED_WAVES_PER_BLOCK 2
 
 // the active frame a seed is observed in (seeds of many frames / sequences share a launch)
-struct SeedFrameDev {
-  hso_se3 T_f_w;
-  double exposure;
-  const uint8_t* cur_base;   // resident tables: the seed's own cur_base is null and the frame's is used
-};
-
 struct SeedConsts {
   hso_camera cam;
   PyrGeom g;
@@ -1299,6 +1293,38 @@ static int seed_table_observe_impl(hso_gpu_ctx* ctx, const hso_camera* cam, int 
   }
   return HSO_OK;
 }
+
+}  // extern "C"
+
+int hso_seed_table_chain_frames(hso_gpu_ctx* ctx, int table, int n_groups, SeedFrameDev** d_frames)
+{
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || n_groups <= 0) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: no such seed table");
+  if (t->max_group >= n_groups) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: a seed's group lies beyond n_seed_groups");
+  if (int rc = grow_dev(ctx, &t->d_frames, &t->frames_cap, (size_t)n_groups, 0)) return rc;
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(t->d_frames, 0, (size_t)n_groups * sizeof(SeedFrameDev), ctx->stream));   // cur_base = null: every group sits out
+  *d_frames = t->d_frames;
+  return HSO_OK;
+}
+
+int hso_seed_table_chain_launch(hso_gpu_ctx* ctx, const hso_camera* cam, int table, int n_groups, double px_error_angle, const hso_seed_brief** d_brief, int* n_slots)
+{
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: no such seed table");
+  *n_slots = (int)t->n; *d_brief = nullptr;
+  if (t->n == 0) return HSO_OK;
+  if (cam->width != t->g.w[0] || cam->height != t->g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: camera size differs from the seeds' frame size");
+  if (int rc = grow_dev(ctx, &t->d_brief, &t->brief_cap, t->n, 0)) return rc;
+  SeedConsts C;
+  C.cam = *cam; C.g = t->g; C.frames = t->d_frames; C.px_error_angle = px_error_angle; C.update_in_place = 1; C.brief = t->d_brief; C.px = nullptr; C.frame_keys = nullptr; C.n_frame_keys = 0;
+  if (int rc = seed_observe_launch(ctx, C, t->d, (int)t->n, nullptr)) return rc;
+  *d_brief = t->d_brief;
+  (void)n_groups;
+  return HSO_OK;
+}
+
+extern "C" {
 
 int hso_gpu_seed_table_observe(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const hso_seed_frame* frames, int n_frames,
                                double px_error_angle, hso_seed_brief* brief_out, hso_seed_out* full_out)

@@ -471,6 +471,7 @@ struct FinishArgs {
   const ChainJobDev* jobs; const ChainCur* cur; const hso_track_result* track; const hso_pose_result* pose; const int* counts; const int* offs;
   const hso_frame_match* records; const int32_t* ids; const uint8_t* projected; const uint8_t* mask; const int* n_feats;
   const int32_t* kf_nfts; int32_t* events; hso_seq_result* results;
+  SeedFrameDev* seed_frames;   // the seed table's per-group frame records (null: no observation chained)
   int feat_cap, quality_min_fts;
 };
 
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_finish(FinishArgs A, hso_
   // 335-338; needNewKf ignores its depth argument): formed when the job says the frame is one for sure (the frame after the
   // initialisation) or the flow criterion says it will be; two 4096-key sorts otherwise saved
   bool want_depth = (J.flags & HSO_SEQ_DEPTH_STATS) != 0;
+  bool make_kf = want_depth;
   if (!want_depth && J.last_kf_row >= 0 && flow_count > 0) {
     // needNewKf's test, as the caller evaluates it (:486-506)
     float ff_full = flow_full / (float)flow_count;
@@ -665,7 +667,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_finish(FinishArgs A, hso_
       const float w_shift = 0.04 * nominal, w_full = 0.02 * nominal, w_global = 0.75;
       const int extent = cam.width + cam.height;
       const float score = w_global * w_shift * ff_shift / extent + w_global * w_full * ff_full / extent;
-      want_depth = score > 0.9f;                                   // a margin below the threshold of 1: the caller decides
+      want_depth = score > 0.9f;                                   // a margin below the threshold of 1
+      make_kf = score > 1;                                          // needNewKf's answer (:506)
     }
   }
   if (want_depth) {
@@ -698,8 +701,19 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_finish(FinishArgs A, hso_
       __syncthreads();
     }
   } else if (tid == 0) { R.depth_median = 0.0; R.dist_median = 0.0; R.depth_min = -1.0; }   // depth_min < 0: not computed
+  // (4e) DepthFilter::addFrame for a regular frame: the sequence's seeds are observed in it (the chain's next kernels), with the
+  // pose and exposure the frame ends with — unless processFrame stops before (too few matches / inliers, :224-254), the seed branch
+  // takes over, or the frame becomes a keyframe (its local BA moves the pose first: the caller observes after that)
+  const bool observe = A.seed_frames && J.seed_group >= 0 && n_matches >= A.quality_min_fts && PR.status == 0 && PR.num_obs >= A.quality_min_fts &&
+                       !((J.flags & HSO_SEQ_SEED_BRANCH) && n_matches < 100) && !make_kf;
+  if (tid == 0 && observe) {
+    SeedFrameDev f;
+    f.T_f_w = PR.T_f_w; f.exposure = C.exposure; f.cur_base = J.cur_base;
+    A.seed_frames[J.seed_group] = f;
+  }
   // (5) the result record
   if (tid == 0) {
+    R.make_kf = make_kf ? 1 : 0; R.seeds_observed = observe ? 1 : 0;
     if (J.flags & HSO_SEQ_NO_TRACK) memset(&R.track, 0, sizeof(R.track)); else R.track = A.track[c];
     R.pose = PR;
     R.T_tracked = C.T_cur_w; R.exposure = C.exposure;
@@ -796,6 +810,8 @@ extern "C" int hso_gpu_seq_chain(hso_gpu_ctx* ctx, const hso_camera* cam, const 
     total += cap;
     J.temps_begin = jb.temps_begin; J.n_temps = jb.n_temps;
     J.kf_begin = kf_begin[(size_t)c]; kf_begin[(size_t)c + 1] = kf_begin[(size_t)c] + nk;
+    J.seed_group = cfg->seed_table >= 0 ? jb.seed_group : -1;
+    if (J.seed_group >= cfg->n_seed_groups) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: seed_group beyond n_seed_groups");
     table_doubles += 6 * (size_t)J.n_ref_stride;
     n_max_stride = std::max(n_max_stride, J.n_ref_stride);
     if (J.n_ref == 0) J.flags |= HSO_SEQ_NO_TRACK;
@@ -947,9 +963,15 @@ extern "C" int hso_gpu_seq_chain(hso_gpu_ctx* ctx, const hso_camera* cam, const 
     if (int rc = hso_pose_launch_device(ctx, cam, reinterpret_cast<const PoseJobDev*>(d + o_pj), n_jobs, feat_cap,
                                         reinterpret_cast<hso_pose_result*>(d + o_pr))) return rc;
   }
-  // ---- (4) + (5) bookkeeping, decision inputs, result records
+  // ---- (4) + (5) bookkeeping, decision inputs, result records; the regular frames' seed observation behind them
+  SeedFrameDev* d_seed_frames = nullptr;
+  if (cfg->seed_table >= 0) {
+    if (cfg->n_seed_groups <= 0 || !cfg->seed_brief_out) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: seed observation without groups or a brief table");
+    if (int rc = hso_seed_table_chain_frames(ctx, cfg->seed_table, cfg->n_seed_groups, &d_seed_frames)) return rc;
+  }
   {
     FinishArgs Fa;
+    Fa.seed_frames = d_seed_frames;
     Fa.jobs = d_jobs; Fa.cur = d_cur; Fa.track = d_track; Fa.pose = reinterpret_cast<const hso_pose_result*>(d + o_pr);
     Fa.counts = reinterpret_cast<const int*>(d + o_counts); Fa.offs = reinterpret_cast<const int*>(d + o_offs);
     Fa.records = reinterpret_cast<const hso_frame_match*>(d + o_rec); Fa.ids = A.d_ids; Fa.projected = reinterpret_cast<const uint8_t*>(d + o_flag);
@@ -960,6 +982,12 @@ extern "C" int hso_gpu_seq_chain(hso_gpu_ctx* ctx, const hso_camera* cam, const 
     HSO_HIP_CHECK(ctx, hipGetLastError());
   }
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(results, d + o_res, sizeof(hso_seq_result) * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));
+  if (cfg->seed_table >= 0) {
+    const hso_seed_brief* d_brief = nullptr; int n_slots = 0;
+    if (int rc = hso_seed_table_chain_launch(ctx, cam, cfg->seed_table, cfg->n_seed_groups, cfg->px_error_angle, &d_brief, &n_slots)) return rc;
+    if (n_slots > cfg->seed_brief_cap) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: seed_brief_out is smaller than the seed table");
+    if (n_slots > 0 && d_brief) HSO_HIP_CHECK(ctx, hipMemcpyAsync(cfg->seed_brief_out, d_brief, sizeof(hso_seed_brief) * (size_t)n_slots, hipMemcpyDeviceToHost, ctx->stream));
+  }
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (int c = 0; c < n_jobs; c++) hso_seqmap_chain_commit(ctx, jobs[c], results[c].n_feats);
   {

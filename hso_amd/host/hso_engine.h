@@ -192,6 +192,7 @@ private:
   void send_features(const std::vector<int>& who);
   void seed_branch(const std::vector<int>& who);
   void decide(int k);
+  void decide_frame(int k);
   void decide_keyframe(int k);
   bool wants_keyframe(int k);
   void link_covisible(int k, bool is_keyframe);
@@ -245,6 +246,7 @@ private:
   int64_t n_steps_ = 0, n_kf_events_ = 0;
   // result tables of the batched calls (kept between steps: no allocation per step)
   Pinned<hso_seq_result> chain_res_;   // the chain's result records
+  Pinned<hso_seed_brief> chain_brief_; // ... and the briefs of the seed observation it chained behind the regular frames (one image per tracker mode)
   Pinned<hso_seq_feature> feat_rows_;  // frame feature tables on their way to / from the device
   Pinned<double> track_tables_;
   Pinned<hso_seed> act_seeds_; Pinned<hso_activate_target> act_targets_; Pinned<int32_t> act_ints_; Pinned<hso_activate_out> act_out_;   // activate_seeds()

@@ -404,6 +404,8 @@ struct StepData {
   std::vector<Id> temps_listed;                // the temporary points the frame lists
   hso_seq_result res{};                        // the chain's result record
   bool host_pose = false;                      // the pose was optimised again over host tables (the seed branch)
+  bool seeds_observed = false;                 // the chain observed the sequence's seeds behind this frame ...
+  const hso_seed_brief* chain_brief = nullptr; // ... and this is where their briefs are (all slots of the table)
   size_t n_inliers = 0;
   double depth_mean = 0, depth_min = 0, dist_mean = 0;
   // keyframe: the local BA window

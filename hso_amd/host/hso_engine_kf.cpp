@@ -263,26 +263,33 @@ void Bank::observe_seeds(const std::vector<int>& who)
   int n_slots = 0, n_live = 0;
   check(hso_gpu_seed_table_size(ctx_, seed_table_, &n_slots, &n_live), "DepthFilter");
   if (n_slots == 0 || n_live == 0) return;
+  // the sequences whose frame was a regular one had their seeds observed behind the frame by the chain itself (hso_seq_chain_cfg:
+  // seed_table); what is left for a call here are the keyframes (observed after local BA moved their pose) and the frames whose
+  // features the host changed (the seed branch)
+  std::vector<int> rest;
+  for (int k : who) if (!step_[k]->seeds_observed) rest.push_back(k);
   std::vector<hso_seed_frame> frames(seq_.size());
   for (hso_seed_frame& f : frames) { f = hso_seed_frame{}; f.frame_id = -1; f.T_f_w = hso_se3{{0, 0, 0, 1}, {0, 0, 0}}; f.exposure_time = 1; }
   bool want_px = false, tracing = false;
-  for (int k : who) {
+  for (int k : rest) {
     const Seq& s = *seq_[k];
     const Frame& C = s.frames[s.cur];
     frames[k].frame_id = C.dev_id; frames[k].T_f_w = C.T.v; frames[k].exposure_time = C.exposure;
     want_px |= step_[k]->make_kf;
     tracing |= s.trace.on();
   }
-  seed_brief_.need(ctx_, (size_t)n_slots);
-  if (want_px) seed_px_.need(ctx_, 2 * (size_t)n_slots);
   std::vector<hso_seed> before; std::vector<hso_seed_out> full;
-  if (tracing) {
-    before.resize((size_t)n_slots); full.resize((size_t)n_slots);
-    check(hso_gpu_seed_table_read(ctx_, seed_table_, 0, n_slots, before.data()), "DepthFilter");
+  if (!rest.empty()) {
+    seed_brief_.need(ctx_, (size_t)n_slots);
+    if (want_px) seed_px_.need(ctx_, 2 * (size_t)n_slots);
+    if (tracing) {
+      before.resize((size_t)n_slots); full.resize((size_t)n_slots);
+      check(hso_gpu_seed_table_read(ctx_, seed_table_, 0, n_slots, before.data()), "DepthFilter");
+    }
+    check(hso_gpu_seed_table_observe_groups(ctx_, &cam_.pod(), seed_table_, frames.data(), (int)frames.size(), px_error_angle_, seed_brief_.data(),
+                                            want_px ? seed_px_.data() : nullptr, tracing ? full.data() : nullptr), "DepthFilter");
   }
-  check(hso_gpu_seed_table_observe_groups(ctx_, &cam_.pod(), seed_table_, frames.data(), (int)frames.size(), px_error_angle_, seed_brief_.data(),
-                                          want_px ? seed_px_.data() : nullptr, tracing ? full.data() : nullptr), "DepthFilter");
-  n_calls_[6]++; n_items_[6] += (int64_t)who.size();
+  if (!rest.empty()) { n_calls_[6]++; n_items_[6] += (int64_t)rest.size(); }
   alg_bytes_[4] += (double)n_live * 13.3 * 64 * 4;                 // per seed: 13.3 epipolar steps of 64 samples (the measured mean)
   par(who, [&](int k) {
     Seq& s = *seq_[k];
@@ -302,7 +309,7 @@ void Bank::observe_seeds(const std::vector<int>& who)
     int dbg_upd = 0, dbg_ok = 0, dbg_live = 0; double dbg_ratio = 1e9;
     for (Seed& sd : s.seeds) {
       if (!sd.alive || sd.slot < 0 || sd.slot >= n_slots) continue;
-      const hso_seed_brief& o = seed_brief_.data()[sd.slot];
+      const hso_seed_brief& o = (d.seeds_observed ? d.chain_brief : seed_brief_.data())[sd.slot];
       sd.updated = o.is_update != 0;
       dbg_live++;
       if (!sd.updated) continue;

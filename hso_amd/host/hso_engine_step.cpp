@@ -305,6 +305,9 @@ void Bank::prepare_job(int k, hso_seq_job& job, std::vector<int32_t>& temps)
     temps.push_back(p);
   }
   job.n_temps = (int32_t)d.temps_listed.size();
+  // DepthFilter::addFrame of a regular frame rides behind the frame on the device (hso_seq_chain_cfg: seed_table); a recorded run
+  // keeps the call of its own (the trace wants the seeds' records before and after)
+  job.seed_group = s.trace.on() ? -1 : s.index;
 }
 
 // what the chain reports about a frame, applied to the sequence's own tables
@@ -369,6 +372,7 @@ void Bank::chain(const std::vector<int>& who)
   std::vector<int> in;
   for (int k : who) if (!(seq_[k]->stage == kRelocalising && !step_[k]->relocalised)) in.push_back(k);
   if (in.empty()) return;
+  previous_collect();                                              // the idle-time pass of the last step, before seeds are observed again
   // the job records: serial (they append to one list of temporary points; a few dozen assignments per sequence)
   std::vector<hso_seq_job> all(in.size());
   std::vector<int32_t> temps;
@@ -381,6 +385,10 @@ void Bank::chain(const std::vector<int>& who)
   bool any_trace = false;
   for (int k : in) any_trace |= seq_[k]->trace.on();
   cfg.want_debug = any_trace ? 1 : 0;
+  int n_slots = 0, n_live = 0;
+  check(hso_gpu_seed_table_size(ctx_, seed_table_, &n_slots, &n_live), "DepthFilter");
+  hso_seed_brief* const brief_images = n_live > 0 ? chain_brief_.need(ctx_, 2 * (size_t)n_slots) : nullptr;
+  cfg.seed_table = n_live > 0 ? seed_table_ : -1; cfg.n_seed_groups = size(); cfg.px_error_angle = px_error_angle_; cfg.seed_brief_cap = n_slots;
   for (int mode = 0; mode < 2; mode++) {
     // one call per tracker mode (almost always one: the mode follows the gradient statistics of consecutive frames); inside a
     // call the sequences whose reference frame has no features come last (the tracker skips them)
@@ -390,6 +398,7 @@ void Bank::chain(const std::vector<int>& who)
         if (step_[in[i]]->inverse == mode && ((all[i].flags & HSO_SEQ_NO_TRACK) != 0) == (pass == 1)) { grp.push_back(in[i]); jobs.push_back(all[i]); }
     if (grp.empty()) continue;
     cfg.track = hso_track_params{mode, cfg_.klt_max_level, cfg_.klt_min_level + 1, 50};
+    cfg.seed_brief_out = brief_images ? brief_images + (size_t)mode * (size_t)n_slots : nullptr;
     hso_seq_result* res = chain_res_.need(ctx_, grp.size());
     check(hso_gpu_seq_chain(ctx_, &cam_.pod(), &cfg, jobs.data(), (int)jobs.size(), temps.empty() ? nullptr : temps.data(), (int)temps.size(), res), "processFrame");
     n_calls_[2]++; n_items_[2] += (int64_t)grp.size();
@@ -401,7 +410,12 @@ void Bank::chain(const std::vector<int>& who)
         check(hso_gpu_seq_events(ctx_, (int)i, more[i].data(), (int)more[i].size()), "processFrame");
       }
     if (any_trace) trace_chain(grp, jobs, cfg, res);
-    pool_->run((int)grp.size(), [&](int i) { consume_result(grp[(size_t)i], res[i], more[(size_t)i]); });
+    pool_->run((int)grp.size(), [&](int i) {
+      consume_result(grp[(size_t)i], res[i], more[(size_t)i]);
+      StepData& d = *step_[grp[(size_t)i]];
+      d.seeds_observed = res[i].seeds_observed != 0; d.chain_brief = cfg.seed_brief_out;
+    });
+    if (cfg.seed_table >= 0) { n_calls_[6]++; for (size_t i = 0; i < grp.size(); i++) n_items_[6] += res[i].seeds_observed; }
     // the algorithmic bytes of this call's work (a measurement aid: hso_vo_multi_alg_bytes)
     {
       static const int PA[5] = {25, 21, 13, 13, 9}, PAD[5] = {2, 3, 2, 2, 1};
@@ -477,6 +491,14 @@ void Bank::send_features(const std::vector<int>& who)
 // decisions FrameHandlerMono::processFrame takes from it (:224-291), up to the choice between a regular frame and a keyframe
 void Bank::decide(int k)
 {
+  decide_frame(k);
+  const StepData& d = *step_[k];
+  // the device observed the seeds exactly where this function lets the frame pass as a regular one
+  if (d.seeds_observed && !(d.ok && !d.make_kf)) throw std::logic_error("the chain observed the seeds of a frame the handler did not accept as a regular one");
+}
+
+void Bank::decide_frame(int k)
+{
   Seq& s = *seq_[k];
   StepData& d = *step_[k];
   Frame& C = s.frames[s.cur];
@@ -505,7 +527,9 @@ void Bank::decide(int k)
   if (std::min(s.n_obs_last, cfg_.max_fts) - (int)d.n_inliers > cfg_.quality_max_drop_fts) s.quality = kBad;
   if (s.quality == kInsufficient) { C.T = L.T; return; }
   d.ok = true;
-  d.make_kf = s.after_init || wants_keyframe(k);
+  // needNewKf: the chain evaluated it on the flow sums it formed (hso_seq_result.make_kf) — and let the frame's seeds be observed
+  // behind it when the answer was no; a pose the host optimised again (the seed branch) is judged here
+  d.make_kf = s.after_init || (d.host_pose ? wants_keyframe(k) : d.res.make_kf != 0);
   if (!d.make_kf) {
     // createCovisibilityGraph of a regular frame (:559-647): the ranking came with the result
     if (!d.host_pose) {

@@ -837,6 +837,8 @@ typedef struct hso_seq_job {
   int32_t covis[5];            /* ref.connectedKeyFrames as keyframe rows in list order, -1 padded (reprojector.cpp:124-170) */
   int32_t temps_begin, n_temps;/* this job's slice of the call's `temps` array: the temporary points to list (not bad, positions already placed) */
   float exposure_rat;          /* cur.integralImage_ / ref.integralImage_: the tracker's initial exposure ratio (src/CoarseTracker.cpp:60) */
+  int32_t seed_group;          /* the sequence's group in cfg.seed_table, or -1: its seeds are not observed by this call */
+  int32_t pad_;
 } hso_seq_job;
 
 typedef struct hso_seq_chain_cfg {
@@ -849,6 +851,15 @@ typedef struct hso_seq_chain_cfg {
   int32_t quality_min_fts;     /* Config::qualityMinFts(): with fewer matches processFrame gives the frame up before the pose
                                   optimiser's result is used (frame_handler_mono.cpp:224-230) — its culling is then not applied */
   int32_t want_debug;          /* 1: keep the intermediate tables for hso_gpu_debug_fetch (recorded runs) */
+  /* DepthFilter::addFrame -> updateSeeds (src/depth_filter.cpp:136-144, 330-509) chained behind the frame for the sequences whose
+   * frame is a regular one — at least quality_min_fts matches and inliers, not the seed branch, no keyframe (the chain evaluates
+   * needNewKf's score itself: hso_seq_result.make_kf): one observation of every live seed of their groups in the resident table, with
+   * the pose the frame ends with and its exposure; the briefs of ALL slots (zero for groups that sat out) come back with the results.
+   * seed_table < 0: no observation (the caller observes). */
+  int32_t seed_table, n_seed_groups;
+  double px_error_angle;       /* DepthFilter::px_error_angle_ */
+  hso_seed_brief* seed_brief_out;  /* host, seed_brief_cap entries >= the table's slots */
+  int32_t seed_brief_cap, pad_;
 } hso_seq_chain_cfg;
 
 typedef struct hso_seq_result {
@@ -866,6 +877,8 @@ typedef struct hso_seq_result {
   int32_t n_covis;             /* keyframes observing at least one of the frame's points */
   int32_t covis[HSO_SEQ_MAX_COVIS], covis_votes[HSO_SEQ_MAX_COVIS];   /* the ranking of createCovisibilityGraph: keyframe rows, best first */
   int32_t covis_best;          /* the keyframe row with the most votes (the fallback when none reaches the bar) */
+  int32_t make_kf;             /* needNewKf as the chain evaluated it (frame_handler_mono.cpp:486-506) or HSO_SEQ_DEPTH_STATS: the frame becomes a keyframe */
+  int32_t seeds_observed;      /* 1: the seeds of the job's group were observed in this frame (cfg.seed_table) */
   double depth_median, dist_median, depth_min;   /* getSceneDepth / getSceneDistance over the frame's points; depth_min = DBL_MAX when none */
   int32_t n_events;            /* kind changes of points, in the order the reference makes them; > HSO_SEQ_EVENTS: fetch them all with hso_gpu_seq_events */
   int32_t events[HSO_SEQ_EVENTS];   /* (HSO_EV_* << 28) | point row */

@@ -296,6 +296,9 @@ static void select_walk(const std::vector<Cand>& cand, const int32_t* cell_order
   counts[0] = (int)examined.size(); counts[1] = n_matches;
 }
 
+int hso_gpu_seed_table_observe_groups(hso_gpu_ctx* c, const hso_camera* cam, int t, const hso_seed_frame* frames, int n_frames, double px_error_angle,
+                                      hso_seed_brief* brief, float* px, hso_seed_out* full);
+
 // hso_gpu_seq_chain on the restatement: FrameHandlerMono::processFrame from the motion prior to the inputs of its decisions
 // (src/frame_handler_mono.cpp:173-291), one sequence after the other, every step the sequential way the reference does it.
 int hso_gpu_seq_chain(hso_gpu_ctx* c, const hso_camera* cam, const hso_seq_chain_cfg* cfg, const hso_seq_job* jobs, int n, const int32_t* temps, int,
@@ -591,12 +594,43 @@ int hso_gpu_seq_chain(hso_gpu_ctx* c, const hso_camera* cam, const hso_seq_chain
       }
       R.flow_full = full; R.flow_shift = shift; R.flow_count = count;
     }
+    // ---- needNewKf's answer (:486-506) and whether the frame's seeds are observed behind it (a regular frame: DepthFilter::addFrame)
+    {
+      bool make_kf = (J.flags & HSO_SEQ_DEPTH_STATS) != 0;
+      if (!make_kf && J.last_kf_row >= 0 && R.flow_count > 0) {
+        float ff_full = R.flow_full / (float)R.flow_count;
+        if (!(ff_full < 133.f)) {
+          ff_full = sqrtf(ff_full);
+          const float ff_shift = sqrtf(R.flow_shift / (float)R.flow_count);
+          const int nominal = 752 + 480;
+          const float w_shift = 0.04 * nominal, w_full = 0.02 * nominal, w_global = 0.75;
+          const int extent = cam->width + cam->height;
+          const float score = w_global * w_shift * ff_shift / extent + w_global * w_full * ff_full / extent;
+          make_kf = score > 1;
+        }
+      }
+      R.make_kf = make_kf ? 1 : 0;
+      const bool observe = cfg->seed_table >= 0 && J.seed_group >= 0 && R.counts[1] >= cfg->quality_min_fts && R.pose.status == 0 && R.pose.num_obs >= cfg->quality_min_fts &&
+                           !((J.flags & HSO_SEQ_SEED_BRANCH) && R.counts[1] < 100) && !make_kf;
+      R.seeds_observed = observe ? 1 : 0;
+    }
     // ---- the new frame's table becomes the map's newest
     const int cur_buf = ref_buf >= 0 ? 1 - ref_buf : 1 - M->ff_newest;
     M->ff[cur_buf] = ff; M->ff_frame[cur_buf] = J.cur_frame_id; M->ff_newest = cur_buf;
   }
   c->dbg_slices[(size_t)n] = (int32_t)c->dbg_proj.size();
   c->dbg_exbegin[(size_t)n] = (int32_t)c->dbg_brief.size();
+  if (cfg->seed_table >= 0) {
+    std::vector<hso_seed_frame> fr((size_t)cfg->n_seed_groups);
+    for (hso_seed_frame& f : fr) { f = hso_seed_frame{}; f.frame_id = -1; f.T_f_w = hso_se3{{0, 0, 0, 1}, {0, 0, 0}}; f.exposure_time = 1; }
+    for (int j = 0; j < n; j++) {
+      if (!results[j].seeds_observed) continue;
+      hso_seed_frame& f = fr[(size_t)jobs[j].seed_group];
+      f.frame_id = jobs[j].cur_frame_id; f.T_f_w = results[j].pose.T_f_w; f.exposure_time = results[j].exposure;
+    }
+    if ((int)c->tables[cfg->seed_table]->s.size() > cfg->seed_brief_cap) return fail(c, HSO_E_INVALID, "seq_chain: seed_brief_out is smaller than the seed table");
+    if (int rc = hso_gpu_seed_table_observe_groups(c, cam, cfg->seed_table, fr.data(), cfg->n_seed_groups, cfg->px_error_angle, cfg->seed_brief_out, nullptr, nullptr)) return rc;
+  }
   return HSO_OK;
 }
 
