@@ -101,6 +101,7 @@ hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind
 hipError_t hso_memset_async(void* dst, int value, size_t bytes, hipStream_t stream);   // counted (hso_gpu_debug_census)
 hipError_t hso_stream_sync(hipStream_t stream);
 void hso_stream_forget(hipStream_t stream);   // context teardown: free the stream's staging chunks
+void hso_stream_set_yielding(hipStream_t stream, bool on);   // waits on the stream sleep (blocking event) instead of polling
 void hso_stream_abandon(hipStream_t stream);  // error path: wait for the stream, then DROP the pending copies into caller memory
                                               // (the entry point returns an error; the caller may free its buffers at once)
 #ifndef HSO_RAW_HIP_COPIES

@@ -16,6 +16,8 @@ struct StageFix { void* dst; const char* src; size_t bytes, dpitch, width, heigh
 struct Stager {
   std::vector<StageChunk> chunks;
   std::vector<StageFix> fixes;      // device-to-host copies to finish after the next synchronisation
+  bool yield = false;               // hso_stream_set_yielding: waits on this stream sleep instead of polling
+  hipEvent_t wait_ev = nullptr;     // ... through this event (hipEventBlockingSync)
 };
 std::mutex g_stage_mutex;
 std::unordered_map<hipStream_t, Stager> g_stagers;
@@ -101,10 +103,38 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
   return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream);
 }
 
+// A context that shares the device with others (several banks of sequences per GPU) waits for its stream many times per step, and the
+// runtime's hipStreamSynchronize polls: six banks waiting = six of the host's CPUs spent polling while the pools that do the
+// bookkeeping compete for the rest of a 16-CPU quota.  A yielding stream waits on an event created with hipEventBlockingSync instead:
+// the thread sleeps until the interrupt (a few tens of microseconds later than a poll would notice — nothing against a multi-
+// millisecond step whose device time the other banks fill anyway).
+void hso_stream_set_yielding(hipStream_t stream, bool on)
+{
+  std::lock_guard<std::mutex> lk(g_stage_mutex);
+  g_stagers[stream].yield = on;
+}
+
+static hipError_t stream_wait(hipStream_t stream)
+{
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_stage_mutex);
+    auto it = g_stagers.find(stream);
+    if (it != g_stagers.end() && it->second.yield) {
+      if (!it->second.wait_ev && hipEventCreateWithFlags(&it->second.wait_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) it->second.wait_ev = nullptr;
+      ev = it->second.wait_ev;
+    }
+  }
+  if (!ev) return hipStreamSynchronize(stream);
+  hipError_t e = hipEventRecord(ev, stream);
+  if (e == hipSuccess) e = hipEventSynchronize(ev);
+  return e;
+}
+
 hipError_t hso_stream_sync(hipStream_t stream)
 {
   const auto t0 = std::chrono::steady_clock::now();
-  const hipError_t e = hipStreamSynchronize(stream);
+  const hipError_t e = stream_wait(stream);
   census(HSO_CENSUS_SYNCS);
   census(HSO_CENSUS_SYNC_NS, std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
   std::lock_guard<std::mutex> lk(g_stage_mutex);
@@ -146,6 +176,7 @@ void hso_stream_forget(hipStream_t stream)
   auto it = g_stagers.find(stream);
   if (it == g_stagers.end()) return;
   for (StageChunk& c : it->second.chunks) (void)hipHostFree(c.p);
+  if (it->second.wait_ev) (void)hipEventDestroy(it->second.wait_ev);
   g_stagers.erase(it);
 }
 
@@ -396,6 +427,7 @@ int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared)
 {
   if (!ctx) return HSO_E_INVALID;
   ctx->shared_device = shared != 0;
+  hso_stream_set_yielding(ctx->stream, ctx->shared_device && !getenv("HSO_POLLING_SYNC"));
   return HSO_OK;
 }
 

@@ -1166,7 +1166,7 @@ int hso_gpu_seed_table_erase(hso_gpu_ctx* ctx, int table, const int32_t* slots, 
   hipLaunchKernelGGL(k_seed_mark_dead, dim3((unsigned)((dead.size() + 255) / 256)), dim3(256), 0, ctx->stream, t->d, reinterpret_cast<const int32_t*>(ctx->d_batch),
                      (int)dead.size());
   HSO_HIP_CHECK(ctx, hipGetLastError());
-  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // no wait: the slot list was staged by the copy wrapper, nothing comes back, and every reader of the table runs on this stream
   return HSO_OK;
 }
 

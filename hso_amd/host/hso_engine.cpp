@@ -54,11 +54,13 @@ int pool_threads_for(int n_sequences)
   int ranks = 1;
   if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
   const int budget = (int)cpu_budget(), banks = g_host_share.load();
-  // Workers sleep between a step's phases and while the bank waits for the device, so the pools together may hold about 2.5 x the
+  // Workers sleep between a step's phases and while the bank waits for the device, so the pools together may hold about 3.5 x the
   // budget before the scheduler's quota bites (measured on the 16-CPU GPU boxes, 120-frame runs at 2000 features: 4 banks x 9
   // workers 20.2 k frames/s against 16.8 k with 6 and 15.8 k with 3; 6 banks x 7: 22.0 k against 17.6 k with 4; 6 x 15: 20.0 k with
   // 38 of 75 scheduler periods throttled).  A lone bank keeps one CPU for its own thread.
-  const int workers = banks * ranks == 1 ? budget - 1 : (5 * budget) / (2 * ranks * banks);
+  // (With the banks' own threads asleep while they wait for the device — hso_gpu_set_shared_device — 6 banks x 9 workers gave
+  // 24.7 k over the whole run / 22.9 k in the steady state, 8 x 7 24.8 k / 20.3 k: 3.5 x the budget.)
+  const int workers = banks * ranks == 1 ? budget - 1 : (7 * budget) / (2 * ranks * banks);
   return std::max(1, std::min(std::min(workers, n_sequences - 1), 31));
 }
 
