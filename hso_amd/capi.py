@@ -335,6 +335,8 @@ def load():
     lib.hso_gpu_seed_activate_multi.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), P(i32), P(ActivateOut),
                                                 P(AlignOut)]
     lib.hso_gpu_seed_observe.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, C.c_double, P(Seed), i32, P(SeedOut)]
+    lib.hso_gpu_seed_activate_frames.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(i32), P(ActivateTarget), i32, P(i32), P(ActivateOut)]
+    lib.hso_gpu_seed_table_activate.argtypes = [vp, P(Camera), i32, P(i32), i32, P(i32), P(i32), P(ActivateTarget), i32, P(i32), P(ActivateOut)]
     lib.hso_gpu_seed_observe_multi.argtypes = [vp, P(Camera), P(SeedFrame), i32, vp, C.c_double, P(Seed), i32, P(SeedOut)]
     lib.hso_gpu_seed_activate.argtypes = [vp, P(Camera), P(Seed), i32, P(i32), P(ActivateTarget), i32, P(ActivateOut),
                                           P(AlignOut)]
@@ -375,7 +377,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
     "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize", "hso_gpu_ba_optimize_multi",
-    "hso_gpu_seed_activate_multi", "hso_gpu_seed_activate_frames", "hso_gpu_reproject_select",
+    "hso_gpu_seed_activate_multi", "hso_gpu_seed_activate_frames", "hso_gpu_seed_table_activate", "hso_gpu_reproject_select",
     "hso_gpu_seed_reproject_match",
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
@@ -930,6 +932,35 @@ class Context:
         self._check(self.lib.hso_gpu_seed_activate_multi(self.h, C.byref(cam), sarr, len(seeds),
                                                          begin.ctypes.data_as(C.POINTER(C.c_int32)), tarr,
                                                          nm.ctypes.data_as(C.POINTER(C.c_int32)), out, None), "seed_activate_multi")
+        return list(out)
+
+    def _activate_tables(self, targets_per_seed, frames, n_mean_converge_frame, n):
+        begin = np.zeros(n + 1, np.int32)
+        begin[1:] = np.cumsum([len(t) for t in targets_per_seed])
+        pair = np.ascontiguousarray([q for ts in targets_per_seed for q in ts] or [0], np.int32)
+        farr = (ActivateTarget * max(len(frames), 1))(*frames)
+        nm = np.ascontiguousarray(n_mean_converge_frame, np.int32)
+        assert len(nm) == n and len(targets_per_seed) == n
+        return begin, pair, farr, nm
+
+    def seed_activate_frames(self, cam, seeds, targets_per_seed, frames, n_mean_converge_frame):
+        """targets_per_seed[i]: indices into `frames` (the unique target frames of the call)."""
+        begin, pair, farr, nm = self._activate_tables(targets_per_seed, frames, n_mean_converge_frame, len(seeds))
+        sarr = (Seed * len(seeds))(*seeds)
+        out = (ActivateOut * len(seeds))()
+        i32p = C.POINTER(C.c_int32)
+        self._check(self.lib.hso_gpu_seed_activate_frames(self.h, C.byref(cam), sarr, len(seeds), begin.ctypes.data_as(i32p), pair.ctypes.data_as(i32p),
+                                                          farr, len(frames), nm.ctypes.data_as(i32p), out), "seed_activate_frames")
+        return list(out)
+
+    def seed_table_activate(self, cam, table, slots, targets_per_seed, frames, n_mean_converge_frame):
+        """The same for seeds named by their slots in a resident seed table."""
+        sl = np.ascontiguousarray(slots, np.int32)
+        begin, pair, farr, nm = self._activate_tables(targets_per_seed, frames, n_mean_converge_frame, len(sl))
+        out = (ActivateOut * len(sl))()
+        i32p = C.POINTER(C.c_int32)
+        self._check(self.lib.hso_gpu_seed_table_activate(self.h, C.byref(cam), table, sl.ctypes.data_as(i32p), len(sl), begin.ctypes.data_as(i32p),
+                                                         pair.ctypes.data_as(i32p), farr, len(frames), nm.ctypes.data_as(i32p), out), "seed_table_activate")
         return list(out)
 
     def tracker_eval(self, cam, params, job, level, T, exposure_rat, huber=-1.0, outlier=-1.0,

@@ -437,6 +437,93 @@ static int seed_activate_impl(hso_gpu_ctx* ctx, const hso_camera* cam, const hso
   return HSO_OK;
 }
 
+// ---- activation by slots: the seeds are rows of a resident seed table (hso_seed.hip) ----
+struct ActSlotIn { int32_t slot, first, count, n_mean; };
+// one thread per seed: its record from the table's row, its pairs' (seed, frame) records from the 16-bit frame indices
+static __global__ void k_activate_expand(const char* __restrict__ rows, size_t stride, size_t seed_offset, const ActSlotIn* __restrict__ in,
+                                         const uint16_t* __restrict__ pair_frame, int n_seeds, ActSeedDev* __restrict__ seeds, ActPairIn* __restrict__ pairs,
+                                         const ActFrameDev* __restrict__ frames_in, ActFrameDev* __restrict__ frames_out, int n_frames)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_frames) frames_out[i] = frames_in[i];                 // the frame table moves to its place in the layout
+  if (i >= n_seeds) return;
+  const ActSlotIn a = in[i];
+  const char* row = rows + (size_t)a.slot * stride;
+  ActSeedDev r;
+  r.ref_base = *reinterpret_cast<const uint8_t* const*>(row);
+  r.s = *reinterpret_cast<const hso_seed*>(row + seed_offset);
+  r.first = a.first; r.count = a.count; r.n_mean_converge_frame = a.n_mean; r._pad = 0;
+  seeds[i] = r;
+  for (int k = a.first; k < a.first + a.count; k++) { ActPairIn p; p.seed = i; p.frame = (int32_t)pair_frame[k]; pairs[k] = p; }
+}
+
+extern "C" int hso_gpu_seed_table_activate(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int32_t* slots, int n_seeds, const int32_t* target_begin,
+                                           const int32_t* target_frame, const hso_activate_target* frames, int n_frames,
+                                           const int32_t* n_mean_converge_frame, hso_activate_out* out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!cam || n_seeds < 0 || n_frames < 0 || n_frames > 65536 || (n_seeds > 0 && (!slots || !target_begin || !n_mean_converge_frame || !out)))
+    return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: bad argument");
+  if (n_seeds == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int n_pairs = target_begin[n_seeds];
+  if (target_begin[0] != 0 || n_pairs < 0 || (n_pairs > 0 && (!frames || !target_frame))) return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: bad target ranges");
+  const char* rows = nullptr; size_t stride = 0, seed_offset = 0; PyrGeom g;
+  if (int rc = hso_seed_table_rows(ctx, table, slots, n_seeds, &rows, &stride, &seed_offset, &g)) return rc;
+  const ActLayout L = act_layout(n_seeds, n_pairs, n_frames);
+  // what crosses the bus: [frames | (slot, first, count, n_mean) per seed | 16-bit frame index per pair]
+  auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const size_t o_in = al((size_t)std::max(n_frames, 1) * sizeof(ActFrameDev)), o_pf = o_in + al((size_t)n_seeds * sizeof(ActSlotIn));
+  const size_t up_bytes = o_pf + al((size_t)std::max(n_pairs, 1) * sizeof(uint16_t));
+  char* h = hso_pinned(ctx, 0, up_bytes);
+  if (!h) return HSO_E_NOMEM;
+  ActFrameDev* hf = reinterpret_cast<ActFrameDev*>(h);
+  ActSlotIn* hin = reinterpret_cast<ActSlotIn*>(h + o_in);
+  uint16_t* hpf = reinterpret_cast<uint16_t*>(h + o_pf);
+  for (int k = 0; k < n_frames; k++) {
+    auto itt = ctx->frames.find(frames[k].frame_id);
+    if (itt == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seed_table_activate: target frame not resident");
+    if (!same_geom(itt->second.g, g)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: frames must share one size");
+    hf[k].base = itt->second.base; hf[k].T_f_w = frames[k].T_f_w; hf[k].exposure = frames[k].exposure;
+  }
+  for (int i = 0; i < n_seeds; i++) {
+    const int b = target_begin[i], e = target_begin[i + 1];
+    if (e < b || e - b > HSO_ACTIVATE_MAX_TARGETS) return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: a seed has more than HSO_ACTIVATE_MAX_TARGETS targets");
+    hin[i].slot = slots[i]; hin[i].first = b; hin[i].count = e - b; hin[i].n_mean = n_mean_converge_frame[i];
+    for (int k = b; k < e; k++) {
+      if (target_frame[k] < 0 || target_frame[k] >= n_frames) return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: target frame index out of range");
+      hpf[k] = (uint16_t)target_frame[k];
+    }
+  }
+  if (cam->width != g.w[0] || cam->height != g.h[0]) return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: camera size differs from the frame size");
+  const size_t need = L.need + up_bytes;
+  if (ctx->batch_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_batch), hso_grown(need)));
+    ctx->batch_cap = hso_grown(need);
+  }
+  char* d = ctx->d_batch;
+  char* d_up = d + L.need;
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+  ActSeedDev* d_seeds = reinterpret_cast<ActSeedDev*>(d + L.o_seeds);
+  hipLaunchKernelGGL(k_activate_expand, dim3((std::max(n_seeds, n_frames) + 127) / 128), dim3(128), 0, ctx->stream, rows, stride, seed_offset,
+                     reinterpret_cast<const ActSlotIn*>(d_up + o_in), reinterpret_cast<const uint16_t*>(d_up + o_pf), n_seeds, d_seeds,
+                     reinterpret_cast<ActPairIn*>(d + L.o_pin), reinterpret_cast<const ActFrameDev*>(d_up), reinterpret_cast<ActFrameDev*>(d + L.o_frames), n_frames);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  if (int rc = act_match_pairs(ctx, cam, g, 0.0001, d, L, n_pairs)) return rc;
+  ActConsts C;
+  C.cam = *cam; C.g = g; C.z_min = 0.0001;
+  ActPair* d_pout = reinterpret_cast<ActPair*>(d + L.o_pout);
+  hso_activate_out* d_out = reinterpret_cast<hso_activate_out*>(d + L.o_out);
+  hipLaunchKernelGGL(k_activate_opt, dim3((n_seeds + ACT_OPT_WAVES - 1) / ACT_OPT_WAVES), dim3(64 * ACT_OPT_WAVES), 0, ctx->stream, C, d_seeds, n_seeds, d_pout, d_out);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)n_seeds * sizeof(hso_activate_out), hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
 // the per-pair form of the targets: every pair names its own frame record (table = the pairs' records, index = identity)
 static int seed_activate_pairs(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seed* seeds, int n_seeds, const int32_t* target_begin,
                                const hso_activate_target* targets, const int32_t* n_mean_per_seed, int n_mean_all, hso_activate_out* out, hso_align_out* match_out)

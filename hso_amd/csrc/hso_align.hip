@@ -450,6 +450,7 @@ struct SeqMap {
   std::vector<hso_kf> kfs;
   std::vector<int32_t> key_points;                            // 5 per keyframe row
   SeqKfDev* d_kfs = nullptr; size_t kfs_cap = 0;
+  bool kfs_stale = false;                                     // the device copy waits for seqmap_flush_kfs
   int fts_cap = 0;
   int32_t* d_kf_fts = nullptr; size_t kf_rows_cap = 0;       // [rows][fts_cap]
   std::vector<int32_t> kf_nfts;                               // length of every keyframe's list
@@ -460,6 +461,8 @@ struct SeqMap {
 struct SeqMaps {
   std::vector<SeqMap*> m;
   PyrGeom g{}; bool have_g = false;
+  std::vector<int> stale_kfs;                                 // maps whose keyframe table changed since the last flush
+  char* d_kfup = nullptr; size_t kfup_cap = 0;                // [rows | destination per row] of a flush
   // where the last hso_gpu_seq_chain call left its tables (hso_gpu_debug_fetch)
   const void* dbg[HSO_DBG_N] = {nullptr}; size_t dbg_bytes[HSO_DBG_N] = {0};
 };
@@ -475,6 +478,7 @@ void hso_seqmaps_free(hso_gpu_ctx* ctx)
 {
   if (!ctx->seqmaps) return;
   for (SeqMap* m : ctx->seqmaps->m) if (m) seqmap_release(m);
+  (void)hipFree(ctx->seqmaps->d_kfup);
   delete ctx->seqmaps;
   ctx->seqmaps = nullptr;
 }
@@ -607,23 +611,64 @@ static int seqmap_work_area(hso_gpu_ctx* ctx, size_t need)
   return HSO_OK;
 }
 
-// the device copy of the keyframe table (+ base pointers, key points): rebuilt whenever either half changes (keyframe rate)
-static int seqmap_upload_kfs(hso_gpu_ctx* ctx, SeqMap* m)
+// the device copy of the keyframe table (+ base pointers, key points): rebuilt whenever either half changes (keyframe rate).  The
+// change is only noted here; the rows of ALL the maps that changed go up together, one copy and one scatter launch, when the chain
+// next runs (hso_seqmap_flush_kfs) — a copy per map was 10-20 copies per step of 128 sequences.
+static int seqmap_upload_kfs(hso_gpu_ctx* ctx, SeqMap* m, int map)
 {
   const size_t n = m->kfs.size();
   if (n == 0) return HSO_OK;
-  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (int rc = seqmap_grow(ctx, &m->d_kfs, &m->kfs_cap, n, 0, 0, 256)) return rc;
-  std::vector<SeqKfDev> rows(n);
-  for (size_t k = 0; k < n; k++) {
-    auto it = ctx->frames.find(m->kfs[k].frame_id);
-    if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seqmap: keyframe not resident");
-    SeqKfDev& r = rows[k];
-    r.T_f_w = m->kfs[k].T_f_w; r.exposure_time = m->kfs[k].exposure_time; r.base = it->second.base; r.frame_id = m->kfs[k].frame_id;
-    r.keyframe_id = m->kfs[k].keyframe_id;
-    for (int q = 0; q < 5; q++) r.key_point[q] = 5 * k + q < m->key_points.size() ? m->key_points[5 * k + q] : -1;
+  if (m->kfs_cap < n) {
+    HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (int rc = seqmap_grow(ctx, &m->d_kfs, &m->kfs_cap, n, 0, 0, 256)) return rc;
   }
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(m->d_kfs, rows.data(), sizeof(SeqKfDev) * n, hipMemcpyHostToDevice, ctx->stream));   // staged: `rows` may go
+  if (!m->kfs_stale) { m->kfs_stale = true; ctx->seqmaps->stale_kfs.push_back(map); }
+  return HSO_OK;
+}
+static_assert(sizeof(SeqKfDev) % 8 == 0, "keyframe rows move in 8-byte granules");
+
+int hso_seqmap_flush_kfs(hso_gpu_ctx* ctx)
+{
+  SeqMaps* S = ctx->seqmaps;
+  if (!S || S->stale_kfs.empty()) return HSO_OK;
+  size_t n_rows = 0;
+  for (int id : S->stale_kfs) if (SeqMap* m = seqmap_of(ctx, id)) if (m->kfs_stale) n_rows += m->kfs.size();
+  std::vector<SeqKfDev> rows; rows.reserve(n_rows);
+  std::vector<unsigned long long*> dst; dst.reserve(n_rows);
+  for (int id : S->stale_kfs) {
+    SeqMap* m = seqmap_of(ctx, id);
+    if (!m || !m->kfs_stale) continue;                            // destroyed since, or named twice
+    m->kfs_stale = false;
+    for (size_t k = 0; k < m->kfs.size(); k++) {
+      auto it = ctx->frames.find(m->kfs[k].frame_id);
+      if (it == ctx->frames.end()) { S->stale_kfs.clear(); return hso_fail(ctx, HSO_E_NOFRAME, "seqmap: keyframe not resident"); }
+      SeqKfDev r{};
+      r.T_f_w = m->kfs[k].T_f_w; r.exposure_time = m->kfs[k].exposure_time; r.base = it->second.base; r.frame_id = m->kfs[k].frame_id;
+      r.keyframe_id = m->kfs[k].keyframe_id;
+      for (int q = 0; q < 5; q++) r.key_point[q] = 5 * k + q < m->key_points.size() ? m->key_points[5 * k + q] : -1;
+      rows.push_back(r); dst.push_back(reinterpret_cast<unsigned long long*>(m->d_kfs + k));
+    }
+  }
+  S->stale_kfs.clear();
+  if (rows.empty()) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t row_bytes = sizeof(SeqKfDev) * rows.size(), need = row_bytes + sizeof(void*) * rows.size();
+  if (S->kfup_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (S->d_kfup) (void)hipFree(S->d_kfup);
+    S->d_kfup = nullptr; S->kfup_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&S->d_kfup), hso_grown(need)));
+    S->kfup_cap = hso_grown(need);
+  }
+  // staged by the copy wrapper: the vectors may go when this returns
+  std::vector<char> image(need);
+  memcpy(image.data(), rows.data(), row_bytes); memcpy(image.data() + row_bytes, dst.data(), sizeof(void*) * rows.size());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(S->d_kfup, image.data(), need, hipMemcpyHostToDevice, ctx->stream));
+  const int granules = (int)(sizeof(SeqKfDev) / 8);
+  const size_t total = rows.size() * (size_t)granules;
+  hipLaunchKernelGGL(k_scatter_rows_to, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<unsigned long long* const*>(S->d_kfup + row_bytes), reinterpret_cast<const unsigned long long*>(S->d_kfup), (int)rows.size(), granules);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
 }
 
@@ -674,7 +719,7 @@ int hso_gpu_seqmap_set_keyframes(hso_gpu_ctx* ctx, int map, const hso_kf* kfs, i
   m->kfs.assign(kfs, kfs + n_kfs);
   m->key_points.resize(5 * (size_t)n_kfs, -1);
   m->kf_nfts.resize((size_t)n_kfs, 0);
-  return seqmap_upload_kfs(ctx, m);
+  return seqmap_upload_kfs(ctx, m, map);
 }
 
 int hso_gpu_seqmap_set_key_points(hso_gpu_ctx* ctx, int map, const int32_t* key_points, int n_kfs)
@@ -684,7 +729,7 @@ int hso_gpu_seqmap_set_key_points(hso_gpu_ctx* ctx, int map, const int32_t* key_
   if (!m || n_kfs < 0 || (size_t)n_kfs != m->kfs.size() || (n_kfs > 0 && !key_points)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_set_key_points: one row of five per keyframe of the table");
   for (int i = 0; i < 5 * n_kfs; i++) if (key_points[i] < -1 || (key_points[i] >= 0 && (size_t)key_points[i] >= m->n_pts)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_set_key_points: point row out of range");
   m->key_points.assign(key_points, key_points + 5 * (size_t)n_kfs);
-  return seqmap_upload_kfs(ctx, m);
+  return seqmap_upload_kfs(ctx, m, map);
 }
 
 int hso_gpu_seqmap_patch(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, const hso_map_point* points, int n_points,

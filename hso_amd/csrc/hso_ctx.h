@@ -140,6 +140,7 @@ int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases,
 int hso_frame_resize_into(hso_gpu_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh);
 void hso_track_state_free(hso_gpu_ctx* ctx);
 void hso_seed_tables_free(hso_gpu_ctx* ctx);
+int hso_seed_table_rows(hso_gpu_ctx* ctx, int table, const int32_t* slots, int n, const char** rows, size_t* stride, size_t* seed_offset, PyrGeom* g);
 int hso_seed_async_quiesce(hso_gpu_ctx* ctx);   // wait for a previous-frame pass in flight (its results stay collectable)
 bool hso_seed_tables_pin(hso_gpu_ctx* ctx, int64_t frame_id);   // a resident seed table hosts live seeds in this frame
 void hso_seqmaps_free(hso_gpu_ctx* ctx);
@@ -187,6 +188,7 @@ struct ChainCur {              // what the chain's kernels hand on about a job's
 struct ReprojKf;               // hso_align.hip
 struct AlignJobDev;
 // a map's device view for one chain job; flips the map's frame-feature tables (the previous new frame becomes the reference)
+int hso_seqmap_flush_kfs(hso_gpu_ctx* ctx);   // the keyframe tables that changed since the last chain, in one copy + one launch
 int hso_seqmap_chain_view(hso_gpu_ctx* ctx, const hso_seq_job& job, SeqMapDev* out, int* n_kfs, const int32_t** kf_nfts_host);
 int hso_seqmap_chain_reserve(hso_gpu_ctx* ctx, int map, int rows);        // room for `rows` features in the map's two frame tables (before any view)
 void hso_seqmap_chain_commit(hso_gpu_ctx* ctx, const hso_seq_job& job, int n_feats);   // after a successful call: the new frame's table is the map's newest

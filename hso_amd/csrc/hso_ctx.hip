@@ -5,6 +5,8 @@
 #include <string.h>
 #include <atomic>
 #include <chrono>
+#include <time.h>
+#include <sys/prctl.h>
 #include <mutex>
 #include <unordered_set>
 #include <vector>
@@ -14,13 +16,21 @@ namespace {
 struct StageChunk { char* p; size_t cap, used; };
 struct StageFix { void* dst; const char* src; size_t bytes, dpitch, width, height; };   // height 0: a flat copy of `bytes`
 struct Stager {
+  std::mutex m;                     // a stream's stager is its own: the banks sharing a device do not queue behind one another's copies
   std::vector<StageChunk> chunks;
   std::vector<StageFix> fixes;      // device-to-host copies to finish after the next synchronisation
   bool yield = false;               // hso_stream_set_yielding: waits on this stream sleep instead of polling
   hipEvent_t wait_ev = nullptr;     // ... through this event (hipEventBlockingSync)
 };
-std::mutex g_stage_mutex;
+std::mutex g_stage_mutex;           // the table itself (element addresses are stable)
 std::unordered_map<hipStream_t, Stager> g_stagers;
+Stager& stager_of(hipStream_t stream) { std::lock_guard<std::mutex> lk(g_stage_mutex); return g_stagers[stream]; }
+Stager* stager_find(hipStream_t stream)
+{
+  std::lock_guard<std::mutex> lk(g_stage_mutex);
+  auto it = g_stagers.find(stream);
+  return it == g_stagers.end() ? nullptr : &it->second;
+}
 std::unordered_set<hipStream_t> g_streams_in_use;   // caller-provided streams that a live context launches on
 
 bool host_is_page_locked(const void* p)
@@ -62,16 +72,17 @@ hipError_t hso_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKin
   census(HSO_CENSUS_COPIES); census(HSO_CENSUS_COPY_BYTES, (int64_t)bytes);
   if (kind == hipMemcpyHostToDevice && !host_is_page_locked(src)) {
     census(HSO_CENSUS_STAGED);
-    std::lock_guard<std::mutex> lk(g_stage_mutex);
-    char* p = stage_alloc(g_stagers[stream], bytes);
+    Stager& S = stager_of(stream);
+    std::lock_guard<std::mutex> lk(S.m);
+    char* p = stage_alloc(S, bytes);
     if (!p) return hipErrorOutOfMemory;
     memcpy(p, src, bytes);
     return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, stream);
   }
   if (kind == hipMemcpyDeviceToHost && !host_is_page_locked(dst)) {
     census(HSO_CENSUS_STAGED);
-    std::lock_guard<std::mutex> lk(g_stage_mutex);
-    Stager& S = g_stagers[stream];
+    Stager& S = stager_of(stream);
+    std::lock_guard<std::mutex> lk(S.m);
     char* p = stage_alloc(S, bytes);
     if (!p) return hipErrorOutOfMemory;
     S.fixes.push_back({dst, p, bytes, 0, 0, 0});
@@ -86,16 +97,17 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
   if (width == 0 || height == 0) return hipSuccess;
   census(HSO_CENSUS_COPIES); census(HSO_CENSUS_COPY_BYTES, (int64_t)(width * height));
   if (kind == hipMemcpyDeviceToHost && !host_is_page_locked(dst)) {   // rows packed in the chunk, spread out after the synchronisation
-    std::lock_guard<std::mutex> lk(g_stage_mutex);
-    Stager& S = g_stagers[stream];
+    Stager& S = stager_of(stream);
+    std::lock_guard<std::mutex> lk(S.m);
     char* p = stage_alloc(S, width * height);
     if (!p) return hipErrorOutOfMemory;
     S.fixes.push_back({dst, p, width * height, dpitch, width, height});
     return hipMemcpy2DAsync(p, width, src, spitch, width, height, hipMemcpyDeviceToHost, stream);
   }
   if (kind == hipMemcpyHostToDevice && !host_is_page_locked(src)) {
-    std::lock_guard<std::mutex> lk(g_stage_mutex);
-    char* p = stage_alloc(g_stagers[stream], width * height);
+    Stager& S = stager_of(stream);
+    std::lock_guard<std::mutex> lk(S.m);
+    char* p = stage_alloc(S, width * height);
     if (!p) return hipErrorOutOfMemory;
     for (size_t r = 0; r < height; r++) memcpy(p + r * width, static_cast<const char*>(src) + r * spitch, width);
     return hipMemcpy2DAsync(dst, dpitch, p, width, width, height, hipMemcpyHostToDevice, stream);
@@ -105,30 +117,50 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
 
 // A context that shares the device with others (several banks of sequences per GPU) waits for its stream many times per step, and the
 // runtime's hipStreamSynchronize polls: six banks waiting = six of the host's CPUs spent polling while the pools that do the
-// bookkeeping compete for the rest of a 16-CPU quota.  A yielding stream waits on an event created with hipEventBlockingSync instead:
-// the thread sleeps until the interrupt (a few tens of microseconds later than a poll would notice — nothing against a multi-
-// millisecond step whose device time the other banks fill anyway).
+// bookkeeping compete for the rest of a 16-CPU quota.  A yielding stream records an event and sleeps between queries instead (or, with
+// HSO_SYNC_MODE=block, waits on an event created with hipEventBlockingSync): a few tens of microseconds later than a poll would
+// notice — nothing against a multi-millisecond step whose device time the other banks fill anyway.
 void hso_stream_set_yielding(hipStream_t stream, bool on)
 {
-  std::lock_guard<std::mutex> lk(g_stage_mutex);
-  g_stagers[stream].yield = on;
+  Stager& S = stager_of(stream);
+  std::lock_guard<std::mutex> lk(S.m);
+  S.yield = on;
+}
+
+// how a yielding stream waits: 0 = the blocking event alone, 1 (default) = query the event, briefly spinning, then in short naps
+// (HSO_SYNC_MODE=block / nap).  The blocking wait's wake-up comes with the interrupt and was measured bimodal on the GPU boxes (the
+// same 6 x 128 run at 24.7 k or at 13-14 k frames/s from one launch to the next); the napping wait is bounded by the nap.
+static int yield_mode()
+{
+  static const int mode = [] { const char* e = getenv("HSO_SYNC_MODE"); return e && !strcmp(e, "block") ? 0 : 1; }();
+  return mode;
 }
 
 static hipError_t stream_wait(hipStream_t stream)
 {
   hipEvent_t ev = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(g_stage_mutex);
-    auto it = g_stagers.find(stream);
-    if (it != g_stagers.end() && it->second.yield) {
-      if (!it->second.wait_ev && hipEventCreateWithFlags(&it->second.wait_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) it->second.wait_ev = nullptr;
-      ev = it->second.wait_ev;
+  if (Stager* S = stager_find(stream)) {
+    std::lock_guard<std::mutex> lk(S->m);
+    if (S->yield) {
+      const unsigned flags = (yield_mode() == 0 ? hipEventBlockingSync : 0u) | hipEventDisableTiming;
+      if (!S->wait_ev && hipEventCreateWithFlags(&S->wait_ev, flags) != hipSuccess) S->wait_ev = nullptr;
+      ev = S->wait_ev;
     }
   }
   if (!ev) return hipStreamSynchronize(stream);
   hipError_t e = hipEventRecord(ev, stream);
-  if (e == hipSuccess) e = hipEventSynchronize(ev);
-  return e;
+  if (e != hipSuccess) return e;
+  if (yield_mode() == 0) return hipEventSynchronize(ev);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(40)) continue;   // short waits: no sleep at all
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL); slack_set = true; }   // the default slack (50 us) would triple the nap
+    timespec ts{0, 20000};
+    nanosleep(&ts, nullptr);
+  }
 }
 
 hipError_t hso_stream_sync(hipStream_t stream)
@@ -137,10 +169,10 @@ hipError_t hso_stream_sync(hipStream_t stream)
   const hipError_t e = stream_wait(stream);
   census(HSO_CENSUS_SYNCS);
   census(HSO_CENSUS_SYNC_NS, std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
-  std::lock_guard<std::mutex> lk(g_stage_mutex);
-  auto it = g_stagers.find(stream);
-  if (it == g_stagers.end()) return e;
-  Stager& S = it->second;
+  Stager* const Sp = stager_find(stream);
+  if (!Sp) return e;
+  Stager& S = *Sp;
+  std::lock_guard<std::mutex> lk(S.m);
   if (e == hipSuccess)
     for (const StageFix& f : S.fixes) {
       if (f.height == 0) memcpy(f.dst, f.src, f.bytes);
@@ -163,11 +195,11 @@ void hso_stream_abandon(hipStream_t stream)
 {
   (void)hipStreamSynchronize(stream);                      // the raw call: nothing is copied out
   (void)hipGetLastError();
-  std::lock_guard<std::mutex> lk(g_stage_mutex);
-  auto it = g_stagers.find(stream);
-  if (it == g_stagers.end()) return;
-  it->second.fixes.clear();
-  for (StageChunk& c : it->second.chunks) c.used = 0;
+  Stager* const S = stager_find(stream);
+  if (!S) return;
+  std::lock_guard<std::mutex> lk(S->m);
+  S->fixes.clear();
+  for (StageChunk& c : S->chunks) c.used = 0;
 }
 
 void hso_stream_forget(hipStream_t stream)
@@ -195,9 +227,7 @@ int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg)
   ctx->err = msg;
   bool pending = false;
   {
-    std::lock_guard<std::mutex> lk(g_stage_mutex);
-    auto it = g_stagers.find(ctx->stream);
-    pending = it != g_stagers.end() && !it->second.fixes.empty();
+    if (Stager* S = stager_find(ctx->stream)) { std::lock_guard<std::mutex> lk(S->m); pending = !S->fixes.empty(); }
   }
   if (pending) hso_stream_abandon(ctx->stream);
   return code;

@@ -1057,6 +1057,21 @@ static SeedTable* seed_table_of(hso_gpu_ctx* ctx, int table)
   return ctx->seed_tables->t[table];
 }
 
+// for the activation by slots (hso_activate.hip): the table's device rows — `ref_base` first, the hso_seed at *seed_offset — after
+// the depth filter's own stream has drained; every named slot must hold a live seed
+int hso_seed_table_rows(hso_gpu_ctx* ctx, int table, const int32_t* slots, int n, const char** rows, size_t* stride, size_t* seed_offset, PyrGeom* g)
+{
+  if (int rc = hso_seed_async_quiesce(ctx)) return rc;
+  SeedTable* t = seed_table_of(ctx, table);
+  if (!t || n < 0 || (n > 0 && !slots)) return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: bad argument");
+  for (int i = 0; i < n; i++)
+    if (slots[i] < 0 || (size_t)slots[i] >= t->n || !t->alive[(size_t)slots[i]]) return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: slot out of range or erased");
+  if (n > 0 && !t->have_g) return hso_fail(ctx, HSO_E_INVALID, "seed_table_activate: empty table");
+  static_assert(offsetof(SeedDev, ref_base) == 0, "hso_activate.hip reads the base pointer at the start of a row");
+  *rows = reinterpret_cast<const char*>(t->d); *stride = sizeof(SeedDev); *seed_offset = offsetof(SeedDev, s); *g = t->g;
+  return HSO_OK;
+}
+
 template <typename T> static int grow_dev(hso_gpu_ctx* ctx, T** p, size_t* cap, size_t need, size_t keep)
 {
   if (*cap >= need) return HSO_OK;

@@ -774,6 +774,7 @@ extern "C" int hso_gpu_seq_chain(hso_gpu_ctx* ctx, const hso_camera* cam, const 
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   // ---- per job: frames, the map's view, the list slice (as long as the list can get: every point row once, or every feature of
   // max_kfs + 5 keyframes plus candidates and temporary points, whichever is smaller)
+  if (int rc = hso_seqmap_flush_kfs(ctx)) return rc;
   for (int c = 0; c < n_jobs; c++) {
     for (int q = 0; q < c; q++) if (jobs[q].map == jobs[c].map) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: a map appears twice in one call");
     if (int rc = hso_seqmap_chain_reserve(ctx, jobs[c].map, feat_cap)) return rc;

@@ -133,7 +133,7 @@ Bank::~Bank()
     delete s;
   }
   for (StepData* d : step_) delete d;
-  chain_res_.release(); chain_brief_.release(); feat_rows_.release(); track_tables_.release(); act_seeds_.release(); act_targets_.release(); act_ints_.release(); act_out_.release(); seed_brief_.release(); seed_px_.release(); det_corners_.release(); det_fill_.release(); det_edgelets_.release();   // before the context goes
+  chain_res_.release(); chain_brief_.release(); feat_rows_.release(); track_tables_.release(); act_seeds_.release(); act_targets_.release(); act_ints_.release(); act_slots_.release(); act_out_.release(); seed_brief_.release(); seed_px_.release(); det_corners_.release(); det_fill_.release(); det_edgelets_.release();   // before the context goes
   if (owns_ctx_) hso_gpu_destroy(ctx_);
 }
 

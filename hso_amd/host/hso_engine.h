@@ -249,7 +249,7 @@ private:
   Pinned<hso_seed_brief> chain_brief_; // ... and the briefs of the seed observation it chained behind the regular frames (one image per tracker mode)
   Pinned<hso_seq_feature> feat_rows_;  // frame feature tables on their way to / from the device
   Pinned<double> track_tables_;
-  Pinned<hso_seed> act_seeds_; Pinned<hso_activate_target> act_targets_; Pinned<int32_t> act_ints_; Pinned<hso_activate_out> act_out_;   // activate_seeds()
+  Pinned<hso_seed> act_seeds_; Pinned<hso_activate_target> act_targets_; Pinned<int32_t> act_ints_; Pinned<int32_t> act_slots_; Pinned<hso_activate_out> act_out_;   // activate_seeds()
   Pinned<hso_seed_brief> seed_brief_;
   Pinned<float> seed_px_;
   Pinned<hso_corner> det_corners_, det_fill_;   // detect(): the candidate lists of a step's new keyframes

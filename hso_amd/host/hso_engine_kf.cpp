@@ -378,7 +378,17 @@ void Bank::activate_seeds(const std::vector<int>& who)
     at[w + 1] = at[w] + d.conv.size(); tg_at[w + 1] = tg_at[w] + n_tg[w]; fr_at[w + 1] = fr_at[w] + d.act_frames.size();
   }
   const size_t n_seeds = at.back(), n_pairs = tg_at.back(), n_frames = fr_at.back();
-  hso_seed* const seeds = act_seeds_.need(ctx_, std::max(n_seeds, (size_t)1));
+  // the converged seeds are rows of the resident table, which holds what the host mirrors (the observations run from it): the call
+  // names them by slot.  Records are assembled only for a recorded run (the trace keeps them) or for a seed that never got a slot.
+  bool by_slot = n_frames <= 65536, tracing = false;
+  for (size_t w = 0; w < who.size() && by_slot; w++) {
+    const Seq& s = *seq_[who[w]];
+    if (s.trace.on()) tracing = true;
+    for (int i : step_[who[w]]->conv) if (s.seeds[(size_t)i].slot < 0) { by_slot = false; break; }
+  }
+  const bool want_records = !by_slot || tracing;
+  hso_seed* const seeds = act_seeds_.need(ctx_, want_records ? std::max(n_seeds, (size_t)1) : (size_t)1);
+  int32_t* const slots = act_slots_.need(ctx_, std::max(n_seeds, (size_t)1));
   hso_activate_target* const targets = act_targets_.need(ctx_, std::max(n_frames, (size_t)1));
   int32_t* const ints = act_ints_.need(ctx_, 2 * n_seeds + 2 + n_pairs);     // [target_begin (n + 1) | n_mean (n) | frame index per pair]
   hso_activate_out* const out = act_out_.need(ctx_, std::max(n_seeds, (size_t)1));
@@ -396,7 +406,8 @@ void Bank::activate_seeds(const std::vector<int>& who)
     size_t t = tg_at[w], local = 0;
     for (size_t c = 0; c < d.conv.size(); c++) {
       const Seed& sd = s.seeds[d.conv[c]];
-      seeds[at[w] + c] = seed_record(s, sd);
+      if (want_records) seeds[at[w] + c] = seed_record(s, sd);
+      slots[at[w] + c] = sd.slot;
       const size_t np = sd.seen_before.size() + sd.seen.size();
       for (size_t q = 0; q < np; q++) pair_frame[t++] = (int32_t)fr_at[w] + d.act_pair_frame[local++];
       begin[at[w] + c + 1] = (int32_t)t;
@@ -405,7 +416,8 @@ void Bank::activate_seeds(const std::vector<int>& who)
   });
   if (n_seeds > 0) {
     if (n_frames == 0) targets[0] = hso_activate_target{};
-    check(hso_gpu_seed_activate_frames(ctx_, &cam_.pod(), seeds, (int)n_seeds, begin, pair_frame, targets, (int)n_frames, n_mean, out), "DepthFilter::activatePoint");
+    if (by_slot) check(hso_gpu_seed_table_activate(ctx_, &cam_.pod(), seed_table_, slots, (int)n_seeds, begin, pair_frame, targets, (int)n_frames, n_mean, out), "DepthFilter::activatePoint");
+    else check(hso_gpu_seed_activate_frames(ctx_, &cam_.pod(), seeds, (int)n_seeds, begin, pair_frame, targets, (int)n_frames, n_mean, out), "DepthFilter::activatePoint");
     n_calls_[7]++; n_items_[7] += (int64_t)who.size();
   }
   pool_->run((int)who.size(), [&](int w) {

@@ -686,6 +686,15 @@ int hso_gpu_seed_activate_frames(hso_gpu_ctx* ctx, const hso_camera* cam, const 
                                  const int32_t* target_frame, const hso_activate_target* frames, int n_frames,
                                  const int32_t* n_mean_converge_frame, hso_activate_out* out);
 
+/* The same for seeds that live in a resident seed table (hso_gpu_seed_table_*): seed i is the record in `slots[i]` as the table holds
+ * it — mu / sigma2 / b as its last observation left them, the host keyframe's pose as hso_gpu_seed_table_set_host_pose left it — so
+ * 4 bytes per seed cross the bus instead of a 192-byte record (1 MB per step of 128 sequences), and the caller does not assemble
+ * records it already mirrored.  A dead slot is an error.  Results are those of hso_gpu_seed_activate_frames on
+ * hso_gpu_seed_table_read's records of the same slots. */
+int hso_gpu_seed_table_activate(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int32_t* slots, int n_seeds, const int32_t* target_begin,
+                                const int32_t* target_frame, const hso_activate_target* frames, int n_frames,
+                                const int32_t* n_mean_converge_frame, hso_activate_out* out);
+
 /* The seed branch of Reprojector::reprojectMap (src/reprojector.cpp:309-329): reprojectorSeed (:531-554) — pTarget =
  * (T_cur_w * T_ref_w^-1) * (f / mu), rejected when its z < 0.001 or its truncated pixel lies within 8 px of the border —
  * and Matcher::findMatchSeed (src/matcher.cpp:442-518: parallax test, warp, exposure compensation, align1D / align2D,

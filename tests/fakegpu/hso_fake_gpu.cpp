@@ -841,6 +841,18 @@ int hso_gpu_seed_activate_frames(hso_gpu_ctx* c, const hso_camera* cam, const hs
   return HSO_OK;
 }
 
+int hso_gpu_seed_table_activate(hso_gpu_ctx* c, const hso_camera* cam, int t, const int32_t* slots, int n, const int32_t* begin, const int32_t* target_frame,
+                                const hso_activate_target* frames, int n_frames, const int32_t* n_mean, hso_activate_out* out)
+{
+  FakeSeedTable* T = c->tables.at((size_t)t);
+  std::vector<hso_seed> seeds((size_t)n);
+  for (int i = 0; i < n; i++) {
+    if (slots[i] < 0 || (size_t)slots[i] >= T->s.size() || !T->alive[(size_t)slots[i]]) return fail(c, HSO_E_INVALID, "seed_table_activate: slot out of range or erased");
+    seeds[(size_t)i] = T->s[(size_t)slots[i]];
+  }
+  return hso_gpu_seed_activate_frames(c, cam, seeds.data(), n, begin, target_frame, frames, n_frames, n_mean, out);
+}
+
 int hso_gpu_seed_reproject_match(hso_gpu_ctx* c, const hso_camera* cam, int64_t cur_id, const hso_se3* T_cur_w, double cur_exposure, const hso_seed* seeds, int n,
                                  int cell_size, int grid_n_cols, hso_reproj_point* proj, hso_align_out* match)
 {

@@ -111,6 +111,43 @@ def test_seed_activate_matches_oracle(orc, cam, gpu_ctx, act_problem):
 
 
 @pytest.mark.gpu
+def test_seed_activate_by_frames_and_by_slots_equal_the_per_pair_form(cam, gpu_ctx, act_problem):
+    """The three argument forms of one computation: every pair with its own target record (hso_gpu_seed_activate_multi), the
+    unique target frames + an index per pair (hso_gpu_seed_activate_frames), and the seeds named by their slots in a resident
+    seed table (hso_gpu_seed_table_activate).  Bit-equal; an erased slot is refused."""
+    P = act_problem[0]
+    ids = [P["host_frame_id"]] + [t.frame_id for t in P["targets"]]
+    gpu_ctx.frame_upload(ids[0], P["host"])
+    for t, f in zip(P["targets"], P["frames"]):
+        gpu_ctx.frame_upload(t.frame_id, f)
+    table = gpu_ctx.seed_table_create()
+    try:
+        n = len(P["seeds"])
+        n_mean = [6 + (i % 3) * 7 for i in range(n)]
+        want = gpu_ctx.seed_activate_multi(cam, P["seeds"], P["per_seed"], n_mean)
+        index = {t.frame_id: k for k, t in enumerate(P["targets"])}
+        per_seed_ix = [[index[t.frame_id] for t in tl] for tl in P["per_seed"]]
+        got_f = gpu_ctx.seed_activate_frames(cam, P["seeds"], per_seed_ix, P["targets"], n_mean)
+        assert [bytes(a) for a in got_f] == [bytes(a) for a in want]
+        # the table holds the seeds in another order, with a stranger in front
+        order = list(range(n))[::-1]
+        first = gpu_ctx.seed_table_append(table, [P["seeds"][0]] + [P["seeds"][i] for i in order])
+        slot_of = {i: first + 1 + k for k, i in enumerate(order)}
+        got_s = gpu_ctx.seed_table_activate(cam, table, [slot_of[i] for i in range(n)], per_seed_ix, P["targets"], n_mean)
+        assert [bytes(a) for a in got_s] == [bytes(a) for a in want]
+        assert sum(a.activated for a in want) > 60
+        gpu_ctx.seed_table_erase(table, [slot_of[3]])
+        with pytest.raises(RuntimeError):
+            gpu_ctx.seed_table_activate(cam, table, [slot_of[3]], [per_seed_ix[3]], P["targets"], [6])
+        with pytest.raises(RuntimeError):
+            gpu_ctx.seed_table_activate(cam, table, [first + n + 5], [per_seed_ix[3]], P["targets"], [6])
+    finally:
+        gpu_ctx.seed_table_destroy(table)
+        for i in ids:
+            gpu_ctx.frame_release(i)
+
+
+@pytest.mark.gpu
 def test_seed_activate_errors(cam, gpu_ctx, act_problem):
     P = act_problem[0]
     with pytest.raises(RuntimeError):
