@@ -257,6 +257,34 @@ def start_pose(sc, variant):
     return synth.rotvec_to_quat(rv0), t0
 
 
+def deal_features(feats, q, t, spec, level):
+    """Experiment (profiles/r5_headline_levers.md): the same features in another table order — dealt round-robin over
+    the 32 LDS banks of the dword their pattern's row 0 starts at in the CURRENT frame's level-`level` image (positions predicted with
+    the job's start pose), so that the 32 lanes an LDS access serves mostly hit distinct banks.  The tracker sums over the features, so
+    only the order of the fp32 sums changes."""
+    from hso_amd import synth
+    X = feats["f"] * feats["dist"][:, None]
+    X = X @ synth.quat_to_R(np.asarray(q, float)).T + np.asarray(t, float)
+    z = np.where(np.abs(X[:, 2]) > 1e-9, X[:, 2], 1.0)
+    x, y = X[:, 0] / z, X[:, 1] / z
+    d = spec.get("d")
+    if d is not None:
+        r2 = x * x + y * y
+        rad = 1 + d[0] * r2 + d[1] * r2 * r2 + d[4] * r2 ** 3
+        x, y = x * rad + 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x), y * rad + d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y
+    u = np.floor((spec["fx"] * x + spec["cx"]) / (1 << level)).astype(np.int64)
+    v = np.floor((spec["fy"] * y + spec["cy"]) / (1 << level)).astype(np.int64)
+    stride = spec["width"] >> level
+    bank = (((v * stride + u - 3) >> 2) % 32 + 32) % 32
+    buckets = [list(np.nonzero(bank == b)[0][::-1]) for b in range(32)]
+    order = []
+    while any(buckets):
+        for b in range(32):
+            if buckets[b]:
+                order.append(buckets[b].pop())
+    return np.ascontiguousarray(feats[np.asarray(order)])
+
+
 def rot_angle(qa, qb):
     """Angle of qa * qb^-1 for unit quaternions (x, y, z, w)."""
     d = abs(float(np.dot(qa, qb)))
@@ -326,6 +354,7 @@ def main():
     ap.add_argument("--native-gather", type=int, default=-1,
                     help="1: repeat the trajectory gather through libhso_gather.so (ncclAllGather from C, include/hso_vo.h) and "
                          "require it to equal the torch.distributed one; reported in bench_detail.json.  -1 (default): on when N > 1")
+    ap.add_argument("--deal-features", type=int, default=0, help="experiment: > 0 = reorder every job's features by LDS bank at this pyramid level (deal_features)")
     ap.add_argument("--overlap-readback", type=int, default=1, help="1: step k's result read-back is waited for after step k + 1 is enqueued (collect_begin / _end); 0: the synchronous collect")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
@@ -386,7 +415,8 @@ def main():
             a0 = float(np.float32(st_cur[i].integral_image / st_ref[i].integral_image))  # CoarseTracker.cpp:60
             a0s.append(a0)
             starts.append(start_pose(sc, (i // n_sc) % 4))
-            jobs.append(ctx.make_job(ref_ids[i], cur_ids[i], sc["feats"], capi.SE3.from_arrays(*starts[i]), a0))
+            fts = deal_features(sc["feats"], starts[i][0], starts[i][1], spec, args.deal_features) if args.deal_features > 0 else sc["feats"]
+            jobs.append(ctx.make_job(ref_ids[i], cur_ids[i], fts, capi.SE3.from_arrays(*starts[i]), a0))
         ctx.coarse_track_prepare(cam, params, jobs)
 
         overlap = bool(args.overlap_readback) and hasattr(ctx, "coarse_track_collect_begin")

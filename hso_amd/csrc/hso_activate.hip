@@ -7,9 +7,9 @@
 // (src/vikit/robust_cost.cpp:67-74).
 //
 // MI355X mapping: the reference visits a seed's <=30 target frames one after another on the
-// mapping thread.  Here kernel 1 gives every (seed, target) pair its own wavefront (projection,
-// parallax test and the 8x8 Lucas-Kanade of findMatchSeed, lane = patch pixel — the same
-// device body as the reprojection matcher), and kernel 2 gives every seed one wavefront with
+// mapping thread.  Here every (seed, target) pair gets a thread for its geometry (k_activate_prep: projection and
+// parallax tests, the matcher's job record) and a quarter of a wavefront for the 8x8 Lucas-Kanade of findMatchSeed
+// (the reprojection matcher's own kernel, k_align_t<true>, over those jobs), and kernel 2 gives every seed one wavefront with
 // lane = target frame: residuals and Jacobians of all targets are evaluated in parallel, the
 // sums over targets are formed in the reference's order (see k_activate_opt), so they carry the
 // reference's rounding (the only non-IEEE step is pow(x,3) in the damping update).

@@ -744,63 +744,79 @@ int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches,
 {
   if (!ctx) return HSO_E_INVALID;
   if (n_patches < 0 || (n_patches > 0 && !patches)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: bad argument");
-  size_t tp = 0, to = 0;
+  size_t tp = 0, to = 0, rows_total = 0;
   for (int i = 0; i < n_patches; i++) {
     const hso_seqmap_rows& P = patches[i];
     SeqMap* m = seqmap_of(ctx, P.map);
     if (!m || P.n_points < 0 || P.n_obs < 0 || (P.n_points > 0 && (!P.point_ids || !P.points)) || (P.n_obs > 0 && (!P.obs_ids || !P.obs)))
       return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: bad patch");
-    // the kernels trust the tables: check every index a row carries before it reaches the device
+    rows_total += (size_t)P.n_points + (size_t)P.n_obs;
+    for (int q = 0; q < i; q++) if (patches[q].map == P.map) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch_multi: a map appears twice in one call");
+  }
+  // the kernels trust the tables: check every index a row carries before it reaches the device (per patch, on a few threads when
+  // a keyframe step sends tens of thousands of rows)
+  std::vector<const char*> bad((size_t)n_patches, nullptr);
+  std::vector<size_t> need_p((size_t)n_patches), need_o((size_t)n_patches);
+  hso_host_parallel(n_patches, rows_total * 64, [&](int i) {
+    const hso_seqmap_rows& P = patches[i];
+    const SeqMap* m = seqmap_of(ctx, P.map);
     const int nk = (int)m->kfs.size();
     size_t need_pts = m->n_pts, need_obs = m->n_obs;
-    for (int k = 0; k < P.n_obs; k++) { if (P.obs_ids[k] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: negative observation id"); need_obs = std::max(need_obs, (size_t)P.obs_ids[k] + 1); }
-    for (int k = 0; k < P.n_points; k++) { if (P.point_ids[k] < 0) return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: negative point id"); need_pts = std::max(need_pts, (size_t)P.point_ids[k] + 1); }
+    for (int k = 0; k < P.n_obs; k++) { if (P.obs_ids[k] < 0) { bad[(size_t)i] = "seqmap_patch: negative observation id"; return; } need_obs = std::max(need_obs, (size_t)P.obs_ids[k] + 1); }
+    for (int k = 0; k < P.n_points; k++) { if (P.point_ids[k] < 0) { bad[(size_t)i] = "seqmap_patch: negative point id"; return; } need_pts = std::max(need_pts, (size_t)P.point_ids[k] + 1); }
     for (int k = 0; k < P.n_obs; k++) {
       const hso_obs& o = P.obs[k];
-      if (o.kf < 0 || o.kf >= nk || o.level < 0 || o.level >= HSO_N_PYR_LEVELS || o.pad_ < -1 || (o.pad_ >= 0 && (size_t)o.pad_ >= need_obs))
-        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: observation row out of range (keyframe table set first?)");
-      if (P.obs_point && (P.obs_point[k] < -1 || (P.obs_point[k] >= 0 && (size_t)P.obs_point[k] >= need_pts)))
-        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: Feature::point link out of range");
+      if (o.kf < 0 || o.kf >= nk || o.level < 0 || o.level >= HSO_N_PYR_LEVELS || o.pad_ < -1 || (o.pad_ >= 0 && (size_t)o.pad_ >= need_obs)) {
+        bad[(size_t)i] = "seqmap_patch: observation row out of range (keyframe table set first?)"; return;
+      }
+      if (P.obs_point && (P.obs_point[k] < -1 || (P.obs_point[k] >= 0 && (size_t)P.obs_point[k] >= need_pts))) { bad[(size_t)i] = "seqmap_patch: Feature::point link out of range"; return; }
     }
     for (int k = 0; k < P.n_points; k++) {
       const hso_map_point& p = P.points[k];
-      if (p.host_kf < 0 || p.host_kf >= nk || p.obs_count < 0 || (p.obs_count > 0 && (p.obs_begin < 0 || (size_t)p.obs_begin >= need_obs)))
-        return hso_fail(ctx, HSO_E_INVALID, "seqmap_patch: point row out of range");
+      if (p.host_kf < 0 || p.host_kf >= nk || p.obs_count < 0 || (p.obs_count > 0 && (p.obs_begin < 0 || (size_t)p.obs_begin >= need_obs))) { bad[(size_t)i] = "seqmap_patch: point row out of range"; return; }
     }
-    if (int rc = seqmap_grow_tables(ctx, m, need_pts, need_obs)) return rc;
-    m->n_pts = need_pts; m->n_obs = need_obs;
-    tp += (size_t)P.n_points; to += (size_t)P.n_obs;
+    need_p[(size_t)i] = need_pts; need_o[(size_t)i] = need_obs;
+  });
+  for (int i = 0; i < n_patches; i++) if (bad[(size_t)i]) return hso_fail(ctx, HSO_E_INVALID, bad[(size_t)i]);
+  std::vector<size_t> at_p((size_t)n_patches + 1, 0), at_o((size_t)n_patches + 1, 0), at_l((size_t)n_patches + 1, 0);
+  for (int i = 0; i < n_patches; i++) {
+    const hso_seqmap_rows& P = patches[i];
+    SeqMap* m = seqmap_of(ctx, P.map);
+    if (int rc = seqmap_grow_tables(ctx, m, need_p[(size_t)i], need_o[(size_t)i])) return rc;
+    m->n_pts = need_p[(size_t)i]; m->n_obs = need_o[(size_t)i];
+    at_p[(size_t)i + 1] = at_p[(size_t)i] + (size_t)P.n_points; at_o[(size_t)i + 1] = at_o[(size_t)i] + (size_t)P.n_obs;
+    at_l[(size_t)i + 1] = at_l[(size_t)i] + (P.obs_point ? (size_t)P.n_obs : 0);
   }
+  tp = at_p.back(); to = at_o.back();
   if (tp + to == 0) return HSO_OK;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   // [destination row pointers of the points | of the observations | of the links | point rows | observation rows | links]
-  size_t tl = 0;
-  for (int i = 0; i < n_patches; i++) if (patches[i].obs_point) tl += (size_t)patches[i].n_obs;
+  const size_t tl = at_l.back();
   const size_t b_dp = al(sizeof(void*) * tp), b_do = al(sizeof(void*) * to), b_dl = al(sizeof(void*) * tl);
   const size_t b_p = al(sizeof(hso_map_point) * tp), b_o = al(sizeof(hso_obs) * to), b_l = al(sizeof(int32_t) * tl);
   const size_t need = b_dp + b_do + b_dl + b_p + b_o + b_l;
-  // the image is assembled in ordinary memory and leaves through the stream's page-locked staging chunks (hso_copy_async): no wait
-  // for the copy here — a step patches before its chain call, whose own synchronisation releases the chunks
-  std::vector<char> img(need);
-  char* h = img.data();
+  // the image is assembled in the stream's page-locked staging chunks and leaves with one DMA: no wait for the copy here — a step
+  // patches before its chain call, whose own synchronisation releases the chunks
   if (int rc = seqmap_work_area(ctx, need)) return rc;
+  char* h = hso_stage_reserve(ctx->stream, need);
+  if (!h) return hso_fail(ctx, HSO_E_NOMEM, "seqmap_patch: no staging memory");
   hso_map_point** dp = reinterpret_cast<hso_map_point**>(h);
   hso_obs** dob = reinterpret_cast<hso_obs**>(h + b_dp);
   int32_t** dl = reinterpret_cast<int32_t**>(h + b_dp + b_do);
   hso_map_point* rp = reinterpret_cast<hso_map_point*>(h + b_dp + b_do + b_dl);
   hso_obs* ro = reinterpret_cast<hso_obs*>(h + b_dp + b_do + b_dl + b_p);
   int32_t* rl = reinterpret_cast<int32_t*>(h + b_dp + b_do + b_dl + b_p + b_o);
-  size_t ip = 0, io = 0, il = 0;
-  for (int i = 0; i < n_patches; i++) {
+  hso_host_parallel(n_patches, need, [&](int i) {
     const hso_seqmap_rows& P = patches[i];
-    SeqMap* m = seqmap_of(ctx, P.map);
+    const SeqMap* m = seqmap_of(ctx, P.map);
+    size_t ip = at_p[(size_t)i], io = at_o[(size_t)i], il = at_l[(size_t)i];
     for (int k = 0; k < P.n_points; k++) { dp[ip] = m->d_pts + P.point_ids[k]; rp[ip] = P.points[k]; ip++; }
     for (int k = 0; k < P.n_obs; k++) {
       dob[io] = m->d_obs + P.obs_ids[k]; ro[io] = P.obs[k]; io++;
       if (P.obs_point) { dl[il] = m->d_obs_pt + P.obs_ids[k]; rl[il] = P.obs_point[k]; il++; }
     }
-  }
+  });
   char* d = ctx->d_batch;
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, ctx->stream));
   if (tp) hipLaunchKernelGGL(k_scatter_points_to, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, ctx->stream,

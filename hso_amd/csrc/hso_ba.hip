@@ -703,6 +703,15 @@ struct BaBatch {
 };
 #define BA_N_LISTS 6
 
+static bool ba_edges_ok(const hso_ba_edge* edges, int n_edges, int n_points, int n_poses)
+{
+  for (int k = 0; k < n_edges; k++) {
+    const hso_ba_edge& e = edges[k];
+    if (e.point < 0 || e.point >= n_points || e.host < 0 || e.host >= n_poses || e.target < 0 || e.target >= n_poses ||
+        e.host == e.target || e.level < 0 || e.level > 14) return false;
+  }
+  return true;
+}
 static int ba_check_edges(hso_gpu_ctx* ctx, const hso_ba_edge* edges, int n_edges, int n_points, int n_poses, const char* who)
 {
   for (int k = 0; k < n_edges; k++) {
@@ -820,9 +829,13 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   size_t od = hdr, oh = hdr;
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
-    const hso_ba_problem& P = problems[q];
     B.d = d + od; B.h_in = h + oh;
     od += B.total; oh += B.in_bytes;
+  }
+  // the windows' input images, assembled side by side in the page-locked block (a few threads: tens of megabytes per keyframe step)
+  hso_host_parallel(n, pin_in - hdr, [&](int q) {
+    const BaWin& B = Q.win[q];
+    const hso_ba_problem& P = problems[q];
     char* w = B.h_in;
     memset(w, 0, B.in_bytes);
     memcpy(w + B.o_poses, P.poses_f_w, sizeof(hso_se3) * B.n_poses);
@@ -834,6 +847,10 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
     memcpy(w + B.o_poff, B.poff.data(), sizeof(int) * (B.n_pairs + 1));
     memcpy(w + B.o_plist, B.plist.data(), sizeof(int) * 3 * (size_t)B.n_edges);
     memcpy(w + B.o_col, B.col.data(), sizeof(int) * B.n_poses);
+  });
+  for (int q = 0; q < n; q++) {
+    BaWin& B = Q.win[q];
+    char* w = B.h_in;
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d, w, B.in_bytes, hipMemcpyHostToDevice, ctx->stream));
     BaProb& R = hp[q];
     char* dd = B.d;
@@ -994,7 +1011,6 @@ extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job
       return hso_fail(ctx, HSO_E_INVALID, "ba_huber_deltas: bad argument");
     J.huber_corner = 0; J.huber_edge = 0;
     if (J.n_edges == 0) continue;   // both error lists empty: the reference leaves the deltas uninitialised
-    if (int rc = ba_check_edges(ctx, J.edges, J.n_edges, J.n_points, J.n_poses, "ba_huber_deltas")) return rc;
     Lay& L = lay[(size_t)j];
     L.o_poses = o; o += al(sizeof(hso_se3) * (size_t)J.n_poses);
     L.o_idist = o; o += al(sizeof(double) * (size_t)J.n_points);
@@ -1003,6 +1019,15 @@ extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job
     live.push_back(j); max_edges = std::max(max_edges, (int)J.n_edges);
   }
   if (live.empty()) return HSO_OK;
+  {
+    std::vector<uint8_t> bad(live.size(), 0);
+    hso_host_parallel((int)live.size(), o, [&](int wi) {
+      const hso_ba_deltas_job& J = jobs[live[(size_t)wi]];
+      bad[(size_t)wi] = ba_edges_ok(J.edges, J.n_edges, J.n_points, J.n_poses) ? 0 : 1;
+    });
+    for (size_t w = 0; w < live.size(); w++)
+      if (bad[w]) { const hso_ba_deltas_job& J = jobs[live[w]]; return ba_check_edges(ctx, J.edges, J.n_edges, J.n_points, J.n_poses, "ba_huber_deltas"); }
+  }
   const size_t in_bytes = o;
   for (int j : live) { lay[(size_t)j].o_err = o; o += al(sizeof(float) * (size_t)jobs[j].n_edges); }
   const size_t err_bytes = o - in_bytes;
@@ -1019,7 +1044,8 @@ extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job
   char* he = hso_pinned(ctx, 1, err_bytes);
   if (!h || !he) return HSO_E_NOMEM;
   MadWin* hw = reinterpret_cast<MadWin*>(h);
-  for (size_t w = 0; w < live.size(); w++) {
+  hso_host_parallel((int)live.size(), in_bytes, [&](int wi) {
+    const size_t w = (size_t)wi;
     const hso_ba_deltas_job& J = jobs[live[w]];
     const Lay& L = lay[(size_t)live[w]];
     memcpy(h + L.o_poses, J.poses_f_w, sizeof(hso_se3) * (size_t)J.n_poses);
@@ -1029,18 +1055,19 @@ extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job
     hw[w].poses = reinterpret_cast<const hso_se3*>(d + L.o_poses); hw[w].idist = reinterpret_cast<const double*>(d + L.o_idist);
     hw[w].edges = reinterpret_cast<const hso_ba_edge*>(d + L.o_edges); hw[w].uv = reinterpret_cast<const double*>(d + L.o_uv);
     hw[w].err = reinterpret_cast<float*>(d + L.o_err); hw[w].n_edges = J.n_edges; hw[w].pad_ = 0;
-  }
+  });
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_ba_mad_errors, dim3((max_edges + BA_THREADS - 1) / BA_THREADS, (unsigned)live.size()), dim3(BA_THREADS), 0, ctx->stream,
                      reinterpret_cast<const MadWin*>(d));
   HSO_HIP_CHECK(ctx, hipGetLastError());
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(he, d + in_bytes, err_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<float> errors_pt, errors_ls;
-  for (int j : live) {
+  // the medians, a window per item (an nth_element over tens of thousands of errors each)
+  hso_host_parallel((int)live.size(), err_bytes * 16, [&](int wi) {
+    const int j = live[(size_t)wi];
     hso_ba_deltas_job& J = jobs[j];
     const float* err = reinterpret_cast<const float*>(he + (lay[(size_t)j].o_err - in_bytes));
-    errors_pt.clear(); errors_ls.clear();
+    std::vector<float> errors_pt, errors_ls;
     for (int k = 0; k < J.n_edges; k++) (J.edges[k].type == HSO_FTR_EDGELET ? errors_ls : errors_pt).push_back(err[k]);
     // src/bundle_adjustment.cpp:664-680
     if (!errors_pt.empty() && !errors_ls.empty()) {
@@ -1053,7 +1080,7 @@ extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job
       J.huber_corner = (float)(1.4826 * upper_median(errors_pt));
       J.huber_edge = (float)(0.5 / error_multiplier2);
     }
-  }
+  });
   return HSO_OK;
 }
 
@@ -1187,12 +1214,23 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
   BaBatch Q;
   Q.win.resize(n_problems);
   std::vector<BaLm> lm(n_problems);
+  size_t edges_total = 0;
   for (int q = 0; q < n_problems; q++) {
     const hso_ba_problem& P = problems[q];
     if (!P.poses_f_w || !P.pose_fixed || !P.idist || !P.edges || !P.result || P.n_poses <= 0 || P.n_points <= 0 || P.n_edges <= 0 || P.n_iter < 0)
       return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: bad argument");
-    if (int rc = ba_check_edges(ctx, P.edges, P.n_edges, P.n_points, P.n_poses, "ba_optimize")) return rc;
+    edges_total += (size_t)P.n_edges;
+  }
+  // per window: the index check of its edges and the adjacency lists of the layout (hso_host_parallel: the windows of a step of 128
+  // sequences hold half a million edges)
+  std::vector<uint8_t> bad_edges((size_t)n_problems, 0);
+  hso_host_parallel(n_problems, edges_total * 128, [&](int q) {
+    const hso_ba_problem& P = problems[q];
+    if (!ba_edges_ok(P.edges, P.n_edges, P.n_points, P.n_poses)) { bad_edges[(size_t)q] = 1; return; }
     ba_layout(Q.win[q], P.n_poses, P.n_points, P.pose_fixed, P.edges, P.n_edges, P.huber_corner, P.huber_edge);
+  });
+  for (int q = 0; q < n_problems; q++) {
+    if (bad_edges[(size_t)q]) return ba_check_edges(ctx, problems[q].edges, problems[q].n_edges, problems[q].n_points, problems[q].n_poses, "ba_optimize");
     if (Q.win[q].M > 96) return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: more than 16 free poses in one window (the reference's core is 7 keyframes)");
   }
   if (int rc = ba_batch_begin(Q, ctx, problems, n_problems)) return rc;

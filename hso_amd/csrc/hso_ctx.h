@@ -2,8 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <string>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 #include "../../include/hso_gpu.h"
 
@@ -100,6 +102,9 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
 hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t hso_memset_async(void* dst, int value, size_t bytes, hipStream_t stream);   // counted (hso_gpu_debug_census)
 hipError_t hso_stream_sync(hipStream_t stream);
+// room in the stream's page-locked staging chunks, the caller's until the stream's next synchronisation: a table assembled there
+// goes to the device with one DMA and without the second copy hso_copy_async makes for pageable memory
+char* hso_stage_reserve(hipStream_t stream, size_t bytes);
 void hso_stream_forget(hipStream_t stream);   // context teardown: free the stream's staging chunks
 void hso_stream_set_yielding(hipStream_t stream, bool on);   // waits on the stream sleep (blocking event) instead of polling
 void hso_stream_abandon(hipStream_t stream);  // error path: wait for the stream, then DROP the pending copies into caller memory
@@ -124,6 +129,22 @@ void hso_stream_abandon(hipStream_t stream);  // error path: wait for the stream
   } while (0)
 
 int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg);
+
+// The host side of a batched entry point — staging many megabytes of the caller's tables, checking their indices, sorting per
+// window — ran on the calling thread alone while the device waited: 2.7 + 5.2 ms per keyframe step of 128 sequences in the local-BA
+// calls, 1 ms per step in the map patches.  The library has no pool of its own (a context is driven by one thread), so such loops
+// take a few short-lived threads: fn(i) for i in [0, n), items dealt round-robin; `work` = bytes (or comparable) the loop touches —
+// below ~1 MB the calling thread does it alone.  fn must not touch the HIP runtime or ctx->err.
+template <class F> void hso_host_parallel(int n, size_t work, F&& fn)
+{
+  const int nt = work < (size_t(1) << 20) ? 1 : std::min(n, 4);
+  if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)nt - 1);
+  for (int t = 1; t < nt; t++) th.emplace_back([&fn, t, nt, n] { for (int i = t; i < n; i += nt) fn(i); });
+  for (int i = 0; i < n; i += nt) fn(i);
+  for (std::thread& x : th) x.join();
+}
 // size of a grow-only buffer that must hold `need` bytes now: half again as much + 1 MB, so that tables that grow a little with
 // every keyframe do not re-allocate (hipFree synchronises the device: 0.2-0.4 ms each, 18 per step at 32 sequences before this)
 inline size_t hso_grown(size_t need) { return need + need / 2 + (size_t(1) << 20); }

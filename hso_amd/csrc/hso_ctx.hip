@@ -70,6 +70,7 @@ hipError_t hso_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKin
 {
   if (bytes == 0) return hipSuccess;
   census(HSO_CENSUS_COPIES); census(HSO_CENSUS_COPY_BYTES, (int64_t)bytes);
+  if (kind == hipMemcpyHostToDevice) census(HSO_CENSUS_H2D_BYTES, (int64_t)bytes);
   if (kind == hipMemcpyHostToDevice && !host_is_page_locked(src)) {
     census(HSO_CENSUS_STAGED);
     Stager& S = stager_of(stream);
@@ -96,6 +97,7 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
 {
   if (width == 0 || height == 0) return hipSuccess;
   census(HSO_CENSUS_COPIES); census(HSO_CENSUS_COPY_BYTES, (int64_t)(width * height));
+  if (kind == hipMemcpyHostToDevice) census(HSO_CENSUS_H2D_BYTES, (int64_t)(width * height));
   if (kind == hipMemcpyDeviceToHost && !host_is_page_locked(dst)) {   // rows packed in the chunk, spread out after the synchronisation
     Stager& S = stager_of(stream);
     std::lock_guard<std::mutex> lk(S.m);
@@ -189,6 +191,13 @@ hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind
   const hipError_t e = hso_copy_async(dst, src, bytes, kind, nullptr);
   if (e != hipSuccess) return e;
   return hso_stream_sync(nullptr);
+}
+
+char* hso_stage_reserve(hipStream_t stream, size_t bytes)
+{
+  Stager& S = stager_of(stream);
+  std::lock_guard<std::mutex> lk(S.m);
+  return stage_alloc(S, std::max<size_t>(bytes, 1));
 }
 
 void hso_stream_abandon(hipStream_t stream)

@@ -311,7 +311,7 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   // a context that shares the device with others (hso_gpu_set_shared_device) leaves medium batches on the one-workgroup shape:
   // the other contexts' kernels fill the CUs a batch of < 256 jobs leaves idle, splitting jobs only adds exchange work (7.8 us per
   // job against 3.3), and cooperative launches of several contexts take turns (one at a time per device)
-  const bool medium_ok = !ctx->shared_device;
+  const bool medium_ok = !ctx->shared_device || getenv("HSO_TRACK_SHARED_COOP");   // the knob: measurement only
   if (max_grid <= 0 && (n_jobs <= COOP_MAX_JOBS || (share >= 2 && medium_ok)) && !st->coop_broken && !getenv("HSO_TRACK_NO_COOP")) {
     const int per_xcd = std::min(std::min(COOP_KMAX, std::max(1, ctx->n_cu / 8)), share);
     int fpw = COOP_FEATS_PER_WG;

@@ -116,13 +116,18 @@ Bank::~Bank()
   if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0) {
     static const char* const names[9] = {"upload", "track", "reproject+select+pose", "decide", "local BA", "seed observe", "seed activate", "new seeds", "flush+finish"};
     for (int k = 0; k < 9; k++)
-      fprintf(stderr, "[hso engine]   %-22s per step: %6.1f copies (%5.1f staged, %8.1f KB), %5.1f syncs (%.3f ms blocked), %5.1f memsets\n", names[k],
-              (double)phase_census_[k][0] / n_steps_, (double)phase_census_[k][2] / n_steps_, (double)phase_census_[k][1] / n_steps_ / 1024.0,
+      fprintf(stderr, "[hso engine]   %-22s per step: %6.1f copies (%5.1f staged, %8.1f KB of which %8.1f KB to the device), %5.1f syncs (%.3f ms blocked), %5.1f memsets\n", names[k],
+              (double)phase_census_[k][0] / n_steps_, (double)phase_census_[k][2] / n_steps_, (double)phase_census_[k][1] / n_steps_ / 1024.0, (double)phase_census_[k][6] / n_steps_ / 1024.0,
               (double)phase_census_[k][3] / n_steps_, (double)phase_census_[k][4] / n_steps_ * 1e-6, (double)phase_census_[k][5] / n_steps_);
   }
   if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0)
     fprintf(stderr, "[hso engine] reproject+select+pose = list points + patch maps %.3f, device call %.3f, apply %.3f\n", sub_ms_[0] / n_steps_, sub_ms_[1] / n_steps_,
             sub_ms_[2] / n_steps_);
+  if (timing_ && n_steps_ > 0) {
+    fprintf(stderr, "[hso engine] sections, ms per step:");
+    for (const auto& e : sections_) fprintf(stderr, " %s %.3f,", e.first, e.second / n_steps_);
+    fprintf(stderr, "\n");
+  }
   delete pool_;
   if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);   // before the frames its seeds are hosted in (waits for a pass in flight)
   for (int64_t id : after_prev_release_) (void)hso_gpu_frame_release(ctx_, id);

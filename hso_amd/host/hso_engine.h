@@ -27,6 +27,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 #include "../../include/hso_vo.h"
 #include "hso_math.h"
@@ -234,6 +235,20 @@ private:
   double px_error_angle_ = -1;
   int64_t n_calls_[10] = {0}, n_items_[10] = {0};
   double alg_bytes_[5] = {0, 0, 0, 0, 0};
+  // HSO_ENGINE_TIMING: named sections of the step, timed on the engine's own thread (Sub is a scope timer)
+  std::vector<std::pair<const char*, double>> sections_;
+  bool timing_ = false;
+  struct Sub {
+    Bank* b; const char* name; std::chrono::steady_clock::time_point t;
+    Sub(Bank* bank, const char* n) : b(bank->timing_ ? bank : nullptr), name(n) { if (b) t = std::chrono::steady_clock::now(); }
+    ~Sub()
+    {
+      if (!b) return;
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+      for (auto& e : b->sections_) if (e.first == name) { e.second += ms; return; }
+      b->sections_.emplace_back(name, ms);
+    }
+  };
   double sub_ms_[4] = {0};         // HSO_ENGINE_TIMING: reproject() split into listing / device call / applying
   // the previous-frame pass between previous_begin and previous_collect
   struct PendingPrev { bool on = false, async = false; std::vector<int> who; std::vector<size_t> n_lists; int n_slots = 0;
@@ -242,7 +257,7 @@ private:
   std::vector<int64_t> to_release_;
   std::vector<int64_t> after_prev_release_;   // frames the previous-frame pass dropped from its lists: released once the pass is collected
   double phase_ms_[9] = {0};
-  int64_t phase_census_[9][6] = {{0}};   // per phase: copies, bytes, staged copies, synchronisations, ns blocked in them, memsets
+  int64_t phase_census_[9][7] = {{0}};   // per phase: copies, bytes, staged copies, synchronisations, ns blocked in them, memsets, host-to-device bytes
   int64_t n_steps_ = 0, n_kf_events_ = 0;
   // result tables of the batched calls (kept between steps: no allocation per step)
   Pinned<hso_seq_result> chain_res_;   // the chain's result records

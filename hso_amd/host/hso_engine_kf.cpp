@@ -1,6 +1,7 @@
 // hso_engine_kf.cpp — the keyframe-rate half of a step: the local BA window, the depth filter's seed bookkeeping around the
 // resident seed table, new seeds, the mirror of the sequence tables on the device, the end of a frame.
 #include "hso_engine_impl.h"
+#include <optional>
 
 namespace hso {
 namespace engine {
@@ -79,6 +80,7 @@ void Bank::keyframe_ba(const std::vector<int>& who)
       j.poses_f_w = d.ba_poses.data(); j.n_poses = (int)d.ba_poses.size(); j.idist = d.ba_idist.data(); j.n_points = (int)d.ba_idist.size();
       j.edges = d.ba_edges.data(); j.obs_uv = d.ba_uv.data(); j.n_edges = (int)d.ba_edges.size();
     }
+    Sub t(this, "ba: huber deltas call");
     if (!with.empty()) check(hso_gpu_ba_huber_deltas_multi(ctx_, dj.data(), (int)dj.size(), fmean), "LocalBundleAdjustment");
     for (size_t i = 0; i < with.size(); i++) { step_[with[i]]->huber_corner = dj[i].huber_corner; step_[with[i]]->huber_edge = dj[i].huber_edge; }
   }
@@ -104,7 +106,7 @@ void Bank::keyframe_ba(const std::vector<int>& who)
       p.n_poses = (int)d.ba_poses.size(); p.n_points = (int)d.ba_idist.size(); p.n_edges = (int)d.ba_edges.size(); p.n_iter = d.ba_iters;
       p.huber_corner = d.huber_corner; p.huber_edge = d.huber_edge;
     }
-    check(hso_gpu_ba_optimize_multi(ctx_, pr.data(), (int)pr.size()), "LocalBundleAdjustment");
+    { Sub t(this, "ba: optimize call"); check(hso_gpu_ba_optimize_multi(ctx_, pr.data(), (int)pr.size()), "LocalBundleAdjustment"); }
     n_calls_[8]++; n_items_[8] += (int64_t)pr.size();
     for (size_t i = 0; i < with.size(); i++) {
       Seq& s = *seq_[with[i]];
@@ -119,7 +121,8 @@ void Bank::keyframe_ba(const std::vector<int>& who)
       t.field("edge_chi2", d.ba_chi2.data(), sizeof(double) * d.ba_chi2.size()); t.field("result", &d.ba_res, sizeof(d.ba_res));
     }
   }
-  par(with, [&](int k) { apply_window(k); });
+  { Sub t(this, "ba: apply_window"); par(with, [&](int k) { apply_window(k); }); }
+  Sub t_tail(this, "ba: keys + seed poses");
   // setKeyPoints of the overlap keyframes (src/frame_handler_mono.cpp:331)
   par(who, [&](int k) { Seq& s = *seq_[k]; for (Id kf : step_[k]->visit) s.refresh_keys(s.frames[kf]); });
   // the resident seeds of the moved keyframes follow them
@@ -909,6 +912,8 @@ void Bank::flush_maps(const std::vector<int>& who)
     bool kf = false, key = false;
   };
   std::vector<Patch> patch(who.size());
+  std::optional<Sub> t_sec;
+  t_sec.emplace(this, "flush: build (pool)");
   pool_->run((int)who.size(), [&](int i) {
     Seq& s = *seq_[who[i]];
     Patch& P = patch[i];
@@ -986,6 +991,7 @@ void Bank::flush_maps(const std::vector<int>& who)
       }
     }
   });
+  t_sec.emplace(this, "flush: device calls");
   std::vector<hso_seqmap_rows> rows;
   std::vector<hso_seqmap_list_patch> lists;
   for (size_t i = 0; i < who.size(); i++) {
@@ -1014,7 +1020,18 @@ void Bank::flush_maps(const std::vector<int>& who)
 // FrameHandlerMono::addImage's tail (:113-122) and FrameHandlerBase::finishFrameProcessingCommon (src/frame_handler_base.cpp:116-152)
 void Bank::finish(const std::vector<int>& who)
 {
+  // a failed start drops everything and pauses the handler (resetAll): device calls, so on this thread (rare)
   for (int k : who) {
+    Seq& s = *seq_[k];
+    StepData& d = *step_[k];
+    if (d.stage0 == kRunning || d.stage0 == kRelocalising || s.outcome != kFailure) continue;
+    for (Frame& F : s.frames) if (F.in_use && F.dev_id >= 0) to_release_.push_back(F.dev_id);
+    drop_sequence_seeds(k);
+    s.reset_tables();
+    s.stage = kPaused; s.quality = kInsufficient; s.n_obs_last = 0;
+  }
+  // everything else touches one sequence's tables only
+  par(who, [&](int k) {
     Seq& s = *seq_[k];
     StepData& d = *step_[k];
     if (d.stage0 == kRunning || d.stage0 == kRelocalising) {
@@ -1029,18 +1046,11 @@ void Bank::finish(const std::vector<int>& who)
       } else if (d.relocalised) C.T = d.reloc_pose;               // "reset to last well localized pose"
       s.log.n_seeds = (int)s.seeds.size() - s.n_dead_seeds; s.log.n_candidates = (int)s.candidates.size();
       if (s.outcome == kFailure) { s.stage = kRelocalising; s.quality = kInsufficient; }
-    } else if (s.outcome == kFailure) {
-      // a failed start: everything is dropped and the handler pauses (resetAll)
-      for (Frame& F : s.frames) if (F.in_use && F.dev_id >= 0) to_release_.push_back(F.dev_id);
-      drop_sequence_seeds(k);
-      s.reset_tables();
-      s.stage = kPaused; s.quality = kInsufficient; s.n_obs_last = 0;
-      continue;
-    }
+    } else if (s.stage == kPaused) return;                        // the failed start handled above
     // the new frame becomes the last one
     const Id old = s.last;
     s.last = s.cur; s.cur = kNone;
-    if (old != kNone && old != s.last) release_frame(s, old);
+    if (old != kNone && old != s.last) release_frame_deferred(s, d, old);
     s.n_obs_last = s.frames[s.last].n_inliers;
     s.hist_stamp.push_back(s.frames[s.last].stamp); s.hist_pose.push_back(s.frames[s.last].T.v);
     // dead seeds leave the list once they are the majority (list order of the live ones is kept)
@@ -1049,6 +1059,11 @@ void Bank::finish(const std::vector<int>& who)
       for (size_t i = 0; i < s.seeds.size(); i++) if (s.seeds[i].alive) { if (keep != i) s.seeds[keep] = std::move(s.seeds[i]); keep++; }
       s.seeds.resize(keep); s.n_dead_seeds = 0;
     }
+  });
+  for (int k : who) {
+    StepData& d = *step_[k];
+    to_release_.insert(to_release_.end(), d.released.begin(), d.released.end());
+    d.released.clear();
   }
   // the resident table drops its erased slots once they are the majority
   int n_slots = 0, n_live = 0;

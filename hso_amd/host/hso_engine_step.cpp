@@ -1,6 +1,7 @@
 // hso_engine_step.cpp — the per-frame phases of a step: frame construction, CoarseTracker, reprojection + selection + pose
 // optimisation, and what FrameHandlerMono::processFrame decides from their results.
 #include "hso_engine_impl.h"
+#include <unistd.h>
 #include <chrono>
 
 namespace hso {
@@ -10,18 +11,18 @@ namespace {
 // developer probe (HSO_ENGINE_TIMING=1): wall time per phase of a step, printed when the bank goes away
 // and what the device library asked of the runtime meanwhile (hso_gpu_debug_census; process-wide, so meaningful for one bank)
 struct Clock {
-  double* acc; int64_t (*cen)[6]; bool on;
+  double* acc; int64_t (*cen)[7]; bool on;
   std::chrono::steady_clock::time_point t;
-  int64_t c0[6];
-  Clock(double* a, int64_t (*c)[6], bool o) : acc(a), cen(c), on(o) { if (on) { t = std::chrono::steady_clock::now(); hso_gpu_debug_census(c0, 6); } }
+  int64_t c0[7], begin[7];
+  Clock(double* a, int64_t (*c)[7], bool o) : acc(a), cen(c), on(o) { if (on) { t = std::chrono::steady_clock::now(); hso_gpu_debug_census(c0, 7); for (int i = 0; i < 7; i++) begin[i] = c0[i]; } }
   void lap(int k)
   {
     if (!on) return;
     const auto u = std::chrono::steady_clock::now();
     acc[k] += std::chrono::duration<double, std::milli>(u - t).count();
-    int64_t c1[6];
-    hso_gpu_debug_census(c1, 6);
-    for (int i = 0; i < 6; i++) { cen[k][i] += c1[i] - c0[i]; c0[i] = c1[i]; }
+    int64_t c1[7];
+    hso_gpu_debug_census(c1, 7);
+    for (int i = 0; i < 7; i++) { cen[k][i] += c1[i] - c0[i]; c0[i] = c1[i]; }
     t = std::chrono::steady_clock::now();
   }
 };
@@ -65,7 +66,8 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
   if (who.empty()) return;
   release_queued();
 
-  Clock ck(phase_ms_, phase_census_, getenv("HSO_ENGINE_TIMING") != nullptr);
+  timing_ = getenv("HSO_ENGINE_TIMING") != nullptr;
+  Clock ck(phase_ms_, phase_census_, timing_);
   upload(who, imgs, w, h, stamps, on_device);
   ck.lap(0);
   std::vector<int> starting, running;
@@ -105,20 +107,27 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
       n_kf_events_ += (int64_t)kf.size();
     }
   }
-  flush_maps(who);
-  finish(who);
-  release_queued();
+  if (const char* e = getenv("HSO_ENGINE_EXTRA_US")) usleep((useconds_t)atoi(e));   // measurement aid: is the host's serial time on the critical path?
+  { Sub t(this, "end: flush_maps"); flush_maps(who); }
+  { Sub t(this, "end: finish"); finish(who); }
+  { Sub t(this, "end: release"); release_queued(); }
   // the depth filter's idle-time sweep over the sequences that stepped, beside the next step's tracking
   {
     std::vector<int> swept;
     for (int k : who) if (seq_[k]->stage == kRunning && step_[k]->ok) swept.push_back(k);
+    Sub t(this, "end: previous_begin");
     if (!swept.empty()) previous_begin(swept);
   }
   ck.lap(8);
   n_steps_++;
   if (const char* e = getenv("HSO_ENGINE_TIMING")) if (atoi(e) >= 2) {   // one line per step: the phases' wall time since the last step's line
     static thread_local double last[9] = {0};
-    fprintf(stderr, "[hso engine step %lld] kf %lld |", (long long)n_steps_, (long long)n_kf_events_);
+    static thread_local long long last_kf = 0;
+    // keyframes taken in this step, then what the step asked of the runtime (all contexts of the process: read it from a lone bank)
+    fprintf(stderr, "[hso engine step %lld] kf %lld (+%lld) | copies %lld syncs %lld to-device KB %.1f from-device KB %.1f |", (long long)n_steps_, (long long)n_kf_events_,
+            (long long)n_kf_events_ - last_kf, (long long)(ck.c0[0] - ck.begin[0]), (long long)(ck.c0[3] - ck.begin[3]), (double)(ck.c0[6] - ck.begin[6]) / 1024.0,
+            (double)((ck.c0[1] - ck.begin[1]) - (ck.c0[6] - ck.begin[6])) / 1024.0);
+    last_kf = (long long)n_kf_events_;
     for (int k = 0; k < 9; k++) { fprintf(stderr, " %.2f", phase_ms_[k] - last[k]); last[k] = phase_ms_[k]; }
     fprintf(stderr, "\n");
   }
@@ -372,12 +381,12 @@ void Bank::chain(const std::vector<int>& who)
   std::vector<int> in;
   for (int k : who) if (!(seq_[k]->stage == kRelocalising && !step_[k]->relocalised)) in.push_back(k);
   if (in.empty()) return;
-  previous_collect();                                              // the idle-time pass of the last step, before seeds are observed again
+  { Sub t(this, "chain: previous_collect"); previous_collect(); }   // the idle-time pass of the last step, before seeds are observed again
   // the job records: serial (they append to one list of temporary points; a few dozen assignments per sequence)
   std::vector<hso_seq_job> all(in.size());
   std::vector<int32_t> temps;
-  for (size_t i = 0; i < in.size(); i++) prepare_job(in[i], all[i], temps);
-  flush_maps(in);                                                 // the rows, lists and links that changed since the last frame
+  { Sub t(this, "chain: prepare_job"); for (size_t i = 0; i < in.size(); i++) prepare_job(in[i], all[i], temps); }
+  { Sub t(this, "chain: flush_maps"); flush_maps(in); }           // the rows, lists and links that changed since the last frame
   hso_seq_chain_cfg cfg{};
   cfg.cell_size = cell_size_; cfg.grid_n_cols = grid_cols_; cfg.n_cells = (int)cell_order_.size(); cfg.max_fts = cfg_.max_fts;
   cfg.cell_order = cell_order_.data(); cfg.max_kfs = cfg_.reproject_max_kfs; cfg.pose_n_iter = 12; cfg.pose_reproj_thresh = cfg_.poseoptim_thresh;
@@ -400,7 +409,7 @@ void Bank::chain(const std::vector<int>& who)
     cfg.track = hso_track_params{mode, cfg_.klt_max_level, cfg_.klt_min_level + 1, 50};
     cfg.seed_brief_out = brief_images ? brief_images + (size_t)mode * (size_t)n_slots : nullptr;
     hso_seq_result* res = chain_res_.need(ctx_, grp.size());
-    check(hso_gpu_seq_chain(ctx_, &cam_.pod(), &cfg, jobs.data(), (int)jobs.size(), temps.empty() ? nullptr : temps.data(), (int)temps.size(), res), "processFrame");
+    { Sub t(this, "chain: device call"); check(hso_gpu_seq_chain(ctx_, &cam_.pod(), &cfg, jobs.data(), (int)jobs.size(), temps.empty() ? nullptr : temps.data(), (int)temps.size(), res), "processFrame"); }
     n_calls_[2]++; n_items_[2] += (int64_t)grp.size();
     n_calls_[3]++; n_items_[3] += (int64_t)grp.size();
     std::vector<std::vector<int32_t>> more(grp.size());
@@ -410,6 +419,7 @@ void Bank::chain(const std::vector<int>& who)
         check(hso_gpu_seq_events(ctx_, (int)i, more[i].data(), (int)more[i].size()), "processFrame");
       }
     if (any_trace) trace_chain(grp, jobs, cfg, res);
+    Sub t_consume(this, "chain: consume");
     pool_->run((int)grp.size(), [&](int i) {
       consume_result(grp[(size_t)i], res[i], more[(size_t)i]);
       StepData& d = *step_[grp[(size_t)i]];

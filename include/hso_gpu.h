@@ -688,7 +688,7 @@ int hso_gpu_seed_activate_frames(hso_gpu_ctx* ctx, const hso_camera* cam, const 
 
 /* The same for seeds that live in a resident seed table (hso_gpu_seed_table_*): seed i is the record in `slots[i]` as the table holds
  * it — mu / sigma2 / b as its last observation left them, the host keyframe's pose as hso_gpu_seed_table_set_host_pose left it — so
- * 4 bytes per seed cross the bus instead of a 192-byte record (1 MB per step of 128 sequences), and the caller does not assemble
+ * 4 bytes per seed cross the bus instead of a 152-byte record (0.8 MB per step of 128 sequences), and the caller does not assemble
  * records it already mirrored.  A dead slot is an error.  Results are those of hso_gpu_seed_activate_frames on
  * hso_gpu_seed_table_read's records of the same slots. */
 int hso_gpu_seed_table_activate(hso_gpu_ctx* ctx, const hso_camera* cam, int table, const int32_t* slots, int n_seeds, const int32_t* target_begin,
@@ -762,6 +762,7 @@ typedef struct hso_seqmap_rows {
   const int32_t* obs_ids; const hso_obs* obs;
   const int32_t* obs_point;    /* may be NULL: Feature::point of the patched observation rows (point row, -1: NULL) */
 } hso_seqmap_rows;
+/* a map appears at most once per call */
 int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches, int n_patches);
 int hso_gpu_seqmap_size(hso_gpu_ctx* ctx, int map, int* n_kfs, int* n_points, int* n_obs);
 /* parity / trace read-back of rows as the device holds them now */
@@ -933,7 +934,7 @@ int hso_gpu_debug_fetch(hso_gpu_ctx* ctx, int what, void* out, size_t bytes);
  * bytes, copies that went through page-locked staging because the caller's memory was pageable, stream synchronisations, nanoseconds
  * the calling threads spent blocked in them, memsets.  out[i] for i < n; entries beyond HSO_CENSUS_N read 0.  A driver that
  * differences it around its phases sees where the host round trips of a step are (hso_amd/host: HSO_ENGINE_TIMING=1). */
-enum { HSO_CENSUS_COPIES = 0, HSO_CENSUS_COPY_BYTES = 1, HSO_CENSUS_STAGED = 2, HSO_CENSUS_SYNCS = 3, HSO_CENSUS_SYNC_NS = 4, HSO_CENSUS_MEMSETS = 5, HSO_CENSUS_N = 6 };
+enum { HSO_CENSUS_COPIES = 0, HSO_CENSUS_COPY_BYTES = 1, HSO_CENSUS_STAGED = 2, HSO_CENSUS_SYNCS = 3, HSO_CENSUS_SYNC_NS = 4, HSO_CENSUS_MEMSETS = 5, HSO_CENSUS_H2D_BYTES = 6 /* the host-to-device part of COPY_BYTES */, HSO_CENSUS_N = 7 };
 void hso_gpu_debug_census(int64_t* out, int n);
 
 /* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
