@@ -2,6 +2,7 @@
 construction, tracker, reprojection + matching + selection + pose, local BA, depth filter, all on one evolving state per sequence)
 for many sequences in lockstep on one GPU.  `distinct` rendered sequences are replicated to `sequences` (same images = same work).
 Prints one JSON line; HSO_ENGINE_TIMING=1 adds the engine's phase split on stderr."""
+import os
 import json
 import sys
 import time
@@ -66,7 +67,23 @@ def _gpu_busy_reader(device):
     cards = sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))
     if not cards:
         return None
-    path = cards[min(device, len(cards) - 1)]
+    path = None
+    try:
+        # the card whose PCI address is the HIP device's (sysfs numbers every card of the host; the process may see one of them)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
+            bus = buf.value.decode().lower()
+            for c in cards:
+                if os.path.realpath(os.path.dirname(c)).lower().endswith(bus):
+                    path = c
+    except (OSError, AttributeError):
+        pass
+    if path is None:
+        if len(cards) > 1:
+            return None                      # which of the host's cards is ours is not known: no figure rather than another GPU's
+        path = cards[0]
 
     def read():
         try:

@@ -757,7 +757,7 @@ int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches,
   // a keyframe step sends tens of thousands of rows)
   std::vector<const char*> bad((size_t)n_patches, nullptr);
   std::vector<size_t> need_p((size_t)n_patches), need_o((size_t)n_patches);
-  hso_host_parallel(n_patches, rows_total * 64, [&](int i) {
+  hso_host_parallel(ctx, n_patches, rows_total * 64, [&](int i) {
     const hso_seqmap_rows& P = patches[i];
     const SeqMap* m = seqmap_of(ctx, P.map);
     const int nk = (int)m->kfs.size();
@@ -807,7 +807,7 @@ int hso_gpu_seqmap_patch_multi(hso_gpu_ctx* ctx, const hso_seqmap_rows* patches,
   hso_map_point* rp = reinterpret_cast<hso_map_point*>(h + b_dp + b_do + b_dl);
   hso_obs* ro = reinterpret_cast<hso_obs*>(h + b_dp + b_do + b_dl + b_p);
   int32_t* rl = reinterpret_cast<int32_t*>(h + b_dp + b_do + b_dl + b_p + b_o);
-  hso_host_parallel(n_patches, need, [&](int i) {
+  hso_host_parallel(ctx, n_patches, need, [&](int i) {
     const hso_seqmap_rows& P = patches[i];
     const SeqMap* m = seqmap_of(ctx, P.map);
     size_t ip = at_p[(size_t)i], io = at_o[(size_t)i], il = at_l[(size_t)i];

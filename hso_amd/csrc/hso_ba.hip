@@ -833,7 +833,7 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
     od += B.total; oh += B.in_bytes;
   }
   // the windows' input images, assembled side by side in the page-locked block (a few threads: tens of megabytes per keyframe step)
-  hso_host_parallel(n, pin_in - hdr, [&](int q) {
+  hso_host_parallel(ctx, n, pin_in - hdr, [&](int q) {
     const BaWin& B = Q.win[q];
     const hso_ba_problem& P = problems[q];
     char* w = B.h_in;
@@ -1021,7 +1021,7 @@ extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job
   if (live.empty()) return HSO_OK;
   {
     std::vector<uint8_t> bad(live.size(), 0);
-    hso_host_parallel((int)live.size(), o, [&](int wi) {
+    hso_host_parallel(ctx, (int)live.size(), o, [&](int wi) {
       const hso_ba_deltas_job& J = jobs[live[(size_t)wi]];
       bad[(size_t)wi] = ba_edges_ok(J.edges, J.n_edges, J.n_points, J.n_poses) ? 0 : 1;
     });
@@ -1044,7 +1044,7 @@ extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job
   char* he = hso_pinned(ctx, 1, err_bytes);
   if (!h || !he) return HSO_E_NOMEM;
   MadWin* hw = reinterpret_cast<MadWin*>(h);
-  hso_host_parallel((int)live.size(), in_bytes, [&](int wi) {
+  hso_host_parallel(ctx, (int)live.size(), in_bytes, [&](int wi) {
     const size_t w = (size_t)wi;
     const hso_ba_deltas_job& J = jobs[live[w]];
     const Lay& L = lay[(size_t)live[w]];
@@ -1063,7 +1063,7 @@ extern "C" int hso_gpu_ba_huber_deltas_multi(hso_gpu_ctx* ctx, hso_ba_deltas_job
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(he, d + in_bytes, err_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   // the medians, a window per item (an nth_element over tens of thousands of errors each)
-  hso_host_parallel((int)live.size(), err_bytes * 16, [&](int wi) {
+  hso_host_parallel(ctx, (int)live.size(), err_bytes * 16, [&](int wi) {
     const int j = live[(size_t)wi];
     hso_ba_deltas_job& J = jobs[j];
     const float* err = reinterpret_cast<const float*>(he + (lay[(size_t)j].o_err - in_bytes));
@@ -1224,7 +1224,7 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
   // per window: the index check of its edges and the adjacency lists of the layout (hso_host_parallel: the windows of a step of 128
   // sequences hold half a million edges)
   std::vector<uint8_t> bad_edges((size_t)n_problems, 0);
-  hso_host_parallel(n_problems, edges_total * 128, [&](int q) {
+  hso_host_parallel(ctx, n_problems, edges_total * 128, [&](int q) {
     const hso_ba_problem& P = problems[q];
     if (!ba_edges_ok(P.edges, P.n_edges, P.n_points, P.n_poses)) { bad_edges[(size_t)q] = 1; return; }
     ba_layout(Q.win[q], P.n_poses, P.n_points, P.pose_fixed, P.edges, P.n_edges, P.huber_corner, P.huber_edge);

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <string>
 #include <unordered_map>
+#include <functional>
 #include <thread>
 #include <vector>
 #include "../../include/hso_gpu.h"
@@ -48,6 +49,7 @@ struct hso_gpu_ctx {
   hipStream_t stream;
   bool own_stream;
   int n_cu;
+  struct HostHelpers* helpers = nullptr;   // hso_host_parallel_run
   bool shared_device = false;   // hso_gpu_set_shared_device: other contexts keep the device busy beside this one
   std::string err;
   std::unordered_map<int64_t, FrameRec> frames;
@@ -131,19 +133,18 @@ void hso_stream_abandon(hipStream_t stream);  // error path: wait for the stream
 int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg);
 
 // The host side of a batched entry point — staging many megabytes of the caller's tables, checking their indices, sorting per
-// window — ran on the calling thread alone while the device waited: 2.7 + 5.2 ms per keyframe step of 128 sequences in the local-BA
-// calls, 1 ms per step in the map patches.  The library has no pool of its own (a context is driven by one thread), so such loops
-// take a few short-lived threads: fn(i) for i in [0, n), items dealt round-robin; `work` = bytes (or comparable) the loop touches —
-// below ~1 MB the calling thread does it alone.  fn must not touch the HIP runtime or ctx->err.
-template <class F> void hso_host_parallel(int n, size_t work, F&& fn)
+// window — runs on the calling thread while the device waits: 2.7 + 5.2 ms per keyframe step of 128 sequences in the local-BA calls,
+// 1 ms per step in the map patches.  hso_host_parallel(ctx, n, work, fn) can spread such a loop over three helper threads the
+// context keeps (started at the first use, asleep in between): fn(i) for i in [0, n), handed out one at a time to the helpers and
+// the caller; `work` = bytes (or comparable) the loop touches — below ~1 MB the calling thread does it alone.  fn must not touch
+// the HIP runtime or ctx->err.  OFF by default (HSO_HOST_PARALLEL=1): see hso_host_parallel_on in hso_ctx.hip.
+void hso_host_parallel_run(hso_gpu_ctx* ctx, int n, const std::function<void(int)>& fn);   // hso_ctx.hip: the context's helper threads
+bool hso_host_parallel_on();   // HSO_HOST_PARALLEL=1 turns the helper threads on (off by default: see hso_ctx.hip)
+template <class F> void hso_host_parallel(hso_gpu_ctx* ctx, int n, size_t work, F&& fn)
 {
-  const int nt = work < (size_t(1) << 20) ? 1 : std::min(n, 4);
-  if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
-  std::vector<std::thread> th;
-  th.reserve((size_t)nt - 1);
-  for (int t = 1; t < nt; t++) th.emplace_back([&fn, t, nt, n] { for (int i = t; i < n; i += nt) fn(i); });
-  for (int i = 0; i < n; i += nt) fn(i);
-  for (std::thread& x : th) x.join();
+  if (n < 2 || work < (size_t(1) << 20) || !hso_host_parallel_on()) { for (int i = 0; i < n; i++) fn(i); return; }
+  const std::function<void(int)> f(std::ref(fn));
+  hso_host_parallel_run(ctx, n, f);
 }
 // size of a grow-only buffer that must hold `need` bytes now: half again as much + 1 MB, so that tables that grow a little with
 // every keyframe do not re-allocate (hipFree synchronises the device: 0.2-0.4 ms each, 18 per step at 32 sequences before this)

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <time.h>
 #include <sys/prctl.h>
+#include <condition_variable>
 #include <mutex>
 #include <unordered_set>
 #include <vector>
@@ -193,6 +194,65 @@ hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind
   return hso_stream_sync(nullptr);
 }
 
+// Off unless HSO_HOST_PARALLEL=1: the helpers shorten the local-BA phase of a lone engine (3.85 -> 3.04 ms per step of 128 sequences),
+// but six engines inside bench.py's process lost 20-35 % of their steady-state throughput with them when the engines' stream waits
+// nap (profiles/r5_engine_host.md section 6) — threads that the scheduler places anywhere on a two-socket host copy into page-locked
+// blocks of another node while the engines' own pools are already 3.5 x oversubscribed.
+bool hso_host_parallel_on() { static const bool on = getenv("HSO_HOST_PARALLEL") != nullptr && getenv("HSO_HOST_SERIAL") == nullptr; return on; }
+
+// ---- the context's helper threads (hso_ctx.h: hso_host_parallel) ----
+struct HostHelpers {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable go, done;
+  const std::function<void(int)>* fn = nullptr;
+  int n = 0, generation = 0, busy = 0;
+  std::atomic<int> next{0};
+  bool stop = false;
+  void work() { for (int i = next.fetch_add(1, std::memory_order_relaxed); i < n; i = next.fetch_add(1, std::memory_order_relaxed)) (*fn)(i); }
+  void loop()
+  {
+    int seen = 0;
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      go.wait(lk, [&] { return stop || generation != seen; });
+      if (stop) return;
+      seen = generation;
+      lk.unlock();
+      work();
+      lk.lock();
+      if (--busy == 0) done.notify_one();
+    }
+  }
+};
+
+void hso_host_parallel_run(hso_gpu_ctx* ctx, int n, const std::function<void(int)>& fn)
+{
+  if (!ctx->helpers) {
+    ctx->helpers = new HostHelpers();
+    for (int t = 0; t < 3; t++) ctx->helpers->th.emplace_back([h = ctx->helpers] { h->loop(); });
+  }
+  HostHelpers& H = *ctx->helpers;
+  {
+    std::lock_guard<std::mutex> lk(H.m);
+    H.fn = &fn; H.n = n; H.next.store(0, std::memory_order_relaxed); H.busy = (int)H.th.size(); H.generation++;
+  }
+  H.go.notify_all();
+  H.work();
+  std::unique_lock<std::mutex> lk(H.m);
+  H.done.wait(lk, [&] { return H.busy == 0; });
+}
+
+static void host_helpers_free(hso_gpu_ctx* ctx)
+{
+  if (!ctx->helpers) return;
+  { std::lock_guard<std::mutex> lk(ctx->helpers->m); ctx->helpers->stop = true; }
+  ctx->helpers->go.notify_all();
+  for (std::thread& t : ctx->helpers->th) t.join();
+  delete ctx->helpers;
+  ctx->helpers = nullptr;
+}
+
 char* hso_stage_reserve(hipStream_t stream, size_t bytes)
 {
   Stager& S = stager_of(stream);
@@ -344,6 +404,7 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  host_helpers_free(ctx);
   hso_track_state_free(ctx);
   hso_seed_tables_free(ctx);
   hso_seqmaps_free(ctx);

@@ -98,7 +98,8 @@ int hso_vo_multi_get_trajectory(hso_vo_multi* m, int sequence, double* timestamp
 int hso_vo_multi_call_counts(hso_vo_multi* m, int64_t* calls, int64_t* items, int cap);
 /* The host side of a bank is a small thread pool (per-sequence bookkeeping between the device calls).  A process that runs several
  * banks side by side (one thread each, independent sequences shard freely within a GPU too) says so BEFORE it creates them: every
- * bank then sizes its pool to max(1, cpu quota / (LOCAL_WORLD_SIZE * banks_in_process) - 1) workers — the CPUs the process may keep
+ * bank then sizes its pool to max(1, (7 * cpu quota) / (2 * LOCAL_WORLD_SIZE * banks_in_process)) workers (3.5 x oversubscribed: most
+ * workers of a bank sleep while its device call runs; a lone bank: quota - 1) and shares the device — the CPUs the process may keep
  * busy (hardware threads, or its cgroup's cpu.max) shared among the ranks of a node (LOCAL_WORLD_SIZE of the launcher) and its own
  * banks.  HSO_ENGINE_THREADS overrides.  hso_vo_multi_threads: the workers a bank got; hso_vo_host_cpu_quota: the quota. */
 int hso_vo_host_share(int banks_in_process);

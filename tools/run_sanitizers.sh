@@ -35,4 +35,4 @@ set +x
 ( time $OUT/pool_stress_tsan 6 20000 ) > $OUT/pool_stress_tsan.log 2>&1; echo "pool_stress_tsan rc=$?" | tee -a $OUT/pool_stress_tsan.log
 ( time HSO_ENGINE_THREADS=4 $OUT/engine_tsan $OUT/seq.bin 4 120 3 ) > $OUT/engine_tsan.log 2>&1; echo "engine_tsan rc=$?" | tee -a $OUT/engine_tsan.log
 ( time HSO_ENGINE_THREADS=4 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 $OUT/engine_asan $OUT/seq.bin 4 120 3 ) > $OUT/engine_asan.log 2>&1; echo "engine_asan rc=$?" | tee -a $OUT/engine_asan.log
-tail -3 $OUT/pool_stress_tsan.log $OUT/engine_tsan.log $OUT/engine_asan.log
+tail -n 3 $OUT/pool_stress_tsan.log $OUT/engine_tsan.log $OUT/engine_asan.log
