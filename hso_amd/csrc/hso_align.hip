@@ -632,16 +632,21 @@ int hso_seqmap_flush_kfs(hso_gpu_ctx* ctx)
   SeqMaps* S = ctx->seqmaps;
   if (!S || S->stale_kfs.empty()) return HSO_OK;
   size_t n_rows = 0;
-  for (int id : S->stale_kfs) if (SeqMap* m = seqmap_of(ctx, id)) if (m->kfs_stale) n_rows += m->kfs.size();
+  for (int id : S->stale_kfs)
+    if (SeqMap* m = seqmap_of(ctx, id))
+      if (m->kfs_stale) {
+        // nothing is marked clean before every keyframe of every stale map is known to be resident: a failing call leaves the list as it is
+        for (const hso_kf& k : m->kfs) if (!ctx->frames.count(k.frame_id)) return hso_fail(ctx, HSO_E_NOFRAME, "seqmap: keyframe not resident");
+        n_rows += m->kfs.size();
+      }
   std::vector<SeqKfDev> rows; rows.reserve(n_rows);
   std::vector<unsigned long long*> dst; dst.reserve(n_rows);
   for (int id : S->stale_kfs) {
     SeqMap* m = seqmap_of(ctx, id);
-    if (!m || !m->kfs_stale) continue;                            // destroyed since, or named twice
-    m->kfs_stale = false;
+    if (!m || !m->kfs_stale) continue;                            // destroyed since
     for (size_t k = 0; k < m->kfs.size(); k++) {
       auto it = ctx->frames.find(m->kfs[k].frame_id);
-      if (it == ctx->frames.end()) { S->stale_kfs.clear(); return hso_fail(ctx, HSO_E_NOFRAME, "seqmap: keyframe not resident"); }
+      if (it == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "seqmap: keyframe not resident");   // checked above
       SeqKfDev r{};
       r.T_f_w = m->kfs[k].T_f_w; r.exposure_time = m->kfs[k].exposure_time; r.base = it->second.base; r.frame_id = m->kfs[k].frame_id;
       r.keyframe_id = m->kfs[k].keyframe_id;
@@ -649,8 +654,8 @@ int hso_seqmap_flush_kfs(hso_gpu_ctx* ctx)
       rows.push_back(r); dst.push_back(reinterpret_cast<unsigned long long*>(m->d_kfs + k));
     }
   }
-  S->stale_kfs.clear();
-  if (rows.empty()) return HSO_OK;
+  auto mark_clean = [&] { for (int id : S->stale_kfs) if (SeqMap* m = seqmap_of(ctx, id)) m->kfs_stale = false; S->stale_kfs.clear(); };
+  if (rows.empty()) { mark_clean(); return HSO_OK; }
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t row_bytes = sizeof(SeqKfDev) * rows.size(), need = row_bytes + sizeof(void*) * rows.size();
   if (S->kfup_cap < need) {
@@ -669,6 +674,7 @@ int hso_seqmap_flush_kfs(hso_gpu_ctx* ctx)
   hipLaunchKernelGGL(k_scatter_rows_to, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                      reinterpret_cast<unsigned long long* const*>(S->d_kfup + row_bytes), reinterpret_cast<const unsigned long long*>(S->d_kfup), (int)rows.size(), granules);
   HSO_HIP_CHECK(ctx, hipGetLastError());
+  mark_clean();                                                   // only now: a failing exit above leaves every map on the list
   return HSO_OK;
 }
 

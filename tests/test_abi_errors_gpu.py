@@ -74,3 +74,77 @@ def test_null_and_inconsistent_arguments(gpu_ctx, cam, pair200):
     # a null context never dereferences
     assert lib.hso_gpu_frame_release(None, 1) == E_INVALID
     assert lib.hso_gpu_synchronize(None) == E_INVALID
+
+
+class _Kf(C.Structure):
+    _fields_ = [("frame_id", C.c_int64), ("T_f_w", capi.SE3), ("exposure_time", C.c_double), ("keyframe_id", C.c_int32), ("pad_", C.c_int32)]
+
+
+class _MapPoint(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("idist", C.c_double), ("host_f", C.c_double * 3), ("host_kf", C.c_int32),
+                ("obs_begin", C.c_int32), ("obs_count", C.c_int32), ("pad_", C.c_int32)]
+
+
+class _Obs(C.Structure):
+    _fields_ = [("kf", C.c_int32), ("level", C.c_int32), ("type", C.c_int32), ("pad_", C.c_int32),
+                ("px", C.c_double * 2), ("f", C.c_double * 3), ("grad", C.c_double * 2)]
+
+
+class _Rows(C.Structure):
+    _fields_ = [("map", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32), ("pad_", C.c_int32),
+                ("point_ids", C.POINTER(C.c_int32)), ("points", C.POINTER(_MapPoint)),
+                ("obs_ids", C.POINTER(C.c_int32)), ("obs", C.POINTER(_Obs)), ("obs_point", C.POINTER(C.c_int32))]
+
+
+def test_sequence_map_arguments(gpu_ctx, pair200):
+    """hso_gpu_seqmap_*: what the engine sends every frame, checked before it reaches the kernels (they trust the tables)."""
+    lib = capi.load()
+    h = gpu_ctx.h
+    for fn in ("hso_gpu_seqmap_create", "hso_gpu_seqmap_destroy", "hso_gpu_seqmap_set_keyframes", "hso_gpu_seqmap_patch_multi",
+               "hso_gpu_seqmap_size", "hso_gpu_seqmap_set_key_points", "hso_gpu_seqmap_configure", "hso_gpu_seq_chain"):
+        getattr(lib, fn).restype = C.c_int
+    lib.hso_gpu_seqmap_patch_multi.argtypes = [C.c_void_p, C.POINTER(_Rows), C.c_int]
+    lib.hso_gpu_seqmap_set_keyframes.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Kf), C.c_int]
+    lib.hso_gpu_seqmap_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    m0, m1 = C.c_int(-1), C.c_int(-1)
+    assert lib.hso_gpu_seqmap_create(h, C.byref(m0)) == 0 and lib.hso_gpu_seqmap_create(h, C.byref(m1)) == 0 and m0.value != m1.value
+    gpu_ctx.frame_upload(9700, pair200["ref"])
+    try:
+        assert lib.hso_gpu_seqmap_destroy(h, 12345) == E_INVALID
+        kf = _Kf(9701, capi.SE3.identity(), 1.0, 0, 0)
+        assert lib.hso_gpu_seqmap_set_keyframes(h, m0.value, C.byref(kf), 1) == E_NOFRAME          # keyframe not resident
+        kf.frame_id = 9700
+        assert lib.hso_gpu_seqmap_set_keyframes(h, m0.value, C.byref(kf), 1) == 0
+        assert lib.hso_gpu_seqmap_set_keyframes(h, m0.value, None, 1) == E_INVALID
+        ids = (C.c_int32 * 2)(0, 1)
+        pts = (_MapPoint * 2)()
+        for p in pts:
+            p.host_kf = 0; p.obs_begin = 0; p.obs_count = 0
+        obs_ids = (C.c_int32 * 1)(0)
+        obs = (_Obs * 1)()
+        obs[0].kf = 0; obs[0].pad_ = -1
+        good = _Rows(m0.value, 2, 1, 0, ids, pts, obs_ids, obs, None)
+        assert lib.hso_gpu_seqmap_patch_multi(h, C.byref(good), 1) == 0
+        nk, np_, no = C.c_int(), C.c_int(), C.c_int()
+        assert lib.hso_gpu_seqmap_size(h, m0.value, C.byref(nk), C.byref(np_), C.byref(no)) == 0 and (nk.value, np_.value, no.value) == (1, 2, 1)
+        twice = (_Rows * 2)(good, good)
+        assert lib.hso_gpu_seqmap_patch_multi(h, twice, 2) == E_INVALID and "twice" in _err(gpu_ctx)
+        pts[1].host_kf = 3                                                                         # keyframe row the map does not have
+        assert lib.hso_gpu_seqmap_patch_multi(h, C.byref(good), 1) == E_INVALID
+        pts[1].host_kf = 0
+        ids[1] = -4
+        assert lib.hso_gpu_seqmap_patch_multi(h, C.byref(good), 1) == E_INVALID and "negative" in _err(gpu_ctx)
+        ids[1] = 1
+        obs[0].kf = 5
+        assert lib.hso_gpu_seqmap_patch_multi(h, C.byref(good), 1) == E_INVALID
+        obs[0].kf = 0
+        link = (C.c_int32 * 1)(7)                                                                  # Feature::point beyond the point table
+        bad_link = _Rows(m0.value, 2, 1, 0, ids, pts, obs_ids, obs, link)
+        assert lib.hso_gpu_seqmap_patch_multi(h, C.byref(bad_link), 1) == E_INVALID
+        other = _Rows(m1.value, 2, 0, 0, ids, pts, None, None, None)                               # the second map has no keyframe table yet
+        assert lib.hso_gpu_seqmap_patch_multi(h, C.byref(other), 1) == E_INVALID
+        assert lib.hso_gpu_seqmap_patch_multi(h, C.byref(good), 1) == 0                            # the context is still usable
+        assert lib.hso_gpu_seq_chain(h, None, None, None, 1, None, 0, None) == E_INVALID
+    finally:
+        assert lib.hso_gpu_seqmap_destroy(h, m0.value) == 0 and lib.hso_gpu_seqmap_destroy(h, m1.value) == 0
+        gpu_ctx.frame_release(9700)
