@@ -554,6 +554,21 @@ static __global__ void k_scatter_links(int32_t* __restrict__ dst, const int32_t*
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[ids[i]] = src[i];
 }
+// inclusive scan of v over a workgroup of W wavefronts; *total = the sum (all threads must call)
+template <int W> __device__ int sel_scan_waves(int v, int* s_wave, int& total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  __syncthreads();
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0; total = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) { if (w < wave) base += s_wave[w]; total += s_wave[w]; }
+  return incl + base;
+}
 // inclusive scan of v over a 256-thread workgroup; *total = the sum (all threads must call)
 __device__ int sel_scan256(int v, int* s_wave, int& total)
 {
@@ -1236,9 +1251,12 @@ __global__ __launch_bounds__(256) void k_chain_visit(ChainFrontDev F, hso_camera
 // per frame: the first feature that names a point lists it; deleted and temporary points are skipped), then the candidates, then the
 // temporary points.  One workgroup per job; "first feature that names it" = atomicMin over the flat feature positions, kept
 // entries compacted in order by block scans: the result is the sequential walk's.
-__global__ __launch_bounds__(256) void k_chain_list(ChainFrontDev F)
+// 1024 threads per sequence: the walk is three dependent loads per feature row (list -> link -> state word) over ~20 000 rows, and
+// what bounds it is how many of those are in flight (256 threads: 0.32 ms per 128 sequences)
+#define LIST_THREADS 1024
+__global__ __launch_bounds__(LIST_THREADS) void k_chain_list(ChainFrontDev F)
 {
-  __shared__ int s_wave[4];
+  __shared__ int s_wave[LIST_THREADS / 64];
   __shared__ int s_off[HSO_SEQ_MAX_VISIT + 1];
   const int b = blockIdx.x, tid = threadIdx.x;
   const ChainJobDev& J = F.jobs[b];
@@ -1263,38 +1281,38 @@ __global__ __launch_bounds__(256) void k_chain_list(ChainFrontDev F)
     if (kind == 0 || kind == 1) return -1;                         // TYPE_DELETED (its features' links are NULL in the reference), TYPE_TEMPORARY
     return p;
   };
-  for (int g = tid; g < total; g += 256) { int key; const int p = point_at(g, key); if (p >= 0) atomicMin(&J.M.first[p], g); }
+  for (int g = tid; g < total; g += LIST_THREADS) { int key; const int p = point_at(g, key); if (p >= 0) atomicMin(&J.M.first[p], g); }
   __threadfence_block();
   __syncthreads();
   int n = 0;
-  for (int g0 = 0; g0 < total; g0 += 256) {
+  for (int g0 = 0; g0 < total; g0 += LIST_THREADS) {
     const int g = g0 + tid;
     int key = 0, p = -1;
     if (g < total) { p = point_at(g, key); if (p >= 0 && J.M.first[p] != g) p = -1; }
     int tot;
-    const int pos = sel_scan256(p >= 0 ? 1 : 0, s_wave, tot) + n - (p >= 0 ? 1 : 0);
+    const int pos = sel_scan_waves<LIST_THREADS / 64>(p >= 0 ? 1 : 0, s_wave, tot) + n - (p >= 0 ? 1 : 0);
     if (p >= 0 && pos < J.slice_cap) { ids[pos] = p; qual[pos] = (uint8_t)key; }
     n += tot;
     __syncthreads();
   }
-  for (int g = tid; g < total; g += 256) { int key; const int p = point_at(g, key); if (p >= 0) J.M.first[p] = SEQ_FIRST_UNSET; }
+  for (int g = tid; g < total; g += LIST_THREADS) { int key; const int p = point_at(g, key); if (p >= 0) J.M.first[p] = SEQ_FIRST_UNSET; }
   const int n_kf_points = n < J.slice_cap ? n : J.slice_cap;
   n = n_kf_points;
   // MapPointCandidates::candidates_ in list order (an entry the device deleted since the caller last sent the list is skipped)
   int n_c = 0;
-  for (int i0 = 0; i0 < J.M.n_cands; i0 += 256) {
+  for (int i0 = 0; i0 < J.M.n_cands; i0 += LIST_THREADS) {
     const int i = i0 + tid;
     int key = 0, p = -1;
     if (i < J.M.n_cands) { p = J.M.cands[i]; key = (int)((uint32_t)J.M.pts[p].pad_ & 0xffu); if ((key >> 4) != 2) p = -1; }
     int tot;
-    const int pos = sel_scan256(p >= 0 ? 1 : 0, s_wave, tot) + n - (p >= 0 ? 1 : 0);
+    const int pos = sel_scan_waves<LIST_THREADS / 64>(p >= 0 ? 1 : 0, s_wave, tot) + n - (p >= 0 ? 1 : 0);
     if (p >= 0 && pos < J.slice_cap) { ids[pos] = p; qual[pos] = (uint8_t)key; }
     n += tot; n_c += tot;
     __syncthreads();
   }
   if (n > J.slice_cap) { n_c -= n - J.slice_cap; n = J.slice_cap; }
   const int n_before_temps = n;
-  for (int i = tid; i < J.n_temps; i += 256) {
+  for (int i = tid; i < J.n_temps; i += LIST_THREADS) {
     const int p = F.temps[J.temps_begin + i];
     if (n_before_temps + i < J.slice_cap) { ids[n_before_temps + i] = p; qual[n_before_temps + i] = (uint8_t)((uint32_t)J.M.pts[p].pad_ & 0xffu); }
   }
@@ -1336,7 +1354,7 @@ int hso_chain_front_launch(hso_gpu_ctx* ctx, const hso_camera* cam, const ChainF
   F.jobs = A.d_jobs; F.cur = A.d_cur; F.track = A.d_track; F.kf_nfts = A.d_kf_nfts; F.temps = A.d_temps; F.kfs = A.d_kfs; F.ids = A.d_ids; F.quality = A.d_quality;
   F.pose_jobs = A.d_pose_jobs; F.n_jobs = A.n_jobs; F.n_total = A.n_total; F.max_kfs = A.max_kfs; F.cell_size = A.cell_size; F.grid_n_cols = A.grid_n_cols;
   hipLaunchKernelGGL(k_chain_visit, dim3(A.n_jobs), dim3(256), 0, ctx->stream, F, *cam);
-  hipLaunchKernelGGL(k_chain_list, dim3(A.n_jobs), dim3(256), 0, ctx->stream, F);
+  hipLaunchKernelGGL(k_chain_list, dim3(A.n_jobs), dim3(LIST_THREADS), 0, ctx->stream, F);
   if (A.n_total > 0) {
     HSO_HIP_CHECK(ctx, hipMemsetAsync(A.d_match, 0, sizeof(hso_align_out) * (size_t)A.n_total, ctx->stream));
     hipLaunchKernelGGL(k_chain_reproject, dim3((A.n_total + 255) / 256), dim3(256), 0, ctx->stream, F, *cam, A.d_align, A.d_proj);
