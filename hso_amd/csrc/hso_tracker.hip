@@ -289,7 +289,9 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   // Coarse levels on two 256-thread workgroups per CU when the batch fills the chip at least twice and the coarse images fit
   // the smaller LDS share; a single sequence (latency, not throughput) keeps all eight wavefronts of a CU on its one job.
   st->split_level = -1;
-  if (max_grid <= 0 && n_jobs >= 2 * ctx->n_cu && C.max_level >= 2 && C.min_level <= 1 && !getenv("HSO_TRACK_NO_SPLIT")) {
+  int split_min_jobs = 2 * ctx->n_cu;
+  if (const char* e = getenv("HSO_TRACK_SPLIT_MIN_JOBS")) split_min_jobs = std::max(1, atoi(e));   // measurement knob
+  if (max_grid <= 0 && n_jobs >= split_min_jobs && C.max_level >= 2 && C.min_level <= 1 && !getenv("HSO_TRACK_NO_SPLIT")) {
     int lvl = 2;   // levels max_level .. 2 on trk2, 1 .. min_level on trk1
     if (getenv("HSO_TRACK_ALL_TRK2")) lvl = C.min_level;   // experiment: every level on trk2 (the finest image read from memory)
     const size_t need = (size_t)g.w[lvl] * g.h[lvl] + g.w[lvl] + 64;
