@@ -685,8 +685,12 @@ struct BaWin {
   // byte offsets inside the window's device slice
   size_t o_trial, o_poses, o_idist, o_fixed, o_edges, o_off, o_list, o_poff, o_plist, o_col, in_bytes;
   size_t o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc, o_bc, o_err, o_chi, o_sum, o_S, o_rhs, o_xp, o_bak, o_pbak, total;
-  char* d;              // device slice
-  char* h_in;           // pinned: the window's upload image (first in_bytes of the slice)
+  // the device slice comes in two pieces: the upload images of all windows of a batch lie side by side (one copy brings them all),
+  // the work areas behind them; an offset below in_bytes is in the first piece, any other in the second
+  char* d;              // the window's upload image on the device (offsets < in_bytes)
+  char* dw;             // its work area MINUS in_bytes (so that dw + o_x is the address of a work table)
+  char* h_in;           // pinned: the window's upload image
+  char* at(size_t off) const { return off < in_bytes ? d + off : dw + off; }
 };
 
 struct BaBatch {
@@ -826,11 +830,11 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   Q.h_active = reinterpret_cast<int*>(h + o_act);
   Q.h_lambda = reinterpret_cast<double*>(h + o_lam);
   Q.h_sums = reinterpret_cast<double*>(ho);
-  size_t od = hdr, oh = hdr;
+  size_t ow = pin_in, oh = hdr;   // [header | upload images | work areas]: the pinned block mirrors the first two
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
-    B.d = d + od; B.h_in = h + oh;
-    od += B.total; oh += B.in_bytes;
+    B.d = d + oh; B.h_in = h + oh; B.dw = d + ow - B.in_bytes;
+    ow += B.total - B.in_bytes; oh += B.in_bytes;
   }
   // the windows' input images, assembled side by side in the page-locked block (a few threads: tens of megabytes per keyframe step)
   hso_host_parallel(ctx, n, pin_in - hdr, [&](int q) {
@@ -850,32 +854,31 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   });
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
-    char* w = B.h_in;
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(B.d, w, B.in_bytes, hipMemcpyHostToDevice, ctx->stream));
     BaProb& R = hp[q];
     char* dd = B.d;
     R.a.poses = reinterpret_cast<const hso_se3*>(dd + B.o_poses); R.a.fixed = reinterpret_cast<const uint8_t*>(dd + B.o_fixed);
     R.a.idist = reinterpret_cast<const double*>(dd + B.o_idist); R.a.edges = reinterpret_cast<const hso_ba_edge*>(dd + B.o_edges);
     R.a.n_poses = B.n_poses; R.a.n_points = B.n_points; R.a.n_edges = B.n_edges;
     R.a.huber_corner = B.huber_corner; R.a.huber_edge = B.huber_edge;
-    R.a.lin = reinterpret_cast<double*>(dd + B.o_lin); R.a.edge_err = reinterpret_cast<double*>(dd + B.o_err);
-    R.a.edge_chi2 = reinterpret_cast<double*>(dd + B.o_chi); R.a.edge_rho = reinterpret_cast<double*>(dd + B.o_rho);
+    R.a.lin = reinterpret_cast<double*>(B.at(B.o_lin)); R.a.edge_err = reinterpret_cast<double*>(B.at(B.o_err));
+    R.a.edge_chi2 = reinterpret_cast<double*>(B.at(B.o_chi)); R.a.edge_rho = reinterpret_cast<double*>(B.at(B.o_rho));
     R.off = reinterpret_cast<const int*>(dd + B.o_off); R.list = reinterpret_cast<const int*>(dd + B.o_list);
     R.poff = reinterpret_cast<const int*>(dd + B.o_poff); R.plist = reinterpret_cast<const int*>(dd + B.o_plist);
-    R.Hpp = reinterpret_cast<double*>(dd + B.o_Hpp); R.bp = reinterpret_cast<double*>(dd + B.o_bp);
-    R.Hpc = reinterpret_cast<double*>(dd + B.o_Hpc); R.Hcc = reinterpret_cast<double*>(dd + B.o_Hcc);
-    R.bc = reinterpret_cast<double*>(dd + B.o_bc); R.sum = Q.d_sums + 8 * (size_t)q; R.lam = Q.d_lambda + q;
+    R.Hpp = reinterpret_cast<double*>(B.at(B.o_Hpp)); R.bp = reinterpret_cast<double*>(B.at(B.o_bp));
+    R.Hpc = reinterpret_cast<double*>(B.at(B.o_Hpc)); R.Hcc = reinterpret_cast<double*>(B.at(B.o_Hcc));
+    R.bc = reinterpret_cast<double*>(B.at(B.o_bc)); R.sum = Q.d_sums + 8 * (size_t)q; R.lam = Q.d_lambda + q;
     R.col = reinterpret_cast<const int*>(dd + B.o_col);
-    R.S = reinterpret_cast<double*>(dd + B.o_S); R.rhs = reinterpret_cast<double*>(dd + B.o_rhs);
+    R.S = reinterpret_cast<double*>(B.at(B.o_S)); R.rhs = reinterpret_cast<double*>(B.at(B.o_rhs));
     R.trial = reinterpret_cast<const double*>(dd + B.o_trial);
-    R.xp = reinterpret_cast<double*>(dd + B.o_xp);
-    R.idist_rw = reinterpret_cast<double*>(dd + B.o_idist); R.idist_bak = reinterpret_cast<double*>(dd + B.o_bak);
+    R.xp = reinterpret_cast<double*>(B.at(B.o_xp));
+    R.idist_rw = reinterpret_cast<double*>(dd + B.o_idist); R.idist_bak = reinterpret_cast<double*>(B.at(B.o_bak));
     R.trial_rw = reinterpret_cast<double*>(dd + B.o_trial);
-    R.poses_rw = reinterpret_cast<hso_se3*>(dd + B.o_poses); R.poses_bak = reinterpret_cast<hso_se3*>(dd + B.o_pbak);
+    R.poses_rw = reinterpret_cast<hso_se3*>(dd + B.o_poses); R.poses_bak = reinterpret_cast<hso_se3*>(B.at(B.o_pbak));
     R.M = B.M; R.n_pairs = B.n_pairs;
-    R.zero_begin = dd + B.o_out; R.zero_bytes = B.o_sum + 256 - B.o_out;
+    R.zero_begin = B.at(B.o_out); R.zero_bytes = B.o_sum + 256 - B.o_out;
   }
-  HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_probs, hp, sizeof(BaProb) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  // the window records, the (not yet filled) launch lists and every window's upload image in ONE copy (it was one per window)
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, pin_in, hipMemcpyHostToDevice, ctx->stream));
   return HSO_OK;
 }
 
@@ -927,7 +930,7 @@ static int ba_launch_errors(BaBatch& Q, int slot, const std::vector<int>& which)
 }
 static int ba_get(BaBatch& Q, int q, void* dst, size_t off, size_t bytes)
 {
-  HSO_HIP_CHECK(Q.ctx, hipMemcpyAsync(dst, Q.win[q].d + off, bytes, hipMemcpyDeviceToHost, Q.ctx->stream));
+  HSO_HIP_CHECK(Q.ctx, hipMemcpyAsync(dst, Q.win[q].at(off), bytes, hipMemcpyDeviceToHost, Q.ctx->stream));
   return HSO_OK;
 }
 
@@ -1289,7 +1292,7 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
       const BaWin& B = Q.win[q];
       back.push_back({lm[q].idist, B.d + B.o_idist, sizeof(double) * (size_t)B.n_points});
       back.push_back({lm[q].poses_f_w, B.d + B.o_poses, sizeof(hso_se3) * (size_t)B.n_poses});
-      if (lm[q].edge_chi2_out) back.push_back({lm[q].edge_chi2_out, B.d + B.o_chi, sizeof(double) * (size_t)B.n_edges});
+      if (lm[q].edge_chi2_out) back.push_back({lm[q].edge_chi2_out, B.at(B.o_chi), sizeof(double) * (size_t)B.n_edges});
     }
     if (int rc = hso_lists_to_host(ctx, back)) return rc;   // synchronises (also when there is nothing to read back)
     for (int q = 0; q < n_problems; q++) if (lm[q].want != BaLm::W_NONE) lm[q].advance();

@@ -25,7 +25,10 @@
 
 using namespace hso_dev;
 
-#define SEL_THREADS 256
+// 1024 threads per frame: these kernels are rounds of barrier-separated passes over ~5600 grid cells / ~3000 candidates with
+// dependent loads from global scratch at one workgroup per frame; four times fewer rounds is what shortens them (256 threads:
+// k_select 102 us, k_sel_emit_feats 48 us for ONE 2000-feature frame).  All results are integers or per-thread fp64: order-free.
+#define SEL_THREADS 1024
 #define SEL_WAVES (SEL_THREADS / 64)
 
 struct SelFrame {
