@@ -158,6 +158,8 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
         t.start()
     gate.wait()
     c0 = _cgroup_cpu()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     busy_read = _gpu_busy_reader(device)
     busy = []
@@ -177,11 +179,16 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
         stop.set(); sampler.join()
     wall = max(t_end) - t0
     c1 = _cgroup_cpu()
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
     out = dict(banks=n_banks, sequences_per_bank=n_seq, sequences=n_banks * n_seq, frames=frames - 1, max_fts=max_fts, images="device",
                distinct=len(seqs), frames_per_s=n_banks * n_seq * (frames - 1) / wall, wall_s=wall,
                ms_per_step_mean_per_bank=[r["ms_per_step_mean"] for r in res], ms_per_step_median_per_bank=[r["ms_per_step_median"] for r in res],
                keyframes_per_sequence=float(np.mean([r["keyframes"] for r in res])),
                failures=sum(r["failures"] for r in res), trans_err_max=max(r["trans_err_max"] for r in res))
+    # what the host side asked of the kernel over the timed steps: page faults (fresh allocations), context switches (waits, pool hand-offs)
+    out["host_rusage"] = dict(minor_faults=ru1.ru_minflt - ru0.ru_minflt, major_faults=ru1.ru_majflt - ru0.ru_majflt,
+                              voluntary_switches=ru1.ru_nvcsw - ru0.ru_nvcsw, involuntary_switches=ru1.ru_nivcsw - ru0.ru_nivcsw,
+                              user_s=ru1.ru_utime - ru0.ru_utime, system_s=ru1.ru_stime - ru0.ru_stime)
     out["host_cpu_quota"] = host_quota
     out["threads_per_bank"] = threads_per_bank[0]
     # steady state: the window in which every bank is past step `steady_from` and none has finished

@@ -46,7 +46,7 @@ def main():
                 del os.environ[k]
         row = dict(variant=name, banks=banks, sequences_per_bank=n, env=env, steady=r.get("steady_frames_per_s"), whole=r["frames_per_s"],
                    warmup=r.get("warmup_frames_per_s"), failures=r["failures"], trans_err_max=r["trans_err_max"],
-                   keyframes=r["keyframes_per_sequence"], gpu_busy=r.get("steady_gpu_busy_frac"), cpus=r.get("host_cpus_used"))
+                   keyframes=r["keyframes_per_sequence"], gpu_busy=r.get("steady_gpu_busy_frac"), cpus=r.get("host_cpus_used"), rusage=r.get("host_rusage"), wall_s=r["wall_s"])
         rows.append(row)
         print(json.dumps(row), flush=True)
         json.dump(rows, open(out_path, "w"), indent=1)
