@@ -301,6 +301,7 @@ def load():
     lib.hso_gpu_abi_version.argtypes = []
     lib.hso_gpu_synchronize.argtypes = [vp]
     lib.hso_gpu_set_shared_device.argtypes = [vp, i32]
+    lib.hso_gpu_set_host_parallel.argtypes = [vp, vp, vp]
     lib.hso_gpu_frame_upload.argtypes = [vp, i64, vp, i32, i32, i32, P(FrameStats)]
     lib.hso_gpu_frame_upload_resized.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, P(FrameStats)]
     lib.hso_gpu_frame_upload_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
@@ -326,6 +327,7 @@ def load():
     lib.hso_gpu_ba_huber_deltas_multi.argtypes = [vp, P(BaDeltasJob), i32, C.c_double]
     lib.hso_gpu_ba_optimize.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.c_double, C.c_double, i32, vp, P(BaResult)]
     lib.hso_gpu_ba_optimize_multi.argtypes = [vp, P(BaProblem), i32]
+    lib.hso_gpu_ba_local_multi.argtypes = [vp, P(BaProblem), P(vp), i32, C.c_double, P(C.c_float)]
     lib.hso_gpu_reproject_select.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.hso_gpu_host_alloc.argtypes = [vp, C.c_size_t, P(vp)]
     lib.hso_gpu_host_free.argtypes = [vp, vp]
@@ -366,9 +368,9 @@ def load():
 
 # Every symbol include/hso_gpu.h declares; tests check the library exports all of them.
 EXPORTED_SYMBOLS = [
-    "hso_gpu_debug_census", "hso_gpu_ba_huber_deltas_multi",
+    "hso_gpu_debug_census", "hso_gpu_ba_huber_deltas_multi", "hso_gpu_ba_local_multi",
     "hso_gpu_create", "hso_gpu_destroy", "hso_gpu_last_error", "hso_gpu_abi_version",
-    "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
+    "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_set_host_parallel", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_coarse_track_collect_begin", "hso_gpu_coarse_track_collect_end", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
@@ -735,6 +737,30 @@ class Context:
             P_.huber_corner, P_.huber_edge = hc, he
         self._check(self.lib.hso_gpu_ba_optimize_multi(self.h, arr, len(problems)), "ba_optimize_multi")
         return [(list(k[0]), k[2], k[4], k[5]) for k in keep]
+
+    def ba_local_multi(self, problems, error_multiplier2):
+        """hso_gpu_ba_local_multi: problems = list of (poses, fixed, idist, edges, obs_uv, n_iter); the Huber deltas are formed on
+        the device, then the windows are optimised with them.  Returns (list of (poses, idist, edge_chi2, BaResult), hubers[n, 2])."""
+        keep, arr = [], (BaProblem * len(problems))()
+        uvp = (C.c_void_p * max(len(problems), 1))()
+        for q, (poses, fixed, idist, edges, obs_uv, n_iter) in enumerate(problems):
+            parr = (SE3 * len(poses))(*poses)
+            fixed = np.ascontiguousarray(fixed, np.uint8)
+            idist = np.array(idist, np.float64)
+            edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+            uv = np.ascontiguousarray(obs_uv, np.float64)
+            chi2 = np.zeros(len(edges))
+            res = BaResult()
+            keep.append((parr, fixed, idist, edges, chi2, res, uv))
+            P_ = arr[q]
+            P_.poses_f_w = C.cast(parr, C.c_void_p).value; P_.pose_fixed = fixed.ctypes.data; P_.idist = idist.ctypes.data
+            P_.edges = edges.ctypes.data; P_.edge_chi2_out = chi2.ctypes.data; P_.result = C.addressof(res)
+            P_.n_poses, P_.n_points, P_.n_edges, P_.n_iter = len(poses), len(idist), len(edges), n_iter
+            P_.huber_corner, P_.huber_edge = 0.0, 0.0
+            uvp[q] = uv.ctypes.data
+        hub = np.zeros((max(len(problems), 1), 2), np.float32)
+        self._check(self.lib.hso_gpu_ba_local_multi(self.h, arr, uvp, len(problems), float(error_multiplier2), hub.ctypes.data_as(C.POINTER(C.c_float))), "ba_local_multi")
+        return [(list(k[0]), k[2], k[4], k[5]) for k in keep], hub[:len(problems)]
 
     # -- depth-filter seed observation
     def seed_observe(self, cam, cur_frame_id, cur_T_f_w, cur_exposure, px_error_angle, seeds, as_list=True):

@@ -69,6 +69,9 @@ struct BaProb {
   hso_se3* poses_bak;
   int M, n_pairs;
   char* zero_begin; size_t zero_bytes;  // [Hpp ... chi2 sums]: what a linearisation accumulates into (16-byte units)
+  // hso_gpu_ba_local_multi (the Huber deltas formed on the device before the optimisation): the observations' project2d(obs->f)
+  // [2 * n_edges], per-edge error magnitudes (scratch: the edge_err table before its first use), the two deltas as floats
+  const double* uv; float* mad; float* hub;
 };
 
 // ---- g2o's SE3Quat update (host and device: the optimiser applies it on the device, the tests' helpers on the host)
@@ -681,9 +684,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_restore(const BaProb* probs, 
 struct BaWin {
   int n_poses, n_points, n_edges, n_pairs, M;
   double huber_corner, huber_edge;
-  std::vector<int> off, list, poff, plist, col;
+  std::vector<int> col;
   // byte offsets inside the window's device slice
-  size_t o_trial, o_poses, o_idist, o_fixed, o_edges, o_off, o_list, o_poff, o_plist, o_col, in_bytes;
+  size_t o_trial, o_poses, o_idist, o_fixed, o_edges, o_off, o_list, o_poff, o_plist, o_col, o_uv, in_bytes;
   size_t o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc, o_bc, o_err, o_chi, o_sum, o_S, o_rhs, o_xp, o_bak, o_pbak, total;
   // the device slice comes in two pieces: the upload images of all windows of a batch lie side by side (one copy brings them all),
   // the work areas behind them; an offset below in_bytes is in the first piece, any other in the second
@@ -703,6 +706,8 @@ struct BaBatch {
   double* h_lambda = nullptr;    // pinned
   double* d_sums = nullptr;      // [n][8] chi2, robust chi2, scale (points), scale (poses), solvable
   double* h_sums = nullptr;      // pinned (results staging)
+  float* d_hub = nullptr;        // [n][2] the Huber deltas formed on the device (hso_gpu_ba_local_multi)
+  float* h_hub = nullptr;        // pinned
   int n = 0;
 };
 #define BA_N_LISTS 6
@@ -729,36 +734,15 @@ static int ba_check_edges(hso_gpu_ctx* ctx, const hso_ba_edge* edges, int n_edge
   return HSO_OK;
 }
 
-// sizes, offsets and the CSR tables of one window (no device work)
-static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_fixed, const hso_ba_edge* edges, int n_edges,
-                      double huber_corner, double huber_edge)
+// sizes and offsets of one window (no device work)
+static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_fixed, int n_edges,
+                      double huber_corner, double huber_edge, bool with_uv = false)
 {
   B.n_poses = n_poses; B.n_points = n_points; B.n_edges = n_edges;
   B.huber_corner = huber_corner; B.huber_edge = huber_edge;
-  // CSR of edges by point, edge order kept inside a point (g2o visits edges in insertion order)
-  B.off.assign(n_points + 1, 0); B.list.assign(n_edges, 0);
-  for (int k = 0; k < n_edges; k++) B.off[edges[k].point + 1]++;
-  for (int p = 0; p < n_points; p++) B.off[p + 1] += B.off[p];
-  { std::vector<int> cur(B.off.begin(), B.off.end() - 1); for (int k = 0; k < n_edges; k++) B.list[cur[edges[k].point]++] = k; }
-  // CSR of edges by pose-pair block (same block numbering as k_ba_poses), edge order kept
-  const int n_pairs = n_poses * (n_poses + 1) / 2;
-  B.n_pairs = n_pairs;
-  auto pair_id = [n_poses](int i, int j) { return i * n_poses - i * (i - 1) / 2 + (j - i); };  // i <= j
-  B.poff.assign(n_pairs + 1, 0); B.plist.assign((size_t)3 * n_edges, 0);
-  for (int k = 0; k < n_edges; k++) {
-    const int h_ = edges[k].host, t_ = edges[k].target;
-    B.poff[pair_id(h_, h_) + 1]++; B.poff[pair_id(t_, t_) + 1]++;
-    B.poff[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_) + 1]++;
-  }
-  for (int q = 0; q < n_pairs; q++) B.poff[q + 1] += B.poff[q];
-  {
-    std::vector<int> cur(B.poff.begin(), B.poff.end() - 1);
-    for (int k = 0; k < n_edges; k++) {
-      const int h_ = edges[k].host, t_ = edges[k].target;
-      B.plist[cur[pair_id(h_, h_)]++] = k; B.plist[cur[pair_id(t_, t_)]++] = k;
-      B.plist[cur[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_)]++] = k;
-    }
-  }
+  // (the CSR tables of the edges — by point, by pose-pair block — are built straight into the upload image: ba_stage_window)
+  B.n_pairs = n_poses * (n_poses + 1) / 2;
+  const int n_pairs = B.n_pairs;
   // the reduced system: free poses in index order
   B.col.assign(n_poses, -1);
   int n_free = 0;
@@ -778,6 +762,7 @@ static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_f
   B.o_poff = o; o += al(sizeof(int) * (n_pairs + 1));
   B.o_plist = o; o += al(sizeof(int) * 3 * (size_t)n_edges);
   B.o_col = o; o += al(sizeof(int) * n_poses);
+  B.o_uv = o; if (with_uv) o += al(sizeof(double) * 2 * (size_t)n_edges);
   B.in_bytes = o;
   B.o_lin = o; o += al(sizeof(double) * BA_LIN * n_edges);
   B.o_rho = o; o += al(sizeof(double) * n_edges);
@@ -800,15 +785,59 @@ static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_f
   B.total = o;
 }
 
+// One window's upload image, written where it is copied from (B.h_in): state, edges, and the two CSR tables of the edges — by
+// point (edge order kept inside a point: g2o visits edges in insertion order) and by pose-pair block (same block numbering as
+// k_ba_poses; per edge the blocks (h,h), (t,t), (min,max) in that order).  False: an edge index is out of range (nothing to trust).
+static bool ba_stage_window(const BaWin& B, const hso_ba_problem& P, const double* obs_uv)
+{
+  char* w = B.h_in;
+  const int n_poses = B.n_poses, n_points = B.n_points, n_edges = B.n_edges, n_pairs = B.n_pairs;
+  memset(w + B.o_trial, 0, B.o_poses - B.o_trial);   // lambda, pose steps, the "no step" flag (the gaps between tables are never read)
+  memcpy(w + B.o_poses, P.poses_f_w, sizeof(hso_se3) * n_poses);
+  memcpy(w + B.o_idist, P.idist, sizeof(double) * n_points);
+  memcpy(w + B.o_fixed, P.pose_fixed, n_poses);
+  memcpy(w + B.o_col, B.col.data(), sizeof(int) * n_poses);
+  if (obs_uv) memcpy(w + B.o_uv, obs_uv, sizeof(double) * 2 * (size_t)n_edges);
+  hso_ba_edge* ed = reinterpret_cast<hso_ba_edge*>(w + B.o_edges);
+  int* off = reinterpret_cast<int*>(w + B.o_off); int* list = reinterpret_cast<int*>(w + B.o_list);
+  int* poff = reinterpret_cast<int*>(w + B.o_poff); int* plist = reinterpret_cast<int*>(w + B.o_plist);
+  std::fill(off, off + n_points + 1, 0);
+  std::fill(poff, poff + n_pairs + 1, 0);
+  auto pair_id = [n_poses](int i, int j) { return i * n_poses - i * (i - 1) / 2 + (j - i); };  // i <= j
+  for (int k = 0; k < n_edges; k++) {
+    const hso_ba_edge e = P.edges[k];
+    if (e.point < 0 || e.point >= n_points || e.host < 0 || e.host >= n_poses || e.target < 0 || e.target >= n_poses ||
+        e.host == e.target || e.level < 0 || e.level > 14) return false;
+    ed[k] = e;
+    off[e.point + 1]++;
+    const int h_ = e.host, t_ = e.target;
+    poff[pair_id(h_, h_) + 1]++; poff[pair_id(t_, t_) + 1]++;
+    poff[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_) + 1]++;
+  }
+  for (int p = 0; p < n_points; p++) off[p + 1] += off[p];
+  for (int q = 0; q < n_pairs; q++) poff[q + 1] += poff[q];
+  thread_local std::vector<int> cur;
+  cur.assign(off, off + n_points);
+  for (int k = 0; k < n_edges; k++) list[cur[ed[k].point]++] = k;
+  cur.assign(poff, poff + n_pairs);
+  for (int k = 0; k < n_edges; k++) {
+    const int h_ = ed[k].host, t_ = ed[k].target;
+    plist[cur[pair_id(h_, h_)]++] = k; plist[cur[pair_id(t_, t_)]++] = k;
+    plist[cur[pair_id(h_ < t_ ? h_ : t_, h_ < t_ ? t_ : h_)]++] = k;
+  }
+  return true;
+}
+
 // reserve the work area and staging for all windows, upload everything that does not change between evaluations
-static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n)
+static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n, const double* const* obs_uv = nullptr)
 {
   Q.ctx = ctx; Q.n = n;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t o_act = al(sizeof(BaProb) * (size_t)n), o_lam = o_act + al(sizeof(int) * (size_t)n * BA_N_LISTS);
   const size_t o_sums = o_lam + al(sizeof(double) * (size_t)n);
-  size_t dev = o_sums + al(sizeof(double) * 8 * (size_t)n), pin_in = dev, pin_out = al(sizeof(double) * 8 * (size_t)n);
+  const size_t o_hub = o_sums + al(sizeof(double) * 8 * (size_t)n);
+  size_t dev = o_hub + al(sizeof(float) * 2 * (size_t)n), pin_in = dev, pin_out = al(sizeof(double) * 8 * (size_t)n) + al(sizeof(float) * 2 * (size_t)n);
   const size_t hdr = dev;
   for (int q = 0; q < n; q++) { dev += Q.win[q].total; pin_in += Q.win[q].in_bytes; }
   if (ctx->batch_cap < dev) {  // grow-only work area of the context (shared with the other batched entry points)
@@ -830,28 +859,22 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   Q.h_active = reinterpret_cast<int*>(h + o_act);
   Q.h_lambda = reinterpret_cast<double*>(h + o_lam);
   Q.h_sums = reinterpret_cast<double*>(ho);
+  Q.d_hub = reinterpret_cast<float*>(d + o_hub);
+  Q.h_hub = reinterpret_cast<float*>(ho + al(sizeof(double) * 8 * (size_t)n));
   size_t ow = pin_in, oh = hdr;   // [header | upload images | work areas]: the pinned block mirrors the first two
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
     B.d = d + oh; B.h_in = h + oh; B.dw = d + ow - B.in_bytes;
     ow += B.total - B.in_bytes; oh += B.in_bytes;
   }
-  // the windows' input images, assembled side by side in the page-locked block (a few threads: tens of megabytes per keyframe step)
+  // the windows' input images, assembled side by side in the page-locked block (tens of megabytes per keyframe step): ONE pass over
+  // a window's edges checks their indices, copies them and counts both adjacency tables, a second fills the tables — in place
+  std::vector<uint8_t> bad((size_t)n, 0);
   hso_host_parallel(ctx, n, pin_in - hdr, [&](int q) {
-    const BaWin& B = Q.win[q];
-    const hso_ba_problem& P = problems[q];
-    char* w = B.h_in;
-    memset(w, 0, B.in_bytes);
-    memcpy(w + B.o_poses, P.poses_f_w, sizeof(hso_se3) * B.n_poses);
-    memcpy(w + B.o_idist, P.idist, sizeof(double) * B.n_points);
-    memcpy(w + B.o_fixed, P.pose_fixed, B.n_poses);
-    memcpy(w + B.o_edges, P.edges, sizeof(hso_ba_edge) * B.n_edges);
-    memcpy(w + B.o_off, B.off.data(), sizeof(int) * (B.n_points + 1));
-    memcpy(w + B.o_list, B.list.data(), sizeof(int) * B.n_edges);
-    memcpy(w + B.o_poff, B.poff.data(), sizeof(int) * (B.n_pairs + 1));
-    memcpy(w + B.o_plist, B.plist.data(), sizeof(int) * 3 * (size_t)B.n_edges);
-    memcpy(w + B.o_col, B.col.data(), sizeof(int) * B.n_poses);
+    if (!ba_stage_window(Q.win[q], problems[q], obs_uv ? obs_uv[q] : nullptr)) bad[(size_t)q] = 1;
   });
+  for (int q = 0; q < n; q++)
+    if (bad[(size_t)q]) return ba_check_edges(ctx, problems[q].edges, problems[q].n_edges, problems[q].n_points, problems[q].n_poses, "ba_optimize");
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
     BaProb& R = hp[q];
@@ -876,6 +899,8 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
     R.poses_rw = reinterpret_cast<hso_se3*>(dd + B.o_poses); R.poses_bak = reinterpret_cast<hso_se3*>(B.at(B.o_pbak));
     R.M = B.M; R.n_pairs = B.n_pairs;
     R.zero_begin = B.at(B.o_out); R.zero_bytes = B.o_sum + 256 - B.o_out;
+    R.uv = obs_uv ? reinterpret_cast<const double*>(dd + B.o_uv) : nullptr;
+    R.mad = reinterpret_cast<float*>(B.at(B.o_err)); R.hub = Q.d_hub + 2 * (size_t)q;
   }
   // the window records, the (not yet filled) launch lists and every window's upload image in ONE copy (it was one per window)
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, pin_in, hipMemcpyHostToDevice, ctx->stream));
@@ -946,7 +971,7 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   if (int rc = ba_check_edges(ctx, edges, n_edges, n_points, n_poses, "ba_linearize")) return rc;
   BaBatch Q;
   Q.win.resize(1);
-  ba_layout(Q.win[0], n_poses, n_points, pose_fixed, edges, n_edges, huber_corner, huber_edge);
+  ba_layout(Q.win[0], n_poses, n_points, pose_fixed, n_edges, huber_corner, huber_edge);
   hso_ba_problem P;
   memset(&P, 0, sizeof(P));
   P.poses_f_w = const_cast<hso_se3*>(poses_f_w); P.pose_fixed = pose_fixed; P.idist = const_cast<double*>(idist); P.edges = edges;
@@ -993,6 +1018,78 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_mad_errors(const MadWin* wins
     const double sc = 1.0 / (double)(1 << e.level);
     ex *= sc; ey *= sc;
     W.err[k] = (e.type == HSO_FTR_EDGELET) ? (float)fabs(e.normal[0] * ex + e.normal[1] * ey) : (float)sqrt(ex * ex + ey * ey);
+  }
+}
+
+// The same error magnitudes for the windows of an optimisation batch (hso_gpu_ba_local_multi): the tables are the window's own,
+// already on the device for the optimisation that follows; blockIdx.y = window.
+__global__ __launch_bounds__(BA_THREADS) void k_ba_mad_errors_win(const BaProb* probs)
+{
+  const BaProb& P = probs[blockIdx.y];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P.a.n_edges; k += gridDim.x * blockDim.x) {
+    const hso_ba_edge e = P.a.edges[k];
+    const Se3 Tth = se3_mul(se3_from(P.a.poses[e.target]), se3_inverse(se3_from(P.a.poses[e.host])));
+    const double inv = 1.0 / P.a.idist[e.point];
+    double x, y, z;
+    se3_apply(Tth, e.fH[0] * inv, e.fH[1] * inv, e.fH[2] * inv, x, y, z);
+    double ex = P.uv[2 * k] - x / z, ey = P.uv[2 * k + 1] - y / z;
+    const double sc = 1.0 / (double)(1 << e.level);
+    ex *= sc; ey *= sc;
+    P.mad[k] = (e.type == HSO_FTR_EDGELET) ? (float)fabs(e.normal[0] * ex + e.normal[1] * ey) : (float)sqrt(ex * ex + ey * ey);
+  }
+}
+
+// huber_corner / huber_edge of a window (src/bundle_adjustment.cpp:664-680): 1.4826 x hso::getMedian of the corner / edgelet error
+// magnitudes = the element nth_element leaves at floor(n / 2) (include/hso/vikit/math_utils.h:119-126).  The magnitudes are
+// non-negative floats, so their bit patterns order like their values: an exact radix select (four 8-bit digits, histogram in LDS)
+// per kind; one workgroup per window.  The deltas go into the window record the optimisation's kernels read, and out as floats.
+__global__ __launch_bounds__(BA_THREADS) void k_ba_mad_select(BaProb* probs, double error_multiplier2)
+{
+  BaProb& P = probs[blockIdx.x];
+  const int n = P.a.n_edges, tid = threadIdx.x;
+  const hso_ba_edge* E = P.a.edges; const float* err = P.mad;
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_prefix, s_rank;
+  __shared__ int s_cnt[2];
+  if (tid < 2) s_cnt[tid] = 0;
+  __syncthreads();
+  { int c[2] = {0, 0}; for (int k = tid; k < n; k += BA_THREADS) c[E[k].type == HSO_FTR_EDGELET ? 1 : 0]++; if (c[0]) atomicAdd(&s_cnt[0], c[0]); if (c[1]) atomicAdd(&s_cnt[1], c[1]); }
+  __syncthreads();
+  float med[2] = {0.f, 0.f};
+  for (int kind = 0; kind < 2; kind++) {
+    const int cnt = s_cnt[kind];
+    if (cnt == 0) continue;            // uniform: every thread reads the same shared count
+    if (tid == 0) { s_prefix = 0u; s_rank = (unsigned)(cnt / 2); }
+    unsigned mask = 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      s_hist[tid & 255] = 0u;          // BA_THREADS == 256
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+      for (int k = tid; k < n; k += BA_THREADS) {
+        if ((E[k].type == HSO_FTR_EDGELET ? 1 : 0) != kind) continue;
+        const unsigned key = __float_as_uint(err[k]);
+        if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned r = s_rank, b = 0;
+        for (; b < 255u; b++) { const unsigned hcount = s_hist[b]; if (r < hcount) break; r -= hcount; }
+        s_rank = r; s_prefix = prefix | (b << shift);
+      }
+      mask |= 255u << shift;
+      __syncthreads();
+    }
+    med[kind] = __uint_as_float(s_prefix);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float hc = 0.f, he = 0.f;
+    const bool pt = s_cnt[0] > 0, ls = s_cnt[1] > 0;
+    if (pt && ls) { hc = (float)(1.4826 * (double)med[0]); he = (float)(1.4826 * (double)med[1]); }
+    else if (!pt && ls) { hc = (float)(1.0 / error_multiplier2); he = (float)(1.4826 * (double)med[1]); }
+    else if (pt && !ls) { hc = (float)(1.4826 * (double)med[0]); he = (float)(0.5 / error_multiplier2); }
+    P.a.huber_corner = (double)hc; P.a.huber_edge = (double)he;
+    P.hub[0] = hc; P.hub[1] = he;
   }
 }
 
@@ -1209,34 +1306,43 @@ struct BaLm {
   }
 };
 
-extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems)
+// obs_uv != null: the Huber deltas are formed on the device from the windows' initial state first (hso_gpu_ba_local_multi) and
+// returned in huber_out [2 * n_problems]; the problems' own huber_corner / huber_edge are ignored then
+static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems, const double* const* obs_uv,
+                                  double error_multiplier2, float* huber_out)
 {
   if (!ctx) return HSO_E_INVALID;
   if (n_problems < 0 || (n_problems > 0 && !problems)) return hso_fail(ctx, HSO_E_INVALID, "ba_optimize_multi: bad argument");
   if (n_problems == 0) return HSO_OK;
+  if (obs_uv) {
+    if (!huber_out) return hso_fail(ctx, HSO_E_INVALID, "ba_local_multi: bad argument");
+    for (int q = 0; q < n_problems; q++) if (!obs_uv[q]) return hso_fail(ctx, HSO_E_INVALID, "ba_local_multi: bad argument");
+  }
   BaBatch Q;
   Q.win.resize(n_problems);
   std::vector<BaLm> lm(n_problems);
-  size_t edges_total = 0;
   for (int q = 0; q < n_problems; q++) {
     const hso_ba_problem& P = problems[q];
     if (!P.poses_f_w || !P.pose_fixed || !P.idist || !P.edges || !P.result || P.n_poses <= 0 || P.n_points <= 0 || P.n_edges <= 0 || P.n_iter < 0)
       return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: bad argument");
-    edges_total += (size_t)P.n_edges;
   }
-  // per window: the index check of its edges and the adjacency lists of the layout (hso_host_parallel: the windows of a step of 128
-  // sequences hold half a million edges)
-  std::vector<uint8_t> bad_edges((size_t)n_problems, 0);
-  hso_host_parallel(ctx, n_problems, edges_total * 128, [&](int q) {
-    const hso_ba_problem& P = problems[q];
-    if (!ba_edges_ok(P.edges, P.n_edges, P.n_points, P.n_poses)) { bad_edges[(size_t)q] = 1; return; }
-    ba_layout(Q.win[q], P.n_poses, P.n_points, P.pose_fixed, P.edges, P.n_edges, P.huber_corner, P.huber_edge);
-  });
   for (int q = 0; q < n_problems; q++) {
-    if (bad_edges[(size_t)q]) return ba_check_edges(ctx, problems[q].edges, problems[q].n_edges, problems[q].n_points, problems[q].n_poses, "ba_optimize");
+    const hso_ba_problem& P = problems[q];
+    ba_layout(Q.win[q], P.n_poses, P.n_points, P.pose_fixed, P.n_edges, P.huber_corner, P.huber_edge, obs_uv != nullptr);
     if (Q.win[q].M > 96) return hso_fail(ctx, HSO_E_INVALID, "ba_optimize: more than 16 free poses in one window (the reference's core is 7 keyframes)");
   }
-  if (int rc = ba_batch_begin(Q, ctx, problems, n_problems)) return rc;
+  // (the edges' index check rides in the staging pass of ba_batch_begin)
+  if (int rc = ba_batch_begin(Q, ctx, problems, n_problems, obs_uv)) return rc;
+  bool hub_pending = false;
+  if (obs_uv) {
+    int max_edges = 0;
+    for (int q = 0; q < n_problems; q++) max_edges = std::max(max_edges, problems[q].n_edges);
+    hipLaunchKernelGGL(k_ba_mad_errors_win, dim3((max_edges + BA_THREADS - 1) / BA_THREADS, n_problems), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs);
+    hipLaunchKernelGGL(k_ba_mad_select, dim3(n_problems), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, error_multiplier2);
+    HSO_HIP_CHECK(ctx, hipGetLastError());
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_hub, Q.d_hub, sizeof(float) * 2 * (size_t)n_problems, hipMemcpyDeviceToHost, ctx->stream));
+    hub_pending = true;   // read after the first round's synchronisation
+  }
   for (int q = 0; q < n_problems; q++) {
     const hso_ba_problem& P = problems[q];
     BaLm& L = lm[q];
@@ -1295,9 +1401,23 @@ extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem*
       if (lm[q].edge_chi2_out) back.push_back({lm[q].edge_chi2_out, B.at(B.o_chi), sizeof(double) * (size_t)B.n_edges});
     }
     if (int rc = hso_lists_to_host(ctx, back)) return rc;   // synchronises (also when there is nothing to read back)
+    if (hub_pending) { memcpy(huber_out, Q.h_hub, sizeof(float) * 2 * (size_t)n_problems); hub_pending = false; }
     for (int q = 0; q < n_problems; q++) if (lm[q].want != BaLm::W_NONE) lm[q].advance();
   }
   return HSO_OK;
+}
+
+extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems)
+{
+  return ba_optimize_multi_impl(ctx, problems, n_problems, nullptr, 0.0, nullptr);
+}
+
+extern "C" int hso_gpu_ba_local_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, const double* const* obs_uv, int n_problems,
+                                      double error_multiplier2, float* huber_out)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_problems > 0 && !obs_uv) return hso_fail(ctx, HSO_E_INVALID, "ba_local_multi: bad argument");
+  return ba_optimize_multi_impl(ctx, problems, n_problems, obs_uv, error_multiplier2, huber_out);
 }
 
 extern "C" int hso_gpu_ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses_f_w, const uint8_t* pose_fixed, int n_poses, double* idist,

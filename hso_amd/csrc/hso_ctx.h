@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <functional>
 #include <thread>
@@ -50,6 +51,7 @@ struct hso_gpu_ctx {
   bool own_stream;
   int n_cu;
   struct HostHelpers* helpers = nullptr;   // hso_host_parallel_run
+  hso_parallel_for_fn par_fn = nullptr; void* par_user = nullptr;   // hso_gpu_set_host_parallel: the caller's own worker pool
   bool shared_device = false;   // hso_gpu_set_shared_device: other contexts keep the device busy beside this one
   std::string err;
   std::unordered_map<int64_t, FrameRec> frames;
@@ -142,6 +144,11 @@ void hso_host_parallel_run(hso_gpu_ctx* ctx, int n, const std::function<void(int
 bool hso_host_parallel_on();   // HSO_HOST_PARALLEL=1 turns the helper threads on (off by default: see hso_ctx.hip)
 template <class F> void hso_host_parallel(hso_gpu_ctx* ctx, int n, size_t work, F&& fn)
 {
+  if (n >= 2 && work >= (size_t(1) << 20) && ctx->par_fn) {   // the caller lent its pool (hso_gpu_set_host_parallel)
+    using Fn = typename std::remove_reference<F>::type;
+    ctx->par_fn(ctx->par_user, n, [](void* a, int i) { (*static_cast<Fn*>(a))(i); }, const_cast<void*>(static_cast<const void*>(&fn)));
+    return;
+  }
   if (n < 2 || work < (size_t(1) << 20) || !hso_host_parallel_on()) { for (int i = 0; i < n; i++) fn(i); return; }
   const std::function<void(int)> f(std::ref(fn));
   hso_host_parallel_run(ctx, n, f);

@@ -523,6 +523,13 @@ void hso_gpu_debug_census(int64_t* out, int n)
   for (int i = 0; i < n; i++) out[i] = i < HSO_CENSUS_N ? g_census[i].load(std::memory_order_relaxed) : 0;
 }
 
+int hso_gpu_set_host_parallel(hso_gpu_ctx* ctx, hso_parallel_for_fn parallel_for, void* user)
+{
+  if (!ctx) return HSO_E_INVALID;
+  ctx->par_fn = parallel_for; ctx->par_user = parallel_for ? user : nullptr;
+  return HSO_OK;
+}
+
 int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared)
 {
   if (!ctx) return HSO_E_INVALID;

@@ -69,6 +69,7 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
 {
   // a constructor that throws runs no destructor: everything made so far is taken down here (and the context, when it is the bank's)
   auto undo = [&]() {
+    if (ctx_) (void)hso_gpu_set_host_parallel(ctx_, nullptr, nullptr);
     delete pool_; pool_ = nullptr;
     for (Seq* s : seq_) { if (s->map >= 0) (void)hso_gpu_seqmap_destroy(ctx_, s->map); delete s; }
     for (StepData* d : step_) delete d;
@@ -103,6 +104,12 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
     if (g_host_share.load() > 1) check(hso_gpu_set_shared_device(ctx_, 1), "set_shared_device");   // throughput shapes: the other banks fill the device
     n_threads_ = pool_threads_for(n_sequences);
     pool_ = new Pool(n_threads_);
+    // the device library's own host loops (local-BA window staging, map-patch staging) run on this pool too: the engine's thread is
+    // inside the library then and the workers are idle (HSO_ENGINE_NO_LIB_POOL=1: on the calling thread, as before)
+    if (!getenv("HSO_ENGINE_NO_LIB_POOL"))
+      check(hso_gpu_set_host_parallel(ctx_, [](void* user, int n, void (*body)(void*, int), void* arg) {
+        static_cast<Pool*>(user)->run(n, [&](int i) { body(arg, i); });
+      }, pool_), "set_host_parallel");
   } catch (...) { undo(); throw; }
 }
 
@@ -128,6 +135,7 @@ Bank::~Bank()
     for (const auto& e : sections_) fprintf(stderr, " %s %.3f,", e.first, e.second / n_steps_);
     fprintf(stderr, "\n");
   }
+  (void)hso_gpu_set_host_parallel(ctx_, nullptr, nullptr);   // before the pool goes
   delete pool_;
   if (seed_table_ >= 0) (void)hso_gpu_seed_table_destroy(ctx_, seed_table_);   // before the frames its seeds are hosted in (waits for a pass in flight)
   for (int64_t id : after_prev_release_) (void)hso_gpu_frame_release(ctx_, id);

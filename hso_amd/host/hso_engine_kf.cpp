@@ -70,8 +70,10 @@ void Bank::keyframe_ba(const std::vector<int>& who)
   const double fmean = cam_.errorMultiplier2();
   std::vector<std::vector<hso_se3>> poses_in(with.size());
   std::vector<std::vector<double>> idist_in(with.size());
-  {
-    // the Huber deltas of every window of the step in one device call
+  // the Huber deltas and the optimisation of every window of the step in one device call (hso_gpu_ba_local_multi: the windows go
+  // up once, the medians are taken on the device); HSO_BA_TWO_CALLS=1 keeps the two-call form (tests compare the two)
+  const bool two_calls = getenv("HSO_BA_TWO_CALLS") != nullptr;
+  if (two_calls) {
     std::vector<hso_ba_deltas_job> dj(with.size());
     for (size_t i = 0; i < with.size(); i++) {
       StepData& d = *step_[with[i]];
@@ -84,20 +86,12 @@ void Bank::keyframe_ba(const std::vector<int>& who)
     if (!with.empty()) check(hso_gpu_ba_huber_deltas_multi(ctx_, dj.data(), (int)dj.size(), fmean), "LocalBundleAdjustment");
     for (size_t i = 0; i < with.size(); i++) { step_[with[i]]->huber_corner = dj[i].huber_corner; step_[with[i]]->huber_edge = dj[i].huber_edge; }
   }
-  for (size_t i = 0; i < with.size(); i++) {
-    Seq& s = *seq_[with[i]];
-    StepData& d = *step_[with[i]];
-    if (s.trace.on()) {
-      Trace& t = s.trace;
-      t.begin("ba_huber_deltas", 7);
-      t.field("poses", d.ba_poses.data(), sizeof(hso_se3) * d.ba_poses.size()); t.field("idist", d.ba_idist.data(), sizeof(double) * d.ba_idist.size());
-      t.field("edges", d.ba_edges.data(), sizeof(hso_ba_edge) * d.ba_edges.size()); t.field("obs_uv", d.ba_uv.data(), sizeof(double) * d.ba_uv.size());
-      t.scalar("error_multiplier2", fmean); t.scalar("huber_corner", d.huber_corner); t.scalar("huber_edge", d.huber_edge);
-      poses_in[i] = d.ba_poses; idist_in[i] = d.ba_idist;
-    }
-  }
+  // a traced sequence records the window's state before the optimisation moves it
+  for (size_t i = 0; i < with.size(); i++)
+    if (seq_[with[i]]->trace.on()) { poses_in[i] = step_[with[i]]->ba_poses; idist_in[i] = step_[with[i]]->ba_idist; }
   if (!with.empty()) {
     std::vector<hso_ba_problem> pr(with.size());
+    std::vector<const double*> uv(with.size());
     for (size_t i = 0; i < with.size(); i++) {
       StepData& d = *step_[with[i]];
       hso_ba_problem& p = pr[i];
@@ -105,9 +99,29 @@ void Bank::keyframe_ba(const std::vector<int>& who)
       p.edge_chi2_out = d.ba_chi2.data(); p.result = &d.ba_res;
       p.n_poses = (int)d.ba_poses.size(); p.n_points = (int)d.ba_idist.size(); p.n_edges = (int)d.ba_edges.size(); p.n_iter = d.ba_iters;
       p.huber_corner = d.huber_corner; p.huber_edge = d.huber_edge;
+      uv[i] = d.ba_uv.data();
     }
-    { Sub t(this, "ba: optimize call"); check(hso_gpu_ba_optimize_multi(ctx_, pr.data(), (int)pr.size()), "LocalBundleAdjustment"); }
+    if (two_calls) { Sub t(this, "ba: optimize call"); check(hso_gpu_ba_optimize_multi(ctx_, pr.data(), (int)pr.size()), "LocalBundleAdjustment"); }
+    else {
+      Sub t(this, "ba: local call");
+      std::vector<float> hub(2 * with.size());
+      check(hso_gpu_ba_local_multi(ctx_, pr.data(), uv.data(), (int)pr.size(), fmean, hub.data()), "LocalBundleAdjustment");
+      for (size_t i = 0; i < with.size(); i++) { step_[with[i]]->huber_corner = hub[2 * i]; step_[with[i]]->huber_edge = hub[2 * i + 1]; }
+    }
     n_calls_[8]++; n_items_[8] += (int64_t)pr.size();
+  }
+  for (size_t i = 0; i < with.size(); i++) {
+    Seq& s = *seq_[with[i]];
+    StepData& d = *step_[with[i]];
+    if (s.trace.on()) {
+      Trace& t = s.trace;
+      t.begin("ba_huber_deltas", 7);
+      t.field("poses", poses_in[i].data(), sizeof(hso_se3) * poses_in[i].size()); t.field("idist", idist_in[i].data(), sizeof(double) * idist_in[i].size());
+      t.field("edges", d.ba_edges.data(), sizeof(hso_ba_edge) * d.ba_edges.size()); t.field("obs_uv", d.ba_uv.data(), sizeof(double) * d.ba_uv.size());
+      t.scalar("error_multiplier2", fmean); t.scalar("huber_corner", d.huber_corner); t.scalar("huber_edge", d.huber_edge);
+    }
+  }
+  if (!with.empty()) {
     for (size_t i = 0; i < with.size(); i++) {
       Seq& s = *seq_[with[i]];
       StepData& d = *step_[with[i]];

@@ -82,6 +82,13 @@ int hso_gpu_synchronize(hso_gpu_ctx* ctx);
  * idle CUs — the other contexts' work fills those — which is what gives the best THROUGHPUT; the default (0) gives a lone batch
  * the best LATENCY.  Results agree within the tracker's stated tolerance either way. */
 int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared);
+/* The host side of the batched entry points (staging tens of megabytes of local-BA windows, checking and staging map patches) is a
+ * loop over independent items.  A caller that keeps a worker pool of its own lends it here: the library then calls
+ * parallel_for(user, n, body, arg) and expects body(arg, i) to have run for every i in [0, n), on any threads, when it returns;
+ * it does so only from inside an entry point called with this context, on the calling thread, for loops above ~1 MB of work.
+ * body never touches the HIP runtime.  parallel_for == NULL takes the pool away (the loops run on the calling thread). */
+typedef void (*hso_parallel_for_fn)(void* user, int n, void (*body)(void* arg, int i), void* arg);
+int hso_gpu_set_host_parallel(hso_gpu_ctx* ctx, hso_parallel_for_fn parallel_for, void* user);
 /* Page-locked host memory for the tables a caller hands to / receives from the entry points.  Every entry point accepts any host
  * pointer; result and input tables that live in memory from this allocator are DMA targets / sources as they are (tens of GB/s),
  * pageable memory goes through the runtime's staging copies (and its first-touch page faults) at a fraction of that — with tens
@@ -386,7 +393,7 @@ typedef struct hso_match_brief {
   int32_t cell;                /* grid cell, -1: reprojectPoint returned false */
   int32_t ref_obs;             /* chosen observation, index into the map's obs table; -1: none within 60 degrees */
   int8_t success, stage, search_level, ref_type;   /* findMatchDirect's result, HSO_ALIGN_* stage, Matcher::search_level_, ref_ftr_->type */
-  int32_t pad_;                /* hso_gpu_reproject_select_maps: the point's index in its map */
+  int32_t pad_;                /* hso_gpu_seq_chain: the point's position in its job's list */
 } hso_match_brief;
 
 /* ---- pose_optimizer::optimizeLevenbergMarquardt3rd, src/pose_optimizer.cpp:399-771 ---- */
@@ -532,6 +539,15 @@ typedef struct hso_ba_problem {
   double huber_corner, huber_edge;
 } hso_ba_problem;
 int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems);
+
+/* ba::LocalBundleAdjustment's two device stages in ONE call (src/bundle_adjustment.cpp:618-680 then :815-830): the Huber deltas
+ * of every window from its initial state — hso_gpu_ba_huber_deltas' arithmetic, the two medians by an exact radix select on the
+ * device — and then hso_gpu_ba_optimize_multi with them.  The windows go up once (the two-call form staged and sent the edge
+ * tables twice and read every window's error magnitudes back for the medians).  obs_uv[q] = project2d(obs->f) of window q's
+ * edges [2 * n_edges]; problems[q].huber_corner / huber_edge are ignored; huber_out[2 * q], [2 * q + 1] receive the deltas used
+ * (corner, edge).  Results are those of the two calls in sequence, bit for bit. */
+int hso_gpu_ba_local_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, const double* const* obs_uv, int n_problems,
+                           double error_multiplier2, float* huber_out);
 
 /* ---- DepthFilter seed observation: DepthFilter::observeDepthRow (src/depth_filter.cpp:580-675),
  *      updateSeed :528-537, computeTau :539-555; Matcher::doLineStereo (src/matcher.cpp:802-1049),
@@ -781,7 +797,7 @@ int hso_gpu_seqmap_read(hso_gpu_ctx* ctx, int map, const int32_t* point_ids, int
  *           nearest first, up to max_kfs; the points of their features once each (Point::last_projected_kf_id_), TYPE_TEMPORARY
  *           skipped; then the candidates; then the temporary points the job lists;
  *        3. projection, reference choice, findMatchDirect, the grid selection, the frame's features, optimizeLevenbergMarquardt3rd
- *           (what hso_gpu_reproject_select_pose_frames chained, now over the device's own list);
+ *           (one launch sequence over the device's own list);
  *        4. the bookkeeping of reprojectCell / reprojectCellAll on the examined candidates (:366-425, :214-222, :247-251):
  *           n_failed_reproj_ / n_succeeded_reproj_, UNKNOWN -> GOOD above 10 successes, deletion above 15 / 30 failures — applied to
  *           the point rows' state words, the changes of kind reported as events; the outlier mask of the pose optimiser applied to the

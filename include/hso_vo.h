@@ -63,9 +63,9 @@ int hso_vo_get_trajectory(hso_vo* vo, double* timestamps, hso_se3* T_f_w, int ca
 
 /* ---- N independent sequences over one device context, in lockstep (hso_amd/host/hso_engine*.cpp): BASELINE north_star
  * "independent sequences ... batched"; configs[4] = what test/euroc_batch.sh:9-18 runs one after the other.  One step takes one
- * image per sequence and runs every stage ONCE for all of them: hso_gpu_frame_upload_batch, hso_gpu_coarse_track_batch (N jobs),
- * hso_gpu_reproject_select_pose_frames (projection + matching + grid selection + pose optimisation on the sequences' resident
- * maps), hso_gpu_ba_huber_deltas_multi / hso_gpu_ba_optimize_multi for the sequences that take a keyframe,
+ * image per sequence and runs every stage ONCE for all of them: hso_gpu_frame_upload_batch, hso_gpu_seq_chain (the tracker's reference tables,
+ * CoarseTracker::run for N jobs, projection + matching + grid selection + pose optimisation and the keyframe decision's inputs
+ * on the sequences' resident maps), hso_gpu_ba_local_multi (Huber deltas + optimisation of all windows in one call) for the sequences that take a keyframe,
  * hso_gpu_seed_table_observe_groups, hso_gpu_seed_activate_multi, hso_gpu_detect_candidates; the depth filter's idle-time pass
  * (hso_gpu_seed_table_observe_previous_begin / _end) runs on its own stream beside the next step's tracking.  A sequence run
  * among up to 8 equals the same sequence run alone through hso_vo_* bit for bit (tests/test_multi_gpu.py); in larger banks the

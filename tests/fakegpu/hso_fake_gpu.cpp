@@ -66,6 +66,7 @@ void hso_gpu_destroy(hso_gpu_ctx* c)
 const char* hso_gpu_last_error(const hso_gpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int hso_gpu_synchronize(hso_gpu_ctx*) { return HSO_OK; }
 int hso_gpu_set_shared_device(hso_gpu_ctx*, int) { return HSO_OK; }
+int hso_gpu_set_host_parallel(hso_gpu_ctx*, hso_parallel_for_fn, void*) { return HSO_OK; }   // the restatement is sequential
 int hso_gpu_host_alloc(hso_gpu_ctx*, size_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? HSO_OK : HSO_E_NOMEM; }
 int hso_gpu_host_free(hso_gpu_ctx*, void* p) { free(p); return HSO_OK; }
 
@@ -894,6 +895,19 @@ int hso_gpu_ba_optimize_multi(hso_gpu_ctx*, const hso_ba_problem* p, int n)
   for (int i = 0; i < n; i++)
     hso_or_ba_optimize(p[i].poses_f_w, p[i].pose_fixed, p[i].n_poses, p[i].idist, p[i].n_points, p[i].edges, p[i].n_edges, p[i].huber_corner, p[i].huber_edge, p[i].n_iter,
                        p[i].edge_chi2_out, p[i].result);
+  return HSO_OK;
+}
+
+// the two stages in one call: the restatement's deltas, then its optimisation with them
+int hso_gpu_ba_local_multi(hso_gpu_ctx*, const hso_ba_problem* p, const double* const* obs_uv, int n, double em2, float* huber_out)
+{
+  for (int i = 0; i < n; i++) {
+    float hc = 0, he = 0;
+    hso_or_ba_huber_deltas(p[i].poses_f_w, p[i].n_poses, p[i].idist, p[i].n_points, p[i].edges, obs_uv[i], p[i].n_edges, em2, &hc, &he);
+    huber_out[2 * i] = hc; huber_out[2 * i + 1] = he;
+    hso_or_ba_optimize(p[i].poses_f_w, p[i].pose_fixed, p[i].n_poses, p[i].idist, p[i].n_points, p[i].edges, p[i].n_edges, (double)hc, (double)he, p[i].n_iter,
+                       p[i].edge_chi2_out, p[i].result);
+  }
   return HSO_OK;
 }
 

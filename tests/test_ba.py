@@ -301,6 +301,33 @@ def test_ba_huber_deltas_multi_equals_single_calls(gpu_ctx, orc):
     assert got[1][1] == np.float32(0.5 / 480.0)                         # no edgelet edge: the fallback (:664-680)
 
 
+@pytest.mark.gpu
+def test_ba_local_multi_equals_deltas_then_optimize(gpu_ctx, orc):
+    """hso_gpu_ba_local_multi (the Huber deltas formed on the device by an exact radix select, then the optimisation, the windows
+    uploaded once) against the two calls it replaces: deltas equal to the oracle's and to hso_gpu_ba_huber_deltas', poses, inverse
+    depths, per-edge chi2 and result records equal to hso_gpu_ba_optimize with those deltas, bit for bit.  Windows of different size,
+    one with corner edges only (the fallback delta, src/bundle_adjustment.cpp:664-680), even and odd numbers of errors per kind
+    (getMedian takes the element at floor(n / 2))."""
+    problems = []
+    for shape, seed, n_iter in (((9, 300, 4), 51, 6), ((4, 60, 3), 52, 3), ((12, 500, 5), 53, 5), ((7, 201, 3), 54, 4)):
+        poses, fixed, idist, edges = synth.ba_problem(*shape, seed=seed, px_noise=0.3)
+        rng = np.random.default_rng(seed)
+        uv = _obs_uv(edges, rng)
+        problems.append([poses, fixed, idist, edges, uv, n_iter])
+    e1 = problems[1][3].copy()
+    e1["type"][e1["type"] == capi.FTR_EDGELET] = capi.FTR_CORNER          # no edgelet edge in this window: the fallback delta
+    problems[1][3] = e1
+    got, hub = gpu_ctx.ba_local_multi([tuple(p) for p in problems], 480.0)
+    for (poses, fixed, idist, edges, uv, n_iter), (pg, ig, cg, rg), h in zip(problems, got, hub):
+        hc, he = gpu_ctx.ba_huber_deltas(poses, idist, edges, uv, 480.0)
+        assert (float(h[0]), float(h[1])) == (hc, he) == orc.ba_huber_deltas(poses, idist, edges, uv, 480.0)
+        ps, is_, cs, rs = gpu_ctx.ba_optimize(poses, fixed, idist, edges, hc, he, n_iter)
+        assert bytes(rs) == bytes(rg)
+        assert np.array_equal(is_, ig) and np.array_equal(cs, cg)
+        for a, b_ in zip(ps, pg):
+            assert a.q[:] == b_.q[:] and a.t[:] == b_.t[:]
+    assert hub[1][1] == np.float32(0.5 / 480.0)
+
 
 _HELPERS_SCRIPT = r"""
 import numpy as np

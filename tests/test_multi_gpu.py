@@ -121,6 +121,32 @@ def test_depth_filter_stream_gives_the_results_of_the_synchronous_pass(monkeypat
     assert all(len(k) >= 2 for k in kfs_o) and counts["other"][0] > 10        # the pass ran (it is counted with the other calls)
 
 
+def test_local_ba_in_one_call_gives_the_results_of_the_two_calls(monkeypatch):
+    """The engine's keyframe steps send every window once (hso_gpu_ba_local_multi: Huber deltas by a radix select on the device, then
+    the optimisation); the two-call form it replaced (hso_gpu_ba_huber_deltas_multi, medians on the host, then
+    hso_gpu_ba_optimize_multi; HSO_BA_TWO_CALLS=1) gives every status record and keyframe bit for bit."""
+    spec = synth.EUROC
+    cam = synth.camera(spec)
+    seqs = [synth.sequence(40, spec=spec, seed=4400 + 13 * k, step=(0.018 + 0.002 * k, 0.005, 0.006)) for k in range(3)]
+
+    def run():
+        multi = vo.MultiVisualOdometry(cam, len(seqs), 300)
+        multi.set_first_frames([S["images"][0] for S in seqs], [S["depth0"] for S in seqs])
+        got = []
+        for k in range(1, 40):
+            multi.add_images([S["images"][k] for S in seqs], [float(k)] * len(seqs))
+            got.append([_status_bytes(multi.status(q)) for q in range(len(seqs))])
+        kfs = [[(ts, bytes(T), fid) for ts, T, fid in multi.keyframes(q)] for q in range(len(seqs))]
+        multi.close()
+        return got, kfs
+
+    one, kfs_one = run()
+    monkeypatch.setenv("HSO_BA_TWO_CALLS", "1")
+    two, kfs_two = run()
+    assert one == two and kfs_one == kfs_two
+    assert all(len(k) >= 3 for k in kfs_one)                                  # local BA ran (a window needs keyframes)
+
+
 def test_bank_of_96_at_2000_features_equals_solo_runs(monkeypatch):
     """The end-to-end figure's shape — a bank of 96 sequences at 2000 features — against the same sequences alone, status record by
     status record.  Both runs keep the tracker on its one-workgroup-per-job shape (what a bank that shares the device runs,
