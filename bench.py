@@ -656,6 +656,9 @@ def main():
         out["sequences_failures"] = mres["failures"]
         out["sequences_roofline_frac"] = mres.get("roofline_frac_hbm")      # sum of SURVEY 8(d) algorithmic bytes of the chain's kernels / wall / 8 TB/s
         out["sequences_gpu_busy_frac"] = mres.get("steady_gpu_busy_frac")   # amdgpu gpu_busy_percent sampled every 20 ms over the steady window
+        # what that figure is worth: it counts queues that are not empty; a kernel timeline of the same run has a kernel in flight for
+        # about half of the time (profiles/r5_banks_overlap.json, profiles/r5_engine_host.md section 7)
+        out["sequences_gpu_busy_note"] = "sysfs gpu_busy_percent (non-empty queues); kernels in flight ~0.5-0.6 of the run by rocprofv3 timeline"
         out["host_cpu_quota"] = mres.get("host_cpu_quota"); out["threads_per_bank"] = mres.get("threads_per_bank")
         out["host_cpus_used"] = mres.get("host_cpus_used")
     if extras and seq_S is not None and args.single:

@@ -925,12 +925,11 @@ static int ba_max(const BaBatch& Q, const std::vector<int>& which, int BaWin::*f
   return m;
 }
 // computeActiveErrors + buildSystem at the resident state; the blocks stay on the device
-static int ba_launch_linearize(BaBatch& Q, int slot, const std::vector<int>& which)
+static int ba_launch_linearize(BaBatch& Q, int slot, const std::vector<int>& which, const int* dl = nullptr)
 {
   hso_gpu_ctx* ctx = Q.ctx;
   if (which.empty()) return HSO_OK;
-  const int* dl;
-  if (int rc = ba_list(Q, slot, which, &dl)) return rc;
+  if (!dl) if (int rc = ba_list(Q, slot, which, &dl)) return rc;   // (dl given: the round's lists went up in one copy)
   const int ny = (int)which.size();
   hipLaunchKernelGGL(k_ba_zero, dim3(64, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
   hipLaunchKernelGGL(k_ba_edges<true>, dim3((ba_max(Q, which, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
@@ -941,12 +940,11 @@ static int ba_launch_linearize(BaBatch& Q, int slot, const std::vector<int>& whi
   return HSO_OK;
 }
 // computeActiveErrors only (an LM trial): per-edge error / chi2 / rho and the two sums
-static int ba_launch_errors(BaBatch& Q, int slot, const std::vector<int>& which)
+static int ba_launch_errors(BaBatch& Q, int slot, const std::vector<int>& which, const int* dl = nullptr)
 {
   hso_gpu_ctx* ctx = Q.ctx;
   if (which.empty()) return HSO_OK;
-  const int* dl;
-  if (int rc = ba_list(Q, slot, which, &dl)) return rc;
+  if (!dl) if (int rc = ba_list(Q, slot, which, &dl)) return rc;
   const int ny = (int)which.size();
   hipLaunchKernelGGL(k_ba_edges<false>, dim3((ba_max(Q, which, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
   hipLaunchKernelGGL(k_ba_chi2, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
@@ -1219,7 +1217,7 @@ struct BaLm {
   double* edge_chi2_out; hso_ba_result* result;
   double lambda, ni, currentChi, tempChi, iniChi, rho;
   int nBad, stop, it, qmax;
-  bool need_restore;
+  bool need_restore, first_lin;
   State st; Want want;
 
   double* sums;       // pinned: chi2, robust chi2, scale (points), scale (poses), solvable — of the last device step
@@ -1230,7 +1228,11 @@ struct BaLm {
   {
     memset(result, 0, sizeof(*result));
     lambda = -1.; ni = 2.; nBad = 0; stop = 0; it = 0; qmax = 0; rho = 0; currentChi = tempChi = iniChi = 0; need_restore = false;
-    st = INIT_WAIT; want = W_ERRORS;
+    // The first linearisation evaluates the errors at the very state init_error is taken at, and sums them the same way
+    // (k_ba_poses' extra block = k_ba_chi2's reduction): with at least one iteration to run, the errors-only round is left out
+    // and init_chi2 comes from the first linearisation's sums (one round = one synchronisation less per call)
+    first_lin = n_iter > 0;
+    if (first_lin) { st = LIN_WAIT; want = W_LINEARIZE; } else { st = INIT_WAIT; want = W_ERRORS; }
   }
   void finish() { result->stop = stop; result->lambda = lambda; st = FINAL_WAIT; want = W_FINAL; }
 
@@ -1246,6 +1248,7 @@ struct BaLm {
         st = LIN_WAIT; want = W_LINEARIZE;
         return;
       case LIN_WAIT:
+        if (first_lin) { result->init_chi2 = out_sum()[0]; result->robust_chi2 = out_sum()[1]; first_lin = false; }
         // solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem
         result->final_chi2 = out_sum()[0];
         currentChi = out_sum()[1]; tempChi = currentChi;
@@ -1365,18 +1368,22 @@ static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* proble
         case BaLm::W_NONE: break;
       }
     if (w_err.empty() && w_lin.empty() && w_trial.empty() && w_final.empty()) break;
-    // the damping of this round's trials: one copy for all windows (poses and points are owned by the device during the optimisation)
-    if (!w_trial.empty()) HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_lambda, Q.h_lambda, sizeof(double) * (size_t)n_problems, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = ba_launch_errors(Q, 0, w_err)) return rc;
-    if (!w_restore.empty()) {   // g2o's pop() after a rejected step, before anything reads the state again
-      const int* dl;
-      if (int rc = ba_list(Q, 1, w_restore, &dl)) return rc;
-      hipLaunchKernelGGL(k_ba_restore, dim3(1, (int)w_restore.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-    }
-    if (int rc = ba_launch_linearize(Q, 2, w_lin)) return rc;
+    // this round's launch lists and the damping of its trials: ONE copy (the lists and the damping lie side by side in the header
+    // of the batch, in page-locked memory and on the device; poses and points are owned by the device during the optimisation)
+    auto fill = [&](int slot, const std::vector<int>& which) -> const int* {
+      int* hl = Q.h_active + (size_t)slot * Q.n;
+      for (size_t k = 0; k < which.size(); k++) hl[k] = which[k];
+      return Q.d_active + (size_t)slot * Q.n;
+    };
+    const int* dl_err = fill(0, w_err); const int* dl_restore = fill(1, w_restore); const int* dl_lin = fill(2, w_lin); const int* dl_trial = fill(3, w_trial);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_active, Q.h_active, (size_t)(reinterpret_cast<char*>(Q.h_lambda + n_problems) - reinterpret_cast<char*>(Q.h_active)),
+                                      hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = ba_launch_errors(Q, 0, w_err, dl_err)) return rc;
+    if (!w_restore.empty())   // g2o's pop() after a rejected step, before anything reads the state again
+      hipLaunchKernelGGL(k_ba_restore, dim3(1, (int)w_restore.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl_restore);
+    if (int rc = ba_launch_linearize(Q, 2, w_lin, dl_lin)) return rc;
     if (!w_trial.empty()) {
-      const int* dl;
-      if (int rc = ba_list(Q, 3, w_trial, &dl)) return rc;
+      const int* dl = dl_trial;
       const int ny = (int)w_trial.size(), max_m = ba_max(Q, w_trial, &BaWin::M);
       hipLaunchKernelGGL(k_ba_schur, dim3(ba_max(Q, w_trial, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
       static bool solve_attr = false;   // 96 x 96 doubles = 72 KiB of dynamic LDS: above the 64 KiB a launch gets without asking
@@ -1386,7 +1393,7 @@ static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* proble
       }
       hipLaunchKernelGGL(k_ba_solve, dim3(1, ny), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, dl);
       hipLaunchKernelGGL(k_ba_backsub, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-      if (int rc = ba_launch_errors(Q, 4, w_trial)) return rc;
+      if (int rc = ba_launch_errors(Q, 4, w_trial, dl_trial)) return rc;
     }
     HSO_HIP_CHECK(ctx, hipGetLastError());
     // --- results

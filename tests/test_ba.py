@@ -328,6 +328,47 @@ def test_ba_local_multi_equals_deltas_then_optimize(gpu_ctx, orc):
             assert a.q[:] == b_.q[:] and a.t[:] == b_.t[:]
     assert hub[1][1] == np.float32(0.5 / 480.0)
 
+@pytest.mark.gpu
+def test_host_loops_on_the_callers_pool(gpu_ctx):
+    """hso_gpu_set_host_parallel: the library hands its host-side loops (here the staging of four local-BA windows, > 1 MB) to the
+    caller's parallel_for; the items may run in any order on any threads — this one runs them last to first on two threads — and the
+    results equal the single calls bit for bit.  NULL takes the pool away again."""
+    import ctypes as C
+    import threading
+    problems = []
+    for shape, seed, n_iter in (((12, 3000, 5), 71, 4), ((10, 2500, 5), 72, 3), ((14, 3500, 5), 73, 5), ((9, 2000, 5), 74, 2)):
+        poses, fixed, idist, edges = synth.ba_problem(*shape, seed=seed, px_noise=0.3)
+        problems.append((poses, fixed, idist, edges, 1.0, 0.6, n_iter))
+    singles = [gpu_ctx.ba_optimize(*p) for p in problems]
+    BODY = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+    PFOR = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+    seen = []
+
+    def pfor(user, n, body, arg):
+        fn = C.cast(body, BODY)
+        seen.append(n)
+        idx = list(range(n))[::-1]
+        th = [threading.Thread(target=lambda part: [fn(arg, i) for i in part], args=(idx[k::2],)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    cb = PFOR(pfor)
+    assert gpu_ctx.lib.hso_gpu_set_host_parallel(gpu_ctx.h, C.cast(cb, C.c_void_p), None) == 0
+    try:
+        multi = gpu_ctx.ba_optimize_multi(problems)
+    finally:
+        assert gpu_ctx.lib.hso_gpu_set_host_parallel(gpu_ctx.h, None, None) == 0
+    assert seen and seen[0] == len(problems)
+    for (ps, is_, cs, rs), (pm, im, cm, rm) in zip(singles, multi):
+        assert bytes(rs) == bytes(rm) and np.array_equal(is_, im) and np.array_equal(cs, cm)
+        for a, b_ in zip(ps, pm):
+            assert a.q[:] == b_.q[:] and a.t[:] == b_.t[:]
+    n_before = len(seen)
+    gpu_ctx.ba_optimize_multi(problems)
+    assert len(seen) == n_before                                             # the pool is gone: nothing is handed out
+
 
 _HELPERS_SCRIPT = r"""
 import numpy as np
