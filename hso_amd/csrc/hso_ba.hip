@@ -74,6 +74,10 @@ struct BaProb {
   const double* uv; float* mad; float* hub;
 };
 
+// the damping of a window's current trial; a negative value = "computeLambdaInit of the linearisation just made": tau (1e-5) x the
+// largest diagonal entry (k_ba_maxdiag -> sum[5]) — the first trial of a window rides in the round of its first linearisation
+__device__ inline double ba_lambda(const BaProb& P) { const double l = P.lam[0]; return l < 0 ? 1e-5 * P.sum[5] : l; }
+
 // ---- g2o's SE3Quat update (host and device: the optimiser applies it on the device, the tests' helpers on the host)
 struct Q4 { double x, y, z, w; };
 
@@ -417,7 +421,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, co
   if (threadIdx.x < 44) {
     double t = 0;
     for (int w = 0; w < BA_WAVES; w++) t += s_part[w][threadIdx.x];
-    if (chi_block) { if (threadIdx.x < 2) chi2_sum[threadIdx.x] = t; }
+    // ([6], [7]: the linearisation's own copy — a trial launched behind it in the same round overwrites [0], [1])
+    if (chi_block) { if (threadIdx.x < 2) { chi2_sum[threadIdx.x] = t; chi2_sum[6 + threadIdx.x] = t; } }
     else if (threadIdx.x < 36) Hcc[((size_t)i * np + j) * 36 + threadIdx.x] = t;
     else if (i == j && threadIdx.x < 42) bc[i * 6 + threadIdx.x - 36] = t;
   }
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_schur(const BaProb* probs, co
   const int np = P.a.n_poses, n_pairs = np * (np + 1) / 2, M = P.M;
   int b = blockIdx.x, i = 0;
   if (b > n_pairs) return;
-  const double lambda = P.lam[0];
+  const double lambda = ba_lambda(P);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (b == n_pairs) {   // the extra block: is every point diagonal invertible?  (the host solver's `ok`)
     int bad = 0;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_solve(const BaProb* probs, co
   __shared__ int s_ok;
   const BaProb& P = probs[active[blockIdx.y]];
   const int M = P.M, np = P.a.n_poses, tid = threadIdx.x;
-  const double lambda = P.lam[0];
+  const double lambda = ba_lambda(P);
   for (int q = tid; q < M * M; q += BA_THREADS) s_S[q] = P.S[q];
   if (tid == 0) s_ok = (P.S[(size_t)M * M] != 0.0) ? 1 : 0;
   __syncthreads();
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, 
   __shared__ double s_part[BA_WAVES];
   const BaProb& P = probs[active[blockIdx.y]];
   const int np = P.a.n_poses;
-  const double lambda = P.lam[0];
+  const double lambda = ba_lambda(P);
   const double* xc = P.trial + 1;
   const bool no_step = P.trial[1 + 6 * np] != 0.0;   // the reduced system could not be solved: x = 0 (the trial is rejected)
   double sc = 0;
@@ -1232,7 +1237,7 @@ struct BaLm {
     // (k_ba_poses' extra block = k_ba_chi2's reduction): with at least one iteration to run, the errors-only round is left out
     // and init_chi2 comes from the first linearisation's sums (one round = one synchronisation less per call)
     first_lin = n_iter > 0;
-    if (first_lin) { st = LIN_WAIT; want = W_LINEARIZE; } else { st = INIT_WAIT; want = W_ERRORS; }
+    if (first_lin) { st = LIN_WAIT; want = W_LINEARIZE; *lam_stage = -1.0; } else { st = INIT_WAIT; want = W_ERRORS; }
   }
   void finish() { result->stop = stop; result->lambda = lambda; st = FINAL_WAIT; want = W_FINAL; }
 
@@ -1245,22 +1250,24 @@ struct BaLm {
         result->robust_chi2 = out_sum()[1];
         result->final_chi2 = out_sum()[0];
         if (it >= n_iter) { finish(); return; }
+        *lam_stage = -1.0;
         st = LIN_WAIT; want = W_LINEARIZE;
         return;
       case LIN_WAIT:
-        if (first_lin) { result->init_chi2 = out_sum()[0]; result->robust_chi2 = out_sum()[1]; first_lin = false; }
+        // A linearisation and the first trial behind it ran in ONE round (the damping of the trial is known before: carried over,
+        // or formed on the device from the linearisation's largest diagonal entry).  The linearisation's sums are in [6], [7], [5].
+        if (first_lin) { result->init_chi2 = out_sum()[6]; result->robust_chi2 = out_sum()[7]; first_lin = false; }
         // solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem
-        result->final_chi2 = out_sum()[0];
-        currentChi = out_sum()[1]; tempChi = currentChi;
+        result->final_chi2 = out_sum()[6];
+        currentChi = out_sum()[7]; tempChi = currentChi;
         iniChi = currentChi;
         if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices (k_ba_maxdiag)
           lambda = 1e-5 * out_sum()[5];
           ni = 2; nBad = 0;
         }
         rho = 0; qmax = 0;
-        *lam_stage = lambda;
-        st = STEP_WAIT; want = W_TRIAL;
-        return;
+        st = STEP_WAIT;
+        [[fallthrough]];   // the trial's results are in this round's sums too
       case STEP_WAIT: {
         const bool ok2 = out_sum()[4] != 0.0;
         result->n_solves++;
@@ -1297,6 +1304,7 @@ struct BaLm {
         if (nBad >= 3) { stop = 2; finish(); return; }
         it++;
         if (it >= n_iter) { finish(); return; }
+        *lam_stage = lambda;                 // the damping of the trial that rides behind the next linearisation
         st = LIN_WAIT; want = W_LINEARIZE;   // (need_restore: only after a step with a NaN gain ratio; the driver restores first)
         return;
       }
@@ -1361,7 +1369,7 @@ static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* proble
     for (int q = 0; q < n_problems; q++)
       switch (lm[q].want) {
         case BaLm::W_ERRORS: w_err.push_back(q); break;
-        case BaLm::W_LINEARIZE: w_lin.push_back(q); if (lm[q].need_restore) { w_restore.push_back(q); lm[q].need_restore = false; } break;
+        case BaLm::W_LINEARIZE: w_lin.push_back(q); w_trial.push_back(q); if (lm[q].need_restore) { w_restore.push_back(q); lm[q].need_restore = false; } break;
         case BaLm::W_RESTORE_THEN_TRIAL: w_restore.push_back(q); w_trial.push_back(q); break;
         case BaLm::W_TRIAL: w_trial.push_back(q); break;
         case BaLm::W_FINAL: w_final.push_back(q); if (lm[q].need_restore) w_restore.push_back(q); break;
