@@ -25,13 +25,14 @@ def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/seq_shape_variants.json"
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 121
     only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+    seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 777          # bench.py renders its sequences from 2024 + 1000 * rank
     from hso_amd import synth, bank_bench
     import pickle
-    cache = "/tmp/hso_seqs_%d.pkl" % frames          # one rendering for several processes of a box
+    cache = "/tmp/hso_seqs_%d_%d.pkl" % (frames, seed0)          # one rendering for several processes of a box
     if os.path.exists(cache):
         seqs = pickle.load(open(cache, "rb"))
     else:
-        seqs = [dict(images=q["images"], depth0=q["depth0"], T_f_w=q["T_f_w"]) for q in synth.sequences(8, frames, spec=synth.EUROC, seed0=777)]
+        seqs = [dict(images=q["images"], depth0=q["depth0"], T_f_w=q["T_f_w"]) for q in synth.sequences(8, frames, spec=synth.EUROC, seed0=seed0)]
         pickle.dump(seqs, open(cache, "wb"))
     rows = []
     for name, banks, n, env in VARIANTS:
