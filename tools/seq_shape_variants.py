@@ -10,6 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 VARIANTS = [
     ("plain", 6, 128, {}),
     ("plain8", 8, 128, {}),
+    ("plain7", 7, 128, {}),
+    ("plain5", 5, 128, {}),
+    ("plain6x160", 6, 160, {}),
+    ("plain_again", 6, 128, {}),
     ("plain12x64", 12, 64, {}),
     ("default", 6, 128, {}),
     ("split", 6, 128, {"HSO_TRACK_SPLIT_MIN_JOBS": "1"}),
