@@ -357,6 +357,7 @@ def load():
     lib.hso_gpu_fast_detect.argtypes = [vp, i64, i32, i32, i32, vp, i32, P(i32)]
     lib.hso_gpu_fast_detect_batch.argtypes = [vp, P(i64), i32, i32, i32, i32, vp, i32, vp]
     lib.hso_gpu_detect_candidates.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
+    lib.hso_gpu_detect_candidates_multi.argtypes = [vp, P(i64), i32, i32, vp, vp, i32, vp, vp, i32, vp]
     lib.hso_gpu_detect_candidates_init.argtypes = [vp, P(i64), i32, i32, i32, vp, i32, vp, vp, i32, vp]
     lib.hso_gpu_select_octree.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
     lib.hso_gpu_reproject_match_multi.argtypes = [vp, P(Camera), vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp]
@@ -377,7 +378,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_align_batch", "hso_gpu_align_multi", "hso_gpu_pose_optimize_batch", "hso_gpu_ba_linearize",
     "hso_gpu_seed_observe", "hso_gpu_seed_activate", "hso_gpu_fast_detect", "hso_gpu_fast_detect_batch",
     "hso_gpu_detect_candidates", "hso_gpu_select_octree", "hso_gpu_reproject_match", "hso_gpu_seed_observe_multi",
-    "hso_gpu_detect_candidates_init", "hso_gpu_frame_upload_resized",
+    "hso_gpu_detect_candidates_init", "hso_gpu_detect_candidates_multi", "hso_gpu_frame_upload_resized",
     "hso_gpu_reproject_match_multi", "hso_gpu_ba_huber_deltas", "hso_gpu_ba_optimize", "hso_gpu_ba_optimize_multi",
     "hso_gpu_seed_activate_multi", "hso_gpu_seed_activate_frames", "hso_gpu_seed_table_activate", "hso_gpu_reproject_select",
     "hso_gpu_seed_reproject_match",
@@ -915,6 +916,19 @@ class Context:
         cc, ec = np.zeros((n, n_levels), np.int32), np.zeros((n, n_levels), np.int32)
         self._check(self.lib.hso_gpu_detect_candidates(self.h, ids, n, n_levels, min_thresh, _ptr(co), corner_cap, _ptr(cc),
                                                        _ptr(eo), edgelet_cap, _ptr(ec)), "detect_candidates")
+        return co, cc, eo, ec
+
+    def detect_candidates_multi(self, frame_ids, min_thresh, n_levels=3, corner_cap=8192, edgelet_cap=4800):
+        """hso_gpu_detect_candidates_multi: one barrier per frame (min_thresh[i] of frame i); returns what detect_candidates does."""
+        n = len(frame_ids)
+        ids = (C.c_int64 * n)(*frame_ids)
+        th = np.ascontiguousarray(min_thresh, np.int32)
+        assert len(th) == n
+        co = np.zeros((n, n_levels, corner_cap), CORNER_DTYPE) if corner_cap > 0 else None
+        eo = np.zeros((n, n_levels, edgelet_cap), EDGELET_DTYPE) if edgelet_cap > 0 else None
+        cc, ec = np.zeros((n, n_levels), np.int32), np.zeros((n, n_levels), np.int32)
+        self._check(self.lib.hso_gpu_detect_candidates_multi(self.h, ids, n, n_levels, _ptr(th), _ptr(co), corner_cap, _ptr(cc),
+                                                             _ptr(eo), edgelet_cap, _ptr(ec)), "detect_candidates_multi")
         return co, cc, eo, ec
 
     def detect_candidates_init(self, frame_ids, n_levels=3, min_thresh=20, corner_cap=8192, fill_cap=4800):

@@ -58,6 +58,7 @@ struct EdgeArgs {
   int* flags;                        // [EDGE_ROUND + 1], per round: flags[k + 1] != 0: pass k of the round changed a pixel; flags[0] = the round before
   int* totals;                       // [n_frames][n_levels]
   int n_levels, low, high, cap, pass, slot;
+  const int* low_tab; const int* high_tab;   // the Canny thresholds of every frame (null: low / high for all)
 };
 
 // static selection of the level record: a dynamic index into the by-value argument would force a
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void k_canny_nms(EdgeArgs A)
     }
   }
   __syncthreads();
-  const int low = A.low, high = A.high;
+  const int low = A.low_tab ? A.low_tab[blockIdx.z] : A.low, high = A.high_tab ? A.high_tab[blockIdx.z] : A.high;
   for (int i = t; i < (CLOSE_TH + 2) * (CLOSE_TW + 2); i += 256) {
     const int ly = i / (CLOSE_TW + 2), lx = i - ly * (CLOSE_TW + 2);
     const int y = y0 + ly - 1, x = x0 + lx - 1;
@@ -415,15 +416,33 @@ __global__ __launch_bounds__(PACK_THREADS) void k_edgelet_pack(EdgeArgs A)
   if (t == 0) A.totals[(size_t)blockIdx.z * A.n_levels + blockIdx.y] = base;
 }
 
-extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int min_thresh,
-                                         hso_corner* corners, int corner_cap, int32_t* corner_counts,
-                                         hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts)
+// cv::Canny threshold preparation (L2gradient) for minThresh_: 31 x and 70 x, clamped to 32767, squared, floored
+static void canny_thresholds(int min_thresh, int* low, int* high)
+{
+  double lo = 31.0 * min_thresh, hi = 70.0 * min_thresh;
+  lo = lo < 32767.0 ? lo : 32767.0; hi = hi < 32767.0 ? hi : 32767.0;
+  *low = (int)(lo * lo); *high = (int)(hi * hi);
+}
+
+// thresh_per_frame != null: every frame has its own minThresh_ (min_thresh is ignored)
+static int detect_candidates_impl(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int min_thresh, const int32_t* thresh_per_frame,
+                                  hso_corner* corners, int corner_cap, int32_t* corner_counts,
+                                  hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts)
 {
   if (!ctx) return HSO_E_INVALID;
   if (!frame_ids || n_frames < 0 || n_levels < 1 || n_levels > EDGE_LEVELS || min_thresh < 0 || min_thresh > 255 || corner_cap < 0 ||
       edgelet_cap < 0 || !corner_counts || !edgelet_counts || (corner_cap > 0 && !corners) || (edgelet_cap > 0 && !edgelets))
     return hso_fail(ctx, HSO_E_INVALID, "detect_candidates: bad argument");
   if (n_frames == 0) return HSO_OK;
+  std::vector<int32_t> tab3;   // [FAST threshold | Canny low | Canny high] per frame
+  if (thresh_per_frame) {
+    tab3.resize(3 * (size_t)n_frames);
+    for (int i = 0; i < n_frames; i++) {
+      if (thresh_per_frame[i] < 0 || thresh_per_frame[i] > 255) return hso_fail(ctx, HSO_E_INVALID, "detect_candidates: bad argument");
+      tab3[(size_t)i] = thresh_per_frame[i];
+      canny_thresholds(thresh_per_frame[i], &tab3[(size_t)n_frames + i], &tab3[2 * (size_t)n_frames + i]);
+    }
+  }
   auto it0 = ctx->frames.find(frame_ids[0]);
   if (it0 == ctx->frames.end()) return hso_fail(ctx, HSO_E_NOFRAME, "detect_candidates: frame not resident");
   const PyrGeom g = it0->second.g;
@@ -469,7 +488,8 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
   const size_t extra = o_slices + slice * (size_t)n_frames;
 
   FastPlan P;
-  const int rc = hso_fast_enqueue(ctx, frame_ids, n_frames, n_levels, min_thresh, 8, corner_cap, extra, &P);   // fastThresh = floor(minThresh_), border 8 (:520-522)
+  const int rc = hso_fast_enqueue(ctx, frame_ids, n_frames, n_levels, min_thresh, 8, corner_cap, extra, &P,   // fastThresh = floor(minThresh_), border 8 (:520-522)
+                                  thresh_per_frame ? tab3.data() : nullptr);
   if (rc != HSO_OK) return rc;
   char* x = P.d + P.o_extra;
   for (int l = 0; l < n_levels; l++) {
@@ -483,11 +503,10 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
   A.flags = reinterpret_cast<int*>(x + o_flags);
   A.totals = reinterpret_cast<int*>(x + o_totals);
   A.n_levels = n_levels; A.cap = edgelet_cap;
-  {
-    // cv::Canny threshold preparation (L2gradient): clamp to 32767, square, floor
-    double lo = 31.0 * min_thresh, hi = 70.0 * min_thresh;
-    lo = lo < 32767.0 ? lo : 32767.0; hi = hi < 32767.0 ? hi : 32767.0;
-    A.low = (int)(lo * lo); A.high = (int)(hi * hi);
+  canny_thresholds(min_thresh, &A.low, &A.high);
+  if (thresh_per_frame) {
+    A.low_tab = reinterpret_cast<const int*>(P.d + P.o_thr) + n_frames;
+    A.high_tab = reinterpret_cast<const int*>(P.d + P.o_thr) + 2 * (size_t)n_frames;
   }
   HSO_HIP_CHECK(ctx, hipMemsetAsync(x + o_flags, 0, sizeof(int) * (EDGE_ROUND + 1), ctx->stream));
   HSO_HIP_CHECK(ctx, hipMemset2DAsync(A.work + o, slice, 0, have_per_frame, (size_t)n_frames, ctx->stream));
@@ -539,6 +558,22 @@ extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_
       if (n > 0) lists.push_back({edgelets + ((size_t)i * n_levels + l) * edgelet_cap, A.work + (size_t)i * slice + A.lv[l].o_out, sizeof(hso_edgelet) * (size_t)n});
     }
   return hso_lists_to_host(ctx, lists);     // corners and edgelets of every frame and level: one DMA
+}
+
+extern "C" int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int min_thresh,
+                                         hso_corner* corners, int corner_cap, int32_t* corner_counts,
+                                         hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts)
+{
+  return detect_candidates_impl(ctx, frame_ids, n_frames, n_levels, min_thresh, nullptr, corners, corner_cap, corner_counts, edgelets, edgelet_cap, edgelet_counts);
+}
+
+extern "C" int hso_gpu_detect_candidates_multi(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, const int32_t* min_thresh,
+                                               hso_corner* corners, int corner_cap, int32_t* corner_counts,
+                                               hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_frames > 0 && !min_thresh) return hso_fail(ctx, HSO_E_INVALID, "detect_candidates: bad argument");
+  return detect_candidates_impl(ctx, frame_ids, n_frames, n_levels, 0, min_thresh, corners, corner_cap, corner_counts, edgelets, edgelet_cap, edgelet_counts);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ struct FastArgs {
   size_t per_frame, o_cnt, o_mask, o_off, o_out;  // slice size and the level's offsets inside a slice
   int* totals;                  // [n_frames][n_levels]
   int n_levels, level;
+  const int* thr;               // the threshold of every frame (null: `threshold` for all)
 };
 
 template <int ARC>
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void k_fast_mask(FastArgs A)
   char* slice = A.work + (size_t)blockIdx.z * A.per_frame;
   unsigned long long* mask = reinterpret_cast<unsigned long long*>(slice + A.o_mask);
   int* row_count = reinterpret_cast<int*>(slice + A.o_cnt);
-  const int W = A.W, H = A.H, threshold = A.threshold, border = A.border, words_per_row = A.words_per_row;
+  const int W = A.W, H = A.H, threshold = A.thr ? A.thr[blockIdx.z] : A.threshold, border = A.border, words_per_row = A.words_per_row;
   const int x0 = blockIdx.x * FAST_TW, y0 = blockIdx.y * FAST_TH;
   const int t = threadIdx.x;
   for (int i = t; i < (FAST_TH + 8) * (FAST_TW + 8); i += 256) {
@@ -222,18 +223,19 @@ size_t hso_fast_plan(const PyrGeom& g, int n_frames, int n_levels, int cap, Fast
   P.per_frame = o;
   P.o_tab = P.per_frame * (size_t)n_frames;
   P.o_tot = P.o_tab + al(sizeof(void*) * (size_t)n_frames);
-  P.o_extra = P.o_tot + al(sizeof(int) * (size_t)n_frames * n_levels);
+  P.o_thr = P.o_tot + al(sizeof(int) * (size_t)n_frames * n_levels);
+  P.o_extra = P.o_thr + al(sizeof(int) * 3 * (size_t)n_frames);
   return P.o_extra;
 }
 
-int hso_fast_launch(hso_gpu_ctx* ctx, const FastPlan& P, const uint8_t* const* d_bases, int threshold, int border, int arc)
+int hso_fast_launch(hso_gpu_ctx* ctx, const FastPlan& P, const uint8_t* const* d_bases, int threshold, int border, int arc, const int* d_thr)
 {
   const PyrGeom& g = P.g;
   const int n_frames = P.n_frames, n_levels = P.n_levels, cap = P.cap;
   HSO_HIP_CHECK(ctx, hipMemset2DAsync(P.d, P.per_frame, 0, P.cnt_bytes, (size_t)n_frames, ctx->stream));  // the row counters of every slice
   FastArgs A;
   A.bases = d_bases;
-  A.threshold = threshold; A.border = border; A.cap = cap;
+  A.threshold = threshold; A.border = border; A.cap = cap; A.thr = d_thr;
   A.work = P.d; A.per_frame = P.per_frame;
   A.totals = reinterpret_cast<int*>(P.d + P.o_tot);
   A.n_levels = n_levels;
@@ -254,7 +256,7 @@ int hso_fast_launch(hso_gpu_ctx* ctx, const FastPlan& P, const uint8_t* const* d
 }
 
 int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int threshold, int border, int cap,
-                     size_t extra, FastPlan* plan)
+                     size_t extra, FastPlan* plan, const int32_t* per_frame3)
 {
   FastPlan& P = *plan;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -278,7 +280,12 @@ int hso_fast_enqueue(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, i
   char* d = reinterpret_cast<char*>(ctx->d_batch);
   P.d = d;
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + P.o_tab, h_bases.data(), sizeof(void*) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
-  return hso_fast_launch(ctx, P, reinterpret_cast<const uint8_t* const*>(d + P.o_tab), threshold, border, 9);
+  const int* d_thr = nullptr;
+  if (per_frame3) {
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(d + P.o_thr, per_frame3, sizeof(int32_t) * 3 * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
+    d_thr = reinterpret_cast<const int*>(d + P.o_thr);
+  }
+  return hso_fast_launch(ctx, P, reinterpret_cast<const uint8_t* const*>(d + P.o_tab), threshold, border, 9, d_thr);
 }
 
 int hso_fast_collect(hso_gpu_ctx* ctx, const FastPlan& P, hso_corner* out, int32_t* counts, std::vector<HsoListCopy>* more)

@@ -615,10 +615,14 @@ void Bank::detect(const std::vector<int>& who, const std::vector<Id>& frame, con
   std::vector<int> todo(who.size());
   std::iota(todo.begin(), todo.end(), 0);
   while (!todo.empty()) {
+    // the keyframes of a step in ONE call, each at its own barrier (hso_gpu_detect_candidates_multi); the initialisation branch —
+    // once per sequence — is still grouped by barrier
     const int th = thresh[todo[0]];
     std::vector<int> grp, rest;
-    for (int i : todo) (thresh[i] == th ? grp : rest).push_back(i);
+    for (int i : todo) ((!init || thresh[i] == th) ? grp : rest).push_back(i);
     todo.swap(rest);
+    std::vector<int32_t> ths;
+    for (int i : grp) ths.push_back(thresh[i]);
     std::vector<int64_t> ids;
     for (int i : grp) ids.push_back(seq_[who[i]]->frames[frame[i]].dev_id);
     const int n = (int)grp.size();
@@ -632,7 +636,7 @@ void Bank::detect(const std::vector<int>& who, const std::vector<Id>& frame, con
     for (;;) {
       co = det_corners_.need(ctx_, (size_t)n * n_levels * corner_cap);
       const int rc = init ? hso_gpu_detect_candidates_init(ctx_, ids.data(), n, n_levels, th, co, corner_cap, nc.data(), fill, second_cap, ns.data())
-                          : hso_gpu_detect_candidates(ctx_, ids.data(), n, n_levels, th, co, corner_cap, nc.data(), ed, second_cap, ns.data());
+                          : hso_gpu_detect_candidates_multi(ctx_, ids.data(), n, n_levels, ths.data(), co, corner_cap, nc.data(), ed, second_cap, ns.data());
       check(rc, "FeatureExtractor");
       n_calls_[9]++; n_items_[9] += n;
       const int most = *std::max_element(nc.begin(), nc.end());
@@ -647,7 +651,7 @@ void Bank::detect(const std::vector<int>& who, const std::vector<Id>& frame, con
       if (s.trace.on()) {
         Trace& t = s.trace;
         t.begin("detect_candidates", 5 + 2 * (uint32_t)n_levels + 1);
-        t.scalar("init", init ? 1 : 0); t.scalar("frame_id", (double)ids[g]); t.scalar("n_levels", n_levels); t.scalar("min_thresh", th);
+        t.scalar("init", init ? 1 : 0); t.scalar("frame_id", (double)ids[g]); t.scalar("n_levels", n_levels); t.scalar("min_thresh", ths[(size_t)g]);
         t.field("corner_counts", ncg, sizeof(int32_t) * (size_t)n_levels);
         for (int L = 0; L < n_levels; L++) t.field(("corners" + std::to_string(L)).c_str(), cg + (size_t)L * corner_cap, sizeof(hso_corner) * (size_t)ncg[L]);
         if (init) {

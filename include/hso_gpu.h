@@ -1003,6 +1003,12 @@ typedef struct hso_edgelet {
 int hso_gpu_detect_candidates(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, int min_thresh,
                               hso_corner* corners, int corner_cap, int32_t* corner_counts,
                               hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts);
+/* The same with one minThresh_ per frame (FeatureExtractor::detect takes Frame::gradMean_ as its barrier,
+ * src/feature_detection.cpp:408-445: the keyframes of different sequences have different ones): min_thresh[n_frames], each in
+ * [0, 255].  One call for the keyframes a bank of sequences takes in a step; every frame's lists equal the single-barrier call's. */
+int hso_gpu_detect_candidates_multi(hso_gpu_ctx* ctx, const int64_t* frame_ids, int n_frames, int n_levels, const int32_t* min_thresh,
+                                    hso_corner* corners, int corner_cap, int32_t* corner_counts,
+                                    hso_edgelet* edgelets, int edgelet_cap, int32_t* edgelet_counts);
 
 /* The initialisation branch of FeatureExtractor::detect (:439-442): fastDetectMT as above, then
  * fillingHole on level 0 (src/feature_detection.cpp:1125-1154) — fast_corner_detect_plain_12,

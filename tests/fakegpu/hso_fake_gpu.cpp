@@ -942,6 +942,16 @@ int hso_gpu_detect_candidates(hso_gpu_ctx* c, const int64_t* ids, int n, int n_l
 {
   return detect_impl(c, ids, n, n_levels, min_thresh, co, cap, nc, ed, nullptr, ecap, ne, false);
 }
+int hso_gpu_detect_candidates_multi(hso_gpu_ctx* c, const int64_t* ids, int n, int n_levels, const int32_t* min_thresh, hso_corner* co, int cap, int32_t* nc, hso_edgelet* ed,
+                                    int ecap, int32_t* ne)
+{
+  for (int f = 0; f < n; f++) {   // a frame at a time, each at its own barrier
+    const int rc = detect_impl(c, ids + f, 1, n_levels, min_thresh[f], co ? co + (size_t)f * n_levels * cap : nullptr, cap, nc + (size_t)f * n_levels,
+                               ed ? ed + (size_t)f * n_levels * ecap : nullptr, nullptr, ecap, ne + (size_t)f * n_levels, false);
+    if (rc != HSO_OK) return rc;
+  }
+  return HSO_OK;
+}
 int hso_gpu_detect_candidates_init(hso_gpu_ctx* c, const int64_t* ids, int n, int n_levels, int min_thresh, hso_corner* co, int cap, int32_t* nc, hso_corner* fill,
                                    int fcap, int32_t* nf)
 {

@@ -190,6 +190,39 @@ def test_detect_candidates_long_weak_chains_and_batch(gpu_ctx, orc):
 
 
 @pytest.mark.gpu
+def test_detect_candidates_multi_one_barrier_per_frame(gpu_ctx, orc):
+    """hso_gpu_detect_candidates_multi: the keyframes of different sequences carry different minThresh_ (Frame::gradMean_,
+    src/feature_detection.cpp:408-445).  Four frames at barriers 12, 5, 27, 5 in one call: every frame's corner and edgelet lists
+    equal the oracle's at its own barrier and the single-barrier call's bytes; a barrier outside [0, 255] is refused."""
+    h, w = 480, 640
+    rng = np.random.default_rng(5)
+    imgs = [synth.config2_pair(10, seed=71)["ref"], synth.config2_pair(10, seed=72)["ref"],
+            (np.kron(rng.integers(0, 2, (h // 8, w // 8)), np.ones((8, 8))) * 40 + 60).astype(np.uint8), synth.config2_pair(10, seed=73)["ref"]]
+    ths = [12, 5, 27, 5]
+    ids = [9760 + k for k in range(len(imgs))]
+    for i, im in zip(ids, imgs):
+        gpu_ctx.frame_upload(i, im)
+    try:
+        co, cc, eo, ec = gpu_ctx.detect_candidates_multi(ids, ths, n_levels=3, corner_cap=40000, edgelet_cap=4800)
+        for k, (im, thr) in enumerate(zip(imgs, ths)):
+            pyr, sob = _frame_images(orc, im)
+            for L in range(3):
+                corners, edgelets, _ = orc.detect_candidates_level(np.ascontiguousarray(pyr[L]), sob[L][0], sob[L][1], L, w, h, thr)
+                assert (cc[k, L], ec[k, L]) == (len(corners), len(edgelets)), (thr, k, L)
+                _check(co[k, L, :cc[k, L]], corners, "corners")
+                _check(eo[k, L, :ec[k, L]], edgelets, "edgelets")
+            solo = gpu_ctx.detect_candidates([ids[k]], n_levels=3, min_thresh=thr, corner_cap=40000, edgelet_cap=4800)
+            assert (solo[1][0] == cc[k]).all() and (solo[3][0] == ec[k]).all()
+            assert solo[0][0].tobytes() == co[k].tobytes() and solo[2][0].tobytes() == eo[k].tobytes()
+        assert cc[1].sum() != cc[3].sum() or ec[1].sum() != ec[3].sum()          # different images at the same barrier
+        with pytest.raises(Exception):
+            gpu_ctx.detect_candidates_multi(ids, [12, 5, 256, 5])
+    finally:
+        for i in ids:
+            gpu_ctx.frame_release(i)
+
+
+@pytest.mark.gpu
 def test_detect_candidates_serpentine_chain_needs_many_closure_passes(gpu_ctx, orc):
     """One weak contour that winds through far more than 64 tile borders (a ribbon of +3 grey levels snaking over the
     whole frame) with a single strong stretch: cv::Canny's flood fill follows it to the end, so must the tiled closure,
