@@ -93,10 +93,13 @@ def _gpu_busy_reader(device):
     return read if read() is not None else None
 
 
-def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False, lib_path=None, to_device=None, steady_from=None):
+def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False, lib_path=None, to_device=None, steady_from=None,
+              host_images=False):
     """n_banks engines of n_seq sequences each, every one on its own host thread with its own device context / stream: the
     device work of one bank overlaps the bookkeeping and the PCIe traffic of the others (independent sequences shard freely, also
-    within one GPU).  Whole-run throughput: all frames / wall time from the first step to the last bank's last step."""
+    within one GPU).  Whole-run throughput: all frames / wall time from the first step to the last bank's last step.
+    host_images: every step's images are handed over as page-locked HOST buffers (FrameHandlerMono::addImage takes a host image): 361 KB
+    of PCIe per frame inside the step, one bank's copies beside the other banks' kernels."""
     import threading
     from hso_amd import synth
     spec = spec or synth.EUROC
@@ -126,7 +129,10 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
         m = vo.MultiVisualOdometry(cam, n_seq, max_fts, device=device, lib=vo.load_from(lib_path) if lib_path else None)
         m.set_first_frames([q["images"][0] for q in pick], [q["depth0"] for q in pick])
         threads_per_bank[b] = int(m.lib.hso_vo_multi_threads(m.h))
-        if to_device is None:
+        if host_images:
+            import torch
+            dev = [[torch.from_numpy(np.ascontiguousarray(im)).pin_memory() for im in q["images"]] for q in seqs]
+        elif to_device is None:
             import torch
             dev = [[torch.from_numpy(np.ascontiguousarray(im)).cuda(device) for im in q["images"]] for q in seqs]
             torch.cuda.synchronize(device)
@@ -138,7 +144,7 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
         for k in range(1, frames):
             ptrs = [dev[q % len(seqs)][k].data_ptr() for q in range(n_seq)]
             t0 = time.perf_counter()
-            m.add_images_device(ptrs, w, h, [float(k)] * n_seq)
+            (m.add_images_host_ptrs if host_images else m.add_images_device)(ptrs, w, h, [float(k)] * n_seq)
             t1 = time.perf_counter()
             ms.append(1e3 * (t1 - t0))
             ends.append(t1)
@@ -180,7 +186,7 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
     wall = max(t_end) - t0
     c1 = _cgroup_cpu()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
-    out = dict(banks=n_banks, sequences_per_bank=n_seq, sequences=n_banks * n_seq, frames=frames - 1, max_fts=max_fts, images="device",
+    out = dict(banks=n_banks, sequences_per_bank=n_seq, sequences=n_banks * n_seq, frames=frames - 1, max_fts=max_fts, images="page-locked host" if host_images else "device",
                distinct=len(seqs), frames_per_s=n_banks * n_seq * (frames - 1) / wall, wall_s=wall,
                ms_per_step_mean_per_bank=[r["ms_per_step_mean"] for r in res], ms_per_step_median_per_bank=[r["ms_per_step_median"] for r in res],
                keyframes_per_sequence=float(np.mean([r["keyframes"] for r in res])),

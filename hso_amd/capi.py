@@ -13,6 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HSO_GPU_LIB") or os.path.join(_HERE, "csrc", "libhso_gpu.so")   # HSO_GPU_LIB: developer experiments only
 
+ABI_VERSION = 2      # include/hso_gpu.h: HSO_GPU_ABI_VERSION
 N_PYR_LEVELS = 5
 N_SOBEL_LEVELS = 3
 CAM_PINHOLE, CAM_FOV, CAM_EQUIDISTANT = 0, 1, 2
@@ -363,13 +364,16 @@ def load():
     lib.hso_gpu_reproject_match_multi.argtypes = [vp, P(Camera), vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp]
     lib.hso_gpu_reproject_match.argtypes = [vp, P(Camera), i64, P(SE3), C.c_double, i32, vp, i32, vp, i32, vp, i32, i32, i32,
                                             vp, vp]
+    if lib.hso_gpu_abi_version() != ABI_VERSION:
+        raise HsoGpuError("libhso_gpu.so reports ABI version %d, this binding is written against %d (include/hso_gpu.h: HSO_GPU_ABI_VERSION); rebuild"
+                          % (lib.hso_gpu_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
 
 # Every symbol include/hso_gpu.h declares; tests check the library exports all of them.
 EXPORTED_SYMBOLS = [
-    "hso_gpu_debug_census", "hso_gpu_ba_huber_deltas_multi", "hso_gpu_ba_local_multi",
+    "hso_gpu_ba_huber_deltas_multi", "hso_gpu_ba_local_multi",
     "hso_gpu_create", "hso_gpu_destroy", "hso_gpu_last_error", "hso_gpu_abi_version",
     "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_set_host_parallel", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
@@ -384,13 +388,18 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_seed_reproject_match",
     "hso_gpu_seed_table_create", "hso_gpu_seed_table_destroy", "hso_gpu_seed_table_append", "hso_gpu_seed_table_erase",
     "hso_gpu_seed_table_size", "hso_gpu_seed_table_observe", "hso_gpu_seed_table_read",
-    "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_klt_debug_level", "hso_gpu_host_alloc", "hso_gpu_host_free", "hso_gpu_seed_table_compact",
+    "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_host_alloc", "hso_gpu_host_free", "hso_gpu_seed_table_compact",
     "hso_gpu_seqmap_create", "hso_gpu_seqmap_destroy", "hso_gpu_seqmap_set_keyframes", "hso_gpu_seqmap_patch", "hso_gpu_seqmap_patch_multi", "hso_gpu_seqmap_size", "hso_gpu_seqmap_read",
     "hso_gpu_seqmap_configure", "hso_gpu_seqmap_patch_lists", "hso_gpu_seqmap_patch_links", "hso_gpu_seqmap_set_key_points",
-    "hso_gpu_seq_chain", "hso_gpu_seq_events", "hso_gpu_seq_frame_features", "hso_gpu_seq_set_frame_features", "hso_gpu_seq_debug_list", "hso_gpu_seq_debug_ref_table",
-    "hso_gpu_debug_fetch", "hso_gpu_seed_table_observe_groups", "hso_gpu_seed_table_set_host_pose",
+    "hso_gpu_seq_chain", "hso_gpu_seq_events", "hso_gpu_seq_frame_features", "hso_gpu_seq_set_frame_features",
+    "hso_gpu_seed_table_observe_groups", "hso_gpu_seed_table_set_host_pose",
     "hso_gpu_seed_table_observe_previous", "hso_gpu_seed_table_observe_previous_begin", "hso_gpu_seed_table_observe_previous_end",
 ]
+
+
+# ... and every symbol include/hso_gpu_debug.h declares (parity / trace read-backs, developer probes: not part of the boundary)
+DEBUG_SYMBOLS = ["hso_gpu_debug_census", "hso_gpu_klt_debug_level", "hso_gpu_seq_debug_list", "hso_gpu_seq_debug_ref_table", "hso_gpu_debug_fetch",
+                 "hso_gpu_seqmap_debug_dump"]
 
 
 def select_octree(keys, width, height, n_features):

@@ -1036,6 +1036,42 @@ int hso_gpu_debug_fetch(hso_gpu_ctx* ctx, int what, void* out, size_t bytes)
   return HSO_OK;
 }
 
+// a sequence map as the library holds it (include/hso_gpu_debug.h): host-side tables from the host copies, device tables by one
+// copy behind whatever patches are still queued on the stream
+int hso_gpu_seqmap_debug_dump(hso_gpu_ctx* ctx, int map, int what, void* out, size_t bytes)
+{
+  if (!ctx) return HSO_E_INVALID;
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || !out || what < 0 || what >= HSO_DUMP_N) return hso_fail(ctx, HSO_E_INVALID, "seqmap_debug_dump: bad argument");
+  const size_t nk = m->kfs.size();
+  const void* host = nullptr; const void* dev = nullptr; size_t want = 0;
+  int64_t sizes[HSO_DUMP_N_SIZES] = {(int64_t)nk, (int64_t)m->n_pts, (int64_t)m->n_obs, m->fts_cap, m->n_cands, m->ff_n[0], m->ff_n[1], m->ff_frame[0], m->ff_frame[1],
+                                     m->ff_newest, (int64_t)sizeof(hso_kf), (int64_t)sizeof(hso_map_point), (int64_t)sizeof(hso_obs), (int64_t)sizeof(hso_seq_feature),
+                                     (int64_t)sizeof(hso_seq_job), (int64_t)sizeof(hso_seq_result)};
+  std::vector<int32_t> lists;
+  switch (what) {
+    case HSO_DUMP_SIZES: host = sizes; want = sizeof(sizes); break;
+    case HSO_DUMP_KFS: host = m->kfs.data(); want = sizeof(hso_kf) * nk; break;
+    case HSO_DUMP_KEY_POINTS: host = m->key_points.data(); want = sizeof(int32_t) * 5 * nk; break;
+    case HSO_DUMP_KF_NFTS: host = m->kf_nfts.data(); want = sizeof(int32_t) * nk; break;
+    case HSO_DUMP_POINTS: dev = m->d_pts; want = sizeof(hso_map_point) * m->n_pts; break;
+    case HSO_DUMP_OBS: dev = m->d_obs; want = sizeof(hso_obs) * m->n_obs; break;
+    case HSO_DUMP_OBS_POINT: dev = m->d_obs_pt; want = sizeof(int32_t) * m->n_obs; break;
+    case HSO_DUMP_KF_FTS: dev = m->d_kf_fts; want = sizeof(int32_t) * nk * (size_t)m->fts_cap; break;
+    case HSO_DUMP_CANDS: dev = m->d_cands; want = sizeof(int32_t) * (size_t)m->n_cands; break;
+    case HSO_DUMP_FRAME_FEATS0: dev = m->d_ff[0]; want = sizeof(hso_seq_feature) * (size_t)m->ff_n[0]; break;
+    default: dev = m->d_ff[1]; want = sizeof(hso_seq_feature) * (size_t)m->ff_n[1]; break;
+  }
+  if (want != bytes) return hso_fail(ctx, HSO_E_INVALID, "seqmap_debug_dump: bytes differs from the table's size");
+  if (bytes == 0) return HSO_OK;
+  if (host) { memcpy(out, host, bytes); return HSO_OK; }
+  if (!dev || (what == HSO_DUMP_KF_FTS && m->kf_rows_cap < nk)) return hso_fail(ctx, HSO_E_INVALID, "seqmap_debug_dump: the table was never sent");
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return HSO_OK;
+}
+
 }  // extern "C"
 
 void hso_seqmaps_debug_set(hso_gpu_ctx* ctx, int what, const void* d, size_t bytes)
@@ -1057,6 +1093,10 @@ int hso_seqmap_chain_view(hso_gpu_ctx* ctx, const hso_seq_job& job, SeqMapDev* o
   if (!m) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: no such map");
   if (m->kfs.empty() || !m->d_kfs) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: the map has no keyframes");
   const int nk = (int)m->kfs.size();
+  // the visiting order and the covisibility votes are formed in tables of HSO_SEQ_MAX_KFS rows (k_chain_visit, k_chain_finish): a
+  // longer keyframe table would silently leave its NEWEST rows out of both.  The reference never gets there — Map keeps at most
+  // Config::maxNKfs() = 2000 keyframes by dropping the farthest (src/frame_handler_mono.cpp:340-346) — so a caller that does is refused.
+  if (nk > HSO_SEQ_MAX_KFS) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: the map's keyframe table exceeds HSO_SEQ_MAX_KFS rows");
   if (m->fts_cap < 1 || m->kf_rows_cap < (size_t)nk) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: the keyframes' feature lists were never sent (hso_gpu_seqmap_patch_lists)");
   if (job.last_kf_row < -1 || job.last_kf_row >= nk || job.ref_kf_row < -1 || job.ref_kf_row >= nk) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: keyframe row out of range");
   for (int q = 0; q < 5; q++) if (job.covis[q] < -1 || job.covis[q] >= nk) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: covisible keyframe row out of range");
@@ -1152,7 +1192,7 @@ int hso_chain_table_launch(hso_gpu_ctx* ctx, const ChainJobDev* d_jobs, int n_jo
 // ---- after the tracker: the write-back of CoarseTracker::run (:198-202), the per-keyframe products of the reprojection, and which
 // keyframes the frame visits (Reprojector::reprojectMap, src/reprojector.cpp:108-199: the reference frame's connected keyframes,
 // then Map::getCloseKeyframes (src/map.cpp:193-213) sorted by distance, until max_kfs).  One workgroup per job.
-#define CHAIN_MAX_KFS 2048
+#define CHAIN_MAX_KFS HSO_SEQ_MAX_KFS
 struct ChainFrontDev {
   const ChainJobDev* jobs; ChainCur* cur; const hso_track_result* track; const int32_t* kf_nfts; const int32_t* temps;
   ReprojKf* kfs; int32_t* ids; uint8_t* quality; PoseJobDev* pose_jobs;

@@ -10,6 +10,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/hso_gpu.h"
+#include "../../include/hso_gpu_debug.h"
 
 // Geometry of one resident frame: 5-level u8 pyramid + Sobel images of levels 0-2.
 // Every level starts 256-byte aligned and is followed by at least one zeroed

@@ -155,15 +155,17 @@ static hipError_t stream_wait(hipStream_t stream)
   if (e != hipSuccess) return e;
   if (yield_mode() == 0) return hipEventSynchronize(ev);
   const auto t0 = std::chrono::steady_clock::now();
+  long slack = -1;                                                  // the caller's timer slack, put back before this returns
   for (;;) {
     e = hipEventQuery(ev);
-    if (e != hipErrorNotReady) return e;
+    if (e != hipErrorNotReady) break;
     if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(40)) continue;   // short waits: no sleep at all
-    static thread_local bool slack_set = false;
-    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL); slack_set = true; }   // the default slack (50 us) would triple the nap
+    if (slack < 0) { slack = prctl(PR_GET_TIMERSLACK); if (slack < 0) slack = 0; (void)prctl(PR_SET_TIMERSLACK, 2000UL); }   // the default slack (50 us) would triple the nap
     timespec ts{0, 20000};
     nanosleep(&ts, nullptr);
   }
+  if (slack > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack);
+  return e;
 }
 
 hipError_t hso_stream_sync(hipStream_t stream)

@@ -590,17 +590,17 @@ __global__ __launch_bounds__(FIN_THREADS) void k_chain_finish(FinishArgs A, hso_
     __syncthreads();
   }
   // (4b) createCovisibilityGraph (src/frame_handler_mono.cpp:559-647): a vote per observation of each of the frame's points
-  for (int k = tid; k < 2048; k += FIN_THREADS) s_votes[k] = 0;
+  for (int k = tid; k < HSO_SEQ_MAX_KFS; k += FIN_THREADS) s_votes[k] = 0;
   __syncthreads();
   for (int i = tid; i < nf; i += FIN_THREADS) {
     const int p = ff[i].point;
     if (p < 0) continue;
     const hso_map_point& P = pts[p];
-    for (int q = 0, o = P.obs_begin; q < P.obs_count && o >= 0; q++) { const hso_obs& ob = J.M.obs[o]; if (ob.kf < 2048) atomicAdd(&s_votes[ob.kf], 1); o = ob.pad_; }
+    for (int q = 0, o = P.obs_begin; q < P.obs_count && o >= 0; q++) { const hso_obs& ob = J.M.obs[o]; if (ob.kf >= 0 && ob.kf < HSO_SEQ_MAX_KFS) atomicAdd(&s_votes[ob.kf], 1); o = ob.pad_; }
   }
   __syncthreads();
   if (tid == 0) {
-    const int nk = J.M.n_kfs < 2048 ? J.M.n_kfs : 2048;
+    const int nk = J.M.n_kfs < HSO_SEQ_MAX_KFS ? J.M.n_kfs : HSO_SEQ_MAX_KFS;
     const int need = n_pt > 30 ? 5 : 3;
     int seen = 0, best = -1;
     for (int k = 0; k < nk; k++) if (s_votes[k] > 0) { seen++; if (best < 0 || s_votes[k] > s_votes[best]) best = k; }
@@ -787,6 +787,14 @@ extern "C" int hso_gpu_seq_chain(hso_gpu_ctx* ctx, const hso_camera* cam, const 
     }
   }
   if (n_jobs == 0) return HSO_OK;
+  // everything about the chained seed observation is checked before the first kernel is queued: the observation updates the seeds
+  // in place, so a refusal after it would report failure with the seeds' state already advanced
+  if (cfg->seed_table >= 0) {
+    if (cfg->n_seed_groups <= 0 || !cfg->seed_brief_out) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: seed observation without groups or a brief table");
+    int n_slots = 0, n_live = 0;
+    if (int rc = hso_gpu_seed_table_size(ctx, cfg->seed_table, &n_slots, &n_live)) return rc;
+    if (n_slots > cfg->seed_brief_cap) return hso_fail(ctx, HSO_E_INVALID, "seq_chain: seed_brief_out is smaller than the seed table");
+  }
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int n_cells = cfg->n_cells, max_fts = cfg->max_fts, feat_cap = max_fts;
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };

@@ -495,7 +495,8 @@ extern "C" {
 // the next the stream never runs dry (0.21 ms of a 16.9 ms step at 4096 pairs were the synchronous read-back + the next launches).
 int hso_gpu_coarse_track_collect_begin(hso_gpu_ctx* ctx)
 {
-  if (!ctx || !ctx->track || ctx->track->n_jobs <= 0) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_collect_begin: nothing launched");
+  if (!ctx) return HSO_E_INVALID;
+  if (!ctx->track || ctx->track->n_jobs <= 0) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_collect_begin: nothing launched");
   TrackBatchState* st = ctx->track;
   if (st->coop_K) return hso_fail(ctx, HSO_E_UNSUPPORTED, "coarse_track_collect_begin: a cooperative launch (a batch smaller than the chip) is collected with hso_gpu_coarse_track_collect");
   if (st->n_pend >= 2) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_collect_begin: two read-backs are in flight already");
@@ -516,7 +517,8 @@ int hso_gpu_coarse_track_collect_begin(hso_gpu_ctx* ctx)
 
 int hso_gpu_coarse_track_collect_end(hso_gpu_ctx* ctx, hso_track_result* results)
 {
-  if (!ctx || !ctx->track || !results) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_collect_end: bad argument");
+  if (!ctx) return HSO_E_INVALID;
+  if (!ctx->track || !results) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_collect_end: bad argument");
   TrackBatchState* st = ctx->track;
   if (st->n_pend <= 0) return hso_fail(ctx, HSO_E_INVALID, "coarse_track_collect_end: no read-back in flight");
   const int slot = st->pend[0], n = st->pend_n[0];

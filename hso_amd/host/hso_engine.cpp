@@ -167,6 +167,13 @@ bool Bank::trace(int k, const char* path)
   return seq_[k]->trace.open(path);
 }
 
+bool Bank::trace_state(int k, bool on)
+{
+  if (k < 0 || k >= size()) return false;
+  seq_[k]->trace.state = on;
+  return true;
+}
+
 void Bank::call_counts(int64_t* calls, int64_t* items, int cap) const
 {
   for (int i = 0; i < cap && i < 10; i++) { if (calls) calls[i] = n_calls_[i]; if (items) items[i] = n_items_[i]; }
@@ -216,9 +223,11 @@ void Bank::release_queued()
   if (to_release_.empty()) return;
   std::sort(to_release_.begin(), to_release_.end());
   to_release_.erase(std::unique(to_release_.begin(), to_release_.end()), to_release_.end());
+  std::vector<int64_t> again;
   if (hso_gpu_frame_release_batch(ctx_, to_release_.data(), (int)to_release_.size()) < 0)
-    for (int64_t id : to_release_) (void)hso_gpu_frame_release(ctx_, id);   // one of them cannot go (yet): the others still do
-  to_release_.clear();
+    for (int64_t id : to_release_)                                  // one of them cannot go (yet): the others still do, and
+      if (hso_gpu_frame_release(ctx_, id) == HSO_E_INVALID) again.push_back(id);   // a frame still hosting live seeds stays queued for the next step
+  to_release_.swap(again);
 }
 
 void Bank::release_frame(Seq& s, Id fr)

@@ -30,6 +30,7 @@
 #include <chrono>
 #include <vector>
 #include "../../include/hso_vo.h"
+#include "../../include/hso_gpu_debug.h"
 #include "hso_math.h"
 
 namespace hso {
@@ -141,6 +142,7 @@ template <typename T> struct Pinned {
 
 struct Trace {                    // device-call recorder (hso_trace.h format), one per sequence
   FILE* f = nullptr;
+  bool state = false;             // hso_vo_trace_state: a recorded chain call also keeps the sequence map as it stood before the call
   ~Trace() { close(); }
   bool open(const char* path);
   void close();
@@ -172,6 +174,7 @@ public:
   // every frame the sequence has processed since its start: (timestamp, T_f_w as it stood when the frame was finished)
   int trajectory(int k, double* stamps, hso_se3* T_f_w, int cap) const;
   bool trace(int k, const char* path);
+  bool trace_state(int k, bool on);
   void call_counts(int64_t* calls, int64_t* items, int cap) const;
   // algorithmic bytes (SURVEY.md section 8(d) units) of the steps so far: [frame build, tracker, matcher, pose optimiser, seeds]
   void alg_bytes(double* out, int cap) const { for (int i = 0; i < cap && i < 5; i++) out[i] = alg_bytes_[i]; }
@@ -189,6 +192,7 @@ private:
   void prepare_job(int k, hso_seq_job& job, std::vector<int32_t>& temps);
   void consume_result(int k, const hso_seq_result& r, const std::vector<int32_t>& more_events);
   void trace_chain(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const hso_seq_result* res);
+  void trace_chain_state(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const std::vector<int32_t>& temps);
   void fetch_features(const std::vector<int>& who);
   void send_features(const std::vector<int>& who);
   void seed_branch(const std::vector<int>& who);

@@ -16,6 +16,8 @@ namespace {
 Bank* make_bank(const hso_camera* cam, int max_fts, int n, int device, int* rc)
 {
   hso_gpu_ctx* ctx = nullptr;
+  // the engine was compiled against include/hso_gpu.h's struct layouts: a device library of another ABI generation is refused
+  if (hso_gpu_abi_version() != HSO_GPU_ABI_VERSION) { *rc = HSO_E_UNSUPPORTED; return nullptr; }
   *rc = hso_gpu_create(&ctx, device, nullptr);
   if (*rc < 0) return nullptr;
   Settings cfg;
@@ -58,6 +60,7 @@ int hso_vo_create(hso_vo** out, const hso_camera* cam, int max_fts, int device)
 void hso_vo_destroy(hso_vo* v) { if (v) { delete v->bank; delete v; } }
 const char* hso_vo_last_error(const hso_vo* v) { return v ? v->bank->err.c_str() : "null handle"; }
 int hso_vo_trace(hso_vo* v, const char* path) { return (v && v->bank->trace(0, path)) ? HSO_OK : HSO_E_INVALID; }
+int hso_vo_trace_state(hso_vo* v, int on) { return (v && v->bank->trace_state(0, on != 0)) ? HSO_OK : HSO_E_INVALID; }
 
 int hso_vo_set_first_frame(hso_vo* v, const uint8_t* img, int width, int height, double timestamp, const float* depth_z, const hso_se3* T_f_w)
 {
@@ -94,6 +97,7 @@ void hso_vo_multi_destroy(hso_vo_multi* m) { if (m) { delete m->bank; delete m; 
 const char* hso_vo_multi_last_error(const hso_vo_multi* m) { return m ? m->bank->err.c_str() : "null handle"; }
 int hso_vo_multi_size(const hso_vo_multi* m) { return m ? m->bank->size() : HSO_E_INVALID; }
 int hso_vo_multi_trace(hso_vo_multi* m, int sequence, const char* path) { return (m && m->bank->trace(sequence, path)) ? HSO_OK : HSO_E_INVALID; }
+int hso_vo_multi_trace_state(hso_vo_multi* m, int sequence, int on) { return (m && m->bank->trace_state(sequence, on != 0)) ? HSO_OK : HSO_E_INVALID; }
 int hso_vo_multi_set_first_frames(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps,
                                   const float* const* depth_z, const hso_se3* T_f_w)
 {

@@ -257,6 +257,39 @@ void Bank::initialise(const std::vector<int>& who)
 // feature table the device built, "reproject_match" in the value-passing call's layout (the device's own point list, the
 // observation lists flattened), "reproject_select" (the examined candidates) and "pose_optimize" (the feature table the device
 // built from them).
+// hso_vo_trace_state: the sequence map exactly as the device holds it right before a chain call, with the job and the call's
+// configuration (tests/test_seq_chain.py rebuilds the state in a fresh context and in the restatement and compares the two calls)
+void Bank::trace_chain_state(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const std::vector<int32_t>& temps)
+{
+  for (size_t i = 0; i < who.size(); i++) {
+    Seq& s = *seq_[who[i]];
+    if (!s.trace.on() || !s.trace.state) continue;
+    int64_t sz[HSO_DUMP_N_SIZES];
+    check(hso_gpu_seqmap_debug_dump(ctx_, s.map, HSO_DUMP_SIZES, sz, sizeof(sz)), "trace");
+    const size_t nk = (size_t)sz[0], np = (size_t)sz[1], no = (size_t)sz[2], cap = (size_t)sz[3], nc = (size_t)sz[4];
+    std::vector<hso_kf> kfs(nk); std::vector<hso_map_point> pts(np); std::vector<hso_obs> obs(no);
+    std::vector<int32_t> obs_pt(no), keys(5 * nk), nfts(nk), lists(nk * cap), cands(nc);
+    std::vector<hso_seq_feature> ff0((size_t)sz[5]), ff1((size_t)sz[6]);
+    auto get = [&](int what, void* out, size_t bytes) { if (bytes) check(hso_gpu_seqmap_debug_dump(ctx_, s.map, what, out, bytes), "trace"); };
+    get(HSO_DUMP_KFS, kfs.data(), sizeof(hso_kf) * nk); get(HSO_DUMP_POINTS, pts.data(), sizeof(hso_map_point) * np); get(HSO_DUMP_OBS, obs.data(), sizeof(hso_obs) * no);
+    get(HSO_DUMP_OBS_POINT, obs_pt.data(), 4 * no); get(HSO_DUMP_KEY_POINTS, keys.data(), 4 * keys.size()); get(HSO_DUMP_KF_NFTS, nfts.data(), 4 * nk);
+    get(HSO_DUMP_KF_FTS, lists.data(), 4 * lists.size()); get(HSO_DUMP_CANDS, cands.data(), 4 * nc);
+    get(HSO_DUMP_FRAME_FEATS0, ff0.data(), sizeof(hso_seq_feature) * ff0.size()); get(HSO_DUMP_FRAME_FEATS1, ff1.data(), sizeof(hso_seq_feature) * ff1.size());
+    const hso_seq_job& jb = jobs[i];
+    const int32_t none = 0;
+    Trace& t = s.trace;
+    t.begin("seq_chain_state", 17);
+    t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("job", &jb, sizeof(jb)); t.field("cfg", &cfg, sizeof(cfg));
+    t.field("cell_order", cell_order_.data(), sizeof(int32_t) * cell_order_.size());
+    t.field("temps", jb.n_temps > 0 ? temps.data() + jb.temps_begin : &none, sizeof(int32_t) * (size_t)jb.n_temps);
+    t.field("sizes", sz, sizeof(sz)); t.field("kfs", kfs.data(), sizeof(hso_kf) * nk); t.field("points", pts.data(), sizeof(hso_map_point) * np);
+    t.field("obs", obs.data(), sizeof(hso_obs) * no); t.field("obs_point", obs_pt.data(), 4 * no); t.field("key_points", keys.data(), 4 * keys.size());
+    t.field("kf_nfts", nfts.data(), 4 * nk); t.field("kf_fts", lists.data(), 4 * lists.size()); t.field("cands", cands.data(), 4 * nc);
+    t.field("frame_feats0", ff0.data(), sizeof(hso_seq_feature) * ff0.size()); t.field("frame_feats1", ff1.data(), sizeof(hso_seq_feature) * ff1.size());
+    t.scalar("max_fts", cfg_.max_fts);
+  }
+}
+
 void Bank::trace_chain(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const hso_seq_result* res)
 {
   const int n = (int)who.size(), cap = std::max(cfg_.max_fts, 1);
@@ -283,6 +316,15 @@ void Bank::trace_chain(const std::vector<int>& who, const std::vector<hso_seq_jo
     const hso_seq_job& jb = jobs[(size_t)i];
     const hso_seq_result& r = res[i];
     Trace& t = s.trace;
+    if (s.trace.state) {
+      std::vector<int32_t> ev((size_t)std::max(r.n_events, 1));
+      if (r.n_events > 0) check(hso_gpu_seq_events(ctx_, i, ev.data(), (int)ev.size()), "trace");
+      std::vector<hso_seq_feature> ff((size_t)std::max(cap, 1));
+      int32_t n_ff = 0;
+      check(hso_gpu_seq_frame_features(ctx_, &s.map, &jb.cur_frame_id, 1, ff.data(), (int)ff.size(), &n_ff), "trace");
+      t.begin("seq_chain_result", 3);
+      t.field("result", &r, sizeof(r)); t.field("events", ev.data(), sizeof(int32_t) * (size_t)r.n_events); t.field("features", ff.data(), sizeof(hso_seq_feature) * (size_t)n_ff);
+    }
     // ---- CoarseTracker::run over the table the device built
     if (!(jb.flags & HSO_SEQ_NO_TRACK)) {
       std::vector<hso_ref_feat> rec((size_t)std::max(jb.n_ref_feats, 1));

@@ -409,6 +409,7 @@ void Bank::chain(const std::vector<int>& who)
     cfg.track = hso_track_params{mode, cfg_.klt_max_level, cfg_.klt_min_level + 1, 50};
     cfg.seed_brief_out = brief_images ? brief_images + (size_t)mode * (size_t)n_slots : nullptr;
     hso_seq_result* res = chain_res_.need(ctx_, grp.size());
+    if (any_trace) trace_chain_state(grp, jobs, cfg, temps);
     { Sub t(this, "chain: device call"); check(hso_gpu_seq_chain(ctx_, &cam_.pod(), &cfg, jobs.data(), (int)jobs.size(), temps.empty() ? nullptr : temps.data(), (int)temps.size(), res), "processFrame"); }
     n_calls_[2]++; n_items_[2] += (int64_t)grp.size();
     n_calls_[3]++; n_items_[3] += (int64_t)grp.size();

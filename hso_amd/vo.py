@@ -35,6 +35,8 @@ def _declare(lib):
     lib.hso_vo_last_error.argtypes = [vp]
     lib.hso_vo_last_error.restype = C.c_char_p
     lib.hso_vo_trace.argtypes = [vp, C.c_char_p]
+    lib.hso_vo_trace_state.argtypes = [vp, i32]
+    lib.hso_vo_multi_trace_state.argtypes = [vp, i32, i32]
     lib.hso_vo_set_first_frame.argtypes = [vp, vp, i32, i32, C.c_double, vp, P(capi.SE3)]
     lib.hso_vo_add_image.argtypes = [vp, vp, i32, i32, C.c_double]
     lib.hso_vo_start.argtypes = [vp]
@@ -85,7 +87,7 @@ EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso
                     "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes", "hso_vo_start", "hso_vo_init_compute_matrix",
                     "hso_vo_multi_create", "hso_vo_multi_destroy", "hso_vo_multi_last_error", "hso_vo_multi_size",
                     "hso_vo_multi_set_first_frames", "hso_vo_multi_add_images", "hso_vo_multi_get_status", "hso_vo_multi_get_keyframes",
-                    "hso_vo_multi_call_counts", "hso_vo_host_share", "hso_vo_multi_alg_bytes", "hso_vo_multi_threads", "hso_vo_host_cpu_quota", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device", "hso_vo_multi_get_trajectory", "hso_vo_get_trajectory"]
+                    "hso_vo_multi_call_counts", "hso_vo_host_share", "hso_vo_multi_alg_bytes", "hso_vo_multi_threads", "hso_vo_host_cpu_quota", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device", "hso_vo_multi_get_trajectory", "hso_vo_get_trajectory", "hso_vo_trace_state", "hso_vo_multi_trace_state"]
 
 CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_select_pose", "align", "pose", "seed_observe", "seed_activate", "ba", "other"]
 
@@ -140,6 +142,12 @@ class MultiVisualOdometry:
         ts = np.ascontiguousarray(timestamps, np.float64)
         shape = next(i.shape for i in imgs if i is not None)
         self._check(self.lib.hso_vo_multi_add_images(self.h, self._ptrs(imgs), shape[1], shape[0], ts.ctypes.data), "add_images")
+
+    def add_images_host_ptrs(self, ptrs, width, height, timestamps):
+        """ptrs: one HOST pointer (int) per sequence (e.g. page-locked buffers a camera driver fills), 0 / None = sits out"""
+        arr = (C.c_void_p * len(ptrs))(*[p if p else None for p in ptrs])
+        ts = np.ascontiguousarray(timestamps, np.float64)
+        self._check(self.lib.hso_vo_multi_add_images(self.h, arr, width, height, ts.ctypes.data), "add_images")
 
     def add_images_device(self, ptrs, width, height, timestamps):
         """ptrs: one device pointer (int) per sequence, 0 / None = the sequence sits this step out."""
@@ -203,7 +211,9 @@ class VisualOdometry:
         if rc < 0:
             raise capi.HsoGpuError("%s failed (%d): %s" % (what, rc, (self.lib.hso_vo_last_error(self.h) or b"?").decode()))
 
-    def trace(self, path):
+    def trace(self, path, state=False):
+        """record the device calls to `path` (None stops); state=True: every chain call with the sequence map it ran on (hso_vo_trace_state)"""
+        self._check(self.lib.hso_vo_trace_state(self.h, 1 if state else 0), "trace_state")
         self._check(self.lib.hso_vo_trace(self.h, path.encode() if path else None), "trace")
 
     def set_first_frame(self, img, depth_z, timestamp=0.0, T_f_w=None):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HSO_GPU_ABI_VERSION 1
+#define HSO_GPU_ABI_VERSION 2
 #define HSO_N_PYR_LEVELS 5   /* max(n_pyr_levels=3, klt_max_level+1=5), src/frame.cpp:92 */
 #define HSO_N_SOBEL_LEVELS 3 /* Config::nPyrLevels(), src/frame.cpp:214 */
 
@@ -834,6 +834,7 @@ int hso_gpu_seqmap_patch_links(hso_gpu_ctx* ctx, int map, const int32_t* obs_ids
 int hso_gpu_seqmap_set_key_points(hso_gpu_ctx* ctx, int map, const int32_t* key_points /* 5 * n_kfs */, int n_kfs);
 
 #define HSO_SEQ_MAX_VISIT 24
+#define HSO_SEQ_MAX_KFS 2048      /* rows of a sequence map's keyframe table the chain accepts (the reference keeps Config::maxNKfs() = 2000) */
 #define HSO_SEQ_MAX_COVIS 8
 #define HSO_SEQ_EVENTS 120
 enum { HSO_EV_ERASE_POINT = 1,       /* Map::safeDeletePoint (a TYPE_UNKNOWN point failed more than 15 times, reprojector.cpp:376-381) */
@@ -930,28 +931,8 @@ typedef struct hso_seq_feature {
 int hso_gpu_seq_frame_features(hso_gpu_ctx* ctx, const int32_t* maps, const int64_t* frame_ids, int n_maps, hso_seq_feature* out, int cap, int32_t* n_out);
 /* replace the table a map holds (the caller changed the frame's features: the seed branch of reprojectMap, a two-view start) */
 int hso_gpu_seq_set_frame_features(hso_gpu_ctx* ctx, int map, int64_t frame_id, const hso_seq_feature* feats, int n);
-/* recorded runs / parity: the list of job `job` of the last chain call (point rows and quality keys, n_listed of them), and its
- * reference feature table in hso_ref_feat records */
-int hso_gpu_seq_debug_list(hso_gpu_ctx* ctx, int job, int32_t* ids_out, uint8_t* quality_out, int cap);
-int hso_gpu_seq_debug_ref_table(hso_gpu_ctx* ctx, int job, hso_ref_feat* out, int cap);
-
-/* trace / parity hook: tables the last hso_gpu_seq_chain call (cfg.want_debug = 1) left in the work area (valid until the next
- * entry point that uses it).  The listed points of the jobs lie in slices of the call: job j's at HSO_DBG_SLICES[j] (n_jobs + 1
- * int32; a slice is as long as the job's list can get, its first n_listed entries are used).  HSO_DBG_PROJ = hso_reproj_point per
- * slice entry, HSO_DBG_MATCH = hso_align_out per slice entry, HSO_DBG_BRIEF = hso_match_brief per EXAMINED candidate (job j's at
- * HSO_DBG_EXAMINED_BEGIN[j], n_jobs + 1 int32; pad_ = the candidate's position in its list), HSO_DBG_PROJECTED = one byte per slice
- * entry (reprojectPoint's return value), HSO_DBG_POSE_FEATS = n_jobs rows of max(max_fts, 1) hso_pose_feat (host_pose = index into
- * HSO_DBG_POSE_POSES' row), HSO_DBG_POSE_POSES = n_jobs rows of 128 hso_se3, HSO_DBG_POSE_NPOSES = n_jobs int32, HSO_DBG_POSE_MASK =
- * n_jobs rows of max(max_fts, 1) bytes.  bytes must equal the table's size. */
-enum { HSO_DBG_PROJ = 0, HSO_DBG_MATCH = 1, HSO_DBG_POSE_FEATS = 2, HSO_DBG_POSE_POSES = 3, HSO_DBG_POSE_NPOSES = 4, HSO_DBG_SLICES = 5,
-       HSO_DBG_BRIEF = 6, HSO_DBG_EXAMINED_BEGIN = 7, HSO_DBG_PROJECTED = 8, HSO_DBG_POSE_MASK = 9, HSO_DBG_N = 10 };
-int hso_gpu_debug_fetch(hso_gpu_ctx* ctx, int what, void* out, size_t bytes);
-/* developer census: what the library has asked of the HIP runtime since the process started (all contexts): copies enqueued, their
- * bytes, copies that went through page-locked staging because the caller's memory was pageable, stream synchronisations, nanoseconds
- * the calling threads spent blocked in them, memsets.  out[i] for i < n; entries beyond HSO_CENSUS_N read 0.  A driver that
- * differences it around its phases sees where the host round trips of a step are (hso_amd/host: HSO_ENGINE_TIMING=1). */
-enum { HSO_CENSUS_COPIES = 0, HSO_CENSUS_COPY_BYTES = 1, HSO_CENSUS_STAGED = 2, HSO_CENSUS_SYNCS = 3, HSO_CENSUS_SYNC_NS = 4, HSO_CENSUS_MEMSETS = 5, HSO_CENSUS_H2D_BYTES = 6 /* the host-to-device part of COPY_BYTES */, HSO_CENSUS_N = 7 };
-void hso_gpu_debug_census(int64_t* out, int n);
+/* recorded runs / parity read-backs of the chain (hso_gpu_seq_debug_*, hso_gpu_debug_fetch, hso_gpu_seqmap_debug_dump) and the developer
+ * census: include/hso_gpu_debug.h */
 
 /* ---- FeatureExtractor::fastDetect, src/feature_detection.cpp:518-587 (fastDetectST per level, fastDetect) (SURVEY.md section 8f rank 1,
  *      first stage): FAST-9 corners of pyramid levels 0..n_levels-1 — fast_corner_detect_9_sse2,
@@ -1065,10 +1046,6 @@ typedef struct hso_klt_result {
 int hso_gpu_klt_track(hso_gpu_ctx* ctx, int64_t frame_prev, int64_t frame_cur, const float* px_prev, const float* px_init, int n,
                       const hso_klt_params* params, hso_klt_result* out);
 int hso_gpu_klt_levels(int width, int height, int win, int max_level);   /* index of the coarsest level the call above uses */
-/* test hook: Gaussian pyramid level `level` of a resident frame (cv::pyrDown chain) and its Scharr derivative image
- * (interleaved Ix, Iy); either output may be NULL */
-int hso_gpu_klt_debug_level(hso_gpu_ctx* ctx, int64_t frame, int level, uint8_t* img_out, int16_t* deriv_out);
-
 /* static tables of include/hso/CoarseTracker.h:58-120 for a level */
 int hso_gpu_tracker_pattern(int max_level, int level, int* patch_area,
                             int* half_patch, int8_t* offsets_xy /* 2*40 */);

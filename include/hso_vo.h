@@ -31,6 +31,12 @@ void hso_vo_destroy(hso_vo* vo);
 const char* hso_vo_last_error(const hso_vo* vo);
 /* record every device call of the driver (inputs and outputs in the C-ABI's table layouts) to `path`; NULL stops */
 int hso_vo_trace(hso_vo* vo, const char* path);
+/* on != 0: while recording, every per-frame chain call (hso_gpu_seq_chain) is preceded by a "seq_chain_state" record — the job, the
+ * call's configuration and the sequence map exactly as the device holds it at that moment (hso_gpu_seqmap_debug_dump,
+ * include/hso_gpu_debug.h) — and followed by a "seq_chain_result" record (the raw result, every event, the frame's feature table).
+ * With it a test hands ONE map state to the device call and to its CPU restatement (tests/test_seq_chain.py).  A few MB per frame
+ * at 2000 features: meant for a handful of frames, not for whole runs. */
+int hso_vo_trace_state(hso_vo* vo, int on);
 /* first keyframe: features are detected the way the initialisation detects them and every feature with
  * depth_z[y * width + x] > 0 (depth along the optical axis, metres) becomes a map point hosted in this frame */
 int hso_vo_set_first_frame(hso_vo* vo, const uint8_t* img, int width, int height, double timestamp, const float* depth_z,
@@ -89,6 +95,7 @@ int hso_vo_multi_add_images(hso_vo_multi* m, const uint8_t* const* imgs, int wid
 int hso_vo_multi_add_images_device(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps);
 /* hso_vo_trace for one sequence of the bank */
 int hso_vo_multi_trace(hso_vo_multi* m, int sequence, const char* path);
+int hso_vo_multi_trace_state(hso_vo_multi* m, int sequence, int on);
 int hso_vo_multi_get_status(hso_vo_multi* m, int sequence, hso_vo_status* st);
 int hso_vo_multi_get_keyframes(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
 int hso_vo_multi_get_trajectory(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int cap);

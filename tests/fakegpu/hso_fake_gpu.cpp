@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 #include "../../oracle/hso_oracle.h"
+#include "../../include/hso_gpu_debug.h"
 
 struct FakeFrame {
   int w = 0, h = 0;
@@ -653,6 +654,38 @@ int hso_gpu_seq_debug_ref_table(hso_gpu_ctx* c, int job, hso_ref_feat* out, int 
   if (job < 0 || (size_t)job >= c->last_table.size() || (int)c->last_table[(size_t)job].size() > cap) return fail(c, HSO_E_INVALID, "seq_debug_ref_table: bad argument");
   std::copy(c->last_table[(size_t)job].begin(), c->last_table[(size_t)job].end(), out);
   return (int)c->last_table[(size_t)job].size();
+}
+
+int hso_gpu_seqmap_debug_dump(hso_gpu_ctx* c, int m, int what, void* out, size_t bytes)
+{
+  if (m < 0 || (size_t)m >= c->maps.size() || !c->maps[m] || !out) return fail(c, HSO_E_INVALID, "seqmap_debug_dump: bad argument");
+  FakeMap* M = c->maps[m];
+  const size_t nk = M->kfs.size();
+  const int64_t sizes[HSO_DUMP_N_SIZES] = {(int64_t)nk, (int64_t)M->pts.size(), (int64_t)M->obs.size(), M->fts_cap, (int64_t)M->cands.size(), (int64_t)M->ff[0].size(), (int64_t)M->ff[1].size(),
+                                           M->ff_frame[0], M->ff_frame[1], M->ff_newest, (int64_t)sizeof(hso_kf), (int64_t)sizeof(hso_map_point), (int64_t)sizeof(hso_obs),
+                                           (int64_t)sizeof(hso_seq_feature), (int64_t)sizeof(hso_seq_job), (int64_t)sizeof(hso_seq_result)};
+  std::vector<int32_t> ints;
+  const void* src = nullptr; size_t have = 0;
+  switch (what) {
+    case HSO_DUMP_SIZES: src = sizes; have = sizeof(sizes); break;
+    case HSO_DUMP_KFS: src = M->kfs.data(); have = sizeof(hso_kf) * nk; break;
+    case HSO_DUMP_POINTS: src = M->pts.data(); have = sizeof(hso_map_point) * M->pts.size(); break;
+    case HSO_DUMP_OBS: src = M->obs.data(); have = sizeof(hso_obs) * M->obs.size(); break;
+    case HSO_DUMP_OBS_POINT: src = M->obs_pt.data(); have = sizeof(int32_t) * M->obs_pt.size(); break;
+    case HSO_DUMP_KEY_POINTS: ints = M->keys; ints.resize(5 * nk, -1); src = ints.data(); have = sizeof(int32_t) * ints.size(); break;
+    case HSO_DUMP_KF_NFTS: for (size_t k = 0; k < nk; k++) ints.push_back(k < M->kf_fts.size() ? (int32_t)M->kf_fts[k].size() : 0); src = ints.data(); have = sizeof(int32_t) * ints.size(); break;
+    case HSO_DUMP_KF_FTS:
+      ints.assign(nk * (size_t)M->fts_cap, 0);
+      for (size_t k = 0; k < nk && k < M->kf_fts.size(); k++) std::copy(M->kf_fts[k].begin(), M->kf_fts[k].end(), ints.begin() + (std::ptrdiff_t)(k * (size_t)M->fts_cap));
+      src = ints.data(); have = sizeof(int32_t) * ints.size(); break;
+    case HSO_DUMP_CANDS: src = M->cands.data(); have = sizeof(int32_t) * M->cands.size(); break;
+    case HSO_DUMP_FRAME_FEATS0: src = M->ff[0].data(); have = sizeof(hso_seq_feature) * M->ff[0].size(); break;
+    case HSO_DUMP_FRAME_FEATS1: src = M->ff[1].data(); have = sizeof(hso_seq_feature) * M->ff[1].size(); break;
+    default: return fail(c, HSO_E_INVALID, "seqmap_debug_dump: no such table");
+  }
+  if (have != bytes) return fail(c, HSO_E_INVALID, "seqmap_debug_dump: bytes differs from the table's size");
+  if (bytes) memcpy(out, src, bytes);
+  return HSO_OK;
 }
 
 void hso_gpu_debug_census(int64_t* out, int n) { for (int i = 0; i < n; i++) out[i] = 0; }   // no runtime underneath

@@ -19,8 +19,8 @@ def lib():
     return capi.load()
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "hso_gpu.h")).read()
+def declared_symbols(header="hso_gpu.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(hso_gpu_\w+)\s*\(", src)))
 
@@ -31,10 +31,16 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), "libhso_gpu.so does not export %s" % n
     assert sorted(capi.EXPORTED_SYMBOLS) == names, "capi.EXPORTED_SYMBOLS out of sync with the header"
+    # the parity / trace read-backs live in their own header: none of them is declared by the boundary's
+    dbg = declared_symbols("hso_gpu_debug.h")
+    for n in dbg:
+        assert hasattr(lib, n), "libhso_gpu.so does not export %s" % n
+    assert sorted(capi.DEBUG_SYMBOLS) == dbg and not set(dbg) & set(names)
+    assert not [n for n in names if "debug" in n]
 
 
 def test_abi_version_and_struct_layout(lib):
-    assert lib.hso_gpu_abi_version() == 1
+    assert lib.hso_gpu_abi_version() == capi.ABI_VERSION == 2
     # POD layouts the header promises (checked against the C compiler's view by the sizes the
     # library itself was built with: a mismatch shows up as corrupted results in the GPU tests)
     assert C.sizeof(capi.Camera) == 16 + 4 * 8 + 5 * 8

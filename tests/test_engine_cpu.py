@@ -94,3 +94,43 @@ def test_worker_pool_hands_out_every_item_once(tmp_path):
     for threads in (3, 12):
         out = subprocess.run([exe, str(threads), "60000"], capture_output=True, text=True, timeout=240)
         assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-400:]
+
+
+def test_chain_state_record_reproduces_the_call(fake, small_seq, tmp_path):
+    """hso_vo_trace_state (include/hso_vo.h): the recorded sequence map + job, rebuilt in a fresh context through the public
+    hso_gpu_seqmap_* calls, gives the recorded result of hso_gpu_seq_chain bit for bit — i.e. the record holds everything the call
+    reads.  Here on the restatement (the `-m gpu` half, tests/test_seq_chain.py, hands the same kind of record to the device)."""
+    import chain_state as cs
+    S = small_seq
+    odo = vo.VisualOdometry(synth.camera(S["spec"]), 120, lib=fake)
+    odo.set_first_frame(S["images"][0], S["depth0"], 0.0)
+    recs = []
+    for k in range(1, 30):
+        path = str(tmp_path / ("t%d.bin" % k))
+        if k in (12, 29):
+            odo.trace(path, state=True)
+        odo.add_image(S["images"][k], float(k))
+        if k in (12, 29):
+            odo.trace(None)
+            recs.append(vo.read_trace(path))
+    n_kf = len(odo.keyframes())
+    odo.close()
+    assert n_kf >= 3
+    lib = cs.ChainLib(fake)
+    images = {k: S["images"][k] for k in range(30)}                 # one sequence: frame id = image index (hso_engine_impl.h: Seq::new_frame)
+    for rec in recs:
+        names = [n for n, _ in rec]
+        assert names.count("seq_chain_state") == 1 and names.count("seq_chain_result") == 1
+        st = cs.state_from_record(dict(rec)["seq_chain_state"])
+        want = cs.result_from_record(dict(rec)["seq_chain_result"])
+        assert len(st["kfs"]) >= 2 and len(st["points"]) > 100
+        ls = cs.LoadedState(lib, st, images)
+        back = ls.dump()                                            # what went in comes out: every table of the rebuilt map
+        for key in ("kfs", "points", "obs", "obs_point", "key_points", "kf_nfts", "cands"):
+            assert back[key].tobytes() == st[key].tobytes(), key
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(back["kf_fts"], st["kf_fts"]))
+        got = ls.run()
+        assert not cs.fields_differ(got["result"], want["result"])
+        assert np.array_equal(got["events"], want["events"]) and got["features"].tobytes() == want["features"].tobytes()
+        ls.close()
+    assert len(st["kfs"]) >= 3 and len(st["cands"]) > 0 and want["result"]["n_events"] >= 0
