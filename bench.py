@@ -355,6 +355,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=400, help="frames in the cpu_baseline sample (about 7 s on one host core)")
     ap.add_argument("--seq-frames", type=int, default=121, help="frames per sequence of the end-to-end runs through libhso_host.so (0 = skip): 120 steps = 8 "
                     "keyframes per sequence, i.e. full local-BA windows (7 core keyframes) and three live seed batches in the second half — the steady state")
+    ap.add_argument("--seq-warmup-frames", type=int, default=31, help="frames of the untimed warm-up pass of the end-to-end engines (0 = none): 30 steps = two "
+                    "keyframes per sequence, so every kernel of the keyframe path has run once")
     ap.add_argument("--sequences", type=int, default=128, help="sequences per engine (bank) of the end-to-end run (hso_vo_multi_*; 0 = skip)")
     ap.add_argument("--banks", type=int, default=6, help="engines per GPU, each on its own host thread and stream")
     ap.add_argument("--seq-feats", type=int, default=2000, help="Config::maxFts() of the end-to-end run")
@@ -687,6 +689,16 @@ def main():
         side.release_cached()
         if world > 1:
             dist.barrier()
+        # an untimed pass of the same engines over the first frames (like --warmup of the headline): on a fresh box the first engines of
+        # a process page the libraries' code in and load every kernel of the keyframe path for the first time — the first of four
+        # identical runs in one process measured 18.5 k frames/s steady, the next three 22-25 k (tools/r6_repeat_banks.py, profiles/r6_*)
+        t_w0 = time.perf_counter()
+        if args.seq_warmup_frames > 1:
+            bank_bench.run_banks(args.banks, args.sequences, min(args.seq_warmup_frames, args.seq_frames), args.seq_feats, spec=spec, device=local_rank,
+                                 seqs=seq_list, lib_path=side.engine_lib, to_device=side.to_device)
+        t_seq_warm = time.perf_counter() - t_w0
+        if world > 1:
+            dist.barrier()
         mres, traj = bank_bench.run_banks(args.banks, args.sequences, args.seq_frames, args.seq_feats, spec=spec, device=local_rank, seqs=seq_list,
                                           want_traj=True, lib_path=side.engine_lib, to_device=side.to_device)
         mres_h = None
@@ -742,6 +754,7 @@ def main():
             out["sequences_with_h2d_whole_run_frames_per_s"] = float(th[1].item())
             out["sequences_h2d_pcie_gb_per_s_per_gpu"] = float(th[0].item()) / world * spec["width"] * spec["height"] / 1e9
             detail_extra["sequences_with_h2d"] = mres_h
+        out["sequences_warmup_pass_s"] = t_seq_warm
         out["sequences_failures"] = mres["failures"]
         out["sequences_roofline_frac"] = mres.get("roofline_frac_hbm")      # sum of SURVEY 8(d) algorithmic bytes of the chain's kernels / wall / 8 TB/s
         out["sequences_gpu_busy_frac"] = mres.get("steady_gpu_busy_frac")   # amdgpu gpu_busy_percent sampled every 20 ms over the steady window

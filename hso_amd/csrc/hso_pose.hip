@@ -39,10 +39,11 @@ struct PoseShared {
   double chi2, new_chi2, mu, nu, rho;
   float scale_pt, scale_ls;
   int n_pt, n_ls, n_obs, stop, accept, n_trials, iters, n_trials_total, n_deleted;
+  int iter_cur, done, nan_step;               // the LM loop's control words (written by the first wavefront between two barriers)
   int cnt[POSE_WAVES];
-  unsigned hist[256];                       // radix select: digit histogram
-  unsigned sel_bin, sel_rank;
-  unsigned long long keys64[POSE_MAX_FEATS];   // also the 32-bit keys of the MAD scales (never live together)
+  unsigned hist[3][256];                    // radix select: digit histograms (three order statistics at a time)
+  unsigned sel_bin[3], sel_rank[3], sel_cnt[3];
+  unsigned long long found;
 };
 
 HSO_DEV double p_readlane_d(double v, int src)
@@ -84,42 +85,91 @@ HSO_DEV int pose_block_count(PoseShared& s, int v)
   return t;
 }
 
-// k-th smallest (0-based) of n keys held in LDS — exactly the element nth_element would leave at position k
-// (math_utils.h:119-126, robust_cost.cpp:70-71) — by an MSB-first radix select, 8 bits per pass: histogram of the digit over
-// the keys that match the prefix found so far (LDS atomics), the bin that holds the rank located by the first 256 threads.
-// Empty slots hold all-ones keys (larger than any valid key; k is always below the number of valid keys).
-template <typename KeyT, int BITS>
-HSO_DEV KeyT pose_select(PoseShared& s, const KeyT* keys, int n, int k)
+// The bin of a 256-bin histogram that holds rank `rank` (0-based), found by the four wavefronts [4 * half, 4 * half + 4): inclusive scan
+// inside each wavefront, then across the four.  Writes s.sel_bin / sel_rank / sel_cnt [which].  All 512 threads call it (the
+// barrier inside is the workgroup's); `half` selects which four wavefronts work on this histogram.
+HSO_DEV void pose_pick_bin(PoseShared& s, int which, int half, unsigned rank)
 {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  KeyT prefix = 0;
-  unsigned rank = (unsigned)k;
-  for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+  const bool mine = (wave >> 2) == half;
+  const int bin = tid & 255, w4 = wave & 3;
+  unsigned c = 0, incl = 0;
+  if (mine) {
+    c = s.hist[which][bin];
+    incl = c;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) s.cnt[wave] = (int)incl;
+  }
+  __syncthreads();
+  if (mine) {
+    for (int w = 0; w < w4; w++) incl += (unsigned)s.cnt[(half << 2) + w];
+    if (rank >= incl - c && rank < incl) { s.sel_bin[which] = (unsigned)bin; s.sel_rank[which] = rank - (incl - c); s.sel_cnt[which] = c; }
+  }
+}
+
+// Three order statistics in one sweep of radix passes over keys the threads hold in REGISTERS: the element of rank r0 among all
+// valid k0 keys (the initial median, :441-455), of rank r1 among the k1 keys of corner features and of rank r2 among the k1 keys
+// of edgelet features (the two MAD scales, :459-483).  Exact (the values nth_element would leave at those positions); a select
+// whose count is 0 returns garbage that the caller ignores.  Before: three selects one after the other, each over keys written
+// to LDS first (12 radix passes, ~60 barriers); now 4 passes.
+template <int FPT>
+HSO_DEV void pose_select3(PoseShared& s, const unsigned (&k0)[FPT], const unsigned (&k1)[FPT], const int (&kind)[FPT], unsigned r0, unsigned r1, unsigned r2,
+                          unsigned (&out)[3])
+{
+  const int tid = threadIdx.x;
+  unsigned prefix[3] = {0, 0, 0}, rank[3] = {r0, r1, r2};
+  for (int shift = 24; shift >= 0; shift -= 8) {
     __syncthreads();
-    if (tid < 256) s.hist[tid] = 0;
+    for (int i = tid; i < 768; i += POSE_THREADS) (&s.hist[0][0])[i] = 0;
     __syncthreads();
-    const KeyT hi_mask = (shift + 8 >= BITS) ? (KeyT)0 : (KeyT)(~(KeyT)0 << (shift + 8));
-    for (int i = tid; i < n; i += POSE_THREADS) {
-      const KeyT key = keys[i];
-      if ((key & hi_mask) == prefix) atomicAdd(&s.hist[(unsigned)(key >> shift) & 255u], 1u);
+    const unsigned hi_mask = shift == 24 ? 0u : (~0u << (shift + 8));
+#pragma unroll
+    for (int q = 0; q < FPT; q++) {
+      if (!(kind[q] & 3)) continue;
+      if ((k0[q] & hi_mask) == prefix[0]) atomicAdd(&s.hist[0][(k0[q] >> shift) & 255u], 1u);
+      const int w = (kind[q] & 3) == 2 ? 2 : 1;
+      if ((k1[q] & hi_mask) == prefix[w]) atomicAdd(&s.hist[w][(k1[q] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    // inclusive scan of the 256 bins: within each of the first four wavefronts, then across them
-    unsigned c = 0, incl = 0;
-    if (tid < 256) {
-      c = s.hist[tid];
-      incl = c;
-      for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-      if (lane == 63) s.cnt[wave] = (int)incl;
-    }
+    pose_pick_bin(s, 0, 0, rank[0]);       // wavefronts 0..3
+    pose_pick_bin(s, 1, 1, rank[1]);       // wavefronts 4..7, beside the first (the barrier inside each is shared by all)
+    pose_pick_bin(s, 2, 0, rank[2]);
     __syncthreads();
-    if (tid < 256) {
-      for (int w = 0; w < wave; w++) incl += (unsigned)s.cnt[w];
-      if (rank >= incl - c && rank < incl) { s.sel_bin = (unsigned)tid; s.sel_rank = rank - (incl - c); }
-    }
+#pragma unroll
+    for (int w = 0; w < 3; w++) { prefix[w] |= s.sel_bin[w] << shift; rank[w] = s.sel_rank[w]; }
+  }
+  out[0] = prefix[0]; out[1] = prefix[1]; out[2] = prefix[2];
+}
+
+// One order statistic of 64-bit keys held in registers, MSB first, 8 bits per pass; stops as soon as the bin that holds the rank
+// holds a single key (squared errors of a frame: after three or four of the eight passes) — that key is then fetched from its owner.
+template <int FPT>
+HSO_DEV unsigned long long pose_select64(PoseShared& s, const unsigned long long (&k)[FPT], const bool (&valid)[FPT], unsigned r)
+{
+  const int tid = threadIdx.x;
+  unsigned long long prefix = 0;
+  unsigned rank = r;
+  for (int shift = 56; shift >= 0; shift -= 8) {
     __syncthreads();
-    prefix |= (KeyT)s.sel_bin << shift;
-    rank = s.sel_rank;
+    if (tid < 256) s.hist[0][tid] = 0;
+    __syncthreads();
+    const unsigned long long hi_mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+#pragma unroll
+    for (int q = 0; q < FPT; q++)
+      if (valid[q] && (k[q] & hi_mask) == prefix) atomicAdd(&s.hist[0][(unsigned)(k[q] >> shift) & 255u], 1u);
+    __syncthreads();
+    pose_pick_bin(s, 0, 0, rank);
+    __syncthreads();
+    prefix |= (unsigned long long)s.sel_bin[0] << shift;
+    rank = s.sel_rank[0];
+    if (s.sel_cnt[0] == 1 && shift > 0) {
+      // one key left under this prefix: it is the answer
+      const unsigned long long m = ~0ull << shift;
+#pragma unroll
+      for (int q = 0; q < FPT; q++) if (valid[q] && (k[q] & m) == prefix) s.found = k[q];
+      __syncthreads();
+      return s.found;
+    }
   }
   return prefix;
 }
@@ -182,13 +232,10 @@ HSO_DEV void pose_set_Tth(PoseShared& s, const Se3& T, int n_poses)
 
 // A.ldlt().solve(b) for the 6x6 system in s.A/s.b (pivoted LDL^T on eight lanes, broadcasts by
 // v_readlane_b32; same scheme as the tracker's 7x7 solve).  Result in s.dT[0..5].
-HSO_DEV void pose_ldlt6(PoseShared& s)
+// a[i]: lane j < 6 holds A(i, j), lanes >= 6 hold b(i) (lane 6 is the one that is read)
+HSO_DEV void pose_ldlt6(PoseShared& s, double (&a)[6])
 {
   const int lane = threadIdx.x & 63;
-  const int j = lane < 7 ? lane : 6;  // lanes 0..5: columns, lane 6: rhs
-  double a[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) a[i] = (j < 6) ? s.A[i * 6 + j] : s.b[i];
   int perm[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) perm[i] = i;
@@ -296,6 +343,83 @@ HSO_DEV void pose_normal_pass(const PoseShared& s, const PoseFeatReg (&pf)[FPT],
   }
 }
 
+// The serial part of an LM trial, run by the first wavefront between two barriers (see k_pose).  Out of line on purpose: inlined,
+// its temporaries (the 6x6 elimination, SE3::exp, the host table) raise the kernel's register demand at the point where every
+// thread also holds its features, and the whole kernel spills (100 VGPRs instead of ~30).
+__attribute__((noinline)) HSO_DEV void pose_lm_serial(PoseShared& s, int n_iter, int n_poses, bool first)
+{
+  const int tid = threadIdx.x;
+  struct { int n_iter, n_poses; } J{n_iter, n_poses};
+  const int lane = tid;
+  if (lane == 0 && !first) {
+    // ---- the trial just evaluated (:644-674)
+    const bool nan_step = s.nan_step != 0;
+    const double new_chi2 = nan_step ? 0.0 : s.red_n[27];
+    s.rho = nan_step ? -1.0 : (s.chi2 - new_chi2);
+    if (s.rho > 0) {
+      s.T = s.Tn;
+      s.chi2 = new_chi2;
+      for (int q = 0; q < 27; q++) s.red[q] = s.red_n[q];
+      double nm = -1;
+      for (int q = 0; q < 6; q++) { const double a = fabs(s.dT[q]); if (a > nm) nm = a; }
+      s.stop = nm <= 0.0000000001;  // hso::EPS
+      const double t = 2 * s.rho - 1;
+      s.mu *= fmax(1. / 3., fmin(1. - t * t * t, 2. / 3.));
+      s.nu = 2.;
+    } else {
+      s.mu *= s.nu;
+      s.nu *= 2.;
+      if (s.mu < 0.0001) s.mu = 0.0001;
+      ++s.n_trials;
+      if (s.n_trials >= 5) s.stop = 1;
+    }
+    if (s.rho > 0 || s.stop) {                                 // the iteration is over
+      if (s.stop || s.iter_cur + 1 >= J.n_iter) s.done = 1;
+      else { s.iter_cur++; s.rho = 0; s.n_trials = 0; s.iters = s.iter_cur + 1; }
+    }
+  }
+  // lane 0's words, read back by the whole wavefront (same wavefront: LDS operations complete in program order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool done = *(volatile int*)&s.done != 0;
+  if (!done) {
+    // ---- the next trial: A = sums, A += (A.diagonal() * mu).asDiagonal() (:594), A.ldlt().solve(b) (:595)
+    const int j = lane < 6 ? lane : 6;
+    const double mu = *(volatile double*)&s.mu;
+    double a[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      if (j < 6) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        double v = *(volatile double*)&s.red[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        if (i == j) v += v * mu;
+        a[i] = v;
+        s.A[i * 6 + j] = v;                                    // the last damped A is what the covariance inverts (:692)
+      } else a[i] = *(volatile double*)&s.red[21 + i];
+    }
+    if (lane == 6) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) s.b[i] = a[i];
+    }
+    pose_ldlt6(s, a);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double dT[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dT[i] = *(volatile double*)&s.dT[i];
+    const bool nan_step = isnan(dT[0]);
+    if (lane == 0) { s.n_trials_total++; s.nan_step = nan_step ? 1 : 0; }
+    if (!nan_step) {
+      // every lane forms the same trial pose (no broadcast needed), lane 0 keeps it; the lanes then fill the host table
+      const Se3 Tn = se3_mul(se3_exp(dT), s.T);
+      if (lane == 0) s.Tn = Tn;
+      for (int h = lane; h < J.n_poses; h += 64) s.Tth[h] = se3_mul(Tn, s.hinv[h]);
+    }
+  }
+}
+
 // One 512-thread workgroup per frame (two wavefronts per SIMD); a thread owns up to FPT features (slot i = tid + q * 512 keeps
 // the feature order) and holds what it needs of them in registers for the whole optimisation, so a pass touches no global
 // memory: the previous form re-read the 96-byte feature records from L2 in every one of the ~60 passes, one dependent load
@@ -308,7 +432,6 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
   hso_pose_result& out = results[blockIdx.x];
   const int tid = threadIdx.x, n = J.n_feats;
   const double em2 = (cam.fx * cam.fy < 0) ? fabs(cam.fx) : fabs((cam.fx + cam.fy) * 0.5);  // camera.cpp:59
-  unsigned* const keys32 = reinterpret_cast<unsigned*>(s.keys64);
 
   if (tid == 0) {
     s.T = se3_from(J.T);
@@ -327,29 +450,31 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
   __syncthreads();
   pose_set_Tth(s, s.T, J.n_poses);
 
-  // ---- pass 0: initial errors (:426-454).  Slot i keeps the feature order; empty slots hold
-  // all-ones keys (larger than any valid key) so that order statistics ignore them.  The squared errors are products of
-  // floats (`float error_pt` / `float error_ls`, :441-450, pushed into a vector<double>): non-negative fp32 bit patterns order
-  // like the doubles they convert to, so the median is a 32-bit select (4 radix passes instead of 8) and converts exactly.
+  // ---- pass 0: initial errors (:426-454) and the MAD scales' inputs (:459-483) from ONE evaluation of the residuals.  The squared
+  // errors are products of floats (`float error_pt` / `float error_ls`, :441-450, pushed into a vector<double>): non-negative fp32
+  // bit patterns order like the doubles they convert to, so the median is a 32-bit select and converts exactly; the scales'
+  // keys are the float magnitudes themselves (robust_cost.cpp:67-74).
   int c_pt = 0, c_ls = 0;
+  unsigned k0[FPT], k1[FPT];
+  int kinds[FPT];
 #pragma unroll
   for (int q = 0; q < FPT; q++) {
-    const int i = tid + q * POSE_THREADS;
-    if (i >= n) continue;
-    unsigned k32 = 0xFFFFFFFFu;
+    k0[q] = k1[q] = 0xFFFFFFFFu;
+    kinds[q] = pf[q].kind;
     if (pf[q].kind & 3) {
       const Resid r = pose_residual(s, pf[q]);
       if ((pf[q].kind & 3) == 2) {
         const float error_ls = (float)(pf[q].g0 * r.e0 + pf[q].g1 * r.e1);
-        k32 = __float_as_uint(error_ls * error_ls);
+        k0[q] = __float_as_uint(error_ls * error_ls);
+        k1[q] = __float_as_uint(fabsf(error_ls));
         c_ls++;
       } else {
         const float error_pt = (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
-        k32 = __float_as_uint(error_pt * error_pt);
+        k0[q] = __float_as_uint(error_pt * error_pt);
+        k1[q] = __float_as_uint(error_pt);
         c_pt++;
       }
     }
-    keys32[i] = k32;
   }
   const int n_pt = pose_block_count(s, c_pt), n_ls = pose_block_count(s, c_ls);
   if (n_pt == 0 && n_ls == 0) {  // :456
@@ -361,31 +486,11 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
     return;
   }
   const int n_init = n_pt + n_ls;
-  const double med_init = (double)__uint_as_float(pose_select<unsigned, 32>(s, keys32, n, n_init / 2));
-
-  // ---- MAD scales (:459-483): 1.4826f * nth_element(|error|) per residual kind
-  float scale_pt = 0, scale_ls = 0;
-  for (int kind = 0; kind < 2; kind++) {
-    const int cnt = kind == 0 ? n_pt : n_ls;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < FPT; q++) {
-      const int i = tid + q * POSE_THREADS;
-      if (i >= n) continue;
-      unsigned key = 0xFFFFFFFFu;
-      if ((pf[q].kind & 3) == (kind == 1 ? 2 : 1)) {
-        const Resid r = pose_residual(s, pf[q]);
-        const float e = (kind == 1) ? fabsf((float)(pf[q].g0 * r.e0 + pf[q].g1 * r.e1)) : (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
-        key = __float_as_uint(e);
-      }
-      keys32[i] = key;
-    }
-    __syncthreads();
-    if (cnt > 0) {
-      const float med = __uint_as_float(pose_select<unsigned, 32>(s, keys32, n, cnt / 2));
-      if (kind == 0) scale_pt = 1.4826f * med; else scale_ls = 1.4826f * med;
-    }
-  }
+  unsigned sel[3];
+  pose_select3<FPT>(s, k0, k1, kinds, (unsigned)(n_init / 2), (unsigned)(n_pt / 2), (unsigned)(n_ls / 2), sel);
+  const double med_init = (double)__uint_as_float(sel[0]);
+  // ---- MAD scales: 1.4826f * nth_element(|error|) per residual kind
+  float scale_pt = n_pt > 0 ? 1.4826f * __uint_as_float(sel[1]) : 0.f, scale_ls = n_ls > 0 ? 1.4826f * __uint_as_float(sel[2]) : 0.f;
   if (n_pt > 0 && n_ls == 0) scale_ls = (float)(0.5 * (double)scale_pt);
   if (n_pt == 0 && n_ls > 0) scale_pt = (float)(2 * scale_ls);
   __syncthreads();
@@ -401,55 +506,26 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
     if (tid == 0) s.chi2 = s.red[27];
     __syncthreads();
   }
-  for (int iter = 0; iter < J.n_iter; iter++) {
-    if (tid == 0) { s.rho = 0; s.n_trials = 0; s.iters = iter + 1; }
+  // The loop of :531-689 — per iteration up to five trials: damp, solve, step, evaluate, accept or raise the damping — as ONE loop
+  // whose serial part runs on the first wavefront between two barriers: the decision about the trial just evaluated, and, unless
+  // the optimisation is over, the next trial's damped system (lane j builds column j of A from the sums in place), its 6x6 LDL^T,
+  // SE3::exp, the trial pose and the table T * host^-1 of every host frame.  Every value is formed by the operations of the
+  // reference's statements in their order (the same bits as the one-lane form: tid 0 build / wave solve / tid 0 step / table, each
+  // behind a barrier of its own: 8 barriers per trial, now 3).
+  if (tid < 64) {
+    if (tid == 0) { s.iter_cur = 0; s.done = J.n_iter <= 0; s.rho = 0; s.n_trials = 0; if (J.n_iter > 0) s.iters = 1; s.nan_step = 0; }
+  }
+  bool first = true;
+  for (;;) {
+    if (tid < 64) pose_lm_serial(s, J.n_iter, J.n_poses, first);
+    first = false;
     __syncthreads();
-    for (;;) {
-      if (tid == 0) {
-        int idx = 0;
-        for (int a = 0; a < 6; a++)
-          for (int c = a; c < 6; c++) { s.A[a * 6 + c] = s.A[c * 6 + a] = s.red[idx]; idx++; }
-        for (int a = 0; a < 6; a++) s.b[a] = s.red[21 + a];
-        for (int a = 0; a < 6; a++) s.A[a * 6 + a] += s.A[a * 6 + a] * s.mu;  // A += (A.diagonal()*mu).asDiagonal()
-        s.n_trials_total++;
-      }
-      __syncthreads();
-      if (tid < 64) pose_ldlt6(s);
-      __syncthreads();
-      const bool nan_step = isnan(s.dT[0]);
-      if (!nan_step) {
-        if (tid == 0) s.Tn = se3_mul(se3_exp(s.dT), s.T);
-        __syncthreads();
-        pose_set_Tth(s, s.Tn, J.n_poses);
-        double acc[32], c;
-        pose_normal_pass<FPT, true>(s, pf, acc, c);
-        pose_block_sum27_1(s, acc, c, s.red_n);
-      }
-      if (tid == 0) {
-        const double new_chi2 = nan_step ? 0.0 : s.red_n[27];
-        s.rho = nan_step ? -1.0 : (s.chi2 - new_chi2);
-        if (s.rho > 0) {
-          s.T = s.Tn;
-          s.chi2 = new_chi2;
-          for (int q = 0; q < 27; q++) s.red[q] = s.red_n[q];
-          double nm = -1;
-          for (int q = 0; q < 6; q++) { const double a = fabs(s.dT[q]); if (a > nm) nm = a; }
-          s.stop = nm <= 0.0000000001;  // hso::EPS
-          const double t = 2 * s.rho - 1;
-          s.mu *= fmax(1. / 3., fmin(1. - t * t * t, 2. / 3.));
-          s.nu = 2.;
-        } else {
-          s.mu *= s.nu;
-          s.nu *= 2.;
-          if (s.mu < 0.0001) s.mu = 0.0001;
-          ++s.n_trials;
-          if (s.n_trials >= 5) s.stop = 1;
-        }
-      }
-      __syncthreads();
-      if (s.rho > 0 || s.stop) break;
-    }
-    if (s.stop) break;
+    if (s.done) break;
+    if (!s.nan_step) {
+      double acc[32], c;
+      pose_normal_pass<FPT, true>(s, pf, acc, c);
+      pose_block_sum27_1(s, acc, c, s.red_n);                      // ends with a barrier
+    } else __syncthreads();
   }
 
   // ---- covariance, culling, statistics (:691-767)
@@ -457,27 +533,31 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose(hso_camera cam, const 
   const float thr_pt = (n < 80) ? (float)(sqrt(5.991) / em2) : (float)(J.reproj_thresh / em2);
   const float thr_ls = (float)(1.3 / em2);
   int n_del = 0;
+  unsigned long long k64[FPT];
+  bool k64_valid[FPT];
 #pragma unroll
   for (int q = 0; q < FPT; q++) {
     const int i = tid + q * POSE_THREADS;
+    k64[q] = ~0ull; k64_valid[q] = false;
     if (i >= n) continue;
-    unsigned long long k64 = ~0ull;
     if (pf[q].kind & 3) {
       const Resid r = pose_residual(s, pf[q]);
+      k64_valid[q] = true;
       if ((pf[q].kind & 3) == 2) {
         const double error_ls = pf[q].g0 * r.e0 + pf[q].g1 * r.e1;
         if (fabs(error_ls) > (double)thr_ls) { n_del++; if (J.mask) J.mask[i] = 1; }
-        k64 = (unsigned long long)__double_as_longlong(error_ls * error_ls);
+        k64[q] = (unsigned long long)__double_as_longlong(error_ls * error_ls);
       } else {
         const float error_pt = (float)sqrt(r.e0 * r.e0 + r.e1 * r.e1);
         if (error_pt > thr_pt) { n_del++; if (J.mask) J.mask[i] = 1; }
-        k64 = (unsigned long long)__double_as_longlong((double)(error_pt * error_pt));
+        k64[q] = (unsigned long long)__double_as_longlong((double)(error_pt * error_pt));
       }
     }
-    s.keys64[i] = k64;
   }
   n_del = pose_block_count(s, n_del);
-  const double med_final = __longlong_as_double((long long)pose_select<unsigned long long, 64>(s, s.keys64, n, n_init / 2));
+  // the final median (:750-760): edgelet errors are squared in double there, so the keys are 64-bit; non-negative doubles order like
+  // their bit patterns
+  const double med_final = __longlong_as_double((long long)pose_select64<FPT>(s, k64, k64_valid, (unsigned)(n_init / 2)));
   if (tid < 64) {
     // Cov_ = (A * em2^2)^-1 (:692): Gauss-Jordan with partial pivoting on the last damped A — lane r holds row r of
     // [A | I] in registers (12 doubles, static indices: the one-lane form indexed a 6 x 12 array dynamically and lived in

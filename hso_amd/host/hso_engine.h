@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <functional>
 #include <new>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>

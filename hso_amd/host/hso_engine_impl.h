@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <numeric>
 #include <stdexcept>
 
@@ -149,8 +150,13 @@ struct Seq {
   std::vector<Id> free_slots;
   std::vector<Feat> feats;
   std::vector<Point> points;
-  std::vector<Seed> seeds;
+  std::vector<Seed> seeds;        // in batch order (a keyframe's seeds are appended together; compaction keeps the order)
   int n_dead_seeds = 0;
+  // the seeds the convergence loop of updateSeeds has to look at (indices): a seed's test sqrt(sigma2) < z_range / thresh can only
+  // change its answer when sigma2 changes, and its validity only when an observation clears it — both happen where a brief is
+  // applied, which is where the seed is noted.  check_all: the indices were invalidated (the list was compacted): look at every seed once.
+  std::vector<int> check_seeds;
+  bool check_all = true;
   std::vector<Id> kfs;            // Map::keyframes_
   std::vector<Id> dev_kfs;        // rows of the device keyframe table (promotion order)
   std::vector<Id> candidates, temps;
@@ -210,6 +216,14 @@ struct Seq {
     return true;
   }
   size_t n_feats(const Frame& F) const { return F.kf_row >= 0 ? F.fts.size() : (size_t)F.n_fts; }
+  // the seeds of one keyframe (Seed::batch_id): a contiguous run of the list
+  std::pair<size_t, size_t> seed_range(int32_t batch) const
+  {
+    auto lo = std::lower_bound(seeds.begin(), seeds.end(), batch, [](const Seed& a, int32_t b) { return a.batch < b; });
+    auto hi = std::upper_bound(lo, seeds.end(), batch, [](int32_t b, const Seed& a) { return b < a.batch; });
+    return {(size_t)(lo - seeds.begin()), (size_t)(hi - seeds.begin())};
+  }
+  static bool seed_converged(const Seed& sd) { return std::sqrt(sd.sigma2) < sd.z_range / sd.converge; }   // src/depth_filter.cpp:411
   void list_grew(Id fr) { if (std::find(dirty_lists.begin(), dirty_lists.end(), fr) == dirty_lists.end()) dirty_lists.push_back(fr); }
   Feat& feat_of(Frame& F, size_t i) { return F.kf_row >= 0 ? feats[F.fts[i]] : F.loose[i]; }
   const Feat& feat_of(const Frame& F, size_t i) const { return F.kf_row >= 0 ? feats[F.fts[i]] : F.loose[i]; }
@@ -380,7 +394,7 @@ struct Seq {
   }
   void reset_tables()
   {
-    frames.clear(); free_slots.clear(); feats.clear(); points.clear(); seeds.clear(); n_dead_seeds = 0;
+    frames.clear(); free_slots.clear(); feats.clear(); points.clear(); seeds.clear(); n_dead_seeds = 0; check_seeds.clear(); check_all = true;
     kfs.clear(); dev_kfs.clear(); candidates.clear(); temps.clear(); dirty_pts.clear(); dirty_obs.clear(); pt_flag.clear(); obs_flag.clear();
     dirty_lists.clear(); dev_cands.clear(); keys_dirty = true;
     kfs_dirty = true; local_map.clear(); converge_hist.clear(); prior.clear(); pre_lists.clear(); init.clear(); hist_stamp.clear(); hist_pose.clear();

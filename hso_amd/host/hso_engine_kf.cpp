@@ -246,7 +246,7 @@ void Bank::drop_sequence_seeds(int k)
   std::vector<int32_t> slots;
   for (Seed& sd : s.seeds) if (sd.alive && sd.slot >= 0) slots.push_back(sd.slot);
   if (!slots.empty()) check(hso_gpu_seed_table_erase(ctx_, seed_table_, slots.data(), (int)slots.size()), "DepthFilter");
-  s.seeds.clear(); s.n_dead_seeds = 0;
+  s.seeds.clear(); s.n_dead_seeds = 0; s.check_seeds.clear(); s.check_all = true;
 }
 
 // DepthFilter::updateSeeds (src/depth_filter.cpp:330-509) for the frames of all sequences: the bookkeeping before the
@@ -269,9 +269,10 @@ void Bank::observe_seeds(const std::vector<int>& who)
       s.prior.erase(s.prior.begin() + (std::ptrdiff_t)i);
     }
     // seeds older than max_n_kfs keyframes (:368-401)
-    for (size_t i = 0; i < s.seeds.size(); i++) {
+    for (size_t i = 0; i < s.seeds.size(); i++) {                   // the list is in batch order: the old ones are its head
       Seed& sd = s.seeds[i];
-      if (!sd.alive || s.batch - sd.batch <= cfg_.seed_max_kfs) continue;
+      if (s.batch - sd.batch <= cfg_.seed_max_kfs) break;
+      if (!sd.alive) continue;
       if (sd.temp != kNone && sd.reprojected) s.points[sd.temp].seed_state = -1;
       kill_seed(s, d, (int)i, sd.temp != kNone && sd.reprojected);
     }
@@ -335,6 +336,7 @@ void Bank::observe_seeds(const std::vector<int>& who)
       if (sd.seen.size() < 15) { sd.seen.push_back(s.cur); s.hold(s.cur); }
       if (!o.is_valid) sd.valid = false;
       sd.mu = o.mu; sd.sigma2 = o.sigma2; sd.b = o.b;
+      if (!sd.valid || Seq::seed_converged(sd)) s.check_seeds.push_back((int)(&sd - s.seeds.data()));
       if (o.result != 1) continue;
       sd.n_dist++;
       if (d.make_kf) {                                            // FeatureExtractor::setGridOccpuancy
@@ -372,10 +374,16 @@ void Bank::activate_seeds(const std::vector<int>& who)
     d.conv.clear(); d.act_frames.clear(); d.act_pair_frame.clear();
     std::vector<int>& ix = s.votes;                                // scratch: frame slot -> index in this sequence's frame table
     ix.assign(s.frames.size(), -1);
-    for (size_t i = 0; i < s.seeds.size(); i++) {
+    // which seeds to look at: the ones noted when their brief was applied (ascending, each once), or all of them
+    std::vector<int>& chk = s.check_seeds;
+    if (s.check_all) { chk.resize(s.seeds.size()); std::iota(chk.begin(), chk.end(), 0); s.check_all = false; }
+    else { std::sort(chk.begin(), chk.end()); chk.erase(std::unique(chk.begin(), chk.end()), chk.end()); }
+    for (const int ci : chk) {
+      const size_t i = (size_t)ci;
+      if (i >= s.seeds.size()) continue;
       Seed& sd = s.seeds[i];
       if (!sd.alive) continue;
-      if (std::sqrt(sd.sigma2) < sd.z_range / sd.converge) {
+      if (Seq::seed_converged(sd)) {
         d.conv.push_back((int)i);
         for (const std::vector<Id>* lst : {&sd.seen_before, &sd.seen})
           for (Id fr : *lst) {
@@ -385,6 +393,7 @@ void Bank::activate_seeds(const std::vector<int>& who)
       }
       else if (!sd.valid) kill_seed(s, d, (int)i, false);         // "z_min is NaN" (:494-498)
     }
+    chk.clear();
     n_tg[w] = d.act_pair_frame.size();
   });
   // where each sequence's records go in the call's tables (page-locked, kept between steps: the sequences write their parts in
@@ -510,7 +519,8 @@ void Bank::previous_begin(const std::vector<int>& who)
     for (size_t i = 0; i < s.pre_lists.size();) {
       Seq::PreList& L = s.pre_lists[i];
       bool any = false;
-      for (const Seed& sd : s.seeds) if (sd.alive && sd.batch == L.batch) { any = true; break; }
+      const auto rg = s.seed_range(L.batch);
+      for (size_t q = rg.first; q < rg.second; q++) if (s.seeds[q].alive) { any = true; break; }
       if (any && !L.frames.empty()) { ++i; continue; }
       for (Id fr : L.frames) release_frame_deferred(s, d, fr);
       s.pre_lists.erase(s.pre_lists.begin() + (std::ptrdiff_t)i);
@@ -590,12 +600,17 @@ void Bank::previous_collect()
         t.scalar("exposure", F.exposure); t.scalar("px_error_angle", px_error_angle_);
         t.field("seeds", in.data(), sizeof(hso_seed) * in.size()); t.field("out", out.data(), sizeof(hso_seed_out) * out.size());
       }
-      for (Seed& sd : s.seeds) {
-        if (!sd.alive || sd.batch != L.batch || sd.slot < 0 || sd.slot >= n_slots) continue;
+      const auto rg = s.seed_range(L.batch);
+      for (size_t q = rg.first; q < rg.second; q++) {
+        Seed& sd = s.seeds[q];
+        if (!sd.alive || sd.slot < 0 || sd.slot >= n_slots) continue;
         const hso_seed_brief& o = seed_brief_.data()[sd.slot];
         if (!o.is_update) continue;
         if (sd.seen_before.size() < 15) { sd.seen_before.push_back(fr); s.hold(fr); }   // optFrames_P (:702-703)
-        if (o.result == 1) { sd.mu = o.mu; sd.sigma2 = o.sigma2; }                      // updateSeed (:721)
+        if (o.result == 1) {                                                             // updateSeed (:721)
+          sd.mu = o.mu; sd.sigma2 = o.sigma2;
+          if (Seq::seed_converged(sd)) s.check_seeds.push_back((int)q);
+        }
       }
       release_frame_deferred(s, d, fr);                              // pre_frames.erase(begin()) on every path (:693-724)
       L.frames.erase(L.frames.begin());
@@ -1076,6 +1091,7 @@ void Bank::finish(const std::vector<int>& who)
       size_t keep = 0;
       for (size_t i = 0; i < s.seeds.size(); i++) if (s.seeds[i].alive) { if (keep != i) s.seeds[keep] = std::move(s.seeds[i]); keep++; }
       s.seeds.resize(keep); s.n_dead_seeds = 0;
+      s.check_seeds.clear(); s.check_all = true;                   // the noted indices are stale
     }
   });
   for (int k : who) {

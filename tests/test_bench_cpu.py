@@ -19,7 +19,7 @@ def test_bench_self_launch_and_gathers(gpus, orc, tmp_path):
     env = dict(os.environ, HSO_BENCH_SIDE="bench_cpu_side:CpuSide", PYTHONPATH=HERE + os.pathsep + ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
                MASTER_ADDR="127.0.0.1", HSO_BENCH_DETAIL=str(tmp_path / "bench_detail.json"))   # not the tracked file
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--batch", "4", "--scenes", "2",
-           "--feats", "150", "--shape", "vga", "--cpu-frames", "0", "--sequences", "2", "--banks", "2", "--seq-feats", "60", "--seq-frames", "4", "--seq-distinct", "2", "--single", "0"]
+           "--feats", "150", "--shape", "vga", "--cpu-frames", "0", "--sequences", "2", "--banks", "2", "--seq-feats", "60", "--seq-frames", "4", "--seq-distinct", "2", "--single", "0", "--seq-warmup-frames", "0"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]

@@ -1,0 +1,20 @@
+"""python tools/r6_repeat_banks.py [runs] [banks] [sequences]: the end-to-end run (bank_bench.run_banks) several times in ONE process on the same rendered
+sequences: is the first set of engines of a process slower than the following ones (bench.py's end-to-end figure is the first)?"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401
+from hso_amd import bank_bench, synth  # noqa: E402
+
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+banks = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+nseq = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+seqs = synth.sequences(8, 121, spec=synth.EUROC, seed0=777)
+for r in range(runs):
+    t0 = time.time()
+    m = bank_bench.run_banks(banks, nseq, 121, 2000, seqs=seqs)
+    print(json.dumps(dict(run=r, banks=banks, sequences=nseq, steady=m.get("steady_frames_per_s"), whole=m["frames_per_s"], warmup=m.get("warmup_frames_per_s"),
+                          cpus=m.get("host_cpus_used"), throttled=m.get("host_throttled_periods"), set_up_s=time.time() - t0 - m["wall_s"])), flush=True)
