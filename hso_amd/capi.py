@@ -268,6 +268,15 @@ def make_camera(model, width, height, fx, fy, cx, cy, d=(0, 0, 0, 0, 0), distort
     return cam
 
 
+WAIT_DEFAULT, WAIT_POLL, WAIT_NAP, WAIT_BLOCK = 0, 1, 2, 3
+
+
+class GpuOptions(C.Structure):
+    # hso_gpu_options (include/hso_gpu.h): per-context kernel-shape / wait choices; zero = default
+    _fields_ = [("size", C.c_int32), ("wait_mode", C.c_int32), ("track_no_coop", C.c_int32), ("track_coop_scatter", C.c_int32),
+                ("track_coop_feats_per_wg", C.c_int32), ("track_coop_workgroups", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
 class HsoGpuError(RuntimeError):
     pass
 
@@ -302,6 +311,7 @@ def load():
     lib.hso_gpu_abi_version.argtypes = []
     lib.hso_gpu_synchronize.argtypes = [vp]
     lib.hso_gpu_set_shared_device.argtypes = [vp, i32]
+    lib.hso_gpu_configure.argtypes = [vp, P(GpuOptions)]
     lib.hso_gpu_set_host_parallel.argtypes = [vp, vp, vp]
     lib.hso_gpu_frame_upload.argtypes = [vp, i64, vp, i32, i32, i32, P(FrameStats)]
     lib.hso_gpu_frame_upload_resized.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, P(FrameStats)]
@@ -375,7 +385,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "hso_gpu_ba_huber_deltas_multi", "hso_gpu_ba_local_multi",
     "hso_gpu_create", "hso_gpu_destroy", "hso_gpu_last_error", "hso_gpu_abi_version",
-    "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_set_host_parallel", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
+    "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_configure", "hso_gpu_set_host_parallel", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_coarse_track_collect_begin", "hso_gpu_coarse_track_collect_end", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
@@ -459,6 +469,12 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.hso_gpu_synchronize(self.h), "synchronize")
+
+    def configure(self, wait_mode=0, track_no_coop=False, track_coop_scatter=False, track_coop_feats_per_wg=0, track_coop_workgroups=0):
+        """hso_gpu_configure: the context's kernel-shape / wait choices (every call sets all of them; no arguments = the defaults)"""
+        o = GpuOptions(C.sizeof(GpuOptions), int(wait_mode), int(bool(track_no_coop)), int(bool(track_coop_scatter)), int(track_coop_feats_per_wg),
+                       int(track_coop_workgroups))
+        self._check(self.lib.hso_gpu_configure(self.h, C.byref(o)), "configure")
 
     def host_array(self, shape, dtype):
         """A numpy array over page-locked memory of hso_gpu_host_alloc (zeroed): pass it as an `out=` / input table and the DMA goes

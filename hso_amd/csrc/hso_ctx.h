@@ -51,9 +51,9 @@ struct hso_gpu_ctx {
   hipStream_t stream;
   bool own_stream;
   int n_cu;
-  struct HostHelpers* helpers = nullptr;   // hso_host_parallel_run
   hso_parallel_for_fn par_fn = nullptr; void* par_user = nullptr;   // hso_gpu_set_host_parallel: the caller's own worker pool
   bool shared_device = false;   // hso_gpu_set_shared_device: other contexts keep the device busy beside this one
+  hso_gpu_options opt{};        // hso_gpu_configure
   std::string err;
   std::unordered_map<int64_t, FrameRec> frames;
   // recycled frame allocations, one free list per geometry (key = width << 32 | height; their padding rows are still zero)
@@ -111,7 +111,7 @@ hipError_t hso_stream_sync(hipStream_t stream);
 // goes to the device with one DMA and without the second copy hso_copy_async makes for pageable memory
 char* hso_stage_reserve(hipStream_t stream, size_t bytes);
 void hso_stream_forget(hipStream_t stream);   // context teardown: free the stream's staging chunks
-void hso_stream_set_yielding(hipStream_t stream, bool on);   // waits on the stream sleep (blocking event) instead of polling
+void hso_stream_set_wait(hipStream_t stream, int mode);   // how waits on the stream wait: HSO_WAIT_POLL / _NAP / _BLOCK
 void hso_stream_abandon(hipStream_t stream);  // error path: wait for the stream, then DROP the pending copies into caller memory
                                               // (the entry point returns an error; the caller may free its buffers at once)
 #ifndef HSO_RAW_HIP_COPIES
@@ -137,22 +137,19 @@ int hso_fail(hso_gpu_ctx* ctx, int code, const char* msg);
 
 // The host side of a batched entry point — staging many megabytes of the caller's tables, checking their indices, sorting per
 // window — runs on the calling thread while the device waits: 2.7 + 5.2 ms per keyframe step of 128 sequences in the local-BA calls,
-// 1 ms per step in the map patches.  hso_host_parallel(ctx, n, work, fn) can spread such a loop over three helper threads the
-// context keeps (started at the first use, asleep in between): fn(i) for i in [0, n), handed out one at a time to the helpers and
-// the caller; `work` = bytes (or comparable) the loop touches — below ~1 MB the calling thread does it alone.  fn must not touch
-// the HIP runtime or ctx->err.  OFF by default (HSO_HOST_PARALLEL=1): see hso_host_parallel_on in hso_ctx.hip.
-void hso_host_parallel_run(hso_gpu_ctx* ctx, int n, const std::function<void(int)>& fn);   // hso_ctx.hip: the context's helper threads
-bool hso_host_parallel_on();   // HSO_HOST_PARALLEL=1 turns the helper threads on (off by default: see hso_ctx.hip)
+// 1 ms per step in the map patches.  hso_host_parallel(ctx, n, work, fn) spreads such a loop over the worker pool the caller lent
+// (hso_gpu_set_host_parallel: the sequence engine lends its own, whose workers are idle while the engine's thread is inside the
+// library): fn(i) for i in [0, n); `work` = bytes (or comparable) the loop touches — below ~1 MB, or without a lent pool, the
+// calling thread does it alone.  fn must not touch the HIP runtime or ctx->err.  (Round 5 also kept three helper threads per
+// context behind an environment switch; they cost six engines 20-35 % and are gone.)
 template <class F> void hso_host_parallel(hso_gpu_ctx* ctx, int n, size_t work, F&& fn)
 {
-  if (n >= 2 && work >= (size_t(1) << 20) && ctx->par_fn) {   // the caller lent its pool (hso_gpu_set_host_parallel)
+  if (n >= 2 && work >= (size_t(1) << 20) && ctx->par_fn) {
     using Fn = typename std::remove_reference<F>::type;
     ctx->par_fn(ctx->par_user, n, [](void* a, int i) { (*static_cast<Fn*>(a))(i); }, const_cast<void*>(static_cast<const void*>(&fn)));
     return;
   }
-  if (n < 2 || work < (size_t(1) << 20) || !hso_host_parallel_on()) { for (int i = 0; i < n; i++) fn(i); return; }
-  const std::function<void(int)> f(std::ref(fn));
-  hso_host_parallel_run(ctx, n, f);
+  for (int i = 0; i < n; i++) fn(i);
 }
 // size of a grow-only buffer that must hold `need` bytes now: half again as much + 1 MB, so that tables that grow a little with
 // every keyframe do not re-allocate (hipFree synchronises the device: 0.2-0.4 ms each, 18 per step at 32 sequences before this)

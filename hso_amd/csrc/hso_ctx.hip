@@ -20,7 +20,7 @@ struct Stager {
   std::mutex m;                     // a stream's stager is its own: the banks sharing a device do not queue behind one another's copies
   std::vector<StageChunk> chunks;
   std::vector<StageFix> fixes;      // device-to-host copies to finish after the next synchronisation
-  bool yield = false;               // hso_stream_set_yielding: waits on this stream sleep instead of polling
+  int wait_mode = HSO_WAIT_POLL;    // hso_stream_set_wait
   hipEvent_t wait_ev = nullptr;     // ... through this event (hipEventBlockingSync)
 };
 std::mutex g_stage_mutex;           // the table itself (element addresses are stable)
@@ -36,9 +36,6 @@ std::unordered_set<hipStream_t> g_streams_in_use;   // caller-provided streams t
 
 bool host_is_page_locked(const void* p)
 {
-  // measurement knob: hand pageable memory to the runtime like rounds 1-2 did (profiles/r3_host_memory_eviction.txt)
-  static const bool passthrough = getenv("HSO_COPY_PASSTHROUGH") != nullptr;
-  if (passthrough) return true;
   hipPointerAttribute_t at{};
   if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime: ordinary memory
   return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeArray;
@@ -123,29 +120,27 @@ hipError_t hso_copy2d_async(void* dst, size_t dpitch, const void* src, size_t sp
 // bookkeeping compete for the rest of a 16-CPU quota.  A yielding stream records an event and sleeps between queries instead (or, with
 // HSO_SYNC_MODE=block, waits on an event created with hipEventBlockingSync): a few tens of microseconds later than a poll would
 // notice — nothing against a multi-millisecond step whose device time the other banks fill anyway.
-void hso_stream_set_yielding(hipStream_t stream, bool on)
+void hso_stream_set_wait(hipStream_t stream, int mode)
 {
   Stager& S = stager_of(stream);
   std::lock_guard<std::mutex> lk(S.m);
-  S.yield = on;
+  if (S.wait_ev && ((S.wait_mode == HSO_WAIT_BLOCK) != (mode == HSO_WAIT_BLOCK))) { (void)hipEventDestroy(S.wait_ev); S.wait_ev = nullptr; }   // the event's flags follow the mode
+  S.wait_mode = mode;
 }
 
-// how a yielding stream waits: 0 = the blocking event alone, 1 (default) = query the event, briefly spinning, then in short naps
-// (HSO_SYNC_MODE=block / nap).  The blocking wait's wake-up comes with the interrupt and was measured bimodal on the GPU boxes (the
-// same 6 x 128 run at 24.7 k or at 13-14 k frames/s from one launch to the next); the napping wait is bounded by the nap.
-static int yield_mode()
-{
-  static const int mode = [] { const char* e = getenv("HSO_SYNC_MODE"); return e && !strcmp(e, "block") ? 0 : 1; }();
-  return mode;
-}
-
+// how a stream waits (hso_gpu_configure: wait_mode): POLL = hipStreamSynchronize; NAP = record an event, query it, briefly spinning,
+// then in short naps; BLOCK = wait on an event created with hipEventBlockingSync.  The blocking wait's wake-up comes with the
+// interrupt and was measured bimodal on the GPU boxes (the same 6 x 128 run at 24.7 k or at 13-14 k frames/s from one launch to the
+// next); the napping wait is bounded by the nap.
 static hipError_t stream_wait(hipStream_t stream)
 {
   hipEvent_t ev = nullptr;
+  int mode = HSO_WAIT_POLL;
   if (Stager* S = stager_find(stream)) {
     std::lock_guard<std::mutex> lk(S->m);
-    if (S->yield) {
-      const unsigned flags = (yield_mode() == 0 ? hipEventBlockingSync : 0u) | hipEventDisableTiming;
+    mode = S->wait_mode;
+    if (mode != HSO_WAIT_POLL) {
+      const unsigned flags = (mode == HSO_WAIT_BLOCK ? hipEventBlockingSync : 0u) | hipEventDisableTiming;
       if (!S->wait_ev && hipEventCreateWithFlags(&S->wait_ev, flags) != hipSuccess) S->wait_ev = nullptr;
       ev = S->wait_ev;
     }
@@ -153,7 +148,7 @@ static hipError_t stream_wait(hipStream_t stream)
   if (!ev) return hipStreamSynchronize(stream);
   hipError_t e = hipEventRecord(ev, stream);
   if (e != hipSuccess) return e;
-  if (yield_mode() == 0) return hipEventSynchronize(ev);
+  if (mode == HSO_WAIT_BLOCK) return hipEventSynchronize(ev);
   const auto t0 = std::chrono::steady_clock::now();
   long slack = -1;                                                  // the caller's timer slack, put back before this returns
   for (;;) {
@@ -194,65 +189,6 @@ hipError_t hso_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind
   const hipError_t e = hso_copy_async(dst, src, bytes, kind, nullptr);
   if (e != hipSuccess) return e;
   return hso_stream_sync(nullptr);
-}
-
-// Off unless HSO_HOST_PARALLEL=1: the helpers shorten the local-BA phase of a lone engine (3.85 -> 3.04 ms per step of 128 sequences),
-// but six engines inside bench.py's process lost 20-35 % of their steady-state throughput with them when the engines' stream waits
-// nap (profiles/r5_engine_host.md section 6) — threads that the scheduler places anywhere on a two-socket host copy into page-locked
-// blocks of another node while the engines' own pools are already 3.5 x oversubscribed.
-bool hso_host_parallel_on() { static const bool on = getenv("HSO_HOST_PARALLEL") != nullptr && getenv("HSO_HOST_SERIAL") == nullptr; return on; }
-
-// ---- the context's helper threads (hso_ctx.h: hso_host_parallel) ----
-struct HostHelpers {
-  std::vector<std::thread> th;
-  std::mutex m;
-  std::condition_variable go, done;
-  const std::function<void(int)>* fn = nullptr;
-  int n = 0, generation = 0, busy = 0;
-  std::atomic<int> next{0};
-  bool stop = false;
-  void work() { for (int i = next.fetch_add(1, std::memory_order_relaxed); i < n; i = next.fetch_add(1, std::memory_order_relaxed)) (*fn)(i); }
-  void loop()
-  {
-    int seen = 0;
-    std::unique_lock<std::mutex> lk(m);
-    for (;;) {
-      go.wait(lk, [&] { return stop || generation != seen; });
-      if (stop) return;
-      seen = generation;
-      lk.unlock();
-      work();
-      lk.lock();
-      if (--busy == 0) done.notify_one();
-    }
-  }
-};
-
-void hso_host_parallel_run(hso_gpu_ctx* ctx, int n, const std::function<void(int)>& fn)
-{
-  if (!ctx->helpers) {
-    ctx->helpers = new HostHelpers();
-    for (int t = 0; t < 3; t++) ctx->helpers->th.emplace_back([h = ctx->helpers] { h->loop(); });
-  }
-  HostHelpers& H = *ctx->helpers;
-  {
-    std::lock_guard<std::mutex> lk(H.m);
-    H.fn = &fn; H.n = n; H.next.store(0, std::memory_order_relaxed); H.busy = (int)H.th.size(); H.generation++;
-  }
-  H.go.notify_all();
-  H.work();
-  std::unique_lock<std::mutex> lk(H.m);
-  H.done.wait(lk, [&] { return H.busy == 0; });
-}
-
-static void host_helpers_free(hso_gpu_ctx* ctx)
-{
-  if (!ctx->helpers) return;
-  { std::lock_guard<std::mutex> lk(ctx->helpers->m); ctx->helpers->stop = true; }
-  ctx->helpers->go.notify_all();
-  for (std::thread& t : ctx->helpers->th) t.join();
-  delete ctx->helpers;
-  ctx->helpers = nullptr;
 }
 
 char* hso_stage_reserve(hipStream_t stream, size_t bytes)
@@ -406,7 +342,6 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  host_helpers_free(ctx);
   hso_track_state_free(ctx);
   hso_seed_tables_free(ctx);
   hso_seqmaps_free(ctx);
@@ -525,6 +460,12 @@ void hso_gpu_debug_census(int64_t* out, int n)
   for (int i = 0; i < n; i++) out[i] = i < HSO_CENSUS_N ? g_census[i].load(std::memory_order_relaxed) : 0;
 }
 
+static void hso_apply_wait_mode(hso_gpu_ctx* ctx)
+{
+  const int m = ctx->opt.wait_mode != HSO_WAIT_DEFAULT ? ctx->opt.wait_mode : (ctx->shared_device ? HSO_WAIT_NAP : HSO_WAIT_POLL);
+  hso_stream_set_wait(ctx->stream, m);
+}
+
 int hso_gpu_set_host_parallel(hso_gpu_ctx* ctx, hso_parallel_for_fn parallel_for, void* user)
 {
   if (!ctx) return HSO_E_INVALID;
@@ -536,7 +477,20 @@ int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared)
 {
   if (!ctx) return HSO_E_INVALID;
   ctx->shared_device = shared != 0;
-  hso_stream_set_yielding(ctx->stream, ctx->shared_device && !getenv("HSO_POLLING_SYNC"));
+  hso_apply_wait_mode(ctx);
+  return HSO_OK;
+}
+
+int hso_gpu_configure(hso_gpu_ctx* ctx, const hso_gpu_options* o)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!o || o->size < (int32_t)(4 * sizeof(int32_t)) || o->size > (int32_t)sizeof(hso_gpu_options)) return hso_fail(ctx, HSO_E_INVALID, "configure: options missing or of an unknown size");
+  hso_gpu_options n{};
+  memcpy(&n, o, (size_t)o->size);
+  if (n.wait_mode < HSO_WAIT_DEFAULT || n.wait_mode > HSO_WAIT_BLOCK || n.track_coop_feats_per_wg < 0 || n.track_coop_workgroups < 0)
+    return hso_fail(ctx, HSO_E_INVALID, "configure: value out of range");
+  ctx->opt = n;
+  hso_apply_wait_mode(ctx);
   return HSO_OK;
 }
 

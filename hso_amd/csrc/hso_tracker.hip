@@ -289,13 +289,11 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   // Coarse levels on two 256-thread workgroups per CU when the batch fills the chip at least twice and the coarse images fit
   // the smaller LDS share; a single sequence (latency, not throughput) keeps all eight wavefronts of a CU on its one job.
   st->split_level = -1;
-  int split_min_jobs = 2 * ctx->n_cu;
-  if (const char* e = getenv("HSO_TRACK_SPLIT_MIN_JOBS")) split_min_jobs = std::max(1, atoi(e));   // measurement knob
-  if (max_grid <= 0 && n_jobs >= split_min_jobs && C.max_level >= 2 && C.min_level <= 1 && !getenv("HSO_TRACK_NO_SPLIT")) {
-    int lvl = 2;   // levels max_level .. 2 on trk2, 1 .. min_level on trk1
-    if (getenv("HSO_TRACK_ALL_TRK2")) lvl = C.min_level;   // experiment: every level on trk2 (the finest image read from memory)
+  const int split_min_jobs = 2 * ctx->n_cu;
+  if (max_grid <= 0 && n_jobs >= split_min_jobs && C.max_level >= 2 && C.min_level <= 1) {
+    const int lvl = 2;   // levels max_level .. 2 on trk2, 1 .. min_level on trk1
     const size_t need = (size_t)g.w[lvl] * g.h[lvl] + g.w[lvl] + 64;
-    if (need <= (size_t)trk2::kImgCap || getenv("HSO_TRACK_ALL_TRK2")) st->split_level = lvl;
+    if (need <= (size_t)trk2::kImgCap) st->split_level = lvl;
   }
   st->grid2 = std::min(n_jobs, TRK2_PER_CU * ctx->n_cu);
   st->scratch_stride = scratch_bytes(C.n_max);
@@ -303,25 +301,24 @@ static int track_prepare(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_trac
   // (hso_tracker_coop.hip).  K_j follows the job's own feature count — about COOP_FEATS_PER_WG per workgroup — so a job's
   // result does not depend on what else is in the batch; all workgroups of the launch are resident at once (K_j <= CUs per XCD).
   st->coop_K = 0;
-  st->coop_scatter = getenv("HSO_TRACK_COOP_SCATTER") ? 1 : 0;
+  st->coop_scatter = ctx->opt.track_coop_scatter ? 1 : 0;
   // Medium batches (more jobs than XCDs, fewer than CUs: a bank of 16..128 sequences): the chip would run one workgroup per job
   // and leave the other CUs idle for the ~1.3 ms a 2000-feature job takes; instead every job is split over floor(CUs / jobs)
   // workgroups, spread over the XCDs (the placement-independent transport).  Here K does depend on the batch size — results of a
-  // job agree with its solo run within the tracker's tolerance, not bit for bit (HSO_TRACK_NO_COOP=1 pins the one-workgroup shape).
+  // job agree with its solo run within the tracker's tolerance, not bit for bit (hso_gpu_options.track_no_coop pins the one-workgroup shape).
   const int share = n_jobs > COOP_MAX_JOBS ? ctx->n_cu / n_jobs : COOP_KMAX;
   if (n_jobs > COOP_MAX_JOBS && share >= 2) st->coop_scatter = 1;
   // a context that shares the device with others (hso_gpu_set_shared_device) leaves medium batches on the one-workgroup shape:
   // the other contexts' kernels fill the CUs a batch of < 256 jobs leaves idle, splitting jobs only adds exchange work (7.8 us per
   // job against 3.3), and cooperative launches of several contexts take turns (one at a time per device)
-  const bool medium_ok = !ctx->shared_device || getenv("HSO_TRACK_SHARED_COOP");   // the knob: measurement only
-  if (max_grid <= 0 && (n_jobs <= COOP_MAX_JOBS || (share >= 2 && medium_ok)) && !st->coop_broken && !getenv("HSO_TRACK_NO_COOP")) {
+  const bool medium_ok = !ctx->shared_device;
+  if (max_grid <= 0 && (n_jobs <= COOP_MAX_JOBS || (share >= 2 && medium_ok)) && !st->coop_broken && !ctx->opt.track_no_coop) {
     const int per_xcd = std::min(std::min(COOP_KMAX, std::max(1, ctx->n_cu / 8)), share);
-    int fpw = COOP_FEATS_PER_WG;
-    if (const char* e = getenv("HSO_TRACK_COOP_FPW")) fpw = std::max(1, atoi(e));
+    const int fpw = ctx->opt.track_coop_feats_per_wg > 0 ? ctx->opt.track_coop_feats_per_wg : COOP_FEATS_PER_WG;
     int kmax = 0;
     for (int j = 0; j < n_jobs; j++) {
       int K = std::max(1, (st->h_jobs[j].n + fpw - 1) / fpw);
-      if (const char* e = getenv("HSO_TRACK_COOP_K")) K = std::max(1, atoi(e));
+      if (ctx->opt.track_coop_workgroups > 0) K = ctx->opt.track_coop_workgroups;
       K = std::min(K, per_xcd);
       st->h_jobs[j].coop_K = K;
       kmax = std::max(kmax, K);
@@ -400,7 +397,7 @@ int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx)
   TrackConsts C = st->C;
   if (st->coop_K) {
     C.lds_img_cap = hso_track_coop_img_cap();
-    if (!getenv("HSO_TRACK_COOP_NO_TURNS")) coop_turn_take(ctx, st);   // given back by the collect (measurement knob: no turns)
+    coop_turn_take(ctx, st);   // given back by the collect
     hipError_t e = hipMemsetAsync(st->d_counter, 0, 2 * sizeof(int), ctx->stream);   // [1] = the fail flag
     if (e == hipSuccess) e = hipMemsetAsync(st->d_coop, 0, sizeof(CoopJobState) * st->n_jobs, ctx->stream);
     if (e == hipSuccess) e = hso_track_coop_launch(ctx->stream, C, st->d_subjobs, st->n_jobs, st->coop_K, st->coop_scatter, st->d_coop,
@@ -424,7 +421,6 @@ int hso_gpu_coarse_track_launch(hso_gpu_ctx* ctx)
     C.level_first = st->split_level - 1; C.level_last = C.min_level; C.resume = 1;
   }
   C.lds_img_cap = trk1::kImgCap;
-  if (const char* e = getenv("HSO_LDS_IMG_CAP")) C.lds_img_cap = atoi(e);  // experiment knob
   HSO_HIP_CHECK(ctx, hipMemsetAsync(st->d_counter, 0, sizeof(int), ctx->stream));
   if (C.inverse)
     hipLaunchKernelGGL(trk1::k_track<true>, dim3(st->grid), dim3(TRK1_THREADS), st->lds_bytes, ctx->stream, C, st->d_jobs,
@@ -455,7 +451,7 @@ int hso_gpu_coarse_track_collect(hso_gpu_ctx* ctx, hso_track_result* results)
       // requirement — and keep this context on them from now on.
       st->coop_K = 0;
       st->coop_broken = true;
-      if (getenv("HSO_TRACK_DEBUG")) fprintf(stderr, "[hso tracker] cooperative launch of %d jobs timed out: this context stays on the one-workgroup shape\n", st->n_jobs);
+      ctx->err = "note: a cooperative tracker launch timed out; this context stays on the one-workgroup shape (results unaffected)";   // readable with hso_gpu_last_error
       if (int rc = hso_gpu_coarse_track_launch(ctx)) return rc;
       return hso_gpu_coarse_track_collect(ctx, results);
     }

@@ -577,6 +577,12 @@ HSO_DEV void precompute_reference(const Shared& s, const LevelCtx& L, Ptr ref32)
 #ifndef TRK_PRECOMPUTE_ROWS
 #define TRK_PRECOMPUTE_ROWS 1   // pattern-specialised reference patch precompute (forward mode, reference level in LDS)
 #endif
+#ifndef TRK_IC_ROWS
+#define TRK_IC_ROWS 1       // pattern-specialised pixel loop for the inverse-compositional mode too (round 6)
+#endif
+#ifndef TRK_IC_PREFETCH
+#define TRK_IC_PREFETCH 4
+#endif
 #ifndef TRK_GLOBAL_ROWS
 #define TRK_GLOBAL_ROWS 1   // pattern-specialised loops also for images left in device memory (level 0 when relocalising)
 #endif
@@ -1326,6 +1332,88 @@ __device__ __forceinline__ Moments feature_terms_rows(IP img, GlbF32 ref_patch, 
   return m;
 }
 
+// The inverse-compositional twin of feature_terms_rows: the residual needs only the bilinear intensity of the CURRENT frame (two
+// rows of windows live, as in collect_terms_rows), the gradient is the cached reference gradient (precompute_reference: ref_dx /
+// ref_dy beside the patch cache, [pattern pixel][feature]).  The reference takes this mode whenever the new frame's gradient mean
+// does not exceed the last frame's by 0.5 (src/frame_handler_mono.cpp:184) — nearly every frame of a sequence — so this is the
+// loop the sequence engine spends its tracker time in; until round 6 it ran the generic per-tap loop (run-time pattern table, two
+// LDS reads and three dependent cache loads per term, one term of prefetch).  Here: tap and cache offsets are compile-time
+// expressions, 8-14 LDS reads per feature instead of 2 per term, the three cached values of a term requested PF terms ahead.
+// The per-term decision arithmetic (intensity, residual, saturation test) is the generic loop's expression by expression; the
+// moments are summed in row order instead of pattern order (tolerance-compared quantities, like the forward mode's).
+template <int PI, typename IP>
+__device__ __forceinline__ Moments feature_terms_rows_ic(IP img, GlbF32 ref_patch, GlbF32 ref_dx, GlbF32 ref_dy, int base, float w_tl, float w_tr,
+                                                       float w_bl, float w_br, uint32_t fb, uint32_t nb, int stride, float a, float huber,
+                                                       float outlier, float max_energy, int top)
+{
+  constexpr auto P = PatRows<PI>::v;
+  constexpr int PA = h_pattern_num[PI];
+  constexpr int NB = P.max_ox - P.min_ox + 4;
+  constexpr int NW = (NB + 3) / 4;
+  constexpr int R0 = P.min_oy, R1 = P.max_oy + 1;
+  Moments m;
+  m.ee = m.ex = m.ey = m.xx = m.xy = m.yy = m.re = m.rx = m.ry = 0; m.E = 0; m.nt = PA; m.nsat = 0;
+  stride = __builtin_amdgcn_readfirstlane(stride);
+  nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+  typedef const __attribute__((address_space(1))) char* GlbBytes;
+  const GlbBytes rpb = (GlbBytes)ref_patch, rxb = (GlbBytes)ref_dx, ryb = (GlbBytes)ref_dy;
+  constexpr int PF = TRK_IC_PREFETCH;   // cached values requested PF terms ahead of their use (row order)
+  float ipf[PF], xpf[PF], ypf[PF];
+#pragma unroll
+  for (int t = 0; t < PF && t < PA; t++) {
+    const uint32_t off = fb + (uint32_t)P.idx[t] * nb;
+    ipf[t] = *(GlbF32)(rpb + off); xpf[t] = *(GlbF32)(rxb + off); ypf[t] = *(GlbF32)(ryb + off);
+  }
+  uint32_t win[2][3];
+  const int c0 = base + P.min_ox;
+  int t = 0;
+#pragma unroll
+  for (int R = R0; R <= R1; R++) {
+    {
+      const int addr = c0 + R * stride;
+      const int A = addr >> 2;
+      const uint32_t sh = (uint32_t)(addr & 3);
+      uint32_t (&w)[3] = win[(R - R0) & 1];
+      const uint32_t d0 = img[A], d1 = img[A + 1], d2 = img[A + 2];
+      w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      if (NW == 3) { const uint32_t d3 = img[A + 3]; w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); } else w[2] = 0;
+    }
+    const int oy = R - 1;                              // the terms whose two rows are now complete
+#pragma unroll
+    for (int q = 0; q < PA; q++) {
+      if (h_pattern[PI][P.idx[q]][1] != oy) continue;
+      const int kk = P.idx[q];
+      const int j = h_pattern[PI][kk][0] - P.min_ox;
+      const uint32_t (&w1)[3] = win[(oy - R0) & 1];
+      const uint32_t (&w2)[3] = win[(oy + 1 - R0) & 1];
+      const float iref = ipf[t % PF], dx = xpf[t % PF], dy = ypf[t % PF];
+      if (t + PF < PA) {
+        const uint32_t off = fb + (uint32_t)P.idx[(t + PF) < PA ? (t + PF) : 0] * nb;
+        ipf[t % PF] = *(GlbF32)(rpb + off); xpf[t % PF] = *(GlbF32)(rxb + off); ypf[t % PF] = *(GlbF32)(ryb + off);
+      }
+      t++;
+      const float p11 = win_byte(w1, j + 1), p12 = win_byte(w1, j + 2), p21 = win_byte(w2, j + 1), p22 = win_byte(w2, j + 2);
+      // decision arithmetic: exactly the reference's expression order (:339-348)
+      const float cur = ((w_tl * p11 + w_tr * p12) + w_bl * p21) + w_br * p22;
+      const float res = cur - a * iref;
+      const float ares = fabsf(res);
+      const float hw = ares < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ares);
+      const bool sat = (ares > outlier) && !top;
+      const float e_term = top ? (hw * res) * res : ((hw * res) * res) * (2 - hw);
+      m.E += sat ? max_energy : e_term;
+      m.nsat += sat ? 1 : 0;
+      const float wgt = sat ? 0.0f : hw;
+      const float e = -iref;
+      const float we = wgt * e, wx = wgt * dx, wy = wgt * dy, wr = wgt * res;
+      m.ee = fmaf(we, e, m.ee); m.ex = fmaf(we, dx, m.ex); m.ey = fmaf(we, dy, m.ey);
+      m.xx = fmaf(wx, dx, m.xx); m.xy = fmaf(wx, dy, m.xy); m.yy = fmaf(wy, dy, m.yy);
+      m.re = fmaf(wr, e, m.re); m.rx = fmaf(wr, dx, m.rx); m.ry = fmaf(wr, dy, m.ry);
+    }
+  }
+  return m;
+}
+
 // Expand one feature's moments into the 28 + 7 normal-equation entries (computeGS, :499-525).
 // A = fx_l * J.row(0), B = fy_l * J.row(1) (frame.h:192-212); in inverse-compositional mode the
 // Jacobian is taken at the reference point and scaled by the exposure ratio
@@ -1459,7 +1547,13 @@ HSO_PHASE void eval_terms(Shared& s, const LevelCtx& L, Ptr img, const Se3& T, f
       nxt = load_feature(L, fidx(r * FPT + q + 1));  // next feature's record in flight during this pixel loop
       p[q] = project_feature(L, T, raw, border);
       DBG_T(0);
-      if constexpr (PI >= 0) {
+      if constexpr (PI >= 0 && IC) {
+        if (p[q].ok)
+          m[q] = feature_terms_rows_ic<PI>(img, (GlbF32)L.sc.ref_patch, (GlbF32)L.sc.ref_dx, (GlbF32)L.sc.ref_dy, p[q].base, p[q].w_tl, p[q].w_tr, p[q].w_bl,
+                                           p[q].w_br, (uint32_t)f * 4u, (uint32_t)L.C->n_max * 4u, L.cols, a, huber, outlier, max_energy, top ? 1 : 0);
+        else
+          m[q] = Moments{};
+      } else if constexpr (PI >= 0) {
         if (p[q].ok)
 #if TRK_ROW_WINDOWS
           m[q] = feature_terms_rows<PI>(img, (GlbF32)L.sc.ref_patch, p[q].base, p[q].w_tl, p[q].w_tr, p[q].w_bl, p[q].w_br,
@@ -1522,7 +1616,7 @@ HSO_DEV void eval_dispatch(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
 {
   if (s.S == 1) {
     if (s.use_lds) {
-      if constexpr (!IC) {
+      if constexpr (!IC || TRK_IC_ROWS) {
         switch (s.pi) {  // pattern-specialised pixel loops for the patterns levels 4..1 use
           case 2: eval_terms<IC, true, LdsPtr, 2>(s, L, lds_img, T, a); return;
           case 3: eval_terms<IC, true, LdsPtr, 3>(s, L, lds_img, T, a); return;
@@ -1535,7 +1629,7 @@ HSO_DEV void eval_dispatch(Shared& s, const LevelCtx& L, LdsPtr lds_img, const S
       eval_terms<IC, true, LdsPtr>(s, L, lds_img, T, a);
     } else {
 #if TRK_GLOBAL_ROWS
-      if constexpr (!IC) {
+      if constexpr (!IC || TRK_IC_ROWS) {
         switch (s.pi) {  // the same row-window loops on the image in device memory (a level that does not fit this shape's LDS)
           case 2: eval_terms<IC, true, GlbW32, 2>(s, L, (GlbW32)L.cur_glb, T, a); return;
           case 3: eval_terms<IC, true, GlbW32, 3>(s, L, (GlbW32)L.cur_glb, T, a); return;

@@ -44,6 +44,9 @@ static unsigned cpu_budget()
 // How many engines share this process's CPU budget (hso_vo_host_share) and how many processes share the host (LOCAL_WORLD_SIZE of a
 // torchrun launch, one rank per GPU): a bank sizes its pool to its share.  Round 4 sized every pool to the whole quota: 8 ranks x 3
 // banks x 15 workers on a 16-CPU quota would have spent the run in the CFS throttle.
+// developer probe: HSO_ENGINE_TIMING=1 prints the phases' wall time when a bank goes away, =2 one line per step as well
+int timing_level() { static const int v = [] { const char* e = getenv("HSO_ENGINE_TIMING"); return e ? std::max(1, atoi(e)) : 0; }(); return v; }
+
 static std::atomic<int> g_host_share{1};
 void set_host_share(int banks_in_process) { g_host_share.store(std::max(1, banks_in_process)); }
 int host_cpu_budget() { return (int)cpu_budget(); }
@@ -87,8 +90,7 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
     grid_rows_ = (int)std::ceil((double)cam.height / cell_size_);
     cell_order_.resize((size_t)grid_cols_ * grid_rows_);
     std::iota(cell_order_.begin(), cell_order_.end(), 0);
-    sync_previous_ = getenv("HSO_ENGINE_SYNC_PREVIOUS") != nullptr;
-    if (getenv("HSO_ENGINE_NO_PREVIOUS")) cfg_.previous_frame_pass = false;   // measurement aid: the step without the idle-time pass
+    sync_previous_ = cfg.sync_previous;
     px_error_angle_ = std::atan(1.0 / (2.0 * cam_.errorMultiplier2())) * 2.0;   // one pixel of noise (src/depth_filter.cpp:360-366)
     for (int k = 0; k < n_sequences; k++) {
       Seq* s = new Seq();
@@ -105,29 +107,28 @@ Bank::Bank(hso_gpu_ctx* ctx, bool owns_ctx, const hso_camera& cam, const Setting
     n_threads_ = pool_threads_for(n_sequences);
     pool_ = new Pool(n_threads_);
     // the device library's own host loops (local-BA window staging, map-patch staging) run on this pool too: the engine's thread is
-    // inside the library then and the workers are idle (HSO_ENGINE_NO_LIB_POOL=1: on the calling thread, as before)
-    if (!getenv("HSO_ENGINE_NO_LIB_POOL"))
-      check(hso_gpu_set_host_parallel(ctx_, [](void* user, int n, void (*body)(void*, int), void* arg) {
-        static_cast<Pool*>(user)->run(n, [&](int i) { body(arg, i); });
-      }, pool_), "set_host_parallel");
+    // inside the library then and the workers are idle
+    check(hso_gpu_set_host_parallel(ctx_, [](void* user, int n, void (*body)(void*, int), void* arg) {
+      static_cast<Pool*>(user)->run(n, [&](int i) { body(arg, i); });
+    }, pool_), "set_host_parallel");
   } catch (...) { undo(); throw; }
 }
 
 Bank::~Bank()
 {
-  if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0)
+  if (timing_level() > 0 && n_steps_ > 0)
     fprintf(stderr, "[hso engine] %lld steps of %d sequences, %lld keyframes; ms per step: upload %.3f, track %.3f, reproject+select+pose %.3f, decide %.3f, "
             "local BA %.3f, seed observe %.3f, seed activate %.3f, new seeds %.3f, flush+finish %.3f\n", (long long)n_steps_, size(), (long long)n_kf_events_,
             phase_ms_[0] / n_steps_, phase_ms_[1] / n_steps_, phase_ms_[2] / n_steps_, phase_ms_[3] / n_steps_, phase_ms_[4] / n_steps_, phase_ms_[5] / n_steps_,
             phase_ms_[6] / n_steps_, phase_ms_[7] / n_steps_, phase_ms_[8] / n_steps_);
-  if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0) {
+  if (timing_level() > 0 && n_steps_ > 0) {
     static const char* const names[9] = {"upload", "track", "reproject+select+pose", "decide", "local BA", "seed observe", "seed activate", "new seeds", "flush+finish"};
     for (int k = 0; k < 9; k++)
       fprintf(stderr, "[hso engine]   %-22s per step: %6.1f copies (%5.1f staged, %8.1f KB of which %8.1f KB to the device), %5.1f syncs (%.3f ms blocked), %5.1f memsets\n", names[k],
               (double)phase_census_[k][0] / n_steps_, (double)phase_census_[k][2] / n_steps_, (double)phase_census_[k][1] / n_steps_ / 1024.0, (double)phase_census_[k][6] / n_steps_ / 1024.0,
               (double)phase_census_[k][3] / n_steps_, (double)phase_census_[k][4] / n_steps_ * 1e-6, (double)phase_census_[k][5] / n_steps_);
   }
-  if (getenv("HSO_ENGINE_TIMING") && n_steps_ > 0)
+  if (timing_level() > 0 && n_steps_ > 0)
     fprintf(stderr, "[hso engine] reproject+select+pose = list points + patch maps %.3f, device call %.3f, apply %.3f\n", sub_ms_[0] / n_steps_, sub_ms_[1] / n_steps_,
             sub_ms_[2] / n_steps_);
   if (timing_ && n_steps_ > 0) {
@@ -172,6 +173,15 @@ bool Bank::trace_state(int k, bool on)
   if (k < 0 || k >= size()) return false;
   seq_[k]->trace.state = on;
   return true;
+}
+
+void Bank::set_options(bool sync_previous, bool track_no_coop)
+{
+  previous_collect();                                            // a pass in flight is applied under the old setting
+  sync_previous_ = sync_previous;
+  hso_gpu_options o{};
+  o.size = (int32_t)sizeof(o); o.track_no_coop = track_no_coop ? 1 : 0;
+  check(hso_gpu_configure(ctx_, &o), "configure");
 }
 
 void Bank::call_counts(int64_t* calls, int64_t* items, int cap) const

@@ -53,6 +53,8 @@ struct Settings {                 // src/config.cpp:28-64 and the Options struct
   float reproject_seed_thresh = 86;
   int seed_max_kfs = 3;           // DepthFilter::Options::max_n_kfs
   bool previous_frame_pass = true;   // the depth thread's idle-time pass (src/depth_filter.cpp:254-263): one sweep per frame
+  bool sync_previous = false;        // ... inside the step instead of on the depth filter's own stream (hso_vo_multi_set_option: tests compare the two)
+  bool track_no_coop = false;        // hso_gpu_options.track_no_coop of the bank's context
   double map_scale = 1.0, init_min_disparity = 40.0;
   int init_min_tracked = 50, init_min_inliers = 40;
 };
@@ -120,6 +122,7 @@ class Pool;                       // the bookkeeping threads
 void set_host_share(int banks_in_process);   // how many banks this process runs side by side (each sizes its pool to its share)
 int pool_threads_for(int n_sequences);        // worker threads a bank of n sequences would get now
 int host_cpu_budget();                        // CPUs the process may keep busy (hardware threads, or the cgroup quota)
+int timing_level();                           // HSO_ENGINE_TIMING (developer probe): 0 off, 1 phase split at the end, 2 a line per step
 
 // a grow-only array in page-locked host memory (hso_gpu_host_alloc): the result tables of the batched calls are DMA targets as they
 // are — no staging copy on the way back
@@ -176,6 +179,7 @@ public:
   int trajectory(int k, double* stamps, hso_se3* T_f_w, int cap) const;
   bool trace(int k, const char* path);
   bool trace_state(int k, bool on);
+  void set_options(bool sync_previous, bool track_no_coop);
   void call_counts(int64_t* calls, int64_t* items, int cap) const;
   // algorithmic bytes (SURVEY.md section 8(d) units) of the steps so far: [frame build, tracker, matcher, pose optimiser, seeds]
   void alg_bytes(double* out, int cap) const { for (int i = 0; i < cap && i < 5; i++) out[i] = alg_bytes_[i]; }

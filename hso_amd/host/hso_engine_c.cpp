@@ -60,6 +60,12 @@ int hso_vo_create(hso_vo** out, const hso_camera* cam, int max_fts, int device)
 void hso_vo_destroy(hso_vo* v) { if (v) { delete v->bank; delete v; } }
 const char* hso_vo_last_error(const hso_vo* v) { return v ? v->bank->err.c_str() : "null handle"; }
 int hso_vo_trace(hso_vo* v, const char* path) { return (v && v->bank->trace(0, path)) ? HSO_OK : HSO_E_INVALID; }
+static int set_opts(Bank* b, const hso_vo_options* o)
+{
+  if (!b || !o || o->size < 12 || o->size > (int32_t)sizeof(hso_vo_options)) return HSO_E_INVALID;
+  return guarded(b, [&]() { b->set_options(o->sync_previous != 0, o->track_no_coop != 0); });
+}
+int hso_vo_set_options(hso_vo* v, const hso_vo_options* o) { return v ? set_opts(v->bank, o) : HSO_E_INVALID; }
 int hso_vo_trace_state(hso_vo* v, int on) { return (v && v->bank->trace_state(0, on != 0)) ? HSO_OK : HSO_E_INVALID; }
 
 int hso_vo_set_first_frame(hso_vo* v, const uint8_t* img, int width, int height, double timestamp, const float* depth_z, const hso_se3* T_f_w)
@@ -97,6 +103,7 @@ void hso_vo_multi_destroy(hso_vo_multi* m) { if (m) { delete m->bank; delete m; 
 const char* hso_vo_multi_last_error(const hso_vo_multi* m) { return m ? m->bank->err.c_str() : "null handle"; }
 int hso_vo_multi_size(const hso_vo_multi* m) { return m ? m->bank->size() : HSO_E_INVALID; }
 int hso_vo_multi_trace(hso_vo_multi* m, int sequence, const char* path) { return (m && m->bank->trace(sequence, path)) ? HSO_OK : HSO_E_INVALID; }
+int hso_vo_multi_set_options(hso_vo_multi* m, const hso_vo_options* o) { return m ? set_opts(m->bank, o) : HSO_E_INVALID; }
 int hso_vo_multi_trace_state(hso_vo_multi* m, int sequence, int on) { return (m && m->bank->trace_state(sequence, on != 0)) ? HSO_OK : HSO_E_INVALID; }
 int hso_vo_multi_set_first_frames(hso_vo_multi* m, const uint8_t* const* imgs, int width, int height, const double* timestamps,
                                   const float* const* depth_z, const hso_se3* T_f_w)

@@ -43,7 +43,7 @@ inline int8_t point_face(int8_t feature_type) { return feature_type == HSO_FTR_E
 // parallel-for over the sequences of a phase; the caller takes part, so a pool of zero threads is the serial engine.
 // A step is a chain of ~20 short parallel phases (0.1-1 ms of work each) separated by device calls, so what a wake-up costs
 // decides how well the phases scale.  A worker that finds no work can keep polling the generation counter for HSO_ENGINE_SPIN_US
-// microseconds before it blocks on the condition variable — off by default: on a host whose CPU time is capped (the GPU boxes of
+// microseconds before it blocks on the condition variable — compiled out (spin_us_ = 0): on a host whose CPU time is capped (the GPU boxes of
 // this project run under a 16-CPU cgroup quota) polling workers burn the quota the bookkeeping itself needs, and whole steps then
 // stall for a scheduler period (measured: 10 k -> 6 k frames/s for one bank of 128, 17 k -> 5 k for three banks).  The caller
 // polls for the last stragglers of a phase (microseconds).  Work is handed out through one 64-bit ticket (generation << 32 |
@@ -52,7 +52,6 @@ class Pool {
 public:
   explicit Pool(int n_threads)
   {
-    if (const char* e = getenv("HSO_ENGINE_SPIN_US")) spin_us_ = std::max(0, atoi(e));
     for (int i = 0; i < n_threads; i++) th_.emplace_back([this] { loop(); });
   }
   ~Pool()

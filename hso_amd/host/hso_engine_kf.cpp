@@ -71,21 +71,7 @@ void Bank::keyframe_ba(const std::vector<int>& who)
   std::vector<std::vector<hso_se3>> poses_in(with.size());
   std::vector<std::vector<double>> idist_in(with.size());
   // the Huber deltas and the optimisation of every window of the step in one device call (hso_gpu_ba_local_multi: the windows go
-  // up once, the medians are taken on the device); HSO_BA_TWO_CALLS=1 keeps the two-call form (tests compare the two)
-  const bool two_calls = getenv("HSO_BA_TWO_CALLS") != nullptr;
-  if (two_calls) {
-    std::vector<hso_ba_deltas_job> dj(with.size());
-    for (size_t i = 0; i < with.size(); i++) {
-      StepData& d = *step_[with[i]];
-      hso_ba_deltas_job& j = dj[i];
-      j = hso_ba_deltas_job{};
-      j.poses_f_w = d.ba_poses.data(); j.n_poses = (int)d.ba_poses.size(); j.idist = d.ba_idist.data(); j.n_points = (int)d.ba_idist.size();
-      j.edges = d.ba_edges.data(); j.obs_uv = d.ba_uv.data(); j.n_edges = (int)d.ba_edges.size();
-    }
-    Sub t(this, "ba: huber deltas call");
-    if (!with.empty()) check(hso_gpu_ba_huber_deltas_multi(ctx_, dj.data(), (int)dj.size(), fmean), "LocalBundleAdjustment");
-    for (size_t i = 0; i < with.size(); i++) { step_[with[i]]->huber_corner = dj[i].huber_corner; step_[with[i]]->huber_edge = dj[i].huber_edge; }
-  }
+  // up once, the medians are taken on the device)
   // a traced sequence records the window's state before the optimisation moves it
   for (size_t i = 0; i < with.size(); i++)
     if (seq_[with[i]]->trace.on()) { poses_in[i] = step_[with[i]]->ba_poses; idist_in[i] = step_[with[i]]->ba_idist; }
@@ -101,8 +87,7 @@ void Bank::keyframe_ba(const std::vector<int>& who)
       p.huber_corner = d.huber_corner; p.huber_edge = d.huber_edge;
       uv[i] = d.ba_uv.data();
     }
-    if (two_calls) { Sub t(this, "ba: optimize call"); check(hso_gpu_ba_optimize_multi(ctx_, pr.data(), (int)pr.size()), "LocalBundleAdjustment"); }
-    else {
+    {
       Sub t(this, "ba: local call");
       std::vector<float> hub(2 * with.size());
       check(hso_gpu_ba_local_multi(ctx_, pr.data(), uv.data(), (int)pr.size(), fmean, hub.data()), "LocalBundleAdjustment");
@@ -324,15 +309,11 @@ void Bank::observe_seeds(const std::vector<int>& who)
     }
     // DepthFilter::observeDepthRow's effects on the seed (:593-673)
     d.occupied.clear();
-    int dbg_upd = 0, dbg_ok = 0, dbg_live = 0; double dbg_ratio = 1e9;
     for (Seed& sd : s.seeds) {
       if (!sd.alive || sd.slot < 0 || sd.slot >= n_slots) continue;
       const hso_seed_brief& o = (d.seeds_observed ? d.chain_brief : seed_brief_.data())[sd.slot];
       sd.updated = o.is_update != 0;
-      dbg_live++;
       if (!sd.updated) continue;
-      dbg_upd++; if (o.result == 1) dbg_ok++;
-      dbg_ratio = std::min(dbg_ratio, (double)std::sqrt(o.sigma2) / (sd.z_range / sd.converge));
       if (sd.seen.size() < 15) { sd.seen.push_back(s.cur); s.hold(s.cur); }
       if (!o.is_valid) sd.valid = false;
       sd.mu = o.mu; sd.sigma2 = o.sigma2; sd.b = o.b;
@@ -345,7 +326,6 @@ void Bank::observe_seeds(const std::vector<int>& who)
         d.occupied.push_back(kp);
       }
     }
-    if (getenv("HSO_ENGINE_DEBUG")) fprintf(stderr, "[seq %d] seeds live %d updated %d matched %d, closest to convergence %.2f\n", k, dbg_live, dbg_upd, dbg_ok, dbg_ratio);
   });
 }
 

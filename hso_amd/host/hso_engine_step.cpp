@@ -66,7 +66,7 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
   if (who.empty()) return;
   release_queued();
 
-  timing_ = getenv("HSO_ENGINE_TIMING") != nullptr;
+  timing_ = timing_level() > 0;
   Clock ck(phase_ms_, phase_census_, timing_);
   upload(who, imgs, w, h, stamps, on_device);
   ck.lap(0);
@@ -107,7 +107,6 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
       n_kf_events_ += (int64_t)kf.size();
     }
   }
-  if (const char* e = getenv("HSO_ENGINE_EXTRA_US")) usleep((useconds_t)atoi(e));   // measurement aid: is the host's serial time on the critical path?
   { Sub t(this, "end: flush_maps"); flush_maps(who); }
   { Sub t(this, "end: finish"); finish(who); }
   { Sub t(this, "end: release"); release_queued(); }
@@ -120,7 +119,7 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
   }
   ck.lap(8);
   n_steps_++;
-  if (const char* e = getenv("HSO_ENGINE_TIMING")) if (atoi(e) >= 2) {   // one line per step: the phases' wall time since the last step's line
+  if (timing_level() >= 2) {   // one line per step: the phases' wall time since the last step's line
     static thread_local double last[9] = {0};
     static thread_local long long last_kf = 0;
     // keyframes taken in this step, then what the step asked of the runtime (all contexts of the process: read it from a lone bank)

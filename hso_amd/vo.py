@@ -24,6 +24,11 @@ class VoStatus(C.Structure):
                 ("ba_error_final", C.c_double)]
 
 
+class VoOptions(C.Structure):
+    # hso_vo_options (include/hso_vo.h)
+    _fields_ = [("size", C.c_int32), ("sync_previous", C.c_int32), ("track_no_coop", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
 _lib = None
 
 
@@ -36,6 +41,8 @@ def _declare(lib):
     lib.hso_vo_last_error.restype = C.c_char_p
     lib.hso_vo_trace.argtypes = [vp, C.c_char_p]
     lib.hso_vo_trace_state.argtypes = [vp, i32]
+    lib.hso_vo_set_options.argtypes = [vp, P(VoOptions)]
+    lib.hso_vo_multi_set_options.argtypes = [vp, P(VoOptions)]
     lib.hso_vo_multi_trace_state.argtypes = [vp, i32, i32]
     lib.hso_vo_set_first_frame.argtypes = [vp, vp, i32, i32, C.c_double, vp, P(capi.SE3)]
     lib.hso_vo_add_image.argtypes = [vp, vp, i32, i32, C.c_double]
@@ -87,7 +94,7 @@ EXPORTED_SYMBOLS = ["hso_vo_create", "hso_vo_destroy", "hso_vo_last_error", "hso
                     "hso_vo_add_image", "hso_vo_get_status", "hso_vo_get_keyframes", "hso_vo_start", "hso_vo_init_compute_matrix",
                     "hso_vo_multi_create", "hso_vo_multi_destroy", "hso_vo_multi_last_error", "hso_vo_multi_size",
                     "hso_vo_multi_set_first_frames", "hso_vo_multi_add_images", "hso_vo_multi_get_status", "hso_vo_multi_get_keyframes",
-                    "hso_vo_multi_call_counts", "hso_vo_host_share", "hso_vo_multi_alg_bytes", "hso_vo_multi_threads", "hso_vo_host_cpu_quota", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device", "hso_vo_multi_get_trajectory", "hso_vo_get_trajectory", "hso_vo_trace_state", "hso_vo_multi_trace_state"]
+                    "hso_vo_multi_call_counts", "hso_vo_host_share", "hso_vo_multi_alg_bytes", "hso_vo_multi_threads", "hso_vo_host_cpu_quota", "hso_vo_multi_start", "hso_vo_multi_trace", "hso_vo_multi_add_images_device", "hso_vo_multi_get_trajectory", "hso_vo_get_trajectory", "hso_vo_trace_state", "hso_vo_multi_trace_state", "hso_vo_set_options", "hso_vo_multi_set_options"]
 
 CALL_KINDS = ["frame_upload", "frame_release", "track", "reproject_select_pose", "align", "pose", "seed_observe", "seed_activate", "ba", "other"]
 
@@ -131,6 +138,10 @@ class MultiVisualOdometry:
 
     def trace(self, k, path):
         self._check(self.lib.hso_vo_multi_trace(self.h, int(k), path.encode() if path else None), "trace")
+
+    def set_options(self, sync_previous=False, track_no_coop=False):
+        o = VoOptions(C.sizeof(VoOptions), int(bool(sync_previous)), int(bool(track_no_coop)))
+        self._check(self.lib.hso_vo_multi_set_options(self.h, C.byref(o)), "set_options")
 
     def start(self, which=None):
         w = np.ascontiguousarray(which, np.uint8) if which is not None else None
@@ -215,6 +226,10 @@ class VisualOdometry:
         """record the device calls to `path` (None stops); state=True: every chain call with the sequence map it ran on (hso_vo_trace_state)"""
         self._check(self.lib.hso_vo_trace_state(self.h, 1 if state else 0), "trace_state")
         self._check(self.lib.hso_vo_trace(self.h, path.encode() if path else None), "trace")
+
+    def set_options(self, sync_previous=False, track_no_coop=False):
+        o = VoOptions(C.sizeof(VoOptions), int(bool(sync_previous)), int(bool(track_no_coop)))
+        self._check(self.lib.hso_vo_set_options(self.h, C.byref(o)), "set_options")
 
     def set_first_frame(self, img, depth_z, timestamp=0.0, T_f_w=None):
         img = np.ascontiguousarray(img, np.uint8)

@@ -82,6 +82,21 @@ int hso_gpu_synchronize(hso_gpu_ctx* ctx);
  * idle CUs — the other contexts' work fills those — which is what gives the best THROUGHPUT; the default (0) gives a lone batch
  * the best LATENCY.  Results agree within the tracker's stated tolerance either way. */
 int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared);
+/* The remaining choices of kernel shape and of how a context waits, per context (until round 5: process-wide environment
+ * variables).  Zero = the default everywhere; the struct may be extended at its end (size = sizeof of the caller's). */
+enum { HSO_WAIT_DEFAULT = 0,   /* a lone context polls (hipStreamSynchronize); one that shares its device naps between event queries */
+       HSO_WAIT_POLL = 1, HSO_WAIT_NAP = 2, HSO_WAIT_BLOCK = 3 /* a blocking event: lowest CPU use, wake-ups measured bimodal on the GPU boxes */ };
+typedef struct hso_gpu_options {
+  int32_t size;                /* sizeof(hso_gpu_options) */
+  int32_t wait_mode;           /* HSO_WAIT_* */
+  int32_t track_no_coop;       /* 1: batches smaller than the chip stay on the one-workgroup-per-job tracker (a job's result then does
+                                  not depend on the batch it is in; the cooperative shape agrees within the tracker's tolerance) */
+  int32_t track_coop_scatter;  /* 1: a job's workgroups spread over all XCDs (the placement-independent exchange; same bits) */
+  int32_t track_coop_feats_per_wg;   /* features per workgroup the cooperative shape aims for (0: 256) */
+  int32_t track_coop_workgroups;     /* workgroups per job of the cooperative shape (0: from the feature count) */
+  int32_t reserved[2];
+} hso_gpu_options;
+int hso_gpu_configure(hso_gpu_ctx* ctx, const hso_gpu_options* options);
 /* The host side of the batched entry points (staging tens of megabytes of local-BA windows, checking and staging map patches) is a
  * loop over independent items.  A caller that keeps a worker pool of its own lends it here: the library then calls
  * parallel_for(user, n, body, arg) and expects body(arg, i) to have run for every i in [0, n), on any threads, when it returns;

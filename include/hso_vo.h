@@ -37,6 +37,14 @@ int hso_vo_trace(hso_vo* vo, const char* path);
  * With it a test hands ONE map state to the device call and to its CPU restatement (tests/test_seq_chain.py).  A few MB per frame
  * at 2000 features: meant for a handful of frames, not for whole runs. */
 int hso_vo_trace_state(hso_vo* vo, int on);
+/* Choices that were process-wide environment variables until round 5, per handle; zero = default.  May be set between frames. */
+typedef struct hso_vo_options {
+  int32_t size;               /* sizeof(hso_vo_options) */
+  int32_t sync_previous;      /* 1: the depth filter's idle-time pass runs inside the step instead of on its own stream (same results: tests compare) */
+  int32_t track_no_coop;      /* 1: the tracker keeps one workgroup per job whatever the batch size (hso_gpu_options.track_no_coop) */
+  int32_t reserved[5];
+} hso_vo_options;
+int hso_vo_set_options(hso_vo* vo, const hso_vo_options* options);
 /* first keyframe: features are detected the way the initialisation detects them and every feature with
  * depth_z[y * width + x] > 0 (depth along the optical axis, metres) becomes a map point hosted in this frame */
 int hso_vo_set_first_frame(hso_vo* vo, const uint8_t* img, int width, int height, double timestamp, const float* depth_z,
@@ -96,6 +104,7 @@ int hso_vo_multi_add_images_device(hso_vo_multi* m, const uint8_t* const* imgs, 
 /* hso_vo_trace for one sequence of the bank */
 int hso_vo_multi_trace(hso_vo_multi* m, int sequence, const char* path);
 int hso_vo_multi_trace_state(hso_vo_multi* m, int sequence, int on);
+int hso_vo_multi_set_options(hso_vo_multi* m, const hso_vo_options* options);
 int hso_vo_multi_get_status(hso_vo_multi* m, int sequence, hso_vo_status* st);
 int hso_vo_multi_get_keyframes(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int32_t* frame_ids, int cap);
 int hso_vo_multi_get_trajectory(hso_vo_multi* m, int sequence, double* timestamps, hso_se3* T_f_w, int cap);

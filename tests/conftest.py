@@ -55,22 +55,13 @@ import contextlib
 
 
 @contextlib.contextmanager
-def track_env(mode, feats_per_wg=None):
-    """Select the tracker shape for the calls inside the block (the library reads these at prepare time):
+def track_env(ctx, mode, feats_per_wg=None):
+    """Select the tracker shape for the calls of `ctx` inside the block (hso_gpu_configure; the library reads it at prepare time):
     "coop" (default for <= 8 jobs: several workgroups per job), "scatter" (the same with a job's workgroups spread over the
     XCDs, i.e. the placement-independent transport), "one_wg" (the batch shapes: one workgroup per job).  feats_per_wg
     overrides the features per workgroup the host aims for (default 256), i.e. the number of workgroups per job."""
-    keys = dict({"coop": {}, "scatter": {"HSO_TRACK_COOP_SCATTER": "1"}, "one_wg": {"HSO_TRACK_NO_COOP": "1"}}[mode])
-    if feats_per_wg is not None:
-        keys["HSO_TRACK_COOP_FPW"] = str(feats_per_wg)
-    old = {k: os.environ.get(k) for k in ("HSO_TRACK_COOP_SCATTER", "HSO_TRACK_NO_COOP", "HSO_TRACK_COOP_FPW")}
-    for k in old:
-        os.environ.pop(k, None)
-    os.environ.update(keys)
+    ctx.configure(track_no_coop=(mode == "one_wg"), track_coop_scatter=(mode == "scatter"), track_coop_feats_per_wg=feats_per_wg or 0)
     try:
         yield
     finally:
-        for k, v in old.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
+        ctx.configure()

@@ -368,43 +368,3 @@ def test_host_loops_on_the_callers_pool(gpu_ctx):
     n_before = len(seen)
     gpu_ctx.ba_optimize_multi(problems)
     assert len(seen) == n_before                                             # the pool is gone: nothing is handed out
-
-
-_HELPERS_SCRIPT = r"""
-import numpy as np
-from hso_amd import capi, synth
-ctx = capi.Context()
-problems, wins = [], []
-for shape, seed, n_iter in (((12, 3000, 5), 71, 4), ((10, 2500, 5), 72, 3), ((14, 3500, 5), 73, 5), ((9, 2000, 5), 74, 2)):
-    poses, fixed, idist, edges = synth.ba_problem(*shape, seed=seed, px_noise=0.3)
-    problems.append((poses, fixed, idist, edges, 1.0, 0.6, n_iter))
-    rng = np.random.default_rng(seed)
-    uv = np.stack([rng.normal(0, 1, len(edges)), rng.normal(0, 1, len(edges))], 1)
-    wins.append((poses, idist, edges, uv))
-assert sum(len(p[3]) for p in problems) * 128 > (1 << 20)          # enough work for hso_host_parallel to use its helpers
-singles = [ctx.ba_optimize(*p) for p in problems]
-multi = ctx.ba_optimize_multi(problems)
-for (ps, is_, cs, rs), (pm, im, cm, rm) in zip(singles, multi):
-    assert bytes(rs) == bytes(rm) and np.array_equal(is_, im) and np.array_equal(cs, cm)
-    for a, b in zip(ps, pm):
-        assert a.q[:] == b.q[:] and a.t[:] == b.t[:]
-got = ctx.ba_huber_deltas_multi(wins, 480.0)
-for w, g in zip(wins, got):
-    assert g == ctx.ba_huber_deltas(*w, 480.0)
-print("helpers ok", [r[3].iterations for r in multi])
-"""
-
-
-@pytest.mark.gpu
-def test_ba_multi_with_helper_threads_equals_single_calls():
-    """The batched BA calls stage their windows on the calling thread by default; HSO_HOST_PARALLEL=1 spreads staging, index checks,
-    layout and medians over the context's three helper threads (hso_ctx.h: hso_host_parallel).  Same bytes either way: four windows
-    big enough to use the helpers (the single calls stay below the threshold), in a process of their own because the switch is read
-    once per process."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSO_HOST_PARALLEL="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, "-c", _HELPERS_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "helpers ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

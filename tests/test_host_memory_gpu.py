@@ -7,8 +7,8 @@ process's GPU queues; the next launch starts 10-35 ms late.  Found in the multi-
 afterwards can have that effect.  The first test drives the caller-side pattern — multi-megabyte tables in and out through the
 direct-copy path of a value-passing call, freed at once, then a small call — and requires the small call to keep its normal
 latency.  It is a guard, not a reproduction: from a single-threaded caller glibc keeps the freed memory after the first large
-free, and the stall does not appear even with `HSO_COPY_PASSTHROUGH=1` (the measurement knob that hands pageable memory to the
-runtime as rounds 1-2 did); the reproduction is the multi-sequence run recorded in the profile note."""
+free; the reproduction is the multi-sequence run recorded in the profile note (made with a build that handed pageable memory to the
+runtime as rounds 1-2 did)."""
 import gc
 import time
 

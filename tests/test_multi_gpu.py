@@ -97,13 +97,14 @@ def test_two_sequences_started_from_images_equal_their_single_runs():
 def test_depth_filter_stream_gives_the_results_of_the_synchronous_pass(monkeypatch):
     """The idle-time pass of the depth filter (observeDepthWithPreviousFrameOnce) runs on its own stream beside the next frame's
     tracking and is collected before the first thing that reads seeds: every status record and keyframe equals the run in which
-    the pass executes inside the step (HSO_ENGINE_SYNC_PREVIOUS=1), bit for bit."""
+    the pass executes inside the step (hso_vo_options.sync_previous), bit for bit."""
     spec = synth.EUROC
     cam = synth.camera(spec)
     seqs = [synth.sequence(30, spec=spec, seed=3300 + 11 * k, step=(0.018 + 0.002 * k, 0.005, 0.006)) for k in range(3)]
 
-    def run():
+    def run(sync_previous=False):
         multi = vo.MultiVisualOdometry(cam, len(seqs), 300)
+        multi.set_options(sync_previous=sync_previous)
         multi.set_first_frames([S["images"][0] for S in seqs], [S["depth0"] for S in seqs])
         got = []
         for k in range(1, 30):
@@ -115,36 +116,9 @@ def test_depth_filter_stream_gives_the_results_of_the_synchronous_pass(monkeypat
         return got, kfs, counts
 
     overlapped, kfs_o, counts = run()
-    monkeypatch.setenv("HSO_ENGINE_SYNC_PREVIOUS", "1")
-    inside, kfs_i, _ = run()
+    inside, kfs_i, _ = run(sync_previous=True)
     assert overlapped == inside and kfs_o == kfs_i
     assert all(len(k) >= 2 for k in kfs_o) and counts["other"][0] > 10        # the pass ran (it is counted with the other calls)
-
-
-def test_local_ba_in_one_call_gives_the_results_of_the_two_calls(monkeypatch):
-    """The engine's keyframe steps send every window once (hso_gpu_ba_local_multi: Huber deltas by a radix select on the device, then
-    the optimisation); the two-call form it replaced (hso_gpu_ba_huber_deltas_multi, medians on the host, then
-    hso_gpu_ba_optimize_multi; HSO_BA_TWO_CALLS=1) gives every status record and keyframe bit for bit."""
-    spec = synth.EUROC
-    cam = synth.camera(spec)
-    seqs = [synth.sequence(40, spec=spec, seed=4400 + 13 * k, step=(0.018 + 0.002 * k, 0.005, 0.006)) for k in range(3)]
-
-    def run():
-        multi = vo.MultiVisualOdometry(cam, len(seqs), 300)
-        multi.set_first_frames([S["images"][0] for S in seqs], [S["depth0"] for S in seqs])
-        got = []
-        for k in range(1, 40):
-            multi.add_images([S["images"][k] for S in seqs], [float(k)] * len(seqs))
-            got.append([_status_bytes(multi.status(q)) for q in range(len(seqs))])
-        kfs = [[(ts, bytes(T), fid) for ts, T, fid in multi.keyframes(q)] for q in range(len(seqs))]
-        multi.close()
-        return got, kfs
-
-    one, kfs_one = run()
-    monkeypatch.setenv("HSO_BA_TWO_CALLS", "1")
-    two, kfs_two = run()
-    assert one == two and kfs_one == kfs_two
-    assert all(len(k) >= 3 for k in kfs_one)                                  # local BA ran (a window needs keyframes)
 
 
 def test_bank_of_96_at_2000_features_equals_solo_runs(monkeypatch):
@@ -152,7 +126,6 @@ def test_bank_of_96_at_2000_features_equals_solo_runs(monkeypatch):
     status record.  Both runs keep the tracker on its one-workgroup-per-job shape (what a bank that shares the device runs,
     hso_gpu_set_shared_device; a lone sequence would otherwise split its job over workgroups, whose partial sums add in another
     order: equal within the tracker's tolerance only)."""
-    monkeypatch.setenv("HSO_TRACK_NO_COOP", "1")
     spec = synth.EUROC
     cam = synth.camera(spec)
     n_frames = 18
@@ -160,10 +133,12 @@ def test_bank_of_96_at_2000_features_equals_solo_runs(monkeypatch):
     solo = []
     for S in seqs:
         odo = vo.VisualOdometry(cam, 2000)
+        odo.set_options(track_no_coop=True)
         odo.set_first_frame(S["images"][0], S["depth0"], 0.0)
         solo.append([_status_bytes(odo.add_image(S["images"][k], float(k))) for k in range(1, n_frames)])
         odo.close()
     bank = vo.MultiVisualOdometry(cam, 96, 2000)
+    bank.set_options(track_no_coop=True)
     pick = [seqs[q % 4] for q in range(96)]
     bank.set_first_frames([S["images"][0] for S in pick], [S["depth0"] for S in pick])
     for k in range(1, n_frames):

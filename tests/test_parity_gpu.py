@@ -305,7 +305,7 @@ def test_coarse_track_batch_is_deterministic_and_order_free(gpu_ctx, orc, cam, p
     jC = gpu_ctx.make_job(1, 2, pair2000["feats"][:700], capi.SE3.identity(), 1.04)
     # the one-workgroup-per-job shapes (a solo call would otherwise take the cooperative shape: tests/test_track_coop_gpu.py)
     from conftest import track_env
-    with track_env("one_wg"):
+    with track_env(gpu_ctx, "one_wg"):
         solo = [gpu_ctx.coarse_track_batch(cam, p, [j])[0] for j in (jA, jB, jC)]
         batch = gpu_ctx.coarse_track_batch(cam, p, [jA, jB, jC] * 40)
     for i, r in enumerate(batch):
@@ -334,7 +334,7 @@ def test_coarse_track_large_batch_takes_the_two_launch_path(gpu_ctx, orc, cam, p
     n = 2 * n_cu + 7
     batch = gpu_ctx.coarse_track_batch(cam, p, [jobs[i % 3] for i in range(n)])
     from conftest import track_env
-    with track_env("one_wg"):
+    with track_env(gpu_ctx, "one_wg"):
         solo = [gpu_ctx.coarse_track_batch(cam, p, [j])[0] for j in jobs]         # one launch, 512 threads
     rp, cp = orc.create_pyramid(pair2000["ref"]), orc.create_pyramid(pair2000["cur"])
     ro = orc.Tracker(cam, p, rp, cp, pair2000["feats"]).run(T0, 1.04)

@@ -60,7 +60,7 @@ def test_coop_equals_oracle_through_both_transports(gpu_ctx, orc, spec_name, n_f
     try:
         res = {}
         for mode in ("coop", "scatter", "one_wg"):
-            with track_env(mode, fpw):
+            with track_env(gpu_ctx, mode, fpw):
                 res[mode] = gpu_ctx.coarse_track_batch(cam, p, job)[0]
     finally:
         gpu_ctx.frame_release(8801); gpu_ctx.frame_release(8802)
@@ -85,7 +85,7 @@ def test_coop_placement_census(gpu_ctx, cam, pair2000):
     driver / firmware change that breaks the affinity shows up as a failed expectation, not as a silent slow-down."""
     gpu_ctx.frame_upload(8811, pair2000["ref"]); gpu_ctx.frame_upload(8812, pair2000["cur"])
     try:
-        with track_env("coop", 64):     # 2000 / 64 -> 32 workgroups per job x 8 jobs = every CU of the chip
+        with track_env(gpu_ctx, "coop", 64):     # 2000 / 64 -> 32 workgroups per job x 8 jobs = every CU of the chip
             r = gpu_ctx.coarse_track_batch(cam, capi.TrackParams(0, 4, 1, 50), [gpu_ctx.make_job(8811, 8812, pair2000["feats"], capi.SE3.identity(), 1.0)] * 8)
     finally:
         gpu_ctx.frame_release(8811); gpu_ctx.frame_release(8812)
@@ -101,7 +101,7 @@ def test_coop_result_is_free_of_batch_composition_and_repeatable(gpu_ctx, cam, p
     jB = gpu_ctx.make_job(8823, 8824, pair200["feats"], capi.SE3.identity(), 1.0)
     jC = gpu_ctx.make_job(8821, 8822, pair2000["feats"][:700], capi.SE3.identity(), 1.04)
     try:
-        with track_env("coop"):
+        with track_env(gpu_ctx, "coop"):
             solo = [gpu_ctx.coarse_track_batch(cam, p, [j])[0] for j in (jA, jB, jC)]
             order = [0, 1, 2, 2, 1, 0, 0, 1]
             for rep in range(5):
@@ -126,7 +126,7 @@ def test_coop_under_competing_load(gpu_ctx, cam, pair2000):
     big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda"); big2 = torch.empty_like(big)
     try:
         for mode, fpw in (("coop", 256), ("scatter", 256), ("scatter", 64)):
-            with track_env(mode, fpw):
+            with track_env(gpu_ctx, mode, fpw):
                 idle = gpu_ctx.coarse_track_batch(cam, p, jobs)
                 for rep in range(12):
                     with torch.cuda.stream(side):
