@@ -451,23 +451,40 @@ __global__ __launch_bounds__(64) void k_frame_stats(PyrGeom g, uint8_t* const* b
   }
 }
 
+#ifndef HSO_FRAME_CHUNK_MB
+#define HSO_FRAME_CHUNK_MB 96   // pyramid levels a chunk of frames leaves for its Sobel pass, in MB (0: one launch pair for the whole batch)
+#endif
 int hso_frame_build(hso_gpu_ctx* ctx, const PyrGeom& g, uint8_t* const* d_bases, const uint8_t* const* d_srcs,
                     hso_frame_stats* d_stats, int n)
 {
-  if ((g.w[0] % 16) == 0 && (g.h[0] % 16) == 0) {  // halfSample pyramid, src/frame.cpp:302-305
-    const int cells = (g.w[0] >> 4) * (g.h[0] >> 4);
-    dim3 gp((cells + 255) / 256, n);
-    hipLaunchKernelGGL(k_pyramid, gp, dim3(256), 0, ctx->stream, g, d_bases, d_srcs);
-  } else {                                         // cv::resize pyramid, :307-312
-    if (d_srcs) hipLaunchKernelGGL(k_copy_level0, dim3((g.w[0] * g.h[0] + 255) / 256, n), dim3(256), 0, ctx->stream, g, d_bases, d_srcs);
-    for (int l = 1; l < HSO_N_PYR_LEVELS; l++)
-      hipLaunchKernelGGL(k_resize_level, dim3((g.w[l] * g.h[l] + 255) / 256, n), dim3(256), 0, ctx->stream, g, d_bases, l);
-  }
+  // Large batches are built in chunks: the Sobel pass re-reads levels 0..2 (1.31 W H bytes per frame) that the pyramid pass has
+  // just written; with both passes over a few hundred frames at a time those bytes come out of the 256 MB Infinity Cache instead
+  // of HBM (4096 EuRoC frames leave 1.9 GB of levels: nothing of it survives to the Sobel pass of a whole-batch launch).  This
+  // is what a fused pyramid + Sobel kernel would save, without its halo bookkeeping (profiles/r6_fused_frame.md).
+  const bool half = (g.w[0] % 16) == 0 && (g.h[0] % 16) == 0;
+  const size_t per_frame = (size_t)g.pyr_bytes;
+  int chunk = n;
+  if (HSO_FRAME_CHUNK_MB > 0 && half && (size_t)n * per_frame > ((size_t)2 * HSO_FRAME_CHUNK_MB << 20))
+    chunk = (int)std::max<size_t>(64, ((size_t)HSO_FRAME_CHUNK_MB << 20) / per_frame);
   const int sob_total = g.sobel_blocks[0] + g.sobel_blocks[1] + g.sobel_blocks[2];
   bool all_fast = true;
   for (int l = 0; l < HSO_N_SOBEL_LEVELS; l++) all_fast = all_fast && (g.w[l] & 3) == 0;
-  if (all_fast) hipLaunchKernelGGL(k_sobel<true>, dim3(sob_total, n), dim3(256), 0, ctx->stream, g, d_bases);
-  else hipLaunchKernelGGL(k_sobel<false>, dim3(sob_total, n), dim3(256), 0, ctx->stream, g, d_bases);
+  for (int c0 = 0; c0 < n; c0 += chunk) {
+    const int m = std::min(chunk, n - c0);
+    uint8_t* const* bases = d_bases + c0;
+    const uint8_t* const* srcs = d_srcs ? d_srcs + c0 : nullptr;
+    if (half) {  // halfSample pyramid, src/frame.cpp:302-305
+      const int cells = (g.w[0] >> 4) * (g.h[0] >> 4);
+      dim3 gp((cells + 255) / 256, m);
+      hipLaunchKernelGGL(k_pyramid, gp, dim3(256), 0, ctx->stream, g, bases, srcs);
+    } else {                                         // cv::resize pyramid, :307-312
+      if (srcs) hipLaunchKernelGGL(k_copy_level0, dim3((g.w[0] * g.h[0] + 255) / 256, m), dim3(256), 0, ctx->stream, g, bases, srcs);
+      for (int l = 1; l < HSO_N_PYR_LEVELS; l++)
+        hipLaunchKernelGGL(k_resize_level, dim3((g.w[l] * g.h[l] + 255) / 256, m), dim3(256), 0, ctx->stream, g, bases, l);
+    }
+    if (all_fast) hipLaunchKernelGGL(k_sobel<true>, dim3(sob_total, m), dim3(256), 0, ctx->stream, g, bases);
+    else hipLaunchKernelGGL(k_sobel<false>, dim3(sob_total, m), dim3(256), 0, ctx->stream, g, bases);
+  }
   hipLaunchKernelGGL(k_frame_stats, dim3(n), dim3(64), 0, ctx->stream, g, d_bases, d_stats);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;

@@ -9,11 +9,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402,F401
 from hso_amd import bank_bench, synth  # noqa: E402
 
-runs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-banks = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-nseq = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+runs = int(args[0]) if len(args) > 0 else 3
+banks = int(args[1]) if len(args) > 1 else 6
+nseq = int(args[2]) if len(args) > 2 else 128
 seqs = synth.sequences(8, 121, spec=synth.EUROC, seed0=777)
+empty = "--empty-cache" in sys.argv
 for r in range(runs):
+    if empty:
+        import gc
+        gc.collect(); torch.cuda.empty_cache()      # is the slow first half of a process's later runs tied to torch's cached blocks?
     t0 = time.time()
     m = bank_bench.run_banks(banks, nseq, 121, 2000, seqs=seqs)
     print(json.dumps(dict(run=r, banks=banks, sequences=nseq, steady=m.get("steady_frames_per_s"), whole=m["frames_per_s"], warmup=m.get("warmup_frames_per_s"),
