@@ -563,7 +563,7 @@ def main():
 
     # HBM-side bytes of the same kernel: only a PMC record collected for exactly this workload counts
     traffic, traffic_src, valu = None, None, None
-    for fn in ("r5_pmc_k_track.json", "r4_pmc_k_track.json", "r3_pmc_k_track.json", "r2_pmc_k_track.json"):
+    for fn in ("r6_pmc_k_track.json", "r5_pmc_k_track.json", "r4_pmc_k_track.json", "r3_pmc_k_track.json", "r2_pmc_k_track.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
             for e in pmc["records"]:

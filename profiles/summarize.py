@@ -77,7 +77,7 @@ def main():
     # the bench line's roofline fraction, reproduced from the kernel-stats pass: algorithmic bytes per batch (the line's own
     # figure) / summed average duration of the tracker kernels of one batch / 8 TB/s
     line = bench_line("bench_trace.log")
-    stats = glob.glob(os.path.join(SRC, "*_kernel_stats.csv"))
+    stats = [os.path.join(SRC, TAG + "_kernel_stats.csv")] if os.path.exists(os.path.join(SRC, TAG + "_kernel_stats.csv")) else glob.glob(os.path.join(SRC, "*_kernel_stats.csv"))   # the pass of THIS tag (round 6 adds a <tag>_ic pass)
     if line and stats:
         dur = {}
         with open(stats[0]) as fh:
