@@ -368,6 +368,7 @@ def main():
                          "require it to equal the torch.distributed one; reported in bench_detail.json.  -1 (default): on when N > 1")
     ap.add_argument("--deal-features", type=int, default=0, help="experiment: > 0 = reorder every job's features by LDS bank at this pyramid level (deal_features)")
     ap.add_argument("--overlap-readback", type=int, default=1, help="1: step k's result read-back is waited for after step k + 1 is enqueued (collect_begin / _end); 0: the synchronous collect")
+    ap.add_argument("--ic-steps", type=int, default=3, help="tracker launches in inverse-compositional mode on the same pairs, reported as tracker_inverse_mode_launch_ms (0 = skip)")
     ap.add_argument("--h2d", type=int, default=1, help="1: also time the headline steps and the end-to-end run with the image upload (page-locked host memory -> HBM) inside the timed region")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
@@ -544,6 +545,20 @@ def main():
                                                      "inside the timed region, double-buffered against frame build + tracker" % B}
             del host_sets, dev_in
 
+        # ---- the tracker's other mode on the same resident pairs (untimed for `value`): the reference runs CoarseTracker in
+        # inverse-compositional mode whenever the new frame's gradient mean does not exceed the last frame's by 0.5
+        # (src/frame_handler_mono.cpp:184) — the mode the end-to-end engines spend their tracker time in
+        ic_ms = None
+        if not args.inverse and args.ic_steps > 0:
+            ctx.coarse_track_prepare(cam, capi.TrackParams(1, 4, args.min_level, 50), jobs)
+            ev_ic = [(side.event(), side.event()) for _ in range(args.ic_steps + 1)]
+            for k in range(args.ic_steps + 1):
+                ev_ic[k][0].record(stream)
+                ctx.coarse_track_launch()
+                ev_ic[k][1].record(stream)
+                ctx.coarse_track_collect(as_list=False)
+            ic_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_ic[1:]]))
+
     elapsed = hdist.max_over_ranks(t1 - t0, device=dev)
     local_fps = B * args.steps / (t1 - t0)
     per_gpu = [local_fps]
@@ -605,6 +620,8 @@ def main():
                                 "the algorithmic bytes (DESIGN.md section 3.2)",
                      "launch_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch},
     }
+    if ic_ms is not None:
+        out["tracker_inverse_mode_launch_ms"] = ic_ms     # beside roofline.launch_ms (forward mode): same pairs, same poses
     if h2d:
         out["value_with_h2d"] = h2d["value_with_h2d"]
         out["h2d_pcie_gb_per_s_per_gpu"] = h2d["pcie_gb_per_s_per_gpu"]

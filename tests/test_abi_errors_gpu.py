@@ -148,3 +148,40 @@ def test_sequence_map_arguments(gpu_ctx, pair200):
     finally:
         assert lib.hso_gpu_seqmap_destroy(h, m0.value) == 0 and lib.hso_gpu_seqmap_destroy(h, m1.value) == 0
         gpu_ctx.frame_release(9700)
+
+
+def test_options_and_debug_read_backs_refuse_bad_arguments(gpu_ctx):
+    """hso_gpu_configure (round 6: per-context options instead of environment switches) and the parity read-backs of
+    include/hso_gpu_debug.h: unknown sizes, out-of-range values and missing tables are refused, the context stays usable."""
+    lib = capi.load()
+    h = gpu_ctx.h
+    lib.hso_gpu_seqmap_debug_dump.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    assert lib.hso_gpu_configure(None, None) == E_INVALID
+    assert lib.hso_gpu_configure(h, None) == E_INVALID and "options" in _err(gpu_ctx)
+    o = capi.GpuOptions()
+    assert lib.hso_gpu_configure(h, C.byref(o)) == E_INVALID                                 # size 0: not a struct this library knows
+    o.size = C.sizeof(capi.GpuOptions) + 64
+    assert lib.hso_gpu_configure(h, C.byref(o)) == E_INVALID                                 # a newer, larger struct
+    o.size = C.sizeof(capi.GpuOptions); o.wait_mode = 9
+    assert lib.hso_gpu_configure(h, C.byref(o)) == E_INVALID and "range" in _err(gpu_ctx)
+    o.wait_mode = capi.WAIT_NAP; o.track_coop_feats_per_wg = -1
+    assert lib.hso_gpu_configure(h, C.byref(o)) == E_INVALID
+    o.track_coop_feats_per_wg = 0
+    assert lib.hso_gpu_configure(h, C.byref(o)) == 0                                         # a napping wait on a lone context is legal
+    short = capi.GpuOptions(16, capi.WAIT_DEFAULT, 1, 0)                                     # a caller built against a shorter struct: the tail defaults
+    assert lib.hso_gpu_configure(h, C.byref(short)) == 0
+    gpu_ctx.configure()
+    # the dump of a map that does not exist / a table of another size
+    buf = np.zeros(16, np.int64)
+    assert lib.hso_gpu_seqmap_debug_dump(h, 12345, 0, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == E_INVALID
+    m = C.c_int(-1)
+    assert lib.hso_gpu_seqmap_create(h, C.byref(m)) == 0
+    try:
+        assert lib.hso_gpu_seqmap_debug_dump(h, m.value, 0, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0 and buf[0] == 0 and buf[1] == 0
+        assert lib.hso_gpu_seqmap_debug_dump(h, m.value, 0, buf.ctypes.data_as(C.c_void_p), 8) == E_INVALID and "size" in _err(gpu_ctx)
+        assert lib.hso_gpu_seqmap_debug_dump(h, m.value, 99, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == E_INVALID
+        assert lib.hso_gpu_seqmap_debug_dump(h, m.value, 2, buf.ctypes.data_as(C.c_void_p), 0) == 0      # an empty point table: nothing to copy
+    finally:
+        assert lib.hso_gpu_seqmap_destroy(h, m.value) == 0
+    # a keyframe table beyond HSO_SEQ_MAX_KFS rows is refused by the chain (ADVICE r5), not silently truncated: checked on the header's constant
+    assert "HSO_SEQ_MAX_KFS 2048" in open(__import__("os").path.join(__import__("os").path.dirname(capi.__file__), "..", "include", "hso_gpu.h")).read()
