@@ -401,7 +401,7 @@ EXPORTED_SYMBOLS = [
     "hso_gpu_klt_track", "hso_gpu_klt_levels", "hso_gpu_host_alloc", "hso_gpu_host_free", "hso_gpu_seed_table_compact",
     "hso_gpu_seqmap_create", "hso_gpu_seqmap_destroy", "hso_gpu_seqmap_set_keyframes", "hso_gpu_seqmap_patch", "hso_gpu_seqmap_patch_multi", "hso_gpu_seqmap_size", "hso_gpu_seqmap_read",
     "hso_gpu_seqmap_configure", "hso_gpu_seqmap_patch_lists", "hso_gpu_seqmap_patch_links", "hso_gpu_seqmap_set_key_points",
-    "hso_gpu_seq_chain", "hso_gpu_seq_events", "hso_gpu_seq_frame_features", "hso_gpu_seq_set_frame_features",
+    "hso_gpu_seq_chain", "hso_gpu_seq_local_ba", "hso_gpu_seq_events", "hso_gpu_seq_frame_features", "hso_gpu_seq_set_frame_features",
     "hso_gpu_seed_table_observe_groups", "hso_gpu_seed_table_set_host_pose",
     "hso_gpu_seed_table_observe_previous", "hso_gpu_seed_table_observe_previous_begin", "hso_gpu_seed_table_observe_previous_end",
 ]
@@ -409,7 +409,7 @@ EXPORTED_SYMBOLS = [
 
 # ... and every symbol include/hso_gpu_debug.h declares (parity / trace read-backs, developer probes: not part of the boundary)
 DEBUG_SYMBOLS = ["hso_gpu_debug_census", "hso_gpu_klt_debug_level", "hso_gpu_seq_debug_list", "hso_gpu_seq_debug_ref_table", "hso_gpu_debug_fetch",
-                 "hso_gpu_seqmap_debug_dump"]
+                 "hso_gpu_seqmap_debug_dump", "hso_gpu_seq_ba_debug_window"]
 
 
 def select_octree(keys, width, height, n_features):

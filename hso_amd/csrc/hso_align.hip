@@ -1117,6 +1117,32 @@ int hso_seqmap_chain_view(hso_gpu_ctx* ctx, const hso_seq_job& job, SeqMapDev* o
   return HSO_OK;
 }
 
+// hso_gpu_seq_local_ba (hso_ba.hip): a map's tables as the window assembly reads them, the library's own keyframe table and the
+// lengths of the keyframes' feature lists; _ba_set_pose: a core keyframe's pose after the optimisation (the device copy of the
+// keyframe table follows with the next flush)
+int hso_seqmap_ba_view(hso_gpu_ctx* ctx, int map, SeqMapDev* out, const hso_kf** kfs_host, const int32_t** kf_nfts_host)
+{
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: no such map");
+  const int nk = (int)m->kfs.size();
+  if (nk == 0) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: the map has no keyframes");
+  if (nk > HSO_SEQ_MAX_KFS) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: the map's keyframe table exceeds HSO_SEQ_MAX_KFS rows");
+  if (m->fts_cap < 1 || m->kf_rows_cap < (size_t)nk) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: the keyframes' feature lists were never sent (hso_gpu_seqmap_patch_lists)");
+  memset(out, 0, sizeof(*out));
+  out->pts = m->d_pts; out->obs = m->d_obs; out->obs_pt = m->d_obs_pt; out->kfs = m->d_kfs; out->kf_fts = m->d_kf_fts; out->cands = m->d_cands;
+  out->first = m->d_first;
+  out->n_pts = (int)m->n_pts; out->n_obs = (int)m->n_obs; out->n_kfs = nk; out->fts_cap = m->fts_cap; out->n_cands = m->n_cands; out->ff_cap = m->ff_cap;
+  *kfs_host = m->kfs.data(); *kf_nfts_host = m->kf_nfts.data();
+  return HSO_OK;
+}
+void hso_seqmap_ba_set_pose(hso_gpu_ctx* ctx, int map, int row, const hso_se3& T)
+{
+  SeqMap* m = seqmap_of(ctx, map);
+  if (!m || row < 0 || (size_t)row >= m->kfs.size()) return;
+  m->kfs[(size_t)row].T_f_w = T;
+  if (!m->kfs_stale) { m->kfs_stale = true; ctx->seqmaps->stale_kfs.push_back(map); }
+}
+
 // the new frame's table needs room for max_fts rows in both buffers (before any view is taken)
 int hso_seqmap_chain_reserve(hso_gpu_ctx* ctx, int map, int rows)
 {

@@ -25,6 +25,7 @@
 #include <string.h>
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <vector>
 
 using namespace hso_dev;
@@ -691,14 +692,19 @@ struct BaWin {
   double huber_corner, huber_edge;
   std::vector<int> col;
   // byte offsets inside the window's device slice
-  size_t o_trial, o_poses, o_idist, o_fixed, o_edges, o_off, o_list, o_poff, o_plist, o_col, o_uv, in_bytes;
-  size_t o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc, o_bc, o_err, o_chi, o_sum, o_S, o_rhs, o_xp, o_bak, o_pbak, total;
-  // the device slice comes in two pieces: the upload images of all windows of a batch lie side by side (one copy brings them all),
-  // the work areas behind them; an offset below in_bytes is in the first piece, any other in the second
-  char* d;              // the window's upload image on the device (offsets < in_bytes)
-  char* dw;             // its work area MINUS in_bytes (so that dw + o_x is the address of a work table)
-  char* h_in;           // pinned: the window's upload image
-  char* at(size_t off) const { return off < in_bytes ? d + off : dw + off; }
+  size_t o_trial, o_poses, o_fixed, o_col, small_bytes, o_idist, o_edges, o_off, o_list, o_poff, o_plist, o_uv, o_eobs, in_bytes;
+  size_t o_lin, o_rho, o_out, o_Hpp, o_bp, o_Hpc, o_Hcc, o_bc, o_err, o_chi, o_sum, o_S, o_rhs, o_xp, o_bak, o_pbak, o_pcnt, o_cull, total;
+  int n_free = 0, n_bins = 0, n_chunks = 0;   // resident windows: free poses, their pair blocks, chunks of RBA_CHUNK edges
+  // the device slice comes in pieces.  Value-passing windows: the upload images of all windows of a batch lie side by side (one
+  // copy brings them all), the work areas behind them.  Resident windows (hso_gpu_seq_local_ba): only the head of the image — trial
+  // block, poses, fixed flags, columns: what the host writes — is uploaded (the heads lie side by side behind the batch header); the
+  // rest of the image is filled by kernels.  An offset below small_bytes is in the head, one below in_bytes in the image, any other
+  // in the work area.
+  char* ds;             // the head MINUS 0 (ds + off, off < small_bytes)
+  char* d;              // the image (d + off, small_bytes <= off < in_bytes; value-passing windows: ds == d)
+  char* dw;             // the work area MINUS in_bytes (so that dw + o_x is the address of a work table)
+  char* h_in;           // pinned: the window's upload image (value-passing) / its head (resident)
+  char* at(size_t off) const { return off < small_bytes ? ds + off : (off < in_bytes ? d + off : dw + off); }
 };
 
 struct BaBatch {
@@ -740,8 +746,9 @@ static int ba_check_edges(hso_gpu_ctx* ctx, const hso_ba_edge* edges, int n_edge
 }
 
 // sizes and offsets of one window (no device work)
+#define RBA_CHUNK 1024   // edges per workgroup of the pair-block lists' counting sort (resident windows)
 static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_fixed, int n_edges,
-                      double huber_corner, double huber_edge, bool with_uv = false)
+                      double huber_corner, double huber_edge, bool with_uv = false, bool resident = false)
 {
   B.n_poses = n_poses; B.n_points = n_points; B.n_edges = n_edges;
   B.huber_corner = huber_corner; B.huber_edge = huber_edge;
@@ -753,21 +760,24 @@ static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_f
   int n_free = 0;
   for (int i = 0; i < n_poses; i++) if (!pose_fixed[i]) B.col[i] = 6 * n_free++;
   B.M = 6 * n_free;
+  B.n_free = n_free; B.n_bins = n_free * (n_free + 1) / 2; B.n_chunks = (n_edges + RBA_CHUNK - 1) / RBA_CHUNK;
 
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   size_t o = 0;
-  // [lambda | xc | pad | poses | idist]: the trial block first, the state right behind it
+  // [lambda | xc | pad | poses | fixed | col]: the trial block first, the state right behind it; then what only goes up
   B.o_trial = o; o += al(sizeof(double) * (2 + 6 * (size_t)n_poses));   // lambda, xc, "no step" flag
   B.o_poses = o; o += al(sizeof(hso_se3) * n_poses);
-  B.o_idist = o; o += al(sizeof(double) * n_points);
   B.o_fixed = o; o += al(n_poses);
+  B.o_col = o; o += al(sizeof(int) * n_poses);
+  B.small_bytes = resident ? o : 0;
+  B.o_idist = o; o += al(sizeof(double) * n_points);
   B.o_edges = o; o += al(sizeof(hso_ba_edge) * n_edges);
   B.o_off = o; o += al(sizeof(int) * (n_points + 1));
   B.o_list = o; o += al(sizeof(int) * n_edges);
   B.o_poff = o; o += al(sizeof(int) * (n_pairs + 1));
   B.o_plist = o; o += al(sizeof(int) * 3 * (size_t)n_edges);
-  B.o_col = o; o += al(sizeof(int) * n_poses);
   B.o_uv = o; if (with_uv) o += al(sizeof(double) * 2 * (size_t)n_edges);
+  B.o_eobs = o; if (resident) o += al(sizeof(int) * (size_t)n_edges);
   B.in_bytes = o;
   B.o_lin = o; o += al(sizeof(double) * BA_LIN * n_edges);
   B.o_rho = o; o += al(sizeof(double) * n_edges);
@@ -787,6 +797,8 @@ static void ba_layout(BaWin& B, int n_poses, int n_points, const uint8_t* pose_f
   B.o_xp = o; o += al(sizeof(double) * n_points);
   B.o_bak = o; o += al(sizeof(double) * n_points);
   B.o_pbak = o; o += al(sizeof(hso_se3) * n_poses);
+  B.o_pcnt = o; if (resident) o += al(sizeof(int) * ((size_t)B.n_chunks + 1) * (size_t)std::max(B.n_bins, 1));
+  B.o_cull = o; if (resident) o += al(sizeof(int) * (2 + (size_t)n_edges));
   B.total = o;
 }
 
@@ -834,7 +846,12 @@ static bool ba_stage_window(const BaWin& B, const hso_ba_problem& P, const doubl
 }
 
 // reserve the work area and staging for all windows, upload everything that does not change between evaluations
-static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n, const double* const* obs_uv = nullptr)
+// Resident windows (hso_gpu_seq_local_ba; problems == null): `head` writes window q's head image (trial block, poses, fixed flags,
+// columns) where it is copied from, the rest of the image is the caller's kernels' to fill; extra_hdr bytes behind the batch
+// header go up with it (the caller's own per-window records: *h_extra to write them, *d_extra where they will be).
+struct BaResident { std::function<void(int, char*)> head; size_t extra_hdr = 0; char* d_extra = nullptr; char* h_extra = nullptr; };
+static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n, const double* const* obs_uv = nullptr,
+                          BaResident* res = nullptr)
 {
   Q.ctx = ctx; Q.n = n;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -842,9 +859,10 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   const size_t o_act = al(sizeof(BaProb) * (size_t)n), o_lam = o_act + al(sizeof(int) * (size_t)n * BA_N_LISTS);
   const size_t o_sums = o_lam + al(sizeof(double) * (size_t)n);
   const size_t o_hub = o_sums + al(sizeof(double) * 8 * (size_t)n);
-  size_t dev = o_hub + al(sizeof(float) * 2 * (size_t)n), pin_in = dev, pin_out = al(sizeof(double) * 8 * (size_t)n) + al(sizeof(float) * 2 * (size_t)n);
+  const size_t o_extra = o_hub + al(sizeof(float) * 2 * (size_t)n);
+  size_t dev = o_extra + al(res ? res->extra_hdr : 0), pin_in = dev, pin_out = al(sizeof(double) * 8 * (size_t)n) + al(sizeof(float) * 2 * (size_t)n);
   const size_t hdr = dev;
-  for (int q = 0; q < n; q++) { dev += Q.win[q].total; pin_in += Q.win[q].in_bytes; }
+  for (int q = 0; q < n; q++) { dev += Q.win[q].total; pin_in += res ? Q.win[q].small_bytes : Q.win[q].in_bytes; }
   if (ctx->batch_cap < dev) {  // grow-only work area of the context (shared with the other batched entry points)
     HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -866,45 +884,50 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   Q.h_sums = reinterpret_cast<double*>(ho);
   Q.d_hub = reinterpret_cast<float*>(d + o_hub);
   Q.h_hub = reinterpret_cast<float*>(ho + al(sizeof(double) * 8 * (size_t)n));
-  size_t ow = pin_in, oh = hdr;   // [header | upload images | work areas]: the pinned block mirrors the first two
+  size_t ow = pin_in, oh = hdr;   // [header | upload images (resident: their heads) | the rest]: the pinned block mirrors the first two
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
-    B.d = d + oh; B.h_in = h + oh; B.dw = d + ow - B.in_bytes;
-    ow += B.total - B.in_bytes; oh += B.in_bytes;
+    B.ds = d + oh; B.h_in = h + oh;
+    if (res) { B.d = B.dw = d + ow - B.small_bytes; ow += B.total - B.small_bytes; oh += B.small_bytes; }
+    else { B.d = B.ds; B.dw = d + ow - B.in_bytes; ow += B.total - B.in_bytes; oh += B.in_bytes; }
   }
-  // the windows' input images, assembled side by side in the page-locked block (tens of megabytes per keyframe step): ONE pass over
-  // a window's edges checks their indices, copies them and counts both adjacency tables, a second fills the tables — in place
-  std::vector<uint8_t> bad((size_t)n, 0);
-  hso_host_parallel(ctx, n, pin_in - hdr, [&](int q) {
-    if (!ba_stage_window(Q.win[q], problems[q], obs_uv ? obs_uv[q] : nullptr)) bad[(size_t)q] = 1;
-  });
-  for (int q = 0; q < n; q++)
-    if (bad[(size_t)q]) return ba_check_edges(ctx, problems[q].edges, problems[q].n_edges, problems[q].n_points, problems[q].n_poses, "ba_optimize");
+  if (res) {
+    res->d_extra = d + o_extra; res->h_extra = h + o_extra;
+    for (int q = 0; q < n; q++) res->head(q, Q.win[q].h_in);
+  } else {
+    // the windows' input images, assembled side by side in the page-locked block (tens of megabytes per keyframe step): ONE pass over
+    // a window's edges checks their indices, copies them and counts both adjacency tables, a second fills the tables — in place
+    std::vector<uint8_t> bad((size_t)n, 0);
+    hso_host_parallel(ctx, n, pin_in - hdr, [&](int q) {
+      if (!ba_stage_window(Q.win[q], problems[q], obs_uv ? obs_uv[q] : nullptr)) bad[(size_t)q] = 1;
+    });
+    for (int q = 0; q < n; q++)
+      if (bad[(size_t)q]) return ba_check_edges(ctx, problems[q].edges, problems[q].n_edges, problems[q].n_points, problems[q].n_poses, "ba_optimize");
+  }
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
     BaProb& R = hp[q];
-    char* dd = B.d;
-    R.a.poses = reinterpret_cast<const hso_se3*>(dd + B.o_poses); R.a.fixed = reinterpret_cast<const uint8_t*>(dd + B.o_fixed);
-    R.a.idist = reinterpret_cast<const double*>(dd + B.o_idist); R.a.edges = reinterpret_cast<const hso_ba_edge*>(dd + B.o_edges);
+    R.a.poses = reinterpret_cast<const hso_se3*>(B.at(B.o_poses)); R.a.fixed = reinterpret_cast<const uint8_t*>(B.at(B.o_fixed));
+    R.a.idist = reinterpret_cast<const double*>(B.at(B.o_idist)); R.a.edges = reinterpret_cast<const hso_ba_edge*>(B.at(B.o_edges));
     R.a.n_poses = B.n_poses; R.a.n_points = B.n_points; R.a.n_edges = B.n_edges;
     R.a.huber_corner = B.huber_corner; R.a.huber_edge = B.huber_edge;
     R.a.lin = reinterpret_cast<double*>(B.at(B.o_lin)); R.a.edge_err = reinterpret_cast<double*>(B.at(B.o_err));
     R.a.edge_chi2 = reinterpret_cast<double*>(B.at(B.o_chi)); R.a.edge_rho = reinterpret_cast<double*>(B.at(B.o_rho));
-    R.off = reinterpret_cast<const int*>(dd + B.o_off); R.list = reinterpret_cast<const int*>(dd + B.o_list);
-    R.poff = reinterpret_cast<const int*>(dd + B.o_poff); R.plist = reinterpret_cast<const int*>(dd + B.o_plist);
+    R.off = reinterpret_cast<const int*>(B.at(B.o_off)); R.list = reinterpret_cast<const int*>(B.at(B.o_list));
+    R.poff = reinterpret_cast<const int*>(B.at(B.o_poff)); R.plist = reinterpret_cast<const int*>(B.at(B.o_plist));
     R.Hpp = reinterpret_cast<double*>(B.at(B.o_Hpp)); R.bp = reinterpret_cast<double*>(B.at(B.o_bp));
     R.Hpc = reinterpret_cast<double*>(B.at(B.o_Hpc)); R.Hcc = reinterpret_cast<double*>(B.at(B.o_Hcc));
     R.bc = reinterpret_cast<double*>(B.at(B.o_bc)); R.sum = Q.d_sums + 8 * (size_t)q; R.lam = Q.d_lambda + q;
-    R.col = reinterpret_cast<const int*>(dd + B.o_col);
+    R.col = reinterpret_cast<const int*>(B.at(B.o_col));
     R.S = reinterpret_cast<double*>(B.at(B.o_S)); R.rhs = reinterpret_cast<double*>(B.at(B.o_rhs));
-    R.trial = reinterpret_cast<const double*>(dd + B.o_trial);
+    R.trial = reinterpret_cast<const double*>(B.at(B.o_trial));
     R.xp = reinterpret_cast<double*>(B.at(B.o_xp));
-    R.idist_rw = reinterpret_cast<double*>(dd + B.o_idist); R.idist_bak = reinterpret_cast<double*>(B.at(B.o_bak));
-    R.trial_rw = reinterpret_cast<double*>(dd + B.o_trial);
-    R.poses_rw = reinterpret_cast<hso_se3*>(dd + B.o_poses); R.poses_bak = reinterpret_cast<hso_se3*>(B.at(B.o_pbak));
+    R.idist_rw = reinterpret_cast<double*>(B.at(B.o_idist)); R.idist_bak = reinterpret_cast<double*>(B.at(B.o_bak));
+    R.trial_rw = reinterpret_cast<double*>(B.at(B.o_trial));
+    R.poses_rw = reinterpret_cast<hso_se3*>(B.at(B.o_poses)); R.poses_bak = reinterpret_cast<hso_se3*>(B.at(B.o_pbak));
     R.M = B.M; R.n_pairs = B.n_pairs;
     R.zero_begin = B.at(B.o_out); R.zero_bytes = B.o_sum + 256 - B.o_out;
-    R.uv = obs_uv ? reinterpret_cast<const double*>(dd + B.o_uv) : nullptr;
+    R.uv = (obs_uv || res) ? reinterpret_cast<const double*>(B.at(B.o_uv)) : nullptr;
     R.mad = reinterpret_cast<float*>(B.at(B.o_err)); R.hub = Q.d_hub + 2 * (size_t)q;
   }
   // the window records, the (not yet filled) launch lists and every window's upload image in ONE copy (it was one per window)
@@ -1317,6 +1340,74 @@ struct BaLm {
   }
 };
 
+// The lockstep Levenberg loop over the windows of a batch (see BaLm).  `on_final` (resident windows): called once per round with the
+// windows that finish in it, after the round's launches — it queues the write-back kernels (list slot 5 holds those windows) and adds
+// its own read-backs; without it a finishing window hands its state back to the caller's arrays.
+typedef std::function<int(const std::vector<int>& w_final, const int* dl_final, std::vector<HsoListCopy>& back)> BaFinalHook;
+static int ba_run(hso_gpu_ctx* ctx, BaBatch& Q, std::vector<BaLm>& lm, bool hub_pending, float* huber_out, const BaFinalHook* on_final)
+{
+  const int n_problems = Q.n;
+  std::vector<int> w_err, w_lin, w_trial, w_restore, w_final;
+  for (;;) {
+    w_err.clear(); w_lin.clear(); w_trial.clear(); w_restore.clear(); w_final.clear();
+    for (int q = 0; q < n_problems; q++)
+      switch (lm[q].want) {
+        case BaLm::W_ERRORS: w_err.push_back(q); break;
+        case BaLm::W_LINEARIZE: w_lin.push_back(q); w_trial.push_back(q); if (lm[q].need_restore) { w_restore.push_back(q); lm[q].need_restore = false; } break;
+        case BaLm::W_RESTORE_THEN_TRIAL: w_restore.push_back(q); w_trial.push_back(q); break;
+        case BaLm::W_TRIAL: w_trial.push_back(q); break;
+        case BaLm::W_FINAL: w_final.push_back(q); if (lm[q].need_restore) w_restore.push_back(q); break;
+        case BaLm::W_NONE: break;
+      }
+    if (w_err.empty() && w_lin.empty() && w_trial.empty() && w_final.empty()) break;
+    // this round's launch lists and the damping of its trials: ONE copy (the lists and the damping lie side by side in the header
+    // of the batch, in page-locked memory and on the device; poses and points are owned by the device during the optimisation)
+    auto fill = [&](int slot, const std::vector<int>& which) -> const int* {
+      int* hl = Q.h_active + (size_t)slot * Q.n;
+      for (size_t k = 0; k < which.size(); k++) hl[k] = which[k];
+      return Q.d_active + (size_t)slot * Q.n;
+    };
+    const int* dl_err = fill(0, w_err); const int* dl_restore = fill(1, w_restore); const int* dl_lin = fill(2, w_lin); const int* dl_trial = fill(3, w_trial);
+    const int* dl_final = fill(5, w_final);
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_active, Q.h_active, (size_t)(reinterpret_cast<char*>(Q.h_lambda + n_problems) - reinterpret_cast<char*>(Q.h_active)),
+                                      hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = ba_launch_errors(Q, 0, w_err, dl_err)) return rc;
+    if (!w_restore.empty())   // g2o's pop() after a rejected step, before anything reads the state again
+      hipLaunchKernelGGL(k_ba_restore, dim3(1, (int)w_restore.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl_restore);
+    if (int rc = ba_launch_linearize(Q, 2, w_lin, dl_lin)) return rc;
+    if (!w_trial.empty()) {
+      const int* dl = dl_trial;
+      const int ny = (int)w_trial.size(), max_m = ba_max(Q, w_trial, &BaWin::M);
+      hipLaunchKernelGGL(k_ba_schur, dim3(ba_max(Q, w_trial, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+      static bool solve_attr = false;   // 96 x 96 doubles = 72 KiB of dynamic LDS: above the 64 KiB a launch gets without asking
+      if (!solve_attr) {
+        HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * (int)sizeof(double)));
+        solve_attr = true;
+      }
+      hipLaunchKernelGGL(k_ba_solve, dim3(1, ny), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, dl);
+      hipLaunchKernelGGL(k_ba_backsub, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+      if (int rc = ba_launch_errors(Q, 4, w_trial, dl_trial)) return rc;
+    }
+    HSO_HIP_CHECK(ctx, hipGetLastError());
+    // --- results
+    // the sums of every window in one copy (windows that did nothing this round keep their old values, nobody reads them)
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_sums, Q.d_sums, sizeof(double) * 8 * (size_t)n_problems, hipMemcpyDeviceToHost, ctx->stream));
+    // the windows that finished this round hand back their state: every table of every such window in one DMA
+    std::vector<HsoListCopy> back;
+    if (on_final) { if (int rc = (*on_final)(w_final, dl_final, back)) return rc; }
+    else for (int q : w_final) {
+      const BaWin& B = Q.win[q];
+      back.push_back({lm[q].idist, B.at(B.o_idist), sizeof(double) * (size_t)B.n_points});
+      back.push_back({lm[q].poses_f_w, B.at(B.o_poses), sizeof(hso_se3) * (size_t)B.n_poses});
+      if (lm[q].edge_chi2_out) back.push_back({lm[q].edge_chi2_out, B.at(B.o_chi), sizeof(double) * (size_t)B.n_edges});
+    }
+    if (int rc = hso_lists_to_host(ctx, back)) return rc;   // synchronises (also when there is nothing to read back)
+    if (hub_pending) { memcpy(huber_out, Q.h_hub, sizeof(float) * 2 * (size_t)n_problems); hub_pending = false; }
+    for (int q = 0; q < n_problems; q++) if (lm[q].want != BaLm::W_NONE) lm[q].advance();
+  }
+  return HSO_OK;
+}
+
 // obs_uv != null: the Huber deltas are formed on the device from the windows' initial state first (hso_gpu_ba_local_multi) and
 // returned in huber_out [2 * n_problems]; the problems' own huber_corner / huber_edge are ignored then
 static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems, const double* const* obs_uv,
@@ -1363,63 +1454,7 @@ static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* proble
     L.sums = Q.h_sums + 8 * (size_t)q; L.lam_stage = Q.h_lambda + q;
     L.begin();
   }
-  std::vector<int> w_err, w_lin, w_trial, w_restore, w_final;
-  for (;;) {
-    w_err.clear(); w_lin.clear(); w_trial.clear(); w_restore.clear(); w_final.clear();
-    for (int q = 0; q < n_problems; q++)
-      switch (lm[q].want) {
-        case BaLm::W_ERRORS: w_err.push_back(q); break;
-        case BaLm::W_LINEARIZE: w_lin.push_back(q); w_trial.push_back(q); if (lm[q].need_restore) { w_restore.push_back(q); lm[q].need_restore = false; } break;
-        case BaLm::W_RESTORE_THEN_TRIAL: w_restore.push_back(q); w_trial.push_back(q); break;
-        case BaLm::W_TRIAL: w_trial.push_back(q); break;
-        case BaLm::W_FINAL: w_final.push_back(q); if (lm[q].need_restore) w_restore.push_back(q); break;
-        case BaLm::W_NONE: break;
-      }
-    if (w_err.empty() && w_lin.empty() && w_trial.empty() && w_final.empty()) break;
-    // this round's launch lists and the damping of its trials: ONE copy (the lists and the damping lie side by side in the header
-    // of the batch, in page-locked memory and on the device; poses and points are owned by the device during the optimisation)
-    auto fill = [&](int slot, const std::vector<int>& which) -> const int* {
-      int* hl = Q.h_active + (size_t)slot * Q.n;
-      for (size_t k = 0; k < which.size(); k++) hl[k] = which[k];
-      return Q.d_active + (size_t)slot * Q.n;
-    };
-    const int* dl_err = fill(0, w_err); const int* dl_restore = fill(1, w_restore); const int* dl_lin = fill(2, w_lin); const int* dl_trial = fill(3, w_trial);
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_active, Q.h_active, (size_t)(reinterpret_cast<char*>(Q.h_lambda + n_problems) - reinterpret_cast<char*>(Q.h_active)),
-                                      hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = ba_launch_errors(Q, 0, w_err, dl_err)) return rc;
-    if (!w_restore.empty())   // g2o's pop() after a rejected step, before anything reads the state again
-      hipLaunchKernelGGL(k_ba_restore, dim3(1, (int)w_restore.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl_restore);
-    if (int rc = ba_launch_linearize(Q, 2, w_lin, dl_lin)) return rc;
-    if (!w_trial.empty()) {
-      const int* dl = dl_trial;
-      const int ny = (int)w_trial.size(), max_m = ba_max(Q, w_trial, &BaWin::M);
-      hipLaunchKernelGGL(k_ba_schur, dim3(ba_max(Q, w_trial, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-      static bool solve_attr = false;   // 96 x 96 doubles = 72 KiB of dynamic LDS: above the 64 KiB a launch gets without asking
-      if (!solve_attr) {
-        HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * (int)sizeof(double)));
-        solve_attr = true;
-      }
-      hipLaunchKernelGGL(k_ba_solve, dim3(1, ny), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, dl);
-      hipLaunchKernelGGL(k_ba_backsub, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-      if (int rc = ba_launch_errors(Q, 4, w_trial, dl_trial)) return rc;
-    }
-    HSO_HIP_CHECK(ctx, hipGetLastError());
-    // --- results
-    // the sums of every window in one copy (windows that did nothing this round keep their old values, nobody reads them)
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_sums, Q.d_sums, sizeof(double) * 8 * (size_t)n_problems, hipMemcpyDeviceToHost, ctx->stream));
-    // the windows that finished this round hand back their state: every table of every such window in one DMA
-    std::vector<HsoListCopy> back;
-    for (int q : w_final) {
-      const BaWin& B = Q.win[q];
-      back.push_back({lm[q].idist, B.d + B.o_idist, sizeof(double) * (size_t)B.n_points});
-      back.push_back({lm[q].poses_f_w, B.d + B.o_poses, sizeof(hso_se3) * (size_t)B.n_poses});
-      if (lm[q].edge_chi2_out) back.push_back({lm[q].edge_chi2_out, B.at(B.o_chi), sizeof(double) * (size_t)B.n_edges});
-    }
-    if (int rc = hso_lists_to_host(ctx, back)) return rc;   // synchronises (also when there is nothing to read back)
-    if (hub_pending) { memcpy(huber_out, Q.h_hub, sizeof(float) * 2 * (size_t)n_problems); hub_pending = false; }
-    for (int q = 0; q < n_problems; q++) if (lm[q].want != BaLm::W_NONE) lm[q].advance();
-  }
-  return HSO_OK;
+  return ba_run(ctx, Q, lm, hub_pending, huber_out, nullptr);
 }
 
 extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems)
@@ -1444,4 +1479,605 @@ extern "C" int hso_gpu_ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses_f_w, const u
   P.edges = edges; P.n_edges = n_edges; P.huber_corner = huber_corner; P.huber_edge = huber_edge; P.n_iter = n_iter;
   P.edge_chi2_out = edge_chi2_out; P.result = result;
   return hso_gpu_ba_optimize_multi(ctx, &P, 1);
+}
+
+// ================================================================================================================================
+// ba::LocalBundleAdjustment on a sequence map (hso_gpu_seq_local_ba; src/bundle_adjustment.cpp:577-892): the window is assembled
+// from the map's resident tables by the kernels below, optimised by the kernels and the driver above, and written back here.
+//   stage A (one wait): k_rba_mark -> k_rba_compact -> k_rba_count -> k_rba_sizes: the window's points (ascending rows), the edges per
+//            point, the vertex of every keyframe (first appearance in the reference's walk), the three sizes;
+//   stage B: k_rba_fill (state, edges, the by-point table), k_rba_pairs<false> -> k_rba_pair_scan -> k_rba_pairs<true> (the edges of
+//            every pose-pair block whose two poses are free, ascending — a stable counting sort; blocks with a fixed pose are never
+//            read, k_ba_poses leaves before it looks at their list);
+//   stage C (with the loop's last round): k_rba_writeback (idist_, pos_ into the point rows and out), k_rba_cull (:855-892's inputs).
+#define RBA_MAX_POSES 512        // vertices of a window the sizing read-back names (the dense Hcc table of 512 poses is 75 MB)
+#define RBA_SIZES (4 + RBA_MAX_POSES)
+#define RBA_NO_KEY 0xffffffffffffffffull
+#define RBA_CULL_FIRST 2046      // culled observations that ride in the final read-back; a longer list costs one more copy
+#define RBA_MAX_BINS (HSO_SEQ_BA_MAX_CORE * (HSO_SEQ_BA_MAX_CORE + 1) / 2)
+
+struct RbaJobDev {
+  hso_map_point* pts; const hso_obs* obs; const int32_t* obs_pt; const int32_t* kf_fts;
+  int n_pts, n_obs, n_kfs, fts_cap;
+  int n_core, nb;                                // nb: bound of the window's points (rows of ids / eoff / idist0 / state)
+  int core[HSO_SEQ_BA_MAX_CORE], core_len[HSO_SEQ_BA_MAX_CORE];
+  int32_t* mark;                                 // [n_pts] 1: a feature of a core keyframe observes the point
+  int32_t* ids;                                  // [nb] the window's points, ascending
+  int32_t* eoff;                                 // [nb + 1] edges per point, then their exclusive prefix
+  unsigned long long* fkey;                      // [n_kfs] (window point << 32 | position in its walk) of a keyframe's first appearance
+  int32_t* vtx;                                  // [n_kfs] vertex of a keyframe row, -1: not in the window
+  int32_t* sizes;                                // [RBA_SIZES] n_points, n_edges, n_poses, overflow flag, then the vertices' rows
+  double* idist0;                                // [nb] idist_ before the optimisation (hso_gpu_seq_ba_debug_window)
+  double* state;                                 // [4 * nb] idist, pos after it
+};
+struct RbaWinDev {
+  RbaJobDev J;
+  double* idist; hso_ba_edge* edges; double* uv; int* off; int* list; int* poff; int* plist; int* eobs; int* pcnt; int* cull;
+  const int* col; const hso_se3* poses; const double* chi2;
+  int n_points, n_edges, n_poses, n_pairs, n_free, n_bins, n_chunks, pad_;
+  double chi2_corner, chi2_edgelet;
+};
+
+// exclusive prefix of v over the workgroup (W wavefronts), total = the sum; s_wave: W ints
+template <int W> __device__ inline int rba_scan(int v, int* s_wave, int& total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) { const int c = s_wave[w]; if (w < wave) base += c; tot += c; }
+  total = tot;
+  __syncthreads();
+  return base + x - v;
+}
+
+// :592-616: the core keyframes are vertices 0 .. n_core-1; every point one of their features observes is in the window
+__global__ __launch_bounds__(256) void k_rba_mark(const RbaJobDev* jobs)
+{
+  const RbaJobDev& J = jobs[blockIdx.y];
+  const int c = blockIdx.z;
+  if (c >= J.n_core) return;
+  const int r = J.core[c];
+  if (blockIdx.x == 0 && threadIdx.x == 0) J.vtx[r] = c;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= J.core_len[c]) return;
+  const int f = J.kf_fts[(size_t)r * J.fts_cap + t];
+  if (f < 0 || f >= J.n_obs) return;
+  const int p = J.obs_pt[f];
+  if (p >= 0 && p < J.n_pts) J.mark[p] = 1;
+}
+
+// the window's points in ascending row order (one workgroup per job)
+__global__ __launch_bounds__(1024) void k_rba_compact(const RbaJobDev* jobs)
+{
+  __shared__ int s_wave[16];
+  const RbaJobDev& J = jobs[blockIdx.x];
+  int n = 0;
+  for (int base = 0; base < J.n_pts; base += 1024) {
+    const int p = base + (int)threadIdx.x;
+    const int m = (p < J.n_pts && J.mark[p]) ? 1 : 0;
+    int tot;
+    const int pos = n + rba_scan<16>(m, s_wave, tot);
+    if (m && pos < J.nb) J.ids[pos] = p;
+    n += tot;
+  }
+  if (threadIdx.x == 0) J.sizes[0] = n < J.nb ? n : J.nb;
+}
+
+// :690-812, first pass: per window point its edges (observations in keyframes other than the host's) and, for every keyframe outside
+// the core that the walk meets, where it meets it first
+__global__ __launch_bounds__(256) void k_rba_count(const RbaJobDev* jobs)
+{
+  const RbaJobDev& J = jobs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= J.sizes[0]) return;
+  const hso_map_point& P = J.pts[J.ids[i]];
+  const int hk = P.host_kf;
+  if (hk >= 0 && hk < J.n_kfs && J.vtx[hk] < 0) atomicMin(&J.fkey[hk], (unsigned long long)i << 32);
+  int cnt = 0, row = P.obs_begin;
+  for (int q = 0; q < P.obs_count; q++) {
+    if (row < 0 || row >= J.n_obs) break;
+    const int kf = J.obs[row].kf, next = J.obs[row].pad_;
+    if (kf != hk && kf >= 0 && kf < J.n_kfs) {
+      cnt++;
+      if (J.vtx[kf] < 0) atomicMin(&J.fkey[kf], ((unsigned long long)i << 32) | (unsigned)(q + 1));
+    }
+    row = next;
+  }
+  J.eoff[i] = cnt;
+}
+
+// the edges' offsets per point, the vertices of the keyframes outside the core in order of first appearance, the sizes
+__global__ __launch_bounds__(1024) void k_rba_sizes(const RbaJobDev* jobs)
+{
+  __shared__ int s_wave[16];
+  __shared__ unsigned long long s_key[HSO_SEQ_MAX_KFS];
+  __shared__ int s_extra;
+  const RbaJobDev& J = jobs[blockIdx.x];
+  const int np = J.sizes[0], tid = threadIdx.x;
+  int n = 0;
+  for (int base = 0; base < np; base += 1024) {
+    const int i = base + tid;
+    const int v = i < np ? J.eoff[i] : 0;
+    int tot;
+    const int ex = rba_scan<16>(v, s_wave, tot);
+    if (i < np) J.eoff[i] = n + ex;
+    n += tot;
+  }
+  if (tid == 0) { J.eoff[np] = n; J.sizes[1] = n; s_extra = 0; }
+  for (int r = tid; r < J.n_kfs; r += 1024) s_key[r] = J.fkey[r];
+  __syncthreads();
+  for (int r = tid; r < J.n_kfs; r += 1024) {
+    const unsigned long long k = s_key[r];
+    if (k == RBA_NO_KEY) continue;
+    int rank = 0;
+    for (int o = 0; o < J.n_kfs; o++) rank += s_key[o] < k ? 1 : 0;
+    const int v = J.n_core + rank;
+    J.vtx[r] = v;
+    if (v < RBA_MAX_POSES) J.sizes[4 + v] = r;
+    atomicAdd(&s_extra, 1);
+  }
+  if (tid < J.n_core) J.sizes[4 + tid] = J.core[tid];
+  __syncthreads();
+  if (tid == 0) { const int nv = J.n_core + s_extra; J.sizes[2] = nv; J.sizes[3] = nv > RBA_MAX_POSES ? 1 : 0; }
+}
+
+// :690-812, second pass: the window's state and edges (the reference's setHostBearing / setMeasurement / setTargetNormal /
+// information, bundle_adjustment.cpp:740-800), the by-point table (an edge list in point order IS grouped by point)
+__global__ __launch_bounds__(256) void k_rba_fill(const RbaWinDev* wins)
+{
+  const RbaWinDev& W = wins[blockIdx.y];
+  const RbaJobDev& J = W.J;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W.n_points) return;
+  const hso_map_point& P = J.pts[J.ids[i]];
+  W.idist[i] = P.idist; J.idist0[i] = P.idist;
+  int k = J.eoff[i];
+  W.off[i] = k;
+  if (i == 0) W.off[W.n_points] = W.n_edges;
+  const int hk = P.host_kf;
+  const int vh = (hk >= 0 && hk < J.n_kfs) ? J.vtx[hk] : 0;
+  int row = P.obs_begin;
+  for (int q = 0; q < P.obs_count; q++) {
+    if (row < 0 || row >= J.n_obs) break;
+    const hso_obs ob = J.obs[row];
+    if (ob.kf != hk && ob.kf >= 0 && ob.kf < J.n_kfs) {
+      hso_ba_edge e;
+      e.point = i; e.host = vh; e.target = J.vtx[ob.kf];
+      e.type = ob.type == HSO_FTR_EDGELET ? HSO_FTR_EDGELET : HSO_FTR_CORNER;
+      e.level = ob.level; e._pad = 0;
+      e.fH[0] = P.host_f[0]; e.fH[1] = P.host_f[1]; e.fH[2] = P.host_f[2];
+      const double u = ob.f[0] / ob.f[2], v = ob.f[1] / ob.f[2];
+      if (e.type == HSO_FTR_EDGELET) { e.normal[0] = ob.grad[0]; e.normal[1] = ob.grad[1]; e.meas[0] = ob.grad[0] * u + ob.grad[1] * v; e.meas[1] = 0.0; }
+      else { e.normal[0] = 1.0; e.normal[1] = 0.0; e.meas[0] = u; e.meas[1] = v; }
+      W.edges[k] = e; W.uv[2 * k] = u; W.uv[2 * k + 1] = v; W.eobs[k] = row; W.list[k] = k;
+      k++;
+    }
+    row = ob.pad_;
+  }
+}
+
+// The edges of every pose-pair block, ascending (the order the value-passing call's host-built table has, so that the sums of
+// k_ba_poses are formed in the same order): a stable counting sort over the blocks of two FREE poses — at most 16 of them, 136 blocks.
+// An edge belongs to (h, h), (t, t) and (min, max).  A workgroup takes RBA_CHUNK edges as 16 slices of 64; inside a slice a lane's
+// rank in a block's list = the number of lower lanes in the same block (one ballot per distinct block of the slice).
+// SCATTER = false: the chunk's count per block.  SCATTER = true: the same ranks again, now behind the chunk's and the slice's base.
+__device__ inline int rba_bin(int a, int b, int nf) { return a * nf - a * (a - 1) / 2 + (b - a); }   // a <= b
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_rba_pairs(const RbaWinDev* wins)
+{
+  __shared__ unsigned short s_cnt[16][RBA_MAX_BINS];
+  __shared__ int s_base[RBA_MAX_BINS];
+  const RbaWinDev& W = wins[blockIdx.y];
+  const int chunk = blockIdx.x;
+  if (chunk >= W.n_chunks || W.n_bins == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nf = W.n_free, nb = W.n_bins;
+  for (int q = tid; q < 16 * RBA_MAX_BINS; q += 256) (&s_cnt[0][0])[q] = 0;
+  __syncthreads();
+  int key[4][3], rnk[4][3];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int sl = r * 4 + wave, e = chunk * RBA_CHUNK + sl * 64 + lane;
+    int k0 = -1, k1 = -1, k2 = -1;
+    if (e < W.n_edges) {
+      const int ch = W.col[W.edges[e].host], ct = W.col[W.edges[e].target];
+      const int fh = ch >= 0 ? ch / 6 : -1, ft = ct >= 0 ? ct / 6 : -1;
+      if (fh >= 0) k0 = rba_bin(fh, fh, nf);
+      if (ft >= 0) k1 = rba_bin(ft, ft, nf);
+      if (fh >= 0 && ft >= 0) k2 = fh < ft ? rba_bin(fh, ft, nf) : rba_bin(ft, fh, nf);
+    }
+    key[r][0] = k0; key[r][1] = k1; key[r][2] = k2;
+    int p0 = k0, p1 = k1, p2 = k2, r0 = 0, r1 = 0, r2 = 0;
+    for (;;) {
+      int mine = 0x7fffffff;
+      if (p0 >= 0) mine = p0;
+      if (p1 >= 0 && p1 < mine) mine = p1;
+      if (p2 >= 0 && p2 < mine) mine = p2;
+      const unsigned long long any = __ballot(mine != 0x7fffffff);
+      if (!any) break;
+      const int B = __shfl(mine, __ffsll((long long)any) - 1);
+      const bool hit = p0 == B || p1 == B || p2 == B;
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (p0 == B) { r0 = rank; p0 = -1; } else if (p1 == B) { r1 = rank; p1 = -1; } else { r2 = rank; p2 = -1; }
+      }
+      if (lane == 0) s_cnt[sl][B] = (unsigned short)__popcll(m);
+    }
+    rnk[r][0] = r0; rnk[r][1] = r1; rnk[r][2] = r2;
+  }
+  __syncthreads();
+  if (!SCATTER) {
+    for (int b = tid; b < nb; b += 256) { int t = 0; for (int sl = 0; sl < 16; sl++) t += s_cnt[sl][b]; W.pcnt[(size_t)chunk * nb + b] = t; }
+    return;
+  }
+  for (int b = tid; b < nb; b += 256) {
+    int run = 0;
+    for (int sl = 0; sl < 16; sl++) { const int c = s_cnt[sl][b]; s_cnt[sl][b] = (unsigned short)run; run += c; }
+    s_base[b] = W.pcnt[(size_t)W.n_chunks * nb + b] + W.pcnt[(size_t)chunk * nb + b];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int sl = r * 4 + wave, e = chunk * RBA_CHUNK + sl * 64 + lane;
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { const int b = key[r][kk]; if (b >= 0) W.plist[s_base[b] + s_cnt[sl][b] + rnk[r][kk]] = e; }
+  }
+}
+
+// per block: the chunks' counts become offsets inside the block's list, the blocks' totals the lists' starts (row n_chunks of the
+// table); then the offset of EVERY pose pair of the window (k_ba_poses reads two of them before it asks whether a pose is fixed):
+// a pair with a fixed pose owns no entries
+__global__ __launch_bounds__(256) void k_rba_pair_scan(const RbaWinDev* wins)
+{
+  __shared__ int s_tot[RBA_MAX_BINS + 1];
+  __shared__ int s_cf[HSO_SEQ_BA_MAX_CORE + 1];
+  const RbaWinDev& W = wins[blockIdx.x];
+  const int tid = threadIdx.x, nb = W.n_bins, nf = W.n_free, np = W.n_poses;
+  for (int b = tid; b < nb; b += 256) {
+    int run = 0;
+    for (int c = 0; c < W.n_chunks; c++) { const int v = W.pcnt[(size_t)c * nb + b]; W.pcnt[(size_t)c * nb + b] = run; run += v; }
+    s_tot[b] = run;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 0; b < nb; b++) { const int v = s_tot[b]; s_tot[b] = run; run += v; }
+    s_tot[nb] = run;
+    int cf = 0;   // free poses below vertex v (they are all among the core: v <= n_core)
+    for (int v = 0; v <= HSO_SEQ_BA_MAX_CORE; v++) { s_cf[v] = cf; if (v < np && v < HSO_SEQ_BA_MAX_CORE && W.col[v] >= 0) cf++; }
+  }
+  __syncthreads();
+  for (int b = tid; b < nb; b += 256) W.pcnt[(size_t)W.n_chunks * nb + b] = s_tot[b];
+  // pair (i, j), i <= j, has id i * np - i (i - 1) / 2 + (j - i); the free-free blocks before it: those of the free rows below i, and
+  // in row i (when i is free) the free columns in [i, j)
+  for (int i = 0; i < np; i++) {
+    const int ci = s_cf[i < HSO_SEQ_BA_MAX_CORE ? i : HSO_SEQ_BA_MAX_CORE];
+    const bool fi = i < HSO_SEQ_BA_MAX_CORE && W.col[i] >= 0;
+    const int row0 = ci * nf - ci * (ci - 1) / 2;
+    const int pid0 = i * np - i * (i - 1) / 2;
+    for (int j = i + tid; j < np; j += 256) {
+      const int cj = s_cf[j < HSO_SEQ_BA_MAX_CORE ? j : HSO_SEQ_BA_MAX_CORE];
+      W.poff[pid0 + (j - i)] = s_tot[row0 + (fi ? cj - ci : 0)];
+    }
+  }
+  if (tid == 0) W.poff[W.n_pairs] = s_tot[nb];
+}
+
+// :826-853: idist_ and pos_ = T_host^-1 * (host_f * (1 / idist)) of the window's points, into the map's rows and out
+__global__ __launch_bounds__(256) void k_rba_writeback(const RbaWinDev* wins, const int* active)
+{
+  const RbaWinDev& W = wins[active[blockIdx.y]];
+  const RbaJobDev& J = W.J;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W.n_points) return;
+  hso_map_point& P = J.pts[J.ids[i]];
+  const double idv = W.idist[i];
+  const int hk = P.host_kf;
+  const int vh = (hk >= 0 && hk < J.n_kfs) ? J.vtx[hk] : 0;
+  const Se3 inv = se3_inverse(se3_from(W.poses[vh]));
+  const double s = 1.0 / idv;
+  double x, y, z;
+  se3_apply(inv, P.host_f[0] * s, P.host_f[1] * s, P.host_f[2] * s, x, y, z);
+  P.idist = idv; P.pos[0] = x; P.pos[1] = y; P.pos[2] = z;
+  double* o = J.state + 4 * (size_t)i;
+  o[0] = idv; o[1] = x; o[2] = y; o[3] = z;
+}
+
+// :855-892: the observations of the edges above the threshold, corner edges first, in edge order (one workgroup per window)
+__global__ __launch_bounds__(1024) void k_rba_cull(const RbaWinDev* wins, const int* active)
+{
+  __shared__ int s_wave[16];
+  const RbaWinDev& W = wins[active[blockIdx.x]];
+  int n = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const int n0 = n;
+    for (int base = 0; base < W.n_edges; base += 1024) {
+      const int e = base + (int)threadIdx.x;
+      int m = 0;
+      if (e < W.n_edges) {
+        const bool edgelet = W.edges[e].type == HSO_FTR_EDGELET;
+        m = (edgelet == (pass == 1) && W.chi2[e] > (edgelet ? W.chi2_edgelet : W.chi2_corner)) ? 1 : 0;
+      }
+      int tot;
+      const int pos = n + rba_scan<16>(m, s_wave, tot);
+      if (m) W.cull[2 + pos] = W.eobs[e];
+      n += tot;
+    }
+    if (threadIdx.x == 0) W.cull[pass] = n - n0;
+  }
+}
+
+// what the last call of a context left for hso_gpu_seq_ba_debug_window
+struct RbaLast {
+  struct Win {
+    int status = 1, n_poses = 0, n_points = 0, n_edges = 0;
+    std::vector<int32_t> rows; std::vector<uint8_t> fixed; std::vector<hso_se3> poses_in;
+    const hso_ba_edge* d_edges = nullptr; const double* d_uv = nullptr; const int* d_eobs = nullptr; const double* d_chi2 = nullptr;
+    const hso_se3* d_poses = nullptr; const double* d_idist0 = nullptr;
+  };
+  std::vector<Win> win;
+};
+
+void hso_rba_forget(hso_gpu_ctx* ctx)
+{
+  if (ctx->d_rba) (void)hipFree(ctx->d_rba);
+  ctx->d_rba = nullptr; ctx->rba_cap = 0;
+  delete ctx->rba_last;
+  ctx->rba_last = nullptr;
+}
+
+extern "C" int hso_gpu_seq_local_ba(hso_gpu_ctx* ctx, const hso_seq_ba_job* jobs, int n_jobs, double error_multiplier2, double chi2_corner,
+                                    double chi2_edgelet, hso_seq_ba_result* results)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (n_jobs < 0 || (n_jobs > 0 && (!jobs || !results))) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: bad argument");
+  if (ctx->rba_last) ctx->rba_last->win.clear();
+  if (n_jobs == 0) return HSO_OK;
+  HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  // ---- the jobs against their maps; the per-job tables of stage A
+  std::vector<SeqMapDev> view((size_t)n_jobs);
+  std::vector<const hso_kf*> kfs_host((size_t)n_jobs);
+  std::vector<RbaJobDev> hj((size_t)n_jobs);
+  size_t zero_bytes = 0, ones_bytes = 0, rest_bytes = 0;
+  int max_len = 1, max_core = 1, max_nb = 1;
+  for (int j = 0; j < n_jobs; j++) {
+    const hso_seq_ba_job& A = jobs[j];
+    if (A.n_core < 1 || A.n_core > HSO_SEQ_BA_MAX_CORE || A.n_iter < 0 || A.point_cap < 0 || A.cull_cap < 0 || (A.point_cap > 0 && (!A.point_ids || !A.point_state)) ||
+        (A.cull_cap > 0 && !A.culled))
+      return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: bad argument");
+    for (int i = 0; i < j; i++) if (jobs[i].map == A.map) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: a map appears twice");
+    const int32_t* nfts = nullptr;
+    if (int rc = hso_seqmap_ba_view(ctx, A.map, &view[(size_t)j], &kfs_host[(size_t)j], &nfts)) return rc;
+    const SeqMapDev& M = view[(size_t)j];
+    RbaJobDev& J = hj[(size_t)j];
+    memset(&J, 0, sizeof(J));
+    J.pts = M.pts; J.obs = M.obs; J.obs_pt = M.obs_pt; J.kf_fts = M.kf_fts;
+    J.n_pts = M.n_pts; J.n_obs = M.n_obs; J.n_kfs = M.n_kfs; J.fts_cap = M.fts_cap; J.n_core = A.n_core;
+    size_t len = 0;
+    for (int c = 0; c < A.n_core; c++) {
+      if (A.core[c] < 0 || A.core[c] >= M.n_kfs) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: no such keyframe row");
+      for (int k = 0; k < c; k++) if (A.core[k] == A.core[c]) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: a core keyframe appears twice");
+      J.core[c] = A.core[c]; J.core_len[c] = nfts[A.core[c]];
+      len += (size_t)J.core_len[c]; max_len = std::max(max_len, J.core_len[c]);
+    }
+    J.nb = (int)std::min<size_t>(len, (size_t)M.n_pts);
+    max_core = std::max(max_core, A.n_core); max_nb = std::max(max_nb, J.nb);
+    zero_bytes += al(sizeof(int32_t) * (size_t)M.n_pts);
+    ones_bytes += al(sizeof(unsigned long long) * (size_t)M.n_kfs) + al(sizeof(int32_t) * (size_t)M.n_kfs);
+    rest_bytes += al(sizeof(int32_t) * (size_t)J.nb) + al(sizeof(int32_t) * ((size_t)J.nb + 1)) + al(sizeof(double) * (size_t)J.nb) + al(sizeof(double) * 4 * (size_t)J.nb);
+  }
+  const size_t sz_bytes = sizeof(int32_t) * RBA_SIZES * (size_t)n_jobs;   // the jobs' sizes side by side: one copy brings them
+  const size_t o_jobs = 0, o_sizes = al(sizeof(RbaJobDev) * (size_t)n_jobs), o_zero = o_sizes + al(sz_bytes), o_ones = o_zero + zero_bytes, o_rest = o_ones + ones_bytes,
+               need = o_rest + rest_bytes;
+  if (ctx->rba_cap < need) {
+    HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_rba) (void)hipFree(ctx->d_rba);
+    ctx->d_rba = nullptr; ctx->rba_cap = 0;
+    HSO_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_rba), hso_grown(need)));
+    ctx->rba_cap = hso_grown(need);
+  }
+  char* dr = ctx->d_rba;
+  {
+    size_t z = o_zero, o = o_ones, r = o_rest;
+    for (int j = 0; j < n_jobs; j++) {
+      RbaJobDev& J = hj[(size_t)j];
+      J.mark = reinterpret_cast<int32_t*>(dr + z); z += al(sizeof(int32_t) * (size_t)J.n_pts);
+      J.fkey = reinterpret_cast<unsigned long long*>(dr + o); o += al(sizeof(unsigned long long) * (size_t)J.n_kfs);
+      J.vtx = reinterpret_cast<int32_t*>(dr + o); o += al(sizeof(int32_t) * (size_t)J.n_kfs);
+      J.ids = reinterpret_cast<int32_t*>(dr + r); r += al(sizeof(int32_t) * (size_t)J.nb);
+      J.eoff = reinterpret_cast<int32_t*>(dr + r); r += al(sizeof(int32_t) * ((size_t)J.nb + 1));
+      J.sizes = reinterpret_cast<int32_t*>(dr + o_sizes) + RBA_SIZES * (size_t)j;
+      J.idist0 = reinterpret_cast<double*>(dr + r); r += al(sizeof(double) * (size_t)J.nb);
+      J.state = reinterpret_cast<double*>(dr + r); r += al(sizeof(double) * 4 * (size_t)J.nb);
+    }
+  }
+  char* hp0 = hso_pinned(ctx, 0, sizeof(RbaJobDev) * (size_t)n_jobs);
+  char* hp1 = hso_pinned(ctx, 1, std::max<size_t>(sz_bytes, 256));
+  if (!hp0 || !hp1) return HSO_E_NOMEM;
+  memcpy(hp0, hj.data(), sizeof(RbaJobDev) * (size_t)n_jobs);
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(dr + o_jobs, hp0, sizeof(RbaJobDev) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+  if (zero_bytes) HSO_HIP_CHECK(ctx, hipMemsetAsync(dr + o_zero, 0, zero_bytes, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipMemsetAsync(dr + o_ones, 0xff, ones_bytes, ctx->stream));
+  const RbaJobDev* d_jobs = reinterpret_cast<const RbaJobDev*>(dr + o_jobs);
+  hipLaunchKernelGGL(k_rba_mark, dim3((max_len + 255) / 256, n_jobs, max_core), dim3(256), 0, ctx->stream, d_jobs);
+  hipLaunchKernelGGL(k_rba_compact, dim3(n_jobs), dim3(1024), 0, ctx->stream, d_jobs);
+  hipLaunchKernelGGL(k_rba_count, dim3((max_nb + 255) / 256, n_jobs), dim3(256), 0, ctx->stream, d_jobs);
+  hipLaunchKernelGGL(k_rba_sizes, dim3(n_jobs), dim3(1024), 0, ctx->stream, d_jobs);
+  HSO_HIP_CHECK(ctx, hipGetLastError());
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(hp1, dr + o_sizes, sz_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<int32_t> sizes(reinterpret_cast<int32_t*>(hp1), reinterpret_cast<int32_t*>(hp1) + RBA_SIZES * (size_t)n_jobs);   // (the pinned blocks serve the batch next)
+
+  // ---- the windows that have something to optimise
+  if (!ctx->rba_last) ctx->rba_last = new RbaLast();
+  RbaLast& last = *ctx->rba_last;
+  last.win.assign((size_t)n_jobs, RbaLast::Win());
+  std::vector<int> act;                          // window q of the batch = job act[q]
+  for (int j = 0; j < n_jobs; j++) {
+    const int32_t* sz = &sizes[RBA_SIZES * (size_t)j];
+    hso_seq_ba_result& R = results[j];
+    memset(&R, 0, sizeof(R));
+    R.n_points = sz[0]; R.n_edges = sz[1]; R.n_poses = sz[2];
+    if (sz[3]) return hso_fail(ctx, HSO_E_UNSUPPORTED, "seq_local_ba: more than 512 keyframes in one window");
+    if (R.n_points > jobs[j].point_cap) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: point_cap is smaller than the window");
+    RbaLast::Win& L = last.win[(size_t)j];
+    L.n_poses = R.n_poses; L.n_points = R.n_points; L.n_edges = R.n_edges;
+    L.rows.assign(sz + 4, sz + 4 + R.n_poses);
+    L.fixed.assign((size_t)R.n_poses, 1);
+    for (int c = 0; c < jobs[j].n_core; c++) L.fixed[(size_t)c] = jobs[j].fixed[c] ? 1 : 0;
+    L.poses_in.resize((size_t)R.n_poses);
+    for (int v = 0; v < R.n_poses; v++) L.poses_in[(size_t)v] = kfs_host[(size_t)j][L.rows[(size_t)v]].T_f_w;
+    for (int c = 0; c < jobs[j].n_core; c++) R.core_pose[c] = L.poses_in[(size_t)c];
+    R.status = (R.n_edges > 0 && R.n_points > 0) ? 0 : 1;
+    L.status = R.status;
+    if (R.status == 0) act.push_back(j);
+  }
+  const int nw = (int)act.size();
+  std::vector<HsoListCopy> back;
+  if (nw == 0) {
+    for (int j = 0; j < n_jobs; j++) back.push_back({jobs[j].point_ids, hj[(size_t)j].ids, sizeof(int32_t) * (size_t)results[j].n_points});
+    return hso_lists_to_host(ctx, back);
+  }
+  BaBatch Q;
+  Q.win.resize((size_t)nw);
+  for (int q = 0; q < nw; q++) {
+    const RbaLast::Win& L = last.win[(size_t)act[q]];
+    ba_layout(Q.win[(size_t)q], L.n_poses, L.n_points, L.fixed.data(), L.n_edges, 0.0, 0.0, true, true);
+    if (Q.win[(size_t)q].M > 96) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: more than 16 free poses in one window");
+  }
+  BaResident res;
+  res.extra_hdr = sizeof(RbaWinDev) * (size_t)nw;
+  res.head = [&](int q, char* w) {
+    const BaWin& B = Q.win[(size_t)q];
+    const RbaLast::Win& L = last.win[(size_t)act[q]];
+    memset(w + B.o_trial, 0, B.o_poses - B.o_trial);
+    memcpy(w + B.o_poses, L.poses_in.data(), sizeof(hso_se3) * (size_t)B.n_poses);
+    memcpy(w + B.o_fixed, L.fixed.data(), (size_t)B.n_poses);
+    memcpy(w + B.o_col, B.col.data(), sizeof(int) * (size_t)B.n_poses);
+  };
+  if (int rc = ba_batch_begin(Q, ctx, nullptr, nw, nullptr, &res)) return rc;
+  // (ba_batch_begin has queued the header's copy; the records behind the header were not written yet: they go up now)
+  RbaWinDev* hw = reinterpret_cast<RbaWinDev*>(res.h_extra);
+  int max_np = 1, max_chunks = 1;
+  for (int q = 0; q < nw; q++) {
+    const BaWin& B = Q.win[(size_t)q];
+    RbaWinDev& W = hw[q];
+    memset(&W, 0, sizeof(W));
+    W.J = hj[(size_t)act[q]];
+    W.idist = reinterpret_cast<double*>(B.at(B.o_idist)); W.edges = reinterpret_cast<hso_ba_edge*>(B.at(B.o_edges)); W.uv = reinterpret_cast<double*>(B.at(B.o_uv));
+    W.off = reinterpret_cast<int*>(B.at(B.o_off)); W.list = reinterpret_cast<int*>(B.at(B.o_list)); W.poff = reinterpret_cast<int*>(B.at(B.o_poff));
+    W.plist = reinterpret_cast<int*>(B.at(B.o_plist)); W.eobs = reinterpret_cast<int*>(B.at(B.o_eobs)); W.pcnt = reinterpret_cast<int*>(B.at(B.o_pcnt));
+    W.cull = reinterpret_cast<int*>(B.at(B.o_cull)); W.col = reinterpret_cast<const int*>(B.at(B.o_col)); W.poses = reinterpret_cast<const hso_se3*>(B.at(B.o_poses));
+    W.chi2 = reinterpret_cast<const double*>(B.at(B.o_chi));
+    W.n_points = B.n_points; W.n_edges = B.n_edges; W.n_poses = B.n_poses; W.n_pairs = B.n_pairs; W.n_free = B.n_free; W.n_bins = B.n_bins; W.n_chunks = B.n_chunks;
+    W.chi2_corner = chi2_corner; W.chi2_edgelet = chi2_edgelet;
+    max_np = std::max(max_np, B.n_points); max_chunks = std::max(max_chunks, B.n_chunks);
+    RbaLast::Win& L = last.win[(size_t)act[q]];
+    L.d_edges = W.edges; L.d_uv = W.uv; L.d_eobs = W.eobs; L.d_chi2 = W.chi2; L.d_poses = W.poses; L.d_idist0 = W.J.idist0;
+  }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(res.d_extra, res.h_extra, sizeof(RbaWinDev) * (size_t)nw, hipMemcpyHostToDevice, ctx->stream));
+  const RbaWinDev* d_wins = reinterpret_cast<const RbaWinDev*>(res.d_extra);
+  hipLaunchKernelGGL(k_rba_fill, dim3((max_np + 255) / 256, nw), dim3(256), 0, ctx->stream, d_wins);
+  hipLaunchKernelGGL(k_rba_pairs<false>, dim3(max_chunks, nw), dim3(256), 0, ctx->stream, d_wins);
+  hipLaunchKernelGGL(k_rba_pair_scan, dim3(nw), dim3(256), 0, ctx->stream, d_wins);
+  hipLaunchKernelGGL(k_rba_pairs<true>, dim3(max_chunks, nw), dim3(256), 0, ctx->stream, d_wins);
+  // :618-680: the Huber deltas of the windows' initial state
+  {
+    int max_edges = 0;
+    for (int q = 0; q < nw; q++) max_edges = std::max(max_edges, Q.win[(size_t)q].n_edges);
+    hipLaunchKernelGGL(k_ba_mad_errors_win, dim3((max_edges + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs);
+    hipLaunchKernelGGL(k_ba_mad_select, dim3(nw), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, error_multiplier2);
+    HSO_HIP_CHECK(ctx, hipGetLastError());
+    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_hub, Q.d_hub, sizeof(float) * 2 * (size_t)nw, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  std::vector<BaLm> lm((size_t)nw);
+  std::vector<float> hub(2 * (size_t)nw);
+  std::vector<std::vector<int32_t>> cull((size_t)nw);
+  std::vector<std::vector<hso_se3>> poses_out((size_t)nw);
+  for (int q = 0; q < nw; q++) {
+    const BaWin& B = Q.win[(size_t)q];
+    BaLm& L = lm[(size_t)q];
+    L.B = &Q.win[(size_t)q]; L.poses_f_w = nullptr; L.pose_fixed = last.win[(size_t)act[q]].fixed.data(); L.idist = nullptr;
+    L.n_poses = B.n_poses; L.n_points = B.n_points; L.n_edges = B.n_edges; L.n_iter = jobs[act[q]].n_iter;
+    L.edge_chi2_out = nullptr; L.result = &results[act[q]].lm;
+    L.sums = Q.h_sums + 8 * (size_t)q; L.lam_stage = Q.h_lambda + q;
+    L.begin();
+    cull[(size_t)q].assign(2 + (size_t)std::min(B.n_edges, RBA_CULL_FIRST), 0);
+    poses_out[(size_t)q].resize((size_t)jobs[act[q]].n_core);
+  }
+  const BaFinalHook on_final = [&](const std::vector<int>& w_final, const int* dl_final, std::vector<HsoListCopy>& out) -> int {
+    if (w_final.empty()) return HSO_OK;
+    int np = 1;
+    for (int q : w_final) np = std::max(np, Q.win[(size_t)q].n_points);
+    hipLaunchKernelGGL(k_rba_writeback, dim3((np + 255) / 256, (int)w_final.size()), dim3(256), 0, ctx->stream, d_wins, dl_final);
+    hipLaunchKernelGGL(k_rba_cull, dim3((int)w_final.size()), dim3(1024), 0, ctx->stream, d_wins, dl_final);
+    HSO_HIP_CHECK(ctx, hipGetLastError());
+    for (int q : w_final) {
+      const BaWin& B = Q.win[(size_t)q];
+      const hso_seq_ba_job& A = jobs[act[q]];
+      const RbaJobDev& J = hj[(size_t)act[q]];
+      out.push_back({A.point_ids, J.ids, sizeof(int32_t) * (size_t)B.n_points});
+      out.push_back({A.point_state, J.state, sizeof(double) * 4 * (size_t)B.n_points});
+      out.push_back({poses_out[(size_t)q].data(), B.at(B.o_poses), sizeof(hso_se3) * (size_t)A.n_core});
+      out.push_back({cull[(size_t)q].data(), B.at(B.o_cull), sizeof(int32_t) * cull[(size_t)q].size()});
+    }
+    return HSO_OK;
+  };
+  if (int rc = ba_run(ctx, Q, lm, true, hub.data(), &on_final)) return rc;
+  // ---- what the caller mirrors
+  for (int q = 0; q < nw; q++) {
+    const int j = act[q];
+    const hso_seq_ba_job& A = jobs[j];
+    hso_seq_ba_result& R = results[j];
+    const BaWin& B = Q.win[(size_t)q];
+    R.huber_corner = hub[2 * (size_t)q]; R.huber_edge = hub[2 * (size_t)q + 1];
+    for (int c = 0; c < A.n_core; c++) { R.core_pose[c] = poses_out[(size_t)q][(size_t)c]; hso_seqmap_ba_set_pose(ctx, A.map, A.core[c], R.core_pose[c]); }
+    R.n_culled[0] = cull[(size_t)q][0]; R.n_culled[1] = cull[(size_t)q][1];
+    const int nc = R.n_culled[0] + R.n_culled[1], first = (int)cull[(size_t)q].size() - 2;
+    for (int e = 0; e < nc && e < first && e < A.cull_cap; e++) A.culled[e] = cull[(size_t)q][2 + (size_t)e];
+    if (nc > first && A.cull_cap > first) {      // a list longer than what rode in the final read-back: the rest in its own copy
+      const int more = std::min(nc, A.cull_cap) - first;
+      HSO_HIP_CHECK(ctx, hso_copy_sync(A.culled + first, reinterpret_cast<const int32_t*>(B.at(B.o_cull)) + 2 + first, sizeof(int32_t) * (size_t)more, hipMemcpyDeviceToHost));
+    }
+  }
+  // the windows that were left alone still name their points
+  back.clear();
+  for (int j = 0; j < n_jobs; j++) if (results[j].status != 0) back.push_back({jobs[j].point_ids, hj[(size_t)j].ids, sizeof(int32_t) * (size_t)results[j].n_points});
+  if (!back.empty()) return hso_lists_to_host(ctx, back);
+  return HSO_OK;
+}
+
+extern "C" int hso_gpu_seq_ba_debug_window(hso_gpu_ctx* ctx, int job, int what, void* out, size_t bytes)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!ctx->rba_last || job < 0 || (size_t)job >= ctx->rba_last->win.size() || !out) return hso_fail(ctx, HSO_E_INVALID, "seq_ba_debug_window: bad argument");
+  const RbaLast::Win& L = ctx->rba_last->win[(size_t)job];
+  const int32_t sizes[4] = {L.n_poses, L.n_points, L.n_edges, L.status};
+  const void* host = nullptr; const void* dev = nullptr; size_t have = 0;
+  switch (what) {
+    case HSO_BAW_SIZES: host = sizes; have = sizeof(sizes); break;
+    case HSO_BAW_VERTEX_ROWS: host = L.rows.data(); have = sizeof(int32_t) * L.rows.size(); break;
+    case HSO_BAW_FIXED: host = L.fixed.data(); have = L.fixed.size(); break;
+    case HSO_BAW_POSES_IN: host = L.poses_in.data(); have = sizeof(hso_se3) * L.poses_in.size(); break;
+    case HSO_BAW_EDGES: dev = L.d_edges; have = sizeof(hso_ba_edge) * (size_t)L.n_edges; break;
+    case HSO_BAW_OBS_UV: dev = L.d_uv; have = sizeof(double) * 2 * (size_t)L.n_edges; break;
+    case HSO_BAW_EDGE_OBS: dev = L.d_eobs; have = sizeof(int32_t) * (size_t)L.n_edges; break;
+    case HSO_BAW_EDGE_CHI2: dev = L.d_chi2; have = sizeof(double) * (size_t)L.n_edges; break;
+    case HSO_BAW_POSES_OUT: dev = L.d_poses; have = sizeof(hso_se3) * (size_t)L.n_poses; break;
+    case HSO_BAW_IDIST_IN: dev = L.d_idist0; have = sizeof(double) * (size_t)L.n_points; break;
+    default: return hso_fail(ctx, HSO_E_INVALID, "seq_ba_debug_window: no such table");
+  }
+  if (L.status != 0 && !host) have = 0;          // a window that was left alone has no device tables
+  if (have != bytes) return hso_fail(ctx, HSO_E_INVALID, "seq_ba_debug_window: bytes differs from the table's size");
+  HSO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (bytes == 0) return HSO_OK;
+  if (host) { memcpy(out, host, bytes); return HSO_OK; }
+  HSO_HIP_CHECK(ctx, hso_copy_sync(out, dev, bytes, hipMemcpyDeviceToHost));
+  return HSO_OK;
 }

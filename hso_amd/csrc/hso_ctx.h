@@ -64,6 +64,9 @@ struct hso_gpu_ctx {
   SeqMaps* seqmaps;
   // staging for batched frame uploads: [bases | srcs | stats]
   char* d_batch; size_t batch_cap;
+  // hso_gpu_seq_local_ba: the window assembly's per-job tables (they outlive the batch's own area: the write-back reads them), and what
+  // hso_gpu_seq_ba_debug_window serves
+  char* d_rba = nullptr; size_t rba_cap = 0; struct RbaLast* rba_last = nullptr;
   // between the three kernels of a seed observation (hso_seed.hip): [SeedPre | SeedMid] per seed, grow-only
   char* d_seed_scratch; size_t seed_scratch_cap;
   // The depth filter's own stream (the reference runs it on its own thread, src/depth_filter.cpp:130-162): the previous-frame pass
@@ -217,6 +220,8 @@ struct AlignJobDev;
 // a map's device view for one chain job; flips the map's frame-feature tables (the previous new frame becomes the reference)
 int hso_seqmap_flush_kfs(hso_gpu_ctx* ctx);   // the keyframe tables that changed since the last chain, in one copy + one launch
 int hso_seqmap_chain_view(hso_gpu_ctx* ctx, const hso_seq_job& job, SeqMapDev* out, int* n_kfs, const int32_t** kf_nfts_host);
+int hso_seqmap_ba_view(hso_gpu_ctx* ctx, int map, SeqMapDev* out, const hso_kf** kfs_host, const int32_t** kf_nfts_host);   // hso_gpu_seq_local_ba
+void hso_seqmap_ba_set_pose(hso_gpu_ctx* ctx, int map, int row, const hso_se3& T);
 int hso_seqmap_chain_reserve(hso_gpu_ctx* ctx, int map, int rows);        // room for `rows` features in the map's two frame tables (before any view)
 void hso_seqmap_chain_commit(hso_gpu_ctx* ctx, const hso_seq_job& job, int n_feats);   // after a successful call: the new frame's table is the map's newest
 // stage launchers (asynchronous on the context's stream); d_* are device pointers into the work area
@@ -231,6 +236,7 @@ int hso_chain_front_launch(hso_gpu_ctx* ctx, const hso_camera* cam, const ChainF
 size_t hso_chain_sizeof_reproj_kf();
 size_t hso_chain_sizeof_align_job();
 PyrGeom hso_seqmaps_geom(hso_gpu_ctx* ctx, bool* have);
+void hso_rba_forget(hso_gpu_ctx* ctx);     // hso_ba.hip: the same for hso_gpu_seq_local_ba
 void hso_chain_forget(hso_gpu_ctx* ctx);   // hso_select.hip: drop what the last chain call of a context left (context teardown)
 // hso_seed.hip: the frame a group of a resident seed table is observed in (cur_base == null: the group sits the observation out)
 struct SeedFrameDev {

@@ -348,6 +348,7 @@ void hso_gpu_destroy(hso_gpu_ctx* ctx)
   hso_chain_forget(ctx);
   for (auto* p : ctx->frame_slabs) (void)hipFree(p);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+  hso_rba_forget(ctx);
   if (ctx->d_seed_scratch) (void)hipFree(ctx->d_seed_scratch);
   if (ctx->seed_stream) { (void)hipStreamSynchronize(ctx->seed_stream); (void)hipStreamDestroy(ctx->seed_stream); }
   if (ctx->seed_go) (void)hipEventDestroy(ctx->seed_go);

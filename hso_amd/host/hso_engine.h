@@ -197,6 +197,7 @@ private:
   void prepare_job(int k, hso_seq_job& job, std::vector<int32_t>& temps);
   void consume_result(int k, const hso_seq_result& r, const std::vector<int32_t>& more_events);
   void trace_chain(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const hso_seq_result* res);
+  void trace_ba_state(const std::vector<int>& who, const std::vector<hso_seq_ba_job>& jobs, double error_multiplier2, double chi2_corner, double chi2_edgelet);
   void trace_chain_state(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const std::vector<int32_t>& temps);
   void fetch_features(const std::vector<int>& who);
   void send_features(const std::vector<int>& who);
@@ -208,7 +209,7 @@ private:
   void link_covisible(int k, bool is_keyframe);
   void promote(int k);
   void make_keyframe(Seq& s, Id fr);
-  void assemble_window(int k);
+  void window_job(int k);
   void keyframe_ba(const std::vector<int>& who);
   void apply_window(int k);
   void observe_seeds(const std::vector<int>& who);

@@ -422,9 +422,10 @@ struct StepData {
   size_t n_inliers = 0;
   double depth_mean = 0, depth_min = 0, dist_mean = 0;
   // keyframe: the local BA window
-  std::vector<Id> ba_frames; std::vector<uint8_t> ba_fixed; std::vector<hso_se3> ba_poses;
-  std::vector<Id> ba_points; std::vector<double> ba_idist;
-  std::vector<hso_ba_edge> ba_edges; std::vector<Id> ba_edge_feat; std::vector<double> ba_uv, ba_chi2;
+  std::vector<Id> ba_frames; std::vector<uint8_t> ba_fixed;        // the core keyframes (vertex order)
+  std::vector<Id> ba_points; std::vector<double> ba_state;          // out: the window's points, their idist + pos after the optimisation
+  std::vector<Id> ba_culled;                                        // out: observations to remove
+  hso_seq_ba_result ba{};
   hso_ba_result ba_res{};
   float huber_corner = 0, huber_edge = 0;
   int ba_iters = 0;

@@ -259,34 +259,68 @@ void Bank::initialise(const std::vector<int>& who)
 // built from them).
 // hso_vo_trace_state: the sequence map exactly as the device holds it right before a chain call, with the job and the call's
 // configuration (tests/test_seq_chain.py rebuilds the state in a fresh context and in the restatement and compares the two calls)
+namespace {
+// a sequence map exactly as the device holds it (hso_gpu_seqmap_debug_dump), as eleven fields of a trace record
+struct MapDump {
+  int64_t sz[HSO_DUMP_N_SIZES];
+  std::vector<hso_kf> kfs; std::vector<hso_map_point> pts; std::vector<hso_obs> obs;
+  std::vector<int32_t> obs_pt, keys, nfts, lists, cands;
+  std::vector<hso_seq_feature> ff0, ff1;
+  static constexpr int kFields = 11;
+  MapDump(hso_gpu_ctx* ctx, int map, const std::function<void(int, const char*)>& check)
+  {
+    check(hso_gpu_seqmap_debug_dump(ctx, map, HSO_DUMP_SIZES, sz, sizeof(sz)), "trace");
+    const size_t nk = (size_t)sz[0], np = (size_t)sz[1], no = (size_t)sz[2], cap = (size_t)sz[3], nc = (size_t)sz[4];
+    kfs.resize(nk); pts.resize(np); obs.resize(no); obs_pt.resize(no); keys.resize(5 * nk); nfts.resize(nk); lists.resize(nk * cap); cands.resize(nc);
+    ff0.resize((size_t)sz[5]); ff1.resize((size_t)sz[6]);
+    auto get = [&](int what, void* out, size_t bytes) { if (bytes) check(hso_gpu_seqmap_debug_dump(ctx, map, what, out, bytes), "trace"); };
+    get(HSO_DUMP_KFS, kfs.data(), sizeof(hso_kf) * nk); get(HSO_DUMP_POINTS, pts.data(), sizeof(hso_map_point) * np); get(HSO_DUMP_OBS, obs.data(), sizeof(hso_obs) * no);
+    get(HSO_DUMP_OBS_POINT, obs_pt.data(), 4 * no); get(HSO_DUMP_KEY_POINTS, keys.data(), 4 * keys.size()); get(HSO_DUMP_KF_NFTS, nfts.data(), 4 * nk);
+    get(HSO_DUMP_KF_FTS, lists.data(), 4 * lists.size()); get(HSO_DUMP_CANDS, cands.data(), 4 * nc);
+    get(HSO_DUMP_FRAME_FEATS0, ff0.data(), sizeof(hso_seq_feature) * ff0.size()); get(HSO_DUMP_FRAME_FEATS1, ff1.data(), sizeof(hso_seq_feature) * ff1.size());
+  }
+  void fields(Trace& t) const
+  {
+    t.field("sizes", sz, sizeof(sz)); t.field("kfs", kfs.data(), sizeof(hso_kf) * kfs.size()); t.field("points", pts.data(), sizeof(hso_map_point) * pts.size());
+    t.field("obs", obs.data(), sizeof(hso_obs) * obs.size()); t.field("obs_point", obs_pt.data(), 4 * obs_pt.size()); t.field("key_points", keys.data(), 4 * keys.size());
+    t.field("kf_nfts", nfts.data(), 4 * nfts.size()); t.field("kf_fts", lists.data(), 4 * lists.size()); t.field("cands", cands.data(), 4 * cands.size());
+    t.field("frame_feats0", ff0.data(), sizeof(hso_seq_feature) * ff0.size()); t.field("frame_feats1", ff1.data(), sizeof(hso_seq_feature) * ff1.size());
+  }
+};
+}  // namespace
+
 void Bank::trace_chain_state(const std::vector<int>& who, const std::vector<hso_seq_job>& jobs, const hso_seq_chain_cfg& cfg, const std::vector<int32_t>& temps)
 {
   for (size_t i = 0; i < who.size(); i++) {
     Seq& s = *seq_[who[i]];
     if (!s.trace.on() || !s.trace.state) continue;
-    int64_t sz[HSO_DUMP_N_SIZES];
-    check(hso_gpu_seqmap_debug_dump(ctx_, s.map, HSO_DUMP_SIZES, sz, sizeof(sz)), "trace");
-    const size_t nk = (size_t)sz[0], np = (size_t)sz[1], no = (size_t)sz[2], cap = (size_t)sz[3], nc = (size_t)sz[4];
-    std::vector<hso_kf> kfs(nk); std::vector<hso_map_point> pts(np); std::vector<hso_obs> obs(no);
-    std::vector<int32_t> obs_pt(no), keys(5 * nk), nfts(nk), lists(nk * cap), cands(nc);
-    std::vector<hso_seq_feature> ff0((size_t)sz[5]), ff1((size_t)sz[6]);
-    auto get = [&](int what, void* out, size_t bytes) { if (bytes) check(hso_gpu_seqmap_debug_dump(ctx_, s.map, what, out, bytes), "trace"); };
-    get(HSO_DUMP_KFS, kfs.data(), sizeof(hso_kf) * nk); get(HSO_DUMP_POINTS, pts.data(), sizeof(hso_map_point) * np); get(HSO_DUMP_OBS, obs.data(), sizeof(hso_obs) * no);
-    get(HSO_DUMP_OBS_POINT, obs_pt.data(), 4 * no); get(HSO_DUMP_KEY_POINTS, keys.data(), 4 * keys.size()); get(HSO_DUMP_KF_NFTS, nfts.data(), 4 * nk);
-    get(HSO_DUMP_KF_FTS, lists.data(), 4 * lists.size()); get(HSO_DUMP_CANDS, cands.data(), 4 * nc);
-    get(HSO_DUMP_FRAME_FEATS0, ff0.data(), sizeof(hso_seq_feature) * ff0.size()); get(HSO_DUMP_FRAME_FEATS1, ff1.data(), sizeof(hso_seq_feature) * ff1.size());
+    const MapDump dump(ctx_, s.map, [this](int rc, const char* what) { check(rc, what); });
     const hso_seq_job& jb = jobs[i];
     const int32_t none = 0;
     Trace& t = s.trace;
-    t.begin("seq_chain_state", 17);
+    t.begin("seq_chain_state", 6 + MapDump::kFields);
     t.field("cam", &cam_.pod(), sizeof(hso_camera)); t.field("job", &jb, sizeof(jb)); t.field("cfg", &cfg, sizeof(cfg));
     t.field("cell_order", cell_order_.data(), sizeof(int32_t) * cell_order_.size());
     t.field("temps", jb.n_temps > 0 ? temps.data() + jb.temps_begin : &none, sizeof(int32_t) * (size_t)jb.n_temps);
-    t.field("sizes", sz, sizeof(sz)); t.field("kfs", kfs.data(), sizeof(hso_kf) * nk); t.field("points", pts.data(), sizeof(hso_map_point) * np);
-    t.field("obs", obs.data(), sizeof(hso_obs) * no); t.field("obs_point", obs_pt.data(), 4 * no); t.field("key_points", keys.data(), 4 * keys.size());
-    t.field("kf_nfts", nfts.data(), 4 * nk); t.field("kf_fts", lists.data(), 4 * lists.size()); t.field("cands", cands.data(), 4 * nc);
-    t.field("frame_feats0", ff0.data(), sizeof(hso_seq_feature) * ff0.size()); t.field("frame_feats1", ff1.data(), sizeof(hso_seq_feature) * ff1.size());
+    dump.fields(t);
     t.scalar("max_fts", cfg_.max_fts);
+  }
+}
+
+// the same before a hso_gpu_seq_local_ba call: the map, the window's core and what the call is asked (tests/test_seq_ba.py)
+void Bank::trace_ba_state(const std::vector<int>& who, const std::vector<hso_seq_ba_job>& jobs, double error_multiplier2, double chi2_corner, double chi2_edgelet)
+{
+  for (size_t i = 0; i < who.size(); i++) {
+    Seq& s = *seq_[who[i]];
+    if (!s.trace.on() || !s.trace.state) continue;
+    const MapDump dump(ctx_, s.map, [this](int rc, const char* what) { check(rc, what); });
+    const hso_seq_ba_job& jb = jobs[i];
+    Trace& t = s.trace;
+    t.begin("seq_ba_state", 7 + MapDump::kFields);
+    t.field("core", jb.core, sizeof(int32_t) * (size_t)jb.n_core); t.field("fixed", jb.fixed, (size_t)jb.n_core);
+    t.scalar("n_iter", jb.n_iter); t.scalar("error_multiplier2", error_multiplier2); t.scalar("chi2_corner", chi2_corner); t.scalar("chi2_edgelet", chi2_edgelet);
+    t.scalar("point_cap", jb.point_cap);
+    dump.fields(t);
   }
 }
 

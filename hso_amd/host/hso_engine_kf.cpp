@@ -7,130 +7,113 @@ namespace hso {
 namespace engine {
 
 // ------------------------------------------------------------------------------------------------ local BA
-// ba::LocalBundleAdjustment's graph (src/bundle_adjustment.cpp:592-812) as flat tables: the window's keyframes first (the
-// reference walks std::set<Frame*> / std::set<Point*> in address order; frame serials and point ids give a run-independent one),
-// then every keyframe that hosts or observes one of their points, fixed.
-void Bank::assemble_window(int k)
+// ba::LocalBundleAdjustment (src/bundle_adjustment.cpp:577-892) runs on the sequence's resident map (hso_gpu_seq_local_ba): the
+// engine names the window's core keyframes — the reference walks std::set<Frame*> in address order; frame serials give a
+// run-independent one — and which of them are fixed (:595), and mirrors what comes back.
+void Bank::window_job(int k)
 {
   Seq& s = *seq_[k];
   StepData& d = *step_[k];
   const Frame& C = s.frames[s.cur];
   std::vector<Id> core = s.local_map;
   std::sort(core.begin(), core.end(), [&](Id a, Id b) { return s.frames[a].serial < s.frames[b].serial; });
-  std::vector<int> vertex(s.frames.size(), -1);
-  std::vector<uint8_t> in_window(s.points.size(), 0);
-  d.ba_frames.clear(); d.ba_fixed.clear(); d.ba_points.clear(); d.ba_edges.clear(); d.ba_edge_feat.clear(); d.ba_uv.clear();
+  if (core.size() > HSO_SEQ_BA_MAX_CORE) throw Refused("LocalBundleAdjustment: more core keyframes than the reduced system holds");
+  d.ba_frames = core;
+  d.ba_fixed.clear();
+  size_t cap = 0;
   for (Id kf : core) {
     const Frame& K = s.frames[kf];
-    vertex[kf] = (int)d.ba_frames.size();
-    d.ba_frames.push_back(kf);
     d.ba_fixed.push_back((K.serial == 0 || K.kf_id + 20 < C.kf_id) ? 1 : 0);   // :595
-    for (Id f : K.fts) if (s.feats[f].point != kNone) in_window[(size_t)s.feats[f].point] = 1;
+    cap += K.fts.size();
   }
-  for (size_t p = 0; p < in_window.size(); p++) if (in_window[p]) d.ba_points.push_back((Id)p);   // ascending point ids, each once
-  auto vertex_of = [&](Id fr) {
-    if (vertex[fr] < 0) { vertex[fr] = (int)d.ba_frames.size(); d.ba_frames.push_back(fr); d.ba_fixed.push_back(1); }   // :700-737
-    return vertex[fr];
-  };
-  d.ba_idist.resize(d.ba_points.size());
-  for (size_t i = 0; i < d.ba_points.size(); i++) {
-    Point& P = s.points[d.ba_points[i]];
-    d.ba_idist[i] = P.idist;
-    P.n_ba++;
-    const Feat& host = s.feats[P.host];
-    const int vh = vertex_of(host.frame);
-    for (Id o = P.head; o != kNone; o = s.feats[o].next) {
-      const Feat& ob = s.feats[o];
-      if (ob.frame == host.frame) continue;
-      hso_ba_edge e{};
-      e.point = (int)i; e.host = vh; e.target = vertex_of(ob.frame);
-      e.type = ob.type == HSO_FTR_EDGELET ? HSO_FTR_EDGELET : HSO_FTR_CORNER;
-      e.level = ob.level;
-      e.fH[0] = host.f[0]; e.fH[1] = host.f[1]; e.fH[2] = host.f[2];
-      const double u = ob.f[0] / ob.f[2], v = ob.f[1] / ob.f[2];
-      if (e.type == HSO_FTR_EDGELET) { e.normal[0] = ob.grad[0]; e.normal[1] = ob.grad[1]; e.meas[0] = ob.grad[0] * u + ob.grad[1] * v; }
-      else { e.normal[0] = 1; e.normal[1] = 0; e.meas[0] = u; e.meas[1] = v; }
-      d.ba_edges.push_back(e); d.ba_edge_feat.push_back(o);
-      d.ba_uv.push_back(u); d.ba_uv.push_back(v);
-    }
-  }
-  d.ba_poses.resize(d.ba_frames.size());
-  for (size_t i = 0; i < d.ba_frames.size(); i++) d.ba_poses[i] = s.frames[d.ba_frames[i]].T.v;
-  d.ba_chi2.assign(d.ba_edges.size(), 0.0);
+  d.ba_points.assign(std::min(cap, s.points.size()), kNone);
+  d.ba_state.assign(4 * d.ba_points.size(), 0.0);
+  d.ba_culled.assign(s.feats.size(), kNone);
   d.ba_iters = 100;                                               // :815-823
   if (s.kfs.size() > 5) d.ba_iters = C.fts.size() < 100 ? cfg_.loba_num_iter + 10 : cfg_.loba_num_iter;
   d.n_core = (int)core.size();
 }
 
-void Bank::keyframe_ba(const std::vector<int>& who)
+void Bank::keyframe_ba(const std::vector<int>& all)
 {
   previous_collect();                                              // the keyframes' new poses go to the seed table below
-  std::vector<int> with;
-  for (int k : who) if (!step_[k]->ba_edges.empty() && !step_[k]->ba_points.empty()) with.push_back(k);
+  std::vector<int> who;
+  for (int k : all) if (step_[k]->n_core > 0) who.push_back(k);
   const double fmean = cam_.errorMultiplier2();
-  std::vector<std::vector<hso_se3>> poses_in(with.size());
-  std::vector<std::vector<double>> idist_in(with.size());
-  // the Huber deltas and the optimisation of every window of the step in one device call (hso_gpu_ba_local_multi: the windows go
-  // up once, the medians are taken on the device)
-  // a traced sequence records the window's state before the optimisation moves it
-  for (size_t i = 0; i < with.size(); i++)
-    if (seq_[with[i]]->trace.on()) { poses_in[i] = step_[with[i]]->ba_poses; idist_in[i] = step_[with[i]]->ba_idist; }
-  if (!with.empty()) {
-    std::vector<hso_ba_problem> pr(with.size());
-    std::vector<const double*> uv(with.size());
-    for (size_t i = 0; i < with.size(); i++) {
-      StepData& d = *step_[with[i]];
-      hso_ba_problem& p = pr[i];
-      p.poses_f_w = d.ba_poses.data(); p.pose_fixed = d.ba_fixed.data(); p.idist = d.ba_idist.data(); p.edges = d.ba_edges.data();
-      p.edge_chi2_out = d.ba_chi2.data(); p.result = &d.ba_res;
-      p.n_poses = (int)d.ba_poses.size(); p.n_points = (int)d.ba_idist.size(); p.n_edges = (int)d.ba_edges.size(); p.n_iter = d.ba_iters;
-      p.huber_corner = d.huber_corner; p.huber_edge = d.huber_edge;
-      uv[i] = d.ba_uv.data();
-    }
-    {
-      Sub t(this, "ba: local call");
-      std::vector<float> hub(2 * with.size());
-      check(hso_gpu_ba_local_multi(ctx_, pr.data(), uv.data(), (int)pr.size(), fmean, hub.data()), "LocalBundleAdjustment");
-      for (size_t i = 0; i < with.size(); i++) { step_[with[i]]->huber_corner = hub[2 * i]; step_[with[i]]->huber_edge = hub[2 * i + 1]; }
-    }
-    n_calls_[8]++; n_items_[8] += (int64_t)pr.size();
+  const double tight = 1.2 / fmean, loose = 2.0 / fmean;           // :855-892
+  std::vector<hso_seq_ba_job> jobs(who.size());
+  std::vector<hso_seq_ba_result> res(who.size());
+  for (size_t i = 0; i < who.size(); i++) {
+    Seq& s = *seq_[who[i]];
+    StepData& d = *step_[who[i]];
+    hso_seq_ba_job& J = jobs[i];
+    memset(&J, 0, sizeof(J));
+    J.map = s.map; J.n_core = d.n_core;
+    for (int c = 0; c < d.n_core; c++) { J.core[c] = s.frames[d.ba_frames[(size_t)c]].kf_row; J.fixed[c] = d.ba_fixed[(size_t)c]; }
+    J.n_iter = d.ba_iters;
+    J.point_cap = (int32_t)d.ba_points.size(); J.cull_cap = (int32_t)d.ba_culled.size();
+    J.point_ids = d.ba_points.data(); J.point_state = d.ba_state.data(); J.culled = d.ba_culled.data();
   }
-  for (size_t i = 0; i < with.size(); i++) {
-    Seq& s = *seq_[with[i]];
-    StepData& d = *step_[with[i]];
-    if (s.trace.on()) {
-      Trace& t = s.trace;
-      t.begin("ba_huber_deltas", 7);
-      t.field("poses", poses_in[i].data(), sizeof(hso_se3) * poses_in[i].size()); t.field("idist", idist_in[i].data(), sizeof(double) * idist_in[i].size());
-      t.field("edges", d.ba_edges.data(), sizeof(hso_ba_edge) * d.ba_edges.size()); t.field("obs_uv", d.ba_uv.data(), sizeof(double) * d.ba_uv.size());
-      t.scalar("error_multiplier2", fmean); t.scalar("huber_corner", d.huber_corner); t.scalar("huber_edge", d.huber_edge);
-    }
+  trace_ba_state(who, jobs, fmean, loose * loose, tight * tight);
+  if (!who.empty()) {
+    Sub t(this, "ba: local call");
+    check(hso_gpu_seq_local_ba(ctx_, jobs.data(), (int)jobs.size(), fmean, loose * loose, tight * tight, res.data()), "LocalBundleAdjustment");
+    n_calls_[8]++; n_items_[8] += (int64_t)jobs.size();
   }
-  if (!with.empty()) {
-    for (size_t i = 0; i < with.size(); i++) {
-      Seq& s = *seq_[with[i]];
-      StepData& d = *step_[with[i]];
-      if (!s.trace.on()) continue;
-      Trace& t = s.trace;
-      t.begin("ba_optimize", 11);
-      t.field("poses_in", poses_in[i].data(), sizeof(hso_se3) * poses_in[i].size()); t.field("fixed", d.ba_fixed.data(), d.ba_fixed.size());
-      t.field("idist_in", idist_in[i].data(), sizeof(double) * idist_in[i].size()); t.field("edges", d.ba_edges.data(), sizeof(hso_ba_edge) * d.ba_edges.size());
-      t.scalar("huber_corner", d.huber_corner); t.scalar("huber_edge", d.huber_edge); t.scalar("n_iter", d.ba_iters);
-      t.field("poses_out", d.ba_poses.data(), sizeof(hso_se3) * d.ba_poses.size()); t.field("idist_out", d.ba_idist.data(), sizeof(double) * d.ba_idist.size());
-      t.field("edge_chi2", d.ba_chi2.data(), sizeof(double) * d.ba_chi2.size()); t.field("result", &d.ba_res, sizeof(d.ba_res));
+  std::vector<int> with;
+  for (size_t i = 0; i < who.size(); i++) {
+    StepData& d = *step_[who[i]];
+    d.ba = res[i];
+    d.ba_points.resize((size_t)res[i].n_points);
+    d.ba_culled.resize((size_t)std::min<int64_t>((int64_t)res[i].n_culled[0] + res[i].n_culled[1], (int64_t)d.ba_culled.size()));
+    d.huber_corner = res[i].huber_corner; d.huber_edge = res[i].huber_edge; d.ba_res = res[i].lm;
+    if (res[i].status == 0) with.push_back(who[i]);
+  }
+  // a traced sequence records the window the device assembled and what the optimisation made of it (the records the value-passing
+  // calls hso_gpu_ba_huber_deltas / hso_gpu_ba_optimize are replayed from)
+  for (size_t i = 0; i < who.size(); i++) {
+    Seq& s = *seq_[who[i]];
+    StepData& d = *step_[who[i]];
+    if (!s.trace.on() || res[i].status != 0) continue;
+    const size_t np = (size_t)res[i].n_poses, ne = (size_t)res[i].n_edges, npt = (size_t)res[i].n_points;
+    std::vector<hso_se3> poses_in(np), poses_out(np); std::vector<uint8_t> fixed(np); std::vector<hso_ba_edge> edges(ne); std::vector<double> uv(2 * ne), chi2(ne), idist_in(npt), idist_out(npt);
+    std::vector<int32_t> rows(np), edge_obs(ne);
+    auto get = [&](int what, void* out, size_t bytes) { check(hso_gpu_seq_ba_debug_window(ctx_, (int)i, what, out, bytes), "LocalBundleAdjustment (trace)"); };
+    get(HSO_BAW_VERTEX_ROWS, rows.data(), sizeof(int32_t) * np); get(HSO_BAW_FIXED, fixed.data(), np); get(HSO_BAW_EDGES, edges.data(), sizeof(hso_ba_edge) * ne);
+    get(HSO_BAW_OBS_UV, uv.data(), sizeof(double) * 2 * ne); get(HSO_BAW_EDGE_OBS, edge_obs.data(), sizeof(int32_t) * ne); get(HSO_BAW_EDGE_CHI2, chi2.data(), sizeof(double) * ne);
+    get(HSO_BAW_POSES_OUT, poses_out.data(), sizeof(hso_se3) * np); get(HSO_BAW_POSES_IN, poses_in.data(), sizeof(hso_se3) * np); get(HSO_BAW_IDIST_IN, idist_in.data(), sizeof(double) * npt);
+    for (size_t q = 0; q < npt; q++) idist_out[q] = d.ba_state[4 * q];
+    Trace& t = s.trace;
+    t.begin("ba_huber_deltas", 7);
+    t.field("poses", poses_in.data(), sizeof(hso_se3) * np); t.field("idist", idist_in.data(), sizeof(double) * npt);
+    t.field("edges", edges.data(), sizeof(hso_ba_edge) * ne); t.field("obs_uv", uv.data(), sizeof(double) * 2 * ne);
+    t.scalar("error_multiplier2", fmean); t.scalar("huber_corner", d.huber_corner); t.scalar("huber_edge", d.huber_edge);
+    t.begin("ba_optimize", 14);
+    t.field("poses_in", poses_in.data(), sizeof(hso_se3) * np); t.field("fixed", fixed.data(), np);
+    t.field("idist_in", idist_in.data(), sizeof(double) * npt); t.field("edges", edges.data(), sizeof(hso_ba_edge) * ne);
+    t.scalar("huber_corner", d.huber_corner); t.scalar("huber_edge", d.huber_edge); t.scalar("n_iter", d.ba_iters);
+    t.field("poses_out", poses_out.data(), sizeof(hso_se3) * np); t.field("idist_out", idist_out.data(), sizeof(double) * npt);
+    t.field("edge_chi2", chi2.data(), sizeof(double) * ne); t.field("result", &d.ba_res, sizeof(d.ba_res));
+    t.field("vertex_rows", rows.data(), sizeof(int32_t) * np); t.field("edge_obs", edge_obs.data(), sizeof(int32_t) * ne);
+    t.field("point_rows", d.ba_points.data(), sizeof(int32_t) * npt);
+    if (s.trace.state) {
+      t.begin("seq_ba_result", 4);
+      t.field("result", &res[i], sizeof(res[i])); t.field("point_ids", d.ba_points.data(), sizeof(int32_t) * npt);
+      t.field("point_state", d.ba_state.data(), sizeof(double) * 4 * npt); t.field("culled", d.ba_culled.data(), sizeof(int32_t) * d.ba_culled.size());
     }
   }
   { Sub t(this, "ba: apply_window"); par(with, [&](int k) { apply_window(k); }); }
   Sub t_tail(this, "ba: keys + seed poses");
   // setKeyPoints of the overlap keyframes (src/frame_handler_mono.cpp:331)
-  par(who, [&](int k) { Seq& s = *seq_[k]; for (Id kf : step_[k]->visit) s.refresh_keys(s.frames[kf]); });
+  par(all, [&](int k) { Seq& s = *seq_[k]; for (Id kf : step_[k]->visit) s.refresh_keys(s.frames[kf]); });
   // the resident seeds of the moved keyframes follow them
   std::vector<int64_t> ids; std::vector<hso_se3> poses;
   for (int k : with) for (Id kf : step_[k]->moved_kfs) { ids.push_back(seq_[k]->frames[kf].dev_id); poses.push_back(seq_[k]->frames[kf].T.v); }
   if (!ids.empty()) check(hso_gpu_seed_table_set_host_pose(ctx_, seed_table_, ids.data(), poses.data(), (int)ids.size()), "DepthFilter");
 }
 
-// what LocalBundleAdjustment does with the optimiser's result (:826-892)
+// what LocalBundleAdjustment does with the optimiser's result (:826-892), on the engine's mirror of the map: the device has written
+// its own rows (poses, idist_, pos_), so nothing of it is marked for the next patch
 void Bank::apply_window(int k)
 {
   Seq& s = *seq_[k];
@@ -138,48 +121,44 @@ void Bank::apply_window(int k)
   const double fmean = cam_.errorMultiplier2();
   d.moved_kfs.clear();
   for (int i = 0; i < d.n_core; i++) {
-    const Id kf = d.ba_frames[i];
-    Frame& K = s.frames[kf];
-    K.T.v = d.ba_poses[i];
-    if (!d.ba_fixed[i]) d.moved_kfs.push_back(kf);
+    const Id kf = d.ba_frames[(size_t)i];
+    s.frames[kf].T.v = d.ba.core_pose[i];
+    if (!d.ba_fixed[(size_t)i]) d.moved_kfs.push_back(kf);
   }
   s.kfs_dirty = true;
-  // pos_ = T_host^-1 * (f / idist) of every point of the window and of the candidates hosted in its keyframes
-  // (MapPointCandidates::changeCandidatePosition): the inverse pose once per host keyframe, not once per point (16 000 points per
-  // window at 2000 features: the per-point inverse was the largest single item of a keyframe's bookkeeping)
-  std::vector<int8_t> have(s.frames.size(), 0);
-  std::vector<SE3> inv(s.frames.size());
-  auto place = [&](Id p) {
-    Point& P = s.points[p];
-    const Id h = P.host_frame;
-    if (!have[(size_t)h]) { inv[(size_t)h] = s.frames[h].T.inverse(); have[(size_t)h] = 1; }
-    const Vector3d w = inv[(size_t)h] * along(P.host_f, 1.0 / P.idist);
-    P.pos[0] = w[0]; P.pos[1] = w[1]; P.pos[2] = w[2];
-    s.touch_point(p);
-  };
-  {
-    std::vector<int8_t> core(s.frames.size(), 0);
-    for (int i = 0; i < d.n_core; i++) core[(size_t)d.ba_frames[i]] = 1;
-    for (Id c : s.candidates) if (core[(size_t)s.feats[s.points[c].host].frame]) place(c);
-  }
   for (size_t i = 0; i < d.ba_points.size(); i++) {
-    s.points[d.ba_points[i]].idist = d.ba_idist[i];
-    place(d.ba_points[i]);
+    Point& P = s.points[d.ba_points[i]];
+    const double* st = &d.ba_state[4 * i];
+    P.idist = st[0]; P.pos[0] = st[1]; P.pos[1] = st[2]; P.pos[2] = st[3];
+    P.n_ba++;
   }
-  const double tight = 1.2 / fmean, loose = 2.0 / fmean;
-  int dropped[2] = {0, 0};
-  for (int pass = 0; pass < 2; pass++)                            // corner edges first, then edgelet edges
-    for (size_t e = 0; e < d.ba_edges.size(); e++) {
-      const bool edgelet = d.ba_edges[e].type == HSO_FTR_EDGELET;
-      if (edgelet != (pass == 1)) continue;
-      const Id f = d.ba_edge_feat[e];
-      const Id p = s.feats[f].point;
-      if (p == kNone) continue;
-      if (!(d.ba_chi2[e] > (edgelet ? tight * tight : loose * loose))) continue;
-      if (s.points[p].kind == kPtTemporary) { s.points[p].bad = true; continue; }
-      s.detach(s.feats[f].frame, f);
-      dropped[pass]++;
+  // MapPointCandidates::changeCandidatePosition: the candidates hosted in the window's keyframes follow them (pos_ = T_host^-1 *
+  // (f / idist); rows the engine patches)
+  {
+    std::vector<int8_t> core(s.frames.size(), 0), have(s.frames.size(), 0);
+    std::vector<SE3> inv(s.frames.size());
+    for (int i = 0; i < d.n_core; i++) core[(size_t)d.ba_frames[(size_t)i]] = 1;
+    for (Id c : s.candidates) {
+      Point& P = s.points[c];
+      const Id h = P.host_frame;
+      if (!core[(size_t)s.feats[P.host].frame]) continue;
+      if (!have[(size_t)h]) { inv[(size_t)h] = s.frames[h].T.inverse(); have[(size_t)h] = 1; }
+      const Vector3d w = inv[(size_t)h] * along(P.host_f, 1.0 / P.idist);
+      P.pos[0] = w[0]; P.pos[1] = w[1]; P.pos[2] = w[2];
+      s.touch_point(c);
     }
+  }
+  // the observations whose edge the optimisation left above the threshold, corner edges first (:855-892)
+  int dropped[2] = {0, 0};
+  for (size_t e = 0; e < d.ba_culled.size(); e++) {
+    const int pass = (int64_t)e < (int64_t)d.ba.n_culled[0] ? 0 : 1;
+    const Id f = d.ba_culled[e];
+    const Id p = s.feats[f].point;
+    if (p == kNone) continue;
+    if (s.points[p].kind == kPtTemporary) { s.points[p].bad = true; continue; }
+    s.detach(s.feats[f].frame, f);
+    dropped[pass]++;
+  }
   s.log.ba_removed_1 = dropped[0]; s.log.ba_removed_2 = dropped[1];
   s.log.ba_error_init = std::sqrt(d.ba_res.init_chi2) * fmean;
   s.log.ba_error_final = std::sqrt(d.ba_res.final_chi2) * fmean;

@@ -94,7 +94,10 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
         par(kf, [&](int k) { decide_keyframe(k); });
       }
       ck.lap(3);
-      if (!kf.empty()) keyframe_ba(kf);
+      if (!kf.empty()) {
+        { Sub t(this, "ba: flush_maps"); flush_maps(kf); }          // the window is assembled from the resident map: the new keyframe's rows go first
+        keyframe_ba(kf);
+      }
       ck.lap(4);
       if (!ok.empty()) {
         observe_seeds(ok);
@@ -684,7 +687,7 @@ void Bank::promote(int k)
     s.candidates.resize(keep);
   }
   link_covisible(k, true);
-  if (cfg_.loba_num_iter > 0) assemble_window(k);
+  if (cfg_.loba_num_iter > 0) window_job(k);
   (void)d;
 }
 

@@ -932,6 +932,49 @@ int hso_gpu_seq_chain(hso_gpu_ctx* ctx, const hso_camera* cam, const hso_seq_cha
 /* every event of job `job` of the last chain call (n_events of them) */
 int hso_gpu_seq_events(hso_gpu_ctx* ctx, int job, int32_t* events_out, int cap);
 
+/* ---- ba::LocalBundleAdjustment on a sequence map (src/bundle_adjustment.cpp:577-892; the resident form of hso_gpu_ba_local_multi,
+ *      SURVEY.md section 8(f)).  The window is assembled on the device from the map's own tables, optimised there and written back
+ *      there; the caller names the core keyframes and receives what its mirror of the map needs.  Per job:
+ *        1. the graph (:592-812): vertices 0 .. n_core-1 = the core keyframes in the caller's order; the window's points = every point
+ *           a feature of a core keyframe's list observes (Feature::point != NULL), each once, ascending by point row (the reference
+ *           walks std::set<Point*> in address order; rows give a run-independent one); per point in that order its host keyframe and
+ *           then, along the observation list, every observing keyframe that is not the host gets the next vertex number on its first
+ *           appearance (fixed, :700-737) and every such observation one edge (hso_ba_edge as the value-passing calls take it:
+ *           fH = the point row's host_f, meas = project2d(obs f) — an edgelet's: grad^T of it —, information 1 / 4^level);
+ *        2. the Huber deltas of the window's initial state (:618-680) and the Levenberg loop (:815-823): hso_gpu_ba_local_multi's
+ *           kernels and driver on the tables of step 1, bit for bit what that call returns for the same tables;
+ *        3. the write-back (:826-853): the core keyframes' poses (the library's keyframe table of the map and core_pose), idist_ of the
+ *           window's points and pos_ = T_host^-1 * (host_f * (1 / idist)) in the point rows and in point_state;
+ *        4. the inputs of the culling (:855-892): the observation rows of the edges whose chi2 exceeds chi2_corner / chi2_edgelet, corner
+ *           edges first (edge order), then edgelet edges — the caller removes them from its tables (removePtFrameRef walks the pointer
+ *           graph it owns) and patches the rows that changes.
+ *      A window without edges or points (status 1) is left alone (the reference would optimise an empty graph). ---- */
+#define HSO_SEQ_BA_MAX_CORE 16   /* the dense reduced system holds 16 free poses; the reference's core is Config::coreNKfs() (7) + 2 */
+typedef struct hso_seq_ba_job {
+  int32_t map;
+  int32_t n_core;
+  int32_t core[HSO_SEQ_BA_MAX_CORE];    /* keyframe rows of the map, in vertex order */
+  uint8_t fixed[HSO_SEQ_BA_MAX_CORE];   /* v->setFixed of a core keyframe (:595) */
+  int32_t n_iter;
+  int32_t point_cap;                    /* entries point_ids / point_state hold: at least the window's points (<= the sum of the core lists' lengths) */
+  int32_t cull_cap;                     /* entries culled holds */
+  int32_t pad_;
+  int32_t* point_ids;                   /* out: the window's points (rows), ascending */
+  double* point_state;                  /* out [4 * point_cap]: idist, pos[3] of every window point after the optimisation (what the rows hold) */
+  int32_t* culled;                      /* out: observation rows, in removal order; entries past cull_cap are dropped (n_culled says how many there were) */
+} hso_seq_ba_job;
+typedef struct hso_seq_ba_result {
+  hso_ba_result lm;
+  float huber_corner, huber_edge;       /* the deltas used */
+  int32_t status;                       /* 0: optimised; 1: no edges or no points, nothing done (point_ids / n_points still returned) */
+  int32_t n_poses, n_points, n_edges;
+  int32_t n_culled[2];                  /* corner edges, edgelet edges */
+  hso_se3 core_pose[HSO_SEQ_BA_MAX_CORE];   /* T_f_w of the core keyframes after the optimisation */
+} hso_seq_ba_result;
+/* Every map at most once per call; its patches must have been sent.  error_multiplier2 = cam->errorMultiplier2(). */
+int hso_gpu_seq_local_ba(hso_gpu_ctx* ctx, const hso_seq_ba_job* jobs, int n_jobs, double error_multiplier2, double chi2_corner,
+                         double chi2_edgelet, hso_seq_ba_result* results);
+
 /* A frame's features as the chain keeps them for the sequence's newest frame (Frame::fts_ of a frame that is not a keyframe) */
 typedef struct hso_seq_feature {
   double px[2];                /* Feature::px */

@@ -52,6 +52,19 @@ enum { HSO_DUMP_SIZES = 0, HSO_DUMP_KFS = 1, HSO_DUMP_POINTS = 2, HSO_DUMP_OBS =
 #define HSO_DUMP_N_SIZES 16
 int hso_gpu_seqmap_debug_dump(hso_gpu_ctx* ctx, int map, int what, void* out, size_t bytes);
 
+/* The windows of the last hso_gpu_seq_local_ba call of a context as the device assembled them (traces record them; the parity tests
+ * compare them with the restatement's and replay them through the value-passing calls).  `job` indexes that call's jobs:
+ *   HSO_BAW_SIZES        int32[4]: n_poses, n_points, n_edges, status
+ *   HSO_BAW_VERTEX_ROWS  int32[n_poses]  (keyframe row of every vertex)         HSO_BAW_FIXED     uint8[n_poses]
+ *   HSO_BAW_EDGES        hso_ba_edge[n_edges]                                   HSO_BAW_OBS_UV    double[2 * n_edges]
+ *   HSO_BAW_EDGE_OBS     int32[n_edges]  (observation row of every edge)        HSO_BAW_EDGE_CHI2 double[n_edges] (after the optimisation)
+ *   HSO_BAW_POSES_OUT    hso_se3[n_poses]                                       HSO_BAW_POSES_IN / HSO_BAW_IDIST_IN: the state the
+ *                                                                               optimisation started from, hso_se3[n_poses] / double[n_points]
+ * bytes must equal the table's size.  Valid until the context's next batched call.  Synchronises the context's stream. */
+enum { HSO_BAW_SIZES = 0, HSO_BAW_VERTEX_ROWS = 1, HSO_BAW_FIXED = 2, HSO_BAW_EDGES = 3, HSO_BAW_OBS_UV = 4, HSO_BAW_EDGE_OBS = 5,
+       HSO_BAW_EDGE_CHI2 = 6, HSO_BAW_POSES_OUT = 7, HSO_BAW_POSES_IN = 8, HSO_BAW_IDIST_IN = 9, HSO_BAW_N = 10 };
+int hso_gpu_seq_ba_debug_window(hso_gpu_ctx* ctx, int job, int what, void* out, size_t bytes);
+
 /* test hook: Gaussian pyramid level `level` of a resident frame (cv::pyrDown chain) and its Scharr derivative image
  * (interleaved Ix, Iy); either output may be NULL */
 int hso_gpu_klt_debug_level(hso_gpu_ctx* ctx, int64_t frame, int level, uint8_t* img_out, int16_t* deriv_out);

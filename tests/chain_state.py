@@ -44,6 +44,16 @@ EV_ERASE_POINT, EV_ERASE_CANDIDATE, EV_TEMP_BAD, EV_GOOD = 1, 2, 3, 4
 DUMP = dict(sizes=0, kfs=1, points=2, obs=3, obs_point=4, key_points=5, kf_nfts=6, kf_fts=7, cands=8, frame_feats0=9, frame_feats1=10)
 
 
+SEQ_BA_JOB = np.dtype([("map", "<i4"), ("n_core", "<i4"), ("core", "<i4", 16), ("fixed", "u1", 16), ("n_iter", "<i4"), ("point_cap", "<i4"), ("cull_cap", "<i4"),
+                       ("pad_", "<i4"), ("point_ids", "<u8"), ("point_state", "<u8"), ("culled", "<u8")])
+BA_RESULT = np.dtype([("init_chi2", "<f8"), ("final_chi2", "<f8"), ("robust_chi2", "<f8"), ("lambda_", "<f8"), ("iterations", "<i4"), ("n_solves", "<i4"),
+                      ("n_accepted", "<i4"), ("stop", "<i4")])
+SEQ_BA_RESULT = np.dtype([("lm", BA_RESULT), ("huber_corner", "<f4"), ("huber_edge", "<f4"), ("status", "<i4"), ("n_poses", "<i4"), ("n_points", "<i4"),
+                          ("n_edges", "<i4"), ("n_culled", "<i4", 2), ("core_pose", SE3, 16)])
+assert SEQ_BA_JOB.itemsize == 128 and SEQ_BA_RESULT.itemsize == 80 + 16 * 56
+BAW = dict(sizes=0, vertex_rows=1, fixed=2, edges=3, obs_uv=4, edge_obs=5, edge_chi2=6, poses_out=7, poses_in=8, idist_in=9)
+
+
 def pt_word(key, n_fail=0, bad=False, n_ok=0):
     """HSO_PT_WORD (include/hso_gpu.h): the state word of a sequence map's point row"""
     w = (key & 0xff) | ((n_fail & 0x3ff) << 8) | ((1 << 18) if bad else 0) | ((n_ok & 0x7ff) << 20)
@@ -94,6 +104,31 @@ def state_from_record(rec):
     return S
 
 
+def _scalar(rec, key):
+    return float(np.frombuffer(rec[key], "<f8")[0])
+
+
+def ba_state_from_record(rec):
+    """a "seq_ba_state" trace record (trace_ba_state) -> the map's tables and what the call was asked"""
+    sz = np.frombuffer(rec["sizes"], "<i8")
+    assert (sz[10], sz[11], sz[12], sz[13]) == (KF.itemsize, MAP_POINT.itemsize, OBS.itemsize, SEQ_FEATURE.itemsize), ("struct layouts of this file differ from the library's", sz[10:14])
+    S = dict(sizes=sz.copy(), job=None, kfs=np.frombuffer(rec["kfs"], KF).copy(), points=np.frombuffer(rec["points"], MAP_POINT).copy(), obs=np.frombuffer(rec["obs"], OBS).copy(),
+             obs_point=np.frombuffer(rec["obs_point"], "<i4").copy(), key_points=np.frombuffer(rec["key_points"], "<i4").copy(), kf_nfts=np.frombuffer(rec["kf_nfts"], "<i4").copy(),
+             cands=np.frombuffer(rec["cands"], "<i4").copy(), ff=[np.frombuffer(rec["frame_feats0"], SEQ_FEATURE).copy(), np.frombuffer(rec["frame_feats1"], SEQ_FEATURE).copy()],
+             ff_frame=[int(sz[7]), int(sz[8])], ff_newest=int(sz[9]), fts_cap=int(sz[3]),
+             core=np.frombuffer(rec["core"], "<i4").copy(), fixed=np.frombuffer(rec["fixed"], "u1").copy(), n_iter=int(_scalar(rec, "n_iter")),
+             error_multiplier2=_scalar(rec, "error_multiplier2"), chi2_corner=_scalar(rec, "chi2_corner"), chi2_edgelet=_scalar(rec, "chi2_edgelet"))
+    nk = len(S["kfs"])
+    lists = np.frombuffer(rec["kf_fts"], "<i4").reshape(nk, S["fts_cap"]) if nk else np.zeros((0, 0), "<i4")
+    S["kf_fts"] = [lists[r, :S["kf_nfts"][r]].copy() for r in range(nk)]
+    return S
+
+
+def ba_result_from_record(rec):
+    return dict(result=np.frombuffer(rec["result"], SEQ_BA_RESULT).copy()[0], point_ids=np.frombuffer(rec["point_ids"], "<i4").copy(),
+                point_state=np.frombuffer(rec["point_state"], "<f8").reshape(-1, 4).copy(), culled=np.frombuffer(rec["culled"], "<i4").copy())
+
+
 def result_from_record(rec):
     return dict(result=np.frombuffer(rec["result"], SEQ_RESULT).copy()[0], events=np.frombuffer(rec["events"], "<i4").copy(),
                 features=np.frombuffer(rec["features"], SEQ_FEATURE).copy())
@@ -123,6 +158,8 @@ class ChainLib:
         L.hso_gpu_seq_debug_list.argtypes = [vp, i32, vp, vp, i32]
         L.hso_gpu_seq_debug_ref_table.argtypes = [vp, i32, vp, i32]
         L.hso_gpu_seqmap_debug_dump.argtypes = [vp, i32, i32, vp, C.c_size_t]
+        L.hso_gpu_seq_local_ba.argtypes = [vp, vp, i32, C.c_double, C.c_double, C.c_double, vp]
+        L.hso_gpu_seq_ba_debug_window.argtypes = [vp, i32, i32, vp, C.c_size_t]
 
     def check(self, ctx, rc, what):
         if rc < 0:
@@ -144,7 +181,12 @@ class LoadedState:
         self.ctx = C.c_void_p()
         lib.check(None, L.hso_gpu_create(C.byref(self.ctx), 0, None), "create")
         ctx = self.ctx
-        need = sorted(set(int(k) for k in S["kfs"]["frame_id"]) | {int(S["job"]["ref_frame_id"][0]), int(S["job"]["cur_frame_id"][0])})
+        need = set(int(k) for k in S["kfs"]["frame_id"])
+        if S.get("job") is not None:
+            need |= {int(S["job"]["ref_frame_id"][0]), int(S["job"]["cur_frame_id"][0])}
+        need = sorted(need)
+        if images is None:                                           # a call that never looks at pixels (local BA): any resident frame will do
+            images = {i: np.zeros((64, 64), np.uint8) for i in need}
         h, w = next(iter(images.values())).shape
         imgs = [np.ascontiguousarray(images[i], np.uint8) for i in need]
         ids = np.array(need, np.int64)
@@ -234,6 +276,41 @@ class LoadedState:
         maps = np.array([self.map], np.int32); fid = np.array([int(job["cur_frame_id"][0])], np.int64)
         self.lib.check(ctx, L.hso_gpu_seq_frame_features(ctx, _p(maps), _p(fid), 1, _p(ff), cap, _p(n_out)), "seq_frame_features")
         out["features"] = ff[:int(n_out[0])].copy()
+        out["after"] = self.dump()
+        return out
+
+    def run_ba(self, core, fixed, n_iter, error_multiplier2, chi2_corner, chi2_edgelet, cull_cap=None, point_cap=None):
+        """one hso_gpu_seq_local_ba call on this state -> result record, the window's points / state / culled observations, the window
+        as the library assembled it (hso_gpu_seq_ba_debug_window) and the map afterwards"""
+        L, ctx, S = self.lib.L, self.ctx, self.S
+        core = np.asarray(core, np.int32)
+        job = np.zeros(1, SEQ_BA_JOB)
+        job["map"] = self.map; job["n_core"] = len(core); job["core"][0, :len(core)] = core; job["fixed"][0, :len(core)] = np.asarray(fixed, np.uint8)
+        job["n_iter"] = n_iter
+        pcap = int(point_cap if point_cap is not None else min(len(S["points"]), sum(len(S["kf_fts"][r]) for r in core)))
+        ccap = int(cull_cap if cull_cap is not None else len(S["obs"]))
+        ids = np.full(max(pcap, 1), -1, np.int32); state = np.zeros(4 * max(pcap, 1)); culled = np.full(max(ccap, 1), -1, np.int32)
+        job["point_cap"] = pcap; job["cull_cap"] = ccap
+        job["point_ids"] = ids.ctypes.data; job["point_state"] = state.ctypes.data; job["culled"] = culled.ctypes.data
+        res = np.zeros(1, SEQ_BA_RESULT)
+        self.lib.check(ctx, L.hso_gpu_seq_local_ba(ctx, _p(job), 1, float(error_multiplier2), float(chi2_corner), float(chi2_edgelet), _p(res)), "seq_local_ba")
+        r = res[0]
+        n_pts, n_cull = int(r["n_points"]), int(r["n_culled"].sum())
+        out = dict(result=r, point_ids=ids[:n_pts].copy(), point_state=state[:4 * n_pts].reshape(-1, 4).copy(), culled=culled[:min(n_cull, ccap)].copy())
+        sz = np.zeros(4, np.int32)
+        self.lib.check(ctx, L.hso_gpu_seq_ba_debug_window(ctx, 0, BAW["sizes"], _p(sz), sz.nbytes), "ba window sizes")
+        assert (int(sz[0]), int(sz[1]), int(sz[2]), int(sz[3])) == (int(r["n_poses"]), n_pts, int(r["n_edges"]), int(r["status"]))
+        npo, ne = int(sz[0]), int(sz[2]) if int(sz[3]) == 0 else 0
+
+        def get(what, dtype, n):
+            a = np.zeros(n, dtype)
+            self.lib.check(ctx, L.hso_gpu_seq_ba_debug_window(ctx, 0, BAW[what], _p(a) if a.nbytes else _p(np.zeros(1)), a.nbytes), "ba window " + what)
+            return a
+        W = dict(vertex_rows=get("vertex_rows", "<i4", npo), fixed=get("fixed", "u1", npo), poses_in=get("poses_in", SE3, npo))
+        if int(sz[3]) == 0:
+            W.update(edges=get("edges", capi.BA_EDGE_DTYPE, ne), obs_uv=get("obs_uv", "<f8", 2 * ne), edge_obs=get("edge_obs", "<i4", ne), edge_chi2=get("edge_chi2", "<f8", ne),
+                     poses_out=get("poses_out", SE3, npo), idist_in=get("idist_in", "<f8", n_pts))
+        out["window"] = W
         out["after"] = self.dump()
         return out
 

@@ -47,6 +47,12 @@ struct hso_gpu_ctx {
   std::vector<uint8_t> dbg_projected, dbg_mask;
   std::vector<std::vector<int32_t>> last_ids, last_events; std::vector<std::vector<uint8_t>> last_quality; std::vector<std::vector<hso_ref_feat>> last_table;
   std::vector<hso_seed_brief> prev_briefs; int prev_table = -1;   // hso_gpu_seed_table_observe_previous_begin / _end
+  // hso_gpu_seq_ba_debug_window: the windows of the last hso_gpu_seq_local_ba call
+  struct BaWindow {
+    std::vector<int32_t> rows, edge_obs; std::vector<uint8_t> fixed; std::vector<hso_ba_edge> edges; std::vector<double> uv, chi2, idist_in;
+    std::vector<hso_se3> poses_in, poses_out; int32_t n_points = 0, status = 0;
+  };
+  std::vector<BaWindow> ba_windows;
 };
 
 static int fail(hso_gpu_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
@@ -942,6 +948,134 @@ int hso_gpu_ba_local_multi(hso_gpu_ctx*, const hso_ba_problem* p, const double* 
     hso_or_ba_optimize(p[i].poses_f_w, p[i].pose_fixed, p[i].n_poses, p[i].idist, p[i].n_points, p[i].edges, p[i].n_edges, (double)hc, (double)he, p[i].n_iter,
                        p[i].edge_chi2_out, p[i].result);
   }
+  return HSO_OK;
+}
+
+// ---- ba::LocalBundleAdjustment on a sequence map (src/bundle_adjustment.cpp:577-892): the graph from the map's tables in the
+// reference's order of construction, the restatement's deltas and optimisation, the write-back, the culling's inputs
+int hso_gpu_seq_local_ba(hso_gpu_ctx* c, const hso_seq_ba_job* jobs, int n, double em2, double chi2_corner, double chi2_edgelet, hso_seq_ba_result* res)
+{
+  if (!c) return HSO_E_INVALID;
+  if (n < 0 || (n > 0 && (!jobs || !res))) return fail(c, HSO_E_INVALID, "seq_local_ba: bad argument");
+  for (int j = 0; j < n; j++) {
+    const hso_seq_ba_job& J = jobs[j];
+    if (J.map < 0 || (size_t)J.map >= c->maps.size() || !c->maps[J.map]) return fail(c, HSO_E_INVALID, "seq_local_ba: no such map");
+    for (int i = 0; i < j; i++) if (jobs[i].map == J.map) return fail(c, HSO_E_INVALID, "seq_local_ba: a map appears twice");
+    if (J.n_core < 1 || J.n_core > HSO_SEQ_BA_MAX_CORE || J.n_iter < 0 || J.point_cap < 0 || J.cull_cap < 0 || (J.point_cap > 0 && (!J.point_ids || !J.point_state)) || (J.cull_cap > 0 && !J.culled))
+      return fail(c, HSO_E_INVALID, "seq_local_ba: bad argument");
+    const FakeMap* M = c->maps[J.map];
+    for (int i = 0; i < J.n_core; i++) {
+      if (J.core[i] < 0 || (size_t)J.core[i] >= M->kfs.size()) return fail(c, HSO_E_INVALID, "seq_local_ba: no such keyframe row");
+      for (int k = 0; k < i; k++) if (J.core[k] == J.core[i]) return fail(c, HSO_E_INVALID, "seq_local_ba: a core keyframe appears twice");
+    }
+  }
+  c->ba_windows.assign((size_t)n, hso_gpu_ctx::BaWindow());
+  for (int j = 0; j < n; j++) {
+    const hso_seq_ba_job& J = jobs[j];
+    FakeMap* M = c->maps[J.map];
+    hso_seq_ba_result& R = res[j];
+    memset(&R, 0, sizeof(R));
+    hso_gpu_ctx::BaWindow& W = c->ba_windows[(size_t)j];
+    std::vector<int> vertex(M->kfs.size(), -1);
+    std::vector<uint8_t> in_window(M->pts.size(), 0);
+    for (int i = 0; i < J.n_core; i++) {                            // :592-616
+      vertex[(size_t)J.core[i]] = (int)W.rows.size();
+      W.rows.push_back(J.core[i]); W.fixed.push_back(J.fixed[i] ? 1 : 0);
+      if ((size_t)J.core[i] < M->kf_fts.size())
+        for (int32_t f : M->kf_fts[(size_t)J.core[i]]) { const int32_t p = M->obs_pt.at((size_t)f); if (p >= 0) in_window.at((size_t)p) = 1; }
+    }
+    std::vector<int32_t> pts;
+    for (size_t p = 0; p < in_window.size(); p++) if (in_window[p]) pts.push_back((int32_t)p);
+    auto vertex_of = [&](int row) {
+      if (vertex[(size_t)row] < 0) { vertex[(size_t)row] = (int)W.rows.size(); W.rows.push_back(row); W.fixed.push_back(1); }   // :700-737
+      return vertex[(size_t)row];
+    };
+    std::vector<double> idist(pts.size());
+    for (size_t i = 0; i < pts.size(); i++) {                       // :690-812
+      const hso_map_point& P = M->pts[(size_t)pts[i]];
+      idist[i] = P.idist;
+      const int vh = vertex_of(P.host_kf);
+      for (int q = 0, row = P.obs_begin; q < P.obs_count; q++, row = M->obs[(size_t)row].pad_) {
+        const hso_obs& ob = M->obs.at((size_t)row);
+        if (ob.kf == P.host_kf) continue;
+        hso_ba_edge e{};
+        e.point = (int)i; e.host = vh; e.target = vertex_of(ob.kf);
+        e.type = ob.type == HSO_FTR_EDGELET ? HSO_FTR_EDGELET : HSO_FTR_CORNER;
+        e.level = ob.level;
+        e.fH[0] = P.host_f[0]; e.fH[1] = P.host_f[1]; e.fH[2] = P.host_f[2];
+        const double u = ob.f[0] / ob.f[2], v = ob.f[1] / ob.f[2];
+        if (e.type == HSO_FTR_EDGELET) { e.normal[0] = ob.grad[0]; e.normal[1] = ob.grad[1]; e.meas[0] = ob.grad[0] * u + ob.grad[1] * v; }
+        else { e.normal[0] = 1; e.normal[1] = 0; e.meas[0] = u; e.meas[1] = v; }
+        W.edges.push_back(e); W.edge_obs.push_back(row);
+        W.uv.push_back(u); W.uv.push_back(v);
+      }
+    }
+    W.n_points = (int32_t)pts.size();
+    R.n_poses = (int32_t)W.rows.size(); R.n_points = (int32_t)pts.size(); R.n_edges = (int32_t)W.edges.size();
+    if ((int)pts.size() > J.point_cap) return fail(c, HSO_E_INVALID, "seq_local_ba: point_cap is smaller than the window");
+    for (size_t i = 0; i < pts.size(); i++) J.point_ids[i] = pts[i];
+    W.poses_in.resize(W.rows.size());
+    for (size_t v = 0; v < W.rows.size(); v++) W.poses_in[v] = M->kfs[(size_t)W.rows[v]].T_f_w;
+    W.poses_out = W.poses_in; W.idist_in = idist;
+    for (int i = 0; i < J.n_core; i++) R.core_pose[i] = W.poses_in[(size_t)i];
+    W.chi2.assign(W.edges.size(), 0.0);
+    if (W.edges.empty() || pts.empty()) {
+      R.status = 1; W.status = 1;
+      for (size_t i = 0; i < pts.size(); i++) { const hso_map_point& P = M->pts[(size_t)pts[i]]; double* o = J.point_state + 4 * i; o[0] = P.idist; o[1] = P.pos[0]; o[2] = P.pos[1]; o[3] = P.pos[2]; }
+      continue;
+    }
+    float hc = 0, he = 0;                                           // :618-680, :815-823
+    hso_or_ba_huber_deltas(W.poses_out.data(), (int)W.rows.size(), idist.data(), (int)pts.size(), W.edges.data(), W.uv.data(), (int)W.edges.size(), em2, &hc, &he);
+    R.huber_corner = hc; R.huber_edge = he;
+    hso_or_ba_optimize(W.poses_out.data(), W.fixed.data(), (int)W.rows.size(), idist.data(), (int)pts.size(), W.edges.data(), (int)W.edges.size(), (double)hc, (double)he, J.n_iter,
+                       W.chi2.data(), &R.lm);
+    // :826-853 (the poses of the core; pos_ of every point of the window from its host keyframe's new pose)
+    for (int i = 0; i < J.n_core; i++) { M->kfs[(size_t)J.core[i]].T_f_w = W.poses_out[(size_t)i]; R.core_pose[i] = W.poses_out[(size_t)i]; }
+    for (size_t i = 0; i < pts.size(); i++) {
+      hso_map_point& P = M->pts[(size_t)pts[i]];
+      P.idist = idist[i];
+      hso_se3 inv;
+      hso_or_se3_inverse(&M->kfs[(size_t)P.host_kf].T_f_w, &inv);
+      const double s = 1.0 / P.idist;
+      const double in_host[3] = {P.host_f[0] * s, P.host_f[1] * s, P.host_f[2] * s};
+      hso_or_se3_apply(&inv, in_host, P.pos);
+      double* o = J.point_state + 4 * i; o[0] = P.idist; o[1] = P.pos[0]; o[2] = P.pos[1]; o[3] = P.pos[2];
+    }
+    // :855-892: corner edges first, then edgelet edges
+    int nc = 0;
+    for (int pass = 0; pass < 2; pass++)
+      for (size_t e = 0; e < W.edges.size(); e++) {
+        const bool edgelet = W.edges[e].type == HSO_FTR_EDGELET;
+        if (edgelet != (pass == 1)) continue;
+        if (!(W.chi2[e] > (edgelet ? chi2_edgelet : chi2_corner))) continue;
+        if (nc < J.cull_cap) J.culled[nc] = W.edge_obs[e];
+        nc++; R.n_culled[pass]++;
+      }
+  }
+  return HSO_OK;
+}
+
+int hso_gpu_seq_ba_debug_window(hso_gpu_ctx* c, int job, int what, void* out, size_t bytes)
+{
+  if (!c || job < 0 || (size_t)job >= c->ba_windows.size() || !out) return fail(c, HSO_E_INVALID, "seq_ba_debug_window: bad argument");
+  const hso_gpu_ctx::BaWindow& W = c->ba_windows[(size_t)job];
+  const int32_t sizes[4] = {(int32_t)W.rows.size(), W.n_points, (int32_t)W.edges.size(), W.status};
+  const void* src = nullptr; size_t have = 0;
+  switch (what) {
+    case HSO_BAW_SIZES: src = sizes; have = sizeof(sizes); break;
+    case HSO_BAW_VERTEX_ROWS: src = W.rows.data(); have = sizeof(int32_t) * W.rows.size(); break;
+    case HSO_BAW_FIXED: src = W.fixed.data(); have = W.fixed.size(); break;
+    case HSO_BAW_EDGES: src = W.edges.data(); have = sizeof(hso_ba_edge) * W.edges.size(); break;
+    case HSO_BAW_OBS_UV: src = W.uv.data(); have = sizeof(double) * W.uv.size(); break;
+    case HSO_BAW_EDGE_OBS: src = W.edge_obs.data(); have = sizeof(int32_t) * W.edge_obs.size(); break;
+    case HSO_BAW_EDGE_CHI2: src = W.chi2.data(); have = sizeof(double) * W.chi2.size(); break;
+    case HSO_BAW_POSES_OUT: src = W.poses_out.data(); have = sizeof(hso_se3) * W.poses_out.size(); break;
+    case HSO_BAW_POSES_IN: src = W.poses_in.data(); have = sizeof(hso_se3) * W.poses_in.size(); break;
+    case HSO_BAW_IDIST_IN: src = W.idist_in.data(); have = sizeof(double) * W.idist_in.size(); break;
+    default: return fail(c, HSO_E_INVALID, "seq_ba_debug_window: no such table");
+  }
+  if (have != bytes) return fail(c, HSO_E_INVALID, "seq_ba_debug_window: bytes differs from the table's size");
+  if (bytes) memcpy(out, src, bytes);
   return HSO_OK;
 }
 

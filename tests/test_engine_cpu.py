@@ -134,3 +134,62 @@ def test_chain_state_record_reproduces_the_call(fake, small_seq, tmp_path):
         assert np.array_equal(got["events"], want["events"]) and got["features"].tobytes() == want["features"].tobytes()
         ls.close()
     assert len(st["kfs"]) >= 3 and len(st["cands"]) > 0 and want["result"]["n_events"] >= 0
+
+
+def test_local_ba_state_record_reproduces_the_call(fake, small_seq, tmp_path):
+    """the same for hso_gpu_seq_local_ba: the map recorded before a keyframe's local BA, rebuilt in a fresh context of the
+    restatement, gives the recorded window, state and culling list bit for bit; and the restatement's window is the graph of
+    src/bundle_adjustment.cpp:592-812 (checked here against an independent statement in numpy)."""
+    import chain_state as cs
+    S = small_seq
+    odo = vo.VisualOdometry(synth.camera(S["spec"]), 120, lib=fake)
+    odo.set_first_frame(S["images"][0], S["depth0"], 0.0)
+    recs = []
+    for k in range(1, 30):
+        path = str(tmp_path / ("b%d.bin" % k))
+        odo.trace(path, state=True)
+        odo.add_image(S["images"][k], float(k))
+        odo.trace(None)
+        r = dict(vo.read_trace(path))
+        if "seq_ba_state" in r:
+            recs.append(r)
+    odo.close()
+    assert len(recs) >= 2
+    lib = cs.ChainLib(fake)
+    for r in recs:
+        st = cs.ba_state_from_record(r["seq_ba_state"])
+        want = cs.ba_result_from_record(r["seq_ba_result"])
+        ls = cs.LoadedState(lib, st, None)
+        got = ls.run_ba(st["core"], st["fixed"], st["n_iter"], st["error_multiplier2"], st["chi2_corner"], st["chi2_edgelet"])
+        ls.close()
+        assert got["result"].tobytes() == want["result"].tobytes()
+        assert np.array_equal(got["point_ids"], want["point_ids"]) and got["point_state"].tobytes() == want["point_state"].tobytes() and np.array_equal(got["culled"], want["culled"])
+        W = got["window"]
+        assert W["edges"].tobytes() == r["ba_optimize"]["edges"] and W["edge_obs"].tobytes() == r["ba_optimize"]["edge_obs"]
+        # ---- the graph, restated: points of the core keyframes' features (ascending), vertices in order of first appearance
+        core = [int(c) for c in st["core"]]
+        pts = sorted({int(st["obs_point"][f]) for row in core for f in st["kf_fts"][row] if st["obs_point"][f] >= 0})
+        assert pts == got["point_ids"].tolist()
+        vertex = {row: v for v, row in enumerate(core)}
+        edges = []
+        for i, p in enumerate(pts):
+            P = st["points"][p]
+            vertex.setdefault(int(P["host_kf"]), len(vertex))
+            row = int(P["obs_begin"])
+            for _ in range(int(P["obs_count"])):
+                ob = st["obs"][row]
+                if ob["kf"] != P["host_kf"]:
+                    vertex.setdefault(int(ob["kf"]), len(vertex))
+                    edges.append((i, vertex[int(P["host_kf"])], vertex[int(ob["kf"])], row, 1 if ob["type"] == 1 else 0, int(ob["level"])))
+                row = int(ob["pad_"])
+        assert [row for row, v in sorted(vertex.items(), key=lambda kv: kv[1])] == W["vertex_rows"].tolist()
+        E = W["edges"]
+        assert [(int(e["point"]), int(e["host"]), int(e["target"])) for e in E] == [(a, b, c) for a, b, c, _, _, _ in edges]
+        assert W["edge_obs"].tolist() == [e[3] for e in edges] and E["type"].tolist() == [e[4] for e in edges] and E["level"].tolist() == [e[5] for e in edges]
+        ob = st["obs"][W["edge_obs"]]
+        uv = ob["f"][:, :2] / ob["f"][:, 2:3]
+        assert np.array_equal(W["obs_uv"].reshape(-1, 2), uv)
+        corner = E["type"] == 0
+        assert np.array_equal(E["meas"][corner], uv[corner]) and np.array_equal(E["meas"][~corner, 0], ob["grad"][~corner, 0] * uv[~corner, 0] + ob["grad"][~corner, 1] * uv[~corner, 1])
+        assert np.array_equal(E["fH"], st["points"]["host_f"][got["point_ids"]][E["point"]])
+        assert W["fixed"].tolist() == [int(x) for x in st["fixed"]] + [1] * (len(W["fixed"]) - len(core))
