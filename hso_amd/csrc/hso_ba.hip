@@ -33,6 +33,7 @@ using namespace hso_dev;
 #define BA_THREADS 256
 #define BA_WAVES (BA_THREADS / 64)
 #define BA_LIN 32  // doubles per edge in the linearisation record
+#define BA_BACKSUB_BLOCKS 16   // workgroups per window of k_ba_backsub (<= 32: their partial sums lie in the window's 256-byte sum slot)
 
 // record layout (SoA over edges, stride = n_edges): [0..1] err, [2..3] Jp, [4..15] Jh, [16..27] Jt,
 // [28] omega (= rho' * information), [29] rho' * information applied to -err is folded as omega_r = -omega*err,
@@ -62,6 +63,7 @@ struct BaProb {
   double* S; double* rhs;               // reduced (Schur) system [M * M], [M]; S[M * M] doubles as the "solvable" flag slot
   const double* trial;                  // [0] lambda, [1 ...] pose steps xc [6 * n_poses], then != 0: the solve failed, no step
   double* xp;                           // [n_points] point steps of the last back-substitution
+  double* part;                         // [BA_BACKSUB_BLOCKS] the back-substitution's partial sums of the points' computeScale
   double* idist_rw;                     // a.idist, writable
   double* idist_bak;                    // the state before the last step (g2o's push())
   double* trial_rw;                     // = trial, writable: the solve kernel leaves the pose steps and the "no step" flag there
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_maxdiag(const BaProb* probs, 
 
 // sum of chi2 and of the robustified rho(chi2) over all edges (activeChi2 / activeRobustChi2,
 // thirdparty/g2o/g2o/core/sparse_optimizer.cpp:100-113): one workgroup, fixed tree => deterministic
-__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, const int* active, int with_scale)
 {
   __shared__ double s_part[BA_WAVES][2];
   const BaProb& P = probs[active[blockIdx.y]];
@@ -483,6 +485,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, con
     for (int w = 0; w < BA_WAVES; w++) t += s_part[w][threadIdx.x];
     chi2_sum[threadIdx.x] = t;
   }
+  // the end of an LM trial: the points' part of computeScale from k_ba_backsub's workgroups, in index order
+  if (with_scale && threadIdx.x == 2) { double t = 0; for (int g = 0; g < BA_BACKSUB_BLOCKS; g++) t += P.part[g]; chi2_sum[2] = t; }
 }
 
 // The reduced system of one LM trial on the device: S = Hcc_free + lambda I - sum_p Hpc_p^T (Hpp_p + lambda)^-1 Hpc_p and
@@ -639,7 +643,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_solve(const BaProb* probs, co
 
 // Back-substitution of the points, their update and the point part of computeScale: x_p = (bp_p - Hpc_p . xc) / (Hpp_p +
 // lambda) with the poses in index order (products with the zero rows of unconnected poses change nothing, so the value
-// equals the sparse loop's); idist_bak keeps the state before the step (g2o's push()).  One block per window.
+// equals the sparse loop's); idist_bak keeps the state before the step (g2o's push()).  BA_BACKSUB_BLOCKS workgroups per window
+// (one workgroup streamed a window's 2-3 MB of Hpc rows at the latency of 256 threads: 53 us per launch, 8.5 launches per window):
+// workgroup g takes the points g * 256 + t, g * 256 + t + 16 * 256, ... and leaves its part of the scale in part[g]; k_ba_chi2,
+// which ends every trial, adds the parts in index order — a fixed tree, whatever else runs beside the window.
 __global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, const int* active)
 {
   __shared__ double s_part[BA_WAVES];
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, 
   const double* xc = P.trial + 1;
   const bool no_step = P.trial[1 + 6 * np] != 0.0;   // the reduced system could not be solved: x = 0 (the trial is rejected)
   double sc = 0;
-  for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) {
+  for (int p = blockIdx.x * BA_THREADS + threadIdx.x; p < P.a.n_points; p += BA_BACKSUB_BLOCKS * BA_THREADS) {
     const double dpp = P.Hpp[p] + lambda;
     const double inv = 1.0 / dpp;
     double s = P.bp[p];
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, 
   sc = wave_butterfly_sum(sc);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sc;
   __syncthreads();
-  if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < BA_WAVES; w++) t += s_part[w]; P.sum[2] = t; }
+  if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < BA_WAVES; w++) t += s_part[w]; P.part[blockIdx.x] = t; }
 }
 
 // g2o's pop() for the points: the state before the rejected step
@@ -921,7 +928,7 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
     R.col = reinterpret_cast<const int*>(B.at(B.o_col));
     R.S = reinterpret_cast<double*>(B.at(B.o_S)); R.rhs = reinterpret_cast<double*>(B.at(B.o_rhs));
     R.trial = reinterpret_cast<const double*>(B.at(B.o_trial));
-    R.xp = reinterpret_cast<double*>(B.at(B.o_xp));
+    R.xp = reinterpret_cast<double*>(B.at(B.o_xp)); R.part = reinterpret_cast<double*>(B.at(B.o_sum));
     R.idist_rw = reinterpret_cast<double*>(B.at(B.o_idist)); R.idist_bak = reinterpret_cast<double*>(B.at(B.o_bak));
     R.trial_rw = reinterpret_cast<double*>(B.at(B.o_trial));
     R.poses_rw = reinterpret_cast<hso_se3*>(B.at(B.o_poses)); R.poses_bak = reinterpret_cast<hso_se3*>(B.at(B.o_pbak));
@@ -968,14 +975,14 @@ static int ba_launch_linearize(BaBatch& Q, int slot, const std::vector<int>& whi
   return HSO_OK;
 }
 // computeActiveErrors only (an LM trial): per-edge error / chi2 / rho and the two sums
-static int ba_launch_errors(BaBatch& Q, int slot, const std::vector<int>& which, const int* dl = nullptr)
+static int ba_launch_errors(BaBatch& Q, int slot, const std::vector<int>& which, const int* dl = nullptr, bool trial = false)
 {
   hso_gpu_ctx* ctx = Q.ctx;
   if (which.empty()) return HSO_OK;
   if (!dl) if (int rc = ba_list(Q, slot, which, &dl)) return rc;
   const int ny = (int)which.size();
   hipLaunchKernelGGL(k_ba_edges<false>, dim3((ba_max(Q, which, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-  hipLaunchKernelGGL(k_ba_chi2, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+  hipLaunchKernelGGL(k_ba_chi2, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl, trial ? 1 : 0);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
 }
@@ -1069,7 +1076,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_mad_errors_win(const BaProb* 
 // magnitudes = the element nth_element leaves at floor(n / 2) (include/hso/vikit/math_utils.h:119-126).  The magnitudes are
 // non-negative floats, so their bit patterns order like their values: an exact radix select (four 8-bit digits, histogram in LDS)
 // per kind; one workgroup per window.  The deltas go into the window record the optimisation's kernels read, and out as floats.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_mad_select(BaProb* probs, double error_multiplier2)
+#define BA_MAD_THREADS 1024   // one workgroup per window sweeps its edges eight times (two kinds, four digits)
+__global__ __launch_bounds__(BA_MAD_THREADS) void k_ba_mad_select(BaProb* probs, double error_multiplier2)
 {
   BaProb& P = probs[blockIdx.x];
   const int n = P.a.n_edges, tid = threadIdx.x;
@@ -1079,7 +1087,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_mad_select(BaProb* probs, dou
   __shared__ int s_cnt[2];
   if (tid < 2) s_cnt[tid] = 0;
   __syncthreads();
-  { int c[2] = {0, 0}; for (int k = tid; k < n; k += BA_THREADS) c[E[k].type == HSO_FTR_EDGELET ? 1 : 0]++; if (c[0]) atomicAdd(&s_cnt[0], c[0]); if (c[1]) atomicAdd(&s_cnt[1], c[1]); }
+  { int c[2] = {0, 0}; for (int k = tid; k < n; k += BA_MAD_THREADS) c[E[k].type == HSO_FTR_EDGELET ? 1 : 0]++; if (c[0]) atomicAdd(&s_cnt[0], c[0]); if (c[1]) atomicAdd(&s_cnt[1], c[1]); }
   __syncthreads();
   float med[2] = {0.f, 0.f};
   for (int kind = 0; kind < 2; kind++) {
@@ -1088,10 +1096,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_mad_select(BaProb* probs, dou
     if (tid == 0) { s_prefix = 0u; s_rank = (unsigned)(cnt / 2); }
     unsigned mask = 0u;
     for (int shift = 24; shift >= 0; shift -= 8) {
-      s_hist[tid & 255] = 0u;          // BA_THREADS == 256
+      if (tid < 256) s_hist[tid] = 0u;
       __syncthreads();
       const unsigned prefix = s_prefix;
-      for (int k = tid; k < n; k += BA_THREADS) {
+      for (int k = tid; k < n; k += BA_MAD_THREADS) {
         if ((E[k].type == HSO_FTR_EDGELET ? 1 : 0) != kind) continue;
         const unsigned key = __float_as_uint(err[k]);
         if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
@@ -1385,8 +1393,8 @@ static int ba_run(hso_gpu_ctx* ctx, BaBatch& Q, std::vector<BaLm>& lm, bool hub_
         solve_attr = true;
       }
       hipLaunchKernelGGL(k_ba_solve, dim3(1, ny), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, dl);
-      hipLaunchKernelGGL(k_ba_backsub, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-      if (int rc = ba_launch_errors(Q, 4, w_trial, dl_trial)) return rc;
+      hipLaunchKernelGGL(k_ba_backsub, dim3(BA_BACKSUB_BLOCKS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+      if (int rc = ba_launch_errors(Q, 4, w_trial, dl_trial, true)) return rc;
     }
     HSO_HIP_CHECK(ctx, hipGetLastError());
     // --- results
@@ -1440,7 +1448,7 @@ static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* proble
     int max_edges = 0;
     for (int q = 0; q < n_problems; q++) max_edges = std::max(max_edges, problems[q].n_edges);
     hipLaunchKernelGGL(k_ba_mad_errors_win, dim3((max_edges + BA_THREADS - 1) / BA_THREADS, n_problems), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs);
-    hipLaunchKernelGGL(k_ba_mad_select, dim3(n_problems), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, error_multiplier2);
+    hipLaunchKernelGGL(k_ba_mad_select, dim3(n_problems), dim3(BA_MAD_THREADS), 0, ctx->stream, Q.d_probs, error_multiplier2);
     HSO_HIP_CHECK(ctx, hipGetLastError());
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_hub, Q.d_hub, sizeof(float) * 2 * (size_t)n_problems, hipMemcpyDeviceToHost, ctx->stream));
     hub_pending = true;   // read after the first round's synchronisation
@@ -1992,7 +2000,7 @@ extern "C" int hso_gpu_seq_local_ba(hso_gpu_ctx* ctx, const hso_seq_ba_job* jobs
     int max_edges = 0;
     for (int q = 0; q < nw; q++) max_edges = std::max(max_edges, Q.win[(size_t)q].n_edges);
     hipLaunchKernelGGL(k_ba_mad_errors_win, dim3((max_edges + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs);
-    hipLaunchKernelGGL(k_ba_mad_select, dim3(nw), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, error_multiplier2);
+    hipLaunchKernelGGL(k_ba_mad_select, dim3(nw), dim3(BA_MAD_THREADS), 0, ctx->stream, Q.d_probs, error_multiplier2);
     HSO_HIP_CHECK(ctx, hipGetLastError());
     HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_hub, Q.d_hub, sizeof(float) * 2 * (size_t)nw, hipMemcpyDeviceToHost, ctx->stream));
   }
