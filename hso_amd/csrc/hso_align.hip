@@ -1321,10 +1321,12 @@ __global__ __launch_bounds__(256) void k_chain_visit(ChainFrontDev F, hso_camera
 // 1024 threads per sequence: the walk is three dependent loads per feature row (list -> link -> state word) over ~20 000 rows, and
 // what bounds it is how many of those are in flight (256 threads: 0.32 ms per 128 sequences)
 #define LIST_THREADS 1024
+#define LIST_CACHE 16   // rows per thread and round of the keyframes' feature lists (16 384 rows per round)
 __global__ __launch_bounds__(LIST_THREADS) void k_chain_list(ChainFrontDev F)
 {
   __shared__ int s_wave[LIST_THREADS / 64];
   __shared__ int s_off[HSO_SEQ_MAX_VISIT + 1];
+  __shared__ int s_cnt[LIST_CACHE * (LIST_THREADS / 64)];
   const int b = blockIdx.x, tid = threadIdx.x;
   const ChainJobDev& J = F.jobs[b];
   ChainCur& C = F.cur[b];
@@ -1348,21 +1350,73 @@ __global__ __launch_bounds__(LIST_THREADS) void k_chain_list(ChainFrontDev F)
     if (kind == 0 || kind == 1) return -1;                         // TYPE_DELETED (its features' links are NULL in the reference), TYPE_TEMPORARY
     return p;
   };
-  for (int g = tid; g < total; g += LIST_THREADS) { int key; const int p = point_at(g, key); if (p >= 0) atomicMin(&J.M.first[p], g); }
-  __threadfence_block();
-  __syncthreads();
+  // Rounds of LIST_CACHE x LIST_THREADS rows.  A thread's rows g = base + k * LIST_THREADS + tid (coalesced per k) are resolved in
+  // three sweeps of independent loads — list entry, link, state word: LIST_CACHE of each in flight per thread instead of one chain
+  // per barrier — and kept in registers as (point << 8 | key); the rows that name their point first are then placed by ONE scan
+  // over the (k, wavefront) ballot counts instead of a block scan per k.  "First" only looks at smaller g, so a round needs the
+  // stamps of its own and of earlier rounds: the rounds run one after the other, the stamps are reset after the last.
+  // (16 rows per thread: 86 registers; 32 rows spill at the 128 a workgroup of 1024 threads has.)
   int n = 0;
-  for (int g0 = 0; g0 < total; g0 += LIST_THREADS) {
-    const int g = g0 + tid;
-    int key = 0, p = -1;
-    if (g < total) { p = point_at(g, key); if (p >= 0 && J.M.first[p] != g) p = -1; }
-    int tot;
-    const int pos = sel_scan_waves<LIST_THREADS / 64>(p >= 0 ? 1 : 0, s_wave, tot) + n - (p >= 0 ? 1 : 0);
-    if (p >= 0 && pos < J.slice_cap) { ids[pos] = p; qual[pos] = (uint8_t)key; }
-    n += tot;
+  int cache[LIST_CACHE];
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int base = 0; base < total; base += LIST_CACHE * LIST_THREADS) {
+    int v = 0;                                                     // g grows with k: the keyframe a row belongs to only moves forward
+#pragma unroll
+    for (int k = 0; k < LIST_CACHE; k++) {
+      const int g = base + k * LIST_THREADS + tid;
+      cache[k] = -1;
+      if (g < total) {
+        while (v + 1 < nv && s_off[v + 1] <= g) v++;
+        cache[k] = J.M.kf_fts[(size_t)C.visit[v] * J.M.fts_cap + (g - s_off[v])];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LIST_CACHE; k++) { int pt = -1; if (cache[k] >= 0 && cache[k] < J.M.n_obs) pt = J.M.obs_pt[cache[k]]; cache[k] = (pt >= 0 && pt < J.M.n_pts) ? pt : -1; }
+#pragma unroll
+    for (int k = 0; k < LIST_CACHE; k++) {
+      if (cache[k] >= 0) {
+        const int key = (int)((uint32_t)J.M.pts[cache[k]].pad_ & 0xffu);
+        const int kind = key >> 4;
+        cache[k] = (kind != 0 && kind != 1) ? (cache[k] << 8) | key : -1;   // not TYPE_DELETED (its features' links are NULL in the reference), not TYPE_TEMPORARY
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LIST_CACHE; k++) if (cache[k] >= 0) atomicMin(&J.M.first[cache[k] >> 8], base + k * LIST_THREADS + tid);
+    __threadfence_block();
     __syncthreads();
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < LIST_CACHE; k++) if (cache[k] >= 0 && J.M.first[cache[k] >> 8] == base + k * LIST_THREADS + tid) keep |= 1u << k;
+#pragma unroll
+    for (int k = 0; k < LIST_CACHE; k++) {
+      const unsigned long long bl = __ballot((keep >> k) & 1u);
+      if (lane == 0) s_cnt[k * (LIST_THREADS / 64) + wave] = __popcll(bl);
+    }
+    __syncthreads();
+    {
+      static_assert(LIST_CACHE * (LIST_THREADS / 64) <= LIST_THREADS, "one thread per (k, wavefront) count");
+      const int mine = tid < LIST_CACHE * (LIST_THREADS / 64) ? s_cnt[tid] : 0;
+      int tot;
+      const int incl = sel_scan_waves<LIST_THREADS / 64>(mine, s_wave, tot);
+      __syncthreads();
+      if (tid < LIST_CACHE * (LIST_THREADS / 64)) s_cnt[tid] = incl - mine;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < LIST_CACHE; k++) {
+        const bool kp = (keep >> k) & 1u;
+        const unsigned long long bl = __ballot(kp);
+        if (kp) {
+          const int pos = n + s_cnt[k * (LIST_THREADS / 64) + wave] + __popcll(bl & ((1ull << lane) - 1ull));
+          if (pos < J.slice_cap) { ids[pos] = cache[k] >> 8; qual[pos] = (uint8_t)(cache[k] & 0xff); }
+        }
+      }
+      n += tot;
+      __syncthreads();
+    }
   }
-  for (int g = tid; g < total; g += LIST_THREADS) { int key; const int p = point_at(g, key); if (p >= 0) J.M.first[p] = SEQ_FIRST_UNSET; }
+  // the stamps go back to "unset": every stamped point has exactly one first row, and that row is in the list
+  if (n <= J.slice_cap) { for (int i = tid; i < n; i += LIST_THREADS) J.M.first[ids[i]] = SEQ_FIRST_UNSET; }
+  else for (int g = tid; g < total; g += LIST_THREADS) { int key; const int p = point_at(g, key); if (p >= 0) J.M.first[p] = SEQ_FIRST_UNSET; }
   const int n_kf_points = n < J.slice_cap ? n : J.slice_cap;
   n = n_kf_points;
   // MapPointCandidates::candidates_ in list order (an entry the device deleted since the caller last sent the list is skipped)
