@@ -81,6 +81,24 @@ struct BaProb {
 // largest diagonal entry (k_ba_maxdiag -> sum[5]) — the first trial of a window rides in the round of its first linearisation
 __device__ inline double ba_lambda(const BaProb& P) { const double l = P.lam[0]; return l < 0 ? 1e-5 * P.sum[5] : l; }
 
+// The Levenberg loop's state of one window, on the device (OptimizationAlgorithmLevenberg::solve as a state machine: see BaLm's
+// comment below, which this is the device form of).  `want` says which device work the window takes part in during the NEXT round;
+// every kernel of a round is launched for all windows (blockIdx.y = window) and leaves at once for a window that does not want it.
+enum { BA_W_ERRORS = 1, BA_W_RESTORE = 2, BA_W_LINEARIZE = 4, BA_W_TRIAL = 8 };
+enum { BA_ST_INIT_WAIT = 0, BA_ST_LIN_WAIT = 1, BA_ST_STEP_WAIT = 2, BA_ST_FINAL_WAIT = 3, BA_ST_DONE = 4 };
+struct BaLmDev {
+  double lambda, ni, currentChi, tempChi, iniChi, rho;
+  hso_ba_result res;
+  int32_t nBad, stop, it, qmax, n_iter, st, want, need_restore, first_lin, written, pad_[2];
+};
+// the window a workgroup works on; null: the window sits this kernel out (lm == null: a call outside the loop, every window takes part)
+__device__ inline const BaProb* ba_window(const BaProb* probs, const BaLmDev* lm, int mask)
+{
+  const int w = blockIdx.y;
+  if (lm && !(lm[w].want & mask)) return nullptr;
+  return probs + w;
+}
+
 // ---- g2o's SE3Quat update (host and device: the optimiser applies it on the device, the tests' helpers on the host)
 struct Q4 { double x, y, z, w; };
 
@@ -160,9 +178,11 @@ HSO_HD void se3quat_exp_times(const double* upd, hso_se3& pose)
 
 
 template <bool LIN>   // LIN = false: errors, chi2 and rho only (an LM trial's computeActiveErrors)
-__global__ __launch_bounds__(BA_THREADS) void k_ba_edges(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_edges(const BaProb* probs, const BaLmDev* lm, int mask)
 {
-  const BaArgs a = probs[active[blockIdx.y]].a;
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaArgs a = PP->a;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.n_edges) return;
   const hso_ba_edge e = a.edges[k];
@@ -286,9 +306,11 @@ HSO_DEV double ba_omega_r(const BaArgs& a, int k, const EdgeLin& L, int d)
   return -(om * L.err[d]) * rho1;
 }
 
-__global__ __launch_bounds__(BA_THREADS) void k_ba_points(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_points(const BaProb* probs, const BaLmDev* lm, int mask)
 {
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   const BaArgs a = P.a;
   const int* pt_off = P.off; const int* pt_edges = P.list;
   double* Hpp = P.Hpp; double* bp = P.bp; double* Hpc = P.Hpc;
@@ -333,10 +355,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(const BaProb* probs, c
 // pr_off / pr_edges: CSR of the edges that touch each block's pose pair (host-built, edge order
 // kept): diagonal block i lists every edge with host == i or target == i, block (i, j) every edge
 // whose two frames are {i, j} — a block reads only its own edges instead of scanning all of them.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, const BaLmDev* lm, int mask)
 {
   __shared__ double s_part[BA_WAVES][44];
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   const BaArgs a = P.a;
   const int* pr_off = P.poff; const int* pr_edges = P.plist;
   double* Hcc = P.Hcc; double* bc = P.bc; double* chi2_sum = P.sum;
@@ -433,9 +457,11 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, co
 
 
 // the blocks a linearisation accumulates into, zeroed for every window of the launch at once (was: one memset per window)
-__global__ __launch_bounds__(BA_THREADS) void k_ba_zero(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_zero(const BaProb* probs, const BaLmDev* lm, int mask)
 {
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   uint4* z = reinterpret_cast<uint4*>(P.zero_begin);
   const size_t n = P.zero_bytes / 16;
   for (size_t i = (size_t)blockIdx.x * BA_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * BA_THREADS) z[i] = make_uint4(0, 0, 0, 0);
@@ -444,10 +470,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_zero(const BaProb* probs, con
 // computeLambdaInit (thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:191-201): the largest |diagonal entry| of the
 // Hessian blocks of every free vertex — points: Hpp, free poses: the diagonal of their Hcc block — into sum[5].  A maximum does
 // not depend on the order it is taken in; the host used to read Hpp and the whole Hcc table of every window for this one number.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_maxdiag(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_maxdiag(const BaProb* probs, const BaLmDev* lm, int mask)
 {
   __shared__ double s_part[BA_WAVES];
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   const int np = P.a.n_poses;
   double m = 0;
   for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) m = fmax(m, fabs(P.Hpp[p]));
@@ -464,10 +492,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_maxdiag(const BaProb* probs, 
 
 // sum of chi2 and of the robustified rho(chi2) over all edges (activeChi2 / activeRobustChi2,
 // thirdparty/g2o/g2o/core/sparse_optimizer.cpp:100-113): one workgroup, fixed tree => deterministic
-__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, const int* active, int with_scale)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, const BaLmDev* lm, int mask, int with_scale)
 {
   __shared__ double s_part[BA_WAVES][2];
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   const BaArgs a = P.a;
   double* chi2_sum = P.sum;
   double c = 0, r = 0;
@@ -494,10 +524,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, con
 // pose-pair block (i <= j) of the window: threads stride over the points (rows of Hpc of unconnected poses are zero), then
 // the fixed tree of k_ba_poses; the block writes its 6x6 piece to both triangles of S.  Only M * M + M doubles go back to the
 // host for the dense factorisation — not the n_points x n_poses x 6 block table.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_schur(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_schur(const BaProb* probs, const BaLmDev* lm, int mask)
 {
   __shared__ double s_part[BA_WAVES][44];
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   const int np = P.a.n_poses, n_pairs = np * (np + 1) / 2, M = P.M;
   int b = blockIdx.x, i = 0;
   if (b > n_pairs) return;
@@ -567,12 +599,14 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_schur(const BaProb* probs, co
 // over the threads; the substitutions are column sweeps (x_k final, then x_i -= L_ik x_k for all i at once).  A vanishing or
 // non-finite pivot, or a point diagonal that cannot be inverted (flag from k_ba_schur), means "no step": g2o's solver reports
 // failure and the trial is rejected.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_solve(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_solve(const BaProb* probs, const BaLmDev* lm, int mask)
 {
   extern __shared__ double s_S[];
   __shared__ double s_x[96], s_col[96], s_sc[16];   // s_sc: one entry per FREE pose (M <= 96 unknowns = 16 poses)
   __shared__ int s_ok;
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   const int M = P.M, np = P.a.n_poses, tid = threadIdx.x;
   const double lambda = ba_lambda(P);
   for (int q = tid; q < M * M; q += BA_THREADS) s_S[q] = P.S[q];
@@ -647,10 +681,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_solve(const BaProb* probs, co
 // (one workgroup streamed a window's 2-3 MB of Hpc rows at the latency of 256 threads: 53 us per launch, 8.5 launches per window):
 // workgroup g takes the points g * 256 + t, g * 256 + t + 16 * 256, ... and leaves its part of the scale in part[g]; k_ba_chi2,
 // which ends every trial, adds the parts in index order — a fixed tree, whatever else runs beside the window.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, const BaLmDev* lm, int mask)
 {
   __shared__ double s_part[BA_WAVES];
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   const int np = P.a.n_poses;
   const double lambda = ba_lambda(P);
   const double* xc = P.trial + 1;
@@ -680,11 +716,97 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, 
 }
 
 // g2o's pop() for the points: the state before the rejected step
-__global__ __launch_bounds__(BA_THREADS) void k_ba_restore(const BaProb* probs, const int* active)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_restore(const BaProb* probs, const BaLmDev* lm, int mask)
 {
-  const BaProb& P = probs[active[blockIdx.y]];
+  const BaProb* PP = ba_window(probs, lm, mask);
+  if (!PP) return;
+  const BaProb& P = *PP;
   for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) P.idist_rw[p] = P.idist_bak[p];
   for (int i = threadIdx.x; i < P.a.n_poses; i += BA_THREADS) P.poses_rw[i] = P.poses_bak[i];
+}
+
+// The accept / reject decision of OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-164) and the
+// iteration control of SparseOptimizer::optimize (sparse_optimizer.cpp:354-420) for every window, from the sums the round's
+// kernels left: one thread per window.  It writes what the window wants in the next round and the damping its next trial uses
+// (negative: computeLambdaInit of the linearisation that precedes it, taken on the device: ba_lambda).  Until round 6 the host
+// took this decision — five doubles per window came back and one synchronisation ended every round, ~10 per call; now a call
+// enqueues its rounds back to back and waits once.
+__global__ void k_ba_decide(const BaProb* probs, BaLmDev* lms, double* lam_next, int n)
+{
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  BaLmDev& L = lms[w];
+  if (L.st == BA_ST_DONE) { L.want = 0; return; }
+  const double* sum = probs[w].sum;
+  hso_ba_result& R = L.res;
+  auto finish = [&]() {
+    R.stop = L.stop; R.lambda = L.lambda;
+    // _optimizer->pop() of a last rejected step still has to happen: one more round that only restores
+    if (L.need_restore) { L.need_restore = 0; L.st = BA_ST_FINAL_WAIT; L.want = BA_W_RESTORE; } else { L.st = BA_ST_DONE; L.want = 0; }
+  };
+  switch (L.st) {
+    case BA_ST_INIT_WAIT:
+      R.init_chi2 = sum[0]; R.robust_chi2 = sum[1]; R.final_chi2 = sum[0];
+      if (L.it >= L.n_iter) { finish(); return; }
+      lam_next[w] = -1.0;
+      L.st = BA_ST_LIN_WAIT; L.want = BA_W_LINEARIZE | BA_W_TRIAL;
+      return;
+    case BA_ST_FINAL_WAIT:
+      L.st = BA_ST_DONE; L.want = 0;
+      return;
+    case BA_ST_LIN_WAIT:
+      // a linearisation and the first trial behind it ran in ONE round; the linearisation's sums are in [6], [7], [5]
+      if (L.first_lin) { R.init_chi2 = sum[6]; R.robust_chi2 = sum[7]; L.first_lin = 0; }
+      R.final_chi2 = sum[6];
+      L.currentChi = sum[7]; L.tempChi = L.currentChi; L.iniChi = L.currentChi;
+      if (L.it == 0) { L.lambda = 1e-5 * sum[5]; L.ni = 2; L.nBad = 0; }   // computeLambdaInit
+      L.rho = 0; L.qmax = 0;
+      L.st = BA_ST_STEP_WAIT;
+      [[fallthrough]];
+    case BA_ST_STEP_WAIT: {
+      const bool ok2 = sum[4] != 0.0;
+      R.n_solves++;
+      R.final_chi2 = sum[0];                                        // activeChi2() of the last computeActiveErrors
+      L.tempChi = ok2 ? sum[1] : 1.7976931348623157e308;
+      double rho = L.currentChi - L.tempChi;
+      double scale = sum[2] + sum[3];                               // computeScale (zero when the solve failed: no step)
+      scale += 1e-3;
+      rho /= scale;
+      L.rho = rho;
+      bool restore = false;
+      if (rho > 0 && isfinite(L.tempChi)) {
+        double alpha = 1. - pow(2 * rho - 1, 3.0);
+        alpha = fmin(alpha, 2. / 3.);
+        L.lambda *= fmax(1. / 3., alpha);
+        L.ni = 2;
+        L.currentChi = L.tempChi;
+        R.n_accepted++;
+      } else {
+        L.lambda *= L.ni;
+        L.ni *= 2;
+        restore = true;                                             // _optimizer->pop(): vertices only, edge errors stay
+      }
+      L.qmax++;
+      if (rho < 0 && L.qmax < 5) {                                  // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
+        lam_next[w] = L.lambda;
+        L.st = BA_ST_STEP_WAIT; L.want = (restore ? BA_W_RESTORE : 0) | BA_W_TRIAL;
+        return;
+      }
+      L.need_restore = restore ? 1 : 0;
+      R.iterations = L.it + 1;
+      R.robust_chi2 = L.currentChi;
+      if (L.qmax == 5 || rho == 0) { L.stop = 1; finish(); return; }
+      if ((L.iniChi - L.currentChi) * 1e3 < L.iniChi) L.nBad++; else L.nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
+      if (L.nBad >= 3) { L.stop = 2; finish(); return; }
+      L.it++;
+      if (L.it >= L.n_iter) { finish(); return; }
+      lam_next[w] = L.lambda;                                       // the damping of the trial that rides behind the next linearisation
+      L.st = BA_ST_LIN_WAIT;
+      L.want = BA_W_LINEARIZE | BA_W_TRIAL | (L.need_restore ? BA_W_RESTORE : 0);   // (need_restore: only after a step with a NaN gain ratio)
+      L.need_restore = 0;
+      return;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -718,17 +840,14 @@ struct BaBatch {
   hso_gpu_ctx* ctx;
   std::vector<BaWin> win;
   BaProb* d_probs = nullptr;
-  int* d_active = nullptr;       // BA_N_LISTS lists of n windows each
-  int* h_active = nullptr;       // pinned
+  BaLmDev* d_lm = nullptr;       // [n] the Levenberg loop's state per window (k_ba_decide)
+  BaLmDev* h_lm = nullptr;       // pinned: the initial states go up with the header
   double* d_lambda = nullptr;    // [n] the damping of each window's current trial
   double* h_lambda = nullptr;    // pinned
   double* d_sums = nullptr;      // [n][8] chi2, robust chi2, scale (points), scale (poses), solvable
-  double* h_sums = nullptr;      // pinned (results staging)
   float* d_hub = nullptr;        // [n][2] the Huber deltas formed on the device (hso_gpu_ba_local_multi)
-  float* h_hub = nullptr;        // pinned
   int n = 0;
 };
-#define BA_N_LISTS 6
 
 static bool ba_edges_ok(const hso_ba_edge* edges, int n_edges, int n_points, int n_poses)
 {
@@ -863,11 +982,11 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   Q.ctx = ctx; Q.n = n;
   HSO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  const size_t o_act = al(sizeof(BaProb) * (size_t)n), o_lam = o_act + al(sizeof(int) * (size_t)n * BA_N_LISTS);
+  const size_t o_act = al(sizeof(BaProb) * (size_t)n), o_lam = o_act + al(sizeof(BaLmDev) * (size_t)n);
   const size_t o_sums = o_lam + al(sizeof(double) * (size_t)n);
   const size_t o_hub = o_sums + al(sizeof(double) * 8 * (size_t)n);
   const size_t o_extra = o_hub + al(sizeof(float) * 2 * (size_t)n);
-  size_t dev = o_extra + al(res ? res->extra_hdr : 0), pin_in = dev, pin_out = al(sizeof(double) * 8 * (size_t)n) + al(sizeof(float) * 2 * (size_t)n);
+  size_t dev = o_extra + al(res ? res->extra_hdr : 0), pin_in = dev;
   const size_t hdr = dev;
   for (int q = 0; q < n; q++) { dev += Q.win[q].total; pin_in += res ? Q.win[q].small_bytes : Q.win[q].in_bytes; }
   if (ctx->batch_cap < dev) {  // grow-only work area of the context (shared with the other batched entry points)
@@ -879,18 +998,17 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
   }
   char* d = reinterpret_cast<char*>(ctx->d_batch);
   char* h = hso_pinned(ctx, 0, pin_in);
-  char* ho = hso_pinned(ctx, 1, std::max<size_t>(pin_out, 256));
-  if (!h || !ho) return HSO_E_NOMEM;
+  if (!h) return HSO_E_NOMEM;
   Q.d_probs = reinterpret_cast<BaProb*>(d);
-  Q.d_active = reinterpret_cast<int*>(d + o_act);
+  Q.d_lm = reinterpret_cast<BaLmDev*>(d + o_act);
   Q.d_lambda = reinterpret_cast<double*>(d + o_lam);
   Q.d_sums = reinterpret_cast<double*>(d + o_sums);
   BaProb* hp = reinterpret_cast<BaProb*>(h);
-  Q.h_active = reinterpret_cast<int*>(h + o_act);
+  Q.h_lm = reinterpret_cast<BaLmDev*>(h + o_act);
   Q.h_lambda = reinterpret_cast<double*>(h + o_lam);
-  Q.h_sums = reinterpret_cast<double*>(ho);
+  memset(Q.h_lm, 0, sizeof(BaLmDev) * (size_t)n);                  // want == 0: a window takes part in nothing until ba_run sets it up
+  for (int q = 0; q < n; q++) Q.h_lambda[q] = -1.0;
   Q.d_hub = reinterpret_cast<float*>(d + o_hub);
-  Q.h_hub = reinterpret_cast<float*>(ho + al(sizeof(double) * 8 * (size_t)n));
   size_t ow = pin_in, oh = hdr;   // [header | upload images (resident: their heads) | the rest]: the pinned block mirrors the first two
   for (int q = 0; q < n; q++) {
     BaWin& B = Q.win[q];
@@ -944,45 +1062,35 @@ static int ba_batch_begin(BaBatch& Q, hso_gpu_ctx* ctx, const hso_ba_problem* pr
 
 // Launch helpers: `which` = the windows (indices) this launch works on, written to list slot `slot` (a slot may be reused
 // only after a synchronise, which every round of the driver ends with).
-static int ba_list(BaBatch& Q, int slot, const std::vector<int>& which, const int** d_list)
-{
-  int* hl = Q.h_active + (size_t)slot * Q.n;
-  for (size_t k = 0; k < which.size(); k++) hl[k] = which[k];
-  int* dl = Q.d_active + (size_t)slot * Q.n;
-  HSO_HIP_CHECK(Q.ctx, hipMemcpyAsync(dl, hl, sizeof(int) * which.size(), hipMemcpyHostToDevice, Q.ctx->stream));
-  *d_list = dl;
-  return HSO_OK;
-}
-static int ba_max(const BaBatch& Q, const std::vector<int>& which, int BaWin::*field)
+static int ba_max(const BaBatch& Q, int BaWin::*field)
 {
   int m = 0;
-  for (int q : which) m = std::max(m, Q.win[q].*field);
+  for (const BaWin& B : Q.win) m = std::max(m, B.*field);
   return m;
 }
+// Launch helpers.  Every kernel runs for all windows of the batch (blockIdx.y = window); lm != null: a window takes part when its
+// state record wants `mask` (the loop), lm == null: every window does (a call outside the loop).
 // computeActiveErrors + buildSystem at the resident state; the blocks stay on the device
-static int ba_launch_linearize(BaBatch& Q, int slot, const std::vector<int>& which, const int* dl = nullptr)
+static int ba_launch_linearize(BaBatch& Q, const BaLmDev* lm)
 {
   hso_gpu_ctx* ctx = Q.ctx;
-  if (which.empty()) return HSO_OK;
-  if (!dl) if (int rc = ba_list(Q, slot, which, &dl)) return rc;   // (dl given: the round's lists went up in one copy)
-  const int ny = (int)which.size();
-  hipLaunchKernelGGL(k_ba_zero, dim3(64, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-  hipLaunchKernelGGL(k_ba_edges<true>, dim3((ba_max(Q, which, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-  hipLaunchKernelGGL(k_ba_points, dim3((ba_max(Q, which, &BaWin::n_points) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-  hipLaunchKernelGGL(k_ba_poses, dim3(ba_max(Q, which, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-  hipLaunchKernelGGL(k_ba_maxdiag, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
+  const int ny = Q.n, m = BA_W_LINEARIZE;
+  hipLaunchKernelGGL(k_ba_zero, dim3(64, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
+  hipLaunchKernelGGL(k_ba_edges<true>, dim3((ba_max(Q, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
+  hipLaunchKernelGGL(k_ba_points, dim3((ba_max(Q, &BaWin::n_points) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
+  hipLaunchKernelGGL(k_ba_poses, dim3(ba_max(Q, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
+  hipLaunchKernelGGL(k_ba_maxdiag, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
 }
-// computeActiveErrors only (an LM trial): per-edge error / chi2 / rho and the two sums
-static int ba_launch_errors(BaBatch& Q, int slot, const std::vector<int>& which, const int* dl = nullptr, bool trial = false)
+// computeActiveErrors only: per-edge error / chi2 / rho and the two sums (mask BA_W_ERRORS: the errors-only round; BA_W_TRIAL: the end
+// of an LM trial, where k_ba_chi2 also adds up the back-substitution's parts of computeScale)
+static int ba_launch_errors(BaBatch& Q, const BaLmDev* lm, int mask)
 {
   hso_gpu_ctx* ctx = Q.ctx;
-  if (which.empty()) return HSO_OK;
-  if (!dl) if (int rc = ba_list(Q, slot, which, &dl)) return rc;
-  const int ny = (int)which.size();
-  hipLaunchKernelGGL(k_ba_edges<false>, dim3((ba_max(Q, which, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-  hipLaunchKernelGGL(k_ba_chi2, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl, trial ? 1 : 0);
+  const int ny = Q.n;
+  hipLaunchKernelGGL(k_ba_edges<false>, dim3((ba_max(Q, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, mask);
+  hipLaunchKernelGGL(k_ba_chi2, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, mask, mask == BA_W_TRIAL ? 1 : 0);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
 }
@@ -1009,8 +1117,7 @@ extern "C" int hso_gpu_ba_linearize(hso_gpu_ctx* ctx, const hso_se3* poses_f_w, 
   memset(&P, 0, sizeof(P));
   P.poses_f_w = const_cast<hso_se3*>(poses_f_w); P.pose_fixed = pose_fixed; P.idist = const_cast<double*>(idist); P.edges = edges;
   if (int rc = ba_batch_begin(Q, ctx, &P, 1)) return rc;
-  const std::vector<int> all(1, 0);
-  if (int rc = ba_launch_linearize(Q, 0, all)) return rc;
+  if (int rc = ba_launch_linearize(Q, nullptr)) return rc;
   const BaWin& B = Q.win[0];
   int rc = HSO_OK;
   if (!rc) rc = ba_get(Q, 0, Hpp, B.o_Hpp, sizeof(double) * n_points);
@@ -1238,181 +1345,80 @@ namespace {
 
 }  // namespace
 
-// One local-BA window being optimised: the Levenberg loop of OptimizationAlgorithmLevenberg::solve written as a state
-// machine, so that many windows advance in lockstep.  A round of the driver asks every unfinished window what it needs
-// next (want), launches each kind of device work ONCE for all windows that want it (blockIdx.y = window), synchronises once,
-// and lets every window consume its results (advance).  An LM trial is ONE device sequence — reduced system (k_ba_schur),
-// dense LDL^T + pose update (k_ba_solve), back-substitution + point update (k_ba_backsub), error evaluation
-// (k_ba_edges<false>, k_ba_chi2) — and five doubles come back; the host only takes the accept / reject decision.
-struct BaLm {
-  enum Want { W_ERRORS, W_LINEARIZE, W_TRIAL, W_RESTORE_THEN_TRIAL, W_FINAL, W_NONE };
-  enum State { INIT_WAIT, LIN_WAIT, STEP_WAIT, FINAL_WAIT, DONE };
-  BaWin* B;
-  hso_se3* poses_f_w; const uint8_t* pose_fixed; double* idist;
-  int n_poses, n_points, n_edges, n_iter;
-  double* edge_chi2_out; hso_ba_result* result;
-  double lambda, ni, currentChi, tempChi, iniChi, rho;
-  int nBad, stop, it, qmax;
-  bool need_restore, first_lin;
-  State st; Want want;
-
-  double* sums;       // pinned: chi2, robust chi2, scale (points), scale (poses), solvable — of the last device step
-  double* lam_stage;  // pinned: the damping the next trial uses
-  double* out_sum() const { return sums; }
-
-  void begin()   // runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()
-  {
-    memset(result, 0, sizeof(*result));
-    lambda = -1.; ni = 2.; nBad = 0; stop = 0; it = 0; qmax = 0; rho = 0; currentChi = tempChi = iniChi = 0; need_restore = false;
-    // The first linearisation evaluates the errors at the very state init_error is taken at, and sums them the same way
-    // (k_ba_poses' extra block = k_ba_chi2's reduction): with at least one iteration to run, the errors-only round is left out
-    // and init_chi2 comes from the first linearisation's sums (one round = one synchronisation less per call)
-    first_lin = n_iter > 0;
-    if (first_lin) { st = LIN_WAIT; want = W_LINEARIZE; *lam_stage = -1.0; } else { st = INIT_WAIT; want = W_ERRORS; }
-  }
-  void finish() { result->stop = stop; result->lambda = lambda; st = FINAL_WAIT; want = W_FINAL; }
-
-  // consume the results of the device work asked for by `want`; decide what is needed next
-  void advance()
-  {
-    switch (st) {
-      case INIT_WAIT:
-        result->init_chi2 = out_sum()[0];
-        result->robust_chi2 = out_sum()[1];
-        result->final_chi2 = out_sum()[0];
-        if (it >= n_iter) { finish(); return; }
-        *lam_stage = -1.0;
-        st = LIN_WAIT; want = W_LINEARIZE;
-        return;
-      case LIN_WAIT:
-        // A linearisation and the first trial behind it ran in ONE round (the damping of the trial is known before: carried over,
-        // or formed on the device from the linearisation's largest diagonal entry).  The linearisation's sums are in [6], [7], [5].
-        if (first_lin) { result->init_chi2 = out_sum()[6]; result->robust_chi2 = out_sum()[7]; first_lin = false; }
-        // solve(): computeActiveErrors, currentChi = activeRobustChi2, buildSystem
-        result->final_chi2 = out_sum()[6];
-        currentChi = out_sum()[7]; tempChi = currentChi;
-        iniChi = currentChi;
-        if (it == 0) {   // computeLambdaInit: tau (1e-5) * the largest diagonal entry over all free vertices (k_ba_maxdiag)
-          lambda = 1e-5 * out_sum()[5];
-          ni = 2; nBad = 0;
-        }
-        rho = 0; qmax = 0;
-        st = STEP_WAIT;
-        [[fallthrough]];   // the trial's results are in this round's sums too
-      case STEP_WAIT: {
-        const bool ok2 = out_sum()[4] != 0.0;
-        result->n_solves++;
-        result->final_chi2 = out_sum()[0];   // activeChi2() of the last computeActiveErrors
-        tempChi = ok2 ? out_sum()[1] : 1.7976931348623157e308;
-        rho = currentChi - tempChi;
-        double scale = out_sum()[2] + out_sum()[3];                      // computeScale (zero when the solve failed: no step)
-        scale += 1e-3;
-        rho /= scale;
-        bool restore = false;
-        if (rho > 0 && std::isfinite(tempChi)) {
-          double alpha = 1. - std::pow((2 * rho - 1), 3);
-          alpha = std::min(alpha, 2. / 3.);
-          lambda *= std::max(1. / 3., alpha);
-          ni = 2;
-          currentChi = tempChi;
-          result->n_accepted++;
-        } else {
-          lambda *= ni;
-          ni *= 2;
-          restore = true;                                                // _optimizer->pop(): vertices only, edge errors stay
-        }
-        qmax++;
-        if (rho < 0 && qmax < 5) {   // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
-          *lam_stage = lambda;
-          st = STEP_WAIT; want = restore ? W_RESTORE_THEN_TRIAL : W_TRIAL;
-          return;
-        }
-        need_restore = restore;
-        result->iterations = it + 1;
-        result->robust_chi2 = currentChi;
-        if (qmax == 5 || rho == 0) { stop = 1; finish(); return; }
-        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
-        if (nBad >= 3) { stop = 2; finish(); return; }
-        it++;
-        if (it >= n_iter) { finish(); return; }
-        *lam_stage = lambda;                 // the damping of the trial that rides behind the next linearisation
-        st = LIN_WAIT; want = W_LINEARIZE;   // (need_restore: only after a step with a NaN gain ratio; the driver restores first)
-        return;
-      }
-      case FINAL_WAIT:
-        st = DONE; want = W_NONE;
-        return;
-      case DONE:
-        return;
-    }
-  }
+// The Levenberg loop of OptimizationAlgorithmLevenberg::solve for the windows of a batch, in lockstep rounds.  A round = for every
+// window the device work its state record asks for — restore (g2o's pop()), linearisation (computeActiveErrors + buildSystem), an LM
+// trial as ONE device sequence: reduced system (k_ba_schur), dense LDL^T + pose update (k_ba_solve), back-substitution + point
+// update (k_ba_backsub), error evaluation (k_ba_edges<false>, k_ba_chi2) — and then k_ba_decide, which takes the accept / reject
+// decision and says what the window does next.  Each kind of work is launched ONCE per round for all windows (blockIdx.y = window;
+// a window that does not want it leaves at once), so the small kernels of different windows run side by side; a window's arithmetic
+// does not depend on what runs beside it.  The host enqueues rounds back to back and looks at the state records only every
+// BA_ROUNDS_FIRST / BA_ROUNDS_MORE rounds (a window of the engine needs 8-10): one wait per call where every round had one.
+// `finalise` (resident windows): enqueued behind every block of rounds — the write-back kernels of the windows that are done — and
+// told which read-backs to make; value-passing windows hand their state back to the caller's arrays.
+#define BA_ROUNDS_FIRST 10
+#define BA_ROUNDS_MORE 4
+struct BaLmHost {   // what the caller gives and gets per window
+  hso_se3* poses_f_w; double* idist; double* edge_chi2_out; hso_ba_result* result; int n_iter;
 };
-
-// The lockstep Levenberg loop over the windows of a batch (see BaLm).  `on_final` (resident windows): called once per round with the
-// windows that finish in it, after the round's launches — it queues the write-back kernels (list slot 5 holds those windows) and adds
-// its own read-backs; without it a finishing window hands its state back to the caller's arrays.
-typedef std::function<int(const std::vector<int>& w_final, const int* dl_final, std::vector<HsoListCopy>& back)> BaFinalHook;
-static int ba_run(hso_gpu_ctx* ctx, BaBatch& Q, std::vector<BaLm>& lm, bool hub_pending, float* huber_out, const BaFinalHook* on_final)
+typedef std::function<int(std::vector<HsoListCopy>& back)> BaFinalHook;
+static int ba_run(hso_gpu_ctx* ctx, BaBatch& Q, const std::vector<BaLmHost>& lm, float* huber_out, const BaFinalHook* finalise)
 {
-  const int n_problems = Q.n;
-  std::vector<int> w_err, w_lin, w_trial, w_restore, w_final;
-  for (;;) {
-    w_err.clear(); w_lin.clear(); w_trial.clear(); w_restore.clear(); w_final.clear();
-    for (int q = 0; q < n_problems; q++)
-      switch (lm[q].want) {
-        case BaLm::W_ERRORS: w_err.push_back(q); break;
-        case BaLm::W_LINEARIZE: w_lin.push_back(q); w_trial.push_back(q); if (lm[q].need_restore) { w_restore.push_back(q); lm[q].need_restore = false; } break;
-        case BaLm::W_RESTORE_THEN_TRIAL: w_restore.push_back(q); w_trial.push_back(q); break;
-        case BaLm::W_TRIAL: w_trial.push_back(q); break;
-        case BaLm::W_FINAL: w_final.push_back(q); if (lm[q].need_restore) w_restore.push_back(q); break;
-        case BaLm::W_NONE: break;
-      }
-    if (w_err.empty() && w_lin.empty() && w_trial.empty() && w_final.empty()) break;
-    // this round's launch lists and the damping of its trials: ONE copy (the lists and the damping lie side by side in the header
-    // of the batch, in page-locked memory and on the device; poses and points are owned by the device during the optimisation)
-    auto fill = [&](int slot, const std::vector<int>& which) -> const int* {
-      int* hl = Q.h_active + (size_t)slot * Q.n;
-      for (size_t k = 0; k < which.size(); k++) hl[k] = which[k];
-      return Q.d_active + (size_t)slot * Q.n;
-    };
-    const int* dl_err = fill(0, w_err); const int* dl_restore = fill(1, w_restore); const int* dl_lin = fill(2, w_lin); const int* dl_trial = fill(3, w_trial);
-    const int* dl_final = fill(5, w_final);
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_active, Q.h_active, (size_t)(reinterpret_cast<char*>(Q.h_lambda + n_problems) - reinterpret_cast<char*>(Q.h_active)),
-                                      hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = ba_launch_errors(Q, 0, w_err, dl_err)) return rc;
-    if (!w_restore.empty())   // g2o's pop() after a rejected step, before anything reads the state again
-      hipLaunchKernelGGL(k_ba_restore, dim3(1, (int)w_restore.size()), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl_restore);
-    if (int rc = ba_launch_linearize(Q, 2, w_lin, dl_lin)) return rc;
-    if (!w_trial.empty()) {
-      const int* dl = dl_trial;
-      const int ny = (int)w_trial.size(), max_m = ba_max(Q, w_trial, &BaWin::M);
-      hipLaunchKernelGGL(k_ba_schur, dim3(ba_max(Q, w_trial, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-      static bool solve_attr = false;   // 96 x 96 doubles = 72 KiB of dynamic LDS: above the 64 KiB a launch gets without asking
-      if (!solve_attr) {
-        HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * (int)sizeof(double)));
-        solve_attr = true;
-      }
-      hipLaunchKernelGGL(k_ba_solve, dim3(1, ny), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, dl);
-      hipLaunchKernelGGL(k_ba_backsub, dim3(BA_BACKSUB_BLOCKS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, dl);
-      if (int rc = ba_launch_errors(Q, 4, w_trial, dl_trial, true)) return rc;
-    }
-    HSO_HIP_CHECK(ctx, hipGetLastError());
-    // --- results
-    // the sums of every window in one copy (windows that did nothing this round keep their old values, nobody reads them)
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_sums, Q.d_sums, sizeof(double) * 8 * (size_t)n_problems, hipMemcpyDeviceToHost, ctx->stream));
-    // the windows that finished this round hand back their state: every table of every such window in one DMA
-    std::vector<HsoListCopy> back;
-    if (on_final) { if (int rc = (*on_final)(w_final, dl_final, back)) return rc; }
-    else for (int q : w_final) {
-      const BaWin& B = Q.win[q];
-      back.push_back({lm[q].idist, B.at(B.o_idist), sizeof(double) * (size_t)B.n_points});
-      back.push_back({lm[q].poses_f_w, B.at(B.o_poses), sizeof(hso_se3) * (size_t)B.n_poses});
-      if (lm[q].edge_chi2_out) back.push_back({lm[q].edge_chi2_out, B.at(B.o_chi), sizeof(double) * (size_t)B.n_edges});
-    }
-    if (int rc = hso_lists_to_host(ctx, back)) return rc;   // synchronises (also when there is nothing to read back)
-    if (hub_pending) { memcpy(huber_out, Q.h_hub, sizeof(float) * 2 * (size_t)n_problems); hub_pending = false; }
-    for (int q = 0; q < n_problems; q++) if (lm[q].want != BaLm::W_NONE) lm[q].advance();
+  const int n = Q.n;
+  // the loop's initial state per window (runSparseBAOptimizer: computeActiveErrors(); init_error = activeChi2()).  The first
+  // linearisation evaluates the errors at the very state init_error is taken at, and sums them the same way (k_ba_poses' extra
+  // block = k_ba_chi2's reduction): with at least one iteration to run, the errors-only round is left out and init_chi2 comes
+  // from the first linearisation's sums
+  bool any_errors_round = false;
+  for (int q = 0; q < n; q++) {
+    BaLmDev& L = Q.h_lm[q];
+    memset(&L, 0, sizeof(L));
+    L.lambda = -1.; L.ni = 2.; L.n_iter = lm[(size_t)q].n_iter;
+    L.first_lin = L.n_iter > 0 ? 1 : 0;
+    if (L.first_lin) { L.st = BA_ST_LIN_WAIT; L.want = BA_W_LINEARIZE | BA_W_TRIAL; } else { L.st = BA_ST_INIT_WAIT; L.want = BA_W_ERRORS; any_errors_round = true; }
+    Q.h_lambda[q] = -1.0;
   }
+  HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_lm, Q.h_lm, (size_t)(reinterpret_cast<char*>(Q.h_lambda + n) - reinterpret_cast<char*>(Q.h_lm)), hipMemcpyHostToDevice, ctx->stream));
+  static bool solve_attr = false;   // 96 x 96 doubles = 72 KiB of dynamic LDS: above the 64 KiB a launch gets without asking
+  if (!solve_attr) {
+    HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * (int)sizeof(double)));
+    solve_attr = true;
+  }
+  const int max_m = ba_max(Q, &BaWin::M), max_pairs = ba_max(Q, &BaWin::n_pairs);
+  std::vector<BaLmDev> state((size_t)n);
+  std::vector<float> hub(2 * (size_t)n);
+  bool first = true;
+  for (int rounds = BA_ROUNDS_FIRST;; rounds = BA_ROUNDS_MORE) {
+    for (int r = 0; r < rounds; r++) {
+      // (the errors-only round of a window that runs zero iterations: only the call's first round can hold one)
+      if (first && any_errors_round) { if (int rc = ba_launch_errors(Q, Q.d_lm, BA_W_ERRORS)) return rc; }
+      hipLaunchKernelGGL(k_ba_restore, dim3(1, n), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, Q.d_lm, (int)BA_W_RESTORE);
+      if (int rc = ba_launch_linearize(Q, Q.d_lm)) return rc;
+      hipLaunchKernelGGL(k_ba_schur, dim3(max_pairs + 1, n), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, Q.d_lm, (int)BA_W_TRIAL);
+      hipLaunchKernelGGL(k_ba_solve, dim3(1, n), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, Q.d_lm, (int)BA_W_TRIAL);
+      hipLaunchKernelGGL(k_ba_backsub, dim3(BA_BACKSUB_BLOCKS, n), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, Q.d_lm, (int)BA_W_TRIAL);
+      if (int rc = ba_launch_errors(Q, Q.d_lm, BA_W_TRIAL)) return rc;
+      hipLaunchKernelGGL(k_ba_decide, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, Q.d_probs, Q.d_lm, Q.d_lambda, n);
+      HSO_HIP_CHECK(ctx, hipGetLastError());
+      first = false;
+    }
+    // what comes back: the state records (is every window done?), once the Huber deltas, and the finished windows' results
+    std::vector<HsoListCopy> back;
+    back.push_back({state.data(), Q.d_lm, sizeof(BaLmDev) * (size_t)n});
+    if (huber_out) back.push_back({hub.data(), Q.d_hub, sizeof(float) * 2 * (size_t)n});
+    if (finalise) { if (int rc = (*finalise)(back)) return rc; }
+    else for (int q = 0; q < n; q++) {
+      const BaWin& B = Q.win[(size_t)q];
+      back.push_back({lm[(size_t)q].idist, B.at(B.o_idist), sizeof(double) * (size_t)B.n_points});
+      back.push_back({lm[(size_t)q].poses_f_w, B.at(B.o_poses), sizeof(hso_se3) * (size_t)B.n_poses});
+      if (lm[(size_t)q].edge_chi2_out) back.push_back({lm[(size_t)q].edge_chi2_out, B.at(B.o_chi), sizeof(double) * (size_t)B.n_edges});
+    }
+    if (int rc = hso_lists_to_host(ctx, back)) return rc;   // synchronises
+    bool done = true;
+    for (int q = 0; q < n; q++) done = done && state[(size_t)q].st == BA_ST_DONE;
+    if (done) break;
+  }
+  for (int q = 0; q < n; q++) *lm[(size_t)q].result = state[(size_t)q].res;
+  if (huber_out) memcpy(huber_out, hub.data(), sizeof(float) * 2 * (size_t)n);
   return HSO_OK;
 }
 
@@ -1430,7 +1436,6 @@ static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* proble
   }
   BaBatch Q;
   Q.win.resize(n_problems);
-  std::vector<BaLm> lm(n_problems);
   for (int q = 0; q < n_problems; q++) {
     const hso_ba_problem& P = problems[q];
     if (!P.poses_f_w || !P.pose_fixed || !P.idist || !P.edges || !P.result || P.n_poses <= 0 || P.n_points <= 0 || P.n_edges <= 0 || P.n_iter < 0)
@@ -1443,26 +1448,19 @@ static int ba_optimize_multi_impl(hso_gpu_ctx* ctx, const hso_ba_problem* proble
   }
   // (the edges' index check rides in the staging pass of ba_batch_begin)
   if (int rc = ba_batch_begin(Q, ctx, problems, n_problems, obs_uv)) return rc;
-  bool hub_pending = false;
   if (obs_uv) {
     int max_edges = 0;
     for (int q = 0; q < n_problems; q++) max_edges = std::max(max_edges, problems[q].n_edges);
     hipLaunchKernelGGL(k_ba_mad_errors_win, dim3((max_edges + BA_THREADS - 1) / BA_THREADS, n_problems), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs);
     hipLaunchKernelGGL(k_ba_mad_select, dim3(n_problems), dim3(BA_MAD_THREADS), 0, ctx->stream, Q.d_probs, error_multiplier2);
     HSO_HIP_CHECK(ctx, hipGetLastError());
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_hub, Q.d_hub, sizeof(float) * 2 * (size_t)n_problems, hipMemcpyDeviceToHost, ctx->stream));
-    hub_pending = true;   // read after the first round's synchronisation
   }
+  std::vector<BaLmHost> lm((size_t)n_problems);
   for (int q = 0; q < n_problems; q++) {
     const hso_ba_problem& P = problems[q];
-    BaLm& L = lm[q];
-    L.B = &Q.win[q]; L.poses_f_w = P.poses_f_w; L.pose_fixed = P.pose_fixed; L.idist = P.idist;
-    L.n_poses = P.n_poses; L.n_points = P.n_points; L.n_edges = P.n_edges; L.n_iter = P.n_iter;
-    L.edge_chi2_out = P.edge_chi2_out; L.result = P.result;
-    L.sums = Q.h_sums + 8 * (size_t)q; L.lam_stage = Q.h_lambda + q;
-    L.begin();
+    lm[(size_t)q] = {P.poses_f_w, P.idist, P.edge_chi2_out, P.result, P.n_iter};
   }
-  return ba_run(ctx, Q, lm, hub_pending, huber_out, nullptr);
+  return ba_run(ctx, Q, lm, obs_uv ? huber_out : nullptr, nullptr);
 }
 
 extern "C" int hso_gpu_ba_optimize_multi(hso_gpu_ctx* ctx, const hso_ba_problem* problems, int n_problems)
@@ -1777,9 +1775,10 @@ __global__ __launch_bounds__(256) void k_rba_pair_scan(const RbaWinDev* wins)
 }
 
 // :826-853: idist_ and pos_ = T_host^-1 * (host_f * (1 / idist)) of the window's points, into the map's rows and out
-__global__ __launch_bounds__(256) void k_rba_writeback(const RbaWinDev* wins, const int* active)
+__global__ __launch_bounds__(256) void k_rba_writeback(const RbaWinDev* wins, const BaLmDev* lm)
 {
-  const RbaWinDev& W = wins[active[blockIdx.y]];
+  if (lm[blockIdx.y].st != BA_ST_DONE || lm[blockIdx.y].written) return;   // not finished yet / written by an earlier block of rounds
+  const RbaWinDev& W = wins[blockIdx.y];
   const RbaJobDev& J = W.J;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= W.n_points) return;
@@ -1797,10 +1796,11 @@ __global__ __launch_bounds__(256) void k_rba_writeback(const RbaWinDev* wins, co
 }
 
 // :855-892: the observations of the edges above the threshold, corner edges first, in edge order (one workgroup per window)
-__global__ __launch_bounds__(1024) void k_rba_cull(const RbaWinDev* wins, const int* active)
+__global__ __launch_bounds__(1024) void k_rba_cull(const RbaWinDev* wins, BaLmDev* lm)
 {
   __shared__ int s_wave[16];
-  const RbaWinDev& W = wins[active[blockIdx.x]];
+  if (lm[blockIdx.x].st != BA_ST_DONE || lm[blockIdx.x].written) return;
+  const RbaWinDev& W = wins[blockIdx.x];
   int n = 0;
   for (int pass = 0; pass < 2; pass++) {
     const int n0 = n;
@@ -1818,6 +1818,7 @@ __global__ __launch_bounds__(1024) void k_rba_cull(const RbaWinDev* wins, const 
     }
     if (threadIdx.x == 0) W.cull[pass] = n - n0;
   }
+  if (threadIdx.x == 0) lm[blockIdx.x].written = 1;               // (k_rba_writeback ran before this kernel)
 }
 
 // what the last call of a context left for hso_gpu_seq_ba_debug_window
@@ -2002,31 +2003,24 @@ extern "C" int hso_gpu_seq_local_ba(hso_gpu_ctx* ctx, const hso_seq_ba_job* jobs
     hipLaunchKernelGGL(k_ba_mad_errors_win, dim3((max_edges + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs);
     hipLaunchKernelGGL(k_ba_mad_select, dim3(nw), dim3(BA_MAD_THREADS), 0, ctx->stream, Q.d_probs, error_multiplier2);
     HSO_HIP_CHECK(ctx, hipGetLastError());
-    HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.h_hub, Q.d_hub, sizeof(float) * 2 * (size_t)nw, hipMemcpyDeviceToHost, ctx->stream));
   }
-  std::vector<BaLm> lm((size_t)nw);
+  std::vector<BaLmHost> lm((size_t)nw);
   std::vector<float> hub(2 * (size_t)nw);
   std::vector<std::vector<int32_t>> cull((size_t)nw);
   std::vector<std::vector<hso_se3>> poses_out((size_t)nw);
   for (int q = 0; q < nw; q++) {
     const BaWin& B = Q.win[(size_t)q];
-    BaLm& L = lm[(size_t)q];
-    L.B = &Q.win[(size_t)q]; L.poses_f_w = nullptr; L.pose_fixed = last.win[(size_t)act[q]].fixed.data(); L.idist = nullptr;
-    L.n_poses = B.n_poses; L.n_points = B.n_points; L.n_edges = B.n_edges; L.n_iter = jobs[act[q]].n_iter;
-    L.edge_chi2_out = nullptr; L.result = &results[act[q]].lm;
-    L.sums = Q.h_sums + 8 * (size_t)q; L.lam_stage = Q.h_lambda + q;
-    L.begin();
+    lm[(size_t)q] = {nullptr, nullptr, nullptr, &results[act[q]].lm, jobs[act[q]].n_iter};
     cull[(size_t)q].assign(2 + (size_t)std::min(B.n_edges, RBA_CULL_FIRST), 0);
     poses_out[(size_t)q].resize((size_t)jobs[act[q]].n_core);
   }
-  const BaFinalHook on_final = [&](const std::vector<int>& w_final, const int* dl_final, std::vector<HsoListCopy>& out) -> int {
-    if (w_final.empty()) return HSO_OK;
-    int np = 1;
-    for (int q : w_final) np = std::max(np, Q.win[(size_t)q].n_points);
-    hipLaunchKernelGGL(k_rba_writeback, dim3((np + 255) / 256, (int)w_final.size()), dim3(256), 0, ctx->stream, d_wins, dl_final);
-    hipLaunchKernelGGL(k_rba_cull, dim3((int)w_final.size()), dim3(1024), 0, ctx->stream, d_wins, dl_final);
+  // behind every block of rounds: the write-back of the windows that are done (a window is written once), and everything the caller
+  // mirrors — final for the finished windows; the loop ends when all are
+  const BaFinalHook finalise = [&](std::vector<HsoListCopy>& out) -> int {
+    hipLaunchKernelGGL(k_rba_writeback, dim3((max_np + 255) / 256, nw), dim3(256), 0, ctx->stream, d_wins, Q.d_lm);
+    hipLaunchKernelGGL(k_rba_cull, dim3(nw), dim3(1024), 0, ctx->stream, d_wins, Q.d_lm);
     HSO_HIP_CHECK(ctx, hipGetLastError());
-    for (int q : w_final) {
+    for (int q = 0; q < nw; q++) {
       const BaWin& B = Q.win[(size_t)q];
       const hso_seq_ba_job& A = jobs[act[q]];
       const RbaJobDev& J = hj[(size_t)act[q]];
@@ -2037,7 +2031,7 @@ extern "C" int hso_gpu_seq_local_ba(hso_gpu_ctx* ctx, const hso_seq_ba_job* jobs
     }
     return HSO_OK;
   };
-  if (int rc = ba_run(ctx, Q, lm, true, hub.data(), &on_final)) return rc;
+  if (int rc = ba_run(ctx, Q, lm, hub.data(), &finalise)) return rc;
   // ---- what the caller mirrors
   for (int q = 0; q < nw; q++) {
     const int j = act[q];
