@@ -20,6 +20,8 @@
 // The reference accumulates serially in edge order in fp64; the tree order differs by rounding
 // (parity tolerance 1e-11 relative).  Sizes are small (<= ~15 poses, a few hundred points,
 // 1-3 k edges): latency-bound; throughput comes from issuing many keyframes' problems on one stream.
+// Around them (further down): the Levenberg loop as a device state machine (BaLmDev, k_ba_decide, ba_run), the Huber deltas
+// (k_ba_mad_*), and hso_gpu_seq_local_ba — the window assembled from a sequence map's resident tables (k_rba_*).
 #include "hso_ctx.h"
 #include "hso_dev_math.h"
 #include <string.h>

@@ -540,9 +540,10 @@ int hso_gpu_ba_optimize(hso_gpu_ctx* ctx, hso_se3* poses_f_w, const uint8_t* pos
                         int n_iter, double* edge_chi2_out, hso_ba_result* result);
 
 /* The local-BA windows of many sequences (one per keyframe event) in one call: the problems advance through the
- * Levenberg loop in lockstep — per round every unfinished problem queues its next device work, ONE synchronise serves them
- * all — so a multi-sequence driver pays one round trip per LM step instead of one per problem and step, and the small
- * kernels of different windows run back to back.  Each problem's arithmetic is exactly that of hso_gpu_ba_optimize. */
+ * Levenberg loop in lockstep rounds — per round each kind of device work is launched once for all problems that want it, and the
+ * accept / reject decision of the round is taken on the device too, so the rounds of a call are enqueued back to back and the
+ * caller's thread waits once (it was one round trip per LM step, and before that one per problem and step).  Each problem's
+ * arithmetic is exactly that of hso_gpu_ba_optimize. */
 typedef struct hso_ba_problem {
   hso_se3* poses_f_w;          /* in / out */
   const uint8_t* pose_fixed;
