@@ -1,6 +1,6 @@
 #!/bin/bash
-# Same-box A/B of the keyframe path: build/exp/old = the tree of commit 575adf1 (local BA windows assembled on the host, value-passing
-# call, patch of the window's points afterwards; `git worktree add build/exp/old 575adf1 && (cd build/exp/old && python -m hso_amd.build)`)
+# Same-box A/B of the keyframe path: build/exp/old = the tree of a build of an earlier commit (575adf1: local BA windows assembled on the host, value-passing
+# call, patch of the window's points afterwards; 53d7eb2: the Levenberg loop decided on the host; `git worktree add build/exp/old <commit> && (cd build/exp/old && python -m hso_amd.build)`)
 # against the working tree (hso_gpu_seq_local_ba + this round's later kernel work); six engines x 128 x 2000, alternating.
 #   bash tools/r6_resident_ba_ab.sh   (GPU box, repo root)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
