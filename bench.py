@@ -192,6 +192,25 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def bind_to_device_node(ctx):
+    """numactl --cpunodebind for this process, from the inside: all its threads (the ones that exist; later ones inherit) onto the CPUs
+    of the NUMA node the context's device hangs off, intersected with what the process may use.  -> description for the JSON line"""
+    try:
+        node = ctx.device_cpulist()
+        allowed = os.sched_getaffinity(0)
+        cpus = node & allowed
+        if len(cpus) < 2 or cpus == allowed:
+            return "unchanged (%d CPUs; the device's node has %d)" % (len(allowed), len(node))
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except OSError:
+                pass
+        return "%d CPUs of the device's NUMA node (of %d allowed)" % (len(cpus), len(allowed))
+    except Exception as e:                                            # a stand-in context without the call (tests/test_bench_cpu.py)
+        return "unchanged (%s)" % type(e).__name__
+
+
 class GpuSide:
     """Everything bench.py needs of the device side in one place: HIP stream / events through torch, the C-ABI context, device
     copies of images, the collective backend.  tests/test_bench_cpu.py swaps it (HSO_BENCH_SIDE="module:Class") for a stand-in over
@@ -369,6 +388,9 @@ def main():
     ap.add_argument("--deal-features", type=int, default=0, help="experiment: > 0 = reorder every job's features by LDS bank at this pyramid level (deal_features)")
     ap.add_argument("--overlap-readback", type=int, default=1, help="1: step k's result read-back is waited for after step k + 1 is enqueued (collect_begin / _end); 0: the synchronous collect")
     ap.add_argument("--ic-steps", type=int, default=3, help="tracker launches in inverse-compositional mode on the same pairs, reported as tracker_inverse_mode_launch_ms (0 = skip)")
+    ap.add_argument("--numa-bind", type=int, default=1, help="1: every thread of the rank's process is confined to the CPUs of the NUMA node its GPU is attached to "
+                    "(what `numactl --cpunodebind` does for a deployment; the engines do it for their own threads anyway: hso_vo_options.no_numa_pin). "
+                    "Reported as host_affinity.  The timed headline region has no host work in it; the end-to-end figures do")
     ap.add_argument("--h2d", type=int, default=1, help="1: also time the headline steps and the end-to-end run with the image upload (page-locked host memory -> HBM) inside the timed region")
     ap.add_argument("--shape", choices=["euroc", "vga"], default="euroc",
                     help="euroc (default, the judged line): EuRoC-shaped 752x480 frames, radtan camera — the shape "
@@ -416,6 +438,7 @@ def main():
 
     with side.on(stream):
         ctx = side.context(stream)
+        numa = bind_to_device_node(ctx) if args.numa_bind else None
         ref_ids = list(range(0, B))
         cur_ids = list(range(B, 2 * B))
         st_ref = ctx.frame_upload_batch(ref_ids, imgs=[scenes[i % n_sc]["ref"] for i in range(B)])
@@ -779,6 +802,7 @@ def main():
         # about half of the time (profiles/r5_banks_overlap.json, profiles/r5_engine_host.md section 7)
         out["sequences_gpu_busy_note"] = "sysfs gpu_busy_percent (non-empty queues); kernels in flight ~0.5-0.6 of the run by rocprofv3 timeline"
         out["host_cpu_quota"] = mres.get("host_cpu_quota"); out["threads_per_bank"] = mres.get("threads_per_bank")
+        out["host_affinity"] = numa
         out["host_cpus_used"] = mres.get("host_cpus_used")
     if extras and seq_S is not None and args.single:
         ctx2 = side.context(stream)

@@ -94,7 +94,7 @@ def _gpu_busy_reader(device):
 
 
 def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, seqs=None, want_traj=False, lib_path=None, to_device=None, steady_from=None,
-              host_images=False):
+              host_images=False, no_numa_pin=False):
     """n_banks engines of n_seq sequences each, every one on its own host thread with its own device context / stream: the
     device work of one bank overlaps the bookkeeping and the PCIe traffic of the others (independent sequences shard freely, also
     within one GPU).  Whole-run throughput: all frames / wall time from the first step to the last bank's last step.
@@ -127,6 +127,8 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
         cam = synth.camera(spec)
         pick = [seqs[q % len(seqs)] for q in range(n_seq)]
         m = vo.MultiVisualOdometry(cam, n_seq, max_fts, device=device, lib=vo.load_from(lib_path) if lib_path else None)
+        if no_numa_pin:
+            m.set_options(no_numa_pin=True)
         m.set_first_frames([q["images"][0] for q in pick], [q["depth0"] for q in pick])
         threads_per_bank[b] = int(m.lib.hso_vo_multi_threads(m.h))
         if host_images:
@@ -224,7 +226,7 @@ def run_banks(n_banks, n_seq, frames, max_fts, distinct=8, spec=None, device=0, 
 if __name__ == "__main__":
     if sys.argv[1] == "banks":
         a = [int(x) for x in sys.argv[2:]]
-        print(json.dumps(run_banks(a[0], a[1], a[2], a[3], a[4] if len(a) > 4 else 8)))
+        print(json.dumps(run_banks(a[0], a[1], a[2], a[3], a[4] if len(a) > 4 else 8, no_numa_pin=(len(a) > 5 and a[5] != 0))))   # sixth number != 0: hso_vo_options.no_numa_pin
     else:
         a = [int(x) for x in sys.argv[1:]]
         print(json.dumps(run(a[0], a[1], a[2], a[3] if len(a) > 3 else 8, on_device=(a[4] != 0 if len(a) > 4 else True))))

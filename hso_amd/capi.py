@@ -385,7 +385,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "hso_gpu_ba_huber_deltas_multi", "hso_gpu_ba_local_multi",
     "hso_gpu_create", "hso_gpu_destroy", "hso_gpu_last_error", "hso_gpu_abi_version",
-    "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_configure", "hso_gpu_set_host_parallel", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
+    "hso_gpu_synchronize", "hso_gpu_set_shared_device", "hso_gpu_device_cpulist", "hso_gpu_configure", "hso_gpu_set_host_parallel", "hso_gpu_frame_upload", "hso_gpu_frame_upload_batch", "hso_gpu_frame_release", "hso_gpu_frame_release_batch",
     "hso_gpu_frame_download_level", "hso_gpu_frame_download_sobel", "hso_gpu_make_depth_ref",
     "hso_gpu_coarse_track_batch", "hso_gpu_coarse_track_prepare", "hso_gpu_coarse_track_launch",
     "hso_gpu_coarse_track_collect", "hso_gpu_coarse_track_collect_begin", "hso_gpu_coarse_track_collect_end", "hso_gpu_tracker_eval", "hso_gpu_tracker_pattern",
@@ -475,6 +475,19 @@ class Context:
         o = GpuOptions(C.sizeof(GpuOptions), int(wait_mode), int(bool(track_no_coop)), int(bool(track_coop_scatter)), int(track_coop_feats_per_wg),
                        int(track_coop_workgroups))
         self._check(self.lib.hso_gpu_configure(self.h, C.byref(o)), "configure")
+
+    def device_cpulist(self):
+        """hso_gpu_device_cpulist: the CPUs of the NUMA node the device is attached to, as a set of ints (empty: unknown)"""
+        buf = C.create_string_buffer(2048)
+        self.lib.hso_gpu_device_cpulist.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        self._check(self.lib.hso_gpu_device_cpulist(self.h, buf, len(buf)), "device_cpulist")
+        cpus = set()
+        for part in buf.value.decode().split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return cpus
 
     def host_array(self, shape, dtype):
         """A numpy array over page-locked memory of hso_gpu_host_alloc (zeroed): pass it as an `out=` / input table and the DMA goes

@@ -474,6 +474,28 @@ int hso_gpu_set_host_parallel(hso_gpu_ctx* ctx, hso_parallel_for_fn parallel_for
   return HSO_OK;
 }
 
+int hso_gpu_device_cpulist(hso_gpu_ctx* ctx, char* out, size_t cap)
+{
+  if (!ctx) return HSO_E_INVALID;
+  if (!out || cap == 0) return hso_fail(ctx, HSO_E_INVALID, "device_cpulist: bad argument");
+  out[0] = 0;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, ctx->device) != hipSuccess) { (void)hipGetLastError(); return HSO_OK; }
+  for (char* c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');   // sysfs spells bus addresses in lower case
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  int node = -1;
+  if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+  if (node < 0) return HSO_OK;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  if (FILE* f = fopen(path, "r")) {
+    if (!fgets(out, (int)cap, f)) out[0] = 0;
+    fclose(f);
+    for (char* c = out; *c; ++c) if (*c == '\n' || *c == ' ') { *c = 0; break; }
+  }
+  return HSO_OK;
+}
+
 int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared)
 {
   if (!ctx) return HSO_E_INVALID;

@@ -18,6 +18,8 @@
 // (src/map.cpp).  The schedule of the reference's depth-filter thread is the synchronous one (its thread keeping up): a frame's
 // seed update runs before the next frame is tracked.
 #pragma once
+#include <sched.h>
+#include <pthread.h>
 #include <array>
 #include <condition_variable>
 #include <cstdint>
@@ -179,7 +181,7 @@ public:
   int trajectory(int k, double* stamps, hso_se3* T_f_w, int cap) const;
   bool trace(int k, const char* path);
   bool trace_state(int k, bool on);
-  void set_options(bool sync_previous, bool track_no_coop);
+  void set_options(bool sync_previous, bool track_no_coop, bool no_numa_pin = false);
   void call_counts(int64_t* calls, int64_t* items, int cap) const;
   // algorithmic bytes (SURVEY.md section 8(d) units) of the steps so far: [frame build, tracker, matcher, pose optimiser, seeds]
   void alg_bytes(double* out, int cap) const { for (int i = 0; i < cap && i < 5; i++) out[i] = alg_bytes_[i]; }
@@ -264,6 +266,12 @@ private:
   struct PendingPrev { bool on = false, async = false; std::vector<int> who; std::vector<size_t> n_lists; int n_slots = 0;
                        std::vector<hso_seed> before; std::vector<hso_seed_out> full; } pending_prev_;
   bool sync_previous_ = false;     // HSO_ENGINE_SYNC_PREVIOUS=1: the pass runs inside the step (tests compare both modes)
+  // hso_vo_options.no_numa_pin == 0: the driving thread and the workers stay on the CPUs of the device's NUMA node (pin_threads)
+  bool no_numa_pin_ = false, numa_known_ = false, workers_pinned_ = false;
+  cpu_set_t numa_cpus_;
+  pthread_t pinned_driver_{};
+  bool driver_pinned_ = false;
+  void pin_threads();
   std::vector<int64_t> to_release_;
   std::vector<int64_t> after_prev_release_;   // frames the previous-frame pass dropped from its lists: released once the pass is collected
   double phase_ms_[9] = {0};

@@ -63,7 +63,8 @@ int hso_vo_trace(hso_vo* v, const char* path) { return (v && v->bank->trace(0, p
 static int set_opts(Bank* b, const hso_vo_options* o)
 {
   if (!b || !o || o->size < 12 || o->size > (int32_t)sizeof(hso_vo_options)) return HSO_E_INVALID;
-  return guarded(b, [&]() { b->set_options(o->sync_previous != 0, o->track_no_coop != 0); });
+  const bool no_pin = o->size >= 16 && o->no_numa_pin != 0;
+  return guarded(b, [&]() { b->set_options(o->sync_previous != 0, o->track_no_coop != 0, no_pin); });
 }
 int hso_vo_set_options(hso_vo* v, const hso_vo_options* o) { return v ? set_opts(v->bank, o) : HSO_E_INVALID; }
 int hso_vo_trace_state(hso_vo* v, int on) { return (v && v->bank->trace_state(0, on != 0)) ? HSO_OK : HSO_E_INVALID; }

@@ -1,6 +1,8 @@
 // hso_engine_impl.h — what the engine's translation units share: the per-sequence tables with their list / map operations,
 // the scratch a sequence carries through a step, the worker pool.
 #pragma once
+#include <sched.h>
+#include <pthread.h>
 #include "hso_engine.h"
 #include <algorithm>
 #include <atomic>
@@ -54,6 +56,8 @@ public:
   {
     for (int i = 0; i < n_threads; i++) th_.emplace_back([this] { loop(); });
   }
+  // confine the workers to a CPU set (the device's NUMA node: Bank::pin_threads)
+  void pin(const cpu_set_t& set) { for (auto& t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set); }
   ~Pool()
   {
     { std::lock_guard<std::mutex> lk(m_); quit_.store(true); gen_.fetch_add(1); }

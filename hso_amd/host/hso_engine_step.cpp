@@ -64,6 +64,7 @@ void Bank::step(const uint8_t* const* imgs, int w, int h, const double* stamps, 
     who.push_back(k);
   }
   if (who.empty()) return;
+  pin_threads();
   release_queued();
 
   timing_ = timing_level() > 0;

@@ -26,7 +26,7 @@ class VoStatus(C.Structure):
 
 class VoOptions(C.Structure):
     # hso_vo_options (include/hso_vo.h)
-    _fields_ = [("size", C.c_int32), ("sync_previous", C.c_int32), ("track_no_coop", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("size", C.c_int32), ("sync_previous", C.c_int32), ("track_no_coop", C.c_int32), ("no_numa_pin", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 _lib = None
@@ -139,8 +139,8 @@ class MultiVisualOdometry:
     def trace(self, k, path):
         self._check(self.lib.hso_vo_multi_trace(self.h, int(k), path.encode() if path else None), "trace")
 
-    def set_options(self, sync_previous=False, track_no_coop=False):
-        o = VoOptions(C.sizeof(VoOptions), int(bool(sync_previous)), int(bool(track_no_coop)))
+    def set_options(self, sync_previous=False, track_no_coop=False, no_numa_pin=False):
+        o = VoOptions(C.sizeof(VoOptions), int(bool(sync_previous)), int(bool(track_no_coop)), int(bool(no_numa_pin)))
         self._check(self.lib.hso_vo_multi_set_options(self.h, C.byref(o)), "set_options")
 
     def start(self, which=None):
@@ -227,8 +227,8 @@ class VisualOdometry:
         self._check(self.lib.hso_vo_trace_state(self.h, 1 if state else 0), "trace_state")
         self._check(self.lib.hso_vo_trace(self.h, path.encode() if path else None), "trace")
 
-    def set_options(self, sync_previous=False, track_no_coop=False):
-        o = VoOptions(C.sizeof(VoOptions), int(bool(sync_previous)), int(bool(track_no_coop)))
+    def set_options(self, sync_previous=False, track_no_coop=False, no_numa_pin=False):
+        o = VoOptions(C.sizeof(VoOptions), int(bool(sync_previous)), int(bool(track_no_coop)), int(bool(no_numa_pin)))
         self._check(self.lib.hso_vo_set_options(self.h, C.byref(o)), "set_options")
 
     def set_first_frame(self, img, depth_z, timestamp=0.0, T_f_w=None):

@@ -82,6 +82,10 @@ int hso_gpu_synchronize(hso_gpu_ctx* ctx);
  * idle CUs — the other contexts' work fills those — which is what gives the best THROUGHPUT; the default (0) gives a lone batch
  * the best LATENCY.  Results agree within the tracker's stated tolerance either way. */
 int hso_gpu_set_shared_device(hso_gpu_ctx* ctx, int shared);
+/* The CPUs of the NUMA node the context's device is attached to, in the kernel's list format ("0-63,128-191"); an empty string when
+ * the node is unknown.  A driver whose threads stay there keeps its page-locked staging memory, the runtime's queues and the
+ * device's doorbells on one node (the sequence engine does: hso_vo_options.no_numa_pin). */
+int hso_gpu_device_cpulist(hso_gpu_ctx* ctx, char* out, size_t cap);
 /* The remaining choices of kernel shape and of how a context waits, per context (until round 5: process-wide environment
  * variables).  Zero = the default everywhere; the struct may be extended at its end (size = sizeof of the caller's). */
 enum { HSO_WAIT_DEFAULT = 0,   /* a lone context polls (hipStreamSynchronize); one that shares its device naps between event queries */

@@ -42,7 +42,10 @@ typedef struct hso_vo_options {
   int32_t size;               /* sizeof(hso_vo_options) */
   int32_t sync_previous;      /* 1: the depth filter's idle-time pass runs inside the step instead of on its own stream (same results: tests compare) */
   int32_t track_no_coop;      /* 1: the tracker keeps one workgroup per job whatever the batch size (hso_gpu_options.track_no_coop) */
-  int32_t reserved[5];
+  int32_t no_numa_pin;        /* 0 (default): from a handle's next step on, the thread that drives it and its worker threads run on the CPUs of the NUMA node
+                                 the device is attached to (hso_gpu_device_cpulist, intersected with the affinity the process has) — page-locked
+                                 staging and the runtime's queues stay node-local; 1: affinities are left alone (set before the first frame) */
+  int32_t reserved[4];
 } hso_vo_options;
 int hso_vo_set_options(hso_vo* vo, const hso_vo_options* options);
 /* first keyframe: features are detected the way the initialisation detects them and every feature with

@@ -73,6 +73,7 @@ void hso_gpu_destroy(hso_gpu_ctx* c)
 const char* hso_gpu_last_error(const hso_gpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int hso_gpu_synchronize(hso_gpu_ctx*) { return HSO_OK; }
 int hso_gpu_set_shared_device(hso_gpu_ctx*, int) { return HSO_OK; }
+int hso_gpu_device_cpulist(hso_gpu_ctx*, char* out, size_t cap) { if (out && cap) out[0] = 0; return HSO_OK; }   // no device, no node
 int hso_gpu_configure(hso_gpu_ctx*, const hso_gpu_options*) { return HSO_OK; }   // kernel shapes and wait modes: nothing to choose here
 int hso_gpu_set_host_parallel(hso_gpu_ctx*, hso_parallel_for_fn, void*) { return HSO_OK; }   // the restatement is sequential
 int hso_gpu_host_alloc(hso_gpu_ctx*, size_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? HSO_OK : HSO_E_NOMEM; }

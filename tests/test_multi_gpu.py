@@ -200,3 +200,37 @@ def test_traced_sequence_inside_three_concurrent_banks_replays(orc, tmp_path):
     print("traced sequence inside 3 x 96 x 2000:", s)
     assert s["track"]["n"] == n_frames - 1 and s["pose"]["n"] == n_frames - 1 and s["select"]["n"] == n_frames - 1
     assert s["reproject"]["success"] >= 0.8 * s["reproject"]["matched_calls"]
+
+
+def test_engine_threads_stay_on_the_devices_numa_node():
+    """hso_vo_options.no_numa_pin: by default the thread that drives a handle runs, from its first step on, on the CPUs of the NUMA
+    node the device is attached to (hso_gpu_device_cpulist ∩ the affinity it had); with the option set nothing changes.  Results do not
+    depend on it (same status records)."""
+    import os
+    import threading
+    from hso_amd import capi
+    ctx = capi.Context()
+    node = ctx.device_cpulist()
+    ctx.close()
+    before = os.sched_getaffinity(0)
+    expect = node & before if len(node & before) >= 2 and (node & before) != before else before
+    small = dict(synth.EUROC, width=384, height=256, fx=240.0, fy=240.0, cx=191.5, cy=127.5)
+    S = synth.sequence(6, spec=small, workers=4)
+    cam = synth.camera(small)
+    seen, status = {}, {}
+
+    def run(tag, no_pin):
+        odo = vo.VisualOdometry(cam, 120)
+        if no_pin:
+            odo.set_options(no_numa_pin=True)
+        odo.set_first_frame(S["images"][0], S["depth0"], 0.0)
+        status[tag] = [bytes(odo.add_image(S["images"][k], float(k))) for k in range(1, 6)]
+        seen[tag] = os.sched_getaffinity(0)                         # of this thread
+        odo.close()
+    for tag, no_pin in (("left alone", True), ("pinned", False)):   # a thread each: the pinned one keeps its affinity
+        t = threading.Thread(target=run, args=(tag, no_pin))
+        t.start(); t.join()
+    assert seen["left alone"] == before
+    assert seen["pinned"] == expect, (sorted(seen["pinned"])[:8], sorted(expect)[:8], len(node))
+    assert status["pinned"] == status["left alone"]
+    assert os.sched_getaffinity(0) == before                        # the test's own thread was never touched
