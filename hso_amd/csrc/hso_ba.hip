@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 using namespace hso_dev;
@@ -1380,11 +1381,12 @@ static int ba_run(hso_gpu_ctx* ctx, BaBatch& Q, const std::vector<BaLmHost>& lm,
     Q.h_lambda[q] = -1.0;
   }
   HSO_HIP_CHECK(ctx, hipMemcpyAsync(Q.d_lm, Q.h_lm, (size_t)(reinterpret_cast<char*>(Q.h_lambda + n) - reinterpret_cast<char*>(Q.h_lm)), hipMemcpyHostToDevice, ctx->stream));
-  static bool solve_attr = false;   // 96 x 96 doubles = 72 KiB of dynamic LDS: above the 64 KiB a launch gets without asking
-  if (!solve_attr) {
-    HSO_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * (int)sizeof(double)));
-    solve_attr = true;
-  }
+  // 96 x 96 doubles = 72 KiB of dynamic LDS: above the 64 KiB a launch gets without asking (once per process; several engines call this
+  // function from their own threads)
+  static std::once_flag solve_attr;
+  hipError_t attr_rc = hipSuccess;
+  std::call_once(solve_attr, [&] { attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * (int)sizeof(double)); });
+  HSO_HIP_CHECK(ctx, attr_rc);
   const int max_m = ba_max(Q, &BaWin::M), max_pairs = ba_max(Q, &BaWin::n_pairs);
   std::vector<BaLmDev> state((size_t)n);
   std::vector<float> hub(2 * (size_t)n);
