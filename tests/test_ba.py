@@ -264,6 +264,35 @@ def test_ba_optimize_multi_equals_single_calls(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_ba_device_loop_mixed_budgets_in_one_call(gpu_ctx, orc):
+    """The Levenberg loop decides on the device (k_ba_decide) and a call enqueues its rounds in blocks (ten, then four at a time):
+    windows that run zero iterations (the errors-only round), one, a handful and a budget of 100 — far more rounds than one block —
+    share ONE call and each returns exactly what it returns alone; the long one follows the oracle's loop trial for trial."""
+    problems = []
+    for shape, seed, n_iter, noise, dp, di in (((6, 150, 3), 71, 0, 0.3, 6e-3, 0.05), ((9, 300, 4), 72, 1, 0.3, 6e-3, 0.05), ((4, 60, 3), 73, 4, 0.3, 6e-3, 0.05),
+                                              ((8, 250, 4), 74, 100, 0.5, 3e-2, 0.3), ((5, 90, 3), 75, 0, 0.3, 6e-3, 0.05)):
+        poses, fixed, idist, edges = synth.ba_problem(*shape, seed=seed, px_noise=noise)
+        rng = np.random.default_rng(seed)
+        pert = [orc.se3_mul(orc.se3_exp(np.concatenate([rng.normal(0, dp, 3), rng.normal(0, dp / 2, 3)])), p) if not fixed[i] else p for i, p in enumerate(poses)]
+        problems.append((pert, fixed, idist * np.clip(1 + di * rng.normal(size=len(idist)), 0.2, 3), edges, 1.2, 0.6, n_iter))
+    singles = [gpu_ctx.ba_optimize(*p) for p in problems]
+    multi = gpu_ctx.ba_optimize_multi(problems)
+    for q, ((ps, is_, cs, rs), (pm, im, cm, rm)) in enumerate(zip(singles, multi)):
+        assert bytes(rs) == bytes(rm), q
+        assert np.array_equal(is_, im) and np.array_equal(cs, cm), q
+        for a, b_ in zip(ps, pm):
+            assert a.q[:] == b_.q[:] and a.t[:] == b_.t[:], q
+    for q in (0, 4):                                                 # zero iterations: nothing moves, the chi2 of the given state comes back
+        assert multi[q][3].iterations == 0 and multi[q][3].n_solves == 0 and np.array_equal(multi[q][1], problems[q][2])
+        assert multi[q][3].init_chi2 == multi[q][3].final_chi2 > 0
+    long = multi[3][3]
+    assert long.n_solves > 14, long.n_solves                          # more rounds than the first block plus one more
+    po, io, co, ro = orc.ba_optimize(*problems[3])
+    assert (long.iterations, long.n_solves, long.n_accepted, long.stop) == (ro.iterations, ro.n_solves, ro.n_accepted, ro.stop)
+    assert np.abs(multi[3][1] - io).max() <= 1e-7 * max(1.0, np.abs(io).max())
+
+
+@pytest.mark.gpu
 def test_ba_optimize_points_only_window(gpu_ctx, orc):
     """Every pose fixed: the reduced system is empty (M = 0), the optimisation moves the inverse depths only — the device solve
     has nothing to factor and must still follow the oracle's Levenberg loop."""
