@@ -149,6 +149,13 @@ Bank::~Bank()
             "local BA %.3f, seed observe %.3f, seed activate %.3f, new seeds %.3f, flush+finish %.3f\n", (long long)n_steps_, size(), (long long)n_kf_events_,
             phase_ms_[0] / n_steps_, phase_ms_[1] / n_steps_, phase_ms_[2] / n_steps_, phase_ms_[3] / n_steps_, phase_ms_[4] / n_steps_, phase_ms_[5] / n_steps_,
             phase_ms_[6] / n_steps_, phase_ms_[7] / n_steps_, phase_ms_[8] / n_steps_);
+  // the same phases under the reference's timer names (g_permon, src/frame_handler_base.cpp:54-66; HSO_START_TIMER in
+  // src/frame_handler_mono.cpp:90, 188, 215, 237, 316): the resident chain is ONE device call, so four of its timers are one figure
+  if (timing_level() > 0 && n_steps_ > 0)
+    fprintf(stderr, "[hso engine] reference timers, ms per step: pyramid_creation %.3f | sparse_img_align + reproject (reproject_kfs, reproject_candidates, "
+            "feature_align) + pose_optimizer %.3f | local_ba %.3f | (depth filter: seeds observed %.3f, point_optimizer / activation %.3f, new seeds %.3f) | tot_time %.3f\n",
+            phase_ms_[0] / n_steps_, (phase_ms_[1] + phase_ms_[2]) / n_steps_, phase_ms_[4] / n_steps_, phase_ms_[5] / n_steps_, phase_ms_[6] / n_steps_, phase_ms_[7] / n_steps_,
+            (phase_ms_[0] + phase_ms_[1] + phase_ms_[2] + phase_ms_[3] + phase_ms_[4] + phase_ms_[5] + phase_ms_[6] + phase_ms_[7] + phase_ms_[8]) / n_steps_);
   if (timing_level() > 0 && n_steps_ > 0) {
     static const char* const names[9] = {"upload", "track", "reproject+select+pose", "decide", "local BA", "seed observe", "seed activate", "new seeds", "flush+finish"};
     for (int k = 0; k < 9; k++)
