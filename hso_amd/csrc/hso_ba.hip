@@ -1859,12 +1859,12 @@ extern "C" int hso_gpu_seq_local_ba(hso_gpu_ctx* ctx, const hso_seq_ba_job* jobs
   std::vector<RbaJobDev> hj((size_t)n_jobs);
   size_t zero_bytes = 0, ones_bytes = 0, rest_bytes = 0;
   int max_len = 1, max_core = 1, max_nb = 1;
+  for (int j = 0; j < n_jobs; j++) for (int i = 0; i < j; i++) if (jobs[i].map == jobs[j].map) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: a map appears twice");
   for (int j = 0; j < n_jobs; j++) {
     const hso_seq_ba_job& A = jobs[j];
     if (A.n_core < 1 || A.n_core > HSO_SEQ_BA_MAX_CORE || A.n_iter < 0 || A.point_cap < 0 || A.cull_cap < 0 || (A.point_cap > 0 && (!A.point_ids || !A.point_state)) ||
         (A.cull_cap > 0 && !A.culled))
       return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: bad argument");
-    for (int i = 0; i < j; i++) if (jobs[i].map == A.map) return hso_fail(ctx, HSO_E_INVALID, "seq_local_ba: a map appears twice");
     const int32_t* nfts = nullptr;
     if (int rc = hso_seqmap_ba_view(ctx, A.map, &view[(size_t)j], &kfs_host[(size_t)j], &nfts)) return rc;
     const SeqMapDev& M = view[(size_t)j];

@@ -185,3 +185,47 @@ def test_options_and_debug_read_backs_refuse_bad_arguments(gpu_ctx):
         assert lib.hso_gpu_seqmap_destroy(h, m.value) == 0
     # a keyframe table beyond HSO_SEQ_MAX_KFS rows is refused by the chain, not silently truncated: checked on the header's constant
     assert "HSO_SEQ_MAX_KFS 2048" in open(__import__("os").path.join(__import__("os").path.dirname(capi.__file__), "..", "include", "hso_gpu.h")).read()
+
+
+def test_resident_local_ba_and_cpulist_refuse_bad_arguments(gpu_ctx):
+    """hso_gpu_seq_local_ba, its window read-back and hso_gpu_device_cpulist: null / out-of-range arguments -> negative status with a
+    message, nothing touched, the context stays usable (the parity half is tests/test_seq_ba.py)."""
+    lib = capi.load()
+    h = gpu_ctx.h
+    lib.hso_gpu_seq_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.hso_gpu_seq_ba_debug_window.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.hso_gpu_device_cpulist.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(64)
+    assert lib.hso_gpu_device_cpulist(None, buf, 64) == E_INVALID
+    assert lib.hso_gpu_device_cpulist(h, None, 64) == E_INVALID and lib.hso_gpu_device_cpulist(h, buf, 0) == E_INVALID
+    assert lib.hso_gpu_device_cpulist(h, buf, 64) == 0                                           # a list, possibly cut, or an empty string
+    assert all(c in b"0123456789,-" for c in buf.value)
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import chain_state as cs
+    job = np.zeros(1, cs.SEQ_BA_JOB); res = np.zeros(1, cs.SEQ_BA_RESULT)
+    pj, pr = job.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p)
+    assert lib.hso_gpu_seq_local_ba(None, pj, 1, 1.0, 1.0, 1.0, pr) == E_INVALID
+    assert lib.hso_gpu_seq_local_ba(h, None, 1, 1.0, 1.0, 1.0, pr) == E_INVALID and lib.hso_gpu_seq_local_ba(h, pj, 1, 1.0, 1.0, 1.0, None) == E_INVALID
+    assert lib.hso_gpu_seq_local_ba(h, pj, -1, 1.0, 1.0, 1.0, pr) == E_INVALID
+    assert lib.hso_gpu_seq_local_ba(h, pj, 0, 1.0, 1.0, 1.0, pr) == 0                            # no jobs: nothing to do
+    job["map"] = 0; job["n_core"] = 0
+    assert lib.hso_gpu_seq_local_ba(h, pj, 1, 1.0, 1.0, 1.0, pr) == E_INVALID                    # a window needs a core keyframe
+    job["n_core"] = 17
+    assert lib.hso_gpu_seq_local_ba(h, pj, 1, 1.0, 1.0, 1.0, pr) == E_INVALID                    # more than HSO_SEQ_BA_MAX_CORE
+    job["n_core"] = 1; job["map"] = 4242
+    assert lib.hso_gpu_seq_local_ba(h, pj, 1, 1.0, 1.0, 1.0, pr) == E_INVALID and "map" in _err(gpu_ctx)
+    m = C.c_int(-1)
+    assert lib.hso_gpu_seqmap_create(h, C.byref(m)) == 0
+    try:
+        job["map"] = m.value
+        assert lib.hso_gpu_seq_local_ba(h, pj, 1, 1.0, 1.0, 1.0, pr) == E_INVALID and "keyframes" in _err(gpu_ctx)   # an empty map
+        two = np.zeros(2, cs.SEQ_BA_JOB); two["map"] = m.value; two["n_core"] = 1
+        res2 = np.zeros(2, cs.SEQ_BA_RESULT)
+        assert lib.hso_gpu_seq_local_ba(h, two.ctypes.data_as(C.c_void_p), 2, 1.0, 1.0, 1.0, res2.ctypes.data_as(C.c_void_p)) == E_INVALID and "twice" in _err(gpu_ctx)
+    finally:
+        assert lib.hso_gpu_seqmap_destroy(h, m.value) == 0
+    four = np.zeros(4, np.int32)
+    assert lib.hso_gpu_seq_ba_debug_window(None, 0, 0, four.ctypes.data_as(C.c_void_p), 16) == E_INVALID
+    assert lib.hso_gpu_seq_ba_debug_window(h, 7, 0, four.ctypes.data_as(C.c_void_p), 16) == E_INVALID   # no such job in the last call
+    assert lib.hso_gpu_synchronize(h) == 0
