@@ -122,3 +122,10 @@ def test_trace_reader_round_trip(tmp_path):
     p.write_bytes(rec * 2)
     out = vo.read_trace(str(p))
     assert [n for n, _ in out] == ["call", "call"] and vo.scalar(out[1][1], "x") == 2.5 and out[0][1]["tab"] == b"abc"
+
+
+def test_graft_entry_build_passes_on_this_tree():
+    """the driver's "does it build" check (__graft_entry__.build(): compile what is stale, load every library, check the ABI generation
+    and every exported symbol) — run here so that a bumped ABI version or a renamed symbol cannot leave it behind"""
+    import __graft_entry__ as entry
+    entry.build()
