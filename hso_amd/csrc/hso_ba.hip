@@ -20,7 +20,7 @@
 // The reference accumulates serially in edge order in fp64; the tree order differs by rounding
 // (parity tolerance 1e-11 relative).  Sizes are small (<= ~15 poses, a few hundred points,
 // 1-3 k edges): latency-bound; throughput comes from issuing many keyframes' problems on one stream.
-// Around them (further down): the Levenberg loop as a device state machine (BaLmDev, k_ba_decide, ba_run), the Huber deltas
+// Around them (further down): the Levenberg loop as a device state machine (BaLmDev, ba_decide at the tail of k_ba_chi2, ba_run), the Huber deltas
 // (k_ba_mad_*), and hso_gpu_seq_local_ba — the window assembled from a sequence map's resident tables (k_rba_*).
 #include "hso_ctx.h"
 #include "hso_dev_math.h"
@@ -460,14 +460,21 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_poses(const BaProb* probs, co
 
 
 // the blocks a linearisation accumulates into, zeroed for every window of the launch at once (was: one memset per window)
-__global__ __launch_bounds__(BA_THREADS) void k_ba_zero(const BaProb* probs, const BaLmDev* lm, int mask)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_begin(const BaProb* probs, const BaLmDev* lm)
 {
-  const BaProb* PP = ba_window(probs, lm, mask);
-  if (!PP) return;
-  const BaProb& P = *PP;
-  uint4* z = reinterpret_cast<uint4*>(P.zero_begin);
-  const size_t n = P.zero_bytes / 16;
-  for (size_t i = (size_t)blockIdx.x * BA_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * BA_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+  const int want = lm ? lm[blockIdx.y].want : BA_W_LINEARIZE;
+  if (!(want & (BA_W_RESTORE | BA_W_LINEARIZE))) return;
+  const BaProb& P = probs[blockIdx.y];
+  const size_t first = (size_t)blockIdx.x * BA_THREADS + threadIdx.x, step = (size_t)gridDim.x * BA_THREADS;
+  if (want & BA_W_RESTORE) {                                        // g2o's pop(): the state before the rejected step
+    for (size_t p = first; p < (size_t)P.a.n_points; p += step) P.idist_rw[p] = P.idist_bak[p];
+    for (size_t i = first; i < (size_t)P.a.n_poses; i += step) P.poses_rw[i] = P.poses_bak[i];
+  }
+  if (want & BA_W_LINEARIZE) {
+    uint4* z = reinterpret_cast<uint4*>(P.zero_begin);
+    const size_t n = P.zero_bytes / 16;
+    for (size_t i = first; i < n; i += step) z[i] = make_uint4(0, 0, 0, 0);
+  }
 }
 
 // computeLambdaInit (thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:191-201): the largest |diagonal entry| of the
@@ -493,11 +500,97 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_maxdiag(const BaProb* probs, 
   if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < BA_WAVES; w++) t = fmax(t, s_part[w]); P.sum[5] = t; }
 }
 
+// The accept / reject decision of OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-164) and the
+// iteration control of SparseOptimizer::optimize (sparse_optimizer.cpp:354-420) for every window, from the sums the round's
+// kernels left: one thread per window.  It writes what the window wants in the next round and the damping its next trial uses
+// (negative: computeLambdaInit of the linearisation that precedes it, taken on the device: ba_lambda).  Until round 6 the host
+// took this decision — five doubles per window came back and one synchronisation ended every round, ~10 per call; now a call
+// enqueues its rounds back to back and waits once.  It runs at the tail of k_ba_chi2, the kernel that ends every round a window
+// takes part in (one thread of the window's workgroup, after the sums are out).
+__device__ void ba_decide(const double* sum, BaLmDev& L, double* lam_next)
+{
+  if (L.st == BA_ST_DONE) { L.want = 0; return; }
+  hso_ba_result& R = L.res;
+  auto finish = [&]() {
+    R.stop = L.stop; R.lambda = L.lambda;
+    // _optimizer->pop() of a last rejected step still has to happen: one more round that only restores
+    if (L.need_restore) { L.need_restore = 0; L.st = BA_ST_FINAL_WAIT; L.want = BA_W_RESTORE; } else { L.st = BA_ST_DONE; L.want = 0; }
+  };
+  switch (L.st) {
+    case BA_ST_INIT_WAIT:
+      R.init_chi2 = sum[0]; R.robust_chi2 = sum[1]; R.final_chi2 = sum[0];
+      if (L.it >= L.n_iter) { finish(); return; }
+      lam_next[0] = -1.0;
+      L.st = BA_ST_LIN_WAIT; L.want = BA_W_LINEARIZE | BA_W_TRIAL;
+      return;
+    case BA_ST_FINAL_WAIT:
+      L.st = BA_ST_DONE; L.want = 0;
+      return;
+    case BA_ST_LIN_WAIT:
+      // a linearisation and the first trial behind it ran in ONE round; the linearisation's sums are in [6], [7], [5]
+      if (L.first_lin) { R.init_chi2 = sum[6]; R.robust_chi2 = sum[7]; L.first_lin = 0; }
+      R.final_chi2 = sum[6];
+      L.currentChi = sum[7]; L.tempChi = L.currentChi; L.iniChi = L.currentChi;
+      if (L.it == 0) { L.lambda = 1e-5 * sum[5]; L.ni = 2; L.nBad = 0; }   // computeLambdaInit
+      L.rho = 0; L.qmax = 0;
+      L.st = BA_ST_STEP_WAIT;
+      [[fallthrough]];
+    case BA_ST_STEP_WAIT: {
+      const bool ok2 = sum[4] != 0.0;
+      R.n_solves++;
+      R.final_chi2 = sum[0];                                        // activeChi2() of the last computeActiveErrors
+      L.tempChi = ok2 ? sum[1] : 1.7976931348623157e308;
+      double rho = L.currentChi - L.tempChi;
+      double scale = sum[2] + sum[3];                               // computeScale (zero when the solve failed: no step)
+      scale += 1e-3;
+      rho /= scale;
+      L.rho = rho;
+      bool restore = false;
+      if (rho > 0 && isfinite(L.tempChi)) {
+        double alpha = 1. - pow(2 * rho - 1, 3.0);
+        alpha = fmin(alpha, 2. / 3.);
+        L.lambda *= fmax(1. / 3., alpha);
+        L.ni = 2;
+        L.currentChi = L.tempChi;
+        R.n_accepted++;
+      } else {
+        L.lambda *= L.ni;
+        L.ni *= 2;
+        restore = true;                                             // _optimizer->pop(): vertices only, edge errors stay
+      }
+      L.qmax++;
+      if (rho < 0 && L.qmax < 5) {                                  // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
+        lam_next[0] = L.lambda;
+        L.st = BA_ST_STEP_WAIT; L.want = (restore ? BA_W_RESTORE : 0) | BA_W_TRIAL;
+        return;
+      }
+      L.need_restore = restore ? 1 : 0;
+      R.iterations = L.it + 1;
+      R.robust_chi2 = L.currentChi;
+      if (L.qmax == 5 || rho == 0) { L.stop = 1; finish(); return; }
+      if ((L.iniChi - L.currentChi) * 1e3 < L.iniChi) L.nBad++; else L.nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
+      if (L.nBad >= 3) { L.stop = 2; finish(); return; }
+      L.it++;
+      if (L.it >= L.n_iter) { finish(); return; }
+      lam_next[0] = L.lambda;                                       // the damping of the trial that rides behind the next linearisation
+      L.st = BA_ST_LIN_WAIT;
+      L.want = BA_W_LINEARIZE | BA_W_TRIAL | (L.need_restore ? BA_W_RESTORE : 0);   // (need_restore: only after a step with a NaN gain ratio)
+      L.need_restore = 0;
+      return;
+    }
+  }
+}
+
 // sum of chi2 and of the robustified rho(chi2) over all edges (activeChi2 / activeRobustChi2,
 // thirdparty/g2o/g2o/core/sparse_optimizer.cpp:100-113): one workgroup, fixed tree => deterministic
-__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, const BaLmDev* lm, int mask, int with_scale)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, BaLmDev* lm, int mask, int with_scale, double* lam_next)
 {
   __shared__ double s_part[BA_WAVES][2];
+  // a window whose last step was rejected spends one more round restoring (k_ba_begin): that round ends here
+  if (lm && mask == BA_W_TRIAL && lm[blockIdx.y].st == BA_ST_FINAL_WAIT) {
+    if (threadIdx.x == 0) { lm[blockIdx.y].st = BA_ST_DONE; lm[blockIdx.y].want = 0; }
+    return;
+  }
   const BaProb* PP = ba_window(probs, lm, mask);
   if (!PP) return;
   const BaProb& P = *PP;
@@ -520,6 +613,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_chi2(const BaProb* probs, con
   }
   // the end of an LM trial: the points' part of computeScale from k_ba_backsub's workgroups, in index order
   if (with_scale && threadIdx.x == 2) { double t = 0; for (int g = 0; g < BA_BACKSUB_BLOCKS; g++) t += P.part[g]; chi2_sum[2] = t; }
+  if (!lm) return;
+  __threadfence_block();
+  __syncthreads();
+  if (threadIdx.x == 0) ba_decide(chi2_sum, lm[blockIdx.y], lam_next + blockIdx.y);
 }
 
 // The reduced system of one LM trial on the device: S = Hcc_free + lambda I - sum_p Hpc_p^T (Hpp_p + lambda)^-1 Hpc_p and
@@ -719,98 +816,6 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_backsub(const BaProb* probs, 
 }
 
 // g2o's pop() for the points: the state before the rejected step
-__global__ __launch_bounds__(BA_THREADS) void k_ba_restore(const BaProb* probs, const BaLmDev* lm, int mask)
-{
-  const BaProb* PP = ba_window(probs, lm, mask);
-  if (!PP) return;
-  const BaProb& P = *PP;
-  for (int p = threadIdx.x; p < P.a.n_points; p += BA_THREADS) P.idist_rw[p] = P.idist_bak[p];
-  for (int i = threadIdx.x; i < P.a.n_poses; i += BA_THREADS) P.poses_rw[i] = P.poses_bak[i];
-}
-
-// The accept / reject decision of OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-164) and the
-// iteration control of SparseOptimizer::optimize (sparse_optimizer.cpp:354-420) for every window, from the sums the round's
-// kernels left: one thread per window.  It writes what the window wants in the next round and the damping its next trial uses
-// (negative: computeLambdaInit of the linearisation that precedes it, taken on the device: ba_lambda).  Until round 6 the host
-// took this decision — five doubles per window came back and one synchronisation ended every round, ~10 per call; now a call
-// enqueues its rounds back to back and waits once.
-__global__ void k_ba_decide(const BaProb* probs, BaLmDev* lms, double* lam_next, int n)
-{
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n) return;
-  BaLmDev& L = lms[w];
-  if (L.st == BA_ST_DONE) { L.want = 0; return; }
-  const double* sum = probs[w].sum;
-  hso_ba_result& R = L.res;
-  auto finish = [&]() {
-    R.stop = L.stop; R.lambda = L.lambda;
-    // _optimizer->pop() of a last rejected step still has to happen: one more round that only restores
-    if (L.need_restore) { L.need_restore = 0; L.st = BA_ST_FINAL_WAIT; L.want = BA_W_RESTORE; } else { L.st = BA_ST_DONE; L.want = 0; }
-  };
-  switch (L.st) {
-    case BA_ST_INIT_WAIT:
-      R.init_chi2 = sum[0]; R.robust_chi2 = sum[1]; R.final_chi2 = sum[0];
-      if (L.it >= L.n_iter) { finish(); return; }
-      lam_next[w] = -1.0;
-      L.st = BA_ST_LIN_WAIT; L.want = BA_W_LINEARIZE | BA_W_TRIAL;
-      return;
-    case BA_ST_FINAL_WAIT:
-      L.st = BA_ST_DONE; L.want = 0;
-      return;
-    case BA_ST_LIN_WAIT:
-      // a linearisation and the first trial behind it ran in ONE round; the linearisation's sums are in [6], [7], [5]
-      if (L.first_lin) { R.init_chi2 = sum[6]; R.robust_chi2 = sum[7]; L.first_lin = 0; }
-      R.final_chi2 = sum[6];
-      L.currentChi = sum[7]; L.tempChi = L.currentChi; L.iniChi = L.currentChi;
-      if (L.it == 0) { L.lambda = 1e-5 * sum[5]; L.ni = 2; L.nBad = 0; }   // computeLambdaInit
-      L.rho = 0; L.qmax = 0;
-      L.st = BA_ST_STEP_WAIT;
-      [[fallthrough]];
-    case BA_ST_STEP_WAIT: {
-      const bool ok2 = sum[4] != 0.0;
-      R.n_solves++;
-      R.final_chi2 = sum[0];                                        // activeChi2() of the last computeActiveErrors
-      L.tempChi = ok2 ? sum[1] : 1.7976931348623157e308;
-      double rho = L.currentChi - L.tempChi;
-      double scale = sum[2] + sum[3];                               // computeScale (zero when the solve failed: no step)
-      scale += 1e-3;
-      rho /= scale;
-      L.rho = rho;
-      bool restore = false;
-      if (rho > 0 && isfinite(L.tempChi)) {
-        double alpha = 1. - pow(2 * rho - 1, 3.0);
-        alpha = fmin(alpha, 2. / 3.);
-        L.lambda *= fmax(1. / 3., alpha);
-        L.ni = 2;
-        L.currentChi = L.tempChi;
-        R.n_accepted++;
-      } else {
-        L.lambda *= L.ni;
-        L.ni *= 2;
-        restore = true;                                             // _optimizer->pop(): vertices only, edge errors stay
-      }
-      L.qmax++;
-      if (rho < 0 && L.qmax < 5) {                                  // setMaxTrialsAfterFailure(5), src/bundle_adjustment.cpp:571
-        lam_next[w] = L.lambda;
-        L.st = BA_ST_STEP_WAIT; L.want = (restore ? BA_W_RESTORE : 0) | BA_W_TRIAL;
-        return;
-      }
-      L.need_restore = restore ? 1 : 0;
-      R.iterations = L.it + 1;
-      R.robust_chi2 = L.currentChi;
-      if (L.qmax == 5 || rho == 0) { L.stop = 1; finish(); return; }
-      if ((L.iniChi - L.currentChi) * 1e3 < L.iniChi) L.nBad++; else L.nBad = 0;   // optimization_algorithm_levenberg.cpp:154-161
-      if (L.nBad >= 3) { L.stop = 2; finish(); return; }
-      L.it++;
-      if (L.it >= L.n_iter) { finish(); return; }
-      lam_next[w] = L.lambda;                                       // the damping of the trial that rides behind the next linearisation
-      L.st = BA_ST_LIN_WAIT;
-      L.want = BA_W_LINEARIZE | BA_W_TRIAL | (L.need_restore ? BA_W_RESTORE : 0);   // (need_restore: only after a step with a NaN gain ratio)
-      L.need_restore = 0;
-      return;
-    }
-  }
-}
 
 // ------------------------------------------------------------------ host side
 
@@ -843,7 +848,7 @@ struct BaBatch {
   hso_gpu_ctx* ctx;
   std::vector<BaWin> win;
   BaProb* d_probs = nullptr;
-  BaLmDev* d_lm = nullptr;       // [n] the Levenberg loop's state per window (k_ba_decide)
+  BaLmDev* d_lm = nullptr;       // [n] the Levenberg loop's state per window (ba_decide)
   BaLmDev* h_lm = nullptr;       // pinned: the initial states go up with the header
   double* d_lambda = nullptr;    // [n] the damping of each window's current trial
   double* h_lambda = nullptr;    // pinned
@@ -1078,7 +1083,7 @@ static int ba_launch_linearize(BaBatch& Q, const BaLmDev* lm)
 {
   hso_gpu_ctx* ctx = Q.ctx;
   const int ny = Q.n, m = BA_W_LINEARIZE;
-  hipLaunchKernelGGL(k_ba_zero, dim3(64, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
+  hipLaunchKernelGGL(k_ba_begin, dim3(64, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm);   // (the loop: also the pop() of a rejected step)
   hipLaunchKernelGGL(k_ba_edges<true>, dim3((ba_max(Q, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
   hipLaunchKernelGGL(k_ba_points, dim3((ba_max(Q, &BaWin::n_points) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
   hipLaunchKernelGGL(k_ba_poses, dim3(ba_max(Q, &BaWin::n_pairs) + 1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, m);
@@ -1088,12 +1093,12 @@ static int ba_launch_linearize(BaBatch& Q, const BaLmDev* lm)
 }
 // computeActiveErrors only: per-edge error / chi2 / rho and the two sums (mask BA_W_ERRORS: the errors-only round; BA_W_TRIAL: the end
 // of an LM trial, where k_ba_chi2 also adds up the back-substitution's parts of computeScale)
-static int ba_launch_errors(BaBatch& Q, const BaLmDev* lm, int mask)
+static int ba_launch_errors(BaBatch& Q, BaLmDev* lm, int mask)
 {
   hso_gpu_ctx* ctx = Q.ctx;
   const int ny = Q.n;
   hipLaunchKernelGGL(k_ba_edges<false>, dim3((ba_max(Q, &BaWin::n_edges) + BA_THREADS - 1) / BA_THREADS, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, mask);
-  hipLaunchKernelGGL(k_ba_chi2, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, mask, mask == BA_W_TRIAL ? 1 : 0);
+  hipLaunchKernelGGL(k_ba_chi2, dim3(1, ny), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, lm, mask, mask == BA_W_TRIAL ? 1 : 0, Q.d_lambda);
   HSO_HIP_CHECK(ctx, hipGetLastError());
   return HSO_OK;
 }
@@ -1351,7 +1356,7 @@ namespace {
 // The Levenberg loop of OptimizationAlgorithmLevenberg::solve for the windows of a batch, in lockstep rounds.  A round = for every
 // window the device work its state record asks for — restore (g2o's pop()), linearisation (computeActiveErrors + buildSystem), an LM
 // trial as ONE device sequence: reduced system (k_ba_schur), dense LDL^T + pose update (k_ba_solve), back-substitution + point
-// update (k_ba_backsub), error evaluation (k_ba_edges<false>, k_ba_chi2) — and then k_ba_decide, which takes the accept / reject
+// update (k_ba_backsub), error evaluation (k_ba_edges<false>, k_ba_chi2) — and at k_ba_chi2's tail ba_decide, which takes the accept / reject
 // decision and says what the window does next.  Each kind of work is launched ONCE per round for all windows (blockIdx.y = window;
 // a window that does not want it leaves at once), so the small kernels of different windows run side by side; a window's arithmetic
 // does not depend on what runs beside it.  The host enqueues rounds back to back and looks at the state records only every
@@ -1395,14 +1400,11 @@ static int ba_run(hso_gpu_ctx* ctx, BaBatch& Q, const std::vector<BaLmHost>& lm,
     for (int r = 0; r < rounds; r++) {
       // (the errors-only round of a window that runs zero iterations: only the call's first round can hold one)
       if (first && any_errors_round) { if (int rc = ba_launch_errors(Q, Q.d_lm, BA_W_ERRORS)) return rc; }
-      hipLaunchKernelGGL(k_ba_restore, dim3(1, n), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, Q.d_lm, (int)BA_W_RESTORE);
       if (int rc = ba_launch_linearize(Q, Q.d_lm)) return rc;
       hipLaunchKernelGGL(k_ba_schur, dim3(max_pairs + 1, n), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, Q.d_lm, (int)BA_W_TRIAL);
       hipLaunchKernelGGL(k_ba_solve, dim3(1, n), dim3(BA_THREADS), sizeof(double) * (size_t)std::max(max_m * max_m, 1), ctx->stream, Q.d_probs, Q.d_lm, (int)BA_W_TRIAL);
       hipLaunchKernelGGL(k_ba_backsub, dim3(BA_BACKSUB_BLOCKS, n), dim3(BA_THREADS), 0, ctx->stream, Q.d_probs, Q.d_lm, (int)BA_W_TRIAL);
-      if (int rc = ba_launch_errors(Q, Q.d_lm, BA_W_TRIAL)) return rc;
-      hipLaunchKernelGGL(k_ba_decide, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, Q.d_probs, Q.d_lm, Q.d_lambda, n);
-      HSO_HIP_CHECK(ctx, hipGetLastError());
+      if (int rc = ba_launch_errors(Q, Q.d_lm, BA_W_TRIAL)) return rc;   // ... and the round's decision (ba_decide)
       first = false;
     }
     // what comes back: the state records (is every window done?), once the Huber deltas, and the finished windows' results
