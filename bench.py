@@ -374,8 +374,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=400, help="frames in the cpu_baseline sample (about 7 s on one host core)")
     ap.add_argument("--seq-frames", type=int, default=121, help="frames per sequence of the end-to-end runs through libhso_host.so (0 = skip): 120 steps = 8 "
                     "keyframes per sequence, i.e. full local-BA windows (7 core keyframes) and three live seed batches in the second half — the steady state")
-    ap.add_argument("--seq-warmup-frames", type=int, default=31, help="frames of the untimed warm-up pass of the end-to-end engines (0 = none): 30 steps = two "
-                    "keyframes per sequence, so every kernel of the keyframe path has run once")
+    ap.add_argument("--seq-warmup-frames", type=int, default=121, help="frames of the untimed warm-up pass of the end-to-end engines (0 = none).  A full-length "
+                    "pass: on a box whose device memory has not been touched since it came up, the FIRST run that grows to the full footprint (768 sequences: "
+                    "~30 GB of frames and maps) runs at 60-70 %% of every later one, whatever ran before it at a smaller footprint — a 30-step pass did not "
+                    "always cover that (profiles/r6_engine_host.md section 8)")
     ap.add_argument("--sequences", type=int, default=128, help="sequences per engine (bank) of the end-to-end run (hso_vo_multi_*; 0 = skip)")
     ap.add_argument("--banks", type=int, default=6, help="engines per GPU, each on its own host thread and stream")
     ap.add_argument("--seq-feats", type=int, default=2000, help="Config::maxFts() of the end-to-end run")
